@@ -1,0 +1,262 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/_build/libsf_oracle.so (the C++ CPU restatement of the
+reference algorithm).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; solverforge_amd/ never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "_build", "libsf_oracle.so")
+
+MOVE_DTYPE = np.dtype(
+    [("kind", "<i4"), ("a", "<i4"), ("a_pos", "<i4"), ("b", "<i4"), ("b_pos", "<i4"), ("value", "<i4")]
+)
+KIND_CHANGE, KIND_SWAP, KIND_LIST_CHANGE, KIND_LIST_SWAP = 0, 1, 2, 3
+ORDER_ORIGINAL, ORDER_SORTED, ORDER_PROBABILISTIC, ORDER_RANDOM, ORDER_SHUFFLED = 0, 1, 2, 3, 4
+LEAF_SCALAR_CHANGE, LEAF_SCALAR_SWAP, LEAF_LIST_CHANGE, LEAF_LIST_SWAP = 1, 2, 4, 8
+LEAF_NEARBY_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP = 16, 32
+ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
+FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
+UNION_SEQUENTIAL, UNION_ROUND_ROBIN, UNION_ROTATING, UNION_RANDOM, UNION_STRATIFIED = 0, 1, 2, 3, 4
+
+
+def build(force=False):
+    """Compile the oracle (g++).  Building the checker is not using it."""
+    if force or not os.path.exists(_LIB) or any(
+        os.path.getmtime(os.path.join(_DIR, f)) > os.path.getmtime(_LIB)
+        for f in os.listdir(_DIR)
+        if f.endswith((".hpp", ".cpp"))
+    ):
+        subprocess.check_call(["make", "-C", _DIR, "-j4"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        u64, i64, i32, u32, vp = C.c_uint64, C.c_int64, C.c_int32, C.c_uint32, C.c_void_p
+        dbl = C.c_double
+        sig = {
+            "sfo_splitmix64": (u64, [u64]),
+            "sfo_step_seed": (u64, [u64, u64]),
+            "sfo_ctx_mixed_seed": (u64, [u64, u64, u64]),
+            "sfo_ctx_random_index": (u64, [u64, u64, u64, u64]),
+            "sfo_ctx_random_stride": (u64, [u64, u64, u64, u64]),
+            "sfo_ctx_selection_index": (u64, [u64, u64, i32, u64, u64, u64]),
+            "sfo_ctx_selection_index_wo": (u64, [u64, u64, i32, u64, u64, u64]),
+            "sfo_reservoir_pick": (i32, [u64, u64]),
+            "sfo_sort_and_limit": (i32, [vp, i32, i32, vp]),
+            "sfo_nqueens_create": (vp, [i32, vp]),
+            "sfo_graph_coloring_create": (vp, [i32, i32, vp, vp, vp]),
+            "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
+            "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
+            "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
+            "sfo_model_destroy": (None, [vp]),
+            "sfo_model_score": (None, [vp, vp]),
+            "sfo_model_fresh_score": (None, [vp, vp]),
+            "sfo_model_reset": (None, [vp]),
+            "sfo_model_configure": (None, [vp, i32, i32, i32, i32, i32, i32, u32, i32, i32, u64, i32]),
+            "sfo_model_set_step_seeds": (None, [vp, vp, i32]),
+            "sfo_model_phase_start": (None, [vp]),
+            "sfo_model_steps": (None, [vp, i64]),
+            "sfo_model_steps_timed": (i64, [vp, dbl]),
+            "sfo_model_step_traced": (i32, [vp, vp, vp, vp, i32, vp, vp]),
+            "sfo_model_stats": (None, [vp, vp]),
+            "sfo_model_last_step_score": (None, [vp, vp]),
+            "sfo_model_best_score": (None, [vp, vp]),
+            "sfo_model_enumerate": (i64, [vp, u32, u64, u64, i32, vp, i64]),
+            "sfo_model_enumerate_count": (i64, [vp, u32, u64, u64, i32]),
+            "sfo_model_evaluate_moves": (None, [vp, vp, i64, vp, vp]),
+            "sfo_model_apply_move": (None, [vp, vp]),
+            "sfo_model_construct_first_fit": (None, [vp]),
+            "sfo_model_get_vars": (i32, [vp, i32, i32, vp]),
+            "sfo_model_get_lists": (i32, [vp, i32, vp, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def csr(lists):
+    off = np.zeros(len(lists) + 1, dtype=np.uint32)
+    for i, l in enumerate(lists):
+        off[i + 1] = off[i] + len(l)
+    vals = np.array([v for l in lists for v in l], dtype=np.uint32)
+    if vals.size == 0:
+        vals = np.zeros(1, dtype=np.uint32)
+    return off, vals
+
+
+class Model:
+    """Handle on one oracle model (ScoreDirector + slots + LocalSearch)."""
+
+    def __init__(self, handle, n_entities_by_desc, keep=()):
+        self.h = C.c_void_p(handle)
+        self.n_by_desc = n_entities_by_desc
+        self._keep = keep
+
+    def __del__(self):
+        try:
+            lib().sfo_model_destroy(self.h)
+        except Exception:
+            pass
+
+    # -- constructors -----------------------------------------------------------------
+    @staticmethod
+    def nqueens(rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        return Model(lib().sfo_nqueens_create(len(rows), _p(rows)), [len(rows)])
+
+    @staticmethod
+    def graph_coloring(n_colors, adj_off, adj, colors):
+        adj_off = np.ascontiguousarray(adj_off, dtype=np.uint32)
+        adj = np.ascontiguousarray(adj, dtype=np.uint32)
+        colors = np.ascontiguousarray(colors, dtype=np.int64)
+        n = len(colors)
+        return Model(lib().sfo_graph_coloring_create(n, n_colors, _p(adj_off), _p(adj), _p(colors)), [n])
+
+    @staticmethod
+    def cvrp(capacity, depot, demands, matrix, customers, routes):
+        demands = np.ascontiguousarray(demands, dtype=np.int32)
+        matrix = np.ascontiguousarray(matrix, dtype=np.int64)
+        customers = np.ascontiguousarray(customers, dtype=np.uint32)
+        off, vals = csr(routes)
+        dim = matrix.shape[0]
+        h = lib().sfo_cvrp_create(
+            len(customers), len(routes), int(capacity), int(depot), dim, _p(demands), _p(matrix), _p(customers),
+            _p(off), _p(vals),
+        )
+        return Model(h, [len(routes)])
+
+    @staticmethod
+    def list_toy(routes, meter="equal"):
+        off, vals = csr(routes)
+        h = lib().sfo_list_toy_create(len(routes), _p(off), _p(vals), 0 if meter == "equal" else 1)
+        return Model(h, [len(routes)])
+
+    @staticmethod
+    def jobshop(job, machine_idx, sequences, bendable=True):
+        job = np.ascontiguousarray(job, dtype=np.int64)
+        machine_idx = np.ascontiguousarray(machine_idx, dtype=np.int64)
+        off, vals = csr(sequences)
+        h = lib().sfo_jobshop_create(len(job), len(sequences), _p(job), _p(machine_idx), _p(off), _p(vals), int(bendable))
+        return Model(h, [len(job), len(sequences)])
+
+    # -- director ---------------------------------------------------------------------
+    def score(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().sfo_model_score(self.h, _p(out))
+        return out
+
+    def fresh_score(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().sfo_model_fresh_score(self.h, _p(out))
+        return out
+
+    def reset(self):
+        lib().sfo_model_reset(self.h)
+
+    # -- search -----------------------------------------------------------------------
+    def configure(self, acceptor=ACCEPT_LATE_ACCEPTANCE, la_size=400, forager=FORAGER_ACCEPTED_COUNT, limit=256,
+                  random_ties=True, selection_order=ORDER_RANDOM, leaves=0, max_nearby=20, union_order=-1,
+                  random_seed=0, public_entity_order=False):
+        lib().sfo_model_configure(self.h, acceptor, la_size, forager, limit, int(random_ties), selection_order,
+                                  leaves, max_nearby, union_order, random_seed, int(public_entity_order))
+
+    def set_step_seeds(self, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        lib().sfo_model_set_step_seeds(self.h, _p(seeds), len(seeds))
+
+    def phase_start(self):
+        lib().sfo_model_phase_start(self.h)
+
+    def steps(self, n):
+        lib().sfo_model_steps(self.h, n)
+
+    def steps_timed(self, seconds):
+        return lib().sfo_model_steps_timed(self.h, float(seconds))
+
+    def step_traced(self, cap=1 << 20):
+        moves = np.zeros(cap, dtype=MOVE_DTYPE)
+        scores = np.zeros((cap, 4), dtype=np.int64)
+        flags = np.zeros(cap, dtype=np.int32)
+        applied = C.c_int32(0)
+        applied_move = np.zeros(1, dtype=MOVE_DTYPE)
+        n = lib().sfo_model_step_traced(self.h, _p(moves), _p(scores), _p(flags), cap, C.byref(applied), _p(applied_move))
+        n = min(n, cap)
+        return moves[:n], scores[:n], flags[:n], bool(applied.value), applied_move[0]
+
+    def stats(self):
+        out = np.zeros(8, dtype=np.uint64)
+        lib().sfo_model_stats(self.h, _p(out))
+        keys = ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied",
+                "score_calculations", "moves_not_doable"]
+        return {k: int(out[i]) for i, k in enumerate(keys)}
+
+    def last_step_score(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().sfo_model_last_step_score(self.h, _p(out))
+        return out
+
+    def best_score(self):
+        out = np.zeros(4, dtype=np.int64)
+        lib().sfo_model_best_score(self.h, _p(out))
+        return out
+
+    def enumerate(self, leaf, step_index=0, step_seed=0, order=ORDER_ORIGINAL, cap=None):
+        if cap is None:
+            cap = lib().sfo_model_enumerate_count(self.h, leaf, step_index, step_seed, order)
+        out = np.zeros(max(cap, 1), dtype=MOVE_DTYPE)
+        n = lib().sfo_model_enumerate(self.h, leaf, step_index, step_seed, order, _p(out), cap)
+        return out[: min(n, cap)]
+
+    def enumerate_count(self, leaf, step_index=0, step_seed=0, order=ORDER_ORIGINAL):
+        return lib().sfo_model_enumerate_count(self.h, leaf, step_index, step_seed, order)
+
+    def evaluate_moves(self, moves):
+        moves = np.ascontiguousarray(moves, dtype=MOVE_DTYPE)
+        scores = np.zeros((len(moves), 4), dtype=np.int64)
+        doable = np.zeros(len(moves), dtype=np.int32)
+        lib().sfo_model_evaluate_moves(self.h, _p(moves), len(moves), _p(scores), _p(doable))
+        return scores, doable
+
+    def apply_move(self, move):
+        mv = np.zeros(1, dtype=MOVE_DTYPE)
+        mv[0] = move
+        lib().sfo_model_apply_move(self.h, _p(mv))
+
+    def construct_first_fit(self):
+        lib().sfo_model_construct_first_fit(self.h)
+
+    def get_vars(self, desc=0, var=0):
+        out = np.zeros(self.n_by_desc[desc], dtype=np.int64)
+        lib().sfo_model_get_vars(self.h, desc, var, _p(out))
+        return out
+
+    def get_lists(self, desc=0, max_elements=1 << 20):
+        n = self.n_by_desc[desc]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        vals = np.zeros(max_elements, dtype=np.uint32)
+        t = lib().sfo_model_get_lists(self.h, desc, _p(off), _p(vals))
+        return [list(map(int, vals[off[i]: off[i + 1]])) for i in range(n)]
+
+
+def splitmix64(v):
+    return lib().sfo_splitmix64(v & 0xFFFFFFFFFFFFFFFF)

@@ -1,0 +1,267 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see sfo_core.hpp header).
+// extern "C" surface of the CPU oracle, loaded with ctypes by tests/, smoke() and
+// bench.py's cpu_baseline leg.  The product path (solverforge_amd/) never links this.
+#include <chrono>
+#include <cstring>
+
+#include "sfo_models.hpp"
+
+using namespace sfo;
+
+extern "C" {
+
+// Wire format of one candidate move; identical to sf_move_t in include/solverforge_amd.h.
+struct sfo_move_t {
+    int32_t kind;   // 0 Change, 1 Swap, 2 ListChange, 3 ListSwap
+    int32_t a;      // Change: entity; Swap: left entity; List*: source / first entity
+    int32_t a_pos;  // List*: source / first position
+    int32_t b;      // Swap: right entity; List*: destination / second entity
+    int32_t b_pos;  // List*: destination / second position (pre-removal coords for ListChange)
+    int32_t value;  // Change: to_value (-1 = None)
+};
+
+static void to_wire(const Move& m, sfo_move_t* w) {
+    w->kind = (int32_t)m.kind;
+    w->a = (int32_t)m.a;
+    w->a_pos = (int32_t)m.a_pos;
+    w->b = (int32_t)m.b;
+    w->b_pos = (int32_t)m.b_pos;
+    w->value = (int32_t)m.to_value;
+}
+static Move from_wire(const Model& model, const sfo_move_t& w) {
+    Move m;
+    m.kind = (Move::Kind)w.kind;
+    m.a = (size_t)w.a;
+    m.a_pos = (size_t)w.a_pos;
+    m.b = (size_t)w.b;
+    m.b_pos = (size_t)w.b_pos;
+    m.to_value = w.value;
+    if (m.kind == Move::Change || m.kind == Move::Swap) {
+        m.descriptor = model.scalar_slot.descriptor_index;
+        m.variable = model.scalar_slot.variable_index;
+        m.allows_unassigned = model.scalar_slot.allows_unassigned;
+    } else {
+        m.descriptor = model.list_slot.descriptor_index;
+    }
+    return m;
+}
+
+// ---- stream context -----------------------------------------------------------
+uint64_t sfo_splitmix64(uint64_t v) { return splitmix64(v); }
+uint64_t sfo_step_seed(uint64_t random_seed, uint64_t draw) { return sf_step_seed(random_seed, draw); }
+static MoveStreamContext mk_ctx(uint64_t idx, uint64_t seed, int32_t order) {
+    return MoveStreamContext(idx, seed).with_selection_order((SelectionOrder)order);
+}
+uint64_t sfo_ctx_mixed_seed(uint64_t idx, uint64_t seed, uint64_t salt) { return mk_ctx(idx, seed, 3).mixed_seed(salt); }
+uint64_t sfo_ctx_random_index(uint64_t idx, uint64_t seed, uint64_t len, uint64_t salt) {
+    return mk_ctx(idx, seed, 3).random_index(len, salt);
+}
+uint64_t sfo_ctx_random_stride(uint64_t idx, uint64_t seed, uint64_t len, uint64_t salt) {
+    return mk_ctx(idx, seed, 3).random_stride(len, salt);
+}
+uint64_t sfo_ctx_selection_index(uint64_t idx, uint64_t seed, int32_t order, uint64_t offset, uint64_t len,
+                                 uint64_t salt) {
+    return mk_ctx(idx, seed, order).selection_index(offset, len, salt);
+}
+uint64_t sfo_ctx_selection_index_wo(uint64_t idx, uint64_t seed, int32_t order, uint64_t offset, uint64_t len,
+                                    uint64_t salt) {
+    return mk_ctx(idx, seed, order).selection_index_without_replacement(offset, len, salt);
+}
+int32_t sfo_reservoir_pick(uint64_t step_seed, uint64_t equal_count) {
+    return reservoir_pick(step_seed, equal_count) ? 1 : 0;
+}
+// stable bounded top-k over (distance) with ordinal payload; returns kept count
+int32_t sfo_sort_and_limit(const double* dist, int32_t n, int32_t max_nearby, int32_t* out_idx) {
+    std::vector<NearbyCandidate> c;
+    for (int32_t i = 0; i < n; ++i) c.push_back({(size_t)i, (size_t)i, dist[i]});
+    sort_and_limit_nearby_candidates(c, (size_t)max_nearby);
+    for (size_t i = 0; i < c.size(); ++i) out_idx[i] = (int32_t)c[i].entity;
+    return (int32_t)c.size();
+}
+
+// ---- models -------------------------------------------------------------------
+void* sfo_nqueens_create(int32_t n, const int64_t* rows) { return make_nqueens((size_t)n, rows).release(); }
+void* sfo_graph_coloring_create(int32_t n, int32_t n_colors, const uint32_t* adj_off, const uint32_t* adj,
+                                const int64_t* colors) {
+    return make_graph_coloring((size_t)n, (size_t)n_colors, adj_off, adj, colors).release();
+}
+void* sfo_cvrp_create(int32_t n_customers, int32_t n_vehicles, int64_t capacity, int32_t depot, int32_t dim,
+                      const int32_t* demands, const int64_t* matrix, const uint32_t* customers,
+                      const uint32_t* route_off, const uint32_t* route_vals) {
+    return make_cvrp((size_t)n_customers, (size_t)n_vehicles, capacity, (size_t)depot, (size_t)dim, demands,
+                     matrix, customers, route_off, route_vals)
+        .release();
+}
+void* sfo_list_toy_create(int32_t n_entities, const uint32_t* off, const uint32_t* vals, int32_t meter) {
+    return make_list_toy((size_t)n_entities, off, vals, meter == 0 ? ToyMeter::Equal : ToyMeter::Position)
+        .release();
+}
+void* sfo_jobshop_create(int32_t n_ops, int32_t n_machines, const int64_t* job, const int64_t* machine_idx,
+                         const uint32_t* seq_off, const uint32_t* seq_vals, int32_t bendable) {
+    return make_jobshop((size_t)n_ops, (size_t)n_machines, job, machine_idx, seq_off, seq_vals, bendable != 0)
+        .release();
+}
+void sfo_model_destroy(void* h) { delete (Model*)h; }
+
+void sfo_model_score(void* h, int64_t* out4) {  // Director::calculate_score
+    Score s = ((Model*)h)->director.calculate_score();
+    std::memcpy(out4, s.v, sizeof(s.v));
+}
+void sfo_model_fresh_score(void* h, int64_t* out4) {  // Director::fresh_score (evaluate_all)
+    Score s = ((Model*)h)->director.fresh_score();
+    std::memcpy(out4, s.v, sizeof(s.v));
+}
+void sfo_model_reset(void* h) { ((Model*)h)->director.reset(); }
+
+// acceptor: 0 HillClimbing, 1 LateAcceptance(size).  forager: 0 AcceptedCount(limit), 1 FirstAccepted, 2 BestScore.
+// union_order: 0 Sequential 1 RoundRobin 2 RotatingRoundRobin 3 Random 4 StratifiedRandom; -1 = default policy
+void sfo_model_configure(void* h, int32_t acceptor, int32_t la_size, int32_t forager, int32_t limit,
+                         int32_t random_ties, int32_t selection_order, uint32_t leaves, int32_t max_nearby,
+                         int32_t union_order, uint64_t random_seed, int32_t public_entity_order) {
+    Model* m = (Model*)h;
+    if (acceptor == 0)
+        m->search.acceptor = std::make_unique<HillClimbingAcceptor>();
+    else
+        m->search.acceptor = std::make_unique<LateAcceptanceAcceptor>((size_t)la_size);
+    m->search.forager.kind = (Forager::Kind)forager;
+    m->search.forager.accepted_count_limit = (size_t)limit;
+    m->search.forager.best.random_ties = random_ties != 0;
+    m->search.selection_order = (SelectionOrder)selection_order;
+    m->search.random_seed = random_seed;
+    m->leaves = leaves;
+    m->max_nearby = (size_t)max_nearby;
+    m->list_slot.public_selector_entity_order = public_entity_order != 0;
+    size_t n_leaves = (size_t)__builtin_popcount(leaves);
+    if (union_order < 0)
+        m->union_order = n_leaves <= 1 ? UnionOrder::Sequential : UnionOrder::StratifiedRandom;
+    else
+        m->union_order = (UnionOrder)union_order;
+}
+void sfo_model_set_step_seeds(void* h, const uint64_t* seeds, int32_t n) {
+    ((Model*)h)->search.explicit_step_seeds.assign(seeds, seeds + n);
+}
+void sfo_model_phase_start(void* h) { ((Model*)h)->search.phase_start(); }
+void sfo_model_steps(void* h, int64_t n) {
+    Model* m = (Model*)h;
+    for (int64_t i = 0; i < n; ++i) m->search.step();
+}
+// Runs steps until `seconds` elapsed (checked per step); returns steps executed.
+int64_t sfo_model_steps_timed(void* h, double seconds) {
+    Model* m = (Model*)h;
+    auto t0 = std::chrono::steady_clock::now();
+    int64_t n = 0;
+    for (;;) {
+        m->search.step();
+        ++n;
+        double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el >= seconds) break;
+    }
+    return n;
+}
+// One traced step: every pulled candidate with doable/score/accepted; returns count (<= cap recorded).
+int32_t sfo_model_step_traced(void* h, sfo_move_t* moves, int64_t* scores4, int32_t* flags, int32_t cap,
+                              int32_t* applied, sfo_move_t* applied_move) {
+    Model* m = (Model*)h;
+    std::vector<StepTrace> tr;
+    m->search.trace = &tr;
+    m->search.step();
+    m->search.trace = nullptr;
+    int32_t n = (int32_t)tr.size();
+    for (int32_t i = 0; i < n && i < cap; ++i) {
+        to_wire(tr[i].move, &moves[i]);
+        std::memcpy(&scores4[4 * i], tr[i].score.v, 4 * sizeof(int64_t));
+        flags[i] = (tr[i].doable ? 1 : 0) | (tr[i].accepted ? 2 : 0);
+    }
+    *applied = m->search.last_step_applied ? 1 : 0;
+    if (m->search.last_step_applied) to_wire(m->search.last_applied_move, applied_move);
+    return n;
+}
+void sfo_model_stats(void* h, uint64_t* out8) {
+    const SolverStats& s = ((Model*)h)->search.stats;
+    out8[0] = s.step_count;
+    out8[1] = s.moves_generated;
+    out8[2] = s.moves_evaluated;
+    out8[3] = s.moves_accepted;
+    out8[4] = s.moves_applied;
+    out8[5] = s.score_calculations;
+    out8[6] = s.moves_not_doable;
+    out8[7] = 0;
+}
+void sfo_model_last_step_score(void* h, int64_t* out4) {
+    std::memcpy(out4, ((Model*)h)->search.last_step_score.v, 4 * sizeof(int64_t));
+}
+void sfo_model_best_score(void* h, int64_t* out4) {
+    std::memcpy(out4, ((Model*)h)->search.best_score.v, 4 * sizeof(int64_t));
+}
+
+// Enumerate the candidate stream of one leaf (leaf = single LeafBits bit) or of the configured
+// union (leaf = 0) for MoveStreamContext(step_index, step_seed).with_selection_order(order).
+int64_t sfo_model_enumerate(void* h, uint32_t leaf, uint64_t step_index, uint64_t step_seed, int32_t order,
+                            sfo_move_t* out, int64_t cap) {
+    Model* m = (Model*)h;
+    MoveStreamContext ctx = mk_ctx(step_index, step_seed, order);
+    std::unique_ptr<Cursor> cur = leaf == 0 ? m->open_union(m->director, ctx) : m->open_leaf(leaf, m->director, ctx);
+    int64_t n = 0;
+    Move mv;
+    while (cur->next(mv)) {
+        if (n < cap && out) to_wire(mv, &out[n]);
+        ++n;
+    }
+    return n;
+}
+// FNV-1a style order hash + count of a leaf stream (benches/selector_cursor_gate.rs mix()).
+int64_t sfo_model_enumerate_count(void* h, uint32_t leaf, uint64_t step_index, uint64_t step_seed,
+                                  int32_t order) {
+    return sfo_model_enumerate(h, leaf, step_index, step_seed, order, nullptr, 0);
+}
+
+// n x evaluate_candidate (phase/localsearch/evaluation.rs:20-115): state unchanged.
+void sfo_model_evaluate_moves(void* h, const sfo_move_t* moves, int64_t n, int64_t* scores4, int32_t* doable) {
+    Model* m = (Model*)h;
+    m->director.calculate_score();
+    for (int64_t i = 0; i < n; ++i) {
+        Move mv = from_wire(*m, moves[i]);
+        if (!move_is_doable(m->director, mv)) {
+            doable[i] = 0;
+            std::memset(&scores4[4 * i], 0, 4 * sizeof(int64_t));
+            continue;
+        }
+        doable[i] = 1;
+        DirectorScoreState st = m->director.snapshot_score_state();
+        MoveUndo u = move_do(m->director, mv);
+        Score sc = m->director.calculate_score();
+        move_undo(m->director, mv, u);
+        m->director.restore_score_state(st);
+        std::memcpy(&scores4[4 * i], sc.v, 4 * sizeof(int64_t));
+    }
+}
+void sfo_model_apply_move(void* h, const sfo_move_t* mv) {  // committed do_move
+    Model* m = (Model*)h;
+    m->director.calculate_score();
+    Move mm = from_wire(*m, *mv);
+    move_do(m->director, mm);
+    m->director.calculate_score();
+}
+void sfo_model_construct_first_fit(void* h) {
+    Model* m = (Model*)h;
+    construct_first_fit(m->director, m->scalar_slot, &m->search.stats);
+}
+
+int32_t sfo_model_get_vars(void* h, int32_t desc, int32_t var, int64_t* out) {
+    const EntityClass& c = ((Model*)h)->director.working.classes[(size_t)desc];
+    for (size_t i = 0; i < c.n; ++i) out[i] = c.vars[(size_t)var][i];
+    return (int32_t)c.n;
+}
+// CSR download of a list variable; returns total element count.
+int32_t sfo_model_get_lists(void* h, int32_t desc, uint32_t* off, uint32_t* vals) {
+    const EntityClass& c = ((Model*)h)->director.working.classes[(size_t)desc];
+    uint32_t t = 0;
+    for (size_t e = 0; e < c.n; ++e) {
+        off[e] = t;
+        for (uint32_t v : c.lists[e]) vals[t++] = v;
+    }
+    off[c.n] = t;
+    return (int32_t)t;
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see sfo_core.hpp header).
+//
+// The four benchmark models of BASELINE.json, expressed with the oracle's
+// constraint nodes exactly as the reference examples express them with
+// ConstraintFactory streams.
+//
+// Follows:
+//   examples/nqueens/src/domain/board.rs:21-47
+//   examples/scalar-graph-coloring/src/domain/graph_coloring.rs:21-44
+//   examples/mixed-job-shop/src/domain/job_shop_plan.rs:28-69
+//   crates/solverforge/tests/list_clarke_wright_publication/domain/publication_plan.rs:51-65
+//       (CVRP "all customers assigned" not-exists)
+//   examples/list-tsp/src/domain/tour_plan.rs:37-40 (uni-on-routes weight pattern)
+//   crates/solverforge-cvrp/src/problem_data.rs:6-47, meters.rs:10-28
+#pragma once
+#include <memory>
+#include <vector>
+
+#include "sfo_search.hpp"
+
+namespace sfo {
+
+constexpr int64_t UNREACHABLE = INT64_MAX;            // problem_data.rs:6
+constexpr int64_t MAX_SAFE_LEG_COST = INT64_MAX / 4;  // problem_data.rs:8
+
+struct CvrpFacts {
+    int64_t capacity = 0;
+    size_t depot = 0;
+    size_t dim = 0;
+    std::vector<int32_t> demands;      // per node
+    std::vector<int64_t> matrix;       // dim x dim row-major
+    std::vector<uint32_t> customers;   // Customer.id facts (node ids)
+    bool finite(size_t from, size_t to, int64_t& out) const {  // problem_data.rs:44-47
+        if (from >= dim || to >= dim) return false;
+        int64_t v = matrix[from * dim + to];
+        if (v >= 0 && v != UNREACHABLE) {
+            out = v;
+            return true;
+        }
+        return false;
+    }
+    int64_t distance_cost(size_t from, size_t to) const {  // problem_data.rs:28-31
+        int64_t v;
+        return finite(from, to, v) ? v : MAX_SAFE_LEG_COST;
+    }
+};
+
+struct GraphFacts {
+    size_t n = 0, n_colors = 0;
+    std::vector<uint32_t> adj_off;  // n+1
+    std::vector<uint32_t> adj;      // neighbor ids (Node.neighbors, in given order)
+};
+struct QueensFacts {
+    size_t n = 0;
+    std::vector<int64_t> column;
+};
+struct JobShopFacts {
+    size_t n_ops = 0, n_machines = 0;
+    std::vector<int64_t> job;
+};
+
+enum LeafBits : uint32_t {
+    LEAF_SCALAR_CHANGE = 1,
+    LEAF_SCALAR_SWAP = 2,
+    LEAF_LIST_CHANGE = 4,
+    LEAF_LIST_SWAP = 8,
+    LEAF_NEARBY_LIST_CHANGE = 16,
+    LEAF_NEARBY_LIST_SWAP = 32,
+};
+
+struct Model {
+    ScoreDirector director;
+    bool has_scalar = false, has_list = false;
+    ScalarSlot scalar_slot;
+    ListSlot list_slot;
+    LocalSearch search;
+    uint32_t leaves = 0;
+    size_t max_nearby = 20;
+    UnionOrder union_order = UnionOrder::StratifiedRandom;
+
+    std::unique_ptr<Cursor> open_leaf(uint32_t leaf, const ScoreDirector& d, const MoveStreamContext& ctx) const {
+        switch (leaf) {
+            case LEAF_SCALAR_CHANGE:
+                return std::make_unique<ScalarChangeCursor>(scalar_slot, d.working, ctx);
+            case LEAF_SCALAR_SWAP:
+                return std::make_unique<ScalarSwapCursor>(scalar_slot, d.working, ctx);
+            case LEAF_LIST_CHANGE:
+                return std::make_unique<ListChangeCursor>(list_slot, d.working, ctx);
+            case LEAF_LIST_SWAP:
+                return std::make_unique<ListSwapCursor>(list_slot, d.working, ctx);
+            case LEAF_NEARBY_LIST_CHANGE:
+                return std::make_unique<NearbyListChangeCursor>(list_slot, d.working, ctx, max_nearby);
+            case LEAF_NEARBY_LIST_SWAP:
+                return std::make_unique<NearbyListSwapCursor>(list_slot, d.working, ctx, max_nearby);
+        }
+        return nullptr;
+    }
+    // Leaf order = default policy declaration order: list rules first (nearby change, nearby swap
+    // / plain change, plain swap), then ordinary scalar change, scalar swap
+    // (runtime/compiler/default_local_search/policy.rs:104-108, policy/list.rs:24-33,
+    //  policy/scalar.rs:67-106).
+    std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
+        static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
+                                         LEAF_LIST_SWAP,          LEAF_SCALAR_CHANGE, LEAF_SCALAR_SWAP};
+        std::vector<std::unique_ptr<Cursor>> children;
+        for (uint32_t leaf : order)
+            if (leaves & leaf) children.push_back(open_leaf(leaf, d, ctx));
+        if (children.size() == 1) return std::move(children[0]);
+        return std::make_unique<UnionCursor>(std::move(children), union_order, ctx);
+    }
+    void wire_search() {
+        search.director = &director;
+        search.open_cursor = [this](const ScoreDirector& d, const MoveStreamContext& ctx) {
+            return open_union(d, ctx);
+        };
+    }
+};
+
+inline std::unique_ptr<UniConstraint> make_unassigned(size_t desc, size_t var, const Score& w,
+                                                      const char* name) {
+    // for_each(entities).unassigned().penalize(w)
+    auto c = std::make_unique<UniConstraint>();
+    c->name = name;
+    c->impact = Impact::Penalty;
+    c->source = ChangeSource::descriptor(desc);
+    c->count = [desc](const Solution& s) { return s.classes[desc].n; };
+    c->filter = [desc, var](const Solution& s, size_t i) { return s.classes[desc].vars[var][i] == NONE; };
+    c->weight = [w](const Solution&, size_t) { return w; };
+    return c;
+}
+
+// ---- N-queens (board.rs:21-47) --------------------------------------------
+inline std::unique_ptr<Model> make_nqueens(size_t n, const int64_t* rows) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<QueensFacts>();
+    facts->n = n;
+    facts->column.resize(n);
+    for (size_t i = 0; i < n; ++i) facts->column[i] = (int64_t)i;
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n;
+    s.classes[0].vars.assign(1, std::vector<int64_t>(rows, rows + n));
+    s.facts = facts;
+    m->director.constraints.members.push_back(make_unassigned(0, 0, Score::of(1, 0), "Unassigned queen"));
+    auto conflict = std::make_unique<CrossBiConstraint>();
+    conflict->name = "Queen conflict";
+    conflict->impact = Impact::Penalty;
+    conflict->a_source = conflict->b_source = ChangeSource::descriptor(0);
+    conflict->a_count = conflict->b_count = [](const Solution& s) { return s.classes[0].n; };
+    conflict->key_a = conflict->key_b = [](const Solution&, size_t) { return (int64_t)0; };  // predicate join
+    const QueensFacts* qf = facts.get();
+    conflict->filter = [qf](const Solution& s, size_t a, size_t b) {
+        int64_t ca = qf->column[a], cb = qf->column[b];
+        if (ca >= cb) return false;
+        int64_t ra = s.classes[0].vars[0][a], rb = s.classes[0].vars[0][b];
+        if (ra == NONE || rb == NONE) return false;
+        int64_t dr = ra > rb ? ra - rb : rb - ra;
+        int64_t dc = ca > cb ? ca - cb : cb - ca;
+        return ra == rb || dr == dc;
+    };
+    conflict->weight = [](const Solution&, size_t, size_t) { return Score::of(1, 0); };
+    m->director.constraints.members.push_back(std::move(conflict));
+    m->has_scalar = true;
+    m->scalar_slot.descriptor_index = 0;
+    m->scalar_slot.variable_index = 0;
+    m->scalar_slot.allows_unassigned = true;
+    m->scalar_slot.values_for_entity = [n](const Solution&, size_t, std::vector<int64_t>& out) {
+        out.clear();
+        for (size_t v = 0; v < n; ++v) out.push_back((int64_t)v);
+    };
+    m->leaves = LEAF_SCALAR_CHANGE | LEAF_SCALAR_SWAP;
+    m->wire_search();
+    return m;
+}
+
+// ---- graph colouring (graph_coloring.rs:21-44) ----------------------------
+inline std::unique_ptr<Model> make_graph_coloring(size_t n, size_t n_colors, const uint32_t* adj_off,
+                                                  const uint32_t* adj, const int64_t* colors) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<GraphFacts>();
+    facts->n = n;
+    facts->n_colors = n_colors;
+    facts->adj_off.assign(adj_off, adj_off + n + 1);
+    facts->adj.assign(adj, adj + adj_off[n]);
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n;
+    s.classes[0].vars.assign(1, std::vector<int64_t>(colors, colors + n));
+    s.facts = facts;
+    m->director.constraints.members.push_back(make_unassigned(0, 0, Score::of(1, 0), "Unassigned color"));
+    auto conflict = std::make_unique<CrossBiConstraint>();
+    conflict->name = "Adjacent color conflict";
+    conflict->impact = Impact::Penalty;
+    conflict->a_source = conflict->b_source = ChangeSource::descriptor(0);
+    conflict->a_count = conflict->b_count = [](const Solution& s) { return s.classes[0].n; };
+    conflict->key_a = conflict->key_b = [](const Solution&, size_t) { return (int64_t)0; };
+    const GraphFacts* gf = facts.get();
+    conflict->filter = [gf](const Solution& s, size_t a, size_t b) {
+        if (!(a < b)) return false;  // left.id < right.id (ids are indices)
+        bool adjacent = false;       // left.neighbors.contains(&right.id): linear Vec scan
+        for (uint32_t p = gf->adj_off[a]; p < gf->adj_off[a + 1]; ++p)
+            if (gf->adj[p] == b) {
+                adjacent = true;
+                break;
+            }
+        if (!adjacent) return false;
+        int64_t ca = s.classes[0].vars[0][a];
+        return ca != NONE && ca == s.classes[0].vars[0][b];
+    };
+    conflict->weight = [](const Solution&, size_t, size_t) { return Score::of(1, 0); };
+    m->director.constraints.members.push_back(std::move(conflict));
+    m->has_scalar = true;
+    m->scalar_slot.descriptor_index = 0;
+    m->scalar_slot.variable_index = 0;
+    m->scalar_slot.allows_unassigned = true;
+    m->scalar_slot.values_for_entity = [n_colors](const Solution&, size_t, std::vector<int64_t>& out) {
+        out.clear();
+        for (size_t v = 0; v < n_colors; ++v) out.push_back((int64_t)v);
+    };
+    m->leaves = LEAF_SCALAR_CHANGE | LEAF_SCALAR_SWAP;
+    m->wire_search();
+    return m;
+}
+
+// ---- CVRP -------------------------------------------------------------------
+inline int64_t cvrp_route_distance(const CvrpFacts& f, const std::vector<uint32_t>& route) {
+    if (route.empty()) return 0;
+    int64_t total = f.distance_cost(f.depot, route[0]);
+    for (size_t i = 0; i + 1 < route.size(); ++i) total = wrap_add(total, f.distance_cost(route[i], route[i + 1]));
+    return wrap_add(total, f.distance_cost(route.back(), f.depot));
+}
+inline int64_t cvrp_route_load(const CvrpFacts& f, const std::vector<uint32_t>& route) {
+    int64_t total = 0;
+    for (uint32_t v : route) total = wrap_add(total, (int64_t)f.demands[v]);
+    return total;
+}
+
+inline std::unique_ptr<Model> make_cvrp(size_t n_customers, size_t n_vehicles, int64_t capacity, size_t depot,
+                                        size_t dim, const int32_t* demands, const int64_t* matrix,
+                                        const uint32_t* customers, const uint32_t* route_off,
+                                        const uint32_t* route_vals) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<CvrpFacts>();
+    facts->capacity = capacity;
+    facts->depot = depot;
+    facts->dim = dim;
+    facts->demands.assign(demands, demands + dim);
+    facts->matrix.assign(matrix, matrix + dim * dim);
+    facts->customers.assign(customers, customers + n_customers);
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n_vehicles;
+    s.classes[0].lists.resize(n_vehicles);
+    for (size_t v = 0; v < n_vehicles; ++v)
+        s.classes[0].lists[v].assign(route_vals + route_off[v], route_vals + route_off[v + 1]);
+    s.facts = facts;
+    const CvrpFacts* cf = facts.get();
+
+    auto assigned = std::make_unique<ExistsConstraint>();
+    assigned->name = "all_customers_assigned";
+    assigned->impact = Impact::Penalty;
+    assigned->mode = ExistenceMode::NotExists;
+    assigned->a_source = ChangeSource::fixed();           // problem facts
+    assigned->parent_source = ChangeSource::descriptor(0);  // routes
+    assigned->a_count = [cf](const Solution&) { return cf->customers.size(); };
+    assigned->parent_count = [](const Solution& s) { return s.classes[0].n; };
+    assigned->filter_a = [](const Solution&, size_t) { return true; };
+    assigned->filter_parent = [](const Solution&, size_t) { return true; };
+    assigned->key_a = [cf](const Solution&, size_t i) { return (int64_t)cf->customers[i]; };
+    assigned->flatten = [](const Solution& s, size_t p, std::vector<int64_t>& out) {
+        for (uint32_t v : s.classes[0].lists[p]) out.push_back((int64_t)v);
+    };
+    assigned->weight = [](const Solution&, size_t) { return Score::of(1, 0); };
+    assigned->indexed_usize = true;
+    m->director.constraints.members.push_back(std::move(assigned));
+
+    auto cap = std::make_unique<UniConstraint>();
+    cap->name = "vehicle_capacity";
+    cap->impact = Impact::Penalty;
+    cap->source = ChangeSource::descriptor(0);
+    cap->count = [](const Solution& s) { return s.classes[0].n; };
+    cap->filter = [](const Solution&, size_t) { return true; };
+    cap->weight = [cf](const Solution& s, size_t r) {
+        int64_t over = wrap_sub(cvrp_route_load(*cf, s.classes[0].lists[r]), cf->capacity);
+        return Score::of(over > 0 ? over : 0, 0);
+    };
+    m->director.constraints.members.push_back(std::move(cap));
+
+    auto dist = std::make_unique<UniConstraint>();
+    dist->name = "total_distance";
+    dist->impact = Impact::Penalty;
+    dist->source = ChangeSource::descriptor(0);
+    dist->count = [](const Solution& s) { return s.classes[0].n; };
+    dist->filter = [](const Solution&, size_t) { return true; };
+    dist->weight = [cf](const Solution& s, size_t r) {
+        return Score::of(0, cvrp_route_distance(*cf, s.classes[0].lists[r]));
+    };
+    m->director.constraints.members.push_back(std::move(dist));
+
+    m->has_list = true;
+    m->list_slot.descriptor_index = 0;
+    // MatrixDistanceMeter (meters.rs:10-28)
+    m->list_slot.meter = [cf](const Solution& s, size_t se, size_t sp, size_t de, size_t dp) -> double {
+        const auto& sv = s.classes[0].lists[se];
+        const auto& dv = s.classes[0].lists[de];
+        if (sp >= sv.size() || dp >= dv.size()) return std::numeric_limits<double>::infinity();
+        int64_t v;
+        if (!cf->finite(sv[sp], dv[dp], v)) return std::numeric_limits<double>::infinity();
+        return (double)v;
+    };
+    m->leaves = LEAF_NEARBY_LIST_CHANGE | LEAF_NEARBY_LIST_SWAP;
+    m->wire_search();
+    return m;
+}
+
+// ---- plain list model for selector goldens (Vehicle/Plan toy domain of
+// heuristic/selector/tests/*.rs and benches/selector_cursor_gate.rs) -------------
+enum class ToyMeter { Equal, Position };
+inline std::unique_ptr<Model> make_list_toy(size_t n_entities, const uint32_t* off, const uint32_t* vals,
+                                            ToyMeter meter) {
+    auto m = std::make_unique<Model>();
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n_entities;
+    s.classes[0].lists.resize(n_entities);
+    for (size_t v = 0; v < n_entities; ++v) s.classes[0].lists[v].assign(vals + off[v], vals + off[v + 1]);
+    m->has_list = true;
+    m->list_slot.descriptor_index = 0;
+    if (meter == ToyMeter::Equal)  // EqualDistanceMeter (tests/nearby_list.rs)
+        m->list_slot.meter = [](const Solution&, size_t, size_t, size_t, size_t) { return 1.0; };
+    else  // PositionDistanceMeter (benches/selector_cursor_gate.rs:131-146)
+        m->list_slot.meter = [](const Solution&, size_t se, size_t sp, size_t de, size_t dp) {
+            double de_ = (double)(se > de ? se - de : de - se);
+            double dp_ = (double)(sp > dp ? sp - dp : dp - sp);
+            return de_ * 100.0 + dp_;
+        };
+    m->leaves = LEAF_LIST_CHANGE;
+    m->wire_search();
+    return m;
+}
+
+// ---- mixed job shop (job_shop_plan.rs:28-69) mapped to BendableScore<2,1> -----
+// level 0 = hard[0] unassigned machine, level 1 = hard[1] unscheduled operation,
+// level 2 = soft[0] same-job-same-machine.  (The reference example itself uses
+// HardSoftScore; Bendable is a BASELINE.json requirement)
+inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, const int64_t* job,
+                                           const int64_t* machine_idx, const uint32_t* seq_off,
+                                           const uint32_t* seq_vals, bool bendable) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<JobShopFacts>();
+    facts->n_ops = n_ops;
+    facts->n_machines = n_machines;
+    facts->job.assign(job, job + n_ops);
+    Solution& s = m->director.working;
+    s.classes.resize(2);
+    s.classes[0].n = n_ops;
+    s.classes[0].vars.assign(1, std::vector<int64_t>(machine_idx, machine_idx + n_ops));
+    s.classes[1].n = n_machines;
+    s.classes[1].lists.resize(n_machines);
+    for (size_t v = 0; v < n_machines; ++v)
+        s.classes[1].lists[v].assign(seq_vals + seq_off[v], seq_vals + seq_off[v + 1]);
+    s.facts = facts;
+    const JobShopFacts* jf = facts.get();
+    Score w_unassigned = bendable ? Score::level(0, 1) : Score::of(1, 0);
+    Score w_unscheduled = bendable ? Score::level(1, 1) : Score::of(1, 0);
+    Score w_reuse = bendable ? Score::level(2, 1) : Score::of(0, 1);
+    if (bendable) {
+        m->director.levels = 3;
+        m->director.hard_levels = 2;
+    }
+    m->director.constraints.members.push_back(make_unassigned(0, 0, w_unassigned, "Unassigned operation machine"));
+
+    auto unsched = std::make_unique<ExistsConstraint>();
+    unsched->name = "Unscheduled operation";
+    unsched->impact = Impact::Penalty;
+    unsched->mode = ExistenceMode::NotExists;
+    unsched->a_source = ChangeSource::descriptor(0);
+    unsched->parent_source = ChangeSource::descriptor(1);
+    unsched->a_count = [](const Solution& s) { return s.classes[0].n; };
+    unsched->parent_count = [](const Solution& s) { return s.classes[1].n; };
+    unsched->filter_a = [](const Solution&, size_t) { return true; };
+    unsched->filter_parent = [](const Solution&, size_t) { return true; };
+    unsched->key_a = [](const Solution&, size_t i) { return (int64_t)i; };  // operation.id
+    unsched->flatten = [](const Solution& s, size_t p, std::vector<int64_t>& out) {
+        for (uint32_t v : s.classes[1].lists[p]) out.push_back((int64_t)v);
+    };
+    unsched->weight = [w_unscheduled](const Solution&, size_t) { return w_unscheduled; };
+    m->director.constraints.members.push_back(std::move(unsched));
+
+    auto reuse = std::make_unique<CrossBiConstraint>();
+    reuse->name = "Same job machine reuse";
+    reuse->impact = Impact::Penalty;
+    reuse->a_source = reuse->b_source = ChangeSource::descriptor(0);
+    reuse->a_count = reuse->b_count = [](const Solution& s) { return s.classes[0].n; };
+    reuse->key_a = reuse->key_b = [](const Solution&, size_t) { return (int64_t)0; };
+    reuse->filter = [jf](const Solution& s, size_t a, size_t b) {
+        if (!(a < b)) return false;
+        if (jf->job[a] != jf->job[b]) return false;
+        int64_t ma = s.classes[0].vars[0][a];
+        return ma != NONE && ma == s.classes[0].vars[0][b];
+    };
+    reuse->weight = [w_reuse](const Solution&, size_t, size_t) { return w_reuse; };
+    m->director.constraints.members.push_back(std::move(reuse));
+
+    m->has_scalar = true;
+    m->scalar_slot.descriptor_index = 0;
+    m->scalar_slot.variable_index = 0;
+    m->scalar_slot.allows_unassigned = true;
+    m->scalar_slot.values_for_entity = [n_machines](const Solution&, size_t, std::vector<int64_t>& out) {
+        out.clear();
+        for (size_t v = 0; v < n_machines; ++v) out.push_back((int64_t)v);
+    };
+    m->has_list = true;
+    m->list_slot.descriptor_index = 1;
+    m->leaves = LEAF_LIST_CHANGE | LEAF_LIST_SWAP | LEAF_SCALAR_CHANGE | LEAF_SCALAR_SWAP;
+    m->wire_search();
+    return m;
+}
+
+}  // namespace sfo

@@ -1,0 +1,821 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see sfo_core.hpp header).
+//
+// CPU restatement of the in-scope moves and seeded candidate cursors.
+//
+// Follows:
+//   heuristic/move/traits.rs:30-95, move/change.rs:118-221, move/swap.rs:150-215
+//   heuristic/selector/scalar_neighborhood/move/apply.rs:10-335 (doable / apply_one / apply_many)
+//   heuristic/move/list_kernel/change.rs:16-153, list_kernel/swap.rs:17-110
+//   heuristic/selector/scalar_neighborhood/cursor/change.rs:27-121, cursor/swap.rs:22-160,
+//       cursor.rs:371-378 (slot_identity)
+//   heuristic/selector/list_kernel/change.rs:25-241, list_kernel/swap.rs:25-270
+//   heuristic/selector/list_kernel/nearby_change.rs:17-233, nearby_swap.rs:17-260
+//   heuristic/selector/nearby_list_support.rs:3-34 (stable bounded top-k)
+//   heuristic/selector/list_support.rs:13-26,62-70
+//   runtime/compiler/executor/list_leaf/cursor/slot.rs:196-499 (runtime leaf entity order)
+//   heuristic/selector/decorator/vec_union.rs:190-365 (UnionScheduler)
+// (all paths under crates/solverforge-solver/src/)
+#pragma once
+#include <cmath>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#include "sfo_scoring.hpp"
+
+namespace sfo {
+
+struct Move {
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3 } kind = Change;
+    size_t descriptor = 0;
+    size_t variable = 0;
+    // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
+    // ListChange: (a, a_pos) -> (b, b_pos) [pre-removal destination coords].
+    // ListSwap: (a, a_pos) <-> (b, b_pos).
+    size_t a = 0, a_pos = 0, b = 0, b_pos = 0;
+    int64_t to_value = NONE;
+    bool allows_unassigned = false;
+};
+inline bool operator==(const Move& x, const Move& y) {
+    return x.kind == y.kind && x.descriptor == y.descriptor && x.variable == y.variable && x.a == y.a &&
+           x.a_pos == y.a_pos && x.b == y.b && x.b_pos == y.b_pos && x.to_value == y.to_value;
+}
+
+struct MoveUndo {
+    int64_t old_a = NONE, old_b = NONE;
+};
+
+inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
+    const Solution& s = d.working;
+    const EntityClass& c = s.classes[m.descriptor];
+    switch (m.kind) {
+        case Move::Change: {  // scalar_neighborhood/move/apply.rs:15-24,219-230
+            if (m.a >= c.n) return false;
+            if (c.vars[m.variable][m.a] == m.to_value) return false;
+            return m.to_value != NONE || m.allows_unassigned;
+        }
+        case Move::Swap: {  // apply.rs:25-35,232-245
+            if (m.a == m.b || m.a >= c.n || m.b >= c.n) return false;
+            return c.vars[m.variable][m.a] != c.vars[m.variable][m.b];
+        }
+        case Move::ListChange: {  // move/list_kernel/change.rs:44-71
+            size_t src_len = c.lists[m.a].size();
+            if (m.a_pos >= src_len) return false;
+            bool intra = m.a == m.b;
+            size_t max_dst = intra ? src_len : c.lists[m.b].size();
+            if (m.b_pos > max_dst) return false;
+            return !intra || (m.a_pos != m.b_pos && m.b_pos != m.a_pos + 1);
+        }
+        case Move::ListSwap: {  // move/list_kernel/swap.rs:30-56
+            if (m.a_pos >= c.lists[m.a].size() || m.b_pos >= c.lists[m.b].size()) return false;
+            if (m.a == m.b && m.a_pos == m.b_pos) return false;
+            return c.lists[m.a][m.a_pos] != c.lists[m.b][m.b_pos];
+        }
+    }
+    return false;
+}
+
+inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
+    MoveUndo u;
+    EntityClass& c = d.working.classes[m.descriptor];
+    switch (m.kind) {
+        case Move::Change: {  // apply_one (apply.rs:288-303)
+            u.old_a = c.vars[m.variable][m.a];
+            d.before_variable_changed(m.descriptor, m.a);
+            c.vars[m.variable][m.a] = m.to_value;
+            d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
+        case Move::Swap: {  // apply_many (apply.rs:305-335)
+            u.old_a = c.vars[m.variable][m.a];
+            u.old_b = c.vars[m.variable][m.b];
+            d.before_variable_changed(m.descriptor, m.a);
+            d.before_variable_changed(m.descriptor, m.b);
+            c.vars[m.variable][m.a] = u.old_b;
+            c.vars[m.variable][m.b] = u.old_a;
+            d.after_variable_changed(m.descriptor, m.a);
+            d.after_variable_changed(m.descriptor, m.b);
+            break;
+        }
+        case Move::ListChange: {  // move/list_kernel/change.rs:73-120
+            bool intra = m.a == m.b;
+            d.before_variable_changed(m.descriptor, m.a);
+            if (!intra) d.before_variable_changed(m.descriptor, m.b);
+            uint32_t value = c.lists[m.a][m.a_pos];
+            c.lists[m.a].erase(c.lists[m.a].begin() + (ptrdiff_t)m.a_pos);
+            size_t dst = (intra && m.b_pos > m.a_pos) ? m.b_pos - 1 : m.b_pos;  // adjusted_destination
+            c.lists[m.b].insert(c.lists[m.b].begin() + (ptrdiff_t)dst, value);
+            d.after_variable_changed(m.descriptor, m.a);
+            if (!intra) d.after_variable_changed(m.descriptor, m.b);
+            break;
+        }
+        case Move::ListSwap: {  // move/list_kernel/swap.rs:58-110
+            bool intra = m.a == m.b;
+            uint32_t first = c.lists[m.a][m.a_pos];
+            uint32_t second = c.lists[m.b][m.b_pos];
+            d.before_variable_changed(m.descriptor, m.a);
+            if (!intra) d.before_variable_changed(m.descriptor, m.b);
+            c.lists[m.a][m.a_pos] = second;
+            c.lists[m.b][m.b_pos] = first;
+            d.after_variable_changed(m.descriptor, m.a);
+            if (!intra) d.after_variable_changed(m.descriptor, m.b);
+            break;
+        }
+    }
+    return u;
+}
+
+inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
+    EntityClass& c = d.working.classes[m.descriptor];
+    switch (m.kind) {
+        case Move::Change: {
+            d.before_variable_changed(m.descriptor, m.a);
+            c.vars[m.variable][m.a] = u.old_a;
+            d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
+        case Move::Swap: {
+            d.before_variable_changed(m.descriptor, m.a);
+            d.before_variable_changed(m.descriptor, m.b);
+            c.vars[m.variable][m.a] = u.old_a;
+            c.vars[m.variable][m.b] = u.old_b;
+            d.after_variable_changed(m.descriptor, m.a);
+            d.after_variable_changed(m.descriptor, m.b);
+            break;
+        }
+        case Move::ListChange: {  // change_undo_move (move/list_kernel/change.rs:122-153)
+            bool intra = m.a == m.b;
+            size_t dst = (intra && m.b_pos > m.a_pos) ? m.b_pos - 1 : m.b_pos;
+            d.before_variable_changed(m.descriptor, m.b);
+            if (!intra) d.before_variable_changed(m.descriptor, m.a);
+            uint32_t value = c.lists[m.b][dst];
+            c.lists[m.b].erase(c.lists[m.b].begin() + (ptrdiff_t)dst);
+            c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)m.a_pos, value);
+            d.after_variable_changed(m.descriptor, m.b);
+            if (!intra) d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
+        case Move::ListSwap: {  // swap is its own inverse
+            MoveUndo ignored = move_do(d, m);
+            (void)ignored;
+            break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Cursors
+// ---------------------------------------------------------------------------
+struct Cursor {
+    virtual ~Cursor() = default;
+    virtual bool next(Move& out) = 0;
+};
+
+struct ScalarSlot {
+    size_t descriptor_index = 0;
+    size_t variable_index = 0;
+    bool allows_unassigned = false;
+    bool empty_value_source = false;
+    // canonical candidate values for one entity (ValueSource; builder/context/scalar/variable.rs:138-192)
+    std::function<void(const Solution&, size_t entity, std::vector<int64_t>& out)> values_for_entity;
+    uint64_t identity() const {  // cursor.rs:371-378
+        return ((uint64_t)descriptor_index << 32) ^ (uint64_t)variable_index;
+    }
+};
+
+// Scalar change leaf (scalar_neighborhood/cursor/change.rs:27-121).
+struct ScalarChangeCursor : Cursor {
+    static constexpr uint64_t VALUE_SALT = 0xC4A46E0000000000ULL;
+    static constexpr uint64_t ENTITY_SALT = 0xC4A46E0000000001ULL;
+    struct Row {
+        size_t entity;
+        std::vector<int64_t> values;
+        bool current_assigned;
+    };
+    ScalarSlot slot;
+    std::vector<Row> rows;
+    size_t row_offset = 0, value_offset = 0;
+    bool unassigned_pending = false;
+
+    ScalarChangeCursor(const ScalarSlot& sl, const Solution& solution_in, const MoveStreamContext& ctx)
+        : slot(sl) {
+        Solution solution = solution_in;  // the leaf clones the working solution (cursor.rs:89)
+        uint64_t identity = slot.identity();
+        size_t n = solution.classes[slot.descriptor_index].n;
+        rows.reserve(n);
+        std::vector<int64_t> canonical;
+        for (size_t off = 0; off < n; ++off) {
+            size_t e = ctx.selection_index_without_replacement(off, n, ENTITY_SALT ^ identity);
+            canonical.clear();
+            slot.values_for_entity(solution, e, canonical);
+            size_t vc = canonical.size();
+            Row row;
+            row.entity = e;
+            row.values.resize(vc);
+            for (size_t vo = 0; vo < vc; ++vo)
+                row.values[vo] = canonical[ctx.selection_index(vo, vc, VALUE_SALT ^ (uint64_t)e ^ identity)];
+            row.current_assigned = solution.classes[slot.descriptor_index].vars[slot.variable_index][e] != NONE;
+            rows.push_back(std::move(row));
+        }
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (row_offset >= rows.size()) return false;
+            Row& row = rows[row_offset];
+            if (value_offset < row.values.size()) {
+                out = Move{};
+                out.kind = Move::Change;
+                out.descriptor = slot.descriptor_index;
+                out.variable = slot.variable_index;
+                out.a = row.entity;
+                out.to_value = row.values[value_offset++];
+                out.allows_unassigned = slot.allows_unassigned;
+                return true;
+            }
+            if (!unassigned_pending && slot.allows_unassigned && row.current_assigned) {
+                unassigned_pending = true;
+                out = Move{};
+                out.kind = Move::Change;
+                out.descriptor = slot.descriptor_index;
+                out.variable = slot.variable_index;
+                out.a = row.entity;
+                out.to_value = NONE;
+                out.allows_unassigned = slot.allows_unassigned;
+                return true;
+            }
+            ++row_offset;
+            value_offset = 0;
+            unassigned_pending = false;
+        }
+    }
+};
+
+// Scalar swap leaf (scalar_neighborhood/cursor/swap.rs:22-160).
+struct ScalarSwapCursor : Cursor {
+    static constexpr uint64_t LEFT_SALT = 0x5A095CA1AA000001ULL;
+    static constexpr uint64_t RIGHT_SALT = 0x5A095CA1AA000002ULL;
+    static constexpr uint64_t ENTITY_STRIDE_MIX = 0xD1B54A32D192ED03ULL;
+    ScalarSlot slot;
+    MoveStreamContext ctx;
+    std::vector<int64_t> current_values;
+    std::vector<std::vector<int64_t>> legal_values;
+    size_t left_offset = 0, right_offset = 0;
+
+    ScalarSwapCursor(const ScalarSlot& sl, const Solution& solution_in, const MoveStreamContext& c)
+        : slot(sl), ctx(c) {
+        Solution solution = solution_in;
+        size_t n = solution.classes[slot.descriptor_index].n;
+        current_values = solution.classes[slot.descriptor_index].vars[slot.variable_index];
+        legal_values.resize(n);
+        for (size_t e = 0; e < n; ++e) slot.values_for_entity(solution, e, legal_values[e]);
+    }
+    bool destination_is_legal(size_t e, int64_t value) const {  // swap.rs:103-123
+        if (slot.empty_value_source) return value != NONE;
+        if (value == NONE) return slot.allows_unassigned;
+        for (int64_t v : legal_values[e])
+            if (v == value) return true;
+        return false;
+    }
+    bool next(Move& out) override {  // swap.rs:125-160
+        size_t n = current_values.size();
+        uint64_t identity = slot.identity();
+        while (left_offset < n) {
+            size_t left = n <= 1 ? 0
+                                 : ctx.selection_index_without_replacement(
+                                       left_offset, n, (LEFT_SALT ^ identity) ^ ENTITY_STRIDE_MIX);
+            while (right_offset < n) {
+                size_t right =
+                    n <= 1 ? 0
+                           : ctx.selection_index(right_offset, n,
+                                                 (RIGHT_SALT ^ (uint64_t)left ^ (uint64_t)slot.variable_index) ^
+                                                     ENTITY_STRIDE_MIX);
+                ++right_offset;
+                if (left >= right) continue;
+                int64_t lv = current_values[left], rv = current_values[right];
+                if (lv == rv || !destination_is_legal(left, rv) || !destination_is_legal(right, lv)) continue;
+                out = Move{};
+                out.kind = Move::Swap;
+                out.descriptor = slot.descriptor_index;
+                out.variable = slot.variable_index;
+                out.a = left;
+                out.b = right;
+                out.allows_unassigned = slot.allows_unassigned;
+                return true;
+            }
+            ++left_offset;
+            right_offset = 0;
+        }
+        return false;
+    }
+};
+
+// ---- list leaves -----------------------------------------------------------
+using DistanceMeter =
+    std::function<double(const Solution&, size_t src_e, size_t src_p, size_t dst_e, size_t dst_p)>;
+
+struct ListSlot {
+    size_t descriptor_index = 0;
+    DistanceMeter meter;  // CrossEntityDistanceMeter (selector/nearby_list_change.rs:22-31)
+    // Entity order profile.  The compiled runtime leaf orders entities WITHOUT replacement
+    // (list_leaf/cursor/slot.rs:468-499); the public selectors re-index WITH replacement
+    // (selector/list_support.rs:13-26).  Both are identity under SelectionOrder::Original.
+    bool public_selector_entity_order = false;
+};
+
+inline void selected_entities(const ListSlot& slot, const Solution& s, const MoveStreamContext& ctx,
+                              uint64_t salt, std::vector<size_t>& entities,
+                              std::vector<size_t>& route_lens) {
+    const EntityClass& c = s.classes[slot.descriptor_index];
+    size_t n = c.n;
+    entities.resize(n);
+    route_lens.resize(n);
+    for (size_t off = 0; off < n; ++off) {
+        size_t e;
+        if (n <= 1)
+            e = off;
+        else if (slot.public_selector_entity_order)
+            e = ctx.selection_index(off, n, salt);
+        else
+            e = ctx.selection_index_without_replacement(off, n, salt);
+        entities[off] = e;
+        route_lens[off] = c.lists[e].size();
+    }
+}
+
+inline Move make_list_move(Move::Kind k, size_t desc, size_t a, size_t ap, size_t b, size_t bp) {
+    Move m;
+    m.kind = k;
+    m.descriptor = desc;
+    m.a = a;
+    m.a_pos = ap;
+    m.b = b;
+    m.b_pos = bp;
+    return m;
+}
+
+// Full list change (selector/list_kernel/change.rs:25-241).
+struct ListChangeCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x1157C4A46E000001ULL;
+    static constexpr uint64_t SALT_SOURCE = 0x1157C4A46E000002ULL;
+    static constexpr uint64_t SALT_INTRA = 0x1157C4A46E000003ULL;
+    static constexpr uint64_t SALT_INTER = 0x1157C4A46E000004ULL;
+    size_t desc;
+    MoveStreamContext ctx;
+    std::vector<size_t> entities, route_lens;
+    size_t src_idx = 0, src_pos_offset = 0;
+    bool stage_intra = true;
+    size_t intra_dst_offset = 0, dst_idx = 0, inter_dst_pos_offset = 0;
+
+    ListChangeCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c)
+        : desc(slot.descriptor_index), ctx(c) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    void advance_source_position() {
+        ++src_pos_offset;
+        stage_intra = true;
+        intra_dst_offset = 0;
+        dst_idx = 0;
+        inter_dst_pos_offset = 0;
+        while (src_idx < route_lens.size() && src_pos_offset >= route_lens[src_idx]) {
+            ++src_idx;
+            src_pos_offset = 0;
+        }
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (src_idx >= entities.size()) return false;
+            size_t se = entities[src_idx];
+            size_t slen = route_lens[src_idx];
+            if (slen == 0) {
+                ++src_idx;
+                continue;
+            }
+            size_t sp = ctx.selection_index(src_pos_offset, slen, SALT_SOURCE ^ (uint64_t)se ^ (uint64_t)desc);
+            if (stage_intra) {
+                while (intra_dst_offset <= slen) {
+                    size_t dp = ctx.selection_index(intra_dst_offset, slen + 1,
+                                                    SALT_INTRA ^ (uint64_t)se ^ (uint64_t)sp);
+                    ++intra_dst_offset;
+                    if (sp == dp || dp == sp + 1) continue;
+                    out = make_list_move(Move::ListChange, desc, se, sp, se, dp);
+                    return true;
+                }
+                stage_intra = false;
+                dst_idx = 0;
+                inter_dst_pos_offset = 0;
+            } else {
+                while (dst_idx < entities.size()) {
+                    if (dst_idx == src_idx) {
+                        ++dst_idx;
+                        inter_dst_pos_offset = 0;
+                        continue;
+                    }
+                    size_t de = entities[dst_idx];
+                    size_t dlen = route_lens[dst_idx];
+                    if (inter_dst_pos_offset <= dlen) {
+                        size_t dp = ctx.selection_index(inter_dst_pos_offset, dlen + 1,
+                                                        SALT_INTER ^ (uint64_t)se ^ (uint64_t)de ^ (uint64_t)sp);
+                        ++inter_dst_pos_offset;
+                        out = make_list_move(Move::ListChange, desc, se, sp, de, dp);
+                        return true;
+                    }
+                    ++dst_idx;
+                    inter_dst_pos_offset = 0;
+                }
+                advance_source_position();
+            }
+        }
+    }
+};
+
+// Full list swap (selector/list_kernel/swap.rs:25-270).
+struct ListSwapCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x11575A0900000001ULL;
+    static constexpr uint64_t SALT_FIRST = 0x11575A0900000002ULL;
+    static constexpr uint64_t SALT_SECOND = 0x11575A0900000003ULL;
+    static constexpr uint64_t SALT_INTER_FIRST = 0x11575A0900000004ULL;
+    static constexpr uint64_t SALT_INTER_SECOND = 0x11575A0900000005ULL;
+    size_t desc;
+    MoveStreamContext ctx;
+    std::vector<size_t> entities, route_lens;
+    size_t entity_idx = 0;
+    bool stage_intra = true;
+    size_t first_off = 0, second_off = 0, destination_idx = 1, inter_first_off = 0, inter_second_off = 0;
+
+    ListSwapCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c)
+        : desc(slot.descriptor_index), ctx(c) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    void advance_entity() {
+        ++entity_idx;
+        stage_intra = true;
+        first_off = second_off = 0;
+        destination_idx = entity_idx + 1;
+        inter_first_off = inter_second_off = 0;
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (entity_idx >= entities.size()) return false;
+            size_t fe = entities[entity_idx];
+            size_t flen = route_lens[entity_idx];
+            if (flen == 0) {
+                advance_entity();
+                continue;
+            }
+            if (stage_intra) {
+                while (first_off < flen) {
+                    size_t fp = ctx.selection_index(first_off, flen, SALT_FIRST ^ (uint64_t)fe ^ (uint64_t)desc);
+                    size_t second_count = flen > fp + 1 ? flen - (fp + 1) : 0;
+                    if (second_off < second_count) {
+                        size_t sp = fp + 1 +
+                                    ctx.selection_index(second_off, second_count,
+                                                        SALT_SECOND ^ (uint64_t)fe ^ (uint64_t)fp);
+                        ++second_off;
+                        out = make_list_move(Move::ListSwap, desc, fe, fp, fe, sp);
+                        return true;
+                    }
+                    ++first_off;
+                    second_off = 0;
+                }
+                stage_intra = false;
+                destination_idx = entity_idx + 1;
+                inter_first_off = inter_second_off = 0;
+            } else {
+                while (destination_idx < entities.size()) {
+                    size_t se = entities[destination_idx];
+                    size_t slen = route_lens[destination_idx];
+                    if (slen == 0) {
+                        ++destination_idx;
+                        continue;
+                    }
+                    while (inter_first_off < flen) {
+                        size_t fp = ctx.selection_index(inter_first_off, flen,
+                                                        SALT_INTER_FIRST ^ (uint64_t)fe ^ (uint64_t)se);
+                        if (inter_second_off < slen) {
+                            size_t sp = ctx.selection_index(
+                                inter_second_off, slen,
+                                SALT_INTER_SECOND ^ (uint64_t)fe ^ (uint64_t)se ^ (uint64_t)fp);
+                            ++inter_second_off;
+                            out = make_list_move(Move::ListSwap, desc, fe, fp, se, sp);
+                            return true;
+                        }
+                        ++inter_first_off;
+                        inter_second_off = 0;
+                    }
+                    ++destination_idx;
+                    inter_first_off = inter_second_off = 0;
+                }
+                advance_entity();
+            }
+        }
+    }
+};
+
+struct NearbyCandidate {
+    size_t entity, position;
+    double distance;
+};
+
+// Stable bounded top-k (selector/nearby_list_support.rs:3-34): equivalent to a stable
+// sort by partial_cmp (incomparable == Equal) followed by truncate(max_nearby).
+inline void sort_and_limit_nearby_candidates(std::vector<NearbyCandidate>& c, size_t max_nearby) {
+    if (max_nearby == 0) {
+        c.clear();
+        return;
+    }
+    size_t retained = 0;
+    for (size_t read = 0; read < c.size(); ++read) {
+        NearbyCandidate cand = c[read];
+        // partition_point(|existing| existing.partial_cmp(cand) != Greater)
+        size_t lo = 0, hi = retained;
+        while (lo < hi) {
+            size_t mid = lo + (hi - lo) / 2;
+            bool greater = c[mid].distance > cand.distance;  // NaN compares false => "Equal"
+            if (!greater)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        size_t insertion = lo;
+        if (insertion >= max_nearby) continue;
+        size_t next_retained = retained + 1 < max_nearby ? retained + 1 : max_nearby;
+        for (size_t i = next_retained - 1; i > insertion; --i) c[i] = c[i - 1];
+        c[insertion] = cand;
+        retained = next_retained;
+    }
+    c.resize(retained);
+}
+
+// Nearby list change (selector/list_kernel/nearby_change.rs:17-233).
+struct NearbyListChangeCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0xA1EA2B17C4A40001ULL;
+    static constexpr uint64_t SALT_SOURCE = 0xA1EA2B17C4A40002ULL;
+    size_t desc;
+    MoveStreamContext ctx;
+    Solution solution;  // the runtime leaf clones the solution on open (slot.rs:238)
+    DistanceMeter meter;
+    size_t max_nearby;
+    std::vector<size_t> entities, route_lens;
+    size_t source_idx = 0, source_pos_offset = 0;
+    size_t cur_e = 0, cur_p = 0;
+    std::vector<NearbyCandidate> candidates;
+    std::vector<std::pair<size_t, size_t>> destinations;
+    size_t destination_offset = 0;
+    uint64_t probes = 0;  // distance-meter calls (generation cost)
+
+    NearbyListChangeCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c, size_t k)
+        : desc(slot.descriptor_index), ctx(c), solution(s), meter(slot.meter), max_nearby(k) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    bool load_next_source() {
+        while (source_idx < entities.size()) {
+            size_t se = entities[source_idx];
+            size_t slen = route_lens[source_idx];
+            if (slen == 0) {
+                ++source_idx;
+                source_pos_offset = 0;
+                continue;
+            }
+            while (source_pos_offset < slen) {
+                size_t sp = ctx.selection_index(source_pos_offset, slen,
+                                                SALT_SOURCE ^ (uint64_t)se ^ (uint64_t)desc);
+                ++source_pos_offset;
+                candidates.clear();
+                for (size_t dp = 0; dp <= slen; ++dp) {
+                    if (dp == sp || dp == sp + 1) continue;
+                    size_t ref = dp < slen - 1 ? dp : slen - 1;  // min(dp, len.saturating_sub(1))
+                    double dist = meter(solution, se, sp, se, ref);
+                    ++probes;
+                    if (std::isfinite(dist)) candidates.push_back({se, dp, dist});
+                }
+                for (size_t di = 0; di < entities.size(); ++di) {
+                    if (di == source_idx) continue;
+                    size_t de = entities[di];
+                    size_t dlen = route_lens[di];
+                    for (size_t dp = 0; dp <= dlen; ++dp) {
+                        size_t last = dlen > 0 ? dlen - 1 : 0;
+                        size_t ref = dp < last ? dp : last;
+                        double dist = meter(solution, se, sp, de, ref);
+                        ++probes;
+                        if (std::isfinite(dist)) candidates.push_back({de, dp, dist});
+                    }
+                }
+                sort_and_limit_nearby_candidates(candidates, max_nearby);
+                if (candidates.empty()) continue;
+                cur_e = se;
+                cur_p = sp;
+                destinations.clear();
+                for (auto& cd : candidates) destinations.push_back({cd.entity, cd.position});
+                destination_offset = 0;
+                return true;
+            }
+            ++source_idx;
+            source_pos_offset = 0;
+        }
+        return false;
+    }
+    bool next(Move& out) override {
+        if (destination_offset >= destinations.size() && !load_next_source()) return false;
+        auto& d = destinations[destination_offset++];
+        out = make_list_move(Move::ListChange, desc, cur_e, cur_p, d.first, d.second);
+        return true;
+    }
+};
+
+// Nearby list swap (selector/list_kernel/nearby_swap.rs:17-260).
+struct NearbyListSwapCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0xA1EA25A090000001ULL;
+    static constexpr uint64_t SALT_SOURCE = 0xA1EA25A090000002ULL;
+    size_t desc;
+    MoveStreamContext ctx;
+    Solution solution;
+    DistanceMeter meter;
+    size_t max_nearby;
+    std::vector<size_t> entities, route_lens;
+    size_t source_idx = 0, source_pos_offset = 0;
+    size_t cur_e = 0, cur_p = 0;
+    std::vector<NearbyCandidate> candidates;
+    std::vector<std::pair<size_t, size_t>> destinations;
+    size_t destination_offset = 0;
+    uint64_t probes = 0;
+
+    NearbyListSwapCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c, size_t k)
+        : desc(slot.descriptor_index), ctx(c), solution(s), meter(slot.meter), max_nearby(k) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    bool load_next_source() {
+        while (source_idx < entities.size()) {
+            size_t se = entities[source_idx];
+            size_t slen = route_lens[source_idx];
+            if (slen == 0) {
+                ++source_idx;
+                source_pos_offset = 0;
+                continue;
+            }
+            while (source_pos_offset < slen) {
+                size_t sp = ctx.selection_index(source_pos_offset, slen,
+                                                SALT_SOURCE ^ (uint64_t)se ^ (uint64_t)desc);
+                ++source_pos_offset;
+                candidates.clear();
+                for (size_t dp = sp + 1; dp < slen; ++dp) {
+                    double dist = meter(solution, se, sp, se, dp);
+                    ++probes;
+                    if (std::isfinite(dist)) candidates.push_back({se, dp, dist});
+                }
+                for (size_t di = 0; di < entities.size(); ++di) {
+                    if (di <= source_idx) continue;
+                    size_t de = entities[di];
+                    size_t dlen = route_lens[di];
+                    if (dlen == 0) continue;
+                    for (size_t dp = 0; dp < dlen; ++dp) {
+                        double dist = meter(solution, se, sp, de, dp);
+                        ++probes;
+                        if (std::isfinite(dist)) candidates.push_back({de, dp, dist});
+                    }
+                }
+                sort_and_limit_nearby_candidates(candidates, max_nearby);
+                if (candidates.empty()) continue;
+                cur_e = se;
+                cur_p = sp;
+                destinations.clear();
+                for (auto& cd : candidates) destinations.push_back({cd.entity, cd.position});
+                destination_offset = 0;
+                return true;
+            }
+            ++source_idx;
+            source_pos_offset = 0;
+        }
+        return false;
+    }
+    bool next(Move& out) override {
+        if (destination_offset >= destinations.size() && !load_next_source()) return false;
+        auto& d = destinations[destination_offset++];
+        out = make_list_move(Move::ListSwap, desc, cur_e, cur_p, d.first, d.second);
+        return true;
+    }
+};
+
+// ---- union of leaves (selector/decorator/vec_union.rs:190-365) -------------
+enum class UnionOrder { Sequential, RoundRobin, RotatingRoundRobin, Random, StratifiedRandom };
+
+struct UnionScheduler {
+    size_t current_cursor = 0;
+    UnionOrder order;
+    std::vector<bool> exhausted;
+    size_t live = 0;
+    size_t cursor_offset = 0, cursor_stride = 1;
+    MoveStreamContext ctx;
+    uint64_t random_draw = 0;
+    std::vector<uint64_t> weights;
+    std::vector<__int128> weighted_current;
+    uint64_t total_live_weight = 0;
+
+    UnionScheduler(size_t n, UnionOrder o, const MoveStreamContext& c, const std::vector<uint64_t>& w)
+        : order(o), ctx(c), weights(w) {
+        exhausted.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            exhausted[i] = weights[i] == 0;
+            if (!exhausted[i]) ++live;
+            total_live_weight += weights[i];
+        }
+        if (o == UnionOrder::RotatingRoundRobin || o == UnionOrder::StratifiedRandom)
+            cursor_offset = ctx.random_index(n, 0xA11CE5E1EC700001ULL);
+        if (o == UnionOrder::StratifiedRandom) cursor_stride = ctx.random_stride(n, 0xA11CE5E1EC700002ULL);
+        current_cursor = o == UnionOrder::StratifiedRandom ? 0 : cursor_offset;
+        weighted_current.assign(n, 0);
+    }
+    // next_child(i) pulls from child i; returns false when that child is exhausted.
+    template <class F>
+    bool next(size_t n, F&& next_child, size_t& which) {
+        switch (order) {
+            case UnionOrder::Sequential:
+                while (current_cursor < n) {
+                    if (next_child(current_cursor)) {
+                        which = current_cursor;
+                        return true;
+                    }
+                    ++current_cursor;
+                }
+                return false;
+            case UnionOrder::RoundRobin:
+            case UnionOrder::RotatingRoundRobin:
+                while (live > 0) {
+                    size_t i = current_cursor % n;
+                    current_cursor = (current_cursor + 1) % n;
+                    if (exhausted[i]) continue;
+                    if (next_child(i)) {
+                        which = i;
+                        return true;
+                    }
+                    exhausted[i] = true;
+                    --live;
+                }
+                return false;
+            case UnionOrder::Random:
+                while (live > 0) {
+                    uint64_t draw = ctx.random_seed(0xA11CE5E1EC701000ULL + random_draw) % total_live_weight;
+                    ++random_draw;
+                    uint64_t cumulative = 0;
+                    size_t pick = n;
+                    for (size_t i = 0; i < n; ++i) {
+                        if (exhausted[i]) continue;
+                        cumulative += weights[i];
+                        if (draw < cumulative) {
+                            pick = i;
+                            break;
+                        }
+                    }
+                    if (next_child(pick)) {
+                        which = pick;
+                        return true;
+                    }
+                    exhausted[pick] = true;
+                    --live;
+                    total_live_weight -= weights[pick];
+                }
+                return false;
+            case UnionOrder::StratifiedRandom:
+                while (live > 0) {
+                    size_t selected = n;
+                    __int128 selected_weight = 0;
+                    bool have = false;
+                    for (size_t pos = 0; pos < n; ++pos) {
+                        size_t i = (cursor_offset + pos * cursor_stride) % n;
+                        if (exhausted[i]) continue;
+                        weighted_current[i] += (__int128)weights[i];
+                        if (!have || weighted_current[i] > selected_weight) {
+                            selected = i;
+                            selected_weight = weighted_current[i];
+                            have = true;
+                        }
+                    }
+                    weighted_current[selected] -= (__int128)total_live_weight;
+                    if (next_child(selected)) {
+                        which = selected;
+                        return true;
+                    }
+                    exhausted[selected] = true;
+                    --live;
+                    total_live_weight -= weights[selected];
+                }
+                return false;
+        }
+        return false;
+    }
+};
+
+struct UnionCursor : Cursor {
+    std::vector<std::unique_ptr<Cursor>> children;
+    UnionScheduler sched;
+    size_t last_child = 0;
+    UnionCursor(std::vector<std::unique_ptr<Cursor>> ch, UnionOrder order, const MoveStreamContext& ctx)
+        : children(std::move(ch)),
+          sched(children.size(), order, ctx, std::vector<uint64_t>(children.size(), 1)) {}
+    bool next(Move& out) override {
+        return sched.next(
+            children.size(), [&](size_t i) { return children[i]->next(out); }, last_child);
+    }
+};
+
+}  // namespace sfo

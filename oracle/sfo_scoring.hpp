@@ -1,0 +1,937 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see sfo_core.hpp header).
+//
+// CPU restatement of the incremental constraint nodes and the ScoreDirector.
+// Data structures deliberately mirror the reference (hash-indexed match sets,
+// per-candidate retract/insert) so this is also a fair CPU baseline.
+//
+// Follows:
+//   crates/solverforge-scoring/src/stream/collection_extract.rs:51-94  (ChangeSource)
+//   crates/solverforge-scoring/src/constraint/incremental.rs:19-193    (uni)
+//   crates/solverforge-scoring/src/constraint/nary_incremental/bi.rs:12-313 (self-join bi)
+//   crates/solverforge-scoring/src/constraint/cross_bi_incremental/{state,incremental}.rs
+//   crates/solverforge-scoring/src/constraint/exists.rs:42-437 + exists/key_state.rs
+//   crates/solverforge-scoring/src/constraint/grouped/{state,scorer,shared_set}.rs
+//   crates/solverforge-scoring/src/api/constraint_set/incremental.rs:339-407 (tuple fold)
+//   crates/solverforge-scoring/src/director/score_director/incremental.rs:141-218
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <utility>
+#include <vector>
+
+#include "sfo_core.hpp"
+
+namespace sfo {
+
+constexpr int64_t NONE = -1;  // Option<usize>::None for scalar planning variables
+
+// Generic working solution: entity classes addressed by descriptor_index
+// (crates/solverforge-core/src/domain/descriptor/solution.rs:16-33).
+struct EntityClass {
+    size_t n = 0;
+    std::vector<std::vector<int64_t>> vars;    // vars[variable_index][entity]; NONE = unassigned
+    std::vector<std::vector<uint32_t>> lists;  // lists[entity] — the class's list variable (if any)
+};
+
+struct Solution {
+    std::vector<EntityClass> classes;
+    std::shared_ptr<const void> facts;  // immutable problem facts (model specific)
+    bool has_score = false;
+    Score score;
+};
+
+enum class Impact { Penalty, Reward };
+
+struct ChangeSource {  // collection_extract.rs:51-94
+    enum Kind { Unknown, Static, Descriptor } kind = Unknown;
+    size_t index = 0;
+    static ChangeSource unknown() { return {Unknown, 0}; }
+    static ChangeSource fixed() { return {Static, 0}; }
+    static ChangeSource descriptor(size_t i) { return {Descriptor, i}; }
+    bool reacts_to(size_t d) const {
+        return kind == Unknown || (kind == Descriptor && index == d);
+    }
+    bool owns_descriptor(size_t d) const { return kind == Descriptor && index == d; }
+    bool same_index_domain(const ChangeSource& o) const {
+        return kind == Descriptor && o.kind == Descriptor && index == o.index;
+    }
+    bool assert_localizes(size_t d, const std::string& name) const {
+        if (owns_descriptor(d)) return true;
+        if (reacts_to(d))
+            throw std::runtime_error("constraint `" + name +
+                                     "` cannot localize entity indexes");  // panic! in the reference
+        return false;
+    }
+};
+
+struct Constraint {
+    std::string name;
+    bool is_hard = false;
+    virtual ~Constraint() = default;
+    virtual Score evaluate(const Solution& s) const = 0;
+    virtual size_t match_count(const Solution& s) const = 0;
+    virtual Score initialize(const Solution& s) = 0;
+    virtual Score on_insert(const Solution& s, size_t entity, size_t descriptor) = 0;
+    virtual Score on_retract(const Solution& s, size_t entity, size_t descriptor) = 0;
+    virtual void reset() = 0;
+};
+
+using CountFn = std::function<size_t(const Solution&)>;
+using Filter1 = std::function<bool(const Solution&, size_t)>;
+using Weight1 = std::function<Score(const Solution&, size_t)>;
+using Key1 = std::function<int64_t(const Solution&, size_t)>;
+using Filter2 = std::function<bool(const Solution&, size_t, size_t)>;
+using Weight2 = std::function<Score(const Solution&, size_t, size_t)>;
+
+inline Score apply_impact(Impact impact, const Score& base) {
+    return impact == Impact::Penalty ? -base : base;
+}
+
+// ---- uni (constraint/incremental.rs:19-193): stateless ---------------------
+struct UniConstraint : Constraint {
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Filter1 filter;
+    Weight1 weight;
+
+    Score evaluate(const Solution& s) const override {
+        Score total;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) total = total + apply_impact(impact, weight(s, i));
+        return total;
+    }
+    size_t match_count(const Solution& s) const override {
+        size_t c = 0, n = count(s);
+        for (size_t i = 0; i < n; ++i) c += filter(s, i) ? 1 : 0;
+        return c;
+    }
+    Score initialize(const Solution& s) override { return evaluate(s); }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        if (e >= count(s)) return Score::zero();
+        return filter(s, e) ? apply_impact(impact, weight(s, e)) : Score::zero();
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        if (e >= count(s)) return Score::zero();
+        return filter(s, e) ? -apply_impact(impact, weight(s, e)) : Score::zero();
+    }
+    void reset() override {}
+};
+
+struct PairHash {
+    size_t operator()(const std::pair<size_t, size_t>& p) const {
+        return std::hash<uint64_t>()(((uint64_t)p.first << 32) ^ (uint64_t)p.second ^
+                                     ((uint64_t)p.first >> 32));
+    }
+};
+using Pair = std::pair<size_t, size_t>;
+using PairSet = std::unordered_set<Pair, PairHash>;
+
+// ---- keyed self-join (nary_incremental/bi.rs:12-313) ----------------------
+struct SelfJoinBiConstraint : Constraint {
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Key1 key;
+    Filter2 filter;  // (low, high)
+    Weight2 weight;  // (low, high)
+
+    std::unordered_map<size_t, PairSet> entity_to_matches;
+    PairSet matches;
+    std::unordered_map<int64_t, std::unordered_set<size_t>> key_to_indices;
+    std::unordered_map<size_t, int64_t> index_to_key;
+
+    Score compute(const Solution& s, size_t a, size_t b) const {
+        return apply_impact(impact, weight(s, a, b));
+    }
+    Score insert_entity(const Solution& s, size_t index) {  // bi.rs:78-130
+        size_t n = count(s);
+        if (index >= n) return Score::zero();
+        int64_t k = key(s, index);
+        index_to_key[index] = k;
+        key_to_indices[k].insert(index);
+        Score total;
+        auto it = key_to_indices.find(k);
+        if (it != key_to_indices.end()) {
+            for (size_t other : it->second) {
+                if (other == index) continue;
+                size_t low = index < other ? index : other;
+                size_t high = index < other ? other : index;
+                if (filter(s, low, high)) {
+                    Pair p{low, high};
+                    if (matches.insert(p).second) {
+                        entity_to_matches[low].insert(p);
+                        entity_to_matches[high].insert(p);
+                        total = total + compute(s, low, high);
+                    }
+                }
+            }
+        }
+        return total;
+    }
+    Score retract_entity(const Solution& s, size_t index) {  // bi.rs:132-166
+        auto ik = index_to_key.find(index);
+        if (ik != index_to_key.end()) {
+            auto kb = key_to_indices.find(ik->second);
+            if (kb != key_to_indices.end()) {
+                kb->second.erase(index);
+                if (kb->second.empty()) key_to_indices.erase(kb);
+            }
+            index_to_key.erase(ik);
+        }
+        auto em = entity_to_matches.find(index);
+        if (em == entity_to_matches.end()) return Score::zero();
+        PairSet pairs = std::move(em->second);
+        entity_to_matches.erase(em);
+        size_t n = count(s);
+        Score total;
+        for (const Pair& p : pairs) {
+            matches.erase(p);
+            size_t other = p.first == index ? p.second : p.first;
+            auto om = entity_to_matches.find(other);
+            if (om != entity_to_matches.end()) {
+                om->second.erase(p);
+                if (om->second.empty()) entity_to_matches.erase(om);
+            }
+            // weight recomputed on retract from the pre-change state (bi.rs:158-162)
+            if (p.first < n && p.second < n) total = total - compute(s, p.first, p.second);
+        }
+        return total;
+    }
+
+    Score evaluate(const Solution& s) const override {  // bi.rs:181-206
+        size_t n = count(s);
+        std::unordered_map<int64_t, std::vector<size_t>> tmp;
+        for (size_t i = 0; i < n; ++i) tmp[key(s, i)].push_back(i);
+        Score total;
+        for (auto& kv : tmp) {
+            auto& idx = kv.second;
+            for (size_t i = 0; i < idx.size(); ++i)
+                for (size_t j = i + 1; j < idx.size(); ++j)
+                    if (filter(s, idx[i], idx[j])) total = total + compute(s, idx[i], idx[j]);
+        }
+        return total;
+    }
+    size_t match_count(const Solution& s) const override {
+        size_t n = count(s), c = 0;
+        std::unordered_map<int64_t, std::vector<size_t>> tmp;
+        for (size_t i = 0; i < n; ++i) tmp[key(s, i)].push_back(i);
+        for (auto& kv : tmp) {
+            auto& idx = kv.second;
+            for (size_t i = 0; i < idx.size(); ++i)
+                for (size_t j = i + 1; j < idx.size(); ++j)
+                    if (filter(s, idx[i], idx[j])) ++c;
+        }
+        return c;
+    }
+    Score initialize(const Solution& s) override {
+        reset();
+        Score total;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i) total = total + insert_entity(s, i);
+        return total;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        return insert_entity(s, e);
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        return retract_entity(s, e);
+    }
+    void reset() override {
+        entity_to_matches.clear();
+        matches.clear();
+        key_to_indices.clear();
+        index_to_key.clear();
+    }
+};
+
+// ---- cross join A x B (cross_bi_incremental/{state,incremental}.rs) -------
+// Predicate joins use a constant key for both sides (stream/join_target.rs:82-110).
+struct CrossBiConstraint : Constraint {
+    Impact impact;
+    ChangeSource a_source, b_source;
+    CountFn a_count, b_count;
+    Key1 key_a, key_b;
+    Filter2 filter;  // (a_idx, b_idx)
+    Weight2 weight;  // (a_idx, b_idx)
+
+    struct MatchRow {
+        Pair pair;
+        Score score;
+        size_t a_pos, b_pos;
+    };
+    std::unordered_map<Pair, size_t, PairHash> matches;
+    std::vector<MatchRow> match_rows;
+    std::unordered_map<size_t, std::vector<size_t>> a_to_matches, b_to_matches;
+    std::unordered_map<int64_t, std::vector<size_t>> a_by_key, b_by_key;
+    std::unordered_map<size_t, int64_t> a_index_to_key, b_index_to_key;
+
+    Score compute(const Solution& s, size_t a, size_t b) const {
+        return apply_impact(impact, weight(s, a, b));
+    }
+    Score add_match(const Solution& s, size_t a, size_t b) {  // state.rs:260-296
+        Pair pair{a, b};
+        if (matches.count(pair)) return Score::zero();
+        if (!filter(s, a, b)) return Score::zero();
+        Score score = compute(s, a, b);  // frozen at add time (state.rs:280-295)
+        size_t row = match_rows.size();
+        auto& ab = a_to_matches[a];
+        size_t a_pos = ab.size();
+        ab.push_back(row);
+        auto& bb = b_to_matches[b];
+        size_t b_pos = bb.size();
+        bb.push_back(row);
+        match_rows.push_back({pair, score, a_pos, b_pos});
+        matches[pair] = row;
+        return score;
+    }
+    void remove_from_bucket(std::unordered_map<size_t, std::vector<size_t>>& buckets, size_t idx,
+                            size_t pos, bool a_side) {
+        auto it = buckets.find(idx);
+        if (it == buckets.end()) return;
+        auto& v = it->second;
+        v[pos] = v.back();
+        v.pop_back();
+        if (pos < v.size()) {
+            if (a_side)
+                match_rows[v[pos]].a_pos = pos;
+            else
+                match_rows[v[pos]].b_pos = pos;
+        }
+        if (v.empty()) buckets.erase(it);
+    }
+    Score remove_match_at(size_t row_idx) {  // state.rs:298-322
+        if (row_idx >= match_rows.size()) return Score::zero();
+        MatchRow row = match_rows[row_idx];
+        matches.erase(row.pair);
+        remove_from_bucket(a_to_matches, row.pair.first, row.a_pos, true);
+        remove_from_bucket(b_to_matches, row.pair.second, row.b_pos, false);
+        size_t last = match_rows.size() - 1;
+        match_rows[row_idx] = match_rows[last];
+        match_rows.pop_back();
+        if (row_idx != last) {
+            MatchRow& moved = match_rows[row_idx];
+            matches[moved.pair] = row_idx;
+            auto am = a_to_matches.find(moved.pair.first);
+            if (am != a_to_matches.end()) am->second[moved.a_pos] = row_idx;
+            auto bm = b_to_matches.find(moved.pair.second);
+            if (bm != b_to_matches.end()) bm->second[moved.b_pos] = row_idx;
+        }
+        return -row.score;
+    }
+    static void remove_index_from_key_bucket(std::unordered_map<int64_t, std::vector<size_t>>& m,
+                                             int64_t k, size_t idx) {
+        auto it = m.find(k);
+        if (it == m.end()) return;
+        auto& v = it->second;
+        for (size_t p = 0; p < v.size(); ++p)
+            if (v[p] == idx) {
+                v[p] = v.back();
+                v.pop_back();
+                break;
+            }
+        if (v.empty()) m.erase(it);
+    }
+    Score insert_a(const Solution& s, size_t a) {  // state.rs:372-401
+        if (a >= a_count(s)) return Score::zero();
+        int64_t k = key_a(s, a);
+        a_index_to_key[a] = k;
+        a_by_key[k].push_back(a);
+        std::vector<size_t> bs;
+        auto it = b_by_key.find(k);
+        if (it != b_by_key.end()) bs = it->second;  // cloned like the reference
+        Score total;
+        for (size_t b : bs) total = total + add_match(s, a, b);
+        return total;
+    }
+    Score retract_a(size_t a) {  // state.rs:403-418
+        auto ik = a_index_to_key.find(a);
+        if (ik != a_index_to_key.end()) {
+            remove_index_from_key_bucket(a_by_key, ik->second, a);
+            a_index_to_key.erase(ik);
+        }
+        Score total;
+        for (;;) {
+            auto it = a_to_matches.find(a);
+            if (it == a_to_matches.end() || it->second.empty()) break;
+            total = total + remove_match_at(it->second.back());
+        }
+        return total;
+    }
+    Score insert_b(const Solution& s, size_t b) {  // state.rs:420-446
+        if (b >= b_count(s)) return Score::zero();
+        int64_t k = key_b(s, b);
+        b_index_to_key[b] = k;
+        b_by_key[k].push_back(b);
+        std::vector<size_t> as;
+        auto it = a_by_key.find(k);
+        if (it != a_by_key.end()) as = it->second;
+        Score total;
+        for (size_t a : as) total = total + add_match(s, a, b);
+        return total;
+    }
+    Score retract_b(size_t b) {  // state.rs:448-461
+        auto ik = b_index_to_key.find(b);
+        if (ik != b_index_to_key.end()) {
+            remove_index_from_key_bucket(b_by_key, ik->second, b);
+            b_index_to_key.erase(ik);
+        }
+        Score total;
+        for (;;) {
+            auto it = b_to_matches.find(b);
+            if (it == b_to_matches.end() || it->second.empty()) break;
+            total = total + remove_match_at(it->second.back());
+        }
+        return total;
+    }
+
+    Score evaluate(const Solution& s) const override {  // incremental.rs:27-47
+        size_t na = a_count(s), nb = b_count(s);
+        std::unordered_map<int64_t, std::vector<size_t>> bk;
+        for (size_t b = 0; b < nb; ++b) bk[key_b(s, b)].push_back(b);
+        Score total;
+        for (size_t a = 0; a < na; ++a) {
+            auto it = bk.find(key_a(s, a));
+            if (it == bk.end()) continue;
+            for (size_t b : it->second)
+                if (filter(s, a, b)) total = total + compute(s, a, b);
+        }
+        return total;
+    }
+    size_t match_count(const Solution& s) const override {
+        size_t na = a_count(s), nb = b_count(s), c = 0;
+        std::unordered_map<int64_t, std::vector<size_t>> bk;
+        for (size_t b = 0; b < nb; ++b) bk[key_b(s, b)].push_back(b);
+        for (size_t a = 0; a < na; ++a) {
+            auto it = bk.find(key_a(s, a));
+            if (it == bk.end()) continue;
+            for (size_t b : it->second) c += filter(s, a, b) ? 1 : 0;
+        }
+        return c;
+    }
+    Score initialize(const Solution& s) override {  // incremental.rs:71-91
+        reset();
+        size_t na = a_count(s), nb = b_count(s);
+        for (size_t a = 0; a < na; ++a) {
+            int64_t k = key_a(s, a);
+            a_index_to_key[a] = k;
+            a_by_key[k].push_back(a);
+        }
+        for (size_t b = 0; b < nb; ++b) {
+            int64_t k = key_b(s, b);
+            b_index_to_key[b] = k;
+            b_by_key[k].push_back(b);
+        }
+        Score total;
+        for (size_t a = 0; a < na; ++a) {
+            auto it = b_by_key.find(key_a(s, a));
+            if (it == b_by_key.end()) continue;
+            std::vector<size_t> bs = it->second;
+            for (size_t b : bs) total = total + add_match(s, a, b);
+        }
+        return total;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {  // incremental.rs:93-115
+        bool a_changed = a_source.assert_localizes(d, name);
+        bool b_changed = b_source.assert_localizes(d, name);
+        Score total;
+        if (!a_changed && !b_changed) return total;
+        if (a_changed) total = total + insert_a(s, e);
+        if (b_changed) total = total + insert_b(s, e);
+        return total;
+    }
+    Score on_retract(const Solution&, size_t e, size_t d) override {  // incremental.rs:117-137
+        bool a_changed = a_source.assert_localizes(d, name);
+        bool b_changed = b_source.assert_localizes(d, name);
+        Score total;
+        if (!a_changed && !b_changed) return total;
+        if (a_changed) total = total + retract_a(e);
+        if (b_changed) total = total + retract_b(e);
+        return total;
+    }
+    void reset() override {
+        matches.clear();
+        match_rows.clear();
+        a_to_matches.clear();
+        b_to_matches.clear();
+        a_by_key.clear();
+        b_by_key.clear();
+        a_index_to_key.clear();
+        b_index_to_key.clear();
+    }
+};
+
+// ---- exists / not-exists over a (flattened) B side (constraint/exists.rs) ---
+enum class ExistenceMode { Exists, NotExists };
+using FlattenFn = std::function<void(const Solution&, size_t parent, std::vector<int64_t>& keys_out)>;
+
+struct ExistsConstraint : Constraint {
+    Impact impact;
+    ExistenceMode mode;
+    ChangeSource a_source, parent_source;
+    CountFn a_count, parent_count;
+    Filter1 filter_a, filter_parent;
+    Key1 key_a;
+    FlattenFn flatten;  // keys of the parent's flattened B items (a plain B row = one key)
+    Weight1 weight;
+    bool indexed_usize = true;  // usize keys use dense Vec tables (exists/key_state.rs:33-60)
+
+    struct ASlot {
+        bool has_key = false;
+        int64_t key = 0;
+        size_t bucket_pos = 0;
+        Score score;
+    };
+    std::vector<ASlot> a_slots;
+    // dense storage
+    std::vector<std::vector<size_t>> d_a_indices;
+    std::vector<Score> d_a_totals;
+    std::vector<size_t> d_b_counts;
+    // hashed storage
+    std::unordered_map<int64_t, std::vector<size_t>> h_a_indices;
+    std::unordered_map<int64_t, Score> h_a_totals;
+    std::unordered_map<int64_t, size_t> h_b_counts;
+
+    bool matches_count(size_t c) const {
+        return mode == ExistenceMode::Exists ? c > 0 : c == 0;
+    }
+    size_t b_count(int64_t k) const {
+        if (indexed_usize) return (size_t)k < d_b_counts.size() ? d_b_counts[(size_t)k] : 0;
+        auto it = h_b_counts.find(k);
+        return it == h_b_counts.end() ? 0 : it->second;
+    }
+    void inc_b(int64_t k, size_t by) {
+        if (indexed_usize) {
+            if (d_b_counts.size() <= (size_t)k) d_b_counts.resize((size_t)k + 1, 0);
+            d_b_counts[(size_t)k] += by;
+        } else
+            h_b_counts[k] += by;
+    }
+    void dec_b(int64_t k, size_t by) {
+        if (indexed_usize) {
+            if ((size_t)k < d_b_counts.size())
+                d_b_counts[(size_t)k] = d_b_counts[(size_t)k] >= by ? d_b_counts[(size_t)k] - by : 0;
+        } else {
+            auto it = h_b_counts.find(k);
+            if (it != h_b_counts.end()) {
+                it->second = it->second >= by ? it->second - by : 0;
+                if (it->second == 0) h_b_counts.erase(it);
+            }
+        }
+    }
+    Score a_total(int64_t k) const {
+        if (indexed_usize) return (size_t)k < d_a_totals.size() ? d_a_totals[(size_t)k] : Score::zero();
+        auto it = h_a_totals.find(k);
+        return it == h_a_totals.end() ? Score::zero() : it->second;
+    }
+    void add_a_total(int64_t k, const Score& sc) {
+        if (indexed_usize) {
+            if (d_a_totals.size() <= (size_t)k) d_a_totals.resize((size_t)k + 1);
+            d_a_totals[(size_t)k] = d_a_totals[(size_t)k] + sc;
+        } else
+            h_a_totals[k] = h_a_totals[k] + sc;
+    }
+    std::vector<size_t>& a_bucket(int64_t k) {
+        if (indexed_usize) {
+            if (d_a_indices.size() <= (size_t)k) d_a_indices.resize((size_t)k + 1);
+            return d_a_indices[(size_t)k];
+        }
+        return h_a_indices[k];
+    }
+    Score compute(const Solution& s, size_t a) const { return apply_impact(impact, weight(s, a)); }
+
+    Score retract_a(size_t idx) {  // exists.rs:168-186
+        if (idx >= a_slots.size()) return Score::zero();
+        ASlot slot = a_slots[idx];
+        if (!slot.has_key) return Score::zero();
+        Score contribution = matches_count(b_count(slot.key)) ? slot.score : Score::zero();
+        auto& bucket = a_bucket(slot.key);
+        if (slot.bucket_pos < bucket.size()) {
+            bucket[slot.bucket_pos] = bucket.back();
+            bucket.pop_back();
+            if (slot.bucket_pos < bucket.size()) a_slots[bucket[slot.bucket_pos]].bucket_pos = slot.bucket_pos;
+        }
+        add_a_total(slot.key, -slot.score);
+        a_slots[idx] = ASlot{};
+        return -contribution;
+    }
+    Score insert_a(const Solution& s, size_t idx) {  // exists.rs:188-216
+        size_t n = a_count(s);
+        if (idx >= n) return Score::zero();
+        if (a_slots.size() < n) a_slots.resize(n);
+        if (!filter_a(s, idx)) {
+            a_slots[idx] = ASlot{};
+            return Score::zero();
+        }
+        int64_t k = key_a(s, idx);
+        auto& bucket = a_bucket(k);
+        size_t pos = bucket.size();
+        bucket.push_back(idx);
+        Score sc = compute(s, idx);
+        add_a_total(k, sc);
+        Score contribution = matches_count(b_count(k)) ? sc : Score::zero();
+        a_slots[idx] = ASlot{true, k, pos, sc};
+        return contribution;
+    }
+    Score key_existence_delta(int64_t k, size_t old_c, size_t new_c) const {  // exists.rs:218-231
+        bool o = matches_count(old_c), n = matches_count(new_c);
+        if (o == n) return Score::zero();
+        return n ? a_total(k) : -a_total(k);
+    }
+    using KeyCounts = std::vector<std::pair<int64_t, size_t>>;
+    Score update_key_counts(const KeyCounts& kc, bool insert) {  // exists.rs:233-247
+        Score total;
+        for (auto& e : kc) {
+            size_t old_c = b_count(e.first);
+            if (insert)
+                inc_b(e.first, e.second);
+            else
+                dec_b(e.first, e.second);
+            total = total + key_existence_delta(e.first, old_c, b_count(e.first));
+        }
+        return total;
+    }
+    KeyCounts parent_key_counts(const Solution& s, size_t idx) const {  // exists.rs:249-272
+        KeyCounts kc;
+        if (idx >= parent_count(s)) return kc;
+        if (!filter_parent(s, idx)) return kc;
+        std::vector<int64_t> keys;
+        flatten(s, idx, keys);
+        for (int64_t k : keys) {
+            bool found = false;
+            for (auto& e : kc)
+                if (e.first == k) {
+                    e.second += 1;
+                    found = true;
+                    break;
+                }
+            if (!found) kc.push_back({k, 1});
+        }
+        return kc;
+    }
+    void rebuild_b_counts(const Solution& s) {
+        d_b_counts.clear();
+        h_b_counts.clear();
+        size_t np = parent_count(s);
+        std::vector<int64_t> keys;
+        for (size_t p = 0; p < np; ++p) {
+            if (!filter_parent(s, p)) continue;
+            keys.clear();
+            flatten(s, p, keys);
+            for (int64_t k : keys) inc_b(k, 1);
+        }
+    }
+    Score evaluate(const Solution& s) const override {  // exists.rs:337-352
+        ExistsConstraint tmp;
+        tmp.indexed_usize = indexed_usize;
+        tmp.parent_count = parent_count;
+        tmp.filter_parent = filter_parent;
+        tmp.flatten = flatten;
+        tmp.rebuild_b_counts(s);
+        Score total;
+        size_t n = a_count(s);
+        for (size_t a = 0; a < n; ++a) {
+            if (!filter_a(s, a)) continue;
+            if (matches_count(tmp.b_count(key_a(s, a)))) total = total + compute(s, a);
+        }
+        return total;
+    }
+    size_t match_count(const Solution& s) const override {
+        ExistsConstraint tmp;
+        tmp.indexed_usize = indexed_usize;
+        tmp.parent_count = parent_count;
+        tmp.filter_parent = filter_parent;
+        tmp.flatten = flatten;
+        tmp.rebuild_b_counts(s);
+        size_t n = a_count(s), c = 0;
+        for (size_t a = 0; a < n; ++a)
+            if (filter_a(s, a) && matches_count(tmp.b_count(key_a(s, a)))) ++c;
+        return c;
+    }
+    Score initialize(const Solution& s) override {  // exists.rs:358-362
+        reset();
+        rebuild_b_counts(s);
+        size_t n = a_count(s);
+        a_slots.assign(n, ASlot{});
+        Score total;
+        for (size_t a = 0; a < n; ++a) total = total + insert_a(s, a);
+        return total;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {  // exists.rs:364-391
+        bool a_changed = a_source.assert_localizes(d, name);
+        bool p_changed = parent_source.assert_localizes(d, name);
+        bool same = a_source.same_index_domain(parent_source) && a_changed && p_changed;
+        Score total;
+        if (same) {
+            KeyCounts kc = parent_key_counts(s, e);
+            total = total + update_key_counts(kc, true);
+            total = total + insert_a(s, e);
+            return total;
+        }
+        if (p_changed) total = total + update_key_counts(parent_key_counts(s, e), true);
+        if (a_changed) total = total + insert_a(s, e);
+        return total;
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {  // exists.rs:393-420
+        bool a_changed = a_source.assert_localizes(d, name);
+        bool p_changed = parent_source.assert_localizes(d, name);
+        bool same = a_source.same_index_domain(parent_source) && a_changed && p_changed;
+        Score total;
+        if (same) {
+            KeyCounts kc = parent_key_counts(s, e);
+            total = total + retract_a(e);
+            total = total + update_key_counts(kc, false);
+            return total;
+        }
+        if (a_changed) total = total + retract_a(e);
+        if (p_changed) total = total + update_key_counts(parent_key_counts(s, e), false);
+        return total;
+    }
+    void reset() override {
+        a_slots.clear();
+        d_a_indices.clear();
+        d_a_totals.clear();
+        d_b_counts.clear();
+        h_a_indices.clear();
+        h_a_totals.clear();
+        h_b_counts.clear();
+    }
+};
+
+// ---- grouped uni: group_by(key, count|sum) -> weight(key, result) ---------
+// (grouped/state.rs:43-247, grouped/scorer.rs:46-152, stream/collector/{sum,count}.rs)
+using GroupWeight = std::function<Score(int64_t key, int64_t result)>;
+using Value1 = std::function<int64_t(const Solution&, size_t)>;
+
+struct GroupedConstraint : Constraint {
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Filter1 filter;
+    Key1 key;
+    Value1 value;  // count collector: value == 1 per entity; sum collector: mapped value
+    GroupWeight weight;
+
+    struct Group {
+        int64_t key;
+        int64_t acc;
+        size_t count;
+    };
+    std::vector<Group> groups;
+    std::unordered_map<int64_t, size_t> group_of_key;
+    std::unordered_map<size_t, size_t> entity_groups;
+    std::unordered_map<size_t, int64_t> entity_retractions;
+    std::vector<size_t> changed_groups;
+    std::vector<Score> cached_scores;
+
+    Score compute(int64_t k, int64_t r) const { return apply_impact(impact, weight(k, r)); }
+    void mark_changed(size_t g) {
+        for (size_t c : changed_groups)
+            if (c == g) return;
+        changed_groups.push_back(g);
+    }
+    size_t group_id_for_key(int64_t k) {
+        auto it = group_of_key.find(k);
+        if (it != group_of_key.end()) return it->second;
+        size_t g = groups.size();
+        groups.push_back({k, 0, 0});
+        group_of_key[k] = g;
+        return g;
+    }
+    void insert_entity(const Solution& s, size_t idx) {  // state.rs:216-229
+        size_t g = group_id_for_key(key(s, idx));
+        if (groups[g].count == 0) groups[g].acc = 0;
+        int64_t v = value(s, idx);
+        groups[g].acc = wrap_add(groups[g].acc, v);
+        groups[g].count += 1;
+        entity_groups[idx] = g;
+        entity_retractions[idx] = v;
+        mark_changed(g);
+    }
+    void retract_entity(size_t idx) {  // state.rs:231-244
+        auto eg = entity_groups.find(idx);
+        if (eg == entity_groups.end()) return;
+        size_t g = eg->second;
+        entity_groups.erase(eg);
+        auto er = entity_retractions.find(idx);
+        if (er == entity_retractions.end()) return;
+        int64_t v = er->second;
+        entity_retractions.erase(er);
+        groups[g].acc = wrap_sub(groups[g].acc, v);
+        groups[g].count = groups[g].count > 0 ? groups[g].count - 1 : 0;
+        mark_changed(g);
+    }
+    Score replace_cached(size_t slot, const Score& sc) {  // scorer.rs:145-152
+        while (cached_scores.size() <= slot) cached_scores.push_back(Score::zero());
+        Score prev = cached_scores[slot];
+        cached_scores[slot] = sc;
+        return sc - prev;
+    }
+    Score refresh_changed() {  // scorer.rs:89-101
+        Score delta;
+        for (size_t g : changed_groups) {
+            if (g >= groups.size()) continue;
+            Score sc = groups[g].count == 0 ? Score::zero() : compute(groups[g].key, groups[g].acc);
+            delta = delta + replace_cached(g, sc);
+        }
+        return delta;
+    }
+    Score evaluate(const Solution& s) const override {
+        std::unordered_map<int64_t, int64_t> acc;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i) {
+            if (!filter(s, i)) continue;
+            int64_t k = key(s, i);
+            acc[k] = wrap_add(acc[k], value(s, i));
+        }
+        Score total;
+        for (auto& kv : acc) total = total + compute(kv.first, kv.second);
+        return total;
+    }
+    size_t match_count(const Solution& s) const override {
+        std::unordered_set<int64_t> keys;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) keys.insert(key(s, i));
+        return keys.size();
+    }
+    Score initialize(const Solution& s) override {
+        reset();
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) insert_entity(s, i);
+        changed_groups.clear();
+        cached_scores.clear();
+        Score total;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            Score sc = groups[g].count == 0 ? Score::zero() : compute(groups[g].key, groups[g].acc);
+            replace_cached(g, sc);
+            total = total + sc;
+        }
+        return total;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {
+        changed_groups.clear();
+        if (!source.assert_localizes(d, name)) return refresh_changed();
+        if (e < count(s) && filter(s, e)) insert_entity(s, e);
+        return refresh_changed();
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {
+        (void)s;
+        changed_groups.clear();
+        if (!source.assert_localizes(d, name)) return refresh_changed();
+        retract_entity(e);
+        return refresh_changed();
+    }
+    void reset() override {
+        groups.clear();
+        group_of_key.clear();
+        entity_groups.clear();
+        entity_retractions.clear();
+        changed_groups.clear();
+        cached_scores.clear();
+    }
+};
+
+// ---- ConstraintSet tuple fold (api/constraint_set/incremental.rs:339-407) ----
+struct ConstraintSet {
+    std::vector<std::unique_ptr<Constraint>> members;
+    Score evaluate_all(const Solution& s) const {
+        Score t;
+        for (auto& c : members) t = t + c->evaluate(s);
+        return t;
+    }
+    Score initialize_all(const Solution& s) {
+        Score t;
+        for (auto& c : members) t = t + c->initialize(s);
+        return t;
+    }
+    Score on_insert_all(const Solution& s, size_t e, size_t d) {
+        Score t;
+        for (auto& c : members) t = t + c->on_insert(s, e, d);
+        return t;
+    }
+    Score on_retract_all(const Solution& s, size_t e, size_t d) {
+        Score t;
+        for (auto& c : members) t = t + c->on_retract(s, e, d);
+        return t;
+    }
+    void reset_all() {
+        for (auto& c : members) c->reset();
+    }
+};
+
+// ---- ScoreDirector (director/score_director/incremental.rs:64-394) -------
+struct DirectorScoreState {
+    bool solution_has_score;
+    Score solution_score;
+    bool initialized;
+    Score committed_score;
+};
+
+struct ScoreDirector {
+    Solution working;
+    ConstraintSet constraints;
+    Score cached;
+    bool initialized = false;
+    int levels = 2, hard_levels = 1;
+    // stats mirrored from crates/solverforge-solver/src/stats/solver.rs
+    uint64_t retract_calls = 0, insert_calls = 0;
+
+    Score calculate_score() {  // incremental.rs:141-149
+        if (!initialized) {
+            cached = constraints.initialize_all(working);
+            initialized = true;
+        }
+        working.has_score = true;
+        working.score = cached;
+        return cached;
+    }
+    Score fresh_score() const {  // incremental.rs:151-155 (clone + evaluate_all)
+        Solution clone = working;
+        return constraints.evaluate_all(clone);
+    }
+    void before_variable_changed(size_t d, size_t e) {  // incremental.rs:157-169
+        if (!initialized) return;
+        ++retract_calls;
+        cached = cached + constraints.on_retract_all(working, e, d);
+    }
+    void after_variable_changed(size_t d, size_t e) {  // incremental.rs:171-185
+        if (!initialized) return;
+        ++insert_calls;
+        cached = cached + constraints.on_insert_all(working, e, d);
+    }
+    DirectorScoreState snapshot_score_state() const {  // incremental.rs:193-201
+        return {working.has_score, working.score, initialized, cached};
+    }
+    void restore_score_state(const DirectorScoreState& st) {  // incremental.rs:203-218
+        working.has_score = st.solution_has_score;
+        working.score = st.solution_score;
+        if (st.initialized) {
+            cached = st.committed_score;
+            initialized = true;
+        } else {
+            constraints.reset_all();
+            cached = Score::zero();
+            initialized = false;
+        }
+    }
+    void reset() {
+        constraints.reset_all();
+        initialized = false;
+        cached = Score::zero();
+    }
+    size_t entity_count(size_t d) const { return d < working.classes.size() ? working.classes[d].n : 0; }
+};
+
+}  // namespace sfo

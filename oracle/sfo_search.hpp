@@ -1,0 +1,338 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see sfo_core.hpp header).
+//
+// CPU restatement of the local-search step loop, acceptors, foragers, counters
+// and first-fit construction.
+//
+// Follows (paths under crates/solverforge-solver/src/):
+//   phase/localsearch/phase.rs:237-320           (phase loop)
+//   phase/localsearch/phase/step.rs:30-225       (execute_step)
+//   phase/localsearch/phase/candidates.rs:47-285 (evaluate_candidates)
+//   phase/localsearch/evaluation.rs:20-115       (evaluate_candidate)
+//   phase/localsearch/forager.rs:70-425          (BestCandidate / AcceptedCount / FirstAccepted / BestScore)
+//   phase/localsearch/acceptor/hill_climbing.rs:33-41, late_acceptance.rs:89-125
+//   scope/solver/scope_progress.rs:89-107        (update_best_solution)
+//   stats/solver.rs:23,112-119,246               (counter definitions)
+//   phase/construction/forager_step.rs:149-226, decision.rs:56-64, evaluation.rs:6-18 (first fit)
+#pragma once
+#include <functional>
+#include <memory>
+#include <vector>
+
+#include "sfo_moves.hpp"
+
+namespace sfo {
+
+// Build-defined step-seed stream.  The reference draws step seeds from rand 0.10.1
+// StdRng (ChaCha12; scope/solver/scope_core.rs:463-466, phase/step.rs:60-64) whose
+// source is not in the tree => parity unpinned.  Both this oracle and the HIP path
+// use this documented splitmix64 counter stream instead; parity tests may also pass
+// explicit step_seed arrays.
+inline uint64_t sf_step_seed(uint64_t random_seed, uint64_t draw_index) {
+    return splitmix64(random_seed + draw_index * 0x9E3779B97F4A7C15ULL);
+}
+
+struct Acceptor {
+    virtual ~Acceptor() = default;
+    virtual bool is_accepted(const Score& last_step, const Score& move_score) = 0;
+    virtual void phase_started(const Score&) {}
+    virtual void step_started() {}
+    virtual void step_ended(const Score&) {}
+};
+
+struct HillClimbingAcceptor : Acceptor {  // hill_climbing.rs:33-41
+    bool is_accepted(const Score& last, const Score& mv) override { return mv > last; }
+};
+
+struct LateAcceptanceAcceptor : Acceptor {  // late_acceptance.rs:89-125
+    size_t size;
+    std::vector<Score> history;
+    std::vector<bool> filled;
+    size_t current = 0;
+    explicit LateAcceptanceAcceptor(size_t n) : size(n), history(n), filled(n, false) {}
+    bool is_accepted(const Score& last, const Score& mv) override {
+        if (mv >= last) return true;
+        if (filled[current]) return mv >= history[current];
+        return true;
+    }
+    void phase_started(const Score& initial) override {
+        for (size_t i = 0; i < size; ++i) {
+            history[i] = initial;
+            filled[i] = true;
+        }
+        current = 0;
+    }
+    void step_ended(const Score& step_score) override {
+        history[current] = step_score;
+        filled[current] = true;
+        current = (current + 1) % size;
+    }
+};
+
+inline bool reservoir_pick(uint64_t step_seed, uint64_t equal_count) {  // forager.rs:143-148
+    uint64_t mixed =
+        splitmix64(step_seed ^ (equal_count * 0x9E3779B97F4A7C15ULL) ^ 0xF04A63E239B74D11ULL);
+    return mixed % equal_count == 0;
+}
+
+struct BestCandidate {  // forager.rs:70-141
+    bool has = false;
+    size_t index = 0;
+    Score score;
+    uint64_t equal_count = 0;
+    uint64_t step_seed = 0;
+    bool random_ties = true;
+    void reset(uint64_t seed) {
+        has = false;
+        equal_count = 0;
+        step_seed = seed;
+    }
+    void consider(size_t idx, const Score& sc) {
+        if (!has) {
+            has = true;
+            index = idx;
+            score = sc;
+            equal_count = 1;
+            return;
+        }
+        int c = cmp(sc, score);
+        if (c < 0) return;
+        if (c > 0) {
+            equal_count = 1;
+            index = idx;
+            score = sc;
+            return;
+        }
+        ++equal_count;
+        if (random_ties && reservoir_pick(step_seed, equal_count)) {
+            index = idx;
+            score = sc;
+        }
+    }
+};
+
+struct Forager {
+    enum Kind { AcceptedCount, FirstAccepted, BestScore } kind = AcceptedCount;
+    size_t accepted_count_limit = 256;
+    size_t accepted_count = 0;
+    BestCandidate best;
+    void step_started(uint64_t seed) {
+        accepted_count = 0;
+        best.reset(seed);
+    }
+    void add_move_index(size_t idx, const Score& sc) {
+        switch (kind) {
+            case AcceptedCount:  // forager.rs:232-239
+                if (accepted_count >= accepted_count_limit) return;
+                ++accepted_count;
+                best.consider(idx, sc);
+                return;
+            case FirstAccepted:  // forager.rs:318-325
+                if (!best.has) {
+                    best.has = true;
+                    best.index = idx;
+                    best.score = sc;
+                }
+                return;
+            case BestScore:  // forager.rs:410-412
+                best.consider(idx, sc);
+                return;
+        }
+    }
+    bool is_quit_early() const {
+        switch (kind) {
+            case AcceptedCount:
+                return accepted_count >= accepted_count_limit;
+            case FirstAccepted:
+                return best.has;
+            case BestScore:
+                return false;
+        }
+        return false;
+    }
+    int64_t limit_for_context() const {
+        if (kind == AcceptedCount) return (int64_t)accepted_count_limit;
+        if (kind == FirstAccepted) return 1;
+        return -1;
+    }
+};
+
+struct SolverStats {  // stats/solver.rs
+    uint64_t step_count = 0;
+    uint64_t moves_generated = 0;
+    uint64_t moves_evaluated = 0;  // includes not-doable candidates (evaluation.rs:33-49)
+    uint64_t moves_accepted = 0;
+    uint64_t moves_applied = 0;
+    uint64_t score_calculations = 0;  // only scored trials (evaluation.rs:60)
+    uint64_t moves_not_doable = 0;
+};
+
+using CursorFactory =
+    std::function<std::unique_ptr<Cursor>(const ScoreDirector&, const MoveStreamContext&)>;
+
+struct StepTrace {  // one record per pulled candidate (for order/score parity tests)
+    Move move;
+    bool doable;
+    Score score;
+    bool accepted;
+};
+
+struct LocalSearch {
+    ScoreDirector* director = nullptr;
+    CursorFactory open_cursor;
+    std::unique_ptr<Acceptor> acceptor;
+    Forager forager;
+    SelectionOrder selection_order = SelectionOrder::Random;
+    uint64_t random_seed = 0;
+    std::vector<uint64_t> explicit_step_seeds;  // optional override
+
+    SolverStats stats;
+    Score last_step_score;
+    bool has_best = false;
+    Score best_score;
+    Solution best_solution;
+    uint64_t phase_step_index = 0;
+    uint64_t seed_draws = 0;
+    std::vector<StepTrace>* trace = nullptr;  // when set, records every pulled candidate of a step
+    bool last_step_applied = false;
+    Move last_applied_move;
+
+    void update_best_solution() {  // scope_progress.rs:89-107
+        Score current = director->calculate_score();
+        if (!has_best || current > best_score) {
+            best_solution = director->working;
+            best_solution.has_score = true;
+            best_solution.score = current;
+            best_score = current;
+            has_best = true;
+        }
+    }
+    void phase_start() {  // phase.rs:250-261 (+ initialize_working_solution_as_best)
+        last_step_score = director->calculate_score();
+        update_best_solution();
+        acceptor->phase_started(last_step_score);
+        phase_step_index = 0;
+    }
+    uint64_t next_step_seed() {
+        uint64_t seed = seed_draws < explicit_step_seeds.size() ? explicit_step_seeds[seed_draws]
+                                                                 : sf_step_seed(random_seed, seed_draws);
+        ++seed_draws;
+        return seed;
+    }
+    // One local-search step (step.rs:30-225 around candidates.rs:47-285).
+    void step() {
+        uint64_t step_index = phase_step_index;
+        uint64_t step_seed = next_step_seed();
+        forager.step_started(step_seed);
+        acceptor->step_started();
+        MoveStreamContext ctx(step_index, step_seed, forager.limit_for_context());
+        ctx = ctx.with_selection_order(selection_order);
+        std::unique_ptr<Cursor> cursor = open_cursor(*director, ctx);
+        if (trace) trace->clear();
+
+        std::vector<Move> kept;  // candidate ids are stream indices; keep moves to apply the winner
+        size_t candidate_index = 0;
+        Move mv;
+        while (!forager.is_quit_early()) {
+            if (!cursor->next(mv)) break;
+            size_t id = candidate_index++;
+            kept.push_back(mv);
+            ++stats.moves_generated;
+            ++stats.moves_evaluated;
+            // evaluate_candidate (evaluation.rs:20-115)
+            if (!move_is_doable(*director, mv)) {
+                ++stats.moves_not_doable;
+                if (trace) trace->push_back({mv, false, Score::zero(), false});
+                continue;
+            }
+            DirectorScoreState st = director->snapshot_score_state();
+            MoveUndo undo = move_do(*director, mv);
+            Score move_score = director->calculate_score();
+            move_undo(*director, mv, undo);
+            director->restore_score_state(st);
+            ++stats.score_calculations;
+            bool accepted = acceptor->is_accepted(last_step_score, move_score);
+            if (trace) trace->push_back({mv, true, move_score, accepted});
+            if (accepted) {
+                ++stats.moves_accepted;
+                forager.add_move_index(id, move_score);
+            }
+        }
+        last_step_applied = false;
+        if (forager.best.has) {  // pick_move_index + apply_owned_candidate
+            const Move& winner = kept[forager.best.index];
+            MoveUndo ignored = move_do(*director, winner);
+            (void)ignored;
+            director->calculate_score();
+            ++stats.moves_applied;
+            last_step_score = forager.best.score;
+            last_step_applied = true;
+            last_applied_move = winner;
+            update_best_solution();
+            forager.best.has = false;
+        }
+        acceptor->step_ended(last_step_score);  // always (step.rs:216-221)
+        ++phase_step_index;
+        ++stats.step_count;
+    }
+};
+
+// First-fit construction over one scalar slot (phase/construction/forager_step.rs:149-226,
+// decision.rs:56-64): entities in index order; when keep-current is legal (the variable
+// allows unassigned) the baseline is the current score and the first candidate value whose
+// trial score is strictly better is selected; otherwise the first doable candidate wins.
+inline void construct_first_fit(ScoreDirector& d, const ScalarSlot& slot, SolverStats* stats = nullptr) {
+    d.calculate_score();
+    EntityClass& c = d.working.classes[slot.descriptor_index];
+    std::vector<int64_t> values;
+    for (size_t e = 0; e < c.n; ++e) {
+        if (c.vars[slot.variable_index][e] != NONE) continue;
+        values.clear();
+        slot.values_for_entity(d.working, e, values);
+        bool keep_current_legal = slot.allows_unassigned;
+        Score baseline = d.calculate_score();
+        bool chosen = false;
+        int64_t chosen_value = NONE;
+        for (int64_t v : values) {
+            Move m;
+            m.kind = Move::Change;
+            m.descriptor = slot.descriptor_index;
+            m.variable = slot.variable_index;
+            m.a = e;
+            m.to_value = v;
+            m.allows_unassigned = slot.allows_unassigned;
+            if (!move_is_doable(d, m)) continue;
+            if (!keep_current_legal) {
+                chosen = true;
+                chosen_value = v;
+                break;
+            }
+            DirectorScoreState st = d.snapshot_score_state();
+            MoveUndo u = move_do(d, m);
+            Score sc = d.calculate_score();
+            move_undo(d, m, u);
+            d.restore_score_state(st);
+            if (stats) {
+                ++stats->moves_evaluated;
+                ++stats->score_calculations;
+            }
+            if (sc > baseline) {
+                chosen = true;
+                chosen_value = v;
+                break;
+            }
+        }
+        if (chosen) {
+            Move m;
+            m.kind = Move::Change;
+            m.descriptor = slot.descriptor_index;
+            m.variable = slot.variable_index;
+            m.a = e;
+            m.to_value = chosen_value;
+            m.allows_unassigned = slot.allows_unassigned;
+            move_do(d, m);
+            d.calculate_score();
+        }
+    }
+}
+
+}  // namespace sfo

@@ -1,0 +1,393 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.
+// Pins the oracle's constraint nodes against the reference's own known-answer tests.
+// Every CASE cites the reference test it re-derives (values copied by hand from the
+// assertions, never source text).  Output: one "ok <name>" / "FAIL <name>" line per case;
+// exit status = number of failures.  Driven by tests/test_oracle_golden.py.
+#include <cstdio>
+#include <string>
+
+#include "sfo_models.hpp"
+
+using namespace sfo;
+
+static int failures = 0;
+#define CHECK(name, cond)                          \
+    do {                                           \
+        if (cond)                                  \
+            std::printf("ok %s\n", name);          \
+        else {                                     \
+            std::printf("FAIL %s (line %d)\n", name, __LINE__); \
+            ++failures;                            \
+        }                                          \
+    } while (0)
+
+static Score soft(int64_t v) { return Score::level(0, v); }  // SoftScore::of(v): single level
+
+// Toy solution: class 0 rows with two int columns (vars[0], vars[1]).
+static Solution two_col(std::vector<int64_t> c0, std::vector<int64_t> c1) {
+    Solution s;
+    s.classes.resize(1);
+    s.classes[0].n = c0.size();
+    s.classes[0].vars = {c0, c1};
+    return s;
+}
+
+// Row-conflict self-join of constraint/tests/bi_incr.rs: key = row, filter a.col < b.col.
+static SelfJoinBiConstraint row_conflict(Impact impact, Weight2 w, Filter2 f = nullptr) {
+    SelfJoinBiConstraint c;
+    c.name = "Row conflict";
+    c.impact = impact;
+    c.source = ChangeSource::descriptor(0);
+    c.count = [](const Solution& s) { return s.classes[0].n; };
+    c.key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    c.filter = f ? f : [](const Solution& s, size_t a, size_t b) {
+        return s.classes[0].vars[1][a] < s.classes[0].vars[1][b];
+    };
+    c.weight = w;
+    return c;
+}
+static Weight2 const_w(int64_t v) {
+    return [v](const Solution&, size_t, size_t) { return soft(v); };
+}
+
+static void bi_incr_cases() {
+    {  // bi_incr.rs:21-48 test_evaluate_no_conflicts
+        auto c = row_conflict(Impact::Penalty, const_w(1));
+        Solution s = two_col({0, 1, 2}, {0, 1, 2});
+        CHECK("bi_incr.evaluate_no_conflicts", c.evaluate(s) == soft(0) && c.match_count(s) == 0);
+    }
+    {  // bi_incr.rs:50-76 test_evaluate_with_conflicts
+        auto c = row_conflict(Impact::Penalty, const_w(1));
+        Solution s = two_col({0, 0, 2}, {0, 1, 2});
+        CHECK("bi_incr.evaluate_with_conflicts", c.evaluate(s) == soft(-1) && c.match_count(s) == 1);
+    }
+    {  // bi_incr.rs:78-117 test_incremental_insert: deltas 0, -1, 0
+        auto c = row_conflict(Impact::Penalty, const_w(1));
+        Solution s = two_col({0, 0, 2}, {0, 1, 2});
+        c.initialize(s);
+        c.reset();
+        bool ok = c.on_insert(s, 0, 0) == soft(0);
+        ok = ok && c.on_insert(s, 1, 0) == soft(-1);
+        ok = ok && c.on_insert(s, 2, 0) == soft(0);
+        CHECK("bi_incr.incremental_insert", ok);
+    }
+    {  // bi_incr.rs:119-143 test_incremental_retract: +1
+        auto c = row_conflict(Impact::Penalty, const_w(1));
+        Solution s = two_col({0, 0}, {0, 1});
+        c.initialize(s);
+        c.reset();
+        c.on_insert(s, 0, 0);
+        c.on_insert(s, 1, 0);
+        CHECK("bi_incr.incremental_retract", c.on_retract(s, 0, 0) == soft(1));
+    }
+    {  // bi_incr.rs:145-168 test_reward_type: +2
+        auto c = row_conflict(Impact::Reward, const_w(2), [](const Solution& s, size_t a, size_t b) {
+            int64_t ca = s.classes[0].vars[1][a], cb = s.classes[0].vars[1][b];
+            return ca < cb && (ca - cb == 1 || cb - ca == 1);
+        });
+        Solution s = two_col({0, 0}, {0, 1});
+        CHECK("bi_incr.reward_type", c.evaluate(s) == soft(2));
+    }
+    {  // bi_incr.rs:170-194 test_dynamic_weight: -3
+        auto c = row_conflict(Impact::Penalty, [](const Solution& s, size_t a, size_t b) {
+            int64_t d = s.classes[0].vars[1][b] - s.classes[0].vars[1][a];
+            return soft(d < 0 ? -d : d);
+        });
+        Solution s = two_col({0, 0}, {0, 3});
+        CHECK("bi_incr.dynamic_weight", c.evaluate(s) == soft(-3));
+    }
+    {  // bi_incr.rs:196-219 test_multiple_conflicts: -3, 3 matches
+        auto c = row_conflict(Impact::Penalty, const_w(1));
+        Solution s = two_col({0, 0, 0}, {0, 1, 2});
+        CHECK("bi_incr.multiple_conflicts", c.evaluate(s) == soft(-3) && c.match_count(s) == 3);
+    }
+    {  // bi_incr.rs:221-246 test_reset: insert after reset -> 0
+        auto c = row_conflict(Impact::Penalty, const_w(1));
+        Solution s = two_col({0, 0}, {0, 1});
+        c.initialize(s);
+        c.reset();
+        c.on_insert(s, 0, 0);
+        c.on_insert(s, 1, 0);
+        c.reset();
+        CHECK("bi_incr.reset", c.on_insert(s, 0, 0) == soft(0));
+    }
+    {  // bi_incr.rs:248-273 test_in_constraint_set: evaluate_all == -1
+        ConstraintSet set;
+        set.members.push_back(std::make_unique<SelfJoinBiConstraint>(row_conflict(Impact::Penalty, const_w(1))));
+        Solution s = two_col({0, 0, 2}, {0, 1, 2});
+        CHECK("bi_incr.in_constraint_set", set.evaluate_all(s) == soft(-1));
+    }
+    {  // bi_incr.rs:275-311 test_out_of_bounds: zero deltas
+        auto c = row_conflict(Impact::Penalty, const_w(1));
+        Solution s = two_col({0}, {0});
+        c.initialize(s);
+        CHECK("bi_incr.out_of_bounds", c.on_insert(s, 100, 0) == soft(0) && c.on_retract(s, 100, 0) == soft(0));
+    }
+}
+
+// cross_bi_incr.rs: Schedule{shifts(employee_id, day) = class 0, employees(id, unavailable_day) = class 1}
+static Solution schedule(std::vector<int64_t> shift_emp, std::vector<int64_t> shift_day,
+                         std::vector<int64_t> emp_id, std::vector<int64_t> emp_unavail) {
+    Solution s;
+    s.classes.resize(2);
+    s.classes[0].n = shift_emp.size();
+    s.classes[0].vars = {shift_emp, shift_day};
+    s.classes[1].n = emp_id.size();
+    s.classes[1].vars = {emp_id, emp_unavail};  // one unavailable day per employee (NONE = none)
+    return s;
+}
+static CrossBiConstraint unavailable_employee() {  // cross_bi_incr.rs:60-83
+    CrossBiConstraint c;
+    c.name = "Unavailable employee";
+    c.impact = Impact::Penalty;
+    c.a_source = ChangeSource::descriptor(0);
+    c.b_source = ChangeSource::descriptor(1);
+    c.a_count = [](const Solution& s) { return s.classes[0].n; };
+    c.b_count = [](const Solution& s) { return s.classes[1].n; };
+    c.key_a = [](const Solution& s, size_t a) { return s.classes[0].vars[0][a]; };
+    c.key_b = [](const Solution& s, size_t b) { return s.classes[1].vars[0][b]; };
+    c.filter = [](const Solution& s, size_t a, size_t b) {
+        return s.classes[0].vars[0][a] != NONE && s.classes[1].vars[1][b] == s.classes[0].vars[1][a];
+    };
+    c.weight = [](const Solution&, size_t, size_t) { return soft(1); };
+    return c;
+}
+
+static void cross_bi_cases() {
+    Solution sample = schedule({0, 0}, {5, 6}, {0}, {5});  // sample_schedule() cross_bi_incr.rs:110-128
+    {  // cross_bi_incr.rs:205-216 evaluate / match_count without initialize
+        auto c = unavailable_employee();
+        CHECK("cross_bi.evaluate_without_initialize", c.evaluate(sample) == soft(-1) && c.match_count(sample) == 1);
+    }
+    {  // cross_bi_incr.rs:247-259 incremental updates: init -1, retract +1, insert -1
+        auto c = unavailable_employee();
+        bool ok = c.initialize(sample) == soft(-1);
+        ok = ok && c.on_retract(sample, 0, 0) == soft(1);
+        ok = ok && c.on_insert(sample, 0, 0) == soft(-1);
+        CHECK("cross_bi.incremental_updates", ok);
+    }
+    {  // cross_bi_incr.rs:261-273 b-side retract/insert: unavailable day 5 -> 6 keeps total -1
+        auto c = unavailable_employee();
+        Solution s = sample;
+        Score total = c.initialize(s);
+        bool ok = total == soft(-1);
+        total = total + c.on_retract(s, 0, 1);
+        s.classes[1].vars[1][0] = 6;
+        total = total + c.on_insert(s, 0, 1);
+        CHECK("cross_bi.b_side_updates", ok && total == soft(-1) && total == c.evaluate(s));
+    }
+    {  // cross_bi_incr.rs:372-381 unrelated descriptor is a no-op
+        auto c = unavailable_employee();
+        Score initial = c.initialize(sample);
+        CHECK("cross_bi.unrelated_descriptor_noop", initial == soft(-1) && c.on_retract(sample, 0, 2) == soft(0));
+    }
+    {  // cross_bi_incr.rs:307-335 filter sees source indexes: (shift 1, employee 0), weight = day 6 -> -6
+        CrossBiConstraint c = unavailable_employee();
+        c.filter = [](const Solution&, size_t a, size_t b) { return a == 1 && b == 0; };
+        c.weight = [](const Solution& s, size_t a, size_t) { return soft(s.classes[0].vars[1][a]); };
+        Solution two = schedule({0, 0}, {5, 6}, {0, 1}, {NONE, NONE});
+        CHECK("cross_bi.filter_source_indexes", c.match_count(two) == 1 && c.evaluate(two) == soft(-6));
+    }
+    {  // same-descriptor predicate join fires both sides and tests (i,i) (incremental.rs:93-115)
+        CrossBiConstraint c;
+        c.name = "pair";
+        c.impact = Impact::Penalty;
+        c.a_source = c.b_source = ChangeSource::descriptor(0);
+        c.a_count = c.b_count = [](const Solution& s) { return s.classes[0].n; };
+        c.key_a = c.key_b = [](const Solution&, size_t) { return (int64_t)0; };
+        c.filter = [](const Solution& s, size_t a, size_t b) {
+            return a < b && s.classes[0].vars[0][a] == s.classes[0].vars[0][b];
+        };
+        c.weight = [](const Solution&, size_t, size_t) { return soft(1); };
+        Solution s = two_col({1, 1, 2, 1}, {0, 0, 0, 0});
+        Score total = c.initialize(s);
+        bool ok = total == soft(-3) && total == c.evaluate(s);
+        total = total + c.on_retract(s, 1, 0);
+        s.classes[0].vars[0][1] = 2;
+        total = total + c.on_insert(s, 1, 0);
+        ok = ok && total == soft(-2) && total == c.evaluate(s);
+        CHECK("cross_bi.same_descriptor_both_sides", ok);
+    }
+}
+
+static void exists_cases() {
+    {  // exists.rs:92-121 flattened not-exists: init -3, after route=[1,2,3] -> 0
+        Solution s;
+        s.classes.resize(1);
+        s.classes[0].n = 1;
+        s.classes[0].lists = {{}};
+        std::vector<int64_t> customers = {1, 2, 3};
+        ExistsConstraint c;
+        c.name = "missing assignment";
+        c.impact = Impact::Penalty;
+        c.mode = ExistenceMode::NotExists;
+        c.a_source = ChangeSource::fixed();
+        c.parent_source = ChangeSource::descriptor(0);
+        c.a_count = [customers](const Solution&) { return customers.size(); };
+        c.parent_count = [](const Solution& s) { return s.classes[0].n; };
+        c.filter_a = [](const Solution&, size_t) { return true; };
+        c.filter_parent = [](const Solution&, size_t) { return true; };
+        c.key_a = [customers](const Solution&, size_t i) { return customers[i]; };
+        c.flatten = [](const Solution& s, size_t p, std::vector<int64_t>& out) {
+            for (uint32_t v : s.classes[0].lists[p]) out.push_back(v);
+        };
+        c.weight = [](const Solution&, size_t) { return soft(1); };
+        Score total = c.initialize(s);
+        bool ok = total == soft(-3);
+        total = total + c.on_retract(s, 0, 0);
+        s.classes[0].lists[0] = {1, 2, 3};
+        total = total + c.on_insert(s, 0, 0);
+        CHECK("exists.flattened_not_exists_route_change", ok && total == c.evaluate(s) && total == soft(0));
+    }
+    {  // exists.rs:34-78 exists: tasks(assignee) static, workers(available) descriptor 0; 0 -> -2
+        // class 0 = workers {id, available}; tasks held as facts
+        Solution s = two_col({0, 1}, {1, 1});
+        std::vector<int64_t> assignee = {0, 0, 1};
+        ExistsConstraint c;
+        c.name = "unavailable worker";
+        c.impact = Impact::Penalty;
+        c.mode = ExistenceMode::Exists;
+        c.a_source = ChangeSource::fixed();
+        c.parent_source = ChangeSource::descriptor(0);
+        c.a_count = [assignee](const Solution&) { return assignee.size(); };
+        c.parent_count = [](const Solution& s) { return s.classes[0].n; };
+        c.filter_a = [assignee](const Solution&, size_t i) { return assignee[i] != NONE; };
+        c.filter_parent = [](const Solution& s, size_t p) { return s.classes[0].vars[1][p] == 0; };  // !available
+        c.key_a = [assignee](const Solution&, size_t i) { return assignee[i]; };
+        c.flatten = [](const Solution& s, size_t p, std::vector<int64_t>& out) {
+            out.push_back(s.classes[0].vars[0][p]);  // SelfFlatten: one B row = one key (worker.id)
+        };
+        c.weight = [](const Solution&, size_t) { return soft(1); };
+        Score total = c.initialize(s);
+        bool ok = total == soft(0);
+        total = total + c.on_retract(s, 0, 0);
+        s.classes[0].vars[1][0] = 0;  // worker 0 becomes unavailable
+        total = total + c.on_insert(s, 0, 0);
+        CHECK("exists.b_descriptor_change_updates_all_a", ok && total == c.evaluate(s) && total == soft(-2));
+    }
+    {  // exists.rs:139-190 same source on both sides: -2 -> 0 when the enabled peer is disabled
+        Solution s = two_col({1, 1}, {0, 1});  // {key, enabled}
+        ExistsConstraint c;
+        c.name = "key has enabled peer";
+        c.impact = Impact::Penalty;
+        c.mode = ExistenceMode::Exists;
+        c.a_source = c.parent_source = ChangeSource::descriptor(0);
+        c.a_count = c.parent_count = [](const Solution& s) { return s.classes[0].n; };
+        c.filter_a = [](const Solution&, size_t) { return true; };
+        c.filter_parent = [](const Solution& s, size_t p) { return s.classes[0].vars[1][p] != 0; };
+        c.key_a = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+        c.flatten = [](const Solution& s, size_t p, std::vector<int64_t>& out) {
+            out.push_back(s.classes[0].vars[0][p]);
+        };
+        c.weight = [](const Solution&, size_t) { return soft(1); };
+        Score total = c.initialize(s);
+        bool ok = total == soft(-2);
+        total = total + c.on_retract(s, 1, 0);
+        s.classes[0].vars[1][1] = 0;
+        total = total + c.on_insert(s, 1, 0);
+        CHECK("exists.same_source_consistent", ok && total == c.evaluate(s) && total == soft(0));
+    }
+}
+
+static GroupedConstraint workload(Impact impact, GroupWeight w) {  // grouped.rs helper shape
+    GroupedConstraint c;
+    c.name = "Workload";
+    c.impact = impact;
+    c.source = ChangeSource::descriptor(0);
+    c.count = [](const Solution& s) { return s.classes[0].n; };
+    c.filter = [](const Solution&, size_t) { return true; };
+    c.key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    c.value = [](const Solution&, size_t) { return (int64_t)1; };  // count()
+    c.weight = w;
+    return c;
+}
+
+static void grouped_cases() {
+    {  // grouped.rs:26-58 evaluate: counts 3,1 with weight count^2 -> -10
+        auto c = workload(Impact::Penalty, [](int64_t, int64_t n) { return soft(n * n); });
+        Solution s = two_col({1, 1, 1, 2}, {0, 0, 0, 0});
+        CHECK("grouped.evaluate", c.evaluate(s) == soft(-10));
+    }
+    {  // grouped.rs:60-103 incremental: init -3, retract +1, insert -1
+        auto c = workload(Impact::Penalty, [](int64_t, int64_t n) { return soft(n); });
+        Solution s = two_col({1, 1, 2}, {0, 0, 0});
+        bool ok = c.initialize(s) == soft(-3);
+        ok = ok && c.on_retract(s, 0, 0) == soft(1);
+        ok = ok && c.on_insert(s, 0, 0) == soft(-1);
+        CHECK("grouped.incremental", ok);
+    }
+    {  // grouped.rs:105-125 reward: +2
+        auto c = workload(Impact::Reward, [](int64_t, int64_t n) { return soft(n); });
+        Solution s = two_col({1, 1}, {0, 0});
+        CHECK("grouped.reward", c.evaluate(s) == soft(2));
+    }
+    {  // grouped.rs:127-147 weight can use key: 1*1 + 2*2 -> -5
+        auto c = workload(Impact::Penalty, [](int64_t k, int64_t n) { return soft(k * n); });
+        Solution s = two_col({1, 2, 2}, {0, 0, 0});
+        CHECK("grouped.weight_uses_key", c.evaluate(s) == soft(-5));
+    }
+}
+
+// director/tests/benchmarks.rs:116-182: incremental == calculate_full after 1000 do/undo moves.
+static void director_case() {
+    const size_t n = 100;
+    ScoreDirector d;
+    Solution& s = d.working;
+    s.classes.resize(1);
+    s.classes[0].n = n;
+    s.classes[0].vars.assign(3, std::vector<int64_t>(n));
+    for (size_t i = 0; i < n; ++i) {
+        s.classes[0].vars[0][i] = 0;                      // employee_id = Some(0)
+        s.classes[0].vars[1][i] = (int64_t)(i % 24);      // start_hour
+        s.classes[0].vars[2][i] = (int64_t)(i % 24) + 1;  // end_hour
+    }
+    auto full = [](const Solution& s) {  // benchmarks.rs:45-70 calculate_full
+        int64_t penalty = 0;
+        size_t n = s.classes[0].n;
+        auto& e = s.classes[0].vars[0];
+        auto& st = s.classes[0].vars[1];
+        auto& en = s.classes[0].vars[2];
+        for (size_t i = 0; i < n; ++i)
+            if (e[i] == NONE) ++penalty;
+        for (size_t i = 0; i < n; ++i)
+            for (size_t j = i + 1; j < n; ++j)
+                if (e[i] != NONE && e[i] == e[j] && st[i] < en[j] && st[j] < en[i]) penalty += 10;
+        return soft(-penalty);
+    };
+    d.constraints.members.push_back(make_unassigned(0, 0, soft(1), "Unassigned"));
+    auto ov = std::make_unique<SelfJoinBiConstraint>();
+    ov->name = "Overlapping";
+    ov->impact = Impact::Penalty;
+    ov->source = ChangeSource::descriptor(0);
+    ov->count = [](const Solution& s) { return s.classes[0].n; };
+    ov->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    ov->filter = [](const Solution& s, size_t a, size_t b) {
+        return a < b && s.classes[0].vars[1][a] < s.classes[0].vars[2][b] &&
+               s.classes[0].vars[1][b] < s.classes[0].vars[2][a];
+    };
+    ov->weight = [](const Solution&, size_t, size_t) { return soft(10); };
+    d.constraints.members.push_back(std::move(ov));
+    bool ok = d.calculate_score() == full(d.working);
+    for (size_t i = 0; i < 1000; ++i) {
+        size_t idx = i % n;
+        int64_t old = d.working.classes[0].vars[0][idx];
+        d.before_variable_changed(0, idx);
+        d.working.classes[0].vars[0][idx] = (int64_t)(i % 5) + 1;
+        d.after_variable_changed(0, idx);
+        ok = ok && d.cached == full(d.working);
+        d.before_variable_changed(0, idx);
+        d.working.classes[0].vars[0][idx] = old;
+        d.after_variable_changed(0, idx);
+    }
+    CHECK("director.incremental_equals_full", ok && d.cached == full(d.working));
+}
+
+int main() {
+    bi_incr_cases();
+    cross_bi_cases();
+    exists_cases();
+    grouped_cases();
+    director_case();
+    std::printf("%s %d failures\n", failures ? "FAILED" : "PASSED", failures);
+    return failures;
+}
