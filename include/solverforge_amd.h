@@ -1,0 +1,238 @@
+/*
+ * solverforge_amd.h — C ABI of the MI355X-native SolverForge hot path.
+ *
+ * The reference (SolverForge/solverforge, 100 % Rust) exposes no FFI; its seams are
+ * monomorphised traits.  This header is the boundary a Rust `extern "C"` shim binds to
+ * implement those traits on top of the HIP path (INTEGRATION.md shows the shim):
+ *
+ *   Director<S>            crates/solverforge-scoring/src/director/traits.rs:27-95
+ *   ConstraintSet<S,Sc>    crates/solverforge-scoring/src/api/constraint_set/incremental.rs:152-212
+ *   MoveSelector/MoveCursor crates/solverforge-solver/src/heuristic/selector/move_selector/iter.rs:239-279
+ *   MoveCursorSource       crates/solverforge-solver/src/phase/localsearch/cursor_source.rs:23-48
+ *   ValueSelector          crates/solverforge-solver/src/heuristic/selector/value_selector.rs:21-41
+ *   ScalarCandidateProvider crates/solverforge-solver/src/planning/scalar/candidate.rs:190
+ *   SolutionDescriptor     crates/solverforge-core/src/domain/descriptor/solution.rs:16-33
+ *
+ * Conventions: every entry point is extern "C", takes plain pointers and sizes, returns an
+ * int32 status (0 = SF_OK, <0 = error; text via sf_last_error).  Input buffers are borrowed
+ * for the duration of the call; the context owns all device memory.  One context = one HIP
+ * stream; calls on one context are not re-entrant, distinct contexts are independent.
+ * A context holds `n_replicas` independent searches of the same problem (a per-GPU batch of
+ * the seed portfolio); replica r is a full Director + search state.
+ * There is no CPU fallback: every call fails with SF_ERR_NO_DEVICE when no gfx950 device exists.
+ */
+#ifndef SOLVERFORGE_AMD_H
+#define SOLVERFORGE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sf_ctx sf_ctx;
+
+enum {
+    SF_OK = 0,
+    SF_ERR_INVALID = -1,     /* bad argument / call order (the reference would panic!) */
+    SF_ERR_NO_DEVICE = -2,   /* no HIP device: the product path never falls back to the CPU */
+    SF_ERR_HIP = -3,         /* HIP runtime error, see sf_last_error */
+    SF_ERR_UNSUPPORTED = -4, /* valid reference feature outside this build's scope */
+    SF_ERR_CAPACITY = -5     /* output buffer too small */
+};
+
+#define SF_MAX_LEVELS 4
+#define SF_NONE (-1) /* Option<usize>::None for scalar planning variables */
+
+/* One candidate move.  A ScalarEdit{descriptor_index, entity_index, variable_name, to_value}
+ * (crates/solverforge-solver/src/planning/scalar/candidate.rs:6-82) is kind = SF_MOVE_CHANGE
+ * with a = entity_index, value = to_value; descriptor/variable come from the selector's slot. */
+typedef struct sf_move_t {
+    int32_t kind;  /* sf_move_kind */
+    int32_t a;     /* Change: entity; Swap: left entity; List*: source / first entity */
+    int32_t a_pos; /* List*: source / first position */
+    int32_t b;     /* Swap: right entity; List*: destination / second entity */
+    int32_t b_pos; /* List*: destination / second position (ListChange: pre-removal coordinates,
+                      heuristic/move/list_kernel/change.rs:28-34) */
+    int32_t value; /* Change: to_value (SF_NONE = unassign) */
+} sf_move_t;
+
+typedef enum sf_move_kind {
+    SF_MOVE_CHANGE = 0,      /* heuristic/move/change.rs:118-221 */
+    SF_MOVE_SWAP = 1,        /* heuristic/move/swap.rs:150-215 */
+    SF_MOVE_LIST_CHANGE = 2, /* heuristic/move/list_kernel/change.rs:16-153 */
+    SF_MOVE_LIST_SWAP = 3    /* heuristic/move/list_kernel/swap.rs:17-110 */
+} sf_move_kind;
+
+/* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
+ * cannot run on a GPU).  Each is the device form of one incremental node. */
+typedef enum sf_constraint_kind {
+    /* for_each(E).unassigned().penalize(w) — IncrementalUniConstraint, constraint/incremental.rs:19-193 */
+    SF_C_UNI_UNASSIGNED = 1,
+    /* predicate cross-join on one class: left.id<right.id && adjacent(left,right) &&
+     * assigned && equal value — cross_bi_incremental::Bi with constant key
+     * (examples/scalar-graph-coloring/src/domain/graph_coloring.rs:28-41); `fact_a` = CSR adjacency */
+    SF_C_CROSS_ADJACENT_EQUAL = 2,
+    /* predicate cross-join: left.id<right.id && group[left]==group[right] && assigned && equal value
+     * (examples/mixed-job-shop/src/domain/job_shop_plan.rs:50-62); `fact_a` = i32 group column */
+    SF_C_CROSS_GROUP_EQUAL = 3,
+    /* N-queens row/diagonal conflicts (examples/nqueens/src/domain/board.rs:30-44); `fact_a` = column */
+    SF_C_CROSS_QUEENS = 4,
+    /* for_each(A).if_not_exists(for_each(owners).flattened(list), equal_bi(A.id, item)) —
+     * IncrementalExistsConstraint, constraint/exists.rs:42-437; `fact_a` = u32 key column of A */
+    SF_C_NOT_EXISTS_FLATTENED = 5,
+    /* for_each(routes).penalize(max(0, sum(demand[visit]) - capacity)) — uni on list owners;
+     * `fact_a` = i32 demand column, `param` = capacity */
+    SF_C_ROUTE_CAPACITY = 6,
+    /* for_each(routes).penalize(depot->...->depot matrix sum) — uni on list owners
+     * (ProblemData::distance_cost, crates/solverforge-cvrp/src/problem_data.rs:28-31);
+     * `fact_a` = i64 matrix, `param` = depot node */
+    SF_C_ROUTE_DISTANCE = 7
+} sf_constraint_kind;
+
+typedef enum sf_selector_kind {
+    SF_SEL_SCALAR_CHANGE = 1,      /* selector/scalar_neighborhood/cursor/change.rs:27-121 */
+    SF_SEL_SCALAR_SWAP = 2,        /* selector/scalar_neighborhood/cursor/swap.rs:22-160 */
+    SF_SEL_LIST_CHANGE = 4,        /* selector/list_kernel/change.rs:25-241 */
+    SF_SEL_LIST_SWAP = 8,          /* selector/list_kernel/swap.rs:25-270 */
+    SF_SEL_NEARBY_LIST_CHANGE = 16,/* selector/list_kernel/nearby_change.rs:17-233 */
+    SF_SEL_NEARBY_LIST_SWAP = 32   /* selector/list_kernel/nearby_swap.rs:17-260 */
+} sf_selector_kind;
+
+typedef enum sf_selection_order { /* solverforge_config::SelectionOrder */
+    SF_ORDER_ORIGINAL = 0, SF_ORDER_SORTED = 1, SF_ORDER_PROBABILISTIC = 2,
+    SF_ORDER_RANDOM = 3, SF_ORDER_SHUFFLED = 4
+} sf_selection_order;
+
+typedef enum sf_acceptor_kind {
+    SF_ACCEPT_HILL_CLIMBING = 0,  /* phase/localsearch/acceptor/hill_climbing.rs:33-41 */
+    SF_ACCEPT_LATE_ACCEPTANCE = 1 /* phase/localsearch/acceptor/late_acceptance.rs:89-125 */
+} sf_acceptor_kind;
+
+typedef enum sf_forager_kind {
+    SF_FORAGER_ACCEPTED_COUNT = 0, /* phase/localsearch/forager.rs:157-250 */
+    SF_FORAGER_FIRST_ACCEPTED = 1, /* phase/localsearch/forager.rs:252-337 */
+    SF_FORAGER_BEST_SCORE = 2      /* phase/localsearch/forager.rs:339-420 */
+} sf_forager_kind;
+
+typedef struct sf_solver_config {
+    int32_t acceptor;            /* sf_acceptor_kind */
+    int32_t late_acceptance_size;/* default 400: runtime/compiler/default_local_search/policy.rs:18 */
+    int32_t forager;             /* sf_forager_kind */
+    int32_t accepted_count_limit;/* default 256: policy.rs:19 */
+    int32_t random_ties;         /* ScoreTieBreak::Random = 1 (solverforge-config/src/forager.rs:5-9) */
+    int32_t selection_order;     /* sf_selection_order; default policy = SF_ORDER_RANDOM */
+    uint64_t random_seed;        /* replica r searches with random_seed + r */
+} sf_solver_config;
+
+/* SolverStats counters (crates/solverforge-solver/src/stats/solver.rs:23,112-119,246). */
+typedef struct sf_stats {
+    uint64_t step_count;
+    uint64_t moves_generated;     /* candidates pulled from the cursor */
+    uint64_t moves_evaluated;     /* consumed candidates, incl. not-doable (evaluation.rs:33-49) */
+    uint64_t moves_accepted;
+    uint64_t moves_applied;
+    uint64_t score_calculations;  /* scored trials only (evaluation.rs:60) */
+    uint64_t moves_not_doable;
+    uint64_t candidates_scored;   /* device work incl. the speculative tail of each step */
+} sf_stats;
+
+/* ---- context ------------------------------------------------------------------------- */
+int32_t sf_ctx_create(int32_t device_id, int32_t score_levels, int32_t hard_levels,
+                      int32_t n_replicas, sf_ctx** out);
+void sf_ctx_destroy(sf_ctx* ctx);
+const char* sf_last_error(const sf_ctx* ctx); /* ctx may be NULL: last create error */
+int32_t sf_device_count(void);
+int32_t sf_sync(sf_ctx* ctx); /* hipStreamSynchronize on the context stream */
+
+/* ---- schema: SolutionDescriptor mirror (descriptor_index / variable_index addressing) ---- */
+int32_t sf_schema_add_entity_class(sf_ctx* ctx, int32_t descriptor_index, int32_t n_rows);
+/* scalar planning variable, value range 0..n_values (ValueSource::CountableRange / SolutionCount);
+ * `initial[n_rows]` int32, SF_NONE = unassigned; replicated to every replica */
+int32_t sf_schema_add_scalar_variable(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index,
+                                      int32_t n_values, int32_t allows_unassigned,
+                                      const int32_t* initial);
+/* list planning variable as CSR: offsets[n_rows+1], values[offsets[n_rows]];
+ * `element_capacity` = max total elements (element ids < element_id_bound) */
+int32_t sf_schema_add_list_variable(sf_ctx* ctx, int32_t descriptor_index,
+                                    const uint32_t* offsets, const uint32_t* values,
+                                    int32_t element_capacity, int32_t element_id_bound);
+/* problem facts (immutable, shared by all replicas) */
+int32_t sf_fact_matrix_i64(sf_ctx* ctx, int32_t fact_id, int32_t rows, int32_t cols, const int64_t* data);
+int32_t sf_fact_column_i32(sf_ctx* ctx, int32_t fact_id, int32_t n, const int32_t* data);
+int32_t sf_fact_column_u32(sf_ctx* ctx, int32_t fact_id, int32_t n, const uint32_t* data);
+int32_t sf_fact_csr_u32(sf_ctx* ctx, int32_t fact_id, int32_t n_rows, const uint32_t* offsets,
+                        const uint32_t* values);
+
+/* ---- constraints / selectors ------------------------------------------------------------- */
+/* weight is added to score level `level` as a penalty (ImpactType::Penalty). */
+int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int32_t variable_index,
+                          int32_t fact_a, int64_t param, int32_t level, int64_t weight);
+/* leaves are unioned in default-policy declaration order; >1 leaf => StratifiedRandom with equal
+ * weights, 1 leaf => Sequential (default_local_search/policy.rs:104-108).
+ * `fact_meter` = i64 matrix for MatrixDistanceMeter (crates/solverforge-cvrp/src/meters.rs:10-28). */
+int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int32_t variable_index,
+                        int32_t max_nearby, int32_t fact_meter);
+
+/* ---- Director surface -------------------------------------------------------------------- */
+/* ≙ first Director::calculate_score (initialize_all): builds per-replica aggregates.
+ * out_scores[n_replicas * score_levels] (may be NULL). */
+int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores);
+/* ≙ Director::fresh_score (evaluate_all from scratch; FullAssert check) */
+int32_t sf_evaluate_all(sf_ctx* ctx, int64_t* out_scores);
+/* committed (cached) score of every replica */
+int32_t sf_get_scores(sf_ctx* ctx, int64_t* out_scores);
+/* ≙ n x evaluate_candidate (phase/localsearch/evaluation.rs:20-115) against replica `replica`:
+ * one launch, state unchanged.  out_scores[n * score_levels], out_doable[n]. */
+int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, int64_t n,
+                         int64_t* out_scores, int32_t* out_doable);
+/* ≙ committed Move::do_move + before/after_variable_changed + calculate_score */
+int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* move);
+
+/* ---- MoveSelector / cursor surface ------------------------------------------------------- */
+/* Opens the configured union cursor for MoveStreamContext(step_index, step_seed) with the given
+ * selection order on replica `replica`, drains it, and returns every candidate in cursor order
+ * together with its trial score (state unchanged).  out_scores/out_doable may be NULL. */
+int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint64_t step_seed,
+                         int32_t selection_order, sf_move_t* out_moves, int64_t* out_scores,
+                         int32_t* out_doable, int64_t cap, int64_t* out_count);
+
+/* ---- local search phase ------------------------------------------------------------------ */
+int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg);
+/* explicit step seeds for parity runs (n_steps per replica, replica-major); NULL clears */
+int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps);
+/* ≙ phase start: last_step_score = calculate_score, acceptor.phase_started, best = working */
+int32_t sf_phase_start(sf_ctx* ctx);
+/* ≙ n_steps x execute_step (phase/localsearch/phase/step.rs:30-225) for EVERY replica, fused in
+ * one persistent launch (generate -> trial-score -> accept -> forage -> apply). Asynchronous. */
+int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps);
+/* one traced step on every replica: per consumed candidate move/score/flags (bit0 doable, bit1
+ * accepted) of replica `replica`; out_applied = 1 and *out_applied_move when a move was committed */
+int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves, int64_t* out_scores,
+                             int32_t* out_flags, int64_t cap, int64_t* out_count,
+                             int32_t* out_applied, sf_move_t* out_applied_move);
+int32_t sf_get_stats(sf_ctx* ctx, int32_t replica, sf_stats* out);
+int32_t sf_get_best_scores(sf_ctx* ctx, int64_t* out_scores);
+/* duration (ms, HIP events on the context stream) and launch count of sf_solve_steps launches
+ * since the last call */
+int32_t sf_profile_solve(sf_ctx* ctx, double* out_ms, int64_t* out_launches);
+
+/* ---- state download ---------------------------------------------------------------------- */
+int32_t sf_download_scalar(sf_ctx* ctx, int32_t replica, int32_t descriptor_index,
+                           int32_t variable_index, int32_t* out, int32_t best);
+int32_t sf_download_list(sf_ctx* ctx, int32_t replica, int32_t descriptor_index, uint32_t* out_offsets,
+                         uint32_t* out_values, int32_t best);
+
+/* ---- portfolio (multi-GPU): RCCL all-gather of (score levels, rank) + lexicographic max ---- */
+int32_t sf_portfolio_unique_id(uint8_t* out_id128);          /* rank 0: ncclGetUniqueId */
+int32_t sf_portfolio_init(sf_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world_size);
+/* gathers every rank's best score over xGMI; all ranks get the same winner */
+int32_t sf_portfolio_allgather_best(sf_ctx* ctx, int64_t* out_best_score, int32_t* out_winner_rank,
+                                    int32_t* out_winner_replica);
+int32_t sf_portfolio_destroy(sf_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOLVERFORGE_AMD_H */

@@ -1,0 +1,16 @@
+"""solverforge_amd — MI355X-native SolverForge hot path (incremental scoring + neighbourhood sweep).
+
+Host-side mirror of the reference's Director / MoveSelector / local-search surface on top of the
+C ABI in include/solverforge_amd.h.  PyTorch is plumbing only (multi-GPU rendezvous); compute is
+hand-written HIP for gfx950.
+"""
+from .director import (  # noqa: F401
+    Acceptor,
+    Forager,
+    GpuScoreDirector,
+    MoveKind,
+    SelectionOrder,
+    SolverConfig,
+)
+from .models import build_cvrp  # noqa: F401
+from ._lib import MOVE_DTYPE, SolverForgeError  # noqa: F401

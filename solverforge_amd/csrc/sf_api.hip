@@ -1,0 +1,778 @@
+// C ABI of the MI355X hot path (include/solverforge_amd.h): context, schema upload into
+// SoA HBM tables, constraint/selector wiring, and kernel launches on the context's stream.
+// No CPU fallback lives here: without a HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/solverforge_amd.h"
+#include "sf_list_kernels.hip"
+#include "sf_scalar_kernels.hip"
+
+using namespace sf;
+
+static std::string g_create_error;
+
+struct Fact {
+    int type = 0;  // 1 matrix i64, 2 col i32, 3 col u32, 4 csr u32
+    void* d0 = nullptr;
+    void* d1 = nullptr;
+    int rows = 0, cols = 0;
+    int64_t max_finite = 0;
+};
+struct ConstraintSpec {
+    int kind, desc, var, fact;
+    int64_t param;
+    int level;
+    int64_t weight;
+};
+struct SelectorSpec {
+    int kind, desc, var, max_nearby, fact;
+};
+struct ClassSpec {
+    int n_rows = 0;
+    bool has_scalar = false;
+    int var_index = 0, n_values = 0, allows_unassigned = 0;
+    std::vector<int32_t> scalar_init;
+    bool has_list = false;
+    std::vector<uint32_t> list_off, list_vals;
+    int element_capacity = 0, element_bound = 0;
+};
+
+struct sf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int levels = 2, hard_levels = 1, R = 1;
+    std::string err;
+    std::map<int, ClassSpec> classes;
+    std::map<int, Fact> facts;
+    std::vector<ConstraintSpec> constraints;
+    std::vector<SelectorSpec> selectors;
+    bool initialized = false;
+    // list model
+    bool has_list_model = false;
+    int list_desc = -1;
+    ListModel lm{};
+    // scalar model
+    bool has_scalar_model = false;
+    int scalar_desc = -1;
+    ScalarModel sm{};
+    // search
+    sf_solver_config cfg{SF_ACCEPT_LATE_ACCEPTANCE, 400, SF_FORAGER_ACCEPTED_COUNT, 256, 1, SF_ORDER_RANDOM, 0};
+    SearchParams sp{};
+    bool search_alloc = false;
+    uint64_t* d_explicit = nullptr;
+    int64_t n_explicit = 0;
+    // trace buffers
+    int32_t* d_trace_moves = nullptr;
+    int64_t* d_trace_scores = nullptr;
+    int32_t* d_trace_flags = nullptr;
+    int64_t* d_trace_count = nullptr;
+    int32_t* d_trace_applied = nullptr;
+    int64_t trace_cap = 0;
+    // scratch
+    int64_t* d_scores_out = nullptr;
+    int32_t* d_ok = nullptr;
+    // profiling
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<void*> allocs;
+    void* rccl = nullptr;  // portfolio state (sf_portfolio.cpp part below)
+};
+
+#define HIPCHK(ctx, expr)                                                                   \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                 \
+            return SF_ERR_HIP;                                                              \
+        }                                                                                   \
+    } while (0)
+
+static int fail(sf_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+template <class T>
+static int dalloc(sf_ctx* ctx, T** out, size_t n) {
+    void* p = nullptr;
+    HIPCHK(ctx, hipMalloc(&p, n * sizeof(T) + 16));
+    ctx->allocs.push_back(p);
+    HIPCHK(ctx, hipMemsetAsync(p, 0, n * sizeof(T) + 16, ctx->stream));
+    *out = (T*)p;
+    return SF_OK;
+}
+template <class T>
+static int upload(sf_ctx* ctx, T** out, const T* src, size_t n) {
+    int rc = dalloc(ctx, out, n ? n : 1);
+    if (rc) return rc;
+    if (n) HIPCHK(ctx, hipMemcpyAsync(*out, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+extern "C" {
+
+int32_t sf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t sf_ctx_create(int32_t device_id, int32_t score_levels, int32_t hard_levels, int32_t n_replicas,
+                      sf_ctx** out) {
+    if (!out) return SF_ERR_INVALID;
+    *out = nullptr;
+    if (score_levels < 1 || score_levels > SF_MAX_LEVELS || hard_levels < 0 || hard_levels > score_levels ||
+        n_replicas < 1) {
+        g_create_error = "invalid score levels / replica count";
+        return SF_ERR_INVALID;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0 || device_id < 0 || device_id >= n) {
+        g_create_error = "no HIP device available (the HIP path has no CPU fallback)";
+        return SF_ERR_NO_DEVICE;
+    }
+    sf_ctx* ctx = new sf_ctx();
+    ctx->device = device_id;
+    ctx->levels = score_levels;
+    ctx->hard_levels = hard_levels;
+    ctx->R = n_replicas;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        g_create_error = "hipSetDevice/hipStreamCreate failed";
+        delete ctx;
+        return SF_ERR_HIP;
+    }
+    *out = ctx;
+    return SF_OK;
+}
+
+void sf_ctx_destroy(sf_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->allocs) (void)hipFree(p);
+    for (auto& ev : ctx->events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* sf_last_error(const sf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int32_t sf_sync(sf_ctx* ctx) {
+    if (!ctx) return SF_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+// ---- schema --------------------------------------------------------------------------
+int32_t sf_schema_add_entity_class(sf_ctx* ctx, int32_t d, int32_t n_rows) {
+    if (!ctx || d < 0 || n_rows < 0) return fail(ctx, SF_ERR_INVALID, "bad entity class");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "schema is frozen after sf_initialize");
+    ctx->classes[d].n_rows = n_rows;
+    return SF_OK;
+}
+
+int32_t sf_schema_add_scalar_variable(sf_ctx* ctx, int32_t d, int32_t var, int32_t n_values,
+                                      int32_t allows_unassigned, const int32_t* initial) {
+    if (!ctx || !ctx->classes.count(d) || !initial || n_values < 0)
+        return fail(ctx, SF_ERR_INVALID, "bad scalar variable");
+    ClassSpec& c = ctx->classes[d];
+    if (c.has_scalar) return fail(ctx, SF_ERR_UNSUPPORTED, "one scalar planning variable per class");
+    c.has_scalar = true;
+    c.var_index = var;
+    c.n_values = n_values;
+    c.allows_unassigned = allows_unassigned;
+    c.scalar_init.assign(initial, initial + c.n_rows);
+    return SF_OK;
+}
+
+int32_t sf_schema_add_list_variable(sf_ctx* ctx, int32_t d, const uint32_t* offsets, const uint32_t* values,
+                                    int32_t element_capacity, int32_t element_id_bound) {
+    if (!ctx || !ctx->classes.count(d) || !offsets) return fail(ctx, SF_ERR_INVALID, "bad list variable");
+    ClassSpec& c = ctx->classes[d];
+    c.has_list = true;
+    c.list_off.assign(offsets, offsets + c.n_rows + 1);
+    uint32_t total = offsets[c.n_rows];
+    if ((int32_t)total > element_capacity) return fail(ctx, SF_ERR_INVALID, "element_capacity too small");
+    c.list_vals.assign(values, values + total);
+    for (uint32_t v : c.list_vals)
+        if ((int32_t)v >= element_id_bound) return fail(ctx, SF_ERR_INVALID, "element id out of bound");
+    c.element_capacity = element_capacity;
+    c.element_bound = element_id_bound;
+    return SF_OK;
+}
+
+int32_t sf_fact_matrix_i64(sf_ctx* ctx, int32_t id, int32_t rows, int32_t cols, const int64_t* data) {
+    if (!ctx || !data || rows <= 0 || cols <= 0) return fail(ctx, SF_ERR_INVALID, "bad matrix");
+    Fact f;
+    f.type = 1;
+    f.rows = rows;
+    f.cols = cols;
+    int64_t mx = 0;
+    for (size_t i = 0; i < (size_t)rows * cols; ++i)
+        if (data[i] >= 0 && data[i] != INT64_MAX && data[i] > mx) mx = data[i];
+    f.max_finite = mx;
+    int64_t* d = nullptr;
+    int rc = upload(ctx, &d, data, (size_t)rows * cols);
+    if (rc) return rc;
+    f.d0 = d;
+    ctx->facts[id] = f;
+    return SF_OK;
+}
+int32_t sf_fact_column_i32(sf_ctx* ctx, int32_t id, int32_t n, const int32_t* data) {
+    if (!ctx || !data || n < 0) return fail(ctx, SF_ERR_INVALID, "bad column");
+    Fact f;
+    f.type = 2;
+    f.rows = n;
+    int32_t* d = nullptr;
+    int rc = upload(ctx, &d, data, (size_t)n);
+    if (rc) return rc;
+    f.d0 = d;
+    ctx->facts[id] = f;
+    return SF_OK;
+}
+int32_t sf_fact_column_u32(sf_ctx* ctx, int32_t id, int32_t n, const uint32_t* data) {
+    if (!ctx || !data || n < 0) return fail(ctx, SF_ERR_INVALID, "bad column");
+    Fact f;
+    f.type = 3;
+    f.rows = n;
+    uint32_t* d = nullptr;
+    int rc = upload(ctx, &d, data, (size_t)n);
+    if (rc) return rc;
+    f.d0 = d;
+    ctx->facts[id] = f;
+    return SF_OK;
+}
+int32_t sf_fact_csr_u32(sf_ctx* ctx, int32_t id, int32_t n_rows, const uint32_t* offsets, const uint32_t* values) {
+    if (!ctx || !offsets || n_rows < 0) return fail(ctx, SF_ERR_INVALID, "bad csr");
+    Fact f;
+    f.type = 4;
+    f.rows = n_rows;
+    f.cols = (int)offsets[n_rows];
+    uint32_t *d0 = nullptr, *d1 = nullptr;
+    int rc = upload(ctx, &d0, offsets, (size_t)n_rows + 1);
+    if (rc) return rc;
+    rc = upload(ctx, &d1, values, (size_t)offsets[n_rows]);
+    if (rc) return rc;
+    f.d0 = d0;
+    f.d1 = d1;
+    ctx->facts[id] = f;
+    return SF_OK;
+}
+
+int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32_t fact_a, int64_t param,
+                          int32_t level, int64_t weight) {
+    if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
+    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_ROUTE_DISTANCE) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
+    return SF_OK;
+}
+
+int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32_t max_nearby, int32_t fact_meter) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
+    ctx->selectors.push_back({kind, d, var, max_nearby, fact_meter});
+    return SF_OK;
+}
+
+}  // extern "C"
+
+// ---- model assembly --------------------------------------------------------------------
+static int build_list_model(sf_ctx* ctx, int d) {
+    ClassSpec& c = ctx->classes[d];
+    ListModel& m = ctx->lm;
+    m = ListModel{};
+    m.V = c.n_rows;
+    m.n_cap = c.element_capacity;
+    m.dim = c.element_bound;
+    m.levels = ctx->levels;
+    m.cap_level = m.dist_level = m.ne_level = -1;
+    if (m.V > 32767) return fail(ctx, SF_ERR_UNSUPPORTED, "list owners > 32767");
+    for (auto& cs : ctx->constraints) {
+        if (cs.kind == SF_C_ROUTE_CAPACITY && cs.desc == d) {
+            if (!ctx->facts.count(cs.fact) || ctx->facts[cs.fact].type != 2) return fail(ctx, SF_ERR_INVALID, "capacity needs an i32 demand column");
+            if (ctx->facts[cs.fact].rows < m.dim) return fail(ctx, SF_ERR_INVALID, "demand column shorter than element id bound");
+            m.demand = (const int32_t*)ctx->facts[cs.fact].d0;
+            m.capacity = cs.param;
+            m.cap_level = cs.level;
+            m.cap_weight = cs.weight;
+        } else if (cs.kind == SF_C_ROUTE_DISTANCE && cs.desc == d) {
+            if (!ctx->facts.count(cs.fact) || ctx->facts[cs.fact].type != 1) return fail(ctx, SF_ERR_INVALID, "distance needs an i64 matrix");
+            Fact& f = ctx->facts[cs.fact];
+            if (f.rows != f.cols || f.rows < m.dim) return fail(ctx, SF_ERR_INVALID, "matrix smaller than element id bound");
+            m.mat = (const int64_t*)f.d0;
+            m.dim = f.rows;
+            m.depot = (int32_t)cs.param;
+            m.dist_level = cs.level;
+            m.dist_weight = cs.weight;
+        } else if (cs.kind == SF_C_NOT_EXISTS_FLATTENED && cs.desc == d) {
+            if (!ctx->facts.count(cs.fact) || ctx->facts[cs.fact].type != 3) return fail(ctx, SF_ERR_INVALID, "not-exists needs a u32 key column");
+            m.ne_keys = (const uint32_t*)ctx->facts[cs.fact].d0;
+            m.ne_n = ctx->facts[cs.fact].rows;
+            m.ne_level = cs.level;
+            m.ne_weight = cs.weight;
+        }
+    }
+    // nearby meter must be the same matrix (MatrixDistanceMeter)
+    for (auto& s : ctx->selectors)
+        if ((s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP) && s.desc == d) {
+            if (!ctx->facts.count(s.fact) || ctx->facts[s.fact].type != 1) return fail(ctx, SF_ERR_INVALID, "nearby selector needs an i64 matrix meter");
+            Fact& f = ctx->facts[s.fact];
+            if (f.max_finite >= MAX_PACKED_DISTANCE) return fail(ctx, SF_ERR_UNSUPPORTED, "matrix values >= 2^40 (packed top-k keys)");
+            if (m.mat && m.mat != (const int64_t*)f.d0) return fail(ctx, SF_ERR_UNSUPPORTED, "meter matrix must be the distance matrix");
+            if (!m.mat) {
+                m.mat = (const int64_t*)f.d0;
+                m.dim = f.rows;
+            }
+            if (s.max_nearby < 1 || s.max_nearby > 64) return fail(ctx, SF_ERR_UNSUPPORTED, "max_nearby must be 1..64");
+        }
+    if (m.dim > 65535 * 16) return fail(ctx, SF_ERR_UNSUPPORTED, "node id bound too large");
+    const int R = ctx->R;
+    int rc;
+    if ((rc = dalloc(ctx, &m.visits, (size_t)R * m.n_cap))) return rc;
+    if ((rc = dalloc(ctx, &m.off, (size_t)R * (m.V + 1)))) return rc;
+    if ((rc = dalloc(ctx, &m.load, (size_t)R * m.V))) return rc;
+    if ((rc = dalloc(ctx, &m.score, (size_t)R * 4))) return rc;
+    if ((rc = dalloc(ctx, &m.best_visits, (size_t)R * m.n_cap))) return rc;
+    if ((rc = dalloc(ctx, &m.best_off, (size_t)R * (m.V + 1)))) return rc;
+    if ((rc = dalloc(ctx, &m.best_score, (size_t)R * 4))) return rc;
+    for (int r = 0; r < R; ++r) {
+        HIPCHK(ctx, hipMemcpyAsync(m.visits + (size_t)r * m.n_cap, c.list_vals.data(), c.list_vals.size() * 4,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(m.off + (size_t)r * (m.V + 1), c.list_off.data(), c.list_off.size() * 4,
+                                   hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_list_model = true;
+    ctx->list_desc = d;
+    return SF_OK;
+}
+
+static int build_scalar_model(sf_ctx* ctx, int d);  // sf_api_scalar.inc
+static int launch_scalar_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace);
+
+static int alloc_search(sf_ctx* ctx) {
+    if (ctx->search_alloc) return SF_OK;
+    SearchParams& p = ctx->sp;
+    const int R = ctx->R;
+    int rc;
+    int la = ctx->cfg.late_acceptance_size > 0 ? ctx->cfg.late_acceptance_size : 1;
+    if ((rc = dalloc(ctx, &p.last_step_score, (size_t)R * 4))) return rc;
+    if ((rc = dalloc(ctx, &p.la_hist, (size_t)R * la * 4))) return rc;
+    if ((rc = dalloc(ctx, &p.la_idx, (size_t)R))) return rc;
+    if ((rc = dalloc(ctx, &p.step_index, (size_t)R))) return rc;
+    if ((rc = dalloc(ctx, &p.seed_draws, (size_t)R))) return rc;
+    if ((rc = dalloc(ctx, &p.stats, (size_t)R * 8))) return rc;
+    if ((rc = dalloc(ctx, &p.has_best, (size_t)R))) return rc;
+    if ((rc = dalloc(ctx, &ctx->d_trace_count, 1))) return rc;
+    if ((rc = dalloc(ctx, &ctx->d_trace_applied, 8))) return rc;
+    if ((rc = dalloc(ctx, &ctx->d_ok, 4))) return rc;
+    p.la_size = la;
+    ctx->search_alloc = true;
+    return SF_OK;
+}
+
+static int ensure_trace(sf_ctx* ctx, int64_t cap) {
+    if (cap <= ctx->trace_cap) return SF_OK;
+    int rc;
+    if ((rc = dalloc(ctx, &ctx->d_trace_moves, (size_t)cap * 6))) return rc;
+    if ((rc = dalloc(ctx, &ctx->d_trace_scores, (size_t)cap * 4))) return rc;
+    if ((rc = dalloc(ctx, &ctx->d_trace_flags, (size_t)cap))) return rc;
+    ctx->trace_cap = cap;
+    return SF_OK;
+}
+
+static void fill_search_params(sf_ctx* ctx, SearchParams& p) {
+    p.acceptor = ctx->cfg.acceptor;
+    p.forager = ctx->cfg.forager;
+    p.limit = ctx->cfg.accepted_count_limit > 0 ? ctx->cfg.accepted_count_limit : 1;
+    p.random_ties = ctx->cfg.random_ties;
+    p.order = ctx->cfg.selection_order;
+    p.random_seed = ctx->cfg.random_seed;
+    p.dry_run = 0;
+    p.replica_base = 0;
+    p.explicit_seeds = ctx->d_explicit;
+    p.n_explicit = ctx->n_explicit;
+    p.trace_replica = -1;
+    p.trace_moves = ctx->d_trace_moves;
+    p.trace_scores = ctx->d_trace_scores;
+    p.trace_flags = ctx->d_trace_flags;
+    p.trace_cap = ctx->trace_cap;
+    p.trace_count = ctx->d_trace_count;
+    p.trace_applied = ctx->d_trace_applied;
+}
+
+static int fill_list_leaves(sf_ctx* ctx, SearchParams& p) {
+    p.n_leaves = 0;
+    // default-policy declaration order: nearby change, then nearby swap (policy/list.rs:24-33)
+    for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP})
+        for (auto& s : ctx->selectors)
+            if (s.kind == kind && s.desc == ctx->list_desc) {
+                if (p.n_leaves >= MAX_LEAVES) return fail(ctx, SF_ERR_UNSUPPORTED, "more than two list leaves");
+                p.leaf[p.n_leaves++] = LeafSpec{s.kind, s.max_nearby, s.desc};
+            }
+    for (auto& s : ctx->selectors)
+        if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP))
+            return fail(ctx, SF_ERR_UNSUPPORTED, "plain list change/swap leaves are not in the fused kernel yet");
+    if (p.n_leaves == 0) return fail(ctx, SF_ERR_INVALID, "no list selector configured");
+    return SF_OK;
+}
+
+template <int L, bool TRACE>
+static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid) {
+    Carve<L> cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim);
+    size_t lds = cv.total;
+    if (lds > 160 * 1024) return fail(ctx, SF_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of one CU");
+    auto kern = k_list_search<L, TRACE>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, ctx->lm, p);
+    HIPCHK(ctx, hipGetLastError());
+    return SF_OK;
+}
+static int launch_list_search(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
+    switch (ctx->levels) {
+        case 1:
+            return trace ? launch_list_search_t<1, true>(ctx, p, grid) : launch_list_search_t<1, false>(ctx, p, grid);
+        case 2:
+            return trace ? launch_list_search_t<2, true>(ctx, p, grid) : launch_list_search_t<2, false>(ctx, p, grid);
+        case 3:
+            return trace ? launch_list_search_t<3, true>(ctx, p, grid) : launch_list_search_t<3, false>(ctx, p, grid);
+        default:
+            return trace ? launch_list_search_t<4, true>(ctx, p, grid) : launch_list_search_t<4, false>(ctx, p, grid);
+    }
+}
+
+static int download_scores(sf_ctx* ctx, const int64_t* d_src4, int64_t* out) {
+    std::vector<int64_t> tmp((size_t)ctx->R * 4);
+    HIPCHK(ctx, hipMemcpyAsync(tmp.data(), d_src4, tmp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < ctx->R; ++r)
+        for (int k = 0; k < ctx->levels; ++k) out[(size_t)r * ctx->levels + k] = tmp[(size_t)r * 4 + k];
+    return SF_OK;
+}
+
+static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit) {
+    int rc;
+    if (!ctx->d_scores_out && (rc = dalloc(ctx, &ctx->d_scores_out, (size_t)ctx->R * 4))) return rc;
+    if (ctx->has_list_model) {
+        size_t lds = ((size_t)ctx->lm.dim + 31) / 32 * 4 + 16;
+        hipLaunchKernelGGL(k_list_evaluate_all, dim3(ctx->R), dim3(256), lds, ctx->stream, ctx->lm,
+                           ctx->d_scores_out, commit);
+    } else if (ctx->has_scalar_model) {
+        hipLaunchKernelGGL(k_scalar_evaluate_all, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->sm,
+                           ctx->d_scores_out, commit);
+    } else
+        return fail(ctx, SF_ERR_INVALID, "no planning variable configured");
+    HIPCHK(ctx, hipGetLastError());
+    if (out) {
+        std::vector<int64_t> tmp((size_t)ctx->R * ctx->levels);
+        HIPCHK(ctx, hipMemcpyAsync(tmp.data(), ctx->d_scores_out, tmp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        std::memcpy(out, tmp.data(), tmp.size() * 8);
+    } else
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+extern "C" {
+
+int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores) {
+    if (!ctx) return SF_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->initialized) {
+        int n_list = 0, n_scalar = 0, ld = -1, sd = -1;
+        for (auto& kv : ctx->classes) {
+            if (kv.second.has_list) {
+                ++n_list;
+                ld = kv.first;
+            }
+            if (kv.second.has_scalar) {
+                ++n_scalar;
+                sd = kv.first;
+            }
+        }
+        if (n_list + n_scalar == 0) return fail(ctx, SF_ERR_INVALID, "no planning variable configured");
+        if (n_list > 1 || n_scalar > 1 || (n_list && n_scalar))
+            return fail(ctx, SF_ERR_UNSUPPORTED, "this build drives one planning variable per context (mixed models: next)");
+        int rc;
+        if (n_list && (rc = build_list_model(ctx, ld))) return rc;
+        if (n_scalar && (rc = build_scalar_model(ctx, sd))) return rc;
+        ctx->initialized = true;
+    }
+    return run_evaluate_all(ctx, out_scores, 1);
+}
+
+int32_t sf_evaluate_all(sf_ctx* ctx, int64_t* out_scores) {
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    return run_evaluate_all(ctx, out_scores, 0);
+}
+
+int32_t sf_get_scores(sf_ctx* ctx, int64_t* out_scores) {
+    if (!ctx || !ctx->initialized || !out_scores) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    return download_scores(ctx, ctx->has_list_model ? ctx->lm.score : ctx->sm.score, out_scores);
+}
+
+int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, int64_t n, int64_t* out_scores,
+                         int32_t* out_doable) {
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (replica < 0 || replica >= ctx->R || n < 0 || !moves || !out_scores || !out_doable)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate arguments");
+    if (n == 0) return SF_OK;
+    int32_t* d_moves = nullptr;
+    int64_t* d_sc = nullptr;
+    int32_t* d_do = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)&d_moves, (size_t)n * 24));
+    HIPCHK(ctx, hipMalloc((void**)&d_sc, (size_t)n * ctx->levels * 8));
+    HIPCHK(ctx, hipMalloc((void**)&d_do, (size_t)n * 4));
+    HIPCHK(ctx, hipMemcpyAsync(d_moves, moves, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    int grid = (int)((n + 255) / 256);
+    if (ctx->has_list_model)
+        hipLaunchKernelGGL(k_list_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->lm, replica, d_moves, n, d_sc, d_do);
+    else
+        hipLaunchKernelGGL(k_scalar_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->sm, replica, d_moves, n, d_sc, d_do);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_moves);
+    (void)hipFree(d_sc);
+    (void)hipFree(d_do);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return SF_OK;
+}
+
+int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
+    if (!ctx || !ctx->initialized || !mv || replica < 0 || replica >= ctx->R)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    if (ctx->has_list_model) {
+        if (mv->kind != SF_MOVE_LIST_CHANGE && mv->kind != SF_MOVE_LIST_SWAP)
+            return fail(ctx, SF_ERR_INVALID, "list model expects list moves");
+        if (mv->a < 0 || mv->a >= ctx->lm.V || mv->b < 0 || mv->b >= ctx->lm.V || mv->a_pos < 0 || mv->b_pos < 0)
+            return fail(ctx, SF_ERR_INVALID, "move out of range");
+        hipLaunchKernelGGL(k_list_apply, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, mv->kind,
+                           (uint32_t)mv->a, (uint32_t)mv->a_pos, (uint32_t)mv->b, (uint32_t)mv->b_pos, ctx->d_ok);
+    } else {
+        hipLaunchKernelGGL(k_scalar_apply, dim3(1), dim3(64), 0, ctx->stream, ctx->sm, replica, mv->kind, mv->a,
+                           mv->b, mv->value, ctx->d_ok);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    int32_t ok = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&ok, ctx->d_ok, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ok) return fail(ctx, SF_ERR_INVALID, "move is not doable");
+    return SF_OK;
+}
+
+// ---- search ------------------------------------------------------------------------------
+int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg) {
+    if (!ctx || !cfg) return SF_ERR_INVALID;
+    if (ctx->search_alloc && cfg->late_acceptance_size > ctx->sp.la_size)
+        return fail(ctx, SF_ERR_INVALID, "late_acceptance_size cannot grow after the search state exists");
+    if (cfg->acceptor != SF_ACCEPT_HILL_CLIMBING && cfg->acceptor != SF_ACCEPT_LATE_ACCEPTANCE)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "acceptor (SimulatedAnnealing needs f64 exp + rand SmallRng: host-side, unpinned)");
+    if (cfg->forager < 0 || cfg->forager > 2) return fail(ctx, SF_ERR_UNSUPPORTED, "forager");
+    if (cfg->forager == SF_FORAGER_ACCEPTED_COUNT && cfg->accepted_count_limit <= 0)
+        return fail(ctx, SF_ERR_INVALID, "AcceptedCountForager: accepted_count_limit must be > 0");
+    if (cfg->acceptor == SF_ACCEPT_LATE_ACCEPTANCE && cfg->late_acceptance_size <= 0)
+        return fail(ctx, SF_ERR_INVALID, "late_acceptance_size must be > 0");
+    ctx->cfg = *cfg;
+    if (ctx->search_alloc) ctx->sp.la_size = cfg->late_acceptance_size > 0 ? cfg->late_acceptance_size : 1;
+    return SF_OK;
+}
+
+int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (!seeds || n_steps <= 0) {
+        ctx->d_explicit = nullptr;
+        ctx->n_explicit = 0;
+        return SF_OK;
+    }
+    uint64_t* d = nullptr;
+    int rc = upload(ctx, &d, seeds, (size_t)n_steps * ctx->R);
+    if (rc) return rc;
+    ctx->d_explicit = d;
+    ctx->n_explicit = n_steps;
+    return SF_OK;
+}
+
+int32_t sf_phase_start(sf_ctx* ctx) {
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->sp.seed_draws, 0, (size_t)ctx->R * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->sp.stats, 0, (size_t)ctx->R * 64, ctx->stream));
+    if (ctx->has_list_model)
+        hipLaunchKernelGGL(k_list_phase_start, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->lm, ctx->sp);
+    else
+        hipLaunchKernelGGL(k_scalar_phase_start, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->sm, ctx->sp);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
+    if (ctx->has_list_model) {
+        int rc = fill_list_leaves(ctx, p);
+        if (rc) return rc;
+        return launch_list_search(ctx, p, grid, trace);
+    }
+    return launch_scalar_search(ctx, p, grid, trace);
+}
+
+int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) {
+    if (!ctx || !ctx->initialized || !ctx->search_alloc) return fail(ctx, SF_ERR_INVALID, "sf_phase_start first");
+    if (n_steps <= 0) return SF_OK;
+    SearchParams p = ctx->sp;
+    fill_search_params(ctx, p);
+    p.n_steps = n_steps;
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    int rc = launch_search(ctx, p, ctx->R, false);
+    if (rc) return rc;
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    ctx->events.push_back({e0, e1});
+    return SF_OK;
+}
+
+int32_t sf_profile_solve(sf_ctx* ctx, double* out_ms, int64_t* out_launches) {
+    if (!ctx) return SF_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    for (auto& ev : ctx->events) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        total += ms;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (out_ms) *out_ms = total;
+    if (out_launches) *out_launches = (int64_t)ctx->events.size();
+    ctx->events.clear();
+    return SF_OK;
+}
+
+static int fetch_trace(sf_ctx* ctx, sf_move_t* out_moves, int64_t* out_scores, int32_t* out_flags, int64_t cap,
+                       int64_t* out_count) {
+    int64_t n = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n, ctx->d_trace_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_count) *out_count = n;
+    int64_t m = n < cap ? n : cap;
+    if (m > ctx->trace_cap) m = ctx->trace_cap;
+    if (m > 0) {
+        if (out_moves) HIPCHK(ctx, hipMemcpyAsync(out_moves, ctx->d_trace_moves, (size_t)m * 24, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_scores) HIPCHK(ctx, hipMemcpyAsync(out_scores, ctx->d_trace_scores, (size_t)m * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (out_flags) HIPCHK(ctx, hipMemcpyAsync(out_flags, ctx->d_trace_flags, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n > cap) return fail(ctx, SF_ERR_CAPACITY, "trace capacity too small");
+    return SF_OK;
+}
+
+int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint64_t step_seed, int32_t order,
+                         sf_move_t* out_moves, int64_t* out_scores, int32_t* out_doable, int64_t cap,
+                         int64_t* out_count) {
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (replica < 0 || replica >= ctx->R || cap <= 0 || !out_moves) return fail(ctx, SF_ERR_INVALID, "bad sf_step_generate arguments");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    if ((rc = ensure_trace(ctx, cap))) return rc;
+    SearchParams p = ctx->sp;
+    fill_search_params(ctx, p);
+    p.acceptor = 2;  // never accept: pure enumeration + trial scores
+    p.forager = 2;
+    p.order = order;
+    p.dry_run = 1;
+    p.dry_step_index = step_index;
+    p.dry_step_seed = step_seed;
+    p.n_steps = 1;
+    p.replica_base = replica;
+    p.trace_replica = replica;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_trace_count, 0, 8, ctx->stream));
+    if ((rc = launch_search(ctx, p, 1, true))) return rc;
+    std::vector<int32_t> flags((size_t)cap);
+    rc = fetch_trace(ctx, out_moves, out_scores, flags.data(), cap, out_count);
+    if (out_doable && out_count)
+        for (int64_t i = 0; i < *out_count && i < cap; ++i) out_doable[i] = flags[(size_t)i] & 1;
+    return rc;
+}
+
+int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves, int64_t* out_scores,
+                             int32_t* out_flags, int64_t cap, int64_t* out_count, int32_t* out_applied,
+                             sf_move_t* out_applied_move) {
+    if (!ctx || !ctx->initialized || !ctx->search_alloc) return fail(ctx, SF_ERR_INVALID, "sf_phase_start first");
+    if (replica < 0 || replica >= ctx->R || cap <= 0) return fail(ctx, SF_ERR_INVALID, "bad arguments");
+    int rc = ensure_trace(ctx, cap);
+    if (rc) return rc;
+    SearchParams p = ctx->sp;
+    fill_search_params(ctx, p);
+    p.n_steps = 1;
+    p.trace_replica = replica;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_trace_count, 0, 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_trace_applied, 0, 32, ctx->stream));
+    if ((rc = launch_search(ctx, p, ctx->R, true))) return rc;
+    rc = fetch_trace(ctx, out_moves, out_scores, out_flags, cap, out_count);
+    int32_t ap[8];
+    HIPCHK(ctx, hipMemcpyAsync(ap, ctx->d_trace_applied, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (out_applied) *out_applied = ap[0];
+    if (out_applied_move && ap[0]) std::memcpy(out_applied_move, &ap[1], 24);
+    return rc;
+}
+
+int32_t sf_get_stats(sf_ctx* ctx, int32_t replica, sf_stats* out) {
+    if (!ctx || !ctx->search_alloc || !out || replica < 0 || replica >= ctx->R) return fail(ctx, SF_ERR_INVALID, "bad sf_get_stats");
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->sp.stats + (size_t)replica * 8, 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+int32_t sf_get_best_scores(sf_ctx* ctx, int64_t* out) {
+    if (!ctx || !ctx->initialized || !out) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    return download_scores(ctx, ctx->has_list_model ? ctx->lm.best_score : ctx->sm.best_score, out);
+}
+
+int32_t sf_download_list(sf_ctx* ctx, int32_t replica, int32_t d, uint32_t* out_off, uint32_t* out_vals, int32_t best) {
+    if (!ctx || !ctx->has_list_model || d != ctx->list_desc || replica < 0 || replica >= ctx->R)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_download_list");
+    const ListModel& m = ctx->lm;
+    const uint32_t* so = (best ? m.best_off : m.off) + (size_t)replica * (m.V + 1);
+    const uint32_t* sv = (best ? m.best_visits : m.visits) + (size_t)replica * m.n_cap;
+    HIPCHK(ctx, hipMemcpyAsync(out_off, so, (size_t)(m.V + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t total = out_off[m.V];
+    if (total) HIPCHK(ctx, hipMemcpyAsync(out_vals, sv, (size_t)total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+int32_t sf_download_scalar(sf_ctx* ctx, int32_t replica, int32_t d, int32_t var, int32_t* out, int32_t best) {
+    if (!ctx || !ctx->has_scalar_model || d != ctx->scalar_desc || replica < 0 || replica >= ctx->R)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_download_scalar");
+    (void)var;
+    const ScalarModel& m = ctx->sm;
+    const int32_t* src = (best ? m.best_vals : m.vals) + (size_t)replica * m.n;
+    HIPCHK(ctx, hipMemcpyAsync(out, src, (size_t)m.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+}  // extern "C"
+
+#include "sf_api_scalar.inc"
+#include "sf_portfolio.inc"

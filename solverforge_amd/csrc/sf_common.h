@@ -1,0 +1,120 @@
+// Shared host/device primitives of the MI355X hot path: seeded stream context, salts,
+// score vectors.  Integer code is bit-identical on host and device.
+//
+// Semantics restated from (paths under crates/solverforge-solver/src/):
+//   heuristic/selector/move_selector/iter.rs:14-207   MoveStreamContext
+//   phase/localsearch/forager.rs:143-155              reservoir_pick
+// and crates/solverforge-core/src/score/{hard_soft,bendable,macros}.rs for the score algebra.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SF_HD __host__ __device__ __forceinline__
+#else
+#define SF_HD inline
+#endif
+
+namespace sf {
+
+constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ULL;
+constexpr uint64_t OFFSET_MIX = 0xD1B54A32D192ED03ULL;     // iter.rs:122
+constexpr uint64_t STRIDE_SALT_MIX = 0xA24BAED4963EE407ULL; // iter.rs:126,145
+
+// leaf salts
+constexpr uint64_t SALT_SCALAR_CHANGE_VALUE = 0xC4A46E0000000000ULL;   // cursor/change.rs:10
+constexpr uint64_t SALT_SCALAR_CHANGE_ENTITY = 0xC4A46E0000000001ULL;  // cursor/change.rs:11
+constexpr uint64_t SALT_SCALAR_SWAP_LEFT = 0x5A095CA1AA000001ULL;      // cursor/swap.rs:10
+constexpr uint64_t SALT_SCALAR_SWAP_RIGHT = 0x5A095CA1AA000002ULL;     // cursor/swap.rs:11
+constexpr uint64_t SALT_NEARBY_CHANGE_ENTITY = 0xA1EA2B17C4A40001ULL;  // nearby_change.rs:19
+constexpr uint64_t SALT_NEARBY_CHANGE_SOURCE = 0xA1EA2B17C4A40002ULL;  // nearby_change.rs:20
+constexpr uint64_t SALT_NEARBY_SWAP_ENTITY = 0xA1EA25A090000001ULL;    // nearby_swap.rs:19
+constexpr uint64_t SALT_NEARBY_SWAP_SOURCE = 0xA1EA25A090000002ULL;    // nearby_swap.rs:20
+constexpr uint64_t SALT_UNION_OFFSET = 0xA11CE5E1EC700001ULL;          // vec_union.rs:232
+constexpr uint64_t SALT_UNION_STRIDE = 0xA11CE5E1EC700002ULL;          // vec_union.rs:240
+constexpr uint64_t SALT_RESERVOIR = 0xF04A63E239B74D11ULL;             // forager.rs:145
+
+constexpr int64_t UNREACHABLE = INT64_MAX;            // crates/solverforge-cvrp/src/problem_data.rs:6
+constexpr int64_t MAX_SAFE_LEG_COST = INT64_MAX / 4;  // problem_data.rs:8
+
+SF_HD uint64_t splitmix64(uint64_t v) {  // iter.rs:193-198
+    v += GOLDEN;
+    v = (v ^ (v >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    v = (v ^ (v >> 27)) * 0x94D049BB133111EBULL;
+    return v ^ (v >> 31);
+}
+
+SF_HD uint32_t gcd_u32(uint32_t a, uint32_t b) {  // iter.rs:200-207
+    while (b != 0) {
+        uint32_t r = a % b;
+        a = b;
+        b = r;
+    }
+    return a;
+}
+
+// Build-defined step-seed stream (the reference's rand 0.10.1 StdRng is not in the tree:
+// parity unpinned).  draw k of replica seed s.
+SF_HD uint64_t step_seed(uint64_t random_seed, uint64_t draw) { return splitmix64(random_seed + draw * GOLDEN); }
+
+struct StreamCtx {
+    uint64_t step_index;
+    uint64_t step_seed;
+    int32_t order;  // sf_selection_order
+
+    SF_HD bool canonical() const { return order <= 2; }
+    SF_HD uint64_t mixed_seed(uint64_t salt) const {  // iter.rs:182-184
+        return splitmix64(step_seed ^ (step_index * GOLDEN) ^ salt);
+    }
+    SF_HD uint32_t random_index(uint32_t len, uint64_t salt) const {  // iter.rs:90-95
+        if (len <= 1) return 0;
+        return (uint32_t)(mixed_seed(salt) % len);
+    }
+    SF_HD uint32_t random_stride(uint32_t len, uint64_t salt) const {  // iter.rs:97-106
+        if (len <= 1) return 1;
+        uint32_t s = (uint32_t)(mixed_seed(salt) % (len - 1)) + 1;
+        while (gcd_u32(s, len) != 1) s = (s == len - 1) ? 1 : s + 1;
+        return s;
+    }
+    // selection_index (iter.rs:112-128)
+    SF_HD uint32_t selection_index(uint32_t offset, uint32_t len, uint64_t salt) const {
+        if (order <= 2) return offset;
+        if (order == 3) return random_index(len, salt ^ ((uint64_t)offset * OFFSET_MIX));
+        uint32_t start = random_index(len, salt);
+        uint32_t st = random_stride(len, salt ^ STRIDE_SALT_MIX);
+        return (uint32_t)(((uint64_t)start + (uint64_t)offset * st) % len);
+    }
+    // permutation parameters of selection_index_without_replacement (iter.rs:133-150)
+    SF_HD void perm_params(uint32_t len, uint64_t salt, uint32_t& start, uint32_t& stride) const {
+        if (order <= 2) {
+            start = 0;
+            stride = 1;
+            return;
+        }
+        start = random_index(len, salt);
+        stride = random_stride(len, salt ^ STRIDE_SALT_MIX);
+    }
+};
+
+SF_HD bool reservoir_pick(uint64_t seed, uint64_t equal_count) {  // forager.rs:143-148
+    uint64_t mixed = splitmix64(seed ^ (equal_count * GOLDEN) ^ SALT_RESERVOIR);
+    return mixed % equal_count == 0;
+}
+
+SF_HD int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+SF_HD int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+
+template <int L>
+struct ScoreV {
+    int64_t v[L];
+};
+template <int L>
+SF_HD int score_cmp(const ScoreV<L>& a, const ScoreV<L>& b) {  // hard_soft.rs:130-137, bendable.rs:210-230
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        if (a.v[i] < b.v[i]) return -1;
+        if (a.v[i] > b.v[i]) return 1;
+    }
+    return 0;
+}
+
+}  // namespace sf

@@ -1,0 +1,1072 @@
+// Hand-written HIP kernels (gfx950 / CDNA4, wave64) for the list-variable hot path:
+// seeded nearby candidate generation, per-candidate delta scoring, acceptor/forager replay
+// and move application, fused into ONE persistent kernel per launch (one workgroup = one
+// search replica whose routes, loads and candidate rings live in LDS for the whole launch).
+//
+// Reference semantics restated (paths under crates/solverforge-solver/src/ unless noted):
+//   heuristic/selector/list_kernel/nearby_change.rs:102-216   destination enumeration + top-k
+//   heuristic/selector/list_kernel/nearby_swap.rs:104-216
+//   heuristic/selector/nearby_list_support.rs:3-34            stable bounded top-k
+//   runtime/compiler/executor/list_leaf/cursor/slot.rs:468-499 entity order w/o replacement
+//   heuristic/selector/decorator/vec_union.rs:334-362          StratifiedRandom union (2 leaves)
+//   phase/localsearch/phase/step.rs:30-225, phase/candidates.rs:47-285, evaluation.rs:20-115
+//   phase/localsearch/forager.rs:70-250, acceptor/{hill_climbing,late_acceptance}.rs
+//   heuristic/move/list_kernel/{change,swap}.rs               move semantics
+//   crates/solverforge-cvrp/src/{problem_data,meters}.rs      distance_cost / MatrixDistanceMeter
+//
+// GPU formulation (not a translation): every candidate of a step is scored against the same
+// immutable step snapshot, so the reference's do/score/undo (4x retract+insert per entity per
+// constraint) becomes a stateless O(1) integer delta per candidate; integer addition is
+// associative, so cur + delta == the reference's incremental score bit for bit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sf_list_model.h"
+
+namespace sf {
+
+// ---------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_le(uint32_t lane) {
+    return lane == 63 ? ~0ULL : ((1ULL << (lane + 1)) - 1ULL);
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src);
+    hi = __shfl(hi, src);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int delta) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_up(lo, delta);
+    hi = __shfl_up(hi, delta);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane_id() >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// ProblemData::distance_cost (problem_data.rs:28-31,44-47)
+__device__ __forceinline__ int64_t dist_cost(const int64_t* __restrict__ mat, int32_t dim, uint32_t from,
+                                             uint32_t to) {
+    int64_t v = mat[(size_t)from * (size_t)dim + to];
+    return (v >= 0 && v != UNREACHABLE) ? v : MAX_SAFE_LEG_COST;
+}
+__device__ __forceinline__ int64_t over_cap(int64_t load, int64_t cap) {
+    int64_t o = wsub(load, cap);
+    return o > 0 ? o : 0;
+}
+
+// Trial score deltas of one list move against the step snapshot.  d_cap / d_dist are the
+// changes of the (positive) penalty sums of the capacity and distance constraints.
+struct ListDelta {
+    int64_t d_cap;
+    int64_t d_dist;
+    bool doable;
+};
+
+// ListChangeMove (a,i) -> (b,j), j in pre-removal coordinates (move/list_kernel/change.rs:28-34).
+__device__ __forceinline__ ListDelta eval_list_change(const ListModel& m, const uint32_t* visits,
+                                                      const uint32_t* off, const int64_t* load, uint32_t a,
+                                                      uint32_t i, uint32_t b, uint32_t j) {
+    ListDelta r{0, 0, true};
+    uint32_t oa = off[a], la = off[a + 1] - oa;
+    if (i >= la) {
+        r.doable = false;
+        return r;
+    }
+    uint32_t x = visits[oa + i];
+    bool intra = a == b;
+    uint32_t ob = off[b], lb = off[b + 1] - ob;
+    if (j > (intra ? la : lb) || (intra && (j == i || j == i + 1))) {
+        r.doable = false;
+        return r;
+    }
+    const uint32_t depot = (uint32_t)m.depot;
+    if (m.dist_level >= 0) {
+        uint32_t pa = i > 0 ? visits[oa + i - 1] : depot;
+        uint32_t na = i + 1 < la ? visits[oa + i + 1] : depot;
+        int64_t rem;
+        if (la == 1)
+            rem = -wadd(dist_cost(m.mat, m.dim, depot, x), dist_cost(m.mat, m.dim, x, depot));
+        else
+            rem = wsub(dist_cost(m.mat, m.dim, pa, na),
+                       wadd(dist_cost(m.mat, m.dim, pa, x), dist_cost(m.mat, m.dim, x, na)));
+        uint32_t pl, nr;
+        bool dst_empty;
+        if (!intra) {
+            pl = j > 0 ? visits[ob + j - 1] : depot;
+            nr = j < lb ? visits[ob + j] : depot;
+            dst_empty = lb == 0;
+        } else {
+            // sequence after removal s'[t] = t<i ? s[t] : s[t+1]; insert at jj
+            uint32_t jj = j > i ? j - 1 : j;
+            uint32_t l2 = la - 1;
+            auto at = [&](uint32_t t) { return visits[oa + (t < i ? t : t + 1)]; };
+            pl = jj > 0 ? at(jj - 1) : depot;
+            nr = jj < l2 ? at(jj) : depot;
+            dst_empty = false;
+        }
+        int64_t ins = wadd(dist_cost(m.mat, m.dim, pl, x), dist_cost(m.mat, m.dim, x, nr));
+        if (!dst_empty) ins = wsub(ins, dist_cost(m.mat, m.dim, pl, nr));
+        r.d_dist = wadd(rem, ins);
+    }
+    if (m.cap_level >= 0 && !intra) {
+        int64_t dx = (int64_t)m.demand[x];
+        int64_t la0 = load[a], lb0 = load[b];
+        int64_t before = wadd(over_cap(la0, m.capacity), over_cap(lb0, m.capacity));
+        int64_t after = wadd(over_cap(wsub(la0, dx), m.capacity), over_cap(wadd(lb0, dx), m.capacity));
+        r.d_cap = wsub(after, before);
+    }
+    return r;
+}
+
+// ListSwapMove (a,i) <-> (b,j) (move/list_kernel/swap.rs:30-110).
+__device__ __forceinline__ ListDelta eval_list_swap(const ListModel& m, const uint32_t* visits,
+                                                    const uint32_t* off, const int64_t* load, uint32_t a,
+                                                    uint32_t i, uint32_t b, uint32_t j) {
+    ListDelta r{0, 0, true};
+    uint32_t oa = off[a], la = off[a + 1] - oa;
+    uint32_t ob = off[b], lb = off[b + 1] - ob;
+    if (i >= la || j >= lb || (a == b && i == j)) {
+        r.doable = false;
+        return r;
+    }
+    uint32_t x = visits[oa + i], y = visits[ob + j];
+    if (x == y) {
+        r.doable = false;
+        return r;
+    }
+    const uint32_t depot = (uint32_t)m.depot;
+    if (m.dist_level >= 0) {
+        if (a == b) {
+            if (i > j) {  // normalise i < j (x stays the element at the lower position)
+                uint32_t t = i;
+                i = j;
+                j = t;
+                t = x;
+                x = y;
+                y = t;
+            }
+            uint32_t pa = i > 0 ? visits[oa + i - 1] : depot;
+            uint32_t nb = j + 1 < la ? visits[oa + j + 1] : depot;
+            if (j == i + 1) {
+                int64_t after = wadd(wadd(dist_cost(m.mat, m.dim, pa, y), dist_cost(m.mat, m.dim, y, x)),
+                                     dist_cost(m.mat, m.dim, x, nb));
+                int64_t before = wadd(wadd(dist_cost(m.mat, m.dim, pa, x), dist_cost(m.mat, m.dim, x, y)),
+                                      dist_cost(m.mat, m.dim, y, nb));
+                r.d_dist = wsub(after, before);
+            } else {
+                uint32_t na = visits[oa + i + 1];
+                uint32_t pb = visits[oa + j - 1];
+                int64_t da = wsub(wadd(dist_cost(m.mat, m.dim, pa, y), dist_cost(m.mat, m.dim, y, na)),
+                                  wadd(dist_cost(m.mat, m.dim, pa, x), dist_cost(m.mat, m.dim, x, na)));
+                int64_t db = wsub(wadd(dist_cost(m.mat, m.dim, pb, x), dist_cost(m.mat, m.dim, x, nb)),
+                                  wadd(dist_cost(m.mat, m.dim, pb, y), dist_cost(m.mat, m.dim, y, nb)));
+                r.d_dist = wadd(da, db);
+            }
+        } else {
+            uint32_t pa = i > 0 ? visits[oa + i - 1] : depot;
+            uint32_t na = i + 1 < la ? visits[oa + i + 1] : depot;
+            uint32_t pb = j > 0 ? visits[ob + j - 1] : depot;
+            uint32_t nb = j + 1 < lb ? visits[ob + j + 1] : depot;
+            int64_t da = wsub(wadd(dist_cost(m.mat, m.dim, pa, y), dist_cost(m.mat, m.dim, y, na)),
+                              wadd(dist_cost(m.mat, m.dim, pa, x), dist_cost(m.mat, m.dim, x, na)));
+            int64_t db = wsub(wadd(dist_cost(m.mat, m.dim, pb, x), dist_cost(m.mat, m.dim, x, nb)),
+                              wadd(dist_cost(m.mat, m.dim, pb, y), dist_cost(m.mat, m.dim, y, nb)));
+            r.d_dist = wadd(da, db);
+        }
+    }
+    if (m.cap_level >= 0 && a != b) {
+        int64_t dx = (int64_t)m.demand[x], dy = (int64_t)m.demand[y];
+        int64_t la0 = load[a], lb0 = load[b];
+        int64_t before = wadd(over_cap(la0, m.capacity), over_cap(lb0, m.capacity));
+        int64_t after = wadd(over_cap(wadd(wsub(la0, dx), dy), m.capacity),
+                             over_cap(wadd(wsub(lb0, dy), dx), m.capacity));
+        r.d_cap = wsub(after, before);
+    }
+    return r;
+}
+
+template <int L>
+__device__ __forceinline__ ScoreV<L> apply_delta(const ListModel& m, const int64_t* cur, const ListDelta& d) {
+    ScoreV<L> s;
+#pragma unroll
+    for (int k = 0; k < L; ++k) s.v[k] = cur[k];
+    // penalties: score level -= weight * delta(penalty sum)
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        if (k == m.cap_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.cap_weight * (uint64_t)d.d_cap));
+        if (k == m.dist_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.dist_weight * (uint64_t)d.d_dist));
+    }
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// evaluate_all / initialize: full recomputation from scratch (fresh_score; FullAssert)
+// grid = R blocks.  commit != 0 also (re)builds the per-route load aggregate + cached score.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_list_evaluate_all(ListModel m, int64_t* out_scores, int commit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* present = (uint32_t*)smem;  // bitmap over node ids
+    __shared__ unsigned long long s_cap, s_dist, s_missing;
+    const int r = blockIdx.x;
+    const uint32_t* visits = m.visits + (size_t)r * m.n_cap;
+    const uint32_t* off = m.off + (size_t)r * (m.V + 1);
+    int64_t* load = m.load + (size_t)r * m.V;
+    int words = (m.dim + 31) / 32;
+    for (int w = threadIdx.x; w < words; w += blockDim.x) present[w] = 0;
+    if (threadIdx.x == 0) {
+        s_cap = 0;
+        s_dist = 0;
+        s_missing = 0;
+    }
+    __syncthreads();
+    unsigned long long cap_sum = 0, dist_sum = 0;
+    for (int v = threadIdx.x; v < m.V; v += blockDim.x) {
+        uint32_t o = off[v], len = off[v + 1] - o;
+        int64_t ld = 0, ds = 0;
+        for (uint32_t p = 0; p < len; ++p) {
+            uint32_t x = visits[o + p];
+            atomicOr(&present[x >> 5], 1u << (x & 31));
+            if (m.demand) ld = wadd(ld, (int64_t)m.demand[x]);
+            if (m.dist_level >= 0) {
+                uint32_t prev = p > 0 ? visits[o + p - 1] : (uint32_t)m.depot;
+                ds = wadd(ds, dist_cost(m.mat, m.dim, prev, x));
+                if (p + 1 == len) ds = wadd(ds, dist_cost(m.mat, m.dim, x, (uint32_t)m.depot));
+            }
+        }
+        if (commit) load[v] = ld;
+        if (m.cap_level >= 0) cap_sum += (unsigned long long)over_cap(ld, m.capacity);
+        dist_sum += (unsigned long long)ds;
+    }
+    atomicAdd(&s_cap, cap_sum);
+    atomicAdd(&s_dist, dist_sum);
+    __syncthreads();
+    unsigned long long missing = 0;
+    if (m.ne_level >= 0)
+        for (int k = threadIdx.x; k < m.ne_n; k += blockDim.x) {
+            uint32_t key = m.ne_keys[k];
+            bool here = key < (uint32_t)m.dim && ((present[key >> 5] >> (key & 31)) & 1u);
+            missing += here ? 0 : 1;
+        }
+    atomicAdd(&s_missing, missing);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t sc[SF_MAX_LEVELS_CONST] = {0, 0, 0, 0};
+        if (m.ne_level >= 0) sc[m.ne_level] = wsub(sc[m.ne_level], (int64_t)((uint64_t)m.ne_weight * s_missing));
+        if (m.cap_level >= 0) sc[m.cap_level] = wsub(sc[m.cap_level], (int64_t)((uint64_t)m.cap_weight * s_cap));
+        if (m.dist_level >= 0) sc[m.dist_level] = wsub(sc[m.dist_level], (int64_t)((uint64_t)m.dist_weight * s_dist));
+        for (int k = 0; k < m.levels; ++k) {
+            if (out_scores) out_scores[(size_t)r * m.levels + k] = sc[k];
+            if (commit) m.score[(size_t)r * 4 + k] = sc[k];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// n x evaluate_candidate for host-provided moves (the ScalarCandidateProvider / MoveSelector
+// plugin surface): one thread per move against replica `replica`, state unchanged.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int replica, const int32_t* moves,
+                                                             int64_t n, int64_t* out_scores,
+                                                             int32_t* out_doable) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
+    const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
+    const int64_t* load = m.load + (size_t)replica * m.V;
+    const int64_t* cur = m.score + (size_t)replica * 4;
+    const int32_t* mv = moves + t * 6;
+    int32_t kind = mv[0];
+    ListDelta d{0, 0, false};
+    bool in_range = mv[1] >= 0 && mv[1] < m.V && mv[3] >= 0 && mv[3] < m.V && mv[2] >= 0 && mv[4] >= 0;
+    if (in_range) {
+        if (kind == 2)
+            d = eval_list_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);
+        else if (kind == 3)
+            d = eval_list_swap(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);
+    }
+    out_doable[t] = d.doable ? 1 : 0;
+    ScoreV<4> s = apply_delta<4>(m, cur, d);
+    for (int k = 0; k < m.levels; ++k) out_scores[t * m.levels + k] = d.doable ? s.v[k] : 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Committed move application on global state (sf_apply): one block per call.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32_t* visits, uint32_t* off,
+                                                      int64_t* load, int kind, uint32_t a, uint32_t i,
+                                                      uint32_t b, uint32_t j) {
+    // all threads of the block call this; contains __syncthreads
+    const uint32_t total = off[m.V];
+    if (kind == 2) {
+        uint32_t P = off[a] + i, Q = off[b] + j;
+        uint32_t x = visits[P];
+        __syncthreads();
+        // gather old values for the range this thread rewrites
+        for (uint32_t base = 0; base < total; base += blockDim.x) {
+            uint32_t t = base + threadIdx.x;
+            uint32_t nv = 0;
+            bool wr = false;
+            if (t < total) {
+                if (P < Q) {
+                    if (t >= P && t + 1 < Q) {
+                        nv = visits[t + 1];
+                        wr = true;
+                    } else if (t + 1 == Q) {
+                        nv = x;
+                        wr = true;
+                    }
+                } else if (P > Q) {
+                    if (t > Q && t <= P) {
+                        nv = visits[t - 1];
+                        wr = true;
+                    } else if (t == Q) {
+                        nv = x;
+                        wr = true;
+                    }
+                }
+            }
+            __syncthreads();
+            if (wr) visits[t] = nv;
+            __syncthreads();
+        }
+        if (a != b) {
+            for (uint32_t rr = threadIdx.x; rr <= (uint32_t)m.V; rr += blockDim.x) {
+                if (a < b && rr > a && rr <= b) off[rr] -= 1;
+                if (a > b && rr > b && rr <= a) off[rr] += 1;
+            }
+            if (threadIdx.x == 0 && m.demand) {
+                int64_t dx = (int64_t)m.demand[x];
+                load[a] = wsub(load[a], dx);
+                load[b] = wadd(load[b], dx);
+            }
+        }
+    } else if (kind == 3) {
+        if (threadIdx.x == 0) {
+            uint32_t pa = off[a] + i, pb = off[b] + j;
+            uint32_t x = visits[pa], y = visits[pb];
+            visits[pa] = y;
+            visits[pb] = x;
+            if (a != b && m.demand) {
+                int64_t dx = (int64_t)m.demand[x], dy = (int64_t)m.demand[y];
+                load[a] = wadd(wsub(load[a], dx), dy);
+                load[b] = wadd(wsub(load[b], dy), dx);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, int kind, uint32_t a, uint32_t i,
+                                                    uint32_t b, uint32_t j, int32_t* out_ok) {
+    uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
+    uint32_t* off = m.off + (size_t)replica * (m.V + 1);
+    int64_t* load = m.load + (size_t)replica * m.V;
+    int64_t* cur = m.score + (size_t)replica * 4;
+    __shared__ ListDelta s_d;
+    if (threadIdx.x == 0) {
+        s_d = kind == 2 ? eval_list_change(m, visits, off, load, a, i, b, j)
+                        : eval_list_swap(m, visits, off, load, a, i, b, j);
+    }
+    __syncthreads();
+    ListDelta d = s_d;
+    if (!d.doable) {
+        if (threadIdx.x == 0) *out_ok = 0;
+        return;
+    }
+    apply_list_move_block(m, visits, off, load, kind, a, i, b, j);
+    if (threadIdx.x == 0) {
+        ScoreV<4> s = apply_delta<4>(m, cur, d);
+        for (int k = 0; k < 4; ++k) cur[k] = s.v[k];
+        *out_ok = 1;
+    }
+}
+
+// phase start: last_step_score = score; LA history filled; best = working (phase.rs:250-261)
+__global__ __launch_bounds__(256) void k_list_phase_start(ListModel m, SearchParams p) {
+    const int r = blockIdx.x;
+    const int64_t* cur = m.score + (size_t)r * 4;
+    for (int k = threadIdx.x; k < 4; k += blockDim.x) {
+        p.last_step_score[(size_t)r * 4 + k] = cur[k];
+        m.best_score[(size_t)r * 4 + k] = cur[k];
+    }
+    for (int h = threadIdx.x; h < p.la_size * 4; h += blockDim.x)
+        p.la_hist[(size_t)r * p.la_size * 4 + h] = cur[h & 3];
+    for (int t = threadIdx.x; t < m.n_cap; t += blockDim.x)
+        m.best_visits[(size_t)r * m.n_cap + t] = m.visits[(size_t)r * m.n_cap + t];
+    for (int t = threadIdx.x; t <= m.V; t += blockDim.x)
+        m.best_off[(size_t)r * (m.V + 1) + t] = m.off[(size_t)r * (m.V + 1) + t];
+    if (threadIdx.x == 0) {
+        p.la_idx[r] = 0;
+        p.step_index[r] = 0;
+        p.has_best[r] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The fused persistent search kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int MAXW = 16;  // waves per workgroup (1024 threads)
+
+template <int L>
+struct Ctl {
+    uint64_t step_index, step_seed;
+    int64_t cur[L], late[L], best[L], best_sol[L];
+    uint32_t best_m0, best_m1;
+    int32_t best_kind, has_best;
+    uint64_t equal_count;
+    uint32_t accepted;
+    uint32_t head[MAX_LEAVES], tail[MAX_LEAVES], src_next[MAX_LEAVES], src_total[MAX_LEAVES];
+    uint32_t perm_start[MAX_LEAVES], perm_stride[MAX_LEAVES];
+    int32_t gen_done[MAX_LEAVES], exhausted[MAX_LEAVES];
+    uint32_t pulls;
+    int32_t first_leaf;
+    int32_t done;
+    int32_t wave_leaf[MAXW];
+    uint32_t wave_src[MAXW], wave_cnt[MAXW];
+    uint64_t st[8];
+    uint64_t trace_n;
+};
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// LDS carve (bytes); mirrored by list_search_lds_bytes() on the host.
+template <int L>
+struct Carve {
+    size_t ctl, load, qscore, visits, off, node, qmove, slotbase, routeat, rankof, total;
+    __host__ __device__ Carve(int V, int n_cap, int dim) {
+        size_t o = 0;
+        ctl = o;
+        o = align_up(o + sizeof(Ctl<L>), 16);
+        load = o;
+        o = align_up(o + sizeof(int64_t) * V, 16);
+        qscore = o;
+        o = align_up(o + sizeof(int64_t) * L * QCAP * MAX_LEAVES, 16);
+        visits = o;
+        o = align_up(o + sizeof(uint32_t) * n_cap, 16);
+        off = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        node = o;
+        o = align_up(o + sizeof(uint32_t) * dim, 16);
+        qmove = o;
+        o = align_up(o + sizeof(uint32_t) * 2 * QCAP * MAX_LEAVES, 16);
+        slotbase = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1) * MAX_LEAVES, 16);
+        routeat = o;
+        o = align_up(o + sizeof(uint32_t) * V * MAX_LEAVES, 16);
+        rankof = o;
+        o = align_up(o + sizeof(uint32_t) * V * MAX_LEAVES, 16);
+        total = o;
+    }
+};
+
+template <int L>
+__device__ __forceinline__ ScoreV<L> wave_max_score(ScoreV<L> s, bool valid) {
+    // lexicographic max across the wave; invalid lanes contribute -inf
+    if (!valid) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) s.v[k] = INT64_MIN;
+    }
+#pragma unroll
+    for (int mlane = 32; mlane >= 1; mlane >>= 1) {
+        ScoreV<L> o;
+#pragma unroll
+        for (int k = 0; k < L; ++k) o.v[k] = (int64_t)shfl_xor_u64((uint64_t)s.v[k], mlane);
+        if (score_cmp<L>(o, s) > 0) s = o;
+    }
+    return s;
+}
+
+// Sorted top-K list held one entry per lane (lane i = i-th smallest key).
+struct TopK {
+    uint64_t key;
+    uint32_t pay;
+    uint64_t kth;  // wave-uniform current K-th key (threshold)
+};
+
+__device__ __forceinline__ void topk_insert(TopK& t, uint32_t K, uint64_t bk, uint32_t bp) {
+    const uint32_t lane = lane_id();
+    uint32_t pos = (uint32_t)__popcll(__ballot(lane < K && t.key < bk));
+    if (pos < K) {
+        uint64_t upk = shfl_up_u64(t.key, 1);
+        uint32_t upp = __shfl_up(t.pay, 1);
+        if (lane > pos && lane < K) {
+            t.key = upk;
+            t.pay = upp;
+        }
+        if (lane == pos) {
+            t.key = bk;
+            t.pay = bp;
+        }
+        t.kth = shfl_u64(t.key, (int)K - 1);
+    }
+}
+
+__device__ __forceinline__ void topk_offer(TopK& t, uint32_t K, uint64_t key, uint32_t pay) {
+    uint64_t mask = __ballot(key < t.kth);
+    while (mask) {
+        int j = __ffsll((unsigned long long)mask) - 1;
+        mask &= mask - 1;
+        uint64_t bk = shfl_u64(key, j);
+        uint32_t bp = __shfl(pay, j);
+        if (bk < t.kth) topk_insert(t, K, bk, bp);
+    }
+}
+
+template <int L, bool TRACE>
+__global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Carve<L> cv(m.V, m.n_cap, m.dim);
+    Ctl<L>& c = *(Ctl<L>*)(smem + cv.ctl);
+    int64_t* s_load = (int64_t*)(smem + cv.load);
+    int64_t* q_score = (int64_t*)(smem + cv.qscore);
+    uint32_t* s_visits = (uint32_t*)(smem + cv.visits);
+    uint32_t* s_off = (uint32_t*)(smem + cv.off);
+    uint32_t* node_slot = (uint32_t*)(smem + cv.node);
+    uint32_t* q_move = (uint32_t*)(smem + cv.qmove);
+    uint32_t* slot_base = (uint32_t*)(smem + cv.slotbase);
+    uint32_t* route_at = (uint32_t*)(smem + cv.routeat);
+    uint32_t* rank_of = (uint32_t*)(smem + cv.rankof);
+
+    const int r = blockIdx.x + p.replica_base;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t NW = blockDim.x >> 6;
+    const int V = m.V;
+    uint32_t* g_visits = m.visits + (size_t)r * m.n_cap;
+    uint32_t* g_off = m.off + (size_t)r * (V + 1);
+    int64_t* g_load = m.load + (size_t)r * V;
+    int64_t* g_score = m.score + (size_t)r * 4;
+    const bool tracing = TRACE && r == p.trace_replica;
+
+    // ---- load replica state into LDS ----
+    for (uint32_t t = tid; t <= (uint32_t)V; t += blockDim.x) s_off[t] = g_off[t];
+    for (uint32_t t = tid; t < (uint32_t)V; t += blockDim.x) s_load[t] = g_load[t];
+    for (uint32_t t = tid; t < (uint32_t)m.dim; t += blockDim.x) node_slot[t] = NODE_NONE;
+    __syncthreads();
+    const uint32_t total0 = s_off[V];
+    for (uint32_t t = tid; t < total0; t += blockDim.x) s_visits[t] = g_visits[t];
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            c.cur[k] = g_score[k];
+            c.best_sol[k] = m.best_score[(size_t)r * 4 + k];
+        }
+        for (int k = 0; k < 8; ++k) c.st[k] = 0;
+        c.trace_n = 0;
+    }
+    __syncthreads();
+    for (uint32_t v = tid; v < (uint32_t)V; v += blockDim.x) {
+        uint32_t o = s_off[v], len = s_off[v + 1] - o;
+        for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
+    }
+    __syncthreads();
+
+    for (int64_t step = 0; step < p.n_steps; ++step) {
+        // ---- (A) step start ------------------------------------------------------------
+        if (tid == 0) {
+            uint64_t sidx, sseed;
+            if (p.dry_run) {
+                sidx = p.dry_step_index;
+                sseed = p.dry_step_seed;
+            } else {
+                sidx = p.step_index[r] + (uint64_t)step;
+                uint64_t draw = p.seed_draws[r] + (uint64_t)step;
+                if (p.explicit_seeds && (int64_t)draw < p.n_explicit)
+                    sseed = p.explicit_seeds[(size_t)r * p.n_explicit + draw];
+                else
+                    sseed = step_seed(p.random_seed + (uint64_t)r, draw);
+            }
+            c.step_index = sidx;
+            c.step_seed = sseed;
+            StreamCtx ctx{sidx, sseed, p.order};
+            if (p.acceptor == 1) {
+                int idx = p.dry_run ? 0 : (int)((p.la_idx[r] + step) % p.la_size);
+#pragma unroll
+                for (int k = 0; k < L; ++k) c.late[k] = p.la_hist[((size_t)r * p.la_size + idx) * 4 + k];
+            }
+            c.has_best = 0;
+            c.equal_count = 0;
+            c.accepted = 0;
+            c.pulls = 0;
+            c.done = 0;
+            for (int l = 0; l < p.n_leaves; ++l) {
+                uint64_t ent_salt = (p.leaf[l].kind == 16 ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^
+                                    (uint64_t)p.leaf[l].descriptor;
+                uint32_t st, sd;
+                ctx.perm_params((uint32_t)V, ent_salt, st, sd);
+                c.perm_start[l] = st;
+                c.perm_stride[l] = sd;
+                c.head[l] = c.tail[l] = 0;
+                c.src_next[l] = 0;
+                c.src_total[l] = s_off[V];
+                c.gen_done[l] = s_off[V] == 0;
+                c.exhausted[l] = 0;
+            }
+            // union: >1 leaf => StratifiedRandom, equal weights (vec_union.rs:229-245); with two
+            // children the stride is always 1, so the order is first, other, first, ...
+            c.first_leaf = p.n_leaves > 1 ? (int32_t)ctx.random_index((uint32_t)p.n_leaves, SALT_UNION_OFFSET) : 0;
+        }
+        __syncthreads();
+        // ---- (B) per-leaf entity order tables -------------------------------------------
+        for (int l = 0; l < p.n_leaves; ++l) {
+            for (uint32_t k = tid; k < (uint32_t)V; k += blockDim.x) {
+                uint32_t e = (uint32_t)(((uint64_t)c.perm_start[l] + (uint64_t)k * c.perm_stride[l]) % (uint32_t)V);
+                route_at[l * V + k] = e;
+                rank_of[l * V + e] = k;
+            }
+        }
+        __syncthreads();
+        if (wave < (uint32_t)p.n_leaves) {  // slot_base[k] = sum_{k'<k} (len(route_at[k'])+1)
+            const int l = wave;
+            uint32_t carry = 0;
+            for (uint32_t base = 0; base < (uint32_t)V; base += 64) {
+                uint32_t k = base + lane;
+                uint32_t v = 0;
+                if (k < (uint32_t)V) {
+                    uint32_t e = route_at[l * V + k];
+                    v = s_off[e + 1] - s_off[e] + 1;
+                }
+                uint32_t inc = wave_incl_scan(v);
+                if (k < (uint32_t)V) slot_base[l * (V + 1) + k] = carry + inc - v;
+                carry += __shfl(inc, 63);
+            }
+            if (lane == 0) slot_base[l * (V + 1) + V] = carry;
+        }
+        __syncthreads();
+
+        // ---- (C) candidate rounds ------------------------------------------------------
+        for (;;) {
+            // C1: wave -> (leaf, source) assignment by one lane
+            if (tid == 0) {
+                uint32_t assigned[MAX_LEAVES] = {0, 0};
+                for (uint32_t w = 0; w < NW; ++w) {
+                    int pick = -1;
+                    uint32_t pick_pending = 0xFFFFFFFFu;
+                    for (int l = 0; l < p.n_leaves; ++l) {
+                        if (c.gen_done[l]) continue;
+                        uint32_t K = (uint32_t)p.leaf[l].max_nearby;
+                        uint32_t pending = (c.tail[l] - c.head[l]) + assigned[l] * K;
+                        if (pending + K > QCAP) continue;
+                        if (pending < pick_pending) {
+                            pick = l;
+                            pick_pending = pending;
+                        }
+                    }
+                    c.wave_leaf[w] = pick;
+                    c.wave_cnt[w] = 0;
+                    if (pick >= 0) {
+                        c.wave_src[w] = c.src_next[pick]++;
+                        assigned[pick]++;
+                        if (c.src_next[pick] >= c.src_total[pick]) c.gen_done[pick] = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            // C2: per-wave source scan + stable top-k
+            const int wl = c.wave_leaf[wave];
+            TopK tk{~0ULL, 0u, ~0ULL};
+            uint32_t K = 0, cnt = 0, se = 0, sp = 0, sx = 0;
+            bool is_change = false;
+            if (wl >= 0) {
+                const int l = wl;
+                K = (uint32_t)p.leaf[l].max_nearby;
+                is_change = p.leaf[l].kind == 16;
+                const uint32_t s = c.wave_src[wave];
+                const uint32_t* sb = slot_base + l * (V + 1);
+                // rank k with src_base[k] <= s < src_base[k+1], src_base[k] = slot_base[k] - k
+                uint32_t lo = 0, hi = (uint32_t)V;  // invariant: src_base[lo] <= s < src_base[hi]
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (sb[mid] - mid <= s)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint32_t k = lo;
+                se = route_at[l * V + k];
+                const uint32_t len = s_off[se + 1] - s_off[se];
+                const uint32_t o = s - (sb[k] - k);
+                StreamCtx ctx{c.step_index, c.step_seed, p.order};
+                const uint64_t src_salt = (is_change ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^
+                                          (uint64_t)se ^ (uint64_t)p.leaf[l].descriptor;
+                sp = ctx.selection_index(o, len, src_salt);
+                sx = s_visits[s_off[se] + sp];
+                const int64_t* row = m.mat + (size_t)sx * (size_t)m.dim;
+                for (uint32_t base = 0; base < (uint32_t)m.dim; base += 64) {
+                    const uint32_t y = base + lane;
+                    uint64_t key0 = ~0ULL, key1 = ~0ULL;
+                    uint32_t pay0 = 0, pay1 = 0;
+                    if (y < (uint32_t)m.dim) {
+                        const uint32_t slot = node_slot[y];
+                        if (slot != NODE_NONE) {
+                            const uint32_t r2 = slot >> 16, dp = slot & 0xFFFFu;
+                            const int64_t v = row[y];
+                            if (v >= 0 && v != UNREACHABLE) {  // finite_distance (problem_data.rs:44-47)
+                                const uint64_t hi_key = (uint64_t)v << 24;
+                                if (is_change) {
+                                    if (r2 == se) {
+                                        if (dp != sp && dp != sp + 1) {
+                                            key0 = hi_key | dp;
+                                            pay0 = slot;
+                                        }
+                                        if (dp + 1 == len && len != sp + 1) {  // end slot dp2 = len
+                                            key1 = hi_key | len;
+                                            pay1 = (r2 << 16) | len;
+                                        }
+                                    } else {
+                                        const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
+                                        const uint32_t ord = ORD_INTER_BASE + sb[rank_of[l * V + r2]] + dp;
+                                        key0 = hi_key | ord;
+                                        pay0 = slot;
+                                        if (dp + 1 == len2) {
+                                            key1 = hi_key | (ord + 1);
+                                            pay1 = (r2 << 16) | len2;
+                                        }
+                                    }
+                                } else {
+                                    if (r2 == se) {
+                                        if (dp > sp) {
+                                            key0 = hi_key | dp;
+                                            pay0 = slot;
+                                        }
+                                    } else if (rank_of[l * V + r2] > k) {
+                                        key0 = hi_key | (ORD_INTER_BASE + sb[rank_of[l * V + r2]] + dp);
+                                        pay0 = slot;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    topk_offer(tk, K, key0, pay0);
+                    if (is_change) topk_offer(tk, K, key1, pay1);
+                }
+                cnt = (uint32_t)__popcll(__ballot(lane < K && tk.key != ~0ULL));
+                if (lane == 0) c.wave_cnt[wave] = cnt;
+            }
+            __syncthreads();
+            // C3: trial-score the kept candidates and append them to the leaf ring in source order
+            if (wl >= 0 && cnt > 0) {
+                uint32_t offq = c.tail[wl];
+                for (uint32_t w2 = 0; w2 < wave; ++w2)
+                    if (c.wave_leaf[w2] == wl) offq += c.wave_cnt[w2];
+                if (lane < cnt) {
+                    const uint32_t r2 = tk.pay >> 16, dp = tk.pay & 0xFFFFu;
+                    ListDelta d = is_change ? eval_list_change(m, s_visits, s_off, s_load, se, sp, r2, dp)
+                                            : eval_list_swap(m, s_visits, s_off, s_load, se, sp, r2, dp);
+                    ScoreV<L> sc = apply_delta<L>(m, c.cur, d);
+                    const uint32_t qi = (offq + lane) & (QCAP - 1);
+                    uint32_t* qm = q_move + ((size_t)wl * QCAP + qi) * 2;
+                    qm[0] = (se << 16) | sp | (d.doable ? 0u : 0x80000000u);
+                    qm[1] = tk.pay;
+                    int64_t* qs = q_score + ((size_t)wl * QCAP + qi) * L;
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) qs[kk] = sc.v[kk];
+                }
+            }
+            __syncthreads();
+            // C4: union replay by wave 0 (acceptor + forager in cursor order)
+            if (wave == 0) {
+                if (lane == 0) {
+                    uint64_t scored = 0;
+                    for (uint32_t w2 = 0; w2 < NW; ++w2)
+                        if (c.wave_leaf[w2] >= 0) {
+                            c.tail[c.wave_leaf[w2]] += c.wave_cnt[w2];
+                            scored += c.wave_cnt[w2];
+                        }
+                    c.st[7] += scored;
+                }
+                __builtin_amdgcn_wave_barrier();
+                // wave-uniform replay state kept in registers
+                uint32_t head0 = c.head[0], head1 = c.head[1];
+                const uint32_t tail0 = c.tail[0], tail1 = c.tail[1];
+                int ex0 = c.exhausted[0], ex1 = p.n_leaves > 1 ? c.exhausted[1] : 1;
+                const int gd0 = c.gen_done[0], gd1 = p.n_leaves > 1 ? c.gen_done[1] : 1;
+                uint32_t pulls = c.pulls, accepted = c.accepted;
+                int has_best = c.has_best;
+                uint64_t equal_count = c.equal_count;
+                ScoreV<L> best, cur, late;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    best.v[kk] = c.best[kk];
+                    cur.v[kk] = c.cur[kk];
+                    late.v[kk] = c.late[kk];
+                }
+                uint32_t best_m0 = c.best_m0, best_m1 = c.best_m1;
+                int best_kind = c.best_kind;
+                uint64_t st_gen = 0, st_acc = 0, st_calc = 0, st_nd = 0;
+                int done = 0;
+                for (;;) {
+                    const bool live0 = !ex0, live1 = !ex1;
+                    if (!live0 && !live1) {
+                        done = 1;
+                        break;
+                    }
+                    uint32_t lf, idx;
+                    if (live0 && live1) {
+                        const uint32_t l0 = ((uint32_t)c.first_leaf + pulls) & 1u;
+                        lf = (l0 + lane) & 1u;
+                        idx = (lf ? head1 : head0) + (lane >> 1);
+                    } else {
+                        lf = live0 ? 0u : 1u;
+                        idx = (lf ? head1 : head0) + lane;
+                    }
+                    const bool avail = idx < (lf ? tail1 : tail0);
+                    const uint64_t availmask = __ballot(avail);
+                    const uint32_t nvalid = availmask == ~0ULL ? 64u : (uint32_t)(__ffsll((unsigned long long)~availmask) - 1);
+                    if (nvalid == 0) {
+                        const uint32_t lf0 = __shfl(lf, 0);
+                        const int gd = lf0 ? gd1 : gd0;
+                        if (gd) {  // the scheduler discovers the exhausted child at this pull
+                            if (lf0)
+                                ex1 = 1;
+                            else
+                                ex0 = 1;
+                            continue;
+                        }
+                        break;  // need another generation round
+                    }
+                    const bool valid = lane < nvalid;
+                    uint32_t m0 = 0, m1 = 0;
+                    ScoreV<L> sc;
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) sc.v[kk] = 0;
+                    if (valid) {
+                        const uint32_t qi = idx & (QCAP - 1);
+                        const uint32_t* qm = q_move + ((size_t)lf * QCAP + qi) * 2;
+                        m0 = qm[0];
+                        m1 = qm[1];
+                        const int64_t* qs = q_score + ((size_t)lf * QCAP + qi) * L;
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) sc.v[kk] = qs[kk];
+                    }
+                    const bool doable = valid && !(m0 & 0x80000000u);
+                    bool acc = false;
+                    if (doable) {
+                        if (p.acceptor == 0)
+                            acc = score_cmp<L>(sc, cur) > 0;
+                        else if (p.acceptor == 1)
+                            acc = score_cmp<L>(sc, cur) >= 0 || score_cmp<L>(sc, late) >= 0;
+                    }
+                    uint64_t accmask = __ballot(acc);
+                    uint32_t nconsumed = nvalid;
+                    if (p.forager != 2) {
+                        const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
+                        const uint32_t pre = (uint32_t)__popcll(accmask & lanemask_le(lane));
+                        const uint64_t cutmask = __ballot(acc && pre == remaining);
+                        if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
+                    }
+                    const bool consumed = lane < nconsumed;
+                    acc = acc && consumed;
+                    accmask = __ballot(acc);
+                    if (accmask) {
+                        if (p.forager == 1) {
+                            if (!has_best) {
+                                const int sel = __ffsll((unsigned long long)accmask) - 1;
+#pragma unroll
+                                for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)shfl_u64((uint64_t)sc.v[kk], sel);
+                                best_m0 = __shfl(m0, sel);
+                                best_m1 = __shfl(m1, sel);
+                                best_kind = (int)__shfl(lf, sel);
+                                has_best = 1;
+                            }
+                        } else {
+                            const ScoreV<L> M = wave_max_score<L>(sc, acc);
+                            const int cm = has_best ? score_cmp<L>(M, best) : 1;
+                            if (cm >= 0) {
+                                const bool newmax = cm > 0;
+                                const uint64_t base = newmax ? 0 : equal_count;
+                                const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
+                                const uint64_t eq = __ballot(in_eq);
+                                const uint32_t rank = (uint32_t)__popcll(eq & lanemask_le(lane));
+                                const uint64_t cntq = base + rank;
+                                const bool pick = in_eq && ((newmax && rank == 1) ||
+                                                            (p.random_ties && cntq > 1 && reservoir_pick(c.step_seed, cntq)));
+                                const uint64_t pm = __ballot(pick);
+                                if (pm) {
+                                    const int sel = 63 - __clzll((unsigned long long)pm);
+                                    best_m0 = __shfl(m0, sel);
+                                    best_m1 = __shfl(m1, sel);
+                                    best_kind = (int)__shfl(lf, sel);
+                                }
+                                best = M;
+                                equal_count = base + (uint64_t)__popcll(eq);
+                                has_best = 1;
+                            }
+                        }
+                    }
+                    const uint32_t nacc = (uint32_t)__popcll(accmask);
+                    accepted += nacc;
+                    st_gen += nconsumed;
+                    st_acc += nacc;
+                    const uint32_t ndo = (uint32_t)__popcll(__ballot(consumed && doable));
+                    st_calc += ndo;
+                    st_nd += nconsumed - ndo;
+                    if (tracing && consumed) {
+                        const uint64_t ti = c.trace_n + lane;
+                        if ((int64_t)ti < p.trace_cap) {
+                            int32_t* tm = p.trace_moves + ti * 6;
+                            tm[0] = p.leaf[lf].kind == 16 ? 2 : 3;
+                            tm[1] = (int32_t)((m0 & 0x7FFFFFFFu) >> 16);
+                            tm[2] = (int32_t)(m0 & 0xFFFFu);
+                            tm[3] = (int32_t)(m1 >> 16);
+                            tm[4] = (int32_t)(m1 & 0xFFFFu);
+                            tm[5] = -1;
+                            for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
+                            p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                        }
+                    }
+                    if (tracing) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) c.trace_n += nconsumed;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    const uint32_t c1 = (uint32_t)__popcll(__ballot(consumed && lf == 1u));
+                    head1 += c1;
+                    head0 += nconsumed - c1;
+                    pulls += nconsumed;
+                    if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) {
+                        done = 1;
+                        break;
+                    }
+                }
+                if (lane == 0) {
+                    c.head[0] = head0;
+                    c.head[1] = head1;
+                    c.exhausted[0] = ex0;
+                    if (p.n_leaves > 1) c.exhausted[1] = ex1;
+                    c.pulls = pulls;
+                    c.accepted = accepted;
+                    c.has_best = has_best;
+                    c.equal_count = equal_count;
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) c.best[kk] = best.v[kk];
+                    c.best_m0 = best_m0;
+                    c.best_m1 = best_m1;
+                    c.best_kind = best_kind;
+                    c.st[1] += st_gen;
+                    c.st[2] += st_gen;
+                    c.st[3] += st_acc;
+                    c.st[5] += st_calc;
+                    c.st[6] += st_nd;
+                    c.done = done;
+                }
+            }
+            __syncthreads();
+            if (c.done) break;
+        }
+
+        // ---- (D) commit the forager's pick ----------------------------------------------
+        const bool applied = c.has_best && !p.dry_run;
+        if (applied) {
+            const int kind = p.leaf[c.best_kind].kind == 16 ? 2 : 3;
+            const uint32_t a = (c.best_m0 & 0x7FFFFFFFu) >> 16, i = c.best_m0 & 0xFFFFu;
+            const uint32_t b = c.best_m1 >> 16, j = c.best_m1 & 0xFFFFu;
+            if (tracing && tid == 0) {
+                p.trace_applied[0] = 1;
+                p.trace_applied[1] = kind;
+                p.trace_applied[2] = (int32_t)a;
+                p.trace_applied[3] = (int32_t)i;
+                p.trace_applied[4] = (int32_t)b;
+                p.trace_applied[5] = (int32_t)j;
+                p.trace_applied[6] = -1;
+            }
+            apply_list_move_block(m, s_visits, s_off, s_load, kind, a, i, b, j);
+            // refresh node -> (route, position) for the two touched routes
+            {
+                const uint32_t oa = s_off[a], la = s_off[a + 1] - oa;
+                const uint32_t ob = s_off[b], lb = s_off[b + 1] - ob;
+                for (uint32_t t = tid; t < la + (a != b ? lb : 0u); t += blockDim.x) {
+                    if (t < la)
+                        node_slot[s_visits[oa + t]] = (a << 16) | t;
+                    else
+                        node_slot[s_visits[ob + (t - la)]] = (b << 16) | (t - la);
+                }
+            }
+            if (tid == 0) {
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) c.cur[kk] = c.best[kk];
+                c.st[4] += 1;
+            }
+            __syncthreads();
+        } else if (tracing && tid == 0) {
+            p.trace_applied[0] = 0;
+        }
+        if (!p.dry_run) {
+            // update_best_solution (scope_progress.rs:89-107): clone on strict improvement
+            bool improved = false;
+            if (applied) {
+                ScoreV<L> cs, bs;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    cs.v[kk] = c.cur[kk];
+                    bs.v[kk] = c.best_sol[kk];
+                }
+                improved = score_cmp<L>(cs, bs) > 0;
+            }
+            __syncthreads();
+            if (improved) {
+                const uint32_t total = s_off[V];
+                for (uint32_t t = tid; t < total; t += blockDim.x) m.best_visits[(size_t)r * m.n_cap + t] = s_visits[t];
+                for (uint32_t t = tid; t <= (uint32_t)V; t += blockDim.x) m.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+            }
+            __syncthreads();
+            if (improved && tid == 0) {
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    c.best_sol[kk] = c.cur[kk];
+                    m.best_score[(size_t)r * 4 + kk] = c.cur[kk];
+                }
+            }
+            if (tid == 0) {
+                // acceptor.step_ended(last_step_score) always (step.rs:216-221)
+                if (p.acceptor == 1) {
+                    const int idx = (int)((p.la_idx[r] + step) % p.la_size);
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + idx) * 4 + kk] = c.cur[kk];
+                }
+                c.st[0] += 1;
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- write back ------------------------------------------------------------------
+    if (!p.dry_run) {
+        const uint32_t total = s_off[V];
+        for (uint32_t t = tid; t < total; t += blockDim.x) g_visits[t] = s_visits[t];
+        for (uint32_t t = tid; t <= (uint32_t)V; t += blockDim.x) g_off[t] = s_off[t];
+        for (uint32_t t = tid; t < (uint32_t)V; t += blockDim.x) g_load[t] = s_load[t];
+        if (tid == 0) {
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) {
+                g_score[kk] = c.cur[kk];
+                p.last_step_score[(size_t)r * 4 + kk] = c.cur[kk];
+            }
+            p.la_idx[r] = (int32_t)((p.la_idx[r] + p.n_steps) % p.la_size);
+            p.step_index[r] += (uint64_t)p.n_steps;
+            p.seed_draws[r] += (uint64_t)p.n_steps;
+        }
+    }
+    if (tid == 0) {
+        if (!p.dry_run)
+            for (int k = 0; k < 8; ++k) p.stats[(size_t)r * 8 + k] += c.st[k];
+        if (tracing) *p.trace_count = (int64_t)c.trace_n;
+    }
+}
+
+}  // namespace sf

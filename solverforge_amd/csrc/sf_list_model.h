@@ -1,0 +1,84 @@
+// Device-side parameter blocks of the list-variable (CVRP-shaped) hot path.
+#pragma once
+#include <stdint.h>
+
+#include "sf_common.h"
+
+namespace sf {
+
+constexpr int SF_MAX_LEVELS_CONST = 4;
+constexpr int MAX_LEAVES = 2;        // fused kernel: up to two list leaves in one union
+constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
+constexpr uint32_t QCAP = 1024;      // per-leaf candidate ring capacity (power of two)
+constexpr uint32_t ORD_INTER_BASE = 1u << 20;
+constexpr int64_t MAX_PACKED_DISTANCE = (int64_t)1 << 40;  // (distance << 24 | ordinal) key packing
+
+// Immutable problem facts + constraint wiring + per-replica state base pointers (SoA in HBM).
+struct ListModel {
+    int32_t V;          // list owners (routes)
+    int32_t n_cap;      // element capacity of the flat visits array (stride per replica)
+    int32_t dim;        // node-id bound (= matrix dimension when a matrix is attached)
+    int32_t levels;     // score levels
+    // facts
+    const int64_t* mat; // dim x dim row-major (MatrixDistanceMeter + distance constraint)
+    const int32_t* demand;
+    const uint32_t* ne_keys;  // not-exists A-side keys (Customer.id)
+    int32_t ne_n;
+    int32_t depot;
+    int64_t capacity;
+    // constraints: level < 0 = absent
+    int32_t cap_level, dist_level, ne_level;
+    int64_t cap_weight, dist_weight, ne_weight;
+    // per-replica committed state
+    uint32_t* visits;  // [R][n_cap]  flat CSR values, owner-major
+    uint32_t* off;     // [R][V+1]
+    int64_t* load;     // [R][V]      per-route demand sum (capacity aggregate)
+    int64_t* score;    // [R][SF_MAX_LEVELS] committed (cached) score
+    uint32_t* best_visits;  // [R][n_cap]
+    uint32_t* best_off;     // [R][V+1]
+    int64_t* best_score;    // [R][4]
+};
+
+struct LeafSpec {
+    int32_t kind;        // sf_selector_kind
+    int32_t max_nearby;
+    int32_t descriptor;  // descriptor_index (salts)
+};
+
+struct SearchParams {
+    int32_t n_leaves;
+    LeafSpec leaf[MAX_LEAVES];
+    int32_t acceptor;     // 0 HC, 1 LA, 2 never (dry run)
+    int32_t la_size;
+    int32_t forager;      // 0 accepted count, 1 first accepted, 2 best score
+    int32_t limit;
+    int32_t random_ties;
+    int32_t order;        // sf_selection_order
+    int32_t dry_run;      // 1: enumerate+score one step, no state change
+    int32_t replica_base; // replica of block 0 (single-replica launches)
+    int64_t n_steps;
+    uint64_t random_seed; // replica r uses random_seed + r
+    // dry-run explicit context
+    uint64_t dry_step_index, dry_step_seed;
+    // optional explicit step seeds [R][n_explicit]
+    const uint64_t* explicit_seeds;
+    int64_t n_explicit;
+    // per-replica search state
+    int64_t* last_step_score;  // [R][4]
+    int64_t* la_hist;          // [R][la_size][4]
+    int32_t* la_idx;           // [R]
+    uint64_t* step_index;      // [R] phase step counter
+    uint64_t* seed_draws;      // [R]
+    uint64_t* stats;           // [R][8]  (sf_stats layout)
+    int32_t* has_best;         // [R]
+    // trace of replica `trace_replica` (TRACE kernels only)
+    int32_t trace_replica;
+    int32_t* trace_moves;      // [cap][6]
+    int64_t* trace_scores;     // [cap][levels]
+    int32_t* trace_flags;      // [cap]
+    int64_t trace_cap;
+    int64_t* trace_count;      // [1]
+    int32_t* trace_applied;    // [1 + 6]
+};
+
+}  // namespace sf

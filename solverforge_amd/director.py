@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference seams on top of the C ABI.
+
+GpuScoreDirector ≙ Director<S> (crates/solverforge-scoring/src/director/traits.rs:27-95) plus the
+MoveCursorSource / local-search phase surface
+(crates/solverforge-solver/src/phase/localsearch/cursor_source.rs:23-48, phase.rs:237-320).
+Same names, argument meaning and error behaviour as the reference where a counterpart exists:
+invalid use raises (the reference panics), there are no silent fallbacks.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import MOVE_DTYPE, SolverConfigStruct, SolverForgeError, StatsStruct, check, ptr
+
+
+class MoveKind:
+    CHANGE, SWAP, LIST_CHANGE, LIST_SWAP = 0, 1, 2, 3
+
+
+class SelectionOrder:  # solverforge_config::SelectionOrder
+    ORIGINAL, SORTED, PROBABILISTIC, RANDOM, SHUFFLED = 0, 1, 2, 3, 4
+
+
+class Acceptor:
+    HILL_CLIMBING, LATE_ACCEPTANCE = 0, 1
+
+
+class Forager:
+    ACCEPTED_COUNT, FIRST_ACCEPTED, BEST_SCORE = 0, 1, 2
+
+
+class ConstraintKind:
+    UNI_UNASSIGNED, CROSS_ADJACENT_EQUAL, CROSS_GROUP_EQUAL, CROSS_QUEENS = 1, 2, 3, 4
+    NOT_EXISTS_FLATTENED, ROUTE_CAPACITY, ROUTE_DISTANCE = 5, 6, 7
+
+
+class SelectorKind:
+    SCALAR_CHANGE, SCALAR_SWAP, LIST_CHANGE, LIST_SWAP = 1, 2, 4, 8
+    NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP = 16, 32
+
+
+@dataclass
+class SolverConfig:
+    """Default policy of a list model: LateAcceptance(400) + AcceptedCount(256), every leaf
+    SelectionOrder::Random (runtime/compiler/default_local_search/policy.rs:18-20,48-79,114-118)."""
+
+    acceptor: int = Acceptor.LATE_ACCEPTANCE
+    late_acceptance_size: int = 400
+    forager: int = Forager.ACCEPTED_COUNT
+    accepted_count_limit: int = 256
+    random_ties: bool = True
+    selection_order: int = SelectionOrder.RANDOM
+    random_seed: int = 0
+
+
+class GpuScoreDirector:
+    """One device context = `n_replicas` independent Director + search states of one problem."""
+
+    def __init__(self, score_levels=2, hard_levels=1, n_replicas=1, device_id=0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.sf_ctx_create(device_id, score_levels, hard_levels, n_replicas, C.byref(h))
+        if rc != 0:
+            check(rc, None)
+        self._h = h
+        self.levels = score_levels
+        self.hard_levels = hard_levels
+        self.n_replicas = n_replicas
+        self._entity_counts = {}
+        self._list_capacity = {}
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sf_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- schema (SolutionDescriptor seam) ---------------------------------------------
+    def add_entity_class(self, descriptor_index, n_rows):
+        check(self._L.sf_schema_add_entity_class(self._h, descriptor_index, n_rows), self._h)
+        self._entity_counts[descriptor_index] = n_rows
+
+    def add_scalar_variable(self, descriptor_index, variable_index, n_values, allows_unassigned, initial):
+        initial = np.ascontiguousarray(initial, dtype=np.int32)
+        check(self._L.sf_schema_add_scalar_variable(self._h, descriptor_index, variable_index, n_values,
+                                                    int(allows_unassigned), ptr(initial)), self._h)
+
+    def add_list_variable(self, descriptor_index, lists, element_capacity, element_id_bound):
+        off = np.zeros(len(lists) + 1, dtype=np.uint32)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + len(l)
+        vals = np.array([v for l in lists for v in l] or [0], dtype=np.uint32)
+        check(self._L.sf_schema_add_list_variable(self._h, descriptor_index, ptr(off), ptr(vals),
+                                                  element_capacity, element_id_bound), self._h)
+        self._list_capacity[descriptor_index] = element_capacity
+
+    def add_fact_matrix(self, fact_id, matrix):
+        matrix = np.ascontiguousarray(matrix, dtype=np.int64)
+        check(self._L.sf_fact_matrix_i64(self._h, fact_id, matrix.shape[0], matrix.shape[1], ptr(matrix)), self._h)
+
+    def add_fact_column_i32(self, fact_id, column):
+        column = np.ascontiguousarray(column, dtype=np.int32)
+        check(self._L.sf_fact_column_i32(self._h, fact_id, len(column), ptr(column)), self._h)
+
+    def add_fact_column_u32(self, fact_id, column):
+        column = np.ascontiguousarray(column, dtype=np.uint32)
+        check(self._L.sf_fact_column_u32(self._h, fact_id, len(column), ptr(column)), self._h)
+
+    def add_fact_csr(self, fact_id, offsets, values):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint32)
+        values = np.ascontiguousarray(values if len(values) else [0], dtype=np.uint32)
+        check(self._L.sf_fact_csr_u32(self._h, fact_id, len(offsets) - 1, ptr(offsets), ptr(values)), self._h)
+
+    def add_constraint(self, kind, descriptor_index, variable_index=0, fact=-1, param=0, level=0, weight=1):
+        check(self._L.sf_constraint_add(self._h, kind, descriptor_index, variable_index, fact, param, level, weight), self._h)
+
+    def add_selector(self, kind, descriptor_index, variable_index=0, max_nearby=0, fact_meter=-1):
+        check(self._L.sf_selector_add(self._h, kind, descriptor_index, variable_index, max_nearby, fact_meter), self._h)
+
+    # ---- Director surface ------------------------------------------------------------
+    def _scores(self, fn):
+        out = np.zeros((self.n_replicas, self.levels), dtype=np.int64)
+        check(fn(self._h, ptr(out)), self._h)
+        return out
+
+    def calculate_score(self):
+        """First call ≙ initialize_all; later calls return the cached (committed) scores."""
+        if not getattr(self, "_initialized", False):
+            self._initialized = True
+            return self._scores(self._L.sf_initialize)
+        return self._scores(self._L.sf_get_scores)
+
+    def fresh_score(self):
+        """≙ Director::fresh_score: full evaluate_all on the device (FullAssert check)."""
+        return self._scores(self._L.sf_evaluate_all)
+
+    def entity_count(self, descriptor_index):
+        return self._entity_counts.get(descriptor_index)
+
+    def evaluate_moves(self, moves, replica=0):
+        """≙ n x evaluate_candidate: one launch, state unchanged -> (scores[n, levels], doable[n])."""
+        moves = np.ascontiguousarray(moves, dtype=MOVE_DTYPE)
+        scores = np.zeros((len(moves), self.levels), dtype=np.int64)
+        doable = np.zeros(len(moves), dtype=np.int32)
+        check(self._L.sf_step_evaluate(self._h, replica, ptr(moves), len(moves), ptr(scores), ptr(doable)), self._h)
+        return scores, doable
+
+    def apply_move(self, move, replica=0):
+        mv = np.zeros(1, dtype=MOVE_DTYPE)
+        mv[0] = move
+        check(self._L.sf_apply(self._h, replica, ptr(mv)), self._h)
+
+    # ---- MoveSelector / cursor surface ---------------------------------------------------
+    def open_cursor(self, step_index, step_seed, selection_order=SelectionOrder.RANDOM, replica=0, cap=1 << 16):
+        """Drains the configured union cursor for MoveStreamContext(step_index, step_seed):
+        returns (moves, trial scores, doable) in cursor order; state unchanged."""
+        moves = np.zeros(cap, dtype=MOVE_DTYPE)
+        scores = np.zeros((cap, self.levels), dtype=np.int64)
+        doable = np.zeros(cap, dtype=np.int32)
+        n = C.c_int64(0)
+        check(self._L.sf_step_generate(self._h, replica, step_index, step_seed, selection_order, ptr(moves),
+                                       ptr(scores), ptr(doable), cap, C.byref(n)), self._h)
+        k = n.value
+        return moves[:k], scores[:k], doable[:k]
+
+    # ---- local search phase ----------------------------------------------------------------
+    def configure(self, cfg: SolverConfig):
+        s = SolverConfigStruct(cfg.acceptor, cfg.late_acceptance_size, cfg.forager, cfg.accepted_count_limit,
+                               int(cfg.random_ties), cfg.selection_order, cfg.random_seed)
+        check(self._L.sf_solver_configure(self._h, C.byref(s)), self._h)
+
+    def set_step_seeds(self, seeds):
+        if seeds is None:
+            check(self._L.sf_solver_set_step_seeds(self._h, None, 0), self._h)
+            return
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(self.n_replicas, -1)
+        check(self._L.sf_solver_set_step_seeds(self._h, ptr(seeds), seeds.shape[1]), self._h)
+
+    def phase_start(self):
+        check(self._L.sf_phase_start(self._h), self._h)
+
+    def solve_steps(self, n_steps, sync=True):
+        check(self._L.sf_solve_steps(self._h, n_steps), self._h)
+        if sync:
+            check(self._L.sf_sync(self._h), self._h)
+
+    def sync(self):
+        check(self._L.sf_sync(self._h), self._h)
+
+    def solve_step_traced(self, replica=0, cap=1 << 16):
+        moves = np.zeros(cap, dtype=MOVE_DTYPE)
+        scores = np.zeros((cap, self.levels), dtype=np.int64)
+        flags = np.zeros(cap, dtype=np.int32)
+        n = C.c_int64(0)
+        applied = C.c_int32(0)
+        applied_move = np.zeros(1, dtype=MOVE_DTYPE)
+        check(self._L.sf_solve_step_traced(self._h, replica, ptr(moves), ptr(scores), ptr(flags), cap,
+                                           C.byref(n), C.byref(applied), ptr(applied_move)), self._h)
+        k = n.value
+        return moves[:k], scores[:k], flags[:k], bool(applied.value), applied_move[0]
+
+    def stats(self, replica=0):
+        st = StatsStruct()
+        check(self._L.sf_get_stats(self._h, replica, C.byref(st)), self._h)
+        return {name: int(getattr(st, name)) for name, _ in StatsStruct._fields_}
+
+    def total_stats(self):
+        tot = {}
+        for r in range(self.n_replicas):
+            for k, v in self.stats(r).items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
+
+    def best_scores(self):
+        return self._scores(self._L.sf_get_best_scores)
+
+    def profile_solve(self):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        check(self._L.sf_profile_solve(self._h, C.byref(ms), C.byref(n)), self._h)
+        return ms.value, n.value
+
+    # ---- state download --------------------------------------------------------------------
+    def working_lists(self, descriptor_index=0, replica=0, best=False):
+        n = self._entity_counts[descriptor_index]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        vals = np.zeros(max(self._list_capacity[descriptor_index], 1), dtype=np.uint32)
+        check(self._L.sf_download_list(self._h, replica, descriptor_index, ptr(off), ptr(vals), int(best)), self._h)
+        return [list(map(int, vals[off[i]: off[i + 1]])) for i in range(n)]
+
+    def working_values(self, descriptor_index=0, variable_index=0, replica=0, best=False):
+        n = self._entity_counts[descriptor_index]
+        out = np.zeros(n, dtype=np.int32)
+        check(self._L.sf_download_scalar(self._h, replica, descriptor_index, variable_index, ptr(out), int(best)), self._h)
+        return out
+
+    # ---- portfolio -------------------------------------------------------------------------
+    def portfolio_unique_id(self):
+        buf = np.zeros(128, dtype=np.uint8)
+        check(self._L.sf_portfolio_unique_id(ptr(buf)), self._h)
+        return buf
+
+    def portfolio_init(self, unique_id, rank, world_size):
+        unique_id = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        check(self._L.sf_portfolio_init(self._h, ptr(unique_id), rank, world_size), self._h)
+
+    def portfolio_allgather_best(self):
+        best = np.zeros(self.levels, dtype=np.int64)
+        rank = C.c_int32(0)
+        rep = C.c_int32(0)
+        check(self._L.sf_portfolio_allgather_best(self._h, ptr(best), C.byref(rank), C.byref(rep)), self._h)
+        return best, rank.value, rep.value
+
+    def portfolio_destroy(self):
+        check(self._L.sf_portfolio_destroy(self._h), self._h)

@@ -1,0 +1,32 @@
+"""Model definitions: the device form of the reference examples' `define_constraints()`.
+
+Each builder wires schema + constraint archetypes + default-policy selectors exactly as the
+corresponding reference model does with ConstraintFactory streams.
+"""
+from .director import ConstraintKind, GpuScoreDirector, SelectorKind
+
+FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN = 0, 1, 2, 3, 4, 5
+
+
+def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearby_change", "nearby_swap")):
+    """CVRP: HardSoftScore; all_customers_assigned (not-exists, 1 hard each —
+    crates/solverforge/tests/list_clarke_wright_publication/domain/publication_plan.rs:51-65),
+    vehicle_capacity (uni on routes, max(0, load-cap) hard), total_distance (uni on routes,
+    depot->...->depot, soft); leaves = default list policy nearby change + nearby swap with
+    MatrixDistanceMeter, max_nearby 20 (default_local_search/policy/list.rs:19,97-141)."""
+    d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
+    n_vehicles = len(problem["routes"])
+    dim = problem["matrix"].shape[0]
+    d.add_entity_class(0, n_vehicles)
+    d.add_list_variable(0, problem["routes"], element_capacity=len(problem["customers"]), element_id_bound=dim)
+    d.add_fact_matrix(FACT_MATRIX, problem["matrix"])
+    d.add_fact_column_i32(FACT_DEMAND, problem["demands"])
+    d.add_fact_column_u32(FACT_CUSTOMERS, problem["customers"])
+    d.add_constraint(ConstraintKind.NOT_EXISTS_FLATTENED, 0, fact=FACT_CUSTOMERS, level=0, weight=1)
+    d.add_constraint(ConstraintKind.ROUTE_CAPACITY, 0, fact=FACT_DEMAND, param=int(problem["capacity"]), level=0, weight=1)
+    d.add_constraint(ConstraintKind.ROUTE_DISTANCE, 0, fact=FACT_MATRIX, param=int(problem["depot"]), level=1, weight=1)
+    if "nearby_change" in leaves:
+        d.add_selector(SelectorKind.NEARBY_LIST_CHANGE, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
+    if "nearby_swap" in leaves:
+        d.add_selector(SelectorKind.NEARBY_LIST_SWAP, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
+    return d

@@ -1,0 +1,237 @@
+"""GPU parity tests (through the C ABI): HIP list-variable hot path vs the CPU oracle.
+Bit-exact: integer HardSoftScore, candidate order, accept flags, applied moves, counters."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(oracle, problem, n_replicas=1, max_nearby=20, leaves=("nearby_change", "nearby_swap")):
+    import solverforge_amd as sfa
+
+    d = sfa.build_cvrp(problem, n_replicas=n_replicas, max_nearby=max_nearby, leaves=leaves)
+    o = oracle.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
+                          problem["customers"], problem["routes"])
+    bits = 0
+    if "nearby_change" in leaves:
+        bits |= oracle.LEAF_NEARBY_LIST_CHANGE
+    if "nearby_swap" in leaves:
+        bits |= oracle.LEAF_NEARBY_LIST_SWAP
+    return d, o, bits
+
+
+def _tuples(moves):
+    return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"]], axis=1)
+
+
+def _small(seed=1, n=40, v=5, cap=30):
+    from solverforge_amd import datasets
+
+    return datasets.make_cvrp(n, v, cap, seed=seed)
+
+
+def test_initialize_and_fresh_score_match_oracle(oracle):
+    p = _small()
+    d, o, _ = _mk(oracle, p)
+    s = d.calculate_score()
+    assert s.shape == (1, 2)
+    assert (s[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.fresh_score()[:2]).all()
+
+
+@pytest.mark.parametrize("order", [0, 3, 4])  # Original, Random, Shuffled
+@pytest.mark.parametrize("leaves", [("nearby_change",), ("nearby_swap",), ("nearby_change", "nearby_swap")])
+def test_cursor_order_and_trial_scores(oracle, order, leaves):
+    """Candidate stream (seeded order, stable nearby top-k, union scheduling) and every trial score."""
+    p = _small(seed=2, n=57, v=6)
+    d, o, bits = _mk(oracle, p, leaves=leaves)
+    o.configure(leaves=bits, max_nearby=20, selection_order=order)
+    d.calculate_score()
+    for step_index, step_seed in [(0, 0), (7, 41), (123, 0xDEADBEEFCAFEF00D)]:
+        gm, gs, gd = d.open_cursor(step_index, step_seed, selection_order=order)
+        om = o.enumerate(0, step_index, step_seed, order)
+        assert len(gm) == len(om) > 0
+        assert (_tuples(gm) == _tuples(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all()
+        assert (gs == os_[:, :2]).all()
+
+
+def test_step_evaluate_arbitrary_moves(oracle):
+    """sf_step_evaluate on host-provided ListChange/ListSwap batches (full plain neighbourhoods)."""
+    p = _small(seed=3, n=30, v=4)
+    p["routes"][1] = []  # an empty route: insertion into / removal down to empty
+    p["routes"][0] = p["routes"][0] + [c for c in range(1, 31) if c % 4 == 2]
+    seen = set()
+    p["routes"] = [[c for c in r if not (c in seen or seen.add(c))] for r in p["routes"]]
+    d, o, _ = _mk(oracle, p)
+    d.calculate_score()
+    o.configure(leaves=oracle.LEAF_LIST_CHANGE | oracle.LEAF_LIST_SWAP)
+    moves = np.concatenate([o.enumerate(oracle.LEAF_LIST_CHANGE), o.enumerate(oracle.LEAF_LIST_SWAP)])
+    assert len(moves) > 1000
+    os_, od = o.evaluate_moves(moves)
+    gs, gd = d.evaluate_moves(moves)
+    assert (gd == od).all()
+    assert (gs == os_[:, :2]).all()
+    # not-doable coordinates are reported, not scored
+    bad = moves[:3].copy()
+    bad["a_pos"] = 10_000
+    _, bd = d.evaluate_moves(bad)
+    assert (bd == 0).all()
+
+
+def test_apply_matches_oracle(oracle):
+    p = _small(seed=4, n=35, v=5)
+    d, o, bits = _mk(oracle, p)
+    o.configure(leaves=bits)
+    d.calculate_score()
+    rng = np.random.default_rng(0)
+    for it in range(40):
+        om = o.enumerate(0, it, 99 + it, 3)
+        mv = om[rng.integers(len(om))]
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert d.working_lists(0, 0) == o.get_lists(0)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 256), (0, 0, 4), (1, 1, 1), (0, 2, 1)])
+def test_traced_steps_match_oracle(oracle, acceptor, forager, limit):
+    """Per step: consumed candidates in order, scores, accept flags, the committed move, then state."""
+    import solverforge_amd as sfa
+
+    p = _small(seed=5, n=64, v=7, cap=40)
+    d, o, bits = _mk(oracle, p)
+    o.configure(acceptor=acceptor, la_size=7, forager=forager, limit=limit, leaves=bits, random_seed=11)
+    d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=7, forager=forager,
+                                 accepted_count_limit=limit, random_seed=11))
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    n_steps = 12 if forager == 2 else 40
+    for step in range(n_steps):
+        gm, gs, gf, gap, gmv = d.solve_step_traced()
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_tuples(gm) == _tuples(om)).all(), step
+        assert (gf == of).all(), step
+        assert (gs == os_[:, :2]).all(), step
+        assert gap == oap, step
+        if gap:
+            assert tuple(gmv)[:5] == tuple(omv)[:5], step
+        assert d.working_lists(0, 0) == o.get_lists(0), step
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.best_scores()[0] == o.best_score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied",
+              "score_calculations", "moves_not_doable"]:
+        assert gst[k] == ost[k], k
+
+
+def test_fused_solve_matches_oracle_multi_replica(oracle):
+    """sf_solve_steps: many steps per launch, several replicas (seed + r), explicit step seeds too."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(150, 12, 70, seed=6)
+    R = 3
+    d, _, bits = _mk(oracle, p, n_replicas=R)
+    d.configure(sfa.SolverConfig(random_seed=5))
+    d.calculate_score()
+    d.phase_start()
+    d.solve_steps(30)
+    d.solve_steps(45)  # state carries across launches (LA history index, step counters)
+    scores = d.calculate_score()
+    best = d.best_scores()
+    for r in range(R):
+        o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+        o.configure(leaves=bits, random_seed=5 + r)
+        o.phase_start()
+        o.steps(75)
+        assert (scores[r] == o.score()[:2]).all(), r
+        assert (best[r] == o.best_score()[:2]).all(), r
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        gst, ost = d.stats(r), o.stats()
+        assert gst["moves_evaluated"] == ost["moves_evaluated"], r
+        assert gst["moves_accepted"] == ost["moves_accepted"], r
+    assert (d.fresh_score() == scores).all()  # FullAssert: incremental == full recalculation
+    # the best snapshot is a real solution with the best score
+    assert sum(len(r_) for r_ in d.working_lists(0, 0, best=True)) == 150
+
+
+def test_explicit_step_seeds(oracle):
+    import solverforge_amd as sfa
+
+    p = _small(seed=8, n=48, v=6)
+    d, o, bits = _mk(oracle, p)
+    seeds = np.array([3, 1 << 63, 77, 0, 123456789, 42, 42, 9], dtype=np.uint64)
+    o.configure(leaves=bits, random_seed=1)
+    o.set_step_seeds(seeds)
+    d.configure(sfa.SolverConfig(random_seed=1))
+    d.set_step_seeds(seeds)
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(8)
+    o.steps(8)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+
+
+def test_unreachable_legs_and_ties(oracle):
+    """UNREACHABLE / negative matrix entries: excluded from nearby (meters.rs:21-23) and priced
+    MAX_SAFE_LEG_COST by distance_cost (problem_data.rs:28-31); many equal distances exercise the
+    stable tie order."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(40, 5, 30, seed=9, coord_range=6)  # tiny grid => massive distance ties
+    m = p["matrix"]
+    m[3, 7] = np.iinfo(np.int64).max
+    m[7, 3] = -5
+    m[0, 12] = np.iinfo(np.int64).max
+    d, o, bits = _mk(oracle, p)
+    o.configure(leaves=bits, random_seed=2)
+    d.configure(sfa.SolverConfig(random_seed=2))
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    for step_index, step_seed in [(0, 5), (3, 6)]:
+        gm, gs, gd = d.open_cursor(step_index, step_seed, selection_order=3)
+        om = o.enumerate(0, step_index, step_seed, 3)
+        assert (_tuples(gm) == _tuples(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gs == os_[:, :2]).all()
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(20)
+    o.steps(20)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+
+
+def test_cvrp_1000_properties(oracle):
+    """BASELINE.json size (1000 customers / 100 vehicles): size-independent checks — the element
+    multiset is preserved, incremental == full recalculation, best >= start, and the first steps
+    equal the oracle."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(1000, 100, 55, seed=0)
+    d, o, bits = _mk(oracle, p, n_replicas=4)
+    d.configure(sfa.SolverConfig(random_seed=0))
+    start = d.calculate_score().copy()
+    assert (start[0] == o.score()[:2]).all()
+    d.phase_start()
+    d.solve_steps(60)
+    o.configure(leaves=bits, random_seed=0)
+    o.phase_start()
+    o.steps(60)
+    sc = d.calculate_score()
+    assert (sc[0] == o.score()[:2]).all()
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.fresh_score() == sc).all()
+    for r in range(4):
+        routes = d.working_lists(0, r)
+        assert sorted(c for rt in routes for c in rt) == list(range(1, 1001))
+        b = d.best_scores()[r]
+        assert tuple(b) >= tuple(start[r])

@@ -1,0 +1,106 @@
+"""CPU tests: the oracle against the reference's own golden vectors."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "selector_goldens.json")))
+
+
+def _tuples(moves):
+    return [[int(m["a"]), int(m["a_pos"]), int(m["b"]), int(m["b_pos"])] for m in moves]
+
+
+def test_constraint_node_goldens(oracle):
+    """bi_incr / cross_bi_incr / exists / grouped / director known answers (oracle/test_golden.cpp)."""
+    exe = os.path.join(os.path.dirname(oracle._LIB), "test_golden")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    lines = [l for l in out.stdout.splitlines() if l.startswith(("ok", "FAIL"))]
+    assert len(lines) >= 24
+    assert all(l.startswith("ok") for l in lines), out.stdout
+    assert out.returncode == 0
+
+
+def test_list_change_canonical_order(oracle):
+    g = GOLD["list_change_order"]
+    m = oracle.Model.list_toy(g["routes"])
+    assert _tuples(m.enumerate(oracle.LEAF_LIST_CHANGE)) == g["expected"]
+
+
+def test_list_swap_canonical_order(oracle):
+    g = GOLD["list_swap_order"]
+    m = oracle.Model.list_toy(g["routes"])
+    assert _tuples(m.enumerate(oracle.LEAF_LIST_SWAP)) == g["expected"]
+
+
+def test_nearby_change_stable_tie_order(oracle):
+    g = GOLD["nearby_change_stable_ties"]
+    m = oracle.Model.list_toy(g["routes"], meter=g["meter"])
+    m.configure(max_nearby=g["max_nearby"])
+    assert _tuples(m.enumerate(oracle.LEAF_NEARBY_LIST_CHANGE))[:3] == g["expected_prefix"]
+
+
+def test_nearby_swap_pairs(oracle):
+    g = GOLD["nearby_swap_pairs"]
+    m = oracle.Model.list_toy(g["routes"], meter=g["meter"])
+    m.configure(max_nearby=g["max_nearby"])
+    assert _tuples(m.enumerate(oracle.LEAF_NEARBY_LIST_SWAP)) == g["expected"]
+
+
+def test_known_answer_candidate_counts(oracle):
+    g = GOLD["candidate_counts"]
+    routes = [[v * 1000 + i for i in range(g["visits_per_vehicle"])] for v in range(g["vehicles"])]
+    m = oracle.Model.list_toy(routes, meter="position")
+    m.configure(max_nearby=g["max_nearby"])
+    assert m.enumerate_count(oracle.LEAF_LIST_CHANGE) == g["list_change"]
+    assert m.enumerate_count(oracle.LEAF_LIST_SWAP) == g["list_swap"]
+    assert m.enumerate_count(oracle.LEAF_NEARBY_LIST_CHANGE) == g["nearby_change"]
+    assert m.enumerate_count(oracle.LEAF_NEARBY_LIST_SWAP) == g["nearby_swap"]
+
+
+def test_bounded_top_k_matches_stable_sort(oracle):
+    """nearby_list_support.rs:52-73 property, same LCG inputs (incl. -0.0 ties)."""
+    import ctypes as C
+
+    L = oracle.lib()
+    for length in range(0, 96):
+        state = (0x9E3779B9 ^ length) & 0xFFFFFFFF
+        dist = []
+        for index in range(length):
+            state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+            dist.append(-0.0 if index % 17 == 0 else float(state % 11))
+        d = np.array(dist, dtype=np.float64)
+        for max_nearby in range(0, length + 3):
+            out = np.zeros(max(length, 1), dtype=np.int32)
+            n = L.sfo_sort_and_limit(d.ctypes.data_as(C.c_void_p), length, max_nearby, out.ctypes.data_as(C.c_void_p))
+            expected = sorted(range(length), key=lambda i: (d[i] + 0.0, i))[:max_nearby]  # stable; -0.0 == 0.0
+            assert list(out[:n]) == expected, (length, max_nearby)
+
+
+def test_stream_context_is_a_permutation(oracle):
+    """selection_index_without_replacement visits every row once; stride is coprime (iter.rs:94-147)."""
+    from math import gcd
+
+    L = oracle.lib()
+    for length in [1, 2, 3, 7, 16, 100, 1000]:
+        for seed in [0, 41, 2**63 + 5]:
+            idx = [L.sfo_ctx_selection_index_wo(7, seed, oracle.ORDER_RANDOM, o, length, 0xABCDEF) for o in range(length)]
+            assert sorted(idx) == list(range(length))
+            assert gcd(L.sfo_ctx_random_stride(7, seed, length, 1234), length) == 1
+    # canonical orders are the identity (iter.rs:175-180)
+    assert [L.sfo_ctx_selection_index(3, 9, oracle.ORDER_ORIGINAL, o, 10, 5) for o in range(10)] == list(range(10))
+
+
+def test_splitmix64_known_values(oracle):
+    """splitmix64 (iter.rs:193-198) against the published reference outputs of the algorithm
+    (seed 0 stream: 0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F)."""
+    golden = 0x9E3779B97F4A7C15
+    assert oracle.splitmix64(0) == 0xE220A8397B1DCDAF
+    assert oracle.splitmix64(golden) == 0x6E789E6AA1B965F4
+    assert oracle.splitmix64((2 * golden) & (2**64 - 1)) == 0x06C45D188009454F
+    from solverforge_amd import datasets
+
+    assert [int(v) for v in datasets.stream(0, 3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
