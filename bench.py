@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py — moves-evaluated/sec of the MI355X hot path on BASELINE.json's CVRP-1000 workload.
+
+One bench "step" = ONE persistent-kernel launch (sf_solve_steps) that runs `--ls-steps`
+local-search steps (seeded nearby-list candidate generation -> trial delta score -> LateAcceptance
+-> AcceptedCount(256) forager -> apply) for each of `--replicas` independently seeded searches
+resident on the GPU (the per-GPU batch of the seed portfolio).  `value` counts
+CONSUMED candidates (`moves_evaluated`, the reference's counter definition, evaluation.rs:33-49),
+not the speculative tail; inputs are resident in HBM before the timed region.
+
+Multi-GPU (`torchrun ... bench.py --gpus N`): one process per GPU, independent seeds per rank
+(weak scaling, no data-path collective); after the timed region every rank contributes its best
+score to one RCCL all-gather over xGMI (sf_portfolio_allgather_best) and all ranks name the same
+winner.  torch.distributed (gloo) is used only for rendezvous / barrier / max-over-ranks.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# SURVEY.md §8(d) algorithmic bytes (C3): one scored list-change/list-swap candidate at route
+# length 10+10 = 368 B; nearby generation per source = (N+V)*12 B.
+B_ALG_CANDIDATE = 368
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(problem, seconds, seed):
+    """The oracle (C++ restatement of the reference algorithm, 1 thread) on the same workload."""
+    from oracle import sfo
+
+    o = sfo.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
+                       problem["customers"], problem["routes"])
+    o.configure(leaves=sfo.LEAF_NEARBY_LIST_CHANGE | sfo.LEAF_NEARBY_LIST_SWAP, max_nearby=20, random_seed=seed)
+    o.phase_start()
+    t0 = time.perf_counter()
+    steps = o.steps_timed(seconds)
+    dt = time.perf_counter() - t0
+    st = o.stats()
+    return {
+        "value": st["moves_evaluated"] / dt,
+        "unit": "moves/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{steps} local-search steps ({st['moves_evaluated']} moves) of the same CVRP-1000 workload, "
+                  f"seed {seed}, {dt:.1f}s on 1 host core",
+        "best_score": [int(v) for v in o.best_score()[:2]],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--replicas", type=int, default=512, help="independent searches resident per GPU")
+    ap.add_argument("--ls-steps", type=int, default=40, help="local-search steps per launch")
+    ap.add_argument("--customers", type=int, default=1000)
+    ap.add_argument("--vehicles", type=int, default=100)
+    ap.add_argument("--capacity", type=int, default=55)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--solve-seconds", type=float, default=0.0, help="extra: timed solve after the bench (best score)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod  # plumbing only: rendezvous + barrier (gloo, CPU tensors)
+        import torch
+
+        dist = dist_mod
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import __graft_entry__ as entry
+
+    entry.build()
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    problem = datasets.make_cvrp(args.customers, args.vehicles, args.capacity, seed=args.seed)
+    d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank)
+    # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
+    d.configure(sfa.SolverConfig(random_seed=args.seed + rank * args.replicas))
+    start_score = d.calculate_score()[0].tolist()
+    d.phase_start()
+
+    def barrier():
+        d.sync()
+        if dist is not None:
+            dist.barrier()
+        d.sync()
+
+    for _ in range(args.warmup):
+        d.solve_steps(args.ls_steps, sync=False)
+    barrier()
+    d.profile_solve()  # drop warmup events
+    before = d.total_stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d.solve_steps(args.ls_steps, sync=False)
+    d.sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms, launches = d.profile_solve()  # HIP events on the context stream
+    after = d.total_stats()
+    delta = {k: after[k] - before[k] for k in after}
+
+    moves_local = delta["moves_evaluated"]
+    scored_local = delta["candidates_scored"]
+    moves_total = moves_local
+    if dist is not None:
+        import torch
+
+        t = torch.tensor([moves_local], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        moves_total = float(t.item())
+
+    # portfolio exchange: RCCL all-gather of best scores (correctness: identical winner everywhere)
+    exchange = "single-rank"
+    best_local = max(tuple(int(v) for v in s) for s in d.best_scores())
+    winner = {"score": list(best_local), "rank": 0}
+    if dist is not None:
+        import torch
+
+        try:
+            uid = d.portfolio_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8)
+            tu = torch.from_numpy(uid.copy())
+            dist.broadcast(tu, src=0)
+            d.portfolio_init(tu.numpy(), rank, world)
+            bs, wr, wrep = d.portfolio_allgather_best()
+            winner = {"score": [int(v) for v in bs], "rank": int(wr), "replica": int(wrep)}
+            exchange = "rccl-allgather"
+            d.portfolio_destroy()
+        except Exception as e:  # keep the bench alive; report the fallback honestly
+            tl = torch.tensor(list(best_local), dtype=torch.int64)
+            gathered = [torch.zeros_like(tl) for _ in range(world)]
+            dist.all_gather(gathered, tl)
+            scores = [tuple(int(v) for v in g) for g in gathered]
+            wr = max(range(world), key=lambda q: (scores[q], -q))
+            winner = {"score": list(scores[wr]), "rank": wr}
+            exchange = f"gloo-fallback ({type(e).__name__}: {e})"
+
+    if rank == 0:
+        n_sources = scored_local / 20.0  # every nearby source keeps <= max_nearby(20) candidates
+        gen_bytes = n_sources * (args.customers + args.vehicles) * 12
+        alg_bytes = scored_local * B_ALG_CANDIDATE + gen_bytes
+        avg_launch_ms = kernel_ms / max(launches, 1)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            "metric": "moves-evaluated/sec, CVRP-1000 (nearby-list selector, LateAcceptance(400)+AcceptedCount(256))",
+            "value": moves_total / elapsed,
+            "unit": "moves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"solverforge-cvrp {args.customers} customers / {args.vehicles} vehicles, nearby-list "
+                            "change+swap union (max_nearby 20), default list policy",
+                "replicas_per_gpu": args.replicas,
+                "ls_steps_per_launch": args.ls_steps,
+                "parallelism": f"portfolio x{world} (independent seeds, {exchange})",
+                "seed": args.seed,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "k_list_search<2,false>",
+                "avg_launch_ms": avg_launch_ms,
+                "launches": launches,
+                "candidates_scored_per_launch": scored_local / max(launches, 1),
+                "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
+                "bytes_per_candidate": B_ALG_CANDIDATE,
+                "generation_bytes_per_source": (args.customers + args.vehicles) * 12,
+            },
+            "extra": {
+                "candidates_scored_per_s": scored_local * world / elapsed,
+                "moves_accepted": delta["moves_accepted"],
+                "ls_steps": delta["step_count"],
+                "start_score": start_score,
+                "best_score": winner["score"],
+                "winner": winner,
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(problem, args.cpu_seconds, args.seed)
+            out["extra"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if args.solve_seconds > 0:
+            t1 = time.perf_counter()
+            while time.perf_counter() - t1 < args.solve_seconds:
+                d.solve_steps(args.ls_steps, sync=True)
+            out["extra"]["solve_seconds"] = args.solve_seconds
+            out["extra"]["best_score_after_solve"] = list(max(tuple(int(v) for v in s) for s in d.best_scores()))
+            out["extra"]["moves_evaluated_total"] = d.total_stats()["moves_evaluated"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
