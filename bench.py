@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--vehicles", type=int, default=100)
     ap.add_argument("--capacity", type=int, default=55)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--engine", choices=["auto", "block", "wave"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve-seconds", type=float, default=0.0, help="extra: timed solve after the bench (best score)")
@@ -90,6 +91,7 @@ def main():
     problem = datasets.make_cvrp(args.customers, args.vehicles, args.capacity, seed=args.seed)
     d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank)
     # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
+    d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
     d.configure(sfa.SolverConfig(random_seed=args.seed + rank * args.replicas))
     start_score = d.calculate_score()[0].tolist()
     d.phase_start()

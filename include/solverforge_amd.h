@@ -116,6 +116,12 @@ typedef enum sf_forager_kind {
     SF_FORAGER_BEST_SCORE = 2      /* phase/localsearch/forager.rs:339-420 */
 } sf_forager_kind;
 
+/* Search engines of the fused local-search kernel (same results, different GPU mapping):
+ * WAVE  = one wavefront per replica, presorted neighbour index (many small replicas);
+ * BLOCK = one 1024-thread workgroup per replica, matrix-row scan (large problems);
+ * AUTO  = WAVE when a replica's LDS slice allows >= 4 replicas per CU, else BLOCK. */
+typedef enum sf_engine_kind { SF_ENGINE_AUTO = 0, SF_ENGINE_BLOCK = 1, SF_ENGINE_WAVE = 2 } sf_engine_kind;
+
 typedef struct sf_solver_config {
     int32_t acceptor;            /* sf_acceptor_kind */
     int32_t late_acceptance_size;/* default 400: runtime/compiler/default_local_search/policy.rs:18 */
@@ -136,6 +142,8 @@ typedef struct sf_stats {
     uint64_t score_calculations;  /* scored trials only (evaluation.rs:60) */
     uint64_t moves_not_doable;
     uint64_t candidates_scored;   /* device work incl. the speculative tail of each step */
+    uint64_t sources_scanned;     /* nearby sources whose destination scan ran (generation work) */
+    uint64_t reserved;
 } sf_stats;
 
 /* ---- context ------------------------------------------------------------------------- */
@@ -200,6 +208,7 @@ int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint
 
 /* ---- local search phase ------------------------------------------------------------------ */
 int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg);
+int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine); /* sf_engine_kind; SF_ERR_UNSUPPORTED if it cannot run this model */
 /* explicit step seeds for parity runs (n_steps per replica, replica-major); NULL clears */
 int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps);
 /* ≙ phase start: last_step_score = calculate_score, acceptor.phase_started, best = working */

@@ -34,7 +34,7 @@ class SolverConfigStruct(C.Structure):
 class StatsStruct(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied",
-        "score_calculations", "moves_not_doable", "candidates_scored")]
+        "score_calculations", "moves_not_doable", "candidates_scored", "sources_scanned", "reserved")]
 
 
 class SolverForgeError(RuntimeError):
@@ -48,7 +48,7 @@ SYMBOLS = [
     "sf_fact_matrix_i64", "sf_fact_column_i32", "sf_fact_column_u32", "sf_fact_csr_u32",
     "sf_constraint_add", "sf_selector_add", "sf_initialize", "sf_evaluate_all", "sf_get_scores",
     "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_solver_set_step_seeds",
-    "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_best_scores",
+    "sf_solver_set_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
     "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_destroy",
 ]
@@ -91,6 +91,7 @@ def load():
     L.sf_apply.argtypes = [vp, i32, vp]
     L.sf_step_generate.argtypes = [vp, i32, u64, u64, i32, vp, vp, vp, i64, vp]
     L.sf_solver_configure.argtypes = [vp, C.POINTER(SolverConfigStruct)]
+    L.sf_solver_set_engine.argtypes = [vp, i32]
     L.sf_solver_set_step_seeds.argtypes = [vp, vp, i64]
     L.sf_phase_start.argtypes = [vp]
     L.sf_solve_steps.argtypes = [vp, i64]

@@ -12,6 +12,7 @@
 
 #include "../../include/solverforge_amd.h"
 #include "sf_list_kernels.hip"
+#include "sf_list_wave.hip"
 #include "sf_scalar_kernels.hip"
 
 using namespace sf;
@@ -58,6 +59,8 @@ struct sf_ctx {
     bool has_list_model = false;
     int list_desc = -1;
     ListModel lm{};
+    NbrIndex nbr{nullptr, nullptr};  // presorted neighbour index (wave engine)
+    int engine = SF_ENGINE_AUTO;
     // scalar model
     bool has_scalar_model = false;
     int scalar_desc = -1;
@@ -356,7 +359,41 @@ static int build_list_model(sf_ctx* ctx, int d) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_list_model = true;
     ctx->list_desc = d;
+    // presorted neighbour index for the wave engine: every matrix row sorted by (distance, node)
+    bool nearby = false;
+    for (auto& s : ctx->selectors)
+        if ((s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP) && s.desc == d) nearby = true;
+    int P = 2;
+    while (P < m.dim) P <<= 1;
+    if (nearby && m.mat && (size_t)P * 8 <= 128 * 1024) {
+        uint64_t* keys = nullptr;
+        uint32_t* cnt = nullptr;
+        if ((rc = dalloc(ctx, &keys, (size_t)m.dim * m.dim))) return rc;
+        if ((rc = dalloc(ctx, &cnt, (size_t)m.dim))) return rc;
+        HIPCHK(ctx, hipFuncSetAttribute((const void*)k_nbr_presort, hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
+        hipLaunchKernelGGL(k_nbr_presort, dim3(m.dim), dim3(256), (size_t)P * 8, ctx->stream, m.mat, m.dim, P, keys, cnt);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->nbr = NbrIndex{keys, cnt};
+    }
     return SF_OK;
+}
+
+// engine resolution: WAVE needs the neighbour index, u16-packable coordinates and an LDS slice per
+// replica small enough for several replicas per CU.
+static bool wave_engine_possible(sf_ctx* ctx) {
+    const ListModel& m = ctx->lm;
+    if (!ctx->nbr.keys || m.n_cap > 65535) return false;
+    for (auto& s : ctx->selectors)
+        if (s.desc == ctx->list_desc && (s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP) &&
+            s.max_nearby > 64)
+            return false;
+    return WCarve(m.V, m.n_cap, m.dim).total * WPB <= 160 * 1024;
+}
+static bool use_wave_engine(sf_ctx* ctx) {
+    if (ctx->engine == SF_ENGINE_BLOCK) return false;
+    if (ctx->engine == SF_ENGINE_WAVE) return true;  // validated in sf_solver_set_engine / launch
+    return wave_engine_possible(ctx) && WCarve(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim).total <= 40 * 1024;
 }
 
 static int build_scalar_model(sf_ctx* ctx, int d);  // sf_api_scalar.inc
@@ -373,7 +410,7 @@ static int alloc_search(sf_ctx* ctx) {
     if ((rc = dalloc(ctx, &p.la_idx, (size_t)R))) return rc;
     if ((rc = dalloc(ctx, &p.step_index, (size_t)R))) return rc;
     if ((rc = dalloc(ctx, &p.seed_draws, (size_t)R))) return rc;
-    if ((rc = dalloc(ctx, &p.stats, (size_t)R * 8))) return rc;
+    if ((rc = dalloc(ctx, &p.stats, (size_t)R * SF_STATS_WORDS))) return rc;
     if ((rc = dalloc(ctx, &p.has_best, (size_t)R))) return rc;
     if ((rc = dalloc(ctx, &ctx->d_trace_count, 1))) return rc;
     if ((rc = dalloc(ctx, &ctx->d_trace_applied, 8))) return rc;
@@ -440,7 +477,33 @@ static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid) {
     HIPCHK(ctx, hipGetLastError());
     return SF_OK;
 }
+template <int L, bool TRACE>
+static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas) {
+    WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim);
+    size_t lds = cv.total * WPB;
+    auto kern = k_list_search_wave<L, TRACE>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SearchParams q = p;
+    q.n_launch = n_replicas;
+    hipLaunchKernelGGL(kern, dim3((n_replicas + WPB - 1) / WPB), dim3(64 * WPB), lds, ctx->stream, ctx->lm, q, ctx->nbr);
+    HIPCHK(ctx, hipGetLastError());
+    return SF_OK;
+}
+static int launch_list_wave(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
+    if (!wave_engine_possible(ctx)) return fail(ctx, SF_ERR_UNSUPPORTED, "wave engine cannot run this model (needs a nearby matrix meter, <= 65535 elements, LDS slice <= 160 KiB)");
+    switch (ctx->levels) {
+        case 1:
+            return trace ? launch_list_wave_t<1, true>(ctx, p, grid) : launch_list_wave_t<1, false>(ctx, p, grid);
+        case 2:
+            return trace ? launch_list_wave_t<2, true>(ctx, p, grid) : launch_list_wave_t<2, false>(ctx, p, grid);
+        case 3:
+            return trace ? launch_list_wave_t<3, true>(ctx, p, grid) : launch_list_wave_t<3, false>(ctx, p, grid);
+        default:
+            return trace ? launch_list_wave_t<4, true>(ctx, p, grid) : launch_list_wave_t<4, false>(ctx, p, grid);
+    }
+}
 static int launch_list_search(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
+    if (use_wave_engine(ctx)) return launch_list_wave(ctx, p, grid, trace);
     switch (ctx->levels) {
         case 1:
             return trace ? launch_list_search_t<1, true>(ctx, p, grid) : launch_list_search_t<1, false>(ctx, p, grid);
@@ -593,6 +656,14 @@ int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg) {
     return SF_OK;
 }
 
+int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine) {
+    if (!ctx || engine < SF_ENGINE_AUTO || engine > SF_ENGINE_WAVE) return fail(ctx, SF_ERR_INVALID, "bad engine");
+    if (engine == SF_ENGINE_WAVE && ctx->initialized && !wave_engine_possible(ctx))
+        return fail(ctx, SF_ERR_UNSUPPORTED, "wave engine cannot run this model");
+    ctx->engine = engine;
+    return SF_OK;
+}
+
 int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps) {
     if (!ctx) return SF_ERR_INVALID;
     if (!seeds || n_steps <= 0) {
@@ -613,7 +684,7 @@ int32_t sf_phase_start(sf_ctx* ctx) {
     int rc = alloc_search(ctx);
     if (rc) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->sp.seed_draws, 0, (size_t)ctx->R * 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->sp.stats, 0, (size_t)ctx->R * 64, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->sp.stats, 0, (size_t)ctx->R * SF_STATS_WORDS * 8, ctx->stream));
     if (ctx->has_list_model)
         hipLaunchKernelGGL(k_list_phase_start, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->lm, ctx->sp);
     else
@@ -737,7 +808,8 @@ int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves,
 
 int32_t sf_get_stats(sf_ctx* ctx, int32_t replica, sf_stats* out) {
     if (!ctx || !ctx->search_alloc || !out || replica < 0 || replica >= ctx->R) return fail(ctx, SF_ERR_INVALID, "bad sf_get_stats");
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->sp.stats + (size_t)replica * 8, 64, hipMemcpyDeviceToHost, ctx->stream));
+    static_assert(sizeof(sf_stats) == SF_STATS_WORDS * 8, "sf_stats layout");
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->sp.stats + (size_t)replica * SF_STATS_WORDS, sizeof(sf_stats), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }

@@ -439,7 +439,7 @@ struct Ctl {
     int32_t done;
     int32_t wave_leaf[MAXW];
     uint32_t wave_src[MAXW], wave_cnt[MAXW];
-    uint64_t st[8];
+    uint64_t st[SF_STATS_WORDS];
     uint64_t trace_n;
 };
 
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
             c.cur[k] = g_score[k];
             c.best_sol[k] = m.best_score[(size_t)r * 4 + k];
         }
-        for (int k = 0; k < 8; ++k) c.st[k] = 0;
+        for (int k = 0; k < SF_STATS_WORDS; ++k) c.st[k] = 0;
         c.trace_n = 0;
     }
     __syncthreads();
@@ -782,13 +782,15 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
             // C4: union replay by wave 0 (acceptor + forager in cursor order)
             if (wave == 0) {
                 if (lane == 0) {
-                    uint64_t scored = 0;
+                    uint64_t scored = 0, nsrc = 0;
                     for (uint32_t w2 = 0; w2 < NW; ++w2)
                         if (c.wave_leaf[w2] >= 0) {
                             c.tail[c.wave_leaf[w2]] += c.wave_cnt[w2];
                             scored += c.wave_cnt[w2];
+                            ++nsrc;
                         }
                     c.st[7] += scored;
+                    c.st[8] += nsrc;
                 }
                 __builtin_amdgcn_wave_barrier();
                 // wave-uniform replay state kept in registers
@@ -1064,7 +1066,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
     }
     if (tid == 0) {
         if (!p.dry_run)
-            for (int k = 0; k < 8; ++k) p.stats[(size_t)r * 8 + k] += c.st[k];
+            for (int k = 0; k < SF_STATS_WORDS; ++k) p.stats[(size_t)r * SF_STATS_WORDS + k] += c.st[k];
         if (tracing) *p.trace_count = (int64_t)c.trace_n;
     }
 }

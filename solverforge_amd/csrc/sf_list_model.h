@@ -12,6 +12,7 @@ constexpr uint32_t NODE_NONE = 0xFFFFFFFFu;
 constexpr uint32_t QCAP = 1024;      // per-leaf candidate ring capacity (power of two)
 constexpr uint32_t ORD_INTER_BASE = 1u << 20;
 constexpr int64_t MAX_PACKED_DISTANCE = (int64_t)1 << 40;  // (distance << 24 | ordinal) key packing
+constexpr int SF_STATS_WORDS = 10;  // sf_stats as u64 words
 
 // Immutable problem facts + constraint wiring + per-replica state base pointers (SoA in HBM).
 struct ListModel {
@@ -56,6 +57,7 @@ struct SearchParams {
     int32_t order;        // sf_selection_order
     int32_t dry_run;      // 1: enumerate+score one step, no state change
     int32_t replica_base; // replica of block 0 (single-replica launches)
+    int32_t n_launch;     // replicas covered by this launch (wave engine: grid rounding)
     int64_t n_steps;
     uint64_t random_seed; // replica r uses random_seed + r
     // dry-run explicit context
@@ -69,7 +71,7 @@ struct SearchParams {
     int32_t* la_idx;           // [R]
     uint64_t* step_index;      // [R] phase step counter
     uint64_t* seed_draws;      // [R]
-    uint64_t* stats;           // [R][8]  (sf_stats layout)
+    uint64_t* stats;           // [R][SF_STATS_WORDS]  (sf_stats layout)
     int32_t* has_best;         // [R]
     // trace of replica `trace_replica` (TRACE kernels only)
     int32_t trace_replica;

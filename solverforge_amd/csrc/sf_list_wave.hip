@@ -1,0 +1,720 @@
+// Wave-per-replica search engine (gfx950 / CDNA4, wave64) for the list-variable hot path.
+//
+// One 64-lane wavefront owns one search replica for the whole launch: its routes (flat CSR),
+// per-route loads, node -> (route, position) table, per-leaf entity-order tables and the
+// per-leaf candidate rings live in that wave's private slice of LDS.  Everything inside a
+// replica is wave-synchronous (ballot / shuffle / prefix-scan, LDS in program order), so the
+// kernel contains NO workgroup barrier; the CU hides a wave's memory latency behind the other
+// replicas resident on it.  Same reference semantics as the block engine in
+// sf_list_kernels.hip (citations there); what differs is the GPU formulation:
+//
+//  * generation reads a PRESORTED neighbour index (k_nbr_presort: every matrix row sorted by
+//    (distance, node) once at sf_initialize, the matrix is an immutable problem fact) instead
+//    of scanning the whole matrix row per source: the stable bounded top-k of
+//    nearby_list_support.rs:3-34 is then "walk the row in distance order until max_nearby
+//    valid destinations are complete", usually one 64-entry chunk;
+//  * the (distance, enumeration ordinal) order inside a chunk is recovered by counting
+//    inversions inside equal-distance groups (lanes are already distance-sorted), not by
+//    serial insertion;
+//  * trial scoring happens at replay time with all 64 lanes busy (lane i = i-th candidate of
+//    the union cursor order), so the rings only hold move coordinates.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sf_list_model.h"
+
+namespace sf {
+
+constexpr uint32_t RC = 128;  // ring capacity per leaf (>= 64 + max_nearby - 1, power of two)
+constexpr int WPB = 1;        // waves (= replicas) per workgroup
+
+struct NbrIndex {
+    const uint64_t* keys;  // [dim][dim]  (distance << 24 | node), ascending per row; finite legs only
+    const uint32_t* cnt;   // [dim]       finite entries per row
+};
+
+// wavefront-scope ordering of LDS/global traffic between lanes of one wave (no instruction cost:
+// a wave executes in lockstep and its DS/VMEM queues are in order; this pins the compiler).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | (uint64_t)uni((uint32_t)v);
+}
+
+// ---------------------------------------------------------------------------------------
+// Neighbour index: bitonic sort of every matrix row in LDS.  grid = dim rows.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__ mat, int dim, int P,
+                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* sk = (uint64_t*)smem;
+    __shared__ unsigned int s_cnt;
+    const int row = blockIdx.x;
+    const int64_t* rp = mat + (size_t)row * dim;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (int t = threadIdx.x; t < P; t += blockDim.x) {
+        uint64_t k = ~0ULL;
+        if (t < dim) {
+            const int64_t v = rp[t];
+            if (v >= 0 && v != UNREACHABLE) {  // finite_distance (problem_data.rs:44-47)
+                k = ((uint64_t)v << 24) | (uint64_t)(uint32_t)t;
+                ++mine;
+            }
+        }
+        sk[t] = k;
+    }
+    atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const int lo = (t / stride) * 2 * stride + (t % stride);
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t a = sk[lo], b = sk[hi];
+                if ((a > b) == up) {
+                    sk[lo] = b;
+                    sk[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (int t = threadIdx.x; t < dim; t += blockDim.x) keys[(size_t)row * dim + t] = sk[t];
+    if (threadIdx.x == 0) cnt[row] = s_cnt;
+}
+
+// LDS carve of ONE replica (bytes); mirrored on the host.
+struct WCarve {
+    size_t load, visits, off, node, ring, slotbase, routeat, rankof, total;
+    __host__ __device__ WCarve(int V, int n_cap, int dim) {
+        size_t o = 0;
+        load = o;
+        o = align_up(o + sizeof(int64_t) * V, 16);
+        visits = o;
+        o = align_up(o + sizeof(uint32_t) * n_cap, 16);
+        off = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        node = o;
+        o = align_up(o + sizeof(uint32_t) * dim, 16);
+        ring = o;
+        o = align_up(o + sizeof(uint32_t) * 2 * RC * MAX_LEAVES, 16);
+        slotbase = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1) * MAX_LEAVES, 16);
+        routeat = o;
+        o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
+        rankof = o;
+        o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
+        total = o;
+    }
+};
+
+// One neighbour-row entry seen from source (se, sp) of a leaf: up to two consecutive keys
+// (destination slot dp, and the end slot of its route when the node is the last element).
+struct NearbyItem {
+    uint32_t w;     // number of valid keys (0, 1, 2)
+    uint32_t ord;   // enumeration ordinal of the first valid key (the second is ord + 1)
+    uint32_t pay0;  // (route << 16 | position) of the first valid key
+    uint32_t pay1;  // second key
+};
+
+__device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot, uint32_t se, uint32_t sp,
+                                                  uint32_t len, uint32_t k, const uint32_t* s_off,
+                                                  const uint32_t* sb, const uint16_t* ro) {
+    NearbyItem it{0u, 0u, 0u, 0u};
+    if (slot == NODE_NONE) return it;
+    const uint32_t r2 = slot >> 16, dp = slot & 0xFFFFu;
+    if (is_change) {  // nearby_change.rs:133-195
+        if (r2 == se) {
+            const bool v0 = dp != sp && dp != sp + 1;
+            const bool v1 = dp + 1 == len && len != sp + 1;  // end slot `len` probes element len-1
+            if (v0) {
+                it.ord = dp;
+                it.pay0 = slot;
+                it.w = 1;
+                if (v1) {
+                    it.pay1 = (r2 << 16) | len;
+                    it.w = 2;
+                }
+            } else if (v1) {
+                it.ord = len;
+                it.pay0 = (r2 << 16) | len;
+                it.w = 1;
+            }
+        } else {
+            const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
+            it.ord = ORD_INTER_BASE + sb[ro[r2]] + dp;
+            it.pay0 = slot;
+            it.w = 1;
+            if (dp + 1 == len2) {
+                it.pay1 = (r2 << 16) | len2;
+                it.w = 2;
+            }
+        }
+    } else {  // nearby_swap.rs: intra partners after the source, inter only higher-ranked entities
+        if (r2 == se) {
+            if (dp > sp) {
+                it.ord = dp;
+                it.pay0 = slot;
+                it.w = 1;
+            }
+        } else {
+            const uint32_t rk = ro[r2];
+            if (rk > k) {
+                it.ord = ORD_INTER_BASE + sb[rk] + dp;
+                it.pay0 = slot;
+                it.w = 1;
+            }
+        }
+    }
+    return it;
+}
+
+// Committed move application on the wave's LDS state (ListChange / ListSwap do_move).
+__device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint32_t* visits, uint32_t* off,
+                                                     int64_t* load, int kind, uint32_t a, uint32_t i, uint32_t b,
+                                                     uint32_t j) {
+    const uint32_t lane = threadIdx.x & 63u;
+    if (kind == 2) {
+        const uint32_t P = off[a] + i, Q = off[b] + j;
+        const uint32_t x = visits[P];
+        wave_sync();
+        if (P < Q) {  // [P, Q-2] <- t+1 ; Q-1 <- x   (ascending chunks: reads run ahead of writes)
+            for (uint32_t t0 = P; t0 < Q; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                uint32_t nv = 0;
+                if (t < Q) nv = (t + 1 < Q) ? visits[t + 1] : x;
+                wave_sync();
+                if (t < Q) visits[t] = nv;
+                wave_sync();
+            }
+        } else if (P > Q) {  // (Q, P] <- t-1 ; Q <- x   (descending chunks)
+            for (uint32_t c0 = 0; c0 <= P - Q; c0 += 64) {
+                const uint32_t dd = c0 + lane;
+                const bool in = dd <= P - Q;
+                const uint32_t t = P - (in ? dd : 0u);
+                uint32_t nv = 0;
+                if (in) nv = t > Q ? visits[t - 1] : x;
+                wave_sync();
+                if (in) visits[t] = nv;
+                wave_sync();
+            }
+        }
+        if (a != b) {
+            for (uint32_t rr = lane; rr <= (uint32_t)m.V; rr += 64) {
+                if (a < b && rr > a && rr <= b) off[rr] -= 1;
+                if (a > b && rr > b && rr <= a) off[rr] += 1;
+            }
+            if (lane == 0 && m.demand) {
+                const int64_t dx = (int64_t)m.demand[x];
+                load[a] = wsub(load[a], dx);
+                load[b] = wadd(load[b], dx);
+            }
+        }
+    } else if (kind == 3) {
+        if (lane == 0) {
+            const uint32_t pa = off[a] + i, pb = off[b] + j;
+            const uint32_t x = visits[pa], y = visits[pb];
+            visits[pa] = y;
+            visits[pb] = x;
+            if (a != b && m.demand) {
+                const int64_t dx = (int64_t)m.demand[x], dy = (int64_t)m.demand[y];
+                load[a] = wadd(wsub(load[a], dx), dy);
+                load[b] = wadd(wsub(load[b], dy), dx);
+            }
+        }
+    }
+    wave_sync();
+}
+
+template <int L, bool TRACE>
+__global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int rr = (int)(blockIdx.x * WPB + (threadIdx.x >> 6));
+    if (rr >= p.n_launch) return;  // no workgroup barrier anywhere below
+    const int r = rr + p.replica_base;
+    const int V = m.V;
+    const WCarve cv(V, m.n_cap, m.dim);
+    unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
+    int64_t* s_load = (int64_t*)(mem + cv.load);
+    uint32_t* s_visits = (uint32_t*)(mem + cv.visits);
+    uint32_t* s_off = (uint32_t*)(mem + cv.off);
+    uint32_t* node_slot = (uint32_t*)(mem + cv.node);
+    uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][RC][2]
+    uint32_t* slot_base = (uint32_t*)(mem + cv.slotbase);
+    uint16_t* route_at = (uint16_t*)(mem + cv.routeat);
+    uint16_t* rank_of = (uint16_t*)(mem + cv.rankof);
+
+    uint32_t* g_visits = m.visits + (size_t)r * m.n_cap;
+    uint32_t* g_off = m.off + (size_t)r * (V + 1);
+    int64_t* g_load = m.load + (size_t)r * V;
+    int64_t* g_score = m.score + (size_t)r * 4;
+    const bool tracing = TRACE && r == p.trace_replica;
+
+    // leaf constants (no dynamic indexing of the kernarg block)
+    const int n_leaves = p.n_leaves;
+    const uint32_t K0 = (uint32_t)p.leaf[0].max_nearby, K1 = n_leaves > 1 ? (uint32_t)p.leaf[1].max_nearby : 1u;
+    const bool chg0 = p.leaf[0].kind == 16, chg1 = n_leaves > 1 && p.leaf[1].kind == 16;
+    const uint64_t desc0 = (uint64_t)p.leaf[0].descriptor, desc1 = n_leaves > 1 ? (uint64_t)p.leaf[1].descriptor : 0;
+
+    // ---- load replica state into LDS ----
+    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
+    for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = g_load[t];
+    for (uint32_t t = lane; t < (uint32_t)m.dim; t += 64) node_slot[t] = NODE_NONE;
+    wave_sync();
+    const uint32_t total0 = uni(s_off[V]);
+    for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = g_visits[t];
+    wave_sync();
+    for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
+        const uint32_t o = s_off[v], len = s_off[v + 1] - o;
+        for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
+    }
+    wave_sync();
+
+    int64_t cur[L], best_sol[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        cur[k] = g_score[k];
+        best_sol[k] = m.best_score[(size_t)r * 4 + k];
+    }
+    uint64_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_nd = 0, st_scored = 0, st_sources = 0;
+    uint64_t trace_n = 0;
+    const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
+    const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
+    const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
+
+    for (int64_t step = 0; step < p.n_steps; ++step) {
+        // ---- (A) step start (step.rs:60-74) -------------------------------------------------
+        uint64_t sidx, sseed;
+        if (p.dry_run) {
+            sidx = p.dry_step_index;
+            sseed = p.dry_step_seed;
+        } else {
+            sidx = step_index0 + (uint64_t)step;
+            const uint64_t draw = seed_draws0 + (uint64_t)step;
+            if (p.explicit_seeds && (int64_t)draw < p.n_explicit)
+                sseed = p.explicit_seeds[(size_t)r * p.n_explicit + draw];
+            else
+                sseed = step_seed(p.random_seed + (uint64_t)r, draw);
+        }
+        sidx = uni64(sidx);
+        sseed = uni64(sseed);
+        const StreamCtx ctx{sidx, sseed, p.order};
+        ScoreV<L> late;
+#pragma unroll
+        for (int k = 0; k < L; ++k) late.v[k] = 0;
+        const int la_slot = p.dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
+        if (p.acceptor == 1) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
+        }
+        int has_best = 0;
+        uint64_t equal_count = 0;
+        uint32_t accepted = 0, pulls = 0;
+        ScoreV<L> best;
+#pragma unroll
+        for (int k = 0; k < L; ++k) best.v[k] = 0;
+        uint32_t best_m0 = 0, best_m1 = 0;
+        int best_leaf = 0;
+        uint32_t head0 = 0, head1 = 0, tail0 = 0, tail1 = 0;
+        const uint32_t total = uni(s_off[V]);
+        uint32_t left0 = total, left1 = n_leaves > 1 ? total : 0u;  // sources not yet generated
+        int ex0 = 0, ex1 = n_leaves > 1 ? 0 : 1;
+        uint32_t gk0 = 0, gk1 = 0, go0 = 0, go1 = 0;  // source iterator (entity rank, offset)
+        // union: >1 leaf => StratifiedRandom, equal weights (vec_union.rs:229-245); with two children
+        // the stride is always 1, so the order is first, other, first, ...
+        const uint32_t first_leaf = n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u;
+
+        // ---- (B) per-leaf entity order tables (slot.rs:468-499) --------------------------------
+        for (int l = 0; l < n_leaves; ++l) {
+            const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
+            uint32_t pst, psd;
+            ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
+            pst = uni(pst);
+            psd = uni(psd);
+            uint16_t* ra = route_at + l * V;
+            uint16_t* ro = rank_of + l * V;
+            uint32_t* sb = slot_base + l * (V + 1);
+            for (uint32_t k = lane; k < (uint32_t)V; k += 64) {
+                const uint32_t e = (uint32_t)(((uint64_t)pst + (uint64_t)k * psd) % (uint32_t)V);
+                ra[k] = (uint16_t)e;
+                ro[e] = (uint16_t)k;
+            }
+            wave_sync();
+            uint32_t carry = 0;  // slot_base[k] = sum_{k'<k} (len(route_at[k']) + 1)
+            for (uint32_t base = 0; base < (uint32_t)V; base += 64) {
+                const uint32_t k = base + lane;
+                uint32_t v = 0;
+                if (k < (uint32_t)V) {
+                    const uint32_t e = ra[k];
+                    v = s_off[e + 1] - s_off[e] + 1;
+                }
+                const uint32_t inc = wave_incl_scan(v);
+                if (k < (uint32_t)V) sb[k] = carry + inc - v;
+                carry += __shfl(inc, 63);
+            }
+            if (lane == 0) sb[V] = carry;
+        }
+        wave_sync();
+
+        // ---- (C) candidate rounds: fill the rings, replay one 64-wide batch, repeat -----------
+        int done = 0;
+        while (!done) {
+            // C1: generation.  Keep >= 32 (both leaves live) / >= 64 (one leaf) candidates pending.
+            const uint32_t target = (!ex0 && !ex1) ? 32u : 64u;
+            for (int l = 0; l < n_leaves; ++l) {
+                for (;;) {
+                    const uint32_t left = l ? left1 : left0;
+                    const uint32_t pend = l ? tail1 - head1 : tail0 - head0;
+                    if ((l ? ex1 : ex0) || left == 0 || pend >= target) break;
+                    // -- next source of leaf l (selection order: entity rank, then offset) --
+                    const bool is_change = l ? chg1 : chg0;
+                    const uint32_t K = l ? K1 : K0;
+                    const uint16_t* ra = route_at + l * V;
+                    const uint16_t* ro = rank_of + l * V;
+                    const uint32_t* sb = slot_base + l * (V + 1);
+                    uint32_t k = l ? gk1 : gk0, o = l ? go1 : go0;
+                    uint32_t se = 0, len = 0;
+                    for (;;) {  // skip empty routes
+                        se = uni((uint32_t)ra[k]);
+                        len = uni(s_off[se + 1] - s_off[se]);
+                        if (o < len) break;
+                        ++k;
+                        o = 0;
+                    }
+                    const uint64_t src_salt = (is_change ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^
+                                              (uint64_t)se ^ (l ? desc1 : desc0);
+                    const uint32_t sp = uni(ctx.selection_index(o, len, src_salt));
+                    const uint32_t sx = uni(s_visits[s_off[se] + sp]);
+                    const uint32_t cnt_row = uni(nb.cnt[sx]);
+                    const uint64_t* rowk = nb.keys + (size_t)sx * (size_t)m.dim;
+                    const uint32_t tl = l ? tail1 : tail0;
+                    uint32_t* rq = ring + (size_t)l * RC * 2;
+                    const uint32_t mv0 = (se << 16) | sp;
+                    uint32_t need = K, emitted = 0, base = 0;
+                    while (need > 0 && base < cnt_row) {
+                        const uint32_t jj = base + lane;
+                        const bool have = jj < cnt_row;
+                        const uint64_t key = have ? rowk[jj] : ~0ULL;
+                        const uint32_t y = (uint32_t)key & 0xFFFFFFu;
+                        const uint32_t dlo = (uint32_t)(key >> 24), dhi = (uint32_t)(key >> 56);
+                        NearbyItem it{0u, 0u, 0u, 0u};
+                        if (have) it = nearby_item(is_change, node_slot[y], se, sp, len, k, s_off, sb, ro);
+                        // equal-distance groups are contiguous lane ranges
+                        const uint32_t pdlo = __shfl_up(dlo, 1), pdhi = __shfl_up(dhi, 1);
+                        const bool is_start = have && (lane == 0 || dlo != pdlo || dhi != pdhi);
+                        const uint64_t startmask = __ballot(is_start);
+                        const uint32_t nhave = (uint32_t)__popcll(__ballot(have));
+                        const bool more = base + 64 < cnt_row;
+                        const uint32_t fo = 63u - (uint32_t)__clzll((unsigned long long)startmask);  // first lane of the last group
+                        if (more && fo == 0) {
+                            // one distance group wider than a chunk (degenerate ties): exact serial
+                            // insertion top-k over the rest of the row.
+                            TopK tk{~0ULL, 0u, ~0ULL};
+                            for (uint32_t b2 = base; b2 < cnt_row; b2 += 64) {
+                                const uint32_t j2 = b2 + lane;
+                                const bool hv = j2 < cnt_row;
+                                const uint64_t ky = hv ? rowk[j2] : ~0ULL;
+                                NearbyItem i2{0u, 0u, 0u, 0u};
+                                if (hv) i2 = nearby_item(is_change, node_slot[(uint32_t)ky & 0xFFFFFFu], se, sp, len, k, s_off, sb, ro);
+                                const uint64_t hk = ky & ~0xFFFFFFULL;
+                                topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
+                                topk_offer(tk, need, i2.w == 2 ? (hk | (i2.ord + 1)) : ~0ULL, i2.pay1);
+                            }
+                            const uint32_t cnt = (uint32_t)__popcll(__ballot(lane < need && tk.key != ~0ULL));
+                            if (lane < cnt) {
+                                const uint32_t qi = (tl + emitted + lane) & (RC - 1);
+                                rq[qi * 2] = mv0;
+                                rq[qi * 2 + 1] = tk.pay;
+                            }
+                            emitted += cnt;
+                            need = 0;
+                            break;
+                        }
+                        const uint32_t nclosed = more ? fo : nhave;  // lanes [0, nclosed) belong to complete groups
+                        const bool closed = lane < nclosed;
+                        const uint32_t wc = closed ? it.w : 0u;
+                        const uint32_t inc = wave_incl_scan(wc);
+                        const uint32_t Wc = uni(__shfl(inc, 63));
+                        if (Wc > 0) {
+                            // sorted position = weight before me, corrected by the inversions inside my group
+                            const uint32_t gid = (uint32_t)__popcll(startmask & lanemask_le(lane));
+                            const uint32_t packed = (it.ord << 2) | wc;
+                            int32_t pos = (int32_t)(inc - wc);
+                            for (uint32_t d = 1; d < 64; ++d) {
+                                const uint32_t g_dn = __shfl_down(gid, d);
+                                const bool same_dn = closed && lane + d < nclosed && g_dn == gid;
+                                if (!__ballot(same_dn)) break;
+                                const uint32_t p_dn = __shfl_down(packed, d);
+                                const uint32_t g_up = __shfl_up(gid, d), p_up = __shfl_up(packed, d);
+                                const bool same_up = closed && lane >= d && g_up == gid;
+                                if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
+                                if (same_up && (p_up >> 2) > it.ord) pos -= (int32_t)(p_up & 3u);
+                            }
+                            if (wc >= 1 && (uint32_t)pos < need) {
+                                const uint32_t qi = (tl + emitted + (uint32_t)pos) & (RC - 1);
+                                rq[qi * 2] = mv0;
+                                rq[qi * 2 + 1] = it.pay0;
+                            }
+                            if (wc == 2 && (uint32_t)pos + 1 < need) {
+                                const uint32_t qi = (tl + emitted + (uint32_t)pos + 1) & (RC - 1);
+                                rq[qi * 2] = mv0;
+                                rq[qi * 2 + 1] = it.pay1;
+                            }
+                            const uint32_t ne = Wc < need ? Wc : need;
+                            emitted += ne;
+                            need -= ne;
+                        }
+                        base += more ? nclosed : 64u;
+                    }
+                    // commit iterator + ring tail
+                    ++o;
+                    if (l) {
+                        gk1 = k;
+                        go1 = o;
+                        tail1 = tl + emitted;
+                        left1 = left - 1;
+                    } else {
+                        gk0 = k;
+                        go0 = o;
+                        tail0 = tl + emitted;
+                        left0 = left - 1;
+                    }
+                    st_sources += 1;
+                }
+            }
+            wave_sync();
+
+            // C2: replay one batch in union cursor order: trial score, acceptor, forager
+            {
+                const bool live0 = !ex0, live1 = !ex1;
+                if (!live0 && !live1) {
+                    done = 1;
+                    break;
+                }
+                uint32_t lf, idx;
+                if (live0 && live1) {
+                    const uint32_t l0 = (first_leaf + pulls) & 1u;
+                    lf = (l0 + lane) & 1u;
+                    idx = (lf ? head1 : head0) + (lane >> 1);
+                } else {
+                    lf = live0 ? 0u : 1u;
+                    idx = (lf ? head1 : head0) + lane;
+                }
+                const bool avail = (int32_t)((lf ? tail1 : tail0) - idx) > 0;
+                const uint64_t availmask = __ballot(avail);
+                const uint32_t nvalid = availmask == ~0ULL ? 64u : (uint32_t)(__ffsll((unsigned long long)~availmask) - 1);
+                if (nvalid == 0) {
+                    // the scheduler discovers an exhausted child at this pull (vec_union.rs:334-362);
+                    // a leaf with sources left was refilled above, so an empty ring means exhausted.
+                    const uint32_t lf0 = uni(__shfl(lf, 0));
+                    if (lf0)
+                        ex1 = 1;
+                    else
+                        ex0 = 1;
+                    continue;
+                }
+                const bool valid = lane < nvalid;
+                uint32_t m0 = 0, m1 = 0;
+                ListDelta dl{0, 0, false};
+                if (valid) {
+                    const uint32_t qi = idx & (RC - 1);
+                    const uint32_t* rq = ring + ((size_t)lf * RC + qi) * 2;
+                    m0 = rq[0];
+                    m1 = rq[1];
+                    const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
+                    if (lf ? chg1 : chg0)
+                        dl = eval_list_change(m, s_visits, s_off, s_load, a, i, b, j);
+                    else
+                        dl = eval_list_swap(m, s_visits, s_off, s_load, a, i, b, j);
+                }
+                const ScoreV<L> sc = apply_delta<L>(m, cur, dl);
+                ScoreV<L> curv;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) curv.v[kk] = cur[kk];
+                const bool doable = valid && dl.doable;
+                bool acc = false;
+                if (doable) {
+                    if (p.acceptor == 0)
+                        acc = score_cmp<L>(sc, curv) > 0;
+                    else if (p.acceptor == 1)
+                        acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
+                }
+                uint64_t accmask = __ballot(acc);
+                uint32_t nconsumed = nvalid;
+                if (p.forager != 2) {
+                    const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
+                    const uint32_t pre = (uint32_t)__popcll(accmask & lanemask_le(lane));
+                    const uint64_t cutmask = __ballot(acc && pre == remaining);
+                    if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
+                }
+                const bool consumed = lane < nconsumed;
+                acc = acc && consumed;
+                accmask = __ballot(acc);
+                if (accmask) {
+                    if (p.forager == 1) {
+                        if (!has_best) {
+                            const int sel = __ffsll((unsigned long long)accmask) - 1;
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)shfl_u64((uint64_t)sc.v[kk], sel);
+                            best_m0 = __shfl(m0, sel);
+                            best_m1 = __shfl(m1, sel);
+                            best_leaf = (int)__shfl(lf, sel);
+                            has_best = 1;
+                        }
+                    } else {
+                        const ScoreV<L> M = wave_max_score<L>(sc, acc);
+                        const int cm = has_best ? score_cmp<L>(M, best) : 1;
+                        if (cm >= 0) {
+                            const bool newmax = cm > 0;
+                            const uint64_t eq_base = newmax ? 0 : equal_count;
+                            const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
+                            const uint64_t eq = __ballot(in_eq);
+                            const uint32_t rank = (uint32_t)__popcll(eq & lanemask_le(lane));
+                            const uint64_t cntq = eq_base + rank;
+                            const bool pick = in_eq && ((newmax && rank == 1) ||
+                                                        (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
+                            const uint64_t pm = __ballot(pick);
+                            if (pm) {
+                                const int sel = 63 - __clzll((unsigned long long)pm);
+                                best_m0 = __shfl(m0, sel);
+                                best_m1 = __shfl(m1, sel);
+                                best_leaf = (int)__shfl(lf, sel);
+                            }
+                            best = M;
+                            equal_count = eq_base + (uint64_t)__popcll(eq);
+                            has_best = 1;
+                        }
+                    }
+                }
+                const uint32_t nacc = (uint32_t)__popcll(accmask);
+                accepted += nacc;
+                st_gen += nconsumed;
+                st_acc += nacc;
+                st_scored += nvalid;
+                const uint32_t ndo = (uint32_t)__popcll(__ballot(consumed && doable));
+                st_calc += ndo;
+                st_nd += nconsumed - ndo;
+                if (tracing && consumed) {
+                    const uint64_t ti = trace_n + lane;
+                    if ((int64_t)ti < p.trace_cap) {
+                        int32_t* tm = p.trace_moves + ti * 6;
+                        tm[0] = (lf ? chg1 : chg0) ? 2 : 3;
+                        tm[1] = (int32_t)(m0 >> 16);
+                        tm[2] = (int32_t)(m0 & 0xFFFFu);
+                        tm[3] = (int32_t)(m1 >> 16);
+                        tm[4] = (int32_t)(m1 & 0xFFFFu);
+                        tm[5] = -1;
+                        for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
+                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                    }
+                }
+                if (tracing) trace_n += nconsumed;
+                const uint32_t c1 = (uint32_t)__popcll(__ballot(consumed && lf == 1u));
+                head1 += c1;
+                head0 += nconsumed - c1;
+                pulls += nconsumed;
+                if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
+            }
+        }
+
+        // ---- (D) commit the forager's pick (step.rs:122-221) ----------------------------------
+        const bool applied = has_best && !p.dry_run;
+        if (applied) {
+            const int kind = (best_leaf ? chg1 : chg0) ? 2 : 3;
+            const uint32_t a = uni(best_m0 >> 16), i = uni(best_m0 & 0xFFFFu);
+            const uint32_t b = uni(best_m1 >> 16), j = uni(best_m1 & 0xFFFFu);
+            if (tracing && lane == 0) {
+                p.trace_applied[0] = 1;
+                p.trace_applied[1] = kind;
+                p.trace_applied[2] = (int32_t)a;
+                p.trace_applied[3] = (int32_t)i;
+                p.trace_applied[4] = (int32_t)b;
+                p.trace_applied[5] = (int32_t)j;
+                p.trace_applied[6] = -1;
+            }
+            apply_list_move_wave(m, s_visits, s_off, s_load, kind, a, i, b, j);
+            {  // refresh node -> (route, position) for the two touched routes
+                const uint32_t oa = s_off[a], la = s_off[a + 1] - oa;
+                const uint32_t ob = s_off[b], lb = s_off[b + 1] - ob;
+                for (uint32_t t = lane; t < la + (a != b ? lb : 0u); t += 64) {
+                    if (t < la)
+                        node_slot[s_visits[oa + t]] = (a << 16) | t;
+                    else
+                        node_slot[s_visits[ob + (t - la)]] = (b << 16) | (t - la);
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) cur[kk] = best.v[kk];
+            st_applied += 1;
+        } else if (tracing && lane == 0) {
+            p.trace_applied[0] = 0;
+        }
+        if (!p.dry_run) {
+            // update_best_solution (scope_progress.rs:89-107): clone on strict improvement
+            bool improved = false;
+            if (applied) {
+                ScoreV<L> cs, bs;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    cs.v[kk] = cur[kk];
+                    bs.v[kk] = best_sol[kk];
+                }
+                improved = score_cmp<L>(cs, bs) > 0;
+            }
+            if (improved) {
+                const uint32_t tot = uni(s_off[V]);
+                for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = s_visits[t];
+                for (uint32_t t = lane; t <= (uint32_t)V; t += 64) m.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
+            }
+            // acceptor.step_ended(last_step_score) always (step.rs:216-221)
+            if (p.acceptor == 1 && lane == 0) {
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
+            }
+            wave_sync();
+            st_steps += 1;
+        }
+    }
+
+    // ---- write back ----------------------------------------------------------------------
+    if (!p.dry_run) {
+        const uint32_t tot = uni(s_off[V]);
+        for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
+        for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
+        for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = s_load[t];
+        if (lane == 0) {
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) {
+                g_score[kk] = cur[kk];
+                p.last_step_score[(size_t)r * 4 + kk] = cur[kk];
+                m.best_score[(size_t)r * 4 + kk] = best_sol[kk];
+            }
+            p.la_idx[r] = (int32_t)(((int64_t)la_idx0 + p.n_steps) % p.la_size);
+            p.step_index[r] = step_index0 + (uint64_t)p.n_steps;
+            p.seed_draws[r] = seed_draws0 + (uint64_t)p.n_steps;
+            uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
+            gs[0] += st_steps;
+            gs[1] += st_gen;
+            gs[2] += st_gen;
+            gs[3] += st_acc;
+            gs[4] += st_applied;
+            gs[5] += st_calc;
+            gs[6] += st_nd;
+            gs[7] += st_scored;
+            gs[8] += st_sources;
+        }
+    }
+    if (tracing && lane == 0) *p.trace_count = (int64_t)trace_n;
+}
+
+}  // namespace sf

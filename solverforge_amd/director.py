@@ -31,6 +31,10 @@ class Forager:
     ACCEPTED_COUNT, FIRST_ACCEPTED, BEST_SCORE = 0, 1, 2
 
 
+class Engine:  # sf_engine_kind
+    AUTO, BLOCK, WAVE = 0, 1, 2
+
+
 class ConstraintKind:
     UNI_UNASSIGNED, CROSS_ADJACENT_EQUAL, CROSS_GROUP_EQUAL, CROSS_QUEENS = 1, 2, 3, 4
     NOT_EXISTS_FLATTENED, ROUTE_CAPACITY, ROUTE_DISTANCE = 5, 6, 7
@@ -176,6 +180,10 @@ class GpuScoreDirector:
         s = SolverConfigStruct(cfg.acceptor, cfg.late_acceptance_size, cfg.forager, cfg.accepted_count_limit,
                                int(cfg.random_ties), cfg.selection_order, cfg.random_seed)
         check(self._L.sf_solver_configure(self._h, C.byref(s)), self._h)
+
+    def set_engine(self, engine):
+        """Pick the fused-kernel mapping (Engine.AUTO / BLOCK / WAVE); results are identical."""
+        check(self._L.sf_solver_set_engine(self._h, engine), self._h)
 
     def set_step_seeds(self, seeds):
         if seeds is None:

@@ -5,11 +5,22 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+_ENGINE = {"value": 0}
+
+
+@pytest.fixture(params=["block", "wave"], autouse=True)
+def engine(request):
+    """Every parity test runs against both mappings of the fused search kernel."""
+    _ENGINE["value"] = {"block": 1, "wave": 2}[request.param]
+    yield request.param
+    _ENGINE["value"] = 0
+
 
 def _mk(oracle, problem, n_replicas=1, max_nearby=20, leaves=("nearby_change", "nearby_swap")):
     import solverforge_amd as sfa
 
     d = sfa.build_cvrp(problem, n_replicas=n_replicas, max_nearby=max_nearby, leaves=leaves)
+    d.set_engine(_ENGINE["value"])
     o = oracle.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
                           problem["customers"], problem["routes"])
     bits = 0
@@ -235,3 +246,51 @@ def test_cvrp_1000_properties(oracle):
         assert sorted(c for rt in routes for c in rt) == list(range(1, 1001))
         b = d.best_scores()[r]
         assert tuple(b) >= tuple(start[r])
+
+
+def test_degenerate_ties_wider_than_a_wave(oracle):
+    """All customers at one point: every distance group is wider than a 64-lane chunk, so the
+    wave engine's exact serial top-k fallback (and the block engine's row scan) must reproduce the
+    stable enumeration-order tie break."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(150, 9, 60, seed=12, coord_range=1)
+    assert int(p["matrix"].max()) == 0
+    d, o, bits = _mk(oracle, p)
+    d.configure(sfa.SolverConfig(random_seed=4))
+    d.calculate_score()
+    for step_index, step_seed in [(0, 1), (5, 99)]:
+        for order in (0, 3):
+            o.configure(leaves=bits, random_seed=4, selection_order=order)
+            gm, gs, gd = d.open_cursor(step_index, step_seed, selection_order=order)
+            om = o.enumerate(0, step_index, step_seed, order)
+            assert len(gm) == len(om) > 0
+            assert (_tuples(gm) == _tuples(om)).all()
+    o.configure(leaves=bits, random_seed=4)
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(10)
+    o.steps(10)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("max_nearby", [1, 5, 64])
+def test_max_nearby_extremes(oracle, max_nearby):
+    import solverforge_amd as sfa
+
+    p = _small(seed=13, n=90, v=8, cap=50)
+    d, o, bits = _mk(oracle, p, max_nearby=max_nearby)
+    o.configure(leaves=bits, max_nearby=max_nearby, random_seed=3)
+    d.configure(sfa.SolverConfig(random_seed=3))
+    d.calculate_score()
+    gm, gs, gd = d.open_cursor(2, 17, selection_order=3)
+    om = o.enumerate(0, 2, 17, 3)
+    assert (_tuples(gm) == _tuples(om)).all()
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(15)
+    o.steps(15)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
