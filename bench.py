@@ -8,6 +8,11 @@ resident on the GPU (the per-GPU batch of the seed portfolio).  
 CONSUMED candidates (`moves_evaluated`, the reference's counter definition, evaluation.rs:33-49),
 not the speculative tail; inputs are resident in HBM before the timed region.
 
+cpu_baseline: the oracle (C++ restatement of the reference algorithm, 1 thread) runs the SAME
+local-search step window as GPU replica 0 (same seed: warmup*ls_steps untimed steps, then
+steps*ls_steps timed steps, bounded by --cpu-seconds), and when it completes the window its
+working score is compared bit for bit with replica 0's (`extra.replica0_matches_cpu_oracle`).
+
 Multi-GPU (`torchrun ... bench.py --gpus N`): one process per GPU, independent seeds per rank
 (weak scaling, no data-path collective); after the timed region every rank contributes its best
 score to one RCCL all-gather over xGMI (sf_portfolio_allgather_best) and all ranks name the same
@@ -26,30 +31,43 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 # SURVEY.md §8(d) algorithmic bytes (C3): one scored list-change/list-swap candidate at route
-# length 10+10 = 368 B; nearby generation per source = (N+V)*12 B.
+# length 10+10 = 368 B; nearby generation per source = (N+V)*12 B (the reference probes every
+# destination slot of every source).  These are the bytes of the ALGORITHM as the reference states
+# it; the wave engine's presorted neighbour index touches far fewer.
 B_ALG_CANDIDATE = 368
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(problem, seconds, seed):
-    """The oracle (C++ restatement of the reference algorithm, 1 thread) on the same workload."""
+def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
+    """oracle/ timed on one host core over the same step window as GPU replica 0."""
     from oracle import sfo
 
     o = sfo.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
                        problem["customers"], problem["routes"])
     o.configure(leaves=sfo.LEAF_NEARBY_LIST_CHANGE | sfo.LEAF_NEARBY_LIST_SWAP, max_nearby=20, random_seed=seed)
     o.phase_start()
+    aligned = warm_steps <= 2000
+    if aligned and warm_steps:
+        o.steps(warm_steps)
+    m0 = o.stats()["moves_evaluated"]
+    done = 0
     t0 = time.perf_counter()
-    steps = o.steps_timed(seconds)
+    while done < timed_steps and time.perf_counter() - t0 < budget_s:
+        n = min(100, timed_steps - done)
+        o.steps(n)
+        done += n
     dt = time.perf_counter() - t0
-    st = o.stats()
+    moves = o.stats()["moves_evaluated"] - m0
+    first = warm_steps if aligned else 0
     return {
-        "value": st["moves_evaluated"] / dt,
+        "value": moves / dt,
         "unit": "moves/s",
         "cores": 1,
         "kind": "port",
-        "sample": f"{steps} local-search steps ({st['moves_evaluated']} moves) of the same CVRP-1000 workload, "
-                  f"seed {seed}, {dt:.1f}s on 1 host core",
+        "sample": f"local-search steps [{first}, {first + done}) of the same CVRP workload, seed {seed} "
+                  f"(= GPU replica 0's search): {moves} moves in {dt:.1f}s on 1 host core",
+        "steps": done,
+        "working_score": [int(v) for v in o.score()[:2]] if (aligned and done == timed_steps) else None,
         "best_score": [int(v) for v in o.best_score()[:2]],
     }
 
@@ -59,14 +77,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=512, help="independent searches resident per GPU")
-    ap.add_argument("--ls-steps", type=int, default=40, help="local-search steps per launch")
+    ap.add_argument("--replicas", type=int, default=3072, help="independent searches resident per GPU")
+    ap.add_argument("--ls-steps", type=int, default=200, help="local-search steps per launch")
     ap.add_argument("--customers", type=int, default=1000)
     ap.add_argument("--vehicles", type=int, default=100)
     ap.add_argument("--capacity", type=int, default=55)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--engine", choices=["auto", "block", "wave"], default="auto")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve-seconds", type=float, default=0.0, help="extra: timed solve after the bench (best score)")
     args = ap.parse_args()
@@ -77,7 +95,6 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist_mod  # plumbing only: rendezvous + barrier (gloo, CPU tensors)
-        import torch
 
         dist = dist_mod
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -90,10 +107,11 @@ def main():
 
     problem = datasets.make_cvrp(args.customers, args.vehicles, args.capacity, seed=args.seed)
     d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank)
-    # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
     d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
+    # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
     d.configure(sfa.SolverConfig(random_seed=args.seed + rank * args.replicas))
     start_score = d.calculate_score()[0].tolist()
+    engine = {1: "block", 2: "wave"}[d.engine()]
     d.phase_start()
 
     def barrier():
@@ -110,7 +128,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         d.solve_steps(args.ls_steps, sync=False)
-    d.sync()
+    barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
@@ -118,9 +136,10 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms, launches = d.profile_solve()  # HIP events on the context stream
+    kernel_ms, launches = d.profile_solve()  # HIP events on the context stream (the launch stream)
     after = d.total_stats()
     delta = {k: after[k] - before[k] for k in after}
+    replica0_score = [int(v) for v in d.calculate_score()[0]]
 
     moves_local = delta["moves_evaluated"]
     scored_local = delta["candidates_scored"]
@@ -158,11 +177,17 @@ def main():
             exchange = f"gloo-fallback ({type(e).__name__}: {e})"
 
     if rank == 0:
-        n_sources = scored_local / 20.0  # every nearby source keeps <= max_nearby(20) candidates
-        gen_bytes = n_sources * (args.customers + args.vehicles) * 12
-        alg_bytes = scored_local * B_ALG_CANDIDATE + gen_bytes
+        gen_bytes_per_source = (args.customers + args.vehicles) * 12
+        alg_bytes = scored_local * B_ALG_CANDIDATE + delta["sources_scanned"] * gen_bytes_per_source
         avg_launch_ms = kernel_ms / max(launches, 1)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        kernel = "k_list_search_wave<2,false>" if engine == "wave" else "k_list_search<2,false>"
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{engine}.json")
+        if os.path.exists(tpath):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
+            tj = json.load(open(tpath))
+            if tj.get("replicas") == args.replicas and tj.get("ls_steps") == args.ls_steps:
+                traffic = tj.get("hbm_bytes_per_launch")
         out = {
             "metric": "moves-evaluated/sec, CVRP-1000 (nearby-list selector, LateAcceptance(400)+AcceptedCount(256))",
             "value": moves_total / elapsed,
@@ -181,6 +206,7 @@ def main():
                             "change+swap union (max_nearby 20), default list policy",
                 "replicas_per_gpu": args.replicas,
                 "ls_steps_per_launch": args.ls_steps,
+                "engine": engine,
                 "parallelism": f"portfolio x{world} (independent seeds, {exchange})",
                 "seed": args.seed,
             },
@@ -190,27 +216,34 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "k_list_search<2,false>",
+                "traffic": traffic,
+                "kernel": kernel,
                 "avg_launch_ms": avg_launch_ms,
                 "launches": launches,
                 "candidates_scored_per_launch": scored_local / max(launches, 1),
+                "sources_scanned_per_launch": delta["sources_scanned"] / max(launches, 1),
                 "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
                 "bytes_per_candidate": B_ALG_CANDIDATE,
-                "generation_bytes_per_source": (args.customers + args.vehicles) * 12,
+                "generation_bytes_per_source": gen_bytes_per_source,
             },
             "extra": {
                 "candidates_scored_per_s": scored_local * world / elapsed,
                 "moves_accepted": delta["moves_accepted"],
                 "ls_steps": delta["step_count"],
+                "moves_per_ls_step": moves_local / max(delta["step_count"], 1),
                 "start_score": start_score,
+                "replica0_working_score": replica0_score,
                 "best_score": winner["score"],
                 "winner": winner,
             },
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(problem, args.cpu_seconds, args.seed)
-            out["extra"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            cb = cpu_baseline(problem, args.seed, args.warmup * args.ls_steps, args.steps * args.ls_steps,
+                              args.cpu_seconds)
+            ws = cb.pop("working_score")
+            out["cpu_baseline"] = cb
+            out["extra"]["gpu_over_cpu"] = out["value"] / cb["value"]
+            out["extra"]["replica0_matches_cpu_oracle"] = None if ws is None else bool(ws == replica0_score)
         if args.solve_seconds > 0:
             t1 = time.perf_counter()
             while time.perf_counter() - t1 < args.solve_seconds:

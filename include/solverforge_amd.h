@@ -209,6 +209,7 @@ int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint
 /* ---- local search phase ------------------------------------------------------------------ */
 int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg);
 int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine); /* sf_engine_kind; SF_ERR_UNSUPPORTED if it cannot run this model */
+int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine); /* the engine launches resolve to (after sf_initialize) */
 /* explicit step seeds for parity runs (n_steps per replica, replica-major); NULL clears */
 int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps);
 /* ≙ phase start: last_step_score = calculate_score, acceptor.phase_started, best = working */
@@ -222,6 +223,7 @@ int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves,
                              int32_t* out_flags, int64_t cap, int64_t* out_count,
                              int32_t* out_applied, sf_move_t* out_applied_move);
 int32_t sf_get_stats(sf_ctx* ctx, int32_t replica, sf_stats* out);
+int32_t sf_get_stats_sum(sf_ctx* ctx, sf_stats* out); /* counters summed over all replicas */
 int32_t sf_get_best_scores(sf_ctx* ctx, int64_t* out_scores);
 /* duration (ms, HIP events on the context stream) and launch count of sf_solve_steps launches
  * since the last call */

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libsolverforge_amd.so")
+# SF_AMD_LIB: kernel-variant experiments only (scripts/); the product always loads the in-tree build
+LIB_PATH = os.environ.get("SF_AMD_LIB") or os.path.join(_DIR, "libsolverforge_amd.so")
 
 SF_OK = 0
 ERRORS = {-1: "SF_ERR_INVALID", -2: "SF_ERR_NO_DEVICE", -3: "SF_ERR_HIP", -4: "SF_ERR_UNSUPPORTED", -5: "SF_ERR_CAPACITY"}
@@ -48,7 +49,7 @@ SYMBOLS = [
     "sf_fact_matrix_i64", "sf_fact_column_i32", "sf_fact_column_u32", "sf_fact_csr_u32",
     "sf_constraint_add", "sf_selector_add", "sf_initialize", "sf_evaluate_all", "sf_get_scores",
     "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_solver_set_step_seeds",
-    "sf_solver_set_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_best_scores",
+    "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
     "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_destroy",
 ]
@@ -92,11 +93,13 @@ def load():
     L.sf_step_generate.argtypes = [vp, i32, u64, u64, i32, vp, vp, vp, i64, vp]
     L.sf_solver_configure.argtypes = [vp, C.POINTER(SolverConfigStruct)]
     L.sf_solver_set_engine.argtypes = [vp, i32]
+    L.sf_solver_get_engine.argtypes = [vp, C.POINTER(i32)]
     L.sf_solver_set_step_seeds.argtypes = [vp, vp, i64]
     L.sf_phase_start.argtypes = [vp]
     L.sf_solve_steps.argtypes = [vp, i64]
     L.sf_solve_step_traced.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.sf_get_stats.argtypes = [vp, i32, C.POINTER(StatsStruct)]
+    L.sf_get_stats_sum.argtypes = [vp, C.POINTER(StatsStruct)]
     L.sf_get_best_scores.argtypes = [vp, vp]
     L.sf_profile_solve.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.sf_download_scalar.argtypes = [vp, i32, i32, i32, vp, i32]

@@ -59,7 +59,7 @@ struct sf_ctx {
     bool has_list_model = false;
     int list_desc = -1;
     ListModel lm{};
-    NbrIndex nbr{nullptr, nullptr};  // presorted neighbour index (wave engine)
+    NbrIndex nbr{nullptr};  // presorted neighbour index (wave engine)
     int engine = SF_ENGINE_AUTO;
     // scalar model
     bool has_scalar_model = false;
@@ -367,33 +367,36 @@ static int build_list_model(sf_ctx* ctx, int d) {
     while (P < m.dim) P <<= 1;
     if (nearby && m.mat && (size_t)P * 8 <= 128 * 1024) {
         uint64_t* keys = nullptr;
-        uint32_t* cnt = nullptr;
         if ((rc = dalloc(ctx, &keys, (size_t)m.dim * m.dim))) return rc;
-        if ((rc = dalloc(ctx, &cnt, (size_t)m.dim))) return rc;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_nbr_presort, hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
-        hipLaunchKernelGGL(k_nbr_presort, dim3(m.dim), dim3(256), (size_t)P * 8, ctx->stream, m.mat, m.dim, P, keys, cnt);
+        hipLaunchKernelGGL(k_nbr_presort, dim3(m.dim), dim3(256), (size_t)P * 8, ctx->stream, m.mat, m.dim, P, keys);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        ctx->nbr = NbrIndex{keys, cnt};
+        ctx->nbr = NbrIndex{keys};
     }
     return SF_OK;
 }
 
 // engine resolution: WAVE needs the neighbour index, u16-packable coordinates and an LDS slice per
 // replica small enough for several replicas per CU.
-static bool wave_engine_possible(sf_ctx* ctx) {
-    const ListModel& m = ctx->lm;
-    if (!ctx->nbr.keys || m.n_cap > 65535) return false;
+static int list_max_nearby(sf_ctx* ctx) {
+    int mk = 1;
     for (auto& s : ctx->selectors)
         if (s.desc == ctx->list_desc && (s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP) &&
-            s.max_nearby > 64)
-            return false;
-    return WCarve(m.V, m.n_cap, m.dim).total * WPB <= 160 * 1024;
+            s.max_nearby > mk)
+            mk = s.max_nearby;
+    return mk;
+}
+static bool wave_engine_possible(sf_ctx* ctx) {
+    const ListModel& m = ctx->lm;
+    // u16 element ids / ordinals in LDS; one wave's LDS slice must fit a CU
+    if (!ctx->nbr.keys || m.dim > 16384 || m.n_cap + m.V > 65535 || list_max_nearby(ctx) > 64) return false;
+    return WCarve(m.V, m.n_cap, m.dim, list_max_nearby(ctx)).total * WPB <= 160 * 1024;
 }
 static bool use_wave_engine(sf_ctx* ctx) {
     if (ctx->engine == SF_ENGINE_BLOCK) return false;
     if (ctx->engine == SF_ENGINE_WAVE) return true;  // validated in sf_solver_set_engine / launch
-    return wave_engine_possible(ctx) && WCarve(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim).total <= 40 * 1024;
+    return wave_engine_possible(ctx) && WCarve(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx)).total <= 40 * 1024;
 }
 
 static int build_scalar_model(sf_ctx* ctx, int d);  // sf_api_scalar.inc
@@ -479,7 +482,7 @@ static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid) {
 }
 template <int L, bool TRACE>
 static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas) {
-    WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim);
+    WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx));
     size_t lds = cv.total * WPB;
     auto kern = k_list_search_wave<L, TRACE>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -664,6 +667,12 @@ int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine) {
     return SF_OK;
 }
 
+int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine) {
+    if (!ctx || !ctx->initialized || !out_engine) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    *out_engine = ctx->has_list_model && use_wave_engine(ctx) ? SF_ENGINE_WAVE : SF_ENGINE_BLOCK;
+    return SF_OK;
+}
+
 int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps) {
     if (!ctx) return SF_ERR_INVALID;
     if (!seeds || n_steps <= 0) {
@@ -811,6 +820,18 @@ int32_t sf_get_stats(sf_ctx* ctx, int32_t replica, sf_stats* out) {
     static_assert(sizeof(sf_stats) == SF_STATS_WORDS * 8, "sf_stats layout");
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->sp.stats + (size_t)replica * SF_STATS_WORDS, sizeof(sf_stats), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+int32_t sf_get_stats_sum(sf_ctx* ctx, sf_stats* out) {
+    if (!ctx || !ctx->search_alloc || !out) return fail(ctx, SF_ERR_INVALID, "bad sf_get_stats_sum");
+    std::vector<uint64_t> all((size_t)ctx->R * SF_STATS_WORDS);
+    HIPCHK(ctx, hipMemcpyAsync(all.data(), ctx->sp.stats, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t sum[SF_STATS_WORDS] = {0};
+    for (int r = 0; r < ctx->R; ++r)
+        for (int k = 0; k < SF_STATS_WORDS; ++k) sum[k] += all[(size_t)r * SF_STATS_WORDS + k];
+    std::memcpy(out, sum, sizeof(sf_stats));
     return SF_OK;
 }
 

@@ -79,7 +79,8 @@ struct ListDelta {
 };
 
 // ListChangeMove (a,i) -> (b,j), j in pre-removal coordinates (move/list_kernel/change.rs:28-34).
-__device__ __forceinline__ ListDelta eval_list_change(const ListModel& m, const uint32_t* visits,
+template <class VT>
+__device__ __forceinline__ ListDelta eval_list_change(const ListModel& m, const VT* visits,
                                                       const uint32_t* off, const int64_t* load, uint32_t a,
                                                       uint32_t i, uint32_t b, uint32_t j) {
     ListDelta r{0, 0, true};
@@ -115,7 +116,7 @@ __device__ __forceinline__ ListDelta eval_list_change(const ListModel& m, const 
             // sequence after removal s'[t] = t<i ? s[t] : s[t+1]; insert at jj
             uint32_t jj = j > i ? j - 1 : j;
             uint32_t l2 = la - 1;
-            auto at = [&](uint32_t t) { return visits[oa + (t < i ? t : t + 1)]; };
+            auto at = [&](uint32_t t) { return (uint32_t)visits[oa + (t < i ? t : t + 1)]; };
             pl = jj > 0 ? at(jj - 1) : depot;
             nr = jj < l2 ? at(jj) : depot;
             dst_empty = false;
@@ -135,7 +136,8 @@ __device__ __forceinline__ ListDelta eval_list_change(const ListModel& m, const 
 }
 
 // ListSwapMove (a,i) <-> (b,j) (move/list_kernel/swap.rs:30-110).
-__device__ __forceinline__ ListDelta eval_list_swap(const ListModel& m, const uint32_t* visits,
+template <class VT>
+__device__ __forceinline__ ListDelta eval_list_swap(const ListModel& m, const VT* visits,
                                                     const uint32_t* off, const int64_t* load, uint32_t a,
                                                     uint32_t i, uint32_t b, uint32_t j) {
     ListDelta r{0, 0, true};

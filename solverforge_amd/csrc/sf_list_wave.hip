@@ -25,12 +25,19 @@
 
 namespace sf {
 
-constexpr uint32_t RC = 128;  // ring capacity per leaf (>= 64 + max_nearby - 1, power of two)
-constexpr int WPB = 1;        // waves (= replicas) per workgroup
+constexpr uint32_t RC_MAX = 128;   // ring capacity per leaf when max_nearby > 32 (>= 64 + 64 - 1)
+constexpr uint32_t RC_SMALL = 64;  // ring capacity per leaf when max_nearby <= 32 (>= 32 + 32)
+constexpr uint64_t NBR_NODE_MASK = 0x7FFFFFull;   // node id (dim <= 16384 in the wave engine)
+constexpr uint64_t NBR_SAME_FLAG = 0x800000ull;   // same distance as the previous entry of the row
+#ifndef SF_WPB
+#define SF_WPB 4
+#endif
+constexpr int WPB = SF_WPB;  // waves (= replicas) per workgroup
 
 struct NbrIndex {
-    const uint64_t* keys;  // [dim][dim]  (distance << 24 | node), ascending per row; finite legs only
-    const uint32_t* cnt;   // [dim]       finite entries per row
+    // [dim][dim] per row ascending (distance << 24 | same-distance-as-previous flag << 23 | node);
+    // non-finite legs (negative / UNREACHABLE, meters.rs:21-23) sort to the end as ~0
+    const uint64_t* keys;
 };
 
 // wavefront-scope ordering of LDS/global traffic between lanes of one wave (no instruction cost:
@@ -49,27 +56,19 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 // Neighbour index: bitonic sort of every matrix row in LDS.  grid = dim rows.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__ mat, int dim, int P,
-                                                     uint64_t* __restrict__ keys, uint32_t* __restrict__ cnt) {
+                                                     uint64_t* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* sk = (uint64_t*)smem;
-    __shared__ unsigned int s_cnt;
     const int row = blockIdx.x;
     const int64_t* rp = mat + (size_t)row * dim;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    unsigned int mine = 0;
     for (int t = threadIdx.x; t < P; t += blockDim.x) {
         uint64_t k = ~0ULL;
         if (t < dim) {
             const int64_t v = rp[t];
-            if (v >= 0 && v != UNREACHABLE) {  // finite_distance (problem_data.rs:44-47)
-                k = ((uint64_t)v << 24) | (uint64_t)(uint32_t)t;
-                ++mine;
-            }
+            if (v >= 0 && v != UNREACHABLE) k = ((uint64_t)v << 24) | (uint64_t)(uint32_t)t;  // finite_distance (problem_data.rs:44-47)
         }
         sk[t] = k;
     }
-    atomicAdd(&s_cnt, mine);
     __syncthreads();
     for (int size = 2; size <= P; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -85,27 +84,32 @@ __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__
             }
             __syncthreads();
         }
-    for (int t = threadIdx.x; t < dim; t += blockDim.x) keys[(size_t)row * dim + t] = sk[t];
-    if (threadIdx.x == 0) cnt[row] = s_cnt;
+    for (int t = threadIdx.x; t < dim; t += blockDim.x) {
+        uint64_t k = sk[t];
+        if (k != ~0ULL && t > 0 && (sk[t - 1] >> 24) == (k >> 24)) k |= NBR_SAME_FLAG;
+        keys[(size_t)row * dim + t] = k;
+    }
 }
 
 // LDS carve of ONE replica (bytes); mirrored on the host.
 struct WCarve {
-    size_t load, visits, off, node, ring, slotbase, routeat, rankof, total;
-    __host__ __device__ WCarve(int V, int n_cap, int dim) {
+    size_t load, off, node, ring, visits, slotbase, routeat, rankof, total;
+    uint32_t rc;  // ring capacity per leaf
+    __host__ __device__ WCarve(int V, int n_cap, int dim, int max_k) {
+        rc = max_k <= 32 ? RC_SMALL : RC_MAX;
         size_t o = 0;
         load = o;
         o = align_up(o + sizeof(int64_t) * V, 16);
-        visits = o;
-        o = align_up(o + sizeof(uint32_t) * n_cap, 16);
         off = o;
         o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
         node = o;
         o = align_up(o + sizeof(uint32_t) * dim, 16);
         ring = o;
-        o = align_up(o + sizeof(uint32_t) * 2 * RC * MAX_LEAVES, 16);
+        o = align_up(o + sizeof(uint32_t) * 2 * rc * MAX_LEAVES, 16);
+        visits = o;
+        o = align_up(o + sizeof(uint16_t) * n_cap, 16);
         slotbase = o;
-        o = align_up(o + sizeof(uint32_t) * (V + 1) * MAX_LEAVES, 16);
+        o = align_up(o + sizeof(uint16_t) * (V + 1) * MAX_LEAVES, 16);
         routeat = o;
         o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
         rankof = o;
@@ -125,7 +129,7 @@ struct NearbyItem {
 
 __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot, uint32_t se, uint32_t sp,
                                                   uint32_t len, uint32_t k, const uint32_t* s_off,
-                                                  const uint32_t* sb, const uint16_t* ro) {
+                                                  const uint16_t* sb, const uint16_t* ro) {
     NearbyItem it{0u, 0u, 0u, 0u};
     if (slot == NODE_NONE) return it;
     const uint32_t r2 = slot >> 16, dp = slot & 0xFFFFu;
@@ -148,7 +152,7 @@ __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot,
             }
         } else {
             const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
-            it.ord = ORD_INTER_BASE + sb[ro[r2]] + dp;
+            it.ord = ORD_INTER_BASE + (uint32_t)sb[ro[r2]] + dp;
             it.pay0 = slot;
             it.w = 1;
             if (dp + 1 == len2) {
@@ -166,7 +170,7 @@ __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot,
         } else {
             const uint32_t rk = ro[r2];
             if (rk > k) {
-                it.ord = ORD_INTER_BASE + sb[rk] + dp;
+                it.ord = ORD_INTER_BASE + (uint32_t)sb[rk] + dp;
                 it.pay0 = slot;
                 it.w = 1;
             }
@@ -175,8 +179,13 @@ __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot,
     return it;
 }
 
+// number of set bits of `mask` below this lane (v_mbcnt: no LDS crossbar involved)
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 // Committed move application on the wave's LDS state (ListChange / ListSwap do_move).
-__device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint32_t* visits, uint32_t* off,
+__device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_t* visits, uint32_t* off,
                                                      int64_t* load, int kind, uint32_t a, uint32_t i, uint32_t b,
                                                      uint32_t j) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -188,9 +197,9 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint32_
             for (uint32_t t0 = P; t0 < Q; t0 += 64) {
                 const uint32_t t = t0 + lane;
                 uint32_t nv = 0;
-                if (t < Q) nv = (t + 1 < Q) ? visits[t + 1] : x;
+                if (t < Q) nv = (t + 1 < Q) ? (uint32_t)visits[t + 1] : x;
                 wave_sync();
-                if (t < Q) visits[t] = nv;
+                if (t < Q) visits[t] = (uint16_t)nv;
                 wave_sync();
             }
         } else if (P > Q) {  // (Q, P] <- t-1 ; Q <- x   (descending chunks)
@@ -199,9 +208,9 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint32_
                 const bool in = dd <= P - Q;
                 const uint32_t t = P - (in ? dd : 0u);
                 uint32_t nv = 0;
-                if (in) nv = t > Q ? visits[t - 1] : x;
+                if (in) nv = t > Q ? (uint32_t)visits[t - 1] : x;
                 wave_sync();
-                if (in) visits[t] = nv;
+                if (in) visits[t] = (uint16_t)nv;
                 wave_sync();
             }
         }
@@ -219,7 +228,7 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint32_
     } else if (kind == 3) {
         if (lane == 0) {
             const uint32_t pa = off[a] + i, pb = off[b] + j;
-            const uint32_t x = visits[pa], y = visits[pb];
+            const uint16_t x = visits[pa], y = visits[pb];
             visits[pa] = y;
             visits[pb] = x;
             if (a != b && m.demand) {
@@ -232,22 +241,43 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint32_
     wave_sync();
 }
 
+// Per-leaf cursor state of one step.  The NEXT source of the leaf is always resolved ahead of use
+// and the first 64-entry chunk of its neighbour row is already in flight (`pk`), so the global
+// load latency hides behind the other leaf's generation and the replay batches.
+struct LeafCursor {
+    uint32_t head, tail;  // candidate ring (monotonic counters)
+    uint32_t left;        // sources not yet generated
+    uint32_t k, o;        // next source: entity rank / offset inside the entity's list
+    uint32_t se, len, sp, sx;  // next source resolved: entity, its list length, position, element
+    int ex;               // exhausted (union scheduler)
+    uint64_t pk;          // per lane: prefetched key chunk 0 of the next source's neighbour row
+};
+
 template <int L, bool TRACE>
-__global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
+__global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const int rr = (int)(blockIdx.x * WPB + (threadIdx.x >> 6));
     if (rr >= p.n_launch) return;  // no workgroup barrier anywhere below
     const int r = rr + p.replica_base;
     const int V = m.V;
-    const WCarve cv(V, m.n_cap, m.dim);
+    const uint32_t dim = (uint32_t)m.dim;
+
+    // leaf constants (no dynamic indexing of the kernarg block)
+    const int n_leaves = p.n_leaves;
+    const uint32_t K0 = (uint32_t)p.leaf[0].max_nearby, K1 = n_leaves > 1 ? (uint32_t)p.leaf[1].max_nearby : 1u;
+    const bool chg0 = p.leaf[0].kind == 16, chg1 = n_leaves > 1 && p.leaf[1].kind == 16;
+    const uint64_t desc0 = (uint64_t)p.leaf[0].descriptor, desc1 = n_leaves > 1 ? (uint64_t)p.leaf[1].descriptor : 0;
+
+    const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1));
+    const uint32_t RCM = cv.rc - 1;
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     int64_t* s_load = (int64_t*)(mem + cv.load);
-    uint32_t* s_visits = (uint32_t*)(mem + cv.visits);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint32_t* node_slot = (uint32_t*)(mem + cv.node);
-    uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][RC][2]
-    uint32_t* slot_base = (uint32_t*)(mem + cv.slotbase);
+    uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][rc][2]
+    uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
+    uint16_t* slot_base = (uint16_t*)(mem + cv.slotbase);
     uint16_t* route_at = (uint16_t*)(mem + cv.routeat);
     uint16_t* rank_of = (uint16_t*)(mem + cv.rankof);
 
@@ -257,19 +287,13 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
     int64_t* g_score = m.score + (size_t)r * 4;
     const bool tracing = TRACE && r == p.trace_replica;
 
-    // leaf constants (no dynamic indexing of the kernarg block)
-    const int n_leaves = p.n_leaves;
-    const uint32_t K0 = (uint32_t)p.leaf[0].max_nearby, K1 = n_leaves > 1 ? (uint32_t)p.leaf[1].max_nearby : 1u;
-    const bool chg0 = p.leaf[0].kind == 16, chg1 = n_leaves > 1 && p.leaf[1].kind == 16;
-    const uint64_t desc0 = (uint64_t)p.leaf[0].descriptor, desc1 = n_leaves > 1 ? (uint64_t)p.leaf[1].descriptor : 0;
-
     // ---- load replica state into LDS ----
     for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
     for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = g_load[t];
-    for (uint32_t t = lane; t < (uint32_t)m.dim; t += 64) node_slot[t] = NODE_NONE;
+    for (uint32_t t = lane; t < dim; t += 64) node_slot[t] = NODE_NONE;
     wave_sync();
     const uint32_t total0 = uni(s_off[V]);
-    for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = g_visits[t];
+    for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = (uint16_t)g_visits[t];
     wave_sync();
     for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
         const uint32_t o = s_off[v], len = s_off[v + 1] - o;
@@ -288,6 +312,7 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
     const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
     const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
     const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
+    const uint64_t lanebit = 1ULL << lane;
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         // ---- (A) step start (step.rs:60-74) -------------------------------------------------
@@ -322,16 +347,38 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
         for (int k = 0; k < L; ++k) best.v[k] = 0;
         uint32_t best_m0 = 0, best_m1 = 0;
         int best_leaf = 0;
-        uint32_t head0 = 0, head1 = 0, tail0 = 0, tail1 = 0;
         const uint32_t total = uni(s_off[V]);
-        uint32_t left0 = total, left1 = n_leaves > 1 ? total : 0u;  // sources not yet generated
-        int ex0 = 0, ex1 = n_leaves > 1 ? 0 : 1;
-        uint32_t gk0 = 0, gk1 = 0, go0 = 0, go1 = 0;  // source iterator (entity rank, offset)
         // union: >1 leaf => StratifiedRandom, equal weights (vec_union.rs:229-245); with two children
         // the stride is always 1, so the order is first, other, first, ...
         const uint32_t first_leaf = n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u;
 
+        // resolve the source at cursor (k, o) of leaf l and put its first key chunk in flight
+        auto resolve = [&](LeafCursor& c, int l) {
+            const uint16_t* ra = route_at + l * V;
+            uint32_t k = c.k, o = c.o, se = 0, len = 0;
+            for (;;) {  // skip empty routes (left > 0 guarantees a source exists)
+                se = uni((uint32_t)ra[k]);
+                len = uni(s_off[se + 1] - s_off[se]);
+                if (o < len) break;
+                ++k;
+                o = 0;
+            }
+            const uint64_t src_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^
+                                      (uint64_t)se ^ (l ? desc1 : desc0);
+            const uint32_t sp = uni(ctx.selection_index(o, len, src_salt));
+            const uint32_t sx = uni((uint32_t)s_visits[s_off[se] + sp]);
+            c.k = k;
+            c.o = o;
+            c.se = se;
+            c.len = len;
+            c.sp = sp;
+            c.sx = sx;
+            c.pk = lane < dim ? nb.keys[(size_t)sx * dim + lane] : ~0ULL;
+        };
+
         // ---- (B) per-leaf entity order tables (slot.rs:468-499) --------------------------------
+        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0, ~0ULL};
+        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, n_leaves > 1 ? 0 : 1, ~0ULL};
         for (int l = 0; l < n_leaves; ++l) {
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
@@ -340,7 +387,7 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
             psd = uni(psd);
             uint16_t* ra = route_at + l * V;
             uint16_t* ro = rank_of + l * V;
-            uint32_t* sb = slot_base + l * (V + 1);
+            uint16_t* sb = slot_base + l * (V + 1);
             for (uint32_t k = lane; k < (uint32_t)V; k += 64) {
                 const uint32_t e = (uint32_t)(((uint64_t)pst + (uint64_t)k * psd) % (uint32_t)V);
                 ra[k] = (uint16_t)e;
@@ -356,114 +403,105 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
                     v = s_off[e + 1] - s_off[e] + 1;
                 }
                 const uint32_t inc = wave_incl_scan(v);
-                if (k < (uint32_t)V) sb[k] = carry + inc - v;
+                if (k < (uint32_t)V) sb[k] = (uint16_t)(carry + inc - v);
                 carry += __shfl(inc, 63);
             }
-            if (lane == 0) sb[V] = carry;
+            if (lane == 0) sb[V] = (uint16_t)carry;
         }
         wave_sync();
+        if (total > 0) {
+            resolve(C0, 0);
+            if (n_leaves > 1) resolve(C1, 1);
+        }
 
         // ---- (C) candidate rounds: fill the rings, replay one 64-wide batch, repeat -----------
         int done = 0;
         while (!done) {
-            // C1: generation.  Keep >= 32 (both leaves live) / >= 64 (one leaf) candidates pending.
-            const uint32_t target = (!ex0 && !ex1) ? 32u : 64u;
+            // C1: generation.  Keep >= 32 candidates pending per live leaf (>= min(64, rc - K) when
+            // only one leaf is live) so that the replay batch below finds every lane a candidate.
             for (int l = 0; l < n_leaves; ++l) {
-                for (;;) {
-                    const uint32_t left = l ? left1 : left0;
-                    const uint32_t pend = l ? tail1 - head1 : tail0 - head0;
-                    if ((l ? ex1 : ex0) || left == 0 || pend >= target) break;
-                    // -- next source of leaf l (selection order: entity rank, then offset) --
-                    const bool is_change = l ? chg1 : chg0;
-                    const uint32_t K = l ? K1 : K0;
-                    const uint16_t* ra = route_at + l * V;
-                    const uint16_t* ro = rank_of + l * V;
-                    const uint32_t* sb = slot_base + l * (V + 1);
-                    uint32_t k = l ? gk1 : gk0, o = l ? go1 : go0;
-                    uint32_t se = 0, len = 0;
-                    for (;;) {  // skip empty routes
-                        se = uni((uint32_t)ra[k]);
-                        len = uni(s_off[se + 1] - s_off[se]);
-                        if (o < len) break;
-                        ++k;
-                        o = 0;
-                    }
-                    const uint64_t src_salt = (is_change ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^
-                                              (uint64_t)se ^ (l ? desc1 : desc0);
-                    const uint32_t sp = uni(ctx.selection_index(o, len, src_salt));
-                    const uint32_t sx = uni(s_visits[s_off[se] + sp]);
-                    const uint32_t cnt_row = uni(nb.cnt[sx]);
-                    const uint64_t* rowk = nb.keys + (size_t)sx * (size_t)m.dim;
-                    const uint32_t tl = l ? tail1 : tail0;
-                    uint32_t* rq = ring + (size_t)l * RC * 2;
+                LeafCursor c = l ? C1 : C0;
+                const bool is_change = l ? chg1 : chg0;
+                const uint32_t K = l ? K1 : K0;
+                const uint32_t single = cv.rc - K < 64u ? cv.rc - K : 64u;
+                const uint32_t target = (!C0.ex && !C1.ex) ? 32u : single;
+                const uint16_t* ro = rank_of + l * V;
+                const uint16_t* sb = slot_base + l * (V + 1);
+                uint32_t* rq = ring + (size_t)l * cv.rc * 2;
+                while (!c.ex && c.left > 0 && c.tail - c.head < target) {
+                    const uint32_t se = c.se, sp = c.sp, len = c.len, k = c.k;
+                    const uint64_t* rowk = nb.keys + (size_t)c.sx * dim;
                     const uint32_t mv0 = (se << 16) | sp;
+                    uint64_t key = c.pk;
+                    // put the next source's first chunk in flight before working on this one
+                    c.left -= 1;
+                    c.o += 1;
+                    if (c.left > 0) resolve(c, l);
+                    st_sources += 1;
                     uint32_t need = K, emitted = 0, base = 0;
-                    while (need > 0 && base < cnt_row) {
-                        const uint32_t jj = base + lane;
-                        const bool have = jj < cnt_row;
-                        const uint64_t key = have ? rowk[jj] : ~0ULL;
-                        const uint32_t y = (uint32_t)key & 0xFFFFFFu;
-                        const uint32_t dlo = (uint32_t)(key >> 24), dhi = (uint32_t)(key >> 56);
+                    for (;;) {
+                        const bool have = key != ~0ULL;
+                        const uint64_t havemask = __ballot(have);
+                        if (havemask == 0) break;  // finite entries of the row exhausted
                         NearbyItem it{0u, 0u, 0u, 0u};
-                        if (have) it = nearby_item(is_change, node_slot[y], se, sp, len, k, s_off, sb, ro);
-                        // equal-distance groups are contiguous lane ranges
-                        const uint32_t pdlo = __shfl_up(dlo, 1), pdhi = __shfl_up(dhi, 1);
-                        const bool is_start = have && (lane == 0 || dlo != pdlo || dhi != pdhi);
-                        const uint64_t startmask = __ballot(is_start);
-                        const uint32_t nhave = (uint32_t)__popcll(__ballot(have));
-                        const bool more = base + 64 < cnt_row;
+                        if (have) it = nearby_item(is_change, node_slot[(uint32_t)(key & NBR_NODE_MASK)], se, sp, len, k, s_off, sb, ro);
+                        // equal-distance groups are contiguous lane ranges; the index marks entries that
+                        // continue the previous entry's distance
+                        const uint64_t startmask = __ballot(have && (lane == 0 || !(key & NBR_SAME_FLAG)));
+                        const bool more = havemask == ~0ULL && base + 64 < dim;
                         const uint32_t fo = 63u - (uint32_t)__clzll((unsigned long long)startmask);  // first lane of the last group
                         if (more && fo == 0) {
                             // one distance group wider than a chunk (degenerate ties): exact serial
                             // insertion top-k over the rest of the row.
                             TopK tk{~0ULL, 0u, ~0ULL};
-                            for (uint32_t b2 = base; b2 < cnt_row; b2 += 64) {
+                            for (uint32_t b2 = base; b2 < dim; b2 += 64) {
                                 const uint32_t j2 = b2 + lane;
-                                const bool hv = j2 < cnt_row;
-                                const uint64_t ky = hv ? rowk[j2] : ~0ULL;
+                                const uint64_t ky = j2 < dim ? rowk[j2] : ~0ULL;
                                 NearbyItem i2{0u, 0u, 0u, 0u};
-                                if (hv) i2 = nearby_item(is_change, node_slot[(uint32_t)ky & 0xFFFFFFu], se, sp, len, k, s_off, sb, ro);
+                                if (ky != ~0ULL) i2 = nearby_item(is_change, node_slot[(uint32_t)(ky & NBR_NODE_MASK)], se, sp, len, k, s_off, sb, ro);
+                                if (!__ballot(ky != ~0ULL)) break;
                                 const uint64_t hk = ky & ~0xFFFFFFULL;
                                 topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
                                 topk_offer(tk, need, i2.w == 2 ? (hk | (i2.ord + 1)) : ~0ULL, i2.pay1);
                             }
                             const uint32_t cnt = (uint32_t)__popcll(__ballot(lane < need && tk.key != ~0ULL));
                             if (lane < cnt) {
-                                const uint32_t qi = (tl + emitted + lane) & (RC - 1);
+                                const uint32_t qi = (c.tail + emitted + lane) & RCM;
                                 rq[qi * 2] = mv0;
                                 rq[qi * 2 + 1] = tk.pay;
                             }
                             emitted += cnt;
-                            need = 0;
                             break;
                         }
-                        const uint32_t nclosed = more ? fo : nhave;  // lanes [0, nclosed) belong to complete groups
-                        const bool closed = lane < nclosed;
+                        const uint32_t nclosed = more ? fo : (uint32_t)__popcll(havemask);  // lanes [0, nclosed): complete groups
+                        const uint64_t closedmask = nclosed >= 64 ? ~0ULL : ((1ULL << nclosed) - 1ULL);
+                        const bool closed = (closedmask & lanebit) != 0;
                         const uint32_t wc = closed ? it.w : 0u;
-                        const uint32_t inc = wave_incl_scan(wc);
-                        const uint32_t Wc = uni(__shfl(inc, 63));
+                        const uint64_t w1 = __ballot(wc == 1), w2 = __ballot(wc == 2);
+                        const uint32_t Wc = (uint32_t)__popcll(w1) + 2u * (uint32_t)__popcll(w2);
                         if (Wc > 0) {
                             // sorted position = weight before me, corrected by the inversions inside my group
-                            const uint32_t gid = (uint32_t)__popcll(startmask & lanemask_le(lane));
-                            const uint32_t packed = (it.ord << 2) | wc;
-                            int32_t pos = (int32_t)(inc - wc);
-                            for (uint32_t d = 1; d < 64; ++d) {
-                                const uint32_t g_dn = __shfl_down(gid, d);
-                                const bool same_dn = closed && lane + d < nclosed && g_dn == gid;
-                                if (!__ballot(same_dn)) break;
-                                const uint32_t p_dn = __shfl_down(packed, d);
-                                const uint32_t g_up = __shfl_up(gid, d), p_up = __shfl_up(packed, d);
-                                const bool same_up = closed && lane >= d && g_up == gid;
-                                if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
-                                if (same_up && (p_up >> 2) > it.ord) pos -= (int32_t)(p_up & 3u);
+                            int32_t pos = (int32_t)(mbcnt64(w1) + 2u * mbcnt64(w2));
+                            const uint64_t nonstart = ~startmask & closedmask;  // lane continues the group of lane-1
+                            if (nonstart) {
+                                const uint32_t packed = (it.ord << 2) | wc;
+                                uint64_t run = nonstart;  // bit t: lanes t-d .. t are one group
+                                for (uint32_t d = 1; run != 0; ++d) {
+                                    const uint32_t p_dn = __shfl_down(packed, d), p_up = __shfl_up(packed, d);
+                                    const bool same_up = (run & lanebit) != 0;
+                                    const bool same_dn = ((run >> d) & lanebit) != 0;
+                                    if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
+                                    if (same_up && (p_up >> 2) > it.ord) pos -= (int32_t)(p_up & 3u);
+                                    run &= nonstart << d;
+                                }
                             }
                             if (wc >= 1 && (uint32_t)pos < need) {
-                                const uint32_t qi = (tl + emitted + (uint32_t)pos) & (RC - 1);
+                                const uint32_t qi = (c.tail + emitted + (uint32_t)pos) & RCM;
                                 rq[qi * 2] = mv0;
                                 rq[qi * 2 + 1] = it.pay0;
                             }
                             if (wc == 2 && (uint32_t)pos + 1 < need) {
-                                const uint32_t qi = (tl + emitted + (uint32_t)pos + 1) & (RC - 1);
+                                const uint32_t qi = (c.tail + emitted + (uint32_t)pos + 1) & RCM;
                                 rq[qi * 2] = mv0;
                                 rq[qi * 2 + 1] = it.pay1;
                             }
@@ -471,29 +509,23 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
                             emitted += ne;
                             need -= ne;
                         }
-                        base += more ? nclosed : 64u;
+                        if (need == 0 || !more) break;
+                        base += nclosed;
+                        const uint32_t jj = base + lane;
+                        key = jj < dim ? rowk[jj] : ~0ULL;
                     }
-                    // commit iterator + ring tail
-                    ++o;
-                    if (l) {
-                        gk1 = k;
-                        go1 = o;
-                        tail1 = tl + emitted;
-                        left1 = left - 1;
-                    } else {
-                        gk0 = k;
-                        go0 = o;
-                        tail0 = tl + emitted;
-                        left0 = left - 1;
-                    }
-                    st_sources += 1;
+                    c.tail += emitted;
                 }
+                if (l)
+                    C1 = c;
+                else
+                    C0 = c;
             }
             wave_sync();
 
             // C2: replay one batch in union cursor order: trial score, acceptor, forager
             {
-                const bool live0 = !ex0, live1 = !ex1;
+                const bool live0 = !C0.ex, live1 = !C1.ex;
                 if (!live0 && !live1) {
                     done = 1;
                     break;
@@ -502,12 +534,12 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
                 if (live0 && live1) {
                     const uint32_t l0 = (first_leaf + pulls) & 1u;
                     lf = (l0 + lane) & 1u;
-                    idx = (lf ? head1 : head0) + (lane >> 1);
+                    idx = (lf ? C1.head : C0.head) + (lane >> 1);
                 } else {
                     lf = live0 ? 0u : 1u;
-                    idx = (lf ? head1 : head0) + lane;
+                    idx = (lf ? C1.head : C0.head) + lane;
                 }
-                const bool avail = (int32_t)((lf ? tail1 : tail0) - idx) > 0;
+                const bool avail = (int32_t)((lf ? C1.tail : C0.tail) - idx) > 0;
                 const uint64_t availmask = __ballot(avail);
                 const uint32_t nvalid = availmask == ~0ULL ? 64u : (uint32_t)(__ffsll((unsigned long long)~availmask) - 1);
                 if (nvalid == 0) {
@@ -515,17 +547,17 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
                     // a leaf with sources left was refilled above, so an empty ring means exhausted.
                     const uint32_t lf0 = uni(__shfl(lf, 0));
                     if (lf0)
-                        ex1 = 1;
+                        C1.ex = 1;
                     else
-                        ex0 = 1;
+                        C0.ex = 1;
                     continue;
                 }
                 const bool valid = lane < nvalid;
                 uint32_t m0 = 0, m1 = 0;
                 ListDelta dl{0, 0, false};
                 if (valid) {
-                    const uint32_t qi = idx & (RC - 1);
-                    const uint32_t* rq = ring + ((size_t)lf * RC + qi) * 2;
+                    const uint32_t qi = idx & RCM;
+                    const uint32_t* rq = ring + ((size_t)lf * cv.rc + qi) * 2;
                     m0 = rq[0];
                     m1 = rq[1];
                     const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
@@ -550,7 +582,7 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
                 uint32_t nconsumed = nvalid;
                 if (p.forager != 2) {
                     const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
-                    const uint32_t pre = (uint32_t)__popcll(accmask & lanemask_le(lane));
+                    const uint32_t pre = mbcnt64(accmask) + (acc ? 1u : 0u);
                     const uint64_t cutmask = __ballot(acc && pre == remaining);
                     if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
                 }
@@ -576,7 +608,7 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
                             const uint64_t eq_base = newmax ? 0 : equal_count;
                             const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
                             const uint64_t eq = __ballot(in_eq);
-                            const uint32_t rank = (uint32_t)__popcll(eq & lanemask_le(lane));
+                            const uint32_t rank = mbcnt64(eq) + 1u;
                             const uint64_t cntq = eq_base + rank;
                             const bool pick = in_eq && ((newmax && rank == 1) ||
                                                         (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
@@ -617,8 +649,8 @@ __global__ __launch_bounds__(64 * WPB) void k_list_search_wave(ListModel m, Sear
                 }
                 if (tracing) trace_n += nconsumed;
                 const uint32_t c1 = (uint32_t)__popcll(__ballot(consumed && lf == 1u));
-                head1 += c1;
-                head0 += nconsumed - c1;
+                C1.head += c1;
+                C0.head += nconsumed - c1;
                 pulls += nconsumed;
                 if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
             }

@@ -221,11 +221,15 @@ class GpuScoreDirector:
         return {name: int(getattr(st, name)) for name, _ in StatsStruct._fields_}
 
     def total_stats(self):
-        tot = {}
-        for r in range(self.n_replicas):
-            for k, v in self.stats(r).items():
-                tot[k] = tot.get(k, 0) + v
-        return tot
+        st = StatsStruct()
+        check(self._L.sf_get_stats_sum(self._h, C.byref(st)), self._h)
+        return {name: int(getattr(st, name)) for name, _ in StatsStruct._fields_}
+
+    def engine(self):
+        """The engine launches resolve to: Engine.BLOCK or Engine.WAVE."""
+        e = C.c_int32(0)
+        check(self._L.sf_solver_get_engine(self._h, C.byref(e)), self._h)
+        return e.value
 
     def best_scores(self):
         return self._scores(self._L.sf_get_best_scores)
