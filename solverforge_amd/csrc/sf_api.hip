@@ -484,7 +484,9 @@ template <int L, bool TRACE>
 static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas) {
     WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx));
     size_t lds = cv.total * WPB;
-    auto kern = k_list_search_wave<L, TRACE>;
+    const bool fast = !TRACE && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
+                      p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
+    auto kern = fast ? k_list_search_wave<L, false, true> : k_list_search_wave<L, TRACE, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SearchParams q = p;
     q.n_launch = n_replicas;
@@ -866,6 +868,15 @@ int32_t sf_download_scalar(sf_ctx* ctx, int32_t replica, int32_t d, int32_t var,
 }
 
 }  // extern "C"
+
+#ifdef SF_PHASE_PROFILE
+extern "C" int32_t sf_debug_phases(uint64_t* out8) {  // diagnostic builds only (scripts/phase_probe.py)
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_phase), 64) != hipSuccess) return SF_ERR_HIP;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sf::g_phase), z, 64);
+    return SF_OK;
+}
+#endif
 
 #include "sf_api_scalar.inc"
 #include "sf_portfolio.inc"

@@ -56,6 +56,17 @@ SF_HD uint32_t gcd_u32(uint32_t a, uint32_t b) {  // iter.rs:200-207
 // parity unpinned).  draw k of replica seed s.
 SF_HD uint64_t step_seed(uint64_t random_seed, uint64_t draw) { return splitmix64(random_seed + draw * GOLDEN); }
 
+// x % n.  For n < 2^16 (entity counts, list lengths, leaf counts) four 32-bit remainders over the
+// 16-bit limbs of x replace the 64-bit software division the GPU would otherwise expand to.
+SF_HD uint32_t mod_u64(uint64_t x, uint32_t n) {
+    if (n >= 65536u) return (uint32_t)(x % n);
+    uint32_t r = (uint32_t)(x >> 48) % n;
+    r = ((r << 16) | (uint32_t)((x >> 32) & 0xFFFFu)) % n;
+    r = ((r << 16) | (uint32_t)((x >> 16) & 0xFFFFu)) % n;
+    r = ((r << 16) | (uint32_t)(x & 0xFFFFu)) % n;
+    return r;
+}
+
 struct StreamCtx {
     uint64_t step_index;
     uint64_t step_seed;
@@ -67,11 +78,11 @@ struct StreamCtx {
     }
     SF_HD uint32_t random_index(uint32_t len, uint64_t salt) const {  // iter.rs:90-95
         if (len <= 1) return 0;
-        return (uint32_t)(mixed_seed(salt) % len);
+        return mod_u64(mixed_seed(salt), len);
     }
     SF_HD uint32_t random_stride(uint32_t len, uint64_t salt) const {  // iter.rs:97-106
         if (len <= 1) return 1;
-        uint32_t s = (uint32_t)(mixed_seed(salt) % (len - 1)) + 1;
+        uint32_t s = mod_u64(mixed_seed(salt), len - 1) + 1;
         while (gcd_u32(s, len) != 1) s = (s == len - 1) ? 1 : s + 1;
         return s;
     }
@@ -81,7 +92,7 @@ struct StreamCtx {
         if (order == 3) return random_index(len, salt ^ ((uint64_t)offset * OFFSET_MIX));
         uint32_t start = random_index(len, salt);
         uint32_t st = random_stride(len, salt ^ STRIDE_SALT_MIX);
-        return (uint32_t)(((uint64_t)start + (uint64_t)offset * st) % len);
+        return mod_u64((uint64_t)start + (uint64_t)offset * st, len);
     }
     // permutation parameters of selection_index_without_replacement (iter.rs:133-150)
     SF_HD void perm_params(uint32_t len, uint64_t salt, uint32_t& start, uint32_t& stride) const {
@@ -97,7 +108,7 @@ struct StreamCtx {
 
 SF_HD bool reservoir_pick(uint64_t seed, uint64_t equal_count) {  // forager.rs:143-148
     uint64_t mixed = splitmix64(seed ^ (equal_count * GOLDEN) ^ SALT_RESERVOIR);
-    return mixed % equal_count == 0;
+    return (equal_count < 65536u ? (uint64_t)mod_u64(mixed, (uint32_t)equal_count) : mixed % equal_count) == 0;
 }
 
 SF_HD int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }

@@ -203,6 +203,99 @@ __device__ __forceinline__ ListDelta eval_list_swap(const ListModel& m, const VT
     return r;
 }
 
+// Branch-light trial delta of a ListChange (is_change) or ListSwap move: the move is reduced to at
+// most eight signed matrix legs whose gathers are all issued together (one memory round trip per
+// 64-candidate batch, no divergence between change and swap lanes).  Same results as
+// eval_list_change / eval_list_swap (wrapping i64 sums are order-independent).
+template <class VT>
+__device__ __forceinline__ ListDelta eval_list_move_legs(const ListModel& m, const VT* visits, const uint32_t* off,
+                                                         const int64_t* load, bool is_change, uint32_t a,
+                                                         uint32_t i, uint32_t b, uint32_t j) {
+    ListDelta r{0, 0, false};
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    const uint32_t ob = off[b], lb = off[b + 1] - ob;
+    const bool intra = a == b;
+    if (is_change) {  // move/list_kernel/change.rs:44-71
+        if (i >= la || j > lb || (intra && (j == i || j == i + 1))) return r;
+    } else {  // move/list_kernel/swap.rs:30-56
+        if (i >= la || j >= lb || (intra && i == j)) return r;
+    }
+    const uint32_t depot = (uint32_t)m.depot;
+    if (!is_change && intra && i > j) {  // normalise i < j for the adjacent case (symmetric otherwise)
+        const uint32_t t = i;
+        i = j;
+        j = t;
+    }
+    const uint32_t P = oa + i, Q = ob + j;
+    const uint32_t x = visits[P];
+    const uint32_t pa = i > 0 ? (uint32_t)visits[P - 1] : depot;
+    const uint32_t na = i + 1 < la ? (uint32_t)visits[P + 1] : depot;
+    const uint32_t vq = j < lb ? (uint32_t)visits[Q] : depot;  // change: right neighbour of the slot; swap: y
+    const uint32_t pb = j > 0 ? (uint32_t)visits[Q - 1] : depot;
+    const uint32_t nb = j + 1 < lb ? (uint32_t)visits[Q + 1] : depot;
+    if (!is_change && x == vq) return r;
+    r.doable = true;
+    uint32_t f[8], t[8];
+    int32_t sg[8];
+    if (is_change) {
+        // remove x from (pa, x, na); insert it into the slot (pb, vq) — pre-removal coordinates reduce
+        // to the same neighbours for intra moves (j != i, i+1)
+        const bool src_single = la == 1;
+        const bool dst_empty = !intra && lb == 0;
+        f[0] = pa, t[0] = x, sg[0] = -1;
+        f[1] = x, t[1] = na, sg[1] = -1;
+        f[2] = pa, t[2] = na, sg[2] = src_single ? 0 : 1;
+        f[3] = pb, t[3] = x, sg[3] = 1;
+        f[4] = x, t[4] = vq, sg[4] = 1;
+        f[5] = pb, t[5] = vq, sg[5] = dst_empty ? 0 : -1;
+        f[6] = 0, t[6] = 0, sg[6] = 0;
+        f[7] = 0, t[7] = 0, sg[7] = 0;
+    } else {
+        const uint32_t y = vq;
+        if (intra && j == i + 1) {
+            f[0] = pa, t[0] = y, sg[0] = 1;
+            f[1] = y, t[1] = x, sg[1] = 1;
+            f[2] = x, t[2] = nb, sg[2] = 1;
+            f[3] = pa, t[3] = x, sg[3] = -1;
+            f[4] = x, t[4] = y, sg[4] = -1;
+            f[5] = y, t[5] = nb, sg[5] = -1;
+            f[6] = 0, t[6] = 0, sg[6] = 0;
+            f[7] = 0, t[7] = 0, sg[7] = 0;
+        } else {
+            f[0] = pa, t[0] = y, sg[0] = 1;
+            f[1] = y, t[1] = na, sg[1] = 1;
+            f[2] = pa, t[2] = x, sg[2] = -1;
+            f[3] = x, t[3] = na, sg[3] = -1;
+            f[4] = pb, t[4] = x, sg[4] = 1;
+            f[5] = x, t[5] = nb, sg[5] = 1;
+            f[6] = pb, t[6] = y, sg[6] = -1;
+            f[7] = y, t[7] = nb, sg[7] = -1;
+        }
+    }
+    if (m.dist_level >= 0) {
+        int64_t v[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) v[s] = m.mat[(size_t)f[s] * (size_t)m.dim + t[s]];
+        int64_t acc = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int64_t c = (v[s] >= 0 && v[s] != UNREACHABLE) ? v[s] : MAX_SAFE_LEG_COST;
+            acc = wadd(acc, (int64_t)((uint64_t)c * (uint64_t)(int64_t)sg[s]));
+        }
+        r.d_dist = acc;
+    }
+    if (m.cap_level >= 0 && !intra) {
+        const int64_t dx = (int64_t)m.demand[x];
+        const int64_t dy = is_change ? 0 : (int64_t)m.demand[vq];
+        const int64_t la0 = load[a], lb0 = load[b];
+        const int64_t before = wadd(over_cap(la0, m.capacity), over_cap(lb0, m.capacity));
+        const int64_t after = wadd(over_cap(wadd(wsub(la0, dx), dy), m.capacity),
+                                   over_cap(wadd(wsub(lb0, dy), dx), m.capacity));
+        r.d_cap = wsub(after, before);
+    }
+    return r;
+}
+
 template <int L>
 __device__ __forceinline__ ScoreV<L> apply_delta(const ListModel& m, const int64_t* cur, const ListDelta& d) {
     ScoreV<L> s;

@@ -241,6 +241,23 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
     wave_sync();
 }
 
+#ifdef SF_PHASE_PROFILE
+__device__ unsigned long long g_phase[8];
+#define PH_DECL uint64_t ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(i)                          \
+    {                                  \
+        const uint64_t _t = clock64(); \
+        ph_acc[i] += _t - ph_t;        \
+        ph_t = _t;                     \
+    }
+#define PH_DUMP \
+    if (lane == 0) for (int _k = 0; _k < 8; ++_k) atomicAdd(&g_phase[_k], (unsigned long long)ph_acc[_k]);
+#else
+#define PH_DECL
+#define PH(i)
+#define PH_DUMP
+#endif
+
 // Per-leaf cursor state of one step.  The NEXT source of the leaf is always resolved ahead of use
 // and the first 64-entry chunk of its neighbour row is already in flight (`pk`), so the global
 // load latency hides behind the other leaf's generation and the replay batches.
@@ -253,7 +270,9 @@ struct LeafCursor {
     uint64_t pk;          // per lane: prefetched key chunk 0 of the next source's neighbour row
 };
 
-template <int L, bool TRACE>
+// FAST: compile-time specialisation for the default list policy (nearby change + nearby swap union,
+// LateAcceptance + AcceptedCount, committed steps) — fewer live scalars and branches in the hot loops.
+template <int L, bool TRACE, bool FAST>
 __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -264,9 +283,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
     const uint32_t dim = (uint32_t)m.dim;
 
     // leaf constants (no dynamic indexing of the kernarg block)
-    const int n_leaves = p.n_leaves;
+    const int n_leaves = FAST ? 2 : p.n_leaves;
     const uint32_t K0 = (uint32_t)p.leaf[0].max_nearby, K1 = n_leaves > 1 ? (uint32_t)p.leaf[1].max_nearby : 1u;
-    const bool chg0 = p.leaf[0].kind == 16, chg1 = n_leaves > 1 && p.leaf[1].kind == 16;
+    const bool chg0 = FAST ? true : p.leaf[0].kind == 16, chg1 = FAST ? false : (n_leaves > 1 && p.leaf[1].kind == 16);
+    const int acceptor = FAST ? 1 : p.acceptor, forager = FAST ? 0 : p.forager;
+    const bool dry_run = FAST ? false : p.dry_run != 0;
     const uint64_t desc0 = (uint64_t)p.leaf[0].descriptor, desc1 = n_leaves > 1 ? (uint64_t)p.leaf[1].descriptor : 0;
 
     const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1));
@@ -307,17 +328,19 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
         cur[k] = g_score[k];
         best_sol[k] = m.best_score[(size_t)r * 4 + k];
     }
-    uint64_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_nd = 0, st_scored = 0, st_sources = 0;
+    uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;  // per launch
     uint64_t trace_n = 0;
-    const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
-    const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
-    const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
+    const uint64_t step_index0 = dry_run ? 0 : p.step_index[r];
+    const uint64_t seed_draws0 = dry_run ? 0 : p.seed_draws[r];
+    const int la_idx0 = dry_run ? 0 : p.la_idx[r];
     const uint64_t lanebit = 1ULL << lane;
+    PH_DECL
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
+        PH(7)
         // ---- (A) step start (step.rs:60-74) -------------------------------------------------
         uint64_t sidx, sseed;
-        if (p.dry_run) {
+        if (dry_run) {
             sidx = p.dry_step_index;
             sseed = p.dry_step_seed;
         } else {
@@ -334,8 +357,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
         ScoreV<L> late;
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
-        const int la_slot = p.dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
-        if (p.acceptor == 1) {
+        const int la_slot = dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
+        if (acceptor == 1) {
 #pragma unroll
             for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
         }
@@ -376,6 +399,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             c.pk = lane < dim ? nb.keys[(size_t)sx * dim + lane] : ~0ULL;
         };
 
+        PH(0)
         // ---- (B) per-leaf entity order tables (slot.rs:468-499) --------------------------------
         LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0, ~0ULL};
         LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, n_leaves > 1 ? 0 : 1, ~0ULL};
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             uint16_t* ro = rank_of + l * V;
             uint16_t* sb = slot_base + l * (V + 1);
             for (uint32_t k = lane; k < (uint32_t)V; k += 64) {
-                const uint32_t e = (uint32_t)(((uint64_t)pst + (uint64_t)k * psd) % (uint32_t)V);
+                const uint32_t e = (pst + k * psd) % (uint32_t)V;  // pst, k, psd < V <= 32767
                 ra[k] = (uint16_t)e;
                 ro[e] = (uint16_t)k;
             }
@@ -414,9 +438,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             if (n_leaves > 1) resolve(C1, 1);
         }
 
+        PH(1)
         // ---- (C) candidate rounds: fill the rings, replay one 64-wide batch, repeat -----------
         int done = 0;
         while (!done) {
+            PH(4)
             // C1: generation.  Keep >= 32 candidates pending per live leaf (>= min(64, rc - K) when
             // only one leaf is live) so that the replay batch below finds every lane a candidate.
             for (int l = 0; l < n_leaves; ++l) {
@@ -522,6 +548,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                     C0 = c;
             }
             wave_sync();
+            PH(2)
 
             // C2: replay one batch in union cursor order: trial score, acceptor, forager
             {
@@ -561,10 +588,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                     m0 = rq[0];
                     m1 = rq[1];
                     const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
-                    if (lf ? chg1 : chg0)
-                        dl = eval_list_change(m, s_visits, s_off, s_load, a, i, b, j);
-                    else
-                        dl = eval_list_swap(m, s_visits, s_off, s_load, a, i, b, j);
+                    dl = eval_list_move_legs(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j);
                 }
                 const ScoreV<L> sc = apply_delta<L>(m, cur, dl);
                 ScoreV<L> curv;
@@ -573,15 +597,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 const bool doable = valid && dl.doable;
                 bool acc = false;
                 if (doable) {
-                    if (p.acceptor == 0)
+                    if (acceptor == 0)
                         acc = score_cmp<L>(sc, curv) > 0;
-                    else if (p.acceptor == 1)
+                    else if (acceptor == 1)
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
                 }
                 uint64_t accmask = __ballot(acc);
                 uint32_t nconsumed = nvalid;
-                if (p.forager != 2) {
-                    const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
+                if (forager != 2) {
+                    const uint32_t remaining = forager == 0 ? (uint32_t)p.limit - accepted : 1u;
                     const uint32_t pre = mbcnt64(accmask) + (acc ? 1u : 0u);
                     const uint64_t cutmask = __ballot(acc && pre == remaining);
                     if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
@@ -590,7 +614,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 acc = acc && consumed;
                 accmask = __ballot(acc);
                 if (accmask) {
-                    if (p.forager == 1) {
+                    if (forager == 1) {
                         if (!has_best) {
                             const int sel = __ffsll((unsigned long long)accmask) - 1;
 #pragma unroll
@@ -600,7 +624,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                             best_leaf = (int)__shfl(lf, sel);
                             has_best = 1;
                         }
-                    } else {
+                    } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
                         const ScoreV<L> M = wave_max_score<L>(sc, acc);
                         const int cm = has_best ? score_cmp<L>(M, best) : 1;
                         if (cm >= 0) {
@@ -632,7 +656,6 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 st_scored += nvalid;
                 const uint32_t ndo = (uint32_t)__popcll(__ballot(consumed && doable));
                 st_calc += ndo;
-                st_nd += nconsumed - ndo;
                 if (tracing && consumed) {
                     const uint64_t ti = trace_n + lane;
                     if ((int64_t)ti < p.trace_cap) {
@@ -652,12 +675,14 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 C1.head += c1;
                 C0.head += nconsumed - c1;
                 pulls += nconsumed;
-                if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
+                if ((forager == 0 && accepted >= (uint32_t)p.limit) || (forager == 1 && has_best)) done = 1;
             }
+            PH(3)
         }
+        PH(4)
 
         // ---- (D) commit the forager's pick (step.rs:122-221) ----------------------------------
-        const bool applied = has_best && !p.dry_run;
+        const bool applied = has_best && !dry_run;
         if (applied) {
             const int kind = (best_leaf ? chg1 : chg0) ? 2 : 3;
             const uint32_t a = uni(best_m0 >> 16), i = uni(best_m0 & 0xFFFFu);
@@ -689,7 +714,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
         } else if (tracing && lane == 0) {
             p.trace_applied[0] = 0;
         }
-        if (!p.dry_run) {
+        if (!dry_run) {
             // update_best_solution (scope_progress.rs:89-107): clone on strict improvement
             bool improved = false;
             if (applied) {
@@ -709,17 +734,19 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
             }
             // acceptor.step_ended(last_step_score) always (step.rs:216-221)
-            if (p.acceptor == 1 && lane == 0) {
+            if (acceptor == 1 && lane == 0) {
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
             }
             wave_sync();
             st_steps += 1;
         }
+        PH(5)
     }
+    PH_DUMP
 
     // ---- write back ----------------------------------------------------------------------
-    if (!p.dry_run) {
+    if (!dry_run) {
         const uint32_t tot = uni(s_off[V]);
         for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
         for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
@@ -741,7 +768,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             gs[3] += st_acc;
             gs[4] += st_applied;
             gs[5] += st_calc;
-            gs[6] += st_nd;
+            gs[6] += st_gen - st_calc;
             gs[7] += st_scored;
             gs[8] += st_sources;
         }
