@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__
 
 // LDS carve of ONE replica (bytes); mirrored on the host.
 struct WCarve {
-    size_t load, off, node, ring, visits, slotbase, routeat, rankof, total;
+    size_t load, off, node, ring, visits, slotbase, routeat, rankof, spvec, total;
     uint32_t rc;  // ring capacity per leaf
     __host__ __device__ WCarve(int V, int n_cap, int dim, int max_k) {
         rc = max_k <= 32 ? RC_SMALL : RC_MAX;
@@ -114,6 +114,8 @@ struct WCarve {
         o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
         rankof = o;
         o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
+        spvec = o;
+        o = align_up(o + sizeof(uint16_t) * 64 * MAX_LEAVES, 16);
         total = o;
     }
 };
@@ -130,51 +132,28 @@ struct NearbyItem {
 __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot, uint32_t se, uint32_t sp,
                                                   uint32_t len, uint32_t k, const uint32_t* s_off,
                                                   const uint16_t* sb, const uint16_t* ro) {
-    NearbyItem it{0u, 0u, 0u, 0u};
-    if (slot == NODE_NONE) return it;
-    const uint32_t r2 = slot >> 16, dp = slot & 0xFFFFu;
+    // branch-free: every lane reads its route's length / rank / slot base (route 0 for unassigned nodes)
+    const bool some = slot != NODE_NONE;
+    const uint32_t r2 = some ? slot >> 16 : 0u, dp = slot & 0xFFFFu;
+    const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
+    const uint32_t rk = ro[r2];
+    const uint32_t inter_ord = ORD_INTER_BASE + (uint32_t)sb[rk] + dp;
+    const bool intra = r2 == se;
+    const uint32_t end_pay = (r2 << 16) | len2;
+    NearbyItem it;
     if (is_change) {  // nearby_change.rs:133-195
-        if (r2 == se) {
-            const bool v0 = dp != sp && dp != sp + 1;
-            const bool v1 = dp + 1 == len && len != sp + 1;  // end slot `len` probes element len-1
-            if (v0) {
-                it.ord = dp;
-                it.pay0 = slot;
-                it.w = 1;
-                if (v1) {
-                    it.pay1 = (r2 << 16) | len;
-                    it.w = 2;
-                }
-            } else if (v1) {
-                it.ord = len;
-                it.pay0 = (r2 << 16) | len;
-                it.w = 1;
-            }
-        } else {
-            const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
-            it.ord = ORD_INTER_BASE + (uint32_t)sb[ro[r2]] + dp;
-            it.pay0 = slot;
-            it.w = 1;
-            if (dp + 1 == len2) {
-                it.pay1 = (r2 << 16) | len2;
-                it.w = 2;
-            }
-        }
+        const bool v0 = !intra || (dp != sp && dp != sp + 1);
+        const bool v1 = dp + 1 == len2 && (!intra || len != sp + 1);  // end slot `len` probes element len-1
+        it.w = some ? (uint32_t)v0 + (uint32_t)v1 : 0u;
+        it.ord = intra ? (v0 ? dp : len) : inter_ord;
+        it.pay0 = v0 ? slot : end_pay;
+        it.pay1 = end_pay;
     } else {  // nearby_swap.rs: intra partners after the source, inter only higher-ranked entities
-        if (r2 == se) {
-            if (dp > sp) {
-                it.ord = dp;
-                it.pay0 = slot;
-                it.w = 1;
-            }
-        } else {
-            const uint32_t rk = ro[r2];
-            if (rk > k) {
-                it.ord = ORD_INTER_BASE + (uint32_t)sb[rk] + dp;
-                it.pay0 = slot;
-                it.w = 1;
-            }
-        }
+        const bool v = intra ? dp > sp : rk > k;
+        it.w = (some && v) ? 1u : 0u;
+        it.ord = intra ? dp : inter_ord;
+        it.pay0 = slot;
+        it.pay1 = 0;
     }
     return it;
 }
@@ -266,6 +245,7 @@ struct LeafCursor {
     uint32_t left;        // sources not yet generated
     uint32_t k, o;        // next source: entity rank / offset inside the entity's list
     uint32_t se, len, sp, sx;  // next source resolved: entity, its list length, position, element
+    uint32_t vk, vbase;        // entity rank / offset base the leaf's spvec holds (0xFFFFFFFF = none)
     int ex;               // exhausted (union scheduler)
     uint64_t pk;          // per lane: prefetched key chunk 0 of the next source's neighbour row
 };
@@ -301,6 +281,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
     uint16_t* slot_base = (uint16_t*)(mem + cv.slotbase);
     uint16_t* route_at = (uint16_t*)(mem + cv.routeat);
     uint16_t* rank_of = (uint16_t*)(mem + cv.rankof);
+    uint16_t* spvec = (uint16_t*)(mem + cv.spvec);  // [leaf][64] source positions of the current entity
 
     uint32_t* g_visits = m.visits + (size_t)r * m.n_cap;
     uint32_t* g_off = m.off + (size_t)r * (V + 1);
@@ -386,9 +367,18 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 ++k;
                 o = 0;
             }
-            const uint64_t src_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^
-                                      (uint64_t)se ^ (l ? desc1 : desc0);
-            const uint32_t sp = uni(ctx.selection_index(o, len, src_salt));
+            uint16_t* spv = spvec + l * 64;
+            if (k != c.vk || (o & ~63u) != c.vbase) {
+                // source positions of 64 consecutive offsets of this entity, one per lane
+                const uint64_t src_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^
+                                          (uint64_t)se ^ (l ? desc1 : desc0);
+                const uint32_t oo = (o & ~63u) + lane;
+                spv[lane] = (uint16_t)(oo < len ? ctx.selection_index(oo, len, src_salt) : 0u);
+                c.vk = k;
+                c.vbase = o & ~63u;
+                wave_sync();
+            }
+            const uint32_t sp = uni((uint32_t)spv[o & 63u]);
             const uint32_t sx = uni((uint32_t)s_visits[s_off[se] + sp]);
             c.k = k;
             c.o = o;
@@ -401,8 +391,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
 
         PH(0)
         // ---- (B) per-leaf entity order tables (slot.rs:468-499) --------------------------------
-        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0, ~0ULL};
-        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, n_leaves > 1 ? 0 : 1, ~0ULL};
+        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, ~0ULL};
+        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, n_leaves > 1 ? 0 : 1, ~0ULL};
         for (int l = 0; l < n_leaves; ++l) {
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
