@@ -103,13 +103,16 @@ def main():
 
     entry.build()
     import solverforge_amd as sfa
-    from solverforge_amd import datasets
+    from solverforge_amd import datasets, portfolio
 
     problem = datasets.make_cvrp(args.customers, args.vehicles, args.capacity, seed=args.seed)
-    d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank)
+    from solverforge_amd import _lib
+
+    n_dev = max(_lib.load().sf_device_count(), 1)
+    d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank % n_dev)
     d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
     # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
-    d.configure(sfa.SolverConfig(random_seed=args.seed + rank * args.replicas))
+    d.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, args.replicas)))
     start_score = d.calculate_score()[0].tolist()
     engine = {1: "block", 2: "wave"}[d.engine()]
     d.phase_start()
@@ -131,11 +134,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
-
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = portfolio.max_over_ranks(dist, elapsed)
     kernel_ms, launches = d.profile_solve()  # HIP events on the context stream (the launch stream)
     after = d.total_stats()
     delta = {k: after[k] - before[k] for k in after}
@@ -145,11 +144,7 @@ def main():
     scored_local = delta["candidates_scored"]
     moves_total = moves_local
     if dist is not None:
-        import torch
-
-        t = torch.tensor([moves_local], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        moves_total = float(t.item())
+        moves_total = portfolio.sum_over_ranks(dist, moves_local)
 
     # portfolio exchange: RCCL all-gather of best scores (correctness: identical winner everywhere)
     exchange = "single-rank"
@@ -168,12 +163,8 @@ def main():
             exchange = "rccl-allgather"
             d.portfolio_destroy()
         except Exception as e:  # keep the bench alive; report the fallback honestly
-            tl = torch.tensor(list(best_local), dtype=torch.int64)
-            gathered = [torch.zeros_like(tl) for _ in range(world)]
-            dist.all_gather(gathered, tl)
-            scores = [tuple(int(v) for v in g) for g in gathered]
-            wr = max(range(world), key=lambda q: (scores[q], -q))
-            winner = {"score": list(scores[wr]), "rank": wr}
+            wr, ws = portfolio.gloo_allgather_best(dist, best_local, rank, world)
+            winner = {"score": ws, "rank": wr}
             exchange = f"gloo-fallback ({type(e).__name__}: {e})"
 
     if rank == 0:
@@ -255,6 +246,12 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        # torch bundles its own HIP runtime next to the ROCm one this library links: skip the
+        # interpreter's exit-time destructors of the two copies
+        sys.stdout.flush()
+        sys.stderr.flush()
+        d.close()
+        os._exit(0)
 
 
 if __name__ == "__main__":
