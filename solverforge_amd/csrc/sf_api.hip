@@ -359,6 +359,16 @@ static int build_list_model(sf_ctx* ctx, int d) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_list_model = true;
     ctx->list_desc = d;
+    // compact u32 matrix copy (4-byte gathers in the trial-score path) when every finite leg fits
+    for (auto& kv : ctx->facts)
+        if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat && kv.second.max_finite < 0xFFFFFFFFLL) {
+            uint32_t* m32 = nullptr;
+            const size_t n = (size_t)m.dim * m.dim;
+            if ((rc = dalloc(ctx, &m32, n))) return rc;
+            hipLaunchKernelGGL(k_mat_compress, dim3(1024), dim3(256), 0, ctx->stream, m.mat, n, m32);
+            HIPCHK(ctx, hipGetLastError());
+            m.mat32 = m32;
+        }
     // presorted neighbour index for the wave engine: every matrix row sorted by (distance, node)
     bool nearby = false;
     for (auto& s : ctx->selectors)
@@ -366,7 +376,7 @@ static int build_list_model(sf_ctx* ctx, int d) {
     int P = 2;
     while (P < m.dim) P <<= 1;
     if (nearby && m.mat && (size_t)P * 8 <= 128 * 1024) {
-        uint64_t* keys = nullptr;
+        uint16_t* keys = nullptr;
         if ((rc = dalloc(ctx, &keys, (size_t)m.dim * m.dim))) return rc;
         HIPCHK(ctx, hipFuncSetAttribute((const void*)k_nbr_presort, hipFuncAttributeMaxDynamicSharedMemorySize, P * 8));
         hipLaunchKernelGGL(k_nbr_presort, dim3(m.dim), dim3(256), (size_t)P * 8, ctx->stream, m.mat, m.dim, P, keys);
@@ -484,7 +494,7 @@ template <int L, bool TRACE>
 static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas) {
     WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx));
     size_t lds = cv.total * WPB;
-    const bool fast = !TRACE && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
+    const bool fast = !TRACE && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
                       p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
     auto kern = fast ? k_list_search_wave<L, false, true> : k_list_search_wave<L, TRACE, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -210,7 +210,7 @@ __device__ __forceinline__ ListDelta eval_list_swap(const ListModel& m, const VT
 // most eight signed matrix legs whose gathers are all issued together (one memory round trip per
 // 64-candidate batch, no divergence between change and swap lanes).  Same results as
 // eval_list_change / eval_list_swap (wrapping i64 sums are order-independent).
-template <class VT>
+template <class VT, bool M32>
 __device__ __forceinline__ ListDelta eval_list_move_legs(const ListModel& m, const VT* visits, const uint32_t* off,
                                                          const int64_t* load, bool is_change, uint32_t a,
                                                          uint32_t i, uint32_t b, uint32_t j) {
@@ -276,14 +276,25 @@ __device__ __forceinline__ ListDelta eval_list_move_legs(const ListModel& m, con
         }
     }
     if (m.dist_level >= 0) {
-        int64_t v[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = m.mat[(size_t)f[s] * (size_t)m.dim + t[s]];
         int64_t acc = 0;
+        if (M32) {  // compact matrix copy: 4-byte gathers
+            uint32_t v[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int64_t c = (v[s] >= 0 && v[s] != UNREACHABLE) ? v[s] : MAX_SAFE_LEG_COST;
-            acc = wadd(acc, (int64_t)((uint64_t)c * (uint64_t)(int64_t)sg[s]));
+            for (int s = 0; s < 8; ++s) v[s] = m.mat32[(size_t)f[s] * (size_t)m.dim + t[s]];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int64_t c = v[s] != 0xFFFFFFFFu ? (int64_t)v[s] : MAX_SAFE_LEG_COST;
+                acc = wadd(acc, (int64_t)((uint64_t)c * (uint64_t)(int64_t)sg[s]));
+            }
+        } else {
+            int64_t v[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v[s] = m.mat[(size_t)f[s] * (size_t)m.dim + t[s]];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int64_t c = (v[s] >= 0 && v[s] != UNREACHABLE) ? v[s] : MAX_SAFE_LEG_COST;
+                acc = wadd(acc, (int64_t)((uint64_t)c * (uint64_t)(int64_t)sg[s]));
+            }
         }
         r.d_dist = acc;
     }
@@ -311,6 +322,15 @@ __device__ __forceinline__ ScoreV<L> apply_delta(const ListModel& m, const int64
         if (k == m.dist_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.dist_weight * (uint64_t)d.d_dist));
     }
     return s;
+}
+
+// compact u32 copy of the distance matrix (distance_cost semantics preserved: not-finite -> sentinel)
+__global__ __launch_bounds__(256) void k_mat_compress(const int64_t* __restrict__ mat, size_t n,
+                                                      uint32_t* __restrict__ out) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int64_t v = mat[t];
+        out[t] = (v >= 0 && v != UNREACHABLE) ? (uint32_t)v : 0xFFFFFFFFu;
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -22,6 +22,7 @@ struct ListModel {
     int32_t levels;     // score levels
     // facts
     const int64_t* mat; // dim x dim row-major (MatrixDistanceMeter + distance constraint)
+    const uint32_t* mat32;  // optional compact copy: finite legs < 2^32-1 as u32, 0xFFFFFFFF = not finite
     const int32_t* demand;
     const uint32_t* ne_keys;  // not-exists A-side keys (Customer.id)
     int32_t ne_n;

@@ -27,17 +27,20 @@ namespace sf {
 
 constexpr uint32_t RC_MAX = 128;   // ring capacity per leaf when max_nearby > 32 (>= 64 + 64 - 1)
 constexpr uint32_t RC_SMALL = 64;  // ring capacity per leaf when max_nearby <= 32 (>= 32 + 32)
-constexpr uint64_t NBR_NODE_MASK = 0x7FFFFFull;   // node id (dim <= 16384 in the wave engine)
-constexpr uint64_t NBR_SAME_FLAG = 0x800000ull;   // same distance as the previous entry of the row
+constexpr uint32_t NBR_NODE_MASK = 0x7FFFu;  // node id (dim <= 16384 in the wave engine)
+constexpr uint32_t NBR_SAME_FLAG = 0x8000u;  // same distance as the previous entry of the row
+constexpr uint32_t NBR_END = 0xFFFFu;        // past the finite entries of the row
 #ifndef SF_WPB
 #define SF_WPB 4
 #endif
 constexpr int WPB = SF_WPB;  // waves (= replicas) per workgroup
 
 struct NbrIndex {
-    // [dim][dim] per row ascending (distance << 24 | same-distance-as-previous flag << 23 | node);
-    // non-finite legs (negative / UNREACHABLE, meters.rs:21-23) sort to the end as ~0
-    const uint64_t* keys;
+    // [dim][dim] u16 per entry: the nodes of every matrix row in ascending (distance, node) order as
+    // (same-distance-as-previous flag << 15 | node); non-finite legs (negative / UNREACHABLE,
+    // meters.rs:21-23) sort to the end as NBR_END.  Distances themselves are not stored: the
+    // (distance, enumeration ordinal) order only needs the group boundaries.
+    const uint16_t* keys;
 };
 
 // wavefront-scope ordering of LDS/global traffic between lanes of one wave (no instruction cost:
@@ -56,7 +59,7 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 // Neighbour index: bitonic sort of every matrix row in LDS.  grid = dim rows.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__ mat, int dim, int P,
-                                                     uint64_t* __restrict__ keys) {
+                                                     uint16_t* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* sk = (uint64_t*)smem;
     const int row = blockIdx.x;
@@ -85,9 +88,13 @@ __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__
             __syncthreads();
         }
     for (int t = threadIdx.x; t < dim; t += blockDim.x) {
-        uint64_t k = sk[t];
-        if (k != ~0ULL && t > 0 && (sk[t - 1] >> 24) == (k >> 24)) k |= NBR_SAME_FLAG;
-        keys[(size_t)row * dim + t] = k;
+        const uint64_t k = sk[t];
+        uint32_t e = NBR_END;
+        if (k != ~0ULL) {
+            e = (uint32_t)k & NBR_NODE_MASK;
+            if (t > 0 && (sk[t - 1] >> 24) == (k >> 24)) e |= NBR_SAME_FLAG;
+        }
+        keys[(size_t)row * dim + t] = (uint16_t)e;
     }
 }
 
@@ -247,7 +254,7 @@ struct LeafCursor {
     uint32_t se, len, sp, sx;  // next source resolved: entity, its list length, position, element
     uint32_t vk, vbase;        // entity rank / offset base the leaf's spvec holds (0xFFFFFFFF = none)
     int ex;               // exhausted (union scheduler)
-    uint64_t pk;          // per lane: prefetched key chunk 0 of the next source's neighbour row
+    uint32_t pk;          // per lane: prefetched entry of chunk 0 of the next source's neighbour row
 };
 
 // FAST: compile-time specialisation for the default list policy (nearby change + nearby swap union,
@@ -386,13 +393,13 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             c.len = len;
             c.sp = sp;
             c.sx = sx;
-            c.pk = lane < dim ? nb.keys[(size_t)sx * dim + lane] : ~0ULL;
+            c.pk = lane < dim ? (uint32_t)nb.keys[(size_t)sx * dim + lane] : NBR_END;
         };
 
         PH(0)
         // ---- (B) per-leaf entity order tables (slot.rs:468-499) --------------------------------
-        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, ~0ULL};
-        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, n_leaves > 1 ? 0 : 1, ~0ULL};
+        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, NBR_END};
+        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, n_leaves > 1 ? 0 : 1, NBR_END};
         for (int l = 0; l < n_leaves; ++l) {
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
@@ -446,9 +453,10 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 uint32_t* rq = ring + (size_t)l * cv.rc * 2;
                 while (!c.ex && c.left > 0 && c.tail - c.head < target) {
                     const uint32_t se = c.se, sp = c.sp, len = c.len, k = c.k;
-                    const uint64_t* rowk = nb.keys + (size_t)c.sx * dim;
+                    const uint16_t* rowk = nb.keys + (size_t)c.sx * dim;
+                    const uint32_t sx = c.sx;
                     const uint32_t mv0 = (se << 16) | sp;
-                    uint64_t key = c.pk;
+                    uint32_t key = c.pk;
                     // put the next source's first chunk in flight before working on this one
                     c.left -= 1;
                     c.o += 1;
@@ -456,11 +464,11 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                     st_sources += 1;
                     uint32_t need = K, emitted = 0, base = 0;
                     for (;;) {
-                        const bool have = key != ~0ULL;
+                        const bool have = key != NBR_END;
                         const uint64_t havemask = __ballot(have);
                         if (havemask == 0) break;  // finite entries of the row exhausted
                         NearbyItem it{0u, 0u, 0u, 0u};
-                        if (have) it = nearby_item(is_change, node_slot[(uint32_t)(key & NBR_NODE_MASK)], se, sp, len, k, s_off, sb, ro);
+                        if (have) it = nearby_item(is_change, node_slot[key & NBR_NODE_MASK], se, sp, len, k, s_off, sb, ro);
                         // equal-distance groups are contiguous lane ranges; the index marks entries that
                         // continue the previous entry's distance
                         const uint64_t startmask = __ballot(have && (lane == 0 || !(key & NBR_SAME_FLAG)));
@@ -472,11 +480,15 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                             TopK tk{~0ULL, 0u, ~0ULL};
                             for (uint32_t b2 = base; b2 < dim; b2 += 64) {
                                 const uint32_t j2 = b2 + lane;
-                                const uint64_t ky = j2 < dim ? rowk[j2] : ~0ULL;
+                                const uint32_t ky = j2 < dim ? (uint32_t)rowk[j2] : NBR_END;
                                 NearbyItem i2{0u, 0u, 0u, 0u};
-                                if (ky != ~0ULL) i2 = nearby_item(is_change, node_slot[(uint32_t)(ky & NBR_NODE_MASK)], se, sp, len, k, s_off, sb, ro);
-                                if (!__ballot(ky != ~0ULL)) break;
-                                const uint64_t hk = ky & ~0xFFFFFFULL;
+                                uint64_t hk = 0;
+                                if (ky != NBR_END) {
+                                    const uint32_t y2 = ky & NBR_NODE_MASK;
+                                    i2 = nearby_item(is_change, node_slot[y2], se, sp, len, k, s_off, sb, ro);
+                                    hk = (uint64_t)m.mat[(size_t)sx * dim + y2] << 24;  // finite by construction of the index
+                                }
+                                if (!__ballot(ky != NBR_END)) break;
                                 topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
                                 topk_offer(tk, need, i2.w == 2 ? (hk | (i2.ord + 1)) : ~0ULL, i2.pay1);
                             }
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                         if (need == 0 || !more) break;
                         base += nclosed;
                         const uint32_t jj = base + lane;
-                        key = jj < dim ? rowk[jj] : ~0ULL;
+                        key = jj < dim ? (uint32_t)rowk[jj] : NBR_END;
                     }
                     c.tail += emitted;
                 }
@@ -578,7 +590,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                     m0 = rq[0];
                     m1 = rq[1];
                     const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
-                    dl = eval_list_move_legs(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j);
+                    dl = eval_list_move_legs<uint16_t, FAST>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j);
                 }
                 const ScoreV<L> sc = apply_delta<L>(m, cur, dl);
                 ScoreV<L> curv;
