@@ -313,8 +313,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
     int64_t cur[L], best_sol[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-        cur[k] = g_score[k];
-        best_sol[k] = m.best_score[(size_t)r * 4 + k];
+        cur[k] = (int64_t)uni64((uint64_t)g_score[k]);  // wave-uniform: keep in scalar registers
+        best_sol[k] = (int64_t)uni64((uint64_t)m.best_score[(size_t)r * 4 + k]);
     }
     uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;  // per launch
     uint64_t trace_n = 0;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
         const int la_slot = dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
         if (acceptor == 1) {
 #pragma unroll
-            for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
+            for (int k = 0; k < L; ++k) late.v[k] = (int64_t)uni64((uint64_t)p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k]);
         }
         int has_best = 0;
         uint64_t equal_count = 0;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                         if (!has_best) {
                             const int sel = __ffsll((unsigned long long)accmask) - 1;
 #pragma unroll
-                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)shfl_u64((uint64_t)sc.v[kk], sel);
+                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64(shfl_u64((uint64_t)sc.v[kk], sel));
                             best_m0 = __shfl(m0, sel);
                             best_m1 = __shfl(m1, sel);
                             best_leaf = (int)__shfl(lf, sel);
@@ -645,7 +645,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                                 best_m1 = __shfl(m1, sel);
                                 best_leaf = (int)__shfl(lf, sel);
                             }
-                            best = M;
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64((uint64_t)M.v[kk]);
                             equal_count = eq_base + (uint64_t)__popcll(eq);
                             has_best = 1;
                         }
