@@ -1,0 +1,35 @@
+"""M2 of BASELINE.md: best HardSoftScore after `seconds` of wall time, GPU portfolio vs the CPU oracle
+(1 host core), same CVRP-1000 instance and default list policy."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import solverforge_amd as sfa
+from solverforge_amd import datasets
+from oracle import sfo
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+replicas = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+p = datasets.make_cvrp(1000, 100, 55, seed=0)
+d = sfa.build_cvrp(p, n_replicas=replicas)
+d.configure(sfa.SolverConfig(random_seed=0))
+d.calculate_score(); d.phase_start()
+t0 = time.perf_counter(); trace = []
+while time.perf_counter() - t0 < seconds:
+    d.solve_steps(200)
+    if len(trace) % 25 == 0:
+        trace.append((round(time.perf_counter() - t0, 1), list(max(tuple(int(v) for v in s) for s in d.best_scores()))))
+    else:
+        trace.append(None)
+gt = time.perf_counter() - t0
+st = d.total_stats()
+gpu = {"seconds": gt, "replicas": replicas, "best_score": list(max(tuple(int(v) for v in s) for s in d.best_scores())),
+       "moves_evaluated": st["moves_evaluated"], "ls_steps_per_replica": st["step_count"] // replicas,
+       "moves_per_s": st["moves_evaluated"] / gt, "trace": [t for t in trace if t]}
+o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+o.configure(leaves=sfo.LEAF_NEARBY_LIST_CHANGE | sfo.LEAF_NEARBY_LIST_SWAP, max_nearby=20, random_seed=0)
+o.phase_start()
+t0 = time.perf_counter()
+steps = o.steps_timed(seconds)
+ct = time.perf_counter() - t0
+cpu = {"seconds": ct, "best_score": [int(v) for v in o.best_score()[:2]], "ls_steps": int(steps),
+       "moves_evaluated": o.stats()["moves_evaluated"], "moves_per_s": o.stats()["moves_evaluated"] / ct}
+print(json.dumps({"gpu": gpu, "cpu_oracle_1core": cpu}))

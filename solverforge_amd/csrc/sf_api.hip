@@ -3,6 +3,7 @@
 // No CPU fallback lives here: without a HIP device every entry point fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -681,7 +682,7 @@ int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine) {
 
 int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine) {
     if (!ctx || !ctx->initialized || !out_engine) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
-    *out_engine = ctx->has_list_model && use_wave_engine(ctx) ? SF_ENGINE_WAVE : SF_ENGINE_BLOCK;
+    *out_engine = (ctx->has_scalar_model || use_wave_engine(ctx)) ? SF_ENGINE_WAVE : SF_ENGINE_BLOCK;
     return SF_OK;
 }
 

@@ -1,5 +1,25 @@
-// Scalar-variable hot path (graph colouring / N-queens / job-shop machine assignment).
-// Round-1 status: parameter block + placeholders; the fused scalar search kernel lands next.
+// Scalar-variable hot path (graph colouring / N-queens / machine assignment), gfx950 wave64.
+//
+// Reference semantics restated (paths under crates/solverforge-solver/src/ unless noted):
+//   heuristic/selector/scalar_neighborhood/cursor/change.rs:27-121   scalar change stream
+//   heuristic/selector/scalar_neighborhood/cursor/swap.rs:22-160     scalar swap stream
+//   heuristic/selector/scalar_neighborhood/cursor.rs:371-378         slot_identity
+//   heuristic/selector/scalar_neighborhood/move/apply.rs:15-35,219-245 doability
+//   heuristic/move/change.rs:118-221, heuristic/move/swap.rs:150-215 move semantics
+//   crates/solverforge-scoring/src/constraint/incremental.rs:19-193              uni (unassigned)
+//   crates/solverforge-scoring/src/constraint/cross_bi_incremental/{state,incremental}.rs
+//       predicate cross-join on one class (constant key, stream/join_target.rs:82-110)
+//   examples/scalar-graph-coloring/src/domain/graph_coloring.rs:21-44, examples/nqueens/src/domain/board.rs:21-47
+//
+// GPU formulation: the reference re-tests all n rows of the predicate join on every insert
+// (cross_bi_incremental/state.rs:392-397).  A predicate "partners with an equal value" only ever
+// matches inside a declared partner set (graph adjacency, same group), so the device keeps a
+// symmetric partner CSR and a trial delta is conflicts(e, new) - conflicts(e, old): deg(e) colour
+// lookups, no state mutation, identical integer result.
+//
+// Engine: one wavefront = one search replica, values (i8 / i16) in the wave's LDS slice, rings of
+// candidate coordinates per leaf, 64-wide replay in union cursor order (same step loop as
+// sf_list_wave.hip; citations for acceptor / forager / union there and in sf_list_kernels.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,20 +28,604 @@
 
 namespace sf {
 
+enum ScalarCrossKind : int32_t { SC_NONE = 0, SC_PARTNERS_EQUAL = 1, SC_QUEENS = 2 };
+
 struct ScalarModel {
-    int32_t n = 0;        // entities
+    int32_t n = 0;  // entities
     int32_t n_values = 0;
     int32_t allows_unassigned = 0;
     int32_t levels = 2;
-    int32_t* vals = nullptr;       // [R][n]  (-1 = None)
-    int64_t* score = nullptr;      // [R][4]
-    int32_t* best_vals = nullptr;  // [R][n]
-    int64_t* best_score = nullptr; // [R][4]
+    int32_t descriptor = 0, variable = 0;  // slot identity (cursor.rs:371-378)
+    // constraints (level < 0 = absent)
+    int32_t un_level = -1, cross_level = -1, cross_kind = SC_NONE;
+    int64_t un_weight = 0, cross_weight = 0;
+    const uint32_t* pn_off = nullptr;  // [n+1] symmetric partner CSR (SC_PARTNERS_EQUAL)
+    const uint32_t* pn = nullptr;
+    const int32_t* col = nullptr;      // [n] column fact (SC_QUEENS)
+    // per-replica committed state
+    int32_t* vals = nullptr;        // [R][n]  (-1 = None)
+    int64_t* score = nullptr;       // [R][4]
+    int32_t* best_vals = nullptr;   // [R][n]
+    int64_t* best_score = nullptr;  // [R][4]
 };
 
-__global__ void k_scalar_evaluate_all(ScalarModel, int64_t*, int) {}
-__global__ void k_scalar_evaluate_moves(ScalarModel, int, const int32_t*, int64_t, int64_t*, int32_t*) {}
-__global__ void k_scalar_apply(ScalarModel, int, int, int, int, int, int32_t*) {}
-__global__ void k_scalar_phase_start(ScalarModel, SearchParams) {}
+// matches of entity e holding `val` against every partner except `skip`
+template <class VT>
+__device__ __forceinline__ int64_t scalar_conflicts(const ScalarModel& m, const VT* vals, uint32_t e, int32_t val,
+                                                    uint32_t skip) {
+    if (val < 0) return 0;
+    int64_t c = 0;
+    if (m.cross_kind == SC_PARTNERS_EQUAL) {
+        const uint32_t p1 = m.pn_off[e + 1];
+        for (uint32_t p = m.pn_off[e]; p < p1; ++p) {
+            const uint32_t o = m.pn[p];
+            if (o != skip && (int32_t)vals[o] == val) ++c;
+        }
+    } else if (m.cross_kind == SC_QUEENS) {  // board.rs:30-44: distinct columns, same row or same diagonal
+        const int32_t ce = m.col[e];
+        for (uint32_t o = 0; o < (uint32_t)m.n; ++o) {
+            const int32_t vo = (int32_t)vals[o], co = m.col[o];
+            if (o == e || o == skip || vo < 0 || co == ce) continue;
+            const int32_t dr = vo > val ? vo - val : val - vo;
+            const int32_t dc = co > ce ? co - ce : ce - co;
+            if (vo == val || dr == dc) ++c;
+        }
+    }
+    return c;
+}
+
+struct ScalarDelta {
+    int64_t d_un;     // change of the number of unassigned entities
+    int64_t d_cross;  // change of the number of matched pairs
+    bool doable;
+};
+
+// kind 0: Change(a -> value); kind 1: Swap(a, b)
+template <class VT>
+__device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, const VT* vals, int kind, uint32_t a,
+                                                        uint32_t b, int32_t value) {
+    ScalarDelta r{0, 0, false};
+    if (kind == 0) {  // apply.rs:15-24,219-230
+        if (a >= (uint32_t)m.n || value >= m.n_values || value < -1) return r;
+        const int32_t old = (int32_t)vals[a];
+        if (old == value) return r;
+        if (value < 0 && !m.allows_unassigned) return r;
+        r.doable = true;
+        r.d_un = (value < 0 ? 1 : 0) - (old < 0 ? 1 : 0);
+        if (m.cross_level >= 0)
+            r.d_cross = scalar_conflicts(m, vals, a, value, 0xFFFFFFFFu) - scalar_conflicts(m, vals, a, old, 0xFFFFFFFFu);
+    } else {  // apply.rs:25-35,232-245
+        if (a >= (uint32_t)m.n || b >= (uint32_t)m.n || a == b) return r;
+        const int32_t va = (int32_t)vals[a], vb = (int32_t)vals[b];
+        if (va == vb) return r;
+        r.doable = true;
+        if (m.cross_level >= 0)
+            r.d_cross = scalar_conflicts(m, vals, a, vb, b) - scalar_conflicts(m, vals, a, va, b) +
+                        scalar_conflicts(m, vals, b, va, a) - scalar_conflicts(m, vals, b, vb, a);
+    }
+    return r;
+}
+
+template <int L>
+__device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, const int64_t* cur, const ScalarDelta& d) {
+    ScoreV<L> s;
+#pragma unroll
+    for (int k = 0; k < L; ++k) s.v[k] = cur[k];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        if (k == m.un_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.un_weight * (uint64_t)d.d_un));
+        if (k == m.cross_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.cross_weight * (uint64_t)d.d_cross));
+    }
+    return s;
+}
+
+// evaluate_all / initialize: full recomputation (fresh_score; FullAssert).  grid = R blocks.
+__global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit) {
+    __shared__ unsigned long long s_un, s_cross;
+    const int r = blockIdx.x;
+    const int32_t* vals = m.vals + (size_t)r * m.n;
+    if (threadIdx.x == 0) {
+        s_un = 0;
+        s_cross = 0;
+    }
+    __syncthreads();
+    unsigned long long un = 0, cross = 0;
+    for (uint32_t e = threadIdx.x; e < (uint32_t)m.n; e += blockDim.x) {
+        const int32_t v = vals[e];
+        if (v < 0) ++un;
+        if (m.cross_level >= 0 && v >= 0) {
+            // every matched pair is seen from both sides: count it at its lower index
+            if (m.cross_kind == SC_PARTNERS_EQUAL) {
+                for (uint32_t p = m.pn_off[e]; p < m.pn_off[e + 1]; ++p) {
+                    const uint32_t o = m.pn[p];
+                    if (o > e && vals[o] == v) ++cross;
+                }
+            } else if (m.cross_kind == SC_QUEENS) {
+                const int32_t ce = m.col[e];
+                for (uint32_t o = e + 1; o < (uint32_t)m.n; ++o) {
+                    const int32_t vo = vals[o], co = m.col[o];
+                    if (vo < 0 || co == ce) continue;
+                    const int32_t dr = vo > v ? vo - v : v - vo, dc = co > ce ? co - ce : ce - co;
+                    if (vo == v || dr == dc) ++cross;
+                }
+            }
+        }
+    }
+    atomicAdd(&s_un, un);
+    atomicAdd(&s_cross, cross);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int64_t sc[SF_MAX_LEVELS_CONST] = {0, 0, 0, 0};
+        if (m.un_level >= 0) sc[m.un_level] = wsub(sc[m.un_level], (int64_t)((uint64_t)m.un_weight * s_un));
+        if (m.cross_level >= 0) sc[m.cross_level] = wsub(sc[m.cross_level], (int64_t)((uint64_t)m.cross_weight * s_cross));
+        for (int k = 0; k < m.levels; ++k) {
+            if (out_scores) out_scores[(size_t)r * m.levels + k] = sc[k];
+            if (commit) m.score[(size_t)r * 4 + k] = sc[k];
+        }
+    }
+}
+
+// n x evaluate_candidate for host-provided moves (the ScalarCandidateProvider surface: a batch of
+// ScalarEdit{entity, to_value} is kind = SF_MOVE_CHANGE): one thread per move, state unchanged.
+__global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, int replica, const int32_t* moves,
+                                                               int64_t n, int64_t* out_scores, int32_t* out_doable) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int32_t* vals = m.vals + (size_t)replica * m.n;
+    const int64_t* cur = m.score + (size_t)replica * 4;
+    const int32_t* mv = moves + t * 6;
+    ScalarDelta d{0, 0, false};
+    if (mv[0] == 0 && mv[1] >= 0)
+        d = eval_scalar_move(m, vals, 0, (uint32_t)mv[1], 0u, mv[5]);
+    else if (mv[0] == 1 && mv[1] >= 0 && mv[3] >= 0)
+        d = eval_scalar_move(m, vals, 1, (uint32_t)mv[1], (uint32_t)mv[3], 0);
+    out_doable[t] = d.doable ? 1 : 0;
+    const ScoreV<4> s = apply_scalar_delta<4>(m, cur, d);
+    for (int k = 0; k < m.levels; ++k) out_scores[t * m.levels + k] = d.doable ? s.v[k] : 0;
+}
+
+// committed Change / Swap on global state (sf_apply)
+__global__ __launch_bounds__(64) void k_scalar_apply(ScalarModel m, int replica, int kind, int a, int b, int value,
+                                                     int32_t* out_ok) {
+    if (threadIdx.x != 0) return;
+    int32_t* vals = m.vals + (size_t)replica * m.n;
+    int64_t* cur = m.score + (size_t)replica * 4;
+    const ScalarDelta d = eval_scalar_move(m, vals, kind, (uint32_t)a, (uint32_t)b, value);
+    if (!d.doable) {
+        *out_ok = 0;
+        return;
+    }
+    const ScoreV<4> s = apply_scalar_delta<4>(m, cur, d);
+    if (kind == 0)
+        vals[a] = value;
+    else {
+        const int32_t t = vals[a];
+        vals[a] = vals[b];
+        vals[b] = t;
+    }
+    for (int k = 0; k < 4; ++k) cur[k] = s.v[k];
+    *out_ok = 1;
+}
+
+__global__ __launch_bounds__(256) void k_scalar_phase_start(ScalarModel m, SearchParams p) {
+    const int r = blockIdx.x;
+    const int64_t* cur = m.score + (size_t)r * 4;
+    for (int k = threadIdx.x; k < 4; k += blockDim.x) {
+        p.last_step_score[(size_t)r * 4 + k] = cur[k];
+        m.best_score[(size_t)r * 4 + k] = cur[k];
+    }
+    for (int h = threadIdx.x; h < p.la_size * 4; h += blockDim.x) p.la_hist[(size_t)r * p.la_size * 4 + h] = cur[h & 3];
+    for (int t = threadIdx.x; t < m.n; t += blockDim.x) m.best_vals[(size_t)r * m.n + t] = m.vals[(size_t)r * m.n + t];
+    if (threadIdx.x == 0) {
+        p.la_idx[r] = 0;
+        p.step_index[r] = 0;
+        p.has_best[r] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused search kernel: one wavefront = one replica.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t SRC = 128;  // ring capacity per leaf (entries of 2 x u32)
+
+template <class VT>
+struct SCarve {
+    size_t vals, ring, total;
+    __host__ __device__ explicit SCarve(int n) {
+        size_t o = 0;
+        ring = o;
+        o = align_up(o + sizeof(uint32_t) * 2 * SRC * 2, 16);
+        vals = o;
+        o = align_up(o + sizeof(VT) * n, 16);
+        total = o;
+    }
+};
+
+// VT = int8_t (n_values <= 127) or int16_t: the replica's values in LDS
+template <int L, bool TRACE, class VT>
+__global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, SearchParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int rr = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (rr >= p.n_launch) return;  // no workgroup barrier below
+    const int r = rr + p.replica_base;
+    const uint32_t n = (uint32_t)m.n;
+    const SCarve<VT> cv(m.n);
+    unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
+    uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][SRC][2]
+    VT* s_vals = (VT*)(mem + cv.vals);
+    int32_t* g_vals = m.vals + (size_t)r * n;
+    int64_t* g_score = m.score + (size_t)r * 4;
+    const bool tracing = TRACE && r == p.trace_replica;
+
+    // leaves in default-policy declaration order: change, then swap (policy/scalar.rs:67-106)
+    const int n_leaves = p.n_leaves;
+    const bool chg0 = p.leaf[0].kind == 1, chg1 = n_leaves > 1 && p.leaf[1].kind == 1;
+    const uint64_t identity = ((uint64_t)(uint32_t)m.descriptor << 32) ^ (uint64_t)(uint32_t)m.variable;
+    const uint32_t vc = (uint32_t)m.n_values;  // ValueSource::CountableRange 0..n_values
+
+    for (uint32_t t = lane; t < n; t += 64) s_vals[t] = (VT)g_vals[t];
+    wave_sync();
+    int64_t cur[L], best_sol[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        cur[k] = g_score[k];
+        best_sol[k] = m.best_score[(size_t)r * 4 + k];
+    }
+    uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;
+    uint64_t trace_n = 0;
+    const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
+    const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
+    const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
+
+    for (int64_t step = 0; step < p.n_steps; ++step) {
+        uint64_t sidx, sseed;
+        if (p.dry_run) {
+            sidx = p.dry_step_index;
+            sseed = p.dry_step_seed;
+        } else {
+            sidx = step_index0 + (uint64_t)step;
+            const uint64_t draw = seed_draws0 + (uint64_t)step;
+            if (p.explicit_seeds && (int64_t)draw < p.n_explicit)
+                sseed = p.explicit_seeds[(size_t)r * p.n_explicit + draw];
+            else
+                sseed = step_seed(p.random_seed + (uint64_t)r, draw);
+        }
+        sidx = uni64(sidx);
+        sseed = uni64(sseed);
+        const StreamCtx ctx{sidx, sseed, p.order};
+        ScoreV<L> late;
+#pragma unroll
+        for (int k = 0; k < L; ++k) late.v[k] = 0;
+        const int la_slot = p.dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
+        if (p.acceptor == 1) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
+        }
+        int has_best = 0;
+        uint64_t equal_count = 0;
+        uint32_t accepted = 0, pulls = 0;
+        ScoreV<L> best;
+#pragma unroll
+        for (int k = 0; k < L; ++k) best.v[k] = 0;
+        uint32_t best_m0 = 0, best_m1 = 0;
+        int best_leaf = 0;
+        const uint32_t first_leaf = n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u;
+
+        // entity permutations (selection_index_without_replacement)
+        uint32_t cst = 0, csd = 1, lst = 0, lsd = 1;
+        ctx.perm_params(n, SALT_SCALAR_CHANGE_ENTITY ^ identity, cst, csd);
+        ctx.perm_params(n, (SALT_SCALAR_SWAP_LEFT ^ identity) ^ OFFSET_MIX, lst, lsd);
+        cst = uni(cst), csd = uni(csd), lst = uni(lst), lsd = uni(lsd);
+
+        // per-leaf cursor: (row, inner) = change: (entity offset, value offset incl. the to-None slot);
+        // swap: (left offset, right offset)
+        uint32_t head[2] = {0, 0}, tail[2] = {0, 0}, row[2] = {0, 0}, inner[2] = {0, 0};
+        int gen_done[2] = {n == 0, n_leaves > 1 ? (n == 0) : 1}, ex[2] = {0, n_leaves > 1 ? 0 : 1};
+
+        int done = 0;
+        while (!done) {
+            // C1: fill the rings (>= 32 pending per live leaf, >= 64 when one leaf is live)
+            const uint32_t target = (!ex[0] && !ex[1]) ? 32u : 64u;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                if (l >= n_leaves) continue;
+                const bool is_change = l ? chg1 : chg0;
+                uint32_t* rq = ring + (size_t)l * SRC * 2;
+                while (!ex[l] && !gen_done[l] && tail[l] - head[l] < target) {
+                    st_sources += 1;
+                    if (is_change) {
+                        // 64 consecutive (row, value-offset) slots of the change stream, one per lane
+                        const uint32_t e_row = (uint32_t)(((uint64_t)cst + (uint64_t)row[l] * csd) % n);
+                        const bool has_none = m.allows_unassigned && (int32_t)s_vals[e_row] >= 0;
+                        const uint32_t per0 = vc + (has_none ? 1u : 0u);  // candidates of the current row
+                        // lanes walk rows starting at (row, inner): rows have vc or vc+1 candidates
+                        uint32_t my_row = row[l], my_in = inner[l] + lane;
+                        uint32_t per = per0;
+                        bool valid = true;
+                        for (;;) {  // skip whole rows (per-lane loop; <= 64/vc + 1 iterations)
+                            if (my_row >= n) {
+                                valid = false;
+                                break;
+                            }
+                            if (my_in < per) break;
+                            my_in -= per;
+                            ++my_row;
+                            if (my_row < n) {
+                                const uint32_t e2 = (uint32_t)(((uint64_t)cst + (uint64_t)my_row * csd) % n);
+                                per = vc + ((m.allows_unassigned && (int32_t)s_vals[e2] >= 0) ? 1u : 0u);
+                            }
+                        }
+                        uint32_t e = 0;
+                        int32_t v = -1;
+                        if (valid) {
+                            e = (uint32_t)(((uint64_t)cst + (uint64_t)my_row * csd) % n);
+                            if (my_in < vc) v = (int32_t)ctx.selection_index(my_in, vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)e ^ identity);
+                        }
+                        const uint64_t vm = __ballot(valid);
+                        const uint32_t cnt = (uint32_t)__popcll(vm);  // valid lanes are a prefix
+                        if (valid) {
+                            const uint32_t qi = (tail[l] + lane) & (SRC - 1);
+                            rq[qi * 2] = e;
+                            rq[qi * 2 + 1] = (uint32_t)v;
+                        }
+                        tail[l] += cnt;
+                        // advance the cursor past the last valid lane
+                        const uint32_t last = cnt ? cnt - 1 : 0;
+                        const uint32_t lr = uni(__shfl(my_row, (int)last)), li = uni(__shfl(my_in, (int)last));
+                        if (cnt == 0) {
+                            gen_done[l] = 1;
+                        } else {
+                            row[l] = lr;
+                            inner[l] = li + 1;  // may equal the row's count: the next walk skips the row
+                            if (cnt < 64) gen_done[l] = 1;
+                        }
+                    } else {
+                        // 64 consecutive right offsets of the current left row, filtered (swap.rs:125-160)
+                        if (row[l] >= n) {
+                            gen_done[l] = 1;
+                            break;
+                        }
+                        const uint32_t left = n <= 1 ? 0u : (uint32_t)(((uint64_t)lst + (uint64_t)row[l] * lsd) % n);
+                        const uint32_t ro = inner[l] + lane;
+                        bool keep = false;
+                        uint32_t right = 0;
+                        if (ro < n) {
+                            right = n <= 1 ? 0u
+                                           : ctx.selection_index(ro, n, (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)m.variable) ^ OFFSET_MIX);
+                            if (left < right) {
+                                const int32_t lv = (int32_t)s_vals[left], rv = (int32_t)s_vals[right];
+                                const bool legal = (lv >= 0 || m.allows_unassigned) && (rv >= 0 || m.allows_unassigned);
+                                keep = lv != rv && legal;
+                            }
+                        }
+                        const uint64_t km = __ballot(keep);
+                        if (keep) {
+                            const uint32_t qi = (tail[l] + mbcnt64(km)) & (SRC - 1);
+                            rq[qi * 2] = left;
+                            rq[qi * 2 + 1] = right;
+                        }
+                        tail[l] += (uint32_t)__popcll(km);
+                        inner[l] += 64;
+                        if (inner[l] >= n) {
+                            inner[l] = 0;
+                            row[l] += 1;
+                            if (row[l] >= n) gen_done[l] = 1;
+                        }
+                    }
+                }
+            }
+            wave_sync();
+
+            // C2: replay one batch in union cursor order
+            {
+                const bool live0 = !ex[0], live1 = !ex[1];
+                if (!live0 && !live1) {
+                    done = 1;
+                    break;
+                }
+                uint32_t lf, idx;
+                if (live0 && live1) {
+                    const uint32_t l0 = (first_leaf + pulls) & 1u;
+                    lf = (l0 + lane) & 1u;
+                    idx = (lf ? head[1] : head[0]) + (lane >> 1);
+                } else {
+                    lf = live0 ? 0u : 1u;
+                    idx = (lf ? head[1] : head[0]) + lane;
+                }
+                const bool avail = (int32_t)((lf ? tail[1] : tail[0]) - idx) > 0;
+                const uint64_t availmask = __ballot(avail);
+                const uint32_t nvalid = availmask == ~0ULL ? 64u : (uint32_t)(__ffsll((unsigned long long)~availmask) - 1);
+                if (nvalid == 0) {
+                    const uint32_t lf0 = uni(__shfl(lf, 0));
+                    if (lf0 ? gen_done[1] : gen_done[0]) {
+                        if (lf0)
+                            ex[1] = 1;
+                        else
+                            ex[0] = 1;
+                    }
+                    continue;  // not exhausted: the fill above continues the leaf
+                }
+                const bool valid = lane < nvalid;
+                uint32_t m0 = 0, m1 = 0;
+                ScalarDelta dl{0, 0, false};
+                const bool lane_change = lf ? chg1 : chg0;
+                if (valid) {
+                    const uint32_t qi = idx & (SRC - 1);
+                    const uint32_t* rq = ring + ((size_t)lf * SRC + qi) * 2;
+                    m0 = rq[0];
+                    m1 = rq[1];
+                    dl = lane_change ? eval_scalar_move(m, s_vals, 0, m0, 0u, (int32_t)m1)
+                                     : eval_scalar_move(m, s_vals, 1, m0, m1, 0);
+                }
+                const ScoreV<L> sc = apply_scalar_delta<L>(m, cur, dl);
+                ScoreV<L> curv;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) curv.v[kk] = cur[kk];
+                const bool doable = valid && dl.doable;
+                bool acc = false;
+                if (doable) {
+                    if (p.acceptor == 0)
+                        acc = score_cmp<L>(sc, curv) > 0;
+                    else if (p.acceptor == 1)
+                        acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
+                }
+                uint64_t accmask = __ballot(acc);
+                uint32_t nconsumed = nvalid;
+                if (p.forager != 2) {
+                    const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
+                    const uint32_t pre = mbcnt64(accmask) + (acc ? 1u : 0u);
+                    const uint64_t cutmask = __ballot(acc && pre == remaining);
+                    if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
+                }
+                const bool consumed = lane < nconsumed;
+                acc = acc && consumed;
+                accmask = __ballot(acc);
+                if (accmask) {
+                    if (p.forager == 1) {
+                        if (!has_best) {
+                            const int sel = __ffsll((unsigned long long)accmask) - 1;
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)shfl_u64((uint64_t)sc.v[kk], sel);
+                            best_m0 = __shfl(m0, sel);
+                            best_m1 = __shfl(m1, sel);
+                            best_leaf = (int)__shfl(lf, sel);
+                            has_best = 1;
+                        }
+                    } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
+                        const ScoreV<L> M = wave_max_score<L>(sc, acc);
+                        const int cm = has_best ? score_cmp<L>(M, best) : 1;
+                        if (cm >= 0) {
+                            const bool newmax = cm > 0;
+                            const uint64_t eq_base = newmax ? 0 : equal_count;
+                            const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
+                            const uint64_t eq = __ballot(in_eq);
+                            const uint32_t rank = mbcnt64(eq) + 1u;
+                            const uint64_t cntq = eq_base + rank;
+                            const bool pick = in_eq && ((newmax && rank == 1) ||
+                                                        (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
+                            const uint64_t pm = __ballot(pick);
+                            if (pm) {
+                                const int sel = 63 - __clzll((unsigned long long)pm);
+                                best_m0 = __shfl(m0, sel);
+                                best_m1 = __shfl(m1, sel);
+                                best_leaf = (int)__shfl(lf, sel);
+                            }
+                            best = M;
+                            equal_count = eq_base + (uint64_t)__popcll(eq);
+                            has_best = 1;
+                        }
+                    }
+                }
+                const uint32_t nacc = (uint32_t)__popcll(accmask);
+                accepted += nacc;
+                st_gen += nconsumed;
+                st_acc += nacc;
+                st_scored += nvalid;
+                st_calc += (uint32_t)__popcll(__ballot(consumed && doable));
+                if (tracing && consumed) {
+                    const uint64_t ti = trace_n + lane;
+                    if ((int64_t)ti < p.trace_cap) {
+                        int32_t* tm = p.trace_moves + ti * 6;
+                        tm[0] = lane_change ? 0 : 1;
+                        tm[1] = (int32_t)m0;
+                        tm[2] = 0;
+                        tm[3] = lane_change ? 0 : (int32_t)m1;
+                        tm[4] = 0;
+                        tm[5] = lane_change ? (int32_t)m1 : -1;
+                        for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
+                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                    }
+                }
+                if (tracing) trace_n += nconsumed;
+                const uint32_t c1 = (uint32_t)__popcll(__ballot(consumed && lf == 1u));
+                head[1] += c1;
+                head[0] += nconsumed - c1;
+                pulls += nconsumed;
+                if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
+            }
+        }
+
+        // ---- commit the forager's pick ----
+        const bool applied = has_best && !p.dry_run;
+        if (applied) {
+            const bool pick_change = best_leaf ? chg1 : chg0;
+            const uint32_t a = uni(best_m0), b = uni(best_m1);
+            if (tracing && lane == 0) {
+                p.trace_applied[0] = 1;
+                p.trace_applied[1] = pick_change ? 0 : 1;
+                p.trace_applied[2] = (int32_t)a;
+                p.trace_applied[3] = 0;
+                p.trace_applied[4] = pick_change ? 0 : (int32_t)b;
+                p.trace_applied[5] = 0;
+                p.trace_applied[6] = pick_change ? (int32_t)b : -1;
+            }
+            if (lane == 0) {
+                if (pick_change)
+                    s_vals[a] = (VT)(int32_t)b;
+                else {
+                    const VT t = s_vals[a];
+                    s_vals[a] = s_vals[b];
+                    s_vals[b] = t;
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) cur[kk] = best.v[kk];
+            st_applied += 1;
+        } else if (tracing && lane == 0) {
+            p.trace_applied[0] = 0;
+        }
+        if (!p.dry_run) {
+            bool improved = false;
+            if (applied) {
+                ScoreV<L> cs, bs;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    cs.v[kk] = cur[kk];
+                    bs.v[kk] = best_sol[kk];
+                }
+                improved = score_cmp<L>(cs, bs) > 0;
+            }
+            if (improved) {  // update_best_solution (scope_progress.rs:89-107)
+                for (uint32_t t = lane; t < n; t += 64) m.best_vals[(size_t)r * n + t] = (int32_t)s_vals[t];
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
+            }
+            if (p.acceptor == 1 && lane == 0) {
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
+            }
+            wave_sync();
+            st_steps += 1;
+        }
+    }
+
+    if (!p.dry_run) {
+        for (uint32_t t = lane; t < n; t += 64) g_vals[t] = (int32_t)s_vals[t];
+        if (lane == 0) {
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) {
+                g_score[kk] = cur[kk];
+                p.last_step_score[(size_t)r * 4 + kk] = cur[kk];
+                m.best_score[(size_t)r * 4 + kk] = best_sol[kk];
+            }
+            p.la_idx[r] = (int32_t)(((int64_t)la_idx0 + p.n_steps) % p.la_size);
+            p.step_index[r] = step_index0 + (uint64_t)p.n_steps;
+            p.seed_draws[r] = seed_draws0 + (uint64_t)p.n_steps;
+            uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
+            gs[0] += st_steps;
+            gs[1] += st_gen;
+            gs[2] += st_gen;
+            gs[3] += st_acc;
+            gs[4] += st_applied;
+            gs[5] += st_calc;
+            gs[6] += st_gen - st_calc;
+            gs[7] += st_scored;
+            gs[8] += st_sources;
+        }
+    }
+    if (tracing && lane == 0) *p.trace_count = (int64_t)trace_n;
+}
 
 }  // namespace sf

@@ -30,3 +30,41 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
     if "nearby_swap" in leaves:
         d.add_selector(SelectorKind.NEARBY_LIST_SWAP, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
     return d
+
+
+def build_graph_coloring(problem, n_replicas=1, device_id=0, leaves=("change", "swap")):
+    """Graph colouring: HardSoftScore; `Unassigned color` (uni, 1 hard each) and `Adjacent color
+    conflict` (predicate cross-join left.id < right.id && neighbours && equal colour, 1 hard each —
+    examples/scalar-graph-coloring/src/domain/graph_coloring.rs:21-44); leaves = scalar change +
+    scalar swap on `color_idx` (value range 0..n_colors, allows_unassigned)."""
+    d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
+    n = problem["n"]
+    d.add_entity_class(0, n)
+    d.add_scalar_variable(0, 0, problem["n_colors"], True, problem["colors"])
+    d.add_fact_csr(FACT_ADJ, problem["adj_off"], problem["adj"])
+    d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
+    d.add_constraint(ConstraintKind.CROSS_ADJACENT_EQUAL, 0, fact=FACT_ADJ, level=0, weight=1)
+    if "change" in leaves:
+        d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
+    if "swap" in leaves:
+        d.add_selector(SelectorKind.SCALAR_SWAP, 0)
+    return d
+
+
+def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap")):
+    """N-queens: queen i sits in column i, planning variable row_idx in 0..n (allows_unassigned);
+    `Unassigned` + row/diagonal conflicts (examples/nqueens/src/domain/board.rs:21-47)."""
+    import numpy as np
+
+    n = len(rows)
+    d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
+    d.add_entity_class(0, n)
+    d.add_scalar_variable(0, 0, n, True, rows)
+    d.add_fact_column_i32(FACT_COLUMN, np.arange(n, dtype=np.int32))
+    d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
+    d.add_constraint(ConstraintKind.CROSS_QUEENS, 0, fact=FACT_COLUMN, level=0, weight=1)
+    if "change" in leaves:
+        d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
+    if "swap" in leaves:
+        d.add_selector(SelectorKind.SCALAR_SWAP, 0)
+    return d

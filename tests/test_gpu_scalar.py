@@ -1,0 +1,178 @@
+"""GPU parity tests (through the C ABI): HIP scalar-variable hot path (graph colouring, N-queens)
+vs the CPU oracle.  Bit-exact integer scores, candidate order, accept flags, applied moves, counters."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(moves):
+    return np.stack([moves["kind"], moves["a"], moves["b"], moves["value"]], axis=1)
+
+
+def _graph(n=300, e=1500, k=6, seed=3, assign=True):
+    from solverforge_amd import datasets
+
+    g = datasets.make_graph(n, e, k, seed=seed)
+    if assign:  # a deterministic partial colouring with conflicts and some unassigned nodes
+        r = datasets.stream(seed + 99, n)
+        g["colors"] = (r % np.uint64(k + 1)).astype(np.int64) - 1
+    return g
+
+
+def _mk(oracle, g, n_replicas=1, leaves=("change", "swap")):
+    import solverforge_amd as sfa
+
+    d = sfa.build_graph_coloring(g, n_replicas=n_replicas, leaves=leaves)
+    o = oracle.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+    bits = (oracle.LEAF_SCALAR_CHANGE if "change" in leaves else 0) | (oracle.LEAF_SCALAR_SWAP if "swap" in leaves else 0)
+    return d, o, bits
+
+
+def test_graph_initialize_and_fresh_score(oracle):
+    g = _graph()
+    d, o, _ = _mk(oracle, g)
+    s = d.calculate_score()
+    assert (s[0] == o.score()[:2]).all() and s[0][0] < 0
+    assert (d.fresh_score()[0] == o.fresh_score()[:2]).all()
+
+
+@pytest.mark.parametrize("order", [0, 3, 4])
+@pytest.mark.parametrize("leaves", [("change",), ("swap",), ("change", "swap")])
+def test_graph_cursor_order_and_trial_scores(oracle, order, leaves):
+    g = _graph(n=90, e=400, k=5, seed=4)
+    d, o, bits = _mk(oracle, g, leaves=leaves)
+    o.configure(leaves=bits, selection_order=order)
+    d.calculate_score()
+    for step_index, step_seed in [(0, 0), (7, 41), (123, 0xDEADBEEFCAFEF00D)]:
+        gm, gs, gd = d.open_cursor(step_index, step_seed, selection_order=order, cap=1 << 17)
+        om = o.enumerate(0, step_index, step_seed, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm) == _t(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all()
+        assert (gs == os_[:, :2]).all()
+
+
+def test_graph_step_evaluate_and_apply(oracle):
+    g = _graph(n=120, e=700, k=4, seed=5)
+    d, o, bits = _mk(oracle, g)
+    o.configure(leaves=bits)
+    d.calculate_score()
+    rng = np.random.default_rng(1)
+    for it in range(25):
+        om = o.enumerate(0, it, 1000 + it, 3)
+        os_, od = o.evaluate_moves(om)
+        gs, gd = d.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+        doable = np.flatnonzero(od)
+        mv = om[doable[rng.integers(len(doable))]]
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 64), (0, 0, 3), (1, 1, 1), (0, 2, 1)])
+def test_graph_traced_steps(oracle, acceptor, forager, limit):
+    import solverforge_amd as sfa
+
+    g = _graph(n=70, e=260, k=4, seed=6)
+    d, o, bits = _mk(oracle, g)
+    o.configure(acceptor=acceptor, la_size=5, forager=forager, limit=limit, leaves=bits, random_seed=9)
+    d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=5, forager=forager,
+                                 accepted_count_limit=limit, random_seed=9))
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    for step in range(10 if forager == 2 else 30):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 17)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all(), step
+        assert (gf == of).all(), step
+        assert (gs == os_[:, :2]).all(), step
+        assert gap == oap, step
+        if gap:
+            assert (gmv["kind"], gmv["a"], gmv["b"], gmv["value"]) == (omv["kind"], omv["a"], omv["b"], omv["value"]), step
+        assert (d.working_values(0, 0) == o.get_vars(0, 0)).all(), step
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.best_scores()[0] == o.best_score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied",
+              "score_calculations", "moves_not_doable"]:
+        assert gst[k] == ost[k], k
+
+
+def test_graph_fused_multi_replica_from_unassigned(oracle):
+    """All nodes start unassigned (the reference example's initial state); several replicas."""
+    import solverforge_amd as sfa
+
+    g = _graph(n=400, e=2400, k=8, seed=7, assign=False)
+    R = 3
+    d, _, bits = _mk(oracle, g, n_replicas=R)
+    d.configure(sfa.SolverConfig(random_seed=2))
+    d.calculate_score()
+    d.phase_start()
+    d.solve_steps(40)
+    d.solve_steps(35)
+    sc = d.calculate_score()
+    for r in range(R):
+        o = oracle.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+        o.configure(leaves=bits, random_seed=2 + r)
+        o.phase_start()
+        o.steps(75)
+        assert (sc[r] == o.score()[:2]).all(), r
+        assert (d.working_values(0, 0, r) == o.get_vars(0, 0)).all(), r
+        assert d.stats(r)["moves_evaluated"] == o.stats()["moves_evaluated"], r
+    assert (d.fresh_score() == sc).all()
+
+
+def test_nqueens_64(oracle):
+    """BASELINE config 1 shape (N = 64) on the device: queens predicate join + unassigned."""
+    import solverforge_amd as sfa
+
+    n = 64
+    rows = (np.arange(n) * 7 % (n + 1)).astype(np.int64) - 1  # some unassigned, many conflicts
+    d = sfa.build_nqueens(rows)
+    o = oracle.Model.nqueens(rows)
+    bits = oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
+    o.configure(leaves=bits, random_seed=3)
+    d.configure(sfa.SolverConfig(random_seed=3))
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    gm, gs, gd = d.open_cursor(1, 5, selection_order=3, cap=1 << 16)
+    om = o.enumerate(0, 1, 5, 3)
+    assert (_t(gm) == _t(om)).all()
+    os_, od = o.evaluate_moves(om)
+    assert (gd == od).all() and (gs == os_[:, :2]).all()
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(50)
+    o.steps(50)
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+def test_graph_10k_properties(oracle):
+    """BASELINE config 2 size (10k nodes / 100k edges, 16 colours): incremental == full
+    recalculation, the first steps equal the oracle, scores never exceed 0."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    g = datasets.make_graph(10000, 100000, 16, seed=0)
+    d, o, bits = _mk(oracle, g, n_replicas=2)
+    d.configure(sfa.SolverConfig(random_seed=0))
+    s0 = d.calculate_score()
+    assert (s0[0] == [-10000, 0]).all()
+    d.phase_start()
+    d.solve_steps(30)
+    o.configure(leaves=bits, random_seed=0)
+    o.phase_start()
+    o.steps(30)
+    sc = d.calculate_score()
+    assert (sc[0] == o.score()[:2]).all()
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.fresh_score() == sc).all()
+    assert (sc <= 0).all() and (sc[:, 0] > -10000).all()
