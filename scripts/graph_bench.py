@@ -1,0 +1,40 @@
+"""BASELINE config 2 (graph colouring 10k nodes / 100k edges / 16 colours, scalar change + swap):
+moves/s of the HIP scalar path vs the CPU oracle over the same step window of replica 0."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import solverforge_amd as sfa
+from solverforge_amd import datasets
+from oracle import sfo
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+ls = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+g = datasets.make_graph(10000, 100000, 16, seed=0)
+d = sfa.build_graph_coloring(g, n_replicas=R)
+d.configure(sfa.SolverConfig(random_seed=0))
+d.calculate_score(); d.phase_start()
+d.solve_steps(ls); d.profile_solve()
+b = d.total_stats()
+t0 = time.perf_counter()
+for _ in range(K): d.solve_steps(ls, sync=False)
+d.sync()
+dt = time.perf_counter() - t0
+ms, n = d.profile_solve()
+a = d.total_stats()
+moves = a["moves_evaluated"] - b["moves_evaluated"]; scored = a["candidates_scored"] - b["candidates_scored"]
+o = sfo.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+o.configure(leaves=sfo.LEAF_SCALAR_CHANGE | sfo.LEAF_SCALAR_SWAP, random_seed=0)
+o.phase_start(); o.steps(ls)
+m0 = o.stats()["moves_evaluated"]; t1 = time.perf_counter(); done = 0
+while done < K * ls and time.perf_counter() - t1 < 20: o.steps(10); done += 10
+ct = time.perf_counter() - t1
+cm = o.stats()["moves_evaluated"] - m0
+match = bool((d.calculate_score()[0] == o.score()[:2]).all()) if done == K * ls else None
+# change candidate 28 + 8*deg = 188 B, swap 36 + 8*(deg u + deg v) = 356 B at deg 20
+alg = scored * (188 + 356) / 2
+print(json.dumps({"workload": "graph colouring 10k/100k/16", "replicas": R, "gpu_moves_per_s": moves / dt,
+                  "gpu_candidates_scored_per_s": scored / dt, "kernel_ms_per_launch": ms / n,
+                  "alg_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12,
+                  "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done, "replica0_matches_oracle": match,
+                  "gpu_over_cpu": (moves / dt) / (cm / ct), "score_replica0": d.calculate_score()[0].tolist()}))

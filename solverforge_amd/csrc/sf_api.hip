@@ -402,7 +402,7 @@ static bool wave_engine_possible(sf_ctx* ctx) {
     const ListModel& m = ctx->lm;
     // u16 element ids / ordinals in LDS; one wave's LDS slice must fit a CU
     if (!ctx->nbr.keys || m.dim > 16384 || m.n_cap + m.V > 65535 || list_max_nearby(ctx) > 64) return false;
-    return WCarve(m.V, m.n_cap, m.dim, list_max_nearby(ctx)).total * WPB <= 160 * 1024;
+    return WCarve(m.V, m.n_cap, m.dim, list_max_nearby(ctx)).total <= 160 * 1024;
 }
 static bool use_wave_engine(sf_ctx* ctx) {
     if (ctx->engine == SF_ENGINE_BLOCK) return false;
@@ -494,14 +494,16 @@ static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid) {
 template <int L, bool TRACE>
 static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas) {
     WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx));
-    size_t lds = cv.total * WPB;
+    int wpb = (int)((160 * 1024) / cv.total);  // replicas (waves) per workgroup: as many as the LDS holds, <= WPB
+    if (wpb > WPB) wpb = WPB;
+    size_t lds = cv.total * wpb;
     const bool fast = !TRACE && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
                       p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
     auto kern = fast ? k_list_search_wave<L, false, true> : k_list_search_wave<L, TRACE, false>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SearchParams q = p;
     q.n_launch = n_replicas;
-    hipLaunchKernelGGL(kern, dim3((n_replicas + WPB - 1) / WPB), dim3(64 * WPB), lds, ctx->stream, ctx->lm, q, ctx->nbr);
+    hipLaunchKernelGGL(kern, dim3((n_replicas + wpb - 1) / wpb), dim3(64 * wpb), lds, ctx->stream, ctx->lm, q, ctx->nbr);
     HIPCHK(ctx, hipGetLastError());
     return SF_OK;
 }

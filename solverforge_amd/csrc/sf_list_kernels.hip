@@ -435,8 +435,12 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
         uint32_t P = off[a] + i, Q = off[b] + j;
         uint32_t x = visits[P];
         __syncthreads();
-        // gather old values for the range this thread rewrites
-        for (uint32_t base = 0; base < total; base += blockDim.x) {
+        // gather old values for the range this thread rewrites.  Chunk order matters once the flat
+        // array is longer than the block: a left shift (P < Q) reads t+1, so chunks go upwards;
+        // a right shift (P > Q) reads t-1, so chunks go downwards (reads stay ahead of writes).
+        const uint32_t n_chunks = (total + blockDim.x - 1) / blockDim.x;
+        for (uint32_t ci = 0; ci < n_chunks; ++ci) {
+            const uint32_t base = (P > Q ? n_chunks - 1 - ci : ci) * blockDim.x;
             uint32_t t = base + threadIdx.x;
             uint32_t nv = 0;
             bool wr = false;

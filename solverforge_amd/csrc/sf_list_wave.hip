@@ -263,7 +263,7 @@ template <int L, bool TRACE, bool FAST>
 __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
-    const int rr = (int)(blockIdx.x * WPB + (threadIdx.x >> 6));
+    const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));  // 1..WPB replicas per workgroup
     if (rr >= p.n_launch) return;  // no workgroup barrier anywhere below
     const int r = rr + p.replica_base;
     const int V = m.V;

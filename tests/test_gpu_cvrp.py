@@ -294,3 +294,29 @@ def test_max_nearby_extremes(oracle, max_nearby):
     o.steps(15)
     assert d.working_lists(0, 0) == o.get_lists(0)
     assert (d.calculate_score()[0] == o.score()[:2]).all()
+
+
+def test_cvrp_5000_properties(oracle):
+    """BASELINE config 5 size (5000 customers / 500 vehicles, one portfolio member per replica):
+    both engines at the large size — the element multiset is preserved, incremental == full
+    recalculation, and the first steps equal the oracle."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(5000, 500, 55, seed=0)
+    d, o, bits = _mk(oracle, p, n_replicas=2)
+    d.configure(sfa.SolverConfig(random_seed=0))
+    start = d.calculate_score().copy()
+    assert (start[0] == o.score()[:2]).all()
+    d.phase_start()
+    d.solve_steps(12)
+    o.configure(leaves=bits, random_seed=0)
+    o.phase_start()
+    o.steps(12)
+    sc = d.calculate_score()
+    assert (sc[0] == o.score()[:2]).all()
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.fresh_score() == sc).all()
+    for r in range(2):
+        routes = d.working_lists(0, r)
+        assert sorted(c for rt in routes for c in rt) == list(range(1, 5001))
