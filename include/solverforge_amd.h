@@ -119,7 +119,7 @@ typedef enum sf_forager_kind {
 /* Search engines of the fused local-search kernel (same results, different GPU mapping):
  * WAVE  = one wavefront per replica, presorted neighbour index (many small replicas);
  * BLOCK = one 1024-thread workgroup per replica, matrix-row scan (large problems);
- * AUTO  = WAVE when a replica's LDS slice allows >= 4 replicas per CU, else BLOCK. */
+ * AUTO  = WAVE when a replica's LDS slice allows >= 2 replicas per CU (<= 80 KiB), else BLOCK. */
 typedef enum sf_engine_kind { SF_ENGINE_AUTO = 0, SF_ENGINE_BLOCK = 1, SF_ENGINE_WAVE = 2 } sf_engine_kind;
 
 typedef struct sf_solver_config {

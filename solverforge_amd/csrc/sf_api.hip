@@ -407,7 +407,7 @@ static bool wave_engine_possible(sf_ctx* ctx) {
 static bool use_wave_engine(sf_ctx* ctx) {
     if (ctx->engine == SF_ENGINE_BLOCK) return false;
     if (ctx->engine == SF_ENGINE_WAVE) return true;  // validated in sf_solver_set_engine / launch
-    return wave_engine_possible(ctx) && WCarve(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx)).total <= 40 * 1024;
+    return wave_engine_possible(ctx) && WCarve(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx)).total <= 80 * 1024;
 }
 
 static int build_scalar_model(sf_ctx* ctx, int d);  // sf_api_scalar.inc
