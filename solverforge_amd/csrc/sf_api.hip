@@ -15,6 +15,7 @@
 #include "sf_list_kernels.hip"
 #include "sf_list_wave.hip"
 #include "sf_scalar_kernels.hip"
+#include "sf_mixed_wave.hip"
 
 using namespace sf;
 
@@ -546,15 +547,15 @@ static int download_scores(sf_ctx* ctx, const int64_t* d_src4, int64_t* out) {
 static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit) {
     int rc;
     if (!ctx->d_scores_out && (rc = dalloc(ctx, &ctx->d_scores_out, (size_t)ctx->R * 4))) return rc;
+    if (!ctx->has_list_model && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "no planning variable configured");
     if (ctx->has_list_model) {
         size_t lds = ((size_t)ctx->lm.dim + 31) / 32 * 4 + 16;
         hipLaunchKernelGGL(k_list_evaluate_all, dim3(ctx->R), dim3(256), lds, ctx->stream, ctx->lm,
                            ctx->d_scores_out, commit);
-    } else if (ctx->has_scalar_model) {
+    }
+    if (ctx->has_scalar_model)  // mixed model: the scalar class adds its constraints to the list class's scores
         hipLaunchKernelGGL(k_scalar_evaluate_all, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->sm,
-                           ctx->d_scores_out, commit);
-    } else
-        return fail(ctx, SF_ERR_INVALID, "no planning variable configured");
+                           ctx->d_scores_out, commit, ctx->has_list_model ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     if (out) {
         std::vector<int64_t> tmp((size_t)ctx->R * ctx->levels);
@@ -584,11 +585,15 @@ int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores) {
             }
         }
         if (n_list + n_scalar == 0) return fail(ctx, SF_ERR_INVALID, "no planning variable configured");
-        if (n_list > 1 || n_scalar > 1 || (n_list && n_scalar))
-            return fail(ctx, SF_ERR_UNSUPPORTED, "this build drives one planning variable per context (mixed models: next)");
+        if (n_list > 1 || n_scalar > 1)
+            return fail(ctx, SF_ERR_UNSUPPORTED, "at most one list class and one scalar class per context");
         int rc;
         if (n_list && (rc = build_list_model(ctx, ld))) return rc;
         if (n_scalar && (rc = build_scalar_model(ctx, sd))) return rc;
+        if (n_list && n_scalar) {  // mixed model: one committed / best score, kept with the list class
+            ctx->sm.score = ctx->lm.score;
+            ctx->sm.best_score = ctx->lm.best_score;
+        }
         ctx->initialized = true;
     }
     return run_evaluate_all(ctx, out_scores, 1);
@@ -618,10 +623,15 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     HIPCHK(ctx, hipMalloc((void**)&d_do, (size_t)n * 4));
     HIPCHK(ctx, hipMemcpyAsync(d_moves, moves, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
     int grid = (int)((n + 255) / 256);
+    const int mixed = ctx->has_list_model && ctx->has_scalar_model;
+    if (mixed) {
+        (void)hipMemsetAsync(d_sc, 0, (size_t)n * ctx->levels * 8, ctx->stream);
+        (void)hipMemsetAsync(d_do, 0, (size_t)n * 4, ctx->stream);
+    }
     if (ctx->has_list_model)
-        hipLaunchKernelGGL(k_list_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->lm, replica, d_moves, n, d_sc, d_do);
-    else
-        hipLaunchKernelGGL(k_scalar_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->sm, replica, d_moves, n, d_sc, d_do);
+        hipLaunchKernelGGL(k_list_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->lm, replica, d_moves, n, d_sc, d_do, mixed);
+    if (ctx->has_scalar_model)
+        hipLaunchKernelGGL(k_scalar_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->sm, replica, d_moves, n, d_sc, d_do, mixed);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -638,9 +648,10 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
     int rc = alloc_search(ctx);
     if (rc) return rc;
-    if (ctx->has_list_model) {
-        if (mv->kind != SF_MOVE_LIST_CHANGE && mv->kind != SF_MOVE_LIST_SWAP)
-            return fail(ctx, SF_ERR_INVALID, "list model expects list moves");
+    const bool list_move = mv->kind == SF_MOVE_LIST_CHANGE || mv->kind == SF_MOVE_LIST_SWAP;
+    if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
+    if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");
+    if (list_move) {
         if (mv->a < 0 || mv->a >= ctx->lm.V || mv->b < 0 || mv->b >= ctx->lm.V || mv->a_pos < 0 || mv->b_pos < 0)
             return fail(ctx, SF_ERR_INVALID, "move out of range");
         hipLaunchKernelGGL(k_list_apply, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, mv->kind,
@@ -711,14 +722,79 @@ int32_t sf_phase_start(sf_ctx* ctx) {
     HIPCHK(ctx, hipMemsetAsync(ctx->sp.stats, 0, (size_t)ctx->R * SF_STATS_WORDS * 8, ctx->stream));
     if (ctx->has_list_model)
         hipLaunchKernelGGL(k_list_phase_start, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->lm, ctx->sp);
-    else
+    if (ctx->has_scalar_model)  // mixed: same committed score (aliased), adds the best snapshot of the values
         hipLaunchKernelGGL(k_scalar_phase_start, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->sm, ctx->sp);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SF_OK;
 }
 
+}  // extern "C"
+
+// generic N-leaf engine: mixed models, and list models whose union has plain list change / swap leaves
+template <int L, bool TRACE, class VT>
+static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
+    const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
+    GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0);
+    if (cv.total > 160 * 1024) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
+    int wpb = (int)((160 * 1024) / cv.total);
+    if (wpb > 4) wpb = 4;
+    auto kern = k_mixed_search_wave<L, TRACE, VT>;
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cv.total * wpb)));
+    SearchParams q = p;
+    q.n_launch = n_replicas;
+    hipLaunchKernelGGL(kern, dim3((n_replicas + wpb - 1) / wpb), dim3(64 * wpb), cv.total * wpb, ctx->stream, ctx->lm,
+                       ctx->sm, gl, q, ctx->has_list_model ? 1 : 0, ctx->has_scalar_model ? 1 : 0);
+    HIPCHK(ctx, hipGetLastError());
+    return SF_OK;
+}
+static bool has_plain_list_leaves(sf_ctx* ctx) {
+    for (auto& s : ctx->selectors)
+        if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP)) return true;
+    return false;
+}
+static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
+    GLeaves gl{};
+    gl.list_desc = ctx->has_list_model ? ctx->list_desc : 0;
+    // default-policy declaration order: list rules first, then scalar change, scalar swap
+    // (runtime/compiler/default_local_search/policy.rs:104-108)
+    for (int kind : {SF_SEL_LIST_CHANGE, SF_SEL_LIST_SWAP, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+        for (auto& s : ctx->selectors) {
+            const bool is_list = kind == SF_SEL_LIST_CHANGE || kind == SF_SEL_LIST_SWAP;
+            if (s.kind != kind) continue;
+            if (is_list ? (!ctx->has_list_model || s.desc != ctx->list_desc) : (!ctx->has_scalar_model || s.desc != ctx->scalar_desc))
+                continue;
+            if (gl.n >= GL) return fail(ctx, SF_ERR_UNSUPPORTED, "more than four leaves");
+            gl.kind[gl.n++] = kind;
+        }
+    for (auto& s : ctx->selectors)
+        if (s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP)
+            return fail(ctx, SF_ERR_UNSUPPORTED, "nearby leaves cannot be unioned with plain / scalar leaves yet");
+    if (gl.n == 0) return fail(ctx, SF_ERR_INVALID, "no selector configured");
+    if (ctx->has_list_model && (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536))
+        return fail(ctx, SF_ERR_UNSUPPORTED, "generic engine packs list elements and positions in 16 bits");
+    p.n_leaves = gl.n;
+    const bool small = !ctx->has_scalar_model || ctx->sm.n_values <= 127;
+#define SF_MIXED_CASE(LV)                                                                                      \
+    case LV:                                                                                                   \
+        if (small)                                                                                             \
+            return trace ? launch_mixed_t<LV, true, int8_t>(ctx, p, gl, grid) : launch_mixed_t<LV, false, int8_t>(ctx, p, gl, grid); \
+        return trace ? launch_mixed_t<LV, true, int16_t>(ctx, p, gl, grid) : launch_mixed_t<LV, false, int16_t>(ctx, p, gl, grid);
+    switch (ctx->levels) {
+        SF_MIXED_CASE(1)
+        SF_MIXED_CASE(2)
+        SF_MIXED_CASE(3)
+        default:
+            SF_MIXED_CASE(4)
+    }
+#undef SF_MIXED_CASE
+}
+
+extern "C" {
+
 static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
+    if ((ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)))
+        return launch_mixed(ctx, p, grid, trace);
     if (ctx->has_list_model) {
         int rc = fill_list_leaves(ctx, p);
         if (rc) return rc;

@@ -401,9 +401,10 @@ __global__ __launch_bounds__(256) void k_list_evaluate_all(ListModel m, int64_t*
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int replica, const int32_t* moves,
                                                              int64_t n, int64_t* out_scores,
-                                                             int32_t* out_doable) {
+                                                             int32_t* out_doable, int skip_foreign) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (skip_foreign && moves[t * 6] != 2 && moves[t * 6] != 3) return;  // a scalar move of a mixed model
     const uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
     const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
     const int64_t* load = m.load + (size_t)replica * m.V;

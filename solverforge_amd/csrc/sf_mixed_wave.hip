@@ -1,0 +1,730 @@
+// Generic N-leaf search engine (gfx950 wave64): one wavefront = one replica of a model with an
+// optional scalar class and an optional list class, and a union of up to four PLAIN leaves —
+// scalar change, scalar swap, list change, list swap — scheduled by the reference's
+// StratifiedRandom union (mixed job shop: all four; list models without a distance meter: the two
+// list leaves).  The nearby-list union of the CVRP default policy has its own engines
+// (sf_list_wave.hip / sf_list_kernels.hip).
+//
+// Reference semantics restated (paths under crates/solverforge-solver/src/):
+//   heuristic/selector/list_kernel/change.rs:25-241   list change stream (salts :25-30)
+//   heuristic/selector/list_kernel/swap.rs:25-270     list swap stream   (salts :25-31)
+//   runtime/compiler/executor/list_leaf/cursor/slot.rs:468-499  entity order without replacement
+//   heuristic/selector/scalar_neighborhood/cursor/{change,swap}.rs  scalar streams
+//   heuristic/selector/decorator/vec_union.rs:190-365 UnionScheduler::StratifiedRandom, equal weights
+//   phase/localsearch/{phase/step.rs,phase/candidates.rs,forager.rs,acceptor/*}  step loop
+//
+// Every leaf generator walks 64 consecutive OFFSETS of its innermost loop per call (one per
+// lane), applies the stream's skip rules and compacts the survivors into the leaf's ring with a
+// ballot / mbcnt prefix, so the ring order is the cursor order.  The replay simulates the union
+// scheduler pull by pull (wave-uniform scalar code) to lay 64 candidates onto the lanes, scores
+// them against the step snapshot and replays acceptor + forager exactly like the other engines.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sf_list_model.h"
+
+namespace sf {
+
+constexpr int GL = 4;          // max leaves of the generic union
+constexpr uint32_t GRC = 128;  // ring capacity per leaf
+
+constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
+constexpr uint64_t SALT_LC_INTRA = 0x1157C4A46E000003ULL, SALT_LC_INTER = 0x1157C4A46E000004ULL;
+constexpr uint64_t SALT_LS_ENTITY = 0x11575A0900000001ULL, SALT_LS_FIRST = 0x11575A0900000002ULL;
+constexpr uint64_t SALT_LS_SECOND = 0x11575A0900000003ULL, SALT_LS_IFIRST = 0x11575A0900000004ULL;
+constexpr uint64_t SALT_LS_ISECOND = 0x11575A0900000005ULL;
+
+struct GLeaves {
+    int32_t n;
+    int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap
+    int32_t list_desc;  // descriptor_index of the list class (stream salts)
+};
+
+template <class VT>
+struct GCarve {
+    size_t ring, load, off, visits, vals, total;
+    __host__ __device__ GCarve(int n_scalar, int V, int n_cap) {
+        size_t o = 0;
+        ring = o;
+        o = align_up(o + sizeof(uint32_t) * 2 * GRC * GL, 16);
+        load = o;
+        o = align_up(o + sizeof(int64_t) * V, 16);
+        off = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        visits = o;
+        o = align_up(o + sizeof(uint16_t) * n_cap, 16);
+        vals = o;
+        o = align_up(o + sizeof(VT) * n_scalar, 16);
+        total = o;
+    }
+};
+
+// Generator state of one leaf.  Field meaning per kind:
+//  scalar change: a = row offset, b = inner offset (value offset incl. the to-None slot)
+//  scalar swap:   a = left offset, b = right offset
+//  list change:   a = source entity rank, b = source position offset, c = stage (0 intra, 1 inter),
+//                 d = destination entity rank (inter), e = destination position offset
+//  list swap:     a = entity rank, c = stage, b = first offset, e = second offset, d = destination rank
+struct GGen {
+    uint32_t a, b, c, d, e;
+    int done;
+};
+
+template <int L, bool TRACE, class VT>
+__global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p,
+                                                          int has_list, int has_scalar) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (rr >= p.n_launch) return;  // no workgroup barrier below
+    const int r = rr + p.replica_base;
+    const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
+    const int V = has_list ? lm.V : 0;
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0);
+    unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
+    uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
+    int64_t* s_load = (int64_t*)(mem + cv.load);
+    uint32_t* s_off = (uint32_t*)(mem + cv.off);
+    uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
+    VT* s_vals = (VT*)(mem + cv.vals);
+    const bool tracing = TRACE && r == p.trace_replica;
+    const int nl = gl.n;
+    const uint64_t identity = ((uint64_t)(uint32_t)sm.descriptor << 32) ^ (uint64_t)(uint32_t)sm.variable;
+    const uint32_t vc = (uint32_t)sm.n_values;
+    const uint64_t ldesc = (uint64_t)(uint32_t)gl.list_desc;
+
+    uint32_t* g_visits = has_list ? lm.visits + (size_t)r * lm.n_cap : nullptr;
+    uint32_t* g_off = has_list ? lm.off + (size_t)r * (V + 1) : nullptr;
+    int64_t* g_load = has_list ? lm.load + (size_t)r * V : nullptr;
+    int32_t* g_vals = has_scalar ? sm.vals + (size_t)r * ns : nullptr;
+    // the committed score lives with the list model when there is one
+    int64_t* g_score = (has_list ? lm.score : sm.score) + (size_t)r * 4;
+    int64_t* g_best_score = (has_list ? lm.best_score : sm.best_score) + (size_t)r * 4;
+
+    if (has_list) {
+        for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
+        for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = g_load[t];
+        wave_sync();
+        const uint32_t tot = uni(s_off[V]);
+        for (uint32_t t = lane; t < tot; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+    }
+    for (uint32_t t = lane; t < ns; t += 64) s_vals[t] = (VT)g_vals[t];
+    wave_sync();
+
+    int64_t cur[L], best_sol[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        cur[k] = g_score[k];
+        best_sol[k] = g_best_score[k];
+    }
+    uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;
+    uint64_t trace_n = 0;
+    const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
+    const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
+    const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
+
+    for (int64_t step = 0; step < p.n_steps; ++step) {
+        uint64_t sidx, sseed;
+        if (p.dry_run) {
+            sidx = p.dry_step_index;
+            sseed = p.dry_step_seed;
+        } else {
+            sidx = step_index0 + (uint64_t)step;
+            const uint64_t draw = seed_draws0 + (uint64_t)step;
+            if (p.explicit_seeds && (int64_t)draw < p.n_explicit)
+                sseed = p.explicit_seeds[(size_t)r * p.n_explicit + draw];
+            else
+                sseed = step_seed(p.random_seed + (uint64_t)r, draw);
+        }
+        sidx = uni64(sidx);
+        sseed = uni64(sseed);
+        const StreamCtx ctx{sidx, sseed, p.order};
+        ScoreV<L> late;
+#pragma unroll
+        for (int k = 0; k < L; ++k) late.v[k] = 0;
+        const int la_slot = p.dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
+        if (p.acceptor == 1) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
+        }
+        int has_best = 0;
+        uint64_t equal_count = 0;
+        uint32_t accepted = 0;
+        ScoreV<L> best;
+#pragma unroll
+        for (int k = 0; k < L; ++k) best.v[k] = 0;
+        uint32_t best_m0 = 0, best_m1 = 0;
+        int best_leaf = 0;
+
+        // entity permutations (selection_index_without_replacement) of the four streams
+        uint32_t sc_st = 0, sc_sd = 1, ss_st = 0, ss_sd = 1, lc_st = 0, lc_sd = 1, ls_st = 0, ls_sd = 1;
+        if (has_scalar) {
+            ctx.perm_params(ns, SALT_SCALAR_CHANGE_ENTITY ^ identity, sc_st, sc_sd);
+            ctx.perm_params(ns, (SALT_SCALAR_SWAP_LEFT ^ identity) ^ OFFSET_MIX, ss_st, ss_sd);
+        }
+        if (has_list) {
+            ctx.perm_params((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd);
+            ctx.perm_params((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd);
+        }
+        sc_st = uni(sc_st), sc_sd = uni(sc_sd), ss_st = uni(ss_st), ss_sd = uni(ss_sd);
+        lc_st = uni(lc_st), lc_sd = uni(lc_sd), ls_st = uni(ls_st), ls_sd = uni(ls_sd);
+        auto lc_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lc_st + (uint64_t)rank * lc_sd) % (uint32_t)V); };
+        auto ls_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)ls_st + (uint64_t)rank * ls_sd) % (uint32_t)V); };
+        auto rlen = [&](uint32_t e) { return uni(s_off[e + 1] - s_off[e]); };
+
+        GGen G[GL];
+        uint32_t head[GL], tail[GL];
+        int ex[GL];
+#pragma unroll
+        for (int l = 0; l < GL; ++l) {
+            G[l] = GGen{0, 0, 0, 0, 0, l >= nl};
+            head[l] = tail[l] = 0;
+            ex[l] = l >= nl;
+        }
+        // union scheduler (vec_union.rs:190-365): StratifiedRandom with equal weights when > 1 leaf
+        const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
+        const uint32_t u_str = nl > 1 ? ctx.random_stride((uint32_t)nl, SALT_UNION_STRIDE) : 1u;
+        int64_t wcur[GL] = {0, 0, 0, 0};
+        int64_t live_weight = nl;
+
+        int done = 0;
+        while (!done) {
+            // ---- C1: fill every live leaf's ring to >= 64 pending (or until its stream ends) ----
+#pragma unroll
+            for (int l = 0; l < GL; ++l) {
+                if (l >= nl) continue;
+                const int kind = gl.kind[l];
+                uint32_t* rq = ring + (size_t)l * GRC * 2;
+                GGen g = G[l];
+                uint32_t tl = tail[l];
+                while (!ex[l] && !g.done && tl - head[l] < 64u) {
+                    st_sources += 1;
+                    bool keep = false;
+                    uint32_t w0 = 0, w1 = 0;
+                    if (kind == 1) {  // ---- scalar change ----
+                        if (g.a >= ns) {
+                            g.done = 1;
+                            break;
+                        }
+                        uint32_t my_row = g.a, my_in = g.b + lane;
+                        const uint32_t e0 = (uint32_t)(((uint64_t)sc_st + (uint64_t)my_row * sc_sd) % ns);
+                        uint32_t per = vc + ((sm.allows_unassigned && (int32_t)s_vals[e0] >= 0) ? 1u : 0u);
+                        bool valid = true;
+                        for (;;) {
+                            if (my_row >= ns) {
+                                valid = false;
+                                break;
+                            }
+                            if (my_in < per) break;
+                            my_in -= per;
+                            ++my_row;
+                            if (my_row < ns) {
+                                const uint32_t e2 = (uint32_t)(((uint64_t)sc_st + (uint64_t)my_row * sc_sd) % ns);
+                                per = vc + ((sm.allows_unassigned && (int32_t)s_vals[e2] >= 0) ? 1u : 0u);
+                            }
+                        }
+                        if (valid) {
+                            w0 = (uint32_t)(((uint64_t)sc_st + (uint64_t)my_row * sc_sd) % ns);
+                            int32_t v = -1;
+                            if (my_in < vc) v = (int32_t)ctx.selection_index(my_in, vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)w0 ^ identity);
+                            w1 = (uint32_t)v;
+                        }
+                        keep = valid;
+                        const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+                        if (cnt == 0)
+                            g.done = 1;
+                        else {
+                            g.a = uni(__shfl(my_row, (int)cnt - 1));
+                            g.b = uni(__shfl(my_in, (int)cnt - 1)) + 1;
+                            if (cnt < 64) g.done = 1;
+                        }
+                    } else if (kind == 2) {  // ---- scalar swap ----
+                        if (g.a >= ns) {
+                            g.done = 1;
+                            break;
+                        }
+                        const uint32_t left = ns <= 1 ? 0u : (uint32_t)(((uint64_t)ss_st + (uint64_t)g.a * ss_sd) % ns);
+                        const uint32_t ro = g.b + lane;
+                        if (ro < ns) {
+                            const uint32_t right = ns <= 1 ? 0u
+                                                           : ctx.selection_index(ro, ns, (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)sm.variable) ^ OFFSET_MIX);
+                            if (left < right) {
+                                const int32_t lv = (int32_t)s_vals[left], rv = (int32_t)s_vals[right];
+                                keep = lv != rv && (lv >= 0 || sm.allows_unassigned) && (rv >= 0 || sm.allows_unassigned);
+                            }
+                            w0 = left;
+                            w1 = right;
+                        }
+                        g.b += 64;
+                        if (g.b >= ns) {
+                            g.b = 0;
+                            g.a += 1;
+                            if (g.a >= ns) g.done = 1;
+                        }
+                    } else if (kind == 4) {  // ---- list change (list_kernel/change.rs:142-241) ----
+                        // advance to a source with a non-empty list
+                        uint32_t se = 0, slen = 0;
+                        for (;;) {
+                            if (g.a >= (uint32_t)V) break;
+                            se = lc_ent(g.a);
+                            slen = rlen(se);
+                            if (g.b < slen) break;
+                            g.a += 1;
+                            g.b = 0;
+                            g.c = 0;
+                            g.d = 0;
+                            g.e = 0;
+                        }
+                        if (g.a >= (uint32_t)V) {
+                            g.done = 1;
+                            break;
+                        }
+                        const uint32_t sp = ctx.selection_index(g.b, slen, SALT_LC_SOURCE ^ (uint64_t)se ^ ldesc);
+                        if (g.c == 0) {  // intra destinations 0..=slen, skipping dp == sp and dp == sp + 1
+                            const uint32_t o = g.e + lane;
+                            if (o <= slen) {
+                                const uint32_t dp = ctx.selection_index(o, slen + 1, SALT_LC_INTRA ^ (uint64_t)se ^ (uint64_t)sp);
+                                keep = dp != sp && dp != sp + 1;
+                                w0 = (se << 16) | sp;
+                                w1 = (se << 16) | dp;
+                            }
+                            g.e += 64;
+                            if (g.e > slen) {
+                                g.c = 1;
+                                g.d = 0;
+                                g.e = 0;
+                            }
+                        } else {  // inter: every other entity in order, positions 0..=dlen
+                            if (g.d == g.a) {
+                                g.d += 1;
+                                g.e = 0;
+                            }
+                            if (g.d >= (uint32_t)V) {  // next source position
+                                g.b += 1;
+                                g.c = 0;
+                                g.d = 0;
+                                g.e = 0;
+                                st_sources -= 1;
+                                continue;
+                            }
+                            const uint32_t de = lc_ent(g.d);
+                            const uint32_t dlen = rlen(de);
+                            const uint32_t o = g.e + lane;
+                            if (o <= dlen) {
+                                const uint32_t dp = ctx.selection_index(o, dlen + 1, SALT_LC_INTER ^ (uint64_t)se ^ (uint64_t)de ^ (uint64_t)sp);
+                                keep = true;
+                                w0 = (se << 16) | sp;
+                                w1 = (de << 16) | dp;
+                            }
+                            g.e += 64;
+                            if (g.e > dlen) {
+                                g.d += 1;
+                                g.e = 0;
+                            }
+                        }
+                    } else {  // ---- list swap (list_kernel/swap.rs) ----
+                        uint32_t fe = 0, flen = 0;
+                        for (;;) {  // entities with an empty list are skipped
+                            if (g.a >= (uint32_t)V) break;
+                            fe = ls_ent(g.a);
+                            flen = rlen(fe);
+                            if (flen != 0) break;
+                            g.a += 1;
+                            g.b = 0;
+                            g.c = 0;
+                            g.e = 0;
+                            g.d = g.a + 1;
+                        }
+                        if (g.a >= (uint32_t)V) {
+                            g.done = 1;
+                            break;
+                        }
+                        if (g.c == 0) {  // intra pairs first < second
+                            if (g.b >= flen) {
+                                g.c = 1;
+                                g.d = g.a + 1;
+                                g.b = 0;
+                                g.e = 0;
+                                st_sources -= 1;
+                                continue;
+                            }
+                            const uint32_t fp = ctx.selection_index(g.b, flen, SALT_LS_FIRST ^ (uint64_t)fe ^ ldesc);
+                            const uint32_t second_count = flen > fp + 1 ? flen - (fp + 1) : 0u;
+                            const uint32_t o = g.e + lane;
+                            if (o < second_count) {
+                                const uint32_t sp = fp + 1 + ctx.selection_index(o, second_count, SALT_LS_SECOND ^ (uint64_t)fe ^ (uint64_t)fp);
+                                keep = true;
+                                w0 = (fe << 16) | fp;
+                                w1 = (fe << 16) | sp;
+                            }
+                            g.e += 64;
+                            if (g.e >= second_count) {
+                                g.b += 1;
+                                g.e = 0;
+                            }
+                        } else {  // inter with entities after this one in list order
+                            uint32_t se2 = 0, slen2 = 0;
+                            for (;;) {
+                                if (g.d >= (uint32_t)V) break;
+                                se2 = ls_ent(g.d);
+                                slen2 = rlen(se2);
+                                if (slen2 != 0) break;
+                                g.d += 1;
+                            }
+                            if (g.d >= (uint32_t)V) {  // advance_entity
+                                g.a += 1;
+                                g.c = 0;
+                                g.b = 0;
+                                g.e = 0;
+                                g.d = g.a + 1;
+                                st_sources -= 1;
+                                continue;
+                            }
+                            if (g.b >= flen) {
+                                g.d += 1;
+                                g.b = 0;
+                                g.e = 0;
+                                st_sources -= 1;
+                                continue;
+                            }
+                            const uint32_t fp = ctx.selection_index(g.b, flen, SALT_LS_IFIRST ^ (uint64_t)fe ^ (uint64_t)se2);
+                            const uint32_t o = g.e + lane;
+                            if (o < slen2) {
+                                const uint32_t sp = ctx.selection_index(o, slen2, SALT_LS_ISECOND ^ (uint64_t)fe ^ (uint64_t)se2 ^ (uint64_t)fp);
+                                keep = true;
+                                w0 = (fe << 16) | fp;
+                                w1 = (se2 << 16) | sp;
+                            }
+                            g.e += 64;
+                            if (g.e >= slen2) {
+                                g.b += 1;
+                                g.e = 0;
+                            }
+                        }
+                    }
+                    const uint64_t km = __ballot(keep);
+                    if (keep) {
+                        const uint32_t qi = (tl + mbcnt64(km)) & (GRC - 1);
+                        rq[qi * 2] = w0;
+                        rq[qi * 2 + 1] = w1;
+                    }
+                    tl += (uint32_t)__popcll(km);
+                }
+                G[l] = g;
+                tail[l] = tl;
+            }
+            wave_sync();
+
+            // ---- C2: lay the next 64 pulls of the union scheduler onto the lanes ----
+            uint32_t my_leaf = 0, my_idx = 0;
+            uint32_t taken[GL] = {0, 0, 0, 0};
+            uint32_t nvalid = 0;
+            bool need_more = false;
+            {
+                int nlive = 0;
+#pragma unroll
+                for (int l = 0; l < GL; ++l) nlive += !ex[l];
+                while (nvalid < 64 && nlive > 0) {
+                    int sel = -1;
+                    int64_t selw = 0;
+                    if (nl == 1) {
+                        sel = 0;
+                    } else {
+                        for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
+                            const uint32_t i = (u_off + pos * u_str) % (uint32_t)nl;
+#pragma unroll
+                            for (int l = 0; l < GL; ++l)
+                                if ((uint32_t)l == i && !ex[l]) {
+                                    wcur[l] += 1;
+                                    if (sel < 0 || wcur[l] > selw) {
+                                        sel = l;
+                                        selw = wcur[l];
+                                    }
+                                }
+                        }
+                    }
+                    bool avail = false, gdone = false;
+#pragma unroll
+                    for (int l = 0; l < GL; ++l)
+                        if (l == sel) {
+                            avail = (int32_t)(tail[l] - (head[l] + taken[l])) > 0;
+                            gdone = G[l].done != 0;
+                        }
+                    if (!avail && !gdone) {
+                        // the child has more candidates that are not generated yet: undo this pull's
+                        // bookkeeping and refill first
+                        if (nl > 1) {
+#pragma unroll
+                            for (int l = 0; l < GL; ++l)
+                                if (!ex[l]) wcur[l] -= 1;
+                        }
+                        need_more = true;
+                        break;
+                    }
+                    if (nl > 1) {
+#pragma unroll
+                        for (int l = 0; l < GL; ++l)
+                            if (l == sel) wcur[l] -= live_weight;
+                    }
+                    if (!avail) {  // exhausted child discovered at this pull
+#pragma unroll
+                        for (int l = 0; l < GL; ++l)
+                            if (l == sel) ex[l] = 1;
+                        nlive -= 1;
+                        live_weight -= 1;
+                        continue;
+                    }
+                    uint32_t idx = 0;
+#pragma unroll
+                    for (int l = 0; l < GL; ++l)
+                        if (l == sel) {
+                            idx = head[l] + taken[l];
+                            taken[l] += 1;
+                        }
+                    if (lane == nvalid) {
+                        my_leaf = (uint32_t)sel;
+                        my_idx = idx;
+                    }
+                    nvalid += 1;
+                }
+                if (nvalid == 0) {
+                    if (need_more) continue;
+                    done = 1;  // every child exhausted
+                    break;
+                }
+            }
+
+            // ---- C3: trial score, acceptor, forager ----
+            {
+                const bool valid = lane < nvalid;
+                uint32_t m0 = 0, m1 = 0;
+                int my_kind = 0;
+#pragma unroll
+                for (int l = 0; l < GL; ++l)
+                    if (my_leaf == (uint32_t)l) my_kind = gl.kind[l];
+                bool doable = false;
+                ScoreV<L> sc;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) sc.v[kk] = cur[kk];
+                if (valid) {
+                    const uint32_t* rq = ring + ((size_t)my_leaf * GRC + (my_idx & (GRC - 1))) * 2;
+                    m0 = rq[0];
+                    m1 = rq[1];
+                    if (my_kind <= 2) {
+                        const ScalarDelta d = my_kind == 1 ? eval_scalar_move(sm, s_vals, 0, m0, 0u, (int32_t)m1)
+                                                           : eval_scalar_move(sm, s_vals, 1, m0, m1, 0);
+                        doable = d.doable;
+                        sc = apply_scalar_delta<L>(sm, cur, d);
+                    } else {
+                        const ListDelta d = eval_list_move_legs<uint16_t, false>(lm, s_visits, s_off, s_load, my_kind == 4,
+                                                                                 m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
+                        doable = d.doable;
+                        sc = apply_delta<L>(lm, cur, d);
+                    }
+                }
+                ScoreV<L> curv;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) curv.v[kk] = cur[kk];
+                doable = doable && valid;
+                bool acc = false;
+                if (doable) {
+                    if (p.acceptor == 0)
+                        acc = score_cmp<L>(sc, curv) > 0;
+                    else if (p.acceptor == 1)
+                        acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
+                }
+                uint64_t accmask = __ballot(acc);
+                uint32_t nconsumed = nvalid;
+                if (p.forager != 2) {
+                    const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
+                    const uint32_t pre = mbcnt64(accmask) + (acc ? 1u : 0u);
+                    const uint64_t cutmask = __ballot(acc && pre == remaining);
+                    if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
+                }
+                const bool consumed = lane < nconsumed;
+                acc = acc && consumed;
+                accmask = __ballot(acc);
+                if (accmask) {
+                    if (p.forager == 1) {
+                        if (!has_best) {
+                            const int sel = __ffsll((unsigned long long)accmask) - 1;
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)shfl_u64((uint64_t)sc.v[kk], sel);
+                            best_m0 = __shfl(m0, sel);
+                            best_m1 = __shfl(m1, sel);
+                            best_leaf = (int)__shfl(my_leaf, sel);
+                            has_best = 1;
+                        }
+                    } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
+                        const ScoreV<L> M = wave_max_score<L>(sc, acc);
+                        const int cm = has_best ? score_cmp<L>(M, best) : 1;
+                        if (cm >= 0) {
+                            const bool newmax = cm > 0;
+                            const uint64_t eq_base = newmax ? 0 : equal_count;
+                            const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
+                            const uint64_t eq = __ballot(in_eq);
+                            const uint32_t rank = mbcnt64(eq) + 1u;
+                            const uint64_t cntq = eq_base + rank;
+                            const bool pick = in_eq && ((newmax && rank == 1) ||
+                                                        (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
+                            const uint64_t pm = __ballot(pick);
+                            if (pm) {
+                                const int sel = 63 - __clzll((unsigned long long)pm);
+                                best_m0 = __shfl(m0, sel);
+                                best_m1 = __shfl(m1, sel);
+                                best_leaf = (int)__shfl(my_leaf, sel);
+                            }
+                            best = M;
+                            equal_count = eq_base + (uint64_t)__popcll(eq);
+                            has_best = 1;
+                        }
+                    }
+                }
+                const uint32_t nacc = (uint32_t)__popcll(accmask);
+                accepted += nacc;
+                st_gen += nconsumed;
+                st_acc += nacc;
+                st_scored += nvalid;
+                st_calc += (uint32_t)__popcll(__ballot(consumed && doable));
+                if (tracing && consumed) {
+                    const uint64_t ti = trace_n + lane;
+                    if ((int64_t)ti < p.trace_cap) {
+                        int32_t* tm = p.trace_moves + ti * 6;
+                        if (my_kind <= 2) {
+                            tm[0] = my_kind == 1 ? 0 : 1;
+                            tm[1] = (int32_t)m0;
+                            tm[2] = 0;
+                            tm[3] = my_kind == 1 ? 0 : (int32_t)m1;
+                            tm[4] = 0;
+                            tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
+                        } else {
+                            tm[0] = my_kind == 4 ? 2 : 3;
+                            tm[1] = (int32_t)(m0 >> 16);
+                            tm[2] = (int32_t)(m0 & 0xFFFFu);
+                            tm[3] = (int32_t)(m1 >> 16);
+                            tm[4] = (int32_t)(m1 & 0xFFFFu);
+                            tm[5] = -1;
+                        }
+                        for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * L + kk] = doable ? sc.v[kk] : 0;
+                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                    }
+                }
+                if (tracing) trace_n += nconsumed;
+                // every laid-out pull is consumed unless the forager cut the step (which ends it)
+#pragma unroll
+                for (int l = 0; l < GL; ++l) head[l] += taken[l];
+                if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
+            }
+        }
+
+        // ---- commit the forager's pick ----
+        const bool applied = has_best && !p.dry_run;
+        if (applied) {
+            int kind = 0;
+#pragma unroll
+            for (int l = 0; l < GL; ++l)
+                if (best_leaf == l) kind = gl.kind[l];
+            const uint32_t a = uni(best_m0), b = uni(best_m1);
+            if (kind <= 2) {
+                if (tracing && lane == 0) {
+                    p.trace_applied[0] = 1;
+                    p.trace_applied[1] = kind == 1 ? 0 : 1;
+                    p.trace_applied[2] = (int32_t)a;
+                    p.trace_applied[3] = 0;
+                    p.trace_applied[4] = kind == 1 ? 0 : (int32_t)b;
+                    p.trace_applied[5] = 0;
+                    p.trace_applied[6] = kind == 1 ? (int32_t)b : -1;
+                }
+                if (lane == 0) {
+                    if (kind == 1)
+                        s_vals[a] = (VT)(int32_t)b;
+                    else {
+                        const VT t = s_vals[a];
+                        s_vals[a] = s_vals[b];
+                        s_vals[b] = t;
+                    }
+                }
+                wave_sync();
+            } else {
+                if (tracing && lane == 0) {
+                    p.trace_applied[0] = 1;
+                    p.trace_applied[1] = kind == 4 ? 2 : 3;
+                    p.trace_applied[2] = (int32_t)(a >> 16);
+                    p.trace_applied[3] = (int32_t)(a & 0xFFFFu);
+                    p.trace_applied[4] = (int32_t)(b >> 16);
+                    p.trace_applied[5] = (int32_t)(b & 0xFFFFu);
+                    p.trace_applied[6] = -1;
+                }
+                apply_list_move_wave(lm, s_visits, s_off, s_load, kind == 4 ? 2 : 3, a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu);
+            }
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) cur[kk] = best.v[kk];
+            st_applied += 1;
+        } else if (tracing && lane == 0) {
+            p.trace_applied[0] = 0;
+        }
+        if (!p.dry_run) {
+            bool improved = false;
+            if (applied) {
+                ScoreV<L> cs, bs;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    cs.v[kk] = cur[kk];
+                    bs.v[kk] = best_sol[kk];
+                }
+                improved = score_cmp<L>(cs, bs) > 0;
+            }
+            if (improved) {  // update_best_solution (scope_progress.rs:89-107)
+                if (has_list) {
+                    const uint32_t tot = uni(s_off[V]);
+                    for (uint32_t t = lane; t < tot; t += 64) lm.best_visits[(size_t)r * lm.n_cap + t] = s_visits[t];
+                    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) lm.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+                }
+                for (uint32_t t = lane; t < ns; t += 64) sm.best_vals[(size_t)r * ns + t] = (int32_t)s_vals[t];
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
+            }
+            if (p.acceptor == 1 && lane == 0) {
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
+            }
+            wave_sync();
+            st_steps += 1;
+        }
+    }
+
+    if (!p.dry_run) {
+        if (has_list) {
+            const uint32_t tot = uni(s_off[V]);
+            for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
+            for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
+            for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = s_load[t];
+        }
+        for (uint32_t t = lane; t < ns; t += 64) g_vals[t] = (int32_t)s_vals[t];
+        if (lane == 0) {
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) {
+                g_score[kk] = cur[kk];
+                p.last_step_score[(size_t)r * 4 + kk] = cur[kk];
+                g_best_score[kk] = best_sol[kk];
+            }
+            p.la_idx[r] = (int32_t)(((int64_t)la_idx0 + p.n_steps) % p.la_size);
+            p.step_index[r] = step_index0 + (uint64_t)p.n_steps;
+            p.seed_draws[r] = seed_draws0 + (uint64_t)p.n_steps;
+            uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
+            gs[0] += st_steps;
+            gs[1] += st_gen;
+            gs[2] += st_gen;
+            gs[3] += st_acc;
+            gs[4] += st_applied;
+            gs[5] += st_calc;
+            gs[6] += st_gen - st_calc;
+            gs[7] += st_scored;
+            gs[8] += st_sources;
+        }
+    }
+    if (tracing && lane == 0) *p.trace_count = (int64_t)trace_n;
+}
+
+}  // namespace sf

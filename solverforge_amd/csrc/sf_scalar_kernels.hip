@@ -120,7 +120,9 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
 }
 
 // evaluate_all / initialize: full recomputation (fresh_score; FullAssert).  grid = R blocks.
-__global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit) {
+// accumulate != 0: add this class's constraint scores to what the list class already wrote (mixed models)
+__global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
+                                                             int accumulate) {
     __shared__ unsigned long long s_un, s_cross;
     const int r = blockIdx.x;
     const int32_t* vals = m.vals + (size_t)r * m.n;
@@ -159,8 +161,8 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         if (m.un_level >= 0) sc[m.un_level] = wsub(sc[m.un_level], (int64_t)((uint64_t)m.un_weight * s_un));
         if (m.cross_level >= 0) sc[m.cross_level] = wsub(sc[m.cross_level], (int64_t)((uint64_t)m.cross_weight * s_cross));
         for (int k = 0; k < m.levels; ++k) {
-            if (out_scores) out_scores[(size_t)r * m.levels + k] = sc[k];
-            if (commit) m.score[(size_t)r * 4 + k] = sc[k];
+            if (out_scores) out_scores[(size_t)r * m.levels + k] = accumulate ? wadd(out_scores[(size_t)r * m.levels + k], sc[k]) : sc[k];
+            if (commit) m.score[(size_t)r * 4 + k] = accumulate ? wadd(m.score[(size_t)r * 4 + k], sc[k]) : sc[k];
         }
     }
 }
@@ -168,9 +170,11 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
 // n x evaluate_candidate for host-provided moves (the ScalarCandidateProvider surface: a batch of
 // ScalarEdit{entity, to_value} is kind = SF_MOVE_CHANGE): one thread per move, state unchanged.
 __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, int replica, const int32_t* moves,
-                                                               int64_t n, int64_t* out_scores, int32_t* out_doable) {
+                                                               int64_t n, int64_t* out_scores, int32_t* out_doable,
+                                                               int skip_foreign) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    if (skip_foreign && moves[t * 6] != 0 && moves[t * 6] != 1) return;  // a list move of a mixed model
     const int32_t* vals = m.vals + (size_t)replica * m.n;
     const int64_t* cur = m.score + (size_t)replica * 4;
     const int32_t* mv = moves + t * 6;

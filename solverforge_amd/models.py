@@ -9,6 +9,7 @@ FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN = 0,
 
 
 def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearby_change", "nearby_swap")):
+    # leaves may also name the plain streams "list_change" / "list_swap" (generic N-leaf engine)
     """CVRP: HardSoftScore; all_customers_assigned (not-exists, 1 hard each —
     crates/solverforge/tests/list_clarke_wright_publication/domain/publication_plan.rs:51-65),
     vehicle_capacity (uni on routes, max(0, load-cap) hard), total_distance (uni on routes,
@@ -29,6 +30,10 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
         d.add_selector(SelectorKind.NEARBY_LIST_CHANGE, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
     if "nearby_swap" in leaves:
         d.add_selector(SelectorKind.NEARBY_LIST_SWAP, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
+    if "list_change" in leaves:
+        d.add_selector(SelectorKind.LIST_CHANGE, 0)
+    if "list_swap" in leaves:
+        d.add_selector(SelectorKind.LIST_SWAP, 0)
     return d
 
 
@@ -63,6 +68,39 @@ def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap")):
     d.add_fact_column_i32(FACT_COLUMN, np.arange(n, dtype=np.int32))
     d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
     d.add_constraint(ConstraintKind.CROSS_QUEENS, 0, fact=FACT_COLUMN, level=0, weight=1)
+    if "change" in leaves:
+        d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
+    if "swap" in leaves:
+        d.add_selector(SelectorKind.SCALAR_SWAP, 0)
+    return d
+
+
+def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
+                  leaves=("list_change", "list_swap", "change", "swap")):
+    """Mixed job shop (examples/mixed-job-shop/src/domain/job_shop_plan.rs:28-69): class 0 =
+    operations with the scalar `machine_idx` (0..n_machines, allows_unassigned), class 1 = machines
+    with the list variable `sequence` of operation ids.  BendableScore<2,1> (BASELINE.json):
+    level 0 unassigned machine, level 1 unscheduled operation (not-exists over the flattened
+    sequences), level 2 same job on the same machine (predicate cross-join on operations)."""
+    import numpy as np
+
+    levels, hard = (3, 2) if bendable else (2, 1)
+    lv = (0, 1, 2) if bendable else (0, 0, 1)
+    d = GpuScoreDirector(score_levels=levels, hard_levels=hard, n_replicas=n_replicas, device_id=device_id)
+    n_ops, n_m = problem["n_ops"], problem["n_machines"]
+    d.add_entity_class(0, n_ops)
+    d.add_scalar_variable(0, 0, n_m, True, problem["machine_idx"])
+    d.add_entity_class(1, n_m)
+    d.add_list_variable(1, problem["sequences"], element_capacity=n_ops, element_id_bound=n_ops)
+    d.add_fact_column_i32(FACT_GROUP, np.asarray(problem["job"], dtype=np.int32))
+    d.add_fact_column_u32(FACT_CUSTOMERS, np.arange(n_ops, dtype=np.uint32))
+    d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=lv[0], weight=1)
+    d.add_constraint(ConstraintKind.NOT_EXISTS_FLATTENED, 1, fact=FACT_CUSTOMERS, level=lv[1], weight=1)
+    d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=lv[2], weight=1)
+    if "list_change" in leaves:
+        d.add_selector(SelectorKind.LIST_CHANGE, 1)
+    if "list_swap" in leaves:
+        d.add_selector(SelectorKind.LIST_SWAP, 1)
     if "change" in leaves:
         d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
     if "swap" in leaves:

@@ -1,0 +1,191 @@
+"""GPU parity tests (through the C ABI) of the generic N-leaf engine vs the CPU oracle:
+the mixed job shop (scalar + list variable, 4-leaf StratifiedRandom union, BendableScore<2,1>) and
+list models with the plain list change / swap streams."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(moves):
+    return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"], moves["value"]], axis=1)
+
+
+def _jobshop(n_jobs=12, n_machines=5, seed=1):
+    """Operations with a partial machine assignment and partially filled machine sequences."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_jobshop(n_jobs, n_machines)
+    n = p["n_ops"]
+    r = datasets.stream(seed, 3 * n)
+    p["machine_idx"] = (r[:n] % np.uint64(n_machines + 1)).astype(np.int64) - 1
+    seqs = [[] for _ in range(n_machines)]
+    for op in range(n):
+        where = int(r[n + op] % np.uint64(n_machines + 2))
+        if where < n_machines:  # some operations stay unscheduled
+            seqs[where].append(op)
+    p["sequences"] = seqs
+    return p
+
+
+def _mk_jobshop(oracle, p, n_replicas=1, bendable=True):
+    import solverforge_amd as sfa
+
+    d = sfa.build_jobshop(p, n_replicas=n_replicas, bendable=bendable)
+    o = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=bendable)
+    bits = oracle.LEAF_LIST_CHANGE | oracle.LEAF_LIST_SWAP | oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
+    return d, o, bits
+
+
+@pytest.mark.parametrize("bendable", [True, False])
+def test_jobshop_scores(oracle, bendable):
+    p = _jobshop()
+    d, o, _ = _mk_jobshop(oracle, p, bendable=bendable)
+    L = 3 if bendable else 2
+    s = d.calculate_score()
+    assert s.shape == (1, L)
+    assert (s[0] == o.score()[:L]).all() and (s[0] < 0).any()
+    assert (d.fresh_score()[0] == o.fresh_score()[:L]).all()
+
+
+@pytest.mark.parametrize("order", [0, 3, 4])
+def test_jobshop_four_leaf_union_order_and_scores(oracle, order):
+    """Union of list change, list swap, scalar change, scalar swap (StratifiedRandom, exhaustion of
+    the short scalar streams mid-way) + every trial score, BendableScore<2,1>."""
+    p = _jobshop(n_jobs=6, n_machines=4, seed=2)
+    d, o, bits = _mk_jobshop(oracle, p)
+    o.configure(leaves=bits, selection_order=order)
+    d.calculate_score()
+    for step_index, step_seed in [(0, 0), (7, 41), (3, 0xDEADBEEFCAFEF00D)]:
+        gm, gs, gd = d.open_cursor(step_index, step_seed, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, step_index, step_seed, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm) == _t(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all()
+        assert (gs == os_[:, :3]).all()
+        es, ed = d.evaluate_moves(om)  # sf_step_evaluate on a mixed batch
+        assert (ed == od).all() and (es == os_[:, :3]).all()
+
+
+@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 32), (0, 0, 3), (1, 1, 1)])
+def test_jobshop_traced_steps(oracle, acceptor, forager, limit):
+    import solverforge_amd as sfa
+
+    p = _jobshop(n_jobs=8, n_machines=4, seed=3)
+    d, o, bits = _mk_jobshop(oracle, p)
+    o.configure(acceptor=acceptor, la_size=5, forager=forager, limit=limit, leaves=bits, random_seed=4)
+    d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=5, forager=forager,
+                                 accepted_count_limit=limit, random_seed=4))
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    for step in range(30):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all(), step
+        assert (gf == of).all(), step
+        assert (gs == os_[:, :3]).all(), step
+        assert gap == oap, step
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+        assert (d.working_values(0, 0) == o.get_vars(0, 0)).all(), step
+        assert d.working_lists(1, 0) == o.get_lists(1), step
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    assert (d.fresh_score()[0] == o.score()[:3]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied",
+              "score_calculations", "moves_not_doable"]:
+        assert gst[k] == ost[k], k
+
+
+def test_jobshop_apply_and_fused_multi_replica(oracle):
+    import solverforge_amd as sfa
+
+    p = _jobshop(n_jobs=20, n_machines=6, seed=5)
+    R = 3
+    d, o, bits = _mk_jobshop(oracle, p, n_replicas=R)
+    o.configure(leaves=bits)
+    d.calculate_score()
+    rng = np.random.default_rng(2)
+    for it in range(12):  # committed moves of all four kinds through sf_apply
+        om = o.enumerate(0, it, 50 + it, 3)
+        _, od = o.evaluate_moves(om)
+        mv = om[np.flatnonzero(od)[rng.integers(int(od.sum()))]]
+        o.apply_move(mv)
+        for r in range(R):
+            d.apply_move(mv, replica=r)
+        assert (d.calculate_score()[0] == o.score()[:3]).all()
+    assert (d.fresh_score() == d.calculate_score()).all()
+    d.configure(sfa.SolverConfig(random_seed=9))
+    d.phase_start()
+    d.solve_steps(25)
+    d.solve_steps(20)
+    sc = d.calculate_score()
+    for r in range(R):
+        o2 = oracle.Model.jobshop(p["job"], o.get_vars(0, 0), o.get_lists(1), bendable=True)
+        o2.configure(leaves=bits, random_seed=9 + r)
+        o2.phase_start()
+        o2.steps(45)
+        assert (sc[r] == o2.score()[:3]).all(), r
+        assert (d.working_values(0, 0, r) == o2.get_vars(0, 0)).all(), r
+        assert d.working_lists(1, r) == o2.get_lists(1), r
+    assert (d.fresh_score() == sc).all()
+
+
+def test_jobshop_c4_size_properties(oracle):
+    """BASELINE config 4 size (500 jobs x 20 machines = 10,000 operations, BendableScore): start from
+    the reference example's empty state, incremental == full recalculation, first steps == oracle."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_jobshop(500, 20)
+    d, o, bits = _mk_jobshop(oracle, p, n_replicas=2)
+    d.configure(sfa.SolverConfig(random_seed=0))
+    s0 = d.calculate_score()
+    assert (s0[0] == [-10000, -10000, 0]).all()
+    d.phase_start()
+    d.solve_steps(20)
+    o.configure(leaves=bits, random_seed=0)
+    o.phase_start()
+    o.steps(20)
+    sc = d.calculate_score()
+    assert (sc[0] == o.score()[:3]).all()
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.fresh_score() == sc).all()
+
+
+@pytest.mark.parametrize("leaves", [("list_change",), ("list_swap",), ("list_change", "list_swap")])
+def test_cvrp_plain_list_leaves(oracle, leaves):
+    """Plain (non-nearby) list change / swap streams on a CVRP model: full candidate order, trial
+    scores with the distance / capacity deltas, and fused steps."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(26, 4, 30, seed=4)
+    p["routes"][2] = []  # an empty route in the stream
+    seen = set()
+    p["routes"][0] = p["routes"][0] + [c for c in range(1, 27) if c % 4 == 3]
+    p["routes"] = [[c for c in r if not (c in seen or seen.add(c))] for r in p["routes"]]
+    d = sfa.build_cvrp(p, leaves=leaves)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    bits = (oracle.LEAF_LIST_CHANGE if "list_change" in leaves else 0) | (oracle.LEAF_LIST_SWAP if "list_swap" in leaves else 0)
+    d.calculate_score()
+    for order in (0, 3, 4):
+        o.configure(leaves=bits, selection_order=order, random_seed=6)
+        gm, gs, gd = d.open_cursor(5, 77, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 5, 77, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm)[:, :5] == _t(om)[:, :5]).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+    o.configure(leaves=bits, random_seed=6)
+    d.configure(sfa.SolverConfig(random_seed=6))
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(25)
+    o.steps(25)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
