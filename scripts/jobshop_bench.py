@@ -1,0 +1,37 @@
+"""BASELINE config 4 (mixed job shop 500 jobs x 20 machines, list + scalar moves, BendableScore<2,1>):
+moves/s of the generic N-leaf HIP engine vs the CPU oracle over the same step window of replica 0."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import solverforge_amd as sfa
+from solverforge_amd import datasets
+from oracle import sfo
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+ls = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+p = datasets.make_jobshop(500, 20)
+d = sfa.build_jobshop(p, n_replicas=R)
+d.configure(sfa.SolverConfig(random_seed=0))
+d.calculate_score(); d.phase_start()
+d.solve_steps(ls); d.profile_solve()
+b = d.total_stats()
+t0 = time.perf_counter()
+for _ in range(K): d.solve_steps(ls, sync=False)
+d.sync()
+dt = time.perf_counter() - t0
+ms, n = d.profile_solve()
+a = d.total_stats()
+moves = a["moves_evaluated"] - b["moves_evaluated"]
+o = sfo.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True)
+bits = sfo.LEAF_LIST_CHANGE | sfo.LEAF_LIST_SWAP | sfo.LEAF_SCALAR_CHANGE | sfo.LEAF_SCALAR_SWAP
+o.configure(leaves=bits, random_seed=0)
+o.phase_start(); o.steps(ls)
+m0 = o.stats()["moves_evaluated"]; t1 = time.perf_counter(); done = 0
+while done < K * ls and time.perf_counter() - t1 < 20: o.steps(5); done += 5
+ct = time.perf_counter() - t1
+cm = o.stats()["moves_evaluated"] - m0
+match = bool((d.calculate_score()[0] == o.score()[:3]).all()) if done == K * ls else None
+print(json.dumps({"workload": "mixed job shop 500x20, Bendable<2,1>", "replicas": R, "gpu_moves_per_s": moves / dt,
+                  "kernel_ms_per_launch": ms / n, "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done,
+                  "replica0_matches_oracle": match, "gpu_over_cpu": (moves / dt) / (cm / ct),
+                  "score_replica0": d.calculate_score()[0].tolist()}))
