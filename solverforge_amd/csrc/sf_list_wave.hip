@@ -321,6 +321,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
     const uint64_t step_index0 = dry_run ? 0 : p.step_index[r];
     const uint64_t seed_draws0 = dry_run ? 0 : p.seed_draws[r];
     const int la_idx0 = dry_run ? 0 : p.la_idx[r];
+    int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
     const uint64_t lanebit = 1ULL << lane;
     PH_DECL
 
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
         ScoreV<L> late;
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
-        const int la_slot = dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
+        const int la_slot = la_cursor;  // LateAcceptance history slot of this step
         if (acceptor == 1) {
 #pragma unroll
             for (int k = 0; k < L; ++k) late.v[k] = (int64_t)uni64((uint64_t)p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k]);
@@ -743,6 +744,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             }
             wave_sync();
             st_steps += 1;
+            la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
         }
         PH(5)
     }
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
                 p.last_step_score[(size_t)r * 4 + kk] = cur[kk];
                 m.best_score[(size_t)r * 4 + kk] = best_sol[kk];
             }
-            p.la_idx[r] = (int32_t)(((int64_t)la_idx0 + p.n_steps) % p.la_size);
+            p.la_idx[r] = la_cursor;
             p.step_index[r] = step_index0 + (uint64_t)p.n_steps;
             p.seed_draws[r] = seed_draws0 + (uint64_t)p.n_steps;
             uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
     const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
     const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
+    int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         uint64_t sidx, sseed;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         ScoreV<L> late;
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
-        const int la_slot = p.dry_run ? 0 : (int)(((int64_t)la_idx0 + step) % p.la_size);
+        const int la_slot = la_cursor;  // LateAcceptance history slot of this step
         if (p.acceptor == 1) {
 #pragma unroll
             for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             }
             wave_sync();
             st_steps += 1;
+            la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
         }
     }
 
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                 p.last_step_score[(size_t)r * 4 + kk] = cur[kk];
                 g_best_score[kk] = best_sol[kk];
             }
-            p.la_idx[r] = (int32_t)(((int64_t)la_idx0 + p.n_steps) % p.la_size);
+            p.la_idx[r] = la_cursor;
             p.step_index[r] = step_index0 + (uint64_t)p.n_steps;
             p.seed_draws[r] = seed_draws0 + (uint64_t)p.n_steps;
             uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
