@@ -394,7 +394,8 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             c.len = len;
             c.sp = sp;
             c.sx = sx;
-            c.pk = lane < dim ? (uint32_t)nb.keys[(size_t)sx * dim + lane] : NBR_END;
+            const uint32_t ent = l ? ((lane + 32u) & 63u) : lane;  // leaf 1: lanes 32-63 hold entries 0-31
+            c.pk = ent < dim ? (uint32_t)nb.keys[(size_t)sx * dim + ent] : NBR_END;
         };
 
         PH(0)
@@ -443,112 +444,208 @@ __global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, S
             PH(4)
             // C1: generation.  Keep >= 32 candidates pending per live leaf (>= min(64, rc - K) when
             // only one leaf is live) so that the replay batch below finds every lane a candidate.
-            for (int l = 0; l < n_leaves; ++l) {
-                LeafCursor c = l ? C1 : C0;
+            //
+            // gen_rest: one source of leaf l from neighbour-row offset `base` on, `key` = the 64 row
+            // entries at base (lane i = entry base + i); returns the number of candidates appended.
+            auto gen_rest = [&](int l, uint32_t se, uint32_t sp, uint32_t len, uint32_t k, uint32_t sx, uint32_t tl,
+                                uint32_t key, uint32_t base, uint32_t need, uint32_t emitted) -> uint32_t {
                 const bool is_change = l ? chg1 : chg0;
-                const uint32_t K = l ? K1 : K0;
-                const uint32_t single = cv.rc - K < 64u ? cv.rc - K : 64u;
-                const uint32_t target = (!C0.ex && !C1.ex) ? 32u : single;
                 const uint16_t* ro = rank_of + l * V;
                 const uint16_t* sb = slot_base + l * (V + 1);
                 uint32_t* rq = ring + (size_t)l * cv.rc * 2;
-                while (!c.ex && c.left > 0 && c.tail - c.head < target) {
-                    const uint32_t se = c.se, sp = c.sp, len = c.len, k = c.k;
-                    const uint16_t* rowk = nb.keys + (size_t)c.sx * dim;
-                    const uint32_t sx = c.sx;
-                    const uint32_t mv0 = (se << 16) | sp;
-                    uint32_t key = c.pk;
-                    // put the next source's first chunk in flight before working on this one
+                const uint16_t* rowk = nb.keys + (size_t)sx * dim;
+                const uint32_t mv0 = (se << 16) | sp;
+                for (;;) {
+                    const bool have = key != NBR_END;
+                    const uint64_t havemask = __ballot(have);
+                    if (havemask == 0) break;  // finite entries of the row exhausted
+                    NearbyItem it{0u, 0u, 0u, 0u};
+                    if (have) it = nearby_item(is_change, node_slot[key & NBR_NODE_MASK], se, sp, len, k, s_off, sb, ro);
+                    // equal-distance groups are contiguous lane ranges; the index marks entries that
+                    // continue the previous entry's distance
+                    const uint64_t startmask = __ballot(have && (lane == 0 || !(key & NBR_SAME_FLAG)));
+                    const bool more = havemask == ~0ULL && base + 64 < dim;
+                    const uint32_t fo = 63u - (uint32_t)__clzll((unsigned long long)startmask);  // first lane of the last group
+                    if (more && fo == 0) {
+                        // one distance group wider than a chunk (degenerate ties): exact serial
+                        // insertion top-k over the rest of the row.
+                        TopK tk{~0ULL, 0u, ~0ULL};
+                        for (uint32_t b2 = base; b2 < dim; b2 += 64) {
+                            const uint32_t j2 = b2 + lane;
+                            const uint32_t ky = j2 < dim ? (uint32_t)rowk[j2] : NBR_END;
+                            NearbyItem i2{0u, 0u, 0u, 0u};
+                            uint64_t hk = 0;
+                            if (ky != NBR_END) {
+                                const uint32_t y2 = ky & NBR_NODE_MASK;
+                                i2 = nearby_item(is_change, node_slot[y2], se, sp, len, k, s_off, sb, ro);
+                                hk = (uint64_t)m.mat[(size_t)sx * dim + y2] << 24;  // finite by construction of the index
+                            }
+                            if (!__ballot(ky != NBR_END)) break;
+                            topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
+                            topk_offer(tk, need, i2.w == 2 ? (hk | (i2.ord + 1)) : ~0ULL, i2.pay1);
+                        }
+                        const uint32_t cnt = (uint32_t)__popcll(__ballot(lane < need && tk.key != ~0ULL));
+                        if (lane < cnt) {
+                            const uint32_t qi = (tl + emitted + lane) & RCM;
+                            rq[qi * 2] = mv0;
+                            rq[qi * 2 + 1] = tk.pay;
+                        }
+                        emitted += cnt;
+                        break;
+                    }
+                    const uint32_t nclosed = more ? fo : (uint32_t)__popcll(havemask);  // lanes [0, nclosed): complete groups
+                    const uint64_t closedmask = nclosed >= 64 ? ~0ULL : ((1ULL << nclosed) - 1ULL);
+                    const bool closed = (closedmask & lanebit) != 0;
+                    const uint32_t wc = closed ? it.w : 0u;
+                    const uint64_t w1 = __ballot(wc == 1), w2 = __ballot(wc == 2);
+                    const uint32_t Wc = (uint32_t)__popcll(w1) + 2u * (uint32_t)__popcll(w2);
+                    if (Wc > 0) {
+                        // sorted position = weight before me, corrected by the inversions inside my group
+                        int32_t pos = (int32_t)(mbcnt64(w1) + 2u * mbcnt64(w2));
+                        const uint64_t nonstart = ~startmask & closedmask;  // lane continues the group of lane-1
+                        if (nonstart) {
+                            const uint32_t packed = (it.ord << 2) | wc;
+                            uint64_t run = nonstart;  // bit t: lanes t-d .. t are one group
+                            for (uint32_t d = 1; run != 0; ++d) {
+                                const uint32_t p_dn = __shfl_down(packed, d), p_up = __shfl_up(packed, d);
+                                const bool same_up = (run & lanebit) != 0;
+                                const bool same_dn = ((run >> d) & lanebit) != 0;
+                                if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
+                                if (same_up && (p_up >> 2) > it.ord) pos -= (int32_t)(p_up & 3u);
+                                run &= nonstart << d;
+                            }
+                        }
+                        if (wc >= 1 && (uint32_t)pos < need) {
+                            const uint32_t qi = (tl + emitted + (uint32_t)pos) & RCM;
+                            rq[qi * 2] = mv0;
+                            rq[qi * 2 + 1] = it.pay0;
+                        }
+                        if (wc == 2 && (uint32_t)pos + 1 < need) {
+                            const uint32_t qi = (tl + emitted + (uint32_t)pos + 1) & RCM;
+                            rq[qi * 2] = mv0;
+                            rq[qi * 2 + 1] = it.pay1;
+                        }
+                        const uint32_t ne = Wc < need ? Wc : need;
+                        emitted += ne;
+                        need -= ne;
+                    }
+                    if (need == 0 || !more) break;
+                    base += nclosed;
+                    const uint32_t jj = base + lane;
+                    key = jj < dim ? (uint32_t)rowk[jj] : NBR_END;
+                }
+                return emitted;
+            };
+            const uint32_t single0 = cv.rc - K0 < 64u ? cv.rc - K0 : 64u, single1 = cv.rc - K1 < 64u ? cv.rc - K1 : 64u;
+            for (;;) {
+                const bool both_live = !C0.ex && !C1.ex;
+                const bool need0 = !C0.ex && C0.left > 0 && C0.tail - C0.head < (both_live ? 32u : single0);
+                const bool need1 = n_leaves > 1 && !C1.ex && C1.left > 0 && C1.tail - C1.head < (both_live ? 32u : single1);
+                if (!need0 && !need1) break;
+                if (need0 && need1) {
+                    // ---- paired pass: lanes 0-31 = the first 32 row entries of leaf 0's source, lanes
+                    // 32-63 = the first 32 of leaf 1's (its prefetch is stored rotated by 32 lanes) ----
+                    const bool hi = lane >= 32;
+                    const uint32_t seA = C0.se, spA = C0.sp, lenA = C0.len, kA = C0.k, sxA = C0.sx, tlA = C0.tail;
+                    const uint32_t seB = C1.se, spB = C1.sp, lenB = C1.len, kB = C1.k, sxB = C1.sx, tlB = C1.tail;
+                    const uint32_t key = hi ? C1.pk : C0.pk;
+                    C0.left -= 1;
+                    C0.o += 1;
+                    if (C0.left > 0) resolve(C0, 0);
+                    C1.left -= 1;
+                    C1.o += 1;
+                    if (C1.left > 0) resolve(C1, 1);
+                    st_sources += 2;
+                    const uint32_t se = hi ? seB : seA, sp = hi ? spB : spA, len = hi ? lenB : lenA, kk = hi ? kB : kA;
+                    const uint32_t Kh = hi ? K1 : K0;
+                    const bool have = key != NBR_END;
+                    NearbyItem it{0u, 0u, 0u, 0u};
+                    {
+                        const uint32_t slot = have ? node_slot[key & NBR_NODE_MASK] : NODE_NONE;
+                        const uint16_t* sbh = slot_base + (hi ? (V + 1) : 0);
+                        const uint16_t* roh = rank_of + (hi ? V : 0);
+                        const NearbyItem ic = nearby_item(true, slot, se, sp, len, kk, s_off, sbh, roh);
+                        const NearbyItem is = nearby_item(false, slot, se, sp, len, kk, s_off, sbh, roh);
+                        const bool lane_change = hi ? chg1 : chg0;
+                        it.w = lane_change ? ic.w : is.w;
+                        it.ord = lane_change ? ic.ord : is.ord;
+                        it.pay0 = lane_change ? ic.pay0 : is.pay0;
+                        it.pay1 = lane_change ? ic.pay1 : is.pay1;
+                    }
+                    const uint64_t havemask = __ballot(have);
+                    const uint64_t startmask = __ballot(have && ((lane & 31u) == 0 || !(key & NBR_SAME_FLAG)));
+                    const uint32_t hvA = (uint32_t)havemask, hvB = (uint32_t)(havemask >> 32);
+                    const uint32_t stA = (uint32_t)startmask, stB = (uint32_t)(startmask >> 32);
+                    const bool moreA = hvA == 0xFFFFFFFFu && 32u < dim, moreB = hvB == 0xFFFFFFFFu && 32u < dim;
+                    // complete groups of each half (a half whose only group is still open contributes nothing)
+                    const uint32_t ncA = moreA ? 31u - (uint32_t)__clz(stA) : (uint32_t)__popc(hvA);
+                    const uint32_t ncB = moreB ? 31u - (uint32_t)__clz(stB) : (uint32_t)__popc(hvB);
+                    const uint64_t closedmask = (uint64_t)(ncA >= 32 ? 0xFFFFFFFFu : ((1u << ncA) - 1u)) |
+                                                ((uint64_t)(ncB >= 32 ? 0xFFFFFFFFu : ((1u << ncB) - 1u)) << 32);
+                    const bool closed = (closedmask & lanebit) != 0;
+                    const uint32_t wc = closed ? it.w : 0u;
+                    const uint64_t w1 = __ballot(wc == 1), w2 = __ballot(wc == 2);
+                    const uint32_t WcA = (uint32_t)__popc((uint32_t)w1) + 2u * (uint32_t)__popc((uint32_t)w2);
+                    const uint32_t WcB = (uint32_t)__popc((uint32_t)(w1 >> 32)) + 2u * (uint32_t)__popc((uint32_t)(w2 >> 32));
+                    if (WcA + WcB > 0) {
+                        const uint32_t pa = __builtin_amdgcn_mbcnt_lo((uint32_t)w1, 0u) + 2u * __builtin_amdgcn_mbcnt_lo((uint32_t)w2, 0u);
+                        const uint32_t pb = __builtin_amdgcn_mbcnt_hi((uint32_t)(w1 >> 32), 0u) + 2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(w2 >> 32), 0u);
+                        int32_t pos = (int32_t)(hi ? pb : pa);
+                        const uint64_t nonstart = ~startmask & closedmask;  // never crosses lane 32 (forced start)
+                        if (nonstart) {
+                            const uint32_t packed = (it.ord << 2) | wc;
+                            uint64_t run = nonstart;
+                            for (uint32_t d = 1; run != 0; ++d) {
+                                const uint32_t p_dn = __shfl_down(packed, d), p_up = __shfl_up(packed, d);
+                                const bool same_up = (run & lanebit) != 0;
+                                const bool same_dn = ((run >> d) & lanebit) != 0;
+                                if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
+                                if (same_up && (p_up >> 2) > it.ord) pos -= (int32_t)(p_up & 3u);
+                                run &= nonstart << d;
+                            }
+                        }
+                        uint32_t* rq = ring + (hi ? (size_t)cv.rc * 2 : 0);
+                        const uint32_t tl = hi ? tlB : tlA;
+                        const uint32_t mv0 = (se << 16) | sp;
+                        if (wc >= 1 && (uint32_t)pos < Kh) {
+                            const uint32_t qi = (tl + (uint32_t)pos) & RCM;
+                            rq[qi * 2] = mv0;
+                            rq[qi * 2 + 1] = it.pay0;
+                        }
+                        if (wc == 2 && (uint32_t)pos + 1 < Kh) {
+                            const uint32_t qi = (tl + (uint32_t)pos + 1) & RCM;
+                            rq[qi * 2] = mv0;
+                            rq[qi * 2 + 1] = it.pay1;
+                        }
+                    }
+                    uint32_t emA = WcA < K0 ? WcA : K0, emB = WcB < K1 ? WcB : K1;
+                    if (emA < K0 && moreA) {  // rare: leaf 0's source needs entries beyond its half
+                        const uint32_t jj = ncA + lane;
+                        emA = gen_rest(0, seA, spA, lenA, kA, sxA, tlA, jj < dim ? (uint32_t)nb.keys[(size_t)sxA * dim + jj] : NBR_END, ncA, K0 - emA, emA);
+                    }
+                    if (emB < K1 && moreB) {
+                        const uint32_t jj = ncB + lane;
+                        emB = gen_rest(1, seB, spB, lenB, kB, sxB, tlB, jj < dim ? (uint32_t)nb.keys[(size_t)sxB * dim + jj] : NBR_END, ncB, K1 - emB, emB);
+                    }
+                    C0.tail = tlA + emA;
+                    C1.tail = tlB + emB;
+                } else {
+                    // ---- single source of the one leaf that needs candidates ----
+                    const int l = need0 ? 0 : 1;
+                    LeafCursor c = l ? C1 : C0;
+                    const uint32_t se = c.se, sp = c.sp, len = c.len, k = c.k, sx = c.sx;
+                    // leaf 1 keeps its prefetched entries rotated by 32 lanes for the paired pass
+                    const uint32_t key = l ? __shfl(c.pk, (int)((lane + 32u) & 63u)) : c.pk;
                     c.left -= 1;
                     c.o += 1;
                     if (c.left > 0) resolve(c, l);
                     st_sources += 1;
-                    uint32_t need = K, emitted = 0, base = 0;
-                    for (;;) {
-                        const bool have = key != NBR_END;
-                        const uint64_t havemask = __ballot(have);
-                        if (havemask == 0) break;  // finite entries of the row exhausted
-                        NearbyItem it{0u, 0u, 0u, 0u};
-                        if (have) it = nearby_item(is_change, node_slot[key & NBR_NODE_MASK], se, sp, len, k, s_off, sb, ro);
-                        // equal-distance groups are contiguous lane ranges; the index marks entries that
-                        // continue the previous entry's distance
-                        const uint64_t startmask = __ballot(have && (lane == 0 || !(key & NBR_SAME_FLAG)));
-                        const bool more = havemask == ~0ULL && base + 64 < dim;
-                        const uint32_t fo = 63u - (uint32_t)__clzll((unsigned long long)startmask);  // first lane of the last group
-                        if (more && fo == 0) {
-                            // one distance group wider than a chunk (degenerate ties): exact serial
-                            // insertion top-k over the rest of the row.
-                            TopK tk{~0ULL, 0u, ~0ULL};
-                            for (uint32_t b2 = base; b2 < dim; b2 += 64) {
-                                const uint32_t j2 = b2 + lane;
-                                const uint32_t ky = j2 < dim ? (uint32_t)rowk[j2] : NBR_END;
-                                NearbyItem i2{0u, 0u, 0u, 0u};
-                                uint64_t hk = 0;
-                                if (ky != NBR_END) {
-                                    const uint32_t y2 = ky & NBR_NODE_MASK;
-                                    i2 = nearby_item(is_change, node_slot[y2], se, sp, len, k, s_off, sb, ro);
-                                    hk = (uint64_t)m.mat[(size_t)sx * dim + y2] << 24;  // finite by construction of the index
-                                }
-                                if (!__ballot(ky != NBR_END)) break;
-                                topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
-                                topk_offer(tk, need, i2.w == 2 ? (hk | (i2.ord + 1)) : ~0ULL, i2.pay1);
-                            }
-                            const uint32_t cnt = (uint32_t)__popcll(__ballot(lane < need && tk.key != ~0ULL));
-                            if (lane < cnt) {
-                                const uint32_t qi = (c.tail + emitted + lane) & RCM;
-                                rq[qi * 2] = mv0;
-                                rq[qi * 2 + 1] = tk.pay;
-                            }
-                            emitted += cnt;
-                            break;
-                        }
-                        const uint32_t nclosed = more ? fo : (uint32_t)__popcll(havemask);  // lanes [0, nclosed): complete groups
-                        const uint64_t closedmask = nclosed >= 64 ? ~0ULL : ((1ULL << nclosed) - 1ULL);
-                        const bool closed = (closedmask & lanebit) != 0;
-                        const uint32_t wc = closed ? it.w : 0u;
-                        const uint64_t w1 = __ballot(wc == 1), w2 = __ballot(wc == 2);
-                        const uint32_t Wc = (uint32_t)__popcll(w1) + 2u * (uint32_t)__popcll(w2);
-                        if (Wc > 0) {
-                            // sorted position = weight before me, corrected by the inversions inside my group
-                            int32_t pos = (int32_t)(mbcnt64(w1) + 2u * mbcnt64(w2));
-                            const uint64_t nonstart = ~startmask & closedmask;  // lane continues the group of lane-1
-                            if (nonstart) {
-                                const uint32_t packed = (it.ord << 2) | wc;
-                                uint64_t run = nonstart;  // bit t: lanes t-d .. t are one group
-                                for (uint32_t d = 1; run != 0; ++d) {
-                                    const uint32_t p_dn = __shfl_down(packed, d), p_up = __shfl_up(packed, d);
-                                    const bool same_up = (run & lanebit) != 0;
-                                    const bool same_dn = ((run >> d) & lanebit) != 0;
-                                    if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
-                                    if (same_up && (p_up >> 2) > it.ord) pos -= (int32_t)(p_up & 3u);
-                                    run &= nonstart << d;
-                                }
-                            }
-                            if (wc >= 1 && (uint32_t)pos < need) {
-                                const uint32_t qi = (c.tail + emitted + (uint32_t)pos) & RCM;
-                                rq[qi * 2] = mv0;
-                                rq[qi * 2 + 1] = it.pay0;
-                            }
-                            if (wc == 2 && (uint32_t)pos + 1 < need) {
-                                const uint32_t qi = (c.tail + emitted + (uint32_t)pos + 1) & RCM;
-                                rq[qi * 2] = mv0;
-                                rq[qi * 2 + 1] = it.pay1;
-                            }
-                            const uint32_t ne = Wc < need ? Wc : need;
-                            emitted += ne;
-                            need -= ne;
-                        }
-                        if (need == 0 || !more) break;
-                        base += nclosed;
-                        const uint32_t jj = base + lane;
-                        key = jj < dim ? (uint32_t)rowk[jj] : NBR_END;
-                    }
-                    c.tail += emitted;
+                    c.tail += gen_rest(l, se, sp, len, k, sx, c.tail, key, 0u, l ? K1 : K0, 0u);
+                    if (l)
+                        C1 = c;
+                    else
+                        C0 = c;
                 }
-                if (l)
-                    C1 = c;
-                else
-                    C0 = c;
             }
             wave_sync();
             PH(2)
