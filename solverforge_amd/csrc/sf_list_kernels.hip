@@ -280,7 +280,7 @@ __device__ __forceinline__ ListDelta eval_list_move_legs(const ListModel& m, con
         if (M32) {  // compact matrix copy: 4-byte gathers
             uint32_t v[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) v[s] = m.mat32[(size_t)f[s] * (size_t)m.dim + t[s]];
+            for (int s = 0; s < 8; ++s) v[s] = m.mat32[f[s] * (uint32_t)m.dim + t[s]];  // dim <= 16384: 32-bit offsets
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int64_t c = v[s] != 0xFFFFFFFFu ? (int64_t)v[s] : MAX_SAFE_LEG_COST;
