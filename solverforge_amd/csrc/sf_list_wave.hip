@@ -260,7 +260,10 @@ struct LeafCursor {
 // FAST: compile-time specialisation for the default list policy (nearby change + nearby swap union,
 // LateAcceptance + AcceptedCount, committed steps) — fewer live scalars and branches in the hot loops.
 template <int L, bool TRACE, bool FAST>
-__global__ __launch_bounds__(64 * WPB, 4) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
+#ifndef SF_WAVES_PER_EU
+#define SF_WAVES_PER_EU 4
+#endif
+__global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));  // 1..WPB replicas per workgroup
