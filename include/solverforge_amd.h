@@ -88,7 +88,14 @@ typedef enum sf_constraint_kind {
     /* for_each(routes).penalize(depot->...->depot matrix sum) — uni on list owners
      * (ProblemData::distance_cost, crates/solverforge-cvrp/src/problem_data.rs:28-31);
      * `fact_a` = i64 matrix, `param` = depot node */
-    SF_C_ROUTE_DISTANCE = 7
+    SF_C_ROUTE_DISTANCE = 7,
+    /* for_each(E).join(equal(value)) on one scalar class, both assigned: `weight` per pair —
+     * keyed self-join IncrementalBiConstraint, constraint/nary_incremental/bi.rs:12-313 */
+    SF_C_SELFJOIN_VALUE_EQUAL = 8,
+    /* for_each(E).filter(assigned).group_by(value, sum(fact_a)).penalize(weight * w(sum)) — grouped node +
+     * sum collector, constraint/grouped/{state,scorer}.rs, stream/collector/sum.rs;
+     * `fact_a` = i32 column summed per group, `param` < 0: w = sum^2, `param` >= 0: w = max(0, sum - param) */
+    SF_C_GROUPED_VALUE_SUM = 9
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {

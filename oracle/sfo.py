@@ -58,6 +58,7 @@ def lib():
             "sfo_sort_and_limit": (i32, [vp, i32, i32, vp]),
             "sfo_nqueens_create": (vp, [i32, vp]),
             "sfo_graph_coloring_create": (vp, [i32, i32, vp, vp, vp]),
+            "sfo_balance_create": (vp, [i32, i32, vp, vp, i64, i64]),
             "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
@@ -131,6 +132,12 @@ class Model:
         colors = np.ascontiguousarray(colors, dtype=np.int64)
         n = len(colors)
         return Model(lib().sfo_graph_coloring_create(n, n_colors, _p(adj_off), _p(adj), _p(colors)), [n])
+
+    @staticmethod
+    def balance(n_bins, bins, sizes, w_pair=1, cap=-1):
+        bins = np.ascontiguousarray(bins, dtype=np.int64)
+        sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+        return Model(lib().sfo_balance_create(len(bins), n_bins, _p(bins), _p(sizes), w_pair, cap), [len(bins)])
 
     @staticmethod
     def cvrp(capacity, depot, demands, matrix, customers, routes):

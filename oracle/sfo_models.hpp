@@ -50,6 +50,9 @@ struct GraphFacts {
     std::vector<uint32_t> adj_off;  // n+1
     std::vector<uint32_t> adj;      // neighbor ids (Node.neighbors, in given order)
 };
+struct BalanceFacts {  // "bin balance" toy: entity sizes for the grouped-sum constraint
+    std::vector<int64_t> size;
+};
 struct QueensFacts {
     size_t n = 0;
     std::vector<int64_t> column;
@@ -216,6 +219,65 @@ inline std::unique_ptr<Model> make_graph_coloring(size_t n, size_t n_colors, con
     m->scalar_slot.values_for_entity = [n_colors](const Solution&, size_t, std::vector<int64_t>& out) {
         out.clear();
         for (size_t v = 0; v < n_colors; ++v) out.push_back((int64_t)v);
+    };
+    m->leaves = LEAF_SCALAR_CHANGE | LEAF_SCALAR_SWAP;
+    m->wire_search();
+    return m;
+}
+
+// ---- bin balance: keyed self-join + grouped sum on one scalar variable ------------------------
+// The node shapes the reference pins in constraint/tests/bi_incr.rs:21-311 (self-join keyed by the
+// planning value, penalty per pair) and constraint/tests/grouped.rs:26-147 + cross_bi_incr.rs:97-120
+// (group by key, sum collector, weight(key, sum)), on a model with a ScalarChange/ScalarSwap
+// neighbourhood: entities carry a size, the planning value is a bin.
+//   level 0: unassigned entity (uni), 1 each
+//   level 1: pairs of entities in the same bin (IncrementalBiConstraint keyed by bin), `w_pair` each
+//   level 1: per bin, weight(bin, sum of sizes): cap < 0 -> sum^2 ; cap >= 0 -> max(0, sum - cap)
+inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_t* bins, const int64_t* sizes,
+                                           int64_t w_pair, int64_t cap) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<BalanceFacts>();
+    facts->size.assign(sizes, sizes + n);
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n;
+    s.classes[0].vars.assign(1, std::vector<int64_t>(bins, bins + n));
+    s.facts = facts;
+    const BalanceFacts* bf = facts.get();
+    m->director.constraints.members.push_back(make_unassigned(0, 0, Score::of(1, 0), "Unassigned bin"));
+
+    auto pairs = std::make_unique<SelfJoinBiConstraint>();
+    pairs->name = "Same bin pair";
+    pairs->impact = Impact::Penalty;
+    pairs->source = ChangeSource::descriptor(0);
+    pairs->count = [](const Solution& s) { return s.classes[0].n; };
+    pairs->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    pairs->filter = [](const Solution& s, size_t a, size_t) { return s.classes[0].vars[0][a] != NONE; };
+    pairs->weight = [w_pair](const Solution&, size_t, size_t) { return Score::of(0, w_pair); };
+    m->director.constraints.members.push_back(std::move(pairs));
+
+    auto load = std::make_unique<GroupedConstraint>();
+    load->name = "Bin load";
+    load->impact = Impact::Penalty;
+    load->source = ChangeSource::descriptor(0);
+    load->count = [](const Solution& s) { return s.classes[0].n; };
+    load->filter = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i] != NONE; };
+    load->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    load->value = [bf](const Solution&, size_t i) { return bf->size[i]; };
+    load->weight = [cap](int64_t, int64_t sum) {
+        if (cap < 0) return Score::of(0, (int64_t)((uint64_t)sum * (uint64_t)sum));
+        int64_t over = wrap_sub(sum, cap);
+        return Score::of(0, over > 0 ? over : 0);
+    };
+    m->director.constraints.members.push_back(std::move(load));
+
+    m->has_scalar = true;
+    m->scalar_slot.descriptor_index = 0;
+    m->scalar_slot.variable_index = 0;
+    m->scalar_slot.allows_unassigned = true;
+    m->scalar_slot.values_for_entity = [n_bins](const Solution&, size_t, std::vector<int64_t>& out) {
+        out.clear();
+        for (size_t v = 0; v < n_bins; ++v) out.push_back((int64_t)v);
     };
     m->leaves = LEAF_SCALAR_CHANGE | LEAF_SCALAR_SWAP;
     m->wire_search();

@@ -279,7 +279,7 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
                           int32_t level, int64_t weight) {
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
-    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_ROUTE_DISTANCE) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_GROUPED_VALUE_SUM) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
     ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
     return SF_OK;
 }
@@ -412,6 +412,7 @@ static bool use_wave_engine(sf_ctx* ctx) {
 }
 
 static int build_scalar_model(sf_ctx* ctx, int d);  // sf_api_scalar.inc
+static size_t scalar_table_bytes(sf_ctx* ctx);
 static int launch_scalar_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace);
 
 static int alloc_search(sf_ctx* ctx) {
@@ -554,7 +555,7 @@ static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit) {
                            ctx->d_scores_out, commit);
     }
     if (ctx->has_scalar_model)  // mixed model: the scalar class adds its constraints to the list class's scores
-        hipLaunchKernelGGL(k_scalar_evaluate_all, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->sm,
+        hipLaunchKernelGGL(k_scalar_evaluate_all, dim3(ctx->R), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm,
                            ctx->d_scores_out, commit, ctx->has_list_model ? 1 : 0);
     HIPCHK(ctx, hipGetLastError());
     if (out) {
@@ -631,7 +632,7 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     if (ctx->has_list_model)
         hipLaunchKernelGGL(k_list_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->lm, replica, d_moves, n, d_sc, d_do, mixed);
     if (ctx->has_scalar_model)
-        hipLaunchKernelGGL(k_scalar_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->sm, replica, d_moves, n, d_sc, d_do, mixed);
+        hipLaunchKernelGGL(k_scalar_evaluate_moves, dim3(grid), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, d_moves, n, d_sc, d_do, mixed);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -657,7 +658,7 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         hipLaunchKernelGGL(k_list_apply, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, mv->kind,
                            (uint32_t)mv->a, (uint32_t)mv->a_pos, (uint32_t)mv->b, (uint32_t)mv->b_pos, ctx->d_ok);
     } else {
-        hipLaunchKernelGGL(k_scalar_apply, dim3(1), dim3(64), 0, ctx->stream, ctx->sm, replica, mv->kind, mv->a,
+        hipLaunchKernelGGL(k_scalar_apply, dim3(1), dim3(64), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, mv->kind, mv->a,
                            mv->b, mv->value, ctx->d_ok);
     }
     HIPCHK(ctx, hipGetLastError());
@@ -771,6 +772,8 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         if (s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP)
             return fail(ctx, SF_ERR_UNSUPPORTED, "nearby leaves cannot be unioned with plain / scalar leaves yet");
     if (gl.n == 0) return fail(ctx, SF_ERR_INVALID, "no selector configured");
+    if (ctx->has_scalar_model && (ctx->sm.sj_level >= 0 || ctx->sm.grp_level >= 0))
+        return fail(ctx, SF_ERR_UNSUPPORTED, "value-keyed constraints (self-join / grouped sum) run in the scalar engine only");
     if (ctx->has_list_model && (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536))
         return fail(ctx, SF_ERR_UNSUPPORTED, "generic engine packs list elements and positions in 16 bits");
     p.n_leaves = gl.n;

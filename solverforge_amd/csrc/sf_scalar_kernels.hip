@@ -42,6 +42,10 @@ struct ScalarModel {
     const uint32_t* pn_off = nullptr;  // [n+1] symmetric partner CSR (SC_PARTNERS_EQUAL)
     const uint32_t* pn = nullptr;
     const int32_t* col = nullptr;      // [n] column fact (SC_QUEENS)
+    // value-keyed aggregates (per-value count / sum tables, maintained at apply):
+    int32_t sj_level = -1, grp_level = -1;  // keyed self-join pairs; grouped sum
+    int64_t sj_weight = 0, grp_weight = 0, grp_cap = -1;
+    const int32_t* size = nullptr;     // [n] summed fact of the grouped constraint
     // per-replica committed state
     int32_t* vals = nullptr;        // [R][n]  (-1 = None)
     int64_t* score = nullptr;       // [R][4]
@@ -76,15 +80,28 @@ __device__ __forceinline__ int64_t scalar_conflicts(const ScalarModel& m, const 
 
 struct ScalarDelta {
     int64_t d_un;     // change of the number of unassigned entities
-    int64_t d_cross;  // change of the number of matched pairs
+    int64_t d_cross;  // change of the number of matched pairs (predicate join)
+    int64_t d_pairs;  // change of the number of same-value pairs (keyed self-join)
+    int64_t d_grp;    // change of the summed group weights
     bool doable;
 };
 
+// grouped/scorer.rs:89-101: an empty group scores zero
+__device__ __forceinline__ int64_t group_weight(const ScalarModel& m, int64_t sum, uint32_t count) {
+    if (count == 0) return 0;
+    if (m.grp_cap < 0) return (int64_t)((uint64_t)sum * (uint64_t)sum);
+    const int64_t over = wsub(sum, m.grp_cap);
+    return over > 0 ? over : 0;
+}
+
 // kind 0: Change(a -> value); kind 1: Swap(a, b)
+// `cnt` / `sum`: per-value entity count and summed size of the step snapshot (null when the model has
+// no value-keyed constraint)
 template <class VT>
 __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, const VT* vals, int kind, uint32_t a,
-                                                        uint32_t b, int32_t value) {
-    ScalarDelta r{0, 0, false};
+                                                        uint32_t b, int32_t value, const uint32_t* cnt = nullptr,
+                                                        const int64_t* sum = nullptr) {
+    ScalarDelta r{0, 0, 0, 0, false};
     if (kind == 0) {  // apply.rs:15-24,219-230
         if (a >= (uint32_t)m.n || value >= m.n_values || value < -1) return r;
         const int32_t old = (int32_t)vals[a];
@@ -94,6 +111,14 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
         r.d_un = (value < 0 ? 1 : 0) - (old < 0 ? 1 : 0);
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflicts(m, vals, a, value, 0xFFFFFFFFu) - scalar_conflicts(m, vals, a, old, 0xFFFFFFFFu);
+        if (m.sj_level >= 0) r.d_pairs = (value >= 0 ? (int64_t)cnt[value] : 0) - (old >= 0 ? (int64_t)cnt[old] - 1 : 0);
+        if (m.grp_level >= 0) {
+            const int64_t sz = (int64_t)m.size[a];
+            int64_t d = 0;
+            if (old >= 0) d = wsub(group_weight(m, wsub(sum[old], sz), cnt[old] - 1), group_weight(m, sum[old], cnt[old]));
+            if (value >= 0) d = wadd(d, wsub(group_weight(m, wadd(sum[value], sz), cnt[value] + 1), group_weight(m, sum[value], cnt[value])));
+            r.d_grp = d;
+        }
     } else {  // apply.rs:25-35,232-245
         if (a >= (uint32_t)m.n || b >= (uint32_t)m.n || a == b) return r;
         const int32_t va = (int32_t)vals[a], vb = (int32_t)vals[b];
@@ -102,8 +127,52 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflicts(m, vals, a, vb, b) - scalar_conflicts(m, vals, a, va, b) +
                         scalar_conflicts(m, vals, b, va, a) - scalar_conflicts(m, vals, b, vb, a);
+        // a swap exchanges two members: per-value counts (and so the same-value pairs) do not change
+        if (m.grp_level >= 0) {
+            const int64_t sa = (int64_t)m.size[a], sb = (int64_t)m.size[b];
+            int64_t d = 0;
+            if (va >= 0) d = wsub(group_weight(m, wadd(wsub(sum[va], sa), sb), cnt[va]), group_weight(m, sum[va], cnt[va]));
+            if (vb >= 0) d = wadd(d, wsub(group_weight(m, wadd(wsub(sum[vb], sb), sa), cnt[vb]), group_weight(m, sum[vb], cnt[vb])));
+            r.d_grp = d;
+        }
     }
     return r;
+}
+
+// committed update of the per-value tables (one lane)
+template <class VT>
+__device__ __forceinline__ void scalar_tables_apply(const ScalarModel& m, const VT* vals, int kind, uint32_t a, uint32_t b,
+                                                    int32_t value, uint32_t* cnt, int64_t* sum) {
+    if (kind == 0) {
+        const int32_t old = (int32_t)vals[a];
+        const int64_t sz = m.size ? (int64_t)m.size[a] : 0;
+        if (old >= 0) {
+            cnt[old] -= 1;
+            sum[old] = wsub(sum[old], sz);
+        }
+        if (value >= 0) {
+            cnt[value] += 1;
+            sum[value] = wadd(sum[value], sz);
+        }
+    } else {
+        const int32_t va = (int32_t)vals[a], vb = (int32_t)vals[b];
+        const int64_t sa = m.size ? (int64_t)m.size[a] : 0, sb = m.size ? (int64_t)m.size[b] : 0;
+        if (va >= 0) sum[va] = wadd(wsub(sum[va], sa), sb);
+        if (vb >= 0) sum[vb] = wadd(wsub(sum[vb], sb), sa);
+    }
+}
+
+// builds the per-value tables of `vals` with all threads of the block / wave (tables pre-zeroed)
+template <class VT>
+__device__ __forceinline__ void scalar_tables_accumulate(const ScalarModel& m, const VT* vals, uint32_t tid, uint32_t nthreads,
+                                                         uint32_t* cnt, int64_t* sum) {
+    for (uint32_t e = tid; e < (uint32_t)m.n; e += nthreads) {
+        const int32_t v = (int32_t)vals[e];
+        if (v >= 0) {
+            atomicAdd(&cnt[v], 1u);
+            atomicAdd((unsigned long long*)&sum[v], (unsigned long long)(int64_t)(m.size ? m.size[e] : 0));
+        }
+    }
 }
 
 template <int L>
@@ -115,6 +184,8 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
     for (int k = 0; k < L; ++k) {
         if (k == m.un_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.un_weight * (uint64_t)d.d_un));
         if (k == m.cross_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.cross_weight * (uint64_t)d.d_cross));
+        if (k == m.sj_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.sj_weight * (uint64_t)d.d_pairs));
+        if (k == m.grp_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.grp_weight * (uint64_t)d.d_grp));
     }
     return s;
 }
@@ -123,14 +194,37 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
 // accumulate != 0: add this class's constraint scores to what the list class already wrote (mixed models)
 __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
                                                              int accumulate) {
-    __shared__ unsigned long long s_un, s_cross;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];  // per-value tables (when used)
+    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp;
     const int r = blockIdx.x;
     const int32_t* vals = m.vals + (size_t)r * m.n;
+    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    int64_t* t_sum = (int64_t*)tab_mem;
+    uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
     if (threadIdx.x == 0) {
         s_un = 0;
         s_cross = 0;
+        s_pairs = 0;
+        s_grp = 0;
     }
+    if (tables)
+        for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
     __syncthreads();
+    if (tables) {
+        scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
+        __syncthreads();
+        unsigned long long pairs = 0, grp = 0;
+        for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+            const unsigned long long c = t_cnt[v];
+            pairs += c * (c - (c ? 1 : 0)) / 2;
+            grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
+        }
+        atomicAdd(&s_pairs, pairs);
+        atomicAdd(&s_grp, grp);
+    }
     unsigned long long un = 0, cross = 0;
     for (uint32_t e = threadIdx.x; e < (uint32_t)m.n; e += blockDim.x) {
         const int32_t v = vals[e];
@@ -160,6 +254,8 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         int64_t sc[SF_MAX_LEVELS_CONST] = {0, 0, 0, 0};
         if (m.un_level >= 0) sc[m.un_level] = wsub(sc[m.un_level], (int64_t)((uint64_t)m.un_weight * s_un));
         if (m.cross_level >= 0) sc[m.cross_level] = wsub(sc[m.cross_level], (int64_t)((uint64_t)m.cross_weight * s_cross));
+        if (m.sj_level >= 0) sc[m.sj_level] = wsub(sc[m.sj_level], (int64_t)((uint64_t)m.sj_weight * s_pairs));
+        if (m.grp_level >= 0) sc[m.grp_level] = wsub(sc[m.grp_level], (int64_t)((uint64_t)m.grp_weight * s_grp));
         for (int k = 0; k < m.levels; ++k) {
             if (out_scores) out_scores[(size_t)r * m.levels + k] = accumulate ? wadd(out_scores[(size_t)r * m.levels + k], sc[k]) : sc[k];
             if (commit) m.score[(size_t)r * 4 + k] = accumulate ? wadd(m.score[(size_t)r * 4 + k], sc[k]) : sc[k];
@@ -172,17 +268,30 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
 __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, int replica, const int32_t* moves,
                                                                int64_t n, int64_t* out_scores, int32_t* out_doable,
                                                                int skip_foreign) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
+    const int32_t* vals = m.vals + (size_t)replica * m.n;
+    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    int64_t* t_sum = (int64_t*)tab_mem;
+    uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
+    if (tables) {  // every block rebuilds the per-value tables of the snapshot
+        for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
+        __syncthreads();
+        scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
+        __syncthreads();
+    }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     if (skip_foreign && moves[t * 6] != 0 && moves[t * 6] != 1) return;  // a list move of a mixed model
-    const int32_t* vals = m.vals + (size_t)replica * m.n;
     const int64_t* cur = m.score + (size_t)replica * 4;
     const int32_t* mv = moves + t * 6;
-    ScalarDelta d{0, 0, false};
+    ScalarDelta d{0, 0, 0, 0, false};
     if (mv[0] == 0 && mv[1] >= 0)
-        d = eval_scalar_move(m, vals, 0, (uint32_t)mv[1], 0u, mv[5]);
+        d = eval_scalar_move(m, vals, 0, (uint32_t)mv[1], 0u, mv[5], t_cnt, t_sum);
     else if (mv[0] == 1 && mv[1] >= 0 && mv[3] >= 0)
-        d = eval_scalar_move(m, vals, 1, (uint32_t)mv[1], (uint32_t)mv[3], 0);
+        d = eval_scalar_move(m, vals, 1, (uint32_t)mv[1], (uint32_t)mv[3], 0, t_cnt, t_sum);
     out_doable[t] = d.doable ? 1 : 0;
     const ScoreV<4> s = apply_scalar_delta<4>(m, cur, d);
     for (int k = 0; k < m.levels; ++k) out_scores[t * m.levels + k] = d.doable ? s.v[k] : 0;
@@ -191,10 +300,22 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, in
 // committed Change / Swap on global state (sf_apply)
 __global__ __launch_bounds__(64) void k_scalar_apply(ScalarModel m, int replica, int kind, int a, int b, int value,
                                                      int32_t* out_ok) {
-    if (threadIdx.x != 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
     int32_t* vals = m.vals + (size_t)replica * m.n;
+    int64_t* t_sum = (int64_t*)tab_mem;
+    uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
+    if (m.sj_level >= 0 || m.grp_level >= 0) {
+        for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
+        __syncthreads();
+        scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     int64_t* cur = m.score + (size_t)replica * 4;
-    const ScalarDelta d = eval_scalar_move(m, vals, kind, (uint32_t)a, (uint32_t)b, value);
+    const ScalarDelta d = eval_scalar_move(m, vals, kind, (uint32_t)a, (uint32_t)b, value, t_cnt, t_sum);
     if (!d.doable) {
         *out_ok = 0;
         return;
@@ -234,11 +355,15 @@ constexpr uint32_t SRC = 128;  // ring capacity per leaf (entries of 2 x u32)
 
 template <class VT>
 struct SCarve {
-    size_t vals, ring, total;
-    __host__ __device__ explicit SCarve(int n) {
+    size_t vals, ring, tsum, tcnt, total;
+    __host__ __device__ SCarve(int n, int n_table) {  // n_table = n_values when a value-keyed constraint exists, else 0
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * SRC * 2, 16);
+        tsum = o;
+        o = align_up(o + sizeof(int64_t) * n_table, 16);
+        tcnt = o;
+        o = align_up(o + sizeof(uint32_t) * n_table, 16);
         vals = o;
         o = align_up(o + sizeof(VT) * n, 16);
         total = o;
@@ -254,10 +379,13 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     if (rr >= p.n_launch) return;  // no workgroup barrier below
     const int r = rr + p.replica_base;
     const uint32_t n = (uint32_t)m.n;
-    const SCarve<VT> cv(m.n);
+    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    const SCarve<VT> cv(m.n, tables ? m.n_values : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][SRC][2]
     VT* s_vals = (VT*)(mem + cv.vals);
+    int64_t* t_sum = (int64_t*)(mem + cv.tsum);  // per-value summed size / entity count of the working state
+    uint32_t* t_cnt = (uint32_t*)(mem + cv.tcnt);
     int32_t* g_vals = m.vals + (size_t)r * n;
     int64_t* g_score = m.score + (size_t)r * 4;
     const bool tracing = TRACE && r == p.trace_replica;
@@ -269,7 +397,16 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     const uint32_t vc = (uint32_t)m.n_values;  // ValueSource::CountableRange 0..n_values
 
     for (uint32_t t = lane; t < n; t += 64) s_vals[t] = (VT)g_vals[t];
+    if (tables)
+        for (uint32_t v = lane; v < (uint32_t)m.n_values; v += 64) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
     wave_sync();
+    if (tables) {
+        scalar_tables_accumulate(m, s_vals, lane, 64u, t_cnt, t_sum);
+        wave_sync();
+    }
     int64_t cur[L], best_sol[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) {
@@ -453,15 +590,15 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 }
                 const bool valid = lane < nvalid;
                 uint32_t m0 = 0, m1 = 0;
-                ScalarDelta dl{0, 0, false};
+                ScalarDelta dl{0, 0, 0, 0, false};
                 const bool lane_change = lf ? chg1 : chg0;
                 if (valid) {
                     const uint32_t qi = idx & (SRC - 1);
                     const uint32_t* rq = ring + ((size_t)lf * SRC + qi) * 2;
                     m0 = rq[0];
                     m1 = rq[1];
-                    dl = lane_change ? eval_scalar_move(m, s_vals, 0, m0, 0u, (int32_t)m1)
-                                     : eval_scalar_move(m, s_vals, 1, m0, m1, 0);
+                    dl = lane_change ? eval_scalar_move(m, s_vals, 0, m0, 0u, (int32_t)m1, t_cnt, t_sum)
+                                     : eval_scalar_move(m, s_vals, 1, m0, m1, 0, t_cnt, t_sum);
                 }
                 const ScoreV<L> sc = apply_scalar_delta<L>(m, cur, dl);
                 ScoreV<L> curv;
@@ -566,6 +703,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 p.trace_applied[6] = pick_change ? (int32_t)b : -1;
             }
             if (lane == 0) {
+                if (tables) scalar_tables_apply(m, s_vals, pick_change ? 0 : 1, a, b, (int32_t)b, t_cnt, t_sum);
                 if (pick_change)
                     s_vals[a] = (VT)(int32_t)b;
                 else {

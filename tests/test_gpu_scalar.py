@@ -176,3 +176,60 @@ def test_graph_10k_properties(oracle):
     assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
     assert (d.fresh_score() == sc).all()
     assert (sc <= 0).all() and (sc[:, 0] > -10000).all()
+
+
+def _balance(n=80, k=7, seed=11):
+    from solverforge_amd import datasets
+
+    r = datasets.stream(seed, 2 * n)
+    bins = (r[:n] % np.uint64(k + 1)).astype(np.int64) - 1
+    sizes = (r[n:] % np.uint64(9)).astype(np.int64) + 1
+    return bins, sizes, k
+
+
+@pytest.mark.parametrize("cap", [-1, 25])
+def test_keyed_selfjoin_and_grouped_sum(oracle, cap):
+    """Value-keyed aggregates: pairs sharing a bin (keyed self-join bi node) and group_by(bin,
+    sum(size)) with sum^2 / excess-over-cap weights (grouped node + sum collector): full scores, the
+    whole candidate stream with trial scores, committed moves, traced steps and a fused solve."""
+    import solverforge_amd as sfa
+
+    bins, sizes, k = _balance()
+    d = sfa.build_balance(bins, sizes, k, w_pair=3, cap=cap)
+    o = oracle.Model.balance(k, bins, sizes, w_pair=3, cap=cap)
+    bits = oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
+    o.configure(leaves=bits, random_seed=5, la_size=6, limit=40)
+    d.configure(sfa.SolverConfig(random_seed=5, late_acceptance_size=6, accepted_count_limit=40))
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.fresh_score()[:2]).all()
+    for order in (0, 3):
+        o.configure(leaves=bits, random_seed=5, la_size=6, limit=40, selection_order=order)
+        gm, gs, gd = d.open_cursor(2, 99, selection_order=order, cap=1 << 16)
+        om = o.enumerate(0, 2, 99, order)
+        assert (_t(gm) == _t(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+        es, ed = d.evaluate_moves(om)
+        assert (ed == od).all() and (es == os_[:, :2]).all()
+    o.configure(leaves=bits, random_seed=5, la_size=6, limit=40)
+    rng = np.random.default_rng(3)
+    for it in range(10):
+        om = o.enumerate(0, it, 7 + it, 3)
+        _, od = o.evaluate_moves(om)
+        mv = om[np.flatnonzero(od)[rng.integers(int(od.sum()))]]
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(15):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 16)
+        om, os_, of, oap, omv = o.step_traced()
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+    d.solve_steps(40)
+    o.steps(40)
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
