@@ -37,4 +37,4 @@ print(json.dumps({"workload": "graph colouring 10k/100k/16", "replicas": R, "gpu
                   "gpu_candidates_scored_per_s": scored / dt, "kernel_ms_per_launch": ms / n,
                   "alg_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12,
                   "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done, "replica0_matches_oracle": match,
-                  "gpu_over_cpu": (moves / dt) / (cm / ct), "score_replica0": d.calculate_score()[0].tolist()}))
+                  "gpu_over_cpu": (moves / dt) / (cm / ct), "score_replica0": d.calculate_score()[0].tolist(), "fill_calls_per_step": (a["sources_scanned"] - b["sources_scanned"]) / max(a["step_count"] - b["step_count"], 1), "moves_per_step": moves / max(a["step_count"] - b["step_count"], 1), "scored_per_step": scored / max(a["step_count"] - b["step_count"], 1)}))

@@ -67,6 +67,36 @@ SF_HD uint32_t mod_u64(uint64_t x, uint32_t n) {
     return r;
 }
 
+// Exact remainder by a divisor that stays fixed for many draws (entity count, value count):
+// Barrett reduction with M = floor((2^64 - 1) / n): q = hi64(x * M) is floor(x / n) or up to two
+// less, so x - q * n needs at most two conditional subtractions; only its low 32 bits are needed
+// (remainder < 3n).  One 64x64 high multiply instead of a software division.
+struct FastMod {
+    uint64_t M;
+    uint32_t n;
+};
+SF_HD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+SF_HD FastMod make_fastmod(uint32_t n) {
+    FastMod f;
+    f.n = n;
+    f.M = n ? ~0ULL / n : 0;
+    return f;
+}
+SF_HD uint32_t fastmod_u64(uint64_t x, const FastMod& f) {
+    if (f.n >= 0x40000000u) return (uint32_t)(x % f.n);  // keep 3n inside 32 bits
+    const uint64_t q = mulhi64(x, f.M);
+    uint32_t r = (uint32_t)x - (uint32_t)q * f.n;
+    if (r >= f.n) r -= f.n;
+    if (r >= f.n) r -= f.n;
+    return r;
+}
+
 struct StreamCtx {
     uint64_t step_index;
     uint64_t step_seed;
@@ -93,6 +123,13 @@ struct StreamCtx {
         uint32_t start = random_index(len, salt);
         uint32_t st = random_stride(len, salt ^ STRIDE_SALT_MIX);
         return mod_u64((uint64_t)start + (uint64_t)offset * st, len);
+    }
+    // selection_index for a length whose FastMod the caller keeps (same results, no division)
+    SF_HD uint32_t selection_index_fm(uint32_t offset, const FastMod& f, uint64_t salt) const {
+        if (order <= 2) return offset;
+        if (f.n <= 1) return 0;
+        if (order == 3) return fastmod_u64(mixed_seed(salt ^ ((uint64_t)offset * OFFSET_MIX)), f);
+        return selection_index(offset, f.n, salt);
     }
     // permutation parameters of selection_index_without_replacement (iter.rs:133-150)
     SF_HD void perm_params(uint32_t len, uint64_t salt, uint32_t& start, uint32_t& stride) const {

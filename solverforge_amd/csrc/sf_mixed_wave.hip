@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     const int nl = gl.n;
     const uint64_t identity = ((uint64_t)(uint32_t)sm.descriptor << 32) ^ (uint64_t)(uint32_t)sm.variable;
     const uint32_t vc = (uint32_t)sm.n_values;
+    const FastMod fm_n = make_fastmod(ns), fm_vc = make_fastmod(vc);  // fixed divisors of the scalar streams
     const uint64_t ldesc = (uint64_t)(uint32_t)gl.list_desc;
 
     uint32_t* g_visits = has_list ? lm.visits + (size_t)r * lm.n_cap : nullptr;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         if (valid) {
                             w0 = (uint32_t)(((uint64_t)sc_st + (uint64_t)my_row * sc_sd) % ns);
                             int32_t v = -1;
-                            if (my_in < vc) v = (int32_t)ctx.selection_index(my_in, vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)w0 ^ identity);
+                            if (my_in < vc) v = (int32_t)ctx.selection_index_fm(my_in, fm_vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)w0 ^ identity);
                             w1 = (uint32_t)v;
                         }
                         keep = valid;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         const uint32_t ro = g.b + lane;
                         if (ro < ns) {
                             const uint32_t right = ns <= 1 ? 0u
-                                                           : ctx.selection_index(ro, ns, (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)sm.variable) ^ OFFSET_MIX);
+                                                           : ctx.selection_index_fm(ro, fm_n, (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)sm.variable) ^ OFFSET_MIX);
                             if (left < right) {
                                 const int32_t lv = (int32_t)s_vals[left], rv = (int32_t)s_vals[right];
                                 keep = lv != rv && (lv >= 0 || sm.allows_unassigned) && (rv >= 0 || sm.allows_unassigned);

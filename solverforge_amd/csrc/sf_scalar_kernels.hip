@@ -53,29 +53,46 @@ struct ScalarModel {
     int64_t* best_score = nullptr;  // [R][4]
 };
 
-// matches of entity e holding `val` against every partner except `skip`
+// matches of entity e against every partner except `skip`, for two candidate values at once:
+// returns conflicts(e, v_new) - conflicts(e, v_old) in ONE pass over the partner list, sixteen
+// partner ids in flight per iteration (the list lives in HBM/L2, the values in LDS): an average
+// graph-colouring row (degree 20) costs two memory round trips instead of twenty.
 template <class VT>
-__device__ __forceinline__ int64_t scalar_conflicts(const ScalarModel& m, const VT* vals, uint32_t e, int32_t val,
-                                                    uint32_t skip) {
-    if (val < 0) return 0;
-    int64_t c = 0;
+__device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, const VT* vals, uint32_t e, int32_t v_new,
+                                                         int32_t v_old, uint32_t skip) {
+    int32_t c = 0;
     if (m.cross_kind == SC_PARTNERS_EQUAL) {
         const uint32_t p1 = m.pn_off[e + 1];
-        for (uint32_t p = m.pn_off[e]; p < p1; ++p) {
-            const uint32_t o = m.pn[p];
-            if (o != skip && (int32_t)vals[o] == val) ++c;
+        constexpr int W = 16;
+        for (uint32_t p = m.pn_off[e]; p < p1; p += W) {
+            uint32_t o[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) o[q] = p + q < p1 ? m.pn[p + q] : skip;
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                if (o[q] == skip || p + q >= p1) continue;
+                const int32_t vo = (int32_t)vals[o[q]];
+                c += (v_new >= 0 && vo == v_new) ? 1 : 0;
+                c -= (v_old >= 0 && vo == v_old) ? 1 : 0;
+            }
         }
     } else if (m.cross_kind == SC_QUEENS) {  // board.rs:30-44: distinct columns, same row or same diagonal
         const int32_t ce = m.col[e];
         for (uint32_t o = 0; o < (uint32_t)m.n; ++o) {
             const int32_t vo = (int32_t)vals[o], co = m.col[o];
             if (o == e || o == skip || vo < 0 || co == ce) continue;
-            const int32_t dr = vo > val ? vo - val : val - vo;
             const int32_t dc = co > ce ? co - ce : ce - co;
-            if (vo == val || dr == dc) ++c;
+            if (v_new >= 0) {
+                const int32_t dr = vo > v_new ? vo - v_new : v_new - vo;
+                c += (vo == v_new || dr == dc) ? 1 : 0;
+            }
+            if (v_old >= 0) {
+                const int32_t dr = vo > v_old ? vo - v_old : v_old - vo;
+                c -= (vo == v_old || dr == dc) ? 1 : 0;
+            }
         }
     }
-    return c;
+    return (int64_t)c;
 }
 
 struct ScalarDelta {
@@ -110,7 +127,7 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
         r.doable = true;
         r.d_un = (value < 0 ? 1 : 0) - (old < 0 ? 1 : 0);
         if (m.cross_level >= 0)
-            r.d_cross = scalar_conflicts(m, vals, a, value, 0xFFFFFFFFu) - scalar_conflicts(m, vals, a, old, 0xFFFFFFFFu);
+            r.d_cross = scalar_conflict_delta(m, vals, a, value, old, 0xFFFFFFFFu);
         if (m.sj_level >= 0) r.d_pairs = (value >= 0 ? (int64_t)cnt[value] : 0) - (old >= 0 ? (int64_t)cnt[old] - 1 : 0);
         if (m.grp_level >= 0) {
             const int64_t sz = (int64_t)m.size[a];
@@ -125,8 +142,7 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
         if (va == vb) return r;
         r.doable = true;
         if (m.cross_level >= 0)
-            r.d_cross = scalar_conflicts(m, vals, a, vb, b) - scalar_conflicts(m, vals, a, va, b) +
-                        scalar_conflicts(m, vals, b, va, a) - scalar_conflicts(m, vals, b, vb, a);
+            r.d_cross = scalar_conflict_delta(m, vals, a, vb, va, b) + scalar_conflict_delta(m, vals, b, va, vb, a);
         // a swap exchanges two members: per-value counts (and so the same-value pairs) do not change
         if (m.grp_level >= 0) {
             const int64_t sa = (int64_t)m.size[a], sb = (int64_t)m.size[b];
@@ -395,6 +411,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     const bool chg0 = p.leaf[0].kind == 1, chg1 = n_leaves > 1 && p.leaf[1].kind == 1;
     const uint64_t identity = ((uint64_t)(uint32_t)m.descriptor << 32) ^ (uint64_t)(uint32_t)m.variable;
     const uint32_t vc = (uint32_t)m.n_values;  // ValueSource::CountableRange 0..n_values
+    const FastMod fm_n = make_fastmod(n), fm_vc = make_fastmod(vc);  // fixed divisors of the two streams
 
     for (uint32_t t = lane; t < n; t += 64) s_vals[t] = (VT)g_vals[t];
     if (tables)
@@ -502,7 +519,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                         int32_t v = -1;
                         if (valid) {
                             e = (uint32_t)(((uint64_t)cst + (uint64_t)my_row * csd) % n);
-                            if (my_in < vc) v = (int32_t)ctx.selection_index(my_in, vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)e ^ identity);
+                            if (my_in < vc) v = (int32_t)ctx.selection_index_fm(my_in, fm_vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)e ^ identity);
                         }
                         const uint64_t vm = __ballot(valid);
                         const uint32_t cnt = (uint32_t)__popcll(vm);  // valid lanes are a prefix
@@ -523,32 +540,51 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                             if (cnt < 64) gen_done[l] = 1;
                         }
                     } else {
-                        // 64 consecutive right offsets of the current left row, filtered (swap.rs:125-160)
+                        // 4 x 64 consecutive right offsets of the current left row, filtered
+                        // (swap.rs:125-160).  The four chunks are independent draws (ILP hides the
+                        // splitmix / remainder / LDS latency); they are appended in stream order and a
+                        // chunk that would overfill the ring is left for the next call.
                         if (row[l] >= n) {
                             gen_done[l] = 1;
                             break;
                         }
                         const uint32_t left = n <= 1 ? 0u : (uint32_t)(((uint64_t)lst + (uint64_t)row[l] * lsd) % n);
-                        const uint32_t ro = inner[l] + lane;
-                        bool keep = false;
-                        uint32_t right = 0;
-                        if (ro < n) {
-                            right = n <= 1 ? 0u
-                                           : ctx.selection_index(ro, n, (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)m.variable) ^ OFFSET_MIX);
-                            if (left < right) {
-                                const int32_t lv = (int32_t)s_vals[left], rv = (int32_t)s_vals[right];
-                                const bool legal = (lv >= 0 || m.allows_unassigned) && (rv >= 0 || m.allows_unassigned);
-                                keep = lv != rv && legal;
+                        const int32_t lv = (int32_t)s_vals[left];
+                        const bool l_legal = lv >= 0 || m.allows_unassigned;
+                        const uint64_t rsalt = (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)m.variable) ^ OFFSET_MIX;
+                        bool keep[4];
+                        uint32_t right[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t ro = inner[l] + 64u * q + lane;
+                            keep[q] = false;
+                            right[q] = 0;
+                            if (ro < n) {
+                                right[q] = n <= 1 ? 0u : ctx.selection_index_fm(ro, fm_n, rsalt);
+                                if (left < right[q]) {
+                                    const int32_t rv = (int32_t)s_vals[right[q]];
+                                    keep[q] = lv != rv && l_legal && (rv >= 0 || m.allows_unassigned);
+                                }
                             }
                         }
-                        const uint64_t km = __ballot(keep);
-                        if (keep) {
-                            const uint32_t qi = (tail[l] + mbcnt64(km)) & (SRC - 1);
-                            rq[qi * 2] = left;
-                            rq[qi * 2 + 1] = right;
+                        uint32_t chunks_done = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint64_t km = __ballot(keep[q]);
+                            const uint32_t cq = (uint32_t)__popcll(km);
+                            const bool fits = chunks_done == (uint32_t)q && (q == 0 || tail[l] - head[l] + cq <= SRC) &&
+                                              inner[l] + 64u * q < n;
+                            if (fits) {
+                                if (keep[q]) {
+                                    const uint32_t qi = (tail[l] + mbcnt64(km)) & (SRC - 1);
+                                    rq[qi * 2] = left;
+                                    rq[qi * 2 + 1] = right[q];
+                                }
+                                tail[l] += cq;
+                                chunks_done = q + 1;
+                            }
                         }
-                        tail[l] += (uint32_t)__popcll(km);
-                        inner[l] += 64;
+                        inner[l] += 64u * chunks_done;
                         if (inner[l] >= n) {
                             inner[l] = 0;
                             row[l] += 1;
