@@ -101,7 +101,13 @@ def main():
 
     import __graft_entry__ as entry
 
-    entry.build()
+    # one builder per node: the other ranks wait, then only load the finished library
+    if dist is None or local_rank == 0:
+        entry.build()
+    if dist is not None:
+        dist.barrier()
+        if local_rank != 0:
+            entry.build()  # no-op when the library is current
     import solverforge_amd as sfa
     from solverforge_amd import datasets, portfolio
 

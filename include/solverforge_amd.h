@@ -62,7 +62,8 @@ typedef enum sf_move_kind {
     SF_MOVE_CHANGE = 0,      /* heuristic/move/change.rs:118-221 */
     SF_MOVE_SWAP = 1,        /* heuristic/move/swap.rs:150-215 */
     SF_MOVE_LIST_CHANGE = 2, /* heuristic/move/list_kernel/change.rs:16-153 */
-    SF_MOVE_LIST_SWAP = 3    /* heuristic/move/list_kernel/swap.rs:17-110 */
+    SF_MOVE_LIST_SWAP = 3,   /* heuristic/move/list_kernel/swap.rs:17-110 */
+    SF_MOVE_LIST_REVERSE = 4 /* heuristic/move/list_kernel/reverse.rs:15-57: reverse list `a` over [a_pos, b_pos) (b = a) */
 } sf_move_kind;
 
 /* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
@@ -104,7 +105,8 @@ typedef enum sf_selector_kind {
     SF_SEL_LIST_CHANGE = 4,        /* selector/list_kernel/change.rs:25-241 */
     SF_SEL_LIST_SWAP = 8,          /* selector/list_kernel/swap.rs:25-270 */
     SF_SEL_NEARBY_LIST_CHANGE = 16,/* selector/list_kernel/nearby_change.rs:17-233 */
-    SF_SEL_NEARBY_LIST_SWAP = 32   /* selector/list_kernel/nearby_swap.rs:17-260 */
+    SF_SEL_NEARBY_LIST_SWAP = 32,  /* selector/list_kernel/nearby_swap.rs:17-260 */
+    SF_SEL_LIST_REVERSE = 64       /* selector/list_kernel/reverse.rs:12-108 (intra-list 2-opt) */
 } sf_selector_kind;
 
 typedef enum sf_selection_order { /* solverforge_config::SelectionOrder */

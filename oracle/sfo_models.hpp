@@ -69,6 +69,7 @@ enum LeafBits : uint32_t {
     LEAF_LIST_SWAP = 8,
     LEAF_NEARBY_LIST_CHANGE = 16,
     LEAF_NEARBY_LIST_SWAP = 32,
+    LEAF_LIST_REVERSE = 64,
 };
 
 struct Model {
@@ -95,6 +96,8 @@ struct Model {
                 return std::make_unique<NearbyListChangeCursor>(list_slot, d.working, ctx, max_nearby);
             case LEAF_NEARBY_LIST_SWAP:
                 return std::make_unique<NearbyListSwapCursor>(list_slot, d.working, ctx, max_nearby);
+            case LEAF_LIST_REVERSE:
+                return std::make_unique<ListReverseCursor>(list_slot, d.working, ctx);
         }
         return nullptr;
     }
@@ -104,7 +107,8 @@ struct Model {
     //  policy/scalar.rs:67-106).
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
         static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
-                                         LEAF_LIST_SWAP,          LEAF_SCALAR_CHANGE, LEAF_SCALAR_SWAP};
+                                         LEAF_LIST_SWAP,          LEAF_LIST_REVERSE, LEAF_SCALAR_CHANGE,
+                                         LEAF_SCALAR_SWAP};
         std::vector<std::unique_ptr<Cursor>> children;
         for (uint32_t leaf : order)
             if (leaves & leaf) children.push_back(open_leaf(leaf, d, ctx));

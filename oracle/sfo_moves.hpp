@@ -16,6 +16,7 @@
 //   heuristic/selector/decorator/vec_union.rs:190-365 (UnionScheduler)
 // (all paths under crates/solverforge-solver/src/)
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <functional>
 #include <limits>
@@ -27,12 +28,13 @@
 namespace sfo {
 
 struct Move {
-    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3 } kind = Change;
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4 } kind = Change;
     size_t descriptor = 0;
     size_t variable = 0;
     // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
     // ListChange: (a, a_pos) -> (b, b_pos) [pre-removal destination coords].
     // ListSwap: (a, a_pos) <-> (b, b_pos).
+    // ListReverse: reverse list a over [a_pos, b_pos) (b = a).
     size_t a = 0, a_pos = 0, b = 0, b_pos = 0;
     int64_t to_value = NONE;
     bool allows_unassigned = false;
@@ -72,6 +74,8 @@ inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
             if (m.a == m.b && m.a_pos == m.b_pos) return false;
             return c.lists[m.a][m.a_pos] != c.lists[m.b][m.b_pos];
         }
+        case Move::ListReverse:  // move/list_kernel/reverse.rs:22-36
+            return m.a < c.lists.size() && m.b_pos > m.a_pos + 1 && m.b_pos <= c.lists[m.a].size();
     }
     return false;
 }
@@ -122,6 +126,12 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
             if (!intra) d.after_variable_changed(m.descriptor, m.b);
             break;
         }
+        case Move::ListReverse: {  // move/list_kernel/reverse.rs:38-57
+            d.before_variable_changed(m.descriptor, m.a);
+            std::reverse(c.lists[m.a].begin() + (ptrdiff_t)m.a_pos, c.lists[m.a].begin() + (ptrdiff_t)m.b_pos);
+            d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
     }
     return u;
 }
@@ -156,7 +166,8 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             if (!intra) d.after_variable_changed(m.descriptor, m.a);
             break;
         }
-        case Move::ListSwap: {  // swap is its own inverse
+        case Move::ListSwap:       // swap is its own inverse
+        case Move::ListReverse: {  // so is a reversal
             MoveUndo ignored = move_do(d, m);
             (void)ignored;
             break;
@@ -508,6 +519,50 @@ struct ListSwapCursor : Cursor {
                 }
                 advance_entity();
             }
+        }
+    }
+};
+
+// Intra-list reversal / 2-opt (selector/list_kernel/reverse.rs:12-108): per entity with len >= 2,
+// start = ordered_index(start_offset, len), end = start + 2 + ordered_index(end_offset, len - start - 1),
+// i.e. every range [start, end) of at least two elements.
+struct ListReverseCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x11572A0700000001ULL;
+    static constexpr uint64_t SALT_START = 0x11572A0700000002ULL;
+    static constexpr uint64_t SALT_END = 0x11572A0700000003ULL;
+    size_t desc;
+    MoveStreamContext ctx;
+    std::vector<size_t> entities, route_lens;
+    size_t entity_idx = 0, start_offset = 0, end_offset = 0;
+
+    ListReverseCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c)
+        : desc(slot.descriptor_index), ctx(c) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (entity_idx >= entities.size()) return false;
+            size_t entity = entities[entity_idx];
+            size_t len = route_lens[entity_idx];
+            if (len < 2) {
+                ++entity_idx;
+                start_offset = end_offset = 0;
+                continue;
+            }
+            while (start_offset < len) {
+                size_t start = ctx.selection_index(start_offset, len, SALT_START ^ (uint64_t)entity ^ (uint64_t)desc);
+                size_t end_count = len > start + 1 ? len - (start + 1) : 0;
+                if (end_offset < end_count) {
+                    size_t end = start + 2 + ctx.selection_index(end_offset, end_count, SALT_END ^ (uint64_t)entity ^ (uint64_t)start);
+                    ++end_offset;
+                    out = make_list_move(Move::ListReverse, desc, entity, start, entity, end);
+                    return true;
+                }
+                ++start_offset;
+                end_offset = 0;
+            }
+            ++entity_idx;
+            start_offset = end_offset = 0;
         }
     }
 };

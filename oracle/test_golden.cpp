@@ -382,7 +382,52 @@ static void director_case() {
     CHECK("director.incremental_equals_full", ok && d.cached == full(d.working));
 }
 
+// heuristic/move/tests/list_reverse.rs:63-171: do / undo of a reversal, doability bounds
+static void list_reverse_cases() {
+    auto mk = [](std::vector<uint32_t> cities) {
+        ScoreDirector d;
+        d.working.classes.resize(1);
+        d.working.classes[0].n = 1;
+        d.working.classes[0].lists = {cities};
+        return d;
+    };
+    auto rev = [](size_t start, size_t end) {
+        Move m;
+        m.kind = Move::ListReverse;
+        m.a = m.b = 0;
+        m.a_pos = start;
+        m.b_pos = end;
+        return m;
+    };
+    {
+        ScoreDirector d = mk({1, 2, 3, 4, 5});
+        Move m = rev(1, 4);
+        bool ok = move_is_doable(d, m);
+        MoveUndo u = move_do(d, m);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 4, 3, 2, 5});
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4, 5});
+        CHECK("list_reverse.reverse_segment", ok);
+    }
+    {
+        ScoreDirector d = mk({1, 2, 3, 4});
+        Move m = rev(0, 4);
+        bool ok = move_is_doable(d, m);
+        MoveUndo u = move_do(d, m);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({4, 3, 2, 1});
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4});
+        CHECK("list_reverse.reverse_entire_list", ok);
+    }
+    {
+        ScoreDirector d = mk({1, 2, 3});
+        CHECK("list_reverse.single_element_not_doable", !move_is_doable(d, rev(1, 2)));
+        CHECK("list_reverse.out_of_bounds_not_doable", !move_is_doable(d, rev(1, 10)));
+    }
+}
+
 int main() {
+    list_reverse_cases();
     bi_incr_cases();
     cross_bi_cases();
     exists_cases();

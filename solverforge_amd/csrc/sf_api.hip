@@ -649,7 +649,7 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
     int rc = alloc_search(ctx);
     if (rc) return rc;
-    const bool list_move = mv->kind == SF_MOVE_LIST_CHANGE || mv->kind == SF_MOVE_LIST_SWAP;
+    const bool list_move = mv->kind == SF_MOVE_LIST_CHANGE || mv->kind == SF_MOVE_LIST_SWAP || mv->kind == SF_MOVE_LIST_REVERSE;
     if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
     if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");
     if (list_move) {
@@ -751,7 +751,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
 }
 static bool has_plain_list_leaves(sf_ctx* ctx) {
     for (auto& s : ctx->selectors)
-        if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP)) return true;
+        if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP || s.kind == SF_SEL_LIST_REVERSE)) return true;
     return false;
 }
 static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
@@ -759,13 +759,13 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     gl.list_desc = ctx->has_list_model ? ctx->list_desc : 0;
     // default-policy declaration order: list rules first, then scalar change, scalar swap
     // (runtime/compiler/default_local_search/policy.rs:104-108)
-    for (int kind : {SF_SEL_LIST_CHANGE, SF_SEL_LIST_SWAP, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+    for (int kind : {SF_SEL_LIST_CHANGE, SF_SEL_LIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
         for (auto& s : ctx->selectors) {
-            const bool is_list = kind == SF_SEL_LIST_CHANGE || kind == SF_SEL_LIST_SWAP;
+            const bool is_list = kind == SF_SEL_LIST_CHANGE || kind == SF_SEL_LIST_SWAP || kind == SF_SEL_LIST_REVERSE;
             if (s.kind != kind) continue;
             if (is_list ? (!ctx->has_list_model || s.desc != ctx->list_desc) : (!ctx->has_scalar_model || s.desc != ctx->scalar_desc))
                 continue;
-            if (gl.n >= GL) return fail(ctx, SF_ERR_UNSUPPORTED, "more than four leaves");
+            if (gl.n >= GL) return fail(ctx, SF_ERR_UNSUPPORTED, "too many leaves for the generic engine");
             gl.kind[gl.n++] = kind;
         }
     for (auto& s : ctx->selectors)

@@ -310,6 +310,33 @@ __device__ __forceinline__ ListDelta eval_list_move_legs(const ListModel& m, con
     return r;
 }
 
+// ListReverseMove: reverse list `a` over [start, end) (move/list_kernel/reverse.rs:22-57).  The
+// matrix may be asymmetric, so every leg inside the range changes direction.
+template <class VT>
+__device__ __forceinline__ ListDelta eval_list_reverse(const ListModel& m, const VT* visits, const uint32_t* off,
+                                                       uint32_t a, uint32_t start, uint32_t end) {
+    ListDelta r{0, 0, false};
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    if (!(end > start + 1 && end <= la)) return r;
+    r.doable = true;
+    if (m.dist_level >= 0) {
+        const uint32_t depot = (uint32_t)m.depot;
+        const uint32_t prev = start > 0 ? (uint32_t)visits[oa + start - 1] : depot;
+        const uint32_t next = end < la ? (uint32_t)visits[oa + end] : depot;
+        const uint32_t first = visits[oa + start], last = visits[oa + end - 1];
+        int64_t acc = wsub(wadd(dist_cost(m.mat, m.dim, prev, last), dist_cost(m.mat, m.dim, first, next)),
+                           wadd(dist_cost(m.mat, m.dim, prev, first), dist_cost(m.mat, m.dim, last, next)));
+        uint32_t u = first;
+        for (uint32_t t = start + 1; t < end; ++t) {
+            const uint32_t w = visits[oa + t];
+            acc = wadd(acc, wsub(dist_cost(m.mat, m.dim, w, u), dist_cost(m.mat, m.dim, u, w)));
+            u = w;
+        }
+        r.d_dist = acc;
+    }
+    return r;
+}
+
 template <int L>
 __device__ __forceinline__ ScoreV<L> apply_delta(const ListModel& m, const int64_t* cur, const ListDelta& d) {
     ScoreV<L> s;
@@ -404,7 +431,7 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
                                                              int32_t* out_doable, int skip_foreign) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    if (skip_foreign && moves[t * 6] != 2 && moves[t * 6] != 3) return;  // a scalar move of a mixed model
+    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 4)) return;  // a scalar move of a mixed model
     const uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
     const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
     const int64_t* load = m.load + (size_t)replica * m.V;
@@ -418,6 +445,8 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
             d = eval_list_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);
         else if (kind == 3)
             d = eval_list_swap(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);
+        else if (kind == 4 && mv[1] == mv[3])
+            d = eval_list_reverse(m, visits, off, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[4]);
     }
     out_doable[t] = d.doable ? 1 : 0;
     ScoreV<4> s = apply_delta<4>(m, cur, d);
@@ -479,6 +508,13 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
                 load[b] = wadd(load[b], dx);
             }
         }
+    } else if (kind == 4) {  // reverse [i, j) of list a: thread t exchanges the t-th pair from the ends
+        const uint32_t lo = off[a] + i, hi = off[a] + j;  // hi exclusive
+        for (uint32_t t = threadIdx.x; t < (hi - lo) / 2; t += blockDim.x) {
+            const uint32_t x = visits[lo + t], y = visits[hi - 1 - t];
+            visits[lo + t] = y;
+            visits[hi - 1 - t] = x;
+        }
     } else if (kind == 3) {
         if (threadIdx.x == 0) {
             uint32_t pa = off[a] + i, pb = off[b] + j;
@@ -503,8 +539,9 @@ __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, in
     int64_t* cur = m.score + (size_t)replica * 4;
     __shared__ ListDelta s_d;
     if (threadIdx.x == 0) {
-        s_d = kind == 2 ? eval_list_change(m, visits, off, load, a, i, b, j)
-                        : eval_list_swap(m, visits, off, load, a, i, b, j);
+        s_d = kind == 2   ? eval_list_change(m, visits, off, load, a, i, b, j)
+              : kind == 3 ? eval_list_swap(m, visits, off, load, a, i, b, j)
+                          : eval_list_reverse(m, visits, off, a, i, j);
     }
     __syncthreads();
     ListDelta d = s_d;

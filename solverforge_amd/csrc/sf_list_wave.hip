@@ -211,6 +211,13 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
                 load[b] = wadd(load[b], dx);
             }
         }
+    } else if (kind == 4) {  // reverse [i, j) of list a
+        const uint32_t lo = off[a] + i, hi = off[a] + j;
+        for (uint32_t t = lane; t < (hi - lo) / 2; t += 64) {
+            const uint16_t x = visits[lo + t], y = visits[hi - 1 - t];
+            visits[lo + t] = y;
+            visits[hi - 1 - t] = x;
+        }
     } else if (kind == 3) {
         if (lane == 0) {
             const uint32_t pa = off[a] + i, pb = off[b] + j;

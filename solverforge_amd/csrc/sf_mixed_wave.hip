@@ -26,7 +26,7 @@
 
 namespace sf {
 
-constexpr int GL = 4;          // max leaves of the generic union
+constexpr int GL = 6;          // max leaves of the generic union
 constexpr uint32_t GRC = 128;  // ring capacity per leaf
 
 constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
@@ -34,10 +34,12 @@ constexpr uint64_t SALT_LC_INTRA = 0x1157C4A46E000003ULL, SALT_LC_INTER = 0x1157
 constexpr uint64_t SALT_LS_ENTITY = 0x11575A0900000001ULL, SALT_LS_FIRST = 0x11575A0900000002ULL;
 constexpr uint64_t SALT_LS_SECOND = 0x11575A0900000003ULL, SALT_LS_IFIRST = 0x11575A0900000004ULL;
 constexpr uint64_t SALT_LS_ISECOND = 0x11575A0900000005ULL;
+constexpr uint64_t SALT_LR_ENTITY = 0x11572A0700000001ULL, SALT_LR_START = 0x11572A0700000002ULL;  // reverse.rs:12-14
+constexpr uint64_t SALT_LR_END = 0x11572A0700000003ULL;
 
 struct GLeaves {
     int32_t n;
-    int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap
+    int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap, 64 list reverse
     int32_t list_desc;  // descriptor_index of the list class (stream salts)
 };
 
@@ -66,6 +68,7 @@ struct GCarve {
 //  list change:   a = source entity rank, b = source position offset, c = stage (0 intra, 1 inter),
 //                 d = destination entity rank (inter), e = destination position offset
 //  list swap:     a = entity rank, c = stage, b = first offset, e = second offset, d = destination rank
+//  list reverse:  a = entity rank, b = start offset, e = end offset
 struct GGen {
     uint32_t a, b, c, d, e;
     int done;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         int best_leaf = 0;
 
         // entity permutations (selection_index_without_replacement) of the four streams
-        uint32_t sc_st = 0, sc_sd = 1, ss_st = 0, ss_sd = 1, lc_st = 0, lc_sd = 1, ls_st = 0, ls_sd = 1;
+        uint32_t sc_st = 0, sc_sd = 1, ss_st = 0, ss_sd = 1, lc_st = 0, lc_sd = 1, ls_st = 0, ls_sd = 1, lr_st = 0, lr_sd = 1;
         if (has_scalar) {
             ctx.perm_params(ns, SALT_SCALAR_CHANGE_ENTITY ^ identity, sc_st, sc_sd);
             ctx.perm_params(ns, (SALT_SCALAR_SWAP_LEFT ^ identity) ^ OFFSET_MIX, ss_st, ss_sd);
@@ -168,9 +171,12 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         if (has_list) {
             ctx.perm_params((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd);
             ctx.perm_params((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd);
+            ctx.perm_params((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd);
         }
         sc_st = uni(sc_st), sc_sd = uni(sc_sd), ss_st = uni(ss_st), ss_sd = uni(ss_sd);
         lc_st = uni(lc_st), lc_sd = uni(lc_sd), ls_st = uni(ls_st), ls_sd = uni(ls_sd);
+        lr_st = uni(lr_st), lr_sd = uni(lr_sd);
+        auto lr_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lr_st + (uint64_t)rank * lr_sd) % (uint32_t)V); };
         auto lc_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lc_st + (uint64_t)rank * lc_sd) % (uint32_t)V); };
         auto ls_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)ls_st + (uint64_t)rank * ls_sd) % (uint32_t)V); };
         auto rlen = [&](uint32_t e) { return uni(s_off[e + 1] - s_off[e]); };
@@ -187,7 +193,9 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         // union scheduler (vec_union.rs:190-365): StratifiedRandom with equal weights when > 1 leaf
         const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
         const uint32_t u_str = nl > 1 ? ctx.random_stride((uint32_t)nl, SALT_UNION_STRIDE) : 1u;
-        int64_t wcur[GL] = {0, 0, 0, 0};
+        int64_t wcur[GL];
+#pragma unroll
+        for (int l = 0; l < GL; ++l) wcur[l] = 0;
         int64_t live_weight = nl;
 
         int done = 0;
@@ -325,6 +333,35 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                 g.e = 0;
                             }
                         }
+                    } else if (kind == 64) {  // ---- list reverse / 2-opt (list_kernel/reverse.rs:68-108) ----
+                        uint32_t ent = 0, len = 0;
+                        for (;;) {  // entities shorter than two elements are skipped
+                            if (g.a >= (uint32_t)V) break;
+                            ent = lr_ent(g.a);
+                            len = rlen(ent);
+                            if (len >= 2 && g.b < len) break;
+                            g.a += 1;
+                            g.b = 0;
+                            g.e = 0;
+                        }
+                        if (g.a >= (uint32_t)V) {
+                            g.done = 1;
+                            break;
+                        }
+                        const uint32_t start = ctx.selection_index(g.b, len, SALT_LR_START ^ (uint64_t)ent ^ ldesc);
+                        const uint32_t end_count = len > start + 1 ? len - (start + 1) : 0u;
+                        const uint32_t o = g.e + lane;
+                        if (o < end_count) {
+                            const uint32_t end = start + 2 + ctx.selection_index(o, end_count, SALT_LR_END ^ (uint64_t)ent ^ (uint64_t)start);
+                            keep = true;
+                            w0 = (ent << 16) | start;
+                            w1 = (ent << 16) | end;
+                        }
+                        g.e += 64;
+                        if (g.e >= end_count) {
+                            g.b += 1;
+                            g.e = 0;
+                        }
                     } else {  // ---- list swap (list_kernel/swap.rs) ----
                         uint32_t fe = 0, flen = 0;
                         for (;;) {  // entities with an empty list are skipped
@@ -420,7 +457,9 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
 
             // ---- C2: lay the next 64 pulls of the union scheduler onto the lanes ----
             uint32_t my_leaf = 0, my_idx = 0;
-            uint32_t taken[GL] = {0, 0, 0, 0};
+            uint32_t taken[GL];
+#pragma unroll
+            for (int l = 0; l < GL; ++l) taken[l] = 0;
             uint32_t nvalid = 0;
             bool need_more = false;
             {
@@ -519,8 +558,10 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
                     } else {
-                        const ListDelta d = eval_list_move_legs<uint16_t, false>(lm, s_visits, s_off, s_load, my_kind == 4,
-                                                                                 m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
+                        const ListDelta d = my_kind == 64
+                                                ? eval_list_reverse(lm, s_visits, s_off, m0 >> 16, m0 & 0xFFFFu, m1 & 0xFFFFu)
+                                                : eval_list_move_legs<uint16_t, false>(lm, s_visits, s_off, s_load, my_kind == 4,
+                                                                                      m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
                         doable = d.doable;
                         sc = apply_delta<L>(lm, cur, d);
                     }
@@ -601,7 +642,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
                         } else {
-                            tm[0] = my_kind == 4 ? 2 : 3;
+                            tm[0] = my_kind == 4 ? 2 : (my_kind == 8 ? 3 : 4);
                             tm[1] = (int32_t)(m0 >> 16);
                             tm[2] = (int32_t)(m0 & 0xFFFFu);
                             tm[3] = (int32_t)(m1 >> 16);
@@ -651,14 +692,15 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             } else {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
-                    p.trace_applied[1] = kind == 4 ? 2 : 3;
+                    p.trace_applied[1] = kind == 4 ? 2 : (kind == 8 ? 3 : 4);
                     p.trace_applied[2] = (int32_t)(a >> 16);
                     p.trace_applied[3] = (int32_t)(a & 0xFFFFu);
                     p.trace_applied[4] = (int32_t)(b >> 16);
                     p.trace_applied[5] = (int32_t)(b & 0xFFFFu);
                     p.trace_applied[6] = -1;
                 }
-                apply_list_move_wave(lm, s_visits, s_off, s_load, kind == 4 ? 2 : 3, a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu);
+                apply_list_move_wave(lm, s_visits, s_off, s_load, kind == 4 ? 2 : (kind == 8 ? 3 : 4), a >> 16, a & 0xFFFFu, b >> 16,
+                                     b & 0xFFFFu);
             }
 #pragma unroll
             for (int kk = 0; kk < L; ++kk) cur[kk] = best.v[kk];

@@ -16,7 +16,7 @@ from ._lib import MOVE_DTYPE, SolverConfigStruct, SolverForgeError, StatsStruct,
 
 
 class MoveKind:
-    CHANGE, SWAP, LIST_CHANGE, LIST_SWAP = 0, 1, 2, 3
+    CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE = 0, 1, 2, 3, 4
 
 
 class SelectionOrder:  # solverforge_config::SelectionOrder
@@ -43,7 +43,7 @@ class ConstraintKind:
 
 class SelectorKind:
     SCALAR_CHANGE, SCALAR_SWAP, LIST_CHANGE, LIST_SWAP = 1, 2, 4, 8
-    NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP = 16, 32
+    NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE = 16, 32, 64
 
 
 @dataclass

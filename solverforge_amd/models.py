@@ -34,6 +34,8 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
         d.add_selector(SelectorKind.LIST_CHANGE, 0)
     if "list_swap" in leaves:
         d.add_selector(SelectorKind.LIST_SWAP, 0)
+    if "list_reverse" in leaves:
+        d.add_selector(SelectorKind.LIST_REVERSE, 0)
     return d
 
 

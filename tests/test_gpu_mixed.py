@@ -189,3 +189,66 @@ def test_cvrp_plain_list_leaves(oracle, leaves):
     assert d.working_lists(0, 0) == o.get_lists(0)
     assert (d.calculate_score()[0] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("leaves", [("list_reverse",), ("list_change", "list_swap", "list_reverse")])
+def test_cvrp_list_reverse_leaf(oracle, leaves):
+    """Intra-list reversal (2-opt) stream on an ASYMMETRIC matrix with unreachable legs: every leg
+    inside the reversed range changes direction; alone and in a 3-leaf union with list change/swap."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(30, 4, 40, seed=8)
+    r = datasets.stream(123, p["matrix"].size).reshape(p["matrix"].shape)
+    p["matrix"] = (p["matrix"] + (r % np.uint64(17)).astype(np.int64)).astype(np.int64)  # asymmetric
+    np.fill_diagonal(p["matrix"], 0)
+    p["matrix"][4, 9] = np.iinfo(np.int64).max
+    p["matrix"][11, 2] = -3
+    p["routes"][3] = p["routes"][3][:1]  # a one-element route (no reversal there)
+    seen = set()
+    p["routes"][0] = p["routes"][0] + [c for c in range(1, 31)]
+    p["routes"] = [[c for c in rt if not (c in seen or seen.add(c))] for rt in p["routes"]]
+    d = sfa.build_cvrp(p, leaves=leaves)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    bits = 0
+    for name, bit in [("list_change", oracle.LEAF_LIST_CHANGE), ("list_swap", oracle.LEAF_LIST_SWAP),
+                      ("list_reverse", oracle.LEAF_LIST_REVERSE)]:
+        if name in leaves:
+            bits |= bit
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    for order in (0, 3, 4):
+        o.configure(leaves=bits, selection_order=order, random_seed=3)
+        gm, gs, gd = d.open_cursor(4, 1234, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 4, 1234, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm)[:, :5] == _t(om)[:, :5]).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+        es, ed = d.evaluate_moves(om)
+        assert (ed == od).all() and (es == os_[:, :2]).all()
+    o.configure(leaves=bits, random_seed=3, la_size=5, limit=30)
+    d.configure(sfa.SolverConfig(random_seed=3, late_acceptance_size=5, accepted_count_limit=30))
+    rng = np.random.default_rng(5)
+    rev = o.enumerate(oracle.LEAF_LIST_REVERSE, 0, 9, 3)
+    for it in range(6):  # committed reversals through sf_apply
+        mv = rev[rng.integers(len(rev))]
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert d.working_lists(0, 0) == o.get_lists(0)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(12):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert (_t(gm)[:, :5] == _t(om)[:, :5]).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv)[:5] == tuple(omv)[:5], step
+        assert d.working_lists(0, 0) == o.get_lists(0), step
+    d.solve_steps(30)
+    o.steps(30)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
