@@ -736,7 +736,7 @@ int32_t sf_phase_start(sf_ctx* ctx) {
 template <int L, bool TRACE, class VT>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
-    GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0);
+    GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0);
     if (cv.total > 160 * 1024) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     int wpb = (int)((160 * 1024) / cv.total);
     if (wpb > 4) wpb = 4;
@@ -745,7 +745,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     SearchParams q = p;
     q.n_launch = n_replicas;
     hipLaunchKernelGGL(kern, dim3((n_replicas + wpb - 1) / wpb), dim3(64 * wpb), cv.total * wpb, ctx->stream, ctx->lm,
-                       ctx->sm, gl, q, ctx->has_list_model ? 1 : 0, ctx->has_scalar_model ? 1 : 0);
+                       ctx->sm, gl, q, ctx->has_list_model ? 1 : 0, ctx->has_scalar_model ? 1 : 0, ctx->nbr);
     HIPCHK(ctx, hipGetLastError());
     return SF_OK;
 }
@@ -759,18 +759,22 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     gl.list_desc = ctx->has_list_model ? ctx->list_desc : 0;
     // default-policy declaration order: list rules first, then scalar change, scalar swap
     // (runtime/compiler/default_local_search/policy.rs:104-108)
-    for (int kind : {SF_SEL_LIST_CHANGE, SF_SEL_LIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+    for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_LIST_REVERSE,
+                     SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
         for (auto& s : ctx->selectors) {
-            const bool is_list = kind == SF_SEL_LIST_CHANGE || kind == SF_SEL_LIST_SWAP || kind == SF_SEL_LIST_REVERSE;
+            const bool is_list = kind != SF_SEL_SCALAR_CHANGE && kind != SF_SEL_SCALAR_SWAP;
             if (s.kind != kind) continue;
             if (is_list ? (!ctx->has_list_model || s.desc != ctx->list_desc) : (!ctx->has_scalar_model || s.desc != ctx->scalar_desc))
                 continue;
             if (gl.n >= GL) return fail(ctx, SF_ERR_UNSUPPORTED, "too many leaves for the generic engine");
+            if (kind == SF_SEL_NEARBY_LIST_CHANGE || kind == SF_SEL_NEARBY_LIST_SWAP) {
+                if (!wave_engine_possible(ctx)) return fail(ctx, SF_ERR_UNSUPPORTED, "nearby leaves need the neighbour index (matrix meter, <= 16384 nodes)");
+                if (gl.has_nearby >= 2) return fail(ctx, SF_ERR_UNSUPPORTED, "at most two nearby leaves per union");
+                gl.has_nearby += 1;
+                gl.max_nearby[gl.n] = s.max_nearby;
+            }
             gl.kind[gl.n++] = kind;
         }
-    for (auto& s : ctx->selectors)
-        if (s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP)
-            return fail(ctx, SF_ERR_UNSUPPORTED, "nearby leaves cannot be unioned with plain / scalar leaves yet");
     if (gl.n == 0) return fail(ctx, SF_ERR_INVALID, "no selector configured");
     if (ctx->has_scalar_model && (ctx->sm.sj_level >= 0 || ctx->sm.grp_level >= 0))
         return fail(ctx, SF_ERR_UNSUPPORTED, "value-keyed constraints (self-join / grouped sum) run in the scalar engine only");
@@ -796,6 +800,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
 extern "C" {
 
 static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
+    // the 2-leaf nearby union has its own engines; every other union runs in the generic N-leaf engine
     if ((ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)))
         return launch_mixed(ctx, p, grid, trace);
     if (ctx->has_list_model) {

@@ -234,6 +234,102 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
     wave_sync();
 }
 
+// One nearby source into a leaf ring (free-function form of the wave engine's generation loop, used
+// by the generic N-leaf engine): walks the presorted neighbour row of element `sx` from offset
+// `base`, `key` = the 64 row entries at base; appends at ring position tl + emitted; returns the
+// number of candidates appended so far.
+__device__ __forceinline__ uint32_t nearby_source_to_ring(const ListModel& m, const NbrIndex& nb, bool is_change, uint32_t se,
+                                                          uint32_t sp, uint32_t len, uint32_t k, uint32_t sx,
+                                                          const uint32_t* node_slot, const uint32_t* s_off, const uint16_t* sb,
+                                                          const uint16_t* ro, uint32_t* rq, uint32_t RCM, uint32_t tl,
+                                                          uint32_t key, uint32_t base, uint32_t need, uint32_t emitted) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t lanebit = 1ULL << lane;
+    const uint32_t dim = (uint32_t)m.dim;
+    const uint16_t* rowk = nb.keys + (size_t)sx * dim;
+    const uint32_t mv0 = (se << 16) | sp;
+    for (;;) {
+        const bool have = key != NBR_END;
+        const uint64_t havemask = __ballot(have);
+        if (havemask == 0) break;  // finite entries of the row exhausted
+        NearbyItem it{0u, 0u, 0u, 0u};
+        if (have) it = nearby_item(is_change, node_slot[key & NBR_NODE_MASK], se, sp, len, k, s_off, sb, ro);
+        // equal-distance groups are contiguous lane ranges; the index marks entries that
+        // continue the previous entry's distance
+        const uint64_t startmask = __ballot(have && (lane == 0 || !(key & NBR_SAME_FLAG)));
+        const bool more = havemask == ~0ULL && base + 64 < dim;
+        const uint32_t fo = 63u - (uint32_t)__clzll((unsigned long long)startmask);  // first lane of the last group
+        if (more && fo == 0) {
+            // one distance group wider than a chunk (degenerate ties): exact serial
+            // insertion top-k over the rest of the row.
+            TopK tk{~0ULL, 0u, ~0ULL};
+            for (uint32_t b2 = base; b2 < dim; b2 += 64) {
+                const uint32_t j2 = b2 + lane;
+                const uint32_t ky = j2 < dim ? (uint32_t)rowk[j2] : NBR_END;
+                NearbyItem i2{0u, 0u, 0u, 0u};
+                uint64_t hk = 0;
+                if (ky != NBR_END) {
+                    const uint32_t y2 = ky & NBR_NODE_MASK;
+                    i2 = nearby_item(is_change, node_slot[y2], se, sp, len, k, s_off, sb, ro);
+                    hk = (uint64_t)m.mat[(size_t)sx * dim + y2] << 24;  // finite by construction of the index
+                }
+                if (!__ballot(ky != NBR_END)) break;
+                topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
+                topk_offer(tk, need, i2.w == 2 ? (hk | (i2.ord + 1)) : ~0ULL, i2.pay1);
+            }
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(lane < need && tk.key != ~0ULL));
+            if (lane < cnt) {
+                const uint32_t qi = (tl + emitted + lane) & RCM;
+                rq[qi * 2] = mv0;
+                rq[qi * 2 + 1] = tk.pay;
+            }
+            emitted += cnt;
+            break;
+        }
+        const uint32_t nclosed = more ? fo : (uint32_t)__popcll(havemask);  // lanes [0, nclosed): complete groups
+        const uint64_t closedmask = nclosed >= 64 ? ~0ULL : ((1ULL << nclosed) - 1ULL);
+        const bool closed = (closedmask & lanebit) != 0;
+        const uint32_t wc = closed ? it.w : 0u;
+        const uint64_t w1 = __ballot(wc == 1), w2 = __ballot(wc == 2);
+        const uint32_t Wc = (uint32_t)__popcll(w1) + 2u * (uint32_t)__popcll(w2);
+        if (Wc > 0) {
+            // sorted position = weight before me, corrected by the inversions inside my group
+            int32_t pos = (int32_t)(mbcnt64(w1) + 2u * mbcnt64(w2));
+            const uint64_t nonstart = ~startmask & closedmask;  // lane continues the group of lane-1
+            if (nonstart) {
+                const uint32_t packed = (it.ord << 2) | wc;
+                uint64_t run = nonstart;  // bit t: lanes t-d .. t are one group
+                for (uint32_t d = 1; run != 0; ++d) {
+                    const uint32_t p_dn = __shfl_down(packed, d), p_up = __shfl_up(packed, d);
+                    const bool same_up = (run & lanebit) != 0;
+                    const bool same_dn = ((run >> d) & lanebit) != 0;
+                    if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
+                    if (same_up && (p_up >> 2) > it.ord) pos -= (int32_t)(p_up & 3u);
+                    run &= nonstart << d;
+                }
+            }
+            if (wc >= 1 && (uint32_t)pos < need) {
+                const uint32_t qi = (tl + emitted + (uint32_t)pos) & RCM;
+                rq[qi * 2] = mv0;
+                rq[qi * 2 + 1] = it.pay0;
+            }
+            if (wc == 2 && (uint32_t)pos + 1 < need) {
+                const uint32_t qi = (tl + emitted + (uint32_t)pos + 1) & RCM;
+                rq[qi * 2] = mv0;
+                rq[qi * 2 + 1] = it.pay1;
+            }
+            const uint32_t ne = Wc < need ? Wc : need;
+            emitted += ne;
+            need -= ne;
+        }
+        if (need == 0 || !more) break;
+        base += nclosed;
+        const uint32_t jj = base + lane;
+        key = jj < dim ? (uint32_t)rowk[jj] : NBR_END;
+    }
+    return emitted;
+}
+
 #ifdef SF_PHASE_PROFILE
 __device__ unsigned long long g_phase[8];
 #define PH_DECL uint64_t ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -41,15 +41,29 @@ struct GLeaves {
     int32_t n;
     int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap, 64 list reverse
     int32_t list_desc;  // descriptor_index of the list class (stream salts)
+    int32_t max_nearby[GL];  // nearby leaves (kinds 16 / 32)
+    int32_t has_nearby;
 };
 
 template <class VT>
 struct GCarve {
-    size_t ring, load, off, visits, vals, total;
-    __host__ __device__ GCarve(int n_scalar, int V, int n_cap) {
+    size_t ring, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, total;
+    // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
+    // entity-order tables), else 0
+    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * GRC * GL, 16);
+        node = o;
+        o = align_up(o + sizeof(uint32_t) * dim_nearby, 16);
+        slotbase = o;
+        o = align_up(o + (dim_nearby ? sizeof(uint16_t) * (V + 1) * 2 : 0), 16);
+        routeat = o;
+        o = align_up(o + (dim_nearby ? sizeof(uint16_t) * V * 2 : 0), 16);
+        rankof = o;
+        o = align_up(o + (dim_nearby ? sizeof(uint16_t) * V * 2 : 0), 16);
+        spvec = o;
+        o = align_up(o + (dim_nearby ? sizeof(uint16_t) * 64 * 2 : 0), 16);
         load = o;
         o = align_up(o + sizeof(int64_t) * V, 16);
         off = o;
@@ -69,6 +83,8 @@ struct GCarve {
 //                 d = destination entity rank (inter), e = destination position offset
 //  list swap:     a = entity rank, c = stage, b = first offset, e = second offset, d = destination rank
 //  list reverse:  a = entity rank, b = start offset, e = end offset
+//  nearby change / swap: a = entity rank, b = offset in the entity's list, c / d = rank / offset base the
+//                 leaf's position vector holds, e = sources left
 struct GGen {
     uint32_t a, b, c, d, e;
     int done;
@@ -76,7 +92,7 @@ struct GGen {
 
 template <int L, bool TRACE, class VT>
 __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p,
-                                                          int has_list, int has_scalar) {
+                                                          int has_list, int has_scalar, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -84,13 +100,19 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     const int r = rr + p.replica_base;
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
     const int V = has_list ? lm.V : 0;
-    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0);
+    const bool has_nearby = gl.has_nearby != 0;
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
     int64_t* s_load = (int64_t*)(mem + cv.load);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
     VT* s_vals = (VT*)(mem + cv.vals);
+    uint32_t* node_slot = (uint32_t*)(mem + cv.node);
+    uint16_t* nb_slot_base = (uint16_t*)(mem + cv.slotbase);  // [nearby leaf 0/1][V+1]
+    uint16_t* nb_route_at = (uint16_t*)(mem + cv.routeat);
+    uint16_t* nb_rank_of = (uint16_t*)(mem + cv.rankof);
+    uint16_t* nb_spvec = (uint16_t*)(mem + cv.spvec);
     const bool tracing = TRACE && r == p.trace_replica;
     const int nl = gl.n;
     const uint64_t identity = ((uint64_t)(uint32_t)sm.descriptor << 32) ^ (uint64_t)(uint32_t)sm.variable;
@@ -115,6 +137,15 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     }
     for (uint32_t t = lane; t < ns; t += 64) s_vals[t] = (VT)g_vals[t];
     wave_sync();
+    if (has_nearby) {  // node -> (route << 16 | position)
+        for (uint32_t t = lane; t < (uint32_t)lm.dim; t += 64) node_slot[t] = NODE_NONE;
+        wave_sync();
+        for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
+            const uint32_t o = s_off[v], len = s_off[v + 1] - o;
+            for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
+        }
+        wave_sync();
+    }
 
     int64_t cur[L], best_sol[L];
 #pragma unroll
@@ -189,6 +220,45 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             G[l] = GGen{0, 0, 0, 0, 0, l >= nl};
             head[l] = tail[l] = 0;
             ex[l] = l >= nl;
+        }
+        // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
+        if (has_nearby) {
+            const uint32_t total = uni(s_off[V]);
+            int ni = 0;
+#pragma unroll
+            for (int l = 0; l < GL; ++l) {
+                if (l >= nl || (gl.kind[l] != 16 && gl.kind[l] != 32)) continue;
+                const uint64_t ent_salt = (gl.kind[l] == 16 ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ ldesc;
+                uint32_t pst, psd;
+                ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
+                pst = uni(pst);
+                psd = uni(psd);
+                uint16_t* ra = nb_route_at + ni * V;
+                uint16_t* ro = nb_rank_of + ni * V;
+                uint16_t* sb = nb_slot_base + ni * (V + 1);
+                for (uint32_t k = lane; k < (uint32_t)V; k += 64) {
+                    const uint32_t e = (pst + k * psd) % (uint32_t)V;
+                    ra[k] = (uint16_t)e;
+                    ro[e] = (uint16_t)k;
+                }
+                wave_sync();
+                uint32_t carry = 0;
+                for (uint32_t base = 0; base < (uint32_t)V; base += 64) {
+                    const uint32_t k = base + lane;
+                    uint32_t v = 0;
+                    if (k < (uint32_t)V) {
+                        const uint32_t e = ra[k];
+                        v = s_off[e + 1] - s_off[e] + 1;
+                    }
+                    const uint32_t inc = wave_incl_scan(v);
+                    if (k < (uint32_t)V) sb[k] = (uint16_t)(carry + inc - v);
+                    carry += __shfl(inc, 63);
+                }
+                if (lane == 0) sb[V] = (uint16_t)carry;
+                G[l] = GGen{0, 0, 0xFFFFFFFFu, 0, total, total == 0};
+                ++ni;
+            }
+            wave_sync();
         }
         // union scheduler (vec_union.rs:190-365): StratifiedRandom with equal weights when > 1 leaf
         const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
@@ -333,6 +403,43 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                 g.e = 0;
                             }
                         }
+                    } else if (kind == 16 || kind == 32) {  // ---- nearby list change / swap: one source per call ----
+                        if (g.e == 0) {
+                            g.done = 1;
+                            break;
+                        }
+                        int ni = 0;  // which nearby table set this leaf owns
+#pragma unroll
+                        for (int l2 = 0; l2 < GL; ++l2)
+                            if (l2 < l && (gl.kind[l2] == 16 || gl.kind[l2] == 32)) ni += 1;
+                        const uint16_t* ra = nb_route_at + ni * V;
+                        const uint16_t* ro = nb_rank_of + ni * V;
+                        const uint16_t* sb = nb_slot_base + ni * (V + 1);
+                        uint16_t* spv = nb_spvec + ni * 64;
+                        uint32_t se = 0, len = 0;
+                        for (;;) {  // skip empty routes (sources left > 0 guarantees one exists)
+                            se = uni((uint32_t)ra[g.a]);
+                            len = rlen(se);
+                            if (g.b < len) break;
+                            g.a += 1;
+                            g.b = 0;
+                        }
+                        if (g.a != g.c || (g.b & ~63u) != g.d) {
+                            const uint64_t src_salt = (kind == 16 ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^ (uint64_t)se ^ ldesc;
+                            const uint32_t oo = (g.b & ~63u) + lane;
+                            spv[lane] = (uint16_t)(oo < len ? ctx.selection_index(oo, len, src_salt) : 0u);
+                            g.c = g.a;
+                            g.d = g.b & ~63u;
+                            wave_sync();
+                        }
+                        const uint32_t sp = uni((uint32_t)spv[g.b & 63u]);
+                        const uint32_t sx = uni((uint32_t)s_visits[s_off[se] + sp]);
+                        const uint32_t key0 = lane < (uint32_t)lm.dim ? (uint32_t)nb.keys[(size_t)sx * (uint32_t)lm.dim + lane] : NBR_END;
+                        tl += nearby_source_to_ring(lm, nb, kind == 16, se, sp, len, g.a, sx, node_slot, s_off, sb, ro, rq, GRC - 1, tl,
+                                                    key0, 0u, (uint32_t)gl.max_nearby[l], 0u);
+                        g.b += 1;
+                        g.e -= 1;
+                        if (g.e == 0) g.done = 1;
                     } else if (kind == 64) {  // ---- list reverse / 2-opt (list_kernel/reverse.rs:68-108) ----
                         uint32_t ent = 0, len = 0;
                         for (;;) {  // entities shorter than two elements are skipped
@@ -560,7 +667,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     } else {
                         const ListDelta d = my_kind == 64
                                                 ? eval_list_reverse(lm, s_visits, s_off, m0 >> 16, m0 & 0xFFFFu, m1 & 0xFFFFu)
-                                                : eval_list_move_legs<uint16_t, false>(lm, s_visits, s_off, s_load, my_kind == 4,
+                                                : eval_list_move_legs<uint16_t, false>(lm, s_visits, s_off, s_load, my_kind == 4 || my_kind == 16,
                                                                                       m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
                         doable = d.doable;
                         sc = apply_delta<L>(lm, cur, d);
@@ -642,7 +749,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
                         } else {
-                            tm[0] = my_kind == 4 ? 2 : (my_kind == 8 ? 3 : 4);
+                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : 4);
                             tm[1] = (int32_t)(m0 >> 16);
                             tm[2] = (int32_t)(m0 & 0xFFFFu);
                             tm[3] = (int32_t)(m1 >> 16);
@@ -692,15 +799,27 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             } else {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
-                    p.trace_applied[1] = kind == 4 ? 2 : (kind == 8 ? 3 : 4);
+                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : 4);
                     p.trace_applied[2] = (int32_t)(a >> 16);
                     p.trace_applied[3] = (int32_t)(a & 0xFFFFu);
                     p.trace_applied[4] = (int32_t)(b >> 16);
                     p.trace_applied[5] = (int32_t)(b & 0xFFFFu);
                     p.trace_applied[6] = -1;
                 }
-                apply_list_move_wave(lm, s_visits, s_off, s_load, kind == 4 ? 2 : (kind == 8 ? 3 : 4), a >> 16, a & 0xFFFFu, b >> 16,
-                                     b & 0xFFFFu);
+                apply_list_move_wave(lm, s_visits, s_off, s_load, (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : 4),
+                                     a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu);
+                if (has_nearby) {  // refresh node -> (route, position) for the touched routes
+                    const uint32_t ra_ = a >> 16, rb_ = b >> 16;
+                    const uint32_t oa = s_off[ra_], la = s_off[ra_ + 1] - oa;
+                    const uint32_t ob = s_off[rb_], lb = s_off[rb_ + 1] - ob;
+                    for (uint32_t t = lane; t < la + (ra_ != rb_ ? lb : 0u); t += 64) {
+                        if (t < la)
+                            node_slot[s_visits[oa + t]] = (ra_ << 16) | t;
+                        else
+                            node_slot[s_visits[ob + (t - la)]] = (rb_ << 16) | (t - la);
+                    }
+                    wave_sync();
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < L; ++kk) cur[kk] = best.v[kk];

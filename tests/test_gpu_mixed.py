@@ -252,3 +252,57 @@ def test_cvrp_list_reverse_leaf(oracle, leaves):
     assert d.working_lists(0, 0) == o.get_lists(0)
     assert (d.calculate_score()[0] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("leaves", [
+    ("nearby_change", "nearby_swap", "list_reverse"),
+    ("nearby_change", "list_change", "nearby_swap", "list_swap", "list_reverse"),
+    ("nearby_swap", "list_reverse"),
+])
+def test_cvrp_nearby_union_with_other_leaves(oracle, leaves):
+    """Nearby list change / swap unioned with the reversal and plain list leaves in the generic
+    N-leaf engine (StratifiedRandom over up to five children): cursor order, trial scores, traced
+    steps and a fused multi-replica solve against the oracle."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(70, 7, 45, seed=10)
+    bitmap = {"nearby_change": oracle.LEAF_NEARBY_LIST_CHANGE, "nearby_swap": oracle.LEAF_NEARBY_LIST_SWAP,
+              "list_change": oracle.LEAF_LIST_CHANGE, "list_swap": oracle.LEAF_LIST_SWAP,
+              "list_reverse": oracle.LEAF_LIST_REVERSE}
+    bits = 0
+    for name in leaves:
+        bits |= bitmap[name]
+    R = 2
+    d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves, max_nearby=8)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    d.calculate_score()
+    for order in (0, 3):
+        o.configure(leaves=bits, selection_order=order, max_nearby=8, random_seed=2)
+        gm, gs, gd = d.open_cursor(6, 4242, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 6, 4242, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm)[:, :5] == _t(om)[:, :5]).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+    o.configure(leaves=bits, max_nearby=8, random_seed=2, la_size=9, limit=48)
+    d.configure(sfa.SolverConfig(random_seed=2, late_acceptance_size=9, accepted_count_limit=48))
+    d.phase_start()
+    o.phase_start()
+    for step in range(15):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert (_t(gm)[:, :5] == _t(om)[:, :5]).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        assert d.working_lists(0, 0) == o.get_lists(0), step
+    d.solve_steps(40)
+    o.steps(40)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    sc = d.calculate_score()
+    assert (sc[0] == o.score()[:2]).all()
+    o2 = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o2.configure(leaves=bits, max_nearby=8, random_seed=3, la_size=9, limit=48)
+    o2.phase_start()
+    o2.steps(55)
+    assert d.working_lists(0, 1) == o2.get_lists(0)
+    assert (d.fresh_score() == sc).all()
