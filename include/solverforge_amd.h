@@ -63,7 +63,9 @@ typedef enum sf_move_kind {
     SF_MOVE_SWAP = 1,        /* heuristic/move/swap.rs:150-215 */
     SF_MOVE_LIST_CHANGE = 2, /* heuristic/move/list_kernel/change.rs:16-153 */
     SF_MOVE_LIST_SWAP = 3,   /* heuristic/move/list_kernel/swap.rs:17-110 */
-    SF_MOVE_LIST_REVERSE = 4 /* heuristic/move/list_kernel/reverse.rs:15-57: reverse list `a` over [a_pos, b_pos) (b = a) */
+    SF_MOVE_LIST_REVERSE = 4,/* heuristic/move/list_kernel/reverse.rs:15-57: reverse list `a` over [a_pos, b_pos) (b = a) */
+    SF_MOVE_SUBLIST_CHANGE = 5 /* heuristic/move/list_kernel/sublist_change.rs:18-130: segment [a_pos, value) of list `a`
+                                  -> list `b` at b_pos (post-removal coordinates when a == b) */
 } sf_move_kind;
 
 /* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
@@ -106,7 +108,8 @@ typedef enum sf_selector_kind {
     SF_SEL_LIST_SWAP = 8,          /* selector/list_kernel/swap.rs:25-270 */
     SF_SEL_NEARBY_LIST_CHANGE = 16,/* selector/list_kernel/nearby_change.rs:17-233 */
     SF_SEL_NEARBY_LIST_SWAP = 32,  /* selector/list_kernel/nearby_swap.rs:17-260 */
-    SF_SEL_LIST_REVERSE = 64       /* selector/list_kernel/reverse.rs:12-108 (intra-list 2-opt) */
+    SF_SEL_LIST_REVERSE = 64,      /* selector/list_kernel/reverse.rs:12-108 (intra-list 2-opt) */
+    SF_SEL_SUBLIST_CHANGE = 128    /* selector/list_kernel/sublist_change.rs:13-266 (Or-opt); sizes via sf_selector_add_sublist */
 } sf_selector_kind;
 
 typedef enum sf_selection_order { /* solverforge_config::SelectionOrder */
@@ -191,6 +194,9 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, i
  * `fact_meter` = i64 matrix for MatrixDistanceMeter (crates/solverforge-cvrp/src/meters.rs:10-28). */
 int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int32_t variable_index,
                         int32_t max_nearby, int32_t fact_meter);
+/* sublist leaves: segment sizes min_size..=max_size (default 1..=3, solverforge-config/src/move_selector.rs:713-715; <= 15) */
+int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int32_t variable_index,
+                                int32_t min_size, int32_t max_size);
 
 /* ---- Director surface -------------------------------------------------------------------- */
 /* ≙ first Director::calculate_score (initialize_all): builds per-replica aggregates.

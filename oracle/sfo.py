@@ -16,11 +16,12 @@ _LIB = os.path.join(_DIR, "_build", "libsf_oracle.so")
 MOVE_DTYPE = np.dtype(
     [("kind", "<i4"), ("a", "<i4"), ("a_pos", "<i4"), ("b", "<i4"), ("b_pos", "<i4"), ("value", "<i4")]
 )
-KIND_CHANGE, KIND_SWAP, KIND_LIST_CHANGE, KIND_LIST_SWAP, KIND_LIST_REVERSE = 0, 1, 2, 3, 4
+KIND_CHANGE, KIND_SWAP, KIND_LIST_CHANGE, KIND_LIST_SWAP, KIND_LIST_REVERSE, KIND_SUBLIST_CHANGE = 0, 1, 2, 3, 4, 5
 ORDER_ORIGINAL, ORDER_SORTED, ORDER_PROBABILISTIC, ORDER_RANDOM, ORDER_SHUFFLED = 0, 1, 2, 3, 4
 LEAF_SCALAR_CHANGE, LEAF_SCALAR_SWAP, LEAF_LIST_CHANGE, LEAF_LIST_SWAP = 1, 2, 4, 8
 LEAF_NEARBY_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP = 16, 32
 LEAF_LIST_REVERSE = 64
+LEAF_SUBLIST_CHANGE = 128
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
 UNION_SEQUENTIAL, UNION_ROUND_ROBIN, UNION_ROTATING, UNION_RANDOM, UNION_STRATIFIED = 0, 1, 2, 3, 4
@@ -69,6 +70,7 @@ def lib():
             "sfo_model_reset": (None, [vp]),
             "sfo_model_configure": (None, [vp, i32, i32, i32, i32, i32, i32, u32, i32, i32, u64, i32]),
             "sfo_model_set_step_seeds": (None, [vp, vp, i32]),
+            "sfo_model_set_sublist_sizes": (None, [vp, i32, i32]),
             "sfo_model_phase_start": (None, [vp]),
             "sfo_model_steps": (None, [vp, i64]),
             "sfo_model_steps_timed": (i64, [vp, dbl]),
@@ -187,6 +189,9 @@ class Model:
                   random_seed=0, public_entity_order=False):
         lib().sfo_model_configure(self.h, acceptor, la_size, forager, limit, int(random_ties), selection_order,
                                   leaves, max_nearby, union_order, random_seed, int(public_entity_order))
+
+    def set_sublist_sizes(self, min_size, max_size):
+        lib().sfo_model_set_sublist_sizes(self.h, min_size, max_size)
 
     def set_step_seeds(self, seeds):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

@@ -141,6 +141,11 @@ void sfo_model_configure(void* h, int32_t acceptor, int32_t la_size, int32_t for
     else
         m->union_order = (UnionOrder)union_order;
 }
+void sfo_model_set_sublist_sizes(void* h, int32_t min_size, int32_t max_size) {
+    Model* m = (Model*)h;
+    m->sublist_min = (size_t)min_size;
+    m->sublist_max = (size_t)max_size;
+}
 void sfo_model_set_step_seeds(void* h, const uint64_t* seeds, int32_t n) {
     ((Model*)h)->search.explicit_step_seeds.assign(seeds, seeds + n);
 }

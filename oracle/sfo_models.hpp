@@ -70,6 +70,7 @@ enum LeafBits : uint32_t {
     LEAF_NEARBY_LIST_CHANGE = 16,
     LEAF_NEARBY_LIST_SWAP = 32,
     LEAF_LIST_REVERSE = 64,
+    LEAF_SUBLIST_CHANGE = 128,
 };
 
 struct Model {
@@ -80,6 +81,7 @@ struct Model {
     LocalSearch search;
     uint32_t leaves = 0;
     size_t max_nearby = 20;
+    size_t sublist_min = 1, sublist_max = 3;
     UnionOrder union_order = UnionOrder::StratifiedRandom;
 
     std::unique_ptr<Cursor> open_leaf(uint32_t leaf, const ScoreDirector& d, const MoveStreamContext& ctx) const {
@@ -98,6 +100,8 @@ struct Model {
                 return std::make_unique<NearbyListSwapCursor>(list_slot, d.working, ctx, max_nearby);
             case LEAF_LIST_REVERSE:
                 return std::make_unique<ListReverseCursor>(list_slot, d.working, ctx);
+            case LEAF_SUBLIST_CHANGE:  // default sizes 1..=3 (solverforge-config/src/move_selector.rs:713-715)
+                return std::make_unique<SublistChangeCursor>(list_slot, d.working, ctx, sublist_min, sublist_max);
         }
         return nullptr;
     }
@@ -107,8 +111,8 @@ struct Model {
     //  policy/scalar.rs:67-106).
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
         static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
-                                         LEAF_LIST_SWAP,          LEAF_LIST_REVERSE, LEAF_SCALAR_CHANGE,
-                                         LEAF_SCALAR_SWAP};
+                                         LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_LIST_REVERSE,
+                                         LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
         std::vector<std::unique_ptr<Cursor>> children;
         for (uint32_t leaf : order)
             if (leaves & leaf) children.push_back(open_leaf(leaf, d, ctx));

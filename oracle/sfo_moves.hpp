@@ -28,13 +28,15 @@
 namespace sfo {
 
 struct Move {
-    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4 } kind = Change;
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5 } kind = Change;
     size_t descriptor = 0;
     size_t variable = 0;
     // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
     // ListChange: (a, a_pos) -> (b, b_pos) [pre-removal destination coords].
     // ListSwap: (a, a_pos) <-> (b, b_pos).
     // ListReverse: reverse list a over [a_pos, b_pos) (b = a).
+    // SublistChange: segment [a_pos, to_value) of list a -> list b at position b_pos (post-removal
+    //                coordinates when a == b).
     size_t a = 0, a_pos = 0, b = 0, b_pos = 0;
     int64_t to_value = NONE;
     bool allows_unassigned = false;
@@ -76,6 +78,15 @@ inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
         }
         case Move::ListReverse:  // move/list_kernel/reverse.rs:22-36
             return m.a < c.lists.size() && m.b_pos > m.a_pos + 1 && m.b_pos <= c.lists[m.a].size();
+        case Move::SublistChange: {  // move/list_kernel/sublist_change.rs:18-50
+            size_t start = m.a_pos, end = (size_t)m.to_value;
+            if (m.to_value < 0 || start >= end) return false;
+            size_t src_len = c.lists[m.a].size();
+            if (end > src_len) return false;
+            size_t max_dst = m.a == m.b ? src_len - (end - start) : c.lists[m.b].size();
+            if (m.b_pos > max_dst) return false;
+            return m.a != m.b || m.b_pos != start;
+        }
     }
     return false;
 }
@@ -132,6 +143,19 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
             d.after_variable_changed(m.descriptor, m.a);
             break;
         }
+        case Move::SublistChange: {  // apply_sublist_change (move/list_kernel/sublist_change.rs:88-130)
+            bool intra = m.a == m.b;
+            d.before_variable_changed(m.descriptor, m.a);
+            if (!intra) d.before_variable_changed(m.descriptor, m.b);
+            auto& src = c.lists[m.a];
+            std::vector<uint32_t> seg(src.begin() + (ptrdiff_t)m.a_pos, src.begin() + (ptrdiff_t)m.to_value);
+            src.erase(src.begin() + (ptrdiff_t)m.a_pos, src.begin() + (ptrdiff_t)m.to_value);
+            auto& dst = c.lists[m.b];
+            dst.insert(dst.begin() + (ptrdiff_t)m.b_pos, seg.begin(), seg.end());
+            d.after_variable_changed(m.descriptor, m.a);
+            if (!intra) d.after_variable_changed(m.descriptor, m.b);
+            break;
+        }
     }
     return u;
 }
@@ -164,6 +188,18 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)m.a_pos, value);
             d.after_variable_changed(m.descriptor, m.b);
             if (!intra) d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
+        case Move::SublistChange: {  // inverse relocation (move/segment_layout.rs:48-72)
+            Move inv = m;
+            size_t len = (size_t)m.to_value - m.a_pos;
+            inv.a = m.b;
+            inv.a_pos = m.b_pos;
+            inv.to_value = (int64_t)(m.b_pos + len);
+            inv.b = m.a;
+            inv.b_pos = m.a_pos;
+            MoveUndo ignored = move_do(d, inv);
+            (void)ignored;
             break;
         }
         case Move::ListSwap:       // swap is its own inverse
@@ -563,6 +599,103 @@ struct ListReverseCursor : Cursor {
             }
             ++entity_idx;
             start_offset = end_offset = 0;
+        }
+    }
+};
+
+// Contiguous sublist relocation / Or-opt (selector/list_kernel/sublist_change.rs:13-266): source
+// entity -> segment start -> segment size (min..=max) -> intra destinations 0..=(len - size) except
+// the start itself (post-removal coordinates) -> every other entity, positions 0..=len.
+struct SublistChangeCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x5B157C4A46E00001ULL, SALT_START = 0x5B157C4A46E00002ULL;
+    static constexpr uint64_t SALT_SIZE = 0x5B157C4A46E00003ULL, SALT_INTRA = 0x5B157C4A46E00004ULL;
+    static constexpr uint64_t SALT_INTER = 0x5B157C4A46E00005ULL;
+    size_t desc, min_size, max_size;
+    MoveStreamContext ctx;
+    std::vector<size_t> entities, route_lens;
+    size_t source_idx = 0, start_offset = 0, size_offset = 0;
+    bool stage_intra = true;
+    size_t intra_offset = 0, destination_idx = 0, inter_offset = 0;
+
+    SublistChangeCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c, size_t mn, size_t mx)
+        : desc(slot.descriptor_index), min_size(mn), max_size(mx), ctx(c) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    size_t size_count(size_t len, size_t start) const {  // sublist_change.rs:109-115
+        size_t max_valid = std::min(max_size, len > start ? len - start : 0);
+        return (max_valid > min_size ? max_valid - min_size : 0) + (max_valid >= min_size ? 1 : 0);
+    }
+    // (entity, len, start, end, size) of the current segment; size 0 = nothing here
+    bool current(size_t& ent, size_t& len, size_t& start, size_t& end, size_t& size) const {
+        if (source_idx >= entities.size()) return false;
+        ent = entities[source_idx];
+        len = route_lens[source_idx];
+        start = end = size = 0;
+        if (len < min_size) return true;
+        start = ctx.selection_index(start_offset, len, SALT_START ^ (uint64_t)ent ^ (uint64_t)desc);
+        size_t sc = size_count(len, start);
+        if (sc == 0) return true;
+        size_t so = ctx.selection_index(size_offset, sc, SALT_SIZE ^ (uint64_t)ent ^ (uint64_t)start);
+        size = min_size + so;
+        end = start + size;
+        return true;
+    }
+    void advance_segment() {
+        size_t ent, len, start, end, size;
+        if (!current(ent, len, start, end, size)) return;
+        size_t sc = size_count(len, start);
+        ++size_offset;
+        if (size_offset >= sc) {
+            size_offset = 0;
+            ++start_offset;
+        }
+        while (source_idx < route_lens.size() && start_offset >= route_lens[source_idx]) {
+            ++source_idx;
+            start_offset = size_offset = 0;
+        }
+        stage_intra = true;
+        intra_offset = destination_idx = inter_offset = 0;
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            size_t ent, len, start, end, size;
+            if (!current(ent, len, start, end, size)) return false;
+            if (len < min_size || size == 0) {
+                advance_segment();
+                continue;
+            }
+            if (stage_intra) {
+                size_t post = len - size;
+                while (intra_offset <= post) {
+                    size_t dp = ctx.selection_index(intra_offset, post + 1, SALT_INTRA ^ (uint64_t)ent ^ (uint64_t)start);
+                    ++intra_offset;
+                    if (dp == start) continue;
+                    out = make_list_move(Move::SublistChange, desc, ent, start, ent, dp);
+                    out.to_value = (int64_t)end;
+                    return true;
+                }
+                stage_intra = false;
+                destination_idx = inter_offset = 0;
+            } else {
+                while (destination_idx < entities.size()) {
+                    if (destination_idx == source_idx) {
+                        ++destination_idx;
+                        continue;
+                    }
+                    size_t de = entities[destination_idx], dlen = route_lens[destination_idx];
+                    if (inter_offset <= dlen) {
+                        size_t dp = ctx.selection_index(inter_offset, dlen + 1,
+                                                        SALT_INTER ^ (uint64_t)ent ^ (uint64_t)de ^ (uint64_t)start);
+                        ++inter_offset;
+                        out = make_list_move(Move::SublistChange, desc, ent, start, de, dp);
+                        out.to_value = (int64_t)end;
+                        return true;
+                    }
+                    ++destination_idx;
+                    inter_offset = 0;
+                }
+                advance_segment();
+            }
         }
     }
 };

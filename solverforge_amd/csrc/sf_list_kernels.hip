@@ -337,6 +337,89 @@ __device__ __forceinline__ ListDelta eval_list_reverse(const ListModel& m, const
     return r;
 }
 
+// SublistChangeMove: segment [s, e) of list a -> list b at position dp, dp in post-removal coordinates
+// when a == b (move/list_kernel/sublist_change.rs:18-130).  The segment keeps its direction.
+template <class VT>
+__device__ __forceinline__ ListDelta eval_sublist_change(const ListModel& m, const VT* visits, const uint32_t* off,
+                                                         const int64_t* load, uint32_t a, uint32_t s, uint32_t e, uint32_t b,
+                                                         uint32_t dp) {
+    ListDelta r{0, 0, false};
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    const uint32_t ob = off[b], lb = off[b + 1] - ob;
+    const bool intra = a == b;
+    if (!(s < e && e <= la)) return r;
+    const uint32_t z = e - s;
+    if (dp > (intra ? la - z : lb) || (intra && dp == s)) return r;
+    r.doable = true;
+    const uint32_t depot = (uint32_t)m.depot;
+    if (m.dist_level >= 0) {
+        const uint32_t first = visits[oa + s], last = visits[oa + e - 1];
+        const uint32_t prev = s > 0 ? (uint32_t)visits[oa + s - 1] : depot;
+        const uint32_t next = e < la ? (uint32_t)visits[oa + e] : depot;
+        int64_t acc = -wadd(dist_cost(m.mat, m.dim, prev, first), dist_cost(m.mat, m.dim, last, next));
+        if (la > z) acc = wadd(acc, dist_cost(m.mat, m.dim, prev, next));  // the source list is not emptied
+        uint32_t pl, pr;
+        bool dst_empty = false;
+        if (!intra) {
+            pl = dp > 0 ? (uint32_t)visits[ob + dp - 1] : depot;
+            pr = dp < lb ? (uint32_t)visits[ob + dp] : depot;
+            dst_empty = lb == 0;
+        } else {
+            const uint32_t l2 = la - z;
+            auto at = [&](uint32_t t) { return (uint32_t)visits[oa + (t < s ? t : t + z)]; };
+            pl = dp > 0 ? at(dp - 1) : depot;
+            pr = dp < l2 ? at(dp) : depot;
+        }
+        acc = wadd(acc, wadd(dist_cost(m.mat, m.dim, pl, first), dist_cost(m.mat, m.dim, last, pr)));
+        if (!dst_empty) acc = wsub(acc, dist_cost(m.mat, m.dim, pl, pr));
+        r.d_dist = acc;
+    }
+    if (m.cap_level >= 0 && !intra) {
+        int64_t dsum = 0;
+        for (uint32_t t = s; t < e; ++t) dsum = wadd(dsum, (int64_t)m.demand[visits[oa + t]]);
+        const int64_t la0 = load[a], lb0 = load[b];
+        const int64_t before = wadd(over_cap(la0, m.capacity), over_cap(lb0, m.capacity));
+        const int64_t after = wadd(over_cap(wsub(la0, dsum), m.capacity), over_cap(wadd(lb0, dsum), m.capacity));
+        r.d_cap = wsub(after, before);
+    }
+    return r;
+}
+
+// Relocates the flat range [P, P+z) so that it starts where flat position Q was (Q <= P or Q >= P+z),
+// shifting the elements in between; `sync` separates the read and write halves of every chunk
+// (wave_sync for one wavefront on LDS, __syncthreads for a workgroup on global memory).
+template <class VT, class SYNC>
+__device__ __forceinline__ void relocate_flat_segment(VT* visits, uint32_t P, uint32_t z, uint32_t Q, uint32_t tid,
+                                                      uint32_t nthreads, SYNC sync) {
+    // the segment itself (z <= 15) is carried in registers by the first z threads
+    const VT segv = tid < z ? visits[P + tid] : (VT)0;
+    sync();
+    if (Q >= P + z) {  // left shift of [P+z, Q) by z, ascending chunks
+        const uint32_t n = Q - (P + z);
+        for (uint32_t c0 = 0; c0 < n; c0 += nthreads) {
+            const bool in = c0 + tid < n;
+            const uint32_t t = P + c0 + tid;
+            const VT nv = in ? visits[t + z] : (VT)0;
+            sync();
+            if (in) visits[t] = nv;
+            sync();
+        }
+        if (tid < z) visits[Q - z + tid] = segv;
+    } else {  // right shift of [Q, P) by z, descending chunks
+        const uint32_t n = P - Q;
+        for (uint32_t c0 = 0; c0 < n; c0 += nthreads) {
+            const bool in = c0 + tid < n;
+            const uint32_t t = P + z - 1 - (in ? c0 + tid : 0u);
+            const VT nv = in ? visits[t - z] : (VT)0;
+            sync();
+            if (in) visits[t] = nv;
+            sync();
+        }
+        if (tid < z) visits[Q + tid] = segv;
+    }
+    sync();
+}
+
 template <int L>
 __device__ __forceinline__ ScoreV<L> apply_delta(const ListModel& m, const int64_t* cur, const ListDelta& d) {
     ScoreV<L> s;
@@ -431,7 +514,7 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
                                                              int32_t* out_doable, int skip_foreign) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 4)) return;  // a scalar move of a mixed model
+    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 5)) return;  // a scalar move of a mixed model
     const uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
     const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
     const int64_t* load = m.load + (size_t)replica * m.V;
@@ -447,6 +530,8 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
             d = eval_list_swap(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);
         else if (kind == 4 && mv[1] == mv[3])
             d = eval_list_reverse(m, visits, off, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[4]);
+        else if (kind == 5 && mv[5] >= 0)
+            d = eval_sublist_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[5], (uint32_t)mv[3], (uint32_t)mv[4]);
     }
     out_doable[t] = d.doable ? 1 : 0;
     ScoreV<4> s = apply_delta<4>(m, cur, d);
@@ -458,7 +543,7 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32_t* visits, uint32_t* off,
                                                       int64_t* load, int kind, uint32_t a, uint32_t i,
-                                                      uint32_t b, uint32_t j) {
+                                                      uint32_t b, uint32_t j, uint32_t ext = 0) {
     // all threads of the block call this; contains __syncthreads
     const uint32_t total = off[m.V];
     if (kind == 2) {
@@ -508,6 +593,24 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
                 load[b] = wadd(load[b], dx);
             }
         }
+    } else if (kind == 5) {  // sublist change: segment [i, ext) of list a -> list b at j
+        const uint32_t z = ext - i, P = off[a] + i;
+        const uint32_t Q = a != b ? off[b] + j : (j <= i ? off[a] + j : off[a] + j + z);
+        int64_t dsum = 0;
+        if (threadIdx.x == 0 && a != b && m.demand)
+            for (uint32_t t = 0; t < z; ++t) dsum = wadd(dsum, (int64_t)m.demand[visits[P + t]]);
+        __syncthreads();
+        relocate_flat_segment(visits, P, z, Q, threadIdx.x, blockDim.x, [] { __syncthreads(); });
+        if (a != b) {
+            for (uint32_t rr = threadIdx.x; rr <= (uint32_t)m.V; rr += blockDim.x) {
+                if (a < b && rr > a && rr <= b) off[rr] -= z;
+                if (a > b && rr > b && rr <= a) off[rr] += z;
+            }
+            if (threadIdx.x == 0 && m.demand) {
+                load[a] = wsub(load[a], dsum);
+                load[b] = wadd(load[b], dsum);
+            }
+        }
     } else if (kind == 4) {  // reverse [i, j) of list a: thread t exchanges the t-th pair from the ends
         const uint32_t lo = off[a] + i, hi = off[a] + j;  // hi exclusive
         for (uint32_t t = threadIdx.x; t < (hi - lo) / 2; t += blockDim.x) {
@@ -532,7 +635,7 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
 }
 
 __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, int kind, uint32_t a, uint32_t i,
-                                                    uint32_t b, uint32_t j, int32_t* out_ok) {
+                                                    uint32_t b, uint32_t j, uint32_t ext, int32_t* out_ok) {
     uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
     uint32_t* off = m.off + (size_t)replica * (m.V + 1);
     int64_t* load = m.load + (size_t)replica * m.V;
@@ -541,7 +644,8 @@ __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, in
     if (threadIdx.x == 0) {
         s_d = kind == 2   ? eval_list_change(m, visits, off, load, a, i, b, j)
               : kind == 3 ? eval_list_swap(m, visits, off, load, a, i, b, j)
-                          : eval_list_reverse(m, visits, off, a, i, j);
+              : kind == 4 ? eval_list_reverse(m, visits, off, a, i, j)
+                          : eval_sublist_change(m, visits, off, load, a, i, ext, b, j);
     }
     __syncthreads();
     ListDelta d = s_d;
@@ -549,7 +653,7 @@ __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, in
         if (threadIdx.x == 0) *out_ok = 0;
         return;
     }
-    apply_list_move_block(m, visits, off, load, kind, a, i, b, j);
+    apply_list_move_block(m, visits, off, load, kind, a, i, b, j, ext);
     if (threadIdx.x == 0) {
         ScoreV<4> s = apply_delta<4>(m, cur, d);
         for (int k = 0; k < 4; ++k) cur[k] = s.v[k];

@@ -173,7 +173,7 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 // Committed move application on the wave's LDS state (ListChange / ListSwap do_move).
 __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_t* visits, uint32_t* off,
                                                      int64_t* load, int kind, uint32_t a, uint32_t i, uint32_t b,
-                                                     uint32_t j) {
+                                                     uint32_t j, uint32_t ext = 0) {
     const uint32_t lane = threadIdx.x & 63u;
     if (kind == 2) {
         const uint32_t P = off[a] + i, Q = off[b] + j;
@@ -209,6 +209,24 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
                 const int64_t dx = (int64_t)m.demand[x];
                 load[a] = wsub(load[a], dx);
                 load[b] = wadd(load[b], dx);
+            }
+        }
+    } else if (kind == 5) {  // sublist change: segment [i, ext) of list a -> list b at j
+        const uint32_t z = ext - i, P = off[a] + i;
+        const uint32_t Q = a != b ? off[b] + j : (j <= i ? off[a] + j : off[a] + j + z);
+        int64_t dsum = 0;
+        if (a != b && m.demand)
+            for (uint32_t t = 0; t < z; ++t) dsum = wadd(dsum, (int64_t)m.demand[visits[P + t]]);
+        wave_sync();
+        relocate_flat_segment(visits, P, z, Q, lane, 64u, [] { wave_sync(); });
+        if (a != b) {
+            for (uint32_t rr = lane; rr <= (uint32_t)m.V; rr += 64) {
+                if (a < b && rr > a && rr <= b) off[rr] -= z;
+                if (a > b && rr > b && rr <= a) off[rr] += z;
+            }
+            if (lane == 0 && m.demand) {
+                load[a] = wsub(load[a], dsum);
+                load[b] = wadd(load[b], dsum);
             }
         }
     } else if (kind == 4) {  // reverse [i, j) of list a

@@ -36,24 +36,31 @@ constexpr uint64_t SALT_LS_SECOND = 0x11575A0900000003ULL, SALT_LS_IFIRST = 0x11
 constexpr uint64_t SALT_LS_ISECOND = 0x11575A0900000005ULL;
 constexpr uint64_t SALT_LR_ENTITY = 0x11572A0700000001ULL, SALT_LR_START = 0x11572A0700000002ULL;  // reverse.rs:12-14
 constexpr uint64_t SALT_LR_END = 0x11572A0700000003ULL;
+constexpr uint64_t SALT_SC_ENTITY = 0x5B157C4A46E00001ULL, SALT_SC_START = 0x5B157C4A46E00002ULL;  // sublist_change.rs:22-28
+constexpr uint64_t SALT_SC_SIZE = 0x5B157C4A46E00003ULL, SALT_SC_INTRA = 0x5B157C4A46E00004ULL;
+constexpr uint64_t SALT_SC_INTER = 0x5B157C4A46E00005ULL;
 
 struct GLeaves {
     int32_t n;
-    int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap, 64 list reverse
+    int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap, 64 list reverse,
+                        // 16 / 32 nearby change / swap, 128 sublist change
     int32_t list_desc;  // descriptor_index of the list class (stream salts)
     int32_t max_nearby[GL];  // nearby leaves (kinds 16 / 32)
     int32_t has_nearby;
+    int32_t min_size[GL], max_size[GL];  // sublist leaves
 };
 
 template <class VT>
 struct GCarve {
-    size_t ring, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, total;
+    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
     __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * GRC * GL, 16);
+        ringx = o;  // one extra byte per ring entry (segment size of the sublist leaves)
+        o = align_up(o + GRC * GL, 16);
         node = o;
         o = align_up(o + sizeof(uint32_t) * dim_nearby, 16);
         slotbase = o;
@@ -83,10 +90,12 @@ struct GCarve {
 //                 d = destination entity rank (inter), e = destination position offset
 //  list swap:     a = entity rank, c = stage, b = first offset, e = second offset, d = destination rank
 //  list reverse:  a = entity rank, b = start offset, e = end offset
+//  sublist change: a = source rank, b = segment start offset, f = segment size offset, c = stage,
+//                 d = destination rank, e = destination position offset
 //  nearby change / swap: a = entity rank, b = offset in the entity's list, c / d = rank / offset base the
 //                 leaf's position vector holds, e = sources left
 struct GGen {
-    uint32_t a, b, c, d, e;
+    uint32_t a, b, c, d, e, f;
     int done;
 };
 
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
+    uint8_t* ringx = (uint8_t*)(mem + cv.ringx);  // [leaf][GRC]
     int64_t* s_load = (int64_t*)(mem + cv.load);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
@@ -190,11 +200,12 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         ScoreV<L> best;
 #pragma unroll
         for (int k = 0; k < L; ++k) best.v[k] = 0;
-        uint32_t best_m0 = 0, best_m1 = 0;
+        uint32_t best_m0 = 0, best_m1 = 0, best_x = 0;
         int best_leaf = 0;
 
         // entity permutations (selection_index_without_replacement) of the four streams
         uint32_t sc_st = 0, sc_sd = 1, ss_st = 0, ss_sd = 1, lc_st = 0, lc_sd = 1, ls_st = 0, ls_sd = 1, lr_st = 0, lr_sd = 1;
+        uint32_t sb_st = 0, sb_sd = 1;  // sublist change entity permutation
         if (has_scalar) {
             ctx.perm_params(ns, SALT_SCALAR_CHANGE_ENTITY ^ identity, sc_st, sc_sd);
             ctx.perm_params(ns, (SALT_SCALAR_SWAP_LEFT ^ identity) ^ OFFSET_MIX, ss_st, ss_sd);
@@ -203,10 +214,13 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             ctx.perm_params((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd);
             ctx.perm_params((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd);
             ctx.perm_params((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd);
+            ctx.perm_params((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd);
         }
         sc_st = uni(sc_st), sc_sd = uni(sc_sd), ss_st = uni(ss_st), ss_sd = uni(ss_sd);
         lc_st = uni(lc_st), lc_sd = uni(lc_sd), ls_st = uni(ls_st), ls_sd = uni(ls_sd);
         lr_st = uni(lr_st), lr_sd = uni(lr_sd);
+        sb_st = uni(sb_st), sb_sd = uni(sb_sd);
+        auto sb_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)sb_st + (uint64_t)rank * sb_sd) % (uint32_t)V); };
         auto lr_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lr_st + (uint64_t)rank * lr_sd) % (uint32_t)V); };
         auto lc_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lc_st + (uint64_t)rank * lc_sd) % (uint32_t)V); };
         auto ls_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)ls_st + (uint64_t)rank * ls_sd) % (uint32_t)V); };
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         int ex[GL];
 #pragma unroll
         for (int l = 0; l < GL; ++l) {
-            G[l] = GGen{0, 0, 0, 0, 0, l >= nl};
+            G[l] = GGen{0, 0, 0, 0, 0, 0, l >= nl};
             head[l] = tail[l] = 0;
             ex[l] = l >= nl;
         }
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     carry += __shfl(inc, 63);
                 }
                 if (lane == 0) sb[V] = (uint16_t)carry;
-                G[l] = GGen{0, 0, 0xFFFFFFFFu, 0, total, total == 0};
+                G[l] = GGen{0, 0, 0xFFFFFFFFu, 0, total, 0, total == 0};
                 ++ni;
             }
             wave_sync();
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                 while (!ex[l] && !g.done && tl - head[l] < 64u) {
                     st_sources += 1;
                     bool keep = false;
-                    uint32_t w0 = 0, w1 = 0;
+                    uint32_t w0 = 0, w1 = 0, wx = 0;
                     if (kind == 1) {  // ---- scalar change ----
                         if (g.a >= ns) {
                             g.done = 1;
@@ -402,6 +416,87 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                 g.d += 1;
                                 g.e = 0;
                             }
+                        }
+                    } else if (kind == 128) {  // ---- sublist change / Or-opt (list_kernel/sublist_change.rs:109-266) ----
+                        const uint32_t mn = (uint32_t)gl.min_size[l], mx = (uint32_t)gl.max_size[l];
+                        uint32_t ent = 0, len = 0, start = 0, sc = 0;
+                        for (;;) {  // current segment start with at least one legal size
+                            if (g.a >= (uint32_t)V) break;
+                            ent = sb_ent(g.a);
+                            len = rlen(ent);
+                            if (len < mn || g.b >= len) {
+                                g.a += 1;
+                                g.b = 0;
+                                g.f = 0;
+                                g.c = 0;
+                                g.d = 0;
+                                g.e = 0;
+                                continue;
+                            }
+                            start = ctx.selection_index(g.b, len, SALT_SC_START ^ (uint64_t)ent ^ ldesc);
+                            const uint32_t max_valid = mx < len - start ? mx : len - start;
+                            sc = (max_valid > mn ? max_valid - mn : 0u) + (max_valid >= mn ? 1u : 0u);
+                            if (sc != 0) break;
+                            g.b += 1;
+                            g.f = 0;
+                        }
+                        if (g.a >= (uint32_t)V) {
+                            g.done = 1;
+                            break;
+                        }
+                        const uint32_t z = mn + ctx.selection_index(g.f, sc, SALT_SC_SIZE ^ (uint64_t)ent ^ (uint64_t)start);
+                        bool segment_done = false;
+                        if (g.c == 0) {  // intra destinations 0..=(len - z) in post-removal coordinates, except `start`
+                            const uint32_t post = len - z;
+                            const uint32_t o = g.e + lane;
+                            if (o <= post) {
+                                const uint32_t dp = ctx.selection_index(o, post + 1, SALT_SC_INTRA ^ (uint64_t)ent ^ (uint64_t)start);
+                                keep = dp != start;
+                                w0 = (ent << 16) | start;
+                                w1 = (ent << 16) | dp;
+                            }
+                            g.e += 64;
+                            if (g.e > post) {
+                                g.c = 1;
+                                g.d = 0;
+                                g.e = 0;
+                            }
+                        } else {
+                            if (g.d == g.a) {
+                                g.d += 1;
+                                g.e = 0;
+                            }
+                            if (g.d >= (uint32_t)V) {
+                                segment_done = true;
+                            } else {
+                                const uint32_t de = sb_ent(g.d);
+                                const uint32_t dlen = rlen(de);
+                                const uint32_t o = g.e + lane;
+                                if (o <= dlen) {
+                                    const uint32_t dp = ctx.selection_index(o, dlen + 1, SALT_SC_INTER ^ (uint64_t)ent ^ (uint64_t)de ^ (uint64_t)start);
+                                    keep = true;
+                                    w0 = (ent << 16) | start;
+                                    w1 = (de << 16) | dp;
+                                }
+                                g.e += 64;
+                                if (g.e > dlen) {
+                                    g.d += 1;
+                                    g.e = 0;
+                                }
+                            }
+                        }
+                        wx = z;
+                        if (segment_done) {  // advance_segment
+                            g.f += 1;
+                            if (g.f >= sc) {
+                                g.f = 0;
+                                g.b += 1;
+                            }
+                            g.c = 0;
+                            g.d = 0;
+                            g.e = 0;
+                            st_sources -= 1;
+                            continue;
                         }
                     } else if (kind == 16 || kind == 32) {  // ---- nearby list change / swap: one source per call ----
                         if (g.e == 0) {
@@ -554,6 +649,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         const uint32_t qi = (tl + mbcnt64(km)) & (GRC - 1);
                         rq[qi * 2] = w0;
                         rq[qi * 2 + 1] = w1;
+                        ringx[l * GRC + qi] = (uint8_t)wx;
                     }
                     tl += (uint32_t)__popcll(km);
                 }
@@ -646,7 +742,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             // ---- C3: trial score, acceptor, forager ----
             {
                 const bool valid = lane < nvalid;
-                uint32_t m0 = 0, m1 = 0;
+                uint32_t m0 = 0, m1 = 0, mx_ = 0;
                 int my_kind = 0;
 #pragma unroll
                 for (int l = 0; l < GL; ++l)
@@ -659,13 +755,17 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     const uint32_t* rq = ring + ((size_t)my_leaf * GRC + (my_idx & (GRC - 1))) * 2;
                     m0 = rq[0];
                     m1 = rq[1];
+                    mx_ = ringx[my_leaf * GRC + (my_idx & (GRC - 1))];
                     if (my_kind <= 2) {
                         const ScalarDelta d = my_kind == 1 ? eval_scalar_move(sm, s_vals, 0, m0, 0u, (int32_t)m1)
                                                            : eval_scalar_move(sm, s_vals, 1, m0, m1, 0);
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
                     } else {
-                        const ListDelta d = my_kind == 64
+                        const ListDelta d = my_kind == 128
+                                                ? eval_sublist_change(lm, s_visits, s_off, s_load, m0 >> 16, m0 & 0xFFFFu, (m0 & 0xFFFFu) + mx_,
+                                                                      m1 >> 16, m1 & 0xFFFFu)
+                                            : my_kind == 64
                                                 ? eval_list_reverse(lm, s_visits, s_off, m0 >> 16, m0 & 0xFFFFu, m1 & 0xFFFFu)
                                                 : eval_list_move_legs<uint16_t, false>(lm, s_visits, s_off, s_load, my_kind == 4 || my_kind == 16,
                                                                                       m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
@@ -703,6 +803,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)shfl_u64((uint64_t)sc.v[kk], sel);
                             best_m0 = __shfl(m0, sel);
                             best_m1 = __shfl(m1, sel);
+                            best_x = __shfl(mx_, sel);
                             best_leaf = (int)__shfl(my_leaf, sel);
                             has_best = 1;
                         }
@@ -723,6 +824,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                 const int sel = 63 - __clzll((unsigned long long)pm);
                                 best_m0 = __shfl(m0, sel);
                                 best_m1 = __shfl(m1, sel);
+                                best_x = __shfl(mx_, sel);
                                 best_leaf = (int)__shfl(my_leaf, sel);
                             }
                             best = M;
@@ -749,12 +851,12 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
                         } else {
-                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : 4);
+                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : (my_kind == 64 ? 4 : 5));
                             tm[1] = (int32_t)(m0 >> 16);
                             tm[2] = (int32_t)(m0 & 0xFFFFu);
                             tm[3] = (int32_t)(m1 >> 16);
                             tm[4] = (int32_t)(m1 & 0xFFFFu);
-                            tm[5] = -1;
+                            tm[5] = my_kind == 128 ? (int32_t)((m0 & 0xFFFFu) + mx_) : -1;
                         }
                         for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * L + kk] = doable ? sc.v[kk] : 0;
                         p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
@@ -799,15 +901,16 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             } else {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
-                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : 4);
+                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : 5));
                     p.trace_applied[2] = (int32_t)(a >> 16);
                     p.trace_applied[3] = (int32_t)(a & 0xFFFFu);
                     p.trace_applied[4] = (int32_t)(b >> 16);
                     p.trace_applied[5] = (int32_t)(b & 0xFFFFu);
-                    p.trace_applied[6] = -1;
+                    p.trace_applied[6] = kind == 128 ? (int32_t)((a & 0xFFFFu) + uni(best_x)) : -1;
                 }
-                apply_list_move_wave(lm, s_visits, s_off, s_load, (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : 4),
-                                     a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu);
+                apply_list_move_wave(lm, s_visits, s_off, s_load,
+                                     (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : 5)), a >> 16,
+                                     a & 0xFFFFu, b >> 16, b & 0xFFFFu, (a & 0xFFFFu) + uni(best_x));
                 if (has_nearby) {  // refresh node -> (route, position) for the touched routes
                     const uint32_t ra_ = a >> 16, rb_ = b >> 16;
                     const uint32_t oa = s_off[ra_], la = s_off[ra_ + 1] - oa;

@@ -16,7 +16,7 @@ from ._lib import MOVE_DTYPE, SolverConfigStruct, SolverForgeError, StatsStruct,
 
 
 class MoveKind:
-    CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE = 0, 1, 2, 3, 4
+    CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE = 0, 1, 2, 3, 4, 5
 
 
 class SelectionOrder:  # solverforge_config::SelectionOrder
@@ -43,7 +43,7 @@ class ConstraintKind:
 
 class SelectorKind:
     SCALAR_CHANGE, SCALAR_SWAP, LIST_CHANGE, LIST_SWAP = 1, 2, 4, 8
-    NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE = 16, 32, 64
+    NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE = 16, 32, 64, 128
 
 
 @dataclass
@@ -129,6 +129,9 @@ class GpuScoreDirector:
 
     def add_selector(self, kind, descriptor_index, variable_index=0, max_nearby=0, fact_meter=-1):
         check(self._L.sf_selector_add(self._h, kind, descriptor_index, variable_index, max_nearby, fact_meter), self._h)
+
+    def add_sublist_selector(self, kind, descriptor_index, variable_index=0, min_size=1, max_size=3):
+        check(self._L.sf_selector_add_sublist(self._h, kind, descriptor_index, variable_index, min_size, max_size), self._h)
 
     # ---- Director surface ------------------------------------------------------------
     def _scores(self, fn):

@@ -8,7 +8,8 @@ from .director import ConstraintKind, GpuScoreDirector, SelectorKind
 FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN = 0, 1, 2, 3, 4, 5
 
 
-def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearby_change", "nearby_swap")):
+def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearby_change", "nearby_swap"),
+               sublist_sizes=(1, 3)):
     # leaves may also name the plain streams "list_change" / "list_swap" (generic N-leaf engine)
     """CVRP: HardSoftScore; all_customers_assigned (not-exists, 1 hard each —
     crates/solverforge/tests/list_clarke_wright_publication/domain/publication_plan.rs:51-65),
@@ -36,6 +37,8 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
         d.add_selector(SelectorKind.LIST_SWAP, 0)
     if "list_reverse" in leaves:
         d.add_selector(SelectorKind.LIST_REVERSE, 0)
+    if "sublist_change" in leaves:
+        d.add_sublist_selector(SelectorKind.SUBLIST_CHANGE, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
     return d
 
 

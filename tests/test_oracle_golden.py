@@ -104,3 +104,16 @@ def test_splitmix64_known_values(oracle):
     from solverforge_amd import datasets
 
     assert [int(v) for v in datasets.stream(0, 3)] == [0xE220A8397B1DCDAF, 0x6E789E6AA1B965F4, 0x06C45D188009454F]
+
+
+def test_sublist_change_canonical_order_and_count(oracle):
+    g = GOLD["sublist_change_order"]
+    m = oracle.Model.list_toy(g["routes"])
+    m.set_sublist_sizes(g["min"], g["max"])
+    mv = m.enumerate(oracle.LEAF_SUBLIST_CHANGE)
+    assert [[int(x["a"]), int(x["a_pos"]), int(x["value"]), int(x["b"]), int(x["b_pos"])] for x in mv] == g["expected"]
+    c = GOLD["candidate_counts_sublist"]
+    routes = [[v * 1000 + i for i in range(c["visits_per_vehicle"])] for v in range(c["vehicles"])]
+    m = oracle.Model.list_toy(routes)
+    m.set_sublist_sizes(c["min"], c["max"])
+    assert m.enumerate_count(oracle.LEAF_SUBLIST_CHANGE) == c["sublist_change"]
