@@ -64,8 +64,10 @@ typedef enum sf_move_kind {
     SF_MOVE_LIST_CHANGE = 2, /* heuristic/move/list_kernel/change.rs:16-153 */
     SF_MOVE_LIST_SWAP = 3,   /* heuristic/move/list_kernel/swap.rs:17-110 */
     SF_MOVE_LIST_REVERSE = 4,/* heuristic/move/list_kernel/reverse.rs:15-57: reverse list `a` over [a_pos, b_pos) (b = a) */
-    SF_MOVE_SUBLIST_CHANGE = 5 /* heuristic/move/list_kernel/sublist_change.rs:18-130: segment [a_pos, value) of list `a`
+    SF_MOVE_SUBLIST_CHANGE = 5,/* heuristic/move/list_kernel/sublist_change.rs:18-130: segment [a_pos, value) of list `a`
                                   -> list `b` at b_pos (post-removal coordinates when a == b) */
+    SF_MOVE_SUBLIST_SWAP = 6   /* heuristic/move/list_kernel/sublist_swap.rs:17-160: segment [a_pos, a_pos + (value & 0xFFFF)) of
+                                  list `a` <-> segment [b_pos, b_pos + (value >> 16)) of list `b` */
 } sf_move_kind;
 
 /* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
@@ -109,7 +111,8 @@ typedef enum sf_selector_kind {
     SF_SEL_NEARBY_LIST_CHANGE = 16,/* selector/list_kernel/nearby_change.rs:17-233 */
     SF_SEL_NEARBY_LIST_SWAP = 32,  /* selector/list_kernel/nearby_swap.rs:17-260 */
     SF_SEL_LIST_REVERSE = 64,      /* selector/list_kernel/reverse.rs:12-108 (intra-list 2-opt) */
-    SF_SEL_SUBLIST_CHANGE = 128    /* selector/list_kernel/sublist_change.rs:13-266 (Or-opt); sizes via sf_selector_add_sublist */
+    SF_SEL_SUBLIST_CHANGE = 128,   /* selector/list_kernel/sublist_change.rs:13-266 (Or-opt); sizes via sf_selector_add_sublist */
+    SF_SEL_SUBLIST_SWAP = 256      /* selector/list_kernel/sublist_swap.rs:13-330; sizes via sf_selector_add_sublist */
 } sf_selector_kind;
 
 typedef enum sf_selection_order { /* solverforge_config::SelectionOrder */

@@ -16,12 +16,13 @@ _LIB = os.path.join(_DIR, "_build", "libsf_oracle.so")
 MOVE_DTYPE = np.dtype(
     [("kind", "<i4"), ("a", "<i4"), ("a_pos", "<i4"), ("b", "<i4"), ("b_pos", "<i4"), ("value", "<i4")]
 )
-KIND_CHANGE, KIND_SWAP, KIND_LIST_CHANGE, KIND_LIST_SWAP, KIND_LIST_REVERSE, KIND_SUBLIST_CHANGE = 0, 1, 2, 3, 4, 5
+KIND_CHANGE, KIND_SWAP, KIND_LIST_CHANGE, KIND_LIST_SWAP, KIND_LIST_REVERSE, KIND_SUBLIST_CHANGE, KIND_SUBLIST_SWAP = 0, 1, 2, 3, 4, 5, 6
 ORDER_ORIGINAL, ORDER_SORTED, ORDER_PROBABILISTIC, ORDER_RANDOM, ORDER_SHUFFLED = 0, 1, 2, 3, 4
 LEAF_SCALAR_CHANGE, LEAF_SCALAR_SWAP, LEAF_LIST_CHANGE, LEAF_LIST_SWAP = 1, 2, 4, 8
 LEAF_NEARBY_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP = 16, 32
 LEAF_LIST_REVERSE = 64
 LEAF_SUBLIST_CHANGE = 128
+LEAF_SUBLIST_SWAP = 256
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
 UNION_SEQUENTIAL, UNION_ROUND_ROBIN, UNION_ROTATING, UNION_RANDOM, UNION_STRATIFIED = 0, 1, 2, 3, 4

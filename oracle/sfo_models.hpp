@@ -71,6 +71,7 @@ enum LeafBits : uint32_t {
     LEAF_NEARBY_LIST_SWAP = 32,
     LEAF_LIST_REVERSE = 64,
     LEAF_SUBLIST_CHANGE = 128,
+    LEAF_SUBLIST_SWAP = 256,
 };
 
 struct Model {
@@ -100,6 +101,8 @@ struct Model {
                 return std::make_unique<NearbyListSwapCursor>(list_slot, d.working, ctx, max_nearby);
             case LEAF_LIST_REVERSE:
                 return std::make_unique<ListReverseCursor>(list_slot, d.working, ctx);
+            case LEAF_SUBLIST_SWAP:
+                return std::make_unique<SublistSwapCursor>(list_slot, d.working, ctx, sublist_min, sublist_max);
             case LEAF_SUBLIST_CHANGE:  // default sizes 1..=3 (solverforge-config/src/move_selector.rs:713-715)
                 return std::make_unique<SublistChangeCursor>(list_slot, d.working, ctx, sublist_min, sublist_max);
         }
@@ -111,7 +114,7 @@ struct Model {
     //  policy/scalar.rs:67-106).
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
         static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
-                                         LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_LIST_REVERSE,
+                                         LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_SUBLIST_SWAP, LEAF_LIST_REVERSE,
                                          LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
         std::vector<std::unique_ptr<Cursor>> children;
         for (uint32_t leaf : order)

@@ -28,7 +28,7 @@
 namespace sfo {
 
 struct Move {
-    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5 } kind = Change;
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6 } kind = Change;
     size_t descriptor = 0;
     size_t variable = 0;
     // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
@@ -37,6 +37,8 @@ struct Move {
     // ListReverse: reverse list a over [a_pos, b_pos) (b = a).
     // SublistChange: segment [a_pos, to_value) of list a -> list b at position b_pos (post-removal
     //                coordinates when a == b).
+    // SublistSwap: segment [a_pos, a_pos + (to_value & 0xFFFF)) of list a <-> segment
+    //                [b_pos, b_pos + (to_value >> 16)) of list b.
     size_t a = 0, a_pos = 0, b = 0, b_pos = 0;
     int64_t to_value = NONE;
     bool allows_unassigned = false;
@@ -78,6 +80,14 @@ inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
         }
         case Move::ListReverse:  // move/list_kernel/reverse.rs:22-36
             return m.a < c.lists.size() && m.b_pos > m.a_pos + 1 && m.b_pos <= c.lists[m.a].size();
+        case Move::SublistSwap: {  // move/list_kernel/sublist_swap.rs:17-43
+            if (m.to_value < 0) return false;
+            size_t fs = m.a_pos, fe = m.a_pos + (size_t)(m.to_value & 0xFFFF);
+            size_t ss = m.b_pos, se = m.b_pos + (size_t)(m.to_value >> 16);
+            if (fs >= fe || ss >= se) return false;
+            if (fe > c.lists[m.a].size() || se > c.lists[m.b].size()) return false;
+            return !(m.a == m.b && fs < se && ss < fe);
+        }
         case Move::SublistChange: {  // move/list_kernel/sublist_change.rs:18-50
             size_t start = m.a_pos, end = (size_t)m.to_value;
             if (m.to_value < 0 || start >= end) return false;
@@ -143,6 +153,36 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
             d.after_variable_changed(m.descriptor, m.a);
             break;
         }
+        case Move::SublistSwap: {  // apply_sublist_swap (move/list_kernel/sublist_swap.rs:78-160): the segments
+                                   // trade places, each keeping its internal order
+            bool intra = m.a == m.b;
+            size_t fs = m.a_pos, fe = m.a_pos + (size_t)(m.to_value & 0xFFFF);
+            size_t ss = m.b_pos, se = m.b_pos + (size_t)(m.to_value >> 16);
+            d.before_variable_changed(m.descriptor, m.a);
+            if (!intra) d.before_variable_changed(m.descriptor, m.b);
+            if (intra) {
+                auto& l = c.lists[m.a];
+                size_t es = fs < ss ? fs : ss, ee = fs < ss ? fe : se, ls = fs < ss ? ss : fs, le = fs < ss ? se : fe;
+                std::vector<uint32_t> out(l.begin(), l.begin() + (ptrdiff_t)es);
+                out.insert(out.end(), l.begin() + (ptrdiff_t)ls, l.begin() + (ptrdiff_t)le);
+                out.insert(out.end(), l.begin() + (ptrdiff_t)ee, l.begin() + (ptrdiff_t)ls);
+                out.insert(out.end(), l.begin() + (ptrdiff_t)es, l.begin() + (ptrdiff_t)ee);
+                out.insert(out.end(), l.begin() + (ptrdiff_t)le, l.end());
+                l = out;
+            } else {
+                auto& la = c.lists[m.a];
+                auto& lb = c.lists[m.b];
+                std::vector<uint32_t> sa(la.begin() + (ptrdiff_t)fs, la.begin() + (ptrdiff_t)fe);
+                std::vector<uint32_t> sb(lb.begin() + (ptrdiff_t)ss, lb.begin() + (ptrdiff_t)se);
+                la.erase(la.begin() + (ptrdiff_t)fs, la.begin() + (ptrdiff_t)fe);
+                la.insert(la.begin() + (ptrdiff_t)fs, sb.begin(), sb.end());
+                lb.erase(lb.begin() + (ptrdiff_t)ss, lb.begin() + (ptrdiff_t)se);
+                lb.insert(lb.begin() + (ptrdiff_t)ss, sa.begin(), sa.end());
+            }
+            d.after_variable_changed(m.descriptor, m.a);
+            if (!intra) d.after_variable_changed(m.descriptor, m.b);
+            break;
+        }
         case Move::SublistChange: {  // apply_sublist_change (move/list_kernel/sublist_change.rs:88-130)
             bool intra = m.a == m.b;
             d.before_variable_changed(m.descriptor, m.a);
@@ -188,6 +228,23 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)m.a_pos, value);
             d.after_variable_changed(m.descriptor, m.b);
             if (!intra) d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
+        case Move::SublistSwap: {  // the inverse exchanges the segments where they now sit
+            Move inv = m;
+            size_t za = (size_t)(m.to_value & 0xFFFF), zb = (size_t)(m.to_value >> 16);
+            if (m.a == m.b) {
+                if (m.a_pos < m.b_pos) {  // early segment now has size zb; the late one ends where it ended
+                    inv.a_pos = m.a_pos;
+                    inv.b_pos = m.b_pos + zb - za;
+                } else {
+                    inv.b_pos = m.b_pos;
+                    inv.a_pos = m.a_pos + za - zb;
+                }
+            }
+            inv.to_value = (int64_t)(zb | (za << 16));
+            MoveUndo ignored = move_do(d, inv);
+            (void)ignored;
             break;
         }
         case Move::SublistChange: {  // inverse relocation (move/segment_layout.rs:48-72)
@@ -696,6 +753,120 @@ struct SublistChangeCursor : Cursor {
                 }
                 advance_segment();
             }
+        }
+    }
+};
+
+// Contiguous sublist exchange (selector/list_kernel/sublist_swap.rs:13-330).  A segment cursor walks
+// (start, size) of one entity; the move stream pairs every first segment with the segments of the
+// same entity that start at or after its end, then with every segment of the later entities.
+struct SublistSegmentCursor {
+    size_t entity = 0, len = 0, min_size = 1, max_size = 3, desc = 0;
+    const MoveStreamContext* ctx = nullptr;
+    size_t start_offset = 0, size_offset = 0, size_count = 0, cur_start = 0;
+    bool has_start = false;
+    bool next(size_t& start, size_t& end) {  // sublist_swap.rs:57-101
+        if (len < min_size) return false;
+        for (;;) {
+            if (has_start) {
+                if (size_offset < size_count) {
+                    size_t size = min_size + ctx->selection_index(size_offset, size_count,
+                                                                  0x5B1575A090000003ULL ^ (uint64_t)entity ^ (uint64_t)cur_start);
+                    ++size_offset;
+                    start = cur_start;
+                    end = cur_start + size;
+                    return true;
+                }
+                has_start = false;
+            }
+            if (start_offset >= len) return false;
+            size_t st = ctx->selection_index(start_offset, len, 0x5B1575A090000002ULL ^ (uint64_t)entity ^ (uint64_t)desc);
+            ++start_offset;
+            size_t max_valid = std::min(max_size, len - st);
+            if (max_valid < min_size) continue;
+            has_start = true;
+            cur_start = st;
+            size_count = max_valid - min_size + 1;
+            size_offset = 0;
+        }
+    }
+};
+
+struct SublistSwapCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x5B1575A090000001ULL;
+    size_t desc, min_size, max_size;
+    MoveStreamContext ctx;
+    std::vector<size_t> entities, route_lens;
+    size_t first_idx = 0, second_idx = 0;
+    SublistSegmentCursor first_segments, second_segments;
+    bool have_first_cursor = false, have_first = false, have_second_cursor = false;
+    size_t fs = 0, fe = 0;
+
+    SublistSwapCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c, size_t mn, size_t mx)
+        : desc(slot.descriptor_index), min_size(mn), max_size(mx), ctx(c) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    SublistSegmentCursor segment_cursor(size_t idx) const {
+        SublistSegmentCursor sc;
+        sc.entity = entities[idx];
+        sc.len = route_lens[idx];
+        sc.min_size = min_size;
+        sc.max_size = max_size;
+        sc.desc = desc;
+        sc.ctx = &ctx;
+        return sc;
+    }
+    bool next_first() {  // next_first_segment
+        for (;;) {
+            if (first_idx >= entities.size()) return false;
+            if (!have_first_cursor) {
+                first_segments = segment_cursor(first_idx);
+                have_first_cursor = true;
+            }
+            if (first_segments.next(fs, fe)) {
+                have_first = true;
+                second_idx = first_idx;
+                have_second_cursor = false;
+                return true;
+            }
+            ++first_idx;
+            have_first_cursor = false;
+            have_first = false;
+            second_idx = first_idx;
+            have_second_cursor = false;
+        }
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (first_idx >= entities.size()) return false;
+            if (!have_first && !next_first()) return false;
+            size_t first_entity = entities[first_idx];
+            if (second_idx < first_idx) {
+                second_idx = first_idx;
+                have_second_cursor = false;
+            }
+            while (second_idx < entities.size()) {
+                size_t second_entity = entities[second_idx];
+                if (!have_second_cursor) {
+                    second_segments = segment_cursor(second_idx);
+                    have_second_cursor = true;
+                }
+                size_t ss, se;
+                while (second_segments.next(ss, se)) {
+                    if (first_idx == second_idx) {
+                        if (ss < fe) continue;
+                        if (fs == ss && fe == se) continue;
+                    }
+                    out = make_list_move(Move::SublistSwap, desc, first_entity, fs, second_entity, ss);
+                    out.to_value = (int64_t)((fe - fs) | ((se - ss) << 16));
+                    return true;
+                }
+                ++second_idx;
+                have_second_cursor = false;
+            }
+            have_first = false;
+            second_idx = first_idx;
+            have_second_cursor = false;
         }
     }
 };

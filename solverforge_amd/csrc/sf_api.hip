@@ -295,7 +295,7 @@ int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32
 int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32_t min_size, int32_t max_size) {
     if (!ctx) return SF_ERR_INVALID;
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
-    if (kind != SF_SEL_SUBLIST_CHANGE) return fail(ctx, SF_ERR_UNSUPPORTED, "sublist selector kind");
+    if (kind != SF_SEL_SUBLIST_CHANGE && kind != SF_SEL_SUBLIST_SWAP) return fail(ctx, SF_ERR_UNSUPPORTED, "sublist selector kind");
     if (min_size < 1 || max_size < min_size || max_size > 15) return fail(ctx, SF_ERR_INVALID, "sublist sizes must satisfy 1 <= min <= max <= 15");
     SelectorSpec s{kind, d, var, 0, -1};
     s.min_size = min_size;
@@ -662,7 +662,7 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
     int rc = alloc_search(ctx);
     if (rc) return rc;
-    const bool list_move = mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_SUBLIST_CHANGE;
+    const bool list_move = mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_SUBLIST_SWAP;
     if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
     if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");
     if (list_move) {
@@ -670,6 +670,9 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
             return fail(ctx, SF_ERR_INVALID, "move out of range");
         if (mv->kind == SF_MOVE_SUBLIST_CHANGE && (mv->value <= mv->a_pos || mv->value - mv->a_pos > 255))
             return fail(ctx, SF_ERR_INVALID, "sublist move: value must be the segment end (segment of 1..255 elements)");
+        if (mv->kind == SF_MOVE_SUBLIST_SWAP && (mv->value <= 0 || (mv->value & 0xFFFF) == 0 || (mv->value & 0xFFFF) > 255 ||
+                                                 (mv->value >> 16) == 0 || (mv->value >> 16) > 255))
+            return fail(ctx, SF_ERR_INVALID, "sublist swap: value packs the two segment sizes (1..255 each)");
         hipLaunchKernelGGL(k_list_apply, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, mv->kind,
                            (uint32_t)mv->a, (uint32_t)mv->a_pos, (uint32_t)mv->b, (uint32_t)mv->b_pos,
                            (uint32_t)(mv->value > 0 ? mv->value : 0), ctx->d_ok);
@@ -768,7 +771,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
 static bool has_plain_list_leaves(sf_ctx* ctx) {
     for (auto& s : ctx->selectors)
         if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP || s.kind == SF_SEL_LIST_REVERSE ||
-                                         s.kind == SF_SEL_SUBLIST_CHANGE))
+                                         s.kind == SF_SEL_SUBLIST_CHANGE || s.kind == SF_SEL_SUBLIST_SWAP))
             return true;
     return false;
 }
@@ -778,7 +781,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // default-policy declaration order: list rules first, then scalar change, scalar swap
     // (runtime/compiler/default_local_search/policy.rs:104-108)
     for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
-                     SF_SEL_LIST_REVERSE, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+                     SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
         for (auto& s : ctx->selectors) {
             const bool is_list = kind != SF_SEL_SCALAR_CHANGE && kind != SF_SEL_SCALAR_SWAP;
             if (s.kind != kind) continue;

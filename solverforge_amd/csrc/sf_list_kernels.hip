@@ -385,6 +385,58 @@ __device__ __forceinline__ ListDelta eval_sublist_change(const ListModel& m, con
     return r;
 }
 
+// SublistSwapMove: segment [fs, fe) of list a <-> segment [ss, se) of list b, each keeping its order
+// (move/list_kernel/sublist_swap.rs:17-160).
+template <class VT>
+__device__ __forceinline__ ListDelta eval_sublist_swap(const ListModel& m, const VT* visits, const uint32_t* off,
+                                                       const int64_t* load, uint32_t a, uint32_t fs, uint32_t fe, uint32_t b,
+                                                       uint32_t ss, uint32_t se) {
+    ListDelta r{0, 0, false};
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    const uint32_t ob = off[b], lb = off[b + 1] - ob;
+    const bool intra = a == b;
+    if (!(fs < fe && ss < se && fe <= la && se <= lb)) return r;
+    if (intra && fs < se && ss < fe) return r;  // overlapping ranges
+    r.doable = true;
+    if (intra && ss < fs) {  // the early segment first (the exchange is symmetric)
+        uint32_t t = fs;
+        fs = ss;
+        ss = t;
+        t = fe;
+        fe = se;
+        se = t;
+    }
+    const uint32_t depot = (uint32_t)m.depot;
+    if (m.dist_level >= 0) {
+        const uint32_t A0 = visits[oa + fs], Al = visits[oa + fe - 1], B0 = visits[ob + ss], Bl = visits[ob + se - 1];
+        const uint32_t pa = fs > 0 ? (uint32_t)visits[oa + fs - 1] : depot;
+        const uint32_t nb = se < lb ? (uint32_t)visits[ob + se] : depot;
+        int64_t acc;
+        if (intra && fe == ss) {  // adjacent: pa A B nb -> pa B A nb
+            acc = wsub(wadd(wadd(dist_cost(m.mat, m.dim, pa, B0), dist_cost(m.mat, m.dim, Bl, A0)), dist_cost(m.mat, m.dim, Al, nb)),
+                       wadd(wadd(dist_cost(m.mat, m.dim, pa, A0), dist_cost(m.mat, m.dim, Al, B0)), dist_cost(m.mat, m.dim, Bl, nb)));
+        } else {
+            const uint32_t na = fe < la ? (uint32_t)visits[oa + fe] : depot;
+            const uint32_t pb = ss > 0 ? (uint32_t)visits[ob + ss - 1] : depot;
+            acc = wsub(wadd(dist_cost(m.mat, m.dim, pa, B0), dist_cost(m.mat, m.dim, Bl, na)),
+                       wadd(dist_cost(m.mat, m.dim, pa, A0), dist_cost(m.mat, m.dim, Al, na)));
+            acc = wadd(acc, wsub(wadd(dist_cost(m.mat, m.dim, pb, A0), dist_cost(m.mat, m.dim, Al, nb)),
+                                 wadd(dist_cost(m.mat, m.dim, pb, B0), dist_cost(m.mat, m.dim, Bl, nb))));
+        }
+        r.d_dist = acc;
+    }
+    if (m.cap_level >= 0 && !intra) {
+        int64_t da = 0, db = 0;
+        for (uint32_t t = fs; t < fe; ++t) da = wadd(da, (int64_t)m.demand[visits[oa + t]]);
+        for (uint32_t t = ss; t < se; ++t) db = wadd(db, (int64_t)m.demand[visits[ob + t]]);
+        const int64_t la0 = load[a], lb0 = load[b];
+        const int64_t before = wadd(over_cap(la0, m.capacity), over_cap(lb0, m.capacity));
+        const int64_t after = wadd(over_cap(wadd(wsub(la0, da), db), m.capacity), over_cap(wadd(wsub(lb0, db), da), m.capacity));
+        r.d_cap = wsub(after, before);
+    }
+    return r;
+}
+
 // Relocates the flat range [P, P+z) so that it starts where flat position Q was (Q <= P or Q >= P+z),
 // shifting the elements in between; `sync` separates the read and write halves of every chunk
 // (wave_sync for one wavefront on LDS, __syncthreads for a workgroup on global memory).
@@ -514,7 +566,7 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
                                                              int32_t* out_doable, int skip_foreign) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 5)) return;  // a scalar move of a mixed model
+    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 6)) return;  // a scalar move of a mixed model
     const uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
     const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
     const int64_t* load = m.load + (size_t)replica * m.V;
@@ -530,6 +582,9 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
             d = eval_list_swap(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);
         else if (kind == 4 && mv[1] == mv[3])
             d = eval_list_reverse(m, visits, off, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[4]);
+        else if (kind == 6 && mv[5] >= 0)
+            d = eval_sublist_swap(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[2] + ((uint32_t)mv[5] & 0xFFFFu),
+                                  (uint32_t)mv[3], (uint32_t)mv[4], (uint32_t)mv[4] + ((uint32_t)mv[5] >> 16));
         else if (kind == 5 && mv[5] >= 0)
             d = eval_sublist_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[5], (uint32_t)mv[3], (uint32_t)mv[4]);
     }
@@ -593,6 +648,28 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
                 load[b] = wadd(load[b], dx);
             }
         }
+    } else if (kind == 6) {  // sublist swap: [i, i + (ext & 0xFFFF)) of a <-> [j, j + (ext >> 16)) of b
+        const uint32_t za = ext & 0xFFFFu, zb = ext >> 16;
+        const uint32_t PA = off[a] + i, PB = off[b] + j;
+        const bool a_first = PA < PB;  // X = the segment at the lower flat position
+        const uint32_t PX = a_first ? PA : PB, zx = a_first ? za : zb, PY = a_first ? PB : PA, zy = a_first ? zb : za;
+        const uint32_t ox = a_first ? a : b, oy = a_first ? b : a;
+        int64_t da = 0, db = 0;
+        if (threadIdx.x == 0 && a != b && m.demand) {
+            for (uint32_t t = 0; t < za; ++t) da = wadd(da, (int64_t)m.demand[visits[PA + t]]);
+            for (uint32_t t = 0; t < zb; ++t) db = wadd(db, (int64_t)m.demand[visits[PB + t]]);
+        }
+        __syncthreads();
+        relocate_flat_segment(visits, PY, zy, PX, threadIdx.x, blockDim.x, [] { __syncthreads(); });            // Y X mid
+        relocate_flat_segment(visits, PX + zy, zx, PY + zy, threadIdx.x, blockDim.x, [] { __syncthreads(); });  // Y mid X
+        if (a != b) {
+            for (uint32_t rr = threadIdx.x; rr <= (uint32_t)m.V; rr += blockDim.x)
+                if (rr > ox && rr <= oy) off[rr] = off[rr] + zy - zx;
+            if (threadIdx.x == 0 && m.demand) {
+                load[a] = wadd(wsub(load[a], da), db);
+                load[b] = wadd(wsub(load[b], db), da);
+            }
+        }
     } else if (kind == 5) {  // sublist change: segment [i, ext) of list a -> list b at j
         const uint32_t z = ext - i, P = off[a] + i;
         const uint32_t Q = a != b ? off[b] + j : (j <= i ? off[a] + j : off[a] + j + z);
@@ -645,7 +722,8 @@ __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, in
         s_d = kind == 2   ? eval_list_change(m, visits, off, load, a, i, b, j)
               : kind == 3 ? eval_list_swap(m, visits, off, load, a, i, b, j)
               : kind == 4 ? eval_list_reverse(m, visits, off, a, i, j)
-                          : eval_sublist_change(m, visits, off, load, a, i, ext, b, j);
+              : kind == 5 ? eval_sublist_change(m, visits, off, load, a, i, ext, b, j)
+                          : eval_sublist_swap(m, visits, off, load, a, i, i + (ext & 0xFFFFu), b, j, j + (ext >> 16));
     }
     __syncthreads();
     ListDelta d = s_d;

@@ -211,6 +211,28 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
                 load[b] = wadd(load[b], dx);
             }
         }
+    } else if (kind == 6) {  // sublist swap: [i, i + (ext & 0xFFFF)) of a <-> [j, j + (ext >> 16)) of b
+        const uint32_t za = ext & 0xFFFFu, zb = ext >> 16;
+        const uint32_t PA = off[a] + i, PB = off[b] + j;
+        const bool a_first = PA < PB;
+        const uint32_t PX = a_first ? PA : PB, zx = a_first ? za : zb, PY = a_first ? PB : PA, zy = a_first ? zb : za;
+        const uint32_t ox = a_first ? a : b, oy = a_first ? b : a;
+        int64_t da = 0, db = 0;
+        if (a != b && m.demand) {
+            for (uint32_t t = 0; t < za; ++t) da = wadd(da, (int64_t)m.demand[visits[PA + t]]);
+            for (uint32_t t = 0; t < zb; ++t) db = wadd(db, (int64_t)m.demand[visits[PB + t]]);
+        }
+        wave_sync();
+        relocate_flat_segment(visits, PY, zy, PX, lane, 64u, [] { wave_sync(); });            // Y X mid
+        relocate_flat_segment(visits, PX + zy, zx, PY + zy, lane, 64u, [] { wave_sync(); });  // Y mid X
+        if (a != b) {
+            for (uint32_t rr = lane; rr <= (uint32_t)m.V; rr += 64)
+                if (rr > ox && rr <= oy) off[rr] = off[rr] + zy - zx;
+            if (lane == 0 && m.demand) {
+                load[a] = wadd(wsub(load[a], da), db);
+                load[b] = wadd(wsub(load[b], db), da);
+            }
+        }
     } else if (kind == 5) {  // sublist change: segment [i, ext) of list a -> list b at j
         const uint32_t z = ext - i, P = off[a] + i;
         const uint32_t Q = a != b ? off[b] + j : (j <= i ? off[a] + j : off[a] + j + z);

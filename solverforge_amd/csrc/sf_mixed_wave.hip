@@ -26,7 +26,7 @@
 
 namespace sf {
 
-constexpr int GL = 6;          // max leaves of the generic union
+constexpr int GL = 8;          // max leaves of the generic union
 constexpr uint32_t GRC = 128;  // ring capacity per leaf
 
 constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
@@ -39,11 +39,13 @@ constexpr uint64_t SALT_LR_END = 0x11572A0700000003ULL;
 constexpr uint64_t SALT_SC_ENTITY = 0x5B157C4A46E00001ULL, SALT_SC_START = 0x5B157C4A46E00002ULL;  // sublist_change.rs:22-28
 constexpr uint64_t SALT_SC_SIZE = 0x5B157C4A46E00003ULL, SALT_SC_INTRA = 0x5B157C4A46E00004ULL;
 constexpr uint64_t SALT_SC_INTER = 0x5B157C4A46E00005ULL;
+constexpr uint64_t SALT_SS_ENTITY = 0x5B1575A090000001ULL, SALT_SS_START = 0x5B1575A090000002ULL;  // sublist_swap.rs:74,89,104
+constexpr uint64_t SALT_SS_SIZE = 0x5B1575A090000003ULL;
 
 struct GLeaves {
     int32_t n;
     int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap, 64 list reverse,
-                        // 16 / 32 nearby change / swap, 128 sublist change
+                        // 16 / 32 nearby change / swap, 128 sublist change, 256 sublist swap
     int32_t list_desc;  // descriptor_index of the list class (stream salts)
     int32_t max_nearby[GL];  // nearby leaves (kinds 16 / 32)
     int32_t has_nearby;
@@ -92,6 +94,8 @@ struct GCarve {
 //  list reverse:  a = entity rank, b = start offset, e = end offset
 //  sublist change: a = source rank, b = segment start offset, f = segment size offset, c = stage,
 //                 d = destination rank, e = destination position offset
+//  sublist swap:  a = first entity rank, b / f = first segment start / size offset, d = second entity rank,
+//                 e = second segment start offset window
 //  nearby change / swap: a = entity rank, b = offset in the entity's list, c / d = rank / offset base the
 //                 leaf's position vector holds, e = sources left
 struct GGen {
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
 
         // entity permutations (selection_index_without_replacement) of the four streams
         uint32_t sc_st = 0, sc_sd = 1, ss_st = 0, ss_sd = 1, lc_st = 0, lc_sd = 1, ls_st = 0, ls_sd = 1, lr_st = 0, lr_sd = 1;
-        uint32_t sb_st = 0, sb_sd = 1;  // sublist change entity permutation
+        uint32_t sb_st = 0, sb_sd = 1, sw_st = 0, sw_sd = 1;  // sublist change / swap entity permutations
         if (has_scalar) {
             ctx.perm_params(ns, SALT_SCALAR_CHANGE_ENTITY ^ identity, sc_st, sc_sd);
             ctx.perm_params(ns, (SALT_SCALAR_SWAP_LEFT ^ identity) ^ OFFSET_MIX, ss_st, ss_sd);
@@ -215,11 +219,14 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             ctx.perm_params((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd);
             ctx.perm_params((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd);
             ctx.perm_params((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd);
+            ctx.perm_params((uint32_t)V, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd);
         }
         sc_st = uni(sc_st), sc_sd = uni(sc_sd), ss_st = uni(ss_st), ss_sd = uni(ss_sd);
         lc_st = uni(lc_st), lc_sd = uni(lc_sd), ls_st = uni(ls_st), ls_sd = uni(ls_sd);
         lr_st = uni(lr_st), lr_sd = uni(lr_sd);
         sb_st = uni(sb_st), sb_sd = uni(sb_sd);
+        sw_st = uni(sw_st), sw_sd = uni(sw_sd);
+        auto sw_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)sw_st + (uint64_t)rank * sw_sd) % (uint32_t)V); };
         auto sb_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)sb_st + (uint64_t)rank * sb_sd) % (uint32_t)V); };
         auto lr_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lr_st + (uint64_t)rank * lr_sd) % (uint32_t)V); };
         auto lc_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lc_st + (uint64_t)rank * lc_sd) % (uint32_t)V); };
@@ -417,6 +424,71 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                 g.e = 0;
                             }
                         }
+                    } else if (kind == 256) {  // ---- sublist swap (list_kernel/sublist_swap.rs:57-101,228-300) ----
+                        const uint32_t mn = (uint32_t)gl.min_size[l], mx = (uint32_t)gl.max_size[l];
+                        uint32_t fent = 0, flen = 0, fstart = 0, sc1 = 0;
+                        for (;;) {  // the current first segment
+                            if (g.a >= (uint32_t)V) break;
+                            fent = sw_ent(g.a);
+                            flen = rlen(fent);
+                            if (flen < mn || g.b >= flen) {
+                                g.a += 1;
+                                g.b = 0;
+                                g.f = 0;
+                                g.d = g.a;
+                                g.e = 0;
+                                continue;
+                            }
+                            fstart = ctx.selection_index(g.b, flen, SALT_SS_START ^ (uint64_t)fent ^ ldesc);
+                            const uint32_t max_valid = mx < flen - fstart ? mx : flen - fstart;
+                            sc1 = max_valid >= mn ? max_valid - mn + 1 : 0u;
+                            if (g.f >= sc1) {  // no (more) sizes at this start
+                                g.b += 1;
+                                g.f = 0;
+                                g.d = g.a;
+                                g.e = 0;
+                                continue;
+                            }
+                            break;
+                        }
+                        if (g.a >= (uint32_t)V) {
+                            g.done = 1;
+                            break;
+                        }
+                        const uint32_t fsize = mn + ctx.selection_index(g.f, sc1, SALT_SS_SIZE ^ (uint64_t)fent ^ (uint64_t)fstart);
+                        const uint32_t fend = fstart + fsize;
+                        if (g.d < g.a) g.d = g.a;
+                        if (g.d >= (uint32_t)V) {  // every partner of this first segment is out: next first segment
+                            g.f += 1;
+                            g.d = g.a;
+                            g.e = 0;
+                            st_sources -= 1;
+                            continue;
+                        }
+                        const uint32_t sent = sw_ent(g.d);
+                        const uint32_t slen = rlen(sent);
+                        if (slen < mn || g.e >= slen) {
+                            g.d += 1;
+                            g.e = 0;
+                            st_sources -= 1;
+                            continue;
+                        }
+                        // lanes = (second start offset, size offset) pairs in cursor order
+                        const uint32_t S = mx - mn + 1, per = 64u / S;
+                        const uint32_t sl = lane / S, q = lane % S;
+                        const uint32_t so = g.e + sl;
+                        if (sl < per && so < slen) {
+                            const uint32_t sstart = ctx.selection_index(so, slen, SALT_SS_START ^ (uint64_t)sent ^ ldesc);
+                            const uint32_t mv2 = mx < slen - sstart ? mx : slen - sstart;
+                            if (mv2 >= mn && q < mv2 - mn + 1) {
+                                const uint32_t ssize = mn + ctx.selection_index(q, mv2 - mn + 1, SALT_SS_SIZE ^ (uint64_t)sent ^ (uint64_t)sstart);
+                                keep = !(g.d == g.a && (sstart < fend || (fstart == sstart && fend == sstart + ssize)));
+                                w0 = (fent << 16) | fstart;
+                                w1 = (sent << 16) | sstart;
+                                wx = fsize | (ssize << 4);
+                            }
+                        }
+                        g.e += per;
                     } else if (kind == 128) {  // ---- sublist change / Or-opt (list_kernel/sublist_change.rs:109-266) ----
                         const uint32_t mn = (uint32_t)gl.min_size[l], mx = (uint32_t)gl.max_size[l];
                         uint32_t ent = 0, len = 0, start = 0, sc = 0;
@@ -762,7 +834,10 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
                     } else {
-                        const ListDelta d = my_kind == 128
+                        const ListDelta d = my_kind == 256
+                                                ? eval_sublist_swap(lm, s_visits, s_off, s_load, m0 >> 16, m0 & 0xFFFFu, (m0 & 0xFFFFu) + (mx_ & 15u),
+                                                                    m1 >> 16, m1 & 0xFFFFu, (m1 & 0xFFFFu) + (mx_ >> 4))
+                                            : my_kind == 128
                                                 ? eval_sublist_change(lm, s_visits, s_off, s_load, m0 >> 16, m0 & 0xFFFFu, (m0 & 0xFFFFu) + mx_,
                                                                       m1 >> 16, m1 & 0xFFFFu)
                                             : my_kind == 64
@@ -851,12 +926,12 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
                         } else {
-                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : (my_kind == 64 ? 4 : 5));
+                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : (my_kind == 64 ? 4 : (my_kind == 128 ? 5 : 6)));
                             tm[1] = (int32_t)(m0 >> 16);
                             tm[2] = (int32_t)(m0 & 0xFFFFu);
                             tm[3] = (int32_t)(m1 >> 16);
                             tm[4] = (int32_t)(m1 & 0xFFFFu);
-                            tm[5] = my_kind == 128 ? (int32_t)((m0 & 0xFFFFu) + mx_) : -1;
+                            tm[5] = my_kind == 128 ? (int32_t)((m0 & 0xFFFFu) + mx_) : (my_kind == 256 ? (int32_t)((mx_ & 15u) | ((mx_ >> 4) << 16)) : -1);
                         }
                         for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * L + kk] = doable ? sc.v[kk] : 0;
                         p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
@@ -901,16 +976,18 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             } else {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
-                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : 5));
+                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : 6)));
                     p.trace_applied[2] = (int32_t)(a >> 16);
                     p.trace_applied[3] = (int32_t)(a & 0xFFFFu);
                     p.trace_applied[4] = (int32_t)(b >> 16);
                     p.trace_applied[5] = (int32_t)(b & 0xFFFFu);
-                    p.trace_applied[6] = kind == 128 ? (int32_t)((a & 0xFFFFu) + uni(best_x)) : -1;
+                    p.trace_applied[6] = kind == 128 ? (int32_t)((a & 0xFFFFu) + uni(best_x))
+                                                      : (kind == 256 ? (int32_t)((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16)) : -1);
                 }
                 apply_list_move_wave(lm, s_visits, s_off, s_load,
-                                     (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : 5)), a >> 16,
-                                     a & 0xFFFFu, b >> 16, b & 0xFFFFu, (a & 0xFFFFu) + uni(best_x));
+                                     (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : 6))),
+                                     a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu,
+                                     kind == 256 ? ((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16)) : (a & 0xFFFFu) + uni(best_x));
                 if (has_nearby) {  // refresh node -> (route, position) for the touched routes
                     const uint32_t ra_ = a >> 16, rb_ = b >> 16;
                     const uint32_t oa = s_off[ra_], la = s_off[ra_ + 1] - oa;

@@ -16,7 +16,7 @@ from ._lib import MOVE_DTYPE, SolverConfigStruct, SolverForgeError, StatsStruct,
 
 
 class MoveKind:
-    CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE = 0, 1, 2, 3, 4, 5
+    CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 0, 1, 2, 3, 4, 5, 6
 
 
 class SelectionOrder:  # solverforge_config::SelectionOrder
@@ -43,7 +43,7 @@ class ConstraintKind:
 
 class SelectorKind:
     SCALAR_CHANGE, SCALAR_SWAP, LIST_CHANGE, LIST_SWAP = 1, 2, 4, 8
-    NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE = 16, 32, 64, 128
+    NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 16, 32, 64, 128, 256
 
 
 @dataclass

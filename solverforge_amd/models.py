@@ -39,6 +39,8 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
         d.add_selector(SelectorKind.LIST_REVERSE, 0)
     if "sublist_change" in leaves:
         d.add_sublist_selector(SelectorKind.SUBLIST_CHANGE, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
+    if "sublist_swap" in leaves:
+        d.add_sublist_selector(SelectorKind.SUBLIST_SWAP, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
     return d
 
 

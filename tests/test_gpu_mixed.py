@@ -375,3 +375,74 @@ def test_cvrp_sublist_change_leaf(oracle, leaves, sizes):
     assert d.working_lists(0, 0) == o.get_lists(0)
     assert (d.calculate_score()[0] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("leaves,sizes", [
+    (("sublist_swap",), (1, 3)),
+    (("sublist_swap",), (2, 2)),
+    (("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse"), (1, 3)),
+])
+def test_cvrp_sublist_swap_leaf(oracle, leaves, sizes):
+    """Contiguous sublist exchange (segments of different sizes, intra and inter list): stream order,
+    trial scores, committed moves (offsets shift by the size difference), traced steps; alone and in
+    the 5-leaf union nearby change + nearby swap + sublist change + sublist swap + reverse — five of
+    the seven leaves of the reference's default list policy."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(34, 5, 40, seed=15)
+    p["routes"][2] = []
+    p["routes"][3] = p["routes"][3][:1]
+    seen = set()
+    p["routes"][0] = p["routes"][0] + [c for c in range(1, 35)]
+    p["routes"] = [[c for c in rt if not (c in seen or seen.add(c))] for rt in p["routes"]]
+    bitmap = {"nearby_change": oracle.LEAF_NEARBY_LIST_CHANGE, "nearby_swap": oracle.LEAF_NEARBY_LIST_SWAP,
+              "sublist_change": oracle.LEAF_SUBLIST_CHANGE, "sublist_swap": oracle.LEAF_SUBLIST_SWAP,
+              "list_reverse": oracle.LEAF_LIST_REVERSE}
+    bits = 0
+    for name in leaves:
+        bits |= bitmap[name]
+    d = sfa.build_cvrp(p, leaves=leaves, max_nearby=6, sublist_sizes=sizes)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.set_sublist_sizes(*sizes)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    for order in (0, 3, 4):
+        o.configure(leaves=bits, selection_order=order, max_nearby=6, random_seed=7)
+        gm, gs, gd = d.open_cursor(11, 777, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 11, 777, order)
+        assert len(gm) == len(om) > 0
+        seg = om["kind"] >= 5
+        assert (_t(gm)[:, :5] == _t(om)[:, :5]).all()
+        assert (gm["value"][seg] == om["value"][seg]).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+        es, ed = d.evaluate_moves(om)
+        assert (ed == od).all() and (es == os_[:, :2]).all()
+    o.configure(leaves=bits, max_nearby=6, random_seed=7, la_size=5, limit=40)
+    d.configure(sfa.SolverConfig(random_seed=7, late_acceptance_size=5, accepted_count_limit=40))
+    rng = np.random.default_rng(10)
+    for it in range(10):  # committed exchanges through sf_apply
+        sm = o.enumerate(oracle.LEAF_SUBLIST_SWAP, it, 50 + it, 3)
+        mv = sm[rng.integers(len(sm))]
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert d.working_lists(0, 0) == o.get_lists(0)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(12):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert (_t(gm)[:, :5] == _t(om)[:, :5]).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv)[:5] == tuple(omv)[:5], step
+            if omv["kind"] >= 5:
+                assert gmv["value"] == omv["value"]
+        assert d.working_lists(0, 0) == o.get_lists(0), step
+    d.solve_steps(40)
+    o.steps(40)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()

@@ -117,3 +117,34 @@ def test_sublist_change_canonical_order_and_count(oracle):
     m = oracle.Model.list_toy(routes)
     m.set_sublist_sizes(c["min"], c["max"])
     assert m.enumerate_count(oracle.LEAF_SUBLIST_CHANGE) == c["sublist_change"]
+
+
+def test_sublist_swap_canonical_order_and_count(oracle):
+    g = GOLD["sublist_swap_order"]
+    m = oracle.Model.list_toy(g["routes"])
+    m.set_sublist_sizes(g["min"], g["max"])
+    mv = m.enumerate(oracle.LEAF_SUBLIST_SWAP)
+    got = [[int(x["a"]), int(x["a_pos"]), int(x["a_pos"]) + (int(x["value"]) & 0xFFFF), int(x["b"]), int(x["b_pos"]),
+            int(x["b_pos"]) + (int(x["value"]) >> 16)] for x in mv]
+    assert got == g["expected"]
+    c = GOLD["candidate_counts_sublist"]
+    routes = [[v * 1000 + i for i in range(c["visits_per_vehicle"])] for v in range(c["vehicles"])]
+    m = oracle.Model.list_toy(routes)
+    m.set_sublist_sizes(c["min"], c["max"])
+    assert m.enumerate_count(oracle.LEAF_SUBLIST_SWAP) == c["sublist_swap"]
+
+
+def test_oracle_incremental_equals_fresh_with_segment_leaves(oracle):
+    """FullAssert on the oracle itself (director/tests/benchmarks.rs:116-182 style): do / score / undo of
+    reversals, sublist relocations and sublist exchanges leaves the committed score == full recalculation."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(28, 4, 35, seed=21)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    bits = oracle.LEAF_LIST_REVERSE | oracle.LEAF_SUBLIST_CHANGE | oracle.LEAF_SUBLIST_SWAP
+    o.configure(leaves=bits, random_seed=1, la_size=5, limit=25)
+    o.phase_start()
+    for _ in range(12):
+        o.steps(5)
+        assert (o.score() == o.fresh_score()).all()
+        assert sorted(c for r in o.get_lists(0) for c in r) == list(range(1, 29))
