@@ -741,7 +741,67 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                 int nlive = 0;
 #pragma unroll
                 for (int l = 0; l < GL; ++l) nlive += !ex[l];
-                while (nvalid < 64 && nlive > 0) {
+                // Fast path: with equal weights the smooth weighted round-robin is a plain cycle over the
+                // live children in rotated order whenever all their running weights are equal (true at the
+                // start of every step and after every whole cycle).  Lay out whole cycles directly; the
+                // pull-by-pull simulation below handles partial cycles, exhaustion and refills.
+                if (nl > 1 && nlive > 1) {
+                    bool aligned = true;
+                    int64_t w0 = 0;
+                    bool first = true;
+#pragma unroll
+                    for (int l = 0; l < GL; ++l)
+                        if (!ex[l]) {
+                            if (first) {
+                                w0 = wcur[l];
+                                first = false;
+                            } else if (wcur[l] != w0)
+                                aligned = false;
+                        }
+                    if (aligned) {
+                        // my pull t = lane: cycle t / nlive, child = (t % nlive)-th live leaf in rotated order
+                        const uint32_t cyc = lane / (uint32_t)nlive, slot = lane % (uint32_t)nlive;
+                        uint32_t leaf = 0, seen = 0;
+                        bool found = false;
+                        for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
+                            const uint32_t i = (u_off + pos * u_str) % (uint32_t)nl;
+                            bool live_i = false;
+#pragma unroll
+                            for (int l = 0; l < GL; ++l)
+                                if ((uint32_t)l == i) live_i = !ex[l];
+                            if (live_i) {
+                                if (!found && seen == slot) {
+                                    leaf = i;
+                                    found = true;
+                                }
+                                seen += 1;
+                            }
+                        }
+                        uint32_t hd = 0, tlq = 0;
+#pragma unroll
+                        for (int l = 0; l < GL; ++l)
+                            if (leaf == (uint32_t)l) {
+                                hd = head[l];
+                                tlq = tail[l];
+                            }
+                        const bool ok = (int32_t)(tlq - (hd + cyc)) > 0;
+                        const uint64_t okm = __ballot(ok);
+                        const uint32_t upto = okm == ~0ULL ? 64u : (uint32_t)(__ffsll((unsigned long long)~okm) - 1);
+                        const uint32_t cycles = upto / (uint32_t)nlive;  // whole cycles only: the state stays aligned
+                        if (cycles > 0) {
+                            nvalid = cycles * (uint32_t)nlive;
+                            if (lane < nvalid) {
+                                my_leaf = leaf;
+                                my_idx = hd + cyc;
+                            }
+#pragma unroll
+                            for (int l = 0; l < GL; ++l)
+                                if (!ex[l]) taken[l] = cycles;  // running weights: +nvalid - cycles * nlive = 0
+                        }
+                    }
+                }
+                const bool fast_done = nvalid > 0;
+                while (!fast_done && nvalid < 64 && nlive > 0) {
                     int sel = -1;
                     int64_t selw = 0;
                     if (nl == 1) {
