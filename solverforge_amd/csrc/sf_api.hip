@@ -524,29 +524,15 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
 }
 static int launch_list_wave(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
     if (!wave_engine_possible(ctx)) return fail(ctx, SF_ERR_UNSUPPORTED, "wave engine cannot run this model (needs a nearby matrix meter, <= 65535 elements, LDS slice <= 160 KiB)");
-    switch (ctx->levels) {
-        case 1:
-            return trace ? launch_list_wave_t<1, true>(ctx, p, grid) : launch_list_wave_t<1, false>(ctx, p, grid);
-        case 2:
-            return trace ? launch_list_wave_t<2, true>(ctx, p, grid) : launch_list_wave_t<2, false>(ctx, p, grid);
-        case 3:
-            return trace ? launch_list_wave_t<3, true>(ctx, p, grid) : launch_list_wave_t<3, false>(ctx, p, grid);
-        default:
-            return trace ? launch_list_wave_t<4, true>(ctx, p, grid) : launch_list_wave_t<4, false>(ctx, p, grid);
-    }
+    // kernels are instantiated for 2 and 4 score levels; 1- and 3-level models run with one padded
+    // (always zero) least-significant level, which never changes a lexicographic comparison
+    if (ctx->levels <= 2) return trace ? launch_list_wave_t<2, true>(ctx, p, grid) : launch_list_wave_t<2, false>(ctx, p, grid);
+    return trace ? launch_list_wave_t<4, true>(ctx, p, grid) : launch_list_wave_t<4, false>(ctx, p, grid);
 }
 static int launch_list_search(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
     if (use_wave_engine(ctx)) return launch_list_wave(ctx, p, grid, trace);
-    switch (ctx->levels) {
-        case 1:
-            return trace ? launch_list_search_t<1, true>(ctx, p, grid) : launch_list_search_t<1, false>(ctx, p, grid);
-        case 2:
-            return trace ? launch_list_search_t<2, true>(ctx, p, grid) : launch_list_search_t<2, false>(ctx, p, grid);
-        case 3:
-            return trace ? launch_list_search_t<3, true>(ctx, p, grid) : launch_list_search_t<3, false>(ctx, p, grid);
-        default:
-            return trace ? launch_list_search_t<4, true>(ctx, p, grid) : launch_list_search_t<4, false>(ctx, p, grid);
-    }
+    if (ctx->levels <= 2) return trace ? launch_list_search_t<2, true>(ctx, p, grid) : launch_list_search_t<2, false>(ctx, p, grid);
+    return trace ? launch_list_search_t<4, true>(ctx, p, grid) : launch_list_search_t<4, false>(ctx, p, grid);
 }
 
 static int download_scores(sf_ctx* ctx, const int64_t* d_src4, int64_t* out) {
@@ -804,20 +790,11 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     if (ctx->has_list_model && (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536))
         return fail(ctx, SF_ERR_UNSUPPORTED, "generic engine packs list elements and positions in 16 bits");
     p.n_leaves = gl.n;
-    const bool small = !ctx->has_scalar_model || ctx->sm.n_values <= 127;
-#define SF_MIXED_CASE(LV)                                                                                      \
-    case LV:                                                                                                   \
-        if (small)                                                                                             \
-            return trace ? launch_mixed_t<LV, true, int8_t>(ctx, p, gl, grid) : launch_mixed_t<LV, false, int8_t>(ctx, p, gl, grid); \
-        return trace ? launch_mixed_t<LV, true, int16_t>(ctx, p, gl, grid) : launch_mixed_t<LV, false, int16_t>(ctx, p, gl, grid);
-    switch (ctx->levels) {
-        SF_MIXED_CASE(1)
-        SF_MIXED_CASE(2)
-        SF_MIXED_CASE(3)
-        default:
-            SF_MIXED_CASE(4)
-    }
-#undef SF_MIXED_CASE
+    // one value width (i16) and two level counts (2, 4) in the generic engine: fewer instantiations
+    gl.levels = ctx->levels;
+    if (ctx->levels <= 2)
+        return trace ? launch_mixed_t<2, true, int16_t>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t>(ctx, p, gl, grid);
+    return trace ? launch_mixed_t<4, true, int16_t>(ctx, p, gl, grid) : launch_mixed_t<4, false, int16_t>(ctx, p, gl, grid);
 }
 
 extern "C" {

@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                             tm[3] = (int32_t)(m1 >> 16);
                             tm[4] = (int32_t)(m1 & 0xFFFFu);
                             tm[5] = -1;
-                            for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
+                            for (int kk = 0; kk < L && kk < m.levels; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
                             p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
                         }
                     }

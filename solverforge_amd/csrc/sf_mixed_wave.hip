@@ -49,6 +49,7 @@ struct GLeaves {
     int32_t list_desc;  // descriptor_index of the list class (stream salts)
     int32_t max_nearby[GL];  // nearby leaves (kinds 16 / 32)
     int32_t has_nearby;
+    int32_t levels;  // score levels of the model (the kernel is instantiated for 2 or 4)
     int32_t min_size[GL], max_size[GL];  // sublist leaves
 };
 
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             tm[4] = (int32_t)(m1 & 0xFFFFu);
                             tm[5] = my_kind == 128 ? (int32_t)((m0 & 0xFFFFu) + mx_) : (my_kind == 256 ? (int32_t)((mx_ & 15u) | ((mx_ >> 4) << 16)) : -1);
                         }
-                        for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * L + kk] = doable ? sc.v[kk] : 0;
+                        for (int kk = 0; kk < L && kk < gl.levels; ++kk) p.trace_scores[ti * gl.levels + kk] = doable ? sc.v[kk] : 0;
                         p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
                     }
                 }

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                         tm[3] = lane_change ? 0 : (int32_t)m1;
                         tm[4] = 0;
                         tm[5] = lane_change ? (int32_t)m1 : -1;
-                        for (int kk = 0; kk < L; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
+                        for (int kk = 0; kk < L && kk < m.levels; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
                         p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
                     }
                 }

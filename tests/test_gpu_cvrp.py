@@ -320,3 +320,37 @@ def test_cvrp_5000_properties(oracle):
     for r in range(2):
         routes = d.working_lists(0, r)
         assert sorted(c for rt in routes for c in rt) == list(range(1, 5001))
+
+
+def test_single_level_score_model():
+    """A SoftScore-style (1 level) list model runs on the 2-level kernels with a padded zero level:
+    incremental == full recalculation, the distance only goes down under HillClimbing, and the level-0
+    value equals the soft level of the equivalent HardSoft model."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+    from solverforge_amd.director import ConstraintKind, GpuScoreDirector, SelectorKind
+
+    p = datasets.make_cvrp(80, 6, 1000, seed=5)  # capacity never binds
+    dim = p["matrix"].shape[0]
+    d1 = GpuScoreDirector(score_levels=1, hard_levels=0, n_replicas=2)
+    d1.set_engine(_ENGINE["value"])
+    d1.add_entity_class(0, len(p["routes"]))
+    d1.add_list_variable(0, p["routes"], element_capacity=len(p["customers"]), element_id_bound=dim)
+    d1.add_fact_matrix(0, p["matrix"])
+    d1.add_constraint(ConstraintKind.ROUTE_DISTANCE, 0, fact=0, param=int(p["depot"]), level=0, weight=1)
+    d1.add_selector(SelectorKind.NEARBY_LIST_CHANGE, 0, max_nearby=10, fact_meter=0)
+    d1.add_selector(SelectorKind.NEARBY_LIST_SWAP, 0, max_nearby=10, fact_meter=0)
+    d2 = sfa.build_cvrp(p, n_replicas=2, max_nearby=10)
+    d2.set_engine(_ENGINE["value"])
+    cfg = sfa.SolverConfig(acceptor=sfa.Acceptor.HILL_CLIMBING, accepted_count_limit=8, random_seed=3)
+    for d in (d1, d2):
+        d.configure(cfg)
+    s1, s2 = d1.calculate_score(), d2.calculate_score()
+    assert s1.shape == (2, 1) and (s1[:, 0] == s2[:, 1]).all()
+    for d in (d1, d2):
+        d.phase_start()
+        d.solve_steps(60)
+    e1, e2 = d1.calculate_score(), d2.calculate_score()
+    assert (e1[:, 0] == e2[:, 1]).all() and (e1[:, 0] > s1[:, 0]).all()
+    assert (d1.fresh_score() == e1).all()
+    assert d1.working_lists(0, 1) == d2.working_lists(0, 1)
