@@ -122,8 +122,33 @@ typedef enum sf_selection_order { /* solverforge_config::SelectionOrder */
 
 typedef enum sf_acceptor_kind {
     SF_ACCEPT_HILL_CLIMBING = 0,  /* phase/localsearch/acceptor/hill_climbing.rs:33-41 */
-    SF_ACCEPT_LATE_ACCEPTANCE = 1 /* phase/localsearch/acceptor/late_acceptance.rs:89-125 */
+    SF_ACCEPT_LATE_ACCEPTANCE = 1,/* phase/localsearch/acceptor/late_acceptance.rs:89-125 */
+    /* 2 is reserved (internal "never accept" of the dry-run enumeration) */
+    SF_ACCEPT_SIMULATED_ANNEALING = 3 /* phase/localsearch/acceptor/simulated_annealing.rs:11-430; the default of
+                                       * scalar-only models (default_local_search/policy.rs:56-61).  Parameters:
+                                       * sf_solver_configure_annealing; without it the reference defaults apply
+                                       * (auto-calibrated, decay 0.999985, rng seed = random_seed). */
 } sf_acceptor_kind;
+
+typedef enum sf_annealing_mode {
+    SF_ANNEAL_SINGLE = 0,     /* SimulatedAnnealingAcceptor::with_seed: one temperature for every level (:115-133) */
+    SF_ANNEAL_PER_LEVEL = 1,  /* with_level_temperatures_and_seed (:140-154) */
+    SF_ANNEAL_CALIBRATED = 2  /* auto_calibrate_with_seed / with_calibration_and_seed (:180-220) */
+} sf_annealing_mode;
+
+/* SimulatedAnnealingConfig of the reference (builder/acceptor.rs:270-335) */
+typedef struct sf_annealing_config {
+    int32_t mode;                          /* sf_annealing_mode */
+    int32_t never_accept_hard_regression;  /* HardRegressionPolicy (:18-21); levels < hard_levels are Hard */
+    int32_t calibration_sample_size;       /* default 128 (:13) */
+    int32_t reserved;
+    double temperatures[4];                /* SINGLE: [0]; PER_LEVEL: one per score level */
+    double decay_rate;                     /* (0, 1]; default 0.999985 (:11) */
+    double hill_climbing_temperature;      /* default 1e-9 (:12) */
+    double target_acceptance_probability;  /* (0, 1); default 0.80 (:14) */
+    double fallback_temperature;           /* default 1.0 (:15) */
+    uint64_t seed;                         /* SmallRng::seed_from_u64(seed + replica) */
+} sf_annealing_config;
 
 typedef enum sf_forager_kind {
     SF_FORAGER_ACCEPTED_COUNT = 0, /* phase/localsearch/forager.rs:157-250 */
@@ -226,6 +251,11 @@ int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint
 
 /* ---- local search phase ------------------------------------------------------------------ */
 int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg);
+/* parameters of SF_ACCEPT_SIMULATED_ANNEALING (takes effect at the next sf_phase_start); validation follows
+ * assert_simulated_annealing_parameters (simulated_annealing.rs:305-336) -> SF_ERR_INVALID instead of a panic */
+int32_t sf_solver_configure_annealing(sf_ctx* ctx, const sf_annealing_config* cfg);
+/* acceptor state of one replica: current temperatures [score_levels] and whether it is still calibrating */
+int32_t sf_get_annealing_state(sf_ctx* ctx, int32_t replica, double* out_temperatures, int32_t* out_calibrating);
 int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine); /* sf_engine_kind; SF_ERR_UNSUPPORTED if it cannot run this model */
 int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine); /* the engine launches resolve to (after sf_initialize) */
 /* explicit step seeds for parity runs (n_steps per replica, replica-major); NULL clears */

@@ -70,6 +70,10 @@ def lib():
             "sfo_model_fresh_score": (None, [vp, vp]),
             "sfo_model_reset": (None, [vp]),
             "sfo_model_configure": (None, [vp, i32, i32, i32, i32, i32, i32, u32, i32, i32, u64, i32]),
+            "sfo_model_configure_annealing": (None, [vp, i32, vp, i32, i32, dbl, dbl, i32, i32, dbl, dbl, u64]),
+            "sfo_model_annealing_state": (None, [vp, vp, vp, vp]),
+            "sfo_xoshiro256pp": (None, [vp, i32, vp]),
+            "sfo_small_rng_seed": (None, [u64, vp]),
             "sfo_model_set_step_seeds": (None, [vp, vp, i32]),
             "sfo_model_set_sublist_sizes": (None, [vp, i32, i32]),
             "sfo_model_phase_start": (None, [vp]),
@@ -190,6 +194,23 @@ class Model:
                   random_seed=0, public_entity_order=False):
         lib().sfo_model_configure(self.h, acceptor, la_size, forager, limit, int(random_ties), selection_order,
                                   leaves, max_nearby, union_order, random_seed, int(public_entity_order))
+
+    def configure_annealing(self, mode=2, temperatures=(), levels=2, hard_levels=1, decay_rate=0.999985,
+                            hill_climbing_temperature=1.0e-9, never_accept_hard=False, sample_size=128,
+                            target_probability=0.80, fallback_temperature=1.0, seed=0):
+        """Install a SimulatedAnnealingAcceptor (call after configure()). mode: 0 single, 1 per level, 2 calibrated."""
+        t = np.zeros(4, dtype=np.float64)
+        t[:len(temperatures)] = temperatures
+        lib().sfo_model_configure_annealing(self.h, mode, _p(t), levels, hard_levels, decay_rate,
+                                            hill_climbing_temperature, int(never_accept_hard), sample_size,
+                                            target_probability, fallback_temperature, seed)
+
+    def annealing_state(self):
+        t = np.zeros(4, dtype=np.float64)
+        r = np.zeros(4, dtype=np.uint64)
+        c = np.zeros(1, dtype=np.int32)
+        lib().sfo_model_annealing_state(self.h, _p(t), _p(r), _p(c))
+        return t, r, int(c[0])
 
     def set_sublist_sizes(self, min_size, max_size):
         lib().sfo_model_set_sublist_sizes(self.h, min_size, max_size)

@@ -141,6 +141,46 @@ void sfo_model_configure(void* h, int32_t acceptor, int32_t la_size, int32_t for
     else
         m->union_order = (UnionOrder)union_order;
 }
+// SimulatedAnnealingAcceptor (simulated_annealing.rs): mode 0 Single(temps[0]), 1 PerLevel(temps[0..levels]),
+// 2 Calibrated(sample_size, target, fallback).  Replaces the acceptor sfo_model_configure installed.
+void sfo_model_configure_annealing(void* h, int32_t mode, const double* temps, int32_t levels, int32_t hard_levels,
+                                   double decay_rate, double hill_climbing_temperature, int32_t never_accept_hard,
+                                   int32_t sample_size, double target_probability, double fallback_temperature,
+                                   uint64_t seed) {
+    Model* m = (Model*)h;
+    auto sa = std::make_unique<SimulatedAnnealingAcceptor>();
+    sa->mode = (SimulatedAnnealingAcceptor::Mode)mode;
+    sa->levels = levels;
+    sa->hard_levels = hard_levels;
+    if (mode == 0) sa->single_temperature = temps[0];
+    if (mode == 1) sa->level_temperatures.assign(temps, temps + levels);
+    sa->decay_rate = decay_rate;
+    sa->hill_climbing_temperature = hill_climbing_temperature;
+    sa->never_accept_hard_regression = never_accept_hard != 0;
+    sa->sample_size = (size_t)sample_size;
+    sa->target_acceptance_probability = target_probability;
+    sa->fallback_temperature = fallback_temperature;
+    sa->rng = SmallRng::seed_from_u64(seed);
+    m->search.acceptor = std::move(sa);
+}
+// acceptor state after the steps run so far: temperatures[levels], rng state[4], calibrating flag
+void sfo_model_annealing_state(void* h, double* out_temps, uint64_t* out_rng, int32_t* out_calibrating) {
+    auto* sa = dynamic_cast<SimulatedAnnealingAcceptor*>(((Model*)h)->search.acceptor.get());
+    if (!sa) return;
+    for (size_t k = 0; k < sa->current.size(); ++k) out_temps[k] = sa->current[k];
+    for (int i = 0; i < 4; ++i) out_rng[i] = sa->rng.s[i];
+    *out_calibrating = sa->calibrating ? 1 : 0;
+}
+// xoshiro256++ from an explicit state: n outputs (known-answer check of the SmallRng restatement)
+void sfo_xoshiro256pp(const uint64_t* state4, int32_t n, uint64_t* out) {
+    SmallRng r;
+    for (int i = 0; i < 4; ++i) r.s[i] = state4[i];
+    for (int32_t i = 0; i < n; ++i) out[i] = r.next_u64();
+}
+void sfo_small_rng_seed(uint64_t seed, uint64_t* out_state4) {
+    SmallRng r = SmallRng::seed_from_u64(seed);
+    for (int i = 0; i < 4; ++i) out_state4[i] = r.s[i];
+}
 void sfo_model_set_sublist_sizes(void* h, int32_t min_size, int32_t max_size) {
     Model* m = (Model*)h;
     m->sublist_min = (size_t)min_size;

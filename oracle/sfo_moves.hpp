@@ -10,6 +10,8 @@
 //       cursor.rs:371-378 (slot_identity)
 //   heuristic/selector/list_kernel/change.rs:25-241, list_kernel/swap.rs:25-270
 //   heuristic/selector/list_kernel/nearby_change.rs:17-233, nearby_swap.rs:17-260
+//   heuristic/selector/list_kernel/reverse.rs:12-108, sublist_change.rs:13-266, sublist_swap.rs:13-330
+//   heuristic/move/list_kernel/reverse.rs:15-57, sublist_change.rs:18-130, sublist_swap.rs:17-160
 //   heuristic/selector/nearby_list_support.rs:3-34 (stable bounded top-k)
 //   heuristic/selector/list_support.rs:13-26,62-70
 //   runtime/compiler/executor/list_leaf/cursor/slot.rs:196-499 (runtime leaf entity order)

@@ -9,11 +9,13 @@
 //   phase/localsearch/phase/candidates.rs:47-285 (evaluate_candidates)
 //   phase/localsearch/evaluation.rs:20-115       (evaluate_candidate)
 //   phase/localsearch/forager.rs:70-425          (BestCandidate / AcceptedCount / FirstAccepted / BestScore)
-//   phase/localsearch/acceptor/hill_climbing.rs:33-41, late_acceptance.rs:89-125
+//   phase/localsearch/acceptor/hill_climbing.rs:33-41, late_acceptance.rs:89-125,
+//   simulated_annealing.rs:11-430 (calibration :48-88, is_accepted :338-375, step_ended :417-430)
 //   scope/solver/scope_progress.rs:89-107        (update_best_solution)
 //   stats/solver.rs:23,112-119,246               (counter definitions)
 //   phase/construction/forager_step.rs:149-226, decision.rs:56-64, evaluation.rs:6-18 (first fit)
 #pragma once
+#include <cmath>
 #include <functional>
 #include <memory>
 #include <vector>
@@ -65,6 +67,124 @@ struct LateAcceptanceAcceptor : Acceptor {  // late_acceptance.rs:89-125
         history[current] = step_score;
         filled[current] = true;
         current = (current + 1) % size;
+    }
+};
+
+// rand 0.10.1 SmallRng on 64-bit targets = xoshiro256++ (Blackman/Vigna, public domain
+// algorithm); `seed_from_u64` expands the seed with splitmix64 and `random::<f64>()` is the
+// 53-bit multiply sample `(next_u64 >> 11) * 2^-53`.  The crate source is NOT under
+// /root/reference (Cargo.lock:314-338) => the draw stream is "parity unpinned" (SURVEY §8c);
+// the generator itself is checked against the published xoshiro256++ test vector.
+struct SmallRng {
+    uint64_t s[4] = {0, 0, 0, 0};
+    static SmallRng seed_from_u64(uint64_t state) {
+        SmallRng r;
+        for (int i = 0; i < 4; ++i) {
+            state += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            r.s[i] = z ^ (z >> 31);
+        }
+        return r;
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next_u64() {
+        const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return result;
+    }
+    double random_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+};
+
+// simulated_annealing.rs:11-430.  `levels` = Score::levels_count(), `hard_levels` = how many
+// leading levels carry ScoreLevel::Hard (HardSoft: 1; Bendable<H,S>: H).
+struct SimulatedAnnealingAcceptor : Acceptor {
+    enum Mode { Single = 0, PerLevel = 1, Calibrated = 2 };
+    Mode mode = Calibrated;
+    double single_temperature = 0.0;
+    std::vector<double> level_temperatures;
+    // SimulatedAnnealingCalibration::default (:30-38)
+    size_t sample_size = 128;
+    double target_acceptance_probability = 0.80;
+    double fallback_temperature = 1.0;
+    double decay_rate = 0.999985;               // DEFAULT_DECAY_RATE (:11)
+    double hill_climbing_temperature = 1.0e-9;  // DEFAULT_HILL_CLIMBING_TEMPERATURE (:12)
+    bool never_accept_hard_regression = false;  // HardRegressionPolicy (:18-21)
+    int levels = 2, hard_levels = 1;
+    SmallRng rng;
+
+    std::vector<double> current;  // current_temperatures
+    bool calibrating = false;     // calibration_state.is_some()
+    std::vector<std::vector<int64_t>> samples_by_level;
+    size_t samples_seen = 0;
+
+    std::vector<double> calibrated_temperatures() const {  // CalibrationState::temperatures :72-87
+        const double denominator = -std::log(target_acceptance_probability);
+        std::vector<double> out;
+        for (const auto& samples : samples_by_level) {
+            if (samples.empty()) {
+                out.push_back(fallback_temperature);
+            } else {
+                __int128 total = 0;
+                for (int64_t v : samples) total += (__int128)v;
+                const double mean = (double)total / (double)samples.size();
+                out.push_back(std::max(mean / denominator, fallback_temperature));
+            }
+        }
+        return out;
+    }
+
+    bool is_accepted(const Score& last, const Score& mv) override {  // :338-375
+        if (mv >= last) return true;
+        int level = -1;
+        for (int k = 0; k < levels; ++k)
+            if (last.v[k] != mv.v[k]) {
+                level = k;
+                break;
+            }
+        if (level < 0) return false;
+        const int64_t delta = wrap_sub(mv.v[level], last.v[level]);
+        if (delta >= 0) return false;  // worsening_delta_at_first_difference :289-296
+        if (never_accept_hard_regression && level < hard_levels) return false;
+        if (calibrating) {
+            const int64_t abs = delta == INT64_MIN ? INT64_MAX : -delta;  // saturating_abs
+            samples_by_level[(size_t)level].push_back(abs);
+            samples_seen += 1;
+            if (samples_seen < sample_size) return false;
+            current = calibrated_temperatures();  // finalize_calibration_if_ready :257-266
+            calibrating = false;
+        }
+        const double temperature = current[(size_t)level];
+        if (temperature <= hill_climbing_temperature) return false;
+        const double probability = std::exp((double)delta / temperature);
+        return rng.random_f64() < probability;
+    }
+    void phase_started(const Score&) override {  // :377-415
+        calibrating = false;
+        samples_seen = 0;
+        if (mode == Single)
+            current.assign((size_t)levels, single_temperature);
+        else if (mode == PerLevel)
+            current = level_temperatures;
+        else {
+            current.assign((size_t)levels, 0.0);
+            samples_by_level.assign((size_t)levels, {});
+            calibrating = true;
+        }
+    }
+    void step_ended(const Score&) override {  // :417-430
+        if (calibrating) return;
+        for (double& t : current) {
+            t *= decay_rate;
+            if (t < hill_climbing_temperature) t = hill_climbing_temperature;
+        }
     }
 };
 

@@ -426,7 +426,125 @@ static void list_reverse_cases() {
     }
 }
 
+// phase/localsearch/acceptor/simulated_annealing/tests.rs:40-273 (every case) + the published
+// xoshiro256++ test vector for the SmallRng restatement.
+static void simulated_annealing_cases() {
+    auto mk = [](SimulatedAnnealingAcceptor::Mode mode, std::vector<double> temps, double decay, double hc,
+                 bool never_hard, uint64_t seed, int levels) {
+        SimulatedAnnealingAcceptor a;
+        a.mode = mode;
+        a.levels = levels;
+        a.hard_levels = levels > 1 ? 1 : 0;
+        if (mode == SimulatedAnnealingAcceptor::Single) a.single_temperature = temps[0];
+        if (mode == SimulatedAnnealingAcceptor::PerLevel) a.level_temperatures = temps;
+        a.decay_rate = decay;
+        a.hill_climbing_temperature = hc;
+        a.never_accept_hard_regression = never_hard;
+        a.rng = SmallRng::seed_from_u64(seed);
+        return a;
+    };
+    auto soft1 = [](int64_t v) { return Score::level(0, v); };  // SoftScore: one level
+    {
+        // xoshiro256plusplus.c reference vector (state 1,2,3,4), as asserted by rand's own test
+        SmallRng r;
+        r.s[0] = 1, r.s[1] = 2, r.s[2] = 3, r.s[3] = 4;
+        const uint64_t expect[10] = {41943041ULL,           58720359ULL,           3588806011781223ULL,
+                                     3591011842654386ULL,   9228616714210784205ULL, 9973669472204895162ULL,
+                                     14011001112246962877ULL, 12406186145184390807ULL, 15849039046786891736ULL,
+                                     10450023813501588000ULL};
+        bool ok = true;
+        for (uint64_t e : expect) ok = ok && r.next_u64() == e;
+        CHECK("sa.xoshiro256pp_reference_vector", ok);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::Single, {1000.0}, 0.99, 1.0e-9, false, 42, 1);
+        CHECK("sa.accepts_improving_and_equal", a.is_accepted(soft1(-10), soft1(-5)) && a.is_accepted(soft1(-10), soft1(-10)));
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::Single, {1000000.0}, 0.99, 1.0e-9, false, 42, 1);
+        a.phase_started(soft1(0));
+        int acc = 0;
+        for (int i = 0; i < 100; ++i) acc += a.is_accepted(soft1(-10), soft1(-11));
+        CHECK("sa.high_temperature_accepts_most", acc > 90);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::Single, {0.001}, 0.99, 1.0e-9, false, 42, 1);
+        a.phase_started(soft1(0));
+        int acc = 0;
+        for (int i = 0; i < 100; ++i) acc += a.is_accepted(soft1(-10), soft1(-20));
+        CHECK("sa.low_temperature_rejects_most", acc < 5);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::PerLevel, {100.0}, 0.5, 20.0, false, 42, 1);
+        a.phase_started(soft1(0));
+        bool ok = a.current[0] == 100.0;
+        a.step_ended(soft1(0));
+        ok = ok && a.current[0] == 50.0;
+        a.step_ended(soft1(0));
+        ok = ok && a.current[0] == 25.0;
+        a.step_ended(soft1(0));
+        ok = ok && a.current[0] == 20.0;
+        CHECK("sa.temperature_decays_to_hill_climbing_threshold", ok);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::PerLevel, {1.0e-9, 1.0e12}, 1.0, 1.0e-9, false, 42, 2);
+        a.phase_started(Score::of(-10, -1000000));
+        bool ok = true;
+        for (int i = 0; i < 100; ++i) ok = ok && !a.is_accepted(Score::of(-10, -1000000), Score::of(-11, 0));
+        CHECK("sa.soft_improvement_does_not_mask_hard_regression", ok);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::Single, {0.0}, 1.0, 1.0e-9, false, 42, 2);
+        CHECK("sa.hard_improvement_with_soft_regression_accepted", a.is_accepted(Score::of(-2, 0), Score::of(-1, -1000000)));
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::PerLevel, {0.0, 1000000.0}, 1.0, 1.0e-9, false, 42, 2);
+        a.phase_started(Score::of(0, 0));
+        int acc = 0;
+        for (int i = 0; i < 100; ++i) acc += a.is_accepted(Score::of(0, -10), Score::of(0, -11));
+        CHECK("sa.soft_regression_uses_soft_temperature", acc > 90);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::PerLevel, {1.0e12, 1.0e12}, 1.0, 1.0e-9, true, 42, 2);
+        a.phase_started(Score::of(0, 0));
+        CHECK("sa.never_accept_hard_regression", !a.is_accepted(Score::of(-10, 0), Score::of(-11, 10000)));
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::PerLevel, {100.0, 100.0}, 0.1, 1.1, false, 42, 2);
+        HillClimbingAcceptor hill;
+        a.phase_started(Score::of(0, 0));
+        for (int i = 0; i < 3; ++i) a.step_ended(Score::of(0, 0));
+        const Score pairs[3][2] = {{Score::of(0, 0), Score::of(0, -1)},
+                                   {Score::of(-1, 0), Score::of(-2, 10000)},
+                                   {Score::of(-1, 0), Score::of(0, -10000)}};
+        bool ok = true;
+        for (auto& pr : pairs) ok = ok && a.is_accepted(pr[0], pr[1]) == hill.is_accepted(pr[0], pr[1]);
+        CHECK("sa.cooled_matches_hill_climbing", ok);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::Calibrated, {}, 1.0, 1.0e-9, false, 42, 2);
+        a.sample_size = 2;
+        a.target_acceptance_probability = 0.5;
+        a.fallback_temperature = 1.0;
+        a.phase_started(Score::of(0, 0));
+        bool ok = !a.is_accepted(Score::of(0, 0), Score::of(-4, 0));
+        (void)a.is_accepted(Score::of(0, 0), Score::of(0, -10));
+        // 4/ln2 = 5.77..., 10/ln2 = 14.42...
+        ok = ok && a.current[0] > 5.0 && a.current[1] > 14.0 && !a.calibrating;
+        ok = ok && a.current[0] == 4.0 / -std::log(0.5) && a.current[1] == 10.0 / -std::log(0.5);
+        CHECK("sa.sampled_calibration_per_level", ok);
+    }
+    {
+        auto a = mk(SimulatedAnnealingAcceptor::Calibrated, {}, 0.999, 1.0e-9, false, 42, 2);
+        auto b = mk(SimulatedAnnealingAcceptor::Calibrated, {}, 0.999, 1.0e-9, false, 42, 2);
+        a.phase_started(Score::of(-576, -1000));
+        b.phase_started(Score::of(-576, -1000));
+        CHECK("sa.seeded_calibration_same_start", a.current == b.current && a.current[0] == 0.0 && a.calibrating);
+    }
+}
+
 int main() {
+    simulated_annealing_cases();
     list_reverse_cases();
     bi_incr_cases();
     cross_bi_cases();

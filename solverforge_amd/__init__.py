@@ -6,6 +6,7 @@ hand-written HIP for gfx950.
 """
 from .director import (  # noqa: F401
     Acceptor,
+    AnnealingMode,
     Engine,
     Forager,
     GpuScoreDirector,

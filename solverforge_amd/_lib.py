@@ -32,6 +32,21 @@ class SolverConfigStruct(C.Structure):
     ]
 
 
+class AnnealingConfigStruct(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("never_accept_hard_regression", C.c_int32),
+        ("calibration_sample_size", C.c_int32),
+        ("reserved", C.c_int32),
+        ("temperatures", C.c_double * 4),
+        ("decay_rate", C.c_double),
+        ("hill_climbing_temperature", C.c_double),
+        ("target_acceptance_probability", C.c_double),
+        ("fallback_temperature", C.c_double),
+        ("seed", C.c_uint64),
+    ]
+
+
 class StatsStruct(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied",
@@ -48,7 +63,8 @@ SYMBOLS = [
     "sf_schema_add_entity_class", "sf_schema_add_scalar_variable", "sf_schema_add_list_variable",
     "sf_fact_matrix_i64", "sf_fact_column_i32", "sf_fact_column_u32", "sf_fact_csr_u32",
     "sf_constraint_add", "sf_selector_add", "sf_selector_add_sublist", "sf_initialize", "sf_evaluate_all", "sf_get_scores",
-    "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_solver_set_step_seeds",
+    "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_solver_configure_annealing",
+    "sf_get_annealing_state", "sf_solver_set_step_seeds",
     "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
     "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_destroy",
@@ -93,6 +109,8 @@ def load():
     L.sf_step_generate.argtypes = [vp, i32, u64, u64, i32, vp, vp, vp, i64, vp]
     L.sf_selector_add_sublist.argtypes = [vp, i32, i32, i32, i32, i32]
     L.sf_solver_configure.argtypes = [vp, C.POINTER(SolverConfigStruct)]
+    L.sf_solver_configure_annealing.argtypes = [vp, C.POINTER(AnnealingConfigStruct)]
+    L.sf_get_annealing_state.argtypes = [vp, i32, vp, C.POINTER(i32)]
     L.sf_solver_set_engine.argtypes = [vp, i32]
     L.sf_solver_get_engine.argtypes = [vp, C.POINTER(i32)]
     L.sf_solver_set_step_seeds.argtypes = [vp, vp, i64]

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -72,6 +73,9 @@ struct sf_ctx {
     sf_solver_config cfg{SF_ACCEPT_LATE_ACCEPTANCE, 400, SF_FORAGER_ACCEPTED_COUNT, 256, 1, SF_ORDER_RANDOM, 0};
     SearchParams sp{};
     bool search_alloc = false;
+    // SimulatedAnnealingCalibration::default + DEFAULT_* (simulated_annealing.rs:11-38); seed_set = false -> cfg.random_seed
+    sf_annealing_config anneal{SF_ANNEAL_CALIBRATED, 0, 128, 0, {0, 0, 0, 0}, 0.999985, 1.0e-9, 0.80, 1.0, 0};
+    bool anneal_seed_set = false;
     uint64_t* d_explicit = nullptr;
     int64_t n_explicit = 0;
     // trace buffers
@@ -89,6 +93,10 @@ struct sf_ctx {
     std::vector<void*> allocs;
     void* rccl = nullptr;  // portfolio state (sf_portfolio.cpp part below)
 };
+
+// dynamic LDS a workgroup may request: 160 KiB per CU minus the 1 KiB of static LDS the search kernels declare
+// for the SimulatedAnnealing acceptor state (sf_anneal.h)
+static constexpr size_t SF_LDS_BUDGET = 160 * 1024 - 1024;
 
 #define HIPCHK(ctx, expr)                                                                   \
     do {                                                                                    \
@@ -416,12 +424,12 @@ static bool wave_engine_possible(sf_ctx* ctx) {
     const ListModel& m = ctx->lm;
     // u16 element ids / ordinals in LDS; one wave's LDS slice must fit a CU
     if (!ctx->nbr.keys || m.dim > 16384 || m.n_cap + m.V > 65535 || list_max_nearby(ctx) > 64) return false;
-    return WCarve(m.V, m.n_cap, m.dim, list_max_nearby(ctx)).total <= 160 * 1024;
+    return WCarve(m.V, m.n_cap, m.dim, list_max_nearby(ctx)).total <= SF_LDS_BUDGET;
 }
 static bool use_wave_engine(sf_ctx* ctx) {
     if (ctx->engine == SF_ENGINE_BLOCK) return false;
     if (ctx->engine == SF_ENGINE_WAVE) return true;  // validated in sf_solver_set_engine / launch
-    return wave_engine_possible(ctx) && WCarve(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx)).total <= 80 * 1024;
+    return wave_engine_possible(ctx) && WCarve(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx)).total <= SF_LDS_BUDGET / 2;
 }
 
 static int build_scalar_model(sf_ctx* ctx, int d);  // sf_api_scalar.inc
@@ -444,6 +452,7 @@ static int alloc_search(sf_ctx* ctx) {
     if ((rc = dalloc(ctx, &ctx->d_trace_count, 1))) return rc;
     if ((rc = dalloc(ctx, &ctx->d_trace_applied, 8))) return rc;
     if ((rc = dalloc(ctx, &ctx->d_ok, 4))) return rc;
+    if ((rc = dalloc(ctx, &p.sa.state, (size_t)R * SA_WORDS))) return rc;
     p.la_size = la;
     ctx->search_alloc = true;
     return SF_OK;
@@ -488,9 +497,7 @@ static int fill_list_leaves(sf_ctx* ctx, SearchParams& p) {
                 if (p.n_leaves >= MAX_LEAVES) return fail(ctx, SF_ERR_UNSUPPORTED, "more than two list leaves");
                 p.leaf[p.n_leaves++] = LeafSpec{s.kind, s.max_nearby, s.desc};
             }
-    for (auto& s : ctx->selectors)
-        if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP))
-            return fail(ctx, SF_ERR_UNSUPPORTED, "plain list change/swap leaves are not in the fused kernel yet");
+    // (unions with any other leaf kind are routed to the generic N-leaf engine by launch_search)
     if (p.n_leaves == 0) return fail(ctx, SF_ERR_INVALID, "no list selector configured");
     return SF_OK;
 }
@@ -499,7 +506,7 @@ template <int L, bool TRACE>
 static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid) {
     Carve<L> cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim);
     size_t lds = cv.total;
-    if (lds > 160 * 1024) return fail(ctx, SF_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of one CU");
+    if (lds > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of one CU");
     auto kern = k_list_search<L, TRACE>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, ctx->lm, p);
@@ -509,7 +516,7 @@ static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid) {
 template <int L, bool TRACE>
 static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas) {
     WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx));
-    int wpb = (int)((160 * 1024) / cv.total);  // replicas (waves) per workgroup: as many as the LDS holds, <= WPB
+    int wpb = (int)((SF_LDS_BUDGET) / cv.total);  // replicas (waves) per workgroup: as many as the LDS holds, <= WPB
     if (wpb > WPB) wpb = WPB;
     size_t lds = cv.total * wpb;
     const bool fast = !TRACE && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
@@ -679,8 +686,9 @@ int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg) {
     if (!ctx || !cfg) return SF_ERR_INVALID;
     if (ctx->search_alloc && cfg->late_acceptance_size > ctx->sp.la_size)
         return fail(ctx, SF_ERR_INVALID, "late_acceptance_size cannot grow after the search state exists");
-    if (cfg->acceptor != SF_ACCEPT_HILL_CLIMBING && cfg->acceptor != SF_ACCEPT_LATE_ACCEPTANCE)
-        return fail(ctx, SF_ERR_UNSUPPORTED, "acceptor (SimulatedAnnealing needs f64 exp + rand SmallRng: host-side, unpinned)");
+    if (cfg->acceptor != SF_ACCEPT_HILL_CLIMBING && cfg->acceptor != SF_ACCEPT_LATE_ACCEPTANCE &&
+        cfg->acceptor != SF_ACCEPT_SIMULATED_ANNEALING)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "acceptor kind");
     if (cfg->forager < 0 || cfg->forager > 2) return fail(ctx, SF_ERR_UNSUPPORTED, "forager");
     if (cfg->forager == SF_FORAGER_ACCEPTED_COUNT && cfg->accepted_count_limit <= 0)
         return fail(ctx, SF_ERR_INVALID, "AcceptedCountForager: accepted_count_limit must be > 0");
@@ -688,6 +696,79 @@ int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg) {
         return fail(ctx, SF_ERR_INVALID, "late_acceptance_size must be > 0");
     ctx->cfg = *cfg;
     if (ctx->search_alloc) ctx->sp.la_size = cfg->late_acceptance_size > 0 ? cfg->late_acceptance_size : 1;
+    return SF_OK;
+}
+
+// assert_simulated_annealing_parameters (simulated_annealing.rs:305-336): the reference panics, the C ABI reports
+int32_t sf_solver_configure_annealing(sf_ctx* ctx, const sf_annealing_config* cfg) {
+    if (!ctx || !cfg) return SF_ERR_INVALID;
+    auto temperature_ok = [](double v) { return std::isfinite(v) && v >= 0.0; };
+    if (cfg->mode < SF_ANNEAL_SINGLE || cfg->mode > SF_ANNEAL_CALIBRATED) return fail(ctx, SF_ERR_INVALID, "annealing mode");
+    if (!(std::isfinite(cfg->decay_rate) && cfg->decay_rate > 0.0 && cfg->decay_rate <= 1.0))
+        return fail(ctx, SF_ERR_INVALID, "simulated_annealing decay_rate must be finite and in (0, 1]");
+    if (!temperature_ok(cfg->hill_climbing_temperature))
+        return fail(ctx, SF_ERR_INVALID, "simulated_annealing hill_climbing_temperature must be finite and non-negative");
+    const int nt = cfg->mode == SF_ANNEAL_SINGLE ? 1 : cfg->mode == SF_ANNEAL_PER_LEVEL ? ctx->levels : 0;
+    for (int k = 0; k < nt; ++k)
+        if (!temperature_ok(cfg->temperatures[k]))
+            return fail(ctx, SF_ERR_INVALID, "simulated_annealing level_temperatures must be finite and non-negative");
+    if (cfg->mode == SF_ANNEAL_CALIBRATED) {
+        if (cfg->calibration_sample_size <= 0)
+            return fail(ctx, SF_ERR_INVALID, "simulated_annealing calibration sample_size must be greater than 0");
+        if (!(std::isfinite(cfg->target_acceptance_probability) && cfg->target_acceptance_probability > 0.0 &&
+              cfg->target_acceptance_probability < 1.0))
+            return fail(ctx, SF_ERR_INVALID, "simulated_annealing calibration target_acceptance_probability must be in (0, 1)");
+        if (!temperature_ok(cfg->fallback_temperature))
+            return fail(ctx, SF_ERR_INVALID, "simulated_annealing calibration fallback_temperature must be finite and non-negative");
+    }
+    ctx->anneal = *cfg;
+    ctx->anneal_seed_set = true;
+    return SF_OK;
+}
+
+// acceptor.phase_started (simulated_annealing.rs:377-415) for every replica; rng = SmallRng::seed_from_u64(seed + r)
+static int anneal_phase_start(sf_ctx* ctx) {
+    const sf_annealing_config& a = ctx->anneal;
+    SearchParams& p = ctx->sp;
+    p.sa.decay_rate = a.decay_rate;
+    p.sa.hill_climbing_temperature = a.hill_climbing_temperature;
+    p.sa.denominator = -std::log(a.target_acceptance_probability);
+    p.sa.fallback_temperature = a.fallback_temperature;
+    p.sa.sample_size = a.calibration_sample_size > 0 ? a.calibration_sample_size : 1;
+    p.sa.never_accept_hard = a.never_accept_hard_regression;
+    p.sa.hard_levels = ctx->hard_levels;
+    p.sa.levels = ctx->levels;
+    const uint64_t seed = ctx->anneal_seed_set ? a.seed : ctx->cfg.random_seed;
+    std::vector<uint64_t> st((size_t)ctx->R * SA_WORDS, 0);
+    for (int r = 0; r < ctx->R; ++r) {
+        uint64_t* w = st.data() + (size_t)r * SA_WORDS;
+        uint64_t state = seed + (uint64_t)r;
+        for (int i = 0; i < 4; ++i) {  // xoshiro256++ seed_from_u64: splitmix64 expansion
+            state += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            w[SA_RNG + i] = z ^ (z >> 31);
+        }
+        for (int k = 0; k < ctx->levels; ++k) {
+            double t = a.mode == SF_ANNEAL_SINGLE ? a.temperatures[0] : a.mode == SF_ANNEAL_PER_LEVEL ? a.temperatures[k] : 0.0;
+            std::memcpy(&w[SA_TEMP + k], &t, 8);
+        }
+        w[SA_CALIBRATING] = a.mode == SF_ANNEAL_CALIBRATED ? 1 : 0;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(p.sa.state, st.data(), st.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
+
+int32_t sf_get_annealing_state(sf_ctx* ctx, int32_t replica, double* out_temperatures, int32_t* out_calibrating) {
+    if (!ctx || !ctx->search_alloc || replica < 0 || replica >= ctx->R || !out_temperatures || !out_calibrating)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_get_annealing_state");
+    uint64_t w[SA_WORDS];
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(w, ctx->sp.sa.state + (size_t)replica * SA_WORDS, sizeof(w), hipMemcpyDeviceToHost));
+    for (int k = 0; k < ctx->levels; ++k) std::memcpy(&out_temperatures[k], &w[SA_TEMP + k], 8);
+    *out_calibrating = (int32_t)w[SA_CALIBRATING];
     return SF_OK;
 }
 
@@ -726,6 +807,7 @@ int32_t sf_phase_start(sf_ctx* ctx) {
     if (rc) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->sp.seed_draws, 0, (size_t)ctx->R * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->sp.stats, 0, (size_t)ctx->R * SF_STATS_WORDS * 8, ctx->stream));
+    if ((rc = anneal_phase_start(ctx))) return rc;
     if (ctx->has_list_model)
         hipLaunchKernelGGL(k_list_phase_start, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->lm, ctx->sp);
     if (ctx->has_scalar_model)  // mixed: same committed score (aliased), adds the best snapshot of the values
@@ -742,8 +824,8 @@ template <int L, bool TRACE, class VT>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0);
-    if (cv.total > 160 * 1024) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
-    int wpb = (int)((160 * 1024) / cv.total);
+    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
+    int wpb = (int)((SF_LDS_BUDGET) / cv.total);
     if (wpb > 4) wpb = 4;
     auto kern = k_mixed_search_wave<L, TRACE, VT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cv.total * wpb)));
@@ -822,7 +904,11 @@ int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) {
     HIPCHK(ctx, hipEventCreate(&e1));
     HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
     int rc = launch_search(ctx, p, ctx->R, false);
-    if (rc) return rc;
+    if (rc) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return rc;
+    }
     HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
     ctx->events.push_back({e0, e1});
     return SF_OK;

@@ -894,6 +894,9 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
     int64_t* g_load = m.load + (size_t)r * V;
     int64_t* g_score = m.score + (size_t)r * 4;
     const bool tracing = TRACE && r == p.trace_replica;
+    __shared__ uint64_t s_sa[SA_WORDS];  // SimulatedAnnealing acceptor state (touched by wave 0 only)
+    const bool annealing = p.acceptor == 3;
+    if (annealing && wave == 0) sa_load(s_sa, p.sa, r, lane);
 
     // ---- load replica state into LDS ----
     for (uint32_t t = tid; t <= (uint32_t)V; t += blockDim.x) s_off[t] = g_off[t];
@@ -1206,6 +1209,8 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                         else if (p.acceptor == 1)
                             acc = score_cmp<L>(sc, cur) >= 0 || score_cmp<L>(sc, late) >= 0;
                     }
+                    SaChunk sach;
+                    if (annealing) acc = sa_decide<L>(s_sa, p.sa, doable, sc, cur, lane, sach);
                     uint64_t accmask = __ballot(acc);
                     uint32_t nconsumed = nvalid;
                     if (p.forager != 2) {
@@ -1215,6 +1220,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                         if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
                     }
                     const bool consumed = lane < nconsumed;
+                    if (annealing) sa_commit<L>(s_sa, p.sa, sach, nconsumed, lane);
                     acc = acc && consumed;
                     accmask = __ballot(acc);
                     if (accmask) {
@@ -1385,12 +1391,14 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                 }
                 c.st[0] += 1;
             }
+            if (annealing && wave == 0) sa_step_ended(s_sa, p.sa, lane);
             __syncthreads();
         }
     }
 
     // ---- write back ------------------------------------------------------------------
     if (!p.dry_run) {
+        if (annealing && wave == 0) sa_store(s_sa, p.sa, r, lane);
         const uint32_t total = s_off[V];
         for (uint32_t t = tid; t < total; t += blockDim.x) g_visits[t] = s_visits[t];
         for (uint32_t t = tid; t <= (uint32_t)V; t += blockDim.x) g_off[t] = s_off[t];

@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include "sf_common.h"
+#include "sf_anneal.h"
 
 namespace sf {
 
@@ -50,7 +51,7 @@ struct LeafSpec {
 struct SearchParams {
     int32_t n_leaves;
     LeafSpec leaf[MAX_LEAVES];
-    int32_t acceptor;     // 0 HC, 1 LA, 2 never (dry run)
+    int32_t acceptor;     // 0 HC, 1 LA, 2 never (dry run), 3 simulated annealing (state in `sa`)
     int32_t la_size;
     int32_t forager;      // 0 accepted count, 1 first accepted, 2 best score
     int32_t limit;
@@ -82,6 +83,7 @@ struct SearchParams {
     int64_t trace_cap;
     int64_t* trace_count;      // [1]
     int32_t* trace_applied;    // [1 + 6]
+    SaParams sa;               // acceptor 3
 };
 
 }  // namespace sf

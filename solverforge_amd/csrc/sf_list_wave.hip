@@ -421,6 +421,11 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
     const bool chg0 = FAST ? true : p.leaf[0].kind == 16, chg1 = FAST ? false : (n_leaves > 1 && p.leaf[1].kind == 16);
     const int acceptor = FAST ? 1 : p.acceptor, forager = FAST ? 0 : p.forager;
     const bool dry_run = FAST ? false : p.dry_run != 0;
+    __shared__ uint64_t s_sa[WPB][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
+    uint64_t* saw = s_sa[threadIdx.x >> 6];
+    const bool annealing = !FAST && acceptor == 3;
+    if constexpr (!FAST)
+        if (annealing) sa_load(saw, p.sa, r, lane);
     const uint64_t desc0 = (uint64_t)p.leaf[0].descriptor, desc1 = n_leaves > 1 ? (uint64_t)p.leaf[1].descriptor : 0;
 
     const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1));
@@ -848,6 +853,9 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                     else if (acceptor == 1)
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
                 }
+                SaChunk sach;
+                if constexpr (!FAST)
+                    if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
                 uint64_t accmask = __ballot(acc);
                 uint32_t nconsumed = nvalid;
                 if (forager != 2) {
@@ -857,6 +865,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                     if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
                 }
                 const bool consumed = lane < nconsumed;
+                if constexpr (!FAST)
+                    if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
                 acc = acc && consumed;
                 accmask = __ballot(acc);
                 if (accmask) {
@@ -985,6 +995,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
             }
+            if constexpr (!FAST)
+                if (annealing) sa_step_ended(saw, p.sa, lane);
             wave_sync();
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
@@ -995,6 +1007,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
 
     // ---- write back ----------------------------------------------------------------------
     if (!dry_run) {
+        if constexpr (!FAST)
+            if (annealing) sa_store(saw, p.sa, r, lane);
         const uint32_t tot = uni(s_off[V]);
         for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
         for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];

@@ -112,6 +112,10 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (rr >= p.n_launch) return;  // no workgroup barrier below
     const int r = rr + p.replica_base;
+    __shared__ uint64_t s_sa[4][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
+    uint64_t* saw = s_sa[threadIdx.x >> 6];
+    const bool annealing = p.acceptor == 3;
+    if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
@@ -920,6 +924,8 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     else if (p.acceptor == 1)
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
                 }
+                SaChunk sach;
+                if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
                 uint64_t accmask = __ballot(acc);
                 uint32_t nconsumed = nvalid;
                 if (p.forager != 2) {
@@ -929,6 +935,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
                 }
                 const bool consumed = lane < nconsumed;
+                if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
                 acc = acc && consumed;
                 accmask = __ballot(acc);
                 if (accmask) {
@@ -1093,6 +1100,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
             }
+            if (annealing) sa_step_ended(saw, p.sa, lane);
             wave_sync();
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
@@ -1100,6 +1108,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     }
 
     if (!p.dry_run) {
+        if (annealing) sa_store(saw, p.sa, r, lane);
         if (has_list) {
             const uint32_t tot = uni(s_off[V]);
             for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];

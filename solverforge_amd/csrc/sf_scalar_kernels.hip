@@ -390,10 +390,14 @@ struct SCarve {
 template <int L, bool TRACE, class VT>
 __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, SearchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint64_t s_sa[4][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
     const uint32_t lane = threadIdx.x & 63u;
     const int rr = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (rr >= p.n_launch) return;  // no workgroup barrier below
     const int r = rr + p.replica_base;
+    uint64_t* saw = s_sa[threadIdx.x >> 6];
+    const bool annealing = p.acceptor == 3;
+    if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t n = (uint32_t)m.n;
     const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
     const SCarve<VT> cv(m.n, tables ? m.n_values : 0);
@@ -648,6 +652,8 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                     else if (p.acceptor == 1)
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
                 }
+                SaChunk sach;
+                if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
                 uint64_t accmask = __ballot(acc);
                 uint32_t nconsumed = nvalid;
                 if (p.forager != 2) {
@@ -657,6 +663,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                     if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
                 }
                 const bool consumed = lane < nconsumed;
+                if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
                 acc = acc && consumed;
                 accmask = __ballot(acc);
                 if (accmask) {
@@ -775,6 +782,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
             }
+            if (annealing) sa_step_ended(saw, p.sa, lane);
             wave_sync();
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
@@ -782,6 +790,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     }
 
     if (!p.dry_run) {
+        if (annealing) sa_store(saw, p.sa, r, lane);
         for (uint32_t t = lane; t < n; t += 64) g_vals[t] = (int32_t)s_vals[t];
         if (lane == 0) {
 #pragma unroll

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib
-from ._lib import MOVE_DTYPE, SolverConfigStruct, SolverForgeError, StatsStruct, check, ptr
+from ._lib import MOVE_DTYPE, AnnealingConfigStruct, SolverConfigStruct, SolverForgeError, StatsStruct, check, ptr
 
 
 class MoveKind:
@@ -25,6 +25,11 @@ class SelectionOrder:  # solverforge_config::SelectionOrder
 
 class Acceptor:
     HILL_CLIMBING, LATE_ACCEPTANCE = 0, 1
+    SIMULATED_ANNEALING = 3  # default of scalar-only models (default_local_search/policy.rs:56-61)
+
+
+class AnnealingMode:
+    SINGLE, PER_LEVEL, CALIBRATED = 0, 1, 2
 
 
 class Forager:
@@ -184,6 +189,23 @@ class GpuScoreDirector:
         s = SolverConfigStruct(cfg.acceptor, cfg.late_acceptance_size, cfg.forager, cfg.accepted_count_limit,
                                int(cfg.random_ties), cfg.selection_order, cfg.random_seed)
         check(self._L.sf_solver_configure(self._h, C.byref(s)), self._h)
+
+    def configure_annealing(self, mode=AnnealingMode.CALIBRATED, temperatures=(), decay_rate=0.999985,
+                            hill_climbing_temperature=1.0e-9, never_accept_hard_regression=False,
+                            calibration_sample_size=128, target_acceptance_probability=0.80,
+                            fallback_temperature=1.0, seed=0):
+        """SimulatedAnnealingConfig (builder/acceptor.rs:270-335); replica r draws from SmallRng(seed + r)."""
+        t = (C.c_double * 4)(*([float(x) for x in temperatures] + [0.0] * (4 - len(temperatures))))
+        s = AnnealingConfigStruct(mode, int(never_accept_hard_regression), calibration_sample_size, 0, t, decay_rate,
+                                  hill_climbing_temperature, target_acceptance_probability, fallback_temperature, seed)
+        check(self._L.sf_solver_configure_annealing(self._h, C.byref(s)), self._h)
+
+    def annealing_state(self, replica=0):
+        """(current temperatures per score level, still calibrating?) of one replica's acceptor."""
+        t = np.zeros(4, dtype=np.float64)
+        c = C.c_int32(0)
+        check(self._L.sf_get_annealing_state(self._h, replica, ptr(t), C.byref(c)), self._h)
+        return t[:self.levels].copy(), bool(c.value)
 
     def set_engine(self, engine):
         """Pick the fused-kernel mapping (Engine.AUTO / BLOCK / WAVE); results are identical."""
