@@ -10,9 +10,15 @@ from oracle import sfo
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ls = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+# "la" = LateAcceptance(400)+AcceptedCount(256) (the list-policy components); "sa" = the reference's default
+# for scalar-only models: auto-calibrated SimulatedAnnealing + AcceptedCount(1) (default_local_search/policy.rs:56-77)
+policy = sys.argv[4] if len(sys.argv) > 4 else "la"
 g = datasets.make_graph(10000, 100000, 16, seed=0)
 d = sfa.build_graph_coloring(g, n_replicas=R)
-d.configure(sfa.SolverConfig(random_seed=0))
+if policy == "sa":
+    d.configure(sfa.SolverConfig(acceptor=sfa.Acceptor.SIMULATED_ANNEALING, accepted_count_limit=1, random_seed=0))
+else:
+    d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
 d.solve_steps(ls); d.profile_solve()
 b = d.total_stats()
@@ -24,16 +30,19 @@ ms, n = d.profile_solve()
 a = d.total_stats()
 moves = a["moves_evaluated"] - b["moves_evaluated"]; scored = a["candidates_scored"] - b["candidates_scored"]
 o = sfo.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
-o.configure(leaves=sfo.LEAF_SCALAR_CHANGE | sfo.LEAF_SCALAR_SWAP, random_seed=0)
+o.configure(leaves=sfo.LEAF_SCALAR_CHANGE | sfo.LEAF_SCALAR_SWAP, random_seed=0, limit=1 if policy == "sa" else 256)
+if policy == "sa":
+    o.configure_annealing(seed=0)
 o.phase_start(); o.steps(ls)
 m0 = o.stats()["moves_evaluated"]; t1 = time.perf_counter(); done = 0
-while done < K * ls and time.perf_counter() - t1 < 20: o.steps(10); done += 10
+while done < K * ls and time.perf_counter() - t1 < 10: o.steps(10); done += 10
 ct = time.perf_counter() - t1
 cm = o.stats()["moves_evaluated"] - m0
 match = bool((d.calculate_score()[0] == o.score()[:2]).all()) if done == K * ls else None
 # change candidate 28 + 8*deg = 188 B, swap 36 + 8*(deg u + deg v) = 356 B at deg 20
 alg = scored * (188 + 356) / 2
-print(json.dumps({"workload": "graph colouring 10k/100k/16", "replicas": R, "gpu_moves_per_s": moves / dt,
+print(json.dumps({"workload": "graph colouring 10k/100k/16", "policy": policy,
+                  "gpu_steps_per_s": (a["step_count"] - b["step_count"]) / dt, "cpu_steps_per_s": done / ct, "replicas": R, "gpu_moves_per_s": moves / dt,
                   "gpu_candidates_scored_per_s": scored / dt, "kernel_ms_per_launch": ms / n,
                   "alg_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12,
                   "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done, "replica0_matches_oracle": match,

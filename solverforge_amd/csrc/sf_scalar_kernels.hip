@@ -440,6 +440,9 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
     const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
     int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
+    // pulls per accepted candidate of the previous step: how far ahead of the forager's quota it pays to
+    // generate and trial-score (scheduling only: the consumed prefix, hence every result, is unchanged)
+    uint32_t prev_pulls = 64, prev_accepted = 1;
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         uint64_t sidx, sseed;
@@ -488,8 +491,15 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
 
         int done = 0;
         while (!done) {
-            // C1: fill the rings (>= 32 pending per live leaf, >= 64 when one leaf is live)
-            const uint32_t target = (!ex[0] && !ex[1]) ? 32u : 64u;
+            // C1: fill the rings: as many pending candidates as the forager is expected to consume before it
+            // quits (quota left x pulls per accept of the last step x 1.5), 8..64, split over the live leaves
+            uint32_t spec = 64;
+            if (p.forager != 2) {
+                const uint32_t want = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
+                const uint64_t est = ((uint64_t)want * prev_pulls * 3u) / (2u * prev_accepted);
+                spec = est >= 64 ? 64u : est < 8 ? 8u : (uint32_t)est;
+            }
+            const uint32_t target = (!ex[0] && !ex[1]) ? (spec + 1) / 2 : spec;
 #pragma unroll
             for (int l = 0; l < 2; ++l) {
                 if (l >= n_leaves) continue;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                     st_sources += 1;
                     if (is_change) {
                         // 64 consecutive (row, value-offset) slots of the change stream, one per lane
-                        const uint32_t e_row = (uint32_t)(((uint64_t)cst + (uint64_t)row[l] * csd) % n);
+                        const uint32_t e_row = fastmod_u64((uint64_t)cst + (uint64_t)row[l] * csd, fm_n);
                         const bool has_none = m.allows_unassigned && (int32_t)s_vals[e_row] >= 0;
                         const uint32_t per0 = vc + (has_none ? 1u : 0u);  // candidates of the current row
                         // lanes walk rows starting at (row, inner): rows have vc or vc+1 candidates
@@ -515,14 +525,14 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                             my_in -= per;
                             ++my_row;
                             if (my_row < n) {
-                                const uint32_t e2 = (uint32_t)(((uint64_t)cst + (uint64_t)my_row * csd) % n);
+                                const uint32_t e2 = fastmod_u64((uint64_t)cst + (uint64_t)my_row * csd, fm_n);
                                 per = vc + ((m.allows_unassigned && (int32_t)s_vals[e2] >= 0) ? 1u : 0u);
                             }
                         }
                         uint32_t e = 0;
                         int32_t v = -1;
                         if (valid) {
-                            e = (uint32_t)(((uint64_t)cst + (uint64_t)my_row * csd) % n);
+                            e = fastmod_u64((uint64_t)cst + (uint64_t)my_row * csd, fm_n);
                             if (my_in < vc) v = (int32_t)ctx.selection_index_fm(my_in, fm_vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)e ^ identity);
                         }
                         const uint64_t vm = __ballot(valid);
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                             gen_done[l] = 1;
                             break;
                         }
-                        const uint32_t left = n <= 1 ? 0u : (uint32_t)(((uint64_t)lst + (uint64_t)row[l] * lsd) % n);
+                        const uint32_t left = n <= 1 ? 0u : fastmod_u64((uint64_t)lst + (uint64_t)row[l] * lsd, fm_n);
                         const int32_t lv = (int32_t)s_vals[left];
                         const bool l_legal = lv >= 0 || m.allows_unassigned;
                         const uint64_t rsalt = (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)m.variable) ^ OFFSET_MIX;
@@ -730,6 +740,9 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
             }
         }
+
+        prev_pulls = pulls ? pulls : 1u;
+        prev_accepted = accepted ? accepted : 1u;
 
         // ---- commit the forager's pick ----
         const bool applied = has_best && !p.dry_run;
