@@ -23,6 +23,7 @@ LEAF_NEARBY_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP = 16, 32
 LEAF_LIST_REVERSE = 64
 LEAF_SUBLIST_CHANGE = 128
 LEAF_SUBLIST_SWAP = 256
+LEAF_KOPT = 512
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
 UNION_SEQUENTIAL, UNION_ROUND_ROBIN, UNION_ROTATING, UNION_RANDOM, UNION_STRATIFIED = 0, 1, 2, 3, 4
@@ -70,6 +71,7 @@ def lib():
             "sfo_model_fresh_score": (None, [vp, vp]),
             "sfo_model_reset": (None, [vp]),
             "sfo_model_configure": (None, [vp, i32, i32, i32, i32, i32, i32, u32, i32, i32, u64, i32]),
+            "sfo_model_set_kopt": (None, [vp, i32, i32]),
             "sfo_model_configure_annealing": (None, [vp, i32, vp, i32, i32, dbl, dbl, i32, i32, dbl, dbl, u64]),
             "sfo_model_annealing_state": (None, [vp, vp, vp, vp]),
             "sfo_xoshiro256pp": (None, [vp, i32, vp]),
@@ -214,6 +216,10 @@ class Model:
 
     def set_sublist_sizes(self, min_size, max_size):
         lib().sfo_model_set_sublist_sizes(self.h, min_size, max_size)
+
+    def set_kopt(self, min_segment_len=1, max_nearby=20):
+        """3-opt leaf parameters; max_nearby = 0 selects the full-enumeration cursor."""
+        lib().sfo_model_set_kopt(self.h, min_segment_len, max_nearby)
 
     def set_step_seeds(self, seeds):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

@@ -186,6 +186,11 @@ void sfo_model_set_sublist_sizes(void* h, int32_t min_size, int32_t max_size) {
     m->sublist_min = (size_t)min_size;
     m->sublist_max = (size_t)max_size;
 }
+void sfo_model_set_kopt(void* h, int32_t min_segment_len, int32_t max_nearby) {  // max_nearby 0 = full enumeration
+    Model* m = (Model*)h;
+    m->kopt_min_seg = (size_t)min_segment_len;
+    m->kopt_max_nearby = (size_t)max_nearby;
+}
 void sfo_model_set_step_seeds(void* h, const uint64_t* seeds, int32_t n) {
     ((Model*)h)->search.explicit_step_seeds.assign(seeds, seeds + n);
 }

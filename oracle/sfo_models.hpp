@@ -72,6 +72,7 @@ enum LeafBits : uint32_t {
     LEAF_LIST_REVERSE = 64,
     LEAF_SUBLIST_CHANGE = 128,
     LEAF_SUBLIST_SWAP = 256,
+    LEAF_KOPT = 512,  // k = 3; kopt_max_nearby > 0: distance-pruned (default policy with an intra-distance meter), 0: full
 };
 
 struct Model {
@@ -83,6 +84,7 @@ struct Model {
     uint32_t leaves = 0;
     size_t max_nearby = 20;
     size_t sublist_min = 1, sublist_max = 3;
+    size_t kopt_min_seg = 1, kopt_max_nearby = 20;  // KOptMoveSelectorConfig defaults + DEFAULT_LIST_NEARBY_LIMIT (policy/list.rs:19,144-160)
     UnionOrder union_order = UnionOrder::StratifiedRandom;
 
     std::unique_ptr<Cursor> open_leaf(uint32_t leaf, const ScoreDirector& d, const MoveStreamContext& ctx) const {
@@ -103,6 +105,9 @@ struct Model {
                 return std::make_unique<ListReverseCursor>(list_slot, d.working, ctx);
             case LEAF_SUBLIST_SWAP:
                 return std::make_unique<SublistSwapCursor>(list_slot, d.working, ctx, sublist_min, sublist_max);
+            case LEAF_KOPT:
+                if (kopt_max_nearby == 0) return std::make_unique<KOptCursor>(list_slot, d.working, ctx, kopt_min_seg);
+                return std::make_unique<NearbyKOptCursor>(list_slot, d.working, ctx, kopt_min_seg, kopt_max_nearby);
             case LEAF_SUBLIST_CHANGE:  // default sizes 1..=3 (solverforge-config/src/move_selector.rs:713-715)
                 return std::make_unique<SublistChangeCursor>(list_slot, d.working, ctx, sublist_min, sublist_max);
         }
@@ -115,7 +120,7 @@ struct Model {
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
         static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
                                          LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_SUBLIST_SWAP, LEAF_LIST_REVERSE,
-                                         LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
+                                         LEAF_KOPT,               LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
         std::vector<std::unique_ptr<Cursor>> children;
         for (uint32_t leaf : order)
             if (leaves & leaf) children.push_back(open_leaf(leaf, d, ctx));

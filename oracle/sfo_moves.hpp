@@ -30,7 +30,7 @@
 namespace sfo {
 
 struct Move {
-    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6 } kind = Change;
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6, KOpt = 7 } kind = Change;
     size_t descriptor = 0;
     size_t variable = 0;
     // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
@@ -41,6 +41,8 @@ struct Move {
     //                coordinates when a == b).
     // SublistSwap: segment [a_pos, a_pos + (to_value & 0xFFFF)) of list a <-> segment
     //                [b_pos, b_pos + (to_value >> 16)) of list b.
+    // KOpt (3-opt, one list): list a cut at positions a_pos < b < b_pos (NOTE: `b` carries the middle
+    //                cut, not an entity), reconnected by THREE_OPT_RECONNECTIONS[to_value].
     size_t a = 0, a_pos = 0, b = 0, b_pos = 0;
     int64_t to_value = NONE;
     bool allows_unassigned = false;
@@ -52,6 +54,21 @@ inline bool operator==(const Move& x, const Move& y) {
 
 struct MoveUndo {
     int64_t old_a = NONE, old_b = NONE;
+    std::vector<uint32_t> old_list;  // KOpt: the route before the reconnection (k_opt_do_move returns it)
+};
+
+// Reconnection patterns of a k-opt move (heuristic/move/k_opt_reconnection.rs:54-58,203-211):
+// `order[p]` = which of the k+1 segments sits at position p afterwards, bit i of `reverse` = segment i
+// (ORIGINAL index) is reversed.
+struct KOptReconnection {
+    uint8_t order[6];
+    uint8_t reverse;
+    uint8_t len;
+};
+static const KOptReconnection THREE_OPT_RECONNECTIONS[7] = {
+    {{0, 1, 2, 3, 0, 0}, 0b0010, 4}, {{0, 1, 2, 3, 0, 0}, 0b0100, 4}, {{0, 1, 2, 3, 0, 0}, 0b0110, 4},
+    {{0, 2, 1, 3, 0, 0}, 0b0000, 4}, {{0, 2, 1, 3, 0, 0}, 0b0010, 4}, {{0, 2, 1, 3, 0, 0}, 0b0100, 4},
+    {{0, 2, 1, 3, 0, 0}, 0b0110, 4},
 };
 
 inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
@@ -82,6 +99,12 @@ inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
         }
         case Move::ListReverse:  // move/list_kernel/reverse.rs:22-36
             return m.a < c.lists.size() && m.b_pos > m.a_pos + 1 && m.b_pos <= c.lists[m.a].size();
+        case Move::KOpt: {  // k_opt_is_doable (move/list_kernel/k_opt.rs:13-41): cuts inside the list, strictly increasing
+            if (m.to_value < 0 || m.to_value >= 7 || m.a >= c.lists.size()) return false;
+            size_t len = c.lists[m.a].size();
+            if (m.a_pos > len || m.b > len || m.b_pos > len) return false;
+            return m.b > m.a_pos && m.b_pos > m.b;
+        }
         case Move::SublistSwap: {  // move/list_kernel/sublist_swap.rs:17-43
             if (m.to_value < 0) return false;
             size_t fs = m.a_pos, fe = m.a_pos + (size_t)(m.to_value & 0xFFFF);
@@ -185,6 +208,24 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
             if (!intra) d.after_variable_changed(m.descriptor, m.b);
             break;
         }
+        case Move::KOpt: {  // k_opt_do_move (move/list_kernel/k_opt.rs:43-96)
+            d.before_variable_changed(m.descriptor, m.a);
+            auto& l = c.lists[m.a];
+            u.old_list = l;
+            const KOptReconnection& r = THREE_OPT_RECONNECTIONS[m.to_value];
+            const size_t bounds[5] = {0, m.a_pos, m.b, m.b_pos, l.size()};
+            std::vector<uint32_t> out;
+            out.reserve(l.size());
+            for (size_t p = 0; p < r.len; ++p) {
+                size_t seg = r.order[p];
+                std::vector<uint32_t> part(u.old_list.begin() + (ptrdiff_t)bounds[seg], u.old_list.begin() + (ptrdiff_t)bounds[seg + 1]);
+                if ((r.reverse >> seg) & 1) std::reverse(part.begin(), part.end());
+                out.insert(out.end(), part.begin(), part.end());
+            }
+            l = out;
+            d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
         case Move::SublistChange: {  // apply_sublist_change (move/list_kernel/sublist_change.rs:88-130)
             bool intra = m.a == m.b;
             d.before_variable_changed(m.descriptor, m.a);
@@ -259,6 +300,12 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             inv.b_pos = m.a_pos;
             MoveUndo ignored = move_do(d, inv);
             (void)ignored;
+            break;
+        }
+        case Move::KOpt: {  // k_opt_undo_move (move/list_kernel/k_opt.rs:98-119): put the old route back
+            d.before_variable_changed(m.descriptor, m.a);
+            c.lists[m.a] = u.old_list;
+            d.after_variable_changed(m.descriptor, m.a);
             break;
         }
         case Move::ListSwap:       // swap is its own inverse
@@ -1163,6 +1210,286 @@ struct UnionScheduler {
                 return false;
         }
         return false;
+    }
+};
+
+// ---- k-opt (3-opt) leaves ----------------------------------------------------------------
+inline size_t kopt_binomial(size_t n, size_t k) {  // selector/k_opt/iterators.rs:163-178
+    if (k > n) return 0;
+    if (k == 0 || k == n) return 1;
+    k = std::min(k, n - k);
+    size_t result = 1;
+    for (size_t i = 0; i < k; ++i) result = result * (n - i) / (i + 1);
+    return result;
+}
+inline size_t count_cut_combinations(size_t k, size_t len, size_t min_seg) {  // iterators.rs:98-106
+    size_t min_len = (k + 1) * min_seg;
+    if (len < min_len) return 0;
+    return kopt_binomial(len - min_len + k, k);
+}
+// rank -> cut positions in lexicographic order (iterators.rs:108-161)
+inline bool cut_combination_at(size_t k, size_t len, size_t min_seg, size_t rank, std::vector<size_t>& cuts) {
+    if (k == 0 || min_seg == 0 || len < (k + 1) * min_seg) return false;
+    size_t choice_count = len - (k + 1) * min_seg + k;
+    if (rank >= kopt_binomial(choice_count, k)) return false;
+    cuts.clear();
+    size_t start = 0;
+    for (size_t position = 0; position < k; ++position) {
+        size_t remaining = k - position - 1;
+        size_t maximum = choice_count - (k - position);
+        bool found = false;
+        size_t selected = 0;
+        for (size_t candidate = start; candidate <= maximum; ++candidate) {
+            size_t suffix = kopt_binomial(choice_count - candidate - 1, remaining);
+            if (rank < suffix) {
+                selected = candidate;
+                found = true;
+                break;
+            }
+            rank -= suffix;
+        }
+        if (!found) return false;
+        cuts.push_back(selected + min_seg + position * (min_seg - 1));
+        start = selected + 1;
+    }
+    return true;
+}
+inline Move make_kopt_move(size_t desc, size_t entity, const size_t cuts[3], size_t pattern) {
+    Move m;
+    m.kind = Move::KOpt;
+    m.descriptor = desc;
+    m.a = entity;
+    m.a_pos = cuts[0];
+    m.b = cuts[1];
+    m.b_pos = cuts[2];
+    m.to_value = (int64_t)pattern;
+    return m;
+}
+
+// Full-enumeration k-opt cursor (selector/list_kernel/k_opt/full.rs:12-101): per entity (order without
+// replacement), move offset -> selection_index over cut_count * patterns -> (cut rank, pattern).
+struct KOptCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x4B0F7E1171000001ULL, SALT_MOVE = 0x4B0F7E1171000002ULL;
+    size_t desc, k = 3, min_seg;
+    MoveStreamContext ctx;
+    std::vector<std::pair<size_t, size_t>> entity_lens;
+    size_t entity_offset = 0, move_offset = 0;
+    KOptCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c, size_t min_segment_len)
+        : desc(slot.descriptor_index), min_seg(min_segment_len), ctx(c) {
+        const EntityClass& cls = s.classes[desc];
+        std::vector<std::pair<size_t, size_t>> canonical;
+        for (size_t e = 0; e < cls.n; ++e) canonical.push_back({e, cls.lists[e].size()});
+        entity_lens = canonical;  // apply_selection_order_without_replacement (iter.rs:159-173)
+        if (!ctx.is_canonical())
+            for (size_t off = 0; off < canonical.size(); ++off)
+                entity_lens[off] = canonical[ctx.selection_index_without_replacement(off, canonical.size(), SALT_ENTITY ^ (uint64_t)desc)];
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (entity_offset >= entity_lens.size()) return false;
+            size_t entity = entity_lens[entity_offset].first, route_len = entity_lens[entity_offset].second;
+            size_t move_count = count_cut_combinations(k, route_len, min_seg) * 7;
+            if (move_offset >= move_count) {
+                ++entity_offset;
+                move_offset = 0;
+                continue;
+            }
+            size_t selected = ctx.selection_index(move_offset, move_count, SALT_MOVE ^ (uint64_t)desc ^ (uint64_t)entity);
+            ++move_offset;
+            std::vector<size_t> cuts;
+            cut_combination_at(k, route_len, min_seg, selected / 7, cuts);
+            out = make_kopt_move(desc, entity, cuts.data(), selected % 7);
+            return true;
+        }
+    }
+};
+
+// Lazy distance-pruned cut generation (selector/list_kernel/k_opt/nearby_state.rs:22-241), k = 3.
+struct NearbyCutState {
+    size_t entity, k = 3, len, max_nearby, min_seg;
+    std::vector<std::pair<size_t, size_t>> stack;  // (position, index in the level's cache)
+    std::vector<std::vector<size_t>> nearby_cache;
+    std::vector<size_t> first_positions;
+    size_t first_offset = 0;
+    MoveStreamContext ctx;
+    uint64_t salt;
+    bool done = false;
+    const Solution* sol;
+    const DistanceMeter* meter;
+
+    NearbyCutState(size_t e, size_t len_, size_t min_segment_len, size_t max_nearby_, const MoveStreamContext& c,
+                   uint64_t salt_, const Solution* s, const DistanceMeter* m)
+        : entity(e), len(len_), max_nearby(max_nearby_), min_seg(min_segment_len), ctx(c), salt(salt_), sol(s), meter(m) {
+        if (len < (k + 1) * min_seg) {  // :71-88
+            done = true;
+            return;
+        }
+        size_t maximum_first = len - min_seg * k;
+        std::vector<size_t> canonical;
+        for (size_t p = min_seg; p <= maximum_first; ++p) canonical.push_back(p);
+        first_positions = canonical;
+        if (!ctx.is_canonical())
+            for (size_t off = 0; off < canonical.size(); ++off)
+                first_positions[off] = canonical[ctx.selection_index_without_replacement(off, canonical.size(), salt ^ 0x4B0F7E1172EA0001ULL)];
+        stack.push_back({first_positions[0], 0});
+        nearby_cache.push_back({});
+    }
+    std::vector<size_t> nearby_positions(size_t origin) const {  // :22-52: stable sort by distance, truncate
+        std::vector<std::pair<size_t, double>> pos;
+        for (size_t p = 0; p < len; ++p)
+            if (p != origin) pos.push_back({p, (*meter)(*sol, entity, origin, entity, p)});
+        std::stable_sort(pos.begin(), pos.end(), [](const auto& l, const auto& r) { return l.second < r.second; });
+        if (pos.size() > max_nearby) pos.resize(max_nearby);
+        std::vector<size_t> out;
+        for (auto& pr : pos) out.push_back(pr.first);
+        return out;
+    }
+    bool backtrack() {  // :159-193
+        while (!stack.empty()) {
+            stack.pop_back();
+            nearby_cache.pop_back();
+            if (!stack.empty()) {
+                size_t cache_index = nearby_cache.size();
+                if (cache_index > 0) {
+                    const std::vector<size_t>& cache = nearby_cache[cache_index - 1];
+                    size_t next_index = stack.back().second + 1;
+                    if (next_index < cache.size()) {
+                        stack.back().second = next_index;
+                        size_t position = stack.back().first, next_position = cache[next_index];
+                        if (next_position > position) {
+                            stack.back() = {next_position, next_index};
+                            return true;
+                        }
+                    }
+                }
+            } else {
+                first_offset += 1;
+                if (first_offset < first_positions.size()) {
+                    stack.push_back({first_positions[first_offset], 0});
+                    nearby_cache.push_back({});
+                    return true;
+                }
+            }
+        }
+        return false;
+    }
+    void extend_stack() {  // :113-157
+        while (stack.size() < k && !done) {
+            size_t last_position = stack.back().first;
+            std::vector<size_t> nearby = nearby_positions(last_position);
+            size_t remaining_cuts = k - stack.size();
+            size_t minimum_position = last_position + min_seg;
+            size_t maximum_position = len - min_seg * remaining_cuts;
+            std::vector<size_t> valid;
+            for (size_t p : nearby)
+                if (p >= minimum_position && p <= maximum_position) valid.push_back(p);
+            if (!ctx.is_canonical()) {  // apply_selection_order: WITH replacement under Random (iter.rs:149-157)
+                std::vector<size_t> canonical = valid;
+                uint64_t s2 = salt ^ 0x4B0F7E1172EA0002ULL ^ ((uint64_t)last_position * 0x9E3779B97F4A7C15ULL) ^ (uint64_t)stack.size();
+                for (size_t off = 0; off < valid.size(); ++off) valid[off] = canonical[ctx.selection_index(off, canonical.size(), s2)];
+            }
+            if (valid.empty()) {
+                if (!backtrack()) {
+                    done = true;
+                    return;
+                }
+            } else {
+                size_t next_position = valid[0];
+                nearby_cache.push_back(valid);
+                stack.push_back({next_position, 0});
+            }
+        }
+    }
+    void advance() {  // :195-219
+        if (done || stack.empty()) {
+            done = true;
+            return;
+        }
+        const std::vector<size_t>& cache = nearby_cache.back();
+        size_t next_index = stack.back().second + 1;
+        if (next_index < cache.size()) {
+            stack.back() = {cache[next_index], next_index};
+            return;
+        }
+        if (backtrack())
+            extend_stack();
+        else
+            done = true;
+    }
+    bool next_cuts(size_t out[3]) {  // :221-240
+        extend_stack();
+        if (done || stack.size() != k) return false;
+        for (size_t i = 0; i < k; ++i) out[i] = stack[i].first;
+        advance();
+        return true;
+    }
+};
+
+// Distance-pruned k-opt cursor (selector/list_kernel/k_opt/nearby.rs:16-148): entities without
+// replacement, per entity the lazy cut stream, per cut set the 7 patterns in selection_index order.
+struct NearbyKOptCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x4B0F7E1172EA0003ULL, SALT_STATE = 0x4B0F7E1172EA0004ULL;
+    static constexpr uint64_t SALT_PATTERN = 0x4B0F7E1172EA0005ULL;
+    size_t desc, min_seg, max_nearby;
+    MoveStreamContext ctx;
+    Solution solution;  // the cursor works on a clone taken at open (slot.rs:436)
+    DistanceMeter meter;
+    std::vector<std::pair<size_t, size_t>> entity_lens;
+    size_t entity_offset = 0;
+    std::unique_ptr<NearbyCutState> state;
+    bool has_pending = false;
+    size_t pending[3] = {0, 0, 0}, pending_entity = 0, pattern_offset = 0;
+
+    NearbyKOptCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c, size_t min_segment_len, size_t max_nearby_)
+        : desc(slot.descriptor_index), min_seg(min_segment_len), max_nearby(max_nearby_), ctx(c), solution(s), meter(slot.meter) {
+        const EntityClass& cls = s.classes[desc];
+        std::vector<std::pair<size_t, size_t>> canonical;
+        for (size_t e = 0; e < cls.n; ++e) canonical.push_back({e, cls.lists[e].size()});
+        entity_lens = canonical;
+        if (!ctx.is_canonical())
+            for (size_t off = 0; off < canonical.size(); ++off)
+                entity_lens[off] = canonical[ctx.selection_index_without_replacement(off, canonical.size(), SALT_ENTITY ^ (uint64_t)desc)];
+    }
+    bool load_next_cut_state() {  // :85-104
+        while (entity_offset < entity_lens.size()) {
+            size_t entity = entity_lens[entity_offset].first, route_len = entity_lens[entity_offset].second;
+            ++entity_offset;
+            auto st = std::make_unique<NearbyCutState>(entity, route_len, min_seg, max_nearby, ctx,
+                                                       SALT_STATE ^ (uint64_t)desc ^ (uint64_t)entity, &solution, &meter);
+            if (!st->done) {
+                state = std::move(st);
+                return true;
+            }
+        }
+        return false;
+    }
+    bool next(Move& out) override {  // :112-148
+        for (;;) {
+            if (has_pending) {
+                if (pattern_offset < 7) {
+                    uint64_t salt = SALT_PATTERN ^ (uint64_t)desc;
+                    for (size_t i = 0; i < 3; ++i)
+                        salt ^= ((uint64_t)pending_entity * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)pending[i] * 0xBF58476D1CE4E5B9ULL);
+                    size_t pattern = ctx.selection_index(pattern_offset, 7, salt);
+                    ++pattern_offset;
+                    out = make_kopt_move(desc, pending_entity, pending, pattern);
+                    return true;
+                }
+                has_pending = false;
+                pattern_offset = 0;
+            }
+            if (!state && !load_next_cut_state()) return false;
+            size_t cuts[3];
+            if (state->next_cuts(cuts)) {
+                std::sort(cuts, cuts + 3);
+                for (size_t i = 0; i < 3; ++i) pending[i] = cuts[i];
+                pending_entity = state->entity;
+                has_pending = true;
+                pattern_offset = 0;
+                continue;
+            }
+            state.reset();
+        }
     }
 };
 

@@ -426,6 +426,84 @@ static void list_reverse_cases() {
     }
 }
 
+// heuristic/move/tests/k_opt.rs:86-222 (do / undo / doability), selector/k_opt/tests.rs:80-147 and
+// selector/tests/k_opt.rs (first combination, 35 combinations, 245 moves, all doable),
+// benches/selector_cursor_gate.rs:370-382 (4,760 moves on an 18-element route)
+static void k_opt_cases() {
+    auto mk = [](std::vector<uint32_t> cities) {
+        ScoreDirector d;
+        d.working.classes.resize(1);
+        d.working.classes[0].n = 1;
+        d.working.classes[0].lists = {cities};
+        return d;
+    };
+    auto kopt = [](size_t c1, size_t c2, size_t c3, size_t pattern) {
+        const size_t cuts[3] = {c1, c2, c3};
+        return make_kopt_move(0, 0, cuts, pattern);
+    };
+    {
+        ScoreDirector d = mk({1, 2, 3, 4, 5, 6, 7, 8});
+        Move m = kopt(2, 4, 6, 3);
+        bool ok = move_is_doable(d, m);
+        MoveUndo u = move_do(d, m);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 5, 6, 3, 4, 7, 8});
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4, 5, 6, 7, 8});
+        CHECK("k_opt.three_opt_swap_segments", ok);
+    }
+    {
+        ScoreDirector d = mk({1, 2, 3, 4, 5, 6, 7, 8});
+        Move m = kopt(2, 4, 6, 0);
+        bool ok = move_is_doable(d, m);
+        MoveUndo u = move_do(d, m);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 4, 3, 5, 6, 7, 8});
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4, 5, 6, 7, 8});
+        CHECK("k_opt.three_opt_reverse_segment", ok);
+    }
+    {
+        ScoreDirector d = mk({1, 2, 3});
+        CHECK("k_opt.invalid_cuts_not_doable", !move_is_doable(d, kopt(2, 4, 10, 0)));
+        ScoreDirector e = mk({1, 2, 3, 4, 5, 6, 7, 8});
+        CHECK("k_opt.cuts_not_sorted_not_doable", !move_is_doable(e, kopt(4, 2, 6, 0)));
+    }
+    {
+        std::vector<size_t> cuts;
+        bool ok = cut_combination_at(3, 8, 1, 0, cuts) && cuts == std::vector<size_t>({1, 2, 3});
+        ok = ok && count_cut_combinations(3, 8, 1) == 35 && count_cut_combinations(3, 6, 2) == 0;
+        ok = ok && kopt_binomial(5, 2) == 10 && kopt_binomial(7, 3) == 35 && kopt_binomial(10, 5) == 252;
+        // every rank maps to a distinct increasing triple inside 1..=7, in lexicographic order
+        std::vector<size_t> prev;
+        for (size_t r = 0; r < 35; ++r) {
+            ok = ok && cut_combination_at(3, 8, 1, r, cuts) && cuts[0] >= 1 && cuts[0] < cuts[1] && cuts[1] < cuts[2] && cuts[2] <= 7;
+            if (r) ok = ok && prev < cuts;
+            prev = cuts;
+        }
+        ok = ok && !cut_combination_at(3, 8, 1, 35, cuts);
+        CHECK("k_opt.cut_combinations", ok);
+    }
+    {
+        ScoreDirector d = mk({1, 2, 3, 4, 5, 6, 7, 8});
+        ListSlot slot;
+        KOptCursor cur(slot, d.working, MoveStreamContext(), 1);
+        Move m;
+        size_t count = 0;
+        bool all_doable = true;
+        while (cur.next(m)) {
+            ++count;
+            all_doable = all_doable && move_is_doable(d, m);
+        }
+        CHECK("k_opt.selector_generates_245_doable_moves", count == 245 && all_doable);
+        std::vector<uint32_t> route(18);
+        for (size_t i = 0; i < 18; ++i) route[i] = (uint32_t)i;
+        ScoreDirector g = mk(route);
+        KOptCursor gate(slot, g.working, MoveStreamContext(), 1);
+        count = 0;
+        while (gate.next(m)) ++count;
+        CHECK("k_opt.selector_gate_4760", count == 4760);
+    }
+}
+
 // phase/localsearch/acceptor/simulated_annealing/tests.rs:40-273 (every case) + the published
 // xoshiro256++ test vector for the SmallRng restatement.
 static void simulated_annealing_cases() {
@@ -544,6 +622,7 @@ static void simulated_annealing_cases() {
 }
 
 int main() {
+    k_opt_cases();
     simulated_annealing_cases();
     list_reverse_cases();
     bi_incr_cases();
