@@ -66,8 +66,11 @@ typedef enum sf_move_kind {
     SF_MOVE_LIST_REVERSE = 4,/* heuristic/move/list_kernel/reverse.rs:15-57: reverse list `a` over [a_pos, b_pos) (b = a) */
     SF_MOVE_SUBLIST_CHANGE = 5,/* heuristic/move/list_kernel/sublist_change.rs:18-130: segment [a_pos, value) of list `a`
                                   -> list `b` at b_pos (post-removal coordinates when a == b) */
-    SF_MOVE_SUBLIST_SWAP = 6   /* heuristic/move/list_kernel/sublist_swap.rs:17-160: segment [a_pos, a_pos + (value & 0xFFFF)) of
+    SF_MOVE_SUBLIST_SWAP = 6,  /* heuristic/move/list_kernel/sublist_swap.rs:17-160: segment [a_pos, a_pos + (value & 0xFFFF)) of
                                   list `a` <-> segment [b_pos, b_pos + (value >> 16)) of list `b` */
+    SF_MOVE_KOPT = 7           /* heuristic/move/list_kernel/k_opt.rs:13-96 with k = 3: list `a` cut at a_pos < b < b_pos (`b`
+                                  carries the MIDDLE CUT, not an entity) and reconnected by
+                                  THREE_OPT_RECONNECTIONS[value] (move/k_opt_reconnection.rs:203-211), value in 0..6 */
 } sf_move_kind;
 
 /* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
@@ -112,6 +115,10 @@ typedef enum sf_selector_kind {
     SF_SEL_NEARBY_LIST_SWAP = 32,  /* selector/list_kernel/nearby_swap.rs:17-260 */
     SF_SEL_LIST_REVERSE = 64,      /* selector/list_kernel/reverse.rs:12-108 (intra-list 2-opt) */
     SF_SEL_SUBLIST_CHANGE = 128,   /* selector/list_kernel/sublist_change.rs:13-266 (Or-opt); sizes via sf_selector_add_sublist */
+    SF_SEL_KOPT = 512,             /* 3-opt leaf, sf_selector_add_kopt: max_nearby > 0 = distance-pruned cursor
+                                      (selector/list_kernel/k_opt/nearby.rs, nearby_state.rs; the default-policy leaf of lists
+                                      with an intra-distance meter, policy/list.rs:144-160), 0 = full enumeration
+                                      (selector/list_kernel/k_opt/full.rs) */
     SF_SEL_SUBLIST_SWAP = 256      /* selector/list_kernel/sublist_swap.rs:13-330; sizes via sf_selector_add_sublist */
 } sf_selector_kind;
 
@@ -225,6 +232,10 @@ int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int
 /* sublist leaves: segment sizes min_size..=max_size (default 1..=3, solverforge-config/src/move_selector.rs:713-715; <= 15) */
 int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int32_t variable_index,
                                 int32_t min_size, int32_t max_size);
+/* k-opt leaf (KOptMoveSelectorConfig, solverforge-config/src/move_selector.rs:521-550): k = 3 only; min_segment_len default 1;
+ * max_nearby = 0 -> full enumeration, 1..64 -> distance-pruned by the list's matrix meter (the default policy passes 20) */
+int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t k,
+                             int32_t min_segment_len, int32_t max_nearby);
 
 /* ---- Director surface -------------------------------------------------------------------- */
 /* ≙ first Director::calculate_score (initialize_all): builds per-replica aggregates.

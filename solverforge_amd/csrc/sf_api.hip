@@ -86,6 +86,7 @@ struct sf_ctx {
     int32_t* d_trace_applied = nullptr;
     int64_t trace_cap = 0;
     // scratch
+    uint64_t* d_kopt_scratch = nullptr;  // [R][n_cap] distance keys of long routes (distance-pruned 3-opt leaf)
     int64_t* d_scores_out = nullptr;
     int32_t* d_ok = nullptr;
     // profiling
@@ -297,6 +298,19 @@ int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32
     if (!ctx) return SF_ERR_INVALID;
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
     ctx->selectors.push_back({kind, d, var, max_nearby, fact_meter});
+    return SF_OK;
+}
+
+int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t d, int32_t var, int32_t k, int32_t min_segment_len, int32_t max_nearby) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
+    if (k != 3) return fail(ctx, SF_ERR_UNSUPPORTED, "k-opt leaf: only k = 3 (the reference default) runs on the device");
+    if (min_segment_len < 1 || min_segment_len > 4096) return fail(ctx, SF_ERR_INVALID, "k-opt min_segment_len must be >= 1");
+    if (max_nearby < 0 || max_nearby > (int32_t)KOPT_MAX_NEARBY) return fail(ctx, SF_ERR_UNSUPPORTED, "k-opt max_nearby must be 0 (full enumeration) or 1..64");
+    SelectorSpec s{SF_SEL_KOPT, d, var, max_nearby, -1};
+    s.min_size = min_segment_len;
+    s.max_size = min_segment_len;
+    ctx->selectors.push_back(s);
     return SF_OK;
 }
 
@@ -655,12 +669,15 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
     int rc = alloc_search(ctx);
     if (rc) return rc;
-    const bool list_move = mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_SUBLIST_SWAP;
+    const bool list_move = mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_KOPT;
     if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
     if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");
     if (list_move) {
-        if (mv->a < 0 || mv->a >= ctx->lm.V || mv->b < 0 || mv->b >= ctx->lm.V || mv->a_pos < 0 || mv->b_pos < 0)
+        if (mv->a < 0 || mv->a >= ctx->lm.V || mv->b < 0 || (mv->kind != SF_MOVE_KOPT && mv->b >= ctx->lm.V) || mv->a_pos < 0 ||
+            mv->b_pos < 0)
             return fail(ctx, SF_ERR_INVALID, "move out of range");
+        if (mv->kind == SF_MOVE_KOPT && (mv->value < 0 || mv->value >= 7))
+            return fail(ctx, SF_ERR_INVALID, "3-opt move: value is the reconnection pattern 0..6");
         if (mv->kind == SF_MOVE_SUBLIST_CHANGE && (mv->value <= mv->a_pos || mv->value - mv->a_pos > 255))
             return fail(ctx, SF_ERR_INVALID, "sublist move: value must be the segment end (segment of 1..255 elements)");
         if (mv->kind == SF_MOVE_SUBLIST_SWAP && (mv->value <= 0 || (mv->value & 0xFFFF) == 0 || (mv->value & 0xFFFF) > 255 ||
@@ -823,7 +840,8 @@ int32_t sf_phase_start(sf_ctx* ctx) {
 template <int L, bool TRACE, class VT>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
-    GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0);
+    GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
+                  gl.kopt_nearby);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     int wpb = (int)((SF_LDS_BUDGET) / cv.total);
     if (wpb > 4) wpb = 4;
@@ -839,7 +857,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
 static bool has_plain_list_leaves(sf_ctx* ctx) {
     for (auto& s : ctx->selectors)
         if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP || s.kind == SF_SEL_LIST_REVERSE ||
-                                         s.kind == SF_SEL_SUBLIST_CHANGE || s.kind == SF_SEL_SUBLIST_SWAP))
+                                         s.kind == SF_SEL_SUBLIST_CHANGE || s.kind == SF_SEL_SUBLIST_SWAP || s.kind == SF_SEL_KOPT))
             return true;
     return false;
 }
@@ -849,7 +867,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // default-policy declaration order: list rules first, then scalar change, scalar swap
     // (runtime/compiler/default_local_search/policy.rs:104-108)
     for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
-                     SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+                     SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
         for (auto& s : ctx->selectors) {
             const bool is_list = kind != SF_SEL_SCALAR_CHANGE && kind != SF_SEL_SCALAR_SWAP;
             if (s.kind != kind) continue;
@@ -861,6 +879,20 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                 if (gl.has_nearby >= 2) return fail(ctx, SF_ERR_UNSUPPORTED, "at most two nearby leaves per union");
                 gl.has_nearby += 1;
                 gl.max_nearby[gl.n] = s.max_nearby;
+            }
+            if (kind == SF_SEL_KOPT) {
+                for (int l = 0; l < gl.n; ++l)
+                    if (gl.kind[l] == SF_SEL_KOPT) return fail(ctx, SF_ERR_UNSUPPORTED, "one 3-opt leaf per union");
+                gl.max_nearby[gl.n] = s.max_nearby;
+                if (s.max_nearby > 0) {
+                    if (!ctx->lm.mat) return fail(ctx, SF_ERR_INVALID, "distance-pruned 3-opt needs the matrix meter");
+                    if (!ctx->d_kopt_scratch) {
+                        int rc = dalloc(ctx, &ctx->d_kopt_scratch, (size_t)ctx->R * ctx->lm.n_cap);
+                        if (rc) return rc;
+                    }
+                    gl.kopt_nearby = 1;
+                    gl.kopt_scratch = ctx->d_kopt_scratch;
+                }
             }
             gl.min_size[gl.n] = s.min_size;
             gl.max_size[gl.n] = s.max_size;

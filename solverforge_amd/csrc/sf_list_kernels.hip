@@ -337,6 +337,59 @@ __device__ __forceinline__ ListDelta eval_list_reverse(const ListModel& m, const
     return r;
 }
 
+// Reconnection patterns of a 3-opt move (heuristic/move/k_opt_reconnection.rs:203-211,
+// THREE_OPT_RECONNECTIONS): patterns 0..2 keep the order A B C D, patterns 3..6 place C before B;
+// bit 1 / bit 2 of the mask reverse segment B / C (flags follow the ORIGINAL segment index,
+// move/list_kernel/k_opt.rs:73-80).
+__device__ __forceinline__ bool kopt_swaps_segments(uint32_t pattern) { return pattern >= 3; }
+__device__ __forceinline__ uint32_t kopt_reverse_mask(uint32_t pattern) {
+    return pattern < 3 ? (pattern + 1u) << 1 : (pattern - 3u) << 1;  // {2,4,6} / {0,2,4,6}
+}
+
+// KOptMove with k = 3 on one list (move/list_kernel/k_opt.rs:13-96): cuts c1 < c2 < c3 split list a into
+// A = [0,c1) B = [c1,c2) C = [c2,c3) D = [c3,len).  Only the distance aggregate can change; the matrix may
+// be asymmetric, so a reversed segment is re-walked in the other direction.
+template <class VT>
+__device__ __forceinline__ ListDelta eval_kopt(const ListModel& m, const VT* visits, const uint32_t* off, uint32_t a,
+                                               uint32_t c1, uint32_t c2, uint32_t c3, uint32_t pattern) {
+    ListDelta r{0, 0, false};
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    if (!(pattern < 7 && c1 < c2 && c2 < c3 && c3 <= la)) return r;  // k_opt_is_doable
+    r.doable = true;
+    if (m.dist_level >= 0) {
+        const uint32_t depot = (uint32_t)m.depot;
+        const uint32_t prev = c1 > 0 ? (uint32_t)visits[oa + c1 - 1] : depot;
+        const uint32_t next = c3 < la ? (uint32_t)visits[oa + c3] : depot;
+        const uint32_t bf = visits[oa + c1], bl = visits[oa + c2 - 1], cf = visits[oa + c2], cl = visits[oa + c3 - 1];
+        int64_t fB = 0, gB = 0, fC = 0, gC = 0;  // forward / backward internal leg sums
+        uint32_t u = bf;
+        for (uint32_t t = c1 + 1; t < c2; ++t) {
+            const uint32_t w = visits[oa + t];
+            fB = wadd(fB, dist_cost(m.mat, m.dim, u, w));
+            gB = wadd(gB, dist_cost(m.mat, m.dim, w, u));
+            u = w;
+        }
+        u = cf;
+        for (uint32_t t = c2 + 1; t < c3; ++t) {
+            const uint32_t w = visits[oa + t];
+            fC = wadd(fC, dist_cost(m.mat, m.dim, u, w));
+            gC = wadd(gC, dist_cost(m.mat, m.dim, w, u));
+            u = w;
+        }
+        const int64_t old_cost = wadd(wadd(wadd(dist_cost(m.mat, m.dim, prev, bf), fB), wadd(dist_cost(m.mat, m.dim, bl, cf), fC)),
+                                      dist_cost(m.mat, m.dim, cl, next));
+        const uint32_t mask = kopt_reverse_mask(pattern);
+        const bool rb = (mask >> 1) & 1u, rc = (mask >> 2) & 1u, sw = kopt_swaps_segments(pattern);
+        const uint32_t Bf = rb ? bl : bf, Bl = rb ? bf : bl, Cf = rc ? cl : cf, Cl = rc ? cf : cl;
+        const int64_t cB = rb ? gB : fB, cC = rc ? gC : fC;
+        const uint32_t Xf = sw ? Cf : Bf, Xl = sw ? Cl : Bl, Yf = sw ? Bf : Cf, Yl = sw ? Bl : Cl;
+        const int64_t new_cost = wadd(wadd(wadd(dist_cost(m.mat, m.dim, prev, Xf), cB), wadd(dist_cost(m.mat, m.dim, Xl, Yf), cC)),
+                                      dist_cost(m.mat, m.dim, Yl, next));
+        r.d_dist = wsub(new_cost, old_cost);
+    }
+    return r;
+}
+
 // SublistChangeMove: segment [s, e) of list a -> list b at position dp, dp in post-removal coordinates
 // when a == b (move/list_kernel/sublist_change.rs:18-130).  The segment keeps its direction.
 template <class VT>
@@ -566,7 +619,7 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
                                                              int32_t* out_doable, int skip_foreign) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 6)) return;  // a scalar move of a mixed model
+    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 7)) return;  // a scalar move of a mixed model
     const uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
     const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
     const int64_t* load = m.load + (size_t)replica * m.V;
@@ -574,7 +627,8 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
     const int32_t* mv = moves + t * 6;
     int32_t kind = mv[0];
     ListDelta d{0, 0, false};
-    bool in_range = mv[1] >= 0 && mv[1] < m.V && mv[3] >= 0 && mv[3] < m.V && mv[2] >= 0 && mv[4] >= 0;
+    // (a 3-opt move carries its middle cut in `b`, not an entity)
+    bool in_range = mv[1] >= 0 && mv[1] < m.V && mv[3] >= 0 && (kind == 7 || mv[3] < m.V) && mv[2] >= 0 && mv[4] >= 0;
     if (in_range) {
         if (kind == 2)
             d = eval_list_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);
@@ -587,6 +641,8 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
                                   (uint32_t)mv[3], (uint32_t)mv[4], (uint32_t)mv[4] + ((uint32_t)mv[5] >> 16));
         else if (kind == 5 && mv[5] >= 0)
             d = eval_sublist_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[5], (uint32_t)mv[3], (uint32_t)mv[4]);
+        else if (kind == 7 && mv[5] >= 0 && mv[3] >= 0)  // (a, a_pos = cut 1, b = cut 2, b_pos = cut 3, value = pattern)
+            d = eval_kopt(m, visits, off, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4], (uint32_t)mv[5]);
     }
     out_doable[t] = d.doable ? 1 : 0;
     ScoreV<4> s = apply_delta<4>(m, cur, d);
@@ -695,6 +751,27 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
             visits[lo + t] = y;
             visits[hi - 1 - t] = x;
         }
+    } else if (kind == 7) {  // 3-opt: cuts i < b < j of list a, pattern = ext; at most three range reversals
+        const uint32_t base = off[a], c1 = i, c2 = b, c3 = j;
+        const uint32_t mask = kopt_reverse_mask(ext);
+        const bool rb = (mask >> 1) & 1u, rc = (mask >> 2) & 1u;
+        auto reverse_range = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t t = threadIdx.x; t < (hi - lo) / 2; t += blockDim.x) {
+                const uint32_t x = visits[base + lo + t], y = visits[base + hi - 1 - t];
+                visits[base + lo + t] = y;
+                visits[base + hi - 1 - t] = x;
+            }
+            __syncthreads();
+        };
+        if (!kopt_swaps_segments(ext)) {
+            if (rb) reverse_range(c1, c2);
+            if (rc) reverse_range(c2, c3);
+        } else {  // B C -> reverse all = C^r B^r, then undo the reversal of whichever segment keeps its direction
+            const uint32_t zc = c3 - c2;
+            reverse_range(c1, c3);
+            if (!rc) reverse_range(c1, c1 + zc);
+            if (!rb) reverse_range(c1 + zc, c3);
+        }
     } else if (kind == 3) {
         if (threadIdx.x == 0) {
             uint32_t pa = off[a] + i, pb = off[b] + j;
@@ -722,6 +799,7 @@ __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, in
         s_d = kind == 2   ? eval_list_change(m, visits, off, load, a, i, b, j)
               : kind == 3 ? eval_list_swap(m, visits, off, load, a, i, b, j)
               : kind == 4 ? eval_list_reverse(m, visits, off, a, i, j)
+              : kind == 7 ? eval_kopt(m, visits, off, a, i, b, j, ext)
               : kind == 5 ? eval_sublist_change(m, visits, off, load, a, i, ext, b, j)
                           : eval_sublist_swap(m, visits, off, load, a, i, i + (ext & 0xFFFFu), b, j, j + (ext >> 16));
     }

@@ -258,6 +258,27 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
             visits[lo + t] = y;
             visits[hi - 1 - t] = x;
         }
+    } else if (kind == 7) {  // 3-opt: cuts i < b < j of list a (b carries the middle cut), pattern = ext
+        const uint32_t base = off[a], c1 = i, c2 = b, c3 = j;
+        const uint32_t mask = kopt_reverse_mask(ext);
+        const bool rb = (mask >> 1) & 1u, rc = (mask >> 2) & 1u;
+        auto reverse_range = [&](uint32_t lo, uint32_t hi) {
+            for (uint32_t t = lane; t < (hi - lo) / 2; t += 64) {
+                const uint16_t x = visits[base + lo + t], y = visits[base + hi - 1 - t];
+                visits[base + lo + t] = y;
+                visits[base + hi - 1 - t] = x;
+            }
+            wave_sync();
+        };
+        if (!kopt_swaps_segments(ext)) {
+            if (rb) reverse_range(c1, c2);
+            if (rc) reverse_range(c2, c3);
+        } else {
+            const uint32_t zc = c3 - c2;
+            reverse_range(c1, c3);
+            if (!rc) reverse_range(c1, c1 + zc);
+            if (!rb) reverse_range(c1 + zc, c3);
+        }
     } else if (kind == 3) {
         if (lane == 0) {
             const uint32_t pa = off[a] + i, pb = off[b] + j;

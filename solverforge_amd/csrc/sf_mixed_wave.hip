@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sf_kopt.h"
 #include "sf_list_model.h"
 
 namespace sf {
@@ -50,15 +51,17 @@ struct GLeaves {
     int32_t max_nearby[GL];  // nearby leaves (kinds 16 / 32)
     int32_t has_nearby;
     int32_t levels;  // score levels of the model (the kernel is instantiated for 2 or 4)
-    int32_t min_size[GL], max_size[GL];  // sublist leaves
+    int32_t min_size[GL], max_size[GL];  // sublist leaves; k-opt leaf: min_size = min_segment_len
+    int32_t kopt_nearby;     // the union has a distance-pruned 3-opt leaf (kind 512, max_nearby > 0)
+    uint64_t* kopt_scratch;  // [R][n_cap] distance keys of routes longer than KOPT_LDS_KEYS
 };
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, total;
+    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
-    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby) {
+    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * GRC * GL, 16);
@@ -82,6 +85,8 @@ struct GCarve {
         o = align_up(o + sizeof(uint16_t) * n_cap, 16);
         vals = o;
         o = align_up(o + sizeof(VT) * n_scalar, 16);
+        kopt = o;  // working set of the distance-pruned 3-opt stream
+        o = align_up(o + (kopt_nearby ? KoptLds::bytes : 0), 16);
         total = o;
     }
 };
@@ -99,6 +104,8 @@ struct GCarve {
 //                 e = second segment start offset window
 //  nearby change / swap: a = entity rank, b = offset in the entity's list, c / d = rank / offset base the
 //                 leaf's position vector holds, e = sources left
+//  3-opt (full):  a = entity rank, b / c = low / high word of the move offset
+//  3-opt (distance-pruned): a = entity rank of the NEXT entity to open (the cut state machine lives in LDS)
 struct GGen {
     uint32_t a, b, c, d, e, f;
     int done;
@@ -119,7 +126,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
-    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0);
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
     uint8_t* ringx = (uint8_t*)(mem + cv.ringx);  // [leaf][GRC]
@@ -215,6 +222,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         // entity permutations (selection_index_without_replacement) of the four streams
         uint32_t sc_st = 0, sc_sd = 1, ss_st = 0, ss_sd = 1, lc_st = 0, lc_sd = 1, ls_st = 0, ls_sd = 1, lr_st = 0, lr_sd = 1;
         uint32_t sb_st = 0, sb_sd = 1, sw_st = 0, sw_sd = 1;  // sublist change / swap entity permutations
+        uint32_t ko_st = 0, ko_sd = 1;                        // 3-opt entity permutation
         if (has_scalar) {
             ctx.perm_params(ns, SALT_SCALAR_CHANGE_ENTITY ^ identity, sc_st, sc_sd);
             ctx.perm_params(ns, (SALT_SCALAR_SWAP_LEFT ^ identity) ^ OFFSET_MIX, ss_st, ss_sd);
@@ -225,12 +233,20 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             ctx.perm_params((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd);
             ctx.perm_params((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd);
             ctx.perm_params((uint32_t)V, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd);
+            ctx.perm_params((uint32_t)V, (gl.kopt_nearby ? SALT_KN_ENTITY : SALT_KF_ENTITY) ^ ldesc, ko_st, ko_sd);
         }
         sc_st = uni(sc_st), sc_sd = uni(sc_sd), ss_st = uni(ss_st), ss_sd = uni(ss_sd);
         lc_st = uni(lc_st), lc_sd = uni(lc_sd), ls_st = uni(ls_st), ls_sd = uni(ls_sd);
         lr_st = uni(lr_st), lr_sd = uni(lr_sd);
         sb_st = uni(sb_st), sb_sd = uni(sb_sd);
         sw_st = uni(sw_st), sw_sd = uni(sw_sd);
+        ko_st = uni(ko_st), ko_sd = uni(ko_sd);
+        auto ko_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)ko_st + (uint64_t)rank * ko_sd) % (uint32_t)V); };
+        if (gl.kopt_nearby) {  // a fresh cursor per step: no entity open yet
+            KoptLds km(mem + cv.kopt);
+            if (lane == 0) km.st[15] = 0;
+            wave_sync();
+        }
         auto sw_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)sw_st + (uint64_t)rank * sw_sd) % (uint32_t)V); };
         auto sb_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)sb_st + (uint64_t)rank * sb_sd) % (uint32_t)V); };
         auto lr_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lr_st + (uint64_t)rank * lr_sd) % (uint32_t)V); };
@@ -612,6 +628,87 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         g.b += 1;
                         g.e -= 1;
                         if (g.e == 0) g.done = 1;
+                    } else if (kind == 512 && gl.max_nearby[l] == 0) {  // ---- 3-opt, full enumeration (k_opt/full.rs:62-92) ----
+                        const uint32_t mseg = (uint32_t)gl.min_size[l];
+                        uint32_t ent = 0, len = 0;
+                        uint64_t mc = 0, mo = 0;
+                        for (;;) {
+                            if (g.a >= (uint32_t)V) break;
+                            ent = ko_ent(g.a);
+                            len = rlen(ent);
+                            mc = kopt_cut_count(len, mseg) * 7ull;
+                            mo = ((uint64_t)g.c << 32) | g.b;
+                            if (mo < mc) break;
+                            g.a += 1;
+                            g.b = 0;
+                            g.c = 0;
+                        }
+                        if (g.a >= (uint32_t)V) {
+                            g.done = 1;
+                            break;
+                        }
+                        const uint64_t o = mo + lane;
+                        if (o < mc) {
+                            const uint64_t selected = kopt_selection_index64(ctx, o, mc, SALT_KF_MOVE ^ ldesc ^ (uint64_t)ent);
+                            uint32_t c1, c2, c3;
+                            kopt_unrank(len, mseg, selected / 7ull, c1, c2, c3);
+                            keep = true;
+                            w0 = (ent << 16) | c1;
+                            w1 = (c2 << 16) | c3;
+                            wx = (uint32_t)(selected % 7ull);
+                        }
+                        mo += 64;
+                        g.b = (uint32_t)mo;
+                        g.c = (uint32_t)(mo >> 32);
+                    } else if (kind == 512) {  // ---- 3-opt, distance-pruned (k_opt/nearby.rs:106-148, nearby_state.rs) ----
+                        const KoptLds km(mem + cv.kopt);
+                        const KoptEnv env{&lm,   s_visits, s_off, km, gl.kopt_scratch + (size_t)r * lm.n_cap, ctx, ldesc,
+                                          (uint32_t)gl.min_size[l], (uint32_t)gl.max_nearby[l], lane};
+                        KoptS ks;
+                        kopt_load_state(km.st, ks);
+                        uint32_t ntr = 0;
+                        while (ntr < KOPT_TRIPLES) {
+                            if (!ks.active) {  // load_next_cut_state: the next entity whose route admits three cuts
+                                bool opened = false;
+                                while (g.a < (uint32_t)V) {
+                                    const uint32_t ent = ko_ent(g.a);
+                                    g.a += 1;
+                                    kopt_open_entity(env, ks, ent, rlen(ent));
+                                    if (!ks.done) {
+                                        opened = true;
+                                        break;
+                                    }
+                                }
+                                if (!opened) {
+                                    ks.active = 0;
+                                    g.done = 1;
+                                    break;
+                                }
+                            }
+                            uint32_t c1 = 0, c2 = 0, c3 = 0;
+                            if (kopt_next_cuts(env, ks, c1, c2, c3)) {
+                                if (lane == 0) {
+                                    km.trip[ntr * 4] = (uint16_t)ks.entity;
+                                    km.trip[ntr * 4 + 1] = (uint16_t)c1;
+                                    km.trip[ntr * 4 + 2] = (uint16_t)c2;
+                                    km.trip[ntr * 4 + 3] = (uint16_t)c3;
+                                }
+                                ntr += 1;
+                            } else {
+                                ks.active = 0;
+                            }
+                        }
+                        kopt_store_state(km.st, ks, lane);
+                        wave_sync();
+                        const uint32_t t = lane / 7u, q = lane % 7u;
+                        if (t < ntr) {
+                            const uint32_t ent = km.trip[t * 4], c1 = km.trip[t * 4 + 1], c2 = km.trip[t * 4 + 2], c3 = km.trip[t * 4 + 3];
+                            keep = true;
+                            w0 = (ent << 16) | c1;
+                            w1 = (c2 << 16) | c3;
+                            wx = ctx.selection_index(q, 7u, kopt_pattern_salt(ldesc, ent, c1, c2, c3));
+                        }
+                        wave_sync();  // the triples are consumed before the next call overwrites them
                     } else if (kind == 64) {  // ---- list reverse / 2-opt (list_kernel/reverse.rs:68-108) ----
                         uint32_t ent = 0, len = 0;
                         for (;;) {  // entities shorter than two elements are skipped
@@ -905,6 +1002,8 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                             : my_kind == 128
                                                 ? eval_sublist_change(lm, s_visits, s_off, s_load, m0 >> 16, m0 & 0xFFFFu, (m0 & 0xFFFFu) + mx_,
                                                                       m1 >> 16, m1 & 0xFFFFu)
+                                            : my_kind == 512
+                                                ? eval_kopt(lm, s_visits, s_off, m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu, mx_)
                                             : my_kind == 64
                                                 ? eval_list_reverse(lm, s_visits, s_off, m0 >> 16, m0 & 0xFFFFu, m1 & 0xFFFFu)
                                                 : eval_list_move_legs<uint16_t, false>(lm, s_visits, s_off, s_load, my_kind == 4 || my_kind == 16,
@@ -994,12 +1093,13 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
                         } else {
-                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : (my_kind == 64 ? 4 : (my_kind == 128 ? 5 : 6)));
+                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : (my_kind == 64 ? 4 : (my_kind == 128 ? 5 : (my_kind == 512 ? 7 : 6))));
                             tm[1] = (int32_t)(m0 >> 16);
                             tm[2] = (int32_t)(m0 & 0xFFFFu);
                             tm[3] = (int32_t)(m1 >> 16);
                             tm[4] = (int32_t)(m1 & 0xFFFFu);
-                            tm[5] = my_kind == 128 ? (int32_t)((m0 & 0xFFFFu) + mx_) : (my_kind == 256 ? (int32_t)((mx_ & 15u) | ((mx_ >> 4) << 16)) : -1);
+                            tm[5] = my_kind == 128 ? (int32_t)((m0 & 0xFFFFu) + mx_)
+                                                   : (my_kind == 256 ? (int32_t)((mx_ & 15u) | ((mx_ >> 4) << 16)) : (my_kind == 512 ? (int32_t)mx_ : -1));
                         }
                         for (int kk = 0; kk < L && kk < gl.levels; ++kk) p.trace_scores[ti * gl.levels + kk] = doable ? sc.v[kk] : 0;
                         p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
@@ -1044,20 +1144,22 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             } else {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
-                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : 6)));
+                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : (kind == 512 ? 7 : 6))));
                     p.trace_applied[2] = (int32_t)(a >> 16);
                     p.trace_applied[3] = (int32_t)(a & 0xFFFFu);
                     p.trace_applied[4] = (int32_t)(b >> 16);
                     p.trace_applied[5] = (int32_t)(b & 0xFFFFu);
                     p.trace_applied[6] = kind == 128 ? (int32_t)((a & 0xFFFFu) + uni(best_x))
-                                                      : (kind == 256 ? (int32_t)((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16)) : -1);
+                                                      : (kind == 256 ? (int32_t)((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16))
+                                                                     : (kind == 512 ? (int32_t)uni(best_x) : -1));
                 }
                 apply_list_move_wave(lm, s_visits, s_off, s_load,
-                                     (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : 6))),
+                                     (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : (kind == 512 ? 7 : 6)))),
                                      a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu,
-                                     kind == 256 ? ((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16)) : (a & 0xFFFFu) + uni(best_x));
+                                     kind == 512 ? uni(best_x)
+                                                 : (kind == 256 ? ((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16)) : (a & 0xFFFFu) + uni(best_x)));
                 if (has_nearby) {  // refresh node -> (route, position) for the touched routes
-                    const uint32_t ra_ = a >> 16, rb_ = b >> 16;
+                    const uint32_t ra_ = a >> 16, rb_ = kind == 512 ? (a >> 16) : (b >> 16);  // 3-opt: b packs cuts, not a route
                     const uint32_t oa = s_off[ra_], la = s_off[ra_ + 1] - oa;
                     const uint32_t ob = s_off[rb_], lb = s_off[rb_ + 1] - ob;
                     for (uint32_t t = lane; t < la + (ra_ != rb_ ? lb : 0u); t += 64) {

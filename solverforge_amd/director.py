@@ -17,6 +17,7 @@ from ._lib import MOVE_DTYPE, AnnealingConfigStruct, SolverConfigStruct, SolverF
 
 class MoveKind:
     CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 0, 1, 2, 3, 4, 5, 6
+    KOPT = 7  # a = list, a_pos / b / b_pos = the three cuts, value = reconnection pattern
 
 
 class SelectionOrder:  # solverforge_config::SelectionOrder
@@ -49,6 +50,7 @@ class ConstraintKind:
 class SelectorKind:
     SCALAR_CHANGE, SCALAR_SWAP, LIST_CHANGE, LIST_SWAP = 1, 2, 4, 8
     NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 16, 32, 64, 128, 256
+    KOPT = 512
 
 
 @dataclass
@@ -134,6 +136,10 @@ class GpuScoreDirector:
 
     def add_selector(self, kind, descriptor_index, variable_index=0, max_nearby=0, fact_meter=-1):
         check(self._L.sf_selector_add(self._h, kind, descriptor_index, variable_index, max_nearby, fact_meter), self._h)
+
+    def add_kopt_selector(self, descriptor_index, variable_index=0, k=3, min_segment_len=1, max_nearby=20):
+        """3-opt leaf (KOptMoveSelectorConfig); max_nearby = 0 enumerates every cut set, > 0 prunes by distance."""
+        check(self._L.sf_selector_add_kopt(self._h, descriptor_index, variable_index, k, min_segment_len, max_nearby), self._h)
 
     def add_sublist_selector(self, kind, descriptor_index, variable_index=0, min_size=1, max_size=3):
         check(self._L.sf_selector_add_sublist(self._h, kind, descriptor_index, variable_index, min_size, max_size), self._h)
