@@ -841,10 +841,22 @@ template <int L, bool TRACE, class VT>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
-                  gl.kopt_nearby);
+                  gl.kopt_nearby, gl.n);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
-    int wpb = (int)((SF_LDS_BUDGET) / cv.total);
-    if (wpb > 4) wpb = 4;
+    // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
+    // allocated as a whole; the kernel is built for 2 workgroups of 4 waves per CU); ties go to the larger group
+    int wpb = 1;
+    size_t best_resident = 0;
+    for (int w = 1; w <= 4; ++w) {
+        const size_t per_wg = cv.total * w + 1024;  // + the static annealing state
+        if (per_wg > 160 * 1024) break;
+        size_t groups = (160 * 1024) / per_wg;
+        if (groups * w > 8) groups = 8 / w;  // 2 waves per SIMD by register budget
+        if (groups * w >= best_resident) {
+            best_resident = groups * w;
+            wpb = w;
+        }
+    }
     auto kern = k_mixed_search_wave<L, TRACE, VT>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cv.total * wpb)));
     SearchParams q = p;

@@ -58,15 +58,16 @@ struct GLeaves {
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, total;
+    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, leaftab, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
-    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0) {
+    // n_leaves rings only: the LDS slice decides how many replicas a CU holds
+    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL) {
         size_t o = 0;
         ring = o;
-        o = align_up(o + sizeof(uint32_t) * 2 * GRC * GL, 16);
+        o = align_up(o + sizeof(uint32_t) * 2 * GRC * n_leaves, 16);
         ringx = o;  // one extra byte per ring entry (segment size of the sublist leaves)
-        o = align_up(o + GRC * GL, 16);
+        o = align_up(o + GRC * n_leaves, 16);
         node = o;
         o = align_up(o + sizeof(uint32_t) * dim_nearby, 16);
         slotbase = o;
@@ -87,6 +88,8 @@ struct GCarve {
         o = align_up(o + sizeof(VT) * n_scalar, 16);
         kopt = o;  // working set of the distance-pruned 3-opt stream
         o = align_up(o + (kopt_nearby ? KoptLds::bytes : 0), 16);
+        leaftab = o;  // per-leaf generator / ring / scheduler state (LeafTab)
+        o = align_up(o + sizeof(uint32_t) * 16 * GL, 16);
         total = o;
     }
 };
@@ -111,8 +114,30 @@ struct GGen {
     int done;
 };
 
+// Per-leaf state of one replica, in LDS (16 words per leaf) instead of 8-way unrolled register arrays: the
+// kernel stays small enough for several waves per SIMD and the leaf loops index it dynamically.  Every lane
+// issues the same (wave-uniform) access, so a value stored by all lanes is what each lane reads back: no
+// lane-0 predicate, no fence.
+struct LeafTab {
+    enum : int { GEN = 0, DONE = 6, HEAD = 7, TAIL = 8, EX = 9, TAKEN = 10, WCUR = 11, KIND = 12, MAXNB = 13, MINSZ = 14, MAXSZ = 15 };
+    uint32_t* w;
+    __device__ __forceinline__ uint32_t get(int l, int f) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)w[l * 16 + f]); }
+    __device__ __forceinline__ int32_t geti(int l, int f) const { return __builtin_amdgcn_readfirstlane((int)w[l * 16 + f]); }
+    __device__ __forceinline__ void set(int l, int f, uint32_t v) const { w[l * 16 + f] = v; }
+    __device__ __forceinline__ GGen gen(int l) const {
+        return GGen{get(l, 0), get(l, 1), get(l, 2), get(l, 3), get(l, 4), get(l, 5), geti(l, DONE)};
+    }
+    __device__ __forceinline__ void put_gen(int l, const GGen& g) const {
+        set(l, 0, g.a), set(l, 1, g.b), set(l, 2, g.c), set(l, 3, g.d), set(l, 4, g.e), set(l, 5, g.f), set(l, DONE, (uint32_t)g.done);
+    }
+};
+
+// workgroups of 4 waves: 2 resident workgroups per CU = 2 waves per SIMD (<= 256 VGPRs)
+#ifndef SF_MIXED_BLOCKS_PER_CU
+#define SF_MIXED_BLOCKS_PER_CU 2
+#endif
 template <int L, bool TRACE, class VT>
-__global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p,
+__global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p,
                                                           int has_list, int has_scalar, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -126,7 +151,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
-    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby);
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
     uint8_t* ringx = (uint8_t*)(mem + cv.ringx);  // [leaf][GRC]
@@ -141,6 +166,14 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
     uint16_t* nb_spvec = (uint16_t*)(mem + cv.spvec);
     const bool tracing = TRACE && r == p.trace_replica;
     const int nl = gl.n;
+    const LeafTab lt{(uint32_t*)(mem + cv.leaftab)};
+#pragma unroll
+    for (int l = 0; l < GL; ++l) {  // constants of the leaves (compile-time l: no dynamic indexing of the kernarg block)
+        lt.set(l, LeafTab::KIND, (uint32_t)gl.kind[l]);
+        lt.set(l, LeafTab::MAXNB, (uint32_t)gl.max_nearby[l]);
+        lt.set(l, LeafTab::MINSZ, (uint32_t)gl.min_size[l]);
+        lt.set(l, LeafTab::MAXSZ, (uint32_t)gl.max_size[l]);
+    }
     const uint64_t identity = ((uint64_t)(uint32_t)sm.descriptor << 32) ^ (uint64_t)(uint32_t)sm.variable;
     const uint32_t vc = (uint32_t)sm.n_values;
     const FastMod fm_n = make_fastmod(ns), fm_vc = make_fastmod(vc);  // fixed divisors of the scalar streams
@@ -254,23 +287,21 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         auto ls_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)ls_st + (uint64_t)rank * ls_sd) % (uint32_t)V); };
         auto rlen = [&](uint32_t e) { return uni(s_off[e + 1] - s_off[e]); };
 
-        GGen G[GL];
-        uint32_t head[GL], tail[GL];
-        int ex[GL];
-#pragma unroll
         for (int l = 0; l < GL; ++l) {
-            G[l] = GGen{0, 0, 0, 0, 0, 0, l >= nl};
-            head[l] = tail[l] = 0;
-            ex[l] = l >= nl;
+            lt.put_gen(l, GGen{0, 0, 0, 0, 0, 0, l >= nl});
+            lt.set(l, LeafTab::HEAD, 0);
+            lt.set(l, LeafTab::TAIL, 0);
+            lt.set(l, LeafTab::EX, l >= nl);
+            lt.set(l, LeafTab::WCUR, 0);
         }
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
         if (has_nearby) {
             const uint32_t total = uni(s_off[V]);
             int ni = 0;
-#pragma unroll
-            for (int l = 0; l < GL; ++l) {
-                if (l >= nl || (gl.kind[l] != 16 && gl.kind[l] != 32)) continue;
-                const uint64_t ent_salt = (gl.kind[l] == 16 ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ ldesc;
+            for (int l = 0; l < nl; ++l) {
+                const int lk = lt.geti(l, LeafTab::KIND);
+                if (lk != 16 && lk != 32) continue;
+                const uint64_t ent_salt = (lk == 16 ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ ldesc;
                 uint32_t pst, psd;
                 ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
                 pst = uni(pst);
@@ -297,7 +328,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     carry += __shfl(inc, 63);
                 }
                 if (lane == 0) sb[V] = (uint16_t)carry;
-                G[l] = GGen{0, 0, 0xFFFFFFFFu, 0, total, 0, total == 0};
+                lt.put_gen(l, GGen{0, 0, 0xFFFFFFFFu, 0, total, 0, total == 0});
                 ++ni;
             }
             wave_sync();
@@ -305,22 +336,20 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         // union scheduler (vec_union.rs:190-365): StratifiedRandom with equal weights when > 1 leaf
         const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
         const uint32_t u_str = nl > 1 ? ctx.random_stride((uint32_t)nl, SALT_UNION_STRIDE) : 1u;
-        int64_t wcur[GL];
-#pragma unroll
-        for (int l = 0; l < GL; ++l) wcur[l] = 0;
-        int64_t live_weight = nl;
+        int32_t live_weight = nl;  // running weights of the smooth weighted round-robin live in the leaf table
 
         int done = 0;
         while (!done) {
             // ---- C1: fill every live leaf's ring to >= 64 pending (or until its stream ends) ----
-#pragma unroll
-            for (int l = 0; l < GL; ++l) {
-                if (l >= nl) continue;
-                const int kind = gl.kind[l];
+            for (int l = 0; l < nl; ++l) {
+                const int kind = lt.geti(l, LeafTab::KIND);
                 uint32_t* rq = ring + (size_t)l * GRC * 2;
-                GGen g = G[l];
-                uint32_t tl = tail[l];
-                while (!ex[l] && !g.done && tl - head[l] < 64u) {
+                GGen g = lt.gen(l);
+                uint32_t tl = lt.get(l, LeafTab::TAIL);
+                const uint32_t hd_l = lt.get(l, LeafTab::HEAD);
+                const bool ex_l = lt.get(l, LeafTab::EX) != 0;
+                const uint32_t leaf_max_nearby = lt.get(l, LeafTab::MAXNB), leaf_min = lt.get(l, LeafTab::MINSZ), leaf_max = lt.get(l, LeafTab::MAXSZ);
+                while (!ex_l && !g.done && tl - hd_l < 64u) {
                     st_sources += 1;
                     bool keep = false;
                     uint32_t w0 = 0, w1 = 0, wx = 0;
@@ -446,7 +475,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             }
                         }
                     } else if (kind == 256) {  // ---- sublist swap (list_kernel/sublist_swap.rs:57-101,228-300) ----
-                        const uint32_t mn = (uint32_t)gl.min_size[l], mx = (uint32_t)gl.max_size[l];
+                        const uint32_t mn = leaf_min, mx = leaf_max;
                         uint32_t fent = 0, flen = 0, fstart = 0, sc1 = 0;
                         for (;;) {  // the current first segment
                             if (g.a >= (uint32_t)V) break;
@@ -511,7 +540,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         }
                         g.e += per;
                     } else if (kind == 128) {  // ---- sublist change / Or-opt (list_kernel/sublist_change.rs:109-266) ----
-                        const uint32_t mn = (uint32_t)gl.min_size[l], mx = (uint32_t)gl.max_size[l];
+                        const uint32_t mn = leaf_min, mx = leaf_max;
                         uint32_t ent = 0, len = 0, start = 0, sc = 0;
                         for (;;) {  // current segment start with at least one legal size
                             if (g.a >= (uint32_t)V) break;
@@ -597,9 +626,10 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                             break;
                         }
                         int ni = 0;  // which nearby table set this leaf owns
-#pragma unroll
-                        for (int l2 = 0; l2 < GL; ++l2)
-                            if (l2 < l && (gl.kind[l2] == 16 || gl.kind[l2] == 32)) ni += 1;
+                        for (int l2 = 0; l2 < l; ++l2) {
+                            const int k2 = lt.geti(l2, LeafTab::KIND);
+                            if (k2 == 16 || k2 == 32) ni += 1;
+                        }
                         const uint16_t* ra = nb_route_at + ni * V;
                         const uint16_t* ro = nb_rank_of + ni * V;
                         const uint16_t* sb = nb_slot_base + ni * (V + 1);
@@ -624,12 +654,12 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         const uint32_t sx = uni((uint32_t)s_visits[s_off[se] + sp]);
                         const uint32_t key0 = lane < (uint32_t)lm.dim ? (uint32_t)nb.keys[(size_t)sx * (uint32_t)lm.dim + lane] : NBR_END;
                         tl += nearby_source_to_ring(lm, nb, kind == 16, se, sp, len, g.a, sx, node_slot, s_off, sb, ro, rq, GRC - 1, tl,
-                                                    key0, 0u, (uint32_t)gl.max_nearby[l], 0u);
+                                                    key0, 0u, leaf_max_nearby, 0u);
                         g.b += 1;
                         g.e -= 1;
                         if (g.e == 0) g.done = 1;
-                    } else if (kind == 512 && gl.max_nearby[l] == 0) {  // ---- 3-opt, full enumeration (k_opt/full.rs:62-92) ----
-                        const uint32_t mseg = (uint32_t)gl.min_size[l];
+                    } else if (kind == 512 && leaf_max_nearby == 0) {  // ---- 3-opt, full enumeration (k_opt/full.rs:62-92) ----
+                        const uint32_t mseg = leaf_min;
                         uint32_t ent = 0, len = 0;
                         uint64_t mc = 0, mo = 0;
                         for (;;) {
@@ -663,7 +693,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     } else if (kind == 512) {  // ---- 3-opt, distance-pruned (k_opt/nearby.rs:106-148, nearby_state.rs) ----
                         const KoptLds km(mem + cv.kopt);
                         const KoptEnv env{&lm,   s_visits, s_off, km, gl.kopt_scratch + (size_t)r * lm.n_cap, ctx, ldesc,
-                                          (uint32_t)gl.min_size[l], (uint32_t)gl.max_nearby[l], lane};
+                                          leaf_min, leaf_max_nearby, lane};
                         KoptS ks;
                         kopt_load_state(km.st, ks);
                         uint32_t ntr = 0;
@@ -827,37 +857,34 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                     }
                     tl += (uint32_t)__popcll(km);
                 }
-                G[l] = g;
-                tail[l] = tl;
+                lt.put_gen(l, g);
+                lt.set(l, LeafTab::TAIL, tl);
             }
             wave_sync();
 
             // ---- C2: lay the next 64 pulls of the union scheduler onto the lanes ----
             uint32_t my_leaf = 0, my_idx = 0;
-            uint32_t taken[GL];
-#pragma unroll
-            for (int l = 0; l < GL; ++l) taken[l] = 0;
+            for (int l = 0; l < nl; ++l) lt.set(l, LeafTab::TAKEN, 0);
             uint32_t nvalid = 0;
             bool need_more = false;
             {
                 int nlive = 0;
-#pragma unroll
-                for (int l = 0; l < GL; ++l) nlive += !ex[l];
+                for (int l = 0; l < nl; ++l) nlive += lt.get(l, LeafTab::EX) ? 0 : 1;
                 // Fast path: with equal weights the smooth weighted round-robin is a plain cycle over the
                 // live children in rotated order whenever all their running weights are equal (true at the
                 // start of every step and after every whole cycle).  Lay out whole cycles directly; the
                 // pull-by-pull simulation below handles partial cycles, exhaustion and refills.
                 if (nl > 1 && nlive > 1) {
                     bool aligned = true;
-                    int64_t w0 = 0;
+                    int32_t w0 = 0;
                     bool first = true;
-#pragma unroll
-                    for (int l = 0; l < GL; ++l)
-                        if (!ex[l]) {
+                    for (int l = 0; l < nl; ++l)
+                        if (!lt.get(l, LeafTab::EX)) {
+                            const int32_t wl = lt.geti(l, LeafTab::WCUR);
                             if (first) {
-                                w0 = wcur[l];
+                                w0 = wl;
                                 first = false;
-                            } else if (wcur[l] != w0)
+                            } else if (wl != w0)
                                 aligned = false;
                         }
                     if (aligned) {
@@ -867,11 +894,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                         bool found = false;
                         for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
                             const uint32_t i = (u_off + pos * u_str) % (uint32_t)nl;
-                            bool live_i = false;
-#pragma unroll
-                            for (int l = 0; l < GL; ++l)
-                                if ((uint32_t)l == i) live_i = !ex[l];
-                            if (live_i) {
+                            if (!lt.get((int)i, LeafTab::EX)) {
                                 if (!found && seen == slot) {
                                     leaf = i;
                                     found = true;
@@ -879,13 +902,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                 seen += 1;
                             }
                         }
-                        uint32_t hd = 0, tlq = 0;
-#pragma unroll
-                        for (int l = 0; l < GL; ++l)
-                            if (leaf == (uint32_t)l) {
-                                hd = head[l];
-                                tlq = tail[l];
-                            }
+                        const uint32_t hd = lt.w[leaf * 16 + LeafTab::HEAD], tlq = lt.w[leaf * 16 + LeafTab::TAIL];  // per-lane leaf
                         const bool ok = (int32_t)(tlq - (hd + cyc)) > 0;
                         const uint64_t okm = __ballot(ok);
                         const uint32_t upto = okm == ~0ULL ? 64u : (uint32_t)(__ffsll((unsigned long long)~okm) - 1);
@@ -896,73 +913,54 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                                 my_leaf = leaf;
                                 my_idx = hd + cyc;
                             }
-#pragma unroll
-                            for (int l = 0; l < GL; ++l)
-                                if (!ex[l]) taken[l] = cycles;  // running weights: +nvalid - cycles * nlive = 0
+                            for (int l = 0; l < nl; ++l)
+                                if (!lt.get(l, LeafTab::EX)) lt.set(l, LeafTab::TAKEN, cycles);  // running weights: +nvalid - cycles * nlive = 0
                         }
                     }
                 }
                 const bool fast_done = nvalid > 0;
                 while (!fast_done && nvalid < 64 && nlive > 0) {
                     int sel = -1;
-                    int64_t selw = 0;
+                    int32_t selw = 0;
                     if (nl == 1) {
                         sel = 0;
                     } else {
                         for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
-                            const uint32_t i = (u_off + pos * u_str) % (uint32_t)nl;
-#pragma unroll
-                            for (int l = 0; l < GL; ++l)
-                                if ((uint32_t)l == i && !ex[l]) {
-                                    wcur[l] += 1;
-                                    if (sel < 0 || wcur[l] > selw) {
-                                        sel = l;
-                                        selw = wcur[l];
-                                    }
+                            const int i = (int)((u_off + pos * u_str) % (uint32_t)nl);
+                            if (!lt.get(i, LeafTab::EX)) {
+                                const int32_t wi = lt.geti(i, LeafTab::WCUR) + 1;
+                                lt.set(i, LeafTab::WCUR, (uint32_t)wi);
+                                if (sel < 0 || wi > selw) {
+                                    sel = i;
+                                    selw = wi;
                                 }
+                            }
                         }
                     }
-                    bool avail = false, gdone = false;
-#pragma unroll
-                    for (int l = 0; l < GL; ++l)
-                        if (l == sel) {
-                            avail = (int32_t)(tail[l] - (head[l] + taken[l])) > 0;
-                            gdone = G[l].done != 0;
-                        }
+                    const uint32_t sel_taken = lt.get(sel, LeafTab::TAKEN), sel_head = lt.get(sel, LeafTab::HEAD);
+                    const bool avail = (int32_t)(lt.get(sel, LeafTab::TAIL) - (sel_head + sel_taken)) > 0;
+                    const bool gdone = lt.get(sel, LeafTab::DONE) != 0;
                     if (!avail && !gdone) {
                         // the child has more candidates that are not generated yet: undo this pull's
                         // bookkeeping and refill first
                         if (nl > 1) {
-#pragma unroll
-                            for (int l = 0; l < GL; ++l)
-                                if (!ex[l]) wcur[l] -= 1;
+                            for (int l = 0; l < nl; ++l)
+                                if (!lt.get(l, LeafTab::EX)) lt.set(l, LeafTab::WCUR, (uint32_t)(lt.geti(l, LeafTab::WCUR) - 1));
                         }
                         need_more = true;
                         break;
                     }
-                    if (nl > 1) {
-#pragma unroll
-                        for (int l = 0; l < GL; ++l)
-                            if (l == sel) wcur[l] -= live_weight;
-                    }
+                    if (nl > 1) lt.set(sel, LeafTab::WCUR, (uint32_t)(lt.geti(sel, LeafTab::WCUR) - live_weight));
                     if (!avail) {  // exhausted child discovered at this pull
-#pragma unroll
-                        for (int l = 0; l < GL; ++l)
-                            if (l == sel) ex[l] = 1;
+                        lt.set(sel, LeafTab::EX, 1);
                         nlive -= 1;
                         live_weight -= 1;
                         continue;
                     }
-                    uint32_t idx = 0;
-#pragma unroll
-                    for (int l = 0; l < GL; ++l)
-                        if (l == sel) {
-                            idx = head[l] + taken[l];
-                            taken[l] += 1;
-                        }
+                    lt.set(sel, LeafTab::TAKEN, sel_taken + 1);
                     if (lane == nvalid) {
                         my_leaf = (uint32_t)sel;
-                        my_idx = idx;
+                        my_idx = sel_head + sel_taken;
                     }
                     nvalid += 1;
                 }
@@ -977,10 +975,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
             {
                 const bool valid = lane < nvalid;
                 uint32_t m0 = 0, m1 = 0, mx_ = 0;
-                int my_kind = 0;
-#pragma unroll
-                for (int l = 0; l < GL; ++l)
-                    if (my_leaf == (uint32_t)l) my_kind = gl.kind[l];
+                const int my_kind = (int)lt.w[my_leaf * 16 + LeafTab::KIND];  // per-lane leaf
                 bool doable = false;
                 ScoreV<L> sc;
 #pragma unroll
@@ -1107,8 +1102,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
                 }
                 if (tracing) trace_n += nconsumed;
                 // every laid-out pull is consumed unless the forager cut the step (which ends it)
-#pragma unroll
-                for (int l = 0; l < GL; ++l) head[l] += taken[l];
+                for (int l = 0; l < nl; ++l) lt.set(l, LeafTab::HEAD, lt.get(l, LeafTab::HEAD) + lt.get(l, LeafTab::TAKEN));
                 if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
             }
         }
@@ -1116,10 +1110,7 @@ __global__ __launch_bounds__(256) void k_mixed_search_wave(ListModel lm, ScalarM
         // ---- commit the forager's pick ----
         const bool applied = has_best && !p.dry_run;
         if (applied) {
-            int kind = 0;
-#pragma unroll
-            for (int l = 0; l < GL; ++l)
-                if (best_leaf == l) kind = gl.kind[l];
+            const int kind = lt.geti(uni((uint32_t)best_leaf), LeafTab::KIND);
             const uint32_t a = uni(best_m0), b = uni(best_m1);
             if (kind <= 2) {
                 if (tracing && lane == 0) {
