@@ -110,6 +110,16 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
         d.add_selector(SelectorKind.LIST_CHANGE, 1)
     if "list_swap" in leaves:
         d.add_selector(SelectorKind.LIST_SWAP, 1)
+    # the rest of the default policy of a list without a distance meter (policy/list.rs:24-33,161-171):
+    # sublist change / swap (sizes 1..=3), reverse, unbounded 3-opt
+    if "sublist_change" in leaves:
+        d.add_sublist_selector(SelectorKind.SUBLIST_CHANGE, 1)
+    if "sublist_swap" in leaves:
+        d.add_sublist_selector(SelectorKind.SUBLIST_SWAP, 1)
+    if "list_reverse" in leaves:
+        d.add_selector(SelectorKind.LIST_REVERSE, 1)
+    if "kopt" in leaves:
+        d.add_kopt_selector(1, max_nearby=0)
     if "change" in leaves:
         d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
     if "swap" in leaves:

@@ -146,6 +146,60 @@ def test_kopt_apply_and_traced_steps(oracle, problem, leaves, kopt):
         assert gst[k] == ost[k], k
 
 
+def test_jobshop_default_policy_eight_leaf_union(oracle):
+    """Mixed job shop with the reference's whole default policy minus ruin: list change, list swap, sublist
+    change, sublist swap, reverse, unbounded 3-opt, scalar change, scalar swap (8 leaves, StratifiedRandom)."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_jobshop(8, 4)
+    n = p["n_ops"]
+    r = datasets.stream(3, 3 * n)
+    p["machine_idx"] = (r[:n] % np.uint64(5)).astype(np.int64) - 1
+    seqs = [[] for _ in range(4)]
+    for op in range(n):
+        where = int(r[n + op] % np.uint64(5))
+        if where < 4:
+            seqs[where].append(op)
+    p["sequences"] = seqs
+    leaves = ("list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt", "change", "swap")
+    d = sfa.build_jobshop(p, leaves=leaves)
+    o = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True)
+    o.set_kopt(1, 0)
+    bits = 4 | 8 | 128 | 256 | 64 | 512 | 1 | 2
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    for order in (0, 3):
+        o.configure(leaves=bits, selection_order=order)
+        gm, gs, gd = d.open_cursor(3, 17, selection_order=order, cap=1 << 20)
+        om = o.enumerate(0, 3, 17, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm) == _t(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :3]).all()
+    o.configure(leaves=bits, random_seed=6, la_size=7, limit=48)
+    d.configure(sfa.SolverConfig(random_seed=6, late_acceptance_size=7, accepted_count_limit=48))
+    d.phase_start()
+    o.phase_start()
+    kinds = set()
+    for step in range(30):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 20)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :3]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+            kinds.add(int(gmv["kind"]))
+        assert d.working_lists(1, 0) == o.get_lists(1), step
+        assert (d.working_values(0, 0) == o.get_vars(0, 0)).all(), step
+    assert len(kinds) >= 3
+    d.solve_steps(40)
+    o.steps(40)
+    assert d.working_lists(1, 0) == o.get_lists(1)
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    assert (d.fresh_score()[0] == o.score()[:3]).all()
+
+
 def test_kopt_selector_validation():
     import solverforge_amd as sfa
     from solverforge_amd import datasets
