@@ -636,13 +636,23 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     if (replica < 0 || replica >= ctx->R || n < 0 || !moves || !out_scores || !out_doable)
         return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate arguments");
     if (n == 0) return SF_OK;
+    // one allocation per call, released on every path (hipFree(nullptr) is a no-op)
     int32_t* d_moves = nullptr;
     int64_t* d_sc = nullptr;
     int32_t* d_do = nullptr;
-    HIPCHK(ctx, hipMalloc((void**)&d_moves, (size_t)n * 24));
-    HIPCHK(ctx, hipMalloc((void**)&d_sc, (size_t)n * ctx->levels * 8));
-    HIPCHK(ctx, hipMalloc((void**)&d_do, (size_t)n * 4));
-    HIPCHK(ctx, hipMemcpyAsync(d_moves, moves, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    auto release = [&]() {
+        (void)hipFree(d_moves);
+        (void)hipFree(d_sc);
+        (void)hipFree(d_do);
+    };
+    hipError_t ea = hipMalloc((void**)&d_moves, (size_t)n * 24);
+    if (ea == hipSuccess) ea = hipMalloc((void**)&d_sc, (size_t)n * ctx->levels * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void**)&d_do, (size_t)n * 4);
+    if (ea == hipSuccess) ea = hipMemcpyAsync(d_moves, moves, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream);
+    if (ea != hipSuccess) {
+        release();
+        return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
+    }
     int grid = (int)((n + 255) / 256);
     const int mixed = ctx->has_list_model && ctx->has_scalar_model;
     if (mixed) {
@@ -657,9 +667,7 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_moves);
-    (void)hipFree(d_sc);
-    (void)hipFree(d_do);
+    release();
     if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
     return SF_OK;
 }
