@@ -180,16 +180,35 @@ def main():
         th = threading.Thread(target=rccl_exchange, daemon=True)
         th.start()
         th.join(timeout=float(os.environ.get("SF_RCCL_TIMEOUT_S", "120")))
-        ok_local = 1.0 if "result" in box else 0.0
-        ok_all = -portfolio.max_over_ranks(dist, -ok_local)  # min over ranks: everyone or no one
-        if ok_all > 0.5:
+        def all_ranks_ok(flag):
+            return -portfolio.max_over_ranks(dist, -(1.0 if flag else 0.0)) > 0.5  # min over ranks: everyone or no one
+
+        if all_ranks_ok("result" in box):
             bs, wr, wrep = box["result"]
             winner = {"score": [int(v) for v in bs], "rank": int(wr), "replica": int(wrep)}
-            exchange = "rccl-allgather"
+            exchange = "rccl-allgather (C ABI sf_portfolio_allgather_best)"
         else:
-            wr, ws = portfolio.gloo_allgather_best(dist, best_local, rank, world)
-            winner = {"score": ws, "rank": wr}
-            exchange = "gloo-fallback (" + box.get("error", "RCCL communicator not up before the deadline") + ")"
+            why = box.get("error", "RCCL communicator not up before the deadline")
+            # second choice: the same all-gather through torch.distributed's "nccl" backend (RCCL over xGMI)
+            box2 = {}
+
+            def torch_exchange():
+                try:
+                    box2["result"] = portfolio.torch_rccl_allgather_best(dist, best_local, rank, world, local_rank % n_dev)
+                except Exception as e:
+                    box2["error"] = f"{type(e).__name__}: {e}"
+
+            th2 = threading.Thread(target=torch_exchange, daemon=True)
+            th2.start()
+            th2.join(timeout=float(os.environ.get("SF_RCCL_TIMEOUT_S", "120")))
+            if all_ranks_ok("result" in box2):
+                wr, ws = box2["result"]
+                winner = {"score": ws, "rank": wr}
+                exchange = f"rccl-allgather (torch.distributed nccl backend; C ABI path: {why})"
+            else:
+                wr, ws = portfolio.gloo_allgather_best(dist, best_local, rank, world)
+                winner = {"score": ws, "rank": wr}
+                exchange = f"gloo-fallback ({why}; torch nccl: " + box2.get("error", "deadline") + ")"
 
     if rank == 0:
         gen_bytes_per_source = (args.customers + args.vehicles) * 12

@@ -44,6 +44,19 @@ def gloo_allgather_best(dist, local_best: Sequence[int], rank: int, world: int):
     return pick_winner([g.tolist() for g in gathered])
 
 
+def torch_rccl_allgather_best(dist, local_best: Sequence[int], rank: int, world: int, device_index: int):
+    """The same exchange through torch.distributed's "nccl" backend (= RCCL over xGMI on ROCm) on device
+    tensors: one all_gather of the score levels per rank.  Collective: every rank must call it."""
+    import torch
+
+    group = dist.new_group(backend="nccl")
+    t = torch.tensor([int(v) for v in local_best], dtype=torch.int64, device=f"cuda:{device_index}")
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t, group=group)
+    torch.cuda.synchronize(device_index)
+    return pick_winner([g.cpu().tolist() for g in gathered])
+
+
 def max_over_ranks(dist, value: float) -> float:
     import torch
 
