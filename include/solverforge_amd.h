@@ -245,6 +245,10 @@ int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores);
 int32_t sf_evaluate_all(sf_ctx* ctx, int64_t* out_scores);
 /* committed (cached) score of every replica */
 int32_t sf_get_scores(sf_ctx* ctx, int64_t* out_scores);
+/* ≙ ConstraintSet::evaluate_each (api/constraint_set/incremental.rs:172,237-244): score and match count of every
+ * declared constraint (declaration order = sf_constraint_add order) on `replica`'s working solution, by full
+ * recomputation.  out_scores[n_constraints * score_levels], out_match_counts[n_constraints]. */
+int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int64_t* out_match_counts);
 /* ≙ n x evaluate_candidate (phase/localsearch/evaluation.rs:20-115) against replica `replica`:
  * one launch, state unchanged.  out_scores[n * score_levels], out_doable[n]. */
 int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, int64_t n,

@@ -72,6 +72,7 @@ def lib():
             "sfo_model_reset": (None, [vp]),
             "sfo_model_configure": (None, [vp, i32, i32, i32, i32, i32, i32, u32, i32, i32, u64, i32]),
             "sfo_model_set_kopt": (None, [vp, i32, i32]),
+            "sfo_model_evaluate_each": (i32, [vp, vp, vp, i32]),
             "sfo_model_configure_annealing": (None, [vp, i32, vp, i32, i32, dbl, dbl, i32, i32, dbl, dbl, u64]),
             "sfo_model_annealing_state": (None, [vp, vp, vp, vp]),
             "sfo_xoshiro256pp": (None, [vp, i32, vp]),
@@ -189,6 +190,13 @@ class Model:
 
     def reset(self):
         lib().sfo_model_reset(self.h)
+
+    def evaluate_each(self, cap=16):
+        """ConstraintSet::evaluate_each: (scores [n, 4], match counts [n]) in declaration order."""
+        sc = np.zeros((cap, 4), dtype=np.int64)
+        cnt = np.zeros(cap, dtype=np.int64)
+        n = lib().sfo_model_evaluate_each(self.h, _p(sc), _p(cnt), cap)
+        return sc[:n], cnt[:n]
 
     # -- search -----------------------------------------------------------------------
     def configure(self, acceptor=ACCEPT_LATE_ACCEPTANCE, la_size=400, forager=FORAGER_ACCEPTED_COUNT, limit=256,

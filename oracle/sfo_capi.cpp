@@ -116,6 +116,21 @@ void sfo_model_fresh_score(void* h, int64_t* out4) {  // Director::fresh_score (
     std::memcpy(out4, s.v, sizeof(s.v));
 }
 void sfo_model_reset(void* h) { ((Model*)h)->director.reset(); }
+// ConstraintSet::evaluate_each (api/constraint_set/incremental.rs:172,237-244): per constraint, in declaration
+// order, its score on the working solution and its match count.  Returns the number of constraints.
+int32_t sfo_model_evaluate_each(void* h, int64_t* out_scores4, int64_t* out_counts, int32_t cap) {
+    Model* m = (Model*)h;
+    int32_t n = 0;
+    for (auto& c : m->director.constraints.members) {
+        if (n < cap) {
+            Score s = c->evaluate(m->director.working);
+            std::memcpy(out_scores4 + (size_t)n * 4, s.v, sizeof(s.v));
+            out_counts[n] = (int64_t)c->match_count(m->director.working);
+        }
+        ++n;
+    }
+    return n;
+}
 
 // acceptor: 0 HillClimbing, 1 LateAcceptance(size).  forager: 0 AcceptedCount(limit), 1 FirstAccepted, 2 BestScore.
 // union_order: 0 Sequential 1 RoundRobin 2 RotatingRoundRobin 3 Random 4 StratifiedRandom; -1 = default policy

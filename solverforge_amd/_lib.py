@@ -62,7 +62,7 @@ SYMBOLS = [
     "sf_ctx_create", "sf_ctx_destroy", "sf_last_error", "sf_device_count", "sf_sync",
     "sf_schema_add_entity_class", "sf_schema_add_scalar_variable", "sf_schema_add_list_variable",
     "sf_fact_matrix_i64", "sf_fact_column_i32", "sf_fact_column_u32", "sf_fact_csr_u32",
-    "sf_constraint_add", "sf_selector_add", "sf_selector_add_sublist", "sf_selector_add_kopt", "sf_initialize", "sf_evaluate_all", "sf_get_scores",
+    "sf_constraint_add", "sf_selector_add", "sf_selector_add_sublist", "sf_selector_add_kopt", "sf_initialize", "sf_evaluate_all", "sf_evaluate_each", "sf_get_scores",
     "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_solver_configure_annealing",
     "sf_get_annealing_state", "sf_solver_set_step_seeds",
     "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
@@ -104,6 +104,7 @@ def load():
     L.sf_initialize.argtypes = [vp, vp]
     L.sf_evaluate_all.argtypes = [vp, vp]
     L.sf_get_scores.argtypes = [vp, vp]
+    L.sf_evaluate_each.argtypes = [vp, i32, vp, vp]
     L.sf_step_evaluate.argtypes = [vp, i32, vp, i64, vp, vp]
     L.sf_apply.argtypes = [vp, i32, vp]
     L.sf_step_generate.argtypes = [vp, i32, u64, u64, i32, vp, vp, vp, i64, vp]

@@ -86,6 +86,7 @@ struct sf_ctx {
     int32_t* d_trace_applied = nullptr;
     int64_t trace_cap = 0;
     // scratch
+    int64_t* d_each = nullptr;           // [R][SF_EACH_WORDS] evaluate_each aggregates
     uint64_t* d_kopt_scratch = nullptr;  // [R][n_cap] distance keys of long routes (distance-pruned 3-opt leaf)
     int64_t* d_scores_out = nullptr;
     int32_t* d_ok = nullptr;
@@ -565,18 +566,18 @@ static int download_scores(sf_ctx* ctx, const int64_t* d_src4, int64_t* out) {
     return SF_OK;
 }
 
-static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit) {
+static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit, int64_t* d_parts = nullptr) {
     int rc;
     if (!ctx->d_scores_out && (rc = dalloc(ctx, &ctx->d_scores_out, (size_t)ctx->R * 4))) return rc;
     if (!ctx->has_list_model && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "no planning variable configured");
     if (ctx->has_list_model) {
         size_t lds = ((size_t)ctx->lm.dim + 31) / 32 * 4 + 16;
         hipLaunchKernelGGL(k_list_evaluate_all, dim3(ctx->R), dim3(256), lds, ctx->stream, ctx->lm,
-                           ctx->d_scores_out, commit);
+                           ctx->d_scores_out, commit, d_parts);
     }
     if (ctx->has_scalar_model)  // mixed model: the scalar class adds its constraints to the list class's scores
         hipLaunchKernelGGL(k_scalar_evaluate_all, dim3(ctx->R), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm,
-                           ctx->d_scores_out, commit, ctx->has_list_model ? 1 : 0);
+                           ctx->d_scores_out, commit, ctx->has_list_model ? 1 : 0, d_parts);
     HIPCHK(ctx, hipGetLastError());
     if (out) {
         std::vector<int64_t> tmp((size_t)ctx->R * ctx->levels);
@@ -623,6 +624,42 @@ int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores) {
 int32_t sf_evaluate_all(sf_ctx* ctx, int64_t* out_scores) {
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     return run_evaluate_all(ctx, out_scores, 0);
+}
+
+// ConstraintSet::evaluate_each (crates/solverforge-scoring/src/api/constraint_set/incremental.rs:172,237-244): one full
+// recomputation, reported per declared constraint
+int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int64_t* out_match_counts) {
+    if (!ctx || !ctx->initialized || replica < 0 || replica >= ctx->R || !out_scores || !out_match_counts)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_evaluate_each arguments");
+    int rc;
+    if (!ctx->d_each && (rc = dalloc(ctx, &ctx->d_each, (size_t)ctx->R * SF_EACH_WORDS))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_each, 0, (size_t)ctx->R * SF_EACH_WORDS * 8, ctx->stream));
+    if ((rc = run_evaluate_all(ctx, nullptr, 0, ctx->d_each))) return rc;
+    int64_t q[SF_EACH_WORDS];
+    HIPCHK(ctx, hipMemcpy(q, ctx->d_each + (size_t)replica * SF_EACH_WORDS, sizeof(q), hipMemcpyDeviceToHost));
+    size_t i = 0;
+    for (auto& cs : ctx->constraints) {
+        int64_t raw = 0, count = 0;
+        const bool on_list = ctx->has_list_model && cs.desc == ctx->list_desc;
+        switch (cs.kind) {
+            case SF_C_ROUTE_CAPACITY: raw = q[0], count = ctx->lm.V; break;  // filter = every route (uni on the owners)
+            case SF_C_ROUTE_DISTANCE: raw = q[1], count = ctx->lm.V; break;
+            case SF_C_NOT_EXISTS_FLATTENED: raw = q[2], count = q[2]; break;
+            case SF_C_UNI_UNASSIGNED: raw = q[3], count = q[3]; break;
+            case SF_C_CROSS_ADJACENT_EQUAL:
+            case SF_C_CROSS_GROUP_EQUAL:
+            case SF_C_CROSS_QUEENS: raw = q[4], count = q[4]; break;
+            case SF_C_SELFJOIN_VALUE_EQUAL: raw = q[5], count = q[5]; break;
+            case SF_C_GROUPED_VALUE_SUM: raw = q[6], count = q[7]; break;
+            default: return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind in sf_evaluate_each");
+        }
+        (void)on_list;
+        for (int k = 0; k < ctx->levels; ++k) out_scores[i * ctx->levels + k] = 0;
+        out_scores[i * ctx->levels + cs.level] = (int64_t)(0 - (uint64_t)cs.weight * (uint64_t)raw);  // penalties
+        out_match_counts[i] = count;
+        ++i;
+    }
+    return SF_OK;
 }
 
 int32_t sf_get_scores(sf_ctx* ctx, int64_t* out_scores) {

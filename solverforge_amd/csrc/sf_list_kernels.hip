@@ -552,7 +552,8 @@ __global__ __launch_bounds__(256) void k_mat_compress(const int64_t* __restrict_
 // evaluate_all / initialize: full recomputation from scratch (fresh_score; FullAssert)
 // grid = R blocks.  commit != 0 also (re)builds the per-route load aggregate + cached score.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_list_evaluate_all(ListModel m, int64_t* out_scores, int commit) {
+// out_parts (optional, [R][SF_EACH_WORDS]): raw per-constraint aggregates for ConstraintSet::evaluate_each
+__global__ __launch_bounds__(256) void k_list_evaluate_all(ListModel m, int64_t* out_scores, int commit, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* present = (uint32_t*)smem;  // bitmap over node ids
     __shared__ unsigned long long s_cap, s_dist, s_missing;
@@ -606,6 +607,12 @@ __global__ __launch_bounds__(256) void k_list_evaluate_all(ListModel m, int64_t*
         for (int k = 0; k < m.levels; ++k) {
             if (out_scores) out_scores[(size_t)r * m.levels + k] = sc[k];
             if (commit) m.score[(size_t)r * 4 + k] = sc[k];
+        }
+        if (out_parts) {
+            int64_t* q = out_parts + (size_t)r * SF_EACH_WORDS;
+            q[0] = (int64_t)s_cap;      // sum over routes of max(0, load - capacity)
+            q[1] = (int64_t)s_dist;     // sum over routes of the depot -> ... -> depot walk
+            q[2] = (int64_t)s_missing;  // A rows without a flattened B match
         }
     }
 }

@@ -42,6 +42,10 @@ struct ListModel {
     int64_t* best_score;    // [R][4]
 };
 
+// words per replica of the evaluate_each aggregates: list class 0..2 (capacity, distance, not-exists), scalar class
+// 3..7 (unassigned, predicate-join pairs, keyed self-join pairs, grouped weight sum, non-empty groups)
+constexpr int SF_EACH_WORDS = 8;
+
 struct LeafSpec {
     int32_t kind;        // sf_selector_kind
     int32_t max_nearby;

@@ -209,9 +209,9 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
 // evaluate_all / initialize: full recomputation (fresh_score; FullAssert).  grid = R blocks.
 // accumulate != 0: add this class's constraint scores to what the list class already wrote (mixed models)
 __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
-                                                             int accumulate) {
+                                                             int accumulate, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];  // per-value tables (when used)
-    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp;
+    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups;
     const int r = blockIdx.x;
     const int32_t* vals = m.vals + (size_t)r * m.n;
     const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         s_cross = 0;
         s_pairs = 0;
         s_grp = 0;
+        s_groups = 0;
     }
     if (tables)
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
@@ -232,14 +233,16 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
     if (tables) {
         scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
         __syncthreads();
-        unsigned long long pairs = 0, grp = 0;
+        unsigned long long pairs = 0, grp = 0, groups = 0;
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
             const unsigned long long c = t_cnt[v];
             pairs += c * (c - (c ? 1 : 0)) / 2;
             grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
+            groups += c ? 1 : 0;
         }
         atomicAdd(&s_pairs, pairs);
         atomicAdd(&s_grp, grp);
+        atomicAdd(&s_groups, groups);
     }
     unsigned long long un = 0, cross = 0;
     for (uint32_t e = threadIdx.x; e < (uint32_t)m.n; e += blockDim.x) {
@@ -275,6 +278,14 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         for (int k = 0; k < m.levels; ++k) {
             if (out_scores) out_scores[(size_t)r * m.levels + k] = accumulate ? wadd(out_scores[(size_t)r * m.levels + k], sc[k]) : sc[k];
             if (commit) m.score[(size_t)r * 4 + k] = accumulate ? wadd(m.score[(size_t)r * 4 + k], sc[k]) : sc[k];
+        }
+        if (out_parts) {
+            int64_t* q = out_parts + (size_t)r * SF_EACH_WORDS;
+            q[3] = (int64_t)s_un;
+            q[4] = (int64_t)s_cross;
+            q[5] = (int64_t)s_pairs;
+            q[6] = (int64_t)s_grp;
+            q[7] = (int64_t)s_groups;
         }
     }
 }

@@ -133,6 +133,15 @@ class GpuScoreDirector:
 
     def add_constraint(self, kind, descriptor_index, variable_index=0, fact=-1, param=0, level=0, weight=1):
         check(self._L.sf_constraint_add(self._h, kind, descriptor_index, variable_index, fact, param, level, weight), self._h)
+        self._n_constraints = getattr(self, "_n_constraints", 0) + 1
+
+    def evaluate_each(self, replica=0):
+        """ConstraintSet::evaluate_each: (scores [n_constraints, levels], match counts) in declaration order."""
+        n = getattr(self, "_n_constraints", 0)
+        sc = np.zeros((max(n, 1), self.levels), dtype=np.int64)
+        cnt = np.zeros(max(n, 1), dtype=np.int64)
+        check(self._L.sf_evaluate_each(self._h, replica, ptr(sc), ptr(cnt)), self._h)
+        return sc[:n], cnt[:n]
 
     def add_selector(self, kind, descriptor_index, variable_index=0, max_nearby=0, fact_meter=-1):
         check(self._L.sf_selector_add(self._h, kind, descriptor_index, variable_index, max_nearby, fact_meter), self._h)

@@ -233,3 +233,70 @@ def test_keyed_selfjoin_and_grouped_sum(oracle, cap):
     assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
     assert (d.calculate_score()[0] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+def test_evaluate_each_matches_oracle_per_constraint(oracle):
+    """ConstraintSet::evaluate_each: per-constraint score and match count (graph colouring, N-queens, bin balance,
+    CVRP, job shop) after some committed steps."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    def check(d, o, levels, steps=15):
+        d.calculate_score()
+        d.phase_start()
+        o.phase_start()
+        for it in range(2):
+            gs, gc = d.evaluate_each(0)
+            os_, oc = o.evaluate_each()
+            assert len(gs) == len(os_) > 0
+            assert (gs == os_[:, :levels]).all(), (gs, os_)
+            assert (gc == oc).all(), (gc, oc)
+            assert (gs.sum(axis=0) == d.fresh_score()[0]).all()
+            d.solve_steps(steps)
+            o.steps(steps)
+
+    g = _graph(n=150, e=600, k=5, seed=8)
+    d, o, bits = _mk(oracle, g)
+    o.configure(leaves=bits, random_seed=2)
+    d.configure(sfa.SolverConfig(random_seed=2))
+    check(d, o, 2)
+
+    rows = [int(v) for v in (datasets.stream(5, 12) % np.uint64(13)).astype(np.int64) - 1]
+    d = sfa.build_nqueens(rows)
+    o = oracle.Model.nqueens(rows)
+    o.configure(leaves=oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP, random_seed=3)
+    d.configure(sfa.SolverConfig(random_seed=3))
+    check(d, o, 2)
+
+    n, nb = 60, 7
+    bins = (datasets.stream(11, n) % np.uint64(nb + 1)).astype(np.int64) - 1
+    sizes = (datasets.stream(12, n) % np.uint64(9)).astype(np.int64) + 1
+    for cap in (-1, 20):
+        d = sfa.build_balance(bins, sizes, nb, w_pair=3, cap=cap)
+        o = oracle.Model.balance(nb, bins, sizes, 3, cap)
+        o.configure(leaves=oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP, random_seed=4)
+        d.configure(sfa.SolverConfig(random_seed=4))
+        check(d, o, 2)
+
+    p = datasets.make_cvrp(50, 5, 35, seed=2)
+    d = sfa.build_cvrp(p)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.configure(leaves=oracle.LEAF_NEARBY_LIST_CHANGE | oracle.LEAF_NEARBY_LIST_SWAP, random_seed=5)
+    d.configure(sfa.SolverConfig(random_seed=5))
+    check(d, o, 2)
+
+    pj = datasets.make_jobshop(6, 3)
+    nops = pj["n_ops"]
+    r = datasets.stream(9, 2 * nops)
+    pj["machine_idx"] = (r[:nops] % np.uint64(4)).astype(np.int64) - 1
+    seqs = [[] for _ in range(3)]
+    for op in range(nops):
+        w = int(r[nops + op] % np.uint64(4))
+        if w < 3:
+            seqs[w].append(op)
+    pj["sequences"] = seqs
+    d = sfa.build_jobshop(pj)
+    o = oracle.Model.jobshop(pj["job"], pj["machine_idx"], pj["sequences"], bendable=True)
+    o.configure(leaves=4 | 8 | 1 | 2, random_seed=6)
+    d.configure(sfa.SolverConfig(random_seed=6))
+    check(d, o, 3)
