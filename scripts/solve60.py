@@ -8,24 +8,29 @@ from oracle import sfo
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 replicas = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+# optional third argument: comma-separated leaves (default = the nearby change + nearby swap pair); e.g. the default
+# list policy without ruin: nearby_change,nearby_swap,sublist_change,sublist_swap,list_reverse,kopt
+leaves = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("nearby_change", "nearby_swap")
+BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512,
+        "list_change": 4, "list_swap": 8}
 p = datasets.make_cvrp(1000, 100, 55, seed=0)
-d = sfa.build_cvrp(p, n_replicas=replicas)
+d = sfa.build_cvrp(p, n_replicas=replicas, leaves=leaves)
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
 t0 = time.perf_counter(); trace = []
 while time.perf_counter() - t0 < seconds:
-    d.solve_steps(200)
+    d.solve_steps(200 if len(leaves) == 2 else 50)
     if len(trace) % 25 == 0:
         trace.append((round(time.perf_counter() - t0, 1), list(max(tuple(int(v) for v in s) for s in d.best_scores()))))
     else:
         trace.append(None)
 gt = time.perf_counter() - t0
 st = d.total_stats()
-gpu = {"seconds": gt, "replicas": replicas, "best_score": list(max(tuple(int(v) for v in s) for s in d.best_scores())),
+gpu = {"seconds": gt, "replicas": replicas, "leaves": list(leaves), "best_score": list(max(tuple(int(v) for v in s) for s in d.best_scores())),
        "moves_evaluated": st["moves_evaluated"], "ls_steps_per_replica": st["step_count"] // replicas,
        "moves_per_s": st["moves_evaluated"] / gt, "trace": [t for t in trace if t]}
 o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
-o.configure(leaves=sfo.LEAF_NEARBY_LIST_CHANGE | sfo.LEAF_NEARBY_LIST_SWAP, max_nearby=20, random_seed=0)
+o.configure(leaves=sum(BITS[x] for x in leaves), max_nearby=20, random_seed=0)
 o.phase_start()
 t0 = time.perf_counter()
 steps = o.steps_timed(seconds)
