@@ -91,7 +91,9 @@ struct sf_ctx {
     int64_t* d_scores_out = nullptr;
     int32_t* d_ok = nullptr;
     // profiling
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;  // launches since the last fold / sf_profile_solve
+    double prof_ms = 0;                                      // folded totals (events are bounded, see fold_events)
+    int64_t prof_launches = 0;
     std::vector<void*> allocs;
     void* rccl = nullptr;  // portfolio state (sf_portfolio.cpp part below)
 };
@@ -169,10 +171,13 @@ int32_t sf_ctx_create(int32_t device_id, int32_t score_levels, int32_t hard_leve
     return SF_OK;
 }
 
+int32_t sf_portfolio_destroy(sf_ctx* ctx);
+
 void sf_ctx_destroy(sf_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)sf_portfolio_destroy(ctx);  // a communicator the caller did not tear down
     for (void* p : ctx->allocs) (void)hipFree(p);
     for (auto& ev : ctx->events) {
         (void)hipEventDestroy(ev.first);
@@ -858,6 +863,15 @@ int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_s
     uint64_t* d = nullptr;
     int rc = upload(ctx, &d, seeds, (size_t)n_steps * ctx->R);
     if (rc) return rc;
+    if (ctx->d_explicit) {  // release the previous sequence (no launch is using it: calls on a ctx are not re-entrant)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto it = ctx->allocs.begin(); it != ctx->allocs.end(); ++it)
+            if (*it == (void*)ctx->d_explicit) {
+                ctx->allocs.erase(it);
+                break;
+            }
+        (void)hipFree(ctx->d_explicit);
+    }
     ctx->d_explicit = d;
     ctx->n_explicit = n_steps;
     return SF_OK;
@@ -982,9 +996,15 @@ static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     return launch_scalar_search(ctx, p, grid, trace);
 }
 
+static int fold_events(sf_ctx* ctx);
+
 int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) {
     if (!ctx || !ctx->initialized || !ctx->search_alloc) return fail(ctx, SF_ERR_INVALID, "sf_phase_start first");
     if (n_steps <= 0) return SF_OK;
+    if (ctx->events.size() >= 1024) {  // a long-lived context never holds more than 1024 event pairs
+        int rcf = fold_events(ctx);
+        if (rcf) return rcf;
+    }
     SearchParams p = ctx->sp;
     fill_search_params(ctx, p);
     p.n_steps = n_steps;
@@ -1003,20 +1023,33 @@ int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) {
     return SF_OK;
 }
 
-int32_t sf_profile_solve(sf_ctx* ctx, double* out_ms, int64_t* out_launches) {
-    if (!ctx) return SF_ERR_INVALID;
+// add the finished launches' durations to the running totals and release their events
+static int fold_events(sf_ctx* ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    double total = 0;
     for (auto& ev : ctx->events) {
         float ms = 0;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
-        total += ms;
+        hipError_t e = hipEventElapsedTime(&ms, ev.first, ev.second);
         (void)hipEventDestroy(ev.first);
         (void)hipEventDestroy(ev.second);
+        if (e != hipSuccess) {
+            ctx->events.clear();
+            return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+        }
+        ctx->prof_ms += ms;
+        ctx->prof_launches += 1;
     }
-    if (out_ms) *out_ms = total;
-    if (out_launches) *out_launches = (int64_t)ctx->events.size();
     ctx->events.clear();
+    return SF_OK;
+}
+
+int32_t sf_profile_solve(sf_ctx* ctx, double* out_ms, int64_t* out_launches) {
+    if (!ctx) return SF_ERR_INVALID;
+    int rc = fold_events(ctx);
+    if (rc) return rc;
+    if (out_ms) *out_ms = ctx->prof_ms;
+    if (out_launches) *out_launches = ctx->prof_launches;
+    ctx->prof_ms = 0;
+    ctx->prof_launches = 0;
     return SF_OK;
 }
 
