@@ -9,7 +9,10 @@ from oracle import sfo
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ls = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+# start = constructed state (every operation assigned and scheduled); argv[4] = 'empty' keeps the all-unassigned start
 p = datasets.make_jobshop(500, 20)
+if not (len(sys.argv) > 4 and sys.argv[4] == 'empty'):
+    p = datasets.construct_jobshop(p)
 d = sfa.build_jobshop(p, n_replicas=R)
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
@@ -34,4 +37,6 @@ match = bool((d.calculate_score()[0] == o.score()[:3]).all()) if done == K * ls 
 print(json.dumps({"workload": "mixed job shop 500x20, Bendable<2,1>", "replicas": R, "gpu_moves_per_s": moves / dt,
                   "kernel_ms_per_launch": ms / n, "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done,
                   "replica0_matches_oracle": match, "gpu_over_cpu": (moves / dt) / (cm / ct),
-                  "score_replica0": d.calculate_score()[0].tolist()}))
+                  "score_replica0": d.calculate_score()[0].tolist(),
+                  "per_step": {k: (a[k] - b[k]) / max(a["step_count"] - b["step_count"], 1)
+                               for k in ("moves_evaluated", "candidates_scored", "sources_scanned", "moves_accepted", "moves_applied")}}))

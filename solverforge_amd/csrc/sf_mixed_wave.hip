@@ -340,7 +340,14 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 
         int done = 0;
         while (!done) {
-            // ---- C1: fill every live leaf's ring to >= 64 pending (or until its stream ends) ----
+            // ---- C1: fill every live leaf's ring (or until its stream ends).  A replay batch takes 64 pulls in whole
+            // scheduler cycles, i.e. ceil(64 / live leaves) candidates per leaf: keep that many (+8) pending, not 64 ----
+            uint32_t fill_thr = 64;
+            {
+                uint32_t live = 0;
+                for (int l = 0; l < nl; ++l) live += lt.get(l, LeafTab::EX) ? 0u : 1u;
+                if (live > 1) fill_thr = (63u + live) / live + 8u;
+            }
             for (int l = 0; l < nl; ++l) {
                 const int kind = lt.geti(l, LeafTab::KIND);
                 uint32_t* rq = ring + (size_t)l * GRC * 2;
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 const uint32_t hd_l = lt.get(l, LeafTab::HEAD);
                 const bool ex_l = lt.get(l, LeafTab::EX) != 0;
                 const uint32_t leaf_max_nearby = lt.get(l, LeafTab::MAXNB), leaf_min = lt.get(l, LeafTab::MINSZ), leaf_max = lt.get(l, LeafTab::MAXSZ);
-                while (!ex_l && !g.done && tl - hd_l < 64u) {
+                while (!ex_l && !g.done && tl - hd_l < fill_thr) {
                     st_sources += 1;
                     bool keep = false;
                     uint32_t w0 = 0, w1 = 0, wx = 0;

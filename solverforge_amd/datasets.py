@@ -106,3 +106,18 @@ def make_jobshop(n_jobs=500, n_machines=20):
         "machine_idx": np.full(n_ops, -1, dtype=np.int64),
         "sequences": [[] for _ in range(n_machines)],
     }
+
+
+def construct_jobshop(p, seed=0):
+    """A post-construction start state for C4 (the reference runs a construction phase before local search;
+    construction itself is out of scope): every operation gets a machine drawn from the
+    documented splitmix64 stream and is appended to a machine sequence drawn from the same stream."""
+    n, m = p["n_ops"], p["n_machines"]
+    r = stream(seed + 4242, 2 * n)
+    q = dict(p)
+    q["machine_idx"] = (r[:n] % np.uint64(m)).astype(np.int64)
+    seqs = [[] for _ in range(m)]
+    for op in range(n):
+        seqs[int(r[n + op] % np.uint64(m))].append(op)
+    q["sequences"] = seqs
+    return q
