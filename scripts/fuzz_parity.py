@@ -1,0 +1,133 @@
+"""Randomised differential run: random small instances x random policy (leaves, acceptor, forager, limits,
+selection order, engine) -> traced steps + fused steps on the GPU vs the CPU oracle.  Prints one JSON line;
+`failures` lists the seeds whose runs diverged (none expected).  Usage: fuzz_parity.py <seconds> [first_seed]"""
+import json, os, sys, time, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import solverforge_amd as sfa
+from solverforge_amd import datasets
+from oracle import sfo
+
+BITS = {"nearby_change": 16, "nearby_swap": 32, "list_change": 4, "list_swap": 8, "list_reverse": 64,
+        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "change": 1, "swap": 2}
+
+
+def t6(m):
+    return np.stack([m["kind"], m["a"], m["a_pos"], m["b"], m["b_pos"], m["value"]], axis=1)
+
+
+def run_case(seed):
+    rng = np.random.default_rng(seed)
+    model = ["cvrp", "cvrp", "graph", "jobshop"][int(rng.integers(4))]
+    acceptor = int(rng.choice([0, 1, 1, 3]))
+    forager = int(rng.choice([0, 0, 1, 2]))
+    limit = int(rng.choice([1, 2, 7, 40, 256]))
+    order = int(rng.choice([0, 3, 3, 4]))
+    la = int(rng.choice([1, 3, 50]))
+    levels = 2
+    desc = {"seed": seed, "model": model, "acceptor": acceptor, "forager": forager, "limit": limit, "order": order}
+    if model == "cvrp":
+        n = int(rng.integers(8, 70)); v = int(rng.integers(1, 9)); cap = int(rng.integers(10, 80))
+        p = datasets.make_cvrp(n, v, cap, seed=seed)
+        if rng.random() < 0.4:  # asymmetric + unreachable legs + ties
+            r = datasets.stream(seed + 5, p["matrix"].size).reshape(p["matrix"].shape)
+            p["matrix"] = (p["matrix"] // int(rng.choice([1, 1, 50])) + (r % np.uint64(int(rng.choice([1, 5])))).astype(np.int64)).astype(np.int64)
+            np.fill_diagonal(p["matrix"], 0)
+            if n > 10:
+                p["matrix"][3, 7] = np.iinfo(np.int64).max
+                p["matrix"][5, 2] = -1
+        if rng.random() < 0.3 and v > 2:  # empty and one-element routes
+            moved = p["routes"][1]
+            p["routes"][1] = []
+            p["routes"][0] = p["routes"][0] + moved
+            if len(p["routes"][2]) > 1:
+                p["routes"][0] = p["routes"][0] + p["routes"][2][1:]
+                p["routes"][2] = p["routes"][2][:1]
+        pool = ["nearby_change", "nearby_swap", "list_change", "list_swap", "list_reverse", "sublist_change", "sublist_swap", "kopt"]
+        chosen = set(rng.choice(pool, size=int(rng.integers(1, 7)), replace=False).tolist())
+        leaves = tuple(x for x in pool if x in chosen)
+        mn = int(rng.choice([1, 3, 20, 64]))
+        kopt = (int(rng.choice([1, 1, 2])), int(rng.choice([0, 2, 20])))
+        sub = (1, int(rng.choice([1, 3, 5])))
+        engine = int(rng.choice([0, 1, 2])) if set(leaves) <= {"nearby_change", "nearby_swap"} else 0
+        desc.update(n=n, v=v, leaves=leaves, max_nearby=mn, kopt=kopt, sublist=sub, engine=engine)
+        d = sfa.build_cvrp(p, leaves=leaves, max_nearby=mn, kopt=kopt, sublist_sizes=sub)
+        if engine:
+            d.set_engine(engine)
+        o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+        o.set_kopt(*kopt); o.set_sublist_sizes(*sub)
+        lists = lambda: (d.working_lists(0, 0), o.get_lists(0))
+    elif model == "graph":
+        n = int(rng.integers(5, 200)); e = int(rng.integers(n, 4 * n)); k = int(rng.integers(2, 9))
+        g = datasets.make_graph(n, min(e, n * (n - 1) // 2), k, seed=seed)
+        if rng.random() < 0.7:
+            g["colors"] = (datasets.stream(seed + 9, n) % np.uint64(k + 1)).astype(np.int64) - 1
+        leaves = [("change",), ("swap",), ("change", "swap")][int(rng.integers(3))]
+        desc.update(n=n, e=e, k=k, leaves=leaves)
+        d = sfa.build_graph_coloring(g, leaves=leaves)
+        o = sfo.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+        lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
+    else:
+        nj = int(rng.integers(2, 9)); nm = int(rng.integers(2, 6))
+        p = datasets.make_jobshop(nj, nm)
+        if rng.random() < 0.8:
+            p = datasets.construct_jobshop(p, seed=seed)
+        pool = ["list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt", "change", "swap"]
+        chosen = set(rng.choice(pool, size=int(rng.integers(1, 9)), replace=False).tolist())
+        leaves = tuple(x for x in pool if x in chosen)
+        levels = 3
+        desc.update(nj=nj, nm=nm, leaves=leaves)
+        d = sfa.build_jobshop(p, leaves=leaves)
+        o = sfo.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True)
+        o.set_kopt(1, 0)
+        lists = lambda: ((d.working_lists(1, 0), d.working_values(0, 0).tolist()), (o.get_lists(1), o.get_vars(0, 0).tolist()))
+    bits = sum(BITS[x] for x in leaves)
+    o.configure(acceptor=1 if acceptor == 3 else acceptor, la_size=la, forager=forager, limit=limit, leaves=bits,
+                selection_order=order, random_seed=seed, max_nearby=desc.get("max_nearby", 20))
+    d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=la, forager=forager, accepted_count_limit=limit,
+                                 selection_order=order, random_seed=seed))
+    if acceptor == 3:
+        ss = int(rng.choice([1, 9, 128]))
+        o.configure_annealing(mode=2, levels=levels, hard_levels=levels - 1, sample_size=ss, seed=seed)
+        d.configure_annealing(mode=2, calibration_sample_size=ss, seed=seed)
+    assert (d.calculate_score()[0] == o.score()[:levels]).all(), "initial score"
+    d.phase_start(); o.phase_start()
+    for step in range(6 if forager == 2 else 14):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 20)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), f"step {step}: trace length {len(gm)} vs {len(om)}"
+        assert (t6(gm) == t6(om)).all(), f"step {step}: candidate order"
+        assert (gs == os_[:, :levels]).all(), f"step {step}: trial scores"
+        assert (gf == of).all(), f"step {step}: flags"
+        assert gap == oap and (not gap or tuple(gmv) == tuple(omv)), f"step {step}: applied move"
+        a, b = lists()
+        assert a == b, f"step {step}: state"
+    n_fused = 5 if forager == 2 else 40
+    d.solve_steps(n_fused); o.steps(n_fused)
+    a, b = lists()
+    assert a == b, "fused state"
+    assert (d.calculate_score()[0] == o.score()[:levels]).all() and (d.fresh_score()[0] == o.score()[:levels]).all(), "fused score"
+    gst, ost = d.stats(0), o.stats()
+    for k2 in ["step_count", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k2] == ost[k2], f"counter {k2}"
+    return desc
+
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t0 = time.time(); ran = 0; failures = []; by_model = {}
+while time.time() - t0 < budget:
+    try:
+        desc = run_case(seed)
+        by_model[desc["model"]] = by_model.get(desc["model"], 0) + 1
+    except sfa.SolverForgeError as e:
+        if "SF_ERR_UNSUPPORTED" not in str(e):
+            failures.append({"seed": seed, "error": str(e)[:300]})
+        else:
+            by_model["unsupported"] = by_model.get("unsupported", 0) + 1
+    except AssertionError as e:
+        failures.append({"seed": seed, "error": str(e)[:300]})
+    except Exception as e:
+        failures.append({"seed": seed, "error": traceback.format_exc()[-400:]})
+    ran += 1; seed += 1
+print(json.dumps({"cases": ran, "by_model": by_model, "failures": failures[:20], "n_failures": len(failures)}))
