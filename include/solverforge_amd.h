@@ -280,8 +280,9 @@ int32_t sf_phase_start(sf_ctx* ctx);
 /* ≙ n_steps x execute_step (phase/localsearch/phase/step.rs:30-225) for EVERY replica, fused in
  * one persistent launch (generate -> trial-score -> accept -> forage -> apply). Asynchronous. */
 int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps);
-/* one traced step on every replica: per consumed candidate move/score/flags (bit0 doable, bit1
- * accepted) of replica `replica`; out_applied = 1 and *out_applied_move when a move was committed */
+/* one traced step on every replica: per consumed candidate move/score/flags of replica `replica` (bit0 doable, bit1
+ * accepted, bit2 = the forager's pick that the step committed, bits 8..15 = MoveCursor::selector_index = the leaf's
+ * position in the union); out_applied = 1 and *out_applied_move when a move was committed */
 int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves, int64_t* out_scores,
                              int32_t* out_flags, int64_t cap, int64_t* out_count,
                              int32_t* out_applied, sf_move_t* out_applied_move);
@@ -305,6 +306,32 @@ int32_t sf_portfolio_init(sf_ctx* ctx, const uint8_t* id128, int32_t rank, int32
 int32_t sf_portfolio_allgather_best(sf_ctx* ctx, int64_t* out_best_score, int32_t* out_winner_rank,
                                     int32_t* out_winner_replica);
 int32_t sf_portfolio_destroy(sf_ctx* ctx);
+
+/* ---- candidate trace, wire format v3 (stats/candidate_trace.rs:15-60,718-812) ---------------
+ * Host-side framing of what sf_solve_step_traced returned: every pull becomes the reference's canonical
+ * CandidatePullTelemetry bytes and is folded into the two-lane CandidateTraceDigest, so a whole run's pull order,
+ * identities and dispositions compare against a reference run's `prefix_digest` as one 128-bit value. */
+typedef struct sf_trace_digest {
+    uint64_t first;  /* FNV-1a 64 lane   (candidate_trace.rs:30-31,50-51) */
+    uint64_t second; /* rotate-multiply lane (:32-33,53-58) */
+} sf_trace_digest;
+typedef struct sf_trace_scope {
+    int32_t phase_index;         /* CandidatePullTelemetry::phase_index (0-based index of the phase in the run) */
+    const char* phase_type;      /* "Local Search" for LocalSearchPhase (phase/localsearch/phase.rs:253) */
+    int32_t list_descriptor;     /* descriptor_index + variable_name of List* / k-opt moves */
+    const char* list_variable;
+    int32_t scalar_descriptor;   /* descriptor_index + variable_name of Change / Swap moves */
+    const char* scalar_variable;
+} sf_trace_scope;
+void sf_trace_digest_init(sf_trace_digest* d);                                     /* CandidateTraceDigest::empty */
+void sf_trace_digest_update(sf_trace_digest* d, const void* bytes, size_t n);      /* CandidateTraceDigest::update */
+/* Frames the n pulls of ONE traced step (moves/flags as sf_solve_step_traced wrote them; `first_ordinal` = pulls
+ * recorded before this step; `step_index` = steps the phase had completed).  Writes the canonical bytes to `out`
+ * (may be NULL: size query) and updates `digest` (may be NULL) pull by pull.  Returns the byte count, or
+ * SF_ERR_INVALID (unknown move kind) / SF_ERR_CAPACITY (`out` too small). */
+int64_t sf_trace_encode_step(const sf_trace_scope* scope, uint64_t first_ordinal, uint64_t step_index,
+                             const sf_move_t* moves, const int32_t* flags, int64_t n, uint8_t* out, int64_t cap,
+                             sf_trace_digest* digest);
 
 #ifdef __cplusplus
 }

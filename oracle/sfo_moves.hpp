@@ -323,6 +323,8 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
 struct Cursor {
     virtual ~Cursor() = default;
     virtual bool next(Move& out) = 0;
+    // MoveCursor::selector_index of the candidate `next` just returned (vec_union.rs:505-509: the child cursor index)
+    virtual size_t last_selector() const { return 0; }
 };
 
 struct ScalarSlot {
@@ -1504,6 +1506,7 @@ struct UnionCursor : Cursor {
         return sched.next(
             children.size(), [&](size_t i) { return children[i]->next(out); }, last_child);
     }
+    size_t last_selector() const override { return last_child; }
 };
 
 }  // namespace sfo

@@ -294,6 +294,8 @@ struct StepTrace {  // one record per pulled candidate (for order/score parity t
     bool doable;
     Score score;
     bool accepted;
+    size_t selector = 0;    // cursor.selector_index(candidate_id) (candidates.rs:84)
+    bool selected = false;  // the forager's pick, committed at the end of the step (step.rs:122-147)
 };
 
 struct LocalSearch {
@@ -361,7 +363,7 @@ struct LocalSearch {
             // evaluate_candidate (evaluation.rs:20-115)
             if (!move_is_doable(*director, mv)) {
                 ++stats.moves_not_doable;
-                if (trace) trace->push_back({mv, false, Score::zero(), false});
+                if (trace) trace->push_back({mv, false, Score::zero(), false, cursor->last_selector(), false});
                 continue;
             }
             DirectorScoreState st = director->snapshot_score_state();
@@ -371,7 +373,7 @@ struct LocalSearch {
             director->restore_score_state(st);
             ++stats.score_calculations;
             bool accepted = acceptor->is_accepted(last_step_score, move_score);
-            if (trace) trace->push_back({mv, true, move_score, accepted});
+            if (trace) trace->push_back({mv, true, move_score, accepted, cursor->last_selector(), false});
             if (accepted) {
                 ++stats.moves_accepted;
                 forager.add_move_index(id, move_score);
@@ -380,6 +382,7 @@ struct LocalSearch {
         last_step_applied = false;
         if (forager.best.has) {  // pick_move_index + apply_owned_candidate
             const Move& winner = kept[forager.best.index];
+            if (trace) (*trace)[forager.best.index].selected = true;
             MoveUndo ignored = move_do(*director, winner);
             (void)ignored;
             director->calculate_score();

@@ -53,6 +53,15 @@ class StatsStruct(C.Structure):
         "score_calculations", "moves_not_doable", "candidates_scored", "sources_scanned", "reserved")]
 
 
+class TraceDigestStruct(C.Structure):
+    _fields_ = [("first", C.c_uint64), ("second", C.c_uint64)]
+
+
+class TraceScopeStruct(C.Structure):
+    _fields_ = [("phase_index", C.c_int32), ("phase_type", C.c_char_p), ("list_descriptor", C.c_int32),
+                ("list_variable", C.c_char_p), ("scalar_descriptor", C.c_int32), ("scalar_variable", C.c_char_p)]
+
+
 class SolverForgeError(RuntimeError):
     pass
 
@@ -68,6 +77,7 @@ SYMBOLS = [
     "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
     "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_destroy",
+    "sf_trace_digest_init", "sf_trace_digest_update", "sf_trace_encode_step",
 ]
 
 _lib = None
@@ -129,9 +139,16 @@ def load():
     L.sf_portfolio_init.argtypes = [vp, vp, i32, i32]
     L.sf_portfolio_allgather_best.argtypes = [vp, vp, vp, vp]
     L.sf_portfolio_destroy.argtypes = [vp]
+    L.sf_trace_digest_init.argtypes = [C.POINTER(TraceDigestStruct)]
+    L.sf_trace_digest_update.argtypes = [C.POINTER(TraceDigestStruct), vp, C.c_size_t]
+    L.sf_trace_encode_step.argtypes = [C.POINTER(TraceScopeStruct), u64, u64, vp, vp, i64, vp, i64, C.POINTER(TraceDigestStruct)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("sf_ctx_destroy", "sf_last_error"):
+        if name in ("sf_trace_digest_init", "sf_trace_digest_update"):
+            fn.restype = None
+        elif name == "sf_trace_encode_step":
+            fn.restype = i64
+        elif name not in ("sf_ctx_destroy", "sf_last_error"):
             fn.restype = i32
     _lib = L
     return L

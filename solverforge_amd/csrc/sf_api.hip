@@ -1185,3 +1185,4 @@ extern "C" int32_t sf_debug_phases(uint64_t* out8) {  // diagnostic builds only 
 
 #include "sf_api_scalar.inc"
 #include "sf_portfolio.inc"
+#include "sf_candidate_trace.inc"

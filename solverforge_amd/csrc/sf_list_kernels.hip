@@ -868,6 +868,7 @@ struct Ctl {
     uint32_t wave_src[MAXW], wave_cnt[MAXW];
     uint64_t st[SF_STATS_WORDS];
     uint64_t trace_n;
+    uint64_t best_ti;  // trace ordinal (within the step) of the forager's current pick
 };
 
 __host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1317,6 +1318,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                                 best_m0 = __shfl(m0, sel);
                                 best_m1 = __shfl(m1, sel);
                                 best_kind = (int)__shfl(lf, sel);
+                                if (TRACE && lane == 0) c.best_ti = c.trace_n + (uint64_t)sel;
                                 has_best = 1;
                             }
                         } else {
@@ -1337,6 +1339,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                                     best_m0 = __shfl(m0, sel);
                                     best_m1 = __shfl(m1, sel);
                                     best_kind = (int)__shfl(lf, sel);
+                                    if (TRACE && lane == 0) c.best_ti = c.trace_n + (uint64_t)sel;
                                 }
                                 best = M;
                                 equal_count = base + (uint64_t)__popcll(eq);
@@ -1362,7 +1365,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                             tm[4] = (int32_t)(m1 & 0xFFFFu);
                             tm[5] = -1;
                             for (int kk = 0; kk < L && kk < m.levels; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
-                            p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                            p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0) | ((int32_t)lf << 8);
                         }
                     }
                     if (tracing) {
@@ -1413,6 +1416,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
             const uint32_t b = c.best_m1 >> 16, j = c.best_m1 & 0xFFFFu;
             if (tracing && tid == 0) {
                 p.trace_applied[0] = 1;
+                if ((int64_t)c.best_ti < p.trace_cap) p.trace_flags[c.best_ti] |= 4;  // Selected + Applied
                 p.trace_applied[1] = kind;
                 p.trace_applied[2] = (int32_t)a;
                 p.trace_applied[3] = (int32_t)i;

@@ -531,6 +531,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         for (int k = 0; k < L; ++k) best.v[k] = 0;
         uint32_t best_m0 = 0, best_m1 = 0;
         int best_leaf = 0;
+        uint64_t best_ti = 0;  // trace ordinal (within the step) of the forager's current pick
         const uint32_t total = uni(s_off[V]);
         // union: >1 leaf => StratifiedRandom, equal weights (vec_union.rs:229-245); with two children
         // the stride is always 1, so the order is first, other, first, ...
@@ -899,6 +900,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                             best_m0 = __shfl(m0, sel);
                             best_m1 = __shfl(m1, sel);
                             best_leaf = (int)__shfl(lf, sel);
+                            if (TRACE) best_ti = trace_n + (uint64_t)sel;
                             has_best = 1;
                         }
                     } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
@@ -919,6 +921,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                                 best_m0 = __shfl(m0, sel);
                                 best_m1 = __shfl(m1, sel);
                                 best_leaf = (int)__shfl(lf, sel);
+                                if (TRACE) best_ti = trace_n + (uint64_t)sel;
                             }
 #pragma unroll
                             for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64((uint64_t)M.v[kk]);
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                         tm[4] = (int32_t)(m1 & 0xFFFFu);
                         tm[5] = -1;
                         for (int kk = 0; kk < L && kk < m.levels; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
-                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0) | ((int32_t)lf << 8);
                     }
                 }
                 if (tracing) trace_n += nconsumed;
@@ -967,6 +970,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
             const uint32_t b = uni(best_m1 >> 16), j = uni(best_m1 & 0xFFFFu);
             if (tracing && lane == 0) {
                 p.trace_applied[0] = 1;
+                if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied
                 p.trace_applied[1] = kind;
                 p.trace_applied[2] = (int32_t)a;
                 p.trace_applied[3] = (int32_t)i;

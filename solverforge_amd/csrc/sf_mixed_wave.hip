@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         for (int k = 0; k < L; ++k) best.v[k] = 0;
         uint32_t best_m0 = 0, best_m1 = 0, best_x = 0;
         int best_leaf = 0;
+        uint64_t best_ti = 0;  // trace ordinal (within the step) of the forager's current pick
 
         // entity permutations (selection_index_without_replacement) of the four streams
         uint32_t sc_st = 0, sc_sd = 1, ss_st = 0, ss_sd = 1, lc_st = 0, lc_sd = 1, ls_st = 0, ls_sd = 1, lr_st = 0, lr_sd = 1;
@@ -1049,6 +1050,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             best_m1 = __shfl(m1, sel);
                             best_x = __shfl(mx_, sel);
                             best_leaf = (int)__shfl(my_leaf, sel);
+                            if (TRACE) best_ti = trace_n + (uint64_t)sel;
                             has_best = 1;
                         }
                     } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
@@ -1070,6 +1072,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 best_m1 = __shfl(m1, sel);
                                 best_x = __shfl(mx_, sel);
                                 best_leaf = (int)__shfl(my_leaf, sel);
+                                if (TRACE) best_ti = trace_n + (uint64_t)sel;
                             }
                             best = M;
                             equal_count = eq_base + (uint64_t)__popcll(eq);
@@ -1104,7 +1107,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                                    : (my_kind == 256 ? (int32_t)((mx_ & 15u) | ((mx_ >> 4) << 16)) : (my_kind == 512 ? (int32_t)mx_ : -1));
                         }
                         for (int kk = 0; kk < L && kk < gl.levels; ++kk) p.trace_scores[ti * gl.levels + kk] = doable ? sc.v[kk] : 0;
-                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0) | ((int32_t)my_leaf << 8);
                     }
                 }
                 if (tracing) trace_n += nconsumed;
@@ -1122,6 +1125,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             if (kind <= 2) {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
+                    if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied
                     p.trace_applied[1] = kind == 1 ? 0 : 1;
                     p.trace_applied[2] = (int32_t)a;
                     p.trace_applied[3] = 0;
@@ -1142,6 +1146,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             } else {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
+                    if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied
                     p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : (kind == 512 ? 7 : 6))));
                     p.trace_applied[2] = (int32_t)(a >> 16);
                     p.trace_applied[3] = (int32_t)(a & 0xFFFFu);

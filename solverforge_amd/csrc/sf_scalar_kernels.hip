@@ -487,6 +487,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
         for (int k = 0; k < L; ++k) best.v[k] = 0;
         uint32_t best_m0 = 0, best_m1 = 0;
         int best_leaf = 0;
+        uint64_t best_ti = 0;  // trace ordinal (within the step) of the forager's current pick
         const uint32_t first_leaf = n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u;
 
         // entity permutations (selection_index_without_replacement)
@@ -696,6 +697,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                             best_m0 = __shfl(m0, sel);
                             best_m1 = __shfl(m1, sel);
                             best_leaf = (int)__shfl(lf, sel);
+                            if (TRACE) best_ti = trace_n + (uint64_t)sel;
                             has_best = 1;
                         }
                     } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
@@ -716,6 +718,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                                 best_m0 = __shfl(m0, sel);
                                 best_m1 = __shfl(m1, sel);
                                 best_leaf = (int)__shfl(lf, sel);
+                                if (TRACE) best_ti = trace_n + (uint64_t)sel;
                             }
                             best = M;
                             equal_count = eq_base + (uint64_t)__popcll(eq);
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                         tm[4] = 0;
                         tm[5] = lane_change ? (int32_t)m1 : -1;
                         for (int kk = 0; kk < L && kk < m.levels; ++kk) p.trace_scores[ti * m.levels + kk] = doable ? sc.v[kk] : 0;
-                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0);
+                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0) | ((int32_t)lf << 8);
                     }
                 }
                 if (tracing) trace_n += nconsumed;
@@ -762,6 +765,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
             const uint32_t a = uni(best_m0), b = uni(best_m1);
             if (tracing && lane == 0) {
                 p.trace_applied[0] = 1;
+                if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied
                 p.trace_applied[1] = pick_change ? 0 : 1;
                 p.trace_applied[2] = (int32_t)a;
                 p.trace_applied[3] = 0;

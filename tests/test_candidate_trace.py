@@ -1,0 +1,176 @@
+"""Candidate-trace wire format v3 (reference stats/candidate_trace.rs): the native encoder
+(sf_trace_encode_step / sf_trace_digest_*) against an independent restatement (oracle/trace_v3.py), hand-framed bytes,
+the published FNV-1a vectors for digest lane one, and — on the GPU — the digest of a traced device run against the
+digest of the CPU oracle's run."""
+import struct
+
+import numpy as np
+import pytest
+
+import solverforge_amd as sfa
+from oracle import sfo, trace_v3
+from solverforge_amd import candidate_trace as ct
+from solverforge_amd import datasets
+
+BITS = {"nearby_change": 16, "nearby_swap": 32, "list_change": 4, "list_swap": 8, "list_reverse": 64,
+        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "change": 1, "swap": 2}
+
+
+def t6(m):
+    return np.stack([m["kind"], m["a"], m["a_pos"], m["b"], m["b_pos"], m["value"]], axis=1)
+
+
+def test_digest_lane_one_is_fnv1a64():
+    # published FNV-1a 64 vectors (offset basis / prime = candidate_trace.rs:30-31)
+    assert ct.digest_of_bytes(b"")[0] == 0xCBF29CE484222325
+    assert ct.digest_of_bytes(b"a")[0] == 0xAF63DC4C8601EC8C
+    assert ct.digest_of_bytes(b"foobar")[0] == 0x85944171F73967E8
+    assert ct.digest_of_bytes(b"")[1] == 0x9E3779B97F4A7C15  # CandidateTraceDigest::empty
+    for data in (b"", b"a", b"foobar", bytes(range(256)) * 3):
+        assert ct.digest_of_bytes(data) == trace_v3.Digest().update(data).value()
+
+
+def test_digest_is_incremental():
+    t = ct.CandidateTrace()
+    mv = np.zeros(3, dtype=sfa.MOVE_DTYPE)
+    mv["kind"] = [2, 3, 4]
+    mv["a"], mv["a_pos"], mv["b"], mv["b_pos"], mv["value"] = [1, 2, 3], [4, 5, 6], [1, 0, 3], [7, 8, 9], -1
+    t.record_step(mv[:2], np.array([3, 1], dtype=np.int32))
+    t.record_step(mv[2:], np.array([7 | (2 << 8)], dtype=np.int32))
+    assert ct.digest_of_bytes(t.canonical_bytes()) == t.prefix_digest
+    assert (t.total_pulls, t.step_index) == (3, 2)
+
+
+def test_one_pull_framed_by_hand():
+    """A list_change pull written out byte by byte from append_canonical_bytes (candidate_trace.rs:778-812,724-739)."""
+    q = lambda v: struct.pack("<Q", v)
+    s = lambda x: q(len(x)) + x
+    expect = (b"\x45" + q(5)            # 0x45, ordinal
+              + b"\x02"                 # CandidateTraceSource::LocalSearch
+              + q(1) + s(b"Local Search") + q(9)   # phase_index, phase_type, step_index
+              + b"\x01" + q(1)          # selector_index Some(1)
+              + q(0)                    # candidate_index
+              + b"\x00"                 # construction_target None
+              + b"\x01"                 # identity Some
+              + b"\x4f" + q(0) + b"\x01" + s(b"visits") + s(b"list_change")
+              + q(5) + b"".join(b"\x01" + q(v) for v in (2, 1, 2, 4, 3))   # intra move: adjusted destination 4 - 1
+              + q(3) + bytes([2, 8, 9]))  # Evaluated, Selected, Applied
+    t = ct.CandidateTrace(phase_index=1)
+    t.total_pulls, t.step_index = 5, 9
+    mv = np.zeros(1, dtype=sfa.MOVE_DTYPE)
+    mv["kind"], mv["a"], mv["a_pos"], mv["b"], mv["b_pos"], mv["value"] = 2, 2, 1, 2, 4, -1
+    t.record_step(mv, np.array([7 | (1 << 8)], dtype=np.int32))
+    assert t.canonical_bytes() == expect
+    # to-None scalar change: the value coordinate is Absent (tag 2, no payload)
+    t2 = ct.CandidateTrace(scalar_descriptor=3, scalar_variable="machine_idx")
+    mv["kind"], mv["a"], mv["value"] = 0, 17, -1
+    t2.record_step(mv, np.array([1], dtype=np.int32))
+    tail = b"\x4f" + q(3) + b"\x01" + s(b"machine_idx") + s(b"scalar_change") + q(2) + b"\x01" + q(17) + b"\x02" + q(2) + bytes([2, 6])
+    assert t2.canonical_bytes().endswith(tail)
+
+
+def test_unknown_move_kind_is_rejected():
+    t = ct.CandidateTrace()
+    mv = np.zeros(1, dtype=sfa.MOVE_DTYPE)
+    mv["kind"] = 42
+    with pytest.raises(sfa.SolverForgeError):
+        t.record_step(mv, np.array([1], dtype=np.int32))
+
+
+def _oracle_models():
+    p = datasets.make_cvrp(40, 5, 40, seed=2)
+    o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.set_kopt(1, 5)
+    o.set_sublist_sizes(1, 3)
+    leaves = ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt")
+    o.configure(acceptor=1, la_size=5, forager=0, limit=40, leaves=sum(BITS[x] for x in leaves), selection_order=3,
+                random_seed=4, max_nearby=10)
+    yield "cvrp", o, dict(list_scope=(0, "visits")), p, leaves
+    j = datasets.construct_jobshop(datasets.make_jobshop(6, 4), seed=1)
+    oj = sfo.Model.jobshop(j["job"], j["machine_idx"], j["sequences"], bendable=True)
+    oj.set_kopt(1, 0)
+    jl = ("list_change", "list_swap", "change", "swap")
+    oj.configure(acceptor=1, la_size=5, forager=0, limit=30, leaves=sum(BITS[x] for x in jl), selection_order=3, random_seed=2)
+    yield "jobshop", oj, dict(list_scope=(1, "sequence"), scalar_scope=(0, "machine_idx")), j, jl
+
+
+def test_native_encoder_matches_restatement_on_oracle_traces():
+    """Every move family, selector indices of a 6-leaf union, all four disposition shapes."""
+    seen_kinds, seen_disp = set(), set()
+    for name, o, scopes, _, _ in _oracle_models():
+        ls, ss = scopes.get("list_scope", (0, "visits")), scopes.get("scalar_scope", (0, "value"))
+        native = ct.CandidateTrace(list_descriptor=ls[0], list_variable=ls[1], scalar_descriptor=ss[0], scalar_variable=ss[1])
+        ref = trace_v3.Trace(list_scope=ls, scalar_scope=ss)
+        o.phase_start()
+        for _ in range(12):
+            mv, _, fl, applied, _ = o.step_traced()
+            assert int(((fl & 4) != 0).sum()) == (1 if applied else 0)  # exactly the committed pick is Selected
+            assert ((fl & 4) == 0).all() or (fl[(fl & 4) != 0] & 3 == 3).all()
+            native.record_step(mv, fl)
+            ref.record_step(t6(mv), fl)
+            seen_kinds |= set(mv["kind"].tolist())
+            seen_disp |= set((fl & 7).tolist())
+        assert native.canonical_bytes() == ref.canonical_bytes(), name
+        assert native.prefix_digest == ref.digest.value(), name
+        assert native.total_pulls == ref.total_pulls > 0
+    assert seen_kinds == {0, 1, 2, 3, 4, 5, 6, 7}
+    assert seen_disp >= {0, 1, 3, 7}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", [0, 1, 2])
+def test_gpu_trace_digest_equals_oracle_digest(engine):
+    """The whole pull stream of a device run — order, identities, selector indices, dispositions, the committed pick —
+    compared with the CPU oracle's as one 128-bit digest (and step by step, so a mismatch is localised)."""
+    for name, o, scopes, data, leaves in _oracle_models():
+        if name == "cvrp":
+            if engine:  # the wave / block engines run the two nearby leaves
+                leaves = ("nearby_change", "nearby_swap")
+                o.configure(acceptor=1, la_size=5, forager=0, limit=40, leaves=48, selection_order=3, random_seed=4, max_nearby=10)
+            d = sfa.build_cvrp(data, leaves=leaves, max_nearby=10, kopt=(1, 5), sublist_sizes=(1, 3))
+            if engine:
+                d.set_engine(engine)
+            cfg = sfa.SolverConfig(acceptor=1, late_acceptance_size=5, forager=0, accepted_count_limit=40, selection_order=3, random_seed=4)
+        else:
+            if engine:
+                continue
+            d = sfa.build_jobshop(data, leaves=leaves)
+            cfg = sfa.SolverConfig(acceptor=1, late_acceptance_size=5, forager=0, accepted_count_limit=30, selection_order=3, random_seed=2)
+        d.configure(cfg)
+        ls, ss = scopes.get("list_scope", (0, "visits")), scopes.get("scalar_scope", (0, "value"))
+        gpu = ct.CandidateTrace(list_descriptor=ls[0], list_variable=ls[1], scalar_descriptor=ss[0], scalar_variable=ss[1], keep_bytes=False)
+        cpu = trace_v3.Trace(list_scope=ls, scalar_scope=ss)
+        d.calculate_score()
+        d.phase_start()
+        o.phase_start()
+        for step in range(25):
+            gm, _, gf, gap, _ = d.solve_step_traced(cap=1 << 18)
+            om, _, of, oap, _ = o.step_traced()
+            gpu.record_step(gm, gf)
+            cpu.record_step(t6(om), of)
+            assert gpu.prefix_digest == cpu.digest.value(), (name, step)
+            assert gap == oap
+        assert gpu.total_pulls == cpu.total_pulls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("forager", [0, 1, 2])
+def test_gpu_trace_digest_scalar_engine(forager):
+    g = datasets.make_graph(60, 150, 4, seed=3)
+    g["colors"] = (datasets.stream(12, 60) % np.uint64(5)).astype(np.int64) - 1
+    d = sfa.build_graph_coloring(g, leaves=("change", "swap"))
+    o = sfo.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+    o.configure(acceptor=1, la_size=3, forager=forager, limit=7, leaves=3, selection_order=3, random_seed=5)
+    d.configure(sfa.SolverConfig(acceptor=1, late_acceptance_size=3, forager=forager, accepted_count_limit=7, selection_order=3, random_seed=5))
+    gpu = ct.CandidateTrace(scalar_variable="color", keep_bytes=False)
+    cpu = trace_v3.Trace(scalar_scope=(0, "color"))
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    for step in range(6):
+        gm, _, gf, _, _ = d.solve_step_traced(cap=1 << 18)
+        om, _, of, _, _ = o.step_traced()
+        gpu.record_step(gm, gf)
+        cpu.record_step(t6(om), of)
+        assert gpu.prefix_digest == cpu.digest.value(), (forager, step)
+    assert gpu.total_pulls == cpu.total_pulls > 0
