@@ -280,6 +280,12 @@ int32_t sf_phase_start(sf_ctx* ctx);
 /* ≙ n_steps x execute_step (phase/localsearch/phase/step.rs:30-225) for EVERY replica, fused in
  * one persistent launch (generate -> trial-score -> accept -> forage -> apply). Asynchronous. */
 int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps);
+/* Work-balanced launch for time-budgeted solves (termination by wall clock, not step count): every replica runs
+ * whole steps until it has pulled >= move_budget candidates IN THIS LAUNCH or max_steps steps, whichever comes
+ * first, so replicas whose steps are long (few accepted moves late in a search) do not hold the launch back while
+ * the others sit idle.  Each replica's trajectory is still exactly the reference's for the steps it ran
+ * (sf_get_stats(replica).step_count); replicas simply differ in how many steps they have completed. Asynchronous. */
+int32_t sf_solve_moves(sf_ctx* ctx, int64_t max_steps, int64_t move_budget);
 /* one traced step on every replica: per consumed candidate move/score/flags of replica `replica` (bit0 doable, bit1
  * accepted, bit2 = the forager's pick that the step committed, bits 8..15 = MoveCursor::selector_index = the leaf's
  * position in the union); out_applied = 1 and *out_applied_move when a move was committed */

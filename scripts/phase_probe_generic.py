@@ -1,0 +1,32 @@
+"""Diagnostic: per-phase shader-clock shares of the generic N-leaf engine on the CVRP-1000 default-policy union (needs a
+-DSF_PHASE_PROFILE build passed via SF_AMD_LIB).  Phases: 0 step start + order tables, 1 fill nearby / plain leaves,
+2 fill sublist leaves, 3 fill reverse, 4 fill 3-opt, 5 scheduler layout, 6 trial score + acceptor + forager, 7 commit."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import solverforge_amd as sfa
+from solverforge_amd import datasets, _lib
+p = datasets.make_cvrp(1000, 100, 55, seed=0)
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+leaves = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt")
+d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves)
+d.configure(sfa.SolverConfig(random_seed=0))
+d.calculate_score(); d.phase_start()
+L = _lib.load()
+out = np.zeros(8, dtype=np.uint64)
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # local-search steps before the probe (late-phase behaviour)
+if warm:
+    d.solve_steps(warm)
+    L.sf_debug_phases(out.ctypes.data_as(ctypes.c_void_p))
+    d.profile_solve()
+for it in range(3):
+    b = d.total_stats()
+    d.solve_steps(100)
+    L.sf_debug_phases(out.ctypes.data_as(ctypes.c_void_p))
+    ms, n = d.profile_solve()
+    a = d.total_stats()
+    tot = out.sum()
+    print("launch", it, "ms %.1f" % ms, "Gmoves/s %.2f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / ms / 1e6),
+          "moves/step %.0f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / R / 100),
+          "fill calls/step %.0f" % ((a["sources_scanned"] - b["sources_scanned"]) / R / 100),
+          "cycles/step/wave %.0f" % (tot / R / 100), "shares %", np.round(out / tot * 100, 1))

@@ -18,8 +18,14 @@ d = sfa.build_cvrp(p, n_replicas=replicas, leaves=leaves)
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
 t0 = time.perf_counter(); trace = []
+# optional fourth argument: candidates per replica per launch (sf_solve_moves: work-balanced launches); 0 = fixed
+# step counts per launch (sf_solve_steps)
+budget = int(sys.argv[4]) if len(sys.argv) > 4 else 100_000
 while time.perf_counter() - t0 < seconds:
-    d.solve_steps(200 if len(leaves) == 2 else 50)
+    if budget:
+        d.solve_moves(1 << 20, budget)
+    else:
+        d.solve_steps(200 if len(leaves) == 2 else 50)
     if len(trace) % 25 == 0:
         trace.append((round(time.perf_counter() - t0, 1), list(max(tuple(int(v) for v in s) for s in d.best_scores()))))
     else:
@@ -27,7 +33,7 @@ while time.perf_counter() - t0 < seconds:
 gt = time.perf_counter() - t0
 st = d.total_stats()
 gpu = {"seconds": gt, "replicas": replicas, "leaves": list(leaves), "best_score": list(max(tuple(int(v) for v in s) for s in d.best_scores())),
-       "moves_evaluated": st["moves_evaluated"], "ls_steps_per_replica": st["step_count"] // replicas,
+       "moves_evaluated": st["moves_evaluated"], "ls_steps_per_replica": st["step_count"] // replicas, "launch_move_budget": budget,
        "moves_per_s": st["moves_evaluated"] / gt, "trace": [t for t in trace if t]}
 o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
 o.configure(leaves=sum(BITS[x] for x in leaves), max_nearby=20, random_seed=0)

@@ -74,7 +74,7 @@ SYMBOLS = [
     "sf_constraint_add", "sf_selector_add", "sf_selector_add_sublist", "sf_selector_add_kopt", "sf_initialize", "sf_evaluate_all", "sf_evaluate_each", "sf_get_scores",
     "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_solver_configure_annealing",
     "sf_get_annealing_state", "sf_solver_set_step_seeds",
-    "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
+    "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_moves", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
     "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_destroy",
     "sf_trace_digest_init", "sf_trace_digest_update", "sf_trace_encode_step",
@@ -128,6 +128,7 @@ def load():
     L.sf_solver_set_step_seeds.argtypes = [vp, vp, i64]
     L.sf_phase_start.argtypes = [vp]
     L.sf_solve_steps.argtypes = [vp, i64]
+    L.sf_solve_moves.argtypes = [vp, i64, i64]
     L.sf_solve_step_traced.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp]
     L.sf_get_stats.argtypes = [vp, i32, C.POINTER(StatsStruct)]
     L.sf_get_stats_sum.argtypes = [vp, C.POINTER(StatsStruct)]

@@ -998,7 +998,16 @@ static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
 
 static int fold_events(sf_ctx* ctx);
 
-int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) {
+static int32_t solve_launch(sf_ctx* ctx, int64_t n_steps, int64_t move_budget);
+
+int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) { return solve_launch(ctx, n_steps, 0); }
+
+int32_t sf_solve_moves(sf_ctx* ctx, int64_t max_steps, int64_t move_budget) {
+    if (move_budget <= 0) return fail(ctx, SF_ERR_INVALID, "sf_solve_moves: move_budget must be positive");
+    return solve_launch(ctx, max_steps, move_budget);
+}
+
+static int32_t solve_launch(sf_ctx* ctx, int64_t n_steps, int64_t move_budget) {
     if (!ctx || !ctx->initialized || !ctx->search_alloc) return fail(ctx, SF_ERR_INVALID, "sf_phase_start first");
     if (n_steps <= 0) return SF_OK;
     if (ctx->events.size() >= 1024) {  // a long-lived context never holds more than 1024 event pairs
@@ -1008,6 +1017,7 @@ int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) {
     SearchParams p = ctx->sp;
     fill_search_params(ctx, p);
     p.n_steps = n_steps;
+    p.move_budget = move_budget;
     hipEvent_t e0, e1;
     HIPCHK(ctx, hipEventCreate(&e0));
     HIPCHK(ctx, hipEventCreate(&e1));

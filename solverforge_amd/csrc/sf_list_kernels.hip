@@ -1482,6 +1482,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
             }
             if (annealing && wave == 0) sa_step_ended(s_sa, p.sa, lane);
             __syncthreads();
+            if (p.move_budget > 0 && (int64_t)c.st[1] >= p.move_budget) break;  // uniform: c.st lives in LDS, read after the barrier
         }
     }
 
@@ -1498,9 +1499,10 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                 g_score[kk] = c.cur[kk];
                 p.last_step_score[(size_t)r * 4 + kk] = c.cur[kk];
             }
-            p.la_idx[r] = (int32_t)((p.la_idx[r] + p.n_steps) % p.la_size);
-            p.step_index[r] += (uint64_t)p.n_steps;
-            p.seed_draws[r] += (uint64_t)p.n_steps;
+            const int64_t steps_run = (int64_t)c.st[0];  // a move budget can end the launch before n_steps
+            p.la_idx[r] = (int32_t)((p.la_idx[r] + steps_run) % p.la_size);
+            p.step_index[r] += (uint64_t)steps_run;
+            p.seed_draws[r] += (uint64_t)steps_run;
         }
     }
     if (tid == 0) {

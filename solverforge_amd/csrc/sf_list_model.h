@@ -65,6 +65,7 @@ struct SearchParams {
     int32_t replica_base; // replica of block 0 (single-replica launches)
     int32_t n_launch;     // replicas covered by this launch (wave engine: grid rounding)
     int64_t n_steps;
+    int64_t move_budget;  // > 0: a replica stops after the step in which its candidates of THIS launch reach the budget
     uint64_t random_seed; // replica r uses random_seed + r
     // dry-run explicit context
     uint64_t dry_step_index, dry_step_seed;

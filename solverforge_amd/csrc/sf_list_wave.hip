@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
             wave_sync();
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
+            if (p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
         }
         PH(5)
     }
@@ -1046,8 +1047,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 m.best_score[(size_t)r * 4 + kk] = best_sol[kk];
             }
             p.la_idx[r] = la_cursor;
-            p.step_index[r] = step_index0 + (uint64_t)p.n_steps;
-            p.seed_draws[r] = seed_draws0 + (uint64_t)p.n_steps;
+            p.step_index[r] = step_index0 + (uint64_t)st_steps;  // steps actually run (a move budget can end the launch early)
+            p.seed_draws[r] = seed_draws0 + (uint64_t)st_steps;
             uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
             gs[0] += st_steps;
             gs[1] += st_gen;

@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
     const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
     int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
+    PH_DECL
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         uint64_t sidx, sseed;
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         const uint32_t u_str = nl > 1 ? ctx.random_stride((uint32_t)nl, SALT_UNION_STRIDE) : 1u;
         int32_t live_weight = nl;  // running weights of the smooth weighted round-robin live in the leaf table
 
+        PH(0)
         int done = 0;
         while (!done) {
             // ---- C1: fill every live leaf's ring (or until its stream ends).  A replay batch takes 64 pulls in whole
@@ -867,6 +869,9 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 }
                 lt.put_gen(l, g);
                 lt.set(l, LeafTab::TAIL, tl);
+#ifdef SF_PHASE_PROFILE
+                PH((kind == 128 || kind == 256) ? 2 : (kind == 64 ? 3 : (kind == 512 ? 4 : 1)))
+#endif
             }
             wave_sync();
 
@@ -979,6 +984,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 }
             }
 
+            PH(5)
             // ---- C3: trial score, acceptor, forager ----
             {
                 const bool valid = lane < nvalid;
@@ -1115,6 +1121,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 for (int l = 0; l < nl; ++l) lt.set(l, LeafTab::HEAD, lt.get(l, LeafTab::HEAD) + lt.get(l, LeafTab::TAKEN));
                 if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
             }
+            PH(6)
         }
 
         // ---- commit the forager's pick ----
@@ -1210,7 +1217,10 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
         }
+        PH(7)
+        if (!p.dry_run && p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
     }
+    PH_DUMP
 
     if (!p.dry_run) {
         if (annealing) sa_store(saw, p.sa, r, lane);
@@ -1229,8 +1239,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 g_best_score[kk] = best_sol[kk];
             }
             p.la_idx[r] = la_cursor;
-            p.step_index[r] = step_index0 + (uint64_t)p.n_steps;
-            p.seed_draws[r] = seed_draws0 + (uint64_t)p.n_steps;
+            p.step_index[r] = step_index0 + (uint64_t)st_steps;  // steps actually run (a move budget can end the launch early)
+            p.seed_draws[r] = seed_draws0 + (uint64_t)st_steps;
             uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
             gs[0] += st_steps;
             gs[1] += st_gen;

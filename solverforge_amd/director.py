@@ -241,6 +241,13 @@ class GpuScoreDirector:
         if sync:
             check(self._L.sf_sync(self._h), self._h)
 
+    def solve_moves(self, max_steps, move_budget, sync=True):
+        """Work-balanced launch: every replica runs whole steps until it has pulled `move_budget` candidates in this
+        launch (or `max_steps` steps).  `stats(r)["step_count"]` says how far replica r got."""
+        check(self._L.sf_solve_moves(self._h, max_steps, move_budget), self._h)
+        if sync:
+            check(self._L.sf_sync(self._h), self._h)
+
     def sync(self):
         check(self._L.sf_sync(self._h), self._h)
 

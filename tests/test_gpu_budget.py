@@ -1,0 +1,47 @@
+"""sf_solve_moves (work-balanced launches for wall-clock solves): per-replica parity with the CPU oracle."""
+import pytest
+
+import solverforge_amd as sfa
+from oracle import sfo
+from solverforge_amd import datasets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", [0, 1, 2])
+def test_move_budgeted_launch_matches_oracle_per_replica(engine):
+    """sf_solve_moves: replicas stop after different step counts (each once its own candidates reach the budget); every
+    replica is still exactly the oracle's state after the number of steps it reports, across two launches."""
+    p = datasets.make_cvrp(70, 7, 45, seed=6)
+    leaves = ("nearby_change", "nearby_swap") if engine else ("nearby_change", "nearby_swap", "sublist_change", "list_reverse", "kopt")
+    R = 6
+    d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves, max_nearby=8, kopt=(1, 4))
+    if engine:
+        d.set_engine(engine)
+    d.configure(sfa.SolverConfig(acceptor=1, late_acceptance_size=7, forager=0, accepted_count_limit=16, random_seed=11))
+    d.calculate_score()
+    d.phase_start()
+    bits = {"nearby_change": 16, "nearby_swap": 32, "sublist_change": 128, "list_reverse": 64, "kopt": 512}
+    oracles = []
+    for r in range(R):
+        o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+        o.set_kopt(1, 4)
+        o.configure(acceptor=1, la_size=7, forager=0, limit=16, leaves=sum(bits[x] for x in leaves), random_seed=11 + r, max_nearby=8)
+        o.phase_start()
+        oracles.append([o, 0])
+    seen = set()
+    for launch, budget in enumerate((400, 900)):
+        d.solve_moves(10_000, budget)
+        for r in range(R):
+            st = d.stats(r)
+            o, done = oracles[r]
+            o.steps(st["step_count"] - done)
+            oracles[r][1] = st["step_count"]
+            assert d.working_lists(0, r) == o.get_lists(0), (launch, r)
+            assert (d.calculate_score()[r] == o.score()[:2]).all(), (launch, r)
+            so = o.stats()
+            assert st["moves_evaluated"] == so["moves_evaluated"] and st["step_count"] == so["step_count"]
+            seen.add(st["step_count"])
+    # the launch ended on the budget, not on max_steps, and replicas got different distances
+    assert max(seen) < 10_000 and len(seen) > 1
+    with pytest.raises(sfa.SolverForgeError):
+        d.solve_moves(10, 0)

@@ -354,3 +354,4 @@ def test_single_level_score_model():
     assert (e1[:, 0] == e2[:, 1]).all() and (e1[:, 0] > s1[:, 0]).all()
     assert (d1.fresh_score() == e1).all()
     assert d1.working_lists(0, 1) == d2.working_lists(0, 1)
+
