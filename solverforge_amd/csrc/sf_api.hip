@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -28,6 +29,7 @@ struct Fact {
     void* d1 = nullptr;
     int rows = 0, cols = 0;
     int64_t max_finite = 0;
+    bool symmetric = false;  // matrices: data[i][j] == data[j][i] everywhere
 };
 struct ConstraintSpec {
     int kind, desc, var, fact;
@@ -243,6 +245,13 @@ int32_t sf_fact_matrix_i64(sf_ctx* ctx, int32_t id, int32_t rows, int32_t cols, 
     for (size_t i = 0; i < (size_t)rows * cols; ++i)
         if (data[i] >= 0 && data[i] != INT64_MAX && data[i] > mx) mx = data[i];
     f.max_finite = mx;
+    f.symmetric = rows == cols;
+    for (int32_t i = 0; i < rows && f.symmetric; ++i)
+        for (int32_t j = i + 1; j < cols; ++j)
+            if (data[(size_t)i * cols + j] != data[(size_t)j * cols + i]) {
+                f.symmetric = false;
+                break;
+            }
     int64_t* d = nullptr;
     int rc = upload(ctx, &d, data, (size_t)rows * cols);
     if (rc) return rc;
@@ -412,6 +421,8 @@ static int build_list_model(sf_ctx* ctx, int d) {
             HIPCHK(ctx, hipGetLastError());
             m.mat32 = m32;
         }
+    for (auto& kv : ctx->facts)
+        if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat) m.mat_symmetric = kv.second.symmetric ? 1 : 0;
     // presorted neighbour index for the wave engine: every matrix row sorted by (distance, node)
     bool nearby = false;
     for (auto& s : ctx->selectors)
@@ -496,6 +507,10 @@ static void fill_search_params(sf_ctx* ctx, SearchParams& p) {
     p.order = ctx->cfg.selection_order;
     p.random_seed = ctx->cfg.random_seed;
     p.dry_run = 0;
+    {  // diagnostics only (A/B measurements of the generic engine's trial evaluators)
+        static const bool legacy = std::getenv("SF_AMD_LEGACY_EVAL") != nullptr;
+        p.legacy_eval = legacy ? 1 : 0;
+    }
     p.replica_base = 0;
     p.explicit_seeds = ctx->d_explicit;
     p.n_explicit = ctx->n_explicit;

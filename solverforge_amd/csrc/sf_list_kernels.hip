@@ -490,6 +490,194 @@ __device__ __forceinline__ ListDelta eval_sublist_swap(const ListModel& m, const
     return r;
 }
 
+// One trial delta for every list move kind of the generic engine on a SYMMETRIC matrix (m.mat_symmetric, checked at
+// upload): every kind reduces to at most eight signed boundary legs — the legs inside a reversed segment cost the same
+// in both directions and cancel exactly in wrapping i64 arithmetic — so lanes of different kinds share ONE gather round
+// trip instead of running the five per-kind evaluators one after the other.  Results are bit-identical to
+// eval_list_move_legs / eval_list_reverse / eval_kopt / eval_sublist_change / eval_sublist_swap (parity tests run both).
+// kind = selector kind of the lane (4/16 change, 8/32 swap, 64 reverse, 128 sublist change, 256 sublist swap, 512 3-opt);
+// (m0, m1, mx) = the ring entry as the generic engine packs it.
+template <class VT>
+__device__ __forceinline__ ListDelta eval_list_unified(const ListModel& m, const VT* visits, const uint32_t* off,
+                                                       const int64_t* load, int kind, uint32_t m0, uint32_t m1, uint32_t mx) {
+    ListDelta r{0, 0, false};
+    const uint32_t depot = (uint32_t)m.depot;
+    const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu;
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    uint32_t f[8], t[8];
+    int32_t sg[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f[s] = 0, t[s] = 0, sg[s] = 0;
+    uint32_t b = a, PA = 0, zA = 0, PB = 0, zB = 0;  // capacity: flat ranges of the elements leaving list a / list b
+    auto at = [&](uint32_t flat) { return (uint32_t)visits[flat]; };
+    if (kind == 64) {  // reverse [i, e)
+        const uint32_t e = m1 & 0xFFFFu;
+        if (!(e > i + 1 && e <= la)) return r;
+        const uint32_t prev = i > 0 ? at(oa + i - 1) : depot, next = e < la ? at(oa + e) : depot;
+        const uint32_t first = at(oa + i), last = at(oa + e - 1);
+        f[0] = prev, t[0] = last, sg[0] = 1;
+        f[1] = first, t[1] = next, sg[1] = 1;
+        f[2] = prev, t[2] = first, sg[2] = -1;
+        f[3] = last, t[3] = next, sg[3] = -1;
+    } else if (kind == 512) {  // 3-opt: cuts c1 = i < c2 < c3, pattern mx
+        const uint32_t c1 = i, c2 = m1 >> 16, c3 = m1 & 0xFFFFu;
+        if (!(mx < 7 && c1 < c2 && c2 < c3 && c3 <= la)) return r;
+        const uint32_t prev = c1 > 0 ? at(oa + c1 - 1) : depot, next = c3 < la ? at(oa + c3) : depot;
+        const uint32_t bf = at(oa + c1), bl = at(oa + c2 - 1), cf = at(oa + c2), cl = at(oa + c3 - 1);
+        const uint32_t mask = kopt_reverse_mask(mx);
+        const bool rb = (mask >> 1) & 1u, rc = (mask >> 2) & 1u, sw = kopt_swaps_segments(mx);
+        const uint32_t Bf = rb ? bl : bf, Bl = rb ? bf : bl, Cf = rc ? cl : cf, Cl = rc ? cf : cl;
+        const uint32_t Xf = sw ? Cf : Bf, Xl = sw ? Cl : Bl, Yf = sw ? Bf : Cf, Yl = sw ? Bl : Cl;
+        f[0] = prev, t[0] = Xf, sg[0] = 1;
+        f[1] = Xl, t[1] = Yf, sg[1] = 1;
+        f[2] = Yl, t[2] = next, sg[2] = 1;
+        f[3] = prev, t[3] = bf, sg[3] = -1;
+        f[4] = bl, t[4] = cf, sg[4] = -1;
+        f[5] = cl, t[5] = next, sg[5] = -1;
+    } else {
+        b = m1 >> 16;
+        const uint32_t j = m1 & 0xFFFFu;
+        const uint32_t ob = off[b], lb = off[b + 1] - ob;
+        const bool intra = a == b;
+        if (kind == 128) {  // sublist change: [i, e) of a -> b at dp = j (post-removal coordinates when intra)
+            const uint32_t e = i + mx;
+            if (!(i < e && e <= la)) return r;
+            const uint32_t z = e - i;
+            if (j > (intra ? la - z : lb) || (intra && j == i)) return r;
+            const uint32_t first = at(oa + i), last = at(oa + e - 1);
+            const uint32_t prev = i > 0 ? at(oa + i - 1) : depot, next = e < la ? at(oa + e) : depot;
+            uint32_t pl, pr;
+            bool dst_empty = false;
+            if (!intra) {
+                pl = j > 0 ? at(ob + j - 1) : depot;
+                pr = j < lb ? at(ob + j) : depot;
+                dst_empty = lb == 0;
+            } else {
+                const uint32_t l2 = la - z;
+                pl = j > 0 ? at(oa + (j - 1 < i ? j - 1 : j - 1 + z)) : depot;
+                pr = j < l2 ? at(oa + (j < i ? j : j + z)) : depot;
+            }
+            f[0] = prev, t[0] = first, sg[0] = -1;
+            f[1] = last, t[1] = next, sg[1] = -1;
+            f[2] = prev, t[2] = next, sg[2] = la > z ? 1 : 0;
+            f[3] = pl, t[3] = first, sg[3] = 1;
+            f[4] = last, t[4] = pr, sg[4] = 1;
+            f[5] = pl, t[5] = pr, sg[5] = dst_empty ? 0 : -1;
+            PA = oa + i, zA = z;
+        } else if (kind == 256) {  // sublist swap: [fs, fe) of a <-> [ss, se) of b
+            uint32_t fs = i, fe = i + (mx & 15u), ss = j, se = j + (mx >> 4);
+            if (!(fs < fe && ss < se && fe <= la && se <= lb)) return r;
+            if (intra && fs < se && ss < fe) return r;
+            if (intra && ss < fs) {
+                uint32_t q = fs;
+                fs = ss, ss = q;
+                q = fe;
+                fe = se, se = q;
+            }
+            const uint32_t A0 = at(oa + fs), Al = at(oa + fe - 1), B0 = at(ob + ss), Bl = at(ob + se - 1);
+            const uint32_t pa = fs > 0 ? at(oa + fs - 1) : depot, nb = se < lb ? at(ob + se) : depot;
+            if (intra && fe == ss) {
+                f[0] = pa, t[0] = B0, sg[0] = 1;
+                f[1] = Bl, t[1] = A0, sg[1] = 1;
+                f[2] = Al, t[2] = nb, sg[2] = 1;
+                f[3] = pa, t[3] = A0, sg[3] = -1;
+                f[4] = Al, t[4] = B0, sg[4] = -1;
+                f[5] = Bl, t[5] = nb, sg[5] = -1;
+            } else {
+                const uint32_t na = fe < la ? at(oa + fe) : depot, pb = ss > 0 ? at(ob + ss - 1) : depot;
+                f[0] = pa, t[0] = B0, sg[0] = 1;
+                f[1] = Bl, t[1] = na, sg[1] = 1;
+                f[2] = pa, t[2] = A0, sg[2] = -1;
+                f[3] = Al, t[3] = na, sg[3] = -1;
+                f[4] = pb, t[4] = A0, sg[4] = 1;
+                f[5] = Al, t[5] = nb, sg[5] = 1;
+                f[6] = pb, t[6] = B0, sg[6] = -1;
+                f[7] = Bl, t[7] = nb, sg[7] = -1;
+            }
+            PA = oa + fs, zA = fe - fs, PB = ob + ss, zB = se - ss;
+        } else {  // list change / list swap (plain and nearby): same legs as eval_list_move_legs
+            const bool is_change = kind == 4 || kind == 16;
+            uint32_t ii = i, jj = j;
+            if (is_change) {
+                if (ii >= la || jj > lb || (intra && (jj == ii || jj == ii + 1))) return r;
+            } else {
+                if (ii >= la || jj >= lb || (intra && ii == jj)) return r;
+                if (intra && ii > jj) {
+                    const uint32_t q = ii;
+                    ii = jj, jj = q;
+                }
+            }
+            const uint32_t P = oa + ii, Q = ob + jj;
+            const uint32_t x = at(P);
+            const uint32_t pa = ii > 0 ? at(P - 1) : depot, na = ii + 1 < la ? at(P + 1) : depot;
+            const uint32_t vq = jj < lb ? at(Q) : depot;
+            const uint32_t pb = jj > 0 ? at(Q - 1) : depot, nb = jj + 1 < lb ? at(Q + 1) : depot;
+            if (!is_change && x == vq) return r;
+            if (is_change) {
+                f[0] = pa, t[0] = x, sg[0] = -1;
+                f[1] = x, t[1] = na, sg[1] = -1;
+                f[2] = pa, t[2] = na, sg[2] = la == 1 ? 0 : 1;
+                f[3] = pb, t[3] = x, sg[3] = 1;
+                f[4] = x, t[4] = vq, sg[4] = 1;
+                f[5] = pb, t[5] = vq, sg[5] = (!intra && lb == 0) ? 0 : -1;
+                PA = P, zA = 1;
+            } else if (intra && jj == ii + 1) {
+                f[0] = pa, t[0] = vq, sg[0] = 1;
+                f[1] = vq, t[1] = x, sg[1] = 1;
+                f[2] = x, t[2] = nb, sg[2] = 1;
+                f[3] = pa, t[3] = x, sg[3] = -1;
+                f[4] = x, t[4] = vq, sg[4] = -1;
+                f[5] = vq, t[5] = nb, sg[5] = -1;
+            } else {
+                f[0] = pa, t[0] = vq, sg[0] = 1;
+                f[1] = vq, t[1] = na, sg[1] = 1;
+                f[2] = pa, t[2] = x, sg[2] = -1;
+                f[3] = x, t[3] = na, sg[3] = -1;
+                f[4] = pb, t[4] = x, sg[4] = 1;
+                f[5] = x, t[5] = nb, sg[5] = 1;
+                f[6] = pb, t[6] = vq, sg[6] = -1;
+                f[7] = vq, t[7] = nb, sg[7] = -1;
+                PA = P, zA = 1, PB = Q, zB = 1;
+            }
+            if (!is_change && intra) zA = 0, zB = 0;
+        }
+    }
+    r.doable = true;
+    if (m.dist_level >= 0) {
+        int64_t acc = 0;
+        if (m.mat32) {
+            uint32_t v[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v[s] = m.mat32[f[s] * (uint32_t)m.dim + t[s]];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int64_t c = v[s] != 0xFFFFFFFFu ? (int64_t)v[s] : MAX_SAFE_LEG_COST;
+                acc = wadd(acc, (int64_t)((uint64_t)c * (uint64_t)(int64_t)sg[s]));
+            }
+        } else {
+            int64_t v[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v[s] = m.mat[(size_t)f[s] * (size_t)m.dim + t[s]];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int64_t c = (v[s] >= 0 && v[s] != UNREACHABLE) ? v[s] : MAX_SAFE_LEG_COST;
+                acc = wadd(acc, (int64_t)((uint64_t)c * (uint64_t)(int64_t)sg[s]));
+            }
+        }
+        r.d_dist = acc;
+    }
+    if (m.cap_level >= 0 && a != b) {
+        int64_t da = 0, db = 0;
+        for (uint32_t q = 0; q < zA; ++q) da = wadd(da, (int64_t)m.demand[at(PA + q)]);
+        for (uint32_t q = 0; q < zB; ++q) db = wadd(db, (int64_t)m.demand[at(PB + q)]);
+        const int64_t la0 = load[a], lb0 = load[b];
+        const int64_t before = wadd(over_cap(la0, m.capacity), over_cap(lb0, m.capacity));
+        const int64_t after = wadd(over_cap(wadd(wsub(la0, da), db), m.capacity), over_cap(wadd(wsub(lb0, db), da), m.capacity));
+        r.d_cap = wsub(after, before);
+    }
+    return r;
+}
+
 // Relocates the flat range [P, P+z) so that it starts where flat position Q was (Q <= P or Q >= P+z),
 // shifting the elements in between; `sync` separates the read and write halves of every chunk
 // (wave_sync for one wavefront on LDS, __syncthreads for a workgroup on global memory).

@@ -24,6 +24,7 @@ struct ListModel {
     // facts
     const int64_t* mat; // dim x dim row-major (MatrixDistanceMeter + distance constraint)
     const uint32_t* mat32;  // optional compact copy: finite legs < 2^32-1 as u32, 0xFFFFFFFF = not finite
+    int32_t mat_symmetric;  // mat[i][j] == mat[j][i] for every pair (checked on the host at upload)
     const int32_t* demand;
     const uint32_t* ne_keys;  // not-exists A-side keys (Customer.id)
     int32_t ne_n;
@@ -65,6 +66,7 @@ struct SearchParams {
     int32_t replica_base; // replica of block 0 (single-replica launches)
     int32_t n_launch;     // replicas covered by this launch (wave engine: grid rounding)
     int64_t n_steps;
+    int32_t legacy_eval;  // diagnostics / parity tests: force the per-kind trial evaluators of the generic engine
     int64_t move_budget;  // > 0: a replica stops after the step in which its candidates of THIS launch reach the budget
     uint64_t random_seed; // replica r uses random_seed + r
     // dry-run explicit context

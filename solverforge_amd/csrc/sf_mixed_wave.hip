@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
+    const bool unified_eval = has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval;
     const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
@@ -1005,7 +1006,11 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
                     } else {
-                        const ListDelta d = my_kind == 256
+                        ListDelta d;
+                        if (unified_eval)  // symmetric matrix: one shared gather for every kind
+                            d = eval_list_unified(lm, s_visits, s_off, s_load, my_kind, m0, m1, mx_);
+                        else
+                            d = my_kind == 256
                                                 ? eval_sublist_swap(lm, s_visits, s_off, s_load, m0 >> 16, m0 & 0xFFFFu, (m0 & 0xFFFFu) + (mx_ & 15u),
                                                                     m1 >> 16, m1 & 0xFFFFu, (m1 & 0xFFFFu) + (mx_ >> 4))
                                             : my_kind == 128
