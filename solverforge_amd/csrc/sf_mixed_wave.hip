@@ -132,6 +132,25 @@ struct LeafTab {
     }
 };
 
+// Lays consecutive groups onto the 64 lanes: lane k holds the size `cnt` of group k (groups in stream order); slot q = lane
+// belongs to the last group whose exclusive prefix is <= q.  Returns that group and the offset inside it; `total` = all
+// slots of the 64 groups (slots >= min(64, total) are not valid).  One DPP scan + a 6-step shuffle search: a generator
+// call emits up to 64 candidates across several short lists instead of one list's handful.
+__device__ __forceinline__ void map_slots_to_groups(uint32_t cnt, uint32_t lane, uint32_t& group, uint32_t& offset, uint32_t& total) {
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint32_t pre = incl - cnt;
+    total = (uint32_t)__shfl((int)incl, 63);
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t stepw = 32; stepw; stepw >>= 1) {
+        const uint32_t cand = lo + stepw;  // <= 63
+        const uint32_t pc = (uint32_t)__shfl((int)pre, (int)cand);
+        if (pc <= lane) lo = cand;
+    }
+    group = lo;
+    offset = lane - (uint32_t)__shfl((int)pre, (int)lo);
+}
+
 // workgroups of 4 waves: 2 resident workgroups per CU = 2 waves per SIMD (<= 256 VGPRs)
 #ifndef SF_MIXED_BLOCKS_PER_CU
 #define SF_MIXED_BLOCKS_PER_CU 2
@@ -595,26 +614,42 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 g.e = 0;
                             }
                         } else {
-                            if (g.d == g.a) {
-                                g.d += 1;
-                                g.e = 0;
-                            }
+                            // inter destinations: every other entity in leaf order, positions 0..=dlen.  Lane k looks at
+                            // destination rank g.d + k, the slots of up to 64 short lists are laid onto the lanes at once.
                             if (g.d >= (uint32_t)V) {
                                 segment_done = true;
                             } else {
-                                const uint32_t de = sb_ent(g.d);
-                                const uint32_t dlen = rlen(de);
-                                const uint32_t o = g.e + lane;
-                                if (o <= dlen) {
-                                    const uint32_t dp = ctx.selection_index(o, dlen + 1, SALT_SC_INTER ^ (uint64_t)ent ^ (uint64_t)de ^ (uint64_t)start);
+                                const uint32_t rk = g.d + lane;
+                                uint32_t de_k = 0, full_k = 0;
+                                if (rk < (uint32_t)V && rk != g.a) {
+                                    de_k = (uint32_t)(((uint64_t)sb_st + (uint64_t)rk * sb_sd) % (uint32_t)V);
+                                    full_k = s_off[de_k + 1] - s_off[de_k] + 1;
+                                }
+                                const uint32_t cnt_k = (lane == 0 && full_k) ? full_k - g.e : full_k;  // g.e < full of rank g.d
+                                uint32_t grp, o, total;
+                                map_slots_to_groups(cnt_k, lane, grp, o, total);
+                                const uint32_t de = (uint32_t)__shfl((int)de_k, (int)grp);
+                                const uint32_t slots = (uint32_t)__shfl((int)full_k, (int)grp);
+                                if (grp == 0) o += g.e;
+                                if (lane < total) {
+                                    const uint32_t dp = ctx.selection_index(o, slots, SALT_SC_INTER ^ (uint64_t)ent ^ (uint64_t)de ^ (uint64_t)start);
                                     keep = true;
                                     w0 = (ent << 16) | start;
                                     w1 = (de << 16) | dp;
                                 }
-                                g.e += 64;
-                                if (g.e > dlen) {
-                                    g.d += 1;
+                                if (total <= 64) {  // all 64 ranks consumed
+                                    g.d += 64;
                                     g.e = 0;
+                                } else {  // resume after lane 63's slot
+                                    const uint32_t lg = uni((uint32_t)__shfl((int)grp, 63)), lo_ = uni((uint32_t)__shfl((int)o, 63));
+                                    const uint32_t ls = uni((uint32_t)__shfl((int)slots, 63));
+                                    if (lo_ + 1 >= ls) {
+                                        g.d += lg + 1;
+                                        g.e = 0;
+                                    } else {
+                                        g.d += lg;
+                                        g.e = lo_ + 1;
+                                    }
                                 }
                             }
                         }
@@ -765,19 +800,40 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             g.done = 1;
                             break;
                         }
-                        const uint32_t start = ctx.selection_index(g.b, len, SALT_LR_START ^ (uint64_t)ent ^ ldesc);
-                        const uint32_t end_count = len > start + 1 ? len - (start + 1) : 0u;
-                        const uint32_t o = g.e + lane;
-                        if (o < end_count) {
+                        // lane k looks at start offset g.b + k of this entity; the (start, end) pairs of up to 64 starts are laid
+                        // onto the lanes at once (a short list's whole neighbourhood in one call)
+                        const uint32_t bo = g.b + lane;
+                        uint32_t start_k = 0, full_k = 0;
+                        if (bo < len) {
+                            start_k = ctx.selection_index(bo, len, SALT_LR_START ^ (uint64_t)ent ^ ldesc);
+                            full_k = len > start_k + 1 ? len - (start_k + 1) : 0u;
+                        }
+                        // g.e <= end_count of start offset g.b (== only when that count is 0)
+                        const uint32_t cnt_k = lane == 0 ? (full_k > g.e ? full_k - g.e : 0u) : full_k;
+                        uint32_t grp, o, total;
+                        map_slots_to_groups(cnt_k, lane, grp, o, total);
+                        const uint32_t start = (uint32_t)__shfl((int)start_k, (int)grp);
+                        const uint32_t end_count = (uint32_t)__shfl((int)full_k, (int)grp);
+                        if (grp == 0) o += g.e;
+                        if (lane < total) {
                             const uint32_t end = start + 2 + ctx.selection_index(o, end_count, SALT_LR_END ^ (uint64_t)ent ^ (uint64_t)start);
                             keep = true;
                             w0 = (ent << 16) | start;
                             w1 = (ent << 16) | end;
                         }
-                        g.e += 64;
-                        if (g.e >= end_count) {
-                            g.b += 1;
+                        if (total <= 64) {  // start offsets g.b .. g.b + 63 consumed
+                            g.b += 64;
                             g.e = 0;
+                        } else {
+                            const uint32_t lg = uni((uint32_t)__shfl((int)grp, 63)), lo_ = uni((uint32_t)__shfl((int)o, 63));
+                            const uint32_t lc = uni((uint32_t)__shfl((int)end_count, 63));
+                            if (lo_ + 1 >= lc) {
+                                g.b += lg + 1;
+                                g.e = 0;
+                            } else {
+                                g.b += lg;
+                                g.e = lo_ + 1;
+                            }
                         }
                     } else {  // ---- list swap (list_kernel/swap.rs) ----
                         uint32_t fe = 0, flen = 0;
