@@ -136,7 +136,8 @@ struct LeafTab {
 // belongs to the last group whose exclusive prefix is <= q.  Returns that group and the offset inside it; `total` = all
 // slots of the 64 groups (slots >= min(64, total) are not valid).  One DPP scan + a 6-step shuffle search: a generator
 // call emits up to 64 candidates across several short lists instead of one list's handful.
-__device__ __forceinline__ void map_slots_to_groups(uint32_t cnt, uint32_t lane, uint32_t& group, uint32_t& offset, uint32_t& total) {
+__device__ __forceinline__ void map_slots_to_groups(uint32_t cnt, uint32_t slot, uint32_t& group, uint32_t& offset, uint32_t& total) {
+    const uint32_t lane = slot;  // the caller's slot index (usually its lane id; lane / S when a slot spans S lanes)
     const uint32_t incl = wave_incl_scan(cnt);
     const uint32_t pre = incl - cnt;
     total = (uint32_t)__shfl((int)incl, 63);
@@ -545,30 +546,50 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             st_sources -= 1;
                             continue;
                         }
-                        const uint32_t sent = sw_ent(g.d);
-                        const uint32_t slen = rlen(sent);
-                        if (slen < mn || g.e >= slen) {
-                            g.d += 1;
-                            g.e = 0;
-                            st_sources -= 1;
-                            continue;
-                        }
-                        // lanes = (second start offset, size offset) pairs in cursor order
+                        // lanes = (second start, size offset) pairs in cursor order; lane group k looks at partner rank g.d + k, so
+                        // the 64 / S start slots of one call span several short partner lists
                         const uint32_t S = mx - mn + 1, per = 64u / S;
-                        const uint32_t sl = lane / S, q = lane % S;
-                        const uint32_t so = g.e + sl;
-                        if (sl < per && so < slen) {
+                        const uint32_t u = lane / S, q = lane % S;
+                        const uint32_t rk = g.d + lane;
+                        uint32_t sent_k = 0, slen_k = 0;
+                        if (rk < (uint32_t)V) {
+                            sent_k = (uint32_t)(((uint64_t)sw_st + (uint64_t)rk * sw_sd) % (uint32_t)V);
+                            slen_k = s_off[sent_k + 1] - s_off[sent_k];
+                            if (slen_k < mn) slen_k = 0;
+                        }
+                        const uint32_t cnt_k = lane == 0 ? (slen_k > g.e ? slen_k - g.e : 0u) : slen_k;
+                        uint32_t grp, so, total;
+                        map_slots_to_groups(cnt_k, u, grp, so, total);
+                        const uint32_t sent = (uint32_t)__shfl((int)sent_k, (int)grp);
+                        const uint32_t slen = (uint32_t)__shfl((int)slen_k, (int)grp);
+                        if (grp == 0) so += g.e;
+                        const uint32_t nslots = total < per ? total : per;
+                        if (u < nslots) {
                             const uint32_t sstart = ctx.selection_index(so, slen, SALT_SS_START ^ (uint64_t)sent ^ ldesc);
                             const uint32_t mv2 = mx < slen - sstart ? mx : slen - sstart;
                             if (mv2 >= mn && q < mv2 - mn + 1) {
                                 const uint32_t ssize = mn + ctx.selection_index(q, mv2 - mn + 1, SALT_SS_SIZE ^ (uint64_t)sent ^ (uint64_t)sstart);
-                                keep = !(g.d == g.a && (sstart < fend || (fstart == sstart && fend == sstart + ssize)));
+                                keep = !(g.d + grp == g.a && (sstart < fend || (fstart == sstart && fend == sstart + ssize)));
                                 w0 = (fent << 16) | fstart;
                                 w1 = (sent << 16) | sstart;
                                 wx = fsize | (ssize << 4);
                             }
                         }
-                        g.e += per;
+                        if (total <= per) {  // partner ranks g.d .. g.d + 63 consumed
+                            g.d += 64;
+                            g.e = 0;
+                        } else {  // resume after the last start slot of this call
+                            const int last_lane = (int)((per - 1) * S);
+                            const uint32_t lg = uni((uint32_t)__shfl((int)grp, last_lane)), lo_ = uni((uint32_t)__shfl((int)so, last_lane));
+                            const uint32_t ll = uni((uint32_t)__shfl((int)slen, last_lane));
+                            if (lo_ + 1 >= ll) {
+                                g.d += lg + 1;
+                                g.e = 0;
+                            } else {
+                                g.d += lg;
+                                g.e = lo_ + 1;
+                            }
+                        }
                     } else if (kind == 128) {  // ---- sublist change / Or-opt (list_kernel/sublist_change.rs:109-266) ----
                         const uint32_t mn = leaf_min, mx = leaf_max;
                         uint32_t ent = 0, len = 0, start = 0, sc = 0;
