@@ -28,16 +28,19 @@ constexpr uint64_t KOPT_POS_MIX = 0xBF58476D1CE4E5B9ULL;
 constexpr uint32_t KOPT_LDS_KEYS = 128;   // routes up to this length rank their distances in LDS, longer ones in HBM scratch
 constexpr uint32_t KOPT_MAX_NEARBY = 64;  // one wave pass per level
 constexpr uint32_t KOPT_TRIPLES = 9;      // cut sets per fill call: 9 x 7 patterns = 63 lanes
+constexpr uint32_t KOPT_FAST_LEN = 16;    // routes up to this length rank ALL origins once when the entity is opened
 
 // LDS working set of the distance-pruned stream (one per resident replica)
 struct KoptLds {
-    static constexpr size_t bytes = KOPT_LDS_KEYS * 8 + 64 * 2 + 64 * 2 + 3 * 64 * 2 + KOPT_TRIPLES * 4 * 2 + 8 + 24 * 4;
+    static constexpr size_t bytes = KOPT_LDS_KEYS * 8 + 64 * 2 + 64 * 2 + 3 * 64 * 2 + KOPT_TRIPLES * 4 * 2 + 8 + 24 * 4 + KOPT_FAST_LEN * KOPT_FAST_LEN;
     uint64_t* keys;    // [KOPT_LDS_KEYS] f64 bit patterns of the distances origin -> position
     uint16_t* sorted;  // [64] positions by rank
     uint16_t* vl;      // [64] range-filtered positions, rank order
     uint16_t* cache;   // [3][64] nearby_cache of the stack levels (level 0 is always empty)
     uint16_t* trip;    // [KOPT_TRIPLES][4] (entity, cut 1, cut 2, cut 3) of this fill call
     uint32_t* st;      // [24] machine state between calls
+    uint32_t* dist;    // [KOPT_FAST_LEN][KOPT_FAST_LEN] short routes: compact-matrix legs between the route's positions (aliases `keys`)
+    uint8_t* near;     // [KOPT_FAST_LEN][KOPT_FAST_LEN] short routes: positions by (distance, position) rank, per origin
     __device__ explicit KoptLds(unsigned char* base) {
         keys = (uint64_t*)base;
         sorted = (uint16_t*)(base + KOPT_LDS_KEYS * 8);
@@ -45,6 +48,8 @@ struct KoptLds {
         cache = vl + 64;
         trip = cache + 3 * 64;
         st = (uint32_t*)(base + KOPT_LDS_KEYS * 8 + 64 * 2 + 64 * 2 + 3 * 64 * 2 + KOPT_TRIPLES * 4 * 2 + 8);
+        dist = (uint32_t*)base;
+        near = (uint8_t*)(st + 24);
     }
 };
 
@@ -113,7 +118,7 @@ __device__ __forceinline__ uint64_t kopt_pattern_salt(uint64_t desc, uint32_t en
 // ---- distance-pruned cut state machine ---------------------------------------------------------------------------
 struct KoptS {
     uint32_t depth, p0, p1, p2, i0, i1, i2, n0, n1, n2;
-    uint32_t first_offset, fst, fsd, fcount, done, active, entity, len;
+    uint32_t first_offset, fst, fsd, fcount, done, active, entity, len, fast;
     __device__ __forceinline__ uint32_t pos(uint32_t t) const { return t == 0 ? p0 : (t == 1 ? p1 : p2); }
     __device__ __forceinline__ uint32_t idx(uint32_t t) const { return t == 0 ? i0 : (t == 1 ? i1 : i2); }
     __device__ __forceinline__ uint32_t cnt(uint32_t t) const { return t == 0 ? n0 : (t == 1 ? n1 : n2); }
@@ -140,12 +145,13 @@ __device__ __forceinline__ void kopt_load_state(const uint32_t* st, KoptS& s) {
     s.n0 = kopt_uni(st[7]), s.n1 = kopt_uni(st[8]), s.n2 = kopt_uni(st[9]);
     s.first_offset = kopt_uni(st[10]), s.fst = kopt_uni(st[11]), s.fsd = kopt_uni(st[12]), s.fcount = kopt_uni(st[13]);
     s.done = kopt_uni(st[14]), s.active = kopt_uni(st[15]), s.entity = kopt_uni(st[16]), s.len = kopt_uni(st[17]);
+    s.fast = kopt_uni(st[18]);
 }
 __device__ __forceinline__ void kopt_store_state(uint32_t* st, const KoptS& s, uint32_t lane) {
     if (lane == 0) {
         st[0] = s.depth, st[1] = s.p0, st[2] = s.p1, st[3] = s.p2, st[4] = s.i0, st[5] = s.i1, st[6] = s.i2;
         st[7] = s.n0, st[8] = s.n1, st[9] = s.n2, st[10] = s.first_offset, st[11] = s.fst, st[12] = s.fsd, st[13] = s.fcount;
-        st[14] = s.done, st[15] = s.active, st[16] = s.entity, st[17] = s.len;
+        st[14] = s.done, st[15] = s.active, st[16] = s.entity, st[17] = s.len, st[18] = s.fast;
     }
 }
 
@@ -170,6 +176,25 @@ __device__ __forceinline__ uint32_t kopt_first_position(const KoptEnv& e, const 
 __device__ __forceinline__ uint32_t kopt_build_level(const KoptEnv& e, const KoptS& s, uint32_t level, uint32_t origin,
                                                      uint32_t minp, uint32_t maxp) {
     const uint32_t base = e.off[s.entity], len = s.len, lane = e.lane;
+    if (s.fast) {  // the entity's rank table is already in LDS (kopt_rank_all_origins): no memory round trip per level
+        const uint32_t cnt = len - 1 < e.max_nearby ? len - 1 : e.max_nearby;
+        uint32_t mine = 0;
+        bool ok = false;
+        if (lane < cnt) {
+            mine = e.mem.near[origin * KOPT_FAST_LEN + lane];
+            ok = mine >= minp && mine <= maxp;
+        }
+        const uint64_t okm = __ballot(ok);
+        const uint32_t nv = (uint32_t)__popcll(okm);
+        if (ok) e.mem.vl[__builtin_amdgcn_mbcnt_hi((uint32_t)(okm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)okm, 0u))] = (uint16_t)mine;
+        kopt_sync();
+        if (lane < nv) {
+            const uint64_t salt2 = (SALT_KN_STATE ^ e.desc ^ (uint64_t)s.entity) ^ SALT_KN_LEVEL ^ ((uint64_t)origin * GOLDEN) ^ (uint64_t)level;
+            e.mem.cache[level * 64 + lane] = e.mem.vl[e.ctx.selection_index(lane, nv, salt2)];
+        }
+        kopt_sync();
+        return nv;
+    }
     // routes that do not fit the LDS key buffer rank through the replica's HBM scratch: device-scope
     // accesses, so the lanes of this wave see each other's keys through L2
     const bool glob = len > KOPT_LDS_KEYS;
@@ -288,6 +313,32 @@ __device__ __forceinline__ void kopt_advance(const KoptEnv& e, KoptS& s) {
     else
         s.done = 1;
 }
+// Short routes on a compact matrix: nearby_positions(origin) of EVERY origin of the entity in one pass -- one batched
+// gather of the len x len legs, then the stable (distance, position) rank of each (origin, position) pair -- so the
+// level builds of the depth-first generator read LDS only.  0xFFFFFFFF (not finite) orders last and ties by position,
+// exactly like the f64 INFINITY keys of the general path; finite legs < 2^32 compare like their f64 values.
+__device__ __forceinline__ void kopt_rank_all_origins(const KoptEnv& e, uint32_t entity, uint32_t len) {
+    const uint32_t base = e.off[entity], lane = e.lane;
+    const uint32_t dim = (uint32_t)e.lm->dim;
+    for (uint32_t idx = lane; idx < len * KOPT_FAST_LEN; idx += 64) {
+        const uint32_t o = idx / KOPT_FAST_LEN, p = idx % KOPT_FAST_LEN;
+        if (p < len) e.mem.dist[idx] = e.lm->mat32[(uint32_t)e.visits[base + o] * dim + (uint32_t)e.visits[base + p]];
+    }
+    kopt_sync();
+    for (uint32_t idx = lane; idx < len * KOPT_FAST_LEN; idx += 64) {
+        const uint32_t o = idx / KOPT_FAST_LEN, p = idx % KOPT_FAST_LEN;
+        if (p >= len || p == o) continue;
+        const uint32_t kp = e.mem.dist[idx];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < len; ++q) {
+            const uint32_t kq = e.mem.dist[o * KOPT_FAST_LEN + q];
+            rank += (q != o && (kq < kp || (kq == kp && q < p))) ? 1u : 0u;
+        }
+        if (rank < KOPT_FAST_LEN) e.mem.near[o * KOPT_FAST_LEN + rank] = (uint8_t)p;
+    }
+    kopt_sync();
+}
+
 // NearbyCutState::new (nearby_state.rs:70-111)
 __device__ __forceinline__ void kopt_open_entity(const KoptEnv& e, KoptS& s, uint32_t entity, uint32_t len) {
     s.entity = entity;
@@ -299,6 +350,7 @@ __device__ __forceinline__ void kopt_open_entity(const KoptEnv& e, KoptS& s, uin
     s.n0 = s.n1 = s.n2 = 0;
     s.i0 = s.i1 = s.i2 = 0;
     s.p0 = s.p1 = s.p2 = 0;
+    s.fast = 0;
     if (len < 4u * e.mseg) {
         s.done = 1;
         return;
@@ -310,6 +362,8 @@ __device__ __forceinline__ void kopt_open_entity(const KoptEnv& e, KoptS& s, uin
     s.fsd = kopt_uni(sd);
     s.set(0, kopt_first_position(e, s, 0), 0);
     s.depth = 1;
+    s.fast = (len <= KOPT_FAST_LEN && e.lm->mat32 != nullptr) ? 1u : 0u;
+    if (s.fast) kopt_rank_all_origins(e, entity, len);
 }
 // next_cuts (nearby_state.rs:221-240)
 __device__ __forceinline__ bool kopt_next_cuts(const KoptEnv& e, KoptS& s, uint32_t& c1, uint32_t& c2, uint32_t& c3) {
