@@ -281,7 +281,7 @@ def main():
         if args.solve_seconds > 0:
             t1 = time.perf_counter()
             while time.perf_counter() - t1 < args.solve_seconds:
-                d.solve_steps(args.ls_steps, sync=True)
+                d.solve_moves(1 << 20, 100_000, sync=True)  # work-balanced launches (sf_solve_moves)
             out["extra"]["solve_seconds"] = args.solve_seconds
             out["extra"]["best_score_after_solve"] = list(max(tuple(int(v) for v in s) for s in d.best_scores()))
             out["extra"]["moves_evaluated_total"] = d.total_stats()["moves_evaluated"]
