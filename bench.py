@@ -173,6 +173,11 @@ def main():
                 dist.broadcast(tu, src=0)
                 d.portfolio_init(tu.numpy(), rank, world)
                 box["result"] = d.portfolio_allgather_best()
+                try:  # the winner's routes on every rank: ncclBroadcast of the route CSR from the winning rank
+                    routes = d.portfolio_broadcast_best(int(box["result"][1]), int(box["result"][2]))
+                    box["winner_customers"] = sum(len(r) for r in routes)
+                except Exception as e:
+                    box["broadcast_error"] = f"{type(e).__name__}: {e}"
                 d.portfolio_destroy()
             except Exception as e:  # keep the bench alive; report the fallback honestly
                 box["error"] = f"{type(e).__name__}: {e}"
@@ -186,6 +191,10 @@ def main():
         if all_ranks_ok("result" in box):
             bs, wr, wrep = box["result"]
             winner = {"score": [int(v) for v in bs], "rank": int(wr), "replica": int(wrep)}
+            if "winner_customers" in box:
+                winner["routes_broadcast_customers"] = int(box["winner_customers"])
+            elif "broadcast_error" in box:
+                winner["routes_broadcast_error"] = box["broadcast_error"]
             exchange = "rccl-allgather (C ABI sf_portfolio_allgather_best)"
         else:
             why = box.get("error", "RCCL communicator not up before the deadline")

@@ -311,6 +311,10 @@ int32_t sf_portfolio_init(sf_ctx* ctx, const uint8_t* id128, int32_t rank, int32
 /* gathers every rank's best score over xGMI; all ranks get the same winner */
 int32_t sf_portfolio_allgather_best(sf_ctx* ctx, int64_t* out_best_score, int32_t* out_winner_rank,
                                     int32_t* out_winner_replica);
+/* ncclBroadcast of the winner's best list variable (offsets [n_owners + 1], values [offsets[n_owners]]) from
+ * (winner_rank, winner_replica) to every rank; out buffers sized like sf_download_list's */
+int32_t sf_portfolio_broadcast_best(sf_ctx* ctx, int32_t winner_rank, int32_t winner_replica, uint32_t* out_offsets,
+                                    uint32_t* out_values);
 int32_t sf_portfolio_destroy(sf_ctx* ctx);
 
 /* ---- candidate trace, wire format v3 (stats/candidate_trace.rs:15-60,718-812) ---------------

@@ -319,5 +319,13 @@ class GpuScoreDirector:
         check(self._L.sf_portfolio_allgather_best(self._h, ptr(best), C.byref(rank), C.byref(rep)), self._h)
         return best, rank.value, rep.value
 
+    def portfolio_broadcast_best(self, winner_rank, winner_replica, descriptor_index=0):
+        """The winner's best lists on every rank (ncclBroadcast of the route CSR from the winning rank)."""
+        n = self._entity_counts[descriptor_index]
+        off = np.zeros(n + 1, dtype=np.uint32)
+        vals = np.zeros(max(self._list_capacity[descriptor_index], 1), dtype=np.uint32)
+        check(self._L.sf_portfolio_broadcast_best(self._h, winner_rank, winner_replica, ptr(off), ptr(vals)), self._h)
+        return [list(map(int, vals[off[i]: off[i + 1]])) for i in range(n)]
+
     def portfolio_destroy(self):
         check(self._L.sf_portfolio_destroy(self._h), self._h)

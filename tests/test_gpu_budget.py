@@ -45,3 +45,27 @@ def test_move_budgeted_launch_matches_oracle_per_replica(engine):
     assert max(seen) < 10_000 and len(seen) > 1
     with pytest.raises(sfa.SolverForgeError):
         d.solve_moves(10, 0)
+
+
+@pytest.mark.gpu
+def test_portfolio_allgather_and_winner_broadcast_single_rank():
+    """RCCL communicator of world size 1 on the one GPU of the box: the all-gather names the best replica and the
+    ncclBroadcast of its route CSR returns exactly that replica's best solution."""
+    p = datasets.make_cvrp(50, 5, 45, seed=8)
+    d = sfa.build_cvrp(p, n_replicas=8)
+    d.configure(sfa.SolverConfig(random_seed=3))
+    d.calculate_score()
+    d.phase_start()
+    d.solve_steps(40)
+    d.portfolio_init(d.portfolio_unique_id(), 0, 1)
+    try:
+        best, wr, wrep = d.portfolio_allgather_best()
+        scores = [tuple(int(v) for v in s) for s in d.best_scores()]
+        assert wr == 0 and tuple(int(v) for v in best) == max(scores) == scores[wrep]
+        routes = d.portfolio_broadcast_best(wr, wrep)
+        assert routes == d.working_lists(0, wrep, best=True)
+        assert sorted(c for r in routes for c in r) == sorted(p["customers"])
+        with pytest.raises(sfa.SolverForgeError):
+            d.portfolio_broadcast_best(1, 0)  # rank outside the communicator
+    finally:
+        d.portfolio_destroy()
