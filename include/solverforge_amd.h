@@ -103,7 +103,13 @@ typedef enum sf_constraint_kind {
     /* for_each(E).filter(assigned).group_by(value, sum(fact_a)).penalize(weight * w(sum)) — grouped node +
      * sum collector, constraint/grouped/{state,scorer}.rs, stream/collector/sum.rs;
      * `fact_a` = i32 column summed per group, `param` < 0: w = sum^2, `param` >= 0: w = max(0, sum - param) */
-    SF_C_GROUPED_VALUE_SUM = 9
+    SF_C_GROUPED_VALUE_SUM = 9,
+    /* for_each(E).filter(assigned).group_by(load_balance(value, fact_a)).penalize(weight * unfairness) — the grouped
+     * node with the load_balance collector, stream/collector/load_balance.rs:100-226: unfairness =
+     * round(sqrt(sum(load^2) - (sum load)^2 / keys)) in f64, the one floating-point step of the scoring path
+     * (bit-identical: IEEE division, correctly rounded sqrt, round half away from zero).  `fact_a` = i32 metric
+     * column, every metric >= 1 (SF_ERR_UNSUPPORTED otherwise: the reference skips zero metrics) */
+    SF_C_LOAD_BALANCE_VALUE = 10
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {

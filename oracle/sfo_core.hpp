@@ -49,6 +49,7 @@ struct Score {
     int64_t soft() const { return v[1]; }
 };
 
+inline int64_t wrap_mul(int64_t a, int64_t b) { return (int64_t)((uint64_t)a * (uint64_t)b); }
 inline int64_t wrap_add(int64_t a, int64_t b) {
     return (int64_t)((uint64_t)a + (uint64_t)b);
 }

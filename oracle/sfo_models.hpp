@@ -272,6 +272,18 @@ inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_
     pairs->weight = [w_pair](const Solution&, size_t, size_t) { return Score::of(0, w_pair); };
     m->director.constraints.members.push_back(std::move(pairs));
 
+    if (cap == -2) {  // fairness instead of the per-bin load: group_by(load_balance(bin, size)).penalize(unfairness)
+        auto fair = std::make_unique<LoadBalanceConstraint>();
+        fair->name = "Bin fairness";
+        fair->impact = Impact::Penalty;
+        fair->source = ChangeSource::descriptor(0);
+        fair->count = [](const Solution& s) { return s.classes[0].n; };
+        fair->filter = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i] != NONE; };
+        fair->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+        fair->metric = [bf](const Solution&, size_t i) { return bf->size[i]; };
+        fair->weight = [](int64_t unfairness) { return Score::of(0, unfairness); };
+        m->director.constraints.members.push_back(std::move(fair));
+    }
     auto load = std::make_unique<GroupedConstraint>();
     load->name = "Bin load";
     load->impact = Impact::Penalty;
@@ -285,7 +297,7 @@ inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_
         int64_t over = wrap_sub(sum, cap);
         return Score::of(0, over > 0 ? over : 0);
     };
-    m->director.constraints.members.push_back(std::move(load));
+    if (cap != -2) m->director.constraints.members.push_back(std::move(load));
 
     m->has_scalar = true;
     m->scalar_slot.descriptor_index = 0;

@@ -14,6 +14,7 @@
 //   crates/solverforge-scoring/src/api/constraint_set/incremental.rs:339-407 (tuple fold)
 //   crates/solverforge-scoring/src/director/score_director/incremental.rs:141-218
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -840,6 +841,162 @@ struct GroupedConstraint : Constraint {
         entity_retractions.clear();
         changed_groups.clear();
         cached_scores.clear();
+    }
+};
+
+// ---- load_balance collector (stream/collector/load_balance.rs:100-226) -------------------------------------
+// Incremental squared deviation of the per-key loads: integral = sum(x^2), fraction numerator = -(sum x)^2, kept by
+// the reference's four-term update; unfairness = round(sqrt(fraction / n + integral)) in f64.
+struct LoadBalanceAccumulator {
+    std::unordered_map<int64_t, size_t> item_counts;
+    std::unordered_map<int64_t, int64_t> loads;
+    int64_t sum = 0;
+    int64_t squared_deviation_integral = 0;
+    int64_t squared_deviation_fraction_numerator = 0;
+
+    void update_squared_deviation(int64_t old_value, int64_t new_value) {  // :144-163
+        int64_t term1 = wrap_sub(wrap_mul(new_value, new_value), wrap_mul(old_value, old_value));
+        int64_t sum_others = wrap_mul(2, wrap_sub(sum, old_value));
+        int64_t new_sum = wrap_add(wrap_sub(sum, old_value), new_value);
+        int64_t sum_diff = wrap_sub(sum, new_sum);
+        int64_t term3 = wrap_sub(wrap_mul(new_sum, new_sum), wrap_mul(sum, sum));
+        int64_t term4 = wrap_mul(2, wrap_sub(wrap_mul(old_value, sum), wrap_mul(new_value, new_sum)));
+        int64_t fraction_delta = wrap_add(wrap_add(wrap_mul(sum_others, sum_diff), term3), term4);
+        squared_deviation_integral = wrap_add(squared_deviation_integral, term1);
+        squared_deviation_fraction_numerator = wrap_add(squared_deviation_fraction_numerator, fraction_delta);
+    }
+    void add_to_metric(int64_t key, int64_t diff) {  // :123-132
+        auto it = loads.find(key);
+        int64_t old_value = it == loads.end() ? 0 : it->second;
+        int64_t new_value = wrap_add(old_value, diff);
+        if (old_value != new_value) {
+            loads[key] = new_value;
+            update_squared_deviation(old_value, new_value);
+            sum = wrap_add(sum, diff);
+        }
+    }
+    void reset_metric(int64_t key) {  // :134-141
+        auto it = loads.find(key);
+        if (it == loads.end()) return;
+        int64_t old_value = it->second;
+        loads.erase(it);
+        if (old_value != 0) {
+            update_squared_deviation(old_value, 0);
+            sum = wrap_sub(sum, old_value);
+        }
+    }
+    int64_t unfairness() const {  // compute_unfairness :167-184 (f64::round = half away from zero = llround)
+        size_t n = item_counts.size();
+        if (n == 0) return 0;
+        double tmp = n == 1 ? (double)squared_deviation_fraction_numerator + (double)squared_deviation_integral
+                            : (double)squared_deviation_fraction_numerator / (double)n + (double)squared_deviation_integral;
+        if (!(tmp >= 0.0)) return 0;  // sqrt of a negative radicand is NaN and `NaN as i64` is 0 in Rust
+        return (int64_t)std::round(std::sqrt(tmp));
+    }
+    void accumulate(int64_t key, int64_t metric) {  // :192-201
+        if (metric == 0) return;
+        item_counts[key] += 1;
+        add_to_metric(key, metric);
+    }
+    void retract(int64_t key, int64_t metric) {  // :203-218
+        if (metric == 0) return;
+        auto it = item_counts.find(key);
+        if (it == item_counts.end() || it->second == 0) return;
+        it->second -= 1;
+        if (it->second == 0) {
+            item_counts.erase(it);
+            reset_metric(key);
+        } else {
+            add_to_metric(key, -metric);
+        }
+    }
+    void reset() {  // :228-234
+        item_counts.clear();
+        loads.clear();
+        sum = 0;
+        squared_deviation_integral = 0;
+        squared_deviation_fraction_numerator = 0;
+    }
+};
+
+// for_each(E).filter(f).group_by(load_balance(key, metric)).penalize(w(unfairness)): the grouped node
+// (constraint/grouped/state.rs:216-244, scorer.rs:89-152) with the unit group key and the load-balance accumulator.
+struct LoadBalanceConstraint : Constraint {
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Filter1 filter;
+    Key1 key;
+    Value1 metric;
+    std::function<Score(int64_t unfairness)> weight;
+
+    LoadBalanceAccumulator acc;
+    size_t group_count = 0;  // entities in the (single) group: an empty group scores zero (scorer.rs:89-101)
+    std::unordered_map<size_t, std::pair<int64_t, int64_t>> entity_retractions;
+    Score cached;
+
+    Score current() const { return group_count == 0 ? Score::zero() : apply_impact(impact, weight(acc.unfairness())); }
+    Score refresh() {
+        Score sc = current();
+        Score d = sc - cached;
+        cached = sc;
+        return d;
+    }
+    Score evaluate(const Solution& s) const override {
+        LoadBalanceAccumulator a;
+        size_t n = count(s), members = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) {
+                a.accumulate(key(s, i), metric(s, i));
+                ++members;
+            }
+        return members == 0 ? Score::zero() : apply_impact(impact, weight(a.unfairness()));
+    }
+    size_t match_count(const Solution& s) const override {
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) return 1;  // one group
+        return 0;
+    }
+    Score initialize(const Solution& s) override {
+        reset();
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) {
+                int64_t k = key(s, i), m = metric(s, i);
+                acc.accumulate(k, m);
+                entity_retractions[i] = {k, m};
+                ++group_count;
+            }
+        cached = current();
+        return cached;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        if (e < count(s) && filter(s, e)) {
+            int64_t k = key(s, e), m = metric(s, e);
+            acc.accumulate(k, m);
+            entity_retractions[e] = {k, m};
+            ++group_count;
+        }
+        return refresh();
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {
+        (void)s;
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        auto it = entity_retractions.find(e);
+        if (it != entity_retractions.end()) {
+            acc.retract(it->second.first, it->second.second);
+            entity_retractions.erase(it);
+            group_count = group_count > 0 ? group_count - 1 : 0;
+        }
+        return refresh();
+    }
+    void reset() override {
+        acc.reset();
+        group_count = 0;
+        entity_retractions.clear();
+        cached = Score::zero();
     }
 };
 

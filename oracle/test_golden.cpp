@@ -302,6 +302,54 @@ static GroupedConstraint workload(Impact impact, GroupWeight w) {  // grouped.rs
     return c;
 }
 
+// stream/collector/tests/collector.rs:142-260 (the six load_balance tests)
+static void load_balance_cases() {
+    {  // test_perfectly_balanced
+        LoadBalanceAccumulator a;
+        a.accumulate(0, 1), a.accumulate(1, 1);
+        CHECK("load_balance.perfectly_balanced", a.unfairness() == 0);
+    }
+    {  // test_unbalanced: loads [2, 1] -> sqrt(0.5) rounds to 1; test_retract: back to balanced
+        LoadBalanceAccumulator a;
+        a.accumulate(0, 1), a.accumulate(0, 1), a.accumulate(1, 1);
+        CHECK("load_balance.unbalanced", a.unfairness() == 1);
+        a.retract(0, 1);
+        CHECK("load_balance.retract", a.unfairness() == 0);
+    }
+    {  // test_empty, test_single_item
+        LoadBalanceAccumulator a;
+        CHECK("load_balance.empty", a.unfairness() == 0);
+        a.accumulate(0, 1), a.accumulate(0, 1), a.accumulate(0, 1);
+        CHECK("load_balance.single_item", a.loads[0] == 3 && a.unfairness() == 0);
+    }
+    {  // test_load_balance_standard_deviation: A=2; +B=1 -> 1; +B -> 0; -B -> 1; -B -> 0; -A -> 0
+        LoadBalanceAccumulator a;
+        bool ok = a.unfairness() == 0;
+        a.accumulate(100, 2);
+        ok = ok && a.unfairness() == 0;
+        a.accumulate(200, 1);
+        ok = ok && a.unfairness() == 1;
+        a.accumulate(200, 1);
+        ok = ok && a.unfairness() == 0;
+        a.retract(200, 1);
+        ok = ok && a.unfairness() == 1;
+        a.retract(200, 1);
+        ok = ok && a.unfairness() == 0 && a.item_counts.size() == 1;
+        a.retract(100, 2);
+        ok = ok && a.unfairness() == 0 && a.item_counts.empty() && a.sum == 0 && a.squared_deviation_integral == 0 &&
+             a.squared_deviation_fraction_numerator == 0;
+        CHECK("load_balance.standard_deviation", ok);
+    }
+    {  // zero metrics are skipped (load_balance.rs:194-196); the closed form integral = sum x^2, fraction = -(sum x)^2
+        LoadBalanceAccumulator a;
+        a.accumulate(7, 0);
+        bool ok = a.item_counts.empty();
+        a.accumulate(1, 5), a.accumulate(2, 3), a.accumulate(3, 9), a.accumulate(2, 4);
+        ok = ok && a.squared_deviation_integral == 25 + 49 + 81 && a.squared_deviation_fraction_numerator == -(21 * 21) && a.sum == 21;
+        CHECK("load_balance.closed_form", ok);
+    }
+}
+
 static void grouped_cases() {
     {  // grouped.rs:26-58 evaluate: counts 3,1 with weight count^2 -> -10
         auto c = workload(Impact::Penalty, [](int64_t, int64_t n) { return soft(n * n); });
@@ -629,6 +677,7 @@ int main() {
     cross_bi_cases();
     exists_cases();
     grouped_cases();
+    load_balance_cases();
     director_case();
     std::printf("%s %d failures\n", failures ? "FAILED" : "PASSED", failures);
     return failures;

@@ -18,7 +18,7 @@ def t6(m):
 
 def run_case(seed):
     rng = np.random.default_rng(seed)
-    model = ["cvrp", "cvrp", "graph", "jobshop"][int(rng.integers(4))]
+    model = ["cvrp", "cvrp", "graph", "jobshop", "balance"][int(rng.integers(5))]
     acceptor = int(rng.choice([0, 1, 1, 3]))
     forager = int(rng.choice([0, 0, 1, 2]))
     limit = int(rng.choice([1, 2, 7, 40, 256]))
@@ -66,6 +66,17 @@ def run_case(seed):
         desc.update(n=n, e=e, k=k, leaves=leaves)
         d = sfa.build_graph_coloring(g, leaves=leaves)
         o = sfo.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+        lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
+    elif model == "balance":  # keyed self-join + grouped sum / excess-over-cap / load_balance collector
+        n = int(rng.integers(4, 120)); k = int(rng.integers(2, 12)); cap = int(rng.choice([-1, 25, -2, -2]))
+        r = datasets.stream(seed + 3, 2 * n)
+        bins = (r[:n] % np.uint64(k + 1)).astype(np.int64) - 1
+        sizes = (r[n:] % np.uint64(int(rng.choice([9, 1000, 1_000_000])))).astype(np.int64) + 1
+        wp = int(rng.choice([0, 3]))
+        leaves = [("change",), ("swap",), ("change", "swap")][int(rng.integers(3))]
+        desc.update(n=n, k=k, cap=cap, leaves=leaves)
+        d = sfa.build_balance(bins, sizes, k, w_pair=wp, cap=cap, leaves=leaves)
+        o = sfo.Model.balance(k, bins, sizes, w_pair=wp, cap=cap)
         lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
     else:
         nj = int(rng.integers(2, 9)); nm = int(rng.integers(2, 6))

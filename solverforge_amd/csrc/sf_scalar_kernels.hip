@@ -45,6 +45,7 @@ struct ScalarModel {
     // value-keyed aggregates (per-value count / sum tables, maintained at apply):
     int32_t sj_level = -1, grp_level = -1;  // keyed self-join pairs; grouped sum
     int64_t sj_weight = 0, grp_weight = 0, grp_cap = -1;
+    int32_t grp_mode = 0;  // 0: sum of per-group weights (grouped node + sum collector); 1: load_balance collector (unfairness)
     const int32_t* size = nullptr;     // [n] summed fact of the grouped constraint
     // per-replica committed state
     int32_t* vals = nullptr;        // [R][n]  (-1 = None)
@@ -111,13 +112,43 @@ __device__ __forceinline__ int64_t group_weight(const ScalarModel& m, int64_t su
     return over > 0 ? over : 0;
 }
 
+// load_balance collector (stream/collector/load_balance.rs:167-184): unfairness = round(sqrt(fraction / n + integral)) with
+// integral = sum of squared loads, fraction numerator = -(sum of loads)^2 (what the reference's incremental update
+// maintains), n = keys holding at least one item; the same f64 operations in the same order (IEEE division, correctly
+// rounded sqrt, round half away from zero); a NaN (negative radicand from rounding) casts to 0 like Rust's `as i64`.
+__device__ __forceinline__ int64_t lb_unfairness(int64_t s1, int64_t s2, uint32_t nk) {
+    if (nk == 0) return 0;
+    const double frac = (double)(int64_t)(0ull - (uint64_t)s1 * (uint64_t)s1);
+    const double tmp = nk == 1 ? frac + (double)s2 : frac / (double)nk + (double)s2;
+    if (!(tmp >= 0.0)) return 0;
+    return (int64_t)round(sqrt(tmp));
+}
+// one key's load x -> x + d inside (S1, S2)
+__device__ __forceinline__ void lb_shift(int64_t& s1, int64_t& s2, int64_t x, int64_t d) {
+    const int64_t y = wadd(x, d);
+    s2 = wadd(wsub(s2, (int64_t)((uint64_t)x * (uint64_t)x)), (int64_t)((uint64_t)y * (uint64_t)y));
+    s1 = wadd(s1, d);
+}
+// (S1, S2, keys, unfairness) of a per-value table pair, serially (cold paths: evaluate / apply kernels)
+__device__ __forceinline__ void lb_from_tables(const ScalarModel& m, const uint32_t* cnt, const int64_t* sum, int64_t* lb) {
+    int64_t s1 = 0, s2 = 0;
+    uint32_t nk = 0;
+    for (int v = 0; v < m.n_values; ++v)
+        if (cnt[v]) {
+            s1 = wadd(s1, sum[v]);
+            s2 = wadd(s2, (int64_t)((uint64_t)sum[v] * (uint64_t)sum[v]));
+            nk += 1;
+        }
+    lb[0] = s1, lb[1] = s2, lb[2] = (int64_t)nk, lb[3] = lb_unfairness(s1, s2, nk);
+}
+
 // kind 0: Change(a -> value); kind 1: Swap(a, b)
 // `cnt` / `sum`: per-value entity count and summed size of the step snapshot (null when the model has
 // no value-keyed constraint)
 template <class VT>
 __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, const VT* vals, int kind, uint32_t a,
                                                         uint32_t b, int32_t value, const uint32_t* cnt = nullptr,
-                                                        const int64_t* sum = nullptr) {
+                                                        const int64_t* sum = nullptr, const int64_t* lb = nullptr) {
     ScalarDelta r{0, 0, 0, 0, false};
     if (kind == 0) {  // apply.rs:15-24,219-230
         if (a >= (uint32_t)m.n || value >= m.n_values || value < -1) return r;
@@ -129,7 +160,20 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflict_delta(m, vals, a, value, old, 0xFFFFFFFFu);
         if (m.sj_level >= 0) r.d_pairs = (value >= 0 ? (int64_t)cnt[value] : 0) - (old >= 0 ? (int64_t)cnt[old] - 1 : 0);
-        if (m.grp_level >= 0) {
+        if (m.grp_level >= 0 && m.grp_mode == 1) {  // load balance: metrics are >= 1 (validated at sf_constraint_add)
+            const int64_t sz = (int64_t)m.size[a];
+            int64_t s1 = lb[0], s2 = lb[1];
+            uint32_t nk = (uint32_t)lb[2];
+            if (old >= 0) {
+                lb_shift(s1, s2, sum[old], -sz);
+                nk -= cnt[old] == 1 ? 1u : 0u;
+            }
+            if (value >= 0) {
+                lb_shift(s1, s2, sum[value], sz);
+                nk += cnt[value] == 0 ? 1u : 0u;
+            }
+            r.d_grp = wsub(lb_unfairness(s1, s2, nk), lb[3]);
+        } else if (m.grp_level >= 0) {
             const int64_t sz = (int64_t)m.size[a];
             int64_t d = 0;
             if (old >= 0) d = wsub(group_weight(m, wsub(sum[old], sz), cnt[old] - 1), group_weight(m, sum[old], cnt[old]));
@@ -144,7 +188,15 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflict_delta(m, vals, a, vb, va, b) + scalar_conflict_delta(m, vals, b, va, vb, a);
         // a swap exchanges two members: per-value counts (and so the same-value pairs) do not change
-        if (m.grp_level >= 0) {
+        if (m.grp_level >= 0 && m.grp_mode == 1) {  // a swap exchanges two members: key counts stay, loads shift
+            const int64_t sa = (int64_t)m.size[a], sb = (int64_t)m.size[b];
+            int64_t s1 = lb[0], s2 = lb[1];
+            uint32_t nk = (uint32_t)lb[2];
+            // entity b joins va (unless a was unassigned: then b becomes unassigned) and entity a joins vb
+            if (va >= 0) lb_shift(s1, s2, sum[va], wsub(sb, sa));
+            if (vb >= 0) lb_shift(s1, s2, sum[vb], wsub(sa, sb));
+            r.d_grp = wsub(lb_unfairness(s1, s2, nk), lb[3]);
+        } else if (m.grp_level >= 0) {
             const int64_t sa = (int64_t)m.size[a], sb = (int64_t)m.size[b];
             int64_t d = 0;
             if (va >= 0) d = wsub(group_weight(m, wadd(wsub(sum[va], sa), sb), cnt[va]), group_weight(m, sum[va], cnt[va]));
@@ -237,12 +289,21 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
             const unsigned long long c = t_cnt[v];
             pairs += c * (c - (c ? 1 : 0)) / 2;
-            grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
+            if (m.grp_mode == 0) grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
             groups += c ? 1 : 0;
         }
         atomicAdd(&s_pairs, pairs);
         atomicAdd(&s_grp, grp);
         atomicAdd(&s_groups, groups);
+        if (m.grp_level >= 0 && m.grp_mode == 1) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int64_t lb[4];
+                lb_from_tables(m, t_cnt, t_sum, lb);
+                s_grp = (unsigned long long)lb[3];
+                s_groups = lb[2] ? 1 : 0;  // one group (the unit key) when any entity is in it
+            }
+        }
     }
     unsigned long long un = 0, cross = 0;
     for (uint32_t e = threadIdx.x; e < (uint32_t)m.n; e += blockDim.x) {
@@ -309,6 +370,11 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, in
         scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
         __syncthreads();
     }
+    __shared__ int64_t s_lb[4];
+    if (m.grp_level >= 0 && m.grp_mode == 1) {
+        if (threadIdx.x == 0) lb_from_tables(m, t_cnt, t_sum, s_lb);
+        __syncthreads();
+    }
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     if (skip_foreign && moves[t * 6] != 0 && moves[t * 6] != 1) return;  // a list move of a mixed model
@@ -316,9 +382,9 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, in
     const int32_t* mv = moves + t * 6;
     ScalarDelta d{0, 0, 0, 0, false};
     if (mv[0] == 0 && mv[1] >= 0)
-        d = eval_scalar_move(m, vals, 0, (uint32_t)mv[1], 0u, mv[5], t_cnt, t_sum);
+        d = eval_scalar_move(m, vals, 0, (uint32_t)mv[1], 0u, mv[5], t_cnt, t_sum, s_lb);
     else if (mv[0] == 1 && mv[1] >= 0 && mv[3] >= 0)
-        d = eval_scalar_move(m, vals, 1, (uint32_t)mv[1], (uint32_t)mv[3], 0, t_cnt, t_sum);
+        d = eval_scalar_move(m, vals, 1, (uint32_t)mv[1], (uint32_t)mv[3], 0, t_cnt, t_sum, s_lb);
     out_doable[t] = d.doable ? 1 : 0;
     const ScoreV<4> s = apply_scalar_delta<4>(m, cur, d);
     for (int k = 0; k < m.levels; ++k) out_scores[t * m.levels + k] = d.doable ? s.v[k] : 0;
@@ -342,7 +408,9 @@ __global__ __launch_bounds__(64) void k_scalar_apply(ScalarModel m, int replica,
     }
     if (threadIdx.x != 0) return;
     int64_t* cur = m.score + (size_t)replica * 4;
-    const ScalarDelta d = eval_scalar_move(m, vals, kind, (uint32_t)a, (uint32_t)b, value, t_cnt, t_sum);
+    int64_t lb[4] = {0, 0, 0, 0};
+    if (m.grp_level >= 0 && m.grp_mode == 1) lb_from_tables(m, t_cnt, t_sum, lb);
+    const ScalarDelta d = eval_scalar_move(m, vals, kind, (uint32_t)a, (uint32_t)b, value, t_cnt, t_sum, lb);
     if (!d.doable) {
         *out_ok = 0;
         return;
@@ -456,6 +524,26 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     uint32_t prev_pulls = 64, prev_accepted = 1;
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
+        // load-balance aggregates of the step snapshot (the tables change only at commit): every lane gets the totals
+        int64_t lbv[4] = {0, 0, 0, 0};
+        if (m.grp_level >= 0 && m.grp_mode == 1) {
+            int64_t s1 = 0, s2 = 0;
+            uint32_t nk = 0;
+            for (uint32_t v = lane; v < (uint32_t)m.n_values; v += 64)
+                if (t_cnt[v]) {
+                    const int64_t x = t_sum[v];
+                    s1 = wadd(s1, x);
+                    s2 = wadd(s2, (int64_t)((uint64_t)x * (uint64_t)x));
+                    nk += 1;
+                }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) {
+                s1 = wadd(s1, (int64_t)shfl_u64((uint64_t)s1, (int)(lane ^ (uint32_t)o)));
+                s2 = wadd(s2, (int64_t)shfl_u64((uint64_t)s2, (int)(lane ^ (uint32_t)o)));
+                nk += (uint32_t)__shfl((int)nk, (int)(lane ^ (uint32_t)o));
+            }
+            lbv[0] = s1, lbv[1] = s2, lbv[2] = (int64_t)nk, lbv[3] = lb_unfairness(s1, s2, nk);
+        }
         uint64_t sidx, sseed;
         if (p.dry_run) {
             sidx = p.dry_step_index;
@@ -659,8 +747,8 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                     const uint32_t* rq = ring + ((size_t)lf * SRC + qi) * 2;
                     m0 = rq[0];
                     m1 = rq[1];
-                    dl = lane_change ? eval_scalar_move(m, s_vals, 0, m0, 0u, (int32_t)m1, t_cnt, t_sum)
-                                     : eval_scalar_move(m, s_vals, 1, m0, m1, 0, t_cnt, t_sum);
+                    dl = lane_change ? eval_scalar_move(m, s_vals, 0, m0, 0u, (int32_t)m1, t_cnt, t_sum, lbv)
+                                     : eval_scalar_move(m, s_vals, 1, m0, m1, 0, t_cnt, t_sum, lbv);
                 }
                 const ScoreV<L> sc = apply_scalar_delta<L>(m, cur, dl);
                 ScoreV<L> curv;

@@ -44,7 +44,7 @@ class Engine:  # sf_engine_kind
 class ConstraintKind:
     UNI_UNASSIGNED, CROSS_ADJACENT_EQUAL, CROSS_GROUP_EQUAL, CROSS_QUEENS = 1, 2, 3, 4
     NOT_EXISTS_FLATTENED, ROUTE_CAPACITY, ROUTE_DISTANCE = 5, 6, 7
-    SELFJOIN_VALUE_EQUAL, GROUPED_VALUE_SUM = 8, 9
+    SELFJOIN_VALUE_EQUAL, GROUPED_VALUE_SUM, LOAD_BALANCE_VALUE = 8, 9, 10
 
 
 class SelectorKind:

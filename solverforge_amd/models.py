@@ -131,7 +131,9 @@ def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=
     """Bin balance: the keyed self-join (pairs of entities sharing a bin — IncrementalBiConstraint,
     constraint/nary_incremental/bi.rs:12-313) and the grouped sum (group_by(bin, sum(size)) with
     weight(sum) — constraint/grouped/{state,scorer}.rs) on one scalar variable.  HardSoftScore:
-    hard = unassigned entities, soft = w_pair per same-bin pair + sum^2 (cap < 0) or excess over cap."""
+    hard = unassigned entities, soft = w_pair per same-bin pair + sum^2 (cap == -1) or excess over cap (cap >= 0);
+    cap == -2 replaces the per-bin load by FAIRNESS: group_by(load_balance(bin, size)).penalize(unfairness)
+    (stream/collector/load_balance.rs), sizes >= 1."""
     import numpy as np
 
     d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
@@ -141,7 +143,10 @@ def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=
     d.add_fact_column_i32(FACT_COLUMN, np.asarray(sizes, dtype=np.int32))
     d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
     d.add_constraint(ConstraintKind.SELFJOIN_VALUE_EQUAL, 0, level=1, weight=w_pair)
-    d.add_constraint(ConstraintKind.GROUPED_VALUE_SUM, 0, fact=FACT_COLUMN, param=cap, level=1, weight=1)
+    if cap == -2:
+        d.add_constraint(ConstraintKind.LOAD_BALANCE_VALUE, 0, fact=FACT_COLUMN, level=1, weight=1)
+    else:
+        d.add_constraint(ConstraintKind.GROUPED_VALUE_SUM, 0, fact=FACT_COLUMN, param=cap, level=1, weight=1)
     if "change" in leaves:
         d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
     if "swap" in leaves:

@@ -187,10 +187,11 @@ def _balance(n=80, k=7, seed=11):
     return bins, sizes, k
 
 
-@pytest.mark.parametrize("cap", [-1, 25])
+@pytest.mark.parametrize("cap", [-1, 25, -2])
 def test_keyed_selfjoin_and_grouped_sum(oracle, cap):
     """Value-keyed aggregates: pairs sharing a bin (keyed self-join bi node) and group_by(bin,
-    sum(size)) with sum^2 / excess-over-cap weights (grouped node + sum collector): full scores, the
+    sum(size)) with sum^2 / excess-over-cap weights (grouped node + sum collector), or (cap = -2) the load_balance
+    collector's unfairness = round(sqrt(sum x^2 - (sum x)^2 / keys)) — the f64 step of the scoring path: full scores, the
     whole candidate stream with trial scores, committed moves, traced steps and a fused solve."""
     import solverforge_amd as sfa
 
@@ -271,7 +272,7 @@ def test_evaluate_each_matches_oracle_per_constraint(oracle):
     n, nb = 60, 7
     bins = (datasets.stream(11, n) % np.uint64(nb + 1)).astype(np.int64) - 1
     sizes = (datasets.stream(12, n) % np.uint64(9)).astype(np.int64) + 1
-    for cap in (-1, 20):
+    for cap in (-1, 20, -2):
         d = sfa.build_balance(bins, sizes, nb, w_pair=3, cap=cap)
         o = oracle.Model.balance(nb, bins, sizes, 3, cap)
         o.configure(leaves=oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP, random_seed=4)
@@ -300,3 +301,44 @@ def test_evaluate_each_matches_oracle_per_constraint(oracle):
     o.configure(leaves=4 | 8 | 1 | 2, random_seed=6)
     d.configure(sfa.SolverConfig(random_seed=6))
     check(d, o, 3)
+
+
+def test_load_balance_large_metrics_and_validation(oracle):
+    """load_balance collector with metrics up to 10^6 (radicands ~10^13: the f64 division / sqrt / round must agree bit
+    for bit with the CPU), bins emptying and filling (key count changes), multi-replica fused solve; zero metrics are
+    refused (the reference skips them, the device's shared count table cannot)."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    n, k = 120, 9
+    r = datasets.stream(21, 2 * n)
+    bins = (r[:n] % np.uint64(k + 1)).astype(np.int64) - 1
+    bins[bins == 4] = -1  # bin 4 starts empty
+    sizes = (r[n:] % np.uint64(1_000_000)).astype(np.int64) + 1
+    d = sfa.build_balance(bins, sizes, k, n_replicas=3, w_pair=0, cap=-2)
+    bits = oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
+    d.configure(sfa.SolverConfig(random_seed=8, late_acceptance_size=5, accepted_count_limit=30))
+    assert (d.calculate_score() == d.fresh_score()).all()
+    os_ = []
+    for rep in range(3):
+        o = oracle.Model.balance(k, bins, sizes, w_pair=0, cap=-2)
+        o.configure(leaves=bits, random_seed=8 + rep, la_size=5, limit=30)
+        o.phase_start()
+        os_.append(o)
+    assert (d.calculate_score()[0] == os_[0].score()[:2]).all()
+    om = os_[0].enumerate(0, 1, 5, 3)
+    ref, od = os_[0].evaluate_moves(om)
+    es, ed = d.evaluate_moves(om)
+    assert (ed == od).all() and (es == ref[:, :2]).all()
+    d.phase_start()
+    for chunk in range(4):
+        d.solve_steps(50)
+        for rep, o in enumerate(os_):
+            o.steps(50)
+            assert (d.working_values(0, 0, replica=rep) == o.get_vars(0, 0)).all(), (chunk, rep)
+            assert (d.calculate_score()[rep] == o.score()[:2]).all(), (chunk, rep)
+        assert (d.fresh_score() == d.calculate_score()).all()
+    sizes0 = sizes.copy()
+    sizes0[3] = 0
+    with pytest.raises(sfa.SolverForgeError, match="metrics must be >= 1"):
+        sfa.build_balance(bins, sizes0, k, cap=-2).calculate_score()

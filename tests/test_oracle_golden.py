@@ -148,3 +148,26 @@ def test_oracle_incremental_equals_fresh_with_segment_leaves(oracle):
         o.steps(5)
         assert (o.score() == o.fresh_score()).all()
         assert sorted(c for r in o.get_lists(0) for c in r) == list(range(1, 29))
+
+
+def test_load_balance_model_incremental_equals_fresh(oracle):
+    """Bin fairness (load_balance collector, stream/collector/load_balance.rs): the incremental node's score equals a
+    from-scratch evaluation after every committed step, and the closed form round(sqrt(sum x^2 - (sum x)^2 / keys))."""
+    import numpy as np
+    from solverforge_amd import datasets
+
+    n, k = 50, 6
+    r = datasets.stream(5, 2 * n)
+    bins = (r[:n] % np.uint64(k + 1)).astype(np.int64) - 1
+    sizes = (r[n:] % np.uint64(500)).astype(np.int64) + 1
+    o = oracle.Model.balance(k, bins, sizes, w_pair=0, cap=-2)
+    o.configure(leaves=oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP, random_seed=2, la_size=4, limit=20)
+    o.phase_start()
+    for _ in range(30):
+        o.steps(1)
+        assert (o.score() == o.fresh_score()).all()
+        vals = o.get_vars(0, 0)
+        loads = np.array([sizes[vals == b].sum() for b in range(k) if (vals == b).any()], dtype=np.int64)
+        rad = float(-(int(loads.sum()) ** 2)) / float(len(loads)) + float(int((loads * loads).sum())) if len(loads) > 1 else 0.0
+        unfair = int(np.floor(np.sqrt(rad) + 0.5)) if len(loads) > 1 else 0
+        assert o.score()[1] == -unfair and o.score()[0] == -int((vals < 0).sum())
