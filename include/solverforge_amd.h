@@ -98,7 +98,9 @@ typedef enum sf_constraint_kind {
      * `fact_a` = i64 matrix, `param` = depot node */
     SF_C_ROUTE_DISTANCE = 7,
     /* for_each(E).join(equal(value)) on one scalar class, both assigned: `weight` per pair —
-     * keyed self-join IncrementalBiConstraint, constraint/nary_incremental/bi.rs:12-313 */
+     * keyed self-join IncrementalBiConstraint, constraint/nary_incremental/bi.rs:12-313.  `param` = arity: 0 / 2 =
+     * pairs, 3 / 4 / 5 = IncrementalTri / Quad / PentaConstraint (constraint/nary_incremental/higher_arity/shared.rs):
+     * `weight` per index-sorted tuple of assigned entities sharing a value (C(members, arity) per value) */
     SF_C_SELFJOIN_VALUE_EQUAL = 8,
     /* for_each(E).filter(assigned).group_by(value, sum(fact_a)).penalize(weight * w(sum)) — grouped node +
      * sum collector, constraint/grouped/{state,scorer}.rs, stream/collector/sum.rs;

@@ -63,6 +63,7 @@ def lib():
             "sfo_nqueens_create": (vp, [i32, vp]),
             "sfo_graph_coloring_create": (vp, [i32, i32, vp, vp, vp]),
             "sfo_balance_create": (vp, [i32, i32, vp, vp, i64, i64]),
+            "sfo_balance_create_nary": (vp, [i32, i32, vp, vp, i64, i64, i32]),
             "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
@@ -145,9 +146,11 @@ class Model:
         return Model(lib().sfo_graph_coloring_create(n, n_colors, _p(adj_off), _p(adj), _p(colors)), [n])
 
     @staticmethod
-    def balance(n_bins, bins, sizes, w_pair=1, cap=-1):
+    def balance(n_bins, bins, sizes, w_pair=1, cap=-1, arity=2):
         bins = np.ascontiguousarray(bins, dtype=np.int64)
         sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+        if arity != 2:
+            return Model(lib().sfo_balance_create_nary(len(bins), n_bins, _p(bins), _p(sizes), w_pair, cap, arity), [len(bins)])
         return Model(lib().sfo_balance_create(len(bins), n_bins, _p(bins), _p(sizes), w_pair, cap), [len(bins)])
 
     @staticmethod

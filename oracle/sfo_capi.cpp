@@ -89,6 +89,10 @@ void* sfo_balance_create(int32_t n, int32_t n_bins, const int64_t* bins, const i
                          int64_t cap) {
     return make_balance((size_t)n, (size_t)n_bins, bins, sizes, w_pair, cap).release();
 }
+void* sfo_balance_create_nary(int32_t n, int32_t n_bins, const int64_t* bins, const int64_t* sizes, int64_t w_tuple,
+                              int64_t cap, int32_t arity) {
+    return make_balance((size_t)n, (size_t)n_bins, bins, sizes, w_tuple, cap, (size_t)arity).release();
+}
 void* sfo_cvrp_create(int32_t n_customers, int32_t n_vehicles, int64_t capacity, int32_t depot, int32_t dim,
                       const int32_t* demands, const int64_t* matrix, const uint32_t* customers,
                       const uint32_t* route_off, const uint32_t* route_vals) {

@@ -250,7 +250,7 @@ inline std::unique_ptr<Model> make_graph_coloring(size_t n, size_t n_colors, con
 //   level 1: pairs of entities in the same bin (IncrementalBiConstraint keyed by bin), `w_pair` each
 //   level 1: per bin, weight(bin, sum of sizes): cap < 0 -> sum^2 ; cap >= 0 -> max(0, sum - cap)
 inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_t* bins, const int64_t* sizes,
-                                           int64_t w_pair, int64_t cap) {
+                                           int64_t w_pair, int64_t cap, size_t arity = 2) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<BalanceFacts>();
     facts->size.assign(sizes, sizes + n);
@@ -270,7 +270,20 @@ inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_
     pairs->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
     pairs->filter = [](const Solution& s, size_t a, size_t) { return s.classes[0].vars[0][a] != NONE; };
     pairs->weight = [w_pair](const Solution&, size_t, size_t) { return Score::of(0, w_pair); };
-    m->director.constraints.members.push_back(std::move(pairs));
+    if (arity <= 2) {
+        m->director.constraints.members.push_back(std::move(pairs));
+    } else {  // tri / quad / penta: tuples of assigned entities sharing a bin
+        auto tuples = std::make_unique<SelfJoinNaryConstraint>();
+        tuples->name = "Same bin tuple";
+        tuples->arity = arity;
+        tuples->impact = Impact::Penalty;
+        tuples->source = ChangeSource::descriptor(0);
+        tuples->count = [](const Solution& s) { return s.classes[0].n; };
+        tuples->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+        tuples->filter = [](const Solution& s, const size_t* idx) { return s.classes[0].vars[0][idx[0]] != NONE; };
+        tuples->weight = [w_pair](const Solution&, const size_t*) { return Score::of(0, w_pair); };
+        m->director.constraints.members.push_back(std::move(tuples));
+    }
 
     if (cap == -2) {  // fairness instead of the per-bin load: group_by(load_balance(bin, size)).penalize(unfairness)
         auto fair = std::make_unique<LoadBalanceConstraint>();

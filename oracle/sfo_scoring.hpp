@@ -14,6 +14,8 @@
 //   crates/solverforge-scoring/src/api/constraint_set/incremental.rs:339-407 (tuple fold)
 //   crates/solverforge-scoring/src/director/score_director/incremental.rs:141-218
 #pragma once
+#include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <functional>
@@ -231,6 +233,152 @@ struct SelfJoinBiConstraint : Constraint {
                 for (size_t j = i + 1; j < idx.size(); ++j)
                     if (filter(s, idx[i], idx[j])) ++c;
         }
+        return c;
+    }
+    Score initialize(const Solution& s) override {
+        reset();
+        Score total;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i) total = total + insert_entity(s, i);
+        return total;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        return insert_entity(s, e);
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        return retract_entity(s, e);
+    }
+    void reset() override {
+        entity_to_matches.clear();
+        matches.clear();
+        key_to_indices.clear();
+        index_to_key.clear();
+    }
+};
+
+// ---- tri / quad / penta self-join (constraint/nary_incremental/higher_arity/shared.rs:71-417) ----------------
+// One node for arity 3..5 (the reference stamps the same scaffolding per arity with a macro): entities sharing a
+// key form index-sorted tuples; insert enumerates the combinations of OTHER members of the key bucket in increasing
+// index order (for_each_other_indices_combination :48-69), retract replays the stored tuples.
+struct SelfJoinNaryConstraint : Constraint {
+    using Tuple = std::array<size_t, 5>;  // unused slots = SIZE_MAX
+    struct TupleHash {
+        size_t operator()(const Tuple& t) const {
+            size_t h = 1469598103934665603ull;
+            for (size_t v : t) h = (h ^ v) * 1099511628211ull;
+            return h;
+        }
+    };
+    using TupleSet = std::unordered_set<Tuple, TupleHash>;
+    size_t arity = 3;
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Key1 key;
+    std::function<bool(const Solution&, const size_t* idx)> filter;    // indices ascending
+    std::function<Score(const Solution&, const size_t* idx)> weight;
+
+    std::unordered_map<size_t, TupleSet> entity_to_matches;
+    TupleSet matches;
+    std::unordered_map<int64_t, std::unordered_set<size_t>> key_to_indices;
+    std::unordered_map<size_t, int64_t> index_to_key;
+
+    Score compute(const Solution& s, const Tuple& t) const { return apply_impact(impact, weight(s, t.data())); }
+    // every (arity - 1)-subset of `others` (ascending values, none equal to `index`), shared.rs:48-69
+    template <class F>
+    static void other_combinations(const std::vector<size_t>& sorted_others, size_t need, size_t from, std::vector<size_t>& pick, F&& f) {
+        if (need == 0) {
+            f(pick);
+            return;
+        }
+        for (size_t i = from; i + need <= sorted_others.size(); ++i) {
+            pick.push_back(sorted_others[i]);
+            other_combinations(sorted_others, need - 1, i + 1, pick, f);
+            pick.pop_back();
+        }
+    }
+    Score insert_entity(const Solution& s, size_t index) {  // shared.rs:171-229
+        if (index >= count(s)) return Score::zero();
+        int64_t k = key(s, index);
+        index_to_key[index] = k;
+        key_to_indices[k].insert(index);
+        std::vector<size_t> others;
+        for (size_t o : key_to_indices[k])
+            if (o != index) others.push_back(o);
+        std::sort(others.begin(), others.end());  // the result is a sum over a set of tuples: order-independent
+        Score total;
+        std::vector<size_t> pick;
+        other_combinations(others, arity - 1, 0, pick, [&](const std::vector<size_t>& c) {
+            Tuple t;
+            t.fill(SIZE_MAX);
+            t[0] = index;
+            for (size_t i = 0; i < c.size(); ++i) t[i + 1] = c[i];
+            std::sort(t.begin(), t.begin() + arity);
+            if (matches.count(t)) return;
+            if (filter(s, t.data()) && matches.insert(t).second) {
+                for (size_t i = 0; i < arity; ++i) entity_to_matches[t[i]].insert(t);
+                total = total + compute(s, t);
+            }
+        });
+        return total;
+    }
+    Score retract_entity(const Solution& s, size_t index) {  // shared.rs:231-270
+        auto ik = index_to_key.find(index);
+        if (ik != index_to_key.end()) {
+            auto kb = key_to_indices.find(ik->second);
+            if (kb != key_to_indices.end()) {
+                kb->second.erase(index);
+                if (kb->second.empty()) key_to_indices.erase(kb);
+            }
+            index_to_key.erase(ik);
+        }
+        auto em = entity_to_matches.find(index);
+        if (em == entity_to_matches.end()) return Score::zero();
+        TupleSet tuples = std::move(em->second);
+        entity_to_matches.erase(em);
+        size_t n = count(s);
+        Score total;
+        for (const Tuple& t : tuples) {
+            matches.erase(t);
+            bool in_range = true;
+            for (size_t i = 0; i < arity; ++i) {
+                if (t[i] >= n) in_range = false;
+                if (t[i] == index) continue;
+                auto om = entity_to_matches.find(t[i]);
+                if (om != entity_to_matches.end()) {
+                    om->second.erase(t);
+                    if (om->second.empty()) entity_to_matches.erase(om);
+                }
+            }
+            if (in_range) total = total - compute(s, t);
+        }
+        return total;
+    }
+    template <class F>
+    void for_each_tuple(const Solution& s, F&& f) const {  // evaluate / match_count: shared.rs:287-316
+        size_t n = count(s);
+        std::unordered_map<int64_t, std::vector<size_t>> tmp;
+        for (size_t i = 0; i < n; ++i) tmp[key(s, i)].push_back(i);
+        for (auto& kv : tmp) {
+            std::vector<size_t> pick;
+            other_combinations(kv.second, arity, 0, pick, [&](const std::vector<size_t>& c) {
+                Tuple t;
+                t.fill(SIZE_MAX);
+                for (size_t i = 0; i < c.size(); ++i) t[i] = c[i];
+                if (filter(s, t.data())) f(t);
+            });
+        }
+    }
+    Score evaluate(const Solution& s) const override {
+        Score total;
+        for_each_tuple(s, [&](const Tuple& t) { total = total + compute(s, t); });
+        return total;
+    }
+    size_t match_count(const Solution& s) const override {
+        size_t c = 0;
+        for_each_tuple(s, [&](const Tuple&) { ++c; });
         return c;
     }
     Score initialize(const Solution& s) override {

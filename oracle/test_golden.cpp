@@ -302,6 +302,65 @@ static GroupedConstraint workload(Impact impact, GroupWeight w) {  // grouped.rs
     return c;
 }
 
+// constraint/tests/{tri,quad,penta}_incr.rs: key = team, tuples of `arity` tasks sharing a team
+static SelfJoinNaryConstraint cluster(size_t arity, Impact impact, int64_t w, bool only_indexes_from_one = false) {
+    SelfJoinNaryConstraint c;
+    c.name = "Cluster";
+    c.arity = arity;
+    c.impact = impact;
+    c.source = ChangeSource::descriptor(0);
+    c.count = [](const Solution& s) { return s.classes[0].n; };
+    c.key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    c.filter = [arity, only_indexes_from_one](const Solution&, const size_t* idx) {
+        if (!only_indexes_from_one) return true;
+        for (size_t i = 0; i < arity; ++i)
+            if (idx[i] != i + 1) return false;  // (1, 2, 3[, 4[, 5]]): the filter sees SOURCE indexes
+        return true;
+    };
+    c.weight = [w](const Solution&, const size_t*) { return soft(w); };
+    return c;
+}
+static void nary_cases() {
+    const char* names[6] = {"", "", "", "tri", "quad", "penta"};
+    for (size_t arity = 3; arity <= 5; ++arity) {
+        std::string pre = std::string(names[arity]) + "_incr.";
+        std::vector<int64_t> same(arity, 1), zeros;
+        {  // evaluate: `arity` tasks on team 1 + one on team 2 -> one tuple, -1
+            std::vector<int64_t> t = same;
+            t.push_back(2);
+            Solution s = two_col(t, std::vector<int64_t>(t.size(), 0));
+            auto c = cluster(arity, Impact::Penalty, 1);
+            CHECK((pre + "evaluate").c_str(), c.evaluate(s) == soft(-1) && c.match_count(s) == 1);
+        }
+        {  // multiple: arity + 1 tasks on one team -> C(arity + 1, arity) = arity + 1 tuples (-4 / -5 / -6)
+            std::vector<int64_t> t(arity + 1, 1);
+            Solution s = two_col(t, std::vector<int64_t>(t.size(), 0));
+            auto c = cluster(arity, Impact::Penalty, 1);
+            CHECK((pre + "multiple").c_str(), c.evaluate(s) == soft(-(int64_t)(arity + 1)));
+        }
+        {  // incremental: initialize -1, retract task 0 -> +1, re-insert -> -1
+            Solution s = two_col(same, std::vector<int64_t>(arity, 0));
+            auto c = cluster(arity, Impact::Penalty, 1);
+            bool ok = c.initialize(s) == soft(-1);
+            ok = ok && c.on_retract(s, 0, 0) == soft(1);
+            ok = ok && c.on_insert(s, 0, 0) == soft(-1);
+            CHECK((pre + "incremental").c_str(), ok);
+        }
+        {  // filter_receives_source_indexes: arity + 1 tasks, only (1, 2, ..) passes -> one match
+            std::vector<int64_t> t(arity + 1, 1);
+            Solution s = two_col(t, std::vector<int64_t>(t.size(), 0));
+            auto c = cluster(arity, Impact::Penalty, 1, true);
+            CHECK((pre + "filter_source_indexes").c_str(),
+                  c.match_count(s) == 1 && c.evaluate(s) == soft(-1) && c.initialize(s) == soft(-1));
+        }
+        {  // reward: +5
+            Solution s = two_col(same, std::vector<int64_t>(arity, 0));
+            auto c = cluster(arity, Impact::Reward, 5);
+            CHECK((pre + "reward").c_str(), c.evaluate(s) == soft(5));
+        }
+    }
+}
+
 // stream/collector/tests/collector.rs:142-260 (the six load_balance tests)
 static void load_balance_cases() {
     {  // test_perfectly_balanced
@@ -678,6 +737,7 @@ int main() {
     exists_cases();
     grouped_cases();
     load_balance_cases();
+    nary_cases();
     director_case();
     std::printf("%s %d failures\n", failures ? "FAILED" : "PASSED", failures);
     return failures;

@@ -45,6 +45,7 @@ struct ScalarModel {
     // value-keyed aggregates (per-value count / sum tables, maintained at apply):
     int32_t sj_level = -1, grp_level = -1;  // keyed self-join pairs; grouped sum
     int64_t sj_weight = 0, grp_weight = 0, grp_cap = -1;
+    int32_t sj_arity = 2;  // keyed self-join arity: 2 pairs, 3 / 4 / 5 = tri / quad / penta tuples sharing a value
     int32_t grp_mode = 0;  // 0: sum of per-group weights (grouped node + sum collector); 1: load_balance collector (unfairness)
     const int32_t* size = nullptr;     // [n] summed fact of the grouped constraint
     // per-replica committed state
@@ -112,6 +113,14 @@ __device__ __forceinline__ int64_t group_weight(const ScalarModel& m, int64_t su
     return over > 0 ? over : 0;
 }
 
+// tuples of `k` entities among `c` sharing a value: C(c, k), wrapping u64 (k <= 5; every prefix product is divisible)
+__device__ __forceinline__ uint64_t choose_u64(uint64_t c, int k) {
+    if (c < (uint64_t)k) return 0;
+    uint64_t r = 1;
+    for (int i = 1; i <= k; ++i) r = r * (c - (uint64_t)k + (uint64_t)i) / (uint64_t)i;
+    return r;
+}
+
 // load_balance collector (stream/collector/load_balance.rs:167-184): unfairness = round(sqrt(fraction / n + integral)) with
 // integral = sum of squared loads, fraction numerator = -(sum of loads)^2 (what the reference's incremental update
 // maintains), n = keys holding at least one item; the same f64 operations in the same order (IEEE division, correctly
@@ -159,7 +168,13 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
         r.d_un = (value < 0 ? 1 : 0) - (old < 0 ? 1 : 0);
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflict_delta(m, vals, a, value, old, 0xFFFFFFFFu);
-        if (m.sj_level >= 0) r.d_pairs = (value >= 0 ? (int64_t)cnt[value] : 0) - (old >= 0 ? (int64_t)cnt[old] - 1 : 0);
+        if (m.sj_level >= 0) {  // joining a value of c members adds C(c, k-1) tuples; leaving one of c removes C(c-1, k-1)
+            if (m.sj_arity == 2)
+                r.d_pairs = (value >= 0 ? (int64_t)cnt[value] : 0) - (old >= 0 ? (int64_t)cnt[old] - 1 : 0);
+            else
+                r.d_pairs = (int64_t)((value >= 0 ? choose_u64(cnt[value], m.sj_arity - 1) : 0ull) -
+                                      (old >= 0 ? choose_u64(cnt[old] - 1u, m.sj_arity - 1) : 0ull));
+        }
         if (m.grp_level >= 0 && m.grp_mode == 1) {  // load balance: metrics are >= 1 (validated at sf_constraint_add)
             const int64_t sz = (int64_t)m.size[a];
             int64_t s1 = lb[0], s2 = lb[1];
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         unsigned long long pairs = 0, grp = 0, groups = 0;
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
             const unsigned long long c = t_cnt[v];
-            pairs += c * (c - (c ? 1 : 0)) / 2;
+            pairs += m.sj_arity == 2 ? c * (c - (c ? 1 : 0)) / 2 : choose_u64(c, m.sj_arity);
             if (m.grp_mode == 0) grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
             groups += c ? 1 : 0;
         }

@@ -127,7 +127,7 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
     return d
 
 
-def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=-1, leaves=("change", "swap")):
+def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=-1, leaves=("change", "swap"), arity=2):
     """Bin balance: the keyed self-join (pairs of entities sharing a bin — IncrementalBiConstraint,
     constraint/nary_incremental/bi.rs:12-313) and the grouped sum (group_by(bin, sum(size)) with
     weight(sum) — constraint/grouped/{state,scorer}.rs) on one scalar variable.  HardSoftScore:
@@ -142,7 +142,8 @@ def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=
     d.add_scalar_variable(0, 0, n_bins, True, bins)
     d.add_fact_column_i32(FACT_COLUMN, np.asarray(sizes, dtype=np.int32))
     d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
-    d.add_constraint(ConstraintKind.SELFJOIN_VALUE_EQUAL, 0, level=1, weight=w_pair)
+    # arity 3 / 4 / 5: tri / quad / penta self-join (constraint/nary_incremental/higher_arity/shared.rs)
+    d.add_constraint(ConstraintKind.SELFJOIN_VALUE_EQUAL, 0, level=1, weight=w_pair, param=0 if arity == 2 else arity)
     if cap == -2:
         d.add_constraint(ConstraintKind.LOAD_BALANCE_VALUE, 0, fact=FACT_COLUMN, level=1, weight=1)
     else:

@@ -342,3 +342,39 @@ def test_load_balance_large_metrics_and_validation(oracle):
     sizes0[3] = 0
     with pytest.raises(sfa.SolverForgeError, match="metrics must be >= 1"):
         sfa.build_balance(bins, sizes0, k, cap=-2).calculate_score()
+
+
+@pytest.mark.parametrize("arity", [3, 4, 5])
+def test_tri_quad_penta_selfjoin(oracle, arity):
+    """IncrementalTri / Quad / PentaConstraint (higher_arity/shared.rs): tuples of assigned entities sharing a bin; the
+    oracle replays stored tuples through hash sets, the device counts C(members, arity) per value.  Candidate stream
+    with trial scores, committed moves, traced steps, fused solve, evaluate_each."""
+    import solverforge_amd as sfa
+
+    bins, sizes, k = _balance(n=36, k=4, seed=13 + arity)
+    d = sfa.build_balance(bins, sizes, k, w_pair=2, cap=25, arity=arity)
+    o = oracle.Model.balance(k, bins, sizes, w_pair=2, cap=25, arity=arity)
+    bits = oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
+    o.configure(leaves=bits, random_seed=5, la_size=6, limit=30)
+    d.configure(sfa.SolverConfig(random_seed=5, late_acceptance_size=6, accepted_count_limit=30))
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.fresh_score()[:2]).all()
+    gs, gc = d.evaluate_each(0)
+    os_, oc = o.evaluate_each()
+    assert (np.asarray(gs) == np.asarray(os_)[:, :2]).all() and list(gc) == list(oc)
+    om = o.enumerate(0, 2, 99, 3)
+    ref, od = o.evaluate_moves(om)
+    gm, gsc, gd = d.open_cursor(2, 99, selection_order=3, cap=1 << 16)
+    assert (_t(gm) == _t(om)).all() and (gd == od).all() and (gsc == ref[:, :2]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(10):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 16)
+        om, os_, of, oap, omv = o.step_traced()
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+    d.solve_steps(30)
+    o.steps(30)
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.calculate_score()[0] == o.score()[:2]).all() and (d.fresh_score()[0] == o.score()[:2]).all()
+    with pytest.raises(sfa.SolverForgeError):
+        sfa.build_balance(bins, sizes, k, arity=6).calculate_score()
