@@ -497,6 +497,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
     const uint64_t lanebit = 1ULL << lane;
     PH_DECL
 
+    bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
     for (int64_t step = 0; step < p.n_steps; ++step) {
         PH(7)
         // ---- (A) step start (step.rs:60-74) -------------------------------------------------
@@ -965,6 +966,17 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         // ---- (D) commit the forager's pick (step.rs:122-221) ----------------------------------
         const bool applied = has_best && !dry_run;
         if (applied) {
+            if (best_pending) {
+                ScoreV<L> bs;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) bs.v[kk] = best_sol[kk];
+                if (!(score_cmp<L>(best, bs) > 0)) {  // leaving the best state: write its snapshot first
+                    const uint32_t tot = uni(s_off[V]);
+                    for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = s_visits[t];
+                    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) m.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+                    best_pending = false;
+                }
+            }
             const int kind = (best_leaf ? chg1 : chg0) ? 2 : 3;
             const uint32_t a = uni(best_m0 >> 16), i = uni(best_m0 & 0xFFFFu);
             const uint32_t b = uni(best_m1 >> 16), j = uni(best_m1 & 0xFFFFu);
@@ -1008,10 +1020,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 }
                 improved = score_cmp<L>(cs, bs) > 0;
             }
-            if (improved) {
-                const uint32_t tot = uni(s_off[V]);
-                for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = s_visits[t];
-                for (uint32_t t = lane; t <= (uint32_t)V; t += 64) m.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+            if (improved) {  // the clone is deferred until the search leaves this state (best_pending)
+                best_pending = true;
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
             }
@@ -1036,6 +1046,10 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         if constexpr (!FAST)
             if (annealing) sa_store(saw, p.sa, r, lane);
         const uint32_t tot = uni(s_off[V]);
+        if (best_pending) {  // the launch ends in a best state: its deferred snapshot
+            for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = s_visits[t];
+            for (uint32_t t = lane; t <= (uint32_t)V; t += 64) m.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+        }
         for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
         for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
         for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = s_load[t];

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
     int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
     PH_DECL
+    bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         uint64_t sidx, sseed;
@@ -1207,8 +1208,25 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         }
 
         // ---- commit the forager's pick ----
+        auto write_best_snapshot = [&]() {
+            if (has_list) {
+                const uint32_t tot = uni(s_off[V]);
+                for (uint32_t t = lane; t < tot; t += 64) lm.best_visits[(size_t)r * lm.n_cap + t] = s_visits[t];
+                for (uint32_t t = lane; t <= (uint32_t)V; t += 64) lm.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+            }
+            for (uint32_t t = lane; t < ns; t += 64) sm.best_vals[(size_t)r * ns + t] = (int32_t)s_vals[t];
+        };
         const bool applied = has_best && !p.dry_run;
         if (applied) {
+            if (best_pending) {
+                ScoreV<L> bs;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) bs.v[kk] = best_sol[kk];
+                if (!(score_cmp<L>(best, bs) > 0)) {  // leaving the best state: write its snapshot first
+                    write_best_snapshot();
+                    best_pending = false;
+                }
+            }
             const int kind = lt.geti(uni((uint32_t)best_leaf), LeafTab::KIND);
             const uint32_t a = uni(best_m0), b = uni(best_m1);
             if (kind <= 2) {
@@ -1280,13 +1298,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 }
                 improved = score_cmp<L>(cs, bs) > 0;
             }
-            if (improved) {  // update_best_solution (scope_progress.rs:89-107)
-                if (has_list) {
-                    const uint32_t tot = uni(s_off[V]);
-                    for (uint32_t t = lane; t < tot; t += 64) lm.best_visits[(size_t)r * lm.n_cap + t] = s_visits[t];
-                    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) lm.best_off[(size_t)r * (V + 1) + t] = s_off[t];
-                }
-                for (uint32_t t = lane; t < ns; t += 64) sm.best_vals[(size_t)r * ns + t] = (int32_t)s_vals[t];
+            if (improved) {  // update_best_solution (scope_progress.rs:89-107): the clone is deferred (best_pending)
+                best_pending = true;
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
             }
@@ -1306,6 +1319,14 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 
     if (!p.dry_run) {
         if (annealing) sa_store(saw, p.sa, r, lane);
+        if (best_pending) {  // the launch ends in a best state: its deferred snapshot
+            if (has_list) {
+                const uint32_t tot = uni(s_off[V]);
+                for (uint32_t t = lane; t < tot; t += 64) lm.best_visits[(size_t)r * lm.n_cap + t] = s_visits[t];
+                for (uint32_t t = lane; t <= (uint32_t)V; t += 64) lm.best_off[(size_t)r * (V + 1) + t] = s_off[t];
+            }
+            for (uint32_t t = lane; t < ns; t += 64) sm.best_vals[(size_t)r * ns + t] = (int32_t)s_vals[t];
+        }
         if (has_list) {
             const uint32_t tot = uni(s_off[V]);
             for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];

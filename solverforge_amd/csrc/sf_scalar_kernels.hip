@@ -537,6 +537,11 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     // pulls per accepted candidate of the previous step: how far ahead of the forager's quota it pays to
     // generate and trial-score (scheduling only: the consumed prefix, hence every result, is unchanged)
     uint32_t prev_pulls = 64, prev_accepted = 1;
+    // update_best_solution clones the working solution on every strict improvement (scope_progress.rs:89-107).  While
+    // the search keeps improving, the working state IS the best state, so the clone is deferred: `best_pending` marks
+    // "working == best, not yet written"; the snapshot is written right before a non-improving move leaves that state
+    // (and at the end of the launch).  HBM sees one write per departure from a best state instead of one per improvement.
+    bool best_pending = false;
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         // load-balance aggregates of the step snapshot (the tables change only at commit): every lane gets the totals
@@ -864,6 +869,15 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
         // ---- commit the forager's pick ----
         const bool applied = has_best && !p.dry_run;
         if (applied) {
+            if (best_pending) {
+                ScoreV<L> bs;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) bs.v[kk] = best_sol[kk];
+                if (!(score_cmp<L>(best, bs) > 0)) {  // the pick does not improve on the best: snapshot before leaving it
+                    for (uint32_t t = lane; t < n; t += 64) m.best_vals[(size_t)r * n + t] = (int32_t)s_vals[t];
+                    best_pending = false;
+                }
+            }
             const bool pick_change = best_leaf ? chg1 : chg0;
             const uint32_t a = uni(best_m0), b = uni(best_m1);
             if (tracing && lane == 0) {
@@ -904,8 +918,8 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 }
                 improved = score_cmp<L>(cs, bs) > 0;
             }
-            if (improved) {  // update_best_solution (scope_progress.rs:89-107)
-                for (uint32_t t = lane; t < n; t += 64) m.best_vals[(size_t)r * n + t] = (int32_t)s_vals[t];
+            if (improved) {  // update_best_solution (scope_progress.rs:89-107): the clone is deferred (best_pending)
+                best_pending = true;
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
             }
@@ -923,6 +937,8 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
 
     if (!p.dry_run) {
         if (annealing) sa_store(saw, p.sa, r, lane);
+        if (best_pending)
+            for (uint32_t t = lane; t < n; t += 64) m.best_vals[(size_t)r * n + t] = (int32_t)s_vals[t];
         for (uint32_t t = lane; t < n; t += 64) g_vals[t] = (int32_t)s_vals[t];
         if (lane == 0) {
 #pragma unroll
