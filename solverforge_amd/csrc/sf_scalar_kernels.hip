@@ -542,6 +542,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     // "working == best, not yet written"; the snapshot is written right before a non-improving move leaves that state
     // (and at the end of the launch).  HBM sees one write per departure from a best state instead of one per improvement.
     bool best_pending = false;
+    PH_DECL
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         // load-balance aggregates of the step snapshot (the tables change only at commit): every lane gets the totals
@@ -609,6 +610,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
         uint32_t head[2] = {0, 0}, tail[2] = {0, 0}, row[2] = {0, 0}, inner[2] = {0, 0};
         int gen_done[2] = {n == 0, n_leaves > 1 ? (n == 0) : 1}, ex[2] = {0, n_leaves > 1 ? 0 : 1};
 
+        PH(0)
         int done = 0;
         while (!done) {
             // C1: fill the rings: as many pending candidates as the forager is expected to consume before it
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
             }
             wave_sync();
 
+            PH(1)
             // C2: replay one batch in union cursor order
             {
                 const bool live0 = !ex[0], live1 = !ex[1];
@@ -863,6 +866,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
             }
         }
 
+        PH(2)
         prev_pulls = pulls ? pulls : 1u;
         prev_accepted = accepted ? accepted : 1u;
 
@@ -933,7 +937,9 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
             if (p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
         }
+        PH(3)
     }
+    PH_DUMP
 
     if (!p.dry_run) {
         if (annealing) sa_store(saw, p.sa, r, lane);
