@@ -13,7 +13,12 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 # "la" = LateAcceptance(400)+AcceptedCount(256) (the list-policy components); "sa" = the reference's default
 # for scalar-only models: auto-calibrated SimulatedAnnealing + AcceptedCount(1) (default_local_search/policy.rs:56-77)
 policy = sys.argv[4] if len(sys.argv) > 4 else "la"
+# fifth argument "empty": the all-unassigned start (the swap stream then scans thousands of equal (None, None) pairs per
+# step, a property of the reference's stream); default = the post-construction start of SURVEY 8d (first-fit colouring)
+start = sys.argv[5] if len(sys.argv) > 5 else "constructed"
 g = datasets.make_graph(10000, 100000, 16, seed=0)
+if start != "empty":
+    g = datasets.construct_graph(g)
 d = sfa.build_graph_coloring(g, n_replicas=R)
 if policy == "sa":
     d.configure(sfa.SolverConfig(acceptor=sfa.Acceptor.SIMULATED_ANNEALING, accepted_count_limit=1, random_seed=0))
@@ -41,7 +46,7 @@ cm = o.stats()["moves_evaluated"] - m0
 match = bool((d.calculate_score()[0] == o.score()[:2]).all()) if done == K * ls else None
 # change candidate 28 + 8*deg = 188 B, swap 36 + 8*(deg u + deg v) = 356 B at deg 20
 alg = scored * (188 + 356) / 2
-print(json.dumps({"workload": "graph colouring 10k/100k/16", "policy": policy,
+print(json.dumps({"workload": "graph colouring 10k/100k/16", "policy": policy, "start": start,
                   "gpu_steps_per_s": (a["step_count"] - b["step_count"]) / dt, "cpu_steps_per_s": done / ct, "replicas": R, "gpu_moves_per_s": moves / dt,
                   "gpu_candidates_scored_per_s": scored / dt, "kernel_ms_per_launch": ms / n,
                   "alg_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12,

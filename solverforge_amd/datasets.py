@@ -94,6 +94,26 @@ def make_graph(n=10000, n_edges=100000, n_colors=16, seed=0):
     }
 
 
+def construct_graph(g):
+    """The post-construction start state of C2 ("start = first-fit construction"): the reference's
+    first-fit construction (phase/construction/forager_step.rs:149-226) visits the vertices in index order and takes
+    the first colour whose trial score is strictly better than keeping the vertex unassigned, i.e. the first colour no
+    already-coloured neighbour holds; a vertex with no such colour stays unassigned.  Checked against the oracle's
+    construct_first_fit in tests/test_oracle_golden.py."""
+    n, k = g["n"], g["n_colors"]
+    off, adj = g["adj_off"], g["adj"]
+    colors = np.full(n, -1, dtype=np.int64)
+    for v in range(n):
+        used = set(colors[adj[off[v]:off[v + 1]]].tolist())
+        for c in range(k):
+            if c not in used:
+                colors[v] = c
+                break
+    out = dict(g)
+    out["colors"] = colors
+    return out
+
+
 def make_jobshop(n_jobs=500, n_machines=20):
     """C4: operations id -> (job=id//n_machines, step=id%n_machines); all unassigned / unscheduled."""
     n_ops = n_jobs * n_machines

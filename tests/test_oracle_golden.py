@@ -171,3 +171,19 @@ def test_load_balance_model_incremental_equals_fresh(oracle):
         rad = float(-(int(loads.sum()) ** 2)) / float(len(loads)) + float(int((loads * loads).sum())) if len(loads) > 1 else 0.0
         unfair = int(np.floor(np.sqrt(rad) + 0.5)) if len(loads) > 1 else 0
         assert o.score()[1] == -unfair and o.score()[0] == -int((vals < 0).sum())
+
+
+def test_constructed_graph_start_equals_oracle_first_fit(oracle):
+    """datasets.construct_graph (the C2 start state) is the oracle's first-fit construction phase."""
+    from solverforge_amd import datasets
+
+    for seed, k in ((1, 3), (2, 5), (3, 16)):
+        g = datasets.make_graph(120, 700, k, seed=seed)
+        o = oracle.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+        o.construct_first_fit()
+        c = datasets.construct_graph(g)
+        assert (c["colors"] == o.get_vars(0, 0)).all()
+        if k == 3:
+            assert (c["colors"] < 0).any()  # three colours cannot colour this graph greedily: those vertices stay unassigned
+        if k == 16:
+            assert (c["colors"] >= 0).all()
