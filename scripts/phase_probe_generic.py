@@ -6,10 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import solverforge_amd as sfa
 from solverforge_amd import datasets, _lib
-p = datasets.make_cvrp(1000, 100, 55, seed=0)
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 leaves = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt")
-d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves)
+if leaves[0] == "jobshop":  # BASELINE config 4: mixed job shop 500 x 20, constructed start, 4-leaf union
+    d = sfa.build_jobshop(datasets.construct_jobshop(datasets.make_jobshop(500, 20)), n_replicas=R)
+else:
+    d = sfa.build_cvrp(datasets.make_cvrp(1000, 100, 55, seed=0), n_replicas=R, leaves=leaves)
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
 L = _lib.load()
