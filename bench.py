@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--solve-seconds", type=float, default=0.0, help="extra: timed solve after the bench (best score)")
     args = ap.parse_args()
 
+    # the host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this before HIP initialises
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
