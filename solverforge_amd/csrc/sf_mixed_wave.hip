@@ -1,8 +1,9 @@
 // Generic N-leaf search engine (gfx950 wave64): one wavefront = one replica of a model with an
-// optional scalar class and an optional list class, and a union of up to four PLAIN leaves —
-// scalar change, scalar swap, list change, list swap — scheduled by the reference's
-// StratifiedRandom union (mixed job shop: all four; list models without a distance meter: the two
-// list leaves).  The nearby-list union of the CVRP default policy has its own engines
+// optional scalar class and an optional list class, and a union of up to eight leaves -- scalar
+// change / swap, list change / swap, nearby list change / swap, sublist change / swap, list reverse
+// (2-opt), 3-opt (full or distance-pruned) -- scheduled by the reference's StratifiedRandom union
+// (mixed job shop; CVRP with the default list policy minus ruin; list models without a distance
+// meter).  The two-leaf nearby union of the headline bench has its own engines
 // (sf_list_wave.hip / sf_list_kernels.hip).
 //
 // Reference semantics restated (paths under crates/solverforge-solver/src/):

@@ -28,6 +28,9 @@
 
 namespace sf {
 
+#ifndef SF_CONFLICT_W
+#define SF_CONFLICT_W 16  // partner ids in flight per pass of scalar_conflict_delta
+#endif
 enum ScalarCrossKind : int32_t { SC_NONE = 0, SC_PARTNERS_EQUAL = 1, SC_QUEENS = 2 };
 
 struct ScalarModel {
@@ -65,7 +68,7 @@ __device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, c
     int32_t c = 0;
     if (m.cross_kind == SC_PARTNERS_EQUAL) {
         const uint32_t p1 = m.pn_off[e + 1];
-        constexpr int W = 16;
+        constexpr int W = SF_CONFLICT_W;
         for (uint32_t p = m.pn_off[e]; p < p1; p += W) {
             uint32_t o[W];
 #pragma unroll

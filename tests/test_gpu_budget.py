@@ -69,3 +69,62 @@ def test_portfolio_allgather_and_winner_broadcast_single_rank():
             d.portfolio_broadcast_best(1, 0)  # rank outside the communicator
     finally:
         d.portfolio_destroy()
+
+
+def _rescore_cvrp(p, routes):
+    q = dict(p)
+    q["routes"] = [list(r) for r in routes]
+    d2 = sfa.build_cvrp(q)
+    return tuple(int(v) for v in d2.calculate_score()[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", [0, 1, 2])
+def test_deferred_best_snapshot_is_the_best_solution(engine):
+    """update_best_solution is deferred on the device (written when the search leaves a best state or the launch ends):
+    after several launches with worsening stretches the downloaded best solution of every replica, re-scored from
+    scratch, has exactly the reported best score; replicas whose working score is below their best hold a different
+    solution there."""
+    p = datasets.make_cvrp(60, 6, 40, seed=12)
+    leaves = ("nearby_change", "nearby_swap") if engine else ("nearby_change", "nearby_swap", "sublist_change", "list_reverse")
+    R = 6
+    d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves, max_nearby=6)
+    if engine:
+        d.set_engine(engine)
+    # a short LateAcceptance history lets the search drift away from its best state
+    d.configure(sfa.SolverConfig(acceptor=1, late_acceptance_size=40, forager=0, accepted_count_limit=4, random_seed=21))
+    d.calculate_score()
+    d.phase_start()
+    drifted = 0
+    for launch, steps in enumerate((1, 7, 60, 3, 150)):
+        d.solve_steps(steps)
+        best = d.best_scores()
+        work = d.calculate_score()
+        for r in range(R):
+            routes = d.working_lists(0, r, best=True)
+            assert _rescore_cvrp(p, routes) == tuple(int(v) for v in best[r]), (launch, r)
+            if tuple(work[r]) < tuple(best[r]):
+                assert routes != d.working_lists(0, r)
+                drifted += 1
+            # (equal scores do not imply equal solutions: an equal-score move leaves the best snapshot untouched)
+    assert drifted > 0
+
+
+@pytest.mark.gpu
+def test_deferred_best_snapshot_scalar_engine():
+    g = datasets.construct_graph(datasets.make_graph(80, 300, 4, seed=5))
+    d = sfa.build_graph_coloring(g, n_replicas=4)
+    d.configure(sfa.SolverConfig(acceptor=1, late_acceptance_size=30, forager=0, accepted_count_limit=3, random_seed=2))
+    d.calculate_score()
+    d.phase_start()
+    drifted = 0
+    for steps in (1, 9, 80, 200):
+        d.solve_steps(steps)
+        best, work = d.best_scores(), d.calculate_score()
+        for r in range(4):
+            vals = d.working_values(0, 0, replica=r, best=True)
+            g2 = dict(g)
+            g2["colors"] = vals.astype("int64")
+            assert tuple(int(v) for v in sfa.build_graph_coloring(g2).calculate_score()[0]) == tuple(int(v) for v in best[r])
+            drifted += int(tuple(work[r]) < tuple(best[r]))
+    assert drifted > 0
