@@ -97,6 +97,21 @@ SF_HD uint32_t fastmod_u64(uint64_t x, const FastMod& f) {
     return r;
 }
 
+SF_HD int ctz_u64(uint64_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((unsigned long long)v) - 1;
+#else
+    return __builtin_ctzll(v);
+#endif
+}
+// bit s (1 <= s < len <= 128) set when gcd(s, len) == 1
+SF_HD void coprime_mask(uint32_t len, uint64_t& lo, uint64_t& hi) {
+    lo = 0;
+    hi = 0;
+    for (uint32_t s = 1; s < len && s < 128; ++s)
+        if (gcd_u32(s, len) == 1) (s < 64 ? lo : hi) |= 1ULL << (s & 63u);
+}
+
 struct StreamCtx {
     uint64_t step_index;
     uint64_t step_seed;
@@ -130,6 +145,32 @@ struct StreamCtx {
         if (f.n <= 1) return 0;
         if (order == 3) return fastmod_u64(mixed_seed(salt ^ ((uint64_t)offset * OFFSET_MIX)), f);
         return selection_index(offset, f.n, salt);
+    }
+    // random_stride with the coprimality of every candidate stride precomputed (CoprimeMask): the reference walks
+    // s, s+1, .. (wrapping len-1 -> 1) until gcd(s, len) == 1 (iter.rs:97-106); the same walk is "first set bit at or
+    // after s, else bit 1" on the mask.  Same result, no division loop per step.
+    SF_HD uint32_t random_stride_cm(uint32_t len, uint64_t salt, uint64_t cm_lo, uint64_t cm_hi) const {
+        if (len <= 1) return 1;
+        const uint32_t s = mod_u64(mixed_seed(salt), len - 1) + 1;  // 1 ..= len-1 <= 127
+        uint64_t m;
+        if (s < 64) {
+            m = cm_lo >> s;
+            if (m) return s + (uint32_t)ctz_u64(m);
+            if (cm_hi) return 64u + (uint32_t)ctz_u64(cm_hi);
+        } else {
+            m = cm_hi >> (s - 64);
+            if (m) return s + (uint32_t)ctz_u64(m);
+        }
+        return 1;  // wrapped: gcd(1, len) == 1
+    }
+    SF_HD void perm_params_cm(uint32_t len, uint64_t salt, uint32_t& start, uint32_t& stride, uint64_t cm_lo, uint64_t cm_hi) const {
+        if (order <= 2) {
+            start = 0;
+            stride = 1;
+            return;
+        }
+        start = random_index(len, salt);
+        stride = random_stride_cm(len, salt ^ STRIDE_SALT_MIX, cm_lo, cm_hi);
     }
     // permutation parameters of selection_index_without_replacement (iter.rs:133-150)
     SF_HD void perm_params(uint32_t len, uint64_t salt, uint32_t& start, uint32_t& stride) const {

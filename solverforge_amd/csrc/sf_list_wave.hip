@@ -498,6 +498,10 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
     PH_DECL
 
     bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
+    // coprimality of every candidate permutation stride of the V list owners, once per launch (lane s tests s and s + 64)
+    const bool use_cm = V >= 2 && V <= 128;
+    const uint64_t cm_lo = use_cm ? __ballot(lane >= 1 && lane < (uint32_t)V && gcd_u32(lane, (uint32_t)V) == 1) : 0ull;
+    const uint64_t cm_hi = use_cm ? __ballot(lane + 64 < (uint32_t)V && gcd_u32(lane + 64, (uint32_t)V) == 1) : 0ull;
     for (int64_t step = 0; step < p.n_steps; ++step) {
         PH(7)
         // ---- (A) step start (step.rs:60-74) -------------------------------------------------
@@ -579,7 +583,10 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         for (int l = 0; l < n_leaves; ++l) {
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
-            ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
+            if (use_cm)
+                ctx.perm_params_cm((uint32_t)V, ent_salt, pst, psd, cm_lo, cm_hi);
+            else
+                ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
             pst = uni(pst);
             psd = uni(psd);
             uint16_t* ra = route_at + l * V;

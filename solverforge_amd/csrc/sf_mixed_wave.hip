@@ -242,6 +242,10 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
     PH_DECL
     bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
+    // coprimality of every candidate permutation stride of the V list owners, once per launch (lane s tests s and s + 64)
+    const bool use_cm = V >= 2 && V <= 128;
+    const uint64_t cm_lo = use_cm ? __ballot(lane >= 1 && lane < (uint32_t)V && gcd_u32(lane, (uint32_t)V) == 1) : 0ull;
+    const uint64_t cm_hi = use_cm ? __ballot(lane + 64 < (uint32_t)V && gcd_u32(lane + 64, (uint32_t)V) == 1) : 0ull;
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         uint64_t sidx, sseed;
@@ -286,12 +290,30 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             ctx.perm_params(ns, (SALT_SCALAR_SWAP_LEFT ^ identity) ^ OFFSET_MIX, ss_st, ss_sd);
         }
         if (has_list) {
-            ctx.perm_params((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd);
-            ctx.perm_params((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd);
-            ctx.perm_params((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd);
-            ctx.perm_params((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd);
-            ctx.perm_params((uint32_t)V, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd);
-            ctx.perm_params((uint32_t)V, (gl.kopt_nearby ? SALT_KN_ENTITY : SALT_KF_ENTITY) ^ ldesc, ko_st, ko_sd);
+            if (use_cm)
+                ctx.perm_params_cm((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd, cm_lo, cm_hi);
+            else
+                ctx.perm_params((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd);
+            if (use_cm)
+                ctx.perm_params_cm((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd, cm_lo, cm_hi);
+            else
+                ctx.perm_params((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd);
+            if (use_cm)
+                ctx.perm_params_cm((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd, cm_lo, cm_hi);
+            else
+                ctx.perm_params((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd);
+            if (use_cm)
+                ctx.perm_params_cm((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd, cm_lo, cm_hi);
+            else
+                ctx.perm_params((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd);
+            if (use_cm)
+                ctx.perm_params_cm((uint32_t)V, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd, cm_lo, cm_hi);
+            else
+                ctx.perm_params((uint32_t)V, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd);
+            if (use_cm)
+                ctx.perm_params_cm((uint32_t)V, (gl.kopt_nearby ? SALT_KN_ENTITY : SALT_KF_ENTITY) ^ ldesc, ko_st, ko_sd, cm_lo, cm_hi);
+            else
+                ctx.perm_params((uint32_t)V, (gl.kopt_nearby ? SALT_KN_ENTITY : SALT_KF_ENTITY) ^ ldesc, ko_st, ko_sd);
         }
         sc_st = uni(sc_st), sc_sd = uni(sc_sd), ss_st = uni(ss_st), ss_sd = uni(ss_sd);
         lc_st = uni(lc_st), lc_sd = uni(lc_sd), ls_st = uni(ls_st), ls_sd = uni(ls_sd);
@@ -328,7 +350,10 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 if (lk != 16 && lk != 32) continue;
                 const uint64_t ent_salt = (lk == 16 ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ ldesc;
                 uint32_t pst, psd;
-                ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
+                if (use_cm)
+                    ctx.perm_params_cm((uint32_t)V, ent_salt, pst, psd, cm_lo, cm_hi);
+                else
+                    ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
                 pst = uni(pst);
                 psd = uni(psd);
                 uint16_t* ra = nb_route_at + ni * V;
