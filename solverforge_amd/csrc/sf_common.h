@@ -152,6 +152,9 @@ struct StreamCtx {
     SF_HD uint32_t random_stride_cm(uint32_t len, uint64_t salt, uint64_t cm_lo, uint64_t cm_hi) const {
         if (len <= 1) return 1;
         const uint32_t s = mod_u64(mixed_seed(salt), len - 1) + 1;  // 1 ..= len-1 <= 127
+        return first_coprime_from(s, cm_lo, cm_hi);
+    }
+    SF_HD static uint32_t first_coprime_from(uint32_t s, uint64_t cm_lo, uint64_t cm_hi) {
         uint64_t m;
         if (s < 64) {
             m = cm_lo >> s;
@@ -162,6 +165,17 @@ struct StreamCtx {
             if (m) return s + (uint32_t)ctz_u64(m);
         }
         return 1;  // wrapped: gcd(1, len) == 1
+    }
+    // same, with Barrett remainders by len (fm) and len - 1 (fm1) kept by the caller
+    SF_HD void perm_params_fm(const FastMod& fm, const FastMod& fm1, uint64_t salt, uint32_t& start, uint32_t& stride, uint64_t cm_lo,
+                              uint64_t cm_hi) const {
+        if (order <= 2 || fm.n <= 1) {
+            start = 0;
+            stride = 1;
+            return;
+        }
+        start = fastmod_u64(mixed_seed(salt), fm);
+        stride = first_coprime_from(fastmod_u64(mixed_seed(salt ^ STRIDE_SALT_MIX), fm1) + 1, cm_lo, cm_hi);
     }
     SF_HD void perm_params_cm(uint32_t len, uint64_t salt, uint32_t& start, uint32_t& stride, uint64_t cm_lo, uint64_t cm_hi) const {
         if (order <= 2) {

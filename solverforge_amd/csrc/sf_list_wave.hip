@@ -498,6 +498,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
     PH_DECL
 
     bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
+    const FastMod fm_V = make_fastmod(V > 0 ? (uint32_t)V : 1u);
+    const FastMod fm_V1 = make_fastmod(V > 1 ? (uint32_t)V - 1u : 1u);
     // coprimality of every candidate permutation stride of the V list owners, once per launch (lane s tests s and s + 64)
     const bool use_cm = V >= 2 && V <= 128;
     const uint64_t cm_lo = use_cm ? __ballot(lane >= 1 && lane < (uint32_t)V && gcd_u32(lane, (uint32_t)V) == 1) : 0ull;
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
             if (use_cm)
-                ctx.perm_params_cm((uint32_t)V, ent_salt, pst, psd, cm_lo, cm_hi);
+                ctx.perm_params_fm(fm_V, fm_V1, ent_salt, pst, psd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
             pst = uni(pst);
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
             uint16_t* ro = rank_of + l * V;
             uint16_t* sb = slot_base + l * (V + 1);
             for (uint32_t k = lane; k < (uint32_t)V; k += 64) {
-                const uint32_t e = (pst + k * psd) % (uint32_t)V;  // pst, k, psd < V <= 32767
+                const uint32_t e = fastmod_u64((uint64_t)pst + (uint64_t)k * psd, fm_V);
                 ra[k] = (uint16_t)e;
                 ro[e] = (uint16_t)k;
             }

@@ -242,6 +242,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
     PH_DECL
     bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
+    const FastMod fm_V = make_fastmod(V > 0 ? (uint32_t)V : 1u);  // Barrett remainder by the owner count: no 64-bit division per entity rank
+    const FastMod fm_V1 = make_fastmod(V > 1 ? (uint32_t)V - 1u : 1u);
     // coprimality of every candidate permutation stride of the V list owners, once per launch (lane s tests s and s + 64)
     const bool use_cm = V >= 2 && V <= 128;
     const uint64_t cm_lo = use_cm ? __ballot(lane >= 1 && lane < (uint32_t)V && gcd_u32(lane, (uint32_t)V) == 1) : 0ull;
@@ -291,27 +293,27 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         }
         if (has_list) {
             if (use_cm)
-                ctx.perm_params_cm((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd, cm_lo, cm_hi);
+                ctx.perm_params_fm(fm_V, fm_V1, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, SALT_LC_ENTITY ^ ldesc, lc_st, lc_sd);
             if (use_cm)
-                ctx.perm_params_cm((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd, cm_lo, cm_hi);
+                ctx.perm_params_fm(fm_V, fm_V1, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, SALT_LS_ENTITY ^ ldesc, ls_st, ls_sd);
             if (use_cm)
-                ctx.perm_params_cm((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd, cm_lo, cm_hi);
+                ctx.perm_params_fm(fm_V, fm_V1, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, SALT_LR_ENTITY ^ ldesc, lr_st, lr_sd);
             if (use_cm)
-                ctx.perm_params_cm((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd, cm_lo, cm_hi);
+                ctx.perm_params_fm(fm_V, fm_V1, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, SALT_SC_ENTITY ^ ldesc, sb_st, sb_sd);
             if (use_cm)
-                ctx.perm_params_cm((uint32_t)V, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd, cm_lo, cm_hi);
+                ctx.perm_params_fm(fm_V, fm_V1, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, SALT_SS_ENTITY ^ ldesc, sw_st, sw_sd);
             if (use_cm)
-                ctx.perm_params_cm((uint32_t)V, (gl.kopt_nearby ? SALT_KN_ENTITY : SALT_KF_ENTITY) ^ ldesc, ko_st, ko_sd, cm_lo, cm_hi);
+                ctx.perm_params_fm(fm_V, fm_V1, (gl.kopt_nearby ? SALT_KN_ENTITY : SALT_KF_ENTITY) ^ ldesc, ko_st, ko_sd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, (gl.kopt_nearby ? SALT_KN_ENTITY : SALT_KF_ENTITY) ^ ldesc, ko_st, ko_sd);
         }
@@ -321,17 +323,17 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         sb_st = uni(sb_st), sb_sd = uni(sb_sd);
         sw_st = uni(sw_st), sw_sd = uni(sw_sd);
         ko_st = uni(ko_st), ko_sd = uni(ko_sd);
-        auto ko_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)ko_st + (uint64_t)rank * ko_sd) % (uint32_t)V); };
+        auto ko_ent = [&](uint32_t rank) { return fastmod_u64((uint64_t)ko_st + (uint64_t)rank * ko_sd, fm_V); };
         if (gl.kopt_nearby) {  // a fresh cursor per step: no entity open yet
             KoptLds km(mem + cv.kopt);
             if (lane == 0) km.st[15] = 0;
             wave_sync();
         }
-        auto sw_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)sw_st + (uint64_t)rank * sw_sd) % (uint32_t)V); };
-        auto sb_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)sb_st + (uint64_t)rank * sb_sd) % (uint32_t)V); };
-        auto lr_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lr_st + (uint64_t)rank * lr_sd) % (uint32_t)V); };
-        auto lc_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)lc_st + (uint64_t)rank * lc_sd) % (uint32_t)V); };
-        auto ls_ent = [&](uint32_t rank) { return (uint32_t)(((uint64_t)ls_st + (uint64_t)rank * ls_sd) % (uint32_t)V); };
+        auto sw_ent = [&](uint32_t rank) { return fastmod_u64((uint64_t)sw_st + (uint64_t)rank * sw_sd, fm_V); };
+        auto sb_ent = [&](uint32_t rank) { return fastmod_u64((uint64_t)sb_st + (uint64_t)rank * sb_sd, fm_V); };
+        auto lr_ent = [&](uint32_t rank) { return fastmod_u64((uint64_t)lr_st + (uint64_t)rank * lr_sd, fm_V); };
+        auto lc_ent = [&](uint32_t rank) { return fastmod_u64((uint64_t)lc_st + (uint64_t)rank * lc_sd, fm_V); };
+        auto ls_ent = [&](uint32_t rank) { return fastmod_u64((uint64_t)ls_st + (uint64_t)rank * ls_sd, fm_V); };
         auto rlen = [&](uint32_t e) { return uni(s_off[e + 1] - s_off[e]); };
 
         for (int l = 0; l < GL; ++l) {
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 const uint64_t ent_salt = (lk == 16 ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ ldesc;
                 uint32_t pst, psd;
                 if (use_cm)
-                    ctx.perm_params_cm((uint32_t)V, ent_salt, pst, psd, cm_lo, cm_hi);
+                    ctx.perm_params_fm(fm_V, fm_V1, ent_salt, pst, psd, cm_lo, cm_hi);
                 else
                     ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
                 pst = uni(pst);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 uint16_t* ro = nb_rank_of + ni * V;
                 uint16_t* sb = nb_slot_base + ni * (V + 1);
                 for (uint32_t k = lane; k < (uint32_t)V; k += 64) {
-                    const uint32_t e = (pst + k * psd) % (uint32_t)V;
+                    const uint32_t e = fastmod_u64((uint64_t)pst + (uint64_t)k * psd, fm_V);
                     ra[k] = (uint16_t)e;
                     ro[e] = (uint16_t)k;
                 }
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         const uint32_t rk = g.d + lane;
                         uint32_t sent_k = 0, slen_k = 0;
                         if (rk < (uint32_t)V) {
-                            sent_k = (uint32_t)(((uint64_t)sw_st + (uint64_t)rk * sw_sd) % (uint32_t)V);
+                            sent_k = fastmod_u64((uint64_t)sw_st + (uint64_t)rk * sw_sd, fm_V);
                             slen_k = s_off[sent_k + 1] - s_off[sent_k];
                             if (slen_k < mn) slen_k = 0;
                         }
@@ -670,7 +672,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 const uint32_t rk = g.d + lane;
                                 uint32_t de_k = 0, full_k = 0;
                                 if (rk < (uint32_t)V && rk != g.a) {
-                                    de_k = (uint32_t)(((uint64_t)sb_st + (uint64_t)rk * sb_sd) % (uint32_t)V);
+                                    de_k = fastmod_u64((uint64_t)sb_st + (uint64_t)rk * sb_sd, fm_V);
                                     full_k = s_off[de_k + 1] - s_off[de_k] + 1;
                                 }
                                 const uint32_t cnt_k = (lane == 0 && full_k) ? full_k - g.e : full_k;  // g.e < full of rank g.d
