@@ -56,12 +56,11 @@ SF_HD uint32_t gcd_u32(uint32_t a, uint32_t b) {  // iter.rs:200-207
 // parity unpinned).  draw k of replica seed s.
 SF_HD uint64_t step_seed(uint64_t random_seed, uint64_t draw) { return splitmix64(random_seed + draw * GOLDEN); }
 
-// x % n.  For n < 2^16 (entity counts, list lengths, leaf counts) four 32-bit remainders over the
-// 16-bit limbs of x replace the 64-bit software division the GPU would otherwise expand to.
+// x % n.  For n < 2^16 (entity counts, list lengths, leaf counts) three 32-bit remainders (high word, then the two
+// 16-bit limbs of the low word) replace the 64-bit software division the GPU would otherwise expand to.
 SF_HD uint32_t mod_u64(uint64_t x, uint32_t n) {
     if (n >= 65536u) return (uint32_t)(x % n);
-    uint32_t r = (uint32_t)(x >> 48) % n;
-    r = ((r << 16) | (uint32_t)((x >> 32) & 0xFFFFu)) % n;
+    uint32_t r = (uint32_t)(x >> 32) % n;  // the high word fits a 32-bit remainder directly
     r = ((r << 16) | (uint32_t)((x >> 16) & 0xFFFFu)) % n;
     r = ((r << 16) | (uint32_t)(x & 0xFFFFu)) % n;
     return r;
