@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             lt.set(l, LeafTab::EX, l >= nl);
             lt.set(l, LeafTab::WCUR, 0);
         }
+        uint32_t exmask = 0xFFu & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
         if (has_nearby) {
             const uint32_t total = uni(s_off[V]);
@@ -389,6 +390,9 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
         const uint32_t u_str = nl > 1 ? ctx.random_stride((uint32_t)nl, SALT_UNION_STRIDE) : 1u;
         int32_t live_weight = nl;  // running weights of the smooth weighted round-robin live in the leaf table
+        uint32_t u_order = 0;  // rotated child order of this step, 4 bits per position (nl <= 8)
+        for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) u_order |= ((u_off + pos * u_str) % (uint32_t)nl) << (4u * pos);
+        u_order = uni(u_order);
 
         PH(0)
         int done = 0;
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             uint32_t fill_thr = 64;
             {
                 uint32_t live = 0;
-                for (int l = 0; l < nl; ++l) live += lt.get(l, LeafTab::EX) ? 0u : 1u;
+                for (int l = 0; l < nl; ++l) live += ((exmask >> l) & 1u) ? 0u : 1u;
                 if (live > 1) fill_thr = (63u + live) / live + 8u;
             }
             for (int l = 0; l < nl; ++l) {
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 GGen g = lt.gen(l);
                 uint32_t tl = lt.get(l, LeafTab::TAIL);
                 const uint32_t hd_l = lt.get(l, LeafTab::HEAD);
-                const bool ex_l = lt.get(l, LeafTab::EX) != 0;
+                const bool ex_l = ((exmask >> l) & 1u) != 0;
                 const uint32_t leaf_max_nearby = lt.get(l, LeafTab::MAXNB), leaf_min = lt.get(l, LeafTab::MINSZ), leaf_max = lt.get(l, LeafTab::MAXSZ);
                 while (!ex_l && !g.done && tl - hd_l < fill_thr) {
                     st_sources += 1;
@@ -988,33 +992,25 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             uint32_t nvalid = 0;
             bool need_more = false;
             {
-                int nlive = 0;
-                for (int l = 0; l < nl; ++l) nlive += lt.get(l, LeafTab::EX) ? 0 : 1;
+                int nlive = __popc(~exmask & ((1u << nl) - 1u));
                 // Fast path: with equal weights the smooth weighted round-robin is a plain cycle over the
                 // live children in rotated order whenever all their running weights are equal (true at the
                 // start of every step and after every whole cycle).  Lay out whole cycles directly; the
                 // pull-by-pull simulation below handles partial cycles, exhaustion and refills.
                 if (nl > 1 && nlive > 1) {
-                    bool aligned = true;
-                    int32_t w0 = 0;
-                    bool first = true;
-                    for (int l = 0; l < nl; ++l)
-                        if (!lt.get(l, LeafTab::EX)) {
-                            const int32_t wl = lt.geti(l, LeafTab::WCUR);
-                            if (first) {
-                                w0 = wl;
-                                first = false;
-                            } else if (wl != w0)
-                                aligned = false;
-                        }
+                    // every live child's running weight equal?  one parallel read (lane l = leaf l) instead of nl serial ones
+                    const uint32_t livem = ~exmask & ((1u << nl) - 1u);
+                    const int32_t wc = lane < (uint32_t)nl ? (int32_t)lt.w[lane * 16 + LeafTab::WCUR] : 0;
+                    const int32_t w0 = __shfl(wc, __ffs((int)livem) - 1);
+                    const bool aligned = __ballot(lane < (uint32_t)nl && ((livem >> lane) & 1u) && wc != w0) == 0ull;
                     if (aligned) {
                         // my pull t = lane: cycle t / nlive, child = (t % nlive)-th live leaf in rotated order
                         const uint32_t cyc = lane / (uint32_t)nlive, slot = lane % (uint32_t)nlive;
                         uint32_t leaf = 0, seen = 0;
                         bool found = false;
                         for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
-                            const uint32_t i = (u_off + pos * u_str) % (uint32_t)nl;
-                            if (!lt.get((int)i, LeafTab::EX)) {
+                            const uint32_t i = (u_order >> (4u * pos)) & 15u;
+                            if (!((exmask >> i) & 1u)) {
                                 if (!found && seen == slot) {
                                     leaf = i;
                                     found = true;
@@ -1034,7 +1030,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 my_idx = hd + cyc;
                             }
                             for (int l = 0; l < nl; ++l)
-                                if (!lt.get(l, LeafTab::EX)) lt.set(l, LeafTab::TAKEN, cycles);  // running weights: +nvalid - cycles * nlive = 0
+                                if (!((exmask >> l) & 1u)) lt.set(l, LeafTab::TAKEN, cycles);  // running weights: +nvalid - cycles * nlive = 0
                         }
                     }
                 }
@@ -1046,8 +1042,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         sel = 0;
                     } else {
                         for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
-                            const int i = (int)((u_off + pos * u_str) % (uint32_t)nl);
-                            if (!lt.get(i, LeafTab::EX)) {
+                            const int i = (int)((u_order >> (4u * pos)) & 15u);
+                            if (!((exmask >> i) & 1u)) {
                                 const int32_t wi = lt.geti(i, LeafTab::WCUR) + 1;
                                 lt.set(i, LeafTab::WCUR, (uint32_t)wi);
                                 if (sel < 0 || wi > selw) {
@@ -1065,7 +1061,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         // bookkeeping and refill first
                         if (nl > 1) {
                             for (int l = 0; l < nl; ++l)
-                                if (!lt.get(l, LeafTab::EX)) lt.set(l, LeafTab::WCUR, (uint32_t)(lt.geti(l, LeafTab::WCUR) - 1));
+                                if (!((exmask >> l) & 1u)) lt.set(l, LeafTab::WCUR, (uint32_t)(lt.geti(l, LeafTab::WCUR) - 1));
                         }
                         need_more = true;
                         break;
@@ -1073,6 +1069,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     if (nl > 1) lt.set(sel, LeafTab::WCUR, (uint32_t)(lt.geti(sel, LeafTab::WCUR) - live_weight));
                     if (!avail) {  // exhausted child discovered at this pull
                         lt.set(sel, LeafTab::EX, 1);
+                        exmask |= 1u << sel;
                         nlive -= 1;
                         live_weight -= 1;
                         continue;
