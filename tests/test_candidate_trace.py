@@ -174,3 +174,23 @@ def test_gpu_trace_digest_scalar_engine(forager):
         cpu.record_step(t6(om), of)
         assert gpu.prefix_digest == cpu.digest.value(), (forager, step)
     assert gpu.total_pulls == cpu.total_pulls > 0
+
+
+def test_native_encoder_matches_committed_fixture():
+    """tests/golden/candidate_trace_v3.json (made by tests/golden/make_candidate_trace_golden.py): every move family, all
+    four disposition shapes, selector indices 0..7, two scopes."""
+    import json
+    import os
+
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "candidate_trace_v3.json")))
+    sc = fx["scope"]
+    t = ct.CandidateTrace(phase_index=sc["phase_index"], phase_type=sc["phase_type"], list_descriptor=sc["list"][0],
+                          list_variable=sc["list"][1], scalar_descriptor=sc["scalar"][0], scalar_variable=sc["scalar"][1])
+    for step in fx["steps"]:
+        mv = np.zeros(len(step), dtype=sfa.MOVE_DTYPE)
+        for i, pull in enumerate(step):
+            mv[i] = tuple(pull["move"])
+        t.record_step(mv, np.array([pull["flags"] for pull in step], dtype=np.int32))
+    assert t.canonical_bytes().hex() == fx["canonical_bytes_hex"]
+    assert [str(v) for v in t.prefix_digest] == fx["prefix_digest"]
+    assert t.total_pulls == fx["total_pulls"]
