@@ -446,3 +446,31 @@ def test_cvrp_sublist_swap_leaf(oracle, leaves, sizes):
     assert d.working_lists(0, 0) == o.get_lists(0)
     assert (d.calculate_score()[0] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("bendable", [True, False])
+def test_jobshop_one_byte_values_path(oracle, bendable):
+    """Scalar classes of >= 1024 entities and <= 127 values keep one byte per value in LDS (the i8 instantiation of the
+    generic engine: job shop 500 x 20 fits 4 waves per CU instead of 3): traced steps and a fused run against the oracle
+    on a 1,100-operation job shop (3-level Bendable and 2-level HardSoft instantiations)."""
+    import solverforge_amd as sfa
+
+    p = _jobshop(n_jobs=55, n_machines=20, seed=9)
+    assert p["n_ops"] >= 1024
+    d, o, bits = _mk_jobshop(oracle, p, n_replicas=2, bendable=bendable)
+    lv = 3 if bendable else 2
+    o.configure(acceptor=1, la_size=5, forager=0, limit=12, leaves=bits, random_seed=6)
+    d.configure(sfa.SolverConfig(acceptor=1, late_acceptance_size=5, forager=0, accepted_count_limit=12, random_seed=6))
+    assert (d.calculate_score()[0] == o.score()[:lv]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(4):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om) and (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :lv]).all(), step
+        assert gap == oap and (not gap or tuple(gmv) == tuple(omv)), step
+    d.solve_steps(12)
+    o.steps(12)
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert d.working_lists(1, 0) == o.get_lists(1)
+    assert (d.calculate_score()[0] == o.score()[:lv]).all() and (d.fresh_score()[0] == o.score()[:lv]).all()
