@@ -113,6 +113,24 @@ static constexpr size_t SF_LDS_BUDGET = 160 * 1024 - 1024;
         }                                                                                   \
     } while (0)
 
+// hipSetDevice is per host thread: every entry point that touches HIP binds the calling thread to the context's
+// device for the duration of the call and restores the previous device afterwards, so contexts on different GPUs can
+// be driven from one process / from worker threads other than the creator (a Rust rayon worker, bench.py's RCCL thread).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const sf_ctx* ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 static int fail(sf_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     return code;
@@ -164,10 +182,14 @@ int32_t sf_ctx_create(int32_t device_id, int32_t score_levels, int32_t hard_leve
     ctx->levels = score_levels;
     ctx->hard_levels = hard_levels;
     ctx->R = n_replicas;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
-        g_create_error = "hipSetDevice/hipStreamCreate failed";
-        delete ctx;
-        return SF_ERR_HIP;
+    {
+        DeviceGuard _dev(ctx);
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device_id || hipStreamCreate(&ctx->stream) != hipSuccess) {
+            g_create_error = "hipSetDevice/hipStreamCreate failed";
+            delete ctx;
+            return SF_ERR_HIP;
+        }
     }
     *out = ctx;
     return SF_OK;
@@ -177,21 +199,24 @@ int32_t sf_portfolio_destroy(sf_ctx* ctx);
 
 void sf_ctx_destroy(sf_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)sf_portfolio_destroy(ctx);  // a communicator the caller did not tear down
-    for (void* p : ctx->allocs) (void)hipFree(p);
-    for (auto& ev : ctx->events) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+    {
+        DeviceGuard _dev(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)sf_portfolio_destroy(ctx);  // a communicator the caller did not tear down
+        for (void* p : ctx->allocs) (void)hipFree(p);
+        for (auto& ev : ctx->events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        (void)hipStreamDestroy(ctx->stream);
     }
-    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 const char* sf_last_error(const sf_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int32_t sf_sync(sf_ctx* ctx) {
+    DeviceGuard _dev(ctx);
     if (!ctx) return SF_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SF_OK;
@@ -209,6 +234,7 @@ int32_t sf_schema_add_scalar_variable(sf_ctx* ctx, int32_t d, int32_t var, int32
                                       int32_t allows_unassigned, const int32_t* initial) {
     if (!ctx || !ctx->classes.count(d) || !initial || n_values < 0)
         return fail(ctx, SF_ERR_INVALID, "bad scalar variable");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "schema is frozen after sf_initialize");
     ClassSpec& c = ctx->classes[d];
     if (c.has_scalar) return fail(ctx, SF_ERR_UNSUPPORTED, "one scalar planning variable per class");
     c.has_scalar = true;
@@ -222,20 +248,27 @@ int32_t sf_schema_add_scalar_variable(sf_ctx* ctx, int32_t d, int32_t var, int32
 int32_t sf_schema_add_list_variable(sf_ctx* ctx, int32_t d, const uint32_t* offsets, const uint32_t* values,
                                     int32_t element_capacity, int32_t element_id_bound) {
     if (!ctx || !ctx->classes.count(d) || !offsets) return fail(ctx, SF_ERR_INVALID, "bad list variable");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "schema is frozen after sf_initialize");
+    if (element_capacity < 0 || element_id_bound < 0) return fail(ctx, SF_ERR_INVALID, "negative element capacity / id bound");
     ClassSpec& c = ctx->classes[d];
+    if (offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "list offsets must start at 0");
+    for (int i = 0; i < c.n_rows; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SF_ERR_INVALID, "list offsets must be non-decreasing");
+    const uint32_t total = offsets[c.n_rows];
+    if (total > (uint32_t)element_capacity) return fail(ctx, SF_ERR_INVALID, "element_capacity too small");
+    if (total > 0 && !values) return fail(ctx, SF_ERR_INVALID, "list values missing");
+    for (uint32_t t = 0; t < total; ++t)
+        if (values[t] >= (uint32_t)element_id_bound) return fail(ctx, SF_ERR_INVALID, "element id out of bound");
     c.has_list = true;
     c.list_off.assign(offsets, offsets + c.n_rows + 1);
-    uint32_t total = offsets[c.n_rows];
-    if ((int32_t)total > element_capacity) return fail(ctx, SF_ERR_INVALID, "element_capacity too small");
     c.list_vals.assign(values, values + total);
-    for (uint32_t v : c.list_vals)
-        if ((int32_t)v >= element_id_bound) return fail(ctx, SF_ERR_INVALID, "element id out of bound");
     c.element_capacity = element_capacity;
     c.element_bound = element_id_bound;
     return SF_OK;
 }
 
 int32_t sf_fact_matrix_i64(sf_ctx* ctx, int32_t id, int32_t rows, int32_t cols, const int64_t* data) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !data || rows <= 0 || cols <= 0) return fail(ctx, SF_ERR_INVALID, "bad matrix");
     Fact f;
     f.type = 1;
@@ -260,6 +293,7 @@ int32_t sf_fact_matrix_i64(sf_ctx* ctx, int32_t id, int32_t rows, int32_t cols, 
     return SF_OK;
 }
 int32_t sf_fact_column_i32(sf_ctx* ctx, int32_t id, int32_t n, const int32_t* data) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !data || n < 0) return fail(ctx, SF_ERR_INVALID, "bad column");
     Fact f;
     f.type = 2;
@@ -272,6 +306,7 @@ int32_t sf_fact_column_i32(sf_ctx* ctx, int32_t id, int32_t n, const int32_t* da
     return SF_OK;
 }
 int32_t sf_fact_column_u32(sf_ctx* ctx, int32_t id, int32_t n, const uint32_t* data) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !data || n < 0) return fail(ctx, SF_ERR_INVALID, "bad column");
     Fact f;
     f.type = 3;
@@ -284,7 +319,13 @@ int32_t sf_fact_column_u32(sf_ctx* ctx, int32_t id, int32_t n, const uint32_t* d
     return SF_OK;
 }
 int32_t sf_fact_csr_u32(sf_ctx* ctx, int32_t id, int32_t n_rows, const uint32_t* offsets, const uint32_t* values) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !offsets || n_rows < 0) return fail(ctx, SF_ERR_INVALID, "bad csr");
+    if (offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "csr offsets must start at 0");
+    for (int32_t i = 0; i < n_rows; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SF_ERR_INVALID, "csr offsets must be non-decreasing");
+    if (offsets[n_rows] > 0 && !values) return fail(ctx, SF_ERR_INVALID, "csr values missing");
+    if (offsets[n_rows] > 0x7FFFFFFFu) return fail(ctx, SF_ERR_UNSUPPORTED, "csr with more than 2^31 - 1 entries");
     Fact f;
     f.type = 4;
     f.rows = n_rows;
@@ -368,6 +409,7 @@ static int build_list_model(sf_ctx* ctx, int d) {
             if (f.rows != f.cols || f.rows < m.dim) return fail(ctx, SF_ERR_INVALID, "matrix smaller than element id bound");
             m.mat = (const int64_t*)f.d0;
             m.dim = f.rows;
+            if (cs.param < 0 || cs.param >= (int64_t)f.rows) return fail(ctx, SF_ERR_INVALID, "depot node outside the matrix");
             m.depot = (int32_t)cs.param;
             m.dist_level = cs.level;
             m.dist_weight = cs.weight;
@@ -612,8 +654,8 @@ static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit, int64_t* d_pa
 extern "C" {
 
 int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores) {
+    DeviceGuard _dev(ctx);
     if (!ctx) return SF_ERR_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
     if (!ctx->initialized) {
         int n_list = 0, n_scalar = 0, ld = -1, sd = -1;
         for (auto& kv : ctx->classes) {
@@ -642,6 +684,7 @@ int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores) {
 }
 
 int32_t sf_evaluate_all(sf_ctx* ctx, int64_t* out_scores) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     return run_evaluate_all(ctx, out_scores, 0);
 }
@@ -649,6 +692,7 @@ int32_t sf_evaluate_all(sf_ctx* ctx, int64_t* out_scores) {
 // ConstraintSet::evaluate_each (crates/solverforge-scoring/src/api/constraint_set/incremental.rs:172,237-244): one full
 // recomputation, reported per declared constraint
 int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int64_t* out_match_counts) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || replica < 0 || replica >= ctx->R || !out_scores || !out_match_counts)
         return fail(ctx, SF_ERR_INVALID, "bad sf_evaluate_each arguments");
     int rc;
@@ -684,12 +728,14 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
 }
 
 int32_t sf_get_scores(sf_ctx* ctx, int64_t* out_scores) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !out_scores) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     return download_scores(ctx, ctx->has_list_model ? ctx->lm.score : ctx->sm.score, out_scores);
 }
 
 int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, int64_t n, int64_t* out_scores,
                          int32_t* out_doable) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (replica < 0 || replica >= ctx->R || n < 0 || !moves || !out_scores || !out_doable)
         return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate arguments");
@@ -731,6 +777,7 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
 }
 
 int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !mv || replica < 0 || replica >= ctx->R)
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
     int rc = alloc_search(ctx);
@@ -845,6 +892,7 @@ static int anneal_phase_start(sf_ctx* ctx) {
 }
 
 int32_t sf_get_annealing_state(sf_ctx* ctx, int32_t replica, double* out_temperatures, int32_t* out_calibrating) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->search_alloc || replica < 0 || replica >= ctx->R || !out_temperatures || !out_calibrating)
         return fail(ctx, SF_ERR_INVALID, "bad sf_get_annealing_state");
     uint64_t w[SA_WORDS];
@@ -870,6 +918,7 @@ int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine) {
 }
 
 int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps) {
+    DeviceGuard _dev(ctx);
     if (!ctx) return SF_ERR_INVALID;
     if (!seeds || n_steps <= 0) {
         ctx->d_explicit = nullptr;
@@ -894,6 +943,7 @@ int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_s
 }
 
 int32_t sf_phase_start(sf_ctx* ctx) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     int rc = alloc_search(ctx);
     if (rc) return rc;
@@ -1026,12 +1076,16 @@ int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps) { return solve_launch(ctx, 
 
 int32_t sf_solve_moves(sf_ctx* ctx, int64_t max_steps, int64_t move_budget) {
     if (move_budget <= 0) return fail(ctx, SF_ERR_INVALID, "sf_solve_moves: move_budget must be positive");
+    // the per-launch candidate counter of a replica is 32 bits wide (a launch that long would run for hours)
+    if (move_budget >= ((int64_t)1 << 31)) return fail(ctx, SF_ERR_INVALID, "sf_solve_moves: move_budget must be < 2^31 per launch");
     return solve_launch(ctx, max_steps, move_budget);
 }
 
 static int32_t solve_launch(sf_ctx* ctx, int64_t n_steps, int64_t move_budget) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !ctx->search_alloc) return fail(ctx, SF_ERR_INVALID, "sf_phase_start first");
     if (n_steps <= 0) return SF_OK;
+    if (n_steps >= ((int64_t)1 << 31)) return fail(ctx, SF_ERR_INVALID, "at most 2^31 - 1 steps per launch");
     if (ctx->events.size() >= 1024) {  // a long-lived context never holds more than 1024 event pairs
         int rcf = fold_events(ctx);
         if (rcf) return rcf;
@@ -1075,6 +1129,7 @@ static int fold_events(sf_ctx* ctx) {
 }
 
 int32_t sf_profile_solve(sf_ctx* ctx, double* out_ms, int64_t* out_launches) {
+    DeviceGuard _dev(ctx);
     if (!ctx) return SF_ERR_INVALID;
     int rc = fold_events(ctx);
     if (rc) return rc;
@@ -1106,6 +1161,7 @@ static int fetch_trace(sf_ctx* ctx, sf_move_t* out_moves, int64_t* out_scores, i
 int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint64_t step_seed, int32_t order,
                          sf_move_t* out_moves, int64_t* out_scores, int32_t* out_doable, int64_t cap,
                          int64_t* out_count) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (replica < 0 || replica >= ctx->R || cap <= 0 || !out_moves) return fail(ctx, SF_ERR_INVALID, "bad sf_step_generate arguments");
     int rc = alloc_search(ctx);
@@ -1134,6 +1190,7 @@ int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint
 int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves, int64_t* out_scores,
                              int32_t* out_flags, int64_t cap, int64_t* out_count, int32_t* out_applied,
                              sf_move_t* out_applied_move) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !ctx->search_alloc) return fail(ctx, SF_ERR_INVALID, "sf_phase_start first");
     if (replica < 0 || replica >= ctx->R || cap <= 0) return fail(ctx, SF_ERR_INVALID, "bad arguments");
     int rc = ensure_trace(ctx, cap);
@@ -1155,6 +1212,7 @@ int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves,
 }
 
 int32_t sf_get_stats(sf_ctx* ctx, int32_t replica, sf_stats* out) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->search_alloc || !out || replica < 0 || replica >= ctx->R) return fail(ctx, SF_ERR_INVALID, "bad sf_get_stats");
     static_assert(sizeof(sf_stats) == SF_STATS_WORDS * 8, "sf_stats layout");
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->sp.stats + (size_t)replica * SF_STATS_WORDS, sizeof(sf_stats), hipMemcpyDeviceToHost, ctx->stream));
@@ -1163,6 +1221,7 @@ int32_t sf_get_stats(sf_ctx* ctx, int32_t replica, sf_stats* out) {
 }
 
 int32_t sf_get_stats_sum(sf_ctx* ctx, sf_stats* out) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->search_alloc || !out) return fail(ctx, SF_ERR_INVALID, "bad sf_get_stats_sum");
     std::vector<uint64_t> all((size_t)ctx->R * SF_STATS_WORDS);
     HIPCHK(ctx, hipMemcpyAsync(all.data(), ctx->sp.stats, all.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1175,11 +1234,13 @@ int32_t sf_get_stats_sum(sf_ctx* ctx, sf_stats* out) {
 }
 
 int32_t sf_get_best_scores(sf_ctx* ctx, int64_t* out) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !out) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     return download_scores(ctx, ctx->has_list_model ? ctx->lm.best_score : ctx->sm.best_score, out);
 }
 
 int32_t sf_download_list(sf_ctx* ctx, int32_t replica, int32_t d, uint32_t* out_off, uint32_t* out_vals, int32_t best) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->has_list_model || d != ctx->list_desc || replica < 0 || replica >= ctx->R)
         return fail(ctx, SF_ERR_INVALID, "bad sf_download_list");
     const ListModel& m = ctx->lm;
@@ -1194,6 +1255,7 @@ int32_t sf_download_list(sf_ctx* ctx, int32_t replica, int32_t d, uint32_t* out_
 }
 
 int32_t sf_download_scalar(sf_ctx* ctx, int32_t replica, int32_t d, int32_t var, int32_t* out, int32_t best) {
+    DeviceGuard _dev(ctx);
     if (!ctx || !ctx->has_scalar_model || d != ctx->scalar_desc || replica < 0 || replica >= ctx->R)
         return fail(ctx, SF_ERR_INVALID, "bad sf_download_scalar");
     (void)var;

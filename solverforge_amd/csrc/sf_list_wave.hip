@@ -488,7 +488,26 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         cur[k] = (int64_t)uni64((uint64_t)g_score[k]);  // wave-uniform: keep in scalar registers
         best_sol[k] = (int64_t)uni64((uint64_t)m.best_score[(size_t)r * 4 + k]);
     }
-    uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;  // per launch
+    // per-launch counters in 32 bits (wave-uniform: scalar registers), folded into the replica's 64-bit sf_stats words
+    // before they can wrap (flush_stats): a long fixed-step launch never loses counts
+    uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;
+    uint64_t steps_run = 0;
+    auto flush_stats = [&]() {
+        if (lane == 0) {
+            uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
+            gs[0] += st_steps;
+            gs[1] += st_gen;
+            gs[2] += st_gen;
+            gs[3] += st_acc;
+            gs[4] += st_applied;
+            gs[5] += st_calc;
+            gs[6] += st_gen - st_calc;
+            gs[7] += st_scored;
+            gs[8] += st_sources;
+        }
+        steps_run += st_steps;
+        st_steps = st_gen = st_acc = st_applied = st_calc = st_scored = st_sources = 0;
+    };
     uint64_t trace_n = 0;
     const uint64_t step_index0 = dry_run ? 0 : p.step_index[r];
     const uint64_t seed_draws0 = dry_run ? 0 : p.seed_draws[r];
@@ -1044,7 +1063,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
             wave_sync();
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
-            if (p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
+            if (p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves (budget < 2^31)
+            if (p.move_budget == 0 && st_scored >= 0x70000000u) flush_stats();
         }
         PH(5)
     }
@@ -1070,19 +1090,10 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 m.best_score[(size_t)r * 4 + kk] = best_sol[kk];
             }
             p.la_idx[r] = la_cursor;
-            p.step_index[r] = step_index0 + (uint64_t)st_steps;  // steps actually run (a move budget can end the launch early)
-            p.seed_draws[r] = seed_draws0 + (uint64_t)st_steps;
-            uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
-            gs[0] += st_steps;
-            gs[1] += st_gen;
-            gs[2] += st_gen;
-            gs[3] += st_acc;
-            gs[4] += st_applied;
-            gs[5] += st_calc;
-            gs[6] += st_gen - st_calc;
-            gs[7] += st_scored;
-            gs[8] += st_sources;
+            p.step_index[r] = step_index0 + steps_run + (uint64_t)st_steps;  // steps actually run (a move budget can end the launch early)
+            p.seed_draws[r] = seed_draws0 + steps_run + (uint64_t)st_steps;
         }
+        flush_stats();
     }
     if (tracing && lane == 0) *p.trace_count = (int64_t)trace_n;
 }

@@ -531,7 +531,25 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
         cur[k] = g_score[k];
         best_sol[k] = m.best_score[(size_t)r * 4 + k];
     }
+    // per-launch counters in 32 bits (wave-uniform), folded into the 64-bit sf_stats words before they can wrap
     uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;
+    uint64_t steps_run = 0;
+    auto flush_stats = [&]() {
+        if (lane == 0) {
+            uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
+            gs[0] += st_steps;
+            gs[1] += st_gen;
+            gs[2] += st_gen;
+            gs[3] += st_acc;
+            gs[4] += st_applied;
+            gs[5] += st_calc;
+            gs[6] += st_gen - st_calc;
+            gs[7] += st_scored;
+            gs[8] += st_sources;
+        }
+        steps_run += st_steps;
+        st_steps = st_gen = st_acc = st_applied = st_calc = st_scored = st_sources = 0;
+    };
     uint64_t trace_n = 0;
     const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
     const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
@@ -939,6 +957,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
             if (p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
+            if (!p.dry_run && p.move_budget == 0 && st_scored >= 0x70000000u) flush_stats();
         }
         PH(3)
     }
@@ -957,19 +976,10 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 m.best_score[(size_t)r * 4 + kk] = best_sol[kk];
             }
             p.la_idx[r] = la_cursor;
-            p.step_index[r] = step_index0 + (uint64_t)st_steps;  // steps actually run (a move budget can end the launch early)
-            p.seed_draws[r] = seed_draws0 + (uint64_t)st_steps;
-            uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
-            gs[0] += st_steps;
-            gs[1] += st_gen;
-            gs[2] += st_gen;
-            gs[3] += st_acc;
-            gs[4] += st_applied;
-            gs[5] += st_calc;
-            gs[6] += st_gen - st_calc;
-            gs[7] += st_scored;
-            gs[8] += st_sources;
+            p.step_index[r] = step_index0 + steps_run + (uint64_t)st_steps;  // steps actually run (a move budget can end the launch early)
+            p.seed_draws[r] = seed_draws0 + steps_run + (uint64_t)st_steps;
         }
+        flush_stats();
     }
     if (tracing && lane == 0) *p.trace_count = (int64_t)trace_n;
 }

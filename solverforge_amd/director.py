@@ -102,6 +102,10 @@ class GpuScoreDirector:
 
     def add_scalar_variable(self, descriptor_index, variable_index, n_values, allows_unassigned, initial):
         initial = np.ascontiguousarray(initial, dtype=np.int32)
+        n_rows = self._entity_counts.get(descriptor_index)
+        if n_rows is None or initial.shape != (n_rows,):  # the C side reads n_rows values
+            raise SolverForgeError(f"SF_ERR_INVALID: initial must hold one value per row of class {descriptor_index} "
+                                   f"({n_rows}), got shape {initial.shape}")
         check(self._L.sf_schema_add_scalar_variable(self._h, descriptor_index, variable_index, n_values,
                                                     int(allows_unassigned), ptr(initial)), self._h)
 

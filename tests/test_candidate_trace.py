@@ -194,3 +194,17 @@ def test_native_encoder_matches_committed_fixture():
     assert t.canonical_bytes().hex() == fx["canonical_bytes_hex"]
     assert [str(v) for v in t.prefix_digest] == fx["prefix_digest"]
     assert t.total_pulls == fx["total_pulls"]
+
+
+def test_applied_kopt_pull_with_empty_scalar_variable_name():
+    """The largest pull (an applied 3-opt move: 10 coordinates + three dispositions) must frame when the scope carries
+    no scalar variable name — a list-only model bound from a Rust shim passes NULL / "" there."""
+    mv = np.zeros(1, dtype=sfa.MOVE_DTYPE)
+    mv["kind"], mv["a"], mv["a_pos"], mv["b"], mv["b_pos"], mv["value"] = 7, 3, 2, 5, 9, 4
+    flags = np.array([7 | (5 << 8)], dtype=np.int32)
+    for scalar_name in ("", "value"):
+        t = ct.CandidateTrace(list_variable="v", scalar_variable=scalar_name, phase_type="")
+        t.record_step(mv, flags)
+        ref = trace_v3.Digest().update(t.canonical_bytes()).value()
+        assert t.prefix_digest == ref
+        assert len(t.canonical_bytes()) >= 190
