@@ -1,27 +1,46 @@
 #!/usr/bin/env python
-"""bench.py — moves-evaluated/sec of the MI355X hot path on BASELINE.json's CVRP-1000 workload.
+"""bench.py — moves-evaluated/sec (M1) and best HardSoftScore@60s (M2) of the MI355X hot path on BASELINE.json's
+CVRP-1000 workload.
 
-One bench "step" = ONE persistent-kernel launch (sf_solve_steps) that runs `--ls-steps`
-local-search steps (seeded nearby-list candidate generation -> trial delta score -> LateAcceptance
--> AcceptedCount(256) forager -> apply) for each of `--replicas` independently seeded searches
-resident on the GPU (the per-GPU batch of the seed portfolio).  `value` counts
-CONSUMED candidates (`moves_evaluated`, the reference's counter definition, evaluation.rs:33-49),
-not the speculative tail; inputs are resident in HBM before the timed region.
+M1.  One bench "step" = ONE persistent-kernel launch (sf_solve_steps) that runs `--ls-steps` local-search steps
+(seeded nearby-list candidate generation -> trial delta score -> LateAcceptance -> AcceptedCount(256) forager ->
+apply) for each of `--replicas` independently seeded searches resident on the GPU (the per-GPU batch of the seed
+portfolio).  `value` counts CONSUMED candidates (`moves_evaluated`, the reference's counter definition,
+evaluation.rs:33-49), not the speculative tail; inputs are resident in HBM before the timed region.
 
-cpu_baseline: the oracle (C++ restatement of the reference algorithm, 1 thread) runs the SAME
-local-search step window as GPU replica 0 (same seed: warmup*ls_steps untimed steps, then
-steps*ls_steps timed steps, bounded by --cpu-seconds), and when it completes the window its
-working score is compared bit for bit with replica 0's (`extra.replica0_matches_cpu_oracle`).
+roofline.  The dominant kernel (k_list_search_wave) keeps a replica's whole state in LDS, so HBM is idle (DESIGN.md
+§4); what bounds it is instruction issue.  `roofline.bound = "valu-issue"`: achieved = SQ_INSTS_VALU wave-instructions
+per second, peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md).  The counters
+come from rocprofv3 --pmc passes of THIS command (same warm-up and timed launches) that bench.py runs as child
+processes after the timed region (FETCH_SIZE and WRITE_SIZE each in a pass of their own, the read side doubled as the
+guide prescribes for gfx950); when rocprofv3 is not usable the committed profile of the same command is used and
+`roofline.pmc_source` says so.  SURVEY.md §8(d)'s algorithmic-bytes figure stays as a labelled side number.
 
-Multi-GPU (`torchrun ... bench.py --gpus N`): one process per GPU, independent seeds per rank
-(weak scaling, no data-path collective); after the timed region every rank contributes its best
-score to one RCCL all-gather over xGMI (sf_portfolio_allgather_best) and all ranks name the same
-winner.  torch.distributed (gloo) is used only for rendezvous / barrier / max-over-ranks.
+cpu_baseline.  The oracle (C++ restatement of the reference algorithm, 1 thread) runs the SAME local-search step window
+as GPU replica 0 (same seed), and when it completes the window its working score is compared bit for bit with
+replica 0's (`extra.replica0_matches_cpu_oracle`).
+
+M2 (`--solve-seconds`, default 60).  A fresh portfolio solves for 60 s of wall clock with work-balanced launches
+(sf_solve_moves) while the CPU oracle solves the same problem (seed of replica 0) on one host core for the same
+60 s: `extra.best_score_at_60s` = {"gpu": ..., "cpu_oracle": ...}.
+
+Multi-GPU.  `python bench.py --gpus N` spawns N ranks itself (torch.distributed.run, one process per GPU) when it is
+not already running under a launcher; it refuses to run with fewer devices than ranks.  Independent seeds per rank
+(weak scaling, no data-path collective); at the end every rank contributes its best score to one RCCL all-gather over
+xGMI (sf_portfolio_allgather_best) and all ranks name the same winner, whose routes one RCCL broadcast hands to every
+rank.  torch.distributed (gloo) is used only for rendezvous / barrier / max-over-ranks.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,12 +49,28 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
-# SURVEY.md §8(d) algorithmic bytes (C3): one scored list-change/list-swap candidate at route
-# length 10+10 = 368 B; nearby generation per source = (N+V)*12 B (the reference probes every
-# destination slot of every source).  These are the bytes of the ALGORITHM as the reference states
-# it; the wave engine's presorted neighbour index touches far fewer.
+# SURVEY.md §8(d) algorithmic bytes (C3): one scored list-change/list-swap candidate at route length 10+10 = 368 B;
+# nearby generation per source = (N+V)*12 B (the reference probes every destination slot of every source).
 B_ALG_CANDIDATE = 368
 HBM_PEAK_GBS = 8000.0
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz max clock, a wave64 VALU instruction issues over 2 cycles;
+# one scalar unit per CU (1 SALU instruction per clock), LDS 1 wave-instruction per >= 2 cycles per CU
+N_SIMD = 1024
+N_CU = 256
+CLOCK_HZ = 2.4e9
+VALU_PEAK = N_SIMD * CLOCK_HZ / 2.0  # wave-instructions / s
+SALU_PEAK = N_CU * CLOCK_HZ
+LDS_PEAK = N_CU * CLOCK_HZ / 2.0
+
+# TCC passes first: on this pool a FETCH_SIZE pass that FOLLOWS the SQ cycle-counter pass was seen to hang (twice), while
+# the same pass run first completes in seconds; every pass has its own short deadline and a failed pass only drops its
+# own counters.
+PMC_PASSES = [
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+    ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
+    ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
+]
 
 
 def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
@@ -72,6 +107,110 @@ def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
     }
 
 
+def cpu_solve(problem, seed, seconds, box):
+    """M2 on the host: the oracle searches for `seconds` of wall clock on one core (runs beside the GPU solve; the
+    ctypes call releases the GIL)."""
+    try:
+        from oracle import sfo
+
+        o = sfo.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
+                           problem["customers"], problem["routes"])
+        o.configure(leaves=sfo.LEAF_NEARBY_LIST_CHANGE | sfo.LEAF_NEARBY_LIST_SWAP, max_nearby=20, random_seed=seed)
+        o.phase_start()
+        t0 = time.perf_counter()
+        o.steps_timed(seconds)
+        dt = time.perf_counter() - t0
+        st = o.stats()
+        box["result"] = {"best_score": [int(v) for v in o.best_score()[:2]], "steps": st["step_count"],
+                         "moves_evaluated": st["moves_evaluated"], "seconds": dt, "cores": 1}
+    except Exception as e:  # the bench line still goes out; the gap is visible
+        box["error"] = f"{type(e).__name__}: {e}"
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: one process per GPU over torch.distributed.run."""
+    from solverforge_amd import _lib
+
+    n_dev = _lib.load().sf_device_count()
+    if n_dev < n:
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} HIP devices, this node has {n_dev}; refusing to run fewer "
+                         "ranks than asked for (a 1-rank number must not be reported as an N-GPU one)\n")
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
+    """rocprofv3 --pmc passes of this same command (child mode: warm-up + timed launches only).  Returns
+    ({counter: mean per timed launch}, kernel resource info) or (None, reason)."""
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    info = {}
+    base = tempfile.mkdtemp(prefix="sfpmc_", dir="/tmp")
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    failed = []
+    try:
+        for i, grp in enumerate(PMC_PASSES):
+            d = os.path.join(base, f"pmc_{i}")
+            cmd = [exe, "--pmc"] + grp + ["-f", "csv", "-d", d, "-o", "b", "--", sys.executable,
+                                            os.path.abspath(__file__)] + argv + ["--pmc-child"]
+            # own process group: a pass that hangs is killed together with the profiled grandchild
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                  start_new_session=True)
+            try:
+                _, err = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(pr.pid, 9)
+                except OSError:
+                    pass
+                pr.wait()
+                failed.append(f"{'+'.join(grp)}: timed out after {timeout_s}s")
+                continue
+            if pr.returncode != 0:
+                failed.append(f"{'+'.join(grp)}: rc={pr.returncode} {err.decode(errors='replace')[-160:]}")
+                continue
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            per = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if kernel_substr not in row["Kernel_Name"]:
+                        continue
+                    per.setdefault(row["Counter_Name"], []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+                    info = {"vgpr": int(row.get("VGPR_Count", 0) or 0), "sgpr": int(row.get("SGPR_Count", 0) or 0),
+                            "scratch": int(row.get("Scratch_Size", 0) or 0), "kernel": row["Kernel_Name"]}
+            if not per:
+                failed.append(f"{'+'.join(grp)}: no rows for {kernel_substr}")
+            for c, v in per.items():
+                v.sort()
+                vals = [x for _, x in v][warmup:warmup + steps]  # the timed launches, in dispatch order
+                if len(vals) != steps:
+                    failed.append(f"{c}: {len(v)} dispatches of {kernel_substr}, expected {warmup + steps}")
+                    continue
+                out[c] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    if failed:
+        info = dict(info, failed_passes=failed)
+    if "SQ_INSTS_VALU" not in out:
+        return None, "; ".join(failed) or "no SQ_INSTS_VALU"
+    return out, info
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,22 +225,32 @@ def main():
     ap.add_argument("--engine", choices=["auto", "block", "wave"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--solve-seconds", type=float, default=0.0, help="extra: timed solve after the bench (best score)")
+    ap.add_argument("--solve-seconds", type=float, default=60.0, help="M2: wall-clock budget of the solve leg (0 = skip)")
+    ap.add_argument("--solve-budget", type=int, default=100_000, help="M2: candidates per replica per launch (sf_solve_moves)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline from profiles/)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     # the host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this before HIP initialises
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import __graft_entry__ as entry
+
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        entry.build()
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); refusing to report one as the other\n")
+        sys.exit(2)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod  # plumbing only: rendezvous + barrier (gloo, CPU tensors)
 
         dist = dist_mod
         dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    import __graft_entry__ as entry
 
     # one builder per node: the other ranks wait, then only load the finished library
     if dist is None or local_rank == 0:
@@ -111,42 +260,55 @@ def main():
         if local_rank != 0:
             entry.build()  # no-op when the library is current
     import solverforge_amd as sfa
-    from solverforge_amd import datasets, portfolio
+    from solverforge_amd import _lib, datasets, portfolio
 
     problem = datasets.make_cvrp(args.customers, args.vehicles, args.capacity, seed=args.seed)
-    from solverforge_amd import _lib
+    n_dev = _lib.load().sf_device_count()
+    if n_dev < 1:
+        raise sfa.SolverForgeError("SF_ERR_NO_DEVICE: bench.py measures the HIP path; there is no CPU fallback")
+    if world > n_dev:
+        sys.stderr.write(f"bench.py: {world} ranks but {n_dev} HIP device(s) on this node\n")
+        sys.exit(2)
+    seed_base = portfolio.rank_seed_base(args.seed, rank, args.replicas)
 
-    n_dev = max(_lib.load().sf_device_count(), 1)
-    d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank % n_dev)
-    d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
-    # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
-    d.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, args.replicas)))
+    def new_director():
+        d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank)
+        d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
+        # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
+        d.configure(sfa.SolverConfig(random_seed=seed_base))
+        return d
+
+    d = new_director()
     start_score = d.calculate_score()[0].tolist()
     engine = {1: "block", 2: "wave"}[d.engine()]
     d.phase_start()
 
-    def barrier():
-        d.sync()
+    def barrier(dd):
+        dd.sync()
         if dist is not None:
             dist.barrier()
-        d.sync()
+        dd.sync()
 
     for _ in range(args.warmup):
         d.solve_steps(args.ls_steps, sync=False)
-    barrier()
+    barrier(d)
     d.profile_solve()  # drop warmup events
     before = d.total_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         d.solve_steps(args.ls_steps, sync=False)
-    barrier()
+    barrier(d)
     elapsed = time.perf_counter() - t0
+    if args.pmc_child:  # counters are read by the parent from rocprofv3's CSV
+        d.close()
+        return
     if dist is not None:
         elapsed = portfolio.max_over_ranks(dist, elapsed)
     kernel_ms, launches = d.profile_solve()  # HIP events on the context stream (the launch stream)
     after = d.total_stats()
     delta = {k: after[k] - before[k] for k in after}
     replica0_score = [int(v) for v in d.calculate_score()[0]]
+    m1_best = list(max(tuple(int(v) for v in s) for s in d.best_scores()))
 
     moves_local = delta["moves_evaluated"]
     scored_local = delta["candidates_scored"]
@@ -154,39 +316,76 @@ def main():
     if dist is not None:
         moves_total = portfolio.sum_over_ranks(dist, moves_local)
 
-    # portfolio exchange: RCCL all-gather of best scores (correctness: identical winner everywhere)
+    # ---- M2: a fresh portfolio solves for --solve-seconds of wall clock; the CPU oracle beside it on a host core ----
+    solve = None
+    dx = d  # the context whose best score goes into the portfolio exchange
+    if args.solve_seconds > 0:
+        d.close()
+        d2 = new_director()
+        d2.calculate_score()
+        d2.phase_start()
+        cpu_box = {}
+        cpu_thread = None
+        if rank == 0 and not args.no_cpu_baseline:
+            cpu_thread = threading.Thread(target=cpu_solve, args=(problem, args.seed, args.solve_seconds, cpu_box), daemon=True)
+        barrier(d2)
+        if cpu_thread:
+            cpu_thread.start()
+        t1 = time.perf_counter()
+        n_launch = 0
+        while time.perf_counter() - t1 < args.solve_seconds:
+            d2.solve_moves(1 << 20, args.solve_budget, sync=True)  # work-balanced launches (sf_solve_moves)
+            n_launch += 1
+        gpu_s = time.perf_counter() - t1
+        st2 = d2.total_stats()
+        solve = {
+            "seconds": gpu_s, "launches": n_launch, "moves_evaluated": st2["moves_evaluated"], "ls_steps": st2["step_count"],
+            "best_score_local": list(max(tuple(int(v) for v in s) for s in d2.best_scores())),
+            "moves_per_s": st2["moves_evaluated"] / gpu_s,
+        }
+        if cpu_thread:
+            cpu_thread.join(timeout=args.solve_seconds + 30)
+            solve["cpu_oracle"] = cpu_box.get("result", {"error": cpu_box.get("error", "did not finish")})
+        if dist is not None:
+            solve["moves_evaluated_all_ranks"] = portfolio.sum_over_ranks(dist, st2["moves_evaluated"])
+        dx = d2
+
+    # ---- portfolio exchange: RCCL all-gather of best scores (correctness: identical winner everywhere) -------------
     exchange = "single-rank"
-    best_local = max(tuple(int(v) for v in s) for s in d.best_scores())
+    best_local = max(tuple(int(v) for v in s) for s in dx.best_scores())
     winner = {"score": list(best_local), "rank": 0}
+    ctx_abandoned = False
     if dist is not None:
         import torch
 
-        # The RCCL communicator is set up in a worker thread with a deadline: a rank that cannot bring the
-        # xGMI communicator up (driver / IPC configuration) must not hang the bench; every rank then takes the
-        # same gloo fallback and the JSON line says so.
-        import threading
-
+        # The RCCL communicator is set up in a worker thread with a deadline: a rank that cannot bring the xGMI
+        # communicator up (driver / IPC configuration) must not hang the bench; every rank then takes the same
+        # fallback and the JSON line says so.  A context whose worker thread was abandoned mid-call is never touched
+        # again (calls on one context are not re-entrant): the process leaves through os._exit.
         box = {}
 
         def rccl_exchange():
             try:
-                uid = d.portfolio_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8)
+                uid = dx.portfolio_unique_id() if rank == 0 else np.zeros(128, dtype=np.uint8)
                 tu = torch.from_numpy(uid.copy())
                 dist.broadcast(tu, src=0)
-                d.portfolio_init(tu.numpy(), rank, world)
-                box["result"] = d.portfolio_allgather_best()
+                dx.portfolio_init(tu.numpy(), rank, world)
+                box["result"] = dx.portfolio_allgather_best()
                 try:  # the winner's routes on every rank: ncclBroadcast of the route CSR from the winning rank
-                    routes = d.portfolio_broadcast_best(int(box["result"][1]), int(box["result"][2]))
+                    routes = dx.portfolio_broadcast_best(int(box["result"][1]), int(box["result"][2]))
                     box["winner_customers"] = sum(len(r) for r in routes)
                 except Exception as e:
                     box["broadcast_error"] = f"{type(e).__name__}: {e}"
-                d.portfolio_destroy()
+                dx.portfolio_destroy()
             except Exception as e:  # keep the bench alive; report the fallback honestly
                 box["error"] = f"{type(e).__name__}: {e}"
+            box["finished"] = True
 
         th = threading.Thread(target=rccl_exchange, daemon=True)
         th.start()
         th.join(timeout=float(os.environ.get("SF_RCCL_TIMEOUT_S", "120")))
+        ctx_abandoned = not box.get("finished", False)
+
         def all_ranks_ok(flag):
             return -portfolio.max_over_ranks(dist, -(1.0 if flag else 0.0)) > 0.5  # min over ranks: everyone or no one
 
@@ -205,7 +404,7 @@ def main():
 
             def torch_exchange():
                 try:
-                    box2["result"] = portfolio.torch_rccl_allgather_best(dist, best_local, rank, world, local_rank % n_dev)
+                    box2["result"] = portfolio.torch_rccl_allgather_best(dist, best_local, rank, world, local_rank)
                 except Exception as e:
                     box2["error"] = f"{type(e).__name__}: {e}"
 
@@ -225,14 +424,61 @@ def main():
         gen_bytes_per_source = (args.customers + args.vehicles) * 12
         alg_bytes = scored_local * B_ALG_CANDIDATE + delta["sources_scanned"] * gen_bytes_per_source
         avg_launch_ms = kernel_ms / max(launches, 1)
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        kernel = "k_list_search_wave<2,false>" if engine == "wave" else "k_list_search<2,false>"
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{engine}.json")
-        if os.path.exists(tpath):  # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command
-            tj = json.load(open(tpath))
-            if tj.get("replicas") == args.replicas and tj.get("ls_steps") == args.ls_steps:
-                traffic = tj.get("hbm_bytes_per_launch")
+        launch_s = avg_launch_ms * 1e-3
+        kernel = "k_list_search_wave" if engine == "wave" else "k_list_search"
+        # ---- PMC: rocprofv3 child passes of this command (N = 1 only: one GPU, one process) ----
+        pmc, pmc_info, pmc_source = None, {}, None
+        child_argv = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--replicas", str(args.replicas),
+                      "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
+                      "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
+        if world == 1 and not args.no_pmc:
+            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=90)
+            if pmc is None:
+                pmc_source = f"committed profile (live rocprofv3 passes failed: {pmc_info})"
+                pmc_info = {}
+            else:
+                pmc_source = "rocprofv3 --pmc child passes of this command, mean over the timed launches"
+        if pmc is None:
+            ppath = os.path.join(ROOT, "profiles", f"r02_{engine}_pmc.json")
+            if os.path.exists(ppath):
+                pj = json.load(open(ppath))
+                cfg = pj.get("_config", {})
+                if cfg.get("replicas_per_gpu") == args.replicas and cfg.get("ls_steps_per_launch") == args.ls_steps and \
+                        cfg.get("steps") == args.steps and cfg.get("warmup") == args.warmup:
+                    pmc = {k: v["mean_per_launch"] for k, v in pj.items() if isinstance(v, dict) and "mean_per_launch" in v}
+                    pmc_source = pmc_source or f"committed profile profiles/r02_{engine}_pmc.json (same command)"
+        roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave-instr/s", "frac": None,
+                "traffic": None}
+        if pmc and launch_s > 0:
+            valu = pmc.get("SQ_INSTS_VALU", 0.0) / launch_s
+            salu = pmc.get("SQ_INSTS_SALU", 0.0) / launch_s
+            lds = pmc.get("SQ_INSTS_LDS", 0.0) / launch_s
+            roof["achieved"] = valu / 1e9
+            roof["frac"] = valu / VALU_PEAK
+            roof["salu_frac"] = salu / SALU_PEAK   # one scalar unit per CU, 1 instruction per clock
+            roof["lds_issue_frac"] = lds / LDS_PEAK
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # rocprofv3 reports KiB; gfx950: FETCH_SIZE counts 128-B requests at 64 B -> read side doubled
+                traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+                roof["traffic"] = traffic
+                roof["hbm_frac"] = traffic / launch_s / 1e9 / HBM_PEAK_GBS
+            if pmc.get("SQ_WAVE_CYCLES"):
+                wc = pmc["SQ_WAVE_CYCLES"]
+                roof["wave_cycle_shares"] = {"active": pmc.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wait_mem": pmc.get("SQ_WAIT_ANY", 0) / wc,
+                                             "wait_issue": pmc.get("SQ_WAIT_INST_ANY", 0) / wc}
+            if pmc.get("SQ_BUSY_CYCLES"):  # per-SE busy cycles summed over the 32 shader engines
+                roof["effective_clock_ghz"] = pmc["SQ_BUSY_CYCLES"] / 32.0 / launch_s / 1e9
+            roof["counters_per_launch"] = {k: pmc[k] for k in sorted(pmc)}
+        roof.update({
+            "pmc_source": pmc_source, "kernel": kernel + ("<2,false,true>" if engine == "wave" else "<2,false>"),
+            "kernel_resources": pmc_info or None, "avg_launch_ms": avg_launch_ms, "launches": launches,
+            "candidates_scored_per_launch": scored_local / max(launches, 1),
+            "sources_scanned_per_launch": delta["sources_scanned"] / max(launches, 1),
+            # SURVEY.md §8(d) side number: bytes the REFERENCE algorithm would move for the same candidates / sources;
+            # not a bandwidth this kernel uses (its replica state is LDS-resident, the neighbour index is presorted)
+            "algorithmic_reference_bytes_per_launch": alg_bytes / max(launches, 1),
+            "algorithmic_reference_gbps": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+        })
         out = {
             "metric": "moves-evaluated/sec, CVRP-1000 (nearby-list selector, LateAcceptance(400)+AcceptedCount(256))",
             "value": moves_total / elapsed,
@@ -247,30 +493,16 @@ def main():
             "dtype": "int64",
             "data": "synthetic",
             "config": {
-                "workload": f"solverforge-cvrp {args.customers} customers / {args.vehicles} vehicles, nearby-list "
-                            "change+swap union (max_nearby 20), default list policy",
+                "workload": f"solverforge-cvrp {args.customers} customers / {args.vehicles} vehicles, 2-leaf nearby union "
+                            "(nearby list change + nearby list swap, max_nearby 20), LateAcceptance(400) + AcceptedCount(256), "
+                            "SelectionOrder::Random",
                 "replicas_per_gpu": args.replicas,
                 "ls_steps_per_launch": args.ls_steps,
                 "engine": engine,
                 "parallelism": f"portfolio x{world} (independent seeds, {exchange})",
                 "seed": args.seed,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "kernel": kernel,
-                "avg_launch_ms": avg_launch_ms,
-                "launches": launches,
-                "candidates_scored_per_launch": scored_local / max(launches, 1),
-                "sources_scanned_per_launch": delta["sources_scanned"] / max(launches, 1),
-                "algorithmic_bytes_per_launch": alg_bytes / max(launches, 1),
-                "bytes_per_candidate": B_ALG_CANDIDATE,
-                "generation_bytes_per_source": gen_bytes_per_source,
-            },
+            "roofline": roof,
             "extra": {
                 "candidates_scored_per_s": scored_local * world / elapsed,
                 "moves_accepted": delta["moves_accepted"],
@@ -278,10 +510,22 @@ def main():
                 "moves_per_ls_step": moves_local / max(delta["step_count"], 1),
                 "start_score": start_score,
                 "replica0_working_score": replica0_score,
-                "best_score": winner["score"],
+                "best_score_after_timed_region": m1_best,
                 "winner": winner,
             },
         }
+        if solve is not None:
+            out["extra"]["best_score_at_60s"] = {
+                "seconds": args.solve_seconds,
+                "gpu": winner["score"],  # best over every replica of every rank (the portfolio exchange above)
+                "gpu_moves_evaluated": solve.get("moves_evaluated_all_ranks", solve["moves_evaluated"]),
+                "gpu_moves_per_s_rank0": solve["moves_per_s"],
+                "gpu_ls_steps_rank0": solve["ls_steps"],
+                "gpu_launches": solve["launches"],
+                "cpu_oracle": solve.get("cpu_oracle"),
+                "policy": "2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256); work-balanced launches "
+                          f"(sf_solve_moves, {args.solve_budget} candidates per replica per launch)",
+            }
         if not args.no_cpu_baseline:
             cb = cpu_baseline(problem, args.seed, args.warmup * args.ls_steps, args.steps * args.ls_steps,
                               args.cpu_seconds)
@@ -289,22 +533,18 @@ def main():
             out["cpu_baseline"] = cb
             out["extra"]["gpu_over_cpu"] = out["value"] / cb["value"]
             out["extra"]["replica0_matches_cpu_oracle"] = None if ws is None else bool(ws == replica0_score)
-        if args.solve_seconds > 0:
-            t1 = time.perf_counter()
-            while time.perf_counter() - t1 < args.solve_seconds:
-                d.solve_moves(1 << 20, 100_000, sync=True)  # work-balanced launches (sf_solve_moves)
-            out["extra"]["solve_seconds"] = args.solve_seconds
-            out["extra"]["best_score_after_solve"] = list(max(tuple(int(v) for v in s) for s in d.best_scores()))
-            out["extra"]["moves_evaluated_total"] = d.total_stats()["moves_evaluated"]
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-        # torch bundles its own HIP runtime next to the ROCm one this library links: skip the
-        # interpreter's exit-time destructors of the two copies
-        sys.stdout.flush()
-        sys.stderr.flush()
-        d.close()
+    # torch bundles its own HIP runtime next to the ROCm one this library links: skip the interpreter's exit-time
+    # destructors of the two copies; a context abandoned inside a hung RCCL call is not closed either
+    sys.stdout.flush()
+    sys.stderr.flush()
+    if not ctx_abandoned:
+        dx.close()
+    if dist is not None or ctx_abandoned:
         os._exit(0)
 
 

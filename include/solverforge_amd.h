@@ -168,7 +168,14 @@ typedef struct sf_annealing_config {
 typedef enum sf_forager_kind {
     SF_FORAGER_ACCEPTED_COUNT = 0, /* phase/localsearch/forager.rs:157-250 */
     SF_FORAGER_FIRST_ACCEPTED = 1, /* phase/localsearch/forager.rs:252-337 */
-    SF_FORAGER_BEST_SCORE = 2      /* phase/localsearch/forager.rs:339-420 */
+    SF_FORAGER_BEST_SCORE = 2,     /* phase/localsearch/forager.rs:339-420 */
+    /* phase/localsearch/forager/improving.rs:17-107: the step ends at the first accepted candidate that beats the best
+     * score ever seen; otherwise the best accepted candidate of the whole neighbourhood */
+    SF_FORAGER_FIRST_BEST_SCORE_IMPROVING = 3,
+    /* improving.rs:113-227: the step ends at the first accepted candidate that beats the last step score, or at
+     * accepted_count_limit accepted candidates (<= 0 = no limit).  The default forager of precedence / list models
+     * (limit 256) and of grouped scalar models (no limit): default_local_search/policy.rs:63-71 */
+    SF_FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING = 4
 } sf_forager_kind;
 
 /* Search engines of the fused local-search kernel (same results, different GPU mapping):

@@ -26,6 +26,7 @@ LEAF_SUBLIST_SWAP = 256
 LEAF_KOPT = 512
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
+FORAGER_FIRST_BEST_SCORE_IMPROVING, FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING = 3, 4
 UNION_SEQUENTIAL, UNION_ROUND_ROBIN, UNION_ROTATING, UNION_RANDOM, UNION_STRATIFIED = 0, 1, 2, 3, 4
 
 

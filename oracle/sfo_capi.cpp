@@ -136,7 +136,8 @@ int32_t sfo_model_evaluate_each(void* h, int64_t* out_scores4, int64_t* out_coun
     return n;
 }
 
-// acceptor: 0 HillClimbing, 1 LateAcceptance(size).  forager: 0 AcceptedCount(limit), 1 FirstAccepted, 2 BestScore.
+// acceptor: 0 HillClimbing, 1 LateAcceptance(size).  forager: 0 AcceptedCount(limit), 1 FirstAccepted, 2 BestScore,
+// 3 FirstBestScoreImproving, 4 FirstLastStepScoreImproving(limit; <= 0 = None).
 // union_order: 0 Sequential 1 RoundRobin 2 RotatingRoundRobin 3 Random 4 StratifiedRandom; -1 = default policy
 void sfo_model_configure(void* h, int32_t acceptor, int32_t la_size, int32_t forager, int32_t limit,
                          int32_t random_ties, int32_t selection_order, uint32_t leaves, int32_t max_nearby,
@@ -147,7 +148,7 @@ void sfo_model_configure(void* h, int32_t acceptor, int32_t la_size, int32_t for
     else
         m->search.acceptor = std::make_unique<LateAcceptanceAcceptor>((size_t)la_size);
     m->search.forager.kind = (Forager::Kind)forager;
-    m->search.forager.accepted_count_limit = (size_t)limit;
+    m->search.forager.accepted_count_limit = limit > 0 ? (size_t)limit : 0;  // 0 = None (FirstLastStepScoreImproving)
     m->search.forager.best.random_ties = random_ties != 0;
     m->search.selection_order = (SelectionOrder)selection_order;
     m->search.random_seed = random_seed;

@@ -231,13 +231,26 @@ struct BestCandidate {  // forager.rs:70-141
 };
 
 struct Forager {
-    enum Kind { AcceptedCount, FirstAccepted, BestScore } kind = AcceptedCount;
+    // AcceptedCount / FirstAccepted / BestScore: forager.rs:157-420; FirstBestScoreImproving /
+    // FirstLastStepScoreImproving: forager/improving.rs:17-227 (accepted_count_limit 0 = None)
+    enum Kind { AcceptedCount, FirstAccepted, BestScore, FirstBestScoreImproving, FirstLastStepScoreImproving } kind = AcceptedCount;
     size_t accepted_count_limit = 256;
     size_t accepted_count = 0;
     BestCandidate best;
-    void step_started(uint64_t seed) {
+    Score ref_best_score, ref_last_step_score;  // step_started arguments (improving foragers)
+    bool found_improving = false;
+    void step_started(uint64_t seed, const Score& best_score = Score::zero(), const Score& last_step_score = Score::zero()) {
         accepted_count = 0;
         best.reset(seed);
+        ref_best_score = best_score;
+        ref_last_step_score = last_step_score;
+        found_improving = false;
+    }
+    void replace(size_t idx, const Score& sc) {  // BestCandidate::replace (forager.rs:118-124)
+        best.has = true;
+        best.index = idx;
+        best.score = sc;
+        best.equal_count = 1;
     }
     void add_move_index(size_t idx, const Score& sc) {
         switch (kind) {
@@ -256,6 +269,25 @@ struct Forager {
             case BestScore:  // forager.rs:410-412
                 best.consider(idx, sc);
                 return;
+            case FirstBestScoreImproving:  // improving.rs:91-100
+                if (sc > ref_best_score) {
+                    found_improving = true;
+                    replace(idx, sc);
+                    return;
+                }
+                if (found_improving) return;
+                best.consider(idx, sc);
+                return;
+            case FirstLastStepScoreImproving:  // improving.rs:196-211
+                if (found_improving || (accepted_count_limit > 0 && accepted_count >= accepted_count_limit)) return;
+                ++accepted_count;
+                if (sc > ref_last_step_score) {
+                    found_improving = true;
+                    replace(idx, sc);
+                    return;
+                }
+                best.consider(idx, sc);
+                return;
         }
     }
     bool is_quit_early() const {
@@ -266,12 +298,17 @@ struct Forager {
                 return best.has;
             case BestScore:
                 return false;
+            case FirstBestScoreImproving:  // improving.rs:102-104
+                return found_improving;
+            case FirstLastStepScoreImproving:  // improving.rs:213-218
+                return found_improving || (accepted_count_limit > 0 && accepted_count >= accepted_count_limit);
         }
         return false;
     }
-    int64_t limit_for_context() const {
+    int64_t limit_for_context() const {  // LocalSearchForager::accepted_count_limit
         if (kind == AcceptedCount) return (int64_t)accepted_count_limit;
         if (kind == FirstAccepted) return 1;
+        if (kind == FirstLastStepScoreImproving && accepted_count_limit > 0) return (int64_t)accepted_count_limit;
         return -1;
     }
 };
@@ -344,7 +381,8 @@ struct LocalSearch {
     void step() {
         uint64_t step_index = phase_step_index;
         uint64_t step_seed = next_step_seed();
-        forager.step_started(step_seed);
+        // best score ever seen, else the last step score (step.rs:53-58,65)
+        forager.step_started(step_seed, has_best ? best_score : last_step_score, last_step_score);
         acceptor->step_started();
         MoveStreamContext ctx(step_index, step_seed, forager.limit_for_context());
         ctx = ctx.with_selection_order(selection_order);

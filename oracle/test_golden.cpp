@@ -728,7 +728,76 @@ static void simulated_annealing_cases() {
     }
 }
 
+// phase/localsearch/forager/tests.rs: the forager known answers (values re-derived from the assertions)
+static void forager_cases() {
+    auto soft1 = [](int64_t v) { return Score::level(0, v); };
+    auto mk = [&](Forager::Kind k, size_t limit) {
+        Forager f;
+        f.kind = k;
+        f.accepted_count_limit = limit;
+        f.best.random_ties = false;
+        return f;
+    };
+    {  // tests.rs:30-75 accepted_count_forager_retains_only_the_first_strict_best_candidate
+        Forager f = mk(Forager::AcceptedCount, 4);
+        f.step_started(0, soft1(0), soft1(0));
+        f.add_move_index(0, soft1(-10));
+        f.add_move_index(1, soft1(-12));
+        f.add_move_index(2, soft1(-5));
+        f.add_move_index(3, soft1(-5));
+        CHECK("forager.accepted_count_first_strict_best", f.best.has && f.best.index == 2 && f.best.score == soft1(-5));
+    }
+    {  // tests.rs:77-120 test_accepted_count_forager_quits_at_limit
+        Forager f = mk(Forager::AcceptedCount, 3);
+        f.step_started(0, soft1(0), soft1(0));
+        f.add_move_index(0, soft1(-10));
+        bool ok = !f.is_quit_early();
+        f.add_move_index(1, soft1(-5));
+        ok = ok && !f.is_quit_early();
+        f.add_move_index(2, soft1(-8));
+        CHECK("forager.accepted_count_quits_at_limit", ok && f.is_quit_early());
+    }
+    {  // tests.rs:462-499 test_first_best_score_improving_quits_on_improvement
+        Forager f = mk(Forager::FirstBestScoreImproving, 0);
+        f.step_started(0, soft1(-10), soft1(0));
+        f.add_move_index(0, soft1(-15));
+        bool ok = !f.is_quit_early();
+        f.add_move_index(1, soft1(-5));
+        ok = ok && f.is_quit_early();
+        CHECK("forager.first_best_score_improving", ok && f.best.has && f.best.index == 1 && f.best.score == soft1(-5));
+    }
+    {  // tests.rs:501-540 test_first_last_step_improving_quits_on_improvement
+        Forager f = mk(Forager::FirstLastStepScoreImproving, 0);
+        f.step_started(0, soft1(0), soft1(-10));
+        f.add_move_index(0, soft1(-15));
+        bool ok = !f.is_quit_early();
+        f.add_move_index(1, soft1(-5));
+        ok = ok && f.is_quit_early();
+        CHECK("forager.first_last_step_improving", ok && f.best.has && f.best.index == 1 && f.best.score == soft1(-5));
+    }
+    {  // tests.rs:542-587 first_last_step_improving_falls_back_to_accepted_count_limit
+        Forager f = mk(Forager::FirstLastStepScoreImproving, 2);
+        f.step_started(0, soft1(0), soft1(-10));
+        f.add_move_index(0, soft1(-15));
+        bool ok = !f.is_quit_early();
+        f.add_move_index(1, soft1(-12));
+        ok = ok && f.is_quit_early();
+        f.add_move_index(2, soft1(-5));  // released: the limit was reached
+        CHECK("forager.first_last_step_improving_limit", ok && f.best.has && f.best.index == 1 && f.best.score == soft1(-12) &&
+                                                              f.limit_for_context() == 2);
+    }
+    {  // improving.rs:91-100: after an improving candidate every later accepted candidate is released
+        Forager f = mk(Forager::FirstBestScoreImproving, 0);
+        f.step_started(0, soft1(-10), soft1(0));
+        f.add_move_index(0, soft1(-5));
+        f.add_move_index(1, soft1(-20));
+        f.add_move_index(2, soft1(-1));  // a later improving candidate replaces (score > best_score is tested first)
+        CHECK("forager.first_best_score_improving_later_better_replaces", f.best.index == 2 && f.limit_for_context() == -1);
+    }
+}
+
 int main() {
+    forager_cases();
     k_opt_cases();
     simulated_annealing_cases();
     list_reverse_cases();

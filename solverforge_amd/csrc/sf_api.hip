@@ -545,6 +545,8 @@ static void fill_search_params(sf_ctx* ctx, SearchParams& p) {
     p.acceptor = ctx->cfg.acceptor;
     p.forager = ctx->cfg.forager;
     p.limit = ctx->cfg.accepted_count_limit > 0 ? ctx->cfg.accepted_count_limit : 1;
+    // FirstLastStepScoreImprovingForager: accepted_count_limit is an Option (improving.rs:128-137); <= 0 = None
+    if (ctx->cfg.forager == SF_FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING && ctx->cfg.accepted_count_limit <= 0) p.limit = 0;
     p.random_ties = ctx->cfg.random_ties;
     p.order = ctx->cfg.selection_order;
     p.random_seed = ctx->cfg.random_seed;
@@ -819,7 +821,8 @@ int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg) {
     if (cfg->acceptor != SF_ACCEPT_HILL_CLIMBING && cfg->acceptor != SF_ACCEPT_LATE_ACCEPTANCE &&
         cfg->acceptor != SF_ACCEPT_SIMULATED_ANNEALING)
         return fail(ctx, SF_ERR_UNSUPPORTED, "acceptor kind");
-    if (cfg->forager < 0 || cfg->forager > 2) return fail(ctx, SF_ERR_UNSUPPORTED, "forager");
+    if (cfg->forager < SF_FORAGER_ACCEPTED_COUNT || cfg->forager > SF_FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "forager");
     if (cfg->forager == SF_FORAGER_ACCEPTED_COUNT && cfg->accepted_count_limit <= 0)
         return fail(ctx, SF_ERR_INVALID, "AcceptedCountForager: accepted_count_limit must be > 0");
     if (cfg->acceptor == SF_ACCEPT_LATE_ACCEPTANCE && cfg->late_acceptance_size <= 0)

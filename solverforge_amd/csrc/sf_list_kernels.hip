@@ -1420,12 +1420,13 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                 uint32_t pulls = c.pulls, accepted = c.accepted;
                 int has_best = c.has_best;
                 uint64_t equal_count = c.equal_count;
-                ScoreV<L> best, cur, late;
+                ScoreV<L> best, cur, late, forager_best;  // forager_best: best score ever seen at step start (step.rs:53-58)
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) {
                     best.v[kk] = c.best[kk];
                     cur.v[kk] = c.cur[kk];
                     late.v[kk] = c.late[kk];
+                    forager_best.v[kk] = c.best_sol[kk];
                 }
                 uint32_t best_m0 = c.best_m0, best_m1 = c.best_m1;
                 int best_kind = c.best_kind;
@@ -1486,19 +1487,25 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                     SaChunk sach;
                     if (annealing) acc = sa_decide<L>(s_sa, p.sa, doable, sc, cur, lane, sach);
                     uint64_t accmask = __ballot(acc);
-                    uint32_t nconsumed = nvalid;
-                    if (p.forager != 2) {
-                        const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
-                        const uint32_t pre = (uint32_t)__popcll(accmask & lanemask_le(lane));
-                        const uint64_t cutmask = __ballot(acc && pre == remaining);
-                        if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
-                    }
+                    bool improving_pick = false;
+                    const uint32_t nconsumed = forager_chunk_cut<L>(p.forager, (uint32_t)p.limit, accepted, acc, sc,
+                                                                    p.forager == FORAGER_FIRST_BEST_IMPROVING ? forager_best : cur, nvalid, improving_pick);
                     const bool consumed = lane < nconsumed;
                     if (annealing) sa_commit<L>(s_sa, p.sa, sach, nconsumed, lane);
                     acc = acc && consumed;
                     accmask = __ballot(acc);
                     if (accmask) {
-                        if (p.forager == 1) {
+                        if (improving_pick) {  // BestCandidate::replace by the candidate that ends the step
+                            const int sel = (int)nconsumed - 1;
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)shfl_u64((uint64_t)sc.v[kk], sel);
+                            best_m0 = __shfl(m0, sel);
+                            best_m1 = __shfl(m1, sel);
+                            best_kind = (int)__shfl(lf, sel);
+                            if (TRACE && lane == 0) c.best_ti = c.trace_n + (uint64_t)sel;
+                            equal_count = 1;
+                            has_best = 1;
+                        } else if (p.forager == 1) {
                             if (!has_best) {
                                 const int sel = __ffsll((unsigned long long)accmask) - 1;
 #pragma unroll
@@ -1565,7 +1572,7 @@ __global__ __launch_bounds__(1024) void k_list_search(ListModel m, SearchParams 
                     head1 += c1;
                     head0 += nconsumed - c1;
                     pulls += nconsumed;
-                    if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) {
+                    if (forager_quits(p.forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) {
                         done = 1;
                         break;
                     }

@@ -4,6 +4,7 @@
 
 #include "sf_common.h"
 #include "sf_anneal.h"
+#include "sf_forager.h"
 
 namespace sf {
 
@@ -58,8 +59,8 @@ struct SearchParams {
     LeafSpec leaf[MAX_LEAVES];
     int32_t acceptor;     // 0 HC, 1 LA, 2 never (dry run), 3 simulated annealing (state in `sa`)
     int32_t la_size;
-    int32_t forager;      // 0 accepted count, 1 first accepted, 2 best score
-    int32_t limit;
+    int32_t forager;      // sf_forager_kind: 0 accepted count, 1 first accepted, 2 best score, 3 / 4 improving (sf_forager.h)
+    int32_t limit;        // accepted-count limit (forager 4: 0 = none)
     int32_t random_ties;
     int32_t order;        // sf_selection_order
     int32_t dry_run;      // 1: enumerate+score one step, no state change

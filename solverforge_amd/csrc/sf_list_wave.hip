@@ -908,20 +908,30 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 if constexpr (!FAST)
                     if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
                 uint64_t accmask = __ballot(acc);
-                uint32_t nconsumed = nvalid;
-                if (forager != 2) {
-                    const uint32_t remaining = forager == 0 ? (uint32_t)p.limit - accepted : 1u;
-                    const uint32_t pre = mbcnt64(accmask) + (acc ? 1u : 0u);
-                    const uint64_t cutmask = __ballot(acc && pre == remaining);
-                    if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
+                bool improving_pick = false;
+                ScoreV<L> forager_thr = curv;  // FirstLastStepScoreImproving: the last step score
+                if (forager == FORAGER_FIRST_BEST_IMPROVING) {  // the best score ever seen (step.rs:53-58)
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) forager_thr.v[kk] = best_sol[kk];
                 }
+                const uint32_t nconsumed = forager_chunk_cut<L>(forager, (uint32_t)p.limit, accepted, acc, sc, forager_thr, nvalid, improving_pick);
                 const bool consumed = lane < nconsumed;
                 if constexpr (!FAST)
                     if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
                 acc = acc && consumed;
                 accmask = __ballot(acc);
                 if (accmask) {
-                    if (forager == 1) {
+                    if (improving_pick) {  // BestCandidate::replace by the candidate that ends the step (improving.rs:92-95,205-208)
+                        const int sel = (int)nconsumed - 1;
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64(shfl_u64((uint64_t)sc.v[kk], sel));
+                        best_m0 = __shfl(m0, sel);
+                        best_m1 = __shfl(m1, sel);
+                        best_leaf = (int)__shfl(lf, sel);
+                        if (TRACE) best_ti = trace_n + (uint64_t)sel;
+                        equal_count = 1;
+                        has_best = 1;
+                    } else if (forager == 1) {
                         if (!has_best) {
                             const int sel = __ffsll((unsigned long long)accmask) - 1;
 #pragma unroll
@@ -985,7 +995,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 C1.head += c1;
                 C0.head += nconsumed - c1;
                 pulls += nconsumed;
-                if ((forager == 0 && accepted >= (uint32_t)p.limit) || (forager == 1 && has_best)) done = 1;
+                if (forager_quits(forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) done = 1;
             }
             PH(3)
         }

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
             // C1: fill the rings: as many pending candidates as the forager is expected to consume before it
             // quits (quota left x pulls per accept of the last step x 1.5), 8..64, split over the live leaves
             uint32_t spec = 64;
-            if (p.forager != 2) {
+            if (p.forager <= FORAGER_FIRST_ACCEPTED) {
                 const uint32_t want = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
                 const uint64_t est = ((uint64_t)want * prev_pulls * 3u) / (2u * prev_accepted);
                 spec = est >= 64 ? 64u : est < 8 ? 8u : (uint32_t)est;
@@ -809,19 +809,29 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 SaChunk sach;
                 if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
                 uint64_t accmask = __ballot(acc);
-                uint32_t nconsumed = nvalid;
-                if (p.forager != 2) {
-                    const uint32_t remaining = p.forager == 0 ? (uint32_t)p.limit - accepted : 1u;
-                    const uint32_t pre = mbcnt64(accmask) + (acc ? 1u : 0u);
-                    const uint64_t cutmask = __ballot(acc && pre == remaining);
-                    if (cutmask) nconsumed = (uint32_t)__ffsll((unsigned long long)cutmask);
+                bool improving_pick = false;
+                ScoreV<L> forager_thr = curv;  // FirstLastStepScoreImproving: the last step score
+                if (p.forager == FORAGER_FIRST_BEST_IMPROVING) {  // the best score ever seen (step.rs:53-58)
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) forager_thr.v[kk] = best_sol[kk];
                 }
+                const uint32_t nconsumed = forager_chunk_cut<L>(p.forager, (uint32_t)p.limit, accepted, acc, sc, forager_thr, nvalid, improving_pick);
                 const bool consumed = lane < nconsumed;
                 if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
                 acc = acc && consumed;
                 accmask = __ballot(acc);
                 if (accmask) {
-                    if (p.forager == 1) {
+                    if (improving_pick) {  // BestCandidate::replace by the candidate that ends the step (improving.rs:92-95,205-208)
+                        const int sel = (int)nconsumed - 1;
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64(shfl_u64((uint64_t)sc.v[kk], sel));
+                        best_m0 = __shfl(m0, sel);
+                        best_m1 = __shfl(m1, sel);
+                        best_leaf = (int)__shfl(lf, sel);
+                        if (TRACE) best_ti = trace_n + (uint64_t)sel;
+                        equal_count = 1;
+                        has_best = 1;
+                    } else if (p.forager == 1) {
                         if (!has_best) {
                             const int sel = __ffsll((unsigned long long)accmask) - 1;
 #pragma unroll
@@ -883,7 +893,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 head[1] += c1;
                 head[0] += nconsumed - c1;
                 pulls += nconsumed;
-                if ((p.forager == 0 && accepted >= (uint32_t)p.limit) || (p.forager == 1 && has_best)) done = 1;
+                if (forager_quits(p.forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) done = 1;
             }
         }
 

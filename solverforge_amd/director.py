@@ -35,6 +35,8 @@ class AnnealingMode:
 
 class Forager:
     ACCEPTED_COUNT, FIRST_ACCEPTED, BEST_SCORE = 0, 1, 2
+    # forager/improving.rs: quit at the first accepted candidate better than the best-ever / last-step score
+    FIRST_BEST_SCORE_IMPROVING, FIRST_LAST_STEP_SCORE_IMPROVING = 3, 4
 
 
 class Engine:  # sf_engine_kind

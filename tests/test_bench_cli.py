@@ -1,0 +1,48 @@
+"""CPU tests of bench.py's launcher contract: `--gpus N` must never silently run fewer ranks than asked for, and the
+product path must refuse to run without a HIP device (no CPU fallback)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _device_count():
+    import __graft_entry__ as g
+
+    g.build()
+    from solverforge_amd import _lib
+
+    return _lib.load().sf_device_count()
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+
+
+def test_gpus_n_refuses_to_run_with_fewer_devices():
+    n = _device_count()
+    r = _run(["--gpus", str(n + 2), "--steps", "1", "--warmup", "0", "--solve-seconds", "0", "--no-pmc"])
+    assert r.returncode == 2
+    assert b"refusing to run fewer ranks" in r.stderr
+    assert r.stdout.strip() == b""  # no JSON line: nothing to mistake for an N-GPU result
+
+
+def test_gpus_flag_must_match_the_launcher():
+    r = _run(["--gpus", "1", "--steps", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2
+    assert b"refusing to report one as the other" in r.stderr
+
+
+def test_no_device_no_number():
+    if _device_count() > 0:
+        pytest.skip("a HIP device is present")
+    r = _run(["--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert b"SF_ERR_NO_DEVICE" in r.stderr
+    assert r.stdout.strip() == b""

@@ -107,7 +107,9 @@ def test_apply_matches_oracle(oracle):
         assert (d.fresh_score()[0] == o.score()[:2]).all()
 
 
-@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 256), (0, 0, 4), (1, 1, 1), (0, 2, 1)])
+@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 256), (0, 0, 4), (1, 1, 1), (0, 2, 1),
+                                                    # improving foragers (forager/improving.rs): best-ever / last-step, limit 0 = None
+                                                    (1, 3, 0), (1, 4, 0), (1, 4, 6), (0, 4, 3)])
 def test_traced_steps_match_oracle(oracle, acceptor, forager, limit):
     """Per step: consumed candidates in order, scores, accept flags, the committed move, then state."""
     import solverforge_amd as sfa
@@ -120,7 +122,7 @@ def test_traced_steps_match_oracle(oracle, acceptor, forager, limit):
     d.calculate_score()
     d.phase_start()
     o.phase_start()
-    n_steps = 12 if forager == 2 else 40
+    n_steps = 12 if forager in (2, 3) else 40
     for step in range(n_steps):
         gm, gs, gf, gap, gmv = d.solve_step_traced()
         om, os_, of, oap, omv = o.step_traced()

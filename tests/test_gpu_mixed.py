@@ -68,7 +68,7 @@ def test_jobshop_four_leaf_union_order_and_scores(oracle, order):
         assert (ed == od).all() and (es == os_[:, :3]).all()
 
 
-@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 32), (0, 0, 3), (1, 1, 1)])
+@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 32), (0, 0, 3), (1, 1, 1), (1, 3, 0), (1, 4, 0), (1, 4, 9)])
 def test_jobshop_traced_steps(oracle, acceptor, forager, limit):
     import solverforge_amd as sfa
 
@@ -80,7 +80,7 @@ def test_jobshop_traced_steps(oracle, acceptor, forager, limit):
     d.calculate_score()
     d.phase_start()
     o.phase_start()
-    for step in range(30):
+    for step in range(12 if forager == 3 else 30):
         gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
         om, os_, of, oap, omv = o.step_traced()
         assert len(gm) == len(om), step

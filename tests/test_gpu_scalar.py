@@ -74,7 +74,7 @@ def test_graph_step_evaluate_and_apply(oracle):
         assert (d.fresh_score()[0] == o.score()[:2]).all()
 
 
-@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 64), (0, 0, 3), (1, 1, 1), (0, 2, 1)])
+@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 64), (0, 0, 3), (1, 1, 1), (0, 2, 1), (1, 3, 0), (1, 4, 0), (1, 4, 5)])
 def test_graph_traced_steps(oracle, acceptor, forager, limit):
     import solverforge_amd as sfa
 
@@ -86,7 +86,7 @@ def test_graph_traced_steps(oracle, acceptor, forager, limit):
     d.calculate_score()
     d.phase_start()
     o.phase_start()
-    for step in range(10 if forager == 2 else 30):
+    for step in range(10 if forager in (2, 3) else 30):
         gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 17)
         om, os_, of, oap, omv = o.step_traced()
         assert len(gm) == len(om), step
