@@ -30,6 +30,8 @@ struct Fact {
     int rows = 0, cols = 0;
     int64_t max_finite = 0;
     bool symmetric = false;  // matrices: data[i][j] == data[j][i] everywhere
+    bool all_finite = false; // matrices: no negative / UNREACHABLE entry
+    int64_t abs_sum = 0;     // i32 columns: sum of |value| (saturating at 2^62)
 };
 struct ConstraintSpec {
     int kind, desc, var, fact;
@@ -66,6 +68,7 @@ struct sf_ctx {
     int list_desc = -1;
     ListModel lm{};
     NbrIndex nbr{nullptr};  // presorted neighbour index (wave engine)
+    bool lm_small = false;  // every trial delta of the list model fits 32-bit arithmetic (wave engine MODE 2)
     int engine = SF_ENGINE_AUTO;
     // scalar model
     bool has_scalar_model = false;
@@ -275,8 +278,13 @@ int32_t sf_fact_matrix_i64(sf_ctx* ctx, int32_t id, int32_t rows, int32_t cols, 
     f.rows = rows;
     f.cols = cols;
     int64_t mx = 0;
-    for (size_t i = 0; i < (size_t)rows * cols; ++i)
-        if (data[i] >= 0 && data[i] != INT64_MAX && data[i] > mx) mx = data[i];
+    f.all_finite = true;
+    for (size_t i = 0; i < (size_t)rows * cols; ++i) {
+        if (data[i] >= 0 && data[i] != INT64_MAX) {
+            if (data[i] > mx) mx = data[i];
+        } else
+            f.all_finite = false;
+    }
     f.max_finite = mx;
     f.symmetric = rows == cols;
     for (int32_t i = 0; i < rows && f.symmetric; ++i)
@@ -298,6 +306,10 @@ int32_t sf_fact_column_i32(sf_ctx* ctx, int32_t id, int32_t n, const int32_t* da
     Fact f;
     f.type = 2;
     f.rows = n;
+    for (int32_t i = 0; i < n; ++i) {
+        const int64_t a = data[i] < 0 ? -(int64_t)data[i] : (int64_t)data[i];
+        if (f.abs_sum < ((int64_t)1 << 62)) f.abs_sum += a;
+    }
     int32_t* d = nullptr;
     int rc = upload(ctx, &d, data, (size_t)n);
     if (rc) return rc;
@@ -465,6 +477,28 @@ static int build_list_model(sf_ctx* ctx, int d) {
         }
     for (auto& kv : ctx->facts)
         if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat) m.mat_symmetric = kv.second.symmetric ? 1 : 0;
+    {  // 32-bit trial arithmetic (k_list_search_wave MODE 2): every leg finite and < 2^26, |level delta| < 2^30
+        const int64_t lim = (int64_t)1 << 28;
+        auto mag = [](int64_t v) { return v < 0 ? (v == INT64_MIN ? INT64_MAX : -v) : v; };
+        bool ok = m.mat32 != nullptr && m.dist_level >= 0;
+        int64_t max_leg = 0, dem = 0;
+        for (auto& kv : ctx->facts) {
+            if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat) {
+                ok = ok && kv.second.all_finite && kv.second.max_finite < ((int64_t)1 << 26);
+                max_leg = kv.second.max_finite;
+            }
+            if (kv.second.type == 2 && kv.second.d0 == (void*)m.demand) dem = kv.second.abs_sum;
+        }
+        ok = ok && mag(m.dist_weight) < lim && mag(m.dist_weight) * 8 * (max_leg + 1) < ((int64_t)1 << 29);
+        if (m.cap_level >= 0)
+            ok = ok && dem < lim && mag(m.capacity) < lim && mag(m.cap_weight) < lim &&
+                 mag(m.cap_weight) * 2 * (dem + mag(m.capacity) + 1) < ((int64_t)1 << 29);
+        {
+            static const bool off = std::getenv("SF_AMD_NO_SMALL") != nullptr;  // diagnostics: A/B against MODE 1
+            if (off) ok = false;
+        }
+        ctx->lm_small = ok;
+    }
     // presorted neighbour index for the wave engine: every matrix row sorted by (distance, node)
     bool nearby = false;
     for (auto& s : ctx->selectors)
@@ -600,7 +634,7 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
     size_t lds = cv.total * wpb;
     const bool fast = !TRACE && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
                       p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
-    auto kern = fast ? k_list_search_wave<L, false, true> : k_list_search_wave<L, TRACE, false>;
+    auto kern = fast ? (ctx->lm_small ? k_list_search_wave<L, false, 2> : k_list_search_wave<L, false, 1>) : k_list_search_wave<L, TRACE, 0>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SearchParams q = p;
     q.n_launch = n_replicas;

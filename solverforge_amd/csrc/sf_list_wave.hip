@@ -408,6 +408,113 @@ __device__ unsigned long long g_phase[8];
 #define PH_DUMP
 #endif
 
+// ---- SMALL mode helpers (MODE 2) --------------------------------------------------------------------------------
+// wave64 maximum of an int32 over the DPP network (row shifts + row broadcasts, like wave_incl_scan); all lanes active.
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+    const int lo = (int)0x80000000;
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = max(v, __builtin_amdgcn_update_dpp(lo, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <int L>
+__device__ __forceinline__ bool small_ge(const int32_t (&a)[L], const int32_t (&b)[L]) {  // lexicographic a >= b
+    bool ge = true;
+#pragma unroll
+    for (int k = L - 1; k >= 0; --k) ge = a[k] > b[k] || (a[k] == b[k] && ge);
+    return ge;
+}
+template <int L>
+__device__ __forceinline__ bool small_ge0(const int32_t (&a)[L]) {  // lexicographic a >= 0
+    bool ge = true;
+#pragma unroll
+    for (int k = L - 1; k >= 0; --k) ge = a[k] > 0 || (a[k] == 0 && ge);
+    return ge;
+}
+__device__ __forceinline__ int32_t clamp_i64_to_i32(int64_t v) {
+    return v > 0x7FFFFFFFll ? 0x7FFFFFFF : v < -0x7FFFFFFFll - 1 ? (int32_t)0x80000000 : (int32_t)v;
+}
+
+// Trial delta of a ListChange / ListSwap candidate in 32-bit arithmetic: the same at-most-eight matrix legs as
+// eval_list_move_legs, laid out as four "plus" and four "minus" legs so no lane multiplies by a sign, gathered from
+// the compact u32 matrix through 32-bit byte offsets; every leg finite (host-checked), sums < 2^30.
+// dv[k] = change of score level k.  Returns doable.
+template <int L>
+__device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const uint16_t* visits, const uint32_t* off, const int64_t* load,
+                                                     bool chg, uint32_t a, uint32_t i, uint32_t b, uint32_t j, int32_t (&dv)[L]) {
+#pragma unroll
+    for (int k = 0; k < L; ++k) dv[k] = 0;
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    const uint32_t ob = off[b], lb = off[b + 1] - ob;
+    const bool intra = a == b;
+    if (chg) {  // move/list_kernel/change.rs:44-71
+        if (i >= la || j > lb || (intra && (j == i || j == i + 1))) return false;
+    } else {  // move/list_kernel/swap.rs:30-56
+        if (i >= la || j >= lb || (intra && i == j)) return false;
+    }
+    if (!chg && intra && i > j) {
+        const uint32_t t = i;
+        i = j;
+        j = t;
+    }
+    const uint32_t depot = (uint32_t)m.depot;
+    const uint32_t P = oa + i, Q = ob + j;
+    const uint32_t x = visits[P];
+    const uint32_t pa = i > 0 ? (uint32_t)visits[P - 1] : depot;
+    const uint32_t na = i + 1 < la ? (uint32_t)visits[P + 1] : depot;
+    const uint32_t vq = j < lb ? (uint32_t)visits[Q] : depot;  // change: right neighbour of the slot; swap: y
+    const uint32_t pb = j > 0 ? (uint32_t)visits[Q - 1] : depot;
+    const uint32_t nb = j + 1 < lb ? (uint32_t)visits[Q + 1] : depot;
+    if (!chg && x == vq) return false;
+    const bool adj = !chg && intra && j == i + 1;
+    const bool ca = chg || adj;
+    const bool src_single = la == 1, dst_empty = !intra && lb == 0;
+    // plus legs P0..P3, minus legs M0..M3 (change | swap | adjacent swap):
+    //   P0 (pa,na)* | (pa,y) | (pa,y)      M0 (pa,x)  | (pa,x) | (pa,x)
+    //   P1 (pb,x)   | (y,na) | (y,x)       M1 (x,na)  | (x,na) | (x,y)
+    //   P2 (x,vq)   | (pb,x) | (x,nb)      M2 (pb,vq)*| (pb,y) | (y,nb)
+    //   P3   -      | (x,nb) |   -         M3   -     | (y,nb) |   -          (* absent for a single-element source /
+    //                                                                            an empty destination route)
+    const uint32_t dim4 = (uint32_t)m.dim * 4u;
+    auto leg = [&](uint32_t f, uint32_t t) -> uint32_t {
+        const uint32_t byte_off = f * dim4 + t * 4u;  // dim <= 16384: < 2^30
+        return *(const uint32_t*)((const char*)m.mat32 + byte_off);
+    };
+    const uint32_t p0 = leg(pa, chg ? na : vq);
+    const uint32_t p1 = leg(chg ? pb : vq, ca ? x : na);
+    const uint32_t p2 = leg(ca ? x : pb, chg ? vq : (adj ? nb : x));
+    const uint32_t p3 = leg(x, nb);
+    const uint32_t m0 = leg(pa, x);
+    const uint32_t m1 = leg(x, adj ? vq : na);
+    const uint32_t m2 = leg(adj ? vq : pb, adj ? nb : vq);
+    const uint32_t m3 = leg(vq, nb);
+    int32_t d_cap = 0;
+    if (m.cap_level >= 0) {
+        const int32_t dx = m.demand[x];
+        const int32_t dy = chg ? 0 : m.demand[vq];
+        const int32_t cap = (int32_t)m.capacity;
+        const int32_t la0 = (int32_t)load[a], lb0 = (int32_t)load[b];
+        const int32_t la1 = la0 - dx + dy, lb1 = lb0 - dy + dx;
+        d_cap = max(la1 - cap, 0) + max(lb1 - cap, 0) - max(la0 - cap, 0) - max(lb0 - cap, 0);
+        d_cap = intra ? 0 : d_cap;
+    }
+    const uint32_t plus = ((chg && src_single) ? 0u : p0) + p1 + p2 + (ca ? 0u : p3);
+    const uint32_t minus = m0 + m1 + ((chg && dst_empty) ? 0u : m2) + (ca ? 0u : m3);
+    const int32_t d_dist = (int32_t)(plus - minus);
+    const int32_t cw = (int32_t)m.cap_weight, dw = (int32_t)m.dist_weight;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {  // penalties: score level -= weight * delta(penalty sum)
+        int32_t v = 0;
+        if (k == m.cap_level) v -= cw * d_cap;
+        if (k == m.dist_level) v -= dw * d_dist;
+        dv[k] = v;
+    }
+    return true;
+}
+
 // Per-leaf cursor state of one step.  The NEXT source of the leaf is always resolved ahead of use
 // and the first 64-entry chunk of its neighbour row is already in flight (`pk`), so the global
 // load latency hides behind the other leaf's generation and the replay batches.
@@ -421,13 +528,19 @@ struct LeafCursor {
     uint32_t pk;          // per lane: prefetched entry of chunk 0 of the next source's neighbour row
 };
 
-// FAST: compile-time specialisation for the default list policy (nearby change + nearby swap union,
+// MODE 1 (FAST): compile-time specialisation for the default list policy (nearby change + nearby swap union,
 // LateAcceptance + AcceptedCount, committed steps) — fewer live scalars and branches in the hot loops.
-template <int L, bool TRACE, bool FAST>
+// MODE 2 (FAST + SMALL): additionally every quantity of a trial delta fits 32 bits (host-checked: all matrix legs finite
+// and < 2^26, demands / capacity / weights bounded so that |level delta| < 2^30): the replay scores, accepts and forages
+// in DELTA space — a candidate is the int32 change of each score level against the step's (wave-uniform) current score,
+// `score >= late` becomes `delta >= late - current` with the right-hand side clamped once per step — so no lane carries a
+// 64-bit score vector; the committed score is advanced by the winner's delta.  Same decisions bit for bit.
+template <int L, bool TRACE, int MODE>
 #ifndef SF_WAVES_PER_EU
 #define SF_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
+    constexpr bool FAST = MODE >= 1, SMALL = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));  // 1..WPB replicas per workgroup
@@ -558,6 +671,14 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         uint32_t best_m0 = 0, best_m1 = 0;
         int best_leaf = 0;
         uint64_t best_ti = 0;  // trace ordinal (within the step) of the forager's current pick
+        // MODE 2: the LateAcceptance threshold and the forager's best as level deltas against `cur` (wave-uniform);
+        // |candidate delta| < 2^30, so clamping the threshold to int32 keeps every comparison exact
+        int32_t late_d[L], best_d[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            late_d[k] = SMALL ? clamp_i64_to_i32(wsub(late.v[k], cur[k])) : 0;
+            best_d[k] = 0;
+        }
         const uint32_t total = uni(s_off[V]);
         // union: >1 leaf => StratifiedRandom, equal weights (vec_union.rs:229-245); with two children
         // the stride is always 1, so the order is first, other, first, ...
@@ -883,89 +1004,151 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 }
                 const bool valid = lane < nvalid;
                 uint32_t m0 = 0, m1 = 0;
-                ListDelta dl{0, 0, false};
-                if (valid) {
-                    const uint32_t qi = idx & RCM;
-                    const uint32_t* rq = ring + ((size_t)lf * cv.rc + qi) * 2;
-                    m0 = rq[0];
-                    m1 = rq[1];
-                    const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
-                    dl = eval_list_move_legs<uint16_t, FAST>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j);
-                }
-                const ScoreV<L> sc = apply_delta<L>(m, cur, dl);
-                ScoreV<L> curv;
+                ScoreV<L> sc;
 #pragma unroll
-                for (int kk = 0; kk < L; ++kk) curv.v[kk] = cur[kk];
-                const bool doable = valid && dl.doable;
-                bool acc = false;
-                if (doable) {
-                    if (acceptor == 0)
-                        acc = score_cmp<L>(sc, curv) > 0;
-                    else if (acceptor == 1)
-                        acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
-                }
-                SaChunk sach;
-                if constexpr (!FAST)
-                    if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
-                uint64_t accmask = __ballot(acc);
-                bool improving_pick = false;
-                ScoreV<L> forager_thr = curv;  // FirstLastStepScoreImproving: the last step score
-                if (forager == FORAGER_FIRST_BEST_IMPROVING) {  // the best score ever seen (step.rs:53-58)
+                for (int kk = 0; kk < L; ++kk) sc.v[kk] = 0;
+                bool doable = false, acc = false, consumed = false, improving_pick = false;
+                uint64_t accmask = 0;
+                uint32_t nconsumed = nvalid;
+                if constexpr (SMALL) {
+                    // ---- delta-space replay (MODE 2): int32 level deltas against the step's current score ----
+                    int32_t dv[L];
 #pragma unroll
-                    for (int kk = 0; kk < L; ++kk) forager_thr.v[kk] = best_sol[kk];
-                }
-                const uint32_t nconsumed = forager_chunk_cut<L>(forager, (uint32_t)p.limit, accepted, acc, sc, forager_thr, nvalid, improving_pick);
-                const bool consumed = lane < nconsumed;
-                if constexpr (!FAST)
-                    if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
-                acc = acc && consumed;
-                accmask = __ballot(acc);
-                if (accmask) {
-                    if (improving_pick) {  // BestCandidate::replace by the candidate that ends the step (improving.rs:92-95,205-208)
-                        const int sel = (int)nconsumed - 1;
+                    for (int kk = 0; kk < L; ++kk) dv[kk] = 0;
+                    if (valid) {
+                        const uint32_t qi = idx & RCM;
+                        const uint32_t* rq = ring + ((size_t)lf * cv.rc + qi) * 2;
+                        m0 = rq[0];
+                        m1 = rq[1];
+                        const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
+                        doable = eval_list_move_small<L>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j, dv);
+                    }
+                    // LateAcceptance: score >= last step score || score >= late score (late_acceptance.rs:89-125)
+                    acc = doable && (small_ge0<L>(dv) || small_ge<L>(dv, late_d));
+                    accmask = __ballot(acc);
+                    {  // AcceptedCount quota (forager.rs:232-239)
+                        const uint32_t remaining = (uint32_t)p.limit - accepted;
+                        const uint32_t pre = mbcnt64(accmask) + (acc ? 1u : 0u);
+                        const uint64_t cutmask = __ballot(acc && pre == remaining);
+                        nconsumed = cutmask ? (uint32_t)__ffsll((unsigned long long)cutmask) : nvalid;
+                    }
+                    consumed = lane < nconsumed;
+                    acc = acc && consumed;
+                    accmask = __ballot(acc);
+                    if (accmask && (!has_best || __ballot(acc && small_ge<L>(dv, best_d)))) {
+                        // lexicographic maximum of the accepted lanes, level by level
+                        int32_t M[L];
+                        bool in_max = acc;
 #pragma unroll
-                        for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64(shfl_u64((uint64_t)sc.v[kk], sel));
-                        best_m0 = __shfl(m0, sel);
-                        best_m1 = __shfl(m1, sel);
-                        best_leaf = (int)__shfl(lf, sel);
-                        if (TRACE) best_ti = trace_n + (uint64_t)sel;
-                        equal_count = 1;
-                        has_best = 1;
-                    } else if (forager == 1) {
-                        if (!has_best) {
-                            const int sel = __ffsll((unsigned long long)accmask) - 1;
-#pragma unroll
-                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64(shfl_u64((uint64_t)sc.v[kk], sel));
-                            best_m0 = __shfl(m0, sel);
-                            best_m1 = __shfl(m1, sel);
-                            best_leaf = (int)__shfl(lf, sel);
-                            if (TRACE) best_ti = trace_n + (uint64_t)sel;
-                            has_best = 1;
+                        for (int kk = 0; kk < L; ++kk) {
+                            M[kk] = wave_max_i32(in_max ? dv[kk] : (int32_t)0x80000000);
+                            in_max = in_max && dv[kk] == M[kk];
                         }
-                    } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
-                        const ScoreV<L> M = wave_max_score<L>(sc, acc);
-                        const int cm = has_best ? score_cmp<L>(M, best) : 1;
-                        if (cm >= 0) {
-                            const bool newmax = cm > 0;
+                        const bool ge = !has_best || small_ge<L>(M, best_d);
+                        if (ge) {
+                            const bool newmax = !has_best || !small_ge<L>(best_d, M);
                             const uint64_t eq_base = newmax ? 0 : equal_count;
-                            const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
-                            const uint64_t eq = __ballot(in_eq);
+                            const uint64_t eq = __ballot(in_max);
                             const uint32_t rank = mbcnt64(eq) + 1u;
                             const uint64_t cntq = eq_base + rank;
-                            const bool pick = in_eq && ((newmax && rank == 1) ||
-                                                        (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
+                            const bool pick = in_max && ((newmax && rank == 1) ||
+                                                         (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
                             const uint64_t pm = __ballot(pick);
                             if (pm) {
                                 const int sel = 63 - __clzll((unsigned long long)pm);
                                 best_m0 = __shfl(m0, sel);
                                 best_m1 = __shfl(m1, sel);
                                 best_leaf = (int)__shfl(lf, sel);
-                                if (TRACE) best_ti = trace_n + (uint64_t)sel;
                             }
 #pragma unroll
-                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64((uint64_t)M.v[kk]);
+                            for (int kk = 0; kk < L; ++kk) best_d[kk] = M[kk];
                             equal_count = eq_base + (uint64_t)__popcll(eq);
                             has_best = 1;
+                        }
+                    }
+                } else {
+                    ListDelta dl{0, 0, false};
+                    if (valid) {
+                        const uint32_t qi = idx & RCM;
+                        const uint32_t* rq = ring + ((size_t)lf * cv.rc + qi) * 2;
+                        m0 = rq[0];
+                        m1 = rq[1];
+                        const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
+                        dl = eval_list_move_legs<uint16_t, FAST>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j);
+                    }
+                    sc = apply_delta<L>(m, cur, dl);
+                    ScoreV<L> curv;
+    #pragma unroll
+                    for (int kk = 0; kk < L; ++kk) curv.v[kk] = cur[kk];
+                    doable = valid && dl.doable;
+                    if (doable) {
+                        if (acceptor == 0)
+                            acc = score_cmp<L>(sc, curv) > 0;
+                        else if (acceptor == 1)
+                            acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
+                    }
+                    SaChunk sach;
+                    if constexpr (!FAST)
+                        if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
+                    accmask = __ballot(acc);
+                    ScoreV<L> forager_thr = curv;  // FirstLastStepScoreImproving: the last step score
+                    if (forager == FORAGER_FIRST_BEST_IMPROVING) {  // the best score ever seen (step.rs:53-58)
+    #pragma unroll
+                        for (int kk = 0; kk < L; ++kk) forager_thr.v[kk] = best_sol[kk];
+                    }
+                    nconsumed = forager_chunk_cut<L>(forager, (uint32_t)p.limit, accepted, acc, sc, forager_thr, nvalid, improving_pick);
+                    consumed = lane < nconsumed;
+                    if constexpr (!FAST)
+                        if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
+                    acc = acc && consumed;
+                    accmask = __ballot(acc);
+                    if (accmask) {
+                        if (improving_pick) {  // BestCandidate::replace by the candidate that ends the step (improving.rs:92-95,205-208)
+                            const int sel = (int)nconsumed - 1;
+    #pragma unroll
+                            for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64(shfl_u64((uint64_t)sc.v[kk], sel));
+                            best_m0 = __shfl(m0, sel);
+                            best_m1 = __shfl(m1, sel);
+                            best_leaf = (int)__shfl(lf, sel);
+                            if (TRACE) best_ti = trace_n + (uint64_t)sel;
+                            equal_count = 1;
+                            has_best = 1;
+                        } else if (forager == 1) {
+                            if (!has_best) {
+                                const int sel = __ffsll((unsigned long long)accmask) - 1;
+    #pragma unroll
+                                for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64(shfl_u64((uint64_t)sc.v[kk], sel));
+                                best_m0 = __shfl(m0, sel);
+                                best_m1 = __shfl(m1, sel);
+                                best_leaf = (int)__shfl(lf, sel);
+                                if (TRACE) best_ti = trace_n + (uint64_t)sel;
+                                has_best = 1;
+                            }
+                        } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
+                            const ScoreV<L> M = wave_max_score<L>(sc, acc);
+                            const int cm = has_best ? score_cmp<L>(M, best) : 1;
+                            if (cm >= 0) {
+                                const bool newmax = cm > 0;
+                                const uint64_t eq_base = newmax ? 0 : equal_count;
+                                const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
+                                const uint64_t eq = __ballot(in_eq);
+                                const uint32_t rank = mbcnt64(eq) + 1u;
+                                const uint64_t cntq = eq_base + rank;
+                                const bool pick = in_eq && ((newmax && rank == 1) ||
+                                                            (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
+                                const uint64_t pm = __ballot(pick);
+                                if (pm) {
+                                    const int sel = 63 - __clzll((unsigned long long)pm);
+                                    best_m0 = __shfl(m0, sel);
+                                    best_m1 = __shfl(m1, sel);
+                                    best_leaf = (int)__shfl(lf, sel);
+                                    if (TRACE) best_ti = trace_n + (uint64_t)sel;
+                                }
+    #pragma unroll
+                                for (int kk = 0; kk < L; ++kk) best.v[kk] = (int64_t)uni64((uint64_t)M.v[kk]);
+                                equal_count = eq_base + (uint64_t)__popcll(eq);
+                                has_best = 1;
+                            }
                         }
                     }
                 }
@@ -1002,6 +1185,10 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         PH(4)
 
         // ---- (D) commit the forager's pick (step.rs:122-221) ----------------------------------
+        if constexpr (SMALL) {
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) best.v[kk] = wadd(cur[kk], (int64_t)best_d[kk]);
+        }
         const bool applied = has_best && !dry_run;
         if (applied) {
             if (best_pending) {
