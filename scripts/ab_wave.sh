@@ -2,7 +2,7 @@
 # A/B of wave-kernel variants on the GPU box: parity tests of the list engines, then short bench lines.
 # Usage: bash scripts/ab_wave.sh <tag> [lib1.so lib2.so ...]   (default: the in-tree library, MODE 2 vs SF_AMD_NO_SMALL=1)
 tag=${1:-ab}; shift
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O; cd $R; [ -x build/exp/dpp_run ] && build/exp/dpp_run
 timeout 600 python -m pytest tests/test_gpu_cvrp.py tests/test_gpu_budget.py tests/test_gpu_foragers.py -x -q -m gpu > $O/tests.log 2>&1; tail -3 $O/tests.log
 B="python bench.py --no-pmc --solve-seconds 0 --steps 20 --warmup 5"
 if [ $# -eq 0 ]; then

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__
 
 // LDS carve of ONE replica (bytes); mirrored on the host.
 struct WCarve {
-    size_t load, off, node, ring, visits, slotbase, routeat, rankof, spvec, total;
+    size_t load, off, node, ring, visits, rtab, routeat, total;
     uint32_t rc;  // ring capacity per leaf
     __host__ __device__ WCarve(int V, int n_cap, int dim, int max_k) {
         rc = max_k <= 32 ? RC_SMALL : RC_MAX;
@@ -115,14 +115,10 @@ struct WCarve {
         o = align_up(o + sizeof(uint32_t) * 2 * rc * MAX_LEAVES, 16);
         visits = o;
         o = align_up(o + sizeof(uint16_t) * n_cap, 16);
-        slotbase = o;
-        o = align_up(o + sizeof(uint16_t) * (V + 1) * MAX_LEAVES, 16);
+        rtab = o;  // [leaf][route] u32: rank of the route in the leaf's entity order | first destination slot ordinal << 16
+        o = align_up(o + sizeof(uint32_t) * V * MAX_LEAVES, 16);
         routeat = o;
         o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
-        rankof = o;
-        o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
-        spvec = o;
-        o = align_up(o + sizeof(uint16_t) * 64 * MAX_LEAVES, 16);
         total = o;
     }
 };
@@ -145,6 +141,37 @@ __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot,
     const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
     const uint32_t rk = ro[r2];
     const uint32_t inter_ord = ORD_INTER_BASE + (uint32_t)sb[rk] + dp;
+    const bool intra = r2 == se;
+    const uint32_t end_pay = (r2 << 16) | len2;
+    NearbyItem it;
+    if (is_change) {  // nearby_change.rs:133-195
+        const bool v0 = !intra || (dp != sp && dp != sp + 1);
+        const bool v1 = dp + 1 == len2 && (!intra || len != sp + 1);  // end slot `len` probes element len-1
+        it.w = some ? (uint32_t)v0 + (uint32_t)v1 : 0u;
+        it.ord = intra ? (v0 ? dp : len) : inter_ord;
+        it.pay0 = v0 ? slot : end_pay;
+        it.pay1 = end_pay;
+    } else {  // nearby_swap.rs: intra partners after the source, inter only higher-ranked entities
+        const bool v = intra ? dp > sp : rk > k;
+        it.w = (some && v) ? 1u : 0u;
+        it.ord = intra ? dp : inter_ord;
+        it.pay0 = slot;
+        it.pay1 = 0;
+    }
+    return it;
+}
+
+// Same item with the per-route facts read from ONE packed table (wave engine): rt[route] = rank of the route in the
+// leaf's entity order | ordinal of the route's first destination slot << 16 — one LDS gather instead of the dependent
+// pair rank_of[route] -> slot_base[rank].
+__device__ __forceinline__ NearbyItem nearby_item_rt(bool is_change, uint32_t slot, uint32_t se, uint32_t sp,
+                                                     uint32_t len, uint32_t k, const uint32_t* s_off, const uint32_t* rt) {
+    const bool some = slot != NODE_NONE;
+    const uint32_t r2 = some ? slot >> 16 : 0u, dp = slot & 0xFFFFu;
+    const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
+    const uint32_t t = rt[r2];
+    const uint32_t rk = t & 0xFFFFu;
+    const uint32_t inter_ord = ORD_INTER_BASE + (t >> 16) + dp;
     const bool intra = r2 == se;
     const uint32_t end_pay = (r2 << 16) | len2;
     NearbyItem it;
@@ -486,15 +513,23 @@ __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const u
     const uint32_t p0 = leg(pa, chg ? na : vq);
     const uint32_t p1 = leg(chg ? pb : vq, ca ? x : na);
     const uint32_t p2 = leg(ca ? x : pb, chg ? vq : (adj ? nb : x));
+#ifdef SF_PROBE_HALF_LEGS  // perf probe only (wrong results): four matrix gathers instead of eight
+    const uint32_t p3 = x + nb, m0 = pa + x, m1 = x + na, m3 = vq + nb;
+#else
     const uint32_t p3 = leg(x, nb);
     const uint32_t m0 = leg(pa, x);
     const uint32_t m1 = leg(x, adj ? vq : na);
-    const uint32_t m2 = leg(adj ? vq : pb, adj ? nb : vq);
     const uint32_t m3 = leg(vq, nb);
+#endif
+    const uint32_t m2 = leg(adj ? vq : pb, adj ? nb : vq);
     int32_t d_cap = 0;
     if (m.cap_level >= 0) {
+#ifdef SF_PROBE_NO_DEMAND  // perf probe only (wrong results): how much do the two demand gathers cost?
+        const int32_t dx = 3, dy = chg ? 0 : 5;
+#else
         const int32_t dx = m.demand[x];
         const int32_t dy = chg ? 0 : m.demand[vq];
+#endif
         const int32_t cap = (int32_t)m.capacity;
         const int32_t la0 = (int32_t)load[a], lb0 = (int32_t)load[b];
         const int32_t la1 = la0 - dx + dy, lb1 = lb0 - dy + dx;
@@ -526,6 +561,7 @@ struct LeafCursor {
     uint32_t vk, vbase;        // entity rank / offset base the leaf's spvec holds (0xFFFFFFFF = none)
     int ex;               // exhausted (union scheduler)
     uint32_t pk;          // per lane: prefetched entry of chunk 0 of the next source's neighbour row
+    uint32_t pv;          // per lane: (source position | source element << 16) of offset vbase + lane of entity rank vk
 };
 
 // MODE 1 (FAST): compile-time specialisation for the default list policy (nearby change + nearby swap union,
@@ -570,10 +606,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
     uint32_t* node_slot = (uint32_t*)(mem + cv.node);
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][rc][2]
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
-    uint16_t* slot_base = (uint16_t*)(mem + cv.slotbase);
-    uint16_t* route_at = (uint16_t*)(mem + cv.routeat);
-    uint16_t* rank_of = (uint16_t*)(mem + cv.rankof);
-    uint16_t* spvec = (uint16_t*)(mem + cv.spvec);  // [leaf][64] source positions of the current entity
+    uint32_t* rtab = (uint32_t*)(mem + cv.rtab);      // [leaf][route] rank | first slot ordinal << 16
+    uint16_t* route_at = (uint16_t*)(mem + cv.routeat);  // [leaf][rank] -> route
 
     uint32_t* g_visits = m.visits + (size_t)r * m.n_cap;
     uint32_t* g_off = m.off + (size_t)r * (V + 1);
@@ -687,27 +721,31 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         // resolve the source at cursor (k, o) of leaf l and put its first key chunk in flight
         auto resolve = [&](LeafCursor& c, int l) {
             const uint16_t* ra = route_at + l * V;
-            uint32_t k = c.k, o = c.o, se = 0, len = 0;
-            for (;;) {  // skip empty routes (left > 0 guarantees a source exists)
-                se = uni((uint32_t)ra[k]);
-                len = uni(s_off[se + 1] - s_off[se]);
-                if (o < len) break;
-                ++k;
-                o = 0;
+            uint32_t k = c.k, o = c.o, se = c.se, len = c.len;
+            if (k != c.vk || o >= len) {  // a new entity: its list owner and length (skip empty routes; left > 0
+                                          // guarantees a source exists)
+                for (;;) {
+                    se = uni((uint32_t)ra[k]);
+                    len = uni(s_off[se + 1] - s_off[se]);
+                    if (o < len) break;
+                    ++k;
+                    o = 0;
+                }
             }
-            uint16_t* spv = spvec + l * 64;
             if (k != c.vk || (o & ~63u) != c.vbase) {
-                // source positions of 64 consecutive offsets of this entity, one per lane
+                // 64 consecutive offsets of this entity, one per lane: source position and source element, kept in a
+                // register (`pv` = position | element << 16); a source is then one v_readlane away, no LDS round trip
                 const uint64_t src_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_SOURCE : SALT_NEARBY_SWAP_SOURCE) ^
                                           (uint64_t)se ^ (l ? desc1 : desc0);
                 const uint32_t oo = (o & ~63u) + lane;
-                spv[lane] = (uint16_t)(oo < len ? ctx.selection_index(oo, len, src_salt) : 0u);
+                const uint32_t spl = oo < len ? ctx.selection_index(oo, len, src_salt) : 0u;
+                const uint32_t sxl = oo < len ? (uint32_t)s_visits[s_off[se] + spl] : 0u;
+                c.pv = spl | (sxl << 16);
                 c.vk = k;
                 c.vbase = o & ~63u;
-                wave_sync();
             }
-            const uint32_t sp = uni((uint32_t)spv[o & 63u]);
-            const uint32_t sx = uni((uint32_t)s_visits[s_off[se] + sp]);
+            const uint32_t pvv = (uint32_t)__builtin_amdgcn_readlane((int)c.pv, (int)(o & 63u));
+            const uint32_t sp = pvv & 0xFFFFu, sx = pvv >> 16;
             c.k = k;
             c.o = o;
             c.se = se;
@@ -720,8 +758,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
 
         PH(0)
         // ---- (B) per-leaf entity order tables (slot.rs:468-499) --------------------------------
-        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, NBR_END};
-        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, n_leaves > 1 ? 0 : 1, NBR_END};
+        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, NBR_END, 0};
+        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, n_leaves > 1 ? 0 : 1, NBR_END, 0};
         for (int l = 0; l < n_leaves; ++l) {
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
@@ -732,27 +770,20 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
             pst = uni(pst);
             psd = uni(psd);
             uint16_t* ra = route_at + l * V;
-            uint16_t* ro = rank_of + l * V;
-            uint16_t* sb = slot_base + l * (V + 1);
-            for (uint32_t k = lane; k < (uint32_t)V; k += 64) {
-                const uint32_t e = fastmod_u64((uint64_t)pst + (uint64_t)k * psd, fm_V);
-                ra[k] = (uint16_t)e;
-                ro[e] = (uint16_t)k;
-            }
-            wave_sync();
-            uint32_t carry = 0;  // slot_base[k] = sum_{k'<k} (len(route_at[k']) + 1)
+            uint32_t* rt = rtab + l * V;
+            uint32_t carry = 0;  // first slot ordinal of rank k = sum_{k'<k} (len(route_at[k']) + 1)
             for (uint32_t base = 0; base < (uint32_t)V; base += 64) {
                 const uint32_t k = base + lane;
-                uint32_t v = 0;
+                uint32_t v = 0, e = 0;
                 if (k < (uint32_t)V) {
-                    const uint32_t e = ra[k];
+                    e = fastmod_u64((uint64_t)pst + (uint64_t)k * psd, fm_V);
+                    ra[k] = (uint16_t)e;
                     v = s_off[e + 1] - s_off[e] + 1;
                 }
                 const uint32_t inc = wave_incl_scan(v);
-                if (k < (uint32_t)V) sb[k] = (uint16_t)(carry + inc - v);
+                if (k < (uint32_t)V) rt[e] = k | ((carry + inc - v) << 16);
                 carry += __shfl(inc, 63);
             }
-            if (lane == 0) sb[V] = (uint16_t)carry;
         }
         wave_sync();
         if (total > 0) {
@@ -773,8 +804,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
             auto gen_rest = [&](int l, uint32_t se, uint32_t sp, uint32_t len, uint32_t k, uint32_t sx, uint32_t tl,
                                 uint32_t key, uint32_t base, uint32_t need, uint32_t emitted) -> uint32_t {
                 const bool is_change = l ? chg1 : chg0;
-                const uint16_t* ro = rank_of + l * V;
-                const uint16_t* sb = slot_base + l * (V + 1);
+                const uint32_t* rt = rtab + l * V;
                 uint32_t* rq = ring + (size_t)l * cv.rc * 2;
                 const uint16_t* rowk = nb.keys + (size_t)sx * dim;
                 const uint32_t mv0 = (se << 16) | sp;
@@ -783,7 +813,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                     const uint64_t havemask = __ballot(have);
                     if (havemask == 0) break;  // finite entries of the row exhausted
                     NearbyItem it{0u, 0u, 0u, 0u};
-                    if (have) it = nearby_item(is_change, node_slot[key & NBR_NODE_MASK], se, sp, len, k, s_off, sb, ro);
+                    if (have) it = nearby_item_rt(is_change, node_slot[key & NBR_NODE_MASK], se, sp, len, k, s_off, rt);
                     // equal-distance groups are contiguous lane ranges; the index marks entries that
                     // continue the previous entry's distance
                     const uint64_t startmask = __ballot(have && (lane == 0 || !(key & NBR_SAME_FLAG)));
@@ -800,7 +830,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                             uint64_t hk = 0;
                             if (ky != NBR_END) {
                                 const uint32_t y2 = ky & NBR_NODE_MASK;
-                                i2 = nearby_item(is_change, node_slot[y2], se, sp, len, k, s_off, sb, ro);
+                                i2 = nearby_item_rt(is_change, node_slot[y2], se, sp, len, k, s_off, rt);
                                 hk = (uint64_t)m.mat[(size_t)sx * dim + y2] << 24;  // finite by construction of the index
                             }
                             if (!__ballot(ky != NBR_END)) break;
@@ -829,8 +859,11 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                         if (nonstart) {
                             const uint32_t packed = (it.ord << 2) | wc;
                             uint64_t run = nonstart;  // bit t: lanes t-d .. t are one group
+                            uint32_t p_dn = packed, p_up = packed;
                             for (uint32_t d = 1; run != 0; ++d) {
-                                const uint32_t p_dn = __shfl_down(packed, d), p_up = __shfl_up(packed, d);
+                                // lane i <- lane i +- d: one whole-wave DPP shift per iteration (no LDS crossbar)
+                                p_dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p_dn, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                                p_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p_up, 0x138, 0xf, 0xf, false);  // wave_shr:1
                                 const bool same_up = (run & lanebit) != 0;
                                 const bool same_dn = ((run >> d) & lanebit) != 0;
                                 if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
@@ -885,10 +918,9 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                     NearbyItem it{0u, 0u, 0u, 0u};
                     {
                         const uint32_t slot = have ? node_slot[key & NBR_NODE_MASK] : NODE_NONE;
-                        const uint16_t* sbh = slot_base + (hi ? (V + 1) : 0);
-                        const uint16_t* roh = rank_of + (hi ? V : 0);
-                        const NearbyItem ic = nearby_item(true, slot, se, sp, len, kk, s_off, sbh, roh);
-                        const NearbyItem is = nearby_item(false, slot, se, sp, len, kk, s_off, sbh, roh);
+                        const uint32_t* rth = rtab + (hi ? V : 0);
+                        const NearbyItem ic = nearby_item_rt(true, slot, se, sp, len, kk, s_off, rth);
+                        const NearbyItem is = nearby_item_rt(false, slot, se, sp, len, kk, s_off, rth);
                         const bool lane_change = hi ? chg1 : chg0;
                         it.w = lane_change ? ic.w : is.w;
                         it.ord = lane_change ? ic.ord : is.ord;
@@ -918,8 +950,10 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                         if (nonstart) {
                             const uint32_t packed = (it.ord << 2) | wc;
                             uint64_t run = nonstart;
+                            uint32_t p_dn = packed, p_up = packed;
                             for (uint32_t d = 1; run != 0; ++d) {
-                                const uint32_t p_dn = __shfl_down(packed, d), p_up = __shfl_up(packed, d);
+                                p_dn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p_dn, 0x130, 0xf, 0xf, false);  // wave_shl:1
+                                p_up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p_up, 0x138, 0xf, 0xf, false);  // wave_shr:1
                                 const bool same_up = (run & lanebit) != 0;
                                 const bool same_dn = ((run >> d) & lanebit) != 0;
                                 if (same_dn && (p_dn >> 2) < it.ord) pos += (int32_t)(p_dn & 3u);
