@@ -9,8 +9,9 @@ portfolio).  `value` counts CONSUMED candidates (`moves_evaluate
 evaluation.rs:33-49), not the speculative tail; inputs are resident in HBM before the timed region.
 
 roofline.  The dominant kernel (k_list_search_wave) keeps a replica's whole state in LDS, so HBM is idle (DESIGN.md
-§4); what bounds it is instruction issue.  `roofline.bound = "valu-issue"`: achieved = SQ_INSTS_VALU wave-instructions
-per second, peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md).  The counters
+§4); what bounds it is instruction issue.  `roofline.bound` names the tightest of three issue rooflines — VALU (achieved =
+SQ_INSTS_VALU wave-instructions per second, peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction,
+MI355X_MICROARCH.md), SALU (one scalar unit per CU, 1 instruction per clock) and LDS — all three are reported.  The counters
 come from rocprofv3 --pmc passes of THIS command (same warm-up and timed launches) that bench.py runs as child
 processes after the timed region (FETCH_SIZE and WRITE_SIZE each in a pass of their own, the read side doubled as the
 guide prescribes for gfx950); when rocprofv3 is not usable the committed profile of the same command is used and
@@ -453,9 +454,17 @@ def main():
             valu = pmc.get("SQ_INSTS_VALU", 0.0) / launch_s
             salu = pmc.get("SQ_INSTS_SALU", 0.0) / launch_s
             lds = pmc.get("SQ_INSTS_LDS", 0.0) / launch_s
-            roof["achieved"] = valu / 1e9
-            roof["frac"] = valu / VALU_PEAK
-            roof["salu_frac"] = salu / SALU_PEAK   # one scalar unit per CU, 1 instruction per clock
+            # issue rooflines of the three pipes the kernel lives on; `bound` names the tightest one (the kernel's HBM use is
+            # ~2 % of peak, see hbm_frac).  Peaks: VALU 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; SALU one scalar
+            # unit per CU issuing 1 instruction per clock; LDS 1 wave-instruction per 2 clocks per CU (ds_read_b32 rate).
+            fr = {"valu-issue": (valu, VALU_PEAK), "salu-issue": (salu, SALU_PEAK), "lds-issue": (lds, LDS_PEAK)}
+            bound = max(fr, key=lambda k: fr[k][0] / fr[k][1])
+            roof["bound"] = bound
+            roof["achieved"] = fr[bound][0] / 1e9
+            roof["peak"] = fr[bound][1] / 1e9
+            roof["frac"] = fr[bound][0] / fr[bound][1]
+            roof["valu_frac"] = valu / VALU_PEAK
+            roof["salu_frac"] = salu / SALU_PEAK
             roof["lds_issue_frac"] = lds / LDS_PEAK
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 # rocprofv3 reports KiB; gfx950: FETCH_SIZE counts 128-B requests at 64 B -> read side doubled

@@ -22,7 +22,7 @@ out = {"_command": "python bench.py (default flags): rocprofv3 --pmc child passe
        "_kernel": roof["kernel"], "_pmc_source": roof.get("pmc_source"), "_kernel_resources": roof.get("kernel_resources"),
        "_config": dict(bench["config"], steps=bench["steps"], warmup=bench["warmup"]),
        "_bench_avg_launch_ms": roof["avg_launch_ms"], "_bench_value": bench["value"],
-       "_frac": {k: roof.get(k) for k in ("frac", "salu_frac", "lds_issue_frac", "hbm_frac", "wave_cycle_shares", "effective_clock_ghz")}}
+       "_frac": {k: roof.get(k) for k in ("bound", "frac", "valu_frac", "salu_frac", "lds_issue_frac", "hbm_frac", "wave_cycle_shares", "effective_clock_ghz")}}
 for k, v in (roof.get("counters_per_launch") or {}).items():
     out[k] = {"launches": bench["steps"], "mean_per_launch": v}
 for f in glob.glob(os.path.join(src, "prof", "**", "*kernel_stats.csv"), recursive=True):
