@@ -24,6 +24,8 @@ LEAF_LIST_REVERSE = 64
 LEAF_SUBLIST_CHANGE = 128
 LEAF_SUBLIST_SWAP = 256
 LEAF_KOPT = 512
+LEAF_LIST_RUIN = 1024
+KIND_KOPT, KIND_RUIN = 7, 8
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
 FORAGER_FIRST_BEST_SCORE_IMPROVING, FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING = 3, 4
@@ -80,6 +82,11 @@ def lib():
             "sfo_xoshiro256pp": (None, [vp, i32, vp]),
             "sfo_small_rng_seed": (None, [u64, vp]),
             "sfo_model_set_step_seeds": (None, [vp, vp, i32]),
+            "sfo_model_set_ruin": (None, [vp, i32, i32, i32, i32, i32, C.c_char_p]),
+            "sfo_scoped_seed": (u64, [u64, u64, C.c_char_p, C.c_char_p]),
+            "sfo_hash_str": (u64, [C.c_char_p]),
+            "sfo_siphash": (u64, [i32, i32, u64, u64, vp, i64]),
+            "sfo_random_range_stream": (None, [u64, u64, u64, i32, vp]),
             "sfo_model_set_sublist_sizes": (None, [vp, i32, i32]),
             "sfo_model_phase_start": (None, [vp]),
             "sfo_model_steps": (None, [vp, i64]),
@@ -233,6 +240,12 @@ class Model:
         """3-opt leaf parameters; max_nearby = 0 selects the full-enumeration cursor."""
         lib().sfo_model_set_kopt(self.h, min_segment_len, max_nearby)
 
+    def set_ruin(self, min_count=2, max_count=5, moves_per_step=10, max_source_list_len=0, skip_empty_destinations=False,
+                 variable_name="visits"):
+        """List ruin leaf parameters (ListRuinMoveSelectorConfig defaults); call after configure(): re-seeds the leaf's stream."""
+        lib().sfo_model_set_ruin(self.h, min_count, max_count, moves_per_step, max_source_list_len, int(skip_empty_destinations),
+                                 variable_name.encode())
+
     def set_step_seeds(self, seeds):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         lib().sfo_model_set_step_seeds(self.h, _p(seeds), len(seeds))
@@ -309,6 +322,26 @@ class Model:
         vals = np.zeros(max_elements, dtype=np.uint32)
         t = lib().sfo_model_get_lists(self.h, desc, _p(off), _p(vals))
         return [list(map(int, vals[off[i]: off[i + 1]])) for i in range(n)]
+
+
+def scoped_seed(base_seed, descriptor_index, variable_name, selector_kind):
+    return lib().sfo_scoped_seed(base_seed & 0xFFFFFFFFFFFFFFFF, descriptor_index, variable_name.encode(), selector_kind.encode())
+
+
+def hash_str(s):
+    return lib().sfo_hash_str(s.encode())
+
+
+def random_range_stream(seed, low, high_inclusive, n):
+    out = np.zeros(n, dtype=np.uint64)
+    lib().sfo_random_range_stream(seed, low, high_inclusive, n, _p(out))
+    return out
+
+
+def ruin_positions(move):
+    """The ascending list positions of a KIND_RUIN wire move."""
+    w = [int(move["b"]) & 0xFFFFFFFF, int(move["b_pos"]) & 0xFFFFFFFF, int(move["value"]) & 0xFFFFFFFF]
+    return [(w[i // 2] >> (16 * (i & 1))) & 0xFFFF for i in range(int(move["a_pos"]))]
 
 
 def splitmix64(v):

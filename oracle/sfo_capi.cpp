@@ -27,6 +27,11 @@ static void to_wire(const Move& m, sfo_move_t* w) {
     w->b = (int32_t)m.b;
     w->b_pos = (int32_t)m.b_pos;
     w->value = (int32_t)m.to_value;
+    if (m.kind == Move::Ruin) {  // a = list, a_pos = count, six 16-bit positions in b / b_pos / value
+        w->b = (int32_t)((uint32_t)m.ruin_idx[0] | ((uint32_t)m.ruin_idx[1] << 16));
+        w->b_pos = (int32_t)((uint32_t)m.ruin_idx[2] | ((uint32_t)m.ruin_idx[3] << 16));
+        w->value = (int32_t)((uint32_t)m.ruin_idx[4] | ((uint32_t)m.ruin_idx[5] << 16));
+    }
 }
 static Move from_wire(const Model& model, const sfo_move_t& w) {
     Move m;
@@ -42,6 +47,14 @@ static Move from_wire(const Model& model, const sfo_move_t& w) {
         m.allows_unassigned = model.scalar_slot.allows_unassigned;
     } else {
         m.descriptor = model.list_slot.descriptor_index;
+    }
+    if (m.kind == Move::Ruin) {
+        const uint32_t w3[3] = {(uint32_t)w.b, (uint32_t)w.b_pos, (uint32_t)w.value};
+        for (int i = 0; i < 6; ++i) m.ruin_idx[i] = (uint16_t)(w3[i / 2] >> (16 * (i & 1)));
+        m.b = m.a;
+        m.b_pos = 0;
+        m.to_value = NONE;
+        m.allows_unassigned = model.ruin_skip_empty;
     }
     return m;
 }
@@ -155,6 +168,7 @@ void sfo_model_configure(void* h, int32_t acceptor, int32_t la_size, int32_t for
     m->leaves = leaves;
     m->max_nearby = (size_t)max_nearby;
     m->list_slot.public_selector_entity_order = public_entity_order != 0;
+    m->seed_ruin_stream(random_seed);
     size_t n_leaves = (size_t)__builtin_popcount(leaves);
     if (union_order < 0)
         m->union_order = n_leaves <= 1 ? UnionOrder::Sequential : UnionOrder::StratifiedRandom;
@@ -210,6 +224,31 @@ void sfo_model_set_kopt(void* h, int32_t min_segment_len, int32_t max_nearby) { 
     Model* m = (Model*)h;
     m->kopt_min_seg = (size_t)min_segment_len;
     m->kopt_max_nearby = (size_t)max_nearby;
+}
+// ListRuinMoveSelectorConfig (solverforge-config/src/move_selector.rs:552-587); max_source_list_len 0 = None.  Re-seeds the
+// leaf's per-solve stream: scoped_seed(random_seed, descriptor, variable_name, "list_ruin_move_selector").
+void sfo_model_set_ruin(void* h, int32_t min_count, int32_t max_count, int32_t moves_per_step, int32_t max_source_list_len,
+                        int32_t skip_empty_destinations, const char* variable_name) {
+    Model* m = (Model*)h;
+    m->ruin_min = (size_t)min_count;
+    m->ruin_max = (size_t)max_count;
+    m->ruin_moves_per_step = (size_t)moves_per_step;
+    m->ruin_max_source_len = (size_t)max_source_list_len;
+    m->ruin_skip_empty = skip_empty_destinations != 0;
+    if (variable_name) m->list_variable_name = variable_name;
+    m->seed_ruin_stream(m->search.random_seed);
+}
+uint64_t sfo_scoped_seed(uint64_t base_seed, uint64_t descriptor_index, const char* variable_name, const char* selector_kind) {
+    return scoped_seed(base_seed, (size_t)descriptor_index, variable_name, selector_kind);
+}
+uint64_t sfo_hash_str(const char* s) { return hash_str(s); }
+uint64_t sfo_siphash(int32_t c, int32_t d, uint64_t k0, uint64_t k1, const uint8_t* data, int64_t len) {
+    return siphash(c, d, k0, k1, data, (size_t)len);
+}
+// n draws of SmallRng::seed_from_u64(seed).random_range(low..=high) (known-answer hook for the device restatement)
+void sfo_random_range_stream(uint64_t seed, uint64_t low, uint64_t high_inclusive, int32_t n, uint64_t* out) {
+    SmallRng r = SmallRng::seed_from_u64(seed);
+    for (int32_t i = 0; i < n; ++i) out[i] = r.random_range_inclusive(low, high_inclusive);
 }
 void sfo_model_set_step_seeds(void* h, const uint64_t* seeds, int32_t n) {
     ((Model*)h)->search.explicit_step_seeds.assign(seeds, seeds + n);

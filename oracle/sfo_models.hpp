@@ -13,6 +13,7 @@
 //   examples/list-tsp/src/domain/tour_plan.rs:37-40 (uni-on-routes weight pattern)
 //   crates/solverforge-cvrp/src/problem_data.rs:6-47, meters.rs:10-28
 #pragma once
+#include <string>
 #include <memory>
 #include <vector>
 
@@ -72,6 +73,8 @@ enum LeafBits : uint32_t {
     LEAF_LIST_REVERSE = 64,
     LEAF_SUBLIST_CHANGE = 128,
     LEAF_SUBLIST_SWAP = 256,
+    LEAF_LIST_RUIN = 1024,  // ListRuinMoveSelectorConfig defaults: 2..=5 elements, 10 moves per step (solverforge-config/src/move_selector.rs:574-587,
+                            // list_leaf/spec.rs:245)
     LEAF_KOPT = 512,  // k = 3; kopt_max_nearby > 0: distance-pruned (default policy with an intra-distance meter), 0: full
 };
 
@@ -86,6 +89,15 @@ struct Model {
     size_t sublist_min = 1, sublist_max = 3;
     size_t kopt_min_seg = 1, kopt_max_nearby = 20;  // KOptMoveSelectorConfig defaults + DEFAULT_LIST_NEARBY_LIMIT (policy/list.rs:19,144-160)
     UnionOrder union_order = UnionOrder::StratifiedRandom;
+    // list ruin leaf: the per-solve stream state (list_leaf/cursor.rs:112-145) is one SmallRng seeded from
+    // scoped_seed(random_seed, descriptor, variable, "list_ruin_move_selector"); every cursor open draws one u64 from it
+    size_t ruin_min = 2, ruin_max = 5, ruin_moves_per_step = 10, ruin_max_source_len = 0;
+    bool ruin_skip_empty = false;
+    std::string list_variable_name = "visits";
+    mutable SmallRng ruin_rng;
+    void seed_ruin_stream(uint64_t random_seed) {
+        ruin_rng = SmallRng::seed_from_u64(scoped_seed(random_seed, list_slot.descriptor_index, list_variable_name.c_str(), "list_ruin_move_selector"));
+    }
 
     std::unique_ptr<Cursor> open_leaf(uint32_t leaf, const ScoreDirector& d, const MoveStreamContext& ctx) const {
         switch (leaf) {
@@ -108,6 +120,11 @@ struct Model {
             case LEAF_KOPT:
                 if (kopt_max_nearby == 0) return std::make_unique<KOptCursor>(list_slot, d.working, ctx, kopt_min_seg);
                 return std::make_unique<NearbyKOptCursor>(list_slot, d.working, ctx, kopt_min_seg, kopt_max_nearby);
+            case LEAF_LIST_RUIN: {  // open_cursor_with_stream_state (list_leaf/cursor.rs:58-72), slot.rs:446-465
+                const uint64_t seed = ruin_rng.next_u64() ^ ctx.offset_seed(0x71578011C0DE0001ULL);
+                return std::make_unique<RuinCursor>(list_slot, d.working, seed, ruin_moves_per_step, ruin_min, ruin_max, ruin_max_source_len,
+                                                    ruin_skip_empty);
+            }
             case LEAF_SUBLIST_CHANGE:  // default sizes 1..=3 (solverforge-config/src/move_selector.rs:713-715)
                 return std::make_unique<SublistChangeCursor>(list_slot, d.working, ctx, sublist_min, sublist_max);
         }
@@ -120,7 +137,7 @@ struct Model {
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
         static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
                                          LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_SUBLIST_SWAP, LEAF_LIST_REVERSE,
-                                         LEAF_KOPT,               LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
+                                         LEAF_KOPT,               LEAF_LIST_RUIN,          LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
         std::vector<std::unique_ptr<Cursor>> children;
         for (uint32_t leaf : order)
             if (leaves & leaf) children.push_back(open_leaf(leaf, d, ctx));

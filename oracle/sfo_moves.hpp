@@ -16,6 +16,7 @@
 //   heuristic/selector/list_support.rs:13-26,62-70
 //   runtime/compiler/executor/list_leaf/cursor/slot.rs:196-499 (runtime leaf entity order)
 //   heuristic/selector/decorator/vec_union.rs:190-365 (UnionScheduler)
+//   heuristic/selector/list_kernel/ruin.rs:1-181, heuristic/move/list_kernel/ruin.rs:1-435 (list ruin + greedy recreate)
 // (all paths under crates/solverforge-solver/src/)
 #pragma once
 #include <algorithm>
@@ -30,7 +31,7 @@
 namespace sfo {
 
 struct Move {
-    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6, KOpt = 7 } kind = Change;
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6, KOpt = 7, Ruin = 8 } kind = Change;
     size_t descriptor = 0;
     size_t variable = 0;
     // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
@@ -43,19 +44,40 @@ struct Move {
     //                [b_pos, b_pos + (to_value >> 16)) of list b.
     // KOpt (3-opt, one list): list a cut at positions a_pos < b < b_pos (NOTE: `b` carries the middle
     //                cut, not an entity), reconnected by THREE_OPT_RECONNECTIONS[to_value].
+    // Ruin (list ruin-and-recreate, one source list): list a loses the a_pos elements at the ascending positions
+    //                ruin_idx[0..a_pos) and every removed element is greedily re-inserted (move/list_kernel/ruin.rs:131-281);
+    //                `allows_unassigned` carries skip_empty_destinations.
     size_t a = 0, a_pos = 0, b = 0, b_pos = 0;
     int64_t to_value = NONE;
     bool allows_unassigned = false;
+    uint16_t ruin_idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // SmallVec<[usize; 8]> of the reference; this build caps a ruin at 6
 };
 inline bool operator==(const Move& x, const Move& y) {
     return x.kind == y.kind && x.descriptor == y.descriptor && x.variable == y.variable && x.a == y.a &&
-           x.a_pos == y.a_pos && x.b == y.b && x.b_pos == y.b_pos && x.to_value == y.to_value;
+           x.a_pos == y.a_pos && x.b == y.b && x.b_pos == y.b_pos && x.to_value == y.to_value &&
+           (x.kind != Move::Ruin || std::equal(x.ruin_idx, x.ruin_idx + 8, y.ruin_idx));
 }
 
+struct RuinPlacement {  // RuinUndo entry (move/list_kernel/ruin.rs:16): where a removed element went
+    size_t entity, position, removed_index;
+};
 struct MoveUndo {
     int64_t old_a = NONE, old_b = NONE;
     std::vector<uint32_t> old_list;  // KOpt: the route before the reconnection (k_opt_do_move returns it)
+    std::vector<RuinPlacement> placements;  // Ruin: in insertion order; empty when the recreate was rolled back
 };
+
+// final_positions_after_ordered_insertions (move/list_kernel/ruin.rs:81-95): where each placed element sits after all the
+// later insertions into the same list
+inline std::vector<size_t> ruin_final_positions(const std::vector<RuinPlacement>& placements) {
+    std::vector<size_t> cur;
+    for (size_t i = 0; i < placements.size(); ++i) {
+        for (size_t j = 0; j < i; ++j)
+            if (placements[j].entity == placements[i].entity && cur[j] >= placements[i].position) cur[j] += 1;
+        cur.push_back(placements[i].position);
+    }
+    return cur;
+}
 
 // Reconnection patterns of a k-opt move (heuristic/move/k_opt_reconnection.rs:54-58,203-211):
 // `order[p]` = which of the k+1 segments sits at position p afterwards, bit i of `reverse` = segment i
@@ -104,6 +126,12 @@ inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
             size_t len = c.lists[m.a].size();
             if (m.a_pos > len || m.b > len || m.b_pos > len) return false;
             return m.b > m.a_pos && m.b_pos > m.b;
+        }
+        case Move::Ruin: {  // ruin_is_doable without an owner binding (move/list_kernel/ruin.rs:97-113)
+            if (m.a_pos == 0 || m.a_pos > 8 || m.a >= c.lists.size()) return false;
+            for (size_t i = 0; i < m.a_pos; ++i)
+                if (m.ruin_idx[i] >= c.lists[m.a].size()) return false;
+            return true;
         }
         case Move::SublistSwap: {  // move/list_kernel/sublist_swap.rs:17-43
             if (m.to_value < 0) return false;
@@ -226,6 +254,75 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
             d.after_variable_changed(m.descriptor, m.a);
             break;
         }
+        case Move::Ruin: {  // ruin_do_move (move/list_kernel/ruin.rs:131-281): one source list, no owner binding, no
+                            // precedence graph.  Every trial insertion is a full before / insert / after / calculate_score.
+            struct Removed {
+                size_t removed_index, source, original_position;
+                uint32_t value;
+            };
+            std::vector<Removed> remaining;
+            d.before_variable_changed(m.descriptor, m.a);
+            for (size_t i = m.a_pos; i-- > 0;) {  // indices ascending: remove from the back (:147-153)
+                size_t index = m.ruin_idx[i];
+                remaining.push_back({i, m.a, index, c.lists[m.a][index]});
+                c.lists[m.a].erase(c.lists[m.a].begin() + (ptrdiff_t)index);
+            }
+            std::reverse(remaining.begin(), remaining.end());
+            d.after_variable_changed(m.descriptor, m.a);
+            const std::vector<Removed> removed = remaining;
+            const bool skip_empty = m.allows_unassigned;
+            const size_t entity_count = c.n;
+            bool rolled_back = false;
+            while (!remaining.empty()) {
+                bool have = false;
+                size_t best_ri = 0, best_e = 0, best_p = 0;
+                Score best_score;
+                for (size_t ri = 0; ri < remaining.size(); ++ri) {
+                    for (size_t e = 0; e < entity_count; ++e) {
+                        size_t len = c.lists[e].size();
+                        if (skip_empty && len == 0) continue;
+                        for (size_t pos = 0; pos <= len; ++pos) {
+                            d.before_variable_changed(m.descriptor, e);
+                            c.lists[e].insert(c.lists[e].begin() + (ptrdiff_t)pos, remaining[ri].value);
+                            d.after_variable_changed(m.descriptor, e);
+                            Score cand = d.calculate_score();
+                            if (!have || cand > best_score) {  // strict: the first of equal scores stays (:228-237)
+                                have = true;
+                                best_ri = ri, best_e = e, best_p = pos, best_score = cand;
+                            }
+                            d.before_variable_changed(m.descriptor, e);
+                            c.lists[e].erase(c.lists[e].begin() + (ptrdiff_t)pos);
+                            d.after_variable_changed(m.descriptor, e);
+                        }
+                    }
+                }
+                if (!have) {  // restore_removed_elements (:250-253,375-404)
+                    std::vector<size_t> cur = ruin_final_positions(u.placements);
+                    for (size_t i = u.placements.size(); i-- > 0;) {
+                        size_t e = u.placements[i].entity, at = cur[i];
+                        d.before_variable_changed(m.descriptor, e);
+                        c.lists[e].erase(c.lists[e].begin() + (ptrdiff_t)at);
+                        d.after_variable_changed(m.descriptor, e);
+                        for (size_t j = 0; j < i; ++j)
+                            if (u.placements[j].entity == e && cur[j] > at) cur[j] -= 1;
+                    }
+                    d.before_variable_changed(m.descriptor, m.a);  // restore_values: one source list, ascending positions
+                    for (const Removed& r : removed) c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)r.original_position, r.value);
+                    d.after_variable_changed(m.descriptor, m.a);
+                    u.placements.clear();
+                    rolled_back = true;
+                    break;
+                }
+                Removed r = remaining[best_ri];
+                remaining.erase(remaining.begin() + (ptrdiff_t)best_ri);
+                d.before_variable_changed(m.descriptor, best_e);
+                c.lists[best_e].insert(c.lists[best_e].begin() + (ptrdiff_t)best_p, r.value);
+                d.after_variable_changed(m.descriptor, best_e);
+                u.placements.push_back({best_e, best_p, r.removed_index});
+            }
+            (void)rolled_back;
+            break;
+        }
         case Move::SublistChange: {  // apply_sublist_change (move/list_kernel/sublist_change.rs:88-130)
             bool intra = m.a == m.b;
             d.before_variable_changed(m.descriptor, m.a);
@@ -300,6 +397,30 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             inv.b_pos = m.a_pos;
             MoveUndo ignored = move_do(d, inv);
             (void)ignored;
+            break;
+        }
+        case Move::Ruin: {  // ruin_undo_move (move/list_kernel/ruin.rs:283-322) + restore_values (:406-435)
+            if (u.placements.empty()) break;  // the recreate was rolled back inside do_move
+            std::vector<size_t> cur = ruin_final_positions(u.placements);
+            struct Back {
+                size_t original_position;
+                uint32_t value;
+            };
+            std::vector<Back> values;
+            for (size_t i = u.placements.size(); i-- > 0;) {
+                size_t e = u.placements[i].entity, at = cur[i];
+                d.before_variable_changed(m.descriptor, e);
+                uint32_t value = c.lists[e][at];
+                c.lists[e].erase(c.lists[e].begin() + (ptrdiff_t)at);
+                values.push_back({(size_t)m.ruin_idx[u.placements[i].removed_index], value});  // removed_source_entry
+                d.after_variable_changed(m.descriptor, e);
+                for (size_t j = 0; j < i; ++j)
+                    if (u.placements[j].entity == e && cur[j] > at) cur[j] -= 1;
+            }
+            std::sort(values.begin(), values.end(), [](const Back& x, const Back& y) { return x.original_position < y.original_position; });
+            d.before_variable_changed(m.descriptor, m.a);
+            for (const Back& b : values) c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)b.original_position, b.value);
+            d.after_variable_changed(m.descriptor, m.a);
             break;
         }
         case Move::KOpt: {  // k_opt_undo_move (move/list_kernel/k_opt.rs:98-119): put the old route back
@@ -1492,6 +1613,54 @@ struct NearbyKOptCursor : Cursor {
             }
             state.reset();
         }
+    }
+};
+
+// ---- list ruin leaf (selector/list_kernel/ruin.rs:38-144; runtime pool list_leaf/cursor/probe.rs:218-238) ----------------
+// Unrestricted source pool = every non-empty list (optionally no longer than max_source_list_len) frozen at cursor open;
+// each pull draws the source list, the ruin count and a partial Fisher-Yates of its positions from the cursor's SmallRng.
+// `random_range` is rand's (crate source not under /root/reference): PARITY UNPINNED, see SmallRng in sfo_core.hpp.
+struct RuinCursor : Cursor {
+    size_t descriptor;
+    SmallRng rng;
+    std::vector<std::pair<size_t, size_t>> pool;  // (entity, list_len)
+    size_t remaining_moves, min_ruin_count, max_ruin_count;
+    bool skip_empty_destinations;
+    RuinCursor(const ListSlot& slot, const Solution& s, uint64_t seed, size_t moves_per_step, size_t min_count, size_t max_count,
+               size_t max_source_list_len, bool skip_empty)
+        : descriptor(slot.descriptor_index),
+          rng(SmallRng::seed_from_u64(seed)),
+          remaining_moves(moves_per_step),
+          min_ruin_count(min_count),
+          max_ruin_count(max_count),
+          skip_empty_destinations(skip_empty) {
+        const EntityClass& c = s.classes[descriptor];
+        for (size_t e = 0; e < c.n; ++e) {
+            size_t len = c.lists[e].size();
+            if (len > 0 && (max_source_list_len == 0 || len <= max_source_list_len)) pool.push_back({e, len});
+        }
+    }
+    bool next(Move& out) override {
+        if (remaining_moves == 0 || pool.empty()) return false;
+        --remaining_moves;
+        auto [entity, list_len] = pool[(size_t)rng.random_range(0, pool.size())];
+        size_t mn = std::min(min_ruin_count, list_len), mx = std::min(max_ruin_count, list_len);
+        size_t ruin_count = mn == mx ? mn : (size_t)rng.random_range_inclusive(mn, mx);  // choose_ruin_count (:78-86)
+        std::vector<size_t> indices(list_len);
+        for (size_t i = 0; i < list_len; ++i) indices[i] = i;
+        for (size_t i = 0; i < ruin_count; ++i) std::swap(indices[i], indices[(size_t)rng.random_range(i, list_len)]);
+        indices.resize(ruin_count);
+        std::sort(indices.begin(), indices.end());  // single_ruin_source (move/list_kernel/ruin.rs:28-32)
+        Move m;
+        m.kind = Move::Ruin;
+        m.descriptor = descriptor;
+        m.a = entity;
+        m.b = entity;
+        m.a_pos = ruin_count;
+        m.allows_unassigned = skip_empty_destinations;
+        for (size_t i = 0; i < ruin_count && i < 8; ++i) m.ruin_idx[i] = (uint16_t)indices[i];
+        out = m;
+        return true;
     }
 };
 

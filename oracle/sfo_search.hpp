@@ -70,39 +70,6 @@ struct LateAcceptanceAcceptor : Acceptor {  // late_acceptance.rs:89-125
     }
 };
 
-// rand 0.10.1 SmallRng on 64-bit targets = xoshiro256++ (Blackman/Vigna, public domain
-// algorithm); `seed_from_u64` expands the seed with splitmix64 and `random::<f64>()` is the
-// 53-bit multiply sample `(next_u64 >> 11) * 2^-53`.  The crate source is NOT under
-// /root/reference (Cargo.lock:314-338) => the draw stream is "parity unpinned" (SURVEY §8c);
-// the generator itself is checked against the published xoshiro256++ test vector.
-struct SmallRng {
-    uint64_t s[4] = {0, 0, 0, 0};
-    static SmallRng seed_from_u64(uint64_t state) {
-        SmallRng r;
-        for (int i = 0; i < 4; ++i) {
-            state += 0x9E3779B97F4A7C15ULL;
-            uint64_t z = state;
-            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-            r.s[i] = z ^ (z >> 31);
-        }
-        return r;
-    }
-    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
-    uint64_t next_u64() {
-        const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
-        const uint64_t t = s[1] << 17;
-        s[2] ^= s[0];
-        s[3] ^= s[1];
-        s[1] ^= s[2];
-        s[0] ^= s[3];
-        s[2] ^= t;
-        s[3] = rotl(s[3], 45);
-        return result;
-    }
-    double random_f64() { return (double)(next_u64() >> 11) * (1.0 / 9007199254740992.0); }
-};
-
 // simulated_annealing.rs:11-430.  `levels` = Score::levels_count(), `hard_levels` = how many
 // leading levels carry ScoreLevel::Hard (HardSoft: 1; Bendable<H,S>: H).
 struct SimulatedAnnealingAcceptor : Acceptor {

@@ -533,6 +533,134 @@ static void list_reverse_cases() {
     }
 }
 
+// heuristic/move/tests/list_ruin.rs:191-470 (ruin + greedy recreate: do / undo, first-position tie, recreate order by
+// score, doability, final-position bookkeeping) and the SipHash / scoped_seed plumbing of the ruin seed
+static void list_ruin_cases() {
+    auto mk = [](std::vector<std::vector<uint32_t>> routes, bool prefer_four_before_two) {
+        ScoreDirector d;
+        d.working.classes.resize(1);
+        d.working.classes[0].n = routes.size();
+        d.working.classes[0].lists = routes;
+        if (prefer_four_before_two) {  // RouteScoreConstraint(prefer_four_before_two), list_ruin.rs:158-174
+            auto c = std::make_unique<UniConstraint>();
+            c->name = "routeScore";
+            c->impact = Impact::Reward;
+            c->source = ChangeSource::descriptor(0);
+            c->count = [](const Solution&) { return (size_t)1; };  // scores routes[0] only
+            c->filter = [](const Solution&, size_t) { return true; };
+            c->weight = [](const Solution& s, size_t) {
+                const auto& r = s.classes[0].lists[0];
+                size_t p4 = SIZE_MAX, p2 = SIZE_MAX;
+                for (size_t i = 0; i < r.size(); ++i) {
+                    if (r[i] == 4 && p4 == SIZE_MAX) p4 = i;
+                    if (r[i] == 2 && p2 == SIZE_MAX) p2 = i;
+                }
+                return soft(p4 < p2 ? 100 : 0);
+            };
+            d.constraints.members.push_back(std::move(c));
+        }
+        return d;
+    };
+    auto ruin = [](size_t entity, std::vector<uint16_t> idx) {
+        Move m;
+        m.kind = Move::Ruin;
+        m.a = m.b = entity;
+        std::sort(idx.begin(), idx.end());  // ListRuinMove::new sorts (single_ruin_source)
+        m.a_pos = idx.size();
+        for (size_t i = 0; i < idx.size() && i < 8; ++i) m.ruin_idx[i] = idx[i];
+        return m;
+    };
+    auto sorted = [](std::vector<uint32_t> v) {
+        std::sort(v.begin(), v.end());
+        return v;
+    };
+    {  // ruin_single_element: constant score -> the first tried position (entity 0, position 0) wins
+        ScoreDirector d = mk({{1, 2, 3, 4, 5}}, false);
+        d.calculate_score();
+        Move m = ruin(0, {2});
+        bool ok = move_is_doable(d, m);
+        MoveUndo u = move_do(d, m);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({3, 1, 2, 4, 5});
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4, 5});
+        CHECK("list_ruin.single_element_first_position_wins", ok);
+    }
+    {  // ruin_multiple_elements + ruin_unordered_indices
+        ScoreDirector d = mk({{1, 2, 3, 4, 5}}, false);
+        d.calculate_score();
+        Move m = ruin(0, {3, 1});
+        bool ok = move_is_doable(d, m) && m.ruin_idx[0] == 1 && m.ruin_idx[1] == 3;
+        MoveUndo u = move_do(d, m);
+        ok = ok && sorted(d.working.classes[0].lists[0]) == std::vector<uint32_t>({1, 2, 3, 4, 5}) && u.placements.size() == 2;
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4, 5});
+        CHECK("list_ruin.multiple_elements_do_undo", ok);
+    }
+    {  // ruin_recreate_can_choose_removed_elements_out_of_removal_order
+        ScoreDirector d = mk({{1, 2, 3, 4}}, true);
+        d.calculate_score();
+        Move m = ruin(0, {1, 3});
+        MoveUndo u = move_do(d, m);
+        const auto& r = d.working.classes[0].lists[0];
+        size_t p4 = std::find(r.begin(), r.end(), 4u) - r.begin(), p2 = std::find(r.begin(), r.end(), 2u) - r.begin();
+        bool ok = p4 < p2 && d.calculate_score() == soft(100) && d.calculate_score() == d.fresh_score();
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4}) && d.cached == d.fresh_score();
+        CHECK("list_ruin.recreate_picks_by_score_not_removal_order", ok);
+    }
+    {  // two routes: elements may move across lists, undo restores both exactly
+        ScoreDirector d = mk({{1, 2, 3, 4}, {5, 6, 7}}, true);
+        d.calculate_score();
+        Move m = ruin(1, {0, 2});
+        MoveUndo u = move_do(d, m);
+        bool ok = d.working.classes[0].lists[0].size() + d.working.classes[0].lists[1].size() == 7 && d.cached == d.fresh_score();
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4}) &&
+             d.working.classes[0].lists[1] == std::vector<uint32_t>({5, 6, 7}) && d.cached == d.fresh_score();
+        CHECK("list_ruin.undo_restores_every_list", ok);
+    }
+    {
+        ScoreDirector d = mk({{1, 2, 3}}, false);
+        CHECK("list_ruin.empty_indices_not_doable", !move_is_doable(d, ruin(0, {})));
+        CHECK("list_ruin.out_of_bounds_not_doable", !move_is_doable(d, ruin(0, {0, 10})));
+    }
+    {  // computes_exact_final_positions_for_same_entity_reinsertion + undo_positions_do_not_underflow...
+        std::vector<RuinPlacement> pl = {{0, 0, 0}, {0, 0, 1}, {0, 0, 2}, {0, 1, 3}};
+        std::vector<size_t> cur = ruin_final_positions(pl);
+        bool ok = cur == std::vector<size_t>({3, 2, 0, 1});
+        std::vector<size_t> order;
+        for (size_t i = pl.size(); i-- > 0;) {
+            size_t at = cur[i];
+            order.push_back(at);
+            for (size_t j = 0; j < i; ++j)
+                if (cur[j] > at) cur[j] -= 1;
+        }
+        CHECK("list_ruin.final_positions_and_removal_order", ok && order == std::vector<size_t>({1, 0, 0, 0}));
+    }
+    {  // SipHash-2-4 reference vector of the SipHash paper (key 00..0f, message 00..0e): the round function and the
+       // finalisation that DefaultHasher (SipHash-1-3) shares
+        uint8_t msg[15];
+        for (int i = 0; i < 15; ++i) msg[i] = (uint8_t)i;
+        CHECK("siphash24.paper_vector", siphash(2, 4, 0x0706050403020100ULL, 0x0f0e0d0c0b0a0908ULL, msg, 15) == 0xa129ca6149be45e5ULL);
+        // seeded ruin streams are reproducible (list_leaf/tests/parity.rs:252-266) and scoped by selector kind
+        CHECK("scoped_seed.deterministic_and_scoped",
+              scoped_seed(1337, 0, "visits", "list_ruin_move_selector") == scoped_seed(1337, 0, "visits", "list_ruin_move_selector") &&
+                  scoped_seed(1337, 0, "visits", "list_ruin_move_selector") != scoped_seed(1337, 0, "visits", "other") &&
+                  scoped_seed(1337, 0, "visits", "list_ruin_move_selector") != scoped_seed(1337, 1, "visits", "list_ruin_move_selector"));
+    }
+    {  // random_range stays inside its bounds and hits both ends (Canon's method, 32-bit path)
+        SmallRng r = SmallRng::seed_from_u64(7);
+        bool ok = true, lo = false, hi = false;
+        for (int i = 0; i < 2000; ++i) {
+            uint64_t v = r.random_range_inclusive(2, 5);
+            ok = ok && v >= 2 && v <= 5;
+            lo = lo || v == 2;
+            hi = hi || v == 5;
+        }
+        CHECK("small_rng.random_range_bounds", ok && lo && hi);
+    }
+}
+
 // heuristic/move/tests/k_opt.rs:86-222 (do / undo / doability), selector/k_opt/tests.rs:80-147 and
 // selector/tests/k_opt.rs (first combination, 35 combinations, 245 moves, all doable),
 // benches/selector_cursor_gate.rs:370-382 (4,760 moves on an 18-element route)
@@ -801,6 +929,7 @@ int main() {
     k_opt_cases();
     simulated_annealing_cases();
     list_reverse_cases();
+    list_ruin_cases();
     bi_incr_cases();
     cross_bi_cases();
     exists_cases();
