@@ -68,9 +68,12 @@ typedef enum sf_move_kind {
                                   -> list `b` at b_pos (post-removal coordinates when a == b) */
     SF_MOVE_SUBLIST_SWAP = 6,  /* heuristic/move/list_kernel/sublist_swap.rs:17-160: segment [a_pos, a_pos + (value & 0xFFFF)) of
                                   list `a` <-> segment [b_pos, b_pos + (value >> 16)) of list `b` */
-    SF_MOVE_KOPT = 7           /* heuristic/move/list_kernel/k_opt.rs:13-96 with k = 3: list `a` cut at a_pos < b < b_pos (`b`
+    SF_MOVE_KOPT = 7,          /* heuristic/move/list_kernel/k_opt.rs:13-96 with k = 3: list `a` cut at a_pos < b < b_pos (`b`
                                   carries the MIDDLE CUT, not an entity) and reconnected by
                                   THREE_OPT_RECONNECTIONS[value] (move/k_opt_reconnection.rs:203-211), value in 0..6 */
+    SF_MOVE_LIST_RUIN = 8      /* heuristic/move/list_kernel/ruin.rs:131-281 (one source list): list `a` loses the a_pos (1..6) elements
+                                  at ascending positions packed 16 bits each into b (positions 0, 1), b_pos (2, 3), value (4, 5);
+                                  every removed element is greedily re-inserted at its best (list, position) */
 } sf_move_kind;
 
 /* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
@@ -127,7 +130,9 @@ typedef enum sf_selector_kind {
                                       (selector/list_kernel/k_opt/nearby.rs, nearby_state.rs; the default-policy leaf of lists
                                       with an intra-distance meter, policy/list.rs:144-160), 0 = full enumeration
                                       (selector/list_kernel/k_opt/full.rs) */
-    SF_SEL_SUBLIST_SWAP = 256      /* selector/list_kernel/sublist_swap.rs:13-330; sizes via sf_selector_add_sublist */
+    SF_SEL_SUBLIST_SWAP = 256,     /* selector/list_kernel/sublist_swap.rs:13-330; sizes via sf_selector_add_sublist */
+    SF_SEL_LIST_RUIN = 1024        /* selector/list_kernel/ruin.rs:38-144 + move/list_kernel/ruin.rs:131-281 (ruin and greedy recreate);
+                                      sf_selector_add_ruin.  Last list leaf of the default policy (policy/list.rs:24-33,193-199) */
 } sf_selector_kind;
 
 typedef enum sf_selection_order { /* solverforge_config::SelectionOrder */
@@ -251,6 +256,16 @@ int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t descriptor_in
  * max_nearby = 0 -> full enumeration, 1..64 -> distance-pruned by the list's matrix meter (the default policy passes 20) */
 int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t k,
                              int32_t min_segment_len, int32_t max_nearby);
+
+/* list ruin leaf (ListRuinMoveSelectorConfig, solverforge-config/src/move_selector.rs:552-587; defaults 2, 5, 10, none, false):
+ * per step `moves_per_step` (<= 16) candidates, each removing min..=max (<= 6) elements of one non-empty list (no longer than
+ * max_source_list_len; 0 = no bound) and re-inserting them greedily.  `variable_name` = the list variable's name: the leaf's
+ * per-solve random stream is SmallRng::seed_from_u64(scoped_seed(random_seed + replica, descriptor_index, variable_name,
+ * "list_ruin_move_selector")) (heuristic/selector/seed.rs:3-17, list_leaf/cursor.rs:117-145), (re)seeded by sf_phase_start.
+ * rand's xoshiro256++ / random_range are restated from the published algorithm: parity unpinned against the reference. */
+int32_t sf_selector_add_ruin(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t min_ruin_count,
+                             int32_t max_ruin_count, int32_t moves_per_step, int32_t max_source_list_len,
+                             int32_t skip_empty_destinations, const char* variable_name);
 
 /* ---- Director surface -------------------------------------------------------------------- */
 /* ≙ first Director::calculate_score (initialize_all): builds per-replica aggregates.

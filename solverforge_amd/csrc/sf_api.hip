@@ -41,7 +41,9 @@ struct ConstraintSpec {
 };
 struct SelectorSpec {
     int kind, desc, var, max_nearby, fact;
-    int min_size = 1, max_size = 3;  // sublist leaves
+    int min_size = 1, max_size = 3;  // sublist leaves; ruin leaf: min / max ruin count
+    int moves_per_step = 10, max_source_len = 0, skip_empty = 0;  // ruin leaf (ListRuinMoveSelectorConfig)
+    std::string variable_name;                                    // ruin leaf: scoped_seed hashes the variable name
 };
 struct ClassSpec {
     int n_rows = 0;
@@ -93,6 +95,7 @@ struct sf_ctx {
     // scratch
     int64_t* d_each = nullptr;           // [R][SF_EACH_WORDS] evaluate_each aggregates
     uint64_t* d_kopt_scratch = nullptr;  // [R][n_cap] distance keys of long routes (distance-pruned 3-opt leaf)
+    uint64_t* d_ruin_rng = nullptr;      // [R][4] per-solve SmallRng state of the list ruin leaf
     int64_t* d_scores_out = nullptr;
     int32_t* d_ok = nullptr;
     // profiling
@@ -394,7 +397,93 @@ int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t d, int32_t va
     return SF_OK;
 }
 
+// list ruin leaf (ListRuinMoveSelectorConfig, solverforge-config/src/move_selector.rs:552-587)
+int32_t sf_selector_add_ruin(sf_ctx* ctx, int32_t d, int32_t var, int32_t min_ruin_count, int32_t max_ruin_count, int32_t moves_per_step,
+                             int32_t max_source_list_len, int32_t skip_empty_destinations, const char* variable_name) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
+    if (min_ruin_count < 1 || max_ruin_count < min_ruin_count) return fail(ctx, SF_ERR_INVALID, "ruin counts must satisfy 1 <= min <= max");
+    if (max_ruin_count > (int32_t)RUIN_MAX_COUNT) return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin: at most 6 elements per move on the device");
+    if (moves_per_step < 0 || max_source_list_len < 0) return fail(ctx, SF_ERR_INVALID, "list ruin: negative moves_per_step / max_source_list_len");
+    if (moves_per_step > (int32_t)RUIN_MAX_MOVES) return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin: at most 16 moves per step on the device");
+    SelectorSpec s{SF_SEL_LIST_RUIN, d, var, 0, -1};
+    s.min_size = min_ruin_count;
+    s.max_size = max_ruin_count;
+    s.moves_per_step = moves_per_step;
+    s.max_source_len = max_source_list_len;
+    s.skip_empty = skip_empty_destinations != 0;
+    s.variable_name = variable_name ? variable_name : "";
+    ctx->selectors.push_back(s);
+    return SF_OK;
+}
+
 }  // extern "C"
+
+// std::hash::DefaultHasher = SipHash-1-3 with a zero key (published algorithm, Aumasson & Bernstein): `str::hash` feeds the bytes
+// and a 0xFF terminator (heuristic/move/metadata.rs:125-129).  Host side only: it seeds the list ruin leaf's stream.
+static uint64_t sip13_str(const std::string& str) {
+    uint64_t v0 = 0x736f6d6570736575ULL, v1 = 0x646f72616e646f6dULL, v2 = 0x6c7967656e657261ULL, v3 = 0x7465646279746573ULL;
+    auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+    auto round = [&]() {
+        v0 += v1, v1 = rotl(v1, 13), v1 ^= v0, v0 = rotl(v0, 32);
+        v2 += v3, v3 = rotl(v3, 16), v3 ^= v2;
+        v0 += v3, v3 = rotl(v3, 21), v3 ^= v0;
+        v2 += v1, v1 = rotl(v1, 17), v1 ^= v2, v2 = rotl(v2, 32);
+    };
+    std::string data = str;
+    data.push_back((char)0xFF);
+    const size_t len = data.size();
+    size_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t m = 0;
+        for (int b = 0; b < 8; ++b) m |= (uint64_t)(uint8_t)data[i + b] << (8 * b);
+        v3 ^= m;
+        round();
+        v0 ^= m;
+    }
+    uint64_t last = (uint64_t)(len & 0xFF) << 56;
+    for (size_t b = 0; i + b < len; ++b) last |= (uint64_t)(uint8_t)data[i + b] << (8 * b);
+    v3 ^= last;
+    round();
+    v0 ^= last;
+    v2 ^= 0xFF;
+    round(), round(), round();
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+// scoped_seed (heuristic/selector/seed.rs:3-17)
+static uint64_t scoped_seed(uint64_t base_seed, uint64_t descriptor_index, const std::string& variable_name, const char* selector_kind) {
+    auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+    return splitmix64(base_seed ^ (descriptor_index * 0x9E3779B97F4A7C15ULL) ^ rotl(sip13_str(variable_name), 17) ^ rotl(sip13_str(selector_kind), 41));
+}
+static const SelectorSpec* ruin_selector(const sf_ctx* ctx) {
+    for (auto& s : ctx->selectors)
+        if (s.kind == SF_SEL_LIST_RUIN && ctx->has_list_model && s.desc == ctx->list_desc) return &s;
+    return nullptr;
+}
+// RuntimeListNeighborhoodStreamState::new (list_leaf/cursor.rs:117-145): replica r's stream = SmallRng::seed_from_u64(
+// scoped_seed(random_seed + r, descriptor, variable, "list_ruin_move_selector"))
+static int ruin_phase_start(sf_ctx* ctx) {
+    const SelectorSpec* rs = ruin_selector(ctx);
+    if (!rs) return SF_OK;
+    if (!ctx->d_ruin_rng) {
+        int rc = dalloc(ctx, &ctx->d_ruin_rng, (size_t)ctx->R * 4);
+        if (rc) return rc;
+    }
+    std::vector<uint64_t> st((size_t)ctx->R * 4);
+    for (int r = 0; r < ctx->R; ++r) {
+        uint64_t state = scoped_seed(ctx->cfg.random_seed + (uint64_t)r, (uint64_t)rs->desc, rs->variable_name, "list_ruin_move_selector");
+        for (int i = 0; i < 4; ++i) {  // xoshiro256++ seed_from_u64: splitmix64 expansion
+            state += 0x9E3779B97F4A7C15ULL;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+            st[(size_t)r * 4 + i] = z ^ (z >> 31);
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_ruin_rng, st.data(), st.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SF_OK;
+}
 
 // ---- model assembly --------------------------------------------------------------------
 static int build_list_model(sf_ctx* ctx, int d) {
@@ -987,6 +1076,7 @@ int32_t sf_phase_start(sf_ctx* ctx) {
     HIPCHK(ctx, hipMemsetAsync(ctx->sp.seed_draws, 0, (size_t)ctx->R * 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->sp.stats, 0, (size_t)ctx->R * SF_STATS_WORDS * 8, ctx->stream));
     if ((rc = anneal_phase_start(ctx))) return rc;
+    if ((rc = ruin_phase_start(ctx))) return rc;
     if (ctx->has_list_model)
         hipLaunchKernelGGL(k_list_phase_start, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->lm, ctx->sp);
     if (ctx->has_scalar_model)  // mixed: same committed score (aliased), adds the best snapshot of the values
@@ -1003,7 +1093,7 @@ template <int L, bool TRACE, class VT>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
-                  gl.kopt_nearby, gl.n);
+                  gl.kopt_nearby, gl.n, gl.has_ruin);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for 2 workgroups of 4 waves per CU); ties go to the larger group
@@ -1031,7 +1121,8 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
 static bool has_plain_list_leaves(sf_ctx* ctx) {
     for (auto& s : ctx->selectors)
         if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP || s.kind == SF_SEL_LIST_REVERSE ||
-                                         s.kind == SF_SEL_SUBLIST_CHANGE || s.kind == SF_SEL_SUBLIST_SWAP || s.kind == SF_SEL_KOPT))
+                                         s.kind == SF_SEL_SUBLIST_CHANGE || s.kind == SF_SEL_SUBLIST_SWAP || s.kind == SF_SEL_KOPT ||
+                                         s.kind == SF_SEL_LIST_RUIN))
             return true;
     return false;
 }
@@ -1041,7 +1132,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // default-policy declaration order: list rules first, then scalar change, scalar swap
     // (runtime/compiler/default_local_search/policy.rs:104-108)
     for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
-                     SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+                     SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_LIST_RUIN, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
         for (auto& s : ctx->selectors) {
             const bool is_list = kind != SF_SEL_SCALAR_CHANGE && kind != SF_SEL_SCALAR_SWAP;
             if (s.kind != kind) continue;
@@ -1067,6 +1158,12 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                     gl.kopt_nearby = 1;
                     gl.kopt_scratch = ctx->d_kopt_scratch;
                 }
+            }
+            if (kind == SF_SEL_LIST_RUIN) {
+                if (gl.has_ruin) return fail(ctx, SF_ERR_UNSUPPORTED, "one list ruin leaf per union");
+                if (!ctx->d_ruin_rng) return fail(ctx, SF_ERR_INVALID, "list ruin leaf: sf_phase_start seeds its stream first");
+                gl.has_ruin = 1;
+                gl.ruin = RuinParams{s.min_size, s.max_size, s.moves_per_step, s.max_source_len, s.skip_empty, ctx->d_ruin_rng};
             }
             gl.min_size[gl.n] = s.min_size;
             gl.max_size[gl.n] = s.max_size;

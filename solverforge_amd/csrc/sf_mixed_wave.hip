@@ -30,6 +30,7 @@ namespace sf {
 
 constexpr int GL = 8;          // max leaves of the generic union
 constexpr uint32_t GRC = 128;  // ring capacity per leaf
+constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 64;  // == RuinLds::bytes (sf_ruin.h)
 
 constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
 constexpr uint64_t SALT_LC_INTRA = 0x1157C4A46E000003ULL, SALT_LC_INTER = 0x1157C4A46E000004ULL;
@@ -44,6 +45,12 @@ constexpr uint64_t SALT_SC_INTER = 0x5B157C4A46E00005ULL;
 constexpr uint64_t SALT_SS_ENTITY = 0x5B1575A090000001ULL, SALT_SS_START = 0x5B1575A090000002ULL;  // sublist_swap.rs:74,89,104
 constexpr uint64_t SALT_SS_SIZE = 0x5B1575A090000003ULL;
 
+struct RuinParams {  // list ruin leaf (sf_ruin.h)
+    int32_t min_count, max_count, moves_per_step, max_source_len;  // max_source_len 0 = None
+    int32_t skip_empty;
+    uint64_t* rng;  // [R][4] per-solve SmallRng state of the leaf
+};
+
 struct GLeaves {
     int32_t n;
     int32_t kind[GL];   // sf_selector_kind: 1 scalar change, 2 scalar swap, 4 list change, 8 list swap, 64 list reverse,
@@ -55,15 +62,17 @@ struct GLeaves {
     int32_t min_size[GL], max_size[GL];  // sublist leaves; k-opt leaf: min_size = min_segment_len
     int32_t kopt_nearby;     // the union has a distance-pruned 3-opt leaf (kind 512, max_nearby > 0)
     uint64_t* kopt_scratch;  // [R][n_cap] distance keys of routes longer than KOPT_LDS_KEYS
+    int32_t has_ruin;        // the union has a list ruin leaf (kind 1024); parameters + per-solve stream in `ruin`
+    RuinParams ruin;
 };
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, leaftab, total;
+    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, ruin, leaftab, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
     // n_leaves rings only: the LDS slice decides how many replicas a CU holds
-    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL) {
+    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * GRC * n_leaves, 16);
@@ -89,6 +98,8 @@ struct GCarve {
         o = align_up(o + sizeof(VT) * n_scalar, 16);
         kopt = o;  // working set of the distance-pruned 3-opt stream
         o = align_up(o + (kopt_nearby ? KoptLds::bytes : 0), 16);
+        ruin = o;  // list ruin leaf: streams, candidate table, recreate work area (RuinLds)
+        o = align_up(o + (has_ruin ? RUIN_LDS_BYTES : 0), 16);
         leaftab = o;  // per-leaf generator / ring / scheduler state (LeafTab)
         o = align_up(o + sizeof(uint32_t) * 16 * GL, 16);
         total = o;
@@ -153,6 +164,10 @@ __device__ __forceinline__ void map_slots_to_groups(uint32_t cnt, uint32_t slot,
     offset = lane - (uint32_t)__shfl((int)pre, (int)lo);
 }
 
+}  // namespace sf
+#include "sf_ruin.h"
+namespace sf {
+
 // workgroups of 4 waves: 2 resident workgroups per CU = 2 waves per SIMD (<= 256 VGPRs)
 #ifndef SF_MIXED_BLOCKS_PER_CU
 #define SF_MIXED_BLOCKS_PER_CU 2
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
     const bool unified_eval = has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval;
-    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n);
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, gl.has_ruin);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
     uint8_t* ringx = (uint8_t*)(mem + cv.ringx);  // [leaf][GRC]
@@ -225,6 +240,12 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             const uint32_t o = s_off[v], len = s_off[v + 1] - o;
             for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
         }
+        wave_sync();
+    }
+
+    const RuinLds rl(mem + cv.ruin);
+    if (gl.has_ruin) {  // the leaf's per-solve stream lives in LDS for the launch
+        if (lane < 4) rl.prng[lane] = gl.ruin.rng[(size_t)r * 4 + lane];
         wave_sync();
     }
 
@@ -403,6 +424,11 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 ++ni;
             }
             wave_sync();
+        }
+        if (gl.has_ruin) {  // list ruin leaf: open the cursor (one draw of the per-solve stream), count the source pool
+            const uint32_t pool = ruin_open_cursor(gl.ruin, rl, ctx, s_off, V, !p.dry_run, lane);
+            for (int l = 0; l < nl; ++l)
+                if (lt.geti(l, LeafTab::KIND) == 1024) lt.put_gen(l, GGen{0, 0, 0, 0, pool, 0, pool == 0 || gl.ruin.moves_per_step <= 0});
         }
         // union scheduler (vec_union.rs:190-365): StratifiedRandom with equal weights when > 1 leaf
         const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
@@ -857,6 +883,22 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             wx = ctx.selection_index(q, 7u, kopt_pattern_salt(ldesc, ent, c1, c2, c3));
                         }
                         wave_sync();  // the triples are consumed before the next call overwrites them
+                    } else if (kind == 1024) {  // ---- list ruin (list_kernel/ruin.rs:127-144): one candidate per call, scored right here ----
+                        if (g.a >= (uint32_t)gl.ruin.moves_per_step) {
+                            g.done = 1;
+                            break;
+                        }
+                        ruin_next_candidate(gl.ruin, rl, s_off, V, g.e, g.a, lane);
+                        int64_t base_score[L];
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
+                        ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, rl.work, gl.ruin.skip_empty, false,
+                                         base_score, rl.score + (size_t)g.a * 4);
+                        wave_sync();
+                        keep = lane == 0;
+                        w0 = g.a;
+                        g.a += 1;
+                        if (g.a >= (uint32_t)gl.ruin.moves_per_step) g.done = 1;
                     } else if (kind == 64) {  // ---- list reverse / 2-opt (list_kernel/reverse.rs:68-108) ----
                         uint32_t ent = 0, len = 0;
                         for (;;) {  // entities shorter than two elements are skipped
@@ -1126,6 +1168,10 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                                            : eval_scalar_move(sm, s_vals, 1, m0, m1, 0);
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
+                    } else if (my_kind == 1024) {  // list ruin: scored when it was generated
+                        doable = true;
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) sc.v[kk] = rl.score[(size_t)m0 * 4 + kk];
                     } else {
                         ListDelta d;
                         if (unified_eval)  // symmetric matrix: one shared gather for every kind
@@ -1240,6 +1286,14 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             tm[3] = my_kind == 1 ? 0 : (int32_t)m1;
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
+                        } else if (my_kind == 1024) {  // a = list, a_pos = count, six 16-bit positions in b / b_pos / value
+                            const uint16_t* cd = rl.cand + (size_t)m0 * RuinLds::CAND_WORDS;
+                            tm[0] = 8;
+                            tm[1] = (int32_t)cd[0];
+                            tm[2] = (int32_t)cd[1];
+                            tm[3] = (int32_t)((uint32_t)cd[2] | ((uint32_t)cd[3] << 16));
+                            tm[4] = (int32_t)((uint32_t)cd[4] | ((uint32_t)cd[5] << 16));
+                            tm[5] = (int32_t)((uint32_t)cd[6] | ((uint32_t)cd[7] << 16));
                         } else {
                             tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : (my_kind == 64 ? 4 : (my_kind == 128 ? 5 : (my_kind == 512 ? 7 : 6))));
                             tm[1] = (int32_t)(m0 >> 16);
@@ -1304,6 +1358,30 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     }
                 }
                 wave_sync();
+            } else if (kind == 1024) {  // committed ruin: the same recreate, this time kept
+                const uint16_t* cd = rl.cand + (size_t)a * RuinLds::CAND_WORDS;
+                if (tracing && lane == 0) {
+                    p.trace_applied[0] = 1;
+                    if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied
+                    p.trace_applied[1] = 8;
+                    p.trace_applied[2] = (int32_t)cd[0];
+                    p.trace_applied[3] = (int32_t)cd[1];
+                    p.trace_applied[4] = (int32_t)((uint32_t)cd[2] | ((uint32_t)cd[3] << 16));
+                    p.trace_applied[5] = (int32_t)((uint32_t)cd[4] | ((uint32_t)cd[5] << 16));
+                    p.trace_applied[6] = (int32_t)((uint32_t)cd[6] | ((uint32_t)cd[7] << 16));
+                }
+                int64_t base_score[L];
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
+                ruin_recreate<L>(lm, s_visits, s_off, s_load, cd, rl.work, gl.ruin.skip_empty, true, base_score, rl.score + (size_t)a * 4);
+                wave_sync();
+                if (has_nearby) {  // any list may have changed: rebuild node -> (route, position)
+                    for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
+                        const uint32_t o = s_off[v], len = s_off[v + 1] - o;
+                        for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
+                    }
+                    wave_sync();
+                }
             } else {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
@@ -1374,6 +1452,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 
     if (!p.dry_run) {
         if (annealing) sa_store(saw, p.sa, r, lane);
+        if (gl.has_ruin && lane < 4) gl.ruin.rng[(size_t)r * 4 + lane] = rl.prng[lane];
         if (best_pending) {  // the launch ends in a best state: its deferred snapshot
             if (has_list) {
                 const uint32_t tot = uni(s_off[V]);

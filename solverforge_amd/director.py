@@ -18,6 +18,7 @@ from ._lib import MOVE_DTYPE, AnnealingConfigStruct, SolverConfigStruct, SolverF
 class MoveKind:
     CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 0, 1, 2, 3, 4, 5, 6
     KOPT = 7  # a = list, a_pos / b / b_pos = the three cuts, value = reconnection pattern
+    LIST_RUIN = 8  # a = list, a_pos = count, six 16-bit ascending positions in b / b_pos / value
 
 
 class SelectionOrder:  # solverforge_config::SelectionOrder
@@ -53,6 +54,7 @@ class SelectorKind:
     SCALAR_CHANGE, SCALAR_SWAP, LIST_CHANGE, LIST_SWAP = 1, 2, 4, 8
     NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 16, 32, 64, 128, 256
     KOPT = 512
+    LIST_RUIN = 1024
 
 
 @dataclass
@@ -151,6 +153,12 @@ class GpuScoreDirector:
 
     def add_selector(self, kind, descriptor_index, variable_index=0, max_nearby=0, fact_meter=-1):
         check(self._L.sf_selector_add(self._h, kind, descriptor_index, variable_index, max_nearby, fact_meter), self._h)
+
+    def add_ruin_selector(self, descriptor_index, variable_index=0, min_ruin_count=2, max_ruin_count=5, moves_per_step=10,
+                          max_source_list_len=0, skip_empty_destinations=False, variable_name="visits"):
+        """List ruin leaf (ListRuinMoveSelectorConfig defaults); max_source_list_len 0 = None."""
+        check(self._L.sf_selector_add_ruin(self._h, descriptor_index, variable_index, min_ruin_count, max_ruin_count, moves_per_step,
+                                           max_source_list_len, int(skip_empty_destinations), variable_name.encode()), self._h)
 
     def add_kopt_selector(self, descriptor_index, variable_index=0, k=3, min_segment_len=1, max_nearby=20):
         """3-opt leaf (KOptMoveSelectorConfig); max_nearby = 0 enumerates every cut set, > 0 prunes by distance."""

@@ -9,7 +9,7 @@ FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN = 0,
 
 
 def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearby_change", "nearby_swap"),
-               sublist_sizes=(1, 3), kopt=(1, 20)):
+               sublist_sizes=(1, 3), kopt=(1, 20), ruin=(2, 5, 10)):
     # leaves may also name the plain streams "list_change" / "list_swap" (generic N-leaf engine)
     """CVRP: HardSoftScore; all_customers_assigned (not-exists, 1 hard each —
     crates/solverforge/tests/list_clarke_wright_publication/domain/publication_plan.rs:51-65),
@@ -43,6 +43,8 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
         d.add_sublist_selector(SelectorKind.SUBLIST_SWAP, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
     if "kopt" in leaves:  # kopt = (min_segment_len, max_nearby); max_nearby 0 = full enumeration
         d.add_kopt_selector(0, min_segment_len=kopt[0], max_nearby=kopt[1])
+    if "ruin" in leaves:  # ruin = (min_ruin_count, max_ruin_count, moves_per_step)
+        d.add_ruin_selector(0, min_ruin_count=ruin[0], max_ruin_count=ruin[1], moves_per_step=ruin[2], variable_name="visits")
     return d
 
 
