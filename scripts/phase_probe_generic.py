@@ -28,6 +28,10 @@ for it in range(3):
     ms, n = d.profile_solve()
     a = d.total_stats()
     tot = out.sum()
+    if "ruin" in leaves:  # shader clocks inside ruin_recreate: 0 remove, 1 slot prefix, 2 scan, 3 pick + bookkeeping, 4 placement, 5 undo
+        ro = np.zeros(8, dtype=np.uint64)
+        L.sf_debug_ruin_phases(ro.ctypes.data_as(ctypes.c_void_p))
+        print("  ruin_recreate cycles/step/wave %.0f" % (ro.sum() / R / 100), "shares %", np.round(ro / max(ro.sum(), 1) * 100, 1))
     print("launch", it, "ms %.1f" % ms, "Gmoves/s %.2f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / ms / 1e6),
           "moves/step %.0f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / R / 100),
           "fill calls/step %.0f" % ((a["sources_scanned"] - b["sources_scanned"]) / R / 100),

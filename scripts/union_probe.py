@@ -21,8 +21,9 @@ d.sync(); dt = time.perf_counter() - t0
 ms, n = d.profile_solve(); a = d.total_stats()
 moves = a["moves_evaluated"] - b["moves_evaluated"]
 o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
-BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "list_change": 4, "list_swap": 8, "kopt": 512}
+BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "list_change": 4, "list_swap": 8, "kopt": 512, "ruin": 1024}
 o.configure(leaves=sum(BITS[x] for x in leaves), random_seed=0)
+o.set_ruin()
 o.phase_start(); o.steps(ls)
 m0 = o.stats()["moves_evaluated"]; t1 = time.perf_counter(); done = 0
 while done < K * ls and time.perf_counter() - t1 < 20: o.steps(20); done += 20

@@ -565,7 +565,12 @@ static int build_list_model(sf_ctx* ctx, int d) {
             m.mat32 = m32;
         }
     for (auto& kv : ctx->facts)
-        if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat) m.mat_symmetric = kv.second.symmetric ? 1 : 0;
+        if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat) {
+            m.mat_symmetric = kv.second.symmetric ? 1 : 0;
+            m.leg16 = (kv.second.symmetric && m.mat32 && m.dist_level >= 0 && kv.second.max_finite < 0xFFFF && m.dim <= 65535) ? 1 : 0;
+            const bool no16 = std::getenv("SF_AMD_NO_LEG16") != nullptr;  // diagnostics / parity tests: force the general ruin path
+            if (no16) m.leg16 = 0;
+        }
     {  // 32-bit trial arithmetic (k_list_search_wave MODE 2): every leg finite and < 2^26, |level delta| < 2^30
         const int64_t lim = (int64_t)1 << 28;
         auto mag = [](int64_t v) { return v < 0 ? (v == INT64_MIN ? INT64_MAX : -v) : v; };
@@ -587,6 +592,7 @@ static int build_list_model(sf_ctx* ctx, int d) {
             if (off) ok = false;
         }
         ctx->lm_small = ok;
+        m.small32 = ok ? 1 : 0;
     }
     // presorted neighbour index for the wave engine: every matrix row sorted by (distance, node)
     bool nearby = false;
@@ -1089,11 +1095,11 @@ int32_t sf_phase_start(sf_ctx* ctx) {
 }  // extern "C"
 
 // generic N-leaf engine: mixed models, and list models whose union has plain list change / swap leaves
-template <int L, bool TRACE, class VT>
+template <int L, bool TRACE, class VT, bool RUIN = false>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
-                  gl.kopt_nearby, gl.n, gl.has_ruin);
+                  gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for 2 workgroups of 4 waves per CU); ties go to the larger group
@@ -1109,7 +1115,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
             wpb = w;
         }
     }
-    auto kern = k_mixed_search_wave<L, TRACE, VT>;
+    auto kern = k_mixed_search_wave<L, TRACE, VT, RUIN>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cv.total * wpb)));
     SearchParams q = p;
     q.n_launch = n_replicas;
@@ -1178,6 +1184,11 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // two level counts (2, 4); i16 values, and i8 values for models whose scalar class dominates the LDS slice (a
     // replica's value array in one byte per entity: job shop 500 x 20 fits 4 waves per CU instead of 3)
     gl.levels = ctx->levels;
+    if (gl.has_ruin) {  // the ruin leaf has its own instantiations (i16 values only)
+        if (ctx->levels <= 2)
+            return trace ? launch_mixed_t<2, true, int16_t, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t, true>(ctx, p, gl, grid);
+        return trace ? launch_mixed_t<4, true, int16_t, true>(ctx, p, gl, grid) : launch_mixed_t<4, false, int16_t, true>(ctx, p, gl, grid);
+    }
     if (ctx->has_scalar_model && ctx->sm.n_values <= 127 && ctx->sm.n >= 1024) {
         if (ctx->levels <= 2)
             return trace ? launch_mixed_t<2, true, int8_t>(ctx, p, gl, grid) : launch_mixed_t<2, false, int8_t>(ctx, p, gl, grid);
@@ -1403,6 +1414,12 @@ int32_t sf_download_scalar(sf_ctx* ctx, int32_t replica, int32_t d, int32_t var,
 }  // extern "C"
 
 #ifdef SF_PHASE_PROFILE
+extern "C" int32_t sf_debug_ruin_phases(uint64_t* out8) {  // diagnostic builds only: shader clocks inside ruin_recreate
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_rphase), 64) != hipSuccess) return SF_ERR_HIP;
+    uint64_t z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sf::g_rphase), z, 64);
+    return SF_OK;
+}
 extern "C" int32_t sf_debug_phases(uint64_t* out8) {  // diagnostic builds only (scripts/phase_probe.py)
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_phase), 64) != hipSuccess) return SF_ERR_HIP;
     unsigned long long z[8] = {0};

@@ -26,6 +26,8 @@ struct ListModel {
     const int64_t* mat; // dim x dim row-major (MatrixDistanceMeter + distance constraint)
     const uint32_t* mat32;  // optional compact copy: finite legs < 2^32-1 as u32, 0xFFFFFFFF = not finite
     int32_t mat_symmetric;  // mat[i][j] == mat[j][i] for every pair (checked on the host at upload)
+    int32_t small32;        // every trial delta fits 32-bit arithmetic (all legs finite and < 2^26, small weights / loads)
+    int32_t leg16;          // symmetric, compact copy present, every finite leg < 65535, dim <= 65535: 16-bit leg tables (sf_ruin.h)
     const int32_t* demand;
     const uint32_t* ne_keys;  // not-exists A-side keys (Customer.id)
     int32_t ne_n;

@@ -30,7 +30,7 @@ namespace sf {
 
 constexpr int GL = 8;          // max leaves of the generic union
 constexpr uint32_t GRC = 128;  // ring capacity per leaf
-constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 64;  // == RuinLds::bytes (sf_ruin.h)
+constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 128;  // == RuinLds::bytes (sf_ruin.h)
 
 constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
 constexpr uint64_t SALT_LC_INTRA = 0x1157C4A46E000003ULL, SALT_LC_INTER = 0x1157C4A46E000004ULL;
@@ -68,11 +68,12 @@ struct GLeaves {
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, ruin, leaftab, total;
+    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, leaftab, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
     // n_leaves rings only: the LDS slice decides how many replicas a CU holds
-    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0) {
+    // has_ruin: 0 no ruin leaf, 1 general path (slot prefix only), 2 LDS fast path (+ edge table, list-end edges, matrix row; sf_ruin.h)
+    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * GRC * n_leaves, 16);
@@ -99,7 +100,9 @@ struct GCarve {
         kopt = o;  // working set of the distance-pruned 3-opt stream
         o = align_up(o + (kopt_nearby ? KoptLds::bytes : 0), 16);
         ruin = o;  // list ruin leaf: streams, candidate table, recreate work area (RuinLds)
-        o = align_up(o + (has_ruin ? RUIN_LDS_BYTES : 0), 16);
+        o = align_up(o + (has_ruin ? RUIN_LDS_BYTES + sizeof(uint32_t) * (V + 1) : 0), 16);  // + the slot prefix of a recreate round
+        ruin_fast = o;  // edge[dim], row[dim], edge_end[V], slot[n_cap + V]
+        o = align_up(o + (has_ruin == 2 ? sizeof(uint16_t) * (2 * (size_t)dim + 2 * (size_t)V + n_cap) : 0), 16);
         leaftab = o;  // per-leaf generator / ring / scheduler state (LeafTab)
         o = align_up(o + sizeof(uint32_t) * 16 * GL, 16);
         total = o;
@@ -172,7 +175,8 @@ namespace sf {
 #ifndef SF_MIXED_BLOCKS_PER_CU
 #define SF_MIXED_BLOCKS_PER_CU 2
 #endif
-template <int L, bool TRACE, class VT>
+// RUIN = the union has a list ruin leaf: its own instantiation, so unions without one keep their register allocation
+template <int L, bool TRACE, class VT, bool RUIN = false>
 __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p,
                                                           int has_list, int has_scalar, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
     const bool unified_eval = has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval;
-    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, gl.has_ruin);
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
     uint8_t* ringx = (uint8_t*)(mem + cv.ringx);  // [leaf][GRC]
@@ -244,7 +248,15 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     }
 
     const RuinLds rl(mem + cv.ruin);
-    if (gl.has_ruin) {  // the leaf's per-solve stream lives in LDS for the launch
+    uint32_t* ruin_sbase = (uint32_t*)(mem + cv.ruin + RUIN_LDS_BYTES);
+    RuinFast rfast{nullptr, nullptr, nullptr, nullptr};
+    if (RUIN && lm.leg16) {
+        rfast.edge = (uint16_t*)(mem + cv.ruin_fast);
+        rfast.row = rfast.edge + lm.dim;
+        rfast.edge_end = rfast.row + lm.dim;
+        rfast.slot = rfast.edge_end + V;
+    }
+    if (RUIN) {  // the leaf's per-solve stream lives in LDS for the launch
         if (lane < 4) rl.prng[lane] = gl.ruin.rng[(size_t)r * 4 + lane];
         wave_sync();
     }
@@ -425,7 +437,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             }
             wave_sync();
         }
-        if (gl.has_ruin) {  // list ruin leaf: open the cursor (one draw of the per-solve stream), count the source pool
+        if (RUIN) {  // list ruin leaf: open the cursor (one draw of the per-solve stream), count the source pool
             const uint32_t pool = ruin_open_cursor(gl.ruin, rl, ctx, s_off, V, !p.dry_run, lane);
             for (int l = 0; l < nl; ++l)
                 if (lt.geti(l, LeafTab::KIND) == 1024) lt.put_gen(l, GGen{0, 0, 0, 0, pool, 0, pool == 0 || gl.ruin.moves_per_step <= 0});
@@ -883,17 +895,18 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             wx = ctx.selection_index(q, 7u, kopt_pattern_salt(ldesc, ent, c1, c2, c3));
                         }
                         wave_sync();  // the triples are consumed before the next call overwrites them
-                    } else if (kind == 1024) {  // ---- list ruin (list_kernel/ruin.rs:127-144): one candidate per call, scored right here ----
+                    } else if (RUIN && kind == 1024) {  // ---- list ruin (list_kernel/ruin.rs:127-144): one candidate per call, scored right here ----
                         if (g.a >= (uint32_t)gl.ruin.moves_per_step) {
                             g.done = 1;
                             break;
                         }
+                        if (g.a == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);  // first candidate of the step
                         ruin_next_candidate(gl.ruin, rl, s_off, V, g.e, g.a, lane);
                         int64_t base_score[L];
 #pragma unroll
                         for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
-                        ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, rl.work, gl.ruin.skip_empty, false,
-                                         base_score, rl.score + (size_t)g.a * 4);
+                        ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, rl.work, ruin_sbase, rfast,
+                                         gl.ruin.skip_empty, false, base_score, rl.score + (size_t)g.a * 4);
                         wave_sync();
                         keep = lane == 0;
                         w0 = g.a;
@@ -1041,7 +1054,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 lt.put_gen(l, g);
                 lt.set(l, LeafTab::TAIL, tl);
 #ifdef SF_PHASE_PROFILE
-                PH((kind == 128 || kind == 256) ? 2 : (kind == 64 ? 3 : (kind == 512 ? 4 : 1)))
+                PH((kind == 128 || kind == 256) ? 2 : ((kind == 64 || kind == 1024) ? 3 : (kind == 512 ? 4 : 1)))
 #endif
             }
             wave_sync();
@@ -1058,31 +1071,39 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 // start of every step and after every whole cycle).  Lay out whole cycles directly; the
                 // pull-by-pull simulation below handles partial cycles, exhaustion and refills.
                 if (nl > 1 && nlive > 1) {
-                    // every live child's running weight equal?  one parallel read (lane l = leaf l) instead of nl serial ones
+                    // One cycle of the smooth weighted round-robin with equal weights pulls every live child once, in
+                    // descending running weight (ties: rotated order), and leaves the weights as it found them -- provided
+                    // max - min < live children (true with equal weights at the start of a step, and again a few pulls
+                    // after a child ran dry).  Whole cycles are laid onto the lanes directly; the pull-by-pull simulation
+                    // below only handles the transient after an exhaustion, partial cycles and refills.
                     const uint32_t livem = ~exmask & ((1u << nl) - 1u);
-                    const int32_t wc = lane < (uint32_t)nl ? (int32_t)lt.w[lane * 16 + LeafTab::WCUR] : 0;
-                    const int32_t w0 = __shfl(wc, __ffs((int)livem) - 1);
-                    const bool aligned = __ballot(lane < (uint32_t)nl && ((livem >> lane) & 1u) && wc != w0) == 0ull;
-                    if (aligned) {
-                        // my pull t = lane: cycle t / nlive, child = (t % nlive)-th live leaf in rotated order
+                    const int32_t wc = lane < (uint32_t)nl ? (int32_t)lt.w[lane * 16 + LeafTab::WCUR] : 0;  // lane l = leaf l
+                    uint32_t mypos = 0;
+                    for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos)
+                        if (((u_order >> (4u * pos)) & 15u) == lane) mypos = pos;
+                    int32_t wmax = INT32_MIN, wmin = INT32_MAX;
+                    uint32_t rank = 0;
+                    for (int j = 0; j < nl; ++j) {
+                        if (!((livem >> j) & 1u)) continue;
+                        const int32_t wj = __shfl(wc, j);
+                        const uint32_t pj = (uint32_t)__shfl((int)mypos, j);
+                        wmax = wj > wmax ? wj : wmax;
+                        wmin = wj < wmin ? wj : wmin;
+                        rank += (wj > wc || (wj == wc && pj < mypos)) ? 1u : 0u;
+                    }
+                    if (wmax - wmin < nlive) {
+                        uint32_t r_order = 0;  // live leaves by pull order inside a cycle, 4 bits each
+                        for (int j = 0; j < nl; ++j)
+                            if ((livem >> j) & 1u) r_order |= (uint32_t)j << (4u * (uint32_t)__shfl((int)rank, j));
+                        r_order = uni(r_order);
+                        // my pull t = lane: cycle t / nlive, child = the (t % nlive)-th leaf of the cycle
                         const uint32_t cyc = lane / (uint32_t)nlive, slot = lane % (uint32_t)nlive;
-                        uint32_t leaf = 0, seen = 0;
-                        bool found = false;
-                        for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
-                            const uint32_t i = (u_order >> (4u * pos)) & 15u;
-                            if (!((exmask >> i) & 1u)) {
-                                if (!found && seen == slot) {
-                                    leaf = i;
-                                    found = true;
-                                }
-                                seen += 1;
-                            }
-                        }
+                        const uint32_t leaf = (r_order >> (4u * slot)) & 15u;
                         const uint32_t hd = lt.w[leaf * 16 + LeafTab::HEAD], tlq = lt.w[leaf * 16 + LeafTab::TAIL];  // per-lane leaf
                         const bool ok = (int32_t)(tlq - (hd + cyc)) > 0;
                         const uint64_t okm = __ballot(ok);
                         const uint32_t upto = okm == ~0ULL ? 64u : (uint32_t)(__ffsll((unsigned long long)~okm) - 1);
-                        const uint32_t cycles = upto / (uint32_t)nlive;  // whole cycles only: the state stays aligned
+                        const uint32_t cycles = upto / (uint32_t)nlive;  // whole cycles only: the running weights stay as they are
                         if (cycles > 0) {
                             nvalid = cycles * (uint32_t)nlive;
                             if (lane < nvalid) {
@@ -1090,7 +1111,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 my_idx = hd + cyc;
                             }
                             for (int l = 0; l < nl; ++l)
-                                if (!((exmask >> l) & 1u)) lt.set(l, LeafTab::TAKEN, cycles);  // running weights: +nvalid - cycles * nlive = 0
+                                if (!((exmask >> l) & 1u)) lt.set(l, LeafTab::TAKEN, cycles);
                         }
                     }
                 }
@@ -1168,7 +1189,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                                            : eval_scalar_move(sm, s_vals, 1, m0, m1, 0);
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
-                    } else if (my_kind == 1024) {  // list ruin: scored when it was generated
+                    } else if (RUIN && my_kind == 1024) {  // list ruin: scored when it was generated
                         doable = true;
 #pragma unroll
                         for (int kk = 0; kk < L; ++kk) sc.v[kk] = rl.score[(size_t)m0 * 4 + kk];
@@ -1286,7 +1307,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             tm[3] = my_kind == 1 ? 0 : (int32_t)m1;
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
-                        } else if (my_kind == 1024) {  // a = list, a_pos = count, six 16-bit positions in b / b_pos / value
+                        } else if (RUIN && my_kind == 1024) {  // a = list, a_pos = count, six 16-bit positions in b / b_pos / value
                             const uint16_t* cd = rl.cand + (size_t)m0 * RuinLds::CAND_WORDS;
                             tm[0] = 8;
                             tm[1] = (int32_t)cd[0];
@@ -1358,7 +1379,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     }
                 }
                 wave_sync();
-            } else if (kind == 1024) {  // committed ruin: the same recreate, this time kept
+            } else if (RUIN && kind == 1024) {  // committed ruin: the same recreate, this time kept
                 const uint16_t* cd = rl.cand + (size_t)a * RuinLds::CAND_WORDS;
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
@@ -1373,7 +1394,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 int64_t base_score[L];
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
-                ruin_recreate<L>(lm, s_visits, s_off, s_load, cd, rl.work, gl.ruin.skip_empty, true, base_score, rl.score + (size_t)a * 4);
+                ruin_recreate<L>(lm, s_visits, s_off, s_load, cd, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, true, base_score,
+                                 rl.score + (size_t)a * 4);
                 wave_sync();
                 if (has_nearby) {  // any list may have changed: rebuild node -> (route, position)
                     for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
@@ -1452,7 +1474,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 
     if (!p.dry_run) {
         if (annealing) sa_store(saw, p.sa, r, lane);
-        if (gl.has_ruin && lane < 4) gl.ruin.rng[(size_t)r * 4 + lane] = rl.prng[lane];
+        if (RUIN && lane < 4) gl.ruin.rng[(size_t)r * 4 + lane] = rl.prng[lane];
         if (best_pending) {  // the launch ends in a best state: its deferred snapshot
             if (has_list) {
                 const uint32_t tot = uni(s_off[V]);

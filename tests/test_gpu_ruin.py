@@ -32,6 +32,12 @@ def _problem(kind):
         allc = [c for rt in p["routes"] for c in rt]
         p["routes"] = [allc[:80], [], allc[80:81], allc[81:84], [], allc[84:100], allc[100:]]
         return p
+    if kind == "unreach":  # symmetric matrix with unreachable / negative legs: 16-bit leg tables with sentinels, 64-bit deltas
+        p = datasets.make_cvrp(40, 4, 60, seed=3)
+        big = np.iinfo(np.int64).max
+        for a, b, v in [(4, 9, big), (11, 2, -3), (0, 17, big), (30, 31, big)]:
+            p["matrix"][a, b] = p["matrix"][b, a] = v
+        return p
     if kind == "asym":  # asymmetric matrix with unreachable / negative legs
         p = datasets.make_cvrp(36, 6, 40, seed=8)
         r = datasets.stream(123, p["matrix"].size).reshape(p["matrix"].shape)
@@ -74,11 +80,16 @@ def _check_steps(d, o, n, levels=2, expect_kind=None):
 
 
 @pytest.mark.parametrize("problem,ruin", [("plain", (2, 5, 10)), ("tight", (2, 5, 10)), ("ties", (1, 6, 16)), ("ragged", (2, 5, 10)),
-                                          ("asym", (3, 3, 4)), ("plain", (1, 1, 3))])
-def test_ruin_only_traced_steps(oracle, problem, ruin):
+                                          ("asym", (3, 3, 4)), ("plain", (1, 1, 3)), ("unreach", (2, 5, 10))])
+@pytest.mark.parametrize("general_path", [False, True])
+def test_ruin_only_traced_steps(oracle, problem, ruin, general_path, monkeypatch):
     """One-leaf union: every step pulls `moves_per_step` ruin candidates; candidate identity, trial score, accept flag,
-    committed move and the state after every step equal the oracle's; then a fused window."""
+    committed move and the state after every step equal the oracle's; then a fused window.  `general_path` forces the
+    matrix-gather recreate that asymmetric / wide matrices take (SF_AMD_NO_LEG16) on every problem."""
     import solverforge_amd as sfa
+
+    if general_path:
+        monkeypatch.setenv("SF_AMD_NO_LEG16", "1")
 
     p = _problem(problem)
     d, o = _mk(oracle, p, ("ruin",), ruin=ruin, seed=4, la_size=5, limit=8)
@@ -97,7 +108,7 @@ def test_ruin_only_traced_steps(oracle, problem, ruin):
         assert gst[k] == ost[k], k
 
 
-@pytest.mark.parametrize("problem", ["plain", "tight", "ragged"])
+@pytest.mark.parametrize("problem", ["plain", "tight", "ragged", "unreach"])
 def test_default_list_policy_seven_leaves(oracle, problem):
     """The reference's whole default list policy: nearby change, nearby swap, sublist change, sublist swap, reverse,
     distance-pruned 3-opt, ruin (StratifiedRandom, LateAcceptance + AcceptedCount)."""
