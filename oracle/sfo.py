@@ -99,6 +99,8 @@ def lib():
             "sfo_model_enumerate_count": (i64, [vp, u32, u64, u64, i32]),
             "sfo_model_evaluate_moves": (None, [vp, vp, i64, vp, vp]),
             "sfo_model_apply_move": (None, [vp, vp]),
+            "sfo_model_evaluate_compound": (None, [vp, vp, vp, i64, vp, vp]),
+            "sfo_model_apply_compound": (None, [vp, vp, i64]),
             "sfo_model_construct_first_fit": (None, [vp]),
             "sfo_model_get_vars": (i32, [vp, i32, i32, vp]),
             "sfo_model_get_lists": (i32, [vp, i32, vp, vp]),
@@ -303,6 +305,18 @@ class Model:
         lib().sfo_model_evaluate_moves(self.h, _p(moves), len(moves), _p(scores), _p(doable))
         return scores, doable
 
+    def evaluate_compound(self, candidates):
+        """candidates: list of lists of (entity, to_value) edits (to_value -1 = None), each scored as ONE CompoundScalarMove."""
+        edits, offsets = compound_wire(candidates)
+        scores = np.zeros((len(candidates), 4), dtype=np.int64)
+        doable = np.zeros(len(candidates), dtype=np.int32)
+        lib().sfo_model_evaluate_compound(self.h, _p(edits), _p(offsets), len(candidates), _p(scores), _p(doable))
+        return scores, doable
+
+    def apply_compound(self, candidate):
+        edits, _ = compound_wire([candidate])
+        lib().sfo_model_apply_compound(self.h, _p(edits), len(candidate))
+
     def apply_move(self, move):
         mv = np.zeros(1, dtype=MOVE_DTYPE)
         mv[0] = move
@@ -322,6 +336,20 @@ class Model:
         vals = np.zeros(max_elements, dtype=np.uint32)
         t = lib().sfo_model_get_lists(self.h, desc, _p(off), _p(vals))
         return [list(map(int, vals[off[i]: off[i + 1]])) for i in range(n)]
+
+
+def compound_wire(candidates):
+    """(edits as Change-shaped wire moves, offsets[n + 1]) of a list of multi-edit candidates."""
+    offsets = np.zeros(len(candidates) + 1, dtype=np.int64)
+    for i, c in enumerate(candidates):
+        offsets[i + 1] = offsets[i] + len(c)
+    edits = np.zeros(max(int(offsets[-1]), 1), dtype=MOVE_DTYPE)
+    k = 0
+    for c in candidates:
+        for (entity, value) in c:
+            edits[k] = (KIND_CHANGE, entity, 0, 0, 0, value)
+            k += 1
+    return edits, offsets
 
 
 def scoped_seed(base_seed, descriptor_index, variable_name, selector_kind):

@@ -348,6 +348,48 @@ void sfo_model_evaluate_moves(void* h, const sfo_move_t* moves, int64_t n, int64
         std::memcpy(&scores4[4 * i], sc.v, 4 * sizeof(int64_t));
     }
 }
+// ScalarCandidates (planning/scalar/candidate.rs:85-188) as CompoundScalarMoves: candidate i = edits[offsets[i] .. offsets[i + 1]),
+// every edit a Change-shaped sfo_move_t (a = entity, value = to_value).  n x evaluate_candidate, state unchanged.
+static std::vector<ScalarEditO> edits_of(const Model& m, const sfo_move_t* edits, int64_t b, int64_t e) {
+    std::vector<ScalarEditO> v;
+    std::vector<int64_t> values;
+    for (int64_t k = b; k < e; ++k) {
+        const int64_t to = (int64_t)edits[k].value;
+        bool legal = to == NONE ? m.scalar_slot.allows_unassigned : false;
+        if (to != NONE && edits[k].a >= 0 && (size_t)edits[k].a < m.director.working.classes[m.scalar_slot.descriptor_index].n) {
+            values.clear();
+            m.scalar_slot.values_for_entity(m.director.working, (size_t)edits[k].a, values);
+            legal = std::find(values.begin(), values.end(), to) != values.end();
+        }
+        v.push_back({m.scalar_slot.descriptor_index, m.scalar_slot.variable_index, (size_t)edits[k].a, to, legal});
+    }
+    return v;
+}
+void sfo_model_evaluate_compound(void* h, const sfo_move_t* edits, const int64_t* offsets, int64_t n, int64_t* scores4, int32_t* doable) {
+    Model* m = (Model*)h;
+    m->director.calculate_score();
+    for (int64_t i = 0; i < n; ++i) {
+        std::vector<ScalarEditO> ed = edits_of(*m, edits, offsets[i], offsets[i + 1]);
+        if (!compound_is_doable(m->director, ed)) {
+            doable[i] = 0;
+            std::memset(&scores4[4 * i], 0, 4 * sizeof(int64_t));
+            continue;
+        }
+        doable[i] = 1;
+        DirectorScoreState st = m->director.snapshot_score_state();
+        std::vector<int64_t> u = compound_do(m->director, ed);
+        Score sc = m->director.calculate_score();
+        compound_undo(m->director, ed, u);
+        m->director.restore_score_state(st);
+        std::memcpy(&scores4[4 * i], sc.v, 4 * sizeof(int64_t));
+    }
+}
+void sfo_model_apply_compound(void* h, const sfo_move_t* edits, int64_t n_edits) {  // committed do_move of one candidate
+    Model* m = (Model*)h;
+    m->director.calculate_score();
+    compound_do(m->director, edits_of(*m, edits, 0, n_edits));
+    m->director.calculate_score();
+}
 void sfo_model_apply_move(void* h, const sfo_move_t* mv) {  // committed do_move
     Model* m = (Model*)h;
     m->director.calculate_score();

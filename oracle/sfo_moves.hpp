@@ -439,6 +439,51 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
 }
 
 // ---------------------------------------------------------------------------
+// CompoundScalarMove (heuristic/move/compound_scalar.rs:207-330): several ScalarEdits of one ScalarCandidate
+// (planning/scalar/candidate.rs:85-188) scored and applied as ONE move.
+// ---------------------------------------------------------------------------
+struct ScalarEditO {
+    size_t descriptor, variable, entity;
+    int64_t to_value;  // NONE = unassign
+    bool legal;        // value_is_legal of the slot (:186-204): None only when the variable allows it, Some(v) only from the entity's value list
+};
+inline bool compound_is_doable(const ScoreDirector& d, const std::vector<ScalarEditO>& edits) {  // is_doable_on (:254-270)
+    if (edits.empty()) return false;
+    bool changes = false;
+    for (const ScalarEditO& e : edits) {
+        const EntityClass& c = d.working.classes[e.descriptor];
+        if (e.entity >= c.n) return false;
+        if (!e.legal) return false;
+        changes = changes || c.vars[e.variable][e.entity] != e.to_value;
+    }
+    return changes;
+}
+inline std::vector<std::pair<size_t, size_t>> compound_affected(const std::vector<ScalarEditO>& edits) {  // unique_affected_entities (:395-405)
+    std::vector<std::pair<size_t, size_t>> a;
+    for (const ScalarEditO& e : edits) {
+        std::pair<size_t, size_t> k{e.descriptor, e.entity};
+        if (std::find(a.begin(), a.end(), k) == a.end()) a.push_back(k);
+    }
+    return a;
+}
+// do_move (:291-308): old values first, retract every affected entity, apply every edit in order, insert in reverse order
+inline std::vector<int64_t> compound_do(ScoreDirector& d, const std::vector<ScalarEditO>& edits) {
+    std::vector<int64_t> undo;
+    auto affected = compound_affected(edits);
+    for (const ScalarEditO& e : edits) undo.push_back(d.working.classes[e.descriptor].vars[e.variable][e.entity]);
+    for (auto& a : affected) d.before_variable_changed(a.first, a.second);
+    for (const ScalarEditO& e : edits) d.working.classes[e.descriptor].vars[e.variable][e.entity] = e.to_value;
+    for (size_t i = affected.size(); i-- > 0;) d.after_variable_changed(affected[i].first, affected[i].second);
+    return undo;
+}
+inline void compound_undo(ScoreDirector& d, const std::vector<ScalarEditO>& edits, const std::vector<int64_t>& undo) {  // (:310-321)
+    auto affected = compound_affected(edits);
+    for (auto& a : affected) d.before_variable_changed(a.first, a.second);
+    for (size_t i = 0; i < edits.size(); ++i) d.working.classes[edits[i].descriptor].vars[edits[i].variable][edits[i].entity] = undo[i];
+    for (size_t i = affected.size(); i-- > 0;) d.after_variable_changed(affected[i].first, affected[i].second);
+}
+
+// ---------------------------------------------------------------------------
 // Cursors
 // ---------------------------------------------------------------------------
 struct Cursor {

@@ -661,6 +661,62 @@ static void list_ruin_cases() {
     }
 }
 
+// heuristic/move/tests/compound_scalar.rs:146-262: several edits applied and undone atomically, every edit applied before the
+// first after-notification, no-op and illegal candidates rejected
+static void compound_scalar_cases() {
+    struct SnapshotOnInsert : Constraint {  // records (left[0], left[1]) at every after_variable_changed (RecordingCompoundDirector)
+        std::vector<std::pair<int64_t, int64_t>>* log;
+        Score evaluate(const Solution&) const override { return Score::zero(); }
+        size_t match_count(const Solution&) const override { return 0; }
+        Score initialize(const Solution&) override { return Score::zero(); }
+        Score on_insert(const Solution& s, size_t, size_t) override {
+            log->push_back({s.classes[0].vars[0][0], s.classes[0].vars[0][1]});
+            return Score::zero();
+        }
+        Score on_retract(const Solution&, size_t, size_t) override { return Score::zero(); }
+        void reset() override {}
+    };
+    auto mk = [](std::vector<int64_t> left, std::vector<int64_t> right) {
+        ScoreDirector d;
+        d.working.classes.resize(2);
+        d.working.classes[0].n = left.size();
+        d.working.classes[0].vars = {left};
+        d.working.classes[1].n = right.size();
+        d.working.classes[1].vars = {right};
+        return d;
+    };
+    {
+        ScoreDirector d = mk(std::vector<int64_t>(8, 0), std::vector<int64_t>(8, 1));
+        d.calculate_score();
+        std::vector<ScalarEditO> ed = {{0, 0, 0, 2, true}, {1, 0, 0, 3, true}};
+        bool ok = compound_is_doable(d, ed);
+        std::vector<int64_t> u = compound_do(d, ed);
+        ok = ok && d.working.classes[0].vars[0][0] == 2 && d.working.classes[1].vars[0][0] == 3;
+        compound_undo(d, ed, u);
+        ok = ok && d.working.classes[0].vars[0][0] == 0 && d.working.classes[1].vars[0][0] == 1;
+        CHECK("compound_scalar.applies_and_undoes_atomically", ok);
+    }
+    {
+        ScoreDirector d = mk({0, 1}, {});
+        std::vector<std::pair<int64_t, int64_t>> log;
+        auto c = std::make_unique<SnapshotOnInsert>();
+        c->log = &log;
+        d.constraints.members.push_back(std::move(c));
+        d.calculate_score();
+        std::vector<ScalarEditO> ed = {{0, 0, 0, 2, true}, {0, 0, 1, 3, true}};
+        compound_do(d, ed);
+        bool ok = d.working.classes[0].vars[0] == std::vector<int64_t>({2, 3}) && log.size() == 2 &&
+                  log[0] == std::make_pair<int64_t, int64_t>(2, 3) && log[1] == std::make_pair<int64_t, int64_t>(2, 3);
+        CHECK("compound_scalar.all_edits_before_after_notifications", ok);
+    }
+    {
+        ScoreDirector d = mk({0}, {1});
+        CHECK("compound_scalar.rejects_noop", !compound_is_doable(d, {{0, 0, 0, 0, true}}));
+        CHECK("compound_scalar.rejects_illegal", !compound_is_doable(d, {{0, 0, 0, 2, false}}));
+        CHECK("compound_scalar.rejects_empty", !compound_is_doable(d, {}));
+    }
+}
+
 // heuristic/move/tests/k_opt.rs:86-222 (do / undo / doability), selector/k_opt/tests.rs:80-147 and
 // selector/tests/k_opt.rs (first combination, 35 combinations, 245 moves, all doable),
 // benches/selector_cursor_gate.rs:370-382 (4,760 moves on an 18-element route)
@@ -930,6 +986,7 @@ int main() {
     simulated_annealing_cases();
     list_reverse_cases();
     list_ruin_cases();
+    compound_scalar_cases();
     bi_incr_cases();
     cross_bi_cases();
     exists_cases();

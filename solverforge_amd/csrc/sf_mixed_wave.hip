@@ -1116,51 +1116,61 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     }
                 }
                 const bool fast_done = nvalid > 0;
-                while (!fast_done && nvalid < 64 && nlive > 0) {
-                    int sel = -1;
-                    int32_t selw = 0;
-                    if (nl == 1) {
-                        sel = 0;
-                    } else {
-                        for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) {
-                            const int i = (int)((u_order >> (4u * pos)) & 15u);
-                            if (!((exmask >> i) & 1u)) {
-                                const int32_t wi = lt.geti(i, LeafTab::WCUR) + 1;
-                                lt.set(i, LeafTab::WCUR, (uint32_t)wi);
-                                if (sel < 0 || wi > selw) {
-                                    sel = i;
-                                    selw = wi;
-                                }
-                            }
-                        }
-                    }
-                    const uint32_t sel_taken = lt.get(sel, LeafTab::TAKEN), sel_head = lt.get(sel, LeafTab::HEAD);
-                    const bool avail = (int32_t)(lt.get(sel, LeafTab::TAIL) - (sel_head + sel_taken)) > 0;
-                    const bool gdone = lt.get(sel, LeafTab::DONE) != 0;
-                    if (!avail && !gdone) {
-                        // the child has more candidates that are not generated yet: undo this pull's
-                        // bookkeeping and refill first
+                if (!fast_done && nlive > 0) {
+                    // Pull-by-pull simulation with the leaf table in registers (lane l = leaf l): one pull is a handful of
+                    // DPP / readlane instructions instead of a dozen dependent LDS round trips.
+                    const bool isleaf = lane < (uint32_t)nl;
+                    int32_t wc = isleaf ? (int32_t)lt.w[lane * 16 + LeafTab::WCUR] : 0;
+                    const uint32_t hd = isleaf ? lt.w[lane * 16 + LeafTab::HEAD] : 0u, tlv = isleaf ? lt.w[lane * 16 + LeafTab::TAIL] : 0u;
+                    const uint32_t dn = isleaf ? lt.w[lane * 16 + LeafTab::DONE] : 1u;
+                    uint32_t tk = 0;  // TAKEN was just cleared
+                    uint32_t mypos = 0;
+                    for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos)
+                        if (((u_order >> (4u * pos)) & 15u) == lane) mypos = pos;
+                    while (nvalid < 64 && nlive > 0) {
+                        uint32_t sel = 0;
+                        const bool live_l = isleaf && !((exmask >> lane) & 1u);
                         if (nl > 1) {
-                            for (int l = 0; l < nl; ++l)
-                                if (!((exmask >> l) & 1u)) lt.set(l, LeafTab::WCUR, (uint32_t)(lt.geti(l, LeafTab::WCUR) - 1));
+                            if (live_l) wc += 1;
+                            // max running weight, the earlier rotated position on ties: max of (weight << 4 | 15 - position) over
+                            // lanes 0..7 by a DPP prefix max (row_shr 1, 2, 4), read at lane 7
+                            int32_t key = live_l ? (int32_t)(((uint32_t)wc << 4) | (15u - mypos)) : INT32_MIN;
+                            key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x111, 0xf, 0xf, false));
+                            key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x112, 0xf, 0xf, false));
+                            key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x114, 0xf, 0xf, false));
+                            const uint32_t kmax = (uint32_t)__builtin_amdgcn_readlane(key, 7);
+                            sel = (u_order >> (4u * (15u - (kmax & 15u)))) & 15u;
                         }
-                        need_more = true;
-                        break;
+                        const uint32_t sel_taken = (uint32_t)__builtin_amdgcn_readlane((int)tk, (int)sel);
+                        const uint32_t sel_head = (uint32_t)__builtin_amdgcn_readlane((int)hd, (int)sel);
+                        const bool avail = (int32_t)((uint32_t)__builtin_amdgcn_readlane((int)tlv, (int)sel) - (sel_head + sel_taken)) > 0;
+                        const bool gdone = __builtin_amdgcn_readlane((int)dn, (int)sel) != 0;
+                        if (!avail && !gdone) {
+                            // the child has more candidates that are not generated yet: undo this pull's bookkeeping and refill first
+                            if (nl > 1 && live_l) wc -= 1;
+                            need_more = true;
+                            break;
+                        }
+                        if (nl > 1 && lane == sel) wc -= live_weight;
+                        if (!avail) {  // exhausted child discovered at this pull
+                            exmask |= 1u << sel;
+                            nlive -= 1;
+                            live_weight -= 1;
+                            continue;
+                        }
+                        if (lane == sel) tk += 1;
+                        if (lane == nvalid) {
+                            my_leaf = sel;
+                            my_idx = sel_head + sel_taken;
+                        }
+                        nvalid += 1;
                     }
-                    if (nl > 1) lt.set(sel, LeafTab::WCUR, (uint32_t)(lt.geti(sel, LeafTab::WCUR) - live_weight));
-                    if (!avail) {  // exhausted child discovered at this pull
-                        lt.set(sel, LeafTab::EX, 1);
-                        exmask |= 1u << sel;
-                        nlive -= 1;
-                        live_weight -= 1;
-                        continue;
+                    if (isleaf) {
+                        lt.w[lane * 16 + LeafTab::WCUR] = (uint32_t)wc;
+                        lt.w[lane * 16 + LeafTab::TAKEN] = tk;
+                        lt.w[lane * 16 + LeafTab::EX] = (exmask >> lane) & 1u;
                     }
-                    lt.set(sel, LeafTab::TAKEN, sel_taken + 1);
-                    if (lane == nvalid) {
-                        my_leaf = (uint32_t)sel;
-                        my_idx = sel_head + sel_taken;
-                    }
-                    nvalid += 1;
+                    wave_sync();
                 }
                 if (nvalid == 0) {
                     if (need_more) continue;

@@ -737,23 +737,30 @@ __device__ SF_RUIN_ATTR void ruin_recreate_lds(const RuinModel lm_in, lds_u16* v
         for (int k = 0; k < L; ++k) bdv[k] = INT32_MIN;
         if (fast) {
             ruin_build_slot_lists((uint32_t)lm.V, sbase, rf);
+            // the row of the next element is fetched (16 coalesced loads per lane in flight) while the current one is scanned
+            uint32_t pre[16];
+            auto fetch_row = [&](uint32_t xn) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t c = (uint32_t)k * 64u + lane;
+                    pre[k] = c < (uint32_t)lm.dim ? lm.mat32[xn * (uint32_t)lm.dim + c] : 0u;
+                }
+            };
+            fetch_row(uni((uint32_t)rem[0]));
             for (uint32_t ri = 0; ri < n_rem; ++ri) {
                 const uint32_t x = uni((uint32_t)rem[ri]);
                 wave_sync();  // the previous element's scan is done with the row
-                for (uint32_t c0 = 0; c0 < (uint32_t)lm.dim; c0 += 64u * 16u) {  // 16 coalesced loads in flight per lane
-                    uint32_t v[16];
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const uint32_t c = c0 + (uint32_t)k * 64u + lane;
-                        v[k] = c < (uint32_t)lm.dim ? lm.mat32[x * (uint32_t)lm.dim + c] : 0u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const uint32_t c = c0 + (uint32_t)k * 64u + lane;
-                        if (c < (uint32_t)lm.dim) rf.row[c] = (uint16_t)(v[k] >= 0xFFFFu ? 0xFFFFu : v[k]);
-                    }
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t c = (uint32_t)k * 64u + lane;
+                    if (c < (uint32_t)lm.dim) rf.row[c] = (uint16_t)(pre[k] >= 0xFFFFu ? 0xFFFFu : pre[k]);
+                }
+                for (uint32_t c = 1024u + lane; c < (uint32_t)lm.dim; c += 64) {  // rows longer than the prefetch window
+                    const uint32_t v = lm.mat32[x * (uint32_t)lm.dim + c];
+                    rf.row[c] = (uint16_t)(v >= 0xFFFFu ? 0xFFFFu : v);
                 }
                 wave_sync();
+                if (ri + 1 < n_rem) fetch_row(uni((uint32_t)rem[ri + 1]));
                 RPH(6)
                 if (fast == 2)
                     ruin_scan_element_small<L>(lm, visits, off, load, sbase, rf, ri, has_cap ? (int32_t)lm.demand[x] : 0, ent, (int32_t)parked_dem, bdv,
