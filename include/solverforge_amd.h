@@ -285,6 +285,16 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
                          int64_t* out_scores, int32_t* out_doable);
 /* ≙ committed Move::do_move + before/after_variable_changed + calculate_score */
 int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* move);
+/* ScalarCandidateProvider surface (crates/solverforge-solver/src/planning/scalar/candidate.rs:85-190): a ScalarCandidate carries
+ * several ScalarEdits and is scored / applied as ONE move (CompoundScalarMove, heuristic/move/compound_scalar.rs:207-330: retract
+ * every affected entity, apply every edit in order, insert in reverse order; doable = at least one edit, every to_value legal,
+ * some edit differs from its entity's current value).  Candidate i = edits[offsets[i] .. offsets[i + 1]), every edit a
+ * SF_MOVE_CHANGE-shaped record (a = entity_index, value = to_value), at most 8 edits per candidate.  One launch, state unchanged.
+ * out_scores[n * score_levels], out_doable[n].  SF_ERR_UNSUPPORTED on a load_balance model. */
+int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n,
+                                  int64_t* out_scores, int32_t* out_doable);
+/* committed do_move of one multi-edit candidate */
+int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits);
 
 /* ---- MoveSelector / cursor surface ------------------------------------------------------- */
 /* Opens the configured union cursor for MoveStreamContext(step_index, step_seed) with the given

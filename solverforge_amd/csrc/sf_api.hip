@@ -907,12 +907,95 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     return SF_OK;
 }
 
+// ScalarCandidateProvider surface: multi-edit candidates scored as ONE CompoundScalarMove each
+int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n,
+                                  int64_t* out_scores, int32_t* out_doable) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
+    if (replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_scores || !out_doable)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate_compound arguments");
+    if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode == 1)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance model (floating-point aggregate) are not chained on the device");
+    if (n == 0) return SF_OK;
+    if (offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "offsets[0] must be 0");
+    for (int64_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SF_ERR_INVALID, "offsets must not decrease");
+        if (offsets[i + 1] - offsets[i] > SF_COMPOUND_MAX) return fail(ctx, SF_ERR_UNSUPPORTED, "at most 8 edits per compound candidate on the device");
+    }
+    const int64_t total = offsets[n];
+    if (total > 0 && !edits) return fail(ctx, SF_ERR_INVALID, "edits is NULL");
+    for (int64_t k = 0; k < total; ++k)
+        if (edits[k].kind != SF_MOVE_CHANGE) return fail(ctx, SF_ERR_INVALID, "a ScalarEdit is a SF_MOVE_CHANGE-shaped record");
+    int32_t* d_edits = nullptr;
+    int64_t *d_off = nullptr, *d_sc = nullptr;
+    int32_t* d_do = nullptr;
+    auto release = [&]() {
+        (void)hipFree(d_edits);
+        (void)hipFree(d_off);
+        (void)hipFree(d_sc);
+        (void)hipFree(d_do);
+    };
+    hipError_t ea = hipMalloc((void**)&d_edits, (size_t)(total > 0 ? total : 1) * 24);
+    if (ea == hipSuccess) ea = hipMalloc((void**)&d_off, (size_t)(n + 1) * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void**)&d_sc, (size_t)n * ctx->levels * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void**)&d_do, (size_t)n * 4);
+    if (ea == hipSuccess && total > 0) ea = hipMemcpyAsync(d_edits, edits, (size_t)total * 24, hipMemcpyHostToDevice, ctx->stream);
+    if (ea == hipSuccess) ea = hipMemcpyAsync(d_off, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (ea != hipSuccess) {
+        release();
+        return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
+    }
+    hipLaunchKernelGGL(k_scalar_evaluate_compound, dim3((int)((n + 255) / 256)), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica,
+                       d_edits, d_off, n, d_sc, d_do);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release();
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return SF_OK;
+}
+
+int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized || !edits || replica < 0 || replica >= ctx->R) return fail(ctx, SF_ERR_INVALID, "bad sf_apply_compound arguments");
+    if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
+    if (n_edits <= 0) return fail(ctx, SF_ERR_INVALID, "move is not doable");
+    if (n_edits > SF_COMPOUND_MAX) return fail(ctx, SF_ERR_UNSUPPORTED, "at most 8 edits per compound candidate on the device");
+    if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode == 1)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance model (floating-point aggregate) are not chained on the device");
+    for (int64_t k = 0; k < n_edits; ++k)
+        if (edits[k].kind != SF_MOVE_CHANGE) return fail(ctx, SF_ERR_INVALID, "a ScalarEdit is a SF_MOVE_CHANGE-shaped record");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    int32_t* d_edits = nullptr;
+    hipError_t ea = hipMalloc((void**)&d_edits, (size_t)n_edits * 24);
+    if (ea == hipSuccess) ea = hipMemcpyAsync(d_edits, edits, (size_t)n_edits * 24, hipMemcpyHostToDevice, ctx->stream);
+    if (ea != hipSuccess) {
+        (void)hipFree(d_edits);
+        return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
+    }
+    hipLaunchKernelGGL(k_scalar_apply_compound, dim3(1), dim3(64), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, d_edits, (int)n_edits,
+                       ctx->d_ok);
+    int32_t ok = 0;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&ok, ctx->d_ok, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_edits);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    if (!ok) return fail(ctx, SF_ERR_INVALID, "move is not doable");
+    return SF_OK;
+}
+
 int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !mv || replica < 0 || replica >= ctx->R)
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
     int rc = alloc_search(ctx);
     if (rc) return rc;
+    if (mv->kind == SF_MOVE_LIST_RUIN)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "a list ruin is scored and committed inside the fused step (sf_solve_steps / sf_solve_step_traced)");
     const bool list_move = mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_KOPT;
     if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
     if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");

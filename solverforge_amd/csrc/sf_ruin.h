@@ -723,6 +723,17 @@ __device__ SF_RUIN_ATTR void ruin_recreate_lds(const RuinModel lm_in, lds_u16* v
     // ---- recreate: one wave-wide round per remaining element ----
     uint32_t n_rem = cnt, n_pl = 0;
     bool rolled_back = false;
+    // fast path: the matrix row of the next element to scan is fetched (16 coalesced loads per lane in flight) while the
+    // current element is scanned, and the first row of a round while the previous placement is applied
+    uint32_t pre[16];
+    auto fetch_row = [&](uint32_t xn) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t c = (uint32_t)k * 64u + lane;
+            pre[k] = c < (uint32_t)lm.dim ? lm.mat32[xn * (uint32_t)lm.dim + c] : 0u;
+        }
+    };
+    if (fast) fetch_row(uni((uint32_t)rem[0]));
     while (n_rem > 0) {
         ruin_slot_prefix(lm, off, sbase, ent, n_rem, skip_empty);
         RPH(1)
@@ -737,16 +748,6 @@ __device__ SF_RUIN_ATTR void ruin_recreate_lds(const RuinModel lm_in, lds_u16* v
         for (int k = 0; k < L; ++k) bdv[k] = INT32_MIN;
         if (fast) {
             ruin_build_slot_lists((uint32_t)lm.V, sbase, rf);
-            // the row of the next element is fetched (16 coalesced loads per lane in flight) while the current one is scanned
-            uint32_t pre[16];
-            auto fetch_row = [&](uint32_t xn) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t c = (uint32_t)k * 64u + lane;
-                    pre[k] = c < (uint32_t)lm.dim ? lm.mat32[xn * (uint32_t)lm.dim + c] : 0u;
-                }
-            };
-            fetch_row(uni((uint32_t)rem[0]));
             for (uint32_t ri = 0; ri < n_rem; ++ri) {
                 const uint32_t x = uni((uint32_t)rem[ri]);
                 wave_sync();  // the previous element's scan is done with the row
@@ -799,6 +800,7 @@ __device__ SF_RUIN_ATTR void ruin_recreate_lds(const RuinModel lm_in, lds_u16* v
         const uint32_t w_d0 = uni((uint32_t)__shfl((int)pick.d0, win)), w_next = uni((uint32_t)__shfl((int)pick.next, win));
         // the parked element ri sits at logical end + ri of the source list: an ordinary list change (pre-removal destination)
         const uint32_t src_pos = uni(off[ent + 1]) - uni(off[ent]) - n_rem + ri;
+        if (fast && n_rem > 1) fetch_row(uni((uint32_t)rem[ri == 0 ? 1 : 0]));  // first row of the next round, in flight during the placement
         RPH(3)
         ruin_list_change(lm, visits, off, load, ent, src_pos, be, bp);
         RPH(4)

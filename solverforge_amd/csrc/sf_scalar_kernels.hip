@@ -62,8 +62,9 @@ struct ScalarModel {
 // returns conflicts(e, v_new) - conflicts(e, v_old) in ONE pass over the partner list, sixteen
 // partner ids in flight per iteration (the list lives in HBM/L2, the values in LDS): an average
 // graph-colouring row (degree 20) costs two memory round trips instead of twenty.
-template <class VT>
-__device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, const VT* vals, uint32_t e, int32_t v_new,
+// `vals` is anything indexable by entity: the replica's value array (const VT*) or a view of it (ValsView)
+template <class VA>
+__device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, const VA& vals, uint32_t e, int32_t v_new,
                                                          int32_t v_old, uint32_t skip) {
     int32_t c = 0;
     if (m.cross_kind == SC_PARTNERS_EQUAL) {
@@ -157,10 +158,10 @@ __device__ __forceinline__ void lb_from_tables(const ScalarModel& m, const uint3
 // kind 0: Change(a -> value); kind 1: Swap(a, b)
 // `cnt` / `sum`: per-value entity count and summed size of the step snapshot (null when the model has
 // no value-keyed constraint)
-template <class VT>
-__device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, const VT* vals, int kind, uint32_t a,
-                                                        uint32_t b, int32_t value, const uint32_t* cnt = nullptr,
-                                                        const int64_t* sum = nullptr, const int64_t* lb = nullptr) {
+// vals / cnt / sum: plain arrays, or views with operator[] (a compound candidate chains its edits through ValsView / TableView)
+template <class VA, class CA, class SA>
+__device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, const VA& vals, int kind, uint32_t a,
+                                                          uint32_t b, int32_t value, const CA& cnt, const SA& sum, const int64_t* lb) {
     ScalarDelta r{0, 0, 0, 0, false};
     if (kind == 0) {  // apply.rs:15-24,219-230
         if (a >= (uint32_t)m.n || value >= m.n_values || value < -1) return r;
@@ -225,6 +226,13 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
     return r;
 }
 
+template <class VT>
+__device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, const VT* vals, int kind, uint32_t a,
+                                                        uint32_t b, int32_t value, const uint32_t* cnt = nullptr,
+                                                        const int64_t* sum = nullptr, const int64_t* lb = nullptr) {
+    return eval_scalar_move_v(m, vals, kind, a, b, value, cnt, sum, lb);
+}
+
 // committed update of the per-value tables (one lane)
 template <class VT>
 __device__ __forceinline__ void scalar_tables_apply(const ScalarModel& m, const VT* vals, int kind, uint32_t a, uint32_t b,
@@ -274,6 +282,151 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
         if (k == m.grp_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.grp_weight * (uint64_t)d.d_grp));
     }
     return s;
+}
+
+// ---- compound candidates (planning/scalar/candidate.rs:85-188 -> heuristic/move/compound_scalar.rs:207-330) --------------------
+// A ScalarCandidate of several ScalarEdits is ONE move: every edit is applied, then the score is read.  Every score level is
+// a sum of integer match weights, so the move's delta is the telescoping sum of its edits applied one after the other; edit k
+// is priced against the snapshot as seen through the earlier edits of the same candidate (views below, a few words per lane).
+constexpr int SF_COMPOUND_MAX = 8;  // edits per candidate on the device
+struct ValsView {
+    const int32_t* vals;
+    uint32_t ent[SF_COMPOUND_MAX];
+    int32_t val[SF_COMPOUND_MAX];
+    int n;
+    __device__ __forceinline__ int32_t operator[](uint32_t o) const {
+        int32_t v = vals[o];
+        for (int i = 0; i < n; ++i)
+            if (ent[i] == o) v = val[i];
+        return v;
+    }
+    __device__ __forceinline__ void set(uint32_t o, int32_t v) {
+        for (int i = 0; i < n; ++i)
+            if (ent[i] == o) {
+                val[i] = v;
+                return;
+            }
+        ent[n] = o;
+        val[n] = v;
+        n += 1;
+    }
+};
+template <class T>
+struct TableView {  // per-value count / sum table plus the candidate's own shifts
+    const T* base;
+    int32_t key[2 * SF_COMPOUND_MAX];
+    T delta[2 * SF_COMPOUND_MAX];
+    int n;
+    __device__ __forceinline__ T operator[](int32_t v) const {
+        T x = base ? base[v] : (T)0;
+        for (int i = 0; i < n; ++i)
+            if (key[i] == v) x = (T)(x + delta[i]);
+        return x;
+    }
+    __device__ __forceinline__ void add(int32_t v, T d) {
+        for (int i = 0; i < n; ++i)
+            if (key[i] == v) {
+                delta[i] = (T)(delta[i] + d);
+                return;
+            }
+        key[n] = v;
+        delta[n] = d;
+        n += 1;
+    }
+};
+
+// n x evaluate_candidate for multi-edit candidates: candidate t = edits[offsets[t] .. offsets[t + 1]) (Change-shaped moves).
+// is_doable_on (compound_scalar.rs:254-270): at least one edit, every to_value legal, some edit differs from the CURRENT value.
+__global__ __launch_bounds__(256) void k_scalar_evaluate_compound(ScalarModel m, int replica, const int32_t* edits, const int64_t* offsets, int64_t n,
+                                                                  int64_t* out_scores, int32_t* out_doable) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
+    const int32_t* vals = m.vals + (size_t)replica * m.n;
+    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    int64_t* t_sum = (int64_t*)tab_mem;
+    uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
+    if (tables) {
+        for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
+        __syncthreads();
+        scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
+        __syncthreads();
+    }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t b = offsets[t], e = offsets[t + 1];
+    bool legal = e > b && e - b <= SF_COMPOUND_MAX, changes = false;
+    for (int64_t k = b; k < e && legal; ++k) {
+        const int32_t* mv = edits + k * 6;
+        legal = mv[0] == 0 && mv[1] >= 0 && mv[1] < m.n && mv[5] >= -1 && mv[5] < m.n_values && (mv[5] >= 0 || m.allows_unassigned);
+        if (legal) changes = changes || vals[mv[1]] != mv[5];
+    }
+    const bool doable = legal && changes;
+    ScoreV<4> s;
+    for (int k = 0; k < 4; ++k) s.v[k] = m.score[(size_t)replica * 4 + k];
+    if (doable) {
+        ValsView vv{vals, {}, {}, 0};
+        TableView<uint32_t> cv{tables ? t_cnt : nullptr, {}, {}, 0};
+        TableView<int64_t> sv{tables ? t_sum : nullptr, {}, {}, 0};
+        for (int64_t k = b; k < e; ++k) {
+            const uint32_t a = (uint32_t)edits[k * 6 + 1];
+            const int32_t to = edits[k * 6 + 5];
+            const int32_t old = vv[a];
+            const ScalarDelta d = eval_scalar_move_v(m, vv, 0, a, 0u, to, cv, sv, (const int64_t*)nullptr);
+            if (!d.doable) continue;  // this edit repeats the value its entity already has at this point
+            s = apply_scalar_delta<4>(m, s.v, d);
+            if (tables) {
+                const int64_t sz = m.size ? (int64_t)m.size[a] : 0;
+                if (old >= 0) cv.add(old, (uint32_t)-1), sv.add(old, -sz);
+                if (to >= 0) cv.add(to, 1u), sv.add(to, sz);
+            }
+            vv.set(a, to);
+        }
+    }
+    out_doable[t] = doable ? 1 : 0;
+    for (int k = 0; k < m.levels; ++k) out_scores[t * m.levels + k] = doable ? s.v[k] : 0;
+}
+
+// committed do_move of one compound candidate (compound_scalar.rs:291-308), one lane
+__global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int replica, const int32_t* edits, int n_edits, int32_t* out_ok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
+    int32_t* vals = m.vals + (size_t)replica * m.n;
+    int64_t* t_sum = (int64_t*)tab_mem;
+    uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
+    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    if (tables) {
+        for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
+        __syncthreads();
+        scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    bool legal = n_edits > 0, changes = false;
+    for (int k = 0; k < n_edits && legal; ++k) {
+        const int32_t* mv = edits + k * 6;
+        legal = mv[0] == 0 && mv[1] >= 0 && mv[1] < m.n && mv[5] >= -1 && mv[5] < m.n_values && (mv[5] >= 0 || m.allows_unassigned);
+        if (legal) changes = changes || vals[mv[1]] != mv[5];
+    }
+    if (!legal || !changes) {
+        *out_ok = 0;
+        return;
+    }
+    int64_t* cur = m.score + (size_t)replica * 4;
+    for (int k = 0; k < n_edits; ++k) {
+        const uint32_t a = (uint32_t)edits[k * 6 + 1];
+        const int32_t to = edits[k * 6 + 5];
+        const ScalarDelta d = eval_scalar_move(m, vals, 0, a, 0u, to, t_cnt, t_sum, (const int64_t*)nullptr);
+        if (!d.doable) continue;
+        const ScoreV<4> s = apply_scalar_delta<4>(m, cur, d);
+        if (tables) scalar_tables_apply(m, vals, 0, a, 0u, to, t_cnt, t_sum);
+        vals[a] = to;
+        for (int q = 0; q < 4; ++q) cur[q] = s.v[q];
+    }
+    *out_ok = 1;
 }
 
 // evaluate_all / initialize: full recomputation (fresh_score; FullAssert).  grid = R blocks.

@@ -195,6 +195,33 @@ class GpuScoreDirector:
         check(self._L.sf_step_evaluate(self._h, replica, ptr(moves), len(moves), ptr(scores), ptr(doable)), self._h)
         return scores, doable
 
+    @staticmethod
+    def _compound_wire(candidates):
+        offsets = np.zeros(len(candidates) + 1, dtype=np.int64)
+        for i, c in enumerate(candidates):
+            offsets[i + 1] = offsets[i] + len(c)
+        edits = np.zeros(max(int(offsets[-1]), 1), dtype=MOVE_DTYPE)
+        k = 0
+        for c in candidates:
+            for (entity, value) in c:
+                edits[k] = (MoveKind.CHANGE, entity, 0, 0, 0, value)
+                k += 1
+        return edits, offsets
+
+    def evaluate_candidates(self, candidates, replica=0):
+        """ScalarCandidateProvider surface: `candidates` = list of lists of (entity_index, to_value) ScalarEdits (to_value -1 =
+        None); each list is scored as ONE CompoundScalarMove -> (scores[n, levels], doable[n]).  State unchanged."""
+        edits, offsets = self._compound_wire(candidates)
+        scores = np.zeros((len(candidates), self.levels), dtype=np.int64)
+        doable = np.zeros(len(candidates), dtype=np.int32)
+        check(self._L.sf_step_evaluate_compound(self._h, replica, ptr(edits), ptr(offsets), len(candidates), ptr(scores), ptr(doable)), self._h)
+        return scores, doable
+
+    def apply_candidate(self, candidate, replica=0):
+        """Committed do_move of one multi-edit ScalarCandidate."""
+        edits, _ = self._compound_wire([candidate])
+        check(self._L.sf_apply_compound(self._h, replica, ptr(edits), len(candidate)), self._h)
+
     def apply_move(self, move, replica=0):
         mv = np.zeros(1, dtype=MOVE_DTYPE)
         mv[0] = move
