@@ -114,7 +114,18 @@ typedef enum sf_constraint_kind {
      * round(sqrt(sum(load^2) - (sum load)^2 / keys)) in f64, the one floating-point step of the scoring path
      * (bit-identical: IEEE division, correctly rounded sqrt, round half away from zero).  `fact_a` = i32 metric
      * column, every metric >= 1 (SF_ERR_UNSUPPORTED otherwise: the reference skips zero metrics) */
-    SF_C_LOAD_BALANCE_VALUE = 10
+    SF_C_LOAD_BALANCE_VALUE = 10,
+    /* keyed cross-join of the planning class A with a FACT class B: for_each(A).join(for_each(B), equal(A.value, B.id))
+     * .filter(f).penalize(w) -- cross_bi_incremental::Bi keyed by the planning value (constraint/cross_bi_incremental/state.rs:32-461,
+     * incremental.rs:93-137; the shape of constraint/tests/cross_bi_incr.rs:60-83 "unavailable employee").  The closures become
+     * data: `fact_a` = i64 matrix cost[n_rows][n_values], cost[a][b] = weight of the pair (a, b), 0 = the filter rejects it;
+     * the level gets -weight * cost[a][value(a)] for every assigned a.  Also the uni form for_each(A).filter(f).penalize(w(a, value)). */
+    SF_C_VALUE_COST = 11,
+    /* for_each(B).if_exists / if_not_exists(for_each(A).filter(assigned), equal(B.id, A.value)).penalize(weight * w[B]) with B the
+     * value-keyed fact rows -- IncrementalExistsConstraint in Exists (param 1) or NotExists (param 0) mode over a planning
+     * class (constraint/exists.rs:42-437, key_existence_delta :218-231; constraint/tests/exists.rs:34-190): a row is scored while
+     * some / no entity holds its value.  `fact_a` = i32 per-row weight column [n_values], or -1 for weight 1 */
+    SF_C_EXISTS_VALUE = 12
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {

@@ -343,6 +343,78 @@ inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_
 }
 
 // ---- CVRP -------------------------------------------------------------------
+// ---- assignment: keyed cross-join with a fact class + exists / not-exists of planning entities per fact row -------------
+// The node shapes the reference pins in constraint/tests/cross_bi_incr.rs:60-83,205-381 (shifts joined with employees by
+// equal(shift.employee_id, employee.id), a filter and a weight on the pair) and constraint/tests/exists.rs:34-190
+// (for_each(A).if_exists / if_not_exists(B, equal keys)), on a model with a ScalarChange / ScalarSwap neighbourhood:
+// n entities ("shifts") choose one of n_values fact rows ("employees").
+//   level 0: unassigned entity (uni), 1 each
+//   level 1: cross_bi A x B keyed by the planning value: filter cost[a][b] != 0, weight cost[a][b]
+//   level `ex_level`: for every fact row b with an entity holding it (ex_mode 1) / with none (ex_mode 0): ex_weight * row_w[b]
+struct AssignFacts {
+    size_t n = 0, n_values = 0;
+    std::vector<int64_t> cost;   // [n][n_values]
+    std::vector<int64_t> row_w;  // [n_values]
+};
+inline std::unique_ptr<Model> make_assignment(size_t n, size_t n_values, const int64_t* values, const int64_t* cost, int64_t cost_weight,
+                                              const int64_t* row_w, int32_t ex_mode, int32_t ex_level, int64_t ex_weight) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<AssignFacts>();
+    facts->n = n;
+    facts->n_values = n_values;
+    facts->cost.assign(cost, cost + n * n_values);
+    facts->row_w.assign(row_w, row_w + n_values);
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n;
+    s.classes[0].vars.assign(1, std::vector<int64_t>(values, values + n));
+    s.facts = facts;
+    const AssignFacts* af = facts.get();
+    m->director.constraints.members.push_back(make_unassigned(0, 0, Score::of(1, 0), "Unassigned"));
+
+    auto join = std::make_unique<CrossBiConstraint>();
+    join->name = "Pair cost";
+    join->impact = Impact::Penalty;
+    join->a_source = ChangeSource::descriptor(0);
+    join->b_source = ChangeSource::fixed();  // problem facts
+    join->a_count = [](const Solution& s) { return s.classes[0].n; };
+    join->b_count = [af](const Solution&) { return af->n_values; };
+    join->key_a = [](const Solution& s, size_t a) { return s.classes[0].vars[0][a]; };  // None never equals a row id
+    join->key_b = [](const Solution&, size_t b) { return (int64_t)b; };
+    join->filter = [af](const Solution& s, size_t a, size_t b) { return s.classes[0].vars[0][a] != NONE && af->cost[a * af->n_values + b] != 0; };
+    join->weight = [af, cost_weight](const Solution&, size_t a, size_t b) { return Score::of(0, wrap_mul(cost_weight, af->cost[a * af->n_values + b])); };
+    m->director.constraints.members.push_back(std::move(join));
+
+    if (ex_level >= 0) {
+        auto ex = std::make_unique<ExistsConstraint>();
+        ex->name = ex_mode ? "Row in use" : "Row unused";
+        ex->impact = Impact::Penalty;
+        ex->mode = ex_mode ? ExistenceMode::Exists : ExistenceMode::NotExists;
+        ex->a_source = ChangeSource::fixed();  // the fact rows
+        ex->parent_source = ChangeSource::descriptor(0);
+        ex->a_count = [af](const Solution&) { return af->n_values; };
+        ex->parent_count = [](const Solution& s) { return s.classes[0].n; };
+        ex->filter_a = [](const Solution&, size_t) { return true; };
+        ex->filter_parent = [](const Solution& s, size_t p) { return s.classes[0].vars[0][p] != NONE; };
+        ex->key_a = [](const Solution&, size_t b) { return (int64_t)b; };
+        ex->flatten = [](const Solution& s, size_t p, std::vector<int64_t>& out) { out.push_back(s.classes[0].vars[0][p]); };
+        ex->weight = [af, ex_level, ex_weight](const Solution&, size_t b) { return Score::level(ex_level, wrap_mul(ex_weight, af->row_w[b])); };
+        ex->indexed_usize = true;
+        m->director.constraints.members.push_back(std::move(ex));
+    }
+    m->has_scalar = true;
+    m->scalar_slot.descriptor_index = 0;
+    m->scalar_slot.variable_index = 0;
+    m->scalar_slot.allows_unassigned = true;
+    m->scalar_slot.values_for_entity = [n_values](const Solution&, size_t, std::vector<int64_t>& out) {
+        out.clear();
+        for (size_t v = 0; v < n_values; ++v) out.push_back((int64_t)v);
+    };
+    m->leaves = LEAF_SCALAR_CHANGE | LEAF_SCALAR_SWAP;
+    m->wire_search();
+    return m;
+}
+
 inline int64_t cvrp_route_distance(const CvrpFacts& f, const std::vector<uint32_t>& route) {
     if (route.empty()) return 0;
     int64_t total = f.distance_cost(f.depot, route[0]);

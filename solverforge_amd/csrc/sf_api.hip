@@ -360,7 +360,7 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
                           int32_t level, int64_t weight) {
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
-    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_LOAD_BALANCE_VALUE) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_EXISTS_VALUE) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
     ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
     return SF_OK;
 }
@@ -847,6 +847,8 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_SELFJOIN_VALUE_EQUAL: raw = q[5], count = q[5]; break;
             case SF_C_GROUPED_VALUE_SUM:
             case SF_C_LOAD_BALANCE_VALUE: raw = q[6], count = q[7]; break;
+            case SF_C_VALUE_COST: raw = q[8], count = q[9]; break;
+            case SF_C_EXISTS_VALUE: raw = q[10], count = q[11]; break;
             default: return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind in sf_evaluate_each");
         }
         (void)on_list;
@@ -1259,8 +1261,8 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             gl.kind[gl.n++] = kind;
         }
     if (gl.n == 0) return fail(ctx, SF_ERR_INVALID, "no selector configured");
-    if (ctx->has_scalar_model && (ctx->sm.sj_level >= 0 || ctx->sm.grp_level >= 0))
-        return fail(ctx, SF_ERR_UNSUPPORTED, "value-keyed constraints (self-join / grouped sum) run in the scalar engine only");
+    if (ctx->has_scalar_model && ctx->sm.tables())
+        return fail(ctx, SF_ERR_UNSUPPORTED, "value-keyed constraints (self-join / grouped sum / exists by value) run in the scalar engine only");
     if (ctx->has_list_model && (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536))
         return fail(ctx, SF_ERR_UNSUPPORTED, "generic engine packs list elements and positions in 16 bits");
     p.n_leaves = gl.n;

@@ -51,6 +51,16 @@ struct ScalarModel {
     int32_t sj_arity = 2;  // keyed self-join arity: 2 pairs, 3 / 4 / 5 = tri / quad / penta tuples sharing a value
     int32_t grp_mode = 0;  // 0: sum of per-group weights (grouped node + sum collector); 1: load_balance collector (unfairness)
     const int32_t* size = nullptr;     // [n] summed fact of the grouped constraint
+    // keyed cross-join with a fact side: every assigned entity e matches the fact row its value names; filter + weight of the
+    // pair are the data cost[e][value] (0 = filtered out)
+    int32_t cost_level = -1;
+    int64_t cost_weight = 0;
+    const int64_t* cost = nullptr;     // [n][n_values]
+    // exists / not-exists of planning entities per value-keyed fact row (uses the per-value count table)
+    int32_t ex_level = -1, ex_mode = 1;  // 1: scored while some entity holds the value, 0: while none does
+    int64_t ex_weight = 0;
+    const int32_t* ex_w = nullptr;     // [n_values] per-row weight (null = 1)
+    __host__ __device__ bool tables() const { return sj_level >= 0 || grp_level >= 0 || ex_level >= 0; }
     // per-replica committed state
     int32_t* vals = nullptr;        // [R][n]  (-1 = None)
     int64_t* score = nullptr;       // [R][4]
@@ -106,6 +116,8 @@ struct ScalarDelta {
     int64_t d_cross;  // change of the number of matched pairs (predicate join)
     int64_t d_pairs;  // change of the number of same-value pairs (keyed self-join)
     int64_t d_grp;    // change of the summed group weights
+    int64_t d_cost;   // change of the summed (entity, value) pair costs
+    int64_t d_ex;     // change of the summed weights of the value rows whose existence test holds
     bool doable;
 };
 
@@ -162,7 +174,7 @@ __device__ __forceinline__ void lb_from_tables(const ScalarModel& m, const uint3
 template <class VA, class CA, class SA>
 __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, const VA& vals, int kind, uint32_t a,
                                                           uint32_t b, int32_t value, const CA& cnt, const SA& sum, const int64_t* lb) {
-    ScalarDelta r{0, 0, 0, 0, false};
+    ScalarDelta r{0, 0, 0, 0, 0, 0, false};
     if (kind == 0) {  // apply.rs:15-24,219-230
         if (a >= (uint32_t)m.n || value >= m.n_values || value < -1) return r;
         const int32_t old = (int32_t)vals[a];
@@ -178,6 +190,13 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
             else
                 r.d_pairs = (int64_t)((value >= 0 ? choose_u64(cnt[value], m.sj_arity - 1) : 0ull) -
                                       (old >= 0 ? choose_u64(cnt[old] - 1u, m.sj_arity - 1) : 0ull));
+        }
+        if (m.cost_level >= 0)
+            r.d_cost = wsub(value >= 0 ? m.cost[(size_t)a * m.n_values + value] : 0, old >= 0 ? m.cost[(size_t)a * m.n_values + old] : 0);
+        if (m.ex_level >= 0) {  // the row `value` starts to exist when it had no holder, the row `old` stops when a was its last
+            const int64_t gain = (value >= 0 && cnt[value] == 0) ? (m.ex_w ? (int64_t)m.ex_w[value] : 1) : 0;
+            const int64_t loss = (old >= 0 && cnt[old] == 1) ? (m.ex_w ? (int64_t)m.ex_w[old] : 1) : 0;
+            r.d_ex = m.ex_mode ? wsub(gain, loss) : wsub(loss, gain);
         }
         if (m.grp_level >= 0 && m.grp_mode == 1) {  // load balance: metrics are >= 1 (validated at sf_constraint_add)
             const int64_t sz = (int64_t)m.size[a];
@@ -206,7 +225,13 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
         r.doable = true;
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflict_delta(m, vals, a, vb, va, b) + scalar_conflict_delta(m, vals, b, va, vb, a);
-        // a swap exchanges two members: per-value counts (and so the same-value pairs) do not change
+        if (m.cost_level >= 0) {
+            const size_t ra = (size_t)a * m.n_values, rb = (size_t)b * m.n_values;
+            const int64_t after = wadd(vb >= 0 ? m.cost[ra + vb] : 0, va >= 0 ? m.cost[rb + va] : 0);
+            const int64_t before = wadd(va >= 0 ? m.cost[ra + va] : 0, vb >= 0 ? m.cost[rb + vb] : 0);
+            r.d_cost = wsub(after, before);
+        }
+        // a swap exchanges two members: per-value counts (and so the same-value pairs and every row's existence) do not change
         if (m.grp_level >= 0 && m.grp_mode == 1) {  // a swap exchanges two members: key counts stay, loads shift
             const int64_t sa = (int64_t)m.size[a], sb = (int64_t)m.size[b];
             int64_t s1 = lb[0], s2 = lb[1];
@@ -280,6 +305,8 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
         if (k == m.cross_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.cross_weight * (uint64_t)d.d_cross));
         if (k == m.sj_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.sj_weight * (uint64_t)d.d_pairs));
         if (k == m.grp_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.grp_weight * (uint64_t)d.d_grp));
+        if (k == m.cost_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.cost_weight * (uint64_t)d.d_cost));
+        if (k == m.ex_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.ex_weight * (uint64_t)d.d_ex));
     }
     return s;
 }
@@ -341,7 +368,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_compound(ScalarModel m,
                                                                   int64_t* out_scores, int32_t* out_doable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
     const int32_t* vals = m.vals + (size_t)replica * m.n;
-    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    const bool tables = m.tables();
     int64_t* t_sum = (int64_t*)tab_mem;
     uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
     if (tables) {
@@ -394,7 +421,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
     int32_t* vals = m.vals + (size_t)replica * m.n;
     int64_t* t_sum = (int64_t*)tab_mem;
     uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
-    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    const bool tables = m.tables();
     if (tables) {
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
             t_sum[v] = 0;
@@ -434,10 +461,10 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
 __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
                                                              int accumulate, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];  // per-value tables (when used)
-    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups;
+    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups, s_cost, s_cost_n, s_ex, s_ex_n;
     const int r = blockIdx.x;
     const int32_t* vals = m.vals + (size_t)r * m.n;
-    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    const bool tables = m.tables();
     int64_t* t_sum = (int64_t*)tab_mem;
     uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
     if (threadIdx.x == 0) {
@@ -446,6 +473,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         s_pairs = 0;
         s_grp = 0;
         s_groups = 0;
+        s_cost = s_cost_n = s_ex = s_ex_n = 0;
     }
     if (tables)
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
@@ -456,13 +484,19 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
     if (tables) {
         scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
         __syncthreads();
-        unsigned long long pairs = 0, grp = 0, groups = 0;
+        unsigned long long pairs = 0, grp = 0, groups = 0, ex = 0, ex_n = 0;
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
             const unsigned long long c = t_cnt[v];
             pairs += m.sj_arity == 2 ? c * (c - (c ? 1 : 0)) / 2 : choose_u64(c, m.sj_arity);
-            if (m.grp_mode == 0) grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
+            if (m.grp_mode == 0 && m.grp_level >= 0) grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
             groups += c ? 1 : 0;
+            if (m.ex_level >= 0 && ((c > 0) == (m.ex_mode != 0))) {
+                ex += (unsigned long long)(int64_t)(m.ex_w ? m.ex_w[v] : 1);
+                ex_n += 1;
+            }
         }
+        atomicAdd(&s_ex, ex);
+        atomicAdd(&s_ex_n, ex_n);
         atomicAdd(&s_pairs, pairs);
         atomicAdd(&s_grp, grp);
         atomicAdd(&s_groups, groups);
@@ -476,10 +510,15 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             }
         }
     }
-    unsigned long long un = 0, cross = 0;
+    unsigned long long un = 0, cross = 0, cost = 0, cost_n = 0;
     for (uint32_t e = threadIdx.x; e < (uint32_t)m.n; e += blockDim.x) {
         const int32_t v = vals[e];
         if (v < 0) ++un;
+        if (m.cost_level >= 0 && v >= 0) {
+            const int64_t c = m.cost[(size_t)e * m.n_values + v];
+            cost += (unsigned long long)c;
+            cost_n += c != 0 ? 1 : 0;
+        }
         if (m.cross_level >= 0 && v >= 0) {
             // every matched pair is seen from both sides: count it at its lower index
             if (m.cross_kind == SC_PARTNERS_EQUAL) {
@@ -500,6 +539,8 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
     }
     atomicAdd(&s_un, un);
     atomicAdd(&s_cross, cross);
+    atomicAdd(&s_cost, cost);
+    atomicAdd(&s_cost_n, cost_n);
     __syncthreads();
     if (threadIdx.x == 0) {
         int64_t sc[SF_MAX_LEVELS_CONST] = {0, 0, 0, 0};
@@ -507,6 +548,8 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         if (m.cross_level >= 0) sc[m.cross_level] = wsub(sc[m.cross_level], (int64_t)((uint64_t)m.cross_weight * s_cross));
         if (m.sj_level >= 0) sc[m.sj_level] = wsub(sc[m.sj_level], (int64_t)((uint64_t)m.sj_weight * s_pairs));
         if (m.grp_level >= 0) sc[m.grp_level] = wsub(sc[m.grp_level], (int64_t)((uint64_t)m.grp_weight * s_grp));
+        if (m.cost_level >= 0) sc[m.cost_level] = wsub(sc[m.cost_level], (int64_t)((uint64_t)m.cost_weight * s_cost));
+        if (m.ex_level >= 0) sc[m.ex_level] = wsub(sc[m.ex_level], (int64_t)((uint64_t)m.ex_weight * s_ex));
         for (int k = 0; k < m.levels; ++k) {
             if (out_scores) out_scores[(size_t)r * m.levels + k] = accumulate ? wadd(out_scores[(size_t)r * m.levels + k], sc[k]) : sc[k];
             if (commit) m.score[(size_t)r * 4 + k] = accumulate ? wadd(m.score[(size_t)r * 4 + k], sc[k]) : sc[k];
@@ -518,6 +561,10 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             q[5] = (int64_t)s_pairs;
             q[6] = (int64_t)s_grp;
             q[7] = (int64_t)s_groups;
+            q[8] = (int64_t)s_cost;
+            q[9] = (int64_t)s_cost_n;
+            q[10] = (int64_t)s_ex;
+            q[11] = (int64_t)s_ex_n;
         }
     }
 }
@@ -529,7 +576,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, in
                                                                int skip_foreign) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
     const int32_t* vals = m.vals + (size_t)replica * m.n;
-    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    const bool tables = m.tables();
     int64_t* t_sum = (int64_t*)tab_mem;
     uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
     if (tables) {  // every block rebuilds the per-value tables of the snapshot
@@ -551,7 +598,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, in
     if (skip_foreign && moves[t * 6] != 0 && moves[t * 6] != 1) return;  // a list move of a mixed model
     const int64_t* cur = m.score + (size_t)replica * 4;
     const int32_t* mv = moves + t * 6;
-    ScalarDelta d{0, 0, 0, 0, false};
+    ScalarDelta d{0, 0, 0, 0, 0, 0, false};
     if (mv[0] == 0 && mv[1] >= 0)
         d = eval_scalar_move(m, vals, 0, (uint32_t)mv[1], 0u, mv[5], t_cnt, t_sum, s_lb);
     else if (mv[0] == 1 && mv[1] >= 0 && mv[3] >= 0)
@@ -568,7 +615,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply(ScalarModel m, int replica,
     int32_t* vals = m.vals + (size_t)replica * m.n;
     int64_t* t_sum = (int64_t*)tab_mem;
     uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
-    if (m.sj_level >= 0 || m.grp_level >= 0) {
+    if (m.tables()) {
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
             t_sum[v] = 0;
             t_cnt[v] = 0;
@@ -649,7 +696,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     const bool annealing = p.acceptor == 3;
     if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t n = (uint32_t)m.n;
-    const bool tables = m.sj_level >= 0 || m.grp_level >= 0;
+    const bool tables = m.tables();
     const SCarve<VT> cv(m.n, tables ? m.n_values : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][SRC][2]

@@ -155,3 +155,33 @@ def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=
     if "swap" in leaves:
         d.add_selector(SelectorKind.SCALAR_SWAP, 0)
     return d
+
+
+def build_assignment(values, cost, n_values, n_replicas=1, device_id=0, cost_weight=1, row_w=None, ex_mode=1, ex_level=1, ex_weight=1,
+                     leaves=("change", "swap")):
+    """Assignment: n entities choose one of n_values fact rows.  HardSoftScore: `Unassigned` (uni, 1 hard each); the keyed
+    cross-join of the planning class with the fact class -- for_each(A).join(B, equal(A.value, B.id)).filter(cost != 0)
+    .penalize(cost_weight * cost[a][b]) (cross_bi_incremental::Bi keyed by the planning value, the shape of
+    constraint/tests/cross_bi_incr.rs:60-83) as the matrix fact `cost`; and for_each(B).if_exists / if_not_exists(A, equal(B.id,
+    A.value)).penalize(ex_weight * row_w[b]) (IncrementalExistsConstraint, constraint/exists.rs:42-437) on `ex_level`
+    (ex_level < 0: no exists node)."""
+    import numpy as np
+
+    n = len(values)
+    d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
+    d.add_entity_class(0, n)
+    d.add_scalar_variable(0, 0, n_values, True, values)
+    d.add_fact_matrix(FACT_MATRIX, np.ascontiguousarray(cost, dtype=np.int64).reshape(n, n_values))
+    d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
+    d.add_constraint(ConstraintKind.VALUE_COST, 0, fact=FACT_MATRIX, level=1, weight=cost_weight)
+    if ex_level >= 0:
+        fact = -1
+        if row_w is not None:
+            d.add_fact_column_i32(FACT_COLUMN, np.ascontiguousarray(row_w, dtype=np.int32))
+            fact = FACT_COLUMN
+        d.add_constraint(ConstraintKind.EXISTS_VALUE, 0, fact=fact, param=ex_mode, level=ex_level, weight=ex_weight)
+    if "change" in leaves:
+        d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
+    if "swap" in leaves:
+        d.add_selector(SelectorKind.SCALAR_SWAP, 0)
+    return d
