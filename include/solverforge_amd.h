@@ -307,6 +307,14 @@ int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t*
 /* committed do_move of one multi-edit candidate */
 int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits);
 
+/* ≙ ListCheapestInsertionPhase (crates/solverforge-solver/src/manager/phase_factory/list_construction/cheapest.rs; kernel
+ * cheapest/kernel.rs:57-150, bookkeeping cheapest/live.rs:64-170) on EVERY replica's current lists: the elements of
+ * `elements[n]` (source order; typically the A-side keys of the not-exists constraint) that are in no list yet are placed one by
+ * one at the (list, position) whose trial score is strictly best (the first of equal scores stays).  Unrestricted owners, no
+ * construction order key, no precedence hooks.  Counters: one score_calculation per trial, one accepted + applied step per
+ * placed element.  Commits the score of the constructed lists; out_scores[n_replicas * score_levels] may be NULL. */
+int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores);
+
 /* ---- MoveSelector / cursor surface ------------------------------------------------------- */
 /* Opens the configured union cursor for MoveStreamContext(step_index, step_seed) with the given
  * selection order on replica `replica`, drains it, and returns every candidate in cursor order

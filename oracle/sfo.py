@@ -103,6 +103,7 @@ def lib():
             "sfo_model_evaluate_compound": (None, [vp, vp, vp, i64, vp, vp]),
             "sfo_model_apply_compound": (None, [vp, vp, i64]),
             "sfo_model_construct_first_fit": (None, [vp]),
+            "sfo_model_construct_list_cheapest": (None, [vp, vp, i32]),
             "sfo_model_get_vars": (i32, [vp, i32, i32, vp]),
             "sfo_model_get_lists": (i32, [vp, i32, vp, vp]),
         }
@@ -331,6 +332,11 @@ class Model:
         mv = np.zeros(1, dtype=MOVE_DTYPE)
         mv[0] = move
         lib().sfo_model_apply_move(self.h, _p(mv))
+
+    def construct_list_cheapest(self, elements):
+        """List cheapest-insertion construction of the unassigned `elements` (source order)."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        lib().sfo_model_construct_list_cheapest(self.h, _p(el), len(el))
 
     def construct_first_fit(self):
         lib().sfo_model_construct_first_fit(self.h)

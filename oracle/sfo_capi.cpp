@@ -401,6 +401,11 @@ void sfo_model_apply_move(void* h, const sfo_move_t* mv) {  // committed do_move
     move_do(m->director, mm);
     m->director.calculate_score();
 }
+// ListCheapestInsertionPhase over the list class: `elements` = the unassigned elements in source order
+void sfo_model_construct_list_cheapest(void* h, const uint32_t* elements, int32_t n) {
+    Model* m = (Model*)h;
+    construct_list_cheapest(m->director, m->list_slot.descriptor_index, std::vector<uint32_t>(elements, elements + n), &m->search.stats);
+}
 void sfo_model_construct_first_fit(void* h) {
     Model* m = (Model*)h;
     construct_first_fit(m->director, m->scalar_slot, &m->search.stats);

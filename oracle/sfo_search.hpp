@@ -463,4 +463,48 @@ inline void construct_first_fit(ScoreDirector& d, const ScalarSlot& slot, Solver
     }
 }
 
+// List cheapest-insertion construction (manager/phase_factory/list_construction/cheapest/kernel.rs:57-150, live.rs:64-170): the
+// unassigned elements in (construction order key, source index) order -- no order key here -- are placed one by one; every
+// (list, position) is trial-inserted and fully scored (one score_calculation each), the strictly best score wins (the first of
+// equals stays), the insertion is committed as one accepted + applied step.  Unrestricted owners, no precedence hooks.
+inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned, SolverStats* stats = nullptr) {
+    d.calculate_score();
+    EntityClass& c = d.working.classes[descriptor];
+    if (unassigned.empty() || c.n == 0) return;
+    for (uint32_t element : unassigned) {
+        bool have = false;
+        size_t best_e = 0, best_p = 0;
+        Score best_score;
+        for (size_t e = 0; e < c.n; ++e) {
+            const size_t len = c.lists[e].size();
+            for (size_t pos = 0; pos <= len; ++pos) {
+                DirectorScoreState st = d.snapshot_score_state();
+                d.before_variable_changed(descriptor, e);
+                c.lists[e].insert(c.lists[e].begin() + (ptrdiff_t)pos, element);
+                d.after_variable_changed(descriptor, e);
+                Score sc = d.calculate_score();
+                d.before_variable_changed(descriptor, e);
+                c.lists[e].erase(c.lists[e].begin() + (ptrdiff_t)pos);
+                d.after_variable_changed(descriptor, e);
+                d.restore_score_state(st);
+                if (stats) ++stats->score_calculations;
+                if (!have || sc > best_score) {
+                    have = true;
+                    best_e = e, best_p = pos, best_score = sc;
+                }
+            }
+        }
+        if (!have) continue;
+        d.before_variable_changed(descriptor, best_e);
+        c.lists[best_e].insert(c.lists[best_e].begin() + (ptrdiff_t)best_p, element);
+        d.after_variable_changed(descriptor, best_e);
+        d.calculate_score();
+        if (stats) {
+            ++stats->moves_accepted;
+            ++stats->moves_applied;
+            ++stats->step_count;
+        }
+    }
+}
+
 }  // namespace sfo

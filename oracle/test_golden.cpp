@@ -661,6 +661,21 @@ static void list_ruin_cases() {
     }
 }
 
+// manager/phase_factory/list_construction/cheapest/kernel.rs:57-150 with a constant score (cheapest/tests.rs zero_score): the
+// first tried (list, position) wins every time, so the elements pile up in front of list 0 in reverse source order
+static void cheapest_insertion_cases() {
+    ScoreDirector d;
+    d.working.classes.resize(1);
+    d.working.classes[0].n = 2;
+    d.working.classes[0].lists = {{}, {}};
+    SolverStats st;
+    construct_list_cheapest(d, 0, {0, 1, 2}, &st);
+    CHECK("cheapest_insertion.first_position_wins_ties",
+          d.working.classes[0].lists[0] == std::vector<uint32_t>({2, 1, 0}) && d.working.classes[0].lists[1].empty());
+    // trials: element k sees (k + 1) + 1 slots -> 2 + 3 + 4
+    CHECK("cheapest_insertion.one_score_calculation_per_trial", st.score_calculations == 9 && st.moves_applied == 3 && st.step_count == 3);
+}
+
 // heuristic/move/tests/compound_scalar.rs:146-262: several edits applied and undone atomically, every edit applied before the
 // first after-notification, no-op and illegal candidates rejected
 static void compound_scalar_cases() {
@@ -987,6 +1002,7 @@ int main() {
     list_reverse_cases();
     list_ruin_cases();
     compound_scalar_cases();
+    cheapest_insertion_cases();
     bi_incr_cases();
     cross_bi_cases();
     exists_cases();

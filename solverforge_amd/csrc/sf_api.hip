@@ -18,6 +18,7 @@
 #include "sf_list_wave.hip"
 #include "sf_scalar_kernels.hip"
 #include "sf_mixed_wave.hip"
+#include "sf_construct.hip"
 
 using namespace sf;
 
@@ -1025,6 +1026,45 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (!ok) return fail(ctx, SF_ERR_INVALID, "move is not doable");
     return SF_OK;
+}
+
+// ≙ ListCheapestInsertionPhase over every replica's current lists (csrc/sf_construct.hip)
+int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "cheapest insertion needs the list variable's class");
+    if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_cheapest arguments");
+    if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
+    for (int32_t k = 0; k < n; ++k)
+        if (elements[k] >= (uint32_t)ctx->lm.dim) return fail(ctx, SF_ERR_INVALID, "element id out of range");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    const ConstructCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim);
+    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
+    uint32_t* d_el = nullptr;
+    if (n > 0) {
+        hipError_t ea = hipMalloc((void**)&d_el, (size_t)n * 4);
+        if (ea == hipSuccess) ea = hipMemcpyAsync(d_el, elements, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (ea != hipSuccess) {
+            (void)hipFree(d_el);
+            return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (ctx->levels <= 2) {
+        auto kern = k_list_construct_cheapest<2>;
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, n, ctx->sp.stats);
+    } else {
+        auto kern = k_list_construct_cheapest<4>;
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, n, ctx->sp.stats);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_el);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return run_evaluate_all(ctx, out_scores, 1);  // finish_construction: the committed score of the constructed lists
 }
 
 // ---- search ------------------------------------------------------------------------------

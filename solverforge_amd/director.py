@@ -228,6 +228,14 @@ class GpuScoreDirector:
         mv[0] = move
         check(self._L.sf_apply(self._h, replica, ptr(mv)), self._h)
 
+    def construct_list_cheapest(self, descriptor_index, elements):
+        """≙ ListCheapestInsertionPhase on every replica: places the elements of `elements` (source order) that are in no list
+        yet, each at its best (list, position); returns the committed scores [n_replicas, levels]."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        out = np.zeros((self.n_replicas, self.levels), dtype=np.int64)
+        check(self._L.sf_construct_list_cheapest(self._h, descriptor_index, ptr(el), len(el), ptr(out)), self._h)
+        return out
+
     # ---- MoveSelector / cursor surface ---------------------------------------------------
     def open_cursor(self, step_index, step_seed, selection_order=SelectionOrder.RANDOM, replica=0, cap=1 << 16):
         """Drains the configured union cursor for MoveStreamContext(step_index, step_seed):

@@ -1,0 +1,103 @@
+"""GPU parity tests (through the C ABI): list cheapest-insertion construction on the device (sf_construct_list_cheapest ≙
+ListCheapestInsertionPhase, cheapest/kernel.rs:57-150) vs the oracle: constructed lists, committed score, counters; from empty
+lists, from a partial state, ties, unreachable legs, asymmetric matrix; then local search from the constructed state."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(kind):
+    from solverforge_amd import datasets
+
+    if kind == "plain":
+        p = datasets.make_cvrp(60, 6, 55, seed=3)
+    elif kind == "tight":
+        p = datasets.make_cvrp(80, 8, 30, seed=11)
+    elif kind == "ties":
+        p = datasets.make_cvrp(30, 5, 60, seed=5)
+        p["matrix"][:] = 7
+        np.fill_diagonal(p["matrix"], 0)
+    elif kind == "asym":
+        p = datasets.make_cvrp(36, 6, 40, seed=8)
+        r = datasets.stream(123, p["matrix"].size).reshape(p["matrix"].shape)
+        p["matrix"] = (p["matrix"] + (r % np.uint64(17)).astype(np.int64)).astype(np.int64)
+        np.fill_diagonal(p["matrix"], 0)
+        p["matrix"][4, 9] = np.iinfo(np.int64).max
+        p["matrix"][11, 2] = -3
+    else:
+        raise ValueError(kind)
+    return p
+
+
+@pytest.mark.parametrize("problem,keep", [("plain", 0), ("tight", 0), ("ties", 0), ("asym", 0), ("plain", 2), ("tight", 5)])
+def test_cheapest_insertion_matches_oracle(oracle, problem, keep):
+    """keep = how many of the round-robin start routes stay filled (a partial state: only the missing customers are placed)."""
+    import solverforge_amd as sfa
+
+    p = _problem(problem)
+    p["routes"] = [rt if i < keep else [] for i, rt in enumerate(p["routes"])]
+    d = sfa.build_cvrp(p, n_replicas=3)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    placed = {c for rt in p["routes"] for c in rt}
+    missing = [int(c) for c in p["customers"] if int(c) not in placed]
+    sc = d.construct_list_cheapest(0, p["customers"])  # the elements already in a list are skipped
+    o.construct_list_cheapest(missing)
+    for r in range(3):
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        assert (sc[r] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k] == ost[k], k
+    assert gst["moves_applied"] == len(missing)
+    # local search continues from the constructed state
+    leaves = oracle.LEAF_NEARBY_LIST_CHANGE | oracle.LEAF_NEARBY_LIST_SWAP
+    o.configure(leaves=leaves, random_seed=1, la_size=8, limit=32, max_nearby=10)
+    d2 = sfa.build_cvrp(p, n_replicas=1, max_nearby=10)
+    d2.configure(sfa.SolverConfig(random_seed=1, late_acceptance_size=8, accepted_count_limit=32))
+    d2.calculate_score()
+    d2.construct_list_cheapest(0, p["customers"])
+    d2.phase_start()
+    o.phase_start()
+    d2.solve_steps(40)
+    o.steps(40)
+    assert d2.working_lists(0, 0) == o.get_lists(0)
+    assert (d2.calculate_score()[0] == o.score()[:2]).all()
+
+
+def test_cheapest_insertion_cvrp_1000_properties(oracle):
+    """C3 size: every customer placed exactly once, committed == fresh score, and the first 150 placements equal the oracle's."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(1000, 100, 55, seed=0)
+    p["routes"] = [[] for _ in p["routes"]]
+    d = sfa.build_cvrp(p, n_replicas=2)
+    d.calculate_score()
+    sc = d.construct_list_cheapest(0, p["customers"])
+    lists = d.working_lists(0, 0)
+    assert sorted(c for rt in lists for c in rt) == list(range(1, 1001))
+    assert (sc == d.fresh_score()).all() and sc[0][0] <= 0
+    d3 = sfa.build_cvrp(p, n_replicas=1)
+    d3.calculate_score()
+    d3.construct_list_cheapest(0, p["customers"][:150])
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.construct_list_cheapest(p["customers"][:150])
+    assert d3.working_lists(0, 0) == o.get_lists(0)
+
+
+def test_cheapest_insertion_validation():
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(12, 2, 60, seed=1)
+    d = sfa.build_cvrp(p)
+    d.calculate_score()
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_cheapest(0, [999])  # element id out of range
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_cheapest(3, [1])  # not the list class
+    d.construct_list_cheapest(0, p["customers"])  # nothing missing: a no-op
+    assert d.working_lists(0, 0) == p["routes"]
