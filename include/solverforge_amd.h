@@ -125,7 +125,12 @@ typedef enum sf_constraint_kind {
      * value-keyed fact rows -- IncrementalExistsConstraint in Exists (param 1) or NotExists (param 0) mode over a planning
      * class (constraint/exists.rs:42-437, key_existence_delta :218-231; constraint/tests/exists.rs:34-190): a row is scored while
      * some / no entity holds its value.  `fact_a` = i32 per-row weight column [n_values], or -1 for weight 1 */
-    SF_C_EXISTS_VALUE = 12
+    SF_C_EXISTS_VALUE = 12,
+    /* BalanceConstraint (crates/solverforge-scoring/src/constraint/balance.rs:83-372): group the assigned entities by their value,
+     * count each group, score -round(weight * population standard deviation of the counts) on `level` -- a GLOBAL statistic;
+     * f64 in the reference's operation order, Score::multiply rounding (score/macros.rs:61-63).  `weight` = the base score of one
+     * unit of standard deviation */
+    SF_C_BALANCE_VALUE = 13
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {

@@ -327,7 +327,18 @@ inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_
         int64_t over = wrap_sub(sum, cap);
         return Score::of(0, over > 0 ? over : 0);
     };
-    if (cap != -2) m->director.constraints.members.push_back(std::move(load));
+    if (cap == -3) {  // BalanceConstraint (constraint/balance.rs): 1000 soft per unit of the standard deviation of the bin COUNTS
+        auto bal = std::make_unique<BalanceConstraint>();
+        bal->name = "Bin count balance";
+        bal->impact = Impact::Penalty;
+        bal->source = ChangeSource::descriptor(0);
+        bal->count = [](const Solution& s) { return s.classes[0].n; };
+        bal->filter = [](const Solution&, size_t) { return true; };
+        bal->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+        bal->base_score = Score::of(0, 1000);
+        m->director.constraints.members.push_back(std::move(bal));
+    }
+    if (cap != -2 && cap != -3) m->director.constraints.members.push_back(std::move(load));
 
     m->has_scalar = true;
     m->scalar_slot.descriptor_index = 0;

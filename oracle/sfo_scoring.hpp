@@ -1149,6 +1149,107 @@ struct LoadBalanceConstraint : Constraint {
 };
 
 // ---- ConstraintSet tuple fold (api/constraint_set/incremental.rs:339-407) ----
+// ---- BalanceConstraint (constraint/balance.rs:83-372): base_score x population standard deviation of the per-key entity
+// COUNTS, one global statistic; `Score::multiply(f64)` rounds every level half away from zero (score/macros.rs:61-63) ----------
+struct BalanceConstraint : Constraint {
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Filter1 filter;
+    Key1 key;  // NONE = the key function returns None (entity skipped)
+    Score base_score;
+    std::unordered_map<int64_t, int64_t> counts;
+    std::unordered_map<size_t, int64_t> entity_keys;
+    int64_t group_count = 0, total_count = 0, sum_squared = 0;
+
+    static Score multiply(const Score& s, double f) {
+        Score r;
+        for (int i = 0; i < MAX_LEVELS; ++i) r.v[i] = (int64_t)std::round((double)s.v[i] * f);
+        return r;
+    }
+    static double std_dev_of(int64_t groups, int64_t total, int64_t sum_sq) {  // compute_std_dev (:162-173)
+        if (groups == 0) return 0.0;
+        double n = (double)groups, mean = (double)total / n;
+        double variance = ((double)sum_sq / n) - (mean * mean);
+        return variance <= 0.0 ? 0.0 : std::sqrt(variance);
+    }
+    Score compute_score() const { return apply_impact(impact, multiply(base_score, std_dev_of(group_count, total_count, sum_squared))); }
+    Score evaluate(const Solution& s) const override {  // (:213-236)
+        std::unordered_map<int64_t, int64_t> c;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i) && key(s, i) != NONE) ++c[key(s, i)];
+        if (c.empty()) return Score::zero();
+        int64_t total = 0, sq = 0;
+        for (auto& kv : c) total += kv.second, sq += kv.second * kv.second;
+        return apply_impact(impact, multiply(base_score, std_dev_of((int64_t)c.size(), total, sq)));
+    }
+    size_t match_count(const Solution& s) const override {  // groups deviating from the mean by more than 0.5 (:238-266)
+        std::unordered_map<int64_t, int64_t> c;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i) && key(s, i) != NONE) ++c[key(s, i)];
+        if (c.empty()) return 0;
+        int64_t total = 0;
+        for (auto& kv : c) total += kv.second;
+        double mean = (double)total / (double)c.size();
+        size_t m = 0;
+        for (auto& kv : c) m += std::fabs((double)kv.second - mean) > 0.5 ? 1 : 0;
+        return m;
+    }
+    Score initialize(const Solution& s) override {  // (:268-292)
+        reset();
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i) {
+            if (!filter(s, i) || key(s, i) == NONE) continue;
+            int64_t k = key(s, i), oc = counts.count(k) ? counts[k] : 0, nc = oc + 1;
+            counts[k] = nc;
+            entity_keys[i] = k;
+            if (oc == 0) ++group_count;
+            ++total_count;
+            sum_squared += nc * nc - oc * oc;
+        }
+        return compute_score();
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {  // (:294-329)
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        if (e >= count(s) || !filter(s, e) || key(s, e) == NONE) return Score::zero();
+        Score old = compute_score();
+        int64_t k = key(s, e), oc = counts.count(k) ? counts[k] : 0, nc = oc + 1;
+        counts[k] = nc;
+        entity_keys[e] = k;
+        if (oc == 0) ++group_count;
+        ++total_count;
+        sum_squared += nc * nc - oc * oc;
+        return compute_score() - old;
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {  // (:331-366)
+        if (!source.assert_localizes(d, name)) return Score::zero();
+        if (e >= count(s)) return Score::zero();
+        auto it = entity_keys.find(e);
+        if (it == entity_keys.end()) return Score::zero();
+        int64_t k = it->second;
+        entity_keys.erase(it);
+        Score old = compute_score();
+        int64_t oc = counts.count(k) ? counts[k] : 0;
+        if (oc == 0) return Score::zero();
+        int64_t nc = oc - 1;
+        if (nc == 0) {
+            counts.erase(k);
+            --group_count;
+        } else
+            counts[k] = nc;
+        --total_count;
+        sum_squared += nc * nc - oc * oc;
+        return compute_score() - old;
+    }
+    void reset() override {
+        counts.clear();
+        entity_keys.clear();
+        group_count = total_count = sum_squared = 0;
+    }
+};
+
 struct ConstraintSet {
     std::vector<std::unique_ptr<Constraint>> members;
     Score evaluate_all(const Solution& s) const {

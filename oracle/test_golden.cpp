@@ -661,6 +661,44 @@ static void list_ruin_cases() {
     }
 }
 
+// constraint/tests/balance.rs:21-304: equal / unequal distributions, unassigned filtered, incremental retract / insert, empty,
+// single key, reward
+static void balance_cases() {
+    auto mk = [](Impact impact) {
+        BalanceConstraint c;
+        c.name = "Balance";
+        c.impact = impact;
+        c.source = ChangeSource::descriptor(0);
+        c.count = [](const Solution& s) { return s.classes[0].n; };
+        c.filter = [](const Solution&, size_t) { return true; };
+        c.key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+        c.base_score = soft(1000);
+        return c;
+    };
+    auto sol = [](std::vector<int64_t> emp) {
+        Solution s;
+        s.classes.resize(1);
+        s.classes[0].n = emp.size();
+        s.classes[0].vars = {emp};
+        return s;
+    };
+    CHECK("balance.equal_distribution", mk(Impact::Penalty).evaluate(sol({0, 0, 1, 1})) == soft(0));
+    CHECK("balance.unequal_distribution", mk(Impact::Penalty).evaluate(sol({0, 0, 0, 1})) == soft(-1000));
+    CHECK("balance.filters_unassigned", mk(Impact::Penalty).evaluate(sol({0, 1, NONE, NONE})) == soft(0));
+    {
+        BalanceConstraint c = mk(Impact::Penalty);
+        Solution s = sol({0, 0, 1, 1});
+        bool ok = c.initialize(s) == soft(0);
+        ok = ok && c.on_retract(s, 0, 0) == soft(-500);  // counts 1 and 2: std dev 0.5
+        ok = ok && c.on_insert(s, 0, 0) == soft(500);
+        CHECK("balance.incremental", ok);
+        CHECK("balance.unrelated_descriptor_is_noop", c.on_insert(s, 0, 1) == Score::zero());
+    }
+    CHECK("balance.empty_solution", mk(Impact::Penalty).evaluate(sol({})) == soft(0));
+    CHECK("balance.single_employee", mk(Impact::Penalty).evaluate(sol({0, 0, 0})) == soft(0));
+    CHECK("balance.reward", mk(Impact::Reward).evaluate(sol({0, 0, 0, 1})) == soft(1000));
+}
+
 // manager/phase_factory/list_construction/cheapest/kernel.rs:57-150 with a constant score (cheapest/tests.rs zero_score): the
 // first tried (list, position) wins every time, so the elements pile up in front of list 0 in reverse source order
 static void cheapest_insertion_cases() {
@@ -1003,6 +1041,7 @@ int main() {
     list_ruin_cases();
     compound_scalar_cases();
     cheapest_insertion_cases();
+    balance_cases();
     bi_incr_cases();
     cross_bi_cases();
     exists_cases();

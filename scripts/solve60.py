@@ -12,11 +12,22 @@ replicas = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 # list policy without ruin: nearby_change,nearby_swap,sublist_change,sublist_swap,list_reverse,kopt
 leaves = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("nearby_change", "nearby_swap")
 BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512,
-        "list_change": 4, "list_swap": 8}
+        "list_change": 4, "list_swap": 8, "ruin": 1024}
+# optional fifth argument: "cheapest" = start from the device's list cheapest-insertion construction (both sides) instead of
+# the round-robin fill
+start = sys.argv[5] if len(sys.argv) > 5 else "roundrobin"
 p = datasets.make_cvrp(1000, 100, 55, seed=0)
+if start == "cheapest":
+    p["routes"] = [[] for _ in p["routes"]]
 d = sfa.build_cvrp(p, n_replicas=replicas, leaves=leaves)
 d.configure(sfa.SolverConfig(random_seed=0))
-d.calculate_score(); d.phase_start()
+start_score = [int(v) for v in d.calculate_score()[0]]
+construct_s = 0.0
+if start == "cheapest":
+    tc = time.perf_counter()
+    start_score = [int(v) for v in d.construct_list_cheapest(0, p["customers"])[0]]
+    construct_s = time.perf_counter() - tc
+d.phase_start()
 t0 = time.perf_counter(); trace = []
 # optional fourth argument: candidates per replica per launch (sf_solve_moves: work-balanced launches); 0 = fixed
 # step counts per launch (sf_solve_steps)
@@ -34,13 +45,20 @@ gt = time.perf_counter() - t0
 st = d.total_stats()
 gpu = {"seconds": gt, "replicas": replicas, "leaves": list(leaves), "best_score": list(max(tuple(int(v) for v in s) for s in d.best_scores())),
        "moves_evaluated": st["moves_evaluated"], "ls_steps_per_replica": st["step_count"] // replicas, "launch_move_budget": budget,
-       "moves_per_s": st["moves_evaluated"] / gt, "trace": [t for t in trace if t]}
+       "moves_per_s": st["moves_evaluated"] / gt, "start": start, "start_score": start_score, "construction_seconds": construct_s,
+       "trace": [t for t in trace if t]}
 o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
 o.configure(leaves=sum(BITS[x] for x in leaves), max_nearby=20, random_seed=0)
+o.set_ruin()
+tc = time.perf_counter()
+if start == "cheapest":
+    o.construct_list_cheapest(p["customers"])
+cpu_construct_s = time.perf_counter() - tc
 o.phase_start()
 t0 = time.perf_counter()
 steps = o.steps_timed(seconds)
 ct = time.perf_counter() - t0
 cpu = {"seconds": ct, "best_score": [int(v) for v in o.best_score()[:2]], "ls_steps": int(steps),
-       "moves_evaluated": o.stats()["moves_evaluated"], "moves_per_s": o.stats()["moves_evaluated"] / ct}
+       "moves_evaluated": o.stats()["moves_evaluated"], "moves_per_s": o.stats()["moves_evaluated"] / ct,
+       "construction_seconds": cpu_construct_s}
 print(json.dumps({"gpu": gpu, "cpu_oracle_1core": cpu}))

@@ -361,7 +361,7 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
                           int32_t level, int64_t weight) {
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
-    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_EXISTS_VALUE) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_BALANCE_VALUE) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
     ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
     return SF_OK;
 }
@@ -848,13 +848,15 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_SELFJOIN_VALUE_EQUAL: raw = q[5], count = q[5]; break;
             case SF_C_GROUPED_VALUE_SUM:
             case SF_C_LOAD_BALANCE_VALUE: raw = q[6], count = q[7]; break;
+            case SF_C_BALANCE_VALUE: raw = q[6], count = q[7]; break;
             case SF_C_VALUE_COST: raw = q[8], count = q[9]; break;
             case SF_C_EXISTS_VALUE: raw = q[10], count = q[11]; break;
             default: return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind in sf_evaluate_each");
         }
         (void)on_list;
         for (int k = 0; k < ctx->levels; ++k) out_scores[i * ctx->levels + k] = 0;
-        out_scores[i * ctx->levels + cs.level] = (int64_t)(0 - (uint64_t)cs.weight * (uint64_t)raw);  // penalties
+        // penalties; the balance constraint's base score is already inside `raw` (round(base * standard deviation))
+        out_scores[i * ctx->levels + cs.level] = cs.kind == SF_C_BALANCE_VALUE ? (int64_t)(0 - (uint64_t)raw) : (int64_t)(0 - (uint64_t)cs.weight * (uint64_t)raw);
         out_match_counts[i] = count;
         ++i;
     }
@@ -918,8 +920,8 @@ int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t*
     if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
     if (replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_scores || !out_doable)
         return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate_compound arguments");
-    if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode == 1)
-        return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance model (floating-point aggregate) are not chained on the device");
+    if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode >= 1)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance / balance model (floating-point aggregate) are not chained on the device");
     if (n == 0) return SF_OK;
     if (offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "offsets[0] must be 0");
     for (int64_t i = 0; i < n; ++i) {
@@ -966,8 +968,8 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
     if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
     if (n_edits <= 0) return fail(ctx, SF_ERR_INVALID, "move is not doable");
     if (n_edits > SF_COMPOUND_MAX) return fail(ctx, SF_ERR_UNSUPPORTED, "at most 8 edits per compound candidate on the device");
-    if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode == 1)
-        return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance model (floating-point aggregate) are not chained on the device");
+    if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode >= 1)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance / balance model (floating-point aggregate) are not chained on the device");
     for (int64_t k = 0; k < n_edits; ++k)
         if (edits[k].kind != SF_MOVE_CHANGE) return fail(ctx, SF_ERR_INVALID, "a ScalarEdit is a SF_MOVE_CHANGE-shaped record");
     int rc = alloc_search(ctx);

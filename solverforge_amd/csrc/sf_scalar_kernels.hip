@@ -49,7 +49,9 @@ struct ScalarModel {
     int32_t sj_level = -1, grp_level = -1;  // keyed self-join pairs; grouped sum
     int64_t sj_weight = 0, grp_weight = 0, grp_cap = -1;
     int32_t sj_arity = 2;  // keyed self-join arity: 2 pairs, 3 / 4 / 5 = tri / quad / penta tuples sharing a value
-    int32_t grp_mode = 0;  // 0: sum of per-group weights (grouped node + sum collector); 1: load_balance collector (unfairness)
+    int32_t grp_mode = 0;  // 0: sum of per-group weights (grouped node + sum collector); 1: load_balance collector (unfairness of
+                           // the per-value metric sums); 2: BalanceConstraint (base x standard deviation of the per-value COUNTS)
+    int64_t bal_base = 0;  // mode 2: the base score of one unit of standard deviation on grp_level (grp_weight is 1)
     const int32_t* size = nullptr;     // [n] summed fact of the grouped constraint
     // keyed cross-join with a fact side: every assigned entity e matches the fact row its value names; filter + weight of the
     // pair are the data cost[e][value] (0 = filtered out)
@@ -148,6 +150,19 @@ __device__ __forceinline__ int64_t lb_unfairness(int64_t s1, int64_t s2, uint32_
     if (!(tmp >= 0.0)) return 0;
     return (int64_t)round(sqrt(tmp));
 }
+// BalanceConstraint (constraint/balance.rs:162-184): round(base * sqrt(sum_sq / n - (total / n)^2)), f64 in the reference's
+// operation order; `Score::multiply` rounds half away from zero (score/macros.rs:61-63)
+__device__ __forceinline__ int64_t balance_value(int64_t base, int64_t total, int64_t sum_sq, uint32_t nk) {
+    if (nk == 0) return 0;
+    const double n = (double)nk, mean = (double)total / n;
+    const double variance = ((double)sum_sq / n) - (mean * mean);
+    const double sd = variance <= 0.0 ? 0.0 : sqrt(variance);
+    return (int64_t)round((double)base * sd);
+}
+// the global statistic of the value-keyed loads: mode 1 load_balance unfairness, mode 2 balance
+__device__ __forceinline__ int64_t global_stat(const ScalarModel& m, int64_t s1, int64_t s2, uint32_t nk) {
+    return m.grp_mode == 2 ? balance_value(m.bal_base, s1, s2, nk) : lb_unfairness(s1, s2, nk);
+}
 // one key's load x -> x + d inside (S1, S2)
 __device__ __forceinline__ void lb_shift(int64_t& s1, int64_t& s2, int64_t x, int64_t d) {
     const int64_t y = wadd(x, d);
@@ -160,11 +175,12 @@ __device__ __forceinline__ void lb_from_tables(const ScalarModel& m, const uint3
     uint32_t nk = 0;
     for (int v = 0; v < m.n_values; ++v)
         if (cnt[v]) {
-            s1 = wadd(s1, sum[v]);
-            s2 = wadd(s2, (int64_t)((uint64_t)sum[v] * (uint64_t)sum[v]));
+            const int64_t x = m.grp_mode == 2 ? (int64_t)cnt[v] : sum[v];  // a key's load: its metric sum, or its entity count
+            s1 = wadd(s1, x);
+            s2 = wadd(s2, (int64_t)((uint64_t)x * (uint64_t)x));
             nk += 1;
         }
-    lb[0] = s1, lb[1] = s2, lb[2] = (int64_t)nk, lb[3] = lb_unfairness(s1, s2, nk);
+    lb[0] = s1, lb[1] = s2, lb[2] = (int64_t)nk, lb[3] = global_stat(m, s1, s2, nk);
 }
 
 // kind 0: Change(a -> value); kind 1: Swap(a, b)
@@ -198,19 +214,20 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
             const int64_t loss = (old >= 0 && cnt[old] == 1) ? (m.ex_w ? (int64_t)m.ex_w[old] : 1) : 0;
             r.d_ex = m.ex_mode ? wsub(gain, loss) : wsub(loss, gain);
         }
-        if (m.grp_level >= 0 && m.grp_mode == 1) {  // load balance: metrics are >= 1 (validated at sf_constraint_add)
-            const int64_t sz = (int64_t)m.size[a];
+        if (m.grp_level >= 0 && m.grp_mode >= 1) {  // global statistic (load balance: metrics are >= 1, validated at sf_constraint_add)
+            const bool by_count = m.grp_mode == 2;
+            const int64_t sz = by_count ? 1 : (int64_t)m.size[a];
             int64_t s1 = lb[0], s2 = lb[1];
             uint32_t nk = (uint32_t)lb[2];
             if (old >= 0) {
-                lb_shift(s1, s2, sum[old], -sz);
+                lb_shift(s1, s2, by_count ? (int64_t)cnt[old] : (int64_t)sum[old], -sz);
                 nk -= cnt[old] == 1 ? 1u : 0u;
             }
             if (value >= 0) {
-                lb_shift(s1, s2, sum[value], sz);
+                lb_shift(s1, s2, by_count ? (int64_t)cnt[value] : (int64_t)sum[value], sz);
                 nk += cnt[value] == 0 ? 1u : 0u;
             }
-            r.d_grp = wsub(lb_unfairness(s1, s2, nk), lb[3]);
+            r.d_grp = wsub(global_stat(m, s1, s2, nk), lb[3]);
         } else if (m.grp_level >= 0) {
             const int64_t sz = (int64_t)m.size[a];
             int64_t d = 0;
@@ -240,6 +257,8 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
             if (va >= 0) lb_shift(s1, s2, sum[va], wsub(sb, sa));
             if (vb >= 0) lb_shift(s1, s2, sum[vb], wsub(sa, sb));
             r.d_grp = wsub(lb_unfairness(s1, s2, nk), lb[3]);
+        } else if (m.grp_level >= 0 && m.grp_mode == 2) {
+            r.d_grp = 0;  // the per-value counts do not change under a swap
         } else if (m.grp_level >= 0) {
             const int64_t sa = (int64_t)m.size[a], sb = (int64_t)m.size[b];
             int64_t d = 0;
@@ -500,13 +519,20 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         atomicAdd(&s_pairs, pairs);
         atomicAdd(&s_grp, grp);
         atomicAdd(&s_groups, groups);
-        if (m.grp_level >= 0 && m.grp_mode == 1) {
+        if (m.grp_level >= 0 && m.grp_mode >= 1) {
             __syncthreads();
             if (threadIdx.x == 0) {
                 int64_t lb[4];
                 lb_from_tables(m, t_cnt, t_sum, lb);
                 s_grp = (unsigned long long)lb[3];
                 s_groups = lb[2] ? 1 : 0;  // one group (the unit key) when any entity is in it
+                if (m.grp_mode == 2) {  // match_count of the balance constraint: keys deviating from the mean by more than 0.5
+                    unsigned long long dev = 0;
+                    const double mean = lb[2] ? (double)lb[0] / (double)lb[2] : 0.0;
+                    for (int v = 0; v < m.n_values; ++v)
+                        if (t_cnt[v] && fabs((double)t_cnt[v] - mean) > 0.5) dev += 1;
+                    s_groups = dev;
+                }
             }
         }
     }
@@ -589,7 +615,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, in
         __syncthreads();
     }
     __shared__ int64_t s_lb[4];
-    if (m.grp_level >= 0 && m.grp_mode == 1) {
+    if (m.grp_level >= 0 && m.grp_mode >= 1) {
         if (threadIdx.x == 0) lb_from_tables(m, t_cnt, t_sum, s_lb);
         __syncthreads();
     }
@@ -627,7 +653,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply(ScalarModel m, int replica,
     if (threadIdx.x != 0) return;
     int64_t* cur = m.score + (size_t)replica * 4;
     int64_t lb[4] = {0, 0, 0, 0};
-    if (m.grp_level >= 0 && m.grp_mode == 1) lb_from_tables(m, t_cnt, t_sum, lb);
+    if (m.grp_level >= 0 && m.grp_mode >= 1) lb_from_tables(m, t_cnt, t_sum, lb);
     const ScalarDelta d = eval_scalar_move(m, vals, kind, (uint32_t)a, (uint32_t)b, value, t_cnt, t_sum, lb);
     if (!d.doable) {
         *out_ok = 0;
@@ -768,12 +794,12 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     for (int64_t step = 0; step < p.n_steps; ++step) {
         // load-balance aggregates of the step snapshot (the tables change only at commit): every lane gets the totals
         int64_t lbv[4] = {0, 0, 0, 0};
-        if (m.grp_level >= 0 && m.grp_mode == 1) {
+        if (m.grp_level >= 0 && m.grp_mode >= 1) {
             int64_t s1 = 0, s2 = 0;
             uint32_t nk = 0;
             for (uint32_t v = lane; v < (uint32_t)m.n_values; v += 64)
                 if (t_cnt[v]) {
-                    const int64_t x = t_sum[v];
+                    const int64_t x = m.grp_mode == 2 ? (int64_t)t_cnt[v] : t_sum[v];
                     s1 = wadd(s1, x);
                     s2 = wadd(s2, (int64_t)((uint64_t)x * (uint64_t)x));
                     nk += 1;
@@ -784,7 +810,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                 s2 = wadd(s2, (int64_t)shfl_u64((uint64_t)s2, (int)(lane ^ (uint32_t)o)));
                 nk += (uint32_t)__shfl((int)nk, (int)(lane ^ (uint32_t)o));
             }
-            lbv[0] = s1, lbv[1] = s2, lbv[2] = (int64_t)nk, lbv[3] = lb_unfairness(s1, s2, nk);
+            lbv[0] = s1, lbv[1] = s2, lbv[2] = (int64_t)nk, lbv[3] = global_stat(m, s1, s2, nk);
         }
         uint64_t sidx, sseed;
         if (p.dry_run) {

@@ -48,7 +48,7 @@ class ConstraintKind:
     UNI_UNASSIGNED, CROSS_ADJACENT_EQUAL, CROSS_GROUP_EQUAL, CROSS_QUEENS = 1, 2, 3, 4
     NOT_EXISTS_FLATTENED, ROUTE_CAPACITY, ROUTE_DISTANCE = 5, 6, 7
     SELFJOIN_VALUE_EQUAL, GROUPED_VALUE_SUM, LOAD_BALANCE_VALUE = 8, 9, 10
-    VALUE_COST, EXISTS_VALUE = 11, 12
+    VALUE_COST, EXISTS_VALUE, BALANCE_VALUE = 11, 12, 13
 
 
 class SelectorKind:

@@ -135,7 +135,8 @@ def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=
     weight(sum) — constraint/grouped/{state,scorer}.rs) on one scalar variable.  HardSoftScore:
     hard = unassigned entities, soft = w_pair per same-bin pair + sum^2 (cap == -1) or excess over cap (cap >= 0);
     cap == -2 replaces the per-bin load by FAIRNESS: group_by(load_balance(bin, size)).penalize(unfairness)
-    (stream/collector/load_balance.rs), sizes >= 1."""
+    (stream/collector/load_balance.rs), sizes >= 1; cap == -3 replaces it by the BalanceConstraint (constraint/balance.rs):
+    1000 soft per unit of the standard deviation of the per-bin entity COUNTS."""
     import numpy as np
 
     d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
@@ -148,6 +149,8 @@ def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=
     d.add_constraint(ConstraintKind.SELFJOIN_VALUE_EQUAL, 0, level=1, weight=w_pair, param=0 if arity == 2 else arity)
     if cap == -2:
         d.add_constraint(ConstraintKind.LOAD_BALANCE_VALUE, 0, fact=FACT_COLUMN, level=1, weight=1)
+    elif cap == -3:
+        d.add_constraint(ConstraintKind.BALANCE_VALUE, 0, level=1, weight=1000)
     else:
         d.add_constraint(ConstraintKind.GROUPED_VALUE_SUM, 0, fact=FACT_COLUMN, param=cap, level=1, weight=1)
     if "change" in leaves:

@@ -187,11 +187,12 @@ def _balance(n=80, k=7, seed=11):
     return bins, sizes, k
 
 
-@pytest.mark.parametrize("cap", [-1, 25, -2])
+@pytest.mark.parametrize("cap", [-1, 25, -2, -3])
 def test_keyed_selfjoin_and_grouped_sum(oracle, cap):
     """Value-keyed aggregates: pairs sharing a bin (keyed self-join bi node) and group_by(bin,
     sum(size)) with sum^2 / excess-over-cap weights (grouped node + sum collector), or (cap = -2) the load_balance
-    collector's unfairness = round(sqrt(sum x^2 - (sum x)^2 / keys)) — the f64 step of the scoring path: full scores, the
+    collector's unfairness = round(sqrt(sum x^2 - (sum x)^2 / keys)) — the f64 step of the scoring path — or (cap = -3) the
+    BalanceConstraint's round(1000 * standard deviation of the per-bin counts): full scores, the
     whole candidate stream with trial scores, committed moves, traced steps and a fused solve."""
     import solverforge_amd as sfa
 
@@ -272,7 +273,7 @@ def test_evaluate_each_matches_oracle_per_constraint(oracle):
     n, nb = 60, 7
     bins = (datasets.stream(11, n) % np.uint64(nb + 1)).astype(np.int64) - 1
     sizes = (datasets.stream(12, n) % np.uint64(9)).astype(np.int64) + 1
-    for cap in (-1, 20, -2):
+    for cap in (-1, 20, -2, -3):
         d = sfa.build_balance(bins, sizes, nb, w_pair=3, cap=cap)
         o = oracle.Model.balance(nb, bins, sizes, 3, cap)
         o.configure(leaves=oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP, random_seed=4)
