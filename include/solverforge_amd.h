@@ -273,6 +273,18 @@ int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t descriptor_in
 int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t k,
                              int32_t min_segment_len, int32_t max_nearby);
 
+/* Root union of the configured leaves (UnionMoveSelectorConfig: UnionSelectionOrder + UnionWeighting; scheduler
+ * heuristic/selector/decorator/vec_union.rs:190-365).  selection_order: sf_union_order, -1 = the default policy's choice
+ * (StratifiedRandom for more than one leaf, runtime/compiler/executor/local_search/lower.rs:285-293); weights[n_weights] = one
+ * unsigned weight per leaf in union (declaration) order, NULL / 0 = equal (UnionWeighting::Equal); a zero weight disables the
+ * leaf; weights other than 1 need SF_UNION_RANDOM or SF_UNION_STRATIFIED_RANDOM (vec_union.rs:215-222).  A non-default root
+ * union runs in the generic N-leaf engine.  The weight count is checked against the leaf count at the next launch. */
+typedef enum sf_union_order {
+    SF_UNION_SEQUENTIAL = 0, SF_UNION_ROUND_ROBIN = 1, SF_UNION_ROTATING_ROUND_ROBIN = 2, SF_UNION_RANDOM = 3,
+    SF_UNION_STRATIFIED_RANDOM = 4
+} sf_union_order;
+int32_t sf_union_configure(sf_ctx* ctx, int32_t selection_order, const int64_t* weights, int32_t n_weights);
+
 /* list ruin leaf (ListRuinMoveSelectorConfig, solverforge-config/src/move_selector.rs:552-587; defaults 2, 5, 10, none, false):
  * per step `moves_per_step` (<= 16) candidates, each removing min..=max (<= 6) elements of one non-empty list (no longer than
  * max_source_list_len; 0 = no bound) and re-inserting them greedily.  `variable_name` = the list variable's name: the leaf's

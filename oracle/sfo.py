@@ -83,6 +83,7 @@ def lib():
             "sfo_xoshiro256pp": (None, [vp, i32, vp]),
             "sfo_small_rng_seed": (None, [u64, vp]),
             "sfo_model_set_step_seeds": (None, [vp, vp, i32]),
+            "sfo_model_set_union_weights": (None, [vp, vp, i32]),
             "sfo_model_set_ruin": (None, [vp, i32, i32, i32, i32, i32, C.c_char_p]),
             "sfo_scoped_seed": (u64, [u64, u64, C.c_char_p, C.c_char_p]),
             "sfo_hash_str": (u64, [C.c_char_p]),
@@ -258,6 +259,10 @@ class Model:
         """List ruin leaf parameters (ListRuinMoveSelectorConfig defaults); call after configure(): re-seeds the leaf's stream."""
         lib().sfo_model_set_ruin(self.h, min_count, max_count, moves_per_step, max_source_list_len, int(skip_empty_destinations),
                                  variable_name.encode())
+
+    def set_union_weights(self, weights):
+        w = np.ascontiguousarray(weights, dtype=np.uint64)
+        lib().sfo_model_set_union_weights(self.h, _p(w), len(w))
 
     def set_step_seeds(self, seeds):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)

@@ -254,6 +254,10 @@ void sfo_random_range_stream(uint64_t seed, uint64_t low, uint64_t high_inclusiv
     SmallRng r = SmallRng::seed_from_u64(seed);
     for (int32_t i = 0; i < n; ++i) out[i] = r.random_range_inclusive(low, high_inclusive);
 }
+// UnionWeighting of the root union: one weight per leaf in union order (n = 0: equal)
+void sfo_model_set_union_weights(void* h, const uint64_t* weights, int32_t n) {
+    ((Model*)h)->union_weights.assign(weights, weights + n);
+}
 void sfo_model_set_step_seeds(void* h, const uint64_t* seeds, int32_t n) {
     ((Model*)h)->search.explicit_step_seeds.assign(seeds, seeds + n);
 }

@@ -89,6 +89,7 @@ struct Model {
     size_t sublist_min = 1, sublist_max = 3;
     size_t kopt_min_seg = 1, kopt_max_nearby = 20;  // KOptMoveSelectorConfig defaults + DEFAULT_LIST_NEARBY_LIMIT (policy/list.rs:19,144-160)
     UnionOrder union_order = UnionOrder::StratifiedRandom;
+    std::vector<uint64_t> union_weights;  // UnionWeighting: one per leaf in union order; empty = equal
     // list ruin leaf: the per-solve stream state (list_leaf/cursor.rs:112-145) is one SmallRng seeded from
     // scoped_seed(random_seed, descriptor, variable, "list_ruin_move_selector"); every cursor open draws one u64 from it
     size_t ruin_min = 2, ruin_max = 5, ruin_moves_per_step = 10, ruin_max_source_len = 0;
@@ -142,7 +143,7 @@ struct Model {
         for (uint32_t leaf : order)
             if (leaves & leaf) children.push_back(open_leaf(leaf, d, ctx));
         if (children.size() == 1) return std::move(children[0]);
-        return std::make_unique<UnionCursor>(std::move(children), union_order, ctx);
+        return std::make_unique<UnionCursor>(std::move(children), union_order, ctx, union_weights);
     }
     void wire_search() {
         search.director = &director;

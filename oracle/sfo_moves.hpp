@@ -1713,9 +1713,9 @@ struct UnionCursor : Cursor {
     std::vector<std::unique_ptr<Cursor>> children;
     UnionScheduler sched;
     size_t last_child = 0;
-    UnionCursor(std::vector<std::unique_ptr<Cursor>> ch, UnionOrder order, const MoveStreamContext& ctx)
+    UnionCursor(std::vector<std::unique_ptr<Cursor>> ch, UnionOrder order, const MoveStreamContext& ctx, const std::vector<uint64_t>& weights = {})
         : children(std::move(ch)),
-          sched(children.size(), order, ctx, std::vector<uint64_t>(children.size(), 1)) {}
+          sched(children.size(), order, ctx, weights.size() == children.size() ? weights : std::vector<uint64_t>(children.size(), 1)) {}
     bool next(Move& out) override {
         return sched.next(
             children.size(), [&](size_t i) { return children[i]->next(out); }, last_child);

@@ -97,6 +97,8 @@ struct sf_ctx {
     int64_t* d_each = nullptr;           // [R][SF_EACH_WORDS] evaluate_each aggregates
     uint64_t* d_kopt_scratch = nullptr;  // [R][n_cap] distance keys of long routes (distance-pruned 3-opt leaf)
     uint64_t* d_ruin_rng = nullptr;      // [R][4] per-solve SmallRng state of the list ruin leaf
+    int union_order = -1;                // sf_union_configure: -1 = the default policy's root union
+    std::vector<int32_t> union_weights;  // per leaf in union order; empty = equal
     int64_t* d_scores_out = nullptr;
     int32_t* d_ok = nullptr;
     // profiling
@@ -396,6 +398,30 @@ int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t d, int32_t va
     s.max_size = max_size;
     ctx->selectors.push_back(s);
     return SF_OK;
+}
+
+// UnionMoveSelectorConfig { selection_order, weighting } of the root union
+int32_t sf_union_configure(sf_ctx* ctx, int32_t selection_order, const int64_t* weights, int32_t n_weights) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (selection_order < -1 || selection_order > SF_UNION_STRATIFIED_RANDOM) return fail(ctx, SF_ERR_INVALID, "union selection order");
+    if (n_weights < 0 || (n_weights > 0 && !weights)) return fail(ctx, SF_ERR_INVALID, "bad union weights");
+    std::vector<int32_t> w;
+    bool unit = true;
+    for (int32_t i = 0; i < n_weights; ++i) {
+        if (weights[i] < 0) return fail(ctx, SF_ERR_INVALID, "union weights are unsigned");
+        if (weights[i] > 65535) return fail(ctx, SF_ERR_UNSUPPORTED, "union weights above 65535 are not supported on the device");
+        unit = unit && weights[i] == 1;
+        w.push_back((int32_t)weights[i]);
+    }
+    // UnionScheduler::new asserts this (vec_union.rs:215-222)
+    if (!unit && selection_order != SF_UNION_RANDOM && selection_order != SF_UNION_STRATIFIED_RANDOM && selection_order != -1)
+        return fail(ctx, SF_ERR_INVALID, "union weights require random or stratified_random selection order");
+    ctx->union_order = selection_order;
+    ctx->union_weights = unit ? std::vector<int32_t>() : w;
+    return SF_OK;
+}
+static bool union_is_custom(const sf_ctx* ctx) {
+    return (ctx->union_order >= 0 && ctx->union_order != SF_UNION_STRATIFIED_RANDOM) || !ctx->union_weights.empty();
 }
 
 // list ruin leaf (ListRuinMoveSelectorConfig, solverforge-config/src/move_selector.rs:552-587)
@@ -1303,6 +1329,13 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             gl.kind[gl.n++] = kind;
         }
     if (gl.n == 0) return fail(ctx, SF_ERR_INVALID, "no selector configured");
+    gl.union_order = ctx->union_order >= 0 ? ctx->union_order : (gl.n > 1 ? SF_UNION_STRATIFIED_RANDOM : SF_UNION_SEQUENTIAL);
+    gl.union_custom = union_is_custom(ctx) && gl.n > 1 ? 1 : 0;
+    for (int l = 0; l < GL; ++l) gl.weight[l] = 1;
+    if (!ctx->union_weights.empty()) {
+        if ((int)ctx->union_weights.size() != gl.n) return fail(ctx, SF_ERR_INVALID, "union weight count must match child count");
+        for (int l = 0; l < gl.n; ++l) gl.weight[l] = ctx->union_weights[l];
+    }
     if (ctx->has_scalar_model && ctx->sm.tables())
         return fail(ctx, SF_ERR_UNSUPPORTED, "value-keyed constraints (self-join / grouped sum / exists by value) run in the scalar engine only");
     if (ctx->has_list_model && (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536))
@@ -1330,7 +1363,8 @@ extern "C" {
 
 static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // the 2-leaf nearby union has its own engines; every other union runs in the generic N-leaf engine
-    if ((ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)))
+    // a configured root union (order / weights other than the default policy's) runs in the generic engine too
+    if ((ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)) || union_is_custom(ctx))
         return launch_mixed(ctx, p, grid, trace);
     if (ctx->has_list_model) {
         int rc = fill_list_leaves(ctx, p);

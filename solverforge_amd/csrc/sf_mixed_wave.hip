@@ -62,6 +62,10 @@ struct GLeaves {
     int32_t min_size[GL], max_size[GL];  // sublist leaves; k-opt leaf: min_size = min_segment_len
     int32_t kopt_nearby;     // the union has a distance-pruned 3-opt leaf (kind 512, max_nearby > 0)
     uint64_t* kopt_scratch;  // [R][n_cap] distance keys of routes longer than KOPT_LDS_KEYS
+    // UnionSelectionOrder + UnionWeighting of the root union (vec_union.rs:190-365): order 0 Sequential, 1 RoundRobin,
+    // 2 RotatingRoundRobin, 3 Random, 4 StratifiedRandom; union_custom = 0: the default policy (StratifiedRandom, equal weights)
+    int32_t union_order, union_custom;
+    int32_t weight[GL];
     int32_t has_ruin;        // the union has a list ruin leaf (kind 1024); parameters + per-solve stream in `ruin`
     RuinParams ruin;
 };
@@ -445,7 +449,22 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         // union scheduler (vec_union.rs:190-365): StratifiedRandom with equal weights when > 1 leaf
         const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
         const uint32_t u_str = nl > 1 ? ctx.random_stride((uint32_t)nl, SALT_UNION_STRIDE) : 1u;
-        int32_t live_weight = nl;  // running weights of the smooth weighted round-robin live in the leaf table
+        int32_t live_weight = nl;  // total weight of the live children (running weights of the smooth weighted round-robin: leaf table)
+        uint32_t u_cur = 0, u_draw = 0;  // RoundRobin cursor / Random draw counter of this step's cursor
+        const int u_ord = nl > 1 ? gl.union_order : 0;
+        if (gl.union_custom) {  // weighted children: a zero weight is an exhausted child from the start (vec_union.rs:214-218)
+            live_weight = 0;
+#pragma unroll
+            for (int l = 0; l < GL; ++l) {
+                if (l >= nl) continue;
+                if (gl.weight[l] == 0) {
+                    exmask |= 1u << l;
+                    lt.set(l, LeafTab::EX, 1);
+                }
+                live_weight += gl.weight[l];
+            }
+            if (u_ord == 2) u_cur = u_off;  // RotatingRoundRobin starts at the seeded offset
+        }
         uint32_t u_order = 0;  // rotated child order of this step, 4 bits per position (nl <= 8)
         for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) u_order |= ((u_off + pos * u_str) % (uint32_t)nl) << (4u * pos);
         u_order = uni(u_order);
@@ -1070,7 +1089,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 // live children in rotated order whenever all their running weights are equal (true at the
                 // start of every step and after every whole cycle).  Lay out whole cycles directly; the
                 // pull-by-pull simulation below handles partial cycles, exhaustion and refills.
-                if (nl > 1 && nlive > 1) {
+                if (nl > 1 && nlive > 1 && !gl.union_custom) {
                     // One cycle of the smooth weighted round-robin with equal weights pulls every live child once, in
                     // descending running weight (ties: rotated order), and leaves the weights as it found them -- provided
                     // max - min < live children (true with equal weights at the start of a step, and again a few pulls
@@ -1127,11 +1146,19 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     uint32_t mypos = 0;
                     for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos)
                         if (((u_order >> (4u * pos)) & 15u) == lane) mypos = pos;
+                    int32_t wgt = 1;  // child weight (UnionWeighting); lane l = leaf l
+                    if (gl.union_custom) {
+                        wgt = 0;
+#pragma unroll
+                        for (int l = 0; l < GL; ++l)
+                            if (lane == (uint32_t)l) wgt = gl.weight[l];
+                    }
                     while (nvalid < 64 && nlive > 0) {
                         uint32_t sel = 0;
                         const bool live_l = isleaf && !((exmask >> lane) & 1u);
-                        if (nl > 1) {
-                            if (live_l) wc += 1;
+                        const uint32_t cur_before = u_cur;
+                        if (nl > 1 && u_ord == 4) {  // StratifiedRandom: smooth weighted round-robin (vec_union.rs:334-362)
+                            if (live_l) wc += wgt;
                             // max running weight, the earlier rotated position on ties: max of (weight << 4 | 15 - position) over
                             // lanes 0..7 by a DPP prefix max (row_shr 1, 2, 4), read at lane 7
                             int32_t key = live_l ? (int32_t)(((uint32_t)wc << 4) | (15u - mypos)) : INT32_MIN;
@@ -1140,6 +1167,27 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x114, 0xf, 0xf, false));
                             const uint32_t kmax = (uint32_t)__builtin_amdgcn_readlane(key, 7);
                             sel = (u_order >> (4u * (15u - (kmax & 15u)))) & 15u;
+                        } else if (nl > 1 && u_ord == 0) {  // Sequential: drain the children in declaration order (:249-262)
+                            while (u_cur < (uint32_t)nl && ((exmask >> u_cur) & 1u)) u_cur += 1;
+                            sel = u_cur;
+                        } else if (nl > 1 && u_ord <= 2) {  // RoundRobin / RotatingRoundRobin: the next live child (:264-283)
+                            for (;;) {
+                                sel = u_cur % (uint32_t)nl;
+                                u_cur = (u_cur + 1u) % (uint32_t)nl;
+                                if (!((exmask >> sel) & 1u)) break;
+                            }
+                        } else if (nl > 1) {  // Random: one seeded draw over the live weights per pull (:285-321)
+                            const uint32_t draw = mod_u64(ctx.mixed_seed(0xA11CE5E1EC701000ULL + (uint64_t)u_draw), (uint32_t)live_weight);
+                            u_draw += 1;
+                            uint32_t cum = 0;
+                            for (int i = 0; i < nl; ++i) {
+                                if ((exmask >> i) & 1u) continue;
+                                cum += (uint32_t)__builtin_amdgcn_readlane(wgt, i);
+                                if (draw < cum) {
+                                    sel = (uint32_t)i;
+                                    break;
+                                }
+                            }
                         }
                         const uint32_t sel_taken = (uint32_t)__builtin_amdgcn_readlane((int)tk, (int)sel);
                         const uint32_t sel_head = (uint32_t)__builtin_amdgcn_readlane((int)hd, (int)sel);
@@ -1147,15 +1195,17 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         const bool gdone = __builtin_amdgcn_readlane((int)dn, (int)sel) != 0;
                         if (!avail && !gdone) {
                             // the child has more candidates that are not generated yet: undo this pull's bookkeeping and refill first
-                            if (nl > 1 && live_l) wc -= 1;
+                            if (nl > 1 && u_ord == 4 && live_l) wc -= wgt;
+                            if (u_ord == 1 || u_ord == 2) u_cur = cur_before;
+                            if (u_ord == 3 && nl > 1) u_draw -= 1;
                             need_more = true;
                             break;
                         }
-                        if (nl > 1 && lane == sel) wc -= live_weight;
+                        if (nl > 1 && u_ord == 4 && lane == sel) wc -= live_weight;
                         if (!avail) {  // exhausted child discovered at this pull
                             exmask |= 1u << sel;
                             nlive -= 1;
-                            live_weight -= 1;
+                            live_weight -= __builtin_amdgcn_readlane(wgt, (int)sel);
                             continue;
                         }
                         if (lane == sel) tk += 1;

@@ -155,6 +155,15 @@ class GpuScoreDirector:
     def add_selector(self, kind, descriptor_index, variable_index=0, max_nearby=0, fact_meter=-1):
         check(self._L.sf_selector_add(self._h, kind, descriptor_index, variable_index, max_nearby, fact_meter), self._h)
 
+    def configure_union(self, selection_order=-1, weights=None):
+        """Root union of the leaves: selection_order 0 Sequential, 1 RoundRobin, 2 RotatingRoundRobin, 3 Random,
+        4 StratifiedRandom (-1 = default policy); weights = one unsigned weight per leaf in union order (None = equal)."""
+        if weights is None:
+            check(self._L.sf_union_configure(self._h, selection_order, None, 0), self._h)
+        else:
+            w = np.ascontiguousarray(weights, dtype=np.int64)
+            check(self._L.sf_union_configure(self._h, selection_order, ptr(w), len(w)), self._h)
+
     def add_ruin_selector(self, descriptor_index, variable_index=0, min_ruin_count=2, max_ruin_count=5, moves_per_step=10,
                           max_source_list_len=0, skip_empty_destinations=False, variable_name="visits"):
         """List ruin leaf (ListRuinMoveSelectorConfig defaults); max_source_list_len 0 = None."""

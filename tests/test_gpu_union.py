@@ -1,0 +1,111 @@
+"""GPU parity tests (through the C ABI): the root union's selection orders and weights (UnionMoveSelectorConfig; scheduler
+heuristic/selector/decorator/vec_union.rs:190-365) -- Sequential, RoundRobin, RotatingRoundRobin, Random and StratifiedRandom,
+weighted children (smooth weighted round-robin, weighted random draws, a zero weight) -- vs the oracle's UnionScheduler:
+candidate order with the child index of every pull, trial scores, committed moves, fused steps."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LEAF_BITS = {"nearby_change": 16, "nearby_swap": 32, "list_change": 4, "list_swap": 8, "list_reverse": 64,
+             "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024}
+
+
+def _t(moves):
+    return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"], moves["value"]], axis=1)
+
+
+CASES = [
+    (0, None), (1, None), (2, None), (3, None), (4, None),
+    (3, [3, 1, 2, 1, 5]), (4, [3, 1, 2, 1, 5]), (4, [1, 0, 4, 1, 1]), (3, [0, 2, 0, 1, 1]), (4, [7, 7, 7, 7, 7]),
+]
+
+
+@pytest.mark.parametrize("order,weights", CASES)
+def test_union_orders_and_weights_cvrp(oracle, order, weights):
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    leaves = ("nearby_change", "nearby_swap", "sublist_change", "list_reverse", "kopt")
+    p = datasets.make_cvrp(40, 4, 60, seed=3)
+    d = sfa.build_cvrp(p, leaves=leaves, max_nearby=10)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    bits = sum(LEAF_BITS[x] for x in leaves)
+    d.configure_union(order, weights)
+    d.configure(sfa.SolverConfig(random_seed=3, late_acceptance_size=5, accepted_count_limit=40))
+    d.calculate_score()
+    for sel_order in (3, 0):  # the whole cursor, drained: every child runs dry at some point
+        o.configure(leaves=bits, random_seed=3, la_size=5, limit=40, max_nearby=10, union_order=order, selection_order=sel_order)
+        if weights:
+            o.set_union_weights(weights)
+        for step_index, step_seed in [(0, 0), (7, 0xDEADBEEFCAFEF00D)]:
+            gm, gs, gd = d.open_cursor(step_index, step_seed, selection_order=sel_order, cap=1 << 18)
+            om = o.enumerate(0, step_index, step_seed, sel_order)
+            assert len(gm) == len(om) > 0, (sel_order, step_index)
+            assert (_t(gm) == _t(om)).all(), (sel_order, step_index)
+    o.configure(leaves=bits, random_seed=3, la_size=5, limit=40, max_nearby=10, union_order=order)
+    if weights:
+        o.set_union_weights(weights)
+    d.phase_start()
+    o.phase_start()
+    for step in range(20):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step  # flags carry the child index
+        assert gap == oap
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+    d.solve_steps(60)
+    o.steps(60)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+@pytest.mark.parametrize("order,weights", [(1, None), (3, [3, 1]), (4, [1, 4]), (0, None)])
+def test_union_orders_scalar_model(oracle, order, weights):
+    """A configured root union sends a scalar-only model to the generic engine too."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    g = datasets.make_graph(200, 900, 5, seed=3)
+    g["colors"] = (datasets.stream(9, 200) % np.uint64(6)).astype(np.int64) - 1
+    d = sfa.build_graph_coloring(g)
+    o = oracle.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+    d.configure_union(order, weights)
+    d.configure(sfa.SolverConfig(random_seed=2, late_acceptance_size=5, accepted_count_limit=30))
+    o.configure(leaves=3, random_seed=2, la_size=5, limit=30, union_order=order)
+    if weights:
+        o.set_union_weights(weights)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(15):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+    d.solve_steps(50)
+    o.steps(50)
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+
+
+def test_union_configure_validation():
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(12, 2, 60, seed=1)
+    d = sfa.build_cvrp(p)
+    with pytest.raises(sfa.SolverForgeError):
+        d.configure_union(5)
+    with pytest.raises(sfa.SolverForgeError):
+        d.configure_union(1, [2, 1])  # weights need Random / StratifiedRandom
+    with pytest.raises(sfa.SolverForgeError):
+        d.configure_union(4, [-1, 1])
+    d.configure_union(4, [2, 1, 1])  # count mismatch surfaces at the launch
+    d.calculate_score()
+    d.phase_start()
+    with pytest.raises(sfa.SolverForgeError):
+        d.solve_steps(1)
