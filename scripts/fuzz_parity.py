@@ -9,7 +9,7 @@ from solverforge_amd import datasets
 from oracle import sfo
 
 BITS = {"nearby_change": 16, "nearby_swap": 32, "list_change": 4, "list_swap": 8, "list_reverse": 64,
-        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "change": 1, "swap": 2}
+        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024, "change": 1, "swap": 2}
 
 
 def t6(m):
@@ -18,9 +18,9 @@ def t6(m):
 
 def run_case(seed):
     rng = np.random.default_rng(seed)
-    model = ["cvrp", "cvrp", "graph", "jobshop", "balance"][int(rng.integers(5))]
+    model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment"][int(rng.integers(7))]
     acceptor = int(rng.choice([0, 1, 1, 3]))
-    forager = int(rng.choice([0, 0, 1, 2]))
+    forager = int(rng.choice([0, 0, 1, 2, 3, 4]))
     limit = int(rng.choice([1, 2, 7, 40, 256]))
     order = int(rng.choice([0, 3, 3, 4]))
     la = int(rng.choice([1, 3, 50]))
@@ -43,20 +43,23 @@ def run_case(seed):
             if len(p["routes"][2]) > 1:
                 p["routes"][0] = p["routes"][0] + p["routes"][2][1:]
                 p["routes"][2] = p["routes"][2][:1]
-        pool = ["nearby_change", "nearby_swap", "list_change", "list_swap", "list_reverse", "sublist_change", "sublist_swap", "kopt"]
-        chosen = set(rng.choice(pool, size=int(rng.integers(1, 7)), replace=False).tolist())
-        leaves = tuple(x for x in pool if x in chosen)
+        pool = ["nearby_change", "nearby_swap", "list_change", "list_swap", "list_reverse", "sublist_change", "sublist_swap", "kopt", "ruin"]
+        chosen = set(rng.choice(pool, size=int(rng.integers(1, 8)), replace=False).tolist())
+        leaves = tuple(x for x in ["nearby_change", "list_change", "nearby_swap", "list_swap", "sublist_change", "sublist_swap", "list_reverse",
+                                   "kopt", "ruin"] if x in chosen)  # union (declaration) order
         mn = int(rng.choice([1, 3, 20, 64]))
         kopt = (int(rng.choice([1, 1, 2])), int(rng.choice([0, 2, 20])))
         sub = (1, int(rng.choice([1, 3, 5])))
         engine = int(rng.choice([0, 1, 2])) if set(leaves) <= {"nearby_change", "nearby_swap"} else 0
-        desc.update(n=n, v=v, leaves=leaves, max_nearby=mn, kopt=kopt, sublist=sub, engine=engine)
-        d = sfa.build_cvrp(p, leaves=leaves, max_nearby=mn, kopt=kopt, sublist_sizes=sub)
+        ruin = (int(rng.choice([1, 2])), int(rng.choice([2, 5, 6])), int(rng.choice([1, 3, 10, 16])))
+        desc.update(n=n, v=v, leaves=leaves, max_nearby=mn, kopt=kopt, sublist=sub, engine=engine, ruin=ruin)
+        d = sfa.build_cvrp(p, leaves=leaves, max_nearby=mn, kopt=kopt, sublist_sizes=sub, ruin=ruin)
         if engine:
             d.set_engine(engine)
         o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
         o.set_kopt(*kopt); o.set_sublist_sizes(*sub)
         lists = lambda: (d.working_lists(0, 0), o.get_lists(0))
+        post_configure = lambda: o.set_ruin(*ruin)
     elif model == "graph":
         n = int(rng.integers(5, 200)); e = int(rng.integers(n, 4 * n)); k = int(rng.integers(2, 9))
         g = datasets.make_graph(n, min(e, n * (n - 1) // 2), k, seed=seed)
@@ -68,7 +71,7 @@ def run_case(seed):
         o = sfo.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
         lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
     elif model == "balance":  # keyed self-join + grouped sum / excess-over-cap / load_balance collector
-        n = int(rng.integers(4, 120)); k = int(rng.integers(2, 12)); cap = int(rng.choice([-1, 25, -2, -2]))
+        n = int(rng.integers(4, 120)); k = int(rng.integers(2, 12)); cap = int(rng.choice([-1, 25, -2, -2, -3, -3]))
         r = datasets.stream(seed + 3, 2 * n)
         bins = (r[:n] % np.uint64(k + 1)).astype(np.int64) - 1
         sizes = (r[n:] % np.uint64(int(rng.choice([9, 1000, 1_000_000])))).astype(np.int64) + 1
@@ -78,6 +81,25 @@ def run_case(seed):
         d = sfa.build_balance(bins, sizes, k, w_pair=wp, cap=cap, leaves=leaves)
         o = sfo.Model.balance(k, bins, sizes, w_pair=wp, cap=cap)
         lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
+    elif model == "assignment":  # keyed cross-join with a fact class + exists / not-exists per fact row
+        n = int(rng.integers(4, 100)); k = int(rng.integers(2, 12))
+        r = datasets.stream(seed + 21, n + n * k + k)
+        values = (r[:n] % np.uint64(k + 1)).astype(np.int64) - 1
+        cost = (r[n:n + n * k] % np.uint64(7)).astype(np.int64)
+        cost[cost < int(rng.choice([0, 3, 6]))] = 0
+        row_w = (r[n + n * k:] % np.uint64(20)).astype(np.int64) + 1
+        ex_mode, ex_level = int(rng.integers(2)), int(rng.choice([-1, 0, 1]))
+        leaves = [("change",), ("swap",), ("change", "swap")][int(rng.integers(3))]
+        desc.update(n=n, k=k, ex_mode=ex_mode, ex_level=ex_level, leaves=leaves)
+        d = sfa.build_assignment(values, cost.reshape(n, k), k, cost_weight=2, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3,
+                                 leaves=leaves)
+        o = sfo.Model.assignment(values, cost.reshape(n, k), k, cost_weight=2, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3)
+        lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
+        cands = [[(int(e), int(v)) for e, v in zip(rng.integers(0, n, m), rng.integers(-1, k, m))] for m in rng.integers(1, 9, 40)]
+        d.calculate_score()
+        cs, cd = d.evaluate_candidates(cands)
+        ocs, ocd = o.evaluate_compound(cands)
+        assert (cd == ocd).all() and (cs == ocs[:, :2]).all(), "compound candidates"
     else:
         nj = int(rng.integers(2, 9)); nm = int(rng.integers(2, 6))
         p = datasets.make_jobshop(nj, nm)
@@ -93,8 +115,23 @@ def run_case(seed):
         o.set_kopt(1, 0)
         lists = lambda: ((d.working_lists(1, 0), d.working_values(0, 0).tolist()), (o.get_lists(1), o.get_vars(0, 0).tolist()))
     bits = sum(BITS[x] for x in leaves)
+    # root union: mostly the default policy, sometimes another order / weights (those run in the generic engine; value-keyed
+    # scalar models cannot -> SF_ERR_UNSUPPORTED, counted separately)
+    union_order, union_weights = -1, None
+    if len(leaves) > 1 and rng.random() < 0.35:
+        union_order = int(rng.integers(0, 5))
+        if union_order >= 3 and rng.random() < 0.6:
+            union_weights = [int(w) for w in rng.integers(0, 5, len(leaves))]
+            if sum(union_weights) == 0:
+                union_weights[0] = 1
+        d.configure_union(union_order, union_weights)
+    desc.update(union_order=union_order, union_weights=union_weights)
     o.configure(acceptor=1 if acceptor == 3 else acceptor, la_size=la, forager=forager, limit=limit, leaves=bits,
-                selection_order=order, random_seed=seed, max_nearby=desc.get("max_nearby", 20))
+                selection_order=order, random_seed=seed, max_nearby=desc.get("max_nearby", 20), union_order=union_order)
+    if union_weights:
+        o.set_union_weights(union_weights)
+    if model == "cvrp":
+        post_configure()
     d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=la, forager=forager, accepted_count_limit=limit,
                                  selection_order=order, random_seed=seed))
     if acceptor == 3:
