@@ -1097,24 +1097,36 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     // below only handles the transient after an exhaustion, partial cycles and refills.
                     const uint32_t livem = ~exmask & ((1u << nl) - 1u);
                     const int32_t wc = lane < (uint32_t)nl ? (int32_t)lt.w[lane * 16 + LeafTab::WCUR] : 0;  // lane l = leaf l
-                    uint32_t mypos = 0;
-                    for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos)
-                        if (((u_order >> (4u * pos)) & 15u) == lane) mypos = pos;
+                    // wave-uniform: the live children's running weights and rotated positions through v_readlane (no LDS
+                    // crossbar round trips), rank of every live child = how many live children are pulled before it
                     int32_t wmax = INT32_MIN, wmin = INT32_MAX;
-                    uint32_t rank = 0;
+                    uint32_t r_order = 0;  // live leaves by pull order inside a cycle, 4 bits each
                     for (int j = 0; j < nl; ++j) {
                         if (!((livem >> j) & 1u)) continue;
-                        const int32_t wj = __shfl(wc, j);
-                        const uint32_t pj = (uint32_t)__shfl((int)mypos, j);
+                        const int32_t wj = __builtin_amdgcn_readlane(wc, j);
                         wmax = wj > wmax ? wj : wmax;
                         wmin = wj < wmin ? wj : wmin;
-                        rank += (wj > wc || (wj == wc && pj < mypos)) ? 1u : 0u;
                     }
                     if (wmax - wmin < nlive) {
-                        uint32_t r_order = 0;  // live leaves by pull order inside a cycle, 4 bits each
-                        for (int j = 0; j < nl; ++j)
-                            if ((livem >> j) & 1u) r_order |= (uint32_t)j << (4u * (uint32_t)__shfl((int)rank, j));
-                        r_order = uni(r_order);
+                        uint32_t seen = 0;
+                        for (uint32_t pi = 0; pi < (uint32_t)nl; ++pi) {      // rotated position pi holds leaf i
+                            const uint32_t i = (u_order >> (4u * pi)) & 15u;
+                            if (!((livem >> i) & 1u)) continue;
+                            if (wmax == wmin) {  // equal running weights (the steady state): the rotated order itself
+                                r_order |= i << (4u * seen);
+                                seen += 1;
+                                continue;
+                            }
+                            const int32_t wi = __builtin_amdgcn_readlane(wc, (int)i);
+                            uint32_t rank = 0;
+                            for (uint32_t pj = 0; pj < (uint32_t)nl; ++pj) {
+                                const uint32_t j = (u_order >> (4u * pj)) & 15u;
+                                if (!((livem >> j) & 1u)) continue;
+                                const int32_t wj = __builtin_amdgcn_readlane(wc, (int)j);
+                                rank += (wj > wi || (wj == wi && pj < pi)) ? 1u : 0u;
+                            }
+                            r_order |= i << (4u * rank);
+                        }
                         // my pull t = lane: cycle t / nlive, child = the (t % nlive)-th leaf of the cycle
                         const uint32_t cyc = lane / (uint32_t)nlive, slot = lane % (uint32_t)nlive;
                         const uint32_t leaf = (r_order >> (4u * slot)) & 15u;
