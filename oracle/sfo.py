@@ -66,6 +66,8 @@ def lib():
             "sfo_nqueens_create": (vp, [i32, vp]),
             "sfo_graph_coloring_create": (vp, [i32, i32, vp, vp, vp]),
             "sfo_balance_create": (vp, [i32, i32, vp, vp, i64, i64]),
+            "sfo_graph_coloring_create_indexed": (vp, [i32, i32, vp, vp, vp]),
+            "sfo_jobshop_create_indexed": (vp, [i32, i32, vp, vp, vp, vp, i32]),
             "sfo_balance_create_nary": (vp, [i32, i32, vp, vp, i64, i64, i32]),
             "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
             "sfo_assignment_create": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64]),
@@ -151,12 +153,14 @@ class Model:
         return Model(lib().sfo_nqueens_create(len(rows), _p(rows)), [len(rows)])
 
     @staticmethod
-    def graph_coloring(n_colors, adj_off, adj, colors):
+    def graph_coloring(n_colors, adj_off, adj, colors, indexed=False):
+        """indexed=True: the INDEXED CPU baseline (partner-indexed join) instead of the reference's dense predicate join."""
         adj_off = np.ascontiguousarray(adj_off, dtype=np.uint32)
         adj = np.ascontiguousarray(adj, dtype=np.uint32)
         colors = np.ascontiguousarray(colors, dtype=np.int64)
         n = len(colors)
-        return Model(lib().sfo_graph_coloring_create(n, n_colors, _p(adj_off), _p(adj), _p(colors)), [n])
+        fn = lib().sfo_graph_coloring_create_indexed if indexed else lib().sfo_graph_coloring_create
+        return Model(fn(n, n_colors, _p(adj_off), _p(adj), _p(colors)), [n])
 
     @staticmethod
     def balance(n_bins, bins, sizes, w_pair=1, cap=-1, arity=2):
@@ -195,11 +199,12 @@ class Model:
         return Model(h, [len(routes)])
 
     @staticmethod
-    def jobshop(job, machine_idx, sequences, bendable=True):
+    def jobshop(job, machine_idx, sequences, bendable=True, indexed=False):
         job = np.ascontiguousarray(job, dtype=np.int64)
         machine_idx = np.ascontiguousarray(machine_idx, dtype=np.int64)
         off, vals = csr(sequences)
-        h = lib().sfo_jobshop_create(len(job), len(sequences), _p(job), _p(machine_idx), _p(off), _p(vals), int(bendable))
+        fn = lib().sfo_jobshop_create_indexed if indexed else lib().sfo_jobshop_create
+        h = fn(len(job), len(sequences), _p(job), _p(machine_idx), _p(off), _p(vals), int(bendable))
         return Model(h, [len(job), len(sequences)])
 
     # -- director ---------------------------------------------------------------------

@@ -98,6 +98,14 @@ void* sfo_graph_coloring_create(int32_t n, int32_t n_colors, const uint32_t* adj
                                 const int64_t* colors) {
     return make_graph_coloring((size_t)n, (size_t)n_colors, adj_off, adj, colors).release();
 }
+// INDEXED CPU baselines (partner-indexed predicate join instead of the reference's dense one): same scores, O(partners) per insert
+void* sfo_graph_coloring_create_indexed(int32_t n, int32_t n_colors, const uint32_t* adj_off, const uint32_t* adj, const int64_t* colors) {
+    return make_graph_coloring((size_t)n, (size_t)n_colors, adj_off, adj, colors, true).release();
+}
+void* sfo_jobshop_create_indexed(int32_t n_ops, int32_t n_machines, const int64_t* job, const int64_t* machine_idx, const uint32_t* seq_off,
+                                 const uint32_t* seq_vals, int32_t bendable) {
+    return make_jobshop((size_t)n_ops, (size_t)n_machines, job, machine_idx, seq_off, seq_vals, bendable != 0, true).release();
+}
 void* sfo_balance_create(int32_t n, int32_t n_bins, const int64_t* bins, const int64_t* sizes, int64_t w_pair,
                          int64_t cap) {
     return make_balance((size_t)n, (size_t)n_bins, bins, sizes, w_pair, cap).release();

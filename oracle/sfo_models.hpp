@@ -211,8 +211,30 @@ inline std::unique_ptr<Model> make_nqueens(size_t n, const int64_t* rows) {
 }
 
 // ---- graph colouring (graph_coloring.rs:21-44) ----------------------------
+// `indexed`: the INDEXED CPU baseline (PartnerEqualConstraint) instead of the reference's dense predicate join
+inline void partners_from_adjacency(size_t n, const std::vector<uint32_t>& off, const std::vector<uint32_t>& adj, std::vector<uint32_t>& poff,
+                                    std::vector<uint32_t>& pn) {  // {a, b} is a pair iff b is in neighbors(a) for the lower index a
+    std::vector<std::vector<uint32_t>> lists(n);
+    for (size_t a = 0; a < n; ++a) {
+        std::vector<uint32_t> seen;
+        for (uint32_t p = off[a]; p < off[a + 1]; ++p) {
+            uint32_t b = adj[p];
+            if (b >= n || b <= a || std::find(seen.begin(), seen.end(), b) != seen.end()) continue;
+            seen.push_back(b);
+            lists[a].push_back(b);
+            lists[b].push_back((uint32_t)a);
+        }
+    }
+    poff.assign(n + 1, 0);
+    pn.clear();
+    for (size_t a = 0; a < n; ++a) {
+        poff[a] = (uint32_t)pn.size();
+        pn.insert(pn.end(), lists[a].begin(), lists[a].end());
+    }
+    poff[n] = (uint32_t)pn.size();
+}
 inline std::unique_ptr<Model> make_graph_coloring(size_t n, size_t n_colors, const uint32_t* adj_off,
-                                                  const uint32_t* adj, const int64_t* colors) {
+                                                  const uint32_t* adj, const int64_t* colors, bool indexed = false) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<GraphFacts>();
     facts->n = n;
@@ -245,7 +267,18 @@ inline std::unique_ptr<Model> make_graph_coloring(size_t n, size_t n_colors, con
         return ca != NONE && ca == s.classes[0].vars[0][b];
     };
     conflict->weight = [](const Solution&, size_t, size_t) { return Score::of(1, 0); };
-    m->director.constraints.members.push_back(std::move(conflict));
+    if (indexed) {
+        auto ix = std::make_unique<PartnerEqualConstraint>();
+        ix->name = "Adjacent color conflict (indexed)";
+        ix->impact = Impact::Penalty;
+        ix->source = ChangeSource::descriptor(0);
+        ix->count = [](const Solution& s) { return s.classes[0].n; };
+        ix->value = [](const Solution& s, size_t e) { return s.classes[0].vars[0][e]; };
+        partners_from_adjacency(n, facts->adj_off, facts->adj, ix->poff, ix->pn);
+        ix->weight = Score::of(1, 0);
+        m->director.constraints.members.push_back(std::move(ix));
+    } else
+        m->director.constraints.members.push_back(std::move(conflict));
     m->has_scalar = true;
     m->scalar_slot.descriptor_index = 0;
     m->scalar_slot.variable_index = 0;
@@ -549,7 +582,7 @@ inline std::unique_ptr<Model> make_list_toy(size_t n_entities, const uint32_t* o
 // HardSoftScore; Bendable is a BASELINE.json requirement)
 inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, const int64_t* job,
                                            const int64_t* machine_idx, const uint32_t* seq_off,
-                                           const uint32_t* seq_vals, bool bendable) {
+                                           const uint32_t* seq_vals, bool bendable, bool indexed = false) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<JobShopFacts>();
     facts->n_ops = n_ops;
@@ -604,7 +637,26 @@ inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, cons
         return ma != NONE && ma == s.classes[0].vars[0][b];
     };
     reuse->weight = [w_reuse](const Solution&, size_t, size_t) { return w_reuse; };
-    m->director.constraints.members.push_back(std::move(reuse));
+    if (indexed) {  // partners = the other operations of the same job
+        auto ix = std::make_unique<PartnerEqualConstraint>();
+        ix->name = "Same job machine reuse (indexed)";
+        ix->impact = Impact::Penalty;
+        ix->source = ChangeSource::descriptor(0);
+        ix->count = [](const Solution& s) { return s.classes[0].n; };
+        ix->value = [](const Solution& s, size_t e) { return s.classes[0].vars[0][e]; };
+        std::unordered_map<int64_t, std::vector<uint32_t>> members;
+        for (size_t e = 0; e < n_ops; ++e) members[jf->job[e]].push_back((uint32_t)e);
+        ix->poff.assign(n_ops + 1, 0);
+        for (size_t e = 0; e < n_ops; ++e) {
+            ix->poff[e] = (uint32_t)ix->pn.size();
+            for (uint32_t o2 : members[jf->job[e]])
+                if (o2 != e) ix->pn.push_back(o2);
+        }
+        ix->poff[n_ops] = (uint32_t)ix->pn.size();
+        ix->weight = w_reuse;
+        m->director.constraints.members.push_back(std::move(ix));
+    } else
+        m->director.constraints.members.push_back(std::move(reuse));
 
     m->has_scalar = true;
     m->scalar_slot.descriptor_index = 0;

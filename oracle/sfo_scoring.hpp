@@ -1149,6 +1149,48 @@ struct LoadBalanceConstraint : Constraint {
 };
 
 // ---- ConstraintSet tuple fold (api/constraint_set/incremental.rs:339-407) ----
+// ---- INDEXED CPU baseline for predicate joins (not a reference node) ---------------------------------------------------------
+// The reference evaluates `left.id < right.id && partner(left, right) && equal values` as a cross-join with a constant key: every
+// insert tests all n rows of the other side (CrossBiConstraint above, the dense-faithful baseline).  A CPU implementation that
+// indexes the join by its partner relation does O(partners) work per insert instead; SURVEY.md §7 asks for both numbers.  Same
+// scores by construction (each matched pair counted once, frozen weight = `weight`); stateless.
+struct PartnerEqualConstraint : Constraint {
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Key1 value;                            // NONE = unassigned
+    std::vector<uint32_t> poff, pn;        // symmetric partner CSR
+    Score weight;
+    size_t matches_of(const Solution& s, size_t e) const {
+        int64_t v = value(s, e);
+        if (v == NONE) return 0;
+        size_t c = 0;
+        for (uint32_t p = poff[e]; p < poff[e + 1]; ++p) c += value(s, pn[p]) == v ? 1 : 0;
+        return c;
+    }
+    Score times(size_t c) const {
+        Score r;
+        for (int i = 0; i < MAX_LEVELS; ++i) r.v[i] = wrap_mul(weight.v[i], (int64_t)c);
+        return apply_impact(impact, r);
+    }
+    Score evaluate(const Solution& s) const override { return times(match_count(s)); }
+    size_t match_count(const Solution& s) const override {
+        size_t c = 0, n = count(s);
+        for (size_t e = 0; e < n; ++e) c += matches_of(s, e);
+        return c / 2;  // every pair is seen from both ends
+    }
+    Score initialize(const Solution& s) override { return evaluate(s); }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name) || e >= count(s)) return Score::zero();
+        return times(matches_of(s, e));
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {
+        if (!source.assert_localizes(d, name) || e >= count(s)) return Score::zero();
+        return -times(matches_of(s, e));
+    }
+    void reset() override {}
+};
+
 // ---- BalanceConstraint (constraint/balance.rs:83-372): base_score x population standard deviation of the per-key entity
 // COUNTS, one global statistic; `Score::multiply(f64)` rounds every level half away from zero (score/macros.rs:61-63) ----------
 struct BalanceConstraint : Constraint {

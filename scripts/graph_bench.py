@@ -46,11 +46,24 @@ while done < K * ls and time.perf_counter() - t1 < 10: o.steps(10); done += 10
 ct = time.perf_counter() - t1
 cm = o.stats()["moves_evaluated"] - m0
 match = bool((d.calculate_score()[0] == o.score()[:2]).all()) if done == K * ls else None
+# INDEXED CPU baseline (report both): the same search with the predicate join indexed by its partner relation; the
+# whole timed window fits, so replica 0 is compared with it over all K * ls steps
+oi = sfo.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"], indexed=True)
+oi.configure(leaves=sfo.LEAF_SCALAR_CHANGE | sfo.LEAF_SCALAR_SWAP, random_seed=0, limit=1 if policy == "sa" else 256)
+if policy == "sa":
+    oi.configure_annealing(seed=0)
+oi.phase_start(); oi.steps(ls)
+mi0 = oi.stats()["moves_evaluated"]; t2 = time.perf_counter(); done_i = 0
+while done_i < K * ls and time.perf_counter() - t2 < 20: oi.steps(10); done_i += 10
+cti = time.perf_counter() - t2
+cmi = oi.stats()["moves_evaluated"] - mi0
+match_i = bool((d.calculate_score()[0] == oi.score()[:2]).all()) if done_i == K * ls else None
 # change candidate 28 + 8*deg = 188 B, swap 36 + 8*(deg u + deg v) = 356 B at deg 20
 alg = scored * (188 + 356) / 2
 print(json.dumps({"workload": "graph colouring 10k/100k/16", "policy": policy, "start": start,
                   "gpu_steps_per_s": (a["step_count"] - b["step_count"]) / dt, "cpu_steps_per_s": done / ct, "replicas": R, "gpu_moves_per_s": moves / dt,
                   "gpu_candidates_scored_per_s": scored / dt, "kernel_ms_per_launch": ms / n,
                   "alg_GBps": alg / (ms * 1e-3) / 1e9, "frac_of_8TBps": alg / (ms * 1e-3) / 8e12,
-                  "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done, "replica0_matches_oracle": match, "replica0_matches_oracle_first_%d_steps" % ls: match_warm,
+                  "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done, "cpu_indexed_moves_per_s": cmi / cti, "cpu_indexed_steps": done_i,
+                  "replica0_matches_indexed_cpu": match_i, "gpu_over_cpu_indexed": (moves / dt) / (cmi / cti), "replica0_matches_oracle": match, "replica0_matches_oracle_first_%d_steps" % ls: match_warm,
                   "gpu_over_cpu": (moves / dt) / (cm / ct), "score_replica0": d.calculate_score()[0].tolist(), "fill_calls_per_step": (a["sources_scanned"] - b["sources_scanned"]) / max(a["step_count"] - b["step_count"], 1), "moves_per_step": moves / max(a["step_count"] - b["step_count"], 1), "scored_per_step": scored / max(a["step_count"] - b["step_count"], 1)}))

@@ -36,8 +36,18 @@ while done < K * ls and time.perf_counter() - t1 < 20: o.steps(5); done += 5
 ct = time.perf_counter() - t1
 cm = o.stats()["moves_evaluated"] - m0
 match = bool((d.calculate_score()[0] == o.score()[:3]).all()) if done == K * ls else None
+# INDEXED CPU baseline (report both): the "same job, same machine" join indexed by job
+oi = sfo.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, indexed=True)
+oi.configure(leaves=bits, random_seed=0)
+oi.phase_start(); oi.steps(ls)
+mi0 = oi.stats()["moves_evaluated"]; t2 = time.perf_counter(); done_i = 0
+while done_i < K * ls and time.perf_counter() - t2 < 20: oi.steps(5); done_i += 5
+cti = time.perf_counter() - t2
+cmi = oi.stats()["moves_evaluated"] - mi0
+match_i = bool((d.calculate_score()[0] == oi.score()[:3]).all()) if done_i == K * ls else None
 print(json.dumps({"workload": "mixed job shop 500x20, Bendable<2,1>", "replicas": R, "gpu_moves_per_s": moves / dt,
-                  "kernel_ms_per_launch": ms / n, "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done,
+                  "kernel_ms_per_launch": ms / n, "cpu_oracle_moves_per_s": cm / ct, "cpu_steps": done, "cpu_indexed_moves_per_s": cmi / cti, "cpu_indexed_steps": done_i,
+                  "replica0_matches_indexed_cpu": match_i, "gpu_over_cpu_indexed": (moves / dt) / (cmi / cti),
                   "replica0_matches_oracle": match, "replica0_matches_oracle_first_%d_steps" % ls: match_warm, "gpu_over_cpu": (moves / dt) / (cm / ct),
                   "score_replica0": d.calculate_score()[0].tolist(),
                   "per_step": {k: (a[k] - b[k]) / max(a["step_count"] - b["step_count"], 1)

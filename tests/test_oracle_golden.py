@@ -187,3 +187,32 @@ def test_constructed_graph_start_equals_oracle_first_fit(oracle):
             assert (c["colors"] < 0).any()  # three colours cannot colour this graph greedily: those vertices stay unassigned
         if k == 16:
             assert (c["colors"] >= 0).all()
+
+
+def test_indexed_cpu_baseline_follows_the_dense_faithful_oracle(oracle):
+    """The INDEXED CPU baseline (PartnerEqualConstraint: the predicate join indexed by its partner relation, SURVEY 7 "report
+    both") is not a reference node: it must reproduce the dense-faithful oracle's trajectory exactly (graph colouring, job shop)."""
+    import numpy as np
+    from solverforge_amd import datasets
+
+    g = datasets.make_graph(300, 1500, 6, seed=3)
+    g["colors"] = (datasets.stream(102, 300) % np.uint64(7)).astype(np.int64) - 1
+    a = oracle.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+    b = oracle.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"], indexed=True)
+    assert (a.score() == b.score()).all() and (b.score() == b.fresh_score()).all()
+    for o in (a, b):
+        o.configure(leaves=3, random_seed=5, la_size=7, limit=30)
+        o.phase_start()
+        o.steps(40)
+    assert (a.get_vars(0, 0) == b.get_vars(0, 0)).all() and (a.score() == b.score()).all() and a.stats() == b.stats()
+    sa, ca = a.evaluate_each()
+    sb, cb = b.evaluate_each()
+    assert (sa == sb).all() and (ca == cb).all()
+    p = datasets.construct_jobshop(datasets.make_jobshop(12, 4))
+    a = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"])
+    b = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], indexed=True)
+    for o in (a, b):
+        o.configure(leaves=4 | 8 | 1 | 2, random_seed=2, la_size=5, limit=20)
+        o.phase_start()
+        o.steps(40)
+    assert a.get_lists(1) == b.get_lists(1) and (a.get_vars(0, 0) == b.get_vars(0, 0)).all() and (a.score() == b.score()).all()
