@@ -895,6 +895,34 @@ int32_t sf_get_scores(sf_ctx* ctx, int64_t* out_scores) {
     return download_scores(ctx, ctx->has_list_model ? ctx->lm.score : ctx->sm.score, out_scores);
 }
 
+// SF_MOVE_LIST_RUIN entries of a host batch: one wavefront each (csrc/sf_construct.hip)
+static hipError_t launch_ruin_moves(sf_ctx* ctx, int replica, const int32_t* d_moves, const std::vector<int32_t>& which, int64_t* d_sc, int32_t* d_do,
+                                    int commit) {
+    const SelectorSpec* rs = ruin_selector(ctx);
+    const int skip_empty = rs ? rs->skip_empty : 0;
+    int32_t* d_idx = nullptr;
+    hipError_t e = hipMalloc((void**)&d_idx, which.size() * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, which.data(), which.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    const RuinMoveCarve cv(ctx->lm.V, ctx->lm.n_cap);
+    if (e == hipSuccess) {
+        if (ctx->levels <= 2) {
+            auto kern = k_list_ruin_moves<2>;
+            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(kern, dim3((unsigned)which.size()), dim3(64), cv.total, ctx->stream, ctx->lm, replica, d_moves, d_idx, d_sc, d_do, skip_empty, commit);
+        } else {
+            auto kern = k_list_ruin_moves<4>;
+            e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL(kern, dim3((unsigned)which.size()), dim3(64), cv.total, ctx->stream, ctx->lm, replica, d_moves, d_idx, d_sc, d_do, skip_empty, commit);
+        }
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_idx);
+    return e;
+}
+
 int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, int64_t n, int64_t* out_scores,
                          int32_t* out_doable) {
     DeviceGuard _dev(ctx);
@@ -930,6 +958,18 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     if (ctx->has_scalar_model)
         hipLaunchKernelGGL(k_scalar_evaluate_moves, dim3(grid), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, d_moves, n, d_sc, d_do, mixed);
     hipError_t e = hipGetLastError();
+    if (e == hipSuccess && ctx->has_list_model) {  // list ruin moves: scored by their own kernel, one wavefront per move
+        std::vector<int32_t> which;
+        for (int64_t i = 0; i < n; ++i)
+            if (moves[i].kind == SF_MOVE_LIST_RUIN) which.push_back((int32_t)i);
+        if (!which.empty()) {
+            if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || RuinMoveCarve(ctx->lm.V, ctx->lm.n_cap).total > SF_LDS_BUDGET) {
+                release();
+                return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin moves: the list class must fit one wave's LDS slice with 16-bit elements");
+            }
+            e = launch_ruin_moves(ctx, replica, d_moves, which, d_sc, d_do, 0);
+        }
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1025,8 +1065,28 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
     int rc = alloc_search(ctx);
     if (rc) return rc;
-    if (mv->kind == SF_MOVE_LIST_RUIN)
-        return fail(ctx, SF_ERR_UNSUPPORTED, "a list ruin is scored and committed inside the fused step (sf_solve_steps / sf_solve_step_traced)");
+    if (mv->kind == SF_MOVE_LIST_RUIN) {  // committed ruin + recreate: its own kernel (one wavefront)
+        if (!ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
+        if (ctx->has_scalar_model) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_apply of a list ruin on a mixed model");
+        if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || RuinMoveCarve(ctx->lm.V, ctx->lm.n_cap).total > SF_LDS_BUDGET)
+            return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin moves: the list class must fit one wave's LDS slice with 16-bit elements");
+        int32_t* d_mv = nullptr;
+        int64_t* d_sc = nullptr;
+        int32_t* d_do = nullptr;
+        hipError_t e = hipMalloc((void**)&d_mv, 24);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_sc, 4 * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_do, 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_mv, mv, 24, hipMemcpyHostToDevice, ctx->stream);
+        int32_t ok = 0;
+        if (e == hipSuccess) e = launch_ruin_moves(ctx, replica, d_mv, std::vector<int32_t>{0}, d_sc, d_do, 1);
+        if (e == hipSuccess) e = hipMemcpy(&ok, d_do, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d_mv);
+        (void)hipFree(d_sc);
+        (void)hipFree(d_do);
+        if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+        if (!ok) return fail(ctx, SF_ERR_INVALID, "move is not doable");
+        return SF_OK;
+    }
     const bool list_move = mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_KOPT;
     if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
     if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");

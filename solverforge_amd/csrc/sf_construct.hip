@@ -132,4 +132,98 @@ __global__ __launch_bounds__(64) void k_list_construct_cheapest(ListModel lm, co
     }
 }
 
+// Host-provided list ruin moves (SF_MOVE_LIST_RUIN through sf_step_evaluate / sf_apply): one wavefront per move, the replica's
+// lists copied into LDS, the same recreate the fused step runs (general matrix-gather path).  move t of the batch = moves[idx[t]].
+// doable = ruin_is_doable without an owner binding (move/list_kernel/ruin.rs:97-113) with the wire format's ascending, distinct
+// positions.  commit: the recreate is kept, lists + load + committed score written back (grid = 1).
+struct RuinMoveCarve {
+    size_t visits, off, load, sbase, cand, work, score, total;
+    __host__ __device__ RuinMoveCarve(int V, int n_cap) {
+        size_t o = 0;
+        load = o;
+        o = align_up(o + sizeof(int64_t) * V, 16);
+        score = o;
+        o = align_up(o + sizeof(int64_t) * 4, 16);
+        off = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        sbase = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        visits = o;
+        o = align_up(o + sizeof(uint16_t) * n_cap, 16);
+        cand = o;
+        o = align_up(o + 16, 16);
+        work = o;
+        o = align_up(o + 128, 16);
+        total = o;
+    }
+};
+template <int L>
+__global__ __launch_bounds__(64) void k_list_ruin_moves(ListModel lm, int replica, const int32_t* __restrict__ moves, const int32_t* __restrict__ idx,
+                                                        int64_t* out_scores, int32_t* out_doable, int skip_empty, int commit) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int V = lm.V;
+    const RuinMoveCarve cv(V, lm.n_cap);
+    uint16_t* visits = (uint16_t*)(smem + cv.visits);
+    uint32_t* off = (uint32_t*)(smem + cv.off);
+    int64_t* load = (int64_t*)(smem + cv.load);
+    uint32_t* sbase = (uint32_t*)(smem + cv.sbase);
+    uint16_t* cand = (uint16_t*)(smem + cv.cand);
+    uint16_t* work = (uint16_t*)(smem + cv.work);
+    int64_t* sc = (int64_t*)(smem + cv.score);
+    uint32_t* g_visits = lm.visits + (size_t)replica * lm.n_cap;
+    uint32_t* g_off = lm.off + (size_t)replica * (V + 1);
+    int64_t* g_load = lm.load + (size_t)replica * V;
+    const int64_t t = idx[blockIdx.x];
+    const int32_t* mv = moves + t * 6;
+    for (uint32_t q = lane; q <= (uint32_t)V; q += 64) off[q] = g_off[q];
+    for (uint32_t q = lane; q < (uint32_t)V; q += 64) load[q] = g_load[q];
+    wave_sync();
+    const uint32_t tot = uni(off[V]);
+    for (uint32_t q = lane; q < tot; q += 64) visits[q] = (uint16_t)g_visits[q];
+    const int32_t a = mv[1], cnt = mv[2];
+    bool ok = a >= 0 && a < V && cnt >= 1 && cnt <= (int32_t)RUIN_MAX_COUNT;
+    const uint32_t w3[3] = {(uint32_t)mv[3], (uint32_t)mv[4], (uint32_t)mv[5]};
+    uint32_t pos[RUIN_MAX_COUNT];
+#pragma unroll
+    for (int i = 0; i < (int)RUIN_MAX_COUNT; ++i) pos[i] = (w3[i / 2] >> (16 * (i & 1))) & 0xFFFFu;
+    if (ok) {
+        const uint32_t len = uni(off[a + 1]) - uni(off[a]);
+#pragma unroll
+        for (int i = 0; i < (int)RUIN_MAX_COUNT; ++i)
+            if (i < cnt) ok = ok && pos[i] < len && (i == 0 || pos[i] > pos[i - 1]);
+    }
+    if (lane == 0) {
+        cand[0] = (uint16_t)a;
+        cand[1] = (uint16_t)cnt;
+#pragma unroll
+        for (int i = 0; i < (int)RUIN_MAX_COUNT; ++i) cand[2 + i] = (uint16_t)pos[i];
+    }
+    wave_sync();
+    if (!ok) {
+        if (lane == 0) {
+            out_doable[t] = 0;
+            for (int k = 0; k < lm.levels; ++k) out_scores[t * lm.levels + k] = 0;
+        }
+        return;
+    }
+    int64_t cur[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) cur[k] = lm.score[(size_t)replica * 4 + k];
+    ruin_recreate<L>(lm, visits, off, load, cand, work, sbase, RuinFast{nullptr, nullptr, nullptr, nullptr}, skip_empty, commit != 0, cur, sc);
+    wave_sync();
+    if (lane == 0) {
+        out_doable[t] = 1;
+        for (int k = 0; k < lm.levels; ++k) out_scores[t * lm.levels + k] = k < L ? sc[k] : 0;
+    }
+    if (commit) {
+        const uint32_t tot2 = uni(off[V]);
+        for (uint32_t q = lane; q < tot2; q += 64) g_visits[q] = visits[q];
+        for (uint32_t q = lane; q <= (uint32_t)V; q += 64) g_off[q] = off[q];
+        for (uint32_t q = lane; q < (uint32_t)V; q += 64) g_load[q] = load[q];
+        if (lane == 0)
+            for (int k = 0; k < L; ++k) lm.score[(size_t)replica * 4 + k] = sc[k];
+    }
+}
+
 }  // namespace sf

@@ -178,6 +178,39 @@ def test_ruin_step_generate_is_a_dry_run(oracle):
     _check_steps(d, o2, 5)
 
 
+@pytest.mark.parametrize("problem", ["plain", "tight", "asym", "ragged"])
+def test_ruin_moves_through_step_evaluate_and_apply(oracle, problem):
+    """Host-provided SF_MOVE_LIST_RUIN records (the MoveSelector plugin surface): sf_step_evaluate scores them one wavefront
+    each, also inside a batch with other move kinds; sf_apply commits one; not-doable records are reported."""
+    import solverforge_amd as sfa
+
+    p = _problem(problem)
+    d, o = _mk(oracle, p, ("nearby_change", "ruin"), seed=6, la_size=5, limit=8)
+    d.calculate_score()
+    rng = np.random.default_rng(8)
+    for it in range(6):
+        ruins = o.enumerate(1024, it, 11 + it, 3)  # ten ruin candidates of the oracle's stream
+        others = o.enumerate(16, it, 11 + it, 3)[:40]
+        batch = np.concatenate([ruins[:5], others, ruins[5:]])
+        bad = ruins[:3].copy()
+        bad["a_pos"][0] = 0  # no element
+        bad["b"][1] = 0xFFFF  # position out of range
+        bad["a"][2] = 999  # no such list
+        batch = np.concatenate([batch, bad])
+        gs, gd = d.evaluate_moves(batch)
+        os_, od = o.evaluate_moves(batch)
+        assert (gd == od).all(), it
+        assert (gs == os_[:, :2]).all(), it
+        mv = ruins[int(rng.integers(len(ruins)))]
+        d.apply_move(mv)
+        o.apply_move(mv)
+        assert d.working_lists(0, 0) == o.get_lists(0), it
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
+    with pytest.raises(sfa.SolverForgeError):
+        d.apply_move(bad[0])
+
+
 def test_ruin_selector_validation():
     import solverforge_amd as sfa
     from solverforge_amd import datasets
