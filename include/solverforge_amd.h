@@ -244,6 +244,13 @@ int32_t sf_schema_add_entity_class(sf_ctx* ctx, int32_t descriptor_index, int32_
 int32_t sf_schema_add_scalar_variable(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index,
                                       int32_t n_values, int32_t allows_unassigned,
                                       const int32_t* initial);
+/* ValueSource::EntitySlice (crates/solverforge-solver/src/builder/context/scalar/variable.rs:138-151; ValueSelector::iter,
+ * heuristic/selector/value_selector.rs:21-41): the canonical value list of EVERY entity of a declared scalar variable as CSR --
+ * offsets[n_rows + 1], values[offsets[n_rows]], each value in 0..n_values.  The change stream draws from the entity's list, a
+ * swap needs each value in the other row's list (cursor/swap.rs:103-123), a compound edit's value must be in its entity's list.
+ * Without this call every entity has the countable range 0..n_values. */
+int32_t sf_schema_set_value_lists(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, const uint32_t* offsets,
+                                  const int32_t* values);
 /* list planning variable as CSR: offsets[n_rows+1], values[offsets[n_rows]];
  * `element_capacity` = max total elements (element ids < element_id_bound) */
 int32_t sf_schema_add_list_variable(sf_ctx* ctx, int32_t descriptor_index,

@@ -86,6 +86,7 @@ def lib():
             "sfo_small_rng_seed": (None, [u64, vp]),
             "sfo_model_set_step_seeds": (None, [vp, vp, i32]),
             "sfo_model_set_union_weights": (None, [vp, vp, i32]),
+            "sfo_model_set_value_lists": (None, [vp, vp, vp, i32]),
             "sfo_model_set_ruin": (None, [vp, i32, i32, i32, i32, i32, C.c_char_p]),
             "sfo_scoped_seed": (u64, [u64, u64, C.c_char_p, C.c_char_p]),
             "sfo_hash_str": (u64, [C.c_char_p]),
@@ -264,6 +265,14 @@ class Model:
         """List ruin leaf parameters (ListRuinMoveSelectorConfig defaults); call after configure(): re-seeds the leaf's stream."""
         lib().sfo_model_set_ruin(self.h, min_count, max_count, moves_per_step, max_source_list_len, int(skip_empty_destinations),
                                  variable_name.encode())
+
+    def set_value_lists(self, lists):
+        """ValueSource::EntitySlice for the scalar slot."""
+        off = np.zeros(len(lists) + 1, dtype=np.uint32)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + len(l)
+        vals = np.array([v for l in lists for v in l] or [0], dtype=np.int64)
+        lib().sfo_model_set_value_lists(self.h, _p(off), _p(vals), len(lists))
 
     def set_union_weights(self, weights):
         w = np.ascontiguousarray(weights, dtype=np.uint64)

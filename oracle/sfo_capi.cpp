@@ -266,6 +266,15 @@ void sfo_random_range_stream(uint64_t seed, uint64_t low, uint64_t high_inclusiv
 void sfo_model_set_union_weights(void* h, const uint64_t* weights, int32_t n) {
     ((Model*)h)->union_weights.assign(weights, weights + n);
 }
+// ValueSource::EntitySlice for the scalar slot: entity e draws from values[off[e] .. off[e + 1])
+void sfo_model_set_value_lists(void* h, const uint32_t* off, const int64_t* values, int32_t n) {
+    Model* m = (Model*)h;
+    auto o = std::make_shared<std::vector<uint32_t>>(off, off + n + 1);
+    auto v = std::make_shared<std::vector<int64_t>>(values, values + off[n]);
+    m->scalar_slot.values_for_entity = [o, v](const Solution&, size_t e, std::vector<int64_t>& out) {
+        out.assign(v->begin() + (*o)[e], v->begin() + (*o)[e + 1]);
+    };
+}
 void sfo_model_set_step_seeds(void* h, const uint64_t* seeds, int32_t n) {
     ((Model*)h)->search.explicit_step_seeds.assign(seeds, seeds + n);
 }

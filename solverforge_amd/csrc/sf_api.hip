@@ -51,6 +51,8 @@ struct ClassSpec {
     bool has_scalar = false;
     int var_index = 0, n_values = 0, allows_unassigned = 0;
     std::vector<int32_t> scalar_init;
+    std::vector<uint32_t> value_off;  // ValueSource::EntitySlice: per-entity value lists (empty = the range 0..n_values)
+    std::vector<int32_t> value_list;
     bool has_list = false;
     std::vector<uint32_t> list_off, list_vals;
     int element_capacity = 0, element_bound = 0;
@@ -251,6 +253,25 @@ int32_t sf_schema_add_scalar_variable(sf_ctx* ctx, int32_t d, int32_t var, int32
     c.n_values = n_values;
     c.allows_unassigned = allows_unassigned;
     c.scalar_init.assign(initial, initial + c.n_rows);
+    return SF_OK;
+}
+
+// ValueSource::EntitySlice: the value list of every entity of a scalar variable
+int32_t sf_schema_set_value_lists(sf_ctx* ctx, int32_t d, int32_t var, const uint32_t* offsets, const int32_t* values) {
+    if (!ctx || !ctx->classes.count(d) || !offsets) return fail(ctx, SF_ERR_INVALID, "bad value lists");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "schema is frozen after sf_initialize");
+    ClassSpec& c = ctx->classes[d];
+    if (!c.has_scalar || c.var_index != var) return fail(ctx, SF_ERR_INVALID, "value lists need the scalar variable declared first");
+    if (offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "value list offsets must start at 0");
+    for (int i = 0; i < c.n_rows; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SF_ERR_INVALID, "value list offsets must not decrease");
+    const uint32_t total = offsets[c.n_rows];
+    if (total > 0 && !values) return fail(ctx, SF_ERR_INVALID, "value lists: values is NULL");
+    for (uint32_t k = 0; k < total; ++k)
+        if (values[k] < 0 || values[k] >= c.n_values) return fail(ctx, SF_ERR_INVALID, "value list entry outside 0..n_values");
+    c.value_off.assign(offsets, offsets + c.n_rows + 1);
+    c.value_list.assign(values, values + total);
+    if (c.value_list.empty()) c.value_list.push_back(0);  // keep the upload non-empty
     return SF_OK;
 }
 

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         }
                         uint32_t my_row = g.a, my_in = g.b + lane;
                         const uint32_t e0 = (uint32_t)(((uint64_t)sc_st + (uint64_t)my_row * sc_sd) % ns);
-                        uint32_t per = vc + ((sm.allows_unassigned && (int32_t)s_vals[e0] >= 0) ? 1u : 0u);
+                        uint32_t per = value_count(sm, e0) + ((sm.allows_unassigned && (int32_t)s_vals[e0] >= 0) ? 1u : 0u);
                         bool valid = true;
                         for (;;) {
                             if (my_row >= ns) {
@@ -511,13 +511,13 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             ++my_row;
                             if (my_row < ns) {
                                 const uint32_t e2 = (uint32_t)(((uint64_t)sc_st + (uint64_t)my_row * sc_sd) % ns);
-                                per = vc + ((sm.allows_unassigned && (int32_t)s_vals[e2] >= 0) ? 1u : 0u);
+                                per = value_count(sm, e2) + ((sm.allows_unassigned && (int32_t)s_vals[e2] >= 0) ? 1u : 0u);
                             }
                         }
                         if (valid) {
                             w0 = (uint32_t)(((uint64_t)sc_st + (uint64_t)my_row * sc_sd) % ns);
                             int32_t v = -1;
-                            if (my_in < vc) v = (int32_t)ctx.selection_index_fm(my_in, fm_vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)w0 ^ identity);
+                            if (my_in < value_count(sm, w0)) v = value_at(sm, ctx, w0, my_in, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)w0 ^ identity, fm_vc);
                             w1 = (uint32_t)v;
                         }
                         keep = valid;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                                            : ctx.selection_index_fm(ro, fm_n, (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)sm.variable) ^ OFFSET_MIX);
                             if (left < right) {
                                 const int32_t lv = (int32_t)s_vals[left], rv = (int32_t)s_vals[right];
-                                keep = lv != rv && (lv >= 0 || sm.allows_unassigned) && (rv >= 0 || sm.allows_unassigned);
+                                keep = lv != rv && value_legal(sm, right, lv) && value_legal(sm, left, rv);
                             }
                             w0 = left;
                             w1 = right;

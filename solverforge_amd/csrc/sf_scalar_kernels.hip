@@ -62,6 +62,10 @@ struct ScalarModel {
     int32_t ex_level = -1, ex_mode = 1;  // 1: scored while some entity holds the value, 0: while none does
     int64_t ex_weight = 0;
     const int32_t* ex_w = nullptr;     // [n_values] per-row weight (null = 1)
+    // ValueSource::EntitySlice (builder/context/scalar/variable.rs:138-151): per-entity value lists as CSR, null = the countable
+    // range 0..n_values for every entity
+    const uint32_t* vl_off = nullptr;  // [n + 1]
+    const int32_t* vl = nullptr;       // values, each in 0..n_values
     __host__ __device__ bool tables() const { return sj_level >= 0 || grp_level >= 0 || ex_level >= 0; }
     // per-replica committed state
     int32_t* vals = nullptr;        // [R][n]  (-1 = None)
@@ -69,6 +73,25 @@ struct ScalarModel {
     int32_t* best_vals = nullptr;   // [R][n]
     int64_t* best_score = nullptr;  // [R][4]
 };
+
+// the canonical value list of entity e (ValueSelector::iter, heuristic/selector/value_selector.rs:21-41)
+__device__ __forceinline__ uint32_t value_count(const ScalarModel& m, uint32_t e) {
+    return m.vl_off ? m.vl_off[e + 1] - m.vl_off[e] : (uint32_t)m.n_values;
+}
+// value at stream offset `off` of entity e's list (selection_index over the list, cursor/change.rs:91-104)
+__device__ __forceinline__ int32_t value_at(const ScalarModel& m, const StreamCtx& ctx, uint32_t e, uint32_t off, uint64_t salt, const FastMod& fm_vc) {
+    if (!m.vl_off) return (int32_t)ctx.selection_index_fm(off, fm_vc, salt);
+    const uint32_t b = m.vl_off[e];
+    return m.vl[b + ctx.selection_index(off, m.vl_off[e + 1] - b, salt)];
+}
+// destination_is_legal (cursor/swap.rs:103-123): None needs allows_unassigned, a value must be in the row's list
+__device__ __forceinline__ bool value_legal(const ScalarModel& m, uint32_t e, int32_t v) {
+    if (v < 0) return m.allows_unassigned != 0;
+    if (!m.vl_off) return true;
+    for (uint32_t p = m.vl_off[e]; p < m.vl_off[e + 1]; ++p)
+        if (m.vl[p] == v) return true;
+    return false;
+}
 
 // matches of entity e against every partner except `skip`, for two candidate values at once:
 // returns conflicts(e, v_new) - conflicts(e, v_old) in ONE pass over the partner list, sixteen
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_compound(ScalarModel m,
     bool legal = e > b && e - b <= SF_COMPOUND_MAX, changes = false;
     for (int64_t k = b; k < e && legal; ++k) {
         const int32_t* mv = edits + k * 6;
-        legal = mv[0] == 0 && mv[1] >= 0 && mv[1] < m.n && mv[5] >= -1 && mv[5] < m.n_values && (mv[5] >= 0 || m.allows_unassigned);
+        legal = mv[0] == 0 && mv[1] >= 0 && mv[1] < m.n && mv[5] >= -1 && mv[5] < m.n_values && value_legal(m, (uint32_t)mv[1], mv[5]);
         if (legal) changes = changes || vals[mv[1]] != mv[5];
     }
     const bool doable = legal && changes;
@@ -454,7 +477,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
     bool legal = n_edits > 0, changes = false;
     for (int k = 0; k < n_edits && legal; ++k) {
         const int32_t* mv = edits + k * 6;
-        legal = mv[0] == 0 && mv[1] >= 0 && mv[1] < m.n && mv[5] >= -1 && mv[5] < m.n_values && (mv[5] >= 0 || m.allows_unassigned);
+        legal = mv[0] == 0 && mv[1] >= 0 && mv[1] < m.n && mv[5] >= -1 && mv[5] < m.n_values && value_legal(m, (uint32_t)mv[1], mv[5]);
         if (legal) changes = changes || vals[mv[1]] != mv[5];
     }
     if (!legal || !changes) {
@@ -880,7 +903,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                         // 64 consecutive (row, value-offset) slots of the change stream, one per lane
                         const uint32_t e_row = fastmod_u64((uint64_t)cst + (uint64_t)row[l] * csd, fm_n);
                         const bool has_none = m.allows_unassigned && (int32_t)s_vals[e_row] >= 0;
-                        const uint32_t per0 = vc + (has_none ? 1u : 0u);  // candidates of the current row
+                        const uint32_t per0 = value_count(m, e_row) + (has_none ? 1u : 0u);  // candidates of the current row
                         // lanes walk rows starting at (row, inner): rows have vc or vc+1 candidates
                         uint32_t my_row = row[l], my_in = inner[l] + lane;
                         uint32_t per = per0;
@@ -895,14 +918,14 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                             ++my_row;
                             if (my_row < n) {
                                 const uint32_t e2 = fastmod_u64((uint64_t)cst + (uint64_t)my_row * csd, fm_n);
-                                per = vc + ((m.allows_unassigned && (int32_t)s_vals[e2] >= 0) ? 1u : 0u);
+                                per = value_count(m, e2) + ((m.allows_unassigned && (int32_t)s_vals[e2] >= 0) ? 1u : 0u);
                             }
                         }
                         uint32_t e = 0;
                         int32_t v = -1;
                         if (valid) {
                             e = fastmod_u64((uint64_t)cst + (uint64_t)my_row * csd, fm_n);
-                            if (my_in < vc) v = (int32_t)ctx.selection_index_fm(my_in, fm_vc, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)e ^ identity);
+                            if (my_in < value_count(m, e)) v = value_at(m, ctx, e, my_in, SALT_SCALAR_CHANGE_VALUE ^ (uint64_t)e ^ identity, fm_vc);
                         }
                         const uint64_t vm = __ballot(valid);
                         const uint32_t cnt = (uint32_t)__popcll(vm);  // valid lanes are a prefix
@@ -933,7 +956,6 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                         }
                         const uint32_t left = n <= 1 ? 0u : fastmod_u64((uint64_t)lst + (uint64_t)row[l] * lsd, fm_n);
                         const int32_t lv = (int32_t)s_vals[left];
-                        const bool l_legal = lv >= 0 || m.allows_unassigned;
                         const uint64_t rsalt = (SALT_SCALAR_SWAP_RIGHT ^ (uint64_t)left ^ (uint64_t)(uint32_t)m.variable) ^ OFFSET_MIX;
                         bool keep[4];
                         uint32_t right[4];
@@ -946,7 +968,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
                                 right[q] = n <= 1 ? 0u : ctx.selection_index_fm(ro, fm_n, rsalt);
                                 if (left < right[q]) {
                                     const int32_t rv = (int32_t)s_vals[right[q]];
-                                    keep[q] = lv != rv && l_legal && (rv >= 0 || m.allows_unassigned);
+                                    keep[q] = lv != rv && value_legal(m, right[q], lv) && value_legal(m, left, rv);
                                 }
                             }
                         }

@@ -114,6 +114,14 @@ class GpuScoreDirector:
         check(self._L.sf_schema_add_scalar_variable(self._h, descriptor_index, variable_index, n_values,
                                                     int(allows_unassigned), ptr(initial)), self._h)
 
+    def set_value_lists(self, descriptor_index, variable_index, lists):
+        """ValueSource::EntitySlice: `lists[e]` = the canonical value list of entity e (values in 0..n_values)."""
+        off = np.zeros(len(lists) + 1, dtype=np.uint32)
+        for i, l in enumerate(lists):
+            off[i + 1] = off[i] + len(l)
+        vals = np.array([v for l in lists for v in l] or [0], dtype=np.int32)
+        check(self._L.sf_schema_set_value_lists(self._h, descriptor_index, variable_index, ptr(off), ptr(vals)), self._h)
+
     def add_list_variable(self, descriptor_index, lists, element_capacity, element_id_bound):
         off = np.zeros(len(lists) + 1, dtype=np.uint32)
         for i, l in enumerate(lists):
