@@ -1,0 +1,20 @@
+#!/bin/bash
+# rocprofv3 kernel trace + PMC passes of the generic engine on the SEVEN-leaf default list policy (ruin on), CVRP-1000.
+# Usage (via gpurun): bash scripts/pmc_generic_ruin.sh <tag>   -> gpurun_out/<tag>/generic_ruin_pmc.json, kernel stats
+tag=${1:-rXX}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$tag/gruin
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+U=nearby_change,nearby_swap,sublist_change,sublist_swap,list_reverse,kopt,ruin
+timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $O/trace -o ruin -- python $R/scripts/union_probe.py 1280 50 2 $U > $O/probe.json 2> $O/trace_err.log
+i=0
+for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $grp -f csv -d $O/pmc_$i -- python $R/scripts/union_probe.py 1280 50 2 $U > /dev/null 2> $O/err_$i.log
+done
+python $R/scripts/pmc_dump.py $O k_mixed_search_wave > $R/gpurun_out/$tag/generic_ruin_pmc.json
+cp $O/trace/*kernel_stats.csv $R/gpurun_out/$tag/generic_ruin_kernel_stats.csv 2>/dev/null || find $O/trace -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/$tag/generic_ruin_kernel_stats.csv \;
+cat $O/probe.json | tail -1 | cut -c1-300
+python -c "
+import json; d=json.load(open('$R/gpurun_out/$tag/generic_ruin_pmc.json')); print({k:(round(v['mean']) if isinstance(v,dict) else v) for k,v in d.items()})"

@@ -460,18 +460,32 @@ __device__ __forceinline__ void ruin_scan_element_fast(const RuinModel& lm, cons
     }
 }
 
+#ifndef SF_RUIN_SMALL_U
+#define SF_RUIN_SMALL_U 4  // slots per lane in flight in the 32-bit scan
+#endif
 // The same scan in 32-bit arithmetic, for models whose every trial delta provably fits (ListModel::small32: all legs finite and
 // < 2^26, small weights / loads -- the bounds of the wave engine's delta-space replay): a lane keeps its best as per-level
-// DELTAS against the round's base score, which order exactly like the full scores do.
+// DELTAS against the round's base score, which order exactly like the full scores do.  Branch-free: the PMC profile of the first
+// version showed ~137 VALU instructions per slot, most of them control flow around the per-level compare and the update.
+// A lane visits its slots in increasing (element, slot number) order and slot numbers order like (list, position), so inside a
+// lane a tie never replaces the running best: the update is "strictly better" only, and the key (element << 32 | slot number)
+// is needed by the cross-lane reduction alone.  The winner's (list, position) is decoded from its slot number afterwards.
 template <int L>
 __device__ __forceinline__ void ruin_scan_element_small(const RuinModel& lm, const lds_u16* visits, const lds_u32* off, const lds_i64* load,
                                                         const lds_u32* sbase, const RuinFastLds& rf, uint32_t ri, int32_t dx, uint32_t ent,
                                                         int32_t parked_dem, int32_t (&bdv)[L], uint64_t& bkey, bool& has, RuinPick& pick) {
-    constexpr int U = 8;
+    constexpr int U = SF_RUIN_SMALL_U;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t V = (uint32_t)lm.V, depot = (uint32_t)lm.depot;
     const bool has_cap = lm.cap_level >= 0 && lm.demand != nullptr;
-    const int32_t cap32 = (int32_t)lm.capacity, cw = (int32_t)lm.cap_weight, dw = (int32_t)lm.dist_weight;
+    const int32_t cap32 = (int32_t)lm.capacity;
+    int32_t ca[L], cb[L];  // per-level coefficients: delta[k] = ca[k] * (capacity overshoot delta) + cb[k] * (distance delta)
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        ca[k] = (has_cap && k == lm.cap_level) ? -(int32_t)lm.cap_weight : 0;
+        cb[k] = k == lm.dist_level ? -(int32_t)lm.dist_weight : 0;
+    }
+    const lds_u32* load32 = (const lds_u32*)load;  // low words of the i64 loads (small32: loads < 2^28)
     const uint32_t total = uni(sbase[V]);
     for (uint32_t t0 = 0; t0 < total; t0 += 64u * U) {
         uint32_t tt[U], e[U], b0[U], b1[U], ob[U];
@@ -489,48 +503,50 @@ __device__ __forceinline__ void ruin_scan_element_small(const RuinModel& lm, con
             b1[u] = sbase[e[u] + 1];
             ob[u] = off[e[u]];
         }
-        uint32_t o[U], pv[U], nx[U];
+        uint32_t pvr[U], nxr[U], o[U];
         int32_t ld[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             o[u] = tt[u] - b0[u];
-            const uint32_t le = b1[u] - b0[u] - 1u;
-            pv[u] = o[u] > 0 ? (uint32_t)visits[ob[u] + o[u] - 1] : depot;
-            nx[u] = o[u] < le ? (uint32_t)visits[ob[u] + o[u]] : 0xFFFFFFFFu;
-            ld[u] = has_cap ? (int32_t)load[e[u]] : 0;
+            const uint32_t ip = ob[u] + o[u];
+            pvr[u] = visits[ip - (o[u] > 0 ? 1u : 0u)];  // read unconditionally (a stale word past a list is discarded below)
+            nxr[u] = visits[ip];
+            ld[u] = has_cap ? (int32_t)load32[2u * e[u]] : 0;
         }
-        uint32_t da[U], db[U], d0[U];
+        uint32_t da[U], db[U], d0[U], nxe[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            da[u] = rf.row[pv[u]];
-            db[u] = rf.row[nx[u] != 0xFFFFFFFFu ? nx[u] : depot];
-            d0[u] = nx[u] != 0xFFFFFFFFu ? (uint32_t)rf.edge[nx[u]] : (uint32_t)rf.edge_end[e[u]];
+            const bool at_end = o[u] + 1u >= b1[u] - b0[u];  // o == logical length
+            const uint32_t pv = o[u] > 0 ? pvr[u] : depot;
+            nxe[u] = at_end ? 0xFFFFu : nxr[u];
+            da[u] = rf.row[pv];
+            db[u] = rf.row[at_end ? depot : nxr[u]];
+            const lds_u16* dp = at_end ? rf.edge_end + e[u] : rf.edge + nxr[u];  // an empty list's edge_end is 0
+            d0[u] = *dp;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int32_t dd = (int32_t)da[u] + (int32_t)db[u] - (int32_t)d0[u];
-            int32_t dc = 0;
-            if (has_cap) {
-                const int32_t l0 = e[u] == ent ? ld[u] - parked_dem : ld[u];
-                const int32_t over1 = l0 + dx - cap32, over0 = l0 - cap32;
-                dc = (over1 > 0 ? over1 : 0) - (over0 > 0 ? over0 : 0);
-            }
+            const int32_t l0 = ld[u] - (e[u] == ent ? parked_dem : 0);
+            const int32_t over1 = l0 + dx - cap32, over0 = l0 - cap32;
+            const int32_t dc = (over1 > 0 ? over1 : 0) - (over0 > 0 ? over0 : 0);
             int32_t dv[L];
-            int cmp = 0;
+            bool gt = false, eq = true;
 #pragma unroll
             for (int k = 0; k < L; ++k) {
-                dv[k] = (k == lm.cap_level ? -cw * dc : 0) + (k == lm.dist_level ? -dw * dd : 0);
-                if (cmp == 0) cmp = dv[k] > bdv[k] ? 1 : (dv[k] < bdv[k] ? -1 : 0);
+                dv[k] = ca[k] * dc + cb[k] * dd;
+                gt = gt || (eq && dv[k] > bdv[k]);
+                eq = eq && dv[k] == bdv[k];
             }
-            const uint32_t key32 = (e[u] << 16) | o[u];
-            // an equal score of an earlier element (smaller ri) stays; inside one element the earlier (list, position) wins
-            if (valid[u] && (!has || cmp > 0 || (cmp == 0 && (uint32_t)(bkey >> 32) == ri && key32 < (uint32_t)bkey))) {
+            const bool take = valid[u] && (!has || gt);
 #pragma unroll
-                for (int k = 0; k < L; ++k) bdv[k] = dv[k];
-                bkey = ((uint64_t)ri << 32) | (uint64_t)key32;
-                has = true;
-                pick = RuinPick{da[u], db[u], d0[u], nx[u]};
-            }
+            for (int k = 0; k < L; ++k) bdv[k] = take ? dv[k] : bdv[k];
+            bkey = take ? (((uint64_t)ri << 32) | (uint64_t)tt[u]) : bkey;
+            pick.da = take ? da[u] : pick.da;
+            pick.db = take ? db[u] : pick.db;
+            pick.d0 = take ? d0[u] : pick.d0;
+            pick.next = take ? (nxe[u] == 0xFFFFu ? 0xFFFFFFFFu : nxe[u]) : pick.next;
+            has = has || take;
         }
     }
 }
@@ -793,7 +809,13 @@ __device__ SF_RUIN_ATTR void ruin_recreate_lds(const RuinModel lm_in, lds_u16* v
         const ScoreV<L> M = wave_max_score<L>(bs, has);
         const bool at_max = has && score_cmp<L>(bs, M) == 0;
         const uint64_t kmin = uni64(ruin_wave_min_u64(at_max ? bkey : ~0ull));
-        const uint32_t ri = (uint32_t)(kmin >> 32), be = (uint32_t)(kmin >> 16) & 0xFFFFu, bp = (uint32_t)kmin & 0xFFFFu;
+        const uint32_t ri = (uint32_t)(kmin >> 32);
+        uint32_t be = (uint32_t)(kmin >> 16) & 0xFFFFu, bp = (uint32_t)kmin & 0xFFFFu;
+        if (fast == 2) {  // the 32-bit scan keys its slots by slot number: decode (list, position)
+            const uint32_t tw = (uint32_t)kmin;
+            be = uni((uint32_t)rf.slot[tw]);
+            bp = tw - uni(sbase[be]);
+        }
         const uint32_t x = uni((uint32_t)rem[ri]);
         const int win = __ffsll((unsigned long long)__ballot(at_max && bkey == kmin)) - 1;
         const uint32_t w_da = uni((uint32_t)__shfl((int)pick.da, win)), w_db = uni((uint32_t)__shfl((int)pick.db, win));
