@@ -130,7 +130,10 @@ typedef enum sf_constraint_kind {
      * count each group, score -round(weight * population standard deviation of the counts) on `level` -- a GLOBAL statistic;
      * f64 in the reference's operation order, Score::multiply rounding (score/macros.rs:61-63).  `weight` = the base score of one
      * unit of standard deviation */
-    SF_C_BALANCE_VALUE = 13
+    SF_C_BALANCE_VALUE = 13,
+    /* ListPrecedenceMakespanConstraint (crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707); declared through
+     * sf_constraint_add_list_precedence, listed here for its place in the sf_evaluate_each order */
+    SF_C_LIST_PRECEDENCE_MAKESPAN = 14
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {
@@ -267,6 +270,18 @@ int32_t sf_fact_csr_u32(sf_ctx* ctx, int32_t fact_id, int32_t n_rows, const uint
 /* weight is added to score level `level` as a penalty (ImpactType::Penalty). */
 int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int32_t variable_index,
                           int32_t fact_a, int64_t param, int32_t level, int64_t weight);
+/* ListPrecedenceMakespanConstraint::new(...).with_expected_owner(...) (crates/solverforge-scoring/src/constraint/list_precedence.rs:
+ * 29-59) on the list variable of `descriptor_index`, its hooks as data: node_count nodes = list element ids, durations[node_count]
+ * (node_duration), the fixed successor relation as CSR (fixed_successors; successors >= node_count count as invalid fixed edges),
+ * expected_owner[node_count] (-1 = no expectation) or NULL for no hook.  Score: -(invalid fixed edges + wrong-owner items +
+ * unassigned nodes + node_count if the graph of fixed + consecutive-list-item edges is cyclic) on `hard_level`, -(longest
+ * duration-weighted path, 0 when cyclic) on `makespan_level` (the reference fixes HardSoftScore::of(-penalty, -makespan)).
+ * Every trial is one full evaluation of the trial lists (Kahn over the whole graph by one wavefront); the search runs in the
+ * generic N-leaf engine.  Limits: element ids < node_count, every element in at most one list position, sum of durations < 2^31,
+ * no ruin leaf / cheapest-insertion construction (the reference's "precedence hooks" restriction). */
+int32_t sf_constraint_add_list_precedence(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t node_count,
+                                          const int32_t* durations, const uint32_t* succ_offsets, const uint32_t* succ_values,
+                                          const int32_t* expected_owner, int32_t hard_level, int32_t makespan_level);
 /* leaves are unioned in default-policy declaration order; >1 leaf => StratifiedRandom with equal
  * weights, 1 leaf => Sequential (default_local_search/policy.rs:104-108).
  * `fact_meter` = i64 matrix for MatrixDistanceMeter (crates/solverforge-cvrp/src/meters.rs:10-28). */

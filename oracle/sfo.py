@@ -72,6 +72,7 @@ def lib():
             "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
             "sfo_assignment_create": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
+            "sfo_precedence_shop_create": (vp, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
             "sfo_model_destroy": (None, [vp]),
             "sfo_model_score": (None, [vp, vp]),
@@ -198,6 +199,17 @@ class Model:
         off, vals = csr(routes)
         h = lib().sfo_list_toy_create(len(routes), _p(off), _p(vals), 0 if meter == "equal" else 1)
         return Model(h, [len(routes)])
+
+    @staticmethod
+    def precedence_shop(duration, successors, lists, expected_owner=None, levels=2, hard_levels=1, hard_level=0, soft_level=1):
+        """ListPrecedenceMakespanConstraint on a list-only model: `successors` = fixed successor lists per node."""
+        duration = np.ascontiguousarray(duration, dtype=np.int64)
+        soff, svals = csr(successors)
+        off, vals = csr(lists)
+        eo = None if expected_owner is None else np.ascontiguousarray(expected_owner, dtype=np.int64)
+        h = lib().sfo_precedence_shop_create(len(duration), len(lists), _p(duration), _p(soff), _p(svals),
+                                             None if eo is None else _p(eo), _p(off), _p(vals), levels, hard_levels, hard_level, soft_level)
+        return Model(h, [len(lists)])
 
     @staticmethod
     def jobshop(job, machine_idx, sequences, bendable=True, indexed=False):

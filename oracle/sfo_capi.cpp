@@ -125,6 +125,13 @@ void* sfo_cvrp_create(int32_t n_customers, int32_t n_vehicles, int64_t capacity,
                      matrix, customers, route_off, route_vals)
         .release();
 }
+void* sfo_precedence_shop_create(int32_t n_nodes, int32_t n_owners, const int64_t* duration, const uint32_t* succ_off, const uint32_t* succ,
+                                 const int64_t* expected_owner, const uint32_t* list_off, const uint32_t* list_vals, int32_t levels,
+                                 int32_t hard_levels, int32_t hard_level, int32_t soft_level) {
+    return make_precedence_shop((size_t)n_nodes, (size_t)n_owners, duration, succ_off, succ, expected_owner, list_off, list_vals, levels,
+                                hard_levels, hard_level, soft_level)
+        .release();
+}
 void* sfo_list_toy_create(int32_t n_entities, const uint32_t* off, const uint32_t* vals, int32_t meter) {
     return make_list_toy((size_t)n_entities, off, vals, meter == 0 ? ToyMeter::Equal : ToyMeter::Position)
         .release();

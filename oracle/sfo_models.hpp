@@ -673,4 +673,56 @@ inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, cons
     return m;
 }
 
+// ---- precedence shop: owners (machines) hold lists of node ids (operations); the only constraint is the
+// ListPrecedenceMakespanConstraint (constraint/list_precedence.rs:13-707) over the fixed successor relation (job order) and
+// the consecutive list items.  HardSoftScore by default; `hard_level` / `soft_level` place the two penalties on other levels. -
+struct PrecedenceFacts {
+    std::vector<int64_t> duration, expected_owner;  // expected_owner: NONE = no expectation
+    std::vector<uint32_t> succ_off, succ;
+    bool has_owner = false;
+};
+inline std::unique_ptr<Model> make_precedence_shop(size_t n_nodes, size_t n_owners, const int64_t* duration, const uint32_t* succ_off,
+                                                   const uint32_t* succ, const int64_t* expected_owner, const uint32_t* list_off,
+                                                   const uint32_t* list_vals, int levels, int hard_levels, int hard_level, int soft_level) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<PrecedenceFacts>();
+    facts->duration.assign(duration, duration + n_nodes);
+    facts->succ_off.assign(succ_off, succ_off + n_nodes + 1);
+    facts->succ.assign(succ, succ + succ_off[n_nodes]);
+    if (expected_owner) {
+        facts->expected_owner.assign(expected_owner, expected_owner + n_nodes);
+        facts->has_owner = true;
+    }
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n_owners;
+    s.classes[0].lists.resize(n_owners);
+    for (size_t v = 0; v < n_owners; ++v) s.classes[0].lists[v].assign(list_vals + list_off[v], list_vals + list_off[v + 1]);
+    s.facts = facts;
+    const PrecedenceFacts* pf = facts.get();
+    m->director.levels = levels;
+    m->director.hard_levels = hard_levels;
+    auto c = std::make_unique<ListPrecedenceConstraint>();
+    c->name = "listPrecedenceMakespan";
+    c->is_hard = true;
+    c->list_descriptor = 0;
+    c->node_count = [pf](const Solution&) { return pf->duration.size(); };
+    c->node_duration = [pf](const Solution&, size_t n) { return pf->duration[n]; };
+    c->fixed_successors = [pf](const Solution&, size_t n, std::vector<size_t>& out) {
+        for (uint32_t t = pf->succ_off[n]; t < pf->succ_off[n + 1]; ++t) out.push_back((size_t)pf->succ[t]);
+    };
+    c->owner_count = [](const Solution& s) { return s.classes[0].n; };
+    c->list_len = [](const Solution& s, size_t o) { return s.classes[0].lists[o].size(); };
+    c->list_get = [](const Solution& s, size_t o, size_t p) { return (int64_t)s.classes[0].lists[o][p]; };
+    if (pf->has_owner) c->expected_owner = [pf](const Solution&, size_t n) { return pf->expected_owner[n]; };
+    c->hard = Score::level(hard_level, 1);
+    c->soft = Score::level(soft_level, 1);
+    m->director.constraints.members.push_back(std::move(c));
+    m->has_list = true;
+    m->list_slot.descriptor_index = 0;
+    m->leaves = LEAF_LIST_CHANGE | LEAF_LIST_SWAP;
+    m->wire_search();
+    return m;
+}
+
 }  // namespace sfo

@@ -11,6 +11,7 @@
 //   crates/solverforge-scoring/src/constraint/cross_bi_incremental/{state,incremental}.rs
 //   crates/solverforge-scoring/src/constraint/exists.rs:42-437 + exists/key_state.rs
 //   crates/solverforge-scoring/src/constraint/grouped/{state,scorer,shared_set}.rs
+//   crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707 (ListPrecedenceMakespanConstraint)
 //   crates/solverforge-scoring/src/api/constraint_set/incremental.rs:339-407 (tuple fold)
 //   crates/solverforge-scoring/src/director/score_director/incremental.rs:141-218
 #pragma once
@@ -18,7 +19,9 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -1289,6 +1292,369 @@ struct BalanceConstraint : Constraint {
         counts.clear();
         entity_keys.clear();
         group_count = total_count = sum_squared = 0;
+    }
+};
+
+// ---- ListPrecedenceMakespanConstraint (constraint/list_precedence.rs:13-707) ---------------------------------------------------
+// Nodes = list elements with a duration; edges = the fixed successor relation plus every pair of consecutive elements of
+// every owner's list (edges are counted: one that is both fixed and on a route exists once in the graph).  Score =
+// HardSoft(-(invalid fixed edges + invalid list items + wrong-owner items + assignment penalty + cycle penalty), -makespan),
+// makespan = the longest duration-weighted path; a cyclic graph costs node_count hard and has makespan 0.  The incremental
+// state (earliest starts refreshed over the descendants of changed edges, the cached cycle, the full Kahn rebuild) follows the
+// reference line by line so the GraphRefreshKind sequence of its tests can be pinned.  `hard` / `soft` = the score of one
+// unit of penalty / makespan (the reference fixes HardSoftScore::of(1, 0) / of(0, 1)).
+struct ListPrecedenceConstraint : Constraint {
+    using Edge = std::pair<size_t, size_t>;
+    enum class Refresh { Skipped, Incremental, CycleDetected, CycleRecovered, Full };
+    struct RouteChange {
+        std::vector<Edge> added, removed;
+        bool empty() const { return added.empty() && removed.empty(); }
+    };
+    struct Snapshot {
+        std::vector<size_t> elements;
+        std::vector<Edge> edges;
+        size_t invalid = 0, violation = 0;
+    };
+    struct State {  // ListPrecedenceState (:188-210)
+        size_t node_count = 0;
+        std::vector<int64_t> durations;
+        std::vector<std::vector<std::pair<size_t, size_t>>> edge_counts;
+        std::vector<std::vector<size_t>> successors, predecessors;
+        std::vector<size_t> assigned_counts;
+        std::vector<std::vector<size_t>> owner_elements;
+        std::vector<std::vector<Edge>> owner_edges;
+        std::vector<size_t> owner_invalid, owner_violation;
+        size_t invalid_fixed_edges = 0, owner_invalid_total = 0, owner_violation_total = 0, assignment_penalty = 0, cycle_penalty = 0;
+        std::vector<Edge> cycle_added_edges;
+        std::vector<int64_t> earliest, finishes;
+        size_t hard_penalty = 0;
+        int64_t makespan = 0;
+        size_t last_visited = 0;  // GraphRefreshKind::Incremental { visited }
+
+        State() = default;
+        State(size_t n, size_t owners, std::vector<int64_t> dur)  // (:268-292)
+            : node_count(n), durations(std::move(dur)), edge_counts(n), successors(n), predecessors(n), assigned_counts(n, 0),
+              owner_elements(owners), owner_edges(owners), owner_invalid(owners, 0), owner_violation(owners, 0), assignment_penalty(n),
+              earliest(n, 0), finishes(n, 0) {}
+        static int64_t sat_add(int64_t a, int64_t b) {
+            int64_t r;
+            return __builtin_add_overflow(a, b, &r) ? (b > 0 ? INT64_MAX : INT64_MIN) : r;
+        }
+        static size_t penalty_of(size_t count) { return count == 0 ? 1 : (count == 1 ? 0 : count - 1); }  // (:690-696)
+        static void remove_node(std::vector<size_t>& v, size_t node) {  // swap_remove of the first match (:702-707)
+            for (size_t i = 0; i < v.size(); ++i)
+                if (v[i] == node) {
+                    v[i] = v.back();
+                    v.pop_back();
+                    return;
+                }
+        }
+        bool add_edge(Edge e) {  // (:294-307)
+            for (auto& tc : edge_counts[e.first])
+                if (tc.first == e.second) {
+                    ++tc.second;
+                    return false;
+                }
+            edge_counts[e.first].push_back({e.second, 1});
+            successors[e.first].push_back(e.second);
+            predecessors[e.second].push_back(e.first);
+            return true;
+        }
+        bool remove_edge(Edge e) {  // (:309-326)
+            auto& ec = edge_counts[e.first];
+            for (size_t i = 0; i < ec.size(); ++i)
+                if (ec[i].first == e.second) {
+                    if (--ec[i].second == 0) {
+                        ec[i] = ec.back();
+                        ec.pop_back();
+                        remove_node(successors[e.first], e.second);
+                        remove_node(predecessors[e.second], e.first);
+                        return true;
+                    }
+                    return false;
+                }
+            return false;
+        }
+        bool contains_edge(Edge e) const {  // (:683-688)
+            for (auto& tc : edge_counts[e.first])
+                if (tc.first == e.second && tc.second > 0) return true;
+            return false;
+        }
+        void adjust_assignment(size_t node, size_t new_count) {  // (:328-341)
+            size_t old_count = assigned_counts[node];
+            if (old_count == new_count) return;
+            assignment_penalty = assignment_penalty - penalty_of(old_count) + penalty_of(new_count);
+            assigned_counts[node] = new_count;
+        }
+        RouteChange replace_owner_route(size_t owner, Snapshot snap) {  // (:395-481, diff_owner_assignments / diff_owner_edges)
+            RouteChange change;
+            std::vector<size_t> old_elements = std::move(owner_elements[owner]);
+            {
+                std::map<size_t, std::pair<size_t, size_t>> counts;
+                for (size_t n : old_elements) ++counts[n].first;
+                for (size_t n : snap.elements) ++counts[n].second;
+                for (auto& kv : counts) {
+                    if (kv.second.first == kv.second.second) continue;
+                    size_t cur = assigned_counts[kv.first];
+                    size_t upd = (cur >= kv.second.first ? cur - kv.second.first : 0) + kv.second.second;
+                    adjust_assignment(kv.first, upd);
+                }
+            }
+            owner_elements[owner] = std::move(snap.elements);
+            std::vector<Edge> old_edges = std::move(owner_edges[owner]);
+            {
+                std::map<Edge, std::pair<size_t, size_t>> counts;
+                for (auto& e : old_edges) ++counts[e].first;
+                for (auto& e : snap.edges) ++counts[e].second;
+                for (auto& kv : counts) {  // the reference iterates a HashMap: the ORDER of the change's edges is unspecified there
+                    if (kv.second.first > kv.second.second) {
+                        for (size_t i = 0; i < kv.second.first - kv.second.second; ++i)
+                            if (remove_edge(kv.first)) change.removed.push_back(kv.first);
+                    } else if (kv.second.second > kv.second.first) {
+                        for (size_t i = 0; i < kv.second.second - kv.second.first; ++i)
+                            if (add_edge(kv.first)) change.added.push_back(kv.first);
+                    }
+                }
+            }
+            owner_edges[owner] = std::move(snap.edges);
+            owner_invalid_total = owner_invalid_total - owner_invalid[owner] + snap.invalid;
+            owner_invalid[owner] = snap.invalid;
+            owner_violation_total = owner_violation_total - owner_violation[owner] + snap.violation;
+            owner_violation[owner] = snap.violation;
+            return change;
+        }
+        int64_t max_finish() const {  // (:634-636)
+            int64_t m = 0;
+            bool any = false;
+            for (int64_t f : finishes) m = any ? std::max(m, f) : f, any = true;
+            return any ? m : 0;
+        }
+        void mark_cyclic_without_cache() {  // (:597-603)
+            std::fill(earliest.begin(), earliest.end(), 0);
+            std::fill(finishes.begin(), finishes.end(), 0);
+            cycle_added_edges.clear();
+            cycle_penalty = node_count;
+            makespan = 0;
+        }
+        void rebuild_graph_summary() {  // Kahn (:553-589)
+            std::vector<size_t> indegree(node_count);
+            for (size_t i = 0; i < node_count; ++i) indegree[i] = predecessors[i].size();
+            std::vector<int64_t> e(node_count, 0), f(node_count, 0);
+            std::deque<size_t> ready;
+            for (size_t i = 0; i < node_count; ++i)
+                if (indegree[i] == 0) ready.push_back(i);
+            size_t processed = 0;
+            int64_t mk = 0;
+            while (!ready.empty()) {
+                size_t node = ready.front();
+                ready.pop_front();
+                ++processed;
+                int64_t fin = sat_add(e[node], durations[node]);
+                f[node] = fin;
+                mk = std::max(mk, fin);
+                for (size_t s : successors[node]) {
+                    e[s] = std::max(e[s], fin);
+                    if (--indegree[s] == 0) ready.push_back(s);
+                }
+            }
+            if (processed < node_count)
+                mark_cyclic_without_cache();
+            else {
+                earliest = std::move(e);
+                finishes = std::move(f);
+                cycle_penalty = 0;
+                cycle_added_edges.clear();
+                makespan = mk;
+            }
+        }
+        bool reaches(size_t start, size_t target, size_t visit_id, std::vector<size_t>& visited, std::vector<size_t>& stack) const {  // (:653-681)
+            if (start == target) return true;
+            stack.clear();
+            stack.push_back(start);
+            while (!stack.empty()) {
+                size_t node = stack.back();
+                stack.pop_back();
+                if (visited[node] == visit_id) continue;
+                visited[node] = visit_id;
+                for (size_t s : successors[node]) {
+                    if (s == target) return true;
+                    if (visited[s] != visit_id) stack.push_back(s);
+                }
+            }
+            return false;
+        }
+        bool added_edges_introduce_cycle(const std::vector<Edge>& added) const {  // (:638-651)
+            if (added.empty()) return false;
+            std::vector<size_t> visited(node_count, 0), stack;
+            for (size_t i = 0; i < added.size(); ++i)
+                if (reaches(added[i].second, added[i].first, i + 1, visited, stack)) return true;
+            return false;
+        }
+        bool recover_cached_cycle(const RouteChange& change) {  // (:605-620)
+            if (cycle_added_edges.empty() || !change.added.empty()) return false;
+            for (auto& e : cycle_added_edges)
+                if (contains_edge(e)) return false;
+            cycle_penalty = 0;
+            cycle_added_edges.clear();
+            makespan = max_finish();
+            return true;
+        }
+        void replace_earliest(size_t node, int64_t ne) {  // (:622-632)
+            int64_t old_finish = finishes[node];
+            earliest[node] = ne;
+            int64_t nf = sat_add(ne, durations[node]);
+            finishes[node] = nf;
+            if (nf >= makespan)
+                makespan = nf;
+            else if (old_finish == makespan)
+                makespan = max_finish();
+        }
+        Refresh refresh_graph_after_route_change(const RouteChange& change) {  // (:494-551)
+            if (change.empty()) return Refresh::Skipped;
+            if (cycle_penalty > 0) {
+                if (recover_cached_cycle(change)) return Refresh::CycleRecovered;
+                rebuild_graph_summary();
+                return Refresh::Full;
+            }
+            if (added_edges_introduce_cycle(change.added)) {
+                if (change.removed.empty()) {  // mark_cyclic_from_route_change: the acyclic earliest / finishes stay cached
+                    cycle_added_edges = change.added;
+                    cycle_penalty = node_count;
+                    makespan = 0;
+                } else
+                    mark_cyclic_without_cache();
+                return Refresh::CycleDetected;
+            }
+            std::vector<char> queued(node_count, 0);
+            std::deque<size_t> queue;
+            auto seed = [&](size_t node) {
+                if (node < node_count && !queued[node]) {
+                    queued[node] = 1;
+                    queue.push_back(node);
+                }
+            };
+            for (auto& e : change.added) seed(e.second);
+            for (auto& e : change.removed) seed(e.second);
+            size_t visited = 0;
+            while (!queue.empty()) {
+                size_t node = queue.front();
+                queue.pop_front();
+                queued[node] = 0;
+                ++visited;
+                int64_t ne = 0;
+                bool any = false;
+                for (size_t p : predecessors[node]) {
+                    int64_t v = sat_add(earliest[p], durations[p]);
+                    ne = any ? std::max(ne, v) : v;
+                    any = true;
+                }
+                if (ne == earliest[node]) continue;
+                replace_earliest(node, ne);
+                for (size_t s : successors[node])
+                    if (!queued[s]) {
+                        queued[s] = 1;
+                        queue.push_back(s);
+                    }
+            }
+            makespan = max_finish();
+            last_visited = visited;
+            return Refresh::Incremental;
+        }
+        void refresh_penalty() {  // refresh_score_from_cached_graph (:483-492)
+            hard_penalty = invalid_fixed_edges + owner_invalid_total + owner_violation_total + assignment_penalty + cycle_penalty;
+        }
+    };
+
+    size_t list_descriptor = 0;
+    std::function<size_t(const Solution&)> node_count, owner_count;
+    std::function<int64_t(const Solution&, size_t)> node_duration;
+    std::function<void(const Solution&, size_t, std::vector<size_t>&)> fixed_successors;
+    std::function<size_t(const Solution&, size_t)> list_len;
+    std::function<int64_t(const Solution&, size_t, size_t)> list_get;        // NONE = None
+    std::function<int64_t(const Solution&, size_t)> expected_owner;          // may be empty; NONE = no expectation
+    Score hard = Score::of(1, 0), soft = Score::of(0, 1);
+    bool has_state = false;
+    State state;
+
+    Score score_of(const State& st) const {  // HardSoftScore::of(-hard_penalty, makespan.saturating_neg())
+        Score r;
+        for (int i = 0; i < MAX_LEVELS; ++i) r.v[i] = -(hard.v[i] * (int64_t)st.hard_penalty + soft.v[i] * st.makespan);
+        return r;
+    }
+    Snapshot owner_route_snapshot(const State& st, const Solution& s, size_t owner) const {  // (:357-393)
+        Snapshot snap;
+        size_t len = list_len(s, owner);
+        bool has_prev = false;
+        size_t prev = 0;
+        for (size_t pos = 0; pos < len; ++pos) {
+            int64_t got = list_get(s, owner, pos);
+            if (got == NONE || (size_t)got >= st.node_count) {
+                ++snap.invalid;
+                has_prev = false;
+                continue;
+            }
+            size_t node = (size_t)got;
+            snap.elements.push_back(node);
+            if (expected_owner) {
+                int64_t ex = expected_owner(s, node);
+                if (ex != NONE && (size_t)ex != owner) ++snap.violation;
+            }
+            if (has_prev) snap.edges.push_back({prev, node});
+            prev = node;
+            has_prev = true;
+        }
+        return snap;
+    }
+    State build_state(const Solution& s) const {  // (:62-90)
+        size_t n = node_count(s), owners = owner_count(s);
+        std::vector<int64_t> dur(n);
+        for (size_t i = 0; i < n; ++i) dur[i] = node_duration(s, i);
+        State st(n, owners, std::move(dur));
+        std::vector<size_t> succ;
+        for (size_t node = 0; node < n; ++node) {
+            succ.clear();
+            fixed_successors(s, node, succ);
+            for (size_t t : succ) {
+                if (t < n)
+                    st.add_edge({node, t});
+                else
+                    ++st.invalid_fixed_edges;
+            }
+        }
+        for (size_t o = 0; o < owners; ++o) st.replace_owner_route(o, owner_route_snapshot(st, s, o));
+        st.rebuild_graph_summary();
+        st.refresh_penalty();
+        return st;
+    }
+    Score evaluate(const Solution& s) const override { return score_of(build_state(s)); }
+    size_t match_count(const Solution& s) const override {  // (:96-99)
+        State st = build_state(s);
+        return st.hard_penalty + (st.makespan > 0 ? 1 : 0);
+    }
+    Score initialize(const Solution& s) override {
+        state = build_state(s);
+        has_state = true;
+        return score_of(state);
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {  // (:129-152)
+        if (d != list_descriptor || !has_state || e >= state.owner_edges.size()) return Score::zero();
+        Score before = score_of(state);
+        RouteChange ch = state.replace_owner_route(e, owner_route_snapshot(state, s, e));
+        state.refresh_graph_after_route_change(ch);
+        state.refresh_penalty();
+        return score_of(state) - before;
+    }
+    Score on_retract(const Solution&, size_t e, size_t d) override {  // (:154-174)
+        if (d != list_descriptor || !has_state || e >= state.owner_edges.size()) return Score::zero();
+        Score before = score_of(state);
+        RouteChange ch = state.replace_owner_route(e, Snapshot());
+        state.refresh_graph_after_route_change(ch);
+        state.refresh_penalty();
+        return score_of(state) - before;
+    }
+    void reset() override {
+        has_state = false;
+        state = State();
     }
 };
 

@@ -1033,7 +1033,176 @@ static void forager_cases() {
     }
 }
 
+// constraint/list_precedence.rs:905-1176 (the constraint's own test module): the two-task plan (durations 2, 3; fixed edge
+// 0 -> 1; expected owners 0, 1), the four-task plan and the bare graph states.
+struct PrecPlan {
+    std::vector<int64_t> duration, next, owner;
+};
+static ListPrecedenceConstraint prec_constraint(std::shared_ptr<PrecPlan> plan, bool with_owner) {
+    ListPrecedenceConstraint c;
+    c.name = "listPrecedenceMakespan";
+    c.list_descriptor = 0;
+    c.node_count = [plan](const Solution&) { return plan->duration.size(); };
+    c.node_duration = [plan](const Solution&, size_t n) { return plan->duration[n]; };
+    c.fixed_successors = [plan](const Solution&, size_t n, std::vector<size_t>& out) {
+        if (plan->next[n] != NONE) out.push_back((size_t)plan->next[n]);
+    };
+    c.owner_count = [](const Solution& s) { return s.classes[0].n; };
+    c.list_len = [](const Solution& s, size_t o) { return s.classes[0].lists[o].size(); };
+    c.list_get = [](const Solution& s, size_t o, size_t p) { return (int64_t)s.classes[0].lists[o][p]; };
+    if (with_owner) c.expected_owner = [plan](const Solution&, size_t n) { return plan->owner[n]; };
+    return c;
+}
+static Solution prec_routes(std::vector<std::vector<uint32_t>> routes) {
+    Solution s;
+    s.classes.resize(1);
+    s.classes[0].n = routes.size();
+    s.classes[0].lists = routes;
+    return s;
+}
+static ListPrecedenceConstraint::State prec_graph(size_t n, std::vector<int64_t> dur, std::vector<std::pair<size_t, size_t>> edges) {
+    ListPrecedenceConstraint::State st(n, 0, dur);
+    for (auto& e : edges) st.add_edge(e);
+    st.rebuild_graph_summary();
+    st.refresh_penalty();
+    return st;
+}
+static void list_precedence_cases() {
+    using C = ListPrecedenceConstraint;
+    using R = C::Refresh;
+    auto two = std::make_shared<PrecPlan>(PrecPlan{{2, 3}, {1, NONE}, {0, 1}});
+    auto four = std::make_shared<PrecPlan>(PrecPlan{{1, 1, 1, 1}, {NONE, NONE, NONE, NONE}, {0, 0, 0, 0}});
+    {  // evaluates_fixed_and_list_precedence_makespan (:905-913)
+        auto c = prec_constraint(two, false);
+        CHECK("list_precedence.evaluate", c.evaluate(prec_routes({{0}, {1}})) == Score::of(0, -5));
+    }
+    {  // acyclic_graph_route_change_uses_incremental_descendant_refresh (:915-934)
+        auto st = prec_graph(4, {2, 3, 5, 7}, {{0, 1}, {1, 2}, {0, 3}});
+        bool ok = st.cycle_penalty == 0 && st.makespan == 10;
+        C::RouteChange ch;
+        if (st.remove_edge({1, 2})) ch.removed.push_back({1, 2});
+        ok = ok && st.refresh_graph_after_route_change(ch) == R::Incremental && st.last_visited == 1;
+        ok = ok && st.cycle_penalty == 0 && st.earliest[2] == 0 && st.earliest[3] == 2 && st.makespan == 9;
+        CHECK("list_precedence.incremental_descendant_refresh", ok);
+    }
+    {  // cycle_introducing_route_change_marks_cyclic_without_graph_rebuild (:936-953)
+        auto st = prec_graph(3, {1, 1, 1}, {{0, 1}, {1, 2}});
+        bool ok = st.cycle_penalty == 0 && st.makespan == 3;
+        C::RouteChange ch;
+        if (st.add_edge({2, 0})) ch.added.push_back({2, 0});
+        ok = ok && st.refresh_graph_after_route_change(ch) == R::CycleDetected && st.cycle_penalty == 3 && st.makespan == 0;
+        CHECK("list_precedence.cycle_detected", ok);
+        // cycle_retraction_recovers_cached_acyclic_state_without_graph_rebuild (:955-981)
+        C::RouteChange undo;
+        if (st.remove_edge({2, 0})) undo.removed.push_back({2, 0});
+        ok = ok && st.refresh_graph_after_route_change(undo) == R::CycleRecovered && st.cycle_penalty == 0 &&
+             st.earliest == std::vector<int64_t>({0, 1, 2}) && st.makespan == 3;
+        CHECK("list_precedence.cycle_recovered", ok);
+    }
+    {  // cycle_introduced_with_removed_edges_recovers_by_full_rebuild (:983-1013)
+        auto st = prec_graph(3, {10, 10, 1}, {{0, 1}, {1, 2}});
+        bool ok = st.makespan == 21;
+        C::RouteChange ch;
+        if (st.remove_edge({0, 1})) ch.removed.push_back({0, 1});
+        if (st.add_edge({2, 1})) ch.added.push_back({2, 1});
+        ok = ok && st.refresh_graph_after_route_change(ch) == R::CycleDetected && st.cycle_penalty == 3 && st.cycle_added_edges.empty();
+        C::RouteChange undo;
+        if (st.remove_edge({2, 1})) undo.removed.push_back({2, 1});
+        ok = ok && st.refresh_graph_after_route_change(undo) == R::Full && st.cycle_penalty == 0 &&
+             st.earliest == std::vector<int64_t>({0, 0, 10}) && st.makespan == 11;
+        CHECK("list_precedence.cycle_with_removed_edges_full_rebuild", ok);
+    }
+    {  // owner_route_replacement_diffs_unchanged_prefix_edges (:1015-1031)
+        auto c = prec_constraint(four, false);
+        C::State st(4, 1, {1, 1, 1, 1});
+        st.replace_owner_route(0, c.owner_route_snapshot(st, prec_routes({{0, 1, 2}}), 0));
+        st.rebuild_graph_summary();
+        auto ch = st.replace_owner_route(0, c.owner_route_snapshot(st, prec_routes({{0, 1, 3}}), 0));
+        std::sort(ch.added.begin(), ch.added.end());
+        std::sort(ch.removed.begin(), ch.removed.end());
+        bool ok = ch.removed == std::vector<C::Edge>({{1, 2}}) && ch.added == std::vector<C::Edge>({{1, 3}}) &&
+                  st.assigned_counts == std::vector<size_t>({1, 1, 0, 1}) && st.owner_edges[0] == std::vector<C::Edge>({{0, 1}, {1, 3}});
+        CHECK("list_precedence.route_replacement_diff", ok);
+    }
+    {  // cyclic_state_with_unmatched_change_uses_full_graph_refresh (:1033-1056)
+        auto st = prec_graph(4, {1, 1, 1, 1}, {{0, 1}, {1, 2}});
+        C::RouteChange ch;
+        if (st.add_edge({2, 0})) ch.added.push_back({2, 0});
+        bool ok = st.refresh_graph_after_route_change(ch) == R::CycleDetected;
+        C::RouteChange un;
+        if (st.add_edge({2, 3})) un.added.push_back({2, 3});
+        ok = ok && st.refresh_graph_after_route_change(un) == R::Full && st.cycle_penalty == 4 && st.makespan == 0;
+        CHECK("list_precedence.cyclic_unmatched_change_full_refresh", ok);
+    }
+    {  // partial_cycle_penalizes_whole_precedence_schedule (:1058-1065): assignment penalty 4 + cycle penalty 4
+        auto st = prec_graph(4, {1, 1, 1, 10}, {{0, 1}, {1, 0}});
+        CHECK("list_precedence.partial_cycle", st.cycle_penalty == 4 && st.makespan == 0 && st.hard_penalty == 8);
+    }
+    auto director_with = [&](std::vector<std::vector<uint32_t>> routes, bool owner) {
+        ScoreDirector d;
+        d.working = prec_routes(routes);
+        d.constraints.members.push_back(std::make_unique<ListPrecedenceConstraint>(prec_constraint(two, owner)));
+        return d;
+    };
+    {  // penalizes_cycles_incrementally (:1067-1079)
+        auto d = director_with({{0, 1}}, false);
+        bool ok = d.calculate_score() == Score::of(0, -5);
+        d.before_variable_changed(0, 0);
+        d.working.classes[0].lists[0] = {1, 0};
+        d.after_variable_changed(0, 0);
+        Score sc = d.calculate_score();
+        ok = ok && sc == Score::of(-2, 0) && d.fresh_score() == sc;
+        CHECK("list_precedence.cycles_incrementally", ok);
+    }
+    {  // repeated_route_updates_keep_incremental_score_fresh (:1081-1101)
+        auto d = director_with({{0}, {1}}, false);
+        bool ok = d.fresh_score() == d.calculate_score();
+        std::vector<std::pair<size_t, std::vector<uint32_t>>> upd = {{0, {0, 1}}, {1, {}}, {0, {1, 0}}, {1, {0, 1}}};
+        for (auto& u : upd) {
+            d.before_variable_changed(0, u.first);
+            d.working.classes[0].lists[u.first] = u.second;
+            d.after_variable_changed(0, u.first);
+            ok = ok && d.fresh_score() == d.calculate_score();
+        }
+        CHECK("list_precedence.repeated_updates_fresh", ok);
+    }
+    {  // retract_removes_cached_owner_route_before_insert (:1103-1118)
+        auto c = prec_constraint(two, false);
+        Solution s = prec_routes({{0}, {1}});
+        Score sc = c.initialize(s);
+        bool ok = sc == Score::of(0, -5);
+        sc = sc + c.on_retract(s, 0, 0);
+        ok = ok && sc == Score::of(-1, -5);
+        s.classes[0].lists[0] = {0, 1};
+        sc = sc + c.on_insert(s, 0, 0);
+        ok = ok && sc == Score::of(-1, -5) && c.evaluate(s) == sc;
+        CHECK("list_precedence.retract_before_insert", ok);
+    }
+    {  // incremental_route_update_only_reads_changed_owner_route (:1120-1154): the scores of that sequence
+        auto d = director_with({{0}, {1}}, false);
+        bool ok = d.calculate_score() == Score::of(0, -5);
+        d.before_variable_changed(0, 0);
+        d.working.classes[0].lists[0] = {0, 1};
+        d.after_variable_changed(0, 0);
+        ok = ok && d.calculate_score() == Score::of(-1, -5) && d.fresh_score() == d.calculate_score();
+        CHECK("list_precedence.incremental_route_update", ok);
+    }
+    {  // penalizes_missing_duplicate_and_wrong_owner_assignments (:1156-1164)
+        auto c = prec_constraint(two, true);
+        CHECK("list_precedence.duplicate_and_wrong_owner", c.evaluate(prec_routes({{0, 1}, {1}})) == Score::of(-2, -5));
+    }
+    {  // ignores_unrelated_descriptor_changes (:1166-1176)
+        auto d = director_with({{0}, {1}}, false);
+        Score sc = d.calculate_score();
+        d.before_variable_changed(1, 0);
+        d.working.classes[0].lists[0] = {1, 0};
+        d.after_variable_changed(1, 0);
+        CHECK("list_precedence.unrelated_descriptor", d.calculate_score() == sc);
+    }
+}
+
 int main() {
+    list_precedence_cases();
     forager_cases();
     k_opt_cases();
     simulated_annealing_cases();

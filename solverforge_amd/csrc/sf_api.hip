@@ -19,6 +19,7 @@
 #include "sf_scalar_kernels.hip"
 #include "sf_mixed_wave.hip"
 #include "sf_construct.hip"
+#include "sf_precedence.hip"
 
 using namespace sf;
 
@@ -46,6 +47,13 @@ struct SelectorSpec {
     int moves_per_step = 10, max_source_len = 0, skip_empty = 0;  // ruin leaf (ListRuinMoveSelectorConfig)
     std::string variable_name;                                    // ruin leaf: scoped_seed hashes the variable name
 };
+struct PrecSpec {  // sf_constraint_add_list_precedence: the constraint's hooks as data
+    bool on = false;
+    int desc = 0, var = 0, hard_level = 0, mk_level = 1;
+    std::vector<int32_t> dur, owner;
+    std::vector<uint32_t> succ_off, succ;
+    bool has_owner = false;
+};
 struct ClassSpec {
     int n_rows = 0;
     bool has_scalar = false;
@@ -72,6 +80,8 @@ struct sf_ctx {
     bool has_list_model = false;
     int list_desc = -1;
     ListModel lm{};
+    PrecSpec prec;          // ListPrecedenceMakespanConstraint on the list class (sf_precedence.h)
+    PrecModel pm{};
     NbrIndex nbr{nullptr};  // presorted neighbour index (wave engine)
     bool lm_small = false;  // every trial delta of the list model fits 32-bit arithmetic (wave engine MODE 2)
     int engine = SF_ENGINE_AUTO;
@@ -389,6 +399,39 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
     return SF_OK;
 }
 
+int32_t sf_constraint_add_list_precedence(sf_ctx* ctx, int32_t d, int32_t var, int32_t node_count, const int32_t* durations,
+                                          const uint32_t* succ_offsets, const uint32_t* succ_values, const int32_t* expected_owner,
+                                          int32_t hard_level, int32_t makespan_level) {
+    if (!ctx || hard_level < 0 || hard_level >= ctx->levels || makespan_level < 0 || makespan_level >= ctx->levels || hard_level == makespan_level)
+        return fail(ctx, SF_ERR_INVALID, "list precedence: bad score levels");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
+    if (ctx->prec.on) return fail(ctx, SF_ERR_UNSUPPORTED, "one list precedence constraint per context");
+    if (node_count < 0 || (node_count > 0 && (!durations || !succ_offsets))) return fail(ctx, SF_ERR_INVALID, "list precedence: missing node data");
+    if (node_count > 0 && succ_offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "list precedence: successor offsets must start at 0");
+    int64_t dsum = 0;
+    for (int32_t i = 0; i < node_count; ++i) {
+        if (durations[i] < 0) return fail(ctx, SF_ERR_INVALID, "list precedence: negative duration");  // node_duration returns usize
+        dsum += durations[i];
+        if (succ_offsets[i + 1] < succ_offsets[i]) return fail(ctx, SF_ERR_INVALID, "list precedence: successor offsets must be non-decreasing");
+    }
+    if (dsum >= ((int64_t)1 << 31)) return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence: sum of durations >= 2^31 (32-bit earliest starts)");
+    if (node_count > 0 && succ_offsets[node_count] > 0 && !succ_values) return fail(ctx, SF_ERR_INVALID, "list precedence: successor values missing");
+    PrecSpec& ps = ctx->prec;
+    ps.on = true;
+    ps.desc = d;
+    ps.var = var;
+    ps.hard_level = hard_level;
+    ps.mk_level = makespan_level;
+    ps.dur.assign(durations, durations + node_count);
+    ps.succ_off.assign(succ_offsets, succ_offsets + (node_count > 0 ? node_count + 1 : 0));
+    if (node_count == 0) ps.succ_off.assign(1, 0u);
+    ps.succ.assign(succ_values, succ_values + ps.succ_off.back());
+    ps.has_owner = expected_owner != nullptr;
+    if (expected_owner) ps.owner.assign(expected_owner, expected_owner + node_count);
+    ctx->constraints.push_back({SF_C_LIST_PRECEDENCE_MAKESPAN, d, var, -1, 0, hard_level, (int64_t)makespan_level});
+    return SF_OK;
+}
+
 int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32_t max_nearby, int32_t fact_meter) {
     if (!ctx) return SF_ERR_INVALID;
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
@@ -602,6 +645,59 @@ static int build_list_model(sf_ctx* ctx, int d) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_list_model = true;
     ctx->list_desc = d;
+    ctx->pm = PrecModel{};
+    if (ctx->prec.on) {  // ListPrecedenceMakespanConstraint: fixed graph + per-replica scratch (sf_precedence.h)
+        PrecSpec& ps = ctx->prec;
+        if (ps.desc != d) return fail(ctx, SF_ERR_INVALID, "list precedence: descriptor is not the list class");
+        const int n = (int)ps.dur.size();
+        if (c.element_bound > n) return fail(ctx, SF_ERR_INVALID, "list precedence: element ids must be < node_count");
+        std::vector<char> seen((size_t)n, 0);
+        for (uint32_t x : c.list_vals) {
+            if (seen[x]) return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence: an element appears in more than one list position");
+            seen[x] = 1;
+        }
+        for (auto& sel : ctx->selectors)
+            if (sel.kind == SF_SEL_LIST_RUIN) return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin leaf on a model with precedence hooks");
+        PrecModel& pm = ctx->pm;
+        pm.on = 1;
+        pm.hard_level = ps.hard_level;
+        pm.mk_level = ps.mk_level;
+        pm.n = n;
+        std::vector<uint32_t> soff((size_t)n + 1, 0), sval;
+        std::vector<int32_t> indeg((size_t)n, 0);
+        int64_t invalid = 0;
+        for (int i = 0; i < n; ++i) {
+            for (uint32_t t = ps.succ_off[i]; t < ps.succ_off[i + 1]; ++t) {
+                const uint32_t to = ps.succ[t];
+                if (to < (uint32_t)n) {
+                    sval.push_back(to);
+                    indeg[to] += 1;
+                } else
+                    ++invalid;  // invalid_fixed_edges (list_precedence.rs:78-84)
+            }
+            soff[i + 1] = (uint32_t)sval.size();
+        }
+        pm.const_penalty = invalid;
+        int32_t* d_dur = nullptr;
+        uint32_t *d_soff = nullptr, *d_sval = nullptr;
+        int32_t *d_indeg = nullptr, *d_owner = nullptr;
+        if ((rc = upload(ctx, &d_dur, ps.dur.data(), (size_t)n))) return rc;
+        if ((rc = upload(ctx, &d_soff, soff.data(), soff.size()))) return rc;
+        if ((rc = upload(ctx, &d_sval, sval.data(), sval.size()))) return rc;
+        if ((rc = upload(ctx, &d_indeg, indeg.data(), (size_t)n))) return rc;
+        if (ps.has_owner && (rc = upload(ctx, &d_owner, ps.owner.data(), (size_t)n))) return rc;
+        pm.dur = d_dur;
+        pm.succ_off = d_soff;
+        pm.succ = d_sval;
+        pm.indeg0 = d_indeg;
+        pm.owner = ps.has_owner ? d_owner : nullptr;
+        const size_t words = (size_t)R * (n ? n : 1);
+        if ((rc = dalloc(ctx, &pm.earliest, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.indeg, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.queue, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.lsucc, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.state, (size_t)R * 2))) return rc;
+    }
     // compact u32 matrix copy (4-byte gathers in the trial-score path) when every finite leg fits
     for (auto& kv : ctx->facts)
         if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat && kv.second.max_finite < 0xFFFFFFFFLL) {
@@ -819,6 +915,8 @@ static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit, int64_t* d_pa
     if (ctx->has_scalar_model)  // mixed model: the scalar class adds its constraints to the list class's scores
         hipLaunchKernelGGL(k_scalar_evaluate_all, dim3(ctx->R), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm,
                            ctx->d_scores_out, commit, ctx->has_list_model ? 1 : 0, d_parts);
+    if (ctx->has_list_model && ctx->pm.on)  // after the other constraints wrote their sums: adds its two levels
+        hipLaunchKernelGGL(k_prec_evaluate_all, dim3(ctx->R), dim3(64), 0, ctx->stream, ctx->lm, ctx->pm, ctx->d_scores_out, commit, d_parts);
     HIPCHK(ctx, hipGetLastError());
     if (out) {
         std::vector<int64_t> tmp((size_t)ctx->R * ctx->levels);
@@ -898,12 +996,17 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_BALANCE_VALUE: raw = q[6], count = q[7]; break;
             case SF_C_VALUE_COST: raw = q[8], count = q[9]; break;
             case SF_C_EXISTS_VALUE: raw = q[10], count = q[11]; break;
+            case SF_C_LIST_PRECEDENCE_MAKESPAN: raw = q[12], count = q[12] + (q[13] > 0 ? 1 : 0); break;  // match_count_from_state (:96-99)
             default: return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind in sf_evaluate_each");
         }
         (void)on_list;
         for (int k = 0; k < ctx->levels; ++k) out_scores[i * ctx->levels + k] = 0;
         // penalties; the balance constraint's base score is already inside `raw` (round(base * standard deviation))
         out_scores[i * ctx->levels + cs.level] = cs.kind == SF_C_BALANCE_VALUE ? (int64_t)(0 - (uint64_t)raw) : (int64_t)(0 - (uint64_t)cs.weight * (uint64_t)raw);
+        if (cs.kind == SF_C_LIST_PRECEDENCE_MAKESPAN) {  // two levels: -hard penalty, -makespan (`weight` holds the makespan level)
+            out_scores[i * ctx->levels + cs.level] = -q[12];
+            out_scores[i * ctx->levels + (int)cs.weight] = -q[13];
+        }
         out_match_counts[i] = count;
         ++i;
     }
@@ -989,6 +1092,24 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
                 return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin moves: the list class must fit one wave's LDS slice with 16-bit elements");
             }
             e = launch_ruin_moves(ctx, replica, d_moves, which, d_sc, d_do, 0);
+        }
+    }
+    if (e == hipSuccess && ctx->has_list_model && ctx->pm.on) {  // precedence delta of every doable list move: one wavefront per record
+        const PrecMoveCarve cv(ctx->lm.V, ctx->lm.n_cap);
+        if (ctx->lm.n_cap > 65535 || cv.total > SF_LDS_BUDGET) {
+            release();
+            return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence moves: the list class must fit one wave's LDS slice with 16-bit elements");
+        }
+        for (int64_t i = 0; i < n; ++i)
+            if (moves[i].kind == SF_MOVE_LIST_RUIN) {
+                release();
+                return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin move on a model with precedence hooks");
+            }
+        e = hipFuncSetAttribute((const void*)k_prec_evaluate_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+        for (int64_t base = 0; base < n && e == hipSuccess; base += ctx->R) {
+            const int chunk = (int)std::min<int64_t>(ctx->R, n - base);
+            hipLaunchKernelGGL(k_prec_evaluate_moves, dim3(chunk), dim3(64), cv.total, ctx->stream, ctx->lm, ctx->pm, replica, d_moves, base, d_sc, d_do);
+            e = hipGetLastError();
         }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -1088,6 +1209,7 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
     if (rc) return rc;
     if (mv->kind == SF_MOVE_LIST_RUIN) {  // committed ruin + recreate: its own kernel (one wavefront)
         if (!ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
+        if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin move on a model with precedence hooks");
         if (ctx->has_scalar_model) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_apply of a list ruin on a mixed model");
         if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || RuinMoveCarve(ctx->lm.V, ctx->lm.n_cap).total > SF_LDS_BUDGET)
             return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin moves: the list class must fit one wave's LDS slice with 16-bit elements");
@@ -1125,6 +1247,8 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         hipLaunchKernelGGL(k_list_apply, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, mv->kind,
                            (uint32_t)mv->a, (uint32_t)mv->a_pos, (uint32_t)mv->b, (uint32_t)mv->b_pos,
                            (uint32_t)(mv->value > 0 ? mv->value : 0), ctx->d_ok);
+        if (ctx->pm.on)  // a move that was not doable left the lists alone: the refresh then changes nothing
+            hipLaunchKernelGGL(k_prec_after_apply, dim3(1), dim3(64), 0, ctx->stream, ctx->lm, ctx->pm, replica);
     } else {
         hipLaunchKernelGGL(k_scalar_apply, dim3(1), dim3(64), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, mv->kind, mv->a,
                            mv->b, mv->value, ctx->d_ok);
@@ -1144,6 +1268,7 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "cheapest insertion needs the list variable's class");
     if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_cheapest arguments");
     if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
+    if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "cheapest insertion on a model with precedence hooks");
     for (int32_t k = 0; k < n; ++k)
         if (elements[k] >= (uint32_t)ctx->lm.dim) return fail(ctx, SF_ERR_INVALID, "element id out of range");
     int rc = alloc_search(ctx);
@@ -1329,7 +1454,7 @@ int32_t sf_phase_start(sf_ctx* ctx) {
 }  // extern "C"
 
 // generic N-leaf engine: mixed models, and list models whose union has plain list change / swap leaves
-template <int L, bool TRACE, class VT, bool RUIN = false>
+template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
@@ -1349,7 +1474,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
             wpb = w;
         }
     }
-    auto kern = k_mixed_search_wave<L, TRACE, VT, RUIN>;
+    auto kern = k_mixed_search_wave<L, TRACE, VT, RUIN, PREC>;
     HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cv.total * wpb)));
     SearchParams q = p;
     q.n_launch = n_replicas;
@@ -1425,6 +1550,12 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // two level counts (2, 4); i16 values, and i8 values for models whose scalar class dominates the LDS slice (a
     // replica's value array in one byte per entity: job shop 500 x 20 fits 4 waves per CU instead of 3)
     gl.levels = ctx->levels;
+    gl.prec = ctx->has_list_model ? ctx->pm : PrecModel{};
+    if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations (i16 values only)
+        if (ctx->levels <= 2)
+            return trace ? launch_mixed_t<2, true, int16_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t, false, true>(ctx, p, gl, grid);
+        return trace ? launch_mixed_t<4, true, int16_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<4, false, int16_t, false, true>(ctx, p, gl, grid);
+    }
     if (gl.has_ruin) {  // the ruin leaf has its own instantiations (i16 values only)
         if (ctx->levels <= 2)
             return trace ? launch_mixed_t<2, true, int16_t, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t, true>(ctx, p, gl, grid);
@@ -1445,7 +1576,8 @@ extern "C" {
 static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // the 2-leaf nearby union has its own engines; every other union runs in the generic N-leaf engine
     // a configured root union (order / weights other than the default policy's) runs in the generic engine too
-    if ((ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)) || union_is_custom(ctx))
+    if ((ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)) || union_is_custom(ctx) ||
+        (ctx->has_list_model && ctx->pm.on))  // the precedence constraint is scored by the generic engine only
         return launch_mixed(ctx, p, grid, trace);
     if (ctx->has_list_model) {
         int rc = fill_list_leaves(ctx, p);

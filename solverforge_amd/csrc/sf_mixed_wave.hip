@@ -25,6 +25,7 @@
 
 #include "sf_kopt.h"
 #include "sf_list_model.h"
+#include "sf_precedence.h"
 
 namespace sf {
 
@@ -68,6 +69,7 @@ struct GLeaves {
     int32_t weight[GL];
     int32_t has_ruin;        // the union has a list ruin leaf (kind 1024); parameters + per-solve stream in `ruin`
     RuinParams ruin;
+    PrecModel prec;          // ListPrecedenceMakespanConstraint of the list class (prec.on; PREC instantiations, sf_precedence.h)
 };
 
 template <class VT>
@@ -180,7 +182,9 @@ namespace sf {
 #define SF_MIXED_BLOCKS_PER_CU 2
 #endif
 // RUIN = the union has a list ruin leaf: its own instantiation, so unions without one keep their register allocation
-template <int L, bool TRACE, class VT, bool RUIN = false>
+// PREC = the list class carries a ListPrecedenceMakespanConstraint: every doable list candidate of a chunk is applied to the LDS
+// lists in turn, scored by one full wave-wide evaluation (prec_eval) and undone from the committed copy in HBM
+template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false>
 __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p,
                                                           int has_list, int has_scalar, NbrIndex nb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -270,6 +274,17 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     for (int k = 0; k < L; ++k) {
         cur[k] = g_score[k];
         best_sol[k] = g_best_score[k];
+    }
+    // committed (hard penalty, makespan) of the precedence constraint; the trial deltas are taken against it
+    int64_t prec_pen = 0, prec_mk = 0;
+    int32_t* const prec_E = PREC ? gl.prec.earliest + (size_t)r * gl.prec.n : nullptr;
+    int32_t* const prec_D = PREC ? gl.prec.indeg + (size_t)r * gl.prec.n : nullptr;
+    uint32_t* const prec_Q = PREC ? gl.prec.queue + (size_t)r * gl.prec.n : nullptr;
+    uint32_t* const prec_S = PREC ? gl.prec.lsucc + (size_t)r * gl.prec.n : nullptr;
+    if (PREC) {
+        const PrecResult pr = prec_eval<uint16_t>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+        prec_pen = pr.penalty;
+        prec_mk = pr.makespan;
     }
     // per-launch counters in 32 bits (wave-uniform), folded into the 64-bit sf_stats words before they can wrap
     uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;
@@ -1290,6 +1305,35 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) curv.v[kk] = cur[kk];
                 doable = doable && valid;
+                if (PREC) {
+                    uint64_t todo = __ballot(doable && my_kind >= 4 && my_kind != 1024);
+                    while (todo) {
+                        const int ci = __ffsll((unsigned long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int ck = __builtin_amdgcn_readlane(my_kind, ci);
+                        const uint32_t ca = (uint32_t)__builtin_amdgcn_readlane((int)m0, ci), cb = (uint32_t)__builtin_amdgcn_readlane((int)m1, ci);
+                        const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)mx_, ci);
+                        apply_list_move_wave(lm, s_visits, s_off, s_load,
+                                             (ck == 4 || ck == 16) ? 2 : ((ck == 8 || ck == 32) ? 3 : (ck == 64 ? 4 : (ck == 128 ? 5 : (ck == 512 ? 7 : 6)))),
+                                             ca >> 16, ca & 0xFFFFu, cb >> 16, cb & 0xFFFFu,
+                                             ck == 512 ? cx : (ck == 256 ? ((cx & 15u) | ((cx >> 4) << 16)) : (ca & 0xFFFFu) + cx));
+                        const PrecResult pr = prec_eval<uint16_t>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+                        if ((int)lane == ci) {
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) {
+                                if (kk == gl.prec.hard_level) sc.v[kk] -= pr.penalty - prec_pen;
+                                if (kk == gl.prec.mk_level) sc.v[kk] -= pr.makespan - prec_mk;
+                            }
+                        }
+                        // undo: the committed lists (written back at every commit) from HBM
+                        for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
+                        for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = g_load[t];
+                        wave_sync();
+                        const uint32_t tot = uni(s_off[V]);
+                        for (uint32_t t = lane; t < tot; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+                        wave_sync();
+                    }
+                }
                 bool acc = false;
                 if (doable) {
                     if (p.acceptor == 0)
@@ -1507,6 +1551,16 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     wave_sync();
                 }
             }
+            if (PREC && kind > 2) {  // a list move was committed: the HBM copy the trials undo from, and the constraint's committed state
+                const uint32_t tot = uni(s_off[V]);
+                for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
+                for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
+                for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = s_load[t];
+                prec_sync();
+                const PrecResult pr = prec_eval<uint16_t>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+                prec_pen = pr.penalty;
+                prec_mk = pr.makespan;
+            }
 #pragma unroll
             for (int kk = 0; kk < L; ++kk) cur[kk] = best.v[kk];
             st_applied += 1;
@@ -1562,6 +1616,10 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = s_load[t];
         }
         for (uint32_t t = lane; t < ns; t += 64) g_vals[t] = (int32_t)s_vals[t];
+        if (PREC && lane == 0) {
+            gl.prec.state[(size_t)r * 2] = prec_pen;
+            gl.prec.state[(size_t)r * 2 + 1] = prec_mk;
+        }
         if (lane == 0) {
 #pragma unroll
             for (int kk = 0; kk < L; ++kk) {

@@ -141,3 +141,29 @@ def construct_jobshop(p, seed=0):
         seqs[int(r[n + op] % np.uint64(m))].append(op)
     q["sequences"] = seqs
     return q
+
+
+def make_precedence_shop(n_jobs=10, n_machines=5, seed=0, scheduled=True, max_duration=9):
+    """Classic job shop for the ListPrecedenceMakespanConstraint: operation id = job * n_machines + step; the job order is the
+    fixed successor relation, every operation has a duration in 1..max_duration and an expected machine (a seeded permutation of
+    the machines per job).  scheduled: every machine's sequence holds its operations in job order (acyclic: an operation's
+    sequence position follows the job index, its job predecessors sit on other machines ... not necessarily acyclic -- the
+    constraint scores cycles too); otherwise the sequences are empty."""
+    n = n_jobs * n_machines
+    r = stream(seed + 777, 3 * n + 1)
+    dur = (r[:n] % np.uint64(max_duration)).astype(np.int64) + 1
+    owner = np.zeros(n, dtype=np.int64)
+    for j in range(n_jobs):  # Fisher-Yates with the documented stream
+        perm = list(range(n_machines))
+        for k in range(n_machines - 1, 0, -1):
+            q = int(r[n + j * n_machines + k] % np.uint64(k + 1))
+            perm[k], perm[q] = perm[q], perm[k]
+        owner[j * n_machines:(j + 1) * n_machines] = perm
+    succ = [[op + 1] if (op % n_machines) + 1 < n_machines else [] for op in range(n)]
+    seqs = [[] for _ in range(n_machines)]
+    if scheduled:  # step-major order: every machine sees its operations by (step, job) -- a feasible (acyclic) schedule
+        for step in range(n_machines):
+            for j in range(n_jobs):
+                op = j * n_machines + step
+                seqs[int(owner[op])].append(op)
+    return {"durations": dur, "successors": succ, "expected_owner": owner, "sequences": seqs, "n_jobs": n_jobs, "n_machines": n_machines}

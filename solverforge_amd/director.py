@@ -152,6 +152,19 @@ class GpuScoreDirector:
         check(self._L.sf_constraint_add(self._h, kind, descriptor_index, variable_index, fact, param, level, weight), self._h)
         self._n_constraints = getattr(self, "_n_constraints", 0) + 1
 
+    def add_list_precedence(self, descriptor_index, durations, successors, expected_owner=None, hard_level=0, makespan_level=1,
+                            variable_index=0):
+        """ListPrecedenceMakespanConstraint (constraint/list_precedence.rs): `successors[node]` = fixed successor ids."""
+        dur = np.ascontiguousarray(durations, dtype=np.int32)
+        off = np.zeros(len(successors) + 1, dtype=np.uint32)
+        for i, l in enumerate(successors):
+            off[i + 1] = off[i] + len(l)
+        vals = np.array([v for l in successors for v in l] or [0], dtype=np.uint32)
+        eo = None if expected_owner is None else np.ascontiguousarray(expected_owner, dtype=np.int32)
+        check(self._L.sf_constraint_add_list_precedence(self._h, descriptor_index, variable_index, len(dur), ptr(dur), ptr(off), ptr(vals),
+                                                        None if eo is None else ptr(eo), hard_level, makespan_level), self._h)
+        self._n_constraints = getattr(self, "_n_constraints", 0) + 1
+
     def evaluate_each(self, replica=0):
         """ConstraintSet::evaluate_each: (scores [n_constraints, levels], match counts) in declaration order."""
         n = getattr(self, "_n_constraints", 0)

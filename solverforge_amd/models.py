@@ -129,6 +129,32 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
     return d
 
 
+def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_change", "list_swap"), levels=2, hard_levels=1,
+                          hard_level=0, makespan_level=1, with_owner=True):
+    """Job shop with the makespan objective: class 0 = machines with the list variable `sequence` of operation ids; the one
+    constraint is the ListPrecedenceMakespanConstraint (crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707) over
+    the job order (fixed successors), the machine sequences and the expected machine of every operation."""
+    d = GpuScoreDirector(score_levels=levels, hard_levels=hard_levels, n_replicas=n_replicas, device_id=device_id)
+    n = len(problem["durations"])
+    d.add_entity_class(0, len(problem["sequences"]))
+    d.add_list_variable(0, problem["sequences"], element_capacity=n, element_id_bound=n)
+    d.add_list_precedence(0, problem["durations"], problem["successors"], problem["expected_owner"] if with_owner else None,
+                          hard_level=hard_level, makespan_level=makespan_level)
+    if "list_change" in leaves:
+        d.add_selector(SelectorKind.LIST_CHANGE, 0)
+    if "list_swap" in leaves:
+        d.add_selector(SelectorKind.LIST_SWAP, 0)
+    if "sublist_change" in leaves:
+        d.add_sublist_selector(SelectorKind.SUBLIST_CHANGE, 0)
+    if "sublist_swap" in leaves:
+        d.add_sublist_selector(SelectorKind.SUBLIST_SWAP, 0)
+    if "list_reverse" in leaves:
+        d.add_selector(SelectorKind.LIST_REVERSE, 0)
+    if "kopt" in leaves:
+        d.add_kopt_selector(0, max_nearby=0)
+    return d
+
+
 def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=-1, leaves=("change", "swap"), arity=2):
     """Bin balance: the keyed self-join (pairs of entities sharing a bin — IncrementalBiConstraint,
     constraint/nary_incremental/bi.rs:12-313) and the grouped sum (group_by(bin, sum(size)) with

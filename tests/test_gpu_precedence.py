@@ -1,0 +1,201 @@
+"""GPU parity tests (through the C ABI): ListPrecedenceMakespanConstraint (constraint/list_precedence.rs) on the device --
+full scores of acyclic / cyclic / partly scheduled job shops, evaluate_each, trial scores of every list move kind
+(sf_step_evaluate and the generic engine's cursor), committed moves, traced and fused steps vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LEAF_BITS = {"list_change": 4, "list_swap": 8, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512}
+
+
+def _t(moves):
+    return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"], moves["value"]], axis=1)
+
+
+def _shuffled(p, seed, drop=0):
+    """The scheduled shop with every sequence permuted by the documented stream (cycles likely) and `drop` operations removed."""
+    from solverforge_amd import datasets
+
+    q = dict(p)
+    seqs = [list(s) for s in p["sequences"]]
+    r = datasets.stream(seed, 4096)
+    k = 0
+    for s in seqs:
+        for i in range(len(s) - 1, 0, -1):
+            j = int(r[k] % np.uint64(i + 1))
+            k += 1
+            s[i], s[j] = s[j], s[i]
+    for _ in range(drop):
+        v = int(r[k] % np.uint64(len(seqs)))
+        k += 1
+        if seqs[v]:
+            seqs[v].pop(int(r[k] % np.uint64(len(seqs[v]))))
+            k += 1
+    q["sequences"] = seqs
+    return q
+
+
+def _mk(oracle, p, leaves=("list_change", "list_swap"), n_replicas=1, with_owner=True, levels=2, hard_levels=1, hard_level=0, mk_level=1):
+    import solverforge_amd as sfa
+
+    d = sfa.build_precedence_shop(p, n_replicas=n_replicas, leaves=leaves, with_owner=with_owner, levels=levels, hard_levels=hard_levels,
+                                  hard_level=hard_level, makespan_level=mk_level)
+    o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"] if with_owner else None,
+                                     levels=levels, hard_levels=hard_levels, hard_level=hard_level, soft_level=mk_level)
+    bits = 0
+    for name in leaves:
+        bits |= LEAF_BITS[name]
+    return d, o, bits
+
+
+def test_reference_known_answers(oracle):
+    """The two-task plan of the reference's own tests (list_precedence.rs:905-913, 1067-1079, 1156-1164) through the C ABI."""
+    base = {"durations": [2, 3], "successors": [[1], []], "expected_owner": [0, 1]}
+    for seqs, owner, want in [([[0], [1]], False, [0, -5]), ([[1, 0], []], False, [-2, 0]), ([[0], []], True, [-1, -5])]:
+        p = dict(base, sequences=seqs)
+        d, o, _ = _mk(oracle, p, with_owner=owner)
+        got = d.calculate_score()[0]
+        assert got.tolist() == want and (o.score()[:2] == got).all(), (seqs, got)
+        assert (d.fresh_score()[0] == got).all()
+
+
+@pytest.mark.parametrize("jobs,machines,seed,drop,owner", [(6, 4, 1, 0, True), (10, 5, 2, 3, True), (12, 6, 3, 0, False), (20, 10, 4, 7, True)])
+def test_full_scores_and_evaluate_each(oracle, jobs, machines, seed, drop, owner):
+    from solverforge_amd import datasets
+
+    p0 = datasets.make_precedence_shop(jobs, machines, seed=seed)
+    for p in (p0, _shuffled(p0, seed, drop), datasets.make_precedence_shop(jobs, machines, seed=seed, scheduled=False)):
+        d, o, _ = _mk(oracle, p, with_owner=owner)
+        got = d.calculate_score()[0]
+        assert (got == o.score()[:2]).all(), (got, o.score())
+        assert (d.fresh_score()[0] == got).all()
+        gs, gc = d.evaluate_each()
+        os_, oc = o.evaluate_each()
+        assert (gs == os_[:, :2]).all() and (gc == oc).all()
+    d, o, _ = _mk(oracle, p0, with_owner=owner)
+    assert d.calculate_score()[0][0] == 0 and d.calculate_score()[0][1] < 0  # the step-major schedule is feasible
+
+
+@pytest.mark.parametrize("state", ["scheduled", "shuffled"])
+def test_trial_scores_every_list_move_kind(oracle, state):
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(7, 4, seed=5)
+    if state == "shuffled":
+        p = _shuffled(p, 9, 2)
+    leaves = ("list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt")
+    d, o, bits = _mk(oracle, p, leaves=leaves)
+    o.set_kopt(1, 0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    for order in (0, 3):
+        o.configure(leaves=bits, selection_order=order)
+        gm, gs, gd = d.open_cursor(2, 31, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 2, 31, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm) == _t(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+        es, ed = d.evaluate_moves(om)  # sf_step_evaluate on host-provided records
+        assert (ed == od).all() and (es == os_[:, :2]).all()
+    kinds = set(int(k) for k in _t(gm)[:, 0])
+    assert kinds == {2, 3, 4, 5, 6, 7}
+
+
+def test_apply_traced_and_fused_steps(oracle):
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = _shuffled(datasets.make_precedence_shop(8, 4, seed=7), 3, 1)
+    leaves = ("list_change", "list_swap", "sublist_change", "list_reverse")
+    d, o, bits = _mk(oracle, p, leaves=leaves)
+    d.calculate_score()
+    o.configure(leaves=bits, random_seed=4, la_size=6, limit=24)
+    d.configure(sfa.SolverConfig(random_seed=4, late_acceptance_size=6, accepted_count_limit=24))
+    rng = np.random.default_rng(2)
+    for it in range(6):  # committed moves through sf_apply
+        mv = o.enumerate(0, it, 50 + it, 3)
+        sc, do = o.evaluate_moves(mv)
+        mv = mv[do != 0]
+        mv = mv[rng.integers(len(mv))]
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert d.working_lists(0, 0) == o.get_lists(0), it
+        assert (d.calculate_score()[0] == o.score()[:2]).all(), it
+        assert (d.fresh_score()[0] == o.score()[:2]).all(), it
+    d.phase_start()
+    o.phase_start()
+    for step in range(20):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+        assert d.working_lists(0, 0) == o.get_lists(0), step
+    d.solve_steps(60)
+    o.steps(60)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k] == ost[k], k
+
+
+def test_multi_replica_search_leaves_the_cycle_and_improves(oracle):
+    """8 replicas, distinct seeds: every replica == its own oracle run; starting cyclic (hard = -n), the search reaches a feasible
+    schedule and a shorter makespan than the step-major start."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p0 = datasets.make_precedence_shop(6, 3, seed=11)
+    p = _shuffled(p0, 5)
+    R = 8
+    d, _, bits = _mk(oracle, p, n_replicas=R)
+    d.calculate_score()
+    d.configure(sfa.SolverConfig(random_seed=100, late_acceptance_size=20, accepted_count_limit=32))
+    d.phase_start()
+    d.solve_steps(150)
+    got = d.calculate_score()
+    best = d.best_scores()
+    for r in (0, 3, 7):
+        o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+        o.configure(leaves=bits, random_seed=100 + r, la_size=20, limit=32)
+        o.phase_start()
+        o.steps(150)
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        assert (got[r] == o.score()[:2]).all(), r
+        assert (best[r] == o.best_score()[:2]).all(), r
+    assert (d.fresh_score() == got).all()
+    assert best[:, 0].max() == 0
+
+
+def test_three_levels_and_validation(oracle):
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = _shuffled(datasets.make_precedence_shop(5, 3, seed=2), 8)
+    d, o, bits = _mk(oracle, p, levels=3, hard_levels=2, hard_level=1, mk_level=2)
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    o.configure(leaves=bits, random_seed=1, la_size=4, limit=16)
+    d.configure(sfa.SolverConfig(random_seed=1, late_acceptance_size=4, accepted_count_limit=16))
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(30)
+    o.steps(30)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    # limits: duplicate list items, element ids >= node_count, equal levels
+    bad = dict(p, sequences=[[0, 1], [1], []])
+    with pytest.raises(sfa.SolverForgeError):
+        sfa.build_precedence_shop(bad).calculate_score()
+    with pytest.raises(sfa.SolverForgeError):
+        sfa.build_precedence_shop(p, hard_level=1, makespan_level=1)
+    d2 = sfa.GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=1)
+    d2.add_entity_class(0, 2)
+    d2.add_list_variable(0, [[0], [5]], element_capacity=8, element_id_bound=8)
+    d2.add_list_precedence(0, [1, 1], [[1], []])
+    with pytest.raises(sfa.SolverForgeError):
+        d2.calculate_score()
