@@ -1458,7 +1458,8 @@ template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
-                  gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0);
+                  gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
+                  PREC && gl.prec_lds ? gl.prec.n : 0);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for 2 workgroups of 4 waves per CU); ties go to the larger group
@@ -1551,6 +1552,10 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // replica's value array in one byte per entity: job shop 500 x 20 fits 4 waves per CU instead of 3)
     gl.levels = ctx->levels;
     gl.prec = ctx->has_list_model ? ctx->pm : PrecModel{};
+    {  // the Kahn scratch (16 bytes per node) goes to LDS while at least 4 replicas still fit a CU
+        static const bool no_lds = std::getenv("SF_AMD_PREC_HBM") != nullptr;  // diagnostics / parity tests: force the HBM scratch
+        gl.prec_lds = (gl.prec.on && !no_lds && (size_t)gl.prec.n * 16 <= 36 * 1024) ? 1 : 0;
+    }
     if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations (i16 values only)
         if (ctx->levels <= 2)
             return trace ? launch_mixed_t<2, true, int16_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t, false, true>(ctx, p, gl, grid);

@@ -70,16 +70,19 @@ struct GLeaves {
     int32_t has_ruin;        // the union has a list ruin leaf (kind 1024); parameters + per-solve stream in `ruin`
     RuinParams ruin;
     PrecModel prec;          // ListPrecedenceMakespanConstraint of the list class (prec.on; PREC instantiations, sf_precedence.h)
+    int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
 };
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, leaftab, total;
+    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, leaftab, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
     // n_leaves rings only: the LDS slice decides how many replicas a CU holds
     // has_ruin: 0 no ruin leaf, 1 general path (slot prefix only), 2 LDS fast path (+ edge table, list-end edges, matrix row; sf_ruin.h)
-    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0) {
+    // prec_words: node count of the precedence constraint when its four scratch arrays live in LDS (sf_precedence.h), else 0
+    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0,
+                               int prec_words = 0) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * GRC * n_leaves, 16);
@@ -109,6 +112,8 @@ struct GCarve {
         o = align_up(o + (has_ruin ? RUIN_LDS_BYTES + sizeof(uint32_t) * (V + 1) : 0), 16);  // + the slot prefix of a recreate round
         ruin_fast = o;  // edge[dim], row[dim], edge_end[V], slot[n_cap + V]
         o = align_up(o + (has_ruin == 2 ? sizeof(uint16_t) * (2 * (size_t)dim + 2 * (size_t)V + n_cap) : 0), 16);
+        prec = o;  // earliest start, in-degree, queue, list successor of the precedence constraint's Kahn pass
+        o = align_up(o + sizeof(uint32_t) * 4 * (size_t)prec_words, 16);
         leaftab = o;  // per-leaf generator / ring / scheduler state (LeafTab)
         o = align_up(o + sizeof(uint32_t) * 16 * GL, 16);
         total = o;
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
     const bool unified_eval = has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval;
-    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim);
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim,
+                        PREC && gl.prec_lds ? gl.prec.n : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
     uint8_t* ringx = (uint8_t*)(mem + cv.ringx);  // [leaf][GRC]
@@ -277,10 +283,11 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     }
     // committed (hard penalty, makespan) of the precedence constraint; the trial deltas are taken against it
     int64_t prec_pen = 0, prec_mk = 0;
-    int32_t* const prec_E = PREC ? gl.prec.earliest + (size_t)r * gl.prec.n : nullptr;
-    int32_t* const prec_D = PREC ? gl.prec.indeg + (size_t)r * gl.prec.n : nullptr;
-    uint32_t* const prec_Q = PREC ? gl.prec.queue + (size_t)r * gl.prec.n : nullptr;
-    uint32_t* const prec_S = PREC ? gl.prec.lsucc + (size_t)r * gl.prec.n : nullptr;
+    const bool prec_in_lds = PREC && gl.prec_lds != 0;
+    int32_t* const prec_E = !PREC ? nullptr : (prec_in_lds ? (int32_t*)(mem + cv.prec) : gl.prec.earliest + (size_t)r * gl.prec.n);
+    int32_t* const prec_D = !PREC ? nullptr : (prec_in_lds ? prec_E + gl.prec.n : gl.prec.indeg + (size_t)r * gl.prec.n);
+    uint32_t* const prec_Q = !PREC ? nullptr : (prec_in_lds ? (uint32_t*)(prec_D + gl.prec.n) : gl.prec.queue + (size_t)r * gl.prec.n);
+    uint32_t* const prec_S = !PREC ? nullptr : (prec_in_lds ? prec_Q + gl.prec.n : gl.prec.lsucc + (size_t)r * gl.prec.n);
     if (PREC) {
         const PrecResult pr = prec_eval<uint16_t>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
         prec_pen = pr.penalty;
@@ -1325,12 +1332,14 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 if (kk == gl.prec.mk_level) sc.v[kk] -= pr.makespan - prec_mk;
                             }
                         }
-                        // undo: the committed lists (written back at every commit) from HBM
-                        for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
-                        for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = g_load[t];
+                        // undo: the owners the move touched, from the committed lists in HBM (written back at every commit)
+                        const uint32_t la_ = ca >> 16, lb_ = (ck == 512 || ck == 64) ? la_ : (cb >> 16);  // 3-opt / reverse: one owner
+                        const uint32_t l_lo = la_ < lb_ ? la_ : lb_, l_hi = la_ < lb_ ? lb_ : la_;
+                        for (uint32_t t = l_lo + lane; t <= l_hi + 1; t += 64) s_off[t] = g_off[t];
+                        for (uint32_t t = l_lo + lane; t <= l_hi; t += 64) s_load[t] = g_load[t];
                         wave_sync();
-                        const uint32_t tot = uni(s_off[V]);
-                        for (uint32_t t = lane; t < tot; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+                        const uint32_t r_lo = uni(s_off[l_lo]), r_hi = uni(s_off[l_hi + 1]);
+                        for (uint32_t t = r_lo + lane; t < r_hi; t += 64) s_visits[t] = (uint16_t)g_visits[t];
                         wave_sync();
                     }
                 }
