@@ -74,6 +74,7 @@ def lib():
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
             "sfo_precedence_shop_create": (vp, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
+            "sfo_jobshop_create_makespan": (vp, [i32, i32, vp, vp, vp, vp, i32, i32, vp]),
             "sfo_model_destroy": (None, [vp]),
             "sfo_model_score": (None, [vp, vp]),
             "sfo_model_fresh_score": (None, [vp, vp]),
@@ -212,10 +213,16 @@ class Model:
         return Model(h, [len(lists)])
 
     @staticmethod
-    def jobshop(job, machine_idx, sequences, bendable=True, indexed=False):
+    def jobshop(job, machine_idx, sequences, bendable=True, indexed=False, durations=None):
+        """durations: adds the ListPrecedenceMakespanConstraint (job order + machine sequences) -- the makespan objective."""
         job = np.ascontiguousarray(job, dtype=np.int64)
         machine_idx = np.ascontiguousarray(machine_idx, dtype=np.int64)
         off, vals = csr(sequences)
+        if durations is not None:
+            dur = np.ascontiguousarray(durations, dtype=np.int64)
+            h = lib().sfo_jobshop_create_makespan(len(job), len(sequences), _p(job), _p(machine_idx), _p(off), _p(vals), int(bendable),
+                                                  int(indexed), _p(dur))
+            return Model(h, [len(job), len(sequences)])
         fn = lib().sfo_jobshop_create_indexed if indexed else lib().sfo_jobshop_create
         h = fn(len(job), len(sequences), _p(job), _p(machine_idx), _p(off), _p(vals), int(bendable))
         return Model(h, [len(job), len(sequences)])

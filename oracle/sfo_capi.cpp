@@ -136,6 +136,10 @@ void* sfo_list_toy_create(int32_t n_entities, const uint32_t* off, const uint32_
     return make_list_toy((size_t)n_entities, off, vals, meter == 0 ? ToyMeter::Equal : ToyMeter::Position)
         .release();
 }
+void* sfo_jobshop_create_makespan(int32_t n_ops, int32_t n_machines, const int64_t* job, const int64_t* machine_idx, const uint32_t* seq_off,
+                                  const uint32_t* seq_vals, int32_t bendable, int32_t indexed, const int64_t* duration) {
+    return make_jobshop((size_t)n_ops, (size_t)n_machines, job, machine_idx, seq_off, seq_vals, bendable != 0, indexed != 0, duration).release();
+}
 void* sfo_jobshop_create(int32_t n_ops, int32_t n_machines, const int64_t* job, const int64_t* machine_idx,
                          const uint32_t* seq_off, const uint32_t* seq_vals, int32_t bendable) {
     return make_jobshop((size_t)n_ops, (size_t)n_machines, job, machine_idx, seq_off, seq_vals, bendable != 0)

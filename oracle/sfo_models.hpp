@@ -582,7 +582,8 @@ inline std::unique_ptr<Model> make_list_toy(size_t n_entities, const uint32_t* o
 // HardSoftScore; Bendable is a BASELINE.json requirement)
 inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, const int64_t* job,
                                            const int64_t* machine_idx, const uint32_t* seq_off,
-                                           const uint32_t* seq_vals, bool bendable, bool indexed = false) {
+                                           const uint32_t* seq_vals, bool bendable, bool indexed = false,
+                                           const int64_t* duration = nullptr) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<JobShopFacts>();
     facts->n_ops = n_ops;
@@ -658,6 +659,24 @@ inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, cons
     } else
         m->director.constraints.members.push_back(std::move(reuse));
 
+    if (duration) {  // the makespan objective: ListPrecedenceMakespanConstraint over the job order and the machine sequences
+        auto dur = std::make_shared<std::vector<int64_t>>(duration, duration + n_ops);
+        auto c = std::make_unique<ListPrecedenceConstraint>();
+        c->name = "listPrecedenceMakespan";
+        c->is_hard = true;
+        c->list_descriptor = 1;
+        c->node_count = [n_ops](const Solution&) { return n_ops; };
+        c->node_duration = [dur](const Solution&, size_t n) { return (*dur)[n]; };
+        c->fixed_successors = [jf, n_ops](const Solution&, size_t n, std::vector<size_t>& out) {  // the next operation of the same job
+            if (n + 1 < n_ops && jf->job[n + 1] == jf->job[n]) out.push_back(n + 1);
+        };
+        c->owner_count = [](const Solution& s) { return s.classes[1].n; };
+        c->list_len = [](const Solution& s, size_t o) { return s.classes[1].lists[o].size(); };
+        c->list_get = [](const Solution& s, size_t o, size_t p) { return (int64_t)s.classes[1].lists[o][p]; };
+        c->hard = bendable ? Score::level(1, 1) : Score::of(1, 0);
+        c->soft = bendable ? Score::level(2, 1) : Score::of(0, 1);
+        m->director.constraints.members.push_back(std::move(c));
+    }
     m->has_scalar = true;
     m->scalar_slot.descriptor_index = 0;
     m->scalar_slot.variable_index = 0;

@@ -87,7 +87,7 @@ def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap")):
 
 
 def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
-                  leaves=("list_change", "list_swap", "change", "swap")):
+                  leaves=("list_change", "list_swap", "change", "swap"), makespan=False):
     """Mixed job shop (examples/mixed-job-shop/src/domain/job_shop_plan.rs:28-69): class 0 =
     operations with the scalar `machine_idx` (0..n_machines, allows_unassigned), class 1 = machines
     with the list variable `sequence` of operation ids.  BendableScore<2,1> (BASELINE.json):
@@ -108,6 +108,10 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
     d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=lv[0], weight=1)
     d.add_constraint(ConstraintKind.NOT_EXISTS_FLATTENED, 1, fact=FACT_CUSTOMERS, level=lv[1], weight=1)
     d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=lv[2], weight=1)
+    if makespan:  # the makespan objective (constraint/list_precedence.rs): job order = fixed successors, problem["durations"]
+        job = np.asarray(problem["job"])
+        succ = [[op + 1] if op + 1 < n_ops and job[op + 1] == job[op] else [] for op in range(n_ops)]
+        d.add_list_precedence(1, problem["durations"], succ, None, hard_level=lv[1], makespan_level=lv[2])
     if "list_change" in leaves:
         d.add_selector(SelectorKind.LIST_CHANGE, 1)
     if "list_swap" in leaves:

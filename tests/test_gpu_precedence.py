@@ -199,3 +199,50 @@ def test_three_levels_and_validation(oracle):
     d2.add_list_precedence(0, [1, 1], [[1], []])
     with pytest.raises(sfa.SolverForgeError):
         d2.calculate_score()
+
+
+def test_mixed_jobshop_with_makespan(oracle):
+    """The mixed job shop (scalar machine_idx + machine sequences, BendableScore<2,1>) with the makespan objective added: list and
+    scalar leaves in one union, the precedence constraint on the list class of a two-class model."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.construct_jobshop(datasets.make_jobshop(9, 4), seed=3)
+    p["durations"] = (datasets.stream(5, p["n_ops"]) % np.uint64(9)).astype(np.int64) + 1
+    p["sequences"][2] = p["sequences"][2][::-1]  # one machine against the job order: cycles
+    d = sfa.build_jobshop(p, makespan=True)
+    o = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, durations=p["durations"])
+    bits = 4 | 8 | 1 | 2
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    gs, gc = d.evaluate_each()
+    os_, oc = o.evaluate_each()
+    assert (gs == os_[:, :3]).all() and (gc == oc).all()
+    for order in (0, 3):
+        o.configure(leaves=bits, selection_order=order)
+        gm, gsc, gd = d.open_cursor(1, 5, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 1, 5, order)
+        assert len(gm) == len(om) > 0 and (_t(gm) == _t(om)).all()
+        osc, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gsc == osc[:, :3]).all()
+        es, ed = d.evaluate_moves(om)
+        assert (ed == od).all() and (es == osc[:, :3]).all()
+    o.configure(leaves=bits, random_seed=2, la_size=8, limit=32)
+    d.configure(sfa.SolverConfig(random_seed=2, late_acceptance_size=8, accepted_count_limit=32))
+    d.phase_start()
+    o.phase_start()
+    kinds = set()
+    for step in range(15):
+        gm, gsc, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, osc, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gsc == osc[:, :3]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+            kinds.add(int(gmv["kind"]))
+    d.solve_steps(80)
+    o.steps(80)
+    assert d.working_lists(1, 0) == o.get_lists(1)
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    assert (d.fresh_score()[0] == o.score()[:3]).all()
