@@ -133,7 +133,14 @@ typedef enum sf_constraint_kind {
     SF_C_BALANCE_VALUE = 13,
     /* ListPrecedenceMakespanConstraint (crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707); declared through
      * sf_constraint_add_list_precedence, listed here for its place in the sf_evaluate_each order */
-    SF_C_LIST_PRECEDENCE_MAKESPAN = 14
+    SF_C_LIST_PRECEDENCE_MAKESPAN = 14,
+    /* for_each(E).filter(assigned).group_by(value, consecutive_runs(fact_a)).penalize(weight * sum over the runs of
+     * max(0, run.point_count - param)) -- the grouped node with the consecutive-runs collector (stream/collector/runs.rs:11-229;
+     * the "long work streaks" constraint of examples/minimal-shift-scheduling/src/domain/schedule.rs:45-59).  `fact_a` = i32 point
+     * column (one point per entity, 0 <= point < 4096; duplicates count once per run), `param` = the run length that is still free.
+     * The device keeps a [n_values][points] count table in LDS (<= 48 KiB); a trial reads the run lengths either side of the moved
+     * point.  Scalar engine only; not chained in compound candidates */
+    SF_C_RUNS_VALUE = 15
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {

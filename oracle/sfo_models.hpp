@@ -744,4 +744,79 @@ inline std::unique_ptr<Model> make_precedence_shop(size_t n_nodes, size_t n_owne
     return m;
 }
 
+// ---- shift scheduling (examples/minimal-shift-scheduling/src/domain/schedule.rs:21-83): shifts choose a nurse ---------------
+//   hard: unassigned shift (uni); two shifts of one nurse on one day (predicate cross-join, :31-43)
+//   soft: long work streaks -- group_by(nurse, consecutive_runs(day)).penalize(sum over runs of max(0, point_count - limit)) (:45-59)
+//   soft (count_weight > 0): group_by(nurse, count()).penalize(count^2) (the grouped count node; the example's complemented
+//         |count - target| form needs the complement node, which this build does not restate)
+struct ShiftFacts {
+    std::vector<int64_t> day;
+};
+inline std::unique_ptr<Model> make_shift_schedule(size_t n_shifts, size_t n_nurses, const int64_t* nurse_idx, const int64_t* day, int64_t limit,
+                                                  int64_t w_streak, int64_t count_weight) {
+    auto m = std::make_unique<Model>();
+    auto facts = std::make_shared<ShiftFacts>();
+    facts->day.assign(day, day + n_shifts);
+    Solution& s = m->director.working;
+    s.classes.resize(1);
+    s.classes[0].n = n_shifts;
+    s.classes[0].vars.assign(1, std::vector<int64_t>(nurse_idx, nurse_idx + n_shifts));
+    s.facts = facts;
+    const ShiftFacts* sf = facts.get();
+    m->director.constraints.members.push_back(make_unassigned(0, 0, Score::of(1, 0), "Unassigned required shift"));
+
+    auto clash = std::make_unique<CrossBiConstraint>();
+    clash->name = "One shift per nurse day";
+    clash->impact = Impact::Penalty;
+    clash->a_source = clash->b_source = ChangeSource::descriptor(0);
+    clash->a_count = clash->b_count = [](const Solution& s) { return s.classes[0].n; };
+    clash->key_a = clash->key_b = [](const Solution&, size_t) { return (int64_t)0; };
+    clash->filter = [sf](const Solution& s, size_t a, size_t b) {
+        if (!(a < b) || sf->day[a] != sf->day[b]) return false;
+        int64_t na = s.classes[0].vars[0][a];
+        return na != NONE && na == s.classes[0].vars[0][b];
+    };
+    clash->weight = [](const Solution&, size_t, size_t) { return Score::of(1, 0); };
+    m->director.constraints.members.push_back(std::move(clash));
+
+    auto streak = std::make_unique<GroupedRunsConstraint>();
+    streak->name = "Long work streaks";
+    streak->impact = Impact::Penalty;
+    streak->source = ChangeSource::descriptor(0);
+    streak->count = [](const Solution& s) { return s.classes[0].n; };
+    streak->filter = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i] != NONE; };
+    streak->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    streak->point = [sf](const Solution&, size_t i) { return sf->day[i]; };
+    streak->weight = [limit, w_streak](int64_t, const Runs& runs) {
+        int64_t excess = 0;
+        for (auto& r : runs.runs) excess += (int64_t)r.point_count > limit ? (int64_t)r.point_count - limit : 0;  // saturating_sub
+        return Score::of(0, w_streak * excess);
+    };
+    m->director.constraints.members.push_back(std::move(streak));
+
+    if (count_weight > 0) {
+        auto load = std::make_unique<GroupedConstraint>();
+        load->name = "Workload";
+        load->impact = Impact::Penalty;
+        load->source = ChangeSource::descriptor(0);
+        load->count = [](const Solution& s) { return s.classes[0].n; };
+        load->filter = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i] != NONE; };
+        load->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+        load->value = [](const Solution&, size_t) { return (int64_t)1; };
+        load->weight = [count_weight](int64_t, int64_t c) { return Score::of(0, count_weight * c * c); };
+        m->director.constraints.members.push_back(std::move(load));
+    }
+    m->has_scalar = true;
+    m->scalar_slot.descriptor_index = 0;
+    m->scalar_slot.variable_index = 0;
+    m->scalar_slot.allows_unassigned = true;
+    m->scalar_slot.values_for_entity = [n_nurses](const Solution&, size_t, std::vector<int64_t>& out) {
+        out.clear();
+        for (size_t v = 0; v < n_nurses; ++v) out.push_back((int64_t)v);
+    };
+    m->leaves = LEAF_SCALAR_CHANGE | LEAF_SCALAR_SWAP;
+    m->wire_search();
+    return m;
+}
+
 }  // namespace sfo

@@ -12,6 +12,7 @@
 //   crates/solverforge-scoring/src/constraint/exists.rs:42-437 + exists/key_state.rs
 //   crates/solverforge-scoring/src/constraint/grouped/{state,scorer,shared_set}.rs
 //   crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707 (ListPrecedenceMakespanConstraint)
+//   crates/solverforge-scoring/src/stream/collector/runs.rs:11-229 (consecutive_runs collector)
 //   crates/solverforge-scoring/src/api/constraint_set/incremental.rs:339-407 (tuple fold)
 //   crates/solverforge-scoring/src/director/score_director/incremental.rs:141-218
 #pragma once
@@ -967,6 +968,190 @@ struct GroupedConstraint : Constraint {
         Score total;
         for (size_t g = 0; g < groups.size(); ++g) {
             Score sc = groups[g].count == 0 ? Score::zero() : compute(groups[g].key, groups[g].acc);
+            replace_cached(g, sc);
+            total = total + sc;
+        }
+        return total;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {
+        changed_groups.clear();
+        if (!source.assert_localizes(d, name)) return refresh_changed();
+        if (e < count(s) && filter(s, e)) insert_entity(s, e);
+        return refresh_changed();
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {
+        (void)s;
+        changed_groups.clear();
+        if (!source.assert_localizes(d, name)) return refresh_changed();
+        retract_entity(e);
+        return refresh_changed();
+    }
+    void reset() override {
+        groups.clear();
+        group_of_key.clear();
+        entity_groups.clear();
+        entity_retractions.clear();
+        changed_groups.clear();
+        cached_scores.clear();
+    }
+};
+
+// ---- consecutive_runs collector (stream/collector/runs.rs:11-229) ------------------------------------------------------------
+// Points (i64) with multiplicity in an ordered map; the result lists the maximal runs of consecutive unique points, each with
+// its unique-point count and its item count (duplicates included).
+struct Run {
+    int64_t start, end;
+    size_t point_count, item_count;
+};
+struct Runs {
+    std::vector<Run> runs;
+    size_t point_count = 0, item_count = 0;
+};
+struct RunsAccumulator {  // runs.rs:126-172
+    std::map<int64_t, size_t> points;
+    size_t item_count = 0;
+    void accumulate(int64_t v) {
+        ++points[v];
+        ++item_count;
+    }
+    void retract(int64_t v) {
+        auto it = points.find(v);
+        if (it == points.end()) return;
+        it->second = it->second > 0 ? it->second - 1 : 0;
+        item_count = item_count > 0 ? item_count - 1 : 0;
+        if (it->second == 0) points.erase(it);
+    }
+    Runs finish() const {  // runs_from_counts_and_item_count (:178-229)
+        Runs r;
+        r.point_count = points.size();
+        r.item_count = item_count;
+        bool open = false;
+        int64_t start = 0, prev = 0;
+        size_t pc = 0, ic = 0;
+        for (auto& kv : points) {
+            if (!open) {
+                open = true;
+                start = prev = kv.first;
+                pc = 1;
+                ic = kv.second;
+            } else if (prev != INT64_MAX && prev + 1 == kv.first) {  // checked_add(1) == Some(point)
+                prev = kv.first;
+                pc += 1;
+                ic += kv.second;
+            } else {
+                r.runs.push_back({start, prev, pc, ic});
+                start = prev = kv.first;
+                pc = 1;
+                ic = kv.second;
+            }
+        }
+        if (open) r.runs.push_back({start, prev, pc, ic});
+        return r;
+    }
+    void reset() {
+        points.clear();
+        item_count = 0;
+    }
+};
+
+// for_each(E).filter(f).group_by(key, consecutive_runs(point)).penalize(w(key, runs)): the grouped node
+// (constraint/grouped/state.rs:43-247, scorer.rs:46-152) with the runs accumulator per group
+struct GroupedRunsConstraint : Constraint {
+    Impact impact;
+    ChangeSource source;
+    CountFn count;
+    Filter1 filter;
+    Key1 key;
+    Value1 point;
+    std::function<Score(int64_t, const Runs&)> weight;
+
+    struct Group {
+        int64_t key;
+        RunsAccumulator acc;
+        size_t count;
+    };
+    std::vector<Group> groups;
+    std::unordered_map<int64_t, size_t> group_of_key;
+    std::unordered_map<size_t, size_t> entity_groups;
+    std::unordered_map<size_t, int64_t> entity_retractions;
+    std::vector<size_t> changed_groups;
+    std::vector<Score> cached_scores;
+
+    Score compute(const Group& g) const { return g.count == 0 ? Score::zero() : apply_impact(impact, weight(g.key, g.acc.finish())); }
+    void mark_changed(size_t g) {
+        for (size_t c : changed_groups)
+            if (c == g) return;
+        changed_groups.push_back(g);
+    }
+    size_t group_id_for_key(int64_t k) {
+        auto it = group_of_key.find(k);
+        if (it != group_of_key.end()) return it->second;
+        size_t g = groups.size();
+        groups.push_back({k, RunsAccumulator(), 0});
+        group_of_key[k] = g;
+        return g;
+    }
+    void insert_entity(const Solution& s, size_t idx) {  // state.rs:216-229
+        size_t g = group_id_for_key(key(s, idx));
+        if (groups[g].count == 0) groups[g].acc.reset();
+        int64_t v = point(s, idx);
+        groups[g].acc.accumulate(v);
+        groups[g].count += 1;
+        entity_groups[idx] = g;
+        entity_retractions[idx] = v;
+        mark_changed(g);
+    }
+    void retract_entity(size_t idx) {  // state.rs:231-244
+        auto eg = entity_groups.find(idx);
+        if (eg == entity_groups.end()) return;
+        size_t g = eg->second;
+        entity_groups.erase(eg);
+        auto er = entity_retractions.find(idx);
+        if (er == entity_retractions.end()) return;
+        int64_t v = er->second;
+        entity_retractions.erase(er);
+        groups[g].acc.retract(v);
+        groups[g].count = groups[g].count > 0 ? groups[g].count - 1 : 0;
+        mark_changed(g);
+    }
+    Score replace_cached(size_t slot, const Score& sc) {  // scorer.rs:145-152
+        while (cached_scores.size() <= slot) cached_scores.push_back(Score::zero());
+        Score prev = cached_scores[slot];
+        cached_scores[slot] = sc;
+        return sc - prev;
+    }
+    Score refresh_changed() {  // scorer.rs:89-101
+        Score delta;
+        for (size_t g : changed_groups)
+            if (g < groups.size()) delta = delta + replace_cached(g, compute(groups[g]));
+        return delta;
+    }
+    Score evaluate(const Solution& s) const override {
+        std::map<int64_t, RunsAccumulator> acc;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) acc[key(s, i)].accumulate(point(s, i));
+        Score total;
+        for (auto& kv : acc) total = total + apply_impact(impact, weight(kv.first, kv.second.finish()));
+        return total;
+    }
+    size_t match_count(const Solution& s) const override {
+        std::unordered_set<int64_t> keys;
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) keys.insert(key(s, i));
+        return keys.size();
+    }
+    Score initialize(const Solution& s) override {
+        reset();
+        size_t n = count(s);
+        for (size_t i = 0; i < n; ++i)
+            if (filter(s, i)) insert_entity(s, i);
+        changed_groups.clear();
+        cached_scores.clear();
+        Score total;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            Score sc = compute(groups[g]);
             replace_cached(g, sc);
             total = total + sc;
         }

@@ -1201,7 +1201,57 @@ static void list_precedence_cases() {
     }
 }
 
+// stream/collector/tests/collector.rs:266-320,399-469 (the seven consecutive_runs tests)
+static void runs_cases() {
+    auto feed = [](std::vector<int64_t> v) {
+        RunsAccumulator a;
+        for (int64_t x : v) a.accumulate(x);
+        return a;
+    };
+    {  // test_consecutive_runs_empty
+        Runs r = RunsAccumulator().finish();
+        CHECK("runs.empty", r.runs.empty() && r.point_count == 0 && r.item_count == 0);
+    }
+    {  // test_consecutive_runs_one_run
+        Runs r = feed({3, 1, 2}).finish();
+        CHECK("runs.one_run", r.runs.size() == 1 && r.runs[0].start == 1 && r.runs[0].end == 3 && r.runs[0].point_count == 3 && r.runs[0].item_count == 3);
+    }
+    {  // test_consecutive_runs_multiple_runs
+        Runs r = feed({8, 1, 2, 4, 5, 10}).finish();
+        bool ok = r.runs.size() == 4 && r.runs[0].start == 1 && r.runs[0].end == 2 && r.runs[1].start == 4 && r.runs[1].end == 5 &&
+                  r.runs[2].start == 8 && r.runs[2].end == 8 && r.runs[3].start == 10 && r.runs[3].end == 10;
+        CHECK("runs.multiple_runs", ok);
+    }
+    {  // test_consecutive_runs_duplicates_count_items_not_points
+        Runs r = feed({1, 1, 2, 4, 4, 4}).finish();
+        bool ok = r.point_count == 3 && r.item_count == 6 && r.runs[0].point_count == 2 && r.runs[0].item_count == 3 &&
+                  r.runs[1].point_count == 1 && r.runs[1].item_count == 3;
+        CHECK("runs.duplicates", ok);
+    }
+    {  // test_consecutive_runs_negative_indexes
+        Runs r = feed({-3, -2, -1, 1}).finish();
+        CHECK("runs.negative_indexes", r.runs.size() == 2 && r.runs[0].start == -3 && r.runs[0].end == -1 && r.runs[1].start == 1 && r.runs[1].end == 1);
+    }
+    {  // test_consecutive_runs_i64_max_boundary
+        Runs r = feed({INT64_MIN, INT64_MAX - 1, INT64_MAX}).finish();
+        bool ok = r.runs.size() == 2 && r.runs[0].start == INT64_MIN && r.runs[0].end == INT64_MIN && r.runs[1].start == INT64_MAX - 1 &&
+                  r.runs[1].end == INT64_MAX;
+        CHECK("runs.i64_max_boundary", ok);
+    }
+    {  // test_consecutive_runs_insert_retract_parity
+        RunsAccumulator a = feed({1, 2, 2, 3, 7});
+        a.retract(2);
+        Runs r = a.finish();
+        bool ok = r.runs.size() == 2 && r.runs[0].item_count == 3 && r.item_count == 4;
+        a.retract(2);
+        r = a.finish();
+        ok = ok && r.runs.size() == 3 && r.point_count == 3 && r.item_count == 3;
+        CHECK("runs.insert_retract_parity", ok);
+    }
+}
+
 int main() {
+    runs_cases();
     list_precedence_cases();
     forager_cases();
     k_opt_cases();

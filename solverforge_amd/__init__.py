@@ -14,5 +14,5 @@ from .director import (  # noqa: F401
     SelectionOrder,
     SolverConfig,
 )
-from .models import build_assignment, build_balance, build_cvrp, build_graph_coloring, build_jobshop, build_nqueens, build_precedence_shop  # noqa: F401
+from .models import build_assignment, build_balance, build_cvrp, build_graph_coloring, build_jobshop, build_nqueens, build_precedence_shop, build_shift_schedule  # noqa: F401
 from ._lib import MOVE_DTYPE, SolverForgeError  # noqa: F401

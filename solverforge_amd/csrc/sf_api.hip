@@ -394,7 +394,7 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
                           int32_t level, int64_t weight) {
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
-    if (kind < SF_C_UNI_UNASSIGNED || kind > SF_C_BALANCE_VALUE) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
     ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
     return SF_OK;
 }
@@ -996,6 +996,7 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_BALANCE_VALUE: raw = q[6], count = q[7]; break;
             case SF_C_VALUE_COST: raw = q[8], count = q[9]; break;
             case SF_C_EXISTS_VALUE: raw = q[10], count = q[11]; break;
+            case SF_C_RUNS_VALUE: raw = q[14], count = q[15]; break;
             case SF_C_LIST_PRECEDENCE_MAKESPAN: raw = q[12], count = q[12] + (q[13] > 0 ? 1 : 0); break;  // match_count_from_state (:96-99)
             default: return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind in sf_evaluate_each");
         }
@@ -1130,6 +1131,7 @@ int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t*
         return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate_compound arguments");
     if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode >= 1)
         return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance / balance model (floating-point aggregate) are not chained on the device");
+    if (ctx->sm.run_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a consecutive-runs model are not chained on the device");
     if (n == 0) return SF_OK;
     if (offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "offsets[0] must be 0");
     for (int64_t i = 0; i < n; ++i) {
@@ -1178,6 +1180,7 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
     if (n_edits > SF_COMPOUND_MAX) return fail(ctx, SF_ERR_UNSUPPORTED, "at most 8 edits per compound candidate on the device");
     if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode >= 1)
         return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance / balance model (floating-point aggregate) are not chained on the device");
+    if (ctx->sm.run_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a consecutive-runs model are not chained on the device");
     for (int64_t k = 0; k < n_edits; ++k)
         if (edits[k].kind != SF_MOVE_CHANGE) return fail(ctx, SF_ERR_INVALID, "a ScalarEdit is a SF_MOVE_CHANGE-shaped record");
     int rc = alloc_search(ctx);

@@ -66,7 +66,12 @@ struct ScalarModel {
     // range 0..n_values for every entity
     const uint32_t* vl_off = nullptr;  // [n + 1]
     const int32_t* vl = nullptr;       // values, each in 0..n_values
-    __host__ __device__ bool tables() const { return sj_level >= 0 || grp_level >= 0 || ex_level >= 0; }
+    // group_by(value, consecutive_runs(point)).penalize(weight * sum over the runs of max(0, point_count - run_limit))
+    // (stream/collector/runs.rs): a per-(value, point) count table [n_values][run_P] of u16 follows the per-value tables
+    int32_t run_level = -1, run_P = 0;
+    int64_t run_weight = 0, run_limit = 0;
+    const int32_t* run_point = nullptr;  // [n] point of every entity, in 0..run_P
+    __host__ __device__ bool tables() const { return sj_level >= 0 || grp_level >= 0 || ex_level >= 0 || run_level >= 0; }
     // per-replica committed state
     int32_t* vals = nullptr;        // [R][n]  (-1 = None)
     int64_t* score = nullptr;       // [R][4]
@@ -136,6 +141,43 @@ __device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, c
     return (int64_t)c;
 }
 
+// ---- consecutive-runs collector (stream/collector/runs.rs:11-229) over the per-(value, point) count table ----------------
+// The table sits behind the per-value count table (16-byte aligned): a pointer to the counts locates it.
+__device__ __forceinline__ uint16_t* runs_table(const ScalarModel& m, const uint32_t* cnt) {
+    return (uint16_t*)(((uintptr_t)(cnt + m.n_values) + 15) & ~(uintptr_t)15);
+}
+template <class T>
+struct TableView;
+template <class T>
+__device__ __forceinline__ uint16_t* runs_table(const ScalarModel&, const TableView<T>&) { return nullptr; }  // compound candidates: not supported
+__host__ __device__ inline size_t runs_table_bytes(int n_values, int run_P) { return ((size_t)n_values * run_P * 2 + 31) & ~(size_t)15; }
+__device__ __forceinline__ int64_t run_excess(const ScalarModel& m, int64_t len) { return len > m.run_limit ? len - m.run_limit : 0; }
+// lengths of the runs of present points directly left / right of point d in one value's row; point `ox` counts as absent
+__device__ __forceinline__ void run_neighbours(const uint16_t* row, int P, int d, int ox, int64_t& left, int64_t& right) {
+    left = right = 0;
+    for (int x = d - 1; x >= 0 && x != ox && row[x] != 0; --x) ++left;
+    for (int x = d + 1; x < P && x != ox && row[x] != 0; ++x) ++right;
+}
+// change of a row's summed run excess when point d becomes present (it was absent) / absent (it was the last item of the point)
+__device__ __forceinline__ int64_t run_add_delta(const ScalarModel& m, const uint16_t* row, int d, int ox) {
+    int64_t l, r;
+    run_neighbours(row, m.run_P, d, ox, l, r);
+    return run_excess(m, l + 1 + r) - run_excess(m, l) - run_excess(m, r);
+}
+// summed run excess of one row (full evaluation)
+__device__ __forceinline__ int64_t run_row_excess(const ScalarModel& m, const uint16_t* row) {
+    int64_t total = 0, len = 0;
+    for (int x = 0; x < m.run_P; ++x) {
+        if (row[x] != 0)
+            ++len;
+        else {
+            total += run_excess(m, len);
+            len = 0;
+        }
+    }
+    return total + run_excess(m, len);
+}
+
 struct ScalarDelta {
     int64_t d_un;     // change of the number of unassigned entities
     int64_t d_cross;  // change of the number of matched pairs (predicate join)
@@ -144,6 +186,7 @@ struct ScalarDelta {
     int64_t d_cost;   // change of the summed (entity, value) pair costs
     int64_t d_ex;     // change of the summed weights of the value rows whose existence test holds
     bool doable;
+    int64_t d_run = 0;  // change of the summed run excess (consecutive-runs collector)
 };
 
 // grouped/scorer.rs:89-101: an empty group scores zero
@@ -237,6 +280,14 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
             const int64_t loss = (old >= 0 && cnt[old] == 1) ? (m.ex_w ? (int64_t)m.ex_w[old] : 1) : 0;
             r.d_ex = m.ex_mode ? wsub(gain, loss) : wsub(loss, gain);
         }
+        if (m.run_level >= 0) {  // the point of `a` leaves the row of `old` / joins the row of `value` (distinct rows)
+            const uint16_t* pt = runs_table(m, cnt);
+            if (pt) {
+                const int d = m.run_point[a];
+                if (old >= 0 && pt[(size_t)old * m.run_P + d] == 1) r.d_run -= run_add_delta(m, pt + (size_t)old * m.run_P, d, -1);
+                if (value >= 0 && pt[(size_t)value * m.run_P + d] == 0) r.d_run += run_add_delta(m, pt + (size_t)value * m.run_P, d, -1);
+            }
+        }
         if (m.grp_level >= 0 && m.grp_mode >= 1) {  // global statistic (load balance: metrics are >= 1, validated at sf_constraint_add)
             const bool by_count = m.grp_mode == 2;
             const int64_t sz = by_count ? 1 : (int64_t)m.size[a];
@@ -271,6 +322,24 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
             const int64_t before = wadd(va >= 0 ? m.cost[ra + va] : 0, vb >= 0 ? m.cost[rb + vb] : 0);
             r.d_cost = wsub(after, before);
         }
+        if (m.run_level >= 0) {  // row va loses a's point and gains b's; row vb the other way round (nothing moves when the points agree)
+            const uint16_t* pt = runs_table(m, cnt);
+            const int da = m.run_point[a], db = m.run_point[b];
+            if (pt && da != db) {
+                if (va >= 0) {
+                    const uint16_t* row = pt + (size_t)va * m.run_P;
+                    const bool gone = row[da] == 1;
+                    if (gone) r.d_run -= run_add_delta(m, row, da, -1);
+                    if (row[db] == 0) r.d_run += run_add_delta(m, row, db, gone ? da : -1);
+                }
+                if (vb >= 0) {
+                    const uint16_t* row = pt + (size_t)vb * m.run_P;
+                    const bool gone = row[db] == 1;
+                    if (gone) r.d_run -= run_add_delta(m, row, db, -1);
+                    if (row[da] == 0) r.d_run += run_add_delta(m, row, da, gone ? db : -1);
+                }
+            }
+        }
         // a swap exchanges two members: per-value counts (and so the same-value pairs and every row's existence) do not change
         if (m.grp_level >= 0 && m.grp_mode == 1) {  // a swap exchanges two members: key counts stay, loads shift
             const int64_t sa = (int64_t)m.size[a], sb = (int64_t)m.size[b];
@@ -304,6 +373,26 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move(const ScalarModel& m, co
 template <class VT>
 __device__ __forceinline__ void scalar_tables_apply(const ScalarModel& m, const VT* vals, int kind, uint32_t a, uint32_t b,
                                                     int32_t value, uint32_t* cnt, int64_t* sum) {
+    if (m.run_level >= 0) {  // the per-(value, point) counts
+        uint16_t* pt = runs_table(m, cnt);
+        if (kind == 0) {
+            const int32_t old = (int32_t)vals[a];
+            const int d = m.run_point[a];
+            if (old >= 0) pt[(size_t)old * m.run_P + d] -= 1;
+            if (value >= 0) pt[(size_t)value * m.run_P + d] += 1;
+        } else {
+            const int32_t va = (int32_t)vals[a], vb = (int32_t)vals[b];
+            const int da = m.run_point[a], db = m.run_point[b];
+            if (va >= 0) {
+                pt[(size_t)va * m.run_P + da] -= 1;
+                pt[(size_t)va * m.run_P + db] += 1;
+            }
+            if (vb >= 0) {
+                pt[(size_t)vb * m.run_P + db] -= 1;
+                pt[(size_t)vb * m.run_P + da] += 1;
+            }
+        }
+    }
     if (kind == 0) {
         const int32_t old = (int32_t)vals[a];
         const int64_t sz = m.size ? (int64_t)m.size[a] : 0;
@@ -327,11 +416,27 @@ __device__ __forceinline__ void scalar_tables_apply(const ScalarModel& m, const 
 template <class VT>
 __device__ __forceinline__ void scalar_tables_accumulate(const ScalarModel& m, const VT* vals, uint32_t tid, uint32_t nthreads,
                                                          uint32_t* cnt, int64_t* sum) {
+    uint32_t* pt32 = nullptr;
+    if (m.run_level >= 0) {  // zero the per-(value, point) counts first (two u16 per word; every caller runs this with all its threads)
+        pt32 = (uint32_t*)runs_table(m, cnt);
+        const uint32_t words = ((uint32_t)m.n_values * (uint32_t)m.run_P + 1u) / 2u;
+        for (uint32_t w = tid; w < words; w += nthreads) pt32[w] = 0;
+        if (nthreads == 64u) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else
+            __syncthreads();
+    }
     for (uint32_t e = tid; e < (uint32_t)m.n; e += nthreads) {
         const int32_t v = (int32_t)vals[e];
         if (v >= 0) {
             atomicAdd(&cnt[v], 1u);
             atomicAdd((unsigned long long*)&sum[v], (unsigned long long)(int64_t)(m.size ? m.size[e] : 0));
+            if (pt32) {
+                const uint32_t idx = (uint32_t)v * (uint32_t)m.run_P + (uint32_t)m.run_point[e];
+                atomicAdd(&pt32[idx >> 1], 1u << (16u * (idx & 1u)));
+            }
         }
     }
 }
@@ -349,6 +454,7 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
         if (k == m.grp_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.grp_weight * (uint64_t)d.d_grp));
         if (k == m.cost_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.cost_weight * (uint64_t)d.d_cost));
         if (k == m.ex_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.ex_weight * (uint64_t)d.d_ex));
+        if (k == m.run_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.run_weight * (uint64_t)d.d_run));
     }
     return s;
 }
@@ -503,7 +609,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
 __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
                                                              int accumulate, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];  // per-value tables (when used)
-    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups, s_cost, s_cost_n, s_ex, s_ex_n;
+    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups, s_cost, s_cost_n, s_ex, s_ex_n, s_run, s_run_groups;
     const int r = blockIdx.x;
     const int32_t* vals = m.vals + (size_t)r * m.n;
     const bool tables = m.tables();
@@ -516,6 +622,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         s_grp = 0;
         s_groups = 0;
         s_cost = s_cost_n = s_ex = s_ex_n = 0;
+        s_run = s_run_groups = 0;
     }
     if (tables)
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
@@ -536,6 +643,16 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
                 ex += (unsigned long long)(int64_t)(m.ex_w ? m.ex_w[v] : 1);
                 ex_n += 1;
             }
+        }
+        if (m.run_level >= 0) {  // one value row per thread: its runs
+            unsigned long long run = 0, run_groups = 0;
+            const uint16_t* pt = runs_table(m, t_cnt);
+            for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+                run += (unsigned long long)run_row_excess(m, pt + (size_t)v * m.run_P);
+                run_groups += t_cnt[v] ? 1 : 0;
+            }
+            atomicAdd(&s_run, run);
+            atomicAdd(&s_run_groups, run_groups);
         }
         atomicAdd(&s_ex, ex);
         atomicAdd(&s_ex_n, ex_n);
@@ -599,6 +716,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         if (m.grp_level >= 0) sc[m.grp_level] = wsub(sc[m.grp_level], (int64_t)((uint64_t)m.grp_weight * s_grp));
         if (m.cost_level >= 0) sc[m.cost_level] = wsub(sc[m.cost_level], (int64_t)((uint64_t)m.cost_weight * s_cost));
         if (m.ex_level >= 0) sc[m.ex_level] = wsub(sc[m.ex_level], (int64_t)((uint64_t)m.ex_weight * s_ex));
+        if (m.run_level >= 0) sc[m.run_level] = wsub(sc[m.run_level], (int64_t)((uint64_t)m.run_weight * s_run));
         for (int k = 0; k < m.levels; ++k) {
             if (out_scores) out_scores[(size_t)r * m.levels + k] = accumulate ? wadd(out_scores[(size_t)r * m.levels + k], sc[k]) : sc[k];
             if (commit) m.score[(size_t)r * 4 + k] = accumulate ? wadd(m.score[(size_t)r * 4 + k], sc[k]) : sc[k];
@@ -614,6 +732,8 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             q[9] = (int64_t)s_cost_n;
             q[10] = (int64_t)s_ex;
             q[11] = (int64_t)s_ex_n;
+            q[14] = (int64_t)s_run;
+            q[15] = (int64_t)s_run_groups;
         }
     }
 }
@@ -717,8 +837,9 @@ constexpr uint32_t SRC = 128;  // ring capacity per leaf (entries of 2 x u32)
 
 template <class VT>
 struct SCarve {
-    size_t vals, ring, tsum, tcnt, total;
-    __host__ __device__ SCarve(int n, int n_table) {  // n_table = n_values when a value-keyed constraint exists, else 0
+    size_t vals, ring, tsum, tcnt, tpt, total;
+    // n_table = n_values when a value-keyed constraint exists, else 0; run_P = points of the consecutive-runs table, else 0
+    __host__ __device__ SCarve(int n, int n_table, int run_P = 0) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * SRC * 2, 16);
@@ -726,6 +847,8 @@ struct SCarve {
         o = align_up(o + sizeof(int64_t) * n_table, 16);
         tcnt = o;
         o = align_up(o + sizeof(uint32_t) * n_table, 16);
+        tpt = o;  // == runs_table(cnt): the aligned end of the count table
+        o = align_up(o + (run_P ? runs_table_bytes(n_table, run_P) : 0), 16);
         vals = o;
         o = align_up(o + sizeof(VT) * n, 16);
         total = o;
@@ -746,7 +869,7 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t n = (uint32_t)m.n;
     const bool tables = m.tables();
-    const SCarve<VT> cv(m.n, tables ? m.n_values : 0);
+    const SCarve<VT> cv(m.n, tables ? m.n_values : 0, m.run_level >= 0 ? m.run_P : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][SRC][2]
     VT* s_vals = (VT*)(mem + cv.vals);

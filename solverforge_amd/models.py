@@ -159,6 +159,31 @@ def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_chan
     return d
 
 
+def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, limit=2, w_streak=1, count_weight=0, leaves=("change", "swap")):
+    """examples/minimal-shift-scheduling/src/domain/schedule.rs:21-83: shifts choose a nurse.  Hard: unassigned shift; two shifts of
+    one nurse on one day (predicate cross-join on the day column).  Soft: long work streaks -- group_by(nurse,
+    consecutive_runs(day)).penalize(sum over runs of max(0, point_count - limit)) (stream/collector/runs.rs); optionally
+    count_weight * (shifts per nurse)^2 (grouped count)."""
+    import numpy as np
+
+    n = len(nurse_idx)
+    d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
+    d.add_entity_class(0, n)
+    d.add_scalar_variable(0, 0, n_nurses, True, nurse_idx)
+    d.add_fact_column_i32(FACT_GROUP, np.asarray(day, dtype=np.int32))
+    d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
+    d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=0, weight=1)
+    d.add_constraint(ConstraintKind.RUNS_VALUE, 0, fact=FACT_GROUP, param=limit, level=1, weight=w_streak)
+    if count_weight > 0:
+        d.add_fact_column_i32(FACT_COLUMN, np.ones(n, dtype=np.int32))
+        d.add_constraint(ConstraintKind.GROUPED_VALUE_SUM, 0, fact=FACT_COLUMN, param=-1, level=1, weight=count_weight)
+    if "change" in leaves:
+        d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
+    if "swap" in leaves:
+        d.add_selector(SelectorKind.SCALAR_SWAP, 0)
+    return d
+
+
 def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=-1, leaves=("change", "swap"), arity=2):
     """Bin balance: the keyed self-join (pairs of entities sharing a bin — IncrementalBiConstraint,
     constraint/nary_incremental/bi.rs:12-313) and the grouped sum (group_by(bin, sum(size)) with
