@@ -140,7 +140,13 @@ typedef enum sf_constraint_kind {
      * column (one point per entity, 0 <= point < 4096; duplicates count once per run), `param` = the run length that is still free.
      * The device keeps a [n_values][points] count table in LDS (<= 48 KiB); a trial reads the run lengths either side of the moved
      * point.  Scalar engine only; not chained in compound candidates */
-    SF_C_RUNS_VALUE = 15
+    SF_C_RUNS_VALUE = 15,
+    /* for_each(E).filter(assigned).group_by(value, sum(fact_a)).complement(B, |b| b.id, |_| 0).penalize(weight * |sum - param|)
+     * with B the value-keyed fact rows -- the complemented grouped node (constraint/complemented/{state,helpers,incremental}.rs,
+     * stream/grouped_stream/base.rs:142-200): EVERY value row is scored, a row nobody holds with the default result 0 (the
+     * "balanced workload" constraint of examples/minimal-shift-scheduling/src/domain/schedule.rs:61-74 with a ones column).
+     * `fact_a` = i32 column summed per group, `param` = the target.  Shares the grouped slot (one grouped constraint per class) */
+    SF_C_COMPLEMENTED_VALUE_SUM = 16
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {

@@ -753,7 +753,7 @@ struct ShiftFacts {
     std::vector<int64_t> day;
 };
 inline std::unique_ptr<Model> make_shift_schedule(size_t n_shifts, size_t n_nurses, const int64_t* nurse_idx, const int64_t* day, int64_t limit,
-                                                  int64_t w_streak, int64_t count_weight) {
+                                                  int64_t w_streak, int64_t count_weight, int64_t target = -1) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<ShiftFacts>();
     facts->day.assign(day, day + n_shifts);
@@ -794,7 +794,21 @@ inline std::unique_ptr<Model> make_shift_schedule(size_t n_shifts, size_t n_nurs
     };
     m->director.constraints.members.push_back(std::move(streak));
 
-    if (count_weight > 0) {
+    if (count_weight > 0 && target >= 0) {  // balanced workload (schedule.rs:61-74): count per nurse, complemented by the nurses
+        auto bal = std::make_unique<ComplementedGroupedConstraint>();
+        bal->name = "Balanced workload";
+        bal->impact = Impact::Penalty;
+        bal->a_source = ChangeSource::descriptor(0);
+        bal->b_source = ChangeSource::fixed();  // nurses are problem facts
+        bal->a_count = [](const Solution& s) { return s.classes[0].n; };
+        bal->b_count = [n_nurses](const Solution&) { return n_nurses; };
+        bal->key_a = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+        bal->key_b = [](const Solution&, size_t b) { return (int64_t)b; };
+        bal->value = [](const Solution&, size_t) { return (int64_t)1; };
+        bal->default_b = [](const Solution&, size_t) { return (int64_t)0; };
+        bal->weight = [count_weight, target](int64_t, int64_t c) { return Score::of(0, count_weight * (c > target ? c - target : target - c)); };
+        m->director.constraints.members.push_back(std::move(bal));
+    } else if (count_weight > 0) {
         auto load = std::make_unique<GroupedConstraint>();
         load->name = "Workload";
         load->impact = Impact::Penalty;

@@ -13,6 +13,7 @@
 //   crates/solverforge-scoring/src/constraint/grouped/{state,scorer,shared_set}.rs
 //   crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707 (ListPrecedenceMakespanConstraint)
 //   crates/solverforge-scoring/src/stream/collector/runs.rs:11-229 (consecutive_runs collector)
+//   crates/solverforge-scoring/src/constraint/complemented/{state,helpers,incremental}.rs (complemented grouped)
 //   crates/solverforge-scoring/src/api/constraint_set/incremental.rs:339-407 (tuple fold)
 //   crates/solverforge-scoring/src/director/score_director/incremental.rs:141-218
 #pragma once
@@ -993,6 +994,154 @@ struct GroupedConstraint : Constraint {
         entity_retractions.clear();
         changed_groups.clear();
         cached_scores.clear();
+    }
+};
+
+// ---- complemented grouped constraint (constraint/complemented/{state,helpers,incremental}.rs; stream
+// grouped_stream/base.rs:142-200 `.complement(B, key_b, default)`) -------------------------------------------------------------
+// Groups the A entities by an optional key with a sum / count collector, then scores EVERY B row: with its key's grouped
+// result when a group exists, else with default(b).  B rows are indexed by key (several rows may share one).
+struct ComplementedGroupedConstraint : Constraint {
+    Impact impact;
+    ChangeSource a_source, b_source;
+    CountFn a_count, b_count;
+    Key1 key_a;  // NONE = the key function returns None (entity skipped)
+    Key1 key_b;
+    Value1 value;      // collector extract (count: 1)
+    Value1 default_b;  // default result of a B row without a group
+    GroupWeight weight;
+
+    struct Group {
+        int64_t acc = 0;
+        size_t count = 0;
+    };
+    std::unordered_map<int64_t, Group> groups;
+    std::unordered_map<size_t, int64_t> entity_groups, entity_retractions;
+    std::unordered_map<int64_t, std::vector<size_t>> b_by_key;
+    std::unordered_map<size_t, int64_t> b_index_to_key;
+
+    Score compute(int64_t k, int64_t r) const { return apply_impact(impact, weight(k, r)); }
+    Score b_score_for_index(const Solution& s, int64_t k, size_t b) const {  // helpers.rs:67-82
+        if (b >= b_count(s)) return Score::zero();
+        auto it = groups.find(k);
+        return it != groups.end() ? compute(k, it->second.acc) : compute(k, default_b(s, b));
+    }
+    Score key_score(const Solution& s, int64_t k) const {  // helpers.rs:84-91
+        auto it = b_by_key.find(k);
+        if (it == b_by_key.end()) return Score::zero();
+        Score t;
+        for (size_t b : it->second) t = t + b_score_for_index(s, k, b);
+        return t;
+    }
+    Score insert_entity(const Solution& s, size_t idx) {  // helpers.rs:29-65
+        int64_t k = key_a(s, idx);
+        if (k == NONE) return Score::zero();
+        int64_t v = value(s, idx);
+        Score old = key_score(s, k);
+        Group& g = groups[k];
+        g.acc = wrap_add(g.acc, v);
+        g.count += 1;
+        entity_groups[idx] = k;
+        entity_retractions[idx] = v;
+        return key_score(s, k) - old;
+    }
+    Score retract_entity(const Solution& s, size_t idx) {  // helpers.rs:137-165
+        auto eg = entity_groups.find(idx);
+        if (eg == entity_groups.end()) return Score::zero();
+        int64_t k = eg->second;
+        entity_groups.erase(eg);
+        auto er = entity_retractions.find(idx);
+        if (er == entity_retractions.end()) return Score::zero();
+        int64_t v = er->second;
+        entity_retractions.erase(er);
+        Score old = key_score(s, k);
+        auto g = groups.find(k);
+        if (g == groups.end()) return Score::zero();
+        g->second.acc = wrap_sub(g->second.acc, v);
+        g->second.count = g->second.count > 0 ? g->second.count - 1 : 0;
+        if (g->second.count == 0) groups.erase(g);
+        return key_score(s, k) - old;
+    }
+    void remove_index_from_key_bucket(int64_t k, size_t idx) {  // helpers.rs:93-108
+        auto it = b_by_key.find(k);
+        if (it == b_by_key.end()) return;
+        auto& v = it->second;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == idx) {
+                v[i] = v.back();
+                v.pop_back();
+                break;
+            }
+        if (v.empty()) b_by_key.erase(it);
+    }
+    Score insert_b(const Solution& s, size_t b) {  // helpers.rs:117-124
+        if (b >= b_count(s)) return Score::zero();
+        int64_t k = key_b(s, b);
+        auto old = b_index_to_key.find(b);
+        if (old != b_index_to_key.end()) remove_index_from_key_bucket(old->second, b);
+        b_index_to_key[b] = k;
+        b_by_key[k].push_back(b);
+        return b_score_for_index(s, k, b);
+    }
+    Score retract_b(const Solution& s, size_t b) {  // helpers.rs:126-134
+        auto it = b_index_to_key.find(b);
+        if (it == b_index_to_key.end()) return Score::zero();
+        int64_t k = it->second;
+        b_index_to_key.erase(it);
+        Score delta = -b_score_for_index(s, k, b);
+        remove_index_from_key_bucket(k, b);
+        return delta;
+    }
+    Score evaluate(const Solution& s) const override {  // incremental.rs:31-52
+        std::unordered_map<int64_t, int64_t> acc;
+        size_t na = a_count(s), nb = b_count(s);
+        for (size_t i = 0; i < na; ++i) {
+            int64_t k = key_a(s, i);
+            if (k == NONE) continue;
+            acc[k] = wrap_add(acc.count(k) ? acc[k] : 0, value(s, i));
+        }
+        Score total;
+        for (size_t b = 0; b < nb; ++b) {
+            int64_t k = key_b(s, b);
+            auto it = acc.find(k);
+            total = total + (it != acc.end() ? compute(k, it->second) : compute(k, default_b(s, b)));
+        }
+        return total;
+    }
+    size_t match_count(const Solution& s) const override { return b_count(s); }  // incremental.rs:54-57
+    Score initialize(const Solution& s) override {  // incremental.rs:59-83
+        reset();
+        size_t na = a_count(s), nb = b_count(s);
+        for (size_t b = 0; b < nb; ++b) {
+            int64_t k = key_b(s, b);
+            b_by_key[k].push_back(b);
+            b_index_to_key[b] = k;
+        }
+        Score total;
+        for (size_t b = 0; b < nb; ++b) total = total + compute(key_b(s, b), default_b(s, b));
+        for (size_t i = 0; i < na; ++i) total = total + insert_entity(s, i);
+        return total;
+    }
+    Score on_insert(const Solution& s, size_t e, size_t d) override {  // incremental.rs:85-104
+        bool a_changed = a_source.assert_localizes(d, name), b_changed = b_source.assert_localizes(d, name);
+        Score total;
+        if (a_changed && e < a_count(s)) total = total + insert_entity(s, e);
+        if (b_changed) total = total + insert_b(s, e);
+        return total;
+    }
+    Score on_retract(const Solution& s, size_t e, size_t d) override {  // incremental.rs:106-125
+        bool a_changed = a_source.assert_localizes(d, name), b_changed = b_source.assert_localizes(d, name);
+        Score total;
+        if (a_changed) total = total + retract_entity(s, e);
+        if (b_changed) total = total + retract_b(s, e);
+        return total;
+    }
+    void reset() override {
+        groups.clear();
+        entity_groups.clear();
+        entity_retractions.clear();
+        b_by_key.clear();
+        b_index_to_key.clear();
     }
 };
 

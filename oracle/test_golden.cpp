@@ -1250,7 +1250,98 @@ static void runs_cases() {
     }
 }
 
+// constraint/tests/complemented.rs:34-420: shifts (class 0, vars[0] = employee id or NONE) grouped by employee with count(),
+// complemented by the employees (class 1, vars[0] = id)
+static ComplementedGroupedConstraint complemented(std::function<Score(int64_t, int64_t)> w, int64_t dflt = 0) {
+    ComplementedGroupedConstraint c;
+    c.name = "Shift count";
+    c.impact = Impact::Penalty;
+    c.a_source = ChangeSource::descriptor(0);
+    c.b_source = ChangeSource::descriptor(1);
+    c.a_count = [](const Solution& s) { return s.classes[0].n; };
+    c.b_count = [](const Solution& s) { return s.classes[1].n; };
+    c.key_a = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
+    c.key_b = [](const Solution& s, size_t i) { return s.classes[1].vars[0][i]; };
+    c.value = [](const Solution&, size_t) { return (int64_t)1; };
+    c.default_b = [dflt](const Solution&, size_t) { return dflt; };
+    c.weight = w;
+    return c;
+}
+static Solution shifts_employees(std::vector<int64_t> shifts, std::vector<int64_t> employees) {
+    Solution s;
+    s.classes.resize(2);
+    s.classes[0].n = shifts.size();
+    s.classes[0].vars = {shifts};
+    s.classes[1].n = employees.size();
+    s.classes[1].vars = {employees};
+    return s;
+}
+static void complemented_cases() {
+    auto lin = [](int64_t, int64_t c) { return soft(c); };
+    auto sq = [](int64_t, int64_t c) { return soft(c * c); };
+    {  // test_complemented_evaluate (:34-70), test_complemented_skips_none_keys (:72-112)
+        auto c = complemented(lin);
+        CHECK("complemented.evaluate", c.evaluate(shifts_employees({0, 0}, {0, 1})) == soft(-2));
+        CHECK("complemented.skips_none_keys", c.evaluate(shifts_employees({0, 0, NONE, NONE}, {0, 1})) == soft(-2));
+    }
+    {  // test_complemented_incremental (:114-168)
+        auto c = complemented(lin);
+        Solution s = shifts_employees({0, 0, 1}, {0, 1, 2});
+        bool ok = c.initialize(s) == soft(-3) && c.on_retract(s, 0, 0) == soft(1) && c.on_insert(s, 0, 0) == soft(-1);
+        CHECK("complemented.incremental", ok);
+    }
+    {  // test_complemented_incremental_with_none_keys (:170-217)
+        auto c = complemented(lin);
+        Solution s = shifts_employees({0, NONE, 0}, {0, 1});
+        bool ok = c.initialize(s) == soft(-2) && c.on_retract(s, 1, 0) == soft(0) && c.on_insert(s, 1, 0) == soft(0);
+        CHECK("complemented.incremental_none_keys", ok);
+    }
+    {  // test_complemented_with_default (:219-255)
+        auto c = complemented(sq);
+        CHECK("complemented.with_default", c.evaluate(shifts_employees({0, 0, 0}, {0, 1, 2})) == soft(-9));
+    }
+    {  // test_complemented_incremental_matches_evaluate (:257-314)
+        auto c = complemented(sq);
+        Solution s = shifts_employees({0, 0, 1}, {0, 1});
+        Score t = c.initialize(s);
+        bool ok = t == c.evaluate(s) && t == soft(-5);
+        t = t + c.on_retract(s, 2, 0);
+        ok = ok && t == soft(-4);
+        t = t + c.on_insert(s, 2, 0);
+        CHECK("complemented.incremental_matches_evaluate", ok && t == soft(-5));
+    }
+    {  // test_complemented_b_side_insert_and_retract (:316-353)
+        auto c = complemented(lin);
+        Solution s = shifts_employees({0}, {0});
+        Score t = c.initialize(s);
+        bool ok = t == soft(-1);
+        t = t + c.on_retract(s, 0, 1);
+        s.classes[1].vars[0][0] = 2;
+        t = t + c.on_insert(s, 0, 1);
+        CHECK("complemented.b_side", ok && t == soft(0) && t == c.evaluate(s));
+    }
+    {  // test_complemented_missing_group_weight_can_use_complement_key (:355-378)
+        auto c = complemented([](int64_t k, int64_t cnt) { return soft(k + cnt); });
+        CHECK("complemented.complement_key_weight", c.evaluate(shifts_employees({1}, {1, 3})) == soft(-5));
+    }
+    {  // test_complemented_duplicate_complement_keys_match_incremental (:380-420): default 5, two B rows share key 0
+        auto c = complemented(lin, 5);
+        Solution s = shifts_employees({0}, {0, 0, 1});
+        Score t = c.initialize(s);
+        bool ok = t == soft(-7) && t == c.evaluate(s);
+        t = t + c.on_retract(s, 0, 0);
+        s.classes[0].vars[0][0] = NONE;
+        t = t + c.on_insert(s, 0, 0);
+        ok = ok && t == soft(-15) && t == c.evaluate(s);
+        t = t + c.on_retract(s, 0, 0);
+        s.classes[0].vars[0][0] = 0;
+        t = t + c.on_insert(s, 0, 0);
+        CHECK("complemented.duplicate_complement_keys", ok && t == soft(-7) && t == c.evaluate(s));
+    }
+}
+
 int main() {
+    complemented_cases();
     runs_cases();
     list_precedence_cases();
     forager_cases();

@@ -18,7 +18,7 @@ def t6(m):
 
 def run_case(seed):
     rng = np.random.default_rng(seed)
-    model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment"][int(rng.integers(7))]
+    model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment", "precedence", "precedence", "shift", "shift"][int(rng.integers(11))]
     acceptor = int(rng.choice([0, 1, 1, 3]))
     forager = int(rng.choice([0, 0, 1, 2, 3, 4]))
     limit = int(rng.choice([1, 2, 7, 40, 256]))
@@ -100,6 +100,42 @@ def run_case(seed):
         cs, cd = d.evaluate_candidates(cands)
         ocs, ocd = o.evaluate_compound(cands)
         assert (cd == ocd).all() and (cs == ocs[:, :2]).all(), "compound candidates"
+    elif model == "precedence":  # ListPrecedenceMakespanConstraint: list-only shop (cyclic / partly scheduled / wrong-owner starts)
+        nj = int(rng.integers(2, 11)); nm = int(rng.integers(2, 7))
+        p = datasets.make_precedence_shop(nj, nm, seed=seed, scheduled=rng.random() < 0.9, max_duration=int(rng.choice([1, 9, 1000])))
+        if rng.random() < 0.6:  # permute the sequences (cycles), drop some operations, move some to another machine
+            seqs = [list(x) for x in p["sequences"]]
+            for x in seqs:
+                rng.shuffle(x)
+            for _ in range(int(rng.integers(0, 4))):
+                v = int(rng.integers(nm))
+                if seqs[v]:
+                    x = seqs[v].pop(int(rng.integers(len(seqs[v]))))
+                    if rng.random() < 0.5:
+                        seqs[int(rng.integers(nm))].append(x)
+            p["sequences"] = seqs
+        with_owner = bool(rng.random() < 0.7)
+        pool = ["list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"]
+        chosen = set(rng.choice(pool, size=int(rng.integers(1, 7)), replace=False).tolist())
+        leaves = tuple(x for x in pool if x in chosen)
+        desc.update(nj=nj, nm=nm, leaves=leaves, with_owner=with_owner)
+        d = sfa.build_precedence_shop(p, leaves=leaves, with_owner=with_owner)
+        o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"] if with_owner else None)
+        o.set_kopt(1, 0)
+        lists = lambda: (d.working_lists(0, 0), o.get_lists(0))
+    elif model == "shift":  # consecutive-runs collector + complemented / plain grouped count (examples/minimal-shift-scheduling)
+        nn = int(rng.integers(2, 10)); nd = int(rng.integers(3, 40)); per = int(rng.integers(1, 4))
+        day = np.repeat(np.arange(nd), per).astype(np.int64)
+        if rng.random() < 0.3:
+            day = day * 2  # gaps: no two points are consecutive
+        nurse = (datasets.stream(seed + 31, len(day)) % np.uint64(nn + 1)).astype(np.int64) - 1
+        lim = int(rng.choice([0, 1, 2, 5])); cw = int(rng.choice([0, 1, 3])); tgt = int(rng.choice([-1, 0, 4]))
+        leaves = [("change",), ("swap",), ("change", "swap")][int(rng.integers(3))]
+        desc.update(nn=nn, nd=nd, per=per, limit=lim, cw=cw, target=tgt, leaves=leaves)
+        ws = int(rng.choice([1, 7]))
+        d = sfa.build_shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, leaves=leaves)
+        o = sfo.Model.shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt)
+        lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
     else:
         nj = int(rng.integers(2, 9)); nm = int(rng.integers(2, 6))
         p = datasets.make_jobshop(nj, nm)
@@ -110,8 +146,14 @@ def run_case(seed):
         leaves = tuple(x for x in pool if x in chosen)
         levels = 3
         desc.update(nj=nj, nm=nm, leaves=leaves)
-        d = sfa.build_jobshop(p, leaves=leaves)
-        o = sfo.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True)
+        mk = bool(rng.random() < 0.5)  # add the makespan objective (precedence constraint on the list class of the mixed model)
+        if mk:
+            p["durations"] = (datasets.stream(seed + 41, p["n_ops"]) % np.uint64(9)).astype(np.int64) + 1
+            if rng.random() < 0.5 and len(p["sequences"][0]) > 1:
+                p["sequences"][0] = p["sequences"][0][::-1]  # against the job order: cycles
+        desc.update(makespan=mk)
+        d = sfa.build_jobshop(p, leaves=leaves, makespan=mk)
+        o = sfo.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, durations=p["durations"] if mk else None)
         o.set_kopt(1, 0)
         lists = lambda: ((d.working_lists(1, 0), d.working_values(0, 0).tolist()), (o.get_lists(1), o.get_vars(0, 0).tolist()))
     bits = sum(BITS[x] for x in leaves)

@@ -394,7 +394,7 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
                           int32_t level, int64_t weight) {
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
-    if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE && kind != SF_C_COMPLEMENTED_VALUE_SUM)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
     ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
     return SF_OK;
 }
@@ -992,6 +992,7 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_CROSS_QUEENS: raw = q[4], count = q[4]; break;
             case SF_C_SELFJOIN_VALUE_EQUAL: raw = q[5], count = q[5]; break;
             case SF_C_GROUPED_VALUE_SUM:
+            case SF_C_COMPLEMENTED_VALUE_SUM:
             case SF_C_LOAD_BALANCE_VALUE: raw = q[6], count = q[7]; break;
             case SF_C_BALANCE_VALUE: raw = q[6], count = q[7]; break;
             case SF_C_VALUE_COST: raw = q[8], count = q[9]; break;

@@ -52,6 +52,9 @@ struct ScalarModel {
     int32_t grp_mode = 0;  // 0: sum of per-group weights (grouped node + sum collector); 1: load_balance collector (unfairness of
                            // the per-value metric sums); 2: BalanceConstraint (base x standard deviation of the per-value COUNTS)
     int64_t bal_base = 0;  // mode 2: the base score of one unit of standard deviation on grp_level (grp_weight is 1)
+    // mode 0 variants: grp_shape 1 = |sum - grp_cap| (absolute deviation from a target); grp_complement = every value row is
+    // scored, a row without members with the default result 0 (constraint/complemented/*.rs: `.complement(B, key, |_| 0)`)
+    int32_t grp_shape = 0, grp_complement = 0;
     const int32_t* size = nullptr;     // [n] summed fact of the grouped constraint
     // keyed cross-join with a fact side: every assigned entity e matches the fact row its value names; filter + weight of the
     // pair are the data cost[e][value] (0 = filtered out)
@@ -191,7 +194,12 @@ struct ScalarDelta {
 
 // grouped/scorer.rs:89-101: an empty group scores zero
 __device__ __forceinline__ int64_t group_weight(const ScalarModel& m, int64_t sum, uint32_t count) {
-    if (count == 0) return 0;
+    if (count == 0 && !m.grp_complement) return 0;
+    if (count == 0) sum = 0;  // the complement's default result
+    if (m.grp_shape == 1) {
+        const int64_t dev = wsub(sum, m.grp_cap);
+        return dev < 0 ? wsub(0, dev) : dev;
+    }
     if (m.grp_cap < 0) return (int64_t)((uint64_t)sum * (uint64_t)sum);
     const int64_t over = wsub(sum, m.grp_cap);
     return over > 0 ? over : 0;
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             const unsigned long long c = t_cnt[v];
             pairs += m.sj_arity == 2 ? c * (c - (c ? 1 : 0)) / 2 : choose_u64(c, m.sj_arity);
             if (m.grp_mode == 0 && m.grp_level >= 0) grp += (unsigned long long)group_weight(m, t_sum[v], t_cnt[v]);
-            groups += c ? 1 : 0;
+            groups += (c || m.grp_complement) ? 1 : 0;  // complemented: one match per value row (complemented/incremental.rs:54-57)
             if (m.ex_level >= 0 && ((c > 0) == (m.ex_mode != 0))) {
                 ex += (unsigned long long)(int64_t)(m.ex_w ? m.ex_w[v] : 1);
                 ex_n += 1;

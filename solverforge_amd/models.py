@@ -159,11 +159,13 @@ def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_chan
     return d
 
 
-def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, limit=2, w_streak=1, count_weight=0, leaves=("change", "swap")):
+def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, limit=2, w_streak=1, count_weight=0, target=-1,
+                         leaves=("change", "swap")):
     """examples/minimal-shift-scheduling/src/domain/schedule.rs:21-83: shifts choose a nurse.  Hard: unassigned shift; two shifts of
     one nurse on one day (predicate cross-join on the day column).  Soft: long work streaks -- group_by(nurse,
-    consecutive_runs(day)).penalize(sum over runs of max(0, point_count - limit)) (stream/collector/runs.rs); optionally
-    count_weight * (shifts per nurse)^2 (grouped count)."""
+    consecutive_runs(day)).penalize(sum over runs of max(0, point_count - limit)) (stream/collector/runs.rs); count_weight > 0:
+    target >= 0: balanced workload -- group_by(nurse, count()).complement(nurses, 0).penalize(|count - target|) (:61-74, the
+    complemented grouped node); target < 0: count_weight * (shifts per nurse)^2 (plain grouped count)."""
     import numpy as np
 
     n = len(nurse_idx)
@@ -176,7 +178,10 @@ def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, li
     d.add_constraint(ConstraintKind.RUNS_VALUE, 0, fact=FACT_GROUP, param=limit, level=1, weight=w_streak)
     if count_weight > 0:
         d.add_fact_column_i32(FACT_COLUMN, np.ones(n, dtype=np.int32))
-        d.add_constraint(ConstraintKind.GROUPED_VALUE_SUM, 0, fact=FACT_COLUMN, param=-1, level=1, weight=count_weight)
+        if target >= 0:
+            d.add_constraint(ConstraintKind.COMPLEMENTED_VALUE_SUM, 0, fact=FACT_COLUMN, param=target, level=1, weight=count_weight)
+        else:
+            d.add_constraint(ConstraintKind.GROUPED_VALUE_SUM, 0, fact=FACT_COLUMN, param=-1, level=1, weight=count_weight)
     if "change" in leaves:
         d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
     if "swap" in leaves:

@@ -30,6 +30,18 @@ def _mk(oracle, nurse, day, n_nurses, n_replicas=1, **kw):
     return d, o
 
 
+def test_complemented_known_answer(oracle):
+    """counts 6 / 3 / 0 against the target 4: |6-4| + |3-4| + |0-4| = 7 -- the nurse without shifts is scored (complement)."""
+    day = np.array([0, 1, 2, 3, 4, 0, 1, 2, 5, 6])
+    nurse = np.array([0, 0, 0, 0, 1, 1, 1, -1, 0, 0])
+    d, o = _mk(oracle, nurse, day, 3, limit=2, w_streak=1, count_weight=1, target=4)
+    got = d.calculate_score()[0]
+    assert got.tolist() == [-1, -9] and (o.score()[:2] == got).all()
+    gs, gc = d.evaluate_each()
+    os_, oc = o.evaluate_each()
+    assert (gs == os_[:, :2]).all() and (gc == oc).all() and gc[3] == 3
+
+
 def test_known_answer(oracle):
     """nurse 0 works days {0,1,2,3,5,6}: runs [0..3] (excess 2 over the limit 2) and [5,6]; nurse 1 days {0,1,4}: no excess."""
     day = np.array([0, 1, 2, 3, 4, 0, 1, 2, 5, 6])
@@ -43,10 +55,13 @@ def test_known_answer(oracle):
     assert gs[2].tolist() == [0, -2]
 
 
-@pytest.mark.parametrize("n_nurses,n_days,per_day,limit,w,cw", [(3, 10, 2, 2, 1, 0), (5, 14, 3, 3, 7, 2), (8, 28, 4, 0, 1, 0), (4, 30, 1, 5, 3, 1)])
-def test_scores_cursor_order_and_trial_scores(oracle, n_nurses, n_days, per_day, limit, w, cw):
+@pytest.mark.parametrize("n_nurses,n_days,per_day,limit,w,cw,target", [(3, 10, 2, 2, 1, 0, -1), (5, 14, 3, 3, 7, 2, -1), (8, 28, 4, 0, 1, 0, -1),
+                                                                        (4, 30, 1, 5, 3, 1, -1), (6, 14, 2, 2, 1, 1, 4), (9, 7, 3, 1, 2, 3, 0)])
+def test_scores_cursor_order_and_trial_scores(oracle, n_nurses, n_days, per_day, limit, w, cw, target):
     nurse, day = _problem(n_nurses, n_days, per_day, seed=n_days)
-    d, o = _mk(oracle, nurse, day, n_nurses, limit=limit, w_streak=w, count_weight=cw)
+    if target == 4:
+        nurse[nurse == 5] = 2  # a nurse without shifts: the complement scores |0 - target| for her
+    d, o = _mk(oracle, nurse, day, n_nurses, limit=limit, w_streak=w, count_weight=cw, target=target)
     got = d.calculate_score()[0]
     assert (got == o.score()[:2]).all()
     assert (d.fresh_score()[0] == got).all()
@@ -64,12 +79,13 @@ def test_scores_cursor_order_and_trial_scores(oracle, n_nurses, n_days, per_day,
         assert (ed == od).all() and (es == osc[:, :2]).all()
 
 
-@pytest.mark.parametrize("acceptor", ["late", "anneal"])
-def test_apply_traced_and_fused_steps(oracle, acceptor):
+@pytest.mark.parametrize("acceptor,target", [("late", -1), ("anneal", -1), ("late", 12)])
+def test_apply_traced_and_fused_steps(oracle, acceptor, target):
+    """target >= 0: the example's own constraint set (schedule.rs:21-83) -- the complemented |count - target| workload."""
     import solverforge_amd as sfa
 
     nurse, day = _problem(5, 21, 3, seed=3)
-    d, o = _mk(oracle, nurse, day, 5, limit=2, w_streak=2, count_weight=1)
+    d, o = _mk(oracle, nurse, day, 5, limit=2, w_streak=2, count_weight=1, target=target)
     d.calculate_score()
     rng = np.random.default_rng(1)
     o.configure(leaves=3, selection_order=3)
