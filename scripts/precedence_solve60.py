@@ -1,0 +1,45 @@
+"""Best score after `seconds` of wall time on a job shop with the makespan objective (ListPrecedenceMakespanConstraint, list change +
+swap + reverse + sublist change, LateAcceptance(400) + AcceptedCount(256)): GPU portfolio (work-balanced launches) vs the CPU oracle's
+incremental refresh on one host core, same instance, same start (every machine sequence shuffled: cyclic, hard = -node_count).
+argv: seconds jobs machines replicas"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import solverforge_amd as sfa
+from solverforge_amd import datasets
+from oracle import sfo
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+J = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+M = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+R = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
+leaves = ("list_change", "list_swap", "sublist_change", "list_reverse")
+p = datasets.make_precedence_shop(J, M, seed=1)
+feasible = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"]).score()[:2].tolist()
+rng = np.random.default_rng(7)
+p["sequences"] = [list(rng.permutation(s)) for s in p["sequences"]]  # a cyclic start: the search has to find a feasible order first
+d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves)
+d.configure(sfa.SolverConfig(random_seed=0))
+start = [int(v) for v in d.calculate_score()[0]]
+d.phase_start()
+t0 = time.perf_counter(); trace = []; k = 0
+while time.perf_counter() - t0 < seconds:
+    d.solve_moves(1 << 20, 20_000)
+    if k % 10 == 0:
+        trace.append((round(time.perf_counter() - t0, 1), list(max(tuple(int(v) for v in s) for s in d.best_scores()))))
+    k += 1
+gt = time.perf_counter() - t0
+st = d.total_stats()
+gpu = {"seconds": gt, "replicas": R, "best_score": list(max(tuple(int(v) for v in s) for s in d.best_scores())),
+       "moves_evaluated": st["moves_evaluated"], "moves_per_s": st["moves_evaluated"] / gt, "ls_steps_per_replica": st["step_count"] // R,
+       "trace": trace}
+o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+o.configure(leaves=4 | 8 | 128 | 64, random_seed=0)
+o.phase_start()
+t0 = time.perf_counter()
+steps = o.steps_timed(seconds)
+ct = time.perf_counter() - t0
+cpu = {"seconds": ct, "best_score": [int(v) for v in o.best_score()[:2]], "ls_steps": int(steps), "moves_evaluated": o.stats()["moves_evaluated"],
+       "moves_per_s": o.stats()["moves_evaluated"] / ct}
+print(json.dumps({"workload": "job shop %dx%d, ListPrecedenceMakespan, shuffled (cyclic) start" % (J, M), "leaves": list(leaves), "start_score": start,
+                  "step_major_schedule_score": feasible, "gpu": gpu, "cpu_oracle_1core": cpu}))
