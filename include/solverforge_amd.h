@@ -79,7 +79,10 @@ typedef enum sf_move_kind {
 /* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
  * cannot run on a GPU).  Each is the device form of one incremental node. */
 typedef enum sf_constraint_kind {
-    /* for_each(E).unassigned().penalize(w) — IncrementalUniConstraint, constraint/incremental.rs:19-193 */
+    /* for_each(E).unassigned().penalize(w) — IncrementalUniConstraint, constraint/incremental.rs:19-193.  On a scalar class
+     * `fact_a` >= 0 names an i32 column w[e]: for_each(E).filter(f(e) && unassigned).penalize(weight * w(e)) with the filter and
+     * the per-entity weight as data, 0 = filtered out (e.g. `shift.required && shift.nurse_idx.is_none()`,
+     * examples/minimal-shift-scheduling/src/domain/schedule.rs:23-27); -1 = every entity, weight 1 */
     SF_C_UNI_UNASSIGNED = 1,
     /* predicate cross-join on one class: left.id<right.id && adjacent(left,right) &&
      * assigned && equal value — cross_bi_incremental::Bi with constant key

@@ -72,7 +72,7 @@ def lib():
             "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
             "sfo_assignment_create": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
-            "sfo_shift_schedule_create": (vp, [i32, i32, vp, vp, i64, i64, i64, i64]),
+            "sfo_shift_schedule_create": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, vp]),
             "sfo_precedence_shop_create": (vp, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
             "sfo_jobshop_create_makespan": (vp, [i32, i32, vp, vp, vp, vp, i32, i32, vp]),
@@ -203,11 +203,13 @@ class Model:
         return Model(h, [len(routes)])
 
     @staticmethod
-    def shift_schedule(nurse_idx, day, n_nurses, limit=2, w_streak=1, count_weight=0, target=-1):
+    def shift_schedule(nurse_idx, day, n_nurses, limit=2, w_streak=1, count_weight=0, target=-1, required=None):
         """examples/minimal-shift-scheduling: unassigned, one shift per nurse-day, long work streaks (consecutive_runs), workload."""
         nurse_idx = np.ascontiguousarray(nurse_idx, dtype=np.int64)
         day = np.ascontiguousarray(day, dtype=np.int64)
-        h = lib().sfo_shift_schedule_create(len(nurse_idx), n_nurses, _p(nurse_idx), _p(day), limit, w_streak, count_weight, target)
+        req = None if required is None else np.ascontiguousarray(required, dtype=np.int64)
+        h = lib().sfo_shift_schedule_create(len(nurse_idx), n_nurses, _p(nurse_idx), _p(day), limit, w_streak, count_weight, target,
+                                            None if req is None else _p(req))
         return Model(h, [len(nurse_idx)])
 
     @staticmethod

@@ -133,8 +133,8 @@ void* sfo_precedence_shop_create(int32_t n_nodes, int32_t n_owners, const int64_
         .release();
 }
 void* sfo_shift_schedule_create(int32_t n_shifts, int32_t n_nurses, const int64_t* nurse_idx, const int64_t* day, int64_t limit, int64_t w_streak,
-                                int64_t count_weight, int64_t target) {
-    return make_shift_schedule((size_t)n_shifts, (size_t)n_nurses, nurse_idx, day, limit, w_streak, count_weight, target).release();
+                                int64_t count_weight, int64_t target, const int64_t* required) {
+    return make_shift_schedule((size_t)n_shifts, (size_t)n_nurses, nurse_idx, day, limit, w_streak, count_weight, target, required).release();
 }
 void* sfo_list_toy_create(int32_t n_entities, const uint32_t* off, const uint32_t* vals, int32_t meter) {
     return make_list_toy((size_t)n_entities, off, vals, meter == 0 ? ToyMeter::Equal : ToyMeter::Position)

@@ -750,10 +750,11 @@ inline std::unique_ptr<Model> make_precedence_shop(size_t n_nodes, size_t n_owne
 //   soft (count_weight > 0): group_by(nurse, count()).penalize(count^2) (the grouped count node; the example's complemented
 //         |count - target| form needs the complement node, which this build does not restate)
 struct ShiftFacts {
-    std::vector<int64_t> day;
+    std::vector<int64_t> day, required;  // required[i]: weight of "unassigned required shift" for shift i (0 = not required)
 };
 inline std::unique_ptr<Model> make_shift_schedule(size_t n_shifts, size_t n_nurses, const int64_t* nurse_idx, const int64_t* day, int64_t limit,
-                                                  int64_t w_streak, int64_t count_weight, int64_t target = -1) {
+                                                  int64_t w_streak, int64_t count_weight, int64_t target = -1,
+                                                  const int64_t* required = nullptr) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<ShiftFacts>();
     facts->day.assign(day, day + n_shifts);
@@ -762,8 +763,16 @@ inline std::unique_ptr<Model> make_shift_schedule(size_t n_shifts, size_t n_nurs
     s.classes[0].n = n_shifts;
     s.classes[0].vars.assign(1, std::vector<int64_t>(nurse_idx, nurse_idx + n_shifts));
     s.facts = facts;
+    if (required) facts->required.assign(required, required + n_shifts);
     const ShiftFacts* sf = facts.get();
-    m->director.constraints.members.push_back(make_unassigned(0, 0, Score::of(1, 0), "Unassigned required shift"));
+    {  // for_each(shifts).filter(required && nurse_idx.is_none()).penalize(ONE_HARD) (schedule.rs:23-27)
+        auto un = make_unassigned(0, 0, Score::of(1, 0), "Unassigned required shift");
+        if (required) {
+            un->filter = [sf](const Solution& s, size_t i) { return sf->required[i] != 0 && s.classes[0].vars[0][i] == NONE; };
+            un->weight = [sf](const Solution&, size_t i) { return Score::of(sf->required[i], 0); };
+        }
+        m->director.constraints.members.push_back(std::move(un));
+    }
 
     auto clash = std::make_unique<CrossBiConstraint>();
     clash->name = "One shift per nurse day";

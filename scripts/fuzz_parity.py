@@ -133,8 +133,9 @@ def run_case(seed):
         leaves = [("change",), ("swap",), ("change", "swap")][int(rng.integers(3))]
         desc.update(nn=nn, nd=nd, per=per, limit=lim, cw=cw, target=tgt, leaves=leaves)
         ws = int(rng.choice([1, 7]))
-        d = sfa.build_shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, leaves=leaves)
-        o = sfo.Model.shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt)
+        req = (datasets.stream(seed + 33, len(day)) % np.uint64(3)).astype(np.int64) if rng.random() < 0.5 else None  # required flag / weight
+        d = sfa.build_shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, leaves=leaves, required=req)
+        o = sfo.Model.shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, required=req)
         lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
     else:
         nj = int(rng.integers(2, 9)); nm = int(rng.integers(2, 6))

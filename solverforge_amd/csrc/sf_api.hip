@@ -986,7 +986,7 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_ROUTE_CAPACITY: raw = q[0], count = ctx->lm.V; break;  // filter = every route (uni on the owners)
             case SF_C_ROUTE_DISTANCE: raw = q[1], count = ctx->lm.V; break;
             case SF_C_NOT_EXISTS_FLATTENED: raw = q[2], count = q[2]; break;
-            case SF_C_UNI_UNASSIGNED: raw = q[3], count = q[3]; break;
+            case SF_C_UNI_UNASSIGNED: raw = q[3], count = q[16]; break;  // weighted sum / entities passing the filter
             case SF_C_CROSS_ADJACENT_EQUAL:
             case SF_C_CROSS_GROUP_EQUAL:
             case SF_C_CROSS_QUEENS: raw = q[4], count = q[4]; break;
@@ -1560,7 +1560,12 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         static const bool no_lds = std::getenv("SF_AMD_PREC_HBM") != nullptr;  // diagnostics / parity tests: force the HBM scratch
         gl.prec_lds = (gl.prec.on && !no_lds && (size_t)gl.prec.n * 16 <= 36 * 1024) ? 1 : 0;
     }
-    if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations (i16 values only)
+    if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations
+        if (ctx->has_scalar_model && ctx->sm.n_values <= 127 && ctx->sm.n >= 1024) {  // one-byte value array (C4: 4 waves per CU instead of 3)
+            if (ctx->levels <= 2)
+                return trace ? launch_mixed_t<2, true, int8_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int8_t, false, true>(ctx, p, gl, grid);
+            return trace ? launch_mixed_t<4, true, int8_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<4, false, int8_t, false, true>(ctx, p, gl, grid);
+        }
         if (ctx->levels <= 2)
             return trace ? launch_mixed_t<2, true, int16_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t, false, true>(ctx, p, gl, grid);
         return trace ? launch_mixed_t<4, true, int16_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<4, false, int16_t, false, true>(ctx, p, gl, grid);

@@ -288,8 +288,15 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     int32_t* const prec_D = !PREC ? nullptr : (prec_in_lds ? prec_E + gl.prec.n : gl.prec.indeg + (size_t)r * gl.prec.n);
     uint32_t* const prec_Q = !PREC ? nullptr : (prec_in_lds ? (uint32_t*)(prec_D + gl.prec.n) : gl.prec.queue + (size_t)r * gl.prec.n);
     uint32_t* const prec_S = !PREC ? nullptr : (prec_in_lds ? prec_Q + gl.prec.n : gl.prec.lsucc + (size_t)r * gl.prec.n);
+    // one full evaluation of the lists in LDS: typed LDS accessors when the scratch lives there
+    auto prec_run = [&]() -> PrecResult {
+        if (prec_in_lds)
+            return prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u32*)prec_Q,
+                                                   (prec_lds_u32*)prec_S);
+        return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+    };
     if (PREC) {
-        const PrecResult pr = prec_eval<uint16_t>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+        const PrecResult pr = prec_run();
         prec_pen = pr.penalty;
         prec_mk = pr.makespan;
     }
@@ -1324,7 +1331,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                              (ck == 4 || ck == 16) ? 2 : ((ck == 8 || ck == 32) ? 3 : (ck == 64 ? 4 : (ck == 128 ? 5 : (ck == 512 ? 7 : 6)))),
                                              ca >> 16, ca & 0xFFFFu, cb >> 16, cb & 0xFFFFu,
                                              ck == 512 ? cx : (ck == 256 ? ((cx & 15u) | ((cx >> 4) << 16)) : (ca & 0xFFFFu) + cx));
-                        const PrecResult pr = prec_eval<uint16_t>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+                        const PrecResult pr = prec_run();
                         if ((int)lane == ci) {
 #pragma unroll
                             for (int kk = 0; kk < L; ++kk) {
@@ -1566,7 +1573,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
                 for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = s_load[t];
                 prec_sync();
-                const PrecResult pr = prec_eval<uint16_t>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+                const PrecResult pr = prec_run();
                 prec_pen = pr.penalty;
                 prec_mk = pr.makespan;
             }

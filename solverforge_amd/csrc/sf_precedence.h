@@ -46,10 +46,31 @@ struct PrecResult {
     int64_t penalty, makespan;
 };
 
-__device__ __forceinline__ int32_t prec_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t prec_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void prec_st(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void prec_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Memory policies of the Kahn scratch.  HBM / L2: agent-scope atomic loads / stores (the vector L1 is not coherent with the L2
+// atomics that update the same words).  LDS: address-space typed pointers, so the accesses are ds_read / ds_write / ds_max_rtn /
+// ds_add_rtn instead of FLAT instructions.
+struct PrecMemGlobal {
+    typedef int32_t* I32;
+    typedef uint32_t* U32;
+    static __device__ __forceinline__ int32_t ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ uint32_t ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ void st(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ void st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ void fmax(int32_t* p, int32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    static __device__ __forceinline__ int32_t fadd(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+typedef __attribute__((address_space(3))) int32_t prec_lds_i32;
+typedef __attribute__((address_space(3))) uint32_t prec_lds_u32;
+struct PrecMemLds {
+    typedef prec_lds_i32* I32;
+    typedef prec_lds_u32* U32;
+    static __device__ __forceinline__ int32_t ld(const prec_lds_i32* p) { return *p; }
+    static __device__ __forceinline__ uint32_t ld(const prec_lds_u32* p) { return *p; }
+    static __device__ __forceinline__ void st(prec_lds_i32* p, int32_t v) { *p = v; }
+    static __device__ __forceinline__ void st(prec_lds_u32* p, uint32_t v) { *p = v; }
+    static __device__ __forceinline__ void fmax(prec_lds_i32* p, int32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    static __device__ __forceinline__ int32_t fadd(prec_lds_i32* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
 // cross-lane hand-off through memory inside one wavefront: every outstanding memory operation of the wave has completed
 __device__ __forceinline__ void prec_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -62,15 +83,15 @@ __device__ __forceinline__ uint32_t prec_mbcnt(uint64_t mask) {
 
 // Full evaluation of the lists `visits` / `off` (V owners) by one wavefront; E / D / Q / S = the four scratch arrays of pm.n
 // words.  Wave-uniform result.
-template <class VT>
-__device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, int32_t* E, int32_t* D,
-                                             uint32_t* Q, uint32_t* S) {
+template <class VT, class MEM = PrecMemGlobal>
+__device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
+                                             typename MEM::U32 Q, typename MEM::U32 S) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     for (uint32_t i = lane; i < n; i += 64) {
-        prec_st(E + i, 0);
-        prec_st(D + i, pm.indeg0[i]);
-        prec_st(S + i, PREC_NONE);
+        MEM::st(E + i, 0);
+        MEM::st(D + i, pm.indeg0[i]);
+        MEM::st(S + i, PREC_NONE);
     }
     prec_sync();
     const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[V]);
@@ -87,8 +108,8 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
                     hi = mid;
             }
             const uint32_t x = (uint32_t)visits[t];
-            if (t + 1 != off[lo + 1]) prec_st(S + x, (uint32_t)visits[t + 1]);
-            if (t != off[lo]) prec_st(D + x, pm.indeg0[x] + 1);
+            if (t + 1 != off[lo + 1]) MEM::st(S + x, (uint32_t)visits[t + 1]);
+            if (t != off[lo]) MEM::st(D + x, pm.indeg0[x] + 1);
             if (pm.owner) {
                 const int32_t o = pm.owner[x];
                 viol += (o >= 0 && (uint32_t)o != lo) ? 1u : 0u;
@@ -99,9 +120,9 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
     uint32_t head = 0, tail = 0;
     for (uint32_t b = 0; b < n; b += 64) {
         const uint32_t i = b + lane;
-        const bool ready = i < n && prec_ld(D + i) == 0;
+        const bool ready = i < n && MEM::ld(D + i) == 0;
         const uint64_t m = __ballot(ready);
-        if (ready) prec_st(Q + tail + prec_mbcnt(m), i);
+        if (ready) MEM::st(Q + tail + prec_mbcnt(m), i);
         tail += (uint32_t)__popcll(m);
     }
     prec_sync();
@@ -112,12 +133,12 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
         int32_t fin = 0;
         uint32_t so = 0, deg = 0, ls = PREC_NONE;
         if (act) {
-            const uint32_t node = prec_ld(Q + head + lane);
-            fin = prec_ld(E + node) + pm.dur[node];
+            const uint32_t node = MEM::ld(Q + head + lane);
+            fin = MEM::ld(E + node) + pm.dur[node];
             mk = fin > mk ? fin : mk;
             so = pm.succ_off[node];
             deg = pm.succ_off[node + 1] - so;
-            ls = prec_ld(S + node);
+            ls = MEM::ld(S + node);
         }
         const uint32_t degt = deg + ((act && ls != PREC_NONE) ? 1u : 0u);
         for (uint32_t k = 0;; ++k) {
@@ -127,11 +148,11 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
             uint32_t s = 0;
             if (has) {
                 s = k < deg ? pm.succ[so + k] : ls;
-                __hip_atomic_fetch_max(E + s, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                newly = __hip_atomic_fetch_add(D + s, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1;
+                MEM::fmax(E + s, fin);
+                newly = MEM::fadd(D + s, -1) == 1;
             }
             const uint64_t m = __ballot(newly);
-            if (newly) prec_st(Q + tail + prec_mbcnt(m), s);
+            if (newly) MEM::st(Q + tail + prec_mbcnt(m), s);
             tail += (uint32_t)__popcll(m);
         }
         head += cnt;

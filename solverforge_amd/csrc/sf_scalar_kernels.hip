@@ -42,6 +42,8 @@ struct ScalarModel {
     // constraints (level < 0 = absent)
     int32_t un_level = -1, cross_level = -1, cross_kind = SC_NONE;
     int64_t un_weight = 0, cross_weight = 0;
+    const int32_t* un_w = nullptr;     // [n] optional per-entity weight of the unassigned constraint: for_each(E).filter(f(e) &&
+                                       // unassigned).penalize(w(e)) with f / w as data (0 = filtered out); null = 1 for every entity
     const uint32_t* pn_off = nullptr;  // [n+1] symmetric partner CSR (SC_PARTNERS_EQUAL)
     const uint32_t* pn = nullptr;
     const int32_t* col = nullptr;      // [n] column fact (SC_QUEENS)
@@ -271,7 +273,7 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
         if (old == value) return r;
         if (value < 0 && !m.allows_unassigned) return r;
         r.doable = true;
-        r.d_un = (value < 0 ? 1 : 0) - (old < 0 ? 1 : 0);
+        r.d_un = (int64_t)((value < 0 ? 1 : 0) - (old < 0 ? 1 : 0)) * (m.un_w ? (int64_t)m.un_w[a] : 1);
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflict_delta(m, vals, a, value, old, 0xFFFFFFFFu);
         if (m.sj_level >= 0) {  // joining a value of c members adds C(c, k-1) tuples; leaving one of c removes C(c-1, k-1)
@@ -322,6 +324,8 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
         const int32_t va = (int32_t)vals[a], vb = (int32_t)vals[b];
         if (va == vb) return r;
         r.doable = true;
+        if (m.un_w)  // the None moves to the other entity: the count stays, the per-entity weights differ
+            r.d_un = (int64_t)((vb < 0 ? 1 : 0) - (va < 0 ? 1 : 0)) * ((int64_t)m.un_w[a] - (int64_t)m.un_w[b]);
         if (m.cross_level >= 0)
             r.d_cross = scalar_conflict_delta(m, vals, a, vb, va, b) + scalar_conflict_delta(m, vals, b, va, vb, a);
         if (m.cost_level >= 0) {
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
 __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
                                                              int accumulate, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];  // per-value tables (when used)
-    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups, s_cost, s_cost_n, s_ex, s_ex_n, s_run, s_run_groups;
+    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups, s_cost, s_cost_n, s_ex, s_ex_n, s_run, s_run_groups, s_un_n;
     const int r = blockIdx.x;
     const int32_t* vals = m.vals + (size_t)r * m.n;
     const bool tables = m.tables();
@@ -631,6 +635,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         s_groups = 0;
         s_cost = s_cost_n = s_ex = s_ex_n = 0;
         s_run = s_run_groups = 0;
+        s_un_n = 0;
     }
     if (tables)
         for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
@@ -684,10 +689,13 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             }
         }
     }
-    unsigned long long un = 0, cross = 0, cost = 0, cost_n = 0;
+    unsigned long long un = 0, un_n = 0, cross = 0, cost = 0, cost_n = 0;
     for (uint32_t e = threadIdx.x; e < (uint32_t)m.n; e += blockDim.x) {
         const int32_t v = vals[e];
-        if (v < 0) ++un;
+        if (v < 0) {
+            un += (unsigned long long)(int64_t)(m.un_w ? m.un_w[e] : 1);
+            un_n += (!m.un_w || m.un_w[e] != 0) ? 1 : 0;
+        }
         if (m.cost_level >= 0 && v >= 0) {
             const int64_t c = m.cost[(size_t)e * m.n_values + v];
             cost += (unsigned long long)c;
@@ -712,6 +720,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         }
     }
     atomicAdd(&s_un, un);
+    atomicAdd(&s_un_n, un_n);
     atomicAdd(&s_cross, cross);
     atomicAdd(&s_cost, cost);
     atomicAdd(&s_cost_n, cost_n);
@@ -742,6 +751,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             q[11] = (int64_t)s_ex_n;
             q[14] = (int64_t)s_run;
             q[15] = (int64_t)s_run_groups;
+            q[16] = (int64_t)s_un_n;
         }
     }
 }

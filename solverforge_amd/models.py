@@ -5,7 +5,7 @@ corresponding reference model does with ConstraintFactory streams.
 """
 from .director import ConstraintKind, GpuScoreDirector, SelectorKind
 
-FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN = 0, 1, 2, 3, 4, 5
+FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN, FACT_AUX = 0, 1, 2, 3, 4, 5, 6
 
 
 def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearby_change", "nearby_swap"),
@@ -160,7 +160,7 @@ def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_chan
 
 
 def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, limit=2, w_streak=1, count_weight=0, target=-1,
-                         leaves=("change", "swap")):
+                         leaves=("change", "swap"), required=None):
     """examples/minimal-shift-scheduling/src/domain/schedule.rs:21-83: shifts choose a nurse.  Hard: unassigned shift; two shifts of
     one nurse on one day (predicate cross-join on the day column).  Soft: long work streaks -- group_by(nurse,
     consecutive_runs(day)).penalize(sum over runs of max(0, point_count - limit)) (stream/collector/runs.rs); count_weight > 0:
@@ -173,7 +173,11 @@ def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, li
     d.add_entity_class(0, n)
     d.add_scalar_variable(0, 0, n_nurses, True, nurse_idx)
     d.add_fact_column_i32(FACT_GROUP, np.asarray(day, dtype=np.int32))
-    d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
+    if required is None:
+        d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
+    else:  # filter(required && unassigned): the filter / per-shift weight as a column (0 = not required)
+        d.add_fact_column_i32(FACT_AUX, np.asarray(required, dtype=np.int32))
+        d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, fact=FACT_AUX, level=0, weight=1)
     d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=0, weight=1)
     d.add_constraint(ConstraintKind.RUNS_VALUE, 0, fact=FACT_GROUP, param=limit, level=1, weight=w_streak)
     if count_weight > 0:

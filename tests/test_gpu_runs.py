@@ -81,12 +81,23 @@ def test_scores_cursor_order_and_trial_scores(oracle, n_nurses, n_days, per_day,
 
 @pytest.mark.parametrize("acceptor,target", [("late", -1), ("anneal", -1), ("late", 12)])
 def test_apply_traced_and_fused_steps(oracle, acceptor, target):
-    """target >= 0: the example's own constraint set (schedule.rs:21-83) -- the complemented |count - target| workload."""
+    """target >= 0: the example's own constraint set (schedule.rs:21-83) -- the complemented |count - target| workload and the
+    `required && unassigned` filter (every third shift is optional, some required ones weigh 2)."""
     import solverforge_amd as sfa
 
     nurse, day = _problem(5, 21, 3, seed=3)
-    d, o = _mk(oracle, nurse, day, 5, limit=2, w_streak=2, count_weight=1, target=target)
-    d.calculate_score()
+    kw = {}
+    if target >= 0:
+        req = np.ones(len(nurse), dtype=np.int64)
+        req[::3] = 0
+        req[1::5] = 2
+        kw["required"] = req
+    d, o = _mk(oracle, nurse, day, 5, limit=2, w_streak=2, count_weight=1, target=target, **kw)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    if target >= 0:
+        gs, gc = d.evaluate_each()
+        os_, oc = o.evaluate_each()
+        assert (gs == os_[:, :2]).all() and (gc == oc).all()
     rng = np.random.default_rng(1)
     o.configure(leaves=3, selection_order=3)
     for it in range(8):  # committed changes and swaps through sf_apply
