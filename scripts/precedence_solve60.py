@@ -1,7 +1,9 @@
 """Best score after `seconds` of wall time on a job shop with the makespan objective (ListPrecedenceMakespanConstraint, list change +
 swap + reverse + sublist change, LateAcceptance(400) + AcceptedCount(256)): GPU portfolio (work-balanced launches) vs the CPU oracle's
-incremental refresh on one host core, same instance, same start (every machine sequence shuffled: cyclic, hard = -node_count).
-argv: seconds jobs machines replicas"""
+incremental refresh on one host core, same instance, same start: the feasible step-major schedule (default), or with argv[5] =
+"shuffled" every machine sequence permuted (cyclic, hard = -node_count: the all-or-nothing cycle penalty is a plateau that neither
+side leaves in 60 s at 200+ nodes -- recorded in profiles/r02e_prec_solve60_shuffled_*.json).
+argv: seconds jobs machines replicas [start]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,8 +18,10 @@ R = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 leaves = ("list_change", "list_swap", "sublist_change", "list_reverse")
 p = datasets.make_precedence_shop(J, M, seed=1)
 feasible = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"]).score()[:2].tolist()
-rng = np.random.default_rng(7)
-p["sequences"] = [list(rng.permutation(s)) for s in p["sequences"]]  # a cyclic start: the search has to find a feasible order first
+start_kind = sys.argv[5] if len(sys.argv) > 5 else "feasible"
+if start_kind == "shuffled":
+    rng = np.random.default_rng(7)
+    p["sequences"] = [[int(x) for x in rng.permutation(s)] for s in p["sequences"]]  # a cyclic start
 d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves)
 d.configure(sfa.SolverConfig(random_seed=0))
 start = [int(v) for v in d.calculate_score()[0]]
@@ -41,5 +45,5 @@ steps = o.steps_timed(seconds)
 ct = time.perf_counter() - t0
 cpu = {"seconds": ct, "best_score": [int(v) for v in o.best_score()[:2]], "ls_steps": int(steps), "moves_evaluated": o.stats()["moves_evaluated"],
        "moves_per_s": o.stats()["moves_evaluated"] / ct}
-print(json.dumps({"workload": "job shop %dx%d, ListPrecedenceMakespan, shuffled (cyclic) start" % (J, M), "leaves": list(leaves), "start_score": start,
+print(json.dumps({"workload": "job shop %dx%d, ListPrecedenceMakespan, %s start" % (J, M, start_kind), "leaves": list(leaves), "start_score": start,
                   "step_major_schedule_score": feasible, "gpu": gpu, "cpu_oracle_1core": cpu}))
