@@ -23,7 +23,9 @@ replica 0's (`extra.replica0_matches_cpu_oracle`).
 
 M2 (`--solve-seconds`, default 60).  A fresh portfolio solves for 60 s of wall clock with work-balanced launches
 (sf_solve_moves) while the CPU oracle solves the same problem (seed of replica 0) on one host core for the same
-60 s: `extra.best_score_at_60s` = {"gpu": ..., "cpu_oracle": ...}.
+60 s: `extra.best_score_at_60s` = {"gpu": ..., "cpu_oracle": ...}.  `--solve-start savings | savings_capacity` starts both
+sides from empty routes with the Clarke-Wright savings construction (sf_construct_list_clarke_wright, the reference's default
+construction for the CVRP domain) built inside the budget; the start score is reported beside the best score.
 
 Multi-GPU.  `python bench.py --gpus N` spawns N ranks itself (torch.distributed.run, one process per GPU) when it is
 not already running under a launcher; it refuses to run with fewer devices than ranks.  Independent seeds per rank
@@ -66,6 +68,10 @@ LDS_PEAK = N_CU * CLOCK_HZ / 2.0
 # TCC passes first: on this pool a FETCH_SIZE pass that FOLLOWS the SQ cycle-counter pass was seen to hang (twice), while
 # the same pass run first completes in seconds; every pass has its own short deadline and a failed pass only drops its
 # own counters.
+# M2 start state (see --solve-start).  The round-robin fill stays the default so rounds remain comparable; profiles/r02f_* hold
+# the savings starts.
+SOLVE_START_DEFAULT = "roundrobin"
+
 PMC_PASSES = [
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
@@ -108,22 +114,27 @@ def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
     }
 
 
-def cpu_solve(problem, seed, seconds, box):
+def cpu_solve(problem, seed, seconds, box, start="roundrobin"):
     """M2 on the host: the oracle searches for `seconds` of wall clock on one core (runs beside the GPU solve; the
-    ctypes call releases the GIL)."""
+    ctypes call releases the GIL).  A savings start (Clarke-Wright construction) is built inside the budget."""
     try:
         from oracle import sfo
 
         o = sfo.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
                            problem["customers"], problem["routes"])
         o.configure(leaves=sfo.LEAF_NEARBY_LIST_CHANGE | sfo.LEAF_NEARBY_LIST_SWAP, max_nearby=20, random_seed=seed)
-        o.phase_start()
         t0 = time.perf_counter()
-        o.steps_timed(seconds)
+        if start != "roundrobin":
+            o.construct_list_clarke_wright(problem["customers"], 1 if start == "savings_capacity" else 0)
+        construct_s = time.perf_counter() - t0
+        start_score = [int(v) for v in o.score()[:2]]
+        o.phase_start()
+        o.steps_timed(max(seconds - construct_s, 0.0))
         dt = time.perf_counter() - t0
         st = o.stats()
         box["result"] = {"best_score": [int(v) for v in o.best_score()[:2]], "steps": st["step_count"],
-                         "moves_evaluated": st["moves_evaluated"], "seconds": dt, "cores": 1}
+                         "moves_evaluated": st["moves_evaluated"], "seconds": dt, "cores": 1,
+                         "start_score": start_score, "construction_seconds": construct_s}
     except Exception as e:  # the bench line still goes out; the gap is visible
         box["error"] = f"{type(e).__name__}: {e}"
 
@@ -227,6 +238,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--solve-seconds", type=float, default=60.0, help="M2: wall-clock budget of the solve leg (0 = skip)")
+    ap.add_argument("--solve-start", choices=["roundrobin", "savings", "savings_capacity"], default=SOLVE_START_DEFAULT,
+                    help="M2 start state: the round-robin fill M1 is timed on, or the device's Clarke-Wright savings construction "
+                         "from empty routes (built inside the budget, on both sides): savings = the stock savings hooks "
+                         "(structural feasibility), savings_capacity = the capacity test of route_hooks::feasible")
     ap.add_argument("--solve-budget", type=int, default=100_000, help="M2: candidates per replica per launch (sf_solve_moves)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline from profiles/)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -272,8 +287,8 @@ def main():
         sys.exit(2)
     seed_base = portfolio.rank_seed_base(args.seed, rank, args.replicas)
 
-    def new_director():
-        d = sfa.build_cvrp(problem, n_replicas=args.replicas, device_id=local_rank)
+    def new_director(prob=None):
+        d = sfa.build_cvrp(prob if prob is not None else problem, n_replicas=args.replicas, device_id=local_rank)
         d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
         # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
         d.configure(sfa.SolverConfig(random_seed=seed_base))
@@ -322,17 +337,24 @@ def main():
     dx = d  # the context whose best score goes into the portfolio exchange
     if args.solve_seconds > 0:
         d.close()
-        d2 = new_director()
-        d2.calculate_score()
-        d2.phase_start()
+        prob2 = problem if args.solve_start == "roundrobin" else dict(problem, routes=[[] for _ in problem["routes"]])
+        d2 = new_director(prob2)
+        m2_start = d2.calculate_score()[0].tolist()
         cpu_box = {}
         cpu_thread = None
         if rank == 0 and not args.no_cpu_baseline:
-            cpu_thread = threading.Thread(target=cpu_solve, args=(problem, args.seed, args.solve_seconds, cpu_box), daemon=True)
+            cpu_thread = threading.Thread(target=cpu_solve, args=(prob2, args.seed, args.solve_seconds, cpu_box, args.solve_start),
+                                          daemon=True)
         barrier(d2)
         if cpu_thread:
             cpu_thread.start()
         t1 = time.perf_counter()
+        construct_s = 0.0
+        if args.solve_start != "roundrobin":  # ListClarkeWrightPhase on every replica, inside the budget
+            sc2, _ = d2.construct_list_clarke_wright(0, prob2["customers"], 1 if args.solve_start == "savings_capacity" else 0)
+            m2_start = sc2[0].tolist()
+            construct_s = time.perf_counter() - t1
+        d2.phase_start()
         n_launch = 0
         while time.perf_counter() - t1 < args.solve_seconds:
             d2.solve_moves(1 << 20, args.solve_budget, sync=True)  # work-balanced launches (sf_solve_moves)
@@ -343,6 +365,7 @@ def main():
             "seconds": gpu_s, "launches": n_launch, "moves_evaluated": st2["moves_evaluated"], "ls_steps": st2["step_count"],
             "best_score_local": list(max(tuple(int(v) for v in s) for s in d2.best_scores())),
             "moves_per_s": st2["moves_evaluated"] / gpu_s,
+            "start": args.solve_start, "start_score": m2_start, "construction_seconds": construct_s,
         }
         if cpu_thread:
             cpu_thread.join(timeout=args.solve_seconds + 30)
@@ -531,6 +554,9 @@ def main():
                 "gpu_moves_per_s_rank0": solve["moves_per_s"],
                 "gpu_ls_steps_rank0": solve["ls_steps"],
                 "gpu_launches": solve["launches"],
+                "start": solve["start"],
+                "start_score": solve["start_score"],
+                "gpu_construction_seconds": solve["construction_seconds"],
                 "cpu_oracle": solve.get("cpu_oracle"),
                 "policy": "2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256); work-balanced launches "
                           f"(sf_solve_moves, {args.solve_budget} candidates per replica per launch)",

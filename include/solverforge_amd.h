@@ -370,6 +370,22 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
  * placed element.  Commits the score of the constructed lists; out_scores[n_replicas * score_levels] may be NULL. */
 int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores);
 
+/* ≙ ListClarkeWrightPhase (crates/solverforge-solver/src/manager/phase_factory/list_clarke_wright.rs:196-330; kernel
+ * list_clarke_wright/kernel.rs:59-472, savings.rs:9-18, route_state.rs, owner_assignment.rs, completion.rs) with the hook bundle of
+ * the stock CVRP domain (crates/solverforge-cvrp/src/helpers.rs:40-87): one savings metric class for the whole fleet, the model's
+ * depot, distance_cost legs of the attached matrix.  elements[n] = the declared elements in source order (distinct); elements
+ * already in a list of a replica are not routed there, the depot's own value is never routed.  feasible_mode 0 =
+ * savings_hooks::feasible (structural only: capacity stays scoreable, the merge runs until one route per owner set remains),
+ * 1 = the capacity test of route_hooks::feasible (route demand <= capacity).  Every replica builds the routes on its empty
+ * owners: savings per pair, a stable descending sort (saving, left, right), merge passes, owner matching, completion by savings
+ * insertion when the routes outnumber the empty owners; when the reference leaves the lists untouched (no empty owner, nothing to
+ * route, unmatched routes that cannot be completed) so does the replica.  out_committed[n_replicas] (may be NULL): 1 = routes
+ * committed.  Commits the score of the resulting lists; out_scores[n_replicas * score_levels] may be NULL.  Owner-restricted
+ * elements (element_owner_fn), per-owner depots / metric classes / capacities and time windows are not modelled
+ * (SF_ERR_UNSUPPORTED where detectable).  Solver counters are not advanced. */
+int32_t sf_construct_list_clarke_wright(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int32_t feasible_mode,
+                                        int64_t* out_scores, int32_t* out_committed);
+
 /* ---- MoveSelector / cursor surface ------------------------------------------------------- */
 /* Opens the configured union cursor for MoveStreamContext(step_index, step_seed) with the given
  * selection order on replica `replica`, drains it, and returns every candidate in cursor order

@@ -111,6 +111,7 @@ def lib():
             "sfo_model_apply_compound": (None, [vp, vp, i64]),
             "sfo_model_construct_first_fit": (None, [vp]),
             "sfo_model_construct_list_cheapest": (None, [vp, vp, i32]),
+            "sfo_model_construct_list_clarke_wright": (i32, [vp, vp, i32, i32, vp]),
             "sfo_model_get_vars": (i32, [vp, i32, i32, vp]),
             "sfo_model_get_lists": (i32, [vp, i32, vp, vp]),
         }
@@ -386,6 +387,14 @@ class Model:
         """List cheapest-insertion construction of the unassigned `elements` (source order)."""
         el = np.ascontiguousarray(elements, dtype=np.uint32)
         lib().sfo_model_construct_list_cheapest(self.h, _p(el), len(el))
+
+    def construct_list_clarke_wright(self, elements, feasible_mode=0):
+        """Clarke-Wright savings construction of the unassigned `elements` (source order) with the solverforge-cvrp hooks;
+        feasible_mode 0 = structural (savings_hooks), 1 = capacity (route_hooks).  Returns (committed, stats[5])."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        st = np.zeros(5, dtype=np.uint64)
+        rc = lib().sfo_model_construct_list_clarke_wright(self.h, _p(el), len(el), int(feasible_mode), _p(st))
+        return bool(rc), st
 
     def construct_first_fit(self):
         lib().sfo_model_construct_first_fit(self.h)

@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstring>
 
+#include "sfo_clarke_wright.hpp"
 #include "sfo_models.hpp"
 
 using namespace sfo;
@@ -441,6 +442,47 @@ void sfo_model_apply_move(void* h, const sfo_move_t* mv) {  // committed do_move
 void sfo_model_construct_list_cheapest(void* h, const uint32_t* elements, int32_t n) {
     Model* m = (Model*)h;
     construct_list_cheapest(m->director, m->list_slot.descriptor_index, std::vector<uint32_t>(elements, elements + n), &m->search.stats);
+}
+// ListClarkeWrightPhase over a CVRP model's list class (list_clarke_wright/kernel.rs) with the solverforge-cvrp hook bundle
+// (crates/solverforge-cvrp/src/helpers.rs:40-87): one shared metric class (every vehicle shares the ProblemData), the model's depot,
+// distance_cost legs; feasible_mode 0 = savings_hooks::feasible (structural only: capacity stays scoreable), 1 = the capacity
+// test of route_hooks::feasible (helpers.rs:169-179).  `elements` = the unassigned elements in source order.  Returns 1 when
+// routes were committed, 0 when the phase left the lists untouched; stats[0..5] = savings pairs, merge trials, merges, merge
+// passes, completion trials.
+int32_t sfo_model_construct_list_clarke_wright(void* h, const uint32_t* elements, int32_t n, int32_t feasible_mode, uint64_t* stats) {
+    Model* m = (Model*)h;
+    const CvrpFacts* cf = static_cast<const CvrpFacts*>(m->director.working.facts.get());
+    const size_t desc = m->list_slot.descriptor_index;
+    EntityClass& c = m->director.working.classes[desc];
+    m->director.calculate_score();
+    ClarkeWrightHooks hk;
+    hk.entity_count = c.n;
+    hk.source_values.assign(elements, elements + n);
+    hk.route_len = [&c](size_t e) { return c.lists[e].size(); };
+    hk.depot = [cf](size_t) { return cf->depot; };
+    hk.metric_class = [](size_t) { return (size_t)0; };
+    hk.distance = [cf](size_t, size_t a, size_t b) { return cf->distance_cost(a, b); };
+    hk.feasible = [cf, feasible_mode](size_t, const std::vector<size_t>& route) {
+        for (size_t v : route)
+            if (v >= cf->dim) return false;
+        if (feasible_mode == 0) return true;
+        int64_t total = 0;
+        for (size_t v : route)
+            if (__builtin_add_overflow(total, (int64_t)cf->demands[v], &total)) return false;
+        return total <= cf->capacity;
+    };
+    hk.replace_route = [m, desc, &c](size_t e, const std::vector<size_t>& route) {
+        m->director.before_variable_changed(desc, e);
+        c.lists[e].assign(route.begin(), route.end());
+        m->director.after_variable_changed(desc, e);
+    };
+    std::vector<size_t> bound((size_t)n);
+    for (size_t i = 0; i < (size_t)n; ++i) bound[i] = i;
+    ClarkeWrightStats st;
+    const bool committed = clarke_wright(hk, bound, &st);
+    m->director.calculate_score();
+    if (stats) stats[0] = st.savings_pairs, stats[1] = st.merge_trials, stats[2] = st.merges, stats[3] = st.merge_passes, stats[4] = st.completion_trials;
+    return committed ? 1 : 0;
 }
 void sfo_model_construct_first_fit(void* h) {
     Model* m = (Model*)h;

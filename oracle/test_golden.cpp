@@ -6,14 +6,17 @@
 #include <cstdio>
 #include <string>
 
+#include <array>
+
+#include "sfo_clarke_wright.hpp"
 #include "sfo_models.hpp"
 
 using namespace sfo;
 
 static int failures = 0;
-#define CHECK(name, cond)                          \
+#define CHECK(name, ...)                           \
     do {                                           \
-        if (cond)                                  \
+        if ((__VA_ARGS__))                         \
             std::printf("ok %s\n", name);          \
         else {                                     \
             std::printf("FAIL %s (line %d)\n", name, __LINE__); \
@@ -1340,7 +1343,217 @@ static void complemented_cases() {
     }
 }
 
+// ---- Clarke-Wright savings construction (manager/phase_factory/list_clarke_wright/tests.rs, tests/metric_class.rs) ----------
+// The reference's toy Plan: customer_values = the declared elements (source order), routes = owner lists; an element's source
+// key is its value (usize_element_source_key).
+struct CwPlan {
+    std::vector<size_t> customer_values;
+    std::vector<std::vector<size_t>> routes;
+};
+static std::vector<size_t> cw_unassigned(const CwPlan& p) {  // runtime_list_source.rs:185-223
+    std::vector<size_t> out;
+    for (size_t i = 0; i < p.customer_values.size(); ++i) {
+        bool assigned = false;
+        for (auto& r : p.routes)
+            for (size_t v : r) assigned |= v == p.customer_values[i];
+        if (!assigned) out.push_back(i);
+    }
+    return out;
+}
+static ClarkeWrightHooks cw_hooks(CwPlan& p, std::function<int64_t(size_t, size_t, size_t)> distance,
+                                  std::function<bool(size_t, const std::vector<size_t>&)> feasible, bool shared_class = false) {
+    ClarkeWrightHooks h;
+    h.entity_count = p.routes.size();
+    h.source_values = p.customer_values;
+    h.route_len = [&p](size_t e) { return p.routes[e].size(); };
+    h.depot = [](size_t) { return (size_t)0; };
+    h.metric_class = shared_class ? std::function<size_t(size_t)>([](size_t) { return (size_t)0; })
+                                  : std::function<size_t(size_t)>([](size_t e) { return e; });  // unique_metric_class (list_clarke_wright.rs:184-186)
+    h.distance = distance;
+    h.feasible = feasible;
+    h.replace_route = [&p](size_t e, const std::vector<size_t>& r) { p.routes[e] = r; };
+    return h;
+}
+static std::vector<size_t> cw_sorted(std::vector<size_t> v) {
+    std::sort(v.begin(), v.end());
+    return v;
+}
+static std::vector<size_t> cw_assigned_sorted(const CwPlan& p) {
+    std::vector<size_t> out;
+    for (auto& r : p.routes) out.insert(out.end(), r.begin(), r.end());
+    return cw_sorted(out);
+}
+static bool cw_any_sorted(const CwPlan& p, std::vector<size_t> want) {
+    for (auto& r : p.routes)
+        if (cw_sorted(r) == want) return true;
+    return false;
+}
+static bool cw_any_exact(const CwPlan& p, std::vector<size_t> want) {
+    for (auto& r : p.routes)
+        if (r == want) return true;
+    return false;
+}
+static void clarke_wright_cases() {
+    using V = std::vector<size_t>;
+    auto abs_distance = [](size_t, size_t a, size_t b) { return (int64_t)(a > b ? a - b : b - a); };
+    auto len3 = [](size_t, const V& r) { return r.size() <= 3; };
+    auto single_visit = [](size_t, const V& r) { return r.size() <= 1; };
+    CHECK("clarke_wright.sum_two_minus_one", cw_sum_two_minus_one(10, 8, 3) == 15 && cw_sum_two_minus_one(INT64_MAX, INT64_MAX, -1) == INT64_MAX &&
+                                                 cw_sum_two_minus_one(INT64_MIN, INT64_MIN, 1) == INT64_MIN);  // distance_arithmetic.rs:24-40
+    {  // clarke_wright_hooks_receive_actual_list_values (tests.rs:231-290)
+        CwPlan p{{10, 20, 30}, {{}}};
+        std::vector<size_t> seen;
+        auto h = cw_hooks(
+            p, [&](size_t, size_t a, size_t b) { seen.push_back(a), seen.push_back(b); return (int64_t)(a > b ? a - b : b - a); },
+            [&](size_t, const V& r) { for (size_t v : r) seen.push_back(v); return r.size() <= 3; });
+        clarke_wright(h, cw_unassigned(p));
+        bool ok = cw_sorted(p.routes[0]) == V{10, 20, 30}, big = false;
+        for (size_t v : seen) {
+            big |= v >= 10;
+            ok = ok && (v == 0 || v == 10 || v == 20 || v == 30);
+        }
+        CHECK("clarke_wright.hooks_receive_actual_list_values", ok && big);
+    }
+    {  // clarke_wright_route_feasible_preserves_capacity_hook_behavior (tests.rs:293-340)
+        CwPlan p{{10, 20, 30}, {{}, {}}};
+        auto h = cw_hooks(p, abs_distance, [](size_t, const V& r) { size_t s = 0; for (size_t v : r) s += v; return s <= 30; });
+        clarke_wright(h, cw_unassigned(p));
+        bool ok = cw_assigned_sorted(p) == V{10, 20, 30};
+        for (auto& r : p.routes) {
+            size_t s = 0;
+            for (size_t v : r) s += v;
+            ok = ok && s <= 30;
+        }
+        CHECK("clarke_wright.capacity_hook", ok);
+    }
+    {  // clarke_wright_extreme_distances_do_not_overflow_savings (tests.rs:343-391)
+        CwPlan p{{10, 20, 30}, {{}, {}, {}}};
+        auto h = cw_hooks(p, [](size_t, size_t a, size_t b) { return a == b ? (int64_t)0 : INT64_MAX; }, single_visit);
+        clarke_wright(h, cw_unassigned(p));
+        bool ok = cw_assigned_sorted(p) == V{10, 20, 30};
+        for (auto& r : p.routes) ok = ok && r.size() <= 1;
+        CHECK("clarke_wright.extreme_distances", ok);
+    }
+    {  // clarke_wright_respects_fixed_element_owner (tests.rs:394-431)
+        CwPlan p{{10, 11}, {{}, {}}};
+        auto h = cw_hooks(p, abs_distance, len3);
+        h.element_owner = [&p](size_t s) { return (int64_t)(p.customer_values[s] % 2); };
+        clarke_wright(h, cw_unassigned(p));
+        CHECK("clarke_wright.fixed_element_owner", p.routes[0] == V{10} && p.routes[1] == V{11});
+    }
+    {  // clarke_wright_keeps_unrestricted_elements_when_owner_hook_exists (tests.rs:434-482)
+        CwPlan p{{10, 11, 12}, {{}, {}, {}}};
+        auto h = cw_hooks(p, abs_distance, single_visit);
+        h.element_owner = [&p](size_t s) { return p.customer_values[s] == 11 ? (int64_t)1 : (int64_t)-1; };
+        clarke_wright(h, cw_unassigned(p));
+        CHECK("clarke_wright.mixed_element_owner", p.routes[1] == V{11} && cw_assigned_sorted(p) == V{10, 11, 12});
+    }
+    {  // clarke_wright_preserves_preassigned_routes (tests.rs:485-531): value 0 is the depot of the empty slots and is filtered
+        CwPlan p{{0, 10, 20, 30}, {{20}, {}, {}}};
+        auto h = cw_hooks(p, abs_distance, len3);
+        clarke_wright(h, cw_unassigned(p));
+        V rest;
+        for (size_t e = 1; e < 3; ++e) rest.insert(rest.end(), p.routes[e].begin(), p.routes[e].end());
+        CHECK("clarke_wright.preserves_preassigned_routes", p.routes[0] == V{20} && cw_sorted(rest) == V{10, 30});
+    }
+    {  // clarke_wright_assigns_constructed_routes_to_feasible_owners (tests.rs:534-576)
+        CwPlan p{{10, 11, 20, 21}, {{}, {}}};
+        auto h = cw_hooks(p, abs_distance, [](size_t e, const V& r) {
+            if (r.size() > 2) return false;
+            for (size_t v : r)
+                if (e == 0 ? v >= 20 : e == 1 ? v < 20 : true) return false;
+            return true;
+        });
+        clarke_wright(h, cw_unassigned(p));
+        CHECK("clarke_wright.feasible_owners", cw_sorted(p.routes[0]) == V{10, 11} && cw_sorted(p.routes[1]) == V{20, 21});
+    }
+    {  // clarke_wright_uses_owner_depots_for_savings (tests.rs:579-625)
+        CwPlan p{{10, 20}, {{}, {}}};
+        std::vector<std::array<size_t, 3>> calls;
+        auto h = cw_hooks(p, [&](size_t e, size_t a, size_t b) { calls.push_back({e, a, b}); return (int64_t)(a > b ? a - b : b - a); }, single_visit);
+        h.depot = [](size_t e) { return 100 + e; };
+        clarke_wright(h, cw_unassigned(p));
+        bool a = false, b = false;
+        for (auto& c : calls) a |= c == std::array<size_t, 3>{0, 100, 10}, b |= c == std::array<size_t, 3>{1, 101, 10};
+        CHECK("clarke_wright.owner_depots", a && b);
+    }
+    {  // clarke_wright_skips_merge_that_breaks_global_owner_matching (tests.rs:628-682)
+        CwPlan p{{1, 2, 3, 4}, {{}, {}, {}}};
+        auto h = cw_hooks(
+            p,
+            [](size_t, size_t a, size_t b) -> int64_t {
+                if (a == 0 || b == 0) return 100;
+                const size_t lo = std::min(a, b), hi = std::max(a, b);
+                return lo == 1 && hi == 2 ? 0 : lo == 2 && hi == 3 ? 1 : 100;
+            },
+            [](size_t e, const V& r) {
+                const V s = cw_sorted(r);
+                return e == 0 ? (s == V{4} || s == V{1, 2, 3}) : e == 1 ? s == V{3} : e == 2 ? s == V{1, 2} : false;
+            });
+        clarke_wright(h, cw_unassigned(p));
+        CHECK("clarke_wright.global_owner_matching",
+              cw_assigned_sorted(p) == V{1, 2, 3, 4} && cw_any_sorted(p, {1, 2}) && cw_any_exact(p, {3}) && cw_any_exact(p, {4}));
+    }
+    {  // clarke_wright_completes_unmatched_routes_with_savings_insertion (tests.rs:685-739)
+        CwPlan p{{1, 2, 3, 4, 5}, {{}, {}, {}}};
+        auto feas = [](size_t e, const V& r) {
+            const size_t cap = e == 0 ? 5 : (e == 1 || e == 2) ? 11 : 0;
+            size_t s = 0;
+            for (size_t v : r) s += (v == 1 || v == 2) ? 6 : (v >= 3 && v <= 5) ? 5 : 100;
+            return s <= cap;
+        };
+        auto h = cw_hooks(
+            p,
+            [](size_t, size_t a, size_t b) -> int64_t {
+                if (a == 0 || b == 0) return 100;
+                const size_t lo = std::min(a, b), hi = std::max(a, b);
+                return lo == 3 && hi == 4 ? 0 : lo == 1 && hi == 5 ? 1 : 90;
+            },
+            feas);
+        ClarkeWrightStats st;
+        clarke_wright(h, cw_unassigned(p), &st);
+        bool ok = cw_assigned_sorted(p) == V{1, 2, 3, 4, 5} && st.completed_by_insertion;
+        for (size_t e = 0; e < 3; ++e) ok = ok && feas(e, p.routes[e]);
+        CHECK("clarke_wright.completion_by_insertion", ok);
+    }
+    {  // clarke_wright_computes_savings_once_per_metric_class (tests/metric_class.rs:59-104)
+        CwPlan p{{1, 2, 3, 4}, {{}, {}, {}, {}, {}, {}}};
+        size_t calls = 0;
+        auto h = cw_hooks(p, [&](size_t, size_t a, size_t b) { ++calls; return (int64_t)(a > b ? a - b : b - a); }, len3, true);
+        clarke_wright(h, cw_unassigned(p));
+        CHECK("clarke_wright.savings_once_per_metric_class", calls == 4 * 3 / 2 * 3);
+    }
+    {  // clarke_wright_keeps_feasibility_owner_specific_with_shared_metric_class (tests/metric_class.rs:107-150)
+        CwPlan p{{1, 2}, {{}, {}}};
+        auto h = cw_hooks(p, abs_distance, [](size_t e, const V& r) {
+            return e == 0 ? r.size() <= 1 : e == 1 ? (r.size() <= 1 || cw_sorted(r) == V{1, 2}) : false;
+        }, true);
+        clarke_wright(h, cw_unassigned(p));
+        CHECK("clarke_wright.owner_specific_feasibility_shared_class", p.routes[0].size() <= 1 && cw_sorted(p.routes[1]) == V{1, 2});
+    }
+    {  // clarke_wright_checks_owner_matching_inside_shared_metric_class (tests/metric_class.rs:153-219)
+        CwPlan p{{1, 2, 3, 4}, {{}, {}, {}}};
+        auto h = cw_hooks(
+            p,
+            [](size_t, size_t a, size_t b) -> int64_t {
+                if (a == 0 || b == 0) return 100;
+                const size_t lo = std::min(a, b), hi = std::max(a, b);
+                return lo == 3 && hi == 4 ? 0 : lo == 1 && hi == 2 ? 1 : 100;
+            },
+            [](size_t e, const V& r) {
+                const V s = cw_sorted(r);
+                if (s == V{1, 2} || s == V{3, 4}) return e == 0;
+                return s.size() == 1 && s[0] >= 1 && s[0] <= 4;
+            },
+            true);
+        clarke_wright(h, cw_unassigned(p));
+        CHECK("clarke_wright.owner_matching_inside_shared_class",
+              cw_assigned_sorted(p) == V{1, 2, 3, 4} && cw_any_sorted(p, {3, 4}) && !cw_any_sorted(p, {1, 2}));
+    }
+}
+
 int main() {
+    clarke_wright_cases();
     complemented_cases();
     runs_cases();
     list_precedence_cases();

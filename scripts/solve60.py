@@ -14,10 +14,14 @@ leaves = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else ("nearby_change
 BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512,
         "list_change": 4, "list_swap": 8, "ruin": 1024}
 # optional fifth argument: "cheapest" = start from the device's list cheapest-insertion construction (both sides) instead of
-# the round-robin fill
+# the round-robin fill; "savings" = Clarke-Wright with the stock savings hooks (structural feasibility: the reference's default
+# construction for the CVRP domain, defaults/stages.rs:257-266), "savings_capacity" = Clarke-Wright with the capacity test
 start = sys.argv[5] if len(sys.argv) > 5 else "roundrobin"
-p = datasets.make_cvrp(1000, 100, 55, seed=0)
-if start == "cheapest":
+# optional sixth / seventh argument: customers, vehicles
+n_customers = int(sys.argv[6]) if len(sys.argv) > 6 else 1000
+n_vehicles = int(sys.argv[7]) if len(sys.argv) > 7 else 100
+p = datasets.make_cvrp(n_customers, n_vehicles, 55, seed=0)
+if start != "roundrobin":
     p["routes"] = [[] for _ in p["routes"]]
 d = sfa.build_cvrp(p, n_replicas=replicas, leaves=leaves)
 d.configure(sfa.SolverConfig(random_seed=0))
@@ -26,6 +30,10 @@ construct_s = 0.0
 if start == "cheapest":
     tc = time.perf_counter()
     start_score = [int(v) for v in d.construct_list_cheapest(0, p["customers"])[0]]
+    construct_s = time.perf_counter() - tc
+elif start in ("savings", "savings_capacity"):
+    tc = time.perf_counter()
+    start_score = [int(v) for v in d.construct_list_clarke_wright(0, p["customers"], 1 if start == "savings_capacity" else 0)[0][0]]
     construct_s = time.perf_counter() - tc
 d.phase_start()
 t0 = time.perf_counter(); trace = []
@@ -53,12 +61,15 @@ o.set_ruin()
 tc = time.perf_counter()
 if start == "cheapest":
     o.construct_list_cheapest(p["customers"])
+elif start in ("savings", "savings_capacity"):
+    o.construct_list_clarke_wright(p["customers"], 1 if start == "savings_capacity" else 0)
 cpu_construct_s = time.perf_counter() - tc
+cpu_start_score = [int(v) for v in o.score()[:2]]
 o.phase_start()
 t0 = time.perf_counter()
 steps = o.steps_timed(seconds)
 ct = time.perf_counter() - t0
 cpu = {"seconds": ct, "best_score": [int(v) for v in o.best_score()[:2]], "ls_steps": int(steps),
        "moves_evaluated": o.stats()["moves_evaluated"], "moves_per_s": o.stats()["moves_evaluated"] / ct,
-       "construction_seconds": cpu_construct_s}
+       "construction_seconds": cpu_construct_s, "start_score": cpu_start_score}
 print(json.dumps({"gpu": gpu, "cpu_oracle_1core": cpu}))

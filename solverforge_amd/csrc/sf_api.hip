@@ -19,6 +19,7 @@
 #include "sf_scalar_kernels.hip"
 #include "sf_mixed_wave.hip"
 #include "sf_construct.hip"
+#include "sf_clarke_wright.hip"
 #include "sf_precedence.hip"
 
 using namespace sf;
@@ -1303,6 +1304,82 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
     (void)hipFree(d_el);
     if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
     return run_evaluate_all(ctx, out_scores, 1);  // finish_construction: the committed score of the constructed lists
+}
+
+// ≙ ListClarkeWrightPhase over every replica's current lists with the stock CVRP hook bundle (csrc/sf_clarke_wright.hip)
+int32_t sf_construct_list_clarke_wright(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int32_t feasible_mode,
+                                        int64_t* out_scores, int32_t* out_committed) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "Clarke-Wright needs the list variable's class");
+    if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_clarke_wright arguments");
+    if (feasible_mode != 0 && feasible_mode != 1) return fail(ctx, SF_ERR_INVALID, "feasible_mode: 0 structural, 1 capacity");
+    if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
+    if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "Clarke-Wright on a model with precedence hooks");
+    if (!ctx->lm.mat) return fail(ctx, SF_ERR_UNSUPPORTED, "Clarke-Wright needs the distance matrix (savings_distance)");
+    if (feasible_mode == 1 && !ctx->lm.demand) return fail(ctx, SF_ERR_INVALID, "capacity feasibility needs the demand column");
+    // declared elements in source order; a duplicate source key is a binding error in the reference (runtime_list_source.rs);
+    // elements whose value is the depot of the available owners are not routed (kernel.rs:83-91)
+    std::vector<uint32_t> el;
+    {
+        std::vector<bool> seen((size_t)ctx->lm.dim, false);
+        for (int32_t k = 0; k < n; ++k) {
+            if (elements[k] >= (uint32_t)ctx->lm.dim) return fail(ctx, SF_ERR_INVALID, "element id out of range");
+            if (seen[elements[k]]) return fail(ctx, SF_ERR_INVALID, "duplicate element");
+            seen[elements[k]] = true;
+            if ((int32_t)elements[k] != ctx->lm.depot) el.push_back(elements[k]);
+        }
+    }
+    const int ne = (int)el.size();
+    if (ne > 65535) return fail(ctx, SF_ERR_UNSUPPORTED, "Clarke-Wright: more than 65535 elements");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    if (out_committed) std::fill(out_committed, out_committed + ctx->R, 0);
+    if (ne == 0) return run_evaluate_all(ctx, out_scores, 1);
+    const CwCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, ne);
+    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "route state does not fit one wave's LDS slice");
+    int monotone = 1;
+    if (ctx->lm.demand) {
+        std::vector<int32_t> dem((size_t)ctx->lm.dim);
+        hipError_t ed = hipMemcpy(dem.data(), ctx->lm.demand, dem.size() * 4, hipMemcpyDeviceToHost);
+        if (ed != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(ed));
+        for (uint32_t x : el)
+            if (dem[x] < 0) monotone = 0;
+    }
+    if (feasible_mode == 0) monotone = 1;  // no load test: every rejection is permanent
+    const uint64_t P = (uint64_t)ne * (uint64_t)(ne - 1) / 2;
+    uint32_t *d_el = nullptr, *d_v0 = nullptr, *d_v1 = nullptr;
+    int64_t *d_k0 = nullptr, *d_k1 = nullptr;
+    int32_t* d_flag = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipError_t e = hipMalloc((void**)&d_el, (size_t)ne * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_flag, (size_t)ctx->R * 4);
+    if (e == hipSuccess && P > 0) e = hipMalloc((void**)&d_k0, P * 8);
+    if (e == hipSuccess && P > 0) e = hipMalloc((void**)&d_k1, P * 8);
+    if (e == hipSuccess && P > 0) e = hipMalloc((void**)&d_v0, P * 4);
+    if (e == hipSuccess && P > 0) e = hipMalloc((void**)&d_v1, P * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_el, el.data(), (size_t)ne * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && P > 0) {
+        hipLaunchKernelGGL(k_cw_savings, dim3((unsigned)((ne + 255) / 256), (unsigned)ne), dim3(256), 0, ctx->stream, ctx->lm, d_el, ne, d_k0, d_v0);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)P, 0, 64, ctx->stream);
+        if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs_desc(d_tmp, tmp_bytes, d_k0, d_k1, d_v0, d_v1, (size_t)P, 0, 64, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        e = hipFuncSetAttribute((const void*)k_cw_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(k_cw_merge, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, ne, d_v1, P, feasible_mode, monotone, d_flag,
+                               (uint64_t*)nullptr);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (e == hipSuccess && out_committed) e = hipMemcpyAsync(out_committed, d_flag, (size_t)ctx->R * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
+    (void)hipFree(d_el), (void)hipFree(d_flag), (void)hipFree(d_k0), (void)hipFree(d_k1), (void)hipFree(d_v0), (void)hipFree(d_v1), (void)hipFree(d_tmp);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return run_evaluate_all(ctx, out_scores, 1);  // the committed score of the constructed lists
 }
 
 // ---- search ------------------------------------------------------------------------------

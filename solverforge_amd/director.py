@@ -267,6 +267,16 @@ class GpuScoreDirector:
         check(self._L.sf_construct_list_cheapest(self._h, descriptor_index, ptr(el), len(el), ptr(out)), self._h)
         return out
 
+    def construct_list_clarke_wright(self, descriptor_index, elements, feasible_mode=0):
+        """≙ ListClarkeWrightPhase (stock CVRP hooks) on every replica: savings routes over the elements that are in no list yet,
+        assigned to the empty owners; feasible_mode 0 = structural (savings_hooks), 1 = capacity (route_hooks).  Returns
+        (committed scores [n_replicas, levels], committed flags [n_replicas])."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        out = np.zeros((self.n_replicas, self.levels), dtype=np.int64)
+        flags = np.zeros(self.n_replicas, dtype=np.int32)
+        check(self._L.sf_construct_list_clarke_wright(self._h, descriptor_index, ptr(el), len(el), int(feasible_mode), ptr(out), ptr(flags)), self._h)
+        return out, flags
+
     # ---- MoveSelector / cursor surface ---------------------------------------------------
     def open_cursor(self, step_index, step_seed, selection_order=SelectionOrder.RANDOM, replica=0, cap=1 << 16):
         """Drains the configured union cursor for MoveStreamContext(step_index, step_seed):

@@ -22,6 +22,8 @@ def test_constraint_node_goldens(oracle):
     assert len(lines) >= 24
     assert all(l.startswith("ok") for l in lines), out.stdout
     assert out.returncode == 0
+    # list_clarke_wright/tests.rs (10), tests/metric_class.rs (3), distance_arithmetic.rs (1 line for its three tests)
+    assert sum(l.startswith("ok clarke_wright.") for l in lines) == 14
 
 
 def test_list_change_canonical_order(oracle):
@@ -216,3 +218,30 @@ def test_indexed_cpu_baseline_follows_the_dense_faithful_oracle(oracle):
         o.phase_start()
         o.steps(40)
     assert a.get_lists(1) == b.get_lists(1) and (a.get_vars(0, 0) == b.get_vars(0, 0)).all() and (a.score() == b.score()).all()
+
+
+def test_clarke_wright_cvrp_adapter_properties(oracle):
+    """The CVRP adapter of the Clarke-Wright oracle (stock savings hooks, one metric class): every customer routed once; the
+    structural mode ends in ONE route (capacity stays scoreable, solverforge-cvrp/src/helpers.rs:71-87), the capacity mode in
+    capacity-feasible routes; an over-subscribed fleet leaves the lists untouched (kernel.rs:401-415)."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(200, 20, 55, seed=0)
+    p["routes"] = [[] for _ in p["routes"]]
+    for mode in (0, 1):
+        o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+        committed, st = o.construct_list_clarke_wright(p["customers"], mode)
+        lists = o.get_lists(0)
+        assert committed and int(st[0]) == 200 * 199 // 2 and int(st[4]) == 0
+        assert sorted(c for rt in lists for c in rt) == list(range(1, 201))
+        routes = [rt for rt in lists if rt]
+        if mode == 0:
+            assert len(routes) == 1 and int(st[2]) == 199
+        else:
+            assert all(sum(int(p["demands"][c]) for c in rt) <= 55 for rt in routes) and o.score()[0] == 0
+            assert int(st[2]) == 200 - len(routes)
+    p2 = datasets.make_cvrp(300, 20, 55, seed=0)
+    p2["routes"] = [[] for _ in p2["routes"]]
+    o = oracle.Model.cvrp(p2["capacity"], p2["depot"], p2["demands"], p2["matrix"], p2["customers"], p2["routes"])
+    committed, st = o.construct_list_clarke_wright(p2["customers"], 1)
+    assert not committed and int(st[4]) > 0 and all(not rt for rt in o.get_lists(0))
