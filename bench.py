@@ -68,9 +68,10 @@ LDS_PEAK = N_CU * CLOCK_HZ / 2.0
 # TCC passes first: on this pool a FETCH_SIZE pass that FOLLOWS the SQ cycle-counter pass was seen to hang (twice), while
 # the same pass run first completes in seconds; every pass has its own short deadline and a failed pass only drops its
 # own counters.
-# M2 start state (see --solve-start).  The round-robin fill stays the default so rounds remain comparable; profiles/r02f_* hold
-# the savings starts.
-SOLVE_START_DEFAULT = "roundrobin"
+# M2 start state (see --solve-start).  M1 is always timed on the round-robin fill (comparable across rounds); M2 starts from the
+# Clarke-Wright savings construction with the capacity test, built inside the 60 s on both sides (profiles/r02f_solve60_*: best@60 s
+# [0, -92932] from this start vs [0, -101064] from the round-robin fill).
+SOLVE_START_DEFAULT = "savings_capacity"
 
 PMC_PASSES = [
     ["FETCH_SIZE"],
@@ -558,7 +559,7 @@ def main():
                 "start_score": solve["start_score"],
                 "gpu_construction_seconds": solve["construction_seconds"],
                 "cpu_oracle": solve.get("cpu_oracle"),
-                "policy": "2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256); work-balanced launches "
+                "policy": f"start = {solve['start']}; 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256); work-balanced launches "
                           f"(sf_solve_moves, {args.solve_budget} candidates per replica per launch)",
             }
         if not args.no_cpu_baseline:
