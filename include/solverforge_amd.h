@@ -370,6 +370,18 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
  * placed element.  Commits the score of the constructed lists; out_scores[n_replicas * score_levels] may be NULL. */
 int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores);
 
+/* ≙ ListConstructionPhase, the round-robin list construction (crates/solverforge-solver/src/manager/phase_factory/
+ * list_construction/round_robin.rs; kernel round_robin/kernel.rs:71-175).  elements[n] = the declared elements in source order
+ * (distinct); order_keys[n] (may be NULL) = construction_order_key per element; owners[n] (may be NULL) = the owner hook's value
+ * per element, -1 = unrestricted (a value >= the owner count is OwnerRestriction::Invalid: the element is skipped,
+ * list_placement.rs:54-69).  In every replica the elements that are in no list yet are taken in (order key, source index)
+ * order: an unrestricted one is appended to the round-robin cursor's owner and advances it, a fixed-owner one is appended to its
+ * owner.  Counters as the kernel records them (one generated + evaluated candidate, one accepted + applied step, one score
+ * calculation per appended element).  Commits the score of the resulting lists; out_scores[n_replicas * score_levels] may be
+ * NULL. */
+int32_t sf_construct_list_round_robin(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
+                                      const int32_t* owners, int64_t* out_scores);
+
 /* ≙ ListClarkeWrightPhase (crates/solverforge-solver/src/manager/phase_factory/list_clarke_wright.rs:196-330; kernel
  * list_clarke_wright/kernel.rs:59-472, savings.rs:9-18, route_state.rs, owner_assignment.rs, completion.rs) with the hook bundle of
  * the stock CVRP domain (crates/solverforge-cvrp/src/helpers.rs:40-87): one savings metric class for the whole fleet, the model's

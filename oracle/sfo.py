@@ -112,6 +112,7 @@ def lib():
             "sfo_model_construct_first_fit": (None, [vp]),
             "sfo_model_construct_list_cheapest": (None, [vp, vp, i32]),
             "sfo_model_construct_list_clarke_wright": (i32, [vp, vp, i32, i32, vp]),
+            "sfo_model_construct_list_round_robin": (None, [vp, vp, i32, vp, vp]),
             "sfo_model_get_vars": (i32, [vp, i32, i32, vp]),
             "sfo_model_get_lists": (i32, [vp, i32, vp, vp]),
         }
@@ -395,6 +396,14 @@ class Model:
         st = np.zeros(5, dtype=np.uint64)
         rc = lib().sfo_model_construct_list_clarke_wright(self.h, _p(el), len(el), int(feasible_mode), _p(st))
         return bool(rc), st
+
+    def construct_list_round_robin(self, elements, order_keys=None, owners=None):
+        """Round-robin list construction of the unassigned `elements` (source order); order_keys / owners parallel to it
+        (owners: -1 unrestricted, otherwise the owner hook's value)."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        ks = None if order_keys is None else np.ascontiguousarray(order_keys, dtype=np.int64)
+        ow = None if owners is None else np.ascontiguousarray(owners, dtype=np.int64)
+        lib().sfo_model_construct_list_round_robin(self.h, _p(el), len(el), None if ks is None else _p(ks), None if ow is None else _p(ow))
 
     def construct_first_fit(self):
         lib().sfo_model_construct_first_fit(self.h)

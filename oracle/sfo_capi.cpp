@@ -484,6 +484,14 @@ int32_t sfo_model_construct_list_clarke_wright(void* h, const uint32_t* elements
     if (stats) stats[0] = st.savings_pairs, stats[1] = st.merge_trials, stats[2] = st.merges, stats[3] = st.merge_passes, stats[4] = st.completion_trials;
     return committed ? 1 : 0;
 }
+// ListConstructionPhase (round robin); order_keys / owners parallel to elements, may be NULL
+void sfo_model_construct_list_round_robin(void* h, const uint32_t* elements, int32_t n, const int64_t* order_keys, const int64_t* owners) {
+    Model* m = (Model*)h;
+    std::vector<int64_t> k, o;
+    if (order_keys) k.assign(order_keys, order_keys + n);
+    if (owners) o.assign(owners, owners + n);
+    construct_list_round_robin(m->director, m->list_slot.descriptor_index, std::vector<uint32_t>(elements, elements + n), k, o, &m->search.stats);
+}
 void sfo_model_construct_first_fit(void* h) {
     Model* m = (Model*)h;
     construct_first_fit(m->director, m->scalar_slot, &m->search.stats);

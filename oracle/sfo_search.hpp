@@ -507,4 +507,37 @@ inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const s
     }
 }
 
+// Round-robin list construction (manager/phase_factory/list_construction/round_robin/kernel.rs:71-175): the unassigned elements in
+// (construction order key, source index) order; an unrestricted element is appended to the round-robin cursor's owner and advances
+// it, an element with a fixed owner (list_placement.rs:54-69: owner hook value < entity count) is appended there without advancing,
+// an element whose hook names no valid owner is skipped.  One generated + evaluated candidate, one accepted + applied step and one
+// score calculation per appended element.  `unassigned` in source order; order_keys / owners (parallel to it) may be empty:
+// owners[k] = -1 unrestricted, >= 0 the owner hook's value.
+inline void construct_list_round_robin(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned,
+                                       const std::vector<int64_t>& order_keys, const std::vector<int64_t>& owners, SolverStats* stats = nullptr) {
+    d.calculate_score();
+    EntityClass& c = d.working.classes[descriptor];
+    const size_t n_entities = c.n;
+    if (n_entities == 0 || unassigned.empty()) return;
+    std::vector<size_t> order(unassigned.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    if (!order_keys.empty()) std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return order_keys[a] < order_keys[b]; });
+    size_t entity_idx = 0;
+    for (size_t k : order) {
+        size_t target = entity_idx;
+        bool advance = true;
+        if (!owners.empty() && owners[k] >= 0) {
+            if ((size_t)owners[k] >= n_entities) continue;  // OwnerRestriction::Invalid
+            target = (size_t)owners[k], advance = false;
+        }
+        if (stats) ++stats->moves_generated, ++stats->moves_evaluated, ++stats->moves_accepted;
+        d.before_variable_changed(descriptor, target);
+        c.lists[target].push_back(unassigned[k]);
+        d.after_variable_changed(descriptor, target);
+        d.calculate_score();
+        if (stats) ++stats->moves_applied, ++stats->step_count, ++stats->score_calculations;
+        if (advance) entity_idx = (entity_idx + 1) % n_entities;
+    }
+}
+
 }  // namespace sfo

@@ -1551,8 +1551,39 @@ static void clarke_wright_cases() {
               cw_assigned_sorted(p) == V{1, 2, 3, 4} && cw_any_sorted(p, {3, 4}) && !cw_any_sorted(p, {1, 2}));
     }
 }
+// list_clarke_wright/tests/compiled_parity.rs:468-476 (public / static / dynamic round robin: elements 1..4 over two empty routes ->
+// [[1, 3], [2, 4]]), list_construction/round_robin/tests.rs:99-105 (accepted / applied counted), list_placement.rs:54-69 + round_robin/
+// kernel.rs:114-122 (a fixed owner does not advance the cursor, an out-of-range owner is skipped)
+static void round_robin_cases() {
+    auto mk = [](size_t n) {
+        ScoreDirector d;
+        d.working.classes.resize(1);
+        d.working.classes[0].n = n;
+        d.working.classes[0].lists.assign(n, {});
+        return d;
+    };
+    using L = std::vector<std::vector<uint32_t>>;
+    {
+        ScoreDirector d = mk(2);
+        SolverStats st;
+        construct_list_round_robin(d, 0, {1, 2, 3, 4}, {}, {}, &st);
+        CHECK("round_robin.compiled_parity_routes", d.working.classes[0].lists == L{{1, 3}, {2, 4}});
+        CHECK("round_robin.counters", st.moves_generated == 4 && st.moves_evaluated == 4 && st.moves_accepted == 4 && st.moves_applied == 4 && st.step_count == 4);
+    }
+    {
+        ScoreDirector d = mk(3);
+        construct_list_round_robin(d, 0, {10, 11, 12, 13, 14}, {}, {-1, 2, -1, 7, -1});
+        CHECK("round_robin.fixed_owner_does_not_advance_invalid_is_skipped", d.working.classes[0].lists == L{{10}, {12}, {11, 14}});
+    }
+    {
+        ScoreDirector d = mk(2);
+        construct_list_round_robin(d, 0, {5, 6, 7, 8}, {3, 1, 3, 0}, {});
+        CHECK("round_robin.order_key_then_source_index", d.working.classes[0].lists == L{{8, 5}, {6, 7}});
+    }
+}
 
 int main() {
+    round_robin_cases();
     clarke_wright_cases();
     complemented_cases();
     runs_cases();

@@ -1306,6 +1306,59 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
     return run_evaluate_all(ctx, out_scores, 1);  // finish_construction: the committed score of the constructed lists
 }
 
+// ≙ ListConstructionPhase (round robin) over every replica's current lists (csrc/sf_construct.hip)
+int32_t sf_construct_list_round_robin(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
+                                      const int32_t* owners, int64_t* out_scores) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "round robin needs the list variable's class");
+    if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_round_robin arguments");
+    if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || n > 65535) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
+    if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "round-robin construction on a model with precedence hooks");
+    std::vector<int32_t> order;
+    {
+        std::vector<bool> seen((size_t)ctx->lm.dim, false);
+        for (int32_t k = 0; k < n; ++k) {
+            if (elements[k] >= (uint32_t)ctx->lm.dim) return fail(ctx, SF_ERR_INVALID, "element id out of range");
+            if (seen[elements[k]]) return fail(ctx, SF_ERR_INVALID, "duplicate element");
+            seen[elements[k]] = true;
+            if (owners && owners[k] < -1) return fail(ctx, SF_ERR_INVALID, "owners[k]: -1 = unrestricted, otherwise the owner hook's value");
+            if (owners && owners[k] >= ctx->lm.V) continue;  // OwnerRestriction::Invalid (list_placement.rs:66-67): skipped
+            order.push_back(k);
+        }
+    }
+    if (order_keys) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return order_keys[a] < order_keys[b]; });
+    const int ne = (int)order.size();
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    if (ne == 0 || ctx->lm.V == 0) return run_evaluate_all(ctx, out_scores, 1);
+    std::vector<uint32_t> el((size_t)ne);
+    std::vector<int32_t> ow((size_t)ne, -1);
+    for (int k = 0; k < ne; ++k) {
+        el[k] = elements[order[k]];
+        if (owners) ow[k] = owners[order[k]];
+    }
+    const RoundRobinCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, ne);
+    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
+    uint32_t* d_el = nullptr;
+    int32_t* d_ow = nullptr;
+    hipError_t e = hipMalloc((void**)&d_el, (size_t)ne * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_ow, (size_t)ne * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_el, el.data(), (size_t)ne * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ow, ow.data(), (size_t)ne * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_list_construct_round_robin, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_list_construct_round_robin, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, owners ? d_ow : (const int32_t*)nullptr, ne,
+                           ctx->sp.stats);
+        e = hipGetLastError();
+    }
+    hipError_t es = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = es;
+    (void)hipFree(d_el), (void)hipFree(d_ow);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return run_evaluate_all(ctx, out_scores, 1);
+}
+
 // ≙ ListClarkeWrightPhase over every replica's current lists with the stock CVRP hook bundle (csrc/sf_clarke_wright.hip)
 int32_t sf_construct_list_clarke_wright(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int32_t feasible_mode,
                                         int64_t* out_scores, int32_t* out_committed) {

@@ -132,6 +132,139 @@ __global__ __launch_bounds__(64) void k_list_construct_cheapest(ListModel lm, co
     }
 }
 
+// Round-robin list construction (manager/phase_factory/list_construction/round_robin/kernel.rs:71-175).  The host hands over the
+// declared elements sorted by (construction order key, source index) with the owner hook's value per element (-1 = unrestricted;
+// elements whose hook names no valid owner are dropped on the host: they are skipped in every replica).  One wavefront per
+// replica: an element already in one of the replica's lists is not a candidate; the k-th unrestricted candidate goes to owner
+// k mod V (the cursor advances only for unrestricted elements), a fixed-owner candidate to its owner; every candidate is appended
+// behind what its list holds so far.  64 elements per round: ranks by ballot prefix, the slot inside a list by counting the
+// earlier lanes with the same target.  Counters: one generated + evaluated candidate, one accepted + applied step, one score
+// calculation per appended element.
+struct RoundRobinCarve {
+    size_t load, off, cnt, visits, tgt, pos, present, total;
+    __host__ __device__ RoundRobinCarve(int V, int n_cap, int dim, int n) {
+        size_t o = 0;
+        load = o;
+        o = align_up(o + sizeof(int64_t) * V, 16);
+        off = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        cnt = o;
+        o = align_up(o + sizeof(uint32_t) * V, 16);
+        visits = o;
+        o = align_up(o + sizeof(uint16_t) * n_cap, 16);
+        tgt = o;
+        o = align_up(o + sizeof(uint16_t) * n, 16);
+        pos = o;
+        o = align_up(o + sizeof(uint16_t) * n, 16);
+        present = o;
+        o = align_up(o + sizeof(uint32_t) * (((size_t)dim + 31) / 32), 16);
+        total = o;
+    }
+};
+
+__global__ __launch_bounds__(64) void k_list_construct_round_robin(ListModel lm, const uint32_t* __restrict__ elements, const int32_t* __restrict__ owners,
+                                                                   int n_el, uint64_t* stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int r = blockIdx.x;
+    const uint32_t V = (uint32_t)lm.V;
+    const RoundRobinCarve cv(lm.V, lm.n_cap, lm.dim, n_el);
+    lds_i64* load = (lds_i64*)(smem + cv.load);
+    lds_u32* off = (lds_u32*)(smem + cv.off);
+    lds_u32* cnt = (lds_u32*)(smem + cv.cnt);
+    lds_u16* visits = (lds_u16*)(smem + cv.visits);
+    lds_u16* tgt = (lds_u16*)(smem + cv.tgt);
+    lds_u16* pos = (lds_u16*)(smem + cv.pos);
+    lds_u32* present = (lds_u32*)(smem + cv.present);
+    uint32_t* g_visits = lm.visits + (size_t)r * lm.n_cap;
+    uint32_t* g_off = lm.off + (size_t)r * (V + 1);
+    int64_t* g_load = lm.load + (size_t)r * V;
+    for (uint32_t t = lane; t < V; t += 64) cnt[t] = g_off[t + 1] - g_off[t];
+    for (uint32_t t = lane; t < ((uint32_t)lm.dim + 31u) / 32u; t += 64) present[t] = 0u;
+    wave_sync();
+    const uint32_t tot0 = g_off[V];
+    for (uint32_t t = lane; t < tot0; t += 64) {
+        const uint32_t x = g_visits[t];
+        atomicOr((uint32_t*)&present[x >> 5], 1u << (x & 31u));
+    }
+    wave_sync();
+    const uint32_t room = (uint32_t)lm.n_cap - tot0;
+    uint32_t placed = 0, cursor = 0;  // candidates so far, unrestricted candidates so far
+    for (uint32_t k0 = 0; k0 < (uint32_t)n_el; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        bool act = false, unres = false;
+        int32_t ow = -1;
+        if (k < (uint32_t)n_el) {
+            const uint32_t x = elements[k];
+            ow = owners ? owners[k] : -1;
+            act = !((present[x >> 5] >> (x & 31u)) & 1u);
+        }
+        const uint64_t am = __ballot(act);
+        const uint32_t arank = placed + (uint32_t)__popcll(am & ((1ull << lane) - 1ull));
+        act = act && arank < room;  // element capacity of the flat lists: construction stops when it is reached
+        const uint64_t am2 = __ballot(act);
+        unres = act && ow < 0;
+        const uint64_t um = __ballot(unres);
+        uint32_t target = 0xFFFFFFFFu;
+        if (act) target = unres ? (cursor + (uint32_t)__popcll(um & ((1ull << lane) - 1ull))) % V : (uint32_t)ow;
+        uint32_t intra = 0;
+        for (uint32_t j = 0; j < 64; ++j) {
+            const uint32_t tj = (uint32_t)__shfl((int)target, (int)j, 64);
+            if (j < lane && tj == target) ++intra;
+        }
+        uint32_t at = 0;
+        if (act) at = cnt[target] + intra;
+        wave_sync();
+        if (act) {
+            atomicAdd((uint32_t*)&cnt[target], 1u);
+            tgt[k] = (uint16_t)target;
+            pos[k] = (uint16_t)at;
+        } else if (k < (uint32_t)n_el) {
+            tgt[k] = 0xFFFFu;
+        }
+        wave_sync();
+        placed += (uint32_t)__popcll(am2);
+        cursor += (uint32_t)__popcll(um);
+    }
+    // new offsets, old contents, appended elements, loads
+    uint32_t acc = 0;
+    for (uint32_t e0 = 0; e0 < V; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        const uint32_t len = e < V ? (uint32_t)cnt[e] : 0u;
+        uint32_t inc = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= (uint32_t)d) inc += o;
+        }
+        if (e < V) off[e] = acc + inc - len;
+        acc += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+    if (lane == 0) off[V] = acc;
+    wave_sync();
+    for (uint32_t e = 0; e < V; ++e) {
+        const uint32_t go = g_off[e], len = g_off[e + 1] - go, o = off[e];
+        for (uint32_t t = lane; t < len; t += 64) visits[o + t] = (uint16_t)g_visits[go + t];
+    }
+    for (uint32_t k = lane; k < (uint32_t)n_el; k += 64)
+        if (tgt[k] != 0xFFFFu) visits[off[tgt[k]] + pos[k]] = (uint16_t)elements[k];
+    wave_sync();
+    for (uint32_t e = lane; e < V; e += 64) {
+        int64_t l = 0;
+        if (lm.demand)
+            for (uint32_t t = off[e]; t < off[e + 1]; ++t) l = wadd(l, (int64_t)lm.demand[visits[t]]);
+        load[e] = l;
+    }
+    wave_sync();
+    for (uint32_t t = lane; t < acc; t += 64) g_visits[t] = visits[t];
+    for (uint32_t t = lane; t <= V; t += 64) g_off[t] = off[t];
+    for (uint32_t t = lane; t < V; t += 64) g_load[t] = load[t];
+    if (stats && lane == 0) {
+        uint64_t* gs = stats + (size_t)r * SF_STATS_WORDS;
+        gs[0] += placed, gs[1] += placed, gs[2] += placed, gs[3] += placed, gs[4] += placed, gs[5] += placed, gs[7] += placed;
+    }
+}
+
 // Host-provided list ruin moves (SF_MOVE_LIST_RUIN through sf_step_evaluate / sf_apply): one wavefront per move, the replica's
 // lists copied into LDS, the same recreate the fused step runs (general matrix-gather path).  move t of the batch = moves[idx[t]].
 // doable = ruin_is_doable without an owner binding (move/list_kernel/ruin.rs:97-113) with the wire format's ascending, distinct

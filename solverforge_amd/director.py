@@ -267,6 +267,20 @@ class GpuScoreDirector:
         check(self._L.sf_construct_list_cheapest(self._h, descriptor_index, ptr(el), len(el), ptr(out)), self._h)
         return out
 
+    def construct_list_round_robin(self, descriptor_index, elements, order_keys=None, owners=None):
+        """≙ ListConstructionPhase (round robin) on every replica: the elements of `elements` (source order) that are in no list
+        yet, in (order key, source index) order, appended to the cursor's owner (owners[k] = -1) or to their fixed owner;
+        returns the committed scores [n_replicas, levels]."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        ks = None if order_keys is None else np.ascontiguousarray(order_keys, dtype=np.int64)
+        ow = None if owners is None else np.ascontiguousarray(owners, dtype=np.int32)
+        if (ks is not None and len(ks) != len(el)) or (ow is not None and len(ow) != len(el)):
+            raise ValueError("order_keys / owners: one value per element")
+        out = np.zeros((self.n_replicas, self.levels), dtype=np.int64)
+        check(self._L.sf_construct_list_round_robin(self._h, descriptor_index, ptr(el), len(el), None if ks is None else ptr(ks),
+                                                    None if ow is None else ptr(ow), ptr(out)), self._h)
+        return out
+
     def construct_list_clarke_wright(self, descriptor_index, elements, feasible_mode=0):
         """≙ ListClarkeWrightPhase (stock CVRP hooks) on every replica: savings routes over the elements that are in no list yet,
         assigned to the empty owners; feasible_mode 0 = structural (savings_hooks), 1 = capacity (route_hooks).  Returns

@@ -101,3 +101,69 @@ def test_cheapest_insertion_validation():
         d.construct_list_cheapest(3, [1])  # not the list class
     d.construct_list_cheapest(0, p["customers"])  # nothing missing: a no-op
     assert d.working_lists(0, 0) == p["routes"]
+
+
+# ---- round-robin list construction (sf_construct_list_round_robin ≙ ListConstructionPhase, round_robin/kernel.rs:71-175) ----------
+@pytest.mark.parametrize("problem,keep,keys,owners", [
+    ("plain", 0, False, False), ("plain", 2, False, False), ("tight", 0, True, False), ("plain", 0, False, True),
+    ("tight", 3, True, True), ("asym", 0, True, True), ("ties", 5, False, False),
+])
+def test_round_robin_matches_oracle(oracle, problem, keep, keys, owners):
+    """keep = start routes that stay filled (their customers are not candidates); keys = construction order keys with ties
+    (source index breaks them); owners = owner hook values: unrestricted, fixed (cursor does not advance), out of range
+    (skipped)."""
+    import solverforge_amd as sfa
+
+    p = _problem(problem)
+    p["routes"] = [rt if i < keep else [] for i, rt in enumerate(p["routes"])]
+    nv = len(p["routes"])
+    d = sfa.build_cvrp(p, n_replicas=3)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    d.calculate_score()
+    rng = np.random.default_rng(7)
+    n = len(p["customers"])
+    ks = rng.integers(0, 6, n).astype(np.int64) if keys else None
+    ow = None
+    if owners:
+        ow = np.full(n, -1, dtype=np.int64)
+        pick = rng.choice(n, n // 3, replace=False)
+        ow[pick] = rng.integers(0, nv + 2, len(pick))  # nv, nv + 1 = no valid owner
+    placed = {c for rt in p["routes"] for c in rt}
+    miss = [i for i, c in enumerate(p["customers"]) if int(c) not in placed]
+    sc = d.construct_list_round_robin(0, p["customers"], ks, ow)
+    o.construct_list_round_robin([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss], None if ow is None else ow[miss])
+    for r in range(3):
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        assert (sc[r] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k] == ost[k], k
+    if not owners:
+        assert gst["moves_applied"] == len(miss)
+
+
+def test_round_robin_golden_and_c3_start(oracle):
+    """The reference's known answer (list_clarke_wright/tests/compiled_parity.rs:468-476: 1..4 over two routes -> [[1, 3], [2, 4]])
+    and: the round-robin fill bench.py times M1 on (datasets.make_cvrp) IS this construction from empty routes."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(4, 2, 55, seed=0)
+    p["routes"] = [[], []]
+    d = sfa.build_cvrp(p, n_replicas=1)
+    d.calculate_score()
+    d.construct_list_round_robin(0, [1, 2, 3, 4])
+    assert d.working_lists(0, 0) == [[1, 3], [2, 4]]
+    p = datasets.make_cvrp(1000, 100, 55, seed=0)
+    start = [list(map(int, rt)) for rt in p["routes"]]
+    p["routes"] = [[] for _ in p["routes"]]
+    d = sfa.build_cvrp(p, n_replicas=2)
+    d.calculate_score()
+    sc = d.construct_list_round_robin(0, p["customers"])
+    assert d.working_lists(0, 1) == start
+    assert sc[1].tolist() == [-97, -548558]
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_round_robin(0, [1, 1])
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_round_robin(0, [1, 2], None, [-2, 0])
