@@ -24,8 +24,8 @@ replica 0's (`extra.replica0_matches_cpu_oracle`).
 M2 (`--solve-seconds`, default 60).  A fresh portfolio solves for 60 s of wall clock with work-balanced launches
 (sf_solve_moves) while the CPU oracle solves the same problem (seed of replica 0) on one host core for the same
 60 s: `extra.best_score_at_60s` = {"gpu": ..., "cpu_oracle": ...}.  `--solve-start savings | savings_capacity` starts both
-sides from empty routes with the Clarke-Wright savings construction (sf_construct_list_clarke_wright, the reference's default
-construction for the CVRP domain) built inside the budget; the start score is reported beside the best score.
+sides from empty routes with the reference's default construction for the CVRP domain -- Clarke-Wright savings
+(sf_construct_list_clarke_wright), then the route-local 2-opt of ListKOptPhase (sf_construct_list_k_opt) -- built inside the budget; the start score is reported beside the best score.
 
 Multi-GPU.  `python bench.py --gpus N` spawns N ranks itself (torch.distributed.run, one process per GPU) when it is
 not already running under a launcher; it refuses to run with fewer devices than ranks.  Independent seeds per rank
@@ -127,6 +127,7 @@ def cpu_solve(problem, seed, seconds, box, start="roundrobin"):
         t0 = time.perf_counter()
         if start != "roundrobin":
             o.construct_list_clarke_wright(problem["customers"], 1 if start == "savings_capacity" else 0)
+            o.construct_list_k_opt(2, 1)  # the default construction's second step (ListKOpt with route_hooks::feasible)
         construct_s = time.perf_counter() - t0
         start_score = [int(v) for v in o.score()[:2]]
         o.phase_start()
@@ -353,7 +354,7 @@ def main():
         construct_s = 0.0
         if args.solve_start != "roundrobin":  # ListClarkeWrightPhase on every replica, inside the budget
             sc2, _ = d2.construct_list_clarke_wright(0, prob2["customers"], 1 if args.solve_start == "savings_capacity" else 0)
-            m2_start = sc2[0].tolist()
+            m2_start = d2.construct_list_k_opt(0, 2, 1)[0].tolist()  # ListKOptPhase (route_hooks::feasible): the default's second step
             construct_s = time.perf_counter() - t1
         d2.phase_start()
         n_launch = 0

@@ -370,6 +370,17 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
  * placed element.  Commits the score of the constructed lists; out_scores[n_replicas * score_levels] may be NULL. */
 int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores);
 
+/* ≙ ListKOptPhase (crates/solverforge-solver/src/manager/phase_factory/list_k_opt.rs; kernel list_k_opt/kernel.rs:57-220), the
+ * route-local 2-opt polishing the default construction runs after Clarke-Wright, with the stock CVRP route hooks (the model's
+ * depot, distance_cost legs of the attached matrix).  k: only 2 is implemented by the reference, every other value is a scored
+ * no-op.  feasible_mode 0 = no feasibility hook, 1 = the capacity test of route_hooks::feasible (an over-capacity route takes no
+ * reversal).  Every route with >= 4 visits of every replica is swept to its 2-opt local optimum in the reference's candidate
+ * order (first improving reversal applied in place); max_sweeps >= 1 bounds the sweeps per route (the phase's termination policy:
+ * on an asymmetric metric the 2-opt delta ignores the reversed inner legs and need not converge).  Counters: one generated + evaluated candidate per (i, j), one accepted move
+ * per reversal, applied = the accepted reversals of a changed route, one step + score calculation per changed route.  Commits the
+ * score of the resulting lists; out_scores[n_replicas * score_levels] may be NULL. */
+int32_t sf_construct_list_k_opt(sf_ctx* ctx, int32_t descriptor_index, int32_t k, int32_t feasible_mode, int32_t max_sweeps, int64_t* out_scores);
+
 /* ≙ ListConstructionPhase, the round-robin list construction (crates/solverforge-solver/src/manager/phase_factory/
  * list_construction/round_robin.rs; kernel round_robin/kernel.rs:71-175).  elements[n] = the declared elements in source order
  * (distinct); order_keys[n] (may be NULL) = construction_order_key per element; owners[n] (may be NULL) = the owner hook's value

@@ -113,6 +113,7 @@ def lib():
             "sfo_model_construct_list_cheapest": (None, [vp, vp, i32]),
             "sfo_model_construct_list_clarke_wright": (i32, [vp, vp, i32, i32, vp]),
             "sfo_model_construct_list_round_robin": (None, [vp, vp, i32, vp, vp]),
+            "sfo_model_construct_list_k_opt": (None, [vp, i32, i32, i32, vp]),
             "sfo_model_get_vars": (i32, [vp, i32, i32, vp]),
             "sfo_model_get_lists": (i32, [vp, i32, vp, vp]),
         }
@@ -404,6 +405,13 @@ class Model:
         ks = None if order_keys is None else np.ascontiguousarray(order_keys, dtype=np.int64)
         ow = None if owners is None else np.ascontiguousarray(owners, dtype=np.int64)
         lib().sfo_model_construct_list_round_robin(self.h, _p(el), len(el), None if ks is None else _p(ks), None if ow is None else _p(ow))
+
+    def construct_list_k_opt(self, k=2, feasible_mode=1, max_sweeps=1000):
+        """Route-local 2-opt polishing (ListKOptPhase) with the stock CVRP route hooks; at most max_sweeps sweeps per route
+        (0 = unlimited); returns stats[4] = candidates, accepted, applied, steps."""
+        st = np.zeros(4, dtype=np.uint64)
+        lib().sfo_model_construct_list_k_opt(self.h, int(k), int(feasible_mode), int(max_sweeps), _p(st))
+        return st
 
     def construct_first_fit(self):
         lib().sfo_model_construct_first_fit(self.h)

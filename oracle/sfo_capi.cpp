@@ -484,6 +484,41 @@ int32_t sfo_model_construct_list_clarke_wright(void* h, const uint32_t* elements
     if (stats) stats[0] = st.savings_pairs, stats[1] = st.merge_trials, stats[2] = st.merges, stats[3] = st.merge_passes, stats[4] = st.completion_trials;
     return committed ? 1 : 0;
 }
+// ListKOptPhase (route-local 2-opt) over a CVRP model's list class with the stock route hooks (solverforge-cvrp/src/helpers.rs
+// route_hooks: depot, distance_cost legs; feasible_mode 0 = no feasibility hook, 1 = the capacity test of route_hooks::feasible).
+// stats[0..4] = candidates, accepted reversals, applied (committed) reversals, steps (changed routes).
+void sfo_model_construct_list_k_opt(void* h, int32_t k, int32_t feasible_mode, int32_t max_sweeps, uint64_t* stats) {
+    Model* m = (Model*)h;
+    const CvrpFacts* cf = static_cast<const CvrpFacts*>(m->director.working.facts.get());
+    const size_t desc = m->list_slot.descriptor_index;
+    EntityClass& c = m->director.working.classes[desc];
+    m->director.calculate_score();
+    ListKOptHooks hk;
+    hk.entity_count = c.n;
+    hk.route_values = [&c](size_t e) { return std::vector<size_t>(c.lists[e].begin(), c.lists[e].end()); };
+    hk.replace_route = [m, desc, &c](size_t e, const std::vector<size_t>& route) {
+        m->director.before_variable_changed(desc, e);
+        c.lists[e].assign(route.begin(), route.end());
+        m->director.after_variable_changed(desc, e);
+        m->director.calculate_score();
+    };
+    hk.depot = [cf](size_t) { return cf->depot; };
+    hk.distance = [cf](size_t, size_t a, size_t b) { return cf->distance_cost(a, b); };
+    if (feasible_mode == 1)
+        hk.feasible = [cf](size_t, const std::vector<size_t>& route) {
+            int64_t total = 0;
+            for (size_t v : route)
+                if (v >= cf->dim || __builtin_add_overflow(total, (int64_t)cf->demands[v], &total)) return false;
+            return total <= cf->capacity;
+        };
+    ListKOptStats st;
+    list_k_opt(hk, (size_t)k, &st, (size_t)max_sweeps);
+    m->director.calculate_score();
+    SolverStats& ss = m->search.stats;
+    ss.moves_generated += st.candidates, ss.moves_evaluated += st.candidates, ss.moves_accepted += st.accepted, ss.moves_applied += st.applied;
+    ss.step_count += st.steps, ss.score_calculations += st.steps;
+    if (stats) stats[0] = st.candidates, stats[1] = st.accepted, stats[2] = st.applied, stats[3] = st.steps;
+}
 // ListConstructionPhase (round robin); order_keys / owners parallel to elements, may be NULL
 void sfo_model_construct_list_round_robin(void* h, const uint32_t* elements, int32_t n, const int64_t* order_keys, const int64_t* owners) {
     Model* m = (Model*)h;

@@ -414,4 +414,71 @@ inline bool clarke_wright(const ClarkeWrightHooks& h, const std::vector<size_t>&
     return false;
 }
 
+// ---- route-local 2-opt polishing (manager/phase_factory/list_k_opt/kernel.rs:57-220; the step the default construction runs after
+// Clarke-Wright).  Per owner with >= 4 visits: sweeps over (i, j), i < j, reversing route[i..=j] in place whenever
+// d(a, c) + d(b, e) < d(a, b) + d(c, e) and the reversed route is feasible -- with a = the element before i (or the depot) and
+// b = route[i] READ ONCE PER i (they are not refreshed after a reversal inside the j loop: restated as written), c = route[j],
+// e = the element after j (or the depot) read from the current route -- until a sweep improves nothing; a changed route is committed
+// as one step.  k != 2 is a scored no-op.  distance_arithmetic.rs:1-5 sum_two: exact sum clamped to i64.
+inline int64_t cw_sum_two(int64_t l, int64_t r) {
+    __int128 v = (__int128)l + (__int128)r;
+    if (v > (__int128)INT64_MAX) return INT64_MAX;
+    if (v < (__int128)INT64_MIN) return INT64_MIN;
+    return (int64_t)v;
+}
+struct ListKOptHooks {
+    size_t entity_count = 0;
+    std::function<std::vector<size_t>(size_t)> route_values;
+    std::function<void(size_t, const std::vector<size_t>&)> replace_route;
+    std::function<size_t(size_t)> depot;
+    std::function<int64_t(size_t, size_t, size_t)> distance;
+    std::function<bool(size_t, const std::vector<size_t>&)> feasible;  // empty = always
+};
+struct ListKOptStats {
+    uint64_t candidates = 0, accepted = 0, applied = 0, steps = 0;
+};
+// max_sweeps (0 = unlimited) stands in for the construction's termination policy (kernel.rs:117-121): on an asymmetric metric the
+// 2-opt delta ignores the reversed inner legs and the sweeps need not converge.
+inline void list_k_opt(const ListKOptHooks& h, size_t k, ListKOptStats* stats = nullptr, size_t max_sweeps = 0) {
+    if (k != 2) return;
+    for (size_t ent = 0; ent < h.entity_count; ++ent) {
+        const size_t depot = h.depot(ent);
+        std::vector<size_t> route = h.route_values(ent);
+        const size_t n = route.size();
+        if (n < 4) continue;
+        bool changed = false;
+        uint64_t pending = 0;
+        size_t sweeps = 0;
+        for (;;) {
+            bool improved = false;
+            for (size_t i = 0; i + 1 < n; ++i) {
+                const size_t a = i == 0 ? depot : route[i - 1];
+                const size_t b = route[i];
+                for (size_t j = i + 1; j < n; ++j) {
+                    const size_t c = route[j];
+                    const size_t e = j + 1 < n ? route[j + 1] : depot;
+                    const int64_t proposed = cw_sum_two(h.distance(ent, a, c), h.distance(ent, b, e));
+                    const int64_t current = cw_sum_two(h.distance(ent, a, b), h.distance(ent, c, e));
+                    if (stats) ++stats->candidates;
+                    if (proposed < current) {
+                        std::reverse(route.begin() + (std::ptrdiff_t)i, route.begin() + (std::ptrdiff_t)j + 1);
+                        if (h.feasible && !h.feasible(ent, route)) {
+                            std::reverse(route.begin() + (std::ptrdiff_t)i, route.begin() + (std::ptrdiff_t)j + 1);
+                            continue;
+                        }
+                        if (stats) ++stats->accepted;
+                        ++pending;
+                        improved = changed = true;
+                    }
+                }
+            }
+            if (!improved || (max_sweeps && ++sweeps >= max_sweeps)) break;
+        }
+        if (changed) {
+            h.replace_route(ent, route);
+            if (stats) stats->applied += pending, ++stats->steps;
+        }
+    }
+}
+
 }  // namespace sfo

@@ -1581,8 +1581,32 @@ static void round_robin_cases() {
         CHECK("round_robin.order_key_then_source_index", d.working.classes[0].lists == L{{8, 5}, {6, 7}});
     }
 }
+// manager/phase_factory/list_k_opt.rs:325-395 (route-local 2-opt: improves [1,3,2,4] to [1,2,3,4] on the line metric; a feasibility
+// hook that rejects the reversal keeps the route; extreme distances neither overflow nor accept a wrapped improvement)
+static void list_k_opt_cases() {
+    using V = std::vector<size_t>;
+    auto run = [](V route, std::function<int64_t(size_t, size_t, size_t)> dist, std::function<bool(size_t, const V&)> feas, size_t k = 2) {
+        std::vector<V> routes{route};
+        ListKOptHooks h;
+        h.entity_count = 1;
+        h.route_values = [&](size_t e) { return routes[e]; };
+        h.replace_route = [&](size_t e, const V& r) { routes[e] = r; };
+        h.depot = [](size_t) { return (size_t)0; };
+        h.distance = dist;
+        h.feasible = feas;
+        list_k_opt(h, k);
+        return routes[0];
+    };
+    auto line = [](size_t, size_t a, size_t b) { return (int64_t)(a > b ? a - b : b - a); };
+    CHECK("list_k_opt.improves_route", run({1, 3, 2, 4}, line, nullptr) == V{1, 2, 3, 4});
+    CHECK("list_k_opt.feasibility_hook_rejects", run({1, 3, 2, 4}, line, [](size_t, const V& r) { return r.size() > 2 && r[1] == 3 && r[2] == 2; }) == V{1, 3, 2, 4});
+    CHECK("list_k_opt.extreme_distances", run({1, 3, 2, 4}, [](size_t, size_t a, size_t b) { return a == b ? (int64_t)0 : INT64_MAX; }, nullptr) == V{1, 3, 2, 4});
+    CHECK("list_k_opt.k_other_than_2_is_a_no_op", run({1, 3, 2, 4}, line, nullptr, 3) == V{1, 3, 2, 4});
+    CHECK("list_k_opt.sum_two", cw_sum_two(4, 7) == 11 && cw_sum_two(INT64_MAX, 1) == INT64_MAX && cw_sum_two(INT64_MIN, -1) == INT64_MIN);
+}
 
 int main() {
+    list_k_opt_cases();
     round_robin_cases();
     clarke_wright_cases();
     complemented_cases();

@@ -33,7 +33,8 @@ if start == "cheapest":
     construct_s = time.perf_counter() - tc
 elif start in ("savings", "savings_capacity"):
     tc = time.perf_counter()
-    start_score = [int(v) for v in d.construct_list_clarke_wright(0, p["customers"], 1 if start == "savings_capacity" else 0)[0][0]]
+    d.construct_list_clarke_wright(0, p["customers"], 1 if start == "savings_capacity" else 0)
+    start_score = [int(v) for v in d.construct_list_k_opt(0, 2, 1)[0]]  # the default construction's second step
     construct_s = time.perf_counter() - tc
 d.phase_start()
 t0 = time.perf_counter(); trace = []
@@ -63,6 +64,7 @@ if start == "cheapest":
     o.construct_list_cheapest(p["customers"])
 elif start in ("savings", "savings_capacity"):
     o.construct_list_clarke_wright(p["customers"], 1 if start == "savings_capacity" else 0)
+    o.construct_list_k_opt(2, 1)
 cpu_construct_s = time.perf_counter() - tc
 cpu_start_score = [int(v) for v in o.score()[:2]]
 o.phase_start()

@@ -1306,6 +1306,33 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
     return run_evaluate_all(ctx, out_scores, 1);  // finish_construction: the committed score of the constructed lists
 }
 
+// ≙ ListKOptPhase (route-local 2-opt) over every replica's current lists (csrc/sf_clarke_wright.hip)
+int32_t sf_construct_list_k_opt(sf_ctx* ctx, int32_t descriptor_index, int32_t k, int32_t feasible_mode, int32_t max_sweeps, int64_t* out_scores) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "list k-opt needs the list variable's class");
+    if (feasible_mode != 0 && feasible_mode != 1) return fail(ctx, SF_ERR_INVALID, "feasible_mode: 0 no feasibility hook, 1 capacity");
+    if (max_sweeps < 1) return fail(ctx, SF_ERR_INVALID, "max_sweeps must be >= 1 (the termination policy of the phase)");
+    if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
+    if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "list k-opt on a model with precedence hooks");
+    if (!ctx->lm.mat) return fail(ctx, SF_ERR_UNSUPPORTED, "list k-opt needs the distance matrix (route_distance)");
+    if (feasible_mode == 1 && !ctx->lm.demand) return fail(ctx, SF_ERR_INVALID, "capacity feasibility needs the demand column");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    if (k == 2 && ctx->lm.V > 0) {  // only k = 2 is implemented by the reference: every other value is a scored no-op (kernel.rs:69-77)
+        const size_t lds = align_up((size_t)ctx->lm.n_cap * 2, 16) + 16;
+        if (lds > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "a route does not fit one wave's LDS slice");
+        hipError_t e = hipFuncSetAttribute((const void*)k_list_construct_two_opt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_list_construct_two_opt, dim3((unsigned)ctx->lm.V, (unsigned)ctx->R), dim3(64), lds, ctx->stream, ctx->lm, feasible_mode, max_sweeps, ctx->sp.stats);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    }
+    return run_evaluate_all(ctx, out_scores, 1);
+}
+
 // ≙ ListConstructionPhase (round robin) over every replica's current lists (csrc/sf_construct.hip)
 int32_t sf_construct_list_round_robin(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
                                       const int32_t* owners, int64_t* out_scores) {

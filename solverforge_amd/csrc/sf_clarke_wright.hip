@@ -390,4 +390,82 @@ __global__ __launch_bounds__(64) void k_cw_merge(ListModel lm, const uint32_t* _
     }
 }
 
+// ---- route-local 2-opt polishing (manager/phase_factory/list_k_opt/kernel.rs:57-220), the step the default construction runs
+// after Clarke-Wright.  The reference sweeps (i, j), i < j, per route and reverses route[i..=j] in place at the FIRST improving j,
+// then continues with j + 1 on the modified route; a = the element before i (or the depot) and b = route[i] are read once per i.
+// A reversal of [i..=j0] only touches positions <= j0 and a later j of the same row reads positions j, j + 1 > j0, so every
+// predicate of row i can be evaluated from the route as it stands when the row starts: one wavefront per (route, replica), 64
+// values of j per round, the improving lanes applied in ascending order as wave-parallel segment reversals.  Feasibility (mode 1:
+// the capacity test of route_hooks::feasible) does not depend on the order of a route: it is one flag per route, an infeasible
+// route takes no reversal.  Counters: one generated + evaluated candidate per (i, j), one accepted move per reversal, applied =
+// the accepted reversals of a changed route, one step + score calculation per changed route.
+__global__ __launch_bounds__(64) void k_list_construct_two_opt(ListModel lm, int feasible_mode, int max_sweeps, uint64_t* stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lds_u16* route = (lds_u16*)smem;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t e = blockIdx.x;
+    const int r = blockIdx.y;
+    const uint32_t V = (uint32_t)lm.V;
+    uint32_t* g_visits = lm.visits + (size_t)r * lm.n_cap;
+    const uint32_t* g_off = lm.off + (size_t)r * (V + 1);
+    const uint32_t o = g_off[e], n = g_off[e + 1] - o;
+    if (n < 4) return;
+    for (uint32_t t = lane; t < n; t += 64) route[t] = (uint16_t)g_visits[o + t];
+    wave_sync();
+    const bool feas = feasible_mode == 0 || lm.load[(size_t)r * V + e] <= lm.capacity;
+    const uint32_t depot = (uint32_t)lm.depot;
+    uint64_t cand = 0, acc = 0;
+    bool changed = false;
+    int sweeps = 0;
+    for (;;) {
+        bool improved = false;
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+            const uint32_t a = i == 0 ? depot : (uint32_t)uni(route[i - 1]);
+            const uint32_t b = uni(route[i]);
+            const int64_t dab = cw_dist_cost(lm, a, b);
+            for (uint32_t j0 = i + 1; j0 < n; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                bool imp = false;
+                if (j < n) {
+                    const uint32_t c = route[j];
+                    const uint32_t en = j + 1 < n ? (uint32_t)route[j + 1] : depot;
+                    imp = cw_dist_cost(lm, a, c) + cw_dist_cost(lm, b, en) < dab + cw_dist_cost(lm, c, en);
+                }
+                cand += (n - j0) < 64u ? (n - j0) : 64u;
+                uint64_t mask = __ballot(imp);
+                if (!feas) mask = 0ull;
+                while (mask) {
+                    const uint32_t jj = j0 + (uint32_t)__builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    const uint32_t half = (jj - i + 1u) / 2u;
+                    wave_sync();
+                    for (uint32_t t = lane; t < half; t += 64) {
+                        const uint16_t x = route[i + t], y = route[jj - t];
+                        route[i + t] = y;
+                        route[jj - t] = x;
+                    }
+                    wave_sync();
+                    ++acc;
+                    improved = changed = true;
+                }
+            }
+        }
+        if (!improved || ++sweeps >= max_sweeps) break;  // max_sweeps = the termination policy (kernel.rs:117-121)
+    }
+    if (changed)
+        for (uint32_t t = lane; t < n; t += 64) g_visits[o + t] = route[t];
+    if (stats && lane == 0) {
+        uint64_t* gs = stats + (size_t)r * SF_STATS_WORDS;
+        atomicAdd((unsigned long long*)&gs[1], (unsigned long long)cand);
+        atomicAdd((unsigned long long*)&gs[2], (unsigned long long)cand);
+        atomicAdd((unsigned long long*)&gs[7], (unsigned long long)cand);
+        atomicAdd((unsigned long long*)&gs[3], (unsigned long long)acc);
+        if (changed) {
+            atomicAdd((unsigned long long*)&gs[4], (unsigned long long)acc);
+            atomicAdd((unsigned long long*)&gs[0], 1ull);
+            atomicAdd((unsigned long long*)&gs[5], 1ull);
+        }
+    }
+}
+
 }  // namespace sf

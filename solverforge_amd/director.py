@@ -267,6 +267,14 @@ class GpuScoreDirector:
         check(self._L.sf_construct_list_cheapest(self._h, descriptor_index, ptr(el), len(el), ptr(out)), self._h)
         return out
 
+    def construct_list_k_opt(self, descriptor_index, k=2, feasible_mode=1, max_sweeps=1000):
+        """≙ ListKOptPhase on every replica: every route swept to its 2-opt local optimum (k = 2; other k: scored no-op), at
+        most max_sweeps sweeps per route; feasible_mode 0 = no feasibility hook, 1 = capacity.  Returns the committed scores
+        [n_replicas, levels]."""
+        out = np.zeros((self.n_replicas, self.levels), dtype=np.int64)
+        check(self._L.sf_construct_list_k_opt(self._h, descriptor_index, int(k), int(feasible_mode), int(max_sweeps), ptr(out)), self._h)
+        return out
+
     def construct_list_round_robin(self, descriptor_index, elements, order_keys=None, owners=None):
         """≙ ListConstructionPhase (round robin) on every replica: the elements of `elements` (source order) that are in no list
         yet, in (order key, source index) order, appended to the cursor's owner (owners[k] = -1) or to their fixed owner;

@@ -174,3 +174,72 @@ def test_clarke_wright_validation():
     assert not flags.any() and d.working_lists(0, 0) == [[] for _ in range(4)]
     sc, flags = d.construct_list_clarke_wright(0, [5], 1)  # one element: a singleton route, no savings entry
     assert flags.all() and sorted(c for rt in d.working_lists(0, 0) for c in rt) == [5]
+
+
+# ---- route-local 2-opt polishing (sf_construct_list_k_opt ≙ ListKOptPhase, list_k_opt/kernel.rs:57-220) ------------------------
+KOPT_CASES = [
+    ("plain", "roundrobin", 1, 1000), ("plain", "roundrobin", 0, 1000), ("plain", "savings", 1, 1000), ("ragged", "roundrobin", 0, 1000),
+    ("ties", "roundrobin", 0, 1000), ("asym", "roundrobin", 0, 7), ("asym", "roundrobin", 1, 3), ("infeasible", "roundrobin", 1, 1000),
+    ("infeasible", "roundrobin", 0, 1000), ("ragged", "one_route", 0, 1000), ("plain", "one_route", 1, 1000),
+]
+
+
+@pytest.mark.parametrize("problem,start,mode,max_sweeps", KOPT_CASES)
+def test_list_k_opt_matches_oracle(oracle, problem, start, mode, max_sweeps):
+    """start: the round-robin fill, the savings routes (capacity mode), or every customer in ONE route (> 64 visits: several
+    rounds of j per row; mode 1: over capacity, so no reversal is taken).  The asymmetric cases run under a small sweep bound:
+    parity holds sweep for sweep whether or not the 2-opt delta converges there."""
+    import solverforge_amd as sfa
+
+    p = _problem(problem)
+    if start == "one_route":
+        p["routes"] = [[int(c) for c in p["customers"]]] + [[] for _ in p["routes"][1:]]
+    elif start == "savings":
+        p["routes"] = [[] for _ in p["routes"]]
+    d = sfa.build_cvrp(p, n_replicas=3)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    if start == "savings":
+        d.construct_list_clarke_wright(0, p["customers"], 1)
+        o.construct_list_clarke_wright([int(c) for c in p["customers"]], 1)
+    before = o.get_lists(0)
+    g0, o0 = d.stats(0), o.stats()
+    sc = d.construct_list_k_opt(0, 2, mode, max_sweeps)
+    st = o.construct_list_k_opt(2, mode, max_sweeps)
+    for r in range(3):
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        assert (sc[r] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k] - g0[k] == ost[k] - o0[k], k
+    assert int(st[0]) > 0
+    if problem == "plain" and start == "roundrobin":
+        assert o.get_lists(0) != before and int(st[1]) > 0
+    if (problem == "infeasible" or start == "one_route") and mode == 1:
+        assert o.get_lists(0) == before and int(st[1]) == 0  # over-capacity routes: every reversal is infeasible
+    sc2 = d.construct_list_k_opt(0, 3, mode, max_sweeps)  # k != 2: scored no-op
+    assert (sc2 == sc).all() and d.working_lists(0, 0) == o.get_lists(0)
+
+
+def test_default_construction_pipeline_cvrp_1000(oracle):
+    """The reference's default construction of the CVRP domain (defaults/stages.rs:225-266): Clarke-Wright, then ListKOpt; here with
+    the capacity test on both.  C3 size, lists == the oracle's."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(1000, 100, 55, seed=0)
+    p["routes"] = [[] for _ in p["routes"]]
+    d = sfa.build_cvrp(p, n_replicas=2)
+    d.calculate_score()
+    d.construct_list_clarke_wright(0, p["customers"], 1)
+    sc = d.construct_list_k_opt(0, 2, 1)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.construct_list_clarke_wright(p["customers"], 1)
+    st = o.construct_list_k_opt(2, 1)
+    assert d.working_lists(0, 1) == o.get_lists(0)
+    assert (sc[0] == o.score()[:2]).all() and sc[0].tolist() == [0, -93239] and int(st[1]) == 44
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_k_opt(0, 2, 1, 0)  # max_sweeps >= 1
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_k_opt(0, 2, 2)

@@ -24,6 +24,9 @@ def test_constraint_node_goldens(oracle):
     assert out.returncode == 0
     # list_clarke_wright/tests.rs (10), tests/metric_class.rs (3), distance_arithmetic.rs (1 line for its three tests)
     assert sum(l.startswith("ok clarke_wright.") for l in lines) == 14
+    # round_robin: compiled_parity.rs known answer + counters + owner / order-key semantics; list_k_opt.rs:325-395 + sum_two
+    assert sum(l.startswith("ok round_robin.") for l in lines) == 4
+    assert sum(l.startswith("ok list_k_opt.") for l in lines) == 5
 
 
 def test_list_change_canonical_order(oracle):
@@ -245,3 +248,28 @@ def test_clarke_wright_cvrp_adapter_properties(oracle):
     o = oracle.Model.cvrp(p2["capacity"], p2["depot"], p2["demands"], p2["matrix"], p2["customers"], p2["routes"])
     committed, st = o.construct_list_clarke_wright(p2["customers"], 1)
     assert not committed and int(st[4]) > 0 and all(not rt for rt in o.get_lists(0))
+
+
+def test_construction_pipeline_oracle_properties(oracle):
+    """Round robin reproduces datasets.make_cvrp's fill; ListKOpt after Clarke-Wright never worsens the distance level and keeps
+    every route's visit set; an over-capacity route takes no reversal under the capacity hook."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(200, 20, 55, seed=0)
+    start = [list(map(int, rt)) for rt in p["routes"]]
+    p["routes"] = [[] for _ in p["routes"]]
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.construct_list_round_robin(p["customers"])
+    assert o.get_lists(0) == start
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.construct_list_clarke_wright(p["customers"], 1)
+    before, s0 = o.get_lists(0), o.score()[:2].copy()
+    st = o.construct_list_k_opt(2, 1)
+    after = o.get_lists(0)
+    assert [sorted(rt) for rt in after] == [sorted(rt) for rt in before]
+    assert o.score()[0] == s0[0] and o.score()[1] >= s0[1] and int(st[1]) == int(st[2]) > 0
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.construct_list_clarke_wright(p["customers"], 0)  # one over-capacity route
+    one = o.get_lists(0)
+    st = o.construct_list_k_opt(2, 1)
+    assert o.get_lists(0) == one and int(st[1]) == 0 and int(st[0]) == 200 * 199 // 2
