@@ -203,6 +203,8 @@ def test_list_k_opt_matches_oracle(oracle, problem, start, mode, max_sweeps):
         d.construct_list_clarke_wright(0, p["customers"], 1)
         o.construct_list_clarke_wright([int(c) for c in p["customers"]], 1)
     before = o.get_lists(0)
+    d.construct_list_k_opt(0, 3, mode, max_sweeps)  # k != 2: scored no-op (also allocates the counters)
+    assert d.working_lists(0, 0) == before
     g0, o0 = d.stats(0), o.stats()
     sc = d.construct_list_k_opt(0, 2, mode, max_sweeps)
     st = o.construct_list_k_opt(2, mode, max_sweeps)
