@@ -245,3 +245,27 @@ def test_default_construction_pipeline_cvrp_1000(oracle):
         d.construct_list_k_opt(0, 2, 1, 0)  # max_sweeps >= 1
     with pytest.raises(sfa.SolverForgeError):
         d.construct_list_k_opt(0, 2, 2)
+
+
+def test_clarke_wright_cvrp_5000_properties():
+    """C5 size (12,497,500 savings entries, 148 KB of route state per replica): every customer routed once, capacity-feasible
+    routes, committed == fresh score, the score the oracle's run of this instance produced (profiles/r02f_cw_bench.jsonl:
+    matches_oracle true; the oracle takes 26 s, so it is not re-run here); ListKOpt keeps every route's visit set and does not
+    worsen the distance."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(5000, 500, 55, seed=0)
+    p["routes"] = [[] for _ in p["routes"]]
+    d = sfa.build_cvrp(p, n_replicas=2)
+    d.calculate_score()
+    sc, flags = d.construct_list_clarke_wright(0, p["customers"], 1)
+    assert flags.all() and sc[0].tolist() == [0, -389476] and (sc[1] == sc[0]).all()
+    lists = d.working_lists(0, 1)
+    assert sorted(c for rt in lists for c in rt) == list(range(1, 5001))
+    assert all(sum(int(p["demands"][c]) for c in rt) <= 55 for rt in lists)
+    assert (d.fresh_score()[0] == sc[0]).all()
+    sc2 = d.construct_list_k_opt(0, 2, 1)
+    after = d.working_lists(0, 1)
+    assert [sorted(rt) for rt in after] == [sorted(rt) for rt in lists]
+    assert sc2[0][0] == 0 and sc2[0][1] >= sc[0][1] and (d.fresh_score()[1] == sc2[1]).all()
