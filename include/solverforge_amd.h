@@ -149,7 +149,14 @@ typedef enum sf_constraint_kind {
      * stream/grouped_stream/base.rs:142-200): EVERY value row is scored, a row nobody holds with the default result 0 (the
      * "balanced workload" constraint of examples/minimal-shift-scheduling/src/domain/schedule.rs:61-74 with a ones column).
      * `fact_a` = i32 column summed per group, `param` = the target.  Shares the grouped slot (one grouped constraint per class) */
-    SF_C_COMPLEMENTED_VALUE_SUM = 16
+    SF_C_COMPLEMENTED_VALUE_SUM = 16,
+    /* for_each(E).filter(assigned).group_by(value, indexed_presence(fact_a)).penalize(weight * min(presence.count_in(lo..hi), cap))
+     * -- the grouped node with the indexed-presence collector (stream/collector/indexed_presence.rs:1-147: contains / count /
+     * count_in / any_in over the set of present points).  `fact_a` = i32 point column as for SF_C_RUNS_VALUE; `param` = lo |
+     * hi << 16 | cap << 32 with 0 <= lo <= hi <= 4096: cap 0 = presence.count_in(lo..hi) (lo = 0, hi = 4096: presence.count(), the
+     * distinct points of the group), cap 1 = presence.any_in(lo..hi) as 0 / 1.  Shares the per-(value, point) count table and the
+     * slot of SF_C_RUNS_VALUE (one of the two per class); scalar engine only; not chained in compound candidates */
+    SF_C_PRESENCE_VALUE = 17
 } sf_constraint_kind;
 
 typedef enum sf_selector_kind {

@@ -73,6 +73,7 @@ def lib():
             "sfo_assignment_create": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
             "sfo_shift_schedule_create": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, vp]),
+            "sfo_shift_schedule_create_presence": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, i64, i64, vp]),
             "sfo_precedence_shop_create": (vp, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
             "sfo_jobshop_create_makespan": (vp, [i32, i32, vp, vp, vp, vp, i32, i32, vp]),
@@ -206,11 +207,18 @@ class Model:
         return Model(h, [len(routes)])
 
     @staticmethod
-    def shift_schedule(nurse_idx, day, n_nurses, limit=2, w_streak=1, count_weight=0, target=-1, required=None):
-        """examples/minimal-shift-scheduling: unassigned, one shift per nurse-day, long work streaks (consecutive_runs), workload."""
+    def shift_schedule(nurse_idx, day, n_nurses, limit=2, w_streak=1, count_weight=0, target=-1, required=None, presence=None):
+        """examples/minimal-shift-scheduling: unassigned, one shift per nurse-day, long work streaks (consecutive_runs), workload.
+        presence = (lo, hi, cap): the streak constraint becomes group_by(nurse, indexed_presence(day)) scored
+        w_streak * min(count_in(lo..hi), cap) (cap 0 = uncapped, 1 = any_in)."""
         nurse_idx = np.ascontiguousarray(nurse_idx, dtype=np.int64)
         day = np.ascontiguousarray(day, dtype=np.int64)
         req = None if required is None else np.ascontiguousarray(required, dtype=np.int64)
+        if presence is not None:
+            lo, hi, cap = presence
+            h = lib().sfo_shift_schedule_create_presence(len(nurse_idx), n_nurses, _p(nurse_idx), _p(day), lo, hi, cap, w_streak,
+                                                         count_weight, target, None if req is None else _p(req))
+            return Model(h, [len(nurse_idx)])
         h = lib().sfo_shift_schedule_create(len(nurse_idx), n_nurses, _p(nurse_idx), _p(day), limit, w_streak, count_weight, target,
                                             None if req is None else _p(req))
         return Model(h, [len(nurse_idx)])

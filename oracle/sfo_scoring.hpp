@@ -1203,6 +1203,43 @@ struct RunsAccumulator {  // runs.rs:126-172
     }
 };
 
+// ---- indexed_presence collector (stream/collector/indexed_presence.rs:1-147) ---------------------------------------------------
+// The same ordered point -> multiplicity map as consecutive_runs, read as a presence set: membership, unique-point and item
+// counts, runs of present points, runs of ABSENT points inside a horizon (runs_from_counts over a map of the missing points, one
+// item each), counts inside a half-open range.  Oracle only so far: the device keeps the same per-(value, point) count table for
+// SF_C_RUNS_VALUE, a presence-scored constraint kind is not declared yet.
+struct IndexedPresenceAccumulator {  // indexed_presence.rs:101-147
+    RunsAccumulator acc;
+    void accumulate(int64_t v) { acc.accumulate(v); }
+    void retract(int64_t v) { acc.retract(v); }
+    void reset() {
+        acc.points.clear();
+        acc.item_count = 0;
+    }
+    bool contains(int64_t index) const { return acc.points.count(index) != 0; }  // :49-51
+    size_t count() const { return acc.points.size(); }                            // :54-56
+    size_t item_count() const { return acc.item_count; }                          // :59-61
+    bool is_empty() const { return acc.points.empty(); }                          // :64-66
+    Runs runs() const { return acc.finish(); }                                    // :68-70
+    Runs complement_runs(int64_t start, int64_t end) const {                      // :72-90
+        RunsAccumulator missing;
+        if (start >= end) return missing.finish();
+        for (int64_t index = start; index < end;) {
+            if (!acc.points.count(index)) missing.accumulate(index);
+            if (index == INT64_MAX) break;  // checked_add(1) == None
+            ++index;
+        }
+        return missing.finish();
+    }
+    size_t count_in(int64_t start, int64_t end) const {  // :92-97
+        if (start >= end) return 0;
+        size_t n = 0;
+        for (auto it = acc.points.lower_bound(start); it != acc.points.end() && it->first < end; ++it) ++n;
+        return n;
+    }
+    bool any_in(int64_t start, int64_t end) const { return count_in(start, end) > 0; }  // :99-101
+};
+
 // for_each(E).filter(f).group_by(key, consecutive_runs(point)).penalize(w(key, runs)): the grouped node
 // (constraint/grouped/state.rs:43-247, scorer.rs:46-152) with the runs accumulator per group
 struct GroupedRunsConstraint : Constraint {
@@ -1213,6 +1250,16 @@ struct GroupedRunsConstraint : Constraint {
     Key1 key;
     Value1 point;
     std::function<Score(int64_t, const Runs&)> weight;
+    // set instead of `weight` for group_by(key, indexed_presence(point)): the same accumulator read as a presence set
+    std::function<Score(int64_t, const IndexedPresenceAccumulator&)> presence_weight;
+    Score weigh(int64_t k, const RunsAccumulator& acc) const {
+        if (presence_weight) {
+            IndexedPresenceAccumulator p;
+            p.acc = acc;
+            return presence_weight(k, p);
+        }
+        return weight(k, acc.finish());
+    }
 
     struct Group {
         int64_t key;
@@ -1226,7 +1273,7 @@ struct GroupedRunsConstraint : Constraint {
     std::vector<size_t> changed_groups;
     std::vector<Score> cached_scores;
 
-    Score compute(const Group& g) const { return g.count == 0 ? Score::zero() : apply_impact(impact, weight(g.key, g.acc.finish())); }
+    Score compute(const Group& g) const { return g.count == 0 ? Score::zero() : apply_impact(impact, weigh(g.key, g.acc)); }
     void mark_changed(size_t g) {
         for (size_t c : changed_groups)
             if (c == g) return;
@@ -1281,7 +1328,7 @@ struct GroupedRunsConstraint : Constraint {
         for (size_t i = 0; i < n; ++i)
             if (filter(s, i)) acc[key(s, i)].accumulate(point(s, i));
         Score total;
-        for (auto& kv : acc) total = total + apply_impact(impact, weight(kv.first, kv.second.finish()));
+        for (auto& kv : acc) total = total + apply_impact(impact, weigh(kv.first, kv.second));
         return total;
     }
     size_t match_count(const Solution& s) const override {

@@ -1604,8 +1604,38 @@ static void list_k_opt_cases() {
     CHECK("list_k_opt.k_other_than_2_is_a_no_op", run({1, 3, 2, 4}, line, nullptr, 3) == V{1, 3, 2, 4});
     CHECK("list_k_opt.sum_two", cw_sum_two(4, 7) == 11 && cw_sum_two(INT64_MAX, 1) == INT64_MAX && cw_sum_two(INT64_MIN, -1) == INT64_MIN);
 }
+// stream/collector/tests/collector.rs:333-400 (indexed_presence: membership / counts / runs, complement runs, retract and reset)
+static void indexed_presence_cases() {
+    {
+        IndexedPresenceAccumulator a;
+        for (int64_t v : {4, 2, 3, 7, 7}) a.accumulate(v);
+        Runs r = a.runs();
+        bool ok = a.contains(3) && !a.contains(5) && a.count() == 4 && a.item_count() == 5 && a.count_in(2, 5) == 3 && a.any_in(7, 8);
+        ok = ok && r.runs.size() == 2 && r.runs[0].start == 2 && r.runs[0].end == 4 && r.runs[1].start == 7 && r.runs[1].item_count == 2;
+        CHECK("indexed_presence.active_runs_and_membership", ok);
+    }
+    {
+        IndexedPresenceAccumulator a;
+        for (int64_t v : {0, 2, 5}) a.accumulate(v);
+        Runs c = a.complement_runs(0, 7);
+        bool ok = c.runs.size() == 3 && c.runs[0].start == 1 && c.runs[0].end == 1 && c.runs[1].start == 3 && c.runs[1].end == 4 &&
+                  c.runs[2].start == 6 && c.runs[2].end == 6;
+        CHECK("indexed_presence.complement_runs", ok && a.complement_runs(5, 5).runs.empty());
+    }
+    {
+        IndexedPresenceAccumulator a;
+        a.accumulate(-1), a.accumulate(-1), a.accumulate(0);
+        a.retract(-1);
+        bool ok = a.contains(-1) && a.item_count() == 2;
+        a.retract(-1);
+        ok = ok && !a.contains(-1);
+        a.reset();
+        CHECK("indexed_presence.retract_and_reset", ok && a.is_empty());
+    }
+}
 
 int main() {
+    indexed_presence_cases();
     list_k_opt_cases();
     round_robin_cases();
     clarke_wright_cases();

@@ -395,7 +395,7 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
                           int32_t level, int64_t weight) {
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
-    if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE && kind != SF_C_COMPLEMENTED_VALUE_SUM)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE && kind != SF_C_COMPLEMENTED_VALUE_SUM && kind != SF_C_PRESENCE_VALUE)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
     ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
     return SF_OK;
 }
@@ -998,7 +998,8 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_BALANCE_VALUE: raw = q[6], count = q[7]; break;
             case SF_C_VALUE_COST: raw = q[8], count = q[9]; break;
             case SF_C_EXISTS_VALUE: raw = q[10], count = q[11]; break;
-            case SF_C_RUNS_VALUE: raw = q[14], count = q[15]; break;
+            case SF_C_RUNS_VALUE:
+            case SF_C_PRESENCE_VALUE: raw = q[14], count = q[15]; break;
             case SF_C_LIST_PRECEDENCE_MAKESPAN: raw = q[12], count = q[12] + (q[13] > 0 ? 1 : 0); break;  // match_count_from_state (:96-99)
             default: return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind in sf_evaluate_each");
         }

@@ -75,6 +75,10 @@ struct ScalarModel {
     // (stream/collector/runs.rs): a per-(value, point) count table [n_values][run_P] of u16 follows the per-value tables
     int32_t run_level = -1, run_P = 0;
     int64_t run_weight = 0, run_limit = 0;
+    // run_mode 1: the same table read as an indexed_presence result (stream/collector/indexed_presence.rs): a row scores
+    // min(count_in(run_lo..run_hi), run_cap) -- run_cap 0 = uncapped (count / count_in), 1 = any_in
+    int32_t run_mode = 0, run_lo = 0, run_hi = 0;
+    int64_t run_cap = 0;
     const int32_t* run_point = nullptr;  // [n] point of every entity, in 0..run_P
     __host__ __device__ bool tables() const { return sj_level >= 0 || grp_level >= 0 || ex_level >= 0 || run_level >= 0; }
     // per-replica committed state
@@ -163,14 +167,28 @@ __device__ __forceinline__ void run_neighbours(const uint16_t* row, int P, int d
     for (int x = d - 1; x >= 0 && x != ox && row[x] != 0; --x) ++left;
     for (int x = d + 1; x < P && x != ox && row[x] != 0; ++x) ++right;
 }
+// indexed_presence mode: present points of a row inside [run_lo, run_hi), point `ox` and point `skip` counted as absent
+__device__ __forceinline__ int64_t presence_count(const ScalarModel& m, const uint16_t* row, int skip, int ox) {
+    int64_t c = 0;
+    for (int x = m.run_lo; x < m.run_hi; ++x) c += (x != skip && x != ox && row[x] != 0) ? 1 : 0;
+    return c;
+}
+__device__ __forceinline__ int64_t presence_capped(const ScalarModel& m, int64_t c) { return (m.run_cap > 0 && c > m.run_cap) ? m.run_cap : c; }
 // change of a row's summed run excess when point d becomes present (it was absent) / absent (it was the last item of the point)
 __device__ __forceinline__ int64_t run_add_delta(const ScalarModel& m, const uint16_t* row, int d, int ox) {
+    if (m.run_mode == 1) {  // the row's presence score with d present minus without it
+        if (d < m.run_lo || d >= m.run_hi) return 0;
+        if (m.run_cap <= 0) return 1;
+        const int64_t c = presence_count(m, row, d, ox);
+        return presence_capped(m, c + 1) - presence_capped(m, c);
+    }
     int64_t l, r;
     run_neighbours(row, m.run_P, d, ox, l, r);
     return run_excess(m, l + 1 + r) - run_excess(m, l) - run_excess(m, r);
 }
 // summed run excess of one row (full evaluation)
 __device__ __forceinline__ int64_t run_row_excess(const ScalarModel& m, const uint16_t* row) {
+    if (m.run_mode == 1) return presence_capped(m, presence_count(m, row, -1, -1));
     int64_t total = 0, len = 0;
     for (int x = 0; x < m.run_P; ++x) {
         if (row[x] != 0)

@@ -49,7 +49,7 @@ class ConstraintKind:
     NOT_EXISTS_FLATTENED, ROUTE_CAPACITY, ROUTE_DISTANCE = 5, 6, 7
     SELFJOIN_VALUE_EQUAL, GROUPED_VALUE_SUM, LOAD_BALANCE_VALUE = 8, 9, 10
     VALUE_COST, EXISTS_VALUE, BALANCE_VALUE = 11, 12, 13
-    LIST_PRECEDENCE_MAKESPAN, RUNS_VALUE, COMPLEMENTED_VALUE_SUM = 14, 15, 16
+    LIST_PRECEDENCE_MAKESPAN, RUNS_VALUE, COMPLEMENTED_VALUE_SUM, PRESENCE_VALUE = 14, 15, 16, 17
 
 
 class SelectorKind:

@@ -160,7 +160,7 @@ def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_chan
 
 
 def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, limit=2, w_streak=1, count_weight=0, target=-1,
-                         leaves=("change", "swap"), required=None):
+                         leaves=("change", "swap"), required=None, presence=None):
     """examples/minimal-shift-scheduling/src/domain/schedule.rs:21-83: shifts choose a nurse.  Hard: unassigned shift; two shifts of
     one nurse on one day (predicate cross-join on the day column).  Soft: long work streaks -- group_by(nurse,
     consecutive_runs(day)).penalize(sum over runs of max(0, point_count - limit)) (stream/collector/runs.rs); count_weight > 0:
@@ -179,7 +179,11 @@ def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, li
         d.add_fact_column_i32(FACT_AUX, np.asarray(required, dtype=np.int32))
         d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, fact=FACT_AUX, level=0, weight=1)
     d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=0, weight=1)
-    d.add_constraint(ConstraintKind.RUNS_VALUE, 0, fact=FACT_GROUP, param=limit, level=1, weight=w_streak)
+    if presence is None:
+        d.add_constraint(ConstraintKind.RUNS_VALUE, 0, fact=FACT_GROUP, param=limit, level=1, weight=w_streak)
+    else:  # group_by(nurse, indexed_presence(day)).penalize(w_streak * min(count_in(lo..hi), cap)) instead of the streaks
+        lo, hi, cap = presence
+        d.add_constraint(ConstraintKind.PRESENCE_VALUE, 0, fact=FACT_GROUP, param=lo | (hi << 16) | (cap << 32), level=1, weight=w_streak)
     if count_weight > 0:
         d.add_fact_column_i32(FACT_COLUMN, np.ones(n, dtype=np.int32))
         if target >= 0:

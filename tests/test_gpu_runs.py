@@ -162,3 +162,89 @@ def test_multi_replica_and_limits(oracle):
         sfa.build_shift_schedule(nurse, day - 1, 6).calculate_score()
     with pytest.raises(sfa.SolverForgeError):
         sfa.build_shift_schedule(np.zeros(10, dtype=np.int64), np.arange(10) * 400, 100).calculate_score()
+
+
+# ---- indexed_presence collector (stream/collector/indexed_presence.rs) as a grouped constraint: SF_C_PRESENCE_VALUE ------------------
+def test_presence_known_answer(oracle):
+    """The reference's own case (stream/collector/tests/collector.rs:333-356): points {4, 2, 3, 7, 7} -> count 4, count_in(2..5) 3,
+    any_in(7..8); here as one nurse's days, a second nurse with days {0, 5}."""
+    day = np.array([4, 2, 3, 7, 7, 0, 5])
+    nurse = np.array([0, 0, 0, 0, 0, 1, 1])
+    for presence, want in [((0, 4096, 0), 4 + 2), ((2, 5, 0), 3 + 0), ((7, 8, 1), 1 + 0), ((5, 8, 1), 1 + 1), ((0, 8, 3), 3 + 2), ((3, 3, 0), 0)]:
+        d, o = _mk(oracle, nurse, day, 2, w_streak=1, presence=presence)
+        got = d.calculate_score()[0]
+        assert got.tolist() == [-1, -want], presence  # hard: the two shifts of nurse 0 on day 7
+        assert (o.score()[:2] == got).all() and (d.fresh_score()[0] == got).all()
+        gs, gc = d.evaluate_each()
+        os_, oc = o.evaluate_each()
+        assert (gs == os_[:, :2]).all() and (gc == oc).all()
+
+
+@pytest.mark.parametrize("n_nurses,n_days,per_day,presence,w,cw", [(3, 10, 2, (0, 4096, 0), 1, 0), (5, 14, 3, (3, 9, 0), 7, 2), (8, 28, 4, (5, 7, 1), 1, 0),
+                                                                    (4, 30, 1, (0, 30, 4), 3, 1), (6, 14, 2, (10, 40, 2), 1, 1), (9, 7, 3, (0, 1, 1), 2, 3)])
+def test_presence_scores_cursor_order_and_trial_scores(oracle, n_nurses, n_days, per_day, presence, w, cw):
+    nurse, day = _problem(n_nurses, n_days, per_day, seed=n_days + 1)
+    d, o = _mk(oracle, nurse, day, n_nurses, w_streak=w, count_weight=cw, presence=presence)
+    got = d.calculate_score()[0]
+    assert (got == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == got).all()
+    gs, gc = d.evaluate_each()
+    os_, oc = o.evaluate_each()
+    assert (gs == os_[:, :2]).all() and (gc == oc).all()
+    for order in (0, 3):
+        o.configure(leaves=3, selection_order=order)
+        gm, gsc, gd = d.open_cursor(4, 99, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 4, 99, order)
+        assert len(gm) == len(om) > 0 and (_t(gm) == _t(om)).all()
+        osc, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gsc == osc[:, :2]).all()
+        es, ed = d.evaluate_moves(om)  # sf_step_evaluate
+        assert (ed == od).all() and (es == osc[:, :2]).all()
+
+
+@pytest.mark.parametrize("presence", [(0, 4096, 0), (4, 15, 3), (6, 13, 1)])
+def test_presence_apply_traced_and_fused_steps(oracle, presence):
+    import solverforge_amd as sfa
+
+    nurse, day = _problem(5, 21, 3, seed=4)
+    d, o = _mk(oracle, nurse, day, 5, w_streak=2, count_weight=1, presence=presence)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    rng = np.random.default_rng(2)
+    o.configure(leaves=3, selection_order=3)
+    for it in range(8):
+        mv = o.enumerate(0, it, 7 + it, 3)
+        sc, do = o.evaluate_moves(mv)
+        mv = mv[do != 0]
+        mv = mv[mv["kind"] == it % 2]
+        mv = mv[rng.integers(len(mv))]
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert (d.calculate_score()[0] == o.score()[:2]).all(), it
+        assert (d.fresh_score()[0] == o.score()[:2]).all(), it
+    o.configure(leaves=3, random_seed=5, la_size=9, limit=30)
+    d.configure(sfa.SolverConfig(random_seed=5, late_acceptance_size=9, accepted_count_limit=30))
+    d.phase_start()
+    o.phase_start()
+    for step in range(20):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+    d.solve_steps(300)
+    o.steps(300)
+    assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+
+
+def test_presence_validation():
+    import solverforge_amd as sfa
+
+    nurse, day = _problem(3, 6, 2, seed=1)
+    with pytest.raises(sfa.SolverForgeError):
+        sfa.build_shift_schedule(nurse, day, 3, presence=(5, 2, 0)).calculate_score()  # lo > hi
+    with pytest.raises(sfa.SolverForgeError):
+        sfa.build_shift_schedule(nurse, day, 3, presence=(0, 5000, 0)).calculate_score()  # hi > 4096

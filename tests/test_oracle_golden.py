@@ -27,6 +27,7 @@ def test_constraint_node_goldens(oracle):
     # round_robin: compiled_parity.rs known answer + counters + owner / order-key semantics; list_k_opt.rs:325-395 + sum_two
     assert sum(l.startswith("ok round_robin.") for l in lines) == 4
     assert sum(l.startswith("ok list_k_opt.") for l in lines) == 5
+    assert sum(l.startswith("ok indexed_presence.") for l in lines) == 3  # stream/collector/tests/collector.rs:333-400
 
 
 def test_list_change_canonical_order(oracle):
