@@ -18,7 +18,7 @@ def t6(m):
 
 def run_case(seed):
     rng = np.random.default_rng(seed)
-    model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment", "precedence", "precedence", "shift", "shift"][int(rng.integers(11))]
+    model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment", "precedence", "precedence", "shift", "shift", "shift"][int(rng.integers(12))]
     acceptor = int(rng.choice([0, 1, 1, 3]))
     forager = int(rng.choice([0, 0, 1, 2, 3, 4]))
     limit = int(rng.choice([1, 2, 7, 40, 256]))
@@ -134,8 +134,13 @@ def run_case(seed):
         desc.update(nn=nn, nd=nd, per=per, limit=lim, cw=cw, target=tgt, leaves=leaves)
         ws = int(rng.choice([1, 7]))
         req = (datasets.stream(seed + 33, len(day)) % np.uint64(3)).astype(np.int64) if rng.random() < 0.5 else None  # required flag / weight
-        d = sfa.build_shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, leaves=leaves, required=req)
-        o = sfo.Model.shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, required=req)
+        pres = None
+        if rng.random() < 0.4:  # the indexed_presence collector instead of the runs: count / count_in / capped / any_in
+            lo = int(rng.integers(0, nd)); hi = int(rng.choice([lo, lo + 1, lo + 5, 4096]))
+            pres = (lo if hi != 4096 else int(rng.choice([0, lo])), hi, int(rng.choice([0, 0, 1, 3])))
+            desc.update(presence=pres)
+        d = sfa.build_shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, leaves=leaves, required=req, presence=pres)
+        o = sfo.Model.shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, required=req, presence=pres)
         lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
     else:
         nj = int(rng.integers(2, 9)); nm = int(rng.integers(2, 6))
