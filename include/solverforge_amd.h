@@ -154,7 +154,9 @@ typedef enum sf_constraint_kind {
      * -- the grouped node with the indexed-presence collector (stream/collector/indexed_presence.rs:1-147: contains / count /
      * count_in / any_in over the set of present points).  `fact_a` = i32 point column as for SF_C_RUNS_VALUE; `param` = lo |
      * hi << 16 | cap << 32 with 0 <= lo <= hi <= 4096: cap 0 = presence.count_in(lo..hi) (lo = 0, hi = 4096: presence.count(), the
-     * distinct points of the group), cap 1 = presence.any_in(lo..hi) as 0 / 1.  Shares the per-(value, point) count table and the
+     * distinct points of the group), cap 1 = presence.any_in(lo..hi) as 0 / 1.  param | 1 << 48: the row scores
+     * sum over presence.complement_runs(lo..hi) of max(0, run.point_count - cap) instead -- the runs of ABSENT points inside the
+     * horizon ("consecutive off bounds" of crates/solverforge-macros/tests/ui/pass/solverforge_constraints_indexed_presence.rs).  Shares the per-(value, point) count table and the
      * slot of SF_C_RUNS_VALUE (one of the two per class); scalar engine only; not chained in compound candidates */
     SF_C_PRESENCE_VALUE = 17
 } sf_constraint_kind;

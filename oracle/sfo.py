@@ -73,7 +73,7 @@ def lib():
             "sfo_assignment_create": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
             "sfo_shift_schedule_create": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, vp]),
-            "sfo_shift_schedule_create_presence": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, i64, i64, vp]),
+            "sfo_shift_schedule_create_presence": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
             "sfo_precedence_shop_create": (vp, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
             "sfo_jobshop_create_makespan": (vp, [i32, i32, vp, vp, vp, vp, i32, i32, vp]),
@@ -215,8 +215,9 @@ class Model:
         day = np.ascontiguousarray(day, dtype=np.int64)
         req = None if required is None else np.ascontiguousarray(required, dtype=np.int64)
         if presence is not None:
-            lo, hi, cap = presence
-            h = lib().sfo_shift_schedule_create_presence(len(nurse_idx), n_nurses, _p(nurse_idx), _p(day), lo, hi, cap, w_streak,
+            lo, hi, cap = presence[:3]
+            mode = presence[3] if len(presence) > 3 else 0  # 1: excess of complement_runs(lo..hi) over cap
+            h = lib().sfo_shift_schedule_create_presence(len(nurse_idx), n_nurses, _p(nurse_idx), _p(day), lo, hi, cap, mode, w_streak,
                                                          count_weight, target, None if req is None else _p(req))
             return Model(h, [len(nurse_idx)])
         h = lib().sfo_shift_schedule_create(len(nurse_idx), n_nurses, _p(nurse_idx), _p(day), limit, w_streak, count_weight, target,

@@ -138,8 +138,8 @@ void* sfo_shift_schedule_create(int32_t n_shifts, int32_t n_nurses, const int64_
     return make_shift_schedule((size_t)n_shifts, (size_t)n_nurses, nurse_idx, day, limit, w_streak, count_weight, target, required).release();
 }
 void* sfo_shift_schedule_create_presence(int32_t n_shifts, int32_t n_nurses, const int64_t* nurse_idx, const int64_t* day, int64_t lo, int64_t hi,
-                                         int64_t cap, int64_t w, int64_t count_weight, int64_t target, const int64_t* required) {
-    return make_shift_schedule((size_t)n_shifts, (size_t)n_nurses, nurse_idx, day, 0, w, count_weight, target, required, lo, hi, cap).release();
+                                         int64_t cap, int64_t mode, int64_t w, int64_t count_weight, int64_t target, const int64_t* required) {
+    return make_shift_schedule((size_t)n_shifts, (size_t)n_nurses, nurse_idx, day, 0, w, count_weight, target, required, lo, hi, cap, mode).release();
 }
 void* sfo_list_toy_create(int32_t n_entities, const uint32_t* off, const uint32_t* vals, int32_t meter) {
     return make_list_toy((size_t)n_entities, off, vals, meter == 0 ? ToyMeter::Equal : ToyMeter::Position)

@@ -755,7 +755,7 @@ struct ShiftFacts {
 inline std::unique_ptr<Model> make_shift_schedule(size_t n_shifts, size_t n_nurses, const int64_t* nurse_idx, const int64_t* day, int64_t limit,
                                                   int64_t w_streak, int64_t count_weight, int64_t target = -1,
                                                   const int64_t* required = nullptr, int64_t presence_lo = -1, int64_t presence_hi = -1,
-                                                  int64_t presence_cap = 0) {
+                                                  int64_t presence_cap = 0, int64_t presence_mode = 0) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<ShiftFacts>();
     facts->day.assign(day, day + n_shifts);
@@ -804,7 +804,13 @@ inline std::unique_ptr<Model> make_shift_schedule(size_t n_shifts, size_t n_nurs
     };
     if (presence_lo >= 0) {  // group_by(nurse, indexed_presence(day)).penalize(w * min(count_in(lo..hi), cap)); cap 0 = uncapped, 1 = any_in
         streak->name = "Days worked in the window";
-        streak->presence_weight = [presence_lo, presence_hi, presence_cap, w_streak](int64_t, const IndexedPresenceAccumulator& p) {
+        streak->presence_weight = [presence_lo, presence_hi, presence_cap, presence_mode, w_streak](int64_t, const IndexedPresenceAccumulator& p) {
+            if (presence_mode == 1) {  // "consecutive off bounds": complement_runs(lo..hi), each run's point_count.saturating_sub(cap)
+                int64_t excess = 0;
+                for (auto& r : p.complement_runs(presence_lo, presence_hi).runs)
+                    excess += (int64_t)r.point_count > presence_cap ? (int64_t)r.point_count - presence_cap : 0;
+                return Score::of(0, w_streak * excess);
+            }
             int64_t c = (int64_t)p.count_in(presence_lo, presence_hi);
             if (presence_cap == 1) c = p.any_in(presence_lo, presence_hi) ? 1 : 0;
             else if (presence_cap > 0 && c > presence_cap) c = presence_cap;

@@ -138,6 +138,8 @@ def run_case(seed):
         if rng.random() < 0.4:  # the indexed_presence collector instead of the runs: count / count_in / capped / any_in
             lo = int(rng.integers(0, nd)); hi = int(rng.choice([lo, lo + 1, lo + 5, 4096]))
             pres = (lo if hi != 4096 else int(rng.choice([0, lo])), hi, int(rng.choice([0, 0, 1, 3])))
+            if rng.random() < 0.4:  # complement_runs(lo..hi) excess over cap
+                pres = (pres[0], min(hi, int(rng.choice([nd, nd + 7, 2 * nd + 3]))), pres[2], 1)
             desc.update(presence=pres)
         d = sfa.build_shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, leaves=leaves, required=req, presence=pres)
         o = sfo.Model.shift_schedule(nurse, day, nn, limit=lim, w_streak=ws, count_weight=cw, target=tgt, required=req, presence=pres)

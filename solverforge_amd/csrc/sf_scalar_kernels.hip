@@ -76,7 +76,9 @@ struct ScalarModel {
     int32_t run_level = -1, run_P = 0;
     int64_t run_weight = 0, run_limit = 0;
     // run_mode 1: the same table read as an indexed_presence result (stream/collector/indexed_presence.rs): a row scores
-    // min(count_in(run_lo..run_hi), run_cap) -- run_cap 0 = uncapped (count / count_in), 1 = any_in
+    // min(count_in(run_lo..run_hi), run_cap) -- run_cap 0 = uncapped (count / count_in), 1 = any_in.  run_mode 2: the row scores the
+    // excess of its complement_runs(run_lo..run_hi) -- maximal runs of ABSENT points inside the horizon -- over run_limit; only a
+    // row with members is a group (an empty row scores nothing), points >= run_P are never present
     int32_t run_mode = 0, run_lo = 0, run_hi = 0;
     int64_t run_cap = 0;
     const int32_t* run_point = nullptr;  // [n] point of every entity, in 0..run_P
@@ -174,8 +176,26 @@ __device__ __forceinline__ int64_t presence_count(const ScalarModel& m, const ui
     return c;
 }
 __device__ __forceinline__ int64_t presence_capped(const ScalarModel& m, int64_t c) { return (m.run_cap > 0 && c > m.run_cap) ? m.run_cap : c; }
+// complement mode: lengths of the runs of absent points directly left / right of d inside the horizon; `ox` counts as absent
+__device__ __forceinline__ bool presence_at(const ScalarModel& m, const uint16_t* row, int x, int ox) { return x < m.run_P && x != ox && row[x] != 0; }
+__device__ __forceinline__ void gap_neighbours(const ScalarModel& m, const uint16_t* row, int d, int ox, int64_t& left, int64_t& right) {
+    left = right = 0;
+    for (int x = d - 1; x >= m.run_lo && !presence_at(m, row, x, ox); --x) ++left;
+    for (int x = d + 1; x < m.run_hi && !presence_at(m, row, x, ox); ++x) ++right;
+}
+// complement mode: the score of a row whose only present point is d
+__device__ __forceinline__ int64_t gap_single_point(const ScalarModel& m, int d) {
+    if (d < m.run_lo || d >= m.run_hi) return run_excess(m, (int64_t)m.run_hi - m.run_lo);
+    return run_excess(m, (int64_t)d - m.run_lo) + run_excess(m, (int64_t)m.run_hi - 1 - d);
+}
 // change of a row's summed run excess when point d becomes present (it was absent) / absent (it was the last item of the point)
 __device__ __forceinline__ int64_t run_add_delta(const ScalarModel& m, const uint16_t* row, int d, int ox) {
+    if (m.run_mode == 2) {  // the gap around d splits in two
+        if (d < m.run_lo || d >= m.run_hi) return 0;
+        int64_t l, r;
+        gap_neighbours(m, row, d, ox, l, r);
+        return run_excess(m, l) + run_excess(m, r) - run_excess(m, l + 1 + r);
+    }
     if (m.run_mode == 1) {  // the row's presence score with d present minus without it
         if (d < m.run_lo || d >= m.run_hi) return 0;
         if (m.run_cap <= 0) return 1;
@@ -189,6 +209,18 @@ __device__ __forceinline__ int64_t run_add_delta(const ScalarModel& m, const uin
 // summed run excess of one row (full evaluation)
 __device__ __forceinline__ int64_t run_row_excess(const ScalarModel& m, const uint16_t* row) {
     if (m.run_mode == 1) return presence_capped(m, presence_count(m, row, -1, -1));
+    if (m.run_mode == 2) {  // callers gate on the row having members
+        int64_t total = 0, len = 0;
+        for (int x = m.run_lo; x < m.run_hi; ++x) {
+            if (!presence_at(m, row, x, -1))
+                ++len;
+            else {
+                total += run_excess(m, len);
+                len = 0;
+            }
+        }
+        return total + run_excess(m, len);
+    }
     int64_t total = 0, len = 0;
     for (int x = 0; x < m.run_P; ++x) {
         if (row[x] != 0)
@@ -312,8 +344,19 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
             const uint16_t* pt = runs_table(m, cnt);
             if (pt) {
                 const int d = m.run_point[a];
+                if (m.run_mode == 2) {  // an empty row is no group: the last member leaving drops the row's score, the first brings it
+                    if (old >= 0) {
+                        if (cnt[old] == 1) r.d_run -= gap_single_point(m, d);
+                        else if (pt[(size_t)old * m.run_P + d] == 1) r.d_run -= run_add_delta(m, pt + (size_t)old * m.run_P, d, -1);
+                    }
+                    if (value >= 0) {
+                        if (cnt[value] == 0) r.d_run += gap_single_point(m, d);
+                        else if (pt[(size_t)value * m.run_P + d] == 0) r.d_run += run_add_delta(m, pt + (size_t)value * m.run_P, d, -1);
+                    }
+                } else {
                 if (old >= 0 && pt[(size_t)old * m.run_P + d] == 1) r.d_run -= run_add_delta(m, pt + (size_t)old * m.run_P, d, -1);
                 if (value >= 0 && pt[(size_t)value * m.run_P + d] == 0) r.d_run += run_add_delta(m, pt + (size_t)value * m.run_P, d, -1);
+                }
             }
         }
         if (m.grp_level >= 0 && m.grp_mode >= 1) {  // global statistic (load balance: metrics are >= 1, validated at sf_constraint_add)
@@ -679,7 +722,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             unsigned long long run = 0, run_groups = 0;
             const uint16_t* pt = runs_table(m, t_cnt);
             for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
-                run += (unsigned long long)run_row_excess(m, pt + (size_t)v * m.run_P);
+                if (m.run_mode != 2 || t_cnt[v]) run += (unsigned long long)run_row_excess(m, pt + (size_t)v * m.run_P);
                 run_groups += t_cnt[v] ? 1 : 0;
             }
             atomicAdd(&s_run, run);

@@ -182,8 +182,9 @@ def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, li
     if presence is None:
         d.add_constraint(ConstraintKind.RUNS_VALUE, 0, fact=FACT_GROUP, param=limit, level=1, weight=w_streak)
     else:  # group_by(nurse, indexed_presence(day)).penalize(w_streak * min(count_in(lo..hi), cap)) instead of the streaks
-        lo, hi, cap = presence
-        d.add_constraint(ConstraintKind.PRESENCE_VALUE, 0, fact=FACT_GROUP, param=lo | (hi << 16) | (cap << 32), level=1, weight=w_streak)
+        lo, hi, cap = presence[:3]
+        mode = presence[3] if len(presence) > 3 else 0  # 1: excess of complement_runs(lo..hi) over cap
+        d.add_constraint(ConstraintKind.PRESENCE_VALUE, 0, fact=FACT_GROUP, param=lo | (hi << 16) | (cap << 32) | (mode << 48), level=1, weight=w_streak)
     if count_weight > 0:
         d.add_fact_column_i32(FACT_COLUMN, np.ones(n, dtype=np.int32))
         if target >= 0:

@@ -170,7 +170,9 @@ def test_presence_known_answer(oracle):
     any_in(7..8); here as one nurse's days, a second nurse with days {0, 5}."""
     day = np.array([4, 2, 3, 7, 7, 0, 5])
     nurse = np.array([0, 0, 0, 0, 0, 1, 1])
-    for presence, want in [((0, 4096, 0), 4 + 2), ((2, 5, 0), 3 + 0), ((7, 8, 1), 1 + 0), ((5, 8, 1), 1 + 1), ((0, 8, 3), 3 + 2), ((3, 3, 0), 0)]:
+    # complement_runs(0..7) of {0, 2, 5} = [1], [3, 4], [6] (collector.rs:358-376): nurse 1 below has {0, 5} -> [1..4], [6]
+    for presence, want in [((0, 4096, 0), 4 + 2), ((2, 5, 0), 3 + 0), ((7, 8, 1), 1 + 0), ((5, 8, 1), 1 + 1), ((0, 8, 3), 3 + 2), ((3, 3, 0), 0),
+                           ((0, 7, 1, 1), (1 + 1) + 3), ((0, 12, 0, 1), (2 + 2 + 4) + (4 + 6)), ((0, 7, 5, 1), 0)]:
         d, o = _mk(oracle, nurse, day, 2, w_streak=1, presence=presence)
         got = d.calculate_score()[0]
         assert got.tolist() == [-1, -want], presence  # hard: the two shifts of nurse 0 on day 7
@@ -181,7 +183,9 @@ def test_presence_known_answer(oracle):
 
 
 @pytest.mark.parametrize("n_nurses,n_days,per_day,presence,w,cw", [(3, 10, 2, (0, 4096, 0), 1, 0), (5, 14, 3, (3, 9, 0), 7, 2), (8, 28, 4, (5, 7, 1), 1, 0),
-                                                                    (4, 30, 1, (0, 30, 4), 3, 1), (6, 14, 2, (10, 40, 2), 1, 1), (9, 7, 3, (0, 1, 1), 2, 3)])
+                                                                    (4, 30, 1, (0, 30, 4), 3, 1), (6, 14, 2, (10, 40, 2), 1, 1), (9, 7, 3, (0, 1, 1), 2, 3),
+                                                                    (4, 12, 2, (0, 12, 1, 1), 1, 0), (6, 20, 1, (3, 30, 2, 1), 5, 1), (7, 9, 2, (0, 9, 0, 1), 1, 2),
+                                                                    (12, 6, 1, (2, 5, 1, 1), 3, 0)])
 def test_presence_scores_cursor_order_and_trial_scores(oracle, n_nurses, n_days, per_day, presence, w, cw):
     nurse, day = _problem(n_nurses, n_days, per_day, seed=n_days + 1)
     d, o = _mk(oracle, nurse, day, n_nurses, w_streak=w, count_weight=cw, presence=presence)
@@ -202,7 +206,7 @@ def test_presence_scores_cursor_order_and_trial_scores(oracle, n_nurses, n_days,
         assert (ed == od).all() and (es == osc[:, :2]).all()
 
 
-@pytest.mark.parametrize("presence", [(0, 4096, 0), (4, 15, 3), (6, 13, 1)])
+@pytest.mark.parametrize("presence", [(0, 4096, 0), (4, 15, 3), (6, 13, 1), (0, 21, 1, 1), (5, 40, 0, 1)])
 def test_presence_apply_traced_and_fused_steps(oracle, presence):
     import solverforge_amd as sfa
 
