@@ -14,8 +14,8 @@ SQ_INSTS_VALU wave-instructions per second, peak = 1024 SIMDs x 2.4 GHz / 2 cycl
 MI355X_MICROARCH.md), SALU (one scalar unit per CU, 1 instruction per clock) and LDS — all three are reported.  The counters
 come from rocprofv3 --pmc passes of THIS command (same warm-up and timed launches) that bench.py runs as child
 processes after the timed region (FETCH_SIZE and WRITE_SIZE each in a pass of their own, the read side doubled as the
-guide prescribes for gfx950); when rocprofv3 is not usable the committed profile of the same command is used and
-`roofline.pmc_source` says so.  SURVEY.md §8(d)'s algorithmic-bytes figure stays as a labelled side number.
+guide prescribes for gfx950); when the passes fail `roofline.frac` / `achieved` / `traffic` are null and
+`roofline.pmc_source` says why.  SURVEY.md §8(d)'s algorithmic-bytes figure stays as a labelled side number.
 
 cpu_baseline.  The oracle (C++ restatement of the reference algorithm, 1 thread) runs the SAME local-search step window
 as GPU replica 0 (same seed), and when it completes the window its working score is compared bit for bit with
@@ -24,8 +24,12 @@ replica 0's (`extra.replica0_matches_cpu_oracle`).
 M2 (`--solve-seconds`, default 60).  A fresh portfolio solves for 60 s of wall clock with work-balanced launches
 (sf_solve_moves) while the CPU oracle solves the same problem (seed of replica 0) on one host core for the same
 60 s: `extra.best_score_at_60s` = {"gpu": ..., "cpu_oracle": ...}.  `--solve-start savings | savings_capacity` starts both
-sides from empty routes with the reference's default construction for the CVRP domain -- Clarke-Wright savings
-(sf_construct_list_clarke_wright), then the route-local 2-opt of ListKOptPhase (sf_construct_list_k_opt) -- built inside the budget; the start score is reported beside the best score.
+sides from empty routes with the construction phases of the CVRP domain -- Clarke-Wright savings
+(sf_construct_list_clarke_wright), then the route-local 2-opt of ListKOptPhase (sf_construct_list_k_opt) -- built inside the
+budget; the start score is reported beside the best score.  `savings` is the reference's stock wiring (savings_hooks::feasible
+is structural only, crates/solverforge-cvrp/src/helpers.rs:77-87: the merge ends in ONE route, hard score -4869 at this
+size, and no 60 s search repairs it); the default `savings_capacity` is an EXTENSION: the same phases with a capacity-checking
+`feasible` hook a model may supply (the capacity part of route_hooks::feasible; no time windows are modelled here).
 
 Multi-GPU.  `python bench.py --gpus N` spawns N ranks itself (torch.distributed.run, one process per GPU) when it is
 not already running under a launcher; it refuses to run with fewer devices than ranks.  Independent seeds per rank
@@ -69,8 +73,9 @@ LDS_PEAK = N_CU * CLOCK_HZ / 2.0
 # the same pass run first completes in seconds; every pass has its own short deadline and a failed pass only drops its
 # own counters.
 # M2 start state (see --solve-start).  M1 is always timed on the round-robin fill (comparable across rounds); M2 starts from the
-# Clarke-Wright savings construction with the capacity test, built inside the 60 s on both sides (profiles/r02f_solve60_*: best@60 s
-# [0, -92932] from this start vs [0, -101064] from the round-robin fill).
+# Clarke-Wright savings construction with a capacity-checking feasibility hook (an extension over the stock structural hook, see
+# the module docstring), built inside the 60 s on both sides (profiles/r02f_solve60_*: best@60 s [0, -92932] from this start vs
+# [0, -101064] from the round-robin fill and [-4869, -24557] from the stock structural hook).
 SOLVE_START_DEFAULT = "savings_capacity"
 
 PMC_PASSES = [
@@ -242,10 +247,10 @@ def main():
     ap.add_argument("--solve-seconds", type=float, default=60.0, help="M2: wall-clock budget of the solve leg (0 = skip)")
     ap.add_argument("--solve-start", choices=["roundrobin", "savings", "savings_capacity"], default=SOLVE_START_DEFAULT,
                     help="M2 start state: the round-robin fill M1 is timed on, or the device's Clarke-Wright savings construction "
-                         "from empty routes (built inside the budget, on both sides): savings = the stock savings hooks "
-                         "(structural feasibility), savings_capacity = the capacity test of route_hooks::feasible")
+                         "from empty routes (built inside the budget, on both sides): savings = the reference's stock savings hooks "
+                         "(structural feasibility only), savings_capacity = EXTENSION, a capacity-checking feasible hook")
     ap.add_argument("--solve-budget", type=int, default=100_000, help="M2: candidates per replica per launch (sf_solve_moves)")
-    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline from profiles/)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -459,20 +464,11 @@ def main():
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
         if world == 1 and not args.no_pmc:
             pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=90)
-            if pmc is None:
-                pmc_source = f"committed profile (live rocprofv3 passes failed: {pmc_info})"
+            if pmc is None:  # no counters, no roofline: the line says so instead of quoting an older profile
+                pmc_source = f"none (live rocprofv3 passes failed: {pmc_info})"
                 pmc_info = {}
             else:
                 pmc_source = "rocprofv3 --pmc child passes of this command, mean over the timed launches"
-        if pmc is None:
-            ppath = os.path.join(ROOT, "profiles", f"r02_{engine}_pmc.json")
-            if os.path.exists(ppath):
-                pj = json.load(open(ppath))
-                cfg = pj.get("_config", {})
-                if cfg.get("replicas_per_gpu") == args.replicas and cfg.get("ls_steps_per_launch") == args.ls_steps and \
-                        cfg.get("steps") == args.steps and cfg.get("warmup") == args.warmup:
-                    pmc = {k: v["mean_per_launch"] for k, v in pj.items() if isinstance(v, dict) and "mean_per_launch" in v}
-                    pmc_source = pmc_source or f"committed profile profiles/r02_{engine}_pmc.json (same command)"
         roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave-instr/s", "frac": None,
                 "traffic": None}
         if pmc and launch_s > 0:
@@ -514,7 +510,7 @@ def main():
             "algorithmic_reference_gbps": alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
         })
         out = {
-            "metric": "moves-evaluated/sec, CVRP-1000 (nearby-list selector, LateAcceptance(400)+AcceptedCount(256))",
+            "metric": f"moves-evaluated/sec, CVRP-{args.customers} (nearby-list selector, LateAcceptance(400)+AcceptedCount(256))",
             "value": moves_total / elapsed,
             "unit": "moves/s",
             "n_gpus": world,
@@ -560,6 +556,10 @@ def main():
                 "start_score": solve["start_score"],
                 "gpu_construction_seconds": solve["construction_seconds"],
                 "cpu_oracle": solve.get("cpu_oracle"),
+                "start_note": {"savings_capacity": "extension: Clarke-Wright + ListKOpt with a capacity-checking feasible hook (the reference's "
+                                                   "stock savings_hooks::feasible is structural only)",
+                               "savings": "the reference's stock CVRP construction wiring (structural feasibility)",
+                               "roundrobin": "round-robin fill (the M1 start state)"}[solve["start"]],
                 "policy": f"start = {solve['start']}; 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256); work-balanced launches "
                           f"(sf_solve_moves, {args.solve_budget} candidates per replica per launch)",
             }

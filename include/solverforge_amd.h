@@ -323,7 +323,9 @@ int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t descriptor_index, int32_t vari
 /* Root union of the configured leaves (UnionMoveSelectorConfig: UnionSelectionOrder + UnionWeighting; scheduler
  * heuristic/selector/decorator/vec_union.rs:190-365).  selection_order: sf_union_order, -1 = the default policy's choice
  * (StratifiedRandom for more than one leaf, runtime/compiler/executor/local_search/lower.rs:285-293); weights[n_weights] = one
- * unsigned weight per leaf in union (declaration) order, NULL / 0 = equal (UnionWeighting::Equal); a zero weight disables the
+ * unsigned weight per leaf in union (declaration) order -- a configured union keeps the order of the sf_selector_add calls for
+ * its children (weights, Sequential / RoundRobin child order), the default policy's union uses the policy's own declaration order
+ * (default_local_search/policy/list.rs:24-33) whatever the call order --, NULL / 0 = equal (UnionWeighting::Equal); a zero weight disables the
  * leaf; weights other than 1 need SF_UNION_RANDOM or SF_UNION_STRATIFIED_RANDOM (vec_union.rs:215-222).  A non-default root
  * union runs in the generic N-leaf engine.  The weight count is checked against the leaf count at the next launch. */
 typedef enum sf_union_order {

@@ -69,6 +69,7 @@ def lib():
             "sfo_graph_coloring_create_indexed": (vp, [i32, i32, vp, vp, vp]),
             "sfo_jobshop_create_indexed": (vp, [i32, i32, vp, vp, vp, vp, i32]),
             "sfo_balance_create_nary": (vp, [i32, i32, vp, vp, i64, i64, i32]),
+            "sfo_balance_create_base": (vp, [i32, i32, vp, vp, i64, i64]),
             "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
             "sfo_assignment_create": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
@@ -171,9 +172,11 @@ class Model:
         return Model(fn(n, n_colors, _p(adj_off), _p(adj), _p(colors)), [n])
 
     @staticmethod
-    def balance(n_bins, bins, sizes, w_pair=1, cap=-1, arity=2):
+    def balance(n_bins, bins, sizes, w_pair=1, cap=-1, arity=2, balance_base=1000):
         bins = np.ascontiguousarray(bins, dtype=np.int64)
         sizes = np.ascontiguousarray(sizes, dtype=np.int64)
+        if cap == -3 and balance_base != 1000:
+            return Model(lib().sfo_balance_create_base(len(bins), n_bins, _p(bins), _p(sizes), w_pair, balance_base), [len(bins)])
         if arity != 2:
             return Model(lib().sfo_balance_create_nary(len(bins), n_bins, _p(bins), _p(sizes), w_pair, cap, arity), [len(bins)])
         return Model(lib().sfo_balance_create(len(bins), n_bins, _p(bins), _p(sizes), w_pair, cap), [len(bins)])

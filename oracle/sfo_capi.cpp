@@ -115,6 +115,9 @@ void* sfo_balance_create_nary(int32_t n, int32_t n_bins, const int64_t* bins, co
                               int64_t cap, int32_t arity) {
     return make_balance((size_t)n, (size_t)n_bins, bins, sizes, w_tuple, cap, (size_t)arity).release();
 }
+void* sfo_balance_create_base(int32_t n, int32_t n_bins, const int64_t* bins, const int64_t* sizes, int64_t w_pair, int64_t balance_base) {
+    return make_balance((size_t)n, (size_t)n_bins, bins, sizes, w_pair, -3, 2, balance_base).release();  // BalanceConstraint with a chosen base score
+}
 void* sfo_assignment_create(int32_t n, int32_t n_values, const int64_t* values, const int64_t* cost, int64_t cost_weight, const int64_t* row_w,
                             int32_t ex_mode, int32_t ex_level, int64_t ex_weight) {
     return make_assignment((size_t)n, (size_t)n_values, values, cost, cost_weight, row_w, ex_mode, ex_level, ex_weight).release();

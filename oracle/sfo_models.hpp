@@ -301,7 +301,7 @@ inline std::unique_ptr<Model> make_graph_coloring(size_t n, size_t n_colors, con
 //   level 1: pairs of entities in the same bin (IncrementalBiConstraint keyed by bin), `w_pair` each
 //   level 1: per bin, weight(bin, sum of sizes): cap < 0 -> sum^2 ; cap >= 0 -> max(0, sum - cap)
 inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_t* bins, const int64_t* sizes,
-                                           int64_t w_pair, int64_t cap, size_t arity = 2) {
+                                           int64_t w_pair, int64_t cap, size_t arity = 2, int64_t balance_base = 1000) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<BalanceFacts>();
     facts->size.assign(sizes, sizes + n);
@@ -361,7 +361,7 @@ inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_
         int64_t over = wrap_sub(sum, cap);
         return Score::of(0, over > 0 ? over : 0);
     };
-    if (cap == -3) {  // BalanceConstraint (constraint/balance.rs): 1000 soft per unit of the standard deviation of the bin COUNTS
+    if (cap == -3) {  // BalanceConstraint (constraint/balance.rs): `balance_base` (default 1000) soft per unit of the standard deviation of the bin COUNTS
         auto bal = std::make_unique<BalanceConstraint>();
         bal->name = "Bin count balance";
         bal->impact = Impact::Penalty;
@@ -369,7 +369,7 @@ inline std::unique_ptr<Model> make_balance(size_t n, size_t n_bins, const int64_
         bal->count = [](const Solution& s) { return s.classes[0].n; };
         bal->filter = [](const Solution&, size_t) { return true; };
         bal->key = [](const Solution& s, size_t i) { return s.classes[0].vars[0][i]; };
-        bal->base_score = Score::of(0, 1000);
+        bal->base_score = Score::of(0, balance_base);
         m->director.constraints.members.push_back(std::move(bal));
     }
     if (cap != -2 && cap != -3) m->director.constraints.members.push_back(std::move(load));

@@ -13,11 +13,9 @@
 #include <string>
 #include <vector>
 
+#define SF_TU_MAIN 1  // this unit compiles the plain kernels; the fused search kernels live in sf_tu_*.hip (sf_launch.h)
 #include "../../include/solverforge_amd.h"
-#include "sf_list_kernels.hip"
-#include "sf_list_wave.hip"
-#include "sf_scalar_kernels.hip"
-#include "sf_mixed_wave.hip"
+#include "sf_launch.h"
 #include "sf_construct.hip"
 #include "sf_clarke_wright.hip"
 #include "sf_precedence.hip"
@@ -615,6 +613,11 @@ static int build_list_model(sf_ctx* ctx, int d) {
         }
     }
     // nearby meter must be the same matrix (MatrixDistanceMeter)
+    const auto demand_rows_ok = [&]() {  // the matrix (distance constraint or meter) may raise m.dim after the capacity constraint was visited
+        for (auto& cs : ctx->constraints)
+            if (cs.kind == SF_C_ROUTE_CAPACITY && cs.desc == d && ctx->facts[cs.fact].rows < m.dim) return false;
+        return true;
+    };
     for (auto& s : ctx->selectors)
         if ((s.kind == SF_SEL_NEARBY_LIST_CHANGE || s.kind == SF_SEL_NEARBY_LIST_SWAP) && s.desc == d) {
             if (!ctx->facts.count(s.fact) || ctx->facts[s.fact].type != 1) return fail(ctx, SF_ERR_INVALID, "nearby selector needs an i64 matrix meter");
@@ -628,6 +631,7 @@ static int build_list_model(sf_ctx* ctx, int d) {
             if (s.max_nearby < 1 || s.max_nearby > 64) return fail(ctx, SF_ERR_UNSUPPORTED, "max_nearby must be 1..64");
         }
     if (m.dim > 65535 * 16) return fail(ctx, SF_ERR_UNSUPPORTED, "node id bound too large");
+    if (!demand_rows_ok()) return fail(ctx, SF_ERR_INVALID, "demand column shorter than the distance matrix (every matrix node needs a demand row)");
     const int R = ctx->R;
     int rc;
     if ((rc = dalloc(ctx, &m.visits, (size_t)R * m.n_cap))) return rc;
@@ -855,44 +859,41 @@ static int fill_list_leaves(sf_ctx* ctx, SearchParams& p) {
     return SF_OK;
 }
 
-template <int L, bool TRACE>
-static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid) {
+static SearchLaunch make_launch(sf_ctx* ctx, const SearchParams* p, int grid, int block, size_t lds, const GLeaves* gl = nullptr) {
+    return SearchLaunch{grid, block, lds, ctx->stream, &ctx->lm, &ctx->sm, gl, p, ctx->has_list_model ? 1 : 0, ctx->has_scalar_model ? 1 : 0, ctx->nbr};
+}
+template <int L>
+static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
     Carve<L> cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim);
     size_t lds = cv.total;
     if (lds > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "problem does not fit the 160 KiB LDS of one CU");
-    auto kern = k_list_search<L, TRACE>;
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, ctx->lm, p);
-    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, launch_tu_list_block<L>(trace, make_launch(ctx, &p, grid, 1024, lds)));
     return SF_OK;
 }
-template <int L, bool TRACE>
-static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas) {
+template <int L>
+static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas, bool trace) {
     WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx));
     int wpb = (int)((SF_LDS_BUDGET) / cv.total);  // replicas (waves) per workgroup: as many as the LDS holds, <= WPB
     if (wpb > WPB) wpb = WPB;
     size_t lds = cv.total * wpb;
-    const bool fast = !TRACE && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
+    const bool fast = !trace && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
                       p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
-    auto kern = fast ? (ctx->lm_small ? k_list_search_wave<L, false, 2> : k_list_search_wave<L, false, 1>) : k_list_search_wave<L, TRACE, 0>;
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SearchParams q = p;
     q.n_launch = n_replicas;
-    hipLaunchKernelGGL(kern, dim3((n_replicas + wpb - 1) / wpb), dim3(64 * wpb), lds, ctx->stream, ctx->lm, q, ctx->nbr);
-    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, launch_tu_list_wave<L>(trace, fast ? (ctx->lm_small ? 2 : 1) : 0, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, lds)));
     return SF_OK;
 }
 static int launch_list_wave(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
     if (!wave_engine_possible(ctx)) return fail(ctx, SF_ERR_UNSUPPORTED, "wave engine cannot run this model (needs a nearby matrix meter, <= 65535 elements, LDS slice <= 160 KiB)");
     // kernels are instantiated for 2 and 4 score levels; 1- and 3-level models run with one padded
     // (always zero) least-significant level, which never changes a lexicographic comparison
-    if (ctx->levels <= 2) return trace ? launch_list_wave_t<2, true>(ctx, p, grid) : launch_list_wave_t<2, false>(ctx, p, grid);
-    return trace ? launch_list_wave_t<4, true>(ctx, p, grid) : launch_list_wave_t<4, false>(ctx, p, grid);
+    if (ctx->levels <= 2) return launch_list_wave_t<2>(ctx, p, grid, trace);
+    return launch_list_wave_t<4>(ctx, p, grid, trace);
 }
 static int launch_list_search(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
     if (use_wave_engine(ctx)) return launch_list_wave(ctx, p, grid, trace);
-    if (ctx->levels <= 2) return trace ? launch_list_search_t<2, true>(ctx, p, grid) : launch_list_search_t<2, false>(ctx, p, grid);
-    return trace ? launch_list_search_t<4, true>(ctx, p, grid) : launch_list_search_t<4, false>(ctx, p, grid);
+    if (ctx->levels <= 2) return launch_list_search_t<2>(ctx, p, grid, trace);
+    return launch_list_search_t<4>(ctx, p, grid, trace);
 }
 
 static int download_scores(sf_ctx* ctx, const int64_t* d_src4, int64_t* out) {
@@ -1616,8 +1617,8 @@ int32_t sf_phase_start(sf_ctx* ctx) {
 }  // extern "C"
 
 // generic N-leaf engine: mixed models, and list models whose union has plain list change / swap leaves
-template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false>
-static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas) {
+template <int L, class VT, bool RUIN = false, bool PREC = false>
+static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas, bool trace) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
                   gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
@@ -1637,13 +1638,9 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
             wpb = w;
         }
     }
-    auto kern = k_mixed_search_wave<L, TRACE, VT, RUIN, PREC>;
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(cv.total * wpb)));
     SearchParams q = p;
     q.n_launch = n_replicas;
-    hipLaunchKernelGGL(kern, dim3((n_replicas + wpb - 1) / wpb), dim3(64 * wpb), cv.total * wpb, ctx->stream, ctx->lm,
-                       ctx->sm, gl, q, ctx->has_list_model ? 1 : 0, ctx->has_scalar_model ? 1 : 0, ctx->nbr);
-    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb, &gl))));
     return SF_OK;
 }
 static bool has_plain_list_leaves(sf_ctx* ctx) {
@@ -1658,12 +1655,23 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     GLeaves gl{};
     gl.list_desc = ctx->has_list_model ? ctx->list_desc : 0;
     // default-policy declaration order: list rules first, then scalar change, scalar swap
-    // (runtime/compiler/default_local_search/policy.rs:104-108)
-    for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
-                     SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_LIST_RUIN, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
-        for (auto& s : ctx->selectors) {
+    // (runtime/compiler/default_local_search/policy.rs:104-108).  A configured root union (sf_union_configure) keeps the
+    // order of the sf_selector_add calls instead: its weights and the Sequential / RoundRobin child order follow the
+    // declaration order of the UnionMoveSelectorConfig's children (vec_union.rs:119-124).
+    std::vector<const SelectorSpec*> ordered;
+    if (union_is_custom(ctx)) {
+        for (auto& s : ctx->selectors) ordered.push_back(&s);
+    } else {
+        for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
+                         SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_LIST_RUIN, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+            for (auto& s : ctx->selectors)
+                if (s.kind == kind) ordered.push_back(&s);
+    }
+    {
+        for (const SelectorSpec* sp : ordered) {
+            const SelectorSpec& s = *sp;
+            const int kind = s.kind;
             const bool is_list = kind != SF_SEL_SCALAR_CHANGE && kind != SF_SEL_SCALAR_SWAP;
-            if (s.kind != kind) continue;
             if (is_list ? (!ctx->has_list_model || s.desc != ctx->list_desc) : (!ctx->has_scalar_model || s.desc != ctx->scalar_desc))
                 continue;
             if (gl.n >= GL) return fail(ctx, SF_ERR_UNSUPPORTED, "too many leaves for the generic engine");
@@ -1721,26 +1729,26 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations
         if (ctx->has_scalar_model && ctx->sm.n_values <= 127 && ctx->sm.n >= 1024) {  // one-byte value array (C4: 4 waves per CU instead of 3)
             if (ctx->levels <= 2)
-                return trace ? launch_mixed_t<2, true, int8_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int8_t, false, true>(ctx, p, gl, grid);
-            return trace ? launch_mixed_t<4, true, int8_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<4, false, int8_t, false, true>(ctx, p, gl, grid);
+                return launch_mixed_t<2, int8_t, false, true>(ctx, p, gl, grid, trace);
+            return launch_mixed_t<4, int8_t, false, true>(ctx, p, gl, grid, trace);
         }
         if (ctx->levels <= 2)
-            return trace ? launch_mixed_t<2, true, int16_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t, false, true>(ctx, p, gl, grid);
-        return trace ? launch_mixed_t<4, true, int16_t, false, true>(ctx, p, gl, grid) : launch_mixed_t<4, false, int16_t, false, true>(ctx, p, gl, grid);
+            return launch_mixed_t<2, int16_t, false, true>(ctx, p, gl, grid, trace);
+        return launch_mixed_t<4, int16_t, false, true>(ctx, p, gl, grid, trace);
     }
     if (gl.has_ruin) {  // the ruin leaf has its own instantiations (i16 values only)
         if (ctx->levels <= 2)
-            return trace ? launch_mixed_t<2, true, int16_t, true>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t, true>(ctx, p, gl, grid);
-        return trace ? launch_mixed_t<4, true, int16_t, true>(ctx, p, gl, grid) : launch_mixed_t<4, false, int16_t, true>(ctx, p, gl, grid);
+            return launch_mixed_t<2, int16_t, true>(ctx, p, gl, grid, trace);
+        return launch_mixed_t<4, int16_t, true>(ctx, p, gl, grid, trace);
     }
     if (ctx->has_scalar_model && ctx->sm.n_values <= 127 && ctx->sm.n >= 1024) {
         if (ctx->levels <= 2)
-            return trace ? launch_mixed_t<2, true, int8_t>(ctx, p, gl, grid) : launch_mixed_t<2, false, int8_t>(ctx, p, gl, grid);
-        return trace ? launch_mixed_t<4, true, int8_t>(ctx, p, gl, grid) : launch_mixed_t<4, false, int8_t>(ctx, p, gl, grid);
+            return launch_mixed_t<2, int8_t>(ctx, p, gl, grid, trace);
+        return launch_mixed_t<4, int8_t>(ctx, p, gl, grid, trace);
     }
     if (ctx->levels <= 2)
-        return trace ? launch_mixed_t<2, true, int16_t>(ctx, p, gl, grid) : launch_mixed_t<2, false, int16_t>(ctx, p, gl, grid);
-    return trace ? launch_mixed_t<4, true, int16_t>(ctx, p, gl, grid) : launch_mixed_t<4, false, int16_t>(ctx, p, gl, grid);
+        return launch_mixed_t<2, int16_t>(ctx, p, gl, grid, trace);
+    return launch_mixed_t<4, int16_t>(ctx, p, gl, grid, trace);
 }
 
 extern "C" {

@@ -14,6 +14,14 @@
 #define SF_HD inline
 #endif
 
+// Plain (non-template) kernels are compiled once, in the translation unit of the C ABI (sf_api.hip defines
+// SF_TU_MAIN); the per-engine search units (sf_tu_*.hip, built in parallel) see them as uninstantiated templates.
+#ifdef SF_TU_MAIN
+#define SF_PLAIN_KERNEL
+#else
+#define SF_PLAIN_KERNEL template <int SF_TU_UNUSED_ = 0>
+#endif
+
 namespace sf {
 
 constexpr uint64_t GOLDEN = 0x9E3779B97F4A7C15ULL;

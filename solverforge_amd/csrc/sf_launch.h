@@ -1,0 +1,79 @@
+// Seam between the C-ABI translation unit (sf_api.hip) and the search-kernel translation units (sf_tu_*.hip).
+// The fused search kernels are large templates; each unit instantiates a few of them, so the library builds
+// in parallel (csrc/Makefile) and an edit of one engine recompiles that engine only.  Every launcher sets the
+// dynamic-LDS attribute of its instantiation, launches on the caller's stream and returns hipGetLastError().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sf_list_kernels.hip"
+#include "sf_list_wave.hip"
+#include "sf_scalar_kernels.hip"
+#include "sf_mixed_wave.hip"
+
+namespace sf {
+
+struct SearchLaunch {
+    int grid, block;
+    size_t lds;
+    hipStream_t stream;
+    const ListModel* lm;
+    const ScalarModel* sm;
+    const GLeaves* gl;
+    const SearchParams* p;
+    int has_list, has_scalar;
+    NbrIndex nb;
+};
+
+// block engine: k_list_search<L, TRACE>
+template <int L>
+hipError_t launch_tu_list_block(bool trace, const SearchLaunch& a);
+// wave engine: k_list_search_wave<L, TRACE, MODE> (mode 1 / 2 = the FAST instantiations, never traced)
+template <int L>
+hipError_t launch_tu_list_wave(bool trace, int mode, const SearchLaunch& a);
+// scalar engine: k_scalar_search_wave<L, TRACE, VT>, VT = int8_t (VTB 1) or int16_t (VTB 2)
+template <int L, int VTB>
+hipError_t launch_tu_scalar(bool trace, const SearchLaunch& a);
+// generic N-leaf engine: k_mixed_search_wave<L, TRACE, VT, RUIN, PREC>
+template <int L, int VTB, bool RUIN, bool PREC>
+hipError_t launch_tu_mixed(bool trace, const SearchLaunch& a);
+
+#define SF_TU_DECL_MIXED(L, VTB, RUIN, PREC) \
+    template <>                              \
+    hipError_t launch_tu_mixed<L, VTB, RUIN, PREC>(bool trace, const SearchLaunch& a);
+SF_TU_DECL_MIXED(2, 1, false, false)
+SF_TU_DECL_MIXED(4, 1, false, false)
+SF_TU_DECL_MIXED(2, 2, false, false)
+SF_TU_DECL_MIXED(4, 2, false, false)
+SF_TU_DECL_MIXED(2, 2, true, false)
+SF_TU_DECL_MIXED(4, 2, true, false)
+SF_TU_DECL_MIXED(2, 1, false, true)
+SF_TU_DECL_MIXED(4, 1, false, true)
+SF_TU_DECL_MIXED(2, 2, false, true)
+SF_TU_DECL_MIXED(4, 2, false, true)
+#undef SF_TU_DECL_MIXED
+template <>
+hipError_t launch_tu_scalar<2, 1>(bool trace, const SearchLaunch& a);
+template <>
+hipError_t launch_tu_scalar<2, 2>(bool trace, const SearchLaunch& a);
+template <>
+hipError_t launch_tu_scalar<4, 1>(bool trace, const SearchLaunch& a);
+template <>
+hipError_t launch_tu_scalar<4, 2>(bool trace, const SearchLaunch& a);
+template <>
+hipError_t launch_tu_list_wave<2>(bool trace, int mode, const SearchLaunch& a);
+template <>
+hipError_t launch_tu_list_wave<4>(bool trace, int mode, const SearchLaunch& a);
+template <>
+hipError_t launch_tu_list_block<2>(bool trace, const SearchLaunch& a);
+template <>
+hipError_t launch_tu_list_block<4>(bool trace, const SearchLaunch& a);
+
+template <class K, class... Args>
+inline hipError_t launch_with_lds(K kern, const SearchLaunch& a, Args... args) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(a.block), a.lds, a.stream, args...);
+    return hipGetLastError();
+}
+
+}  // namespace sf

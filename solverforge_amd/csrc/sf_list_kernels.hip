@@ -18,6 +18,7 @@
 // immutable step snapshot, so the reference's do/score/undo (4x retract+insert per entity per
 // constraint) becomes a stateless O(1) integer delta per candidate; integer addition is
 // associative, so cur + delta == the reference's incremental score bit for bit.
+#pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -728,6 +729,7 @@ __device__ __forceinline__ ScoreV<L> apply_delta(const ListModel& m, const int64
 }
 
 // compact u32 copy of the distance matrix (distance_cost semantics preserved: not-finite -> sentinel)
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_mat_compress(const int64_t* __restrict__ mat, size_t n,
                                                       uint32_t* __restrict__ out) {
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(256) void k_mat_compress(const int64_t* __restrict_
 // grid = R blocks.  commit != 0 also (re)builds the per-route load aggregate + cached score.
 // ---------------------------------------------------------------------------------------
 // out_parts (optional, [R][SF_EACH_WORDS]): raw per-constraint aggregates for ConstraintSet::evaluate_each
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_list_evaluate_all(ListModel m, int64_t* out_scores, int commit, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* present = (uint32_t*)smem;  // bitmap over node ids
@@ -809,6 +812,7 @@ __global__ __launch_bounds__(256) void k_list_evaluate_all(ListModel m, int64_t*
 // n x evaluate_candidate for host-provided moves (the ScalarCandidateProvider / MoveSelector
 // plugin surface): one thread per move against replica `replica`, state unchanged.
 // ---------------------------------------------------------------------------------------
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int replica, const int32_t* moves,
                                                              int64_t n, int64_t* out_scores,
                                                              int32_t* out_doable, int skip_foreign) {
@@ -983,6 +987,7 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
     __syncthreads();
 }
 
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, int kind, uint32_t a, uint32_t i,
                                                     uint32_t b, uint32_t j, uint32_t ext, int32_t* out_ok) {
     uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
@@ -1013,6 +1018,7 @@ __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, in
 }
 
 // phase start: last_step_score = score; LA history filled; best = working (phase.rs:250-261)
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_list_phase_start(ListModel m, SearchParams p) {
     const int r = blockIdx.x;
     const int64_t* cur = m.score + (size_t)r * 4;

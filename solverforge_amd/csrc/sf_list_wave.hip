@@ -18,6 +18,7 @@
 //    serial insertion;
 //  * trial scoring happens at replay time with all 64 lanes busy (lane i = i-th candidate of
 //    the union cursor order), so the rings only hold move coordinates.
+#pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -58,6 +59,7 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v) {
 // ---------------------------------------------------------------------------------------
 // Neighbour index: bitonic sort of every matrix row in LDS.  grid = dim rows.
 // ---------------------------------------------------------------------------------------
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__ mat, int dim, int P,
                                                      uint16_t* __restrict__ keys) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

@@ -7,6 +7,7 @@
 namespace sf {
 
 // one wavefront per replica; adds the constraint's two levels to out_scores ([R][levels], already holding the other constraints)
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(64) void k_prec_evaluate_all(ListModel m, PrecModel pm, int64_t* out_scores, int commit, int64_t* out_parts) {
     const int r = blockIdx.x;
     const size_t n = (size_t)pm.n;
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(64) void k_prec_evaluate_all(ListModel m, PrecModel
 }
 
 // after a committed list move of `replica` (k_list_apply updated the lists and the other constraints' score)
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(64) void k_prec_after_apply(ListModel m, PrecModel pm, int replica) {
     const int r = replica;
     const size_t n = (size_t)pm.n;
@@ -57,6 +59,7 @@ struct PrecMoveCarve {
 
 // records [base, base + gridDim.x) of `moves` ([n][6] sf_move_t words) against replica `replica`: adds the constraint's delta to
 // the trial scores the list kernel wrote.  Scratch slot = blockIdx.x (< R).
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(64) void k_prec_evaluate_moves(ListModel m, PrecModel pm, int replica, const int32_t* moves, int64_t base,
                                                             int64_t* out_scores, const int32_t* doable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

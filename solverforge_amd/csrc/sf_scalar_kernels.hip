@@ -585,6 +585,7 @@ struct TableView {  // per-value count / sum table plus the candidate's own shif
 
 // n x evaluate_candidate for multi-edit candidates: candidate t = edits[offsets[t] .. offsets[t + 1]) (Change-shaped moves).
 // is_doable_on (compound_scalar.rs:254-270): at least one edit, every to_value legal, some edit differs from the CURRENT value.
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_scalar_evaluate_compound(ScalarModel m, int replica, const int32_t* edits, const int64_t* offsets, int64_t n,
                                                                   int64_t* out_scores, int32_t* out_doable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
@@ -637,6 +638,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_compound(ScalarModel m,
 }
 
 // committed do_move of one compound candidate (compound_scalar.rs:291-308), one lane
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int replica, const int32_t* edits, int n_edits, int32_t* out_ok) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
     int32_t* vals = m.vals + (size_t)replica * m.n;
@@ -679,6 +681,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
 
 // evaluate_all / initialize: full recomputation (fresh_score; FullAssert).  grid = R blocks.
 // accumulate != 0: add this class's constraint scores to what the list class already wrote (mixed models)
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
                                                              int accumulate, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];  // per-value tables (when used)
@@ -819,6 +822,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
 
 // n x evaluate_candidate for host-provided moves (the ScalarCandidateProvider surface: a batch of
 // ScalarEdit{entity, to_value} is kind = SF_MOVE_CHANGE): one thread per move, state unchanged.
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, int replica, const int32_t* moves,
                                                                int64_t n, int64_t* out_scores, int32_t* out_doable,
                                                                int skip_foreign) {
@@ -857,6 +861,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_moves(ScalarModel m, in
 }
 
 // committed Change / Swap on global state (sf_apply)
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(64) void k_scalar_apply(ScalarModel m, int replica, int kind, int a, int b, int value,
                                                      int32_t* out_ok) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
@@ -893,6 +898,7 @@ __global__ __launch_bounds__(64) void k_scalar_apply(ScalarModel m, int replica,
     *out_ok = 1;
 }
 
+SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_scalar_phase_start(ScalarModel m, SearchParams p) {
     const int r = blockIdx.x;
     const int64_t* cur = m.score + (size_t)r * 4;

@@ -1,0 +1,26 @@
+// One translation unit of the generic N-leaf engine: k_mixed_search_wave<SF_TU_L, *, VT, SF_TU_RUIN, SF_TU_PREC>,
+// traced and untraced.  Built once per (L, VT, RUIN, PREC) combination by csrc/Makefile.
+#include "sf_launch.h"
+
+namespace sf {
+
+template <int VTB>
+struct TuValueType {
+    using type = int16_t;
+};
+template <>
+struct TuValueType<1> {
+    using type = int8_t;
+};
+
+template <>
+hipError_t launch_tu_mixed<SF_TU_L, SF_TU_VTB, SF_TU_RUIN != 0, SF_TU_PREC != 0>(bool trace, const SearchLaunch& a) {
+    using VT = TuValueType<SF_TU_VTB>::type;
+    if (trace)
+        return launch_with_lds(k_mixed_search_wave<SF_TU_L, true, VT, SF_TU_RUIN != 0, SF_TU_PREC != 0>, a, *a.lm, *a.sm, *a.gl, *a.p, a.has_list,
+                               a.has_scalar, a.nb);
+    return launch_with_lds(k_mixed_search_wave<SF_TU_L, false, VT, SF_TU_RUIN != 0, SF_TU_PREC != 0>, a, *a.lm, *a.sm, *a.gl, *a.p, a.has_list,
+                           a.has_scalar, a.nb);
+}
+
+}  // namespace sf

@@ -117,6 +117,10 @@ class GpuScoreDirector:
 
     def set_value_lists(self, descriptor_index, variable_index, lists):
         """ValueSource::EntitySlice: `lists[e]` = the canonical value list of entity e (values in 0..n_values)."""
+        n_rows = self._entity_counts.get(descriptor_index)
+        if n_rows is None or len(lists) != n_rows:  # the C side reads offsets[0..n_rows]
+            raise SolverForgeError(f"SF_ERR_INVALID: value lists must hold one list per row of class {descriptor_index} "
+                                   f"({n_rows}), got {len(lists)}")
         off = np.zeros(len(lists) + 1, dtype=np.uint32)
         for i, l in enumerate(lists):
             off[i + 1] = off[i] + len(l)

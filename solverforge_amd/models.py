@@ -27,24 +27,29 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
     d.add_constraint(ConstraintKind.NOT_EXISTS_FLATTENED, 0, fact=FACT_CUSTOMERS, level=0, weight=1)
     d.add_constraint(ConstraintKind.ROUTE_CAPACITY, 0, fact=FACT_DEMAND, param=int(problem["capacity"]), level=0, weight=1)
     d.add_constraint(ConstraintKind.ROUTE_DISTANCE, 0, fact=FACT_MATRIX, param=int(problem["depot"]), level=1, weight=1)
-    if "nearby_change" in leaves:
-        d.add_selector(SelectorKind.NEARBY_LIST_CHANGE, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
-    if "nearby_swap" in leaves:
-        d.add_selector(SelectorKind.NEARBY_LIST_SWAP, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
-    if "list_change" in leaves:
-        d.add_selector(SelectorKind.LIST_CHANGE, 0)
-    if "list_swap" in leaves:
-        d.add_selector(SelectorKind.LIST_SWAP, 0)
-    if "list_reverse" in leaves:
-        d.add_selector(SelectorKind.LIST_REVERSE, 0)
-    if "sublist_change" in leaves:
-        d.add_sublist_selector(SelectorKind.SUBLIST_CHANGE, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
-    if "sublist_swap" in leaves:
-        d.add_sublist_selector(SelectorKind.SUBLIST_SWAP, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
-    if "kopt" in leaves:  # kopt = (min_segment_len, max_nearby); max_nearby 0 = full enumeration
-        d.add_kopt_selector(0, min_segment_len=kopt[0], max_nearby=kopt[1])
-    if "ruin" in leaves:  # ruin = (min_ruin_count, max_ruin_count, moves_per_step)
-        d.add_ruin_selector(0, min_ruin_count=ruin[0], max_ruin_count=ruin[1], moves_per_step=ruin[2], variable_name="visits")
+    # selectors are declared in the order `leaves` names them: a configured root union (configure_union) schedules and weights
+    # its children in declaration order; the default policy's union ignores it (policy/list.rs:24-33 order)
+    for leaf in leaves:
+        if leaf == "nearby_change":
+            d.add_selector(SelectorKind.NEARBY_LIST_CHANGE, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
+        elif leaf == "nearby_swap":
+            d.add_selector(SelectorKind.NEARBY_LIST_SWAP, 0, max_nearby=max_nearby, fact_meter=FACT_MATRIX)
+        elif leaf == "list_change":
+            d.add_selector(SelectorKind.LIST_CHANGE, 0)
+        elif leaf == "list_swap":
+            d.add_selector(SelectorKind.LIST_SWAP, 0)
+        elif leaf == "list_reverse":
+            d.add_selector(SelectorKind.LIST_REVERSE, 0)
+        elif leaf == "sublist_change":
+            d.add_sublist_selector(SelectorKind.SUBLIST_CHANGE, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
+        elif leaf == "sublist_swap":
+            d.add_sublist_selector(SelectorKind.SUBLIST_SWAP, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
+        elif leaf == "kopt":  # kopt = (min_segment_len, max_nearby); max_nearby 0 = full enumeration
+            d.add_kopt_selector(0, min_segment_len=kopt[0], max_nearby=kopt[1])
+        elif leaf == "ruin":  # ruin = (min_ruin_count, max_ruin_count, moves_per_step)
+            d.add_ruin_selector(0, min_ruin_count=ruin[0], max_ruin_count=ruin[1], moves_per_step=ruin[2], variable_name="visits")
+        else:
+            raise ValueError(f"unknown leaf {leaf!r}")
     return d
 
 
@@ -198,14 +203,14 @@ def build_shift_schedule(nurse_idx, day, n_nurses, n_replicas=1, device_id=0, li
     return d
 
 
-def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=-1, leaves=("change", "swap"), arity=2):
+def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=-1, leaves=("change", "swap"), arity=2, balance_base=1000):
     """Bin balance: the keyed self-join (pairs of entities sharing a bin — IncrementalBiConstraint,
     constraint/nary_incremental/bi.rs:12-313) and the grouped sum (group_by(bin, sum(size)) with
     weight(sum) — constraint/grouped/{state,scorer}.rs) on one scalar variable.  HardSoftScore:
     hard = unassigned entities, soft = w_pair per same-bin pair + sum^2 (cap == -1) or excess over cap (cap >= 0);
     cap == -2 replaces the per-bin load by FAIRNESS: group_by(load_balance(bin, size)).penalize(unfairness)
     (stream/collector/load_balance.rs), sizes >= 1; cap == -3 replaces it by the BalanceConstraint (constraint/balance.rs):
-    1000 soft per unit of the standard deviation of the per-bin entity COUNTS."""
+    `balance_base` (1000) soft per unit of the standard deviation of the per-bin entity COUNTS."""
     import numpy as np
 
     d = GpuScoreDirector(score_levels=2, hard_levels=1, n_replicas=n_replicas, device_id=device_id)
@@ -219,7 +224,7 @@ def build_balance(bins, sizes, n_bins, n_replicas=1, device_id=0, w_pair=1, cap=
     if cap == -2:
         d.add_constraint(ConstraintKind.LOAD_BALANCE_VALUE, 0, fact=FACT_COLUMN, level=1, weight=1)
     elif cap == -3:
-        d.add_constraint(ConstraintKind.BALANCE_VALUE, 0, level=1, weight=1000)
+        d.add_constraint(ConstraintKind.BALANCE_VALUE, 0, level=1, weight=balance_base)
     else:
         d.add_constraint(ConstraintKind.GROUPED_VALUE_SUM, 0, fact=FACT_COLUMN, param=cap, level=1, weight=1)
     if "change" in leaves:

@@ -237,6 +237,28 @@ def test_keyed_selfjoin_and_grouped_sum(oracle, cap):
     assert (d.fresh_score()[0] == o.score()[:2]).all()
 
 
+def test_balance_variance_is_not_contracted_on_the_device(oracle):
+    """hipcc's default -ffp-contract=fast turned `sum_sq / n - mean * mean` into one v_fma_f64; the library is
+    built with -ffp-contract=off.  The counts of tests/test_oracle_golden.py give 13 unfused (reference) and 14 fused; trial
+    deltas around that state must agree with the oracle too."""
+    import solverforge_amd as sfa
+    from test_oracle_golden import BALANCE_FMA_COUNTS, balance_fma_bins
+
+    bins = balance_fma_bins()
+    k = len(BALANCE_FMA_COUNTS)
+    sizes = np.ones(len(bins), dtype=np.int64)
+    d = sfa.build_balance(bins, sizes, k, w_pair=0, cap=-3, balance_base=5)
+    o = oracle.Model.balance(k, bins, sizes, w_pair=0, cap=-3, balance_base=5)
+    assert d.calculate_score()[0].tolist() == [0, -13] == list(o.score()[:2])
+    assert d.fresh_score()[0].tolist() == [0, -13]
+    bits = oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
+    o.configure(leaves=bits, random_seed=1, la_size=4, limit=30)
+    om = o.enumerate(0, 0, 17, 0)
+    os_, od = o.evaluate_moves(om)
+    es, ed = d.evaluate_moves(om)
+    assert (ed == od).all() and (es == os_[:, :2]).all()
+
+
 def test_evaluate_each_matches_oracle_per_constraint(oracle):
     """ConstraintSet::evaluate_each: per-constraint score and match count (graph colouring, N-queens, bin balance,
     CVRP, job shop) after some committed steps."""

@@ -109,3 +109,30 @@ def test_union_configure_validation():
     d.phase_start()
     with pytest.raises(sfa.SolverForgeError):
         d.solve_steps(1)
+
+
+def test_configured_union_keeps_declaration_order(oracle):
+    """a configured union's children are scheduled (and weighted) in the order of the sf_selector_add calls, not
+    in the default policy's kind order.  Sequential drains child 0 first: declared (nearby swap, nearby change), the stream is
+    the swap leaf's stream followed by the change leaf's; a zero weight on declared child 0 leaves only the change leaf."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(30, 3, 60, seed=5)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    streams = {}
+    for name in ("nearby_swap", "nearby_change"):
+        o.configure(leaves=LEAF_BITS[name], random_seed=1, la_size=5, limit=40, max_nearby=8, selection_order=3)
+        streams[name] = _t(o.enumerate(0, 2, 99, 3))
+    d = sfa.build_cvrp(p, leaves=("nearby_swap", "nearby_change"), max_nearby=8)
+    d.configure_union(0, None)  # Sequential
+    d.configure(sfa.SolverConfig(random_seed=1, late_acceptance_size=5, accepted_count_limit=40))
+    d.calculate_score()
+    gm, _, _ = d.open_cursor(2, 99, selection_order=3, cap=1 << 18)
+    assert (_t(gm) == np.concatenate([streams["nearby_swap"], streams["nearby_change"]])).all()
+    d2 = sfa.build_cvrp(p, leaves=("nearby_swap", "nearby_change"), max_nearby=8)
+    d2.configure_union(4, [0, 3])  # weights follow the declaration order: the swap leaf is disabled
+    d2.configure(sfa.SolverConfig(random_seed=1, late_acceptance_size=5, accepted_count_limit=40))
+    d2.calculate_score()
+    gm2, _, _ = d2.open_cursor(2, 99, selection_order=3, cap=1 << 18)
+    assert (_t(gm2) == streams["nearby_change"]).all()

@@ -179,6 +179,26 @@ def test_load_balance_model_incremental_equals_fresh(oracle):
         assert o.score()[1] == -unfair and o.score()[0] == -int((vals < 0).sum())
 
 
+BALANCE_FMA_COUNTS = [1, 6, 2, 6, 9, 4, 5, 7, 2, 9]  # variance 33.3 - 5.1 * 5.1: a fused multiply-subtract rounds 5 * sigma to 14
+
+
+def balance_fma_bins():
+    import numpy as np
+
+    return np.concatenate([np.full(c, b, dtype=np.int64) for b, c in enumerate(BALANCE_FMA_COUNTS)])
+
+
+def test_balance_variance_rounds_the_square_before_subtracting(oracle):
+    """BalanceConstraint (constraint/balance.rs:162-173): variance = sum_sq / n - mean * mean with the product rounded first
+    (Rust never contracts a * b - c into an FMA).  With these counts and base score 5 the reference gives 13; a contracted
+    evaluation gives 14."""
+    import numpy as np
+
+    bins = balance_fma_bins()
+    o = oracle.Model.balance(len(BALANCE_FMA_COUNTS), bins, np.ones(len(bins), dtype=np.int64), w_pair=0, cap=-3, balance_base=5)
+    assert list(o.score()[:2]) == [0, -13] and list(o.fresh_score()[:2]) == [0, -13]
+
+
 def test_constructed_graph_start_equals_oracle_first_fit(oracle):
     """datasets.construct_graph (the C2 start state) is the oracle's first-fit construction phase."""
     from solverforge_amd import datasets
