@@ -188,10 +188,15 @@ typedef enum sf_acceptor_kind {
     SF_ACCEPT_HILL_CLIMBING = 0,  /* phase/localsearch/acceptor/hill_climbing.rs:33-41 */
     SF_ACCEPT_LATE_ACCEPTANCE = 1,/* phase/localsearch/acceptor/late_acceptance.rs:89-125 */
     /* 2 is reserved (internal "never accept" of the dry-run enumeration) */
-    SF_ACCEPT_SIMULATED_ANNEALING = 3 /* phase/localsearch/acceptor/simulated_annealing.rs:11-430; the default of
+    SF_ACCEPT_SIMULATED_ANNEALING = 3,/* phase/localsearch/acceptor/simulated_annealing.rs:11-430; the default of
                                        * scalar-only models (default_local_search/policy.rs:56-61).  Parameters:
                                        * sf_solver_configure_annealing; without it the reference defaults apply
                                        * (auto-calibrated, decay 0.999985, rng seed = random_seed). */
+    SF_ACCEPT_DIVERSIFIED_LATE_ACCEPTANCE = 4 /* phase/localsearch/acceptor/diversified_late_acceptance.rs:40-176; the default
+                                       * of grouped scalar-only models (default_local_search/policy.rs:52-55): late acceptance
+                                       * over sf_solver_config::late_acceptance_size steps, or within `tolerance` of the best step
+                                       * score of the phase (sf_solver_configure_diversified, default 0.01).  Wave, scalar and
+                                       * generic engines (the block engine reports SF_ERR_UNSUPPORTED). */
 } sf_acceptor_kind;
 
 typedef enum sf_annealing_mode {
@@ -433,6 +438,9 @@ int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg);
 /* parameters of SF_ACCEPT_SIMULATED_ANNEALING (takes effect at the next sf_phase_start); validation follows
  * assert_simulated_annealing_parameters (simulated_annealing.rs:305-336) -> SF_ERR_INVALID instead of a panic */
 int32_t sf_solver_configure_annealing(sf_ctx* ctx, const sf_annealing_config* cfg);
+/* tolerance of SF_ACCEPT_DIVERSIFIED_LATE_ACCEPTANCE (DiversifiedLateAcceptanceAcceptor::new, diversified_late_acceptance.rs:86-98):
+ * a candidate is also accepted when it is >= best - |best|.multiply(tolerance), each level rounded half away from zero */
+int32_t sf_solver_configure_diversified(sf_ctx* ctx, double tolerance);
 /* acceptor state of one replica: current temperatures [score_levels] and whether it is still calibrating */
 int32_t sf_get_annealing_state(sf_ctx* ctx, int32_t replica, double* out_temperatures, int32_t* out_calibrating);
 int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine); /* sf_engine_kind; SF_ERR_UNSUPPORTED if it cannot run this model */

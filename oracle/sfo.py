@@ -86,6 +86,7 @@ def lib():
             "sfo_model_set_kopt": (None, [vp, i32, i32]),
             "sfo_model_evaluate_each": (i32, [vp, vp, vp, i32]),
             "sfo_model_configure_annealing": (None, [vp, i32, vp, i32, i32, dbl, dbl, i32, i32, dbl, dbl, u64]),
+            "sfo_model_configure_diversified": (None, [vp, i32, dbl]),
             "sfo_model_annealing_state": (None, [vp, vp, vp, vp]),
             "sfo_xoshiro256pp": (None, [vp, i32, vp]),
             "sfo_small_rng_seed": (None, [u64, vp]),
@@ -290,6 +291,10 @@ class Model:
         lib().sfo_model_configure_annealing(self.h, mode, _p(t), levels, hard_levels, decay_rate,
                                             hill_climbing_temperature, int(never_accept_hard), sample_size,
                                             target_probability, fallback_temperature, seed)
+
+    def configure_diversified(self, la_size=400, tolerance=0.01):
+        """Install a DiversifiedLateAcceptanceAcceptor (call after configure())."""
+        lib().sfo_model_configure_diversified(self.h, la_size, tolerance)
 
     def annealing_state(self):
         t = np.zeros(4, dtype=np.float64)

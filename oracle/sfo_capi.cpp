@@ -232,6 +232,10 @@ void sfo_model_configure_annealing(void* h, int32_t mode, const double* temps, i
     sa->rng = SmallRng::seed_from_u64(seed);
     m->search.acceptor = std::move(sa);
 }
+// DiversifiedLateAcceptanceAcceptor(late_acceptance_size, tolerance).  Replaces the acceptor sfo_model_configure installed.
+void sfo_model_configure_diversified(void* h, int32_t la_size, double tolerance) {
+    ((Model*)h)->search.acceptor = std::make_unique<DiversifiedLateAcceptanceAcceptor>((size_t)la_size, tolerance);
+}
 // acceptor state after the steps run so far: temperatures[levels], rng state[4], calibrating flag
 void sfo_model_annealing_state(void* h, double* out_temps, uint64_t* out_rng, int32_t* out_calibrating) {
     auto* sa = dynamic_cast<SimulatedAnnealingAcceptor*>(((Model*)h)->search.acceptor.get());

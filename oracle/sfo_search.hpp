@@ -70,6 +70,62 @@ struct LateAcceptanceAcceptor : Acceptor {  // late_acceptance.rs:89-125
     }
 };
 
+// diversified_late_acceptance.rs:40-176 -- late acceptance plus "within tolerance of the best step score of this phase":
+// threshold = best - |best|.multiply(tolerance), every level rounded half away from zero (score/macros.rs:61-71).
+// The default acceptor of grouped scalar-only models (runtime/compiler/default_local_search/policy.rs:52-55).
+struct DiversifiedLateAcceptanceAcceptor : Acceptor {
+    size_t size;
+    std::vector<Score> history;
+    std::vector<bool> filled;
+    size_t current = 0;
+    bool has_best = false;
+    Score best;
+    double tolerance;
+    DiversifiedLateAcceptanceAcceptor(size_t n, double tol) : size(n), history(n), filled(n, false), tolerance(tol) {}
+    static int64_t f64_as_i64(double x) {  // Rust `as i64`: saturating, NaN -> 0
+        if (x != x) return 0;
+        if (x >= 9223372036854775808.0) return INT64_MAX;
+        if (x <= -9223372036854775808.0) return INT64_MIN;
+        return (int64_t)x;
+    }
+    static Score threshold(const Score& best, double tolerance) {  // (:139-146)
+        Score t;
+        for (int i = 0; i < MAX_LEVELS; ++i) {
+            int64_t a = best.v[i] < 0 ? wrap_neg(best.v[i]) : best.v[i];
+            t.v[i] = wrap_sub(best.v[i], f64_as_i64(std::round((double)a * tolerance)));
+        }
+        return t;
+    }
+    bool is_accepted(const Score& last, const Score& mv) override {  // (:118-150)
+        if (mv >= last) return true;
+        if (filled[current]) {
+            if (mv >= history[current]) return true;
+        } else {
+            return true;  // no history yet
+        }
+        if (has_best && mv >= threshold(best, tolerance)) return true;
+        return false;
+    }
+    void phase_started(const Score& initial) override {  // (:152-159)
+        for (size_t i = 0; i < size; ++i) {
+            history[i] = initial;
+            filled[i] = true;
+        }
+        current = 0;
+        best = initial;
+        has_best = true;
+    }
+    void step_ended(const Score& step_score) override {  // (:161-176)
+        if (!has_best || step_score > best) {
+            best = step_score;
+            has_best = true;
+        }
+        history[current] = step_score;
+        filled[current] = true;
+        current = (current + 1) % size;
+    }
+};
+
 // simulated_annealing.rs:11-430.  `levels` = Score::levels_count(), `hard_levels` = how many
 // leading levels carry ScoreLevel::Hard (HardSoft: 1; Bendable<H,S>: H).
 struct SimulatedAnnealingAcceptor : Acceptor {

@@ -851,6 +851,45 @@ static void k_opt_cases() {
     }
 }
 
+// phase/localsearch/acceptor/diversified_late_acceptance/tests.rs:17-68 (every case; SoftScore = one level)
+static void diversified_late_acceptance_cases() {
+    auto S = [](int64_t v) { return Score::level(0, v); };
+    {
+        DiversifiedLateAcceptanceAcceptor a(5, 0.1);
+        a.phase_started(S(-100));
+        CHECK("dla.accepts_improving_moves", a.is_accepted(S(-100), S(-90)));
+    }
+    {
+        DiversifiedLateAcceptanceAcceptor a(3, 0.1);
+        a.phase_started(S(-100));
+        CHECK("dla.accepts_late_equal", a.is_accepted(S(-90), S(-100)));
+    }
+    {
+        DiversifiedLateAcceptanceAcceptor a(3, 0.1);
+        a.phase_started(S(-100));
+        a.step_ended(S(-80));
+        a.step_ended(S(-70));
+        a.step_ended(S(-60));
+        CHECK("dla.diversification_accepts_within_tolerance", a.is_accepted(S(-60), S(-65)));  // -60 - round(60 * 0.1) = -66
+    }
+    {
+        DiversifiedLateAcceptanceAcceptor a(3, 0.05);
+        a.phase_started(S(-100));
+        a.step_ended(S(-40));
+        a.step_ended(S(-40));
+        a.step_ended(S(-40));
+        CHECK("dla.rejects_outside_tolerance", !a.is_accepted(S(-40), S(-50)));  // late -40, threshold -42
+    }
+    {
+        DiversifiedLateAcceptanceAcceptor a(3, 0.1);
+        a.phase_started(S(-100));
+        a.step_ended(S(-80));
+        a.step_ended(S(-70));
+        a.step_ended(S(-60));
+        CHECK("dla.history_cycles", a.is_accepted(S(-60), S(-75)));  // history[0] = -80
+    }
+}
+
 // phase/localsearch/acceptor/simulated_annealing/tests.rs:40-273 (every case) + the published
 // xoshiro256++ test vector for the SmallRng restatement.
 static void simulated_annealing_cases() {
@@ -1645,6 +1684,7 @@ int main() {
     forager_cases();
     k_opt_cases();
     simulated_annealing_cases();
+    diversified_late_acceptance_cases();
     list_reverse_cases();
     list_ruin_cases();
     compound_scalar_cases();

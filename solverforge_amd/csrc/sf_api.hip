@@ -95,6 +95,7 @@ struct sf_ctx {
     // SimulatedAnnealingCalibration::default + DEFAULT_* (simulated_annealing.rs:11-38); seed_set = false -> cfg.random_seed
     sf_annealing_config anneal{SF_ANNEAL_CALIBRATED, 0, 128, 0, {0, 0, 0, 0}, 0.999985, 1.0e-9, 0.80, 1.0, 0};
     bool anneal_seed_set = false;
+    double dla_tolerance = 0.01;  // DiversifiedLateAcceptanceAcceptor::default (diversified_late_acceptance.rs:106-110)
     uint64_t* d_explicit = nullptr;
     int64_t n_explicit = 0;
     // trace buffers
@@ -804,6 +805,7 @@ static int alloc_search(sf_ctx* ctx) {
     if ((rc = dalloc(ctx, &ctx->d_trace_applied, 8))) return rc;
     if ((rc = dalloc(ctx, &ctx->d_ok, 4))) return rc;
     if ((rc = dalloc(ctx, &p.sa.state, (size_t)R * SA_WORDS))) return rc;
+    if ((rc = dalloc(ctx, &p.dla_best, (size_t)R * 4))) return rc;
     p.la_size = la;
     ctx->search_alloc = true;
     return SF_OK;
@@ -821,6 +823,7 @@ static int ensure_trace(sf_ctx* ctx, int64_t cap) {
 
 static void fill_search_params(sf_ctx* ctx, SearchParams& p) {
     p.acceptor = ctx->cfg.acceptor;
+    p.dla_tolerance = ctx->dla_tolerance;
     p.forager = ctx->cfg.forager;
     p.limit = ctx->cfg.accepted_count_limit > 0 ? ctx->cfg.accepted_count_limit : 1;
     // FirstLastStepScoreImprovingForager: accepted_count_limit is an Option (improving.rs:128-137); <= 0 = None
@@ -892,6 +895,7 @@ static int launch_list_wave(sf_ctx* ctx, const SearchParams& p, int grid, bool t
 }
 static int launch_list_search(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
     if (use_wave_engine(ctx)) return launch_list_wave(ctx, p, grid, trace);
+    if (p.acceptor == SF_ACCEPT_DIVERSIFIED_LATE_ACCEPTANCE) return fail(ctx, SF_ERR_UNSUPPORTED, "DiversifiedLateAcceptance: wave, scalar and generic engines only");
     if (ctx->levels <= 2) return launch_list_search_t<2>(ctx, p, grid, trace);
     return launch_list_search_t<4>(ctx, p, grid, trace);
 }
@@ -1470,16 +1474,25 @@ int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg) {
     if (ctx->search_alloc && cfg->late_acceptance_size > ctx->sp.la_size)
         return fail(ctx, SF_ERR_INVALID, "late_acceptance_size cannot grow after the search state exists");
     if (cfg->acceptor != SF_ACCEPT_HILL_CLIMBING && cfg->acceptor != SF_ACCEPT_LATE_ACCEPTANCE &&
-        cfg->acceptor != SF_ACCEPT_SIMULATED_ANNEALING)
+        cfg->acceptor != SF_ACCEPT_SIMULATED_ANNEALING && cfg->acceptor != SF_ACCEPT_DIVERSIFIED_LATE_ACCEPTANCE)
         return fail(ctx, SF_ERR_UNSUPPORTED, "acceptor kind");
     if (cfg->forager < SF_FORAGER_ACCEPTED_COUNT || cfg->forager > SF_FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING)
         return fail(ctx, SF_ERR_UNSUPPORTED, "forager");
     if (cfg->forager == SF_FORAGER_ACCEPTED_COUNT && cfg->accepted_count_limit <= 0)
         return fail(ctx, SF_ERR_INVALID, "AcceptedCountForager: accepted_count_limit must be > 0");
-    if (cfg->acceptor == SF_ACCEPT_LATE_ACCEPTANCE && cfg->late_acceptance_size <= 0)
-        return fail(ctx, SF_ERR_INVALID, "late_acceptance_size must be > 0");
+    if ((cfg->acceptor == SF_ACCEPT_LATE_ACCEPTANCE || cfg->acceptor == SF_ACCEPT_DIVERSIFIED_LATE_ACCEPTANCE) && cfg->late_acceptance_size <= 0)
+        return fail(ctx, SF_ERR_INVALID, "late_acceptance_size must be > 0");  // both acceptors assert it (late_acceptance.rs:71, diversified_late_acceptance.rs:87-90)
     ctx->cfg = *cfg;
     if (ctx->search_alloc) ctx->sp.la_size = cfg->late_acceptance_size > 0 ? cfg->late_acceptance_size : 1;
+    return SF_OK;
+}
+
+// DiversifiedLateAcceptanceAcceptor::new(late_acceptance_size, tolerance) (diversified_late_acceptance.rs:86-98); the history
+// size is sf_solver_config::late_acceptance_size
+int32_t sf_solver_configure_diversified(sf_ctx* ctx, double tolerance) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (!std::isfinite(tolerance)) return fail(ctx, SF_ERR_INVALID, "diversified late acceptance: tolerance must be finite");
+    ctx->dla_tolerance = tolerance;
     return SF_OK;
 }
 
@@ -1667,7 +1680,6 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             for (auto& s : ctx->selectors)
                 if (s.kind == kind) ordered.push_back(&s);
     }
-    {
         for (const SelectorSpec* sp : ordered) {
             const SelectorSpec& s = *sp;
             const int kind = s.kind;

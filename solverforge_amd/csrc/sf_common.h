@@ -227,4 +227,24 @@ SF_HD int score_cmp(const ScoreV<L>& a, const ScoreV<L>& b) {  // hard_soft.rs:1
     return 0;
 }
 
+// DiversifiedLateAcceptance threshold (phase/localsearch/acceptor/diversified_late_acceptance.rs:139-146):
+// best - |best|.multiply(tolerance), every level `(x as f64 * t).round() as i64` (score/macros.rs:61-71: round half away
+// from zero, the cast saturates and maps NaN to 0).
+SF_HD int64_t f64_as_i64(double x) {
+    if (x != x) return 0;
+    if (x >= 9223372036854775808.0) return INT64_MAX;
+    if (x <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)x;
+}
+template <int L>
+SF_HD ScoreV<L> dla_threshold(const ScoreV<L>& best, double tolerance) {
+    ScoreV<L> t;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+        const int64_t a = best.v[i] < 0 ? wsub(0, best.v[i]) : best.v[i];
+        t.v[i] = wsub(best.v[i], f64_as_i64(__builtin_round((double)a * tolerance)));
+    }
+    return t;
+}
+
 }  // namespace sf

@@ -1025,6 +1025,7 @@ __global__ __launch_bounds__(256) void k_list_phase_start(ListModel m, SearchPar
     for (int k = threadIdx.x; k < 4; k += blockDim.x) {
         p.last_step_score[(size_t)r * 4 + k] = cur[k];
         m.best_score[(size_t)r * 4 + k] = cur[k];
+        if (p.dla_best) p.dla_best[(size_t)r * 4 + k] = cur[k];  // DiversifiedLateAcceptance::phase_started
     }
     for (int h = threadIdx.x; h < p.la_size * 4; h += blockDim.x)
         p.la_hist[(size_t)r * p.la_size * 4 + h] = cur[h & 3];

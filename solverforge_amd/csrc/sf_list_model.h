@@ -60,7 +60,7 @@ struct LeafSpec {
 struct SearchParams {
     int32_t n_leaves;
     LeafSpec leaf[MAX_LEAVES];
-    int32_t acceptor;     // 0 HC, 1 LA, 2 never (dry run), 3 simulated annealing (state in `sa`)
+    int32_t acceptor;     // 0 HC, 1 LA, 2 never (dry run), 3 simulated annealing (state in `sa`), 4 diversified late acceptance
     int32_t la_size;
     int32_t forager;      // sf_forager_kind: 0 accepted count, 1 first accepted, 2 best score, 3 / 4 improving (sf_forager.h)
     int32_t limit;        // accepted-count limit (forager 4: 0 = none)
@@ -95,6 +95,8 @@ struct SearchParams {
     int64_t* trace_count;      // [1]
     int32_t* trace_applied;    // [1 + 6]
     SaParams sa;               // acceptor 3
+    double dla_tolerance;      // acceptor 4: DiversifiedLateAcceptanceAcceptor::tolerance
+    int64_t* dla_best;         // [R][4] acceptor 4: best step score of this phase
 };
 
 }  // namespace sf

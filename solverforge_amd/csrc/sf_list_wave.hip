@@ -694,9 +694,16 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
         const int la_slot = la_cursor;  // LateAcceptance history slot of this step
-        if (acceptor == 1) {
+        if (acceptor == 1 || acceptor == 4) {
 #pragma unroll
             for (int k = 0; k < L; ++k) late.v[k] = (int64_t)uni64((uint64_t)p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k]);
+        }
+        ScoreV<L> dla_thr = late;  // DiversifiedLateAcceptance: best step score of the phase minus its tolerance band
+        if (acceptor == 4) {
+            ScoreV<L> db;
+#pragma unroll
+            for (int k = 0; k < L; ++k) db.v[k] = (int64_t)uni64((uint64_t)p.dla_best[(size_t)r * 4 + k]);
+            dla_thr = dla_threshold<L>(db, p.dla_tolerance);
         }
         int has_best = 0;
         uint64_t equal_count = 0;
@@ -1122,6 +1129,8 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                             acc = score_cmp<L>(sc, curv) > 0;
                         else if (acceptor == 1)
                             acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
+                        else if (acceptor == 4)
+                            acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0 || score_cmp<L>(sc, dla_thr) >= 0;
                     }
                     SaChunk sach;
                     if constexpr (!FAST)
@@ -1287,9 +1296,21 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
             }
             // acceptor.step_ended(last_step_score) always (step.rs:216-221)
-            if (acceptor == 1 && lane == 0) {
+            if ((acceptor == 1 || acceptor == 4) && lane == 0) {
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
+            }
+            if (acceptor == 4 && lane == 0) {  // step_ended: the phase's best step score (diversified_late_acceptance.rs:161-170)
+                ScoreV<L> cs, db;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    cs.v[kk] = cur[kk];
+                    db.v[kk] = p.dla_best[(size_t)r * 4 + kk];
+                }
+                if (score_cmp<L>(cs, db) > 0) {
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) p.dla_best[(size_t)r * 4 + kk] = cur[kk];
+                }
             }
             if constexpr (!FAST)
                 if (annealing) sa_step_ended(saw, p.sa, lane);

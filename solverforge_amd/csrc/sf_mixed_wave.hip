@@ -353,9 +353,16 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
         const int la_slot = la_cursor;  // LateAcceptance history slot of this step
-        if (p.acceptor == 1) {
+        if (p.acceptor == 1 || p.acceptor == 4) {
 #pragma unroll
             for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
+        }
+        ScoreV<L> dla_thr = late;  // DiversifiedLateAcceptance: best step score of the phase minus its tolerance band
+        if (p.acceptor == 4) {
+            ScoreV<L> db;
+#pragma unroll
+            for (int k = 0; k < L; ++k) db.v[k] = (int64_t)uni64((uint64_t)p.dla_best[(size_t)r * 4 + k]);
+            dla_thr = dla_threshold<L>(db, p.dla_tolerance);
         }
         int has_best = 0;
         uint64_t equal_count = 0;
@@ -1356,6 +1363,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         acc = score_cmp<L>(sc, curv) > 0;
                     else if (p.acceptor == 1)
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
+                    else if (p.acceptor == 4)
+                        acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0 || score_cmp<L>(sc, dla_thr) >= 0;
                 }
                 SaChunk sach;
                 if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
@@ -1599,9 +1608,21 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
             }
-            if (p.acceptor == 1 && lane == 0) {
+            if ((p.acceptor == 1 || p.acceptor == 4) && lane == 0) {
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
+            }
+            if (p.acceptor == 4 && lane == 0) {  // step_ended: the phase's best step score (diversified_late_acceptance.rs:161-170)
+                ScoreV<L> cs, db;
+#pragma unroll
+                for (int kk = 0; kk < L; ++kk) {
+                    cs.v[kk] = cur[kk];
+                    db.v[kk] = p.dla_best[(size_t)r * 4 + kk];
+                }
+                if (score_cmp<L>(cs, db) > 0) {
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) p.dla_best[(size_t)r * 4 + kk] = cur[kk];
+                }
             }
             if (annealing) sa_step_ended(saw, p.sa, lane);
             wave_sync();

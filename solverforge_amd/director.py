@@ -28,6 +28,7 @@ class SelectionOrder:  # solverforge_config::SelectionOrder
 class Acceptor:
     HILL_CLIMBING, LATE_ACCEPTANCE = 0, 1
     SIMULATED_ANNEALING = 3  # default of scalar-only models (default_local_search/policy.rs:56-61)
+    DIVERSIFIED_LATE_ACCEPTANCE = 4  # default of grouped scalar-only models (default_local_search/policy.rs:52-55)
 
 
 class AnnealingMode:
@@ -331,6 +332,11 @@ class GpuScoreDirector:
         s = AnnealingConfigStruct(mode, int(never_accept_hard_regression), calibration_sample_size, 0, t, decay_rate,
                                   hill_climbing_temperature, target_acceptance_probability, fallback_temperature, seed)
         check(self._L.sf_solver_configure_annealing(self._h, C.byref(s)), self._h)
+
+    def configure_diversified(self, tolerance=0.01):
+        """Tolerance of AcceptorKind.DIVERSIFIED_LATE_ACCEPTANCE (DiversifiedLateAcceptanceAcceptor::new); the history size
+        is SolverConfig.late_acceptance_size."""
+        check(self._L.sf_solver_configure_diversified(self._h, float(tolerance)), self._h)
 
     def annealing_state(self, replica=0):
         """(current temperatures per score level, still calibrating?) of one replica's acceptor."""
