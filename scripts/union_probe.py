@@ -9,7 +9,8 @@ R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ls = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 leaves = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("nearby_change", "nearby_swap", "list_reverse")
-p = datasets.make_cvrp(1000, 100, 55, seed=0)
+N = int(sys.argv[5]) if len(sys.argv) > 5 else 1000
+p = datasets.make_cvrp(N, N // 10, 55, seed=0)
 d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves)
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
@@ -30,6 +31,6 @@ while done < K * ls and time.perf_counter() - t1 < 20: o.steps(20); done += 20
 ct = time.perf_counter() - t1
 cm = o.stats()["moves_evaluated"] - m0
 match = bool((d.calculate_score()[0] == o.score()[:2]).all()) if done == K * ls else None
-print(json.dumps({"workload": "CVRP-1000 union " + "+".join(leaves), "replicas": R, "gpu_moves_per_s": moves / dt,
+print(json.dumps({"workload": f"CVRP-{N} union " + "+".join(leaves), "replicas": R, "gpu_moves_per_s": moves / dt,
                   "kernel_ms_per_launch": ms / n, "cpu_oracle_moves_per_s": cm / ct, "replica0_matches_oracle": match,
                   "gpu_over_cpu": (moves / dt) / (cm / ct), "best": list(max(tuple(int(v) for v in s) for s in d.best_scores()))}))

@@ -109,6 +109,8 @@ struct sf_ctx {
     int64_t* d_each = nullptr;           // [R][SF_EACH_WORDS] evaluate_each aggregates
     uint64_t* d_kopt_scratch = nullptr;  // [R][n_cap] distance keys of long routes (distance-pruned 3-opt leaf)
     uint64_t* d_ruin_rng = nullptr;      // [R][4] per-solve SmallRng state of the list ruin leaf
+    uint32_t* d_mixed_ring = nullptr;    // [R][GL][GRC][2] candidate rings of the generic engine (+ [R][GL][GRC] side bytes)
+    uint8_t* d_mixed_ringx = nullptr;
     int union_order = -1;                // sf_union_configure: -1 = the default policy's root union
     std::vector<int32_t> union_weights;  // per leaf in union order; empty = equal
     int64_t* d_scores_out = nullptr;
@@ -1637,15 +1639,22 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
                   gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
                   PREC && gl.prec_lds ? gl.prec.n : 0);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
+    // FAST instantiation: the reference's default list policy on a list-only model (see k_mixed_search_wave)
+    static const bool no_fast = std::getenv("SF_AMD_MIXED_NO_FAST") != nullptr;  // diagnostics / parity tests: force the general instantiation
+    const bool fast = !no_fast && !trace && !PREC && sizeof(VT) == 2 && ctx->has_list_model && !ctx->has_scalar_model && p.acceptor == SF_ACCEPT_LATE_ACCEPTANCE &&
+                      p.forager == SF_FORAGER_ACCEPTED_COUNT && !p.dry_run && !gl.union_custom && gl.union_order == SF_UNION_STRATIFIED_RANDOM && gl.n > 1 &&
+                      (ctx->lm.mat_symmetric || ctx->lm.dist_level < 0) && !p.legacy_eval && !p.explicit_seeds;
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
-    // allocated as a whole; the kernel is built for 2 workgroups of 4 waves per CU); ties go to the larger group
+    // allocated as a whole; the kernel is built for SF_MIXED_BLOCKS_PER_CU workgroups of 4 waves per CU, the FAST
+    // instantiation for SF_MIXED_FAST_BLOCKS_PER_CU); ties go to the larger group
+    const size_t max_waves = 4 * (size_t)(fast ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU);  // by register budget
     int wpb = 1;
     size_t best_resident = 0;
     for (int w = 1; w <= 4; ++w) {
         const size_t per_wg = cv.total * w + 1024;  // + the static annealing state
         if (per_wg > 160 * 1024) break;
         size_t groups = (160 * 1024) / per_wg;
-        if (groups * w > 8) groups = 8 / w;  // 2 waves per SIMD by register budget
+        if (groups * w > max_waves) groups = max_waves / w;
         if (groups * w >= best_resident) {
             best_resident = groups * w;
             wpb = w;
@@ -1653,7 +1662,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     }
     SearchParams q = p;
     q.n_launch = n_replicas;
-    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb, &gl))));
+    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : 0, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb, &gl))));
     return SF_OK;
 }
 static bool has_plain_list_leaves(sf_ctx* ctx) {
@@ -1718,6 +1727,13 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             gl.kind[gl.n++] = kind;
         }
     if (gl.n == 0) return fail(ctx, SF_ERR_INVALID, "no selector configured");
+    if (!ctx->d_mixed_ring) {
+        int rc = dalloc(ctx, &ctx->d_mixed_ring, (size_t)ctx->R * GL * GRC * 2);
+        if (!rc) rc = dalloc(ctx, &ctx->d_mixed_ringx, (size_t)ctx->R * GL * GRC);
+        if (rc) return rc;
+    }
+    gl.ring = ctx->d_mixed_ring;
+    gl.ringx = ctx->d_mixed_ringx;
     gl.union_order = ctx->union_order >= 0 ? ctx->union_order : (gl.n > 1 ? SF_UNION_STRATIFIED_RANDOM : SF_UNION_SEQUENTIAL);
     gl.union_custom = union_is_custom(ctx) && gl.n > 1 ? 1 : 0;
     for (int l = 0; l < GL; ++l) gl.weight[l] = 1;

@@ -33,13 +33,14 @@ hipError_t launch_tu_list_wave(bool trace, int mode, const SearchLaunch& a);
 // scalar engine: k_scalar_search_wave<L, TRACE, VT>, VT = int8_t (VTB 1) or int16_t (VTB 2)
 template <int L, int VTB>
 hipError_t launch_tu_scalar(bool trace, const SearchLaunch& a);
-// generic N-leaf engine: k_mixed_search_wave<L, TRACE, VT, RUIN, PREC>
+// generic N-leaf engine: k_mixed_search_wave<L, TRACE, VT, RUIN, PREC, MODE> (mode 1 = the FAST instantiation of the default
+// list policy: VTB 2, no precedence constraint, never traced)
 template <int L, int VTB, bool RUIN, bool PREC>
-hipError_t launch_tu_mixed(bool trace, const SearchLaunch& a);
+hipError_t launch_tu_mixed(bool trace, int mode, const SearchLaunch& a);
 
 #define SF_TU_DECL_MIXED(L, VTB, RUIN, PREC) \
     template <>                              \
-    hipError_t launch_tu_mixed<L, VTB, RUIN, PREC>(bool trace, const SearchLaunch& a);
+    hipError_t launch_tu_mixed<L, VTB, RUIN, PREC>(bool trace, int mode, const SearchLaunch& a);
 SF_TU_DECL_MIXED(2, 1, false, false)
 SF_TU_DECL_MIXED(4, 1, false, false)
 SF_TU_DECL_MIXED(2, 2, false, false)

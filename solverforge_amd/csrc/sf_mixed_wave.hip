@@ -31,6 +31,9 @@ namespace sf {
 
 constexpr int GL = 8;          // max leaves of the generic union
 constexpr uint32_t GRC = 128;  // ring capacity per leaf
+#ifndef SF_MIXED_RING_LDS
+#define SF_MIXED_RING_LDS 0  // diagnostics: 1 keeps the candidate rings in the replica's LDS slice (the round-2 layout)
+#endif
 constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 128;  // == RuinLds::bytes (sf_ruin.h)
 
 constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
@@ -69,6 +72,10 @@ struct GLeaves {
     int32_t weight[GL];
     int32_t has_ruin;        // the union has a list ruin leaf (kind 1024); parameters + per-solve stream in `ruin`
     RuinParams ruin;
+    // candidate rings [R][GL][GRC] of (m0, m1) + one side byte, in HBM (L2-resident): written by the generators with coalesced
+    // stores, read once per replay round -- the replica's LDS slice keeps only what is touched with dependent latency
+    uint32_t* ring;
+    uint8_t* ringx;
     PrecModel prec;          // ListPrecedenceMakespanConstraint of the list class (prec.on; PREC instantiations, sf_precedence.h)
     int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
 };
@@ -84,10 +91,10 @@ struct GCarve {
     __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0,
                                int prec_words = 0) {
         size_t o = 0;
-        ring = o;
-        o = align_up(o + sizeof(uint32_t) * 2 * GRC * n_leaves, 16);
+        ring = o;  // the candidate rings live in HBM (GLeaves::ring / ringx) unless SF_MIXED_RING_LDS
+        o = align_up(o + (SF_MIXED_RING_LDS ? sizeof(uint32_t) * 2 * GRC * n_leaves : 0), 16);
         ringx = o;  // one extra byte per ring entry (segment size of the sublist leaves)
-        o = align_up(o + GRC * n_leaves, 16);
+        o = align_up(o + (SF_MIXED_RING_LDS ? GRC * n_leaves : 0), 16);
         node = o;
         o = align_up(o + sizeof(uint32_t) * dim_nearby, 16);
         slotbase = o;
@@ -158,6 +165,14 @@ struct LeafTab {
     }
 };
 
+// The generators' ring stores (HBM, through the CU's write-through L1) are visible to every lane's loads of the replay:
+// workgroup scope = wait for the stores, no cache maintenance (one CU, one L1).
+__device__ __forceinline__ void ring_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Lays consecutive groups onto the 64 lanes: lane k holds the size `cnt` of group k (groups in stream order); slot q = lane
 // belongs to the last group whose exclusive prefix is <= q.  Returns that group and the offset inside it; `total` = all
 // slots of the 64 groups (slots >= min(64, total) are not valid).  One DPP scan + a 6-step shuffle search: a generator
@@ -189,9 +204,28 @@ namespace sf {
 // RUIN = the union has a list ruin leaf: its own instantiation, so unions without one keep their register allocation
 // PREC = the list class carries a ListPrecedenceMakespanConstraint: every doable list candidate of a chunk is applied to the LDS
 // lists in turn, scored by one full wave-wide evaluation (prec_eval) and undone from the committed copy in HBM
-template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false>
-__global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p,
-                                                          int has_list, int has_scalar, NbrIndex nb) {
+// MODE 1 (FAST): compile-time specialisation for the reference's default LIST policy -- a list-only model, the default root
+// union (StratifiedRandom, equal weights), LateAcceptance + AcceptedCount, committed untraced steps with generated step seeds,
+// the unified trial delta (symmetric matrix).  The scalar leaves, the other acceptors / foragers / union orders, the dry run and
+// the trace compile out: fewer wave-uniform values stay live across the step loop (the general instantiation spills ~900 SGPRs),
+// so the kernel fits more waves per SIMD (SF_MIXED_FAST_BLOCKS_PER_CU).  Same decisions bit for bit.
+// diagnostics (register-pressure bisection): -DSF_DBG_KINDS=<mask> compiles the generators of the masked leaf kinds out
+#ifdef SF_DBG_KINDS
+#define DBGK(k) (((SF_DBG_KINDS) & (k)) == 0)
+#else
+#define DBGK(k) true
+#endif
+#ifndef SF_MIXED_FAST_BLOCKS_PER_CU
+#define SF_MIXED_FAST_BLOCKS_PER_CU 3
+#endif
+template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false, int MODE = 0>
+__global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(
+    ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p, int has_list_arg, int has_scalar_arg, NbrIndex nb) {
+    constexpr bool FAST = MODE == 1;
+    static_assert(!FAST || (!TRACE && !PREC), "FAST: untraced, no precedence constraint");
+    const int has_list = FAST ? 1 : has_list_arg, has_scalar = FAST ? 0 : has_scalar_arg;
+    const int acceptor = FAST ? 1 : p.acceptor, forager = FAST ? 0 : p.forager, dry_run = FAST ? 0 : p.dry_run;
+    const int union_custom = FAST ? 0 : gl.union_custom;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -199,17 +233,17 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
     const int r = rr + p.replica_base;
     __shared__ uint64_t s_sa[4][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
     uint64_t* saw = s_sa[threadIdx.x >> 6];
-    const bool annealing = p.acceptor == 3;
+    const bool annealing = acceptor == 3;
     if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
-    const bool unified_eval = has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval;
+    const bool unified_eval = FAST || (has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval);
     const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim,
                         PREC && gl.prec_lds ? gl.prec.n : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
-    uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][GRC][2]
-    uint8_t* ringx = (uint8_t*)(mem + cv.ringx);  // [leaf][GRC]
+    uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
+    uint8_t* ringx = SF_MIXED_RING_LDS ? (uint8_t*)(mem + cv.ringx) : gl.ringx + (size_t)r * GL * GRC;   // [leaf][GRC]
     int64_t* s_load = (int64_t*)(mem + cv.load);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
@@ -320,9 +354,9 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         st_steps = st_gen = st_acc = st_applied = st_calc = st_scored = st_sources = 0;
     };
     uint64_t trace_n = 0;
-    const uint64_t step_index0 = p.dry_run ? 0 : p.step_index[r];
-    const uint64_t seed_draws0 = p.dry_run ? 0 : p.seed_draws[r];
-    const int la_idx0 = p.dry_run ? 0 : p.la_idx[r];
+    const uint64_t step_index0 = dry_run ? 0 : p.step_index[r];
+    const uint64_t seed_draws0 = dry_run ? 0 : p.seed_draws[r];
+    const int la_idx0 = dry_run ? 0 : p.la_idx[r];
     int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
     PH_DECL
     bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
@@ -335,13 +369,13 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
         uint64_t sidx, sseed;
-        if (p.dry_run) {
+        if (dry_run) {
             sidx = p.dry_step_index;
             sseed = p.dry_step_seed;
         } else {
             sidx = step_index0 + (uint64_t)step;
             const uint64_t draw = seed_draws0 + (uint64_t)step;
-            if (p.explicit_seeds && (int64_t)draw < p.n_explicit)
+            if (!FAST && p.explicit_seeds && (int64_t)draw < p.n_explicit)
                 sseed = p.explicit_seeds[(size_t)r * p.n_explicit + draw];
             else
                 sseed = step_seed(p.random_seed + (uint64_t)r, draw);
@@ -353,12 +387,12 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
         const int la_slot = la_cursor;  // LateAcceptance history slot of this step
-        if (p.acceptor == 1 || p.acceptor == 4) {
+        if (acceptor == 1 || acceptor == 4) {
 #pragma unroll
             for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
         }
         ScoreV<L> dla_thr = late;  // DiversifiedLateAcceptance: best step score of the phase minus its tolerance band
-        if (p.acceptor == 4) {
+        if (acceptor == 4) {
             ScoreV<L> db;
 #pragma unroll
             for (int k = 0; k < L; ++k) db.v[k] = (int64_t)uni64((uint64_t)p.dla_best[(size_t)r * 4 + k]);
@@ -478,7 +512,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             wave_sync();
         }
         if (RUIN) {  // list ruin leaf: open the cursor (one draw of the per-solve stream), count the source pool
-            const uint32_t pool = ruin_open_cursor(gl.ruin, rl, ctx, s_off, V, !p.dry_run, lane);
+            const uint32_t pool = ruin_open_cursor(gl.ruin, rl, ctx, s_off, V, !dry_run, lane);
             for (int l = 0; l < nl; ++l)
                 if (lt.geti(l, LeafTab::KIND) == 1024) lt.put_gen(l, GGen{0, 0, 0, 0, pool, 0, pool == 0 || gl.ruin.moves_per_step <= 0});
         }
@@ -487,8 +521,8 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         const uint32_t u_str = nl > 1 ? ctx.random_stride((uint32_t)nl, SALT_UNION_STRIDE) : 1u;
         int32_t live_weight = nl;  // total weight of the live children (running weights of the smooth weighted round-robin: leaf table)
         uint32_t u_cur = 0, u_draw = 0;  // RoundRobin cursor / Random draw counter of this step's cursor
-        const int u_ord = nl > 1 ? gl.union_order : 0;
-        if (gl.union_custom) {  // weighted children: a zero weight is an exhausted child from the start (vec_union.rs:214-218)
+        const int u_ord = nl > 1 ? (FAST ? 4 : gl.union_order) : 0;
+        if (union_custom) {  // weighted children: a zero weight is an exhausted child from the start (vec_union.rs:214-218)
             live_weight = 0;
 #pragma unroll
             for (int l = 0; l < GL; ++l) {
@@ -588,7 +622,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             g.a += 1;
                             if (g.a >= ns) g.done = 1;
                         }
-                    } else if (kind == 4) {  // ---- list change (list_kernel/change.rs:142-241) ----
+                    } else if (DBGK(4) && kind == 4) {  // ---- list change (list_kernel/change.rs:142-241) ----
                         // advance to a source with a non-empty list
                         uint32_t se = 0, slen = 0;
                         for (;;) {
@@ -649,7 +683,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 g.e = 0;
                             }
                         }
-                    } else if (kind == 256) {  // ---- sublist swap (list_kernel/sublist_swap.rs:57-101,228-300) ----
+                    } else if (DBGK(256) && kind == 256) {  // ---- sublist swap (list_kernel/sublist_swap.rs:57-101,228-300) ----
                         const uint32_t mn = leaf_min, mx = leaf_max;
                         uint32_t fent = 0, flen = 0, fstart = 0, sc1 = 0;
                         for (;;) {  // the current first segment
@@ -734,7 +768,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 g.e = lo_ + 1;
                             }
                         }
-                    } else if (kind == 128) {  // ---- sublist change / Or-opt (list_kernel/sublist_change.rs:109-266) ----
+                    } else if (DBGK(128) && kind == 128) {  // ---- sublist change / Or-opt (list_kernel/sublist_change.rs:109-266) ----
                         const uint32_t mn = leaf_min, mx = leaf_max;
                         uint32_t ent = 0, len = 0, start = 0, sc = 0;
                         for (;;) {  // current segment start with at least one legal size
@@ -831,7 +865,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                             st_sources -= 1;
                             continue;
                         }
-                    } else if (kind == 16 || kind == 32) {  // ---- nearby list change / swap: one source per call ----
+                    } else if (DBGK(16) && (kind == 16 || kind == 32)) {  // ---- nearby list change / swap: one source per call ----
                         if (g.e == 0) {
                             g.done = 1;
                             break;
@@ -869,7 +903,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         g.b += 1;
                         g.e -= 1;
                         if (g.e == 0) g.done = 1;
-                    } else if (kind == 512 && leaf_max_nearby == 0) {  // ---- 3-opt, full enumeration (k_opt/full.rs:62-92) ----
+                    } else if (DBGK(1) && kind == 512 && leaf_max_nearby == 0) {  // ---- 3-opt, full enumeration (k_opt/full.rs:62-92) ----
                         const uint32_t mseg = leaf_min;
                         uint32_t ent = 0, len = 0;
                         uint64_t mc = 0, mo = 0;
@@ -901,7 +935,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         mo += 64;
                         g.b = (uint32_t)mo;
                         g.c = (uint32_t)(mo >> 32);
-                    } else if (kind == 512) {  // ---- 3-opt, distance-pruned (k_opt/nearby.rs:106-148, nearby_state.rs) ----
+                    } else if (DBGK(512) && kind == 512) {  // ---- 3-opt, distance-pruned (k_opt/nearby.rs:106-148, nearby_state.rs) ----
                         const KoptLds km(mem + cv.kopt);
                         const KoptEnv env{&lm,   s_visits, s_off, km, gl.kopt_scratch + (size_t)r * lm.n_cap, ctx, ldesc,
                                           leaf_min, leaf_max_nearby, lane};
@@ -967,7 +1001,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         w0 = g.a;
                         g.a += 1;
                         if (g.a >= (uint32_t)gl.ruin.moves_per_step) g.done = 1;
-                    } else if (kind == 64) {  // ---- list reverse / 2-opt (list_kernel/reverse.rs:68-108) ----
+                    } else if (DBGK(64) && kind == 64) {  // ---- list reverse / 2-opt (list_kernel/reverse.rs:68-108) ----
                         uint32_t ent = 0, len = 0;
                         for (;;) {  // entities shorter than two elements are skipped
                             if (g.a >= (uint32_t)V) break;
@@ -1017,7 +1051,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                                 g.e = lo_ + 1;
                             }
                         }
-                    } else {  // ---- list swap (list_kernel/swap.rs) ----
+                    } else if (DBGK(8)) {  // ---- list swap (list_kernel/swap.rs) ----
                         uint32_t fe = 0, flen = 0;
                         for (;;) {  // entities with an empty list are skipped
                             if (g.a >= (uint32_t)V) break;
@@ -1112,7 +1146,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 PH((kind == 128 || kind == 256) ? 2 : ((kind == 64 || kind == 1024) ? 3 : (kind == 512 ? 4 : 1)))
 #endif
             }
-            wave_sync();
+            ring_sync();
 
             // ---- C2: lay the next 64 pulls of the union scheduler onto the lanes ----
             uint32_t my_leaf = 0, my_idx = 0;
@@ -1125,7 +1159,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 // live children in rotated order whenever all their running weights are equal (true at the
                 // start of every step and after every whole cycle).  Lay out whole cycles directly; the
                 // pull-by-pull simulation below handles partial cycles, exhaustion and refills.
-                if (nl > 1 && nlive > 1 && !gl.union_custom) {
+                if (nl > 1 && nlive > 1 && !union_custom) {
                     // One cycle of the smooth weighted round-robin with equal weights pulls every live child once, in
                     // descending running weight (ties: rotated order), and leaves the weights as it found them -- provided
                     // max - min < live children (true with equal weights at the start of a step, and again a few pulls
@@ -1195,7 +1229,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                     for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos)
                         if (((u_order >> (4u * pos)) & 15u) == lane) mypos = pos;
                     int32_t wgt = 1;  // child weight (UnionWeighting); lane l = leaf l
-                    if (gl.union_custom) {
+                    if (union_custom) {
                         wgt = 0;
 #pragma unroll
                         for (int l = 0; l < GL; ++l)
@@ -1359,11 +1393,11 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 }
                 bool acc = false;
                 if (doable) {
-                    if (p.acceptor == 0)
+                    if (acceptor == 0)
                         acc = score_cmp<L>(sc, curv) > 0;
-                    else if (p.acceptor == 1)
+                    else if (acceptor == 1)
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
-                    else if (p.acceptor == 4)
+                    else if (acceptor == 4)
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0 || score_cmp<L>(sc, dla_thr) >= 0;
                 }
                 SaChunk sach;
@@ -1371,11 +1405,11 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 uint64_t accmask = __ballot(acc);
                 bool improving_pick = false;
                 ScoreV<L> forager_thr = curv;  // FirstLastStepScoreImproving: the last step score
-                if (p.forager == FORAGER_FIRST_BEST_IMPROVING) {  // the best score ever seen (step.rs:53-58)
+                if (forager == FORAGER_FIRST_BEST_IMPROVING) {  // the best score ever seen (step.rs:53-58)
 #pragma unroll
                     for (int kk = 0; kk < L; ++kk) forager_thr.v[kk] = best_sol[kk];
                 }
-                const uint32_t nconsumed = forager_chunk_cut<L>(p.forager, (uint32_t)p.limit, accepted, acc, sc, forager_thr, nvalid, improving_pick);
+                const uint32_t nconsumed = forager_chunk_cut<L>(forager, (uint32_t)p.limit, accepted, acc, sc, forager_thr, nvalid, improving_pick);
                 const bool consumed = lane < nconsumed;
                 if (annealing) sa_commit<L>(saw, p.sa, sach, nconsumed, lane);
                 acc = acc && consumed;
@@ -1392,7 +1426,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                         if (TRACE) best_ti = trace_n + (uint64_t)sel;
                         equal_count = 1;
                         has_best = 1;
-                    } else if (p.forager == 1) {
+                    } else if (forager == 1) {
                         if (!has_best) {
                             const int sel = __ffsll((unsigned long long)accmask) - 1;
 #pragma unroll
@@ -1472,7 +1506,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
                 if (tracing) trace_n += nconsumed;
                 // every laid-out pull is consumed unless the forager cut the step (which ends it)
                 for (int l = 0; l < nl; ++l) lt.set(l, LeafTab::HEAD, lt.get(l, LeafTab::HEAD) + lt.get(l, LeafTab::TAKEN));
-                if (forager_quits(p.forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) done = 1;
+                if (forager_quits(forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) done = 1;
             }
             PH(6)
         }
@@ -1486,7 +1520,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             }
             for (uint32_t t = lane; t < ns; t += 64) sm.best_vals[(size_t)r * ns + t] = (int32_t)s_vals[t];
         };
-        const bool applied = has_best && !p.dry_run;
+        const bool applied = has_best && !dry_run;
         if (applied) {
             if (best_pending) {
                 ScoreV<L> bs;
@@ -1592,7 +1626,7 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
         } else if (tracing && lane == 0) {
             p.trace_applied[0] = 0;
         }
-        if (!p.dry_run) {
+        if (!dry_run) {
             bool improved = false;
             if (applied) {
                 ScoreV<L> cs, bs;
@@ -1608,11 +1642,11 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) best_sol[kk] = cur[kk];
             }
-            if ((p.acceptor == 1 || p.acceptor == 4) && lane == 0) {
+            if ((acceptor == 1 || acceptor == 4) && lane == 0) {
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + kk] = cur[kk];
             }
-            if (p.acceptor == 4 && lane == 0) {  // step_ended: the phase's best step score (diversified_late_acceptance.rs:161-170)
+            if (acceptor == 4 && lane == 0) {  // step_ended: the phase's best step score (diversified_late_acceptance.rs:161-170)
                 ScoreV<L> cs, db;
 #pragma unroll
                 for (int kk = 0; kk < L; ++kk) {
@@ -1630,12 +1664,12 @@ __global__ __launch_bounds__(256, SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wa
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
         }
         PH(7)
-        if (!p.dry_run && p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
-        if (!p.dry_run && p.move_budget == 0 && st_scored >= 0x70000000u) flush_stats();
+        if (!dry_run && p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
+        if (!dry_run && p.move_budget == 0 && st_scored >= 0x70000000u) flush_stats();
     }
     PH_DUMP
 
-    if (!p.dry_run) {
+    if (!dry_run) {
         if (annealing) sa_store(saw, p.sa, r, lane);
         if (RUIN && lane < 4) gl.ruin.rng[(size_t)r * 4 + lane] = rl.prng[lane];
         if (best_pending) {  // the launch ends in a best state: its deferred snapshot

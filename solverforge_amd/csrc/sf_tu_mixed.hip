@@ -14,8 +14,14 @@ struct TuValueType<1> {
 };
 
 template <>
-hipError_t launch_tu_mixed<SF_TU_L, SF_TU_VTB, SF_TU_RUIN != 0, SF_TU_PREC != 0>(bool trace, const SearchLaunch& a) {
+hipError_t launch_tu_mixed<SF_TU_L, SF_TU_VTB, SF_TU_RUIN != 0, SF_TU_PREC != 0>(bool trace, int mode, const SearchLaunch& a) {
     using VT = TuValueType<SF_TU_VTB>::type;
+#if SF_TU_VTB == 2 && SF_TU_PREC == 0
+    if (mode == 1 && !trace)
+        return launch_with_lds(k_mixed_search_wave<SF_TU_L, false, VT, SF_TU_RUIN != 0, false, 1>, a, *a.lm, *a.sm, *a.gl, *a.p, a.has_list,
+                               a.has_scalar, a.nb);
+#endif
+    (void)mode;
     if (trace)
         return launch_with_lds(k_mixed_search_wave<SF_TU_L, true, VT, SF_TU_RUIN != 0, SF_TU_PREC != 0>, a, *a.lm, *a.sm, *a.gl, *a.p, a.has_list,
                                a.has_scalar, a.nb);
