@@ -175,6 +175,8 @@ typedef enum sf_selector_kind {
                                       with an intra-distance meter, policy/list.rs:144-160), 0 = full enumeration
                                       (selector/list_kernel/k_opt/full.rs) */
     SF_SEL_SUBLIST_SWAP = 256,     /* selector/list_kernel/sublist_swap.rs:13-330; sizes via sf_selector_add_sublist */
+    SF_SEL_NEARBY_SCALAR_CHANGE = 2048, /* scalar_neighborhood/cursor/change.rs:123-392 (NearbyChangeCursor); sf_selector_add_nearby_scalar */
+    SF_SEL_NEARBY_SCALAR_SWAP = 4096,   /* scalar_neighborhood/cursor/swap.rs:162-414 (NearbySwapCursor); sf_selector_add_nearby_scalar */
     SF_SEL_LIST_RUIN = 1024        /* selector/list_kernel/ruin.rs:38-144 + move/list_kernel/ruin.rs:131-281 (ruin and greedy recreate);
                                       sf_selector_add_ruin.  Last list leaf of the default policy (policy/list.rs:24-33,193-199) */
 } sf_selector_kind;
@@ -324,6 +326,21 @@ int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t descriptor_in
  * max_nearby = 0 -> full enumeration, 1..64 -> distance-pruned by the list's matrix meter (the default policy passes 20) */
 int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t k,
                              int32_t min_segment_len, int32_t max_nearby);
+
+/* Nearby scalar leaves of a scalar slot (NearbyChangeMoveSelector / NearbySwapMoveSelector; the default policy declares them with
+ * max_nearby 10 between the list rules and the ordinary change / swap pair, default_local_search/policy/scalar.rs:18-65).  The
+ * slot's hooks arrive as data: offsets[n_rows + 1] / candidates = the nearby source row of every entity in SOURCE order --
+ * nearby_value_candidates (values, kind SF_SEL_NEARBY_SCALAR_CHANGE) or nearby_entity_candidates (entity indices,
+ * SF_SEL_NEARBY_SCALAR_SWAP); a slot without the hook passes what the reference falls back to (its ordinary candidate values /
+ * every entity 0..n).  distances = the slot's nearby_value_distance / nearby_entity_distance per row entry, NULL = no meter (the
+ * source order ranks; non-finite = dropped).  source_limit = value_candidate_limit (<= 0: none; change leaf only).  dynamic_slot
+ * != 0: a DynamicScalarVariableSlot (the change leaf re-checks value legality, the swap leaf emits directional pairs right != left
+ * instead of right > left).  Per row: skip the current value (change) / equal values and illegal exchanges (swap), stable top
+ * max_nearby by (distance, source order, candidate), then apply_selection_order; the change leaf ends an assigned row with its
+ * to-None candidate when the variable allows unassigned.  max_nearby 1..63.  The leaves run in the generic N-leaf engine. */
+int32_t sf_selector_add_nearby_scalar(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, int32_t variable_index, int32_t max_nearby,
+                                      int64_t source_limit, const uint32_t* offsets, const int32_t* candidates, const double* distances,
+                                      int32_t dynamic_slot);
 
 /* Root union of the configured leaves (UnionMoveSelectorConfig: UnionSelectionOrder + UnionWeighting; scheduler
  * heuristic/selector/decorator/vec_union.rs:190-365).  selection_order: sf_union_order, -1 = the default policy's choice

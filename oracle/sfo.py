@@ -25,6 +25,7 @@ LEAF_SUBLIST_CHANGE = 128
 LEAF_SUBLIST_SWAP = 256
 LEAF_KOPT = 512
 LEAF_LIST_RUIN = 1024
+LEAF_NEARBY_SCALAR_CHANGE, LEAF_NEARBY_SCALAR_SWAP = 2048, 4096
 KIND_KOPT, KIND_RUIN = 7, 8
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
@@ -87,6 +88,7 @@ def lib():
             "sfo_model_evaluate_each": (i32, [vp, vp, vp, i32]),
             "sfo_model_configure_annealing": (None, [vp, i32, vp, i32, i32, dbl, dbl, i32, i32, dbl, dbl, u64]),
             "sfo_model_configure_diversified": (None, [vp, i32, dbl]),
+            "sfo_model_set_nearby_scalar": (None, [vp, i32, i32, vp, vp, vp, i32, i32, i64]),
             "sfo_model_annealing_state": (None, [vp, vp, vp, vp]),
             "sfo_xoshiro256pp": (None, [vp, i32, vp]),
             "sfo_small_rng_seed": (None, [u64, vp]),
@@ -291,6 +293,17 @@ class Model:
         lib().sfo_model_configure_annealing(self.h, mode, _p(t), levels, hard_levels, decay_rate,
                                             hill_climbing_temperature, int(never_accept_hard), sample_size,
                                             target_probability, fallback_temperature, seed)
+
+    def set_nearby_scalar(self, which, rows, distances=None, dynamic=False, max_nearby=10, source_limit=0):
+        """Nearby sources of the scalar slot: which = 0 value candidates per entity, 1 entity candidates per left entity; rows in
+        source order; distances = the meter's value per row entry (None: the source order ranks)."""
+        off = np.zeros(len(rows) + 1, dtype=np.uint32)
+        for i, r in enumerate(rows):
+            off[i + 1] = off[i] + len(r)
+        cand = np.array([v for r in rows for v in r] or [0], dtype=np.int64)
+        dist = None if distances is None else np.array([v for r in distances for v in r] or [0.0], dtype=np.float64)
+        lib().sfo_model_set_nearby_scalar(self.h, which, len(rows), _p(off), _p(cand), None if dist is None else _p(dist), int(dynamic),
+                                          max_nearby, source_limit)
 
     def configure_diversified(self, la_size=400, tolerance=0.01):
         """Install a DiversifiedLateAcceptanceAcceptor (call after configure())."""

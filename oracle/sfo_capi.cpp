@@ -232,6 +232,39 @@ void sfo_model_configure_annealing(void* h, int32_t mode, const double* temps, i
     sa->rng = SmallRng::seed_from_u64(seed);
     m->search.acceptor = std::move(sa);
 }
+// Nearby scalar sources of the model's scalar slot (scalar_access.rs:261-340) as data: which = 0 nearby VALUE candidates per
+// entity, 1 nearby ENTITY candidates per left entity; rows in source order (CSR), `dist` = the distance meter's value per row
+// entry or NULL (meter None: the source order ranks).  dynamic != 0: a DynamicScalarVariableSlot (legality re-check, directional
+// swaps).  max_nearby / source_limit (0 = none) of the two nearby leaves.
+void sfo_model_set_nearby_scalar(void* h, int32_t which, int32_t n_rows, const uint32_t* off, const int64_t* cand, const double* dist,
+                                 int32_t dynamic, int32_t max_nearby, int64_t source_limit) {
+    Model* m = (Model*)h;
+    ScalarSlot& sl = m->scalar_slot;
+    sl.dynamic = dynamic != 0;
+    m->scalar_max_nearby = (size_t)max_nearby;
+    m->scalar_source_limit = source_limit > 0 ? (size_t)source_limit : SIZE_MAX;
+    std::vector<std::vector<int64_t>> rows((size_t)n_rows);
+    auto table = std::make_shared<std::vector<std::vector<std::pair<int64_t, double>>>>((size_t)n_rows);
+    for (int32_t r = 0; r < n_rows; ++r)
+        for (uint32_t k = off[r]; k < off[r + 1]; ++k) {
+            rows[(size_t)r].push_back(cand[k]);
+            if (dist) (*table)[(size_t)r].push_back({cand[k], dist[k]});
+        }
+    auto meter = [table](size_t row, int64_t c) -> double {
+        for (auto& kv : (*table)[row])
+            if (kv.first == c) return kv.second;
+        return std::nan("");
+    };
+    if (which == 0) {
+        sl.has_nearby_values = true;
+        sl.nearby_values = std::move(rows);
+        if (dist) sl.nearby_value_distance = meter;
+    } else {
+        sl.has_nearby_entities = true;
+        sl.nearby_entities = std::move(rows);
+        if (dist) sl.nearby_entity_distance = [meter](size_t l, size_t r) { return meter(l, (int64_t)r); };
+    }
+}
 // DiversifiedLateAcceptanceAcceptor(late_acceptance_size, tolerance).  Replaces the acceptor sfo_model_configure installed.
 void sfo_model_configure_diversified(void* h, int32_t la_size, double tolerance) {
     ((Model*)h)->search.acceptor = std::make_unique<DiversifiedLateAcceptanceAcceptor>((size_t)la_size, tolerance);

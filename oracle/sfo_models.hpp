@@ -75,6 +75,10 @@ enum LeafBits : uint32_t {
     LEAF_SUBLIST_SWAP = 256,
     LEAF_LIST_RUIN = 1024,  // ListRuinMoveSelectorConfig defaults: 2..=5 elements, 10 moves per step (solverforge-config/src/move_selector.rs:574-587,
                             // list_leaf/spec.rs:245)
+    // nearby scalar leaves (default_local_search/policy/scalar.rs:18-65: max_nearby 10, declared between the list rules and the
+    // ordinary scalar change / swap pair)
+    LEAF_NEARBY_SCALAR_CHANGE = 2048,
+    LEAF_NEARBY_SCALAR_SWAP = 4096,
     LEAF_KOPT = 512,  // k = 3; kopt_max_nearby > 0: distance-pruned (default policy with an intra-distance meter), 0: full
 };
 
@@ -88,6 +92,7 @@ struct Model {
     size_t max_nearby = 20;
     size_t sublist_min = 1, sublist_max = 3;
     size_t kopt_min_seg = 1, kopt_max_nearby = 20;  // KOptMoveSelectorConfig defaults + DEFAULT_LIST_NEARBY_LIMIT (policy/list.rs:19,144-160)
+    size_t scalar_max_nearby = 10, scalar_source_limit = SIZE_MAX;  // NearbyChangeMoveConfig::max_nearby / value_candidate_limit
     UnionOrder union_order = UnionOrder::StratifiedRandom;
     std::vector<uint64_t> union_weights;  // UnionWeighting: one per leaf in union order; empty = equal
     // list ruin leaf: the per-solve stream state (list_leaf/cursor.rs:112-145) is one SmallRng seeded from
@@ -106,6 +111,10 @@ struct Model {
                 return std::make_unique<ScalarChangeCursor>(scalar_slot, d.working, ctx);
             case LEAF_SCALAR_SWAP:
                 return std::make_unique<ScalarSwapCursor>(scalar_slot, d.working, ctx);
+            case LEAF_NEARBY_SCALAR_CHANGE:
+                return std::make_unique<NearbyScalarChangeCursor>(scalar_slot, d.working, ctx, scalar_max_nearby, scalar_source_limit);
+            case LEAF_NEARBY_SCALAR_SWAP:
+                return std::make_unique<NearbyScalarSwapCursor>(scalar_slot, d.working, ctx, scalar_max_nearby);
             case LEAF_LIST_CHANGE:
                 return std::make_unique<ListChangeCursor>(list_slot, d.working, ctx);
             case LEAF_LIST_SWAP:
@@ -138,7 +147,8 @@ struct Model {
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
         static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
                                          LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_SUBLIST_SWAP, LEAF_LIST_REVERSE,
-                                         LEAF_KOPT,               LEAF_LIST_RUIN,          LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
+                                         LEAF_KOPT,               LEAF_LIST_RUIN,          LEAF_NEARBY_SCALAR_CHANGE, LEAF_NEARBY_SCALAR_SWAP,
+                                         LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
         std::vector<std::unique_ptr<Cursor>> children;
         for (uint32_t leaf : order)
             if (leaves & leaf) children.push_back(open_leaf(leaf, d, ctx));

@@ -21,6 +21,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <functional>
 #include <limits>
 #include <memory>
@@ -503,7 +504,48 @@ struct ScalarSlot {
     uint64_t identity() const {  // cursor.rs:371-378
         return ((uint64_t)descriptor_index << 32) ^ (uint64_t)variable_index;
     }
+    // ---- nearby sources (builder/context/scalar_access.rs:261-340): the slot's hooks as data --------------------------------
+    // nearby_value_candidates / nearby_entity_candidates: one row per entity in SOURCE order (absent = the hook is None: the
+    // cursor falls back to the ordinary candidate values with the source limit / to every entity); the distance meters as a
+    // value per row entry (absent = the meter is None: the distance is the source order, change.rs:332-334, swap.rs:385-387).
+    bool dynamic = false;  // DynamicScalarVariableSlot: nearby change re-checks value legality, nearby swap is directional
+    bool has_nearby_values = false, has_nearby_entities = false;
+    std::vector<std::vector<int64_t>> nearby_values, nearby_entities;
+    // distance meters: called with (entity, candidate); NaN = None
+    std::function<double(size_t entity, int64_t value)> nearby_value_distance;
+    std::function<double(size_t left, size_t right)> nearby_entity_distance;
 };
+
+// NearbyTopK (heuristic/selector/nearby_support.rs:20-90): the best `limit` candidates by (distance total order, source order,
+// candidate), non-finite distances dropped, returned in that order.
+struct RankedNearby {
+    int64_t candidate;
+    double distance;
+    size_t order;
+};
+inline int f64_total_cmp(double a, double b) {  // f64::total_cmp on the values that reach here (finite, -0.0 < +0.0)
+    int64_t x, y;
+    std::memcpy(&x, &a, 8);
+    std::memcpy(&y, &b, 8);
+    x ^= (int64_t)((uint64_t)(x >> 63) >> 1);
+    y ^= (int64_t)((uint64_t)(y >> 63) >> 1);
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+inline std::vector<int64_t> nearby_top_k(std::vector<RankedNearby> all, size_t limit) {
+    std::vector<RankedNearby> kept;
+    for (auto& c : all)
+        if (limit != 0 && std::isfinite(c.distance)) kept.push_back(c);
+    std::sort(kept.begin(), kept.end(), [](const RankedNearby& l, const RankedNearby& r) {
+        int c = f64_total_cmp(l.distance, r.distance);
+        if (c != 0) return c < 0;
+        if (l.order != r.order) return l.order < r.order;
+        return l.candidate < r.candidate;
+    });
+    if (kept.size() > limit) kept.resize(limit);
+    std::vector<int64_t> out;
+    for (auto& c : kept) out.push_back(c.candidate);
+    return out;
+}
 
 // Scalar change leaf (scalar_neighborhood/cursor/change.rs:27-121).
 struct ScalarChangeCursor : Cursor {
@@ -628,6 +670,174 @@ struct ScalarSwapCursor : Cursor {
             right_offset = 0;
         }
         return false;
+    }
+};
+
+// Nearby scalar leaves (scalar_neighborhood/cursor/change.rs:123-392, cursor/swap.rs:162-414).  The native (eager) and the
+// dynamic (lazy) source timing read the same cursor-open snapshot, so both yield the stream restated here.
+inline size_t nearby_ordered_entity(size_t n, size_t offset, const MoveStreamContext& ctx, uint64_t start_salt, uint64_t stride_salt,
+                                    uint64_t identity) {  // change.rs:376-391
+    if (n <= 1) return 0;
+    size_t start = ctx.start_offset(n, start_salt ^ identity);
+    size_t stride = ctx.stride(n, stride_salt ^ identity);
+    return (start + offset * stride) % n;
+}
+template <class T>
+inline void apply_selection_order(const MoveStreamContext& ctx, std::vector<T>& values, uint64_t salt) {  // iter.rs:152-161
+    if (ctx.is_canonical()) return;
+    std::vector<T> canonical = values;
+    for (size_t o = 0; o < values.size(); ++o) values[o] = canonical[ctx.selection_index(o, canonical.size(), salt)];
+}
+
+struct NearbyScalarChangeCursor : Cursor {
+    static constexpr uint64_t ENTITY_START_SALT = 0xC4A46E00AAAA0001ULL, ENTITY_STRIDE_SALT = 0xC4A46E00AAAA0002ULL;
+    static constexpr uint64_t VALUE_SALT = 0xC4A46E00AAAA0003ULL;
+    struct Row {
+        size_t entity;
+        std::vector<int64_t> values;
+        bool unassigned_pending;
+    };
+    ScalarSlot slot;
+    std::vector<Row> rows;
+    size_t row_offset = 0, value_offset = 0;
+
+    static bool value_is_legal(const ScalarSlot& slot, const Solution& s, size_t e, int64_t v) {  // variable.rs:207-227
+        std::vector<int64_t> legal;
+        slot.values_for_entity(s, e, legal);
+        return std::find(legal.begin(), legal.end(), v) != legal.end();
+    }
+    // rank_nearby_values (change.rs:312-374)
+    static std::vector<int64_t> rank(const ScalarSlot& slot, const Solution& s, size_t e, size_t max_nearby, size_t source_limit,
+                                     const MoveStreamContext& ctx) {
+        if (max_nearby == 0 || source_limit == 0) return {};
+        const int64_t current = s.classes[slot.descriptor_index].vars[slot.variable_index][e];
+        std::vector<RankedNearby> all;
+        size_t order = 0;
+        auto visit = [&](int64_t value) {
+            size_t source_order = order++;
+            if (current == value || (slot.dynamic && !value_is_legal(slot, s, e, value))) return;
+            double dist = slot.nearby_value_distance ? slot.nearby_value_distance(e, value) : std::nan("");
+            all.push_back(RankedNearby{value, dist != dist ? (double)source_order : dist, source_order});
+        };
+        if (slot.has_nearby_values) {
+            const auto& row = slot.nearby_values[e];
+            for (size_t i = 0; i < row.size() && i < source_limit; ++i) visit(row[i]);
+        } else {  // visit_candidate_values(.., Some(source_limit), ..)
+            std::vector<int64_t> vals;
+            slot.values_for_entity(s, e, vals);
+            for (size_t i = 0; i < vals.size() && i < source_limit; ++i) visit(vals[i]);
+        }
+        std::vector<int64_t> values = nearby_top_k(std::move(all), max_nearby);
+        apply_selection_order(ctx, values, VALUE_SALT ^ (uint64_t)e ^ slot.identity());
+        return values;
+    }
+    NearbyScalarChangeCursor(const ScalarSlot& sl, const Solution& solution_in, const MoveStreamContext& ctx, size_t max_nearby, size_t source_limit)
+        : slot(sl) {
+        Solution solution = solution_in;
+        size_t n = solution.classes[slot.descriptor_index].n;
+        for (size_t off = 0; off < n; ++off) {
+            size_t e = nearby_ordered_entity(n, off, ctx, ENTITY_START_SALT, ENTITY_STRIDE_SALT, slot.identity());
+            Row row;
+            row.entity = e;
+            row.values = rank(slot, solution, e, max_nearby, source_limit, ctx);
+            row.unassigned_pending = slot.allows_unassigned && solution.classes[slot.descriptor_index].vars[slot.variable_index][e] != NONE;
+            rows.push_back(std::move(row));
+        }
+    }
+    bool next(Move& out) override {  // change.rs:186-216
+        for (;;) {
+            if (row_offset >= rows.size()) return false;
+            Row& row = rows[row_offset];
+            out = Move{};
+            out.kind = Move::Change;
+            out.descriptor = slot.descriptor_index;
+            out.variable = slot.variable_index;
+            out.a = row.entity;
+            out.allows_unassigned = slot.allows_unassigned;
+            if (value_offset < row.values.size()) {
+                out.to_value = row.values[value_offset++];
+                return true;
+            }
+            if (row.unassigned_pending) {
+                row.unassigned_pending = false;
+                out.to_value = NONE;
+                return true;
+            }
+            ++row_offset;
+            value_offset = 0;
+        }
+    }
+};
+
+struct NearbyScalarSwapCursor : Cursor {
+    static constexpr uint64_t ENTITY_START_SALT = 0x5A095CA1AAAA0001ULL, ENTITY_STRIDE_SALT = 0x5A095CA1AAAA0002ULL;
+    static constexpr uint64_t TARGET_SALT = 0x5A095CA1AAAA0003ULL;
+    struct Row {
+        size_t left;
+        std::vector<int64_t> rights;
+    };
+    ScalarSlot slot;
+    std::vector<Row> rows;
+    size_t row_offset = 0, right_offset = 0;
+
+    static bool destination_is_legal(const ScalarSlot& slot, const Solution& s, size_t e, int64_t value) {  // swap.rs:103-123
+        if (slot.empty_value_source) return value != NONE;
+        if (value == NONE) return slot.allows_unassigned;
+        return NearbyScalarChangeCursor::value_is_legal(slot, s, e, value);
+    }
+    // rank_nearby_entities (swap.rs:346-398)
+    static std::vector<int64_t> rank(const ScalarSlot& slot, const Solution& s, size_t left, size_t n, size_t max_nearby,
+                                     const MoveStreamContext& ctx) {
+        if (max_nearby == 0) return {};
+        const auto& vals = s.classes[slot.descriptor_index].vars[slot.variable_index];
+        const int64_t left_value = vals[left];
+        std::vector<RankedNearby> all;
+        size_t order = 0;
+        auto visit = [&](size_t right) {
+            size_t source_order = order++;
+            bool allowed = slot.dynamic ? right != left : right > left;  // DynamicDirectional / StaticCanonical
+            if (!allowed || right >= n) return;
+            const int64_t right_value = vals[right];
+            if (left_value == right_value || !destination_is_legal(slot, s, left, right_value) || !destination_is_legal(slot, s, right, left_value))
+                return;
+            double dist = slot.nearby_entity_distance ? slot.nearby_entity_distance(left, right) : std::nan("");
+            all.push_back(RankedNearby{(int64_t)right, dist != dist ? (double)source_order : dist, source_order});
+        };
+        if (slot.has_nearby_entities) {
+            const auto& row = slot.nearby_entities[left];
+            for (size_t i = 0; i < row.size() && i < n; ++i) visit((size_t)row[i]);  // the source is visited with limit = entity_count
+        } else {
+            for (size_t r = 0; r < n; ++r) visit(r);
+        }
+        std::vector<int64_t> ents = nearby_top_k(std::move(all), max_nearby);
+        apply_selection_order(ctx, ents, TARGET_SALT ^ (uint64_t)left ^ slot.identity());
+        return ents;
+    }
+    NearbyScalarSwapCursor(const ScalarSlot& sl, const Solution& solution_in, const MoveStreamContext& ctx, size_t max_nearby) : slot(sl) {
+        Solution solution = solution_in;
+        size_t n = solution.classes[slot.descriptor_index].n;
+        for (size_t off = 0; off < n; ++off) {
+            size_t left = nearby_ordered_entity(n, off, ctx, ENTITY_START_SALT, ENTITY_STRIDE_SALT, slot.identity());
+            rows.push_back(Row{left, rank(slot, solution, left, n, max_nearby, ctx)});
+        }
+    }
+    bool next(Move& out) override {  // swap.rs:226-246
+        for (;;) {
+            if (row_offset >= rows.size()) return false;
+            Row& row = rows[row_offset];
+            if (right_offset < row.rights.size()) {
+                out = Move{};
+                out.kind = Move::Swap;
+                out.descriptor = slot.descriptor_index;
+                out.variable = slot.variable_index;
+                out.a = row.left;
+                out.b = (size_t)row.rights[right_offset++];
+                out.allows_unassigned = slot.allows_unassigned;
+                return true;
+            }
+            ++row_offset;
+            right_offset = 0;
+        }
     }
 };
 

@@ -851,6 +851,54 @@ static void k_opt_cases() {
     }
 }
 
+// heuristic/selector/scalar_neighborhood/tests.rs:165-204 (both cases): a dynamic slot whose nearby sources decline the row
+// (return false) -> the ordinary candidate values with the source limit / every entity; meters value and |left - right|.
+static void nearby_scalar_cases() {
+    auto mk = [](std::vector<int64_t> values, std::vector<int64_t> candidates) {
+        Solution s;
+        s.classes.resize(1);
+        s.classes[0].n = values.size();
+        s.classes[0].vars.assign(1, values);
+        ScalarSlot slot;
+        slot.allows_unassigned = false;
+        slot.dynamic = true;
+        slot.values_for_entity = [candidates](const Solution&, size_t, std::vector<int64_t>& out) { out = candidates; };
+        slot.nearby_value_distance = [](size_t, int64_t v) { return (double)v; };
+        slot.nearby_entity_distance = [](size_t l, size_t r) { return (double)(l > r ? l - r : r - l); };
+        return std::make_pair(s, slot);
+    };
+    {
+        auto [s, slot] = mk({0}, {0, 2, 1});
+        NearbyScalarChangeCursor c(slot, s, MoveStreamContext(), 2, 2);
+        std::vector<std::pair<size_t, int64_t>> got;
+        Move m;
+        while (c.next(m)) got.push_back({m.a, m.to_value});
+        CHECK("nearby_scalar.change_row_fallback_with_source_limit", got == std::vector<std::pair<size_t, int64_t>>{{0, 2}});
+    }
+    {
+        auto [s, slot] = mk({0, 1, 2}, {0, 1, 2});
+        NearbyScalarSwapCursor c(slot, s, MoveStreamContext(), 1);
+        std::vector<std::pair<size_t, size_t>> got;
+        Move m;
+        while (c.next(m)) got.push_back({m.a, m.b});
+        CHECK("nearby_scalar.swap_all_entity_row_fallback", got == std::vector<std::pair<size_t, size_t>>{{0, 1}, {1, 0}, {2, 1}});
+    }
+    {  // static slot: canonical orientation right > left only (swap.rs:362-366), the declared source rows rank by source order
+        auto [s, slot] = mk({0, 1, 2, 0}, {0, 1, 2});
+        slot.dynamic = false;
+        slot.nearby_entity_distance = nullptr;
+        slot.has_nearby_entities = true;
+        slot.nearby_entities = {{3, 2, 1}, {0, 3, 2}, {1, 0, 3}, {2, 1, 0}};
+        NearbyScalarSwapCursor c(slot, s, MoveStreamContext(), 2);
+        std::vector<std::pair<size_t, size_t>> got;
+        Move m;
+        while (c.next(m)) got.push_back({m.a, m.b});
+        // row 0: 3 has the same value (skipped), then 2, 1; row 1: 3, 2; row 2: 3; row 3: nothing to the right
+        CHECK("nearby_scalar.swap_static_canonical_orientation",
+              got == std::vector<std::pair<size_t, size_t>>{{0, 2}, {0, 1}, {1, 3}, {1, 2}, {2, 3}});
+    }
+}
+
 // phase/localsearch/acceptor/diversified_late_acceptance/tests.rs:17-68 (every case; SoftScore = one level)
 static void diversified_late_acceptance_cases() {
     auto S = [](int64_t v) { return Score::level(0, v); };
@@ -1685,6 +1733,7 @@ int main() {
     k_opt_cases();
     simulated_annealing_cases();
     diversified_late_acceptance_cases();
+    nearby_scalar_cases();
     list_reverse_cases();
     list_ruin_cases();
     compound_scalar_cases();

@@ -46,6 +46,13 @@ struct SelectorSpec {
     int moves_per_step = 10, max_source_len = 0, skip_empty = 0;  // ruin leaf (ListRuinMoveSelectorConfig)
     std::string variable_name;                                    // ruin leaf: scoped_seed hashes the variable name
 };
+struct NearbyScalarSource {  // sf_selector_add_nearby_scalar: rows ranked by (distance, source order, candidate)
+    bool present = false;
+    std::vector<uint32_t> off;
+    std::vector<int32_t> val;
+    uint32_t* d_off = nullptr;
+    int32_t* d_val = nullptr;
+};
 struct PrecSpec {  // sf_constraint_add_list_precedence: the constraint's hooks as data
     bool on = false;
     int desc = 0, var = 0, hard_level = 0, mk_level = 1;
@@ -79,6 +86,8 @@ struct sf_ctx {
     bool has_list_model = false;
     int list_desc = -1;
     ListModel lm{};
+    NearbyScalarSource nearby_scalar[2];  // 0 = nearby value candidates (nearby change leaf), 1 = nearby entity candidates (nearby swap leaf)
+    int nearby_scalar_dynamic = 0;
     PrecSpec prec;          // ListPrecedenceMakespanConstraint on the list class (sf_precedence.h)
     PrecModel pm{};
     NbrIndex nbr{nullptr};  // presorted neighbour index (wave engine)
@@ -438,6 +447,66 @@ int32_t sf_selector_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32
     if (!ctx) return SF_ERR_INVALID;
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
     ctx->selectors.push_back({kind, d, var, max_nearby, fact_meter});
+    return SF_OK;
+}
+
+// Nearby scalar leaves (NearbyChangeMoveSelector / NearbySwapMoveSelector of a scalar slot: scalar_neighborhood/cursor/change.rs:123-392,
+// cursor/swap.rs:162-414).  The slot's nearby source and distance meter arrive as data; the rows are ranked here once
+// (NearbyTopK's order: distance by f64::total_cmp, then source order, then candidate; non-finite distances dropped), so the device
+// only applies the state-dependent filter and takes the first max_nearby survivors.
+int32_t sf_selector_add_nearby_scalar(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32_t max_nearby, int64_t source_limit,
+                                      const uint32_t* offsets, const int32_t* candidates, const double* distances, int32_t dynamic_slot) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
+    if (kind != SF_SEL_NEARBY_SCALAR_CHANGE && kind != SF_SEL_NEARBY_SCALAR_SWAP) return fail(ctx, SF_ERR_UNSUPPORTED, "nearby scalar selector kind");
+    if (max_nearby < 1 || max_nearby > 63) return fail(ctx, SF_ERR_UNSUPPORTED, "nearby scalar leaves: max_nearby must be 1..63");
+    if (!ctx->classes.count(d) || !ctx->classes[d].has_scalar) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: the class has no scalar variable");
+    if (!offsets || !candidates) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: the nearby source rows are required (a slot without the hook passes its "
+                                                                "ordinary candidate values / every entity)");
+    const int which = kind == SF_SEL_NEARBY_SCALAR_CHANGE ? 0 : 1;
+    NearbyScalarSource& src = ctx->nearby_scalar[which];
+    if (src.present) return fail(ctx, SF_ERR_UNSUPPORTED, "one nearby scalar leaf of each kind per model");
+    const ClassSpec& c = ctx->classes[d];
+    const int n = c.n_rows;
+    src.off.assign(1, 0u);
+    struct Ranked {
+        double dist;
+        uint32_t order;
+        int32_t cand;
+    };
+    auto total_key = [](double v) {  // f64::total_cmp
+        int64_t x;
+        std::memcpy(&x, &v, 8);
+        return x ^ (int64_t)((uint64_t)(x >> 63) >> 1);
+    };
+    std::vector<Ranked> row;
+    for (int e = 0; e < n; ++e) {
+        if (offsets[e + 1] < offsets[e]) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: offsets must be non-decreasing");
+        row.clear();
+        // the source is visited with a limit: value_candidate_limit for values (change.rs:351-355), entity_count for entities (swap.rs:389)
+        const uint64_t lim = which == 0 ? (source_limit > 0 ? (uint64_t)source_limit : ~0ull) : (uint64_t)n;
+        for (uint32_t k = offsets[e]; k < offsets[e + 1] && (uint64_t)(k - offsets[e]) < lim; ++k) {
+            const int32_t cand = candidates[k];
+            if (cand < 0 || cand >= (which == 0 ? c.n_values : 0x7FFFFFFF)) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: candidate out of range");
+            const uint32_t order = k - offsets[e];
+            const double dist = distances ? distances[k] : (double)order;  // meter None: the source order (change.rs:332-334)
+            if (!std::isfinite(dist)) continue;                            // NearbyTopK::push drops non-finite distances
+            if (which == 1 && cand > 65535) return fail(ctx, SF_ERR_UNSUPPORTED, "nearby scalar swap: entity ids up to 65535");
+            row.push_back({dist, order, cand});
+        }
+        std::sort(row.begin(), row.end(), [&](const Ranked& l, const Ranked& r) {
+            const int64_t a = total_key(l.dist), b = total_key(r.dist);
+            if (a != b) return a < b;
+            if (l.order != r.order) return l.order < r.order;
+            return l.cand < r.cand;
+        });
+        for (auto& x : row) src.val.push_back(x.cand);
+        src.off.push_back((uint32_t)src.val.size());
+    }
+    src.present = true;
+    ctx->nearby_scalar_dynamic = dynamic_slot ? 1 : 0;
+    SelectorSpec s{kind, d, var, max_nearby, -1};
+    ctx->selectors.push_back(s);
     return SF_OK;
 }
 
@@ -1647,7 +1716,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for SF_MIXED_BLOCKS_PER_CU workgroups of 4 waves per CU, the FAST
     // instantiation for SF_MIXED_FAST_BLOCKS_PER_CU); ties go to the larger group
-    const size_t max_waves = 4 * (size_t)(fast ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU);  // by register budget
+    const size_t max_waves = 4 * (size_t)(fast && !RUIN ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU);  // by register budget
     int wpb = 1;
     size_t best_resident = 0;
     for (int w = 1; w <= 4; ++w) {
@@ -1685,14 +1754,15 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         for (auto& s : ctx->selectors) ordered.push_back(&s);
     } else {
         for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
-                         SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_LIST_RUIN, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})
+                         SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_LIST_RUIN, SF_SEL_NEARBY_SCALAR_CHANGE,
+                         SF_SEL_NEARBY_SCALAR_SWAP, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})  // nearby scalar rules precede the ordinary pair (policy.rs:104-108)
             for (auto& s : ctx->selectors)
                 if (s.kind == kind) ordered.push_back(&s);
     }
         for (const SelectorSpec* sp : ordered) {
             const SelectorSpec& s = *sp;
             const int kind = s.kind;
-            const bool is_list = kind != SF_SEL_SCALAR_CHANGE && kind != SF_SEL_SCALAR_SWAP;
+            const bool is_list = kind != SF_SEL_SCALAR_CHANGE && kind != SF_SEL_SCALAR_SWAP && kind != SF_SEL_NEARBY_SCALAR_CHANGE && kind != SF_SEL_NEARBY_SCALAR_SWAP;
             if (is_list ? (!ctx->has_list_model || s.desc != ctx->list_desc) : (!ctx->has_scalar_model || s.desc != ctx->scalar_desc))
                 continue;
             if (gl.n >= GL) return fail(ctx, SF_ERR_UNSUPPORTED, "too many leaves for the generic engine");
@@ -1700,6 +1770,19 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                 if (!wave_engine_possible(ctx)) return fail(ctx, SF_ERR_UNSUPPORTED, "nearby leaves need the neighbour index (matrix meter, <= 16384 nodes)");
                 if (gl.has_nearby >= 2) return fail(ctx, SF_ERR_UNSUPPORTED, "at most two nearby leaves per union");
                 gl.has_nearby += 1;
+                gl.max_nearby[gl.n] = s.max_nearby;
+            }
+            if (kind == SF_SEL_NEARBY_SCALAR_CHANGE || kind == SF_SEL_NEARBY_SCALAR_SWAP) {
+                const int which = kind == SF_SEL_NEARBY_SCALAR_CHANGE ? 0 : 1;
+                NearbyScalarSource& src = ctx->nearby_scalar[which];
+                if (!src.d_off) {
+                    int rc = upload(ctx, &src.d_off, src.off.data(), src.off.size());
+                    if (!rc) rc = upload(ctx, &src.d_val, src.val.data(), src.val.size());
+                    if (rc) return rc;
+                }
+                gl.ns_off[which] = src.d_off;
+                gl.ns_val[which] = src.d_val;
+                gl.ns_dynamic = ctx->nearby_scalar_dynamic;
                 gl.max_nearby[gl.n] = s.max_nearby;
             }
             if (kind == SF_SEL_KOPT) {
@@ -1784,7 +1867,9 @@ extern "C" {
 static int launch_search(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     // the 2-leaf nearby union has its own engines; every other union runs in the generic N-leaf engine
     // a configured root union (order / weights other than the default policy's) runs in the generic engine too
-    if ((ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)) || union_is_custom(ctx) ||
+    bool nearby_scalar = false;  // the nearby scalar leaves live in the generic engine
+    for (auto& s : ctx->selectors) nearby_scalar = nearby_scalar || s.kind == SF_SEL_NEARBY_SCALAR_CHANGE || s.kind == SF_SEL_NEARBY_SCALAR_SWAP;
+    if (nearby_scalar || (ctx->has_list_model && ctx->has_scalar_model) || (ctx->has_list_model && has_plain_list_leaves(ctx)) || union_is_custom(ctx) ||
         (ctx->has_list_model && ctx->pm.on))  // the precedence constraint is scored by the generic engine only
         return launch_mixed(ctx, p, grid, trace);
     if (ctx->has_list_model) {

@@ -49,6 +49,10 @@ constexpr uint64_t SALT_SC_INTER = 0x5B157C4A46E00005ULL;
 constexpr uint64_t SALT_SS_ENTITY = 0x5B1575A090000001ULL, SALT_SS_START = 0x5B1575A090000002ULL;  // sublist_swap.rs:74,89,104
 constexpr uint64_t SALT_SS_SIZE = 0x5B1575A090000003ULL;
 
+// nearby scalar leaves (scalar_neighborhood/cursor/change.rs:15-17, cursor/swap.rs:12-14)
+constexpr uint64_t SALT_NSC_START = 0xC4A46E00AAAA0001ULL, SALT_NSC_STRIDE = 0xC4A46E00AAAA0002ULL, SALT_NSC_VALUE = 0xC4A46E00AAAA0003ULL;
+constexpr uint64_t SALT_NSW_START = 0x5A095CA1AAAA0001ULL, SALT_NSW_STRIDE = 0x5A095CA1AAAA0002ULL, SALT_NSW_TARGET = 0x5A095CA1AAAA0003ULL;
+
 struct RuinParams {  // list ruin leaf (sf_ruin.h)
     int32_t min_count, max_count, moves_per_step, max_source_len;  // max_source_len 0 = None
     int32_t skip_empty;
@@ -72,6 +76,11 @@ struct GLeaves {
     int32_t weight[GL];
     int32_t has_ruin;        // the union has a list ruin leaf (kind 1024); parameters + per-solve stream in `ruin`
     RuinParams ruin;
+    // nearby scalar leaves (kinds 2048 / 4096): the slot's nearby value / entity sources, one row per entity, already ranked on
+    // the host by (distance, source order, candidate) -- the meters are facts, only the state-dependent filter runs here
+    const uint32_t* ns_off[2];  // [n + 1]  0 = value candidates (nearby change), 1 = entity candidates (nearby swap)
+    const int32_t* ns_val[2];
+    int32_t ns_dynamic;         // DynamicScalarVariableSlot: legality re-check (change), directional pairs (swap)
     // candidate rings [R][GL][GRC] of (m0, m1) + one side byte, in HBM (L2-resident): written by the generators with coalesced
     // stores, read once per replay round -- the replica's LDS slice keeps only what is touched with dependent latency
     uint32_t* ring;
@@ -82,7 +91,7 @@ struct GLeaves {
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, leaftab, total;
+    size_t ring, ringx, load, off, visits, vals, nstmp, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, leaftab, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
     // n_leaves rings only: the LDS slice decides how many replicas a CU holds
@@ -113,6 +122,8 @@ struct GCarve {
         o = align_up(o + sizeof(uint16_t) * n_cap, 16);
         vals = o;
         o = align_up(o + sizeof(VT) * n_scalar, 16);
+        nstmp = o;  // nearby scalar leaves: the ranked survivors of the row being emitted
+        o = align_up(o + (n_scalar ? sizeof(uint16_t) * 64 : 0), 16);
         kopt = o;  // working set of the distance-pruned 3-opt stream
         o = align_up(o + (kopt_nearby ? KoptLds::bytes : 0), 16);
         ruin = o;  // list ruin leaf: streams, candidate table, recreate work area (RuinLds)
@@ -208,7 +219,8 @@ namespace sf {
 // union (StratifiedRandom, equal weights), LateAcceptance + AcceptedCount, committed untraced steps with generated step seeds,
 // the unified trial delta (symmetric matrix).  The scalar leaves, the other acceptors / foragers / union orders, the dry run and
 // the trace compile out: fewer wave-uniform values stay live across the step loop (the general instantiation spills ~900 SGPRs),
-// so the kernel fits more waves per SIMD (SF_MIXED_FAST_BLOCKS_PER_CU).  Same decisions bit for bit.
+// so the kernel fits more waves per SIMD (SF_MIXED_FAST_BLOCKS_PER_CU; the RUIN instantiation keeps 2: its recreate spills 1.3 KB of
+// scratch per lane at 168 VGPRs and ran 1.6x slower, profiles/r03e).  Same decisions bit for bit.
 // diagnostics (register-pressure bisection): -DSF_DBG_KINDS=<mask> compiles the generators of the masked leaf kinds out
 #ifdef SF_DBG_KINDS
 #define DBGK(k) (((SF_DBG_KINDS) & (k)) == 0)
@@ -219,7 +231,7 @@ namespace sf {
 #define SF_MIXED_FAST_BLOCKS_PER_CU 3
 #endif
 template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false, int MODE = 0>
-__global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(
+__global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(
     ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p, int has_list_arg, int has_scalar_arg, NbrIndex nb) {
     constexpr bool FAST = MODE == 1;
     static_assert(!FAST || (!TRACE && !PREC), "FAST: untraced, no precedence constraint");
@@ -248,6 +260,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_M
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
     VT* s_vals = (VT*)(mem + cv.vals);
+    uint16_t* ns_tmp = (uint16_t*)(mem + cv.nstmp);
     uint32_t* node_slot = (uint32_t*)(mem + cv.node);
     uint16_t* nb_slot_base = (uint16_t*)(mem + cv.slotbase);  // [nearby leaf 0/1][V+1]
     uint16_t* nb_route_at = (uint16_t*)(mem + cv.routeat);
@@ -468,6 +481,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_M
             lt.set(l, LeafTab::EX, l >= nl);
             lt.set(l, LeafTab::WCUR, 0);
         }
+        if (!FAST && has_scalar) {  // nearby scalar leaves: ordered_entity's start / stride of this step (change.rs:376-391) in the generator state
+            for (int l = 0; l < nl; ++l) {
+                const int lk = lt.geti(l, LeafTab::KIND);
+                if (lk != 2048 && lk != 4096) continue;
+                const uint64_t sa = (lk == 2048 ? SALT_NSC_START : SALT_NSW_START) ^ identity, sb_ = (lk == 2048 ? SALT_NSC_STRIDE : SALT_NSW_STRIDE) ^ identity;
+                const uint32_t st0 = (ctx.canonical() || ns <= 1) ? 0u : ctx.random_index(ns, sa);
+                const uint32_t sd0 = (ctx.canonical() || ns <= 1) ? 1u : ctx.random_stride(ns, sb_);
+                lt.put_gen(l, GGen{0, 0, uni(st0), uni(sd0), 0, 0, ns == 0});
+            }
+        }
         uint32_t exmask = 0xFFu & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
         if (has_nearby) {
@@ -562,7 +585,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_M
                     st_sources += 1;
                     bool keep = false;
                     uint32_t w0 = 0, w1 = 0, wx = 0;
-                    if (kind == 1) {  // ---- scalar change ----
+                    if (!FAST && kind == 1) {  // ---- scalar change ----
                         if (g.a >= ns) {
                             g.done = 1;
                             break;
@@ -599,7 +622,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_M
                             g.b = uni(__shfl(my_in, (int)cnt - 1)) + 1;
                             if (cnt < 64) g.done = 1;
                         }
-                    } else if (kind == 2) {  // ---- scalar swap ----
+                    } else if (!FAST && kind == 2) {  // ---- scalar swap ----
                         if (g.a >= ns) {
                             g.done = 1;
                             break;
@@ -622,6 +645,51 @@ __global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_M
                             g.a += 1;
                             if (g.a >= ns) g.done = 1;
                         }
+                    } else if (!FAST && (kind == 2048 || kind == 4096)) {  // ---- nearby scalar change / swap: one row per call ----
+                        // (scalar_neighborhood/cursor/change.rs:312-374, cursor/swap.rs:346-398) the row is ranked already; the
+                        // first max_nearby entries that pass the state filter are the stable top-k, then apply_selection_order
+                        if (g.a >= ns) {
+                            g.done = 1;
+                            break;
+                        }
+                        const int which = kind == 2048 ? 0 : 1;
+                        const uint32_t e = ns <= 1 ? 0u : fastmod_u64((uint64_t)g.c + (uint64_t)g.a * g.d, fm_n);
+                        const int32_t cv_ = (int32_t)s_vals[e];
+                        const uint32_t r0 = gl.ns_off[which][e], r1 = gl.ns_off[which][e + 1];
+                        uint32_t cnt = 0;
+                        for (uint32_t b0 = r0; b0 < r1 && cnt < leaf_max_nearby; b0 += 64) {
+                            const uint32_t k = b0 + lane;
+                            int32_t c = -1;
+                            bool ok = false;
+                            if (k < r1) {
+                                c = gl.ns_val[which][k];
+                                if (which == 0) {
+                                    ok = c != cv_ && (!gl.ns_dynamic || value_legal(sm, e, c));
+                                } else if ((uint32_t)c < ns && (gl.ns_dynamic ? (uint32_t)c != e : (uint32_t)c > e)) {
+                                    const int32_t rv = (int32_t)s_vals[c];
+                                    ok = rv != cv_ && value_legal(sm, e, rv) && value_legal(sm, (uint32_t)c, cv_);
+                                }
+                            }
+                            const uint64_t okm = __ballot(ok);
+                            const uint32_t rank = cnt + mbcnt64(okm);
+                            if (ok && rank < leaf_max_nearby) ns_tmp[rank] = (uint16_t)c;
+                            cnt += (uint32_t)__popcll(okm);
+                        }
+                        cnt = uni(cnt < leaf_max_nearby ? cnt : leaf_max_nearby);
+                        wave_sync();
+                        if (lane < cnt) {
+                            const uint32_t idx = ctx.selection_index(lane, cnt, (which == 0 ? SALT_NSC_VALUE : SALT_NSW_TARGET) ^ (uint64_t)e ^ identity);
+                            keep = true;
+                            w0 = e;
+                            w1 = (uint32_t)ns_tmp[idx];
+                        } else if (which == 0 && lane == cnt && sm.allows_unassigned && cv_ >= 0) {  // the row's one to-None candidate
+                            keep = true;
+                            w0 = e;
+                            w1 = 0xFFFFFFFFu;
+                        }
+                        wave_sync();  // the survivors are consumed before the next row overwrites them
+                        g.a += 1;
+                        if (g.a >= ns) g.done = 1;
                     } else if (DBGK(4) && kind == 4) {  // ---- list change (list_kernel/change.rs:142-241) ----
                         // advance to a source with a non-empty list
                         uint32_t se = 0, slen = 0;
@@ -1316,7 +1384,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_M
             {
                 const bool valid = lane < nvalid;
                 uint32_t m0 = 0, m1 = 0, mx_ = 0;
-                const int my_kind = (int)lt.w[my_leaf * 16 + LeafTab::KIND];  // per-lane leaf
+                int my_kind = (int)lt.w[my_leaf * 16 + LeafTab::KIND];  // per-lane leaf
+                if (!FAST) my_kind = my_kind == 2048 ? 1 : (my_kind == 4096 ? 2 : my_kind);  // nearby scalar leaves emit ordinary change / swap moves
                 bool doable = false;
                 ScoreV<L> sc;
 #pragma unroll
@@ -1531,7 +1600,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_M
                     best_pending = false;
                 }
             }
-            const int kind = lt.geti(uni((uint32_t)best_leaf), LeafTab::KIND);
+            int kind = lt.geti(uni((uint32_t)best_leaf), LeafTab::KIND);
+            if (!FAST) kind = kind == 2048 ? 1 : (kind == 4096 ? 2 : kind);
             const uint32_t a = uni(best_m0), b = uni(best_m1);
             if (kind <= 2) {
                 if (tracing && lane == 0) {

@@ -58,6 +58,7 @@ class SelectorKind:
     NEARBY_LIST_CHANGE, NEARBY_LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 16, 32, 64, 128, 256
     KOPT = 512
     LIST_RUIN = 1024
+    NEARBY_SCALAR_CHANGE, NEARBY_SCALAR_SWAP = 2048, 4096
 
 
 @dataclass
@@ -190,6 +191,27 @@ class GpuScoreDirector:
         else:
             w = np.ascontiguousarray(weights, dtype=np.int64)
             check(self._L.sf_union_configure(self._h, selection_order, ptr(w), len(w)), self._h)
+
+    def add_nearby_scalar_selector(self, kind, descriptor_index, rows, distances=None, variable_index=0, max_nearby=10, source_limit=0,
+                                   dynamic=False):
+        """Nearby scalar change / swap leaf (NearbyChangeMoveConfig / NearbySwapMoveConfig; default max_nearby 10,
+        default_local_search/policy/scalar.rs:16).  rows[e] = the slot's nearby source row of entity e in source order (values for the
+        change leaf, entity indices for the swap leaf; a slot without the hook passes its ordinary candidate values / range(n));
+        distances[e][k] = the slot's distance meter for rows[e][k] (None: no meter, the source order ranks)."""
+        n_rows = self._entity_counts.get(descriptor_index)
+        if n_rows is None or len(rows) != n_rows:
+            raise SolverForgeError(f"SF_ERR_INVALID: nearby source must hold one row per entity of class {descriptor_index} ({n_rows}), got {len(rows)}")
+        off = np.zeros(len(rows) + 1, dtype=np.uint32)
+        for i, r in enumerate(rows):
+            off[i + 1] = off[i] + len(r)
+        cand = np.array([v for r in rows for v in r] or [0], dtype=np.int32)
+        dist = None
+        if distances is not None:
+            dist = np.array([v for r in distances for v in r] or [0.0], dtype=np.float64)
+            if len(dist) != max(int(off[-1]), 1):
+                raise SolverForgeError("SF_ERR_INVALID: distances must parallel the source rows")
+        check(self._L.sf_selector_add_nearby_scalar(self._h, kind, descriptor_index, variable_index, max_nearby, source_limit, ptr(off), ptr(cand),
+                                                    None if dist is None else ptr(dist), int(dynamic)), self._h)
 
     def add_ruin_selector(self, descriptor_index, variable_index=0, min_ruin_count=2, max_ruin_count=5, moves_per_step=10,
                           max_source_list_len=0, skip_empty_destinations=False, variable_name="visits"):
