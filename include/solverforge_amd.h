@@ -392,6 +392,24 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* move);
  * out_scores[n * score_levels], out_doable[n].  SF_ERR_UNSUPPORTED on a load_balance model. */
 int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n,
                                   int64_t* out_scores, int32_t* out_doable);
+/* One HOST-DRIVEN local-search step of replica `replica` whose cursor is a GroupedScalarMoveSelector over a candidate-backed
+ * ScalarGroup (builder/selector/grouped_scalar.rs:82-176; declared by the default policy for every scalar group,
+ * default_local_search/policy/scalar.rs:108-136): the ScalarCandidateProvider is a host closure over the working solution
+ * (planning/scalar/candidate.rs:190), so the host calls it (sf_download_scalar gives the solution) and hands its output over --
+ * candidate i = edits[offsets[i] .. offsets[i + 1]) as in sf_step_evaluate_compound.  The library restates the cursor's activation:
+ * apply_selection_order with the salt 0xC0A1_E5CE_AAA0_0001 ^ group_name_len under the replica's step context (step index, step
+ * seed, configured selection order); candidates without edits, repeats of a kept candidate, candidates with two edits on one
+ * entity, with an illegal value or not doable are skipped; at most max_moves_per_step (<= 0: the default 256,
+ * ScalarGroupLimits / grouped_scalar.rs:27-40) are kept.  The kept candidates are pulled in order through the configured acceptor
+ * (HillClimbing / LateAcceptance / DiversifiedLateAcceptance) and forager exactly like a fused step (phase/candidates.rs:47-285), the
+ * pick is committed and the step ends (acceptor history, best solution, counters, step index, step-seed draw).
+ * out_kept[n] / *out_n_kept: provider indices of the kept candidates in pull order; out_scores[n * score_levels] trial scores and
+ * out_flags[n] (bit0 doable, bit1 accepted, bit2 committed) of the *out_consumed pulled ones; *out_selected = ordinal of the
+ * committed candidate in out_kept, -1 when the step applied nothing.  Candidate equality is equality of the edit lists (the
+ * reference also compares the candidate's reason and construction keys, which do not cross this boundary).  Scalar-only models. */
+int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n, int32_t group_name_len,
+                       int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores, int32_t* out_flags,
+                       int64_t* out_consumed, int64_t* out_selected);
 /* committed do_move of one multi-edit candidate */
 int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits);
 

@@ -460,6 +460,111 @@ struct LocalSearch {
     }
 };
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// One local-search step whose cursor is a GroupedScalarMoveSelector over a ScalarCandidateProvider
+// (builder/selector/grouped_scalar.rs:82-176, the Candidates arm of GroupedScalarCursor::activate): `provided` = what the
+// provider returned for the working solution (a host closure in the reference).  The cursor applies the selection order
+// (salt 0xC0A1_E5CE_AAA0_0001 ^ group_name.len()), skips candidates without edits, repeats of a kept candidate and candidates
+// with two edits on one (descriptor, entity, variable), builds the CompoundScalarMove (every value legal:
+// compound_move_for_group_candidate, phase/construction/grouped_scalar/move_build.rs:9-24) and keeps it when it is doable, up to
+// max_moves_per_step (default 256 for a candidate-backed group, grouped_scalar.rs:27-40).  The kept candidates are then pulled
+// through acceptor and forager like any other cursor (candidates.rs:47-285).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct GroupedStepTrace {
+    std::vector<size_t> kept;      // provider indices in pull order
+    std::vector<Score> scores;     // per consumed candidate
+    std::vector<int32_t> flags;    // bit0 doable, bit1 accepted, bit2 selected
+    int64_t selected = -1;         // ordinal (in `kept`) of the committed candidate
+};
+inline GroupedStepTrace grouped_scalar_step(LocalSearch& ls, const std::vector<std::vector<ScalarEditO>>& provided, size_t group_name_len,
+                                            size_t max_moves_per_step) {
+    GroupedStepTrace out;
+    ScoreDirector& d = *ls.director;
+    uint64_t step_index = ls.phase_step_index;
+    uint64_t step_seed = ls.next_step_seed();
+    ls.forager.step_started(step_seed, ls.has_best ? ls.best_score : ls.last_step_score, ls.last_step_score);
+    ls.acceptor->step_started();
+    MoveStreamContext ctx(step_index, step_seed, ls.forager.limit_for_context());
+    ctx = ctx.with_selection_order(ls.selection_order);
+    // activate(): order, filter, cap
+    std::vector<size_t> order(provided.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    if (!ctx.is_canonical()) {
+        std::vector<size_t> canonical = order;
+        for (size_t o = 0; o < order.size(); ++o)
+            order[o] = canonical[ctx.selection_index(o, canonical.size(), 0xC0A1E5CEAAA00001ULL ^ (uint64_t)group_name_len)];
+    }
+    auto same = [](const std::vector<ScalarEditO>& a, const std::vector<ScalarEditO>& b) {
+        if (a.size() != b.size()) return false;
+        for (size_t i = 0; i < a.size(); ++i)
+            if (a[i].descriptor != b[i].descriptor || a[i].entity != b[i].entity || a[i].variable != b[i].variable || a[i].to_value != b[i].to_value)
+                return false;
+        return true;
+    };
+    for (size_t idx : order) {
+        if (out.kept.size() >= max_moves_per_step) break;
+        const auto& cand = provided[idx];
+        if (cand.empty()) continue;
+        bool seen = false;
+        for (size_t k : out.kept) seen = seen || same(provided[k], cand);
+        if (seen) continue;
+        bool dup_target = false;
+        for (size_t i = 0; i < cand.size() && !dup_target; ++i)
+            for (size_t j = 0; j < i; ++j)
+                if (cand[i].descriptor == cand[j].descriptor && cand[i].entity == cand[j].entity && cand[i].variable == cand[j].variable) dup_target = true;
+        if (dup_target) continue;
+        bool legal = true;
+        for (auto& e : cand) legal = legal && e.legal && e.entity < d.working.classes[e.descriptor].n;
+        if (!legal) continue;
+        if (!compound_is_doable(d, cand)) continue;
+        out.kept.push_back(idx);
+    }
+    // the pull loop (candidates.rs:47-285)
+    size_t pulled = 0;
+    while (!ls.forager.is_quit_early()) {
+        if (pulled >= out.kept.size()) break;
+        const auto& cand = provided[out.kept[pulled]];
+        size_t id = pulled++;
+        ++ls.stats.moves_generated;
+        ++ls.stats.moves_evaluated;
+        if (!compound_is_doable(d, cand)) {
+            ++ls.stats.moves_not_doable;
+            out.scores.push_back(Score::zero());
+            out.flags.push_back(0);
+            continue;
+        }
+        DirectorScoreState st = d.snapshot_score_state();
+        std::vector<int64_t> undo = compound_do(d, cand);
+        Score move_score = d.calculate_score();
+        compound_undo(d, cand, undo);
+        d.restore_score_state(st);
+        ++ls.stats.score_calculations;
+        bool accepted = ls.acceptor->is_accepted(ls.last_step_score, move_score);
+        out.scores.push_back(move_score);
+        out.flags.push_back(1 | (accepted ? 2 : 0));
+        if (accepted) {
+            ++ls.stats.moves_accepted;
+            ls.forager.add_move_index(id, move_score);
+        }
+    }
+    ls.last_step_applied = false;
+    if (ls.forager.best.has) {
+        out.selected = (int64_t)ls.forager.best.index;
+        out.flags[ls.forager.best.index] |= 4;
+        (void)compound_do(d, provided[out.kept[ls.forager.best.index]]);
+        d.calculate_score();
+        ++ls.stats.moves_applied;
+        ls.last_step_score = ls.forager.best.score;
+        ls.last_step_applied = true;
+        ls.update_best_solution();
+        ls.forager.best.has = false;
+    }
+    ls.acceptor->step_ended(ls.last_step_score);
+    ++ls.phase_step_index;
+    ++ls.stats.step_count;
+    return out;
+}
+
 // First-fit construction over one scalar slot (phase/construction/forager_step.rs:149-226,
 // decision.rs:56-64): entities in index order; when keep-current is legal (the variable
 // allows unassigned) the baseline is the current score and the first candidate value whose

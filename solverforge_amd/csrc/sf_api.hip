@@ -1283,6 +1283,126 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
     return SF_OK;
 }
 
+// One host-driven local-search step over a ScalarCandidateProvider's output (GroupedScalarMoveSelector; see the header).
+int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n, int32_t group_name_len,
+                       int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores, int32_t* out_flags,
+                       int64_t* out_consumed, int64_t* out_selected) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized || replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_kept || !out_n_kept || !out_scores || !out_flags ||
+        !out_consumed || !out_selected)
+        return fail(ctx, SF_ERR_INVALID, "bad sf_step_decide arguments");
+    if (!ctx->has_scalar_model || ctx->has_list_model) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_decide: scalar-only models (ScalarCandidate edits)");
+    if (ctx->sm.grp_level >= 0 && ctx->sm.grp_mode >= 1)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a load_balance / balance model (floating-point aggregate) are not chained on the device");
+    if (ctx->sm.run_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "compound candidates on a consecutive-runs model are not chained on the device");
+    if (ctx->cfg.acceptor != SF_ACCEPT_HILL_CLIMBING && ctx->cfg.acceptor != SF_ACCEPT_LATE_ACCEPTANCE && ctx->cfg.acceptor != SF_ACCEPT_DIVERSIFIED_LATE_ACCEPTANCE)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_decide: HillClimbing, LateAcceptance or DiversifiedLateAcceptance");
+    if (offsets[0] != 0) return fail(ctx, SF_ERR_INVALID, "offsets[0] must be 0");
+    if (n >= ((int64_t)1 << 31)) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_decide: fewer than 2^31 candidates");
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SF_ERR_INVALID, "offsets must not decrease");
+    if (n > 0 && offsets[n] > 0 && !edits) return fail(ctx, SF_ERR_INVALID, "edits is NULL");
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    SearchParams p = ctx->sp;
+    fill_search_params(ctx, p);
+    const ClassSpec& c = ctx->classes[ctx->scalar_desc];
+    const int ne = ctx->sm.n;
+    // the step's MoveStreamContext and the replica's working values (the cursor filters by is_doable_on)
+    std::vector<int32_t> vals((size_t)ne);
+    uint64_t step_index = 0, draws = 0;
+    HIPCHK(ctx, hipMemcpyAsync(vals.data(), ctx->sm.vals + (size_t)replica * ne, (size_t)ne * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&step_index, p.step_index + replica, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(&draws, p.seed_draws + replica, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t sseed = step_seed(p.random_seed + (uint64_t)replica, draws);
+    if (ctx->d_explicit && (int64_t)draws < ctx->n_explicit) {
+        HIPCHK(ctx, hipMemcpy(&sseed, ctx->d_explicit + (size_t)replica * ctx->n_explicit + draws, 8, hipMemcpyDeviceToHost));
+    }
+    const StreamCtx sctx{step_index, sseed, p.order};
+    const int64_t cap = max_moves_per_step > 0 ? max_moves_per_step : 256;  // candidate-backed group (grouped_scalar.rs:27-40)
+    // GroupedScalarCursor::activate, Candidates arm (grouped_scalar.rs:122-176)
+    std::vector<int64_t> kept;
+    auto legal = [&](int32_t e, int32_t to) {
+        if (e < 0 || e >= ne) return false;
+        if (to < 0) return to == -1 && c.allows_unassigned != 0;
+        if (to >= c.n_values) return false;
+        if (c.value_off.empty()) return true;
+        for (uint32_t q = c.value_off[(size_t)e]; q < c.value_off[(size_t)e + 1]; ++q)
+            if (c.value_list[q] == to) return true;
+        return false;
+    };
+    for (int64_t o = 0; o < n && (int64_t)kept.size() < cap; ++o) {
+        const int64_t idx = (int64_t)sctx.selection_index((uint32_t)o, (uint32_t)n, 0xC0A1E5CEAAA00001ULL ^ (uint64_t)group_name_len);  // apply_selection_order
+        const int64_t b = offsets[idx], e = offsets[idx + 1];
+        if (e == b) continue;
+        if (e - b > SF_COMPOUND_MAX) return fail(ctx, SF_ERR_UNSUPPORTED, "at most 8 edits per compound candidate on the device");
+        bool ok = true, changes = false;
+        for (int64_t k = b; k < e && ok; ++k) {
+            if (edits[k].kind != SF_MOVE_CHANGE) return fail(ctx, SF_ERR_INVALID, "a ScalarEdit is a SF_MOVE_CHANGE-shaped record");
+            for (int64_t j = b; j < k; ++j) ok = ok && edits[j].a != edits[k].a;  // two edits on one (descriptor, entity, variable)
+            ok = ok && legal(edits[k].a, edits[k].value);
+            if (ok) changes = changes || vals[(size_t)edits[k].a] != edits[k].value;
+        }
+        if (!ok || !changes) continue;
+        bool seen = false;
+        for (int64_t q : kept) {
+            if (offsets[q + 1] - offsets[q] != e - b) continue;
+            bool same = true;
+            for (int64_t k = 0; k < e - b && same; ++k) same = edits[offsets[q] + k].a == edits[b + k].a && edits[offsets[q] + k].value == edits[b + k].value;
+            seen = seen || same;
+        }
+        if (seen) continue;
+        kept.push_back(idx);
+    }
+    const int64_t nk = (int64_t)kept.size();
+    *out_n_kept = nk;
+    for (int64_t i = 0; i < nk; ++i) out_kept[i] = kept[(size_t)i];
+    // kept candidates as their own CSR
+    std::vector<sf_move_t> kedits;
+    std::vector<int64_t> koff(1, 0);
+    for (int64_t q : kept) {
+        for (int64_t k = offsets[q]; k < offsets[q + 1]; ++k) kedits.push_back(edits[k]);
+        koff.push_back((int64_t)kedits.size());
+    }
+    int32_t* d_edits = nullptr;
+    int64_t *d_off = nullptr, *d_sc = nullptr, *d_res = nullptr;
+    int32_t *d_do = nullptr, *d_fl = nullptr;
+    auto release = [&]() {
+        (void)hipFree(d_edits), (void)hipFree(d_off), (void)hipFree(d_sc), (void)hipFree(d_res), (void)hipFree(d_do), (void)hipFree(d_fl);
+    };
+    const size_t nk1 = (size_t)(nk > 0 ? nk : 1);
+    hipError_t e = hipMalloc((void**)&d_edits, (kedits.empty() ? 1 : kedits.size()) * 24);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_off, (size_t)(nk + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_sc, nk1 * ctx->levels * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_do, nk1 * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_fl, nk1 * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_res, 16);
+    if (e == hipSuccess && !kedits.empty()) e = hipMemcpyAsync(d_edits, kedits.data(), kedits.size() * 24, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, koff.data(), (size_t)(nk + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_fl, 0, nk1 * 4, ctx->stream);
+    if (e != hipSuccess) {
+        release();
+        return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    }
+    if (nk > 0)
+        hipLaunchKernelGGL(k_scalar_evaluate_compound, dim3((int)((nk + 255) / 256)), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, d_edits,
+                           d_off, nk, d_sc, d_do);
+    hipLaunchKernelGGL(k_scalar_step_decide, dim3(1), dim3(64), scalar_table_bytes(ctx), ctx->stream, ctx->sm, p, replica, d_edits, d_off, nk, d_sc, d_do, d_fl,
+                       d_res);
+    e = hipGetLastError();
+    int64_t res[2] = {0, -1};
+    if (e == hipSuccess) e = hipMemcpyAsync(res, d_res, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && nk > 0) e = hipMemcpyAsync(out_scores, d_sc, (size_t)nk * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && nk > 0) e = hipMemcpyAsync(out_flags, d_fl, (size_t)nk * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    release();
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    *out_consumed = res[0];
+    *out_selected = res[1];
+    return SF_OK;
+}
+
 int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !mv || replica < 0 || replica >= ctx->R)

@@ -679,6 +679,183 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
     *out_ok = 1;
 }
 
+// One HOST-DRIVEN local-search step (sf_step_decide): the candidates were generated on the host (a ScalarCandidateProvider behind a
+// GroupedScalarMoveSelector, builder/selector/grouped_scalar.rs) and scored by k_scalar_evaluate_compound; this wave pulls them in
+// order through the configured acceptor (HillClimbing / LateAcceptance / DiversifiedLateAcceptance) and forager exactly like the
+// fused engines (phase/candidates.rs:47-285), commits the pick (CompoundScalarMove::do_move) and ends the step (step.rs:122-221):
+// acceptor.step_ended, best solution, counters, step index.  One wavefront, replica `replica`.
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(64) void k_scalar_step_decide(ScalarModel m, SearchParams p, int replica, const int32_t* edits, const int64_t* offsets, int64_t n,
+                                                          const int64_t* scores, const int32_t* doable_in, int32_t* out_flags, int64_t* out_result) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
+    constexpr int L = 4;  // scores padded with zero levels: the lexicographic order is unchanged
+    const uint32_t lane = threadIdx.x & 63u;
+    const int r = replica;
+    int32_t* vals = m.vals + (size_t)r * m.n;
+    int64_t* t_sum = (int64_t*)tab_mem;
+    uint32_t* t_cnt = (uint32_t*)(tab_mem + sizeof(int64_t) * (size_t)m.n_values);
+    const bool tables = m.tables();
+    if (tables) {
+        for (int v = threadIdx.x; v < m.n_values; v += blockDim.x) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
+        __syncthreads();
+        scalar_tables_accumulate(m, vals, threadIdx.x, blockDim.x, t_cnt, t_sum);
+        __syncthreads();
+    }
+    ScoreV<L> curv, best_sol, late, dla_thr;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        curv.v[k] = m.score[(size_t)r * 4 + k];
+        best_sol.v[k] = m.best_score[(size_t)r * 4 + k];
+        late.v[k] = 0;
+    }
+    const int la_slot = p.la_idx[r];
+    if (p.acceptor == 1 || p.acceptor == 4) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) late.v[k] = p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k];
+    }
+    dla_thr = late;
+    if (p.acceptor == 4) {
+        ScoreV<L> db;
+#pragma unroll
+        for (int k = 0; k < L; ++k) db.v[k] = p.dla_best[(size_t)r * 4 + k];
+        dla_thr = dla_threshold<L>(db, p.dla_tolerance);
+    }
+    const uint64_t draw = p.seed_draws[r];
+    const uint64_t sseed = (p.explicit_seeds && (int64_t)draw < p.n_explicit) ? p.explicit_seeds[(size_t)r * p.n_explicit + draw]
+                                                                            : step_seed(p.random_seed + (uint64_t)r, draw);
+    int has_best = 0;
+    uint64_t equal_count = 0;
+    uint32_t accepted = 0;
+    ScoreV<L> best = curv;
+    int64_t best_i = -1;
+    uint64_t st_gen = 0, st_acc = 0, st_calc = 0;
+    int64_t consumed_total = 0;
+    for (int64_t base = 0; base < n; base += 64) {
+        const uint32_t nvalid = (uint32_t)((n - base) < 64 ? (n - base) : 64);
+        const bool valid = lane < nvalid;
+        const int64_t ci = base + lane;
+        ScoreV<L> sc = curv;
+        bool doable = false;
+        if (valid) {
+            doable = doable_in[ci] != 0;
+#pragma unroll
+            for (int k = 0; k < L; ++k) sc.v[k] = k < m.levels ? scores[ci * m.levels + k] : 0;
+        }
+        bool acc = false;
+        if (doable) {
+            if (p.acceptor == 0)
+                acc = score_cmp<L>(sc, curv) > 0;
+            else if (p.acceptor == 1)
+                acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0;
+            else if (p.acceptor == 4)
+                acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0 || score_cmp<L>(sc, dla_thr) >= 0;
+        }
+        bool improving_pick = false;
+        const ScoreV<L> forager_thr = p.forager == FORAGER_FIRST_BEST_IMPROVING ? best_sol : curv;
+        const uint32_t nconsumed = forager_chunk_cut<L>(p.forager, (uint32_t)p.limit, accepted, acc, sc, forager_thr, nvalid, improving_pick);
+        const bool consumed = lane < nconsumed;
+        acc = acc && consumed;
+        const uint64_t accmask = __ballot(acc);
+        if (accmask) {
+            if (improving_pick) {
+                const int sel = (int)nconsumed - 1;
+#pragma unroll
+                for (int k = 0; k < L; ++k) best.v[k] = (int64_t)shfl_u64((uint64_t)sc.v[k], sel);
+                best_i = base + sel;
+                equal_count = 1;
+                has_best = 1;
+            } else if (p.forager == 1) {
+                if (!has_best) {
+                    const int sel = __ffsll((unsigned long long)accmask) - 1;
+#pragma unroll
+                    for (int k = 0; k < L; ++k) best.v[k] = (int64_t)shfl_u64((uint64_t)sc.v[k], sel);
+                    best_i = base + sel;
+                    has_best = 1;
+                }
+            } else if (!has_best || __ballot(acc && score_cmp<L>(sc, best) >= 0)) {
+                const ScoreV<L> M = wave_max_score<L>(sc, acc);
+                const int cm = has_best ? score_cmp<L>(M, best) : 1;
+                if (cm >= 0) {
+                    const bool newmax = cm > 0;
+                    const uint64_t eq_base = newmax ? 0 : equal_count;
+                    const bool in_eq = acc && score_cmp<L>(sc, M) == 0;
+                    const uint64_t eq = __ballot(in_eq);
+                    const uint32_t rank = mbcnt64(eq) + 1u;
+                    const uint64_t cntq = eq_base + rank;
+                    const bool pick = in_eq && ((newmax && rank == 1) || (p.random_ties && cntq > 1 && reservoir_pick(sseed, cntq)));
+                    const uint64_t pm = __ballot(pick);
+                    if (pm) best_i = base + (63 - __clzll((unsigned long long)pm));
+                    best = M;
+                    equal_count = eq_base + (uint64_t)__popcll(eq);
+                    has_best = 1;
+                }
+            }
+        }
+        accepted += (uint32_t)__popcll(accmask);
+        st_gen += nconsumed;
+        st_acc += (uint64_t)__popcll(accmask);
+        st_calc += (uint64_t)__popcll(__ballot(consumed && doable));
+        if (consumed) out_flags[ci] = (doable ? 1 : 0) | (acc ? 2 : 0);
+        consumed_total += nconsumed;
+        if (forager_quits(p.forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) break;
+    }
+    __syncthreads();
+    // commit the pick: CompoundScalarMove::do_move (one lane, as k_scalar_apply_compound)
+    if (has_best && lane == 0) {
+        out_flags[best_i] |= 4;
+        int64_t* cur = m.score + (size_t)r * 4;
+        for (int64_t k = offsets[best_i]; k < offsets[best_i + 1]; ++k) {
+            const uint32_t a = (uint32_t)edits[k * 6 + 1];
+            const int32_t to = edits[k * 6 + 5];
+            const ScalarDelta d = eval_scalar_move(m, vals, 0, a, 0u, to, t_cnt, t_sum, (const int64_t*)nullptr);
+            if (!d.doable) continue;
+            const ScoreV<4> s2 = apply_scalar_delta<4>(m, cur, d);
+            if (tables) scalar_tables_apply(m, vals, 0, a, 0u, to, t_cnt, t_sum);
+            vals[a] = to;
+            for (int q = 0; q < 4; ++q) cur[q] = s2.v[q];
+        }
+    }
+    __syncthreads();
+    if (has_best) curv = best;  // == the score the commit accumulated (asserted by the parity tests through sf_get_scores)
+    const bool improved = has_best && score_cmp<L>(curv, best_sol) > 0;
+    if (improved)  // update_best_solution (scope_progress.rs:89-107)
+        for (uint32_t t = lane; t < (uint32_t)m.n; t += 64) m.best_vals[(size_t)r * m.n + t] = vals[t];
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            p.last_step_score[(size_t)r * 4 + k] = curv.v[k];
+            if (improved) m.best_score[(size_t)r * 4 + k] = curv.v[k];
+            if (p.acceptor == 1 || p.acceptor == 4) p.la_hist[((size_t)r * p.la_size + la_slot) * 4 + k] = curv.v[k];
+        }
+        if (p.acceptor == 4) {
+            ScoreV<L> db;
+#pragma unroll
+            for (int k = 0; k < L; ++k) db.v[k] = p.dla_best[(size_t)r * 4 + k];
+            if (score_cmp<L>(curv, db) > 0) {
+#pragma unroll
+                for (int k = 0; k < L; ++k) p.dla_best[(size_t)r * 4 + k] = curv.v[k];
+            }
+        }
+        p.la_idx[r] = la_slot + 1 >= p.la_size ? 0 : la_slot + 1;
+        p.step_index[r] += 1;
+        p.seed_draws[r] += 1;
+        uint64_t* gs = p.stats + (size_t)r * SF_STATS_WORDS;
+        gs[0] += 1;
+        gs[1] += st_gen;
+        gs[2] += st_gen;
+        gs[3] += st_acc;
+        gs[4] += has_best ? 1 : 0;
+        gs[5] += st_calc;
+        gs[6] += st_gen - st_calc;
+        gs[7] += st_gen;
+        out_result[0] = consumed_total;
+        out_result[1] = has_best ? best_i : -1;
+    }
+}
+
 // evaluate_all / initialize: full recomputation (fresh_score; FullAssert).  grid = R blocks.
 // accumulate != 0: add this class's constraint scores to what the list class already wrote (mixed models)
 SF_PLAIN_KERNEL

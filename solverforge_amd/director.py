@@ -276,6 +276,19 @@ class GpuScoreDirector:
         check(self._L.sf_step_evaluate_compound(self._h, replica, ptr(edits), ptr(offsets), len(candidates), ptr(scores), ptr(doable)), self._h)
         return scores, doable
 
+    def step_decide(self, candidates, replica=0, group_name_len=0, max_moves_per_step=0):
+        """One host-driven local-search step over a ScalarCandidateProvider's output (GroupedScalarMoveSelector, sf_step_decide):
+        returns (kept provider indices in pull order, trial scores [consumed, levels], flags [consumed], selected ordinal or -1)."""
+        edits, offsets = self._compound_wire(candidates)
+        n = len(candidates)
+        kept = np.zeros(max(n, 1), dtype=np.int64)
+        scores = np.zeros((max(n, 1), self.levels), dtype=np.int64)
+        flags = np.zeros(max(n, 1), dtype=np.int32)
+        nk, consumed, selected = C.c_int64(0), C.c_int64(0), C.c_int64(-1)
+        check(self._L.sf_step_decide(self._h, replica, ptr(edits), ptr(offsets), n, group_name_len, max_moves_per_step, ptr(kept), C.byref(nk),
+                                     ptr(scores), ptr(flags), C.byref(consumed), C.byref(selected)), self._h)
+        return kept[:nk.value], scores[:consumed.value], flags[:consumed.value], int(selected.value)
+
     def apply_candidate(self, candidate, replica=0):
         """Committed do_move of one multi-edit ScalarCandidate."""
         edits, _ = self._compound_wire([candidate])
