@@ -740,7 +740,7 @@ static int build_list_model(sf_ctx* ctx, int d) {
         pm.hard_level = ps.hard_level;
         pm.mk_level = ps.mk_level;
         pm.n = n;
-        std::vector<uint32_t> soff((size_t)n + 1, 0), sval;
+        std::vector<uint32_t> soff((size_t)n + 1, 0), sval, poff((size_t)n + 1, 0), pval;
         std::vector<int32_t> indeg((size_t)n, 0);
         int64_t invalid = 0;
         for (int i = 0; i < n; ++i) {
@@ -755,6 +755,13 @@ static int build_list_model(sf_ctx* ctx, int d) {
             soff[i + 1] = (uint32_t)sval.size();
         }
         pm.const_penalty = invalid;
+        {  // fixed predecessors (incremental trial refresh)
+            for (int i = 0; i < n; ++i) poff[(size_t)i + 1] = poff[(size_t)i] + (uint32_t)indeg[(size_t)i];
+            pval.resize(sval.size());
+            std::vector<uint32_t> fill(poff.begin(), poff.end() - 1);
+            for (int i = 0; i < n; ++i)
+                for (uint32_t t = soff[(size_t)i]; t < soff[(size_t)i + 1]; ++t) pval[fill[sval[t]]++] = (uint32_t)i;
+        }
         int32_t* d_dur = nullptr;
         uint32_t *d_soff = nullptr, *d_sval = nullptr;
         int32_t *d_indeg = nullptr, *d_owner = nullptr;
@@ -774,6 +781,16 @@ static int build_list_model(sf_ctx* ctx, int d) {
         if ((rc = dalloc(ctx, &pm.queue, words))) return rc;
         if ((rc = dalloc(ctx, &pm.lsucc, words))) return rc;
         if ((rc = dalloc(ctx, &pm.state, (size_t)R * 2))) return rc;
+        uint32_t *d_poff = nullptr, *d_pval = nullptr;
+        if ((rc = upload(ctx, &d_poff, poff.data(), poff.size()))) return rc;
+        if ((rc = upload(ctx, &d_pval, pval.data(), pval.size()))) return rc;
+        pm.pred_off = d_poff;
+        pm.pred = d_pval;
+        if ((rc = dalloc(ctx, &pm.lpred, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.stamp_e, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.stamp_q, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.changed, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.queue2, words))) return rc;
     }
     // compact u32 matrix copy (4-byte gathers in the trial-score path) when every finite leg fits
     for (auto& kv : ctx->facts)
@@ -1954,8 +1971,11 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     gl.levels = ctx->levels;
     gl.prec = ctx->has_list_model ? ctx->pm : PrecModel{};
     {  // the Kahn scratch (16 bytes per node) goes to LDS while at least 4 replicas still fit a CU
-        static const bool no_lds = std::getenv("SF_AMD_PREC_HBM") != nullptr;  // diagnostics / parity tests: force the HBM scratch
+        const bool no_lds = std::getenv("SF_AMD_PREC_HBM") != nullptr;  // diagnostics / parity tests: force the HBM scratch (read at every launch)
         gl.prec_lds = (gl.prec.on && !no_lds && (size_t)gl.prec.n * 16 <= 36 * 1024) ? 1 : 0;
+        // the incremental trial refresh is parity-complete but SLOWER than one full evaluation per trial on every job shop measured
+        // (profiles/r03f_precedence.txt): opt-in for the parity tests and further work
+        gl.prec_inc = std::getenv("SF_AMD_PREC_INC") != nullptr ? 1 : 0;
     }
     if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations
         if (ctx->has_scalar_model && ctx->sm.n_values <= 127 && ctx->sm.n >= 1024) {  // one-byte value array (C4: 4 waves per CU instead of 3)

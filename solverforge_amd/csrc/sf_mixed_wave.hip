@@ -87,6 +87,7 @@ struct GLeaves {
     uint8_t* ringx;
     PrecModel prec;          // ListPrecedenceMakespanConstraint of the list class (prec.on; PREC instantiations, sf_precedence.h)
     int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
+    int32_t prec_inc;        // HBM scratch: list change / swap trials take the incremental refresh (prec_trial_inc; opt-in, see sf_precedence.h)
 };
 
 template <class VT>
@@ -335,12 +336,44 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     int32_t* const prec_D = !PREC ? nullptr : (prec_in_lds ? prec_E + gl.prec.n : gl.prec.indeg + (size_t)r * gl.prec.n);
     uint32_t* const prec_Q = !PREC ? nullptr : (prec_in_lds ? (uint32_t*)(prec_D + gl.prec.n) : gl.prec.queue + (size_t)r * gl.prec.n);
     uint32_t* const prec_S = !PREC ? nullptr : (prec_in_lds ? prec_Q + gl.prec.n : gl.prec.lsucc + (size_t)r * gl.prec.n);
+    // incremental trial refresh (sf_precedence.h: prec_trial_inc) when the scratch lives in HBM: list change / swap candidates are
+    // scored against the committed earliest starts without applying them; everything else takes the full evaluation
+    PrecInc pinc{};
+    const bool prec_incremental = PREC && !prec_in_lds && gl.prec_inc != 0 && gl.prec.lpred != nullptr;
+    if (prec_incremental) {
+        const size_t pn = (size_t)gl.prec.n, pb = (size_t)r * pn;
+        pinc.E = prec_E, pinc.LS = prec_S, pinc.ET = prec_D, pinc.Q1 = prec_Q;
+        pinc.LP = gl.prec.lpred + pb, pinc.SE = gl.prec.stamp_e + pb, pinc.SQ = gl.prec.stamp_q + pb, pinc.CH = gl.prec.changed + pb;
+        pinc.Q2 = gl.prec.queue2 + pb;
+        for (uint32_t t = lane; t < (uint32_t)pn; t += 64) {  // the stamps of earlier launches mean nothing here
+            pinc.SE[t] = 0;
+            pinc.SQ[t] = 0;
+        }
+    }
     // one full evaluation of the lists in LDS: typed LDS accessors when the scratch lives there
     auto prec_run = [&]() -> PrecResult {
         if (prec_in_lds)
             return prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u32*)prec_Q,
                                                    (prec_lds_u32*)prec_S);
-        return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+        if (!prec_incremental) return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+        // committed evaluation: also the list predecessors, the owner violations, the cycle flag and the makespan multiplicity
+        __shared__ uint32_t s_prec_info[4][2];
+        uint32_t* info = s_prec_info[threadIdx.x >> 6];
+        const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, pinc.LP, info);
+        wave_sync();
+        pinc.viol = uni(info[0]);
+        pinc.ok = uni(info[1]) == 0u;
+        pinc.mk = (int32_t)pr.makespan;
+        pinc.pen_fixed = pr.penalty - (int64_t)pinc.viol - (pinc.ok ? 0 : (int64_t)gl.prec.n);
+        prec_sync();
+        pinc.mk_count = pinc.ok ? uni(prec_count_makespan(gl.prec, prec_E, pinc.mk)) : 0u;
+        return pr;
+    };
+    // full evaluation of a TRIAL state (move kinds the incremental refresh does not cover): its own scratch, so the committed
+    // earliest starts / list neighbours survive (trial values, both frontiers and the changed list are free between trials)
+    auto prec_run_trial = [&]() -> PrecResult {
+        if (!prec_incremental) return prec_run();
+        return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, (int32_t*)pinc.CH, prec_D, prec_Q, pinc.Q2);
     };
     if (PREC) {
         const PrecResult pr = prec_run();
@@ -1437,11 +1470,25 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         const int ck = __builtin_amdgcn_readlane(my_kind, ci);
                         const uint32_t ca = (uint32_t)__builtin_amdgcn_readlane((int)m0, ci), cb = (uint32_t)__builtin_amdgcn_readlane((int)m1, ci);
                         const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)mx_, ci);
+                        if (prec_incremental && (ck == 4 || ck == 16 || ck == 8 || ck == 32)) {  // list change / swap: no apply, no undo
+                            PrecResult pi;
+                            if (prec_trial_inc<uint16_t>(gl.prec, pinc, s_visits, s_off, (ck == 4 || ck == 16) ? 2 : 3, ca >> 16, ca & 0xFFFFu, cb >> 16,
+                                                         cb & 0xFFFFu, pi)) {
+                                if ((int)lane == ci) {
+#pragma unroll
+                                    for (int kk = 0; kk < L; ++kk) {
+                                        if (kk == gl.prec.hard_level) sc.v[kk] -= pi.penalty - prec_pen;
+                                        if (kk == gl.prec.mk_level) sc.v[kk] -= pi.makespan - prec_mk;
+                                    }
+                                }
+                                continue;
+                            }
+                        }
                         apply_list_move_wave(lm, s_visits, s_off, s_load,
                                              (ck == 4 || ck == 16) ? 2 : ((ck == 8 || ck == 32) ? 3 : (ck == 64 ? 4 : (ck == 128 ? 5 : (ck == 512 ? 7 : 6)))),
                                              ca >> 16, ca & 0xFFFFu, cb >> 16, cb & 0xFFFFu,
                                              ck == 512 ? cx : (ck == 256 ? ((cx & 15u) | ((cx >> 4) << 16)) : (ca & 0xFFFFu) + cx));
-                        const PrecResult pr = prec_run();
+                        const PrecResult pr = prec_run_trial();
                         if ((int)lane == ci) {
 #pragma unroll
                             for (int kk = 0; kk < L; ++kk) {

@@ -40,6 +40,15 @@ struct PrecModel {
     uint32_t* queue;
     uint32_t* lsucc;
     int64_t* state;  // [R][2] (hard penalty, makespan) of the committed lists
+    // incremental trial refresh (prec_trial_inc; generic engine, scratch in HBM): fixed predecessors, and per replica the list
+    // predecessor of every node, trial earliest starts with their stamps, queue stamps, the nodes a trial changed, a second frontier
+    const uint32_t* pred_off;  // [n + 1] fixed predecessors (valid ones only)
+    const uint32_t* pred;
+    uint32_t* lpred;     // [R][n]
+    uint32_t* stamp_e;   // [R][n] trial id whose earliest start sits in `indeg` (reused as the trial value array)
+    uint32_t* stamp_q;   // [R][n] round stamp: queued for the next frontier / visited by a cycle search
+    uint32_t* changed;   // [R][n] nodes whose earliest start a trial replaced
+    uint32_t* queue2;    // [R][n] second frontier
 };
 
 struct PrecResult {
@@ -85,13 +94,14 @@ __device__ __forceinline__ uint32_t prec_mbcnt(uint64_t mask) {
 // words.  Wave-uniform result.
 template <class VT, class MEM = PrecMemGlobal>
 __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
-                                             typename MEM::U32 Q, typename MEM::U32 S) {
+                                             typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     for (uint32_t i = lane; i < n; i += 64) {
         MEM::st(E + i, 0);
         MEM::st(D + i, pm.indeg0[i]);
         MEM::st(S + i, PREC_NONE);
+        if (LP) LP[i] = PREC_NONE;
     }
     prec_sync();
     const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[V]);
@@ -109,6 +119,7 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
             }
             const uint32_t x = (uint32_t)visits[t];
             if (t + 1 != off[lo + 1]) MEM::st(S + x, (uint32_t)visits[t + 1]);
+            if (LP) LP[x] = t != off[lo] ? (uint32_t)visits[t - 1] : PREC_NONE;  // list predecessor (incremental trial refresh)
             if (t != off[lo]) MEM::st(D + x, pm.indeg0[x] + 1);
             if (pm.owner) {
                 const int32_t o = pm.owner[x];
@@ -165,10 +176,351 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
         mk = other > mk ? other : mk;
         viol += (uint32_t)__shfl_xor((int)viol, o);
     }
+    if (out_info) {  // wave-uniform: wrong-owner items, cyclic flag
+        out_info[0] = viol;
+        out_info[1] = cyclic ? 1u : 0u;
+    }
     PrecResult r;
     r.penalty = pm.const_penalty + (int64_t)viol + (int64_t)(n - total) + (cyclic ? (int64_t)n : 0);
     r.makespan = cyclic ? 0 : (int64_t)mk;
     return r;
+}
+
+// ---- incremental trial refresh (HBM scratch) -------------------------------------------------------------------------------
+// The reference refreshes the earliest starts of the descendants of the changed edges (refresh_graph_after_route_change,
+// list_precedence.rs:494-551) after testing every added edge for a cycle (added_edges_introduce_cycle :638-651).  Same result
+// here without touching the replica's lists: a list change / list swap candidate changes the list neighbours of at most six
+// nodes (an OVERLAY held one entry per lane), the cycle test is a wave-wide breadth-first search from the head of every added
+// edge that prunes by the committed earliest starts (a node that finishes later than every tail of an added edge cannot lead
+// back to one: the committed graph is acyclic, so its earliest starts are a potential), and the refresh relaxes frontiers of
+// nodes 64 at a time against the view "trial value if stamped by this trial, committed value otherwise".  The committed arrays
+// are never written, so there is nothing to undo.  The makespan is the committed one unless every node that attains it moved
+// (then one scan of the view).
+// MEASURED (profiles/r03f_precedence.txt, MI355X): parity-green, but 4x SLOWER than one full wave-wide Kahn pass per trial at
+// 50 x 20 and 100 x 20 (5.6 M vs 22.1 M moves/s with the full pass in LDS) and 9x slower at C4 (500 x 20, 20.8 K vs 187.6 K
+// moves/s): a move early in a machine's list shifts most of the downstream schedule, so the refresh runs as many dependent
+// frontier rounds as the full pass while every round costs several L2 round trips (stamped view, atomic exchange per push) and
+// the search from each added edge walks the whole time window up to the latest tail.  The path stays OPT-IN
+// (SF_AMD_PREC_INC=1; the parity tests run it).  What the numbers say is needed instead: one trial per LANE with private
+// scratch in HBM (64 independent dependent chains in flight per wave instead of one), see DESIGN.md §8.
+struct PrecInc {
+    int32_t* E;        // committed earliest starts (prec_eval)
+    uint32_t* LS;      // committed list successor
+    uint32_t* LP;      // committed list predecessor
+    int32_t* ET;       // trial earliest starts (valid where stamp_e == trial)
+    uint32_t* SE;
+    uint32_t* SQ;
+    uint32_t* CH;
+    uint32_t* Q1;
+    uint32_t* Q2;
+    uint32_t trial;    // stamp counters of this launch (wave-uniform)
+    uint32_t round;
+    int64_t pen_fixed; // const_penalty + unassigned nodes of the committed lists
+    uint32_t viol;     // wrong-owner items of the committed lists
+    int32_t mk;        // committed makespan (acyclic state)
+    uint32_t mk_count; // nodes whose finish equals it
+    int32_t ok;        // the committed state is acyclic: its earliest starts are valid
+};
+__device__ __forceinline__ uint32_t prec_writelane(uint32_t v, int k, uint32_t old) { return (int)(threadIdx.x & 63u) == k ? v : old; }
+struct PrecOverlay {   // lane k < n holds one node's new list neighbours
+    uint32_t key, pr, su;
+    uint32_t n;
+    __device__ __forceinline__ int find(uint32_t node) const {
+        const uint64_t m = __ballot((threadIdx.x & 63u) < n && key == node);
+        return m ? __ffsll((unsigned long long)m) - 1 : -1;
+    }
+    __device__ __forceinline__ int slot(uint32_t node, const PrecInc& st) {  // find or add (fields start as the committed neighbours)
+        int k = find(node);
+        if (k >= 0) return k;
+        k = (int)n;
+        const uint32_t p0 = PrecMemGlobal::ld(st.LP + node), s0 = PrecMemGlobal::ld(st.LS + node);
+        key = prec_writelane(node, k, key);
+        pr = prec_writelane(p0, k, pr);
+        su = prec_writelane(s0, k, su);
+        n += 1;
+        return k;
+    }
+    __device__ __forceinline__ uint32_t pred_of(uint32_t node, const PrecInc& st) const {
+        const int k = find(node);
+        return k >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)pr, k) : PrecMemGlobal::ld(st.LP + node);
+    }
+    __device__ __forceinline__ uint32_t succ_of(uint32_t node, const PrecInc& st) const {
+        const int k = find(node);
+        return k >= 0 ? (uint32_t)__builtin_amdgcn_readlane((int)su, k) : PrecMemGlobal::ld(st.LS + node);
+    }
+    __device__ __forceinline__ void set_pred(uint32_t node, uint32_t v, const PrecInc& st) {
+        if (node == PREC_NONE) return;
+        const int k = slot(node, st);
+        pr = prec_writelane(v, k, pr);
+    }
+    __device__ __forceinline__ void set_succ(uint32_t node, uint32_t v, const PrecInc& st) {
+        if (node == PREC_NONE) return;
+        const int k = slot(node, st);
+        su = prec_writelane(v, k, su);
+    }
+    // per-lane lookups (divergent node): the overlay entries are read through readlane, <= 8 of them
+    __device__ __forceinline__ uint32_t lane_pred(uint32_t node, const PrecInc& st) const {
+        uint32_t v = PrecMemGlobal::ld(st.LP + node);
+        for (uint32_t k = 0; k < n; ++k)
+            if ((uint32_t)__builtin_amdgcn_readlane((int)key, (int)k) == node) v = (uint32_t)__builtin_amdgcn_readlane((int)pr, (int)k);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t lane_succ(uint32_t node, const PrecInc& st) const {
+        uint32_t v = PrecMemGlobal::ld(st.LS + node);
+        for (uint32_t k = 0; k < n; ++k)
+            if ((uint32_t)__builtin_amdgcn_readlane((int)key, (int)k) == node) v = (uint32_t)__builtin_amdgcn_readlane((int)su, (int)k);
+        return v;
+    }
+};
+
+// Committed-state summary after a full evaluation: how many nodes attain the makespan.
+__device__ __forceinline__ uint32_t prec_count_makespan(const PrecModel& pm, const int32_t* E, int32_t mk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t c = 0;
+    for (uint32_t i = lane; i < (uint32_t)pm.n; i += 64) c += (PrecMemGlobal::ld(E + i) + pm.dur[i] == mk) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    return c;
+}
+
+// One trial: ck = 2 list change (a, i) -> (b, j) (j in pre-removal coordinates), ck = 3 list swap (a, i) <-> (b, j), against
+// the committed lists `visits` / `off`.  Returns false when the incremental path does not apply (the caller evaluates fully).
+template <class VT>
+__device__ __noinline__ bool prec_trial_inc(const PrecModel pm, PrecInc& st, const VT* visits, const uint32_t* off, int ck, uint32_t a, uint32_t i,
+                                            uint32_t b, uint32_t j, PrecResult& out) {
+    typedef PrecMemGlobal M;
+    if (!st.ok || (ck != 2 && ck != 3)) return false;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = (uint32_t)pm.n;
+    const uint32_t oa = off[a], la = off[a + 1] - oa, ob = off[b], lb = off[b + 1] - ob;
+    if (i >= la) return false;
+    const uint32_t x = (uint32_t)visits[oa + i];
+    PrecOverlay ov{PREC_NONE, PREC_NONE, PREC_NONE, 0u};
+    int32_t dviol = 0;
+    if (ck == 2) {
+        if (j > lb) return false;
+        if (a == b && (j == i || j == i + 1)) {  // the element stays where it is
+            out.penalty = st.pen_fixed + (int64_t)st.viol;
+            out.makespan = st.mk;
+            return true;
+        }
+        const uint32_t s = j < lb ? (uint32_t)visits[ob + j] : PREC_NONE;  // x goes in front of s (the end of the list when none)
+        const uint32_t p = M::ld(st.LP + x), q = M::ld(st.LS + x);
+        ov.set_succ(p, q, st);
+        ov.set_pred(q, p, st);
+        uint32_t r;  // the element in front of the slot once x is out
+        if (s != PREC_NONE)
+            r = ov.pred_of(s, st);
+        else {
+            r = lb ? (uint32_t)visits[ob + lb - 1] : PREC_NONE;
+            if (r == x) r = p;
+        }
+        ov.set_succ(r, x, st);
+        ov.set_pred(x, r, st);
+        ov.set_succ(x, s, st);
+        ov.set_pred(s, x, st);
+        if (pm.owner && a != b) {
+            const int32_t ow = pm.owner[x];
+            dviol = (ow >= 0 && (uint32_t)ow != b ? 1 : 0) - (ow >= 0 && (uint32_t)ow != a ? 1 : 0);
+        }
+    } else {
+        if (j >= lb) return false;
+        const uint32_t y = (uint32_t)visits[ob + j];
+        if (x == y) {
+            out.penalty = st.pen_fixed + (int64_t)st.viol;
+            out.makespan = st.mk;
+            return true;
+        }
+        const uint32_t px = M::ld(st.LP + x), qx = M::ld(st.LS + x), py = M::ld(st.LP + y), qy = M::ld(st.LS + y);
+        if (qx == y) {  // px x y qy -> px y x qy
+            ov.set_succ(px, y, st), ov.set_pred(y, px, st), ov.set_succ(y, x, st), ov.set_pred(x, y, st), ov.set_succ(x, qy, st), ov.set_pred(qy, x, st);
+        } else if (qy == x) {  // py y x qx -> py x y qx
+            ov.set_succ(py, x, st), ov.set_pred(x, py, st), ov.set_succ(x, y, st), ov.set_pred(y, x, st), ov.set_succ(y, qx, st), ov.set_pred(qx, y, st);
+        } else {
+            ov.set_succ(px, y, st), ov.set_pred(y, px, st), ov.set_succ(y, qx, st), ov.set_pred(qx, y, st);
+            ov.set_succ(py, x, st), ov.set_pred(x, py, st), ov.set_succ(x, qy, st), ov.set_pred(qy, x, st);
+        }
+        if (pm.owner && a != b) {
+            const int32_t ox = pm.owner[x], oy = pm.owner[y];
+            dviol = (ox >= 0 && (uint32_t)ox != b ? 1 : 0) - (ox >= 0 && (uint32_t)ox != a ? 1 : 0) + (oy >= 0 && (uint32_t)oy != a ? 1 : 0) -
+                    (oy >= 0 && (uint32_t)oy != b ? 1 : 0);
+        }
+    }
+    const int64_t pen_ok = st.pen_fixed + (int64_t)((int32_t)st.viol + dviol);
+    // added edges (u -> su'[u] where it differs from the committed successor) and the pruning bound: the latest tail
+    const bool mine = lane < ov.n;
+    const uint32_t old_su = mine ? M::ld(st.LS + ov.key) : PREC_NONE;
+    const bool added = mine && ov.su != PREC_NONE && ov.su != old_su;
+    const uint64_t added_m = __ballot(added);
+    int32_t tb = added ? M::ld(st.E + ov.key) : INT32_MIN;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t other = __shfl_xor(tb, o);
+        tb = other > tb ? other : tb;
+    }
+    const uint64_t tails_m = added_m;
+    // ---- cycle test: from the head of every added edge, is its tail reachable in the new graph? ----
+    bool cyclic = false;
+    for (uint64_t em = added_m; em && !cyclic; em &= em - 1) {
+        const int k = __ffsll((unsigned long long)em) - 1;
+        const uint32_t tail = (uint32_t)__builtin_amdgcn_readlane((int)ov.key, k), head = (uint32_t)__builtin_amdgcn_readlane((int)ov.su, k);
+        st.round += 1;
+        const uint32_t mark = st.round;
+        uint32_t* cur = st.Q1;
+        uint32_t* nxt = st.Q2;
+        uint32_t ncur = 1;
+        if (lane == 0) {
+            M::st(cur, head);
+            M::st(st.SQ + head, mark);
+        }
+        if (head == tail) cyclic = true;
+        prec_sync();
+        while (ncur && !cyclic) {
+            uint32_t nnext = 0;
+            for (uint32_t base = 0; base < ncur && !cyclic; base += 64) {
+                const bool act = base + lane < ncur;
+                uint32_t w = 0, so = 0, deg = 0, ls = PREC_NONE;
+                if (act) {
+                    w = M::ld(cur + base + lane);
+                    so = pm.succ_off[w];
+                    deg = pm.succ_off[w + 1] - so;
+                    ls = ov.lane_succ(w, st);
+                }
+                const uint32_t degt = deg + ((act && ls != PREC_NONE) ? 1u : 0u);
+                for (uint32_t t = 0;; ++t) {
+                    const bool has = t < degt;
+                    if (!__ballot(has)) break;
+                    bool push = false, hit = false;
+                    uint32_t sx = 0;
+                    if (has) {
+                        sx = t < deg ? pm.succ[so + t] : ls;
+                        hit = sx == tail;
+                        if (!hit) {
+                            // a node that is no tail and finishes after every tail started cannot reach one
+                            bool is_tail = false;
+                            for (uint64_t tm = tails_m; tm; tm &= tm - 1)
+                                is_tail = is_tail || (uint32_t)__builtin_amdgcn_readlane((int)ov.key, __ffsll((unsigned long long)tm) - 1) == sx;
+                            const bool prune = !is_tail && M::ld(st.E + sx) + pm.dur[sx] > tb;
+                            if (!prune) push = __hip_atomic_exchange(st.SQ + sx, mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mark;
+                        }
+                    }
+                    if (__ballot(hit)) cyclic = true;
+                    const uint64_t pm_ = __ballot(push);
+                    if (push) M::st(nxt + nnext + prec_mbcnt(pm_), sx);
+                    nnext += (uint32_t)__popcll(pm_);
+                }
+            }
+            prec_sync();
+            uint32_t* t2 = cur;
+            cur = nxt;
+            nxt = t2;
+            ncur = nnext;
+        }
+    }
+    if (cyclic) {
+        out.penalty = pen_ok + (int64_t)n;
+        out.makespan = 0;
+        return true;
+    }
+    // ---- refresh: the nodes whose list predecessor changed, then whatever their new earliest start reaches ----
+    st.trial += 1;
+    const uint32_t tr = st.trial;
+    uint32_t* cur = st.Q1;
+    uint32_t* nxt = st.Q2;
+    const bool seed = mine && ov.pr != M::ld(st.LP + ov.key);
+    const uint64_t seed_m = __ballot(seed);
+    if (seed) M::st(cur + prec_mbcnt(seed_m), ov.key);
+    uint32_t ncur = (uint32_t)__popcll(seed_m), nch = 0, lost = 0, rounds = 0;
+    prec_sync();
+    while (ncur) {
+        if (++rounds > n + 2u) {  // cannot happen on an acyclic graph (a longest path has at most n nodes): never spin on the device
+            out.penalty = pen_ok + (int64_t)n;
+            out.makespan = 0;
+            return true;
+        }
+        st.round += 1;
+        const uint32_t mark = st.round;
+        uint32_t nnext = 0;
+        for (uint32_t base = 0; base < ncur; base += 64) {
+            const bool act = base + lane < ncur;
+            uint32_t w = 0;
+            int32_t ne = 0, oldv = 0;
+            bool changed = false, first = false;
+            if (act) {
+                w = M::ld(cur + base + lane);
+                const uint32_t lp = ov.lane_pred(w, st);
+                if (lp != PREC_NONE) ne = (M::ld(st.SE + lp) == tr ? M::ld(st.ET + lp) : M::ld(st.E + lp)) + pm.dur[lp];
+                for (uint32_t t = pm.pred_off[w]; t < pm.pred_off[w + 1]; ++t) {
+                    const uint32_t pp = pm.pred[t];
+                    const int32_t f = (M::ld(st.SE + pp) == tr ? M::ld(st.ET + pp) : M::ld(st.E + pp)) + pm.dur[pp];
+                    ne = f > ne ? f : ne;
+                }
+                first = M::ld(st.SE + w) != tr;
+                oldv = first ? M::ld(st.E + w) : M::ld(st.ET + w);
+                changed = ne != oldv;
+                if (changed) {
+                    M::st(st.ET + w, ne);
+                    M::st(st.SE + w, tr);
+                }
+            }
+            const uint64_t first_m = __ballot(changed && first);
+            if (changed && first) {
+                M::st(st.CH + nch + prec_mbcnt(first_m), w);
+                lost += (oldv + pm.dur[w] == st.mk) ? 1u : 0u;
+            }
+            nch += (uint32_t)__popcll(first_m);
+            uint32_t so = 0, deg = 0, ls = PREC_NONE;
+            if (changed) {
+                so = pm.succ_off[w];
+                deg = pm.succ_off[w + 1] - so;
+                ls = ov.lane_succ(w, st);
+            }
+            const uint32_t degt = deg + ((changed && ls != PREC_NONE) ? 1u : 0u);
+            for (uint32_t t = 0;; ++t) {
+                const bool has = t < degt;
+                if (!__ballot(has)) break;
+                bool push = false;
+                uint32_t sx = 0;
+                if (has) {
+                    sx = t < deg ? pm.succ[so + t] : ls;
+                    push = __hip_atomic_exchange(st.SQ + sx, mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mark;
+                }
+                const uint64_t pm_ = __ballot(push);
+                if (push) M::st(nxt + nnext + prec_mbcnt(pm_), sx);
+                nnext += (uint32_t)__popcll(pm_);
+            }
+        }
+        prec_sync();
+        uint32_t* t2 = cur;
+        cur = nxt;
+        nxt = t2;
+        ncur = nnext;
+    }
+    // ---- makespan of the view ----
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lost += (uint32_t)__shfl_xor((int)lost, o);
+    int32_t mk = INT32_MIN;
+    for (uint32_t t = lane; t < nch; t += 64) {
+        const uint32_t w = M::ld(st.CH + t);
+        const int32_t f = M::ld(st.ET + w) + pm.dur[w];
+        mk = f > mk ? f : mk;
+    }
+    if (lost < st.mk_count) {  // some node still attains the committed makespan
+        mk = st.mk > mk ? st.mk : mk;
+    } else {  // every node that attained it moved: scan the view
+        for (uint32_t w = lane; w < n; w += 64) {
+            const int32_t f = (M::ld(st.SE + w) == tr ? M::ld(st.ET + w) : M::ld(st.E + w)) + pm.dur[w];
+            mk = f > mk ? f : mk;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t other = __shfl_xor(mk, o);
+        mk = other > mk ? other : mk;
+    }
+    out.penalty = pen_ok;
+    out.makespan = mk < 0 ? 0 : (int64_t)mk;
+    return true;
 }
 
 }  // namespace sf

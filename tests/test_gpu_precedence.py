@@ -6,6 +6,20 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["lds", "hbm", "hbm_incremental"])
+def scratch_mode(request, monkeypatch):
+    """Every test runs with the constraint's scratch in the replica's LDS slice (small graphs), forced into HBM (the layout of
+    large graphs: one full evaluation per trial) and in HBM with the opt-in incremental refresh of list change / swap trials
+    (prec_trial_inc); the library reads SF_AMD_PREC_HBM / SF_AMD_PREC_INC at every launch."""
+    monkeypatch.delenv("SF_AMD_PREC_HBM", raising=False)
+    monkeypatch.delenv("SF_AMD_PREC_INC", raising=False)
+    if request.param != "lds":
+        monkeypatch.setenv("SF_AMD_PREC_HBM", "1")
+    if request.param == "hbm_incremental":
+        monkeypatch.setenv("SF_AMD_PREC_INC", "1")
+    return request.param
+
 LEAF_BITS = {"list_change": 4, "list_swap": 8, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512}
 
 
