@@ -479,11 +479,6 @@ def main():
             # ~2 % of peak, see hbm_frac).  Peaks: VALU 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction; SALU one scalar
             # unit per CU issuing 1 instruction per clock; LDS 1 wave-instruction per 2 clocks per CU (ds_read_b32 rate).
             fr = {"valu-issue": (valu, VALU_PEAK), "salu-issue": (salu, SALU_PEAK), "lds-issue": (lds, LDS_PEAK)}
-            bound = max(fr, key=lambda k: fr[k][0] / fr[k][1])
-            roof["bound"] = bound
-            roof["achieved"] = fr[bound][0] / 1e9
-            roof["peak"] = fr[bound][1] / 1e9
-            roof["frac"] = fr[bound][0] / fr[bound][1]
             roof["valu_frac"] = valu / VALU_PEAK
             roof["salu_frac"] = salu / SALU_PEAK
             roof["lds_issue_frac"] = lds / LDS_PEAK
@@ -492,6 +487,15 @@ def main():
                 traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
                 roof["traffic"] = traffic
                 roof["hbm_frac"] = traffic / launch_s / 1e9 / HBM_PEAK_GBS
+                # the measured memory-side traffic competes with the issue rooflines for `bound`: at CVRP-5000 the facts (100 MB matrix,
+                # 50 MB neighbour index) no longer fit the L2s and HBM is the tightest one
+                fr["hbm"] = (traffic / launch_s, HBM_PEAK_GBS * 1e9)
+            bound = max(fr, key=lambda k: fr[k][0] / fr[k][1])
+            roof["bound"] = bound
+            roof["achieved"] = fr[bound][0] / 1e9
+            roof["peak"] = fr[bound][1] / 1e9
+            roof["unit"] = "GB/s" if bound == "hbm" else "G wave-instr/s"
+            roof["frac"] = fr[bound][0] / fr[bound][1]
             if pmc.get("SQ_WAVE_CYCLES"):
                 wc = pmc["SQ_WAVE_CYCLES"]
                 roof["wave_cycle_shares"] = {"active": pmc.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wait_mem": pmc.get("SQ_WAIT_ANY", 0) / wc,
@@ -500,7 +504,7 @@ def main():
                 roof["effective_clock_ghz"] = pmc["SQ_BUSY_CYCLES"] / 32.0 / launch_s / 1e9
             roof["counters_per_launch"] = {k: pmc[k] for k in sorted(pmc)}
         roof.update({
-            "pmc_source": pmc_source, "kernel": kernel + ("<2,false,true>" if engine == "wave" else "<2,false>"),
+            "pmc_source": pmc_source, "kernel": (pmc_info or {}).get("kernel") or kernel,
             "kernel_resources": pmc_info or None, "avg_launch_ms": avg_launch_ms, "launches": launches,
             "candidates_scored_per_launch": scored_local / max(launches, 1),
             "sources_scanned_per_launch": delta["sources_scanned"] / max(launches, 1),

@@ -963,15 +963,43 @@ static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid, bo
 }
 template <int L>
 static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas, bool trace) {
-    WCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx));
-    int wpb = (int)((SF_LDS_BUDGET) / cv.total);  // replicas (waves) per workgroup: as many as the LDS holds, <= WPB
-    if (wpb > WPB) wpb = WPB;
-    size_t lds = cv.total * wpb;
     const bool fast = !trace && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
                       p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
+    // replicas (waves) per workgroup: as many as the LDS holds, <= WPB; resident replicas per CU = whole workgroups in 160 KiB
+    auto plan = [&](bool compact, int& wpb_out, size_t& lds_out) {
+        WCarve cvx(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx), compact);
+        size_t best = 0;
+        wpb_out = 1;
+        for (int w = 1; w <= WPB; ++w) {  // the workgroup size that keeps the most replicas resident (a workgroup's LDS is allocated whole)
+            const size_t per_wg = cvx.total * (size_t)w + 1024;  // + the static annealing state
+            if (cvx.total * (size_t)w > SF_LDS_BUDGET) break;
+            size_t groups = (160 * 1024) / per_wg;
+            if (groups * (size_t)w > 16) groups = 16 / (size_t)w;  // 16 waves per CU by register budget
+            if (groups * (size_t)w >= best) {
+                best = groups * (size_t)w;
+                wpb_out = w;
+            }
+        }
+        lds_out = cvx.total * (size_t)wpb_out;
+        return best;
+    };
+    int wpb = 1;
+    size_t lds = 0;
+    const size_t resident_wide = plan(false, wpb, lds);
+    int mode = fast ? (ctx->lm_small ? 2 : 1) : 0;
+    if (mode == 2 && node_slot_compact_ok(ctx->lm.V)) {  // the COMPACT slice when it puts more replicas on a CU (CVRP-5000: 5 instead of 3)
+        static const bool no_compact = std::getenv("SF_AMD_NO_COMPACT") != nullptr;  // diagnostics: A/B
+        int wpb_c = 1;
+        size_t lds_c = 0;
+        if (!no_compact && plan(true, wpb_c, lds_c) > resident_wide) {
+            mode = 3;
+            wpb = wpb_c;
+            lds = lds_c;
+        }
+    }
     SearchParams q = p;
     q.n_launch = n_replicas;
-    HIPCHK(ctx, launch_tu_list_wave<L>(trace, fast ? (ctx->lm_small ? 2 : 1) : 0, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, lds)));
+    HIPCHK(ctx, launch_tu_list_wave<L>(trace, mode, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, lds)));
     return SF_OK;
 }
 static int launch_list_wave(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {

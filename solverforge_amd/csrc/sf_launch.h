@@ -27,7 +27,8 @@ struct SearchLaunch {
 // block engine: k_list_search<L, TRACE>
 template <int L>
 hipError_t launch_tu_list_block(bool trace, const SearchLaunch& a);
-// wave engine: k_list_search_wave<L, TRACE, MODE> (mode 1 / 2 = the FAST instantiations, never traced)
+// wave engine: k_list_search_wave<L, TRACE, MODE, COMPACT> (mode 1 / 2 = the FAST instantiations, never traced; 3 = MODE 2 in the
+// COMPACT LDS layout)
 template <int L>
 hipError_t launch_tu_list_wave(bool trace, int mode, const SearchLaunch& a);
 // scalar engine: k_scalar_search_wave<L, TRACE, VT>, VT = int8_t (VTB 1) or int16_t (VTB 2)

@@ -211,9 +211,9 @@ __device__ __forceinline__ ListDelta eval_list_swap(const ListModel& m, const VT
 // most eight signed matrix legs whose gathers are all issued together (one memory round trip per
 // 64-candidate batch, no divergence between change and swap lanes).  Same results as
 // eval_list_change / eval_list_swap (wrapping i64 sums are order-independent).
-template <class VT, bool M32>
+template <class VT, bool M32, class LT = int64_t>
 __device__ __forceinline__ ListDelta eval_list_move_legs(const ListModel& m, const VT* visits, const uint32_t* off,
-                                                         const int64_t* load, bool is_change, uint32_t a,
+                                                         const LT* load, bool is_change, uint32_t a,
                                                          uint32_t i, uint32_t b, uint32_t j) {
     ListDelta r{0, 0, false};
     const uint32_t oa = off[a], la = off[a + 1] - oa;

@@ -22,6 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "sf_list_model.h"
 
 namespace sf {
@@ -104,15 +106,17 @@ __global__ __launch_bounds__(256) void k_nbr_presort(const int64_t* __restrict__
 struct WCarve {
     size_t load, off, node, ring, visits, rtab, routeat, total;
     uint32_t rc;  // ring capacity per leaf
-    __host__ __device__ WCarve(int V, int n_cap, int dim, int max_k) {
+    // compact: the COMPACT instantiation's layout -- per-list loads as int32 (MODE 2 guarantees the range) and the node -> slot
+    // table as 16 bits per node (NodeSlotT<true>): CVRP-5000 / 500 drops from 43 KB to 31 KB per replica (3 -> 5 replicas per CU)
+    __host__ __device__ WCarve(int V, int n_cap, int dim, int max_k, bool compact = false) {
         rc = max_k <= 32 ? RC_SMALL : RC_MAX;
         size_t o = 0;
         load = o;
-        o = align_up(o + sizeof(int64_t) * V, 16);
+        o = align_up(o + (compact ? sizeof(int32_t) : sizeof(int64_t)) * V, 16);
         off = o;
         o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
         node = o;
-        o = align_up(o + sizeof(uint32_t) * dim, 16);
+        o = align_up(o + (compact ? sizeof(uint16_t) : sizeof(uint32_t)) * dim, 16);
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * rc * MAX_LEAVES, 16);
         visits = o;
@@ -124,6 +128,52 @@ struct WCarve {
         total = o;
     }
 };
+
+// node -> (route << 16 | position) of the replica's current lists.  Wide: one u32 per node.  Compact: one u16 per node,
+// route in the top `rb` bits and the position below; a position that does not fit the field is stored as the field's maximum
+// and found by scanning the route from there (routes that long are rare: the field holds 127 positions at 500 routes, 511 at
+// 100); the all-ones pattern means "in no list".  get() returns the wide form either way.
+template <bool COMPACT>
+struct NodeSlotT;
+template <>
+struct NodeSlotT<false> {
+    uint32_t* p;
+    __device__ __forceinline__ NodeSlotT(unsigned char* base, int, const uint16_t*, const uint32_t*) : p((uint32_t*)base) {}
+    __device__ __forceinline__ void clear(uint32_t node) const { p[node] = NODE_NONE; }
+    __device__ __forceinline__ void set(uint32_t node, uint32_t route, uint32_t pos) const { p[node] = (route << 16) | pos; }
+    __device__ __forceinline__ uint32_t get(uint32_t node) const { return p[node]; }
+};
+template <>
+struct NodeSlotT<true> {
+    uint16_t* p;
+    const uint16_t* visits;
+    const uint32_t* off;
+    uint32_t pb, pmax;  // position bits, the saturated position
+    __device__ __forceinline__ NodeSlotT(unsigned char* base, int V, const uint16_t* visits_, const uint32_t* off_)
+        : p((uint16_t*)base), visits(visits_), off(off_) {
+        uint32_t rb = 1;
+        while ((1u << rb) - 1u < (uint32_t)V) ++rb;  // route ids 0 .. V - 1, the all-ones route is "none"
+        pb = 16u - rb;
+        pmax = (1u << pb) - 1u;
+    }
+    __device__ __forceinline__ void clear(uint32_t node) const { p[node] = 0xFFFFu; }
+    __device__ __forceinline__ void set(uint32_t node, uint32_t route, uint32_t pos) const {
+        p[node] = (uint16_t)((route << pb) | (pos < pmax ? pos : pmax));
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t node) const {
+        const uint32_t s = p[node];
+        if (s == 0xFFFFu) return NODE_NONE;
+        const uint32_t route = s >> pb;
+        uint32_t pos = s & pmax;
+        if (pos == pmax) {  // saturated: the node sits at position >= pmax of its route
+            const uint32_t o = off[route], len = off[route + 1] - o;
+            while (pos + 1 < len && (uint32_t)visits[o + pos] != node) ++pos;
+        }
+        return (route << 16) | pos;
+    }
+};
+// does the compact layout carry this model?  route ids need a bit pattern below all-ones, positions at least 6 bits
+__host__ __device__ inline bool node_slot_compact_ok(int V) { return V >= 1 && V <= 1022; }
 
 // One neighbour-row entry seen from source (se, sp) of a leaf: up to two consecutive keys
 // (destination slot dp, and the end slot of its route when the node is the last element).
@@ -200,8 +250,9 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 }
 
 // Committed move application on the wave's LDS state (ListChange / ListSwap do_move).
+template <class LT>  // LT = the replica's per-list load type in LDS: int64_t, or int32_t in the COMPACT wave layout
 __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_t* visits, uint32_t* off,
-                                                     int64_t* load, int kind, uint32_t a, uint32_t i, uint32_t b,
+                                                     LT* load, int kind, uint32_t a, uint32_t i, uint32_t b,
                                                      uint32_t j, uint32_t ext = 0) {
     const uint32_t lane = threadIdx.x & 63u;
     if (kind == 2) {
@@ -236,8 +287,8 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
             }
             if (lane == 0 && m.demand) {
                 const int64_t dx = (int64_t)m.demand[x];
-                load[a] = wsub(load[a], dx);
-                load[b] = wadd(load[b], dx);
+                load[a] = (LT)wsub(load[a], dx);
+                load[b] = (LT)wadd(load[b], dx);
             }
         }
     } else if (kind == 6) {  // sublist swap: [i, i + (ext & 0xFFFF)) of a <-> [j, j + (ext >> 16)) of b
@@ -258,8 +309,8 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
             for (uint32_t rr = lane; rr <= (uint32_t)m.V; rr += 64)
                 if (rr > ox && rr <= oy) off[rr] = off[rr] + zy - zx;
             if (lane == 0 && m.demand) {
-                load[a] = wadd(wsub(load[a], da), db);
-                load[b] = wadd(wsub(load[b], db), da);
+                load[a] = (LT)wadd(wsub(load[a], da), db);
+                load[b] = (LT)wadd(wsub(load[b], db), da);
             }
         }
     } else if (kind == 5) {  // sublist change: segment [i, ext) of list a -> list b at j
@@ -276,8 +327,8 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
                 if (a > b && rr > b && rr <= a) off[rr] += z;
             }
             if (lane == 0 && m.demand) {
-                load[a] = wsub(load[a], dsum);
-                load[b] = wadd(load[b], dsum);
+                load[a] = (LT)wsub(load[a], dsum);
+                load[b] = (LT)wadd(load[b], dsum);
             }
         }
     } else if (kind == 4) {  // reverse [i, j) of list a
@@ -316,8 +367,8 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
             visits[pb] = x;
             if (a != b && m.demand) {
                 const int64_t dx = (int64_t)m.demand[x], dy = (int64_t)m.demand[y];
-                load[a] = wadd(wsub(load[a], dx), dy);
-                load[b] = wadd(wsub(load[b], dy), dx);
+                load[a] = (LT)wadd(wsub(load[a], dx), dy);
+                load[b] = (LT)wadd(wsub(load[b], dy), dx);
             }
         }
     }
@@ -471,8 +522,8 @@ __device__ __forceinline__ int32_t clamp_i64_to_i32(int64_t v) {
 // eval_list_move_legs, laid out as four "plus" and four "minus" legs so no lane multiplies by a sign, gathered from
 // the compact u32 matrix through 32-bit byte offsets; every leg finite (host-checked), sums < 2^30.
 // dv[k] = change of score level k.  Returns doable.
-template <int L>
-__device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const uint16_t* visits, const uint32_t* off, const int64_t* load,
+template <int L, class LT>
+__device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const uint16_t* visits, const uint32_t* off, const LT* load,
                                                      bool chg, uint32_t a, uint32_t i, uint32_t b, uint32_t j, int32_t (&dv)[L]) {
 #pragma unroll
     for (int k = 0; k < L; ++k) dv[k] = 0;
@@ -573,12 +624,16 @@ struct LeafCursor {
 // in DELTA space — a candidate is the int32 change of each score level against the step's (wave-uniform) current score,
 // `score >= late` becomes `delta >= late - current` with the right-hand side clamped once per step — so no lane carries a
 // 64-bit score vector; the committed score is advanced by the winner's delta.  Same decisions bit for bit.
-template <int L, bool TRACE, int MODE>
+// COMPACT (with MODE 2 only): the replica's LDS slice in the compact layout of WCarve, chosen by the host when it lets more
+// replicas share a CU (CVRP-5000: 5 instead of 3).
+template <int L, bool TRACE, int MODE, bool COMPACT = false>
 #ifndef SF_WAVES_PER_EU
 #define SF_WAVES_PER_EU 4
 #endif
 __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     constexpr bool FAST = MODE >= 1, SMALL = MODE == 2;
+    static_assert(!COMPACT || SMALL, "COMPACT stores loads in 32 bits: MODE 2 only");
+    using LT = typename std::conditional<COMPACT, int32_t, int64_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));  // 1..WPB replicas per workgroup
@@ -600,14 +655,14 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         if (annealing) sa_load(saw, p.sa, r, lane);
     const uint64_t desc0 = (uint64_t)p.leaf[0].descriptor, desc1 = n_leaves > 1 ? (uint64_t)p.leaf[1].descriptor : 0;
 
-    const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1));
+    const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1), COMPACT);
     const uint32_t RCM = cv.rc - 1;
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
-    int64_t* s_load = (int64_t*)(mem + cv.load);
+    LT* s_load = (LT*)(mem + cv.load);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
-    uint32_t* node_slot = (uint32_t*)(mem + cv.node);
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][rc][2]
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
+    const NodeSlotT<COMPACT> node_slot(mem + cv.node, V, s_visits, s_off);
     uint32_t* rtab = (uint32_t*)(mem + cv.rtab);      // [leaf][route] rank | first slot ordinal << 16
     uint16_t* route_at = (uint16_t*)(mem + cv.routeat);  // [leaf][rank] -> route
 
@@ -619,15 +674,15 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
 
     // ---- load replica state into LDS ----
     for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
-    for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = g_load[t];
-    for (uint32_t t = lane; t < dim; t += 64) node_slot[t] = NODE_NONE;
+    for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = (LT)g_load[t];
+    for (uint32_t t = lane; t < dim; t += 64) node_slot.clear(t);
     wave_sync();
     const uint32_t total0 = uni(s_off[V]);
     for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = (uint16_t)g_visits[t];
     wave_sync();
     for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
         const uint32_t o = s_off[v], len = s_off[v + 1] - o;
-        for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
+        for (uint32_t q = 0; q < len; ++q) node_slot.set(s_visits[o + q], v, q);
     }
     wave_sync();
 
@@ -822,7 +877,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                     const uint64_t havemask = __ballot(have);
                     if (havemask == 0) break;  // finite entries of the row exhausted
                     NearbyItem it{0u, 0u, 0u, 0u};
-                    if (have) it = nearby_item_rt(is_change, node_slot[key & NBR_NODE_MASK], se, sp, len, k, s_off, rt);
+                    if (have) it = nearby_item_rt(is_change, node_slot.get(key & NBR_NODE_MASK), se, sp, len, k, s_off, rt);
                     // equal-distance groups are contiguous lane ranges; the index marks entries that
                     // continue the previous entry's distance
                     const uint64_t startmask = __ballot(have && (lane == 0 || !(key & NBR_SAME_FLAG)));
@@ -839,7 +894,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                             uint64_t hk = 0;
                             if (ky != NBR_END) {
                                 const uint32_t y2 = ky & NBR_NODE_MASK;
-                                i2 = nearby_item_rt(is_change, node_slot[y2], se, sp, len, k, s_off, rt);
+                                i2 = nearby_item_rt(is_change, node_slot.get(y2), se, sp, len, k, s_off, rt);
                                 hk = (uint64_t)m.mat[(size_t)sx * dim + y2] << 24;  // finite by construction of the index
                             }
                             if (!__ballot(ky != NBR_END)) break;
@@ -926,7 +981,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                     const bool have = key != NBR_END;
                     NearbyItem it{0u, 0u, 0u, 0u};
                     {
-                        const uint32_t slot = have ? node_slot[key & NBR_NODE_MASK] : NODE_NONE;
+                        const uint32_t slot = have ? node_slot.get(key & NBR_NODE_MASK) : NODE_NONE;
                         const uint32_t* rth = rtab + (hi ? V : 0);
                         const NearbyItem ic = nearby_item_rt(true, slot, se, sp, len, kk, s_off, rth);
                         const NearbyItem is = nearby_item_rt(false, slot, se, sp, len, kk, s_off, rth);
@@ -1266,9 +1321,9 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
                 const uint32_t ob = s_off[b], lb = s_off[b + 1] - ob;
                 for (uint32_t t = lane; t < la + (a != b ? lb : 0u); t += 64) {
                     if (t < la)
-                        node_slot[s_visits[oa + t]] = (a << 16) | t;
+                        node_slot.set(s_visits[oa + t], a, t);
                     else
-                        node_slot[s_visits[ob + (t - la)]] = (b << 16) | (t - la);
+                        node_slot.set(s_visits[ob + (t - la)], b, t - la);
                 }
             }
             wave_sync();
@@ -1335,7 +1390,7 @@ __global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(
         }
         for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
         for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
-        for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = s_load[t];
+        for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = (int64_t)s_load[t];
         if (lane == 0) {
 #pragma unroll
             for (int kk = 0; kk < L; ++kk) {
