@@ -235,7 +235,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=4096, help="independent searches resident per GPU")
+    ap.add_argument("--replicas", type=int, default=5120,
+                    help="independent searches resident per GPU (5120 = 20 per CU: the COMPACT wave kernel runs 5 waves per SIMD at CVRP-1000)")
     ap.add_argument("--ls-steps", type=int, default=200, help="local-search steps per launch")
     ap.add_argument("--customers", type=int, default=1000)
     ap.add_argument("--vehicles", type=int, default=100)

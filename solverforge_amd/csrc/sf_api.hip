@@ -966,7 +966,7 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
     const bool fast = !trace && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
                       p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
     // replicas (waves) per workgroup: as many as the LDS holds, <= WPB; resident replicas per CU = whole workgroups in 160 KiB
-    auto plan = [&](bool compact, int& wpb_out, size_t& lds_out) {
+    auto plan = [&](bool compact, size_t wave_cap, int& wpb_out, size_t& lds_out) {
         WCarve cvx(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx), compact);
         size_t best = 0;
         wpb_out = 1;
@@ -974,7 +974,7 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
             const size_t per_wg = cvx.total * (size_t)w + 1024;  // + the static annealing state
             if (cvx.total * (size_t)w > SF_LDS_BUDGET) break;
             size_t groups = (160 * 1024) / per_wg;
-            if (groups * (size_t)w > 16) groups = 16 / (size_t)w;  // 16 waves per CU by register budget
+            if (groups * (size_t)w > wave_cap) groups = wave_cap / (size_t)w;  // waves per CU by register budget
             if (groups * (size_t)w >= best) {
                 best = groups * (size_t)w;
                 wpb_out = w;
@@ -985,13 +985,20 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
     };
     int wpb = 1;
     size_t lds = 0;
-    const size_t resident_wide = plan(false, wpb, lds);
+    const size_t resident_wide = plan(false, 4 * SF_WAVES_PER_EU, wpb, lds);
     int mode = fast ? (ctx->lm_small ? 2 : 1) : 0;
-    if (mode == 2 && node_slot_compact_ok(ctx->lm.V)) {  // the COMPACT slice when it puts more replicas on a CU (CVRP-5000: 5 instead of 3)
+    if (mode == 2 && node_slot_compact_ok(ctx->lm.V)) {
+        // the COMPACT slice when it puts more replicas on a CU: CVRP-5000 5 instead of 3 (LDS-bound, compiled for 4 waves per SIMD);
+        // CVRP-1000 20 instead of 16 with the instantiation compiled for 5 waves per SIMD
         static const bool no_compact = std::getenv("SF_AMD_NO_COMPACT") != nullptr;  // diagnostics: A/B
         int wpb_c = 1;
         size_t lds_c = 0;
-        if (!no_compact && plan(true, wpb_c, lds_c) > resident_wide) {
+        const size_t r5 = no_compact ? 0 : plan(true, 20, wpb_c, lds_c);
+        if (r5 > 16 && r5 > resident_wide) {
+            mode = 4;
+            wpb = wpb_c;
+            lds = lds_c;
+        } else if (!no_compact && plan(true, 4 * SF_WAVES_PER_EU, wpb_c, lds_c) > resident_wide) {
             mode = 3;
             wpb = wpb_c;
             lds = lds_c;

@@ -28,7 +28,7 @@ struct SearchLaunch {
 template <int L>
 hipError_t launch_tu_list_block(bool trace, const SearchLaunch& a);
 // wave engine: k_list_search_wave<L, TRACE, MODE, COMPACT> (mode 1 / 2 = the FAST instantiations, never traced; 3 = MODE 2 in the
-// COMPACT LDS layout)
+// COMPACT LDS layout, 4 = the same compiled for 5 waves per SIMD)
 template <int L>
 hipError_t launch_tu_list_wave(bool trace, int mode, const SearchLaunch& a);
 // scalar engine: k_scalar_search_wave<L, TRACE, VT>, VT = int8_t (VTB 1) or int16_t (VTB 2)

@@ -624,13 +624,15 @@ struct LeafCursor {
 // in DELTA space — a candidate is the int32 change of each score level against the step's (wave-uniform) current score,
 // `score >= late` becomes `delta >= late - current` with the right-hand side clamped once per step — so no lane carries a
 // 64-bit score vector; the committed score is advanced by the winner's delta.  Same decisions bit for bit.
-// COMPACT (with MODE 2 only): the replica's LDS slice in the compact layout of WCarve, chosen by the host when it lets more
-// replicas share a CU (CVRP-5000: 5 instead of 3).
-template <int L, bool TRACE, int MODE, bool COMPACT = false>
 #ifndef SF_WAVES_PER_EU
 #define SF_WAVES_PER_EU 4
 #endif
-__global__ __launch_bounds__(64 * WPB, SF_WAVES_PER_EU) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
+// COMPACT (with MODE 2 only): the replica's LDS slice in the compact layout of WCarve, chosen by the host when it lets more
+// replicas share a CU (CVRP-5000: 5 instead of 3).
+// WPE = waves per SIMD the kernel is compiled for (512 / WPE VGPRs): 4, or 5 for the COMPACT slice of a model small enough for 20
+// replicas per CU (CVRP-1000: 96 VGPRs + 120 B of scratch, +5 % over 4 waves; 6 waves / 80 VGPRs measured -11 %).
+template <int L, bool TRACE, int MODE, bool COMPACT = false, int WPE = SF_WAVES_PER_EU>
+__global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     constexpr bool FAST = MODE >= 1, SMALL = MODE == 2;
     static_assert(!COMPACT || SMALL, "COMPACT stores loads in 32 bits: MODE 2 only");
     using LT = typename std::conditional<COMPACT, int32_t, int64_t>::type;
