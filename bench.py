@@ -187,21 +187,30 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
             d = os.path.join(base, f"pmc_{i}")
             cmd = [exe, "--pmc"] + grp + ["-f", "csv", "-d", d, "-o", "b", "--", sys.executable,
                                             os.path.abspath(__file__)] + argv + ["--pmc-child"]
-            # own process group: a pass that hangs is killed together with the profiled grandchild
-            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
-                                  start_new_session=True)
-            try:
-                _, err = pr.communicate(timeout=timeout_s)
-            except subprocess.TimeoutExpired:
+            # own process group: a pass that hangs is killed together with the profiled grandchild.  rocprofv3 counter passes hang
+            # now and then on this pool (a pass takes ~10 s when it works): one retry per pass before its counters are given up.
+            ok = False
+            for attempt in range(2):
+                shutil.rmtree(d, ignore_errors=True)
+                pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                      start_new_session=True)
                 try:
-                    os.killpg(pr.pid, 9)
-                except OSError:
-                    pass
-                pr.wait()
-                failed.append(f"{'+'.join(grp)}: timed out after {timeout_s}s")
-                continue
-            if pr.returncode != 0:
-                failed.append(f"{'+'.join(grp)}: rc={pr.returncode} {err.decode(errors='replace')[-160:]}")
+                    _, err = pr.communicate(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    try:
+                        os.killpg(pr.pid, 9)
+                    except OSError:
+                        pass
+                    pr.wait()
+                    why = f"{'+'.join(grp)}: timed out after {timeout_s}s (attempt {attempt + 1})"
+                    continue
+                if pr.returncode != 0:
+                    why = f"{'+'.join(grp)}: rc={pr.returncode} {err.decode(errors='replace')[-160:]} (attempt {attempt + 1})"
+                    continue
+                ok = True
+                break
+            if not ok:
+                failed.append(why)
                 continue
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             per = {}
@@ -464,7 +473,7 @@ def main():
                       "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
         if world == 1 and not args.no_pmc:
-            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=90)
+            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=60)
             if pmc is None:  # no counters, no roofline: the line says so instead of quoting an older profile
                 pmc_source = f"none (live rocprofv3 passes failed: {pmc_info})"
                 pmc_info = {}

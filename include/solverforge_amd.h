@@ -71,6 +71,9 @@ typedef enum sf_move_kind {
     SF_MOVE_KOPT = 7,          /* heuristic/move/list_kernel/k_opt.rs:13-96 with k = 3: list `a` cut at a_pos < b < b_pos (`b`
                                   carries the MIDDLE CUT, not an entity) and reconnected by
                                   THREE_OPT_RECONNECTIONS[value] (move/k_opt_reconnection.rs:203-211), value in 0..6 */
+    SF_MOVE_LIST_PERMUTE = 9,  /* heuristic/move/list_kernel/permute.rs:22-72 (ListPermuteMove): the window [a_pos, b_pos) of list `a`
+                                  (b = a, 2..8 positions) reordered by the value-th permutation of its positions in lexicographic
+                                  order (nth_permutation, selector/list_kernel/permute.rs:260-272; value >= 1, 0 would be the identity) */
     SF_MOVE_LIST_RUIN = 8      /* heuristic/move/list_kernel/ruin.rs:131-281 (one source list): list `a` loses the a_pos (1..6) elements
                                   at ascending positions packed 16 bits each into b (positions 0, 1), b_pos (2, 3), value (4, 5);
                                   every removed element is greedily re-inserted at its best (list, position) */
@@ -175,6 +178,7 @@ typedef enum sf_selector_kind {
                                       with an intra-distance meter, policy/list.rs:144-160), 0 = full enumeration
                                       (selector/list_kernel/k_opt/full.rs) */
     SF_SEL_SUBLIST_SWAP = 256,     /* selector/list_kernel/sublist_swap.rs:13-330; sizes via sf_selector_add_sublist */
+    SF_SEL_LIST_PERMUTE = 8192,   /* selector/list_kernel/permute.rs:22-205 (contiguous-window permutations); sf_selector_add_permute */
     SF_SEL_NEARBY_SCALAR_CHANGE = 2048, /* scalar_neighborhood/cursor/change.rs:123-392 (NearbyChangeCursor); sf_selector_add_nearby_scalar */
     SF_SEL_NEARBY_SCALAR_SWAP = 4096,   /* scalar_neighborhood/cursor/swap.rs:162-414 (NearbySwapCursor); sf_selector_add_nearby_scalar */
     SF_SEL_LIST_RUIN = 1024        /* selector/list_kernel/ruin.rs:38-144 + move/list_kernel/ruin.rs:131-281 (ruin and greedy recreate);
@@ -326,6 +330,13 @@ int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t descriptor_in
  * max_nearby = 0 -> full enumeration, 1..64 -> distance-pruned by the list's matrix meter (the default policy passes 20) */
 int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t k,
                              int32_t min_segment_len, int32_t max_nearby);
+
+/* ListPermuteMoveSelector (ListPermuteMoveSelectorConfig: min_window_size 2, max_window_size 5 by default; the default policy
+ * declares it beside ListPrecedence for list slots with precedence hooks, default_local_search/policy/list.rs:62-93): every
+ * non-identity permutation of every window of min..=max consecutive elements.  2 <= min <= max <= 8.  No owner restrictions and no
+ * precedence-route-graph cycle filter (the reference drops permutations that would close a cycle through the route graph,
+ * permute.rs:139-147: not restated).  Generic N-leaf engine. */
+int32_t sf_selector_add_permute(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t min_window_size, int32_t max_window_size);
 
 /* Nearby scalar leaves of a scalar slot (NearbyChangeMoveSelector / NearbySwapMoveSelector; the default policy declares them with
  * max_nearby 10 between the list rules and the ordinary change / swap pair, default_local_search/policy/scalar.rs:18-65).  The

@@ -26,6 +26,7 @@ LEAF_SUBLIST_SWAP = 256
 LEAF_KOPT = 512
 LEAF_LIST_RUIN = 1024
 LEAF_NEARBY_SCALAR_CHANGE, LEAF_NEARBY_SCALAR_SWAP = 2048, 4096
+LEAF_LIST_PERMUTE = 8192
 KIND_KOPT, KIND_RUIN = 7, 8
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2
@@ -85,6 +86,7 @@ def lib():
             "sfo_model_reset": (None, [vp]),
             "sfo_model_configure": (None, [vp, i32, i32, i32, i32, i32, i32, u32, i32, i32, u64, i32]),
             "sfo_model_set_kopt": (None, [vp, i32, i32]),
+            "sfo_model_set_permute": (None, [vp, i32, i32]),
             "sfo_model_evaluate_each": (i32, [vp, vp, vp, i32]),
             "sfo_model_configure_annealing": (None, [vp, i32, vp, i32, i32, dbl, dbl, i32, i32, dbl, dbl, u64]),
             "sfo_model_configure_diversified": (None, [vp, i32, dbl]),
@@ -319,6 +321,9 @@ class Model:
 
     def set_sublist_sizes(self, min_size, max_size):
         lib().sfo_model_set_sublist_sizes(self.h, min_size, max_size)
+
+    def set_permute(self, min_window_size=2, max_window_size=5):
+        lib().sfo_model_set_permute(self.h, min_window_size, max_window_size)
 
     def set_kopt(self, min_segment_len=1, max_nearby=20):
         """3-opt leaf parameters; max_nearby = 0 selects the full-enumeration cursor."""

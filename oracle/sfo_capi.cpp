@@ -292,6 +292,10 @@ void sfo_model_set_sublist_sizes(void* h, int32_t min_size, int32_t max_size) {
     m->sublist_min = (size_t)min_size;
     m->sublist_max = (size_t)max_size;
 }
+void sfo_model_set_permute(void* h, int32_t min_window_size, int32_t max_window_size) {  // ListPermuteMoveConfig (defaults 2..=5)
+    ((Model*)h)->permute_min = (size_t)min_window_size;
+    ((Model*)h)->permute_max = (size_t)max_window_size;
+}
 void sfo_model_set_kopt(void* h, int32_t min_segment_len, int32_t max_nearby) {  // max_nearby 0 = full enumeration
     Model* m = (Model*)h;
     m->kopt_min_seg = (size_t)min_segment_len;

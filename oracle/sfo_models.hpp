@@ -77,6 +77,8 @@ enum LeafBits : uint32_t {
                             // list_leaf/spec.rs:245)
     // nearby scalar leaves (default_local_search/policy/scalar.rs:18-65: max_nearby 10, declared between the list rules and the
     // ordinary scalar change / swap pair)
+    LEAF_LIST_PERMUTE = 8192,  // ListPermuteMoveSelector (window sizes 2..=5 by default, solverforge-config/src/move_selector.rs:406-416); the
+                               // default policy declares it right after ListPrecedence for slots with precedence hooks (policy/list.rs:62-93)
     LEAF_NEARBY_SCALAR_CHANGE = 2048,
     LEAF_NEARBY_SCALAR_SWAP = 4096,
     LEAF_KOPT = 512,  // k = 3; kopt_max_nearby > 0: distance-pruned (default policy with an intra-distance meter), 0: full
@@ -92,6 +94,7 @@ struct Model {
     size_t max_nearby = 20;
     size_t sublist_min = 1, sublist_max = 3;
     size_t kopt_min_seg = 1, kopt_max_nearby = 20;  // KOptMoveSelectorConfig defaults + DEFAULT_LIST_NEARBY_LIMIT (policy/list.rs:19,144-160)
+    size_t permute_min = 2, permute_max = 5;
     size_t scalar_max_nearby = 10, scalar_source_limit = SIZE_MAX;  // NearbyChangeMoveConfig::max_nearby / value_candidate_limit
     UnionOrder union_order = UnionOrder::StratifiedRandom;
     std::vector<uint64_t> union_weights;  // UnionWeighting: one per leaf in union order; empty = equal
@@ -125,6 +128,8 @@ struct Model {
                 return std::make_unique<NearbyListSwapCursor>(list_slot, d.working, ctx, max_nearby);
             case LEAF_LIST_REVERSE:
                 return std::make_unique<ListReverseCursor>(list_slot, d.working, ctx);
+            case LEAF_LIST_PERMUTE:
+                return std::make_unique<ListPermuteCursor>(list_slot, d.working, ctx, permute_min, permute_max);
             case LEAF_SUBLIST_SWAP:
                 return std::make_unique<SublistSwapCursor>(list_slot, d.working, ctx, sublist_min, sublist_max);
             case LEAF_KOPT:
@@ -145,7 +150,7 @@ struct Model {
     // (runtime/compiler/default_local_search/policy.rs:104-108, policy/list.rs:24-33,
     //  policy/scalar.rs:67-106).
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
-        static const uint32_t order[] = {LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
+        static const uint32_t order[] = {LEAF_LIST_PERMUTE, LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
                                          LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_SUBLIST_SWAP, LEAF_LIST_REVERSE,
                                          LEAF_KOPT,               LEAF_LIST_RUIN,          LEAF_NEARBY_SCALAR_CHANGE, LEAF_NEARBY_SCALAR_SWAP,
                                          LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};

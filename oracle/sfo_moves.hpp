@@ -32,7 +32,7 @@
 namespace sfo {
 
 struct Move {
-    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6, KOpt = 7, Ruin = 8 } kind = Change;
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6, KOpt = 7, Ruin = 8, ListPermute = 9 } kind = Change;
     size_t descriptor = 0;
     size_t variable = 0;
     // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
@@ -45,6 +45,8 @@ struct Move {
     //                [b_pos, b_pos + (to_value >> 16)) of list b.
     // KOpt (3-opt, one list): list a cut at positions a_pos < b < b_pos (NOTE: `b` carries the middle
     //                cut, not an entity), reconnected by THREE_OPT_RECONNECTIONS[to_value].
+    // ListPermute: the window [a_pos, b_pos) of list a (b = a) reordered by the to_value-th permutation of its positions in
+    //                lexicographic order (nth_permutation, selector/list_kernel/permute.rs:260-272; rank 0 = identity is no move).
     // Ruin (list ruin-and-recreate, one source list): list a loses the a_pos elements at the ascending positions
     //                ruin_idx[0..a_pos) and every removed element is greedily re-inserted (move/list_kernel/ruin.rs:131-281);
     //                `allows_unassigned` carries skip_empty_destinations.
@@ -94,6 +96,26 @@ static const KOptReconnection THREE_OPT_RECONNECTIONS[7] = {
     {{0, 2, 1, 3, 0, 0}, 0b0110, 4},
 };
 
+// nth_permutation (selector/list_kernel/permute.rs:260-272): the rank-th permutation of 0..len in lexicographic order
+constexpr size_t MAX_LIST_PERMUTE_WINDOW_SIZE = 8;  // move/list_permute.rs:16
+inline size_t permute_factorial(size_t v) {
+    size_t f = 1;
+    for (size_t i = 2; i <= v; ++i) f *= i;
+    return f;
+}
+inline std::vector<size_t> nth_permutation(size_t len, size_t rank) {
+    std::vector<size_t> remaining(len), perm;
+    for (size_t i = 0; i < len; ++i) remaining[i] = i;
+    for (size_t position = 0; position < len; ++position) {
+        size_t step = permute_factorial(len - position - 1);
+        size_t index = rank / step;
+        rank %= step;
+        perm.push_back(remaining[index]);
+        remaining.erase(remaining.begin() + (ptrdiff_t)index);
+    }
+    return perm;
+}
+
 inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
     const Solution& s = d.working;
     const EntityClass& c = s.classes[m.descriptor];
@@ -122,6 +144,12 @@ inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
         }
         case Move::ListReverse:  // move/list_kernel/reverse.rs:22-36
             return m.a < c.lists.size() && m.b_pos > m.a_pos + 1 && m.b_pos <= c.lists[m.a].size();
+        case Move::ListPermute: {  // permute_is_doable (move/list_kernel/permute.rs:22-38): a window inside the list, a non-identity permutation
+            if (m.a >= c.lists.size() || !(m.a_pos < m.b_pos) || m.b_pos > c.lists[m.a].size()) return false;
+            size_t len = m.b_pos - m.a_pos;
+            if (len < 2 || len > MAX_LIST_PERMUTE_WINDOW_SIZE) return false;
+            return m.to_value >= 1 && (size_t)m.to_value < permute_factorial(len);
+        }
         case Move::KOpt: {  // k_opt_is_doable (move/list_kernel/k_opt.rs:13-41): cuts inside the list, strictly increasing
             if (m.to_value < 0 || m.to_value >= 7 || m.a >= c.lists.size()) return false;
             size_t len = c.lists[m.a].size();
@@ -204,6 +232,15 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
         case Move::ListReverse: {  // move/list_kernel/reverse.rs:38-57
             d.before_variable_changed(m.descriptor, m.a);
             std::reverse(c.lists[m.a].begin() + (ptrdiff_t)m.a_pos, c.lists[m.a].begin() + (ptrdiff_t)m.b_pos);
+            d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
+        case Move::ListPermute: {  // permute_do_move (move/list_kernel/permute.rs:40-72): remove the window, re-insert it reordered
+            d.before_variable_changed(m.descriptor, m.a);
+            auto& l = c.lists[m.a];
+            u.old_list.assign(l.begin() + (ptrdiff_t)m.a_pos, l.begin() + (ptrdiff_t)m.b_pos);
+            std::vector<size_t> perm = nth_permutation(m.b_pos - m.a_pos, (size_t)m.to_value);
+            for (size_t k = 0; k < perm.size(); ++k) l[m.a_pos + k] = u.old_list[perm[k]];
             d.after_variable_changed(m.descriptor, m.a);
             break;
         }
@@ -421,6 +458,12 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             std::sort(values.begin(), values.end(), [](const Back& x, const Back& y) { return x.original_position < y.original_position; });
             d.before_variable_changed(m.descriptor, m.a);
             for (const Back& b : values) c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)b.original_position, b.value);
+            d.after_variable_changed(m.descriptor, m.a);
+            break;
+        }
+        case Move::ListPermute: {  // permute_undo_move (move/list_kernel/permute.rs:74-101): the original window back
+            d.before_variable_changed(m.descriptor, m.a);
+            for (size_t k = 0; k < u.old_list.size(); ++k) c.lists[m.a][m.a_pos + k] = u.old_list[k];
             d.after_variable_changed(m.descriptor, m.a);
             break;
         }
@@ -1039,6 +1082,78 @@ struct ListSwapCursor : Cursor {
                 }
                 advance_entity();
             }
+        }
+    }
+};
+
+// Contiguous-window permutation leaf (selector/list_kernel/permute.rs:22-205; compiled runtime leaf: list_leaf/cursor/slot.rs:273-296,
+// entity salt 0x91D7_9E8A_0000_0001 ^ descriptor): per entity, per start (ordered_index), per window size min..=max that fits,
+// every non-identity permutation of the window in ordered_index order of its rank.  No owner restrictions, no precedence graph.
+struct ListPermuteCursor : Cursor {
+    static constexpr uint64_t SALT_ENTITY = 0x91D79E8A00000001ULL, SALT_START = 0x91D79E8A00000002ULL;
+    static constexpr uint64_t SALT_SIZE = 0x91D79E8A00000003ULL, SALT_ORDER = 0x91D79E8A00000004ULL;
+    size_t desc;
+    MoveStreamContext ctx;
+    std::vector<size_t> entities, route_lens;
+    size_t entity_idx = 0, start_offset = 0, size_offset = 0, permutation_offset = 0;
+    bool has_window = false;
+    size_t win_start = 0, win_size = 0;
+    size_t min_size, max_size;
+
+    ListPermuteCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c, size_t min_window_size, size_t max_window_size)
+        : desc(slot.descriptor_index), ctx(c), min_size(min_window_size), max_size(max_window_size) {
+        selected_entities(slot, s, ctx, SALT_ENTITY ^ (uint64_t)desc, entities, route_lens);
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (entity_idx >= entities.size()) return false;
+            size_t entity = entities[entity_idx], route_len = route_lens[entity_idx];
+            auto advance_entity = [&]() {
+                ++entity_idx;
+                start_offset = size_offset = permutation_offset = 0;
+                has_window = false;
+            };
+            auto advance_start = [&]() {
+                ++start_offset;
+                size_offset = permutation_offset = 0;
+                has_window = false;
+            };
+            if (route_len < min_size) {
+                advance_entity();
+                continue;
+            }
+            if (has_window) {
+                size_t count = permute_factorial(win_size) - 1;
+                if (permutation_offset < count) {
+                    size_t rank = ctx.selection_index(permutation_offset, count,
+                                                      SALT_ORDER ^ (uint64_t)entity ^ (uint64_t)win_start ^ (uint64_t)win_size ^ (uint64_t)desc) + 1;
+                    ++permutation_offset;
+                    out = make_list_move(Move::ListPermute, desc, entity, win_start, entity, win_start + win_size);
+                    out.to_value = (int64_t)rank;
+                    return true;
+                }
+                has_window = false;
+                ++size_offset;
+                permutation_offset = 0;
+            }
+            if (start_offset >= route_len) {
+                advance_entity();
+                continue;
+            }
+            size_t start = ctx.selection_index(start_offset, route_len, SALT_START ^ (uint64_t)entity ^ (uint64_t)desc);
+            size_t max_valid = std::min(max_size, route_len - start);
+            if (max_valid < min_size) {
+                advance_start();
+                continue;
+            }
+            size_t size_count = max_valid - min_size + 1;
+            if (size_offset >= size_count) {
+                advance_start();
+                continue;
+            }
+            win_size = min_size + ctx.selection_index(size_offset, size_count, SALT_SIZE ^ (uint64_t)entity ^ (uint64_t)start);
+            win_start = start;
+            has_window = true;
         }
     }
 };

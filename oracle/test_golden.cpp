@@ -851,6 +851,48 @@ static void k_opt_cases() {
     }
 }
 
+// heuristic/selector/tests/list_permute.rs:121-160 (the two cases without owner restrictions) + nth_permutation's order
+static void list_permute_cases() {
+    auto mk = [](std::vector<std::vector<uint32_t>> lists) {
+        Solution s;
+        s.classes.resize(1);
+        s.classes[0].n = lists.size();
+        s.classes[0].lists = lists;
+        return s;
+    };
+    ListSlot slot;
+    {
+        Solution s = mk({{1, 2, 3}});
+        ListPermuteCursor c(slot, s, MoveStreamContext(), 2, 3);
+        std::vector<Move> moves;
+        Move m;
+        while (c.next(m)) moves.push_back(m);
+        bool ok = moves.size() == 7 && moves[0].a_pos == 0 && moves[0].b_pos == 2 && nth_permutation(2, (size_t)moves[0].to_value) == std::vector<size_t>{1, 0};
+        for (auto& mv : moves) ok = ok && mv.a == 0;
+        ScoreDirector d;
+        d.working = s;
+        for (auto& mv : moves) ok = ok && move_is_doable(d, mv);
+        CHECK("list_permute.enumerates_windows_without_batching_moves", ok);
+    }
+    {
+        Solution s = mk({{1, 2, 3, 4}, {100, 101, 102}});
+        ListPermuteCursor c(slot, s, MoveStreamContext(), 2, 3);
+        std::vector<std::tuple<size_t, size_t, size_t, int64_t>> sig;
+        Move m;
+        while (c.next(m)) sig.push_back({m.a, m.a_pos, m.b_pos, m.to_value});
+        // count_list_permute_moves_for_len: len 4 -> starts 0..3: (1 + 5) + (1 + 5) + 1 + 0 = 13; len 3 -> 7
+        std::vector<std::tuple<size_t, size_t, size_t, int64_t>> uniq = sig;
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        CHECK("list_permute.size_matches_streamed_unique_candidates", sig.size() == 20 && uniq.size() == sig.size());
+    }
+    {
+        bool ok = nth_permutation(3, 0) == std::vector<size_t>{0, 1, 2} && nth_permutation(3, 1) == std::vector<size_t>{0, 2, 1} &&
+                  nth_permutation(3, 5) == std::vector<size_t>{2, 1, 0} && nth_permutation(4, 9) == std::vector<size_t>{1, 2, 3, 0};
+        CHECK("list_permute.nth_permutation_is_lexicographic", ok);
+    }
+}
+
 // heuristic/selector/scalar_neighborhood/tests.rs:165-204 (both cases): a dynamic slot whose nearby sources decline the row
 // (return false) -> the ordinary candidate values with the source limit / every entity; meters value and |left - right|.
 static void nearby_scalar_cases() {
@@ -1734,6 +1776,7 @@ int main() {
     simulated_annealing_cases();
     diversified_late_acceptance_cases();
     nearby_scalar_cases();
+    list_permute_cases();
     list_reverse_cases();
     list_ruin_cases();
     compound_scalar_cases();

@@ -523,6 +523,19 @@ int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t d, int32_t var, int32_t k, int
     return SF_OK;
 }
 
+// ListPermuteMoveSelectorConfig (solverforge-config/src/move_selector.rs:391-416: windows of 2..=5 elements by default)
+int32_t sf_selector_add_permute(sf_ctx* ctx, int32_t d, int32_t var, int32_t min_window_size, int32_t max_window_size) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
+    if (min_window_size < 2 || max_window_size < min_window_size || max_window_size > 8)  // list_leaf/spec.rs:260-265,325
+        return fail(ctx, SF_ERR_INVALID, "list permute bounds require 2 <= min <= max <= 8");
+    SelectorSpec s{SF_SEL_LIST_PERMUTE, d, var, 0, -1};
+    s.min_size = min_window_size;
+    s.max_size = max_window_size;
+    ctx->selectors.push_back(s);
+    return SF_OK;
+}
+
 int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32_t min_size, int32_t max_size) {
     if (!ctx) return SF_ERR_INVALID;
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
@@ -1484,7 +1497,7 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         if (!ok) return fail(ctx, SF_ERR_INVALID, "move is not doable");
         return SF_OK;
     }
-    const bool list_move = mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_KOPT;
+    const bool list_move = (mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_KOPT) || mv->kind == SF_MOVE_LIST_PERMUTE;
     if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
     if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");
     if (list_move) {
@@ -1493,6 +1506,8 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
             return fail(ctx, SF_ERR_INVALID, "move out of range");
         if (mv->kind == SF_MOVE_KOPT && (mv->value < 0 || mv->value >= 7))
             return fail(ctx, SF_ERR_INVALID, "3-opt move: value is the reconnection pattern 0..6");
+        if (mv->kind == SF_MOVE_LIST_PERMUTE && (mv->a != mv->b || mv->b_pos - mv->a_pos < 2 || mv->b_pos - mv->a_pos > 8 || mv->value < 1))
+            return fail(ctx, SF_ERR_INVALID, "list permute move: a window of 2..8 positions of one list and a permutation rank >= 1");
         if (mv->kind == SF_MOVE_SUBLIST_CHANGE && (mv->value <= mv->a_pos || mv->value - mv->a_pos > 255))
             return fail(ctx, SF_ERR_INVALID, "sublist move: value must be the segment end (segment of 1..255 elements)");
         if (mv->kind == SF_MOVE_SUBLIST_SWAP && (mv->value <= 0 || (mv->value & 0xFFFF) == 0 || (mv->value & 0xFFFF) > 255 ||
@@ -1910,7 +1925,7 @@ static bool has_plain_list_leaves(sf_ctx* ctx) {
     for (auto& s : ctx->selectors)
         if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP || s.kind == SF_SEL_LIST_REVERSE ||
                                          s.kind == SF_SEL_SUBLIST_CHANGE || s.kind == SF_SEL_SUBLIST_SWAP || s.kind == SF_SEL_KOPT ||
-                                         s.kind == SF_SEL_LIST_RUIN))
+                                         s.kind == SF_SEL_LIST_RUIN || s.kind == SF_SEL_LIST_PERMUTE))
             return true;
     return false;
 }
@@ -1925,7 +1940,8 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     if (union_is_custom(ctx)) {
         for (auto& s : ctx->selectors) ordered.push_back(&s);
     } else {
-        for (int kind : {SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
+        for (int kind : {SF_SEL_LIST_PERMUTE,  // the precedence pair leads the list policy (policy/list.rs:24-33)
+                         SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
                          SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_LIST_RUIN, SF_SEL_NEARBY_SCALAR_CHANGE,
                          SF_SEL_NEARBY_SCALAR_SWAP, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})  // nearby scalar rules precede the ordinary pair (policy.rs:104-108)
             for (auto& s : ctx->selectors)

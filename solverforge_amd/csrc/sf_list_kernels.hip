@@ -338,6 +338,52 @@ __device__ __forceinline__ ListDelta eval_list_reverse(const ListModel& m, const
     return r;
 }
 
+// ListPermuteMove (move/list_kernel/permute.rs:22-72): the window [start, start + size) of list `a` reordered by the rank-th
+// permutation of its positions in lexicographic order (nth_permutation, selector/list_kernel/permute.rs:260-272).  One list:
+// only the distance aggregate can change; the matrix may be asymmetric, so every leg of the window is re-priced.
+__device__ __forceinline__ uint32_t permute_factorial(uint32_t v) {
+    uint32_t f = 1;
+    for (uint32_t i = 2; i <= v; ++i) f *= i;
+    return f;
+}
+// the permutation as nibbles: nibble k = the window position whose element moves to window position k (size <= 8)
+__device__ __forceinline__ uint32_t nth_permutation_nibbles(uint32_t size, uint32_t rank) {
+    uint32_t remaining = 0x76543210u, perm = 0;
+    for (uint32_t position = 0; position < size; ++position) {
+        const uint32_t step = permute_factorial(size - position - 1u);
+        const uint32_t index = rank / step;
+        rank -= index * step;
+        perm |= ((remaining >> (4u * index)) & 15u) << (4u * position);
+        const uint32_t low = index ? (remaining & ((1u << (4u * index)) - 1u)) : 0u;
+        remaining = low | ((index < 7u ? (remaining >> (4u * (index + 1u))) : 0u) << (4u * index));
+    }
+    return perm;
+}
+template <class VT>
+__device__ __forceinline__ ListDelta eval_list_permute(const ListModel& m, const VT* visits, const uint32_t* off, uint32_t a, uint32_t start,
+                                                       uint32_t size, uint32_t rank) {
+    ListDelta r{0, 0, false};
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    if (size < 2 || size > 8 || start + size > la || rank < 1 || rank >= permute_factorial(size)) return r;
+    r.doable = true;
+    if (m.dist_level >= 0) {
+        const uint32_t depot = (uint32_t)m.depot;
+        const uint32_t prev = start > 0 ? (uint32_t)visits[oa + start - 1] : depot;
+        const uint32_t next = start + size < la ? (uint32_t)visits[oa + start + size] : depot;
+        const uint32_t perm = nth_permutation_nibbles(size, rank);
+        int64_t acc = 0;
+        uint32_t uo = prev, un = prev;
+        for (uint32_t k = 0; k < size; ++k) {
+            const uint32_t wo = visits[oa + start + k], wn = visits[oa + start + ((perm >> (4u * k)) & 15u)];
+            acc = wadd(acc, wsub(dist_cost(m.mat, m.dim, un, wn), dist_cost(m.mat, m.dim, uo, wo)));
+            uo = wo;
+            un = wn;
+        }
+        r.d_dist = wadd(acc, wsub(dist_cost(m.mat, m.dim, un, next), dist_cost(m.mat, m.dim, uo, next)));
+    }
+    return r;
+}
+
 // Reconnection patterns of a 3-opt move (heuristic/move/k_opt_reconnection.rs:203-211,
 // THREE_OPT_RECONNECTIONS): patterns 0..2 keep the order A B C D, patterns 3..6 place C before B;
 // bit 1 / bit 2 of the mask reverse segment B / C (flags follow the ORIGINAL segment index,
@@ -842,6 +888,8 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
             d = eval_sublist_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[5], (uint32_t)mv[3], (uint32_t)mv[4]);
         else if (kind == 7 && mv[5] >= 0 && mv[3] >= 0)  // (a, a_pos = cut 1, b = cut 2, b_pos = cut 3, value = pattern)
             d = eval_kopt(m, visits, off, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4], (uint32_t)mv[5]);
+        else if (kind == 9 && mv[1] == mv[3] && mv[4] > mv[2] && mv[5] >= 0)  // (a, a_pos = start, b = a, b_pos = end, value = permutation rank)
+            d = eval_list_permute(m, visits, off, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)(mv[4] - mv[2]), (uint32_t)mv[5]);
     }
     out_doable[t] = d.doable ? 1 : 0;
     ScoreV<4> s = apply_delta<4>(m, cur, d);
@@ -950,6 +998,13 @@ __device__ __forceinline__ void apply_list_move_block(const ListModel& m, uint32
             visits[lo + t] = y;
             visits[hi - 1 - t] = x;
         }
+    } else if (kind == 9) {  // permute the window [i, j) of list a by the ext-th permutation of its positions
+        const uint32_t base = off[a] + i, size = j - i;
+        const uint32_t perm = nth_permutation_nibbles(size, ext);
+        uint32_t nv = 0;
+        if (threadIdx.x < size) nv = visits[base + ((perm >> (4u * threadIdx.x)) & 15u)];
+        __syncthreads();
+        if (threadIdx.x < size) visits[base + threadIdx.x] = nv;
     } else if (kind == 7) {  // 3-opt: cuts i < b < j of list a, pattern = ext; at most three range reversals
         const uint32_t base = off[a], c1 = i, c2 = b, c3 = j;
         const uint32_t mask = kopt_reverse_mask(ext);
@@ -1000,6 +1055,7 @@ __global__ __launch_bounds__(256) void k_list_apply(ListModel m, int replica, in
               : kind == 3 ? eval_list_swap(m, visits, off, load, a, i, b, j)
               : kind == 4 ? eval_list_reverse(m, visits, off, a, i, j)
               : kind == 7 ? eval_kopt(m, visits, off, a, i, b, j, ext)
+              : kind == 9 ? ((a == b && j > i) ? eval_list_permute(m, visits, off, a, i, j - i, ext) : ListDelta{0, 0, false})
               : kind == 5 ? eval_sublist_change(m, visits, off, load, a, i, ext, b, j)
                           : eval_sublist_swap(m, visits, off, load, a, i, i + (ext & 0xFFFFu), b, j, j + (ext >> 16));
     }

@@ -338,6 +338,13 @@ __device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_
             visits[lo + t] = y;
             visits[hi - 1 - t] = x;
         }
+    } else if (kind == 9) {  // permute the window [i, j) of list a by the ext-th permutation of its positions
+        const uint32_t base = off[a] + i, size = j - i;
+        const uint32_t perm = nth_permutation_nibbles(size, ext);
+        uint32_t nv = 0;
+        if (lane < size) nv = visits[base + ((perm >> (4u * lane)) & 15u)];
+        wave_sync();
+        if (lane < size) visits[base + lane] = (uint16_t)nv;
     } else if (kind == 7) {  // 3-opt: cuts i < b < j of list a (b carries the middle cut), pattern = ext
         const uint32_t base = off[a], c1 = i, c2 = b, c3 = j;
         const uint32_t mask = kopt_reverse_mask(ext);

@@ -53,6 +53,18 @@ constexpr uint64_t SALT_SS_SIZE = 0x5B1575A090000003ULL;
 constexpr uint64_t SALT_NSC_START = 0xC4A46E00AAAA0001ULL, SALT_NSC_STRIDE = 0xC4A46E00AAAA0002ULL, SALT_NSC_VALUE = 0xC4A46E00AAAA0003ULL;
 constexpr uint64_t SALT_NSW_START = 0x5A095CA1AAAA0001ULL, SALT_NSW_STRIDE = 0x5A095CA1AAAA0002ULL, SALT_NSW_TARGET = 0x5A095CA1AAAA0003ULL;
 
+// list permute leaf (selector/list_kernel/permute.rs:16-18; entity order: list_leaf/cursor/slot.rs:281)
+constexpr uint64_t SALT_PM_ENTITY = 0x91D79E8A00000001ULL, SALT_PM_START = 0x91D79E8A00000002ULL;
+constexpr uint64_t SALT_PM_SIZE = 0x91D79E8A00000003ULL, SALT_PM_ORDER = 0x91D79E8A00000004ULL;
+// selector kind of a list leaf -> sf_move_kind of the moves it emits
+__device__ __forceinline__ int list_move_kind_of(int k) {
+    return (k == 4 || k == 16) ? 2 : ((k == 8 || k == 32) ? 3 : (k == 64 ? 4 : (k == 128 ? 5 : (k == 512 ? 7 : (k == 8192 ? 9 : 6)))));
+}
+// `ext` argument of apply_list_move_wave for the ring entry (m0, m1, mx) of a leaf of selector kind k
+__device__ __forceinline__ uint32_t list_move_ext_of(int k, uint32_t m0, uint32_t m1, uint32_t mx) {
+    return k == 512 ? mx : (k == 256 ? ((mx & 15u) | ((mx >> 4) << 16)) : (k == 8192 ? (m1 & 0xFFFFu) : (m0 & 0xFFFFu) + mx));
+}
+
 struct RuinParams {  // list ruin leaf (sf_ruin.h)
     int32_t min_count, max_count, moves_per_step, max_source_len;  // max_source_len 0 = None
     int32_t skip_empty;
@@ -514,6 +526,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             lt.set(l, LeafTab::EX, l >= nl);
             lt.set(l, LeafTab::WCUR, 0);
         }
+        if (has_list) {  // list permute leaf: its entity permutation of this step (slot.rs:468-499) in the generator state
+            for (int l = 0; l < nl; ++l) {
+                if (lt.geti(l, LeafTab::KIND) != 8192) continue;
+                uint32_t pst, psd;
+                if (use_cm)
+                    ctx.perm_params_fm(fm_V, fm_V1, SALT_PM_ENTITY ^ ldesc, pst, psd, cm_lo, cm_hi);
+                else
+                    ctx.perm_params((uint32_t)V, SALT_PM_ENTITY ^ ldesc, pst, psd);
+                lt.put_gen(l, GGen{0, 0, uni(pst), uni(psd), 0, 0, V == 0});
+            }
+        }
         if (!FAST && has_scalar) {  // nearby scalar leaves: ordered_entity's start / stride of this step (change.rs:376-391) in the generator state
             for (int l = 0; l < nl; ++l) {
                 const int lk = lt.geti(l, LeafTab::KIND);
@@ -723,6 +746,59 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         wave_sync();  // the survivors are consumed before the next row overwrites them
                         g.a += 1;
                         if (g.a >= ns) g.done = 1;
+                    } else if (kind == 8192) {  // ---- list permute (list_kernel/permute.rs:103-205): the (size, permutation) pairs of one start per call ----
+                        const uint32_t mn = leaf_min, mx = leaf_max;
+                        uint32_t ent = 0, len = 0, start = 0, size_count = 0;
+                        for (;;) {  // the current start with at least one window size
+                            if (g.a >= (uint32_t)V) break;
+                            ent = fastmod_u64((uint64_t)g.c + (uint64_t)g.a * g.d, fm_V);
+                            len = rlen(ent);
+                            if (len < mn || g.b >= len) {
+                                g.a += 1;
+                                g.b = 0;
+                                g.e = 0;
+                                continue;
+                            }
+                            start = ctx.selection_index(g.b, len, SALT_PM_START ^ (uint64_t)ent ^ ldesc);
+                            const uint32_t max_valid = mx < len - start ? mx : len - start;
+                            if (max_valid < mn) {
+                                g.b += 1;
+                                g.e = 0;
+                                continue;
+                            }
+                            size_count = max_valid - mn + 1;
+                            break;
+                        }
+                        if (g.a >= (uint32_t)V) {
+                            g.done = 1;
+                            break;
+                        }
+                        // flat offset f = g.e + lane over the sizes in stream order, factorial(size) - 1 permutations each
+                        const uint32_t f = g.e + lane;
+                        uint32_t cum = 0, my_size = 0, my_po = 0;
+                        bool found = false;
+                        for (uint32_t so = 0; so < size_count; ++so) {
+                            const uint32_t sz = mn + ctx.selection_index(so, size_count, SALT_PM_SIZE ^ (uint64_t)ent ^ (uint64_t)start);
+                            const uint32_t cnt = permute_factorial(sz) - 1u;
+                            if (!found && f < cum + cnt) {
+                                found = true;
+                                my_size = sz;
+                                my_po = f - cum;
+                            }
+                            cum += cnt;
+                        }
+                        if (found) {
+                            const uint32_t rank = ctx.selection_index(my_po, permute_factorial(my_size) - 1u,
+                                                                      SALT_PM_ORDER ^ (uint64_t)ent ^ (uint64_t)start ^ (uint64_t)my_size ^ ldesc) + 1u;
+                            keep = true;
+                            w0 = (ent << 16) | start;
+                            w1 = (my_size << 16) | rank;
+                        }
+                        g.e += 64;
+                        if (g.e >= cum) {
+                            g.b += 1;
+                            g.e = 0;
+                        }
                     } else if (DBGK(4) && kind == 4) {  // ---- list change (list_kernel/change.rs:142-241) ----
                         // advance to a source with a non-empty list
                         uint32_t se = 0, slen = 0;
@@ -1437,6 +1513,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         doable = true;
 #pragma unroll
                         for (int kk = 0; kk < L; ++kk) sc.v[kk] = rl.score[(size_t)m0 * 4 + kk];
+                    } else if (my_kind == 8192) {  // list permute: up to nine legs each way, priced on its own
+                        const ListDelta d = eval_list_permute(lm, s_visits, s_off, m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
+                        doable = d.doable;
+                        sc = apply_delta<L>(lm, cur, d);
                     } else {
                         ListDelta d;
                         if (unified_eval)  // symmetric matrix: one shared gather for every kind
@@ -1484,10 +1564,11 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                 continue;
                             }
                         }
-                        apply_list_move_wave(lm, s_visits, s_off, s_load,
-                                             (ck == 4 || ck == 16) ? 2 : ((ck == 8 || ck == 32) ? 3 : (ck == 64 ? 4 : (ck == 128 ? 5 : (ck == 512 ? 7 : 6)))),
-                                             ca >> 16, ca & 0xFFFFu, cb >> 16, cb & 0xFFFFu,
-                                             ck == 512 ? cx : (ck == 256 ? ((cx & 15u) | ((cx >> 4) << 16)) : (ca & 0xFFFFu) + cx));
+                        if (ck == 8192)  // permute: (list, start, list, end), ext = rank
+                            apply_list_move_wave(lm, s_visits, s_off, s_load, 9, ca >> 16, ca & 0xFFFFu, ca >> 16, (ca & 0xFFFFu) + (cb >> 16), cb & 0xFFFFu);
+                        else
+                            apply_list_move_wave(lm, s_visits, s_off, s_load, list_move_kind_of(ck), ca >> 16, ca & 0xFFFFu, cb >> 16, cb & 0xFFFFu,
+                                                 list_move_ext_of(ck, ca, cb, cx));
                         const PrecResult pr = prec_run_trial();
                         if ((int)lane == ci) {
 #pragma unroll
@@ -1497,7 +1578,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                             }
                         }
                         // undo: the owners the move touched, from the committed lists in HBM (written back at every commit)
-                        const uint32_t la_ = ca >> 16, lb_ = (ck == 512 || ck == 64) ? la_ : (cb >> 16);  // 3-opt / reverse: one owner
+                        const uint32_t la_ = ca >> 16, lb_ = (ck == 512 || ck == 64 || ck == 8192) ? la_ : (cb >> 16);  // 3-opt / reverse / permute: one owner
                         const uint32_t l_lo = la_ < lb_ ? la_ : lb_, l_hi = la_ < lb_ ? lb_ : la_;
                         for (uint32_t t = l_lo + lane; t <= l_hi + 1; t += 64) s_off[t] = g_off[t];
                         for (uint32_t t = l_lo + lane; t <= l_hi; t += 64) s_load[t] = g_load[t];
@@ -1606,8 +1687,15 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                             tm[3] = (int32_t)((uint32_t)cd[2] | ((uint32_t)cd[3] << 16));
                             tm[4] = (int32_t)((uint32_t)cd[4] | ((uint32_t)cd[5] << 16));
                             tm[5] = (int32_t)((uint32_t)cd[6] | ((uint32_t)cd[7] << 16));
+                        } else if (my_kind == 8192) {  // (9, list, start, list, end, rank)
+                            tm[0] = 9;
+                            tm[1] = (int32_t)(m0 >> 16);
+                            tm[2] = (int32_t)(m0 & 0xFFFFu);
+                            tm[3] = (int32_t)(m0 >> 16);
+                            tm[4] = (int32_t)((m0 & 0xFFFFu) + (m1 >> 16));
+                            tm[5] = (int32_t)(m1 & 0xFFFFu);
                         } else {
-                            tm[0] = (my_kind == 4 || my_kind == 16) ? 2 : ((my_kind == 8 || my_kind == 32) ? 3 : (my_kind == 64 ? 4 : (my_kind == 128 ? 5 : (my_kind == 512 ? 7 : 6))));
+                            tm[0] = list_move_kind_of(my_kind);
                             tm[1] = (int32_t)(m0 >> 16);
                             tm[2] = (int32_t)(m0 & 0xFFFFu);
                             tm[3] = (int32_t)(m1 >> 16);
@@ -1700,22 +1788,22 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
                     if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied
-                    p.trace_applied[1] = (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : (kind == 512 ? 7 : 6))));
+                    p.trace_applied[1] = list_move_kind_of(kind);
                     p.trace_applied[2] = (int32_t)(a >> 16);
                     p.trace_applied[3] = (int32_t)(a & 0xFFFFu);
-                    p.trace_applied[4] = (int32_t)(b >> 16);
-                    p.trace_applied[5] = (int32_t)(b & 0xFFFFu);
-                    p.trace_applied[6] = kind == 128 ? (int32_t)((a & 0xFFFFu) + uni(best_x))
+                    p.trace_applied[4] = kind == 8192 ? (int32_t)(a >> 16) : (int32_t)(b >> 16);
+                    p.trace_applied[5] = kind == 8192 ? (int32_t)((a & 0xFFFFu) + (b >> 16)) : (int32_t)(b & 0xFFFFu);
+                    p.trace_applied[6] = kind == 8192 ? (int32_t)(b & 0xFFFFu) : kind == 128 ? (int32_t)((a & 0xFFFFu) + uni(best_x))
                                                       : (kind == 256 ? (int32_t)((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16))
                                                                      : (kind == 512 ? (int32_t)uni(best_x) : -1));
                 }
-                apply_list_move_wave(lm, s_visits, s_off, s_load,
-                                     (kind == 4 || kind == 16) ? 2 : ((kind == 8 || kind == 32) ? 3 : (kind == 64 ? 4 : (kind == 128 ? 5 : (kind == 512 ? 7 : 6)))),
-                                     a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu,
-                                     kind == 512 ? uni(best_x)
-                                                 : (kind == 256 ? ((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16)) : (a & 0xFFFFu) + uni(best_x)));
+                if (kind == 8192)
+                    apply_list_move_wave(lm, s_visits, s_off, s_load, 9, a >> 16, a & 0xFFFFu, a >> 16, (a & 0xFFFFu) + (b >> 16), b & 0xFFFFu);
+                else
+                    apply_list_move_wave(lm, s_visits, s_off, s_load, list_move_kind_of(kind), a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu,
+                                         list_move_ext_of(kind, a, b, uni(best_x)));
                 if (has_nearby) {  // refresh node -> (route, position) for the touched routes
-                    const uint32_t ra_ = a >> 16, rb_ = kind == 512 ? (a >> 16) : (b >> 16);  // 3-opt: b packs cuts, not a route
+                    const uint32_t ra_ = a >> 16, rb_ = (kind == 512 || kind == 8192) ? (a >> 16) : (b >> 16);  // 3-opt / permute: b packs cuts / (size, rank), not a route
                     const uint32_t oa = s_off[ra_], la = s_off[ra_ + 1] - oa;
                     const uint32_t ob = s_off[rb_], lb = s_off[rb_ + 1] - ob;
                     for (uint32_t t = lane; t < la + (ra_ != rb_ ? lb : 0u); t += 64) {

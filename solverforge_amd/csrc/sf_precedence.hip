@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_prec_evaluate_moves(ListModel m, PrecMod
     const int64_t i = base + blockIdx.x;
     const int32_t* mv = moves + i * 6;
     const int kind = mv[0];
-    if (kind < 2 || kind > 7 || !doable[i]) return;
+    if (kind < 2 || (kind > 7 && kind != 9) || !doable[i]) return;
     const uint32_t lane = threadIdx.x & 63u;
     const PrecMoveCarve cv(m.V, m.n_cap);
     int64_t* s_load = (int64_t*)(smem + cv.load);

@@ -19,6 +19,7 @@ class MoveKind:
     CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 0, 1, 2, 3, 4, 5, 6
     KOPT = 7  # a = list, a_pos / b / b_pos = the three cuts, value = reconnection pattern
     LIST_RUIN = 8  # a = list, a_pos = count, six 16-bit ascending positions in b / b_pos / value
+    LIST_PERMUTE = 9  # a = b = list, [a_pos, b_pos) = the window, value = rank of the permutation (lexicographic, >= 1)
 
 
 class SelectionOrder:  # solverforge_config::SelectionOrder
@@ -59,6 +60,7 @@ class SelectorKind:
     KOPT = 512
     LIST_RUIN = 1024
     NEARBY_SCALAR_CHANGE, NEARBY_SCALAR_SWAP = 2048, 4096
+    LIST_PERMUTE = 8192
 
 
 @dataclass
@@ -218,6 +220,11 @@ class GpuScoreDirector:
         """List ruin leaf (ListRuinMoveSelectorConfig defaults); max_source_list_len 0 = None."""
         check(self._L.sf_selector_add_ruin(self._h, descriptor_index, variable_index, min_ruin_count, max_ruin_count, moves_per_step,
                                            max_source_list_len, int(skip_empty_destinations), variable_name.encode()), self._h)
+
+    def add_permute_selector(self, descriptor_index, variable_index=0, min_window_size=2, max_window_size=5):
+        """List permute leaf (ListPermuteMoveSelectorConfig defaults): every non-identity permutation of every window of
+        min..=max consecutive elements."""
+        check(self._L.sf_selector_add_permute(self._h, descriptor_index, variable_index, min_window_size, max_window_size), self._h)
 
     def add_kopt_selector(self, descriptor_index, variable_index=0, k=3, min_segment_len=1, max_nearby=20):
         """3-opt leaf (KOptMoveSelectorConfig); max_nearby = 0 enumerates every cut set, > 0 prunes by distance."""

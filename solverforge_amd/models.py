@@ -9,7 +9,7 @@ FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN, FAC
 
 
 def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearby_change", "nearby_swap"),
-               sublist_sizes=(1, 3), kopt=(1, 20), ruin=(2, 5, 10)):
+               sublist_sizes=(1, 3), kopt=(1, 20), ruin=(2, 5, 10), permute=(2, 5)):
     # leaves may also name the plain streams "list_change" / "list_swap" (generic N-leaf engine)
     """CVRP: HardSoftScore; all_customers_assigned (not-exists, 1 hard each —
     crates/solverforge/tests/list_clarke_wright_publication/domain/publication_plan.rs:51-65),
@@ -44,6 +44,8 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
             d.add_sublist_selector(SelectorKind.SUBLIST_CHANGE, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
         elif leaf == "sublist_swap":
             d.add_sublist_selector(SelectorKind.SUBLIST_SWAP, 0, min_size=sublist_sizes[0], max_size=sublist_sizes[1])
+        elif leaf == "permute":  # permute = (min_window_size, max_window_size)
+            d.add_permute_selector(0, min_window_size=permute[0], max_window_size=permute[1])
         elif leaf == "kopt":  # kopt = (min_segment_len, max_nearby); max_nearby 0 = full enumeration
             d.add_kopt_selector(0, min_segment_len=kopt[0], max_nearby=kopt[1])
         elif leaf == "ruin":  # ruin = (min_ruin_count, max_ruin_count, moves_per_step)
@@ -149,6 +151,8 @@ def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_chan
     d.add_list_variable(0, problem["sequences"], element_capacity=n, element_id_bound=n)
     d.add_list_precedence(0, problem["durations"], problem["successors"], problem["expected_owner"] if with_owner else None,
                           hard_level=hard_level, makespan_level=makespan_level)
+    if "permute" in leaves:  # the precedence pair leads the list policy (policy/list.rs:24-33)
+        d.add_permute_selector(0)
     if "list_change" in leaves:
         d.add_selector(SelectorKind.LIST_CHANGE, 0)
     if "list_swap" in leaves:
