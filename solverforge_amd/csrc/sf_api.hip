@@ -804,6 +804,20 @@ static int build_list_model(sf_ctx* ctx, int d) {
         if ((rc = dalloc(ctx, &pm.stamp_q, words))) return rc;
         if ((rc = dalloc(ctx, &pm.changed, words))) return rc;
         if ((rc = dalloc(ctx, &pm.queue2, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.pos, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.rnd, words))) return rc;
+        if ((rc = dalloc(ctx, &pm.rec, words * 16))) return rc;
+        if ((rc = dalloc(ctx, &pm.roff, words + (size_t)R))) return rc;
+        if ((rc = dalloc(ctx, &pm.pmax, words + (size_t)R))) return rc;
+        pm.has_zero_duration = 0;
+        {
+            int64_t dsum = 0;
+            for (int32_t dv : ps.dur) {
+                if (dv <= 0) pm.has_zero_duration = 1;
+                dsum += dv > 0 ? dv : 0;
+            }
+            if (dsum >= ((int64_t)1 << 27)) pm.has_zero_duration = 1;  // keep transient sweep values far from the i32 range
+        }
     }
     // compact u32 matrix copy (4-byte gathers in the trial-score path) when every finite leg fits
     for (auto& kv : ctx->facts)
@@ -2027,6 +2041,13 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         // the incremental trial refresh is parity-complete but SLOWER than one full evaluation per trial on every job shop measured
         // (profiles/r03f_precedence.txt): opt-in for the parity tests and further work
         gl.prec_inc = std::getenv("SF_AMD_PREC_INC") != nullptr ? 1 : 0;
+        // lane-per-trial sweep (prec_trial_sweep64): the default with the scratch in HBM; SF_AMD_PREC_NO_SWEEP = one full evaluation per trial
+        gl.prec_sweep = (gl.prec.on && !gl.prec_lds && !gl.prec_inc && std::getenv("SF_AMD_PREC_NO_SWEEP") == nullptr) ? 1 : 0;
+        if (gl.prec_sweep && !ctx->pm.elane) {  // [R][n][64] earliest starts of the trials in flight
+            int rc = dalloc(ctx, &ctx->pm.elane, (size_t)ctx->R * (size_t)ctx->pm.n * 64);
+            if (rc) return rc;
+            gl.prec.elane = ctx->pm.elane;
+        }
     }
     if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations
         if (ctx->has_scalar_model && ctx->sm.n_values <= 127 && ctx->sm.n >= 1024) {  // one-byte value array (C4: 4 waves per CU instead of 3)

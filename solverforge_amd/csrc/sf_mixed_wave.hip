@@ -100,6 +100,7 @@ struct GLeaves {
     PrecModel prec;          // ListPrecedenceMakespanConstraint of the list class (prec.on; PREC instantiations, sf_precedence.h)
     int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
     int32_t prec_inc;        // HBM scratch: list change / swap trials take the incremental refresh (prec_trial_inc; opt-in, see sf_precedence.h)
+    int32_t prec_sweep;      // HBM scratch: the list change / swap trials of a replay chunk are scored 64 at a time (prec_trial_sweep64)
 };
 
 template <class VT>
@@ -362,11 +363,97 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             pinc.SQ[t] = 0;
         }
     }
+    const bool prec_sweep = PREC && !prec_in_lds && !prec_incremental && gl.prec_sweep != 0 && gl.prec.elane != nullptr;
+    PrecSweep psw{};
+    uint32_t* const psw_lp = prec_sweep ? gl.prec.lpred + (size_t)r * gl.prec.n : nullptr;
+    uint32_t* const psw_pos = prec_sweep ? gl.prec.pos + (size_t)r * gl.prec.n : nullptr;
+    uint32_t* const psw_roff = prec_sweep ? gl.prec.roff + (size_t)r * ((size_t)gl.prec.n + 1) : nullptr;
+    int32_t* const psw_pmax = prec_sweep ? gl.prec.pmax + (size_t)r * ((size_t)gl.prec.n + 1) : nullptr;
+    uint32_t* const psw_rnd = prec_sweep ? gl.prec.rnd + (size_t)r * gl.prec.n : nullptr;
+    PrecRec* const psw_rec = prec_sweep ? (PrecRec*)gl.prec.rec + (size_t)r * gl.prec.n : nullptr;
     // one full evaluation of the lists in LDS: typed LDS accessors when the scratch lives there
     auto prec_run = [&]() -> PrecResult {
         if (prec_in_lds)
             return prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u32*)prec_Q,
                                                    (prec_lds_u32*)prec_S);
+        if (prec_sweep) {  // committed evaluation + what the lane-per-trial sweep reads: list predecessors, order positions, round starts, prefix maxima
+            __shared__ uint32_t s_psw_info[4][4];
+            uint32_t* info = s_psw_info[threadIdx.x >> 6];
+            const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, psw_lp, info, psw_roff);
+            wave_sync();
+            const uint32_t pn = (uint32_t)gl.prec.n;
+            psw.viol = uni(info[0]);
+            psw.ok = uni(info[1]) == 0u && !gl.prec.has_zero_duration;
+            psw.rounds = uni(info[2]);
+            psw.mk = (int32_t)pr.makespan;
+            psw.pen_fixed = pr.penalty - (int64_t)psw.viol - (uni(info[1]) ? (int64_t)pn : 0);
+            prec_sync();
+            if (psw.ok) {
+                for (uint32_t t = lane; t < pn; t += 64) {
+                    const uint32_t w = PrecMemGlobal::ld(prec_Q + t);
+                    psw_pos[w] = t;
+                    uint32_t lo = 0, hi = psw.rounds;  // the round whose range holds position t
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (PrecMemGlobal::ld(psw_roff + mid) <= t)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    psw_rnd[w] = lo;
+                }
+                int32_t carry = 0;  // prefix maximum of the finish times along the order
+                for (uint32_t base = 0; base < pn; base += 64) {
+                    const uint32_t t = base + lane;
+                    int32_t f = 0;
+                    if (t < pn) {
+                        const uint32_t w = PrecMemGlobal::ld(prec_Q + t);
+                        f = PrecMemGlobal::ld(prec_E + w) + gl.prec.dur[w];
+                    }
+                    int32_t inc = f;  // inclusive max scan over the 64 lanes
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int32_t up = __shfl_up(inc, o);
+                        if ((int)lane >= o) inc = up > inc ? up : inc;
+                    }
+                    inc = inc > carry ? inc : carry;
+                    const int32_t excl = lane == 0 ? carry : (int32_t)__shfl_up(inc, 1);
+                    if (t < pn) psw_pmax[t] = lane == 0 ? carry : excl;
+                    carry = (int32_t)__shfl(inc, 63);
+                }
+                if (lane == 0) psw_pmax[pn] = carry;
+                prec_sync();
+                for (uint32_t t = lane; t < pn; t += 64) {  // the sweep records, one per order position
+                    const uint32_t w = PrecMemGlobal::ld(prec_Q + t);
+                    PrecRec rc;
+                    rc.w = w;
+                    rc.dur_w = (uint32_t)gl.prec.dur[w];
+                    const uint32_t po = gl.prec.pred_off[w];
+                    rc.np = gl.prec.pred_off[w + 1] - po;
+                    rc._pad = 0;
+                    const uint32_t lpc = PrecMemGlobal::ld(psw_lp + w);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const uint32_t pp = q < 2 ? ((uint32_t)q < rc.np ? gl.prec.pred[po + q] : PREC_NONE) : lpc;
+                        rc.p[q] = pp;
+                        rc.pos[q] = rc.dur[q] = rc.cfin[q] = 0;
+                        if (pp != PREC_NONE) {
+                            rc.pos[q] = PrecMemGlobal::ld(psw_pos + pp);
+                            rc.dur[q] = (uint32_t)gl.prec.dur[pp];
+                            rc.cfin[q] = (uint32_t)(PrecMemGlobal::ld(prec_E + pp) + gl.prec.dur[pp]);
+                        }
+                    }
+                    psw_rec[t] = rc;
+                }
+                prec_sync();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the records are read with plain loads: drop what the L1 holds of the last commit's
+            }
+            psw.E = (const PREC_G int32_t*)prec_E, psw.LP = (const PREC_G uint32_t*)psw_lp, psw.LS = (const PREC_G uint32_t*)prec_S;
+            psw.TOPO = (const PREC_G uint32_t*)prec_Q, psw.POS = (const PREC_G uint32_t*)psw_pos, psw.ROFF = (const PREC_G uint32_t*)psw_roff;
+            psw.RND = (const PREC_G uint32_t*)psw_rnd, psw.PMAX = (const PREC_G int32_t*)psw_pmax, psw.REC = (const PREC_G PrecRec*)psw_rec;
+            psw.EL = (PREC_G int32_t*)(gl.prec.elane + (size_t)r * gl.prec.n * 64);
+            return pr;
+        }
         if (!prec_incremental) return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
         // committed evaluation: also the list predecessors, the owner violations, the cycle flag and the makespan multiplicity
         __shared__ uint32_t s_prec_info[4][2];
@@ -384,6 +471,11 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     // full evaluation of a TRIAL state (move kinds the incremental refresh does not cover): its own scratch, so the committed
     // earliest starts / list neighbours survive (trial values, both frontiers and the changed list are free between trials)
     auto prec_run_trial = [&]() -> PrecResult {
+        if (prec_sweep) {  // (earliest, in-degree, queue, list successor) that are no part of the committed summary
+            const size_t pb = (size_t)r * gl.prec.n;
+            return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, (int32_t*)(gl.prec.changed + pb), prec_D, gl.prec.stamp_q + pb,
+                                                      gl.prec.queue2 + pb);
+        }
         if (!prec_incremental) return prec_run();
         return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, (int32_t*)pinc.CH, prec_D, prec_Q, pinc.Q2);
     };
@@ -1544,6 +1636,23 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 doable = doable && valid;
                 if (PREC) {
                     uint64_t todo = __ballot(doable && my_kind >= 4 && my_kind != 1024);
+                    if (prec_sweep && psw.ok) {  // the list change / swap candidates of the chunk: one lane each, scored together
+                        const bool cand = doable && (my_kind == 4 || my_kind == 16 || my_kind == 8 || my_kind == 32);
+                        const uint64_t cm_ = __ballot(cand);
+                        if (cm_) {
+                            int64_t tp = 0, tm_ = 0;
+                            prec_trial_sweep64<uint16_t>(gl.prec, psw, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, cand, (my_kind == 4 || my_kind == 16) ? 2 : 3, m0 >> 16, m0 & 0xFFFFu,
+                                                         m1 >> 16, m1 & 0xFFFFu, tp, tm_);
+                            if (cand) {
+#pragma unroll
+                                for (int kk = 0; kk < L; ++kk) {
+                                    if (kk == gl.prec.hard_level) sc.v[kk] -= tp - prec_pen;
+                                    if (kk == gl.prec.mk_level) sc.v[kk] -= tm_ - prec_mk;
+                                }
+                            }
+                            todo &= ~cm_;
+                        }
+                    }
                     while (todo) {
                         const int ci = __ffsll((unsigned long long)todo) - 1;
                         todo &= todo - 1;

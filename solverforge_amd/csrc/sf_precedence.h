@@ -49,6 +49,14 @@ struct PrecModel {
     uint32_t* stamp_q;   // [R][n] round stamp: queued for the next frontier / visited by a cycle search
     uint32_t* changed;   // [R][n] nodes whose earliest start a trial replaced
     uint32_t* queue2;    // [R][n] second frontier
+    // lane-per-trial sweep (prec_trial_sweep64): the committed topological order lives in `queue` (Kahn's pop order), plus
+    uint32_t* pos;       // [R][n]      position of every node in that order
+    uint32_t* roff;      // [R][n + 1]  start of every Kahn round in the order (the nodes of one round are mutually independent)
+    uint32_t* rnd;       // [R][n]      Kahn round of every node
+    uint32_t* rec;       // [R][n][16]  one 64-byte sweep record per order position (PrecRec)
+    int32_t* pmax;       // [R][n + 1]  prefix maximum of the finish times along the order
+    int32_t* elane;      // [R][n][64]  earliest starts of the 64 trials in flight, node-major (one coalesced 256-byte row per node)
+    int32_t has_zero_duration;  // a zero-duration node could hide a cycle from the sweep: the full evaluation is used instead
 };
 
 struct PrecResult {
@@ -94,7 +102,7 @@ __device__ __forceinline__ uint32_t prec_mbcnt(uint64_t mask) {
 // words.  Wave-uniform result.
 template <class VT, class MEM = PrecMemGlobal>
 __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
-                                             typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr) {
+                                             typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr, uint32_t* ROFF = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     for (uint32_t i = lane; i < n; i += 64) {
@@ -138,8 +146,11 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
     }
     prec_sync();
     int32_t mk = 0;
+    uint32_t rounds = 0;
     while (head < tail) {
         const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
+        if (ROFF && lane == 0) ROFF[rounds] = head;
+        rounds += 1;
         const bool act = lane < cnt;
         int32_t fin = 0;
         uint32_t so = 0, deg = 0, ls = PREC_NONE;
@@ -176,9 +187,11 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
         mk = other > mk ? other : mk;
         viol += (uint32_t)__shfl_xor((int)viol, o);
     }
-    if (out_info) {  // wave-uniform: wrong-owner items, cyclic flag
+    if (ROFF && lane == 0) ROFF[rounds] = head;
+    if (out_info) {  // wave-uniform: wrong-owner items, cyclic flag, Kahn rounds
         out_info[0] = viol;
         out_info[1] = cyclic ? 1u : 0u;
+        out_info[2] = rounds;
     }
     PrecResult r;
     r.penalty = pm.const_penalty + (int64_t)viol + (int64_t)(n - total) + (cyclic ? (int64_t)n : 0);
@@ -521,6 +534,277 @@ __device__ __noinline__ bool prec_trial_inc(const PrecModel pm, PrecInc& st, con
     out.penalty = pen_ok;
     out.makespan = mk < 0 ? 0 : (int64_t)mk;
     return true;
+}
+
+// ---- lane-per-trial sweep (HBM scratch) ------------------------------------------------------------------------------------
+// What the incremental numbers above asked for: 64 trials in flight per wavefront instead of one.  Every list change / list swap
+// candidate of a replay chunk gets a LANE; all lanes walk the COMMITTED topological order (Kahn's pop order of the last full
+// evaluation) together, each recomputing the earliest start of the current node from its own view of the graph -- the fixed
+// predecessors (wave-uniform), plus the list predecessor, which differs from the committed one only for the at most six nodes
+// of the lane's overlay.  The per-trial earliest starts live node-major in HBM ([node][lane]: one coalesced 256-byte row per
+// access); the nodes of one Kahn round are mutually independent, so a round's loads pipeline and the wave synchronises once per
+// round.  The sweep starts at the earliest position any lane's change can reach (everything before keeps its committed value,
+// the prefix maximum of the finish times gives its share of the makespan).
+// Convergence: old edges lead to a LATER Kahn round; only a lane's added edges can lead to the same or an earlier round
+// ("backward": the nodes of one round are priced from the values of the rounds before it).  A path with b backward edges is
+// exact after b + 1 sweeps (Gauss-Seidel over the rounds), so a lane without backward edges is exact -- and acyclic -- after one
+// sweep; a lane with b > 0 backward edges sweeps until nothing changes, and if sweep b + 2 still changes a value the
+// added edges close a cycle (every duration is positive, checked on the host, so a cycle never stabilises).
+// One order position as the sweep reads it: the node, its duration, and per predecessor (two fixed ones and the committed list
+// predecessor; PREC_NONE = absent) the node, its order position, its duration and its committed finish time.  Built at every
+// commit, so a batch of nodes costs one record fetch and one round of earliest-start loads instead of a chain of five.
+// Address-space typed pointers for the out-of-line sweep: behind a call boundary plain pointers compile to FLAT accesses.
+#define PREC_G __attribute__((address_space(1)))
+#define PREC_L __attribute__((address_space(3)))
+struct PrecRec {
+    uint32_t w, dur_w, np, _pad;
+    uint32_t p[3], pos[3], dur[3], cfin[3];
+};
+static_assert(sizeof(PrecRec) == 64, "one cache line per order position");
+struct PrecSweep {
+    const PREC_G PrecRec* REC;
+    const PREC_G int32_t* E;      // committed earliest starts
+    const PREC_G uint32_t* LP;    // committed list predecessor / successor
+    const PREC_G uint32_t* LS;
+    const PREC_G uint32_t* TOPO;  // committed topological order
+    const PREC_G uint32_t* POS;
+    const PREC_G uint32_t* ROFF;
+    const PREC_G uint32_t* RND;
+    const PREC_G int32_t* PMAX;
+    PREC_G int32_t* EL;
+    uint32_t rounds;
+    int64_t pen_fixed;
+    uint32_t viol;
+    int32_t mk;
+    int32_t ok;            // committed state acyclic and every duration positive
+};
+__device__ __forceinline__ uint32_t prec_gld(const PREC_G uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t prec_gld(const PREC_G int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct LaneOverlay {  // one trial's changed list neighbours, in this lane's registers (no dynamic indexing)
+    uint32_t key[6], pr[6], su[6];
+    uint32_t ppos[6], pdur[6], pcfin[6];  // of pr[k]: order position, duration, committed finish (filled by finish())
+    uint32_t n;
+    __device__ __forceinline__ void finish(const PrecModel& pm, const PrecSweep& st) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            ppos[k] = pdur[k] = pcfin[k] = 0;
+            if ((uint32_t)k < n && pr[k] != PREC_NONE) {
+                const int32_t dk = ((const PREC_G int32_t*)pm.dur)[pr[k]];
+                ppos[k] = prec_gld(st.POS + pr[k]);
+                pdur[k] = (uint32_t)dk;
+                pcfin[k] = (uint32_t)(prec_gld(st.E + pr[k]) + dk);
+            }
+        }
+    }
+    __device__ __forceinline__ void init() {
+        n = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) key[k] = pr[k] = su[k] = PREC_NONE;
+    }
+    __device__ __forceinline__ void touch(uint32_t node, const PrecSweep& st, bool set_p, uint32_t p, bool set_s, uint32_t sv) {
+        if (node == PREC_NONE) return;
+        bool found = false;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (!found && (uint32_t)k < n && key[k] == node) {
+                found = true;
+                if (set_p) pr[k] = p;
+                if (set_s) su[k] = sv;
+            }
+        if (found) return;
+        const uint32_t p0 = prec_gld(st.LP + node), s0 = prec_gld(st.LS + node);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if ((uint32_t)k == n) {
+                key[k] = node;
+                pr[k] = set_p ? p : p0;
+                su[k] = set_s ? sv : s0;
+            }
+        n += 1;
+    }
+    __device__ __forceinline__ void set_pred(uint32_t node, uint32_t v, const PrecSweep& st) { touch(node, st, true, v, false, 0u); }
+    __device__ __forceinline__ void set_succ(uint32_t node, uint32_t v, const PrecSweep& st) { touch(node, st, false, 0u, true, v); }
+    __device__ __forceinline__ uint32_t pred_of(uint32_t node, uint32_t committed) const {
+        uint32_t v = committed;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if ((uint32_t)k < n && key[k] == node) v = pr[k];
+        return v;
+    }
+};
+
+// Lanes with `cand` hold one candidate each (ck 2 = list change (a, i) -> (b, j), 3 = list swap); the others idle along.
+// Returns per lane the constraint's (penalty, makespan) of the trial state.
+template <class VT>
+__device__ __noinline__ void prec_trial_sweep64(const PrecModel pm, const PrecSweep st, const PREC_L VT* visits, const PREC_L uint32_t* off, bool cand, int ck, uint32_t a,
+                                                uint32_t i, uint32_t b, uint32_t j, int64_t& out_pen, int64_t& out_mk) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = (uint32_t)pm.n;
+    LaneOverlay ov;
+    ov.init();
+    int32_t dviol = 0;
+    bool same = !cand;  // the candidate leaves the lists as they are
+    if (cand) {
+        const uint32_t oa = off[a], la = off[a + 1] - oa, ob = off[b], lb = off[b + 1] - ob;
+        const uint32_t x = (uint32_t)visits[oa + i];
+        if (ck == 2) {
+            if (a == b && (j == i || j == i + 1)) {
+                same = true;
+            } else {
+                const uint32_t s = j < lb ? (uint32_t)visits[ob + j] : PREC_NONE;  // x goes in front of s (the end of the list when none)
+                const uint32_t p = prec_gld(st.LP + x), q = prec_gld(st.LS + x);
+                ov.set_succ(p, q, st);
+                ov.set_pred(q, p, st);
+                uint32_t r;  // the element in front of the slot once x is out
+                if (s != PREC_NONE)
+                    r = ov.pred_of(s, prec_gld(st.LP + s));
+                else {
+                    r = lb ? (uint32_t)visits[ob + lb - 1] : PREC_NONE;
+                    if (r == x) r = p;
+                }
+                ov.set_succ(r, x, st);
+                ov.set_pred(x, r, st);
+                ov.set_succ(x, s, st);
+                ov.set_pred(s, x, st);
+                if (pm.owner && a != b) {
+                    const int32_t ow = ((const PREC_G int32_t*)pm.owner)[x];
+                    dviol = (ow >= 0 && (uint32_t)ow != b ? 1 : 0) - (ow >= 0 && (uint32_t)ow != a ? 1 : 0);
+                }
+            }
+        } else {
+            const uint32_t y = (uint32_t)visits[ob + j];
+            if (x == y) {
+                same = true;
+            } else {
+                const uint32_t px = prec_gld(st.LP + x), qx = prec_gld(st.LS + x), py = prec_gld(st.LP + y), qy = prec_gld(st.LS + y);
+                if (qx == y) {  // px x y qy -> px y x qy
+                    ov.set_succ(px, y, st), ov.set_pred(y, px, st), ov.set_succ(y, x, st), ov.set_pred(x, y, st), ov.set_succ(x, qy, st), ov.set_pred(qy, x, st);
+                } else if (qy == x) {  // py y x qx -> py x y qx
+                    ov.set_succ(py, x, st), ov.set_pred(x, py, st), ov.set_succ(x, y, st), ov.set_pred(y, x, st), ov.set_succ(y, qx, st), ov.set_pred(qx, y, st);
+                } else {
+                    ov.set_succ(px, y, st), ov.set_pred(y, px, st), ov.set_succ(y, qx, st), ov.set_pred(qx, y, st);
+                    ov.set_succ(py, x, st), ov.set_pred(x, py, st), ov.set_succ(x, qy, st), ov.set_pred(qy, x, st);
+                }
+                if (pm.owner && a != b) {
+                    const int32_t ox = pm.owner[x], oy = pm.owner[y];
+                    dviol = (ox >= 0 && (uint32_t)ox != b ? 1 : 0) - (ox >= 0 && (uint32_t)ox != a ? 1 : 0) + (oy >= 0 && (uint32_t)oy != a ? 1 : 0) -
+                            (oy >= 0 && (uint32_t)oy != b ? 1 : 0);
+                }
+            }
+        }
+    }
+    // where the lane's change starts in the committed order, and how many of its added edges point backward
+    uint32_t start_pos = n, back = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if ((uint32_t)k < ov.n) {
+            const uint32_t node = ov.key[k];
+            const uint32_t pk = prec_gld(st.POS + node);
+            if (ov.pr[k] != prec_gld(st.LP + node)) start_pos = pk < start_pos ? pk : start_pos;
+            if (ov.su[k] != PREC_NONE && ov.su[k] != prec_gld(st.LS + node) &&
+                prec_gld(st.RND + ov.su[k]) <= prec_gld(st.RND + node))  // not into a later round: needs a sweep of its own
+                back += 1;
+        }
+    const bool sweeping = !same && start_pos < n;
+    uint32_t wstart = sweeping ? start_pos : n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)wstart, o);
+        wstart = other < wstart ? other : wstart;
+    }
+    wstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)wstart);
+    const int64_t pen_ok = st.pen_fixed + (int64_t)((int32_t)st.viol + dviol);
+    out_pen = pen_ok;
+    out_mk = st.mk;
+    if (wstart >= n) return;  // no lane changes an earliest start
+    // the round that holds position wstart
+    uint32_t k0 = 0;
+    {
+        uint32_t lo = 0, hi = st.rounds;  // ROFF[lo] <= wstart < ROFF[hi]
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (prec_gld(st.ROFF + mid) <= wstart)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        k0 = lo;
+    }
+    // the committed arrays were written by this wave earlier in the launch: coherent (never scalar-cached) loads (prec_gld)
+    PREC_G int32_t* const el = st.EL + lane;  // this lane's column: only this lane ever touches it, program order is all the ordering it needs
+    bool done = !sweeping;      // this lane's values are final
+    bool cyclic = false;
+    int32_t mk = 0;
+    ov.finish(pm, st);
+    const PREC_G uint32_t* const g_pred = (const PREC_G uint32_t*)pm.pred;
+    const PREC_G uint32_t* const g_pred_off = (const PREC_G uint32_t*)pm.pred_off;
+    const PREC_G int32_t* const g_dur = (const PREC_G int32_t*)pm.dur;
+    constexpr int U = 8;  // nodes of one round priced together: one record fetch, one round of earliest-start loads, then the stores
+    for (uint32_t sweep = 1; __ballot(!done); ++sweep) {
+        const bool live = !done;
+        bool changed = false;
+        int32_t smk = prec_gld(st.PMAX + wstart);  // finish times before the sweep window
+        for (uint32_t k = k0; k < st.rounds; ++k) {
+            const uint32_t q0 = prec_gld(st.ROFF + k), r1 = prec_gld(st.ROFF + k + 1);
+            const uint32_t r0 = q0 < wstart ? wstart : q0;
+            for (uint32_t t = r0; t < r1; t += U) {
+                int32_t ne[U], old[U];
+                uint32_t wn[U], wd[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {  // the batch's tail repeats the round's last node (same value stored twice)
+                    const uint32_t tt = t + (uint32_t)u < r1 ? t + (uint32_t)u : r1 - 1u;
+                    const PrecRec rc = *(const PrecRec*)(st.REC + tt);  // wave-uniform 64-byte record (the cast keeps the host pass happy; the device infers global)
+                    wn[u] = rc.w;
+                    wd[u] = rc.dur_w;
+                    int32_t v = 0;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)  // fixed predecessors
+                        if (rc.p[q] != PREC_NONE) {
+                            const int32_t f = rc.pos[q] >= wstart ? el[(size_t)rc.p[q] * 64] + (int32_t)rc.dur[q] : (int32_t)rc.cfin[q];
+                            v = f > v ? f : v;
+                        }
+                    for (uint32_t q = 2; q < rc.np; ++q) {  // more than two fixed predecessors: the general path
+                        const uint32_t pp = g_pred[g_pred_off[rc.w] + q];
+                        const int32_t f = (prec_gld(st.POS + pp) >= wstart ? el[(size_t)pp * 64] : prec_gld(st.E + pp)) + g_dur[pp];
+                        v = f > v ? f : v;
+                    }
+                    // the list predecessor: the committed one unless this lane's overlay names the node
+                    uint32_t lp = rc.p[2], lpos = rc.pos[2], ldur = rc.dur[2], lcf = rc.cfin[2];
+#pragma unroll
+                    for (int o = 0; o < 6; ++o)
+                        if ((uint32_t)o < ov.n && ov.key[o] == rc.w) lp = ov.pr[o], lpos = ov.ppos[o], ldur = ov.pdur[o], lcf = ov.pcfin[o];
+                    if (lp != PREC_NONE) {
+                        const int32_t f = lpos >= wstart ? el[(size_t)lp * 64] + (int32_t)ldur : (int32_t)lcf;
+                        v = f > v ? f : v;
+                    }
+                    ne[u] = v;
+                    old[u] = sweep > 1 ? el[(size_t)rc.w * 64] : 0;
+                }
+                if (live) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (sweep > 1) changed = changed || old[u] != ne[u];
+                        el[(size_t)wn[u] * 64] = ne[u];
+                        const int32_t f = ne[u] + (int32_t)wd[u];
+                        smk = f > smk ? f : smk;
+                    }
+                }
+            }
+        }
+        if (live) {
+            mk = smk;
+            if (back == 0 || (sweep > 1 && !changed)) {
+                done = true;
+            } else if (sweep >= back + 2u) {  // still moving after every backward edge had its sweep: a cycle
+                done = true;
+                cyclic = true;
+            }
+        }
+    }
+    if (sweeping) {
+        out_pen = cyclic ? pen_ok + (int64_t)n : pen_ok;
+        out_mk = cyclic ? 0 : (int64_t)mk;
+    }
 }
 
 }  // namespace sf

@@ -7,15 +7,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lds", "hbm", "hbm_incremental"])
+@pytest.fixture(autouse=True, params=["lds", "hbm", "hbm_full", "hbm_incremental"])
 def scratch_mode(request, monkeypatch):
-    """Every test runs with the constraint's scratch in the replica's LDS slice (small graphs), forced into HBM (the layout of
-    large graphs: one full evaluation per trial) and in HBM with the opt-in incremental refresh of list change / swap trials
-    (prec_trial_inc); the library reads SF_AMD_PREC_HBM / SF_AMD_PREC_INC at every launch."""
-    monkeypatch.delenv("SF_AMD_PREC_HBM", raising=False)
-    monkeypatch.delenv("SF_AMD_PREC_INC", raising=False)
+    """Every test runs with the constraint's scratch in the replica's LDS slice (small graphs: one full evaluation per trial) and
+    forced into HBM (the layout of large graphs) three ways: the default lane-per-trial sweep of the list change / swap trials
+    (prec_trial_sweep64), one full evaluation per trial, and the opt-in wave-cooperative incremental refresh (prec_trial_inc).
+    The library reads SF_AMD_PREC_HBM / SF_AMD_PREC_NO_SWEEP / SF_AMD_PREC_INC at every launch."""
+    for k in ("SF_AMD_PREC_HBM", "SF_AMD_PREC_INC", "SF_AMD_PREC_NO_SWEEP"):
+        monkeypatch.delenv(k, raising=False)
     if request.param != "lds":
         monkeypatch.setenv("SF_AMD_PREC_HBM", "1")
+    if request.param == "hbm_full":
+        monkeypatch.setenv("SF_AMD_PREC_NO_SWEEP", "1")
     if request.param == "hbm_incremental":
         monkeypatch.setenv("SF_AMD_PREC_INC", "1")
     return request.param
