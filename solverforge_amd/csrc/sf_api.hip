@@ -1905,9 +1905,10 @@ int32_t sf_phase_start(sf_ctx* ctx) {
 template <int L, class VT, bool RUIN = false, bool PREC = false>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas, bool trace) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
+    const bool tables = ctx->has_scalar_model && ctx->sm.tables();
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
                   gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
-                  PREC && gl.prec_lds ? gl.prec.n : 0);
+                  PREC && gl.prec_lds ? gl.prec.n : 0, tables ? ctx->sm.n_values : 0, tables && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     // FAST instantiation: the reference's default list policy on a list-only model (see k_mixed_search_wave)
     static const bool no_fast = std::getenv("SF_AMD_MIXED_NO_FAST") != nullptr;  // diagnostics / parity tests: force the general instantiation
@@ -2026,8 +2027,6 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         if ((int)ctx->union_weights.size() != gl.n) return fail(ctx, SF_ERR_INVALID, "union weight count must match child count");
         for (int l = 0; l < gl.n; ++l) gl.weight[l] = ctx->union_weights[l];
     }
-    if (ctx->has_scalar_model && ctx->sm.tables())
-        return fail(ctx, SF_ERR_UNSUPPORTED, "value-keyed constraints (self-join / grouped sum / exists by value) run in the scalar engine only");
     if (ctx->has_list_model && (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536))
         return fail(ctx, SF_ERR_UNSUPPORTED, "generic engine packs list elements and positions in 16 bits");
     p.n_leaves = gl.n;

@@ -105,14 +105,16 @@ struct GLeaves {
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, nstmp, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, leaftab, total;
+    size_t ring, ringx, load, off, visits, vals, tsum, tcnt, tpt, nstmp, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, leaftab, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
     // n_leaves rings only: the LDS slice decides how many replicas a CU holds
     // has_ruin: 0 no ruin leaf, 1 general path (slot prefix only), 2 LDS fast path (+ edge table, list-end edges, matrix row; sf_ruin.h)
     // prec_words: node count of the precedence constraint when its four scratch arrays live in LDS (sf_precedence.h), else 0
+    // n_table / run_P: per-value tables of the scalar class's value-keyed constraints (n_values entries; the consecutive-runs /
+    // presence table behind the count table, as SCarve lays them out), 0 when the class has none
     __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0,
-                               int prec_words = 0) {
+                               int prec_words = 0, int n_table = 0, int run_P = 0) {
         size_t o = 0;
         ring = o;  // the candidate rings live in HBM (GLeaves::ring / ringx) unless SF_MIXED_RING_LDS
         o = align_up(o + (SF_MIXED_RING_LDS ? sizeof(uint32_t) * 2 * GRC * n_leaves : 0), 16);
@@ -136,6 +138,12 @@ struct GCarve {
         o = align_up(o + sizeof(uint16_t) * n_cap, 16);
         vals = o;
         o = align_up(o + sizeof(VT) * n_scalar, 16);
+        tsum = o;
+        o = align_up(o + sizeof(int64_t) * n_table, 16);
+        tcnt = o;
+        o = align_up(o + sizeof(uint32_t) * n_table, 16);
+        tpt = o;  // == runs_table(cnt): the aligned end of the count table
+        o = align_up(o + (run_P ? runs_table_bytes(n_table, run_P) : 0), 16);
         nstmp = o;  // nearby scalar leaves: the ranked survivors of the row being emitted
         o = align_up(o + (n_scalar ? sizeof(uint16_t) * 64 : 0), 16);
         kopt = o;  // working set of the distance-pruned 3-opt stream
@@ -265,8 +273,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const int V = has_list ? lm.V : 0;
     const bool has_nearby = gl.has_nearby != 0;
     const bool unified_eval = FAST || (has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval);
+    const bool tables = !FAST && has_scalar && sm.tables();  // value-keyed constraints of the scalar class: per-value tables in LDS
     const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim,
-                        PREC && gl.prec_lds ? gl.prec.n : 0);
+                        PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0);
     unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
     uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
     uint8_t* ringx = SF_MIXED_RING_LDS ? (uint8_t*)(mem + cv.ringx) : gl.ringx + (size_t)r * GL * GRC;   // [leaf][GRC]
@@ -275,6 +284,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
     VT* s_vals = (VT*)(mem + cv.vals);
     uint16_t* ns_tmp = (uint16_t*)(mem + cv.nstmp);
+    int64_t* t_sum = (int64_t*)(mem + cv.tsum);  // per-value summed size / entity count of the working state
+    uint32_t* t_cnt = (uint32_t*)(mem + cv.tcnt);
     uint32_t* node_slot = (uint32_t*)(mem + cv.node);
     uint16_t* nb_slot_base = (uint16_t*)(mem + cv.slotbase);  // [nearby leaf 0/1][V+1]
     uint16_t* nb_route_at = (uint16_t*)(mem + cv.routeat);
@@ -311,7 +322,16 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         for (uint32_t t = lane; t < tot; t += 64) s_visits[t] = (uint16_t)g_visits[t];
     }
     for (uint32_t t = lane; t < ns; t += 64) s_vals[t] = (VT)g_vals[t];
+    if (tables)
+        for (uint32_t v = lane; v < (uint32_t)sm.n_values; v += 64) {
+            t_sum[v] = 0;
+            t_cnt[v] = 0;
+        }
     wave_sync();
+    if (tables) {
+        scalar_tables_accumulate(sm, s_vals, lane, 64u, t_cnt, t_sum);
+        wave_sync();
+    }
     if (has_nearby) {  // node -> (route << 16 | position)
         for (uint32_t t = lane; t < (uint32_t)lm.dim; t += 64) node_slot[t] = NODE_NONE;
         wave_sync();
@@ -518,6 +538,26 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const uint64_t cm_hi = use_cm ? __ballot(lane + 64 < (uint32_t)V && gcd_u32(lane + 64, (uint32_t)V) == 1) : 0ull;
 
     for (int64_t step = 0; step < p.n_steps; ++step) {
+        // load-balance / balance aggregates of the step snapshot (the tables change only at commit): every lane gets the totals
+        int64_t lbv[4] = {0, 0, 0, 0};
+        if (tables && sm.grp_level >= 0 && sm.grp_mode >= 1) {
+            int64_t s1 = 0, s2 = 0;
+            uint32_t nk = 0;
+            for (uint32_t v = lane; v < (uint32_t)sm.n_values; v += 64)
+                if (t_cnt[v]) {
+                    const int64_t x = sm.grp_mode == 2 ? (int64_t)t_cnt[v] : t_sum[v];
+                    s1 = wadd(s1, x);
+                    s2 = wadd(s2, (int64_t)((uint64_t)x * (uint64_t)x));
+                    nk += 1;
+                }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) {
+                s1 = wadd(s1, (int64_t)shfl_u64((uint64_t)s1, (int)(lane ^ (uint32_t)o)));
+                s2 = wadd(s2, (int64_t)shfl_u64((uint64_t)s2, (int)(lane ^ (uint32_t)o)));
+                nk += (uint32_t)__shfl((int)nk, (int)(lane ^ (uint32_t)o));
+            }
+            lbv[0] = s1, lbv[1] = s2, lbv[2] = (int64_t)nk, lbv[3] = global_stat(sm, s1, s2, nk);
+        }
         uint64_t sidx, sseed;
         if (dry_run) {
             sidx = p.dry_step_index;
@@ -1597,8 +1637,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     m1 = rq[1];
                     mx_ = ringx[my_leaf * GRC + (my_idx & (GRC - 1))];
                     if (my_kind <= 2) {
-                        const ScalarDelta d = my_kind == 1 ? eval_scalar_move(sm, s_vals, 0, m0, 0u, (int32_t)m1)
-                                                           : eval_scalar_move(sm, s_vals, 1, m0, m1, 0);
+                        const uint32_t* tc = tables ? t_cnt : nullptr;
+                        const int64_t* ts = tables ? t_sum : nullptr;
+                        const ScalarDelta d = my_kind == 1 ? eval_scalar_move(sm, s_vals, 0, m0, 0u, (int32_t)m1, tc, ts, tables ? lbv : nullptr)
+                                                           : eval_scalar_move(sm, s_vals, 1, m0, m1, 0, tc, ts, tables ? lbv : nullptr);
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
                     } else if (RUIN && my_kind == 1024) {  // list ruin: scored when it was generated
@@ -1859,6 +1901,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     p.trace_applied[6] = kind == 1 ? (int32_t)b : -1;
                 }
                 if (lane == 0) {
+                    if (tables) scalar_tables_apply(sm, s_vals, kind == 1 ? 0 : 1, a, b, (int32_t)b, t_cnt, t_sum);
                     if (kind == 1)
                         s_vals[a] = (VT)(int32_t)b;
                     else {

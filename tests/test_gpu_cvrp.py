@@ -8,9 +8,19 @@ pytestmark = pytest.mark.gpu
 _ENGINE = {"value": 0}
 
 
-@pytest.fixture(params=["block", "wave"], autouse=True)
+# The block engine (one 1024-thread workgroup per replica) is kept for models whose replica does not fit a wave's LDS slice; AUTO
+# never picks it at any BASELINE config.  It stays parity-covered by the traced-step, fused multi-replica
+# and CVRP-5000 tests; everything else runs on the wave engine only.
+BLOCK_ALSO = {"test_traced_steps_match_oracle", "test_fused_solve_matches_oracle_multi_replica", "test_cvrp_5000_properties"}
+
+
+def pytest_generate_tests(metafunc):
+    if "engine" in metafunc.fixturenames:
+        metafunc.parametrize("engine", ["wave", "block"] if metafunc.function.__name__ in BLOCK_ALSO else ["wave"], indirect=True)
+
+
+@pytest.fixture(autouse=True)
 def engine(request):
-    """Every parity test runs against both mappings of the fused search kernel."""
     _ENGINE["value"] = {"block": 1, "wave": 2}[request.param]
     yield request.param
     _ENGINE["value"] = 0

@@ -136,3 +136,67 @@ def test_configured_union_keeps_declaration_order(oracle):
     d2.calculate_score()
     gm2, _, _ = d2.open_cursor(2, 99, selection_order=3, cap=1 << 18)
     assert (_t(gm2) == streams["nearby_change"]).all()
+
+
+@pytest.mark.parametrize("model", ["bins_sum2", "bins_cap", "bins_fair", "bins_balance", "bins_tri", "assignment", "shift"])
+def test_value_keyed_constraints_in_the_generic_engine(oracle, model):
+    """the value-keyed nodes (keyed self-join incl. higher arity, grouped sum, load balance, balance,
+    keyed cross-join + exists, consecutive runs + complemented sum) with a configured root union, i.e. through the generic N-leaf
+    engine (per-value tables in the replica's LDS slice, updated at commit): cursor stream with trial scores, traced and fused
+    steps vs the oracle."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    rng = np.random.default_rng(7)
+    n, k = 70, 6
+    bins = rng.integers(-1, k, n).astype(np.int64)
+    sizes = rng.integers(1, 9, n).astype(np.int64)
+    if model.startswith("bins"):
+        cap = {"bins_sum2": -1, "bins_cap": 25, "bins_fair": -2, "bins_balance": -3, "bins_tri": 25}[model]
+        arity = 3 if model == "bins_tri" else 2
+        d = sfa.build_balance(bins, sizes, k, n_replicas=2, w_pair=3, cap=cap, arity=arity)
+        mk = lambda: oracle.Model.balance(k, bins, sizes, w_pair=3, cap=cap, arity=arity)
+    elif model == "assignment":
+        cost = rng.integers(0, 20, (n, k)).astype(np.int64)
+        cost[rng.random((n, k)) < 0.3] = 0
+        row_w = rng.integers(1, 6, k).astype(np.int64)
+        d = sfa.build_assignment(bins, cost, k, n_replicas=2, cost_weight=2, row_w=row_w, ex_mode=1, ex_level=1, ex_weight=3)
+        mk = lambda: oracle.Model.assignment(bins, cost, k, cost_weight=2, row_w=row_w, ex_mode=1, ex_level=1, ex_weight=3)
+    else:
+        n_nurses, n_days = 6, 12  # consecutive-runs (streak excess) + complemented workload: minimal-shift-scheduling's constraints
+        day = np.repeat(np.arange(n_days), 3).astype(np.int64)
+        nurse = rng.integers(-1, n_nurses, len(day)).astype(np.int64)
+        kw = dict(limit=2, w_streak=1, count_weight=1, target=4)
+        d = sfa.build_shift_schedule(nurse, day, n_nurses, n_replicas=2, **kw)
+        mk = lambda: oracle.Model.shift_schedule(nurse, day, n_nurses, **kw)
+    o = mk()
+    d.configure_union(1, None)  # RoundRobin: a configured union runs in the generic engine
+    d.configure(sfa.SolverConfig(random_seed=4, late_acceptance_size=5, accepted_count_limit=30))
+    o.configure(leaves=3, random_seed=4, la_size=5, limit=30, union_order=1)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    for order in (0, 3):
+        o.configure(leaves=3, random_seed=4, la_size=5, limit=30, union_order=1, selection_order=order)
+        gm, gs, gd = d.open_cursor(2, 55, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, 2, 55, order)
+        assert len(gm) == len(om) > 0 and (_t(gm) == _t(om)).all(), order
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all(), order
+    o.configure(leaves=3, random_seed=4, la_size=5, limit=30, union_order=1)
+    d.phase_start()
+    o.phase_start()
+    for step in range(12):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+    d.solve_steps(40)
+    scores = d.calculate_score()
+    for r in range(2):
+        o2 = mk()
+        o2.configure(leaves=3, random_seed=4 + r, la_size=5, limit=30, union_order=1)
+        o2.phase_start()
+        o2.steps(52)
+        assert (scores[r] == o2.score()[:2]).all(), r
+        assert (d.working_values(0, 0, replica=r) == o2.get_vars(0, 0)).all(), r
+    assert (d.fresh_score() == scores).all()
