@@ -828,6 +828,14 @@ static int build_list_model(sf_ctx* ctx, int d) {
             hipLaunchKernelGGL(k_mat_compress, dim3(1024), dim3(256), 0, ctx->stream, m.mat, n, m32);
             HIPCHK(ctx, hipGetLastError());
             m.mat32 = m32;
+            static const bool no16 = std::getenv("SF_AMD_NO_MAT16") != nullptr;  // diagnostics: A/B
+            if (kv.second.max_finite < 0xFFFF && !no16) {  // half-size copy for the trial gathers (ListModel::mat16)
+                uint16_t* m16 = nullptr;
+                if ((rc = dalloc(ctx, &m16, n))) return rc;
+                hipLaunchKernelGGL(k_mat_compress16, dim3(1024), dim3(256), 0, ctx->stream, m.mat, n, m16);
+                HIPCHK(ctx, hipGetLastError());
+                m.mat16 = m16;
+            }
         }
     for (auto& kv : ctx->facts)
         if (kv.second.type == 1 && kv.second.d0 == (void*)m.mat) {
@@ -1014,7 +1022,7 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
     size_t lds = 0;
     const size_t resident_wide = plan(false, 4 * SF_WAVES_PER_EU, wpb, lds);
     int mode = fast ? (ctx->lm_small ? 2 : 1) : 0;
-    if (mode == 2 && node_slot_compact_ok(ctx->lm.V)) {
+    if (mode == 2 && node_slot_compact_ok(ctx->lm.V) && ctx->lm.mat16) {  // (the COMPACT kernels gather from the u16 matrix)
         // the COMPACT slice when it puts more replicas on a CU: CVRP-5000 5 instead of 3 (LDS-bound, compiled for 4 waves per SIMD);
         // CVRP-1000 20 instead of 16 with the instantiation compiled for 5 waves per SIMD
         static const bool no_compact = std::getenv("SF_AMD_NO_COMPACT") != nullptr;  // diagnostics: A/B

@@ -784,6 +784,14 @@ __global__ __launch_bounds__(256) void k_mat_compress(const int64_t* __restrict_
     }
 }
 
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_mat_compress16(const int64_t* __restrict__ mat, size_t n, uint16_t* __restrict__ out) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const int64_t v = mat[t];
+        out[t] = (v >= 0 && v < 0xFFFF) ? (uint16_t)v : (uint16_t)0xFFFFu;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // evaluate_all / initialize: full recomputation from scratch (fresh_score; FullAssert)
 // grid = R blocks.  commit != 0 also (re)builds the per-route load aggregate + cached score.

@@ -25,6 +25,8 @@ struct ListModel {
     // facts
     const int64_t* mat; // dim x dim row-major (MatrixDistanceMeter + distance constraint)
     const uint32_t* mat32;  // optional compact copy: finite legs < 2^32-1 as u32, 0xFFFFFFFF = not finite
+    const uint16_t* mat16;  // optional half-size copy when every finite leg < 65535 (0xFFFF = not finite): the trial gathers of the COMPACT
+                            // wave kernel read it (2 MB instead of 4 at CVRP-1000: +5 %; no gain at CVRP-5000 or in the generic engine's unified delta, measured)
     int32_t mat_symmetric;  // mat[i][j] == mat[j][i] for every pair (checked on the host at upload)
     int32_t small32;        // every trial delta fits 32-bit arithmetic (all legs finite and < 2^26, small weights / loads)
     int32_t leg16;          // symmetric, compact copy present, every finite leg < 65535, dim <= 65535: 16-bit leg tables (sf_ruin.h)

@@ -529,7 +529,7 @@ __device__ __forceinline__ int32_t clamp_i64_to_i32(int64_t v) {
 // eval_list_move_legs, laid out as four "plus" and four "minus" legs so no lane multiplies by a sign, gathered from
 // the compact u32 matrix through 32-bit byte offsets; every leg finite (host-checked), sums < 2^30.
 // dv[k] = change of score level k.  Returns doable.
-template <int L, class LT>
+template <int L, class LT, bool M16 = false>
 __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const uint16_t* visits, const uint32_t* off, const LT* load,
                                                      bool chg, uint32_t a, uint32_t i, uint32_t b, uint32_t j, int32_t (&dv)[L]) {
 #pragma unroll
@@ -565,9 +565,10 @@ __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const u
     //   P2 (x,vq)   | (pb,x) | (x,nb)      M2 (pb,vq)*| (pb,y) | (y,nb)
     //   P3   -      | (x,nb) |   -         M3   -     | (y,nb) |   -          (* absent for a single-element source /
     //                                                                            an empty destination route)
-    const uint32_t dim4 = (uint32_t)m.dim * 4u;
+    const uint32_t dim4 = (uint32_t)m.dim * (M16 ? 2u : 4u);
     auto leg = [&](uint32_t f, uint32_t t) -> uint32_t {
-        const uint32_t byte_off = f * dim4 + t * 4u;  // dim <= 16384: < 2^30
+        const uint32_t byte_off = f * dim4 + t * (M16 ? 2u : 4u);  // dim <= 16384: < 2^30
+        if (M16) return *(const uint16_t*)((const char*)m.mat16 + byte_off);  // every leg finite (MODE 2) and < 65535
         return *(const uint32_t*)((const char*)m.mat32 + byte_off);
     };
     const uint32_t p0 = leg(pa, chg ? na : vq);
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                         m0 = rq[0];
                         m1 = rq[1];
                         const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
-                        doable = eval_list_move_small<L>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j, dv);
+                        doable = eval_list_move_small<L, LT, COMPACT>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j, dv);  // COMPACT reads the u16 matrix
                     }
                     // LateAcceptance: score >= last step score || score >= late score (late_acceptance.rs:89-125)
                     acc = doable && (small_ge0<L>(dv) || small_ge<L>(dv, late_d));
