@@ -22,7 +22,9 @@ as GPU replica 0 (same seed), and when it completes the window its working score
 replica 0's (`extra.replica0_matches_cpu_oracle`).
 
 M2 (`--solve-seconds`, default 60).  A fresh portfolio solves for 60 s of wall clock with work-balanced launches
-(sf_solve_moves) while the CPU oracle solves the same problem (seed of replica 0) on one host core for the same
+(sf_solve_moves) under the reference's DEFAULT LIST POLICY (`--solve-policy default`: the seven leaves of
+default_local_search/policy/list.rs on the generic N-leaf engine; `nearby2` = the two-leaf union M1 is timed on) while the CPU
+oracle solves the same problem with the same leaves (seed of replica 0) on one host core for the same
 60 s: `extra.best_score_at_60s` = {"gpu": ..., "cpu_oracle": ...}.  `--solve-start savings | savings_capacity` starts both
 sides from empty routes with the construction phases of the CVRP domain -- Clarke-Wright savings
 (sf_construct_list_clarke_wright), then the route-local 2-opt of ListKOptPhase (sf_construct_list_k_opt) -- built inside the
@@ -78,12 +80,28 @@ LDS_PEAK = N_CU * CLOCK_HZ / 2.0
 # [0, -101064] from the round-robin fill and [-4869, -24557] from the stock structural hook).
 SOLVE_START_DEFAULT = "savings_capacity"
 
+# M2 policy: the reference's default list policy (default_local_search/policy/list.rs:24-33 without the precedence pair, which the
+# CVRP slot does not declare): nearby change, nearby swap, sublist change, sublist swap, reverse, 3-opt (distance-pruned), ruin --
+# LateAcceptance(400) + AcceptedCount(256), StratifiedRandom root union -- on BOTH sides; `nearby2` = the two-leaf union M1 is timed on.
+M2_POLICIES = {
+    "default": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt", "ruin"),
+    "default6": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"),
+    "nearby2": ("nearby_change", "nearby_swap"),
+}
+M2_REPLICAS = {"default": 1280, "default6": 3072, "nearby2": None}  # replicas per GPU of the M2 leg (None = --replicas)
+LEAF_BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024}
+
+# The instruction counters first (the issue rooflines need them), then the two TCC traffic counters in passes of their own, then the
+# wave-cycle shares.  rocprofv3 counter passes hang now and then on this pool (a pass takes 2-10 s when it works; once a box starts
+# hanging it tends to keep hanging): every pass has a short deadline and ONE retry, and all passes together share PMC_BUDGET_S so the
+# default run stays within a few minutes; a pass that never completes only drops its own counters.
 PMC_PASSES = [
+    ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
-    ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
     ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
 ]
+PMC_BUDGET_S = 120.0
 
 
 def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
@@ -120,7 +138,7 @@ def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
     }
 
 
-def cpu_solve(problem, seed, seconds, box, start="roundrobin"):
+def cpu_solve(problem, seed, seconds, box, start="roundrobin", leaves=("nearby_change", "nearby_swap")):
     """M2 on the host: the oracle searches for `seconds` of wall clock on one core (runs beside the GPU solve; the
     ctypes call releases the GIL).  A savings start (Clarke-Wright construction) is built inside the budget."""
     try:
@@ -128,7 +146,8 @@ def cpu_solve(problem, seed, seconds, box, start="roundrobin"):
 
         o = sfo.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
                            problem["customers"], problem["routes"])
-        o.configure(leaves=sfo.LEAF_NEARBY_LIST_CHANGE | sfo.LEAF_NEARBY_LIST_SWAP, max_nearby=20, random_seed=seed)
+        o.configure(leaves=sum(LEAF_BITS[x] for x in leaves), max_nearby=20, random_seed=seed)
+        o.set_ruin()
         t0 = time.perf_counter()
         if start != "roundrobin":
             o.construct_list_clarke_wright(problem["customers"], 1 if start == "savings_capacity" else 0)
@@ -182,6 +201,7 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
     failed = []
+    t_pmc = time.perf_counter()
     try:
         for i, grp in enumerate(PMC_PASSES):
             d = os.path.join(base, f"pmc_{i}")
@@ -190,19 +210,24 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
             # own process group: a pass that hangs is killed together with the profiled grandchild.  rocprofv3 counter passes hang
             # now and then on this pool (a pass takes ~10 s when it works): one retry per pass before its counters are given up.
             ok = False
+            why = f"{'+'.join(grp)}: the PMC time budget ({PMC_BUDGET_S:.0f} s) was spent by earlier passes"
             for attempt in range(2):
+                left = PMC_BUDGET_S - (time.perf_counter() - t_pmc)
+                if left < 5.0:
+                    break
+                deadline = min(timeout_s, left)
                 shutil.rmtree(d, ignore_errors=True)
                 pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                       start_new_session=True)
                 try:
-                    _, err = pr.communicate(timeout=timeout_s)
+                    _, err = pr.communicate(timeout=deadline)
                 except subprocess.TimeoutExpired:
                     try:
                         os.killpg(pr.pid, 9)
                     except OSError:
                         pass
                     pr.wait()
-                    why = f"{'+'.join(grp)}: timed out after {timeout_s}s (attempt {attempt + 1})"
+                    why = f"{'+'.join(grp)}: timed out after {deadline:.0f}s (attempt {attempt + 1})"
                     continue
                 if pr.returncode != 0:
                     why = f"{'+'.join(grp)}: rc={pr.returncode} {err.decode(errors='replace')[-160:]} (attempt {attempt + 1})"
@@ -259,7 +284,10 @@ def main():
                     help="M2 start state: the round-robin fill M1 is timed on, or the device's Clarke-Wright savings construction "
                          "from empty routes (built inside the budget, on both sides): savings = the reference's stock savings hooks "
                          "(structural feasibility only), savings_capacity = EXTENSION, a capacity-checking feasible hook")
-    ap.add_argument("--solve-budget", type=int, default=100_000, help="M2: candidates per replica per launch (sf_solve_moves)")
+    ap.add_argument("--solve-budget", type=int, default=30_000, help="M2: candidates per replica per launch (sf_solve_moves)")
+    ap.add_argument("--solve-policy", choices=sorted(M2_POLICIES), default="default",
+                    help="M2 leaves on both sides: default = the reference's seven-leaf default list policy, default6 = without ruin, "
+                         "nearby2 = the two-leaf nearby union M1 is timed on")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -304,11 +332,13 @@ def main():
         sys.exit(2)
     seed_base = portfolio.rank_seed_base(args.seed, rank, args.replicas)
 
-    def new_director(prob=None):
-        d = sfa.build_cvrp(prob if prob is not None else problem, n_replicas=args.replicas, device_id=local_rank)
-        d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
+    def new_director(prob=None, leaves=("nearby_change", "nearby_swap"), replicas=None):
+        nrep = replicas or args.replicas
+        d = sfa.build_cvrp(prob if prob is not None else problem, n_replicas=nrep, device_id=local_rank, leaves=leaves)
+        if len(leaves) == 2:
+            d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
         # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
-        d.configure(sfa.SolverConfig(random_seed=seed_base))
+        d.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, nrep)))
         return d
 
     d = new_director()
@@ -355,12 +385,13 @@ def main():
     if args.solve_seconds > 0:
         d.close()
         prob2 = problem if args.solve_start == "roundrobin" else dict(problem, routes=[[] for _ in problem["routes"]])
-        d2 = new_director(prob2)
+        m2_leaves = M2_POLICIES[args.solve_policy]
+        d2 = new_director(prob2, m2_leaves, M2_REPLICAS[args.solve_policy])
         m2_start = d2.calculate_score()[0].tolist()
         cpu_box = {}
         cpu_thread = None
         if rank == 0 and not args.no_cpu_baseline:
-            cpu_thread = threading.Thread(target=cpu_solve, args=(prob2, args.seed, args.solve_seconds, cpu_box, args.solve_start),
+            cpu_thread = threading.Thread(target=cpu_solve, args=(prob2, args.seed, args.solve_seconds, cpu_box, args.solve_start, m2_leaves),
                                           daemon=True)
         barrier(d2)
         if cpu_thread:
@@ -383,6 +414,7 @@ def main():
             "best_score_local": list(max(tuple(int(v) for v in s) for s in d2.best_scores())),
             "moves_per_s": st2["moves_evaluated"] / gpu_s,
             "start": args.solve_start, "start_score": m2_start, "construction_seconds": construct_s,
+            "leaves": list(m2_leaves), "replicas": M2_REPLICAS[args.solve_policy] or args.replicas,
         }
         if cpu_thread:
             cpu_thread.join(timeout=args.solve_seconds + 30)
@@ -473,7 +505,7 @@ def main():
                       "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
         if world == 1 and not args.no_pmc:
-            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=60)
+            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=30)
             if pmc is None:  # no counters, no roofline: the line says so instead of quoting an older profile
                 pmc_source = f"none (live rocprofv3 passes failed: {pmc_info})"
                 pmc_info = {}
@@ -574,7 +606,9 @@ def main():
                                                    "stock savings_hooks::feasible is structural only)",
                                "savings": "the reference's stock CVRP construction wiring (structural feasibility)",
                                "roundrobin": "round-robin fill (the M1 start state)"}[solve["start"]],
-                "policy": f"start = {solve['start']}; 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256); work-balanced launches "
+                "policy": f"start = {solve['start']}; leaves = {'+'.join(solve['leaves'])} ({args.solve_policy}: "
+                          + ("the reference's default list policy" if args.solve_policy == "default" else "a subset of the default list policy")
+                          + f") on both sides, LateAcceptance(400)+AcceptedCount(256), {solve['replicas']} replicas per GPU; work-balanced launches "
                           f"(sf_solve_moves, {args.solve_budget} candidates per replica per launch)",
             }
         if not args.no_cpu_baseline:
