@@ -9,7 +9,7 @@ from solverforge_amd import datasets
 from oracle import sfo
 
 BITS = {"nearby_change": 16, "nearby_swap": 32, "list_change": 4, "list_swap": 8, "list_reverse": 64,
-        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024, "change": 1, "swap": 2}
+        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024, "change": 1, "swap": 2, "permute": 8192}
 
 
 def t6(m):
@@ -19,7 +19,8 @@ def t6(m):
 def run_case(seed):
     rng = np.random.default_rng(seed)
     model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment", "precedence", "precedence", "shift", "shift", "shift"][int(rng.integers(12))]
-    acceptor = int(rng.choice([0, 1, 1, 3]))
+    acceptor = int(rng.choice([0, 1, 1, 3, 4]))  # 4 = DiversifiedLateAcceptance (round 3)
+    dla_tol = float(rng.choice([0.0, 0.01, 0.2]))
     forager = int(rng.choice([0, 0, 1, 2, 3, 4]))
     limit = int(rng.choice([1, 2, 7, 40, 256]))
     order = int(rng.choice([0, 3, 3, 4]))
@@ -43,21 +44,22 @@ def run_case(seed):
             if len(p["routes"][2]) > 1:
                 p["routes"][0] = p["routes"][0] + p["routes"][2][1:]
                 p["routes"][2] = p["routes"][2][:1]
-        pool = ["nearby_change", "nearby_swap", "list_change", "list_swap", "list_reverse", "sublist_change", "sublist_swap", "kopt", "ruin"]
+        pool = ["nearby_change", "nearby_swap", "list_change", "list_swap", "list_reverse", "sublist_change", "sublist_swap", "kopt", "ruin", "permute"]
         chosen = set(rng.choice(pool, size=int(rng.integers(1, 8)), replace=False).tolist())
-        leaves = tuple(x for x in ["nearby_change", "list_change", "nearby_swap", "list_swap", "sublist_change", "sublist_swap", "list_reverse",
+        leaves = tuple(x for x in ["permute", "nearby_change", "list_change", "nearby_swap", "list_swap", "sublist_change", "sublist_swap", "list_reverse",
                                    "kopt", "ruin"] if x in chosen)  # union (declaration) order
+        pw = (int(rng.choice([2, 2, 3])), int(rng.choice([3, 4, 5])))
         mn = int(rng.choice([1, 3, 20, 64]))
         kopt = (int(rng.choice([1, 1, 2])), int(rng.choice([0, 2, 20])))
         sub = (1, int(rng.choice([1, 3, 5])))
         engine = int(rng.choice([0, 1, 2])) if set(leaves) <= {"nearby_change", "nearby_swap"} else 0
         ruin = (int(rng.choice([1, 2])), int(rng.choice([2, 5, 6])), int(rng.choice([1, 3, 10, 16])))
         desc.update(n=n, v=v, leaves=leaves, max_nearby=mn, kopt=kopt, sublist=sub, engine=engine, ruin=ruin)
-        d = sfa.build_cvrp(p, leaves=leaves, max_nearby=mn, kopt=kopt, sublist_sizes=sub, ruin=ruin)
+        d = sfa.build_cvrp(p, leaves=leaves, max_nearby=mn, kopt=kopt, sublist_sizes=sub, ruin=ruin, permute=pw)
         if engine:
             d.set_engine(engine)
         o = sfo.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
-        o.set_kopt(*kopt); o.set_sublist_sizes(*sub)
+        o.set_kopt(*kopt); o.set_sublist_sizes(*sub); o.set_permute(*pw)
         lists = lambda: (d.working_lists(0, 0), o.get_lists(0))
         post_configure = lambda: o.set_ruin(*ruin)
     elif model == "graph":
@@ -115,7 +117,7 @@ def run_case(seed):
                         seqs[int(rng.integers(nm))].append(x)
             p["sequences"] = seqs
         with_owner = bool(rng.random() < 0.7)
-        pool = ["list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"]
+        pool = ["permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"]
         chosen = set(rng.choice(pool, size=int(rng.integers(1, 7)), replace=False).tolist())
         leaves = tuple(x for x in pool if x in chosen)
         desc.update(nj=nj, nm=nm, leaves=leaves, with_owner=with_owner)
@@ -176,7 +178,7 @@ def run_case(seed):
                 union_weights[0] = 1
         d.configure_union(union_order, union_weights)
     desc.update(union_order=union_order, union_weights=union_weights)
-    o.configure(acceptor=1 if acceptor == 3 else acceptor, la_size=la, forager=forager, limit=limit, leaves=bits,
+    o.configure(acceptor=1 if acceptor in (3, 4) else acceptor, la_size=la, forager=forager, limit=limit, leaves=bits,
                 selection_order=order, random_seed=seed, max_nearby=desc.get("max_nearby", 20), union_order=union_order)
     if union_weights:
         o.set_union_weights(union_weights)
@@ -184,6 +186,9 @@ def run_case(seed):
         post_configure()
     d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=la, forager=forager, accepted_count_limit=limit,
                                  selection_order=order, random_seed=seed))
+    if acceptor == 4:
+        o.configure_diversified(la, dla_tol)
+        d.configure_diversified(dla_tol)
     if acceptor == 3:
         ss = int(rng.choice([1, 9, 128]))
         o.configure_annealing(mode=2, levels=levels, hard_levels=levels - 1, sample_size=ss, seed=seed)
