@@ -71,12 +71,20 @@ typedef enum sf_move_kind {
     SF_MOVE_KOPT = 7,          /* heuristic/move/list_kernel/k_opt.rs:13-96 with k = 3: list `a` cut at a_pos < b < b_pos (`b`
                                   carries the MIDDLE CUT, not an entity) and reconnected by
                                   THREE_OPT_RECONNECTIONS[value] (move/k_opt_reconnection.rs:203-211), value in 0..6 */
+    SF_MOVE_LIST_MULTI_SWAP = 10, /* heuristic/move/list_kernel/multi_swap.rs:13-128 (ListMultiSwapMove, emitted by the critical-path leaf): `a` swaps in
+                                    pairwise different lists applied as one move; a_pos / b / b_pos = (list | first position << 16) of swap 0 / 1 / 2,
+                                    value = (second - first) of each swap, one byte per swap.  Requires a score improvement
+                                    (phase/localsearch/evaluation.rs:95-113).  sf_evaluate_moves / sf_apply_move do not take it */
     SF_MOVE_LIST_PERMUTE = 9,  /* heuristic/move/list_kernel/permute.rs:22-72 (ListPermuteMove): the window [a_pos, b_pos) of list `a`
                                   (b = a, 2..8 positions) reordered by the value-th permutation of its positions in lexicographic
                                   order (nth_permutation, selector/list_kernel/permute.rs:260-272; value >= 1, 0 would be the identity) */
     SF_MOVE_LIST_RUIN = 8      /* heuristic/move/list_kernel/ruin.rs:131-281 (one source list): list `a` loses the a_pos (1..6) elements
                                   at ascending positions packed 16 bits each into b (positions 0, 1), b_pos (2, 3), value (4, 5);
-                                  every removed element is greedily re-inserted at its best (list, position) */
+                                  every removed element is greedily re-inserted at its best (list, position).  Ruins of the critical-path
+                                  leaf (at most five elements) use the top half of `value`: bit 31 = the move carries the precedence hooks
+                                  (insertions that close a cycle are skipped, ruin.rs:186-220), bit 30 = two source lists
+                                  (ListRuinMove::new_multi_source, list_ruin.rs:80-100): position 0 lies in list `a`, position 1 in the
+                                  list held by bits 16..29 */
 } sf_move_kind;
 
 /* Declarative constraint archetypes (the reference's closure-typed ConstraintFactory streams
@@ -179,6 +187,9 @@ typedef enum sf_selector_kind {
                                       (selector/list_kernel/k_opt/full.rs) */
     SF_SEL_SUBLIST_SWAP = 256,     /* selector/list_kernel/sublist_swap.rs:13-330; sizes via sf_selector_add_sublist */
     SF_SEL_LIST_PERMUTE = 8192,   /* selector/list_kernel/permute.rs:22-205 (contiguous-window permutations); sf_selector_add_permute */
+    SF_SEL_LIST_PRECEDENCE = 16384, /* selector/list_precedence.rs:121-210 over list_kernel/precedence/{analysis,coordinates,support,cursor,emission}.rs
+                                      (the critical-path leaf); sf_selector_add_precedence.  First list leaf of the default policy
+                                      for slots with precedence hooks (policy/list.rs:24-33,62-93) */
     SF_SEL_NEARBY_SCALAR_CHANGE = 2048, /* scalar_neighborhood/cursor/change.rs:123-392 (NearbyChangeCursor); sf_selector_add_nearby_scalar */
     SF_SEL_NEARBY_SCALAR_SWAP = 4096,   /* scalar_neighborhood/cursor/swap.rs:162-414 (NearbySwapCursor); sf_selector_add_nearby_scalar */
     SF_SEL_LIST_RUIN = 1024        /* selector/list_kernel/ruin.rs:38-144 + move/list_kernel/ruin.rs:131-281 (ruin and greedy recreate);
@@ -337,6 +348,19 @@ int32_t sf_selector_add_kopt(sf_ctx* ctx, int32_t descriptor_index, int32_t vari
  * precedence-route-graph cycle filter (the reference drops permutations that would close a cycle through the route graph,
  * permute.rs:139-147: not restated).  Generic N-leaf engine. */
 int32_t sf_selector_add_permute(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t min_window_size, int32_t max_window_size);
+
+/* ListPrecedenceMoveSelector (heuristic/selector/list_precedence.rs:121-210; ListPrecedenceMoveConfig has no tunables): the critical-path
+ * neighbourhood of a list class that carries the ListPrecedenceMakespanConstraint -- the constraint's fixed successors and durations are
+ * the selector's `fixed_successors` / `node_duration` hooks.  Every step: earliest / latest starts, critical blocks per list
+ * (list_kernel/precedence/analysis.rs:56-112), then the stream of list_kernel/precedence/cursor.rs:182-252: three-list multi-swaps
+ * (critical, critical, support; they require a score improvement, emission.rs:280-294), two-block ruins, then per block the tiered
+ * families change / swap / reverse / adjacent sublist swap / ruin window / sublist change / permutation.  Candidates whose lists would be
+ * cyclic are pruned before they count (coordinates.rs:265-326, precedence_route.rs:257-304); the ruins recreate with the precedence hooks
+ * (move/list_kernel/ruin.rs:186-220: insertions that close a cycle are skipped).  Moves come back as SF_MOVE_LIST_CHANGE .. SF_MOVE_LIST_PERMUTE,
+ * SF_MOVE_LIST_RUIN (value bits 31 / 30 set, see sf_move_t) and SF_MOVE_LIST_MULTI_SWAP.  Generic N-leaf engine; the list class may
+ * carry no distance / capacity / not-exists constraint (the ruin's recreate is scored by the precedence constraint alone), fixed
+ * successor lists without repeats; SF_ERR_UNSUPPORTED otherwise.  One such leaf per union. */
+int32_t sf_selector_add_precedence(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index);
 
 /* Nearby scalar leaves of a scalar slot (NearbyChangeMoveSelector / NearbySwapMoveSelector; the default policy declares them with
  * max_nearby 10 between the list rules and the ordinary change / swap pair, default_local_search/policy/scalar.rs:18-65).  The

@@ -27,6 +27,7 @@ LEAF_KOPT = 512
 LEAF_LIST_RUIN = 1024
 LEAF_NEARBY_SCALAR_CHANGE, LEAF_NEARBY_SCALAR_SWAP = 2048, 4096
 LEAF_LIST_PERMUTE = 8192
+LEAF_LIST_PRECEDENCE = 16384
 KIND_KOPT, KIND_RUIN = 7, 8
 ACCEPT_HILL_CLIMBING, ACCEPT_LATE_ACCEPTANCE = 0, 1
 FORAGER_ACCEPTED_COUNT, FORAGER_FIRST_ACCEPTED, FORAGER_BEST_SCORE = 0, 1, 2

@@ -32,6 +32,20 @@ static void to_wire(const Move& m, sfo_move_t* w) {
         w->b = (int32_t)((uint32_t)m.ruin_idx[0] | ((uint32_t)m.ruin_idx[1] << 16));
         w->b_pos = (int32_t)((uint32_t)m.ruin_idx[2] | ((uint32_t)m.ruin_idx[3] << 16));
         w->value = (int32_t)((uint32_t)m.ruin_idx[4] | ((uint32_t)m.ruin_idx[5] << 16));
+        if (m.prec) {  // ruins of the critical-path leaf (<= 5 elements): bit 31 = precedence hooks, bit 30 = two source lists, the second in bits 16..29
+            uint32_t flags = 0x8000u;
+            if (m.ruin_multi) flags |= 0x4000u | (uint32_t)m.ruin_src[m.a_pos - 1];
+            w->value = (int32_t)((uint32_t)m.ruin_idx[4] | (flags << 16));
+        }
+    }
+    if (m.kind == Move::MultiSwap) {  // a = swaps, (list | first << 16) per swap, value = second - first, one byte per swap
+        int32_t* slot[3] = {&w->a_pos, &w->b, &w->b_pos};
+        w->a = (int32_t)m.a_pos;
+        w->value = 0;
+        for (size_t i = 0; i < 3; ++i) {
+            *slot[i] = i < m.a_pos ? (int32_t)((uint32_t)m.ms_entity[i] | ((uint32_t)m.ms_first[i] << 16)) : 0;
+            if (i < m.a_pos) w->value |= (int32_t)(((uint32_t)(m.ms_second[i] - m.ms_first[i]) & 0xFFu) << (8 * i));
+        }
     }
 }
 static Move from_wire(const Model& model, const sfo_move_t& w) {
@@ -56,6 +70,30 @@ static Move from_wire(const Model& model, const sfo_move_t& w) {
         m.b_pos = 0;
         m.to_value = NONE;
         m.allows_unassigned = model.ruin_skip_empty;
+        if ((uint32_t)w.value & 0x80000000u) {  // a ruin of the critical-path leaf
+            const uint32_t flags = (uint32_t)w.value >> 16;
+            m.ruin_idx[5] = 0;
+            m.prec = model.list_slot.precedence.get();
+            m.allows_unassigned = false;
+            for (size_t i = 0; i < 8; ++i) m.ruin_src[i] = (uint16_t)m.a;
+            if (flags & 0x4000u) {
+                m.ruin_multi = true;
+                m.ruin_src[m.a_pos - 1] = (uint16_t)(flags & 0x3FFFu);
+            }
+        }
+    }
+    if (m.kind == Move::MultiSwap) {
+        const uint32_t slot[3] = {(uint32_t)w.a_pos, (uint32_t)w.b, (uint32_t)w.b_pos};
+        m.a_pos = (size_t)w.a;
+        m.require_improvement = true;
+        for (size_t i = 0; i < m.a_pos && i < 3; ++i) {
+            m.ms_entity[i] = (uint16_t)(slot[i] & 0xFFFFu);
+            m.ms_first[i] = (uint16_t)(slot[i] >> 16);
+            m.ms_second[i] = (uint16_t)(m.ms_first[i] + (int8_t)(((uint32_t)w.value >> (8 * i)) & 0xFFu));
+        }
+        m.a = m.b = m.ms_entity[0];
+        m.b_pos = 0;
+        m.to_value = NONE;
     }
     return m;
 }

@@ -79,6 +79,8 @@ enum LeafBits : uint32_t {
     // ordinary scalar change / swap pair)
     LEAF_LIST_PERMUTE = 8192,  // ListPermuteMoveSelector (window sizes 2..=5 by default, solverforge-config/src/move_selector.rs:406-416); the
                                // default policy declares it right after ListPrecedence for slots with precedence hooks (policy/list.rs:62-93)
+    LEAF_LIST_PRECEDENCE = 16384,  // ListPrecedenceMoveSelector (selector/list_precedence.rs): the critical-path leaf, first list rule of slots with
+                                   // precedence hooks (policy/list.rs:24-33,62-93); needs list_slot.precedence
     LEAF_NEARBY_SCALAR_CHANGE = 2048,
     LEAF_NEARBY_SCALAR_SWAP = 4096,
     LEAF_KOPT = 512,  // k = 3; kopt_max_nearby > 0: distance-pruned (default policy with an intra-distance meter), 0: full
@@ -128,6 +130,8 @@ struct Model {
                 return std::make_unique<NearbyListSwapCursor>(list_slot, d.working, ctx, max_nearby);
             case LEAF_LIST_REVERSE:
                 return std::make_unique<ListReverseCursor>(list_slot, d.working, ctx);
+            case LEAF_LIST_PRECEDENCE:
+                return std::make_unique<ListPrecedenceCursor>(list_slot, d.working, ctx);
             case LEAF_LIST_PERMUTE:
                 return std::make_unique<ListPermuteCursor>(list_slot, d.working, ctx, permute_min, permute_max);
             case LEAF_SUBLIST_SWAP:
@@ -150,7 +154,7 @@ struct Model {
     // (runtime/compiler/default_local_search/policy.rs:104-108, policy/list.rs:24-33,
     //  policy/scalar.rs:67-106).
     std::unique_ptr<Cursor> open_union(const ScoreDirector& d, const MoveStreamContext& ctx) const {
-        static const uint32_t order[] = {LEAF_LIST_PERMUTE, LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
+        static const uint32_t order[] = {LEAF_LIST_PRECEDENCE, LEAF_LIST_PERMUTE, LEAF_NEARBY_LIST_CHANGE, LEAF_LIST_CHANGE, LEAF_NEARBY_LIST_SWAP,
                                          LEAF_LIST_SWAP,          LEAF_SUBLIST_CHANGE, LEAF_SUBLIST_SWAP, LEAF_LIST_REVERSE,
                                          LEAF_KOPT,               LEAF_LIST_RUIN,          LEAF_NEARBY_SCALAR_CHANGE, LEAF_NEARBY_SCALAR_SWAP,
                                          LEAF_SCALAR_CHANGE,      LEAF_SCALAR_SWAP};
@@ -754,6 +758,15 @@ inline std::unique_ptr<Model> make_precedence_shop(size_t n_nodes, size_t n_owne
     m->director.constraints.members.push_back(std::move(c));
     m->has_list = true;
     m->list_slot.descriptor_index = 0;
+    {  // the constraint's graph facts double as the hooks of the critical-path leaf (fixed_successors / node_duration)
+        auto hooks = std::make_shared<PrecedenceHooks>();
+        hooks->node_count = n_nodes;
+        hooks->durations = facts->duration;
+        hooks->successors.resize(n_nodes);
+        for (size_t v = 0; v < n_nodes; ++v)
+            for (uint32_t t = succ_off[v]; t < succ_off[v + 1]; ++t) hooks->successors[v].push_back((size_t)succ[t]);
+        m->list_slot.precedence = hooks;
+    }
     m->leaves = LEAF_LIST_CHANGE | LEAF_LIST_SWAP;
     m->wire_search();
     return m;

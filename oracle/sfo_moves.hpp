@@ -27,12 +27,13 @@
 #include <memory>
 #include <vector>
 
+#include "sfo_precedence_route.hpp"
 #include "sfo_scoring.hpp"
 
 namespace sfo {
 
 struct Move {
-    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6, KOpt = 7, Ruin = 8, ListPermute = 9 } kind = Change;
+    enum Kind : int32_t { Change = 0, Swap = 1, ListChange = 2, ListSwap = 3, ListReverse = 4, SublistChange = 5, SublistSwap = 6, KOpt = 7, Ruin = 8, ListPermute = 9, MultiSwap = 10 } kind = Change;
     size_t descriptor = 0;
     size_t variable = 0;
     // Change: a = entity, to_value.  Swap: a = left entity, b = right entity.
@@ -49,16 +50,30 @@ struct Move {
     //                lexicographic order (nth_permutation, selector/list_kernel/permute.rs:260-272; rank 0 = identity is no move).
     // Ruin (list ruin-and-recreate, one source list): list a loses the a_pos elements at the ascending positions
     //                ruin_idx[0..a_pos) and every removed element is greedily re-inserted (move/list_kernel/ruin.rs:131-281);
-    //                `allows_unassigned` carries skip_empty_destinations.
+    //                `allows_unassigned` carries skip_empty_destinations.  `ruin_multi`: a multi-source ruin (new_multi_source,
+    //                move/list_ruin.rs:80-100): ruin_src[i] = the list ruin_idx[i] belongs to, entries sorted by (list, position)
+    //                as merged_ruin_sources leaves them (a = the first list).  `prec` != null: the move carries the precedence
+    //                hooks (with_precedence_hooks, :148-158) and the recreate skips insertions that close a cycle.
+    // MultiSwap (move/list_kernel/multi_swap.rs:13-128): a_pos swaps (ms_entity[i], ms_first[i]) <-> (ms_entity[i], ms_second[i]) in
+    //                pairwise different lists, applied as one move; `require_improvement` = with_require_score_improvement.
     size_t a = 0, a_pos = 0, b = 0, b_pos = 0;
     int64_t to_value = NONE;
     bool allows_unassigned = false;
     uint16_t ruin_idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // SmallVec<[usize; 8]> of the reference; this build caps a ruin at 6
+    bool ruin_multi = false;
+    uint16_t ruin_src[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const PrecedenceHooks* prec = nullptr;  // not owned; not part of the move's identity
+    uint16_t ms_entity[4] = {0, 0, 0, 0}, ms_first[4] = {0, 0, 0, 0}, ms_second[4] = {0, 0, 0, 0};
+    bool require_improvement = false;  // Move::requires_score_improvement (evaluation.rs:95-113)
+    size_t ruin_source(size_t i) const { return ruin_multi ? (size_t)ruin_src[i] : a; }
 };
 inline bool operator==(const Move& x, const Move& y) {
     return x.kind == y.kind && x.descriptor == y.descriptor && x.variable == y.variable && x.a == y.a &&
            x.a_pos == y.a_pos && x.b == y.b && x.b_pos == y.b_pos && x.to_value == y.to_value &&
-           (x.kind != Move::Ruin || std::equal(x.ruin_idx, x.ruin_idx + 8, y.ruin_idx));
+           (x.kind != Move::Ruin || (std::equal(x.ruin_idx, x.ruin_idx + 8, y.ruin_idx) && x.ruin_multi == y.ruin_multi &&
+                                     (!x.ruin_multi || std::equal(x.ruin_src, x.ruin_src + 8, y.ruin_src)) && (x.prec != nullptr) == (y.prec != nullptr))) &&
+           (x.kind != Move::MultiSwap || (std::equal(x.ms_entity, x.ms_entity + 4, y.ms_entity) && std::equal(x.ms_first, x.ms_first + 4, y.ms_first) &&
+                                          std::equal(x.ms_second, x.ms_second + 4, y.ms_second) && x.require_improvement == y.require_improvement));
 }
 
 struct RuinPlacement {  // RuinUndo entry (move/list_kernel/ruin.rs:16): where a removed element went
@@ -116,6 +131,10 @@ inline std::vector<size_t> nth_permutation(size_t len, size_t rank) {
     return perm;
 }
 
+}  // namespace sfo
+#include "sfo_precedence_leaf.hpp"
+namespace sfo {
+
 inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
     const Solution& s = d.working;
     const EntityClass& c = s.classes[m.descriptor];
@@ -159,7 +178,19 @@ inline bool move_is_doable(const ScoreDirector& d, const Move& m) {
         case Move::Ruin: {  // ruin_is_doable without an owner binding (move/list_kernel/ruin.rs:97-113)
             if (m.a_pos == 0 || m.a_pos > 8 || m.a >= c.lists.size()) return false;
             for (size_t i = 0; i < m.a_pos; ++i)
-                if (m.ruin_idx[i] >= c.lists[m.a].size()) return false;
+                if (m.ruin_source(i) >= c.lists.size() || m.ruin_idx[i] >= c.lists[m.ruin_source(i)].size()) return false;
+            return true;
+        }
+        case Move::MultiSwap: {  // multi_swap_is_doable (move/list_kernel/multi_swap.rs:30-60)
+            if (m.a_pos == 0 || m.a_pos > 4) return false;
+            for (size_t i = 0; i < m.a_pos; ++i) {
+                size_t e = m.ms_entity[i], f = m.ms_first[i], g = m.ms_second[i];
+                if (f == g) return false;
+                for (size_t j = 0; j < i; ++j)
+                    if (m.ms_entity[j] == e) return false;
+                if (e >= c.lists.size() || f >= c.lists[e].size() || g >= c.lists[e].size()) return false;
+                if (c.lists[e][f] == c.lists[e][g]) return false;
+            }
             return true;
         }
         case Move::SublistSwap: {  // move/list_kernel/sublist_swap.rs:17-43
@@ -292,26 +323,35 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
             d.after_variable_changed(m.descriptor, m.a);
             break;
         }
-        case Move::Ruin: {  // ruin_do_move (move/list_kernel/ruin.rs:131-281): one source list, no owner binding, no
-                            // precedence graph.  Every trial insertion is a full before / insert / after / calculate_score.
+        case Move::Ruin: {  // ruin_do_move (move/list_kernel/ruin.rs:131-281): no owner binding.  Every trial insertion is a full
+                            // before / insert / after / calculate_score; with precedence hooks the route graph is rebuilt from
+                            // the working lists every round and insertions that close a cycle are skipped (:186-220).
             struct Removed {
                 size_t removed_index, source, original_position;
                 uint32_t value;
             };
             std::vector<Removed> remaining;
-            d.before_variable_changed(m.descriptor, m.a);
-            for (size_t i = m.a_pos; i-- > 0;) {  // indices ascending: remove from the back (:147-153)
-                size_t index = m.ruin_idx[i];
-                remaining.push_back({i, m.a, index, c.lists[m.a][index]});
-                c.lists[m.a].erase(c.lists[m.a].begin() + (ptrdiff_t)index);
+            for (size_t i0 = 0; i0 < m.a_pos;) {  // one (source, ascending indices) group at a time (:146-164)
+                size_t source = m.ruin_source(i0), i1 = i0;
+                while (i1 < m.a_pos && m.ruin_source(i1) == source) ++i1;
+                d.before_variable_changed(m.descriptor, source);
+                std::vector<Removed> part;
+                for (size_t i = i1; i-- > i0;) {  // remove from the back
+                    size_t index = m.ruin_idx[i];
+                    part.push_back({i, source, index, c.lists[source][index]});
+                    c.lists[source].erase(c.lists[source].begin() + (ptrdiff_t)index);
+                }
+                std::reverse(part.begin(), part.end());
+                remaining.insert(remaining.end(), part.begin(), part.end());
+                d.after_variable_changed(m.descriptor, source);
+                i0 = i1;
             }
-            std::reverse(remaining.begin(), remaining.end());
-            d.after_variable_changed(m.descriptor, m.a);
             const std::vector<Removed> removed = remaining;
             const bool skip_empty = m.allows_unassigned;
             const size_t entity_count = c.n;
-            bool rolled_back = false;
             while (!remaining.empty()) {
+                PrecedenceRouteGraph graph;
+                if (m.prec) graph = PrecedenceRouteGraph::build(*m.prec, c.lists);  // recreate_precedence_graph (ruin_access.rs:129-147)
                 bool have = false;
                 size_t best_ri = 0, best_e = 0, best_p = 0;
                 Score best_score;
@@ -320,6 +360,11 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
                         size_t len = c.lists[e].size();
                         if (skip_empty && len == 0) continue;
                         for (size_t pos = 0; pos <= len; ++pos) {
+                            if (m.prec && (size_t)remaining[ri].value < m.prec->node_count) {
+                                auto node_of = [&](size_t p) { return (size_t)c.lists[e][p] < m.prec->node_count ? (size_t)c.lists[e][p] : SIZE_MAX; };
+                                size_t previous = pos > 0 ? node_of(pos - 1) : SIZE_MAX, next = pos < len ? node_of(pos) : SIZE_MAX;
+                                if (graph.insertion_introduces_cycle(previous, (size_t)remaining[ri].value, next)) continue;
+                            }
                             d.before_variable_changed(m.descriptor, e);
                             c.lists[e].insert(c.lists[e].begin() + (ptrdiff_t)pos, remaining[ri].value);
                             d.after_variable_changed(m.descriptor, e);
@@ -344,11 +389,16 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
                         for (size_t j = 0; j < i; ++j)
                             if (u.placements[j].entity == e && cur[j] > at) cur[j] -= 1;
                     }
-                    d.before_variable_changed(m.descriptor, m.a);  // restore_values: one source list, ascending positions
-                    for (const Removed& r : removed) c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)r.original_position, r.value);
-                    d.after_variable_changed(m.descriptor, m.a);
+                    // restore_values (:406-435): removed is already sorted by (source, original position)
+                    for (size_t i0 = 0; i0 < removed.size();) {
+                        size_t source = removed[i0].source, i1 = i0;
+                        d.before_variable_changed(m.descriptor, source);
+                        for (; i1 < removed.size() && removed[i1].source == source; ++i1)
+                            c.lists[source].insert(c.lists[source].begin() + (ptrdiff_t)removed[i1].original_position, removed[i1].value);
+                        d.after_variable_changed(m.descriptor, source);
+                        i0 = i1;
+                    }
                     u.placements.clear();
-                    rolled_back = true;
                     break;
                 }
                 Removed r = remaining[best_ri];
@@ -358,7 +408,21 @@ inline MoveUndo move_do(ScoreDirector& d, const Move& m) {
                 d.after_variable_changed(m.descriptor, best_e);
                 u.placements.push_back({best_e, best_p, r.removed_index});
             }
-            (void)rolled_back;
+            break;
+        }
+        case Move::MultiSwap: {  // multi_swap_do_move (move/list_kernel/multi_swap.rs:62-112): read every pair, notify every list
+                                 // (the lists are pairwise different: is_doable), write, notify
+            uint32_t first_value[4], second_value[4];
+            for (size_t i = 0; i < m.a_pos; ++i) {
+                first_value[i] = c.lists[m.ms_entity[i]][m.ms_first[i]];
+                second_value[i] = c.lists[m.ms_entity[i]][m.ms_second[i]];
+            }
+            for (size_t i = 0; i < m.a_pos; ++i) d.before_variable_changed(m.descriptor, m.ms_entity[i]);
+            for (size_t i = 0; i < m.a_pos; ++i) {
+                c.lists[m.ms_entity[i]][m.ms_first[i]] = second_value[i];
+                c.lists[m.ms_entity[i]][m.ms_second[i]] = first_value[i];
+            }
+            for (size_t i = 0; i < m.a_pos; ++i) d.after_variable_changed(m.descriptor, m.ms_entity[i]);
             break;
         }
         case Move::SublistChange: {  // apply_sublist_change (move/list_kernel/sublist_change.rs:88-130)
@@ -441,7 +505,7 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             if (u.placements.empty()) break;  // the recreate was rolled back inside do_move
             std::vector<size_t> cur = ruin_final_positions(u.placements);
             struct Back {
-                size_t original_position;
+                size_t source, original_position;
                 uint32_t value;
             };
             std::vector<Back> values;
@@ -450,15 +514,23 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
                 d.before_variable_changed(m.descriptor, e);
                 uint32_t value = c.lists[e][at];
                 c.lists[e].erase(c.lists[e].begin() + (ptrdiff_t)at);
-                values.push_back({(size_t)m.ruin_idx[u.placements[i].removed_index], value});  // removed_source_entry
+                size_t ri = u.placements[i].removed_index;  // removed_source_entry
+                values.push_back({m.ruin_source(ri), (size_t)m.ruin_idx[ri], value});
                 d.after_variable_changed(m.descriptor, e);
                 for (size_t j = 0; j < i; ++j)
                     if (u.placements[j].entity == e && cur[j] > at) cur[j] -= 1;
             }
-            std::sort(values.begin(), values.end(), [](const Back& x, const Back& y) { return x.original_position < y.original_position; });
-            d.before_variable_changed(m.descriptor, m.a);
-            for (const Back& b : values) c.lists[m.a].insert(c.lists[m.a].begin() + (ptrdiff_t)b.original_position, b.value);
-            d.after_variable_changed(m.descriptor, m.a);
+            std::sort(values.begin(), values.end(), [](const Back& x, const Back& y) {
+                return x.source != y.source ? x.source < y.source : x.original_position < y.original_position;
+            });
+            for (size_t i0 = 0; i0 < values.size();) {
+                size_t source = values[i0].source, i1 = i0;
+                d.before_variable_changed(m.descriptor, source);
+                for (; i1 < values.size() && values[i1].source == source; ++i1)
+                    c.lists[source].insert(c.lists[source].begin() + (ptrdiff_t)values[i1].original_position, values[i1].value);
+                d.after_variable_changed(m.descriptor, source);
+                i0 = i1;
+            }
             break;
         }
         case Move::ListPermute: {  // permute_undo_move (move/list_kernel/permute.rs:74-101): the original window back
@@ -473,6 +545,7 @@ inline void move_undo(ScoreDirector& d, const Move& m, const MoveUndo& u) {
             d.after_variable_changed(m.descriptor, m.a);
             break;
         }
+        case Move::MultiSwap:      // multi_swap_undo_move (:114-128) = the same exchange again
         case Move::ListSwap:       // swap is its own inverse
         case Move::ListReverse: {  // so is a reversal
             MoveUndo ignored = move_do(d, m);
@@ -890,6 +963,9 @@ using DistanceMeter =
 
 struct ListSlot {
     size_t descriptor_index = 0;
+    // PrecedencePolicy::Explicit of the slot (successors + durations): what the critical-path leaf analyses and what its ruins
+    // carry into the recreate; null = the slot declares no precedence hooks
+    std::shared_ptr<PrecedenceHooks> precedence;
     DistanceMeter meter;  // CrossEntityDistanceMeter (selector/nearby_list_change.rs:22-31)
     // Entity order profile.  The compiled runtime leaf orders entities WITHOUT replacement
     // (list_leaf/cursor/slot.rs:468-499); the public selectors re-index WITH replacement
@@ -1154,6 +1230,135 @@ struct ListPermuteCursor : Cursor {
             win_size = min_size + ctx.selection_index(size_offset, size_count, SALT_SIZE ^ (uint64_t)entity ^ (uint64_t)start);
             win_start = start;
             has_window = true;
+        }
+    }
+};
+
+
+// Critical-path precedence leaf (selector/list_kernel/precedence/cursor.rs:22-290): the multi-swaps first, then the multi-block
+// ruins, then the blocks in stream order, each block's families through the tiered index; candidates whose routes would close a
+// cycle are pruned before they count.  Entities in index order (runtime leaf: probe.rs:286; FromSolutionEntitySelector in the
+// reference's tests).
+struct ListPrecedenceCursor : Cursor {
+    static constexpr uint64_t SALT_BLOCK = 0xC9171EAF5EED0001ULL, SALT_MOVE = 0xC9171EAF5EED0002ULL, SALT_MULTI_RUIN = 0xC9171EAF5EED0003ULL;
+    static constexpr uint64_t SALT_MULTI_SWAP = 0xC9171EAF5EED0004ULL;
+    static constexpr uint64_t SALT_TIER_ADJACENT = 0xAD1ACE1700000001ULL, SALT_TIER_BOUNDARY = 0xAD1ACE1700000002ULL, SALT_TIER_REST = 0xAD1ACE1700000003ULL;
+    size_t desc;
+    MoveStreamContext ctx;
+    const PrecedenceHooks* hooks;
+    CriticalAnalysis an;
+    std::vector<AdjacentSwap> critical_swaps, support_swaps;
+    size_t block_index = 0, move_index = 0, multi_swap_index = 0, multi_swap_count = 0, multi_ruin_index = 0, multi_ruin_count = 0;
+
+    ListPrecedenceCursor(const ListSlot& slot, const Solution& s, const MoveStreamContext& c) : desc(slot.descriptor_index), ctx(c), hooks(slot.precedence.get()) {
+        if (!hooks) return;  // RuntimeListSlotCursor::Empty (slot.rs:298-303)
+        const EntityClass& cls = s.classes[desc];
+        std::vector<size_t> entities(cls.n);
+        for (size_t e = 0; e < cls.n; ++e) entities[e] = e;
+        an = critical_analysis(*hooks, cls.lists, entities);
+        critical_swaps = critical_adjacent_swaps(an.blocks);
+        support_swaps = support_adjacent_swaps(an.blocks, an.graph);
+        multi_swap_count = multi_support_swap_count(critical_swaps, support_swaps);
+        multi_ruin_count = multi_critical_ruin_count(an.blocks);
+    }
+    size_t tiered_index(const CriticalBlock& bl, size_t offset, uint64_t salt) const {  // tiered_precedence_move_index (coordinates.rs:91-130)
+        size_t adjacent = bl.adjacent_change_move_count();
+        if (offset < adjacent) return ctx.selection_index(offset, adjacent, salt ^ SALT_TIER_ADJACENT);
+        size_t boundary = bl.boundary_change_move_count();
+        if (offset < adjacent + boundary) return adjacent + ctx.selection_index(offset - adjacent, boundary, salt ^ SALT_TIER_BOUNDARY);
+        size_t rest = bl.move_count() - adjacent - boundary;
+        return adjacent + boundary + ctx.selection_index(offset - adjacent - boundary, rest, salt ^ SALT_TIER_REST);
+    }
+    Move ruin_move(const size_t* src, const size_t* idx, size_t count) const {  // precedence_ruin (emission.rs:104-141)
+        Move m;
+        m.kind = Move::Ruin;
+        m.descriptor = desc;
+        m.a = m.b = src[0];
+        m.a_pos = count;
+        m.prec = hooks;
+        for (size_t i = 0; i < count; ++i) {
+            m.ruin_idx[i] = (uint16_t)idx[i];
+            m.ruin_src[i] = (uint16_t)src[i];
+            if (src[i] != src[0]) m.ruin_multi = true;
+        }
+        return m;
+    }
+    Move emit(const CriticalBlock& bl, size_t index) const {  // push_move (cursor.rs:83-179)
+        PrecDecoded p = prec_decode(bl, index);
+        const size_t e = bl.entity;
+        switch (p.family) {
+            case PrecDecoded::Change:
+                return make_list_move(Move::ListChange, desc, e, p.c.a, e, p.c.b);
+            case PrecDecoded::Swap:
+                return make_list_move(Move::ListSwap, desc, e, p.c.a, e, p.c.b);
+            case PrecDecoded::Reverse:
+                return make_list_move(Move::ListReverse, desc, e, p.c.a, e, p.c.b);
+            case PrecDecoded::SublistSwap: {
+                Move m = make_list_move(Move::SublistSwap, desc, e, p.c.a, e, p.c.c);
+                m.to_value = (int64_t)((p.c.b - p.c.a) | ((p.c.d - p.c.c) << 16));
+                return m;
+            }
+            case PrecDecoded::Ruin: {
+                size_t src[8], idx[8];
+                for (size_t i = 0; i < p.c.b; ++i) src[i] = e, idx[i] = p.c.a + i;
+                return ruin_move(src, idx, p.c.b);
+            }
+            case PrecDecoded::SublistChange: {
+                Move m = make_list_move(Move::SublistChange, desc, e, bl.start + p.c.a, e, p.c.c);
+                m.to_value = (int64_t)(bl.start + p.c.a + p.c.b);
+                return m;
+            }
+            case PrecDecoded::Permute: {
+                Move m = make_list_move(Move::ListPermute, desc, e, bl.start + p.c.a, e, bl.start + p.c.a + p.c.b);
+                m.to_value = (int64_t)p.c.c;
+                return m;
+            }
+        }
+        return Move{};
+    }
+    bool next(Move& out) override {
+        for (;;) {
+            if (multi_swap_index < multi_swap_count) {
+                size_t index = ctx.selection_index(multi_swap_index, multi_swap_count, SALT_MULTI_SWAP ^ (uint64_t)desc);
+                ++multi_swap_index;
+                auto swaps = multi_support_swaps(critical_swaps, support_swaps, index);
+                if (an.graph.multi_intra_list_swaps_introduce_cycle(swaps)) continue;
+                Move m;  // emit_multi_swap (emission.rs:280-294)
+                m.kind = Move::MultiSwap;
+                m.descriptor = desc;
+                m.a_pos = swaps.size();
+                m.a = m.b = swaps.empty() ? 0 : swaps[0].entity;
+                m.require_improvement = true;
+                for (size_t i = 0; i < swaps.size() && i < 4; ++i)
+                    m.ms_entity[i] = (uint16_t)swaps[i].entity, m.ms_first[i] = (uint16_t)swaps[i].first, m.ms_second[i] = (uint16_t)swaps[i].second;
+                out = m;
+                return true;
+            }
+            if (multi_ruin_index < multi_ruin_count) {
+                size_t index = ctx.selection_index(multi_ruin_index, multi_ruin_count, SALT_MULTI_RUIN ^ (uint64_t)desc);
+                ++multi_ruin_index;
+                size_t s[4] = {0, 0, 0, 0};
+                multi_critical_ruin_sources(an.blocks, index, s);
+                // merged_ruin_sources (move/list_kernel/ruin.rs:34-54): one source when both elements sit in one list, sorted by entity
+                size_t src[2] = {s[0], s[2]}, idx[2] = {s[1], s[3]};
+                if (src[0] > src[1] || (src[0] == src[1] && idx[0] > idx[1])) std::swap(src[0], src[1]), std::swap(idx[0], idx[1]);
+                if (src[0] == src[1] && idx[0] == idx[1])
+                    out = ruin_move(src, idx, 1);
+                else
+                    out = ruin_move(src, idx, 2);
+                return true;
+            }
+            if (block_index >= an.blocks.size()) return false;
+            const CriticalBlock& bl = an.blocks[ctx.selection_index(block_index, an.blocks.size(), SALT_BLOCK ^ (uint64_t)desc)];
+            if (move_index < bl.move_count()) {
+                size_t index = tiered_index(bl, move_index, SALT_MOVE ^ (uint64_t)desc ^ (uint64_t)bl.entity ^ ((uint64_t)bl.start << 16) ^ ((uint64_t)bl.end << 32));
+                ++move_index;
+                if (prec_move_introduces_route_cycle(bl, index, an.graph)) continue;
+                out = emit(bl, index);
+                return true;
+            }
+            ++block_index;
+            move_index = 0;
         }
     }
 };

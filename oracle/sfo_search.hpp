@@ -433,6 +433,10 @@ struct LocalSearch {
             move_undo(*director, mv, undo);
             director->restore_score_state(st);
             ++stats.score_calculations;
+            if (mv.require_improvement && !(move_score > last_step_score)) {  // RejectedByScoreImprovement (evaluation.rs:95-113): never reaches the acceptor
+                if (trace) trace->push_back({mv, true, move_score, false, cursor->last_selector(), false});
+                continue;
+            }
             bool accepted = acceptor->is_accepted(last_step_score, move_score);
             if (trace) trace->push_back({mv, true, move_score, accepted, cursor->last_selector(), false});
             if (accepted) {

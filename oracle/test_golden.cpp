@@ -1334,6 +1334,174 @@ static void list_precedence_cases() {
 }
 
 // stream/collector/tests/collector.rs:266-320,399-469 (the seven consecutive_runs tests)
+// heuristic/selector/tests/list_precedence.rs:170-623 (all twelve cases): tasks = (duration, fixed successor or none), routes per
+// machine; index_to_element = identity.
+static void list_precedence_selector_cases() {
+    struct Task {
+        int64_t duration;
+        int64_t next;  // -1 = none
+    };
+    struct Fixture {
+        Solution s;
+        ListSlot slot;
+    };
+    auto mk = [](std::vector<Task> tasks, std::vector<std::vector<uint32_t>> routes) {
+        Fixture f;
+        f.s.classes.resize(1);
+        f.s.classes[0].n = routes.size();
+        f.s.classes[0].lists = routes;
+        auto h = std::make_shared<PrecedenceHooks>();
+        h->node_count = tasks.size();
+        for (auto& t : tasks) {
+            h->durations.push_back(t.duration);
+            h->successors.push_back(t.next >= 0 ? std::vector<size_t>{(size_t)t.next} : std::vector<size_t>{});
+        }
+        f.slot.precedence = h;
+        return f;
+    };
+    auto stream = [](Fixture& f, MoveStreamContext ctx = MoveStreamContext()) {
+        ListPrecedenceCursor c(f.slot, f.s, ctx);
+        std::vector<Move> moves;
+        Move m;
+        while (c.next(m)) moves.push_back(m);
+        return moves;
+    };
+    auto size_of = [](Fixture& f) {
+        std::vector<size_t> entities(f.s.classes[0].n);
+        for (size_t e = 0; e < entities.size(); ++e) entities[e] = e;
+        return precedence_selector_size(critical_analysis(*f.slot.precedence, f.s.classes[0].lists, entities));
+    };
+    auto is = [](const Move& m, Move::Kind k, size_t a_pos, size_t b_pos) { return m.kind == k && m.a == 0 && m.b == 0 && m.a_pos == a_pos && m.b_pos == b_pos; };
+    auto sig = [](const Move& m) {
+        std::vector<int64_t> v{(int64_t)m.kind, (int64_t)m.a, (int64_t)m.a_pos, (int64_t)m.b, (int64_t)m.b_pos, m.to_value, (int64_t)m.ruin_multi};
+        for (int i = 0; i < 8; ++i) v.push_back(m.kind == Move::Ruin ? m.ruin_idx[i] : 0), v.push_back(m.kind == Move::Ruin && m.ruin_multi ? m.ruin_src[i] : 0);
+        for (int i = 0; i < 4; ++i)
+            if (m.kind == Move::MultiSwap) v.push_back(m.ms_entity[i]), v.push_back(m.ms_first[i]), v.push_back(m.ms_second[i]);
+        return v;
+    };
+    auto all_unique = [&](const std::vector<Move>& moves) {
+        std::vector<std::vector<int64_t>> sigs;
+        for (auto& m : moves) sigs.push_back(sig(m));
+        std::sort(sigs.begin(), sigs.end());
+        return std::unique(sigs.begin(), sigs.end()) == sigs.end();
+    };
+    auto ruin_window = [](const Move& m) {
+        std::vector<size_t> w;
+        for (size_t i = 0; i < m.a_pos; ++i) w.push_back(m.ruin_idx[i]);
+        return w;
+    };
+    {  // :170-240
+        Fixture f = mk({{3, -1}, {4, -1}, {5, -1}}, {{0, 1, 2}});
+        auto mv = stream(f);
+        bool ok = size_of(f) == 24 && mv.size() == 24;
+        ok = ok && is(mv[0], Move::ListChange, 0, 2) && is(mv[1], Move::ListChange, 1, 3) && is(mv[2], Move::ListChange, 0, 3) &&
+             is(mv[3], Move::ListChange, 2, 0) && is(mv[4], Move::ListChange, 2, 1) && is(mv[5], Move::ListChange, 1, 0);
+        ok = ok && is(mv[6], Move::ListSwap, 0, 1) && is(mv[7], Move::ListSwap, 0, 2) && is(mv[8], Move::ListSwap, 1, 2);
+        ok = ok && is(mv[9], Move::ListReverse, 0, 2) && is(mv[10], Move::ListReverse, 0, 3) && is(mv[11], Move::ListReverse, 1, 3);
+        // SublistSwap [0,1) <-> [1,3) and [0,2) <-> [2,3)
+        ok = ok && is(mv[12], Move::SublistSwap, 0, 1) && mv[12].to_value == (1 | (2 << 16)) && is(mv[13], Move::SublistSwap, 0, 2) &&
+             mv[13].to_value == (2 | (1 << 16));
+        ok = ok && mv[14].kind == Move::Ruin && mv[14].a == 0 && !mv[14].ruin_multi && mv[14].prec != nullptr && ruin_window(mv[14]) == std::vector<size_t>{0, 1, 2};
+        ok = ok && is(mv[15], Move::SublistChange, 0, 1) && mv[15].to_value == 2 && is(mv[16], Move::SublistChange, 1, 0) && mv[16].to_value == 3;
+        ok = ok && is(mv[17], Move::ListPermute, 0, 2) && nth_permutation(2, (size_t)mv[17].to_value) == std::vector<size_t>{1, 0};
+        ok = ok && is(mv[18], Move::ListPermute, 0, 3) && nth_permutation(3, (size_t)mv[18].to_value) == std::vector<size_t>{0, 2, 1};
+        CHECK("list_precedence_selector.emits_critical_block_moves", ok);
+    }
+    {  // :242-274
+        Fixture f = mk({{3, -1}, {4, -1}, {5, -1}, {2, 2}}, {{0, 1, 2}, {3}});
+        auto mv = stream(f);
+        CHECK("list_precedence_selector.size_matches_streamed_unique_candidates", mv.size() == size_of(f) && all_unique(mv) && !mv.empty());
+    }
+    {  // :276-307
+        std::vector<Task> tasks;
+        for (int i = 0; i < 7; ++i) tasks.push_back({i + 1, -1});
+        Fixture f = mk(tasks, {{0, 1, 2, 3, 4, 5, 6}});
+        auto mv = stream(f);
+        std::vector<std::vector<size_t>> windows;
+        for (auto& m : mv)
+            if (m.kind == Move::Ruin) windows.push_back(ruin_window(m));
+        CHECK("list_precedence_selector.streams_all_critical_ruin_windows",
+              mv.size() == size_of(f) && windows == std::vector<std::vector<size_t>>{{0, 1, 2, 3, 4}, {1, 2, 3, 4, 5}, {2, 3, 4, 5, 6}});
+    }
+    {  // :309-335
+        std::vector<Task> tasks(6, Task{5, -1});
+        Fixture f = mk(tasks, {{0, 1, 2}, {3, 4, 5}});
+        auto mv = stream(f);
+        std::vector<Move> multi;
+        for (auto& m : mv)
+            if (m.kind == Move::Ruin && m.ruin_multi) multi.push_back(m);
+        bool ok = mv.size() == size_of(f) && multi.size() == 9;
+        for (auto& m : multi) ok = ok && m.a_pos == 2;
+        ok = ok && !multi.empty() && multi[0].ruin_src[0] == 0 && multi[0].ruin_src[1] == 1;
+        CHECK("list_precedence_selector.streams_multi_block_ruin_candidates", ok);
+    }
+    {  // :337-383
+        Fixture f = mk({{5, -1}, {5, 4}, {10, -1}, {5, 5}, {5, -1}, {5, -1}}, {{0, 1}, {2, 3}, {4, 5}});
+        auto mv = stream(f);
+        bool any = false;
+        for (auto& m : mv)
+            if (m.kind == Move::MultiSwap && m.require_improvement && m.a_pos == 3 && m.ms_entity[0] == 0 && m.ms_first[0] == 0 && m.ms_second[0] == 1 &&
+                m.ms_entity[1] == 1 && m.ms_first[1] == 0 && m.ms_second[1] == 1 && m.ms_entity[2] == 2 && m.ms_first[2] == 0 && m.ms_second[2] == 1)
+                any = true;
+        CHECK("list_precedence_selector.streams_fixed_successor_support_multi_swaps", mv.size() == size_of(f) && any);
+    }
+    {  // :385-429
+        Fixture f = mk({{3, -1}, {4, -1}, {5, -1}, {6, -1}}, {{0, 1, 2, 3}});
+        auto canonical = stream(f);
+        auto contextual = stream(f, MoveStreamContext(11, 23, 8).with_selection_order(SelectionOrder::Shuffled));
+        std::vector<std::vector<int64_t>> a, b;
+        for (auto& m : canonical) a.push_back(sig(m));
+        for (auto& m : contextual) b.push_back(sig(m));
+        bool differs = a != b;
+        std::sort(a.begin(), a.end());
+        std::sort(b.begin(), b.end());
+        CHECK("list_precedence_selector.applies_stream_context_order", a.size() == b.size() && a == b && differs);
+    }
+    {  // :431-475: MoveStreamContext::new(11, 23, Some(8)) keeps the default order; the first tier stays the adjacent changes
+        Fixture f = mk({{3, -1}, {4, -1}, {5, -1}, {6, -1}}, {{0, 1, 2, 3}});
+        auto mv = stream(f, MoveStreamContext(11, 23, 8));
+        bool ok = mv.size() >= 3;
+        for (size_t i = 0; i < 3 && ok; ++i) ok = mv[i].kind == Move::ListChange && mv[i].a == 0 && mv[i].b == 0 && mv[i].b_pos == mv[i].a_pos + 2;
+        CHECK("list_precedence_selector.stream_context_preserves_adjacent_priority_tier_for_short_blocks", ok);
+    }
+    {  // :477-520
+        Fixture f = mk({{3, 1}, {2, -1}, {5, -1}}, {{0, 2}, {1}});
+        auto mv = stream(f);
+        bool ok = mv.size() == 6 && is(mv[0], Move::ListChange, 0, 2) && is(mv[1], Move::ListChange, 1, 0) && is(mv[2], Move::ListSwap, 0, 1) &&
+                  is(mv[3], Move::ListReverse, 0, 2) && mv[4].kind == Move::Ruin && mv[4].a == 0 && ruin_window(mv[4]) == std::vector<size_t>{0, 1} &&
+                  is(mv[5], Move::ListPermute, 0, 2) && nth_permutation(2, (size_t)mv[5].to_value) == std::vector<size_t>{1, 0};
+        CHECK("list_precedence_selector.ignores_noncritical_route_arcs", ok);
+    }
+    {  // :522-547
+        Fixture f = mk({{1, 1}, {1, -1}}, {{0, 1}});
+        auto mv = stream(f);
+        CHECK("list_precedence_selector.skips_moves_that_force_fixed_successor_cycles",
+              size_of(f) == 1 && mv.size() == 1 && mv[0].kind == Move::Ruin && mv[0].a == 0 && ruin_window(mv[0]) == std::vector<size_t>{0, 1});
+    }
+    {  // :549-585
+        Fixture f = mk({{1, -1}, {5, -1}, {5, -1}, {10, 1}}, {{0, 1, 2}, {3}});
+        auto mv = stream(f);
+        bool any = false, all = true;
+        for (auto& m : mv)
+            if (m.kind == Move::SublistChange) {
+                any = any || (m.a_pos == 1 && m.to_value == 3 && m.b_pos == 0);
+                all = all && m.a_pos != m.b_pos;
+            }
+        CHECK("list_precedence_selector.sublist_destinations_use_route_coordinates", mv.size() == size_of(f) && any && all);
+    }
+    {  // :587-611
+        Fixture f = mk({{3, 2}, {1, -1}, {5, -1}}, {{0, 1}, {2}});
+        auto mv = stream(f);
+        bool any = false;
+        for (auto& m : mv) any = any || (m.kind == Move::ListChange && m.a == 0 && m.a_pos == 0 && m.b_pos == 2);
+        CHECK("list_precedence_selector.emits_singleton_critical_node_relocations", mv.size() == size_of(f) && any);
+    }
+    {  // :613-623
+        Fixture f = mk({{1, 1}, {1, -1}}, {{1, 0}});
+        CHECK("list_precedence_selector.skips_cyclic_current_graph", size_of(f) == 0 && stream(f).empty());
+    }
+}
+
 static void runs_cases() {
     auto feed = [](std::vector<int64_t> v) {
         RunsAccumulator a;
@@ -1771,6 +1939,7 @@ int main() {
     complemented_cases();
     runs_cases();
     list_precedence_cases();
+    list_precedence_selector_cases();
     forager_cases();
     k_opt_cases();
     simulated_annealing_cases();

@@ -9,7 +9,7 @@ from solverforge_amd import datasets
 from oracle import sfo
 
 BITS = {"nearby_change": 16, "nearby_swap": 32, "list_change": 4, "list_swap": 8, "list_reverse": 64,
-        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024, "change": 1, "swap": 2, "permute": 8192}
+        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024, "change": 1, "swap": 2, "permute": 8192, "precedence": 16384}
 
 
 def t6(m):
@@ -117,8 +117,8 @@ def run_case(seed):
                         seqs[int(rng.integers(nm))].append(x)
             p["sequences"] = seqs
         with_owner = bool(rng.random() < 0.7)
-        pool = ["permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"]
-        chosen = set(rng.choice(pool, size=int(rng.integers(1, 7)), replace=False).tolist())
+        pool = ["precedence", "permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"]  # critical-path leaf: round 3
+        chosen = set(rng.choice(pool, size=int(rng.integers(1, 8)), replace=False).tolist())
         leaves = tuple(x for x in pool if x in chosen)
         desc.update(nj=nj, nm=nm, leaves=leaves, with_owner=with_owner)
         d = sfa.build_precedence_shop(p, leaves=leaves, with_owner=with_owner)

@@ -90,6 +90,7 @@ struct sf_ctx {
     int nearby_scalar_dynamic = 0;
     PrecSpec prec;          // ListPrecedenceMakespanConstraint on the list class (sf_precedence.h)
     PrecModel pm{};
+    PlfModel plf{};  // critical-path precedence leaf: per-replica tables (allocated at the first launch that has the leaf)
     NbrIndex nbr{nullptr};  // presorted neighbour index (wave engine)
     bool lm_small = false;  // every trial delta of the list model fits 32-bit arithmetic (wave engine MODE 2)
     int engine = SF_ENGINE_AUTO;
@@ -533,6 +534,17 @@ int32_t sf_selector_add_permute(sf_ctx* ctx, int32_t d, int32_t var, int32_t min
     s.min_size = min_window_size;
     s.max_size = max_window_size;
     ctx->selectors.push_back(s);
+    return SF_OK;
+}
+
+// ListPrecedenceMoveSelector (heuristic/selector/list_precedence.rs:121-210; ListPrecedenceMoveConfig has no tunables): the critical-path leaf of
+// a list class that carries the precedence constraint, whose fixed successors and durations are the leaf's hooks
+int32_t sf_selector_add_precedence(sf_ctx* ctx, int32_t d, int32_t var) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
+    for (auto& s : ctx->selectors)
+        if (s.kind == SF_SEL_LIST_PRECEDENCE) return fail(ctx, SF_ERR_UNSUPPORTED, "one list precedence leaf per union");
+    ctx->selectors.push_back(SelectorSpec{SF_SEL_LIST_PRECEDENCE, d, var, 0, -1});
     return SF_OK;
 }
 
@@ -1948,7 +1960,7 @@ static bool has_plain_list_leaves(sf_ctx* ctx) {
     for (auto& s : ctx->selectors)
         if (s.desc == ctx->list_desc && (s.kind == SF_SEL_LIST_CHANGE || s.kind == SF_SEL_LIST_SWAP || s.kind == SF_SEL_LIST_REVERSE ||
                                          s.kind == SF_SEL_SUBLIST_CHANGE || s.kind == SF_SEL_SUBLIST_SWAP || s.kind == SF_SEL_KOPT ||
-                                         s.kind == SF_SEL_LIST_RUIN || s.kind == SF_SEL_LIST_PERMUTE))
+                                         s.kind == SF_SEL_LIST_RUIN || s.kind == SF_SEL_LIST_PERMUTE || s.kind == SF_SEL_LIST_PRECEDENCE))
             return true;
     return false;
 }
@@ -1963,7 +1975,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     if (union_is_custom(ctx)) {
         for (auto& s : ctx->selectors) ordered.push_back(&s);
     } else {
-        for (int kind : {SF_SEL_LIST_PERMUTE,  // the precedence pair leads the list policy (policy/list.rs:24-33)
+        for (int kind : {SF_SEL_LIST_PRECEDENCE, SF_SEL_LIST_PERMUTE,  // the precedence pair leads the list policy (policy/list.rs:24-33)
                          SF_SEL_NEARBY_LIST_CHANGE, SF_SEL_LIST_CHANGE, SF_SEL_NEARBY_LIST_SWAP, SF_SEL_LIST_SWAP, SF_SEL_SUBLIST_CHANGE,
                          SF_SEL_SUBLIST_SWAP, SF_SEL_LIST_REVERSE, SF_SEL_KOPT, SF_SEL_LIST_RUIN, SF_SEL_NEARBY_SCALAR_CHANGE,
                          SF_SEL_NEARBY_SCALAR_SWAP, SF_SEL_SCALAR_CHANGE, SF_SEL_SCALAR_SWAP})  // nearby scalar rules precede the ordinary pair (policy.rs:104-108)
@@ -2010,6 +2022,48 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                     gl.kopt_scratch = ctx->d_kopt_scratch;
                 }
             }
+            if (kind == SF_SEL_LIST_PRECEDENCE) {  // critical-path leaf: per-replica tables (sf_prec_leaf.h)
+                if (!ctx->pm.on) return fail(ctx, SF_ERR_INVALID, "list precedence leaf: the list class carries no precedence constraint");
+                // its ruins recreate by the precedence constraint alone: no other list constraint may score an insertion
+                if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0 || ctx->lm.ne_level >= 0)
+                    return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf on a list class with distance / capacity / not-exists constraints");
+                if (!ctx->plf.on) {
+                    const PrecSpec& ps = ctx->prec;
+                    const size_t n = ps.dur.size();
+                    std::vector<int32_t> deg(n, 0);
+                    for (size_t i = 0; i < n; ++i) {
+                        std::vector<uint32_t> seen;
+                        for (uint32_t t = ps.succ_off[i]; t < ps.succ_off[i + 1]; ++t) {
+                            const uint32_t to = ps.succ[t];
+                            if (to >= n) continue;
+                            if (std::find(seen.begin(), seen.end(), to) != seen.end())
+                                return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf: a node names one fixed successor twice");
+                            seen.push_back(to);
+                            deg[i] += 1, deg[to] += 1;
+                        }
+                    }
+                    PlfModel& pl = ctx->plf;
+                    pl.dmax = 0;
+                    for (int32_t dv : deg) pl.dmax = std::max(pl.dmax, dv);
+                    const size_t R = (size_t)ctx->R, nn = std::max<size_t>(n, 1), nc = (size_t)std::max(ctx->lm.n_cap, 1);
+                    int rc = dalloc(ctx, &pl.latest, R * nn);
+                    if (!rc) rc = dalloc(ctx, &pl.posn, R * nn);
+                    if (!rc) rc = dalloc(ctx, &pl.flag, R * nc);
+                    if (!rc) rc = dalloc(ctx, &pl.roff, R * (nn + 2));
+                    if (!rc) rc = dalloc(ctx, &pl.blk, R * nn * 2);
+                    if (!rc) rc = dalloc(ctx, &pl.csw, R * nn);
+                    if (!rc) rc = dalloc(ctx, &pl.ssw, R * nn);
+                    if (!rc) rc = dalloc(ctx, &pl.first, R * nc);
+                    if (!rc) rc = dalloc(ctx, &pl.cnl, R * nn);
+                    if (!rc) rc = dalloc(ctx, &pl.msrow, R * (nn + 1));
+                    if (!rc) rc = dalloc(ctx, &pl.mrrow, R * (nn + 1));
+                    if (!rc) rc = dalloc(ctx, &pl.sE, R * (size_t)std::max(ctx->lm.V, 1));
+                    if (!rc) rc = dalloc(ctx, &pl.score, R * GRC * 4);
+                    if (rc) return rc;
+                    pl.on = 1;
+                }
+                gl.plf = ctx->plf;
+            }
             if (kind == SF_SEL_LIST_RUIN) {
                 if (gl.has_ruin) return fail(ctx, SF_ERR_UNSUPPORTED, "one list ruin leaf per union");
                 if (!ctx->d_ruin_rng) return fail(ctx, SF_ERR_INVALID, "list ruin leaf: sf_phase_start seeds its stream first");
@@ -2050,6 +2104,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         gl.prec_inc = std::getenv("SF_AMD_PREC_INC") != nullptr ? 1 : 0;
         // lane-per-trial sweep (prec_trial_sweep64): the default with the scratch in HBM; SF_AMD_PREC_NO_SWEEP = one full evaluation per trial
         gl.prec_sweep = (gl.prec.on && !gl.prec_lds && !gl.prec_inc && std::getenv("SF_AMD_PREC_NO_SWEEP") == nullptr) ? 1 : 0;
+        if (gl.plf.on) gl.prec_inc = gl.prec_sweep = 0;  // the critical-path leaf re-evaluates in the main scratch arrays: one full evaluation per trial
         if (gl.prec_sweep && !ctx->pm.elane) {  // [R][n][64] earliest starts of the trials in flight
             int rc = dalloc(ctx, &ctx->pm.elane, (size_t)ctx->R * (size_t)ctx->pm.n * 64);
             if (rc) return rc;

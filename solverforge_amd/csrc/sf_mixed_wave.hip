@@ -26,6 +26,7 @@
 #include "sf_kopt.h"
 #include "sf_list_model.h"
 #include "sf_precedence.h"
+#include "sf_prec_leaf.h"
 
 namespace sf {
 
@@ -101,6 +102,7 @@ struct GLeaves {
     int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
     int32_t prec_inc;        // HBM scratch: list change / swap trials take the incremental refresh (prec_trial_inc; opt-in, see sf_precedence.h)
     int32_t prec_sweep;      // HBM scratch: the list change / swap trials of a replay chunk are scored 64 at a time (prec_trial_sweep64)
+    PlfModel plf;            // critical-path precedence leaf (kind 16384; PREC instantiations, sf_prec_leaf.h)
 };
 
 template <class VT>
@@ -504,6 +506,168 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         prec_pen = pr.penalty;
         prec_mk = pr.makespan;
     }
+    // ---- critical-path precedence leaf (kind 16384): per-replica tables, one full evaluation with the cycle flag ----
+    const bool plf_on = PREC && gl.plf.on != 0;
+    PlfRep plf{};
+    __shared__ uint32_t s_plf_info[4][4];
+    uint32_t* const plf_info = s_plf_info[threadIdx.x >> 6];
+    int64_t* const plf_score = plf_on ? gl.plf.score + (size_t)r * GRC * 4 : nullptr;
+    if (plf_on) {
+        const size_t pn = (size_t)gl.prec.n, pc = (size_t)lm.n_cap;
+        plf.latest = gl.plf.latest + (size_t)r * pn, plf.posn = gl.plf.posn + (size_t)r * pn, plf.flag = gl.plf.flag + (size_t)r * pc;
+        plf.roff = gl.plf.roff + (size_t)r * (pn + 2), plf.blk = gl.plf.blk + (size_t)r * pn * 2, plf.csw = gl.plf.csw + (size_t)r * pn;
+        plf.ssw = gl.plf.ssw + (size_t)r * pn, plf.first = gl.plf.first + (size_t)r * pc, plf.cnl = gl.plf.cnl + (size_t)r * pn;
+        plf.msrow = gl.plf.msrow + (size_t)r * (pn + 1), plf.mrrow = gl.plf.mrrow + (size_t)r * (pn + 1), plf.sE = gl.plf.sE + (size_t)r * V;
+    }
+    // full evaluation of the lists in LDS that also reports the cycle flag (and, with `roff`, Kahn's rounds)
+    auto plf_eval = [&](bool& cyclic, uint32_t* roff) -> PrecResult {
+        PrecResult pr;
+        if (prec_in_lds)
+            pr = prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u32*)prec_Q,
+                                                 (prec_lds_u32*)prec_S, nullptr, plf_info, roff);
+        else
+            pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, nullptr, plf_info, roff);
+        wave_sync();
+        cyclic = uni(plf_info[1]) != 0u;
+        return pr;
+    };
+    auto plf_score_of = [&](const PrecResult& pr) {
+        ScoreV<L> sc;
+#pragma unroll
+        for (int kk = 0; kk < L; ++kk) {
+            sc.v[kk] = cur[kk];
+            if (kk == gl.prec.hard_level) sc.v[kk] -= pr.penalty - prec_pen;
+            if (kk == gl.prec.mk_level) sc.v[kk] -= pr.makespan - prec_mk;
+        }
+        return sc;
+    };
+    auto plf_restore_all = [&]() {  // the committed lists back from their HBM copy (written at every commit)
+        for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
+        wave_sync();
+        const uint32_t tot = uni(s_off[V]);
+        for (uint32_t t = lane; t < tot; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+        wave_sync();
+    };
+    // precedence-aware ruin and recreate (move/list_kernel/ruin.rs:131-281 with recreate_precedence_graph): the removed elements go back
+    // one per round at the best-scoring insertion over every (element, list, position) that does not close a cycle, the first of
+    // equal scores staying.  One element slides through every position with an adjacent exchange (or a list boundary shift) per
+    // step, one full evaluation each.
+    auto plf_ruin = [&](const PlfMove& m, bool keep) -> ScoreV<L> {
+        uint32_t vals[PLF_RUIN_MAX];
+#pragma unroll
+        for (uint32_t k = 0; k < PLF_RUIN_MAX; ++k) vals[k] = 0;
+        for (uint32_t k = m.n; k-- > 0;) {
+            const uint32_t x = plf_list_remove(s_visits, s_off, V, m.el[k] >> 16, m.el[k] & 0xFFFFu);
+#pragma unroll
+            for (uint32_t q = 0; q < PLF_RUIN_MAX; ++q)
+                if (q == k) vals[q] = x;
+        }
+        uint32_t remaining = (1u << m.n) - 1u;
+        ScoreV<L> last;
+#pragma unroll
+        for (int kk = 0; kk < L; ++kk) last.v[kk] = cur[kk];
+        bool rolled = false;
+        for (uint32_t round = 0; round < m.n && !rolled; ++round) {
+            bool have = false;
+            ScoreV<L> best_sc = last;
+            uint32_t b_ri = 0, b_e = 0, b_pos = 0;
+            for (uint32_t ri = 0; ri < m.n; ++ri) {
+                if (!((remaining >> ri) & 1u)) continue;
+                uint32_t x = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < PLF_RUIN_MAX; ++q)
+                    if (q == ri) x = vals[q];
+                plf_list_insert(s_visits, s_off, V, 0, 0, x);
+                uint32_t e = 0, pos = 0, g = 0;
+                for (;;) {
+                    bool cyc;
+                    const PrecResult pr = plf_eval(cyc, nullptr);
+                    if (!cyc) {
+                        const ScoreV<L> sc = plf_score_of(pr);
+                        if (!have || score_cmp<L>(sc, best_sc) > 0) {
+                            have = true;
+                            best_sc = sc, b_ri = ri, b_e = e, b_pos = pos;
+                        }
+                    }
+                    const uint32_t others = uni(s_off[e + 1] - s_off[e]) - 1u;  // list e without the sliding element
+                    if (pos < others) {
+                        if (lane == 0) {
+                            const uint16_t y = s_visits[g + 1];
+                            s_visits[g + 1] = (uint16_t)x;
+                            s_visits[g] = y;
+                        }
+                        g += 1, pos += 1;
+                    } else if (e + 1 < (uint32_t)V) {
+                        if (lane == 0) s_off[e + 1] -= 1;  // the tail of list e becomes the head of list e + 1
+                        e += 1, pos = 0;
+                    } else
+                        break;
+                    wave_sync();
+                }
+                if (lane == 0) s_off[V] -= 1;  // the element sits at the very end: drop it
+                wave_sync();
+            }
+            if (!have) {
+                rolled = true;
+                break;
+            }
+            uint32_t bx = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < PLF_RUIN_MAX; ++q)
+                if (q == b_ri) bx = vals[q];
+            plf_list_insert(s_visits, s_off, V, b_e, b_pos, bx);
+            remaining &= ~(1u << b_ri);
+            last = best_sc;
+        }
+        if (rolled) {  // restore_removed_elements: the move leaves the lists as they were
+#pragma unroll
+            for (int kk = 0; kk < L; ++kk) last.v[kk] = cur[kk];
+        }
+        if (rolled || !keep) plf_restore_all();
+        return last;
+    };
+    // one decoded candidate applied to the LDS lists and scored; false = its lists are cyclic (pruned).  keep: leave it applied.
+    auto plf_apply = [&](const PlfMove& m) {
+        if (m.kind == 10) {
+            if (lane < 3) {
+                const uint32_t w = lane == 0 ? m.el[0] : (lane == 1 ? m.el[1] : m.el[2]);
+                const uint32_t gpos = s_off[w >> 16] + (w & 0xFFFFu);
+                const uint16_t x = s_visits[gpos], y = s_visits[gpos + 1];
+                s_visits[gpos] = y, s_visits[gpos + 1] = x;
+            }
+            wave_sync();
+        } else
+            apply_list_move_wave(lm, s_visits, s_off, s_load, m.kind, m.a, m.ap, m.b, m.bp, m.ext);
+        wave_sync();
+    };
+    auto plf_trial = [&](const PlfMove& m, ScoreV<L>& sc) -> bool {
+        if (m.kind == 8) {
+            sc = plf_ruin(m, false);
+            return true;
+        }
+        plf_apply(m);
+        bool cyc;
+        const PrecResult pr = plf_eval(cyc, nullptr);
+        sc = plf_score_of(pr);
+        if (m.kind == 10)
+            plf_apply(m);  // the same exchanges again
+        else {  // one list changed: its items back from the committed copy
+            const uint32_t lo = uni(s_off[m.a]), hi = uni(s_off[m.a + 1]);
+            for (uint32_t t = lo + lane; t < hi; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+            wave_sync();
+        }
+        return !cyc;
+    };
+    // ring entry (stage << 30 | block, index inside the stage) -> move
+    auto plf_decode = [&](uint32_t w0, uint32_t w1, PlfMove& m) {
+        const uint32_t stage = w0 >> 30;
+        if (stage == 0)
+            plf_decode_multi_swap(plf, w1, m);
+        else if (stage == 1)
+            plf_decode_multi_ruin(plf, w1, m);
+        else
+            plf_decode_block(plf_block(plf, w0 & 0x3FFFFFFFu), w1, m);
+    };
     // per-launch counters in 32 bits (wave-uniform), folded into the 64-bit sf_stats words before they can wrap
     uint32_t st_steps = 0, st_gen = 0, st_acc = 0, st_applied = 0, st_calc = 0, st_scored = 0, st_sources = 0;
     uint64_t steps_run = 0;
@@ -678,6 +842,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 const uint32_t sd0 = (ctx.canonical() || ns <= 1) ? 1u : ctx.random_stride(ns, sb_);
                 lt.put_gen(l, GGen{0, 0, uni(st0), uni(sd0), 0, 0, ns == 0});
             }
+        }
+        if (plf_on) {  // critical-path leaf: the committed evaluation again (the trials overwrote its arrays), then the step's analysis
+            bool cyc;
+            const PrecResult pr = plf_eval(cyc, plf.roff);
+            const uint32_t rounds = uni(plf_info[2]);
+            if (prec_in_lds)
+                plf_analyse<PrecMemLds>(gl.prec, gl.plf, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u32*)prec_Q, (prec_lds_u32*)prec_S, rounds,
+                                        (int32_t)pr.makespan, cyc);
+            else
+                plf_analyse<PrecMemGlobal>(gl.prec, gl.plf, plf, s_visits, s_off, V, prec_E, prec_Q, prec_S, rounds, (int32_t)pr.makespan, cyc);
+            plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni(plf.ms_count), plf.mr_count = uni(plf.mr_count);
         }
         uint32_t exmask = 0xFFu & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
@@ -1293,6 +1468,62 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                             wx = ctx.selection_index(q, 7u, kopt_pattern_salt(ldesc, ent, c1, c2, c3));
                         }
                         wave_sync();  // the triples are consumed before the next call overwrites them
+                    } else if (PREC && kind == 16384) {  // ---- critical-path precedence leaf (precedence/cursor.rs:182-252): one candidate per call,
+                                                         // decoded, applied, scored (and pruned when cyclic) right here.  g.a = stage, g.b = offset
+                                                         // inside the stage, g.c = block offset ----
+                        PlfMove pm_;
+                        bool emit = false;
+                        if (g.a == 0) {
+                            if (g.b >= plf.ms_count) {
+                                g.a = 1, g.b = 0;
+                                st_sources -= 1;
+                                continue;
+                            }
+                            w1 = ctx.selection_index(g.b, plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc);
+                            g.b += 1;
+                            w0 = 0;
+                            plf_decode_multi_swap(plf, w1, pm_);
+                            emit = true;
+                        } else if (g.a == 1) {
+                            if (g.b >= plf.mr_count) {
+                                g.a = 2, g.b = 0, g.c = 0;
+                                st_sources -= 1;
+                                continue;
+                            }
+                            w1 = ctx.selection_index(g.b, plf.mr_count, SALT_PL_MULTI_RUIN ^ ldesc);
+                            g.b += 1;
+                            w0 = 1u << 30;
+                            plf_decode_multi_ruin(plf, w1, pm_);
+                            emit = true;
+                        } else {
+                            if (g.c >= plf.nb) {
+                                g.done = 1;
+                                break;
+                            }
+                            const uint32_t bi = ctx.selection_index(g.c, plf.nb, SALT_PL_BLOCK ^ ldesc);
+                            const PlfBlock bl = plf_block(plf, bi);
+                            if (g.b >= bl.moves()) {
+                                g.c += 1, g.b = 0;
+                                st_sources -= 1;
+                                continue;
+                            }
+                            w1 = plf_tiered_index(ctx, bl, g.b, SALT_PL_MOVE ^ ldesc ^ (uint64_t)bl.e ^ ((uint64_t)bl.start << 16) ^ ((uint64_t)(bl.start + bl.len - 1) << 32));
+                            g.b += 1;
+                            w0 = (2u << 30) | bi;
+                            plf_decode_block(bl, w1, pm_);
+                            emit = true;
+                        }
+                        w0 = uni(w0), w1 = uni(w1);
+                        if (emit) {
+                            ScoreV<L> psc;
+                            if (plf_trial(pm_, psc)) {
+                                keep = lane == 0;
+                                if (lane == 0) {
+#pragma unroll
+                                    for (int kk = 0; kk < L; ++kk) plf_score[(size_t)(tl & (GRC - 1)) * 4 + kk] = psc.v[kk];
+                                }
+                            }
+                        }
                     } else if (RUIN && kind == 1024) {  // ---- list ruin (list_kernel/ruin.rs:127-144): one candidate per call, scored right here ----
                         if (g.a >= (uint32_t)gl.ruin.moves_per_step) {
                             g.done = 1;
@@ -1643,6 +1874,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                                            : eval_scalar_move(sm, s_vals, 1, m0, m1, 0, tc, ts, tables ? lbv : nullptr);
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
+                    } else if (PREC && my_kind == 16384) {  // critical-path leaf: scored when it was generated
+                        doable = true;
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) sc.v[kk] = plf_score[(size_t)(my_idx & (GRC - 1)) * 4 + kk];
                     } else if (RUIN && my_kind == 1024) {  // list ruin: scored when it was generated
                         doable = true;
 #pragma unroll
@@ -1677,7 +1912,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 for (int kk = 0; kk < L; ++kk) curv.v[kk] = cur[kk];
                 doable = doable && valid;
                 if (PREC) {
-                    uint64_t todo = __ballot(doable && my_kind >= 4 && my_kind != 1024);
+                    uint64_t todo = __ballot(doable && my_kind >= 4 && my_kind != 1024 && my_kind != 16384);
                     if (prec_sweep && psw.ok) {  // the list change / swap candidates of the chunk: one lane each, scored together
                         const bool cand = doable && (my_kind == 4 || my_kind == 16 || my_kind == 8 || my_kind == 32);
                         const uint64_t cm_ = __ballot(cand);
@@ -1739,8 +1974,11 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         wave_sync();
                     }
                 }
+                // Move::requires_score_improvement (evaluation.rs:95-113): a multi-swap of the critical-path leaf that does not beat the last
+                // step score is scored and counted, but never reaches the acceptor
+                const bool consult = doable && !(PREC && my_kind == 16384 && (m0 >> 30) == 0u && score_cmp<L>(sc, curv) <= 0);
                 bool acc = false;
-                if (doable) {
+                if (consult) {
                     if (acceptor == 0)
                         acc = score_cmp<L>(sc, curv) > 0;
                     else if (acceptor == 1)
@@ -1749,7 +1987,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         acc = score_cmp<L>(sc, curv) >= 0 || score_cmp<L>(sc, late) >= 0 || score_cmp<L>(sc, dla_thr) >= 0;
                 }
                 SaChunk sach;
-                if (annealing) acc = sa_decide<L>(saw, p.sa, doable, sc, curv, lane, sach);
+                if (annealing) acc = sa_decide<L>(saw, p.sa, consult, sc, curv, lane, sach);
                 uint64_t accmask = __ballot(acc);
                 bool improving_pick = false;
                 ScoreV<L> forager_thr = curv;  // FirstLastStepScoreImproving: the last step score
@@ -1830,6 +2068,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                             tm[3] = my_kind == 1 ? 0 : (int32_t)m1;
                             tm[4] = 0;
                             tm[5] = my_kind == 1 ? (int32_t)m1 : -1;
+                        } else if (PREC && my_kind == 16384) {
+                            // decoded one candidate at a time below (the decoders are wave-uniform)
                         } else if (RUIN && my_kind == 1024) {  // a = list, a_pos = count, six 16-bit positions in b / b_pos / value
                             const uint16_t* cd = rl.cand + (size_t)m0 * RuinLds::CAND_WORDS;
                             tm[0] = 8;
@@ -1856,6 +2096,17 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         }
                         for (int kk = 0; kk < L && kk < gl.levels; ++kk) p.trace_scores[ti * gl.levels + kk] = doable ? sc.v[kk] : 0;
                         p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0) | ((int32_t)my_leaf << 8);
+                    }
+                }
+                if (PREC && tracing) {  // critical-path leaf: the wire form of its consumed candidates
+                    uint64_t pend = __ballot(consumed && my_kind == 16384);
+                    while (pend) {
+                        const int ci = __ffsll((unsigned long long)pend) - 1;
+                        pend &= pend - 1;
+                        PlfMove pm_;
+                        plf_decode((uint32_t)__builtin_amdgcn_readlane((int)m0, ci), (uint32_t)__builtin_amdgcn_readlane((int)m1, ci), pm_);
+                        const uint64_t ti = trace_n + (uint64_t)ci;
+                        if (lane == 0 && (int64_t)ti < p.trace_cap) plf_wire(pm_, p.trace_moves + ti * 6);
                     }
                 }
                 if (tracing) trace_n += nconsumed;
@@ -1911,6 +2162,19 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     }
                 }
                 wave_sync();
+            } else if (PREC && kind == 16384) {  // critical-path leaf: decode the pick again (the analysis tables are the step's), apply it
+                PlfMove pm_;
+                plf_decode(a, b, pm_);
+                if (tracing && lane == 0) {
+                    p.trace_applied[0] = 1;
+                    if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied
+                    plf_wire(pm_, p.trace_applied + 1);
+                }
+                if (pm_.kind == 8) {
+                    const ScoreV<L> ignored = plf_ruin(pm_, true);
+                    (void)ignored;
+                } else
+                    plf_apply(pm_);
             } else if (RUIN && kind == 1024) {  // committed ruin: the same recreate, this time kept
                 const uint16_t* cd = rl.cand + (size_t)a * RuinLds::CAND_WORDS;
                 if (tracing && lane == 0) {

@@ -19,6 +19,7 @@ class MoveKind:
     CHANGE, SWAP, LIST_CHANGE, LIST_SWAP, LIST_REVERSE, SUBLIST_CHANGE, SUBLIST_SWAP = 0, 1, 2, 3, 4, 5, 6
     KOPT = 7  # a = list, a_pos / b / b_pos = the three cuts, value = reconnection pattern
     LIST_RUIN = 8  # a = list, a_pos = count, six 16-bit ascending positions in b / b_pos / value
+    LIST_MULTI_SWAP = 10  # a = swaps; a_pos / b / b_pos = (list | first << 16) per swap; value = second - first, one byte per swap
     LIST_PERMUTE = 9  # a = b = list, [a_pos, b_pos) = the window, value = rank of the permutation (lexicographic, >= 1)
 
 
@@ -61,6 +62,7 @@ class SelectorKind:
     LIST_RUIN = 1024
     NEARBY_SCALAR_CHANGE, NEARBY_SCALAR_SWAP = 2048, 4096
     LIST_PERMUTE = 8192
+    LIST_PRECEDENCE = 16384
 
 
 @dataclass
@@ -220,6 +222,11 @@ class GpuScoreDirector:
         """List ruin leaf (ListRuinMoveSelectorConfig defaults); max_source_list_len 0 = None."""
         check(self._L.sf_selector_add_ruin(self._h, descriptor_index, variable_index, min_ruin_count, max_ruin_count, moves_per_step,
                                            max_source_list_len, int(skip_empty_destinations), variable_name.encode()), self._h)
+
+    def add_precedence_selector(self, descriptor_index, variable_index=0):
+        """Critical-path precedence leaf (ListPrecedenceMoveSelector, heuristic/selector/list_precedence.rs:121-210) of a list class that
+        carries the precedence constraint: multi-swaps, multi-block ruins, then the tiered move families of every critical block."""
+        check(self._L.sf_selector_add_precedence(self._h, descriptor_index, variable_index), self._h)
 
     def add_permute_selector(self, descriptor_index, variable_index=0, min_window_size=2, max_window_size=5):
         """List permute leaf (ListPermuteMoveSelectorConfig defaults): every non-identity permutation of every window of

@@ -151,7 +151,9 @@ def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_chan
     d.add_list_variable(0, problem["sequences"], element_capacity=n, element_id_bound=n)
     d.add_list_precedence(0, problem["durations"], problem["successors"], problem["expected_owner"] if with_owner else None,
                           hard_level=hard_level, makespan_level=makespan_level)
-    if "permute" in leaves:  # the precedence pair leads the list policy (policy/list.rs:24-33)
+    if "precedence" in leaves:  # the precedence pair leads the list policy (policy/list.rs:24-33)
+        d.add_precedence_selector(0)
+    if "permute" in leaves:
         d.add_permute_selector(0)
     if "list_change" in leaves:
         d.add_selector(SelectorKind.LIST_CHANGE, 0)

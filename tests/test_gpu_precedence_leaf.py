@@ -1,0 +1,188 @@
+"""GPU parity tests (through the C ABI): the critical-path precedence leaf (ListPrecedenceMoveSelector,
+heuristic/selector/list_precedence.rs:121-210 over list_kernel/precedence/{analysis,coordinates,support,cursor,emission}.rs -- the first
+list leaf of the default policy for slots with precedence hooks, default_local_search/policy/list.rs:24-33,62-93) in the generic N-leaf
+engine vs the oracle's cursor (pinned to all twelve cases of heuristic/selector/tests/list_precedence.rs in oracle/test_golden.cpp):
+candidate streams with trial scores under Original / Random / Shuffled order -- multi-swaps (score improvement required), two-block
+ruins and ruin windows recreated with the precedence hooks, the tiered block families, cyclic candidates pruned -- traced steps with
+the committed move, fused multi-replica launches with counters; alone and beside the permute / change / swap leaves; Kahn scratch in
+LDS and in HBM."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PREC, PERMUTE = 16384, 8192
+BITS = {"precedence": PREC, "permute": PERMUTE, "list_change": 4, "list_swap": 8, "list_reverse": 64, "sublist_change": 128}
+COUNTERS = ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations", "moves_not_doable"]
+
+
+def _t(moves):
+    return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"], moves["value"]], axis=1)
+
+
+@pytest.fixture(params=["lds", "hbm"])
+def scratch(request):
+    if request.param == "hbm":
+        os.environ["SF_AMD_PREC_HBM"] = "1"
+    yield request.param
+    os.environ.pop("SF_AMD_PREC_HBM", None)
+
+
+def _pair(oracle, p, leaves, seed, n_replicas=1, la=5, limit=25, with_owner=True):
+    import solverforge_amd as sfa
+
+    d = sfa.build_precedence_shop(p, n_replicas=n_replicas, leaves=leaves, with_owner=with_owner)
+    d.configure(sfa.SolverConfig(random_seed=seed, late_acceptance_size=la, accepted_count_limit=limit))
+    bits = sum(BITS[x] for x in leaves)
+
+    def mk(s, order=3):
+        o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"] if with_owner else None)
+        o.configure(leaves=bits, random_seed=s, la_size=la, limit=limit, selection_order=order)
+        return o
+
+    return d, mk, bits
+
+
+@pytest.mark.parametrize("jobs,machines,seed", [(4, 3, 1), (6, 4, 5), (7, 3, 9), (10, 5, 2)])
+@pytest.mark.parametrize("leaves", [("precedence",), ("precedence", "permute", "list_change", "list_swap")])
+def test_streams_with_trial_scores(oracle, scratch, jobs, machines, seed, leaves):
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(jobs, machines, seed=seed)
+    d, mk, bits = _pair(oracle, p, leaves, seed)
+    o = mk(seed)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    seen = set()
+    for order in (0, 3, 4):
+        o = mk(seed, order)
+        for si, ss in ((0, 0), (3, 0xBEEF1234)):
+            gm, gs, gd = d.open_cursor(si, ss, selection_order=order, cap=1 << 18)
+            om = o.enumerate(0, si, ss, order)
+            assert len(gm) == len(om) > 0, (order, si)
+            assert (_t(gm) == _t(om)).all(), (order, si)
+            os_, od = o.evaluate_moves(om)
+            assert (gd == od).all() and (gs == os_[:, :2]).all(), (order, si)
+            seen |= set(int(k) for k in _t(gm)[:, 0])
+    assert {2, 3, 4, 8} <= seen  # change, swap, reverse, ruin at least
+    if jobs >= 6:
+        assert {5, 6, 9, 10} <= seen  # sublist change / swap, permutation, multi-swap
+
+
+def test_four_level_score_and_no_expected_owner(oracle):
+    """The 4-level instantiation (hard penalty on level 1, makespan on level 3), no expected-owner hook."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(6, 3, seed=8)
+    R = 2
+    d = sfa.build_precedence_shop(p, n_replicas=R, leaves=("precedence", "list_change"), levels=4, hard_levels=2, hard_level=1, makespan_level=3,
+                                  with_owner=False)
+    d.configure(sfa.SolverConfig(random_seed=6, late_acceptance_size=4, accepted_count_limit=20))
+
+    def mk(seed):
+        o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], None, levels=4, hard_levels=2, hard_level=1, soft_level=3)
+        o.configure(leaves=PREC | 4, random_seed=seed, la_size=4, limit=20)
+        return o
+
+    o = mk(6)
+    assert (d.calculate_score()[0] == o.score()[:4]).all()
+    gm, gs, gd = d.open_cursor(2, 99, selection_order=3, cap=1 << 18)
+    om = o.enumerate(0, 2, 99, 3)
+    assert len(gm) == len(om) > 0 and (_t(gm) == _t(om)).all()
+    os_, od = o.evaluate_moves(om)
+    assert (gd == od).all() and (gs == os_[:, :4]).all()
+    d.phase_start()
+    d.solve_steps(15)
+    scores = d.calculate_score()
+    for r in range(R):
+        o = mk(6 + r)
+        o.phase_start()
+        o.steps(15)
+        assert (scores[r] == o.score()[:4]).all(), r
+        assert d.working_lists(0, r) == o.get_lists(0), r
+
+
+def test_traced_and_fused_steps(oracle, scratch):
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(6, 4, seed=3)
+    R = 3
+    for leaves in (("precedence",), ("precedence", "permute", "list_change", "list_swap", "list_reverse")):
+        d, mk, bits = _pair(oracle, p, leaves, 11, n_replicas=R)
+        o = mk(11)
+        d.calculate_score()
+        d.phase_start()
+        o.phase_start()
+        kinds = set()
+        for step in range(8):
+            gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+            om, os_, of, oap, omv = o.step_traced()
+            assert len(gm) == len(om), (leaves, step)
+            assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), (leaves, step)
+            assert gap == oap
+            if gap:
+                assert tuple(gmv) == tuple(omv), step
+                kinds.add(int(gmv["kind"]))
+            assert d.working_lists(0, 0) == o.get_lists(0), step
+        d.solve_steps(10)
+        d.solve_steps(10)
+        scores = d.calculate_score()
+        for r in range(R):
+            o = mk(11 + r)
+            o.phase_start()
+            o.steps(28)
+            assert (scores[r] == o.score()[:2]).all(), (leaves, r)
+            assert d.working_lists(0, r) == o.get_lists(0), (leaves, r)
+            gst, ost = d.stats(r), o.stats()
+            for c in COUNTERS:
+                assert gst[c] == ost[c], (leaves, r, c)
+        assert (d.fresh_score() == scores).all()
+
+
+def test_unscheduled_and_cyclic_states(oracle):
+    """A cyclic working state gives the leaf no blocks at all (analysis.rs:61-70); the other leaves still stream."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(5, 3, seed=2)
+    # job 0's second operation moves in front of its first one, on that one's machine: a two-node cycle
+    seqs = [list(s) for s in p["sequences"]]
+    for s in seqs:
+        if 1 in s:
+            s.remove(1)
+    for s in seqs:
+        if 0 in s:
+            s.insert(s.index(0), 1)
+    p["sequences"] = seqs
+    d, mk, bits = _pair(oracle, p, ("precedence", "list_swap"), 4)
+    o = mk(4)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    gm, gs, gd = d.open_cursor(0, 5, selection_order=3, cap=1 << 18)
+    om = o.enumerate(0, 0, 5, 3)
+    assert len(gm) == len(om) > 0 and (_t(gm) == _t(om)).all()
+    assert set(int(k) for k in _t(gm)[:, 0]) == {3}
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(12)
+    o.steps(12)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+
+
+def test_validation():
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(12, 2, 60, seed=1)
+    d = sfa.build_cvrp(p, leaves=("list_change",))
+    d.add_precedence_selector(0)  # no precedence constraint on this list class: refused at the first launch
+    d.configure(sfa.SolverConfig(random_seed=1))
+    d.calculate_score()
+    d.phase_start()
+    with pytest.raises(sfa.SolverForgeError):
+        d.solve_steps(1)
+    q = datasets.make_precedence_shop(3, 2, seed=1)
+    d = sfa.build_precedence_shop(q, leaves=("precedence",))
+    with pytest.raises(sfa.SolverForgeError):
+        d.add_precedence_selector(0)  # one such leaf per union
