@@ -362,6 +362,16 @@ int32_t sf_selector_add_permute(sf_ctx* ctx, int32_t descriptor_index, int32_t v
  * successor lists without repeats; SF_ERR_UNSUPPORTED otherwise.  One such leaf per union. */
 int32_t sf_selector_add_precedence(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index);
 
+/* The precedence policy of the compiled runtime list slot (ListVariableSlot::with_precedence_hooks; RuntimeListSlot::precedence_policy):
+ * with the slot's successors declared, every runtime list leaf -- change, swap, nearby change / swap, sublist change / swap, reverse,
+ * permute -- opens its cursor `with_precedence_route_graph` (list_leaf/cursor/slot.rs:191-404) and drops INTRA-list candidates whose new
+ * route edges close a cycle (precedence_route.rs:171-255,313-317,419-451; the 3-opt cursor is not filtered), and the ruin leaf recreates
+ * with the hooks (ruin_access.rs:195-217, move/list_kernel/ruin.rs:186-220).  enabled = 0 (default) = the public selectors, which do not
+ * know the hooks.  Needs the precedence constraint on the list class (its fixed successors are the hooks); may be changed between
+ * launches.  The ruin leaf on a precedence model -- with or without the policy -- needs a list class without distance / capacity /
+ * not-exists constraints. */
+int32_t sf_list_set_precedence_policy(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t enabled);
+
 /* Nearby scalar leaves of a scalar slot (NearbyChangeMoveSelector / NearbySwapMoveSelector; the default policy declares them with
  * max_nearby 10 between the list rules and the ordinary change / swap pair, default_local_search/policy/scalar.rs:18-65).  The
  * slot's hooks arrive as data: offsets[n_rows + 1] / candidates = the nearby source row of every entity in SOURCE order --

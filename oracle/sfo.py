@@ -88,6 +88,7 @@ def lib():
             "sfo_model_configure": (None, [vp, i32, i32, i32, i32, i32, i32, u32, i32, i32, u64, i32]),
             "sfo_model_set_kopt": (None, [vp, i32, i32]),
             "sfo_model_set_permute": (None, [vp, i32, i32]),
+            "sfo_model_set_precedence_policy": (None, [vp, i32]),
             "sfo_model_evaluate_each": (i32, [vp, vp, vp, i32]),
             "sfo_model_configure_annealing": (None, [vp, i32, vp, i32, i32, dbl, dbl, i32, i32, dbl, dbl, u64]),
             "sfo_model_configure_diversified": (None, [vp, i32, dbl]),
@@ -322,6 +323,11 @@ class Model:
 
     def set_sublist_sizes(self, min_size, max_size):
         lib().sfo_model_set_sublist_sizes(self.h, min_size, max_size)
+
+    def set_precedence_policy(self, on=True):
+        """The list slot declares its precedence hooks to every runtime list leaf (list_leaf/cursor/slot.rs:191-404): intra-list candidates
+        that close a cycle through the route graph are dropped, ruins recreate with the hooks."""
+        lib().sfo_model_set_precedence_policy(self.h, int(bool(on)))
 
     def set_permute(self, min_window_size=2, max_window_size=5):
         lib().sfo_model_set_permute(self.h, min_window_size, max_window_size)

@@ -32,7 +32,7 @@ static void to_wire(const Move& m, sfo_move_t* w) {
         w->b = (int32_t)((uint32_t)m.ruin_idx[0] | ((uint32_t)m.ruin_idx[1] << 16));
         w->b_pos = (int32_t)((uint32_t)m.ruin_idx[2] | ((uint32_t)m.ruin_idx[3] << 16));
         w->value = (int32_t)((uint32_t)m.ruin_idx[4] | ((uint32_t)m.ruin_idx[5] << 16));
-        if (m.prec) {  // ruins of the critical-path leaf (<= 5 elements): bit 31 = precedence hooks, bit 30 = two source lists, the second in bits 16..29
+        if (m.prec && m.a_pos <= 5) {  // the move carries precedence hooks (critical-path leaf, or a ruin leaf of a slot with the policy; <= 5 elements): bit 31 = precedence hooks, bit 30 = two source lists, the second in bits 16..29
             uint32_t flags = 0x8000u;
             if (m.ruin_multi) flags |= 0x4000u | (uint32_t)m.ruin_src[m.a_pos - 1];
             w->value = (int32_t)((uint32_t)m.ruin_idx[4] | (flags << 16));
@@ -70,11 +70,12 @@ static Move from_wire(const Model& model, const sfo_move_t& w) {
         m.b_pos = 0;
         m.to_value = NONE;
         m.allows_unassigned = model.ruin_skip_empty;
-        if ((uint32_t)w.value & 0x80000000u) {  // a ruin of the critical-path leaf
+        if (model.list_slot.precedence_policy) m.prec = model.list_slot.precedence.get();  // the slot's ruin leaf recreates with the hooks
+        if (m.a_pos <= 5 && ((uint32_t)w.value & 0x80000000u)) {  // a ruin that says so itself (critical-path leaf: no skip_empty)
             const uint32_t flags = (uint32_t)w.value >> 16;
             m.ruin_idx[5] = 0;
             m.prec = model.list_slot.precedence.get();
-            m.allows_unassigned = false;
+            if (!model.list_slot.precedence_policy || (flags & 0x4000u)) m.allows_unassigned = false;
             for (size_t i = 0; i < 8; ++i) m.ruin_src[i] = (uint16_t)m.a;
             if (flags & 0x4000u) {
                 m.ruin_multi = true;
@@ -334,6 +335,8 @@ void sfo_model_set_permute(void* h, int32_t min_window_size, int32_t max_window_
     ((Model*)h)->permute_min = (size_t)min_window_size;
     ((Model*)h)->permute_max = (size_t)max_window_size;
 }
+// the list slot declares its precedence hooks to the compiled runtime leaves (route-graph filter of intra-list candidates, ruins with hooks)
+void sfo_model_set_precedence_policy(void* h, int32_t on) { ((Model*)h)->list_slot.precedence_policy = on != 0; }
 void sfo_model_set_kopt(void* h, int32_t min_segment_len, int32_t max_nearby) {  // max_nearby 0 = full enumeration
     Model* m = (Model*)h;
     m->kopt_min_seg = (size_t)min_segment_len;

@@ -111,6 +111,13 @@ struct Model {
     }
 
     std::unique_ptr<Cursor> open_leaf(uint32_t leaf, const ScoreDirector& d, const MoveStreamContext& ctx) const {
+        constexpr uint32_t FILTERED = LEAF_LIST_CHANGE | LEAF_LIST_SWAP | LEAF_NEARBY_LIST_CHANGE | LEAF_NEARBY_LIST_SWAP | LEAF_LIST_REVERSE |
+                                      LEAF_SUBLIST_CHANGE | LEAF_SUBLIST_SWAP | LEAF_LIST_PERMUTE;
+        if ((leaf & FILTERED) && list_slot.precedence_policy && list_slot.precedence)
+            return std::make_unique<RouteGraphFilterCursor>(open_plain_leaf(leaf, d, ctx), list_slot, d.working);
+        return open_plain_leaf(leaf, d, ctx);
+    }
+    std::unique_ptr<Cursor> open_plain_leaf(uint32_t leaf, const ScoreDirector& d, const MoveStreamContext& ctx) const {
         switch (leaf) {
             case LEAF_SCALAR_CHANGE:
                 return std::make_unique<ScalarChangeCursor>(scalar_slot, d.working, ctx);

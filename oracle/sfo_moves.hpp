@@ -966,6 +966,10 @@ struct ListSlot {
     // PrecedencePolicy::Explicit of the slot (successors + durations): what the critical-path leaf analyses and what its ruins
     // carry into the recreate; null = the slot declares no precedence hooks
     std::shared_ptr<PrecedenceHooks> precedence;
+    // the compiled runtime slot's precedence policy (list_leaf/cursor/slot.rs:191-404, ruin_access.rs:195-217): with hooks declared, every
+    // list cursor of the slot drops intra-list candidates that close a cycle through the route graph and the ruin leaf recreates with
+    // the hooks.  false = the public selectors, which know nothing of the hooks (only ListPrecedenceMoveSelector takes them).
+    bool precedence_policy = false;
     DistanceMeter meter;  // CrossEntityDistanceMeter (selector/nearby_list_change.rs:22-31)
     // Entity order profile.  The compiled runtime leaf orders entities WITHOUT replacement
     // (list_leaf/cursor/slot.rs:468-499); the public selectors re-index WITH replacement
@@ -2201,6 +2205,7 @@ struct RuinCursor : Cursor {
     std::vector<std::pair<size_t, size_t>> pool;  // (entity, list_len)
     size_t remaining_moves, min_ruin_count, max_ruin_count;
     bool skip_empty_destinations;
+    const PrecedenceHooks* hooks = nullptr;  // runtime slot with precedence successors: the moves recreate with them (ruin_access.rs:195-217)
     RuinCursor(const ListSlot& slot, const Solution& s, uint64_t seed, size_t moves_per_step, size_t min_count, size_t max_count,
                size_t max_source_list_len, bool skip_empty)
         : descriptor(slot.descriptor_index),
@@ -2208,7 +2213,8 @@ struct RuinCursor : Cursor {
           remaining_moves(moves_per_step),
           min_ruin_count(min_count),
           max_ruin_count(max_count),
-          skip_empty_destinations(skip_empty) {
+          skip_empty_destinations(skip_empty),
+          hooks(slot.precedence_policy ? slot.precedence.get() : nullptr) {
         const EntityClass& c = s.classes[descriptor];
         for (size_t e = 0; e < c.n; ++e) {
             size_t len = c.lists[e].size();
@@ -2233,10 +2239,49 @@ struct RuinCursor : Cursor {
         m.b = entity;
         m.a_pos = ruin_count;
         m.allows_unassigned = skip_empty_destinations;
+        m.prec = hooks;
         for (size_t i = 0; i < ruin_count && i < 8; ++i) m.ruin_idx[i] = (uint16_t)indices[i];
         out = m;
         return true;
     }
+};
+
+
+// The route-graph filter of a runtime list cursor (with_precedence_route_graph: list_kernel/change.rs:174-183, swap.rs:188-197,
+// nearby_change.rs:144-153, nearby_swap.rs:147-156, reverse.rs:98-102, sublist_change.rs:207-216, sublist_swap.rs:288-300,
+// permute.rs:128-137): an INTRA-list candidate whose added route edges close a cycle is skipped before it is emitted; the cursor's
+// own state does not depend on the verdict, so filtering its output is the same stream.  The graph is the one of the cursor open.
+struct RouteGraphFilterCursor : Cursor {
+    std::unique_ptr<Cursor> inner;
+    PrecedenceRouteGraph graph;
+    RouteGraphFilterCursor(std::unique_ptr<Cursor> c, const ListSlot& slot, const Solution& s)
+        : inner(std::move(c)), graph(PrecedenceRouteGraph::build(*slot.precedence, s.classes[slot.descriptor_index].lists)) {}
+    bool closes_cycle(const Move& m) const {
+        if (m.a != m.b && m.kind != Move::ListReverse && m.kind != Move::ListPermute) return false;
+        switch (m.kind) {
+            case Move::ListChange:
+                return graph.intra_list_change_introduces_cycle(m.a, m.a_pos, m.b_pos);
+            case Move::ListSwap:
+                return graph.intra_list_swap_introduces_cycle(m.a, m.a_pos, m.b_pos);
+            case Move::ListReverse:
+                return graph.intra_list_reverse_introduces_cycle(m.a, m.a_pos, m.b_pos);
+            case Move::SublistChange:
+                return graph.intra_sublist_change_introduces_cycle(m.a, m.a_pos, (size_t)m.to_value, m.b_pos);
+            case Move::SublistSwap:
+                return graph.intra_sublist_swap_introduces_cycle(m.a, m.a_pos, m.a_pos + (size_t)(m.to_value & 0xFFFF), m.b_pos,
+                                                                 m.b_pos + (size_t)(m.to_value >> 16));
+            case Move::ListPermute:
+                return graph.intra_list_permutation_introduces_cycle(m.a, m.a_pos, nth_permutation(m.b_pos - m.a_pos, (size_t)m.to_value));
+            default:
+                return false;
+        }
+    }
+    bool next(Move& out) override {
+        while (inner->next(out))
+            if (!closes_cycle(out)) return true;
+        return false;
+    }
+    size_t last_selector() const override { return inner->last_selector(); }
 };
 
 struct UnionCursor : Cursor {

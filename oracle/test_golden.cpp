@@ -1496,6 +1496,28 @@ static void list_precedence_selector_cases() {
         for (auto& m : mv) any = any || (m.kind == Move::ListChange && m.a == 0 && m.a_pos == 0 && m.b_pos == 2);
         CHECK("list_precedence_selector.emits_singleton_critical_node_relocations", mv.size() == size_of(f) && any);
     }
+    {  // heuristic/selector/tests/list_ruin.rs:279-303 (precedence_ruin_recreate_skips_cycle_forming_insertions): elements 0, 1, 2 for the
+       // reference's 1, 2, 3 (index_to_element = identity here), fixed successor 0 -> 1, no constraint (every insertion scores the same):
+       // the ruined middle element may not go in front of its predecessor, so the first acyclic position puts it back
+        Fixture f = mk({{1, 1}, {1, -1}, {1, -1}}, {{0, 1, 2}});
+        ScoreDirector d;
+        d.working = f.s;
+        Move m;
+        m.kind = Move::Ruin;
+        m.a = m.b = 0;
+        m.a_pos = 1;
+        m.ruin_idx[0] = 1;
+        m.prec = f.slot.precedence.get();
+        MoveUndo ignored = move_do(d, m);
+        (void)ignored;
+        bool with_hooks = d.working.classes[0].lists[0] == std::vector<uint32_t>{0, 1, 2};
+        ScoreDirector d2;
+        d2.working = f.s;
+        m.prec = nullptr;  // without the hooks the first position wins
+        MoveUndo ignored2 = move_do(d2, m);
+        (void)ignored2;
+        CHECK("list_ruin.precedence_ruin_recreate_skips_cycle_forming_insertions", with_hooks && d2.working.classes[0].lists[0] == std::vector<uint32_t>{1, 0, 2});
+    }
     {  // :613-623
         Fixture f = mk({{1, 1}, {1, -1}}, {{1, 0}});
         CHECK("list_precedence_selector.skips_cyclic_current_graph", size_of(f) == 0 && stream(f).empty());

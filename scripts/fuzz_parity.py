@@ -117,13 +117,17 @@ def run_case(seed):
                         seqs[int(rng.integers(nm))].append(x)
             p["sequences"] = seqs
         with_owner = bool(rng.random() < 0.7)
-        pool = ["precedence", "permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"]  # critical-path leaf: round 3
+        pool = ["precedence", "permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt", "ruin"]  # critical-path leaf, ruin: round 3
         chosen = set(rng.choice(pool, size=int(rng.integers(1, 8)), replace=False).tolist())
         leaves = tuple(x for x in pool if x in chosen)
-        desc.update(nj=nj, nm=nm, leaves=leaves, with_owner=with_owner)
-        d = sfa.build_precedence_shop(p, leaves=leaves, with_owner=with_owner)
+        policy = bool(rng.random() < 0.5)  # the runtime slot's precedence policy: route-graph filter + ruin hooks
+        ruin = (int(rng.choice([1, 2])), int(rng.choice([2, 5, 6])), int(rng.choice([1, 3, 6])))
+        desc.update(nj=nj, nm=nm, leaves=leaves, with_owner=with_owner, policy=policy, ruin=ruin)
+        d = sfa.build_precedence_shop(p, leaves=leaves, with_owner=with_owner, ruin=ruin, precedence_policy=policy)
         o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"] if with_owner else None)
         o.set_kopt(1, 0)
+        o.set_precedence_policy(policy)
+        post_configure = lambda: o.set_ruin(*ruin)
         lists = lambda: (d.working_lists(0, 0), o.get_lists(0))
     elif model == "shift":  # consecutive-runs collector + complemented / plain grouped count (examples/minimal-shift-scheduling)
         nn = int(rng.integers(2, 10)); nd = int(rng.integers(3, 40)); per = int(rng.integers(1, 4))
@@ -182,7 +186,7 @@ def run_case(seed):
                 selection_order=order, random_seed=seed, max_nearby=desc.get("max_nearby", 20), union_order=union_order)
     if union_weights:
         o.set_union_weights(union_weights)
-    if model == "cvrp":
+    if model in ("cvrp", "precedence"):
         post_configure()
     d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=la, forager=forager, accepted_count_limit=limit,
                                  selection_order=order, random_seed=seed))

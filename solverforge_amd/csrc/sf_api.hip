@@ -90,6 +90,7 @@ struct sf_ctx {
     int nearby_scalar_dynamic = 0;
     PrecSpec prec;          // ListPrecedenceMakespanConstraint on the list class (sf_precedence.h)
     PrecModel pm{};
+    bool prec_policy = false;  // sf_list_set_precedence_policy
     PlfModel plf{};  // critical-path precedence leaf: per-replica tables (allocated at the first launch that has the leaf)
     NbrIndex nbr{nullptr};  // presorted neighbour index (wave engine)
     bool lm_small = false;  // every trial delta of the list model fits 32-bit arithmetic (wave engine MODE 2)
@@ -548,6 +549,15 @@ int32_t sf_selector_add_precedence(sf_ctx* ctx, int32_t d, int32_t var) {
     return SF_OK;
 }
 
+// The compiled runtime slot's precedence policy (list_leaf/cursor/slot.rs:191-404, ruin_access.rs:195-217): the list slot declares its
+// precedence successors to EVERY list leaf, not only to the critical-path one
+int32_t sf_list_set_precedence_policy(sf_ctx* ctx, int32_t d, int32_t var, int32_t enabled) {
+    if (!ctx) return SF_ERR_INVALID;
+    (void)d, (void)var;
+    ctx->prec_policy = enabled != 0;
+    return SF_OK;
+}
+
 int32_t sf_selector_add_sublist(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int32_t min_size, int32_t max_size) {
     if (!ctx) return SF_ERR_INVALID;
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "selectors are frozen after sf_initialize");
@@ -758,8 +768,9 @@ static int build_list_model(sf_ctx* ctx, int d) {
             if (seen[x]) return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence: an element appears in more than one list position");
             seen[x] = 1;
         }
-        for (auto& sel : ctx->selectors)
-            if (sel.kind == SF_SEL_LIST_RUIN) return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin leaf on a model with precedence hooks");
+        for (auto& sel : ctx->selectors)  // its recreate is scored by the precedence constraint alone (plf_ruin)
+            if (sel.kind == SF_SEL_LIST_RUIN && (m.dist_level >= 0 || m.cap_level >= 0 || m.ne_level >= 0))
+                return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin leaf on a precedence model with distance / capacity / not-exists constraints");
         PrecModel& pm = ctx->pm;
         pm.on = 1;
         pm.hard_level = ps.hard_level;
@@ -1964,6 +1975,45 @@ static bool has_plain_list_leaves(sf_ctx* ctx) {
             return true;
     return false;
 }
+// per-replica tables of the critical-path leaf / the route-graph filter / the precedence-aware recreate (sf_prec_leaf.h)
+static int ensure_plf(sf_ctx* ctx) {
+    if (ctx->plf.on) return SF_OK;
+    const PrecSpec& ps = ctx->prec;
+    const size_t n = ps.dur.size();
+    std::vector<int32_t> deg(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        std::vector<uint32_t> seen;
+        for (uint32_t t = ps.succ_off[i]; t < ps.succ_off[i + 1]; ++t) {
+            const uint32_t to = ps.succ[t];
+            if (to >= n) continue;
+            if (std::find(seen.begin(), seen.end(), to) != seen.end())
+                return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf: a node names one fixed successor twice");
+            seen.push_back(to);
+            deg[i] += 1, deg[to] += 1;
+        }
+    }
+    PlfModel& pl = ctx->plf;
+    pl.dmax = 0;
+    for (int32_t dv : deg) pl.dmax = std::max(pl.dmax, dv);
+    const size_t R = (size_t)ctx->R, nn = std::max<size_t>(n, 1), nc = (size_t)std::max(ctx->lm.n_cap, 1);
+    int rc = dalloc(ctx, &pl.latest, R * nn);
+    if (!rc) rc = dalloc(ctx, &pl.posn, R * nn);
+    if (!rc) rc = dalloc(ctx, &pl.flag, R * nc);
+    if (!rc) rc = dalloc(ctx, &pl.roff, R * (nn + 2));
+    if (!rc) rc = dalloc(ctx, &pl.blk, R * nn * 2);
+    if (!rc) rc = dalloc(ctx, &pl.csw, R * nn);
+    if (!rc) rc = dalloc(ctx, &pl.ssw, R * nn);
+    if (!rc) rc = dalloc(ctx, &pl.first, R * nc);
+    if (!rc) rc = dalloc(ctx, &pl.cnl, R * nn);
+    if (!rc) rc = dalloc(ctx, &pl.msrow, R * (nn + 1));
+    if (!rc) rc = dalloc(ctx, &pl.mrrow, R * (nn + 1));
+    if (!rc) rc = dalloc(ctx, &pl.sE, R * (size_t)std::max(ctx->lm.V, 1));
+    if (!rc) rc = dalloc(ctx, &pl.score, R * GRC * 4);
+    if (!rc) rc = dalloc(ctx, &pl.visit, R * nn);
+    if (rc) return rc;
+    pl.on = 1;
+    return SF_OK;
+}
 static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     GLeaves gl{};
     gl.list_desc = ctx->has_list_model ? ctx->list_desc : 0;
@@ -2027,42 +2077,9 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                 // its ruins recreate by the precedence constraint alone: no other list constraint may score an insertion
                 if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0 || ctx->lm.ne_level >= 0)
                     return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf on a list class with distance / capacity / not-exists constraints");
-                if (!ctx->plf.on) {
-                    const PrecSpec& ps = ctx->prec;
-                    const size_t n = ps.dur.size();
-                    std::vector<int32_t> deg(n, 0);
-                    for (size_t i = 0; i < n; ++i) {
-                        std::vector<uint32_t> seen;
-                        for (uint32_t t = ps.succ_off[i]; t < ps.succ_off[i + 1]; ++t) {
-                            const uint32_t to = ps.succ[t];
-                            if (to >= n) continue;
-                            if (std::find(seen.begin(), seen.end(), to) != seen.end())
-                                return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf: a node names one fixed successor twice");
-                            seen.push_back(to);
-                            deg[i] += 1, deg[to] += 1;
-                        }
-                    }
-                    PlfModel& pl = ctx->plf;
-                    pl.dmax = 0;
-                    for (int32_t dv : deg) pl.dmax = std::max(pl.dmax, dv);
-                    const size_t R = (size_t)ctx->R, nn = std::max<size_t>(n, 1), nc = (size_t)std::max(ctx->lm.n_cap, 1);
-                    int rc = dalloc(ctx, &pl.latest, R * nn);
-                    if (!rc) rc = dalloc(ctx, &pl.posn, R * nn);
-                    if (!rc) rc = dalloc(ctx, &pl.flag, R * nc);
-                    if (!rc) rc = dalloc(ctx, &pl.roff, R * (nn + 2));
-                    if (!rc) rc = dalloc(ctx, &pl.blk, R * nn * 2);
-                    if (!rc) rc = dalloc(ctx, &pl.csw, R * nn);
-                    if (!rc) rc = dalloc(ctx, &pl.ssw, R * nn);
-                    if (!rc) rc = dalloc(ctx, &pl.first, R * nc);
-                    if (!rc) rc = dalloc(ctx, &pl.cnl, R * nn);
-                    if (!rc) rc = dalloc(ctx, &pl.msrow, R * (nn + 1));
-                    if (!rc) rc = dalloc(ctx, &pl.mrrow, R * (nn + 1));
-                    if (!rc) rc = dalloc(ctx, &pl.sE, R * (size_t)std::max(ctx->lm.V, 1));
-                    if (!rc) rc = dalloc(ctx, &pl.score, R * GRC * 4);
-                    if (rc) return rc;
-                    pl.on = 1;
-                }
+                if (int rc = ensure_plf(ctx)) return rc;
                 gl.plf = ctx->plf;
+                gl.plf.leaf = 1;
             }
             if (kind == SF_SEL_LIST_RUIN) {
                 if (gl.has_ruin) return fail(ctx, SF_ERR_UNSUPPORTED, "one list ruin leaf per union");
@@ -2075,6 +2092,13 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             gl.kind[gl.n++] = kind;
         }
     if (gl.n == 0) return fail(ctx, SF_ERR_INVALID, "no selector configured");
+    if (ctx->has_list_model && ctx->pm.on && (ctx->prec_policy || gl.has_ruin)) {  // route-graph filter / recreate scored by the precedence constraint
+        if (int rc = ensure_plf(ctx)) return rc;
+        const int leaf = gl.plf.leaf;
+        gl.plf = ctx->plf;
+        gl.plf.leaf = leaf;
+        gl.plf.policy = ctx->prec_policy ? 1 : 0;
+    }
     if (!ctx->d_mixed_ring) {
         int rc = dalloc(ctx, &ctx->d_mixed_ring, (size_t)ctx->R * GL * GRC * 2);
         if (!rc) rc = dalloc(ctx, &ctx->d_mixed_ringx, (size_t)ctx->R * GL * GRC);
@@ -2110,6 +2134,11 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             if (rc) return rc;
             gl.prec.elane = ctx->pm.elane;
         }
+    }
+    if (gl.prec.on && gl.has_ruin) {  // ruin leaf on a precedence model (i16 values)
+        if (ctx->levels <= 2)
+            return launch_mixed_t<2, int16_t, true, true>(ctx, p, gl, grid, trace);
+        return launch_mixed_t<4, int16_t, true, true>(ctx, p, gl, grid, trace);
     }
     if (gl.prec.on) {  // ListPrecedenceMakespanConstraint: its own instantiations
         if (ctx->has_scalar_model && ctx->sm.n_values <= 127 && ctx->sm.n >= 1024) {  // one-byte value array (C4: 4 waves per CU instead of 3)

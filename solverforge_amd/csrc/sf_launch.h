@@ -52,6 +52,8 @@ SF_TU_DECL_MIXED(2, 1, false, true)
 SF_TU_DECL_MIXED(4, 1, false, true)
 SF_TU_DECL_MIXED(2, 2, false, true)
 SF_TU_DECL_MIXED(4, 2, false, true)
+SF_TU_DECL_MIXED(2, 2, true, true)
+SF_TU_DECL_MIXED(4, 2, true, true)
 #undef SF_TU_DECL_MIXED
 template <>
 hipError_t launch_tu_scalar<2, 1>(bool trace, const SearchLaunch& a);

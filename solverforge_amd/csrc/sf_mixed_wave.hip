@@ -508,6 +508,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     }
     // ---- critical-path precedence leaf (kind 16384): per-replica tables, one full evaluation with the cycle flag ----
     const bool plf_on = PREC && gl.plf.on != 0;
+    const bool plf_policy = plf_on && gl.plf.policy != 0;  // runtime slot with precedence hooks: route-graph filter + ruins with hooks
+    bool plf_cur_cyclic = false;                           // the working lists of this step are cyclic
     PlfRep plf{};
     __shared__ uint32_t s_plf_info[4][4];
     uint32_t* const plf_info = s_plf_info[threadIdx.x >> 6];
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         plf.latest = gl.plf.latest + (size_t)r * pn, plf.posn = gl.plf.posn + (size_t)r * pn, plf.flag = gl.plf.flag + (size_t)r * pc;
         plf.roff = gl.plf.roff + (size_t)r * (pn + 2), plf.blk = gl.plf.blk + (size_t)r * pn * 2, plf.csw = gl.plf.csw + (size_t)r * pn;
         plf.ssw = gl.plf.ssw + (size_t)r * pn, plf.first = gl.plf.first + (size_t)r * pc, plf.cnl = gl.plf.cnl + (size_t)r * pn;
-        plf.msrow = gl.plf.msrow + (size_t)r * (pn + 1), plf.mrrow = gl.plf.mrrow + (size_t)r * (pn + 1), plf.sE = gl.plf.sE + (size_t)r * V;
+        plf.msrow = gl.plf.msrow + (size_t)r * (pn + 1), plf.mrrow = gl.plf.mrrow + (size_t)r * (pn + 1), plf.sE = gl.plf.sE + (size_t)r * V, plf.visit = gl.plf.visit + (size_t)r * pn;
     }
     // full evaluation of the lists in LDS that also reports the cycle flag (and, with `roff`, Kahn's rounds)
     auto plf_eval = [&](bool& cyclic, uint32_t* roff) -> PrecResult {
@@ -552,14 +554,14 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     // one per round at the best-scoring insertion over every (element, list, position) that does not close a cycle, the first of
     // equal scores staying.  One element slides through every position with an adjacent exchange (or a list boundary shift) per
     // step, one full evaluation each.
-    auto plf_ruin = [&](const PlfMove& m, bool keep) -> ScoreV<L> {
-        uint32_t vals[PLF_RUIN_MAX];
+    auto plf_ruin = [&](const PlfMove& m, bool keep, bool hooks, bool skip_empty) -> ScoreV<L> {
+        uint32_t vals[PLF_EL_MAX];
 #pragma unroll
-        for (uint32_t k = 0; k < PLF_RUIN_MAX; ++k) vals[k] = 0;
+        for (uint32_t k = 0; k < PLF_EL_MAX; ++k) vals[k] = 0;
         for (uint32_t k = m.n; k-- > 0;) {
             const uint32_t x = plf_list_remove(s_visits, s_off, V, m.el[k] >> 16, m.el[k] & 0xFFFFu);
 #pragma unroll
-            for (uint32_t q = 0; q < PLF_RUIN_MAX; ++q)
+            for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
                 if (q == k) vals[q] = x;
         }
         uint32_t remaining = (1u << m.n) - 1u;
@@ -575,21 +577,23 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 if (!((remaining >> ri) & 1u)) continue;
                 uint32_t x = 0;
 #pragma unroll
-                for (uint32_t q = 0; q < PLF_RUIN_MAX; ++q)
+                for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
                     if (q == ri) x = vals[q];
                 plf_list_insert(s_visits, s_off, V, 0, 0, x);
                 uint32_t e = 0, pos = 0, g = 0;
                 for (;;) {
-                    bool cyc;
-                    const PrecResult pr = plf_eval(cyc, nullptr);
-                    if (!cyc) {
-                        const ScoreV<L> sc = plf_score_of(pr);
-                        if (!have || score_cmp<L>(sc, best_sc) > 0) {
-                            have = true;
-                            best_sc = sc, b_ri = ri, b_e = e, b_pos = pos;
+                    const uint32_t others = uni(s_off[e + 1] - s_off[e]) - 1u;  // list e without the sliding element
+                    if (!(skip_empty && others == 0u)) {  // skip_empty_destinations (ruin.rs:181-183)
+                        bool cyc;
+                        const PrecResult pr = plf_eval(cyc, nullptr);
+                        if (!(cyc && hooks)) {  // with the hooks an insertion that closes a cycle is not tried (ruin.rs:186-220)
+                            const ScoreV<L> sc = plf_score_of(pr);
+                            if (!have || score_cmp<L>(sc, best_sc) > 0) {
+                                have = true;
+                                best_sc = sc, b_ri = ri, b_e = e, b_pos = pos;
+                            }
                         }
                     }
-                    const uint32_t others = uni(s_off[e + 1] - s_off[e]) - 1u;  // list e without the sliding element
                     if (pos < others) {
                         if (lane == 0) {
                             const uint16_t y = s_visits[g + 1];
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             }
             uint32_t bx = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < PLF_RUIN_MAX; ++q)
+            for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
                 if (q == b_ri) bx = vals[q];
             plf_list_insert(s_visits, s_off, V, b_e, b_pos, bx);
             remaining &= ~(1u << b_ri);
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     };
     auto plf_trial = [&](const PlfMove& m, ScoreV<L>& sc) -> bool {
         if (m.kind == 8) {
-            sc = plf_ruin(m, false);
+            sc = plf_ruin(m, false, true, false);
             return true;
         }
         plf_apply(m);
@@ -657,6 +661,47 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             wave_sync();
         }
         return !cyc;
+    };
+    // ordinary ruin leaf on a precedence model: its candidate record (list, count, positions) as a PlfMove
+    auto plf_from_ruin_cand = [&](const uint16_t* cd, PlfMove& m) {
+        m.kind = 8;
+        m.a = m.b = uni((uint32_t)cd[0]);
+        m.n = uni((uint32_t)cd[1]);
+        m.ap = m.n, m.bp = 0, m.ext = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < PLF_EL_MAX; ++k) m.el[k] = (m.a << 16) | uni((uint32_t)cd[2 + k]);
+    };
+    // Route-graph filter of a runtime list leaf (with_precedence_route_graph, precedence_route.rs:313-317,419-451): does the intra-list
+    // candidate just applied to list e close a cycle through a NEW route edge?  After an acyclic working state that is "the lists are
+    // cyclic now"; after a cyclic one, every new edge (u, v) -- in the route now, not in the committed route, not a fixed edge -- is
+    // tested for v reaching u over the graph of the lists as they are now (plf_reaches).  `cyc` = the cycle flag of the evaluation
+    // that just ran on the applied state (its list successors are still in the scratch).
+    auto plf_closes_cycle = [&](uint32_t e, bool cyc) -> bool {
+        if (!cyc) return false;
+        if (!plf_cur_cyclic) return true;
+        const uint32_t lo = uni(s_off[e]), hi = uni(s_off[e + 1]);
+        bool closes = false;
+        for (uint32_t p0 = lo; p0 + 1 < hi && !closes; p0 += 64) {
+            const uint32_t p = p0 + lane;
+            bool fresh = false;
+            uint32_t u = 0, v = 0;
+            if (p + 1 < hi) {
+                u = s_visits[p], v = s_visits[p + 1];
+                const uint32_t w = plf.posn[u];  // u's committed position (in list e: the move is intra-list)
+                const uint32_t old_next = (w & 0xFFFFu) + 1u < g_off[e + 1] - g_off[e] ? g_visits[g_off[e] + (w & 0xFFFFu) + 1u] : PREC_NONE;
+                fresh = old_next != v;
+                for (uint32_t k = gl.prec.succ_off[u]; fresh && k < gl.prec.succ_off[u + 1]; ++k) fresh = gl.prec.succ[k] != v;
+            }
+            uint64_t fm = __ballot(fresh);
+            while (fm && !closes) {
+                const int ci = __ffsll((unsigned long long)fm) - 1;
+                fm &= fm - 1;
+                const uint32_t uu = (uint32_t)__builtin_amdgcn_readlane((int)u, ci), vv = (uint32_t)__builtin_amdgcn_readlane((int)v, ci);
+                closes = prec_in_lds ? plf_reaches<PrecMemLds>(gl.prec, plf.visit, plf.cnl, (prec_lds_u32*)prec_S, vv, uu)
+                                     : plf_reaches<PrecMemGlobal>(gl.prec, plf.visit, plf.cnl, prec_S, vv, uu);
+            }
+        }
+        return closes;
     };
     // ring entry (stage << 30 | block, index inside the stage) -> move
     auto plf_decode = [&](uint32_t w0, uint32_t w1, PlfMove& m) {
@@ -846,6 +891,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         if (plf_on) {  // critical-path leaf: the committed evaluation again (the trials overwrote its arrays), then the step's analysis
             bool cyc;
             const PrecResult pr = plf_eval(cyc, plf.roff);
+            plf_cur_cyclic = cyc;
             const uint32_t rounds = uni(plf_info[2]);
             if (prec_in_lds)
                 plf_analyse<PrecMemLds>(gl.prec, gl.plf, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u32*)prec_Q, (prec_lds_u32*)prec_S, rounds,
@@ -1531,11 +1577,21 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         }
                         if (g.a == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);  // first candidate of the step
                         ruin_next_candidate(gl.ruin, rl, s_off, V, g.e, g.a, lane);
-                        int64_t base_score[L];
+                        if (PREC) {  // precedence model: the recreate is scored by the precedence constraint (with the slot's hooks when declared)
+                            PlfMove pm_;
+                            plf_from_ruin_cand(rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, pm_);
+                            const ScoreV<L> psc = plf_ruin(pm_, false, plf_policy, gl.ruin.skip_empty != 0);
+                            if (lane == 0) {
 #pragma unroll
-                        for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
-                        ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, rl.work, ruin_sbase, rfast,
-                                         gl.ruin.skip_empty, false, base_score, rl.score + (size_t)g.a * 4);
+                                for (int kk = 0; kk < L; ++kk) rl.score[(size_t)g.a * 4 + kk] = psc.v[kk];
+                            }
+                        } else {
+                            int64_t base_score[L];
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
+                            ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, rl.work, ruin_sbase, rfast,
+                                             gl.ruin.skip_empty, false, base_score, rl.score + (size_t)g.a * 4);
+                        }
                         wave_sync();
                         keep = lane == 0;
                         w0 = g.a;
@@ -1669,6 +1725,30 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                 g.b += 1;
                                 g.e = 0;
                             }
+                        }
+                    }
+                    if (PREC && plf_policy && kind >= 4 && kind != 512 && kind != 1024 && kind != 2048 && kind != 4096 && kind != 16384) {
+                        // runtime slot with precedence hooks: intra-list candidates that close a cycle through the route graph never reach the ring
+                        uint64_t chk = __ballot(keep && (kind == 64 || kind == 8192 || (w0 >> 16) == (w1 >> 16)));
+                        while (chk) {
+                            const int ci = __ffsll((unsigned long long)chk) - 1;
+                            chk &= chk - 1;
+                            const uint32_t ca = (uint32_t)__builtin_amdgcn_readlane((int)w0, ci), cb = (uint32_t)__builtin_amdgcn_readlane((int)w1, ci);
+                            const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)wx, ci);
+                            const uint32_t e = ca >> 16;
+                            if (kind == 8192)
+                                apply_list_move_wave(lm, s_visits, s_off, s_load, 9, e, ca & 0xFFFFu, e, (ca & 0xFFFFu) + (cb >> 16), cb & 0xFFFFu);
+                            else
+                                apply_list_move_wave(lm, s_visits, s_off, s_load, list_move_kind_of(kind), e, ca & 0xFFFFu, cb >> 16, cb & 0xFFFFu,
+                                                     list_move_ext_of(kind, ca, cb, cx));
+                            wave_sync();
+                            bool cyc;
+                            (void)plf_eval(cyc, nullptr);
+                            const bool drop = plf_closes_cycle(e, cyc);
+                            const uint32_t lo = uni(s_off[e]), hi = uni(s_off[e + 1]);
+                            for (uint32_t t = lo + lane; t < hi; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+                            wave_sync();
+                            if (drop && (int)lane == ci) keep = false;
                         }
                     }
                     const uint64_t km = __ballot(keep);
@@ -2078,6 +2158,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                             tm[3] = (int32_t)((uint32_t)cd[2] | ((uint32_t)cd[3] << 16));
                             tm[4] = (int32_t)((uint32_t)cd[4] | ((uint32_t)cd[5] << 16));
                             tm[5] = (int32_t)((uint32_t)cd[6] | ((uint32_t)cd[7] << 16));
+                            if (PREC && plf_policy && cd[1] <= 5) tm[5] |= (int32_t)0x80000000u;  // the move carries the slot's precedence hooks
                         } else if (my_kind == 8192) {  // (9, list, start, list, end, rank)
                             tm[0] = 9;
                             tm[1] = (int32_t)(m0 >> 16);
@@ -2171,7 +2252,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     plf_wire(pm_, p.trace_applied + 1);
                 }
                 if (pm_.kind == 8) {
-                    const ScoreV<L> ignored = plf_ruin(pm_, true);
+                    const ScoreV<L> ignored = plf_ruin(pm_, true, true, false);
                     (void)ignored;
                 } else
                     plf_apply(pm_);
@@ -2186,12 +2267,20 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     p.trace_applied[4] = (int32_t)((uint32_t)cd[2] | ((uint32_t)cd[3] << 16));
                     p.trace_applied[5] = (int32_t)((uint32_t)cd[4] | ((uint32_t)cd[5] << 16));
                     p.trace_applied[6] = (int32_t)((uint32_t)cd[6] | ((uint32_t)cd[7] << 16));
+                    if (PREC && plf_policy && cd[1] <= 5) p.trace_applied[6] |= (int32_t)0x80000000u;
                 }
-                int64_t base_score[L];
+                if (PREC) {
+                    PlfMove pm_;
+                    plf_from_ruin_cand(cd, pm_);
+                    const ScoreV<L> ignored = plf_ruin(pm_, true, plf_policy, gl.ruin.skip_empty != 0);
+                    (void)ignored;
+                } else {
+                    int64_t base_score[L];
 #pragma unroll
-                for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
-                ruin_recreate<L>(lm, s_visits, s_off, s_load, cd, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, true, base_score,
-                                 rl.score + (size_t)a * 4);
+                    for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
+                    ruin_recreate<L>(lm, s_visits, s_off, s_load, cd, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, true, base_score,
+                                     rl.score + (size_t)a * 4);
+                }
                 wave_sync();
                 if (has_nearby) {  // any list may have changed: rebuild node -> (route, position)
                     for (uint32_t v = lane; v < (uint32_t)V; v += 64) {

@@ -30,10 +30,14 @@ constexpr uint64_t SALT_PL_BLOCK = 0xC9171EAF5EED0001ULL, SALT_PL_MOVE = 0xC9171
 constexpr uint64_t SALT_PL_MULTI_RUIN = 0xC9171EAF5EED0003ULL, SALT_PL_MULTI_SWAP = 0xC9171EAF5EED0004ULL;
 constexpr uint64_t SALT_PL_ADJACENT = 0xAD1ACE1700000001ULL, SALT_PL_BOUNDARY = 0xAD1ACE1700000002ULL, SALT_PL_REST = 0xAD1ACE1700000003ULL;  // coordinates.rs:91-130
 constexpr uint32_t PLF_RUIN_MAX = 5, PLF_SUBLIST_MAX = 3, PLF_PERMUTE_MAX = 5;  // coordinates.rs:11-13
+constexpr uint32_t PLF_EL_MAX = 6;  // elements of one ruin move (the ordinary ruin leaf takes up to six, sf_ruin.h)
 
 // The leaf's scratch: per replica in HBM (L2-resident at the sizes the leaf is used at), carved on the host.
 struct PlfModel {
     int32_t on;
+    int32_t leaf;       // the union has the critical-path leaf (kind 16384): the blocks are analysed every step
+    int32_t policy;     // the slot declares its precedence hooks to the runtime leaves (list_leaf/cursor/slot.rs:191-404): the other list leaves
+                        // drop intra-list candidates that close a cycle through a new route edge, the ruin leaf recreates with the hooks
     int32_t dmax;       // max (fixed successors + fixed predecessors) of a node: spacing of the support-swap sequence numbers
     int32_t* latest;    // [R][n]
     uint32_t* posn;     // [R][n]      node -> (list << 16 | position), PREC_NONE = in no list
@@ -48,10 +52,11 @@ struct PlfModel {
     uint32_t* mrrow;    // [R][n + 1]  multi-ruin candidates before the rows of block i
     uint32_t* sE;       // [R][V]      support swaps per list
     int64_t* score;     // [R][GRC][4] trial scores of the ring entries
+    uint32_t* visit;    // [R][n]      visited marks of the reachability search (cyclic working state only)
 };
 struct PlfRep {  // one replica's slices + the counts of this step (wave-uniform)
     int32_t* latest;
-    uint32_t *posn, *flag, *roff, *blk, *csw, *ssw, *first, *cnl, *msrow, *mrrow, *sE;
+    uint32_t *posn, *flag, *roff, *blk, *csw, *ssw, *first, *cnl, *msrow, *mrrow, *sE, *visit;
     uint32_t nb, C, S, ms_count, mr_count;
 };
 
@@ -66,8 +71,26 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     t.nb = t.C = t.S = t.ms_count = t.mr_count = 0;
-    if (cyclic) return;
-    prec_sync();  // the rounds were written by lane 0 of the evaluation
+    const uint32_t total = plf_uni(off[V]);
+    // ---- node -> (list, position) of the committed lists (also what the route-graph filter of the other leaves reads) ----
+    for (uint32_t i = lane; i < n; i += 64) t.posn[i] = PREC_NONE;
+    prec_sync();
+    for (uint32_t p0 = 0; p0 < total; p0 += 64) {
+        const uint32_t p = p0 + lane;
+        if (p < total) {
+            uint32_t lo = 0, hi = (uint32_t)V;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (off[mid] <= p)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            t.posn[visits[p]] = (lo << 16) | (p - off[lo]);
+        }
+    }
+    prec_sync();
+    if (cyclic || !pl.leaf) return;
     // ---- latest starts: the rounds in reverse ----
     for (uint32_t rd = rounds; rd-- > 0;) {
         const uint32_t lo = plf_uni(t.roff[rd]), hi = plf_uni(t.roff[rd + 1]);
@@ -89,11 +112,9 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
         }
         prec_sync();
     }
-    // ---- node positions, critical flags per list position ----
-    for (uint32_t i = lane; i < n; i += 64) t.posn[i] = PREC_NONE;
+    // ---- critical flags per list position ----
     for (uint32_t v = lane; v < (uint32_t)V; v += 64) t.sE[v] = 0;
     prec_sync();
-    const uint32_t total = plf_uni(off[V]);
     for (uint32_t p0 = 0; p0 < total; p0 += 64) {
         const uint32_t p = p0 + lane;
         if (p < total) {
@@ -106,7 +127,6 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
                     hi = mid;
             }
             const uint32_t x = visits[p];
-            t.posn[x] = (lo << 16) | (p - off[lo]);
             const int32_t ex = MEM::ld(E + x);
             const bool cn = ex == t.latest[x];
             bool arc = false;
@@ -229,12 +249,61 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
     t.nb = nb, t.C = C, t.S = Sn, t.ms_count = ms_total, t.mr_count = mr_total;
 }
 
+// Does `from` reach `target` over (fixed successors + the list successors S of the lists just evaluated)?  One wavefront, breadth
+// first, 64 frontier nodes per round; visit / queue = n words each.  The slow half of the route-graph filter: only a cyclic working
+// state needs it (reaches_with_route_delta, precedence_route.rs:519-556, over the graph after the move).
+template <class MEM>
+__device__ __noinline__ bool plf_reaches(const PrecModel pm, uint32_t* visit, uint32_t* queue, typename MEM::U32 S, uint32_t from, uint32_t target) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = (uint32_t)pm.n;
+    for (uint32_t i = lane; i < n; i += 64) visit[i] = 0;
+    prec_sync();
+    if (lane == 0) {
+        __hip_atomic_store(visit + from, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(queue, from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    prec_sync();
+    uint32_t head = 0, tail = 1;
+    bool found = from == target;
+    while (head < tail && !found) {
+        const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
+        const bool act = lane < cnt;
+        uint32_t so = 0, deg = 0, ls = PREC_NONE;
+        if (act) {
+            const uint32_t w = plf_ald(queue + head + lane);
+            so = pm.succ_off[w];
+            deg = pm.succ_off[w + 1] - so;
+            ls = MEM::ld(S + w);
+        }
+        const uint32_t degt = deg + ((act && ls != PREC_NONE) ? 1u : 0u);
+        bool hit = false;
+        for (uint32_t k = 0;; ++k) {
+            const bool has = k < degt;
+            if (!__ballot(has)) break;
+            bool fresh = false;
+            uint32_t s = 0;
+            if (has) {
+                s = k < deg ? pm.succ[so + k] : ls;
+                hit = hit || s == target;
+                fresh = __hip_atomic_exchange(visit + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+            }
+            const uint64_t m = __ballot(fresh);
+            if (fresh) __hip_atomic_store(queue + tail + prec_mbcnt(m), s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail += (uint32_t)__popcll(m);
+        }
+        found = __ballot(hit) != 0;
+        head += cnt;
+        prec_sync();
+    }
+    return found;
+}
+
 // ---- decoding (wave-uniform arguments and results) ----
 struct PlfMove {
     int32_t kind;               // sf_move_kind: 2 change, 3 swap, 4 reverse, 5 sublist change, 6 sublist swap, 8 ruin, 9 permute, 10 multi-swap
     uint32_t a, ap, b, bp, ext;  // the arguments of apply_list_move_wave for the single-list kinds
     uint32_t n;                  // ruin: elements (list << 16 | position), sorted by (list, position); multi-swap: (list << 16 | first position)
-    uint32_t el[PLF_RUIN_MAX];
+    uint32_t el[PLF_EL_MAX];
 };
 
 // largest i in [0, rows) with prefix[i] <= idx (prefix exclusive, prefix[rows] = total > idx)

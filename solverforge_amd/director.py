@@ -228,6 +228,11 @@ class GpuScoreDirector:
         carries the precedence constraint: multi-swaps, multi-block ruins, then the tiered move families of every critical block."""
         check(self._L.sf_selector_add_precedence(self._h, descriptor_index, variable_index), self._h)
 
+    def set_precedence_policy(self, descriptor_index, enabled=True, variable_index=0):
+        """The runtime list slot declares its precedence hooks to every list leaf (list_leaf/cursor/slot.rs:191-404): intra-list candidates
+        that close a cycle through the route graph are dropped, the ruin leaf recreates with the hooks."""
+        check(self._L.sf_list_set_precedence_policy(self._h, descriptor_index, variable_index, int(bool(enabled))), self._h)
+
     def add_permute_selector(self, descriptor_index, variable_index=0, min_window_size=2, max_window_size=5):
         """List permute leaf (ListPermuteMoveSelectorConfig defaults): every non-identity permutation of every window of
         min..=max consecutive elements."""

@@ -141,7 +141,7 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
 
 
 def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_change", "list_swap"), levels=2, hard_levels=1,
-                          hard_level=0, makespan_level=1, with_owner=True):
+                          hard_level=0, makespan_level=1, with_owner=True, ruin=(2, 5, 10), precedence_policy=False):
     """Job shop with the makespan objective: class 0 = machines with the list variable `sequence` of operation ids; the one
     constraint is the ListPrecedenceMakespanConstraint (crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707) over
     the job order (fixed successors), the machine sequences and the expected machine of every operation."""
@@ -167,6 +167,10 @@ def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_chan
         d.add_selector(SelectorKind.LIST_REVERSE, 0)
     if "kopt" in leaves:
         d.add_kopt_selector(0, max_nearby=0)
+    if "ruin" in leaves:  # ruin = (min_count, max_count, moves_per_step)
+        d.add_ruin_selector(0, min_ruin_count=ruin[0], max_ruin_count=ruin[1], moves_per_step=ruin[2])
+    if precedence_policy:
+        d.set_precedence_policy(0)
     return d
 
 

@@ -186,3 +186,130 @@ def test_validation():
     d = sfa.build_precedence_shop(q, leaves=("precedence",))
     with pytest.raises(sfa.SolverForgeError):
         d.add_precedence_selector(0)  # one such leaf per union
+
+
+# ---- the runtime slot's precedence policy: route-graph filter on the other list leaves, ruin leaf with the hooks --------------------------
+POLICY_LEAVES = ("precedence", "permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "ruin")
+BITS.update({"sublist_swap": 256, "ruin": 1024, "kopt": 512})
+
+
+def _policy_pair(oracle, p, leaves, seed, n_replicas=1, policy=True, ruin=(2, 5, 4), la=5, limit=25):
+    import solverforge_amd as sfa
+
+    d = sfa.build_precedence_shop(p, n_replicas=n_replicas, leaves=leaves, ruin=ruin, precedence_policy=policy)
+    d.configure(sfa.SolverConfig(random_seed=seed, late_acceptance_size=la, accepted_count_limit=limit))
+    bits = sum(BITS[x] for x in leaves)
+
+    def mk(s, order=3):
+        o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+        o.configure(leaves=bits, random_seed=s, la_size=la, limit=limit, selection_order=order)
+        o.set_ruin(ruin[0], ruin[1], ruin[2])
+        o.set_kopt(1, 0)
+        o.set_precedence_policy(policy)
+        return o
+
+    return d, mk
+
+
+def _shuffled(p, seed, same_machine_pairs=True):
+    """Sequences in a seeded random order, and a few operations moved onto the machine of their job predecessor (so that
+    intra-list moves can close cycles through the job order and cyclic working states occur)."""
+    rng = np.random.default_rng(seed)
+    seqs = [list(s) for s in p["sequences"]]
+    m = p["n_machines"]
+    if same_machine_pairs:
+        for job in range(0, p["n_jobs"], 2):
+            a, b = job * m, job * m + 1
+            for s in seqs:
+                if b in s:
+                    s.remove(b)
+            for s in seqs:
+                if a in s:
+                    s.insert(s.index(a) + 1, b)
+    q = dict(p)
+    q["sequences"] = seqs
+    return q, rng
+
+
+@pytest.mark.parametrize("leaves", [("list_change", "list_swap"), ("permute", "sublist_change", "sublist_swap", "list_reverse"), POLICY_LEAVES[:-1]])
+def test_route_graph_filter_streams(oracle, scratch, leaves):
+    """Every intra-list candidate that would close a cycle is gone from the stream (acyclic start), inter-list ones stay."""
+    from solverforge_amd import datasets
+
+    p, _ = _shuffled(datasets.make_precedence_shop(6, 4, seed=7), 1)
+    for policy in (True, False):
+        d, mk = _policy_pair(oracle, p, leaves, 3, policy=policy)
+        o = mk(3)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        d.phase_start()
+        o.phase_start()
+        for order in (0, 3):
+            o = mk(3, order)
+            o.phase_start()
+            gm, gs, gd = d.open_cursor(2, 41, selection_order=order, cap=1 << 18)
+            om = o.enumerate(0, 2, 41, order)
+            assert len(gm) == len(om) > 0, (policy, order)
+            assert (_t(gm) == _t(om)).all(), (policy, order)
+            os_, od = o.evaluate_moves(om)
+            assert (gd == od).all() and (gs == os_[:, :2]).all(), (policy, order)
+        if policy:
+            n_policy = len(gm)
+        else:
+            assert len(gm) > n_policy  # the unfiltered stream is longer
+
+
+def test_policy_steps_from_acyclic_and_cyclic_starts(oracle, scratch):
+    from solverforge_amd import datasets
+
+    base = datasets.make_precedence_shop(6, 4, seed=12)
+    for cyclic_start in (False, True):
+        p, rng = _shuffled(base, 5)
+        if cyclic_start:  # reverse the machines' sequences: job successors in front of their predecessors
+            p["sequences"] = [list(reversed(s)) for s in p["sequences"]]
+        R = 2
+        d, mk = _policy_pair(oracle, p, POLICY_LEAVES, 21, n_replicas=R)
+        o = mk(21)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        d.phase_start()
+        o.phase_start()
+        for step in range(8):
+            gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+            om, os_, of, oap, omv = o.step_traced()
+            assert len(gm) == len(om), (cyclic_start, step)
+            assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), (cyclic_start, step)
+            assert gap == oap
+            if gap:
+                assert tuple(gmv) == tuple(omv), step
+        d.solve_steps(12)
+        scores = d.calculate_score()
+        for r in range(R):
+            o = mk(21 + r)
+            o.phase_start()
+            o.steps(20)
+            assert (scores[r] == o.score()[:2]).all(), (cyclic_start, r)
+            assert d.working_lists(0, r) == o.get_lists(0), (cyclic_start, r)
+            gst, ost = d.stats(r), o.stats()
+            for c in COUNTERS:
+                assert gst[c] == ost[c], (cyclic_start, r, c)
+        assert (d.fresh_score() == scores).all()
+
+
+def test_ruin_leaf_on_a_precedence_model_without_the_policy(oracle):
+    """The public ListRuinMoveSelector knows no hooks: its recreate scores cyclic insertions like any other."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(5, 3, seed=4)
+    d, mk = _policy_pair(oracle, p, ("ruin", "list_swap"), 8, policy=False, ruin=(1, 6, 5))
+    o = mk(8)
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    for step in range(6):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om) and (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+    d.solve_steps(10)
+    o.steps(10)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
