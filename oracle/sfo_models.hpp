@@ -702,6 +702,13 @@ inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, cons
         c->hard = bendable ? Score::level(1, 1) : Score::of(1, 0);
         c->soft = bendable ? Score::level(2, 1) : Score::of(0, 1);
         m->director.constraints.members.push_back(std::move(c));
+        auto hooks = std::make_shared<PrecedenceHooks>();  // the same facts as the hooks of the critical-path leaf / the slot's policy
+        hooks->node_count = n_ops;
+        hooks->durations = *dur;
+        hooks->successors.resize(n_ops);
+        for (size_t v = 0; v + 1 < n_ops; ++v)
+            if (jf->job[v + 1] == jf->job[v]) hooks->successors[v].push_back(v + 1);
+        m->list_slot.precedence = hooks;
     }
     m->has_scalar = true;
     m->scalar_slot.descriptor_index = 0;

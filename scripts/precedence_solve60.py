@@ -3,7 +3,9 @@ swap + reverse + sublist change, LateAcceptance(400) + AcceptedCount(256)): GPU 
 incremental refresh on one host core, same instance, same start: the feasible step-major schedule (default), or with argv[5] =
 "shuffled" every machine sequence permuted (cyclic, hard = -node_count: the all-or-nothing cycle penalty is a plateau that neither
 side leaves in 60 s at 200+ nodes -- recorded in profiles/r02e_prec_solve60_shuffled_*.json).
-argv: seconds jobs machines replicas [start]"""
+argv: seconds jobs machines replicas [start] [policy]: "policy" = the reference's complete default list policy of a slot with precedence
+hooks and no distance meter (critical-path leaf, permute, change, swap, sublist change / swap, reverse, full 3-opt, ruin; the slot's
+precedence policy on) instead of the four leaves above"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -16,13 +18,18 @@ J = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 R = int(sys.argv[4]) if len(sys.argv) > 4 else 2048
 leaves = ("list_change", "list_swap", "sublist_change", "list_reverse")
+policy = len(sys.argv) > 6 and sys.argv[6] == "policy"
+if policy:
+    leaves = ("precedence", "permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt", "ruin")
+BITS = {"precedence": 16384, "permute": 8192, "list_change": 4, "list_swap": 8, "sublist_change": 128, "sublist_swap": 256, "list_reverse": 64, "kopt": 512,
+        "ruin": 1024}
 p = datasets.make_precedence_shop(J, M, seed=1)
 feasible = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"]).score()[:2].tolist()
 start_kind = sys.argv[5] if len(sys.argv) > 5 else "feasible"
 if start_kind == "shuffled":
     rng = np.random.default_rng(7)
     p["sequences"] = [[int(x) for x in rng.permutation(s)] for s in p["sequences"]]  # a cyclic start
-d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves)
+d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves, precedence_policy=policy)
 d.configure(sfa.SolverConfig(random_seed=0))
 start = [int(v) for v in d.calculate_score()[0]]
 d.phase_start()
@@ -38,7 +45,11 @@ gpu = {"seconds": gt, "replicas": R, "best_score": list(max(tuple(int(v) for v i
        "moves_evaluated": st["moves_evaluated"], "moves_per_s": st["moves_evaluated"] / gt, "ls_steps_per_replica": st["step_count"] // R,
        "trace": trace}
 o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
-o.configure(leaves=4 | 8 | 128 | 64, random_seed=0)
+o.configure(leaves=sum(BITS[x] for x in leaves), random_seed=0)
+o.set_kopt(1, 0)
+if policy:
+    o.set_ruin()
+    o.set_precedence_policy(True)
 o.phase_start()
 t0 = time.perf_counter()
 steps = o.steps_timed(seconds)

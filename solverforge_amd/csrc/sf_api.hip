@@ -769,8 +769,9 @@ static int build_list_model(sf_ctx* ctx, int d) {
             seen[x] = 1;
         }
         for (auto& sel : ctx->selectors)  // its recreate is scored by the precedence constraint alone (plf_ruin)
-            if (sel.kind == SF_SEL_LIST_RUIN && (m.dist_level >= 0 || m.cap_level >= 0 || m.ne_level >= 0))
-                return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin leaf on a precedence model with distance / capacity / not-exists constraints");
+            // (a flattened not-exists with its uniform weight costs every insertion of a round the same and nothing once all are back)
+            if (sel.kind == SF_SEL_LIST_RUIN && (m.dist_level >= 0 || m.cap_level >= 0))
+                return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin leaf on a precedence model with distance / capacity constraints");
         PrecModel& pm = ctx->pm;
         pm.on = 1;
         pm.hard_level = ps.hard_level;
@@ -2075,8 +2076,8 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             if (kind == SF_SEL_LIST_PRECEDENCE) {  // critical-path leaf: per-replica tables (sf_prec_leaf.h)
                 if (!ctx->pm.on) return fail(ctx, SF_ERR_INVALID, "list precedence leaf: the list class carries no precedence constraint");
                 // its ruins recreate by the precedence constraint alone: no other list constraint may score an insertion
-                if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0 || ctx->lm.ne_level >= 0)
-                    return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf on a list class with distance / capacity / not-exists constraints");
+                if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0)
+                    return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf on a list class with distance / capacity constraints");
                 if (int rc = ensure_plf(ctx)) return rc;
                 gl.plf = ctx->plf;
                 gl.plf.leaf = 1;

@@ -30,7 +30,7 @@
 
 namespace sf {
 
-constexpr int GL = 8;          // max leaves of the generic union
+constexpr int GL = 12;         // max leaves of the generic union (a slot with precedence hooks declares nine list leaves; + scalar pair)
 constexpr uint32_t GRC = 128;  // ring capacity per leaf
 #ifndef SF_MIXED_RING_LDS
 #define SF_MIXED_RING_LDS 0  // diagnostics: 1 keeps the candidate rings in the replica's LDS slice (the round-2 layout)
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 plf_analyse<PrecMemGlobal>(gl.prec, gl.plf, plf, s_visits, s_off, V, prec_E, prec_Q, prec_S, rounds, (int32_t)pr.makespan, cyc);
             plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni(plf.ms_count), plf.mr_count = uni(plf.mr_count);
         }
-        uint32_t exmask = 0xFFu & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
+        uint32_t exmask = ((1u << GL) - 1u) & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
         if (has_nearby) {
             const uint32_t total = uni(s_off[V]);
@@ -967,9 +967,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             }
             if (u_ord == 2) u_cur = u_off;  // RotatingRoundRobin starts at the seeded offset
         }
-        uint32_t u_order = 0;  // rotated child order of this step, 4 bits per position (nl <= 8)
-        for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) u_order |= ((u_off + pos * u_str) % (uint32_t)nl) << (4u * pos);
-        u_order = uni(u_order);
+        uint64_t u_order = 0;  // rotated child order of this step, 4 bits per position (nl <= 16)
+        for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) u_order |= (uint64_t)((u_off + pos * u_str) % (uint32_t)nl) << (4u * pos);
+        u_order = uni64(u_order);
 
         PH(0)
         int done = 0;
@@ -1790,7 +1790,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     // wave-uniform: the live children's running weights and rotated positions through v_readlane (no LDS
                     // crossbar round trips), rank of every live child = how many live children are pulled before it
                     int32_t wmax = INT32_MIN, wmin = INT32_MAX;
-                    uint32_t r_order = 0;  // live leaves by pull order inside a cycle, 4 bits each
+                    uint64_t r_order = 0;  // live leaves by pull order inside a cycle, 4 bits each
                     for (int j = 0; j < nl; ++j) {
                         if (!((livem >> j) & 1u)) continue;
                         const int32_t wj = __builtin_amdgcn_readlane(wc, j);
@@ -1800,26 +1800,26 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     if (wmax - wmin < nlive) {
                         uint32_t seen = 0;
                         for (uint32_t pi = 0; pi < (uint32_t)nl; ++pi) {      // rotated position pi holds leaf i
-                            const uint32_t i = (u_order >> (4u * pi)) & 15u;
+                            const uint32_t i = (uint32_t)(u_order >> (4u * pi)) & 15u;
                             if (!((livem >> i) & 1u)) continue;
                             if (wmax == wmin) {  // equal running weights (the steady state): the rotated order itself
-                                r_order |= i << (4u * seen);
+                                r_order |= (uint64_t)i << (4u * seen);
                                 seen += 1;
                                 continue;
                             }
                             const int32_t wi = __builtin_amdgcn_readlane(wc, (int)i);
                             uint32_t rank = 0;
                             for (uint32_t pj = 0; pj < (uint32_t)nl; ++pj) {
-                                const uint32_t j = (u_order >> (4u * pj)) & 15u;
+                                const uint32_t j = (uint32_t)(u_order >> (4u * pj)) & 15u;
                                 if (!((livem >> j) & 1u)) continue;
                                 const int32_t wj = __builtin_amdgcn_readlane(wc, (int)j);
                                 rank += (wj > wi || (wj == wi && pj < pi)) ? 1u : 0u;
                             }
-                            r_order |= i << (4u * rank);
+                            r_order |= (uint64_t)i << (4u * rank);
                         }
                         // my pull t = lane: cycle t / nlive, child = the (t % nlive)-th leaf of the cycle
                         const uint32_t cyc = lane / (uint32_t)nlive, slot = lane % (uint32_t)nlive;
-                        const uint32_t leaf = (r_order >> (4u * slot)) & 15u;
+                        const uint32_t leaf = (uint32_t)(r_order >> (4u * slot)) & 15u;
                         const uint32_t hd = lt.w[leaf * 16 + LeafTab::HEAD], tlq = lt.w[leaf * 16 + LeafTab::TAIL];  // per-lane leaf
                         const bool ok = (int32_t)(tlq - (hd + cyc)) > 0;
                         const uint64_t okm = __ballot(ok);
@@ -1847,7 +1847,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     uint32_t tk = 0;  // TAKEN was just cleared
                     uint32_t mypos = 0;
                     for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos)
-                        if (((u_order >> (4u * pos)) & 15u) == lane) mypos = pos;
+                        if (((uint32_t)(u_order >> (4u * pos)) & 15u) == lane) mypos = pos;
                     int32_t wgt = 1;  // child weight (UnionWeighting); lane l = leaf l
                     if (union_custom) {
                         wgt = 0;
@@ -1862,13 +1862,14 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         if (nl > 1 && u_ord == 4) {  // StratifiedRandom: smooth weighted round-robin (vec_union.rs:334-362)
                             if (live_l) wc += wgt;
                             // max running weight, the earlier rotated position on ties: max of (weight << 4 | 15 - position) over
-                            // lanes 0..7 by a DPP prefix max (row_shr 1, 2, 4), read at lane 7
+                            // lanes 0..15 by a DPP prefix max (row_shr 1, 2, 4, 8), read at lane 15
                             int32_t key = live_l ? (int32_t)(((uint32_t)wc << 4) | (15u - mypos)) : INT32_MIN;
                             key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x111, 0xf, 0xf, false));
                             key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x112, 0xf, 0xf, false));
                             key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x114, 0xf, 0xf, false));
-                            const uint32_t kmax = (uint32_t)__builtin_amdgcn_readlane(key, 7);
-                            sel = (u_order >> (4u * (15u - (kmax & 15u)))) & 15u;
+                            key = max(key, __builtin_amdgcn_update_dpp(INT32_MIN, key, 0x118, 0xf, 0xf, false));
+                            const uint32_t kmax = (uint32_t)__builtin_amdgcn_readlane(key, 15);
+                            sel = (uint32_t)(u_order >> (4u * (15u - (kmax & 15u)))) & 15u;
                         } else if (nl > 1 && u_ord == 0) {  // Sequential: drain the children in declaration order (:249-262)
                             while (u_cur < (uint32_t)nl && ((exmask >> u_cur) & 1u)) u_cur += 1;
                             sel = u_cur;

@@ -94,7 +94,7 @@ def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap")):
 
 
 def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
-                  leaves=("list_change", "list_swap", "change", "swap"), makespan=False):
+                  leaves=("list_change", "list_swap", "change", "swap"), makespan=False, ruin=(2, 5, 10), precedence_policy=False):
     """Mixed job shop (examples/mixed-job-shop/src/domain/job_shop_plan.rs:28-69): class 0 =
     operations with the scalar `machine_idx` (0..n_machines, allows_unassigned), class 1 = machines
     with the list variable `sequence` of operation ids.  BendableScore<2,1> (BASELINE.json):
@@ -119,6 +119,14 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
         job = np.asarray(problem["job"])
         succ = [[op + 1] if op + 1 < n_ops and job[op + 1] == job[op] else [] for op in range(n_ops)]
         d.add_list_precedence(1, problem["durations"], succ, None, hard_level=lv[1], makespan_level=lv[2])
+    if "precedence" in leaves:  # the precedence pair leads the list policy (policy/list.rs:24-33)
+        d.add_precedence_selector(1)
+    if "permute" in leaves:
+        d.add_permute_selector(1)
+    if "ruin" in leaves:
+        d.add_ruin_selector(1, min_ruin_count=ruin[0], max_ruin_count=ruin[1], moves_per_step=ruin[2], variable_name="sequence")
+    if precedence_policy:
+        d.set_precedence_policy(1)
     if "list_change" in leaves:
         d.add_selector(SelectorKind.LIST_CHANGE, 1)
     if "list_swap" in leaves:
