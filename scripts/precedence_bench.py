@@ -14,12 +14,16 @@ R = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 ls = int(sys.argv[4]) if len(sys.argv) > 4 else 5
 K = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 leaves = sys.argv[6] if len(sys.argv) > 6 else "list_change,list_swap"
+slot_policy = False
 if leaves == "policy":
     leaves = "precedence,permute,list_change,list_swap,sublist_change,sublist_swap,list_reverse,kopt"
+if leaves == "policy9":  # the complete default policy of a slot with precedence hooks: nine leaves + the slot's precedence policy
+    leaves = "precedence,permute,list_change,list_swap,sublist_change,sublist_swap,list_reverse,kopt,ruin"
+    slot_policy = True
 leaves = tuple(leaves.split(","))
-BITS = {"precedence": 16384, "permute": 8192, "list_change": 4, "list_swap": 8, "sublist_change": 128, "sublist_swap": 256, "list_reverse": 64, "kopt": 512}
+BITS = {"precedence": 16384, "permute": 8192, "list_change": 4, "list_swap": 8, "sublist_change": 128, "sublist_swap": 256, "list_reverse": 64, "kopt": 512, "ruin": 1024}
 p = datasets.make_precedence_shop(J, M, seed=1)
-d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves)
+d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves, precedence_policy=slot_policy)
 d.configure(sfa.SolverConfig(random_seed=0))
 start = d.calculate_score()[0].tolist()
 d.phase_start()
@@ -36,6 +40,8 @@ moves = a["moves_evaluated"] - b["moves_evaluated"]
 o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
 o.configure(leaves=sum(BITS[x] for x in leaves), random_seed=0)
 o.set_kopt(1, 0)
+o.set_ruin()
+o.set_precedence_policy(slot_policy)
 o.phase_start(); o.steps(ls)
 match_warm = bool((warm == o.score()[:2]).all())
 m0 = o.stats()["moves_evaluated"]; t1 = time.perf_counter(); done = 0

@@ -2100,6 +2100,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         gl.plf.leaf = leaf;
         gl.plf.policy = ctx->prec_policy ? 1 : 0;
     }
+    gl.plf.slow = std::getenv("SF_AMD_PLF_SLOW") != nullptr ? 1 : 0;  // read at every launch
     if (!ctx->d_mixed_ring) {
         int rc = dalloc(ctx, &ctx->d_mixed_ring, (size_t)ctx->R * GL * GRC * 2);
         if (!rc) rc = dalloc(ctx, &ctx->d_mixed_ringx, (size_t)ctx->R * GL * GRC);

@@ -522,13 +522,13 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         plf.msrow = gl.plf.msrow + (size_t)r * (pn + 1), plf.mrrow = gl.plf.mrrow + (size_t)r * (pn + 1), plf.sE = gl.plf.sE + (size_t)r * V, plf.visit = gl.plf.visit + (size_t)r * pn;
     }
     // full evaluation of the lists in LDS that also reports the cycle flag (and, with `roff`, Kahn's rounds)
-    auto plf_eval = [&](bool& cyclic, uint32_t* roff) -> PrecResult {
+    auto plf_eval = [&](bool& cyclic, uint32_t* roff, uint32_t* lp = nullptr) -> PrecResult {
         PrecResult pr;
         if (prec_in_lds)
             pr = prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u32*)prec_Q,
-                                                 (prec_lds_u32*)prec_S, nullptr, plf_info, roff);
+                                                 (prec_lds_u32*)prec_S, lp, plf_info, roff);
         else
-            pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, nullptr, plf_info, roff);
+            pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, lp, plf_info, roff);
         wave_sync();
         cyclic = uni(plf_info[1]) != 0u;
         return pr;
@@ -573,12 +573,43 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             bool have = false;
             ScoreV<L> best_sc = last;
             uint32_t b_ri = 0, b_e = 0, b_pos = 0;
+            // the lists without the remaining elements: acyclic => every slot of every remaining element is priced from one forward
+            // evaluation + one backward pass (plf_best_slot); cyclic => the element slides through the slots, one evaluation each
+            bool base_cyc;
+            const PrecResult base = plf_eval(base_cyc, plf.roff, plf.first);
+            if (gl.plf.slow) base_cyc = true;
+            if (!base_cyc) {
+                const uint32_t rounds = uni(plf_info[2]);
+                if (prec_in_lds)
+                    plf_tails<PrecMemLds>(gl.prec, plf, (prec_lds_u32*)prec_Q, (prec_lds_u32*)prec_S, rounds);
+                else
+                    plf_tails<PrecMemGlobal>(gl.prec, plf, prec_Q, prec_S, rounds);
+            }
+            const int lvl_order = gl.prec.hard_level < gl.prec.mk_level ? 0 : (gl.prec.hard_level > gl.prec.mk_level ? 1 : 2);
             for (uint32_t ri = 0; ri < m.n; ++ri) {
                 if (!((remaining >> ri) & 1u)) continue;
                 uint32_t x = 0;
 #pragma unroll
                 for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
                     if (q == ri) x = vals[q];
+                x = uni(x);
+                if (!base_cyc) {
+                    PlfSlotPick pk{0, 0, 0, 0, 0};
+                    if (prec_in_lds)
+                        plf_best_slot<PrecMemLds>(pk, gl.prec, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u32*)prec_S, base.penalty,
+                                                  (int32_t)base.makespan, x, hooks, skip_empty, lvl_order);
+                    else
+                        plf_best_slot<PrecMemGlobal>(pk, gl.prec, plf, s_visits, s_off, V, prec_E, prec_S, base.penalty, (int32_t)base.makespan, x, hooks,
+                                                     skip_empty, lvl_order);
+                    if (pk.found) {
+                        const ScoreV<L> sc = plf_score_of(PrecResult{pk.pen, pk.mk});
+                        if (!have || score_cmp<L>(sc, best_sc) > 0) {
+                            have = true;
+                            best_sc = sc, b_ri = ri, b_e = pk.e, b_pos = pk.k;
+                        }
+                    }
+                    continue;
+                }
                 plf_list_insert(s_visits, s_off, V, 0, 0, x);
                 uint32_t e = 0, pos = 0, g = 0;
                 for (;;) {
@@ -615,10 +646,12 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 rolled = true;
                 break;
             }
+            b_ri = uni(b_ri), b_e = uni(b_e), b_pos = uni(b_pos);
             uint32_t bx = 0;
 #pragma unroll
             for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
                 if (q == b_ri) bx = vals[q];
+            bx = uni(bx);
             plf_list_insert(s_visits, s_off, V, b_e, b_pos, bx);
             remaining &= ~(1u << b_ri);
             last = best_sc;

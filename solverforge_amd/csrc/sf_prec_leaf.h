@@ -38,6 +38,7 @@ struct PlfModel {
     int32_t leaf;       // the union has the critical-path leaf (kind 16384): the blocks are analysed every step
     int32_t policy;     // the slot declares its precedence hooks to the runtime leaves (list_leaf/cursor/slot.rs:191-404): the other list leaves
                         // drop intra-list candidates that close a cycle through a new route edge, the ruin leaf recreates with the hooks
+    int32_t slow;       // diagnostics / parity tests (SF_AMD_PLF_SLOW): the recreate slides every element through every slot, one evaluation each
     int32_t dmax;       // max (fixed successors + fixed predecessors) of a node: spacing of the support-swap sequence numbers
     int32_t* latest;    // [R][n]
     uint32_t* posn;     // [R][n]      node -> (list << 16 | position), PREC_NONE = in no list
@@ -60,8 +61,18 @@ struct PlfRep {  // one replica's slices + the counts of this step (wave-uniform
     uint32_t nb, C, S, ms_count, mr_count;
 };
 
+// Hand-off through HBM between lanes of one wavefront.  The workgroup-scope fences of prec_sync() compile to nothing on gfx950 (one
+// L1 per CU), which leaves a plain store and a later L2 atomic (or sc1 load) of ANOTHER lane to the same word unordered: wait for
+// the wave's outstanding vector memory operations explicitly.
+__device__ __forceinline__ void plf_gsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 __device__ __forceinline__ uint32_t plf_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t plf_ald(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t plf_aldi(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // One step's analysis.  E / Q / S = earliest starts, pop order, list successor of the committed evaluation that just ran
 // (rounds in t.roff); `cyclic` = that evaluation left nodes unprocessed: no blocks at all (analysis.rs:61-70).
@@ -74,7 +85,7 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
     const uint32_t total = plf_uni(off[V]);
     // ---- node -> (list, position) of the committed lists (also what the route-graph filter of the other leaves reads) ----
     for (uint32_t i = lane; i < n; i += 64) t.posn[i] = PREC_NONE;
-    prec_sync();
+    plf_gsync();
     for (uint32_t p0 = 0; p0 < total; p0 += 64) {
         const uint32_t p = p0 + lane;
         if (p < total) {
@@ -89,11 +100,11 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
             t.posn[visits[p]] = (lo << 16) | (p - off[lo]);
         }
     }
-    prec_sync();
+    plf_gsync();
     if (cyclic || !pl.leaf) return;
     // ---- latest starts: the rounds in reverse ----
     for (uint32_t rd = rounds; rd-- > 0;) {
-        const uint32_t lo = plf_uni(t.roff[rd]), hi = plf_uni(t.roff[rd + 1]);
+        const uint32_t lo = plf_uni(plf_ald(t.roff + rd)), hi = plf_uni(plf_ald(t.roff + rd + 1));
         const uint32_t i = lo + lane;
         if (i < hi) {
             const uint32_t w = MEM::ld(Q + i);
@@ -110,11 +121,11 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
             }
             t.latest[w] = best == INT32_MAX ? mk - d : best;
         }
-        prec_sync();
+        plf_gsync();
     }
     // ---- critical flags per list position ----
     for (uint32_t v = lane; v < (uint32_t)V; v += 64) t.sE[v] = 0;
-    prec_sync();
+    plf_gsync();
     for (uint32_t p0 = 0; p0 < total; p0 += 64) {
         const uint32_t p = p0 + lane;
         if (p < total) {
@@ -139,7 +150,7 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
             t.first[p] = 0xFFFFFFFFu;
         }
     }
-    prec_sync();
+    plf_gsync();
     // ---- blocks, critical swaps, critical nodes: compactions in list order ----
     uint32_t nb = 0, C = 0, NC = 0;
     for (uint32_t p0 = 0; p0 < total; p0 += 64) {
@@ -166,7 +177,7 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
         }
         NC += (uint32_t)__popcll(mc), C += (uint32_t)__popcll(ma), nb += (uint32_t)__popcll(ms);
     }
-    prec_sync();
+    plf_gsync();
     // ---- support swaps (support.rs:38-62,163-188): the swaps around the fixed successors / predecessors of every critical node, first
     // occurrence order.  Item k of critical node t has the sequence number t * 2 * dmax + 2 * k (+ 1 for the swap after the node). ----
     const uint32_t span = 2u * (uint32_t)pl.dmax;
@@ -189,7 +200,7 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
             for_items(t0 + lane, [&](uint32_t seq, uint32_t slot, uint32_t, uint32_t) {
                 __hip_atomic_fetch_min(t.first + slot, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             });
-    prec_sync();
+    plf_gsync();
     uint32_t Sn = 0;
     for (uint32_t t0 = 0; t0 < NC; t0 += 64) {
         uint32_t mine = 0;
@@ -206,7 +217,7 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
             });
         Sn += (uint32_t)__shfl((int)incl, 63);
     }
-    prec_sync();
+    plf_gsync();
     // ---- multi-swap rows (support.rs:64-84): row i = the triples whose first critical swap is i ----
     uint32_t ms_total = 0;
     for (uint32_t i0 = 0; i0 < C; i0 += 64) {
@@ -245,7 +256,7 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
         mr_total += (uint32_t)__shfl((int)ri, 63);
     }
     if (lane == 0) t.mrrow[nb] = mr_total;
-    prec_sync();
+    plf_gsync();
     t.nb = nb, t.C = C, t.S = Sn, t.ms_count = ms_total, t.mr_count = mr_total;
 }
 
@@ -257,12 +268,12 @@ __device__ __noinline__ bool plf_reaches(const PrecModel pm, uint32_t* visit, ui
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     for (uint32_t i = lane; i < n; i += 64) visit[i] = 0;
-    prec_sync();
+    plf_gsync();
     if (lane == 0) {
         __hip_atomic_store(visit + from, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(queue, from, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    prec_sync();
+    plf_gsync();
     uint32_t head = 0, tail = 1;
     bool found = from == target;
     while (head < tail && !found) {
@@ -293,9 +304,179 @@ __device__ __noinline__ bool plf_reaches(const PrecModel pm, uint32_t* visit, ui
         }
         found = __ballot(hit) != 0;
         head += cnt;
-        prec_sync();
+        plf_gsync();
     }
     return found;
+}
+
+
+// ---- one element of one recreate round, every insertion slot at once (acyclic lists) ----------------------------------------------
+// The lists hold everything but the element x.  One forward evaluation (earliest starts E, pop order Q with its rounds, list
+// successors S, list predecessors LP) and one backward pass (TAIL[v] = longest path from the start of v to the end) price every
+// slot without touching the lists: a slot (list e, position k) puts x between p = L[k-1] and q = L[k]; the longest path through x is
+//   max(finish(p), finish(fixed predecessors of x)) + dur(x) + max(TAIL(q), TAIL(fixed successors of x))
+// and every other path of the new graph is a path of the old one (the edge p -> q only moves onto p -> x -> q), so the makespan is
+// the max of that and the old makespan.  The new graph is cyclic iff a successor side of x reaches a predecessor side: q in A,
+// p in B or a fixed predecessor in B, with A = the ancestors of x's fixed predecessors (themselves included) and B = the descendants
+// of x's fixed successors (themselves included) -- two breadth-first searches.  Result: the best slot by (hard penalty, makespan) in
+// the score's level order, the first in (list, position) order among equals; `hooks`: cyclic slots are skipped, else they are priced
+// as the constraint prices a cycle (+ node_count hard, makespan 0).
+struct PlfSlotPick {
+    uint32_t found, e, k;
+    int64_t pen, mk;
+};
+// the backward pass of a recreate round (once per round: the lists are the same for every remaining element)
+template <class MEM>
+__device__ __noinline__ void plf_tails(const PrecModel pm, const PlfRep& t, typename MEM::U32 Q, typename MEM::U32 S, uint32_t rounds) {
+    const uint32_t lane = threadIdx.x & 63u;
+    int32_t* const TAIL = t.latest;
+    plf_gsync();
+    for (uint32_t rd = rounds; rd-- > 0;) {
+        const uint32_t lo = plf_uni(plf_ald(t.roff + rd)), hi = plf_uni(plf_ald(t.roff + rd + 1));
+        const uint32_t i = lo + lane;
+        if (i < hi) {
+            const uint32_t w = MEM::ld(Q + i);
+            int32_t best = 0;
+            for (uint32_t k = pm.succ_off[w]; k < pm.succ_off[w + 1]; ++k) {
+                const int32_t c = plf_aldi(TAIL + pm.succ[k]);
+                best = c > best ? c : best;
+            }
+            const uint32_t ls = MEM::ld(S + w);
+            if (ls != PREC_NONE) {
+                const int32_t c = plf_aldi(TAIL + ls);
+                best = c > best ? c : best;
+            }
+            TAIL[w] = best + pm.dur[w];
+        }
+        plf_gsync();
+    }
+}
+template <class MEM>
+__device__ __noinline__ void plf_best_slot(PlfSlotPick& r, const PrecModel pm, const PlfRep& t, const uint16_t* visits, const uint32_t* off, int V, typename MEM::I32 E,
+                                                  typename MEM::U32 S, int64_t base_pen, int32_t base_mk, uint32_t x, bool hooks, bool skip_empty,
+                                                  int order /* 0: penalty first, 1: makespan first, 2: one level */) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n = (uint32_t)pm.n;
+    int32_t* const TAIL = t.latest;
+    uint32_t* const LP = t.first;   // list predecessors (written by the evaluation)
+    uint32_t* const INA = t.visit;  // ancestors of x's fixed predecessors
+    uint32_t* const INB = t.flag;   // descendants of x's fixed successors
+    uint32_t* const QUE = t.cnl;
+    // ---- A and B ----
+    for (uint32_t i = lane; i < n; i += 64) INA[i] = 0, INB[i] = 0;
+    plf_gsync();
+    for (int side = 0; side < 2; ++side) {
+        uint32_t* const mark = side == 0 ? INA : INB;
+        const uint32_t so = side == 0 ? pm.pred_off[x] : pm.succ_off[x], sn = (side == 0 ? pm.pred_off[x + 1] : pm.succ_off[x + 1]) - so;
+        uint32_t tail = 0;
+        for (uint32_t k0 = 0; k0 < sn; k0 += 64) {  // seeds
+            const bool has = k0 + lane < sn;
+            uint32_t y = 0;
+            bool fresh = false;
+            if (has) {
+                y = side == 0 ? pm.pred[so + k0 + lane] : pm.succ[so + k0 + lane];
+                fresh = __hip_atomic_exchange(mark + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+            }
+            const uint64_t m = __ballot(fresh);
+            if (fresh) __hip_atomic_store(QUE + tail + prec_mbcnt(m), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail += (uint32_t)__popcll(m);
+        }
+        plf_gsync();
+        uint32_t head = 0;
+        while (head < tail) {
+            const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
+            const bool act = lane < cnt;
+            uint32_t fo = 0, deg = 0, ln = PREC_NONE;
+            if (act) {
+                const uint32_t w = plf_ald(QUE + head + lane);
+                fo = side == 0 ? pm.pred_off[w] : pm.succ_off[w];
+                deg = (side == 0 ? pm.pred_off[w + 1] : pm.succ_off[w + 1]) - fo;
+                ln = side == 0 ? plf_ald(LP + w) : MEM::ld(S + w);
+            }
+            const uint32_t degt = deg + ((act && ln != PREC_NONE) ? 1u : 0u);
+            for (uint32_t k = 0;; ++k) {
+                const bool has = k < degt;
+                if (!__ballot(has)) break;
+                bool fresh = false;
+                uint32_t y = 0;
+                if (has) {
+                    y = k < deg ? (side == 0 ? pm.pred[fo + k] : pm.succ[fo + k]) : ln;
+                    fresh = __hip_atomic_exchange(mark + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+                }
+                const uint64_t m = __ballot(fresh);
+                if (fresh) __hip_atomic_store(QUE + tail + prec_mbcnt(m), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tail += (uint32_t)__popcll(m);
+            }
+            head += cnt;
+            plf_gsync();
+        }
+    }
+    // ---- what x brings by itself: its fixed predecessors' latest finish, its fixed successors' longest tail, a cycle through them alone ----
+    int32_t hf = 0, ts = 0;
+    bool always = false;
+    for (uint32_t k = pm.pred_off[x]; k < pm.pred_off[x + 1]; ++k) {
+        const uint32_t f = pm.pred[k];
+        const int32_t c = MEM::ld(E + f) + pm.dur[f];
+        hf = c > hf ? c : hf;
+        always = always || plf_ald(INB + f) != 0u;
+    }
+    for (uint32_t k = pm.succ_off[x]; k < pm.succ_off[x + 1]; ++k) {
+        const int32_t c = plf_aldi(TAIL + pm.succ[k]);
+        ts = c > ts ? c : ts;
+    }
+    const int32_t dx = pm.dur[x];
+    const int32_t ox = pm.owner ? pm.owner[x] : -1;
+    // ---- every slot: lane s handles the slots s, s + 64, .. in (list, position) order ----
+    const uint32_t total = plf_uni(off[V]);
+    const uint32_t slots = total + (uint32_t)V;
+    uint64_t bk1 = ~0ull, bk2 = ~0ull;
+    uint32_t bslot = 0xFFFFFFFFu, be = 0, bkk = 0;
+    int64_t bpen = 0, bmk = 0;
+    for (uint32_t s0 = 0; s0 < slots; s0 += 64) {
+        const uint32_t sl = s0 + lane;
+        if (sl >= slots) continue;
+        // slot sl of list e at position k: slots of list e start at off[e] + e
+        uint32_t lo = 0, hi = (uint32_t)V;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] + mid <= sl)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t e = lo, k = sl - (off[e] + e), len = off[e + 1] - off[e];
+        if (skip_empty && len == 0) continue;
+        const uint32_t p = k > 0 ? (uint32_t)visits[off[e] + k - 1] : PREC_NONE, q = k < len ? (uint32_t)visits[off[e] + k] : PREC_NONE;
+        const bool cyc = always || (q != PREC_NONE && plf_ald(INA + q) != 0u) || (p != PREC_NONE && plf_ald(INB + p) != 0u);
+        if (cyc && hooks) continue;
+        int64_t pen = base_pen - 1 + ((ox >= 0 && (uint32_t)ox != e) ? 1 : 0), mk;
+        if (cyc) {
+            pen += (int64_t)n;
+            mk = 0;
+        } else {
+            const int32_t hp = p != PREC_NONE ? MEM::ld(E + p) + pm.dur[p] : 0;
+            const int32_t tq = q != PREC_NONE ? plf_aldi(TAIL + q) : 0;
+            const int32_t through = (hp > hf ? hp : hf) + dx + (tq > ts ? tq : ts);
+            mk = through > base_mk ? through : base_mk;
+        }
+        const uint64_t k1 = (uint64_t)(order == 0 ? pen : (order == 1 ? mk : pen + mk)), k2 = (uint64_t)(order == 0 ? mk : (order == 1 ? pen : 0));
+        if (k1 < bk1 || (k1 == bk1 && k2 < bk2)) {  // ascending slots per lane: strict improvement keeps the first of equals
+            bk1 = k1, bk2 = k2, bslot = sl, be = e, bkk = k, bpen = pen, bmk = mk;
+        }
+    }
+    // wave argmin of (k1, k2, slot)
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const uint64_t o1 = shfl_xor_u64(bk1, o), o2 = shfl_xor_u64(bk2, o);
+        const uint32_t os = (uint32_t)__shfl_xor((int)bslot, o), oe = (uint32_t)__shfl_xor((int)be, o), ok = (uint32_t)__shfl_xor((int)bkk, o);
+        const int64_t op = (int64_t)shfl_xor_u64((uint64_t)bpen, o), om = (int64_t)shfl_xor_u64((uint64_t)bmk, o);
+        const bool take = os != 0xFFFFFFFFu && (bslot == 0xFFFFFFFFu || o1 < bk1 || (o1 == bk1 && (o2 < bk2 || (o2 == bk2 && os < bslot))));
+        if (take) bk1 = o1, bk2 = o2, bslot = os, be = oe, bkk = ok, bpen = op, bmk = om;
+    }
+    r.found = plf_uni(bslot != 0xFFFFFFFFu ? 1u : 0u);
+    r.e = plf_uni(be), r.k = plf_uni(bkk);
+    r.pen = (int64_t)(((uint64_t)plf_uni((uint32_t)((uint64_t)bpen >> 32)) << 32) | plf_uni((uint32_t)bpen));
+    r.mk = (int64_t)(((uint64_t)plf_uni((uint32_t)((uint64_t)bmk >> 32)) << 32) | plf_uni((uint32_t)bmk));
 }
 
 // ---- decoding (wave-uniform arguments and results) ----

@@ -22,12 +22,17 @@ def _t(moves):
     return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"], moves["value"]], axis=1)
 
 
-@pytest.fixture(params=["lds", "hbm"])
+@pytest.fixture(params=["lds", "hbm", "lds_slow_recreate"])
 def scratch(request):
+    """Kahn scratch in LDS / HBM; slow_recreate: the ruins slide every element through every slot with one evaluation each
+    (SF_AMD_PLF_SLOW) instead of pricing all slots from one forward + one backward pass."""
     if request.param == "hbm":
         os.environ["SF_AMD_PREC_HBM"] = "1"
+    if request.param == "lds_slow_recreate":
+        os.environ["SF_AMD_PLF_SLOW"] = "1"
     yield request.param
     os.environ.pop("SF_AMD_PREC_HBM", None)
+    os.environ.pop("SF_AMD_PLF_SLOW", None)
 
 
 def _pair(oracle, p, leaves, seed, n_replicas=1, la=5, limit=25, with_owner=True):
