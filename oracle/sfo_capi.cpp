@@ -548,7 +548,9 @@ void sfo_model_apply_move(void* h, const sfo_move_t* mv) {  // committed do_move
 // ListCheapestInsertionPhase over the list class: `elements` = the unassigned elements in source order
 void sfo_model_construct_list_cheapest(void* h, const uint32_t* elements, int32_t n) {
     Model* m = (Model*)h;
-    construct_list_cheapest(m->director, m->list_slot.descriptor_index, std::vector<uint32_t>(elements, elements + n), &m->search.stats);
+    // `elements` = the unassigned ones in source order; a slot with the precedence policy hands the phase its hooks (defaults/stages.rs:266-275)
+    construct_list_cheapest(m->director, m->list_slot.descriptor_index, std::vector<uint32_t>(elements, elements + n), &m->search.stats,
+                            m->list_slot.precedence_policy ? m->list_slot.precedence.get() : nullptr);
 }
 // ListClarkeWrightPhase over a CVRP model's list class (list_clarke_wright/kernel.rs) with the solverforge-cvrp hook bundle
 // (crates/solverforge-cvrp/src/helpers.rs:40-87): one shared metric class (every vehicle shares the ProblemData), the model's depot,

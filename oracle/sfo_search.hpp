@@ -632,10 +632,57 @@ inline void construct_first_fit(ScoreDirector& d, const ScalarSlot& slot, Solver
 // unassigned elements in (construction order key, source index) order -- no order key here -- are placed one by one; every
 // (list, position) is trial-inserted and fully scored (one score_calculation each), the strictly best score wins (the first of
 // equals stays), the insertion is committed as one accepted + applied step.  Unrestricted owners, no precedence hooks.
-inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned, SolverStats* stats = nullptr) {
+// precedence_downstream (cheapest/kernel.rs:162-229): with the phase's precedence hooks the elements are re-ranked (stable) by the longest
+// duration-weighted chain of fixed successors AMONG the elements still to place, longest first; a cyclic successor relation leaves the
+// order alone.  `hooks` = the slot's precedence hooks (element = node index), null = the phase has none.
+inline std::vector<uint32_t> cheapest_precedence_order(const std::vector<uint32_t>& elements, const PrecedenceHooks* hooks) {
+    if (!hooks) return elements;
+    const size_t m = elements.size();
+    std::vector<int64_t> position(hooks->node_count, -1);
+    for (size_t i = 0; i < m; ++i) {
+        if ((size_t)elements[i] >= hooks->node_count) return elements;
+        position[elements[i]] = (int64_t)i;
+    }
+    std::vector<std::vector<size_t>> succ(m);
+    std::vector<size_t> preds(m, 0);
+    for (size_t i = 0; i < m; ++i)
+        for (size_t to : hooks->successors[elements[i]]) {
+            if (to >= hooks->node_count || position[to] < 0) continue;
+            succ[i].push_back((size_t)position[to]);
+            preds[(size_t)position[to]] += 1;
+        }
+    std::vector<size_t> ready, topo;
+    for (size_t i = 0; i < m; ++i)
+        if (preds[i] == 0) ready.push_back(i);
+    while (!ready.empty()) {
+        size_t i = ready.back();
+        ready.pop_back();
+        topo.push_back(i);
+        for (size_t s2 : succ[i])
+            if (--preds[s2] == 0) ready.push_back(s2);
+    }
+    if (topo.size() != m) return elements;
+    std::vector<int64_t> down(m);
+    for (size_t i = 0; i < m; ++i) down[i] = hooks->durations[elements[i]];
+    for (size_t t = m; t-- > 0;) {
+        size_t i = topo[t];
+        int64_t tail = 0;
+        for (size_t s2 : succ[i]) tail = std::max(tail, down[s2]);
+        down[i] = hooks->durations[elements[i]] + tail;
+    }
+    std::vector<size_t> idx(m);
+    for (size_t i = 0; i < m; ++i) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return down[a] > down[b]; });
+    std::vector<uint32_t> out;
+    for (size_t i : idx) out.push_back(elements[i]);
+    return out;
+}
+inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned_in, SolverStats* stats = nullptr,
+                                    const PrecedenceHooks* hooks = nullptr) {
     d.calculate_score();
     EntityClass& c = d.working.classes[descriptor];
-    if (unassigned.empty() || c.n == 0) return;
+    if (unassigned_in.empty() || c.n == 0) return;
+    const std::vector<uint32_t> unassigned = cheapest_precedence_order(unassigned_in, hooks);
     for (uint32_t element : unassigned) {
         bool have = false;
         size_t best_e = 0, best_p = 0;

@@ -719,6 +719,32 @@ static void cheapest_insertion_cases() {
 
 // heuristic/move/tests/compound_scalar.rs:146-262: several edits applied and undone atomically, every edit applied before the
 // first after-notification, no-op and illegal candidates rejected
+// manager/phase_factory/list_construction/cheapest/tests.rs:244-258 (precedence_downstream_breaks_cheapest_ties_...): elements [1, 0], one
+// empty route, every insertion scores the same, hooks = unit durations + "0 precedes 1": element 0 has the longer downstream chain, goes
+// first, and element 1 then takes the first of two equal slots -> [1, 0]
+static void cheapest_precedence_cases() {
+    Solution s;
+    s.classes.resize(1);
+    s.classes[0].n = 1;
+    s.classes[0].lists = {{}};
+    PrecedenceHooks h;
+    h.node_count = 2;
+    h.durations = {1, 1};
+    h.successors = {{1}, {}};
+    {
+        ScoreDirector d;
+        d.working = s;
+        construct_list_cheapest(d, 0, {1, 0}, nullptr, &h);
+        CHECK("list_cheapest.precedence_downstream_breaks_cheapest_ties", d.working.classes[0].lists[0] == std::vector<uint32_t>{1, 0});
+    }
+    {  // without the hooks the source order decides: 1 first, then 0 in front of it
+        ScoreDirector d;
+        d.working = s;
+        construct_list_cheapest(d, 0, {1, 0}, nullptr, nullptr);
+        CHECK("list_cheapest.source_order_without_hooks", d.working.classes[0].lists[0] == std::vector<uint32_t>{0, 1});
+    }
+}
+
 static void compound_scalar_cases() {
     struct SnapshotOnInsert : Constraint {  // records (left[0], left[1]) at every after_variable_changed (RecordingCompoundDirector)
         std::vector<std::pair<int64_t, int64_t>>* log;
@@ -1972,6 +1998,7 @@ int main() {
     list_ruin_cases();
     compound_scalar_cases();
     cheapest_insertion_cases();
+    cheapest_precedence_cases();
     balance_cases();
     bi_incr_cases();
     cross_bi_cases();

@@ -1577,17 +1577,102 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
 }
 
 // ≙ ListCheapestInsertionPhase over every replica's current lists (csrc/sf_construct.hip)
+// cheapest insertion on a list class scored by the precedence constraint (k_prec_construct_cheapest); with the slot's precedence policy
+// the phase has the hooks and re-ranks the elements by their downstream chain (cheapest/kernel.rs:75-81,162-229)
+static int ensure_plf(sf_ctx* ctx);
+static int construct_cheapest_precedence(sf_ctx* ctx, const uint32_t* elements, int32_t n, int64_t* out_scores) {
+    if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "cheapest insertion on a precedence model with distance / capacity constraints");
+    if (int rc = ensure_plf(ctx)) return rc;
+    std::vector<uint32_t> order(elements, elements + n);
+    const PrecSpec& ps = ctx->prec;
+    const size_t nodes = ps.dur.size();
+    if (ctx->prec_policy && n > 0) {  // precedence_downstream: unassigned elements only (those already in a list are skipped by the kernel anyway)
+        std::vector<char> in_list(nodes, 0);
+        {
+            std::vector<uint32_t> off((size_t)ctx->lm.V + 1), vis;
+            if (hipMemcpy(off.data(), ctx->lm.off, off.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(ctx, SF_ERR_HIP, "copy of the list offsets");
+            vis.resize(off.back());
+            if (!vis.empty() && hipMemcpy(vis.data(), ctx->lm.visits, vis.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+                return fail(ctx, SF_ERR_HIP, "copy of the lists");
+            for (uint32_t x : vis)
+                if (x < nodes) in_list[x] = 1;
+        }
+        std::vector<uint32_t> el;
+        for (uint32_t x : order)
+            if (x < nodes && !in_list[x]) el.push_back(x);
+        const size_t m = el.size();
+        std::vector<int64_t> position(nodes, -1);
+        bool ok = true;
+        for (size_t i = 0; i < m; ++i) position[el[i]] = (int64_t)i;
+        std::vector<std::vector<size_t>> succ(m);
+        std::vector<size_t> preds(m, 0);
+        for (size_t i = 0; i < m; ++i)
+            for (uint32_t t = ps.succ_off[el[i]]; t < ps.succ_off[el[i] + 1]; ++t) {
+                const uint32_t to = ps.succ[t];
+                if (to >= nodes || position[to] < 0) continue;
+                succ[i].push_back((size_t)position[to]);
+                preds[(size_t)position[to]] += 1;
+            }
+        std::vector<size_t> ready, topo;
+        for (size_t i = 0; i < m; ++i)
+            if (preds[i] == 0) ready.push_back(i);
+        while (!ready.empty()) {
+            const size_t i = ready.back();
+            ready.pop_back();
+            topo.push_back(i);
+            for (size_t s2 : succ[i])
+                if (--preds[s2] == 0) ready.push_back(s2);
+        }
+        ok = topo.size() == m;
+        if (ok) {
+            std::vector<int64_t> down(m);
+            for (size_t t = m; t-- > 0;) {
+                const size_t i = topo[t];
+                int64_t tail = 0;
+                for (size_t s2 : succ[i]) tail = std::max(tail, down[s2]);
+                down[i] = (int64_t)ps.dur[el[i]] + tail;
+            }
+            std::vector<size_t> idx(m);
+            for (size_t i = 0; i < m; ++i) idx[i] = i;
+            std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return down[a] > down[b]; });
+            order.clear();
+            for (size_t i : idx) order.push_back(el[i]);
+        }
+    }
+    const size_t lds = (((size_t)ctx->lm.V + 1 + 3) & ~(size_t)3) * 4 + ((((size_t)ctx->lm.dim + 31) / 32 + 3) & ~(size_t)3) * 4 + (size_t)ctx->lm.n_cap * 2 + 16;
+    if (lds > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
+    uint32_t* d_el = nullptr;
+    if (!order.empty()) {
+        hipError_t ea = hipMalloc((void**)&d_el, order.size() * 4);
+        if (ea == hipSuccess) ea = hipMemcpyAsync(d_el, order.data(), order.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (ea != hipSuccess) {
+            (void)hipFree(d_el);
+            return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
+        }
+    }
+    const int lvl_order = ctx->pm.hard_level < ctx->pm.mk_level ? 0 : (ctx->pm.hard_level > ctx->pm.mk_level ? 1 : 2);
+    auto kern = k_prec_construct_cheapest;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), lds, ctx->stream, ctx->lm, ctx->pm, ctx->plf, d_el, (int)order.size(), lvl_order, ctx->sp.stats);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_el);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return run_evaluate_all(ctx, out_scores, 1);
+}
+
 int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "cheapest insertion needs the list variable's class");
     if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_cheapest arguments");
     if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
-    if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "cheapest insertion on a model with precedence hooks");
     for (int32_t k = 0; k < n; ++k)
         if (elements[k] >= (uint32_t)ctx->lm.dim) return fail(ctx, SF_ERR_INVALID, "element id out of range");
     int rc = alloc_search(ctx);
     if (rc) return rc;
+    if (ctx->pm.on) return construct_cheapest_precedence(ctx, elements, n, out_scores);
     const ConstructCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
     uint32_t* d_el = nullptr;

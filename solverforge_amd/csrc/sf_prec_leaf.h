@@ -351,8 +351,8 @@ __device__ __noinline__ void plf_tails(const PrecModel pm, const PlfRep& t, type
         plf_gsync();
     }
 }
-template <class MEM>
-__device__ __noinline__ void plf_best_slot(PlfSlotPick& r, const PrecModel pm, const PlfRep& t, const uint16_t* visits, const uint32_t* off, int V, typename MEM::I32 E,
+template <class MEM, class VT = uint16_t>
+__device__ __noinline__ void plf_best_slot(PlfSlotPick& r, const PrecModel pm, const PlfRep& t, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E,
                                                   typename MEM::U32 S, int64_t base_pen, int32_t base_mk, uint32_t x, bool hooks, bool skip_empty,
                                                   int order /* 0: penalty first, 1: makespan first, 2: one level */) {
     const uint32_t lane = threadIdx.x & 63u;

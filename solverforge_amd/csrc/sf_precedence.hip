@@ -3,8 +3,107 @@
 // list moves (one wavefront per record: the replica's lists staged in LDS, the move applied there, one full evaluation).
 #pragma once
 #include "sf_precedence.h"
+#include "sf_prec_leaf.h"
 
 namespace sf {
+
+// ≙ ListCheapestInsertionPhase on a list class scored by the precedence constraint (manager/phase_factory/list_construction/cheapest/
+// kernel.rs:57-150; the host orders the elements, incl. precedence_downstream :162-229).  One wavefront per replica, lists staged in
+// LDS.  Per element: one forward evaluation of the lists, one backward pass, two reachability searches and one sweep over every
+// insertion slot (plf_best_slot, hooks = false: a slot that closes a cycle is priced as the constraint prices a cycle) instead of
+// one full evaluation per slot; when the lists are already cyclic the element slides through every slot, one evaluation each.
+// order: 0 hard penalty before makespan, 1 makespan first, 2 both on one level.
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(64) void k_prec_construct_cheapest(ListModel lm, PrecModel pm, PlfModel pl, const uint32_t* __restrict__ elements, int n_el, int order,
+                                                                uint64_t* stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_info[4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int r = blockIdx.x;
+    const int V = lm.V;
+    const size_t pn = (size_t)pm.n, pc = (size_t)lm.n_cap;
+    uint32_t* off = (uint32_t*)smem;
+    uint32_t* present = off + (((size_t)V + 1 + 3) & ~(size_t)3);
+    uint16_t* visits = (uint16_t*)(present + ((((size_t)lm.dim + 31) / 32 + 3) & ~(size_t)3));
+    uint32_t* g_visits = lm.visits + (size_t)r * lm.n_cap;
+    uint32_t* g_off = lm.off + (size_t)r * (V + 1);
+    PlfRep t{};
+    t.latest = pl.latest + (size_t)r * pn, t.posn = pl.posn + (size_t)r * pn, t.flag = pl.flag + (size_t)r * pc, t.roff = pl.roff + (size_t)r * (pn + 2);
+    t.first = pl.first + (size_t)r * pc, t.cnl = pl.cnl + (size_t)r * pn, t.visit = pl.visit + (size_t)r * pn;
+    int32_t* E = pm.earliest + (size_t)r * pn;
+    int32_t* D = pm.indeg + (size_t)r * pn;
+    uint32_t* Q = pm.queue + (size_t)r * pn;
+    uint32_t* S = pm.lsucc + (size_t)r * pn;
+    for (uint32_t i = lane; i <= (uint32_t)V; i += 64) off[i] = g_off[i];
+    for (uint32_t i = lane; i < ((uint32_t)lm.dim + 31u) / 32u; i += 64) present[i] = 0u;
+    plf_sync();
+    const uint32_t tot0 = plf_uni(off[V]);
+    for (uint32_t i = lane; i < tot0; i += 64) {
+        const uint32_t x = g_visits[i];
+        visits[i] = (uint16_t)x;
+        atomicOr(&present[x >> 5], 1u << (x & 31u));
+    }
+    plf_sync();
+    uint64_t trials = 0, placed = 0;
+    for (int k = 0; k < n_el; ++k) {
+        const uint32_t x = elements[k];
+        if (x >= (uint32_t)pm.n || ((plf_uni(present[x >> 5]) >> (x & 31u)) & 1u)) continue;  // already in a list
+        const uint32_t total = plf_uni(off[V]);
+        if (total >= (uint32_t)lm.n_cap) break;
+        trials += total + (uint32_t)V;
+        const PrecResult base = prec_eval<uint16_t, PrecMemGlobal>(pm, visits, off, V, E, D, Q, S, t.first, s_info, t.roff);
+        plf_sync();
+        const bool base_cyc = plf_uni(s_info[1]) != 0u;
+        uint32_t be = 0, bk = 0;
+        if (!base_cyc) {
+            plf_tails<PrecMemGlobal>(pm, t, Q, S, plf_uni(s_info[2]));
+            PlfSlotPick pk{0, 0, 0, 0, 0};
+            plf_best_slot<PrecMemGlobal, uint16_t>(pk, pm, t, visits, off, V, E, S, base.penalty, (int32_t)base.makespan, x, false, false, order);
+            be = pk.e, bk = pk.k;
+        } else {  // the element slides through every slot (ascending (list, position)), one evaluation each
+            plf_list_insert(visits, off, V, 0, 0, x);
+            uint64_t b1 = ~0ull, b2 = ~0ull;
+            uint32_t e = 0, pos = 0, g = 0;
+            for (;;) {
+                const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(pm, visits, off, V, E, D, Q, S);
+                const uint64_t k1 = (uint64_t)(order == 0 ? pr.penalty : (order == 1 ? pr.makespan : pr.penalty + pr.makespan));
+                const uint64_t k2 = (uint64_t)(order == 0 ? pr.makespan : (order == 1 ? pr.penalty : 0));
+                if (k1 < b1 || (k1 == b1 && k2 < b2)) b1 = k1, b2 = k2, be = e, bk = pos;
+                const uint32_t others = plf_uni(off[e + 1] - off[e]) - 1u;
+                if (pos < others) {
+                    if (lane == 0) {
+                        const uint16_t y = visits[g + 1];
+                        visits[g + 1] = (uint16_t)x;
+                        visits[g] = y;
+                    }
+                    g += 1, pos += 1;
+                } else if (e + 1 < (uint32_t)V) {
+                    if (lane == 0) off[e + 1] -= 1;
+                    e += 1, pos = 0;
+                } else
+                    break;
+                plf_sync();
+            }
+            if (lane == 0) off[V] -= 1;
+            plf_sync();
+        }
+        plf_list_insert(visits, off, V, be, bk, x);
+        if (lane == 0) present[x >> 5] |= 1u << (x & 31u);
+        plf_sync();
+        placed += 1;
+    }
+    const uint32_t tot = plf_uni(off[V]);
+    for (uint32_t i = lane; i < tot; i += 64) g_visits[i] = visits[i];
+    for (uint32_t i = lane; i <= (uint32_t)V; i += 64) g_off[i] = off[i];
+    if (stats && lane == 0) {  // live.rs: one score calculation per trial, one accepted + applied step per placed element
+        uint64_t* gs = stats + (size_t)r * SF_STATS_WORDS;
+        gs[0] += placed;
+        gs[3] += placed;
+        gs[4] += placed;
+        gs[5] += trials;
+        gs[7] += trials;
+    }
+}
 
 // one wavefront per replica; adds the constraint's two levels to out_scores ([R][levels], already holding the other constraints)
 SF_PLAIN_KERNEL

@@ -401,3 +401,56 @@ def test_mixed_job_shop_under_the_list_policy(oracle):
             assert d.working_lists(1, r) == o.get_lists(1), (policy, r)
             assert (d.working_values(0, 0, replica=r) == o.get_vars(0, 0)).all(), (policy, r)
         assert (d.fresh_score() == scores).all()
+
+
+@pytest.mark.parametrize("policy", [False, True])
+@pytest.mark.parametrize("start", ["empty", "partial", "cyclic"])
+def test_cheapest_insertion_construction_on_a_precedence_model(oracle, policy, start):
+    """ListCheapestInsertionPhase on a list class scored by the precedence constraint: every slot priced from one forward + one
+    backward pass (or one evaluation per slot when the lists are already cyclic); with the slot's precedence policy the phase has
+    the hooks and ranks the elements by their downstream chain (cheapest/kernel.rs:162-229, pinned in oracle/test_golden.cpp)."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(7, 4, seed=6, scheduled=start != "empty")
+    n = len(p["durations"])
+    rng = np.random.default_rng(3)
+    if start != "empty":
+        seqs = [list(s) for s in p["sequences"]]
+        for _ in range(n // 2):  # take half of the operations out again
+            v = int(rng.integers(len(seqs)))
+            if seqs[v]:
+                seqs[v].pop(int(rng.integers(len(seqs[v]))))
+        if start == "cyclic":
+            seqs = [list(reversed(s)) for s in seqs]
+            a, b = 0, 1  # job 0's second operation in front of its first on one machine: the lists are cyclic before the phase starts
+            for s in seqs:
+                for x in (a, b):
+                    if x in s:
+                        s.remove(x)
+            seqs[0] = [b, a] + seqs[0]
+        p["sequences"] = seqs
+    elements = np.arange(n, dtype=np.uint32)[rng.permutation(n)]
+    R = 2
+    d = sfa.build_precedence_shop(p, n_replicas=R, leaves=("list_change",), precedence_policy=policy)
+    d.configure(sfa.SolverConfig(random_seed=1))
+    o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+    o.configure(leaves=4, random_seed=1)
+    o.set_precedence_policy(policy)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    placed = set(x for s in p["sequences"] for x in s)
+    missing = [int(x) for x in elements if int(x) not in placed]
+    sc = d.construct_list_cheapest(0, elements)
+    o.construct_list_cheapest(missing)
+    for r in range(R):
+        assert d.working_lists(0, r) == o.get_lists(0), (policy, start, r)
+        assert (sc[r] == o.score()[:2]).all()
+    assert (d.fresh_score() == sc).all()
+    gst, ost = d.stats(0), o.stats()
+    for c in ("step_count", "moves_accepted", "moves_applied", "score_calculations"):
+        assert gst[c] == ost[c], c
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(5)
+    o.steps(5)
+    assert d.working_lists(0, 0) == o.get_lists(0)
