@@ -2096,6 +2096,7 @@ static int ensure_plf(sf_ctx* ctx) {
     if (!rc) rc = dalloc(ctx, &pl.sE, R * (size_t)std::max(ctx->lm.V, 1));
     if (!rc) rc = dalloc(ctx, &pl.score, R * GRC * 4);
     if (!rc) rc = dalloc(ctx, &pl.visit, R * nn);
+    if (!rc) rc = dalloc(ctx, &pl.cache, R * GL * GRC * 2);
     if (rc) return rc;
     pl.on = 1;
     return SF_OK;

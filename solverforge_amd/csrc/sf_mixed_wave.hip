@@ -514,6 +514,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     __shared__ uint32_t s_plf_info[4][4];
     uint32_t* const plf_info = s_plf_info[threadIdx.x >> 6];
     int64_t* const plf_score = plf_on ? gl.plf.score + (size_t)r * GRC * 4 : nullptr;
+    int64_t* const plf_cache = plf_on ? gl.plf.cache + (size_t)r * GL * GRC * 2 : nullptr;  // the filter's evaluation per ring slot
     if (plf_on) {
         const size_t pn = (size_t)gl.prec.n, pc = (size_t)lm.n_cap;
         plf.latest = gl.plf.latest + (size_t)r * pn, plf.posn = gl.plf.posn + (size_t)r * pn, plf.flag = gl.plf.flag + (size_t)r * pc;
@@ -1027,6 +1028,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     st_sources += 1;
                     bool keep = false;
                     uint32_t w0 = 0, w1 = 0, wx = 0;
+                    int64_t cache_pen = INT64_MIN, cache_mk = 0;  // route-graph filter: the evaluation of this lane's candidate, if it ran
                     if (!FAST && kind == 1) {  // ---- scalar change ----
                         if (g.a >= ns) {
                             g.done = 1;
@@ -1763,6 +1765,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     if (PREC && plf_policy && kind >= 4 && kind != 512 && kind != 1024 && kind != 2048 && kind != 4096 && kind != 16384) {
                         // runtime slot with precedence hooks: intra-list candidates that close a cycle through the route graph never reach the ring
                         uint64_t chk = __ballot(keep && (kind == 64 || kind == 8192 || (w0 >> 16) == (w1 >> 16)));
+                        cache_pen = INT64_MIN, cache_mk = 0;
                         while (chk) {
                             const int ci = __ffsll((unsigned long long)chk) - 1;
                             chk &= chk - 1;
@@ -1776,7 +1779,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                                      list_move_ext_of(kind, ca, cb, cx));
                             wave_sync();
                             bool cyc;
-                            (void)plf_eval(cyc, nullptr);
+                            const PrecResult fpr = plf_eval(cyc, nullptr);
+                            if ((int)lane == ci) cache_pen = fpr.penalty, cache_mk = fpr.makespan;  // what the replay would evaluate again
                             const bool drop = plf_closes_cycle(e, cyc);
                             const uint32_t lo = uni(s_off[e]), hi = uni(s_off[e + 1]);
                             for (uint32_t t = lo + lane; t < hi; t += 64) s_visits[t] = (uint16_t)g_visits[t];
@@ -1790,6 +1794,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         rq[qi * 2] = w0;
                         rq[qi * 2 + 1] = w1;
                         ringx[l * GRC + qi] = (uint8_t)wx;
+                        if (PREC && plf_policy) {
+                            plf_cache[((size_t)l * GRC + qi) * 2] = cache_pen;
+                            plf_cache[((size_t)l * GRC + qi) * 2 + 1] = cache_mk;
+                        }
                     }
                     tl += (uint32_t)__popcll(km);
                 }
@@ -2027,6 +2035,23 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 doable = doable && valid;
                 if (PREC) {
                     uint64_t todo = __ballot(doable && my_kind >= 4 && my_kind != 1024 && my_kind != 16384);
+                    if (plf_policy) {  // the route-graph filter evaluated the intra-list candidates when they were generated
+                        bool cached = false;
+                        if (doable && my_kind >= 4 && my_kind != 1024 && my_kind != 16384) {
+                            const size_t ci_ = ((size_t)my_leaf * GRC + (my_idx & (GRC - 1))) * 2;
+                            const int64_t cp = plf_cache[ci_];
+                            if (cp != INT64_MIN) {
+                                cached = true;
+                                const int64_t cm2 = plf_cache[ci_ + 1];
+#pragma unroll
+                                for (int kk = 0; kk < L; ++kk) {
+                                    if (kk == gl.prec.hard_level) sc.v[kk] -= cp - prec_pen;
+                                    if (kk == gl.prec.mk_level) sc.v[kk] -= cm2 - prec_mk;
+                                }
+                            }
+                        }
+                        todo &= ~__ballot(cached);
+                    }
                     if (prec_sweep && psw.ok) {  // the list change / swap candidates of the chunk: one lane each, scored together
                         const bool cand = doable && (my_kind == 4 || my_kind == 16 || my_kind == 8 || my_kind == 32);
                         const uint64_t cm_ = __ballot(cand);

@@ -54,6 +54,7 @@ struct PlfModel {
     uint32_t* sE;       // [R][V]      support swaps per list
     int64_t* score;     // [R][GRC][4] trial scores of the ring entries
     uint32_t* visit;    // [R][n]      visited marks of the reachability search (cyclic working state only)
+    int64_t* cache;     // [R][GL][GRC][2] (hard penalty, makespan) of the ring entries the route-graph filter evaluated; penalty INT64_MIN = none
 };
 struct PlfRep {  // one replica's slices + the counts of this step (wave-uniform)
     int32_t* latest;
