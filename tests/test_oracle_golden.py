@@ -294,3 +294,72 @@ def test_construction_pipeline_oracle_properties(oracle):
     one = o.get_lists(0)
     st = o.construct_list_k_opt(2, 1)
     assert o.get_lists(0) == one and int(st[1]) == 0 and int(st[0]) == 200 * 199 // 2
+
+
+def test_precedence_selector_goldens_are_in_the_binary(oracle):
+    """heuristic/selector/tests/list_precedence.rs (12 cases), list_ruin.rs:279-303, list_construction/cheapest/tests.rs:244-258."""
+    exe = os.path.join(os.path.dirname(oracle._LIB), "test_golden")
+    out = subprocess.run([exe], capture_output=True, text=True)
+    lines = [l for l in out.stdout.splitlines() if l.startswith(("ok", "FAIL"))]
+    assert sum(l.startswith("ok list_precedence_selector.") for l in lines) == 12
+    assert "ok list_ruin.precedence_ruin_recreate_skips_cycle_forming_insertions" in lines
+    assert "ok list_cheapest.precedence_downstream_breaks_cheapest_ties" in lines
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_precedence_leaf_properties_on_random_shops(oracle, seed):
+    """Size-independent properties of the critical-path leaf and the slot's precedence policy on random job shops: every streamed
+    candidate is doable, no candidate but a ruin leaves a cyclic graph behind (hard penalty < node count after any acyclic-start trial),
+    the filtered streams of the other leaves are sub-sequences of the unfiltered ones, and a local search under the nine-leaf policy
+    never ends worse than it started."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(HERE))
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(3 + seed, 3, seed=seed)
+    n = len(p["durations"])
+    bits_leaf, bits_other = 16384, 4 | 8 | 64 | 128 | 256 | 8192
+
+    def mk(policy):
+        o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+        o.set_precedence_policy(policy)
+        return o
+
+    o = mk(False)
+    o.configure(leaves=bits_leaf, random_seed=seed, selection_order=3)
+    start = o.score()[:2].copy()
+    assert start[0] == 0  # the step-major start is acyclic and on the expected machines
+    moves = o.enumerate(0, 0, 17 + seed, 3)
+    sc, doable = o.evaluate_moves(moves)
+    assert len(moves) > 0 and doable.all()
+    assert (sc[:, 0] > -n).all()  # nothing cyclic survives the pruning (ruins recreate acyclically with the hooks)
+    kinds = set(int(k) for k in moves["kind"])
+    assert {2, 3, 4, 8} <= kinds
+    plain, filt = mk(False), mk(True)
+    dropped = 0
+    for leaf in (4, 8, 64, 128, 256, 8192):  # leaf by leaf: inside a union the scheduler interleaves the shorter streams differently
+        plain.configure(leaves=leaf, random_seed=seed, selection_order=3)
+        filt.configure(leaves=leaf, random_seed=seed, selection_order=3)
+        a = [tuple(int(x[k]) for k in ("kind", "a", "a_pos", "b", "b_pos", "value")) for x in plain.enumerate(0, 1, 5, 3)]
+        fm = filt.enumerate(0, 1, 5, 3)
+        b = [tuple(int(x[k]) for k in ("kind", "a", "a_pos", "b", "b_pos", "value")) for x in fm]
+        it = iter(a)
+        assert all(any(y == x for y in it) for x in b) and len(b) <= len(a), leaf  # a sub-sequence, in order
+        dropped += len(a) - len(b)
+        fs, fd = filt.evaluate_moves(fm)
+        intra = [i for i, x in enumerate(b) if x[1] == x[3] or x[0] in (4, 9)]
+        assert (fs[intra, 0] > -n).all(), leaf  # no surviving intra-list candidate is cyclic
+        ps, pd = plain.evaluate_moves(plain.enumerate(0, 1, 5, 3))
+        kept = set(b)
+        gone = [i for i, x in enumerate(a) if x not in kept]
+        assert (ps[gone, 0] <= -n).all(), leaf  # and every dropped one is
+    assert dropped > 0
+    o = mk(True)
+    o.configure(leaves=bits_leaf | bits_other | 1024, random_seed=seed, la_size=20, limit=64)
+    o.set_ruin(2, 4, 3)
+    o.phase_start()
+    o.steps(25)
+    best = o.best_score()[:2]
+    assert tuple(best) >= tuple(start)
+    assert (o.fresh_score()[:2] == o.score()[:2]).all()
