@@ -530,7 +530,8 @@ int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine); /* sf_engine_kind; SF
 int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine); /* the engine launches resolve to (after sf_initialize) */
 /* explicit step seeds for parity runs (n_steps per replica, replica-major); NULL clears */
 int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps);
-/* ≙ phase start: last_step_score = calculate_score, acceptor.phase_started, best = working */
+/* ≙ phase start: last_step_score = calculate_score, acceptor.phase_started, best = working.  Zeroes the replicas' counters (sf_get_stats
+ * reports the phase's work; the counters of a construction call are read before it) and restarts the step-seed stream */
 int32_t sf_phase_start(sf_ctx* ctx);
 /* ≙ n_steps x execute_step (phase/localsearch/phase/step.rs:30-225) for EVERY replica, fused in
  * one persistent launch (generate -> trial-score -> accept -> forage -> apply). Asynchronous. */
