@@ -1,10 +1,10 @@
 // Generic N-leaf search engine (gfx950 wave64): one wavefront = one replica of a model with an
-// optional scalar class and an optional list class, and a union of up to eight leaves -- scalar
-// change / swap, list change / swap, nearby list change / swap, sublist change / swap, list reverse
-// (2-opt), 3-opt (full or distance-pruned) -- scheduled by the reference's StratifiedRandom union
-// (mixed job shop; CVRP with the default list policy minus ruin; list models without a distance
-// meter).  The two-leaf nearby union of the headline bench has its own engines
-// (sf_list_wave.hip / sf_list_kernels.hip).
+// optional scalar class and an optional list class, and a union of up to twelve leaves -- scalar
+// change / swap (plain and nearby), list change / swap, nearby list change / swap, sublist change / swap, list
+// reverse (2-opt), 3-opt (full or distance-pruned), list ruin, list permute, the critical-path precedence
+// leaf (sf_prec_leaf.h) -- scheduled by the reference's union scheduler (mixed job shop; CVRP under the
+// default list policy; job shops under the nine-leaf policy of a slot with precedence hooks).  The two-leaf
+// nearby union of the headline bench has its own engines (sf_list_wave.hip / sf_list_kernels.hip).
 //
 // Reference semantics restated (paths under crates/solverforge-solver/src/):
 //   heuristic/selector/list_kernel/change.rs:25-241   list change stream (salts :25-30)
