@@ -455,6 +455,15 @@ int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t*
 int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n, int32_t group_name_len,
                        int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores, int32_t* out_flags,
                        int64_t* out_consumed, int64_t* out_selected);
+/* The same step for candidates that carry evaluate_candidate's gates (phase/localsearch/evaluation.rs:75-113): gates[i] bit 0 =
+ * Move::requires_hard_improvement (the candidate is rejected unless hard_score_delta(last step score, move score) is Improving:
+ * the first differing HARD level is greater, phase/hard_delta.rs:11-35; conflict-repair candidates of the runtime provider cursor,
+ * runtime/provider_cursor.rs), bit 1 = Move::requires_score_improvement (rejected unless move score > last step score).  A rejected
+ * candidate is scored and counted (moves_evaluated, score_calculations) but never reaches the acceptor; its flags read doable,
+ * not accepted.  gates = NULL: no gate (sf_step_decide). */
+int32_t sf_step_decide_gated(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
+                             int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
+                             int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected);
 /* committed do_move of one multi-edit candidate */
 int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits);
 

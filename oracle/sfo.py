@@ -119,6 +119,7 @@ def lib():
             "sfo_model_evaluate_compound": (None, [vp, vp, vp, i64, vp, vp]),
             "sfo_model_apply_compound": (None, [vp, vp, i64]),
             "sfo_model_step_grouped": (i64, [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]),
+            "sfo_model_step_grouped_gated": (i64, [vp, vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]),
             "sfo_model_construct_first_fit": (None, [vp]),
             "sfo_model_construct_list_cheapest": (None, [vp, vp, i32]),
             "sfo_model_construct_list_clarke_wright": (i32, [vp, vp, i32, i32, vp]),
@@ -419,7 +420,7 @@ class Model:
         lib().sfo_model_evaluate_compound(self.h, _p(edits), _p(offsets), len(candidates), _p(scores), _p(doable))
         return scores, doable
 
-    def step_grouped(self, candidates, group_name_len=0, max_moves_per_step=0):
+    def step_grouped(self, candidates, group_name_len=0, max_moves_per_step=0, gates=None):
         """One local-search step of a GroupedScalarMoveSelector over `candidates` (the ScalarCandidateProvider's output for the working
         solution): (kept provider indices in pull order, scores [consumed, 4], flags [consumed], selected ordinal or -1)."""
         edits, offsets = compound_wire(candidates)
@@ -428,6 +429,11 @@ class Model:
         scores = np.zeros((max(n, 1), 4), dtype=np.int64)
         flags = np.zeros(max(n, 1), dtype=np.int32)
         consumed, selected = C.c_int64(0), C.c_int64(-1)
+        if gates is not None:  # bit 0 requires_hard_improvement, bit 1 requires_score_improvement (evaluation.rs:75-113)
+            g = np.ascontiguousarray(gates, dtype=np.int32)
+            k = lib().sfo_model_step_grouped_gated(self.h, _p(edits), _p(offsets), _p(g), n, group_name_len, max_moves_per_step, _p(kept), _p(scores),
+                                                   _p(flags), C.byref(consumed), C.byref(selected))
+            return kept[:k], scores[:consumed.value], flags[:consumed.value], int(selected.value)
         k = lib().sfo_model_step_grouped(self.h, _p(edits), _p(offsets), n, group_name_len, max_moves_per_step, _p(kept), _p(scores), _p(flags),
                                          C.byref(consumed), C.byref(selected))
         return kept[:k], scores[:consumed.value], flags[:consumed.value], int(selected.value)

@@ -498,12 +498,22 @@ static std::vector<ScalarEditO> edits_of(const Model& m, const sfo_move_t* edits
 // One local-search step over a ScalarCandidateProvider's output (GroupedScalarMoveSelector, grouped_scalar_step): returns the number
 // of kept candidates; out_kept[n] provider indices in pull order, out_scores4 / out_flags per consumed candidate, *out_consumed,
 // *out_selected = ordinal of the committed candidate or -1.
+int64_t sfo_model_step_grouped_gated(void* h, const sfo_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n, int64_t group_name_len,
+                                     int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_scores4, int32_t* out_flags, int64_t* out_consumed,
+                                     int64_t* out_selected);
 int64_t sfo_model_step_grouped(void* h, const sfo_move_t* edits, const int64_t* offsets, int64_t n, int64_t group_name_len, int64_t max_moves_per_step,
                                int64_t* out_kept, int64_t* out_scores4, int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected) {
+    return sfo_model_step_grouped_gated(h, edits, offsets, nullptr, n, group_name_len, max_moves_per_step, out_kept, out_scores4, out_flags, out_consumed,
+                                        out_selected);
+}
+int64_t sfo_model_step_grouped_gated(void* h, const sfo_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n, int64_t group_name_len,
+                                     int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_scores4, int32_t* out_flags, int64_t* out_consumed,
+                                     int64_t* out_selected) {
     Model* m = (Model*)h;
     std::vector<std::vector<ScalarEditO>> provided;
     for (int64_t i = 0; i < n; ++i) provided.push_back(edits_of(*m, edits, offsets[i], offsets[i + 1]));
-    GroupedStepTrace t = grouped_scalar_step(m->search, provided, (size_t)group_name_len, max_moves_per_step > 0 ? (size_t)max_moves_per_step : 256);
+    GroupedStepTrace t = grouped_scalar_step(m->search, provided, (size_t)group_name_len, max_moves_per_step > 0 ? (size_t)max_moves_per_step : 256,
+                                             gates ? std::vector<int32_t>(gates, gates + n) : std::vector<int32_t>());
     for (size_t i = 0; i < t.kept.size(); ++i) out_kept[i] = (int64_t)t.kept[i];
     for (size_t i = 0; i < t.scores.size(); ++i) {
         std::memcpy(&out_scores4[4 * i], t.scores[i].v, 4 * sizeof(int64_t));

@@ -480,8 +480,17 @@ struct GroupedStepTrace {
     std::vector<int32_t> flags;    // bit0 doable, bit1 accepted, bit2 selected
     int64_t selected = -1;         // ordinal (in `kept`) of the committed candidate
 };
+// hard_score_delta (phase/hard_delta.rs:11-35): +1 Improving, 0 Neutral, -1 Worse by the first differing HARD level; -2 = the score has no hard level
+inline int hard_score_delta(const Score& previous, const Score& candidate, int hard_levels) {
+    for (int k = 0; k < hard_levels; ++k) {
+        if (candidate.v[k] > previous.v[k]) return 1;
+        if (candidate.v[k] < previous.v[k]) return -1;
+    }
+    return hard_levels > 0 ? 0 : -2;
+}
+// gates[i] of provided candidate i: bit 0 Move::requires_hard_improvement, bit 1 Move::requires_score_improvement (evaluation.rs:75-113)
 inline GroupedStepTrace grouped_scalar_step(LocalSearch& ls, const std::vector<std::vector<ScalarEditO>>& provided, size_t group_name_len,
-                                            size_t max_moves_per_step) {
+                                            size_t max_moves_per_step, const std::vector<int32_t>& gates = {}) {
     GroupedStepTrace out;
     ScoreDirector& d = *ls.director;
     uint64_t step_index = ls.phase_step_index;
@@ -543,6 +552,13 @@ inline GroupedStepTrace grouped_scalar_step(LocalSearch& ls, const std::vector<s
         compound_undo(d, cand, undo);
         d.restore_score_state(st);
         ++ls.stats.score_calculations;
+        const int32_t gate = gates.empty() ? 0 : gates[out.kept[id]];
+        if (((gate & 1) && hard_score_delta(ls.last_step_score, move_score, d.hard_levels) != 1) ||
+            ((gate & 2) && !(move_score > ls.last_step_score))) {  // RejectedByHardImprovement / RejectedByScoreImprovement: the acceptor is not asked
+            out.scores.push_back(move_score);
+            out.flags.push_back(1);
+            continue;
+        }
         bool accepted = ls.acceptor->is_accepted(ls.last_step_score, move_score);
         out.scores.push_back(move_score);
         out.flags.push_back(1 | (accepted ? 2 : 0));

@@ -722,6 +722,47 @@ static void cheapest_insertion_cases() {
 // manager/phase_factory/list_construction/cheapest/tests.rs:244-258 (precedence_downstream_breaks_cheapest_ties_...): elements [1, 0], one
 // empty route, every insertion scores the same, hooks = unit durations + "0 precedes 1": element 0 has the longer downstream chain, goes
 // first, and element 1 then takes the first of two equal slots -> [1, 0]
+// phase/localsearch/phase/tests/foraging.rs:113-134 (score_improvement_required_move_rejects_worse_before_acceptor): two candidates that
+// require a score improvement, trial scores -5 and 3 from 0, an acceptor that accepts everything (LateAcceptance whose history is far
+// below), AcceptedCount(1): the -5 never reaches the acceptor, so the step takes the 3; both are evaluated.  And phase/hard_delta.rs.
+static void gate_cases() {
+    Solution s;
+    s.classes.resize(1);
+    s.classes[0].n = 1;
+    s.classes[0].vars.assign(1, std::vector<int64_t>{0});
+    ScoreDirector d;
+    d.working = s;
+    d.levels = 2;
+    d.hard_levels = 1;
+    auto c = std::make_unique<UniConstraint>();  // soft score = {0, -5, +3}[value]
+    c->name = "value cost";
+    c->impact = Impact::Penalty;
+    c->source = ChangeSource::descriptor(0);
+    c->count = [](const Solution& sol) { return sol.classes[0].n; };
+    c->filter = [](const Solution&, size_t) { return true; };
+    c->weight = [](const Solution& sol, size_t i) {
+        static const int64_t cost[3] = {0, 5, -3};
+        return Score::of(0, cost[sol.classes[0].vars[0][i]]);
+    };
+    d.constraints.members.push_back(std::move(c));
+    LocalSearch ls;
+    ls.director = &d;
+    ls.acceptor = std::make_unique<LateAcceptanceAcceptor>(1);  // accepts whatever is >= the late score
+    ls.forager.kind = Forager::AcceptedCount;
+    ls.forager.accepted_count_limit = 1;
+    ls.selection_order = SelectionOrder::Original;
+    ls.phase_start();
+    static_cast<LateAcceptanceAcceptor*>(ls.acceptor.get())->history.assign(1, Score::of(0, -100));  // "always accept"
+    std::vector<std::vector<ScalarEditO>> provided = {{{0, 0, 0, 1, true}}, {{0, 0, 0, 2, true}}};
+    GroupedStepTrace t = grouped_scalar_step(ls, provided, 0, 256, {2, 2});
+    CHECK("gates.score_improvement_required_move_rejects_worse_before_acceptor",
+          ls.stats.moves_evaluated == 2 && ls.stats.moves_applied == 1 && d.calculate_score() == Score::of(0, 3) && t.flags.size() == 2 && t.flags[0] == 1 &&
+              (t.flags[1] & 6) == 6);
+    bool ok = hard_score_delta(Score::of(-2, 0), Score::of(-1, -50), 1) == 1 && hard_score_delta(Score::of(-1, 0), Score::of(-1, 9), 1) == 0 &&
+              hard_score_delta(Score::of(-1, 0), Score::of(-3, 9), 1) == -1 && hard_score_delta(Score::of(0, 0), Score::of(0, 9), 0) == -2;
+    CHECK("gates.hard_score_delta", ok);
+}
+
 static void cheapest_precedence_cases() {
     Solution s;
     s.classes.resize(1);
@@ -1999,6 +2040,7 @@ int main() {
     compound_scalar_cases();
     cheapest_insertion_cases();
     cheapest_precedence_cases();
+    gate_cases();
     balance_cases();
     bi_incr_cases();
     cross_bi_cases();

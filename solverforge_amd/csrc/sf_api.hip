@@ -1398,6 +1398,13 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
 int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n, int32_t group_name_len,
                        int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores, int32_t* out_flags,
                        int64_t* out_consumed, int64_t* out_selected) {
+    return sf_step_decide_gated(ctx, replica, edits, offsets, nullptr, n, group_name_len, max_moves_per_step, out_kept, out_n_kept, out_scores, out_flags,
+                                out_consumed, out_selected);
+}
+// the same step with Move::requires_hard_improvement / requires_score_improvement per candidate (gates[i]: bit 0 / bit 1)
+int32_t sf_step_decide_gated(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
+                             int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
+                             int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_kept || !out_n_kept || !out_scores || !out_flags ||
         !out_consumed || !out_selected)
@@ -1478,10 +1485,13 @@ int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, con
     }
     int32_t* d_edits = nullptr;
     int64_t *d_off = nullptr, *d_sc = nullptr, *d_res = nullptr;
-    int32_t *d_do = nullptr, *d_fl = nullptr;
+    int32_t *d_do = nullptr, *d_fl = nullptr, *d_gates = nullptr;
     auto release = [&]() {
-        (void)hipFree(d_edits), (void)hipFree(d_off), (void)hipFree(d_sc), (void)hipFree(d_res), (void)hipFree(d_do), (void)hipFree(d_fl);
+        (void)hipFree(d_edits), (void)hipFree(d_off), (void)hipFree(d_sc), (void)hipFree(d_res), (void)hipFree(d_do), (void)hipFree(d_fl), (void)hipFree(d_gates);
     };
+    std::vector<int32_t> kgates;  // in pull order
+    if (gates)
+        for (int64_t q : kept) kgates.push_back(gates[q]);
     const size_t nk1 = (size_t)(nk > 0 ? nk : 1);
     hipError_t e = hipMalloc((void**)&d_edits, (kedits.empty() ? 1 : kedits.size()) * 24);
     if (e == hipSuccess) e = hipMalloc((void**)&d_off, (size_t)(nk + 1) * 8);
@@ -1492,6 +1502,10 @@ int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, con
     if (e == hipSuccess && !kedits.empty()) e = hipMemcpyAsync(d_edits, kedits.data(), kedits.size() * 24, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, koff.data(), (size_t)(nk + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_fl, 0, nk1 * 4, ctx->stream);
+    if (e == hipSuccess && !kgates.empty()) {
+        e = hipMalloc((void**)&d_gates, kgates.size() * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_gates, kgates.data(), kgates.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e != hipSuccess) {
         release();
         return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
@@ -1500,7 +1514,7 @@ int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, con
         hipLaunchKernelGGL(k_scalar_evaluate_compound, dim3((int)((nk + 255) / 256)), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, d_edits,
                            d_off, nk, d_sc, d_do);
     hipLaunchKernelGGL(k_scalar_step_decide, dim3(1), dim3(64), scalar_table_bytes(ctx), ctx->stream, ctx->sm, p, replica, d_edits, d_off, nk, d_sc, d_do, d_fl,
-                       d_res);
+                       d_res, (const int32_t*)d_gates, ctx->hard_levels);
     e = hipGetLastError();
     int64_t res[2] = {0, -1};
     if (e == hipSuccess) e = hipMemcpyAsync(res, d_res, 16, hipMemcpyDeviceToHost, ctx->stream);

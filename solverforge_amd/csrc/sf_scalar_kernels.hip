@@ -686,7 +686,8 @@ __global__ __launch_bounds__(64) void k_scalar_apply_compound(ScalarModel m, int
 // acceptor.step_ended, best solution, counters, step index.  One wavefront, replica `replica`.
 SF_PLAIN_KERNEL
 __global__ __launch_bounds__(64) void k_scalar_step_decide(ScalarModel m, SearchParams p, int replica, const int32_t* edits, const int64_t* offsets, int64_t n,
-                                                          const int64_t* scores, const int32_t* doable_in, int32_t* out_flags, int64_t* out_result) {
+                                                          const int64_t* scores, const int32_t* doable_in, int32_t* out_flags, int64_t* out_result,
+                                                          const int32_t* gates, int hard_levels) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];
     constexpr int L = 4;  // scores padded with zero levels: the lexicographic order is unchanged
     const uint32_t lane = threadIdx.x & 63u;
@@ -744,8 +745,25 @@ __global__ __launch_bounds__(64) void k_scalar_step_decide(ScalarModel m, Search
 #pragma unroll
             for (int k = 0; k < L; ++k) sc.v[k] = k < m.levels ? scores[ci * m.levels + k] : 0;
         }
+        // evaluate_candidate's gates (phase/localsearch/evaluation.rs:75-113): a move that requires a hard improvement (bit 0:
+        // hard_score_delta != Improving, phase/hard_delta.rs:11-35) or a score improvement (bit 1: move score <= last step score) is
+        // scored and counted but never reaches the acceptor
+        bool consult = doable;
+        if (doable && gates) {
+            const int32_t g = gates[ci];
+            if (g & 1) {
+                bool improving = false;
+                for (int k = 0; k < hard_levels && k < L; ++k) {
+                    if (sc.v[k] == curv.v[k]) continue;
+                    improving = sc.v[k] > curv.v[k];
+                    break;
+                }
+                consult = improving;
+            }
+            if (consult && (g & 2) && score_cmp<L>(sc, curv) <= 0) consult = false;
+        }
         bool acc = false;
-        if (doable) {
+        if (consult) {
             if (p.acceptor == 0)
                 acc = score_cmp<L>(sc, curv) > 0;
             else if (p.acceptor == 1)

@@ -295,11 +295,22 @@ class GpuScoreDirector:
         check(self._L.sf_step_evaluate_compound(self._h, replica, ptr(edits), ptr(offsets), len(candidates), ptr(scores), ptr(doable)), self._h)
         return scores, doable
 
-    def step_decide(self, candidates, replica=0, group_name_len=0, max_moves_per_step=0):
+    def step_decide(self, candidates, replica=0, group_name_len=0, max_moves_per_step=0, gates=None):
         """One host-driven local-search step over a ScalarCandidateProvider's output (GroupedScalarMoveSelector, sf_step_decide):
-        returns (kept provider indices in pull order, trial scores [consumed, levels], flags [consumed], selected ordinal or -1)."""
+        returns (kept provider indices in pull order, trial scores [consumed, levels], flags [consumed], selected ordinal or -1).
+        gates[i]: bit 0 = the candidate requires a hard improvement, bit 1 = a score improvement (sf_step_decide_gated)."""
         edits, offsets = self._compound_wire(candidates)
         n = len(candidates)
+        if gates is not None:
+            g = np.ascontiguousarray(gates, dtype=np.int32)
+            assert len(g) == n
+            kept = np.zeros(max(n, 1), dtype=np.int64)
+            scores = np.zeros((max(n, 1), self.levels), dtype=np.int64)
+            flags = np.zeros(max(n, 1), dtype=np.int32)
+            nk, consumed, selected = C.c_int64(0), C.c_int64(0), C.c_int64(-1)
+            check(self._L.sf_step_decide_gated(self._h, replica, ptr(edits), ptr(offsets), ptr(g), n, group_name_len, max_moves_per_step, ptr(kept),
+                                               C.byref(nk), ptr(scores), ptr(flags), C.byref(consumed), C.byref(selected)), self._h)
+            return kept[:nk.value], scores[:consumed.value], flags[:consumed.value], int(selected.value)
         kept = np.zeros(max(n, 1), dtype=np.int64)
         scores = np.zeros((max(n, 1), self.levels), dtype=np.int64)
         flags = np.zeros(max(n, 1), dtype=np.int32)

@@ -92,6 +92,53 @@ def test_grouped_selector_steps(oracle, model, acceptor, forager, limit, order, 
     assert (d.calculate_score()[0] == o.score()[:2]).all()
 
 
+@pytest.mark.parametrize("model,acceptor,forager,limit", [("graph", 1, 0, 6), ("graph", 0, 2, 1), ("bins", DLA, 4, 0)])
+def test_gated_candidates(oracle, model, acceptor, forager, limit):
+    """evaluate_candidate's gates (phase/localsearch/evaluation.rs:75-113): candidates that require a hard improvement
+    (hard_score_delta == Improving, phase/hard_delta.rs) or a score improvement are scored and counted but never reach the acceptor
+    -- the conflict-repair candidates of the runtime provider cursor carry the first, multi-swaps the second."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    rng = np.random.default_rng(8)
+    if model == "graph":
+        g = datasets.make_graph(50, 170, 4, seed=3)
+        g["colors"] = rng.integers(-1, 4, 50).astype(np.int64)
+        d = sfa.build_graph_coloring(g)
+        o = oracle.Model.graph_coloring(g["n_colors"], g["adj_off"], g["adj"], g["colors"])
+        k = 4
+    else:
+        k = 5
+        bins = rng.integers(-1, k, 60).astype(np.int64)
+        sizes = rng.integers(1, 9, 60).astype(np.int64)
+        d = sfa.build_balance(bins, sizes, k, w_pair=3, cap=25)
+        o = oracle.Model.balance(k, bins, sizes, w_pair=3, cap=25)
+    d.configure(sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=4, forager=forager, accepted_count_limit=limit, selection_order=3, random_seed=4))
+    o.configure(acceptor=1 if acceptor == DLA else acceptor, la_size=4, forager=forager, limit=limit, selection_order=3, leaves=3, random_seed=4)
+    if acceptor == DLA:
+        d.configure_diversified(0.05)
+        o.configure_diversified(4, 0.05)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    gated_rejections = 0
+    for step in range(20):
+        values = o.get_vars(0, 0)
+        cands = _provider(values, k, rng, int(rng.integers(1, 80)))
+        gates = rng.integers(0, 4, len(cands)).astype(np.int32)
+        gk, gs, gf, gsel = d.step_decide(cands, group_name_len=5, gates=gates)
+        ok, os_, of, osel = o.step_grouped(cands, group_name_len=5, gates=gates)
+        assert len(gk) == len(ok) and (gk == ok).all(), step
+        assert len(gf) == len(of) and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gsel == osel, step
+        gated_rejections += int(((gf & 3) == 1).sum())
+        assert (d.calculate_score()[0] == o.score()[:2]).all(), step
+    assert gated_rejections > 0
+    gst, ost = d.stats(0), o.stats()
+    for c in COUNTERS:
+        assert gst[c] == ost[c], c
+
+
 def test_step_decide_validation():
     import solverforge_amd as sfa
     from solverforge_amd import datasets
