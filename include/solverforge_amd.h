@@ -358,8 +358,9 @@ int32_t sf_selector_add_permute(sf_ctx* ctx, int32_t descriptor_index, int32_t v
  * cyclic are pruned before they count (coordinates.rs:265-326, precedence_route.rs:257-304); the ruins recreate with the precedence hooks
  * (move/list_kernel/ruin.rs:186-220: insertions that close a cycle are skipped).  Moves come back as SF_MOVE_LIST_CHANGE .. SF_MOVE_LIST_PERMUTE,
  * SF_MOVE_LIST_RUIN (value bits 31 / 30 set, see sf_move_t) and SF_MOVE_LIST_MULTI_SWAP.  Generic N-leaf engine; the list class may
- * carry no distance / capacity / not-exists constraint (the ruin's recreate is scored by the precedence constraint alone), fixed
- * successor lists without repeats; SF_ERR_UNSUPPORTED otherwise.  One such leaf per union. */
+ * carry no distance / capacity constraint (the ruin's recreate is scored by the precedence constraint alone; a flattened not-exists is
+ * fine), fixed successor lists without repeats, at most 2,048 nodes (the multi-swap stream is indexed in 32 bits); SF_ERR_UNSUPPORTED
+ * otherwise.  One such leaf per union. */
 int32_t sf_selector_add_precedence(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index);
 
 /* The precedence policy of the compiled runtime list slot (ListVariableSlot::with_precedence_hooks; RuntimeListSlot::precedence_policy):

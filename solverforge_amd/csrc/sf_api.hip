@@ -2178,6 +2178,8 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                 // its ruins recreate by the precedence constraint alone: no other list constraint may score an insertion
                 if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0)
                     return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf on a list class with distance / capacity constraints");
+                // the multi-swap stream (critical x critical x support triples, < nodes^3 / 2) and its row prefixes are indexed in 32 bits
+                if (ctx->prec.dur.size() > 2048) return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf: more than 2,048 nodes");
                 if (int rc = ensure_plf(ctx)) return rc;
                 gl.plf = ctx->plf;
                 gl.plf.leaf = 1;

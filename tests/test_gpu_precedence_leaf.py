@@ -191,6 +191,13 @@ def test_validation():
     d = sfa.build_precedence_shop(q, leaves=("precedence",))
     with pytest.raises(sfa.SolverForgeError):
         d.add_precedence_selector(0)  # one such leaf per union
+    big = datasets.make_precedence_shop(103, 20, seed=1)  # 2,060 nodes: the multi-swap stream is indexed in 32 bits
+    d = sfa.build_precedence_shop(big, leaves=("precedence", "list_swap"))
+    d.configure(sfa.SolverConfig(random_seed=1))
+    d.calculate_score()
+    d.phase_start()
+    with pytest.raises(sfa.SolverForgeError):
+        d.solve_steps(1)
 
 
 # ---- the runtime slot's precedence policy: route-graph filter on the other list leaves, ruin leaf with the hooks --------------------------
