@@ -74,7 +74,8 @@ typedef enum sf_move_kind {
     SF_MOVE_LIST_MULTI_SWAP = 10, /* heuristic/move/list_kernel/multi_swap.rs:13-128 (ListMultiSwapMove, emitted by the critical-path leaf): `a` swaps in
                                     pairwise different lists applied as one move; a_pos / b / b_pos = (list | first position << 16) of swap 0 / 1 / 2,
                                     value = (second - first) of each swap, one byte per swap.  Requires a score improvement
-                                    (phase/localsearch/evaluation.rs:95-113).  sf_evaluate_moves / sf_apply_move do not take it */
+                                    (phase/localsearch/evaluation.rs:95-113).  sf_step_evaluate scores it (independent lists: the deltas add), sf_apply
+                                    commits it */
     SF_MOVE_LIST_PERMUTE = 9,  /* heuristic/move/list_kernel/permute.rs:22-72 (ListPermuteMove): the window [a_pos, b_pos) of list `a`
                                   (b = a, 2..8 positions) reordered by the value-th permutation of its positions in lexicographic
                                   order (nth_permutation, selector/list_kernel/permute.rs:260-272; value >= 1, 0 would be the identity) */

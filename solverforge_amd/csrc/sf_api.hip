@@ -1557,6 +1557,28 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         if (!ok) return fail(ctx, SF_ERR_INVALID, "move is not doable");
         return SF_OK;
     }
+    if (mv->kind == SF_MOVE_LIST_MULTI_SWAP) {  // the lists are pairwise different: the swaps commute, so they are committed one after the other
+        if (!ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
+        if (mv->a < 1 || mv->a > 3) return fail(ctx, SF_ERR_INVALID, "multi-swap: 1..3 swaps");
+        sf_move_t one[3];
+        const int32_t words[3] = {mv->a_pos, mv->b, mv->b_pos};
+        for (int q = 0; q < mv->a; ++q) {
+            const uint32_t w = (uint32_t)words[q];
+            const int32_t dl = (int32_t)(int8_t)(((uint32_t)mv->value >> (8 * q)) & 0xFFu);
+            one[q] = sf_move_t{SF_MOVE_LIST_SWAP, (int32_t)(w & 0xFFFFu), (int32_t)(w >> 16), (int32_t)(w & 0xFFFFu), (int32_t)(w >> 16) + dl, -1};
+            for (int q2 = 0; q2 < q; ++q2)
+                if (one[q2].a == one[q].a) return fail(ctx, SF_ERR_INVALID, "multi-swap: the swaps must touch pairwise different lists");
+            if (dl == 0 || one[q].b_pos < 0) return fail(ctx, SF_ERR_INVALID, "multi-swap: a swap needs two different positions");
+        }
+        for (int q = 0; q < mv->a; ++q) {
+            const int32_t rc2 = sf_apply(ctx, replica, &one[q]);
+            if (rc2 != SF_OK) {
+                for (int q2 = q - 1; q2 >= 0; --q2) (void)sf_apply(ctx, replica, &one[q2]);  // a swap is its own inverse
+                return rc2;
+            }
+        }
+        return SF_OK;
+    }
     const bool list_move = (mv->kind >= SF_MOVE_LIST_CHANGE && mv->kind <= SF_MOVE_KOPT) || mv->kind == SF_MOVE_LIST_PERMUTE;
     if (list_move && !ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
     if (!list_move && !ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "scalar move on a model without a scalar variable");

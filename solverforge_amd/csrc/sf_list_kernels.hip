@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
                                                              int32_t* out_doable, int skip_foreign) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    if (skip_foreign && (moves[t * 6] < 2 || moves[t * 6] > 7)) return;  // a scalar move of a mixed model
+    if (skip_foreign && (moves[t * 6] < 2 || (moves[t * 6] > 7 && moves[t * 6] != 9 && moves[t * 6] != 10))) return;  // a scalar move of a mixed model
     const uint32_t* visits = m.visits + (size_t)replica * m.n_cap;
     const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
     const int64_t* load = m.load + (size_t)replica * m.V;
@@ -882,6 +882,30 @@ __global__ __launch_bounds__(256) void k_list_evaluate_moves(ListModel m, int re
     ListDelta d{0, 0, false};
     // (a 3-opt move carries its middle cut in `b`, not an entity)
     bool in_range = mv[1] >= 0 && mv[1] < m.V && mv[3] >= 0 && (kind == 7 || mv[3] < m.V) && mv[2] >= 0 && mv[4] >= 0;
+    if (kind == 10) {  // ListMultiSwapMove: `a` swaps (list | first << 16) in pairwise different lists, value = (second - first) per swap, one byte each:
+                       // independent lists, so the deltas add (multi_swap_is_doable, move/list_kernel/multi_swap.rs:30-60)
+        in_range = false;
+        const int cnt = mv[1];
+        bool ok = cnt >= 1 && cnt <= 3;
+        uint32_t le[3] = {0, 0, 0};
+        ListDelta sum{0, 0, true};
+        for (int q = 0; q < cnt && ok; ++q) {
+            const uint32_t w = (uint32_t)mv[2 + q];
+            const uint32_t e = w & 0xFFFFu, f = w >> 16;
+            const int32_t dl = (int32_t)(int8_t)(((uint32_t)mv[5] >> (8 * q)) & 0xFFu);
+            const int64_t g = (int64_t)f + dl;
+            ok = e < (uint32_t)m.V && dl != 0 && g >= 0;
+            for (int q2 = 0; q2 < q && ok; ++q2) ok = le[q2] != e;
+            le[q] = e;
+            if (!ok) break;
+            const ListDelta one = eval_list_swap(m, visits, off, load, e, f, e, (uint32_t)g);
+            ok = one.doable;
+            sum.d_dist = wadd(sum.d_dist, one.d_dist);
+            sum.d_cap = wadd(sum.d_cap, one.d_cap);
+        }
+        sum.doable = ok;
+        if (ok) d = sum;
+    }
     if (in_range) {
         if (kind == 2)
             d = eval_list_change(m, visits, off, load, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4]);

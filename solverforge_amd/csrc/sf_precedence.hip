@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void k_prec_evaluate_moves(ListModel m, PrecMod
     const int64_t i = base + blockIdx.x;
     const int32_t* mv = moves + i * 6;
     const int kind = mv[0];
-    if (kind < 2 || (kind > 7 && kind != 9) || !doable[i]) return;
+    if (kind < 2 || (kind > 7 && kind != 9 && kind != 10) || !doable[i]) return;
     const uint32_t lane = threadIdx.x & 63u;
     const PrecMoveCarve cv(m.V, m.n_cap);
     int64_t* s_load = (int64_t*)(smem + cv.load);
@@ -180,8 +180,18 @@ __global__ __launch_bounds__(64) void k_prec_evaluate_moves(ListModel m, PrecMod
     const uint32_t tot = uni(s_off[m.V]);
     for (uint32_t t = lane; t < tot; t += 64) s_visits[t] = (uint16_t)g_visits[t];
     wave_sync();
-    apply_list_move_wave(m, s_visits, s_off, s_load, kind, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4],
-                         (uint32_t)(mv[5] > 0 ? mv[5] : 0));
+    if (kind == 10) {  // multi-swap: one lane per swap (pairwise different lists)
+        if (lane < (uint32_t)mv[1]) {
+            const uint32_t w = (uint32_t)mv[2 + lane];
+            const uint32_t base_ = s_off[w & 0xFFFFu], f = w >> 16;
+            const uint32_t g = (uint32_t)((int32_t)f + (int32_t)(int8_t)(((uint32_t)mv[5] >> (8 * lane)) & 0xFFu));
+            const uint16_t x = s_visits[base_ + f], y = s_visits[base_ + g];
+            s_visits[base_ + f] = y, s_visits[base_ + g] = x;
+        }
+        wave_sync();
+    } else
+        apply_list_move_wave(m, s_visits, s_off, s_load, kind, (uint32_t)mv[1], (uint32_t)mv[2], (uint32_t)mv[3], (uint32_t)mv[4],
+                             (uint32_t)(mv[5] > 0 ? mv[5] : 0));
     const size_t n = (size_t)pm.n, slot = blockIdx.x;
     const PrecResult pr = prec_eval<uint16_t>(pm, s_visits, s_off, m.V, pm.earliest + slot * n, pm.indeg + slot * n, pm.queue + slot * n,
                                               pm.lsucc + slot * n);

@@ -70,6 +70,10 @@ def test_streams_with_trial_scores(oracle, scratch, jobs, machines, seed, leaves
             os_, od = o.evaluate_moves(om)
             assert (gd == od).all() and (gs == os_[:, :2]).all(), (order, si)
             seen |= set(int(k) for k in _t(gm)[:, 0])
+            host = om[om["kind"] != 8]  # sf_step_evaluate on host-provided records (every kind but the ruins, multi-swaps included)
+            es, ed = d.evaluate_moves(host)
+            hs, hd = o.evaluate_moves(host)
+            assert (ed == hd).all() and (es == hs[:, :2]).all(), (order, si)
     assert {2, 3, 4, 8} <= seen  # change, swap, reverse, ruin at least
     if jobs >= 6:
         assert {5, 6, 9, 10} <= seen  # sublist change / swap, permutation, multi-swap
@@ -107,6 +111,25 @@ def test_four_level_score_and_no_expected_owner(oracle):
         o.steps(15)
         assert (scores[r] == o.score()[:4]).all(), r
         assert d.working_lists(0, r) == o.get_lists(0), r
+
+
+def test_multi_swap_through_sf_apply(oracle):
+    """A multi-swap the cursor handed out is committed by sf_apply (three swaps in pairwise different lists, as one move)."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(6, 4, seed=3)
+    d, mk, bits = _pair(oracle, p, ("precedence",), 2)
+    o = mk(2)
+    d.calculate_score()
+    om = o.enumerate(0, 0, 9, 3)
+    ms = om[om["kind"] == 10]
+    assert len(ms) > 0
+    for mv in (ms[0], ms[len(ms) // 2]):
+        o.apply_move(mv)
+        d.apply_move(mv)
+        assert d.working_lists(0, 0) == o.get_lists(0)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
 
 
 def test_traced_and_fused_steps(oracle, scratch):
