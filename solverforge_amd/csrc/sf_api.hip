@@ -1238,6 +1238,33 @@ static hipError_t launch_ruin_moves(sf_ctx* ctx, int replica, const int32_t* d_m
     return e;
 }
 
+// SF_MOVE_LIST_RUIN records on a precedence model: k_prec_ruin_moves, at most R records per launch (one scratch slot each)
+static int ensure_plf(sf_ctx* ctx);
+static int launch_prec_ruin_moves(sf_ctx* ctx, int replica, const int32_t* d_moves, const std::vector<int32_t>& which, int64_t* d_sc, int32_t* d_do, int commit) {
+    if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin move on a precedence model with distance / capacity constraints");
+    if (int rc = ensure_plf(ctx)) return rc;
+    const size_t lds = (((size_t)ctx->lm.V + 1 + 3) & ~(size_t)3) * 4 + (size_t)ctx->lm.n_cap * 2 + 16;
+    if (ctx->lm.n_cap > 65535 || lds > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin moves: the list class must fit one wave's LDS slice with 16-bit elements");
+    const SelectorSpec* rs = ruin_selector(ctx);
+    const int skip_empty = rs ? rs->skip_empty : 0;
+    const int lvl_order = ctx->pm.hard_level < ctx->pm.mk_level ? 0 : (ctx->pm.hard_level > ctx->pm.mk_level ? 1 : 2);
+    int32_t* d_idx = nullptr;
+    hipError_t e = hipMalloc((void**)&d_idx, which.size() * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, which.data(), which.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_prec_ruin_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (size_t base = 0; base < which.size() && e == hipSuccess; base += (size_t)ctx->R) {
+        const unsigned chunk = (unsigned)std::min<size_t>((size_t)ctx->R, which.size() - base);
+        hipLaunchKernelGGL(k_prec_ruin_moves, dim3(chunk), dim3(64), lds, ctx->stream, ctx->lm, ctx->pm, ctx->plf, replica, d_moves, d_idx + base, d_sc, d_do, commit,
+                           lvl_order, ctx->prec_policy ? 1 : 0, skip_empty);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_idx);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return SF_OK;
+}
+
 int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, int64_t n, int64_t* out_scores,
                          int32_t* out_doable) {
     DeviceGuard _dev(ctx);
@@ -1277,7 +1304,13 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
         std::vector<int32_t> which;
         for (int64_t i = 0; i < n; ++i)
             if (moves[i].kind == SF_MOVE_LIST_RUIN) which.push_back((int32_t)i);
-        if (!which.empty()) {
+        if (!which.empty() && ctx->pm.on) {  // precedence model: the recreate is scored by the precedence constraint (k_prec_ruin_moves)
+            const int rc2 = launch_prec_ruin_moves(ctx, replica, d_moves, which, d_sc, d_do, 0);
+            if (rc2) {
+                release();
+                return rc2;
+            }
+        } else if (!which.empty()) {
             if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || RuinMoveCarve(ctx->lm.V, ctx->lm.n_cap).total > SF_LDS_BUDGET) {
                 release();
                 return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin moves: the list class must fit one wave's LDS slice with 16-bit elements");
@@ -1291,11 +1324,6 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
             release();
             return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence moves: the list class must fit one wave's LDS slice with 16-bit elements");
         }
-        for (int64_t i = 0; i < n; ++i)
-            if (moves[i].kind == SF_MOVE_LIST_RUIN) {
-                release();
-                return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin move on a model with precedence hooks");
-            }
         e = hipFuncSetAttribute((const void*)k_prec_evaluate_moves, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
         for (int64_t base = 0; base < n && e == hipSuccess; base += ctx->R) {
             const int chunk = (int)std::min<int64_t>(ctx->R, n - base);
@@ -1536,7 +1564,26 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
     if (rc) return rc;
     if (mv->kind == SF_MOVE_LIST_RUIN) {  // committed ruin + recreate: its own kernel (one wavefront)
         if (!ctx->has_list_model) return fail(ctx, SF_ERR_INVALID, "list move on a model without a list variable");
-        if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin move on a model with precedence hooks");
+        if (ctx->pm.on) {  // the recreate by the precedence constraint; the committed scores are refreshed from the new lists
+            int32_t* d_mv = nullptr;
+            int64_t* d_sc = nullptr;
+            int32_t* d_do = nullptr;
+            hipError_t e = hipMalloc((void**)&d_mv, 24);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_sc, 4 * 8);
+            if (e == hipSuccess) e = hipMalloc((void**)&d_do, 4);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_mv, mv, 24, hipMemcpyHostToDevice, ctx->stream);
+            int32_t ok = 0;
+            int rc2 = SF_OK;
+            if (e == hipSuccess) rc2 = launch_prec_ruin_moves(ctx, replica, d_mv, std::vector<int32_t>{0}, d_sc, d_do, 1);
+            if (e == hipSuccess && rc2 == SF_OK) e = hipMemcpy(&ok, d_do, 4, hipMemcpyDeviceToHost);
+            (void)hipFree(d_mv);
+            (void)hipFree(d_sc);
+            (void)hipFree(d_do);
+            if (rc2) return rc2;
+            if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+            if (!ok) return fail(ctx, SF_ERR_INVALID, "move is not doable");
+            return run_evaluate_all(ctx, nullptr, 1);
+        }
         if (ctx->has_scalar_model) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_apply of a list ruin on a mixed model");
         if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || RuinMoveCarve(ctx->lm.V, ctx->lm.n_cap).total > SF_LDS_BUDGET)
             return fail(ctx, SF_ERR_UNSUPPORTED, "list ruin moves: the list class must fit one wave's LDS slice with 16-bit elements");

@@ -201,4 +201,160 @@ __global__ __launch_bounds__(64) void k_prec_evaluate_moves(ListModel m, PrecMod
     }
 }
 
+
+// SF_MOVE_LIST_RUIN records of a host batch on a precedence model (sf_step_evaluate / sf_apply): record which[blockIdx.x] of `moves`
+// against replica `replica`, one wavefront each, scratch slot = blockIdx.x (< R).  The recreate of sf_mixed_wave.hip's plf_ruin,
+// restated over HBM scratch: per round one forward evaluation + one backward pass, per remaining element plf_best_slot (exact on
+// acyclic lists) or the one-evaluation-per-slot slide; `hooks`: insertions that close a cycle are skipped (the record's flag bit 31,
+// or the slot's precedence policy).  Writes the trial score (commit = 0) or commits the lists of the replica (commit = 1; the caller
+// refreshes the committed scores).
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(64) void k_prec_ruin_moves(ListModel lm, PrecModel pm, PlfModel pl, int replica, const int32_t* __restrict__ moves,
+                                                        const int32_t* __restrict__ which, int64_t* out_scores, int32_t* out_doable, int commit, int order,
+                                                        int policy, int leaf_skip_empty) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t s_info[4];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int64_t i = which[blockIdx.x];
+    const int32_t* mv = moves + i * 6;
+    const int V = lm.V;
+    const size_t pn = (size_t)pm.n, pc = (size_t)lm.n_cap, slot = blockIdx.x;
+    uint32_t* off = (uint32_t*)smem;
+    uint16_t* visits = (uint16_t*)(off + (((size_t)V + 1 + 3) & ~(size_t)3));
+    uint32_t* g_visits = lm.visits + (size_t)replica * lm.n_cap;
+    uint32_t* g_off = lm.off + (size_t)replica * (V + 1);
+    PlfRep t{};
+    t.latest = pl.latest + slot * pn, t.flag = pl.flag + slot * pc, t.roff = pl.roff + slot * (pn + 2), t.first = pl.first + slot * pc;
+    t.cnl = pl.cnl + slot * pn, t.visit = pl.visit + slot * pn;
+    int32_t* E = pm.earliest + slot * pn;
+    int32_t* D = pm.indeg + slot * pn;
+    uint32_t* Q = pm.queue + slot * pn;
+    uint32_t* S = pm.lsucc + slot * pn;
+    for (uint32_t q = lane; q <= (uint32_t)V; q += 64) off[q] = g_off[q];
+    plf_sync();
+    const uint32_t tot0 = plf_uni(off[V]);
+    for (uint32_t q = lane; q < tot0; q += 64) visits[q] = (uint16_t)g_visits[q];
+    plf_sync();
+    // ---- the record (include/solverforge_amd.h: SF_MOVE_LIST_RUIN) ----
+    const uint32_t cnt = (uint32_t)mv[2];
+    const bool flagged = cnt <= 5 && ((uint32_t)mv[5] & 0x80000000u) != 0u;
+    const bool multi = flagged && ((uint32_t)mv[5] & 0x40000000u) != 0u;
+    const uint32_t second = ((uint32_t)mv[5] >> 16) & 0x3FFFu;
+    const bool hooks = flagged || policy != 0;
+    const bool skip_empty = (flagged && (!policy || multi)) ? false : leaf_skip_empty != 0;
+    uint32_t el[PLF_EL_MAX], vals[PLF_EL_MAX];
+    bool ok = cnt >= 1 && cnt <= PLF_EL_MAX && mv[1] >= 0 && mv[1] < V && (!multi || (cnt == 2 && second < (uint32_t)V));
+#pragma unroll
+    for (uint32_t k = 0; k < PLF_EL_MAX; ++k) {
+        const uint32_t w3 = k < 2 ? (uint32_t)mv[3] : (k < 4 ? (uint32_t)mv[4] : (uint32_t)mv[5]);
+        uint32_t pos = (w3 >> (16u * (k & 1u))) & 0xFFFFu;
+        if (flagged && k == 5) pos = 0;
+        const uint32_t list = (multi && k == cnt - 1) ? second : (uint32_t)mv[1];
+        el[k] = (list << 16) | pos;
+        vals[k] = 0;
+        if (ok && k < cnt) {
+            ok = pos < off[list + 1] - off[list];
+            if (k > 0 && el[k] <= el[k - 1]) ok = false;  // ascending (list, position)
+        }
+    }
+    ok = plf_uni(ok ? 1u : 0u) != 0u;
+    if (lane == 0) out_doable[i] = ok ? 1 : 0;
+    if (!ok) return;
+    const int64_t pen0 = pm.state[(size_t)replica * 2], mk0 = pm.state[(size_t)replica * 2 + 1];
+    auto key_of = [&](int64_t pen, int64_t mk, uint64_t& k1, uint64_t& k2) {
+        k1 = (uint64_t)(order == 0 ? pen : (order == 1 ? mk : pen + mk));
+        k2 = (uint64_t)(order == 0 ? mk : (order == 1 ? pen : 0));
+    };
+    for (uint32_t k = cnt; k-- > 0;) {
+        const uint32_t x = plf_list_remove(visits, off, V, el[k] >> 16, el[k] & 0xFFFFu);
+#pragma unroll
+        for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
+            if (q == k) vals[q] = x;
+    }
+    uint32_t remaining = (1u << cnt) - 1u;
+    int64_t last_pen = pen0, last_mk = mk0;
+    bool rolled = false;
+    for (uint32_t round = 0; round < cnt && !rolled; ++round) {
+        bool have = false;
+        uint64_t b1 = ~0ull, b2 = ~0ull;
+        int64_t b_pen = 0, b_mk = 0;
+        uint32_t b_ri = 0, b_e = 0, b_pos = 0;
+        const PrecResult base = prec_eval<uint16_t, PrecMemGlobal>(pm, visits, off, V, E, D, Q, S, t.first, s_info, t.roff);
+        plf_sync();
+        const bool base_cyc = plf_uni(s_info[1]) != 0u;
+        if (!base_cyc) plf_tails<PrecMemGlobal>(pm, t, Q, S, plf_uni(s_info[2]));
+        for (uint32_t ri = 0; ri < cnt; ++ri) {
+            if (!((remaining >> ri) & 1u)) continue;
+            uint32_t x = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
+                if (q == ri) x = vals[q];
+            x = plf_uni(x);
+            if (!base_cyc) {
+                PlfSlotPick pk{0, 0, 0, 0, 0};
+                plf_best_slot<PrecMemGlobal, uint16_t>(pk, pm, t, visits, off, V, E, S, base.penalty, (int32_t)base.makespan, x, hooks, skip_empty, order);
+                if (pk.found) {
+                    uint64_t k1, k2;
+                    key_of(pk.pen, pk.mk, k1, k2);
+                    if (!have || k1 < b1 || (k1 == b1 && k2 < b2)) have = true, b1 = k1, b2 = k2, b_pen = pk.pen, b_mk = pk.mk, b_ri = ri, b_e = pk.e, b_pos = pk.k;
+                }
+                continue;
+            }
+            plf_list_insert(visits, off, V, 0, 0, x);
+            uint32_t e = 0, pos = 0, g = 0;
+            for (;;) {
+                const uint32_t others = plf_uni(off[e + 1] - off[e]) - 1u;
+                if (!(skip_empty && others == 0u)) {
+                    const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(pm, visits, off, V, E, D, Q, S, nullptr, s_info, nullptr);
+                    plf_sync();
+                    const bool cyc = plf_uni(s_info[1]) != 0u;
+                    if (!(cyc && hooks)) {
+                        uint64_t k1, k2;
+                        key_of(pr.penalty, pr.makespan, k1, k2);
+                        if (!have || k1 < b1 || (k1 == b1 && k2 < b2)) have = true, b1 = k1, b2 = k2, b_pen = pr.penalty, b_mk = pr.makespan, b_ri = ri, b_e = e, b_pos = pos;
+                    }
+                }
+                if (pos < others) {
+                    if (lane == 0) {
+                        const uint16_t y = visits[g + 1];
+                        visits[g + 1] = (uint16_t)x;
+                        visits[g] = y;
+                    }
+                    g += 1, pos += 1;
+                } else if (e + 1 < (uint32_t)V) {
+                    if (lane == 0) off[e + 1] -= 1;
+                    e += 1, pos = 0;
+                } else
+                    break;
+                plf_sync();
+            }
+            if (lane == 0) off[V] -= 1;
+            plf_sync();
+        }
+        if (!have) {
+            rolled = true;
+            break;
+        }
+        b_ri = plf_uni(b_ri), b_e = plf_uni(b_e), b_pos = plf_uni(b_pos);
+        uint32_t bx = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PLF_EL_MAX; ++q)
+            if (q == b_ri) bx = vals[q];
+        plf_list_insert(visits, off, V, b_e, b_pos, plf_uni(bx));
+        remaining &= ~(1u << b_ri);
+        last_pen = b_pen, last_mk = b_mk;
+    }
+    if (rolled) last_pen = pen0, last_mk = mk0;  // restore_removed_elements: the move leaves the lists as they were
+    if (lane == 0) {
+        for (int k = 0; k < lm.levels; ++k) out_scores[i * lm.levels + k] = lm.score[(size_t)replica * 4 + k];
+        out_scores[i * lm.levels + pm.hard_level] -= last_pen - pen0;
+        out_scores[i * lm.levels + pm.mk_level] -= last_mk - mk0;
+    }
+    if (commit && !rolled) {
+        const uint32_t tot = plf_uni(off[V]);
+        for (uint32_t q = lane; q < tot; q += 64) g_visits[q] = visits[q];
+        for (uint32_t q = lane; q <= (uint32_t)V; q += 64) g_off[q] = off[q];
+    }
+}
+
 }  // namespace sf

@@ -70,10 +70,8 @@ def test_streams_with_trial_scores(oracle, scratch, jobs, machines, seed, leaves
             os_, od = o.evaluate_moves(om)
             assert (gd == od).all() and (gs == os_[:, :2]).all(), (order, si)
             seen |= set(int(k) for k in _t(gm)[:, 0])
-            host = om[om["kind"] != 8]  # sf_step_evaluate on host-provided records (every kind but the ruins, multi-swaps included)
-            es, ed = d.evaluate_moves(host)
-            hs, hd = o.evaluate_moves(host)
-            assert (ed == hd).all() and (es == hs[:, :2]).all(), (order, si)
+            es, ed = d.evaluate_moves(om)  # sf_step_evaluate on host-provided records: every kind, multi-swaps and ruins with hooks included
+            assert (ed == od).all() and (es == os_[:, :2]).all(), (order, si)
     assert {2, 3, 4, 8} <= seen  # change, swap, reverse, ruin at least
     if jobs >= 6:
         assert {5, 6, 9, 10} <= seen  # sublist change / swap, permutation, multi-swap
@@ -113,23 +111,26 @@ def test_four_level_score_and_no_expected_owner(oracle):
         assert d.working_lists(0, r) == o.get_lists(0), r
 
 
-def test_multi_swap_through_sf_apply(oracle):
-    """A multi-swap the cursor handed out is committed by sf_apply (three swaps in pairwise different lists, as one move)."""
+def test_multi_swaps_and_ruins_through_sf_apply(oracle):
+    """Moves the cursor handed out are committed by sf_apply: a multi-swap (three swaps in pairwise different lists, as one move), a
+    ruin window and a two-block ruin, both recreated with the precedence hooks."""
     from solverforge_amd import datasets
 
     p = datasets.make_precedence_shop(6, 4, seed=3)
     d, mk, bits = _pair(oracle, p, ("precedence",), 2)
     o = mk(2)
     d.calculate_score()
-    om = o.enumerate(0, 0, 9, 3)
-    ms = om[om["kind"] == 10]
-    assert len(ms) > 0
-    for mv in (ms[0], ms[len(ms) // 2]):
+    for it, pick in enumerate((10, 8, 10, 8, 8)):
+        om = o.enumerate(0, it, 9 + it, 3)
+        ms = om[om["kind"] == pick]
+        if len(ms) == 0:
+            continue
+        mv = ms[(7 * it) % len(ms)]
         o.apply_move(mv)
         d.apply_move(mv)
-        assert d.working_lists(0, 0) == o.get_lists(0)
-        assert (d.calculate_score()[0] == o.score()[:2]).all()
-        assert (d.fresh_score()[0] == o.score()[:2]).all()
+        assert d.working_lists(0, 0) == o.get_lists(0), it
+        assert (d.calculate_score()[0] == o.score()[:2]).all(), it
+        assert (d.fresh_score()[0] == o.score()[:2]).all(), it
 
 
 def test_traced_and_fused_steps(oracle, scratch):
