@@ -325,8 +325,11 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, i
  * unassigned nodes + node_count if the graph of fixed + consecutive-list-item edges is cyclic) on `hard_level`, -(longest
  * duration-weighted path, 0 when cyclic) on `makespan_level` (the reference fixes HardSoftScore::of(-penalty, -makespan)).
  * Every trial is one full evaluation of the trial lists (Kahn over the whole graph by one wavefront); the search runs in the
- * generic N-leaf engine.  Limits: element ids < node_count, every element in at most one list position, sum of durations < 2^31,
- * no ruin leaf / cheapest-insertion construction (the reference's "precedence hooks" restriction). */
+ * generic N-leaf engine.  Limits: element ids < node_count, every element in at most one list position, sum of durations < 2^31.
+ * The constraint's successors and durations double as the list slot's precedence hooks: the critical-path leaf
+ * (sf_selector_add_precedence), the slot's precedence policy (sf_list_set_precedence_policy), the ruin leaf and ruin records
+ * (recreated by this constraint alone: no distance / capacity constraint on the list class) and cheapest insertion
+ * (sf_construct_list_cheapest) read them; Clarke-Wright, round-robin and ListKOpt construction refuse the model. */
 int32_t sf_constraint_add_list_precedence(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t node_count,
                                           const int32_t* durations, const uint32_t* succ_offsets, const uint32_t* succ_values,
                                           const int32_t* expected_owner, int32_t hard_level, int32_t makespan_level);
