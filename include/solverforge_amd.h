@@ -329,7 +329,8 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t descriptor_index, i
  * The constraint's successors and durations double as the list slot's precedence hooks: the critical-path leaf
  * (sf_selector_add_precedence), the slot's precedence policy (sf_list_set_precedence_policy), the ruin leaf and ruin records
  * (recreated by this constraint alone: no distance / capacity constraint on the list class) and cheapest insertion
- * (sf_construct_list_cheapest) read them; Clarke-Wright, round-robin and ListKOpt construction refuse the model. */
+ * (sf_construct_list_cheapest) read them; round-robin construction scores no trial and takes the model as it is; Clarke-Wright and
+ * ListKOpt (distance-matrix route hooks) refuse it. */
 int32_t sf_constraint_add_list_precedence(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, int32_t node_count,
                                           const int32_t* durations, const uint32_t* succ_offsets, const uint32_t* succ_values,
                                           const int32_t* expected_owner, int32_t hard_level, int32_t makespan_level);

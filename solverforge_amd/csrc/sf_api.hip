@@ -1819,7 +1819,6 @@ int32_t sf_construct_list_round_robin(sf_ctx* ctx, int32_t descriptor_index, con
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "round robin needs the list variable's class");
     if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_round_robin arguments");
     if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || n > 65535) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
-    if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "round-robin construction on a model with precedence hooks");
     std::vector<int32_t> order;
     {
         std::vector<bool> seen((size_t)ctx->lm.dim, false);

@@ -485,3 +485,30 @@ def test_cheapest_insertion_construction_on_a_precedence_model(oracle, policy, s
     d.solve_steps(5)
     o.steps(5)
     assert d.working_lists(0, 0) == o.get_lists(0)
+
+
+def test_round_robin_construction_on_a_precedence_model(oracle):
+    """The round-robin phase scores no trial: unassigned operations are dealt onto the machines in order, the committed score carries the
+    precedence constraint."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(6, 4, seed=9, scheduled=False)
+    n = len(p["durations"])
+    d = sfa.build_precedence_shop(p, n_replicas=2, leaves=("list_change", "list_swap"))
+    d.configure(sfa.SolverConfig(random_seed=3))
+    o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+    o.configure(leaves=4 | 8, random_seed=3)
+    d.calculate_score()
+    rng = np.random.default_rng(2)
+    els = rng.permutation(n).astype(np.uint32)
+    owners = np.where(rng.random(n) < 0.5, p["expected_owner"][els], -1).astype(np.int32)
+    sc = d.construct_list_round_robin(0, els, owners=owners)
+    o.construct_list_round_robin(els, owners=owners)
+    assert d.working_lists(0, 1) == o.get_lists(0)
+    assert (sc[0] == o.score()[:2]).all() and (d.fresh_score()[1] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(8)
+    o.steps(8)
+    assert d.working_lists(0, 0) == o.get_lists(0) and (d.calculate_score()[0] == o.score()[:2]).all()
