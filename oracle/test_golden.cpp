@@ -622,6 +622,61 @@ static void list_ruin_cases() {
              d.working.classes[0].lists[1] == std::vector<uint32_t>({5, 6, 7}) && d.cached == d.fresh_score();
         CHECK("list_ruin.undo_restores_every_list", ok);
     }
+    {  // ruin_recreate_restores_multiple_source_entities (:307-338): new_multi_source over two lists, four elements, do + undo
+        ScoreDirector d = mk({{1, 2, 3, 4}, {5, 6, 7}}, true);
+        d.calculate_score();
+        Move m;
+        m.kind = Move::Ruin;
+        m.a = m.b = 0;
+        m.a_pos = 4;
+        m.ruin_multi = true;
+        const uint16_t idx[4] = {1, 3, 0, 2}, src[4] = {0, 0, 1, 1};
+        for (int i = 0; i < 4; ++i) m.ruin_idx[i] = idx[i], m.ruin_src[i] = src[i];
+        bool ok = move_is_doable(d, m);
+        MoveUndo u = move_do(d, m);
+        ok = ok && d.working.classes[0].lists[0].size() + d.working.classes[0].lists[1].size() == 7 && d.cached == d.fresh_score();
+        move_undo(d, m, u);
+        ok = ok && d.working.classes[0].lists[0] == std::vector<uint32_t>({1, 2, 3, 4}) && d.working.classes[0].lists[1] == std::vector<uint32_t>({5, 6, 7}) &&
+             d.cached == d.fresh_score();
+        CHECK("list_ruin.recreate_restores_multiple_source_entities", ok);
+    }
+    {  // precedence_ruin_restores_original_when_recreate_has_no_safe_position (:443-468): two nodes that precede each other (elements 0, 1
+       // for the reference's 1, 2): wherever the ruined element goes, a cycle closes -> nothing is placed, the list comes back
+        ScoreDirector d = mk({{0, 1}}, false);
+        d.calculate_score();
+        PrecedenceHooks h;
+        h.node_count = 2;
+        h.durations = {1, 1};
+        h.successors = {{1}, {0}};
+        Move m = ruin(0, {0});
+        m.prec = &h;
+        MoveUndo u = move_do(d, m);
+        CHECK("list_ruin.precedence_ruin_restores_original_when_recreate_has_no_safe_position",
+              u.placements.empty() && d.working.classes[0].lists[0] == std::vector<uint32_t>({0, 1}));
+    }
+    {  // heuristic/move/tests/list_multi_swap.rs:72-134: three independent intra-list swaps as one move, do + undo; two swaps in one list
+       // are not doable
+        ScoreDirector d = mk({{1, 2, 3}, {10, 20, 30}, {100, 200, 300}}, false);
+        d.calculate_score();
+        Move m;
+        m.kind = Move::MultiSwap;
+        m.a_pos = 3;
+        const uint16_t e[3] = {0, 1, 2}, f[3] = {0, 0, 1}, g[3] = {2, 1, 2};
+        for (int i = 0; i < 3; ++i) m.ms_entity[i] = e[i], m.ms_first[i] = f[i], m.ms_second[i] = g[i];
+        bool ok = move_is_doable(d, m);
+        MoveUndo u = move_do(d, m);
+        const auto& L = d.working.classes[0].lists;
+        ok = ok && L[0] == std::vector<uint32_t>({3, 2, 1}) && L[1] == std::vector<uint32_t>({20, 10, 30}) && L[2] == std::vector<uint32_t>({100, 300, 200});
+        move_undo(d, m, u);
+        ok = ok && L[0] == std::vector<uint32_t>({1, 2, 3}) && L[1] == std::vector<uint32_t>({10, 20, 30}) && L[2] == std::vector<uint32_t>({100, 200, 300});
+        CHECK("list_multi_swap.applies_independent_intra_list_swaps_and_undoes", ok);
+        Move bad;
+        bad.kind = Move::MultiSwap;
+        bad.a_pos = 2;
+        bad.ms_entity[0] = bad.ms_entity[1] = 0;
+        bad.ms_first[0] = 0, bad.ms_second[0] = 1, bad.ms_first[1] = 1, bad.ms_second[1] = 2;
+        CHECK("list_multi_swap.rejects_overlapping_entities", !move_is_doable(d, bad));
+    }
     {
         ScoreDirector d = mk({{1, 2, 3}}, false);
         CHECK("list_ruin.empty_indices_not_doable", !move_is_doable(d, ruin(0, {})));

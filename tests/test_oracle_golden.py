@@ -304,6 +304,11 @@ def test_precedence_selector_goldens_are_in_the_binary(oracle):
     assert sum(l.startswith("ok list_precedence_selector.") for l in lines) == 12
     assert "ok list_ruin.precedence_ruin_recreate_skips_cycle_forming_insertions" in lines
     assert "ok list_cheapest.precedence_downstream_breaks_cheapest_ties" in lines
+    # heuristic/move/tests/list_multi_swap.rs:72-134, move/tests/list_ruin.rs:307-338,443-468, phase/tests/foraging.rs:113-134
+    for name in ("list_multi_swap.applies_independent_intra_list_swaps_and_undoes", "list_multi_swap.rejects_overlapping_entities",
+                 "list_ruin.recreate_restores_multiple_source_entities", "list_ruin.precedence_ruin_restores_original_when_recreate_has_no_safe_position",
+                 "gates.score_improvement_required_move_rejects_worse_before_acceptor", "gates.hard_score_delta"):
+        assert "ok " + name in lines, name
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
