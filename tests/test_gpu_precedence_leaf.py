@@ -512,3 +512,30 @@ def test_round_robin_construction_on_a_precedence_model(oracle):
     d.solve_steps(8)
     o.steps(8)
     assert d.working_lists(0, 0) == o.get_lists(0) and (d.calculate_score()[0] == o.score()[:2]).all()
+
+
+def test_precedence_ruin_rolls_back_when_nothing_is_safe(oracle):
+    """move/tests/list_ruin.rs:443-468 on the device: two nodes that precede each other -- wherever a ruined element would go a cycle
+    closes, so the recreate places nothing, the lists come back and the candidate scores like the current state (ruin leaf with the
+    slot's hooks, traced steps and sf_step_evaluate of a flagged record)."""
+    import solverforge_amd as sfa
+
+    p = {"durations": np.array([1, 1, 2], dtype=np.int64), "successors": [[1], [0], []], "expected_owner": np.array([0, 0, 1], dtype=np.int64),
+         "sequences": [[0, 1], [2]], "n_jobs": 1, "n_machines": 2}
+    d, mk = _policy_pair(oracle, p, ("ruin", "list_swap"), 5, ruin=(1, 1, 4))
+    o = mk(5)
+    start = o.score()[:2].copy()
+    assert (d.calculate_score()[0] == start).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(4):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 16)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om) and (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        assert d.working_lists(0, 0) == o.get_lists(0), step
+    rec = np.zeros(1, dtype=gm.dtype)
+    rec[0] = (8, 0, 1, 0, 0, -2147483648)  # ruin position 0 of list 0 with the hooks
+    es, ed = d.evaluate_moves(rec)
+    hs, hd = o.evaluate_moves(rec)
+    assert (ed == hd).all() and (es == hs[:, :2]).all()
