@@ -2117,7 +2117,11 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for SF_MIXED_BLOCKS_PER_CU workgroups of 4 waves per CU, the FAST
     // instantiation for SF_MIXED_FAST_BLOCKS_PER_CU); ties go to the larger group
-    const size_t max_waves = 4 * (size_t)(fast && !RUIN ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU);  // by register budget
+    // precedence models: the four-workgroups-per-CU build when the launch has more replicas than two workgroups per CU hold and the LDS
+    // slice lets more than eight share a CU (sf_mixed_wave.hip: MODE 2)
+    static const bool no_prec_occ = std::getenv("SF_AMD_PREC_NO_OCC") != nullptr;
+    const bool prec_occ = PREC && !trace && !no_prec_occ && n_replicas > 8 * 256 && (160 * 1024) / (cv.total + 256) > 8;
+    const size_t max_waves = 4 * (size_t)(fast && !RUIN ? SF_MIXED_FAST_BLOCKS_PER_CU : (prec_occ ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU));  // by register budget
     int wpb = 1;
     size_t best_resident = 0;
     for (int w = 1; w <= 4; ++w) {
@@ -2132,7 +2136,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     }
     SearchParams q = p;
     q.n_launch = n_replicas;
-    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : 0, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb, &gl))));
+    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : (prec_occ ? 2 : 0), make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb, &gl))));
     return SF_OK;
 }
 static bool has_plain_list_leaves(sf_ctx* ctx) {

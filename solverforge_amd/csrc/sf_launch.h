@@ -35,7 +35,7 @@ hipError_t launch_tu_list_wave(bool trace, int mode, const SearchLaunch& a);
 template <int L, int VTB>
 hipError_t launch_tu_scalar(bool trace, const SearchLaunch& a);
 // generic N-leaf engine: k_mixed_search_wave<L, TRACE, VT, RUIN, PREC, MODE> (mode 1 = the FAST instantiation of the default
-// list policy: VTB 2, no precedence constraint, never traced)
+// list policy: VTB 2, no precedence constraint, never traced; mode 2 = the PREC instantiations built for four workgroups per CU)
 template <int L, int VTB, bool RUIN, bool PREC>
 hipError_t launch_tu_mixed(bool trace, int mode, const SearchLaunch& a);
 

@@ -254,8 +254,16 @@ namespace sf {
 #ifndef SF_MIXED_FAST_BLOCKS_PER_CU
 #define SF_MIXED_FAST_BLOCKS_PER_CU 3
 #endif
+// MODE 2 (PREC instantiations, untraced): the same code built for four 4-wave workgroups per CU (128 registers per lane).  A precedence
+// trial is one replica's serial chain of Kahn rounds, so a CU that can hold more than eight small replicas (LDS slice permitting) hides
+// that latency with more of them: nine-leaf policy on a 20 x 10 job shop 38.3 M moves/s at 2,048 replicas -> 54.7 M at 4,096, 10 x 5
+// 102.7 M (profiles/r03w_prec_occupancy.txt).  LDS-bound sizes (50 x 20: eight replicas per CU either way) keep MODE 0: -4 % with the
+// smaller register budget.  The host picks per launch (launch_mixed_t).
+#ifndef SF_MIXED_PREC_BLOCKS_PER_CU
+#define SF_MIXED_PREC_BLOCKS_PER_CU 4
+#endif
 template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false, int MODE = 0>
-__global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU) void k_mixed_search_wave(
+__global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PER_CU : (MODE == 2 ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU)) void k_mixed_search_wave(
     ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p, int has_list_arg, int has_scalar_arg, NbrIndex nb) {
     constexpr bool FAST = MODE == 1;
     static_assert(!FAST || (!TRACE && !PREC), "FAST: untraced, no precedence constraint");

@@ -21,6 +21,11 @@ hipError_t launch_tu_mixed<SF_TU_L, SF_TU_VTB, SF_TU_RUIN != 0, SF_TU_PREC != 0>
         return launch_with_lds(k_mixed_search_wave<SF_TU_L, false, VT, SF_TU_RUIN != 0, false, 1>, a, *a.lm, *a.sm, *a.gl, *a.p, a.has_list,
                                a.has_scalar, a.nb);
 #endif
+#if SF_TU_PREC != 0
+    if (mode == 2 && !trace)
+        return launch_with_lds(k_mixed_search_wave<SF_TU_L, false, VT, SF_TU_RUIN != 0, true, 2>, a, *a.lm, *a.sm, *a.gl, *a.p, a.has_list, a.has_scalar,
+                               a.nb);
+#endif
     (void)mode;
     if (trace)
         return launch_with_lds(k_mixed_search_wave<SF_TU_L, true, VT, SF_TU_RUIN != 0, SF_TU_PREC != 0>, a, *a.lm, *a.sm, *a.gl, *a.p, a.has_list,

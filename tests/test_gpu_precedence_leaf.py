@@ -539,3 +539,26 @@ def test_precedence_ruin_rolls_back_when_nothing_is_safe(oracle):
     es, ed = d.evaluate_moves(rec)
     hs, hd = o.evaluate_moves(rec)
     assert (ed == hd).all() and (es == hs[:, :2]).all()
+
+
+def test_high_occupancy_instantiation(oracle):
+    """Launches with more than eight replicas per CU take the PREC kernels built for four workgroups per CU (MODE 2): same results."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(5, 3, seed=4)
+    R = 2304
+    d, mk = _policy_pair(oracle, p, POLICY_LEAVES, 40, n_replicas=R, ruin=(2, 4, 3))
+    d.calculate_score()
+    d.phase_start()
+    d.solve_steps(6)
+    scores = d.calculate_score()
+    for r in (0, 1, 777, R - 1):
+        o = mk(40 + r)
+        o.phase_start()
+        o.steps(6)
+        assert (scores[r] == o.score()[:2]).all(), r
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        gst, ost = d.stats(r), o.stats()
+        for c in COUNTERS:
+            assert gst[c] == ost[c], (r, c)
+    assert (d.fresh_score() == scores).all()
