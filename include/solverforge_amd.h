@@ -466,7 +466,8 @@ int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, con
  * the first differing HARD level is greater, phase/hard_delta.rs:11-35; conflict-repair candidates of the runtime provider cursor,
  * runtime/provider_cursor.rs), bit 1 = Move::requires_score_improvement (rejected unless move score > last step score).  A rejected
  * candidate is scored and counted (moves_evaluated, score_calculations) but never reaches the acceptor; its flags read doable,
- * not accepted.  gates = NULL: no gate (sf_step_decide). */
+ * not accepted, plus bit 3 (RejectedByHardImprovement) or bit 4 (RejectedByScoreImprovement), the candidate-trace dispositions
+ * 4 / 5 of stats/candidate_trace.rs:530-543.  gates = NULL: no gate (sf_step_decide). */
 int32_t sf_step_decide_gated(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
                              int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
                              int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected);
@@ -558,8 +559,9 @@ int32_t sf_solve_steps(sf_ctx* ctx, int64_t n_steps);
  * (sf_get_stats(replica).step_count); replicas simply differ in how many steps they have completed. Asynchronous. */
 int32_t sf_solve_moves(sf_ctx* ctx, int64_t max_steps, int64_t move_budget);
 /* one traced step on every replica: per consumed candidate move/score/flags of replica `replica` (bit0 doable, bit1
- * accepted, bit2 = the forager's pick that the step committed, bits 8..15 = MoveCursor::selector_index = the leaf's
- * position in the union); out_applied = 1 and *out_applied_move when a move was committed */
+ * accepted, bit2 = the forager's pick that the step committed, bit4 = rejected by the score-improvement gate before the
+ * acceptor (ListMultiSwapMove of the critical-path leaf, evaluation.rs:95-113), bits 8..15 = MoveCursor::selector_index = the
+ * leaf's position in the union); out_applied = 1 and *out_applied_move when a move was committed */
 int32_t sf_solve_step_traced(sf_ctx* ctx, int32_t replica, sf_move_t* out_moves, int64_t* out_scores,
                              int32_t* out_flags, int64_t cap, int64_t* out_count,
                              int32_t* out_applied, sf_move_t* out_applied_move);
@@ -608,7 +610,10 @@ void sf_trace_digest_init(sf_trace_digest* d);                                  
 void sf_trace_digest_update(sf_trace_digest* d, const void* bytes, size_t n);      /* CandidateTraceDigest::update */
 /* Frames the n pulls of ONE traced step (moves/flags as sf_solve_step_traced wrote them; `first_ordinal` = pulls
  * recorded before this step; `step_index` = steps the phase had completed).  Writes the canonical bytes to `out`
- * (may be NULL: size query) and updates `digest` (may be NULL) pull by pull.  Returns the byte count, or
+ * (may be NULL: size query) and updates `digest` (may be NULL) pull by pull.  Every sf_move_t kind has its identity: the
+ * scalar and list families, k_opt, and list_permute / list_ruin (sources merged per list) / list_multi_swap
+ * (runtime/compiler/executor/list_leaf/move.rs:403-447, heuristic/move/list_kernel/permute.rs:170-188); flag bits 3 / 4
+ * frame RejectedByHardImprovement / RejectedByScoreImprovement.  Returns the byte count, or
  * SF_ERR_INVALID (unknown move kind) / SF_ERR_CAPACITY (`out` too small). */
 int64_t sf_trace_encode_step(const sf_trace_scope* scope, uint64_t first_ordinal, uint64_t step_index,
                              const sf_move_t* moves, const int32_t* flags, int64_t n, uint8_t* out, int64_t cap,

@@ -413,7 +413,7 @@ int32_t sfo_model_step_traced(void* h, sfo_move_t* moves, int64_t* scores4, int3
     for (int32_t i = 0; i < n && i < cap; ++i) {
         to_wire(tr[i].move, &moves[i]);
         std::memcpy(&scores4[4 * i], tr[i].score.v, 4 * sizeof(int64_t));
-        flags[i] = (tr[i].doable ? 1 : 0) | (tr[i].accepted ? 2 : 0) | (tr[i].selected ? 4 : 0) | ((int32_t)tr[i].selector << 8);
+        flags[i] = (tr[i].doable ? 1 : 0) | (tr[i].accepted ? 2 : 0) | (tr[i].selected ? 4 : 0) | tr[i].gate | ((int32_t)tr[i].selector << 8);
     }
     *applied = m->search.last_step_applied ? 1 : 0;
     if (m->search.last_step_applied) to_wire(m->search.last_applied_move, applied_move);

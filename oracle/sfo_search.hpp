@@ -356,6 +356,7 @@ struct StepTrace {  // one record per pulled candidate (for order/score parity t
     bool accepted;
     size_t selector = 0;    // cursor.selector_index(candidate_id) (candidates.rs:84)
     bool selected = false;  // the forager's pick, committed at the end of the step (step.rs:122-147)
+    int gate = 0;           // 8 RejectedByHardImprovement, 16 RejectedByScoreImprovement (evaluation.rs:75-113)
 };
 
 struct LocalSearch {
@@ -434,7 +435,7 @@ struct LocalSearch {
             director->restore_score_state(st);
             ++stats.score_calculations;
             if (mv.require_improvement && !(move_score > last_step_score)) {  // RejectedByScoreImprovement (evaluation.rs:95-113): never reaches the acceptor
-                if (trace) trace->push_back({mv, true, move_score, false, cursor->last_selector(), false});
+                if (trace) trace->push_back({mv, true, move_score, false, cursor->last_selector(), false, 16});
                 continue;
             }
             bool accepted = acceptor->is_accepted(last_step_score, move_score);
@@ -553,10 +554,10 @@ inline GroupedStepTrace grouped_scalar_step(LocalSearch& ls, const std::vector<s
         d.restore_score_state(st);
         ++ls.stats.score_calculations;
         const int32_t gate = gates.empty() ? 0 : gates[out.kept[id]];
-        if (((gate & 1) && hard_score_delta(ls.last_step_score, move_score, d.hard_levels) != 1) ||
-            ((gate & 2) && !(move_score > ls.last_step_score))) {  // RejectedByHardImprovement / RejectedByScoreImprovement: the acceptor is not asked
-            out.scores.push_back(move_score);
-            out.flags.push_back(1);
+        const bool hard_rejected = (gate & 1) && hard_score_delta(ls.last_step_score, move_score, d.hard_levels) != 1;
+        if (hard_rejected || ((gate & 2) && !(move_score > ls.last_step_score))) {  // RejectedByHardImprovement / RejectedByScoreImprovement: the
+            out.scores.push_back(move_score);                                       // acceptor is not asked
+            out.flags.push_back(1 | (hard_rejected ? 8 : 16));
             continue;
         }
         bool accepted = ls.acceptor->is_accepted(ls.last_step_score, move_score);

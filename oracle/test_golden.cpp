@@ -811,7 +811,7 @@ static void gate_cases() {
     std::vector<std::vector<ScalarEditO>> provided = {{{0, 0, 0, 1, true}}, {{0, 0, 0, 2, true}}};
     GroupedStepTrace t = grouped_scalar_step(ls, provided, 0, 256, {2, 2});
     CHECK("gates.score_improvement_required_move_rejects_worse_before_acceptor",
-          ls.stats.moves_evaluated == 2 && ls.stats.moves_applied == 1 && d.calculate_score() == Score::of(0, 3) && t.flags.size() == 2 && t.flags[0] == 1 &&
+          ls.stats.moves_evaluated == 2 && ls.stats.moves_applied == 1 && d.calculate_score() == Score::of(0, 3) && t.flags.size() == 2 && t.flags[0] == (1 | 16) &&  // 16: RejectedByScoreImprovement
               (t.flags[1] & 6) == 6);
     bool ok = hard_score_delta(Score::of(-2, 0), Score::of(-1, -50), 1) == 1 && hard_score_delta(Score::of(-1, 0), Score::of(-1, 9), 1) == 0 &&
               hard_score_delta(Score::of(-1, 0), Score::of(-3, 9), 1) == -1 && hard_score_delta(Score::of(0, 0), Score::of(0, 9), 0) == -2;

@@ -76,12 +76,45 @@ def identity(move, list_scope, scalar_scope):
                             [a, a_pos, a_pos + (value & 0xFFFF), b, b_pos, b_pos + (value >> 16)])
     if kind == 7:  # runtime/compiler/executor/list_leaf/move.rs:403-420
         return logical_move(*list_scope, "k_opt", [a, a_pos, a, b, a, b_pos] + SEGMENT_ORDER[value])
+    if kind == 9:  # move/list_kernel/permute.rs:170-188: entity, start, end, len, permutation (nth_permutation of the rank)
+        n = b_pos - a_pos
+        remaining, perm, rank = list(range(n)), [], value
+        for position in range(n):
+            step = 1
+            for t in range(2, n - position):
+                step *= t
+            perm.append(remaining.pop(rank // step))
+            rank %= step
+        return logical_move(*list_scope, "list_permute", [a, a_pos, b_pos, n] + perm)
+    if kind == 8:  # runtime/compiler/executor/list_leaf/move.rs:421-433: (entity, count, positions) per source list
+        u = lambda x: x & 0xFFFFFFFF
+        pos = [(u(w) >> (16 * h)) & 0xFFFF for w in (b, b_pos, value) for h in (0, 1)]
+        flagged = a_pos <= 5 and bool(u(value) & 0x80000000)
+        # sources merged per list, positions ascending, lists ascending (heuristic/move/list_kernel/ruin.rs:27-52)
+        if flagged and (u(value) & 0x40000000):  # the last element comes from the second list
+            second = (u(value) >> 16) & 0x3FFF
+            groups = sorted([(a, sorted(pos[: a_pos - 1])), (second, [pos[a_pos - 1]])], key=lambda g: g[0])
+        else:
+            groups = [(a, sorted(pos[:a_pos]))]
+        return logical_move(*list_scope, "list_ruin", [x for e, idx in groups for x in [e, len(idx)] + idx])
+    if kind == 10:  # list_leaf/move.rs:434-447: (entity, first, second) per swap
+        coords = []
+        for q, w in enumerate((a_pos, b, b_pos)[:a]):
+            w &= 0xFFFFFFFF
+            d = (value >> (8 * q)) & 0xFF
+            first = w >> 16
+            coords += [w & 0xFFFF, first, first + (d - 256 if d > 127 else d)]
+        return logical_move(*list_scope, "list_multi_swap", coords)
     raise ValueError(f"move kind {kind}")
 
 
 def dispositions(flag):  # candidates.rs:127-281, step.rs:122-147,227-243; codes candidate_trace.rs:536-549
     if not flag & 1:
         codes = [2, 3]  # Evaluated, NotDoable
+    elif flag & 8:
+        codes = [2, 4]  # Evaluated, RejectedByHardImprovement (evaluation.rs:75-93)
+    elif flag & 16:
+        codes = [2, 5]  # Evaluated, RejectedByScoreImprovement (evaluation.rs:95-113)
     elif not flag & 2:
         codes = [2, 6]  # Evaluated, AcceptorRejected
     elif not flag & 4:

@@ -2243,7 +2243,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                                    : (my_kind == 256 ? (int32_t)((mx_ & 15u) | ((mx_ >> 4) << 16)) : (my_kind == 512 ? (int32_t)mx_ : -1));
                         }
                         for (int kk = 0; kk < L && kk < gl.levels; ++kk) p.trace_scores[ti * gl.levels + kk] = doable ? sc.v[kk] : 0;
-                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0) | ((int32_t)my_leaf << 8);
+                        p.trace_flags[ti] = (doable ? 1 : 0) | (acc ? 2 : 0) | ((doable && !consult) ? 16 : 0) | ((int32_t)my_leaf << 8);  // 16: RejectedByScoreImprovement
                     }
                 }
                 if (PREC && tracing) {  // critical-path leaf: the wire form of its consumed candidates

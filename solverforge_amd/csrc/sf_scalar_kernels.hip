@@ -749,6 +749,7 @@ __global__ __launch_bounds__(64) void k_scalar_step_decide(ScalarModel m, Search
         // hard_score_delta != Improving, phase/hard_delta.rs:11-35) or a score improvement (bit 1: move score <= last step score) is
         // scored and counted but never reaches the acceptor
         bool consult = doable;
+        int32_t gate_flag = 0;  // 8 RejectedByHardImprovement, 16 RejectedByScoreImprovement
         if (doable && gates) {
             const int32_t g = gates[ci];
             if (g & 1) {
@@ -759,8 +760,9 @@ __global__ __launch_bounds__(64) void k_scalar_step_decide(ScalarModel m, Search
                     break;
                 }
                 consult = improving;
+                if (!consult) gate_flag = 8;
             }
-            if (consult && (g & 2) && score_cmp<L>(sc, curv) <= 0) consult = false;
+            if (consult && (g & 2) && score_cmp<L>(sc, curv) <= 0) consult = false, gate_flag = 16;
         }
         bool acc = false;
         if (consult) {
@@ -816,7 +818,7 @@ __global__ __launch_bounds__(64) void k_scalar_step_decide(ScalarModel m, Search
         st_gen += nconsumed;
         st_acc += (uint64_t)__popcll(accmask);
         st_calc += (uint64_t)__popcll(__ballot(consumed && doable));
-        if (consumed) out_flags[ci] = (doable ? 1 : 0) | (acc ? 2 : 0);
+        if (consumed) out_flags[ci] = (doable ? 1 : 0) | (acc ? 2 : 0) | gate_flag;
         consumed_total += nconsumed;
         if (forager_quits(p.forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) break;
     }

@@ -13,7 +13,8 @@ from solverforge_amd import candidate_trace as ct
 from solverforge_amd import datasets
 
 BITS = {"nearby_change": 16, "nearby_swap": 32, "list_change": 4, "list_swap": 8, "list_reverse": 64,
-        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "change": 1, "swap": 2}
+        "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "change": 1, "swap": 2, "ruin": 1024, "permute": 8192,
+        "precedence": 16384}
 
 
 def t6(m):
@@ -115,6 +116,89 @@ def test_native_encoder_matches_restatement_on_oracle_traces():
         assert native.total_pulls == ref.total_pulls > 0
     assert seen_kinds == {0, 1, 2, 3, 4, 5, 6, 7}
     assert seen_disp >= {0, 1, 3, 7}
+
+
+SHOP_LEAVES = ("precedence", "permute", "list_change", "list_swap", "ruin")
+
+
+def _shop_oracle(policy):
+    p = datasets.make_precedence_shop(7, 4, seed=5)
+    o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+    if policy:
+        o.set_precedence_policy(True)
+    o.configure(acceptor=1, la_size=5, forager=0, limit=30, leaves=sum(BITS[x] for x in SHOP_LEAVES), selection_order=3, random_seed=6)
+    return p, o
+
+
+@pytest.mark.parametrize("policy", [False, True])
+def test_native_encoder_on_precedence_shop_traces(policy):
+    """The critical-path leaf's families: list_ruin (single- and two-source, with hooks), list_multi_swap (rejected by the
+    score-improvement gate before the acceptor, evaluation.rs:95-113), list_permute."""
+    _, o = _shop_oracle(policy)
+    native = ct.CandidateTrace(list_descriptor=0, list_variable="sequence")
+    ref = trace_v3.Trace(list_scope=(0, "sequence"))
+    kinds, gated, multi = set(), 0, 0
+    o.phase_start()
+    for _ in range(15):
+        mv, _, fl, _, _ = o.step_traced()
+        native.record_step(mv, fl)
+        ref.record_step(t6(mv), fl)
+        kinds |= set(mv["kind"].tolist())
+        gated += int(((fl & 16) != 0).sum())
+        assert ((fl[(fl & 16) != 0] & 7) == 1).all() and (mv["kind"][(fl & 16) != 0] == 10).all()
+        multi += int(((mv["kind"] == 8) & ((mv["value"].astype(np.int64) & 0xC0000000) == 0xC0000000)).sum())
+    assert native.canonical_bytes() == ref.canonical_bytes()
+    assert native.prefix_digest == ref.digest.value()
+    assert {8, 9, 10} <= kinds and gated > 0 and multi > 0
+
+
+def test_gate_dispositions_and_new_identities_framed_by_hand():
+    q = lambda v: struct.pack("<Q", v)
+    s = lambda b: q(len(b)) + b
+    mv = np.zeros(4, dtype=sfa.MOVE_DTYPE)
+    fl = np.array([1 | 8, 1 | 16, 3, 3], dtype=np.int32)
+    # two swaps on list 2: (1, 4) and (6, 5)
+    mv[0] = (10, 2, 2 | (1 << 16), 2 | (6 << 16), 0, 3 | (0xFF << 8))
+    # two-source ruin with hooks: positions 3, 1 of list 4 and position 2 of list 1 -> sources merged, lists ascending
+    mv[1] = (8, 4, 3, 3 | (1 << 16), 2, np.int32(np.uint32(0xC0000000 | (1 << 16)).view(np.int32)))
+    mv[2] = (8, 0, 2, 5 | (2 << 16), 0, 0)  # plain ruin: positions ascending
+    mv[3] = (9, 1, 2, 1, 5, 3)  # window [2, 5), rank 3 of 3! -> (1, 2, 0)
+    t = ct.CandidateTrace(list_descriptor=1, list_variable="seq")
+    t.record_step(mv, fl)
+    coords = lambda xs: q(len(xs)) + b"".join(b"\x01" + q(x) for x in xs)
+    ident = lambda fam, xs: b"\x4f" + q(1) + b"\x01" + s(b"seq") + s(fam) + coords(xs)
+    body = t.canonical_bytes()
+    e0 = ident(b"list_multi_swap", [2, 1, 4, 2, 6, 5]) + q(2) + bytes([2, 4])
+    e1 = ident(b"list_ruin", [1, 1, 2, 4, 2, 1, 3]) + q(2) + bytes([2, 5])
+    e2 = ident(b"list_ruin", [0, 2, 2, 5]) + q(2) + bytes([2, 7])
+    e3 = ident(b"list_permute", [1, 2, 5, 3, 1, 2, 0]) + q(2) + bytes([2, 7])
+    for e in (e0, e1, e2, e3):
+        assert e in body, e
+    ref = trace_v3.Trace(list_scope=(1, "seq"))
+    ref.record_step(t6(mv), fl)
+    assert ref.canonical_bytes() == body
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [False, True])
+def test_gpu_trace_digest_precedence_shop(policy):
+    p, o = _shop_oracle(policy)
+    d = sfa.build_precedence_shop(p, leaves=SHOP_LEAVES, precedence_policy=policy)
+    d.configure(sfa.SolverConfig(acceptor=1, late_acceptance_size=5, forager=0, accepted_count_limit=30, selection_order=3, random_seed=6))
+    gpu = ct.CandidateTrace(list_descriptor=0, list_variable="sequence", keep_bytes=False)
+    cpu = trace_v3.Trace(list_scope=(0, "sequence"))
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    for step in range(20):
+        gm, _, gf, gap, _ = d.solve_step_traced(cap=1 << 18)
+        om, _, of, oap, _ = o.step_traced()
+        assert (gf == of).all(), step
+        gpu.record_step(gm, gf)
+        cpu.record_step(t6(om), of)
+        assert gpu.prefix_digest == cpu.digest.value(), (policy, step)
+        assert gap == oap
+    assert gpu.total_pulls == cpu.total_pulls > 0
 
 
 @pytest.mark.gpu
