@@ -452,6 +452,11 @@ class Model:
         el = np.ascontiguousarray(elements, dtype=np.uint32)
         lib().sfo_model_construct_list_cheapest(self.h, _p(el), len(el))
 
+    def construct_list_regret(self, elements):
+        """List regret-insertion construction of the unassigned `elements` (source order)."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        lib().sfo_model_construct_list_regret(self.h, _p(el), len(el))
+
     def construct_list_clarke_wright(self, elements, feasible_mode=0):
         """Clarke-Wright savings construction of the unassigned `elements` (source order) with the solverforge-cvrp hooks;
         feasible_mode 0 = structural (savings_hooks), 1 = capacity (route_hooks).  Returns (committed, stats[5])."""

@@ -736,6 +736,81 @@ inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const s
     }
 }
 
+// Regret-insertion list construction (manager/phase_factory/list_construction/regret/kernel/execute.rs:52-204 over
+// kernel/evaluation.rs:120-230 and kernel/mod.rs:19-75): every round prices every (list, position) of every unassigned element with a
+// full score trial; an element's regret is best - second best trial score (Forced, above every finite regret, when it has one slot
+// only; a second slot that ties the best gives regret zero); the element with the greatest regret is placed at its best slot --
+// ties: the better best score, then the longer precedence downstream (zero without hooks), then the earlier of the unassigned order
+// (construction order key, source index).  Inside an element the first of equal trial scores stays.  Unrestricted owners, no order
+// key, no precedence hooks.  Counters: one generated + evaluated candidate and one score calculation per trial
+// (evaluation.rs:60-66 over phase/construction/telemetry.rs:81-93), one accepted + applied step per placed element.
+inline void construct_list_regret(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned_in, SolverStats* stats = nullptr) {
+    d.calculate_score();
+    EntityClass& c = d.working.classes[descriptor];
+    if (unassigned_in.empty() || c.n == 0) return;
+    std::vector<uint32_t> unassigned = unassigned_in;
+    while (!unassigned.empty()) {
+        bool have_choice = false, choice_forced = false;
+        Score choice_regret, choice_score;
+        size_t choice_li = 0, choice_e = 0, choice_p = 0;
+        for (size_t li = 0; li < unassigned.size(); ++li) {
+            const uint32_t element = unassigned[li];
+            bool have = false, have_second = false;
+            size_t best_e = 0, best_p = 0;
+            Score best_score, second;
+            for (size_t e = 0; e < c.n; ++e) {
+                const size_t len = c.lists[e].size();
+                for (size_t pos = 0; pos <= len; ++pos) {
+                    DirectorScoreState st = d.snapshot_score_state();
+                    d.before_variable_changed(descriptor, e);
+                    c.lists[e].insert(c.lists[e].begin() + (ptrdiff_t)pos, element);
+                    d.after_variable_changed(descriptor, e);
+                    Score sc = d.calculate_score();
+                    d.before_variable_changed(descriptor, e);
+                    c.lists[e].erase(c.lists[e].begin() + (ptrdiff_t)pos);
+                    d.after_variable_changed(descriptor, e);
+                    d.restore_score_state(st);
+                    if (stats) ++stats->score_calculations, ++stats->moves_generated, ++stats->moves_evaluated;
+                    if (!have) {
+                        have = true;
+                        best_e = e, best_p = pos, best_score = sc;
+                    } else if (sc > best_score) {
+                        second = best_score, have_second = true;
+                        best_e = e, best_p = pos, best_score = sc;
+                    } else if (!have_second || sc > second) {
+                        second = sc, have_second = true;
+                    }
+                }
+            }
+            if (!have) continue;
+            const bool forced = !have_second;  // RegretValue::Forced orders above every Finite (mod.rs:46-56)
+            const Score regret = forced ? Score::zero() : best_score - second;
+            bool better = !have_choice;
+            if (have_choice) {
+                const int rc = forced != choice_forced ? (forced ? 1 : -1) : (forced ? 0 : cmp(regret, choice_regret));
+                better = rc > 0 || (rc == 0 && best_score > choice_score);
+            }
+            if (better) {
+                have_choice = true, choice_forced = forced;
+                choice_regret = regret, choice_score = best_score;
+                choice_li = li, choice_e = best_e, choice_p = best_p;
+            }
+        }
+        if (!have_choice) break;
+        const uint32_t element = unassigned[choice_li];
+        unassigned.erase(unassigned.begin() + (ptrdiff_t)choice_li);
+        d.before_variable_changed(descriptor, choice_e);
+        c.lists[choice_e].insert(c.lists[choice_e].begin() + (ptrdiff_t)choice_p, element);
+        d.after_variable_changed(descriptor, choice_e);
+        d.calculate_score();
+        if (stats) {
+            ++stats->moves_accepted;
+            ++stats->moves_applied;
+            ++stats->step_count;
+        }
+    }
+}
+
 // Round-robin list construction (manager/phase_factory/list_construction/round_robin/kernel.rs:71-175): the unassigned elements in
 // (construction order key, source index) order; an unrestricted element is appended to the round-robin cursor's owner and advances
 // it, an element with a fixed owner (list_placement.rs:54-69: owner hook value < entity count) is appended there without advancing,

@@ -818,6 +818,52 @@ static void gate_cases() {
     CHECK("gates.hard_score_delta", ok);
 }
 
+// manager/phase_factory/list_construction/regret/tests.rs:305-326 (regret_requires_only_the_explicit_source_key...): a score that
+// no insertion changes, one list, three elements -> every regret ties, the first unassigned element goes to the first slot each
+// round: [3, 2, 1] in the reference's payloads = source indices [2, 1, 0].  And a two-list case worked by hand (kernel/mod.rs:58-75).
+static void regret_insertion_cases() {
+    {
+        ScoreDirector d;
+        d.working.classes.resize(1);
+        d.working.classes[0].n = 1;
+        d.working.classes[0].lists = {{}};
+        SolverStats st;
+        construct_list_regret(d, 0, {0, 1, 2}, &st);
+        CHECK("list_regret.constant_score_piles_up_in_reverse_source_order",
+              d.working.classes[0].lists[0] == (std::vector<uint32_t>{2, 1, 0}) && st.step_count == 3 && st.moves_applied == 3 &&
+                  st.score_calculations == 3 + 2 * 2 + 3 && st.moves_generated == st.score_calculations);
+    }
+    {  // soft = -sum over lists of (position + 1) * weight[element], weights {1, 5, 3}: two empty lists.
+        // round 1: every element has two equal slots (regret 0) -> the best score decides: element 0 (score -1) to list 0.
+        // round 2: element 1: list 0 front -5 - 2 = -7 (0 shifts), list 0 back -1 - 10 = -11, list 1 -1 - 5 = -6 -> best -6, second -7, regret 1;
+        //          element 2: front -3 - 2 = -5, back -1 - 6 = -7, list 1 -1 - 3 = -4 -> regret 1, score -4 > -6 -> element 2 to list 1.
+        // round 3: element 1: list 0 front -4 - 5 - 2 + 1 ... computed by the director; checked against the expected lists below
+        ScoreDirector d;
+        d.working.classes.resize(1);
+        d.working.classes[0].n = 2;
+        d.working.classes[0].lists = {{}, {}};
+        auto c = std::make_unique<UniConstraint>();
+        c->name = "position weight";
+        c->impact = Impact::Penalty;
+        c->source = ChangeSource::descriptor(0);
+        c->count = [](const Solution& sol) { return sol.classes[0].n; };
+        c->filter = [](const Solution&, size_t) { return true; };
+        c->weight = [](const Solution& sol, size_t e) {
+            static const int64_t w[3] = {1, 5, 3};
+            int64_t t = 0;
+            const auto& l = sol.classes[0].lists[e];
+            for (size_t p = 0; p < l.size(); ++p) t += (int64_t)(p + 1) * w[l[p]];
+            return Score::of(0, t);
+        };
+        d.constraints.members.push_back(std::move(c));
+        construct_list_regret(d, 0, {0, 1, 2}, nullptr);
+        // round 3, element 1: list 0 = [0]: front -(5 + 2) - 3 = -10, back -(1 + 10) - 3 = -14; list 1 = [2]: front -(5 + 6) - 1 = -12, back -(3 + 10) - 1 = -14
+        CHECK("list_regret.greatest_regret_then_best_score",
+              d.working.classes[0].lists[0] == (std::vector<uint32_t>{1, 0}) && d.working.classes[0].lists[1] == (std::vector<uint32_t>{2}) &&
+                  d.calculate_score() == Score::of(0, -10));
+    }
+}
+
 static void cheapest_precedence_cases() {
     Solution s;
     s.classes.resize(1);
@@ -2095,6 +2141,7 @@ int main() {
     compound_scalar_cases();
     cheapest_insertion_cases();
     cheapest_precedence_cases();
+    regret_insertion_cases();
     gate_cases();
     balance_cases();
     bi_incr_cases();

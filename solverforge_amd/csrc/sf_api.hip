@@ -1784,6 +1784,51 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
     return run_evaluate_all(ctx, out_scores, 1);  // finish_construction: the committed score of the constructed lists
 }
 
+// ≙ ListRegretInsertionPhase over every replica's current lists (csrc/sf_construct.hip)
+int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "regret insertion needs the list variable's class");
+    if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_regret arguments");
+    if (ctx->lm.n_cap > 65535 || ctx->lm.dim > 65536 || n > 65535) return fail(ctx, SF_ERR_UNSUPPORTED, "construction packs list elements in 16 bits");
+    if (ctx->pm.on) return fail(ctx, SF_ERR_UNSUPPORTED, "regret insertion on a model with precedence hooks");
+    {
+        std::vector<uint8_t> seen((size_t)ctx->lm.dim, 0);
+        for (int32_t k = 0; k < n; ++k) {
+            if (elements[k] >= (uint32_t)ctx->lm.dim) return fail(ctx, SF_ERR_INVALID, "element id out of range");
+            if (seen[elements[k]]++) return fail(ctx, SF_ERR_INVALID, "duplicate element id (the source binding of the phase refuses it, regret.rs:228-236)");
+        }
+    }
+    int rc = alloc_search(ctx);
+    if (rc) return rc;
+    const RegretCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, n);
+    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
+    uint32_t* d_el = nullptr;
+    if (n > 0) {
+        hipError_t ea = hipMalloc((void**)&d_el, (size_t)n * 4);
+        if (ea == hipSuccess) ea = hipMemcpyAsync(d_el, elements, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (ea != hipSuccess) {
+            (void)hipFree(d_el);
+            return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (ctx->levels <= 2) {
+        auto kern = k_list_construct_regret<2>;
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, n, ctx->sp.stats);
+    } else {
+        auto kern = k_list_construct_regret<4>;
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, n, ctx->sp.stats);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_el);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return run_evaluate_all(ctx, out_scores, 1);  // the committed score of the constructed lists
+}
+
 // ≙ ListKOptPhase (route-local 2-opt) over every replica's current lists (csrc/sf_clarke_wright.hip)
 int32_t sf_construct_list_k_opt(sf_ctx* ctx, int32_t descriptor_index, int32_t k, int32_t feasible_mode, int32_t max_sweeps, int64_t* out_scores) {
     DeviceGuard _dev(ctx);

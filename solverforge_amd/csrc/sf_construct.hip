@@ -132,6 +132,247 @@ __global__ __launch_bounds__(64) void k_list_construct_cheapest(ListModel lm, co
     }
 }
 
+// Regret-insertion list construction (manager/phase_factory/list_construction/regret/kernel/execute.rs:52-204, the element's
+// best / second-best trial kernel/evaluation.rs:120-230, the ordering of choices kernel/mod.rs:19-75; unrestricted owners, no order
+// key, no precedence hooks).  One wavefront = one replica, lists in LDS like the cheapest-insertion kernel above.  A round prices
+// every slot of every still-unassigned element: the slots go over the lanes, NR elements share one pass (one binary search, one
+// pair of neighbours and one removed leg per slot; the 2 * NR legs of a slot's elements are gathers in flight together), every lane
+// keeps each element's best (first of equals) and second-best score of ITS slots; per element a wave max + min finds the best slot
+// and the second best is the max over the other lanes' bests and the winning lane's runner-up.  The choice among the elements
+// (greatest regret, Forced above Finite; then the better score; then the earlier element) is wave-uniform scalar work.
+struct RegretCarve {
+    size_t visits, off, load, sbase, present, un, total;
+    __host__ __device__ RegretCarve(int V, int n_cap, int dim, int n_el) {
+        size_t o = 0;
+        load = o;
+        o = align_up(o + sizeof(int64_t) * V, 16);
+        off = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        sbase = o;
+        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        visits = o;
+        o = align_up(o + sizeof(uint16_t) * n_cap, 16);
+        present = o;
+        o = align_up(o + sizeof(uint32_t) * (((size_t)dim + 31) / 32), 16);
+        un = o;
+        o = align_up(o + sizeof(uint16_t) * (n_el > 0 ? n_el : 1), 16);
+        total = o;
+    }
+};
+
+template <int L, int NR, bool M32>
+__device__ __forceinline__ void regret_scan(const RuinModel& lm, const lds_u16* visits, const lds_u32* off, const lds_i64* load, const lds_u32* sbase,
+                                            const uint32_t (&x)[NR], uint32_t n_x, const ScoreV<L>& s, ScoreV<L> (&bs)[NR], uint32_t (&bkey)[NR],
+                                            bool (&has)[NR], ScoreV<L> (&s2)[NR], bool (&has2)[NR]) {
+    constexpr int U = 2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t V = (uint32_t)lm.V, depot = (uint32_t)lm.depot;
+    const bool has_dist = lm.dist_level >= 0, has_cap = lm.cap_level >= 0 && lm.demand != nullptr;
+    const uint32_t total = uni(sbase[V]);
+    uint32_t top = 1;
+    while (top < V) top <<= 1;
+    int64_t dx[NR];
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) dx[ri] = has_cap ? (int64_t)lm.demand[x[ri]] : 0;
+    for (uint32_t t0 = 0; t0 < total; t0 += 64u * U) {
+        uint32_t e[U], o[U], prev[U], next[U];
+        int64_t ld[U];
+        bool valid[U], empty[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t t = t0 + (uint32_t)u * 64u + lane;
+            valid[u] = t < total;
+            const uint32_t tt = valid[u] ? t : 0u;
+            uint32_t lo = 0;
+            for (uint32_t stepw = top >> 1; stepw; stepw >>= 1) {  // last list whose first slot is <= tt
+                const uint32_t cand = lo + stepw;
+                if (cand < V && sbase[cand] <= tt) lo = cand;
+            }
+            e[u] = lo;
+            const uint32_t b0 = sbase[lo], le = sbase[lo + 1] - b0 - 1u;
+            o[u] = tt - b0;
+            const uint32_t ob = off[lo];
+            prev[u] = o[u] > 0 ? (uint32_t)visits[ob + o[u] - 1] : depot;
+            next[u] = o[u] < le ? (uint32_t)visits[ob + o[u]] : depot;
+            empty[u] = le == 0;
+            ld[u] = has_cap ? load[lo] : 0;
+        }
+        int64_t d0[U], da[U][NR], db[U][NR];
+        if (has_dist) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                d0[u] = ruin_leg_t<M32>(lm, prev[u], next[u]);
+#pragma unroll
+                for (int ri = 0; ri < NR; ++ri) {
+                    da[u][ri] = ruin_leg_t<M32>(lm, prev[u], x[ri]);
+                    db[u][ri] = ruin_leg_t<M32>(lm, x[ri], next[u]);
+                }
+            }
+        }
+#pragma unroll
+        // a lane meets its slots in (list, position) order: a tie never replaces its running best.  The updates are selects, not
+        // branches: the branchy form (if (better) { bs = sc; bkey = key; }) lost the key update of a lane's second slot on gfx950
+        // (ROCm 7.2 hipcc -O3; the scores moved, the key did not) -- caught by the oracle on the last element of a 60-customer run
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int ri = 0; ri < NR; ++ri) {
+                ListDelta d{0, 0, true};
+                if (has_dist) d.d_dist = wsub(wadd(da[u][ri], db[u][ri]), empty[u] ? 0 : d0[u]);
+                if (has_cap) d.d_cap = wsub(over_cap(wadd(ld[u], dx[ri]), lm.capacity), over_cap(ld[u], lm.capacity));
+                const ScoreV<L> sc = ruin_apply_delta<L>(lm, s, d);
+                const uint32_t key = (e[u] << 16) | o[u];
+                const bool live = valid[u] && (uint32_t)ri < n_x;
+                const bool had = has[ri];
+                const bool take = live && (!had || score_cmp<L>(sc, bs[ri]) > 0);
+                ScoreV<L> runner;  // what this slot leaves for the second place: the displaced best, or the slot itself
+#pragma unroll
+                for (int q = 0; q < L; ++q) {
+                    runner.v[q] = take ? bs[ri].v[q] : sc.v[q];
+                    bs[ri].v[q] = take ? sc.v[q] : bs[ri].v[q];
+                }
+                bkey[ri] = take ? key : bkey[ri];
+                has[ri] = had || take;
+                const bool take2 = live && had && (!has2[ri] || score_cmp<L>(runner, s2[ri]) > 0);
+#pragma unroll
+                for (int q = 0; q < L; ++q) s2[ri].v[q] = take2 ? runner.v[q] : s2[ri].v[q];
+                has2[ri] = has2[ri] || take2;
+            }
+        }
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void k_list_construct_regret(ListModel lm, const uint32_t* __restrict__ elements, int n_el, uint64_t* stats) {
+    constexpr int NR = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u;
+    const int r = blockIdx.x;
+    const int V = lm.V;
+    const RegretCarve cv(V, lm.n_cap, lm.dim, n_el);
+    lds_u16* visits = (lds_u16*)(smem + cv.visits);
+    lds_u32* off = (lds_u32*)(smem + cv.off);
+    lds_i64* load = (lds_i64*)(smem + cv.load);
+    lds_u32* sbase = (lds_u32*)(smem + cv.sbase);
+    lds_u16* un = (lds_u16*)(smem + cv.un);
+    lds_u32* present = (lds_u32*)(smem + cv.present);
+    uint32_t* g_visits = lm.visits + (size_t)r * lm.n_cap;
+    uint32_t* g_off = lm.off + (size_t)r * (V + 1);
+    int64_t* g_load = lm.load + (size_t)r * V;
+    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) off[t] = g_off[t];
+    for (uint32_t t = lane; t < (uint32_t)V; t += 64) load[t] = g_load[t];
+    for (uint32_t t = lane; t < ((uint32_t)lm.dim + 31u) / 32u; t += 64) present[t] = 0u;
+    wave_sync();
+    const uint32_t tot0 = uni(off[V]);
+    for (uint32_t t = lane; t < tot0; t += 64) {
+        const uint32_t x = g_visits[t];
+        visits[t] = (uint16_t)x;
+        atomicOr((uint32_t*)&present[x >> 5], 1u << (x & 31u));
+    }
+    wave_sync();
+    // the unassigned elements of this replica, source order kept (the host refuses a repeated id)
+    uint32_t n_un = 0;
+    for (int k0 = 0; k0 < n_el; k0 += 64) {
+        const int k = k0 + (int)lane;
+        const uint32_t x = k < n_el ? elements[k] : 0xFFFFFFFFu;
+        const bool take = k < n_el && x < (uint32_t)lm.dim && !((present[x >> 5] >> (x & 31u)) & 1u);
+        const uint64_t mask = __ballot(take);
+        if (take) un[n_un + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        n_un += (uint32_t)__popcll(mask);
+    }
+    wave_sync();
+    RuinModel rm = ruin_model(lm);
+    const bool has_dist = lm.dist_level >= 0;
+    const bool m32 = lm.mat32 || !has_dist;
+    ScoreV<L> s;
+#pragma unroll
+    for (int k = 0; k < L; ++k) s.v[k] = lm.score[(size_t)r * 4 + k];
+    uint64_t trials = 0, placed = 0;
+    while (n_un > 0 && V > 0) {
+        if (uni(off[V]) >= (uint32_t)lm.n_cap) break;  // element capacity reached
+        ruin_slot_prefix(rm, off, sbase, 0xFFFFFFFFu, 0u, 0);
+        const uint32_t total = uni(sbase[V]);
+        bool c_have = false, c_forced = false;
+        ScoreV<L> c_regret, c_score;
+        uint32_t c_li = 0, c_key = 0;
+#pragma unroll
+        for (int q = 0; q < L; ++q) c_regret.v[q] = 0, c_score.v[q] = 0;
+        for (uint32_t li0 = 0; li0 < n_un; li0 += NR) {
+            const uint32_t n_x = n_un - li0 < (uint32_t)NR ? n_un - li0 : (uint32_t)NR;
+            uint32_t x[NR];
+            ScoreV<L> bs[NR], s2[NR];
+            uint32_t bkey[NR];
+            bool has[NR], has2[NR];
+#pragma unroll
+            for (int ri = 0; ri < NR; ++ri) {
+                x[ri] = uni((uint32_t)un[li0 + ((uint32_t)ri < n_x ? (uint32_t)ri : 0u)]);
+                has[ri] = has2[ri] = false;
+                bkey[ri] = 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < L; ++q) bs[ri].v[q] = s2[ri].v[q] = INT64_MIN;
+            }
+            if (m32)
+                regret_scan<L, NR, true>(rm, visits, off, load, sbase, x, n_x, s, bs, bkey, has, s2, has2);
+            else
+                regret_scan<L, NR, false>(rm, visits, off, load, sbase, x, n_x, s, bs, bkey, has, s2, has2);
+            trials += (uint64_t)total * n_x;
+#pragma unroll
+            for (int ri = 0; ri < NR; ++ri) {
+                if ((uint32_t)ri >= n_x || __ballot(has[ri]) == 0ull) continue;
+                const ScoreV<L> M = wave_max_score<L>(bs[ri], has[ri]);
+                const bool at_max = has[ri] && score_cmp<L>(bs[ri], M) == 0;
+                const uint32_t kmin = uni((uint32_t)ruin_wave_min_u64(at_max ? (uint64_t)bkey[ri] : ~0ull));
+                const bool winner = at_max && bkey[ri] == kmin;
+                const bool other = winner ? has2[ri] : has[ri];
+                const bool forced = __ballot(other) == 0ull;  // RegretValue::Forced: the element has one slot only
+                const ScoreV<L> S2 = wave_max_score<L>(winner ? s2[ri] : bs[ri], other);
+                ScoreV<L> best, regret;
+#pragma unroll
+                for (int q = 0; q < L; ++q) {
+                    best.v[q] = (int64_t)uni64((uint64_t)M.v[q]);
+                    regret.v[q] = forced ? 0 : wsub(best.v[q], (int64_t)uni64((uint64_t)S2.v[q]));
+                }
+                bool better = !c_have;
+                if (c_have) {
+                    const int rc = forced != c_forced ? (forced ? 1 : -1) : (forced ? 0 : score_cmp<L>(regret, c_regret));
+                    better = rc > 0 || (rc == 0 && score_cmp<L>(best, c_score) > 0);
+                }
+                if (better) {
+                    c_have = true, c_forced = forced;
+                    c_regret = regret, c_score = best;
+                    c_li = li0 + (uint32_t)ri, c_key = kmin;
+                }
+            }
+        }
+        if (!c_have) break;
+        const uint32_t x = uni((uint32_t)un[c_li]);
+        construct_list_insert(rm, visits, off, load, c_key >> 16, c_key & 0xFFFFu, x);
+        for (uint32_t t0 = c_li; t0 + 1 < n_un; t0 += 64) {  // unassigned.remove(list_index): the tail moves up by one (ascending chunks)
+            const uint32_t t = t0 + lane;
+            const uint32_t nv = t + 1 < n_un ? (uint32_t)un[t + 1] : 0u;
+            wave_sync();
+            if (t + 1 < n_un) un[t] = (uint16_t)nv;
+            wave_sync();
+        }
+        n_un -= 1;
+        s = c_score;
+        placed += 1;
+    }
+    const uint32_t tot = uni(off[V]);
+    for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = visits[t];
+    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = off[t];
+    for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = load[t];
+    if (stats && lane == 0) {  // evaluation.rs:60-66: one generated + evaluated candidate and one score calculation per trial
+        uint64_t* gs = stats + (size_t)r * SF_STATS_WORDS;
+        gs[0] += placed;
+        gs[1] += trials;
+        gs[2] += trials;
+        gs[3] += placed;
+        gs[4] += placed;
+        gs[5] += trials;
+        gs[7] += trials;
+    }
+}
+
 // Round-robin list construction (manager/phase_factory/list_construction/round_robin/kernel.rs:71-175).  The host hands over the
 // declared elements sorted by (construction order key, source index) with the owner hook's value per element (-1 = unrestricted;
 // elements whose hook names no valid owner are dropped on the host: they are skipped in every replica).  One wavefront per

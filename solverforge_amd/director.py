@@ -337,6 +337,14 @@ class GpuScoreDirector:
         check(self._L.sf_construct_list_cheapest(self._h, descriptor_index, ptr(el), len(el), ptr(out)), self._h)
         return out
 
+    def construct_list_regret(self, descriptor_index, elements):
+        """≙ ListRegretInsertionPhase on every replica: every round the unassigned element whose best and second-best insertion
+        differ most goes to its best (list, position); returns the committed scores [n_replicas, levels]."""
+        el = np.ascontiguousarray(elements, dtype=np.uint32)
+        out = np.zeros((self.n_replicas, self.levels), dtype=np.int64)
+        check(self._L.sf_construct_list_regret(self._h, descriptor_index, ptr(el), len(el), ptr(out)), self._h)
+        return out
+
     def construct_list_k_opt(self, descriptor_index, k=2, feasible_mode=1, max_sweeps=1000):
         """≙ ListKOptPhase on every replica: every route swept to its 2-opt local optimum (k = 2; other k: scored no-op), at
         most max_sweeps sweeps per route; feasible_mode 0 = no feasibility hook, 1 = capacity.  Returns the committed scores

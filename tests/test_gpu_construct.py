@@ -1,6 +1,7 @@
 """GPU parity tests (through the C ABI): list cheapest-insertion construction on the device (sf_construct_list_cheapest ≙
 ListCheapestInsertionPhase, cheapest/kernel.rs:57-150) vs the oracle: constructed lists, committed score, counters; from empty
-lists, from a partial state, ties, unreachable legs, asymmetric matrix; then local search from the constructed state."""
+lists, from a partial state, ties, unreachable legs, asymmetric matrix; then local search from the constructed state.  Regret
+insertion (sf_construct_list_regret ≙ ListRegretInsertionPhase) and round robin the same way."""
 import numpy as np
 import pytest
 
@@ -101,6 +102,106 @@ def test_cheapest_insertion_validation():
         d.construct_list_cheapest(3, [1])  # not the list class
     d.construct_list_cheapest(0, p["customers"])  # nothing missing: a no-op
     assert d.working_lists(0, 0) == p["routes"]
+
+
+# ---- regret insertion (sf_construct_list_regret ≙ ListRegretInsertionPhase, regret/kernel/{execute,evaluation,mod}.rs) -------------
+@pytest.mark.parametrize("problem,keep", [("plain", 0), ("tight", 0), ("ties", 0), ("asym", 0), ("plain", 2), ("tight", 5)])
+def test_regret_insertion_matches_oracle(oracle, problem, keep):
+    import solverforge_amd as sfa
+
+    p = _problem(problem)
+    p["routes"] = [rt if i < keep else [] for i, rt in enumerate(p["routes"])]
+    d = sfa.build_cvrp(p, n_replicas=3)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    placed = {c for rt in p["routes"] for c in rt}
+    missing = [int(c) for c in p["customers"] if int(c) not in placed]
+    sc = d.construct_list_regret(0, p["customers"])  # the elements already in a list are not candidates
+    o.construct_list_regret(missing)
+    for r in range(3):
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        assert (sc[r] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k] == ost[k], k
+    assert gst["moves_applied"] == len(missing)
+    if problem != "ties":  # regret insertion is not cheapest insertion in another order
+        d1 = sfa.build_cvrp(p, n_replicas=1)
+        d1.calculate_score()
+        d1.construct_list_cheapest(0, p["customers"])
+        assert d1.working_lists(0, 0) != d.working_lists(0, 0)
+    # local search continues from the constructed state
+    o.configure(leaves=oracle.LEAF_NEARBY_LIST_CHANGE | oracle.LEAF_NEARBY_LIST_SWAP, random_seed=1, la_size=8, limit=32, max_nearby=10)
+    d2 = sfa.build_cvrp(p, n_replicas=1, max_nearby=10)
+    d2.configure(sfa.SolverConfig(random_seed=1, late_acceptance_size=8, accepted_count_limit=32))
+    d2.calculate_score()
+    d2.construct_list_regret(0, p["customers"])
+    d2.phase_start()
+    o.phase_start()
+    d2.solve_steps(30)
+    o.steps(30)
+    assert d2.working_lists(0, 0) == o.get_lists(0)
+
+
+@pytest.mark.parametrize("n_missing", [1, 2, 3, 4, 5, 9])
+def test_regret_insertion_few_elements_and_single_list(oracle, n_missing):
+    """Groups of four elements share a pass: every remainder; one list only (the first element of an empty list is Forced)."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(14, 1, 400, seed=n_missing)
+    p["routes"] = [[]]
+    cust = [int(c) for c in p["customers"][:n_missing]]
+    d = sfa.build_cvrp(p, n_replicas=2)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    d.calculate_score()
+    sc = d.construct_list_regret(0, cust)
+    o.construct_list_regret(cust)
+    assert d.working_lists(0, 1) == o.get_lists(0) and (sc[1] == o.score()[:2]).all()
+    assert d.stats(1)["score_calculations"] == o.stats()["score_calculations"]
+
+
+def test_regret_insertion_cvrp_300_properties(oracle):
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(300, 30, 55, seed=0)
+    p["routes"] = [[] for _ in p["routes"]]
+    d = sfa.build_cvrp(p, n_replicas=2)
+    d.calculate_score()
+    sc = d.construct_list_regret(0, p["customers"])
+    lists = d.working_lists(0, 0)
+    assert sorted(c for rt in lists for c in rt) == list(range(1, 301))
+    assert (sc == d.fresh_score()).all() and sc[0][0] <= 0
+    d3 = sfa.build_cvrp(p, n_replicas=1)
+    d3.calculate_score()
+    d3.construct_list_regret(0, p["customers"][:50])
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    o.construct_list_regret(p["customers"][:50])
+    assert d3.working_lists(0, 0) == o.get_lists(0)
+
+
+def test_regret_insertion_validation():
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(12, 2, 60, seed=1)
+    d = sfa.build_cvrp(p)
+    d.calculate_score()
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_regret(0, [999])  # element id out of range
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_regret(0, [3, 4, 3])  # duplicate source key (regret/tests.rs:178-192)
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_regret(3, [1])  # not the list class
+    d.construct_list_regret(0, p["customers"])  # nothing missing: a no-op
+    assert d.working_lists(0, 0) == p["routes"]
+    s = datasets.make_precedence_shop(4, 3, seed=1)
+    ds = sfa.build_precedence_shop(s)
+    ds.calculate_score()
+    with pytest.raises(sfa.SolverForgeError):
+        ds.construct_list_regret(0, [0, 1])  # precedence hooks: not built
 
 
 # ---- round-robin list construction (sf_construct_list_round_robin ≙ ListConstructionPhase, round_robin/kernel.rs:71-175) ----------
