@@ -1,7 +1,7 @@
 """Randomised differential run of the list construction phases: random CVRP instances (sizes, capacities from generous to
 impossible, asymmetric / unreachable / tied legs, negative and over-capacity demands) x a random partial start state x a random
 sequence of phases (Clarke-Wright in either feasibility mode, round robin with order keys / owner hook values, ListKOpt under a
-sweep bound, cheapest insertion) on the GPU vs the CPU oracle: lists, committed scores and verdicts after every phase, then a few
+sweep bound, cheapest insertion, regret insertion) on the GPU vs the CPU oracle: lists, committed scores and verdicts after every phase, then a few
 local-search steps from the constructed state.  Prints one JSON line; `failures` lists the seeds whose runs diverged (none
 expected).  Usage: fuzz_construction.py <seconds> [first_seed]"""
 import json, os, sys, time, traceback
@@ -48,7 +48,7 @@ def run_case(seed):
         return [i for i, c in enumerate(p["customers"]) if int(c) not in placed]
 
     for _ in range(int(rng.integers(1, 4))):
-        phase = str(rng.choice(["cw0", "cw1", "cw1", "rr", "kopt", "kopt", "cheapest"]))
+        phase = str(rng.choice(["cw0", "cw1", "cw1", "rr", "kopt", "kopt", "cheapest", "regret", "regret"]))
         desc["phases"].append(phase)
         miss = missing()
         if phase in ("cw0", "cw1"):
@@ -69,6 +69,12 @@ def run_case(seed):
             mode, sweeps = int(rng.integers(0, 2)), int(rng.choice([1, 3, 50]))
             sc = d.construct_list_k_opt(0, 2, mode, sweeps)
             o.construct_list_k_opt(2, mode, sweeps)
+        elif phase == "regret":
+            if len(miss) > 40:  # the oracle prices every slot of every unassigned element every round
+                desc["phases"][-1] = "regret-skipped"
+                continue
+            sc = d.construct_list_regret(0, p["customers"])
+            o.construct_list_regret([int(p["customers"][i]) for i in miss])
         else:
             if len(miss) > 70:  # the oracle's cheapest insertion is cubic
                 desc["phases"][-1] = "cheapest-skipped"
