@@ -481,7 +481,7 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
  * construction order key.  On a list class with the precedence constraint (and no distance / capacity constraint) every slot of an
  * element is priced from one forward + one backward pass over the graph; with the slot's precedence policy
  * (sf_list_set_precedence_policy) the phase has the hooks (with_precedence_hooks, cheapest.rs:112-120) and places the elements in
- * descending order of their downstream chain of fixed successors (precedence_downstream, cheapest/kernel.rs:162-229).  Counters: one score_calculation per trial, one accepted + applied step per
+ * descending order of their downstream chain of fixed successors (precedence_downstream, cheapest/kernel.rs:162-229).  Counters: one generated + evaluated candidate and one score_calculation per trial (live.rs:118-127), one accepted + applied step per
  * placed element.  Commits the score of the constructed lists; out_scores[n_replicas * score_levels] may be NULL. */
 int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores);
 

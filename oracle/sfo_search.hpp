@@ -716,7 +716,7 @@ inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const s
                 c.lists[e].erase(c.lists[e].begin() + (ptrdiff_t)pos);
                 d.after_variable_changed(descriptor, e);
                 d.restore_score_state(st);
-                if (stats) ++stats->score_calculations;
+                if (stats) ++stats->score_calculations, ++stats->moves_generated, ++stats->moves_evaluated;  // live.rs:118-127
                 if (!have || sc > best_score) {
                     have = true;
                     best_e = e, best_p = pos, best_score = sc;

@@ -769,7 +769,7 @@ static void cheapest_insertion_cases() {
     CHECK("cheapest_insertion.first_position_wins_ties",
           d.working.classes[0].lists[0] == std::vector<uint32_t>({2, 1, 0}) && d.working.classes[0].lists[1].empty());
     // trials: element k sees (k + 1) + 1 slots -> 2 + 3 + 4
-    CHECK("cheapest_insertion.one_score_calculation_per_trial", st.score_calculations == 9 && st.moves_applied == 3 && st.step_count == 3);
+    CHECK("cheapest_insertion.one_score_calculation_per_trial", st.score_calculations == 9 && st.moves_generated == 9 && st.moves_evaluated == 9 && st.moves_applied == 3 && st.step_count == 3);
 }
 
 // heuristic/move/tests/compound_scalar.rs:146-262: several edits applied and undone atomically, every edit applied before the

@@ -98,6 +98,8 @@ __global__ __launch_bounds__(64) void k_prec_construct_cheapest(ListModel lm, Pr
     if (stats && lane == 0) {  // live.rs: one score calculation per trial, one accepted + applied step per placed element
         uint64_t* gs = stats + (size_t)r * SF_STATS_WORDS;
         gs[0] += placed;
+        gs[1] += trials;  // record_construction_candidate (live.rs:123-127): a generated + evaluated candidate per trial
+        gs[2] += trials;
         gs[3] += placed;
         gs[4] += placed;
         gs[5] += trials;

@@ -50,9 +50,9 @@ def test_cheapest_insertion_matches_oracle(oracle, problem, keep):
         assert (sc[r] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.score()[:2]).all()
     gst, ost = d.stats(0), o.stats()
-    for k in ["step_count", "moves_accepted", "moves_applied", "score_calculations"]:
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
         assert gst[k] == ost[k], k
-    assert gst["moves_applied"] == len(missing)
+    assert gst["moves_applied"] == len(missing) and gst["moves_generated"] == gst["score_calculations"] > 0
     # local search continues from the constructed state
     leaves = oracle.LEAF_NEARBY_LIST_CHANGE | oracle.LEAF_NEARBY_LIST_SWAP
     o.configure(leaves=leaves, random_seed=1, la_size=8, limit=32, max_nearby=10)

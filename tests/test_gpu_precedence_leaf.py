@@ -478,7 +478,7 @@ def test_cheapest_insertion_construction_on_a_precedence_model(oracle, policy, s
         assert (sc[r] == o.score()[:2]).all()
     assert (d.fresh_score() == sc).all()
     gst, ost = d.stats(0), o.stats()
-    for c in ("step_count", "moves_accepted", "moves_applied", "score_calculations"):
+    for c in ("step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"):
         assert gst[c] == ost[c], c
     d.phase_start()
     o.phase_start()
