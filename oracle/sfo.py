@@ -452,10 +452,11 @@ class Model:
         el = np.ascontiguousarray(elements, dtype=np.uint32)
         lib().sfo_model_construct_list_cheapest(self.h, _p(el), len(el))
 
-    def construct_list_regret(self, elements):
-        """List regret-insertion construction of the unassigned `elements` (source order)."""
+    def construct_list_regret(self, elements, order_keys=None):
+        """List regret-insertion construction of the unassigned `elements` (source order; order_keys = element_order_key)."""
         el = np.ascontiguousarray(elements, dtype=np.uint32)
-        lib().sfo_model_construct_list_regret(self.h, _p(el), len(el))
+        ks = None if order_keys is None else np.ascontiguousarray(order_keys, dtype=np.int64)
+        lib().sfo_model_construct_list_regret(self.h, _p(el), len(el), None if ks is None else _p(ks))
 
     def construct_list_clarke_wright(self, elements, feasible_mode=0):
         """Clarke-Wright savings construction of the unassigned `elements` (source order) with the solverforge-cvrp hooks;

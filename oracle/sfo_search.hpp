@@ -741,14 +741,21 @@ inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const s
 // full score trial; an element's regret is best - second best trial score (Forced, above every finite regret, when it has one slot
 // only; a second slot that ties the best gives regret zero); the element with the greatest regret is placed at its best slot --
 // ties: the better best score, then the longer precedence downstream (zero without hooks), then the earlier of the unassigned order
-// (construction order key, source index).  Inside an element the first of equal trial scores stays.  Unrestricted owners, no order
-// key, no precedence hooks.  Counters: one generated + evaluated candidate and one score calculation per trial
+// (construction order key, source index).  Inside an element the first of equal trial scores stays.  Unrestricted owners, no
+// precedence hooks; `order_keys` (parallel to the elements, may be empty) = element_order_key.  Counters: one generated + evaluated candidate and one score calculation per trial
 // (evaluation.rs:60-66 over phase/construction/telemetry.rs:81-93), one accepted + applied step per placed element.
-inline void construct_list_regret(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned_in, SolverStats* stats = nullptr) {
+inline void construct_list_regret(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned_in, SolverStats* stats = nullptr,
+                                  const std::vector<int64_t>& order_keys = {}) {
     d.calculate_score();
     EntityClass& c = d.working.classes[descriptor];
     if (unassigned_in.empty() || c.n == 0) return;
     std::vector<uint32_t> unassigned = unassigned_in;
+    if (!order_keys.empty()) {  // execute.rs:81-88: sort_by_key((construction_order_key, source_index)); `unassigned_in` is in source order
+        std::vector<size_t> order(unassigned.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return order_keys[a] < order_keys[b]; });
+        for (size_t i = 0; i < order.size(); ++i) unassigned[i] = unassigned_in[order[i]];
+    }
     while (!unassigned.empty()) {
         bool have_choice = false, choice_forced = false;
         Score choice_regret, choice_score;

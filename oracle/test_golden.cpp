@@ -833,6 +833,14 @@ static void regret_insertion_cases() {
               d.working.classes[0].lists[0] == (std::vector<uint32_t>{2, 1, 0}) && st.step_count == 3 && st.moves_applied == 3 &&
                   st.score_calculations == 3 + 2 * 2 + 3 && st.moves_generated == st.score_calculations);
     }
+    {  // construction order keys {2, 0, 1} (execute.rs:81-88): with every regret and score tied the smallest key goes first each round
+        ScoreDirector d;
+        d.working.classes.resize(1);
+        d.working.classes[0].n = 1;
+        d.working.classes[0].lists = {{}};
+        construct_list_regret(d, 0, {0, 1, 2}, nullptr, {2, 0, 1});
+        CHECK("list_regret.order_keys_rank_the_unassigned_elements", d.working.classes[0].lists[0] == (std::vector<uint32_t>{0, 2, 1}));
+    }
     {  // soft = -sum over lists of (position + 1) * weight[element], weights {1, 5, 3}: two empty lists.
         // round 1: every element has two equal slots (regret 0) -> the best score decides: element 0 (score -1) to list 0.
         // round 2: element 1: list 0 front -5 - 2 = -7 (0 shifts), list 0 back -1 - 10 = -11, list 1 -1 - 5 = -6 -> best -6, second -7, regret 1;

@@ -73,8 +73,9 @@ def run_case(seed):
             if len(miss) > 40:  # the oracle prices every slot of every unassigned element every round
                 desc["phases"][-1] = "regret-skipped"
                 continue
-            sc = d.construct_list_regret(0, p["customers"])
-            o.construct_list_regret([int(p["customers"][i]) for i in miss])
+            ks = rng.integers(0, 4, n).astype(np.int64) if rng.random() < 0.5 else None
+            sc = d.construct_list_regret(0, p["customers"], ks)
+            o.construct_list_regret([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss])
         else:
             if len(miss) > 70:  # the oracle's cheapest insertion is cubic
                 desc["phases"][-1] = "cheapest-skipped"

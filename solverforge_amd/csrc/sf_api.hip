@@ -1785,7 +1785,8 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
 }
 
 // ≙ ListRegretInsertionPhase over every replica's current lists (csrc/sf_construct.hip)
-int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores) {
+int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
+                                 int64_t* out_scores) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "regret insertion needs the list variable's class");
@@ -1803,10 +1804,19 @@ int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const ui
     if (rc) return rc;
     const RegretCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, n);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
+    std::vector<uint32_t> sorted;  // execute.rs:81-88: the unassigned elements in (construction order key, source index) order
+    if (order_keys && n > 0) {
+        std::vector<int32_t> order((size_t)n);
+        for (int32_t k = 0; k < n; ++k) order[k] = k;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return order_keys[a] < order_keys[b]; });
+        sorted.resize((size_t)n);
+        for (int32_t k = 0; k < n; ++k) sorted[k] = elements[order[k]];
+        elements = sorted.data();
+    }
     uint32_t* d_el = nullptr;
     if (n > 0) {
         hipError_t ea = hipMalloc((void**)&d_el, (size_t)n * 4);
-        if (ea == hipSuccess) ea = hipMemcpyAsync(d_el, elements, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (ea == hipSuccess) ea = hipMemcpy(d_el, elements, (size_t)n * 4, hipMemcpyHostToDevice);
         if (ea != hipSuccess) {
             (void)hipFree(d_el);
             return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));

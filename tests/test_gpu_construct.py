@@ -162,6 +162,33 @@ def test_regret_insertion_few_elements_and_single_list(oracle, n_missing):
     assert d.stats(1)["score_calculations"] == o.stats()["score_calculations"]
 
 
+@pytest.mark.parametrize("problem,keep", [("ties", 0), ("plain", 0), ("tight", 3)])
+def test_regret_insertion_with_order_keys(oracle, problem, keep):
+    """element_order_key: the unassigned elements are ranked by (key, source index); on the all-ties matrix the keys decide
+    every round."""
+    import solverforge_amd as sfa
+
+    p = _problem(problem)
+    p["routes"] = [rt if i < keep else [] for i, rt in enumerate(p["routes"])]
+    n = len(p["customers"])
+    ks = np.random.default_rng(5).integers(0, 4, n).astype(np.int64)
+    d = sfa.build_cvrp(p, n_replicas=2)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    d.calculate_score()
+    placed = {c for rt in p["routes"] for c in rt}
+    miss = [i for i, c in enumerate(p["customers"]) if int(c) not in placed]
+    sc = d.construct_list_regret(0, p["customers"], ks)
+    o.construct_list_regret([int(p["customers"][i]) for i in miss], ks[miss])
+    assert d.working_lists(0, 1) == o.get_lists(0) and (sc[1] == o.score()[:2]).all()
+    if problem == "ties":
+        d0 = sfa.build_cvrp(p, n_replicas=1)
+        d0.calculate_score()
+        d0.construct_list_regret(0, p["customers"])
+        assert d0.working_lists(0, 0) != d.working_lists(0, 0)
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_regret(0, p["customers"], ks[:-1])
+
+
 def test_regret_insertion_cvrp_300_properties(oracle):
     import solverforge_amd as sfa
     from solverforge_amd import datasets
