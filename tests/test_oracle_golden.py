@@ -311,6 +311,84 @@ def test_precedence_selector_goldens_are_in_the_binary(oracle):
         assert "ok " + name in lines, name
 
 
+def _regret_by_deltas(p, order_keys=None):
+    """Regret insertion restated independently of the oracle's director: leg and capacity deltas on plain Python lists
+    (regret/kernel/execute.rs:52-204, evaluation.rs:120-230, mod.rs:19-75).  Returns the lists and every placement."""
+    M, dep, dem, cap = p["matrix"], int(p["depot"]), p["demands"], int(p["capacity"])
+    lists = [list(rt) for rt in p["routes"]]
+    load = [sum(int(dem[x]) for x in rt) for rt in lists]
+    placed = {c for rt in lists for c in rt}
+    un = [int(c) for c in p["customers"] if int(c) not in placed]
+    if order_keys is not None:
+        keys = {int(c): int(k) for c, k in zip(p["customers"], order_keys)}
+        un.sort(key=lambda c: keys[c])  # stable: source index breaks ties
+    steps = []
+    while un:
+        choice = None
+        for li, x in enumerate(un):
+            best, second = None, None
+            for e, l in enumerate(lists):
+                for pos in range(len(l) + 1):
+                    prev = l[pos - 1] if pos > 0 else dep
+                    nxt = l[pos] if pos < len(l) else dep
+                    dd = int(M[prev, x]) + int(M[x, nxt]) - (int(M[prev, nxt]) if l else 0)
+                    dc = max(0, load[e] + int(dem[x]) - cap) - max(0, load[e] - cap)
+                    sc = (-dc, -dd)
+                    if best is None:
+                        best = (sc, e, pos)
+                    elif sc > best[0]:
+                        second, best = best[0], (sc, e, pos)
+                    elif second is None or sc > second:
+                        second = sc
+            forced = second is None
+            regret = None if forced else (best[0][0] - second[0], best[0][1] - second[1])
+            if choice is None:
+                better = True
+            else:
+                rc = (1 if forced else -1) if forced != choice[0] else (0 if forced else (regret > choice[1]) - (regret < choice[1]))
+                better = rc > 0 or (rc == 0 and best[0] > choice[2])
+            if better:
+                choice = (forced, regret, best[0], li, best[1], best[2])
+        x = un.pop(choice[3])
+        lists[choice[4]].insert(choice[5], x)
+        load[choice[4]] += int(dem[x])
+        steps.append((x, choice[4], choice[5]))
+    return lists, steps
+
+
+@pytest.mark.parametrize("n,v,cap,seed,keep,keys", [(24, 4, 40, 1, 0, False), (30, 5, 25, 2, 2, False), (18, 1, 400, 3, 0, False),
+                                                    (26, 4, 30, 4, 0, True), (22, 3, 12, 5, 1, True)])
+def test_regret_insertion_oracle_equals_an_independent_delta_restatement(oracle, n, v, cap, seed, keep, keys):
+    """The oracle scores every trial through its incremental director (all three CVRP constraints); the restatement above prices
+    the same trial from two legs and one load.  Same placements, one by one; every customer exactly once; counters."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(n, v, cap, seed=seed)
+    p["routes"] = [rt if i < keep else [] for i, rt in enumerate(p["routes"])]
+    ks = np.random.default_rng(seed).integers(0, 3, n).astype(np.int64) if keys else None
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    placed = {c for rt in p["routes"] for c in rt}
+    miss = [i for i, c in enumerate(p["customers"]) if int(c) not in placed]
+    o.construct_list_regret([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss])
+    lists, steps = _regret_by_deltas(p, ks)
+    assert o.get_lists(0) == lists
+    assert sorted(c for rt in lists for c in rt) == sorted(int(c) for c in p["customers"])
+    st = o.stats()
+    assert st["moves_applied"] == st["step_count"] == len(miss)
+    slots_before = sum(len(rt) for rt in p["routes"]) + v
+    trials = sum((len(miss) - k) * (slots_before + k) for k in range(len(miss)))  # round k: every slot of every remaining element
+    assert st["score_calculations"] == st["moves_generated"] == st["moves_evaluated"] == trials
+
+
+def test_regret_goldens_are_in_the_binary(oracle):
+    """list_construction/regret/tests.rs:305-326 (constant score), a two-list case worked by hand, order keys."""
+    exe = os.path.join(os.path.dirname(oracle._LIB), "test_golden")
+    lines = subprocess.run([exe], capture_output=True, text=True).stdout.splitlines()
+    for name in ("list_regret.constant_score_piles_up_in_reverse_source_order", "list_regret.greatest_regret_then_best_score",
+                 "list_regret.order_keys_rank_the_unassigned_elements"):
+        assert "ok " + name in lines, name
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_precedence_leaf_properties_on_random_shops(oracle, seed):
     """Size-independent properties of the critical-path leaf and the slot's precedence policy on random job shops: every streamed
