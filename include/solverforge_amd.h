@@ -491,12 +491,15 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
  * `elements[n]` (source order, no repeated id) that is in no list yet; an element's regret is its best minus its second-best trial
  * score (Forced, above every finite regret, when it has a single slot); the element with the greatest regret goes to its best slot
  * (the first of equal scores) -- ties: the better best score, then the earlier element in (construction order key, source index)
- * order; order_keys[n] (parallel to `elements`, may be NULL) = element_order_key (regret.rs:103-106).  Unrestricted owners;
- * SF_ERR_UNSUPPORTED on a list class with precedence hooks (regret/kernel/precedence.rs, fallback.rs are not built).  Counters:
+ * order; order_keys[n] (parallel to `elements`, may be NULL) = element_order_key (regret.rs:103-106); owners[n] (may be NULL) =
+ * the owner hook per element as in sf_construct_list_round_robin: -1 unrestricted, a list index = only that list's slots are
+ * candidates (candidate_entities, regret/kernel/mod.rs:104-114), a value >= the list count = never placed.  The bounded fallbacks
+ * the reference takes when the fixed-owner elements alone exceed its trial budget (sum len (len + 1) (len + 2) / 6 > 16,384 per
+ * owner bucket, regret/kernel/fallback.rs:58-84) are not built: SF_ERR_UNSUPPORTED.  SF_ERR_UNSUPPORTED also on a list class with precedence hooks (regret/kernel/precedence.rs, fallback.rs are not built).  Counters:
  * one generated + evaluated candidate and one score_calculation per trial, one accepted + applied step per placed element.  Commits
  * the score of the constructed lists; out_scores[n_replicas * score_levels] may be NULL. */
 int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
-                                 int64_t* out_scores);
+                                 const int32_t* owners, int64_t* out_scores);
 
 /* ≙ ListKOptPhase (crates/solverforge-solver/src/manager/phase_factory/list_k_opt.rs; kernel list_k_opt/kernel.rs:57-220), the
  * route-local 2-opt polishing the default construction runs after Clarke-Wright, with the stock CVRP route hooks (the model's

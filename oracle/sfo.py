@@ -452,11 +452,13 @@ class Model:
         el = np.ascontiguousarray(elements, dtype=np.uint32)
         lib().sfo_model_construct_list_cheapest(self.h, _p(el), len(el))
 
-    def construct_list_regret(self, elements, order_keys=None):
-        """List regret-insertion construction of the unassigned `elements` (source order; order_keys = element_order_key)."""
+    def construct_list_regret(self, elements, order_keys=None, owners=None):
+        """List regret-insertion construction of the unassigned `elements` (source order; order_keys = element_order_key;
+        owners = the owner hook's value per element, -1 unrestricted)."""
         el = np.ascontiguousarray(elements, dtype=np.uint32)
         ks = None if order_keys is None else np.ascontiguousarray(order_keys, dtype=np.int64)
-        lib().sfo_model_construct_list_regret(self.h, _p(el), len(el), None if ks is None else _p(ks))
+        ow = None if owners is None else np.ascontiguousarray(owners, dtype=np.int64)
+        lib().sfo_model_construct_list_regret(self.h, _p(el), len(el), None if ks is None else _p(ks), None if ow is None else _p(ow))
 
     def construct_list_clarke_wright(self, elements, feasible_mode=0):
         """Clarke-Wright savings construction of the unassigned `elements` (source order) with the solverforge-cvrp hooks;

@@ -563,10 +563,11 @@ void sfo_model_construct_list_cheapest(void* h, const uint32_t* elements, int32_
                             m->list_slot.precedence_policy ? m->list_slot.precedence.get() : nullptr);
 }
 // ListRegretInsertionPhase (list_construction/regret.rs:223-260) without owner / order-key / precedence hooks
-void sfo_model_construct_list_regret(void* h, const uint32_t* elements, int32_t n, const int64_t* order_keys) {
+void sfo_model_construct_list_regret(void* h, const uint32_t* elements, int32_t n, const int64_t* order_keys, const int64_t* owners) {
     Model* m = (Model*)h;
     construct_list_regret(m->director, m->list_slot.descriptor_index, std::vector<uint32_t>(elements, elements + n), &m->search.stats,
-                          order_keys ? std::vector<int64_t>(order_keys, order_keys + n) : std::vector<int64_t>());
+                          order_keys ? std::vector<int64_t>(order_keys, order_keys + n) : std::vector<int64_t>(),
+                          owners ? std::vector<int64_t>(owners, owners + n) : std::vector<int64_t>());
 }
 // ListClarkeWrightPhase over a CVRP model's list class (list_clarke_wright/kernel.rs) with the solverforge-cvrp hook bundle
 // (crates/solverforge-cvrp/src/helpers.rs:40-87): one shared metric class (every vehicle shares the ProblemData), the model's depot,

@@ -741,20 +741,24 @@ inline void construct_list_cheapest(ScoreDirector& d, size_t descriptor, const s
 // full score trial; an element's regret is best - second best trial score (Forced, above every finite regret, when it has one slot
 // only; a second slot that ties the best gives regret zero); the element with the greatest regret is placed at its best slot --
 // ties: the better best score, then the longer precedence downstream (zero without hooks), then the earlier of the unassigned order
-// (construction order key, source index).  Inside an element the first of equal trial scores stays.  Unrestricted owners, no
-// precedence hooks; `order_keys` (parallel to the elements, may be empty) = element_order_key.  Counters: one generated + evaluated candidate and one score calculation per trial
+// (construction order key, source index).  Inside an element the first of equal trial scores stays.  No precedence hooks;
+// `order_keys` (parallel to the elements, may be empty) = element_order_key; `owners_in` = the owner hook (list_placement.rs:54-69)
+// below the work budget of kernel/fallback.rs:58-84 (the caller checks it: the bounded fallbacks are not restated).  Counters: one generated + evaluated candidate and one score calculation per trial
 // (evaluation.rs:60-66 over phase/construction/telemetry.rs:81-93), one accepted + applied step per placed element.
 inline void construct_list_regret(ScoreDirector& d, size_t descriptor, const std::vector<uint32_t>& unassigned_in, SolverStats* stats = nullptr,
-                                  const std::vector<int64_t>& order_keys = {}) {
+                                  const std::vector<int64_t>& order_keys = {}, const std::vector<int64_t>& owners_in = {}) {
     d.calculate_score();
     EntityClass& c = d.working.classes[descriptor];
     if (unassigned_in.empty() || c.n == 0) return;
     std::vector<uint32_t> unassigned = unassigned_in;
+    std::vector<int64_t> owners = owners_in;  // parallel to the elements: -1 unrestricted, otherwise the owner hook's value
     if (!order_keys.empty()) {  // execute.rs:81-88: sort_by_key((construction_order_key, source_index)); `unassigned_in` is in source order
         std::vector<size_t> order(unassigned.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = i;
         std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return order_keys[a] < order_keys[b]; });
         for (size_t i = 0; i < order.size(); ++i) unassigned[i] = unassigned_in[order[i]];
+        if (!owners_in.empty())
+            for (size_t i = 0; i < order.size(); ++i) owners[i] = owners_in[order[i]];
     }
     while (!unassigned.empty()) {
         bool have_choice = false, choice_forced = false;
@@ -765,7 +769,15 @@ inline void construct_list_regret(ScoreDirector& d, size_t descriptor, const std
             bool have = false, have_second = false;
             size_t best_e = 0, best_p = 0;
             Score best_score, second;
-            for (size_t e = 0; e < c.n; ++e) {
+            // candidate_entities (mod.rs:104-114): every list, the fixed owner's list, or none (an owner hook value >= entity count)
+            size_t e_lo = 0, e_hi = c.n;
+            if (!owners.empty() && owners[li] >= 0) {
+                if ((size_t)owners[li] < c.n)
+                    e_lo = (size_t)owners[li], e_hi = e_lo + 1;
+                else
+                    e_hi = 0;
+            }
+            for (size_t e = e_lo; e < e_hi; ++e) {
                 const size_t len = c.lists[e].size();
                 for (size_t pos = 0; pos <= len; ++pos) {
                     DirectorScoreState st = d.snapshot_score_state();
@@ -806,6 +818,7 @@ inline void construct_list_regret(ScoreDirector& d, size_t descriptor, const std
         if (!have_choice) break;
         const uint32_t element = unassigned[choice_li];
         unassigned.erase(unassigned.begin() + (ptrdiff_t)choice_li);
+        if (!owners.empty()) owners.erase(owners.begin() + (ptrdiff_t)choice_li);
         d.before_variable_changed(descriptor, choice_e);
         c.lists[choice_e].insert(c.lists[choice_e].begin() + (ptrdiff_t)choice_p, element);
         d.after_variable_changed(descriptor, choice_e);

@@ -74,8 +74,13 @@ def run_case(seed):
                 desc["phases"][-1] = "regret-skipped"
                 continue
             ks = rng.integers(0, 4, n).astype(np.int64) if rng.random() < 0.5 else None
-            sc = d.construct_list_regret(0, p["customers"], ks)
-            o.construct_list_regret([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss])
+            ow = None
+            if rng.random() < 0.4:
+                ow = np.full(n, -1, dtype=np.int64)
+                pick = rng.choice(n, max(1, n // 3), replace=False)
+                ow[pick] = rng.integers(0, v + 2, len(pick))
+            sc = d.construct_list_regret(0, p["customers"], ks, ow)
+            o.construct_list_regret([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss], None if ow is None else ow[miss])
         else:
             if len(miss) > 70:  # the oracle's cheapest insertion is cubic
                 desc["phases"][-1] = "cheapest-skipped"

@@ -131,7 +131,7 @@ def load():
     L.sf_schema_set_value_lists.argtypes = [vp, i32, i32, vp, vp]
     L.sf_union_configure.argtypes = [vp, i32, vp, i32]
     L.sf_construct_list_cheapest.argtypes = [vp, i32, vp, i32, vp]
-    L.sf_construct_list_regret.argtypes = [vp, i32, vp, i32, vp, vp]
+    L.sf_construct_list_regret.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.sf_construct_list_clarke_wright.argtypes = [vp, i32, vp, i32, i32, vp, vp]
     L.sf_construct_list_round_robin.argtypes = [vp, i32, vp, i32, vp, vp, vp]
     L.sf_construct_list_k_opt.argtypes = [vp, i32, i32, i32, i32, vp]

@@ -1786,7 +1786,7 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
 
 // ≙ ListRegretInsertionPhase over every replica's current lists (csrc/sf_construct.hip)
 int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
-                                 int64_t* out_scores) {
+                                 const int32_t* owners, int64_t* out_scores) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "regret insertion needs the list variable's class");
@@ -1798,27 +1798,44 @@ int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const ui
         for (int32_t k = 0; k < n; ++k) {
             if (elements[k] >= (uint32_t)ctx->lm.dim) return fail(ctx, SF_ERR_INVALID, "element id out of range");
             if (seen[elements[k]]++) return fail(ctx, SF_ERR_INVALID, "duplicate element id (the source binding of the phase refuses it, regret.rs:228-236)");
+            if (owners && owners[k] < -1) return fail(ctx, SF_ERR_INVALID, "owners[k]: -1 = unrestricted, otherwise the owner hook's value");
         }
     }
     int rc = alloc_search(ctx);
     if (rc) return rc;
-    const RegretCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, n);
-    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
-    std::vector<uint32_t> sorted;  // execute.rs:81-88: the unassigned elements in (construction order key, source index) order
-    if (order_keys && n > 0) {
-        std::vector<int32_t> order((size_t)n);
-        for (int32_t k = 0; k < n; ++k) order[k] = k;
-        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return order_keys[a] < order_keys[b]; });
-        sorted.resize((size_t)n);
-        for (int32_t k = 0; k < n; ++k) sorted[k] = elements[order[k]];
-        elements = sorted.data();
+    // the unassigned elements in (construction order key, source index) order (execute.rs:81-88); an element whose owner hook names
+    // no list has no candidate entity (mod.rs:104-114) and is never placed: dropped here
+    std::vector<int32_t> order;
+    for (int32_t k = 0; k < n; ++k)
+        if (!owners || owners[k] < ctx->lm.V) order.push_back(k);
+    if (order_keys) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return order_keys[a] < order_keys[b]; });
+    const int32_t ne = (int32_t)order.size();
+    std::vector<uint32_t> el((size_t)ne);
+    std::vector<int32_t> ow((size_t)ne, -1);
+    std::vector<uint64_t> bucket((size_t)(ctx->lm.V > 0 ? ctx->lm.V : 1), 0);
+    for (int32_t k = 0; k < ne; ++k) {
+        el[k] = elements[order[k]];
+        if (owners) ow[k] = owners[order[k]];
+        if (ow[k] >= 0) bucket[ow[k]] += 1;
     }
+    if (owners) {  // kernel/fallback.rs:58-84: all-fixed-owner inputs above the trial budget take bounded fallbacks that are not built.  The
+        // budget is checked on the fixed-owner elements handed over (a replica's unassigned subset can only be smaller)
+        uint64_t trials = 0;
+        for (uint64_t len : bucket) trials += len * (len + 1) * (len + 2) / 6;
+        if (trials > 16384) return fail(ctx, SF_ERR_UNSUPPORTED, "owner-restricted regret insertion above the reference's trial budget (regret/kernel/fallback.rs)");
+    }
+    const RegretCarve cv(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, ne);
+    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "list class does not fit one wave's LDS slice");
     uint32_t* d_el = nullptr;
-    if (n > 0) {
-        hipError_t ea = hipMalloc((void**)&d_el, (size_t)n * 4);
-        if (ea == hipSuccess) ea = hipMemcpy(d_el, elements, (size_t)n * 4, hipMemcpyHostToDevice);
+    int32_t* d_ow = nullptr;
+    if (ne > 0) {
+        hipError_t ea = hipMalloc((void**)&d_el, (size_t)ne * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void**)&d_ow, (size_t)ne * 4);
+        if (ea == hipSuccess) ea = hipMemcpy(d_el, el.data(), (size_t)ne * 4, hipMemcpyHostToDevice);
+        if (ea == hipSuccess) ea = hipMemcpy(d_ow, ow.data(), (size_t)ne * 4, hipMemcpyHostToDevice);
         if (ea != hipSuccess) {
             (void)hipFree(d_el);
+            (void)hipFree(d_ow);
             return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
         }
     }
@@ -1826,15 +1843,16 @@ int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const ui
     if (ctx->levels <= 2) {
         auto kern = k_list_construct_regret<2>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
-        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, n, ctx->sp.stats);
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, owners ? d_ow : (const int32_t*)nullptr, ne, ctx->sp.stats);
     } else {
         auto kern = k_list_construct_regret<4>;
         e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cv.total);
-        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, n, ctx->sp.stats);
+        if (e == hipSuccess) hipLaunchKernelGGL(kern, dim3(ctx->R), dim3(64), cv.total, ctx->stream, ctx->lm, d_el, owners ? d_ow : (const int32_t*)nullptr, ne, ctx->sp.stats);
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_el);
+    (void)hipFree(d_ow);
     if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
     return run_evaluate_all(ctx, out_scores, 1);  // the committed score of the constructed lists
 }

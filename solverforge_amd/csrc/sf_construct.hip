@@ -141,9 +141,10 @@ __global__ __launch_bounds__(64) void k_list_construct_cheapest(ListModel lm, co
 // pair of neighbours and one removed leg per slot; the 2 * NR legs of a slot's elements are gathers in flight together), every lane
 // keeps each element's best (first of equals) and second-best score of ITS slots; per element a wave max + min finds the best slot
 // and the second best is the max over the other lanes' bests and the winning lane's runner-up.  The choice among the elements
-// (greatest regret, Forced above Finite; then the better score; then the earlier element) is wave-uniform scalar work.
+// (greatest regret, Forced above Finite; then the better score; then the earlier element) is wave-uniform scalar work.  An element
+// with a fixed owner (the owner hook, list_placement.rs:54-69) takes part in the same pass with the other lists' slots masked.
 struct RegretCarve {
-    size_t visits, off, load, sbase, present, un, total;
+    size_t visits, off, load, sbase, present, un, own, total;
     __host__ __device__ RegretCarve(int V, int n_cap, int dim, int n_el) {
         size_t o = 0;
         load = o;
@@ -158,14 +159,16 @@ struct RegretCarve {
         o = align_up(o + sizeof(uint32_t) * (((size_t)dim + 31) / 32), 16);
         un = o;
         o = align_up(o + sizeof(uint16_t) * (n_el > 0 ? n_el : 1), 16);
+        own = o;
+        o = align_up(o + sizeof(int16_t) * (n_el > 0 ? n_el : 1), 16);
         total = o;
     }
 };
 
 template <int L, int NR, bool M32>
 __device__ __forceinline__ void regret_scan(const RuinModel& lm, const lds_u16* visits, const lds_u32* off, const lds_i64* load, const lds_u32* sbase,
-                                            const uint32_t (&x)[NR], uint32_t n_x, const ScoreV<L>& s, ScoreV<L> (&bs)[NR], uint32_t (&bkey)[NR],
-                                            bool (&has)[NR], ScoreV<L> (&s2)[NR], bool (&has2)[NR]) {
+                                            const uint32_t (&x)[NR], const int32_t (&ow)[NR], uint32_t n_x, const ScoreV<L>& s, ScoreV<L> (&bs)[NR],
+                                            uint32_t (&bkey)[NR], bool (&has)[NR], ScoreV<L> (&s2)[NR], bool (&has2)[NR]) {
     constexpr int U = 2;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t V = (uint32_t)lm.V, depot = (uint32_t)lm.depot;
@@ -223,7 +226,7 @@ __device__ __forceinline__ void regret_scan(const RuinModel& lm, const lds_u16* 
                 if (has_cap) d.d_cap = wsub(over_cap(wadd(ld[u], dx[ri]), lm.capacity), over_cap(ld[u], lm.capacity));
                 const ScoreV<L> sc = ruin_apply_delta<L>(lm, s, d);
                 const uint32_t key = (e[u] << 16) | o[u];
-                const bool live = valid[u] && (uint32_t)ri < n_x;
+                const bool live = valid[u] && (uint32_t)ri < n_x && (ow[ri] < 0 || e[u] == (uint32_t)ow[ri]);  // candidate_entities (mod.rs:104-114)
                 const bool had = has[ri];
                 const bool take = live && (!had || score_cmp<L>(sc, bs[ri]) > 0);
                 ScoreV<L> runner;  // what this slot leaves for the second place: the displaced best, or the slot itself
@@ -244,7 +247,8 @@ __device__ __forceinline__ void regret_scan(const RuinModel& lm, const lds_u16* 
 }
 
 template <int L>
-__global__ __launch_bounds__(64) void k_list_construct_regret(ListModel lm, const uint32_t* __restrict__ elements, int n_el, uint64_t* stats) {
+__global__ __launch_bounds__(64) void k_list_construct_regret(ListModel lm, const uint32_t* __restrict__ elements, const int32_t* __restrict__ owners,
+                                                              int n_el, uint64_t* stats) {
     constexpr int NR = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -256,6 +260,7 @@ __global__ __launch_bounds__(64) void k_list_construct_regret(ListModel lm, cons
     lds_i64* load = (lds_i64*)(smem + cv.load);
     lds_u32* sbase = (lds_u32*)(smem + cv.sbase);
     lds_u16* un = (lds_u16*)(smem + cv.un);
+    __attribute__((address_space(3))) int16_t* own = (__attribute__((address_space(3))) int16_t*)(smem + cv.own);  // owner hook per unassigned element, -1 = unrestricted
     lds_u32* present = (lds_u32*)(smem + cv.present);
     uint32_t* g_visits = lm.visits + (size_t)r * lm.n_cap;
     uint32_t* g_off = lm.off + (size_t)r * (V + 1);
@@ -278,7 +283,11 @@ __global__ __launch_bounds__(64) void k_list_construct_regret(ListModel lm, cons
         const uint32_t x = k < n_el ? elements[k] : 0xFFFFFFFFu;
         const bool take = k < n_el && x < (uint32_t)lm.dim && !((present[x >> 5] >> (x & 31u)) & 1u);
         const uint64_t mask = __ballot(take);
-        if (take) un[n_un + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        if (take) {
+            const uint32_t at = n_un + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            un[at] = (uint16_t)x;
+            own[at] = (int16_t)(owners ? owners[k] : -1);
+        }
         n_un += (uint32_t)__popcll(mask);
     }
     wave_sync();
@@ -301,22 +310,24 @@ __global__ __launch_bounds__(64) void k_list_construct_regret(ListModel lm, cons
         for (uint32_t li0 = 0; li0 < n_un; li0 += NR) {
             const uint32_t n_x = n_un - li0 < (uint32_t)NR ? n_un - li0 : (uint32_t)NR;
             uint32_t x[NR];
+            int32_t ow[NR];
             ScoreV<L> bs[NR], s2[NR];
             uint32_t bkey[NR];
             bool has[NR], has2[NR];
 #pragma unroll
             for (int ri = 0; ri < NR; ++ri) {
                 x[ri] = uni((uint32_t)un[li0 + ((uint32_t)ri < n_x ? (uint32_t)ri : 0u)]);
+                ow[ri] = (int32_t)uni((uint32_t)(int32_t)own[li0 + ((uint32_t)ri < n_x ? (uint32_t)ri : 0u)]);
+                if ((uint32_t)ri < n_x) trials += ow[ri] < 0 ? (uint64_t)total : (uint64_t)(uni(sbase[ow[ri] + 1]) - uni(sbase[ow[ri]]));
                 has[ri] = has2[ri] = false;
                 bkey[ri] = 0xFFFFFFFFu;
 #pragma unroll
                 for (int q = 0; q < L; ++q) bs[ri].v[q] = s2[ri].v[q] = INT64_MIN;
             }
             if (m32)
-                regret_scan<L, NR, true>(rm, visits, off, load, sbase, x, n_x, s, bs, bkey, has, s2, has2);
+                regret_scan<L, NR, true>(rm, visits, off, load, sbase, x, ow, n_x, s, bs, bkey, has, s2, has2);
             else
-                regret_scan<L, NR, false>(rm, visits, off, load, sbase, x, n_x, s, bs, bkey, has, s2, has2);
-            trials += (uint64_t)total * n_x;
+                regret_scan<L, NR, false>(rm, visits, off, load, sbase, x, ow, n_x, s, bs, bkey, has, s2, has2);
 #pragma unroll
             for (int ri = 0; ri < NR; ++ri) {
                 if ((uint32_t)ri >= n_x || __ballot(has[ri]) == 0ull) continue;
@@ -351,8 +362,9 @@ __global__ __launch_bounds__(64) void k_list_construct_regret(ListModel lm, cons
         for (uint32_t t0 = c_li; t0 + 1 < n_un; t0 += 64) {  // unassigned.remove(list_index): the tail moves up by one (ascending chunks)
             const uint32_t t = t0 + lane;
             const uint32_t nv = t + 1 < n_un ? (uint32_t)un[t + 1] : 0u;
+            const int16_t no = t + 1 < n_un ? own[t + 1] : (int16_t)-1;
             wave_sync();
-            if (t + 1 < n_un) un[t] = (uint16_t)nv;
+            if (t + 1 < n_un) un[t] = (uint16_t)nv, own[t] = no;
             wave_sync();
         }
         n_un -= 1;

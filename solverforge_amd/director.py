@@ -337,16 +337,19 @@ class GpuScoreDirector:
         check(self._L.sf_construct_list_cheapest(self._h, descriptor_index, ptr(el), len(el), ptr(out)), self._h)
         return out
 
-    def construct_list_regret(self, descriptor_index, elements, order_keys=None):
+    def construct_list_regret(self, descriptor_index, elements, order_keys=None, owners=None):
         """≙ ListRegretInsertionPhase on every replica: every round the unassigned element whose best and second-best insertion
         differ most goes to its best (list, position); order_keys = the construction order key per element (ties go to the
-        smaller key, then the earlier element).  Returns the committed scores [n_replicas, levels]."""
+        smaller key, then the earlier element); owners = the owner hook's value per element (-1 unrestricted, a list index =
+        only that list, a value >= the list count = never placed).  Returns the committed scores [n_replicas, levels]."""
         el = np.ascontiguousarray(elements, dtype=np.uint32)
         ks = None if order_keys is None else np.ascontiguousarray(order_keys, dtype=np.int64)
-        if ks is not None and len(ks) != len(el):
-            raise SolverForgeError("order_keys and elements differ in length")
+        ow = None if owners is None else np.ascontiguousarray(owners, dtype=np.int32)
+        if (ks is not None and len(ks) != len(el)) or (ow is not None and len(ow) != len(el)):
+            raise SolverForgeError("order_keys / owners and elements differ in length")
         out = np.zeros((self.n_replicas, self.levels), dtype=np.int64)
-        check(self._L.sf_construct_list_regret(self._h, descriptor_index, ptr(el), len(el), None if ks is None else ptr(ks), ptr(out)), self._h)
+        check(self._L.sf_construct_list_regret(self._h, descriptor_index, ptr(el), len(el), None if ks is None else ptr(ks),
+                                               None if ow is None else ptr(ow), ptr(out)), self._h)
         return out
 
     def construct_list_k_opt(self, descriptor_index, k=2, feasible_mode=1, max_sweeps=1000):

@@ -189,6 +189,57 @@ def test_regret_insertion_with_order_keys(oracle, problem, keep):
         d.construct_list_regret(0, p["customers"], ks[:-1])
 
 
+@pytest.mark.parametrize("problem,keep,keys", [("plain", 0, False), ("tight", 3, True), ("ties", 0, False), ("asym", 0, True)])
+def test_regret_insertion_with_owner_hook(oracle, problem, keep, keys):
+    """The owner hook (list_placement.rs:54-69): unrestricted, fixed (only that list's slots; Forced while it is empty), no valid
+    owner (never placed); counters count the candidate slots only."""
+    import solverforge_amd as sfa
+
+    p = _problem(problem)
+    p["routes"] = [rt if i < keep else [] for i, rt in enumerate(p["routes"])]
+    nv, n = len(p["routes"]), len(p["customers"])
+    rng = np.random.default_rng(11)
+    ks = rng.integers(0, 5, n).astype(np.int64) if keys else None
+    ow = np.full(n, -1, dtype=np.int64)
+    pick = rng.choice(n, n // 3, replace=False)
+    ow[pick] = rng.integers(0, nv + 2, len(pick))  # nv, nv + 1 = no valid owner
+    d = sfa.build_cvrp(p, n_replicas=2)
+    o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
+    d.calculate_score()
+    placed = {c for rt in p["routes"] for c in rt}
+    miss = [i for i, c in enumerate(p["customers"]) if int(c) not in placed]
+    sc = d.construct_list_regret(0, p["customers"], ks, ow)
+    o.construct_list_regret([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss], ow[miss])
+    for r in range(2):
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        assert (sc[r] == o.score()[:2]).all()
+    lists = d.working_lists(0, 0)
+    for i in miss:
+        c = int(p["customers"][i])
+        where = [e for e, rt in enumerate(lists) if c in rt]
+        assert where == ([] if ow[i] >= nv else ([int(ow[i])] if ow[i] >= 0 else where)) and (ow[i] >= nv or len(where) == 1)
+    gst, ost = d.stats(1), o.stats()
+    for k in ["step_count", "moves_generated", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k] == ost[k], k
+
+
+def test_regret_insertion_owner_budget_is_refused():
+    """All-fixed-owner inputs above the reference's trial budget take its bounded fallbacks (regret/kernel/fallback.rs): not built."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_cvrp(60, 1, 400, seed=2)
+    p["routes"] = [[]]
+    d = sfa.build_cvrp(p)
+    d.calculate_score()
+    with pytest.raises(sfa.SolverForgeError, match="SF_ERR_UNSUPPORTED"):
+        d.construct_list_regret(0, p["customers"], None, np.zeros(60, dtype=np.int32))  # 60 * 61 * 62 / 6 = 37,820 > 16,384
+    with pytest.raises(sfa.SolverForgeError):
+        d.construct_list_regret(0, p["customers"], None, np.full(60, -2, dtype=np.int32))
+    d.construct_list_regret(0, p["customers"][:40], None, np.zeros(40, dtype=np.int32))  # 11,480 trials: the main loop
+    assert sorted(d.working_lists(0, 0)[0]) == sorted(int(c) for c in p["customers"][:40])
+
+
 def test_regret_insertion_cvrp_300_properties(oracle):
     import solverforge_amd as sfa
     from solverforge_amd import datasets

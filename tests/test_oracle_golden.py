@@ -311,7 +311,7 @@ def test_precedence_selector_goldens_are_in_the_binary(oracle):
         assert "ok " + name in lines, name
 
 
-def _regret_by_deltas(p, order_keys=None):
+def _regret_by_deltas(p, order_keys=None, owners=None):
     """Regret insertion restated independently of the oracle's director: leg and capacity deltas on plain Python lists
     (regret/kernel/execute.rs:52-204, evaluation.rs:120-230, mod.rs:19-75).  Returns the lists and every placement."""
     M, dep, dem, cap = p["matrix"], int(p["depot"]), p["demands"], int(p["capacity"])
@@ -322,12 +322,15 @@ def _regret_by_deltas(p, order_keys=None):
     if order_keys is not None:
         keys = {int(c): int(k) for c, k in zip(p["customers"], order_keys)}
         un.sort(key=lambda c: keys[c])  # stable: source index breaks ties
+    own = {int(c): -1 for c in p["customers"]} if owners is None else {int(c): int(w) for c, w in zip(p["customers"], owners)}
     steps = []
     while un:
         choice = None
         for li, x in enumerate(un):
             best, second = None, None
             for e, l in enumerate(lists):
+                if own[x] >= 0 and own[x] != e:  # candidate_entities: the fixed owner only (none when the hook names no list)
+                    continue
                 for pos in range(len(l) + 1):
                     prev = l[pos - 1] if pos > 0 else dep
                     nxt = l[pos] if pos < len(l) else dep
@@ -340,6 +343,8 @@ def _regret_by_deltas(p, order_keys=None):
                         second, best = best[0], (sc, e, pos)
                     elif second is None or sc > second:
                         second = sc
+            if best is None:
+                continue
             forced = second is None
             regret = None if forced else (best[0][0] - second[0], best[0][1] - second[1])
             if choice is None:
@@ -347,8 +352,12 @@ def _regret_by_deltas(p, order_keys=None):
             else:
                 rc = (1 if forced else -1) if forced != choice[0] else (0 if forced else (regret > choice[1]) - (regret < choice[1]))
                 better = rc > 0 or (rc == 0 and best[0] > choice[2])
+            if best is None:
+                continue
             if better:
                 choice = (forced, regret, best[0], li, best[1], best[2])
+        if choice is None:
+            break
         x = un.pop(choice[3])
         lists[choice[4]].insert(choice[5], x)
         load[choice[4]] += int(dem[x])
@@ -356,9 +365,10 @@ def _regret_by_deltas(p, order_keys=None):
     return lists, steps
 
 
-@pytest.mark.parametrize("n,v,cap,seed,keep,keys", [(24, 4, 40, 1, 0, False), (30, 5, 25, 2, 2, False), (18, 1, 400, 3, 0, False),
-                                                    (26, 4, 30, 4, 0, True), (22, 3, 12, 5, 1, True)])
-def test_regret_insertion_oracle_equals_an_independent_delta_restatement(oracle, n, v, cap, seed, keep, keys):
+@pytest.mark.parametrize("n,v,cap,seed,keep,keys,owners", [
+    (24, 4, 40, 1, 0, False, False), (30, 5, 25, 2, 2, False, False), (18, 1, 400, 3, 0, False, False), (26, 4, 30, 4, 0, True, False),
+    (22, 3, 12, 5, 1, True, False), (28, 4, 30, 6, 0, False, True), (25, 5, 20, 7, 2, True, True)])
+def test_regret_insertion_oracle_equals_an_independent_delta_restatement(oracle, n, v, cap, seed, keep, keys, owners):
     """The oracle scores every trial through its incremental director (all three CVRP constraints); the restatement above prices
     the same trial from two legs and one load.  Same placements, one by one; every customer exactly once; counters."""
     from solverforge_amd import datasets
@@ -369,15 +379,27 @@ def test_regret_insertion_oracle_equals_an_independent_delta_restatement(oracle,
     o = oracle.Model.cvrp(p["capacity"], p["depot"], p["demands"], p["matrix"], p["customers"], p["routes"])
     placed = {c for rt in p["routes"] for c in rt}
     miss = [i for i, c in enumerate(p["customers"]) if int(c) not in placed]
-    o.construct_list_regret([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss])
-    lists, steps = _regret_by_deltas(p, ks)
+    ow = None
+    if owners:  # a third of the customers have a fixed owner, a few of them one that is no list at all
+        rng = np.random.default_rng(seed + 100)
+        ow = np.full(n, -1, dtype=np.int64)
+        pick = rng.choice(n, n // 3, replace=False)
+        ow[pick] = rng.integers(0, v + 2, len(pick))
+    o.construct_list_regret([int(p["customers"][i]) for i in miss], None if ks is None else ks[miss], None if ow is None else ow[miss])
+    lists, steps = _regret_by_deltas(p, ks, ow)
     assert o.get_lists(0) == lists
-    assert sorted(c for rt in lists for c in rt) == sorted(int(c) for c in p["customers"])
+    never = set() if ow is None else {int(p["customers"][i]) for i in miss if ow[i] >= v}
+    assert sorted(c for rt in lists for c in rt) == sorted(int(c) for c in p["customers"] if int(c) not in never)
     st = o.stats()
-    assert st["moves_applied"] == st["step_count"] == len(miss)
-    slots_before = sum(len(rt) for rt in p["routes"]) + v
-    trials = sum((len(miss) - k) * (slots_before + k) for k in range(len(miss)))  # round k: every slot of every remaining element
-    assert st["score_calculations"] == st["moves_generated"] == st["moves_evaluated"] == trials
+    assert st["moves_applied"] == st["step_count"] == len(miss) - len(never)
+    if ow is None:
+        slots_before = sum(len(rt) for rt in p["routes"]) + v
+        trials = sum((len(miss) - k) * (slots_before + k) for k in range(len(miss)))  # round k: every slot of every remaining element
+        assert st["score_calculations"] == st["moves_generated"] == st["moves_evaluated"] == trials
+    else:
+        for c, e, _ in steps:
+            w = int(ow[list(p["customers"]).index(c)])
+            assert w < 0 or w == e
 
 
 def test_regret_goldens_are_in_the_binary(oracle):
