@@ -261,8 +261,8 @@ def test_gpu_trace_digest_scalar_engine(forager):
 
 
 def test_native_encoder_matches_committed_fixture():
-    """tests/golden/candidate_trace_v3.json (made by tests/golden/make_candidate_trace_golden.py): every move family, all
-    four disposition shapes, selector indices 0..7, two scopes."""
+    """tests/golden/candidate_trace_v3.json (made by tests/golden/make_candidate_trace_golden.py): every move family (ruins with
+    one and two sources, permutations and multi-swaps included), all six disposition shapes, selector indices 0..8, two scopes."""
     import json
     import os
 
