@@ -550,6 +550,19 @@ int32_t sf_step_generate(sf_ctx* ctx, int32_t replica, uint64_t step_index, uint
 
 /* ---- local search phase ------------------------------------------------------------------ */
 int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg);
+/* compile_default_local_search_components (runtime/compiler/default_local_search/policy.rs:21-82) as a pure function of the five
+ * model properties it reads: acceptor = LateAcceptance(400) with lists, DiversifiedLateAcceptance(400) for grouped scalar-only
+ * models, SimulatedAnnealing otherwise; forager = FirstLastStepScoreImproving without a limit (accepted_count_limit 0) for grouped
+ * scalar-only models, FirstLastStepScoreImproving(256) when a list slot supports precedence moves, else AcceptedCount(256 with
+ * lists / nearby scalar leaves / conflict repairs, 1 otherwise).  Needs no device. */
+int32_t sf_default_local_search_components(int32_t has_lists, int32_t has_groups, int32_t has_precedence, int32_t has_nearby_scalar,
+                                           int32_t has_conflict_repairs, uint64_t random_seed, sf_solver_config* out);
+/* sf_solver_configure with the components above, the model properties read from the context: has_lists = a list class is declared,
+ * has_precedence = the list slot declares its precedence hooks (sf_list_set_precedence_policy) or carries the critical-path leaf
+ * (list::supports_precedence_moves, policy/list.rs:287-299), has_nearby_scalar = a nearby scalar leaf is declared.  Scalar groups
+ * and conflict repairs are host-side providers: the caller says whether the model has them.  out (may be NULL) = what was set. */
+int32_t sf_solver_configure_default(sf_ctx* ctx, uint64_t random_seed, int32_t has_groups, int32_t has_conflict_repairs,
+                                    sf_solver_config* out);
 /* parameters of SF_ACCEPT_SIMULATED_ANNEALING (takes effect at the next sf_phase_start); validation follows
  * assert_simulated_annealing_parameters (simulated_annealing.rs:305-336) -> SF_ERR_INVALID instead of a panic */
 int32_t sf_solver_configure_annealing(sf_ctx* ctx, const sf_annealing_config* cfg);

@@ -72,7 +72,7 @@ SYMBOLS = [
     "sf_schema_add_entity_class", "sf_schema_add_scalar_variable", "sf_schema_add_list_variable",
     "sf_fact_matrix_i64", "sf_fact_column_i32", "sf_fact_column_u32", "sf_fact_csr_u32",
     "sf_constraint_add", "sf_constraint_add_list_precedence", "sf_selector_add", "sf_selector_add_sublist", "sf_selector_add_kopt", "sf_selector_add_permute", "sf_selector_add_precedence", "sf_list_set_precedence_policy", "sf_selector_add_ruin", "sf_selector_add_nearby_scalar", "sf_step_evaluate_compound", "sf_step_decide", "sf_step_decide_gated", "sf_apply_compound", "sf_construct_list_cheapest", "sf_construct_list_regret", "sf_construct_list_clarke_wright", "sf_construct_list_round_robin", "sf_construct_list_k_opt", "sf_union_configure", "sf_schema_set_value_lists", "sf_initialize", "sf_evaluate_all", "sf_evaluate_each", "sf_get_scores",
-    "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_solver_configure_annealing", "sf_solver_configure_diversified",
+    "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_default_local_search_components", "sf_solver_configure_default", "sf_solver_configure_annealing", "sf_solver_configure_diversified",
     "sf_get_annealing_state", "sf_solver_set_step_seeds",
     "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_moves", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
@@ -138,6 +138,8 @@ def load():
     L.sf_selector_add_nearby_scalar.argtypes = [vp, i32, i32, i32, i32, i64, vp, vp, vp, i32]
     L.sf_selector_add_ruin.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, C.c_char_p]
     L.sf_solver_configure.argtypes = [vp, C.POINTER(SolverConfigStruct)]
+    L.sf_default_local_search_components.argtypes = [i32, i32, i32, i32, i32, u64, C.POINTER(SolverConfigStruct)]
+    L.sf_solver_configure_default.argtypes = [vp, u64, i32, i32, C.POINTER(SolverConfigStruct)]
     L.sf_solver_configure_annealing.argtypes = [vp, C.POINTER(AnnealingConfigStruct)]
     L.sf_solver_configure_diversified.argtypes = [vp, C.c_double]
     L.sf_get_annealing_state.argtypes = [vp, i32, vp, C.POINTER(i32)]

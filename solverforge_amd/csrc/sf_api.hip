@@ -470,7 +470,9 @@ int32_t sf_selector_add_nearby_scalar(sf_ctx* ctx, int32_t kind, int32_t d, int3
     if (src.present) return fail(ctx, SF_ERR_UNSUPPORTED, "one nearby scalar leaf of each kind per model");
     const ClassSpec& c = ctx->classes[d];
     const int n = c.n_rows;
-    src.off.assign(1, 0u);
+    // built into locals and moved into the context on success only: a refused call leaves no partial rows behind for a retry
+    std::vector<uint32_t> off_new(1, 0u);
+    std::vector<int32_t> val_new;
     struct Ranked {
         double dist;
         uint32_t order;
@@ -489,7 +491,7 @@ int32_t sf_selector_add_nearby_scalar(sf_ctx* ctx, int32_t kind, int32_t d, int3
         const uint64_t lim = which == 0 ? (source_limit > 0 ? (uint64_t)source_limit : ~0ull) : (uint64_t)n;
         for (uint32_t k = offsets[e]; k < offsets[e + 1] && (uint64_t)(k - offsets[e]) < lim; ++k) {
             const int32_t cand = candidates[k];
-            if (cand < 0 || cand >= (which == 0 ? c.n_values : 0x7FFFFFFF)) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: candidate out of range");
+            if (cand < 0 || cand >= (which == 0 ? c.n_values : n)) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: candidate out of range");
             const uint32_t order = k - offsets[e];
             const double dist = distances ? distances[k] : (double)order;  // meter None: the source order (change.rs:332-334)
             if (!std::isfinite(dist)) continue;                            // NearbyTopK::push drops non-finite distances
@@ -502,9 +504,11 @@ int32_t sf_selector_add_nearby_scalar(sf_ctx* ctx, int32_t kind, int32_t d, int3
             if (l.order != r.order) return l.order < r.order;
             return l.cand < r.cand;
         });
-        for (auto& x : row) src.val.push_back(x.cand);
-        src.off.push_back((uint32_t)src.val.size());
+        for (auto& x : row) val_new.push_back(x.cand);
+        off_new.push_back((uint32_t)val_new.size());
     }
+    src.off = std::move(off_new);
+    src.val = std::move(val_new);
     src.present = true;
     ctx->nearby_scalar_dynamic = dynamic_slot ? 1 : 0;
     SelectorSpec s{kind, d, var, max_nearby, -1};
@@ -2031,6 +2035,45 @@ int32_t sf_solver_configure(sf_ctx* ctx, const sf_solver_config* cfg) {
     return SF_OK;
 }
 
+// compile_default_local_search_components (runtime/compiler/default_local_search/policy.rs:21-82)
+int32_t sf_default_local_search_components(int32_t has_lists, int32_t has_groups, int32_t has_precedence, int32_t has_nearby_scalar,
+                                           int32_t has_conflict_repairs, uint64_t random_seed, sf_solver_config* out) {
+    if (!out) return SF_ERR_INVALID;
+    sf_solver_config c{};
+    c.late_acceptance_size = 400;  // DEFAULT_LOCAL_SEARCH_LATE_ACCEPTANCE_SIZE (:18)
+    c.acceptor = has_lists ? SF_ACCEPT_LATE_ACCEPTANCE : has_groups ? SF_ACCEPT_DIVERSIFIED_LATE_ACCEPTANCE : SF_ACCEPT_SIMULATED_ANNEALING;
+    if (has_groups && !has_lists) {
+        c.forager = SF_FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING;
+        c.accepted_count_limit = 0;  // accepted_count_limit: None
+    } else if (has_precedence) {
+        c.forager = SF_FORAGER_FIRST_LAST_STEP_SCORE_IMPROVING;
+        c.accepted_count_limit = 256;  // DEFAULT_LOCAL_SEARCH_ACCEPTED_COUNT (:19)
+    } else {
+        c.forager = SF_FORAGER_ACCEPTED_COUNT;
+        c.accepted_count_limit = (has_lists || has_nearby_scalar || has_conflict_repairs) ? 256 : 1;
+    }
+    c.random_ties = 1;
+    c.selection_order = SF_ORDER_RANDOM;  // every default leaf is compiled with SelectionOrder::Random (:118)
+    c.random_seed = random_seed;
+    *out = c;
+    return SF_OK;
+}
+
+int32_t sf_solver_configure_default(sf_ctx* ctx, uint64_t random_seed, int32_t has_groups, int32_t has_conflict_repairs, sf_solver_config* out) {
+    if (!ctx) return SF_ERR_INVALID;
+    bool has_lists = false, has_precedence = ctx->prec_policy, has_nearby_scalar = false;
+    for (const auto& kv : ctx->classes) has_lists = has_lists || kv.second.has_list;
+    for (const auto& s : ctx->selectors) {
+        has_precedence = has_precedence || s.kind == SF_SEL_LIST_PRECEDENCE;
+        has_nearby_scalar = has_nearby_scalar || s.kind == SF_SEL_NEARBY_SCALAR_CHANGE || s.kind == SF_SEL_NEARBY_SCALAR_SWAP;
+    }
+    sf_solver_config c{};
+    sf_default_local_search_components(has_lists, has_groups, has_lists && has_precedence, has_nearby_scalar, has_conflict_repairs, random_seed, &c);
+    const int32_t rc = sf_solver_configure(ctx, &c);
+    if (rc == SF_OK && out) *out = c;
+    return rc;
+}
+
 // DiversifiedLateAcceptanceAcceptor::new(late_acceptance_size, tolerance) (diversified_late_acceptance.rs:86-98); the history
 // size is sf_solver_config::late_acceptance_size
 int32_t sf_solver_configure_diversified(sf_ctx* ctx, double tolerance) {
@@ -2240,7 +2283,9 @@ static int ensure_plf(sf_ctx* ctx) {
     PlfModel& pl = ctx->plf;
     pl.dmax = 0;
     for (int32_t dv : deg) pl.dmax = std::max(pl.dmax, dv);
-    const size_t R = (size_t)ctx->R, nn = std::max<size_t>(n, 1), nc = (size_t)std::max(ctx->lm.n_cap, 1);
+    // flag / first serve as per-position tables (analysis) and as per-node tables (recreate, construction): rows of max(n, n_cap) words
+    const size_t R = (size_t)ctx->R, nn = std::max<size_t>(n, 1), nc = std::max<size_t>(nn, (size_t)std::max(ctx->lm.n_cap, 1));
+    pl.pc = (int32_t)nc;
     int rc = dalloc(ctx, &pl.latest, R * nn);
     if (!rc) rc = dalloc(ctx, &pl.posn, R * nn);
     if (!rc) rc = dalloc(ctx, &pl.flag, R * nc);

@@ -5,12 +5,30 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// A unit names the engine sources it instantiates from with SF_TU_ENGINES (bit 0 block engine + plain list kernels, 1 wave engine,
+// 2 scalar engine, 3 generic engine = all of them) before including this header, so that its object depends on those sources only
+// (csrc/Makefile records the real include set per object); the C-ABI unit takes everything.
+#ifndef SF_TU_ENGINES
+#define SF_TU_ENGINES 15
+#endif
+#include "sf_list_model.h"
+#if SF_TU_ENGINES & 1
 #include "sf_list_kernels.hip"
+#endif
+#if SF_TU_ENGINES & 2
 #include "sf_list_wave.hip"
+#endif
+#if SF_TU_ENGINES & 4
 #include "sf_scalar_kernels.hip"
+#endif
+#if SF_TU_ENGINES & 8
 #include "sf_mixed_wave.hip"
+#endif
 
 namespace sf {
+
+struct ScalarModel;
+struct GLeaves;
 
 struct SearchLaunch {
     int grid, block;

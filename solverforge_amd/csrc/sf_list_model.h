@@ -101,4 +101,12 @@ struct SearchParams {
     int64_t* dla_best;         // [R][4] acceptor 4: best step score of this phase
 };
 
+struct NbrIndex {
+    // [dim][dim] u16 per entry: the nodes of every matrix row in ascending (distance, node) order as
+    // (same-distance-as-previous flag << 15 | node); non-finite legs (negative / UNREACHABLE,
+    // meters.rs:21-23) sort to the end as NBR_END.  Distances themselves are not stored: the
+    // (distance, enumeration ordinal) order only needs the group boundaries.
+    const uint16_t* keys;
+};
+
 }  // namespace sf

@@ -38,13 +38,6 @@ constexpr uint32_t NBR_END = 0xFFFFu;        // past the finite entries of the r
 #endif
 constexpr int WPB = SF_WPB;  // waves (= replicas) per workgroup
 
-struct NbrIndex {
-    // [dim][dim] u16 per entry: the nodes of every matrix row in ascending (distance, node) order as
-    // (same-distance-as-previous flag << 15 | node); non-finite legs (negative / UNREACHABLE,
-    // meters.rs:21-23) sort to the end as NBR_END.  Distances themselves are not stored: the
-    // (distance, enumeration ordinal) order only needs the group boundaries.
-    const uint16_t* keys;
-};
 
 // wavefront-scope ordering of LDS/global traffic between lanes of one wave (no instruction cost:
 // a wave executes in lockstep and its DS/VMEM queues are in order; this pins the compiler).

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     int64_t* const plf_score = plf_on ? gl.plf.score + (size_t)r * GRC * 4 : nullptr;
     int64_t* const plf_cache = plf_on ? gl.plf.cache + (size_t)r * GL * GRC * 2 : nullptr;  // the filter's evaluation per ring slot
     if (plf_on) {
-        const size_t pn = (size_t)gl.prec.n, pc = (size_t)lm.n_cap;
+        const size_t pn = (size_t)gl.prec.n, pc = (size_t)gl.plf.pc;
         plf.latest = gl.plf.latest + (size_t)r * pn, plf.posn = gl.plf.posn + (size_t)r * pn, plf.flag = gl.plf.flag + (size_t)r * pc;
         plf.roff = gl.plf.roff + (size_t)r * (pn + 2), plf.blk = gl.plf.blk + (size_t)r * pn * 2, plf.csw = gl.plf.csw + (size_t)r * pn;
         plf.ssw = gl.plf.ssw + (size_t)r * pn, plf.first = gl.plf.first + (size_t)r * pc, plf.cnl = gl.plf.cnl + (size_t)r * pn;

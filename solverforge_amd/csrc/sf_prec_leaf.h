@@ -40,14 +40,16 @@ struct PlfModel {
                         // drop intra-list candidates that close a cycle through a new route edge, the ruin leaf recreates with the hooks
     int32_t slow;       // diagnostics / parity tests (SF_AMD_PLF_SLOW): the recreate slides every element through every slot, one evaluation each
     int32_t dmax;       // max (fixed successors + fixed predecessors) of a node: spacing of the support-swap sequence numbers
+    int32_t pc;         // row stride of `flag` / `first`: max(node_count, element_capacity) -- they are indexed by list position in the leaf's
+                        // analysis and by node id (predecessor / reachability tables) in the recreate and the construction
     int32_t* latest;    // [R][n]
     uint32_t* posn;     // [R][n]      node -> (list << 16 | position), PREC_NONE = in no list
-    uint32_t* flag;     // [R][n_cap]  per list position: bit 0 critical node, bit 1 critical arc to the next position, bit 2 first of its list
+    uint32_t* flag;     // [R][pc]     per list position: bit 0 critical node, bit 1 critical arc to the next position, bit 2 first of its list
     uint32_t* roff;     // [R][n + 2]  Kahn rounds of the committed evaluation
     uint32_t* blk;      // [R][n][2]   (list << 16 | start, len << 16 | route_len)
     uint32_t* csw;      // [R][n]      critical adjacent swaps (list << 16 | position)
     uint32_t* ssw;      // [R][n]      support adjacent swaps, first-occurrence order
-    uint32_t* first;    // [R][n_cap]  smallest sequence number that named the swap slot
+    uint32_t* first;    // [R][pc]     smallest sequence number that named the swap slot
     uint32_t* cnl;      // [R][n]      list positions of the critical nodes, in list order
     uint32_t* msrow;    // [R][n + 1]  multi-swap candidates before the rows of critical swap i
     uint32_t* mrrow;    // [R][n + 1]  multi-ruin candidates before the rows of block i

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(64) void k_prec_construct_cheapest(ListModel lm, Pr
     const uint32_t lane = threadIdx.x & 63u;
     const int r = blockIdx.x;
     const int V = lm.V;
-    const size_t pn = (size_t)pm.n, pc = (size_t)lm.n_cap;
+    const size_t pn = (size_t)pm.n, pc = (size_t)pl.pc;
     uint32_t* off = (uint32_t*)smem;
     uint32_t* present = off + (((size_t)V + 1 + 3) & ~(size_t)3);
     uint16_t* visits = (uint16_t*)(present + ((((size_t)lm.dim + 31) / 32 + 3) & ~(size_t)3));
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64) void k_prec_ruin_moves(ListModel lm, PrecModel 
     const int64_t i = which[blockIdx.x];
     const int32_t* mv = moves + i * 6;
     const int V = lm.V;
-    const size_t pn = (size_t)pm.n, pc = (size_t)lm.n_cap, slot = blockIdx.x;
+    const size_t pn = (size_t)pm.n, pc = (size_t)pl.pc, slot = blockIdx.x;
     uint32_t* off = (uint32_t*)smem;
     uint16_t* visits = (uint16_t*)(off + (((size_t)V + 1 + 3) & ~(size_t)3));
     uint32_t* g_visits = lm.visits + (size_t)replica * lm.n_cap;

@@ -1,4 +1,5 @@
 // Translation unit of the block engine: k_list_search<L, TRACE> for both level counts.
+#define SF_TU_ENGINES 1
 #include "sf_launch.h"
 
 namespace sf {

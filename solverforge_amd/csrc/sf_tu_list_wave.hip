@@ -1,4 +1,5 @@
 // One translation unit of the wave engine: k_list_search_wave<SF_TU_L, *, MODE> (general traced / untraced, FAST, FAST + SMALL).
+#define SF_TU_ENGINES 3
 #include "sf_launch.h"
 
 namespace sf {

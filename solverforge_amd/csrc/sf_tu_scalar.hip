@@ -1,4 +1,5 @@
 // One translation unit of the scalar engine: k_scalar_search_wave<SF_TU_L, *, VT>, traced and untraced.
+#define SF_TU_ENGINES 7
 #include "sf_launch.h"
 
 namespace sf {

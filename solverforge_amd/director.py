@@ -78,6 +78,21 @@ class SolverConfig:
     selection_order: int = SelectionOrder.RANDOM
     random_seed: int = 0
 
+    @classmethod
+    def default_components(cls, has_lists=False, has_groups=False, has_precedence=False, has_nearby_scalar=False,
+                           has_conflict_repairs=False, random_seed=0):
+        """compile_default_local_search_components (runtime/compiler/default_local_search/policy.rs:21-82) through the C ABI's
+        sf_default_local_search_components: lists -> LateAcceptance(400); grouped scalar-only -> DiversifiedLateAcceptance(400) +
+        FirstLastStepScoreImproving without a limit (accepted_count_limit 0); a list slot with precedence moves ->
+        FirstLastStepScoreImproving(256); otherwise AcceptedCount(256 with lists / nearby scalar leaves / conflict repairs, else 1)
+        and, without lists or groups, SimulatedAnnealing."""
+        s = SolverConfigStruct()
+        check(_lib.load().sf_default_local_search_components(int(has_lists), int(has_groups), int(has_precedence), int(has_nearby_scalar),
+                                                            int(has_conflict_repairs), random_seed, C.byref(s)), None)
+        return cls(acceptor=s.acceptor, late_acceptance_size=s.late_acceptance_size, forager=s.forager,
+                   accepted_count_limit=s.accepted_count_limit, random_ties=bool(s.random_ties), selection_order=s.selection_order,
+                   random_seed=s.random_seed)
+
 
 class GpuScoreDirector:
     """One device context = `n_replicas` independent Director + search states of one problem."""
@@ -402,6 +417,15 @@ class GpuScoreDirector:
         s = SolverConfigStruct(cfg.acceptor, cfg.late_acceptance_size, cfg.forager, cfg.accepted_count_limit,
                                int(cfg.random_ties), cfg.selection_order, cfg.random_seed)
         check(self._L.sf_solver_configure(self._h, C.byref(s)), self._h)
+
+    def configure_default(self, random_seed=0, has_groups=False, has_conflict_repairs=False):
+        """The reference's default acceptor + forager for THIS model (sf_solver_configure_default: lists / precedence hooks / nearby
+        scalar leaves are read from the context); returns the SolverConfig that was set."""
+        s = SolverConfigStruct()
+        check(self._L.sf_solver_configure_default(self._h, random_seed, int(has_groups), int(has_conflict_repairs), C.byref(s)), self._h)
+        return SolverConfig(acceptor=s.acceptor, late_acceptance_size=s.late_acceptance_size, forager=s.forager,
+                            accepted_count_limit=s.accepted_count_limit, random_ties=bool(s.random_ties),
+                            selection_order=s.selection_order, random_seed=s.random_seed)
 
     def configure_annealing(self, mode=AnnealingMode.CALIBRATED, temperatures=(), decay_rate=0.999985,
                             hill_climbing_temperature=1.0e-9, never_accept_hard_regression=False,

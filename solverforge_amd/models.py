@@ -149,14 +149,14 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
 
 
 def build_precedence_shop(problem, n_replicas=1, device_id=0, leaves=("list_change", "list_swap"), levels=2, hard_levels=1,
-                          hard_level=0, makespan_level=1, with_owner=True, ruin=(2, 5, 10), precedence_policy=False):
+                          hard_level=0, makespan_level=1, with_owner=True, ruin=(2, 5, 10), precedence_policy=False, element_capacity=None):
     """Job shop with the makespan objective: class 0 = machines with the list variable `sequence` of operation ids; the one
     constraint is the ListPrecedenceMakespanConstraint (crates/solverforge-scoring/src/constraint/list_precedence.rs:13-707) over
     the job order (fixed successors), the machine sequences and the expected machine of every operation."""
     d = GpuScoreDirector(score_levels=levels, hard_levels=hard_levels, n_replicas=n_replicas, device_id=device_id)
     n = len(problem["durations"])
     d.add_entity_class(0, len(problem["sequences"]))
-    d.add_list_variable(0, problem["sequences"], element_capacity=n, element_id_bound=n)
+    d.add_list_variable(0, problem["sequences"], element_capacity=n if element_capacity is None else element_capacity, element_id_bound=n)
     d.add_list_precedence(0, problem["durations"], problem["successors"], problem["expected_owner"] if with_owner else None,
                           hard_level=hard_level, makespan_level=makespan_level)
     if "precedence" in leaves:  # the precedence pair leads the list policy (policy/list.rs:24-33)

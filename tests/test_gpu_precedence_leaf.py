@@ -229,16 +229,16 @@ POLICY_LEAVES = ("precedence", "permute", "list_change", "list_swap", "sublist_c
 BITS.update({"sublist_swap": 256, "ruin": 1024, "kopt": 512})
 
 
-def _policy_pair(oracle, p, leaves, seed, n_replicas=1, policy=True, ruin=(2, 5, 4), la=5, limit=25):
+def _policy_pair(oracle, p, leaves, seed, n_replicas=1, policy=True, ruin=(2, 5, 4), la=5, limit=25, forager=0, capacity=None):
     import solverforge_amd as sfa
 
-    d = sfa.build_precedence_shop(p, n_replicas=n_replicas, leaves=leaves, ruin=ruin, precedence_policy=policy)
-    d.configure(sfa.SolverConfig(random_seed=seed, late_acceptance_size=la, accepted_count_limit=limit))
+    d = sfa.build_precedence_shop(p, n_replicas=n_replicas, leaves=leaves, ruin=ruin, precedence_policy=policy, element_capacity=capacity)
+    d.configure(sfa.SolverConfig(random_seed=seed, late_acceptance_size=la, accepted_count_limit=limit, forager=forager))
     bits = sum(BITS[x] for x in leaves)
 
     def mk(s, order=3):
         o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
-        o.configure(leaves=bits, random_seed=s, la_size=la, limit=limit, selection_order=order)
+        o.configure(leaves=bits, random_seed=s, la_size=la, limit=limit, selection_order=order, forager=forager)
         o.set_ruin(ruin[0], ruin[1], ruin[2])
         o.set_kopt(1, 0)
         o.set_precedence_policy(policy)
@@ -561,4 +561,157 @@ def test_high_occupancy_instantiation(oracle):
         gst, ost = d.stats(r), o.stats()
         for c in COUNTERS:
             assert gst[c] == ost[c], (r, c)
+    assert (d.fresh_score() == scores).all()
+
+
+# ---- the reference's DEFAULT forager of a model whose list slot supports precedence moves: FirstLastStepScoreImproving(256) --------------
+# compile_default_local_search_components (runtime/compiler/default_local_search/policy.rs:62-71); forager/improving.rs:111-227.  The step
+# ends at the first accepted candidate that beats the last step score (it is the pick whatever came before) or at `limit` accepted
+# candidates; the critical-path leaf's multi-swaps additionally pass the requires_score_improvement gate before they reach the acceptor.
+NINE_LEAVES = ("precedence", "permute", "list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt", "ruin")
+FLSI = 4
+
+
+def test_configure_default_picks_the_precedence_forager(oracle):
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(4, 3, seed=2)
+    d = sfa.build_precedence_shop(p, leaves=NINE_LEAVES, precedence_policy=True)
+    cfg = d.configure_default(random_seed=7)
+    assert (cfg.acceptor, cfg.late_acceptance_size, cfg.forager, cfg.accepted_count_limit) == (sfa.Acceptor.LATE_ACCEPTANCE, 400, FLSI, 256)
+    # a list slot without precedence hooks: AcceptedCount(256)
+    d2 = sfa.build_precedence_shop(p, leaves=("list_change", "list_swap"), precedence_policy=False)
+    cfg2 = d2.configure_default(random_seed=7)
+    assert (cfg2.acceptor, cfg2.forager, cfg2.accepted_count_limit) == (sfa.Acceptor.LATE_ACCEPTANCE, sfa.Forager.ACCEPTED_COUNT, 256)
+    # the default components run: 12 fused steps == oracle under the same components
+    o = oracle.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
+    o.configure(leaves=sum(BITS[x] for x in NINE_LEAVES), random_seed=7, la_size=400, limit=256, forager=FLSI)
+    o.set_ruin()
+    o.set_kopt(1, 0)
+    o.set_precedence_policy(True)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(12)
+    o.steps(12)
+    assert (d.calculate_score()[0] == o.score()[:2]).all() and d.working_lists(0, 0) == o.get_lists(0)
+    gst, ost = d.stats(0), o.stats()
+    for c in COUNTERS:
+        assert gst[c] == ost[c], c
+
+
+@pytest.mark.parametrize("limit", [256, 7, 0])
+@pytest.mark.parametrize("cyclic_start", [False, True])
+def test_nine_leaf_policy_under_the_default_forager(oracle, scratch, limit, cyclic_start):
+    """Traced + fused steps of the complete nine-leaf policy under FirstLastStepScoreImproving: limit 256 = the reference default (the
+    early quit decides almost every step), 7 = the accepted-count cut and the improving cut race inside one replay chunk, 0 = no limit
+    (the grouped-scalar default's form).  Every pull, trial score, flag (incl. the multi-swaps the improvement gate turns away), the
+    committed move and all counters == oracle."""
+    from solverforge_amd import datasets
+
+    p, _ = _shuffled(datasets.make_precedence_shop(6, 4, seed=12), 5)
+    if cyclic_start:
+        p["sequences"] = [list(reversed(s)) for s in p["sequences"]]
+    R = 3
+    d, mk = _policy_pair(oracle, p, NINE_LEAVES, 51, n_replicas=R, ruin=(2, 5, 3), la=6, limit=limit, forager=FLSI)
+    o = mk(51)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    gated = improving = 0
+    for step in range(10):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), (step, len(gm), len(om))
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+        gated += int(((gf >> 4) & 1).sum())
+        improving += int(len(gm) > 0 and (gf[-1] & 6) == 6)  # the step ended on an accepted candidate that is the pick
+    d.solve_steps(15)
+    scores = d.calculate_score()
+    for r in range(R):
+        o = mk(51 + r)
+        o.phase_start()
+        o.steps(25)
+        assert (scores[r] == o.score()[:2]).all(), r
+        assert d.working_lists(0, r) == o.get_lists(0), r
+        gst, ost = d.stats(r), o.stats()
+        for c in COUNTERS:
+            assert gst[c] == ost[c], (r, c)
+    assert (d.fresh_score() == scores).all()
+    if not cyclic_start:
+        assert improving > 0  # the early quit was exercised
+
+
+def test_default_forager_on_the_mixed_job_shop(oracle):
+    """Bendable<2,1> mixed job shop with the makespan objective under LateAcceptance + FirstLastStepScoreImproving(256): list leaves incl.
+    the critical-path leaf and the ruin leaf with hooks beside the scalar pair."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    p = datasets.construct_jobshop(datasets.make_jobshop(8, 4), seed=3)
+    p["durations"] = (datasets.stream(5, p["n_ops"]) % np.uint64(9)).astype(np.int64) + 1
+    leaves = ("precedence", "permute", "list_change", "list_swap", "sublist_change", "ruin", "change", "swap")
+    bits = PREC | PERMUTE | 4 | 8 | 128 | 1024 | 1 | 2
+    ruin = (2, 4, 3)
+    R = 2
+    d = sfa.build_jobshop(p, n_replicas=R, leaves=leaves, makespan=True, ruin=ruin, precedence_policy=True)
+    cfg = d.configure_default(random_seed=5)
+    assert (cfg.forager, cfg.accepted_count_limit) == (FLSI, 256)
+
+    def mk(seed):
+        o = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, durations=p["durations"])
+        o.configure(leaves=bits, random_seed=seed, la_size=400, limit=256, forager=FLSI)
+        o.set_ruin(ruin[0], ruin[1], ruin[2], variable_name="sequence")
+        o.set_precedence_policy(True)
+        return o
+
+    o = mk(5)
+    assert (d.calculate_score()[0] == o.score()[:3]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(8):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :3]).all(), step
+        assert gap == oap
+    d.solve_steps(17)
+    scores = d.calculate_score()
+    for r in range(R):
+        o = mk(5 + r)
+        o.phase_start()
+        o.steps(25)
+        assert (scores[r] == o.score()[:3]).all(), r
+        assert d.working_lists(1, r) == o.get_lists(1), r
+        assert (d.working_values(0, 0, replica=r) == o.get_vars(0, 0)).all(), r
+
+
+def test_element_capacity_below_the_node_count(oracle):
+    """the recreate's per-node tables (list predecessors, reachability marks) are rows of max(node_count, element_capacity)
+    words -- a list class whose capacity is smaller than the precedence graph (some nodes can never be scheduled) must not spill into the
+    next replica's rows."""
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(6, 3, seed=9)
+    n = len(p["durations"])
+    drop = {n - 1, n - 2, n - 4}
+    q = dict(p)
+    q["sequences"] = [[x for x in s if x not in drop] for s in p["sequences"]]
+    R = 3
+    d, mk = _policy_pair(oracle, q, POLICY_LEAVES, 17, n_replicas=R, ruin=(2, 5, 4), capacity=n - len(drop))
+    o = mk(17)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    d.solve_steps(20)
+    scores = d.calculate_score()
+    for r in range(R):
+        o = mk(17 + r)
+        o.phase_start()
+        o.steps(20)
+        assert (scores[r] == o.score()[:2]).all(), r
+        assert d.working_lists(0, r) == o.get_lists(0), r
     assert (d.fresh_score() == scores).all()
