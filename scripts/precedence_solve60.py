@@ -5,7 +5,8 @@ incremental refresh on one host core, same instance, same start: the feasible st
 side leaves in 60 s at 200+ nodes -- recorded in profiles/r02e_prec_solve60_shuffled_*.json).
 argv: seconds jobs machines replicas [start] [policy]: "policy" = the reference's complete default list policy of a slot with precedence
 hooks and no distance meter (critical-path leaf, permute, change, swap, sublist change / swap, reverse, full 3-opt, ruin; the slot's
-precedence policy on) instead of the four leaves above"""
+precedence policy on) instead of the four leaves above, under the reference's default components for such a slot: LateAcceptance(400) +
+FirstLastStepScoreImproving(256) (default_local_search/policy.rs:62-71; argv[7] = "accepted_count" keeps round 3's AcceptedCount(256))"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -30,7 +31,12 @@ if start_kind == "shuffled":
     rng = np.random.default_rng(7)
     p["sequences"] = [[int(x) for x in rng.permutation(s)] for s in p["sequences"]]  # a cyclic start
 d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves, precedence_policy=policy)
-d.configure(sfa.SolverConfig(random_seed=0))
+accepted_count = len(sys.argv) > 7 and sys.argv[7] == "accepted_count"
+if policy and not accepted_count:
+    cfg = d.configure_default(random_seed=0)  # FirstLastStepScoreImproving(256)
+else:
+    cfg = sfa.SolverConfig(random_seed=0)
+    d.configure(cfg)
 start = [int(v) for v in d.calculate_score()[0]]
 d.phase_start()
 t0 = time.perf_counter(); trace = []; k = 0
@@ -45,7 +51,7 @@ gpu = {"seconds": gt, "replicas": R, "best_score": list(max(tuple(int(v) for v i
        "moves_evaluated": st["moves_evaluated"], "moves_per_s": st["moves_evaluated"] / gt, "ls_steps_per_replica": st["step_count"] // R,
        "trace": trace}
 o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"])
-o.configure(leaves=sum(BITS[x] for x in leaves), random_seed=0)
+o.configure(leaves=sum(BITS[x] for x in leaves), random_seed=0, la_size=cfg.late_acceptance_size, forager=cfg.forager, limit=cfg.accepted_count_limit)
 o.set_kopt(1, 0)
 if policy:
     o.set_ruin()
@@ -56,5 +62,7 @@ steps = o.steps_timed(seconds)
 ct = time.perf_counter() - t0
 cpu = {"seconds": ct, "best_score": [int(v) for v in o.best_score()[:2]], "ls_steps": int(steps), "moves_evaluated": o.stats()["moves_evaluated"],
        "moves_per_s": o.stats()["moves_evaluated"] / ct}
-print(json.dumps({"workload": "job shop %dx%d, ListPrecedenceMakespan, %s start" % (J, M, start_kind), "leaves": list(leaves), "start_score": start,
+print(json.dumps({"workload": "job shop %dx%d, ListPrecedenceMakespan, %s start" % (J, M, start_kind), "leaves": list(leaves),
+                  "components": {"acceptor": cfg.acceptor, "late_acceptance_size": cfg.late_acceptance_size, "forager": cfg.forager,
+                                 "accepted_count_limit": cfg.accepted_count_limit}, "start_score": start,
                   "step_major_schedule_score": feasible, "gpu": gpu, "cpu_oracle_1core": cpu}))
