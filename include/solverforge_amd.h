@@ -618,6 +618,15 @@ int32_t sf_portfolio_allgather_best(sf_ctx* ctx, int64_t* out_best_score, int32_
 int32_t sf_portfolio_broadcast_best(sf_ctx* ctx, int32_t winner_rank, int32_t winner_replica, uint32_t* out_offsets,
                                     uint32_t* out_values);
 int32_t sf_portfolio_destroy(sf_ctx* ctx);
+/* EXTENSION (no reference counterpart; never called by parity runs): elite migration between the replicas of ONE context.  Replicas are
+ * ranked by best score (descending, ties to the lower index); the n_replace last ones adopt the best solution of the n_elite first ones
+ * (adopter i takes elite i % n_elite) as their working and best solution: per-route aggregates rebuilt, cached / last-step / best score =
+ * the elite's best score, LateAcceptance history restarted at that score; counters, step index and step seeds keep running, so the copies
+ * diverge.  An adopter whose best score already equals its elite's is left alone.  List-only models, HC / LA / DLA acceptors; call between
+ * launches (after sf_phase_start).  After a migration a replica's trajectory is no longer the reference's single-chain trajectory.
+ * out_adopted (may be NULL) = replicas that took a copy. */
+int32_t sf_portfolio_migrate_local(sf_ctx* ctx, int32_t n_elite, int32_t n_replace, int32_t* out_adopted);
+
 
 /* ---- candidate trace, wire format v3 (stats/candidate_trace.rs:15-60,718-812) ---------------
  * Host-side framing of what sf_solve_step_traced returned: every pull becomes the reference's canonical

@@ -16,7 +16,7 @@ L = _lib.load()
 out = np.zeros(8, dtype=np.uint64)
 for it in range(4):
     d.solve_steps(200)
-    L.sf_debug_phases(out.ctypes.data_as(ctypes.c_void_p))
+    L.sf_debug_phases_wave_2(out.ctypes.data_as(ctypes.c_void_p))
     ms, n = d.profile_solve()
     tot = out.sum()
     print("launch", it, "ms %.1f" % ms, "cycles/step/wave %.0f" % (tot / R / 200), "shares %", np.round(out / tot * 100, 1))

@@ -15,22 +15,25 @@ else:
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
 L = _lib.load()
+TU = "2_2_1_0" if "ruin" in leaves else ("4_2_0_0" if leaves[0] == "jobshop" else "2_2_0_0")  # the translation unit whose counters are read
+phases = getattr(L, "sf_debug_phases_mixed_" + TU)
+ruin_phases = getattr(L, "sf_debug_ruin_phases_mixed_" + TU)
 out = np.zeros(8, dtype=np.uint64)
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # local-search steps before the probe (late-phase behaviour)
 if warm:
     d.solve_steps(warm)
-    L.sf_debug_phases(out.ctypes.data_as(ctypes.c_void_p))
+    phases(out.ctypes.data_as(ctypes.c_void_p))
     d.profile_solve()
 for it in range(3):
     b = d.total_stats()
     d.solve_steps(100)
-    L.sf_debug_phases(out.ctypes.data_as(ctypes.c_void_p))
+    phases(out.ctypes.data_as(ctypes.c_void_p))
     ms, n = d.profile_solve()
     a = d.total_stats()
     tot = out.sum()
     if "ruin" in leaves:  # shader clocks inside ruin_recreate: 0 remove, 1 slot prefix, 2 scan, 3 pick + bookkeeping, 4 placement, 5 undo
         ro = np.zeros(8, dtype=np.uint64)
-        L.sf_debug_ruin_phases(ro.ctypes.data_as(ctypes.c_void_p))
+        ruin_phases(ro.ctypes.data_as(ctypes.c_void_p))
         print("  ruin_recreate cycles/step/wave %.0f" % (ro.sum() / R / 100), "shares %", np.round(ro / max(ro.sum(), 1) * 100, 1))
     print("launch", it, "ms %.1f" % ms, "Gmoves/s %.2f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / ms / 1e6),
           "moves/step %.0f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / R / 100),

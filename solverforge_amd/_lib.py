@@ -76,7 +76,7 @@ SYMBOLS = [
     "sf_get_annealing_state", "sf_solver_set_step_seeds",
     "sf_solver_set_engine", "sf_solver_get_engine", "sf_phase_start", "sf_solve_steps", "sf_solve_moves", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
-    "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_broadcast_best", "sf_portfolio_destroy",
+    "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_broadcast_best", "sf_portfolio_destroy", "sf_portfolio_migrate_local",
     "sf_trace_digest_init", "sf_trace_digest_update", "sf_trace_encode_step",
 ]
 
@@ -161,6 +161,7 @@ def load():
     L.sf_portfolio_allgather_best.argtypes = [vp, vp, vp, vp]
     L.sf_portfolio_destroy.argtypes = [vp]
     L.sf_portfolio_broadcast_best.argtypes = [vp, i32, i32, vp, vp]
+    L.sf_portfolio_migrate_local.argtypes = [vp, i32, i32, C.POINTER(i32)]
     L.sf_trace_digest_init.argtypes = [C.POINTER(TraceDigestStruct)]
     L.sf_trace_digest_update.argtypes = [C.POINTER(TraceDigestStruct), vp, C.c_size_t]
     L.sf_trace_encode_step.argtypes = [C.POINTER(TraceScopeStruct), u64, u64, vp, vp, i64, vp, i64, C.POINTER(TraceDigestStruct)]

@@ -2648,6 +2648,59 @@ int32_t sf_get_best_scores(sf_ctx* ctx, int64_t* out) {
     return download_scores(ctx, ctx->has_list_model ? ctx->lm.best_score : ctx->sm.best_score, out);
 }
 
+// Elite migration between the replicas of one context (extension; see k_list_migrate).  Replicas are ranked by their best score
+// (descending, ties to the lower index); the n_replace last ones adopt the best solution of the n_elite first ones, adopter i
+// taking elite i % n_elite.
+int32_t sf_portfolio_migrate_local(sf_ctx* ctx, int32_t n_elite, int32_t n_replace, int32_t* out_adopted) {
+    DeviceGuard _dev(ctx);
+    if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
+    if (!ctx->search_alloc) return fail(ctx, SF_ERR_INVALID, "sf_phase_start first");
+    if (!ctx->has_list_model || ctx->has_scalar_model)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "elite migration: list-only models (the adopted state is the list class's best solution)");
+    if (ctx->cfg.acceptor == SF_ACCEPT_SIMULATED_ANNEALING)
+        return fail(ctx, SF_ERR_UNSUPPORTED, "elite migration: HillClimbing / LateAcceptance / DiversifiedLateAcceptance (an annealing replica keeps a temperature schedule)");
+    if (n_elite < 1 || n_replace < 0 || (int64_t)n_elite + n_replace > ctx->R)
+        return fail(ctx, SF_ERR_INVALID, "elite migration: n_elite >= 1, n_replace >= 0, n_elite + n_replace <= replicas");
+    if (out_adopted) *out_adopted = 0;
+    if (n_replace == 0) return SF_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> bs((size_t)ctx->R * ctx->levels);
+    if (int rc = download_scores(ctx, ctx->lm.best_score, bs.data())) return rc;
+    std::vector<int32_t> order(ctx->R), src(ctx->R);
+    for (int r = 0; r < ctx->R; ++r) order[r] = src[r] = r;
+    const int L = ctx->levels;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        for (int k = 0; k < L; ++k) {
+            const int64_t x = bs[(size_t)a * L + k], y = bs[(size_t)b * L + k];
+            if (x != y) return x > y;
+        }
+        return false;
+    });
+    int adopted = 0;
+    for (int i = 0; i < n_replace; ++i) {
+        const int32_t adopter = order[(size_t)ctx->R - 1 - i], elite = order[(size_t)(i % n_elite)];
+        bool same = true;  // an adopter that already holds the elite's score keeps searching from its own state
+        for (int k = 0; k < L; ++k) same = same && bs[(size_t)adopter * L + k] == bs[(size_t)elite * L + k];
+        if (same) continue;
+        src[adopter] = elite;
+        adopted += 1;
+    }
+    if (adopted) {
+        int32_t* d_src = nullptr;
+        hipError_t e = hipMalloc((void**)&d_src, (size_t)ctx->R * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_src, src.data(), (size_t)ctx->R * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_list_migrate, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->lm, ctx->sp, d_src);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_src);
+        if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    }
+    if (out_adopted) *out_adopted = adopted;
+    return SF_OK;
+}
+
 int32_t sf_download_list(sf_ctx* ctx, int32_t replica, int32_t d, uint32_t* out_off, uint32_t* out_vals, int32_t best) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->has_list_model || d != ctx->list_desc || replica < 0 || replica >= ctx->R)

@@ -1128,6 +1128,44 @@ __global__ __launch_bounds__(256) void k_list_phase_start(ListModel m, SearchPar
     }
 }
 
+// Elite migration inside one context (sf_portfolio_migrate_local; an extension, not in the reference): replica r with
+// src[r] != r adopts the BEST solution of replica src[r] as its working and best solution.  Its per-route loads are rebuilt
+// from the adopted lists, its cached / last-step / best score is the elite's best score and its LateAcceptance history
+// restarts at that score (phase_started semantics, late_acceptance.rs:89-101); counters, step index and seed draws keep
+// running, so the copies diverge from the elite and from each other.  Elites (src[r] == r) are never written.  grid = R.
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_list_migrate(ListModel m, SearchParams p, const int32_t* __restrict__ src) {
+    const int r = blockIdx.x;
+    const int s = src[r];
+    if (s == r) return;
+    const uint32_t* so = m.best_off + (size_t)s * (m.V + 1);
+    const uint32_t* sv = m.best_visits + (size_t)s * m.n_cap;
+    const uint32_t tot = so[m.V];
+    for (uint32_t t = threadIdx.x; t <= (uint32_t)m.V; t += blockDim.x) {
+        m.off[(size_t)r * (m.V + 1) + t] = so[t];
+        m.best_off[(size_t)r * (m.V + 1) + t] = so[t];
+    }
+    for (uint32_t t = threadIdx.x; t < tot; t += blockDim.x) {
+        m.visits[(size_t)r * m.n_cap + t] = sv[t];
+        m.best_visits[(size_t)r * m.n_cap + t] = sv[t];
+    }
+    for (uint32_t v = threadIdx.x; v < (uint32_t)m.V; v += blockDim.x) {
+        int64_t ld = 0;
+        if (m.demand)
+            for (uint32_t q = so[v]; q < so[v + 1]; ++q) ld = wadd(ld, (int64_t)m.demand[sv[q]]);
+        m.load[(size_t)r * m.V + v] = ld;
+    }
+    const int64_t* bs = m.best_score + (size_t)s * 4;
+    for (int k = threadIdx.x; k < 4; k += blockDim.x) {
+        m.score[(size_t)r * 4 + k] = bs[k];
+        m.best_score[(size_t)r * 4 + k] = bs[k];
+        p.last_step_score[(size_t)r * 4 + k] = bs[k];
+        if (p.dla_best) p.dla_best[(size_t)r * 4 + k] = bs[k];
+    }
+    for (int h = threadIdx.x; h < p.la_size * 4; h += blockDim.x) p.la_hist[(size_t)r * p.la_size * 4 + h] = bs[h & 3];
+    if (threadIdx.x == 0) p.la_idx[r] = 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // The fused persistent search kernel.
 // ---------------------------------------------------------------------------------------

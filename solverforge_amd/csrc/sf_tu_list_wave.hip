@@ -15,3 +15,14 @@ hipError_t launch_tu_list_wave<SF_TU_L>(bool trace, int mode, const SearchLaunch
 }
 
 }  // namespace sf
+
+#ifdef SF_PHASE_PROFILE  // diagnostic builds: this unit's copy of the phase counters (a __device__ variable is per translation unit)
+#define SF_PH_NAME2(l) sf_debug_phases_wave_##l
+#define SF_PH_NAME(l) SF_PH_NAME2(l)
+extern "C" int32_t SF_PH_NAME(SF_TU_L)(uint64_t* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_phase), 64) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sf::g_phase), z, 64);
+    return 0;
+}
+#endif

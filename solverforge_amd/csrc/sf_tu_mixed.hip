@@ -35,3 +35,20 @@ hipError_t launch_tu_mixed<SF_TU_L, SF_TU_VTB, SF_TU_RUIN != 0, SF_TU_PREC != 0>
 }
 
 }  // namespace sf
+
+#ifdef SF_PHASE_PROFILE  // diagnostic builds: this unit's copies of the phase counters (a __device__ variable is per translation unit)
+#define SF_PH_NAME2(p, l, v, r, q) p##_##l##_##v##_##r##_##q
+#define SF_PH_NAME(p, l, v, r, q) SF_PH_NAME2(p, l, v, r, q)
+extern "C" int32_t SF_PH_NAME(sf_debug_phases_mixed, SF_TU_L, SF_TU_VTB, SF_TU_RUIN, SF_TU_PREC)(uint64_t* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_phase), 64) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sf::g_phase), z, 64);
+    return 0;
+}
+extern "C" int32_t SF_PH_NAME(sf_debug_ruin_phases_mixed, SF_TU_L, SF_TU_VTB, SF_TU_RUIN, SF_TU_PREC)(uint64_t* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_rphase), 64) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sf::g_rphase), z, 64);
+    return 0;
+}
+#endif

@@ -554,5 +554,12 @@ class GpuScoreDirector:
         check(self._L.sf_portfolio_broadcast_best(self._h, winner_rank, winner_replica, ptr(off), ptr(vals)), self._h)
         return [list(map(int, vals[off[i]: off[i + 1]])) for i in range(n)]
 
+    def migrate_local(self, n_elite, n_replace):
+        """EXTENSION (sf_portfolio_migrate_local): the n_replace replicas with the worst best score adopt the best solution of the
+        n_elite best ones (LateAcceptance history restarted at the adopted score); returns how many replicas took a copy."""
+        n = C.c_int32(0)
+        check(self._L.sf_portfolio_migrate_local(self._h, int(n_elite), int(n_replace), C.byref(n)), self._h)
+        return n.value
+
     def portfolio_destroy(self):
         check(self._L.sf_portfolio_destroy(self._h), self._h)
