@@ -33,6 +33,13 @@ is structural only, crates/solverforge-cvrp/src/helpers.rs:77-87: the merge ends
 size, and no 60 s search repairs it); the default `savings_capacity` is an EXTENSION: the same phases with a capacity-checking
 `feasible` hook a model may supply (the capacity part of route_hooks::feasible; no time windows are modelled here).
 
+M2, second leg (`--tuned-seconds`, default 60; `extra.best_score_at_60s.tuned`).  An EXTENSION beside the parity leg, labelled as such: the
+same problem, start and leaves as M1 (the two-leaf nearby union on the wave engine), but a configuration a user of the reference may set
+through the same facade -- LateAcceptance(5000) + AcceptedCount(1), i.e. classic late-acceptance hill climbing at the step rate the device
+sustains (the default's best-of-256 forager makes every step a steepest-descent step: its 60 s curve is flat after ~25 s) -- 1,024 replicas,
+and elite migration every 5 s (sf_portfolio_migrate_local: the worse half adopts the best solutions of the top eight).  The CPU oracle runs
+the same configuration on one host core beside it.  profiles/r04b_m2_config_sweep_*.jsonl hold the sweep this configuration came from.
+
 Multi-GPU.  `python bench.py --gpus N` spawns N ranks itself (torch.distributed.run, one process per GPU) when it is
 not already running under a launcher; it refuses to run with fewer devices than ranks.  Independent seeds per rank
 (weak scaling, no data-path collective); at the end every rank contributes its best score to one RCCL all-gather over
@@ -89,6 +96,9 @@ M2_POLICIES = {
     "nearby2": ("nearby_change", "nearby_swap"),
 }
 M2_REPLICAS = {"default": 1280, "default6": 3072, "nearby2": None}  # replicas per GPU of the M2 leg (None = --replicas)
+# M2 extension leg (module docstring): what is varied against the parity leg, and nothing else
+TUNED = {"leaves": ("nearby_change", "nearby_swap"), "late_acceptance_size": 5000, "accepted_count_limit": 1, "replicas": 1024,
+         "migration_period_s": 5.0, "migration_replace_fraction": 0.5, "migration_elite": 8, "launch_move_budget": 200_000}
 LEAF_BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024}
 
 # The instruction counters first (the issue rooflines need them), then the two TCC traffic counters in passes of their own, then the
@@ -138,7 +148,7 @@ def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
     }
 
 
-def cpu_solve(problem, seed, seconds, box, start="roundrobin", leaves=("nearby_change", "nearby_swap")):
+def cpu_solve(problem, seed, seconds, box, start="roundrobin", leaves=("nearby_change", "nearby_swap"), la_size=400, limit=256):
     """M2 on the host: the oracle searches for `seconds` of wall clock on one core (runs beside the GPU solve; the
     ctypes call releases the GIL).  A savings start (Clarke-Wright construction) is built inside the budget."""
     try:
@@ -146,7 +156,7 @@ def cpu_solve(problem, seed, seconds, box, start="roundrobin", leaves=("nearby_c
 
         o = sfo.Model.cvrp(problem["capacity"], problem["depot"], problem["demands"], problem["matrix"],
                            problem["customers"], problem["routes"])
-        o.configure(leaves=sum(LEAF_BITS[x] for x in leaves), max_nearby=20, random_seed=seed)
+        o.configure(leaves=sum(LEAF_BITS[x] for x in leaves), max_nearby=20, random_seed=seed, la_size=la_size, limit=limit)
         o.set_ruin()
         t0 = time.perf_counter()
         if start != "roundrobin":
@@ -269,8 +279,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=5120,
-                    help="independent searches resident per GPU (5120 = 20 per CU: the COMPACT wave kernel runs 5 waves per SIMD at CVRP-1000)")
+    ap.add_argument("--replicas", type=int, default=24576,
+                    help="independent searches per GPU and launch (24576 = 4 x 24 per CU: the COMPACT wave kernel runs 6 waves per SIMD at CVRP-1000, "
+                         "and a launch of several residencies keeps every CU busy while the slower replicas of the first finish -- one residency "
+                         "alone leaves a quarter of the slot time idle, profiles/r04c_wave_replica_sweep.txt)")
     ap.add_argument("--ls-steps", type=int, default=200, help="local-search steps per launch")
     ap.add_argument("--customers", type=int, default=1000)
     ap.add_argument("--vehicles", type=int, default=100)
@@ -288,6 +300,8 @@ def main():
     ap.add_argument("--solve-policy", choices=sorted(M2_POLICIES), default="default",
                     help="M2 leaves on both sides: default = the reference's seven-leaf default list policy, default6 = without ruin, "
                          "nearby2 = the two-leaf nearby union M1 is timed on")
+    ap.add_argument("--tuned-seconds", type=float, default=60.0,
+                    help="M2 extension leg: wall-clock budget of the tuned configuration (0 = skip); see TUNED below")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -332,13 +346,14 @@ def main():
         sys.exit(2)
     seed_base = portfolio.rank_seed_base(args.seed, rank, args.replicas)
 
-    def new_director(prob=None, leaves=("nearby_change", "nearby_swap"), replicas=None):
+    def new_director(prob=None, leaves=("nearby_change", "nearby_swap"), replicas=None, la_size=400, limit=256):
         nrep = replicas or args.replicas
         d = sfa.build_cvrp(prob if prob is not None else problem, n_replicas=nrep, device_id=local_rank, leaves=leaves)
         if len(leaves) == 2:
             d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
         # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
-        d.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, nrep)))
+        d.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, nrep), late_acceptance_size=la_size,
+                                     accepted_count_limit=limit))
         return d
 
     d = new_director()
@@ -422,6 +437,51 @@ def main():
         if dist is not None:
             solve["moves_evaluated_all_ranks"] = portfolio.sum_over_ranks(dist, st2["moves_evaluated"])
         dx = d2
+
+    # ---- M2 extension leg: the tuned configuration (TUNED), elite migration on; the CPU oracle with the same configuration beside it ----
+    tuned = None
+    if args.tuned_seconds > 0 and args.solve_seconds > 0:
+        prob3 = problem if args.solve_start == "roundrobin" else dict(problem, routes=[[] for _ in problem["routes"]])
+        d3 = new_director(prob3, TUNED["leaves"], TUNED["replicas"], TUNED["late_acceptance_size"], TUNED["accepted_count_limit"])
+        d3.calculate_score()
+        cpu_box3 = {}
+        cpu_thread3 = None
+        if rank == 0 and not args.no_cpu_baseline:
+            cpu_thread3 = threading.Thread(target=cpu_solve, args=(prob3, args.seed, args.tuned_seconds, cpu_box3, args.solve_start, TUNED["leaves"],
+                                                                   TUNED["late_acceptance_size"], TUNED["accepted_count_limit"]), daemon=True)
+        barrier(d3)
+        if cpu_thread3:
+            cpu_thread3.start()
+        t3 = time.perf_counter()
+        t3_start = None
+        if args.solve_start != "roundrobin":
+            d3.construct_list_clarke_wright(0, prob3["customers"], 1 if args.solve_start == "savings_capacity" else 0)
+            t3_start = d3.construct_list_k_opt(0, 2, 1)[0].tolist()
+        d3.phase_start()
+        n3, migrations, adopted, next_m = 0, 0, 0, TUNED["migration_period_s"]
+        while time.perf_counter() - t3 < args.tuned_seconds:
+            d3.solve_moves(1 << 20, TUNED["launch_move_budget"], sync=True)
+            n3 += 1
+            now = time.perf_counter() - t3
+            if now >= next_m and now < args.tuned_seconds - 0.5 * TUNED["migration_period_s"]:
+                adopted += d3.migrate_local(TUNED["migration_elite"], int(TUNED["replicas"] * TUNED["migration_replace_fraction"]))
+                migrations += 1
+                next_m += TUNED["migration_period_s"]
+        s3 = time.perf_counter() - t3
+        st3 = d3.total_stats()
+        best3 = max(tuple(int(v) for v in s_) for s_ in d3.best_scores())
+        if dist is not None:  # best over the ranks (host-side gather: the parity leg's exchange below is the RCCL one)
+            best3 = tuple(portfolio.gloo_allgather_best(dist, best3, rank, world)[1])
+        tuned = {"seconds": s3, "gpu": list(best3), "gpu_moves_per_s_rank0": st3["moves_evaluated"] / s3, "gpu_ls_steps_per_replica": st3["step_count"] / TUNED["replicas"],
+                 "gpu_launches": n3, "migrations": migrations, "replicas_that_adopted": adopted, "start_score": t3_start,
+                 "config": dict(TUNED, leaves=list(TUNED["leaves"])),
+                 "note": "EXTENSION beside the parity leg: a configuration of the same facade (LateAcceptance size, AcceptedCount limit) chosen for the "
+                         "device's step rate, plus elite migration (sf_portfolio_migrate_local, no reference counterpart); the replicas are no "
+                         "longer the reference's single-chain trajectories after the first migration"}
+        if cpu_thread3:
+            cpu_thread3.join(timeout=args.tuned_seconds + 30)
+            tuned["cpu_oracle_same_config"] = cpu_box3.get("result", {"error": cpu_box3.get("error", "did not finish")})
+        d3.close()
 
     # ---- portfolio exchange: RCCL all-gather of best scores (correctness: identical winner everywhere) -------------
     exchange = "single-rank"
@@ -611,6 +671,8 @@ def main():
                           + f") on both sides, LateAcceptance(400)+AcceptedCount(256), {solve['replicas']} replicas per GPU; work-balanced launches "
                           f"(sf_solve_moves, {args.solve_budget} candidates per replica per launch)",
             }
+        if solve is not None and tuned is not None:
+            out["extra"]["best_score_at_60s"]["tuned"] = tuned
         if not args.no_cpu_baseline:
             cb = cpu_baseline(problem, args.seed, args.warmup * args.ls_steps, args.steps * args.ls_steps,
                               args.cpu_seconds)

@@ -1027,14 +1027,14 @@ static int launch_list_search_t(sf_ctx* ctx, const SearchParams& p, int grid, bo
 template <int L>
 static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas, bool trace) {
     const bool fast = !trace && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
-                      p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP;
+                      p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP && p.order == SF_ORDER_RANDOM;
     // replicas (waves) per workgroup: as many as the LDS holds, <= WPB; resident replicas per CU = whole workgroups in 160 KiB
     auto plan = [&](bool compact, size_t wave_cap, int& wpb_out, size_t& lds_out) {
         WCarve cvx(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx), compact);
         size_t best = 0;
         wpb_out = 1;
         for (int w = 1; w <= WPB; ++w) {  // the workgroup size that keeps the most replicas resident (a workgroup's LDS is allocated whole)
-            const size_t per_wg = cvx.total * (size_t)w + 1024;  // + the static annealing state
+            const size_t per_wg = cvx.total * (size_t)w + (fast ? 0 : 1024);  // + the static annealing state (the FAST instantiations have none)
             if (cvx.total * (size_t)w > SF_LDS_BUDGET) break;
             size_t groups = (160 * 1024) / per_wg;
             if (groups * (size_t)w > wave_cap) groups = wave_cap / (size_t)w;  // waves per CU by register budget
@@ -1056,8 +1056,14 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
         static const bool no_compact = std::getenv("SF_AMD_NO_COMPACT") != nullptr;  // diagnostics: A/B
         int wpb_c = 1;
         size_t lds_c = 0;
-        const size_t r5 = no_compact ? 0 : plan(true, 20, wpb_c, lds_c);
-        if (r5 > 16 && r5 > resident_wide) {
+        static const int max_wpe = std::getenv("SF_AMD_WAVE_WPE") ? std::atoi(std::getenv("SF_AMD_WAVE_WPE")) : 6;  // diagnostics: cap the waves per SIMD
+        const size_t r6 = (no_compact || max_wpe < 6) ? 0 : plan(true, 24, wpb_c, lds_c);
+        const size_t r5 = (no_compact || max_wpe < 5 || r6 > 20) ? 0 : plan(true, 20, wpb_c, lds_c);
+        if (r6 > 20 && r6 > resident_wide) {  // 24 replicas per CU: the instantiation compiled for 6 waves per SIMD (80 VGPRs)
+            mode = 5;
+            wpb = wpb_c;
+            lds = lds_c;
+        } else if (r5 > 16 && r5 > resident_wide) {
             mode = 4;
             wpb = wpb_c;
             lds = lds_c;

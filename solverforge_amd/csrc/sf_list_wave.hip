@@ -116,8 +116,8 @@ struct WCarve {
         o = align_up(o + sizeof(uint16_t) * n_cap, 16);
         rtab = o;  // [leaf][route] u32: rank of the route in the leaf's entity order | first destination slot ordinal << 16
         o = align_up(o + sizeof(uint32_t) * V * MAX_LEAVES, 16);
-        routeat = o;
-        o = align_up(o + sizeof(uint16_t) * V * MAX_LEAVES, 16);
+        routeat = o;  // [leaf][rank] -> route; the compact layout recomputes it from the leaf's permutation parameters instead
+        o = align_up(o + (compact ? 0 : sizeof(uint16_t) * V * MAX_LEAVES), 16);
         total = o;
     }
 };
@@ -155,14 +155,18 @@ struct NodeSlotT<true> {
     }
     __device__ __forceinline__ uint32_t get(uint32_t node) const {
         const uint32_t s = p[node];
-        if (s == 0xFFFFu) return NODE_NONE;
+        const bool none = s == 0xFFFFu;
         const uint32_t route = s >> pb;
         uint32_t pos = s & pmax;
-        if (pos == pmax) {  // saturated: the node sits at position >= pmax of its route
-            const uint32_t o = off[route], len = off[route + 1] - o;
-            while (pos + 1 < len && (uint32_t)visits[o + pos] != node) ++pos;
+        // saturated: the node sits at position >= pmax of its route.  Rare (routes that long), so the test is ONE wave-uniform branch
+        // on a ballot and the common path has no exec-mask region at all
+        if (__ballot(!none && pos == pmax) != 0ull) {
+            if (!none && pos == pmax) {
+                const uint32_t o = off[route], len = off[route + 1] - o;
+                while (pos + 1 < len && (uint32_t)visits[o + pos] != node) ++pos;
+            }
         }
-        return (route << 16) | pos;
+        return none ? NODE_NONE : ((route << 16) | pos);
     }
 };
 // does the compact layout carry this model?  route ids need a bit pattern below all-ones, positions at least 6 bits
@@ -525,31 +529,28 @@ __device__ __forceinline__ int32_t clamp_i64_to_i32(int64_t v) {
 template <int L, class LT, bool M16 = false>
 __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const uint16_t* visits, const uint32_t* off, const LT* load,
                                                      bool chg, uint32_t a, uint32_t i, uint32_t b, uint32_t j, int32_t (&dv)[L]) {
-#pragma unroll
-    for (int k = 0; k < L; ++k) dv[k] = 0;
+    // Branch-free on purpose: every neighbour is read from a position that always exists (the source position when the real one does
+    // not) and replaced by the depot with a select afterwards, the doability tests are one predicate at the end.  Conditional LDS reads
+    // cost an exec-mask save / restore pair on the scalar unit each, and the scalar unit -- shared by the 20 waves of a CU -- is the
+    // busiest pipe of this kernel.
     const uint32_t oa = off[a], la = off[a + 1] - oa;
     const uint32_t ob = off[b], lb = off[b + 1] - ob;
     const bool intra = a == b;
-    if (chg) {  // move/list_kernel/change.rs:44-71
-        if (i >= la || j > lb || (intra && (j == i || j == i + 1))) return false;
-    } else {  // move/list_kernel/swap.rs:30-56
-        if (i >= la || j >= lb || (intra && i == j)) return false;
-    }
-    if (!chg && intra && i > j) {
-        const uint32_t t = i;
-        i = j;
-        j = t;
-    }
+    // move/list_kernel/change.rs:44-71, swap.rs:30-56
+    bool ok = i < la && (chg ? j <= lb : j < lb) && !(intra && (j == i || (chg && j == i + 1)));
+    const bool flip = !chg && intra && i > j;
+    const uint32_t i2 = flip ? j : i, j2 = flip ? i : j;
     const uint32_t depot = (uint32_t)m.depot;
-    const uint32_t P = oa + i, Q = ob + j;
+    const uint32_t P = ok ? oa + i2 : oa, Q = ob + j2;  // a lane whose candidate is not doable reads its list's first slot (exists or is harmless)
+    const bool has_pa = i2 > 0, has_na = i2 + 1 < la, has_q = j2 < lb, has_pb = j2 > 0, has_nb = j2 + 1 < lb;
     const uint32_t x = visits[P];
-    const uint32_t pa = i > 0 ? (uint32_t)visits[P - 1] : depot;
-    const uint32_t na = i + 1 < la ? (uint32_t)visits[P + 1] : depot;
-    const uint32_t vq = j < lb ? (uint32_t)visits[Q] : depot;  // change: right neighbour of the slot; swap: y
-    const uint32_t pb = j > 0 ? (uint32_t)visits[Q - 1] : depot;
-    const uint32_t nb = j + 1 < lb ? (uint32_t)visits[Q + 1] : depot;
-    if (!chg && x == vq) return false;
-    const bool adj = !chg && intra && j == i + 1;
+    const uint32_t r_pa = visits[has_pa ? P - 1 : P], r_na = visits[has_na ? P + 1 : P];
+    const uint32_t r_q = visits[(ok && has_q) ? Q : P], r_pb = visits[(ok && has_pb) ? Q - 1 : P], r_nb = visits[(ok && has_nb) ? Q + 1 : P];
+    const uint32_t pa = has_pa ? r_pa : depot, na = has_na ? r_na : depot;
+    const uint32_t vq = has_q ? r_q : depot;  // change: right neighbour of the slot; swap: y
+    const uint32_t pb = has_pb ? r_pb : depot, nb = has_nb ? r_nb : depot;
+    ok = ok && (chg || x != vq);
+    const bool adj = !chg && intra && j2 == i2 + 1;
     const bool ca = chg || adj;
     const bool src_single = la == 1, dst_empty = !intra && lb == 0;
     // plus legs P0..P3, minus legs M0..M3 (change | swap | adjacent swap):
@@ -567,23 +568,16 @@ __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const u
     const uint32_t p0 = leg(pa, chg ? na : vq);
     const uint32_t p1 = leg(chg ? pb : vq, ca ? x : na);
     const uint32_t p2 = leg(ca ? x : pb, chg ? vq : (adj ? nb : x));
-#ifdef SF_PROBE_HALF_LEGS  // perf probe only (wrong results): four matrix gathers instead of eight
-    const uint32_t p3 = x + nb, m0 = pa + x, m1 = x + na, m3 = vq + nb;
-#else
     const uint32_t p3 = leg(x, nb);
     const uint32_t m0 = leg(pa, x);
     const uint32_t m1 = leg(x, adj ? vq : na);
     const uint32_t m3 = leg(vq, nb);
-#endif
     const uint32_t m2 = leg(adj ? vq : pb, adj ? nb : vq);
     int32_t d_cap = 0;
     if (m.cap_level >= 0) {
-#ifdef SF_PROBE_NO_DEMAND  // perf probe only (wrong results): how much do the two demand gathers cost?
-        const int32_t dx = 3, dy = chg ? 0 : 5;
-#else
         const int32_t dx = m.demand[x];
-        const int32_t dy = chg ? 0 : m.demand[vq];
-#endif
+        const int32_t dyq = m.demand[vq];  // read for every lane, used by the swaps
+        const int32_t dy = chg ? 0 : dyq;
         const int32_t cap = (int32_t)m.capacity;
         const int32_t la0 = (int32_t)load[a], lb0 = (int32_t)load[b];
         const int32_t la1 = la0 - dx + dy, lb1 = lb0 - dy + dx;
@@ -599,9 +593,9 @@ __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const u
         int32_t v = 0;
         if (k == m.cap_level) v -= cw * d_cap;
         if (k == m.dist_level) v -= dw * d_dist;
-        dv[k] = v;
+        dv[k] = ok ? v : 0;
     }
-    return true;
+    return ok;
 }
 
 // Per-leaf cursor state of one step.  The NEXT source of the leaf is always resolved ahead of use
@@ -630,8 +624,9 @@ struct LeafCursor {
 #endif
 // COMPACT (with MODE 2 only): the replica's LDS slice in the compact layout of WCarve, chosen by the host when it lets more
 // replicas share a CU (CVRP-5000: 5 instead of 3).
-// WPE = waves per SIMD the kernel is compiled for (512 / WPE VGPRs): 4, or 5 for the COMPACT slice of a model small enough for 20
-// replicas per CU (CVRP-1000: 96 VGPRs + 120 B of scratch, +5 % over 4 waves; 6 waves / 80 VGPRs measured -11 %).
+// WPE = waves per SIMD the kernel is compiled for (512 / WPE VGPRs): 4, or 5 / 6 for the COMPACT slice of a model small enough for 20 /
+// 24 replicas per CU.  Round 4: with the replica index declared wave-uniform the per-replica base pointers live in scalar registers and
+// the MODE 2 kernels need 77 VGPRs and no scratch (they were 96 VGPRs + 120 B: 64-bit pointer pairs spilled in the prologue).
 template <int L, bool TRACE, int MODE, bool COMPACT = false, int WPE = SF_WAVES_PER_EU>
 __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     constexpr bool FAST = MODE >= 1, SMALL = MODE == 2;
@@ -639,7 +634,10 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     using LT = typename std::conditional<COMPACT, int32_t, int64_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
-    const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));  // 1..WPB replicas per workgroup
+    // wave-uniform by construction; saying so keeps every per-replica base pointer in scalar registers (they were 64-bit VGPR pairs
+    // spilled to scratch in the prologue and reloaded for the write-back)
+    const uint32_t wave_in_group = uni(threadIdx.x >> 6);
+    const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + wave_in_group);  // 1..WPB replicas per workgroup
     if (rr >= p.n_launch) return;  // no workgroup barrier anywhere below
     const int r = rr + p.replica_base;
     const int V = m.V;
@@ -652,7 +650,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     const int acceptor = FAST ? 1 : p.acceptor, forager = FAST ? 0 : p.forager;
     const bool dry_run = FAST ? false : p.dry_run != 0;
     __shared__ uint64_t s_sa[WPB][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
-    uint64_t* saw = s_sa[threadIdx.x >> 6];
+    uint64_t* saw = s_sa[wave_in_group];
     const bool annealing = !FAST && acceptor == 3;
     if constexpr (!FAST)
         if (annealing) sa_load(saw, p.sa, r, lane);
@@ -660,7 +658,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
 
     const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1), COMPACT);
     const uint32_t RCM = cv.rc - 1;
-    unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
+    unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
     LT* s_load = (LT*)(mem + cv.load);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][rc][2]
@@ -747,7 +745,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         }
         sidx = uni64(sidx);
         sseed = uni64(sseed);
-        const StreamCtx ctx{sidx, sseed, p.order};
+        const StreamCtx ctx{sidx, sseed, FAST ? 3 : p.order};  // FAST: SelectionOrder::Random, the default policy's (host-checked)
         ScoreV<L> late;
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
@@ -785,6 +783,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         // the stride is always 1, so the order is first, other, first, ...
         const uint32_t first_leaf = n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u;
 
+        uint32_t perm_st0 = 0, perm_sd0 = 1, perm_st1 = 0, perm_sd1 = 1;  // entity permutations of the two leaves (set in (B))
         // resolve the source at cursor (k, o) of leaf l and put its first key chunk in flight
         auto resolve = [&](LeafCursor& c, int l) {
             const uint16_t* ra = route_at + l * V;
@@ -792,7 +791,10 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             if (k != c.vk || o >= len) {  // a new entity: its list owner and length (skip empty routes; left > 0
                                           // guarantees a source exists)
                 for (;;) {
-                    se = uni((uint32_t)ra[k]);
+                    if constexpr (COMPACT)  // no rank -> route table in the compact slice: the permutation itself (a few entities per step)
+                        se = uni(fastmod_u64((uint64_t)(l ? perm_st1 : perm_st0) + (uint64_t)k * (l ? perm_sd1 : perm_sd0), fm_V));
+                    else
+                        se = uni((uint32_t)ra[k]);
                     len = uni(s_off[se + 1] - s_off[se]);
                     if (o < len) break;
                     ++k;
@@ -836,6 +838,10 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
             pst = uni(pst);
             psd = uni(psd);
+            if (l)
+                perm_st1 = pst, perm_sd1 = psd;
+            else
+                perm_st0 = pst, perm_sd0 = psd;
             uint16_t* ra = route_at + l * V;
             uint32_t* rt = rtab + l * V;
             uint32_t carry = 0;  // first slot ordinal of rank k = sum_{k'<k} (len(route_at[k']) + 1)
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 uint32_t v = 0, e = 0;
                 if (k < (uint32_t)V) {
                     e = fastmod_u64((uint64_t)pst + (uint64_t)k * psd, fm_V);
-                    ra[k] = (uint16_t)e;
+                    if constexpr (!COMPACT) ra[k] = (uint16_t)e;
                     v = s_off[e + 1] - s_off[e] + 1;
                 }
                 const uint32_t inc = wave_incl_scan(v);
@@ -984,7 +990,8 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                     const bool have = key != NBR_END;
                     NearbyItem it{0u, 0u, 0u, 0u};
                     {
-                        const uint32_t slot = have ? node_slot.get(key & NBR_NODE_MASK) : NODE_NONE;
+                        const uint32_t slot_any = node_slot.get(have ? (key & NBR_NODE_MASK) : 0u);  // unconditional read (node 0 for the lanes past the row)
+                        const uint32_t slot = have ? slot_any : NODE_NONE;
                         const uint32_t* rth = rtab + (hi ? V : 0);
                         const NearbyItem ic = nearby_item_rt(true, slot, se, sp, len, kk, s_off, rth);
                         const NearbyItem is = nearby_item_rt(false, slot, se, sp, len, kk, s_off, rth);

@@ -272,11 +272,14 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const int union_custom = FAST ? 0 : gl.union_custom;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
-    const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    // wave-uniform by construction; saying so keeps the per-replica base pointers (and everything derived from the replica index) in
+    // scalar registers instead of 64-bit VGPR pairs (sf_list_wave.hip: 96 -> 77 VGPRs, scratch 120 B -> 0)
+    const uint32_t wave_in_group = uni(threadIdx.x >> 6);
+    const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + wave_in_group);
     if (rr >= p.n_launch) return;  // no workgroup barrier below
     const int r = rr + p.replica_base;
     __shared__ uint64_t s_sa[4][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
-    uint64_t* saw = s_sa[threadIdx.x >> 6];
+    uint64_t* saw = s_sa[wave_in_group];
     const bool annealing = acceptor == 3;
     if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const bool tables = !FAST && has_scalar && sm.tables();  // value-keyed constraints of the scalar class: per-value tables in LDS
     const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim,
                         PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0);
-    unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
+    unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
     uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
     uint8_t* ringx = SF_MIXED_RING_LDS ? (uint8_t*)(mem + cv.ringx) : gl.ringx + (size_t)r * GL * GRC;   // [leaf][GRC]
     int64_t* s_load = (int64_t*)(mem + cv.load);
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                                    (prec_lds_u32*)prec_S);
         if (prec_sweep) {  // committed evaluation + what the lane-per-trial sweep reads: list predecessors, order positions, round starts, prefix maxima
             __shared__ uint32_t s_psw_info[4][4];
-            uint32_t* info = s_psw_info[threadIdx.x >> 6];
+            uint32_t* info = s_psw_info[wave_in_group];
             const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, psw_lp, info, psw_roff);
             wave_sync();
             const uint32_t pn = (uint32_t)gl.prec.n;
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         if (!prec_incremental) return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
         // committed evaluation: also the list predecessors, the owner violations, the cycle flag and the makespan multiplicity
         __shared__ uint32_t s_prec_info[4][2];
-        uint32_t* info = s_prec_info[threadIdx.x >> 6];
+        uint32_t* info = s_prec_info[wave_in_group];
         const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, pinc.LP, info);
         wave_sync();
         pinc.viol = uni(info[0]);
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     bool plf_cur_cyclic = false;                           // the working lists of this step are cyclic
     PlfRep plf{};
     __shared__ uint32_t s_plf_info[4][4];
-    uint32_t* const plf_info = s_plf_info[threadIdx.x >> 6];
+    uint32_t* const plf_info = s_plf_info[wave_in_group];
     int64_t* const plf_score = plf_on ? gl.plf.score + (size_t)r * GRC * 4 : nullptr;
     int64_t* const plf_cache = plf_on ? gl.plf.cache + (size_t)r * GL * GRC * 2 : nullptr;  // the filter's evaluation per ring slot
     if (plf_on) {

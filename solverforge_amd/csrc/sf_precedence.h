@@ -99,7 +99,8 @@ __device__ __forceinline__ uint32_t prec_mbcnt(uint64_t mask) {
 }
 
 // Full evaluation of the lists `visits` / `off` (V owners) by one wavefront; E / D / Q / S = the four scratch arrays of pm.n
-// words.  Wave-uniform result.
+// words.  Wave-uniform result.  lint: small-pod-return (PrecResult = two int64: returned in four registers; never called inside a
+// conditional expression -- DESIGN 8.15 item 2 was a 32-byte struct through `?:`; scripts/lint_device_patterns.py checks both)
 template <class VT, class MEM = PrecMemGlobal>
 __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
                                              typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr, uint32_t* ROFF = nullptr) {

@@ -1144,16 +1144,17 @@ __global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, Se
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint64_t s_sa[4][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
     const uint32_t lane = threadIdx.x & 63u;
-    const int rr = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t wave_in_group = uni(threadIdx.x >> 6);  // wave-uniform by construction: per-replica base pointers in scalar registers
+    const int rr = (int)(blockIdx.x * 4 + wave_in_group);
     if (rr >= p.n_launch) return;  // no workgroup barrier below
     const int r = rr + p.replica_base;
-    uint64_t* saw = s_sa[threadIdx.x >> 6];
+    uint64_t* saw = s_sa[wave_in_group];
     const bool annealing = p.acceptor == 3;
     if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t n = (uint32_t)m.n;
     const bool tables = m.tables();
     const SCarve<VT> cv(m.n, tables ? m.n_values : 0, m.run_level >= 0 ? m.run_P : 0);
-    unsigned char* mem = smem + (size_t)(threadIdx.x >> 6) * cv.total;
+    unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][SRC][2]
     VT* s_vals = (VT*)(mem + cv.vals);
     int64_t* t_sum = (int64_t*)(mem + cv.tsum);  // per-value summed size / entity count of the working state
