@@ -491,7 +491,9 @@ int32_t sf_selector_add_nearby_scalar(sf_ctx* ctx, int32_t kind, int32_t d, int3
         const uint64_t lim = which == 0 ? (source_limit > 0 ? (uint64_t)source_limit : ~0ull) : (uint64_t)n;
         for (uint32_t k = offsets[e]; k < offsets[e + 1] && (uint64_t)(k - offsets[e]) < lim; ++k) {
             const int32_t cand = candidates[k];
-            if (cand < 0 || cand >= (which == 0 ? c.n_values : n)) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: candidate out of range");
+            // values must name a value of the variable; an entity candidate >= the entity count is legal input -- the reference's swap cursor
+            // skips it when the row is filtered (cursor/swap.rs:346-398) and so does the device (`(uint32_t)c < ns`)
+            if (cand < 0 || (which == 0 && cand >= c.n_values)) return fail(ctx, SF_ERR_INVALID, "nearby scalar leaf: candidate out of range");
             const uint32_t order = k - offsets[e];
             const double dist = distances ? distances[k] : (double)order;  // meter None: the source order (change.rs:332-334)
             if (!std::isfinite(dist)) continue;                            // NearbyTopK::push drops non-finite distances
