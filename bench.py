@@ -112,6 +112,11 @@ PMC_PASSES = [
     ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
 ]
 PMC_BUDGET_S = 120.0
+# rocprofv3 --pmc crashes (SIGSEGV inside the tool, 8 of 8 runs) on launches of more than one residency of this kernel (>= 12,288 replicas
+# = 3,072 workgroups) on this pool, and collects fine at 6,144 (profiles/r04f_pmc_crash_notes.txt).  The counter passes therefore run the
+# SAME command at one residency and the line scales their per-launch counters by the work ratio (consumed candidates of the parent's
+# timed launches / of the child's): per-candidate instruction and byte counts do not depend on how many replicas share a launch.
+PMC_CHILD_MAX_REPLICAS = 6144
 
 
 def cpu_baseline(problem, seed, warm_steps, timed_steps, budget_s):
@@ -215,8 +220,9 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
     try:
         for i, grp in enumerate(PMC_PASSES):
             d = os.path.join(base, f"pmc_{i}")
+            work_file = os.path.join(base, f"work_{i}.json")
             cmd = [exe, "--pmc"] + grp + ["-f", "csv", "-d", d, "-o", "b", "--", sys.executable,
-                                            os.path.abspath(__file__)] + argv + ["--pmc-child"]
+                                            os.path.abspath(__file__)] + argv + ["--pmc-child", "--pmc-child-out", work_file]
             # own process group: a pass that hangs is killed together with the profiled grandchild.  rocprofv3 counter passes hang
             # now and then on this pool (a pass takes ~10 s when it works): one retry per pass before its counters are given up.
             ok = False
@@ -258,6 +264,10 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
                             "scratch": int(row.get("Scratch_Size", 0) or 0), "kernel": row["Kernel_Name"]}
             if not per:
                 failed.append(f"{'+'.join(grp)}: no rows for {kernel_substr}")
+            try:
+                info["child_work"] = json.load(open(work_file))
+            except Exception:
+                pass
             for c, v in per.items():
                 v.sort()
                 vals = [x for _, x in v][warmup:warmup + steps]  # the timed launches, in dispatch order
@@ -304,6 +314,7 @@ def main():
                     help="M2 extension leg: wall-clock budget of the tuned configuration (0 = skip); see TUNED below")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     # the host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this before HIP initialises
@@ -377,7 +388,13 @@ def main():
         d.solve_steps(args.ls_steps, sync=False)
     barrier(d)
     elapsed = time.perf_counter() - t0
-    if args.pmc_child:  # counters are read by the parent from rocprofv3's CSV
+    if args.pmc_child:  # counters are read by the parent from rocprofv3's CSV; the child says how much work its timed launches did
+        after_c = d.total_stats()
+        if args.pmc_child_out:
+            with open(args.pmc_child_out, "w") as f:
+                json.dump({"moves_evaluated": after_c["moves_evaluated"] - before["moves_evaluated"],
+                           "candidates_scored": after_c["candidates_scored"] - before["candidates_scored"], "launches": args.steps,
+                           "replicas": args.replicas}, f)
         d.close()
         return
     if dist is not None:
@@ -561,7 +578,7 @@ def main():
         kernel = "k_list_search_wave" if engine == "wave" else "k_list_search"
         # ---- PMC: rocprofv3 child passes of this command (N = 1 only: one GPU, one process) ----
         pmc, pmc_info, pmc_source = None, {}, None
-        child_argv = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--replicas", str(args.replicas),
+        child_argv = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--replicas", str(min(args.replicas, PMC_CHILD_MAX_REPLICAS)),
                       "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
         if world == 1 and not args.no_pmc:
@@ -571,6 +588,15 @@ def main():
                 pmc_info = {}
             else:
                 pmc_source = "rocprofv3 --pmc child passes of this command, mean over the timed launches"
+                cw = (pmc_info or {}).get("child_work")
+                if cw and cw.get("replicas") != args.replicas and cw.get("moves_evaluated"):
+                    scale = (moves_local / max(launches, 1)) / (cw["moves_evaluated"] / max(cw["launches"], 1))
+                    cyc = {"SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"}
+                    pmc_child_raw = dict(pmc)
+                    # instruction and byte counters scale with the work; the cycle counters are kept as measured (only their ratios are used)
+                    pmc = {k: (v if k in cyc else v * scale) for k, v in pmc.items()}
+                    pmc_source += (f"; the passes ran at {cw['replicas']} replicas per launch (rocprofv3 crashes on larger launches of this kernel on this pool) and the "
+                                   f"instruction / byte counters are scaled by the work ratio {scale:.4f} (consumed candidates per launch, parent / child)")
         roof = {"bound": "valu-issue", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave-instr/s", "frac": None,
                 "traffic": None}
         if pmc and launch_s > 0:
@@ -602,7 +628,8 @@ def main():
                 wc = pmc["SQ_WAVE_CYCLES"]
                 roof["wave_cycle_shares"] = {"active": pmc.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wait_mem": pmc.get("SQ_WAIT_ANY", 0) / wc,
                                              "wait_issue": pmc.get("SQ_WAIT_INST_ANY", 0) / wc}
-            if pmc.get("SQ_BUSY_CYCLES"):  # per-SE busy cycles summed over the 32 shader engines
+            if pmc.get("SQ_BUSY_CYCLES") and not ((pmc_info or {}).get("child_work") or {}).get("replicas", args.replicas) != args.replicas:
+                # per-SE busy cycles summed over the 32 shader engines (only when the passes ran the parent's own launch shape)
                 roof["effective_clock_ghz"] = pmc["SQ_BUSY_CYCLES"] / 32.0 / launch_s / 1e9
             roof["counters_per_launch"] = {k: pmc[k] for k in sorted(pmc)}
         roof.update({

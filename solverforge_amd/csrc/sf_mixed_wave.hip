@@ -35,7 +35,7 @@ constexpr uint32_t GRC = 128;  // ring capacity per leaf
 #ifndef SF_MIXED_RING_LDS
 #define SF_MIXED_RING_LDS 0  // diagnostics: 1 keeps the candidate rings in the replica's LDS slice (the round-2 layout)
 #endif
-constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 128;  // == RuinLds::bytes (sf_ruin.h)
+constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 128 + 6 * 12 * 4;  // == RuinLds::bytes (sf_ruin.h)
 
 constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
 constexpr uint64_t SALT_LC_INTRA = 0x1157C4A46E000003ULL, SALT_LC_INTER = 0x1157C4A46E000004ULL;
