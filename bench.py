@@ -95,7 +95,8 @@ M2_POLICIES = {
     "default6": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"),
     "nearby2": ("nearby_change", "nearby_swap"),
 }
-M2_REPLICAS = {"default": 1280, "default6": 3072, "nearby2": None}  # replicas per GPU of the M2 leg (None = --replicas)
+M2_REPLICAS = {"default": 2048, "default6": 12288, "nearby2": 6144}  # replicas per GPU of the M2 leg (round 4: the RUIN instantiation holds 8 per CU;
+# the six-leaf FAST instantiation 12 per CU and gains from several residencies per launch, profiles/r04g_generic_replicas.jsonl)
 # M2 extension leg (module docstring): what is varied against the parity leg, and nothing else
 TUNED = {"leaves": ("nearby_change", "nearby_swap"), "late_acceptance_size": 5000, "accepted_count_limit": 1, "replicas": 1024,
          "migration_period_s": 5.0, "migration_replace_fraction": 0.5, "migration_elite": 8, "launch_move_budget": 200_000}
@@ -111,7 +112,7 @@ PMC_PASSES = [
     ["WRITE_SIZE"],
     ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
 ]
-PMC_BUDGET_S = 120.0
+PMC_BUDGET_S = 200.0
 # rocprofv3 --pmc crashes (SIGSEGV inside the tool, 8 of 8 runs) on launches of more than one residency of this kernel (>= 12,288 replicas
 # = 3,072 workgroups) on this pool, and collects fine at 6,144 (profiles/r04f_pmc_crash_notes.txt).  The counter passes therefore run the
 # SAME command at one residency and the line scales their per-launch counters by the work ratio (consumed candidates of the parent's
@@ -582,7 +583,7 @@ def main():
                       "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
         if world == 1 and not args.no_pmc:
-            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=30)
+            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=60)
             if pmc is None:  # no counters, no roofline: the line says so instead of quoting an older profile
                 pmc_source = f"none (live rocprofv3 passes failed: {pmc_info})"
                 pmc_info = {}
