@@ -2235,9 +2235,14 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     // FAST instantiation: the reference's default list policy on a list-only model (see k_mixed_search_wave)
     static const bool no_fast = std::getenv("SF_AMD_MIXED_NO_FAST") != nullptr;  // diagnostics / parity tests: force the general instantiation
+    bool fast_kinds = true;  // the leaf kinds the FAST instantiation keeps (the default list policy of a slot with a distance meter)
+    for (int l = 0; l < gl.n; ++l) {
+        const int k = gl.kind[l];
+        fast_kinds = fast_kinds && (k == 16 || k == 32 || k == 64 || k == 128 || k == 256 || k == 1024 || (k == 512 && gl.kopt_nearby));
+    }
     const bool fast = !no_fast && !trace && !PREC && sizeof(VT) == 2 && ctx->has_list_model && !ctx->has_scalar_model && p.acceptor == SF_ACCEPT_LATE_ACCEPTANCE &&
                       p.forager == SF_FORAGER_ACCEPTED_COUNT && !p.dry_run && !gl.union_custom && gl.union_order == SF_UNION_STRATIFIED_RANDOM && gl.n > 1 &&
-                      (ctx->lm.mat_symmetric || ctx->lm.dist_level < 0) && !p.legacy_eval && !p.explicit_seeds;
+                      (ctx->lm.mat_symmetric || ctx->lm.dist_level < 0) && !p.legacy_eval && !p.explicit_seeds && fast_kinds;
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for SF_MIXED_BLOCKS_PER_CU workgroups of 4 waves per CU, the FAST
     // instantiation for SF_MIXED_FAST_BLOCKS_PER_CU); ties go to the larger group

@@ -35,7 +35,7 @@ constexpr uint32_t GRC = 128;  // ring capacity per leaf
 #ifndef SF_MIXED_RING_LDS
 #define SF_MIXED_RING_LDS 0  // diagnostics: 1 keeps the candidate rings in the replica's LDS slice (the round-2 layout)
 #endif
-constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 128 + 6 * 12 * 4;  // == RuinLds::bytes (sf_ruin.h)
+constexpr size_t RUIN_LDS_BYTES = 8 * 8 + 16 * (8 * 2 + 4 * 8) + 128;  // == RuinLds::bytes (sf_ruin.h)
 
 constexpr uint64_t SALT_LC_ENTITY = 0x1157C4A46E000001ULL, SALT_LC_SOURCE = 0x1157C4A46E000002ULL;
 constexpr uint64_t SALT_LC_INTRA = 0x1157C4A46E000003ULL, SALT_LC_INTER = 0x1157C4A46E000004ULL;
@@ -246,10 +246,13 @@ namespace sf {
 // so the kernel fits more waves per SIMD (SF_MIXED_FAST_BLOCKS_PER_CU; the RUIN instantiation keeps 2: its recreate spills 1.3 KB of
 // scratch per lane at 168 VGPRs and ran 1.6x slower, profiles/r03e).  Same decisions bit for bit.
 // diagnostics (register-pressure bisection): -DSF_DBG_KINDS=<mask> compiles the generators of the masked leaf kinds out
+// MODE 1 additionally compiles out the generators / evaluators no default list policy of a slot with a distance meter declares (round 4):
+// plain list change / swap (4, 8), the full 3-opt enumeration (the `1` bit below), list permute (8192) -- the host takes FAST only for
+// unions of nearby change / swap, sublist change / swap, reverse, distance-pruned 3-opt and ruin (launch_mixed_t).
 #ifdef SF_DBG_KINDS
-#define DBGK(k) (((SF_DBG_KINDS) & (k)) == 0)
+#define DBGK(k) ((((SF_DBG_KINDS) & (k)) == 0) && (!FAST || ((k) & (16 | 32 | 64 | 128 | 256 | 512)) != 0))
 #else
-#define DBGK(k) true
+#define DBGK(k) (!FAST || ((k) & (16 | 32 | 64 | 128 | 256 | 512)) != 0)
 #endif
 #ifndef SF_MIXED_FAST_BLOCKS_PER_CU
 #define SF_MIXED_FAST_BLOCKS_PER_CU 3
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             lt.set(l, LeafTab::EX, l >= nl);
             lt.set(l, LeafTab::WCUR, 0);
         }
-        if (has_list) {  // list permute leaf: its entity permutation of this step (slot.rs:468-499) in the generator state
+        if (!FAST && has_list) {  // list permute leaf: its entity permutation of this step (slot.rs:468-499) in the generator state
             for (int l = 0; l < nl; ++l) {
                 if (lt.geti(l, LeafTab::KIND) != 8192) continue;
                 uint32_t pst, psd;
@@ -1145,7 +1148,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         wave_sync();  // the survivors are consumed before the next row overwrites them
                         g.a += 1;
                         if (g.a >= ns) g.done = 1;
-                    } else if (kind == 8192) {  // ---- list permute (list_kernel/permute.rs:103-205): the (size, permutation) pairs of one start per call ----
+                    } else if (!FAST && kind == 8192) {  // ---- list permute (list_kernel/permute.rs:103-205): the (size, permutation) pairs of one start per call ----
                         const uint32_t mn = leaf_min, mx = leaf_max;
                         uint32_t ent = 0, len = 0, start = 0, size_count = 0;
                         for (;;) {  // the current start with at least one window size
@@ -2015,7 +2018,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         doable = true;
 #pragma unroll
                         for (int kk = 0; kk < L; ++kk) sc.v[kk] = rl.score[(size_t)m0 * 4 + kk];
-                    } else if (my_kind == 8192) {  // list permute: up to nine legs each way, priced on its own
+                    } else if (!FAST && my_kind == 8192) {  // list permute: up to nine legs each way, priced on its own
                         const ListDelta d = eval_list_permute(lm, s_visits, s_off, m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
                         doable = d.doable;
                         sc = apply_delta<L>(lm, cur, d);
@@ -2372,7 +2375,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                                       : (kind == 256 ? (int32_t)((uni(best_x) & 15u) | ((uni(best_x) >> 4) << 16))
                                                                      : (kind == 512 ? (int32_t)uni(best_x) : -1));
                 }
-                if (kind == 8192)
+                if (!FAST && kind == 8192)
                     apply_list_move_wave(lm, s_visits, s_off, s_load, 9, a >> 16, a & 0xFFFFu, a >> 16, (a & 0xFFFFu) + (b >> 16), b & 0xFFFFu);
                 else
                     apply_list_move_wave(lm, s_visits, s_off, s_load, list_move_kind_of(kind), a >> 16, a & 0xFFFFu, b >> 16, b & 0xFFFFu,

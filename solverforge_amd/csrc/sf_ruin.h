@@ -77,15 +77,13 @@ __device__ __forceinline__ int64_t ruin_dist_cost(const M& m, uint32_t from, uin
 // Per-replica LDS block of the leaf.
 struct RuinLds {
     static constexpr size_t CAND_WORDS = 8;  // u16: list, count, positions[6]
-    static constexpr size_t CACHE_WORDS = 12;  // per remaining element: best slot, best slot outside the best slot's list (ruin_recreate_lds, fast == 2)
-    static constexpr size_t bytes = 8 * 8 + RUIN_MAX_MOVES * (CAND_WORDS * 2 + 4 * 8) + 128 + RUIN_MAX_COUNT * CACHE_WORDS * 4;
+    static constexpr size_t bytes = 8 * 8 + RUIN_MAX_MOVES * (CAND_WORDS * 2 + 4 * 8) + 128;
     static_assert(bytes == RUIN_LDS_BYTES, "GCarve reserves RUIN_LDS_BYTES");
     uint64_t* prng;   // [4] per-solve stream (loaded at launch start, stored at launch end)
     uint64_t* crng;   // [4] cursor stream of this step
     int64_t* score;   // [RUIN_MAX_MOVES][4] trial score of every generated candidate
     uint16_t* cand;   // [RUIN_MAX_MOVES][CAND_WORDS]
-    uint16_t* work;   // [64]: removed nodes [8], placements (list, position, next element, old edge) [8][4], remaining nodes [8];
-                      // behind it u32 [RUIN_MAX_COUNT][CACHE_WORDS]: the slot cache of the 32-bit fast path
+    uint16_t* work;   // [64]: removed nodes [8], placements (list, position, next element, old edge) [8][4], remaining nodes [8]
     __device__ explicit RuinLds(unsigned char* base) {
         prng = (uint64_t*)base;
         crng = prng + 4;
@@ -553,207 +551,6 @@ __device__ __forceinline__ void ruin_scan_element_small(const RuinModel& lm, con
     }
 }
 
-// ---- slot cache of the 32-bit fast path (round 4) ----------------------------------------------------------------------------
-// The reference re-prices every (remaining element, list, position) in every round of a recreate.  Between two rounds only ONE list
-// changes -- the one that took the placement (its slots shift, its load grows); every other list's slots keep their position and
-// their insertion delta.  So round 1 scans all slots once per element and keeps, per element, the best slot B1 and the best slot B2
-// among the lists other than B1's; after a placement into list e* only e* is re-priced for the remaining elements (one lane per
-// (element, slot) pair) and the pair (B1, B2) is updated from it.  Exact: whenever the update would need a third-best list that was
-// never recorded the element is scanned again in full (`unknown`).  Order of equals as in the reference: smaller element index,
-// then (list, position).  Deltas are int32 per level against the round's base score (ListModel::small32), keys = list << 16 | position.
-constexpr uint32_t RUIN_KEY_NONE = 0xFFFFFFFFu;
-template <int L>
-struct RuinBest {  // wave-uniform
-    int32_t d[L];
-    uint32_t key;  // RUIN_KEY_NONE: no slot
-};
-template <int L>
-__device__ __forceinline__ bool ruin_better(const int32_t (&a)[L], uint32_t ka, const int32_t (&b)[L], uint32_t kb) {  // a strictly before b
-    if (ka == RUIN_KEY_NONE) return false;
-    if (kb == RUIN_KEY_NONE) return true;
-    bool gt = false, eq = true;
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-        gt = gt || (eq && a[k] > b[k]);
-        eq = eq && a[k] == b[k];
-    }
-    return gt || (eq && ka < kb);
-}
-// wave reduction: the lexicographically greatest d among the lanes with `in`, the smallest key among equals
-template <int L>
-__device__ __forceinline__ RuinBest<L> ruin_wave_best(const int32_t (&d)[L], uint32_t key, bool in) {
-    RuinBest<L> r;
-    bool m = in;
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-        r.d[k] = wave_max_i32(m ? d[k] : (int32_t)0x80000000);
-        m = m && d[k] == r.d[k];
-    }
-    // smallest key among the maxima: max of the complement
-    r.key = ~(uint32_t)wave_max_i32((int32_t)((m ? ~key : 0u) ^ 0x80000000u)) ^ 0x80000000u;
-    if (__ballot(in) == 0ull) r.key = RUIN_KEY_NONE;
-    return r;
-}
-
-// Full scan of one element with the two-list record: like ruin_scan_element_small, a lane keeps its best slot b1 and its best slot b2
-// outside b1's list; the wave then names B1 and B2.  `rf.row` holds the element's matrix row.
-template <int L>
-__device__ __forceinline__ void ruin_scan_element_top2(const RuinModel& lm, const lds_u16* visits, const lds_u32* off, const lds_i64* load,
-                                                       const lds_u32* sbase, const RuinFastLds& rf, int32_t dx, uint32_t ent, int32_t parked_dem,
-                                                       RuinBest<L>& B1, RuinBest<L>& B2) {
-    constexpr int U = SF_RUIN_SMALL_U;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t V = (uint32_t)lm.V, depot = (uint32_t)lm.depot;
-    const bool has_cap = lm.cap_level >= 0 && lm.demand != nullptr;
-    const int32_t cap32 = (int32_t)lm.capacity;
-    int32_t ca[L], cb[L];
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-        ca[k] = (has_cap && k == lm.cap_level) ? -(int32_t)lm.cap_weight : 0;
-        cb[k] = k == lm.dist_level ? -(int32_t)lm.dist_weight : 0;
-    }
-    const lds_u32* load32 = (const lds_u32*)load;
-    const uint32_t total = uni(sbase[V]);
-    int32_t d1[L], d2[L];
-#pragma unroll
-    for (int k = 0; k < L; ++k) d1[k] = d2[k] = (int32_t)0x80000000;
-    uint32_t k1 = RUIN_KEY_NONE, k2 = RUIN_KEY_NONE;
-    for (uint32_t t0 = 0; t0 < total; t0 += 64u * U) {
-        uint32_t tt[U], e[U], b0[U], b1[U], ob[U];
-        bool valid[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t t = t0 + (uint32_t)u * 64u + lane;
-            valid[u] = t < total;
-            tt[u] = valid[u] ? t : 0u;
-            e[u] = rf.slot[tt[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            b0[u] = sbase[e[u]];
-            b1[u] = sbase[e[u] + 1];
-            ob[u] = off[e[u]];
-        }
-        uint32_t pvr[U], nxr[U], o[U];
-        int32_t ld[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            o[u] = tt[u] - b0[u];
-            const uint32_t ip = ob[u] + o[u];
-            pvr[u] = visits[ip - (o[u] > 0 ? 1u : 0u)];
-            nxr[u] = visits[ip];
-            ld[u] = has_cap ? (int32_t)load32[2u * e[u]] : 0;
-        }
-        uint32_t da[U], db[U], d0[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool at_end = o[u] + 1u >= b1[u] - b0[u];
-            const uint32_t pv = o[u] > 0 ? pvr[u] : depot;
-            da[u] = rf.row[pv];
-            db[u] = rf.row[at_end ? depot : nxr[u]];
-            const lds_u16* dp = at_end ? rf.edge_end + e[u] : rf.edge + nxr[u];
-            d0[u] = *dp;
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int32_t dd = (int32_t)da[u] + (int32_t)db[u] - (int32_t)d0[u];
-            const int32_t l0 = ld[u] - (e[u] == ent ? parked_dem : 0);
-            const int32_t over1 = l0 + dx - cap32, over0 = l0 - cap32;
-            const int32_t dc = (over1 > 0 ? over1 : 0) - (over0 > 0 ? over0 : 0);
-            int32_t dv[L];
-            bool gt1 = false, eq1 = true, gt2 = false, eq2 = true;
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                dv[k] = ca[k] * dc + cb[k] * dd;
-                gt1 = gt1 || (eq1 && dv[k] > d1[k]);
-                eq1 = eq1 && dv[k] == d1[k];
-                gt2 = gt2 || (eq2 && dv[k] > d2[k]);
-                eq2 = eq2 && dv[k] == d2[k];
-            }
-            // a lane meets its slots in increasing (list, position) order: a tie never replaces an earlier slot
-            const bool h1 = k1 != RUIN_KEY_NONE, h2 = k2 != RUIN_KEY_NONE;
-            const bool same1 = h1 && e[u] == (k1 >> 16);
-            const bool take1 = valid[u] && (!h1 || gt1);
-            const bool demote = take1 && h1 && !same1;           // the old best is the best outside the new best's list
-            const bool take2 = valid[u] && !take1 && !same1 && (!h2 || gt2);
-            const uint32_t key = (e[u] << 16) | o[u];
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                d2[k] = demote ? d1[k] : (take2 ? dv[k] : d2[k]);
-                d1[k] = take1 ? dv[k] : d1[k];
-            }
-            k2 = demote ? k1 : (take2 ? key : k2);
-            k1 = take1 ? key : k1;
-        }
-    }
-    B1 = ruin_wave_best<L>(d1, k1, k1 != RUIN_KEY_NONE);
-    const bool mine_out = k1 != RUIN_KEY_NONE && (k1 >> 16) != (B1.key >> 16);  // this lane's best lies outside B1's list
-    int32_t dc_[L];
-#pragma unroll
-    for (int k = 0; k < L; ++k) dc_[k] = mine_out ? d1[k] : d2[k];
-    const uint32_t kc = mine_out ? k1 : k2;
-    B2 = ruin_wave_best<L>(dc_, kc, B1.key != RUIN_KEY_NONE && kc != RUIN_KEY_NONE);
-}
-
-// After a placement into list `be`: the slots of `be` re-priced for every remaining element, one lane per (element, slot) pair,
-// legs straight from the compact matrix (a handful of gathers).  R[j] = the best slot of element j inside `be`.
-template <int L>
-__device__ __forceinline__ void ruin_rescan_list(const RuinModel& lm, const lds_u16* visits, const lds_u32* off, const lds_i64* load, const lds_u16* rem,
-                                                 uint32_t n_rem, uint32_t be, uint32_t ent, int32_t parked_dem, const RuinFastLds& rf,
-                                                 RuinBest<L> (&R)[RUIN_MAX_COUNT]) {
-    const uint32_t lane = threadIdx.x & 63u, depot = (uint32_t)lm.depot;
-    const bool has_cap = lm.cap_level >= 0 && lm.demand != nullptr;
-    const int32_t cap32 = (int32_t)lm.capacity;
-    int32_t ca[L], cb[L];
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-        ca[k] = (has_cap && k == lm.cap_level) ? -(int32_t)lm.cap_weight : 0;
-        cb[k] = k == lm.dist_level ? -(int32_t)lm.dist_weight : 0;
-    }
-    const lds_u32* load32 = (const lds_u32*)load;
-    const uint32_t ob = uni(off[be]);
-    const uint32_t len = uni(off[be + 1]) - ob - (be == ent ? n_rem : 0u);  // logical length (the source list's parked tail is no destination)
-    const uint32_t S = len + 1u, P = n_rem * S;
-    const int32_t l0 = has_cap ? (int32_t)uni(load32[2u * be]) - (be == ent ? parked_dem : 0) : 0;
-#pragma unroll
-    for (uint32_t j = 0; j < RUIN_MAX_COUNT; ++j) {
-        R[j].key = RUIN_KEY_NONE;
-#pragma unroll
-        for (int k = 0; k < L; ++k) R[j].d[k] = (int32_t)0x80000000;
-    }
-    for (uint32_t q0 = 0; q0 < P; q0 += 64) {
-        const uint32_t q = q0 + lane;
-        const bool valid = q < P;
-        uint32_t j = 0;
-#pragma unroll
-        for (uint32_t t = 1; t < RUIN_MAX_COUNT; ++t) j += (q >= t * S) ? 1u : 0u;
-        j = valid ? j : 0u;
-        const uint32_t sl = valid ? q - j * S : 0u;
-        const uint32_t x = rem[j];
-        const bool at_end = sl >= len;
-        const uint32_t pvr = visits[ob + sl - (sl > 0 ? 1u : 0u)], nxr = visits[ob + sl];
-        const uint32_t pv = sl > 0 ? pvr : depot, nx = at_end ? depot : nxr;
-        const uint32_t da = ruin_raw16(lm, x, pv), db = ruin_raw16(lm, x, nx);
-        const lds_u16* dp = at_end ? rf.edge_end + be : rf.edge + nxr;  // an empty list's edge_end is 0
-        const uint32_t d0 = *dp;
-        const int32_t dx = has_cap ? (int32_t)lm.demand[x] : 0;
-        const int32_t dd = (int32_t)da + (int32_t)db - (int32_t)d0;
-        const int32_t over1 = l0 + dx - cap32, over0 = l0 - cap32;
-        const int32_t dc = (over1 > 0 ? over1 : 0) - (over0 > 0 ? over0 : 0);
-        int32_t dv[L];
-#pragma unroll
-        for (int k = 0; k < L; ++k) dv[k] = ca[k] * dc + cb[k] * dd;
-        const uint32_t key = (be << 16) | sl;
-#pragma unroll
-        for (uint32_t jj = 0; jj < RUIN_MAX_COUNT; ++jj) {
-            if (jj >= n_rem) break;
-            if (__ballot(valid && j == jj) == 0ull) continue;
-            const RuinBest<L> c = ruin_wave_best<L>(dv, key, valid && j == jj);
-            if (ruin_better<L>(c.d, c.key, R[jj].d, R[jj].key)) R[jj] = c;
-        }
-    }
-}
-
 // One round of the recreate (general path): every lane prices insertion slots for the NR remaining elements and keeps its running best.
 // Slots are numbered list by list (slot_base[e] = slots of the lists before e, a list of len elements has len + 1 slots, a
 // skipped empty list none); a lane finds its slot's list with a fixed-depth binary search, so the U chunks of one group are
@@ -953,189 +750,6 @@ __device__ SF_RUIN_ATTR void ruin_recreate_lds(const RuinModel lm_in, lds_u16* v
         }
     };
     if (fast) fetch_row(uni((uint32_t)rem[0]));
-    if (fast == 2) {
-        // ---- 32-bit fast path with the slot cache (see RuinBest above) ----
-        lds_u32* cache = (lds_u32*)(work + 64);  // [RUIN_MAX_COUNT][CACHE_WORDS]: d1[L], k1, d2[L], k2, state of B2 (0 none, 1 known, 2 unknown)
-        constexpr uint32_t CW = (uint32_t)RuinLds::CACHE_WORDS;
-        static_assert(2 * L + 3 <= (int)RuinLds::CACHE_WORDS, "slot cache record");
-        auto cache_put = [&](uint32_t j, const RuinBest<L>& b1, const RuinBest<L>& b2, uint32_t st2) {
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < L; ++k) {
-                    cache[j * CW + k] = (uint32_t)b1.d[k];
-                    cache[j * CW + L + 1 + k] = (uint32_t)b2.d[k];
-                }
-                cache[j * CW + L] = b1.key;
-                cache[j * CW + 2 * L + 1] = b2.key;
-                cache[j * CW + 2 * L + 2] = st2;
-            }
-        };
-        auto cache_get = [&](uint32_t j, RuinBest<L>& b1, RuinBest<L>& b2, uint32_t& st2) {
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                b1.d[k] = (int32_t)uni(cache[j * CW + k]);
-                b2.d[k] = (int32_t)uni(cache[j * CW + L + 1 + k]);
-            }
-            b1.key = uni(cache[j * CW + L]);
-            b2.key = uni(cache[j * CW + 2 * L + 1]);
-            st2 = uni(cache[j * CW + 2 * L + 2]);
-        };
-        // one full scan of the element at index j of `rem` (its row fetched here unless `prefetched`)
-        auto full_scan = [&](uint32_t j, bool prefetched, uint32_t next_x, bool has_next) {
-            const uint32_t x = uni((uint32_t)rem[j]);
-            if (!prefetched) fetch_row(x);
-            wave_sync();  // the previous scan is done with the row
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t c = (uint32_t)k * 64u + lane;
-                if (c < (uint32_t)lm.dim) rf.row[c] = (uint16_t)(pre[k] >= 0xFFFFu ? 0xFFFFu : pre[k]);
-            }
-            for (uint32_t c = 1024u + lane; c < (uint32_t)lm.dim; c += 64) {  // rows longer than the prefetch window
-                const uint32_t v = lm.mat32[x * (uint32_t)lm.dim + c];
-                rf.row[c] = (uint16_t)(v >= 0xFFFFu ? 0xFFFFu : v);
-            }
-            wave_sync();
-            if (has_next) fetch_row(next_x);
-            RPH(6)
-            RuinBest<L> b1, b2;
-            ruin_scan_element_top2<L>(lm, visits, off, load, sbase, rf, has_cap ? (int32_t)lm.demand[x] : 0, ent, (int32_t)parked_dem, b1, b2);
-            cache_put(j, b1, b2, b2.key != RUIN_KEY_NONE ? 1u : 0u);
-            wave_sync();
-            RPH(2)
-        };
-        // round 1: every element against every slot
-        ruin_slot_prefix(lm, off, sbase, ent, n_rem, skip_empty);
-        RPH(1)
-        ruin_build_slot_lists((uint32_t)lm.V, sbase, rf);
-        for (uint32_t ri = 0; ri < n_rem; ++ri) full_scan(ri, true, ri + 1 < n_rem ? uni((uint32_t)rem[ri + 1]) : 0u, ri + 1 < n_rem);
-        while (n_rem > 0) {
-            // the placement of this round: the best B1 over the remaining elements, the earlier element among equals
-            RuinBest<L> pick_b;
-            pick_b.key = RUIN_KEY_NONE;
-#pragma unroll
-            for (int k = 0; k < L; ++k) pick_b.d[k] = (int32_t)0x80000000;
-            uint32_t ri = 0;
-            for (uint32_t j = 0; j < n_rem; ++j) {
-                RuinBest<L> b1, b2;
-                uint32_t st2;
-                cache_get(j, b1, b2, st2);
-                bool gt = false, eq = true;  // strictly greater only: equal scores stay with the earlier element
-#pragma unroll
-                for (int k = 0; k < L; ++k) {
-                    gt = gt || (eq && b1.d[k] > pick_b.d[k]);
-                    eq = eq && b1.d[k] == pick_b.d[k];
-                }
-                if (b1.key != RUIN_KEY_NONE && (pick_b.key == RUIN_KEY_NONE || gt)) {
-                    pick_b = b1;
-                    ri = j;
-                }
-            }
-            if (pick_b.key == RUIN_KEY_NONE) {  // no destination at all: restore_removed_elements (:250-253)
-                rolled_back = true;
-                break;
-            }
-            const uint32_t be = pick_b.key >> 16, bp = pick_b.key & 0xFFFFu;
-            const uint32_t x = uni((uint32_t)rem[ri]);
-            // the legs the placement creates / replaces (what the scan used to hand over), from the lists as they are now
-            const uint32_t ob_ = uni(off[be]);
-            const uint32_t le_ = uni(off[be + 1]) - ob_ - (be == ent ? n_rem : 0u);
-            const uint32_t pv_ = bp > 0 ? uni((uint32_t)visits[ob_ + bp - 1]) : (uint32_t)lm.depot;
-            const uint32_t w_next = bp < le_ ? uni((uint32_t)visits[ob_ + bp]) : 0xFFFFFFFFu;
-            const uint32_t w_da = uni(ruin_raw16(lm, x, pv_)), w_db = uni(ruin_raw16(lm, x, w_next != 0xFFFFFFFFu ? w_next : (uint32_t)lm.depot));
-            const uint32_t w_d0 = w_next != 0xFFFFFFFFu ? uni((uint32_t)rf.edge[w_next]) : uni((uint32_t)rf.edge_end[be]);
-            const uint32_t src_pos = uni(off[ent + 1]) - uni(off[ent]) - n_rem + ri;
-            RPH(3)
-            ruin_list_change(lm, visits, off, load, ent, src_pos, be, bp);
-            RPH(4)
-            if (has_cap) parked_dem = wsub(parked_dem, (int64_t)lm.demand[x]);
-            // drop element ri from the remaining list and from the cache (order preserved)
-            const uint32_t moved = (lane >= ri && lane + 1 < n_rem) ? (uint32_t)rem[lane + 1] : 0u;
-            uint32_t cw_[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t w = (uint32_t)h * 64u + lane;
-                cw_[h] = (w >= ri * CW && w + CW < n_rem * CW) ? cache[w + CW] : 0u;
-            }
-            wave_sync();
-            if (lane >= ri && lane + 1 < n_rem) rem[lane] = (uint16_t)moved;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t w = (uint32_t)h * 64u + lane;
-                if (w >= ri * CW && w + CW < n_rem * CW) cache[w] = cw_[h];
-            }
-            if (lane == 0) {
-                place[n_pl * 4] = (uint16_t)be;
-                place[n_pl * 4 + 1] = (uint16_t)bp;
-                place[n_pl * 4 + 2] = (uint16_t)(w_next == 0xFFFFFFFFu ? 0xFFFFu : w_next);
-                place[n_pl * 4 + 3] = (uint16_t)w_d0;
-                rf.edge[x] = (uint16_t)w_da;  // the two legs the placement created (the third, prev -> next, is what w_d0 remembers)
-                if (w_next == 0xFFFFFFFFu)
-                    rf.edge_end[be] = (uint16_t)w_db;
-                else
-                    rf.edge[w_next] = (uint16_t)w_db;
-            }
-            wave_sync();
-            n_pl += 1;
-            n_rem -= 1;
-#pragma unroll
-            for (int k = 0; k < L; ++k) s.v[k] = wadd(s.v[k], (int64_t)pick_b.d[k]);
-            RPH(3)
-            if (n_rem == 0) break;
-            // list `be` re-priced for the remaining elements; their (B1, B2) updated; a record that would need a third list: full scan
-            RuinBest<L> R[RUIN_MAX_COUNT];
-            ruin_rescan_list<L>(lm, visits, off, load, rem, n_rem, be, ent, (int32_t)parked_dem, rf, R);
-            bool prefix_fresh = false;
-            for (uint32_t j = 0; j < n_rem; ++j) {
-                RuinBest<L> b1, b2, rj;
-                uint32_t st2;
-                cache_get(j, b1, b2, st2);
-                rj.key = RUIN_KEY_NONE;
-#pragma unroll
-                for (int k = 0; k < L; ++k) rj.d[k] = (int32_t)0x80000000;
-#pragma unroll
-                for (uint32_t t = 0; t < RUIN_MAX_COUNT; ++t)
-                    if (t == j) rj = R[t];
-                const uint32_t e1 = b1.key >> 16, e2 = b2.key >> 16;
-                bool rescan = false;
-                if (b1.key != RUIN_KEY_NONE && e1 != be) {
-                    if (ruin_better<L>(rj.d, rj.key, b1.d, b1.key)) {
-                        b2 = b1, st2 = 1u;  // the best outside `be` is the old best
-                        b1 = rj;
-                    } else if (st2 == 1u && e2 != be) {
-                        if (ruin_better<L>(rj.d, rj.key, b2.d, b2.key)) b2 = rj;
-                    } else if (st2 == 0u) {
-                        b2 = rj, st2 = rj.key != RUIN_KEY_NONE ? 1u : 0u;
-                    } else {
-                        st2 = 2u;  // the runner-up sat in `be` (or was unknown already): the third list was never recorded
-                    }
-                } else if (b1.key != RUIN_KEY_NONE) {  // the best sat in `be`: only B2 (the best outside `be`) survives
-                    if (st2 == 2u)
-                        rescan = true;
-                    else if (st2 == 0u)
-                        b1 = rj;  // `be` is the only list with slots
-                    else if (ruin_better<L>(rj.d, rj.key, b2.d, b2.key))
-                        b1 = rj;  // B2 stays the best outside b1's list
-                    else {
-                        b1 = b2;
-                        st2 = 2u;  // best outside e2 = better of rj and a list never recorded
-                    }
-                } else {
-                    rescan = true;  // (no slot before: cannot happen once a placement succeeded; be safe)
-                }
-                if (rescan) {
-                    if (!prefix_fresh) {
-                        ruin_slot_prefix(lm, off, sbase, ent, n_rem, skip_empty);
-                        ruin_build_slot_lists((uint32_t)lm.V, sbase, rf);
-                        prefix_fresh = true;
-                    }
-                    full_scan(j, false, 0u, false);
-                } else {
-                    cache_put(j, b1, b2, st2);
-                    wave_sync();
-                }
-            }
-        }
-    } else
     while (n_rem > 0) {
         ruin_slot_prefix(lm, off, sbase, ent, n_rem, skip_empty);
         RPH(1)
