@@ -108,9 +108,9 @@ LEAF_BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublis
 # default run stays within a few minutes; a pass that never completes only drops its own counters.
 PMC_PASSES = [
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
-    ["FETCH_SIZE"],
-    ["WRITE_SIZE"],
     ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
+    ["FETCH_SIZE"],  # (round 4: the two TCC passes last -- a hanging FETCH_SIZE pass used to eat the budget of the cycle-share pass)
+    ["WRITE_SIZE"],
 ]
 PMC_BUDGET_S = 200.0
 # rocprofv3 --pmc crashes (SIGSEGV inside the tool, 8 of 8 runs) on launches of more than one residency of this kernel (>= 12,288 replicas
@@ -583,7 +583,7 @@ def main():
                       "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
         if world == 1 and not args.no_pmc:
-            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=60)
+            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=45)
             if pmc is None:  # no counters, no roofline: the line says so instead of quoting an older profile
                 pmc_source = f"none (live rocprofv3 passes failed: {pmc_info})"
                 pmc_info = {}
