@@ -78,9 +78,8 @@ VALU_PEAK = N_SIMD * CLOCK_HZ / 2.0  # wave-instructions / s
 SALU_PEAK = N_CU * CLOCK_HZ
 LDS_PEAK = N_CU * CLOCK_HZ / 2.0
 
-# TCC passes first: on this pool a FETCH_SIZE pass that FOLLOWS the SQ cycle-counter pass was seen to hang (twice), while
-# the same pass run first completes in seconds; every pass has its own short deadline and a failed pass only drops its
-# own counters.
+# rocprofv3 counter passes hang now and then on this pool (FETCH_SIZE most often, whatever its position: rounds 2-4); every pass has
+# its own short deadline and a failed pass only drops its own counters.
 # M2 start state (see --solve-start).  M1 is always timed on the round-robin fill (comparable across rounds); M2 starts from the
 # Clarke-Wright savings construction with a capacity-checking feasibility hook (an extension over the stock structural hook, see
 # the module docstring), built inside the 60 s on both sides (profiles/r02f_solve60_*: best@60 s [0, -92932] from this start vs
