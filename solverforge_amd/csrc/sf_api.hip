@@ -2381,8 +2381,9 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                 // its ruins recreate by the precedence constraint alone: no other list constraint may score an insertion
                 if (ctx->lm.dist_level >= 0 || ctx->lm.cap_level >= 0)
                     return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf on a list class with distance / capacity constraints");
-                // the multi-swap stream (critical x critical x support triples, < nodes^3 / 2) and its row prefixes are indexed in 32 bits
-                if (ctx->prec.dur.size() > 2048) return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf: more than 2,048 nodes");
+                // the multi-swap stream (critical x critical x support triples, < nodes^3 / 2) is indexed in 64 bits (round 4; 62 of them travel in a
+                // ring entry); list positions and block lengths are 16-bit fields
+                if (ctx->prec.dur.size() > 65535) return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence leaf: more than 65,535 nodes");
                 if (int rc = ensure_plf(ctx)) return rc;
                 gl.plf = ctx->plf;
                 gl.plf.leaf = 1;
@@ -2406,6 +2407,7 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         gl.plf.policy = ctx->prec_policy ? 1 : 0;
     }
     gl.plf.slow = std::getenv("SF_AMD_PLF_SLOW") != nullptr ? 1 : 0;  // read at every launch
+    gl.plf.force64 = std::getenv("SF_AMD_PLF_FORCE64") != nullptr ? 1 : 0;
     if (!ctx->d_mixed_ring) {
         int rc = dalloc(ctx, &ctx->d_mixed_ring, (size_t)ctx->R * GL * GRC * 2);
         if (!rc) rc = dalloc(ctx, &ctx->d_mixed_ringx, (size_t)ctx->R * GL * GRC);

@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     auto plf_decode = [&](uint32_t w0, uint32_t w1, PlfMove& m) {
         const uint32_t stage = w0 >> 30;
         if (stage == 0)
-            plf_decode_multi_swap(plf, w1, m);
+            plf_decode_multi_swap(plf, ((uint64_t)(w0 & 0x3FFFFFFFu) << 32) | w1, m);
         else if (stage == 1)
             plf_decode_multi_ruin(plf, w1, m);
         else
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                         (int32_t)pr.makespan, cyc);
             else
                 plf_analyse<PrecMemGlobal>(gl.prec, gl.plf, plf, s_visits, s_off, V, prec_E, prec_Q, prec_S, rounds, (int32_t)pr.makespan, cyc);
-            plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni(plf.ms_count), plf.mr_count = uni(plf.mr_count);
+            plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni64(plf.ms_count), plf.mr_count = uni(plf.mr_count);
         }
         uint32_t exmask = ((1u << GL) - 1u) & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
@@ -1568,16 +1568,20 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                                          // inside the stage, g.c = block offset ----
                         PlfMove pm_;
                         bool emit = false;
-                        if (g.a == 0) {
-                            if (g.b >= plf.ms_count) {
-                                g.a = 1, g.b = 0;
+                        if (g.a == 0) {  // stream offset = g.d : g.b (64 bits), ring entry = the selected index (high 30 bits in w0, low 32 in w1)
+                            const uint64_t so = ((uint64_t)g.d << 32) | g.b;
+                            if (so >= plf.ms_count) {
+                                g.a = 1, g.b = 0, g.d = 0;
                                 st_sources -= 1;
                                 continue;
                             }
-                            w1 = ctx.selection_index(g.b, plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc);
+                            const uint64_t si = (plf.ms_count <= 0xFFFFFFFFull && !gl.plf.force64) ? (uint64_t)ctx.selection_index((uint32_t)so, (uint32_t)plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc)
+                                                                              : kopt_selection_index64(ctx, so, plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc);
                             g.b += 1;
-                            w0 = 0;
-                            plf_decode_multi_swap(plf, w1, pm_);
+                            if (g.b == 0) g.d += 1;
+                            w1 = (uint32_t)si;
+                            w0 = (uint32_t)(si >> 32);  // stage 0 in bits 30..31
+                            plf_decode_multi_swap(plf, si, pm_);
                             emit = true;
                         } else if (g.a == 1) {
                             if (g.b >= plf.mr_count) {

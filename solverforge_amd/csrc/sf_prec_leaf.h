@@ -39,6 +39,7 @@ struct PlfModel {
     int32_t policy;     // the slot declares its precedence hooks to the runtime leaves (list_leaf/cursor/slot.rs:191-404): the other list leaves
                         // drop intra-list candidates that close a cycle through a new route edge, the ruin leaf recreates with the hooks
     int32_t slow;       // diagnostics / parity tests (SF_AMD_PLF_SLOW): the recreate slides every element through every slot, one evaluation each
+    int32_t force64;    // diagnostics / parity tests (SF_AMD_PLF_FORCE64): the multi-swap stream takes its 64-bit index path whatever its length
     int32_t dmax;       // max (fixed successors + fixed predecessors) of a node: spacing of the support-swap sequence numbers
     int32_t pc;         // row stride of `flag` / `first`: max(node_count, element_capacity) -- they are indexed by list position in the leaf's
                         // analysis and by node id (predecessor / reachability tables) in the recreate and the construction
@@ -51,7 +52,7 @@ struct PlfModel {
     uint32_t* ssw;      // [R][n]      support adjacent swaps, first-occurrence order
     uint32_t* first;    // [R][pc]     smallest sequence number that named the swap slot
     uint32_t* cnl;      // [R][n]      list positions of the critical nodes, in list order
-    uint32_t* msrow;    // [R][n + 1]  multi-swap candidates before the rows of critical swap i
+    uint64_t* msrow;    // [R][n + 1]  multi-swap candidates before the rows of critical swap i (64 bits: C^2 * S / 2 passes 2^32 near 2,000 nodes)
     uint32_t* mrrow;    // [R][n + 1]  multi-ruin candidates before the rows of block i
     uint32_t* sE;       // [R][V]      support swaps per list
     int64_t* score;     // [R][GRC][4] trial scores of the ring entries
@@ -60,8 +61,10 @@ struct PlfModel {
 };
 struct PlfRep {  // one replica's slices + the counts of this step (wave-uniform)
     int32_t* latest;
-    uint32_t *posn, *flag, *roff, *blk, *csw, *ssw, *first, *cnl, *msrow, *mrrow, *sE, *visit;
-    uint32_t nb, C, S, ms_count, mr_count;
+    uint32_t *posn, *flag, *roff, *blk, *csw, *ssw, *first, *cnl, *mrrow, *sE, *visit;
+    uint64_t* msrow;
+    uint32_t nb, C, S, mr_count;
+    uint64_t ms_count;
 };
 
 // Hand-off through HBM between lanes of one wavefront.  The workgroup-scope fences of prec_sync() compile to nothing on gfx950 (one
@@ -222,7 +225,7 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
     }
     plf_gsync();
     // ---- multi-swap rows (support.rs:64-84): row i = the triples whose first critical swap is i ----
-    uint32_t ms_total = 0;
+    uint64_t ms_total = 0;  // a row holds < C * S <= n^2 < 2^32 triples (n <= 65,535), the stream C^2 * S / 2 of them: 64-bit prefixes
     for (uint32_t i0 = 0; i0 < C; i0 += 64) {
         const uint32_t i = i0 + lane;
         uint32_t cnt = 0;
@@ -234,9 +237,15 @@ __device__ __noinline__ void plf_analyse(const PrecModel pm, const PlfModel pl, 
                 if (ej != ei) cnt += Sn - si - plf_ald(t.sE + ej);
             }
         }
-        const uint32_t incl = wave_incl_scan(cnt);
+        // 64-bit inclusive scan of the 64 row sizes (their sum may pass 2^32): low and high halves scanned apart
+        uint64_t incl = (uint64_t)cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o);
+            if ((int)lane >= o) incl += ((uint64_t)hi << 32) | lo;
+        }
         if (i < C) t.msrow[i] = ms_total + incl - cnt;
-        ms_total += (uint32_t)__shfl((int)incl, 63);
+        ms_total += ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(incl >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)incl, 63);
     }
     if (lane == 0) t.msrow[C] = ms_total;
     // ---- multi-ruin rows (support.rs:124-161): row i = len_i * (the lengths of the blocks after i) ----
@@ -524,9 +533,23 @@ __device__ __forceinline__ uint32_t plf_walk(uint32_t from, uint32_t to, uint32_
 }
 
 // multi_support_swaps (support.rs:86-109)
-__device__ __noinline__ void plf_decode_multi_swap(const PlfRep& t, uint32_t idx, PlfMove& m) {
-    const uint32_t i = plf_find_row(t.msrow, t.C, idx);
-    uint32_t off = idx - plf_uni(t.msrow[i]);
+__device__ __noinline__ void plf_decode_multi_swap(const PlfRep& t, uint64_t idx, PlfMove& m) {
+    uint32_t i = 0;
+    {  // largest row whose 64-bit prefix is <= idx
+        uint32_t lo = 0, hi = t.C;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint64_t pm_ = t.msrow[mid];
+            const uint64_t pu = ((uint64_t)plf_uni((uint32_t)(pm_ >> 32)) << 32) | plf_uni((uint32_t)pm_);
+            if (pu <= idx)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        i = lo;
+    }
+    const uint64_t row0 = t.msrow[i];
+    uint32_t off = (uint32_t)(idx - (((uint64_t)plf_uni((uint32_t)(row0 >> 32)) << 32) | plf_uni((uint32_t)row0)));  // inside a row: < 2^32
     const uint32_t ci = plf_uni(t.csw[i]), ei = ci >> 16;
     const uint32_t si = plf_uni(plf_ald(t.sE + ei));
     const uint32_t j = plf_walk(i + 1, t.C, off, [&](uint32_t jj) {

@@ -22,17 +22,21 @@ def _t(moves):
     return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"], moves["value"]], axis=1)
 
 
-@pytest.fixture(params=["lds", "hbm", "lds_slow_recreate"])
+@pytest.fixture(params=["lds", "hbm", "lds_slow_recreate", "lds_index64"])
 def scratch(request):
     """Kahn scratch in LDS / HBM; slow_recreate: the ruins slide every element through every slot with one evaluation each
-    (SF_AMD_PLF_SLOW) instead of pricing all slots from one forward + one backward pass."""
+    (SF_AMD_PLF_SLOW) instead of pricing all slots from one forward + one backward pass; index64: the multi-swap stream takes its
+    64-bit index path (selection index, ring entry, row search) whatever its length (SF_AMD_PLF_FORCE64)."""
     if request.param == "hbm":
         os.environ["SF_AMD_PREC_HBM"] = "1"
     if request.param == "lds_slow_recreate":
         os.environ["SF_AMD_PLF_SLOW"] = "1"
+    if request.param == "lds_index64":
+        os.environ["SF_AMD_PLF_FORCE64"] = "1"
     yield request.param
     os.environ.pop("SF_AMD_PREC_HBM", None)
     os.environ.pop("SF_AMD_PLF_SLOW", None)
+    os.environ.pop("SF_AMD_PLF_FORCE64", None)
 
 
 def _pair(oracle, p, leaves, seed, n_replicas=1, la=5, limit=25, with_owner=True):
@@ -215,13 +219,7 @@ def test_validation():
     d = sfa.build_precedence_shop(q, leaves=("precedence",))
     with pytest.raises(sfa.SolverForgeError):
         d.add_precedence_selector(0)  # one such leaf per union
-    big = datasets.make_precedence_shop(103, 20, seed=1)  # 2,060 nodes: the multi-swap stream is indexed in 32 bits
-    d = sfa.build_precedence_shop(big, leaves=("precedence", "list_swap"))
-    d.configure(sfa.SolverConfig(random_seed=1))
-    d.calculate_score()
-    d.phase_start()
-    with pytest.raises(sfa.SolverForgeError):
-        d.solve_steps(1)
+    # (round 4: the 2,048-node limit of the leaf is gone -- test_critical_path_leaf_beyond_2048_nodes runs a 2,400-node shop)
 
 
 # ---- the runtime slot's precedence policy: route-graph filter on the other list leaves, ruin leaf with the hooks --------------------------
@@ -715,3 +713,33 @@ def test_element_capacity_below_the_node_count(oracle):
         assert (scores[r] == o.score()[:2]).all(), r
         assert d.working_lists(0, r) == o.get_lists(0), r
     assert (d.fresh_score() == scores).all()
+
+
+def test_critical_path_leaf_beyond_2048_nodes(oracle):
+    """Round 4 lifted the leaf's 2,048-node limit (64-bit multi-swap stream).  A 60 x 40 shop (2,400 nodes: Kahn scratch in HBM): traced
+    steps of the leaf beside change + swap == oracle, then fused steps with the counters.  (At this size the stream still fits 32 bits --
+    the 64-bit plumbing is what the index64 parametrisation of the other tests runs; the reference's own cursor counts its triples with
+    three nested loops, so no oracle run exists where the count passes 2^32.)"""
+    from solverforge_amd import datasets
+
+    p = datasets.make_precedence_shop(60, 40, seed=6)
+    assert len(p["durations"]) == 2400
+    d, mk, bits = _pair(oracle, p, ("precedence", "list_change", "list_swap"), 4, la=5, limit=12)
+    o = mk(4)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    d.phase_start()
+    o.phase_start()
+    for step in range(3):
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all() and (gf == of).all() and (gs == os_[:, :2]).all(), step
+        assert gap == oap
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+    d.solve_steps(2)
+    o.steps(2)
+    assert (d.calculate_score()[0] == o.score()[:2]).all() and d.working_lists(0, 0) == o.get_lists(0)
+    gst, ost = d.stats(0), o.stats()
+    for c in COUNTERS:
+        assert gst[c] == ost[c], c
