@@ -2231,7 +2231,8 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     const bool tables = ctx->has_scalar_model && ctx->sm.tables();
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
                   gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
-                  PREC && gl.prec_lds ? gl.prec.n : 0, tables ? ctx->sm.n_values : 0, tables && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0);
+                  PREC && gl.prec_lds ? gl.prec.n : 0, tables ? ctx->sm.n_values : 0, tables && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0,
+                  PREC && gl.prec_lds ? gl.prec_groups : 0);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     // FAST instantiation: the reference's default list policy on a list-only model (see k_mixed_search_wave)
     static const bool no_fast = std::getenv("SF_AMD_MIXED_NO_FAST") != nullptr;  // diagnostics / parity tests: force the general instantiation
@@ -2436,6 +2437,15 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         // (profiles/r03f_precedence.txt): opt-in for the parity tests and further work
         gl.prec_inc = std::getenv("SF_AMD_PREC_INC") != nullptr ? 1 : 0;
         // lane-per-trial sweep (prec_trial_sweep64): the default with the scratch in HBM; SF_AMD_PREC_NO_SWEEP = one full evaluation per trial
+        // grouped trial evaluator (sf_prec_group.h): T trials per wavefront with private LDS scratch.  SF_AMD_PREC_GROUPS = 0 / 2 / 4 / 8 / 16
+        gl.prec_groups = 0;
+        if (gl.prec.on && gl.prec_lds) {
+            int T = 0;
+            if (const char* e = std::getenv("SF_AMD_PREC_GROUPS")) T = std::atoi(e);
+            if (T != 2 && T != 4 && T != 8 && T != 16) T = 0;
+            while (T > 1 && pgrp_bytes(gl.prec.n, T) > 40 * 1024) T >>= 1;
+            gl.prec_groups = T > 1 ? T : 0;
+        }
         gl.prec_sweep = (gl.prec.on && !gl.prec_lds && !gl.prec_inc && std::getenv("SF_AMD_PREC_NO_SWEEP") == nullptr) ? 1 : 0;
         if (gl.plf.on) gl.prec_inc = gl.prec_sweep = 0;  // the critical-path leaf re-evaluates in the main scratch arrays: one full evaluation per trial
         if (gl.prec_sweep && !ctx->pm.elane) {  // [R][n][64] earliest starts of the trials in flight

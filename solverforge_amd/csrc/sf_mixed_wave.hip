@@ -27,6 +27,7 @@
 #include "sf_list_model.h"
 #include "sf_precedence.h"
 #include "sf_prec_leaf.h"
+#include "sf_prec_group.h"
 
 namespace sf {
 
@@ -102,12 +103,13 @@ struct GLeaves {
     int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
     int32_t prec_inc;        // HBM scratch: list change / swap trials take the incremental refresh (prec_trial_inc; opt-in, see sf_precedence.h)
     int32_t prec_sweep;      // HBM scratch: the list change / swap trials of a replay chunk are scored 64 at a time (prec_trial_sweep64)
+    int32_t prec_groups;     // LDS scratch: trials per wavefront of the grouped evaluator (prec_eval_grouped: 8, 4 or 2; 0 = off)
     PlfModel plf;            // critical-path precedence leaf (kind 16384; PREC instantiations, sf_prec_leaf.h)
 };
 
 template <class VT>
 struct GCarve {
-    size_t ring, ringx, load, off, visits, vals, tsum, tcnt, tpt, nstmp, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, leaftab, total;
+    size_t ring, ringx, load, off, visits, vals, tsum, tcnt, tpt, nstmp, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, pgrp, leaftab, total;
     // dim_nearby = node-id bound when the union has nearby leaves (node -> slot table + two leaves'
     // entity-order tables), else 0
     // n_leaves rings only: the LDS slice decides how many replicas a CU holds
@@ -116,7 +118,7 @@ struct GCarve {
     // n_table / run_P: per-value tables of the scalar class's value-keyed constraints (n_values entries; the consecutive-runs /
     // presence table behind the count table, as SCarve lays them out), 0 when the class has none
     __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0,
-                               int prec_words = 0, int n_table = 0, int run_P = 0) {
+                               int prec_words = 0, int n_table = 0, int run_P = 0, int prec_groups = 0) {
         size_t o = 0;
         ring = o;  // the candidate rings live in HBM (GLeaves::ring / ringx) unless SF_MIXED_RING_LDS
         o = align_up(o + (SF_MIXED_RING_LDS ? sizeof(uint32_t) * 2 * GRC * n_leaves : 0), 16);
@@ -156,6 +158,8 @@ struct GCarve {
         o = align_up(o + (has_ruin == 2 ? sizeof(uint16_t) * (2 * (size_t)dim + 2 * (size_t)V + n_cap) : 0), 16);
         prec = o;  // earliest start, in-degree, queue, list successor of the precedence constraint's Kahn pass
         o = align_up(o + sizeof(uint32_t) * 4 * (size_t)prec_words, 16);
+        pgrp = o;  // grouped trial evaluator (sf_prec_group.h): committed successor / in-degree + per-trial scratch
+        o = align_up(o + pgrp_bytes(prec_words, prec_groups), 16);
         leaftab = o;  // per-leaf generator / ring / scheduler state (LeafTab)
         o = align_up(o + sizeof(uint32_t) * 16 * GL, 16);
         total = o;
@@ -291,7 +295,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const bool unified_eval = FAST || (has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval);
     const bool tables = !FAST && has_scalar && sm.tables();  // value-keyed constraints of the scalar class: per-value tables in LDS
     const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim,
-                        PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0);
+                        PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0,
+                        PREC && gl.prec_lds ? gl.prec_groups : 0);
     unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
     uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
     uint8_t* ringx = SF_MIXED_RING_LDS ? (uint8_t*)(mem + cv.ringx) : gl.ringx + (size_t)r * GL * GRC;   // [leaf][GRC]
@@ -520,6 +525,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         prec_pen = pr.penalty;
         prec_mk = pr.makespan;
     }
+    // grouped trial evaluator (sf_prec_group.h): T candidates of a replay chunk per pass, G = 64 / T lanes each
+    const uint32_t pgrp_T = (PREC && prec_in_lds) ? (uint32_t)gl.prec_groups : 0u;
+    const uint32_t pgrp_shift = pgrp_T ? (uint32_t)__builtin_ctz(64u / pgrp_T) : 6u;
+    uint32_t pgrp_viol = 0;  // wrong-owner items of the committed lists
     // ---- critical-path precedence leaf (kind 16384): per-replica tables, one full evaluation with the cycle flag ----
     const bool plf_on = PREC && gl.plf.on != 0;
     const bool plf_policy = plf_on && gl.plf.policy != 0;  // runtime slot with precedence hooks: route-graph filter + ruins with hooks
@@ -947,6 +956,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             else
                 plf_analyse<PrecMemGlobal>(gl.prec, gl.plf, plf, s_visits, s_off, V, prec_E, prec_Q, prec_S, rounds, (int32_t)pr.makespan, cyc);
             plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni64(plf.ms_count), plf.mr_count = uni(plf.mr_count);
+        }
+        if (pgrp_T) {  // grouped trial evaluator: the committed list edges every trial of this step starts from
+            const PgrpLds pl(mem + cv.pgrp, gl.prec.n, 0);
+            pgrp_viol = uni(pgrp_build_committed<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, pl.Sc, pl.Dc));
         }
         uint32_t exmask = ((1u << GL) - 1u) & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
@@ -2085,6 +2098,36 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                                 }
                             }
                             todo &= ~cm_;
+                        }
+                    }
+                    while (pgrp_T && todo) {  // T candidates side by side, nothing applied to the lists
+                        const uint32_t my_g = lane >> pgrp_shift;
+                        int src = -1, my_slot = -1;  // the candidate lane my group evaluates; the group that evaluates my candidate
+                        for (uint32_t q = 0; q < pgrp_T && todo; ++q) {
+                            const int ci = __ffsll((unsigned long long)todo) - 1;
+                            todo &= todo - 1;
+                            if (my_g == q) src = ci;
+                            if ((int)lane == ci) my_slot = (int)q;
+                        }
+                        const int sl = src < 0 ? (int)lane : src;
+                        const int ck = __shfl(my_kind, sl);
+                        const uint32_t ca = __shfl(m0, sl), cb = __shfl(m1, sl), cx = __shfl(mx_, sl);
+                        PgrpMove gm;
+                        gm.kind = src < 0 ? 0u : (uint32_t)list_move_kind_of(ck);
+                        gm.a = ca >> 16, gm.i = ca & 0xFFFFu, gm.b = cb >> 16, gm.j = cb & 0xFFFFu, gm.el2 = 0;
+                        gm.ext = list_move_ext_of(ck, ca, cb, cx);
+                        if (ck == 8192) gm.b = gm.a, gm.j = gm.i + (cb >> 16);  // permute: (list, start, window, rank)
+                        int64_t gp = 0, gmk = 0;
+                        prec_eval_grouped<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, mem + cv.pgrp, pgrp_shift, gm,
+                                                    gl.prec.const_penalty + (int64_t)((uint32_t)gl.prec.n - uni(s_off[V])), pgrp_viol, gp, gmk);
+                        const int from = my_slot < 0 ? (int)lane : (my_slot << pgrp_shift);
+                        const int64_t tp = (int64_t)shfl_u64((uint64_t)gp, from), tm_ = (int64_t)shfl_u64((uint64_t)gmk, from);
+                        if (my_slot >= 0) {
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk) {
+                                if (kk == gl.prec.hard_level) sc.v[kk] -= tp - prec_pen;
+                                if (kk == gl.prec.mk_level) sc.v[kk] -= tm_ - prec_mk;
+                            }
                         }
                     }
                     while (todo) {

@@ -1,0 +1,289 @@
+// Grouped trial evaluation of the ListPrecedenceMakespanConstraint (round 4): T candidates per wavefront, G = 64 / T lanes each.
+//
+// A job-shop precedence graph is narrow -- a Kahn round of prec_eval (sf_precedence.h) pops a handful of ready nodes onto 64 lanes, and the
+// rounds are a chain of dependent LDS round trips -- so one wave-wide evaluation per candidate leaves the wave mostly idle.  Here T trials
+// walk their rounds side by side, each on its own lane group with private scratch (earliest start, in-degree, queue, list successor: 12 bytes
+// per node and trial, in the replica's LDS slice).  Nothing is applied to the replica's lists: a trial's list edges are written from the
+// committed lists through the candidate's POSITION MAP -- old_index(list, new position) -> position in the committed lists -- for the at most
+// three lists the candidate touches; every other node keeps the committed list successor and in-degree (copied from two shared arrays built
+// once per step).  The evaluation itself is Kahn's algorithm exactly as in prec_eval, so cyclic trials are detected the same way (nodes left
+// unprocessed) and a cyclic COMMITTED state needs no special case.
+//
+// Result per trial: the constraint's (hard penalty, makespan) of the lists after the move -- what prec_eval returns for the applied state.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sf_precedence.h"
+
+namespace sf {
+
+typedef __attribute__((address_space(3))) uint16_t pg_lds_u16;
+typedef __attribute__((address_space(3))) uint32_t pg_lds_u32;
+typedef __attribute__((address_space(3))) int32_t pg_lds_i32;
+
+constexpr uint32_t PG_NONE16 = 0xFFFFu;
+
+// LDS of the grouped evaluator inside one replica's slice: committed list successor + in-degree (shared by the trials), then per trial
+// E (i32), D (i32), S (u16), Q (u16)
+__host__ __device__ inline size_t pgrp_bytes(int n, int trials) {
+    if (trials <= 0) return 0;
+    const size_t per = ((size_t)n * 4 + 15) / 16 * 16 * 2 + ((size_t)n * 2 + 15) / 16 * 16 * 2;
+    return ((size_t)n * 2 + 15) / 16 * 16 * 2 + per * (size_t)trials;
+}
+struct PgrpLds {
+    pg_lds_u16* Sc;  // [n] committed list successor (PG_NONE16 = none)
+    pg_lds_u16* Dc;  // [n] committed in-degree (fixed + list predecessor)
+    pg_lds_i32* E;   // this lane's trial
+    pg_lds_i32* D;
+    pg_lds_u16* S;
+    pg_lds_u16* Q;
+    __device__ PgrpLds(unsigned char* base, int n, uint32_t trial) {
+        const size_t a4 = ((size_t)n * 4 + 15) / 16 * 16, a2 = ((size_t)n * 2 + 15) / 16 * 16;
+        Sc = (pg_lds_u16*)base;
+        Dc = (pg_lds_u16*)(base + a2);
+        unsigned char* t = base + 2 * a2 + (size_t)trial * (2 * a4 + 2 * a2);
+        E = (pg_lds_i32*)t;
+        D = (pg_lds_i32*)(t + a4);
+        S = (pg_lds_u16*)(t + 2 * a4);
+        Q = (pg_lds_u16*)(t + 2 * a4 + a2);
+    }
+};
+
+// committed list successor / in-degree of every node, once per step: one wavefront.  Returns the wrong-owner items of the lists (wave-uniform).
+template <class VT>
+__device__ __forceinline__ uint32_t pgrp_build_committed(const PrecModel& pm, const PREC_L VT* visits, const PREC_L uint32_t* off, int V, pg_lds_u16* Sc, pg_lds_u16* Dc) {
+    const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)pm.n;
+    for (uint32_t i = lane; i < n; i += 64) {
+        Sc[i] = (uint16_t)PG_NONE16;
+        Dc[i] = (uint16_t)pm.indeg0[i];
+    }
+    prec_sync();
+    uint32_t viol = 0;
+    for (uint32_t e = 0; e < (uint32_t)V; ++e) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[e]), len = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[e + 1]) - o;
+        for (uint32_t k = lane; k < len; k += 64) {
+            const uint32_t x = (uint32_t)visits[o + k];
+            if (k + 1 < len) Sc[x] = (uint16_t)visits[o + k + 1];
+            if (k > 0) Dc[x] = (uint16_t)(pm.indeg0[x] + 1);
+            if (pm.owner) {
+                const int32_t ow = pm.owner[x];
+                viol += (ow >= 0 && (uint32_t)ow != e) ? 1u : 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) viol += (uint32_t)__shfl_xor((int)viol, o);
+    prec_sync();
+    return viol;
+}
+
+// One candidate as the generic engine's ring holds it, decoded to the arguments of apply_list_move_wave
+struct PgrpMove {
+    uint32_t kind;  // sf_move_kind: 2 change, 3 swap, 4 reverse, 5 sublist change, 6 sublist swap, 7 3-opt, 9 permute, 10 multi-swap; 0 = idle group
+    uint32_t a, i, b, j, ext;
+    uint32_t el2;   // multi-swap: the third swap (list << 16 | first position); a / i and b / j are the first two
+};
+
+// Position map of a candidate: the flat index (into the committed `visits`) of the element at position k of list e AFTER the move.
+// la / lb = committed lengths of lists a / b.  e is one of the lists the move touches.
+template <class OffP>
+__device__ __forceinline__ uint32_t pgrp_old_flat(const PgrpMove& m, OffP off, uint32_t e, uint32_t k, uint32_t la, uint32_t lb) {
+    const bool one_list = m.kind == 4 || m.kind == 7 || m.kind == 9;  // b / j carry cut positions, not a second list
+    const uint32_t oa = off[m.a], ob = one_list ? oa : off[m.b];
+    const uint32_t a = m.a, b = m.b, i = m.i, j = m.j;
+    switch (m.kind) {
+        case 2: {  // (a, i) -> (b, j), j in pre-removal coordinates
+            if (a != b) {
+                if (e == a) return oa + (k < i ? k : k + 1);
+                return k < j ? ob + k : (k == j ? oa + i : ob + k - 1);
+            }
+            const uint32_t f = j > i ? j - 1 : j;  // final position of the element
+            if (k == f) return oa + i;
+            const uint32_t q = k > f ? k - 1 : k;
+            return oa + (q >= i ? q + 1 : q);
+        }
+        case 3: {  // (a, i) <-> (b, j)
+            if (e == a && k == i) return ob + j;
+            if (e == b && k == j) return oa + i;
+            return off[e] + k;
+        }
+        case 4:  // reverse [i, j) of a
+            return oa + ((k >= i && k < j) ? i + j - 1 - k : k);
+        case 5: {  // [i, ext) of a -> b at j (intra: j in post-removal coordinates)
+            const uint32_t z = m.ext - i;
+            if (a != b) {
+                if (e == a) return oa + (k < i ? k : k + z);
+                return k < j ? ob + k : (k < j + z ? oa + i + (k - j) : ob + k - z);
+            }
+            if (k >= j && k < j + z) return oa + i + (k - j);
+            const uint32_t q = k >= j + z ? k - z : k;
+            return oa + (q >= i ? q + z : q);
+        }
+        case 6: {  // [i, i + za) of a <-> [j, j + zb) of b
+            const uint32_t za = m.ext & 0xFFFFu, zb = m.ext >> 16;
+            if (a != b) {
+                if (e == a) return k < i ? oa + k : (k < i + zb ? ob + j + (k - i) : oa + k - zb + za);
+                return k < j ? ob + k : (k < j + za ? oa + i + (k - j) : ob + k - za + zb);
+            }
+            // one list: X = the earlier segment, Y = the later one; new layout from x0: Y, the elements between them, X
+            const bool a_first = i < j;
+            const uint32_t x0 = a_first ? i : j, zx = a_first ? za : zb, y0 = a_first ? j : i, zy = a_first ? zb : za;
+            const uint32_t mid = y0 - (x0 + zx);
+            if (k < x0 || k >= y0 + zy) return oa + k;
+            if (k < x0 + zy) return oa + y0 + (k - x0);
+            if (k < x0 + zy + mid) return oa + x0 + zx + (k - x0 - zy);
+            return oa + x0 + (k - x0 - zy - mid);
+        }
+        case 7: {  // 3-opt of list a: cuts c1 = i < c2 = b < c3 = j, pattern ext
+            const uint32_t c1 = i, c2 = m.b, c3 = j;
+            const uint32_t mask = kopt_reverse_mask(m.ext);
+            const bool rb = (mask >> 1) & 1u, rc = (mask >> 2) & 1u;
+            if (k < c1 || k >= c3) return oa + k;
+            if (!kopt_swaps_segments(m.ext)) {
+                if (k < c2) return oa + (rb ? c1 + c2 - 1 - k : k);
+                return oa + (rc ? c2 + c3 - 1 - k : k);
+            }
+            const uint32_t zc = c3 - c2;
+            if (k < c1 + zc) {  // the second segment comes first
+                const uint32_t t = k - c1;
+                return oa + (rc ? c3 - 1 - t : c2 + t);
+            }
+            const uint32_t t = k - c1 - zc;
+            return oa + (rb ? c2 - 1 - t : c1 + t);
+        }
+        case 9: {  // window [i, j) of a permuted by the ext-th permutation
+            if (k < i || k >= j) return oa + k;
+            const uint32_t perm = nth_permutation_nibbles(j - i, m.ext);
+            return oa + i + ((perm >> (4u * (k - i))) & 15u);
+        }
+        default: {  // 10: three adjacent swaps in three different lists
+            uint32_t p;
+            if (e == a)
+                p = i;
+            else if (e == b)
+                p = j;
+            else
+                p = m.el2 & 0xFFFFu;
+            return off[e] + (k == p ? p + 1 : (k == p + 1 ? p : k));
+        }
+    }
+}
+
+// T trials side by side.  `gshift` = log2(lanes per group); lane's group g = lane >> gshift, its index inside the group lg.  `mv` is uniform
+// inside a group (kind 0 = the group idles).  Returns, uniform inside each group, the (penalty, makespan) of the trial.
+//   fixed_pen = const_penalty + unassigned nodes (unchanged by a list move that keeps every element), viol_c = wrong-owner items of the
+//   committed lists.
+template <class VT>
+__device__ __noinline__ void prec_eval_grouped(const PrecModel pm, const PREC_L VT* visits, const PREC_L uint32_t* off, int V, unsigned char* lds_base, uint32_t gshift,
+                                               const PgrpMove mv, int64_t fixed_pen, uint32_t viol_c, int64_t& out_pen, int64_t& out_mk) {
+    const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)pm.n;
+    const uint32_t G = 1u << gshift, lg = lane & (G - 1u), g = lane >> gshift;
+    const uint64_t gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (g << gshift);  // this group's lanes
+    const PgrpLds L(lds_base, (int)n, g);
+    const bool active = mv.kind != 0;
+    // ---- the trial's list edges and in-degrees: the committed ones, then the lists the move touches through its position map ----
+    if (active)
+        for (uint32_t v = lg; v < n; v += G) {
+            L.S[v] = L.Sc[v];
+            L.D[v] = (int32_t)L.Dc[v];
+            L.E[v] = 0;
+        }
+    prec_sync();
+    int32_t dviol = 0;
+    if (active) {
+        const bool one_list = mv.kind == 4 || mv.kind == 7 || mv.kind == 9;
+        const uint32_t la = off[mv.a + 1] - off[mv.a], lb = one_list ? la : off[mv.b + 1] - off[mv.b];
+        const uint32_t e3 = mv.el2 >> 16;
+        const uint32_t nl = mv.kind == 10 ? 3u : ((mv.kind == 2 || mv.kind == 3 || mv.kind == 5 || mv.kind == 6) && mv.a != mv.b ? 2u : 1u);
+        for (uint32_t li = 0; li < nl; ++li) {
+            const uint32_t e = li == 0 ? mv.a : (li == 1 ? mv.b : e3);
+            uint32_t len = off[e + 1] - off[e];  // new length of list e
+            if (mv.a != mv.b) {
+                if (mv.kind == 2) len = e == mv.a ? la - 1 : lb + 1;
+                if (mv.kind == 5) {
+                    const uint32_t z = mv.ext - mv.i;
+                    len = e == mv.a ? la - z : lb + z;
+                }
+                if (mv.kind == 6) {
+                    const uint32_t za = mv.ext & 0xFFFFu, zb = mv.ext >> 16;
+                    len = e == mv.a ? la - za + zb : lb - zb + za;
+                }
+            }
+            for (uint32_t k = lg; k < len; k += G) {
+                const uint32_t x = (uint32_t)visits[pgrp_old_flat(mv, off, e, k, la, lb)];
+                const uint32_t nx = k + 1 < len ? (uint32_t)visits[pgrp_old_flat(mv, off, e, k + 1, la, lb)] : PG_NONE16;
+                L.S[x] = (uint16_t)nx;
+                L.D[x] = pm.indeg0[x] + (k > 0 ? 1 : 0);
+                if (pm.owner) {
+                    const int32_t o = pm.owner[x];
+                    dviol += (o >= 0 && (uint32_t)o != e) ? 1 : 0;
+                }
+            }
+            if (pm.owner) {  // minus what the committed list e contributed
+                const uint32_t oe = off[e], le = off[e + 1] - oe;
+                for (uint32_t k = lg; k < le; k += G) {
+                    const int32_t o = pm.owner[(uint32_t)visits[oe + k]];
+                    dviol -= (o >= 0 && (uint32_t)o != e) ? 1 : 0;
+                }
+            }
+        }
+    }
+    if (pm.owner) {  // group sum of dviol (xor butterfly stays inside the group for offsets < G)
+        for (uint32_t o = G >> 1; o; o >>= 1) dviol += __shfl_xor(dviol, (int)o);
+    }
+    prec_sync();
+    // ---- Kahn: ready nodes, then rounds of up to G pops per group ----
+    uint32_t head = 0, tail = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += G) {  // (n is wave-uniform: every group scans the same chunks)
+        const uint32_t v = b0 + lg;
+        const bool ready = active && v < n && L.D[v] == 0;
+        const uint64_t m = __ballot(ready) & gmask;
+        if (ready) L.Q[tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)v;
+        tail += (uint32_t)__popcll(m);
+    }
+    prec_sync();
+    int32_t mk = 0;
+    while (__ballot(head < tail) != 0ull) {
+        const uint32_t cnt = tail - head < G ? tail - head : G;
+        const bool act = lg < cnt;
+        int32_t fin = 0;
+        uint32_t so = 0, deg = 0, ls = PG_NONE16;
+        if (act) {
+            const uint32_t node = (uint32_t)L.Q[head + lg];
+            fin = L.E[node] + pm.dur[node];
+            mk = fin > mk ? fin : mk;
+            so = pm.succ_off[node];
+            deg = pm.succ_off[node + 1] - so;
+            ls = (uint32_t)L.S[node];
+        }
+        const uint32_t degt = deg + ((act && ls != PG_NONE16) ? 1u : 0u);
+        uint32_t ntail = tail;
+        for (uint32_t k = 0;; ++k) {
+            const bool has = k < degt;
+            if (!__ballot(has)) break;
+            bool newly = false;
+            uint32_t s = 0;
+            if (has) {
+                s = k < deg ? pm.succ[so + k] : ls;
+                __hip_atomic_fetch_max(L.E + s, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                newly = __hip_atomic_fetch_add(L.D + s, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+            }
+            const uint64_t m = __ballot(newly) & gmask;
+            if (newly) L.Q[ntail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
+            ntail += (uint32_t)__popcll(m);
+        }
+        head += cnt;
+        tail = ntail;
+        prec_sync();
+    }
+    for (uint32_t o = G >> 1; o; o >>= 1) {  // group maximum of the finish times
+        const int32_t other = __shfl_xor(mk, (int)o);
+        mk = other > mk ? other : mk;
+    }
+    const bool cyclic = head < n;  // Kahn left nodes unprocessed (rebuild_graph_summary :584-588)
+    out_pen = fixed_pen + (int64_t)((int32_t)viol_c + dviol) + (cyclic ? (int64_t)n : 0);
+    out_mk = cyclic ? 0 : (int64_t)mk;
+}
+
+}  // namespace sf
