@@ -529,6 +529,38 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const uint32_t pgrp_T = (PREC && prec_in_lds) ? (uint32_t)gl.prec_groups : 0u;
     const uint32_t pgrp_shift = pgrp_T ? (uint32_t)__builtin_ctz(64u / pgrp_T) : 6u;
     uint32_t pgrp_viol = 0;  // wrong-owner items of the committed lists
+    // one pass: every lane group scores the move it holds (gm uniform inside a group, kind 0 = idle) against the committed lists
+    auto pgrp_eval = [&](const PgrpMove& gm, int64_t& gp, int64_t& gmk, bool& gcyc) {
+        prec_eval_grouped<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, mem + cv.pgrp, pgrp_shift, gm,
+                                    gl.prec.const_penalty + (int64_t)((uint32_t)gl.prec.n - uni(s_off[V])), pgrp_viol, gp, gmk, gcyc);
+    };
+    // the next (up to) T candidates of `todo` -- one per lane: leaf kind and ring words -- through one pass; true on the lanes whose
+    // candidate was scored, with its (penalty, makespan, cycle flag)
+    auto pgrp_batch = [&](uint64_t& todo, int lkind, uint32_t a0, uint32_t a1, uint32_t ax, int64_t& tp, int64_t& tm_, bool& tcyc) -> bool {
+        const uint32_t my_g = lane >> pgrp_shift;
+        int src = -1, my_slot = -1;  // the candidate lane my group evaluates; the group that evaluates my candidate
+        for (uint32_t q = 0; q < pgrp_T && todo; ++q) {
+            const int ci = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            if (my_g == q) src = ci;
+            if ((int)lane == ci) my_slot = (int)q;
+        }
+        const int sl = src < 0 ? (int)lane : src;
+        const int ck = __shfl(lkind, sl);
+        const uint32_t ca = __shfl(a0, sl), cb = __shfl(a1, sl), cx = __shfl(ax, sl);
+        PgrpMove gm;
+        gm.kind = src < 0 ? 0u : (uint32_t)list_move_kind_of(ck);
+        gm.a = ca >> 16, gm.i = ca & 0xFFFFu, gm.b = cb >> 16, gm.j = cb & 0xFFFFu, gm.el2 = 0;
+        gm.ext = list_move_ext_of(ck, ca, cb, cx);
+        if (ck == 8192) gm.b = gm.a, gm.j = gm.i + (cb >> 16);  // permute: (list, start, window, rank)
+        int64_t gp = 0, gmk = 0;
+        bool gcyc = false;
+        pgrp_eval(gm, gp, gmk, gcyc);
+        const int from = my_slot < 0 ? (int)lane : (my_slot << pgrp_shift);
+        tp = (int64_t)shfl_u64((uint64_t)gp, from), tm_ = (int64_t)shfl_u64((uint64_t)gmk, from);
+        tcyc = __shfl((int)gcyc, from) != 0;
+        return my_slot >= 0;
+    };
     // ---- critical-path precedence leaf (kind 16384): per-replica tables, one full evaluation with the cycle flag ----
     const bool plf_on = PREC && gl.plf.on != 0;
     const bool plf_policy = plf_on && gl.plf.policy != 0;  // runtime slot with precedence hooks: route-graph filter + ruins with hooks
@@ -1579,54 +1611,90 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     } else if (PREC && kind == 16384) {  // ---- critical-path precedence leaf (precedence/cursor.rs:182-252): one candidate per call,
                                                          // decoded, applied, scored (and pruned when cyclic) right here.  g.a = stage, g.b = offset
                                                          // inside the stage, g.c = block offset ----
+                        // the next candidate of the stream: 0 = decoded into (c0, c1, m), 1 = a stage / block ended (call again), 2 = the stream ended
+                        auto plf_next = [&](GGen& gg, uint32_t& c0, uint32_t& c1, PlfMove& m) -> int {
+                            if (gg.a == 0) {  // stream offset = gg.d : gg.b (64 bits), ring entry = the selected index (high 30 bits in c0, low 32 in c1)
+                                const uint64_t so = ((uint64_t)gg.d << 32) | gg.b;
+                                if (so >= plf.ms_count) {
+                                    gg.a = 1, gg.b = 0, gg.d = 0;
+                                    return 1;
+                                }
+                                const uint64_t si = (plf.ms_count <= 0xFFFFFFFFull && !gl.plf.force64) ? (uint64_t)ctx.selection_index((uint32_t)so, (uint32_t)plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc)
+                                                                                                  : kopt_selection_index64(ctx, so, plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc);
+                                gg.b += 1;
+                                if (gg.b == 0) gg.d += 1;
+                                c1 = (uint32_t)si;
+                                c0 = (uint32_t)(si >> 32);  // stage 0 in bits 30..31
+                                plf_decode_multi_swap(plf, si, m);
+                            } else if (gg.a == 1) {
+                                if (gg.b >= plf.mr_count) {
+                                    gg.a = 2, gg.b = 0, gg.c = 0;
+                                    return 1;
+                                }
+                                c1 = ctx.selection_index(gg.b, plf.mr_count, SALT_PL_MULTI_RUIN ^ ldesc);
+                                gg.b += 1;
+                                c0 = 1u << 30;
+                                plf_decode_multi_ruin(plf, c1, m);
+                            } else {
+                                if (gg.c >= plf.nb) return 2;
+                                const uint32_t bi = ctx.selection_index(gg.c, plf.nb, SALT_PL_BLOCK ^ ldesc);
+                                const PlfBlock bl = plf_block(plf, bi);
+                                if (gg.b >= bl.moves()) {
+                                    gg.c += 1, gg.b = 0;
+                                    return 1;
+                                }
+                                c1 = plf_tiered_index(ctx, bl, gg.b, SALT_PL_MOVE ^ ldesc ^ (uint64_t)bl.e ^ ((uint64_t)bl.start << 16) ^ ((uint64_t)(bl.start + bl.len - 1) << 32));
+                                gg.b += 1;
+                                c0 = (2u << 30) | bi;
+                                plf_decode_block(bl, c1, m);
+                            }
+                            c0 = uni(c0), c1 = uni(c1);
+                            return 0;
+                        };
                         PlfMove pm_;
-                        bool emit = false;
-                        if (g.a == 0) {  // stream offset = g.d : g.b (64 bits), ring entry = the selected index (high 30 bits in w0, low 32 in w1)
-                            const uint64_t so = ((uint64_t)g.d << 32) | g.b;
-                            if (so >= plf.ms_count) {
-                                g.a = 1, g.b = 0, g.d = 0;
-                                st_sources -= 1;
-                                continue;
-                            }
-                            const uint64_t si = (plf.ms_count <= 0xFFFFFFFFull && !gl.plf.force64) ? (uint64_t)ctx.selection_index((uint32_t)so, (uint32_t)plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc)
-                                                                              : kopt_selection_index64(ctx, so, plf.ms_count, SALT_PL_MULTI_SWAP ^ ldesc);
-                            g.b += 1;
-                            if (g.b == 0) g.d += 1;
-                            w1 = (uint32_t)si;
-                            w0 = (uint32_t)(si >> 32);  // stage 0 in bits 30..31
-                            plf_decode_multi_swap(plf, si, pm_);
-                            emit = true;
-                        } else if (g.a == 1) {
-                            if (g.b >= plf.mr_count) {
-                                g.a = 2, g.b = 0, g.c = 0;
-                                st_sources -= 1;
-                                continue;
-                            }
-                            w1 = ctx.selection_index(g.b, plf.mr_count, SALT_PL_MULTI_RUIN ^ ldesc);
-                            g.b += 1;
-                            w0 = 1u << 30;
-                            plf_decode_multi_ruin(plf, w1, pm_);
-                            emit = true;
-                        } else {
-                            if (g.c >= plf.nb) {
-                                g.done = 1;
-                                break;
-                            }
-                            const uint32_t bi = ctx.selection_index(g.c, plf.nb, SALT_PL_BLOCK ^ ldesc);
-                            const PlfBlock bl = plf_block(plf, bi);
-                            if (g.b >= bl.moves()) {
-                                g.c += 1, g.b = 0;
-                                st_sources -= 1;
-                                continue;
-                            }
-                            w1 = plf_tiered_index(ctx, bl, g.b, SALT_PL_MOVE ^ ldesc ^ (uint64_t)bl.e ^ ((uint64_t)bl.start << 16) ^ ((uint64_t)(bl.start + bl.len - 1) << 32));
-                            g.b += 1;
-                            w0 = (2u << 30) | bi;
-                            plf_decode_block(bl, w1, pm_);
-                            emit = true;
+                        const int nx = plf_next(g, w0, w1, pm_);
+                        if (nx == 1) {
+                            st_sources -= 1;
+                            continue;
                         }
-                        w0 = uni(w0), w1 = uni(w1);
-                        if (emit) {
+                        if (nx == 2) {
+                            g.done = 1;
+                            break;
+                        }
+                        if (pgrp_T && pm_.kind != 8) {  // up to T consecutive candidates (no ruins: those recreate on the lists) in one pass
+                            const uint32_t my_g = lane >> pgrp_shift;
+                            PgrpMove gm;
+                            gm.kind = 0, gm.a = gm.i = gm.b = gm.j = gm.ext = gm.el2 = 0;
+                            uint32_t bw0 = 0, bw1 = 0;
+                            for (uint32_t q = 0;;) {
+                                if (my_g == q) {
+                                    gm.kind = (uint32_t)pm_.kind, gm.a = pm_.a, gm.i = pm_.ap, gm.b = pm_.b, gm.j = pm_.bp, gm.ext = pm_.ext, gm.el2 = pm_.el[2];
+                                    bw0 = w0, bw1 = w1;
+                                }
+                                if (++q >= pgrp_T) break;
+                                const GGen before = g;
+                                if (plf_next(g, w0, w1, pm_) != 0 || pm_.kind == 8) {  // a stage boundary or a ruin: the next call's
+                                    g = before;
+                                    break;
+                                }
+                            }
+                            int64_t gp = 0, gmk = 0;
+                            bool gcyc = false;
+                            pgrp_eval(gm, gp, gmk, gcyc);
+                            keep = gm.kind != 0 && (lane & ((1u << pgrp_shift) - 1u)) == 0 && !gcyc;  // cyclic candidates are pruned
+                            w0 = bw0, w1 = bw1;
+                            const uint64_t km_ = __ballot(keep);
+                            if (keep) {
+                                const size_t slot = (size_t)((tl + mbcnt64(km_)) & (GRC - 1)) * 4;
+#pragma unroll
+                                for (int kk = 0; kk < L; ++kk) {
+                                    int64_t v = cur[kk];
+                                    if (kk == gl.prec.hard_level) v -= gp - prec_pen;
+                                    if (kk == gl.prec.mk_level) v -= gmk - prec_mk;
+                                    plf_score[slot + kk] = v;
+                                }
+                            }
+                        } else {
                             ScoreV<L> psc;
                             if (plf_trial(pm_, psc)) {
                                 keep = lane == 0;
@@ -1797,6 +1865,14 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         // runtime slot with precedence hooks: intra-list candidates that close a cycle through the route graph never reach the ring
                         uint64_t chk = __ballot(keep && (kind == 64 || kind == 8192 || (w0 >> 16) == (w1 >> 16)));
                         cache_pen = INT64_MIN, cache_mk = 0;
+                        while (pgrp_T && !plf_cur_cyclic && chk) {  // acyclic working state: dropped <=> the lists are cyclic afterwards
+                            int64_t tp, tm_;
+                            bool tc;
+                            if (pgrp_batch(chk, kind, w0, w1, wx, tp, tm_, tc)) {
+                                cache_pen = tp, cache_mk = tm_;  // what the replay would evaluate again
+                                if (tc) keep = false;
+                            }
+                        }
                         while (chk) {
                             const int ci = __ffsll((unsigned long long)chk) - 1;
                             chk &= chk - 1;
@@ -2101,28 +2177,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         }
                     }
                     while (pgrp_T && todo) {  // T candidates side by side, nothing applied to the lists
-                        const uint32_t my_g = lane >> pgrp_shift;
-                        int src = -1, my_slot = -1;  // the candidate lane my group evaluates; the group that evaluates my candidate
-                        for (uint32_t q = 0; q < pgrp_T && todo; ++q) {
-                            const int ci = __ffsll((unsigned long long)todo) - 1;
-                            todo &= todo - 1;
-                            if (my_g == q) src = ci;
-                            if ((int)lane == ci) my_slot = (int)q;
-                        }
-                        const int sl = src < 0 ? (int)lane : src;
-                        const int ck = __shfl(my_kind, sl);
-                        const uint32_t ca = __shfl(m0, sl), cb = __shfl(m1, sl), cx = __shfl(mx_, sl);
-                        PgrpMove gm;
-                        gm.kind = src < 0 ? 0u : (uint32_t)list_move_kind_of(ck);
-                        gm.a = ca >> 16, gm.i = ca & 0xFFFFu, gm.b = cb >> 16, gm.j = cb & 0xFFFFu, gm.el2 = 0;
-                        gm.ext = list_move_ext_of(ck, ca, cb, cx);
-                        if (ck == 8192) gm.b = gm.a, gm.j = gm.i + (cb >> 16);  // permute: (list, start, window, rank)
-                        int64_t gp = 0, gmk = 0;
-                        prec_eval_grouped<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, mem + cv.pgrp, pgrp_shift, gm,
-                                                    gl.prec.const_penalty + (int64_t)((uint32_t)gl.prec.n - uni(s_off[V])), pgrp_viol, gp, gmk);
-                        const int from = my_slot < 0 ? (int)lane : (my_slot << pgrp_shift);
-                        const int64_t tp = (int64_t)shfl_u64((uint64_t)gp, from), tm_ = (int64_t)shfl_u64((uint64_t)gmk, from);
-                        if (my_slot >= 0) {
+                        int64_t tp, tm_;
+                        bool tc;
+                        if (pgrp_batch(todo, my_kind, m0, m1, mx_, tp, tm_, tc)) {
 #pragma unroll
                             for (int kk = 0; kk < L; ++kk) {
                                 if (kk == gl.prec.hard_level) sc.v[kk] -= tp - prec_pen;

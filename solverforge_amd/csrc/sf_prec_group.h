@@ -171,12 +171,12 @@ __device__ __forceinline__ uint32_t pgrp_old_flat(const PgrpMove& m, OffP off, u
 }
 
 // T trials side by side.  `gshift` = log2(lanes per group); lane's group g = lane >> gshift, its index inside the group lg.  `mv` is uniform
-// inside a group (kind 0 = the group idles).  Returns, uniform inside each group, the (penalty, makespan) of the trial.
+// inside a group (kind 0 = the group idles).  Returns, uniform inside each group, the (penalty, makespan, cycle flag) of the trial.
 //   fixed_pen = const_penalty + unassigned nodes (unchanged by a list move that keeps every element), viol_c = wrong-owner items of the
 //   committed lists.
 template <class VT>
 __device__ __noinline__ void prec_eval_grouped(const PrecModel pm, const PREC_L VT* visits, const PREC_L uint32_t* off, int V, unsigned char* lds_base, uint32_t gshift,
-                                               const PgrpMove mv, int64_t fixed_pen, uint32_t viol_c, int64_t& out_pen, int64_t& out_mk) {
+                                               const PgrpMove mv, int64_t fixed_pen, uint32_t viol_c, int64_t& out_pen, int64_t& out_mk, bool& out_cyclic) {
     const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)pm.n;
     const uint32_t G = 1u << gshift, lg = lane & (G - 1u), g = lane >> gshift;
     const uint64_t gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (g << gshift);  // this group's lanes
@@ -284,6 +284,7 @@ __device__ __noinline__ void prec_eval_grouped(const PrecModel pm, const PREC_L 
     const bool cyclic = head < n;  // Kahn left nodes unprocessed (rebuild_graph_summary :584-588)
     out_pen = fixed_pen + (int64_t)((int32_t)viol_c + dviol) + (cyclic ? (int64_t)n : 0);
     out_mk = cyclic ? 0 : (int64_t)mk;
+    out_cyclic = cyclic;
 }
 
 }  // namespace sf
