@@ -798,6 +798,7 @@ static int build_list_model(sf_ctx* ctx, int d) {
             soff[i + 1] = (uint32_t)sval.size();
         }
         pm.const_penalty = invalid;
+        pm.n_edges = (int32_t)sval.size();
         {  // fixed predecessors (incremental trial refresh)
             for (int i = 0; i < n; ++i) poff[(size_t)i + 1] = poff[(size_t)i] + (uint32_t)indeg[(size_t)i];
             pval.resize(sval.size());
@@ -2255,7 +2256,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     int wpb = 1;
     size_t best_resident = 0;
     for (int w = 1; w <= 4; ++w) {
-        const size_t per_wg = cv.total * w + 1024;  // + the static annealing state
+        const size_t per_wg = cv.total * w + 1024 + (PREC ? (size_t)gl.prec_static : 0);  // + the static annealing state, the shared copy of the precedence graph
         if (per_wg > 160 * 1024) break;
         size_t groups = (160 * 1024) / per_wg;
         if (groups * w > max_waves) groups = max_waves / w;
@@ -2266,7 +2267,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     }
     SearchParams q = p;
     q.n_launch = n_replicas;
-    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : (prec_occ ? 2 : 0), make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb, &gl))));
+    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : (prec_occ ? 2 : 0), make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb + (PREC ? (size_t)gl.prec_static : 0), &gl))));
     return SF_OK;
 }
 static bool has_plain_list_leaves(sf_ctx* ctx) {
@@ -2445,6 +2446,13 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             if (T != 2 && T != 4 && T != 8 && T != 16) T = 0;
             while (T > 1 && pgrp_bytes(gl.prec.n, T) > 40 * 1024) T >>= 1;
             gl.prec_groups = T > 1 ? T : 0;
+        }
+        // the constraint's static graph (durations, fixed successors / predecessors, in-degrees, owners) once per workgroup in LDS: every Kahn
+        // round reads it behind a dependent LDS access (SF_AMD_PREC_STATIC_HBM = leave it in HBM / L1)
+        gl.prec_static = 0;
+        if (gl.prec.on && gl.prec_lds && std::getenv("SF_AMD_PREC_STATIC_HBM") == nullptr) {
+            const size_t b = prec_static_bytes(gl.prec.n, gl.prec.n_edges, gl.prec.owner != nullptr);
+            if (b <= 12 * 1024) gl.prec_static = (int32_t)b;
         }
         gl.prec_sweep = (gl.prec.on && !gl.prec_lds && !gl.prec_inc && std::getenv("SF_AMD_PREC_NO_SWEEP") == nullptr) ? 1 : 0;
         if (gl.plf.on) gl.prec_inc = gl.prec_sweep = 0;  // the critical-path leaf re-evaluates in the main scratch arrays: one full evaluation per trial

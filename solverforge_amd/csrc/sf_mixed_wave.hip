@@ -103,6 +103,7 @@ struct GLeaves {
     int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
     int32_t prec_inc;        // HBM scratch: list change / swap trials take the incremental refresh (prec_trial_inc; opt-in, see sf_precedence.h)
     int32_t prec_sweep;      // HBM scratch: the list change / swap trials of a replay chunk are scored 64 at a time (prec_trial_sweep64)
+    int32_t prec_static;     // bytes of the workgroup-shared LDS copy of the constraint's static graph (0 = read it from HBM)
     int32_t prec_groups;     // LDS scratch: trials per wavefront of the grouped evaluator (prec_eval_grouped: 8, 4 or 2; 0 = off)
     PlfModel plf;            // critical-path precedence leaf (kind 16384; PREC instantiations, sf_prec_leaf.h)
 };
@@ -181,6 +182,11 @@ struct GCarve {
 //                 leaf's position vector holds, e = sources left
 //  3-opt (full):  a = entity rank, b / c = low / high word of the move offset
 //  3-opt (distance-pruned): a = entity rank of the NEXT entity to open (the cut state machine lives in LDS)
+// workgroup-shared LDS copy of a precedence model's static graph: dur, indeg0, [owner], succ_off, succ, pred_off, pred (32-bit words)
+__host__ __device__ inline size_t prec_static_bytes(int n, int n_edges, bool has_owner) {
+    return 4 * ((size_t)n * (has_owner ? 3 : 2) + 2 * ((size_t)n + 1) + 2 * (size_t)n_edges) + 16;
+}
+
 struct GGen {
     uint32_t a, b, c, d, e, f;
     int done;
@@ -298,6 +304,24 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0,
                         PREC && gl.prec_lds ? gl.prec_groups : 0);
     unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
+    if (PREC && gl.prec_static) {  // every wave writes the same words (no workgroup barrier: a wave may have returned above)
+        uint32_t* sh = (uint32_t*)(smem + (size_t)(blockDim.x >> 6) * cv.total);
+        const uint32_t n = (uint32_t)gl.prec.n, m = (uint32_t)gl.prec.n_edges;
+        auto take = [&](const void* src, uint32_t words) -> const void* {
+            uint32_t* dst = sh;
+            for (uint32_t t = lane; t < words; t += 64) dst[t] = ((const uint32_t*)src)[t];
+            sh += words;
+            return dst;
+        };
+        gl.prec.dur = (const int32_t*)take(gl.prec.dur, n);
+        gl.prec.indeg0 = (const int32_t*)take(gl.prec.indeg0, n);
+        if (gl.prec.owner) gl.prec.owner = (const int32_t*)take(gl.prec.owner, n);
+        gl.prec.succ_off = (const uint32_t*)take(gl.prec.succ_off, n + 1);
+        gl.prec.succ = (const uint32_t*)take(gl.prec.succ, m);
+        gl.prec.pred_off = (const uint32_t*)take(gl.prec.pred_off, n + 1);
+        gl.prec.pred = (const uint32_t*)take(gl.prec.pred, m);
+        wave_sync();
+    }
     uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
     uint8_t* ringx = SF_MIXED_RING_LDS ? (uint8_t*)(mem + cv.ringx) : gl.ringx + (size_t)r * GL * GRC;   // [leaf][GRC]
     int64_t* s_load = (int64_t*)(mem + cv.load);

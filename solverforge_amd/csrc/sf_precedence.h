@@ -28,6 +28,7 @@ struct PrecModel {
     int32_t on;  // 0 = the model has no precedence constraint
     int32_t hard_level, mk_level;
     int32_t n;                 // node_count
+    int32_t n_edges;           // valid fixed edges (entries of succ / pred)
     const int32_t* dur;        // [n]
     const uint32_t* succ_off;  // [n + 1] fixed successors (valid ones only)
     const uint32_t* succ;
