@@ -2265,6 +2265,16 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
             wpb = w;
         }
     }
+    static const bool dbg_launch = std::getenv("SF_AMD_DEBUG_LAUNCH") != nullptr;  // diagnostics: the launch shape, once per change
+    if (dbg_launch) {
+        static size_t last = 0;
+        const size_t key = cv.total * 131 + (size_t)wpb * 7 + (size_t)n_replicas + (prec_occ ? 1 : 0);
+        if (key != last) {
+            last = key;
+            std::fprintf(stderr, "[sf] generic engine launch: L=%d ruin=%d prec=%d fast=%d prec_occ=%d replicas=%d LDS/replica=%zu B (prec groups %d, static %d B) waves/workgroup=%d resident/CU=%zu\n",
+                         L, (int)RUIN, (int)PREC, (int)fast, (int)prec_occ, n_replicas, cv.total, PREC ? gl.prec_groups : 0, PREC ? gl.prec_static : 0, wpb, best_resident);
+        }
+    }
     SearchParams q = p;
     q.n_launch = n_replicas;
     HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : (prec_occ ? 2 : 0), make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb + (PREC ? (size_t)gl.prec_static : 0), &gl))));
@@ -2441,10 +2451,14 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         // grouped trial evaluator (sf_prec_group.h): T trials per wavefront with private LDS scratch.  SF_AMD_PREC_GROUPS = 0 / 2 / 4 / 8 / 16
         gl.prec_groups = 0;
         if (gl.prec.on && gl.prec_lds) {
-            int T = 0;
-            if (const char* e = std::getenv("SF_AMD_PREC_GROUPS")) T = std::atoi(e);
-            if (T != 2 && T != 4 && T != 8 && T != 16) T = 0;
-            while (T > 1 && pgrp_bytes(gl.prec.n, T) > 40 * 1024) T >>= 1;
+            // default: 8 up to 128 nodes, else the largest of 4 / 2 whose scratch stays under 12 KB per replica (4: <= 236 nodes, 2: <= 438);
+            // beyond that the LDS it takes costs more resident replicas than the pass saves (50 x 20: 34.8 -> 26.0 M moves/s with 2)
+            int T = gl.prec.n <= 128 ? 8 : (pgrp_bytes(gl.prec.n, 4) <= 12 * 1024 ? 4 : (pgrp_bytes(gl.prec.n, 2) <= 12 * 1024 ? 2 : 0));
+            if (const char* e = std::getenv("SF_AMD_PREC_GROUPS")) {
+                T = std::atoi(e);
+                if (T != 2 && T != 4 && T != 8 && T != 16) T = 0;
+                while (T > 1 && pgrp_bytes(gl.prec.n, T) > 40 * 1024) T >>= 1;
+            }
             gl.prec_groups = T > 1 ? T : 0;
         }
         // the constraint's static graph (durations, fixed successors / predecessors, in-degrees, owners) once per workgroup in LDS: every Kahn

@@ -601,6 +601,16 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         plf.ssw = gl.plf.ssw + (size_t)r * pn, plf.first = gl.plf.first + (size_t)r * pc, plf.cnl = gl.plf.cnl + (size_t)r * pn;
         plf.msrow = gl.plf.msrow + (size_t)r * (pn + 1), plf.mrrow = gl.plf.mrrow + (size_t)r * (pn + 1), plf.sE = gl.plf.sE + (size_t)r * V, plf.visit = gl.plf.visit + (size_t)r * pn;
     }
+    // the recreate's scratch rows -- tails, list predecessors, the two reachability marks, the search queue, Kahn's rounds: 24 bytes per node --
+    // borrow the grouped evaluator's trial scratch in LDS when it is there (no trial is in flight during a recreate)
+    PlfRep plf_r = plf;
+    if (plf_on && pgrp_T) {
+        const size_t pn = (size_t)gl.prec.n, a2 = (pn * 2 + 15) / 16 * 16;
+        const size_t room = pgrp_bytes((int)pn, (int)pgrp_T) - 2 * a2;
+        uint32_t* w = (uint32_t*)(mem + cv.pgrp + 2 * a2);
+        if (room >= 20 * pn) plf_r.latest = (int32_t*)w, plf_r.first = w + pn, plf_r.visit = w + 2 * pn, plf_r.flag = w + 3 * pn, plf_r.cnl = w + 4 * pn;
+        if (room >= 24 * pn + 8) plf_r.roff = w + 5 * pn;
+    }
     // full evaluation of the lists in LDS that also reports the cycle flag (and, with `roff`, Kahn's rounds)
     auto plf_eval = [&](bool& cyclic, uint32_t* roff, uint32_t* lp = nullptr) -> PrecResult {
         PrecResult pr;
@@ -656,14 +666,14 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             // the lists without the remaining elements: acyclic => every slot of every remaining element is priced from one forward
             // evaluation + one backward pass (plf_best_slot); cyclic => the element slides through the slots, one evaluation each
             bool base_cyc;
-            const PrecResult base = plf_eval(base_cyc, plf.roff, plf.first);
+            const PrecResult base = plf_eval(base_cyc, plf_r.roff, plf_r.first);
             if (gl.plf.slow) base_cyc = true;
             if (!base_cyc) {
                 const uint32_t rounds = uni(plf_info[2]);
                 if (prec_in_lds)
-                    plf_tails<PrecMemLds>(gl.prec, plf, (prec_lds_u32*)prec_Q, (prec_lds_u32*)prec_S, rounds);
+                    plf_tails<PrecMemLds>(gl.prec, plf_r, (prec_lds_u32*)prec_Q, (prec_lds_u32*)prec_S, rounds);
                 else
-                    plf_tails<PrecMemGlobal>(gl.prec, plf, prec_Q, prec_S, rounds);
+                    plf_tails<PrecMemGlobal>(gl.prec, plf_r, prec_Q, prec_S, rounds);
             }
             const int lvl_order = gl.prec.hard_level < gl.prec.mk_level ? 0 : (gl.prec.hard_level > gl.prec.mk_level ? 1 : 2);
             for (uint32_t ri = 0; ri < m.n; ++ri) {
@@ -676,10 +686,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 if (!base_cyc) {
                     PlfSlotPick pk{0, 0, 0, 0, 0};
                     if (prec_in_lds)
-                        plf_best_slot<PrecMemLds>(pk, gl.prec, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u32*)prec_S, base.penalty,
+                        plf_best_slot<PrecMemLds>(pk, gl.prec, plf_r, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u32*)prec_S, base.penalty,
                                                   (int32_t)base.makespan, x, hooks, skip_empty, lvl_order);
                     else
-                        plf_best_slot<PrecMemGlobal>(pk, gl.prec, plf, s_visits, s_off, V, prec_E, prec_S, base.penalty, (int32_t)base.makespan, x, hooks,
+                        plf_best_slot<PrecMemGlobal>(pk, gl.prec, plf_r, s_visits, s_off, V, prec_E, prec_S, base.penalty, (int32_t)base.makespan, x, hooks,
                                                      skip_empty, lvl_order);
                     if (pk.found) {
                         const ScoreV<L> sc = plf_score_of(PrecResult{pk.pen, pk.mk});
