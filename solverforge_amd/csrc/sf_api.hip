@@ -2251,7 +2251,9 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     // precedence models: the four-workgroups-per-CU build when the launch has more replicas than two workgroups per CU hold and the LDS
     // slice lets more than eight share a CU (sf_mixed_wave.hip: MODE 2)
     static const bool no_prec_occ = std::getenv("SF_AMD_PREC_NO_OCC") != nullptr;
-    const bool prec_occ = PREC && !trace && !no_prec_occ && n_replicas > 8 * 256 && (160 * 1024) / (cv.total + 256) > 8;
+    // (not with the grouped evaluator: its scratch leaves room for 8 - 10 replicas per CU, and the 128-register build is slower per wave:
+    // nine-leaf policy 20 x 10 at 6,144 replicas 71 M moves/s with it, 106 M without)
+    const bool prec_occ = PREC && !trace && !no_prec_occ && !gl.prec_groups && n_replicas > 8 * 256 && (160 * 1024) / (cv.total + 256) > 8;
     const size_t max_waves = 4 * (size_t)(fast && !RUIN ? SF_MIXED_FAST_BLOCKS_PER_CU : (prec_occ ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU));  // by register budget
     int wpb = 1;
     size_t best_resident = 0;
@@ -2448,9 +2450,16 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         // (profiles/r03f_precedence.txt): opt-in for the parity tests and further work
         gl.prec_inc = std::getenv("SF_AMD_PREC_INC") != nullptr ? 1 : 0;
         // lane-per-trial sweep (prec_trial_sweep64): the default with the scratch in HBM; SF_AMD_PREC_NO_SWEEP = one full evaluation per trial
+        // the constraint's static graph (durations, fixed successors / predecessors, in-degrees, owners) once per workgroup in LDS: every Kahn
+        // round reads it behind a dependent LDS access (SF_AMD_PREC_STATIC_HBM = leave it in HBM / L1)
+        gl.prec_static = 0;
+        if (gl.prec.on && gl.prec_lds && std::getenv("SF_AMD_PREC_STATIC_HBM") == nullptr) {
+            const size_t b = prec_static_bytes(gl.prec.n, gl.prec.n_edges, gl.prec.owner != nullptr);
+            if (b <= 16 * 1024) gl.prec_static = (int32_t)b;
+        }
         // grouped trial evaluator (sf_prec_group.h): T trials per wavefront with private LDS scratch.  SF_AMD_PREC_GROUPS = 0 / 2 / 4 / 8 / 16
         gl.prec_groups = 0;
-        if (gl.prec.on && gl.prec_lds) {
+        if (gl.prec.on && gl.prec_lds && gl.prec_static) {  // (its node records live in the shared static copy)
             // default: 8 up to 128 nodes, else the largest of 4 / 2 whose scratch stays under 12 KB per replica (4: <= 236 nodes, 2: <= 438);
             // beyond that the LDS it takes costs more resident replicas than the pass saves (50 x 20: 34.8 -> 26.0 M moves/s with 2)
             int T = gl.prec.n <= 128 ? 8 : (pgrp_bytes(gl.prec.n, 4) <= 12 * 1024 ? 4 : (pgrp_bytes(gl.prec.n, 2) <= 12 * 1024 ? 2 : 0));
@@ -2460,13 +2469,6 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                 while (T > 1 && pgrp_bytes(gl.prec.n, T) > 40 * 1024) T >>= 1;
             }
             gl.prec_groups = T > 1 ? T : 0;
-        }
-        // the constraint's static graph (durations, fixed successors / predecessors, in-degrees, owners) once per workgroup in LDS: every Kahn
-        // round reads it behind a dependent LDS access (SF_AMD_PREC_STATIC_HBM = leave it in HBM / L1)
-        gl.prec_static = 0;
-        if (gl.prec.on && gl.prec_lds && std::getenv("SF_AMD_PREC_STATIC_HBM") == nullptr) {
-            const size_t b = prec_static_bytes(gl.prec.n, gl.prec.n_edges, gl.prec.owner != nullptr);
-            if (b <= 12 * 1024) gl.prec_static = (int32_t)b;
         }
         gl.prec_sweep = (gl.prec.on && !gl.prec_lds && !gl.prec_inc && std::getenv("SF_AMD_PREC_NO_SWEEP") == nullptr) ? 1 : 0;
         if (gl.plf.on) gl.prec_inc = gl.prec_sweep = 0;  // the critical-path leaf re-evaluates in the main scratch arrays: one full evaluation per trial

@@ -184,7 +184,7 @@ struct GCarve {
 //  3-opt (distance-pruned): a = entity rank of the NEXT entity to open (the cut state machine lives in LDS)
 // workgroup-shared LDS copy of a precedence model's static graph: dur, indeg0, [owner], succ_off, succ, pred_off, pred (32-bit words)
 __host__ __device__ inline size_t prec_static_bytes(int n, int n_edges, bool has_owner) {
-    return 4 * ((size_t)n * (has_owner ? 3 : 2) + 2 * ((size_t)n + 1) + 2 * (size_t)n_edges) + 16;
+    return 4 * ((size_t)n * (has_owner ? 3 : 2) + 2 * ((size_t)n + 1) + 2 * (size_t)n_edges + 2 * (size_t)n) + 16;  // + the grouped evaluator's node records
 }
 
 struct GGen {
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0,
                         PREC && gl.prec_lds ? gl.prec_groups : 0);
     unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
+    PgrpStatic pgs{};  // the same arrays behind typed LDS pointers
     if (PREC && gl.prec_static) {  // every wave writes the same words (no workgroup barrier: a wave may have returned above)
         uint32_t* sh = (uint32_t*)(smem + (size_t)(blockDim.x >> 6) * cv.total);
         const uint32_t n = (uint32_t)gl.prec.n, m = (uint32_t)gl.prec.n_edges;
@@ -320,6 +321,15 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         gl.prec.succ = (const uint32_t*)take(gl.prec.succ, m);
         gl.prec.pred_off = (const uint32_t*)take(gl.prec.pred_off, n + 1);
         gl.prec.pred = (const uint32_t*)take(gl.prec.pred, m);
+        wave_sync();  // the records read words other lanes copied
+        for (uint32_t t = lane; t < n; t += 64) {  // node records of the grouped evaluator (sf_prec_group.h: PgrpStatic)
+            const uint32_t so = gl.prec.succ_off[t], dg = gl.prec.succ_off[t + 1] - so;
+            sh[2 * t] = (uint32_t)gl.prec.dur[t];
+            sh[2 * t + 1] = ((dg < 0xFFFFu ? dg : 0xFFFFu) << 16) | (dg ? (gl.prec.succ[so] & 0xFFFFu) : 0xFFFFu);
+        }
+        pgs.nd = (const pg_lds_u32*)sh;
+        pgs.succ_off = (const pg_lds_u32*)gl.prec.succ_off, pgs.succ = (const pg_lds_u32*)gl.prec.succ;
+        pgs.indeg0 = (const pg_lds_i32*)gl.prec.indeg0, pgs.owner = (const pg_lds_i32*)gl.prec.owner, pgs.has_owner = gl.prec.owner != nullptr ? 1u : 0u;
         wave_sync();
     }
     uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
@@ -550,12 +560,12 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         prec_mk = pr.makespan;
     }
     // grouped trial evaluator (sf_prec_group.h): T candidates of a replay chunk per pass, G = 64 / T lanes each
-    const uint32_t pgrp_T = (PREC && prec_in_lds) ? (uint32_t)gl.prec_groups : 0u;
+    const uint32_t pgrp_T = (PREC && prec_in_lds && gl.prec_static) ? (uint32_t)gl.prec_groups : 0u;
     const uint32_t pgrp_shift = pgrp_T ? (uint32_t)__builtin_ctz(64u / pgrp_T) : 6u;
     uint32_t pgrp_viol = 0;  // wrong-owner items of the committed lists
     // one pass: every lane group scores the move it holds (gm uniform inside a group, kind 0 = idle) against the committed lists
     auto pgrp_eval = [&](const PgrpMove& gm, int64_t& gp, int64_t& gmk, bool& gcyc) {
-        prec_eval_grouped<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, mem + cv.pgrp, pgrp_shift, gm,
+        prec_eval_grouped<uint16_t>(pgs, (uint32_t)gl.prec.n, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, mem + cv.pgrp, pgrp_shift, gm,
                                     gl.prec.const_penalty + (int64_t)((uint32_t)gl.prec.n - uni(s_off[V])), pgrp_viol, gp, gmk, gcyc);
     };
     // the next (up to) T candidates of `todo` -- one per lane: leaf kind and ring words -- through one pass; true on the lanes whose

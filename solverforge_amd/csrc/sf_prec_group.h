@@ -170,16 +170,29 @@ __device__ __forceinline__ uint32_t pgrp_old_flat(const PgrpMove& m, OffP off, u
     }
 }
 
+// The constraint's static graph as the grouped evaluator reads it: typed LDS pointers into the workgroup-shared copy (sf_mixed_wave.hip).
+struct PgrpStatic {
+    const pg_lds_u32* nd;        // [n][2]: duration; fixed out-degree << 16 | first fixed successor (0xFFFF = none)
+    const pg_lds_u32* succ_off;  // the further fixed successors of a node with more than one
+    const pg_lds_u32* succ;
+    const pg_lds_i32* indeg0;
+    const pg_lds_i32* owner;
+    uint32_t has_owner;          // expected-owner hook (an explicit flag: the null value of an LDS pointer is not 0)
+};
+
 // T trials side by side.  `gshift` = log2(lanes per group); lane's group g = lane >> gshift, its index inside the group lg.  `mv` is uniform
 // inside a group (kind 0 = the group idles).  Returns, uniform inside each group, the (penalty, makespan, cycle flag) of the trial.
 //   fixed_pen = const_penalty + unassigned nodes (unchanged by a list move that keeps every element), viol_c = wrong-owner items of the
 //   committed lists.
+// A Kahn round is four dependent LDS round trips: the popped node; its record, earliest start and list successor; the relaxations of the
+// first fixed successor and of the list successor (issued together); the queue writes.  Pop order is free (the result does not depend on it).
 template <class VT>
-__device__ __noinline__ void prec_eval_grouped(const PrecModel pm, const PREC_L VT* visits, const PREC_L uint32_t* off, int V, unsigned char* lds_base, uint32_t gshift,
+__device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, const PREC_L VT* visits, const PREC_L uint32_t* off, unsigned char* lds_base, uint32_t gshift,
                                                const PgrpMove mv, int64_t fixed_pen, uint32_t viol_c, int64_t& out_pen, int64_t& out_mk, bool& out_cyclic) {
-    const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)pm.n;
+    const uint32_t lane = threadIdx.x & 63u;
     const uint32_t G = 1u << gshift, lg = lane & (G - 1u), g = lane >> gshift;
     const uint64_t gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (g << gshift);  // this group's lanes
+    const uint64_t below = (1ull << lane) - 1ull;
     const PgrpLds L(lds_base, (int)n, g);
     const bool active = mv.kind != 0;
     // ---- the trial's list edges and in-degrees: the committed ones, then the lists the move touches through its position map ----
@@ -214,22 +227,22 @@ __device__ __noinline__ void prec_eval_grouped(const PrecModel pm, const PREC_L 
                 const uint32_t x = (uint32_t)visits[pgrp_old_flat(mv, off, e, k, la, lb)];
                 const uint32_t nx = k + 1 < len ? (uint32_t)visits[pgrp_old_flat(mv, off, e, k + 1, la, lb)] : PG_NONE16;
                 L.S[x] = (uint16_t)nx;
-                L.D[x] = pm.indeg0[x] + (k > 0 ? 1 : 0);
-                if (pm.owner) {
-                    const int32_t o = pm.owner[x];
+                L.D[x] = ps.indeg0[x] + (k > 0 ? 1 : 0);
+                if (ps.has_owner) {
+                    const int32_t o = ps.owner[x];
                     dviol += (o >= 0 && (uint32_t)o != e) ? 1 : 0;
                 }
             }
-            if (pm.owner) {  // minus what the committed list e contributed
+            if (ps.has_owner) {  // minus what the committed list e contributed
                 const uint32_t oe = off[e], le = off[e + 1] - oe;
                 for (uint32_t k = lg; k < le; k += G) {
-                    const int32_t o = pm.owner[(uint32_t)visits[oe + k]];
+                    const int32_t o = ps.owner[(uint32_t)visits[oe + k]];
                     dviol -= (o >= 0 && (uint32_t)o != e) ? 1 : 0;
                 }
             }
         }
     }
-    if (pm.owner) {  // group sum of dviol (xor butterfly stays inside the group for offsets < G)
+    if (ps.has_owner) {  // group sum of dviol (xor butterfly stays inside the group for offsets < G)
         for (uint32_t o = G >> 1; o; o >>= 1) dviol += __shfl_xor(dviol, (int)o);
     }
     prec_sync();
@@ -239,7 +252,7 @@ __device__ __noinline__ void prec_eval_grouped(const PrecModel pm, const PREC_L 
         const uint32_t v = b0 + lg;
         const bool ready = active && v < n && L.D[v] == 0;
         const uint64_t m = __ballot(ready) & gmask;
-        if (ready) L.Q[tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)v;
+        if (ready) L.Q[tail + (uint32_t)__popcll(m & below)] = (uint16_t)v;
         tail += (uint32_t)__popcll(m);
     }
     prec_sync();
@@ -248,30 +261,47 @@ __device__ __noinline__ void prec_eval_grouped(const PrecModel pm, const PREC_L 
         const uint32_t cnt = tail - head < G ? tail - head : G;
         const bool act = lg < cnt;
         int32_t fin = 0;
-        uint32_t so = 0, deg = 0, ls = PG_NONE16;
+        uint32_t node = 0, deg = 0, s1 = PG_NONE16, s2 = PG_NONE16;
         if (act) {
-            const uint32_t node = (uint32_t)L.Q[head + lg];
-            fin = L.E[node] + pm.dur[node];
+            node = (uint32_t)L.Q[head + lg];
+            const uint32_t r0 = ps.nd[2 * node], r1 = ps.nd[2 * node + 1];
+            fin = L.E[node] + (int32_t)r0;
+            s2 = (uint32_t)L.S[node];
             mk = fin > mk ? fin : mk;
-            so = pm.succ_off[node];
-            deg = pm.succ_off[node + 1] - so;
-            ls = (uint32_t)L.S[node];
+            deg = r1 >> 16;
+            s1 = r1 & 0xFFFFu;
         }
-        const uint32_t degt = deg + ((act && ls != PG_NONE16) ? 1u : 0u);
+        bool new1 = false, new2 = false;
+        if (s1 != PG_NONE16) {
+            __hip_atomic_fetch_max(L.E + s1, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            new1 = __hip_atomic_fetch_add(L.D + s1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+        }
+        if (s2 != PG_NONE16) {
+            __hip_atomic_fetch_max(L.E + s2, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            new2 = __hip_atomic_fetch_add(L.D + s2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+        }
+        const uint64_t m1 = __ballot(new1) & gmask, m2 = __ballot(new2) & gmask;
         uint32_t ntail = tail;
-        for (uint32_t k = 0;; ++k) {
-            const bool has = k < degt;
-            if (!__ballot(has)) break;
-            bool newly = false;
-            uint32_t s = 0;
-            if (has) {
-                s = k < deg ? pm.succ[so + k] : ls;
-                __hip_atomic_fetch_max(L.E + s, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                newly = __hip_atomic_fetch_add(L.D + s, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+        if (new1) L.Q[ntail + (uint32_t)__popcll(m1 & below)] = (uint16_t)s1;
+        ntail += (uint32_t)__popcll(m1);
+        if (new2) L.Q[ntail + (uint32_t)__popcll(m2 & below)] = (uint16_t)s2;
+        ntail += (uint32_t)__popcll(m2);
+        if (__ballot(deg > 1u)) {  // further fixed successors (none in a job shop)
+            const uint32_t so = deg > 1u ? ps.succ_off[node] : 0u;
+            for (uint32_t k = 1;; ++k) {
+                const bool has = k < deg;
+                if (!__ballot(has)) break;
+                bool newly = false;
+                uint32_t s = 0;
+                if (has) {
+                    s = ps.succ[so + k];
+                    __hip_atomic_fetch_max(L.E + s, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    newly = __hip_atomic_fetch_add(L.D + s, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
+                }
+                const uint64_t m = __ballot(newly) & gmask;
+                if (newly) L.Q[ntail + (uint32_t)__popcll(m & below)] = (uint16_t)s;
+                ntail += (uint32_t)__popcll(m);
             }
-            const uint64_t m = __ballot(newly) & gmask;
-            if (newly) L.Q[ntail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)s;
-            ntail += (uint32_t)__popcll(m);
         }
         head += cnt;
         tail = ntail;
