@@ -7,20 +7,27 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["lds", "hbm", "hbm_full", "hbm_incremental"])
+@pytest.fixture(autouse=True, params=["lds", "lds_one_trial", "lds_groups16", "lds_static_hbm", "hbm", "hbm_full", "hbm_incremental"])
 def scratch_mode(request, monkeypatch):
-    """Every test runs with the constraint's scratch in the replica's LDS slice (small graphs: one full evaluation per trial) and
-    forced into HBM (the layout of large graphs) three ways: the default lane-per-trial sweep of the list change / swap trials
-    (prec_trial_sweep64), one full evaluation per trial, and the opt-in wave-cooperative incremental refresh (prec_trial_inc).
-    The library reads SF_AMD_PREC_HBM / SF_AMD_PREC_NO_SWEEP / SF_AMD_PREC_INC at every launch."""
-    for k in ("SF_AMD_PREC_HBM", "SF_AMD_PREC_INC", "SF_AMD_PREC_NO_SWEEP"):
+    """Every test runs with the constraint's scratch in the replica's LDS slice -- the grouped trial evaluator at its default width
+    (sf_prec_group.h), switched off (one wave-wide evaluation per applied trial), at 16 trials per wavefront, and without the
+    workgroup-shared LDS copy of the static graph (which also switches the groups off) -- and forced into HBM (the layout of large
+    graphs) three ways: the default lane-per-trial sweep of the list change / swap trials (prec_trial_sweep64), one full evaluation
+    per trial, and the opt-in wave-cooperative incremental refresh (prec_trial_inc).  The library reads the variables at every launch."""
+    for k in ("SF_AMD_PREC_HBM", "SF_AMD_PREC_INC", "SF_AMD_PREC_NO_SWEEP", "SF_AMD_PREC_GROUPS", "SF_AMD_PREC_STATIC_HBM"):
         monkeypatch.delenv(k, raising=False)
-    if request.param != "lds":
+    if request.param.startswith("hbm"):
         monkeypatch.setenv("SF_AMD_PREC_HBM", "1")
     if request.param == "hbm_full":
         monkeypatch.setenv("SF_AMD_PREC_NO_SWEEP", "1")
     if request.param == "hbm_incremental":
         monkeypatch.setenv("SF_AMD_PREC_INC", "1")
+    if request.param == "lds_one_trial":
+        monkeypatch.setenv("SF_AMD_PREC_GROUPS", "0")
+    if request.param == "lds_groups16":
+        monkeypatch.setenv("SF_AMD_PREC_GROUPS", "16")
+    if request.param == "lds_static_hbm":
+        monkeypatch.setenv("SF_AMD_PREC_STATIC_HBM", "1")
     return request.param
 
 LEAF_BITS = {"list_change": 4, "list_swap": 8, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512}

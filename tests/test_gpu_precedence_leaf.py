@@ -22,21 +22,22 @@ def _t(moves):
     return np.stack([moves["kind"], moves["a"], moves["a_pos"], moves["b"], moves["b_pos"], moves["value"]], axis=1)
 
 
-@pytest.fixture(params=["lds", "hbm", "lds_slow_recreate", "lds_index64"])
+@pytest.fixture(params=["lds", "hbm", "lds_slow_recreate", "lds_index64", "lds_one_trial", "lds_groups2", "lds_groups16"])
 def scratch(request):
     """Kahn scratch in LDS / HBM; slow_recreate: the ruins slide every element through every slot with one evaluation each
     (SF_AMD_PLF_SLOW) instead of pricing all slots from one forward + one backward pass; index64: the multi-swap stream takes its
-    64-bit index path (selection index, ring entry, row search) whatever its length (SF_AMD_PLF_FORCE64)."""
-    if request.param == "hbm":
-        os.environ["SF_AMD_PREC_HBM"] = "1"
-    if request.param == "lds_slow_recreate":
-        os.environ["SF_AMD_PLF_SLOW"] = "1"
-    if request.param == "lds_index64":
-        os.environ["SF_AMD_PLF_FORCE64"] = "1"
+    64-bit index path (selection index, ring entry, row search) whatever its length (SF_AMD_PLF_FORCE64).  "lds" runs the grouped
+    trial evaluator at its default width (8 trials per wavefront at these sizes: replay, route-graph filter and the leaf's generator
+    score candidates through position maps, the recreate's rows borrow its LDS); one_trial switches it off (SF_AMD_PREC_GROUPS=0: every
+    trial applied, evaluated wave-wide and restored), groups2 / groups16 run 2 trials on 32 lanes each (the recreate's round offsets
+    stay in HBM) and 16 trials on 4 lanes each (several pops of a Kahn round per group)."""
+    env = {"hbm": ("SF_AMD_PREC_HBM", "1"), "lds_slow_recreate": ("SF_AMD_PLF_SLOW", "1"), "lds_index64": ("SF_AMD_PLF_FORCE64", "1"),
+           "lds_one_trial": ("SF_AMD_PREC_GROUPS", "0"), "lds_groups2": ("SF_AMD_PREC_GROUPS", "2"), "lds_groups16": ("SF_AMD_PREC_GROUPS", "16")}
+    if request.param in env:
+        os.environ[env[request.param][0]] = env[request.param][1]
     yield request.param
-    os.environ.pop("SF_AMD_PREC_HBM", None)
-    os.environ.pop("SF_AMD_PLF_SLOW", None)
-    os.environ.pop("SF_AMD_PLF_FORCE64", None)
+    for k, _ in env.values():
+        os.environ.pop(k, None)
 
 
 def _pair(oracle, p, leaves, seed, n_replicas=1, la=5, limit=25, with_owner=True):
