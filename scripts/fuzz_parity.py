@@ -1,6 +1,7 @@
 """Randomised differential run: random small instances x random policy (leaves, acceptor, forager, limits,
 selection order, engine) -> traced steps + fused steps on the GPU vs the CPU oracle.  Prints one JSON line;
-`failures` lists the seeds whose runs diverged (none expected).  Usage: fuzz_parity.py <seconds> [first_seed]"""
+`failures` lists the seeds whose runs diverged (none expected).  Usage: fuzz_parity.py <seconds> [first_seed]
+SF_FUZZ_MODEL=<family> draws every case from one model family (e.g. precedence)."""
 import json, os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -19,6 +20,7 @@ def t6(m):
 def run_case(seed):
     rng = np.random.default_rng(seed)
     model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment", "precedence", "precedence", "shift", "shift", "shift"][int(rng.integers(12))]
+    model = os.environ.get("SF_FUZZ_MODEL", model)  # a targeted run: every case of one model family
     acceptor = int(rng.choice([0, 1, 1, 3, 4]))  # 4 = DiversifiedLateAcceptance (round 3)
     dla_tol = float(rng.choice([0.0, 0.01, 0.2]))
     forager = int(rng.choice([0, 0, 1, 2, 3, 4]))
@@ -122,7 +124,11 @@ def run_case(seed):
         leaves = tuple(x for x in pool if x in chosen)
         policy = bool(rng.random() < 0.5)  # the runtime slot's precedence policy: route-graph filter + ruin hooks
         ruin = (int(rng.choice([1, 2])), int(rng.choice([2, 5, 6])), int(rng.choice([1, 3, 6])))
-        desc.update(nj=nj, nm=nm, leaves=leaves, with_owner=with_owner, policy=policy, ruin=ruin)
+        groups = str(rng.choice(["auto", "auto", "0", "2", "4", "8", "16"]))  # grouped trial evaluator (round 4): trials per wavefront, read at every launch
+        os.environ.pop("SF_AMD_PREC_GROUPS", None)
+        if groups != "auto":
+            os.environ["SF_AMD_PREC_GROUPS"] = groups
+        desc.update(nj=nj, nm=nm, leaves=leaves, with_owner=with_owner, policy=policy, ruin=ruin, groups=groups)
         d = sfa.build_precedence_shop(p, leaves=leaves, with_owner=with_owner, ruin=ruin, precedence_policy=policy)
         o = sfo.Model.precedence_shop(p["durations"], p["successors"], p["sequences"], p["expected_owner"] if with_owner else None)
         o.set_kopt(1, 0)
