@@ -85,89 +85,131 @@ struct PgrpMove {
     uint32_t el2;   // multi-swap: the third swap (list << 16 | first position); a / i and b / j are the first two
 };
 
-// Position map of a candidate: the flat index (into the committed `visits`) of the element at position k of list e AFTER the move.
+// Position map of a candidate, list by list: the list e AFTER the move is a concatenation of at most five runs of the committed flat
+// array -- [end[s-1], end[s]) of the new list reads src[s] + offset (src[s] - offset when bit s of `rev` is set; the permuted window of a
+// list permute, always run 1, reads src[1] + its nibble).  Built once per (trial, list); a position costs five compares and selects.
+struct PgrpSegs {
+    uint32_t end[5], src[5];
+    uint32_t rev, perm, is_perm;
+    uint32_t len;  // length of list e after the move
+};
 // la / lb = committed lengths of lists a / b.  e is one of the lists the move touches.
 template <class OffP>
-__device__ __forceinline__ uint32_t pgrp_old_flat(const PgrpMove& m, OffP off, uint32_t e, uint32_t k, uint32_t la, uint32_t lb) {
+__device__ __forceinline__ void pgrp_segments(const PgrpMove& m, OffP off, uint32_t e, uint32_t la, uint32_t lb, PgrpSegs& g) {
     const bool one_list = m.kind == 4 || m.kind == 7 || m.kind == 9;  // b / j carry cut positions, not a second list
     const uint32_t oa = off[m.a], ob = one_list ? oa : off[m.b];
     const uint32_t a = m.a, b = m.b, i = m.i, j = m.j;
+    uint32_t e0 = 0, e1 = 0, e2 = 0, e3 = 0, s0 = oa, s1 = 0, s2 = 0, s3 = 0, s4 = 0, len = la, rev = 0, perm = 0, is_perm = 0;
+    bool four = false;  // the fifth run is in use (else it is empty)
     switch (m.kind) {
-        case 2: {  // (a, i) -> (b, j), j in pre-removal coordinates
+        case 2:  // (a, i) -> (b, j), j in pre-removal coordinates
             if (a != b) {
-                if (e == a) return oa + (k < i ? k : k + 1);
-                return k < j ? ob + k : (k == j ? oa + i : ob + k - 1);
+                if (e == a) {
+                    len = la - 1;
+                    e0 = i, e1 = len, s1 = oa + i + 1, e2 = e3 = len;
+                } else {
+                    len = lb + 1;
+                    s0 = ob, e0 = j, e1 = j + 1, s1 = oa + i, e2 = len, s2 = ob + j, e3 = len;
+                }
+            } else {
+                const uint32_t f = j > i ? j - 1 : j;  // final position of the element
+                if (f >= i)
+                    e0 = i, e1 = f, s1 = oa + i + 1, e2 = f + 1, s2 = oa + i, e3 = la, s3 = oa + f + 1;
+                else
+                    e0 = f, e1 = f + 1, s1 = oa + i, e2 = i + 1, s2 = oa + f, e3 = la, s3 = oa + i + 1;
             }
-            const uint32_t f = j > i ? j - 1 : j;  // final position of the element
-            if (k == f) return oa + i;
-            const uint32_t q = k > f ? k - 1 : k;
-            return oa + (q >= i ? q + 1 : q);
-        }
-        case 3: {  // (a, i) <-> (b, j)
-            if (e == a && k == i) return ob + j;
-            if (e == b && k == j) return oa + i;
-            return off[e] + k;
-        }
+            break;
+        case 3:  // (a, i) <-> (b, j)
+            if (a != b) {
+                if (e == a)
+                    e0 = i, e1 = i + 1, s1 = ob + j, e2 = e3 = la, s2 = oa + i + 1;
+                else
+                    len = lb, s0 = ob, e0 = j, e1 = j + 1, s1 = oa + i, e2 = e3 = lb, s2 = ob + j + 1;
+            } else {
+                const uint32_t p = i < j ? i : j, q = i < j ? j : i;
+                e0 = p, e1 = p + 1, s1 = oa + q, e2 = q, s2 = oa + p + 1, e3 = q + 1, s3 = oa + p, s4 = oa + q + 1, four = true;
+            }
+            break;
         case 4:  // reverse [i, j) of a
-            return oa + ((k >= i && k < j) ? i + j - 1 - k : k);
+            e0 = i, e1 = j, s1 = oa + j - 1, rev = 2u, e2 = e3 = la, s2 = oa + j;
+            break;
         case 5: {  // [i, ext) of a -> b at j (intra: j in post-removal coordinates)
             const uint32_t z = m.ext - i;
             if (a != b) {
-                if (e == a) return oa + (k < i ? k : k + z);
-                return k < j ? ob + k : (k < j + z ? oa + i + (k - j) : ob + k - z);
-            }
-            if (k >= j && k < j + z) return oa + i + (k - j);
-            const uint32_t q = k >= j + z ? k - z : k;
-            return oa + (q >= i ? q + z : q);
+                if (e == a) {
+                    len = la - z;
+                    e0 = i, e1 = e2 = e3 = len, s1 = oa + i + z;
+                } else {
+                    len = lb + z;
+                    s0 = ob, e0 = j, e1 = j + z, s1 = oa + i, e2 = e3 = len, s2 = ob + j;
+                }
+            } else if (j <= i)
+                e0 = j, e1 = j + z, s1 = oa + i, e2 = i + z, s2 = oa + j, e3 = la, s3 = oa + i + z;
+            else
+                e0 = i, e1 = j, s1 = oa + i + z, e2 = j + z, s2 = oa + i, e3 = la, s3 = oa + j + z;
+            break;
         }
         case 6: {  // [i, i + za) of a <-> [j, j + zb) of b
             const uint32_t za = m.ext & 0xFFFFu, zb = m.ext >> 16;
             if (a != b) {
-                if (e == a) return k < i ? oa + k : (k < i + zb ? ob + j + (k - i) : oa + k - zb + za);
-                return k < j ? ob + k : (k < j + za ? oa + i + (k - j) : ob + k - za + zb);
+                if (e == a) {
+                    len = la - za + zb;
+                    e0 = i, e1 = i + zb, s1 = ob + j, e2 = e3 = len, s2 = oa + i + za;
+                } else {
+                    len = lb - zb + za;
+                    s0 = ob, e0 = j, e1 = j + za, s1 = oa + i, e2 = e3 = len, s2 = ob + j + zb;
+                }
+            } else {  // one list: X = the earlier segment, Y = the later one; new layout from x0: Y, the elements between them, X
+                const bool a_first = i < j;
+                const uint32_t x0 = a_first ? i : j, zx = a_first ? za : zb, y0 = a_first ? j : i, zy = a_first ? zb : za;
+                const uint32_t mid = y0 - (x0 + zx);
+                e0 = x0, e1 = x0 + zy, s1 = oa + y0, e2 = x0 + zy + mid, s2 = oa + x0 + zx, e3 = y0 + zy, s3 = oa + x0, s4 = oa + y0 + zy, four = true;
             }
-            // one list: X = the earlier segment, Y = the later one; new layout from x0: Y, the elements between them, X
-            const bool a_first = i < j;
-            const uint32_t x0 = a_first ? i : j, zx = a_first ? za : zb, y0 = a_first ? j : i, zy = a_first ? zb : za;
-            const uint32_t mid = y0 - (x0 + zx);
-            if (k < x0 || k >= y0 + zy) return oa + k;
-            if (k < x0 + zy) return oa + y0 + (k - x0);
-            if (k < x0 + zy + mid) return oa + x0 + zx + (k - x0 - zy);
-            return oa + x0 + (k - x0 - zy - mid);
+            break;
         }
         case 7: {  // 3-opt of list a: cuts c1 = i < c2 = b < c3 = j, pattern ext
             const uint32_t c1 = i, c2 = m.b, c3 = j;
             const uint32_t mask = kopt_reverse_mask(m.ext);
             const bool rb = (mask >> 1) & 1u, rc = (mask >> 2) & 1u;
-            if (k < c1 || k >= c3) return oa + k;
+            e0 = c1, e2 = c3, e3 = la, s3 = oa + c3;
             if (!kopt_swaps_segments(m.ext)) {
-                if (k < c2) return oa + (rb ? c1 + c2 - 1 - k : k);
-                return oa + (rc ? c2 + c3 - 1 - k : k);
+                e1 = c2;
+                s1 = rb ? oa + c2 - 1 : oa + c1, s2 = rc ? oa + c3 - 1 : oa + c2;
+                rev = (rb ? 2u : 0u) | (rc ? 4u : 0u);
+            } else {  // the second segment comes first
+                e1 = c1 + (c3 - c2);
+                s1 = rc ? oa + c3 - 1 : oa + c2, s2 = rb ? oa + c2 - 1 : oa + c1;
+                rev = (rc ? 2u : 0u) | (rb ? 4u : 0u);
             }
-            const uint32_t zc = c3 - c2;
-            if (k < c1 + zc) {  // the second segment comes first
-                const uint32_t t = k - c1;
-                return oa + (rc ? c3 - 1 - t : c2 + t);
-            }
-            const uint32_t t = k - c1 - zc;
-            return oa + (rb ? c2 - 1 - t : c1 + t);
+            break;
         }
-        case 9: {  // window [i, j) of a permuted by the ext-th permutation
-            if (k < i || k >= j) return oa + k;
-            const uint32_t perm = nth_permutation_nibbles(j - i, m.ext);
-            return oa + i + ((perm >> (4u * (k - i))) & 15u);
-        }
+        case 9:  // window [i, j) of a permuted by the ext-th permutation
+            e0 = i, e1 = j, s1 = oa + i, perm = nth_permutation_nibbles(j - i, m.ext), is_perm = 1u, e2 = e3 = la, s2 = oa + j;
+            break;
         default: {  // 10: three adjacent swaps in three different lists
-            uint32_t p;
-            if (e == a)
-                p = i;
-            else if (e == b)
-                p = j;
-            else
-                p = m.el2 & 0xFFFFu;
-            return off[e] + (k == p ? p + 1 : (k == p + 1 ? p : k));
+            const uint32_t p = e == a ? i : (e == b ? j : (m.el2 & 0xFFFFu));
+            const uint32_t oe = off[e];
+            len = off[e + 1] - oe;
+            s0 = oe, e0 = p, e1 = p + 1, s1 = oe + p + 1, e2 = p + 2, s2 = oe + p, e3 = len, s3 = oe + p + 2;
+            break;
         }
     }
+    g.end[0] = e0, g.end[1] = e1, g.end[2] = e2, g.end[3] = e3, g.end[4] = four ? len : e3;
+    g.src[0] = s0, g.src[1] = s1, g.src[2] = s2, g.src[3] = s3, g.src[4] = s4;
+    g.rev = rev, g.perm = perm, g.is_perm = is_perm, g.len = four ? len : e3;
+}
+// flat index (into the committed `visits`) of the element at position k of the list after the move
+__device__ __forceinline__ uint32_t pgrp_seg_src(const PgrpSegs& g, uint32_t k) {
+    uint32_t start = 0, res = 0;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const uint32_t o = k - start;
+        uint32_t v = ((g.rev >> s) & 1u) ? g.src[s] - o : g.src[s] + o;
+        if (s == 1) v = g.is_perm ? g.src[1] + ((g.perm >> (4u * (o & 7u))) & 15u) : v;
+        res = (k >= start && k < g.end[s]) ? v : res;
+        start = g.end[s];
+    }
+    return res;
 }
 
 // The constraint's static graph as the grouped evaluator reads it: typed LDS pointers into the workgroup-shared copy (sf_mixed_wave.hip).
@@ -204,30 +246,20 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
         }
     prec_sync();
     int32_t dviol = 0;
-    if (active) {
+    uint32_t nl = 0, len0 = 0, len1 = 0, len2 = 0;  // the lists the move touches and their lengths afterwards
+    if (active) {  // phase A: the touched lists in their new order, one after the other in the (still unused) queue array
         const bool one_list = mv.kind == 4 || mv.kind == 7 || mv.kind == 9;
         const uint32_t la = off[mv.a + 1] - off[mv.a], lb = one_list ? la : off[mv.b + 1] - off[mv.b];
         const uint32_t e3 = mv.el2 >> 16;
-        const uint32_t nl = mv.kind == 10 ? 3u : ((mv.kind == 2 || mv.kind == 3 || mv.kind == 5 || mv.kind == 6) && mv.a != mv.b ? 2u : 1u);
+        nl = mv.kind == 10 ? 3u : ((mv.kind == 2 || mv.kind == 3 || mv.kind == 5 || mv.kind == 6) && mv.a != mv.b ? 2u : 1u);
+        uint32_t base = 0;
         for (uint32_t li = 0; li < nl; ++li) {
             const uint32_t e = li == 0 ? mv.a : (li == 1 ? mv.b : e3);
-            uint32_t len = off[e + 1] - off[e];  // new length of list e
-            if (mv.a != mv.b) {
-                if (mv.kind == 2) len = e == mv.a ? la - 1 : lb + 1;
-                if (mv.kind == 5) {
-                    const uint32_t z = mv.ext - mv.i;
-                    len = e == mv.a ? la - z : lb + z;
-                }
-                if (mv.kind == 6) {
-                    const uint32_t za = mv.ext & 0xFFFFu, zb = mv.ext >> 16;
-                    len = e == mv.a ? la - za + zb : lb - zb + za;
-                }
-            }
-            for (uint32_t k = lg; k < len; k += G) {
-                const uint32_t x = (uint32_t)visits[pgrp_old_flat(mv, off, e, k, la, lb)];
-                const uint32_t nx = k + 1 < len ? (uint32_t)visits[pgrp_old_flat(mv, off, e, k + 1, la, lb)] : PG_NONE16;
-                L.S[x] = (uint16_t)nx;
-                L.D[x] = ps.indeg0[x] + (k > 0 ? 1 : 0);
+            PgrpSegs sg;
+            pgrp_segments(mv, off, e, la, lb, sg);
+            for (uint32_t k = lg; k < sg.len; k += G) {
+                const uint32_t x = (uint32_t)visits[pgrp_seg_src(sg, k)];
+                L.Q[base + k] = (uint16_t)x;
                 if (ps.has_owner) {
                     const int32_t o = ps.owner[x];
                     dviol += (o >= 0 && (uint32_t)o != e) ? 1 : 0;
@@ -240,6 +272,22 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
                     dviol -= (o >= 0 && (uint32_t)o != e) ? 1 : 0;
                 }
             }
+            len0 = li == 0 ? sg.len : len0, len1 = li == 1 ? sg.len : len1, len2 = li == 2 ? sg.len : len2;
+            base += sg.len;
+        }
+    }
+    prec_sync();
+    if (active) {  // phase B: list successor and in-degree of every node of those lists
+        uint32_t base = 0;
+        for (uint32_t li = 0; li < nl; ++li) {
+            const uint32_t len = li == 0 ? len0 : (li == 1 ? len1 : len2);
+            for (uint32_t k = lg; k < len; k += G) {
+                const uint32_t x = (uint32_t)L.Q[base + k];
+                const uint32_t nx = k + 1 < len ? (uint32_t)L.Q[base + k + 1] : PG_NONE16;
+                L.S[x] = (uint16_t)nx;
+                L.D[x] = ps.indeg0[x] + (k > 0 ? 1 : 0);
+            }
+            base += len;
         }
     }
     if (ps.has_owner) {  // group sum of dviol (xor butterfly stays inside the group for offsets < G)
