@@ -15,7 +15,7 @@ d = sfa.build_precedence_shop(p, n_replicas=R, leaves=leaves, precedence_policy=
 d.configure_default(random_seed=0)
 d.calculate_score(); d.phase_start()
 L = _lib.load()
-phases = getattr(L, "sf_debug_phases_mixed_2_2_1_1")
+phases = getattr(L, "sf_debug_phases_mixed_2_2_1_1")  # a -DSF_PHASE_PROFILE -DSF_PHASE_PREC build re-labels the slots: 0 rest, 1 critical-path leaf, 2 permute + change + swap, 3 reverse, 4 recreate: forward evaluation, 5 tails + closure, 6 slot pricing, 7 list edits + the ruin leaf's bookkeeping
 out = np.zeros(8, dtype=np.uint64)
 for it in range(3):
     b = d.total_stats()

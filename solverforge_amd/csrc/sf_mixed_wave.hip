@@ -182,6 +182,13 @@ struct GCarve {
 //                 leaf's position vector holds, e = sources left
 //  3-opt (full):  a = entity rank, b / c = low / high word of the move offset
 //  3-opt (distance-pruned): a = entity rank of the NEXT entity to open (the cut state machine lives in LDS)
+#ifdef SF_PHASE_PREC
+#define PHS(i) PH(0)
+#define PHR(i) PH(i)
+#else
+#define PHS(i) PH(i)
+#define PHR(i)
+#endif
 // workgroup-shared LDS copy of a precedence model's static graph: dur, indeg0, [owner], succ_off, succ, pred_off, pred (32-bit words)
 __host__ __device__ inline size_t prec_static_bytes(int n, int n_edges, bool has_owner) {
     return 4 * ((size_t)n * (has_owner ? 3 : 2) + 2 * ((size_t)n + 1) + 2 * (size_t)n_edges + 2 * (size_t)n) + 16;  // + the grouped evaluator's node records
@@ -304,6 +311,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0,
                         PREC && gl.prec_lds ? gl.prec_groups : 0);
     unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
+    PH_DECL
     PgrpStatic pgs{};  // the same arrays behind typed LDS pointers
     if (PREC && gl.prec_static) {  // every wave writes the same words (no workgroup barrier: a wave may have returned above)
         uint32_t* sh = (uint32_t*)(smem + (size_t)(blockDim.x >> 6) * cv.total);
@@ -676,7 +684,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             // the lists without the remaining elements: acyclic => every slot of every remaining element is priced from one forward
             // evaluation + one backward pass (plf_best_slot); cyclic => the element slides through the slots, one evaluation each
             bool base_cyc;
+            PHR(7)
             const PrecResult base = plf_eval(base_cyc, plf_r.roff, plf_r.first);
+            PHR(4)
             if (gl.plf.slow) base_cyc = true;
             if (!base_cyc) {
                 const uint32_t rounds = uni(plf_info[2]);
@@ -685,6 +695,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 else
                     plf_tails<PrecMemGlobal>(gl.prec, plf_r, prec_Q, prec_S, rounds);
             }
+            PHR(5)
             const int lvl_order = gl.prec.hard_level < gl.prec.mk_level ? 0 : (gl.prec.hard_level > gl.prec.mk_level ? 1 : 2);
             for (uint32_t ri = 0; ri < m.n; ++ri) {
                 if (!((remaining >> ri) & 1u)) continue;
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     else
                         plf_best_slot<PrecMemGlobal>(pk, gl.prec, plf_r, s_visits, s_off, V, prec_E, prec_S, base.penalty, (int32_t)base.makespan, x, hooks,
                                                      skip_empty, lvl_order);
+                    PHR(6)
                     if (pk.found) {
                         const ScoreV<L> sc = plf_score_of(PrecResult{pk.pen, pk.mk});
                         if (!have || score_cmp<L>(sc, best_sc) > 0) {
@@ -870,7 +882,6 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const uint64_t seed_draws0 = dry_run ? 0 : p.seed_draws[r];
     const int la_idx0 = dry_run ? 0 : p.la_idx[r];
     int la_cursor = la_idx0;  // (la_idx0 + step) % la_size, kept incrementally (no 64-bit division per step)
-    PH_DECL
     bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
     const FastMod fm_V = make_fastmod(V > 0 ? (uint32_t)V : 1u);  // Barrett remainder by the owner count: no 64-bit division per entity rank
     const FastMod fm_V1 = make_fastmod(V > 1 ? (uint32_t)V - 1u : 1u);
@@ -1108,7 +1119,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         for (uint32_t pos = 0; pos < (uint32_t)nl; ++pos) u_order |= (uint64_t)((u_off + pos * u_str) % (uint32_t)nl) << (4u * pos);
         u_order = uni64(u_order);
 
-        PH(0)
+        PHS(0)
         int done = 0;
         while (!done) {
             // ---- C1: fill every live leaf's ring (or until its stream ends).  A replay batch takes 64 pulls in whole
@@ -1954,7 +1965,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 }
                 lt.put_gen(l, g);
                 lt.set(l, LeafTab::TAIL, tl);
-#ifdef SF_PHASE_PROFILE
+#ifdef SF_PHASE_PREC  // precedence breakdown: 1 critical-path leaf, 2 permute / change / swap, 3 reverse, 4-7 inside the recreate (PHR), 0 the rest
+                PH(kind == 16384 ? 1 : ((kind == 8192 || kind == 4 || kind == 8) ? 2 : (kind == 64 ? 3 : (kind == 1024 ? 7 : 0))))
+#elif defined(SF_PHASE_PROFILE)
                 PH((kind == 128 || kind == 256) ? 2 : ((kind == 64 || kind == 1024) ? 3 : (kind == 512 ? 4 : 1)))
 #endif
             }
@@ -2124,7 +2137,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 }
             }
 
-            PH(5)
+            PHS(5)
             // ---- C3: trial score, acceptor, forager ----
             {
                 const bool valid = lane < nvalid;
@@ -2416,7 +2429,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 for (int l = 0; l < nl; ++l) lt.set(l, LeafTab::HEAD, lt.get(l, LeafTab::HEAD) + lt.get(l, LeafTab::TAKEN));
                 if (forager_quits(forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) done = 1;
             }
-            PH(6)
+            PHS(6)
         }
 
         // ---- commit the forager's pick ----
@@ -2594,7 +2607,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             st_steps += 1;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
         }
-        PH(7)
+        PHS(7)
         if (!dry_run && p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves
         if (!dry_run && p.move_budget == 0 && st_scored >= 0x70000000u) flush_stats();
     }
