@@ -2,7 +2,7 @@
 configuration: replica count x elite migration (sf_portfolio_migrate_local: every `period` seconds the worst `frac` of the replicas adopt
 the best solutions of the top `elite` replicas).  The CPU leg of the same workload is bench.py's / scripts/solve60.py's.
 usage: m2_sweep.py seconds policy "R[:period:frac:elite[:la_size:accepted_count_limit]],R,..." [budget]
-  policy = default (seven leaves), default6 (without ruin), nearby2"""
+  policy = default (seven leaves), default6 (without ruin), nearby2, nearby2_ruin, nearby2_kopt_ruin"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import solverforge_amd as sfa
@@ -10,7 +10,9 @@ from solverforge_amd import datasets
 
 POL = {"default": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt", "ruin"),
        "default6": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"),
-       "nearby2": ("nearby_change", "nearby_swap")}
+       "nearby2": ("nearby_change", "nearby_swap"),
+       "nearby2_ruin": ("nearby_change", "nearby_swap", "ruin"),
+       "nearby2_kopt_ruin": ("nearby_change", "nearby_swap", "kopt", "ruin")}
 seconds = float(sys.argv[1])
 policy = sys.argv[2]
 configs = sys.argv[3].split(",")
@@ -27,6 +29,8 @@ for cfg in configs:
     limit = int(f[5]) if len(f) > 5 else 256
     d = sfa.build_cvrp(p, n_replicas=R, leaves=POL[policy])
     d.configure(sfa.SolverConfig(random_seed=0, late_acceptance_size=la, accepted_count_limit=limit))
+    if os.environ.get("SF_M2_ENGINE") == "block":  # one workgroup per replica instead of one wavefront (per-chain latency experiment)
+        d.set_engine(sfa.Engine.BLOCK)
     d.calculate_score()
     t0 = time.perf_counter()
     d.construct_list_clarke_wright(0, p["customers"], 1)
