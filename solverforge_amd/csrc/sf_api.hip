@@ -819,6 +819,18 @@ static int build_list_model(sf_ctx* ctx, int d) {
         pm.succ = d_sval;
         pm.indeg0 = d_indeg;
         pm.owner = ps.has_owner ? d_owner : nullptr;
+        {  // node records of the Kahn rounds (prec_eval / prec_eval_grouped): one 8-byte load instead of three dependent ones
+            if (n >= 0xFFFFFF) return fail(ctx, SF_ERR_UNSUPPORTED, "list precedence: node ids are 24 bits in the node records");
+            std::vector<uint32_t> nd((size_t)n * 2);
+            for (int i = 0; i < n; ++i) {
+                const uint32_t dg = soff[(size_t)i + 1] - soff[(size_t)i];
+                nd[(size_t)i * 2] = (uint32_t)ps.dur[(size_t)i];
+                nd[(size_t)i * 2 + 1] = ((dg < 255u ? dg : 255u) << 24) | (dg ? sval[soff[(size_t)i]] : 0xFFFFFFu);
+            }
+            uint32_t* d_nd = nullptr;
+            if ((rc = upload(ctx, &d_nd, nd.data(), nd.size()))) return rc;
+            pm.nd = d_nd;
+        }
         const size_t words = (size_t)R * (n ? n : 1);
         if ((rc = dalloc(ctx, &pm.earliest, words))) return rc;
         if ((rc = dalloc(ctx, &pm.indeg, words))) return rc;

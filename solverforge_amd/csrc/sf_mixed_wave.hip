@@ -329,13 +329,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         gl.prec.succ = (const uint32_t*)take(gl.prec.succ, m);
         gl.prec.pred_off = (const uint32_t*)take(gl.prec.pred_off, n + 1);
         gl.prec.pred = (const uint32_t*)take(gl.prec.pred, m);
-        wave_sync();  // the records read words other lanes copied
-        for (uint32_t t = lane; t < n; t += 64) {  // node records of the grouped evaluator (sf_prec_group.h: PgrpStatic)
-            const uint32_t so = gl.prec.succ_off[t], dg = gl.prec.succ_off[t + 1] - so;
-            sh[2 * t] = (uint32_t)gl.prec.dur[t];
-            sh[2 * t + 1] = ((dg < 0xFFFFu ? dg : 0xFFFFu) << 16) | (dg ? (gl.prec.succ[so] & 0xFFFFu) : 0xFFFFu);
-        }
-        pgs.nd = (const pg_lds_u32*)sh;
+        gl.prec.nd = (const uint32_t*)take(gl.prec.nd, 2 * n);
+        pgs.nd = (const pg_lds_u32*)gl.prec.nd;
         pgs.succ_off = (const pg_lds_u32*)gl.prec.succ_off, pgs.succ = (const pg_lds_u32*)gl.prec.succ;
         pgs.indeg0 = (const pg_lds_i32*)gl.prec.indeg0, pgs.owner = (const pg_lds_i32*)gl.prec.owner, pgs.has_owner = gl.prec.owner != nullptr ? 1u : 0u;
         wave_sync();

@@ -214,7 +214,7 @@ __device__ __forceinline__ uint32_t pgrp_seg_src(const PgrpSegs& g, uint32_t k) 
 
 // The constraint's static graph as the grouped evaluator reads it: typed LDS pointers into the workgroup-shared copy (sf_mixed_wave.hip).
 struct PgrpStatic {
-    const pg_lds_u32* nd;        // [n][2]: duration; fixed out-degree << 16 | first fixed successor (0xFFFF = none)
+    const pg_lds_u32* nd;        // [n][2]: duration; min(fixed out-degree, 255) << 24 | first fixed successor (0xFFFFFF = none) -- PrecModel::nd
     const pg_lds_u32* succ_off;  // the further fixed successors of a node with more than one
     const pg_lds_u32* succ;
     const pg_lds_i32* indeg0;
@@ -316,8 +316,8 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
             fin = L.E[node] + (int32_t)r0;
             s2 = (uint32_t)L.S[node];
             mk = fin > mk ? fin : mk;
-            deg = r1 >> 16;
-            s1 = r1 & 0xFFFFu;
+            deg = r1 >> 24;
+            s1 = (r1 & 0xFFFFFFu) == 0xFFFFFFu ? PG_NONE16 : (r1 & 0xFFFFFFu);
         }
         bool new1 = false, new2 = false;
         if (s1 != PG_NONE16) {
@@ -335,7 +335,11 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
         if (new2) L.Q[ntail + (uint32_t)__popcll(m2 & below)] = (uint16_t)s2;
         ntail += (uint32_t)__popcll(m2);
         if (__ballot(deg > 1u)) {  // further fixed successors (none in a job shop)
-            const uint32_t so = deg > 1u ? ps.succ_off[node] : 0u;
+            uint32_t so = 0;
+            if (deg > 1u) {
+                so = ps.succ_off[node];
+                deg = ps.succ_off[node + 1] - so;  // (the record saturates at 255)
+            }
             for (uint32_t k = 1;; ++k) {
                 const bool has = k < deg;
                 if (!__ballot(has)) break;

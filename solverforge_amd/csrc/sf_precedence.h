@@ -34,6 +34,7 @@ struct PrecModel {
     const uint32_t* succ;
     const int32_t* indeg0;     // [n] fixed in-degree
     const int32_t* owner;      // [n] expected owner, -1 = none; nullptr = no expected-owner hook
+    const uint32_t* nd;        // [n][2] node records: duration; min(out-degree, 255) << 24 | first fixed successor (0xFFFFFF = none)
     int64_t const_penalty;     // invalid fixed edges (successor >= node_count)
     // per-replica scratch in HBM, [R][n] each
     int32_t* earliest;
@@ -149,35 +150,59 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
     prec_sync();
     int32_t mk = 0;
     uint32_t rounds = 0;
+    // A round: the popped node; its record (duration, out-degree, first fixed successor: two independent loads), earliest start and list successor;
+    // the relaxations of that successor and of the list successor; the queue writes.  Further fixed successors (none in a job shop) loop.
     while (head < tail) {
         const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
         if (ROFF && lane == 0) ROFF[rounds] = head;
         rounds += 1;
         const bool act = lane < cnt;
         int32_t fin = 0;
-        uint32_t so = 0, deg = 0, ls = PREC_NONE;
+        uint32_t node = 0, deg = 0, s1 = PREC_NONE, ls = PREC_NONE;
         if (act) {
-            const uint32_t node = MEM::ld(Q + head + lane);
-            fin = MEM::ld(E + node) + pm.dur[node];
+            node = MEM::ld(Q + head + lane);
+            uint2 rec;  // (two loads: the LDS copy of the records is only 4-byte aligned)
+            rec.x = pm.nd[2 * (size_t)node], rec.y = pm.nd[2 * (size_t)node + 1];
+            fin = MEM::ld(E + node) + (int32_t)rec.x;
             mk = fin > mk ? fin : mk;
-            so = pm.succ_off[node];
-            deg = pm.succ_off[node + 1] - so;
+            deg = rec.y >> 24;
+            s1 = (rec.y & 0xFFFFFFu) == 0xFFFFFFu ? PREC_NONE : (rec.y & 0xFFFFFFu);
             ls = MEM::ld(S + node);
         }
-        const uint32_t degt = deg + ((act && ls != PREC_NONE) ? 1u : 0u);
-        for (uint32_t k = 0;; ++k) {
-            const bool has = k < degt;
-            if (!__ballot(has)) break;
-            bool newly = false;
-            uint32_t s = 0;
-            if (has) {
-                s = k < deg ? pm.succ[so + k] : ls;
-                MEM::fmax(E + s, fin);
-                newly = MEM::fadd(D + s, -1) == 1;
+        bool new1 = false, new2 = false;
+        if (s1 != PREC_NONE) {
+            MEM::fmax(E + s1, fin);
+            new1 = MEM::fadd(D + s1, -1) == 1;
+        }
+        if (ls != PREC_NONE) {
+            MEM::fmax(E + ls, fin);
+            new2 = MEM::fadd(D + ls, -1) == 1;
+        }
+        const uint64_t m1 = __ballot(new1), m2 = __ballot(new2);
+        if (new1) MEM::st(Q + tail + prec_mbcnt(m1), s1);
+        tail += (uint32_t)__popcll(m1);
+        if (new2) MEM::st(Q + tail + prec_mbcnt(m2), ls);
+        tail += (uint32_t)__popcll(m2);
+        if (__ballot(deg > 1u)) {
+            uint32_t so = 0;
+            if (deg > 1u) {
+                so = pm.succ_off[node];
+                deg = pm.succ_off[node + 1] - so;  // (the record saturates at 255)
             }
-            const uint64_t m = __ballot(newly);
-            if (newly) MEM::st(Q + tail + prec_mbcnt(m), s);
-            tail += (uint32_t)__popcll(m);
+            for (uint32_t k = 1;; ++k) {
+                const bool has = k < deg;
+                if (!__ballot(has)) break;
+                bool newly = false;
+                uint32_t s = 0;
+                if (has) {
+                    s = pm.succ[so + k];
+                    MEM::fmax(E + s, fin);
+                    newly = MEM::fadd(D + s, -1) == 1;
+                }
+                const uint64_t m = __ballot(newly);
+                if (newly) MEM::st(Q + tail + prec_mbcnt(m), s);
+                tail += (uint32_t)__popcll(m);
+            }
         }
         head += cnt;
         prec_sync();

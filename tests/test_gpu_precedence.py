@@ -101,6 +101,47 @@ def test_full_scores_and_evaluate_each(oracle, jobs, machines, seed, drop, owner
     assert d.calculate_score()[0][0] == 0 and d.calculate_score()[0][1] < 0  # the step-major schedule is feasible
 
 
+def test_fan_out_graph_beyond_the_node_record(oracle):
+    """A general precedence graph: one hub with 260 fixed successors (the Kahn rounds' node record holds the first successor and an
+    out-degree that saturates at 255; the rest come from the CSR), nodes with two and three successors, a chain; most nodes in no
+    list.  Full score and the trial score of every list move kind == oracle, in every scratch mode of the fixture."""
+    n = 272
+    succ = [[] for _ in range(n)]
+    succ[0] = list(range(1, 261))
+    succ[3] = [261, 262]
+    succ[7] = [262, 263, 264]
+    for v in range(264, 271):
+        succ[v] = [v + 1]
+    dur = [int(1 + (v * 7) % 9) for v in range(n)]
+    owner = [v % 3 for v in range(n)]
+    for seqs in ([[0, 3, 261, 10, 264, 265, 40], [7, 262, 5, 263, 266, 100], [2, 267, 268, 200, 1, 271]],
+                 [[3, 0, 261, 264, 10], [262, 7, 263, 5, 270, 269], [268, 267, 2, 1]]):  # the second one is cyclic
+        p = {"durations": dur, "successors": succ, "expected_owner": owner, "sequences": seqs}
+        leaves = ("list_change", "list_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt")
+        d, o, bits = _mk(oracle, p, leaves=leaves)
+        o.set_kopt(1, 0)
+        assert (d.calculate_score()[0] == o.score()[:2]).all() and (d.fresh_score()[0] == o.score()[:2]).all()
+        o.configure(leaves=bits, selection_order=0)
+        gm, gs, gd = d.open_cursor(2, 31, selection_order=0, cap=1 << 18)
+        om = o.enumerate(0, 2, 31, 0)
+        assert len(gm) == len(om) > 0 and (_t(gm) == _t(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all() and (gs == os_[:, :2]).all()
+    # a short fused search from the acyclic plan keeps replica 0 on the oracle
+    p = {"durations": dur, "successors": succ, "expected_owner": owner, "sequences": [[0, 3, 261, 10, 264, 265, 40], [7, 262, 5, 263, 266, 100], [2, 267, 268, 200, 1, 271]]}
+    d, o, bits = _mk(oracle, p, leaves=("list_change", "list_swap", "list_reverse"))
+    import solverforge_amd as sfa
+    d.calculate_score()
+    d.configure(sfa.SolverConfig(random_seed=3, late_acceptance_size=5, accepted_count_limit=20))
+    o.configure(leaves=bits, random_seed=3, la_size=5, limit=20)
+    d.phase_start()
+    o.phase_start()
+    d.solve_steps(25)
+    o.steps(25)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+
+
 @pytest.mark.parametrize("state", ["scheduled", "shuffled"])
 def test_trial_scores_every_list_move_kind(oracle, state):
     from solverforge_amd import datasets
