@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni64(plf.ms_count), plf.mr_count = uni(plf.mr_count);
         }
         if (pgrp_T) {  // grouped trial evaluator: the committed list edges every trial of this step starts from
-            const PgrpLds pl(mem + cv.pgrp, gl.prec.n, 0);
+            const PgrpLds pl(mem + cv.pgrp, gl.prec.n, 0, (int)pgrp_T);
             pgrp_viol = uni(pgrp_build_committed<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, pl.Sc, pl.Dc));
         }
         uint32_t exmask = ((1u << GL) - 1u) & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)

@@ -25,11 +25,13 @@ typedef __attribute__((address_space(3))) int32_t pg_lds_i32;
 constexpr uint32_t PG_NONE16 = 0xFFFFu;
 
 // LDS of the grouped evaluator inside one replica's slice: committed list successor + in-degree (shared by the trials), then per trial
-// E (i32), D (i32), S (u16), Q (u16)
+// E (i32), D (i32), S (u16), Q (u16).  E and D carry one extra word per lane of the group: the "no successor" target of a relaxation, so that
+// both relaxations of a Kahn round are issued without a branch (a lane's own dummy: no same-address serialisation).
+__host__ __device__ inline size_t pgrp_a4(int n, int trials) { return ((size_t)(n + 64 / (trials > 0 ? trials : 1)) * 4 + 15) / 16 * 16; }
 __host__ __device__ inline size_t pgrp_bytes(int n, int trials) {
     if (trials <= 0) return 0;
-    const size_t per = ((size_t)n * 4 + 15) / 16 * 16 * 2 + ((size_t)n * 2 + 15) / 16 * 16 * 2;
-    return ((size_t)n * 2 + 15) / 16 * 16 * 2 + per * (size_t)trials;
+    const size_t a2 = ((size_t)n * 2 + 15) / 16 * 16;
+    return 2 * a2 + (2 * pgrp_a4(n, trials) + 2 * a2) * (size_t)trials;
 }
 struct PgrpLds {
     pg_lds_u16* Sc;  // [n] committed list successor (PG_NONE16 = none)
@@ -38,8 +40,8 @@ struct PgrpLds {
     pg_lds_i32* D;
     pg_lds_u16* S;
     pg_lds_u16* Q;
-    __device__ PgrpLds(unsigned char* base, int n, uint32_t trial) {
-        const size_t a4 = ((size_t)n * 4 + 15) / 16 * 16, a2 = ((size_t)n * 2 + 15) / 16 * 16;
+    __device__ PgrpLds(unsigned char* base, int n, uint32_t trial, int trials) {
+        const size_t a4 = pgrp_a4(n, trials), a2 = ((size_t)n * 2 + 15) / 16 * 16;
         Sc = (pg_lds_u16*)base;
         Dc = (pg_lds_u16*)(base + a2);
         unsigned char* t = base + 2 * a2 + (size_t)trial * (2 * a4 + 2 * a2);
@@ -235,7 +237,7 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
     const uint32_t G = 1u << gshift, lg = lane & (G - 1u), g = lane >> gshift;
     const uint64_t gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (g << gshift);  // this group's lanes
     const uint64_t below = (1ull << lane) - 1ull;
-    const PgrpLds L(lds_base, (int)n, g);
+    const PgrpLds L(lds_base, (int)n, g, (int)(64u >> gshift));
     const bool active = mv.kind != 0;
     // ---- the trial's list edges and in-degrees: the committed ones, then the lists the move touches through its position map ----
     if (active)
@@ -319,15 +321,13 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
             deg = r1 >> 24;
             s1 = (r1 & 0xFFFFFFu) == 0xFFFFFFu ? PG_NONE16 : (r1 & 0xFFFFFFu);
         }
-        bool new1 = false, new2 = false;
-        if (s1 != PG_NONE16) {
-            __hip_atomic_fetch_max(L.E + s1, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            new1 = __hip_atomic_fetch_add(L.D + s1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
-        }
-        if (s2 != PG_NONE16) {
-            __hip_atomic_fetch_max(L.E + s2, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            new2 = __hip_atomic_fetch_add(L.D + s2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
-        }
+        // both relaxations in flight before the first wait: a missing successor relaxes the lane's dummy word behind the arrays
+        const uint32_t t1 = s1 != PG_NONE16 ? s1 : n + lg, t2 = s2 != PG_NONE16 ? s2 : n + lg;
+        __hip_atomic_fetch_max(L.E + t1, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int32_t o1 = __hip_atomic_fetch_add(L.D + t1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(L.E + t2, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int32_t o2 = __hip_atomic_fetch_add(L.D + t2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool new1 = s1 != PG_NONE16 && o1 == 1, new2 = s2 != PG_NONE16 && o2 == 1;
         const uint64_t m1 = __ballot(new1) & gmask, m2 = __ballot(new2) & gmask;
         uint32_t ntail = tail;
         if (new1) L.Q[ntail + (uint32_t)__popcll(m1 & below)] = (uint16_t)s1;
