@@ -2472,13 +2472,13 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         // grouped trial evaluator (sf_prec_group.h): T trials per wavefront with private LDS scratch.  SF_AMD_PREC_GROUPS = 0 / 2 / 4 / 8 / 16
         gl.prec_groups = 0;
         if (gl.prec.on && gl.prec_lds && gl.prec_static) {  // (its node records live in the shared static copy)
-            // default: 8 up to 128 nodes, else the largest of 4 / 2 whose scratch stays under 12 KB per replica (4: <= 236 nodes, 2: <= 438);
+            // default: 8 up to 128 nodes, else the largest of 4 / 2 whose scratch stays under 14 KB per replica (4: up to ~245 nodes, 2: up to the ~450 the static copy allows);
             // beyond that the LDS it takes costs more resident replicas than the pass saves (50 x 20: 34.8 -> 26.0 M moves/s with 2)
-            int T = gl.prec.n <= 128 ? 8 : (pgrp_bytes(gl.prec.n, 4) <= 12 * 1024 ? 4 : (pgrp_bytes(gl.prec.n, 2) <= 12 * 1024 ? 2 : 0));
+            int T = gl.prec.n <= 128 ? 8 : (pgrp_bytes(gl.prec.n, 4, ctx->lm.V) <= 14 * 1024 ? 4 : (pgrp_bytes(gl.prec.n, 2, ctx->lm.V) <= 14 * 1024 ? 2 : 0));
             if (const char* e = std::getenv("SF_AMD_PREC_GROUPS")) {
                 T = std::atoi(e);
                 if (T != 2 && T != 4 && T != 8 && T != 16) T = 0;
-                while (T > 1 && pgrp_bytes(gl.prec.n, T) > 40 * 1024) T >>= 1;
+                while (T > 1 && pgrp_bytes(gl.prec.n, T, ctx->lm.V) > 40 * 1024) T >>= 1;
             }
             gl.prec_groups = T > 1 ? T : 0;
         }

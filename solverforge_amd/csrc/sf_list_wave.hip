@@ -477,6 +477,8 @@ __device__ __forceinline__ uint32_t nearby_source_to_ring(const ListModel& m, co
 
 #ifdef SF_PHASE_PROFILE
 __device__ unsigned long long g_phase[8];
+#endif
+#if defined(SF_PHASE_PROFILE) && !defined(SF_PHASE_PGRP)  // (SF_PHASE_PGRP: the slots belong to the stages of prec_eval_grouped, sf_prec_group.h)
 #define PH_DECL uint64_t ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PH(i)                          \
     {                                  \

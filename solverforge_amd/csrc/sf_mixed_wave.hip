@@ -160,7 +160,7 @@ struct GCarve {
         prec = o;  // earliest start, in-degree, queue, list successor of the precedence constraint's Kahn pass
         o = align_up(o + sizeof(uint32_t) * 4 * (size_t)prec_words, 16);
         pgrp = o;  // grouped trial evaluator (sf_prec_group.h): committed successor / in-degree + per-trial scratch
-        o = align_up(o + pgrp_bytes(prec_words, prec_groups), 16);
+        o = align_up(o + pgrp_bytes(prec_words, prec_groups, V), 16);
         leaftab = o;  // per-leaf generator / ring / scheduler state (LeafTab)
         o = align_up(o + sizeof(uint32_t) * 16 * GL, 16);
         total = o;
@@ -565,11 +565,12 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     // grouped trial evaluator (sf_prec_group.h): T candidates of a replay chunk per pass, G = 64 / T lanes each
     const uint32_t pgrp_T = (PREC && prec_in_lds && gl.prec_static) ? (uint32_t)gl.prec_groups : 0u;
     const uint32_t pgrp_shift = pgrp_T ? (uint32_t)__builtin_ctz(64u / pgrp_T) : 6u;
-    uint32_t pgrp_viol = 0;  // wrong-owner items of the committed lists
+    uint32_t pgrp_viol = 0;   // wrong-owner items of the committed lists
+    uint32_t pgrp_ready = 0;  // nodes without a predecessor in the committed lists
     // one pass: every lane group scores the move it holds (gm uniform inside a group, kind 0 = idle) against the committed lists
     auto pgrp_eval = [&](const PgrpMove& gm, int64_t& gp, int64_t& gmk, bool& gcyc) {
-        prec_eval_grouped<uint16_t>(pgs, (uint32_t)gl.prec.n, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, mem + cv.pgrp, pgrp_shift, gm,
-                                    gl.prec.const_penalty + (int64_t)((uint32_t)gl.prec.n - uni(s_off[V])), pgrp_viol, gp, gmk, gcyc);
+        prec_eval_grouped<uint16_t>(pgs, (uint32_t)gl.prec.n, V, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, mem + cv.pgrp, pgrp_shift, gm,
+                                    gl.prec.const_penalty + (int64_t)((uint32_t)gl.prec.n - uni(s_off[V])), pgrp_viol, pgrp_ready, gp, gmk, gcyc);
     };
     // the next (up to) T candidates of `todo` -- one per lane: leaf kind and ring words -- through one pass; true on the lanes whose
     // candidate was scored, with its (penalty, makespan, cycle flag)
@@ -618,9 +619,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     // borrow the grouped evaluator's trial scratch in LDS when it is there (no trial is in flight during a recreate)
     PlfRep plf_r = plf;
     if (plf_on && pgrp_T) {
-        const size_t pn = (size_t)gl.prec.n, a2 = (pn * 2 + 15) / 16 * 16;
-        const size_t room = pgrp_bytes((int)pn, (int)pgrp_T) - 2 * a2;
-        uint32_t* w = (uint32_t*)(mem + cv.pgrp + 2 * a2);
+        const size_t pn = (size_t)gl.prec.n, shared = pgrp_shared_bytes((int)pn, V);
+        const size_t room = pgrp_bytes((int)pn, (int)pgrp_T, V) - shared;
+        uint32_t* w = (uint32_t*)(mem + cv.pgrp + shared);
         if (room >= 20 * pn) plf_r.latest = (int32_t*)w, plf_r.first = w + pn, plf_r.visit = w + 2 * pn, plf_r.flag = w + 3 * pn, plf_r.cnl = w + 4 * pn;
         if (room >= 24 * pn + 8) plf_r.roff = w + 5 * pn;
     }
@@ -1040,8 +1041,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni64(plf.ms_count), plf.mr_count = uni(plf.mr_count);
         }
         if (pgrp_T) {  // grouped trial evaluator: the committed list edges every trial of this step starts from
-            const PgrpLds pl(mem + cv.pgrp, gl.prec.n, 0, (int)pgrp_T);
-            pgrp_viol = uni(pgrp_build_committed<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, pl.Sc, pl.Dc));
+            const PgrpLds pl(mem + cv.pgrp, gl.prec.n, V, 0, (int)pgrp_T);
+            uint32_t pv = 0, pr = 0;
+            pgrp_build_committed<uint16_t>(gl.prec, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, V, pl, pv, pr);
+            pgrp_viol = uni(pv), pgrp_ready = uni(pr);
         }
         uint32_t exmask = ((1u << GL) - 1u) & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine

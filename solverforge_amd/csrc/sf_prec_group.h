@@ -28,23 +28,30 @@ constexpr uint32_t PG_NONE16 = 0xFFFFu;
 // E (i32), D (i32), S (u16), Q (u16).  E and D carry one extra word per lane of the group: the "no successor" target of a relaxation, so that
 // both relaxations of a Kahn round are issued without a branch (a lane's own dummy: no same-address serialisation).
 __host__ __device__ inline size_t pgrp_a4(int n, int trials) { return ((size_t)(n + 64 / (trials > 0 ? trials : 1)) * 4 + 15) / 16 * 16; }
-__host__ __device__ inline size_t pgrp_bytes(int n, int trials) {
+// shared by the trials of a replica: committed list successor, committed in-degree, the nodes whose committed in-degree is 0 (u16 x n each) and
+// the wrong-owner items of every committed list (u32 x V)
+__host__ __device__ inline size_t pgrp_shared_bytes(int n, int V) { return 3 * (((size_t)n * 2 + 15) / 16 * 16) + ((size_t)V * 4 + 15) / 16 * 16; }
+__host__ __device__ inline size_t pgrp_bytes(int n, int trials, int V) {
     if (trials <= 0) return 0;
     const size_t a2 = ((size_t)n * 2 + 15) / 16 * 16;
-    return 2 * a2 + (2 * pgrp_a4(n, trials) + 2 * a2) * (size_t)trials;
+    return pgrp_shared_bytes(n, V) + (2 * pgrp_a4(n, trials) + 2 * a2) * (size_t)trials;
 }
 struct PgrpLds {
     pg_lds_u16* Sc;  // [n] committed list successor (PG_NONE16 = none)
     pg_lds_u16* Dc;  // [n] committed in-degree (fixed + list predecessor)
+    pg_lds_u16* Rc;  // the nodes with Dc == 0 (a trial's ready set is these, re-checked, plus the heads of the lists it touches)
+    pg_lds_u32* Vl;  // [V] wrong-owner items per committed list
     pg_lds_i32* E;   // this lane's trial
     pg_lds_i32* D;
     pg_lds_u16* S;
     pg_lds_u16* Q;
-    __device__ PgrpLds(unsigned char* base, int n, uint32_t trial, int trials) {
+    __device__ PgrpLds(unsigned char* base, int n, int V, uint32_t trial, int trials) {
         const size_t a4 = pgrp_a4(n, trials), a2 = ((size_t)n * 2 + 15) / 16 * 16;
         Sc = (pg_lds_u16*)base;
         Dc = (pg_lds_u16*)(base + a2);
-        unsigned char* t = base + 2 * a2 + (size_t)trial * (2 * a4 + 2 * a2);
+        Rc = (pg_lds_u16*)(base + 2 * a2);
+        Vl = (pg_lds_u32*)(base + 3 * a2);
+        unsigned char* t = base + pgrp_shared_bytes(n, V) + (size_t)trial * (2 * a4 + 2 * a2);
         E = (pg_lds_i32*)t;
         D = (pg_lds_i32*)(t + a4);
         S = (pg_lds_u16*)(t + 2 * a4);
@@ -52,32 +59,47 @@ struct PgrpLds {
     }
 };
 
-// committed list successor / in-degree of every node, once per step: one wavefront.  Returns the wrong-owner items of the lists (wave-uniform).
+// the shared arrays, once per step: one wavefront.  Returns the wrong-owner items of the lists and the number of committed-ready nodes (wave-uniform).
 template <class VT>
-__device__ __forceinline__ uint32_t pgrp_build_committed(const PrecModel& pm, const PREC_L VT* visits, const PREC_L uint32_t* off, int V, pg_lds_u16* Sc, pg_lds_u16* Dc) {
+__device__ __forceinline__ void pgrp_build_committed(const PrecModel& pm, const PREC_L VT* visits, const PREC_L uint32_t* off, int V, const PgrpLds& L, uint32_t& out_viol,
+                                                     uint32_t& out_ready) {
     const uint32_t lane = threadIdx.x & 63u, n = (uint32_t)pm.n;
     for (uint32_t i = lane; i < n; i += 64) {
-        Sc[i] = (uint16_t)PG_NONE16;
-        Dc[i] = (uint16_t)pm.indeg0[i];
+        L.Sc[i] = (uint16_t)PG_NONE16;
+        L.Dc[i] = (uint16_t)pm.indeg0[i];
     }
+    for (uint32_t e = lane; e < (uint32_t)V; e += 64) L.Vl[e] = 0u;
     prec_sync();
     uint32_t viol = 0;
     for (uint32_t e = 0; e < (uint32_t)V; ++e) {
         const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[e]), len = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[e + 1]) - o;
+        uint32_t mine = 0;
         for (uint32_t k = lane; k < len; k += 64) {
             const uint32_t x = (uint32_t)visits[o + k];
-            if (k + 1 < len) Sc[x] = (uint16_t)visits[o + k + 1];
-            if (k > 0) Dc[x] = (uint16_t)(pm.indeg0[x] + 1);
+            if (k + 1 < len) L.Sc[x] = (uint16_t)visits[o + k + 1];
+            if (k > 0) L.Dc[x] = (uint16_t)(pm.indeg0[x] + 1);
             if (pm.owner) {
                 const int32_t ow = pm.owner[x];
-                viol += (ow >= 0 && (uint32_t)ow != e) ? 1u : 0u;
+                mine += (ow >= 0 && (uint32_t)ow != e) ? 1u : 0u;
             }
         }
+        if (mine) __hip_atomic_fetch_add(L.Vl + e, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        viol += mine;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) viol += (uint32_t)__shfl_xor((int)viol, o);
     prec_sync();
-    return viol;
+    uint32_t cnt = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+        const uint32_t v = b0 + lane;
+        const bool ready = v < n && L.Dc[v] == 0;
+        const uint64_t m = __ballot(ready);
+        if (ready) L.Rc[cnt + prec_mbcnt(m)] = (uint16_t)v;
+        cnt += (uint32_t)__popcll(m);
+    }
+    prec_sync();
+    out_viol = viol;
+    out_ready = cnt;
 }
 
 // One candidate as the generic engine's ring holds it, decoded to the arguments of apply_list_move_wave
@@ -224,6 +246,18 @@ struct PgrpStatic {
     uint32_t has_owner;          // expected-owner hook (an explicit flag: the null value of an LDS pointer is not 0)
 };
 
+#ifdef SF_PHASE_PGRP  // diagnostics (-DSF_PHASE_PROFILE -DSF_PHASE_PGRP): shader clocks per stage of a pass in g_phase[0..4], passes in [7]
+extern __device__ unsigned long long g_phase[8];
+#define PGT(i)                                                                     \
+    {                                                                              \
+        const uint64_t _t = clock64();                                             \
+        if (lane == 0) atomicAdd(&g_phase[i], (unsigned long long)(_t - pg_t));    \
+        pg_t = _t;                                                                 \
+    }
+#else
+#define PGT(i)
+#endif
+
 // T trials side by side.  `gshift` = log2(lanes per group); lane's group g = lane >> gshift, its index inside the group lg.  `mv` is uniform
 // inside a group (kind 0 = the group idles).  Returns, uniform inside each group, the (penalty, makespan, cycle flag) of the trial.
 //   fixed_pen = const_penalty + unassigned nodes (unchanged by a list move that keeps every element), viol_c = wrong-owner items of the
@@ -231,14 +265,18 @@ struct PgrpStatic {
 // A Kahn round is four dependent LDS round trips: the popped node; its record, earliest start and list successor; the relaxations of the
 // first fixed successor and of the list successor (issued together); the queue writes.  Pop order is free (the result does not depend on it).
 template <class VT>
-__device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, const PREC_L VT* visits, const PREC_L uint32_t* off, unsigned char* lds_base, uint32_t gshift,
-                                               const PgrpMove mv, int64_t fixed_pen, uint32_t viol_c, int64_t& out_pen, int64_t& out_mk, bool& out_cyclic) {
+__device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, int V, const PREC_L VT* visits, const PREC_L uint32_t* off, unsigned char* lds_base, uint32_t gshift,
+                                               const PgrpMove mv, int64_t fixed_pen, uint32_t viol_c, uint32_t n_ready, int64_t& out_pen, int64_t& out_mk, bool& out_cyclic) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t G = 1u << gshift, lg = lane & (G - 1u), g = lane >> gshift;
     const uint64_t gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (g << gshift);  // this group's lanes
     const uint64_t below = (1ull << lane) - 1ull;
-    const PgrpLds L(lds_base, (int)n, g, (int)(64u >> gshift));
+    const PgrpLds L(lds_base, (int)n, V, g, (int)(64u >> gshift));
     const bool active = mv.kind != 0;
+#ifdef SF_PHASE_PGRP
+    uint64_t pg_t = clock64();
+    if (lane == 0) atomicAdd(&g_phase[7], 1ull);
+#endif
     // ---- the trial's list edges and in-degrees: the committed ones, then the lists the move touches through its position map ----
     if (active)
         for (uint32_t v = lg; v < n; v += G) {
@@ -247,8 +285,10 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
             L.E[v] = 0;
         }
     prec_sync();
+    PGT(0)
     int32_t dviol = 0;
     uint32_t nl = 0, len0 = 0, len1 = 0, len2 = 0;  // the lists the move touches and their lengths afterwards
+    uint32_t hd0 = 0, hd1 = 0, hd2 = 0;             // their first elements (on the group's first lane)
     if (active) {  // phase A: the touched lists in their new order, one after the other in the (still unused) queue array
         const bool one_list = mv.kind == 4 || mv.kind == 7 || mv.kind == 9;
         const uint32_t la = off[mv.a + 1] - off[mv.a], lb = one_list ? la : off[mv.b + 1] - off[mv.b];
@@ -262,18 +302,13 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
             for (uint32_t k = lg; k < sg.len; k += G) {
                 const uint32_t x = (uint32_t)visits[pgrp_seg_src(sg, k)];
                 L.Q[base + k] = (uint16_t)x;
+                if (k == 0) hd0 = li == 0 ? x : hd0, hd1 = li == 1 ? x : hd1, hd2 = li == 2 ? x : hd2;  // (lane lg == 0)
                 if (ps.has_owner) {
                     const int32_t o = ps.owner[x];
                     dviol += (o >= 0 && (uint32_t)o != e) ? 1 : 0;
                 }
             }
-            if (ps.has_owner) {  // minus what the committed list e contributed
-                const uint32_t oe = off[e], le = off[e + 1] - oe;
-                for (uint32_t k = lg; k < le; k += G) {
-                    const int32_t o = ps.owner[(uint32_t)visits[oe + k]];
-                    dviol -= (o >= 0 && (uint32_t)o != e) ? 1 : 0;
-                }
-            }
+            if (ps.has_owner && lg == 0) dviol -= (int32_t)L.Vl[e];  // minus what the committed list e contributed
             len0 = li == 0 ? sg.len : len0, len1 = li == 1 ? sg.len : len1, len2 = li == 2 ? sg.len : len2;
             base += sg.len;
         }
@@ -296,18 +331,33 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
         for (uint32_t o = G >> 1; o; o >>= 1) dviol += __shfl_xor(dviol, (int)o);
     }
     prec_sync();
+    PGT(1)
     // ---- Kahn: ready nodes, then rounds of up to G pops per group ----
+    // ready set: the committed-ready nodes that still have no predecessor, plus the heads of the touched lists that lost theirs (a node
+    // that is not a list head keeps a list predecessor; the committed-ready ones are covered by the first loop)
     uint32_t head = 0, tail = 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += G) {  // (n is wave-uniform: every group scans the same chunks)
-        const uint32_t v = b0 + lg;
-        const bool ready = active && v < n && L.D[v] == 0;
+    for (uint32_t b0 = 0; b0 < n_ready; b0 += G) {  // (n_ready is wave-uniform: every group scans the same chunks)
+        const uint32_t idx = b0 + lg;
+        const uint32_t v = idx < n_ready ? (uint32_t)L.Rc[idx] : 0u;
+        const bool ready = active && idx < n_ready && L.D[v] == 0;
         const uint64_t m = __ballot(ready) & gmask;
         if (ready) L.Q[tail + (uint32_t)__popcll(m & below)] = (uint16_t)v;
         tail += (uint32_t)__popcll(m);
     }
+#pragma unroll
+    for (uint32_t li = 0; li < 3; ++li) {
+        const uint32_t h = li == 0 ? hd0 : (li == 1 ? hd1 : hd2), len = li == 0 ? len0 : (li == 1 ? len1 : len2);
+        const bool ready = active && lg == 0 && li < nl && len > 0 && L.D[h] == 0 && L.Dc[h] != 0;
+        const uint64_t m = __ballot(ready) & gmask;
+        if (ready) L.Q[tail] = (uint16_t)h;
+        tail += (uint32_t)__popcll(m);
+    }
     prec_sync();
+    PGT(2)
     int32_t mk = 0;
+    uint32_t pg_rounds = 0;
     while (__ballot(head < tail) != 0ull) {
+        pg_rounds += 1;
         const uint32_t cnt = tail - head < G ? tail - head : G;
         const bool act = lg < cnt;
         int32_t fin = 0;
@@ -359,6 +409,10 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
         tail = ntail;
         prec_sync();
     }
+    PGT(3)
+#ifdef SF_PHASE_PGRP
+    if (lane == 0) atomicAdd(&g_phase[6], (unsigned long long)pg_rounds);
+#endif
     for (uint32_t o = G >> 1; o; o >>= 1) {  // group maximum of the finish times
         const int32_t other = __shfl_xor(mk, (int)o);
         mk = other > mk ? other : mk;
