@@ -28,9 +28,9 @@ constexpr uint32_t PG_NONE16 = 0xFFFFu;
 // E (i32), D (i32), S (u16), Q (u16).  E and D carry one extra word per lane of the group: the "no successor" target of a relaxation, so that
 // both relaxations of a Kahn round are issued without a branch (a lane's own dummy: no same-address serialisation).
 __host__ __device__ inline size_t pgrp_a4(int n, int trials) { return ((size_t)(n + 64 / (trials > 0 ? trials : 1)) * 4 + 15) / 16 * 16; }
-// shared by the trials of a replica: committed list successor, committed in-degree, the nodes whose committed in-degree is 0 (u16 x n each) and
-// the wrong-owner items of every committed list (u32 x V)
-__host__ __device__ inline size_t pgrp_shared_bytes(int n, int V) { return 3 * (((size_t)n * 2 + 15) / 16 * 16) + ((size_t)V * 4 + 15) / 16 * 16; }
+// shared by the trials of a replica: committed list successor, committed in-degree, the nodes whose committed in-degree is 0, the fixed
+// in-degree of the element at every flat list position (u16 x n each) and the wrong-owner items of every committed list (u32 x V)
+__host__ __device__ inline size_t pgrp_shared_bytes(int n, int V) { return 4 * (((size_t)n * 2 + 15) / 16 * 16) + ((size_t)V * 4 + 15) / 16 * 16; }
 __host__ __device__ inline size_t pgrp_bytes(int n, int trials, int V) {
     if (trials <= 0) return 0;
     const size_t a2 = ((size_t)n * 2 + 15) / 16 * 16;
@@ -40,6 +40,7 @@ struct PgrpLds {
     pg_lds_u16* Sc;  // [n] committed list successor (PG_NONE16 = none)
     pg_lds_u16* Dc;  // [n] committed in-degree (fixed + list predecessor)
     pg_lds_u16* Rc;  // the nodes with Dc == 0 (a trial's ready set is these, re-checked, plus the heads of the lists it touches)
+    pg_lds_u16* Iv;  // [flat position] fixed in-degree of the element there (a trial reads it beside the element, not behind it)
     pg_lds_u32* Vl;  // [V] wrong-owner items per committed list
     pg_lds_i32* E;   // this lane's trial
     pg_lds_i32* D;
@@ -50,7 +51,8 @@ struct PgrpLds {
         Sc = (pg_lds_u16*)base;
         Dc = (pg_lds_u16*)(base + a2);
         Rc = (pg_lds_u16*)(base + 2 * a2);
-        Vl = (pg_lds_u32*)(base + 3 * a2);
+        Iv = (pg_lds_u16*)(base + 3 * a2);
+        Vl = (pg_lds_u32*)(base + 4 * a2);
         unsigned char* t = base + pgrp_shared_bytes(n, V) + (size_t)trial * (2 * a4 + 2 * a2);
         E = (pg_lds_i32*)t;
         D = (pg_lds_i32*)(t + a4);
@@ -77,7 +79,9 @@ __device__ __forceinline__ void pgrp_build_committed(const PrecModel& pm, const 
         for (uint32_t k = lane; k < len; k += 64) {
             const uint32_t x = (uint32_t)visits[o + k];
             if (k + 1 < len) L.Sc[x] = (uint16_t)visits[o + k + 1];
-            if (k > 0) L.Dc[x] = (uint16_t)(pm.indeg0[x] + 1);
+            const uint32_t i0 = (uint32_t)pm.indeg0[x];
+            L.Iv[o + k] = (uint16_t)i0;
+            if (k > 0) L.Dc[x] = (uint16_t)(i0 + 1);
             if (pm.owner) {
                 const int32_t ow = pm.owner[x];
                 mine += (ow >= 0 && (uint32_t)ow != e) ? 1u : 0u;
@@ -289,19 +293,20 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
     int32_t dviol = 0;
     uint32_t nl = 0, len0 = 0, len1 = 0, len2 = 0;  // the lists the move touches and their lengths afterwards
     uint32_t hd0 = 0, hd1 = 0, hd2 = 0;             // their first elements (on the group's first lane)
-    if (active) {  // phase A: the touched lists in their new order, one after the other in the (still unused) queue array
+    if (active) {  // the touched lists: list successor and in-degree of their elements in the new order
         const bool one_list = mv.kind == 4 || mv.kind == 7 || mv.kind == 9;
         const uint32_t la = off[mv.a + 1] - off[mv.a], lb = one_list ? la : off[mv.b + 1] - off[mv.b];
         const uint32_t e3 = mv.el2 >> 16;
         nl = mv.kind == 10 ? 3u : ((mv.kind == 2 || mv.kind == 3 || mv.kind == 5 || mv.kind == 6) && mv.a != mv.b ? 2u : 1u);
-        uint32_t base = 0;
         for (uint32_t li = 0; li < nl; ++li) {
             const uint32_t e = li == 0 ? mv.a : (li == 1 ? mv.b : e3);
             PgrpSegs sg;
             pgrp_segments(mv, off, e, la, lb, sg);
-            for (uint32_t k = lg; k < sg.len; k += G) {
-                const uint32_t x = (uint32_t)visits[pgrp_seg_src(sg, k)];
-                L.Q[base + k] = (uint16_t)x;
+            for (uint32_t k = lg; k < sg.len; k += G) {  // element, its successor in the new order and its fixed in-degree: three independent reads
+                const uint32_t src = pgrp_seg_src(sg, k), srcn = k + 1 < sg.len ? pgrp_seg_src(sg, k + 1) : src;
+                const uint32_t x = (uint32_t)visits[src], nx = (uint32_t)visits[srcn], i0 = (uint32_t)L.Iv[src];
+                L.S[x] = (uint16_t)(k + 1 < sg.len ? nx : PG_NONE16);
+                L.D[x] = (int32_t)(i0 + (k > 0 ? 1u : 0u));
                 if (k == 0) hd0 = li == 0 ? x : hd0, hd1 = li == 1 ? x : hd1, hd2 = li == 2 ? x : hd2;  // (lane lg == 0)
                 if (ps.has_owner) {
                     const int32_t o = ps.owner[x];
@@ -310,21 +315,6 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
             }
             if (ps.has_owner && lg == 0) dviol -= (int32_t)L.Vl[e];  // minus what the committed list e contributed
             len0 = li == 0 ? sg.len : len0, len1 = li == 1 ? sg.len : len1, len2 = li == 2 ? sg.len : len2;
-            base += sg.len;
-        }
-    }
-    prec_sync();
-    if (active) {  // phase B: list successor and in-degree of every node of those lists
-        uint32_t base = 0;
-        for (uint32_t li = 0; li < nl; ++li) {
-            const uint32_t len = li == 0 ? len0 : (li == 1 ? len1 : len2);
-            for (uint32_t k = lg; k < len; k += G) {
-                const uint32_t x = (uint32_t)L.Q[base + k];
-                const uint32_t nx = k + 1 < len ? (uint32_t)L.Q[base + k + 1] : PG_NONE16;
-                L.S[x] = (uint16_t)nx;
-                L.D[x] = ps.indeg0[x] + (k > 0 ? 1 : 0);
-            }
-            base += len;
         }
     }
     if (ps.has_owner) {  // group sum of dviol (xor butterfly stays inside the group for offsets < G)
