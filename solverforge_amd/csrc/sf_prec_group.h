@@ -282,12 +282,23 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
     if (lane == 0) atomicAdd(&g_phase[7], 1ull);
 #endif
     // ---- the trial's list edges and in-degrees: the committed ones, then the lists the move touches through its position map ----
-    if (active)
-        for (uint32_t v = lg; v < n; v += G) {
-            L.S[v] = L.Sc[v];
-            L.D[v] = (int32_t)L.Dc[v];
-            L.E[v] = 0;
+    if (active) {  // two nodes per lane and iteration (the u16 arrays as 32-bit words), iterations unrolled so that their reads overlap
+        const pg_lds_u32* const Sc2 = (const pg_lds_u32*)L.Sc;
+        const pg_lds_u32* const Dc2 = (const pg_lds_u32*)L.Dc;
+        pg_lds_u32* const S2 = (pg_lds_u32*)L.S;
+        const uint32_t words = (n + 1u) >> 1;  // (the arrays are padded to 16 bytes: the odd tail word exists)
+#pragma unroll 4
+        for (uint32_t w = lg; w < words; w += G) {
+            const uint32_t sc = Sc2[w], dc = Dc2[w];
+            S2[w] = sc;
+            L.D[2 * w] = (int32_t)(dc & 0xFFFFu);
+            L.E[2 * w] = 0;
+            if (2 * w + 1 < n) {
+                L.D[2 * w + 1] = (int32_t)(dc >> 16);
+                L.E[2 * w + 1] = 0;
+            }
         }
+    }
     prec_sync();
     PGT(0)
     int32_t dviol = 0;
