@@ -313,15 +313,22 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
             const uint32_t e = li == 0 ? mv.a : (li == 1 ? mv.b : e3);
             PgrpSegs sg;
             pgrp_segments(mv, off, e, la, lb, sg);
-            for (uint32_t k = lg; k < sg.len; k += G) {  // element, its successor in the new order and its fixed in-degree: three independent reads
-                const uint32_t src = pgrp_seg_src(sg, k), srcn = k + 1 < sg.len ? pgrp_seg_src(sg, k + 1) : src;
-                const uint32_t x = (uint32_t)visits[src], nx = (uint32_t)visits[srcn], i0 = (uint32_t)L.Iv[src];
-                L.S[x] = (uint16_t)(k + 1 < sg.len ? nx : PG_NONE16);
-                L.D[x] = (int32_t)(i0 + (k > 0 ? 1u : 0u));
-                if (k == 0) hd0 = li == 0 ? x : hd0, hd1 = li == 1 ? x : hd1, hd2 = li == 2 ? x : hd2;  // (lane lg == 0)
-                if (ps.has_owner) {
-                    const int32_t o = ps.owner[x];
-                    dviol += (o >= 0 && (uint32_t)o != e) ? 1 : 0;
+            // G - 1 elements per iteration: the group's last lane only supplies the successor of the one before it (the element itself
+            // belongs to the next iteration's first lane), so the position map is evaluated once per lane and the successor is a lane shift
+            for (uint32_t k0 = 0; k0 < sg.len; k0 += G - 1u) {
+                const uint32_t k = k0 + lg;
+                const bool in = k < sg.len;
+                const uint32_t src = in ? pgrp_seg_src(sg, k) : 0u;
+                const uint32_t x = in ? (uint32_t)visits[src] : 0u, i0 = in ? (uint32_t)L.Iv[src] : 0u;
+                const uint32_t nx = (uint32_t)__shfl_down((int)x, 1);  // (inside the group for lg < G - 1)
+                if (in && lg < G - 1u) {
+                    L.S[x] = (uint16_t)(k + 1 < sg.len ? nx : PG_NONE16);
+                    L.D[x] = (int32_t)(i0 + (k > 0 ? 1u : 0u));
+                    if (k == 0) hd0 = li == 0 ? x : hd0, hd1 = li == 1 ? x : hd1, hd2 = li == 2 ? x : hd2;  // (lane lg == 0)
+                    if (ps.has_owner) {
+                        const int32_t o = ps.owner[x];
+                        dviol += (o >= 0 && (uint32_t)o != e) ? 1 : 0;
+                    }
                 }
             }
             if (ps.has_owner && lg == 0) dviol -= (int32_t)L.Vl[e];  // minus what the committed list e contributed
