@@ -348,17 +348,16 @@ __device__ __noinline__ void plf_tails(const PrecModel pm, const PlfRep& t, type
         const uint32_t i = lo + lane;
         if (i < hi) {
             const uint32_t w = MEM::ld(Q + i);
-            int32_t best = 0;
-            for (uint32_t k = pm.succ_off[w]; k < pm.succ_off[w + 1]; ++k) {
-                const int32_t c = plf_aldi(TAIL + pm.succ[k]);
-                best = c > best ? c : best;
-            }
-            const uint32_t ls = MEM::ld(S + w);
-            if (ls != PREC_NONE) {
-                const int32_t c = plf_aldi(TAIL + ls);
-                best = c > best ? c : best;
-            }
-            TAIL[w] = best + pm.dur[w];
+            const uint32_t r0 = pm.nd[2 * (size_t)w], r1 = pm.nd[2 * (size_t)w + 1];  // duration; out-degree << 24 | first fixed successor
+            const uint32_t ls = MEM::ld(S + w), s1 = r1 & 0xFFFFFFu;
+            const int32_t c1 = s1 != 0xFFFFFFu ? plf_aldi(TAIL + s1) : 0, c2 = ls != PREC_NONE ? plf_aldi(TAIL + ls) : 0;  // both tails in flight together
+            int32_t best = c1 > c2 ? c1 : c2;
+            if ((r1 >> 24) > 1u)  // further fixed successors (none in a job shop)
+                for (uint32_t k = pm.succ_off[w] + 1; k < pm.succ_off[w + 1]; ++k) {
+                    const int32_t c = plf_aldi(TAIL + pm.succ[k]);
+                    best = c > best ? c : best;
+                }
+            TAIL[w] = best + (int32_t)r0;
         }
         plf_gsync();
     }
