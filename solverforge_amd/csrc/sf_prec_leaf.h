@@ -397,26 +397,50 @@ __device__ __noinline__ void plf_best_slot(PlfSlotPick& r, const PrecModel pm, c
         while (head < tail) {
             const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
             const bool act = lane < cnt;
-            uint32_t fo = 0, deg = 0, ln = PREC_NONE;
-            if (act) {
+            uint32_t fo = 0, deg = 0, y1 = PREC_NONE, ln = PREC_NONE;
+            if (act) {  // the first fixed neighbour on this side (descendants: from the node record) and the list neighbour
                 const uint32_t w = plf_ald(QUE + head + lane);
-                fo = side == 0 ? pm.pred_off[w] : pm.succ_off[w];
-                deg = (side == 0 ? pm.pred_off[w + 1] : pm.succ_off[w + 1]) - fo;
-                ln = side == 0 ? plf_ald(LP + w) : MEM::ld(S + w);
-            }
-            const uint32_t degt = deg + ((act && ln != PREC_NONE) ? 1u : 0u);
-            for (uint32_t k = 0;; ++k) {
-                const bool has = k < degt;
-                if (!__ballot(has)) break;
-                bool fresh = false;
-                uint32_t y = 0;
-                if (has) {
-                    y = k < deg ? (side == 0 ? pm.pred[fo + k] : pm.succ[fo + k]) : ln;
-                    fresh = __hip_atomic_exchange(mark + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+                if (side == 0) {
+                    fo = pm.pred_off[w];
+                    deg = pm.pred_off[w + 1] - fo;
+                    if (deg) y1 = pm.pred[fo];
+                    ln = plf_ald(LP + w);
+                } else {
+                    const uint32_t rec = pm.nd[2 * (size_t)w + 1];
+                    deg = rec >> 24;
+                    y1 = (rec & 0xFFFFFFu) == 0xFFFFFFu ? PREC_NONE : (rec & 0xFFFFFFu);
+                    if (deg > 1u) {
+                        fo = pm.succ_off[w];
+                        deg = pm.succ_off[w + 1] - fo;  // (the record saturates at 255)
+                    }
+                    ln = MEM::ld(S + w);
                 }
-                const uint64_t m = __ballot(fresh);
-                if (fresh) __hip_atomic_store(QUE + tail + prec_mbcnt(m), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tail += (uint32_t)__popcll(m);
+            }
+            // both marks in flight together
+            const bool h1 = y1 != PREC_NONE, h2 = ln != PREC_NONE;
+            uint32_t o1 = 1u, o2 = 1u;
+            if (h1) o1 = __hip_atomic_exchange(mark + y1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (h2) o2 = __hip_atomic_exchange(mark + ln, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool f1 = h1 && o1 == 0u, f2 = h2 && o2 == 0u;  // (the same node twice: the first exchange took it)
+            const uint64_t m1 = __ballot(f1), m2 = __ballot(f2);
+            if (f1) __hip_atomic_store(QUE + tail + prec_mbcnt(m1), y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail += (uint32_t)__popcll(m1);
+            if (f2) __hip_atomic_store(QUE + tail + prec_mbcnt(m2), ln, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tail += (uint32_t)__popcll(m2);
+            if (__ballot(deg > 1u)) {  // further fixed neighbours (none in a job shop)
+                for (uint32_t k = 1;; ++k) {
+                    const bool has = k < deg;
+                    if (!__ballot(has)) break;
+                    bool fresh = false;
+                    uint32_t y = 0;
+                    if (has) {
+                        y = side == 0 ? pm.pred[fo + k] : pm.succ[fo + k];
+                        fresh = __hip_atomic_exchange(mark + y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+                    }
+                    const uint64_t m = __ballot(fresh);
+                    if (fresh) __hip_atomic_store(QUE + tail + prec_mbcnt(m), y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    tail += (uint32_t)__popcll(m);
+                }
             }
             head += cnt;
             plf_gsync();
