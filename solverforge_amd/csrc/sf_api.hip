@@ -2472,9 +2472,22 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
         // grouped trial evaluator (sf_prec_group.h): T trials per wavefront with private LDS scratch.  SF_AMD_PREC_GROUPS = 0 / 2 / 4 / 8 / 16
         gl.prec_groups = 0;
         if (gl.prec.on && gl.prec_lds && gl.prec_static) {  // (its node records live in the shared static copy)
-            // default: 8 up to 128 nodes, else the largest of 4 / 2 whose scratch stays under 14 KB per replica (4: up to ~245 nodes, 2: up to the ~450 the static copy allows);
-            // beyond that the LDS it takes costs more resident replicas than the pass saves (50 x 20: 34.8 -> 26.0 M moves/s with 2)
-            int T = gl.prec.n <= 128 ? 8 : (pgrp_bytes(gl.prec.n, 4, ctx->lm.V) <= 14 * 1024 ? 4 : (pgrp_bytes(gl.prec.n, 2, ctx->lm.V) <= 14 * 1024 ? 2 : 0));
+            // default: as many trials per wave as the graph's width allows -- a Kahn round pops at most one node per list, so lane groups of
+            // the largest power of two <= the list count (5 machines: 4 lanes, 16 trials; 10: 8 lanes, 8 trials) -- halved until the scratch
+            // fits: under 14 KB, or the replica's precedence state (scratch + 16 B per node of Kahn arrays + ~2.5 KB) under 20 KB, which
+            // keeps eight replicas on a CU.  200 nodes: 4; 300: 2; 1,000: off (50 x 20: 34.8 -> 26.0 M moves/s with 2)
+            int T = 0;
+            {
+                int g = 1;
+                while (g * 2 <= (ctx->lm.V > 2 ? ctx->lm.V : 2)) g *= 2;
+                for (int t = 64 / g > 16 ? 16 : 64 / g; t >= 2; t >>= 1) {
+                    const size_t b = pgrp_bytes(gl.prec.n, t, ctx->lm.V);
+                    if (b <= 14 * 1024 || b + (size_t)gl.prec.n * 16 + 2560 <= 20 * 1024) {
+                        T = t;
+                        break;
+                    }
+                }
+            }
             if (const char* e = std::getenv("SF_AMD_PREC_GROUPS")) {
                 T = std::atoi(e);
                 if (T != 2 && T != 4 && T != 8 && T != 16) T = 0;
