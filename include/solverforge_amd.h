@@ -276,7 +276,9 @@ typedef struct sf_stats {
     uint64_t score_calculations;  /* scored trials only (evaluation.rs:60) */
     uint64_t moves_not_doable;
     uint64_t candidates_scored;   /* device work incl. the speculative tail of each step */
-    uint64_t sources_scanned;     /* nearby sources whose destination scan ran (generation work) */
+    uint64_t sources_scanned;     /* generator calls that produced candidates (nearby sources scanned, batches of the precedence leaf):
+                                     engine-specific generation work -- depends on the launch shape and the trials per wave, never
+                                     compared with the oracle (the seven parity counters are the fields above) */
     uint64_t reserved;
 } sf_stats;
 

@@ -541,13 +541,18 @@ __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const u
     // move/list_kernel/change.rs:44-71, swap.rs:30-56
     bool ok = i < la && (chg ? j <= lb : j < lb) && !(intra && (j == i || (chg && j == i + 1)));
     const bool flip = !chg && intra && i > j;
-    const uint32_t i2 = flip ? j : i, j2 = flip ? i : j;
+    // A lane whose candidate is not doable prices the empty pattern: positions and lengths 0, so every neighbour predicate is false,
+    // every LDS read goes to its list's first slot and every matrix row is the depot's -- nothing is gathered through a value that was
+    // not validated (the selects are vector ops; the scalar unit sees none of this).
+    const uint32_t i2 = ok ? (flip ? j : i) : 0u, j2 = ok ? (flip ? i : j) : 0u;
+    const uint32_t la_ = ok ? la : 0u, lb_ = ok ? lb : 0u;
     const uint32_t depot = (uint32_t)m.depot;
-    const uint32_t P = ok ? oa + i2 : oa, Q = ob + j2;  // a lane whose candidate is not doable reads its list's first slot (exists or is harmless)
-    const bool has_pa = i2 > 0, has_na = i2 + 1 < la, has_q = j2 < lb, has_pb = j2 > 0, has_nb = j2 + 1 < lb;
-    const uint32_t x = visits[P];
+    const uint32_t P = oa + i2, Q = ob + j2;
+    const bool has_pa = i2 > 0, has_na = i2 + 1 < la_, has_q = j2 < lb_, has_pb = j2 > 0, has_nb = j2 + 1 < lb_;
+    const uint32_t r_x = visits[P];
+    const uint32_t x = ok ? r_x : depot;
     const uint32_t r_pa = visits[has_pa ? P - 1 : P], r_na = visits[has_na ? P + 1 : P];
-    const uint32_t r_q = visits[(ok && has_q) ? Q : P], r_pb = visits[(ok && has_pb) ? Q - 1 : P], r_nb = visits[(ok && has_nb) ? Q + 1 : P];
+    const uint32_t r_q = visits[has_q ? Q : P], r_pb = visits[has_pb ? Q - 1 : P], r_nb = visits[has_nb ? Q + 1 : P];
     const uint32_t pa = has_pa ? r_pa : depot, na = has_na ? r_na : depot;
     const uint32_t vq = has_q ? r_q : depot;  // change: right neighbour of the slot; swap: y
     const uint32_t pb = has_pb ? r_pb : depot, nb = has_nb ? r_nb : depot;
@@ -651,8 +656,8 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     const bool chg0 = FAST ? true : p.leaf[0].kind == 16, chg1 = FAST ? false : (n_leaves > 1 && p.leaf[1].kind == 16);
     const int acceptor = FAST ? 1 : p.acceptor, forager = FAST ? 0 : p.forager;
     const bool dry_run = FAST ? false : p.dry_run != 0;
-    __shared__ uint64_t s_sa[WPB][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
-    uint64_t* saw = s_sa[wave_in_group];
+    __shared__ uint64_t s_sa[FAST ? 1 : WPB][FAST ? 1 : SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas (FAST: LateAcceptance only, no static LDS -- the host's occupancy plan counts on that)
+    uint64_t* saw = s_sa[FAST ? 0 : wave_in_group];
     const bool annealing = !FAST && acceptor == 3;
     if constexpr (!FAST)
         if (annealing) sa_load(saw, p.sa, r, lane);
