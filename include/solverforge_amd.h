@@ -575,6 +575,12 @@ int32_t sf_solver_configure_diversified(sf_ctx* ctx, double tolerance);
 int32_t sf_get_annealing_state(sf_ctx* ctx, int32_t replica, double* out_temperatures, int32_t* out_calibrating);
 int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine); /* sf_engine_kind; SF_ERR_UNSUPPORTED if it cannot run this model */
 int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine); /* the engine launches resolve to (after sf_initialize) */
+/* How the wave engine laid out its last fused launch (diagnostics; tests assert the path they mean to cover was taken):
+ * out_mode = 0 general / 1 FAST / 2 FAST + 32-bit deltas / 3..5 the same on the COMPACT LDS slice (4, 5 = built for 5 / 6 waves per SIMD),
+ * -1 = no wave-engine launch yet; out_renumbered = 1 when that launch ran on the internal node numbering (the u16 matrix and the
+ * neighbour index renumbered along a nearest-neighbour chain once they outgrow the L2: DESIGN 11.3; SF_AMD_RENUMBER=0 / 1 overrides).
+ * The numbering is invisible at this boundary: every id that crosses it is the caller's. */
+int32_t sf_list_wave_layout(sf_ctx* ctx, int32_t* out_mode, int32_t* out_renumbered);
 /* explicit step seeds for parity runs (n_steps per replica, replica-major); NULL clears */
 int32_t sf_solver_set_step_seeds(sf_ctx* ctx, const uint64_t* seeds, int64_t n_steps);
 /* ≙ phase start: last_step_score = calculate_score, acceptor.phase_started, best = working.  Zeroes the replicas' counters (sf_get_stats

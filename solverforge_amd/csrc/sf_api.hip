@@ -93,6 +93,15 @@ struct sf_ctx {
     bool prec_policy = false;  // sf_list_set_precedence_policy
     PlfModel plf{};  // critical-path precedence leaf: per-replica tables (allocated at the first launch that has the leaf)
     NbrIndex nbr{nullptr};  // presorted neighbour index (wave engine)
+    ListModel lm_wave{};          // the list model as the COMPACT wave kernel sees it when the nodes are renumbered (ListModel::perm)
+    NbrIndex nbr_wave{nullptr};   // ... and its neighbour index
+    bool wave_renumbered = false;
+    int last_wave_mode = -1;      // launch mode of the last wave-engine launch (sf_list_wave_layout)
+    struct WaveFix {  // what differs in lm_wave from lm (applied at launch: the per-replica state pointers of lm may be set later)
+        const uint16_t *perm, *inv, *mat16;
+        const int32_t* demand;
+        int32_t depot;
+    } lm_wave_fix{};
     bool lm_small = false;  // every trial delta of the list model fits 32-bit arithmetic (wave engine MODE 2)
     int engine = SF_ENGINE_AUTO;
     // scalar model
@@ -925,6 +934,64 @@ static int build_list_model(sf_ctx* ctx, int d) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         ctx->nbr = NbrIndex{keys};
     }
+    // Internal node numbering for the COMPACT wave kernel (ListModel::perm): once the u16 matrix and the neighbour index outgrow an
+    // XCD's 4 MiB L2, every 2-byte leg gather pulls its own line from the Infinity Cache / HBM (CVRP-5000: 352 B of memory-side traffic
+    // per candidate for <= 16 B of legs).  Nodes that are near each other get neighbouring ids -- a nearest-neighbour chain from the
+    // depot, read off the presorted index -- so the legs of a trial (route neighbours, nearby destinations) sit a few entries off the
+    // diagonal of their rows and the hot part of the matrix is a band that stays L2-resident.
+    ctx->wave_renumbered = false;
+    {
+        const char* env = std::getenv("SF_AMD_RENUMBER");  // diagnostics / parity tests: 1 = always, 0 = never (read per model: a test can toggle it)
+        const bool want = env ? std::atoi(env) != 0 : (size_t)m.dim * m.dim * 2 > (size_t)3 * 1024 * 1024;
+        if (want && ctx->nbr.keys && m.mat16 && ctx->lm_small && m.dim <= 0x7FFF && m.depot >= 0 && m.depot < m.dim) {
+            const int dim = m.dim;
+            std::vector<uint16_t> hk((size_t)dim * dim);
+            HIPCHK(ctx, hipMemcpyAsync(hk.data(), ctx->nbr.keys, hk.size() * 2, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<uint16_t> perm((size_t)dim), inv((size_t)dim);
+            std::vector<uint8_t> seen((size_t)dim, 0);
+            std::vector<int> ptr((size_t)dim, 0);  // entries of a row before ptr are all visited: the scans are amortised over the chain
+            int cur = m.depot, low = 0;
+            for (int n = 0; n < dim; ++n) {
+                perm[(size_t)cur] = (uint16_t)n;
+                inv[(size_t)n] = (uint16_t)cur;
+                seen[(size_t)cur] = 1;
+                if (n + 1 == dim) break;
+                int nx = -1;
+                const uint16_t* row = hk.data() + (size_t)cur * dim;
+                for (int& t = ptr[(size_t)cur]; t < dim; ++t) {
+                    const uint32_t e = row[t];
+                    if (e == 0xFFFFu) break;  // past the finite entries
+                    if (!seen[e & 0x7FFFu]) {
+                        nx = (int)(e & 0x7FFFu);
+                        break;
+                    }
+                }
+                if (nx < 0) {  // nothing reachable left from here: the lowest unvisited id
+                    while (seen[(size_t)low]) ++low;
+                    nx = low;
+                }
+                cur = nx;
+            }
+            uint16_t *d_perm = nullptr, *d_inv = nullptr, *d_m16 = nullptr, *d_keys = nullptr;
+            int32_t* d_dem = nullptr;
+            if ((rc = upload(ctx, &d_perm, perm.data(), perm.size()))) return rc;
+            if ((rc = upload(ctx, &d_inv, inv.data(), inv.size()))) return rc;
+            if ((rc = dalloc(ctx, &d_m16, (size_t)dim * dim))) return rc;
+            if ((rc = dalloc(ctx, &d_keys, (size_t)dim * dim))) return rc;
+            hipLaunchKernelGGL(k_mat16_renumber, dim3(dim), dim3(256), 0, ctx->stream, m.mat16, d_inv, dim, d_m16);
+            hipLaunchKernelGGL(k_nbr_renumber, dim3(dim), dim3(256), 0, ctx->stream, ctx->nbr.keys, d_inv, d_perm, dim, d_keys);
+            if (m.demand) {
+                if ((rc = dalloc(ctx, &d_dem, (size_t)dim))) return rc;
+                hipLaunchKernelGGL(k_i32_renumber, dim3((dim + 255) / 256), dim3(256), 0, ctx->stream, m.demand, d_inv, dim, d_dem);
+            }
+            HIPCHK(ctx, hipGetLastError());
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->lm_wave_fix = {d_perm, d_inv, d_m16, d_dem, (int32_t)perm[(size_t)m.depot]};
+            ctx->nbr_wave = NbrIndex{d_keys};
+            ctx->wave_renumbered = true;
+        }
+    }
     return SF_OK;
 }
 
@@ -1090,7 +1157,17 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
     }
     SearchParams q = p;
     q.n_launch = n_replicas;
-    HIPCHK(ctx, launch_tu_list_wave<L>(trace, mode, make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, lds)));
+    SearchLaunch la = make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, lds);
+    ctx->last_wave_mode = mode;
+    if (mode >= 3 && ctx->wave_renumbered) {  // the COMPACT kernels on the internal node numbering (ListModel::perm)
+        ctx->lm_wave = ctx->lm;
+        ctx->lm_wave.perm = ctx->lm_wave_fix.perm, ctx->lm_wave.inv = ctx->lm_wave_fix.inv, ctx->lm_wave.mat16 = ctx->lm_wave_fix.mat16;
+        if (ctx->lm.demand) ctx->lm_wave.demand = ctx->lm_wave_fix.demand;
+        ctx->lm_wave.depot = ctx->lm_wave_fix.depot;
+        la.lm = &ctx->lm_wave;
+        la.nb = ctx->nbr_wave;
+    }
+    HIPCHK(ctx, launch_tu_list_wave<L>(trace, mode, la));
     return SF_OK;
 }
 static int launch_list_wave(sf_ctx* ctx, const SearchParams& p, int grid, bool trace) {
@@ -2189,6 +2266,13 @@ int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine) {
 int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine) {
     if (!ctx || !ctx->initialized || !out_engine) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     *out_engine = (ctx->has_scalar_model || use_wave_engine(ctx)) ? SF_ENGINE_WAVE : SF_ENGINE_BLOCK;
+    return SF_OK;
+}
+
+int32_t sf_list_wave_layout(sf_ctx* ctx, int32_t* out_mode, int32_t* out_renumbered) {
+    if (!ctx || !out_mode || !out_renumbered) return fail(ctx, SF_ERR_INVALID, "sf_list_wave_layout: null argument");
+    *out_mode = ctx->last_wave_mode;
+    *out_renumbered = ctx->last_wave_mode >= 3 && ctx->wave_renumbered ? 1 : 0;
     return SF_OK;
 }
 

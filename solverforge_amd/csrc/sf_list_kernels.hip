@@ -792,6 +792,28 @@ __global__ __launch_bounds__(256) void k_mat_compress16(const int64_t* __restric
     }
 }
 
+// internal node numbering of the COMPACT wave kernel (ListModel::perm): the u16 matrix with rows and columns in internal order ...
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_mat16_renumber(const uint16_t* __restrict__ src, const uint16_t* __restrict__ inv, int dim, uint16_t* __restrict__ dst) {
+    const uint16_t* row = src + (size_t)inv[blockIdx.x] * dim;
+    for (int t = threadIdx.x; t < dim; t += blockDim.x) dst[(size_t)blockIdx.x * dim + t] = row[inv[t]];
+}
+// ... and the neighbour index: row i = the row of external node inv[i], same order (distance, then EXTERNAL id: the order the
+// index was sorted in), entries renamed
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_nbr_renumber(const uint16_t* __restrict__ src, const uint16_t* __restrict__ inv, const uint16_t* __restrict__ perm, int dim,
+                                                      uint16_t* __restrict__ dst) {
+    const uint16_t* row = src + (size_t)inv[blockIdx.x] * dim;
+    for (int t = threadIdx.x; t < dim; t += blockDim.x) {
+        const uint32_t e = row[t];
+        dst[(size_t)blockIdx.x * dim + t] = e == 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)((e & 0x8000u) | perm[e & 0x7FFFu]);
+    }
+}
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_i32_renumber(const int32_t* __restrict__ src, const uint16_t* __restrict__ inv, int n, int32_t* __restrict__ dst) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) dst[t] = src[inv[t]];
+}
+
 // ---------------------------------------------------------------------------------------
 // evaluate_all / initialize: full recomputation from scratch (fresh_score; FullAssert)
 // grid = R blocks.  commit != 0 also (re)builds the per-route load aggregate + cached score.

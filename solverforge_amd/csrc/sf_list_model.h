@@ -30,6 +30,14 @@ struct ListModel {
     int32_t mat_symmetric;  // mat[i][j] == mat[j][i] for every pair (checked on the host at upload)
     int32_t small32;        // every trial delta fits 32-bit arithmetic (all legs finite and < 2^26, small weights / loads)
     int32_t leg16;          // symmetric, compact copy present, every finite leg < 65535, dim <= 65535: 16-bit leg tables (sf_ruin.h)
+    // Internal node numbering of the COMPACT wave kernel (nullptr = identity).  When the u16 matrix and the neighbour index no longer fit
+    // the L2s, the host renumbers the nodes along a nearest-neighbour chain so that the legs a trial gathers (route neighbours, nearby
+    // destinations) sit close to the diagonal of their matrix rows: `perm[external] = internal`, `inv[internal] = external`.  The model
+    // handed to that kernel then carries the permuted mat16 / demand / depot and the permuted neighbour index; the replica's lists are
+    // mapped on the way into LDS and back out, every other kernel and the whole C ABI keep the caller's ids.  Candidate order does not
+    // depend on node ids (equal-distance groups are ordered by enumeration ordinal), so the trajectories are unchanged.
+    const uint16_t* perm;
+    const uint16_t* inv;
     const int32_t* demand;
     const uint32_t* ne_keys;  // not-exists A-side keys (Customer.id)
     int32_t ne_n;

@@ -686,7 +686,11 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     for (uint32_t t = lane; t < dim; t += 64) node_slot.clear(t);
     wave_sync();
     const uint32_t total0 = uni(s_off[V]);
-    for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+    if (COMPACT && m.perm) {  // internal node numbering (ListModel::perm): the lists are renamed on the way in and on every way out
+        for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = m.perm[g_visits[t]];
+    } else {
+        for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = (uint16_t)g_visits[t];
+    }
     wave_sync();
     for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
         const uint32_t o = s_off[v], len = s_off[v + 1] - o;
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     }
     wave_sync();
 
+    auto ext_id = [&](uint32_t x) -> uint32_t { return (COMPACT && m.inv) ? (uint32_t)m.inv[x] : x; };  // an LDS element under the caller's numbering
     int64_t cur[L], best_sol[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) {
@@ -911,7 +916,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                             if (ky != NBR_END) {
                                 const uint32_t y2 = ky & NBR_NODE_MASK;
                                 i2 = nearby_item_rt(is_change, node_slot.get(y2), se, sp, len, k, s_off, rt);
-                                hk = (uint64_t)m.mat[(size_t)sx * dim + y2] << 24;  // finite by construction of the index
+                                hk = (uint64_t)m.mat[(size_t)ext_id(sx) * dim + ext_id(y2)] << 24;  // finite by construction of the index
                             }
                             if (!__ballot(ky != NBR_END)) break;
                             topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
@@ -1314,7 +1319,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 for (int kk = 0; kk < L; ++kk) bs.v[kk] = best_sol[kk];
                 if (!(score_cmp<L>(best, bs) > 0)) {  // leaving the best state: write its snapshot first
                     const uint32_t tot = uni(s_off[V]);
-                    for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = s_visits[t];
+                    for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = ext_id(s_visits[t]);
                     for (uint32_t t = lane; t <= (uint32_t)V; t += 64) m.best_off[(size_t)r * (V + 1) + t] = s_off[t];
                     best_pending = false;
                 }
@@ -1402,10 +1407,10 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             if (annealing) sa_store(saw, p.sa, r, lane);
         const uint32_t tot = uni(s_off[V]);
         if (best_pending) {  // the launch ends in a best state: its deferred snapshot
-            for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = s_visits[t];
+            for (uint32_t t = lane; t < tot; t += 64) m.best_visits[(size_t)r * m.n_cap + t] = ext_id(s_visits[t]);
             for (uint32_t t = lane; t <= (uint32_t)V; t += 64) m.best_off[(size_t)r * (V + 1) + t] = s_off[t];
         }
-        for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = s_visits[t];
+        for (uint32_t t = lane; t < tot; t += 64) g_visits[t] = ext_id(s_visits[t]);
         for (uint32_t t = lane; t <= (uint32_t)V; t += 64) g_off[t] = s_off[t];
         for (uint32_t t = lane; t < (uint32_t)V; t += 64) g_load[t] = (int64_t)s_load[t];
         if (lane == 0) {

@@ -506,6 +506,12 @@ class GpuScoreDirector:
         check(self._L.sf_solver_get_engine(self._h, C.byref(e)), self._h)
         return e.value
 
+    def wave_layout(self):
+        """(launch mode, renumbered) of the wave engine's last fused launch (sf_list_wave_layout): diagnostics for tests."""
+        m, n = C.c_int32(0), C.c_int32(0)
+        check(self._L.sf_list_wave_layout(self._h, C.byref(m), C.byref(n)), self._h)
+        return m.value, bool(n.value)
+
     def best_scores(self):
         return self._scores(self._L.sf_get_best_scores)
 

@@ -17,6 +17,13 @@ def rank_seed_base(base_seed: int, rank: int, replicas_per_rank: int) -> int:
     return int(base_seed) + int(rank) * int(replicas_per_rank)
 
 
+def rank_seed_range(base_seed: int, rank: int, replicas_per_rank: int) -> range:
+    """The seeds rank `rank` searches with in a leg of `replicas_per_rank` replicas per GPU: consecutive ranks tile the seed
+    axis without gaps or overlap, whatever the replica count of the leg (bench.py runs legs of 24,576 / 2,048 / 1,024)."""
+    lo = rank_seed_base(base_seed, rank, replicas_per_rank)
+    return range(lo, lo + int(replicas_per_rank))
+
+
 def better(a: Sequence[int], b: Sequence[int]) -> bool:
     """Lexicographic Score ordering, most significant level first
     (crates/solverforge-core/src/score/hard_soft.rs:130-137, bendable.rs:210-230)."""

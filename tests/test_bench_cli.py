@@ -33,6 +33,16 @@ def test_gpus_n_refuses_to_run_with_fewer_devices():
     assert r.stdout.strip() == b""  # no JSON line: nothing to mistake for an N-GPU result
 
 
+def test_c5_portfolio_refuses_to_run_with_fewer_devices():
+    """BASELINE config 5 (CVRP-5000, the 8-GPU portfolio): the same refusal, before any problem data is built."""
+    n = _device_count()
+    r = _run(["--customers", "5000", "--vehicles", "500", "--replicas", "1280", "--gpus", str(max(n, 0) + 2), "--steps", "1", "--warmup", "0",
+              "--solve-seconds", "0", "--no-pmc"])
+    assert r.returncode == 2
+    assert b"refusing to run fewer ranks" in r.stderr
+    assert r.stdout.strip() == b""
+
+
 def test_gpus_flag_must_match_the_launcher():
     r = _run(["--gpus", "1", "--steps", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2

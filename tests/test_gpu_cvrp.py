@@ -334,6 +334,74 @@ def test_cvrp_5000_properties(oracle):
         assert sorted(c for rt in routes for c in rt) == list(range(1, 5001))
 
 
+@pytest.mark.parametrize("size", [(300, 30, 55, 8), (1000, 100, 55, 4)])
+def test_internal_node_numbering_is_invisible(oracle, monkeypatch, size):
+    """ListModel::perm: with SF_AMD_RENUMBER=1 the COMPACT wave kernel searches on nodes renumbered along a nearest-neighbour chain
+    (u16 matrix, neighbour index, demands, depot; the lists are renamed on the way into LDS and back out).  Nothing may change at
+    the boundary: scores, lists, best solutions and counters of every replica equal the run without it, and replica 0 equals the oracle."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    if _ENGINE["value"] != 2:
+        pytest.skip("wave engine only")
+    n, v, cap, reps = size
+    p = datasets.make_cvrp(n, v, cap, seed=7)
+    runs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SF_AMD_RENUMBER", flag)
+        d, o, bits = _mk(oracle, p, n_replicas=reps)
+        d.configure(sfa.SolverConfig(random_seed=3))
+        d.calculate_score()
+        d.phase_start()
+        d.solve_steps(40)
+        d.solve_steps(25)  # a second launch: the lists went out and came back in under the caller's ids
+        mode, renum = d.wave_layout()
+        assert mode >= 3, mode  # the COMPACT slice (the only kernels that take the numbering)
+        assert renum == (flag == "1")
+        runs[flag] = (d.calculate_score().copy(), [d.working_lists(0, r) for r in range(reps)], d.best_scores().copy(),
+                      [d.working_lists(0, r, best=True) for r in range(reps)], [d.stats(r) for r in range(reps)])
+        assert (d.fresh_score() == runs[flag][0]).all()
+        if flag == "1":
+            o.configure(leaves=bits, random_seed=3)
+            o.phase_start()
+            o.steps(65)
+            assert (runs[flag][0][0] == o.score()[:2]).all()
+            assert runs[flag][1][0] == o.get_lists(0)
+            so = o.stats()
+            assert runs[flag][4][0]["moves_evaluated"] == so["moves_evaluated"]
+        d.close()
+    a, b = runs["1"], runs["0"]
+    assert (a[0] == b[0]).all() and a[1] == b[1] and (a[2] == b[2]).all() and a[3] == b[3]
+    for sa_, sb_ in zip(a[4], b[4]):
+        assert {k: sa_[k] for k in sa_ if k != "sources_scanned"} == {k: sb_[k] for k in sb_ if k != "sources_scanned"}
+
+
+def test_internal_node_numbering_with_unreachable_and_tied_legs(oracle, monkeypatch):
+    """The numbering chain follows the presorted index: unreachable legs end a row early (the chain falls back to the lowest unvisited
+    id) and equal distances keep the index's (distance, EXTERNAL id) order, so the degenerate-tie path (which reads the i64 matrix
+    under the caller's ids) still sees the reference's enumeration order."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    if _ENGINE["value"] != 2:
+        pytest.skip("wave engine only")
+    monkeypatch.setenv("SF_AMD_RENUMBER", "1")
+    p = datasets.make_cvrp(260, 26, 60, seed=5, coord_range=4)  # a 4 x 4 grid of points: every distance group is wide
+    d, o, bits = _mk(oracle, p, n_replicas=3)
+    d.configure(sfa.SolverConfig(random_seed=11))
+    d.calculate_score()
+    d.phase_start()
+    d.solve_steps(30)
+    o.configure(leaves=bits, random_seed=11)
+    o.phase_start()
+    o.steps(30)
+    mode, renum = d.wave_layout()
+    if mode >= 3:  # (a model the COMPACT slice does not take runs without the numbering: nothing to check beyond parity)
+        assert renum
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert d.working_lists(0, 0) == o.get_lists(0)
+
+
 def test_single_level_score_model():
     """A SoftScore-style (1 level) list model runs on the 2-level kernels with a padded zero level:
     incremental == full recalculation, the distance only goes down under HillClimbing, and the level-0

@@ -69,3 +69,24 @@ def test_pick_winner_rule():
     assert portfolio.pick_winner([[-1, 0], [-2, 100]]) == (0, [-1, 0])
     assert portfolio.pick_winner([[0, 0, -3], [0, 0, -3]]) == (0, [0, 0, -3])
     assert portfolio.better([0, -1], [-1, 1000])
+
+
+@pytest.mark.parametrize("replicas", [24576, 2048, 1024, 1280])  # bench.py: the M1 leg, the M2 parity leg, the tuned leg, the C5 side leg
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rank_seed_ranges_tile_without_overlap(replicas, world):
+    """Every portfolio member of a leg has its own seed: the per-rank ranges are disjoint and consecutive, and rank 0 / replica 0
+    is the single-GPU search (same seed as an N = 1 run)."""
+    sys.path.insert(0, ROOT)
+    from solverforge_amd import portfolio
+
+    ranges = [portfolio.rank_seed_range(0, q, replicas) for q in range(world)]
+    assert ranges[0].start == 0
+    for a, b in zip(ranges, ranges[1:]):
+        assert a.stop == b.start and len(a) == replicas
+    seen = set()
+    for rg in ranges:
+        assert seen.isdisjoint(rg)
+        seen.update(rg)
+    assert len(seen) == world * replicas
+    # what bench.py passes to SolverConfig(random_seed=...) is the start of the rank's range
+    assert [portfolio.rank_seed_base(0, q, replicas) for q in range(world)] == [rg.start for rg in ranges]
