@@ -108,10 +108,15 @@ LEAF_BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublis
 PMC_PASSES = [
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
     ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
-    ["FETCH_SIZE"],  # (round 4: the two TCC passes last -- a hanging FETCH_SIZE pass used to eat the budget of the cycle-share pass)
+    # memory-side traffic.  Round 5: the L2's fabric request counters themselves (what FETCH_SIZE / WRITE_SIZE are derived from,
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B) fit ONE pass and complete where the derived FETCH_SIZE pass hung in the
+    # driver's round-4 run; FETCH_SIZE and WRITE_SIZE stay as passes of their own behind it and win when they complete
+    # (profiles/r05_pmc_probe.txt: both routes agree).
+    ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"],
+    ["FETCH_SIZE"],
     ["WRITE_SIZE"],
 ]
-PMC_BUDGET_S = 200.0
+PMC_BUDGET_S = 240.0
 # rocprofv3 --pmc crashes (SIGSEGV inside the tool, 8 of 8 runs) on launches of more than one residency of this kernel (>= 12,288 replicas
 # = 3,072 workgroups) on this pool, and collects fine at 6,144 (profiles/r04f_pmc_crash_notes.txt).  The counter passes therefore run the
 # SAME command at one residency and the line scales their per-launch counters by the work ratio (consumed candidates of the parent's
@@ -204,9 +209,11 @@ def spawn_ranks(n, argv):
     return subprocess.call(cmd, env=env)
 
 
-def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
+def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s, passes=None, attempts=2, budget_s=None, need="SQ_INSTS_VALU"):
     """rocprofv3 --pmc passes of this same command (child mode: warm-up + timed launches only).  Returns
     ({counter: mean per timed launch}, kernel resource info) or (None, reason)."""
+    passes = PMC_PASSES if passes is None else passes
+    budget_s = PMC_BUDGET_S if budget_s is None else budget_s
     exe = shutil.which("rocprofv3")
     if not exe:
         return None, "rocprofv3 not on PATH"
@@ -218,7 +225,7 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
     failed = []
     t_pmc = time.perf_counter()
     try:
-        for i, grp in enumerate(PMC_PASSES):
+        for i, grp in enumerate(passes):
             d = os.path.join(base, f"pmc_{i}")
             work_file = os.path.join(base, f"work_{i}.json")
             cmd = [exe, "--pmc"] + grp + ["-f", "csv", "-d", d, "-o", "b", "--", sys.executable,
@@ -226,9 +233,9 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
             # own process group: a pass that hangs is killed together with the profiled grandchild.  rocprofv3 counter passes hang
             # now and then on this pool (a pass takes ~10 s when it works): one retry per pass before its counters are given up.
             ok = False
-            why = f"{'+'.join(grp)}: the PMC time budget ({PMC_BUDGET_S:.0f} s) was spent by earlier passes"
-            for attempt in range(2):
-                left = PMC_BUDGET_S - (time.perf_counter() - t_pmc)
+            why = f"{'+'.join(grp)}: the PMC time budget ({budget_s:.0f} s) was spent by earlier passes"
+            for attempt in range(attempts):
+                left = budget_s - (time.perf_counter() - t_pmc)
                 if left < 5.0:
                     break
                 deadline = min(timeout_s, left)
@@ -279,8 +286,8 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s):
         shutil.rmtree(base, ignore_errors=True)
     if failed:
         info = dict(info, failed_passes=failed)
-    if "SQ_INSTS_VALU" not in out:
-        return None, "; ".join(failed) or "no SQ_INSTS_VALU"
+    if need not in out:
+        return None, "; ".join(failed) or f"no {need}"
     return out, info
 
 
@@ -312,6 +319,8 @@ def main():
                          "nearby2 = the two-leaf nearby union M1 is timed on")
     ap.add_argument("--tuned-seconds", type=float, default=60.0,
                     help="M2 extension leg: wall-clock budget of the tuned configuration (0 = skip); see TUNED below")
+    ap.add_argument("--c5-seconds", type=float, default=5.0,
+                    help="side leg: seconds of the same 2-leaf search on BASELINE config 5 (CVRP-5000 / 500, 1,280 replicas per GPU; 0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-out", default=None, help=argparse.SUPPRESS)
@@ -500,6 +509,37 @@ def main():
             tuned["cpu_oracle_same_config"] = cpu_box3.get("result", {"error": cpu_box3.get("error", "did not finish")})
         d3.close()
 
+    # ---- side leg: BASELINE config 5 (CVRP-5000 / 500 vehicles, the size an 8-GPU portfolio runs), the same 2-leaf search for a few seconds ----
+    c5 = None
+    if args.c5_seconds > 0 and args.solve_seconds > 0 and args.customers != 5000 and not args.pmc_child:
+        try:
+            prob5 = datasets.make_cvrp(5000, 500, 55, seed=args.seed)
+            d5 = sfa.build_cvrp(prob5, n_replicas=1280, device_id=local_rank, leaves=("nearby_change", "nearby_swap"))
+            d5.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, 1280)))
+            d5.calculate_score()
+            d5.phase_start()
+            d5.solve_steps(100)  # warm-up launch
+            d5.sync()  # (no collective inside this leg: a rank whose side leg fails must not strand the others)
+            b5 = d5.total_stats()
+            t5 = time.perf_counter()
+            n5 = 0
+            while time.perf_counter() - t5 < args.c5_seconds:
+                d5.solve_steps(100, sync=True)
+                n5 += 1
+            s5 = time.perf_counter() - t5
+            a5 = d5.total_stats()
+            mv5 = a5["moves_evaluated"] - b5["moves_evaluated"]
+            mode5, renum5 = d5.wave_layout()
+            c5 = {"workload": "solverforge-cvrp 5000 customers / 500 vehicles, 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256), 1,280 replicas per GPU",
+                  "seconds": s5, "launches": n5, "moves_per_s_rank0": mv5 / s5, "wave_launch_mode": mode5, "internal_node_numbering": renum5,
+                  "best_score_rank0": list(max(tuple(int(v) for v in s_) for s_ in d5.best_scores()))}
+            d5.close()
+        except Exception as e:  # a side leg never costs the headline line
+            c5 = {"error": f"{type(e).__name__}: {e}"}
+        if dist is not None:  # every rank, whatever happened above
+            tot5 = portfolio.sum_over_ranks(dist, c5.get("moves_per_s_rank0", 0.0))
+            c5["moves_per_s_all_ranks"] = tot5
+
     # ---- portfolio exchange: RCCL all-gather of best scores (correctness: identical winner everywhere) -------------
     exchange = "single-rank"
     best_local = max(tuple(int(v) for v in s) for s in dx.best_scores())
@@ -577,12 +617,34 @@ def main():
         launch_s = avg_launch_ms * 1e-3
         kernel = "k_list_search_wave" if engine == "wave" else "k_list_search"
         # ---- PMC: rocprofv3 child passes of this command (N = 1 only: one GPU, one process) ----
-        pmc, pmc_info, pmc_source = None, {}, None
+        pmc, pmc_info, pmc_source, pmc_full, pmc_child_raw = None, {}, None, None, None
         child_argv = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--replicas", str(min(args.replicas, PMC_CHILD_MAX_REPLICAS)),
                       "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
+        # the CPU baseline leg (one host core, ~20 s) runs beside the counter passes (GPU + their own host processes): same clock, fewer minutes
+        cb_box = {}
+        cb_thread = None
+        if not args.no_cpu_baseline:
+            cb_thread = threading.Thread(target=lambda: cb_box.update(result=cpu_baseline(problem, args.seed, args.warmup * args.ls_steps,
+                                                                                       args.steps * args.ls_steps, args.cpu_seconds)), daemon=True)
+            cb_thread.start()
         if world == 1 and not args.no_pmc:
-            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=45)
+            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=60)
+            if pmc is not None and args.replicas > PMC_CHILD_MAX_REPLICAS:
+                # the per-candidate counts the scaling below assumes, checked on the parent's own launch shape: a two-counter pass survives
+                # there now and then (profiles/r04f_pmc_crash_notes.txt: 3 of 5), so three short tries; absent = the tool crashed every time
+                full_argv = list(child_argv)
+                full_argv[full_argv.index("--replicas") + 1] = str(args.replicas)
+                full_argv[full_argv.index("--steps") + 1] = "4"
+                full, full_info = pmc_collect(full_argv, args.warmup, 4, kernel + "<", timeout_s=40, passes=[["SQ_INSTS_VALU", "SQ_INSTS_SALU"]],
+                                              attempts=3, budget_s=100.0)
+                if full is not None and (full_info or {}).get("child_work", {}).get("moves_evaluated"):
+                    fw = full_info["child_work"]
+                    per = fw["moves_evaluated"] / fw["launches"]
+                    pmc_full = {"replicas": fw["replicas"], "salu_per_candidate": full["SQ_INSTS_SALU"] / per, "valu_per_candidate": full["SQ_INSTS_VALU"] / per,
+                                "launches": fw["launches"]}
+                else:
+                    pmc_full = {"replicas": args.replicas, "failed": str(full_info)[-300:]}
             if pmc is None:  # no counters, no roofline: the line says so instead of quoting an older profile
                 pmc_source = f"none (live rocprofv3 passes failed: {pmc_info})"
                 pmc_info = {}
@@ -610,12 +672,22 @@ def main():
             roof["valu_frac"] = valu / VALU_PEAK
             roof["salu_frac"] = salu / SALU_PEAK
             roof["lds_issue_frac"] = lds / LDS_PEAK
-            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-                # rocprofv3 reports KiB; gfx950: FETCH_SIZE counts 128-B requests at 64 B -> read side doubled
-                traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            # memory-side traffic per launch (MI355X_MICROARCH.md "HBM"): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE
+            # tallies the L2's 128-byte fabric read requests at 64 B (FETCH_SIZE = TCC_EA0_RDREQ x 64 B) -> the read side is doubled.  When the
+            # derived-counter passes did not complete the same figures come from the raw request counters of the one-pass route
+            # (reads: TCC_EA0_RDREQ x 64 B, doubled the same way; writes: TCC_EA0_WRREQ x 64 B, an upper bound -- some are 32-byte requests).
+            rd = pmc["FETCH_SIZE"] * 1024.0 if "FETCH_SIZE" in pmc else (pmc["TCC_EA0_RDREQ_sum"] * 64.0 if "TCC_EA0_RDREQ_sum" in pmc else None)
+            wr = pmc["WRITE_SIZE"] * 1024.0 if "WRITE_SIZE" in pmc else (pmc["TCC_EA0_WRREQ_sum"] * 64.0 if "TCC_EA0_WRREQ_sum" in pmc else None)
+            if rd is not None and wr is not None:
+                traffic = 2.0 * rd + wr
                 roof["traffic"] = traffic
+                roof["traffic_source"] = {"read": "FETCH_SIZE x 2" if "FETCH_SIZE" in pmc else "TCC_EA0_RDREQ_sum x 64 B x 2",
+                                          "write": "WRITE_SIZE" if "WRITE_SIZE" in pmc else "TCC_EA0_WRREQ_sum x 64 B"}
+                if "FETCH_SIZE" in pmc and "TCC_EA0_RDREQ_sum" in pmc:  # both routes completed: they should name the same bytes
+                    roof["traffic_source"]["fetch_size_over_rdreq_x64"] = pmc["FETCH_SIZE"] * 1024.0 / max(pmc["TCC_EA0_RDREQ_sum"] * 64.0, 1.0)
                 roof["hbm_frac"] = traffic / launch_s / 1e9 / HBM_PEAK_GBS
-                # the measured memory-side traffic competes with the issue rooflines for `bound`: at CVRP-5000 the facts (100 MB matrix,
+                roof["traffic_bytes_per_candidate"] = traffic / max(scored_local / max(launches, 1), 1)
+                # the measured memory-side traffic competes with the issue rooflines for `bound`: at CVRP-5000 the facts (50 MB matrix,
                 # 50 MB neighbour index) no longer fit the L2s and HBM is the tightest one
                 fr["hbm"] = (traffic / launch_s, HBM_PEAK_GBS * 1e9)
             bound = max(fr, key=lambda k: fr[k][0] / fr[k][1])
@@ -628,11 +700,29 @@ def main():
                 wc = pmc["SQ_WAVE_CYCLES"]
                 roof["wave_cycle_shares"] = {"active": pmc.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wait_mem": pmc.get("SQ_WAIT_ANY", 0) / wc,
                                              "wait_issue": pmc.get("SQ_WAIT_INST_ANY", 0) / wc}
+                cwr = ((pmc_info or {}).get("child_work") or {}).get("replicas", args.replicas)
+                roof["wave_cycle_shares_shape"] = ("the timed launch shape" if cwr == args.replicas else
+                                                   f"one-residency shape: measured on launches of {cwr} replicas (rocprofv3 --pmc crashes on larger launches of this "
+                                                   f"kernel, profiles/r05_pmc_probe.txt), where ~1/4 of the slot time idles behind the slowest replicas; the timed "
+                                                   f"{args.replicas}-replica launches refill a CU as workgroups retire (profiles/r04c_wave_replica_sweep.txt)")
+            cw_ = (pmc_info or {}).get("child_work")
+            if cw_ and cw_.get("moves_evaluated") and pmc_child_raw is not None:
+                per_c = cw_["moves_evaluated"] / max(cw_["launches"], 1)
+                roof["per_candidate"] = {"replicas": cw_["replicas"], "salu": pmc_child_raw.get("SQ_INSTS_SALU", 0.0) / per_c,
+                                         "valu": pmc_child_raw.get("SQ_INSTS_VALU", 0.0) / per_c, "lds": pmc_child_raw.get("SQ_INSTS_LDS", 0.0) / per_c}
+            elif pmc.get("SQ_INSTS_SALU"):
+                per_c = moves_local / max(launches, 1)
+                roof["per_candidate"] = {"replicas": args.replicas, "salu": pmc["SQ_INSTS_SALU"] / per_c, "valu": pmc["SQ_INSTS_VALU"] / per_c,
+                                         "lds": pmc.get("SQ_INSTS_LDS", 0.0) / per_c}
+            if pmc_full is not None:  # the same two counters on the parent's own launch shape, per consumed candidate, side by side
+                roof["per_candidate_full_launch"] = pmc_full
             if pmc.get("SQ_BUSY_CYCLES") and not ((pmc_info or {}).get("child_work") or {}).get("replicas", args.replicas) != args.replicas:
                 # per-SE busy cycles summed over the 32 shader engines (only when the passes ran the parent's own launch shape)
                 roof["effective_clock_ghz"] = pmc["SQ_BUSY_CYCLES"] / 32.0 / launch_s / 1e9
             roof["counters_per_launch"] = {k: pmc[k] for k in sorted(pmc)}
         roof.update({
+            "salu_peak_note": "SALU peak = 256 CUs x 2.4 GHz x 1 instruction per clock = 614.4 G/s; scripts/salu_microbench.hip measures what the chip "
+                              "issues when every CU's scalar unit is saturated (profiles/r05_salu_microbench.jsonl)",
             "pmc_source": pmc_source, "kernel": (pmc_info or {}).get("kernel") or kernel,
             "kernel_resources": pmc_info or None, "avg_launch_ms": avg_launch_ms, "launches": launches,
             "candidates_scored_per_launch": scored_local / max(launches, 1),
@@ -653,12 +743,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int64",
+            # int64 score levels at the boundary and in the committed state; the timed instantiation prices a trial as int32 level deltas
+            # gathered from a u16 copy of the matrix under host-checked bounds (exact strength reduction: DESIGN 2.1, csrc/sf_api.hip lm_small)
+            "dtype": "int64 score / int32 trial deltas (u16 matrix copy)" if engine == "wave" else "int64",
             "data": "synthetic",
             "config": {
-                "workload": f"solverforge-cvrp {args.customers} customers / {args.vehicles} vehicles, 2-leaf nearby union "
-                            "(nearby list change + nearby list swap, max_nearby 20), LateAcceptance(400) + AcceptedCount(256), "
-                            "SelectionOrder::Random",
+                # (short facts first: the driver's parser keeps 120 characters)
+                "workload": f"cvrp {args.customers}/{args.vehicles} nearby-change+nearby-swap max_nearby=20 LA(400) AcceptedCount(256) order=Random; "
+                            f"solverforge-cvrp {args.customers} customers / {args.vehicles} vehicles, capacity {args.capacity}, the two nearby list leaves of the default list policy",
                 "replicas_per_gpu": args.replicas,
                 "ls_steps_per_launch": args.ls_steps,
                 "engine": engine,
@@ -700,9 +792,20 @@ def main():
             }
         if solve is not None and tuned is not None:
             out["extra"]["best_score_at_60s"]["tuned"] = tuned
+        # the numbers a reader compares with other configurations, at the top level of `extra`
+        side = {}
+        if solve is not None:
+            side["cvrp1000_default_list_policy"] = {
+                "what": f"the reference's out-of-the-box CVRP solve: {'+'.join(solve['leaves'])} ({args.solve_policy}), LateAcceptance(400)+AcceptedCount(256), "
+                        f"{solve['replicas']} replicas per GPU, sustained over the {args.solve_seconds:.0f} s M2 leg (generic N-leaf engine)",
+                "moves_per_s_rank0": solve["moves_per_s"], "moves_per_ls_step": solve["moves_evaluated"] / max(solve["ls_steps"], 1)}
+        if c5 is not None:
+            side["cvrp5000_nearby2"] = c5
+        if side:
+            out["extra"]["side_configs"] = side
         if not args.no_cpu_baseline:
-            cb = cpu_baseline(problem, args.seed, args.warmup * args.ls_steps, args.steps * args.ls_steps,
-                              args.cpu_seconds)
+            cb_thread.join()
+            cb = cb_box["result"]
             ws = cb.pop("working_score")
             out["cpu_baseline"] = cb
             out["extra"]["gpu_over_cpu"] = out["value"] / cb["value"]

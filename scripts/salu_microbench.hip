@@ -25,21 +25,24 @@ template <int NCHAIN>
 __global__ void k_salu(uint32_t* out, uint32_t iters, unsigned long long* clocks) {
     uint32_t a = blockIdx.x, b = blockIdx.x + 1, c = blockIdx.x + 2, d = blockIdx.x + 3;
     const unsigned long long t0 = __builtin_readcyclecounter();
+    // ONE asm statement per loop body (the compiler pads separate statements with s_nop) and SCC declared clobbered: s_add_u32
+    // writes it, and without the clobber the loop's own s_cmp was scheduled ahead of the body (a loop that never ends).
+#define R2(x) x x
+#define R4(x) R2(R2(x))
+#define R8(x) R2(R4(x))
+#define R16(x) R2(R8(x))
+#define R32(x) R2(R16(x))
     for (uint32_t it = 0; it < iters; ++it) {
         if (NCHAIN == 1) {
-#pragma unroll
-            for (int k = 0; k < 32; ++k) asm volatile("s_add_u32 %0, %0, 0x11\n s_xor_b32 %0, %0, 0x5a" : "+s"(a));
+            asm volatile(R32("s_add_u32 %0, %0, 0x11\n s_xor_b32 %0, %0, 0x5a\n") : "+s"(a) : : "scc");
         } else if (NCHAIN == 2) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                asm volatile("s_add_u32 %0, %0, 0x11\n s_add_u32 %1, %1, 0x13\n s_xor_b32 %0, %0, 0x5a\n s_xor_b32 %1, %1, 0x3c" : "+s"(a), "+s"(b));
+            asm volatile(R16("s_add_u32 %0, %0, 0x11\n s_add_u32 %1, %1, 0x13\n s_xor_b32 %0, %0, 0x5a\n s_xor_b32 %1, %1, 0x3c\n") : "+s"(a), "+s"(b) : : "scc");
         } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                asm volatile(
-                    "s_add_u32 %0, %0, 0x11\n s_add_u32 %1, %1, 0x13\n s_add_u32 %2, %2, 0x17\n s_add_u32 %3, %3, 0x19\n"
-                    "s_xor_b32 %0, %0, 0x5a\n s_xor_b32 %1, %1, 0x3c\n s_xor_b32 %2, %2, 0x66\n s_xor_b32 %3, %3, 0x71"
-                    : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
+            asm volatile(R8("s_add_u32 %0, %0, 0x11\n s_add_u32 %1, %1, 0x13\n s_add_u32 %2, %2, 0x17\n s_add_u32 %3, %3, 0x19\n"
+                            "s_xor_b32 %0, %0, 0x5a\n s_xor_b32 %1, %1, 0x3c\n s_xor_b32 %2, %2, 0x66\n s_xor_b32 %3, %3, 0x71\n")
+                         : "+s"(a), "+s"(b), "+s"(c), "+s"(d)
+                         :
+                         : "scc");
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();

@@ -942,7 +942,7 @@ static int build_list_model(sf_ctx* ctx, int d) {
     ctx->wave_renumbered = false;
     {
         const char* env = std::getenv("SF_AMD_RENUMBER");  // diagnostics / parity tests: 1 = always, 0 = never (read per model: a test can toggle it)
-        const bool want = env ? std::atoi(env) != 0 : (size_t)m.dim * m.dim * 2 > (size_t)3 * 1024 * 1024;
+        const bool want = env ? std::atoi(env) != 0 : (size_t)m.dim * m.dim * 2 > (size_t)1024 * 1024;  // (CVRP-1000: 2 MB matrix + 2 MB index share a 4 MiB L2 with the replicas' state: +2 %; CVRP-5000: 352 -> 166 B of memory-side traffic per candidate)
         if (want && ctx->nbr.keys && m.mat16 && ctx->lm_small && m.dim <= 0x7FFF && m.depot >= 0 && m.depot < m.dim) {
             const int dim = m.dim;
             std::vector<uint16_t> hk((size_t)dim * dim);
@@ -1111,8 +1111,8 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
     const bool fast = !trace && ctx->lm.mat32 && ctx->lm.dist_level >= 0 && p.acceptor == 1 && p.forager == 0 && !p.dry_run && p.n_leaves == 2 &&
                       p.leaf[0].kind == SF_SEL_NEARBY_LIST_CHANGE && p.leaf[1].kind == SF_SEL_NEARBY_LIST_SWAP && p.order == SF_ORDER_RANDOM;
     // replicas (waves) per workgroup: as many as the LDS holds, <= WPB; resident replicas per CU = whole workgroups in 160 KiB
-    auto plan = [&](bool compact, size_t wave_cap, int& wpb_out, size_t& lds_out) {
-        WCarve cvx(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx), compact);
+    auto plan = [&](bool compact, size_t wave_cap, int& wpb_out, size_t& lds_out, bool node_global = false) {
+        WCarve cvx(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx), compact, node_global);
         size_t best = 0;
         wpb_out = 1;
         for (int w = 1; w <= WPB; ++w) {  // the workgroup size that keeps the most replicas resident (a workgroup's LDS is allocated whole)
@@ -1153,6 +1153,27 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
             mode = 3;
             wpb = wpb_c;
             lds = lds_c;
+        }
+        // large models: the node -> slot table in HBM when that puts more replicas on a CU (a wave runs as fast at CVRP-5000 as at
+        // CVRP-1000; the slice decides how many are resident: 29 KB = 5 per CU, 19 KB = 8)
+        if (mode >= 3) {
+            const char* ng = std::getenv("SF_AMD_NODE_GLOBAL");  // diagnostics / parity tests: 0 = never, 1 = whenever the COMPACT slice is taken
+            const int ngv = ng ? std::atoi(ng) : -1;
+            int wpb_g = 1, wpb_3 = 1;
+            size_t lds_g = 0, lds_3 = 0;
+            const size_t r3 = plan(true, 4 * SF_WAVES_PER_EU, wpb_3, lds_3);
+            const size_t rg = plan(true, 4 * SF_WAVES_PER_EU, wpb_g, lds_g, true);
+            if (ngv != 0 && (ngv == 1 || (mode == 3 && rg > r3))) {
+                if (!ctx->lm.node_tab) {
+                    uint16_t* nt = nullptr;
+                    int rc = dalloc(ctx, &nt, (size_t)ctx->R * ctx->lm.dim);
+                    if (rc) return rc;
+                    ctx->lm.node_tab = nt;
+                }
+                mode = 6;
+                wpb = wpb_g;
+                lds = lds_g;
+            }
         }
     }
     SearchParams q = p;

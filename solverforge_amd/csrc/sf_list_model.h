@@ -38,6 +38,10 @@ struct ListModel {
     // depend on node ids (equal-distance groups are ordered by enumeration ordinal), so the trajectories are unchanged.
     const uint16_t* perm;
     const uint16_t* inv;
+    // [R][dim] u16: the replica's node -> slot table in HBM (L2-resident) instead of its LDS slice -- the NODEG instantiation of the COMPACT
+    // wave kernel, taken when that lets more replicas share a CU (CVRP-5000: 29 KB -> 19 KB per replica, 5 -> 8 per CU).  Scratch: rebuilt
+    // from the lists at the start of every launch.
+    uint16_t* node_tab;
     const int32_t* demand;
     const uint32_t* ne_keys;  // not-exists A-side keys (Customer.id)
     int32_t ne_n;

@@ -101,7 +101,8 @@ struct WCarve {
     uint32_t rc;  // ring capacity per leaf
     // compact: the COMPACT instantiation's layout -- per-list loads as int32 (MODE 2 guarantees the range) and the node -> slot
     // table as 16 bits per node (NodeSlotT<true>): CVRP-5000 / 500 drops from 43 KB to 31 KB per replica (3 -> 5 replicas per CU)
-    __host__ __device__ WCarve(int V, int n_cap, int dim, int max_k, bool compact = false) {
+    // node_global: the node -> slot table lives in HBM (ListModel::node_tab), not in the slice
+    __host__ __device__ WCarve(int V, int n_cap, int dim, int max_k, bool compact = false, bool node_global = false) {
         rc = max_k <= 32 ? RC_SMALL : RC_MAX;
         size_t o = 0;
         load = o;
@@ -109,7 +110,7 @@ struct WCarve {
         off = o;
         o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
         node = o;
-        o = align_up(o + (compact ? sizeof(uint16_t) : sizeof(uint32_t)) * dim, 16);
+        o = align_up(o + (node_global ? 0 : (compact ? sizeof(uint16_t) : sizeof(uint32_t)) * dim), 16);
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * rc * MAX_LEAVES, 16);
         visits = o;
@@ -634,10 +635,14 @@ struct LeafCursor {
 // WPE = waves per SIMD the kernel is compiled for (512 / WPE VGPRs): 4, or 5 / 6 for the COMPACT slice of a model small enough for 20 /
 // 24 replicas per CU.  Round 4: with the replica index declared wave-uniform the per-replica base pointers live in scalar registers and
 // the MODE 2 kernels need 77 VGPRs and no scratch (they were 96 VGPRs + 120 B: 64-bit pointer pairs spilled in the prologue).
-template <int L, bool TRACE, int MODE, bool COMPACT = false, int WPE = SF_WAVES_PER_EU>
+// NODEG (with COMPACT only): the node -> slot table in HBM (ListModel::node_tab) instead of the slice.  A wave's speed does not depend on
+// the model size (CVRP-1000 and CVRP-5000 both run 7.4 M moves/s per resident wave: the wave's own chain of dependent accesses is the
+// bound), the throughput is the number of resident waves -- and at CVRP-5000 the 29 KB slice holds that at 5 per CU.
+template <int L, bool TRACE, int MODE, bool COMPACT = false, int WPE = SF_WAVES_PER_EU, bool NODEG = false>
 __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m, SearchParams p, NbrIndex nb) {
     constexpr bool FAST = MODE >= 1, SMALL = MODE == 2;
     static_assert(!COMPACT || SMALL, "COMPACT stores loads in 32 bits: MODE 2 only");
+    static_assert(!NODEG || COMPACT, "NODEG: the 16-bit table of the COMPACT layout");
     using LT = typename std::conditional<COMPACT, int32_t, int64_t>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -663,14 +668,24 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         if (annealing) sa_load(saw, p.sa, r, lane);
     const uint64_t desc0 = (uint64_t)p.leaf[0].descriptor, desc1 = n_leaves > 1 ? (uint64_t)p.leaf[1].descriptor : 0;
 
-    const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1), COMPACT);
+    const WCarve cv(V, m.n_cap, m.dim, (int)(K0 > K1 ? K0 : K1), COMPACT, NODEG);
     const uint32_t RCM = cv.rc - 1;
     unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
     LT* s_load = (LT*)(mem + cv.load);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][rc][2]
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
-    const NodeSlotT<COMPACT> node_slot(mem + cv.node, V, s_visits, s_off);
+    const NodeSlotT<COMPACT> node_slot(NODEG ? (unsigned char*)(m.node_tab + (size_t)r * dim) : mem + cv.node, V, s_visits, s_off);
+    // table writes -> table reads of other lanes: LDS in program order (wave_sync); HBM through the CU's write-through L1 (ring_sync's fences)
+    auto node_sync = [&]() {
+        if constexpr (NODEG) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        } else {
+            wave_sync();
+        }
+    };
     uint32_t* rtab = (uint32_t*)(mem + cv.rtab);      // [leaf][route] rank | first slot ordinal << 16
     uint16_t* route_at = (uint16_t*)(mem + cv.routeat);  // [leaf][rank] -> route
 
@@ -684,7 +699,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
     for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = (LT)g_load[t];
     for (uint32_t t = lane; t < dim; t += 64) node_slot.clear(t);
-    wave_sync();
+    node_sync();
     const uint32_t total0 = uni(s_off[V]);
     if (COMPACT && m.perm) {  // internal node numbering (ListModel::perm): the lists are renamed on the way in and on every way out
         for (uint32_t t = lane; t < total0; t += 64) s_visits[t] = m.perm[g_visits[t]];
@@ -696,7 +711,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         const uint32_t o = s_off[v], len = s_off[v + 1] - o;
         for (uint32_t q = 0; q < len; ++q) node_slot.set(s_visits[o + q], v, q);
     }
-    wave_sync();
+    node_sync();
 
     auto ext_id = [&](uint32_t x) -> uint32_t { return (COMPACT && m.inv) ? (uint32_t)m.inv[x] : x; };  // an LDS element under the caller's numbering
     int64_t cur[L], best_sol[L];
@@ -1348,7 +1363,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                         node_slot.set(s_visits[ob + (t - la)], b, t - la);
                 }
             }
-            wave_sync();
+            node_sync();
 #pragma unroll
             for (int kk = 0; kk < L; ++kk) cur[kk] = best.v[kk];
             st_applied += 1;

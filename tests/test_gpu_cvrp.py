@@ -332,6 +332,8 @@ def test_cvrp_5000_properties(oracle):
     for r in range(2):
         routes = d.working_lists(0, r)
         assert sorted(c for rt in routes for c in rt) == list(range(1, 5001))
+    if _ENGINE["value"] == 2:  # the layout BASELINE config 5 runs on: node -> slot tables in HBM, internal node numbering
+        assert d.wave_layout() == (6, True)
 
 
 @pytest.mark.parametrize("size", [(300, 30, 55, 8), (1000, 100, 55, 4)])
@@ -374,6 +376,42 @@ def test_internal_node_numbering_is_invisible(oracle, monkeypatch, size):
     assert (a[0] == b[0]).all() and a[1] == b[1] and (a[2] == b[2]).all() and a[3] == b[3]
     for sa_, sb_ in zip(a[4], b[4]):
         assert {k: sa_[k] for k in sa_ if k != "sources_scanned"} == {k: sb_[k] for k in sb_ if k != "sources_scanned"}
+
+
+@pytest.mark.parametrize("renumber", ["0", "1"])
+def test_node_table_in_hbm(oracle, monkeypatch, renumber):
+    """Launch mode 6 (SF_AMD_NODE_GLOBAL=1 forces it at a small size; CVRP-5000 takes it by itself): the replica's node -> slot table in
+    HBM instead of its LDS slice.  Fused multi-launch runs of several replicas == the oracle / the LDS-table run, with and without the
+    internal node numbering."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    if _ENGINE["value"] != 2:
+        pytest.skip("wave engine only")
+    monkeypatch.setenv("SF_AMD_RENUMBER", renumber)
+    p = datasets.make_cvrp(400, 40, 55, seed=9)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SF_AMD_NODE_GLOBAL", flag)
+        d, o, bits = _mk(oracle, p, n_replicas=6)
+        d.configure(sfa.SolverConfig(random_seed=5))
+        d.calculate_score()
+        d.phase_start()
+        for n in (30, 30, 15):
+            d.solve_steps(n)
+        mode, renum = d.wave_layout()
+        assert (mode == 6) == (flag == "1") and mode >= 3, mode
+        assert renum == (renumber == "1")
+        out[flag] = (d.calculate_score().copy(), [d.working_lists(0, r) for r in range(6)], d.best_scores().copy(), [d.stats(r)["moves_evaluated"] for r in range(6)])
+        assert (d.fresh_score() == out[flag][0]).all()
+        if flag == "1":
+            o.configure(leaves=bits, random_seed=5)
+            o.phase_start()
+            o.steps(75)
+            assert (out[flag][0][0] == o.score()[:2]).all() and out[flag][1][0] == o.get_lists(0)
+            assert out[flag][3][0] == o.stats()["moves_evaluated"]
+        d.close()
+    assert (out["1"][0] == out["0"][0]).all() and out["1"][1] == out["0"][1] and (out["1"][2] == out["0"][2]).all() and out["1"][3] == out["0"][3]
 
 
 def test_internal_node_numbering_with_unreachable_and_tied_legs(oracle, monkeypatch):
