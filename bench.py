@@ -107,12 +107,11 @@ LEAF_BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublis
 # default run stays within a few minutes; a pass that never completes only drops its own counters.
 PMC_PASSES = [
     ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM"],
-    ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
     # memory-side traffic.  Round 5: the L2's fabric request counters themselves (what FETCH_SIZE / WRITE_SIZE are derived from,
-    # MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B) fit ONE pass and complete where the derived FETCH_SIZE pass hung in the
-    # driver's round-4 run; FETCH_SIZE and WRITE_SIZE stay as passes of their own behind it and win when they complete
-    # (profiles/r05_pmc_probe.txt: both routes agree).
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE = TCC_EA0_RDREQ x 64 B; measured ratio 0.9996, profiles/r05_c5_bench.json) fit ONE pass; FETCH_SIZE
+    # and WRITE_SIZE stay as passes of their own at the end and win when they complete.
     ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"],
+    ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"],
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
 ]
@@ -228,7 +227,8 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s, passes=None, atte
         for i, grp in enumerate(passes):
             d = os.path.join(base, f"pmc_{i}")
             work_file = os.path.join(base, f"work_{i}.json")
-            cmd = [exe, "--pmc"] + grp + ["-f", "csv", "-d", d, "-o", "b", "--", sys.executable,
+            # counters only for the kernel that is priced (the set-up kernels -- presort, compress, radix sort -- run unprofiled)
+            cmd = [exe, "--pmc"] + grp + ["--kernel-include-regex", kernel_substr.rstrip("<"), "-f", "csv", "-d", d, "-o", "b", "--", sys.executable,
                                             os.path.abspath(__file__)] + argv + ["--pmc-child", "--pmc-child-out", work_file]
             # own process group: a pass that hangs is killed together with the profiled grandchild.  rocprofv3 counter passes hang
             # now and then on this pool (a pass takes ~10 s when it works): one retry per pass before its counters are given up.
@@ -249,8 +249,12 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s, passes=None, atte
                         os.killpg(pr.pid, 9)
                     except OSError:
                         pass
-                    pr.wait()
-                    why = f"{'+'.join(grp)}: timed out after {deadline:.0f}s (attempt {attempt + 1})"
+                    try:
+                        _, err = pr.communicate(timeout=5)
+                    except Exception:
+                        err = b""
+                    # the child arms faulthandler: a pass that hangs says where its Python side was (the tail of its stderr)
+                    why = f"{'+'.join(grp)}: timed out after {deadline:.0f}s (attempt {attempt + 1}); child stderr tail: {err.decode(errors='replace')[-240:]!r}"
                     continue
                 if pr.returncode != 0:
                     why = f"{'+'.join(grp)}: rc={pr.returncode} {err.decode(errors='replace')[-160:]} (attempt {attempt + 1})"
@@ -320,12 +324,16 @@ def main():
     ap.add_argument("--tuned-seconds", type=float, default=60.0,
                     help="M2 extension leg: wall-clock budget of the tuned configuration (0 = skip); see TUNED below")
     ap.add_argument("--c5-seconds", type=float, default=5.0,
-                    help="side leg: seconds of the same 2-leaf search on BASELINE config 5 (CVRP-5000 / 500, 1,280 replicas per GPU; 0 = skip)")
+                    help="side leg: seconds of the same 2-leaf search on BASELINE config 5 (CVRP-5000 / 500, 2,048 replicas per GPU; 0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-out", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.pmc_child:  # a counter pass that hangs (rocprofv3 does now and then on this pool) leaves a Python stack in its stderr
+        import faulthandler
+
+        faulthandler.dump_traceback_later(30, exit=False)
     # the host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this before HIP initialises
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import __graft_entry__ as entry
@@ -514,8 +522,8 @@ def main():
     if args.c5_seconds > 0 and args.solve_seconds > 0 and args.customers != 5000 and not args.pmc_child:
         try:
             prob5 = datasets.make_cvrp(5000, 500, 55, seed=args.seed)
-            d5 = sfa.build_cvrp(prob5, n_replicas=1280, device_id=local_rank, leaves=("nearby_change", "nearby_swap"))
-            d5.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, 1280)))
+            d5 = sfa.build_cvrp(prob5, n_replicas=2048, device_id=local_rank, leaves=("nearby_change", "nearby_swap"))
+            d5.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, 2048)))
             d5.calculate_score()
             d5.phase_start()
             d5.solve_steps(100)  # warm-up launch
@@ -530,7 +538,7 @@ def main():
             a5 = d5.total_stats()
             mv5 = a5["moves_evaluated"] - b5["moves_evaluated"]
             mode5, renum5 = d5.wave_layout()
-            c5 = {"workload": "solverforge-cvrp 5000 customers / 500 vehicles, 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256), 1,280 replicas per GPU",
+            c5 = {"workload": "solverforge-cvrp 5000 customers / 500 vehicles, 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256), 2,048 replicas per GPU (8 per CU: launch mode 6)",
                   "seconds": s5, "launches": n5, "moves_per_s_rank0": mv5 / s5, "wave_launch_mode": mode5, "internal_node_numbering": renum5,
                   "best_score_rank0": list(max(tuple(int(v) for v in s_) for s_ in d5.best_scores()))}
             d5.close()
@@ -629,7 +637,7 @@ def main():
                                                                                        args.steps * args.ls_steps, args.cpu_seconds)), daemon=True)
             cb_thread.start()
         if world == 1 and not args.no_pmc:
-            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=60)
+            pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=40, attempts=3)
             if pmc is not None and args.replicas > PMC_CHILD_MAX_REPLICAS:
                 # the per-candidate counts the scaling below assumes, checked on the parent's own launch shape: a two-counter pass survives
                 # there now and then (profiles/r04f_pmc_crash_notes.txt: 3 of 5), so three short tries; absent = the tool crashed every time
