@@ -11,7 +11,8 @@ leaves = tuple(sys.argv[2].split(",")) if len(sys.argv) > 2 else ("nearby_change
 if leaves[0] == "jobshop":  # BASELINE config 4: mixed job shop 500 x 20, constructed start, 4-leaf union
     d = sfa.build_jobshop(datasets.construct_jobshop(datasets.make_jobshop(500, 20)), n_replicas=R)
 else:
-    d = sfa.build_cvrp(datasets.make_cvrp(1000, 100, 55, seed=0), n_replicas=R, leaves=leaves)
+    mps = int(sys.argv[4]) if len(sys.argv) > 4 else 10  # ruin leaf: moves_per_step (0 = the leaf declared but empty: what the RUIN instantiation costs by itself)
+    d = sfa.build_cvrp(datasets.make_cvrp(1000, 100, 55, seed=0), n_replicas=R, leaves=leaves, ruin=(2, 5, mps))
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score(); d.phase_start()
 L = _lib.load()

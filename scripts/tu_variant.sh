@@ -19,6 +19,7 @@ for u in "$@"; do
   (cd $C && hipcc $FL $defs -c $src -o $T/$u.o -Rpass-analysis=kernel-resource-usage 2> $T/$u.res) || { grep -E "error" $T/$u.res | head; exit 1; }
   skip="$skip -e /$u.o"
 done
-objs=$(ls $C/_obj/*.o | grep -v $skip)
+OBJ_DIR=${OBJ_DIR:-$C/_obj}
+objs=$(ls $OBJ_DIR/*.o | grep -v $skip)
 hipcc --offload-arch=gfx950 -shared -fPIC $objs $T/*.o -o $R/build/libsf_$name.so -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 for u in "$@"; do grep -E "Function Name|VGPRs:|ScratchSize|Occupancy|VGPRs Spill" $T/$u.res | sed 's/.*remark: *//; s/\[-Rpass.*//' | paste - - - - - | grep -E "search_wave" | cut -c1-60,140-260; done

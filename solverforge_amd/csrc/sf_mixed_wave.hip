@@ -1093,6 +1093,26 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             const uint32_t pool = ruin_open_cursor(gl.ruin, rl, ctx, s_off, V, !dry_run, lane);
             for (int l = 0; l < nl; ++l)
                 if (lt.geti(l, LeafTab::KIND) == 1024) lt.put_gen(l, GGen{0, 0, 0, 0, pool, 0, pool == 0 || gl.ruin.moves_per_step <= 0});
+            if (!PREC && pool != 0) {
+                // Every candidate of the step is generated and scored HERE, before the fill / replay loop, not inside it (round 5).  The
+                // leaf's stream depends on the committed state and the step's cursor seed alone, the first fill asked for all of them anyway
+                // (moves_per_step <= 16 < the fill threshold), and a recreate is 10^5 clocks of wave-wide work behind a call: inside the
+                // loop nest every value of the generators, the scheduler and the replay was live across that call, and the register
+                // allocator kept them in scratch for the whole loop (the RUIN instantiations ran the SAME six-leaf work 5x slower than
+                // the kernels without the leaf, profiles/r05_phase7_*.txt).  Out here only step-level values cross it.
+                PHS(0)
+                for (uint32_t c = 0; c < (uint32_t)gl.ruin.moves_per_step; ++c) {
+                    if (c == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);
+                    ruin_next_candidate(gl.ruin, rl, s_off, V, pool, c, lane);
+                    int64_t base_score[L];
+#pragma unroll
+                    for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
+                    ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)c * RuinLds::CAND_WORDS, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, false,
+                                     base_score, rl.score + (size_t)c * 4);
+                    wave_sync();
+                }
+                PHS(3)
+            }
         }
         // union scheduler (vec_union.rs:190-365): StratifiedRandom with equal weights when > 1 leaf
         const uint32_t u_off = nl > 1 ? ctx.random_index((uint32_t)nl, SALT_UNION_OFFSET) : 0u;
@@ -1762,9 +1782,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                             g.done = 1;
                             break;
                         }
-                        if (g.a == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);  // first candidate of the step
-                        ruin_next_candidate(gl.ruin, rl, s_off, V, g.e, g.a, lane);
                         if (PREC) {  // precedence model: the recreate is scored by the precedence constraint (with the slot's hooks when declared)
+                            if (g.a == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);  // first candidate of the step
+                            ruin_next_candidate(gl.ruin, rl, s_off, V, g.e, g.a, lane);
                             PlfMove pm_;
                             plf_from_ruin_cand(rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, pm_);
                             const ScoreV<L> psc = plf_ruin(pm_, false, plf_policy, gl.ruin.skip_empty != 0);
@@ -1772,18 +1792,18 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
 #pragma unroll
                                 for (int kk = 0; kk < L; ++kk) rl.score[(size_t)g.a * 4 + kk] = psc.v[kk];
                             }
-                        } else {
-                            int64_t base_score[L];
-#pragma unroll
-                            for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
-                            ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, rl.work, ruin_sbase, rfast,
-                                             gl.ruin.skip_empty, false, base_score, rl.score + (size_t)g.a * 4);
+                            wave_sync();
+                            keep = lane == 0;
+                            w0 = g.a;
+                            g.a += 1;
+                            if (g.a >= (uint32_t)gl.ruin.moves_per_step) g.done = 1;
+                        } else {  // scored at the start of the step (above): the ring entries name the candidates
+                            const uint32_t n_left = (uint32_t)gl.ruin.moves_per_step - g.a;
+                            keep = lane < n_left;
+                            w0 = g.a + lane;
+                            g.a += n_left;
+                            g.done = 1;
                         }
-                        wave_sync();
-                        keep = lane == 0;
-                        w0 = g.a;
-                        g.a += 1;
-                        if (g.a >= (uint32_t)gl.ruin.moves_per_step) g.done = 1;
                     } else if (DBGK(64) && kind == 64) {  // ---- list reverse / 2-opt (list_kernel/reverse.rs:68-108) ----
                         uint32_t ent = 0, len = 0;
                         for (;;) {  // entities shorter than two elements are skipped
