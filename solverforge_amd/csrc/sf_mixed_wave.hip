@@ -247,6 +247,7 @@ __device__ __forceinline__ void map_slots_to_groups(uint32_t cnt, uint32_t slot,
 
 }  // namespace sf
 #include "sf_ruin.h"
+#include "sf_ruin_v2.h"
 namespace sf {
 
 // workgroups of 4 waves: 2 resident workgroups per CU = 2 waves per SIMD (<= 256 VGPRs)
@@ -1101,14 +1102,51 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                 // allocator kept them in scratch for the whole loop (the RUIN instantiations ran the SAME six-leaf work 5x slower than
                 // the kernels without the leaf, profiles/r05_phase7_*.txt).  Out here only step-level values cross it.
                 PHS(0)
+#ifdef SF_RUIN_NO_V2
+                const bool v2 = false;
+#else
+                // trials without touching the lists (sf_ruin_v2.h) when the model is the default policy's shape; sf_ruin.h otherwise, for a
+                // candidate whose changed lists outgrow the scratch arena, and for the committed move
+                const bool v2 = rfast.edge != nullptr && rv2_model_ok(lm);
+#endif
                 for (uint32_t c = 0; c < (uint32_t)gl.ruin.moves_per_step; ++c) {
                     if (c == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);
+                    if (c == 0 && v2) rv2_build_words(s_off, (uint32_t)V, ruin_sbase);
                     ruin_next_candidate(gl.ruin, rl, s_off, V, pool, c, lane);
                     int64_t base_score[L];
 #pragma unroll
                     for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
-                    ruin_recreate<L>(lm, s_visits, s_off, s_load, rl.cand + (size_t)c * RuinLds::CAND_WORDS, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, false,
-                                     base_score, rl.score + (size_t)c * 4);
+                    const uint16_t* cand_c = rl.cand + (size_t)c * RuinLds::CAND_WORDS;
+                    bool scored = false;
+                    if (v2) scored = ruin_trial_v2<L>(lm, s_visits, s_off, s_load, cand_c, rl.work, ruin_sbase, rfast, rfast.slot, (uint32_t)lm.n_cap + (uint32_t)V,
+                                                      gl.ruin.skip_empty, base_score, rl.score + (size_t)c * 4);
+#ifdef SF_RUIN_V2_CHECK
+                    if (scored) {
+                        wave_sync();
+                        int64_t v2s[L];
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) v2s[kk] = rl.score[(size_t)c * 4 + kk];
+                        ruin_recreate<L>(lm, s_visits, s_off, s_load, cand_c, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, false, base_score, rl.score + (size_t)c * 4);
+                        wave_sync();
+                        bool same = true;
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) same = same && v2s[kk] == rl.score[(size_t)c * 4 + kk];
+                        if (lane == 0) {
+                            atomicAdd(&g_rv2_check[0], 1ull);
+                            if (!same && atomicAdd(&g_rv2_check[1], 1ull) == 0ull) {
+                                g_rv2_check[3] = (unsigned long long)r, g_rv2_check[4] = (unsigned long long)c, g_rv2_check[5] = (unsigned long long)cand_c[1];
+                                g_rv2_check[6] = (unsigned long long)v2s[L - 1], g_rv2_check[7] = (unsigned long long)rl.score[(size_t)c * 4 + L - 1];
+                            }
+                        }
+                        rv2_build_words(s_off, (uint32_t)V, ruin_sbase);
+                    } else if (v2 && lane == 0) {
+                        atomicAdd(&g_rv2_check[2], 1ull);
+                    }
+#endif
+                    if (!scored) {
+                        ruin_recreate<L>(lm, s_visits, s_off, s_load, cand_c, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, false, base_score, rl.score + (size_t)c * 4);
+                        if (v2) rv2_build_words(s_off, (uint32_t)V, ruin_sbase);  // (the slot prefix of sf_ruin.h lives in the same words)
+                    }
                     wave_sync();
                 }
                 PHS(3)

@@ -249,7 +249,10 @@ __device__ unsigned long long g_rphase[8];
 #define RPH_DUMP
 #endif
 
-#ifndef SF_RUIN_INLINE
+// Inlined since round 5 (it was an out-of-line call): with the candidates scored at the start of the step the recreate no longer sits in
+// the fill / replay loop nest, and without the call boundary the seven-leaf step of CVRP-1000 went from 6.6 M to 3.4 M shader clocks
+// (profiles/r05_phase7_variants.txt).  -DSF_RUIN_NOINLINE restores the call (A/B).
+#ifdef SF_RUIN_NOINLINE
 #define SF_RUIN_ATTR __attribute__((noinline))
 #else
 #define SF_RUIN_ATTR __forceinline__

@@ -52,3 +52,12 @@ extern "C" int32_t SF_PH_NAME(sf_debug_ruin_phases_mixed, SF_TU_L, SF_TU_VTB, SF
     return 0;
 }
 #endif
+
+#if defined(SF_RUIN_V2_CHECK) && SF_TU_RUIN != 0
+#define SF_RV2_NAME2(l, v, r, q) sf_debug_rv2_check_##l##_##v##_##r##_##q
+#define SF_RV2_NAME(l, v, r, q) SF_RV2_NAME2(l, v, r, q)
+extern "C" int32_t SF_RV2_NAME(SF_TU_L, SF_TU_VTB, SF_TU_RUIN, SF_TU_PREC)(uint64_t* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_rv2_check), 64) != hipSuccess) return -1;
+    return 0;
+}
+#endif
