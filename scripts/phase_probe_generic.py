@@ -36,6 +36,10 @@ for it in range(3):
         ro = np.zeros(8, dtype=np.uint64)
         ruin_phases(ro.ctypes.data_as(ctypes.c_void_p))
         print("  ruin_recreate cycles/step/wave %.0f" % (ro.sum() / R / 100), "shares %", np.round(ro / max(ro.sum(), 1) * 100, 1))
+        if hasattr(L, "sf_debug_ruin2_phases_mixed_" + TU):  # the list-preserving trial (sf_ruin_v2.h): 0 removal, 1 first scans, 2 best lists, 3 re-pricing, 4 pick + placement, 5 restore
+            r2 = np.zeros(8, dtype=np.uint64)
+            getattr(L, "sf_debug_ruin2_phases_mixed_" + TU)(r2.ctypes.data_as(ctypes.c_void_p))
+            print("  ruin_trial_v2 cycles/step/wave %.0f" % (r2.sum() / R / 100), "shares %", np.round(r2 / max(r2.sum(), 1) * 100, 1))
     print("launch", it, "ms %.1f" % ms, "Gmoves/s %.2f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / ms / 1e6),
           "moves/step %.0f" % ((a["moves_evaluated"] - b["moves_evaluated"]) / R / 100),
           "fill calls/step %.0f" % ((a["sources_scanned"] - b["sources_scanned"]) / R / 100),

@@ -2361,7 +2361,10 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     }
     const bool fast = !no_fast && !trace && !PREC && sizeof(VT) == 2 && ctx->has_list_model && !ctx->has_scalar_model && p.acceptor == SF_ACCEPT_LATE_ACCEPTANCE &&
                       p.forager == SF_FORAGER_ACCEPTED_COUNT && !p.dry_run && !gl.union_custom && gl.union_order == SF_UNION_STRATIFIED_RANDOM && gl.n > 1 &&
-                      (ctx->lm.mat_symmetric || ctx->lm.dist_level < 0) && !p.legacy_eval && !p.explicit_seeds && fast_kinds;
+                      (ctx->lm.mat_symmetric || ctx->lm.dist_level < 0) && !p.legacy_eval && !p.explicit_seeds && fast_kinds &&
+                      p.order == SF_ORDER_RANDOM &&  // (the default policy's SelectionOrder: compiled in, see StreamCtx in the kernel)
+                      // with a ruin leaf the FAST kernel carries the list-preserving recreate only (sf_ruin_v2.h: rv2_model_ok + the edge table)
+                      (!RUIN || (ctx->lm.leg16 && ctx->lm.V <= 128 && ctx->lm.n_cap <= 32767 && ctx->lm.dim <= 32767 && ctx->lm.small32 && ctx->lm.mat16));
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for SF_MIXED_BLOCKS_PER_CU workgroups of 4 waves per CU, the FAST
     // instantiation for SF_MIXED_FAST_BLOCKS_PER_CU); ties go to the larger group

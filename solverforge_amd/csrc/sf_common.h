@@ -66,7 +66,15 @@ SF_HD uint64_t step_seed(uint64_t random_seed, uint64_t draw) { return splitmix6
 
 // x % n.  For n < 2^16 (entity counts, list lengths, leaf counts) three 32-bit remainders (high word, then the two
 // 16-bit limbs of the low word) replace the 64-bit software division the GPU would otherwise expand to.
-SF_HD uint32_t mod_u64(uint64_t x, uint32_t n) {
+// SF_OUTLINE_MOD (the generic engine's units): one out-of-line copy.  Inlined, the three software remainders are ~100 instructions at each
+// of ~90 call sites of that kernel -- 12.7 K of its 65 K instructions, and a kernel of 340 KB runs out of the 64 KB instruction cache
+// two CUs share; a call costs a dozen.
+#if defined(SF_OUTLINE_MOD) && defined(__HIPCC__)
+#define SF_MOD_ATTR __host__ __device__ inline __attribute__((noinline))
+#else
+#define SF_MOD_ATTR SF_HD
+#endif
+SF_MOD_ATTR uint32_t mod_u64(uint64_t x, uint32_t n) {
     if (n >= 65536u) return (uint32_t)(x % n);
     uint32_t r = (uint32_t)(x >> 32) % n;  // the high word fits a 32-bit remainder directly
     r = ((r << 16) | (uint32_t)((x >> 16) & 0xFFFFu)) % n;

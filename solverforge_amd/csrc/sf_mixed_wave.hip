@@ -108,6 +108,9 @@ struct GLeaves {
     PlfModel plf;            // critical-path precedence leaf (kind 16384; PREC instantiations, sf_prec_leaf.h)
 };
 
+// u16 entries of RuinFast::slot: the slot table of sf_ruin.h (n_cap + V) and the arena of sf_ruin_v2.h, which never overflows at n_cap + 21
+// (the lists a candidate changes hold at most n_cap elements together, every newly changed list reserves one entry per element still to place)
+__host__ __device__ inline size_t ruin_arena_cap(int n_cap, int V) { return (size_t)n_cap + (size_t)(V > 24 ? V : 24); }
 template <class VT>
 struct GCarve {
     size_t ring, ringx, load, off, visits, vals, tsum, tcnt, tpt, nstmp, node, slotbase, routeat, rankof, spvec, kopt, ruin, ruin_fast, prec, pgrp, leaftab, total;
@@ -156,7 +159,7 @@ struct GCarve {
         ruin = o;  // list ruin leaf: streams, candidate table, recreate work area (RuinLds)
         o = align_up(o + (has_ruin ? RUIN_LDS_BYTES + sizeof(uint32_t) * (V + 1) : 0), 16);  // + the slot prefix of a recreate round
         ruin_fast = o;  // edge[dim], row[dim], edge_end[V], slot[n_cap + V]
-        o = align_up(o + (has_ruin == 2 ? sizeof(uint16_t) * (2 * (size_t)dim + 2 * (size_t)V + n_cap) : 0), 16);
+        o = align_up(o + (has_ruin == 2 ? sizeof(uint16_t) * (2 * (size_t)dim + (size_t)V + ruin_arena_cap(n_cap, V)) : 0), 16);
         prec = o;  // earliest start, in-degree, queue, list successor of the precedence constraint's Kahn pass
         o = align_up(o + sizeof(uint32_t) * 4 * (size_t)prec_words, 16);
         pgrp = o;  // grouped trial evaluator (sf_prec_group.h): committed successor / in-degree + per-trial scratch
@@ -922,7 +925,9 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
         }
         sidx = uni64(sidx);
         sseed = uni64(sseed);
-        const StreamCtx ctx{sidx, sseed, p.order};
+        // FAST: SelectionOrder::Random, the default policy's (host-checked): every selection_index call site compiles to the one hash +
+        // remainder instead of all three orders (the Shuffled branch alone is two more remainders and a gcd loop per site)
+        const StreamCtx ctx{sidx, sseed, FAST ? 3 : p.order};
         ScoreV<L> late;
 #pragma unroll
         for (int k = 0; k < L; ++k) late.v[k] = 0;
@@ -1107,10 +1112,10 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
 #else
                 // trials without touching the lists (sf_ruin_v2.h) when the model is the default policy's shape; sf_ruin.h otherwise, for a
                 // candidate whose changed lists outgrow the scratch arena, and for the committed move
-                const bool v2 = rfast.edge != nullptr && rv2_model_ok(lm);
+                const bool v2 = FAST ? true : (rfast.edge != nullptr && rv2_model_ok(lm));  // (FAST: host-checked)
 #endif
                 for (uint32_t c = 0; c < (uint32_t)gl.ruin.moves_per_step; ++c) {
-                    if (c == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);
+                    if (c == 0 && (FAST || rfast.edge)) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);
                     if (c == 0 && v2) rv2_build_words(s_off, (uint32_t)V, ruin_sbase);
                     ruin_next_candidate(gl.ruin, rl, s_off, V, pool, c, lane);
                     int64_t base_score[L];
@@ -1118,7 +1123,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
                     const uint16_t* cand_c = rl.cand + (size_t)c * RuinLds::CAND_WORDS;
                     bool scored = false;
-                    if (v2) scored = ruin_trial_v2<L>(lm, s_visits, s_off, s_load, cand_c, rl.work, ruin_sbase, rfast, rfast.slot, (uint32_t)lm.n_cap + (uint32_t)V,
+                    if (v2) scored = ruin_trial_v2<L>(lm, s_visits, s_off, s_load, cand_c, rl.work, ruin_sbase, rfast, rfast.slot, (uint32_t)ruin_arena_cap(lm.n_cap, V),
                                                       gl.ruin.skip_empty, base_score, rl.score + (size_t)c * 4);
 #ifdef SF_RUIN_V2_CHECK
                     if (scored) {
@@ -1143,9 +1148,11 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         atomicAdd(&g_rv2_check[2], 1ull);
                     }
 #endif
-                    if (!scored) {
-                        ruin_recreate<L>(lm, s_visits, s_off, s_load, cand_c, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, false, base_score, rl.score + (size_t)c * 4);
-                        if (v2) rv2_build_words(s_off, (uint32_t)V, ruin_sbase);  // (the slot prefix of sf_ruin.h lives in the same words)
+                    if constexpr (!FAST) {  // (FAST: the host checked the model, the arena cannot overflow -- sf_ruin.h is not in that kernel at all)
+                        if (!scored) {
+                            ruin_recreate<L>(lm, s_visits, s_off, s_load, cand_c, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, false, base_score, rl.score + (size_t)c * 4);
+                            if (v2) rv2_build_words(s_off, (uint32_t)V, ruin_sbase);  // (the slot prefix of sf_ruin.h lives in the same words)
+                        }
                     }
                     wave_sync();
                 }
@@ -2568,8 +2575,14 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                     int64_t base_score[L];
 #pragma unroll
                     for (int kk = 0; kk < L; ++kk) base_score[kk] = cur[kk];
-                    ruin_recreate<L>(lm, s_visits, s_off, s_load, cd, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, true, base_score,
-                                     rl.score + (size_t)a * 4);
+                    if constexpr (FAST) {  // the list-preserving recreate once more, this time kept (sf_ruin_v2.h)
+                        rv2_build_words(s_off, (uint32_t)V, ruin_sbase);
+                        (void)ruin_trial_v2<L>(lm, s_visits, s_off, s_load, cd, rl.work, ruin_sbase, rfast, rfast.slot, (uint32_t)ruin_arena_cap(lm.n_cap, V), gl.ruin.skip_empty,
+                                               base_score, rl.score + (size_t)a * 4, true, g_visits);
+                    } else {
+                        ruin_recreate<L>(lm, s_visits, s_off, s_load, cd, rl.work, ruin_sbase, rfast, gl.ruin.skip_empty, true, base_score,
+                                         rl.score + (size_t)a * 4);
+                    }
                 }
                 wave_sync();
                 if (has_nearby) {  // any list may have changed: rebuild node -> (route, position)

@@ -28,6 +28,9 @@
 
 namespace sf {
 
+#ifdef SF_PHASE_PROFILE  // shader clocks per part of the v2 trial: 0 removal, 1 first scans, 2 best-lists extraction, 3 re-pricing, 4 pick + placement, 5 restore
+__device__ unsigned long long g_rphase2[8];
+#endif
 #ifdef SF_RUIN_V2_CHECK  // diagnostic build: every trial is scored by both paths (scripts/ruin_v2_check.py)
 __device__ unsigned long long g_rv2_check[8];  // 0 candidates, 1 mismatches, 2 fallbacks, 3.. first mismatch: replica, candidate, count, v2 soft, old soft
 #endif
@@ -100,10 +103,13 @@ __device__ __forceinline__ bool rv2_pick(bool offer, const int32_t (&dv)[L], uin
 // Trial score of candidate `cd` = (list, count, ascending positions) on the committed lists.  words = the per-list table of this step
 // (rv2_build_words; restored on return), arena = `arena_cap` u16 of scratch, work = RuinLds::work.  Returns false -- with the edge table
 // and the words as it found them -- when the arena cannot hold the lists the candidate changes; the caller then takes sf_ruin.h's path.
+// `keep` (the committed move, wave-uniform): the recreated lists replace the committed ones -- the flat CSR is rebuilt from the per-list
+// words through `gscratch` (n_cap words of HBM nobody reads inside a launch: the replica's state of the previous launch), offsets and the
+// loads of the changed lists follow; the edge table and the words are left stale (both are rebuilt at the start of the next step).
 template <int L>
-__device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_t* visits, const uint32_t* off, const int64_t* load, const uint16_t* cd,
-                                              uint16_t* work, uint32_t* words, const RuinFast& rf, uint16_t* arena, uint32_t arena_cap, int skip_empty,
-                                              const int64_t* cur, int64_t* out_score) {
+__device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, uint16_t* visits, uint32_t* off, int64_t* load, const uint16_t* cd, uint16_t* work,
+                                              uint32_t* words, const RuinFast& rf, uint16_t* arena, uint32_t arena_cap, int skip_empty, const int64_t* cur,
+                                              int64_t* out_score, bool keep = false, uint32_t* gscratch = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t V = (uint32_t)lm.V, depot = (uint32_t)lm.depot, dim = (uint32_t)lm.dim;
     const bool has_cap = lm.cap_level >= 0 && lm.demand != nullptr;
@@ -118,6 +124,7 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
     const uint16_t* mat16 = lm.mat16;
     const uint32_t ent = uni((uint32_t)cd[0]), cnt = uni((uint32_t)cd[1]);
     const uint32_t oe = uni(off[ent]), plen = uni(off[ent + 1]) - oe, klen = plen - cnt;
+    RPH_DECL
     uint16_t* elog = work;  // [<= 24][2] (edge index | 0x8000 for edge_end, old value), restored in reverse
     uint32_t nlog = 0;
     auto log_edge = [&](uint32_t idx, bool is_end) {  // wave-uniform: remember the old value of edge[idx] / edge_end[idx]
@@ -201,6 +208,7 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
     }
     wave_sync();
 
+    RPH(0)
     // current load of list e (lane-private e): the committed load unless the candidate changed the list
     auto load_of = [&](uint32_t e) -> int32_t {
         int32_t l0 = has_cap ? (int32_t)load32[2u * e] : 0;
@@ -222,9 +230,10 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
     for (uint32_t i = 0; i < cnt; ++i) {
         const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xj, (int)i);
         const int32_t dx = __builtin_amdgcn_readlane(dxj, (int)i);
-        wave_sync();  // the previous element's scan is done with the row
-        for (uint32_t c = lane; c < dim; c += 64) rf.row[c] = mat16[x * dim + c];
-        wave_sync();
+        // The legs of element x come straight from its matrix row (2 KB, 16 lines: they sit in the CU's L1 after the first touches) -- a
+        // slot needs ONE of them, x -> next: x -> prev is the previous slot's.  (sf_ruin.h stages the row in LDS for its slot-parallel scan.)
+        const uint16_t* xrow = mat16 + x * dim;
+        const uint32_t rw_depot = uni((uint32_t)xrow[depot]);
         int32_t b_dv[2][L];
         uint32_t b_pos[2] = {0, 0};
         bool b_has[2] = {false, false};
@@ -244,10 +253,10 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
             const int32_t o1 = l0 + dx - cap32, o0 = l0 - cap32;
             const int32_t dc = has_cap ? (o1 > 0 ? o1 : 0) - (o0 > 0 ? o0 : 0) : 0;
             const uint32_t nslots = uni((uint32_t)wave_max_i32(act ? (int32_t)len + 1 : 0));
-            uint32_t prev = depot;
-            constexpr uint32_t U = 4;
+            uint32_t rw_prev = rw_depot;
+            constexpr uint32_t U = 8;
             for (uint32_t q0 = 0; q0 < nslots; q0 += U) {
-                uint32_t nxr[U], nx[U], da[U], db[U], d0[U];
+                uint32_t nxr[U], rw[U], d0[U];
                 bool at_end[U];
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
@@ -257,17 +266,15 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
-                    nx[u] = at_end[u] ? depot : nxr[u];
-                    const uint32_t pv = u == 0 ? prev : nx[u - 1];
-                    da[u] = rf.row[pv];
-                    db[u] = rf.row[nx[u]];
+                    rw[u] = xrow[at_end[u] ? depot : nxr[u]];
                     const uint16_t* dp = at_end[u] ? rf.edge_end + ec : rf.edge + nxr[u];  // an empty list's edge_end is 0
                     d0[u] = *dp;
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
                     const uint32_t q = q0 + u;
-                    const int32_t dd = (int32_t)da[u] + (int32_t)db[u] - (int32_t)d0[u];
+                    const uint32_t da = u == 0 ? rw_prev : rw[u - 1];
+                    const int32_t dd = (int32_t)da + (int32_t)rw[u] - (int32_t)d0[u];
                     int32_t dv[L];
 #pragma unroll
                     for (int k = 0; k < L; ++k) dv[k] = ca[k] * dc + cb[k] * dd;
@@ -277,9 +284,10 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
                     b_pos[ps] = take ? q : b_pos[ps];
                     b_has[ps] = b_has[ps] || take;
                 }
-                prev = nx[U - 1];
+                rw_prev = rw[U - 1];
             }
         }
+        RPH(1)
         // the cnt best lists of element i in (score, list) order
         for (uint32_t m = 0; m < cnt; ++m) {
             // a lane offers the better of its two lists (the first one on a tie: it is the lower list)
@@ -305,18 +313,27 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
                 T_ok = true;
             }
         }
+        RPH(2)
     }
 
+    RPH(2)
     // ---- rounds: place the best (element, list, position) until nothing remains ----
     uint32_t remmask = (1u << cnt) - 1u;
     bool rolled_back = false;
     while (remmask) {
-        // the lists changed so far, priced again for every remaining element: results in lanes i * 8 + d
-        int32_t R_dv[L];
-        uint32_t R_key = 0;
-        bool R_ok = false;
+        // Every lane keeps ONE running offer (delta, element, list << 16 | position), ordered like the reference's scan: better score, then
+        // the earlier element, then the earlier (list, position).  It starts from the lane's kept entry (if that list is untouched) ...
+        const uint32_t my_i = lane >> 3;
+        bool o_has = T_ok && my_i < cnt && ((remmask >> my_i) & 1u) != 0;
+        for (uint32_t d = 0; d < nmod; ++d) {
+            const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)mod_list, (int)d);
+            if ((dirty >> d) & 1u) o_has = o_has && (T_key >> 16) != le;
+        }
+        int32_t o_dv[L];
 #pragma unroll
-        for (int k = 0; k < L; ++k) R_dv[k] = 0;
+        for (int k = 0; k < L; ++k) o_dv[k] = T_dv[k];
+        uint32_t o_i = my_i, o_key = T_key;
+        // ... and takes in the lists changed so far, priced again for every remaining element (lane = slot): no reduction per list
         for (uint32_t d = 0; d < nmod; ++d) {
             if (!((dirty >> d) & 1u)) continue;
             const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)mod_list, (int)d);
@@ -324,68 +341,43 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
             const uint32_t w = uni(words[le]);
             const uint32_t len = (w >> 16) & 0x7FFFu;
             const uint16_t* lp = arena + (w & 0xFFFFu);
-            uint32_t rm = remmask;
-            while (rm) {
-                const uint32_t i = (uint32_t)__ffs((int)rm) - 1u;
-                rm &= rm - 1u;
-                const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xj, (int)i);
-                const int32_t dx = __builtin_amdgcn_readlane(dxj, (int)i);
-                const int32_t o1 = l0 + dx - cap32, o0 = l0 - cap32;
-                const int32_t dc = has_cap ? (o1 > 0 ? o1 : 0) - (o0 > 0 ? o0 : 0) : 0;
-                int32_t bd[L];
-#pragma unroll
-                for (int k = 0; k < L; ++k) bd[k] = (int32_t)0x80000000;
-                uint32_t bq = 0;
-                bool bh = false;
-                for (uint32_t c0 = 0; c0 <= len; c0 += 64) {  // lane = slot
-                    const uint32_t q = c0 + lane;
-                    const bool in = q <= len;
-                    const bool at_end = q >= len;
-                    const uint32_t pv = (in && q > 0) ? (uint32_t)lp[q - 1] : depot;
-                    const uint32_t nxr = (in && !at_end) ? (uint32_t)lp[q] : 0u;
-                    const uint32_t nx = at_end ? depot : nxr;
-                    const uint32_t da = in ? (uint32_t)mat16[x * dim + pv] : 0u;
-                    const uint32_t db = in ? (uint32_t)mat16[x * dim + nx] : 0u;
-                    const uint16_t* dp = at_end ? rf.edge_end + le : rf.edge + nxr;
-                    const uint32_t d0 = *dp;
-                    const int32_t dd = (int32_t)da + (int32_t)db - (int32_t)d0;
+            for (uint32_t c0 = 0; c0 <= len; c0 += 64) {
+                const uint32_t q = c0 + lane;
+                const bool in = q <= len;
+                const bool at_end = q >= len;
+                const uint32_t pv = (in && q > 0) ? (uint32_t)lp[q - 1] : depot;
+                const uint32_t nxr = (in && !at_end) ? (uint32_t)lp[q] : 0u;
+                const uint32_t nx = at_end ? depot : nxr;
+                const uint16_t* dp = at_end ? rf.edge_end + le : rf.edge + nxr;
+                const int32_t d0 = (int32_t)(uint32_t)*dp;
+                uint32_t rm = remmask;
+                while (rm) {
+                    const uint32_t i = (uint32_t)__ffs((int)rm) - 1u;
+                    rm &= rm - 1u;
+                    const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xj, (int)i);
+                    const int32_t dx = __builtin_amdgcn_readlane(dxj, (int)i);
+                    const int32_t o1 = l0 + dx - cap32, o0 = l0 - cap32;
+                    const int32_t dc = has_cap ? (o1 > 0 ? o1 : 0) - (o0 > 0 ? o0 : 0) : 0;
+                    const int32_t da = (int32_t)(uint32_t)mat16[x * dim + pv], db = (int32_t)(uint32_t)mat16[x * dim + nx];
+                    const int32_t dd = da + db - d0;
                     int32_t dv[L];
 #pragma unroll
                     for (int k = 0; k < L; ++k) dv[k] = ca[k] * dc + cb[k] * dd;
-                    const bool take = in && (!bh || rv2_gt<L>(dv, bd));
+                    const uint32_t key = (le << 16) | q;
+                    const bool gt = rv2_gt<L>(dv, o_dv), lt = rv2_gt<L>(o_dv, dv);
+                    const bool take = in && (!o_has || gt || (!lt && (i < o_i || (i == o_i && key < o_key))));
 #pragma unroll
-                    for (int k = 0; k < L; ++k) bd[k] = take ? dv[k] : bd[k];
-                    bq = take ? q : bq;
-                    bh = bh || take;
-                }
-                int32_t M[L];
-                uint32_t k1 = 0, k2 = 0;
-                const bool any = rv2_pick<L>(bh, bd, bq, 0u, M, k1, k2);
-                if (lane == i * 8u + d) {
-#pragma unroll
-                    for (int k = 0; k < L; ++k) R_dv[k] = M[k];
-                    R_key = (le << 16) | k1;
-                    R_ok = any;
+                    for (int k = 0; k < L; ++k) o_dv[k] = take ? dv[k] : o_dv[k];
+                    o_i = take ? i : o_i;
+                    o_key = take ? key : o_key;
+                    o_has = o_has || take;
                 }
             }
         }
-        // this lane's offer for its element: the kept entry (if its list is untouched) or the re-priced list, whichever is better
-        const uint32_t my_i = lane >> 3;
-        const bool my_rem = my_i < cnt && ((remmask >> my_i) & 1u) != 0;
-        bool t_live = T_ok && my_rem;
-        for (uint32_t d = 0; d < nmod; ++d) {
-            const uint32_t le = (uint32_t)__builtin_amdgcn_readlane((int)mod_list, (int)d);
-            if ((dirty >> d) & 1u) t_live = t_live && (T_key >> 16) != le;
-        }
-        const bool r_live = R_ok && my_rem;
-        const bool use_r = r_live && (!t_live || rv2_gt<L>(R_dv, T_dv) || (!rv2_gt<L>(T_dv, R_dv) && R_key < T_key));
-        int32_t o_dv[L];
-#pragma unroll
-        for (int k = 0; k < L; ++k) o_dv[k] = use_r ? R_dv[k] : T_dv[k];
-        const uint32_t o_key = use_r ? R_key : T_key;
+        RPH(3)
         int32_t M[L];
         uint32_t wi = 0, wkey = 0;
-        if (!rv2_pick<L>(t_live || r_live, o_dv, my_i, o_key, M, wi, wkey)) {  // no destination at all: restore_removed_elements (:250-253)
+        if (!rv2_pick<L>(o_has, o_dv, o_i, o_key, M, wi, wkey)) {  // no destination at all: restore_removed_elements (:250-253)
             rolled_back = true;
             break;
         }
@@ -395,7 +387,7 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
 #pragma unroll
         for (int k = 0; k < L; ++k) s[k] += (int64_t)M[k];
         remmask &= ~(1u << wi);
-        if (!remmask) break;  // the last placement changes nothing anybody reads
+        if (!remmask && !keep) break;  // (a trial: the last placement changes nothing anybody reads)
         // ---- the placement: list `be` gets x at position bp (a copy in the arena; the edge table's two seams) ----
         uint32_t md = 0xFFFFFFFFu;
         for (uint32_t d = 0; d < nmod; ++d)
@@ -447,8 +439,40 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
         if (lane == md) mod_load += dx;
         dirty |= 1u << md;
         wave_sync();
+        RPH(4)
     }
+    RPH(4)
 
+    if (keep && ok && !rolled_back) {
+        // ---- the committed move: new offsets (prefix over the lists' current lengths), every list copied to its new place ----
+        uint32_t carry = 0;
+        for (uint32_t base = 0; base < V; base += 64) {
+            const uint32_t e = base + lane;
+            const uint32_t w = e < V ? words[e] : 0u;
+            const uint32_t len = (w >> 16) & 0x7FFFu;
+            const uint32_t inc = wave_incl_scan(len);
+            const uint32_t no = carry + inc - len;
+            if (e < V) {
+                const uint16_t* src = ((w & RV2_ARENA) ? arena : visits) + (w & 0xFFFFu);
+                for (uint32_t q = 0; q < len; ++q) gscratch[no + q] = src[q];
+            }
+            wave_sync();  // (the reads of `off` by nobody: the sources are named by the words)
+            if (e < V) off[e] = no;
+            carry += (uint32_t)__shfl((int)inc, 63);
+        }
+        if (lane == 0) off[V] = carry;
+        if (has_cap && lane < nmod) load[mod_list] = (int64_t)mod_load;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the copies, through the CU's write-through L1, before their reload
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t t = lane; t < carry; t += 64) visits[t] = (uint16_t)gscratch[t];
+        wave_sync();
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) out_score[k] = s[k];
+        }
+        return true;
+    }
     // ---- leave everything as it was found ----
     for (uint32_t t = nlog; t-- > 0;) {
         if (lane == 0) {
@@ -461,6 +485,10 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, const uint16_
     }
     if (lane < nmod) words[mod_list] = rv2_word(off[mod_list], off[mod_list + 1] - off[mod_list], false);
     wave_sync();
+    RPH(5)
+#ifdef SF_PHASE_PROFILE
+    if (lane == 0) for (int _k = 0; _k < 8; ++_k) atomicAdd(&g_rphase2[_k], (unsigned long long)rph_acc[_k]);
+#endif
     if (!ok) return false;
     if (lane == 0) {
 #pragma unroll

@@ -45,6 +45,12 @@ extern "C" int32_t SF_PH_NAME(sf_debug_phases_mixed, SF_TU_L, SF_TU_VTB, SF_TU_R
     (void)hipMemcpyToSymbol(HIP_SYMBOL(sf::g_phase), z, 64);
     return 0;
 }
+extern "C" int32_t SF_PH_NAME(sf_debug_ruin2_phases_mixed, SF_TU_L, SF_TU_VTB, SF_TU_RUIN, SF_TU_PREC)(uint64_t* out8) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_rphase2), 64) != hipSuccess) return -1;
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(sf::g_rphase2), z, 64);
+    return 0;
+}
 extern "C" int32_t SF_PH_NAME(sf_debug_ruin_phases_mixed, SF_TU_L, SF_TU_VTB, SF_TU_RUIN, SF_TU_PREC)(uint64_t* out8) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(sf::g_rphase), 64) != hipSuccess) return -1;
     unsigned long long z[8] = {0};
