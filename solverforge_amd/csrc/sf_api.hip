@@ -97,6 +97,7 @@ struct sf_ctx {
     NbrIndex nbr_wave{nullptr};   // ... and its neighbour index
     bool wave_renumbered = false;
     int last_wave_mode = -1;      // launch mode of the last wave-engine launch (sf_list_wave_layout)
+    uint32_t* d_node_tab32 = nullptr;  // [R][dim] node -> slot tables of the generic engine's FAST + ruin kernel (GLeaves::node_tab)
     struct WaveFix {  // what differs in lm_wave from lm (applied at launch: the per-replica state pointers of lm may be set later)
         const uint16_t *perm, *inv, *mat16;
         const int32_t* demand;
@@ -2347,11 +2348,6 @@ template <int L, class VT, bool RUIN = false, bool PREC = false>
 static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl, int n_replicas, bool trace) {
     const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
     const bool tables = ctx->has_scalar_model && ctx->sm.tables();
-    GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
-                  gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
-                  PREC && gl.prec_lds ? gl.prec.n : 0, tables ? ctx->sm.n_values : 0, tables && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0,
-                  PREC && gl.prec_lds ? gl.prec_groups : 0);
-    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     // FAST instantiation: the reference's default list policy on a list-only model (see k_mixed_search_wave)
     static const bool no_fast = std::getenv("SF_AMD_MIXED_NO_FAST") != nullptr;  // diagnostics / parity tests: force the general instantiation
     bool fast_kinds = true;  // the leaf kinds the FAST instantiation keeps (the default list policy of a slot with a distance meter)
@@ -2365,6 +2361,23 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
                       p.order == SF_ORDER_RANDOM &&  // (the default policy's SelectionOrder: compiled in, see StreamCtx in the kernel)
                       // with a ruin leaf the FAST kernel carries the list-preserving recreate only (sf_ruin_v2.h: rv2_model_ok + the edge table)
                       (!RUIN || (ctx->lm.leg16 && ctx->lm.V <= 128 && ctx->lm.n_cap <= 32767 && ctx->lm.dim <= 32767 && ctx->lm.small32 && ctx->lm.mat16));
+    // (FAST + ruin: the list-preserving recreate only and the node -> slot table in HBM, see the kernel)
+    const bool nodeg = fast && RUIN;
+    GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
+                  gl.kopt_nearby, gl.n, gl.has_ruin ? (nodeg ? 3 : (ctx->lm.leg16 ? 2 : 1)) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
+                  PREC && gl.prec_lds ? gl.prec.n : 0, tables ? ctx->sm.n_values : 0, tables && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0,
+                  PREC && gl.prec_lds ? gl.prec_groups : 0, nodeg);
+    if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
+    GLeaves gl2 = gl;
+    if (nodeg) {
+        if (!ctx->d_node_tab32) {
+            uint32_t* nt = nullptr;
+            int rc = dalloc(ctx, &nt, (size_t)ctx->R * ctx->lm.dim);
+            if (rc) return rc;
+            ctx->d_node_tab32 = nt;
+        }
+        gl2.node_tab = ctx->d_node_tab32;
+    }
     // replicas (waves) per workgroup: the count that keeps the most waves resident per CU (a workgroup's LDS is
     // allocated as a whole; the kernel is built for SF_MIXED_BLOCKS_PER_CU workgroups of 4 waves per CU, the FAST
     // instantiation for SF_MIXED_FAST_BLOCKS_PER_CU); ties go to the larger group
@@ -2374,11 +2387,11 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     // (not with the grouped evaluator: its scratch leaves room for 8 - 10 replicas per CU, and the 128-register build is slower per wave:
     // nine-leaf policy 20 x 10 at 6,144 replicas 71 M moves/s with it, 106 M without)
     const bool prec_occ = PREC && !trace && !no_prec_occ && !gl.prec_groups && n_replicas > 8 * 256 && (160 * 1024) / (cv.total + 256) > 8;
-    const size_t max_waves = 4 * (size_t)(fast && !RUIN ? SF_MIXED_FAST_BLOCKS_PER_CU : (prec_occ ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU));  // by register budget
+    const size_t max_waves = 4 * (size_t)(fast ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_PER_CU : SF_MIXED_FAST_BLOCKS_PER_CU) : (prec_occ ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU));  // by register budget
     int wpb = 1;
     size_t best_resident = 0;
     for (int w = 1; w <= 4; ++w) {
-        const size_t per_wg = cv.total * w + 1024 + (PREC ? (size_t)gl.prec_static : 0);  // + the static annealing state, the shared copy of the precedence graph
+        const size_t per_wg = cv.total * w + (fast ? 0 : 1024) + (PREC ? (size_t)gl.prec_static : 0);  // + the static annealing state (the FAST kernels have none), the shared copy of the precedence graph
         if (per_wg > 160 * 1024) break;
         size_t groups = (160 * 1024) / per_wg;
         if (groups * w > max_waves) groups = max_waves / w;
@@ -2399,7 +2412,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     }
     SearchParams q = p;
     q.n_launch = n_replicas;
-    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : (prec_occ ? 2 : 0), make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb + (PREC ? (size_t)gl.prec_static : 0), &gl))));
+    HIPCHK(ctx, (launch_tu_mixed<L, (int)sizeof(VT), RUIN, PREC>(trace, fast ? 1 : (prec_occ ? 2 : 0), make_launch(ctx, &q, (n_replicas + wpb - 1) / wpb, 64 * wpb, cv.total * wpb + (PREC ? (size_t)gl.prec_static : 0), &gl2))));
     return SF_OK;
 }
 static bool has_plain_list_leaves(sf_ctx* ctx) {

@@ -106,6 +106,7 @@ struct GLeaves {
     int32_t prec_static;     // bytes of the workgroup-shared LDS copy of the constraint's static graph (0 = read it from HBM)
     int32_t prec_groups;     // LDS scratch: trials per wavefront of the grouped evaluator (prec_eval_grouped: 8, 4 or 2; 0 = off)
     PlfModel plf;            // critical-path precedence leaf (kind 16384; PREC instantiations, sf_prec_leaf.h)
+    uint32_t* node_tab;      // [R][dim] node -> (list << 16 | position) in HBM: the FAST + ruin instantiation keeps it out of the LDS slice (12 replicas per CU)
 };
 
 // u16 entries of RuinFast::slot: the slot table of sf_ruin.h (n_cap + V) and the arena of sf_ruin_v2.h, which never overflows at n_cap + 21
@@ -121,15 +122,17 @@ struct GCarve {
     // prec_words: node count of the precedence constraint when its four scratch arrays live in LDS (sf_precedence.h), else 0
     // n_table / run_P: per-value tables of the scalar class's value-keyed constraints (n_values entries; the consecutive-runs /
     // presence table behind the count table, as SCarve lays them out), 0 when the class has none
+    // has_ruin 3: the list-preserving recreate only (sf_ruin_v2.h; the FAST instantiation): edge table + list-end edges + arena, no matrix row
+    // node_global: the node -> slot table lives in HBM (GLeaves::node_tab)
     __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0,
-                               int prec_words = 0, int n_table = 0, int run_P = 0, int prec_groups = 0) {
+                               int prec_words = 0, int n_table = 0, int run_P = 0, int prec_groups = 0, bool node_global = false) {
         size_t o = 0;
         ring = o;  // the candidate rings live in HBM (GLeaves::ring / ringx) unless SF_MIXED_RING_LDS
         o = align_up(o + (SF_MIXED_RING_LDS ? sizeof(uint32_t) * 2 * GRC * n_leaves : 0), 16);
         ringx = o;  // one extra byte per ring entry (segment size of the sublist leaves)
         o = align_up(o + (SF_MIXED_RING_LDS ? GRC * n_leaves : 0), 16);
         node = o;
-        o = align_up(o + sizeof(uint32_t) * dim_nearby, 16);
+        o = align_up(o + (node_global ? 0 : sizeof(uint32_t) * dim_nearby), 16);
         slotbase = o;
         o = align_up(o + (dim_nearby ? sizeof(uint16_t) * (V + 1) * 2 : 0), 16);
         routeat = o;
@@ -159,7 +162,7 @@ struct GCarve {
         ruin = o;  // list ruin leaf: streams, candidate table, recreate work area (RuinLds)
         o = align_up(o + (has_ruin ? RUIN_LDS_BYTES + sizeof(uint32_t) * (V + 1) : 0), 16);  // + the slot prefix of a recreate round
         ruin_fast = o;  // edge[dim], row[dim], edge_end[V], slot[n_cap + V]
-        o = align_up(o + (has_ruin == 2 ? sizeof(uint16_t) * (2 * (size_t)dim + (size_t)V + ruin_arena_cap(n_cap, V)) : 0), 16);
+        o = align_up(o + (has_ruin >= 2 ? sizeof(uint16_t) * ((has_ruin == 2 ? 2 : 1) * (size_t)dim + (size_t)V + ruin_arena_cap(n_cap, V)) : 0), 16);
         prec = o;  // earliest start, in-degree, queue, list successor of the precedence constraint's Kahn pass
         o = align_up(o + sizeof(uint32_t) * 4 * (size_t)prec_words, 16);
         pgrp = o;  // grouped trial evaluator (sf_prec_group.h): committed successor / in-degree + per-trial scratch
@@ -287,7 +290,10 @@ namespace sf {
 #define SF_MIXED_PREC_BLOCKS_PER_CU 4
 #endif
 template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false, int MODE = 0>
-__global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PER_CU : (MODE == 2 ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU)) void k_mixed_search_wave(
+#ifndef SF_MIXED_FAST_RUIN_BLOCKS_PER_CU
+#define SF_MIXED_FAST_RUIN_BLOCKS_PER_CU 3  // (round 5: 168 registers, 91 spilled values -- like the kernel without the leaf; LDS slice 13.4 KB at CVRP-1000)
+#endif
+__global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_PER_CU : SF_MIXED_FAST_BLOCKS_PER_CU) : (MODE == 2 ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU)) void k_mixed_search_wave(
     ListModel lm, ScalarModel sm, GLeaves gl, SearchParams p, int has_list_arg, int has_scalar_arg, NbrIndex nb) {
     constexpr bool FAST = MODE == 1;
     static_assert(!FAST || (!TRACE && !PREC), "FAST: untraced, no precedence constraint");
@@ -302,8 +308,8 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const int rr = (int)(blockIdx.x * (blockDim.x >> 6) + wave_in_group);
     if (rr >= p.n_launch) return;  // no workgroup barrier below
     const int r = rr + p.replica_base;
-    __shared__ uint64_t s_sa[4][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
-    uint64_t* saw = s_sa[wave_in_group];
+    __shared__ uint64_t s_sa[FAST ? 1 : 4][FAST ? 1 : SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas (FAST: LateAcceptance, no static LDS)
+    uint64_t* saw = s_sa[FAST ? 0 : wave_in_group];
     const bool annealing = acceptor == 3;
     if (annealing) sa_load(saw, p.sa, r, lane);
     const uint32_t ns = has_scalar ? (uint32_t)sm.n : 0u;
@@ -311,9 +317,12 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     const bool has_nearby = gl.has_nearby != 0;
     const bool unified_eval = FAST || (has_list && (lm.mat_symmetric != 0 || lm.dist_level < 0) && !p.legacy_eval);
     const bool tables = !FAST && has_scalar && sm.tables();  // value-keyed constraints of the scalar class: per-value tables in LDS
-    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (lm.leg16 ? 2 : 1) : 0, lm.dim,
+    // FAST + ruin: only the list-preserving recreate (no matrix row in LDS) and the node -> slot table in HBM: 19.4 -> 13.4 KB per replica at
+    // CVRP-1000, twelve replicas per CU with the 168-register build instead of eight
+    constexpr bool NODEG = FAST && RUIN;
+    const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (FAST ? 3 : (lm.leg16 ? 2 : 1)) : 0, lm.dim,
                         PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0,
-                        PREC && gl.prec_lds ? gl.prec_groups : 0);
+                        PREC && gl.prec_lds ? gl.prec_groups : 0, NODEG);
     unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
     PH_DECL
     PgrpStatic pgs{};  // the same arrays behind typed LDS pointers
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
     uint16_t* ns_tmp = (uint16_t*)(mem + cv.nstmp);
     int64_t* t_sum = (int64_t*)(mem + cv.tsum);  // per-value summed size / entity count of the working state
     uint32_t* t_cnt = (uint32_t*)(mem + cv.tcnt);
-    uint32_t* node_slot = (uint32_t*)(mem + cv.node);
+    uint32_t* node_slot = NODEG ? gl.node_tab + (size_t)r * lm.dim : (uint32_t*)(mem + cv.node);
     uint16_t* nb_slot_base = (uint16_t*)(mem + cv.slotbase);  // [nearby leaf 0/1][V+1]
     uint16_t* nb_route_at = (uint16_t*)(mem + cv.routeat);
     uint16_t* nb_rank_of = (uint16_t*)(mem + cv.rankof);
@@ -402,15 +411,16 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
             for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
         }
         wave_sync();
+        if (NODEG) ring_sync();  // (HBM table: through the CU's write-through L1)
     }
 
     const RuinLds rl(mem + cv.ruin);
     uint32_t* ruin_sbase = (uint32_t*)(mem + cv.ruin + RUIN_LDS_BYTES);
     RuinFast rfast{nullptr, nullptr, nullptr, nullptr};
-    if (RUIN && lm.leg16) {
+    if (RUIN && (FAST || lm.leg16)) {
         rfast.edge = (uint16_t*)(mem + cv.ruin_fast);
-        rfast.row = rfast.edge + lm.dim;
-        rfast.edge_end = rfast.row + lm.dim;
+        rfast.row = FAST ? nullptr : rfast.edge + lm.dim;  // (FAST: sf_ruin_v2.h reads the legs from the matrix rows)
+        rfast.edge_end = rfast.edge + (FAST ? 1 : 2) * lm.dim;
         rfast.slot = rfast.edge_end + V;
     }
     if (RUIN) {  // the leaf's per-solve stream lives in LDS for the launch
@@ -2591,6 +2601,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                         for (uint32_t q = 0; q < len; ++q) node_slot[s_visits[o + q]] = (v << 16) | q;
                     }
                     wave_sync();
+                    if (NODEG) ring_sync();
                 }
             } else {
                 if (tracing && lane == 0) {
@@ -2621,6 +2632,7 @@ __global__ __launch_bounds__(256, (MODE == 1 && !RUIN) ? SF_MIXED_FAST_BLOCKS_PE
                             node_slot[s_visits[ob + (t - la)]] = (rb_ << 16) | (t - la);
                     }
                     wave_sync();
+                    if (NODEG) ring_sync();
                 }
             }
             if (PREC && kind > 2) {  // a list move was committed: the HBM copy the trials undo from, and the constraint's committed state

@@ -227,84 +227,114 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, uint16_t* vis
 #pragma unroll
     for (int k = 0; k < L; ++k) T_dv[k] = 0;
     const uint32_t n_pass = (V + 63u) / 64u;  // <= 2
-    for (uint32_t i = 0; i < cnt; ++i) {
-        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)xj, (int)i);
-        const int32_t dx = __builtin_amdgcn_readlane(dxj, (int)i);
-        // The legs of element x come straight from its matrix row (2 KB, 16 lines: they sit in the CU's L1 after the first touches) -- a
-        // slot needs ONE of them, x -> next: x -> prev is the previous slot's.  (sf_ruin.h stages the row in LDS for its slot-parallel scan.)
-        const uint16_t* xrow = mat16 + x * dim;
-        const uint32_t rw_depot = uni((uint32_t)xrow[depot]);
-        int32_t b_dv[2][L];
-        uint32_t b_pos[2] = {0, 0};
-        bool b_has[2] = {false, false};
+    // ONE walk over every list prices its slots for ALL removed elements: the list read, the end test and the edge are the same for each of
+    // them; an element adds its row entry x -> next (x -> prev is the previous slot's) and a compare.  The legs come straight from the
+    // matrix rows (2 KB each, 16 lines: L1 / L2 hits); sf_ruin.h stages one row at a time in LDS for its slot-parallel scan.
+    constexpr uint32_t NE = RUIN_MAX_COUNT;
+    const uint16_t* xrow[NE];
+    int32_t dxs[NE];
+    uint32_t rw_depot[NE];
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) {
+    for (uint32_t i = 0; i < NE; ++i) {
+        const uint32_t x = i < cnt ? (uint32_t)__builtin_amdgcn_readlane((int)xj, (int)i) : depot;
+        dxs[i] = __builtin_amdgcn_readlane(dxj, (int)i);
+        xrow[i] = mat16 + x * dim;
+        rw_depot[i] = uni((uint32_t)xrow[i][depot]);
+    }
+    int32_t b_dv[2][NE][L];
+    uint32_t b_pos[2][NE];
+    uint32_t b_has[2] = {0u, 0u};  // bit i: this lane's list has a slot for element i
 #pragma unroll
-            for (int k = 0; k < L; ++k) b_dv[ps][k] = (int32_t)0x80000000;
-            if ((uint32_t)ps >= n_pass) continue;
-            const uint32_t e = (uint32_t)ps * 64u + lane;
-            const bool in_v = e < V;
-            const uint32_t ec = in_v ? e : 0u;
-            const uint32_t w = words[ec];
-            const uint32_t len = (w >> 16) & 0x7FFFu;
-            const uint16_t* lp = ((w & RV2_ARENA) ? arena : visits) + (w & 0xFFFFu);
-            const bool act = in_v && !(skip_empty && len == 0);
-            const int32_t l0 = load_of(ec);
-            const int32_t o1 = l0 + dx - cap32, o0 = l0 - cap32;
-            const int32_t dc = has_cap ? (o1 > 0 ? o1 : 0) - (o0 > 0 ? o0 : 0) : 0;
-            const uint32_t nslots = uni((uint32_t)wave_max_i32(act ? (int32_t)len + 1 : 0));
-            uint32_t rw_prev = rw_depot;
-            constexpr uint32_t U = 8;
-            for (uint32_t q0 = 0; q0 < nslots; q0 += U) {
-                uint32_t nxr[U], rw[U], d0[U];
-                bool at_end[U];
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+        for (uint32_t i = 0; i < NE; ++i) {
+            b_pos[ps][i] = 0;
+#pragma unroll
+            for (int k = 0; k < L; ++k) b_dv[ps][i][k] = (int32_t)0x80000000;
+        }
+        if ((uint32_t)ps >= n_pass) continue;
+        const uint32_t e = (uint32_t)ps * 64u + lane;
+        const bool in_v = e < V;
+        const uint32_t ec = in_v ? e : 0u;
+        const uint32_t w = words[ec];
+        const uint32_t len = (w >> 16) & 0x7FFFu;
+        const uint16_t* lp = ((w & RV2_ARENA) ? arena : visits) + (w & 0xFFFFu);
+        const bool act = in_v && !(skip_empty && len == 0);
+        const int32_t l0 = load_of(ec);
+        int32_t dcs[NE];
+#pragma unroll
+        for (uint32_t i = 0; i < NE; ++i) {
+            const int32_t o1 = l0 + dxs[i] - cap32, o0 = l0 - cap32;
+            dcs[i] = has_cap ? (o1 > 0 ? o1 : 0) - (o0 > 0 ? o0 : 0) : 0;
+        }
+        const uint32_t nslots = uni((uint32_t)wave_max_i32(act ? (int32_t)len + 1 : 0));
+        uint32_t rw_prev[NE];
+#pragma unroll
+        for (uint32_t i = 0; i < NE; ++i) rw_prev[i] = rw_depot[i];
+        constexpr uint32_t U = 4;
+        for (uint32_t q0 = 0; q0 < nslots; q0 += U) {
+            uint32_t nxr[U], d0[U];
+            bool at_end[U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t q = q0 + u;
+                nxr[u] = lp[q < len ? q : 0u];
+                at_end[u] = q >= len;
+            }
+            uint32_t rw[NE][U];
+#pragma unroll
+            for (uint32_t u = 0; u < U; ++u) {
+                const uint32_t nx = at_end[u] ? depot : nxr[u];
+#pragma unroll
+                for (uint32_t i = 0; i < NE; ++i)
+                    if (i < cnt) rw[i][u] = xrow[i][nx];
+                const uint16_t* dp = at_end[u] ? rf.edge_end + ec : rf.edge + nxr[u];  // an empty list's edge_end is 0
+                d0[u] = *dp;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < NE; ++i) {
+                if (i >= cnt) continue;
 #pragma unroll
                 for (uint32_t u = 0; u < U; ++u) {
                     const uint32_t q = q0 + u;
-                    nxr[u] = lp[q < len ? q : 0u];
-                    at_end[u] = q >= len;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    rw[u] = xrow[at_end[u] ? depot : nxr[u]];
-                    const uint16_t* dp = at_end[u] ? rf.edge_end + ec : rf.edge + nxr[u];  // an empty list's edge_end is 0
-                    d0[u] = *dp;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < U; ++u) {
-                    const uint32_t q = q0 + u;
-                    const uint32_t da = u == 0 ? rw_prev : rw[u - 1];
-                    const int32_t dd = (int32_t)da + (int32_t)rw[u] - (int32_t)d0[u];
+                    const uint32_t da = u == 0 ? rw_prev[i] : rw[i][u - 1];
+                    const int32_t dd = (int32_t)da + (int32_t)rw[i][u] - (int32_t)d0[u];
                     int32_t dv[L];
 #pragma unroll
-                    for (int k = 0; k < L; ++k) dv[k] = ca[k] * dc + cb[k] * dd;
-                    const bool take = act && q <= len && (!b_has[ps] || rv2_gt<L>(dv, b_dv[ps]));  // strictly better: the first of equals stays
+                    for (int k = 0; k < L; ++k) dv[k] = ca[k] * dcs[i] + cb[k] * dd;
+                    const bool has = (b_has[ps] >> i) & 1u;
+                    const bool take = act && q <= len && (!has || rv2_gt<L>(dv, b_dv[ps][i]));  // strictly better: the first of equals stays
 #pragma unroll
-                    for (int k = 0; k < L; ++k) b_dv[ps][k] = take ? dv[k] : b_dv[ps][k];
-                    b_pos[ps] = take ? q : b_pos[ps];
-                    b_has[ps] = b_has[ps] || take;
+                    for (int k = 0; k < L; ++k) b_dv[ps][i][k] = take ? dv[k] : b_dv[ps][i][k];
+                    b_pos[ps][i] = take ? q : b_pos[ps][i];
+                    b_has[ps] |= take ? (1u << i) : 0u;
                 }
-                rw_prev = rw[U - 1];
+                rw_prev[i] = rw[i][U - 1];
             }
         }
-        RPH(1)
-        // the cnt best lists of element i in (score, list) order
+    }
+    RPH(1)
+    // the cnt best lists of every element in (score, list) order -> lanes i * 8 + m
+#pragma unroll
+    for (uint32_t i = 0; i < NE; ++i) {
+        if (i >= cnt) continue;
+        bool h0 = (b_has[0] >> i) & 1u, h1 = (b_has[1] >> i) & 1u;
         for (uint32_t m = 0; m < cnt; ++m) {
             // a lane offers the better of its two lists (the first one on a tie: it is the lower list)
-            const bool second = b_has[1] && (!b_has[0] || rv2_gt<L>(b_dv[1], b_dv[0]));
+            const bool second = h1 && (!h0 || rv2_gt<L>(b_dv[1][i], b_dv[0][i]));
             int32_t o_dv[L];
 #pragma unroll
-            for (int k = 0; k < L; ++k) o_dv[k] = second ? b_dv[1][k] : b_dv[0][k];
-            const bool offer = b_has[0] || b_has[1];
-            const uint32_t o_key = (((second ? 64u : 0u) + lane) << 16) | (second ? b_pos[1] : b_pos[0]);
+            for (int k = 0; k < L; ++k) o_dv[k] = second ? b_dv[1][i][k] : b_dv[0][i][k];
+            const bool offer = h0 || h1;
+            const uint32_t o_key = (((second ? 64u : 0u) + lane) << 16) | (second ? b_pos[1][i] : b_pos[0][i]);
             int32_t M[L];
             uint32_t k1 = 0, k2 = 0;
             if (!rv2_pick<L>(offer, o_dv, o_key, 0u, M, k1, k2)) break;
             if (offer && o_key == k1) {  // the owner retires that list
                 if (second)
-                    b_has[1] = false;
+                    h1 = false;
                 else
-                    b_has[0] = false;
+                    h0 = false;
             }
             if (lane == i * 8u + m) {
 #pragma unroll
@@ -313,9 +343,7 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, uint16_t* vis
                 T_ok = true;
             }
         }
-        RPH(2)
     }
-
     RPH(2)
     // ---- rounds: place the best (element, list, position) until nothing remains ----
     uint32_t remmask = (1u << cnt) - 1u;
