@@ -94,7 +94,7 @@ M2_POLICIES = {
     "default6": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"),
     "nearby2": ("nearby_change", "nearby_swap"),
 }
-M2_REPLICAS = {"default": 2048, "default6": 12288, "nearby2": 6144}  # replicas per GPU of the M2 leg (round 4: the RUIN instantiation holds 8 per CU;
+M2_REPLICAS = {"default": 6144, "default6": 12288, "nearby2": 6144}  # replicas per GPU of the M2 leg (round 4: the RUIN instantiation holds 8 per CU;
 # the six-leaf FAST instantiation 12 per CU and gains from several residencies per launch, profiles/r04g_generic_replicas.jsonl)
 # M2 extension leg (module docstring): what is varied against the parity leg, and nothing else
 TUNED = {"leaves": ("nearby_change", "nearby_swap"), "late_acceptance_size": 5000, "accepted_count_limit": 1, "replicas": 1024,

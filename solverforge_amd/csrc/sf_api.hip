@@ -2362,7 +2362,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
                       // with a ruin leaf the FAST kernel carries the list-preserving recreate only (sf_ruin_v2.h: rv2_model_ok + the edge table)
                       (!RUIN || (ctx->lm.leg16 && ctx->lm.V <= 128 && ctx->lm.n_cap <= 32767 && ctx->lm.dim <= 32767 && ctx->lm.small32 && ctx->lm.mat16));
     // (FAST + ruin: the list-preserving recreate only and the node -> slot table in HBM, see the kernel)
-    const bool nodeg = fast && RUIN;
+    const bool nodeg = fast && (RUIN || SF_MIXED_FAST_NODEG != 0);
     GCarve<VT> cv(ns, ctx->has_list_model ? ctx->lm.V : 0, ctx->has_list_model ? ctx->lm.n_cap : 0, gl.has_nearby ? ctx->lm.dim : 0,
                   gl.kopt_nearby, gl.n, gl.has_ruin ? (nodeg ? 3 : (ctx->lm.leg16 ? 2 : 1)) : 0, ctx->has_list_model ? ctx->lm.dim : 0,
                   PREC && gl.prec_lds ? gl.prec.n : 0, tables ? ctx->sm.n_values : 0, tables && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0,

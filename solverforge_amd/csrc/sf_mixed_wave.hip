@@ -279,7 +279,7 @@ namespace sf {
 #define DBGK(k) (!FAST || ((k) & (16 | 32 | 64 | 128 | 256 | 512)) != 0)
 #endif
 #ifndef SF_MIXED_FAST_BLOCKS_PER_CU
-#define SF_MIXED_FAST_BLOCKS_PER_CU 3
+#define SF_MIXED_FAST_BLOCKS_PER_CU 4
 #endif
 // MODE 2 (PREC instantiations, untraced): the same code built for four 4-wave workgroups per CU (128 registers per lane).  A precedence
 // trial is one replica's serial chain of Kahn rounds, so a CU that can hold more than eight small replicas (LDS slice permitting) hides
@@ -290,6 +290,10 @@ namespace sf {
 #define SF_MIXED_PREC_BLOCKS_PER_CU 4
 #endif
 template <int L, bool TRACE, class VT, bool RUIN = false, bool PREC = false, int MODE = 0>
+// the FAST kernels without a ruin leaf keep their node -> slot table in HBM too (1) or in the LDS slice (0)
+#ifndef SF_MIXED_FAST_NODEG
+#define SF_MIXED_FAST_NODEG 1  // (round 5: with the 128-register build 16 replicas share a CU: six-leaf CVRP-1000 9.1 -> 10.0 G moves/s sustained)
+#endif
 #ifndef SF_MIXED_FAST_RUIN_BLOCKS_PER_CU
 #define SF_MIXED_FAST_RUIN_BLOCKS_PER_CU 3  // (round 5: 168 registers, 91 spilled values -- like the kernel without the leaf; LDS slice 13.4 KB at CVRP-1000)
 #endif
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     const bool tables = !FAST && has_scalar && sm.tables();  // value-keyed constraints of the scalar class: per-value tables in LDS
     // FAST + ruin: only the list-preserving recreate (no matrix row in LDS) and the node -> slot table in HBM: 19.4 -> 13.4 KB per replica at
     // CVRP-1000, twelve replicas per CU with the 168-register build instead of eight
-    constexpr bool NODEG = FAST && RUIN;
+    constexpr bool NODEG = FAST && (RUIN || SF_MIXED_FAST_NODEG != 0);
     const GCarve<VT> cv((int)ns, V, has_list ? lm.n_cap : 0, has_nearby ? lm.dim : 0, gl.kopt_nearby, gl.n, RUIN ? (FAST ? 3 : (lm.leg16 ? 2 : 1)) : 0, lm.dim,
                         PREC && gl.prec_lds ? gl.prec.n : 0, tables ? sm.n_values : 0, tables && sm.run_level >= 0 ? sm.run_P : 0,
                         PREC && gl.prec_lds ? gl.prec_groups : 0, NODEG);
