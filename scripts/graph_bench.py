@@ -7,7 +7,7 @@ import solverforge_amd as sfa
 from solverforge_amd import datasets
 from oracle import sfo
 
-R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 3072  # (12 per CU since round 5)
 ls = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 # "la" = LateAcceptance(400)+AcceptedCount(256) (the list-policy components); "sa" = the reference's default

@@ -1140,7 +1140,10 @@ struct SCarve {
 
 // VT = int8_t (n_values <= 127) or int16_t: the replica's values in LDS
 template <int L, bool TRACE, class VT>
-__global__ __launch_bounds__(64 * 4) void k_scalar_search_wave(ScalarModel m, SearchParams p) {
+#ifndef SF_SCALAR_BLOCKS_PER_CU
+#define SF_SCALAR_BLOCKS_PER_CU 3  // (round 5: 168 registers, 26-33 spilled values; 12 replicas per CU -- graph colouring 10k: LateAcceptance 6.85 -> 8.45 G moves/s, the default SimulatedAnnealing policy 82 -> 103 M, profiles/r05_graph_occupancy.txt)
+#endif
+__global__ __launch_bounds__(64 * 4, SF_SCALAR_BLOCKS_PER_CU) void k_scalar_search_wave(ScalarModel m, SearchParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint64_t s_sa[4][SA_WORDS];  // SimulatedAnnealing acceptor state of the resident replicas
     const uint32_t lane = threadIdx.x & 63u;
