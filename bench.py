@@ -309,6 +309,8 @@ def main():
     ap.add_argument("--vehicles", type=int, default=100)
     ap.add_argument("--capacity", type=int, default=55)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-nearby", type=int, default=20, help="diagnostics (scripts/salu_fit.py): max_nearby of the two nearby leaves (the metric is quoted at 20)")
+    ap.add_argument("--accepted-limit", type=int, default=256, help="diagnostics: AcceptedCount limit (the metric is quoted at 256)")
     ap.add_argument("--engine", choices=["auto", "block", "wave"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -376,7 +378,9 @@ def main():
 
     def new_director(prob=None, leaves=("nearby_change", "nearby_swap"), replicas=None, la_size=400, limit=256):
         nrep = replicas or args.replicas
-        d = sfa.build_cvrp(prob if prob is not None else problem, n_replicas=nrep, device_id=local_rank, leaves=leaves)
+        d = sfa.build_cvrp(prob if prob is not None else problem, n_replicas=nrep, device_id=local_rank, leaves=leaves, max_nearby=args.max_nearby)
+        if limit == 256:
+            limit = args.accepted_limit
         if len(leaves) == 2:
             d.set_engine({"auto": 0, "block": 1, "wave": 2}[args.engine])
         # replica r of rank q searches with seed base + q*replicas + r  (independent portfolio members)
@@ -411,6 +415,7 @@ def main():
             with open(args.pmc_child_out, "w") as f:
                 json.dump({"moves_evaluated": after_c["moves_evaluated"] - before["moves_evaluated"],
                            "candidates_scored": after_c["candidates_scored"] - before["candidates_scored"], "launches": args.steps,
+                           "ls_steps": after_c["step_count"] - before["step_count"], "sources_scanned": after_c["sources_scanned"] - before["sources_scanned"],
                            "replicas": args.replicas}, f)
         d.close()
         return

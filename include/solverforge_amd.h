@@ -576,8 +576,9 @@ int32_t sf_get_annealing_state(sf_ctx* ctx, int32_t replica, double* out_tempera
 int32_t sf_solver_set_engine(sf_ctx* ctx, int32_t engine); /* sf_engine_kind; SF_ERR_UNSUPPORTED if it cannot run this model */
 int32_t sf_solver_get_engine(sf_ctx* ctx, int32_t* out_engine); /* the engine launches resolve to (after sf_initialize) */
 /* How the wave engine laid out its last fused launch (diagnostics; tests assert the path they mean to cover was taken):
- * out_mode = 0 general / 1 FAST / 2 FAST + 32-bit deltas / 3..6 the same on the COMPACT LDS slice (4, 5 = built for 5 / 6 waves per SIMD,
- * 6 = the node -> slot table of every replica in HBM instead of the slice: large models, more replicas per CU),
+ * out_mode = 0 general / 1 FAST / 2 FAST + 32-bit deltas / 3..7 the same on the COMPACT LDS slice (4, 5 = built for 5 / 6 waves per SIMD,
+ * 6 = the node -> slot table of every replica in HBM instead of the slice: large models, more replicas per CU; 7 = the same built for
+ * 8 waves per SIMD: small models, 32 replicas per CU),
  * -1 = no wave-engine launch yet; out_renumbered = 1 when that launch ran on the internal node numbering (the u16 matrix and the
  * neighbour index renumbered along a nearest-neighbour chain once they outgrow the L2: DESIGN 11.3; SF_AMD_RENUMBER=0 / 1 overrides).
  * The numbering is invisible at this boundary: every id that crosses it is the caller's. */

@@ -1139,7 +1139,7 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
         static const bool no_compact = std::getenv("SF_AMD_NO_COMPACT") != nullptr;  // diagnostics: A/B
         int wpb_c = 1;
         size_t lds_c = 0;
-        static const int max_wpe = std::getenv("SF_AMD_WAVE_WPE") ? std::atoi(std::getenv("SF_AMD_WAVE_WPE")) : 6;  // diagnostics: cap the waves per SIMD
+        static const int max_wpe = std::getenv("SF_AMD_WAVE_WPE") ? std::atoi(std::getenv("SF_AMD_WAVE_WPE")) : 6;  // diagnostics: cap the waves per SIMD (8 = launch mode 7: 32 replicas per CU at CVRP-1000, measured 44.5 vs 45.2 G -- the scalar pipe is the bound, more waves do not help)
         const size_t r6 = (no_compact || max_wpe < 6) ? 0 : plan(true, 24, wpb_c, lds_c);
         const size_t r5 = (no_compact || max_wpe < 5 || r6 > 20) ? 0 : plan(true, 20, wpb_c, lds_c);
         if (r6 > 20 && r6 > resident_wide) {  // 24 replicas per CU: the instantiation compiled for 6 waves per SIMD (80 VGPRs)
@@ -1164,7 +1164,21 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
             size_t lds_g = 0, lds_3 = 0;
             const size_t r3 = plan(true, 4 * SF_WAVES_PER_EU, wpb_3, lds_3);
             const size_t rg = plan(true, 4 * SF_WAVES_PER_EU, wpb_g, lds_g, true);
-            if (ngv != 0 && (ngv == 1 || (mode == 3 && rg > r3))) {
+            // small models: 32 replicas per CU with the 64-register build when the slice without the table allows it (CVRP-1000: 4.6 KB)
+            int wpb_8 = 1;
+            size_t lds_8 = 0;
+            const size_t r8 = (ngv == 0 || max_wpe < 8) ? 0 : plan(true, 32, wpb_8, lds_8, true);
+            if (mode == 5 && r8 > 24) {
+                if (!ctx->lm.node_tab) {
+                    uint16_t* nt = nullptr;
+                    int rc = dalloc(ctx, &nt, (size_t)ctx->R * ctx->lm.dim);
+                    if (rc) return rc;
+                    ctx->lm.node_tab = nt;
+                }
+                mode = 7;
+                wpb = wpb_8;
+                lds = lds_8;
+            } else if (ngv != 0 && (ngv == 1 || (mode == 3 && rg > r3))) {
                 if (!ctx->lm.node_tab) {
                     uint16_t* nt = nullptr;
                     int rc = dalloc(ctx, &nt, (size_t)ctx->R * ctx->lm.dim);

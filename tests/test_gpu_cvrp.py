@@ -400,7 +400,7 @@ def test_node_table_in_hbm(oracle, monkeypatch, renumber):
         for n in (30, 30, 15):
             d.solve_steps(n)
         mode, renum = d.wave_layout()
-        assert (mode == 6) == (flag == "1") and mode >= 3, mode
+        assert (mode in (6, 7)) == (flag == "1") and mode >= 3, mode  # (7: the 64-register build, 32 replicas per CU, small models)
         assert renum == (renumber == "1")
         out[flag] = (d.calculate_score().copy(), [d.working_lists(0, r) for r in range(6)], d.best_scores().copy(), [d.stats(r)["moves_evaluated"] for r in range(6)])
         assert (d.fresh_score() == out[flag][0]).all()
