@@ -808,7 +808,23 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         const uint32_t total = uni(s_off[V]);
         // union: >1 leaf => StratifiedRandom, equal weights (vec_union.rs:229-245); with two children
         // the stride is always 1, so the order is first, other, first, ...
-        const uint32_t first_leaf = n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u;
+        // The five hashes a FAST step starts with (the union's first child; start and stride of the two leaves' entity permutations) are
+        // computed SIDE BY SIDE, one per lane, on the vector unit: as wave-uniform values they were ~400 scalar instructions per step (64-bit
+        // multiplies and Barrett remainders expand to a dozen s_mul each), a tenth of the kernel's scalar work, and the scalar unit -- shared by
+        // the 24 waves of a CU -- is its bound (profiles/r05_salu_fit.json: 1,042 scalar instructions per step before this).
+        uint32_t hashed = 0;  // lane l < 5: remainder of mixed_seed(salt_l) by its divisor
+        const bool lane_hash = FAST && use_cm;
+        if (lane_hash) {
+            const uint64_t es0 = SALT_NEARBY_CHANGE_ENTITY ^ desc0, es1 = SALT_NEARBY_SWAP_ENTITY ^ desc1;  // FAST: leaf 0 = nearby change, leaf 1 = nearby swap
+            const uint64_t salt = lane == 0 ? SALT_UNION_OFFSET : lane == 1 ? es0 : lane == 2 ? (es0 ^ STRIDE_SALT_MIX) : lane == 3 ? es1 : (es1 ^ STRIDE_SALT_MIX);
+            const FastMod fm2 = make_fastmod(2u);
+            FastMod f;
+            f.M = lane == 0 ? fm2.M : ((lane & 1u) ? fm_V.M : fm_V1.M);
+            f.n = lane == 0 ? fm2.n : ((lane & 1u) ? fm_V.n : fm_V1.n);
+            hashed = fastmod_u64(ctx.mixed_seed(salt), f);
+        }
+        const uint32_t first_leaf = lane_hash ? (uint32_t)__builtin_amdgcn_readlane((int)hashed, 0)
+                                              : (n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u);
 
         uint32_t perm_st0 = 0, perm_sd0 = 1, perm_st1 = 0, perm_sd1 = 1;  // entity permutations of the two leaves (set in (B))
         // resolve the source at cursor (k, o) of leaf l and put its first key chunk in flight
@@ -859,7 +875,10 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         for (int l = 0; l < n_leaves; ++l) {
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
-            if (use_cm)
+            if (lane_hash) {  // perm_params_fm with the two hashes already taken (above)
+                pst = (uint32_t)__builtin_amdgcn_readlane((int)hashed, l ? 3 : 1);
+                psd = StreamCtx::first_coprime_from((uint32_t)__builtin_amdgcn_readlane((int)hashed, l ? 4 : 2) + 1u, cm_lo, cm_hi);
+            } else if (use_cm)
                 ctx.perm_params_fm(fm_V, fm_V1, ent_salt, pst, psd, cm_lo, cm_hi);
             else
                 ctx.perm_params((uint32_t)V, ent_salt, pst, psd);
