@@ -173,6 +173,43 @@ typedef enum sf_constraint_kind {
     SF_C_PRESENCE_VALUE = 17
 } sf_constraint_kind;
 
+/* ---- pair predicates as data (round 5) -------------------------------------------------------------------------------------
+ * The reference composes the filter of a predicate join from closures (stream/join_target.rs:28-110: a join whose two sides extract
+ * the same planning collection and whose joiner is a predicate takes a CONSTANT key -- every pair (left.id < right.id) is tested;
+ * cross_bi_incremental/state.rs:260-296 add_match).  Here the predicate is a small program: a conjunction of clauses, each clause a
+ * disjunction of terms over (left, right) = the pair in entity-index order, both assigned.  The three model-shaped kinds above are
+ * presets of it:  SF_C_CROSS_ADJACENT_EQUAL = {CSR_CONTAINS(adj)} and {VALUE_EQ};  SF_C_CROSS_GROUP_EQUAL = {COL_EQ(group)} and {VALUE_EQ};
+ * SF_C_CROSS_QUEENS = {COL_NE(column)} and {VALUE_EQ or VALUE_ABSDIFF_EQ_COL(column)}  (examples/scalar-graph-coloring/src/domain/
+ * graph_coloring.rs:28-41, examples/mixed-job-shop/src/domain/job_shop_plan.rs:50-62, examples/nqueens/src/domain/board.rs:30-44).
+ * On the device a clause that is one CSR_CONTAINS or one COL_EQ term becomes the partner index the trial walks (deg(e) tests instead of n);
+ * the remaining clauses are interpreted per candidate pair from the kernel's argument block (wave-uniform control, per-lane data). */
+typedef enum sf_pair_op {
+    SF_PAIR_VALUE_EQ = 1,             /* left.value == right.value */
+    SF_PAIR_VALUE_NE = 2,             /* left.value != right.value */
+    SF_PAIR_VALUE_ABSDIFF_EQ_COL = 3, /* |left.value - right.value| == |col[left] - col[right]|     fact = i32 column */
+    SF_PAIR_COL_EQ = 4,               /* col[left] == col[right]                                     fact = i32 column */
+    SF_PAIR_COL_NE = 5,               /* col[left] != col[right] */
+    SF_PAIR_COL_LT = 6,               /* col[left] < col[right]   (left = the lower entity index) */
+    SF_PAIR_COL_ABSDIFF_EQ = 7,       /* |col[left] - col[right]| == param */
+    SF_PAIR_COL_ABSDIFF_LE = 8,       /* |col[left] - col[right]| <= param */
+    SF_PAIR_CSR_CONTAINS = 9,         /* right in csr[left] or left in csr[right]                    fact = CSR, one row per entity */
+    SF_PAIR_TABLE_NONZERO = 10,       /* table[key[left]][key[right]] != 0      fact = i64 matrix, fact_b = i32 key column (row / column index) */
+    SF_PAIR_VALUE_ABSDIFF_LE = 11     /* |left.value - right.value| <= param */
+} sf_pair_op;
+typedef struct sf_pair_term {
+    int32_t op;      /* sf_pair_op */
+    int32_t clause;  /* terms with the same clause id are OR-ed, the clauses are AND-ed; ids ascend along the array */
+    int32_t fact;    /* column / CSR / matrix fact id (ops that take one), else -1 */
+    int32_t fact_b;  /* SF_PAIR_TABLE_NONZERO: the key column, else -1 */
+    int64_t param;
+} sf_pair_term;
+/* for_each(E).join(for_each(E), predicate).penalize(weight) on the scalar class `descriptor_index`: every pair left.id < right.id of
+ * ASSIGNED entities for which the program holds costs `weight` on `level` (IncrementalBiConstraint over a predicate join:
+ * constraint/cross_bi_incremental/{state,incremental}.rs).  One predicate join per scalar class; <= 8 terms, of which <= 6 remain after
+ * the partner index took its clause.  SF_ERR_INVALID for malformed programs / facts, SF_ERR_UNSUPPORTED beyond the limits. */
+int32_t sf_constraint_add_pair_join(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, const sf_pair_term* terms, int32_t n_terms,
+                                    int32_t level, int64_t weight);
+
 typedef enum sf_selector_kind {
     SF_SEL_SCALAR_CHANGE = 1,      /* selector/scalar_neighborhood/cursor/change.rs:27-121 */
     SF_SEL_SCALAR_SWAP = 2,        /* selector/scalar_neighborhood/cursor/swap.rs:22-160 */

@@ -4,7 +4,8 @@ Host-side mirror of the reference's Director / MoveSelector / local-search surfa
 C ABI in include/solverforge_amd.h.  PyTorch is plumbing only (multi-GPU rendezvous); compute is
 hand-written HIP for gfx950.
 """
-from .director import (  # noqa: F401
+from .director import (
+    PairOp,  # noqa: F401
     Acceptor,
     AnnealingMode,
     Engine,

@@ -39,7 +39,9 @@ struct ConstraintSpec {
     int64_t param;
     int level;
     int64_t weight;
+    std::vector<sf_pair_term> terms;  // SF_C_PAIR_JOIN_: the predicate program (sf_constraint_add_pair_join)
 };
+constexpr int SF_C_PAIR_JOIN_ = 100;  // internal kind of sf_constraint_add_pair_join
 struct SelectorSpec {
     int kind, desc, var, max_nearby, fact;
     int min_size = 1, max_size = 3;  // sublist leaves; ruin leaf: min / max ruin count
@@ -418,7 +420,28 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
     if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE && kind != SF_C_COMPLEMENTED_VALUE_SUM && kind != SF_C_PRESENCE_VALUE)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
-    ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight});
+    ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight, {}});
+    return SF_OK;
+}
+
+int32_t sf_constraint_add_pair_join(sf_ctx* ctx, int32_t d, int32_t var, const sf_pair_term* terms, int32_t n_terms, int32_t level, int64_t weight) {
+    if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
+    if (!terms || n_terms < 1) return fail(ctx, SF_ERR_INVALID, "pair join: empty predicate program");
+    if (n_terms > 8) return fail(ctx, SF_ERR_UNSUPPORTED, "pair join: at most 8 terms");
+    int32_t prev = -1;
+    for (int32_t t = 0; t < n_terms; ++t) {
+        const sf_pair_term& pt = terms[t];
+        if (pt.op < SF_PAIR_VALUE_EQ || pt.op > SF_PAIR_VALUE_ABSDIFF_LE) return fail(ctx, SF_ERR_INVALID, "pair join: unknown op");
+        if (pt.clause < 0 || pt.clause > 127 || pt.clause < prev) return fail(ctx, SF_ERR_INVALID, "pair join: clause ids must ascend (0..127)");
+        prev = pt.clause;
+        const bool needs_fact = pt.op != SF_PAIR_VALUE_EQ && pt.op != SF_PAIR_VALUE_NE && pt.op != SF_PAIR_VALUE_ABSDIFF_LE;
+        if (needs_fact && pt.fact < 0) return fail(ctx, SF_ERR_INVALID, "pair join: the op needs a fact");
+        if (pt.op == SF_PAIR_TABLE_NONZERO && pt.fact_b < 0) return fail(ctx, SF_ERR_INVALID, "pair join: the table op needs a key column (fact_b)");
+    }
+    ConstraintSpec cs{SF_C_PAIR_JOIN_, d, var, -1, 0, level, weight, {}};
+    cs.terms.assign(terms, terms + n_terms);
+    ctx->constraints.push_back(cs);
     return SF_OK;
 }
 
@@ -451,7 +474,7 @@ int32_t sf_constraint_add_list_precedence(sf_ctx* ctx, int32_t d, int32_t var, i
     ps.succ.assign(succ_values, succ_values + ps.succ_off.back());
     ps.has_owner = expected_owner != nullptr;
     if (expected_owner) ps.owner.assign(expected_owner, expected_owner + node_count);
-    ctx->constraints.push_back({SF_C_LIST_PRECEDENCE_MAKESPAN, d, var, -1, 0, hard_level, (int64_t)makespan_level});
+    ctx->constraints.push_back({SF_C_LIST_PRECEDENCE_MAKESPAN, d, var, -1, 0, hard_level, (int64_t)makespan_level, {}});
     return SF_OK;
 }
 
@@ -1315,6 +1338,7 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_UNI_UNASSIGNED: raw = q[3], count = q[16]; break;  // weighted sum / entities passing the filter
             case SF_C_CROSS_ADJACENT_EQUAL:
             case SF_C_CROSS_GROUP_EQUAL:
+            case SF_C_PAIR_JOIN_:
             case SF_C_CROSS_QUEENS: raw = q[4], count = q[4]; break;
             case SF_C_SELFJOIN_VALUE_EQUAL: raw = q[5], count = q[5]; break;
             case SF_C_GROUPED_VALUE_SUM:

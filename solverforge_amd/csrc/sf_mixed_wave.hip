@@ -1113,6 +1113,22 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             const uint32_t pool = ruin_open_cursor(gl.ruin, rl, ctx, s_off, V, !dry_run, lane);
             for (int l = 0; l < nl; ++l)
                 if (lt.geti(l, LeafTab::KIND) == 1024) lt.put_gen(l, GGen{0, 0, 0, 0, pool, 0, pool == 0 || gl.ruin.moves_per_step <= 0});
+            if (PREC && pool != 0) {  // (a precedence model: the recreate is scored by the precedence constraint, with the slot's hooks when declared)
+                PHS(0)
+                for (uint32_t c = 0; c < (uint32_t)gl.ruin.moves_per_step; ++c) {
+                    if (c == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);
+                    ruin_next_candidate(gl.ruin, rl, s_off, V, pool, c, lane);
+                    PlfMove pm_;
+                    plf_from_ruin_cand(rl.cand + (size_t)c * RuinLds::CAND_WORDS, pm_);
+                    const ScoreV<L> psc = plf_ruin(pm_, false, plf_policy, gl.ruin.skip_empty != 0);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < L; ++kk) rl.score[(size_t)c * 4 + kk] = psc.v[kk];
+                    }
+                    wave_sync();
+                }
+                PHS(3)
+            }
             if (!PREC && pool != 0) {
                 // Every candidate of the step is generated and scored HERE, before the fill / replay loop, not inside it (round 5).  The
                 // leaf's stream depends on the committed state and the step's cursor seed alone, the first fill asked for all of them anyway
@@ -1841,22 +1857,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                             g.done = 1;
                             break;
                         }
-                        if (PREC) {  // precedence model: the recreate is scored by the precedence constraint (with the slot's hooks when declared)
-                            if (g.a == 0 && rfast.edge) ruin_build_edges(lm, s_visits, s_off, ruin_sbase, rfast);  // first candidate of the step
-                            ruin_next_candidate(gl.ruin, rl, s_off, V, g.e, g.a, lane);
-                            PlfMove pm_;
-                            plf_from_ruin_cand(rl.cand + (size_t)g.a * RuinLds::CAND_WORDS, pm_);
-                            const ScoreV<L> psc = plf_ruin(pm_, false, plf_policy, gl.ruin.skip_empty != 0);
-                            if (lane == 0) {
-#pragma unroll
-                                for (int kk = 0; kk < L; ++kk) rl.score[(size_t)g.a * 4 + kk] = psc.v[kk];
-                            }
-                            wave_sync();
-                            keep = lane == 0;
-                            w0 = g.a;
-                            g.a += 1;
-                            if (g.a >= (uint32_t)gl.ruin.moves_per_step) g.done = 1;
-                        } else {  // scored at the start of the step (above): the ring entries name the candidates
+                        {  // scored at the start of the step (above): the ring entries name the candidates
                             const uint32_t n_left = (uint32_t)gl.ruin.moves_per_step - g.a;
                             keep = lane < n_left;
                             w0 = g.a + lane;

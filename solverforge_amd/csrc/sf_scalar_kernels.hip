@@ -31,7 +31,20 @@ namespace sf {
 #ifndef SF_CONFLICT_W
 #define SF_CONFLICT_W 16  // partner ids in flight per pass of scalar_conflict_delta
 #endif
-enum ScalarCrossKind : int32_t { SC_NONE = 0, SC_PARTNERS_EQUAL = 1, SC_QUEENS = 2 };
+// SC_PARTNERS_EQUAL / SC_QUEENS are SPECIALISATIONS of the pair-predicate program (include/solverforge_amd.h: sf_pair_term) for the two
+// programs the reference's examples use; SC_IR_PARTNERS / SC_IR_DENSE interpret any program (partner-index driven / every other entity).
+enum ScalarCrossKind : int32_t { SC_NONE = 0, SC_PARTNERS_EQUAL = 1, SC_QUEENS = 2, SC_IR_PARTNERS = 3, SC_IR_DENSE = 4 };
+constexpr int SF_IR_MAX = 6;  // residual terms interpreted per pair
+// one residual term: op (sf_pair_op) | clause << 8, its column / CSR / table
+struct PairTerm {
+    int32_t op_clause;
+    int32_t cols;          // SF_PAIR_TABLE_NONZERO: columns of the table
+    int64_t param;
+    const int32_t* col;    // i32 column (the key column for the table op)
+    const uint32_t* coff;  // SF_PAIR_CSR_CONTAINS: row offsets / values
+    const uint32_t* cval;
+    const int64_t* table;
+};
 
 struct ScalarModel {
     int32_t n = 0;  // entities
@@ -47,6 +60,8 @@ struct ScalarModel {
     const uint32_t* pn_off = nullptr;  // [n+1] symmetric partner CSR (SC_PARTNERS_EQUAL)
     const uint32_t* pn = nullptr;
     const int32_t* col = nullptr;      // [n] column fact (SC_QUEENS)
+    int32_t ir_n = 0;                  // SC_IR_*: residual terms of the pair predicate, clause ids ascending
+    const PairTerm* ir = nullptr;      // [ir_n] in device memory (wave-uniform reads: scalar loads on demand, nothing rides in the argument block)
     // value-keyed aggregates (per-value count / sum tables, maintained at apply):
     int32_t sj_level = -1, grp_level = -1;  // keyed self-join pairs; grouped sum
     int64_t sj_weight = 0, grp_weight = 0, grp_cap = -1;
@@ -109,6 +124,65 @@ __device__ __forceinline__ bool value_legal(const ScalarModel& m, uint32_t e, in
     return false;
 }
 
+// The residual clauses of the pair predicate for the pair (e, o), o assigned with value vo, for TWO candidate values of e at once (a
+// negative candidate = unassigned: never holds).  Returns bit 0 = holds with v0, bit 1 = holds with v1.  Wave-uniform control (the
+// program is read with scalar loads, one term per trip of a loop that is NOT unrolled: inlined and unrolled at every pair of every
+// partner loop it tripled the build time of the search kernels), per-lane data; the column facts are read once for both values.
+// left = the lower entity index (the join's left.id < right.id).
+__device__ __forceinline__ uint32_t pair_program_holds2(const PairTerm* __restrict__ ir, int32_t ir_n, uint32_t e, uint32_t o, int32_t v0, int32_t v1, int32_t vo) {
+    const bool swp = e > o;
+    const uint32_t l = swp ? o : e, r = swp ? e : o;
+    uint32_t all = 3u, any = 0u;
+    int32_t clause = -1;
+#pragma unroll 1
+    for (int t = 0; t < ir_n; ++t) {
+        const PairTerm& pt = ir[t];
+        const int32_t op = pt.op_clause & 255, cl = pt.op_clause >> 8;
+        if (cl != clause) {
+            all &= clause < 0 ? 3u : any;
+            any = 0u;
+            clause = cl;
+        }
+        uint32_t h = 0u;
+        if (op == 1 || op == 2 || op == 11) {  // value-only terms
+            const int32_t d0 = v0 > vo ? v0 - vo : vo - v0, d1 = v1 > vo ? v1 - vo : vo - v1;
+            const bool h0 = op == 1 ? v0 == vo : (op == 2 ? v0 != vo : (int64_t)d0 <= pt.param);
+            const bool h1 = op == 1 ? v1 == vo : (op == 2 ? v1 != vo : (int64_t)d1 <= pt.param);
+            h = (h0 ? 1u : 0u) | (h1 ? 2u : 0u);
+        } else if (op == 9) {  // membership either way: a linear walk of both rows (residual use only: a CSR clause of its own drives the partner index)
+            bool m = false;
+            for (uint32_t q = pt.coff[l]; q < pt.coff[l + 1]; ++q) m = m || pt.cval[q] == r;
+            for (uint32_t q = pt.coff[r]; q < pt.coff[r + 1]; ++q) m = m || pt.cval[q] == l;
+            h = m ? 3u : 0u;
+        } else {
+            const int32_t cl_ = pt.col[l], cr_ = pt.col[r];
+            const int32_t dc = cl_ > cr_ ? cl_ - cr_ : cr_ - cl_;
+            if (op == 3) {
+                const int32_t d0 = v0 > vo ? v0 - vo : vo - v0, d1 = v1 > vo ? v1 - vo : vo - v1;
+                h = (d0 == dc ? 1u : 0u) | (d1 == dc ? 2u : 0u);
+            } else {
+                bool m = false;
+                if (op == 4)
+                    m = cl_ == cr_;
+                else if (op == 5)
+                    m = cl_ != cr_;
+                else if (op == 6)
+                    m = cl_ < cr_;
+                else if (op == 7)
+                    m = (int64_t)dc == pt.param;
+                else if (op == 8)
+                    m = (int64_t)dc <= pt.param;
+                else if (op == 10)
+                    m = pt.table[(size_t)cl_ * (size_t)pt.cols + (size_t)cr_] != 0;
+                h = m ? 3u : 0u;
+            }
+        }
+        any |= h;
+    }
+    all &= clause < 0 ? 3u : any;
+    return all & ((v0 >= 0 ? 1u : 0u) | (v1 >= 0 ? 2u : 0u));
+}
+
 // matches of entity e against every partner except `skip`, for two candidate values at once:
 // returns conflicts(e, v_new) - conflicts(e, v_old) in ONE pass over the partner list, sixteen
 // partner ids in flight per iteration (the list lives in HBM/L2, the values in LDS): an average
@@ -132,6 +206,25 @@ __device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, c
                 c += (v_new >= 0 && vo == v_new) ? 1 : 0;
                 c -= (v_old >= 0 && vo == v_old) ? 1 : 0;
             }
+        }
+    } else if (m.cross_kind == SC_IR_PARTNERS) {  // the partner index names the pairs one clause admits, the program decides the rest
+        const uint32_t p1 = m.pn_off[e + 1];
+#pragma unroll 1
+        for (uint32_t p = m.pn_off[e]; p < p1; ++p) {
+            const uint32_t o = m.pn[p];
+            if (o == skip) continue;
+            const int32_t vo = (int32_t)vals[o];
+            if (vo < 0) continue;
+            const uint32_t h = pair_program_holds2(m.ir, m.ir_n, e, o, v_new, v_old, vo);
+            c += (int32_t)(h & 1u) - (int32_t)(h >> 1);
+        }
+    } else if (m.cross_kind == SC_IR_DENSE) {  // no clause to index by: every other assigned entity
+#pragma unroll 1
+        for (uint32_t o = 0; o < (uint32_t)m.n; ++o) {
+            const int32_t vo = (int32_t)vals[o];
+            if (o == e || o == skip || vo < 0) continue;
+            const uint32_t h = pair_program_holds2(m.ir, m.ir_n, e, o, v_new, v_old, vo);
+            c += (int32_t)(h & 1u) - (int32_t)(h >> 1);
         }
     } else if (m.cross_kind == SC_QUEENS) {  // board.rs:30-44: distinct columns, same row or same diagonal
         const int32_t ce = m.col[e];
@@ -969,6 +1062,14 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
                     const uint32_t o = m.pn[p];
                     if (o > e && vals[o] == v) ++cross;
                 }
+            } else if (m.cross_kind == SC_IR_PARTNERS) {
+                for (uint32_t p = m.pn_off[e]; p < m.pn_off[e + 1]; ++p) {
+                    const uint32_t o = m.pn[p];
+                    if (o > e && vals[o] >= 0 && (pair_program_holds2(m.ir, m.ir_n, e, o, v, -1, vals[o]) & 1u)) ++cross;
+                }
+            } else if (m.cross_kind == SC_IR_DENSE) {
+                for (uint32_t o = e + 1; o < (uint32_t)m.n; ++o)
+                    if (vals[o] >= 0 && (pair_program_holds2(m.ir, m.ir_n, e, o, v, -1, vals[o]) & 1u)) ++cross;
             } else if (m.cross_kind == SC_QUEENS) {
                 const int32_t ce = m.col[e];
                 for (uint32_t o = e + 1; o < (uint32_t)m.n; ++o) {

@@ -47,6 +47,11 @@ class Engine:  # sf_engine_kind
     AUTO, BLOCK, WAVE = 0, 1, 2
 
 
+class PairOp:
+    """sf_pair_op: terms of a pair-predicate program (add_pair_join)."""
+    VALUE_EQ, VALUE_NE, VALUE_ABSDIFF_EQ_COL, COL_EQ, COL_NE, COL_LT, COL_ABSDIFF_EQ, COL_ABSDIFF_LE, CSR_CONTAINS, TABLE_NONZERO, VALUE_ABSDIFF_LE = range(1, 12)
+
+
 class ConstraintKind:
     UNI_UNASSIGNED, CROSS_ADJACENT_EQUAL, CROSS_GROUP_EQUAL, CROSS_QUEENS = 1, 2, 3, 4
     NOT_EXISTS_FLATTENED, ROUTE_CAPACITY, ROUTE_DISTANCE = 5, 6, 7
@@ -176,6 +181,16 @@ class GpuScoreDirector:
 
     def add_constraint(self, kind, descriptor_index, variable_index=0, fact=-1, param=0, level=0, weight=1):
         check(self._L.sf_constraint_add(self._h, kind, descriptor_index, variable_index, fact, param, level, weight), self._h)
+        self._n_constraints = getattr(self, "_n_constraints", 0) + 1
+
+    def add_pair_join(self, descriptor_index, terms, level=0, weight=1, variable_index=0):
+        """Predicate join of a scalar class with itself, the predicate as data (sf_constraint_add_pair_join): `terms` = sequence of
+        (op, clause, fact, fact_b, param) -- a conjunction of clauses, each a disjunction of its terms (PairOp names the ops)."""
+        arr = np.zeros(len(terms), dtype=np.dtype([("op", np.int32), ("clause", np.int32), ("fact", np.int32), ("fact_b", np.int32), ("param", np.int64)]))
+        for i, t in enumerate(terms):
+            t = tuple(t) + (-1, -1, 0)[len(t) - 2:] if len(t) < 5 else tuple(t)
+            arr[i] = t
+        check(self._L.sf_constraint_add_pair_join(self._h, descriptor_index, variable_index, arr.ctypes.data_as(C.c_void_p), len(terms), level, weight), self._h)
         self._n_constraints = getattr(self, "_n_constraints", 0) + 1
 
     def add_list_precedence(self, descriptor_index, durations, successors, expected_owner=None, hard_level=0, makespan_level=1,

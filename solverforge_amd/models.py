@@ -3,7 +3,7 @@
 Each builder wires schema + constraint archetypes + default-policy selectors exactly as the
 corresponding reference model does with ConstraintFactory streams.
 """
-from .director import ConstraintKind, GpuScoreDirector, SelectorKind
+from .director import ConstraintKind, GpuScoreDirector, PairOp, SelectorKind
 
 FACT_MATRIX, FACT_DEMAND, FACT_CUSTOMERS, FACT_ADJ, FACT_GROUP, FACT_COLUMN, FACT_AUX = 0, 1, 2, 3, 4, 5, 6
 
@@ -55,7 +55,7 @@ def build_cvrp(problem, n_replicas=1, device_id=0, max_nearby=20, leaves=("nearb
     return d
 
 
-def build_graph_coloring(problem, n_replicas=1, device_id=0, leaves=("change", "swap")):
+def build_graph_coloring(problem, n_replicas=1, device_id=0, leaves=("change", "swap"), pair_ir=False):
     """Graph colouring: HardSoftScore; `Unassigned color` (uni, 1 hard each) and `Adjacent color
     conflict` (predicate cross-join left.id < right.id && neighbours && equal colour, 1 hard each —
     examples/scalar-graph-coloring/src/domain/graph_coloring.rs:21-44); leaves = scalar change +
@@ -66,7 +66,10 @@ def build_graph_coloring(problem, n_replicas=1, device_id=0, leaves=("change", "
     d.add_scalar_variable(0, 0, problem["n_colors"], True, problem["colors"])
     d.add_fact_csr(FACT_ADJ, problem["adj_off"], problem["adj"])
     d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
-    d.add_constraint(ConstraintKind.CROSS_ADJACENT_EQUAL, 0, fact=FACT_ADJ, level=0, weight=1)
+    if pair_ir:  # the same join with its predicate written out as a program (sf_constraint_add_pair_join): neighbours && equal colour
+        d.add_pair_join(0, [(PairOp.CSR_CONTAINS, 0, FACT_ADJ), (PairOp.VALUE_EQ, 1)], level=0, weight=1)
+    else:
+        d.add_constraint(ConstraintKind.CROSS_ADJACENT_EQUAL, 0, fact=FACT_ADJ, level=0, weight=1)
     if "change" in leaves:
         d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
     if "swap" in leaves:
@@ -74,7 +77,7 @@ def build_graph_coloring(problem, n_replicas=1, device_id=0, leaves=("change", "
     return d
 
 
-def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap")):
+def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap"), pair_ir=False):
     """N-queens: queen i sits in column i, planning variable row_idx in 0..n (allows_unassigned);
     `Unassigned` + row/diagonal conflicts (examples/nqueens/src/domain/board.rs:21-47)."""
     import numpy as np
@@ -85,7 +88,10 @@ def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap")):
     d.add_scalar_variable(0, 0, n, True, rows)
     d.add_fact_column_i32(FACT_COLUMN, np.arange(n, dtype=np.int32))
     d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=0, weight=1)
-    d.add_constraint(ConstraintKind.CROSS_QUEENS, 0, fact=FACT_COLUMN, level=0, weight=1)
+    if pair_ir:  # distinct columns && (same row || same diagonal), board.rs:30-44
+        d.add_pair_join(0, [(PairOp.COL_NE, 0, FACT_COLUMN), (PairOp.VALUE_EQ, 1), (PairOp.VALUE_ABSDIFF_EQ_COL, 1, FACT_COLUMN)], level=0, weight=1)
+    else:
+        d.add_constraint(ConstraintKind.CROSS_QUEENS, 0, fact=FACT_COLUMN, level=0, weight=1)
     if "change" in leaves:
         d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
     if "swap" in leaves:
@@ -94,7 +100,7 @@ def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap")):
 
 
 def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
-                  leaves=("list_change", "list_swap", "change", "swap"), makespan=False, ruin=(2, 5, 10), precedence_policy=False):
+                  leaves=("list_change", "list_swap", "change", "swap"), makespan=False, ruin=(2, 5, 10), precedence_policy=False, pair_ir=False):
     """Mixed job shop (examples/mixed-job-shop/src/domain/job_shop_plan.rs:28-69): class 0 =
     operations with the scalar `machine_idx` (0..n_machines, allows_unassigned), class 1 = machines
     with the list variable `sequence` of operation ids.  BendableScore<2,1> (BASELINE.json):
@@ -114,7 +120,10 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
     d.add_fact_column_u32(FACT_CUSTOMERS, np.arange(n_ops, dtype=np.uint32))
     d.add_constraint(ConstraintKind.UNI_UNASSIGNED, 0, level=lv[0], weight=1)
     d.add_constraint(ConstraintKind.NOT_EXISTS_FLATTENED, 1, fact=FACT_CUSTOMERS, level=lv[1], weight=1)
-    d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=lv[2], weight=1)
+    if pair_ir:  # same job && same machine, job_shop_plan.rs:50-62
+        d.add_pair_join(0, [(PairOp.COL_EQ, 0, FACT_GROUP), (PairOp.VALUE_EQ, 1)], level=lv[2], weight=1)
+    else:
+        d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=lv[2], weight=1)
     if makespan:  # the makespan objective (constraint/list_precedence.rs): job order = fixed successors, problem["durations"]
         job = np.asarray(problem["job"])
         succ = [[op + 1] if op + 1 < n_ops and job[op + 1] == job[op] else [] for op in range(n_ops)]
