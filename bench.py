@@ -326,7 +326,7 @@ def main():
     ap.add_argument("--tuned-seconds", type=float, default=60.0,
                     help="M2 extension leg: wall-clock budget of the tuned configuration (0 = skip); see TUNED below")
     ap.add_argument("--c5-seconds", type=float, default=5.0,
-                    help="side leg: seconds of the same 2-leaf search on BASELINE config 5 (CVRP-5000 / 500, 2,048 replicas per GPU; 0 = skip)")
+                    help="side leg: seconds of the same 2-leaf search on BASELINE config 5 (CVRP-5000 / 500, 2,816 replicas per GPU; 0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-out", default=None, help=argparse.SUPPRESS)
@@ -527,8 +527,8 @@ def main():
     if args.c5_seconds > 0 and args.solve_seconds > 0 and args.customers != 5000 and not args.pmc_child:
         try:
             prob5 = datasets.make_cvrp(5000, 500, 55, seed=args.seed)
-            d5 = sfa.build_cvrp(prob5, n_replicas=2048, device_id=local_rank, leaves=("nearby_change", "nearby_swap"))
-            d5.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, 2048)))
+            d5 = sfa.build_cvrp(prob5, n_replicas=2816, device_id=local_rank, leaves=("nearby_change", "nearby_swap"))
+            d5.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, 2816)))
             d5.calculate_score()
             d5.phase_start()
             d5.solve_steps(100)  # warm-up launch
@@ -543,7 +543,7 @@ def main():
             a5 = d5.total_stats()
             mv5 = a5["moves_evaluated"] - b5["moves_evaluated"]
             mode5, renum5 = d5.wave_layout()
-            c5 = {"workload": "solverforge-cvrp 5000 customers / 500 vehicles, 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256), 2,048 replicas per GPU (8 per CU: launch mode 6)",
+            c5 = {"workload": "solverforge-cvrp 5000 customers / 500 vehicles, 2-leaf nearby union, LateAcceptance(400)+AcceptedCount(256), 2,816 replicas per GPU (11 per CU: launch mode 6)",
                   "seconds": s5, "launches": n5, "moves_per_s_rank0": mv5 / s5, "wave_launch_mode": mode5, "internal_node_numbering": renum5,
                   "best_score_rank0": list(max(tuple(int(v) for v in s_) for s_ in d5.best_scores()))}
             d5.close()

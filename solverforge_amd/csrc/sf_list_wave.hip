@@ -108,7 +108,7 @@ struct WCarve {
         load = o;
         o = align_up(o + (compact ? sizeof(int32_t) : sizeof(int64_t)) * V, 16);
         off = o;
-        o = align_up(o + sizeof(uint32_t) * (V + 1), 16);
+        o = align_up(o + (node_global ? sizeof(uint16_t) : sizeof(uint32_t)) * (V + 1), 16);  // (node_global layout: 16-bit offsets, n_cap <= 65535)
         node = o;
         o = align_up(o + (node_global ? 0 : (compact ? sizeof(uint16_t) : sizeof(uint32_t)) * dim), 16);
         ring = o;
@@ -116,7 +116,7 @@ struct WCarve {
         visits = o;
         o = align_up(o + sizeof(uint16_t) * n_cap, 16);
         rtab = o;  // [leaf][route] u32: rank of the route in the leaf's entity order | first destination slot ordinal << 16
-        o = align_up(o + sizeof(uint32_t) * V * MAX_LEAVES, 16);
+        o = align_up(o + (node_global ? 0 : sizeof(uint32_t) * V * MAX_LEAVES), 16);  // (node_global layout: ListModel::rtab_g)
         routeat = o;  // [leaf][rank] -> route; the compact layout recomputes it from the leaf's permutation parameters instead
         o = align_up(o + (compact ? 0 : sizeof(uint16_t) * V * MAX_LEAVES), 16);
         total = o;
@@ -132,7 +132,7 @@ struct NodeSlotT;
 template <>
 struct NodeSlotT<false> {
     uint32_t* p;
-    __device__ __forceinline__ NodeSlotT(unsigned char* base, int, const uint16_t*, const uint32_t*) : p((uint32_t*)base) {}
+    __device__ __forceinline__ NodeSlotT(unsigned char* base, int, const uint16_t*, const void*, bool = false) : p((uint32_t*)base) {}
     __device__ __forceinline__ void clear(uint32_t node) const { p[node] = NODE_NONE; }
     __device__ __forceinline__ void set(uint32_t node, uint32_t route, uint32_t pos) const { p[node] = (route << 16) | pos; }
     __device__ __forceinline__ uint32_t get(uint32_t node) const { return p[node]; }
@@ -141,10 +141,12 @@ template <>
 struct NodeSlotT<true> {
     uint16_t* p;
     const uint16_t* visits;
-    const uint32_t* off;
+    const void* off;  // uint32_t[V + 1], or uint16_t[V + 1] when off16
+    bool off16;
     uint32_t pb, pmax;  // position bits, the saturated position
-    __device__ __forceinline__ NodeSlotT(unsigned char* base, int V, const uint16_t* visits_, const uint32_t* off_)
-        : p((uint16_t*)base), visits(visits_), off(off_) {
+    __device__ __forceinline__ uint32_t off_at(uint32_t i) const { return off16 ? (uint32_t)((const uint16_t*)off)[i] : ((const uint32_t*)off)[i]; }
+    __device__ __forceinline__ NodeSlotT(unsigned char* base, int V, const uint16_t* visits_, const void* off_, bool off16_ = false)
+        : p((uint16_t*)base), visits(visits_), off(off_), off16(off16_) {
         uint32_t rb = 1;
         while ((1u << rb) - 1u < (uint32_t)V) ++rb;  // route ids 0 .. V - 1, the all-ones route is "none"
         pb = 16u - rb;
@@ -163,7 +165,7 @@ struct NodeSlotT<true> {
         // on a ballot and the common path has no exec-mask region at all
         if (__ballot(!none && pos == pmax) != 0ull) {
             if (!none && pos == pmax) {
-                const uint32_t o = off[route], len = off[route + 1] - o;
+                const uint32_t o = off_at(route), len = off_at(route + 1) - o;
                 while (pos + 1 < len && (uint32_t)visits[o + pos] != node) ++pos;
             }
         }
@@ -214,8 +216,9 @@ __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot,
 // Same item with the per-route facts read from ONE packed table (wave engine): rt[route] = rank of the route in the
 // leaf's entity order | ordinal of the route's first destination slot << 16 — one LDS gather instead of the dependent
 // pair rank_of[route] -> slot_base[rank].
+template <class OT>
 __device__ __forceinline__ NearbyItem nearby_item_rt(bool is_change, uint32_t slot, uint32_t se, uint32_t sp,
-                                                     uint32_t len, uint32_t k, const uint32_t* s_off, const uint32_t* rt) {
+                                                     uint32_t len, uint32_t k, const OT* s_off, const uint32_t* rt) {
     const bool some = slot != NODE_NONE;
     const uint32_t r2 = some ? slot >> 16 : 0u, dp = slot & 0xFFFFu;
     const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
@@ -248,8 +251,8 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t mask) {
 }
 
 // Committed move application on the wave's LDS state (ListChange / ListSwap do_move).
-template <class LT>  // LT = the replica's per-list load type in LDS: int64_t, or int32_t in the COMPACT wave layout
-__device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_t* visits, uint32_t* off,
+template <class LT, class OT>  // LT = the replica's per-list load type in LDS: int64_t, or int32_t in the COMPACT wave layout; OT = offsets, uint32_t or uint16_t
+__device__ __forceinline__ void apply_list_move_wave(const ListModel& m, uint16_t* visits, OT* off,
                                                      LT* load, int kind, uint32_t a, uint32_t i, uint32_t b,
                                                      uint32_t j, uint32_t ext = 0) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -529,8 +532,8 @@ __device__ __forceinline__ int32_t clamp_i64_to_i32(int64_t v) {
 // eval_list_move_legs, laid out as four "plus" and four "minus" legs so no lane multiplies by a sign, gathered from
 // the compact u32 matrix through 32-bit byte offsets; every leg finite (host-checked), sums < 2^30.
 // dv[k] = change of score level k.  Returns doable.
-template <int L, class LT, bool M16 = false>
-__device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const uint16_t* visits, const uint32_t* off, const LT* load,
+template <int L, class LT, bool M16 = false, class OT = uint32_t>
+__device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const uint16_t* visits, const OT* off, const LT* load,
                                                      bool chg, uint32_t a, uint32_t i, uint32_t b, uint32_t j, int32_t (&dv)[L]) {
     // Branch-free on purpose: every neighbour is read from a position that always exists (the source position when the real one does
     // not) and replaced by the depot with a select afterwards, the doability tests are one predicate at the end.  Conditional LDS reads
@@ -644,6 +647,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     static_assert(!COMPACT || SMALL, "COMPACT stores loads in 32 bits: MODE 2 only");
     static_assert(!NODEG || COMPACT, "NODEG: the 16-bit table of the COMPACT layout");
     using LT = typename std::conditional<COMPACT, int32_t, int64_t>::type;
+    using OT = typename std::conditional<NODEG, uint16_t, uint32_t>::type;  // list offsets in the slice (NODEG: 16 bits, n_cap <= 65535 in this engine)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u;
     // wave-uniform by construction; saying so keeps every per-replica base pointer in scalar registers (they were 64-bit VGPR pairs
@@ -672,10 +676,10 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     const uint32_t RCM = cv.rc - 1;
     unsigned char* mem = smem + (size_t)wave_in_group * cv.total;
     LT* s_load = (LT*)(mem + cv.load);
-    uint32_t* s_off = (uint32_t*)(mem + cv.off);
+    OT* s_off = (OT*)(mem + cv.off);
     uint32_t* ring = (uint32_t*)(mem + cv.ring);  // [leaf][rc][2]
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
-    const NodeSlotT<COMPACT> node_slot(NODEG ? (unsigned char*)(m.node_tab + (size_t)r * dim) : mem + cv.node, V, s_visits, s_off);
+    const NodeSlotT<COMPACT> node_slot(NODEG ? (unsigned char*)(m.node_tab + (size_t)r * dim) : mem + cv.node, V, s_visits, (const void*)s_off, NODEG);
     // table writes -> table reads of other lanes: LDS in program order (wave_sync); HBM through the CU's write-through L1 (ring_sync's fences)
     auto node_sync = [&]() {
         if constexpr (NODEG) {
@@ -686,7 +690,8 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             wave_sync();
         }
     };
-    uint32_t* rtab = (uint32_t*)(mem + cv.rtab);      // [leaf][route] rank | first slot ordinal << 16
+    // [leaf][route] rank | first slot ordinal << 16; NODEG: in HBM like the node table (rebuilt every step, read one global round trip behind it)
+    uint32_t* rtab = NODEG ? m.rtab_g + (size_t)r * MAX_LEAVES * V : (uint32_t*)(mem + cv.rtab);
     uint16_t* route_at = (uint16_t*)(mem + cv.routeat);  // [leaf][rank] -> route
 
     uint32_t* g_visits = m.visits + (size_t)r * m.n_cap;
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     const bool tracing = TRACE && r == p.trace_replica;
 
     // ---- load replica state into LDS ----
-    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = g_off[t];
+    for (uint32_t t = lane; t <= (uint32_t)V; t += 64) s_off[t] = (OT)g_off[t];
     for (uint32_t t = lane; t < (uint32_t)V; t += 64) s_load[t] = (LT)g_load[t];
     for (uint32_t t = lane; t < dim; t += 64) node_slot.clear(t);
     node_sync();
@@ -905,6 +910,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             }
         }
         wave_sync();
+        if constexpr (NODEG) node_sync();  // (the route table lives in HBM here)
         if (total > 0) {
             resolve(C0, 0);
             if (n_leaves > 1) resolve(C1, 1);
@@ -1175,7 +1181,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                         m0 = rq[0];
                         m1 = rq[1];
                         const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
-                        doable = eval_list_move_small<L, LT, COMPACT>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j, dv);  // COMPACT reads the u16 matrix
+                        doable = eval_list_move_small<L, LT, COMPACT, OT>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j, dv);  // COMPACT reads the u16 matrix
                     }
                     // LateAcceptance: score >= last step score || score >= late score (late_acceptance.rs:89-125)
                     acc = doable && (small_ge0<L>(dv) || small_ge<L>(dv, late_d));
