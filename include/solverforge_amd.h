@@ -600,6 +600,14 @@ int32_t sf_default_local_search_components(int32_t has_lists, int32_t has_groups
  * has_precedence = the list slot declares its precedence hooks (sf_list_set_precedence_policy) or carries the critical-path leaf
  * (list::supports_precedence_moves, policy/list.rs:287-299), has_nearby_scalar = a nearby scalar leaf is declared.  Scalar groups
  * and conflict repairs are host-side providers: the caller says whether the model has them.  out (may be NULL) = what was set. */
+/* Host-side providers of the model, declared so that the default policy can be derived instead of passed in: a scalar group
+ * (planning/scalar/group.rs: ScalarGroup with a candidate provider or an assignment rule) or a conflict repair
+ * (planning/conflict_repair.rs:62-84: ConflictRepair::new(constraint_name, provider)).  The providers themselves stay on the host -- the
+ * reference's RuntimeProviderCursor (runtime/provider_cursor.rs) pulls, normalises, caps and rotates their output and hands every
+ * compound candidate to sf_step_decide_gated (gate bit 0 = its require_hard_improvement) -- the context only records that they exist. */
+typedef enum sf_provider_kind { SF_PROVIDER_SCALAR_GROUP = 1, SF_PROVIDER_CONFLICT_REPAIR = 2 } sf_provider_kind;
+int32_t sf_provider_declare(sf_ctx* ctx, int32_t kind, const char* name);
+/* has_groups / has_conflict_repairs = -1: derived from sf_provider_declare (0 / 1: as passed, the behaviour of rounds 1-4) */
 int32_t sf_solver_configure_default(sf_ctx* ctx, uint64_t random_seed, int32_t has_groups, int32_t has_conflict_repairs,
                                     sf_solver_config* out);
 /* parameters of SF_ACCEPT_SIMULATED_ANNEALING (takes effect at the next sf_phase_start); validation follows

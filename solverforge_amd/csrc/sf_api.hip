@@ -99,6 +99,7 @@ struct sf_ctx {
     NbrIndex nbr_wave{nullptr};   // ... and its neighbour index
     bool wave_renumbered = false;
     int last_wave_mode = -1;      // launch mode of the last wave-engine launch (sf_list_wave_layout)
+    std::vector<std::pair<int, std::string>> providers;  // host-side providers declared through sf_provider_declare
     uint32_t* d_node_tab32 = nullptr;  // [R][dim] node -> slot tables of the generic engine's FAST + ruin kernel (GLeaves::node_tab)
     struct WaveFix {  // what differs in lm_wave from lm (applied at launch: the per-replica state pointers of lm may be set later)
         const uint16_t *perm, *inv, *mat16;
@@ -2225,8 +2226,25 @@ int32_t sf_default_local_search_components(int32_t has_lists, int32_t has_groups
     return SF_OK;
 }
 
+int32_t sf_provider_declare(sf_ctx* ctx, int32_t kind, const char* name) {
+    if (!ctx) return SF_ERR_INVALID;
+    if (kind != SF_PROVIDER_SCALAR_GROUP && kind != SF_PROVIDER_CONFLICT_REPAIR) return fail(ctx, SF_ERR_INVALID, "sf_provider_declare: unknown provider kind");
+    if (!name || !*name) return fail(ctx, SF_ERR_INVALID, "sf_provider_declare: a provider needs a name (the group's / the repaired constraint's)");
+    ctx->providers.push_back({kind, std::string(name)});
+    return SF_OK;
+}
+
 int32_t sf_solver_configure_default(sf_ctx* ctx, uint64_t random_seed, int32_t has_groups, int32_t has_conflict_repairs, sf_solver_config* out) {
     if (!ctx) return SF_ERR_INVALID;
+    if (has_groups < 0 || has_conflict_repairs < 0) {  // derived from what was declared
+        bool g = false, r = false;
+        for (const auto& pv : ctx->providers) {
+            g = g || pv.first == SF_PROVIDER_SCALAR_GROUP;
+            r = r || pv.first == SF_PROVIDER_CONFLICT_REPAIR;
+        }
+        if (has_groups < 0) has_groups = g ? 1 : 0;
+        if (has_conflict_repairs < 0) has_conflict_repairs = r ? 1 : 0;
+    }
     bool has_lists = false, has_precedence = ctx->prec_policy, has_nearby_scalar = false;
     for (const auto& kv : ctx->classes) has_lists = has_lists || kv.second.has_list;
     for (const auto& s : ctx->selectors) {

@@ -433,11 +433,17 @@ class GpuScoreDirector:
                                int(cfg.random_ties), cfg.selection_order, cfg.random_seed)
         check(self._L.sf_solver_configure(self._h, C.byref(s)), self._h)
 
-    def configure_default(self, random_seed=0, has_groups=False, has_conflict_repairs=False):
+    def declare_provider(self, kind, name):
+        """A host-side provider of the model (sf_provider_declare): kind 1 = scalar group, 2 = conflict repair; configure_default derives
+        the default policy's has_groups / has_conflict_repairs from these when they are not passed."""
+        check(self._L.sf_provider_declare(self._h, int(kind), name.encode()), self._h)
+
+    def configure_default(self, random_seed=0, has_groups=None, has_conflict_repairs=None):
         """The reference's default acceptor + forager for THIS model (sf_solver_configure_default: lists / precedence hooks / nearby
         scalar leaves are read from the context); returns the SolverConfig that was set."""
         s = SolverConfigStruct()
-        check(self._L.sf_solver_configure_default(self._h, random_seed, int(has_groups), int(has_conflict_repairs), C.byref(s)), self._h)
+        check(self._L.sf_solver_configure_default(self._h, random_seed, -1 if has_groups is None else int(has_groups),
+                                                   -1 if has_conflict_repairs is None else int(has_conflict_repairs), C.byref(s)), self._h)
         return SolverConfig(acceptor=s.acceptor, late_acceptance_size=s.late_acceptance_size, forager=s.forager,
                             accepted_count_limit=s.accepted_count_limit, random_ties=bool(s.random_ties),
                             selection_order=s.selection_order, random_seed=s.random_seed)

@@ -58,3 +58,37 @@ def test_truth_table_of_the_default_components():
 def test_named_rows(flags, want):
     cfg = SolverConfig.default_components(*flags)
     assert (cfg.acceptor, cfg.forager, cfg.accepted_count_limit) == want
+
+
+@pytest.mark.gpu
+def test_configure_default_derives_the_provider_flags_from_declarations():
+    """sf_provider_declare: scalar groups and conflict repairs are host-side providers (planning/scalar/group.rs, planning/conflict_repair.rs:62-84);
+    once declared, sf_solver_configure_default reads has_groups / has_conflict_repairs from the context (policy.rs:21-82) instead of taking them
+    from the caller.  Scalar-only model: nothing declared -> SimulatedAnnealing + AcceptedCount(1); a conflict repair -> AcceptedCount(256); a group ->
+    DiversifiedLateAcceptance(400) + FirstLastStepScoreImproving without a limit."""
+    import numpy as np
+
+    import solverforge_amd as sfa
+
+    def model():
+        return sfa.build_nqueens((np.arange(12) % 13).astype(np.int64) - 1)
+
+    d = model()
+    c = d.configure_default(random_seed=1)
+    assert (c.acceptor, c.forager, c.accepted_count_limit) == (sfa.Acceptor.SIMULATED_ANNEALING, sfa.Forager.ACCEPTED_COUNT, 1)
+    d.close()
+    d = model()
+    d.declare_provider(2, "Row conflict")
+    c = d.configure_default(random_seed=1)
+    assert (c.acceptor, c.forager, c.accepted_count_limit) == (sfa.Acceptor.SIMULATED_ANNEALING, sfa.Forager.ACCEPTED_COUNT, 256)
+    assert d.configure_default(random_seed=1, has_conflict_repairs=False).accepted_count_limit == 1  # an explicit flag still wins
+    d.close()
+    d = model()
+    d.declare_provider(1, "rows")
+    c = d.configure_default(random_seed=1)
+    assert (c.acceptor, c.forager, c.accepted_count_limit) == (sfa.Acceptor.DIVERSIFIED_LATE_ACCEPTANCE, sfa.Forager.FIRST_LAST_STEP_SCORE_IMPROVING, 0)
+    with pytest.raises(sfa.SolverForgeError):
+        d.declare_provider(7, "x")
+    with pytest.raises(sfa.SolverForgeError):
+        d.declare_provider(1, "")
+    d.close()
