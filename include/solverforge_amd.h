@@ -170,7 +170,18 @@ typedef enum sf_constraint_kind {
      * sum over presence.complement_runs(lo..hi) of max(0, run.point_count - cap) instead -- the runs of ABSENT points inside the
      * horizon ("consecutive off bounds" of crates/solverforge-macros/tests/ui/pass/solverforge_constraints_indexed_presence.rs).  Shares the per-(value, point) count table and the
      * slot of SF_C_RUNS_VALUE (one of the two per class); scalar engine only; not chained in compound candidates */
-    SF_C_PRESENCE_VALUE = 17
+    SF_C_PRESENCE_VALUE = 17,
+    /* A join of the TWO planning classes of a mixed model, both sides moving (constraint/cross_bi_incremental/incremental.rs:93-137: an
+     * insert / retract of either class runs its own side, state.rs:372-461):
+     *   for_each(E).join(for_each(Owner), equal(e.value, owner.index)).filter(|e, o| !o.list.contains(e.id)).penalize(weight)
+     * -- every entity of the scalar class `descriptor_index` whose assigned value names a list owner that does not hold it (a job-shop
+     * operation assigned to a machine that does not schedule it).  `param` = descriptor of the list class; the scalar variable's values are
+     * the owner indices (n_values == owners), the list elements are the scalar class's entity ids.  A scalar move changes the A side's key, a
+     * list move the B side's filter: both are priced on the device (generic engine), the committed match table is an entity -> holding
+     * list map in HBM.  Fused / traced search, sf_step_generate, sf_initialize / sf_evaluate_all / sf_evaluate_each; the host-driven entry
+     * points (sf_step_evaluate, sf_apply, sf_step_decide*, compound candidates, construction) and unions with ruin / precedence leaves
+     * return SF_ERR_UNSUPPORTED for a model that declares it */
+    SF_C_CROSS_OWNER_MATCH = 18
 } sf_constraint_kind;
 
 /* ---- pair predicates as data (round 5) -------------------------------------------------------------------------------------

@@ -80,6 +80,7 @@ def lib():
             "sfo_shift_schedule_create_presence": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
             "sfo_precedence_shop_create": (vp, [i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32]),
             "sfo_jobshop_create": (vp, [i32, i32, vp, vp, vp, vp, i32]),
+            "sfo_jobshop_create_owner_match": (vp, [i32, i32, vp, vp, vp, vp, i32, i32]),
             "sfo_jobshop_create_makespan": (vp, [i32, i32, vp, vp, vp, vp, i32, i32, vp]),
             "sfo_model_destroy": (None, [vp]),
             "sfo_model_score": (None, [vp, vp]),
@@ -248,11 +249,14 @@ class Model:
         return Model(h, [len(lists)])
 
     @staticmethod
-    def jobshop(job, machine_idx, sequences, bendable=True, indexed=False, durations=None):
+    def jobshop(job, machine_idx, sequences, bendable=True, indexed=False, durations=None, owner_match_level=None):
         """durations: adds the ListPrecedenceMakespanConstraint (job order + machine sequences) -- the makespan objective."""
         job = np.ascontiguousarray(job, dtype=np.int64)
         machine_idx = np.ascontiguousarray(machine_idx, dtype=np.int64)
         off, vals = csr(sequences)
+        if owner_match_level is not None:  # + the join of the two planning classes (an operation on a machine that does not schedule it)
+            h = lib().sfo_jobshop_create_owner_match(len(job), len(sequences), _p(job), _p(machine_idx), _p(off), _p(vals), int(bendable), int(owner_match_level))
+            return Model(h, [len(job), len(sequences)])
         if durations is not None:
             dur = np.ascontiguousarray(durations, dtype=np.int64)
             h = lib().sfo_jobshop_create_makespan(len(job), len(sequences), _p(job), _p(machine_idx), _p(off), _p(vals), int(bendable),

@@ -191,6 +191,10 @@ void* sfo_jobshop_create_makespan(int32_t n_ops, int32_t n_machines, const int64
                                   const uint32_t* seq_vals, int32_t bendable, int32_t indexed, const int64_t* duration) {
     return make_jobshop((size_t)n_ops, (size_t)n_machines, job, machine_idx, seq_off, seq_vals, bendable != 0, indexed != 0, duration).release();
 }
+void* sfo_jobshop_create_owner_match(int32_t n_ops, int32_t n_machines, const int64_t* job, const int64_t* machine_idx, const uint32_t* seq_off,
+                                     const uint32_t* seq_vals, int32_t bendable, int32_t owner_match_level) {
+    return make_jobshop((size_t)n_ops, (size_t)n_machines, job, machine_idx, seq_off, seq_vals, bendable != 0, false, nullptr, owner_match_level).release();
+}
 void* sfo_jobshop_create(int32_t n_ops, int32_t n_machines, const int64_t* job, const int64_t* machine_idx,
                          const uint32_t* seq_off, const uint32_t* seq_vals, int32_t bendable) {
     return make_jobshop((size_t)n_ops, (size_t)n_machines, job, machine_idx, seq_off, seq_vals, bendable != 0)

@@ -609,7 +609,7 @@ inline std::unique_ptr<Model> make_list_toy(size_t n_entities, const uint32_t* o
 inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, const int64_t* job,
                                            const int64_t* machine_idx, const uint32_t* seq_off,
                                            const uint32_t* seq_vals, bool bendable, bool indexed = false,
-                                           const int64_t* duration = nullptr) {
+                                           const int64_t* duration = nullptr, int owner_match_level = -1) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<JobShopFacts>();
     facts->n_ops = n_ops;
@@ -684,6 +684,30 @@ inline std::unique_ptr<Model> make_jobshop(size_t n_ops, size_t n_machines, cons
         m->director.constraints.members.push_back(std::move(ix));
     } else
         m->director.constraints.members.push_back(std::move(reuse));
+
+    if (owner_match_level >= 0) {
+        // A join of the TWO planning classes, both sides moving (constraint/cross_bi_incremental/incremental.rs:93-137: an insert / retract
+        // of an operation runs insert_a / retract_a, of a machine insert_b / retract_b; state.rs:372-461): every operation whose assigned
+        // machine does not schedule it -- for_each(Operation).join(for_each(Machine), equal(op.machine_idx, machine.id))
+        // .filter(|op, m| !m.sequence.contains(op.id)).penalize(1).  Scalar moves change the A side's key, list moves the B side's filter.
+        auto mm = std::make_unique<CrossBiConstraint>();
+        mm->name = "Operation on a machine that does not schedule it";
+        mm->impact = Impact::Penalty;
+        mm->a_source = ChangeSource::descriptor(0);
+        mm->b_source = ChangeSource::descriptor(1);
+        mm->a_count = [](const Solution& s) { return s.classes[0].n; };
+        mm->b_count = [](const Solution& s) { return s.classes[1].n; };
+        mm->key_a = [](const Solution& s, size_t a) { return s.classes[0].vars[0][a]; };  // NONE (-1) joins no machine
+        mm->key_b = [](const Solution&, size_t b) { return (int64_t)b; };
+        mm->filter = [](const Solution& s, size_t a, size_t b) {
+            for (uint32_t v : s.classes[1].lists[b])
+                if ((size_t)v == a) return false;
+            return true;
+        };
+        const Score w_mm = bendable ? Score::level(owner_match_level, 1) : Score::of(owner_match_level == 0 ? 1 : 0, owner_match_level == 0 ? 0 : 1);
+        mm->weight = [w_mm](const Solution&, size_t, size_t) { return w_mm; };
+        m->director.constraints.members.push_back(std::move(mm));
+    }
 
     if (duration) {  // the makespan objective: ListPrecedenceMakespanConstraint over the job order and the machine sequences
         auto dur = std::make_shared<std::vector<int64_t>>(duration, duration + n_ops);

@@ -171,9 +171,11 @@ def run_case(seed):
             p["durations"] = (datasets.stream(seed + 41, p["n_ops"]) % np.uint64(9)).astype(np.int64) + 1
             if rng.random() < 0.5 and len(p["sequences"][0]) > 1:
                 p["sequences"][0] = p["sequences"][0][::-1]  # against the job order: cycles
-        desc.update(makespan=mk)
-        d = sfa.build_jobshop(p, leaves=leaves, makespan=mk)
-        o = sfo.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, durations=p["durations"] if mk else None)
+        # the join of the two planning classes (an operation on a machine that does not schedule it), on a random level
+        own = int(rng.integers(0, 3)) if (not mk and rng.random() < 0.45) else None
+        desc.update(makespan=mk, owner_match_level=own)
+        d = sfa.build_jobshop(p, leaves=leaves, makespan=mk, owner_match_level=own)
+        o = sfo.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, durations=p["durations"] if mk else None, owner_match_level=own)
         o.set_kopt(1, 0)
         lists = lambda: ((d.working_lists(1, 0), d.working_values(0, 0).tolist()), (o.get_lists(1), o.get_vars(0, 0).tolist()))
     bits = sum(BITS[x] for x in leaves)

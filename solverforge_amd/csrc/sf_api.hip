@@ -99,6 +99,9 @@ struct sf_ctx {
     NbrIndex nbr_wave{nullptr};   // ... and its neighbour index
     bool wave_renumbered = false;
     int last_wave_mode = -1;      // launch mode of the last wave-engine launch (sf_list_wave_layout)
+    int xown_level = -1;             // SF_C_CROSS_OWNER_MATCH of a mixed model: level / weight / the [R][n_scalar] entity -> holding list map
+    int64_t xown_weight = 0;
+    uint16_t* d_xown_tab = nullptr;
     std::vector<std::pair<int, std::string>> providers;  // host-side providers declared through sf_provider_declare
     uint32_t* d_node_tab32 = nullptr;  // [R][dim] node -> slot tables of the generic engine's FAST + ruin kernel (GLeaves::node_tab)
     struct WaveFix {  // what differs in lm_wave from lm (applied at launch: the per-replica state pointers of lm may be set later)
@@ -420,7 +423,7 @@ int32_t sf_constraint_add(sf_ctx* ctx, int32_t kind, int32_t d, int32_t var, int
                           int32_t level, int64_t weight) {
     if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
     if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
-    if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE && kind != SF_C_COMPLEMENTED_VALUE_SUM && kind != SF_C_PRESENCE_VALUE)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
+    if (kind < SF_C_UNI_UNASSIGNED || (kind > SF_C_BALANCE_VALUE && kind != SF_C_RUNS_VALUE && kind != SF_C_COMPLEMENTED_VALUE_SUM && kind != SF_C_PRESENCE_VALUE && kind != SF_C_CROSS_OWNER_MATCH)) return fail(ctx, SF_ERR_UNSUPPORTED, "constraint kind");
     ctx->constraints.push_back({kind, d, var, fact_a, param, level, weight, {}});
     return SF_OK;
 }
@@ -1273,6 +1276,9 @@ static int run_evaluate_all(sf_ctx* ctx, int64_t* out, int commit, int64_t* d_pa
     if (ctx->has_scalar_model)  // mixed model: the scalar class adds its constraints to the list class's scores
         hipLaunchKernelGGL(k_scalar_evaluate_all, dim3(ctx->R), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm,
                            ctx->d_scores_out, commit, ctx->has_list_model ? 1 : 0, d_parts);
+    if (ctx->xown_level >= 0)  // the join of the two planning classes adds its level
+        hipLaunchKernelGGL(k_cross_owner_evaluate_all, dim3(ctx->R), dim3(256), 0, ctx->stream, ctx->lm, ctx->sm.vals, ctx->sm.n, ctx->xown_level, ctx->xown_weight,
+                           ctx->d_scores_out, commit, d_parts);
     if (ctx->has_list_model && ctx->pm.on)  // after the other constraints wrote their sums: adds its two levels
         hipLaunchKernelGGL(k_prec_evaluate_all, dim3(ctx->R), dim3(64), 0, ctx->stream, ctx->lm, ctx->pm, ctx->d_scores_out, commit, d_parts);
     HIPCHK(ctx, hipGetLastError());
@@ -1313,6 +1319,18 @@ int32_t sf_initialize(sf_ctx* ctx, int64_t* out_scores) {
             ctx->sm.score = ctx->lm.score;
             ctx->sm.best_score = ctx->lm.best_score;
         }
+        for (auto& cs : ctx->constraints) {
+            if (cs.kind != SF_C_CROSS_OWNER_MATCH) continue;
+            if (!n_list || !n_scalar || cs.desc != sd || (int)cs.param != ld)
+                return fail(ctx, SF_ERR_INVALID, "owner match: a join of the scalar class (descriptor_index) with the list class (param) of a mixed model");
+            if (ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "one join of the two planning classes per context");
+            if (ctx->sm.n_values != ctx->lm.V) return fail(ctx, SF_ERR_INVALID, "owner match: the scalar variable's values must be the list owner indices (n_values == owners)");
+            if (ctx->lm.dim > ctx->sm.n) return fail(ctx, SF_ERR_INVALID, "owner match: the list elements must be entity ids of the scalar class");
+            if (ctx->sm.n > 65534) return fail(ctx, SF_ERR_UNSUPPORTED, "owner match: more than 65534 entities");
+            ctx->xown_level = cs.level;
+            ctx->xown_weight = cs.weight;
+            if ((rc = dalloc(ctx, &ctx->d_xown_tab, (size_t)ctx->R * ctx->sm.n))) return rc;
+        }
         ctx->initialized = true;
     }
     return run_evaluate_all(ctx, out_scores, 1);
@@ -1347,6 +1365,7 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_UNI_UNASSIGNED: raw = q[3], count = q[16]; break;  // weighted sum / entities passing the filter
             case SF_C_CROSS_ADJACENT_EQUAL:
             case SF_C_CROSS_GROUP_EQUAL:
+            case SF_C_CROSS_OWNER_MATCH: raw = q[17], count = q[17]; break;
             case SF_C_PAIR_JOIN_:
             case SF_C_CROSS_QUEENS: raw = q[4], count = q[4]; break;
             case SF_C_SELFJOIN_VALUE_EQUAL: raw = q[5], count = q[5]; break;
@@ -1442,6 +1461,7 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (replica < 0 || replica >= ctx->R || n < 0 || !moves || !out_scores || !out_doable)
         return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate arguments");
+    if (ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_evaluate: a model with the join of its two planning classes is searched by the fused engine only");
     if (n == 0) return SF_OK;
     // one allocation per call, released on every path (hipFree(nullptr) is a no-op)
     int32_t* d_moves = nullptr;
@@ -1514,6 +1534,7 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
 int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n,
                                   int64_t* out_scores, int32_t* out_doable) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_evaluate_compound: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
     if (replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_scores || !out_doable)
@@ -1563,6 +1584,7 @@ int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t*
 
 int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_apply_compound: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized || !edits || replica < 0 || replica >= ctx->R) return fail(ctx, SF_ERR_INVALID, "bad sf_apply_compound arguments");
     if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
     if (n_edits <= 0) return fail(ctx, SF_ERR_INVALID, "move is not doable");
@@ -1605,6 +1627,7 @@ int32_t sf_step_decide_gated(sf_ctx* ctx, int32_t replica, const sf_move_t* edit
                              int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
                              int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_decide_gated: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized || replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_kept || !out_n_kept || !out_scores || !out_flags ||
         !out_consumed || !out_selected)
         return fail(ctx, SF_ERR_INVALID, "bad sf_step_decide arguments");
@@ -1731,6 +1754,7 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !mv || replica < 0 || replica >= ctx->R)
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
+    if (ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_apply: a model with the join of its two planning classes is searched by the fused engine only");
     int rc = alloc_search(ctx);
     if (rc) return rc;
     if (mv->kind == SF_MOVE_LIST_RUIN) {  // committed ruin + recreate: its own kernel (one wavefront)
@@ -1918,6 +1942,7 @@ static int construct_cheapest_precedence(sf_ctx* ctx, const uint32_t* elements, 
 
 int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int64_t* out_scores) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_construct_list_cheapest: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "cheapest insertion needs the list variable's class");
     if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_cheapest arguments");
@@ -1959,6 +1984,7 @@ int32_t sf_construct_list_cheapest(sf_ctx* ctx, int32_t descriptor_index, const 
 int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
                                  const int32_t* owners, int64_t* out_scores) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_construct_list_regret: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "regret insertion needs the list variable's class");
     if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_regret arguments");
@@ -2031,6 +2057,7 @@ int32_t sf_construct_list_regret(sf_ctx* ctx, int32_t descriptor_index, const ui
 // ≙ ListKOptPhase (route-local 2-opt) over every replica's current lists (csrc/sf_clarke_wright.hip)
 int32_t sf_construct_list_k_opt(sf_ctx* ctx, int32_t descriptor_index, int32_t k, int32_t feasible_mode, int32_t max_sweeps, int64_t* out_scores) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_construct_list_k_opt: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "list k-opt needs the list variable's class");
     if (feasible_mode != 0 && feasible_mode != 1) return fail(ctx, SF_ERR_INVALID, "feasible_mode: 0 no feasibility hook, 1 capacity");
@@ -2059,6 +2086,7 @@ int32_t sf_construct_list_k_opt(sf_ctx* ctx, int32_t descriptor_index, int32_t k
 int32_t sf_construct_list_round_robin(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, const int64_t* order_keys,
                                       const int32_t* owners, int64_t* out_scores) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_construct_list_round_robin: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "round robin needs the list variable's class");
     if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_round_robin arguments");
@@ -2111,6 +2139,7 @@ int32_t sf_construct_list_round_robin(sf_ctx* ctx, int32_t descriptor_index, con
 int32_t sf_construct_list_clarke_wright(sf_ctx* ctx, int32_t descriptor_index, const uint32_t* elements, int32_t n, int32_t feasible_mode,
                                         int64_t* out_scores, int32_t* out_committed) {
     DeviceGuard _dev(ctx);
+    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_construct_list_clarke_wright: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_list_model || descriptor_index != ctx->list_desc) return fail(ctx, SF_ERR_INVALID, "Clarke-Wright needs the list variable's class");
     if (n < 0 || (n > 0 && !elements)) return fail(ctx, SF_ERR_INVALID, "bad sf_construct_list_clarke_wright arguments");
@@ -2532,6 +2561,7 @@ static int ensure_plf(sf_ctx* ctx) {
 static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     GLeaves gl{};
     gl.list_desc = ctx->has_list_model ? ctx->list_desc : 0;
+    gl.xown_level = ctx->xown_level, gl.xown_weight = ctx->xown_weight, gl.xown_tab = ctx->d_xown_tab;
     // default-policy declaration order: list rules first, then scalar change, scalar swap
     // (runtime/compiler/default_local_search/policy.rs:104-108).  A configured root union (sf_union_configure) keeps the
     // order of the sf_selector_add calls instead: its weights and the Sequential / RoundRobin child order follow the
@@ -2599,8 +2629,11 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
                 gl.plf = ctx->plf;
                 gl.plf.leaf = 1;
             }
+            if (kind == SF_SEL_LIST_PRECEDENCE && ctx->xown_level >= 0)
+                return fail(ctx, SF_ERR_UNSUPPORTED, "the join of the two planning classes is not priced by the critical-path leaf's block moves");
             if (kind == SF_SEL_LIST_RUIN) {
                 if (gl.has_ruin) return fail(ctx, SF_ERR_UNSUPPORTED, "one list ruin leaf per union");
+                if (ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "the join of the two planning classes is not priced by the ruin leaf's recreate");
                 if (!ctx->d_ruin_rng) return fail(ctx, SF_ERR_INVALID, "list ruin leaf: sf_phase_start seeds its stream first");
                 gl.has_ruin = 1;
                 gl.ruin = RuinParams{s.min_size, s.max_size, s.moves_per_step, s.max_source_len, s.skip_empty, ctx->d_ruin_rng};

@@ -792,6 +792,37 @@ __global__ __launch_bounds__(256) void k_mat_compress16(const int64_t* __restric
     }
 }
 
+// Join of the two planning classes of a mixed model (SF_C_CROSS_OWNER_MATCH): assigned scalar entities whose value is not the list that
+// holds them = assigned - (list elements whose value is their owner).  grid = R; adds its level to the scores the other kernels wrote.
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_cross_owner_evaluate_all(ListModel m, const int32_t* vals, int n_scalar, int level, int64_t weight, int64_t* out_scores,
+                                                                  int commit, int64_t* out_parts) {
+    __shared__ unsigned long long s_cnt[2];
+    const int r = blockIdx.x;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int32_t* v = vals + (size_t)r * n_scalar;
+    unsigned long long assigned = 0, matched = 0;
+    for (int e = threadIdx.x; e < n_scalar; e += blockDim.x) assigned += v[e] >= 0 ? 1 : 0;
+    const uint32_t* off = m.off + (size_t)r * (m.V + 1);
+    const uint32_t* vis = m.visits + (size_t)r * m.n_cap;
+    for (int o = 0; o < m.V; ++o)
+        for (uint32_t q = off[o] + threadIdx.x; q < off[o + 1]; q += blockDim.x) {
+            const uint32_t e = vis[q];
+            matched += (e < (uint32_t)n_scalar && v[e] == o) ? 1 : 0;
+        }
+    atomicAdd(&s_cnt[0], assigned);
+    atomicAdd(&s_cnt[1], matched);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t cnt = (int64_t)(s_cnt[0] - s_cnt[1]);
+        const int64_t pen = (int64_t)((uint64_t)weight * (uint64_t)cnt);
+        if (out_scores) out_scores[(size_t)r * m.levels + level] -= pen;
+        if (commit) m.score[(size_t)r * 4 + level] -= pen;
+        if (out_parts) out_parts[(size_t)r * SF_EACH_WORDS + 17] = cnt;
+    }
+}
+
 // internal node numbering of the COMPACT wave kernel (ListModel::perm): the u16 matrix with rows and columns in internal order ...
 SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_mat16_renumber(const uint16_t* __restrict__ src, const uint16_t* __restrict__ inv, int dim, uint16_t* __restrict__ dst) {

@@ -64,7 +64,7 @@ struct ListModel {
 // words per replica of the evaluate_each aggregates: list class 0..2 (capacity, distance, not-exists), scalar class
 // 3..11 (unassigned, predicate-join pairs, keyed self-join pairs, grouped weight sum, non-empty groups, pair-cost sum, pairs
 // with a non-zero cost, existence weight sum, rows whose existence test holds)
-constexpr int SF_EACH_WORDS = 18;  // + list precedence: 12 hard penalty, 13 makespan; consecutive runs: 14 summed excess, 15 groups; 16 matches of the unassigned filter
+constexpr int SF_EACH_WORDS = 18;  // + list precedence: 12 hard penalty, 13 makespan; consecutive runs: 14 summed excess, 15 groups; 16 matches of the unassigned filter; 17 join of the two planning classes
 
 struct LeafSpec {
     int32_t kind;        // sf_selector_kind

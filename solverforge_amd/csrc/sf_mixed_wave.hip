@@ -106,6 +106,12 @@ struct GLeaves {
     int32_t prec_static;     // bytes of the workgroup-shared LDS copy of the constraint's static graph (0 = read it from HBM)
     int32_t prec_groups;     // LDS scratch: trials per wavefront of the grouped evaluator (prec_eval_grouped: 8, 4 or 2; 0 = off)
     PlfModel plf;            // critical-path precedence leaf (kind 16384; PREC instantiations, sf_prec_leaf.h)
+    // Join of the two planning classes (SF_C_CROSS_OWNER_MATCH; cross_bi_incremental/incremental.rs:93-137 with A = the scalar class keyed
+    // by its value, B = the list owners keyed by their index, filter = the owner's list does not contain the entity): xown_level < 0 = absent.
+    // xown_tab [R][n_scalar] u16 in HBM: the list that holds every scalar entity's id (0xFFFF = none) -- what a scalar move's trial reads.
+    int32_t xown_level;
+    int64_t xown_weight;
+    uint16_t* xown_tab;
     uint32_t* node_tab;      // [R][dim] node -> (list << 16 | position) in HBM: the FAST + ruin instantiation keeps it out of the LDS slice (12 replicas per CU)
 };
 
@@ -249,6 +255,37 @@ __device__ __forceinline__ void map_slots_to_groups(uint32_t cnt, uint32_t slot,
     }
     group = lo;
     offset = lane - (uint32_t)__shfl((int)pre, (int)lo);
+}
+
+// ---- join of the two planning classes: trial deltas of the match count (an assigned entity whose value is not the list holding it) ----
+__device__ __forceinline__ int32_t xown_pen(int32_t v, uint32_t owner) { return (v >= 0 && (uint32_t)v != owner) ? 1 : 0; }
+// a scalar change (kind 1: entity m0 takes value m1) or swap (kind 2: entities m0 and m1 exchange their values)
+template <class VT>
+__device__ __forceinline__ int32_t xown_scalar_delta(int kind, uint32_t m0, uint32_t m1, const VT* vals, const uint16_t* owner_tab) {
+    if (kind == 1) {
+        const uint32_t ow = owner_tab[m0];
+        return xown_pen((int32_t)m1, ow) - xown_pen((int32_t)vals[m0], ow);
+    }
+    const uint32_t o1 = owner_tab[m0], o2 = owner_tab[m1];
+    const int32_t v1 = (int32_t)vals[m0], v2 = (int32_t)vals[m1];
+    return xown_pen(v2, o1) - xown_pen(v1, o1) + xown_pen(v1, o2) - xown_pen(v2, o2);
+}
+// a list move in ring coordinates: the elements that change lists (intra-list moves change nothing)
+template <class VT>
+__device__ __forceinline__ int32_t xown_list_delta(int kind, uint32_t m0, uint32_t m1, uint32_t mx, const uint16_t* visits, const uint32_t* off, const VT* vals) {
+    const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
+    if (a == b || kind == 64 || kind == 512 || kind == 8192) return 0;
+    auto moved = [&](uint32_t e, uint32_t from, uint32_t to) { const int32_t v = (int32_t)vals[e]; return xown_pen(v, to) - xown_pen(v, from); };
+    if (kind == 4 || kind == 16) return moved(visits[off[a] + i], a, b);
+    if (kind == 8 || kind == 32) return moved(visits[off[a] + i], a, b) + moved(visits[off[b] + j], b, a);
+    int32_t d = 0;
+    if (kind == 128) {  // segment [i, i + mx) of a -> b
+        for (uint32_t t = 0; t < mx; ++t) d += moved(visits[off[a] + i + t], a, b);
+    } else if (kind == 256) {  // [i, i + (mx & 15)) of a <-> [j, j + (mx >> 4)) of b
+        for (uint32_t t = 0; t < (mx & 15u); ++t) d += moved(visits[off[a] + i + t], a, b);
+        for (uint32_t t = 0; t < (mx >> 4); ++t) d += moved(visits[off[b] + j + t], b, a);
+    }
+    return d;
 }
 
 }  // namespace sf
@@ -416,6 +453,20 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
         }
         wave_sync();
         if (NODEG) ring_sync();  // (HBM table: through the CU's write-through L1)
+    }
+
+    // join of the two planning classes: entity -> the list that holds it (HBM, L2-resident; through the CU's write-through L1)
+    const bool xown_on = !FAST && has_list && has_scalar && gl.xown_level >= 0;
+    uint16_t* const xown = xown_on ? gl.xown_tab + (size_t)r * ns : nullptr;
+    if (xown_on) {
+        for (uint32_t t = lane; t < ns; t += 64) xown[t] = (uint16_t)0xFFFFu;
+        ring_sync();
+        for (uint32_t v = lane; v < (uint32_t)V; v += 64) {
+            const uint32_t o = s_off[v], len = s_off[v + 1] - o;
+            for (uint32_t q = 0; q < len; ++q)
+                if ((uint32_t)s_visits[o + q] < ns) xown[s_visits[o + q]] = (uint16_t)v;
+        }
+        ring_sync();
     }
 
     const RuinLds rl(mem + cv.ruin);
@@ -2238,6 +2289,12 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                                                            : eval_scalar_move(sm, s_vals, 1, m0, m1, 0, tc, ts, tables ? lbv : nullptr);
                         doable = d.doable;
                         sc = apply_scalar_delta<L>(sm, cur, d);
+                        if (xown_on && doable) {
+                            const int64_t dx = (int64_t)xown_scalar_delta(my_kind, m0, m1, s_vals, xown);
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk)
+                                if (kk == gl.xown_level) sc.v[kk] = wsub(sc.v[kk], (int64_t)((uint64_t)gl.xown_weight * (uint64_t)dx));
+                        }
                     } else if (PREC && my_kind == 16384) {  // critical-path leaf: scored when it was generated
                         doable = true;
 #pragma unroll
@@ -2269,6 +2326,12 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                                                                                       m0 >> 16, m0 & 0xFFFFu, m1 >> 16, m1 & 0xFFFFu);
                         doable = d.doable;
                         sc = apply_delta<L>(lm, cur, d);
+                        if (xown_on && doable) {  // the entities that change lists
+                            const int64_t dx = (int64_t)xown_list_delta(my_kind, m0, m1, mx_, s_visits, s_off, s_vals);
+#pragma unroll
+                            for (int kk = 0; kk < L; ++kk)
+                                if (kk == gl.xown_level) sc.v[kk] = wsub(sc.v[kk], (int64_t)((uint64_t)gl.xown_weight * (uint64_t)dx));
+                        }
                     }
                 }
                 ScoreV<L> curv;
@@ -2638,6 +2701,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                     }
                     wave_sync();
                     if (NODEG) ring_sync();
+                }
+                if (xown_on && kind != 512 && kind != 8192 && kind != 64) {  // the two touched lists name their elements again
+                    const uint32_t ra_ = a >> 16, rb_ = b >> 16;
+                    const uint32_t oa = s_off[ra_], la = s_off[ra_ + 1] - oa;
+                    const uint32_t ob = s_off[rb_], lb = s_off[rb_ + 1] - ob;
+                    for (uint32_t t = lane; t < la + (ra_ != rb_ ? lb : 0u); t += 64) {
+                        const uint32_t e_ = t < la ? (uint32_t)s_visits[oa + t] : (uint32_t)s_visits[ob + (t - la)];
+                        if (e_ < ns) xown[e_] = (uint16_t)(t < la ? ra_ : rb_);
+                    }
+                    ring_sync();
                 }
             }
             if (PREC && kind > 2) {  // a list move was committed: the HBM copy the trials undo from, and the constraint's committed state

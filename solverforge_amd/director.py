@@ -58,6 +58,7 @@ class ConstraintKind:
     SELFJOIN_VALUE_EQUAL, GROUPED_VALUE_SUM, LOAD_BALANCE_VALUE = 8, 9, 10
     VALUE_COST, EXISTS_VALUE, BALANCE_VALUE = 11, 12, 13
     LIST_PRECEDENCE_MAKESPAN, RUNS_VALUE, COMPLEMENTED_VALUE_SUM, PRESENCE_VALUE = 14, 15, 16, 17
+    CROSS_OWNER_MATCH = 18  # join of the two planning classes of a mixed model
 
 
 class SelectorKind:

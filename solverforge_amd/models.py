@@ -100,7 +100,7 @@ def build_nqueens(rows, n_replicas=1, device_id=0, leaves=("change", "swap"), pa
 
 
 def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
-                  leaves=("list_change", "list_swap", "change", "swap"), makespan=False, ruin=(2, 5, 10), precedence_policy=False, pair_ir=False):
+                  leaves=("list_change", "list_swap", "change", "swap"), makespan=False, ruin=(2, 5, 10), precedence_policy=False, pair_ir=False, owner_match_level=None):
     """Mixed job shop (examples/mixed-job-shop/src/domain/job_shop_plan.rs:28-69): class 0 =
     operations with the scalar `machine_idx` (0..n_machines, allows_unassigned), class 1 = machines
     with the list variable `sequence` of operation ids.  BendableScore<2,1> (BASELINE.json):
@@ -124,6 +124,8 @@ def build_jobshop(problem, n_replicas=1, device_id=0, bendable=True,
         d.add_pair_join(0, [(PairOp.COL_EQ, 0, FACT_GROUP), (PairOp.VALUE_EQ, 1)], level=lv[2], weight=1)
     else:
         d.add_constraint(ConstraintKind.CROSS_GROUP_EQUAL, 0, fact=FACT_GROUP, level=lv[2], weight=1)
+    if owner_match_level is not None:  # the join of the two planning classes: an operation on a machine that does not schedule it
+        d.add_constraint(ConstraintKind.CROSS_OWNER_MATCH, 0, param=1, level=owner_match_level, weight=1)
     if makespan:  # the makespan objective (constraint/list_precedence.rs): job order = fixed successors, problem["durations"]
         job = np.asarray(problem["job"])
         succ = [[op + 1] if op + 1 < n_ops and job[op + 1] == job[op] else [] for op in range(n_ops)]

@@ -474,3 +474,105 @@ def test_jobshop_one_byte_values_path(oracle, bendable):
     assert (d.working_values(0, 0) == o.get_vars(0, 0)).all()
     assert d.working_lists(1, 0) == o.get_lists(1)
     assert (d.calculate_score()[0] == o.score()[:lv]).all() and (d.fresh_score()[0] == o.score()[:lv]).all()
+
+
+# ---- a join of the TWO planning classes, both sides moving (cross_bi_incremental/incremental.rs:93-137) ---------------------------
+def _mk_owner(oracle, p, n_replicas=1, level=1):
+    import solverforge_amd as sfa
+
+    d = sfa.build_jobshop(p, n_replicas=n_replicas, bendable=True, owner_match_level=level)
+    o = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, owner_match_level=level)
+    bits = oracle.LEAF_LIST_CHANGE | oracle.LEAF_LIST_SWAP | oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
+    return d, o, bits
+
+
+def test_two_class_join_scores_and_each(oracle):
+    p = _jobshop(n_jobs=14, n_machines=5, seed=3)
+    d, o, _ = _mk_owner(oracle, p)
+    s = d.calculate_score()
+    assert (s[0] == o.score()[:3]).all() and s[0][1] < 0
+    assert (d.fresh_score()[0] == o.fresh_score()[:3]).all()
+    # the join's own row of evaluate_each = the count of operations on a machine that does not schedule them
+    mi, seqs = np.asarray(p["machine_idx"]), p["sequences"]
+    where = {op: m for m, sq in enumerate(seqs) for op in sq}
+    expect = sum(1 for op, m in enumerate(mi) if m >= 0 and where.get(op, -1) != m)
+    sc, cnt = d.evaluate_each(0)
+    assert cnt[-1] == expect and sc[-1][1] == -expect
+
+
+@pytest.mark.parametrize("order", [0, 3, 4])
+def test_two_class_join_trial_scores_of_every_leaf(oracle, order):
+    """Every candidate of the four-leaf union: a scalar move changes the A side's key, a list move the B side's filter."""
+    p = _jobshop(n_jobs=6, n_machines=4, seed=2)
+    d, o, bits = _mk_owner(oracle, p)
+    o.configure(leaves=bits, selection_order=order)
+    d.calculate_score()
+    for step_index, step_seed in [(0, 0), (7, 41), (3, 0xDEADBEEFCAFEF00D)]:
+        gm, gs, gd = d.open_cursor(step_index, step_seed, selection_order=order, cap=1 << 18)
+        om = o.enumerate(0, step_index, step_seed, order)
+        assert len(gm) == len(om) > 0
+        assert (_t(gm) == _t(om)).all()
+        os_, od = o.evaluate_moves(om)
+        assert (gd == od).all()
+        assert (gs == os_[:, :3]).all()
+
+
+@pytest.mark.parametrize("acceptor,forager,limit", [(1, 0, 256), (0, 0, 4), (1, 1, 1)])
+def test_two_class_join_traced_and_fused_steps(oracle, acceptor, forager, limit):
+    import solverforge_amd as sfa
+
+    p = _jobshop(n_jobs=10, n_machines=4, seed=6)
+    R = 3
+    d, o, bits = _mk_owner(oracle, p, n_replicas=R, level=0)
+    cfg = sfa.SolverConfig(acceptor=acceptor, late_acceptance_size=5, forager=forager, accepted_count_limit=limit, random_seed=9)
+    d.configure(cfg)
+    o.configure(leaves=bits, random_seed=9, acceptor=acceptor, la_size=5, forager=forager, limit=limit)
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    for step in range(8):  # traced steps of replica 0: pulls, trial scores, flags, the committed move
+        gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 18)
+        om, os_, of, oap, omv = o.step_traced()
+        assert len(gm) == len(om), step
+        assert (_t(gm) == _t(om)).all(), step
+        assert (gf == of).all() and (gs == os_[:, :3]).all(), step
+        assert gap == oap, step
+        if gap:
+            assert tuple(gmv) == tuple(omv), step
+        assert (d.working_values(0, 0) == o.get_vars(0, 0)).all() and d.working_lists(1, 0) == o.get_lists(1), step
+    sc0 = d.calculate_score()[0]
+    assert (sc0 == o.score()[:3]).all()
+    # fused: every replica against its own oracle
+    d2, _, _ = _mk_owner(oracle, p, n_replicas=R, level=0)
+    d2.configure(cfg)
+    d2.calculate_score()
+    d2.phase_start()
+    d2.solve_steps(25)
+    d2.solve_steps(15)
+    sc = d2.calculate_score()
+    for r in range(R):
+        o2 = oracle.Model.jobshop(p["job"], p["machine_idx"], p["sequences"], bendable=True, owner_match_level=0)
+        o2.configure(leaves=bits, random_seed=9 + r, acceptor=acceptor, la_size=5, forager=forager, limit=limit)
+        o2.phase_start()
+        o2.steps(40)
+        assert (sc[r] == o2.score()[:3]).all(), r
+        assert (d2.working_values(0, 0, r) == o2.get_vars(0, 0)).all(), r
+        assert d2.working_lists(1, r) == o2.get_lists(1), r
+        assert d2.stats(r)["moves_evaluated"] == o2.stats()["moves_evaluated"], r
+    assert (d2.fresh_score() == sc).all()
+
+
+def test_two_class_join_validation():
+    import solverforge_amd as sfa
+
+    p = _jobshop(n_jobs=6, n_machines=4, seed=2)
+    d = sfa.build_jobshop(p, owner_match_level=1)
+    d.calculate_score()
+    with pytest.raises(sfa.SolverForgeError):  # host-driven entry points do not price the join
+        d.evaluate_moves(np.zeros(1, dtype=sfa.MOVE_DTYPE))
+    d2 = sfa.build_jobshop(p, owner_match_level=1, leaves=("list_change", "change", "ruin"))
+    d2.configure(sfa.SolverConfig(random_seed=0))
+    d2.calculate_score()
+    d2.phase_start()
+    with pytest.raises(sfa.SolverForgeError):  # the ruin leaf's recreate does not price it
+        d2.solve_steps(1)
