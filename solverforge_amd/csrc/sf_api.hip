@@ -1365,9 +1365,9 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
             case SF_C_UNI_UNASSIGNED: raw = q[3], count = q[16]; break;  // weighted sum / entities passing the filter
             case SF_C_CROSS_ADJACENT_EQUAL:
             case SF_C_CROSS_GROUP_EQUAL:
-            case SF_C_CROSS_OWNER_MATCH: raw = q[17], count = q[17]; break;
             case SF_C_PAIR_JOIN_:
             case SF_C_CROSS_QUEENS: raw = q[4], count = q[4]; break;
+            case SF_C_CROSS_OWNER_MATCH: raw = q[17], count = q[17]; break;
             case SF_C_SELFJOIN_VALUE_EQUAL: raw = q[5], count = q[5]; break;
             case SF_C_GROUPED_VALUE_SUM:
             case SF_C_COMPLEMENTED_VALUE_SUM:

@@ -1410,9 +1410,16 @@ __global__ __launch_bounds__(64 * 4, SF_SCALAR_BLOCKS_PER_CU) void k_scalar_sear
                 spec = est >= 64 ? 64u : est < 8 ? 8u : (uint32_t)est;
             }
             const uint32_t target = (!ex[0] && !ex[1]) ? (spec + 1) / 2 : spec;
+            // A forager that ends the step at its first accepted candidate (AcceptedCount(1): the reference's default for scalar-only models,
+            // 1.2 consumed candidates per step under SimulatedAnnealing; FirstAccepted) usually never pulls the second child of the union: the
+            // first round fills only the ring of the child the scheduler pulls first, the other one when the replay gets to it.  Same
+            // candidates in the same order; four of five steps skip one fill (the swap stream's is four hashed 64-wide chunks).
+            const bool one_accept = p.forager == FORAGER_FIRST_ACCEPTED || (p.forager == 0 && (uint32_t)p.limit - accepted == 1u);
+            const bool lazy_first = one_accept && n_leaves > 1 && pulls == 0 && !ex[0] && !ex[1];
 #pragma unroll
             for (int l = 0; l < 2; ++l) {
                 if (l >= n_leaves) continue;
+                if (lazy_first && (uint32_t)l != first_leaf) continue;
                 const bool is_change = l ? chg1 : chg0;
                 uint32_t* rq = ring + (size_t)l * SRC * 2;
                 while (!ex[l] && !gen_done[l] && tail[l] - head[l] < target) {
