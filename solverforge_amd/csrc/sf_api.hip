@@ -2675,21 +2675,26 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     gl.prec = ctx->has_list_model ? ctx->pm : PrecModel{};
     {  // the Kahn scratch (16 bytes per node) goes to LDS while at least 4 replicas still fit a CU
         const bool no_lds = std::getenv("SF_AMD_PREC_HBM") != nullptr;  // diagnostics / parity tests: force the HBM scratch (read at every launch)
-        gl.prec_lds = (gl.prec.on && !no_lds && (size_t)gl.prec.n * 16 <= 36 * 1024) ? 1 : 0;
+        gl.prec_lds = (gl.prec.on && !no_lds && prec_lds_scratch_bytes(gl.prec.n) <= 36 * 1024 && gl.prec.n < 65535) ? 1 : 0;
         // the incremental trial refresh is parity-complete but SLOWER than one full evaluation per trial on every job shop measured
         // (profiles/r03f_precedence.txt): opt-in for the parity tests and further work
         gl.prec_inc = std::getenv("SF_AMD_PREC_INC") != nullptr ? 1 : 0;
         // lane-per-trial sweep (prec_trial_sweep64): the default with the scratch in HBM; SF_AMD_PREC_NO_SWEEP = one full evaluation per trial
         // the constraint's static graph (durations, fixed successors / predecessors, in-degrees, owners) once per workgroup in LDS: every Kahn
         // round reads it behind a dependent LDS access (SF_AMD_PREC_STATIC_HBM = leave it in HBM / L1)
-        gl.prec_static = 0;
+        gl.prec_static = 0, gl.prec_static_slim = 0;
         if (gl.prec.on && gl.prec_lds && std::getenv("SF_AMD_PREC_STATIC_HBM") == nullptr) {
             const size_t b = prec_static_bytes(gl.prec.n, gl.prec.n_edges, gl.prec.owner != nullptr);
             if (b <= 16 * 1024) gl.prec_static = (int32_t)b;
+            // beyond that: the node records, fixed in-degrees and owners alone (what every evaluation reads per node; the rounds of a 1,000-node
+            // evaluation waited on an L2 round trip for the record otherwise).  SF_AMD_PREC_STATIC_SLIM=0 leaves them in HBM
+            const size_t sb = prec_static_slim_bytes(gl.prec.n, gl.prec.owner != nullptr);
+            const char* se = std::getenv("SF_AMD_PREC_STATIC_SLIM");
+            if (!gl.prec_static && sb <= 40 * 1024 && !(se && std::atoi(se) == 0)) gl.prec_static = (int32_t)sb, gl.prec_static_slim = 1;
         }
         // grouped trial evaluator (sf_prec_group.h): T trials per wavefront with private LDS scratch.  SF_AMD_PREC_GROUPS = 0 / 2 / 4 / 8 / 16
         gl.prec_groups = 0;
-        if (gl.prec.on && gl.prec_lds && gl.prec_static) {  // (its node records live in the shared static copy)
+        if (gl.prec.on && gl.prec_lds && gl.prec_static && !gl.prec_static_slim) {  // (its node records live in the FULL shared static copy)
             // default: as many trials per wave as the graph's width allows -- a Kahn round pops at most one node per list, so lane groups of
             // the largest power of two <= the list count (5 machines: 4 lanes, 16 trials; 10: 8 lanes, 8 trials) -- halved until the scratch
             // fits: under 14 KB, or the replica's precedence state (scratch + 16 B per node of Kahn arrays + ~2.5 KB) under 20 KB, which

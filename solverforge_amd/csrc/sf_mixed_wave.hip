@@ -104,6 +104,7 @@ struct GLeaves {
     int32_t prec_inc;        // HBM scratch: list change / swap trials take the incremental refresh (prec_trial_inc; opt-in, see sf_precedence.h)
     int32_t prec_sweep;      // HBM scratch: the list change / swap trials of a replay chunk are scored 64 at a time (prec_trial_sweep64)
     int32_t prec_static;     // bytes of the workgroup-shared LDS copy of the constraint's static graph (0 = read it from HBM)
+    int32_t prec_static_slim;  // that copy holds the node records, fixed in-degrees and owners only (the CSR arrays and durations stay in HBM)
     int32_t prec_groups;     // LDS scratch: trials per wavefront of the grouped evaluator (prec_eval_grouped: 8, 4 or 2; 0 = off)
     PlfModel plf;            // critical-path precedence leaf (kind 16384; PREC instantiations, sf_prec_leaf.h)
     // Join of the two planning classes (SF_C_CROSS_OWNER_MATCH; cross_bi_incremental/incremental.rs:93-137 with A = the scalar class keyed
@@ -170,7 +171,7 @@ struct GCarve {
         ruin_fast = o;  // edge[dim], row[dim], edge_end[V], slot[n_cap + V]
         o = align_up(o + (has_ruin >= 2 ? sizeof(uint16_t) * ((has_ruin == 2 ? 2 : 1) * (size_t)dim + (size_t)V + ruin_arena_cap(n_cap, V)) : 0), 16);
         prec = o;  // earliest start, in-degree, queue, list successor of the precedence constraint's Kahn pass
-        o = align_up(o + sizeof(uint32_t) * 4 * (size_t)prec_words, 16);
+        o = align_up(o + prec_lds_scratch_bytes(prec_words), 16);  // (i32, i32, u16, u16)
         pgrp = o;  // grouped trial evaluator (sf_prec_group.h): committed successor / in-degree + per-trial scratch
         o = align_up(o + pgrp_bytes(prec_words, prec_groups, V), 16);
         leaftab = o;  // per-leaf generator / ring / scheduler state (LeafTab)
@@ -315,6 +316,9 @@ namespace sf {
 #else
 #define DBGK(k) (!FAST || ((k) & (16 | 32 | 64 | 128 | 256 | 512)) != 0)
 #endif
+#ifndef SF_PREC_CHAIN  // 1 = register hand-off between Kahn rounds (sf_precedence.h, prec_eval<.., CHAIN>); 0 = every node through the queue
+#define SF_PREC_CHAIN 0
+#endif
 #ifndef SF_MIXED_FAST_BLOCKS_PER_CU
 #define SF_MIXED_FAST_BLOCKS_PER_CU 4
 #endif
@@ -376,13 +380,16 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             sh += words;
             return dst;
         };
-        gl.prec.dur = (const int32_t*)take(gl.prec.dur, n);
+        const bool slim = gl.prec_static_slim != 0;
+        if (!slim) gl.prec.dur = (const int32_t*)take(gl.prec.dur, n);
         gl.prec.indeg0 = (const int32_t*)take(gl.prec.indeg0, n);
         if (gl.prec.owner) gl.prec.owner = (const int32_t*)take(gl.prec.owner, n);
-        gl.prec.succ_off = (const uint32_t*)take(gl.prec.succ_off, n + 1);
-        gl.prec.succ = (const uint32_t*)take(gl.prec.succ, m);
-        gl.prec.pred_off = (const uint32_t*)take(gl.prec.pred_off, n + 1);
-        gl.prec.pred = (const uint32_t*)take(gl.prec.pred, m);
+        if (!slim) {
+            gl.prec.succ_off = (const uint32_t*)take(gl.prec.succ_off, n + 1);
+            gl.prec.succ = (const uint32_t*)take(gl.prec.succ, m);
+            gl.prec.pred_off = (const uint32_t*)take(gl.prec.pred_off, n + 1);
+            gl.prec.pred = (const uint32_t*)take(gl.prec.pred, m);
+        }
         gl.prec.nd = (const uint32_t*)take(gl.prec.nd, 2 * n);
         pgs.nd = (const pg_lds_u32*)gl.prec.nd;
         pgs.succ_off = (const pg_lds_u32*)gl.prec.succ_off, pgs.succ = (const pg_lds_u32*)gl.prec.succ;
@@ -494,8 +501,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     const bool prec_in_lds = PREC && gl.prec_lds != 0;
     int32_t* const prec_E = !PREC ? nullptr : (prec_in_lds ? (int32_t*)(mem + cv.prec) : gl.prec.earliest + (size_t)r * gl.prec.n);
     int32_t* const prec_D = !PREC ? nullptr : (prec_in_lds ? prec_E + gl.prec.n : gl.prec.indeg + (size_t)r * gl.prec.n);
-    uint32_t* const prec_Q = !PREC ? nullptr : (prec_in_lds ? (uint32_t*)(prec_D + gl.prec.n) : gl.prec.queue + (size_t)r * gl.prec.n);
-    uint32_t* const prec_S = !PREC ? nullptr : (prec_in_lds ? prec_Q + gl.prec.n : gl.prec.lsucc + (size_t)r * gl.prec.n);
+    // queue and list successor: 16-bit arrays behind the in-degrees when the scratch lives in LDS (PrecMemLds), 32-bit rows in HBM otherwise
+    uint16_t* const prec_Q16 = (PREC && prec_in_lds) ? (uint16_t*)(prec_D + gl.prec.n) : nullptr;
+    uint16_t* const prec_S16 = (PREC && prec_in_lds) ? prec_Q16 + gl.prec.n : nullptr;
+    uint32_t* const prec_Q = (!PREC || prec_in_lds) ? nullptr : gl.prec.queue + (size_t)r * gl.prec.n;
+    uint32_t* const prec_S = (!PREC || prec_in_lds) ? nullptr : gl.prec.lsucc + (size_t)r * gl.prec.n;
     // incremental trial refresh (sf_precedence.h: prec_trial_inc) when the scratch lives in HBM: list change / swap candidates are
     // scored against the committed earliest starts without applying them; everything else takes the full evaluation
     PrecInc pinc{};
@@ -520,9 +530,9 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     PrecRec* const psw_rec = prec_sweep ? (PrecRec*)gl.prec.rec + (size_t)r * gl.prec.n : nullptr;
     // one full evaluation of the lists in LDS: typed LDS accessors when the scratch lives there
     auto prec_run = [&]() -> PrecResult {
-        if (prec_in_lds)
-            return prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u32*)prec_Q,
-                                                   (prec_lds_u32*)prec_S);
+        if (prec_in_lds)  // (nobody reads the pop order of this evaluation: the leaf and the recreate run plf_eval)
+            return prec_eval<uint16_t, PrecMemLds, SF_PREC_CHAIN != 0>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                                                                        (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16);
         if (prec_sweep) {  // committed evaluation + what the lane-per-trial sweep reads: list predecessors, order positions, round starts, prefix maxima
             __shared__ uint32_t s_psw_info[4][4];
             uint32_t* info = s_psw_info[wave_in_group];
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
         prec_mk = pr.makespan;
     }
     // grouped trial evaluator (sf_prec_group.h): T candidates of a replay chunk per pass, G = 64 / T lanes each
-    const uint32_t pgrp_T = (PREC && prec_in_lds && gl.prec_static) ? (uint32_t)gl.prec_groups : 0u;
+    const uint32_t pgrp_T = (PREC && prec_in_lds && gl.prec_static && !gl.prec_static_slim) ? (uint32_t)gl.prec_groups : 0u;
     const uint32_t pgrp_shift = pgrp_T ? (uint32_t)__builtin_ctz(64u / pgrp_T) : 6u;
     uint32_t pgrp_viol = 0;   // wrong-owner items of the committed lists
     uint32_t pgrp_ready = 0;  // nodes without a predecessor in the committed lists
@@ -698,8 +708,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     auto plf_eval = [&](bool& cyclic, uint32_t* roff, uint32_t* lp = nullptr) -> PrecResult {
         PrecResult pr;
         if (prec_in_lds)
-            pr = prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u32*)prec_Q,
-                                                 (prec_lds_u32*)prec_S, lp, plf_info, roff);
+            pr = prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u16*)prec_Q16,
+                                                 (prec_lds_u16*)prec_S16, lp, plf_info, roff);
         else
             pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, lp, plf_info, roff);
         wave_sync();
@@ -756,7 +766,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             if (!base_cyc) {
                 const uint32_t rounds = uni(plf_info[2]);
                 if (prec_in_lds)
-                    plf_tails<PrecMemLds>(gl.prec, plf_r, (prec_lds_u32*)prec_Q, (prec_lds_u32*)prec_S, rounds);
+                    plf_tails<PrecMemLds>(gl.prec, plf_r, (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, rounds);
                 else
                     plf_tails<PrecMemGlobal>(gl.prec, plf_r, prec_Q, prec_S, rounds);
             }
@@ -772,7 +782,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                 if (!base_cyc) {
                     PlfSlotPick pk{0, 0, 0, 0, 0};
                     if (prec_in_lds)
-                        plf_best_slot<PrecMemLds>(pk, gl.prec, plf_r, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u32*)prec_S, base.penalty,
+                        plf_best_slot<PrecMemLds>(pk, gl.prec, plf_r, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u16*)prec_S16, base.penalty,
                                                   (int32_t)base.makespan, x, hooks, skip_empty, lvl_order);
                     else
                         plf_best_slot<PrecMemGlobal>(pk, gl.prec, plf_r, s_visits, s_off, V, prec_E, prec_S, base.penalty, (int32_t)base.makespan, x, hooks,
@@ -907,7 +917,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                 const int ci = __ffsll((unsigned long long)fm) - 1;
                 fm &= fm - 1;
                 const uint32_t uu = (uint32_t)__builtin_amdgcn_readlane((int)u, ci), vv = (uint32_t)__builtin_amdgcn_readlane((int)v, ci);
-                closes = prec_in_lds ? plf_reaches<PrecMemLds>(gl.prec, plf.visit, plf.cnl, (prec_lds_u32*)prec_S, vv, uu)
+                closes = prec_in_lds ? plf_reaches<PrecMemLds>(gl.prec, plf.visit, plf.cnl, (prec_lds_u16*)prec_S16, vv, uu)
                                      : plf_reaches<PrecMemGlobal>(gl.prec, plf.visit, plf.cnl, prec_S, vv, uu);
             }
         }
@@ -1105,7 +1115,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             plf_cur_cyclic = cyc;
             const uint32_t rounds = uni(plf_info[2]);
             if (prec_in_lds)
-                plf_analyse<PrecMemLds>(gl.prec, gl.plf, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u32*)prec_Q, (prec_lds_u32*)prec_S, rounds,
+                plf_analyse<PrecMemLds>(gl.prec, gl.plf, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, rounds,
                                         (int32_t)pr.makespan, cyc);
             else
                 plf_analyse<PrecMemGlobal>(gl.prec, gl.plf, plf, s_visits, s_off, V, prec_E, prec_Q, prec_S, rounds, (int32_t)pr.makespan, cyc);

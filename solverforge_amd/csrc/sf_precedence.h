@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace sf {
 
 constexpr uint32_t PREC_NONE = 0xFFFFFFFFu;
@@ -61,6 +63,12 @@ struct PrecModel {
     int32_t has_zero_duration;  // a zero-duration node could hide a cycle from the sweep: the full evaluation is used instead
 };
 
+// LDS bytes of the Kahn scratch of one replica (earliest start i32, in-degree i32, queue u16, list successor u16: PrecMemLds)
+__host__ __device__ inline size_t prec_lds_scratch_bytes(int n) { return (size_t)n * 12; }
+// the slim workgroup-shared copy of the static graph: node records, fixed in-degrees, owners -- what every wave-wide evaluation reads per
+// node (models whose full copy -- plus durations and the CSR arrays -- does not fit)
+__host__ __device__ inline size_t prec_static_slim_bytes(int n, bool has_owner) { return 4 * (size_t)n * (has_owner ? 4 : 3) + 16; }
+
 struct PrecResult {
     int64_t penalty, makespan;
 };
@@ -77,18 +85,28 @@ struct PrecMemGlobal {
     static __device__ __forceinline__ void st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     static __device__ __forceinline__ void fmax(int32_t* p, int32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     static __device__ __forceinline__ int32_t fadd(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    template <class T>
+    static __device__ __forceinline__ const T* lists(const T* p) { return p; }  // the lists may live anywhere (generic pointer)
 };
 typedef __attribute__((address_space(3))) int32_t prec_lds_i32;
 typedef __attribute__((address_space(3))) uint32_t prec_lds_u32;
+typedef __attribute__((address_space(3))) uint16_t prec_lds_u16;
+// The index arrays (queue, list successor) are 16 bits wide in LDS -- the scratch lives there for a few thousand nodes at most -- with
+// 0xFFFF standing for PREC_NONE: 12 bytes per node instead of 16, which is what leaves room for the workgroup's copy of the node records.
 struct PrecMemLds {
     typedef prec_lds_i32* I32;
-    typedef prec_lds_u32* U32;
+    typedef prec_lds_u16* U32;
     static __device__ __forceinline__ int32_t ld(const prec_lds_i32* p) { return *p; }
-    static __device__ __forceinline__ uint32_t ld(const prec_lds_u32* p) { return *p; }
+    static __device__ __forceinline__ uint32_t ld(const prec_lds_u16* p) {
+        const uint32_t v = *p;
+        return v == 0xFFFFu ? 0xFFFFFFFFu : v;
+    }
     static __device__ __forceinline__ void st(prec_lds_i32* p, int32_t v) { *p = v; }
-    static __device__ __forceinline__ void st(prec_lds_u32* p, uint32_t v) { *p = v; }
+    static __device__ __forceinline__ void st(prec_lds_u16* p, uint32_t v) { *p = (uint16_t)v; }
     static __device__ __forceinline__ void fmax(prec_lds_i32* p, int32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     static __device__ __forceinline__ int32_t fadd(prec_lds_i32* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    template <class T>  // scratch in LDS <=> the caller's lists are the replica's LDS copy: ds_read instead of FLAT
+    static __device__ __forceinline__ const __attribute__((address_space(3))) T* lists(const T* p) { return (const __attribute__((address_space(3))) T*)p; }
 };
 // cross-lane hand-off through memory inside one wavefront: every outstanding memory operation of the wave has completed
 __device__ __forceinline__ void prec_sync() {
@@ -100,113 +118,267 @@ __device__ __forceinline__ uint32_t prec_mbcnt(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+#ifdef SF_PHASE_PEVAL  // diagnostics (-DSF_PHASE_PROFILE -DSF_PHASE_PEVAL): shader clocks of the stages of prec_eval in g_rphase2 (sf_ruin_v2.h defines it):
+// 0 evaluations, 1 init, 2 list pass, 3 ready scan, 4 Kahn rounds, 5 number of rounds, 6 nodes
+extern __device__ unsigned long long g_rphase2[8];
+#define PEV(i)                                                                       \
+    {                                                                                \
+        const uint64_t _t = clock64();                                               \
+        if (pev_on) atomicAdd(&g_rphase2[i], (unsigned long long)(_t - pev_t));      \
+        pev_t = _t;                                                                  \
+    }
+#else
+#define PEV(i)
+#endif
+
 // Full evaluation of the lists `visits` / `off` (V owners) by one wavefront; E / D / Q / S = the four scratch arrays of pm.n
 // words.  Wave-uniform result.  lint: small-pod-return (PrecResult = two int64: returned in four registers; never called inside a
 // conditional expression -- DESIGN 8.15 item 2 was a 32-byte struct through `?:`; scripts/lint_device_patterns.py checks both)
-template <class VT, class MEM = PrecMemGlobal>
+// CHAIN (LDS scratch, trial and commit evaluations whose pop order nobody reads): a lane keeps the node it made ready in a register and
+// processes it in the next round; only the SECOND node a lane makes ready in a round goes through the queue, and idle lanes pick queued nodes
+// up with a load that travels beside the busy lanes' record reads.  A round is two dependent LDS round trips (records; relaxations) instead
+// of four (pop; records; relaxations; queue writes + hand-off).  The result does not depend on the pop order; Q is NOT the topological order
+// afterwards and ROFF must be null.
+template <class VT, class MEM = PrecMemGlobal, bool CHAIN = false>
 __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
                                              typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr, uint32_t* ROFF = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
-    for (uint32_t i = lane; i < n; i += 64) {
-        MEM::st(E + i, 0);
-        MEM::st(D + i, pm.indeg0[i]);
-        MEM::st(S + i, PREC_NONE);
-        if (LP) LP[i] = PREC_NONE;
-    }
-    prec_sync();
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[V]);
-    uint32_t viol = 0;
-    for (uint32_t t0 = 0; t0 < total; t0 += 64) {  // one list item per lane: its list successor, its in-degree, its owner check
-        const uint32_t t = t0 + lane;
-        if (t < total) {
-            uint32_t lo = 0, hi = (uint32_t)V;  // the owner v with off[v] <= t < off[v + 1]
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (off[mid] <= t)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            const uint32_t x = (uint32_t)visits[t];
-            if (t + 1 != off[lo + 1]) MEM::st(S + x, (uint32_t)visits[t + 1]);
-            if (LP) LP[x] = t != off[lo] ? (uint32_t)visits[t - 1] : PREC_NONE;  // list predecessor (incremental trial refresh)
-            if (t != off[lo]) MEM::st(D + x, pm.indeg0[x] + 1);
-            if (pm.owner) {
-                const int32_t o = pm.owner[x];
-                viol += (o >= 0 && (uint32_t)o != lo) ? 1u : 0u;
+    const auto vis = MEM::lists(visits);
+    const auto offs = MEM::lists(off);
+#ifdef SF_PHASE_PEVAL
+    const bool pev_on = lane == 0 && (blockIdx.x & 31u) == 0u;  // (one workgroup in 32 reports: same-address atomics of every wave would be the bottleneck)
+    uint64_t pev_t = clock64();
+    if (pev_on) atomicAdd(&g_rphase2[0], 1ull), atomicAdd(&g_rphase2[6], (unsigned long long)n);
+#endif
+    // ---- set-up.  Every loop keeps four independent iterations in flight: the evaluation is a chain of dependent round trips from start to end,
+    // and at 1,000 nodes the set-up used to be as long a chain as Kahn's rounds (one binary search over `off` per 64 items, every load waited for).
+    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+        int32_t d0[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64u * u + lane;
+            d0[u] = i < n ? pm.indeg0[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = i0 + 64u * u + lane;
+            if (i < n) {
+                MEM::st(E + i, 0);
+                MEM::st(D + i, d0[u]);
+                MEM::st(S + i, PREC_NONE);
+                if (LP) LP[i] = PREC_NONE;
             }
         }
     }
     prec_sync();
-    uint32_t head = 0, tail = 0;
-    for (uint32_t b = 0; b < n; b += 64) {
-        const uint32_t i = b + lane;
-        const bool ready = i < n && MEM::ld(D + i) == 0;
-        const uint64_t m = __ballot(ready);
-        if (ready) MEM::st(Q + tail + prec_mbcnt(m), i);
-        tail += (uint32_t)__popcll(m);
+    PEV(1)
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[V]);
+    uint32_t viol = 0;
+    {   // list by list, 64 positions per chunk, four chunks in flight: list successor, in-degree and owner check of every item.  The
+        // list offsets sit one per lane (V < 64; otherwise they are read where needed), so walking the chunks costs no memory access.
+        const bool has_owner = pm.owner != nullptr;
+        const int32_t* const own = has_owner ? pm.owner : pm.indeg0;  // (always a readable table)
+        const uint32_t my_off = V < 64 ? (uint32_t)offs[lane <= (uint32_t)V ? lane : (uint32_t)V] : 0u;
+        auto list_pass = [&](auto held_c) {  // (two copies of the loop: the offset source is a compile-time choice inside each)
+        constexpr bool held = decltype(held_c)::value;
+        auto off_at = [&](uint32_t e) -> uint32_t {
+            if constexpr (held) return (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)e);
+            else return (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[e]);
+        };
+        uint32_t e = 0, k0 = 0, eo = V > 0 ? off_at(0) : 0u, en = V > 0 ? off_at(1) : 0u;  // current list, chunk start, its bounds (uniform)
+        for (;;) {
+            uint32_t ce[4], cb[4], cl[4];  // chunk: list, flat index of its first position, positions left in the list from there
+            bool cf[4];                    // the chunk starts its list
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                while (e < (uint32_t)V && eo + k0 >= en) {  // next list with items left
+                    e += 1, k0 = 0, eo = en;
+                    en = e < (uint32_t)V ? off_at(e + 1) : en;
+                }
+                const bool ok = e < (uint32_t)V;
+                ce[u] = e, cb[u] = eo + k0, cl[u] = ok ? en - (eo + k0) : 0u, cf[u] = k0 == 0u;
+                any = any || ok;
+                k0 += 64;
+            }
+            if (!any) break;
+            // every load below is unconditional (an idle lane reads position 0 / node vis[0]): a load inside a lane-masked branch is waited
+            // for at the end of its branch, which serialised the eight table reads of an iteration
+            bool in[4];
+            uint32_t x[4], nx[4], px[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                in[u] = lane < cl[u];
+                const uint32_t t = in[u] ? cb[u] + lane : 0u;
+                const bool more = in[u] && lane + 1 < cl[u];
+                x[u] = (uint32_t)vis[t];
+                nx[u] = (uint32_t)vis[more ? t + 1 : 0u];
+                nx[u] = more ? nx[u] : PREC_NONE;
+                px[u] = PREC_NONE;
+                if (LP) px[u] = (in[u] && (lane > 0 || !cf[u])) ? (uint32_t)vis[t - 1] : PREC_NONE;
+            }
+            int32_t i0v[4], ow[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                i0v[u] = pm.indeg0[x[u]];
+                ow[u] = own[x[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (in[u]) {
+                    const bool first = lane == 0 && cf[u];
+                    MEM::st(S + x[u], nx[u]);
+                    if (LP) LP[x[u]] = px[u];
+                    MEM::st(D + x[u], i0v[u] + (first ? 0 : 1));
+                    viol += (has_owner && ow[u] >= 0 && (uint32_t)ow[u] != ce[u]) ? 1u : 0u;
+                }
+            }
+        }
+        };
+        if (V < 64) list_pass(std::true_type{});
+        else list_pass(std::false_type{});
     }
     prec_sync();
+    PEV(2)
+    uint32_t head = 0, tail = 0;
+    for (uint32_t b = 0; b < n; b += 256) {  // the ready nodes in ascending order (four reads in flight)
+        int32_t dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = b + 64u * u + lane;
+            dv[u] = i < n ? MEM::ld(D + i) : 1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t i = b + 64u * u + lane;
+            const bool ready = dv[u] == 0;
+            const uint64_t m = __ballot(ready);
+            if (ready) MEM::st(Q + tail + prec_mbcnt(m), i);
+            tail += (uint32_t)__popcll(m);
+        }
+    }
+    prec_sync();
+    PEV(3)
     int32_t mk = 0;
     uint32_t rounds = 0;
-    // A round: the popped node; its record (duration, out-degree, first fixed successor: two independent loads), earliest start and list successor;
-    // the relaxations of that successor and of the list successor; the queue writes.  Further fixed successors (none in a job shop) loop.
-    while (head < tail) {
-        const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
-        if (ROFF && lane == 0) ROFF[rounds] = head;
-        rounds += 1;
-        const bool act = lane < cnt;
-        int32_t fin = 0;
-        uint32_t node = 0, deg = 0, s1 = PREC_NONE, ls = PREC_NONE;
-        if (act) {
-            node = MEM::ld(Q + head + lane);
-            uint2 rec;  // (two loads: the LDS copy of the records is only 4-byte aligned)
-            rec.x = pm.nd[2 * (size_t)node], rec.y = pm.nd[2 * (size_t)node + 1];
-            fin = MEM::ld(E + node) + (int32_t)rec.x;
-            mk = fin > mk ? fin : mk;
-            deg = rec.y >> 24;
-            s1 = (rec.y & 0xFFFFFFu) == 0xFFFFFFu ? PREC_NONE : (rec.y & 0xFFFFFFu);
-            ls = MEM::ld(S + node);
+    // A round.  Both relaxations are issued before the first wait: a missing successor relaxes the node itself with operands that change
+    // nothing (max with INT_MIN, add 0) instead of sitting in a branch of its own.  (Same target twice -- a fixed successor that is also the
+    // list successor: LDS executes a wave's instructions in order, so the two decrements return consecutive values; with the scratch in HBM
+    // the second relaxation of such a lane waits for the first.)
+    auto relax2 = [&](bool busy, uint32_t node, int32_t fin, uint32_t s1, uint32_t ls, bool& new1, bool& new2) {
+        new1 = false, new2 = false;
+        const bool same = busy && s1 != PREC_NONE && s1 == ls && !std::is_same<MEM, PrecMemLds>::value;
+        if (busy) {
+            const bool h1 = s1 != PREC_NONE, h2 = ls != PREC_NONE && !same;
+            const uint32_t t1 = h1 ? s1 : node, t2 = h2 ? ls : node;
+            MEM::fmax(E + t1, h1 ? fin : INT32_MIN);
+            const int32_t o1 = MEM::fadd(D + t1, h1 ? -1 : 0);
+            MEM::fmax(E + t2, h2 ? fin : INT32_MIN);
+            const int32_t o2 = MEM::fadd(D + t2, h2 ? -1 : 0);
+            new1 = h1 && o1 == 1, new2 = h2 && o2 == 1;
         }
-        bool new1 = false, new2 = false;
-        if (s1 != PREC_NONE) {
-            MEM::fmax(E + s1, fin);
-            new1 = MEM::fadd(D + s1, -1) == 1;
-        }
-        if (ls != PREC_NONE) {
-            MEM::fmax(E + ls, fin);
-            new2 = MEM::fadd(D + ls, -1) == 1;
-        }
-        const uint64_t m1 = __ballot(new1), m2 = __ballot(new2);
-        if (new1) MEM::st(Q + tail + prec_mbcnt(m1), s1);
-        tail += (uint32_t)__popcll(m1);
-        if (new2) MEM::st(Q + tail + prec_mbcnt(m2), ls);
-        tail += (uint32_t)__popcll(m2);
-        if (__ballot(deg > 1u)) {
-            uint32_t so = 0;
-            if (deg > 1u) {
-                so = pm.succ_off[node];
-                deg = pm.succ_off[node + 1] - so;  // (the record saturates at 255)
-            }
-            for (uint32_t k = 1;; ++k) {
-                const bool has = k < deg;
-                if (!__ballot(has)) break;
-                bool newly = false;
-                uint32_t s = 0;
-                if (has) {
-                    s = pm.succ[so + k];
-                    MEM::fmax(E + s, fin);
-                    newly = MEM::fadd(D + s, -1) == 1;
-                }
-                const uint64_t m = __ballot(newly);
-                if (newly) MEM::st(Q + tail + prec_mbcnt(m), s);
-                tail += (uint32_t)__popcll(m);
+        if (!std::is_same<MEM, PrecMemLds>::value && __ballot(same)) {
+            if (same) {
+                MEM::fmax(E + ls, fin);
+                new2 = MEM::fadd(D + ls, -1) == 1;
             }
         }
-        head += cnt;
-        prec_sync();
+    };
+    // further fixed successors of the nodes of this round (none in a job shop): the record saturates at 255, the CSR has the rest
+    auto more_successors = [&](uint32_t node, uint32_t deg, int32_t fin) {
+        if (!__ballot(deg > 1u)) return;
+        uint32_t so = 0;
+        if (deg > 1u) {
+            so = pm.succ_off[node];
+            deg = pm.succ_off[node + 1] - so;
+        }
+        for (uint32_t k = 1;; ++k) {
+            const bool has = k < deg;
+            if (!__ballot(has)) break;
+            bool newly = false;
+            uint32_t s = 0;
+            if (has) {
+                s = pm.succ[so + k];
+                MEM::fmax(E + s, fin);
+                newly = MEM::fadd(D + s, -1) == 1;
+            }
+            const uint64_t m = __ballot(newly);
+            if (newly) MEM::st(Q + tail + prec_mbcnt(m), s);
+            tail += (uint32_t)__popcll(m);
+        }
+    };
+    if constexpr (CHAIN) {
+        uint32_t cur = PREC_NONE, processed = 0;
+        for (;;) {
+            const bool idle = cur == PREC_NONE;
+            const uint64_t mi = __ballot(idle);
+            const uint32_t avail = tail - head, want = (uint32_t)__popcll(mi), rank = prec_mbcnt(mi);
+            uint32_t popped = PREC_NONE;
+            if (idle && rank < avail) popped = MEM::ld(Q + head + rank);  // (needed at the start of the NEXT round)
+            const uint32_t npop = want < avail ? want : avail;
+            head += npop;
+            if (want == 64u && npop == 0u) break;  // nobody holds a node and the queue is empty
+            rounds += 1;
+            processed += 64u - want;
+            int32_t fin = 0;
+            uint32_t deg = 0, s1 = PREC_NONE, ls = PREC_NONE;
+            if (!idle) {
+                uint2 rec;
+                rec.x = pm.nd[2 * (size_t)cur], rec.y = pm.nd[2 * (size_t)cur + 1];
+                fin = MEM::ld(E + cur) + (int32_t)rec.x;
+                mk = fin > mk ? fin : mk;
+                deg = rec.y >> 24;
+                s1 = (rec.y & 0xFFFFFFu) == 0xFFFFFFu ? PREC_NONE : (rec.y & 0xFFFFFFu);
+                ls = MEM::ld(S + cur);
+            }
+            bool new1, new2;
+            relax2(!idle, cur, fin, s1, ls, new1, new2);
+            const uint32_t nxt = new1 ? s1 : (new2 ? ls : PREC_NONE);
+            const bool extra = new1 && new2;
+            const uint64_t mx = __ballot(extra);
+            if (extra) MEM::st(Q + tail + prec_mbcnt(mx), ls);
+            tail += (uint32_t)__popcll(mx);
+            more_successors(cur, deg, fin);
+            cur = idle ? popped : nxt;
+            __builtin_amdgcn_wave_barrier();  // (LDS executes a wave's instructions in order: the next round's reads follow these writes)
+        }
+        head = processed;
+    } else {
+        // the popped node; its record (duration, out-degree, first fixed successor), earliest start and list successor; the relaxations; the queue writes
+        while (head < tail) {
+            const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
+            if (ROFF && lane == 0) ROFF[rounds] = head;
+            rounds += 1;
+            const bool act = lane < cnt;
+            int32_t fin = 0;
+            uint32_t node = 0, deg = 0, s1 = PREC_NONE, ls = PREC_NONE;
+            if (act) {
+                node = MEM::ld(Q + head + lane);
+                uint2 rec;  // (two loads: the LDS copy of the records is only 4-byte aligned)
+                rec.x = pm.nd[2 * (size_t)node], rec.y = pm.nd[2 * (size_t)node + 1];
+                fin = MEM::ld(E + node) + (int32_t)rec.x;
+                mk = fin > mk ? fin : mk;
+                deg = rec.y >> 24;
+                s1 = (rec.y & 0xFFFFFFu) == 0xFFFFFFu ? PREC_NONE : (rec.y & 0xFFFFFFu);
+                ls = MEM::ld(S + node);
+            }
+            bool new1, new2;
+            relax2(act, node, fin, s1, ls, new1, new2);
+            const uint64_t m1 = __ballot(new1), m2 = __ballot(new2);
+            if (new1) MEM::st(Q + tail + prec_mbcnt(m1), s1);
+            tail += (uint32_t)__popcll(m1);
+            if (new2) MEM::st(Q + tail + prec_mbcnt(m2), ls);
+            tail += (uint32_t)__popcll(m2);
+            more_successors(node, deg, fin);
+            head += cnt;
+            prec_sync();
+        }
     }
+    PEV(4)
+#ifdef SF_PHASE_PEVAL
+    if (pev_on) atomicAdd(&g_rphase2[5], (unsigned long long)rounds);
+#endif
     const bool cyclic = head < n;  // Kahn left nodes unprocessed (rebuild_graph_summary :584-588)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
