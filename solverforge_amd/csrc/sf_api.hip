@@ -2675,7 +2675,19 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
     gl.prec = ctx->has_list_model ? ctx->pm : PrecModel{};
     {  // the Kahn scratch (16 bytes per node) goes to LDS while at least 4 replicas still fit a CU
         const bool no_lds = std::getenv("SF_AMD_PREC_HBM") != nullptr;  // diagnostics / parity tests: force the HBM scratch (read at every launch)
-        gl.prec_lds = (gl.prec.on && !no_lds && prec_lds_scratch_bytes(gl.prec.n) <= 36 * 1024 && gl.prec.n < 65535) ? 1 : 0;
+        // ... and beyond that whenever ONE replica per CU still fits: 10,000 nodes (job shop 500 x 20) run 1.7 x the rate of the HBM scratch with
+        // half the replicas (profiles/r05_prec_eval_ab.txt).  SF_AMD_PREC_LDS_MAX_KB caps the scratch (36 = the round-4 rule)
+        size_t lds_max = SF_LDS_BUDGET;
+        if (const char* e = std::getenv("SF_AMD_PREC_LDS_MAX_KB")) lds_max = (size_t)std::atoi(e) * 1024;
+        bool fits = gl.prec.on && !no_lds && prec_lds_scratch_bytes(gl.prec.n) <= lds_max && gl.prec.n < 65535;
+        if (fits && prec_lds_scratch_bytes(gl.prec.n) > 36 * 1024) {  // the whole slice of a replica with the scratch in it (2-byte values: the larger carve)
+            const int ns = ctx->has_scalar_model ? ctx->sm.n : 0;
+            const bool tables = ctx->has_scalar_model && ctx->sm.tables();
+            const GCarve<int16_t> cv(ns, ctx->lm.V, ctx->lm.n_cap, gl.has_nearby ? ctx->lm.dim : 0, gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0,
+                                     ctx->lm.dim, gl.prec.n, tables ? ctx->sm.n_values : 0, tables && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0, 0, false);
+            fits = cv.total + 1024 <= SF_LDS_BUDGET;
+        }
+        gl.prec_lds = fits ? 1 : 0;
         // the incremental trial refresh is parity-complete but SLOWER than one full evaluation per trial on every job shop measured
         // (profiles/r03f_precedence.txt): opt-in for the parity tests and further work
         gl.prec_inc = std::getenv("SF_AMD_PREC_INC") != nullptr ? 1 : 0;

@@ -316,9 +316,6 @@ namespace sf {
 #else
 #define DBGK(k) (!FAST || ((k) & (16 | 32 | 64 | 128 | 256 | 512)) != 0)
 #endif
-#ifndef SF_PREC_CHAIN  // 1 = register hand-off between Kahn rounds (sf_precedence.h, prec_eval<.., CHAIN>); 0 = every node through the queue
-#define SF_PREC_CHAIN 0
-#endif
 #ifndef SF_MIXED_FAST_BLOCKS_PER_CU
 #define SF_MIXED_FAST_BLOCKS_PER_CU 4
 #endif
@@ -531,7 +528,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     // one full evaluation of the lists in LDS: typed LDS accessors when the scratch lives there
     auto prec_run = [&]() -> PrecResult {
         if (prec_in_lds)  // (nobody reads the pop order of this evaluation: the leaf and the recreate run plf_eval)
-            return prec_eval<uint16_t, PrecMemLds, SF_PREC_CHAIN != 0>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+            return prec_eval<uint16_t, PrecMemLds, false>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
                                                                         (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16);
         if (prec_sweep) {  // committed evaluation + what the lane-per-trial sweep reads: list predecessors, order positions, round starts, prefix maxima
             __shared__ uint32_t s_psw_info[4][4];

@@ -16,10 +16,6 @@
 
 #include "sf_precedence.h"
 
-#ifndef SF_PGRP_CHAIN  // 1 = register hand-off between Kahn rounds; 0 = every node through the group's queue
-#define SF_PGRP_CHAIN 0
-#endif
-
 namespace sf {
 
 typedef __attribute__((address_space(3))) uint16_t pg_lds_u16;
@@ -368,69 +364,6 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
     PGT(2)
     int32_t mk = 0;
     uint32_t pg_rounds = 0;
-#if SF_PGRP_CHAIN
-    // Register hand-off (as prec_eval<.., CHAIN>): a lane processes the node it made ready in the next round; only a lane's second ready node
-    // of a round goes through the group's queue, and idle lanes load queued nodes beside the busy lanes' record reads -- two dependent LDS
-    // round trips per round instead of four.
-    uint32_t cur = PG_NONE16, processed = 0;
-    for (;;) {
-        const bool idle = cur == PG_NONE16;
-        const uint64_t mi = __ballot(idle) & gmask;
-        const uint32_t avail = tail - head, want = (uint32_t)__popcll(mi), rank = (uint32_t)__popcll(mi & below);
-        uint32_t popped = PG_NONE16;
-        if (idle && rank < avail) popped = (uint32_t)L.Q[head + rank];  // (needed at the start of the next round)
-        const uint32_t npop = want < avail ? want : avail;
-        head += npop;
-        if (__ballot(want != G || npop != 0u) == 0ull) break;  // no group holds a node or has one queued
-        pg_rounds += 1;
-        processed += G - want;
-        int32_t fin = 0;
-        uint32_t deg = 0, s1 = PG_NONE16, s2 = PG_NONE16;
-        if (!idle) {
-            const uint32_t r0 = ps.nd[2 * cur], r1 = ps.nd[2 * cur + 1];
-            fin = L.E[cur] + (int32_t)r0;
-            s2 = (uint32_t)L.S[cur];
-            mk = fin > mk ? fin : mk;
-            deg = r1 >> 24;
-            s1 = (r1 & 0xFFFFFFu) == 0xFFFFFFu ? PG_NONE16 : (r1 & 0xFFFFFFu);
-        }
-        const uint32_t t1 = s1 != PG_NONE16 ? s1 : n + lg, t2 = s2 != PG_NONE16 ? s2 : n + lg;
-        __hip_atomic_fetch_max(L.E + t1, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int32_t o1 = __hip_atomic_fetch_add(L.D + t1, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_max(L.E + t2, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int32_t o2 = __hip_atomic_fetch_add(L.D + t2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const bool new1 = s1 != PG_NONE16 && o1 == 1, new2 = s2 != PG_NONE16 && o2 == 1;
-        const uint32_t nxt = new1 ? s1 : (new2 ? s2 : PG_NONE16);
-        const bool extra = new1 && new2;
-        const uint64_t mx = __ballot(extra) & gmask;
-        if (extra) L.Q[tail + (uint32_t)__popcll(mx & below)] = (uint16_t)s2;
-        tail += (uint32_t)__popcll(mx);
-        if (__ballot(deg > 1u)) {  // further fixed successors (none in a job shop)
-            uint32_t so = 0;
-            if (deg > 1u) {
-                so = ps.succ_off[cur];
-                deg = ps.succ_off[cur + 1] - so;  // (the record saturates at 255)
-            }
-            for (uint32_t k = 1;; ++k) {
-                const bool has = k < deg;
-                if (!__ballot(has)) break;
-                bool newly = false;
-                uint32_t s = 0;
-                if (has) {
-                    s = ps.succ[so + k];
-                    __hip_atomic_fetch_max(L.E + s, fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    newly = __hip_atomic_fetch_add(L.D + s, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 1;
-                }
-                const uint64_t m = __ballot(newly) & gmask;
-                if (newly) L.Q[tail + (uint32_t)__popcll(m & below)] = (uint16_t)s;
-                tail += (uint32_t)__popcll(m);
-            }
-        }
-        cur = idle ? popped : nxt;
-        __builtin_amdgcn_wave_barrier();  // (LDS executes a wave's instructions in order)
-    }
-    head = processed;
-#else
     while (__ballot(head < tail) != 0ull) {
         pg_rounds += 1;
         const uint32_t cnt = tail - head < G ? tail - head : G;
@@ -484,7 +417,6 @@ __device__ __noinline__ void prec_eval_grouped(const PgrpStatic ps, uint32_t n, 
         tail = ntail;
         prec_sync();
     }
-#endif
     PGT(3)
 #ifdef SF_PHASE_PGRP
     if (lane == 0) atomicAdd(&g_phase[6], (unsigned long long)pg_rounds);

@@ -87,6 +87,8 @@ struct PrecMemGlobal {
     static __device__ __forceinline__ int32_t fadd(int32_t* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     template <class T>
     static __device__ __forceinline__ const T* lists(const T* p) { return p; }  // the lists may live anywhere (generic pointer)
+    static constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;  // "none" as ld_idx returns it
+    static __device__ __forceinline__ uint32_t ld_idx(const uint32_t* p) { return ld(p); }
 };
 typedef __attribute__((address_space(3))) int32_t prec_lds_i32;
 typedef __attribute__((address_space(3))) uint32_t prec_lds_u32;
@@ -105,6 +107,8 @@ struct PrecMemLds {
     static __device__ __forceinline__ void st(prec_lds_u16* p, uint32_t v) { *p = (uint16_t)v; }
     static __device__ __forceinline__ void fmax(prec_lds_i32* p, int32_t v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
     static __device__ __forceinline__ int32_t fadd(prec_lds_i32* p, int32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    static constexpr uint32_t IDX_NONE = 0xFFFFu;  // "none" as ld_idx returns it: the stored 16 bits, not widened to PREC_NONE
+    static __device__ __forceinline__ uint32_t ld_idx(const prec_lds_u16* p) { return *p; }
     template <class T>  // scratch in LDS <=> the caller's lists are the replica's LDS copy: ds_read instead of FLAT
     static __device__ __forceinline__ const __attribute__((address_space(3))) T* lists(const T* p) { return (const __attribute__((address_space(3))) T*)p; }
 };
@@ -134,12 +138,10 @@ extern __device__ unsigned long long g_rphase2[8];
 // Full evaluation of the lists `visits` / `off` (V owners) by one wavefront; E / D / Q / S = the four scratch arrays of pm.n
 // words.  Wave-uniform result.  lint: small-pod-return (PrecResult = two int64: returned in four registers; never called inside a
 // conditional expression -- DESIGN 8.15 item 2 was a 32-byte struct through `?:`; scripts/lint_device_patterns.py checks both)
-// CHAIN (LDS scratch, trial and commit evaluations whose pop order nobody reads): a lane keeps the node it made ready in a register and
-// processes it in the next round; only the SECOND node a lane makes ready in a round goes through the queue, and idle lanes pick queued nodes
-// up with a load that travels beside the busy lanes' record reads.  A round is two dependent LDS round trips (records; relaxations) instead
-// of four (pop; records; relaxations; queue writes + hand-off).  The result does not depend on the pop order; Q is NOT the topological order
-// afterwards and ROFF must be null.
-template <class VT, class MEM = PrecMemGlobal, bool CHAIN = false>
+// ORDERED = false (trial and commit evaluations whose pop order nobody reads): when every node is in a list, the ready set is collected by the
+// list pass itself (the heads of the lists without a fixed predecessor) instead of a scan over the in-degrees -- the queue then starts in list
+// order, not in ascending node order.  The result does not depend on the pop order.
+template <class VT, class MEM = PrecMemGlobal, bool ORDERED = true>
 __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
                                              typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr, uint32_t* ROFF = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -158,7 +160,7 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + 64u * u + lane;
-            d0[u] = i < n ? pm.indeg0[i] : 0;
+            d0[u] = pm.indeg0[i < n ? i : 0u];  // (unconditional: see the list pass)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -175,6 +177,8 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
     PEV(1)
     const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[V]);
     uint32_t viol = 0;
+    uint32_t head = 0, tail = 0;
+    const bool ready_from_lists = !ORDERED && total == n;  // every node is listed: only list heads can be ready
     {   // list by list, 64 positions per chunk, four chunks in flight: list successor, in-degree and owner check of every item.  The
         // list offsets sit one per lane (V < 64; otherwise they are read where needed), so walking the chunks costs no memory access.
         const bool has_owner = pm.owner != nullptr;
@@ -233,6 +237,12 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
                     MEM::st(D + x[u], i0v[u] + (first ? 0 : 1));
                     viol += (has_owner && ow[u] >= 0 && (uint32_t)ow[u] != ce[u]) ? 1u : 0u;
                 }
+                if (!ORDERED && ready_from_lists && cf[u]) {  // (uniform: the chunk starts a list; at most lane 0 is ready)
+                    const bool ready = in[u] && lane == 0 && i0v[u] == 0;
+                    const uint64_t m = __ballot(ready);
+                    if (ready) MEM::st(Q + tail, x[u]);
+                    tail += (uint32_t)__popcll(m);
+                }
             }
         }
         };
@@ -241,8 +251,7 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
     }
     prec_sync();
     PEV(2)
-    uint32_t head = 0, tail = 0;
-    for (uint32_t b = 0; b < n; b += 256) {  // the ready nodes in ascending order (four reads in flight)
+    for (uint32_t b = 0; b < n && !ready_from_lists; b += 256) {  // the ready nodes in ascending order (four reads in flight)
         int32_t dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -266,25 +275,6 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
     // nothing (max with INT_MIN, add 0) instead of sitting in a branch of its own.  (Same target twice -- a fixed successor that is also the
     // list successor: LDS executes a wave's instructions in order, so the two decrements return consecutive values; with the scratch in HBM
     // the second relaxation of such a lane waits for the first.)
-    auto relax2 = [&](bool busy, uint32_t node, int32_t fin, uint32_t s1, uint32_t ls, bool& new1, bool& new2) {
-        new1 = false, new2 = false;
-        const bool same = busy && s1 != PREC_NONE && s1 == ls && !std::is_same<MEM, PrecMemLds>::value;
-        if (busy) {
-            const bool h1 = s1 != PREC_NONE, h2 = ls != PREC_NONE && !same;
-            const uint32_t t1 = h1 ? s1 : node, t2 = h2 ? ls : node;
-            MEM::fmax(E + t1, h1 ? fin : INT32_MIN);
-            const int32_t o1 = MEM::fadd(D + t1, h1 ? -1 : 0);
-            MEM::fmax(E + t2, h2 ? fin : INT32_MIN);
-            const int32_t o2 = MEM::fadd(D + t2, h2 ? -1 : 0);
-            new1 = h1 && o1 == 1, new2 = h2 && o2 == 1;
-        }
-        if (!std::is_same<MEM, PrecMemLds>::value && __ballot(same)) {
-            if (same) {
-                MEM::fmax(E + ls, fin);
-                new2 = MEM::fadd(D + ls, -1) == 1;
-            }
-        }
-    };
     // further fixed successors of the nodes of this round (none in a job shop): the record saturates at 255, the CSR has the rest
     auto more_successors = [&](uint32_t node, uint32_t deg, int32_t fin) {
         if (!__ballot(deg > 1u)) return;
@@ -308,72 +298,54 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
             tail += (uint32_t)__popcll(m);
         }
     };
-    if constexpr (CHAIN) {
-        uint32_t cur = PREC_NONE, processed = 0;
-        for (;;) {
-            const bool idle = cur == PREC_NONE;
-            const uint64_t mi = __ballot(idle);
-            const uint32_t avail = tail - head, want = (uint32_t)__popcll(mi), rank = prec_mbcnt(mi);
-            uint32_t popped = PREC_NONE;
-            if (idle && rank < avail) popped = MEM::ld(Q + head + rank);  // (needed at the start of the NEXT round)
-            const uint32_t npop = want < avail ? want : avail;
-            head += npop;
-            if (want == 64u && npop == 0u) break;  // nobody holds a node and the queue is empty
-            rounds += 1;
-            processed += 64u - want;
-            int32_t fin = 0;
-            uint32_t deg = 0, s1 = PREC_NONE, ls = PREC_NONE;
-            if (!idle) {
-                uint2 rec;
-                rec.x = pm.nd[2 * (size_t)cur], rec.y = pm.nd[2 * (size_t)cur + 1];
-                fin = MEM::ld(E + cur) + (int32_t)rec.x;
-                mk = fin > mk ? fin : mk;
-                deg = rec.y >> 24;
-                s1 = (rec.y & 0xFFFFFFu) == 0xFFFFFFu ? PREC_NONE : (rec.y & 0xFFFFFFu);
-                ls = MEM::ld(S + cur);
-            }
-            bool new1, new2;
-            relax2(!idle, cur, fin, s1, ls, new1, new2);
-            const uint32_t nxt = new1 ? s1 : (new2 ? ls : PREC_NONE);
-            const bool extra = new1 && new2;
-            const uint64_t mx = __ballot(extra);
-            if (extra) MEM::st(Q + tail + prec_mbcnt(mx), ls);
-            tail += (uint32_t)__popcll(mx);
-            more_successors(cur, deg, fin);
-            cur = idle ? popped : nxt;
-            __builtin_amdgcn_wave_barrier();  // (LDS executes a wave's instructions in order: the next round's reads follow these writes)
+    // A round: the popped node; its record (duration, out-degree, first fixed successor), earliest start and list successor; the relaxations;
+    // the queue writes.  The round has NO lane-masked region -- a wave runs about one instruction per 4 - 8 clocks whatever the lanes do, so the
+    // mask bookkeeping of five small branches was a quarter of a round: a lane without a popped node re-reads the round's first one, a missing
+    // successor (and every idle lane) relaxes a per-lane dummy node with operands that change nothing (max with INT_MIN, add 0), and a lane
+    // without a push rewrites a popped slot with the value it already holds.  (Same target twice -- a fixed successor that is also the list
+    // successor: LDS executes a wave's instructions in order, so the two decrements return consecutive values; with the scratch in HBM the
+    // second relaxation of such a lane waits for the first.)
+    constexpr bool in_lds = std::is_same<MEM, PrecMemLds>::value;
+    const uint32_t dummy = lane < n ? lane : 0u;
+    while (head < tail) {
+        const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
+        if (ORDERED && ROFF && lane == 0) ROFF[rounds] = head;
+        rounds += 1;
+        const bool act = lane < cnt;
+        const auto slot = Q + head + (act ? lane : 0u);
+        const uint32_t node = MEM::ld_idx(slot);
+        const uint32_t r0 = pm.nd[2 * (size_t)node], r1 = pm.nd[2 * (size_t)node + 1];  // (two loads: the LDS copy of the records is only 4-byte aligned)
+        const int32_t fin = MEM::ld(E + node) + (int32_t)r0;
+        const uint32_t ls = MEM::ld_idx(S + node), s1 = r1 & 0xFFFFFFu;
+        mk = fin > mk ? fin : mk;
+        const uint32_t deg = act ? r1 >> 24 : 0u;
+        const bool h1 = act && s1 != 0xFFFFFFu, same = !in_lds && h1 && s1 == ls, h2 = act && ls != MEM::IDX_NONE && !same;
+        const uint32_t t1 = h1 ? s1 : dummy, t2 = h2 ? ls : dummy;
+        int32_t o1 = 0, o2 = 0;
+        if (in_lds || h1) {  // (HBM scratch: no dummy traffic to L2 -- there a round waits on memory, not on the instruction stream)
+            MEM::fmax(E + t1, h1 ? fin : INT32_MIN);
+            o1 = MEM::fadd(D + t1, h1 ? -1 : 0);
         }
-        head = processed;
-    } else {
-        // the popped node; its record (duration, out-degree, first fixed successor), earliest start and list successor; the relaxations; the queue writes
-        while (head < tail) {
-            const uint32_t cnt = tail - head < 64u ? tail - head : 64u;
-            if (ROFF && lane == 0) ROFF[rounds] = head;
-            rounds += 1;
-            const bool act = lane < cnt;
-            int32_t fin = 0;
-            uint32_t node = 0, deg = 0, s1 = PREC_NONE, ls = PREC_NONE;
-            if (act) {
-                node = MEM::ld(Q + head + lane);
-                uint2 rec;  // (two loads: the LDS copy of the records is only 4-byte aligned)
-                rec.x = pm.nd[2 * (size_t)node], rec.y = pm.nd[2 * (size_t)node + 1];
-                fin = MEM::ld(E + node) + (int32_t)rec.x;
-                mk = fin > mk ? fin : mk;
-                deg = rec.y >> 24;
-                s1 = (rec.y & 0xFFFFFFu) == 0xFFFFFFu ? PREC_NONE : (rec.y & 0xFFFFFFu);
-                ls = MEM::ld(S + node);
-            }
-            bool new1, new2;
-            relax2(act, node, fin, s1, ls, new1, new2);
-            const uint64_t m1 = __ballot(new1), m2 = __ballot(new2);
-            if (new1) MEM::st(Q + tail + prec_mbcnt(m1), s1);
-            tail += (uint32_t)__popcll(m1);
-            if (new2) MEM::st(Q + tail + prec_mbcnt(m2), ls);
-            tail += (uint32_t)__popcll(m2);
-            more_successors(node, deg, fin);
-            head += cnt;
-            prec_sync();
+        if (in_lds || h2) {
+            MEM::fmax(E + t2, h2 ? fin : INT32_MIN);
+            o2 = MEM::fadd(D + t2, h2 ? -1 : 0);
         }
+        const bool new1 = h1 && o1 == 1;
+        bool new2 = h2 && o2 == 1;
+        if (!in_lds && __ballot(same)) {
+            if (same) {
+                MEM::fmax(E + ls, fin);
+                new2 = MEM::fadd(D + ls, -1) == 1;
+            }
+        }
+        const uint64_t m1 = __ballot(new1), m2 = __ballot(new2);
+        const uint32_t c1 = (uint32_t)__popcll(m1);
+        MEM::st(new1 ? Q + tail + prec_mbcnt(m1) : slot, new1 ? s1 : node);
+        MEM::st(new2 ? Q + tail + c1 + prec_mbcnt(m2) : slot, new2 ? ls : node);
+        tail += c1 + (uint32_t)__popcll(m2);
+        more_successors(node, deg, fin);
+        head += cnt;
+        prec_sync();
     }
     PEV(4)
 #ifdef SF_PHASE_PEVAL

@@ -14,7 +14,8 @@ def scratch_mode(request, monkeypatch):
     workgroup-shared LDS copy of the static graph (which also switches the groups off) -- and forced into HBM (the layout of large
     graphs) three ways: the default lane-per-trial sweep of the list change / swap trials (prec_trial_sweep64), one full evaluation
     per trial, and the opt-in wave-cooperative incremental refresh (prec_trial_inc).  The library reads the variables at every launch."""
-    for k in ("SF_AMD_PREC_HBM", "SF_AMD_PREC_INC", "SF_AMD_PREC_NO_SWEEP", "SF_AMD_PREC_GROUPS", "SF_AMD_PREC_STATIC_HBM"):
+    for k in ("SF_AMD_PREC_HBM", "SF_AMD_PREC_INC", "SF_AMD_PREC_NO_SWEEP", "SF_AMD_PREC_GROUPS", "SF_AMD_PREC_STATIC_HBM", "SF_AMD_PREC_STATIC_SLIM",
+              "SF_AMD_PREC_LDS_MAX_KB"):
         monkeypatch.delenv(k, raising=False)
     if request.param.startswith("hbm"):
         monkeypatch.setenv("SF_AMD_PREC_HBM", "1")
@@ -201,6 +202,43 @@ def test_apply_traced_and_fused_steps(oracle):
         assert d.working_lists(0, 0) == o.get_lists(0), step
     d.solve_steps(60)
     o.steps(60)
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all()
+    assert (d.fresh_score()[0] == o.score()[:2]).all()
+    gst, ost = d.stats(0), o.stats()
+    for k in ["step_count", "moves_evaluated", "moves_accepted", "moves_applied", "score_calculations"]:
+        assert gst[k] == ost[k], k
+
+
+@pytest.mark.parametrize("jobs,machines,setting", [(30, 20, "default"), (30, 20, "static_in_hbm"), (30, 20, "lds_cap_36"), (3, 70, "default"), (40, 70, "default")])
+def test_larger_shops_setup_paths(oracle, monkeypatch, jobs, machines, setting):
+    """Round 5: the wave-wide evaluation's set-up walks the lists chunk by chunk with the list offsets held one per lane (fewer than 64 lists) or
+    read from the lists' offset table (70 lists here), keeps 16-bit queue / successor arrays in LDS, and reads node records, fixed in-degrees and
+    owners from a slim workgroup-shared LDS copy when the full static copy does not fit (600 nodes and more; SF_AMD_PREC_STATIC_SLIM=0 leaves
+    them in HBM).  2,800 nodes (40 x 70) put the scratch beyond the round-4 LDS limit: it stays in LDS as long as one replica per CU fits.
+    Full scores of scheduled / shuffled / partly assigned states, then fused steps == oracle."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    if setting == "static_in_hbm":
+        monkeypatch.setenv("SF_AMD_PREC_STATIC_SLIM", "0")
+    if setting == "lds_cap_36":
+        monkeypatch.setenv("SF_AMD_PREC_LDS_MAX_KB", "36")
+    p0 = datasets.make_precedence_shop(jobs, machines, seed=9)
+    for p in (p0, _shuffled(p0, 5, 3)):
+        d, o, _ = _mk(oracle, p)
+        assert (d.calculate_score()[0] == o.score()[:2]).all()
+        assert (d.fresh_score()[0] == o.score()[:2]).all()
+    leaves = ("list_change", "list_swap", "sublist_change", "list_reverse")
+    d, o, bits = _mk(oracle, p0, leaves=leaves)
+    d.calculate_score()
+    o.configure(leaves=bits, random_seed=6, la_size=5, limit=12)
+    d.configure(sfa.SolverConfig(random_seed=6, late_acceptance_size=5, accepted_count_limit=12))
+    d.phase_start()
+    o.phase_start()
+    steps = 4 if jobs * machines > 2000 else 10
+    d.solve_steps(steps)
+    o.steps(steps)
     assert d.working_lists(0, 0) == o.get_lists(0)
     assert (d.calculate_score()[0] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.score()[:2]).all()
