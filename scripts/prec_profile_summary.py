@@ -11,7 +11,7 @@ for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recurs
             stats = {"kernel": row["Name"].split("(")[0], "calls": int(row["Calls"]), "average_ms": float(row["AverageNs"]) / 1e6, "min_ms": float(row["MinNs"]) / 1e6,
                      "max_ms": float(row["MaxNs"]) / 1e6, "share_of_gpu_time": float(row["Percentage"]) / 100}
 m = lambda k: d[k]["mean"]
-out = {"command": "python scripts/prec_policy_launches.py 20 10 2048 10 4 (scripts/prec_profile.sh: one rocprofv3 --kernel-trace --stats run, four --pmc passes, -f csv)",
+out = {"command": "python scripts/prec_policy_launches.py " + (sys.argv[3] if len(sys.argv) > 3 else "20 10 2048 10 4") + " (scripts/prec_profile.sh: one rocprofv3 --kernel-trace --stats run, four --pmc passes, -f csv)",
        "untimed_run": plain, "kernel_trace": stats,
        "registers": {"arch_vgpr": d["_vgpr"], "sgpr": d["_sgpr"], "static_lds": d["_lds"], "scratch_bytes_per_lane": d["_scratch"]},
        "per_launch_mean": {k: v["mean"] for k, v in d.items() if isinstance(v, dict)},

@@ -527,9 +527,13 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     PrecRec* const psw_rec = prec_sweep ? (PrecRec*)gl.prec.rec + (size_t)r * gl.prec.n : nullptr;
     // one full evaluation of the lists in LDS: typed LDS accessors when the scratch lives there
     auto prec_run = [&]() -> PrecResult {
-        if (prec_in_lds)  // (nobody reads the pop order of this evaluation: the leaf and the recreate run plf_eval)
-            return prec_eval<uint16_t, PrecMemLds, false>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
-                                                                        (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16);
+        if (prec_in_lds) {  // (nobody reads the pop order of this evaluation: the leaf and the recreate run plf_eval)
+            if (gl.prec_static)
+                return prec_eval<uint16_t, PrecMemLds, false, true>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                                                                    (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16);
+            return prec_eval<uint16_t, PrecMemLds, false, false>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                                                                 (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16);
+        }
         if (prec_sweep) {  // committed evaluation + what the lane-per-trial sweep reads: list predecessors, order positions, round starts, prefix maxima
             __shared__ uint32_t s_psw_info[4][4];
             uint32_t* info = s_psw_info[wave_in_group];
@@ -704,7 +708,10 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     // full evaluation of the lists in LDS that also reports the cycle flag (and, with `roff`, Kahn's rounds)
     auto plf_eval = [&](bool& cyclic, uint32_t* roff, uint32_t* lp = nullptr) -> PrecResult {
         PrecResult pr;
-        if (prec_in_lds)
+        if (prec_in_lds && gl.prec_static)
+            pr = prec_eval<uint16_t, PrecMemLds, true, true>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                                                             (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, lp, plf_info, roff);
+        else if (prec_in_lds)
             pr = prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u16*)prec_Q16,
                                                  (prec_lds_u16*)prec_S16, lp, plf_info, roff);
         else

@@ -138,16 +138,28 @@ extern __device__ unsigned long long g_rphase2[8];
 // Full evaluation of the lists `visits` / `off` (V owners) by one wavefront; E / D / Q / S = the four scratch arrays of pm.n
 // words.  Wave-uniform result.  lint: small-pod-return (PrecResult = two int64: returned in four registers; never called inside a
 // conditional expression -- DESIGN 8.15 item 2 was a 32-byte struct through `?:`; scripts/lint_device_patterns.py checks both)
+// STATIC_LDS: pm.nd / pm.indeg0 / pm.owner point into the workgroup's LDS copy of the static graph (sf_mixed_wave.hip) -- read with ds_read
+// instead of FLAT instructions (a FLAT access that lands in LDS still takes the vector-memory path first).
 // ORDERED = false (trial and commit evaluations whose pop order nobody reads): when every node is in a list, the ready set is collected by the
 // list pass itself (the heads of the lists without a fixed predecessor) instead of a scan over the in-degrees -- the queue then starts in list
 // order, not in ascending node order.  The result does not depend on the pop order.
-template <class VT, class MEM = PrecMemGlobal, bool ORDERED = true>
+template <class VT, class MEM = PrecMemGlobal, bool ORDERED = true, bool STATIC_LDS = false>
 __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
                                              typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr, uint32_t* ROFF = nullptr) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     const auto vis = MEM::lists(visits);
     const auto offs = MEM::lists(off);
+    typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+    typedef __attribute__((address_space(3))) const int32_t lds_ci32;
+    auto nd_at = [&](uint32_t i) -> uint32_t {
+        if constexpr (STATIC_LDS) return ((lds_cu32*)pm.nd)[i];
+        else return pm.nd[i];
+    };
+    auto indeg0_at = [&](uint32_t i) -> int32_t {
+        if constexpr (STATIC_LDS) return ((lds_ci32*)pm.indeg0)[i];
+        else return pm.indeg0[i];
+    };
 #ifdef SF_PHASE_PEVAL
     const bool pev_on = lane == 0 && (blockIdx.x & 31u) == 0u;  // (one workgroup in 32 reports: same-address atomics of every wave would be the bottleneck)
     uint64_t pev_t = clock64();
@@ -155,12 +167,14 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
 #endif
     // ---- set-up.  Every loop keeps four independent iterations in flight: the evaluation is a chain of dependent round trips from start to end,
     // and at 1,000 nodes the set-up used to be as long a chain as Kahn's rounds (one binary search over `off` per 64 items, every load waited for).
-    for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[V]);
+    const bool all_listed = total == n && LP == nullptr;  // the list pass writes every node's three words itself: no init pass
+    for (uint32_t i0 = 0; i0 < n && !all_listed; i0 += 256) {
         int32_t d0[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t i = i0 + 64u * u + lane;
-            d0[u] = pm.indeg0[i < n ? i : 0u];  // (unconditional: see the list pass)
+            d0[u] = indeg0_at(i < n ? i : 0u);  // (unconditional: see the list pass)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -175,7 +189,6 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
     }
     prec_sync();
     PEV(1)
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[V]);
     uint32_t viol = 0;
     uint32_t head = 0, tail = 0;
     const bool ready_from_lists = !ORDERED && total == n;  // every node is listed: only list heads can be ready
@@ -225,14 +238,16 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
             int32_t i0v[4], ow[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                i0v[u] = pm.indeg0[x[u]];
-                ow[u] = own[x[u]];
+                i0v[u] = indeg0_at(x[u]);
+                if constexpr (STATIC_LDS) ow[u] = ((lds_ci32*)own)[x[u]];
+                else ow[u] = own[x[u]];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (in[u]) {
                     const bool first = lane == 0 && cf[u];
                     MEM::st(S + x[u], nx[u]);
+                    MEM::st(E + x[u], 0);
                     if (LP) LP[x[u]] = px[u];
                     MEM::st(D + x[u], i0v[u] + (first ? 0 : 1));
                     viol += (has_owner && ow[u] >= 0 && (uint32_t)ow[u] != ce[u]) ? 1u : 0u;
@@ -314,7 +329,7 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
         const bool act = lane < cnt;
         const auto slot = Q + head + (act ? lane : 0u);
         const uint32_t node = MEM::ld_idx(slot);
-        const uint32_t r0 = pm.nd[2 * (size_t)node], r1 = pm.nd[2 * (size_t)node + 1];  // (two loads: the LDS copy of the records is only 4-byte aligned)
+        const uint32_t r0 = nd_at(2 * node), r1 = nd_at(2 * node + 1);  // (two loads: the LDS copy of the records is only 4-byte aligned)
         const int32_t fin = MEM::ld(E + node) + (int32_t)r0;
         const uint32_t ls = MEM::ld_idx(S + node), s1 = r1 & 0xFFFFFFu;
         mk = fin > mk ? fin : mk;
