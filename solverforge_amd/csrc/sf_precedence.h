@@ -143,6 +143,7 @@ extern __device__ unsigned long long g_rphase2[8];
 // ORDERED = false (trial and commit evaluations whose pop order nobody reads): when every node is in a list, the ready set is collected by the
 // list pass itself (the heads of the lists without a fixed predecessor) instead of a scan over the in-degrees -- the queue then starts in list
 // order, not in ascending node order.  The result does not depend on the pop order.
+// (lint: small-pod-return -- see above)
 template <class VT, class MEM = PrecMemGlobal, bool ORDERED = true, bool STATIC_LDS = false>
 __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
                                              typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr, uint32_t* ROFF = nullptr) {
