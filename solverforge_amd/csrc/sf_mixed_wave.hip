@@ -708,7 +708,14 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     // full evaluation of the lists in LDS that also reports the cycle flag (and, with `roff`, Kahn's rounds)
     auto plf_eval = [&](bool& cyclic, uint32_t* roff, uint32_t* lp = nullptr) -> PrecResult {
         PrecResult pr;
-        if (prec_in_lds && gl.prec_static)
+        if (prec_in_lds && !roff && !lp) {  // the route-graph filter's evaluations: nobody reads their pop order (plf_closes_cycle walks the list successors)
+            if (gl.prec_static)
+                pr = prec_eval<uint16_t, PrecMemLds, false, true>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                                                                  (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, nullptr, plf_info, nullptr);
+            else
+                pr = prec_eval<uint16_t, PrecMemLds, false, false>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                                                                   (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, nullptr, plf_info, nullptr);
+        } else if (prec_in_lds && gl.prec_static)
             pr = prec_eval<uint16_t, PrecMemLds, true, true>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
                                                              (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, lp, plf_info, roff);
         else if (prec_in_lds)
