@@ -200,94 +200,94 @@ __device__ __noinline__ PrecResult prec_eval(const PrecModel pm, const VT* visit
         const uint32_t my_off = V < 64 ? (uint32_t)offs[lane <= (uint32_t)V ? lane : (uint32_t)V] : 0u;
         const uint32_t my_off1 = V < 64 ? (uint32_t)offs[lane + 1 <= (uint32_t)V ? lane + 1 : (uint32_t)V] : 0u;  // (end of list `lane`)
         auto list_pass = [&](auto held_c) {  // (two copies of the loop: the offset source is a compile-time choice inside each)
-        constexpr bool held = decltype(held_c)::value;
-        auto off_at = [&](uint32_t e) -> uint32_t {
-            if constexpr (held) return (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)e);
-            else return (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[e]);
-        };
-        // chunk -> (list, start): with the offsets held per lane, lane e also holds the number of chunks of list e and their running total
-        // (one wave scan per evaluation), and a chunk finds its list with one ballot -- no loop over the lists, nothing divergent
-        uint32_t cstart = 0, nch = 0, n_chunks = 0;
-        if constexpr (held) {
-            const uint32_t len = lane < (uint32_t)V ? my_off1 - my_off : 0u;
-            nch = (len + 63u) >> 6;
-            uint32_t incl = nch;
+            constexpr bool held = decltype(held_c)::value;
+            auto off_at = [&](uint32_t e) -> uint32_t {
+                if constexpr (held) return (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)e);
+                else return (uint32_t)__builtin_amdgcn_readfirstlane((int)offs[e]);
+            };
+            // chunk -> (list, start): with the offsets held per lane, lane e also holds the number of chunks of list e and their running total
+            // (one wave scan per evaluation), and a chunk finds its list with one ballot -- no loop over the lists, nothing divergent
+            uint32_t cstart = 0, nch = 0, n_chunks = 0;
+            if constexpr (held) {
+                const uint32_t len = lane < (uint32_t)V ? my_off1 - my_off : 0u;
+                nch = (len + 63u) >> 6;
+                uint32_t incl = nch;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-                incl += lane >= (uint32_t)o ? up : 0u;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                    incl += lane >= (uint32_t)o ? up : 0u;
+                }
+                cstart = incl - nch;
+                n_chunks = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
-            cstart = incl - nch;
-            n_chunks = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-        uint32_t e = 0, k0 = 0, eo = (!held && V > 0) ? off_at(0) : 0u, en = (!held && V > 0) ? off_at(1) : 0u;  // (walker of the offset-table path)
-        for (uint32_t c0 = 0;; c0 += 4) {
-            uint32_t ce[4], cb[4], cl[4];  // chunk: list, flat index of its first position, positions left in the list from there
-            bool cf[4];                    // the chunk starts its list
-            bool any = false;
+            uint32_t e = 0, k0 = 0, eo = (!held && V > 0) ? off_at(0) : 0u, en = (!held && V > 0) ? off_at(1) : 0u;  // (walker of the offset-table path)
+            for (uint32_t c0 = 0;; c0 += 4) {
+                uint32_t ce[4], cb[4], cl[4];  // chunk: list, flat index of its first position, positions left in the list from there
+                bool cf[4];                    // the chunk starts its list
+                bool any = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if constexpr (held) {
-                    const uint32_t c = c0 + (uint32_t)u;
-                    const uint64_t hit = __ballot(c >= cstart && c < cstart + nch);  // (exactly one lane for c < n_chunks)
-                    const bool ok = c < n_chunks;
-                    const uint32_t le = ok ? (uint32_t)__builtin_ctzll(hit) : 0u;
-                    const uint32_t ko = (c - (uint32_t)__builtin_amdgcn_readlane((int)cstart, (int)le)) << 6;
-                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)le), hi = (uint32_t)__builtin_amdgcn_readlane((int)my_off1, (int)le);
-                    ce[u] = le, cb[u] = ok ? lo + ko : 0u, cl[u] = ok ? hi - (lo + ko) : 0u, cf[u] = ko == 0u;
+                for (int u = 0; u < 4; ++u) {
+                    if constexpr (held) {
+                        const uint32_t c = c0 + (uint32_t)u;
+                        const uint64_t hit = __ballot(c >= cstart && c < cstart + nch);  // (exactly one lane for c < n_chunks)
+                        const bool ok = c < n_chunks;
+                        const uint32_t le = ok ? (uint32_t)__builtin_ctzll(hit) : 0u;
+                        const uint32_t ko = (c - (uint32_t)__builtin_amdgcn_readlane((int)cstart, (int)le)) << 6;
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)my_off, (int)le), hi = (uint32_t)__builtin_amdgcn_readlane((int)my_off1, (int)le);
+                        ce[u] = le, cb[u] = ok ? lo + ko : 0u, cl[u] = ok ? hi - (lo + ko) : 0u, cf[u] = ko == 0u;
+                        any = any || ok;
+                        continue;
+                    }
+                    while (e < (uint32_t)V && eo + k0 >= en) {  // next list with items left
+                        e += 1, k0 = 0, eo = en;
+                        en = e < (uint32_t)V ? off_at(e + 1) : en;
+                    }
+                    const bool ok = e < (uint32_t)V;
+                    ce[u] = e, cb[u] = eo + k0, cl[u] = ok ? en - (eo + k0) : 0u, cf[u] = k0 == 0u;
                     any = any || ok;
-                    continue;
+                    k0 += 64;
                 }
-                while (e < (uint32_t)V && eo + k0 >= en) {  // next list with items left
-                    e += 1, k0 = 0, eo = en;
-                    en = e < (uint32_t)V ? off_at(e + 1) : en;
-                }
-                const bool ok = e < (uint32_t)V;
-                ce[u] = e, cb[u] = eo + k0, cl[u] = ok ? en - (eo + k0) : 0u, cf[u] = k0 == 0u;
-                any = any || ok;
-                k0 += 64;
-            }
-            if (!any) break;
-            // every load below is unconditional (an idle lane reads position 0 / node vis[0]): a load inside a lane-masked branch is waited
-            // for at the end of its branch, which serialised the eight table reads of an iteration
-            bool in[4];
-            uint32_t x[4], nx[4], px[4];
+                if (!any) break;
+                // every load below is unconditional (an idle lane reads position 0 / node vis[0]): a load inside a lane-masked branch is waited
+                // for at the end of its branch, which serialised the eight table reads of an iteration
+                bool in[4];
+                uint32_t x[4], nx[4], px[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                in[u] = lane < cl[u];
-                const uint32_t t = in[u] ? cb[u] + lane : 0u;
-                const bool more = in[u] && lane + 1 < cl[u];
-                x[u] = (uint32_t)vis[t];
-                nx[u] = (uint32_t)vis[more ? t + 1 : 0u];
-                nx[u] = more ? nx[u] : PREC_NONE;
-                px[u] = PREC_NONE;
-                if (LP) px[u] = (in[u] && (lane > 0 || !cf[u])) ? (uint32_t)vis[t - 1] : PREC_NONE;
-            }
-            int32_t i0v[4], ow[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                i0v[u] = indeg0_at(x[u]);
-                if constexpr (STATIC_LDS) ow[u] = ((lds_ci32*)own)[x[u]];
-                else ow[u] = own[x[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (in[u]) {
-                    const bool first = lane == 0 && cf[u];
-                    MEM::st(S + x[u], nx[u]);
-                    MEM::st(E + x[u], 0);
-                    if (LP) LP[x[u]] = px[u];
-                    MEM::st(D + x[u], i0v[u] + (first ? 0 : 1));
-                    viol += (has_owner && ow[u] >= 0 && (uint32_t)ow[u] != ce[u]) ? 1u : 0u;
+                for (int u = 0; u < 4; ++u) {
+                    in[u] = lane < cl[u];
+                    const uint32_t t = in[u] ? cb[u] + lane : 0u;
+                    const bool more = in[u] && lane + 1 < cl[u];
+                    x[u] = (uint32_t)vis[t];
+                    nx[u] = (uint32_t)vis[more ? t + 1 : 0u];
+                    nx[u] = more ? nx[u] : PREC_NONE;
+                    px[u] = PREC_NONE;
+                    if (LP) px[u] = (in[u] && (lane > 0 || !cf[u])) ? (uint32_t)vis[t - 1] : PREC_NONE;
                 }
-                if (!ORDERED && ready_from_lists && cf[u]) {  // (uniform: the chunk starts a list; at most lane 0 is ready)
-                    const bool ready = in[u] && lane == 0 && i0v[u] == 0;
-                    const uint64_t m = __ballot(ready);
-                    if (ready) MEM::st(Q + tail, x[u]);
-                    tail += (uint32_t)__popcll(m);
+                int32_t i0v[4], ow[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    i0v[u] = indeg0_at(x[u]);
+                    if constexpr (STATIC_LDS) ow[u] = ((lds_ci32*)own)[x[u]];
+                    else ow[u] = own[x[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (in[u]) {
+                        const bool first = lane == 0 && cf[u];
+                        MEM::st(S + x[u], nx[u]);
+                        MEM::st(E + x[u], 0);
+                        if (LP) LP[x[u]] = px[u];
+                        MEM::st(D + x[u], i0v[u] + (first ? 0 : 1));
+                        viol += (has_owner && ow[u] >= 0 && (uint32_t)ow[u] != ce[u]) ? 1u : 0u;
+                    }
+                    if (!ORDERED && ready_from_lists && cf[u]) {  // (uniform: the chunk starts a list; at most lane 0 is ready)
+                        const bool ready = in[u] && lane == 0 && i0v[u] == 0;
+                        const uint64_t m = __ballot(ready);
+                        if (ready) MEM::st(Q + tail, x[u]);
+                        tail += (uint32_t)__popcll(m);
+                    }
                 }
             }
-        }
         };
         if (V < 64) list_pass(std::true_type{});
         else list_pass(std::false_type{});
