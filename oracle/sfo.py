@@ -126,6 +126,8 @@ def lib():
             "sfo_model_construct_list_clarke_wright": (i32, [vp, vp, i32, i32, vp]),
             "sfo_model_construct_list_round_robin": (None, [vp, vp, i32, vp, vp]),
             "sfo_model_construct_list_k_opt": (None, [vp, i32, i32, i32, vp]),
+            "sfo_model_set_time_windows": (None, [vp, vp, vp, vp, vp, i64]),
+            "sfo_model_route_feasible": (i32, [vp, vp, i32]),
             "sfo_model_get_vars": (i32, [vp, i32, i32, vp]),
             "sfo_model_get_lists": (i32, [vp, i32, vp, vp]),
         }
@@ -486,6 +488,16 @@ class Model:
         st = np.zeros(4, dtype=np.uint64)
         lib().sfo_model_construct_list_k_opt(self.h, int(k), int(feasible_mode), int(max_sweeps), _p(st))
         return st
+
+    def set_time_windows(self, lo, hi, service, travel, departure=0):
+        """Time windows / service durations / travel times of a CVRP model (solverforge-cvrp problem_data.rs:20-23): read by
+        construct_list_k_opt(feasible_mode=2) and route_feasible; the scoring path does not use them."""
+        a = [np.ascontiguousarray(x, dtype=np.int64) for x in (lo, hi, service, travel)]
+        lib().sfo_model_set_time_windows(self.h, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), int(departure))
+
+    def route_feasible(self, route):
+        r = np.ascontiguousarray(route, dtype=np.uint32)
+        return bool(lib().sfo_model_route_feasible(self.h, _p(r), len(r)))
 
     def construct_first_fit(self):
         lib().sfo_model_construct_first_fit(self.h)

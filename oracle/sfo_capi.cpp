@@ -614,8 +614,26 @@ int32_t sfo_model_construct_list_clarke_wright(void* h, const uint32_t* elements
     if (stats) stats[0] = st.savings_pairs, stats[1] = st.merge_trials, stats[2] = st.merges, stats[3] = st.merge_passes, stats[4] = st.completion_trials;
     return committed ? 1 : 0;
 }
+// Time windows / service durations / travel times of a CVRP model (solverforge-cvrp/src/problem_data.rs:20-23): lo / hi / service per node,
+// travel dim x dim row-major.  Read by feasible_mode 2 of the list k-opt phase; nothing on the scoring path uses them (as in the stock crate).
+void sfo_model_set_time_windows(void* h, const int64_t* lo, const int64_t* hi, const int64_t* service, const int64_t* travel, int64_t departure) {
+    Model* m = (Model*)h;
+    CvrpFacts* cf = const_cast<CvrpFacts*>(static_cast<const CvrpFacts*>(m->director.working.facts.get()));
+    const size_t n = cf->dim;
+    cf->tw_lo.assign(lo, lo + n), cf->tw_hi.assign(hi, hi + n), cf->service.assign(service, service + n);
+    cf->travel.assign(travel, travel + n * n);
+    cf->departure = departure;
+}
+// 1 = the route passes the stock route_hooks::feasible (capacity + time windows; an empty route always does)
+int32_t sfo_model_route_feasible(void* h, const uint32_t* route, int32_t n) {
+    Model* m = (Model*)h;
+    const CvrpFacts* cf = static_cast<const CvrpFacts*>(m->director.working.facts.get());
+    std::vector<size_t> r(route, route + n);
+    return (r.empty() || (cf->capacity_feasible(r) && cf->time_feasible(r))) ? 1 : 0;
+}
 // ListKOptPhase (route-local 2-opt) over a CVRP model's list class with the stock route hooks (solverforge-cvrp/src/helpers.rs
-// route_hooks: depot, distance_cost legs; feasible_mode 0 = no feasibility hook, 1 = the capacity test of route_hooks::feasible).
+// route_hooks: depot, distance_cost legs; feasible_mode 0 = no feasibility hook, 1 = the capacity test of route_hooks::feasible, 2 = the complete
+// hook with the time windows of sfo_model_set_time_windows).
 // stats[0..4] = candidates, accepted reversals, applied (committed) reversals, steps (changed routes).
 void sfo_model_construct_list_k_opt(void* h, int32_t k, int32_t feasible_mode, int32_t max_sweeps, uint64_t* stats) {
     Model* m = (Model*)h;
@@ -641,6 +659,8 @@ void sfo_model_construct_list_k_opt(void* h, int32_t k, int32_t feasible_mode, i
                 if (v >= cf->dim || __builtin_add_overflow(total, (int64_t)cf->demands[v], &total)) return false;
             return total <= cf->capacity;
         };
+    if (feasible_mode == 2)  // the complete route_hooks::feasible: capacity + time windows (helpers.rs:109-119; sfo_model_set_time_windows)
+        hk.feasible = [cf](size_t, const std::vector<size_t>& route) { return route.empty() || (cf->capacity_feasible(route) && cf->time_feasible(route)); };
     ListKOptStats st;
     list_k_opt(hk, (size_t)k, &st, (size_t)max_sweeps);
     m->director.calculate_score();

@@ -44,6 +44,41 @@ struct CvrpFacts {
         int64_t v;
         return finite(from, to, v) ? v : MAX_SAFE_LEG_COST;
     }
+    // time windows / service durations / travel times (problem_data.rs:20-23); empty = the model carries none
+    std::vector<int64_t> tw_lo, tw_hi, service;  // per node
+    std::vector<int64_t> travel;                  // dim x dim row-major
+    int64_t departure = 0;
+    bool travel_time(size_t from, size_t to, int64_t& out) const {  // problem_data.rs:38-41
+        if (from >= dim || to >= dim || travel.size() != dim * dim) return false;
+        const int64_t v = travel[from * dim + to];
+        if (v >= 0 && v != UNREACHABLE) {
+            out = v;
+            return true;
+        }
+        return false;
+    }
+    // route_is_capacity_feasible / route_is_time_feasible (solverforge-cvrp/src/helpers.rs:168-218): checked i64 accumulation, waiting at a
+    // window's start, service before the window's end, a traversable leg back to the depot whose arrival time does not overflow
+    bool capacity_feasible(const std::vector<size_t>& route) const {
+        int64_t total = 0;
+        for (size_t v : route)
+            if (v >= dim || __builtin_add_overflow(total, (int64_t)demands[v], &total)) return false;
+        return total <= capacity;
+    }
+    bool time_feasible(const std::vector<size_t>& route) const {
+        int64_t t = departure, leg;
+        size_t prev = depot;
+        for (size_t v : route) {
+            if (v >= tw_lo.size() || v >= service.size()) return false;  // (route_is_structurally_valid :147-152)
+            if (!travel_time(prev, v, leg) || __builtin_add_overflow(t, leg, &t)) return false;
+            if (t < tw_lo[v]) t = tw_lo[v];
+            if (service[v] < 0 || __builtin_add_overflow(t, service[v], &t)) return false;
+            if (t > tw_hi[v]) return false;
+            prev = v;
+        }
+        int64_t back;
+        return travel_time(prev, depot, leg) && !__builtin_add_overflow(t, leg, &back);
+    }
 };
 
 struct GraphFacts {
