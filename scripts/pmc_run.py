@@ -48,6 +48,19 @@ for i, grp in enumerate(PASSES):
         if vals:
             out[c] = {"launches": len(vals), "mean": sum(vals) / len(vals)}
 shutil.rmtree(base, ignore_errors=True)
+# the kernel's registers / spills / scratch from the code object's own notes (rocprofv3's VGPR_Count is an allocation figure, not the descriptor's)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+try:
+    import elf_resources
+    elf = [k for k in elf_resources.kernels() if k["kernel"] == info.get("kernel")]
+    info["elf"] = elf[0] if elf else None
+    if elf:
+        info["elf"].pop("kernel", None)
+except Exception as e:  # the profile is still worth having without it
+    info["elf"] = {"error": repr(e)}
+import hashlib
+info["library_sha16"] = hashlib.sha256(open(elf_resources.DEFAULT, "rb").read()).hexdigest()[:16]  # the library the counters were read from
+info["commit"] = os.environ.get("SF_COMMIT")  # set by the gpurun wrapper (`SF_COMMIT=$(git rev-parse --short HEAD)`): .git does not travel
 res = {"command": cmd, "kernel": info, "counters_per_launch": out, "failed_passes": failed}
 if "SQ_WAVE_CYCLES" in out:
     wc = out["SQ_WAVE_CYCLES"]["mean"]
