@@ -521,6 +521,19 @@ int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, con
 int32_t sf_step_decide_gated(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
                              int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
                              int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected);
+/* The same step over the pull order of a cursor that has done its own activation -- the reference's RuntimeProviderCursor
+ * (runtime/provider_cursor.rs:37-492; its leaf, runtime/compiler/executor/local_search/leaf.rs:362-402), which serves BOTH the
+ * grouped-scalar leaf and the compound conflict-repair leaf of the default scalar policy (default_local_search/policy/scalar.rs:107-190):
+ * the cursor has rotated (apply_selection_order with the binding's salts), normalised, deduplicated per provider scope, capped
+ * (max_matches_per_step / max_repairs_per_match / max_moves_per_step) and pushed doable moves only (provider_cursor.rs:420-437); the
+ * library restates none of that.  Candidate i is pull i: scored, gated (gates[i] as above; a conflict-repair leaf sets bit 0 when its
+ * config says require_hard_improvement), shown to the acceptor and the forager, the pick committed and the step ended exactly like
+ * sf_step_decide_gated.  A candidate that is not doable on the working solution is pulled and counted (moves_generated, moves_evaluated,
+ * moves_not_doable; flags 0) like evaluate_candidate does (phase/localsearch/evaluation.rs:33-49).  Candidates without edits, with two
+ * edits on one entity or with a value outside the entity's range are SF_ERR_INVALID (the cursor's normalisation removes them).
+ * out_scores[n * score_levels], out_flags[n]; *out_selected = index of the committed candidate, -1 when the step applied nothing. */
+int32_t sf_step_decide_cursor(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
+                              int64_t* out_scores, int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected);
 /* committed do_move of one multi-edit candidate */
 int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits);
 

@@ -1,4 +1,4 @@
-"""Host-side mirror of the reference's stock CVRP domain crate (crates/solverforge-cvrp/src): `ProblemData` with time windows, service
+"""ORACLE (test infrastructure; the product package never imports this file).  A cited CPU restatement of the reference's stock CVRP domain crate (crates/solverforge-cvrp/src): `ProblemData` with time windows, service
 durations and travel times as DATA (problem_data.rs:1-48), the route-local helpers and hook bundles a `#[planning_list_variable(domain =
 "cvrp")]` model gets (helpers.rs:1-218) and the two matrix distance meters (meters.rs:1-51).
 

@@ -1,4 +1,4 @@
-"""Host-side mirror of the reference's compound-provider cursor: the one lazy cursor that schedules grouped-scalar and conflict-repair
+"""ORACLE (test infrastructure; the product package never imports this file).  A cited CPU restatement of the reference's compound-provider cursor: the one lazy cursor that schedules grouped-scalar and conflict-repair
 providers (crates/solverforge-solver/src/runtime/provider_cursor.rs:1-492), with the normalisation kernel it calls
 (builder/context/provider/resolver.rs:90-345), the per-run reason arena (builder/context/provider/types.rs:82-130), the doability rule of the
 move it emits (heuristic/move/runtime_compound.rs:121-137) and the step-seeded selection order it rotates with
@@ -7,8 +7,9 @@ move it emits (heuristic/move/runtime_compound.rs:121-137) and the step-seeded s
 Nothing here touches a score.  The cursor decides WHICH provider is pulled WHEN, with which limits, how its output is rotated, capped,
 resolved to slots, validated and deduplicated; what comes out is a list of compound scalar candidates, which the device prices in one
 launch through `ScoreDirector.step_decide(..., gates=...)` (sf_step_decide_gated; `require_hard_improvement` is gate bit 0).  In a drop-in
-the Rust cursor keeps this job; this module is the same logic for a Python host, with the same names, argument meaning
-and error behaviour, so that `tests/test_provider_cursor.py` reads like `runtime/provider_cursor_tests.rs`.
+the Rust cursor keeps this job; this restatement exists so that the GPU parity tests can drive `sf_step_decide_gated` with
+exactly the candidate stream the reference's cursor would hand it (tests/test_gpu_provider_step.py) and is itself pinned to
+`runtime/provider_cursor_tests.rs` by `tests/test_provider_cursor.py`.
 """
 from __future__ import annotations
 

@@ -444,6 +444,13 @@ class Model:
                                          C.byref(consumed), C.byref(selected))
         return kept[:k], scores[:consumed.value], flags[:consumed.value], int(selected.value)
 
+    def step_cursor(self, candidates, gates=None):
+        """One local-search step over a cursor's own pull order (RuntimeProviderCursor: nothing re-ordered, filtered or capped):
+        (scores [consumed, 4], flags [consumed], committed index or -1)."""
+        g = np.zeros(len(candidates), dtype=np.int32) if gates is None else gates
+        _, sc, fl, sel = self.step_grouped(candidates, group_name_len=-1, gates=g)
+        return sc, fl, sel
+
     def apply_compound(self, candidate):
         edits, _ = compound_wire([candidate])
         lib().sfo_model_apply_compound(self.h, _p(edits), len(candidate))

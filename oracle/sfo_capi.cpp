@@ -516,8 +516,10 @@ int64_t sfo_model_step_grouped_gated(void* h, const sfo_move_t* edits, const int
     Model* m = (Model*)h;
     std::vector<std::vector<ScalarEditO>> provided;
     for (int64_t i = 0; i < n; ++i) provided.push_back(edits_of(*m, edits, offsets[i], offsets[i + 1]));
-    GroupedStepTrace t = grouped_scalar_step(m->search, provided, (size_t)group_name_len, max_moves_per_step > 0 ? (size_t)max_moves_per_step : 256,
-                                             gates ? std::vector<int32_t>(gates, gates + n) : std::vector<int32_t>());
+    // group_name_len < 0: the candidates are a cursor's own pull order (RuntimeProviderCursor): no activation
+    GroupedStepTrace t = grouped_scalar_step(m->search, provided, (size_t)(group_name_len < 0 ? 0 : group_name_len),
+                                             max_moves_per_step > 0 ? (size_t)max_moves_per_step : 256,
+                                             gates ? std::vector<int32_t>(gates, gates + n) : std::vector<int32_t>(), group_name_len < 0);
     for (size_t i = 0; i < t.kept.size(); ++i) out_kept[i] = (int64_t)t.kept[i];
     for (size_t i = 0; i < t.scores.size(); ++i) {
         std::memcpy(&out_scores4[4 * i], t.scores[i].v, 4 * sizeof(int64_t));

@@ -491,7 +491,7 @@ inline int hard_score_delta(const Score& previous, const Score& candidate, int h
 }
 // gates[i] of provided candidate i: bit 0 Move::requires_hard_improvement, bit 1 Move::requires_score_improvement (evaluation.rs:75-113)
 inline GroupedStepTrace grouped_scalar_step(LocalSearch& ls, const std::vector<std::vector<ScalarEditO>>& provided, size_t group_name_len,
-                                            size_t max_moves_per_step, const std::vector<int32_t>& gates = {}) {
+                                            size_t max_moves_per_step, const std::vector<int32_t>& gates = {}, bool cursor_order = false) {
     GroupedStepTrace out;
     ScoreDirector& d = *ls.director;
     uint64_t step_index = ls.phase_step_index;
@@ -515,6 +515,13 @@ inline GroupedStepTrace grouped_scalar_step(LocalSearch& ls, const std::vector<s
                 return false;
         return true;
     };
+    // cursor_order: `provided` IS the pull order of a cursor that did its own activation (RuntimeProviderCursor::next_candidate,
+    // runtime/provider_cursor.rs:447-466, behind the leaf of runtime/compiler/executor/local_search/leaf.rs:362-402): the step loop of
+    // phase/candidates.rs pulls it as it stands
+    if (cursor_order) {
+        for (size_t i = 0; i < provided.size(); ++i) out.kept.push_back(i);
+        order.clear();
+    }
     for (size_t idx : order) {
         if (out.kept.size() >= max_moves_per_step) break;
         const auto& cand = provided[idx];

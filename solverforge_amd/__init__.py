@@ -17,5 +17,3 @@ from .director import (
 )
 from .models import build_assignment, build_balance, build_cvrp, build_graph_coloring, build_jobshop, build_nqueens, build_precedence_shop, build_shift_schedule  # noqa: F401
 from ._lib import MOVE_DTYPE, SolverForgeError  # noqa: F401
-from . import provider_cursor  # noqa: F401,E402  (host-side mirror of runtime/provider_cursor.rs; no device needed)
-from . import cvrp_data  # noqa: F401,E402  (host-side mirror of the stock CVRP crate: time windows / service durations as data)

@@ -71,7 +71,7 @@ SYMBOLS = [
     "sf_ctx_create", "sf_ctx_destroy", "sf_last_error", "sf_device_count", "sf_sync",
     "sf_schema_add_entity_class", "sf_schema_add_scalar_variable", "sf_schema_add_list_variable",
     "sf_fact_matrix_i64", "sf_fact_column_i32", "sf_fact_column_u32", "sf_fact_csr_u32",
-    "sf_constraint_add", "sf_constraint_add_list_precedence", "sf_selector_add", "sf_selector_add_sublist", "sf_selector_add_kopt", "sf_selector_add_permute", "sf_selector_add_precedence", "sf_list_set_precedence_policy", "sf_selector_add_ruin", "sf_selector_add_nearby_scalar", "sf_step_evaluate_compound", "sf_step_decide", "sf_step_decide_gated", "sf_apply_compound", "sf_construct_list_cheapest", "sf_construct_list_regret", "sf_construct_list_clarke_wright", "sf_construct_list_round_robin", "sf_construct_list_k_opt", "sf_union_configure", "sf_schema_set_value_lists", "sf_initialize", "sf_evaluate_all", "sf_evaluate_each", "sf_get_scores",
+    "sf_constraint_add", "sf_constraint_add_list_precedence", "sf_selector_add", "sf_selector_add_sublist", "sf_selector_add_kopt", "sf_selector_add_permute", "sf_selector_add_precedence", "sf_list_set_precedence_policy", "sf_selector_add_ruin", "sf_selector_add_nearby_scalar", "sf_step_evaluate_compound", "sf_step_decide", "sf_step_decide_gated", "sf_step_decide_cursor", "sf_apply_compound", "sf_construct_list_cheapest", "sf_construct_list_regret", "sf_construct_list_clarke_wright", "sf_construct_list_round_robin", "sf_construct_list_k_opt", "sf_union_configure", "sf_schema_set_value_lists", "sf_initialize", "sf_evaluate_all", "sf_evaluate_each", "sf_get_scores",
     "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_default_local_search_components", "sf_solver_configure_default", "sf_solver_configure_annealing", "sf_solver_configure_diversified",
     "sf_get_annealing_state", "sf_solver_set_step_seeds",
     "sf_solver_set_engine", "sf_solver_get_engine", "sf_list_wave_layout", "sf_constraint_add_pair_join", "sf_provider_declare", "sf_phase_start", "sf_solve_steps", "sf_solve_moves", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
@@ -128,6 +128,7 @@ def load():
     L.sf_apply_compound.argtypes = [vp, i32, vp, i64]
     L.sf_step_decide.argtypes = [vp, i32, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp]
     L.sf_step_decide_gated.argtypes = [vp, i32, vp, vp, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp]
+    L.sf_step_decide_cursor.argtypes = [vp, i32, vp, vp, vp, i64, vp, vp, vp, vp]
     L.sf_schema_set_value_lists.argtypes = [vp, i32, i32, vp, vp]
     L.sf_union_configure.argtypes = [vp, i32, vp, i32]
     L.sf_construct_list_cheapest.argtypes = [vp, i32, vp, i32, vp]

@@ -1622,10 +1622,28 @@ int32_t sf_step_decide(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, con
     return sf_step_decide_gated(ctx, replica, edits, offsets, nullptr, n, group_name_len, max_moves_per_step, out_kept, out_n_kept, out_scores, out_flags,
                                 out_consumed, out_selected);
 }
+static int32_t step_decide_impl(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
+                                int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
+                                int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected, bool cursor_order);
 // the same step with Move::requires_hard_improvement / requires_score_improvement per candidate (gates[i]: bit 0 / bit 1)
 int32_t sf_step_decide_gated(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
                              int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
                              int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected) {
+    return step_decide_impl(ctx, replica, edits, offsets, gates, n, group_name_len, max_moves_per_step, out_kept, out_n_kept, out_scores, out_flags, out_consumed,
+                            out_selected, false);
+}
+// the step over a cursor's own pull order (RuntimeProviderCursor, runtime/provider_cursor.rs:447-466): no activation is restated here --
+// the cursor has rotated, normalised, deduplicated per provider scope and capped its store, and pushed doable moves only
+// (provider_cursor.rs:420-437) -- so candidate i is pull i; see the header
+int32_t sf_step_decide_cursor(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
+                              int64_t* out_scores, int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected) {
+    std::vector<int64_t> kept((size_t)(n > 0 ? n : 1));
+    int64_t nk = 0;
+    return step_decide_impl(ctx, replica, edits, offsets, gates, n, 0, 0, kept.data(), &nk, out_scores, out_flags, out_consumed, out_selected, true);
+}
+static int32_t step_decide_impl(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, const int32_t* gates, int64_t n,
+                                int32_t group_name_len, int64_t max_moves_per_step, int64_t* out_kept, int64_t* out_n_kept, int64_t* out_scores,
+                                int32_t* out_flags, int64_t* out_consumed, int64_t* out_selected, bool cursor_order) {
     DeviceGuard _dev(ctx);
     if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_decide_gated: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized || replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_kept || !out_n_kept || !out_scores || !out_flags ||
@@ -1672,7 +1690,19 @@ int32_t sf_step_decide_gated(sf_ctx* ctx, int32_t replica, const sf_move_t* edit
             if (c.value_list[q] == to) return true;
         return false;
     };
-    for (int64_t o = 0; o < n && (int64_t)kept.size() < cap; ++o) {
+    for (int64_t o = 0; cursor_order && o < n; ++o) {  // a cursor's store: pull order, nothing skipped; malformed records are the caller's error
+        const int64_t b = offsets[o], e = offsets[o + 1];
+        if (e == b) return fail(ctx, SF_ERR_INVALID, "sf_step_decide_cursor: a candidate without edits (the cursor normalises its store)");
+        if (e - b > SF_COMPOUND_MAX) return fail(ctx, SF_ERR_UNSUPPORTED, "at most 8 edits per compound candidate on the device");
+        for (int64_t k = b; k < e; ++k) {
+            if (edits[k].kind != SF_MOVE_CHANGE) return fail(ctx, SF_ERR_INVALID, "a ScalarEdit is a SF_MOVE_CHANGE-shaped record");
+            for (int64_t j = b; j < k; ++j)
+                if (edits[j].a == edits[k].a) return fail(ctx, SF_ERR_INVALID, "sf_step_decide_cursor: two edits on one entity (the cursor normalises its store)");
+            if (!legal(edits[k].a, edits[k].value)) return fail(ctx, SF_ERR_INVALID, "sf_step_decide_cursor: an edit outside the entity's value range");
+        }
+        kept.push_back(o);
+    }
+    for (int64_t o = 0; !cursor_order && o < n && (int64_t)kept.size() < cap; ++o) {
         const int64_t idx = (int64_t)sctx.selection_index((uint32_t)o, (uint32_t)n, 0xC0A1E5CEAAA00001ULL ^ (uint64_t)group_name_len);  // apply_selection_order
         const int64_t b = offsets[idx], e = offsets[idx + 1];
         if (e == b) continue;

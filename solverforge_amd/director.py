@@ -350,6 +350,21 @@ class GpuScoreDirector:
                                      ptr(scores), ptr(flags), C.byref(consumed), C.byref(selected)), self._h)
         return kept[:nk.value], scores[:consumed.value], flags[:consumed.value], int(selected.value)
 
+    def step_decide_cursor(self, candidates, gates=None, replica=0):
+        """One host-driven local-search step over a cursor's own pull order (the reference's RuntimeProviderCursor behind the grouped-scalar
+        and conflict-repair leaves; sf_step_decide_cursor): nothing is re-ordered, filtered or capped here.  Returns (trial scores
+        [consumed, levels], flags [consumed], committed index or -1)."""
+        edits, offsets = self._compound_wire(candidates)
+        n = len(candidates)
+        g = None if gates is None else np.ascontiguousarray(gates, dtype=np.int32)
+        assert g is None or len(g) == n
+        scores = np.zeros((max(n, 1), self.levels), dtype=np.int64)
+        flags = np.zeros(max(n, 1), dtype=np.int32)
+        consumed, selected = C.c_int64(0), C.c_int64(-1)
+        check(self._L.sf_step_decide_cursor(self._h, replica, ptr(edits), ptr(offsets), None if g is None else ptr(g), n, ptr(scores), ptr(flags),
+                                            C.byref(consumed), C.byref(selected)), self._h)
+        return scores[:consumed.value], flags[:consumed.value], int(selected.value)
+
     def apply_candidate(self, candidate, replica=0):
         """Committed do_move of one multi-edit ScalarCandidate."""
         edits, _ = self._compound_wire([candidate])

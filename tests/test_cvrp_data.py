@@ -1,12 +1,12 @@
-"""solverforge_amd/cvrp_data.py against the stock CVRP crate's own tests (crates/solverforge-cvrp/src/tests.rs:111-410), one to one: same
+"""oracle/cvrp_data.py (an oracle-side restatement) against the stock CVRP crate's own tests (crates/solverforge-cvrp/src/tests.rs:111-410), one to one: same
 fixture (tests.rs:30-52), same names, same assertions.  CPU only."""
 import copy
 import math
 
 import pytest
 
-from solverforge_amd import cvrp_data as cv
-from solverforge_amd.cvrp_data import UNREACHABLE
+from oracle import cvrp_data as cv
+from oracle.cvrp_data import UNREACHABLE
 
 
 def base_problem_data():  # tests.rs:30-52

@@ -2,11 +2,11 @@
 (capacity + time windows; feasible_mode 2) and is pinned here to the reference's end-to-end test for it,
 crates/solverforge/tests/list_cvrp_k_opt_time_window.rs:9-41 (fixture: list_cvrp_k_opt_time_window/domain/plan.rs:46-88): the 2-opt reversal that
 would shorten [1, 3, 2, 4] to [1, 2, 3, 4] reaches customer 3 after its window closes, so the route must stay as it is.  The oracle's predicate and
-the host-side `solverforge_amd.cvrp_data.route_feasible` (pinned to the crate's own tests in tests/test_cvrp_data.py) are cross-checked on seeded
+the oracle-side `oracle.cvrp_data.route_feasible` (pinned to the crate's own tests in tests/test_cvrp_data.py) are cross-checked on seeded
 routes.  The device's `sf_construct_list_k_opt` implements modes 0 and 1; mode 2 is the next step there."""
 import numpy as np
 
-from solverforge_amd import cvrp_data as cv
+from oracle import cvrp_data as cv
 
 
 def _reference_plan():  # plan.rs:46-88

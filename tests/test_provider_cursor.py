@@ -1,11 +1,11 @@
-"""Host-side provider cursor (solverforge_amd/provider_cursor.py) against the reference's own tests for it
+"""Oracle-side provider cursor (oracle/provider_cursor.py) against the reference's own tests for it
 (crates/solverforge-solver/src/runtime/provider_cursor_tests.rs:220-455: the five scenarios below keep their names, fixtures and
 assertions) plus the scheduling rules the file's comments state (provider_cursor.rs:107-400).  The step-seeded selection order is pinned to
 the C++ oracle's MoveStreamContext (oracle/sfo_core.hpp, itself pinned to iter.rs).  CPU only: the cursor touches no score."""
 import numpy as np
 import pytest
 
-from solverforge_amd import provider_cursor as pc
+from oracle import provider_cursor as pc
 
 
 # ---- the fixture of provider_cursor_tests.rs:25-135: one entity, one scalar variable "worker" with values 0..2 -------------------------
