@@ -97,6 +97,8 @@ M2_POLICIES = {
 M2_REPLICAS = {"default": 6144, "default6": 12288, "nearby2": 6144}  # replicas per GPU of the M2 leg (round 4: the RUIN instantiation holds 8 per CU;
 # the six-leaf FAST instantiation 12 per CU and gains from several residencies per launch, profiles/r04g_generic_replicas.jsonl)
 # M2 extension leg (module docstring): what is varied against the parity leg, and nothing else
+M1_REPLICAS = 24576  # the timed M1 leg: four residencies of 24 replicas per CU
+C5_REPLICAS = 2816  # the CVRP-5000 side leg: 11 replicas per CU (launch mode 6)
 TUNED = {"leaves": ("nearby_change", "nearby_swap"), "late_acceptance_size": 5000, "accepted_count_limit": 1, "replicas": 1024,
          "migration_period_s": 5.0, "migration_replace_fraction": 0.5, "migration_elite": 8, "launch_move_budget": 200_000}
 LEAF_BITS = {"nearby_change": 16, "nearby_swap": 32, "list_reverse": 64, "sublist_change": 128, "sublist_swap": 256, "kopt": 512, "ruin": 1024}
@@ -271,8 +273,8 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s, passes=None, atte
                     if kernel_substr not in row["Kernel_Name"]:
                         continue
                     per.setdefault(row["Counter_Name"], []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
-                    info = {"vgpr": int(row.get("VGPR_Count", 0) or 0), "sgpr": int(row.get("SGPR_Count", 0) or 0),
-                            "scratch": int(row.get("Scratch_Size", 0) or 0), "kernel": row["Kernel_Name"]}
+                    info = {"kernel": row["Kernel_Name"], "rocprofv3_allocation": {"vgpr": int(row.get("VGPR_Count", 0) or 0), "sgpr": int(row.get("SGPR_Count", 0) or 0),
+                                                                                   "scratch": int(row.get("Scratch_Size", 0) or 0)}}
             if not per:
                 failed.append(f"{'+'.join(grp)}: no rows for {kernel_substr}")
             try:
@@ -288,6 +290,8 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s, passes=None, atte
                 out[c] = sum(vals) / len(vals)
     finally:
         shutil.rmtree(base, ignore_errors=True)
+    if info.get("kernel"):
+        info.update(elf_kernel_resources(info["kernel"]))
     if failed:
         info = dict(info, failed_passes=failed)
     if need not in out:
@@ -295,12 +299,40 @@ def pmc_collect(argv, warmup, steps, kernel_substr, timeout_s, passes=None, atte
     return out, info
 
 
+def seconds_to_reach(curve, target):
+    """First time of `curve` [(seconds, score tuple)] at which the score is >= target (lexicographic), or None."""
+    if not curve or not target:
+        return None
+    tgt = tuple(int(v) for v in target)
+    for t, b in curve:
+        if tuple(b) >= tgt:
+            return round(t, 3)
+    return None
+
+
+def elf_kernel_resources(kernel_name):
+    """Registers / spills / scratch of one kernel from the shipped library's gfx950 code objects (the kernel descriptor notes, scripts/elf_resources.py):
+    what the hardware allocates from.  rocprofv3's VGPR_Count / SGPR_Count columns are allocation figures of the dispatch, not the descriptor's counts."""
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "scripts"))
+        import elf_resources
+
+        hit = [k for k in elf_resources.kernels() if k["kernel"] == kernel_name]
+        if not hit:
+            return {"source": "code-object notes: kernel not found"}
+        k = hit[0]
+        return {"vgpr": k.get("vgpr"), "agpr": k.get("agpr"), "sgpr": k.get("sgpr"), "scratch": k.get("scratch"), "sgpr_spills": k.get("sgpr_spills"),
+                "vgpr_spills": k.get("vgpr_spills"), "lds_static": k.get("lds_static"), "source": "code-object notes of libsolverforge_amd.so (llvm-readelf --notes)"}
+    except Exception as e:  # the line is still worth having
+        return {"source": f"code-object notes unavailable: {e!r}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=24576,
+    ap.add_argument("--replicas", type=int, default=M1_REPLICAS,
                     help="independent searches per GPU and launch (24576 = 4 x 24 per CU: the COMPACT wave kernel runs 6 waves per SIMD at CVRP-1000, "
                          "and a launch of several residencies keeps every CU busy while the slower replicas of the first finish -- one residency "
                          "alone leaves a quarter of the slot time idle, profiles/r04c_wave_replica_sweep.txt)")
@@ -458,9 +490,13 @@ def main():
             construct_s = time.perf_counter() - t1
         d2.phase_start()
         n_launch = 0
+        curve = []  # (seconds since the leg started, best score over this rank's replicas) at every improvement: `seconds_to_cpu_best` reads it
         while time.perf_counter() - t1 < args.solve_seconds:
             d2.solve_moves(1 << 20, args.solve_budget, sync=True)  # work-balanced launches (sf_solve_moves)
             n_launch += 1
+            bnow = max(tuple(int(v) for v in s) for s in d2.best_scores())  # (a 200 KB copy per ~40 ms launch)
+            if not curve or bnow > curve[-1][1]:
+                curve.append((time.perf_counter() - t1, bnow))
         gpu_s = time.perf_counter() - t1
         st2 = d2.total_stats()
         solve = {
@@ -468,7 +504,7 @@ def main():
             "best_score_local": list(max(tuple(int(v) for v in s) for s in d2.best_scores())),
             "moves_per_s": st2["moves_evaluated"] / gpu_s,
             "start": args.solve_start, "start_score": m2_start, "construction_seconds": construct_s,
-            "leaves": list(m2_leaves), "replicas": M2_REPLICAS[args.solve_policy] or args.replicas,
+            "leaves": list(m2_leaves), "replicas": M2_REPLICAS[args.solve_policy] or args.replicas, "curve": curve,
         }
         if cpu_thread:
             cpu_thread.join(timeout=args.solve_seconds + 30)
@@ -527,8 +563,8 @@ def main():
     if args.c5_seconds > 0 and args.solve_seconds > 0 and args.customers != 5000 and not args.pmc_child:
         try:
             prob5 = datasets.make_cvrp(5000, 500, 55, seed=args.seed)
-            d5 = sfa.build_cvrp(prob5, n_replicas=2816, device_id=local_rank, leaves=("nearby_change", "nearby_swap"))
-            d5.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, 2816)))
+            d5 = sfa.build_cvrp(prob5, n_replicas=C5_REPLICAS, device_id=local_rank, leaves=("nearby_change", "nearby_swap"))
+            d5.configure(sfa.SolverConfig(random_seed=portfolio.rank_seed_base(args.seed, rank, C5_REPLICAS)))
             d5.calculate_score()
             d5.phase_start()
             d5.solve_steps(100)  # warm-up launch
@@ -634,13 +670,14 @@ def main():
         child_argv = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--replicas", str(min(args.replicas, PMC_CHILD_MAX_REPLICAS)),
                       "--ls-steps", str(args.ls_steps), "--customers", str(args.customers), "--vehicles", str(args.vehicles),
                       "--capacity", str(args.capacity), "--seed", str(args.seed), "--engine", args.engine]
-        # the CPU baseline leg (one host core, ~20 s) runs beside the counter passes (GPU + their own host processes): same clock, fewer minutes
+        # the CPU baseline leg (one host core, ~20 s) runs on a QUIET host, before the counter passes start their own processes (round 5 ran it
+        # beside them: contention could only lower the baseline and inflate gpu_over_cpu); an exception becomes a field of the line, not its loss
         cb_box = {}
-        cb_thread = None
         if not args.no_cpu_baseline:
-            cb_thread = threading.Thread(target=lambda: cb_box.update(result=cpu_baseline(problem, args.seed, args.warmup * args.ls_steps,
-                                                                                       args.steps * args.ls_steps, args.cpu_seconds)), daemon=True)
-            cb_thread.start()
+            try:
+                cb_box["result"] = cpu_baseline(problem, args.seed, args.warmup * args.ls_steps, args.steps * args.ls_steps, args.cpu_seconds)
+            except Exception as e:
+                cb_box["result"] = {"error": repr(e)}
         if world == 1 and not args.no_pmc:
             pmc, pmc_info = pmc_collect(child_argv, args.warmup, args.steps, kernel + "<", timeout_s=40, attempts=3)
             if pmc is not None and args.replicas > PMC_CHILD_MAX_REPLICAS:
@@ -794,6 +831,9 @@ def main():
                 "start_score": solve["start_score"],
                 "gpu_construction_seconds": solve["construction_seconds"],
                 "cpu_oracle": solve.get("cpu_oracle"),
+                # how long this rank's portfolio needed to reach what the CPU oracle holds after the whole leg (null: never reached / no CPU leg)
+                "seconds_to_cpu_best": seconds_to_reach(solve.get("curve"), (solve.get("cpu_oracle") or {}).get("best_score")),
+                "gpu_best_curve_rank0": [[round(t, 2), list(b)] for t, b in (solve.get("curve") or [])][:40],
                 "start_note": {"savings_capacity": "extension: Clarke-Wright + ListKOpt with a capacity-checking feasible hook (the reference's "
                                                    "stock savings_hooks::feasible is structural only)",
                                "savings": "the reference's stock CVRP construction wiring (structural feasibility)",
@@ -817,12 +857,12 @@ def main():
         if side:
             out["extra"]["side_configs"] = side
         if not args.no_cpu_baseline:
-            cb_thread.join()
             cb = cb_box["result"]
-            ws = cb.pop("working_score")
             out["cpu_baseline"] = cb
-            out["extra"]["gpu_over_cpu"] = out["value"] / cb["value"]
-            out["extra"]["replica0_matches_cpu_oracle"] = None if ws is None else bool(ws == replica0_score)
+            if "error" not in cb:
+                ws = cb.pop("working_score")
+                out["extra"]["gpu_over_cpu"] = out["value"] / cb["value"]
+                out["extra"]["replica0_matches_cpu_oracle"] = None if ws is None else bool(ws == replica0_score)
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

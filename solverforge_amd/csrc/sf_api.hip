@@ -1166,7 +1166,7 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
         static const bool no_compact = std::getenv("SF_AMD_NO_COMPACT") != nullptr;  // diagnostics: A/B
         int wpb_c = 1;
         size_t lds_c = 0;
-        static const int max_wpe = std::getenv("SF_AMD_WAVE_WPE") ? std::atoi(std::getenv("SF_AMD_WAVE_WPE")) : 6;  // diagnostics: cap the waves per SIMD (8 = launch mode 7: 32 replicas per CU at CVRP-1000, measured 44.5 vs 45.2 G -- the scalar pipe is the bound, more waves do not help)
+        static const int max_wpe = std::getenv("SF_AMD_WAVE_WPE") ? std::atoi(std::getenv("SF_AMD_WAVE_WPE")) : 6;  // diagnostics: cap the waves per SIMD (4 / 5 / 6)
         const size_t r6 = (no_compact || max_wpe < 6) ? 0 : plan(true, 24, wpb_c, lds_c);
         const size_t r5 = (no_compact || max_wpe < 5 || r6 > 20) ? 0 : plan(true, 20, wpb_c, lds_c);
         if (r6 > 20 && r6 > resident_wide) {  // 24 replicas per CU: the instantiation compiled for 6 waves per SIMD (80 VGPRs)
@@ -1191,25 +1191,9 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
             size_t lds_g = 0, lds_3 = 0;
             const size_t r3 = plan(true, 4 * SF_WAVES_PER_EU, wpb_3, lds_3);
             const size_t rg = plan(true, 4 * SF_WAVES_PER_EU, wpb_g, lds_g, true);
-            // small models: 32 replicas per CU with the 64-register build when the slice without the table allows it (CVRP-1000: 4.6 KB)
-            int wpb_8 = 1;
-            size_t lds_8 = 0;
-            const size_t r8 = (ngv == 0 || max_wpe < 8) ? 0 : plan(true, 32, wpb_8, lds_8, true);
-            if (mode == 5 && r8 > 24) {
-                if (!ctx->lm.node_tab) {
-                    uint16_t* nt = nullptr;
-                    int rc = dalloc(ctx, &nt, (size_t)ctx->R * ctx->lm.dim);
-                    if (rc) return rc;
-                    ctx->lm.node_tab = nt;
-                    uint32_t* rg = nullptr;
-                    rc = dalloc(ctx, &rg, (size_t)ctx->R * MAX_LEAVES * ctx->lm.V);
-                    if (rc) return rc;
-                    ctx->lm.rtab_g = rg;
-                }
-                mode = 7;
-                wpb = wpb_8;
-                lds = lds_8;
-            } else if (ngv != 0 && (ngv == 1 || (mode == 3 && rg > r3))) {
+            // (round 5 also carried a 64-register / 32-replicas-per-CU instantiation, launch mode 7: parity-green and 1.5 % SLOWER at CVRP-1000 --
+            // the scalar pipe is the bound, more waves do not help -- removed in round 6 with its untested code path)
+            if (ngv != 0 && (ngv == 1 || (mode == 3 && rg > r3))) {
                 if (!ctx->lm.node_tab) {
                     uint16_t* nt = nullptr;
                     int rc = dalloc(ctx, &nt, (size_t)ctx->R * ctx->lm.dim);
@@ -2523,6 +2507,7 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
             wpb = w;
         }
     }
+    if (best_resident == 0) return fail(ctx, SF_ERR_UNSUPPORTED, "generic engine: one replica's LDS slice (with the precedence scratch / static copy) exceeds a CU's 160 KiB");
     static const bool dbg_launch = std::getenv("SF_AMD_DEBUG_LAUNCH") != nullptr;  // diagnostics: the launch shape, once per change
     if (dbg_launch) {
         static size_t last = 0;
@@ -2733,6 +2718,15 @@ static int launch_mixed(sf_ctx* ctx, SearchParams& p, int grid, bool trace) {
             const size_t sb = prec_static_slim_bytes(gl.prec.n, gl.prec.owner != nullptr);
             const char* se = std::getenv("SF_AMD_PREC_STATIC_SLIM");
             if (!gl.prec_static && sb <= 40 * 1024 && !(se && std::atoi(se) == 0)) gl.prec_static = (int32_t)sb, gl.prec_static_slim = 1;
+            // the shared copy sits beside the replicas' slices in the workgroup's LDS: when one slice with the Kahn scratch in it leaves no room for
+            // the copy (about 3,100 - 3,400 nodes without owners plus a large list slice), the copy stays in HBM instead of an over-size launch
+            if (gl.prec_static) {
+                const int ns2 = ctx->has_scalar_model ? ctx->sm.n : 0;
+                const bool tables2 = ctx->has_scalar_model && ctx->sm.tables();
+                const GCarve<int16_t> cv2(ns2, ctx->lm.V, ctx->lm.n_cap, gl.has_nearby ? ctx->lm.dim : 0, gl.kopt_nearby, gl.n, gl.has_ruin ? (ctx->lm.leg16 ? 2 : 1) : 0,
+                                          ctx->lm.dim, gl.prec.n, tables2 ? ctx->sm.n_values : 0, tables2 && ctx->sm.run_level >= 0 ? ctx->sm.run_P : 0, 0, false);
+                if (cv2.total + 1024 + (size_t)gl.prec_static > SF_LDS_BUDGET) gl.prec_static = 0, gl.prec_static_slim = 0;
+            }
         }
         // grouped trial evaluator (sf_prec_group.h): T trials per wavefront with private LDS scratch.  SF_AMD_PREC_GROUPS = 0 / 2 / 4 / 8 / 16
         gl.prec_groups = 0;

@@ -66,9 +66,9 @@ SF_HD uint64_t step_seed(uint64_t random_seed, uint64_t draw) { return splitmix6
 
 // x % n.  For n < 2^16 (entity counts, list lengths, leaf counts) three 32-bit remainders (high word, then the two
 // 16-bit limbs of the low word) replace the 64-bit software division the GPU would otherwise expand to.
-// SF_OUTLINE_MOD (the generic engine's units): one out-of-line copy.  Inlined, the three software remainders are ~100 instructions at each
-// of ~90 call sites of that kernel -- 12.7 K of its 65 K instructions, and a kernel of 340 KB runs out of the 64 KB instruction cache
-// two CUs share; a call costs a dozen.
+// SF_OUTLINE_MOD: an EXPERIMENT that was not adopted (no unit of csrc/Makefile defines it).  Inlined, the three software remainders are ~100
+// instructions at each of ~90 call sites of the generic engine -- 12.7 K of its 65 K instructions -- and one out-of-line copy (a call costs a
+// dozen) moved the step time by < 3 %: code size is not that kernel's bound.  The macro stays for diagnostic builds (EXTRA=-DSF_OUTLINE_MOD).
 #if defined(SF_OUTLINE_MOD) && defined(__HIPCC__)
 #define SF_MOD_ATTR __host__ __device__ inline __attribute__((noinline))
 #else

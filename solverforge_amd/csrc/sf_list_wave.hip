@@ -482,6 +482,12 @@ __device__ __forceinline__ uint32_t nearby_source_to_ring(const ListModel& m, co
 #ifdef SF_PHASE_PROFILE
 __device__ unsigned long long g_phase[8];
 #endif
+// analysis builds (-DSF_ISA_MARK): comments in the generated assembly that delimit the hot regions, for static instruction counts per region
+#ifdef SF_ISA_MARK
+#define ISA_MARK(name) asm volatile("; SF_MARK " name)
+#else
+#define ISA_MARK(name)
+#endif
 #if defined(SF_PHASE_PROFILE) && !defined(SF_PHASE_PGRP)  // (SF_PHASE_PGRP: the slots belong to the stages of prec_eval_grouped, sf_prec_group.h)
 #define PH_DECL uint64_t ph_t = clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define PH(i)                          \
@@ -607,6 +613,72 @@ __device__ __forceinline__ bool eval_list_move_small(const ListModel& m, const u
         dv[k] = ok ? v : 0;
     }
     return ok;
+}
+
+// The same trial delta for a candidate the nearby generators of THIS step emitted (the FAST kernels' rings hold nothing else): such a candidate
+// is structurally doable by construction -- nearby_change.rs:133-195 / nearby_swap.rs enumerate destinations of the committed lists only, skip the
+// source slot and its successor, and pair an intra swap with a LATER position -- so move/list_kernel/change.rs:44-71 / swap.rs:30-56 hold and
+// nothing is tested here.  Written for the scalar unit's sake (the kernel's bound): a per-lane predicate is a v_cmp into an SGPR pair, every
+// `&&` / `||` of two predicates one scalar instruction, every compare-then-select a wait state on gfx950; so neighbours are addressed with
+// min() arithmetic, and `chg` arrives as an integer (1 = ListChange, 0 = ListSwap).
+template <int L, class LT, bool M16 = false, class OT = uint32_t>
+__device__ __forceinline__ void eval_generated_small(const ListModel& m, const uint16_t* visits, const OT* off, const LT* load, uint32_t c, uint32_t a,
+                                                     uint32_t i, uint32_t b, uint32_t j, int32_t (&dv)[L]) {
+    const uint32_t oa = off[a], la = off[a + 1] - oa;
+    const uint32_t ob = off[b], lb = off[b + 1] - ob;
+    const uint32_t depot = (uint32_t)m.depot;
+    const uint32_t P = oa + i, Q = ob + j;
+    // 1 when the neighbour exists (its position is then one step away; otherwise the read goes to the slot itself and the depot is selected)
+    const uint32_t h_pa = min(i, 1u), h_na = min(la - 1u - i, 1u);      // i > 0 ; i + 1 < la   (i < la)
+    const uint32_t h_q = min(lb - j, 1u), h_pb = min(j, 1u);            // j < lb ; j > 0       (j <= lb)
+    const uint32_t h_nb = min(max(lb, j + 1u) - (j + 1u), 1u);          // j + 1 < lb
+    const uint32_t x = visits[P];
+    const uint32_t r_pa = visits[P - h_pa], r_na = visits[P + h_na];
+    const uint32_t r_q = visits[Q - (1u - h_q)], r_pb = visits[Q - h_pb], r_nb = visits[Q + h_nb];  // (an end slot reads its left neighbour; unused)
+    const uint32_t pa = h_pa ? r_pa : depot, na = h_na ? r_na : depot;
+    const uint32_t vq = h_q ? r_q : depot;  // change: right neighbour of the slot; swap: y
+    const uint32_t pb = h_pb ? r_pb : depot, nb = h_nb ? r_nb : depot;
+    const bool chg = c != 0;
+    const bool intra = a == b;
+    const bool adj = !chg && intra && j == i + 1;
+    const bool ca = chg || adj;
+    const uint32_t dim4 = (uint32_t)m.dim * (M16 ? 2u : 4u);
+    auto leg = [&](uint32_t f, uint32_t t) -> uint32_t {
+        const uint32_t byte_off = __umul24(f, dim4) + t * (M16 ? 2u : 4u);  // node ids and the row pitch are below 2^24: one full-rate v_mad_u32_u24 (a 32-bit v_mul_lo is quarter rate); dim <= 16384: < 2^30
+        if (M16) return *(const uint16_t*)((const char*)m.mat16 + byte_off);
+        return *(const uint32_t*)((const char*)m.mat32 + byte_off);
+    };
+    // plus legs P0..P3, minus legs M0..M3: the table of eval_list_move_small
+    const uint32_t p0 = leg(pa, chg ? na : vq);
+    const uint32_t p1 = leg(chg ? pb : vq, ca ? x : na);
+    const uint32_t p2 = leg(ca ? x : pb, chg ? vq : (adj ? nb : x));
+    const uint32_t p3 = leg(x, nb);
+    const uint32_t m0 = leg(pa, x);
+    const uint32_t m1 = leg(x, adj ? vq : na);
+    const uint32_t m3 = leg(vq, nb);
+    const uint32_t m2 = leg(adj ? vq : pb, adj ? nb : vq);
+    int32_t d_cap = 0;
+    if (m.cap_level >= 0) {
+        const int32_t dx = m.demand[x];
+        const int32_t dyq = m.demand[vq];
+        const int32_t dy = chg ? 0 : dyq;
+        const int32_t cap = (int32_t)m.capacity;
+        const int32_t la0 = (int32_t)load[a] - cap, lb0 = (int32_t)load[b] - cap;
+        const int32_t sh = dx - dy;
+        d_cap = max(la0 - sh, 0) + max(lb0 + sh, 0) - max(la0, 0) - max(lb0, 0);
+        d_cap = intra ? 0 : d_cap;
+    }
+    const uint32_t plus = ((chg && la == 1) ? 0u : p0) + p1 + p2 + (ca ? 0u : p3);
+    const uint32_t minus = m0 + m1 + ((chg && !intra && lb == 0) ? 0u : m2) + (ca ? 0u : m3);
+    const int32_t d_dist = (int32_t)(plus - minus);
+    // penalties: score level -= weight * delta(penalty sum); a level's share is picked with a 32-bit all-ones / zero word per (level, constraint) --
+    // two wave-uniform words instead of a lane mask in a scalar register pair and a select each
+    const int32_t tc = -((int32_t)m.cap_weight * d_cap), td = -((int32_t)m.dist_weight * d_dist);
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t wc = k == m.cap_level ? 0xFFFFFFFFu : 0u, wd = k == m.dist_level ? 0xFFFFFFFFu : 0u;
+        dv[k] = (int32_t)(((uint32_t)tc & wc) + ((uint32_t)td & wd));
+    }
 }
 
 // Per-leaf cursor state of one step.  The NEXT source of the leaf is always resolved ahead of use
@@ -809,6 +881,15 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         for (int k = 0; k < L; ++k) {
             late_d[k] = SMALL ? clamp_i64_to_i32(wsub(late.v[k], cur[k])) : 0;
             best_d[k] = 0;
+        }
+        // (L == 2) the same thresholds as one signed 64-bit key each: hard x 2^32 + soft
+        int64_t acc_thr = 0, best_key = 0;
+        if constexpr (SMALL && L == 2) {
+            // (|candidate level delta| < 2^30: a hard threshold at or below -2^30 accepts every candidate whatever it is, so the clamp is exact and the
+            // key cannot leave 64 bits)
+            const int64_t lh = late_d[0] < -(1 << 30) ? -(int64_t)(1 << 30) : (int64_t)late_d[0];
+            const int64_t late_key = lh * 4294967296ll + (int64_t)late_d[1];
+            acc_thr = late_key < 0 ? late_key : 0;  // delta >= 0  ||  delta >= late - current
         }
         const uint32_t total = uni(s_off[V]);
         // union: >1 leaf => StratifiedRandom, equal weights (vec_union.rs:229-245); with two children
@@ -1024,6 +1105,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 const bool need1 = n_leaves > 1 && !C1.ex && C1.left > 0 && C1.tail - C1.head < (both_live ? 32u : single1);
                 if (!need0 && !need1) break;
                 if (need0 && need1) {
+                    ISA_MARK("pair_begin");
                     // ---- paired pass: lanes 0-31 = the first 32 row entries of leaf 0's source, lanes
                     // 32-63 = the first 32 of leaf 1's (its prefetch is stored rotated by 32 lanes) ----
                     const bool hi = lane >= 32;
@@ -1112,6 +1194,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                     }
                     C0.tail = tlA + emA;
                     C1.tail = tlB + emB;
+                    ISA_MARK("pair_end");
                 } else {
                     // ---- single source of the one leaf that needs candidates ----
                     const int l = need0 ? 0 : 1;
@@ -1134,6 +1217,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             PH(2)
 
             // C2: replay one batch in union cursor order: trial score, acceptor, forager
+            ISA_MARK("replay_begin");
             {
                 const bool live0 = !C0.ex, live1 = !C1.ex;
                 if (!live0 && !live1) {
@@ -1172,19 +1256,31 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 uint32_t nconsumed = nvalid;
                 if constexpr (SMALL) {
                     // ---- delta-space replay (MODE 2): int32 level deltas against the step's current score ----
+                    // Every ring entry of a FAST kernel is a nearby candidate generated from the committed lists of THIS step: structurally doable
+                    // (eval_generated_small), so there is no doability test, and no exec-mask region either -- a lane past the valid ones re-prices
+                    // the batch's first candidate and is masked out of the decisions.
                     int32_t dv[L];
-#pragma unroll
-                    for (int kk = 0; kk < L; ++kk) dv[kk] = 0;
-                    if (valid) {
-                        const uint32_t qi = idx & RCM;
-                        const uint32_t* rq = ring + ((size_t)lf * cv.rc + qi) * 2;
+                    {
+                        const uint32_t lf0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lf), idx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+                        const uint32_t lfq = valid ? lf : lf0;
+                        const uint32_t qi = (valid ? idx : idx0) & RCM;
+                        const uint32_t* rq = ring + ((size_t)lfq * cv.rc + qi) * 2;
                         m0 = rq[0];
                         m1 = rq[1];
                         const uint32_t a = m0 >> 16, i = m0 & 0xFFFFu, b = m1 >> 16, j = m1 & 0xFFFFu;
-                        doable = eval_list_move_small<L, LT, COMPACT, OT>(m, s_visits, s_off, s_load, lf ? chg1 : chg0, a, i, b, j, dv);  // COMPACT reads the u16 matrix
+                        eval_generated_small<L, LT, COMPACT, OT>(m, s_visits, s_off, s_load, 1u - lfq, a, i, b, j, dv);  // FAST: leaf 0 = change, leaf 1 = swap; COMPACT reads the u16 matrix
                     }
-                    // LateAcceptance: score >= last step score || score >= late score (late_acceptance.rs:89-125)
-                    acc = doable && (small_ge0<L>(dv) || small_ge<L>(dv, late_d));
+                    doable = valid;
+                    // LateAcceptance: score >= last step score || score >= late score (late_acceptance.rs:89-125).  Two levels: the pair of int32 deltas
+                    // is ONE signed 64-bit key (hard x 2^32 + soft, |soft| < 2^31 keeps the order lexicographic), and the two tests are one compare
+                    // against the wave-uniform min(0, late - current)
+                    int64_t key = 0;
+                    if constexpr (L == 2) {
+                        key = (int64_t)(((uint64_t)(uint32_t)dv[0] << 32) + (uint64_t)(int64_t)dv[1]);
+                        acc = valid && key >= acc_thr;
+                    } else {
+                        acc = valid && (small_ge0<L>(dv) || small_ge<L>(dv, late_d));
+                    }
                     accmask = __ballot(acc);
                     {  // AcceptedCount quota (forager.rs:232-239)
                         const uint32_t remaining = (uint32_t)p.limit - accepted;
@@ -1195,7 +1291,12 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                     consumed = lane < nconsumed;
                     acc = acc && consumed;
                     accmask = __ballot(acc);
-                    if (accmask && (!has_best || __ballot(acc && small_ge<L>(dv, best_d)))) {
+                    bool challenger;
+                    if constexpr (L == 2)
+                        challenger = acc && key >= best_key;
+                    else
+                        challenger = acc && small_ge<L>(dv, best_d);
+                    if (accmask && (!has_best || __ballot(challenger))) {
                         // lexicographic maximum of the accepted lanes, level by level
                         int32_t M[L];
                         bool in_max = acc;
@@ -1222,6 +1323,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                             }
 #pragma unroll
                             for (int kk = 0; kk < L; ++kk) best_d[kk] = M[kk];
+                            if constexpr (L == 2) best_key = (int64_t)(((uint64_t)(uint32_t)M[0] << 32) + (uint64_t)(int64_t)M[1]);
                             equal_count = eq_base + (uint64_t)__popcll(eq);
                             has_best = 1;
                         }
@@ -1316,11 +1418,13 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 }
                 const uint32_t nacc = (uint32_t)__popcll(accmask);
                 accepted += nacc;
-                st_gen += nconsumed;
-                st_acc += nacc;
                 st_scored += nvalid;
-                const uint32_t ndo = (uint32_t)__popcll(__ballot(consumed && doable));
-                st_calc += ndo;
+                if constexpr (!SMALL) {  // (SMALL: moves_generated / accepted are added once per step from `pulls` / `accepted`; every candidate is doable)
+                    st_gen += nconsumed;
+                    st_acc += nacc;
+                    const uint32_t ndo = (uint32_t)__popcll(__ballot(consumed && doable));
+                    st_calc += ndo;
+                }
                 if (tracing && consumed) {
                     const uint64_t ti = trace_n + lane;
                     if ((int64_t)ti < p.trace_cap) {
@@ -1336,12 +1440,19 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                     }
                 }
                 if (tracing) trace_n += nconsumed;
-                const uint32_t c1 = (uint32_t)__popcll(__ballot(consumed && lf == 1u));
+                uint32_t c1;
+                if constexpr (SMALL) {  // the lanes alternate the two leaves from the batch's first pull on: no ballot needed
+                    const uint32_t lfirst = (uint32_t)__builtin_amdgcn_readfirstlane((int)lf);
+                    c1 = (live0 && live1) ? ((nconsumed + lfirst) >> 1) : (lfirst ? nconsumed : 0u);
+                } else {
+                    c1 = (uint32_t)__popcll(__ballot(consumed && lf == 1u));
+                }
                 C1.head += c1;
                 C0.head += nconsumed - c1;
                 pulls += nconsumed;
                 if (forager_quits(forager, (uint32_t)p.limit, accepted, has_best, improving_pick)) done = 1;
             }
+            ISA_MARK("replay_end");
             PH(3)
         }
         PH(4)
@@ -1433,6 +1544,11 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 if (annealing) sa_step_ended(saw, p.sa, lane);
             wave_sync();
             st_steps += 1;
+            if constexpr (SMALL) {
+                st_gen += pulls;
+                st_calc += pulls;
+                st_acc += accepted;
+            }
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
             if (p.move_budget > 0 && (int64_t)st_gen >= p.move_budget) break;  // work-balanced launch: see sf_solve_moves (budget < 2^31)
             if (p.move_budget == 0 && st_scored >= 0x70000000u) flush_stats();

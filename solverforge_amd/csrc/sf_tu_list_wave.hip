@@ -6,7 +6,6 @@ namespace sf {
 
 template <>
 hipError_t launch_tu_list_wave<SF_TU_L>(bool trace, int mode, const SearchLaunch& a) {
-    if (mode == 7) return launch_with_lds(k_list_search_wave<SF_TU_L, false, 2, true, 8, true>, a, *a.lm, *a.p, a.nb);  // ... 8 waves per SIMD (64 registers), node table in HBM
     if (mode == 6) return launch_with_lds(k_list_search_wave<SF_TU_L, false, 2, true, 4, true>, a, *a.lm, *a.p, a.nb);  // COMPACT slice, node -> slot table in HBM
     if (mode == 5) return launch_with_lds(k_list_search_wave<SF_TU_L, false, 2, true, 6>, a, *a.lm, *a.p, a.nb);  // ... compiled for 6 waves per SIMD
     if (mode == 4) return launch_with_lds(k_list_search_wave<SF_TU_L, false, 2, true, 5>, a, *a.lm, *a.p, a.nb);  // ... compiled for 5 waves per SIMD

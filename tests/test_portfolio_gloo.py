@@ -71,7 +71,15 @@ def test_pick_winner_rule():
     assert portfolio.better([0, -1], [-1, 1000])
 
 
-@pytest.mark.parametrize("replicas", [24576, 2048, 1024, 1280])  # bench.py: the M1 leg, the M2 parity leg, the tuned leg, the C5 side leg
+def _bench_leg_replicas():
+    """The replica counts bench.py itself uses for its legs (imported, not restated): M1, every M2 policy, the tuned leg, the C5 side leg."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return sorted({bench.M1_REPLICAS, bench.C5_REPLICAS, bench.TUNED["replicas"], *bench.M2_REPLICAS.values()})
+
+
+@pytest.mark.parametrize("replicas", _bench_leg_replicas())
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_rank_seed_ranges_tile_without_overlap(replicas, world):
     """Every portfolio member of a leg has its own seed: the per-rank ranges are disjoint and consecutive, and rank 0 / replica 0
