@@ -693,6 +693,7 @@ struct LeafCursor {
     int ex;               // exhausted (union scheduler)
     uint32_t pk;          // per lane: prefetched entry of chunk 0 of the next source's neighbour row
     uint32_t pv;          // per lane: (source position | source element << 16) of offset vbase + lane of entity rank vk
+    uint32_t cend;        // offsets o < cend of the current entity are served by `pv` as it stands (0 = nothing cached): resolve()'s one-compare fast path
 };
 
 // MODE 1 (FAST): compile-time specialisation for the default list policy (nearby change + nearby swap union,
@@ -828,6 +829,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
     bool best_pending = false;  // working == best, snapshot not yet written (see sf_scalar_kernels.hip: deferred clone)
     const FastMod fm_V = make_fastmod(V > 0 ? (uint32_t)V : 1u);
     const FastMod fm_V1 = make_fastmod(V > 1 ? (uint32_t)V - 1u : 1u);
+    const uint32_t v_recip32 = V > 1 ? (uint32_t)(0x100000000ull / (uint32_t)V) : 0u;  // floor(2^32 / V): resolve()'s 32-bit remainder (V = 1: every rank maps to list 0)
     // coprimality of every candidate permutation stride of the V list owners, once per launch (lane s tests s and s + 64)
     const bool use_cm = V >= 2 && V <= 128;
     const uint64_t cm_lo = use_cm ? __ballot(lane >= 1 && lane < (uint32_t)V && gcd_u32(lane, (uint32_t)V) == 1) : 0ull;
@@ -917,12 +919,20 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
         auto resolve = [&](LeafCursor& c, int l) {
             const uint16_t* ra = route_at + l * V;
             uint32_t k = c.k, o = c.o, se = c.se, len = c.len;
+            // the common case -- the next offset of the same entity inside the 64 offsets `pv` already holds -- is ONE compare: everything below
+            // this test is the per-entity / per-chunk path (it used to be entered through two compound tests, ~20 scalar instructions per source)
+            if (o >= c.cend) {
             if (k != c.vk || o >= len) {  // a new entity: its list owner and length (skip empty routes; left > 0
                                           // guarantees a source exists)
                 for (;;) {
-                    if constexpr (COMPACT)  // no rank -> route table in the compact slice: the permutation itself (a few entities per step)
-                        se = uni(fastmod_u64((uint64_t)(l ? perm_st1 : perm_st0) + (uint64_t)k * (l ? perm_sd1 : perm_sd0), fm_V));
-                    else
+                    if constexpr (COMPACT) {  // no rank -> route table in the compact slice: the permutation itself (a few entities per step)
+                        // start + k x stride < V^2 + V < 2^21 (V <= 1022 in this layout): a 32-bit Barrett step -- the quotient estimate is exact or one
+                        // short -- instead of the 64 x 64 high multiply of fastmod_u64 (two dozen scalar instructions)
+                        const uint32_t xx = (l ? perm_st1 : perm_st0) + k * (l ? perm_sd1 : perm_sd0);
+                        uint32_t rr_ = xx - __umulhi(xx, v_recip32) * (uint32_t)V;
+                        rr_ = rr_ >= (uint32_t)V ? rr_ - (uint32_t)V : rr_;
+                        se = uni(rr_);
+                    } else
                         se = uni((uint32_t)ra[k]);
                     len = uni(s_off[se + 1] - s_off[se]);
                     if (o < len) break;
@@ -942,22 +952,28 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 c.vk = k;
                 c.vbase = o & ~63u;
             }
-            const uint32_t pvv = (uint32_t)__builtin_amdgcn_readlane((int)c.pv, (int)(o & 63u));
-            const uint32_t sp = pvv & 0xFFFFu, sx = pvv >> 16;
+            c.cend = len < (o & ~63u) + 64u ? len : (o & ~63u) + 64u;
             c.k = k;
-            c.o = o;
             c.se = se;
             c.len = len;
+            }
+            const uint32_t pvv = (uint32_t)__builtin_amdgcn_readlane((int)c.pv, (int)(o & 63u));
+            const uint32_t sp = pvv & 0xFFFFu, sx = pvv >> 16;
+            c.o = o;
             c.sp = sp;
             c.sx = sx;
             const uint32_t ent = l ? ((lane + 32u) & 63u) : lane;  // leaf 1: lanes 32-63 hold entries 0-31
-            c.pk = ent < dim ? (uint32_t)nb.keys[(size_t)sx * dim + ent] : NBR_END;
+            // (the index has dim^2 <= 2^28 entries: a 32-bit byte offset per lane on the scalar base pointer, not a 64-bit scalar row address)
+            // unconditional load (a lane past a row shorter than 64 entries reads the row's last entry and is then blanked): no exec-mask region
+            const uint32_t entc = ent < dim ? ent : dim - 1u;
+            const uint32_t pk_any = (uint32_t) * (const uint16_t*)((const char*)nb.keys + ((sx * dim + entc) << 1));
+            c.pk = ent < dim ? pk_any : NBR_END;
         };
 
         PH(0)
         // ---- (B) per-leaf entity order tables (slot.rs:468-499) --------------------------------
-        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, NBR_END, 0};
-        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, n_leaves > 1 ? 0 : 1, NBR_END, 0};
+        LeafCursor C0{0, 0, total, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, 0, NBR_END, 0, 0};
+        LeafCursor C1{0, 0, n_leaves > 1 ? total : 0u, 0, 0, 0, 0, 0, 0, 0xFFFFFFFFu, 0, n_leaves > 1 ? 0 : 1, NBR_END, 0, 0};
         for (int l = 0; l < n_leaves; ++l) {
             const uint64_t ent_salt = ((l ? chg1 : chg0) ? SALT_NEARBY_CHANGE_ENTITY : SALT_NEARBY_SWAP_ENTITY) ^ (l ? desc1 : desc0);
             uint32_t pst, psd;
@@ -1127,13 +1143,32 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                         const uint32_t slot_any = node_slot.get(have ? (key & NBR_NODE_MASK) : 0u);  // unconditional read (node 0 for the lanes past the row)
                         const uint32_t slot = have ? slot_any : NODE_NONE;
                         const uint32_t* rth = rtab + (hi ? V : 0);
-                        const NearbyItem ic = nearby_item_rt(true, slot, se, sp, len, kk, s_off, rth);
-                        const NearbyItem is = nearby_item_rt(false, slot, se, sp, len, kk, s_off, rth);
-                        const bool lane_change = hi ? chg1 : chg0;
-                        it.w = lane_change ? ic.w : is.w;
-                        it.ord = lane_change ? ic.ord : is.ord;
-                        it.pay0 = lane_change ? ic.pay0 : is.pay0;
-                        it.pay1 = lane_change ? ic.pay1 : is.pay1;
+                        if constexpr (FAST) {
+                            // leaf 0 = nearby change (lanes 0-31), leaf 1 = nearby swap (lanes 32-63): the two items of nearby_item_rt written as ONE, the
+                            // facts they share read once and the half a lane belongs to folded into the predicates (nearby_change.rs:133-195, nearby_swap.rs)
+                            const bool some = slot != NODE_NONE;
+                            const uint32_t r2 = some ? slot >> 16 : 0u, dp = slot & 0xFFFFu;
+                            const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
+                            const uint32_t t = rth[r2];
+                            const bool intra = r2 == se;
+                            const uint32_t end_pay = (r2 << 16) | len2;
+                            // change: the slot itself unless it is the source's own or the one behind it (dp - sp is 0 or 1, unsigned); swap: a later position of
+                            // the source's list, or a list ranked after it
+                            const bool v0 = hi ? (intra ? dp > sp : (t & 0xFFFFu) > kk) : (!intra || dp - sp >= 2u);
+                            const bool v1 = !hi && dp + 1 == len2 && (!intra || len != sp + 1);  // change only: the end slot `len` probes element len - 1
+                            it.w = some ? (uint32_t)v0 + (uint32_t)v1 : 0u;
+                            it.ord = intra ? ((hi || v0) ? dp : len) : ORD_INTER_BASE + (t >> 16) + dp;
+                            it.pay0 = (hi || v0) ? slot : end_pay;
+                            it.pay1 = end_pay;
+                        } else {
+                            const NearbyItem ic = nearby_item_rt(true, slot, se, sp, len, kk, s_off, rth);
+                            const NearbyItem is = nearby_item_rt(false, slot, se, sp, len, kk, s_off, rth);
+                            const bool lane_change = hi ? chg1 : chg0;
+                            it.w = lane_change ? ic.w : is.w;
+                            it.ord = lane_change ? ic.ord : is.ord;
+                            it.pay0 = lane_change ? ic.pay0 : is.pay0;
+                            it.pay1 = lane_change ? ic.pay1 : is.pay1;
+                        }
                     }
                     const uint64_t havemask = __ballot(have);
                     const uint64_t startmask = __ballot(have && ((lane & 31u) == 0 || !(key & NBR_SAME_FLAG)));
