@@ -138,6 +138,7 @@ struct sf_ctx {
     uint64_t* d_ruin_rng = nullptr;      // [R][4] per-solve SmallRng state of the list ruin leaf
     uint32_t* d_mixed_ring = nullptr;    // [R][GL][GRC][2] candidate rings of the generic engine (+ [R][GL][GRC] side bytes)
     uint8_t* d_mixed_ringx = nullptr;
+    int32_t* d_mixed_ringd = nullptr;    // [R][GL][GRC][2] trial deltas beside the rings (the FAST instantiations' scoring stage; allocated on first use)
     int union_order = -1;                // sf_union_configure: -1 = the default policy's root union
     std::vector<int32_t> union_weights;  // per leaf in union order; empty = equal
     int64_t* d_scores_out = nullptr;
@@ -2476,6 +2477,17 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
                   PREC && gl.prec_lds ? gl.prec_groups : 0, nodeg);
     if (cv.total > SF_LDS_BUDGET) return fail(ctx, SF_ERR_UNSUPPORTED, "model does not fit one wave's LDS slice");
     GLeaves gl2 = gl;
+    gl2.ringd = nullptr;
+    static const bool no_pre_eval = std::getenv("SF_AMD_MIXED_NO_PRE_EVAL") != nullptr;  // diagnostics / parity tests: score inside the replay as before
+    if (fast && ctx->lm.small32 && !no_pre_eval && !SF_MIXED_RING_LDS) {  // the scoring stage stores 32-bit deltas
+        if (!ctx->d_mixed_ringd) {
+            int32_t* rd = nullptr;
+            int rc = dalloc(ctx, &rd, (size_t)ctx->R * GL * GRC * 2);
+            if (rc) return rc;
+            ctx->d_mixed_ringd = rd;
+        }
+        gl2.ringd = ctx->d_mixed_ringd;
+    }
     if (nodeg) {
         if (!ctx->d_node_tab32) {
             uint32_t* nt = nullptr;

@@ -99,6 +99,9 @@ struct GLeaves {
     // stores, read once per replay round -- the replica's LDS slice keeps only what is touched with dependent latency
     uint32_t* ring;
     uint8_t* ringx;
+    // [R][GL][GRC][2] int32 (capacity-overshoot delta, distance delta; the first word INT32_MIN = not doable): the trial deltas of the list
+    // candidates, written by the FAST kernels' scoring stage -- one leaf at a time, so every lane runs the SAME move kind -- and read by the replay
+    int32_t* ringd;
     PrecModel prec;          // ListPrecedenceMakespanConstraint of the list class (prec.on; PREC instantiations, sf_precedence.h)
     int32_t prec_lds;        // its scratch arrays are carved from the replica's LDS slice (small node counts)
     int32_t prec_inc;        // HBM scratch: list change / swap trials take the incremental refresh (prec_trial_inc; opt-in, see sf_precedence.h)
@@ -395,6 +398,12 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     }
     uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
     uint8_t* ringx = SF_MIXED_RING_LDS ? (uint8_t*)(mem + cv.ringx) : gl.ringx + (size_t)r * GL * GRC;   // [leaf][GRC]
+    // Scoring stage of the FAST kernels (round 6): the trial deltas of the list candidates are computed right after a fill round, ONE LEAF AT A
+    // TIME -- 64 lanes of the same move kind -- and parked beside the ring; the replay, whose 64 pulls interleave six or seven kinds (every kind's
+    // code ran there with a sixth of the lanes), only reads them.  Needs 32-bit deltas (ListModel::small32; the host passes ringd only then).
+    int32_t* const ringd = (FAST && gl.ringd) ? gl.ringd + (size_t)r * GL * GRC * 2 : nullptr;
+    const bool pre_eval = FAST && ringd != nullptr;
+    uint32_t prev_pulls = 0;  // pulls of the replica's previous step in this launch: long steps fill (and score) their rings in lumps of ~64 per leaf
     int64_t* s_load = (int64_t*)(mem + cv.load);
     uint32_t* s_off = (uint32_t*)(mem + cv.off);
     uint16_t* s_visits = (uint16_t*)(mem + cv.visits);
@@ -997,6 +1006,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             }
             lbv[0] = s1, lbv[1] = s2, lbv[2] = (int64_t)nk, lbv[3] = global_stat(sm, s1, s2, nk);
         }
+        uint32_t step_pulls = 0;  // pulls of this step (FAST: decides whether the next step fills its rings in lumps)
         uint64_t sidx, sseed;
         if (dry_run) {
             sidx = p.dry_step_index;
@@ -1295,6 +1305,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                 for (int l = 0; l < nl; ++l) live += ((exmask >> l) & 1u) ? 0u : 1u;
                 if (live > 1) fill_thr = (63u + live) / live + 8u;
             }
+            const bool lump_fill = prev_pulls >= 2048u;  // (a short step would throw most of a 64-entry lump away when it ends)
             for (int l = 0; l < nl; ++l) {
                 const int kind = lt.geti(l, LeafTab::KIND);
                 uint32_t* rq = ring + (size_t)l * GRC * 2;
@@ -1303,7 +1314,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                 const uint32_t hd_l = lt.get(l, LeafTab::HEAD);
                 const bool ex_l = ((exmask >> l) & 1u) != 0;
                 const uint32_t leaf_max_nearby = lt.get(l, LeafTab::MAXNB), leaf_min = lt.get(l, LeafTab::MINSZ), leaf_max = lt.get(l, LeafTab::MAXSZ);
-                while (!ex_l && !g.done && tl - hd_l < fill_thr) {
+                // pre_eval + a long step: hysteresis -- a leaf is refilled when it runs below what the next replay batch needs, and then up to 64 pending
+                // (a generator call appends at most 64, the ring holds 128), so that the scoring stage below finds ~64 new entries of one kind at a time
+                const uint32_t fill_to = (pre_eval && lump_fill) ? (tl - hd_l < fill_thr ? 64u : 0u) : fill_thr;
+                if (pre_eval) lt.set(l, LeafTab::TAKEN, tl);  // (TAKEN is free between two replays) first entry the scoring stage has not seen
+                while (!ex_l && !g.done && tl - hd_l < fill_to) {
                     st_sources += 1;
                     bool keep = false;
                     uint32_t w0 = 0, w1 = 0, wx = 0;
@@ -2122,6 +2137,29 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
 #endif
             }
             ring_sync();
+            if (pre_eval) {
+                // ---- scoring stage: the entries this fill round appended, one leaf (= one move kind) at a time ----
+                bool any_new = false;
+                for (int l = 0; l < nl; ++l) {
+                    const int kind = lt.geti(l, LeafTab::KIND);
+                    if (RUIN && kind == 1024) continue;  // (list ruin: scored when the step started)
+                    const uint32_t t0 = lt.get(l, LeafTab::TAKEN), t1 = lt.get(l, LeafTab::TAIL);
+                    for (uint32_t b0 = t0; (int32_t)(t1 - b0) > 0; b0 += 64) {
+                        const uint32_t t = b0 + lane;
+                        if ((int32_t)(t1 - t) > 0) {
+                            const uint32_t qi = t & (GRC - 1);
+                            const uint32_t* rq = ring + ((size_t)l * GRC + qi) * 2;
+                            const ListDelta d = eval_list_unified(lm, s_visits, s_off, s_load, kind, rq[0], rq[1], (uint32_t)ringx[l * GRC + qi]);
+                            int32_t* rd = ringd + ((size_t)l * GRC + qi) * 2;
+                            rd[0] = d.doable ? (int32_t)d.d_cap : INT32_MIN;
+                            rd[1] = (int32_t)d.d_dist;
+                        }
+                        any_new = true;
+                    }
+                }
+                if (any_new) ring_sync();
+                PHS(6)  // (counted with the replay: it is the replay's trial scoring, moved)
+            }
 
             // ---- C2: lay the next 64 pulls of the union scheduler onto the lanes ----
             uint32_t my_leaf = 0, my_idx = 0;
@@ -2330,7 +2368,13 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                         sc = apply_delta<L>(lm, cur, d);
                     } else {
                         ListDelta d;
-                        if (unified_eval)  // symmetric matrix: one shared gather for every kind
+                        if (pre_eval) {  // scored by the stage above, with every lane on the same kind
+                            const int32_t* rd = ringd + ((size_t)my_leaf * GRC + (my_idx & (GRC - 1))) * 2;
+                            const int32_t dc = rd[0];
+                            d.doable = dc != INT32_MIN;
+                            d.d_cap = d.doable ? (int64_t)dc : 0;
+                            d.d_dist = (int64_t)rd[1];
+                        } else if (unified_eval)  // symmetric matrix: one shared gather for every kind
                             d = eval_list_unified(lm, s_visits, s_off, s_load, my_kind, m0, m1, mx_);
                         else
                             d = my_kind == 256
@@ -2785,6 +2829,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             if (annealing) sa_step_ended(saw, p.sa, lane);
             wave_sync();
             st_steps += 1;
+            prev_pulls = step_pulls;
             la_cursor = la_cursor + 1 >= p.la_size ? 0 : la_cursor + 1;
         }
         PHS(7)
