@@ -1,0 +1,17 @@
+#!/bin/bash
+# A variant library for A/B runs on the GPU box: ONE unit recompiled with extra flags, linked with the stock objects of csrc/_obj.
+# usage: build_variant.sh <name> <unit: list_wave_2 | mixed_2_2_1_0 | ...> "<extra flags>"      -> build/libsf_<name>.so   (SF_AMD_LIB=... selects it)
+set -e
+R=$(cd "$(dirname "$0")/.." && pwd); C=$R/solverforge_amd/csrc; name=$1; unit=$2; extra=$3
+mkdir -p $R/build/var_$name
+case $unit in
+  list_wave_*) src=sf_tu_list_wave.hip; defs="-DSF_TU_L=${unit#list_wave_}";;
+  mixed_*) IFS=_ read -r _ l v ru pr <<< "$unit"; src=sf_tu_mixed.hip; defs="-DSF_TU_L=$l -DSF_TU_VTB=$v -DSF_TU_RUIN=$ru -DSF_TU_PREC=$pr";;
+  scalar_*) IFS=_ read -r _ l v <<< "$unit"; src=sf_tu_scalar.hip; defs="-DSF_TU_L=$l -DSF_TU_VTB=$v";;
+  api) src=sf_api.hip; defs="";;
+  *) echo "unknown unit $unit"; exit 1;;
+esac
+(cd $C && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I/opt/rocm/include $defs $extra -c $src -o $R/build/var_$name/$unit.o)
+objs=$(ls $C/_obj/*.o | grep -v "/$unit.o")
+hipcc --offload-arch=gfx950 -shared -fPIC $objs $R/build/var_$name/$unit.o -o $R/build/libsf_$name.so -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+echo built $R/build/libsf_$name.so

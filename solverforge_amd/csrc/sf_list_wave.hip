@@ -479,7 +479,7 @@ __device__ __forceinline__ uint32_t nearby_source_to_ring(const ListModel& m, co
     return emitted;
 }
 
-#ifdef SF_PHASE_PROFILE
+#if defined(SF_PHASE_PROFILE) || defined(SF_GEN_COUNT)
 __device__ unsigned long long g_phase[8];
 #endif
 // analysis builds (-DSF_ISA_MARK): comments in the generated assembly that delimit the hot regions, for static instruction counts per region
@@ -498,10 +498,20 @@ __device__ unsigned long long g_phase[8];
     }
 #define PH_DUMP \
     if (lane == 0) for (int _k = 0; _k < 8; ++_k) atomicAdd(&g_phase[_k], (unsigned long long)ph_acc[_k]);
+#elif defined(SF_GEN_COUNT)  // event counts of the generation instead of clocks (scripts/gen_count.py): 0 paired passes, 1 / 2 single-source passes of leaf 0 / 1,
+// 3 / 4 gen_rest calls out of a paired pass for leaf 0 / 1, 5 / 6 gen_rest chunk iterations of leaf 0 / 1, 7 iterations that found no key
+#define PH_DECL uint64_t ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define PH(i)
+#define GC(i) ph_acc[i] += 1;
+#define PH_DUMP \
+    if (lane == 0) for (int _k = 0; _k < 8; ++_k) atomicAdd(&g_phase[_k], (unsigned long long)ph_acc[_k]);
 #else
 #define PH_DECL
 #define PH(i)
 #define PH_DUMP
+#endif
+#ifndef GC
+#define GC(i)
 #endif
 
 // ---- SMALL mode helpers (MODE 2) --------------------------------------------------------------------------------
@@ -1074,6 +1084,8 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                     const uint32_t wc = closed ? it.w : 0u;
                     const uint64_t w1 = __ballot(wc == 1), w2 = __ballot(wc == 2);
                     const uint32_t Wc = (uint32_t)__popcll(w1) + 2u * (uint32_t)__popcll(w2);
+                    GC(l ? 6 : 5)
+                    if (Wc == 0) { GC(7) }
                     if (Wc > 0) {
                         // sorted position = weight before me, corrected by the inversions inside my group
                         int32_t pos = (int32_t)(mbcnt64(w1) + 2u * mbcnt64(w2));
@@ -1122,6 +1134,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 if (!need0 && !need1) break;
                 if (need0 && need1) {
                     ISA_MARK("pair_begin");
+                    GC(0)
                     // ---- paired pass: lanes 0-31 = the first 32 row entries of leaf 0's source, lanes
                     // 32-63 = the first 32 of leaf 1's (its prefetch is stored rotated by 32 lanes) ----
                     const bool hi = lane >= 32;
@@ -1220,10 +1233,12 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                     }
                     uint32_t emA = WcA < K0 ? WcA : K0, emB = WcB < K1 ? WcB : K1;
                     if (emA < K0 && moreA) {  // rare: leaf 0's source needs entries beyond its half
+                        GC(3)
                         const uint32_t jj = ncA + lane;
                         emA = gen_rest(0, seA, spA, lenA, kA, sxA, tlA, jj < dim ? (uint32_t)nb.keys[(size_t)sxA * dim + jj] : NBR_END, ncA, K0 - emA, emA);
                     }
                     if (emB < K1 && moreB) {
+                        GC(4)
                         const uint32_t jj = ncB + lane;
                         emB = gen_rest(1, seB, spB, lenB, kB, sxB, tlB, jj < dim ? (uint32_t)nb.keys[(size_t)sxB * dim + jj] : NBR_END, ncB, K1 - emB, emB);
                     }
@@ -1233,6 +1248,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 } else {
                     // ---- single source of the one leaf that needs candidates ----
                     const int l = need0 ? 0 : 1;
+                    GC(l ? 2 : 1)
                     LeafCursor c = l ? C1 : C0;
                     const uint32_t se = c.se, sp = c.sp, len = c.len, k = c.k, sx = c.sx;
                     // leaf 1 keeps its prefetched entries rotated by 32 lanes for the paired pass

@@ -18,7 +18,7 @@ hipError_t launch_tu_list_wave<SF_TU_L>(bool trace, int mode, const SearchLaunch
 
 }  // namespace sf
 
-#ifdef SF_PHASE_PROFILE  // diagnostic builds: this unit's copy of the phase counters (a __device__ variable is per translation unit)
+#if defined(SF_PHASE_PROFILE) || defined(SF_GEN_COUNT)  // diagnostic builds: this unit's copy of the phase counters (a __device__ variable is per translation unit)
 #define SF_PH_NAME2(l) sf_debug_phases_wave_##l
 #define SF_PH_NAME(l) SF_PH_NAME2(l)
 extern "C" int32_t SF_PH_NAME(SF_TU_L)(uint64_t* out8) {
