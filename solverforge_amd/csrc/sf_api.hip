@@ -1200,10 +1200,6 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
                     int rc = dalloc(ctx, &nt, (size_t)ctx->R * ctx->lm.dim);
                     if (rc) return rc;
                     ctx->lm.node_tab = nt;
-                    uint32_t* rg = nullptr;
-                    rc = dalloc(ctx, &rg, (size_t)ctx->R * MAX_LEAVES * ctx->lm.V);
-                    if (rc) return rc;
-                    ctx->lm.rtab_g = rg;
                 }
                 mode = 6;
                 wpb = wpb_g;

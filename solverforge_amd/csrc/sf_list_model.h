@@ -42,7 +42,6 @@ struct ListModel {
     // wave kernel, taken when that lets more replicas share a CU (CVRP-5000: 29 KB -> 19 KB per replica, 5 -> 8 per CU).  Scratch: rebuilt
     // from the lists at the start of every launch.
     uint16_t* node_tab;
-    uint32_t* rtab_g;  // [R][MAX_LEAVES][V] the same layout's per-leaf route table (rank | first slot ordinal << 16), rebuilt every step
     const int32_t* demand;
     const uint32_t* ne_keys;  // not-exists A-side keys (Customer.id)
     int32_t ne_n;

@@ -116,7 +116,7 @@ struct WCarve {
         visits = o;
         o = align_up(o + sizeof(uint16_t) * n_cap, 16);
         rtab = o;  // [leaf][route] u32: rank of the route in the leaf's entity order | first destination slot ordinal << 16
-        o = align_up(o + (node_global ? 0 : sizeof(uint32_t) * V * MAX_LEAVES), 16);  // (node_global layout: ListModel::rtab_g)
+        o = align_up(o + (node_global ? 0 : sizeof(uint32_t) * V * MAX_LEAVES), 16);  // (the node_global layout computes ranks instead: RouteArith)
         routeat = o;  // [leaf][rank] -> route; the compact layout recomputes it from the leaf's permutation parameters instead
         o = align_up(o + (compact ? 0 : sizeof(uint16_t) * V * MAX_LEAVES), 16);
         total = o;
@@ -216,15 +216,42 @@ __device__ __forceinline__ NearbyItem nearby_item(bool is_change, uint32_t slot,
 // Same item with the per-route facts read from ONE packed table (wave engine): rt[route] = rank of the route in the
 // leaf's entity order | ordinal of the route's first destination slot << 16 — one LDS gather instead of the dependent
 // pair rank_of[route] -> slot_base[rank].
-template <class OT>
+// The per-route facts of a leaf's entity order as a table (RouteTab: the word above) or as arithmetic (RouteArith, the wave kernel whose tables live in HBM):
+// the entity order is the permutation rank -> (start + rank x stride) mod V, so the rank of a route is ((route - start) x stride^-1) mod V
+// -- a handful of vector instructions instead of a table that is rebuilt every step (and, in the layout whose tables live in HBM, instead
+// of a dependent global gather per row entry).  The enumeration ordinal of an inter-list slot only ever breaks ties inside one
+// equal-distance group, i.e. it is compared, never added up: (rank, position) compares exactly like first-slot-ordinal-of-rank + position,
+// so the arithmetic form needs no prefix sum over the lists either.
+struct RouteTab {
+    const uint32_t* rt;
+    static constexpr int KEY_SHIFT = 24;  // serial top-k key = distance << KEY_SHIFT | ordinal
+    __device__ __forceinline__ uint32_t word(uint32_t route) const { return rt[route]; }
+    __device__ __forceinline__ static uint32_t rank(uint32_t w) { return w & 0xFFFFu; }
+    __device__ __forceinline__ static uint32_t inter_ord(uint32_t w, uint32_t dp) { return ORD_INTER_BASE + (w >> 16) + dp; }
+};
+constexpr uint32_t ORD_ARITH_BASE = 1u << 26;  // above every intra-list ordinal (a position, < 2^16); rank << 16 | position stays below 2^27
+struct RouteArith {
+    uint32_t st, inv, V, recip;  // permutation start, stride^-1 mod V, V, floor(2^32 / V) (V <= 1022: every product below stays under 2^21)
+    static constexpr int KEY_SHIFT = 28;  // (the legs of a COMPACT kernel are < 2^26)
+    __device__ __forceinline__ uint32_t word(uint32_t route) const {
+        uint32_t x = route + V - st;
+        x = x >= V ? x - V : x;
+        const uint32_t y = x * inv;
+        uint32_t rk = y - __umulhi(y, recip) * V;  // 32-bit Barrett step: the quotient estimate is exact or one short
+        return rk >= V ? rk - V : rk;
+    }
+    __device__ __forceinline__ static uint32_t rank(uint32_t w) { return w; }
+    __device__ __forceinline__ static uint32_t inter_ord(uint32_t w, uint32_t dp) { return ORD_ARITH_BASE + (w << 16) + dp; }
+};
+template <class OT, class RT>
 __device__ __forceinline__ NearbyItem nearby_item_rt(bool is_change, uint32_t slot, uint32_t se, uint32_t sp,
-                                                     uint32_t len, uint32_t k, const OT* s_off, const uint32_t* rt) {
+                                                     uint32_t len, uint32_t k, const OT* s_off, const RT& rt) {
     const bool some = slot != NODE_NONE;
     const uint32_t r2 = some ? slot >> 16 : 0u, dp = slot & 0xFFFFu;
     const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
-    const uint32_t t = rt[r2];
-    const uint32_t rk = t & 0xFFFFu;
-    const uint32_t inter_ord = ORD_INTER_BASE + (t >> 16) + dp;
+    const uint32_t t = rt.word(r2);
+    const uint32_t rk = RT::rank(t);
+    const uint32_t inter_ord = RT::inter_ord(t, dp);
     const bool intra = r2 == se;
     const uint32_t end_pay = (r2 << 16) | len2;
     NearbyItem it;
@@ -773,8 +800,13 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             wave_sync();
         }
     };
-    // [leaf][route] rank | first slot ordinal << 16; NODEG: in HBM like the node table (rebuilt every step, read one global round trip behind it)
-    uint32_t* rtab = NODEG ? m.rtab_g + (size_t)r * MAX_LEAVES * V : (uint32_t*)(mem + cv.rtab);
+    // [leaf][route] rank | first slot ordinal << 16 (RouteTab).  The NODEG layout computes the rank instead (RouteArith) and carries no table: in
+    // round 5 its table lived in HBM, a dependent global gather per row entry behind the node -> slot one -- CVRP-5000 15.9 -> 17.9 G moves/s and
+    // 322 -> 227 B of memory-side traffic per candidate without it.  With the table in LDS (CVRP-1000) the lookup is cheaper than the arithmetic
+    // (50.4 -> 48.8 G when every COMPACT kernel computed ranks, profiles/r06d_route_arith_ab.txt), so those keep it.
+    constexpr bool ARANK = NODEG;
+    using RT = typename std::conditional<ARANK, RouteArith, RouteTab>::type;
+    uint32_t* rtab = (uint32_t*)(mem + cv.rtab);
     uint16_t* route_at = (uint16_t*)(mem + cv.routeat);  // [leaf][rank] -> route
 
     uint32_t* g_visits = m.visits + (size_t)r * m.n_cap;
@@ -925,6 +957,13 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                                               : (n_leaves > 1 ? ctx.random_index((uint32_t)n_leaves, SALT_UNION_OFFSET) : 0u);
 
         uint32_t perm_st0 = 0, perm_sd0 = 1, perm_st1 = 0, perm_sd1 = 1;  // entity permutations of the two leaves (set in (B))
+        uint32_t perm_inv0 = 0, perm_inv1 = 0;                              // ARANK: stride^-1 mod V of each
+        auto route_facts = [&](int l) -> RT {
+            if constexpr (ARANK)
+                return RouteArith{l ? perm_st1 : perm_st0, l ? perm_inv1 : perm_inv0, (uint32_t)V, v_recip32};
+            else
+                return RouteTab{rtab + l * V};
+        };
         // resolve the source at cursor (k, o) of leaf l and put its first key chunk in flight
         auto resolve = [&](LeafCursor& c, int l) {
             const uint16_t* ra = route_at + l * V;
@@ -1000,6 +1039,26 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                 perm_st1 = pst, perm_sd1 = psd;
             else
                 perm_st0 = pst, perm_sd0 = psd;
+            if constexpr (ARANK) {
+                // stride^-1 mod V (the stride is coprime to V): lane c tests c, c + 64, ... -- one or two rounds at 100 lists, eight at 500
+                uint32_t inv = 0;
+                for (uint32_t base = 0; base < (uint32_t)V; base += 64) {
+                    const uint32_t c = base + lane;
+                    const uint32_t xx = psd * c;  // < V^2 + 64 V < 2^21
+                    uint32_t rm = xx - __umulhi(xx, v_recip32) * (uint32_t)V;
+                    rm = rm >= (uint32_t)V ? rm - (uint32_t)V : rm;
+                    const uint64_t hit = __ballot(c < (uint32_t)V && rm == 1u);
+                    if (hit) {
+                        inv = base + (uint32_t)__ffsll((unsigned long long)hit) - 1u;
+                        break;
+                    }
+                }
+                if (l)
+                    perm_inv1 = inv;
+                else
+                    perm_inv0 = inv;
+                continue;  // no tables: resolve() and RouteArith work from (start, stride, stride^-1)
+            }
             uint16_t* ra = route_at + l * V;
             uint32_t* rt = rtab + l * V;
             uint32_t carry = 0;  // first slot ordinal of rank k = sum_{k'<k} (len(route_at[k']) + 1)
@@ -1017,7 +1076,6 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             }
         }
         wave_sync();
-        if constexpr (NODEG) node_sync();  // (the route table lives in HBM here)
         if (total > 0) {
             resolve(C0, 0);
             if (n_leaves > 1) resolve(C1, 1);
@@ -1036,7 +1094,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
             auto gen_rest = [&](int l, uint32_t se, uint32_t sp, uint32_t len, uint32_t k, uint32_t sx, uint32_t tl,
                                 uint32_t key, uint32_t base, uint32_t need, uint32_t emitted) -> uint32_t {
                 const bool is_change = l ? chg1 : chg0;
-                const uint32_t* rt = rtab + l * V;
+                const RT rt = route_facts(l);
                 uint32_t* rq = ring + (size_t)l * cv.rc * 2;
                 const uint16_t* rowk = nb.keys + (size_t)sx * dim;
                 const uint32_t mv0 = (se << 16) | sp;
@@ -1063,7 +1121,7 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                             if (ky != NBR_END) {
                                 const uint32_t y2 = ky & NBR_NODE_MASK;
                                 i2 = nearby_item_rt(is_change, node_slot.get(y2), se, sp, len, k, s_off, rt);
-                                hk = (uint64_t)m.mat[(size_t)ext_id(sx) * dim + ext_id(y2)] << 24;  // finite by construction of the index
+                                hk = (uint64_t)m.mat[(size_t)ext_id(sx) * dim + ext_id(y2)] << RT::KEY_SHIFT;  // finite by construction of the index
                             }
                             if (!__ballot(ky != NBR_END)) break;
                             topk_offer(tk, need, i2.w >= 1 ? (hk | i2.ord) : ~0ULL, i2.pay0);
@@ -1155,22 +1213,26 @@ __global__ __launch_bounds__(64 * WPB, WPE) void k_list_search_wave(ListModel m,
                     {
                         const uint32_t slot_any = node_slot.get(have ? (key & NBR_NODE_MASK) : 0u);  // unconditional read (node 0 for the lanes past the row)
                         const uint32_t slot = have ? slot_any : NODE_NONE;
-                        const uint32_t* rth = rtab + (hi ? V : 0);
+                        RT rth;
+                        if constexpr (ARANK)
+                            rth = RouteArith{hi ? perm_st1 : perm_st0, hi ? perm_inv1 : perm_inv0, (uint32_t)V, v_recip32};
+                        else
+                            rth = RouteTab{rtab + (hi ? V : 0)};
                         if constexpr (FAST) {
                             // leaf 0 = nearby change (lanes 0-31), leaf 1 = nearby swap (lanes 32-63): the two items of nearby_item_rt written as ONE, the
                             // facts they share read once and the half a lane belongs to folded into the predicates (nearby_change.rs:133-195, nearby_swap.rs)
                             const bool some = slot != NODE_NONE;
                             const uint32_t r2 = some ? slot >> 16 : 0u, dp = slot & 0xFFFFu;
                             const uint32_t len2 = s_off[r2 + 1] - s_off[r2];
-                            const uint32_t t = rth[r2];
+                            const uint32_t t = rth.word(r2);
                             const bool intra = r2 == se;
                             const uint32_t end_pay = (r2 << 16) | len2;
                             // change: the slot itself unless it is the source's own or the one behind it (dp - sp is 0 or 1, unsigned); swap: a later position of
                             // the source's list, or a list ranked after it
-                            const bool v0 = hi ? (intra ? dp > sp : (t & 0xFFFFu) > kk) : (!intra || dp - sp >= 2u);
+                            const bool v0 = hi ? (intra ? dp > sp : RT::rank(t) > kk) : (!intra || dp - sp >= 2u);
                             const bool v1 = !hi && dp + 1 == len2 && (!intra || len != sp + 1);  // change only: the end slot `len` probes element len - 1
                             it.w = some ? (uint32_t)v0 + (uint32_t)v1 : 0u;
-                            it.ord = intra ? ((hi || v0) ? dp : len) : ORD_INTER_BASE + (t >> 16) + dp;
+                            it.ord = intra ? ((hi || v0) ? dp : len) : RT::inter_ord(t, dp);
                             it.pay0 = (hi || v0) ? slot : end_pay;
                             it.pay1 = end_pay;
                         } else {

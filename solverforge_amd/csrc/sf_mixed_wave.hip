@@ -134,7 +134,7 @@ struct GCarve {
     // presence table behind the count table, as SCarve lays them out), 0 when the class has none
     // has_ruin 3: the list-preserving recreate only (sf_ruin_v2.h; the FAST instantiation): edge table + list-end edges + arena, no matrix row
     // node_global: the node -> slot table lives in HBM (GLeaves::node_tab)
-    __host__ __device__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0,
+    __host__ __device__ __forceinline__ GCarve(int n_scalar, int V, int n_cap, int dim_nearby, int kopt_nearby = 0, int n_leaves = GL, int has_ruin = 0, int dim = 0,
                                int prec_words = 0, int n_table = 0, int run_P = 0, int prec_groups = 0, bool node_global = false) {
         size_t o = 0;
         ring = o;  // the candidate rings live in HBM (GLeaves::ring / ringx) unless SF_MIXED_RING_LDS
@@ -396,6 +396,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
         pgs.indeg0 = (const pg_lds_i32*)gl.prec.indeg0, pgs.owner = (const pg_lds_i32*)gl.prec.owner, pgs.has_owner = gl.prec.owner != nullptr ? 1u : 0u;
         wave_sync();
     }
+    // ONE private copy of the constraint's parameter blocks for the out-of-line stages (prec_eval, plf_*, prec_trial_*): they take them by
+    // reference.  By value, each of their ~60 inlined call sites built its own 240-byte copy on the stack -- round 5's 5.1 - 5.9 KB of scratch
+    // per lane were mostly those copies, not spilled registers.
+    const PrecModel precm = gl.prec;
+    const PlfModel plfm = gl.plf;
     uint32_t* ring = SF_MIXED_RING_LDS ? (uint32_t*)(mem + cv.ring) : gl.ring + (size_t)r * GL * GRC * 2;  // [leaf][GRC][2]
     uint8_t* ringx = SF_MIXED_RING_LDS ? (uint8_t*)(mem + cv.ringx) : gl.ringx + (size_t)r * GL * GRC;   // [leaf][GRC]
     // Scoring stage of the FAST kernels (round 6): the trial deltas of the list candidates are computed right after a fill round, ONE LEAF AT A
@@ -538,15 +543,15 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     auto prec_run = [&]() -> PrecResult {
         if (prec_in_lds) {  // (nobody reads the pop order of this evaluation: the leaf and the recreate run plf_eval)
             if (gl.prec_static)
-                return prec_eval<uint16_t, PrecMemLds, false, true>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                return prec_eval<uint16_t, PrecMemLds, false, true>(precm, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
                                                                     (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16);
-            return prec_eval<uint16_t, PrecMemLds, false, false>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+            return prec_eval<uint16_t, PrecMemLds, false, false>(precm, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
                                                                  (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16);
         }
         if (prec_sweep) {  // committed evaluation + what the lane-per-trial sweep reads: list predecessors, order positions, round starts, prefix maxima
             __shared__ uint32_t s_psw_info[4][4];
             uint32_t* info = s_psw_info[wave_in_group];
-            const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, psw_lp, info, psw_roff);
+            const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(precm, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, psw_lp, info, psw_roff);
             wave_sync();
             const uint32_t pn = (uint32_t)gl.prec.n;
             psw.viol = uni(info[0]);
@@ -621,11 +626,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             psw.EL = (PREC_G int32_t*)(gl.prec.elane + (size_t)r * gl.prec.n * 64);
             return pr;
         }
-        if (!prec_incremental) return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
+        if (!prec_incremental) return prec_eval<uint16_t, PrecMemGlobal>(precm, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S);
         // committed evaluation: also the list predecessors, the owner violations, the cycle flag and the makespan multiplicity
         __shared__ uint32_t s_prec_info[4][2];
         uint32_t* info = s_prec_info[wave_in_group];
-        const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, pinc.LP, info);
+        const PrecResult pr = prec_eval<uint16_t, PrecMemGlobal>(precm, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, pinc.LP, info);
         wave_sync();
         pinc.viol = uni(info[0]);
         pinc.ok = uni(info[1]) == 0u;
@@ -640,11 +645,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
     auto prec_run_trial = [&]() -> PrecResult {
         if (prec_sweep) {  // (earliest, in-degree, queue, list successor) that are no part of the committed summary
             const size_t pb = (size_t)r * gl.prec.n;
-            return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, (int32_t*)(gl.prec.changed + pb), prec_D, gl.prec.stamp_q + pb,
+            return prec_eval<uint16_t, PrecMemGlobal>(precm, s_visits, s_off, V, (int32_t*)(gl.prec.changed + pb), prec_D, gl.prec.stamp_q + pb,
                                                       gl.prec.queue2 + pb);
         }
         if (!prec_incremental) return prec_run();
-        return prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, (int32_t*)pinc.CH, prec_D, prec_Q, pinc.Q2);
+        return prec_eval<uint16_t, PrecMemGlobal>(precm, s_visits, s_off, V, (int32_t*)pinc.CH, prec_D, prec_Q, pinc.Q2);
     };
     if (PREC) {
         const PrecResult pr = prec_run();
@@ -719,19 +724,19 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
         PrecResult pr;
         if (prec_in_lds && !roff && !lp) {  // the route-graph filter's evaluations: nobody reads their pop order (plf_closes_cycle walks the list successors)
             if (gl.prec_static)
-                pr = prec_eval<uint16_t, PrecMemLds, false, true>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                pr = prec_eval<uint16_t, PrecMemLds, false, true>(precm, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
                                                                   (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, nullptr, plf_info, nullptr);
             else
-                pr = prec_eval<uint16_t, PrecMemLds, false, false>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+                pr = prec_eval<uint16_t, PrecMemLds, false, false>(precm, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
                                                                    (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, nullptr, plf_info, nullptr);
         } else if (prec_in_lds && gl.prec_static)
-            pr = prec_eval<uint16_t, PrecMemLds, true, true>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
+            pr = prec_eval<uint16_t, PrecMemLds, true, true>(precm, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D,
                                                              (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, lp, plf_info, roff);
         else if (prec_in_lds)
-            pr = prec_eval<uint16_t, PrecMemLds>(gl.prec, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u16*)prec_Q16,
+            pr = prec_eval<uint16_t, PrecMemLds>(precm, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_i32*)prec_D, (prec_lds_u16*)prec_Q16,
                                                  (prec_lds_u16*)prec_S16, lp, plf_info, roff);
         else
-            pr = prec_eval<uint16_t, PrecMemGlobal>(gl.prec, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, lp, plf_info, roff);
+            pr = prec_eval<uint16_t, PrecMemGlobal>(precm, s_visits, s_off, V, prec_E, prec_D, prec_Q, prec_S, lp, plf_info, roff);
         wave_sync();
         cyclic = uni(plf_info[1]) != 0u;
         return pr;
@@ -786,9 +791,9 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             if (!base_cyc) {
                 const uint32_t rounds = uni(plf_info[2]);
                 if (prec_in_lds)
-                    plf_tails<PrecMemLds>(gl.prec, plf_r, (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, rounds);
+                    plf_tails<PrecMemLds>(precm, plf_r, (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, rounds);
                 else
-                    plf_tails<PrecMemGlobal>(gl.prec, plf_r, prec_Q, prec_S, rounds);
+                    plf_tails<PrecMemGlobal>(precm, plf_r, prec_Q, prec_S, rounds);
             }
             PHR(5)
             const int lvl_order = gl.prec.hard_level < gl.prec.mk_level ? 0 : (gl.prec.hard_level > gl.prec.mk_level ? 1 : 2);
@@ -802,10 +807,10 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                 if (!base_cyc) {
                     PlfSlotPick pk{0, 0, 0, 0, 0};
                     if (prec_in_lds)
-                        plf_best_slot<PrecMemLds>(pk, gl.prec, plf_r, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u16*)prec_S16, base.penalty,
+                        plf_best_slot<PrecMemLds>(pk, precm, plf_r, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u16*)prec_S16, base.penalty,
                                                   (int32_t)base.makespan, x, hooks, skip_empty, lvl_order);
                     else
-                        plf_best_slot<PrecMemGlobal>(pk, gl.prec, plf_r, s_visits, s_off, V, prec_E, prec_S, base.penalty, (int32_t)base.makespan, x, hooks,
+                        plf_best_slot<PrecMemGlobal>(pk, precm, plf_r, s_visits, s_off, V, prec_E, prec_S, base.penalty, (int32_t)base.makespan, x, hooks,
                                                      skip_empty, lvl_order);
                     PHR(6)
                     if (pk.found) {
@@ -937,8 +942,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                 const int ci = __ffsll((unsigned long long)fm) - 1;
                 fm &= fm - 1;
                 const uint32_t uu = (uint32_t)__builtin_amdgcn_readlane((int)u, ci), vv = (uint32_t)__builtin_amdgcn_readlane((int)v, ci);
-                closes = prec_in_lds ? plf_reaches<PrecMemLds>(gl.prec, plf.visit, plf.cnl, (prec_lds_u16*)prec_S16, vv, uu)
-                                     : plf_reaches<PrecMemGlobal>(gl.prec, plf.visit, plf.cnl, prec_S, vv, uu);
+                closes = prec_in_lds ? plf_reaches<PrecMemLds>(precm, plf.visit, plf.cnl, (prec_lds_u16*)prec_S16, vv, uu)
+                                     : plf_reaches<PrecMemGlobal>(precm, plf.visit, plf.cnl, prec_S, vv, uu);
             }
         }
         return closes;
@@ -1136,10 +1141,10 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             plf_cur_cyclic = cyc;
             const uint32_t rounds = uni(plf_info[2]);
             if (prec_in_lds)
-                plf_analyse<PrecMemLds>(gl.prec, gl.plf, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, rounds,
+                plf_analyse<PrecMemLds>(precm, plfm, plf, s_visits, s_off, V, (prec_lds_i32*)prec_E, (prec_lds_u16*)prec_Q16, (prec_lds_u16*)prec_S16, rounds,
                                         (int32_t)pr.makespan, cyc);
             else
-                plf_analyse<PrecMemGlobal>(gl.prec, gl.plf, plf, s_visits, s_off, V, prec_E, prec_Q, prec_S, rounds, (int32_t)pr.makespan, cyc);
+                plf_analyse<PrecMemGlobal>(precm, plfm, plf, s_visits, s_off, V, prec_E, prec_Q, prec_S, rounds, (int32_t)pr.makespan, cyc);
             plf.nb = uni(plf.nb), plf.C = uni(plf.C), plf.S = uni(plf.S), plf.ms_count = uni64(plf.ms_count), plf.mr_count = uni(plf.mr_count);
         }
         if (pgrp_T) {  // grouped trial evaluator: the committed list edges every trial of this step starts from
@@ -1149,6 +1154,11 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             pgrp_viol = uni(pv), pgrp_ready = uni(pr);
         }
         uint32_t exmask = ((1u << GL) - 1u) & ~((1u << nl) - 1u);  // bit l: leaf l is exhausted (wave-uniform mirror of LeafTab::EX)
+        // the scheduler's pull order inside one whole cycle, kept across the batches of a step: it is a function of the live set and the running
+        // weights, and whole cycles leave both as they found them -- only the pull-by-pull simulation changes them (and drops the cache).  Without
+        // it every batch after a child ran dry mid-cycle (the ruin leaf: ten candidates a step) re-ranked the children, nl^2 v_readlane + compares
+        uint64_t ro_cache = 0;
+        uint32_t ro_live = 0xFFFFFFFFu;  // the live mask `ro_cache` was computed for (all ones: none)
         // nearby leaves: entity order tables of this step (slot.rs:468-499), same layout as the wave engine
         if (has_nearby) {
             const uint32_t total = uni(s_off[V]);
@@ -2184,31 +2194,40 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                     // crossbar round trips), rank of every live child = how many live children are pulled before it
                     int32_t wmax = INT32_MIN, wmin = INT32_MAX;
                     uint64_t r_order = 0;  // live leaves by pull order inside a cycle, 4 bits each
-                    for (int j = 0; j < nl; ++j) {
-                        if (!((livem >> j) & 1u)) continue;
-                        const int32_t wj = __builtin_amdgcn_readlane(wc, j);
-                        wmax = wj > wmax ? wj : wmax;
-                        wmin = wj < wmin ? wj : wmin;
+                    const bool ro_hit = ro_live == livem;
+                    if (!ro_hit) {
+                        for (int j = 0; j < nl; ++j) {
+                            if (!((livem >> j) & 1u)) continue;
+                            const int32_t wj = __builtin_amdgcn_readlane(wc, j);
+                            wmax = wj > wmax ? wj : wmax;
+                            wmin = wj < wmin ? wj : wmin;
+                        }
                     }
-                    if (wmax - wmin < nlive) {
+                    if (ro_hit || wmax - wmin < nlive) {
                         uint32_t seen = 0;
-                        for (uint32_t pi = 0; pi < (uint32_t)nl; ++pi) {      // rotated position pi holds leaf i
-                            const uint32_t i = (uint32_t)(u_order >> (4u * pi)) & 15u;
-                            if (!((livem >> i) & 1u)) continue;
-                            if (wmax == wmin) {  // equal running weights (the steady state): the rotated order itself
-                                r_order |= (uint64_t)i << (4u * seen);
-                                seen += 1;
-                                continue;
+                        if (ro_hit) {
+                            r_order = ro_cache;
+                        } else {
+                            for (uint32_t pi = 0; pi < (uint32_t)nl; ++pi) {      // rotated position pi holds leaf i
+                                const uint32_t i = (uint32_t)(u_order >> (4u * pi)) & 15u;
+                                if (!((livem >> i) & 1u)) continue;
+                                if (wmax == wmin) {  // equal running weights (the steady state): the rotated order itself
+                                    r_order |= (uint64_t)i << (4u * seen);
+                                    seen += 1;
+                                    continue;
+                                }
+                                const int32_t wi = __builtin_amdgcn_readlane(wc, (int)i);
+                                uint32_t rank = 0;
+                                for (uint32_t pj = 0; pj < (uint32_t)nl; ++pj) {
+                                    const uint32_t j = (uint32_t)(u_order >> (4u * pj)) & 15u;
+                                    if (!((livem >> j) & 1u)) continue;
+                                    const int32_t wj = __builtin_amdgcn_readlane(wc, (int)j);
+                                    rank += (wj > wi || (wj == wi && pj < pi)) ? 1u : 0u;
+                                }
+                                r_order |= (uint64_t)i << (4u * rank);
                             }
-                            const int32_t wi = __builtin_amdgcn_readlane(wc, (int)i);
-                            uint32_t rank = 0;
-                            for (uint32_t pj = 0; pj < (uint32_t)nl; ++pj) {
-                                const uint32_t j = (uint32_t)(u_order >> (4u * pj)) & 15u;
-                                if (!((livem >> j) & 1u)) continue;
-                                const int32_t wj = __builtin_amdgcn_readlane(wc, (int)j);
-                                rank += (wj > wi || (wj == wi && pj < pi)) ? 1u : 0u;
-                            }
-                            r_order |= (uint64_t)i << (4u * rank);
+                            ro_cache = r_order;
+                            ro_live = livem;
                         }
                         // my pull t = lane: cycle t / nlive, child = the (t % nlive)-th leaf of the cycle
                         const uint32_t cyc = lane / (uint32_t)nlive, slot = lane % (uint32_t)nlive;
@@ -2234,6 +2253,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                     // Pull-by-pull simulation with the leaf table in registers (lane l = leaf l): one pull is a handful of
                     // DPP / readlane instructions instead of a dozen dependent LDS round trips.
                     const bool isleaf = lane < (uint32_t)nl;
+                    ro_live = 0xFFFFFFFFu;  // the running weights change below
                     int32_t wc = isleaf ? (int32_t)lt.w[lane * 16 + LeafTab::WCUR] : 0;
                     const uint32_t hd = isleaf ? lt.w[lane * 16 + LeafTab::HEAD] : 0u, tlv = isleaf ? lt.w[lane * 16 + LeafTab::TAIL] : 0u;
                     const uint32_t dn = isleaf ? lt.w[lane * 16 + LeafTab::DONE] : 1u;
@@ -2427,7 +2447,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                         const uint64_t cm_ = __ballot(cand);
                         if (cm_) {
                             int64_t tp = 0, tm_ = 0;
-                            prec_trial_sweep64<uint16_t>(gl.prec, psw, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, cand, (my_kind == 4 || my_kind == 16) ? 2 : 3, m0 >> 16, m0 & 0xFFFFu,
+                            prec_trial_sweep64<uint16_t>(precm, psw, (const PREC_L uint16_t*)s_visits, (const PREC_L uint32_t*)s_off, cand, (my_kind == 4 || my_kind == 16) ? 2 : 3, m0 >> 16, m0 & 0xFFFFu,
                                                          m1 >> 16, m1 & 0xFFFFu, tp, tm_);
                             if (cand) {
 #pragma unroll
@@ -2458,7 +2478,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                         const uint32_t cx = (uint32_t)__builtin_amdgcn_readlane((int)mx_, ci);
                         if (prec_incremental && (ck == 4 || ck == 16 || ck == 8 || ck == 32)) {  // list change / swap: no apply, no undo
                             PrecResult pi;
-                            if (prec_trial_inc<uint16_t>(gl.prec, pinc, s_visits, s_off, (ck == 4 || ck == 16) ? 2 : 3, ca >> 16, ca & 0xFFFFu, cb >> 16,
+                            if (prec_trial_inc<uint16_t>(precm, pinc, s_visits, s_off, (ck == 4 || ck == 16) ? 2 : 3, ca >> 16, ca & 0xFFFFu, cb >> 16,
                                                          cb & 0xFFFFu, pi)) {
                                 if ((int)lane == ci) {
 #pragma unroll

@@ -97,7 +97,7 @@ struct ScalarModel {
     int32_t run_mode = 0, run_lo = 0, run_hi = 0;
     int64_t run_cap = 0;
     const int32_t* run_point = nullptr;  // [n] point of every entity, in 0..run_P
-    __host__ __device__ bool tables() const { return sj_level >= 0 || grp_level >= 0 || ex_level >= 0 || run_level >= 0; }
+    __host__ __device__ __forceinline__ bool tables() const { return sj_level >= 0 || grp_level >= 0 || ex_level >= 0 || run_level >= 0; }
     // per-replica committed state
     int32_t* vals = nullptr;        // [R][n]  (-1 = None)
     int64_t* score = nullptr;       // [R][4]
