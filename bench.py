@@ -118,6 +118,11 @@ PMC_PASSES = [
     ["WRITE_SIZE"],
 ]
 PMC_BUDGET_S = 240.0
+# counter record of the M2 leg's kernel (the generic N-leaf engine): the child replays the leg's first M2_PMC_WARM + M2_PMC_TIMED launches (same seeds, same
+# trajectory) under rocprofv3; the parent times the same launch window of its own, unprofiled, leg with HIP events
+M2_PMC_WARM, M2_PMC_TIMED = 60, 6
+M2_PMC_PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"], ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"],
+                 ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]]
 # rocprofv3 --pmc crashes (SIGSEGV inside the tool, 8 of 8 runs) on launches of more than one residency of this kernel (>= 12,288 replicas
 # = 3,072 workgroups) on this pool, and collects fine at 6,144 (profiles/r04f_pmc_crash_notes.txt).  The counter passes therefore run the
 # SAME command at one residency and the line scales their per-launch counters by the work ratio (consumed candidates of the parent's
@@ -355,16 +360,17 @@ def main():
     ap.add_argument("--solve-policy", choices=sorted(M2_POLICIES), default="default",
                     help="M2 leaves on both sides: default = the reference's seven-leaf default list policy, default6 = without ruin, "
                          "nearby2 = the two-leaf nearby union M1 is timed on")
-    ap.add_argument("--tuned-seconds", type=float, default=60.0,
+    ap.add_argument("--tuned-seconds", type=float, default=30.0,
                     help="M2 extension leg: wall-clock budget of the tuned configuration (0 = skip); see TUNED below")
     ap.add_argument("--c5-seconds", type=float, default=5.0,
                     help="side leg: seconds of the same 2-leaf search on BASELINE config 5 (CVRP-5000 / 500, 2,816 replicas per GPU; 0 = skip)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline fields stay null)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-out", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child-m2", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
-    if args.pmc_child:  # a counter pass that hangs (rocprofv3 does now and then on this pool) leaves a Python stack in its stderr
+    if args.pmc_child or args.pmc_child_m2:  # a counter pass that hangs (rocprofv3 does now and then on this pool) leaves a Python stack in its stderr
         import faulthandler
 
         faulthandler.dump_traceback_later(30, exit=False)
@@ -420,6 +426,26 @@ def main():
                                      accepted_count_limit=limit))
         return d
 
+    if args.pmc_child_m2:  # counter pass of the M2 leg's kernel: the leg's first launches again, nothing else
+        prob2 = problem if args.solve_start == "roundrobin" else dict(problem, routes=[[] for _ in problem["routes"]])
+        d2 = new_director(prob2, M2_POLICIES[args.solve_policy], M2_REPLICAS[args.solve_policy])
+        d2.calculate_score()
+        if args.solve_start != "roundrobin":
+            d2.construct_list_clarke_wright(0, prob2["customers"], 1 if args.solve_start == "savings_capacity" else 0)
+            d2.construct_list_k_opt(0, 2, 1)
+        d2.phase_start()
+        for _ in range(M2_PMC_WARM):
+            d2.solve_moves(1 << 20, args.solve_budget, sync=True)
+        b2 = d2.total_stats()
+        for _ in range(M2_PMC_TIMED):
+            d2.solve_moves(1 << 20, args.solve_budget, sync=True)
+        a2 = d2.total_stats()
+        if args.pmc_child_out:
+            with open(args.pmc_child_out, "w") as f:
+                json.dump({"moves_evaluated": a2["moves_evaluated"] - b2["moves_evaluated"], "candidates_scored": a2["candidates_scored"] - b2["candidates_scored"],
+                           "launches": M2_PMC_TIMED, "ls_steps": a2["step_count"] - b2["step_count"], "replicas": M2_REPLICAS[args.solve_policy]}, f)
+        d2.close()
+        return
     d = new_director()
     start_score = d.calculate_score()[0].tolist()
     engine = {1: "block", 2: "wave"}[d.engine()]
@@ -491,9 +517,18 @@ def main():
         d2.phase_start()
         n_launch = 0
         curve = []  # (seconds since the leg started, best score over this rank's replicas) at every improvement: `seconds_to_cpu_best` reads it
+        m2_window = None  # kernel time and work of launches [M2_PMC_WARM, M2_PMC_WARM + M2_PMC_TIMED): the window the counter passes replay
         while time.perf_counter() - t1 < args.solve_seconds:
+            if n_launch == M2_PMC_WARM:
+                d2.profile_solve()
+                m2_wb = d2.total_stats()
             d2.solve_moves(1 << 20, args.solve_budget, sync=True)  # work-balanced launches (sf_solve_moves)
             n_launch += 1
+            if n_launch == M2_PMC_WARM + M2_PMC_TIMED:
+                wms, wn = d2.profile_solve()
+                m2_wa = d2.total_stats()
+                m2_window = {"kernel_ms": wms, "launches": wn, "moves_evaluated": m2_wa["moves_evaluated"] - m2_wb["moves_evaluated"],
+                             "candidates_scored": m2_wa["candidates_scored"] - m2_wb["candidates_scored"], "ls_steps": m2_wa["step_count"] - m2_wb["step_count"]}
             bnow = max(tuple(int(v) for v in s) for s in d2.best_scores())  # (a 200 KB copy per ~40 ms launch)
             if not curve or bnow > curve[-1][1]:
                 curve.append((time.perf_counter() - t1, bnow))
@@ -504,7 +539,7 @@ def main():
             "best_score_local": list(max(tuple(int(v) for v in s) for s in d2.best_scores())),
             "moves_per_s": st2["moves_evaluated"] / gpu_s,
             "start": args.solve_start, "start_score": m2_start, "construction_seconds": construct_s,
-            "leaves": list(m2_leaves), "replicas": M2_REPLICAS[args.solve_policy] or args.replicas, "curve": curve,
+            "leaves": list(m2_leaves), "replicas": M2_REPLICAS[args.solve_policy] or args.replicas, "curve": curve, "window": m2_window,
         }
         if cpu_thread:
             cpu_thread.join(timeout=args.solve_seconds + 30)
@@ -852,6 +887,45 @@ def main():
                 "what": f"the reference's out-of-the-box CVRP solve: {'+'.join(solve['leaves'])} ({args.solve_policy}), LateAcceptance(400)+AcceptedCount(256), "
                         f"{solve['replicas']} replicas per GPU, sustained over the {args.solve_seconds:.0f} s M2 leg (generic N-leaf engine)",
                 "moves_per_s_rank0": solve["moves_per_s"], "moves_per_ls_step": solve["moves_evaluated"] / max(solve["ls_steps"], 1)}
+            # the same three issue rooflines + memory-side traffic for THIS kernel, over launches [M2_PMC_WARM, +M2_PMC_TIMED) of the leg: time from the
+            # leg's own HIP events, counters from rocprofv3 passes over a replay of the same launches (same seeds -> the same work)
+            win = solve.get("window")
+            roof2 = {"bound": None, "frac": None, "window": win, "kernel": "k_mixed_search_wave"}
+            if world == 1 and not args.no_pmc and win and win["launches"] == M2_PMC_TIMED and win["kernel_ms"] > 0:
+                m2_argv = ["--gpus", "1", "--customers", str(args.customers), "--vehicles", str(args.vehicles), "--capacity", str(args.capacity), "--seed", str(args.seed),
+                           "--solve-start", args.solve_start, "--solve-policy", args.solve_policy, "--solve-budget", str(args.solve_budget), "--pmc-child-m2"]
+                pm2, info2 = pmc_collect(m2_argv, M2_PMC_WARM, M2_PMC_TIMED, "k_mixed_search_wave<", timeout_s=60, passes=M2_PMC_PASSES, attempts=2, budget_s=100.0)
+                if pm2 is None:
+                    roof2["pmc_source"] = f"none (live rocprofv3 passes failed: {info2})"
+                else:
+                    ls2 = win["kernel_ms"] * 1e-3 / win["launches"]
+                    cw2 = (info2 or {}).get("child_work") or {}
+                    fr2 = {"valu-issue": (pm2.get("SQ_INSTS_VALU", 0.0) / ls2, VALU_PEAK), "salu-issue": (pm2.get("SQ_INSTS_SALU", 0.0) / ls2, SALU_PEAK),
+                           "lds-issue": (pm2.get("SQ_INSTS_LDS", 0.0) / ls2, LDS_PEAK)}
+                    roof2.update({"valu_frac": fr2["valu-issue"][0] / VALU_PEAK, "salu_frac": fr2["salu-issue"][0] / SALU_PEAK, "lds_issue_frac": fr2["lds-issue"][0] / LDS_PEAK,
+                                  "avg_launch_ms": ls2 * 1e3, "counters_per_launch": pm2,
+                                  "replay_matches_leg": cw2.get("moves_evaluated") == win["moves_evaluated"],
+                                  "pmc_source": f"rocprofv3 --pmc passes over a replay of launches {M2_PMC_WARM}..{M2_PMC_WARM + M2_PMC_TIMED - 1} of this leg "
+                                                "(bench.py --pmc-child-m2), kernel time from the leg's own HIP events"})
+                    per2 = win["moves_evaluated"] / win["launches"]
+                    roof2["per_candidate"] = {"salu": pm2.get("SQ_INSTS_SALU", 0.0) / per2, "valu": pm2.get("SQ_INSTS_VALU", 0.0) / per2,
+                                              "lds": pm2.get("SQ_INSTS_LDS", 0.0) / per2}
+                    if "TCC_EA0_RDREQ_sum" in pm2 and "TCC_EA0_WRREQ_sum" in pm2:
+                        tr2 = 2.0 * pm2["TCC_EA0_RDREQ_sum"] * 64.0 + pm2["TCC_EA0_WRREQ_sum"] * 64.0
+                        roof2["traffic"] = tr2
+                        roof2["hbm_frac"] = tr2 / ls2 / 1e9 / HBM_PEAK_GBS
+                        roof2["traffic_bytes_per_candidate"] = tr2 / per2
+                        fr2["hbm"] = (tr2 / ls2, HBM_PEAK_GBS * 1e9)
+                    b2 = max(fr2, key=lambda k: fr2[k][0] / fr2[k][1])
+                    roof2.update({"bound": b2, "achieved": fr2[b2][0] / 1e9, "peak": fr2[b2][1] / 1e9, "unit": "GB/s" if b2 == "hbm" else "G wave-instr/s",
+                                  "frac": fr2[b2][0] / fr2[b2][1]})
+                    if pm2.get("SQ_WAVE_CYCLES"):
+                        wc2 = pm2["SQ_WAVE_CYCLES"]
+                        roof2["wave_cycle_shares"] = {"active": pm2.get("SQ_ACTIVE_INST_ANY", 0) / wc2, "wait_mem": pm2.get("SQ_WAIT_ANY", 0) / wc2,
+                                                      "wait_issue": pm2.get("SQ_WAIT_INST_ANY", 0) / wc2}
+                    roof2["kernel"] = (info2 or {}).get("kernel", roof2["kernel"])
+                    roof2["kernel_resources"] = {k: v for k, v in (info2 or {}).items() if k not in ("child_work",)}
+            side["cvrp1000_default_list_policy"]["roofline"] = roof2
         if c5 is not None:
             side["cvrp5000_nearby2"] = c5
         if side:

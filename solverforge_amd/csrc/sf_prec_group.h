@@ -269,8 +269,9 @@ extern __device__ unsigned long long g_phase[8];
 // A Kahn round is four dependent LDS round trips: the popped node; its record, earliest start and list successor; the relaxations of the
 // first fixed successor and of the list successor (issued together); the queue writes.  Pop order is free (the result does not depend on it).
 template <class VT>
-__device__ __noinline__ void prec_eval_grouped(const PgrpStatic& ps, uint32_t n, int V, const PREC_L VT* visits, const PREC_L uint32_t* off, unsigned char* lds_base, uint32_t gshift,
+__device__ __noinline__ void prec_eval_grouped(const PgrpStatic& ps_ref, uint32_t n, int V, const PREC_L VT* visits, const PREC_L uint32_t* off, unsigned char* lds_base, uint32_t gshift,
                                                const PgrpMove mv, int64_t fixed_pen, uint32_t viol_c, uint32_t n_ready, int64_t& out_pen, int64_t& out_mk, bool& out_cyclic) {
+    const PgrpStatic ps = ps_ref;  // (a private copy the optimizer can keep in registers: through the reference every field is re-read after each store)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t G = 1u << gshift, lg = lane & (G - 1u), g = lane >> gshift;
     const uint64_t gmask = (G >= 64u ? ~0ull : ((1ull << G) - 1ull)) << (g << gshift);  // this group's lanes

@@ -83,8 +83,10 @@ __device__ __forceinline__ int32_t plf_aldi(const int32_t* p) { return __hip_ato
 // One step's analysis.  E / Q / S = earliest starts, pop order, list successor of the committed evaluation that just ran
 // (rounds in t.roff); `cyclic` = that evaluation left nodes unprocessed: no blocks at all (analysis.rs:61-70).
 template <class MEM>
-__device__ __noinline__ void plf_analyse(const PrecModel& pm, const PlfModel& pl, PlfRep& t, const uint16_t* visits, const uint32_t* off, int V,
+__device__ __noinline__ void plf_analyse(const PrecModel& pm_ref, const PlfModel& pl_ref, PlfRep& t, const uint16_t* visits, const uint32_t* off, int V,
                                          typename MEM::I32 E, typename MEM::U32 Q, typename MEM::U32 S, uint32_t rounds, int32_t mk, bool cyclic) {
+    const PrecModel pm = pm_ref;  // (private copies: see prec_eval)
+    const PlfModel pl = pl_ref;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     t.nb = t.C = t.S = t.ms_count = t.mr_count = 0;
@@ -276,7 +278,8 @@ __device__ __noinline__ void plf_analyse(const PrecModel& pm, const PlfModel& pl
 // first, 64 frontier nodes per round; visit / queue = n words each.  The slow half of the route-graph filter: only a cyclic working
 // state needs it (reaches_with_route_delta, precedence_route.rs:519-556, over the graph after the move).
 template <class MEM>
-__device__ __noinline__ bool plf_reaches(const PrecModel& pm, uint32_t* visit, uint32_t* queue, typename MEM::U32 S, uint32_t from, uint32_t target) {
+__device__ __noinline__ bool plf_reaches(const PrecModel& pm_ref, uint32_t* visit, uint32_t* queue, typename MEM::U32 S, uint32_t from, uint32_t target) {
+    const PrecModel pm = pm_ref;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     for (uint32_t i = lane; i < n; i += 64) visit[i] = 0;
@@ -339,7 +342,8 @@ struct PlfSlotPick {
 };
 // the backward pass of a recreate round (once per round: the lists are the same for every remaining element)
 template <class MEM>
-__device__ __noinline__ void plf_tails(const PrecModel& pm, const PlfRep& t, typename MEM::U32 Q, typename MEM::U32 S, uint32_t rounds) {
+__device__ __noinline__ void plf_tails(const PrecModel& pm_ref, const PlfRep& t, typename MEM::U32 Q, typename MEM::U32 S, uint32_t rounds) {
+    const PrecModel pm = pm_ref;
     const uint32_t lane = threadIdx.x & 63u;
     int32_t* const TAIL = t.latest;
     plf_gsync();
@@ -363,9 +367,10 @@ __device__ __noinline__ void plf_tails(const PrecModel& pm, const PlfRep& t, typ
     }
 }
 template <class MEM, class VT = uint16_t>
-__device__ __noinline__ void plf_best_slot(PlfSlotPick& r, const PrecModel& pm, const PlfRep& t, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E,
+__device__ __noinline__ void plf_best_slot(PlfSlotPick& r, const PrecModel& pm_ref, const PlfRep& t, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E,
                                                   typename MEM::U32 S, int64_t base_pen, int32_t base_mk, uint32_t x, bool hooks, bool skip_empty,
                                                   int order /* 0: penalty first, 1: makespan first, 2: one level */) {
+    const PrecModel pm = pm_ref;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     int32_t* const TAIL = t.latest;
@@ -655,7 +660,8 @@ __device__ __forceinline__ uint32_t plf_nth_dest(uint32_t d, uint32_t source, bo
     return dest;
 }
 // block-local move index -> move (cursor.rs:83-179 over coordinates.rs:132-252)
-__device__ __noinline__ void plf_decode_block(const PlfBlock& bl, uint32_t idx, PlfMove& m) {
+__device__ __noinline__ void plf_decode_block(const PlfBlock& bl_ref, uint32_t idx, PlfMove& m) {
+    const PlfBlock bl = bl_ref;
     m.a = m.b = bl.e;
     m.ext = 0;
     m.n = 0;

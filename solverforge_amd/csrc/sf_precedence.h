@@ -145,8 +145,12 @@ extern __device__ unsigned long long g_rphase2[8];
 // order, not in ascending node order.  The result does not depend on the pop order.
 // (lint: small-pod-return -- see above)
 template <class VT, class MEM = PrecMemGlobal, bool ORDERED = true, bool STATIC_LDS = false>
-__device__ __noinline__ PrecResult prec_eval(const PrecModel& pm, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
+__device__ __noinline__ PrecResult prec_eval(const PrecModel& pm_ref, const VT* visits, const uint32_t* off, int V, typename MEM::I32 E, typename MEM::I32 D,
                                              typename MEM::U32 Q, typename MEM::U32 S, uint32_t* LP = nullptr, uint32_t* out_info = nullptr, uint32_t* ROFF = nullptr) {
+    // the parameter block arrives by reference (one copy per kernel instead of one 240-byte stack copy per inlined call site); the stage works on a
+    // private copy of it -- not escaping, so the optimizer splits it into the fields this stage uses and keeps them in registers; read through the
+    // reference, every field would have to be re-read after each store to the scratch arrays (they may alias)
+    const PrecModel pm = pm_ref;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     const auto vis = MEM::lists(visits);
@@ -513,8 +517,9 @@ __device__ __forceinline__ uint32_t prec_count_makespan(const PrecModel& pm, con
 // One trial: ck = 2 list change (a, i) -> (b, j) (j in pre-removal coordinates), ck = 3 list swap (a, i) <-> (b, j), against
 // the committed lists `visits` / `off`.  Returns false when the incremental path does not apply (the caller evaluates fully).
 template <class VT>
-__device__ __noinline__ bool prec_trial_inc(const PrecModel& pm, PrecInc& st, const VT* visits, const uint32_t* off, int ck, uint32_t a, uint32_t i,
+__device__ __noinline__ bool prec_trial_inc(const PrecModel& pm_ref, PrecInc& st, const VT* visits, const uint32_t* off, int ck, uint32_t a, uint32_t i,
                                             uint32_t b, uint32_t j, PrecResult& out) {
+    const PrecModel pm = pm_ref;
     typedef PrecMemGlobal M;
     if (!st.ok || (ck != 2 && ck != 3)) return false;
     const uint32_t lane = threadIdx.x & 63u;
@@ -850,8 +855,10 @@ struct LaneOverlay {  // one trial's changed list neighbours, in this lane's reg
 // Lanes with `cand` hold one candidate each (ck 2 = list change (a, i) -> (b, j), 3 = list swap); the others idle along.
 // Returns per lane the constraint's (penalty, makespan) of the trial state.
 template <class VT>
-__device__ __noinline__ void prec_trial_sweep64(const PrecModel& pm, const PrecSweep& st, const PREC_L VT* visits, const PREC_L uint32_t* off, bool cand, int ck, uint32_t a,
+__device__ __noinline__ void prec_trial_sweep64(const PrecModel& pm_ref, const PrecSweep& st_ref, const PREC_L VT* visits, const PREC_L uint32_t* off, bool cand, int ck, uint32_t a,
                                                 uint32_t i, uint32_t b, uint32_t j, int64_t& out_pen, int64_t& out_mk) {
+    const PrecModel pm = pm_ref;
+    const PrecSweep st = st_ref;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = (uint32_t)pm.n;
     LaneOverlay ov;

@@ -1223,7 +1223,7 @@ template <class VT>
 struct SCarve {
     size_t vals, ring, tsum, tcnt, tpt, total;
     // n_table = n_values when a value-keyed constraint exists, else 0; run_P = points of the consecutive-runs table, else 0
-    __host__ __device__ SCarve(int n, int n_table, int run_P = 0) {
+    __host__ __device__ __forceinline__ SCarve(int n, int n_table, int run_P = 0) {
         size_t o = 0;
         ring = o;
         o = align_up(o + sizeof(uint32_t) * 2 * SRC * 2, 16);
