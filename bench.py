@@ -94,10 +94,11 @@ M2_POLICIES = {
     "default6": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"),
     "nearby2": ("nearby_change", "nearby_swap"),
 }
-M2_REPLICAS = {"default": 6144, "default6": 12288, "nearby2": 6144}  # replicas per GPU of the M2 leg (round 4: the RUIN instantiation holds 8 per CU;
-# the six-leaf FAST instantiation 12 per CU and gains from several residencies per launch, profiles/r04g_generic_replicas.jsonl)
+M2_REPLICAS = {"default": 12288, "default6": 24576, "nearby2": 6144}  # replicas per GPU of the M2 leg: four residencies of the RUIN instantiation's 12 per CU /
+# six of the six-leaf kernel's 16, with 100,000 candidates per replica per launch (round 6, profiles/r06g_launch_shapes.txt: seven-leaf 6.26 G moves/s at
+# 6,144 x 30,000 -> 7.15 G at 12,288 x 100,000; a launch ends with its slowest replicas, more and longer-running workgroups amortise that tail)
 # M2 extension leg (module docstring): what is varied against the parity leg, and nothing else
-M1_REPLICAS = 24576  # the timed M1 leg: four residencies of 24 replicas per CU
+M1_REPLICAS = 98304  # the timed M1 leg: sixteen residencies of 24 replicas per CU (round 6, profiles/r06g_launch_shapes.txt: 24,576 49.9 G, 49,152 52.3 G, 98,304 53.3 G)
 C5_REPLICAS = 2816  # the CVRP-5000 side leg: 11 replicas per CU (launch mode 6)
 TUNED = {"leaves": ("nearby_change", "nearby_swap"), "late_acceptance_size": 5000, "accepted_count_limit": 1, "replicas": 1024,
          "migration_period_s": 5.0, "migration_replace_fraction": 0.5, "migration_elite": 8, "launch_move_budget": 200_000}
@@ -120,7 +121,7 @@ PMC_PASSES = [
 PMC_BUDGET_S = 240.0
 # counter record of the M2 leg's kernel (the generic N-leaf engine): the child replays the leg's first M2_PMC_WARM + M2_PMC_TIMED launches (same seeds, same
 # trajectory) under rocprofv3; the parent times the same launch window of its own, unprofiled, leg with HIP events
-M2_PMC_WARM, M2_PMC_TIMED = 60, 6
+M2_PMC_WARM, M2_PMC_TIMED = 20, 4  # (2 M candidates per replica in: the long-step regime the leg spends most of its time in)
 M2_PMC_PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"], ["TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"],
                  ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"]]
 # rocprofv3 --pmc crashes (SIGSEGV inside the tool, 8 of 8 runs) on launches of more than one residency of this kernel (>= 12,288 replicas
@@ -338,9 +339,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=M1_REPLICAS,
-                    help="independent searches per GPU and launch (24576 = 4 x 24 per CU: the COMPACT wave kernel runs 6 waves per SIMD at CVRP-1000, "
-                         "and a launch of several residencies keeps every CU busy while the slower replicas of the first finish -- one residency "
-                         "alone leaves a quarter of the slot time idle, profiles/r04c_wave_replica_sweep.txt)")
+                    help="independent searches per GPU and launch (98304 = 16 x 24 per CU: the COMPACT wave kernel runs 6 waves per SIMD at CVRP-1000, "
+                         "and a launch of many residencies keeps every CU busy while the slower replicas of the earlier ones finish -- one residency "
+                         "alone leaves a quarter of the slot time idle, profiles/r04c_wave_replica_sweep.txt, profiles/r06g_launch_shapes.txt)")
     ap.add_argument("--ls-steps", type=int, default=200, help="local-search steps per launch")
     ap.add_argument("--customers", type=int, default=1000)
     ap.add_argument("--vehicles", type=int, default=100)
@@ -356,7 +357,7 @@ def main():
                     help="M2 start state: the round-robin fill M1 is timed on, or the device's Clarke-Wright savings construction "
                          "from empty routes (built inside the budget, on both sides): savings = the reference's stock savings hooks "
                          "(structural feasibility only), savings_capacity = EXTENSION, a capacity-checking feasible hook")
-    ap.add_argument("--solve-budget", type=int, default=30_000, help="M2: candidates per replica per launch (sf_solve_moves)")
+    ap.add_argument("--solve-budget", type=int, default=100_000, help="M2: candidates per replica per launch (sf_solve_moves)")
     ap.add_argument("--solve-policy", choices=sorted(M2_POLICIES), default="default",
                     help="M2 leaves on both sides: default = the reference's seven-leaf default list policy, default6 = without ruin, "
                          "nearby2 = the two-leaf nearby union M1 is timed on")

@@ -178,9 +178,11 @@ typedef enum sf_constraint_kind {
      * operation assigned to a machine that does not schedule it).  `param` = descriptor of the list class; the scalar variable's values are
      * the owner indices (n_values == owners), the list elements are the scalar class's entity ids.  A scalar move changes the A side's key, a
      * list move the B side's filter: both are priced on the device (generic engine), the committed match table is an entity -> holding
-     * list map in HBM.  Fused / traced search, sf_step_generate, sf_initialize / sf_evaluate_all / sf_evaluate_each; the host-driven entry
-     * points (sf_step_evaluate, sf_apply, sf_step_decide*, compound candidates, construction) and unions with ruin / precedence leaves
-     * return SF_ERR_UNSUPPORTED for a model that declares it */
+     * list map in HBM.  Fused / traced search, sf_step_generate, sf_initialize / sf_evaluate_all / sf_evaluate_each, and (round 6) the
+     * host-driven entry points sf_step_evaluate / sf_step_evaluate_compound / sf_apply / sf_apply_compound, which rebuild the map of the one
+     * replica per call and price a record from its coordinates.  Still SF_ERR_UNSUPPORTED for a model that declares it: SF_MOVE_LIST_RUIN
+     * records and unions with a ruin or critical-path leaf (the recreate does not price the join), the construction phases; sf_step_decide*
+     * takes scalar-only models anyway */
     SF_C_CROSS_OWNER_MATCH = 18
 } sf_constraint_kind;
 

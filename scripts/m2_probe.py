@@ -20,7 +20,8 @@ timed = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 budget = int(sys.argv[5]) if len(sys.argv) > 5 else 30000
 p = datasets.make_cvrp(1000, 100, 55, seed=0)
 p["routes"] = [[] for _ in p["routes"]]
-d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves)
+ruin_mps = int(os.environ.get("SF_PROBE_RUIN_MPS", "10"))  # diagnostics: ruin candidates per step (the default policy's 10): the marginal cost of a ruin trial
+d = sfa.build_cvrp(p, n_replicas=R, leaves=leaves, ruin=(2, 5, ruin_mps))
 d.configure(sfa.SolverConfig(random_seed=0))
 d.calculate_score()
 d.construct_list_clarke_wright(0, p["customers"], 1)
@@ -44,7 +45,7 @@ ms, n = d.profile_solve()
 a = d.total_stats()
 mv = a["moves_evaluated"] - b["moves_evaluated"]
 st = a["step_count"] - b["step_count"]
-out = {"replicas": R, "leaves": len(leaves), "start_score": start, "budget": budget, "timed_launches": timed, "kernel_ms_per_launch": round(ms / max(n, 1), 3),
+out = {"replicas": R, "leaves": len(leaves), "ruin_moves_per_step": ruin_mps, "start_score": start, "budget": budget, "timed_launches": timed, "kernel_ms_per_launch": round(ms / max(n, 1), 3),
        "G_moves_per_s_wall": round(mv / dt / 1e9, 3), "G_moves_per_s_kernel": round(mv / ms / 1e6, 3), "moves_per_step": round(mv / max(st, 1), 1),
        "steps_per_replica_per_launch": round(st / R / timed, 2), "sources_per_step": round((a["sources_scanned"] - b["sources_scanned"]) / max(st, 1), 1),
        "scored_per_step": round((a["candidates_scored"] - b["candidates_scored"]) / max(st, 1), 1),

@@ -102,6 +102,7 @@ struct sf_ctx {
     int xown_level = -1;             // SF_C_CROSS_OWNER_MATCH of a mixed model: level / weight / the [R][n_scalar] entity -> holding list map
     int64_t xown_weight = 0;
     uint16_t* d_xown_tab = nullptr;
+    int64_t* d_xown_delta = nullptr;  // sf_apply / sf_apply_compound: the join's delta of the move being committed (xown_price)
     std::vector<std::pair<int, std::string>> providers;  // host-side providers declared through sf_provider_declare
     uint32_t* d_node_tab32 = nullptr;  // [R][dim] node -> slot tables of the generic engine's FAST + ruin kernel (GLeaves::node_tab)
     struct WaveFix {  // what differs in lm_wave from lm (applied at launch: the per-replica state pointers of lm may be set later)
@@ -1144,7 +1145,9 @@ static int launch_list_wave_t(sf_ctx* ctx, const SearchParams& p, int n_replicas
         WCarve cvx(ctx->lm.V, ctx->lm.n_cap, ctx->lm.dim, list_max_nearby(ctx), compact, node_global);
         size_t best = 0;
         wpb_out = 1;
-        for (int w = 1; w <= WPB; ++w) {  // the workgroup size that keeps the most replicas resident (a workgroup's LDS is allocated whole)
+        const char* wenv = std::getenv("SF_AMD_WAVE_WPB");  // diagnostics: cap the replicas per workgroup (A/B of the workgroup shape)
+        const int wmax = wenv && std::atoi(wenv) >= 1 && std::atoi(wenv) < WPB ? std::atoi(wenv) : WPB;
+        for (int w = 1; w <= wmax; ++w) {  // the workgroup size that keeps the most replicas resident (a workgroup's LDS is allocated whole)
             const size_t per_wg = cvx.total * (size_t)w + (fast ? 0 : 1024);  // + the static annealing state (the FAST instantiations have none)
             if (cvx.total * (size_t)w > SF_LDS_BUDGET) break;
             size_t groups = (160 * 1024) / per_wg;
@@ -1442,7 +1445,9 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (replica < 0 || replica >= ctx->R || n < 0 || !moves || !out_scores || !out_doable)
         return fail(ctx, SF_ERR_INVALID, "bad sf_step_evaluate arguments");
-    if (ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_evaluate: a model with the join of its two planning classes is searched by the fused engine only");
+    if (ctx->xown_level >= 0)
+        for (int64_t i = 0; i < n; ++i)
+            if (moves[i].kind == SF_MOVE_LIST_RUIN) return fail(ctx, SF_ERR_UNSUPPORTED, "the join of the two planning classes is not priced by a ruin's recreate");
     if (n == 0) return SF_OK;
     // one allocation per call, released on every path (hipFree(nullptr) is a no-op)
     int32_t* d_moves = nullptr;
@@ -1503,6 +1508,12 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
             e = hipGetLastError();
         }
     }
+    if (e == hipSuccess && ctx->xown_level >= 0) {  // the join of the two planning classes: its delta from the move's coordinates (k_cross_owner_evaluate_moves)
+        hipLaunchKernelGGL(k_cross_owner_holders, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, ctx->sm.n, ctx->d_xown_tab);
+        hipLaunchKernelGGL(k_cross_owner_evaluate_moves, dim3(grid), dim3(256), 0, ctx->stream, ctx->lm, ctx->sm.vals, ctx->sm.n, ctx->d_xown_tab, replica, d_moves, n,
+                           ctx->xown_level, ctx->xown_weight, d_sc, d_do);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1511,11 +1522,12 @@ int32_t sf_step_evaluate(sf_ctx* ctx, int32_t replica, const sf_move_t* moves, i
     return SF_OK;
 }
 
+static int xown_price(sf_ctx* ctx, int32_t replica, const sf_move_t* records, int64_t n_records, const int64_t* compound_offsets);
+static void xown_commit(sf_ctx* ctx, int32_t replica);
 // ScalarCandidateProvider surface: multi-edit candidates scored as ONE CompoundScalarMove each
 int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, const int64_t* offsets, int64_t n,
                                   int64_t* out_scores, int32_t* out_doable) {
     DeviceGuard _dev(ctx);
-    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_step_evaluate_compound: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized) return fail(ctx, SF_ERR_INVALID, "sf_initialize first");
     if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
     if (replica < 0 || replica >= ctx->R || n < 0 || !offsets || !out_scores || !out_doable)
@@ -1554,6 +1566,11 @@ int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t*
     }
     hipLaunchKernelGGL(k_scalar_evaluate_compound, dim3((int)((n + 255) / 256)), dim3(256), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica,
                        d_edits, d_off, n, d_sc, d_do);
+    if (ctx->xown_level >= 0) {  // the join of the two planning classes: a scalar edit changes the A side's key
+        hipLaunchKernelGGL(k_cross_owner_holders, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, ctx->sm.n, ctx->d_xown_tab);
+        hipLaunchKernelGGL(k_cross_owner_evaluate_compound, dim3((int)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->sm.vals, ctx->sm.n, ctx->d_xown_tab, replica, d_edits,
+                           d_off, n, ctx->levels, ctx->xown_level, ctx->xown_weight, d_sc, d_do);
+    }
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out_scores, d_sc, (size_t)n * ctx->levels * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_doable, d_do, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -1565,7 +1582,6 @@ int32_t sf_step_evaluate_compound(sf_ctx* ctx, int32_t replica, const sf_move_t*
 
 int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, int64_t n_edits) {
     DeviceGuard _dev(ctx);
-    if (ctx && ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_apply_compound: a model with the join of its two planning classes is searched by the fused engine only");
     if (!ctx || !ctx->initialized || !edits || replica < 0 || replica >= ctx->R) return fail(ctx, SF_ERR_INVALID, "bad sf_apply_compound arguments");
     if (!ctx->has_scalar_model) return fail(ctx, SF_ERR_INVALID, "compound scalar candidates need a scalar variable");
     if (n_edits <= 0) return fail(ctx, SF_ERR_INVALID, "move is not doable");
@@ -1584,8 +1600,16 @@ int32_t sf_apply_compound(sf_ctx* ctx, int32_t replica, const sf_move_t* edits, 
         (void)hipFree(d_edits);
         return fail(ctx, SF_ERR_HIP, hipGetErrorString(ea));
     }
+    {
+        const int64_t one_candidate[2] = {0, n_edits};
+        if ((rc = xown_price(ctx, replica, edits, n_edits, one_candidate))) {
+            (void)hipFree(d_edits);
+            return rc;
+        }
+    }
     hipLaunchKernelGGL(k_scalar_apply_compound, dim3(1), dim3(64), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, d_edits, (int)n_edits,
                        ctx->d_ok);
+    xown_commit(ctx, replica);
     int32_t ok = 0;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&ok, ctx->d_ok, 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -1761,11 +1785,50 @@ static int32_t step_decide_impl(sf_ctx* ctx, int32_t replica, const sf_move_t* e
     return SF_OK;
 }
 
+// The join of the two planning classes under sf_apply / sf_apply_compound: its delta is priced on the state BEFORE the move (into ctx->d_xown_delta,
+// SF_MAX_LEVELS words), and added to the committed score by xown_commit once the apply kernel has said the move went through (ctx->d_ok).
+static int xown_price(sf_ctx* ctx, int32_t replica, const sf_move_t* records, int64_t n_records, const int64_t* compound_offsets) {
+    if (ctx->xown_level < 0) return SF_OK;
+    if (!ctx->d_xown_delta) {
+        int rc = dalloc(ctx, &ctx->d_xown_delta, (size_t)SF_MAX_LEVELS);
+        if (rc) return rc;
+    }
+    int32_t* d_rec = nullptr;
+    int64_t* d_off = nullptr;
+    hipError_t e = hipMalloc((void**)&d_rec, (size_t)n_records * 24);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rec, records, (size_t)n_records * 24, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->d_xown_delta, 0, (size_t)SF_MAX_LEVELS * 8, ctx->stream);
+    if (e == hipSuccess && compound_offsets) {
+        e = hipMalloc((void**)&d_off, 16);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_off, compound_offsets, 16, hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_cross_owner_holders, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, ctx->sm.n, ctx->d_xown_tab);
+        if (compound_offsets)  // ONE compound candidate: records [0, n_records)
+            hipLaunchKernelGGL(k_cross_owner_evaluate_compound, dim3(1), dim3(256), 0, ctx->stream, ctx->sm.vals, ctx->sm.n, ctx->d_xown_tab, replica, d_rec, d_off,
+                               (int64_t)1, ctx->levels, ctx->xown_level, ctx->xown_weight, ctx->d_xown_delta, (const int32_t*)nullptr);
+        else
+            hipLaunchKernelGGL(k_cross_owner_evaluate_moves, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, ctx->sm.vals, ctx->sm.n, ctx->d_xown_tab, replica, d_rec,
+                               (int64_t)1, ctx->xown_level, ctx->xown_weight, ctx->d_xown_delta, (const int32_t*)nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (the host buffers are released below)
+    (void)hipFree(d_rec);
+    (void)hipFree(d_off);
+    if (e != hipSuccess) return fail(ctx, SF_ERR_HIP, hipGetErrorString(e));
+    return SF_OK;
+}
+static void xown_commit(sf_ctx* ctx, int32_t replica) {
+    if (ctx->xown_level < 0) return;
+    hipLaunchKernelGGL(k_cross_owner_commit, dim3(1), dim3(1), 0, ctx->stream, ctx->lm.score + (size_t)replica * 4 + ctx->xown_level,
+                       ctx->d_xown_delta + ctx->xown_level, ctx->d_ok);
+}
+
 int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
     DeviceGuard _dev(ctx);
     if (!ctx || !ctx->initialized || !mv || replica < 0 || replica >= ctx->R)
         return fail(ctx, SF_ERR_INVALID, "bad sf_apply arguments");
-    if (ctx->xown_level >= 0) return fail(ctx, SF_ERR_UNSUPPORTED, "sf_apply: a model with the join of its two planning classes is searched by the fused engine only");
+    if (ctx->xown_level >= 0 && mv->kind == SF_MOVE_LIST_RUIN) return fail(ctx, SF_ERR_UNSUPPORTED, "the join of the two planning classes is not priced by a ruin's recreate");
     int rc = alloc_search(ctx);
     if (rc) return rc;
     if (mv->kind == SF_MOVE_LIST_RUIN) {  // committed ruin + recreate: its own kernel (one wavefront)
@@ -1848,15 +1911,18 @@ int32_t sf_apply(sf_ctx* ctx, int32_t replica, const sf_move_t* mv) {
         if (mv->kind == SF_MOVE_SUBLIST_SWAP && (mv->value <= 0 || (mv->value & 0xFFFF) == 0 || (mv->value & 0xFFFF) > 255 ||
                                                  (mv->value >> 16) == 0 || (mv->value >> 16) > 255))
             return fail(ctx, SF_ERR_INVALID, "sublist swap: value packs the two segment sizes (1..255 each)");
+        if ((rc = xown_price(ctx, replica, mv, 1, nullptr))) return rc;
         hipLaunchKernelGGL(k_list_apply, dim3(1), dim3(256), 0, ctx->stream, ctx->lm, replica, mv->kind,
                            (uint32_t)mv->a, (uint32_t)mv->a_pos, (uint32_t)mv->b, (uint32_t)mv->b_pos,
                            (uint32_t)(mv->value > 0 ? mv->value : 0), ctx->d_ok);
         if (ctx->pm.on)  // a move that was not doable left the lists alone: the refresh then changes nothing
             hipLaunchKernelGGL(k_prec_after_apply, dim3(1), dim3(64), 0, ctx->stream, ctx->lm, ctx->pm, replica);
     } else {
+        if ((rc = xown_price(ctx, replica, mv, 1, nullptr))) return rc;
         hipLaunchKernelGGL(k_scalar_apply, dim3(1), dim3(64), scalar_table_bytes(ctx), ctx->stream, ctx->sm, replica, mv->kind, mv->a,
                            mv->b, mv->value, ctx->d_ok);
     }
+    xown_commit(ctx, replica);
     HIPCHK(ctx, hipGetLastError());
     int32_t ok = 0;
     HIPCHK(ctx, hipMemcpyAsync(&ok, ctx->d_ok, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2505,7 +2571,9 @@ static int launch_mixed_t(sf_ctx* ctx, const SearchParams& p, const GLeaves& gl,
     const size_t max_waves = 4 * (size_t)(fast ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_PER_CU : SF_MIXED_FAST_BLOCKS_PER_CU) : (prec_occ ? SF_MIXED_PREC_BLOCKS_PER_CU : SF_MIXED_BLOCKS_PER_CU));  // by register budget
     int wpb = 1;
     size_t best_resident = 0;
-    for (int w = 1; w <= 4; ++w) {
+    const char* wenv = std::getenv("SF_AMD_MIXED_WPB");  // diagnostics: cap the replicas per workgroup (A/B of the workgroup shape)
+    const int wmax = wenv && std::atoi(wenv) >= 1 && std::atoi(wenv) < 4 ? std::atoi(wenv) : 4;
+    for (int w = 1; w <= wmax; ++w) {
         const size_t per_wg = cv.total * w + (fast ? 0 : 1024) + (PREC ? (size_t)gl.prec_static : 0);  // + the static annealing state (the FAST kernels have none), the shared copy of the precedence graph
         if (per_wg > 160 * 1024) break;
         size_t groups = (160 * 1024) / per_wg;

@@ -823,6 +823,97 @@ __global__ __launch_bounds__(256) void k_cross_owner_evaluate_all(ListModel m, c
     }
 }
 
+// The same join for the host-driven entry points (sf_step_evaluate / sf_step_evaluate_compound / sf_apply / sf_apply_compound): the fused engines keep an
+// entity -> holding list map per replica and price a move from its coordinates (sf_mixed_wave.hip: xown_scalar_delta / xown_list_delta); here the map of
+// ONE replica is rebuilt from its lists per call (one block), then a thread per record adds the join's delta to the scores the other kernels wrote.
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_cross_owner_holders(ListModel m, int replica, int n_scalar, uint16_t* tab_all) {
+    uint16_t* tab = tab_all + (size_t)replica * n_scalar;
+    for (int e = threadIdx.x; e < n_scalar; e += blockDim.x) tab[e] = 0xFFFFu;  // held by no list
+    __syncthreads();
+    const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
+    const uint32_t* vis = m.visits + (size_t)replica * m.n_cap;
+    for (int o = 0; o < m.V; ++o)
+        for (uint32_t q = off[o] + threadIdx.x; q < off[o + 1]; q += blockDim.x)
+            if (vis[q] < (uint32_t)n_scalar) tab[vis[q]] = (uint16_t)o;
+}
+__device__ __forceinline__ int32_t cross_owner_pen(int32_t v, uint32_t owner) { return (v >= 0 && (uint32_t)v != owner) ? 1 : 0; }
+// moves = sf_move_t records (six int32 each); out-of-range coordinates price nothing (such a record is not doable and its score is not read)
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_cross_owner_evaluate_moves(ListModel m, const int32_t* vals_all, int n_scalar, const uint16_t* tab_all, int replica,
+                                                                    const int32_t* __restrict__ moves, int64_t n, int level, int64_t weight, int64_t* sc,
+                                                                    const int32_t* doable) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (doable && !doable[i])) return;
+    const int32_t* mv = moves + i * 6;
+    const int32_t kind = mv[0], a = mv[1], ap = mv[2], b = mv[3], bp = mv[4], val = mv[5];
+    const int32_t* vals = vals_all + (size_t)replica * n_scalar;
+    const uint16_t* tab = tab_all + (size_t)replica * n_scalar;
+    const uint32_t* off = m.off + (size_t)replica * (m.V + 1);
+    const uint32_t* vis = m.visits + (size_t)replica * m.n_cap;
+    auto moved = [&](uint32_t e, uint32_t from, uint32_t to) -> int64_t {  // element e leaves list `from` for list `to`
+        if (e >= (uint32_t)n_scalar) return 0;
+        const int32_t v = vals[e];
+        return (int64_t)cross_owner_pen(v, to) - (int64_t)cross_owner_pen(v, from);
+    };
+    auto len_of = [&](int32_t o) -> uint32_t { return off[o + 1] - off[o]; };
+    int64_t d = 0;
+    if (kind == 0) {  // SF_MOVE_CHANGE (the wire kinds of include/solverforge_amd.h, as in k_list_evaluate_moves)
+        if (a >= 0 && a < n_scalar) {
+            const uint32_t ow = tab[a];
+            d = (int64_t)cross_owner_pen(val, ow) - (int64_t)cross_owner_pen(vals[a], ow);
+        }
+    } else if (kind == 1) {  // SF_MOVE_SWAP
+        if (a >= 0 && a < n_scalar && b >= 0 && b < n_scalar) {
+            const uint32_t o1 = tab[a], o2 = tab[b];
+            const int32_t v1 = vals[a], v2 = vals[b];
+            d = (int64_t)cross_owner_pen(v2, o1) - cross_owner_pen(v1, o1) + cross_owner_pen(v1, o2) - cross_owner_pen(v2, o2);
+        }
+    } else if (a >= 0 && a < m.V && b >= 0 && b < m.V && a != b && ap >= 0 && bp >= 0) {  // list kinds: only elements that change lists count
+        if (kind == 2) {  // SF_MOVE_LIST_CHANGE
+            if ((uint32_t)ap < len_of(a)) d = moved(vis[off[a] + ap], a, b);
+        } else if (kind == 3) {  // SF_MOVE_LIST_SWAP
+            if ((uint32_t)ap < len_of(a) && (uint32_t)bp < len_of(b)) d = moved(vis[off[a] + ap], a, b) + moved(vis[off[b] + bp], b, a);
+        } else if (kind == 5) {  // SF_MOVE_SUBLIST_CHANGE: segment [a_pos, value) of list a -> list b
+            if (val > ap && (uint32_t)val <= len_of(a))
+                for (int32_t t = ap; t < val; ++t) d += moved(vis[off[a] + t], a, b);
+        } else if (kind == 6) {  // SF_MOVE_SUBLIST_SWAP: [a_pos, a_pos + (value & 0xFFFF)) of a <-> [b_pos, b_pos + (value >> 16)) of b
+            const uint32_t la = (uint32_t)val & 0xFFFFu, lb = (uint32_t)val >> 16;
+            if ((uint32_t)ap + la <= len_of(a) && (uint32_t)bp + lb <= len_of(b)) {
+                for (uint32_t t = 0; t < la; ++t) d += moved(vis[off[a] + ap + t], a, b);
+                for (uint32_t t = 0; t < lb; ++t) d += moved(vis[off[b] + bp + t], b, a);
+            }
+        }
+    }  // reverse / 3-opt / permute / multi-swap stay inside one list: nothing changes
+    sc[i * m.levels + level] -= (int64_t)((uint64_t)weight * (uint64_t)d);
+}
+// compound scalar candidates: the edits of candidate i chain (a later edit of the same entity sees the earlier one's value)
+SF_PLAIN_KERNEL
+__global__ __launch_bounds__(256) void k_cross_owner_evaluate_compound(const int32_t* vals_all, int n_scalar, const uint16_t* tab_all, int replica, const int32_t* __restrict__ edits,
+                                                                       const int64_t* __restrict__ offsets, int64_t n, int levels, int level, int64_t weight, int64_t* sc,
+                                                                       const int32_t* doable) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (doable && !doable[i])) return;
+    const int32_t* vals = vals_all + (size_t)replica * n_scalar;
+    const uint16_t* tab = tab_all + (size_t)replica * n_scalar;
+    int64_t d = 0;
+    for (int64_t k = offsets[i]; k < offsets[i + 1]; ++k) {
+        const int32_t e = edits[k * 6 + 1], nv = edits[k * 6 + 5];
+        if (e < 0 || e >= n_scalar) continue;
+        int32_t cur = vals[e];
+        for (int64_t q = offsets[i]; q < k; ++q)
+            if (edits[q * 6 + 1] == e) cur = edits[q * 6 + 5];
+        const uint32_t ow = tab[e];
+        d += (int64_t)cross_owner_pen(nv, ow) - (int64_t)cross_owner_pen(cur, ow);
+    }
+    sc[i * levels + level] -= (int64_t)((uint64_t)weight * (uint64_t)d);
+}
+// sf_apply / sf_apply_compound: the delta priced before the move is added to the committed score once the move went through
+SF_PLAIN_KERNEL
+__global__ void k_cross_owner_commit(int64_t* score_level, const int64_t* delta_level, const int32_t* ok) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *ok) *score_level += *delta_level;
+}
+
 // internal node numbering of the COMPACT wave kernel (ListModel::perm): the u16 matrix with rows and columns in internal order ...
 SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_mat16_renumber(const uint16_t* __restrict__ src, const uint16_t* __restrict__ inv, int dim, uint16_t* __restrict__ dst) {

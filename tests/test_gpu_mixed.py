@@ -562,14 +562,77 @@ def test_two_class_join_traced_and_fused_steps(oracle, acceptor, forager, limit)
     assert (d2.fresh_score() == sc).all()
 
 
+def test_two_class_join_host_driven_entry_points(oracle):
+    """sf_step_evaluate / sf_apply / the compound-candidate entry points price the join from the move's coordinates (round 6): arbitrary records of
+    every kind that moves an element between lists or changes a value, then committed moves, against the oracle's hash-indexed node."""
+    import solverforge_amd as sfa
+
+    p = _jobshop(n_jobs=9, n_machines=4, seed=4)
+    R = 2
+    d, o, bits = _mk_owner(oracle, p, n_replicas=R, level=1)
+    o.configure(leaves=bits)
+    d.calculate_score()
+    rng = np.random.default_rng(11)
+    n_ops, V = len(p["job"]), len(p["sequences"])
+    for it in range(10):
+        lists = o.get_lists(1)
+        om = o.enumerate(0, it, 90 + it, 3)  # the four-leaf union's candidates ...
+        extra = []  # ... plus segment moves and deliberately bad records
+        for _ in range(24):
+            a, b = (int(v) for v in rng.choice(V, 2, replace=False))
+            la, lb = len(lists[a]), len(lists[b])
+            if la >= 1:
+                i = int(rng.integers(la))
+                e = int(rng.integers(i + 1, min(la, i + 3) + 1))
+                extra.append((sfa.MoveKind.SUBLIST_CHANGE, a, i, b, int(rng.integers(lb + 1)), e))
+            if la >= 1 and lb >= 1:
+                i, j = int(rng.integers(la)), int(rng.integers(lb))
+                sa, sb = int(rng.integers(1, min(3, la - i) + 1)), int(rng.integers(1, min(3, lb - j) + 1))
+                extra.append((sfa.MoveKind.SUBLIST_SWAP, a, i, b, j, sa | (sb << 16)))
+            extra.append((sfa.MoveKind.LIST_CHANGE, a, la + 3, b, 0, -1))  # out of range: not doable on either side
+        allm = np.concatenate([np.asarray(om, dtype=sfa.MOVE_DTYPE), np.array(extra, dtype=sfa.MOVE_DTYPE)])
+        os_, od = o.evaluate_moves(allm)
+        for r in range(R):
+            gs, gd = d.evaluate_moves(allm, replica=r)
+            assert (gd == od).all(), (it, r)
+            assert (gs[od != 0] == os_[od != 0, :3]).all(), (it, r)
+        cands = [[(int(rng.integers(n_ops)), int(rng.integers(-1, V))) for _ in range(int(rng.integers(1, 4)))] for _ in range(40)]
+        cands.append([(0, 1), (0, 2), (0, -1)])  # the same entity three times: the edits chain
+        cs, cd = o.evaluate_compound(cands)
+        gs, gd = d.evaluate_candidates(cands)
+        assert (gd == cd).all() and (gs[cd != 0] == cs[cd != 0, :3]).all(), it
+        if it % 3 == 2:  # commit a compound candidate ...
+            c = cands[int(np.flatnonzero(cd)[rng.integers(int(cd.sum()))])]
+            o.apply_compound(c)
+            for r in range(R):
+                d.apply_candidate(c, replica=r)
+        else:  # ... or a move of the union / a segment move
+            ok = np.flatnonzero(od)
+            mv = allm[ok[rng.integers(len(ok))]]
+            o.apply_move(mv)
+            for r in range(R):
+                d.apply_move(mv, replica=r)
+        sc = d.calculate_score()
+        assert (sc[0] == o.score()[:3]).all() and (sc[1] == sc[0]).all(), it
+        assert (d.fresh_score() == sc).all(), it
+    d.configure(sfa.SolverConfig(random_seed=3))  # and the fused engine carries on from the host-driven state
+    d.phase_start()
+    d.solve_steps(10)
+    assert (d.fresh_score() == d.calculate_score()).all()
+
+
 def test_two_class_join_validation():
     import solverforge_amd as sfa
 
     p = _jobshop(n_jobs=6, n_machines=4, seed=2)
     d = sfa.build_jobshop(p, owner_match_level=1)
     d.calculate_score()
-    with pytest.raises(sfa.SolverForgeError):  # host-driven entry points do not price the join
-        d.evaluate_moves(np.zeros(1, dtype=sfa.MOVE_DTYPE))
+    ruin = np.zeros(1, dtype=sfa.MOVE_DTYPE)
+    ruin[0] = (sfa.MoveKind.LIST_RUIN, 0, 0, 0, 0, 0)
+    with pytest.raises(sfa.SolverForgeError):  # a ruin's recreate does not price the join, host-driven or fused
+        d.evaluate_moves(ruin)
+    with pytest.raises(sfa.SolverForgeError):  # construction phases do not either
+        d.construct_list_cheapest(1, [0])
     d2 = sfa.build_jobshop(p, owner_match_level=1, leaves=("list_change", "change", "ruin"))
     d2.configure(sfa.SolverConfig(random_seed=0))
     d2.calculate_score()
