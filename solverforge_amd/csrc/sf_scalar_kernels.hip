@@ -129,6 +129,9 @@ __device__ __forceinline__ bool value_legal(const ScalarModel& m, uint32_t e, in
 // program is read with scalar loads, one term per trip of a loop that is NOT unrolled: inlined and unrolled at every pair of every
 // partner loop it tripled the build time of the search kernels), per-lane data; the column facts are read once for both values.
 // left = the lower entity index (the join's left.id < right.id).
+#ifndef SF_PAIR_IR_W
+#define SF_PAIR_IR_W 4  // partners of one entity evaluated side by side by the interpreted join (pair_program_holds2_w)
+#endif
 __device__ __forceinline__ uint32_t pair_program_holds2(const PairTerm* __restrict__ ir, int32_t ir_n, uint32_t e, uint32_t o, int32_t v0, int32_t v1, int32_t vo) {
     const bool swp = e > o;
     const uint32_t l = swp ? o : e, r = swp ? e : o;
@@ -183,6 +186,81 @@ __device__ __forceinline__ uint32_t pair_program_holds2(const PairTerm* __restri
     return all & ((v0 >= 0 ? 1u : 0u) | (v1 >= 0 ? 2u : 0u));
 }
 
+// The same program for W partners of e side by side (round 6).  The interpreted join used to walk its partner list one entity at a time -- a partner id
+// from HBM / L2, its value from LDS, then per term the two column facts from HBM again, every load waiting for the one before: 2.9 x slower than the
+// specialised loop, which keeps sixteen partner ids in flight (profiles/r05_pair_ir_graph.txt).  Here the term loop stays wave-uniform and NOT unrolled
+// (one copy of each operator's code), and inside a term the W partners are independent: their fact loads issue together.  An inactive slot
+// (`on[q]` false) carries o[q] = e: every index stays readable, its result is dropped.
+template <int W>
+__device__ __forceinline__ void pair_program_holds2_w(const PairTerm* __restrict__ ir, int32_t ir_n, uint32_t e, const uint32_t (&o)[W], const bool (&on)[W], int32_t v0,
+                                                      int32_t v1, const int32_t (&vo)[W], uint32_t (&out)[W]) {
+    uint32_t l[W], r[W], all[W], any[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        const bool swp = e > o[q];
+        l[q] = swp ? o[q] : e, r[q] = swp ? e : o[q];
+        all[q] = 3u, any[q] = 0u;
+    }
+    int32_t clause = -1;
+#pragma unroll 1
+    for (int t = 0; t < ir_n; ++t) {
+        const PairTerm& pt = ir[t];
+        const int32_t op = pt.op_clause & 255, cl = pt.op_clause >> 8;
+        if (cl != clause) {
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                all[q] &= clause < 0 ? 3u : any[q];
+                any[q] = 0u;
+            }
+            clause = cl;
+        }
+        if (op == 1 || op == 2 || op == 11) {  // value-only terms
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                const int32_t d0 = v0 > vo[q] ? v0 - vo[q] : vo[q] - v0, d1 = v1 > vo[q] ? v1 - vo[q] : vo[q] - v1;
+                const bool h0 = op == 1 ? v0 == vo[q] : (op == 2 ? v0 != vo[q] : (int64_t)d0 <= pt.param);
+                const bool h1 = op == 1 ? v1 == vo[q] : (op == 2 ? v1 != vo[q] : (int64_t)d1 <= pt.param);
+                any[q] |= (h0 ? 1u : 0u) | (h1 ? 2u : 0u);
+            }
+        } else if (op == 9) {  // membership either way: a linear walk of both rows (residual use only)
+#pragma unroll 1
+            for (int q = 0; q < W; ++q) {
+                if (!on[q]) continue;
+                bool m = false;
+                for (uint32_t k = pt.coff[l[q]]; k < pt.coff[l[q] + 1]; ++k) m = m || pt.cval[k] == r[q];
+                for (uint32_t k = pt.coff[r[q]]; k < pt.coff[r[q] + 1]; ++k) m = m || pt.cval[k] == l[q];
+                any[q] |= m ? 3u : 0u;
+            }
+        } else {
+            int32_t cl_[W], cr_[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) cl_[q] = pt.col[l[q]], cr_[q] = pt.col[r[q]];  // 2 W independent loads
+            if (op == 10) {
+                int64_t tb[W];
+#pragma unroll
+                for (int q = 0; q < W; ++q) tb[q] = pt.table[(size_t)cl_[q] * (size_t)pt.cols + (size_t)cr_[q]];
+#pragma unroll
+                for (int q = 0; q < W; ++q) any[q] |= tb[q] != 0 ? 3u : 0u;
+            } else {
+#pragma unroll
+                for (int q = 0; q < W; ++q) {
+                    const int32_t dc = cl_[q] > cr_[q] ? cl_[q] - cr_[q] : cr_[q] - cl_[q];
+                    if (op == 3) {
+                        const int32_t d0 = v0 > vo[q] ? v0 - vo[q] : vo[q] - v0, d1 = v1 > vo[q] ? v1 - vo[q] : vo[q] - v1;
+                        any[q] |= (d0 == dc ? 1u : 0u) | (d1 == dc ? 2u : 0u);
+                    } else {
+                        const bool m = op == 4 ? cl_[q] == cr_[q] : (op == 5 ? cl_[q] != cr_[q] : (op == 6 ? cl_[q] < cr_[q] : (op == 7 ? (int64_t)dc == pt.param : (op == 8 ? (int64_t)dc <= pt.param : false))));
+                        any[q] |= m ? 3u : 0u;
+                    }
+                }
+            }
+        }
+    }
+    const uint32_t vm = (v0 >= 0 ? 1u : 0u) | (v1 >= 0 ? 2u : 0u);
+#pragma unroll
+    for (int q = 0; q < W; ++q) out[q] = on[q] ? ((all[q] & (clause < 0 ? 3u : any[q])) & vm) : 0u;
+}
+
 // matches of entity e against every partner except `skip`, for two candidate values at once:
 // returns conflicts(e, v_new) - conflicts(e, v_old) in ONE pass over the partner list, sixteen
 // partner ids in flight per iteration (the list lives in HBM/L2, the values in LDS): an average
@@ -209,22 +287,39 @@ __device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, c
         }
     } else if (m.cross_kind == SC_IR_PARTNERS) {  // the partner index names the pairs one clause admits, the program decides the rest
         const uint32_t p1 = m.pn_off[e + 1];
+        constexpr int W = SF_PAIR_IR_W;
 #pragma unroll 1
-        for (uint32_t p = m.pn_off[e]; p < p1; ++p) {
-            const uint32_t o = m.pn[p];
-            if (o == skip) continue;
-            const int32_t vo = (int32_t)vals[o];
-            if (vo < 0) continue;
-            const uint32_t h = pair_program_holds2(m.ir, m.ir_n, e, o, v_new, v_old, vo);
-            c += (int32_t)(h & 1u) - (int32_t)(h >> 1);
+        for (uint32_t p = m.pn_off[e]; p < p1; p += W) {
+            uint32_t o[W], h[W];
+            bool on[W];
+            int32_t vo[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) o[q] = p + q < p1 ? m.pn[p + q] : e;
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                vo[q] = (int32_t)vals[o[q]];
+                on[q] = p + q < p1 && o[q] != skip && o[q] != e && vo[q] >= 0;
+            }
+            pair_program_holds2_w<W>(m.ir, m.ir_n, e, o, on, v_new, v_old, vo, h);
+#pragma unroll
+            for (int q = 0; q < W; ++q) c += (int32_t)(h[q] & 1u) - (int32_t)(h[q] >> 1);
         }
     } else if (m.cross_kind == SC_IR_DENSE) {  // no clause to index by: every other assigned entity
+        constexpr int W = SF_PAIR_IR_W;
 #pragma unroll 1
-        for (uint32_t o = 0; o < (uint32_t)m.n; ++o) {
-            const int32_t vo = (int32_t)vals[o];
-            if (o == e || o == skip || vo < 0) continue;
-            const uint32_t h = pair_program_holds2(m.ir, m.ir_n, e, o, v_new, v_old, vo);
-            c += (int32_t)(h & 1u) - (int32_t)(h >> 1);
+        for (uint32_t b = 0; b < (uint32_t)m.n; b += W) {
+            uint32_t o[W], h[W];
+            bool on[W];
+            int32_t vo[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) {
+                o[q] = b + q < (uint32_t)m.n ? b + q : e;
+                vo[q] = (int32_t)vals[o[q]];
+                on[q] = b + q < (uint32_t)m.n && o[q] != e && o[q] != skip && vo[q] >= 0;
+            }
+            pair_program_holds2_w<W>(m.ir, m.ir_n, e, o, on, v_new, v_old, vo, h);
+#pragma unroll
+            for (int q = 0; q < W; ++q) c += (int32_t)(h[q] & 1u) - (int32_t)(h[q] >> 1);
         }
     } else if (m.cross_kind == SC_QUEENS) {  // board.rs:30-44: distinct columns, same row or same diagonal
         const int32_t ce = m.col[e];
