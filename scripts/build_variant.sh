@@ -8,7 +8,7 @@ mkdir -p $R/build/var_$name
 case $unit in
   list_wave_*) src=sf_tu_list_wave.hip; defs="-DSF_TU_L=${unit#list_wave_}";;
   mixed_*) IFS=_ read -r _ l v ru pr <<< "$unit"; src=sf_tu_mixed.hip; defs="-DSF_TU_L=$l -DSF_TU_VTB=$v -DSF_TU_RUIN=$ru -DSF_TU_PREC=$pr";;
-  scalar_*) IFS=_ read -r _ l v <<< "$unit"; src=sf_tu_scalar.hip; defs="-DSF_TU_L=$l -DSF_TU_VTB=$v";;
+  scalar_*) IFS=_ read -r _ l v ir <<< "$unit"; src=sf_tu_scalar.hip; defs="-DSF_TU_L=$l -DSF_TU_VTB=$v -DSF_TU_IR=$ir";;
   api) src=sf_api.hip; defs="";;
   *) echo "unknown unit $unit"; exit 1;;
 esac

@@ -49,8 +49,9 @@ hipError_t launch_tu_list_block(bool trace, const SearchLaunch& a);
 // COMPACT LDS layout, 4 = the same compiled for 5 waves per SIMD)
 template <int L>
 hipError_t launch_tu_list_wave(bool trace, int mode, const SearchLaunch& a);
-// scalar engine: k_scalar_search_wave<L, TRACE, VT>, VT = int8_t (VTB 1) or int16_t (VTB 2)
-template <int L, int VTB>
+// scalar engine: k_scalar_search_wave<L, TRACE, VT, IR>, VT = int8_t (VTB 1) or int16_t (VTB 2); IR = the unit built with the interpreted
+// pair-predicate joins (1) or without them (0: specialised joins only)
+template <int L, int VTB, int IR>
 hipError_t launch_tu_scalar(bool trace, const SearchLaunch& a);
 // generic N-leaf engine: k_mixed_search_wave<L, TRACE, VT, RUIN, PREC, MODE> (mode 1 = the FAST instantiation of the default
 // list policy: VTB 2, no precedence constraint, never traced; mode 2 = the PREC instantiations built for four workgroups per CU)
@@ -73,14 +74,16 @@ SF_TU_DECL_MIXED(4, 2, false, true)
 SF_TU_DECL_MIXED(2, 2, true, true)
 SF_TU_DECL_MIXED(4, 2, true, true)
 #undef SF_TU_DECL_MIXED
-template <>
-hipError_t launch_tu_scalar<2, 1>(bool trace, const SearchLaunch& a);
-template <>
-hipError_t launch_tu_scalar<2, 2>(bool trace, const SearchLaunch& a);
-template <>
-hipError_t launch_tu_scalar<4, 1>(bool trace, const SearchLaunch& a);
-template <>
-hipError_t launch_tu_scalar<4, 2>(bool trace, const SearchLaunch& a);
+#define SF_TU_DECL_SCALAR(L, VTB)                                                \
+    template <>                                                                  \
+    hipError_t launch_tu_scalar<L, VTB, 0>(bool trace, const SearchLaunch& a);   \
+    template <>                                                                  \
+    hipError_t launch_tu_scalar<L, VTB, 1>(bool trace, const SearchLaunch& a);
+SF_TU_DECL_SCALAR(2, 1)
+SF_TU_DECL_SCALAR(2, 2)
+SF_TU_DECL_SCALAR(4, 1)
+SF_TU_DECL_SCALAR(4, 2)
+#undef SF_TU_DECL_SCALAR
 template <>
 hipError_t launch_tu_list_wave<2>(bool trace, int mode, const SearchLaunch& a);
 template <>

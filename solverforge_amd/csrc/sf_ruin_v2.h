@@ -22,6 +22,9 @@
 // from a log at the end, exactly as sf_ruin.h does.  profiles/r05_phase7_*.txt: one recreate of sf_ruin.h costs ~250 K shader clocks of a
 // CVRP-1000 replica (ten per step: 2.5 M of the 3.4 M clocks of a seven-leaf step).
 #pragma once
+#ifndef SF_RV2_U
+#define SF_RV2_U 4
+#endif
 #include <stdint.h>
 
 #include "sf_ruin.h"
@@ -271,7 +274,7 @@ __device__ __forceinline__ bool ruin_trial_v2(const ListModel& lm, uint16_t* vis
         uint32_t rw_prev[NE];
 #pragma unroll
         for (uint32_t i = 0; i < NE; ++i) rw_prev[i] = rw_depot[i];
-        constexpr uint32_t U = 4;
+        constexpr uint32_t U = SF_RV2_U;  // slots of the walk in flight per lane (a variant build sweeps it: scripts/build_variant.sh ... "-DSF_RV2_U=8")
         for (uint32_t q0 = 0; q0 < nslots; q0 += U) {
             uint32_t nxr[U], d0[U];
             bool at_end[U];

@@ -129,6 +129,13 @@ __device__ __forceinline__ bool value_legal(const ScalarModel& m, uint32_t e, in
 // program is read with scalar loads, one term per trip of a loop that is NOT unrolled: inlined and unrolled at every pair of every
 // partner loop it tripled the build time of the search kernels), per-lane data; the column facts are read once for both values.
 // left = the lower entity index (the join's left.id < right.id).
+// SF_SCALAR_PAIR_IR (a scalar-engine unit is built twice, csrc/Makefile): 0 = the interpreted joins compile OUT of scalar_conflict_delta -- the unit of
+// the models whose program matched a specialised loop (graph colouring, queens, job-shop groups): their kernels do not carry the interpreter's live
+// ranges (with it in: 9 -> 61 spilled vector registers and -4 % on the default SA policy of graph colouring, profiles/r06k_pair_ir_ab.txt); 1 = the
+// unit the host launches for SC_IR_PARTNERS / SC_IR_DENSE models.  Every other unit (the generic engine, the C ABI) keeps both.  W = 4 everywhere (8 spills).
+#ifndef SF_SCALAR_PAIR_IR
+#define SF_SCALAR_PAIR_IR 1
+#endif
 #ifndef SF_PAIR_IR_W
 #define SF_PAIR_IR_W 4  // partners of one entity evaluated side by side by the interpreted join (pair_program_holds2_w)
 #endif
@@ -285,6 +292,7 @@ __device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, c
                 c -= (v_old >= 0 && vo == v_old) ? 1 : 0;
             }
         }
+#if SF_SCALAR_PAIR_IR
     } else if (m.cross_kind == SC_IR_PARTNERS) {  // the partner index names the pairs one clause admits, the program decides the rest
         const uint32_t p1 = m.pn_off[e + 1];
         constexpr int W = SF_PAIR_IR_W;
@@ -321,6 +329,7 @@ __device__ __forceinline__ int64_t scalar_conflict_delta(const ScalarModel& m, c
 #pragma unroll
             for (int q = 0; q < W; ++q) c += (int32_t)(h[q] & 1u) - (int32_t)(h[q] >> 1);
         }
+#endif
     } else if (m.cross_kind == SC_QUEENS) {  // board.rs:30-44: distinct columns, same row or same diagonal
         const int32_t ce = m.col[e];
         for (uint32_t o = 0; o < (uint32_t)m.n; ++o) {
@@ -1335,7 +1344,8 @@ struct SCarve {
 };
 
 // VT = int8_t (n_values <= 127) or int16_t: the replica's values in LDS
-template <int L, bool TRACE, class VT>
+// IRK = SF_SCALAR_PAIR_IR of the unit that instantiates it: the two builds of one (L, TRACE, VT) are different kernels by name
+template <int L, bool TRACE, class VT, bool IRK = (SF_SCALAR_PAIR_IR != 0)>
 #ifndef SF_SCALAR_BLOCKS_PER_CU
 #define SF_SCALAR_BLOCKS_PER_CU 3  // (round 5: 168 registers, 26-33 spilled values; 12 replicas per CU -- graph colouring 10k: LateAcceptance 6.85 -> 8.45 G moves/s, the default SimulatedAnnealing policy 82 -> 103 M, profiles/r05_graph_occupancy.txt)
 #endif

@@ -1,11 +1,17 @@
-// One translation unit of the scalar engine: k_scalar_search_wave<SF_TU_L, *, VT>, traced and untraced.
+// One translation unit of the scalar engine: k_scalar_search_wave<SF_TU_L, *, VT>, traced and untraced -- built twice per (L, VT): SF_TU_IR = 0 without
+// the interpreted pair-predicate joins (the models whose program matched a specialised loop), 1 with them (four partners side by side; eight spill:
+// graph colouring interpreted 5.9 -> 4.8 G moves/s, profiles/r06k_pair_ir_ab.txt).
+#ifndef SF_TU_IR
+#define SF_TU_IR 1
+#endif
+#define SF_SCALAR_PAIR_IR SF_TU_IR
 #define SF_TU_ENGINES 7
 #include "sf_launch.h"
 
 namespace sf {
 
 template <>
-hipError_t launch_tu_scalar<SF_TU_L, SF_TU_VTB>(bool trace, const SearchLaunch& a) {
+hipError_t launch_tu_scalar<SF_TU_L, SF_TU_VTB, SF_TU_IR>(bool trace, const SearchLaunch& a) {
 #if SF_TU_VTB == 1
     using VT = int8_t;
 #else
