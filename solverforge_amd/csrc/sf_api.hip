@@ -793,11 +793,14 @@ static int build_list_model(sf_ctx* ctx, int d) {
     if ((rc = dalloc(ctx, &m.best_visits, (size_t)R * m.n_cap))) return rc;
     if ((rc = dalloc(ctx, &m.best_off, (size_t)R * (m.V + 1)))) return rc;
     if ((rc = dalloc(ctx, &m.best_score, (size_t)R * 4))) return rc;
-    for (int r = 0; r < R; ++r) {
-        HIPCHK(ctx, hipMemcpyAsync(m.visits + (size_t)r * m.n_cap, c.list_vals.data(), c.list_vals.size() * 4,
-                                   hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(m.off + (size_t)r * (m.V + 1), c.list_off.data(), c.list_off.size() * 4,
-                                   hipMemcpyHostToDevice, ctx->stream));
+    // replica 0 from the host, then the replicas doubled on the device: 2 + 2 log2(R) copies instead of 2 R (a 98,304-replica context issued 196,608
+    // four-kilobyte uploads, profiles/r06m_bench_kernel_stats.csv)
+    HIPCHK(ctx, hipMemcpyAsync(m.visits, c.list_vals.data(), c.list_vals.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(m.off, c.list_off.data(), c.list_off.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (size_t k = 1; k < (size_t)R; k *= 2) {
+        const size_t nrep = std::min(k, (size_t)R - k);
+        HIPCHK(ctx, hipMemcpyAsync(m.visits + k * m.n_cap, m.visits, nrep * m.n_cap * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(m.off + k * (m.V + 1), m.off, nrep * (m.V + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_list_model = true;
