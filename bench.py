@@ -357,6 +357,7 @@ def main():
                     help="M2 start state: the round-robin fill M1 is timed on, or the device's Clarke-Wright savings construction "
                          "from empty routes (built inside the budget, on both sides): savings = the reference's stock savings hooks "
                          "(structural feasibility only), savings_capacity = EXTENSION, a capacity-checking feasible hook")
+    ap.add_argument("--solve-replicas", type=int, default=0, help="M2: replicas per GPU of the solve leg (0 = M2_REPLICAS of the policy)")
     ap.add_argument("--solve-budget", type=int, default=100_000, help="M2: candidates per replica per launch (sf_solve_moves)")
     ap.add_argument("--solve-policy", choices=sorted(M2_POLICIES), default="default",
                     help="M2 leaves on both sides: default = the reference's seven-leaf default list policy, default6 = without ruin, "
@@ -370,6 +371,7 @@ def main():
     ap.add_argument("--pmc-child-out", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child-m2", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    m2_replicas = args.solve_replicas or M2_REPLICAS[args.solve_policy]
 
     if args.pmc_child or args.pmc_child_m2:  # a counter pass that hangs (rocprofv3 does now and then on this pool) leaves a Python stack in its stderr
         import faulthandler
@@ -429,7 +431,7 @@ def main():
 
     if args.pmc_child_m2:  # counter pass of the M2 leg's kernel: the leg's first launches again, nothing else
         prob2 = problem if args.solve_start == "roundrobin" else dict(problem, routes=[[] for _ in problem["routes"]])
-        d2 = new_director(prob2, M2_POLICIES[args.solve_policy], M2_REPLICAS[args.solve_policy])
+        d2 = new_director(prob2, M2_POLICIES[args.solve_policy], m2_replicas)
         d2.calculate_score()
         if args.solve_start != "roundrobin":
             d2.construct_list_clarke_wright(0, prob2["customers"], 1 if args.solve_start == "savings_capacity" else 0)
@@ -444,7 +446,7 @@ def main():
         if args.pmc_child_out:
             with open(args.pmc_child_out, "w") as f:
                 json.dump({"moves_evaluated": a2["moves_evaluated"] - b2["moves_evaluated"], "candidates_scored": a2["candidates_scored"] - b2["candidates_scored"],
-                           "launches": M2_PMC_TIMED, "ls_steps": a2["step_count"] - b2["step_count"], "replicas": M2_REPLICAS[args.solve_policy]}, f)
+                           "launches": M2_PMC_TIMED, "ls_steps": a2["step_count"] - b2["step_count"], "replicas": m2_replicas}, f)
         d2.close()
         return
     d = new_director()
@@ -499,7 +501,7 @@ def main():
         d.close()
         prob2 = problem if args.solve_start == "roundrobin" else dict(problem, routes=[[] for _ in problem["routes"]])
         m2_leaves = M2_POLICIES[args.solve_policy]
-        d2 = new_director(prob2, m2_leaves, M2_REPLICAS[args.solve_policy])
+        d2 = new_director(prob2, m2_leaves, m2_replicas)
         m2_start = d2.calculate_score()[0].tolist()
         cpu_box = {}
         cpu_thread = None
@@ -540,7 +542,7 @@ def main():
             "best_score_local": list(max(tuple(int(v) for v in s) for s in d2.best_scores())),
             "moves_per_s": st2["moves_evaluated"] / gpu_s,
             "start": args.solve_start, "start_score": m2_start, "construction_seconds": construct_s,
-            "leaves": list(m2_leaves), "replicas": M2_REPLICAS[args.solve_policy] or args.replicas, "curve": curve, "window": m2_window,
+            "leaves": list(m2_leaves), "replicas": m2_replicas or args.replicas, "curve": curve, "window": m2_window,
         }
         if cpu_thread:
             cpu_thread.join(timeout=args.solve_seconds + 30)
@@ -894,7 +896,8 @@ def main():
             roof2 = {"bound": None, "frac": None, "window": win, "kernel": "k_mixed_search_wave"}
             if world == 1 and not args.no_pmc and win and win["launches"] == M2_PMC_TIMED and win["kernel_ms"] > 0:
                 m2_argv = ["--gpus", "1", "--customers", str(args.customers), "--vehicles", str(args.vehicles), "--capacity", str(args.capacity), "--seed", str(args.seed),
-                           "--solve-start", args.solve_start, "--solve-policy", args.solve_policy, "--solve-budget", str(args.solve_budget), "--pmc-child-m2"]
+                           "--solve-start", args.solve_start, "--solve-policy", args.solve_policy, "--solve-budget", str(args.solve_budget), "--solve-replicas", str(m2_replicas),
+                           "--pmc-child-m2"]
                 pm2, info2 = pmc_collect(m2_argv, M2_PMC_WARM, M2_PMC_TIMED, "k_mixed_search_wave<", timeout_s=60, passes=M2_PMC_PASSES, attempts=2, budget_s=100.0)
                 if pm2 is None:
                     roof2["pmc_source"] = f"none (live rocprofv3 passes failed: {info2})"

@@ -5,6 +5,9 @@
 #define SF_TU_IR 1
 #endif
 #define SF_SCALAR_PAIR_IR SF_TU_IR
+#if !SF_TU_IR && !defined(SF_CONFLICT_W)
+#define SF_CONFLICT_W 8  // partner ids in flight per pass of the specialised join: 8 / 16 / 24 / 32 -> 10.0 / 9.8 / 9.3 / 9.4 G on graph colouring (profiles/r06k_pair_ir_ab.txt)
+#endif
 #define SF_TU_ENGINES 7
 #include "sf_launch.h"
 
