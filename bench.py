@@ -94,9 +94,10 @@ M2_POLICIES = {
     "default6": ("nearby_change", "nearby_swap", "sublist_change", "sublist_swap", "list_reverse", "kopt"),
     "nearby2": ("nearby_change", "nearby_swap"),
 }
-M2_REPLICAS = {"default": 12288, "default6": 24576, "nearby2": 6144}  # replicas per GPU of the M2 leg: four residencies of the RUIN instantiation's 12 per CU /
+M2_REPLICAS = {"default": 24576, "default6": 24576, "nearby2": 6144}  # replicas per GPU of the M2 leg: eight residencies of the RUIN instantiation's 12 per CU /
 # six of the six-leaf kernel's 16, with 100,000 candidates per replica per launch (round 6, profiles/r06g_launch_shapes.txt: seven-leaf 6.26 G moves/s at
-# 6,144 x 30,000 -> 7.15 G at 12,288 x 100,000; a launch ends with its slowest replicas, more and longer-running workgroups amortise that tail)
+# 6,144 x 30,000 -> 7.15 G at 12,288 x 100,000 -> 7.53 G at 24,576 x 100,000 in the long-step regime; sustained over the 60 s leg 6.53 / 6.68 / 6.75 G at
+# 12,288 / 18,432 / 24,576; a launch ends with its slowest replicas, more and longer-running workgroups amortise that tail)
 # M2 extension leg (module docstring): what is varied against the parity leg, and nothing else
 M1_REPLICAS = 98304  # the timed M1 leg: sixteen residencies of 24 replicas per CU (round 6, profiles/r06g_launch_shapes.txt: 24,576 49.9 G, 49,152 52.3 G, 98,304 53.3 G)
 C5_REPLICAS = 2816  # the CVRP-5000 side leg: 11 replicas per CU (launch mode 6)
