@@ -56,3 +56,20 @@ def test_no_device_no_number():
     assert r.returncode != 0
     assert b"SF_ERR_NO_DEVICE" in r.stderr
     assert r.stdout.strip() == b""
+
+
+def test_launch_shapes_are_whole_residencies():
+    """The replica counts bench.py launches by default fill the 256 CUs evenly (round 6: the legs run many residencies per launch; a count that is not a
+    multiple of one residency would leave CUs idle at the end of every launch), and the counter window of the M2 leg lies inside a short leg."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.M1_REPLICAS % (24 * 256) == 0  # wave engine, COMPACT slice at CVRP-1000: 24 replicas per CU
+    assert b.M2_REPLICAS["default"] % (12 * 256) == 0  # generic engine, FAST + RUIN: 12 per CU
+    assert b.M2_REPLICAS["default6"] % (16 * 256) == 0  # six-leaf FAST: 16 per CU
+    assert b.C5_REPLICAS % (11 * 256) == 0  # wave engine, launch mode 6 at CVRP-5000: 11 per CU
+    assert b.PMC_CHILD_MAX_REPLICAS % (24 * 256) == 0
+    assert 0 < b.M2_PMC_TIMED <= b.M2_PMC_WARM  # the window [WARM, WARM + TIMED) of launches: past the construction, a few launches long
+    assert [c for p in b.M2_PMC_PASSES for c in p].count("SQ_INSTS_SALU") == 1
