@@ -414,6 +414,34 @@ def test_node_table_in_hbm(oracle, monkeypatch, renumber):
     assert (out["1"][0] == out["0"][0]).all() and out["1"][1] == out["0"][1] and (out["1"][2] == out["0"][2]).all() and out["1"][3] == out["0"][3]
 
 
+@pytest.mark.parametrize("customers,vehicles,coord_range", [(40, 1, 1000), (60, 2, 1000), (90, 3, 1000), (120, 7, 1000), (300, 129, 1000), (150, 9, 1)])
+def test_route_ranks_by_arithmetic_small_and_tied(oracle, monkeypatch, customers, vehicles, coord_range):
+    """Launch mode 6 computes a route's rank in the leaf's entity order -- ((route - start) x stride^-1) mod V -- instead of reading a per-step table (round 6,
+    csrc/sf_list_wave.hip: RouteArith).  Edge cases of that arithmetic against the oracle: one / two / three lists (stride 1, the inverse search's first round),
+    more lists than one round of the search holds, and the all-ties instance, whose serial top-k fallback packs the rank-based ordinal behind a wider shift."""
+    import solverforge_amd as sfa
+    from solverforge_amd import datasets
+
+    if _ENGINE["value"] != 2:
+        pytest.skip("wave engine only")
+    monkeypatch.setenv("SF_AMD_NODE_GLOBAL", "1")
+    p = datasets.make_cvrp(customers, vehicles, 55 if vehicles > 1 else 10_000, seed=21, coord_range=coord_range)
+    d, o, bits = _mk(oracle, p, n_replicas=3)
+    d.configure(sfa.SolverConfig(random_seed=8))
+    o.configure(leaves=bits, random_seed=8)
+    d.calculate_score()
+    d.phase_start()
+    o.phase_start()
+    for n in (12, 13):
+        d.solve_steps(n)
+    o.steps(25)
+    mode, _ = d.wave_layout()
+    assert mode == 6, mode
+    assert d.working_lists(0, 0) == o.get_lists(0)
+    assert (d.calculate_score()[0] == o.score()[:2]).all() and (d.fresh_score() == d.calculate_score()).all()
+    assert d.stats(0)["moves_evaluated"] == o.stats()["moves_evaluated"]
+
+
 def test_internal_node_numbering_with_unreachable_and_tied_legs(oracle, monkeypatch):
     """The numbering chain follows the presorted index: unreachable legs end a row early (the chain falls back to the lowest unvisited
     id) and equal distances keep the index's (distance, EXTERNAL id) order, so the degenerate-tie path (which reads the i64 matrix
