@@ -223,6 +223,40 @@ typedef struct sf_pair_term {
 int32_t sf_constraint_add_pair_join(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, const sf_pair_term* terms, int32_t n_terms,
                                     int32_t level, int64_t weight);
 
+/* ---- uni filters / weights as data (round 6) ---------------------------------------------------------------------------------
+ * for_each(A).filter(|a| pred(a, a.value)).penalize(w(a, a.value)) -- IncrementalUniConstraint with its two closures
+ * (crates/solverforge-scoring/src/constraint/incremental.rs:19-160: on_insert / on_retract test the filter and score the weight of ONE entity).
+ * Both closures see one entity and its assigned value only, so the program is COMPILED at sf_initialize: the host evaluates predicate and weight for
+ * every (entity, value) pair into the cost[n_rows][n_values] matrix that SF_C_VALUE_COST prices on the device -- no interpreter in any kernel, an
+ * unassigned entity never matches.  Programs (and at most one SF_C_VALUE_COST matrix) of one class must share a score level: they fold into one
+ * matrix; sf_evaluate_each still reports each of them on its own row (from per-constraint host copies).
+ * Predicate: a conjunction of clauses, each a disjunction of its terms (as sf_pair_term); term = `lhs cmp param` with lhs one of: */
+typedef enum sf_uni_lhs {
+    SF_UNI_ROW_COL = 1,       /* fact = i32 column over the entities: col[a] */
+    SF_UNI_VALUE = 2,         /* the assigned value itself */
+    SF_UNI_VALUE_COL = 3,     /* fact = i32 column over the values: col[value] */
+    SF_UNI_COL_DIFF = 4,      /* fact (entities), fact_b (values): col_a[a] - col_b[value] */
+    SF_UNI_COL_ABSDIFF = 5,   /* |col_a[a] - col_b[value]| */
+    SF_UNI_TABLE = 6          /* fact_c = i64 matrix, keyed by fact / fact_b: table[col_a[a]][col_b[value]]  (fact = -1: row key = a; fact_b = -1: column key = value) */
+} sf_uni_lhs;
+typedef enum sf_uni_cmp { SF_UNI_EQ = 0, SF_UNI_NE = 1, SF_UNI_LT = 2, SF_UNI_LE = 3, SF_UNI_GT = 4, SF_UNI_GE = 5 } sf_uni_cmp;
+typedef struct sf_uni_term {
+    int32_t lhs;     /* sf_uni_lhs */
+    int32_t cmp;     /* sf_uni_cmp */
+    int32_t clause;  /* ids ascend along the array; same id = OR, different ids = AND */
+    int32_t fact, fact_b, fact_c; /* as the lhs says, else -1 */
+    int64_t param;
+} sf_uni_term;
+/* the weight closure: scale * max(0, lhs-expression) of the same operand kinds (SF_UNI_* above; lhs 0 = the constant 1) */
+typedef struct sf_uni_weight {
+    int32_t lhs;     /* 0 = constant 1, or sf_uni_lhs */
+    int32_t fact, fact_b, fact_c;
+} sf_uni_weight;
+/* n_terms == 0: no filter (every assigned entity matches).  <= 16 terms.  SF_ERR_INVALID for malformed programs / facts (checked at sf_initialize
+ * where the facts are known), SF_ERR_UNSUPPORTED when the class's value-cost constraints sit on different levels. */
+int32_t sf_constraint_add_uni_program(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, const sf_uni_term* terms, int32_t n_terms,
+                                      const sf_uni_weight* weight, int32_t level, int64_t scale);
+
 typedef enum sf_selector_kind {
     SF_SEL_SCALAR_CHANGE = 1,      /* selector/scalar_neighborhood/cursor/change.rs:27-121 */
     SF_SEL_SCALAR_SWAP = 2,        /* selector/scalar_neighborhood/cursor/swap.rs:22-160 */

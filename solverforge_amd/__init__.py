@@ -14,6 +14,8 @@ from .director import (
     MoveKind,
     SelectionOrder,
     SolverConfig,
+    UniCmp,
+    UniLhs,
 )
 from .models import build_assignment, build_balance, build_cvrp, build_graph_coloring, build_jobshop, build_nqueens, build_precedence_shop, build_shift_schedule  # noqa: F401
 from ._lib import MOVE_DTYPE, SolverForgeError  # noqa: F401

@@ -74,7 +74,7 @@ SYMBOLS = [
     "sf_constraint_add", "sf_constraint_add_list_precedence", "sf_selector_add", "sf_selector_add_sublist", "sf_selector_add_kopt", "sf_selector_add_permute", "sf_selector_add_precedence", "sf_list_set_precedence_policy", "sf_selector_add_ruin", "sf_selector_add_nearby_scalar", "sf_step_evaluate_compound", "sf_step_decide", "sf_step_decide_gated", "sf_step_decide_cursor", "sf_apply_compound", "sf_construct_list_cheapest", "sf_construct_list_regret", "sf_construct_list_clarke_wright", "sf_construct_list_round_robin", "sf_construct_list_k_opt", "sf_union_configure", "sf_schema_set_value_lists", "sf_initialize", "sf_evaluate_all", "sf_evaluate_each", "sf_get_scores",
     "sf_step_evaluate", "sf_apply", "sf_step_generate", "sf_solver_configure", "sf_default_local_search_components", "sf_solver_configure_default", "sf_solver_configure_annealing", "sf_solver_configure_diversified",
     "sf_get_annealing_state", "sf_solver_set_step_seeds",
-    "sf_solver_set_engine", "sf_solver_get_engine", "sf_list_wave_layout", "sf_constraint_add_pair_join", "sf_provider_declare", "sf_phase_start", "sf_solve_steps", "sf_solve_moves", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
+    "sf_solver_set_engine", "sf_solver_get_engine", "sf_list_wave_layout", "sf_constraint_add_pair_join", "sf_constraint_add_uni_program", "sf_provider_declare", "sf_phase_start", "sf_solve_steps", "sf_solve_moves", "sf_solve_step_traced", "sf_get_stats", "sf_get_stats_sum", "sf_get_best_scores",
     "sf_profile_solve", "sf_download_scalar", "sf_download_list", "sf_portfolio_unique_id",
     "sf_portfolio_init", "sf_portfolio_allgather_best", "sf_portfolio_broadcast_best", "sf_portfolio_destroy", "sf_portfolio_migrate_local",
     "sf_trace_digest_init", "sf_trace_digest_update", "sf_trace_encode_step",
@@ -148,6 +148,7 @@ def load():
     L.sf_solver_get_engine.argtypes = [vp, C.POINTER(i32)]
     L.sf_list_wave_layout.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.sf_constraint_add_pair_join.argtypes = [vp, i32, i32, vp, i32, i32, C.c_int64]
+    L.sf_constraint_add_uni_program.argtypes = [vp, i32, i32, vp, i32, vp, i32, C.c_int64]
     L.sf_provider_declare.argtypes = [vp, i32, C.c_char_p]
     L.sf_solver_set_step_seeds.argtypes = [vp, vp, i64]
     L.sf_phase_start.argtypes = [vp]

@@ -40,8 +40,17 @@ struct ConstraintSpec {
     int level;
     int64_t weight;
     std::vector<sf_pair_term> terms;  // SF_C_PAIR_JOIN_: the predicate program (sf_constraint_add_pair_join)
+    std::vector<sf_uni_term> uterms;  // SF_C_UNI_PROGRAM_: filter program and weight expression (sf_constraint_add_uni_program)
+    sf_uni_weight uweight{0, -1, -1, -1};
 };
 constexpr int SF_C_PAIR_JOIN_ = 100;  // internal kind of sf_constraint_add_pair_join
+constexpr int SF_C_UNI_PROGRAM_ = 101;  // internal kind of sf_constraint_add_uni_program
+// host copies of the components folded into ScalarModel::cost when a class carries uni programs (sf_evaluate_each rows): scaled cost and filter
+struct UniComponent {
+    size_t constraint_index;
+    std::vector<int64_t> cost;
+    std::vector<uint8_t> pass;
+};
 struct SelectorSpec {
     int kind, desc, var, max_nearby, fact;
     int min_size = 1, max_size = 3;  // sublist leaves; ruin leaf: min / max ruin count
@@ -101,6 +110,7 @@ struct sf_ctx {
     int last_wave_mode = -1;      // launch mode of the last wave-engine launch (sf_list_wave_layout)
     int xown_level = -1;             // SF_C_CROSS_OWNER_MATCH of a mixed model: level / weight / the [R][n_scalar] entity -> holding list map
     int64_t xown_weight = 0;
+    std::vector<UniComponent> uni_components;  // non-empty: ScalarModel::cost is the fold of these (uni programs + at most one SF_C_VALUE_COST)
     uint16_t* d_xown_tab = nullptr;
     int64_t* d_xown_delta = nullptr;  // sf_apply / sf_apply_compound: the join's delta of the move being committed (xown_price)
     std::vector<std::pair<int, std::string>> providers;  // host-side providers declared through sf_provider_declare
@@ -447,6 +457,40 @@ int32_t sf_constraint_add_pair_join(sf_ctx* ctx, int32_t d, int32_t var, const s
     }
     ConstraintSpec cs{SF_C_PAIR_JOIN_, d, var, -1, 0, level, weight, {}};
     cs.terms.assign(terms, terms + n_terms);
+    ctx->constraints.push_back(cs);
+    return SF_OK;
+}
+
+int32_t sf_constraint_add_uni_program(sf_ctx* ctx, int32_t d, int32_t var, const sf_uni_term* terms, int32_t n_terms, const sf_uni_weight* weight, int32_t level,
+                                      int64_t scale) {
+    if (!ctx || level < 0 || level >= ctx->levels) return fail(ctx, SF_ERR_INVALID, "bad constraint level");
+    if (ctx->initialized) return fail(ctx, SF_ERR_INVALID, "constraints are frozen after sf_initialize");
+    if (n_terms < 0 || (n_terms > 0 && !terms) || !weight) return fail(ctx, SF_ERR_INVALID, "uni program: missing terms / weight");
+    if (n_terms > 16) return fail(ctx, SF_ERR_UNSUPPORTED, "uni program: at most 16 terms");
+    auto operands_ok = [&](int32_t lhs, int32_t f, int32_t fb, int32_t fc) {
+        switch (lhs) {
+            case SF_UNI_ROW_COL:
+            case SF_UNI_VALUE_COL: return f >= 0;
+            case SF_UNI_VALUE: return true;
+            case SF_UNI_COL_DIFF:
+            case SF_UNI_COL_ABSDIFF: return f >= 0 && fb >= 0;
+            case SF_UNI_TABLE: return fc >= 0;
+            default: return false;
+        }
+    };
+    int32_t prev = -1;
+    for (int32_t t = 0; t < n_terms; ++t) {
+        const sf_uni_term& ut = terms[t];
+        if (ut.cmp < SF_UNI_EQ || ut.cmp > SF_UNI_GE) return fail(ctx, SF_ERR_INVALID, "uni program: unknown comparison");
+        if (!operands_ok(ut.lhs, ut.fact, ut.fact_b, ut.fact_c)) return fail(ctx, SF_ERR_INVALID, "uni program: unknown operand kind or missing fact");
+        if (ut.clause < 0 || ut.clause > 127 || ut.clause < prev) return fail(ctx, SF_ERR_INVALID, "uni program: clause ids must ascend (0..127)");
+        prev = ut.clause;
+    }
+    if (weight->lhs != 0 && !operands_ok(weight->lhs, weight->fact, weight->fact_b, weight->fact_c))
+        return fail(ctx, SF_ERR_INVALID, "uni program: unknown weight operand or missing fact");
+    ConstraintSpec cs{SF_C_UNI_PROGRAM_, d, var, -1, 0, level, scale, {}};
+    if (n_terms > 0) cs.uterms.assign(terms, terms + n_terms);
+    cs.uweight = *weight;
     ctx->constraints.push_back(cs);
     return SF_OK;
 }
@@ -1341,10 +1385,34 @@ int32_t sf_evaluate_each(sf_ctx* ctx, int32_t replica, int64_t* out_scores, int6
     if ((rc = run_evaluate_all(ctx, nullptr, 0, ctx->d_each))) return rc;
     int64_t q[SF_EACH_WORDS];
     HIPCHK(ctx, hipMemcpy(q, ctx->d_each + (size_t)replica * SF_EACH_WORDS, sizeof(q), hipMemcpyDeviceToHost));
+    // a class with uni programs: its value-cost components were folded into one device matrix; each keeps its own row here, from the host copies
+    std::vector<int32_t> uni_vals;
+    if (!ctx->uni_components.empty()) {
+        uni_vals.resize((size_t)ctx->sm.n);
+        HIPCHK(ctx, hipMemcpy(uni_vals.data(), ctx->sm.vals + (size_t)replica * ctx->sm.n, uni_vals.size() * 4, hipMemcpyDeviceToHost));
+    }
+    auto uni_row = [&](size_t constraint_index, int64_t& raw, int64_t& count) -> bool {
+        for (auto& uc : ctx->uni_components) {
+            if (uc.constraint_index != constraint_index) continue;
+            raw = 0, count = 0;
+            const size_t nv = (size_t)ctx->sm.n_values;
+            for (size_t a = 0; a < uni_vals.size(); ++a)
+                if (uni_vals[a] >= 0) raw += uc.cost[a * nv + (size_t)uni_vals[a]], count += uc.pass[a * nv + (size_t)uni_vals[a]];
+            return true;
+        }
+        return false;
+    };
     size_t i = 0;
     for (auto& cs : ctx->constraints) {
         int64_t raw = 0, count = 0;
         const bool on_list = ctx->has_list_model && cs.desc == ctx->list_desc;
+        if (uni_row(i, raw, count)) {  // (scale / weight are inside `raw`)
+            for (int k = 0; k < ctx->levels; ++k) out_scores[i * ctx->levels + k] = 0;
+            out_scores[i * ctx->levels + cs.level] = (int64_t)(0 - (uint64_t)raw);
+            out_match_counts[i] = count;
+            ++i;
+            continue;
+        }
         switch (cs.kind) {
             case SF_C_ROUTE_CAPACITY: raw = q[0], count = ctx->lm.V; break;  // filter = every route (uni on the owners)
             case SF_C_ROUTE_DISTANCE: raw = q[1], count = ctx->lm.V; break;

@@ -23,6 +23,14 @@ class MoveKind:
     LIST_PERMUTE = 9  # a = b = list, [a_pos, b_pos) = the window, value = rank of the permutation (lexicographic, >= 1)
 
 
+class UniLhs:  # sf_uni_lhs
+    ONE, ROW_COL, VALUE, VALUE_COL, COL_DIFF, COL_ABSDIFF, TABLE = 0, 1, 2, 3, 4, 5, 6
+
+
+class UniCmp:  # sf_uni_cmp
+    EQ, NE, LT, LE, GT, GE = 0, 1, 2, 3, 4, 5
+
+
 class SelectionOrder:  # solverforge_config::SelectionOrder
     ORIGINAL, SORTED, PROBABILISTIC, RANDOM, SHUFFLED = 0, 1, 2, 3, 4
 
@@ -192,6 +200,21 @@ class GpuScoreDirector:
             t = tuple(t) + (-1, -1, 0)[len(t) - 2:] if len(t) < 5 else tuple(t)
             arr[i] = t
         check(self._L.sf_constraint_add_pair_join(self._h, descriptor_index, variable_index, arr.ctypes.data_as(C.c_void_p), len(terms), level, weight), self._h)
+        self._n_constraints = getattr(self, "_n_constraints", 0) + 1
+
+    def add_uni_program(self, descriptor_index, terms, weight=(0, -1, -1, -1), level=0, scale=1, variable_index=0):
+        """for_each(A).filter(pred).penalize(w) with both closures as data (sf_constraint_add_uni_program; compiled on the host into the value-cost
+        matrix at initialize): `terms` = sequence of (lhs, cmp, clause, fact, fact_b, fact_c, param) -- UniLhs / UniCmp name the codes; a conjunction
+        of clauses, each a disjunction of its terms; `weight` = (lhs, fact, fact_b, fact_c), lhs 0 = the constant 1; the entity costs scale * max(0, w)."""
+        tdt = np.dtype([("lhs", np.int32), ("cmp", np.int32), ("clause", np.int32), ("fact", np.int32), ("fact_b", np.int32), ("fact_c", np.int32),
+                        ("param", np.int64)])
+        arr = np.zeros(max(len(terms), 1), dtype=tdt)
+        for i, t in enumerate(terms):
+            arr[i] = tuple(t)
+        w = np.zeros(1, dtype=np.dtype([("lhs", np.int32), ("fact", np.int32), ("fact_b", np.int32), ("fact_c", np.int32)]))
+        w[0] = tuple(weight)
+        check(self._L.sf_constraint_add_uni_program(self._h, descriptor_index, variable_index, arr.ctypes.data_as(C.c_void_p), len(terms),
+                                                    w.ctypes.data_as(C.c_void_p), level, scale), self._h)
         self._n_constraints = getattr(self, "_n_constraints", 0) + 1
 
     def add_list_precedence(self, descriptor_index, durations, successors, expected_owner=None, hard_level=0, makespan_level=1,
