@@ -17,6 +17,43 @@ def t6(m):
     return np.stack([m["kind"], m["a"], m["a_pos"], m["b"], m["b_pos"], m["value"]], axis=1)
 
 
+def uni_matrix(terms, weight, scale, cols, table, n, k):
+    """numpy twin of the library's host compile of one uni program (csrc/sf_api_scalar.inc: compile_uni_programs): cost[a][v] = scale * max(0, w) where the CNF holds"""
+    a = np.arange(n, dtype=np.int64)[:, None]
+    v = np.arange(k, dtype=np.int64)[None, :]
+
+    def val(lhs, f, fb, fc):
+        if lhs == 0:
+            return np.ones((n, k), dtype=np.int64)
+        if lhs == 1:
+            return cols[f].astype(np.int64)[a] + 0 * v
+        if lhs == 2:
+            return v + 0 * a
+        if lhs == 3:
+            return cols[f].astype(np.int64)[v] + 0 * a
+        if lhs in (4, 5):
+            x = cols[f].astype(np.int64)[a] - cols[fb].astype(np.int64)[v]
+            return np.abs(x) if lhs == 5 else x
+        rk = cols[f].astype(np.int64)[a] + 0 * v if f >= 0 else a + 0 * v
+        ck = cols[fb].astype(np.int64)[v] + 0 * a if fb >= 0 else v + 0 * a
+        return table[rk, ck]
+
+    ok = np.ones((n, k), dtype=bool)
+    clause, acc = None, None
+    for (lhs, cmp_, cl, f, fb, fc, param) in terms:
+        x = val(lhs, f, fb, fc)
+        h = [x == param, x != param, x < param, x <= param, x > param, x >= param][cmp_]
+        if cl != clause:
+            if acc is not None:
+                ok &= acc
+            clause, acc = cl, np.zeros((n, k), dtype=bool)
+        acc |= h
+    if acc is not None:
+        ok &= acc
+    w = val(*weight)
+    return np.where(ok, scale * np.maximum(w, 0), 0).astype(np.int64)
+
+
 def run_case(seed):
     rng = np.random.default_rng(seed)
     model = ["cvrp", "cvrp", "cvrp", "graph", "jobshop", "balance", "assignment", "precedence", "precedence", "shift", "shift", "shift"][int(rng.integers(12))]
@@ -97,7 +134,40 @@ def run_case(seed):
         desc.update(n=n, k=k, ex_mode=ex_mode, ex_level=ex_level, leaves=leaves)
         d = sfa.build_assignment(values, cost.reshape(n, k), k, cost_weight=2, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3,
                                  leaves=leaves)
-        o = sfo.Model.assignment(values, cost.reshape(n, k), k, cost_weight=2, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3)
+        ocost, ocw = cost.reshape(n, k), 2
+        if rng.random() < 0.5:  # uni filters / weights as programs (round 6): compiled by the library, restated here for the oracle's matrix
+            cols = {20: rng.integers(-3, 6, n).astype(np.int32), 21: rng.integers(-3, 6, n).astype(np.int32),  # per entity
+                    22: rng.integers(-3, 6, max(n, k)).astype(np.int32)[:max(n, k)], 23: np.arange(max(n, k), dtype=np.int32)}  # per value (long enough either way)
+            cols[24] = rng.integers(0, 4, n).astype(np.int32)  # table keys
+            cols[25] = rng.integers(0, 4, max(n, k)).astype(np.int32)
+            table = rng.integers(-2, 5, (4, 4)).astype(np.int64)
+            for fid, c_ in cols.items():
+                d.add_fact_column_i32(fid, c_)
+            d.add_fact_matrix(26, table)
+            ocost, ocw = 2 * cost.reshape(n, k), 1
+            n_prog = int(rng.integers(1, 4))
+            for _ in range(n_prog):
+                terms, cl = [], 0
+                for _t in range(int(rng.integers(0, 5))):
+                    lhs = int(rng.integers(1, 7))
+                    f, fb, fc = -1, -1, -1
+                    if lhs == 1:
+                        f = int(rng.choice([20, 21]))
+                    elif lhs == 3:
+                        f = int(rng.choice([22, 23]))
+                    elif lhs in (4, 5):
+                        f, fb = int(rng.choice([20, 21])), int(rng.choice([22, 23]))
+                    elif lhs == 6:
+                        f, fb, fc = int(rng.choice([24, -1])) if n <= 4 else 24, int(rng.choice([25, -1])) if k <= 4 else 25, 26
+                    terms.append((lhs, int(rng.integers(0, 6)), cl, f, fb, fc, int(rng.integers(-2, 5))))
+                    cl += int(rng.integers(0, 2))
+                wl = int(rng.choice([0, 1, 3, 5, 6]))
+                weight = {0: (0, -1, -1, -1), 1: (1, 20, -1, -1), 3: (3, 22, -1, -1), 5: (5, 21, 23, -1), 6: (6, 24, 25, 26)}[wl]
+                scale = int(rng.integers(1, 4))
+                d.add_uni_program(0, terms, weight, level=1, scale=scale)
+                ocost = ocost + uni_matrix(terms, weight, scale, cols, table, n, k)
+            desc["uni_programs"] = n_prog
+        o = sfo.Model.assignment(values, ocost, k, cost_weight=ocw, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3)
         lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
         cands = [[(int(e), int(v)) for e, v in zip(rng.integers(0, n, m), rng.integers(-1, k, m))] for m in rng.integers(1, 9, 40)]
         d.calculate_score()
@@ -219,6 +289,16 @@ def run_case(seed):
         gst, stats_base = d.stats(0), o.stats()  # sf_phase_start zeroes the device's counters; the oracle's run on
         for k2 in ["step_count", "moves_accepted", "moves_applied", "score_calculations"]:
             assert gst[k2] == stats_base[k2], f"construction counter {k2}"
+    if model == "jobshop" and desc.get("owner_match_level") is not None:  # round 6: the host-driven entry points price the join too
+        om0 = o.enumerate(0, 0, seed, 3)
+        if len(om0):
+            os0, od0 = o.evaluate_moves(om0)
+            gs0, gd0 = d.evaluate_moves(om0)
+            assert (gd0 == od0).all() and (gs0[od0 != 0] == os0[od0 != 0, :levels]).all(), "host-driven trial scores under the two-class join"
+            if od0.any():
+                mv0 = om0[np.flatnonzero(od0)[0]]
+                o.apply_move(mv0); d.apply_move(mv0)
+                assert (d.calculate_score()[0] == o.score()[:levels]).all() and (d.fresh_score()[0] == o.score()[:levels]).all(), "sf_apply under the two-class join"
     d.phase_start(); o.phase_start()
     for step in range(6 if forager == 2 else 14):
         gm, gs, gf, gap, gmv = d.solve_step_traced(cap=1 << 20)
