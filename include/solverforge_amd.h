@@ -228,8 +228,8 @@ int32_t sf_constraint_add_pair_join(sf_ctx* ctx, int32_t descriptor_index, int32
  * (crates/solverforge-scoring/src/constraint/incremental.rs:19-160: on_insert / on_retract test the filter and score the weight of ONE entity).
  * Both closures see one entity and its assigned value only, so the program is COMPILED at sf_initialize: the host evaluates predicate and weight for
  * every (entity, value) pair into the cost[n_rows][n_values] matrix that SF_C_VALUE_COST prices on the device -- no interpreter in any kernel, an
- * unassigned entity never matches.  Programs (and at most one SF_C_VALUE_COST matrix) of one class must share a score level: they fold into one
- * matrix; sf_evaluate_each still reports each of them on its own row (from per-constraint host copies).
+ * unassigned entity never matches.  Programs (and at most one SF_C_VALUE_COST matrix) of one class fold into one matrix per score level, on at most
+ * TWO levels (a hard filter beside soft weights); sf_evaluate_each still reports each of them on its own row (from per-constraint host copies).
  * Predicate: a conjunction of clauses, each a disjunction of its terms (as sf_pair_term); term = `lhs cmp param` with lhs one of: */
 typedef enum sf_uni_lhs {
     SF_UNI_ROW_COL = 1,       /* fact = i32 column over the entities: col[a] */
@@ -253,7 +253,7 @@ typedef struct sf_uni_weight {
     int32_t fact, fact_b, fact_c;
 } sf_uni_weight;
 /* n_terms == 0: no filter (every assigned entity matches).  <= 16 terms.  SF_ERR_INVALID for malformed programs / facts (checked at sf_initialize
- * where the facts are known), SF_ERR_UNSUPPORTED when the class's value-cost constraints sit on different levels. */
+ * where the facts are known), SF_ERR_UNSUPPORTED when the class's value-cost constraints sit on more than two levels. */
 int32_t sf_constraint_add_uni_program(sf_ctx* ctx, int32_t descriptor_index, int32_t variable_index, const sf_uni_term* terms, int32_t n_terms,
                                       const sf_uni_weight* weight, int32_t level, int64_t scale);
 

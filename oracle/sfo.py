@@ -75,6 +75,7 @@ def lib():
             "sfo_balance_create_base": (vp, [i32, i32, vp, vp, i64, i64]),
             "sfo_cvrp_create": (vp, [i32, i32, i64, i32, i32, vp, vp, vp, vp, vp]),
             "sfo_assignment_create": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64]),
+            "sfo_assignment_create2": (vp, [i32, i32, vp, vp, i64, vp, i32, i32, i64, vp, i32]),
             "sfo_list_toy_create": (vp, [i32, vp, vp, i32]),
             "sfo_shift_schedule_create": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, vp]),
             "sfo_shift_schedule_create_presence": (vp, [i32, i32, vp, vp, i64, i64, i64, i64, i64, i64, i64, vp]),
@@ -194,12 +195,17 @@ class Model:
         return Model(lib().sfo_balance_create(len(bins), n_bins, _p(bins), _p(sizes), w_pair, cap), [len(bins)])
 
     @staticmethod
-    def assignment(values, cost, n_values, cost_weight=1, row_w=None, ex_mode=1, ex_level=1, ex_weight=1):
-        """Keyed cross-join with a fact class (pair cost matrix) + exists / not-exists per fact row; ex_level < 0 = no exists node."""
+    def assignment(values, cost, n_values, cost_weight=1, row_w=None, ex_mode=1, ex_level=1, ex_weight=1, cost2=None, cost2_level=-1):
+        """Keyed cross-join with a fact class (pair cost matrix) + exists / not-exists per fact row; ex_level < 0 = no exists node.
+        cost2 / cost2_level: the same keyed join once more on another score level (weight 1)."""
         values = np.ascontiguousarray(values, dtype=np.int64)
         cost = np.ascontiguousarray(cost, dtype=np.int64)
         row_w = np.ones(n_values, dtype=np.int64) if row_w is None else np.ascontiguousarray(row_w, dtype=np.int64)
-        h = lib().sfo_assignment_create(len(values), n_values, _p(values), _p(cost), cost_weight, _p(row_w), ex_mode, ex_level, ex_weight)
+        if cost2 is not None and cost2_level >= 0:
+            cost2 = np.ascontiguousarray(cost2, dtype=np.int64)
+            h = lib().sfo_assignment_create2(len(values), n_values, _p(values), _p(cost), cost_weight, _p(row_w), ex_mode, ex_level, ex_weight, _p(cost2), cost2_level)
+        else:
+            h = lib().sfo_assignment_create(len(values), n_values, _p(values), _p(cost), cost_weight, _p(row_w), ex_mode, ex_level, ex_weight)
         return Model(h, [len(values)])
 
     @staticmethod

@@ -161,6 +161,10 @@ void* sfo_assignment_create(int32_t n, int32_t n_values, const int64_t* values, 
                             int32_t ex_mode, int32_t ex_level, int64_t ex_weight) {
     return make_assignment((size_t)n, (size_t)n_values, values, cost, cost_weight, row_w, ex_mode, ex_level, ex_weight).release();
 }
+void* sfo_assignment_create2(int32_t n, int32_t n_values, const int64_t* values, const int64_t* cost, int64_t cost_weight, const int64_t* row_w,
+                             int32_t ex_mode, int32_t ex_level, int64_t ex_weight, const int64_t* cost2, int32_t cost2_level) {
+    return make_assignment((size_t)n, (size_t)n_values, values, cost, cost_weight, row_w, ex_mode, ex_level, ex_weight, cost2, cost2_level).release();
+}
 void* sfo_cvrp_create(int32_t n_customers, int32_t n_vehicles, int64_t capacity, int32_t depot, int32_t dim,
                       const int32_t* demands, const int64_t* matrix, const uint32_t* customers,
                       const uint32_t* route_off, const uint32_t* route_vals) {

@@ -461,9 +461,11 @@ struct AssignFacts {
     size_t n = 0, n_values = 0;
     std::vector<int64_t> cost;   // [n][n_values]
     std::vector<int64_t> row_w;  // [n_values]
+    std::vector<int64_t> cost2;  // [n][n_values]: a second keyed cross-join on another level (cost2_level >= 0), weight 1
 };
 inline std::unique_ptr<Model> make_assignment(size_t n, size_t n_values, const int64_t* values, const int64_t* cost, int64_t cost_weight,
-                                              const int64_t* row_w, int32_t ex_mode, int32_t ex_level, int64_t ex_weight) {
+                                              const int64_t* row_w, int32_t ex_mode, int32_t ex_level, int64_t ex_weight, const int64_t* cost2 = nullptr,
+                                              int32_t cost2_level = -1) {
     auto m = std::make_unique<Model>();
     auto facts = std::make_shared<AssignFacts>();
     facts->n = n;
@@ -490,6 +492,21 @@ inline std::unique_ptr<Model> make_assignment(size_t n, size_t n_values, const i
     join->filter = [af](const Solution& s, size_t a, size_t b) { return s.classes[0].vars[0][a] != NONE && af->cost[a * af->n_values + b] != 0; };
     join->weight = [af, cost_weight](const Solution&, size_t a, size_t b) { return Score::of(0, wrap_mul(cost_weight, af->cost[a * af->n_values + b])); };
     m->director.constraints.members.push_back(std::move(join));
+    if (cost2 && cost2_level >= 0) {  // the same node shape once more, on `cost2_level` (uni filters / weights compiled onto two levels, round 6)
+        facts->cost2.assign(cost2, cost2 + n * n_values);
+        auto j2 = std::make_unique<CrossBiConstraint>();
+        j2->name = "Pair cost 2";
+        j2->impact = Impact::Penalty;
+        j2->a_source = ChangeSource::descriptor(0);
+        j2->b_source = ChangeSource::fixed();
+        j2->a_count = [](const Solution& s) { return s.classes[0].n; };
+        j2->b_count = [af](const Solution&) { return af->n_values; };
+        j2->key_a = [](const Solution& s, size_t a) { return s.classes[0].vars[0][a]; };
+        j2->key_b = [](const Solution&, size_t b) { return (int64_t)b; };
+        j2->filter = [af](const Solution& s, size_t a, size_t b) { return s.classes[0].vars[0][a] != NONE && af->cost2[a * af->n_values + b] != 0; };
+        j2->weight = [af, cost2_level](const Solution&, size_t a, size_t b) { return Score::level(cost2_level, af->cost2[a * af->n_values + b]); };
+        m->director.constraints.members.push_back(std::move(j2));
+    }
 
     if (ex_level >= 0) {
         auto ex = std::make_unique<ExistsConstraint>();

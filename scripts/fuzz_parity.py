@@ -134,7 +134,7 @@ def run_case(seed):
         desc.update(n=n, k=k, ex_mode=ex_mode, ex_level=ex_level, leaves=leaves)
         d = sfa.build_assignment(values, cost.reshape(n, k), k, cost_weight=2, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3,
                                  leaves=leaves)
-        ocost, ocw = cost.reshape(n, k), 2
+        ocost, ocw, ocost2 = cost.reshape(n, k), 2, None
         if rng.random() < 0.5:  # uni filters / weights as programs (round 6): compiled by the library, restated here for the oracle's matrix
             cols = {20: rng.integers(-3, 6, n).astype(np.int32), 21: rng.integers(-3, 6, n).astype(np.int32),  # per entity
                     22: rng.integers(-3, 6, max(n, k)).astype(np.int32)[:max(n, k)], 23: np.arange(max(n, k), dtype=np.int32)}  # per value (long enough either way)
@@ -164,10 +164,16 @@ def run_case(seed):
                 wl = int(rng.choice([0, 1, 3, 5, 6]))
                 weight = {0: (0, -1, -1, -1), 1: (1, 20, -1, -1), 3: (3, 22, -1, -1), 5: (5, 21, 23, -1), 6: (6, 24, 25, 26)}[wl]
                 scale = int(rng.integers(1, 4))
-                d.add_uni_program(0, terms, weight, level=1, scale=scale)
-                ocost = ocost + uni_matrix(terms, weight, scale, cols, table, n, k)
+                plevel = int(rng.choice([1, 1, 0]))  # a hard program now and then: the class's programs fold into one matrix per level (two at most)
+                d.add_uni_program(0, terms, weight, level=plevel, scale=scale)
+                um = uni_matrix(terms, weight, scale, cols, table, n, k)
+                if plevel == 1:
+                    ocost = ocost + um
+                else:
+                    ocost2 = um if ocost2 is None else ocost2 + um
             desc["uni_programs"] = n_prog
-        o = sfo.Model.assignment(values, ocost, k, cost_weight=ocw, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3)
+        o = sfo.Model.assignment(values, ocost, k, cost_weight=ocw, row_w=row_w, ex_mode=ex_mode, ex_level=ex_level, ex_weight=3, cost2=ocost2,
+                                 cost2_level=0 if ocost2 is not None else -1)
         lists = lambda: (d.working_values(0, 0).tolist(), o.get_vars(0, 0).tolist())
         cands = [[(int(e), int(v)) for e, v in zip(rng.integers(0, n, m), rng.integers(-1, k, m))] for m in rng.integers(1, 9, 40)]
         d.calculate_score()

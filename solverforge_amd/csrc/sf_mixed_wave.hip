@@ -2361,7 +2361,8 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
                     m0 = rq[0];
                     m1 = rq[1];
                     mx_ = ringx[my_leaf * GRC + (my_idx & (GRC - 1))];
-                    if (my_kind <= 2) {
+                    if (!FAST && my_kind <= 2) {  // (FAST: list-only models -- said at compile time, so that the scalar trial code, the interpreted joins included, is not in those kernels at all:
+                                                  // with it in, the six-leaf kernel spilled 157 vector registers instead of 78 and ran 10 % slower, profiles/r06p_six_leaf_scalar_code.txt)
                         const uint32_t* tc = tables ? t_cnt : nullptr;
                         const int64_t* ts = tables ? t_sum : nullptr;
                         const ScalarDelta d = my_kind == 1 ? eval_scalar_move(sm, s_vals, 0, m0, 0u, (int32_t)m1, tc, ts, tables ? lbv : nullptr)
@@ -2681,7 +2682,7 @@ __global__ __launch_bounds__(256, MODE == 1 ? (RUIN ? SF_MIXED_FAST_RUIN_BLOCKS_
             int kind = lt.geti(uni((uint32_t)best_leaf), LeafTab::KIND);
             if (!FAST) kind = kind == 2048 ? 1 : (kind == 4096 ? 2 : kind);
             const uint32_t a = uni(best_m0), b = uni(best_m1);
-            if (kind <= 2) {
+            if (!FAST && kind <= 2) {
                 if (tracing && lane == 0) {
                     p.trace_applied[0] = 1;
                     if ((int64_t)best_ti < p.trace_cap) p.trace_flags[best_ti] |= 4;  // Selected + Applied

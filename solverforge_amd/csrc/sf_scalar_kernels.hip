@@ -78,6 +78,10 @@ struct ScalarModel {
     int32_t cost_level = -1;
     int64_t cost_weight = 0;
     const int64_t* cost = nullptr;     // [n][n_values]
+    // a second (entity, value) cost matrix on another score level (round 6: the uni programs of a class may sit on two levels -- a hard filter beside
+    // soft weights; weights and scales are folded into the entries)
+    int32_t cost2_level = -1;
+    const int64_t* cost2 = nullptr;    // [n][n_values]
     // exists / not-exists of planning entities per value-keyed fact row (uses the per-value count table)
     int32_t ex_level = -1, ex_mode = 1;  // 1: scored while some entity holds the value, 0: while none does
     int64_t ex_weight = 0;
@@ -439,6 +443,7 @@ struct ScalarDelta {
     int64_t d_ex;     // change of the summed weights of the value rows whose existence test holds
     bool doable;
     int64_t d_run = 0;  // change of the summed run excess (consecutive-runs collector)
+    int64_t d_cost2 = 0;  // change of the second cost matrix's sum (ScalarModel::cost2)
 };
 
 // grouped/scorer.rs:89-101: an empty group scores zero
@@ -532,6 +537,8 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
         }
         if (m.cost_level >= 0)
             r.d_cost = wsub(value >= 0 ? m.cost[(size_t)a * m.n_values + value] : 0, old >= 0 ? m.cost[(size_t)a * m.n_values + old] : 0);
+        if (m.cost2_level >= 0)
+            r.d_cost2 = wsub(value >= 0 ? m.cost2[(size_t)a * m.n_values + value] : 0, old >= 0 ? m.cost2[(size_t)a * m.n_values + old] : 0);
         if (m.ex_level >= 0) {  // the row `value` starts to exist when it had no holder, the row `old` stops when a was its last
             const int64_t gain = (value >= 0 && cnt[value] == 0) ? (m.ex_w ? (int64_t)m.ex_w[value] : 1) : 0;
             const int64_t loss = (old >= 0 && cnt[old] == 1) ? (m.ex_w ? (int64_t)m.ex_w[old] : 1) : 0;
@@ -591,6 +598,12 @@ __device__ __forceinline__ ScalarDelta eval_scalar_move_v(const ScalarModel& m, 
             const int64_t after = wadd(vb >= 0 ? m.cost[ra + vb] : 0, va >= 0 ? m.cost[rb + va] : 0);
             const int64_t before = wadd(va >= 0 ? m.cost[ra + va] : 0, vb >= 0 ? m.cost[rb + vb] : 0);
             r.d_cost = wsub(after, before);
+        }
+        if (m.cost2_level >= 0) {
+            const size_t ra = (size_t)a * m.n_values, rb = (size_t)b * m.n_values;
+            const int64_t after = wadd(vb >= 0 ? m.cost2[ra + vb] : 0, va >= 0 ? m.cost2[rb + va] : 0);
+            const int64_t before = wadd(va >= 0 ? m.cost2[ra + va] : 0, vb >= 0 ? m.cost2[rb + vb] : 0);
+            r.d_cost2 = wsub(after, before);
         }
         if (m.run_level >= 0) {  // row va loses a's point and gains b's; row vb the other way round (nothing moves when the points agree)
             const uint16_t* pt = runs_table(m, cnt);
@@ -723,6 +736,7 @@ __device__ __forceinline__ ScoreV<L> apply_scalar_delta(const ScalarModel& m, co
         if (k == m.sj_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.sj_weight * (uint64_t)d.d_pairs));
         if (k == m.grp_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.grp_weight * (uint64_t)d.d_grp));
         if (k == m.cost_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.cost_weight * (uint64_t)d.d_cost));
+        if (k == m.cost2_level) s.v[k] = wsub(s.v[k], d.d_cost2);
         if (k == m.ex_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.ex_weight * (uint64_t)d.d_ex));
         if (k == m.run_level) s.v[k] = wsub(s.v[k], (int64_t)((uint64_t)m.run_weight * (uint64_t)d.d_run));
     }
@@ -1079,7 +1093,7 @@ SF_PLAIN_KERNEL
 __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int64_t* out_scores, int commit,
                                                              int accumulate, int64_t* out_parts = nullptr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab_mem[];  // per-value tables (when used)
-    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups, s_cost, s_cost_n, s_ex, s_ex_n, s_run, s_run_groups, s_un_n;
+    __shared__ unsigned long long s_un, s_cross, s_pairs, s_grp, s_groups, s_cost, s_cost_n, s_ex, s_ex_n, s_run, s_run_groups, s_un_n, s_cost2;
     const int r = blockIdx.x;
     const int32_t* vals = m.vals + (size_t)r * m.n;
     const bool tables = m.tables();
@@ -1092,6 +1106,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         s_grp = 0;
         s_groups = 0;
         s_cost = s_cost_n = s_ex = s_ex_n = 0;
+        s_cost2 = 0;
         s_run = s_run_groups = 0;
         s_un_n = 0;
     }
@@ -1147,7 +1162,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             }
         }
     }
-    unsigned long long un = 0, un_n = 0, cross = 0, cost = 0, cost_n = 0;
+    unsigned long long un = 0, un_n = 0, cross = 0, cost = 0, cost_n = 0, cost2 = 0;
     for (uint32_t e = threadIdx.x; e < (uint32_t)m.n; e += blockDim.x) {
         const int32_t v = vals[e];
         if (v < 0) {
@@ -1159,6 +1174,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
             cost += (unsigned long long)c;
             cost_n += c != 0 ? 1 : 0;
         }
+        if (m.cost2_level >= 0 && v >= 0) cost2 += (unsigned long long)m.cost2[(size_t)e * m.n_values + v];
         if (m.cross_level >= 0 && v >= 0) {
             // every matched pair is seen from both sides: count it at its lower index
             if (m.cross_kind == SC_PARTNERS_EQUAL) {
@@ -1190,6 +1206,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
     atomicAdd(&s_cross, cross);
     atomicAdd(&s_cost, cost);
     atomicAdd(&s_cost_n, cost_n);
+    atomicAdd(&s_cost2, cost2);
     __syncthreads();
     if (threadIdx.x == 0) {
         int64_t sc[SF_MAX_LEVELS_CONST] = {0, 0, 0, 0};
@@ -1198,6 +1215,7 @@ __global__ __launch_bounds__(256) void k_scalar_evaluate_all(ScalarModel m, int6
         if (m.sj_level >= 0) sc[m.sj_level] = wsub(sc[m.sj_level], (int64_t)((uint64_t)m.sj_weight * s_pairs));
         if (m.grp_level >= 0) sc[m.grp_level] = wsub(sc[m.grp_level], (int64_t)((uint64_t)m.grp_weight * s_grp));
         if (m.cost_level >= 0) sc[m.cost_level] = wsub(sc[m.cost_level], (int64_t)((uint64_t)m.cost_weight * s_cost));
+        if (m.cost2_level >= 0) sc[m.cost2_level] = wsub(sc[m.cost2_level], (int64_t)s_cost2);
         if (m.ex_level >= 0) sc[m.ex_level] = wsub(sc[m.ex_level], (int64_t)((uint64_t)m.ex_weight * s_ex));
         if (m.run_level >= 0) sc[m.run_level] = wsub(sc[m.run_level], (int64_t)((uint64_t)m.run_weight * s_run));
         for (int k = 0; k < m.levels; ++k) {

@@ -65,7 +65,10 @@ def _numpy_matrices(f, n, k):
     return [m.astype(np.int64) for m in (m1, m2, m3, m4)], passes
 
 
-def _build(f, n, k, with_matrix, n_replicas=1):
+HARD_PROGRAM = 1  # index of the program that sits on the hard level in the two-level cases
+
+
+def _build(f, n, k, with_matrix, n_replicas=1, two_levels=False):
     import solverforge_amd as sfa
     from solverforge_amd.director import ConstraintKind, GpuScoreDirector, SelectorKind
 
@@ -79,22 +82,25 @@ def _build(f, n, k, with_matrix, n_replicas=1):
     if with_matrix:
         d.add_fact_matrix(F_COST, f["cost"])
         d.add_constraint(ConstraintKind.VALUE_COST, 0, fact=F_COST, level=1, weight=5)
-    for terms, weight, scale in _programs():
-        d.add_uni_program(0, terms, weight, level=1, scale=scale)
+    for i, (terms, weight, scale) in enumerate(_programs()):
+        d.add_uni_program(0, terms, weight, level=0 if (two_levels and i == HARD_PROGRAM) else 1, scale=scale)
     d.add_selector(SelectorKind.SCALAR_CHANGE, 0)
     d.add_selector(SelectorKind.SCALAR_SWAP, 0)
     return d
 
 
-@pytest.mark.parametrize("with_matrix", [False, True])
-def test_uni_programs_compile_to_the_value_cost_matrix(oracle, with_matrix):
+@pytest.mark.parametrize("with_matrix,two_levels", [(False, False), (True, False), (False, True), (True, True)])
+def test_uni_programs_compile_to_the_value_cost_matrix(oracle, with_matrix, two_levels):
+    """two_levels: one program is a HARD filter (level 0) beside the soft ones -- the class's programs fold into one matrix per level (at most two)."""
     import solverforge_amd as sfa
 
     f, n, k = _facts()
     mats, passes = _numpy_matrices(f, n, k)
-    folded = sum(mats) + (5 * f["cost"] if with_matrix else 0)
-    d = _build(f, n, k, with_matrix)
-    o = oracle.Model.assignment(f["values"], folded, k, cost_weight=1, ex_level=-1)
+    soft = [m for i, m in enumerate(mats) if not (two_levels and i == HARD_PROGRAM)]
+    folded = sum(soft) + (5 * f["cost"] if with_matrix else 0)
+    d = _build(f, n, k, with_matrix, two_levels=two_levels)
+    o = oracle.Model.assignment(f["values"], folded, k, cost_weight=1, ex_level=-1, cost2=mats[HARD_PROGRAM] if two_levels else None,
+                                cost2_level=0 if two_levels else -1)
     bits = oracle.LEAF_SCALAR_CHANGE | oracle.LEAF_SCALAR_SWAP
     assert (d.calculate_score()[0] == o.score()[:2]).all()
     assert (d.fresh_score()[0] == o.fresh_score()[:2]).all()
@@ -104,10 +110,13 @@ def test_uni_programs_compile_to_the_value_cost_matrix(oracle, with_matrix):
     on = vals >= 0
     rows = ([(5 * f["cost"], f["cost"] != 0)] if with_matrix else []) + list(zip(mats, passes))
     assert len(gs) == 1 + len(rows)
+    hard_row = (1 if with_matrix else 0) + HARD_PROGRAM if two_levels else -1
     for i, (m, p) in enumerate(rows):
-        assert gs[1 + i][1] == -int(m[np.flatnonzero(on), vals[on]].sum()), i
+        lv = 0 if i == hard_row else 1
+        assert gs[1 + i][lv] == -int(m[np.flatnonzero(on), vals[on]].sum()) and gs[1 + i][1 - lv] == 0, i
         assert gc[1 + i] == int(p[np.flatnonzero(on), vals[on]].sum()), i
-    assert gs[1:, 1].sum() == o.evaluate_each()[0][1, 1]
+    oe = o.evaluate_each()[0]
+    assert gs[1:, 1].sum() == oe[1, 1] and (not two_levels or gs[1:, 0].sum() == oe[2, 0])
     for order in (0, 3):
         o.configure(leaves=bits, random_seed=5, la_size=6, limit=40, selection_order=order)
         gm, gsc, gd = d.open_cursor(2, 99, selection_order=order, cap=1 << 16)
@@ -172,6 +181,13 @@ def test_uni_program_validation():
         d.calculate_score()
     d2 = fresh()
     d2.add_uni_program(0, [(L.VALUE_COL, C.GT, 0, F_SKILL, -1, -1, 0)], level=1)  # fine: the column is long enough to be indexed by a value
-    d2.add_uni_program(0, [], level=0)  # another level: the class's value-cost constraints fold into ONE matrix
+    d2.add_uni_program(0, [], level=0)  # a second level: fine too (one folded matrix per level)
+    d2.calculate_score()
+    d3 = GpuScoreDirector(score_levels=3, hard_levels=1)
+    d3.add_entity_class(0, n)
+    d3.add_scalar_variable(0, 0, k, True, f["values"])
+    d3.add_selector(SelectorKind.SCALAR_CHANGE, 0)
+    for lv in (0, 1, 2):  # a third level: more than the two matrices a class carries
+        d3.add_uni_program(0, [], level=lv)
     with pytest.raises(sfa.SolverForgeError):
-        d2.calculate_score()
+        d3.calculate_score()
